@@ -1,0 +1,186 @@
+/*
+ * zkhip.h -- C ABI of libzkhip.so, the MI355X (gfx950) STARK proving backend.
+ *
+ * This is the drop-in boundary for the one path of scroll-tech/zkvm-prover that
+ * BASELINE.json names: the work `Prover::gen_proof_stark` hands to
+ * `sdk.prove(..)` (crates/prover/src/prover/mod.rs:355-357), i.e. the STARK
+ * engine the reference selects with its `cuda` cargo feature
+ * (crates/prover/Cargo.toml:41-46, type aliases crates/prover/src/prover/mod.rs:27-39).
+ * A Rust `openvm-hip-backend` shim binds these entry points the
+ * way the upstream CUDA backend binds its `extern "C"` kernels launchers:
+ * plain pointers and sizes, `int` status (0 = ok, negative = error, message via
+ * zkhip_last_error), opaque handles with matching _destroy, caller-owned
+ * output buffers.  No torch or C++ types cross this boundary.
+ *
+ * Conventions
+ *  - Field elements are BabyBear u32.  DEVICE buffers hold Montgomery form
+ *    (R = 2^32), the in-memory form of p3-baby-bear (the reference only
+ *    canonicalises at serialization, prover/mod.rs:136-137).  HOST-visible
+ *    results (roots, proofs, challenges) are canonical little-endian u32.
+ *  - Matrices are column-major: column c occupies [c*stride, c*stride+height).
+ *  - Extension elements (degree 4 over BabyBear, x^4 = 11) are 4 consecutive u32.
+ *  - Digests are 8 u32 (DIGEST_SIZE, crates/types/src/proof.rs:209).
+ *  - One zkhip_ctx per GPU; not thread-safe; all work is issued on the ctx's
+ *    HIP stream (zkhip_set_stream) and is asynchronous unless it returns host data.
+ *  - There is NO CPU fallback: every entry point needs a gfx950 device and
+ *    fails with ZKHIP_ERR_NO_DEVICE otherwise.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKHIP_OK 0
+#define ZKHIP_ERR_NO_DEVICE (-1)
+#define ZKHIP_ERR_HIP (-2)
+#define ZKHIP_ERR_INVALID (-3)
+#define ZKHIP_ERR_NOMEM (-4)
+#define ZKHIP_ERR_SMALL_BUFFER (-5)
+#define ZKHIP_ERR_POW_FAILED (-6)
+#define ZKHIP_ERR_VERIFY (-7)
+#define ZKHIP_ERR_CONSTRAINT (-8)
+
+#define ZKHIP_DIGEST_WORDS 8
+
+typedef struct zkhip_ctx zkhip_ctx;
+
+/* library / ABI version: (major<<16)|minor */
+uint32_t zkhip_version(void);
+
+/* ---- context: replaces `<Engine as StarkEngine>::new(params)` device setup
+ *      (crates/prover/src/prover/mod.rs:209) and the CUDA backend's stream/pool ---- */
+int zkhip_ctx_create(int device, zkhip_ctx **out);
+void zkhip_ctx_destroy(zkhip_ctx *ctx);
+const char *zkhip_last_error(const zkhip_ctx *ctx);
+/* hipStream_t of the caller (e.g. the stream that produced the trace); NULL = default stream */
+int zkhip_set_stream(zkhip_ctx *ctx, void *hip_stream);
+int zkhip_sync(zkhip_ctx *ctx);
+
+/* ---- device memory (replaces openvm-cuda-common DeviceBuffer / VPMM pool, AGENTS.md:136) ---- */
+int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr);
+int zkhip_free(zkhip_ctx *ctx, void *dptr);
+int zkhip_h2d(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int zkhip_d2h(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronises */
+/* in-place canonical <-> Montgomery on a device buffer of n words */
+int zkhip_to_monty(zkhip_ctx *ctx, uint32_t *d, size_t n);
+int zkhip_from_monty(zkhip_ctx *ctx, uint32_t *d, size_t n);
+
+/* ---- NTT / LDE (K1; replaces p3-dft dft_batch / coset_lde_batch as used by the
+ *      engine's trace commit) ---- */
+/* In-place DFT of every column of a height-2^log_n matrix.  Natural order in;
+ * natural order out unless bitrev_out != 0 (then row r holds index bitrev(r)).
+ * inverse != 0 computes the inverse DFT (with the 1/n factor). */
+int zkhip_ntt_batch(zkhip_ctx *ctx, uint32_t *d_mat, unsigned log_n, size_t width, size_t stride,
+                    int inverse, int bitrev_out);
+/* Coset low-degree extension: evaluations over H (natural order, height 2^log_n)
+ * -> evaluations over shift*K, |K| = 2^(log_n+added_bits), rows in BIT-REVERSED
+ * order (the committed-LDE layout).  d_in is preserved.  shift is canonical. */
+int zkhip_lde_batch(zkhip_ctx *ctx, const uint32_t *d_in, size_t in_stride, uint32_t *d_out,
+                    size_t out_stride, unsigned log_n, unsigned added_bits, size_t width,
+                    uint32_t shift);
+
+/* ---- Poseidon2 (K2/K3) ---- */
+/* permutes n independent 16-word states, laid out state-major [n][16] */
+int zkhip_poseidon2_permute_batch(zkhip_ctx *ctx, uint32_t *d_states, size_t n);
+
+typedef struct {
+    const uint32_t *data; /* device, column-major, Montgomery */
+    size_t stride;
+    unsigned log_height;
+    size_t width;
+} zkhip_matrix;
+
+typedef struct zkhip_tree zkhip_tree;
+/* Merkle-Poseidon2 commitment of matrices of (possibly) mixed power-of-two
+ * heights; the matrices must stay alive as long as the tree.  root_out is a
+ * HOST buffer of 8 canonical words (synchronises); pass NULL to stay asynchronous. */
+int zkhip_merkle_commit(zkhip_ctx *ctx, const zkhip_matrix *mats, size_t n_mats,
+                        zkhip_tree **tree, uint32_t *root_out);
+/* device pointer to the Montgomery root digest (8 words) */
+const uint32_t *zkhip_tree_root_device(const zkhip_tree *tree);
+unsigned zkhip_tree_log_height(const zkhip_tree *tree);
+/* copies digest layer `layer` (0 = leaves) to host, canonical; out needs 8<<(log_height-layer) words */
+int zkhip_tree_layer(zkhip_ctx *ctx, const zkhip_tree *tree, unsigned layer, uint32_t *out);
+/* words one opening occupies: sum(widths) + 8*log_height */
+size_t zkhip_merkle_opening_words(const zkhip_tree *tree);
+/* K4: opens n leaf indices; out (HOST, canonical) receives n openings of
+ * zkhip_merkle_opening_words() each: opened rows (matrix order) then sibling digests bottom-up */
+int zkhip_merkle_open(zkhip_ctx *ctx, const zkhip_tree *tree, const uint64_t *indices, size_t n,
+                      uint32_t *out, size_t cap_words);
+void zkhip_tree_destroy(zkhip_ctx *ctx, zkhip_tree *tree);
+
+/* ---- FRI fold (K8): d_in = 2n extension elements in bit-reversed domain order,
+ *      d_out = n; beta = 4 canonical words (host) ---- */
+int zkhip_fri_fold(zkhip_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, unsigned log_n_out,
+                   const uint32_t beta[4]);
+
+/* ---- transcript (T4) and proof-of-work (K9), device resident ---- */
+typedef struct zkhip_transcript zkhip_transcript;
+int zkhip_transcript_create(zkhip_ctx *ctx, zkhip_transcript **out);
+void zkhip_transcript_destroy(zkhip_ctx *ctx, zkhip_transcript *t);
+/* observe n canonical words from host */
+int zkhip_transcript_observe(zkhip_ctx *ctx, zkhip_transcript *t, const uint32_t *vals, size_t n);
+/* sample n base-field elements (canonical) to host; synchronises */
+int zkhip_transcript_sample(zkhip_ctx *ctx, zkhip_transcript *t, uint32_t *out, size_t n);
+/* smallest witness such that observe(w); sample_bits(bits) == 0; advances the transcript */
+int zkhip_transcript_grind(zkhip_ctx *ctx, zkhip_transcript *t, unsigned bits, uint32_t *witness);
+
+/* ---- STARK proving / verification (a7 of SURVEY.md 8(a)): the `StarkEngine::prove`
+ *      replacement.  See DESIGN.md for protocol, AIR bytecode and proof layout. ---- */
+typedef struct {
+    uint32_t log_blowup;         /* openvm.toml:2  */
+    uint32_t log_final_poly_len; /* openvm.toml:3  */
+    uint32_t num_queries;        /* openvm.toml:4  */
+    uint32_t commit_pow_bits;    /* openvm.toml:5  */
+    uint32_t query_pow_bits;     /* openvm.toml:6  */
+} zkhip_params;
+
+typedef struct {
+    const uint32_t *program; /* host, AIR constraint bytecode */
+    size_t program_len;      /* words */
+    unsigned log_height;
+    size_t width;
+    size_t n_pvs;
+} zkhip_air;
+
+typedef struct zkhip_pk zkhip_pk;
+/* keygen: validates the programs, uploads them, plans kernels/workspace/proof layout */
+int zkhip_keygen(zkhip_ctx *ctx, const zkhip_params *params, const zkhip_air *airs, size_t n_airs,
+                 zkhip_pk **out);
+void zkhip_pk_destroy(zkhip_ctx *ctx, zkhip_pk *pk);
+/* exact proof size in bytes for this key (FRI proofs are shape-static) */
+size_t zkhip_proof_size(const zkhip_pk *pk);
+/* d_traces[i]: device, column-major Montgomery trace of AIR i with stride 1<<log_height;
+ * pvs[i]: host canonical public values.  Proof bytes (canonical LE u32) are written to the
+ * HOST buffer `out`.  Runs entirely on the ctx stream; returns after the final D2H. */
+int zkhip_prove(zkhip_ctx *ctx, const zkhip_pk *pk, const uint32_t *const *d_traces,
+                const uint32_t *const *pvs, uint8_t *out, size_t cap, size_t *out_len);
+/* Asynchronous variant for benchmarking / pipelining: leaves the proof in device memory
+ * (retrieve with zkhip_proof_fetch after zkhip_sync) */
+int zkhip_prove_async(zkhip_ctx *ctx, const zkhip_pk *pk, const uint32_t *const *d_traces,
+                      const uint32_t *const *pvs);
+int zkhip_proof_fetch(zkhip_ctx *ctx, const zkhip_pk *pk, uint8_t *out, size_t cap, size_t *out_len);
+/* Host verifier (replaces Sdk::verify_proof as called at crates/verifier/src/verifier.rs:82
+ * for this backend's proofs).  Needs no device. */
+int zkhip_verify(const zkhip_params *params, const zkhip_air *airs, size_t n_airs,
+                 const uint32_t *const *pvs, const uint8_t *proof, size_t len);
+
+/* ---- per-kernel timing (HIP events on the ctx stream), for bench.py's roofline ---- */
+int zkhip_profile_enable(zkhip_ctx *ctx, int on);
+/* copies up to cap entries; returns number of distinct kernel names recorded */
+typedef struct {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+} zkhip_kernel_stat;
+int zkhip_profile_read(zkhip_ctx *ctx, zkhip_kernel_stat *out, size_t cap);
+int zkhip_profile_reset(zkhip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,149 @@
+/*
+ * zk_oracle.h -- CPU restatement ("oracle") of the STARK hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is linked, imported or
+ * executed by the product (zkvm-prover_amd/, libzkhip.so).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and
+ * only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the arithmetic of this path is not in /root/reference.  It
+ * lives in un-vendored dependencies pinned by the reference's Cargo.lock:
+ *   p3-baby-bear / p3-monty-31 / p3-field / p3-dft / p3-poseidon2 /
+ *   p3-symmetric / p3-challenger 0.4.3   (Cargo.lock:5535-5750)
+ *   zkhash-axiom 0.2.0                    (Cargo.lock:10231)
+ *   openvm-stark-backend / -sdk 2.0.0 @16d60de7 (Cargo.lock:4634-4699,5337-5398)
+ * none of which can be built or fetched here (no Rust, no network).  This file
+ * restates their *published* algorithms (BabyBear, x^4-11 extension, radix-2
+ * DFT / coset LDE, Poseidon2-BabyBear-16 with Grain-LFSR constants,
+ * PaddingFreeSponge / TruncatedPermutation, MerkleTreeMmcs, DuplexChallenger,
+ * and the uni-stark + two-adic-FRI pipeline named by BASELINE.json
+ * north_star).  It is pinned only against (i) the constants the reference tree
+ * itself holds (p = 2013265921, scripts/compress_bn254.py:10; DIGEST_SIZE = 8,
+ * crates/types/src/proof.rs:209; FRI parameters,
+ * crates/circuits/chunk-circuit/openvm.toml:1-6), (ii) the Poseidon2 round
+ * constant anchors and permutation self-consistency vectors of SURVEY.md A.3,
+ * and (iii) an independent big-int Python model (tests/golden/gen_golden.py).
+ *
+ * All values crossing this API are CANONICAL u32 in [0, p).  Internally the
+ * oracle computes with 64-bit integers and `% p` (deliberately not the
+ * Montgomery form the HIP product uses).
+ */
+#ifndef ZK_ORACLE_H
+#define ZK_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORA_P 2013265921u /* 2^31 - 2^27 + 1, scripts/compress_bn254.py:10 */
+#define ORA_DIGEST 8      /* crates/types/src/proof.rs:209 DIGEST_SIZE */
+#define ORA_WIDTH 16
+#define ORA_RATE 8
+
+/* ---- base field (p3-baby-bear semantics, canonical representation) ---- */
+uint32_t ora_add(uint32_t a, uint32_t b);
+uint32_t ora_sub(uint32_t a, uint32_t b);
+uint32_t ora_mul(uint32_t a, uint32_t b);
+uint32_t ora_pow(uint32_t a, uint64_t e);
+uint32_t ora_inv(uint32_t a);
+uint32_t ora_two_adic_generator(unsigned bits); /* 0x1a427a41^(2^(27-bits)) */
+
+/* ---- quartic extension F[x]/(x^4 - 11), element = 4 coefficients ---- */
+void ora_ext_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4]);
+void ora_ext_inv(const uint32_t a[4], uint32_t out[4]);
+
+/* ---- DFT (p3-dft Radix2Dit semantics: natural order in, natural out) ---- */
+/* column-major matrix: column c occupies mat[c*stride .. c*stride+n) */
+void ora_dft_batch(uint32_t *mat, unsigned log_n, size_t width, size_t stride, int inverse);
+/* naive O(n^2) definition, for pinning the fast one */
+void ora_dft_naive(const uint32_t *in, uint32_t *out, unsigned log_n, int inverse);
+/* coset LDE: evals over H (natural) -> evals over shift*K, |K| = n<<added_bits.
+ * Output natural order unless bitrev_out, then row r holds point index bitrev(r). */
+void ora_coset_lde_batch(const uint32_t *in, size_t in_stride, uint32_t *out, size_t out_stride,
+                         unsigned log_n, unsigned added_bits, size_t width, uint32_t shift,
+                         int bitrev_out);
+
+/* ---- Poseidon2-BabyBear width 16 (p3-poseidon2 layers + zkhash RC16) ---- */
+const uint32_t *ora_poseidon2_round_constants(void); /* 141 values: 4x16 ext, 13 int, 4x16 ext */
+void ora_poseidon2_permute(uint32_t state[16]);
+/* PaddingFreeSponge<_,16,8,8>: absorb `len` elements, squeeze 8 */
+void ora_hash_slice(const uint32_t *in, size_t len, uint32_t out[8]);
+/* TruncatedPermutation<_,2,8,16> */
+void ora_compress(const uint32_t l[8], const uint32_t r[8], uint32_t out[8]);
+
+/* ---- MerkleTreeMmcs over column-major matrices of (possibly) mixed heights ---- */
+typedef struct {
+    const uint32_t *data; /* column-major */
+    size_t stride;        /* elements between columns */
+    unsigned log_height;
+    size_t width;
+} ora_matrix;
+
+typedef struct ora_tree ora_tree;
+ora_tree *ora_mmcs_commit(const ora_matrix *mats, size_t n_mats, uint32_t root[8]);
+unsigned ora_tree_log_height(const ora_tree *t);
+/* digest layer l (0 = leaves), returns pointer to 8*(2^(log_height-l)) words */
+const uint32_t *ora_tree_layer(const ora_tree *t, unsigned layer);
+/* open at leaf `index` of the tallest matrix: writes opened rows (matrices in
+ * given order, each `width` words, row = index >> (log_height - mat.log_height))
+ * then log_height sibling digests; returns number of words written. */
+size_t ora_mmcs_open(const ora_tree *t, size_t index, uint32_t *out);
+/* returns 1 if the opening verifies against root */
+int ora_mmcs_verify(const uint32_t root[8], const unsigned *log_heights, const size_t *widths,
+                    size_t n_mats, size_t index, const uint32_t *opening);
+void ora_tree_free(ora_tree *t);
+
+/* ---- DuplexChallenger<BabyBear, Perm, 16, 8> ---- */
+typedef struct {
+    uint32_t state[16];
+    uint32_t in_buf[8];
+    unsigned n_in;
+    uint32_t out_buf[8];
+    unsigned n_out;
+} ora_challenger;
+void ora_ch_init(ora_challenger *c);
+void ora_ch_observe(ora_challenger *c, const uint32_t *vals, size_t n);
+uint32_t ora_ch_sample(ora_challenger *c);
+void ora_ch_sample_ext(ora_challenger *c, uint32_t out[4]);
+uint32_t ora_ch_sample_bits(ora_challenger *c, unsigned bits);
+/* smallest witness w in [0,p) with check_witness(bits, w); also advances c */
+uint32_t ora_ch_grind(ora_challenger *c, unsigned bits);
+int ora_ch_check_witness(ora_challenger *c, unsigned bits, uint32_t witness);
+
+/* ---- FRI fold of one layer (p3-fri fold_row semantics, arity 2) ---- */
+/* in: 2*n ext elements (bit-reversed domain order), out: n ext elements */
+void ora_fri_fold(const uint32_t *in, uint32_t *out, unsigned log_n_out, const uint32_t beta[4]);
+
+/* ---- full STARK (see oracle/stark.c) ---- */
+typedef struct {
+    unsigned log_blowup;        /* 1  (openvm.toml:2) */
+    unsigned log_final_poly_len;/* 0  (openvm.toml:3) */
+    unsigned num_queries;       /* 100 (openvm.toml:4) */
+    unsigned commit_pow_bits;   /* 16 (openvm.toml:5) */
+    unsigned query_pow_bits;    /* 16 (openvm.toml:6) */
+} ora_params;
+
+typedef struct {
+    const uint32_t *program; /* constraint bytecode, see DESIGN.md "AIR bytecode" */
+    size_t program_len;      /* words */
+    unsigned log_height;
+    size_t width;
+    const uint32_t *trace;   /* column-major, stride = 1<<log_height, canonical */
+    const uint32_t *pvs;
+    size_t n_pvs;
+} ora_air_instance;
+
+/* Proves; writes proof words (canonical u32 LE) into out (cap words); returns
+ * number of words, or 0 on failure (e.g. constraints unsatisfied when checked). */
+size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size_t n_airs,
+                       uint32_t *out, size_t cap);
+/* Verifies a proof against the AIR programs/public values. 0 = ok, <0 = error code. */
+int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs /* trace ignored */,
+                     size_t n_airs, const uint32_t *proof, size_t n_words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

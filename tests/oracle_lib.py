@@ -1,0 +1,184 @@
+"""ctypes wrapper of oracle/liboracle.so (the CPU restatement).  TEST INFRASTRUCTURE: imported only
+by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORA_DIR = os.path.join(_ROOT, "oracle")
+_LIB = None
+P = 2013265921
+
+
+class OraMatrix(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride", C.c_size_t), ("log_height", C.c_uint), ("width", C.c_size_t)]
+
+
+class OraChallenger(C.Structure):
+    _fields_ = [("state", C.c_uint32 * 16), ("in_buf", C.c_uint32 * 8), ("n_in", C.c_uint),
+                ("out_buf", C.c_uint32 * 8), ("n_out", C.c_uint)]
+
+
+class OraParams(C.Structure):
+    _fields_ = [("log_blowup", C.c_uint), ("log_final_poly_len", C.c_uint), ("num_queries", C.c_uint),
+                ("commit_pow_bits", C.c_uint), ("query_pow_bits", C.c_uint)]
+
+
+class OraAir(C.Structure):
+    _fields_ = [("program", C.POINTER(C.c_uint32)), ("program_len", C.c_size_t), ("log_height", C.c_uint),
+                ("width", C.c_size_t), ("trace", C.POINTER(C.c_uint32)), ("pvs", C.POINTER(C.c_uint32)),
+                ("n_pvs", C.c_size_t)]
+
+
+def build():
+    so = os.path.join(_ORA_DIR, "liboracle.so")
+    srcs = [os.path.join(_ORA_DIR, f) for f in os.listdir(_ORA_DIR) if f.endswith((".c", ".h", "Makefile"))]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _ORA_DIR], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        l = C.CDLL(build())
+        u32p, sz = C.POINTER(C.c_uint32), C.c_size_t
+        l.ora_mul.restype = C.c_uint32
+        l.ora_mul.argtypes = [C.c_uint32, C.c_uint32]
+        l.ora_inv.restype = C.c_uint32
+        l.ora_inv.argtypes = [C.c_uint32]
+        l.ora_pow.restype = C.c_uint32
+        l.ora_pow.argtypes = [C.c_uint32, C.c_uint64]
+        l.ora_two_adic_generator.restype = C.c_uint32
+        l.ora_two_adic_generator.argtypes = [C.c_uint]
+        l.ora_ext_mul.argtypes = [u32p, u32p, u32p]
+        l.ora_ext_inv.argtypes = [u32p, u32p]
+        l.ora_dft_batch.argtypes = [u32p, C.c_uint, sz, sz, C.c_int]
+        l.ora_dft_naive.argtypes = [u32p, u32p, C.c_uint, C.c_int]
+        l.ora_coset_lde_batch.argtypes = [u32p, sz, u32p, sz, C.c_uint, C.c_uint, sz, C.c_uint32, C.c_int]
+        l.ora_poseidon2_round_constants.restype = u32p
+        l.ora_poseidon2_permute.argtypes = [u32p]
+        l.ora_hash_slice.argtypes = [u32p, sz, u32p]
+        l.ora_compress.argtypes = [u32p, u32p, u32p]
+        l.ora_mmcs_commit.restype = C.c_void_p
+        l.ora_mmcs_commit.argtypes = [C.POINTER(OraMatrix), sz, u32p]
+        l.ora_tree_log_height.restype = C.c_uint
+        l.ora_tree_log_height.argtypes = [C.c_void_p]
+        l.ora_tree_layer.restype = u32p
+        l.ora_tree_layer.argtypes = [C.c_void_p, C.c_uint]
+        l.ora_mmcs_open.restype = sz
+        l.ora_mmcs_open.argtypes = [C.c_void_p, sz, u32p]
+        l.ora_mmcs_verify.restype = C.c_int
+        l.ora_mmcs_verify.argtypes = [u32p, C.POINTER(C.c_uint), C.POINTER(sz), sz, sz, u32p]
+        l.ora_tree_free.argtypes = [C.c_void_p]
+        l.ora_ch_init.argtypes = [C.POINTER(OraChallenger)]
+        l.ora_ch_observe.argtypes = [C.POINTER(OraChallenger), u32p, sz]
+        l.ora_ch_sample.restype = C.c_uint32
+        l.ora_ch_sample.argtypes = [C.POINTER(OraChallenger)]
+        l.ora_ch_sample_bits.restype = C.c_uint32
+        l.ora_ch_sample_bits.argtypes = [C.POINTER(OraChallenger), C.c_uint]
+        l.ora_ch_grind.restype = C.c_uint32
+        l.ora_ch_grind.argtypes = [C.POINTER(OraChallenger), C.c_uint]
+        l.ora_fri_fold.argtypes = [u32p, u32p, C.c_uint, u32p]
+        if hasattr(l, "ora_stark_prove"):
+            l.ora_stark_prove.restype = sz
+            l.ora_stark_prove.argtypes = [C.POINTER(OraParams), C.POINTER(OraAir), sz, u32p, sz]
+            l.ora_stark_verify.restype = C.c_int
+            l.ora_stark_verify.argtypes = [C.POINTER(OraParams), C.POINTER(OraAir), sz, u32p, sz]
+        _LIB = l
+    return _LIB
+
+
+def p32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def rand_field(rng, shape):
+    return rng.integers(0, P, size=shape, dtype=np.uint64).astype(np.uint32)
+
+
+def dft_batch(mat_colmajor, log_n, inverse=False):
+    """mat: [width, n] uint32 canonical (row c = column c). Returns transformed copy."""
+    a = np.ascontiguousarray(mat_colmajor, dtype=np.uint32).copy()
+    lib().ora_dft_batch(p32(a), log_n, a.shape[0], a.shape[1], int(inverse))
+    return a
+
+
+def coset_lde_batch(mat_colmajor, log_n, added_bits, shift, bitrev_out=True):
+    a = np.ascontiguousarray(mat_colmajor, dtype=np.uint32)
+    w = a.shape[0]
+    out = np.zeros((w, 1 << (log_n + added_bits)), dtype=np.uint32)
+    lib().ora_coset_lde_batch(p32(a), a.shape[1], p32(out), out.shape[1], log_n, added_bits, w, shift,
+                              int(bitrev_out))
+    return out
+
+
+def permute(state):
+    s = np.ascontiguousarray(state, dtype=np.uint32).copy()
+    lib().ora_poseidon2_permute(p32(s))
+    return s
+
+
+class Tree:
+    def __init__(self, mats):
+        """mats: list of [width, height] uint32 canonical arrays (column-major storage)."""
+        self.mats = [np.ascontiguousarray(m, dtype=np.uint32) for m in mats]
+        arr = (OraMatrix * len(mats))()
+        for i, m in enumerate(self.mats):
+            arr[i] = OraMatrix(m.ctypes.data, m.shape[1], int(np.log2(m.shape[1])), m.shape[0])
+        self.root = np.zeros(8, dtype=np.uint32)
+        self.h = lib().ora_mmcs_commit(arr, len(mats), p32(self.root))
+        self.log_height = lib().ora_tree_log_height(self.h)
+        self.total_width = sum(m.shape[0] for m in self.mats)
+
+    def layer(self, l):
+        n = 8 << (self.log_height - l)
+        ptr = lib().ora_tree_layer(self.h, l)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).copy().reshape(-1, 8)
+
+    def open(self, index):
+        out = np.zeros(self.total_width + 8 * self.log_height, dtype=np.uint32)
+        n = lib().ora_mmcs_open(self.h, index, p32(out))
+        assert n == out.size
+        return out
+
+    def verify(self, index, opening):
+        lhs = (C.c_uint * len(self.mats))(*[int(np.log2(m.shape[1])) for m in self.mats])
+        ws = (C.c_size_t * len(self.mats))(*[m.shape[0] for m in self.mats])
+        op = np.ascontiguousarray(opening, dtype=np.uint32)
+        return bool(lib().ora_mmcs_verify(p32(self.root), lhs, ws, len(self.mats), index, p32(op)))
+
+    def __del__(self):
+        try:
+            lib().ora_tree_free(self.h)
+        except Exception:
+            pass
+
+
+class Challenger:
+    def __init__(self):
+        self.c = OraChallenger()
+        lib().ora_ch_init(C.byref(self.c))
+
+    def observe(self, vals):
+        a = np.ascontiguousarray(vals, dtype=np.uint32)
+        lib().ora_ch_observe(C.byref(self.c), p32(a), a.size)
+
+    def sample(self, n=1):
+        return np.array([lib().ora_ch_sample(C.byref(self.c)) for _ in range(n)], dtype=np.uint32)
+
+    def sample_bits(self, bits):
+        return lib().ora_ch_sample_bits(C.byref(self.c), bits)
+
+    def grind(self, bits):
+        return lib().ora_ch_grind(C.byref(self.c), bits)
+
+
+def fri_fold(vals, log_n_out, beta):
+    a = np.ascontiguousarray(vals, dtype=np.uint32)
+    out = np.zeros(4 << log_n_out, dtype=np.uint32)
+    b = np.asarray(beta, dtype=np.uint32)
+    lib().ora_fri_fold(p32(a), p32(out), log_n_out, p32(b))
+    return out

@@ -1,0 +1,17 @@
+"""zkvm-prover_amd -- host-side Python binding of libzkhip.so (MI355X STARK backend).
+
+The product is the C-ABI library (include/zkhip.h, sources in csrc/).  This module is the thin
+ctypes binding used by tests, bench.py and __graft_entry__; PyTorch only supplies device
+memory, streams and torch.distributed.  There is no CPU fallback: if the HIP library is missing
+or no gfx950 device is present every call raises.
+"""
+from ._binding import (  # noqa: F401
+    P,
+    Context,
+    MerkleTree,
+    Transcript,
+    ZkhipError,
+    library_path,
+    load_library,
+    declared_symbols,
+)

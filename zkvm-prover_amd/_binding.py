@@ -1,0 +1,294 @@
+"""ctypes binding of include/zkhip.h.  Device buffers are torch int32 tensors holding the u32 bit
+patterns (Montgomery form on device, see zkhip.h)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+P = 2013265921
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_LIB = None
+
+
+class ZkhipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libzkhip.so")
+
+
+def declared_symbols():
+    """Every function name declared in include/zkhip.h."""
+    with open(os.path.join(_ROOT, "include", "zkhip.h")) as f:
+        txt = f.read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(zkhip_[a-z0-9_]+)\s*\(", txt)))
+
+
+class _Matrix(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride", C.c_size_t), ("log_height", C.c_uint), ("width", C.c_size_t)]
+
+
+class _Params(C.Structure):
+    _fields_ = [("log_blowup", C.c_uint32), ("log_final_poly_len", C.c_uint32), ("num_queries", C.c_uint32),
+                ("commit_pow_bits", C.c_uint32), ("query_pow_bits", C.c_uint32)]
+
+
+class _Air(C.Structure):
+    _fields_ = [("program", C.POINTER(C.c_uint32)), ("program_len", C.c_size_t), ("log_height", C.c_uint),
+                ("width", C.c_size_t), ("n_pvs", C.c_size_t)]
+
+
+class _KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+def load_library():
+    """Loads libzkhip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ZkhipError("libzkhip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(or make -C zkvm-prover_amd/csrc)")
+    lib = C.CDLL(path)
+    vp, sz, u32p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)
+    sig = {
+        "zkhip_version": (C.c_uint32, []),
+        "zkhip_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "zkhip_ctx_destroy": (None, [vp]),
+        "zkhip_last_error": (C.c_char_p, [vp]),
+        "zkhip_set_stream": (C.c_int, [vp, vp]),
+        "zkhip_sync": (C.c_int, [vp]),
+        "zkhip_malloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
+        "zkhip_free": (C.c_int, [vp, vp]),
+        "zkhip_h2d": (C.c_int, [vp, vp, vp, sz]),
+        "zkhip_d2h": (C.c_int, [vp, vp, vp, sz]),
+        "zkhip_to_monty": (C.c_int, [vp, vp, sz]),
+        "zkhip_from_monty": (C.c_int, [vp, vp, sz]),
+        "zkhip_ntt_batch": (C.c_int, [vp, vp, C.c_uint, sz, sz, C.c_int, C.c_int]),
+        "zkhip_lde_batch": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint, C.c_uint, sz, C.c_uint32]),
+        "zkhip_poseidon2_permute_batch": (C.c_int, [vp, vp, sz]),
+        "zkhip_merkle_commit": (C.c_int, [vp, C.POINTER(_Matrix), sz, C.POINTER(vp), u32p]),
+        "zkhip_tree_root_device": (vp, [vp]),
+        "zkhip_tree_log_height": (C.c_uint, [vp]),
+        "zkhip_tree_layer": (C.c_int, [vp, vp, C.c_uint, u32p]),
+        "zkhip_merkle_opening_words": (sz, [vp]),
+        "zkhip_merkle_open": (C.c_int, [vp, vp, C.POINTER(C.c_uint64), sz, u32p, sz]),
+        "zkhip_tree_destroy": (None, [vp, vp]),
+        "zkhip_fri_fold": (C.c_int, [vp, vp, vp, C.c_uint, u32p]),
+        "zkhip_transcript_create": (C.c_int, [vp, C.POINTER(vp)]),
+        "zkhip_transcript_destroy": (None, [vp, vp]),
+        "zkhip_transcript_observe": (C.c_int, [vp, vp, u32p, sz]),
+        "zkhip_transcript_sample": (C.c_int, [vp, vp, u32p, sz]),
+        "zkhip_transcript_grind": (C.c_int, [vp, vp, C.c_uint, u32p]),
+        "zkhip_keygen": (C.c_int, [vp, C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(vp)]),
+        "zkhip_pk_destroy": (None, [vp, vp]),
+        "zkhip_proof_size": (sz, [vp]),
+        "zkhip_prove": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(u32p), C.POINTER(C.c_uint8), sz, C.POINTER(sz)]),
+        "zkhip_prove_async": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(u32p)]),
+        "zkhip_proof_fetch": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), sz, C.POINTER(sz)]),
+        "zkhip_verify": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(u32p), C.POINTER(C.c_uint8), sz]),
+        "zkhip_profile_enable": (C.c_int, [vp, C.c_int]),
+        "zkhip_profile_read": (C.c_int, [vp, C.POINTER(_KernelStat), sz]),
+        "zkhip_profile_reset": (C.c_int, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def _u32p(arr):
+    return arr.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class Context:
+    """One per GPU (zkhip_ctx).  Work is issued on the current torch stream of `device`."""
+
+    def __init__(self, device=0):
+        import torch
+
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise ZkhipError("no GPU visible: libzkhip has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        rc = self.lib.zkhip_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise ZkhipError("zkhip_ctx_create failed with %d (needs a gfx950 device)" % rc)
+        self.h = h
+        self.use_torch_stream()
+
+    def use_torch_stream(self):
+        import torch
+
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.zkhip_set_stream(self.h, C.c_void_p(s)))
+
+    def close(self):
+        if self.h:
+            self.lib.zkhip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ZkhipError("zkhip error %d: %s" % (rc, self.lib.zkhip_last_error(self.h).decode()))
+
+    def sync(self):
+        self._check(self.lib.zkhip_sync(self.h))
+
+    # ---- data movement -----------------------------------------------------------------------
+    def upload(self, arr_canonical):
+        """numpy uint32 (canonical) -> device int32 tensor in Montgomery form."""
+        import torch
+
+        a = np.ascontiguousarray(arr_canonical, dtype=np.uint32)
+        t = torch.from_numpy(a.view(np.int32)).to(self.device)
+        self._check(self.lib.zkhip_to_monty(self.h, C.c_void_p(t.data_ptr()), t.numel()))
+        return t
+
+    def download(self, t):
+        """device Montgomery tensor -> numpy uint32 canonical (tensor left untouched)."""
+        c = t.clone()
+        self._check(self.lib.zkhip_from_monty(self.h, C.c_void_p(c.data_ptr()), c.numel()))
+        self.sync()
+        return c.cpu().numpy().view(np.uint32)
+
+    # ---- stages --------------------------------------------------------------------------------
+    def ntt_batch(self, t, log_n, width, stride=None, inverse=False, bitrev_out=False):
+        stride = stride or (1 << log_n)
+        self._check(self.lib.zkhip_ntt_batch(self.h, C.c_void_p(t.data_ptr()), log_n, width, stride,
+                                             int(inverse), int(bitrev_out)))
+
+    def lde_batch(self, t_in, log_n, added_bits, width, shift, t_out=None, in_stride=None, out_stride=None):
+        import torch
+
+        in_stride = in_stride or (1 << log_n)
+        out_stride = out_stride or (1 << (log_n + added_bits))
+        if t_out is None:
+            t_out = torch.empty(width * out_stride, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_lde_batch(self.h, C.c_void_p(t_in.data_ptr()), in_stride,
+                                             C.c_void_p(t_out.data_ptr()), out_stride, log_n, added_bits, width,
+                                             shift))
+        return t_out
+
+    def poseidon2_permute_batch(self, t, n):
+        self._check(self.lib.zkhip_poseidon2_permute_batch(self.h, C.c_void_p(t.data_ptr()), n))
+
+    def merkle_commit(self, mats, want_root=True):
+        """mats: list of (tensor, log_height, width[, stride])."""
+        return MerkleTree(self, mats, want_root)
+
+    def fri_fold(self, t_in, log_n_out, beta):
+        import torch
+
+        out = torch.empty(4 << log_n_out, dtype=torch.int32, device=self.device)
+        b = np.asarray(beta, dtype=np.uint32)
+        self._check(self.lib.zkhip_fri_fold(self.h, C.c_void_p(t_in.data_ptr()), C.c_void_p(out.data_ptr()),
+                                            log_n_out, _u32p(b)))
+        return out
+
+    def transcript(self):
+        return Transcript(self)
+
+    # ---- profiling -----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.zkhip_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._check(self.lib.zkhip_profile_reset(self.h))
+
+    def profile_read(self):
+        buf = (_KernelStat * 64)()
+        n = self.lib.zkhip_profile_read(self.h, buf, 64)
+        return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(min(n, 64))}
+
+
+class MerkleTree:
+    def __init__(self, ctx, mats, want_root=True):
+        self.ctx = ctx
+        self._keep = [m[0] for m in mats]
+        arr = (_Matrix * len(mats))()
+        self.widths, self.log_heights = [], []
+        for i, m in enumerate(mats):
+            t, lh, w = m[0], m[1], m[2]
+            stride = m[3] if len(m) > 3 else (1 << lh)
+            arr[i] = _Matrix(t.data_ptr(), stride, lh, w)
+            self.widths.append(w)
+            self.log_heights.append(lh)
+        h = C.c_void_p()
+        root = np.zeros(8, dtype=np.uint32)
+        ctx._check(ctx.lib.zkhip_merkle_commit(ctx.h, arr, len(mats), C.byref(h), _u32p(root) if want_root else None))
+        self.h = h
+        self.root = root if want_root else None
+        self.log_height = ctx.lib.zkhip_tree_log_height(h)
+
+    def layer(self, l):
+        out = np.zeros(8 << (self.log_height - l), dtype=np.uint32)
+        self.ctx._check(self.ctx.lib.zkhip_tree_layer(self.ctx.h, self.h, l, _u32p(out)))
+        return out.reshape(-1, 8)
+
+    def open(self, indices):
+        idx = np.asarray(indices, dtype=np.uint64)
+        words = self.ctx.lib.zkhip_merkle_opening_words(self.h)
+        out = np.zeros(words * len(idx), dtype=np.uint32)
+        self.ctx._check(self.ctx.lib.zkhip_merkle_open(self.ctx.h, self.h, idx.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                       len(idx), _u32p(out), out.size))
+        return out.reshape(len(idx), words)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.zkhip_tree_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Transcript:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(ctx.lib.zkhip_transcript_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def observe(self, vals):
+        a = np.ascontiguousarray(vals, dtype=np.uint32)
+        self.ctx._check(self.ctx.lib.zkhip_transcript_observe(self.ctx.h, self.h, _u32p(a), a.size))
+
+    def sample(self, n=1):
+        out = np.zeros(n, dtype=np.uint32)
+        self.ctx._check(self.ctx.lib.zkhip_transcript_sample(self.ctx.h, self.h, _u32p(out), n))
+        return out
+
+    def grind(self, bits):
+        w = C.c_uint32()
+        self.ctx._check(self.ctx.lib.zkhip_transcript_grind(self.ctx.h, self.h, bits, C.byref(w)))
+        return w.value
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.zkhip_transcript_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,329 @@
+// api.hip -- the extern "C" surface of libzkhip.so (include/zkhip.h): context, memory pool,
+// profiling, and thin argument-checking wrappers around the stage launchers.
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <unordered_map>
+
+#include "transcript.hpp"
+#include "zkhip_internal.hpp"
+
+namespace zk {
+
+int set_error(zkhip_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->last_error = msg;
+    return code;
+}
+
+int get_scratch(zkhip_ctx* ctx, int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->scratch[slot]) {
+            ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            ZK_HIP_CHECK(ctx, hipFree(ctx->scratch[slot]));
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_bytes[slot] = 0;
+        }
+        if (hipMalloc(&ctx->scratch[slot], bytes) != hipSuccess)
+            return set_error(ctx, ZKHIP_ERR_NOMEM, "scratch allocation of " + std::to_string(bytes) + " bytes failed");
+        ctx->scratch_bytes[slot] = bytes;
+    }
+    *out = ctx->scratch[slot];
+    return ZKHIP_OK;
+}
+
+void profile_begin(zkhip_ctx* ctx, const char* name) {
+    if (!ctx->profiling) return;
+    PendingEvent pe;
+    pe.name = name;
+    if (hipEventCreate(&pe.start) != hipSuccess || hipEventCreate(&pe.stop) != hipSuccess) return;
+    hipEventRecord(pe.start, ctx->stream);
+    ctx->pending.push_back(pe);
+}
+void profile_end(zkhip_ctx* ctx) {
+    if (!ctx->profiling || ctx->pending.empty()) return;
+    hipEventRecord(ctx->pending.back().stop, ctx->stream);
+}
+int profile_flush(zkhip_ctx* ctx) {
+    for (auto& pe : ctx->pending) {
+        hipEventSynchronize(pe.stop);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
+            auto& st = ctx->stats[pe.name];
+            st.launches++;
+            st.total_ms += ms;
+        }
+        hipEventDestroy(pe.start);
+        hipEventDestroy(pe.stop);
+    }
+    ctx->pending.clear();
+    return ZKHIP_OK;
+}
+
+int permute_batch(zkhip_ctx* ctx, uint32_t* d_states, size_t n);
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+uint32_t zkhip_version(void) { return (0u << 16) | 1u; }
+
+int zkhip_ctx_create(int device, zkhip_ctx** out) {
+    if (!out) return ZKHIP_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return ZKHIP_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return ZKHIP_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ZKHIP_ERR_NO_DEVICE;
+    zkhip_ctx* ctx = new zkhip_ctx();
+    ctx->device = device;
+    ctx->cu_count = prop.multiProcessorCount;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        // the code object only carries gfx950 ISA: fail loudly instead of at first launch
+        delete ctx;
+        return ZKHIP_ERR_NO_DEVICE;
+    }
+    *out = ctx;
+    return ZKHIP_OK;
+}
+
+void zkhip_ctx_destroy(zkhip_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    profile_flush(ctx);
+    if (ctx->d_tw_fwd) hipFree(ctx->d_tw_fwd);
+    if (ctx->d_tw_inv) hipFree(ctx->d_tw_inv);
+    for (int i = 0; i < 4; i++)
+        if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
+    delete ctx;
+}
+
+const char* zkhip_last_error(const zkhip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "no context"; }
+
+int zkhip_set_stream(zkhip_ctx* ctx, void* hip_stream) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ctx->stream = (hipStream_t)hip_stream;
+    return ZKHIP_OK;
+}
+int zkhip_sync(zkhip_ctx* ctx) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
+int zkhip_malloc(zkhip_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return ZKHIP_ERR_INVALID;
+    if (hipMalloc(dptr, bytes ? bytes : 16) != hipSuccess)
+        return set_error(ctx, ZKHIP_ERR_NOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
+    return ZKHIP_OK;
+}
+int zkhip_free(zkhip_ctx* ctx, void* dptr) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    if (!dptr) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP_CHECK(ctx, hipFree(dptr));
+    return ZKHIP_OK;
+}
+int zkhip_h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // src may be pageable and freed by the caller
+    return ZKHIP_OK;
+}
+int zkhip_d2h(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+int zkhip_to_monty(zkhip_ctx* ctx, uint32_t* d, size_t n) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    return convert_repr(ctx, d, n, true);
+}
+int zkhip_from_monty(zkhip_ctx* ctx, uint32_t* d, size_t n) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    return convert_repr(ctx, d, n, false);
+}
+
+int zkhip_ntt_batch(zkhip_ctx* ctx, uint32_t* d_mat, unsigned log_n, size_t width, size_t stride, int inverse,
+                    int bitrev_out) {
+    if (!ctx || !d_mat) return ZKHIP_ERR_INVALID;
+    return ntt_batch(ctx, d_mat, log_n, width, stride, inverse != 0, bitrev_out != 0);
+}
+int zkhip_lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* d_out, size_t out_stride,
+                    unsigned log_n, unsigned added_bits, size_t width, uint32_t shift) {
+    if (!ctx || !d_in || !d_out) return ZKHIP_ERR_INVALID;
+    if (shift == 0 || shift >= P) return set_error(ctx, ZKHIP_ERR_INVALID, "shift must be in [1,p)");
+    return lde_batch(ctx, d_in, in_stride, d_out, out_stride, log_n, added_bits, width, to_monty(shift));
+}
+
+int zkhip_poseidon2_permute_batch(zkhip_ctx* ctx, uint32_t* d_states, size_t n) {
+    if (!ctx || !d_states) return ZKHIP_ERR_INVALID;
+    return permute_batch(ctx, d_states, n);
+}
+
+int zkhip_merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip_tree** tree,
+                        uint32_t* root_out) {
+    if (!ctx || !mats || !tree) return ZKHIP_ERR_INVALID;
+    ZK_TRY(merkle_commit(ctx, mats, n_mats, tree));
+    if (root_out) {
+        uint32_t tmp[8];
+        ZK_TRY(zkhip_d2h(ctx, tmp, zkhip_tree_root_device(*tree), sizeof tmp));
+        for (int i = 0; i < 8; i++) root_out[i] = from_monty(tmp[i]);
+    }
+    return ZKHIP_OK;
+}
+const uint32_t* zkhip_tree_root_device(const zkhip_tree* t) {
+    return t ? t->d_digests + t->layer_off[t->log_height] * 8 : nullptr;
+}
+unsigned zkhip_tree_log_height(const zkhip_tree* t) { return t ? t->log_height : 0; }
+int zkhip_tree_layer(zkhip_ctx* ctx, const zkhip_tree* t, unsigned layer, uint32_t* out) {
+    if (!ctx || !t || !out || layer > t->log_height) return ZKHIP_ERR_INVALID;
+    size_t words = (size_t)8 << (t->log_height - layer);
+    ZK_TRY(zkhip_d2h(ctx, out, t->d_digests + t->layer_off[layer] * 8, words * 4));
+    for (size_t i = 0; i < words; i++) out[i] = from_monty(out[i]);
+    return ZKHIP_OK;
+}
+size_t zkhip_merkle_opening_words(const zkhip_tree* t) { return t ? t->total_width + 8 * (size_t)t->log_height : 0; }
+int zkhip_merkle_open(zkhip_ctx* ctx, const zkhip_tree* t, const uint64_t* indices, size_t n, uint32_t* out,
+                      size_t cap_words) {
+    if (!ctx || !t || !indices || !out) return ZKHIP_ERR_INVALID;
+    size_t pitch = zkhip_merkle_opening_words(t);
+    if (cap_words < pitch * n) return set_error(ctx, ZKHIP_ERR_SMALL_BUFFER, "merkle_open: output too small");
+    std::vector<uint32_t> idx(n);
+    for (size_t i = 0; i < n; i++) {
+        if (indices[i] >> t->log_height) return set_error(ctx, ZKHIP_ERR_INVALID, "merkle_open: index out of range");
+        idx[i] = (uint32_t)indices[i];
+    }
+    void *d_idx, *d_out;
+    ZK_TRY(get_scratch(ctx, 2, n * 4, &d_idx));
+    ZK_TRY(get_scratch(ctx, 3, pitch * n * 4, &d_out));
+    ZK_TRY(zkhip_h2d(ctx, d_idx, idx.data(), n * 4));
+    ZK_TRY(merkle_open_device(ctx, t, (const uint32_t*)d_idx, 0, n, (uint32_t*)d_out, pitch));
+    return zkhip_d2h(ctx, out, d_out, pitch * n * 4);
+}
+void zkhip_tree_destroy(zkhip_ctx* ctx, zkhip_tree* t) {
+    if (!t) return;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (t->d_colptrs) hipFree(t->d_colptrs);
+    if (t->d_digests && t->owns_digests) hipFree(t->d_digests);
+    delete t;
+}
+
+int zkhip_fri_fold(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, unsigned log_n_out, const uint32_t beta[4]) {
+    if (!ctx || !d_in || !d_out || !beta) return ZKHIP_ERR_INVALID;
+    uint32_t bm[4];
+    for (int i = 0; i < 4; i++) {
+        if (beta[i] >= P) return set_error(ctx, ZKHIP_ERR_INVALID, "beta not canonical");
+        bm[i] = to_monty(beta[i]);
+    }
+    void* d_beta;
+    ZK_TRY(get_scratch(ctx, 2, 16, &d_beta));
+    ZK_TRY(zkhip_h2d(ctx, d_beta, bm, 16));
+    return fri_fold(ctx, d_in, d_out, log_n_out, (const uint32_t*)d_beta, nullptr, false);
+}
+
+// ---- transcript handle ------------------------------------------------------------------------
+struct zkhip_transcript {
+    DevTranscript* d = nullptr;
+    uint32_t* d_buf = nullptr;  // staging for observe/sample
+    size_t buf_words = 0;
+};
+
+static int tr_buf(zkhip_ctx* ctx, zkhip_transcript* t, size_t words) {
+    if (t->buf_words >= words) return ZKHIP_OK;
+    if (t->d_buf) {
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        ZK_HIP_CHECK(ctx, hipFree(t->d_buf));
+    }
+    size_t w = std::max<size_t>(words, 1024);
+    ZK_HIP_CHECK(ctx, hipMalloc(&t->d_buf, w * 4));
+    t->buf_words = w;
+    return ZKHIP_OK;
+}
+
+int zkhip_transcript_create(zkhip_ctx* ctx, zkhip_transcript** out) {
+    if (!ctx || !out) return ZKHIP_ERR_INVALID;
+    zkhip_transcript* t = new zkhip_transcript();
+    if (hipMalloc(&t->d, sizeof(DevTranscript)) != hipSuccess) {
+        delete t;
+        return set_error(ctx, ZKHIP_ERR_NOMEM, "transcript alloc");
+    }
+    int rc = transcript_init(ctx, t->d);
+    if (rc != ZKHIP_OK) {
+        hipFree(t->d);
+        delete t;
+        return rc;
+    }
+    *out = t;
+    return ZKHIP_OK;
+}
+void zkhip_transcript_destroy(zkhip_ctx* ctx, zkhip_transcript* t) {
+    if (!t) return;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (t->d) hipFree(t->d);
+    if (t->d_buf) hipFree(t->d_buf);
+    delete t;
+}
+int zkhip_transcript_observe(zkhip_ctx* ctx, zkhip_transcript* t, const uint32_t* vals, size_t n) {
+    if (!ctx || !t || (!vals && n)) return ZKHIP_ERR_INVALID;
+    if (n == 0) return ZKHIP_OK;
+    for (size_t i = 0; i < n; i++)
+        if (vals[i] >= P) return set_error(ctx, ZKHIP_ERR_INVALID, "observe: value not canonical");
+    ZK_TRY(tr_buf(ctx, t, n));
+    ZK_TRY(zkhip_h2d(ctx, t->d_buf, vals, n * 4));
+    return transcript_observe(ctx, t->d, t->d_buf, (uint32_t)n, true);
+}
+int zkhip_transcript_sample(zkhip_ctx* ctx, zkhip_transcript* t, uint32_t* out, size_t n) {
+    if (!ctx || !t || (!out && n)) return ZKHIP_ERR_INVALID;
+    if (n == 0) return ZKHIP_OK;
+    ZK_TRY(tr_buf(ctx, t, n));
+    ZK_TRY(transcript_sample(ctx, t->d, nullptr, t->d_buf, (uint32_t)n));
+    return zkhip_d2h(ctx, out, t->d_buf, n * 4);
+}
+int zkhip_transcript_grind(zkhip_ctx* ctx, zkhip_transcript* t, unsigned bits, uint32_t* witness) {
+    if (!ctx || !t || !witness) return ZKHIP_ERR_INVALID;
+    ZK_TRY(tr_buf(ctx, t, 1));
+    ZK_TRY(transcript_grind(ctx, t->d, bits, t->d_buf));
+    ZK_TRY(zkhip_d2h(ctx, witness, t->d_buf, 4));
+    DevTranscript h;
+    ZK_TRY(zkhip_d2h(ctx, &h, t->d, sizeof h));
+    if (h.error) return set_error(ctx, ZKHIP_ERR_POW_FAILED, "proof-of-work search failed");
+    return ZKHIP_OK;
+}
+
+// ---- profiling ----------------------------------------------------------------------------------
+int zkhip_profile_enable(zkhip_ctx* ctx, int on) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    if (!on) profile_flush(ctx);
+    ctx->profiling = on != 0;
+    return ZKHIP_OK;
+}
+int zkhip_profile_read(zkhip_ctx* ctx, zkhip_kernel_stat* out, size_t cap) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    profile_flush(ctx);
+    size_t i = 0;
+    for (auto& kv : ctx->stats) {
+        if (out && i < cap) {
+            memset(&out[i], 0, sizeof out[i]);
+            strncpy(out[i].name, kv.first.c_str(), sizeof(out[i].name) - 1);
+            out[i].launches = kv.second.launches;
+            out[i].total_ms = kv.second.total_ms;
+        }
+        i++;
+    }
+    return (int)i;
+}
+int zkhip_profile_reset(zkhip_ctx* ctx) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    profile_flush(ctx);
+    ctx->stats.clear();
+    return ZKHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+// merkle.hip -- Poseidon2 Merkle commitment (K2 row sponge, K3 compression layers, K4 openings).
+//
+// Replaces the engine's "Merkle-Poseidon2 commit" of RS-encoded matrices (SURVEY.md 8(a) a7.2,
+// a7.6): leaf i = PaddingFreeSponge<16,8,8> over the concatenated row i of every tallest matrix,
+// parent = TruncatedPermutation(left || right), and a matrix of height s is injected into the
+// layer of size s as node = compress(node, sponge(row)) -- the published p3 MerkleTreeMmcs rule.
+// Digest = 8 words (crates/types/src/proof.rs:209).
+//
+// gfx950 mapping: one matrix row per lane.  Matrices are column-major, so lane i reading row i
+// of column c is a 256-byte coalesced wave access with no transposition; the 16-word sponge
+// state lives in VGPRs, round constants are literals, the column-pointer table is wave-uniform
+// (scalar loads).  The kernel is integer-VALU bound (~600 Montgomery products per permutation),
+// not HBM bound -- see DESIGN.md "Rooflines".
+#include <algorithm>
+
+#include "poseidon2.hpp"
+#include "zkhip_internal.hpp"
+
+namespace zk {
+
+__device__ __forceinline__ void absorb_rows(uint32_t s[16], const uint32_t* const* __restrict__ cols,
+                                            uint32_t n_cols, size_t row) {
+    uint32_t j = 0;
+    for (; j + 8 <= n_cols; j += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = cols[j + k][row];
+        poseidon2_permute(s);
+    }
+    if (j < n_cols) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (j + k < n_cols) s[k] = cols[j + k][row];
+        poseidon2_permute(s);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hash_rows(const uint32_t* const* __restrict__ cols, uint32_t n_cols,
+                                                   size_t n_rows, uint32_t* __restrict__ out) {
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    uint32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = 0;
+    absorb_rows(s, cols, n_cols, row);
+    uint4* o = reinterpret_cast<uint4*>(out + row * 8);
+    o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// next[i] = compress(prev[2i], prev[2i+1]); with injected matrices: compress(that, sponge(row i))
+__global__ __launch_bounds__(256) void k_compress_layer(const uint32_t* __restrict__ prev,
+                                                        uint32_t* __restrict__ next, size_t n_next,
+                                                        const uint32_t* const* __restrict__ inj_cols,
+                                                        uint32_t n_inj_cols) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_next) return;
+    uint32_t s[16];
+    const uint4* p = reinterpret_cast<const uint4*>(prev + i * 16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint4 v = p[q];
+        s[4 * q] = v.x, s[4 * q + 1] = v.y, s[4 * q + 2] = v.z, s[4 * q + 3] = v.w;
+    }
+    poseidon2_permute(s);
+    if (n_inj_cols) {
+        uint32_t h[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) h[k] = 0;
+        absorb_rows(h, inj_cols, n_inj_cols, i);
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[8 + k] = h[k];
+        poseidon2_permute(s);
+    }
+    uint4* o = reinterpret_cast<uint4*>(next + i * 8);
+    o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+__global__ void k_permute_batch(uint32_t* states, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[16];
+    uint4* p = reinterpret_cast<uint4*>(states + i * 16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint4 v = p[q];
+        s[4 * q] = v.x, s[4 * q + 1] = v.y, s[4 * q + 2] = v.z, s[4 * q + 3] = v.w;
+    }
+    poseidon2_permute(s);
+#pragma unroll
+    for (int q = 0; q < 4; q++) p[q] = make_uint4(s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]);
+}
+
+int permute_batch(zkhip_ctx* ctx, uint32_t* d_states, size_t n) {
+    if (n == 0) return ZKHIP_OK;
+    KernelScope ks(ctx, "poseidon2_permute_batch");
+    hipLaunchKernelGGL(k_permute_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_states, n);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+size_t merkle_digest_count(unsigned log_height) { return ((size_t)2 << log_height) - 1; }
+
+// Layout of the per-tree pointer store (device):
+//   [ all columns in caller order : total_width pointers ]
+//   [ per level L = log_height .. 0 : pointers of the columns of matrices with that height ]
+//   then u32 shifts[total_width] (log_height - mat.log_height) for the open kernel
+int merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip_tree** out) {
+    if (n_mats == 0) return set_error(ctx, ZKHIP_ERR_INVALID, "merkle_commit: no matrices");
+    zkhip_tree* t = new zkhip_tree();
+    t->mats.assign(mats, mats + n_mats);
+    unsigned lh = 0;
+    size_t total_w = 0;
+    for (size_t m = 0; m < n_mats; m++) {
+        lh = std::max(lh, mats[m].log_height);
+        total_w += mats[m].width;
+        if (mats[m].stride < ((size_t)1 << mats[m].log_height)) {
+            delete t;
+            return set_error(ctx, ZKHIP_ERR_INVALID, "merkle_commit: stride < height");
+        }
+    }
+    t->log_height = lh;
+    t->total_width = total_w;
+    // host-side pointer tables
+    std::vector<const uint32_t*> ptrs;
+    std::vector<uint32_t> shifts;
+    for (size_t m = 0; m < n_mats; m++)
+        for (size_t c = 0; c < mats[m].width; c++) {
+            ptrs.push_back(mats[m].data + c * mats[m].stride);
+            shifts.push_back(lh - mats[m].log_height);
+        }
+    std::vector<size_t> level_off(lh + 1), level_cnt(lh + 1);
+    for (unsigned level = 0; level <= lh; level++) {
+        level_off[level] = ptrs.size();
+        size_t cnt = 0;
+        for (size_t m = 0; m < n_mats; m++)
+            if (mats[m].log_height == level)
+                for (size_t c = 0; c < mats[m].width; c++, cnt++) ptrs.push_back(mats[m].data + c * mats[m].stride);
+        level_cnt[level] = cnt;
+    }
+    size_t ptr_bytes = ptrs.size() * sizeof(void*), shift_bytes = shifts.size() * sizeof(uint32_t);
+    if (hipMalloc(&t->d_colptrs, ptr_bytes + shift_bytes + 16) != hipSuccess) {
+        delete t;
+        return set_error(ctx, ZKHIP_ERR_NOMEM, "merkle_commit: pointer table alloc");
+    }
+    // synchronous small copies (pageable host memory): keeps the host vectors' lifetime simple
+    hipError_t e1 = hipMemcpy(t->d_colptrs, ptrs.data(), ptr_bytes, hipMemcpyHostToDevice);
+    hipError_t e2 = shift_bytes ? hipMemcpy((char*)t->d_colptrs + ptr_bytes, shifts.data(), shift_bytes,
+                                            hipMemcpyHostToDevice)
+                                : hipSuccess;
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        hipFree(t->d_colptrs);
+        delete t;
+        return set_error(ctx, ZKHIP_ERR_HIP, "merkle_commit: pointer table upload");
+    }
+    size_t n_dig = merkle_digest_count(lh);
+    if (hipMalloc(&t->d_digests, n_dig * 8 * sizeof(uint32_t)) != hipSuccess) {
+        hipFree(t->d_colptrs);
+        delete t;
+        return set_error(ctx, ZKHIP_ERR_NOMEM, "merkle_commit: digest alloc");
+    }
+    t->layer_off.resize(lh + 1);
+    size_t off = 0;
+    for (unsigned l = 0; l <= lh; l++) {
+        t->layer_off[l] = off;
+        off += (size_t)1 << (lh - l);
+    }
+    const uint32_t* const* d_ptrs = (const uint32_t* const*)t->d_colptrs;
+    size_t n = (size_t)1 << lh;
+    {
+        KernelScope ks(ctx, "poseidon2_hash_rows");
+        hipLaunchKernelGGL(k_hash_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           d_ptrs + level_off[lh], (uint32_t)level_cnt[lh], n, t->d_digests);
+    }
+    for (unsigned l = 1; l <= lh; l++) {
+        unsigned level = lh - l;
+        size_t cnt = (size_t)1 << level;
+        KernelScope ks(ctx, "poseidon2_compress_layer");
+        hipLaunchKernelGGL(k_compress_layer, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                           t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,
+                           d_ptrs + level_off[level], (uint32_t)level_cnt[level]);
+    }
+    if (hipGetLastError() != hipSuccess) {
+        hipFree(t->d_colptrs);
+        hipFree(t->d_digests);
+        delete t;
+        return set_error(ctx, ZKHIP_ERR_HIP, "merkle_commit: launch failed");
+    }
+    *out = t;
+    return ZKHIP_OK;
+}
+
+// One block per opened index: rows of every matrix (canonical) then sibling digests bottom-up.
+__global__ void k_merkle_open(const uint32_t* const* __restrict__ cols, const uint32_t* __restrict__ shifts,
+                              uint32_t total_w, const uint32_t* __restrict__ digests, unsigned log_height,
+                              const uint32_t* __restrict__ indices, unsigned index_shift,
+                              uint32_t* __restrict__ out, size_t pitch) {
+    const size_t q = blockIdx.x;
+    const size_t index = indices[q] >> index_shift;
+    uint32_t* o = out + q * pitch;
+    for (uint32_t c = threadIdx.x; c < total_w; c += blockDim.x) o[c] = from_monty(cols[c][index >> shifts[c]]);
+    size_t layer_off = 0;
+    for (unsigned l = 0; l < log_height; l++) {
+        size_t sib = (index >> l) ^ 1;
+        if (threadIdx.x < 8) o[total_w + 8 * l + threadIdx.x] = from_monty(digests[(layer_off + sib) * 8 + threadIdx.x]);
+        layer_off += (size_t)1 << (log_height - l);
+    }
+}
+
+int merkle_open_device(zkhip_ctx* ctx, const zkhip_tree* t, const uint32_t* d_indices, unsigned index_shift,
+                       size_t n, uint32_t* d_out, size_t out_pitch_words) {
+    if (n == 0) return ZKHIP_OK;
+    KernelScope ks(ctx, "merkle_open");
+    const uint32_t* const* d_ptrs = (const uint32_t* const*)t->d_colptrs;
+    // shifts live after ALL pointer tables; recompute the pointer count
+    size_t n_ptrs = t->total_width * 2;  // caller-order table + per-level tables cover each column once more
+    const uint32_t* d_shifts = (const uint32_t*)((const char*)t->d_colptrs + n_ptrs * sizeof(void*));
+    hipLaunchKernelGGL(k_merkle_open, dim3((unsigned)n), dim3(128), 0, ctx->stream, d_ptrs, d_shifts,
+                       (uint32_t)t->total_width, t->d_digests, t->log_height, d_indices, index_shift, d_out,
+                       out_pitch_words);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+}  // namespace zk

@@ -1,0 +1,132 @@
+// poseidon2.hpp -- Poseidon2-BabyBear width-16 permutation, x^7 S-box, 8 external + 13 internal
+// rounds, on Montgomery residues.  Host + device (the host copy serves the verifier and keygen).
+//
+// Restates (not copies) the structure the reference links: p3-poseidon2 0.4.3 external layer
+// (MDSMat4 "light" permutation) + p3-baby-bear 0.4.3 internal diagonal + zkhash-axiom 0.2.0
+// RC16 round constants (Cargo.lock:5708,5545,10231).  Digest = 8 words
+// (crates/types/src/proof.rs:209).  Sponge = PaddingFreeSponge<16,8,8>, compression =
+// TruncatedPermutation<2,8,16>.
+#pragma once
+#include "babybear.hpp"
+
+namespace zk {
+
+struct Poseidon2Consts {
+    static constexpr uint32_t RC[141] = {
+#include "poseidon2_rc.inc"
+    };
+};
+
+// diag V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 1/2^8, 1/4, 1/8, 1/2^27, -1/2^8, -1/16, -1/2^27]
+// (Montgomery form; entries 0..8 are applied with adds / halving instead of a multiply)
+struct Poseidon2Diag {
+    // 2^-k in Montgomery form = 2^(32-k) mod p
+    static constexpr uint32_t INV_2_8 = (1u << 24);           // 2^-8  * 2^32
+    static constexpr uint32_t INV_4 = (1u << 30);             // 2^-2  * 2^32
+    static constexpr uint32_t INV_8 = (1u << 29);             // 2^-3  * 2^32
+    static constexpr uint32_t INV_16 = (1u << 28);            // 2^-4  * 2^32
+    static constexpr uint32_t INV_2_27 = (1u << 5);           // 2^-27 * 2^32
+};
+
+ZK_HD uint32_t mdouble(uint32_t x) { return red_2p(x << 1); }
+ZK_HD uint32_t mhalve(uint32_t x) { return (x & 1u) ? ((x >> 1) + ((P + 1u) >> 1)) : (x >> 1); }
+
+ZK_HD uint32_t sbox7(uint32_t x) {
+    uint32_t x2 = mmul(x, x);
+    uint32_t x3 = mmul(x2, x);
+    uint32_t x4 = mmul(x2, x2);
+    return mmul(x3, x4);
+}
+
+// M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] on each 4-block, then add column sums.
+ZK_HD void p2_external_linear(uint32_t s[16]) {
+#pragma unroll
+    for (int b = 0; b < 16; b += 4) {
+        uint32_t x0 = s[b], x1 = s[b + 1], x2 = s[b + 2], x3 = s[b + 3];
+        uint32_t t01 = madd(x0, x1), t23 = madd(x2, x3);
+        uint32_t t0123 = madd(t01, t23);
+        uint32_t t01123 = madd(t0123, x1), t01233 = madd(t0123, x3);
+        s[b + 3] = madd(t01233, mdouble(x0));
+        s[b + 1] = madd(t01123, mdouble(x2));
+        s[b + 0] = madd(t01123, t01);
+        s[b + 2] = madd(t01233, t23);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t sum = madd(madd(s[k], s[4 + k]), madd(s[8 + k], s[12 + k]));
+#pragma unroll
+        for (int b = 0; b < 16; b += 4) s[b + k] = madd(s[b + k], sum);
+    }
+}
+
+ZK_HD void p2_internal_linear(uint32_t s[16]) {
+    uint32_t sum = 0;
+    {
+        uint32_t a0 = madd(s[0], s[1]), a1 = madd(s[2], s[3]), a2 = madd(s[4], s[5]), a3 = madd(s[6], s[7]);
+        uint32_t a4 = madd(s[8], s[9]), a5 = madd(s[10], s[11]), a6 = madd(s[12], s[13]), a7 = madd(s[14], s[15]);
+        sum = madd(madd(madd(a0, a1), madd(a2, a3)), madd(madd(a4, a5), madd(a6, a7)));
+    }
+    uint32_t d;
+    s[0] = msub(sum, mdouble(s[0]));                          // -2
+    s[1] = madd(sum, s[1]);                                   //  1
+    s[2] = madd(sum, mdouble(s[2]));                          //  2
+    s[3] = madd(sum, mhalve(s[3]));                           //  1/2
+    d = mdouble(s[4]); s[4] = madd(sum, madd(d, s[4]));       //  3
+    s[5] = madd(sum, mdouble(mdouble(s[5])));                 //  4
+    s[6] = msub(sum, mhalve(s[6]));                           // -1/2
+    d = mdouble(s[7]); s[7] = msub(sum, madd(d, s[7]));       // -3
+    s[8] = msub(sum, mdouble(mdouble(s[8])));                 // -4
+    s[9] = madd(sum, mmul(s[9], Poseidon2Diag::INV_2_8));     //  1/2^8
+    s[10] = madd(sum, mmul(s[10], Poseidon2Diag::INV_4));     //  1/4
+    s[11] = madd(sum, mmul(s[11], Poseidon2Diag::INV_8));     //  1/8
+    s[12] = madd(sum, mmul(s[12], Poseidon2Diag::INV_2_27));  //  1/2^27
+    s[13] = msub(sum, mmul(s[13], Poseidon2Diag::INV_2_8));   // -1/2^8
+    s[14] = msub(sum, mmul(s[14], Poseidon2Diag::INV_16));    // -1/16
+    s[15] = msub(sum, mmul(s[15], Poseidon2Diag::INV_2_27));  // -1/2^27
+}
+
+ZK_HD void poseidon2_permute(uint32_t s[16]) {
+    p2_external_linear(s);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = sbox7(madd(s[i], Poseidon2Consts::RC[r * 16 + i]));
+        p2_external_linear(s);
+    }
+#pragma unroll
+    for (int r = 0; r < 13; r++) {
+        s[0] = sbox7(madd(s[0], Poseidon2Consts::RC[64 + r]));
+        p2_internal_linear(s);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = sbox7(madd(s[i], Poseidon2Consts::RC[77 + r * 16 + i]));
+        p2_external_linear(s);
+    }
+}
+
+// host-side helpers (sponge over a slice, 2-to-1 compression) for the verifier / keygen
+ZK_HD void p2_hash_slice(const uint32_t* in, size_t len, uint32_t out[8]) {
+    uint32_t s[16];
+    for (int i = 0; i < 16; i++) s[i] = 0;
+    size_t i = 0;
+    while (i < len) {
+        size_t n = len - i < 8 ? len - i : 8;
+        for (size_t k = 0; k < n; k++) s[k] = in[i + k];
+        poseidon2_permute(s);
+        i += n;
+    }
+    for (int k = 0; k < 8; k++) out[k] = s[k];
+}
+ZK_HD void p2_compress(const uint32_t l[8], const uint32_t r[8], uint32_t out[8]) {
+    uint32_t s[16];
+    for (int k = 0; k < 8; k++) {
+        s[k] = l[k];
+        s[8 + k] = r[k];
+    }
+    poseidon2_permute(s);
+    for (int k = 0; k < 8; k++) out[k] = s[k];
+}
+
+}  // namespace zk

@@ -1,0 +1,117 @@
+// zkhip_internal.hpp -- context, error handling, launch/profiling helpers shared by the
+// translation units of libzkhip.so.  Not part of the ABI (include/zkhip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/zkhip.h"
+#include "babybear.hpp"
+
+namespace zk {
+
+struct ProfileEntry {
+    uint64_t launches = 0;
+    double total_ms = 0;
+};
+
+struct PendingEvent {
+    std::string name;
+    hipEvent_t start, stop;
+};
+
+}  // namespace zk
+
+struct zkhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    // twiddle tables: w^e (fwd) and w^-e (inv) for w = two_adic_generator(tw_log), e < 2^(tw_log-1)
+    unsigned tw_log = 0;
+    uint32_t* d_tw_fwd = nullptr;
+    uint32_t* d_tw_inv = nullptr;
+    // grow-only scratch buffers (the pool never returns pages to the driver while the ctx lives,
+    // like the VPMM pool it replaces -- AGENTS.md:136)
+    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    // profiling
+    bool profiling = false;
+    std::vector<zk::PendingEvent> pending;
+    std::map<std::string, zk::ProfileEntry> stats;
+    int cu_count = 256;
+};
+
+namespace zk {
+
+int set_error(zkhip_ctx* ctx, int code, const std::string& msg);
+int ensure_twiddles(zkhip_ctx* ctx, unsigned log_n);
+int get_scratch(zkhip_ctx* ctx, int slot, size_t bytes, void** out);
+void profile_begin(zkhip_ctx* ctx, const char* name);
+void profile_end(zkhip_ctx* ctx);
+int profile_flush(zkhip_ctx* ctx);
+
+#define ZK_HIP_CHECK(ctx, expr)                                                              \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return zk::set_error((ctx), ZKHIP_ERR_HIP,                                       \
+                                 std::string(#expr) + ": " + hipGetErrorString(_e));         \
+    } while (0)
+
+#define ZK_TRY(expr)               \
+    do {                           \
+        int _rc = (expr);          \
+        if (_rc != ZKHIP_OK) return _rc; \
+    } while (0)
+
+// RAII-ish scope for per-kernel timing: records HIP events on the ctx stream when profiling is on
+struct KernelScope {
+    zkhip_ctx* ctx;
+    KernelScope(zkhip_ctx* c, const char* name) : ctx(c) { profile_begin(ctx, name); }
+    ~KernelScope() { profile_end(ctx); }
+};
+
+// ---- kernels / stages implemented across the .hip files --------------------------------------
+// ntt.hip
+int ntt_dif_inplace(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint32_t* dst, size_t dst_stride,
+                    unsigned log_n, size_t width, unsigned log_sub, bool inverse);
+int ntt_batch(zkhip_ctx* ctx, uint32_t* d_mat, unsigned log_n, size_t width, size_t stride, bool inverse,
+              bool bitrev_out);
+int lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* d_out, size_t out_stride,
+              unsigned log_n, unsigned added_bits, size_t width, uint32_t shift_monty);
+int convert_repr(zkhip_ctx* ctx, uint32_t* d, size_t n, bool to_monty);
+
+// merkle.hip
+struct TreeLevelInject {
+    // matrices injected at a level (or hashed at the leaf level): column pointer table on device
+    const uint32_t** d_cols = nullptr;  // device array of column base pointers
+    uint32_t n_cols = 0;
+};
+
+}  // namespace zk
+
+struct zkhip_tree {
+    unsigned log_height = 0;
+    std::vector<zkhip_matrix> mats;        // caller order
+    uint32_t* d_digests = nullptr;         // all layers, layer l at offset layer_off[l] (in digests)
+    std::vector<size_t> layer_off;         // in units of 8-word digests
+    void* d_colptrs = nullptr;             // backing store of the column pointer tables
+    bool owns_digests = true;
+    size_t total_width = 0;
+};
+
+namespace zk {
+int merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip_tree** out);
+size_t merkle_digest_count(unsigned log_height);
+// gathers openings for n leaf indices (device array of u32 indices) into a device buffer (canonical)
+int merkle_open_device(zkhip_ctx* ctx, const zkhip_tree* tree, const uint32_t* d_indices, unsigned index_shift,
+                       size_t n, uint32_t* d_out, size_t out_pitch_words);
+
+// fri.hip
+int permute_batch(zkhip_ctx* ctx, uint32_t* d_states, size_t n);
+int fri_fold(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, unsigned log_n_out, const uint32_t* d_beta,
+             const uint32_t* d_add, /* optional: out[i] += beta^2 * add[i] */ bool has_add);
+}  // namespace zk
