@@ -1,0 +1,713 @@
+/*
+ * oracle/stark.c -- CPU restatement of the whole proving path and its verifier.
+ * TEST INFRASTRUCTURE (see zk_oracle.h).  PARITY UNPINNED.
+ *
+ * What it restates: the STARK the reference obtains from `sdk.prove(..)`
+ * (crates/prover/src/prover/mod.rs:355-357) in the shape BASELINE.json's
+ * north_star names -- trace commit -> coset LDE -> Merkle-Poseidon2 commit ->
+ * constraint/quotient evaluation -> FRI fold loop with PoW and queries -- i.e.
+ * the published Plonky3 uni-stark + TwoAdicFriPcs pipeline (multi-matrix,
+ * mixed heights) with the FRI parameters of
+ * crates/circuits/chunk-circuit/openvm.toml:1-6.  The exact transcript / proof
+ * layout of the pinned OpenVM v2 backend (openvm-stark-backend 2.0.0,
+ * Cargo.lock:5337) is NOT available offline (SURVEY.md finding 2, 8c); the
+ * layout below is this repository's own (DESIGN.md "Protocol") and is what the
+ * HIP prover must reproduce byte for byte.
+ *
+ * AIR bytecode (u32 words, all < p):
+ *   [0x31414B5A, n_nodes, n_constraints, n_pvs]
+ *   n_nodes x [op, a, b]   ops: 0 VAR(col a, rotation b in {0,1})  1 PUB(a)
+ *                               2 CONST(a) 3 IS_FIRST 4 IS_LAST 5 IS_TRANSITION
+ *                               6 ADD(a,b) 7 SUB(a,b) 8 MUL(a,b) 9 NEG(a)
+ *   n_constraints x node index (asserted zero on every row)
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "zk_oracle.h"
+
+#define AIR_MAGIC 0x31414B5Au
+#define PROOF_MAGIC 0x31504B5Au
+#define PROTO_TAG 0x5A4B4831u /* "1HKZ" < p */
+#define GEN 31u
+
+enum { OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG };
+
+typedef uint32_t ext_t[4];
+
+static size_t bitrev(size_t x, unsigned bits) {
+    size_t r = 0;
+    for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+static void ext_set(ext_t d, const ext_t s) { memcpy(d, s, 16); }
+static void ext_add(const ext_t a, const ext_t b, ext_t o) {
+    for (int k = 0; k < 4; k++) o[k] = ora_add(a[k], b[k]);
+}
+static void ext_sub(const ext_t a, const ext_t b, ext_t o) {
+    for (int k = 0; k < 4; k++) o[k] = ora_sub(a[k], b[k]);
+}
+static void ext_scale(const ext_t a, uint32_t s, ext_t o) {
+    for (int k = 0; k < 4; k++) o[k] = ora_mul(a[k], s);
+}
+static void ext_from(uint32_t a, ext_t o) {
+    o[0] = a;
+    o[1] = o[2] = o[3] = 0;
+}
+static void ext_pow(const ext_t a, uint64_t e, ext_t o) {
+    ext_t r = {1, 0, 0, 0}, b;
+    ext_set(b, a);
+    while (e) {
+        if (e & 1) ora_ext_mul(r, b, r);
+        ora_ext_mul(b, b, b);
+        e >>= 1;
+    }
+    ext_set(o, r);
+}
+
+/* ---------------------------------------------------------------- program */
+typedef struct {
+    const uint32_t *w;
+    uint32_t n_nodes, n_cons, n_pvs;
+    const uint32_t *nodes, *cons;
+} program;
+
+static int parse_program(const uint32_t *w, size_t len, size_t width, program *p) {
+    if (len < 4 || w[0] != AIR_MAGIC) return -1;
+    p->w = w;
+    p->n_nodes = w[1];
+    p->n_cons = w[2];
+    p->n_pvs = w[3];
+    if ((size_t)4 + 3 * (size_t)p->n_nodes + p->n_cons != len) return -1;
+    p->nodes = w + 4;
+    p->cons = w + 4 + 3 * (size_t)p->n_nodes;
+    for (uint32_t i = 0; i < p->n_nodes; i++) {
+        uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
+        switch (op) {
+        case OP_VAR: if (a >= width || b > 1) return -1; break;
+        case OP_PUB: if (a >= p->n_pvs) return -1; break;
+        case OP_CONST: if (a >= ORA_P) return -1; break;
+        case OP_FIRST: case OP_LAST: case OP_TRANS: break;
+        case OP_ADD: case OP_SUB: case OP_MUL: if (a >= i || b >= i) return -1; break;
+        case OP_NEG: if (a >= i) return -1; break;
+        default: return -1;
+        }
+    }
+    for (uint32_t i = 0; i < p->n_cons; i++)
+        if (p->cons[i] >= p->n_nodes) return -1;
+    return 0;
+}
+
+/* base-field evaluation of all nodes on one row; vals has n_nodes slots */
+static void eval_nodes_base(const program *p, const uint32_t *local, const uint32_t *next, const uint32_t *pvs,
+                            uint32_t is_first, uint32_t is_last, uint32_t is_trans, uint32_t *vals) {
+    for (uint32_t i = 0; i < p->n_nodes; i++) {
+        uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
+        switch (op) {
+        case OP_VAR: vals[i] = b ? next[a] : local[a]; break;
+        case OP_PUB: vals[i] = pvs[a]; break;
+        case OP_CONST: vals[i] = a; break;
+        case OP_FIRST: vals[i] = is_first; break;
+        case OP_LAST: vals[i] = is_last; break;
+        case OP_TRANS: vals[i] = is_trans; break;
+        case OP_ADD: vals[i] = ora_add(vals[a], vals[b]); break;
+        case OP_SUB: vals[i] = ora_sub(vals[a], vals[b]); break;
+        case OP_MUL: vals[i] = ora_mul(vals[a], vals[b]); break;
+        default: vals[i] = ora_sub(0, vals[a]); break;
+        }
+    }
+}
+/* same over the extension (verifier, at zeta) */
+static void eval_nodes_ext(const program *p, const ext_t *local, const ext_t *next, const uint32_t *pvs,
+                           const ext_t is_first, const ext_t is_last, const ext_t is_trans, ext_t *vals) {
+    for (uint32_t i = 0; i < p->n_nodes; i++) {
+        uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
+        switch (op) {
+        case OP_VAR: ext_set(vals[i], b ? next[a] : local[a]); break;
+        case OP_PUB: ext_from(pvs[a], vals[i]); break;
+        case OP_CONST: ext_from(a, vals[i]); break;
+        case OP_FIRST: ext_set(vals[i], is_first); break;
+        case OP_LAST: ext_set(vals[i], is_last); break;
+        case OP_TRANS: ext_set(vals[i], is_trans); break;
+        case OP_ADD: ext_add(vals[a], vals[b], vals[i]); break;
+        case OP_SUB: ext_sub(vals[a], vals[b], vals[i]); break;
+        case OP_MUL: ora_ext_mul(vals[a], vals[b], vals[i]); break;
+        default: {
+            ext_t z = {0, 0, 0, 0};
+            ext_sub(z, vals[a], vals[i]);
+        } break;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- helpers */
+static void observe_preamble(ora_challenger *ch, const ora_params *prm, const ora_air_instance *airs,
+                             size_t n_airs) {
+    uint32_t hdr[7] = {PROTO_TAG, (uint32_t)n_airs, prm->log_blowup, prm->log_final_poly_len,
+                       prm->num_queries, prm->commit_pow_bits, prm->query_pow_bits};
+    ora_ch_observe(ch, hdr, 7);
+    for (size_t a = 0; a < n_airs; a++) {
+        uint32_t dig[8];
+        ora_hash_slice(airs[a].program, airs[a].program_len, dig);
+        uint32_t meta[3] = {airs[a].log_height, (uint32_t)airs[a].width, (uint32_t)airs[a].n_pvs};
+        ora_ch_observe(ch, meta, 3);
+        ora_ch_observe(ch, dig, 8);
+        ora_ch_observe(ch, airs[a].pvs, airs[a].n_pvs);
+    }
+}
+
+/* evaluate the polynomial with the given evaluations over shift*H (natural order) at ext point z */
+static void eval_poly_at(const uint32_t *evals, unsigned log_n, uint32_t shift, const ext_t z, ext_t out) {
+    size_t n = (size_t)1 << log_n;
+    uint32_t *c = (uint32_t *)malloc(n * sizeof(uint32_t));
+    memcpy(c, evals, n * sizeof(uint32_t));
+    ora_dft_batch(c, log_n, 1, n, 1); /* coefficients of f(x) = p(shift*x) */
+    ext_t y, acc = {0, 0, 0, 0};
+    ext_scale(z, ora_inv(shift), y);
+    for (size_t i = n; i-- > 0;) {
+        ora_ext_mul(acc, y, acc);
+        acc[0] = ora_add(acc[0], c[i]);
+    }
+    ext_set(out, acc);
+    free(c);
+}
+
+typedef struct {
+    unsigned n_airs;
+    unsigned b;      /* log_blowup */
+    unsigned hmax;   /* max LDE log height */
+    unsigned n_layers;
+} shape;
+
+/* selectors of the trace domain H (size 2^lh) at an extension point */
+static void selectors_ext(unsigned lh, const ext_t x, ext_t is_first, ext_t is_last, ext_t is_trans, ext_t inv_zh) {
+    ext_t xn, one = {1, 0, 0, 0}, zh, d, di;
+    ext_pow(x, (uint64_t)1 << lh, xn);
+    ext_sub(xn, one, zh);
+    uint32_t winv = ora_inv(ora_two_adic_generator(lh));
+    ext_sub(x, one, d);
+    ora_ext_inv(d, di);
+    ora_ext_mul(zh, di, is_first);
+    ext_t wi = {winv, 0, 0, 0};
+    ext_sub(x, wi, is_trans);
+    ora_ext_inv(is_trans, di);
+    ora_ext_mul(zh, di, is_last);
+    ora_ext_inv(zh, inv_zh);
+}
+
+/* ---------------------------------------------------------------- prover */
+typedef struct {
+    uint32_t *lde;       /* column-major, height M */
+    uint32_t *qlde;      /* 2^b chunk matrices of width 4, each column-major height M, back to back */
+    unsigned lh, h;      /* trace / LDE log heights */
+    size_t width;
+    program prog;
+} air_state;
+
+size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size_t n_airs, uint32_t *out,
+                       size_t cap) {
+    const unsigned b = prm->log_blowup, nch = 1u << b;
+    if (prm->log_final_poly_len != 0 || n_airs == 0 || b == 0) return 0;
+    air_state *st = (air_state *)calloc(n_airs, sizeof(air_state));
+    unsigned hmax = 0;
+    for (size_t a = 0; a < n_airs; a++) {
+        if (airs[a].log_height < 1) return 0;
+        if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &st[a].prog)) return 0;
+        if (st[a].prog.n_pvs != airs[a].n_pvs) return 0;
+        st[a].lh = airs[a].log_height;
+        st[a].h = st[a].lh + b;
+        st[a].width = airs[a].width;
+        if (st[a].h > hmax) hmax = st[a].h;
+    }
+    ora_challenger ch;
+    ora_ch_init(&ch);
+    observe_preamble(&ch, prm, airs, n_airs);
+
+    /* 1. main LDE + commit */
+    ora_matrix *mm = (ora_matrix *)calloc(n_airs, sizeof(ora_matrix));
+    for (size_t a = 0; a < n_airs; a++) {
+        size_t N = (size_t)1 << st[a].lh, M = N << b;
+        st[a].lde = (uint32_t *)malloc(M * st[a].width * sizeof(uint32_t));
+        ora_coset_lde_batch(airs[a].trace, N, st[a].lde, M, st[a].lh, b, st[a].width, GEN, 1);
+        mm[a] = (ora_matrix){st[a].lde, M, st[a].h, st[a].width};
+    }
+    uint32_t root_main[8], root_quot[8];
+    ora_tree *t_main = ora_mmcs_commit(mm, n_airs, root_main);
+    ora_ch_observe(&ch, root_main, 8);
+    ext_t alpha;
+    ora_ch_sample_ext(&ch, alpha);
+
+    /* 2. quotient: evaluate constraints on the LDE domain, divide by Z_H, split, LDE each chunk */
+    ora_matrix *qm = (ora_matrix *)calloc(n_airs * nch, sizeof(ora_matrix));
+    int ok = 1;
+    for (size_t a = 0; a < n_airs; a++) {
+        const program *pg = &st[a].prog;
+        const unsigned lh = st[a].lh, h = st[a].h;
+        const size_t N = (size_t)1 << lh, M = N << b, W = st[a].width;
+        ext_t *ap = (ext_t *)malloc((pg->n_cons + 1) * sizeof(ext_t));
+        { /* constraint i is weighted alpha^(n_cons-1-i) (Horner order of p3's folder) */
+            ext_t cur = {1, 0, 0, 0};
+            for (uint32_t i = pg->n_cons; i-- > 0;) {
+                ext_set(ap[i], cur);
+                ora_ext_mul(cur, alpha, cur);
+            }
+        }
+        uint32_t *q = (uint32_t *)malloc(M * 4 * sizeof(uint32_t)); /* [r][4] */
+        const uint32_t wM = ora_two_adic_generator(h), winv = ora_inv(ora_two_adic_generator(lh));
+#pragma omp parallel
+        {
+            uint32_t *vals = (uint32_t *)malloc(pg->n_nodes * sizeof(uint32_t));
+            uint32_t *loc = (uint32_t *)malloc(W * sizeof(uint32_t)), *nxt = (uint32_t *)malloc(W * sizeof(uint32_t));
+#pragma omp for schedule(static)
+            for (size_t r = 0; r < M; r++) {
+                size_t i = bitrev(r, h), rn = bitrev((i + nch) & (M - 1), h);
+                uint32_t x = ora_mul(GEN, ora_pow(wM, i));
+                for (size_t c = 0; c < W; c++) {
+                    loc[c] = st[a].lde[c * M + r];
+                    nxt[c] = st[a].lde[c * M + rn];
+                }
+                uint32_t zh = ora_sub(ora_pow(x, N), 1);
+                uint32_t is_first = ora_mul(zh, ora_inv(ora_sub(x, 1)));
+                uint32_t is_trans = ora_sub(x, winv);
+                uint32_t is_last = ora_mul(zh, ora_inv(is_trans));
+                eval_nodes_base(pg, loc, nxt, airs[a].pvs, is_first, is_last, is_trans, vals);
+                ext_t acc = {0, 0, 0, 0}, t;
+                for (uint32_t k = 0; k < pg->n_cons; k++) {
+                    ext_scale(ap[k], vals[pg->cons[k]], t);
+                    ext_add(acc, t, acc);
+                }
+                ext_scale(acc, ora_inv(zh), q + 4 * r);
+            }
+            free(vals), free(loc), free(nxt);
+        }
+        /* chunk j = rows [jN,(j+1)N): evaluations over s_j*H (bit-reversed), s_j = g * wM^bitrev_b(j) */
+        st[a].qlde = (uint32_t *)malloc((size_t)nch * 4 * M * sizeof(uint32_t));
+        uint32_t *nat = (uint32_t *)malloc(4 * N * sizeof(uint32_t));
+        for (unsigned j = 0; j < nch; j++) {
+            for (size_t m = 0; m < N; m++)
+                for (int k = 0; k < 4; k++) nat[k * N + m] = q[4 * (j * N + bitrev(m, lh)) + k];
+            uint32_t sj = ora_mul(GEN, ora_pow(wM, bitrev(j, b)));
+            uint32_t *dst = st[a].qlde + (size_t)j * 4 * M;
+            ora_coset_lde_batch(nat, N, dst, M, lh, b, 4, ora_mul(GEN, ora_inv(sj)), 1);
+            qm[a * nch + j] = (ora_matrix){dst, M, h, 4};
+        }
+        free(nat), free(q), free(ap);
+    }
+    ora_tree *t_quot = ora_mmcs_commit(qm, n_airs * nch, root_quot);
+    ora_ch_observe(&ch, root_quot, 8);
+    ext_t zeta;
+    ora_ch_sample_ext(&ch, zeta);
+
+    /* 3. openings */
+    size_t n_open = 0;
+    for (size_t a = 0; a < n_airs; a++) n_open += 2 * st[a].width + 4 * nch;
+    ext_t *opened = (ext_t *)malloc(n_open * sizeof(ext_t)); /* main(all airs) then quotient(all airs) */
+    size_t oi = 0;
+    for (size_t a = 0; a < n_airs; a++) {
+        const size_t N = (size_t)1 << st[a].lh, W = st[a].width;
+        ext_t zn;
+        ext_scale(zeta, ora_two_adic_generator(st[a].lh), zn);
+#pragma omp parallel for schedule(dynamic)
+        for (size_t c = 0; c < W; c++) {
+            eval_poly_at(airs[a].trace + c * N, st[a].lh, 1, zeta, opened[oi + c]);
+            eval_poly_at(airs[a].trace + c * N, st[a].lh, 1, zn, opened[oi + W + c]);
+        }
+        oi += 2 * W;
+    }
+    for (size_t a = 0; a < n_airs; a++) {
+        const size_t N = (size_t)1 << st[a].lh, M = N << b;
+        /* chunk polynomial q_j: known on the first N rows of its own LDE = coset g*H, bit-reversed */
+        uint32_t *nat = (uint32_t *)malloc(N * sizeof(uint32_t));
+        for (unsigned j = 0; j < nch; j++)
+            for (int k = 0; k < 4; k++) {
+                const uint32_t *col = st[a].qlde + ((size_t)j * 4 + k) * M;
+                for (size_t m = 0; m < N; m++) nat[m] = col[bitrev(m, st[a].lh)];
+                eval_poly_at(nat, st[a].lh, GEN, zeta, opened[oi++]);
+            }
+        free(nat);
+    }
+    ora_ch_observe(&ch, (const uint32_t *)opened, 4 * n_open);
+    ext_t alpha_f;
+    ora_ch_sample_ext(&ch, alpha_f);
+
+    /* 4. reduced openings per LDE log-height */
+    ext_t **ro = (ext_t **)calloc(hmax + 1, sizeof(ext_t *));
+    size_t *num_reduced = (size_t *)calloc(hmax + 1, sizeof(size_t));
+    oi = 0;
+    for (int round = 0; round < 2; round++)
+        for (size_t a = 0; a < n_airs; a++) {
+            const unsigned h = st[a].h;
+            const size_t M = (size_t)1 << h;
+            const unsigned n_mats = round == 0 ? 1 : nch;
+            if (!ro[h]) ro[h] = (ext_t *)calloc(M, sizeof(ext_t));
+            for (unsigned j = 0; j < n_mats; j++) {
+                const uint32_t *mat = round == 0 ? st[a].lde : st[a].qlde + (size_t)j * 4 * M;
+                const size_t W = round == 0 ? st[a].width : 4;
+                const unsigned n_pts = round == 0 ? 2 : 1;
+                ext_t *apow = (ext_t *)malloc(W * sizeof(ext_t));
+                {
+                    ext_t cur = {1, 0, 0, 0};
+                    for (size_t k = 0; k < W; k++) {
+                        ext_set(apow[k], cur);
+                        ora_ext_mul(cur, alpha_f, cur);
+                    }
+                }
+                ext_t *rrow = (ext_t *)malloc(M * sizeof(ext_t));
+#pragma omp parallel for schedule(static)
+                for (size_t r = 0; r < M; r++) {
+                    ext_t acc = {0, 0, 0, 0}, t;
+                    for (size_t k = 0; k < W; k++) {
+                        ext_scale(apow[k], mat[k * M + r], t);
+                        ext_add(acc, t, acc);
+                    }
+                    ext_set(rrow[r], acc);
+                }
+                const uint32_t wM = ora_two_adic_generator(h);
+                for (unsigned pt = 0; pt < n_pts; pt++) {
+                    ext_t z, ry = {0, 0, 0, 0}, off, t;
+                    if (pt == 0) ext_set(z, zeta);
+                    else ext_scale(zeta, ora_two_adic_generator(st[a].lh), z);
+                    for (size_t k = 0; k < W; k++) {
+                        ora_ext_mul(apow[k], opened[oi + k], t);
+                        ext_add(ry, t, ry);
+                    }
+                    ext_pow(alpha_f, num_reduced[h], off);
+#pragma omp parallel for schedule(static)
+                    for (size_t r = 0; r < M; r++) {
+                        uint32_t x = ora_mul(GEN, ora_pow(wM, bitrev(r, h)));
+                        ext_t d, di, num, u;
+                        ext_set(d, z);
+                        d[0] = ora_sub(d[0], x);
+                        ora_ext_inv(d, di);
+                        ext_sub(ry, rrow[r], num);
+                        ora_ext_mul(num, di, u);
+                        ora_ext_mul(u, off, u);
+                        ext_add(ro[h][r], u, ro[h][r]);
+                    }
+                    num_reduced[h] += W;
+                    oi += W;
+                }
+                free(apow), free(rrow);
+            }
+        }
+
+    /* 5. FRI commit phase */
+    const unsigned n_layers = hmax - b;
+    ora_tree **ftrees = (ora_tree **)calloc(n_layers, sizeof(ora_tree *));
+    uint32_t **flayers = (uint32_t **)calloc(n_layers + 1, sizeof(uint32_t *)); /* [len][4] each */
+    uint32_t **fleaves = (uint32_t **)calloc(n_layers, sizeof(uint32_t *));      /* column-major 8 x len/2 */
+    uint32_t(*froots)[8] = (uint32_t(*)[8])calloc(n_layers, 32);
+    uint32_t *fpow = (uint32_t *)calloc(n_layers + 1, sizeof(uint32_t));
+    ext_t *betas = (ext_t *)calloc(n_layers, sizeof(ext_t));
+    flayers[0] = (uint32_t *)ro[hmax];
+    for (unsigned l = 0; l < n_layers; l++) {
+        const unsigned log_len = hmax - l;
+        const size_t half = (size_t)1 << (log_len - 1);
+        fleaves[l] = (uint32_t *)malloc(8 * half * sizeof(uint32_t));
+        for (size_t i = 0; i < half; i++)
+            for (int k = 0; k < 8; k++) fleaves[l][k * half + i] = flayers[l][8 * i + k];
+        ora_matrix lm = {fleaves[l], half, log_len - 1, 8};
+        ftrees[l] = ora_mmcs_commit(&lm, 1, froots[l]);
+        ora_ch_observe(&ch, froots[l], 8);
+        fpow[l] = ora_ch_grind(&ch, prm->commit_pow_bits);
+        ora_ch_sample_ext(&ch, betas[l]);
+        flayers[l + 1] = (uint32_t *)malloc(4 * half * sizeof(uint32_t));
+        ora_fri_fold(flayers[l], flayers[l + 1], log_len - 1, betas[l]);
+        if (log_len - 1 <= hmax && ro[log_len - 1]) {
+            ext_t b2;
+            ora_ext_mul(betas[l], betas[l], b2);
+            for (size_t i = 0; i < half; i++) {
+                ext_t t;
+                ora_ext_mul(b2, ro[log_len - 1][i], t);
+                ext_add(flayers[l + 1] + 4 * i, t, flayers[l + 1] + 4 * i);
+            }
+        }
+    }
+    const uint32_t *fin = flayers[n_layers]; /* 2^b values, all equal for a valid proof */
+    for (size_t i = 1; i < ((size_t)1 << b); i++)
+        if (memcmp(fin, fin + 4 * i, 16)) ok = 0;
+    ora_ch_observe(&ch, fin, 4);
+    uint32_t qpow = ora_ch_grind(&ch, prm->query_pow_bits);
+
+    /* 6. assemble the proof */
+    size_t w = 0;
+#define PUT(ptr, n)                                     \
+    do {                                                \
+        if (w + (n) > cap) { ok = 0; goto done; }       \
+        memcpy(out + w, (ptr), (size_t)(n) * 4);        \
+        w += (n);                                       \
+    } while (0)
+    {
+        uint32_t hdr[4] = {PROOF_MAGIC, (uint32_t)n_airs, hmax, n_layers};
+        PUT(hdr, 4);
+        PUT(root_main, 8);
+        PUT(root_quot, 8);
+        PUT(opened, 4 * n_open);
+        for (unsigned l = 0; l < n_layers; l++) {
+            PUT(froots[l], 8);
+            PUT(&fpow[l], 1);
+        }
+        PUT(fin, 4);
+        PUT(&qpow, 1);
+        size_t tmp_words = 0;
+        for (size_t a = 0; a < n_airs; a++) tmp_words += st[a].width + 4 * nch;
+        tmp_words += 8 * (hmax + 1) + 16;
+        uint32_t *tmp = (uint32_t *)malloc(tmp_words * sizeof(uint32_t));
+        for (unsigned qn = 0; qn < prm->num_queries; qn++) {
+            size_t idx = ora_ch_sample_bits(&ch, hmax);
+            size_t n1 = ora_mmcs_open(t_main, idx >> (hmax - ora_tree_log_height(t_main)), tmp);
+            PUT(tmp, n1);
+            n1 = ora_mmcs_open(t_quot, idx >> (hmax - ora_tree_log_height(t_quot)), tmp);
+            PUT(tmp, n1);
+            for (unsigned l = 0; l < n_layers; l++) {
+                size_t il = idx >> l;
+                PUT(flayers[l] + 4 * (il ^ 1), 4);
+                n1 = ora_mmcs_open(ftrees[l], il >> 1, tmp);
+                PUT(tmp + 8, n1 - 8); /* skip the opened row (the pair), keep the path */
+            }
+        }
+        free(tmp);
+    }
+done:
+    for (size_t a = 0; a < n_airs; a++) free(st[a].lde), free(st[a].qlde);
+    for (unsigned l = 0; l < n_layers; l++) {
+        ora_tree_free(ftrees[l]);
+        free(fleaves[l]);
+        free(flayers[l + 1]);
+    }
+    for (unsigned h = 0; h <= hmax; h++) free(ro[h]);
+    ora_tree_free(t_main), ora_tree_free(t_quot);
+    free(ftrees), free(flayers), free(fleaves), free(froots), free(fpow), free(betas);
+    free(ro), free(num_reduced), free(opened), free(mm), free(qm), free(st);
+    return ok ? w : 0;
+}
+
+/* ---------------------------------------------------------------- verifier */
+int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t n_airs, const uint32_t *proof,
+                     size_t n_words) {
+    const unsigned b = prm->log_blowup, nch = 1u << b;
+    if (prm->log_final_poly_len != 0 || n_airs == 0 || b == 0) return -1;
+    program *pg = (program *)calloc(n_airs, sizeof(program));
+    unsigned hmax = 0;
+    size_t n_open = 0;
+    for (size_t a = 0; a < n_airs; a++) {
+        if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &pg[a])) return -2;
+        if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height < 1) return -2;
+        if (airs[a].log_height + b > hmax) hmax = airs[a].log_height + b;
+        n_open += 2 * airs[a].width + 4 * nch;
+    }
+    const unsigned n_layers = hmax - b;
+    size_t r = 0;
+#define NEED(n)                         \
+    do {                                \
+        if (r + (n) > n_words) return -3; \
+    } while (0)
+    for (size_t i = 0; i < n_words; i++)
+        if (proof[i] >= ORA_P && i != 0) return -3; /* all words canonical (magic is < p too) */
+    NEED(4);
+    if (proof[0] != PROOF_MAGIC || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers) return -3;
+    r = 4;
+    NEED(16);
+    const uint32_t *root_main = proof + r, *root_quot = proof + r + 8;
+    r += 16;
+    NEED(4 * n_open);
+    const ext_t *opened = (const ext_t *)(proof + r);
+    r += 4 * n_open;
+    NEED(9 * (size_t)n_layers + 5);
+    const uint32_t *fri_hdr = proof + r;
+    r += 9 * (size_t)n_layers;
+    const uint32_t *fin = proof + r;
+    r += 4;
+    const uint32_t qpow = proof[r++];
+
+    ora_challenger ch;
+    ora_ch_init(&ch);
+    observe_preamble(&ch, prm, airs, n_airs);
+    ora_ch_observe(&ch, root_main, 8);
+    ext_t alpha, zeta, alpha_f;
+    ora_ch_sample_ext(&ch, alpha);
+    ora_ch_observe(&ch, root_quot, 8);
+    ora_ch_sample_ext(&ch, zeta);
+    ora_ch_observe(&ch, (const uint32_t *)opened, 4 * n_open);
+    ora_ch_sample_ext(&ch, alpha_f);
+
+    /* constraint check at zeta for every AIR */
+    size_t om = 0, oq = 0;
+    for (size_t a = 0; a < n_airs; a++) oq += 2 * airs[a].width;
+    for (size_t a = 0; a < n_airs; a++) {
+        const unsigned lh = airs[a].log_height, h = lh + b;
+        const size_t W = airs[a].width;
+        ext_t is_first, is_last, is_trans, inv_zh;
+        selectors_ext(lh, zeta, is_first, is_last, is_trans, inv_zh);
+        ext_t *vals = (ext_t *)malloc(pg[a].n_nodes * sizeof(ext_t));
+        eval_nodes_ext(&pg[a], opened + om, opened + om + W, airs[a].pvs, is_first, is_last, is_trans, vals);
+        ext_t acc = {0, 0, 0, 0};
+        for (uint32_t k = 0; k < pg[a].n_cons; k++) {
+            ora_ext_mul(acc, alpha, acc);
+            ext_add(acc, vals[pg[a].cons[k]], acc);
+        }
+        free(vals);
+        ext_t lhs;
+        ora_ext_mul(acc, inv_zh, lhs);
+        /* quotient(zeta) = sum_j zps_j * sum_k x^k * chunk_{j,k}(zeta) */
+        const uint32_t wM = ora_two_adic_generator(h);
+        ext_t rhs = {0, 0, 0, 0};
+        for (unsigned j = 0; j < nch; j++) {
+            uint32_t sj = ora_mul(GEN, ora_pow(wM, bitrev(j, b)));
+            ext_t zps = {1, 0, 0, 0};
+            for (unsigned k = 0; k < nch; k++) {
+                if (k == j) continue;
+                uint32_t sk = ora_mul(GEN, ora_pow(wM, bitrev(k, b)));
+                /* Z_{D_k}(x) = (x/s_k)^N - 1 */
+                ext_t t, one = {1, 0, 0, 0}, num;
+                ext_scale(zeta, ora_inv(sk), t);
+                ext_pow(t, (uint64_t)1 << lh, t);
+                ext_sub(t, one, num);
+                uint32_t den = ora_sub(ora_pow(ora_mul(sj, ora_inv(sk)), (uint64_t)1 << lh), 1);
+                ext_scale(num, ora_inv(den), num);
+                ora_ext_mul(zps, num, zps);
+            }
+            ext_t v = {0, 0, 0, 0};
+            for (int k = 0; k < 4; k++) {
+                /* basis element x^k times an extension value */
+                ext_t e = {0, 0, 0, 0}, t;
+                e[k] = 1;
+                ora_ext_mul(e, opened[oq + 4 * j + k], t);
+                ext_add(v, t, v);
+            }
+            ora_ext_mul(v, zps, v);
+            ext_add(rhs, v, rhs);
+        }
+        if (memcmp(lhs, rhs, 16)) return -4;
+        om += 2 * W;
+        oq += 4 * nch;
+    }
+
+    /* FRI transcript */
+    ext_t *betas = (ext_t *)calloc(n_layers ? n_layers : 1, sizeof(ext_t));
+    for (unsigned l = 0; l < n_layers; l++) {
+        ora_ch_observe(&ch, fri_hdr + 9 * l, 8);
+        if (!ora_ch_check_witness(&ch, prm->commit_pow_bits, fri_hdr[9 * l + 8])) return -5;
+        ora_ch_sample_ext(&ch, betas[l]);
+    }
+    ora_ch_observe(&ch, fin, 4);
+    if (!ora_ch_check_witness(&ch, prm->query_pow_bits, qpow)) return -5;
+
+    /* shapes of the two input batches */
+    unsigned *lh_main = (unsigned *)malloc(n_airs * sizeof(unsigned));
+    size_t *w_main = (size_t *)malloc(n_airs * sizeof(size_t));
+    unsigned *lh_quot = (unsigned *)malloc(n_airs * nch * sizeof(unsigned));
+    size_t *w_quot = (size_t *)malloc(n_airs * nch * sizeof(size_t));
+    size_t tw_main = 0, tw_quot = 0;
+    for (size_t a = 0; a < n_airs; a++) {
+        lh_main[a] = airs[a].log_height + b;
+        w_main[a] = airs[a].width;
+        tw_main += w_main[a];
+        for (unsigned j = 0; j < nch; j++) {
+            lh_quot[a * nch + j] = lh_main[a];
+            w_quot[a * nch + j] = 4;
+            tw_quot += 4;
+        }
+    }
+    ext_t *roq = (ext_t *)calloc(hmax + 1, sizeof(ext_t));
+    int *has = (int *)calloc(hmax + 1, sizeof(int));
+    size_t *num_reduced = (size_t *)calloc(hmax + 1, sizeof(size_t));
+    int rc = 0;
+    for (unsigned qn = 0; qn < prm->num_queries && rc == 0; qn++) {
+        size_t idx = ora_ch_sample_bits(&ch, hmax);
+        size_t n_main = tw_main + 8 * (size_t)hmax, n_quot = tw_quot + 8 * (size_t)hmax;
+        if (r + n_main + n_quot > n_words) { rc = -3; break; }
+        const uint32_t *op_main = proof + r, *op_quot = proof + r + n_main;
+        r += n_main + n_quot;
+        if (!ora_mmcs_verify(root_main, lh_main, w_main, n_airs, idx, op_main)) { rc = -6; break; }
+        if (!ora_mmcs_verify(root_quot, lh_quot, w_quot, n_airs * nch, idx, op_quot)) { rc = -6; break; }
+        /* reduced openings at this query for every height */
+        memset(roq, 0, (hmax + 1) * sizeof(ext_t));
+        memset(has, 0, (hmax + 1) * sizeof(int));
+        memset(num_reduced, 0, (hmax + 1) * sizeof(size_t));
+        size_t oi = 0;
+        for (int round = 0; round < 2; round++) {
+            const uint32_t *rows = round == 0 ? op_main : op_quot;
+            for (size_t a = 0; a < n_airs; a++) {
+                const unsigned h = airs[a].log_height + b;
+                const unsigned n_mats = round == 0 ? 1 : nch;
+                const size_t W = round == 0 ? airs[a].width : 4;
+                const unsigned n_pts = round == 0 ? 2 : 1;
+                size_t ih = idx >> (hmax - h);
+                uint32_t x = ora_mul(GEN, ora_pow(ora_two_adic_generator(h), bitrev(ih, h)));
+                has[h] = 1;
+                for (unsigned j = 0; j < n_mats; j++) {
+                    ext_t rrow = {0, 0, 0, 0}, cur = {1, 0, 0, 0}, t;
+                    ext_t *apow = (ext_t *)malloc(W * sizeof(ext_t));
+                    for (size_t k = 0; k < W; k++) {
+                        ext_set(apow[k], cur);
+                        ext_scale(cur, rows[k], t);
+                        ext_add(rrow, t, rrow);
+                        ora_ext_mul(cur, alpha_f, cur);
+                    }
+                    for (unsigned pt = 0; pt < n_pts; pt++) {
+                        ext_t z, ry = {0, 0, 0, 0}, off, d, di, num, u;
+                        if (pt == 0) ext_set(z, zeta);
+                        else ext_scale(zeta, ora_two_adic_generator(airs[a].log_height), z);
+                        for (size_t k = 0; k < W; k++) {
+                            ora_ext_mul(apow[k], opened[oi + k], t);
+                            ext_add(ry, t, ry);
+                        }
+                        ext_pow(alpha_f, num_reduced[h], off);
+                        ext_set(d, z);
+                        d[0] = ora_sub(d[0], x);
+                        ora_ext_inv(d, di);
+                        ext_sub(ry, rrow, num);
+                        ora_ext_mul(num, di, u);
+                        ora_ext_mul(u, off, u);
+                        ext_add(roq[h], u, roq[h]);
+                        num_reduced[h] += W;
+                        oi += W;
+                    }
+                    free(apow);
+                    rows += W;
+                }
+            }
+        }
+        /* fold chain */
+        ext_t eval;
+        ext_set(eval, roq[hmax]);
+        for (unsigned l = 0; l < n_layers; l++) {
+            const unsigned log_len = hmax - l;
+            size_t il = idx >> l, n_path = 8 * (size_t)(log_len - 1);
+            if (r + 4 + n_path > n_words) { rc = -3; break; }
+            const uint32_t *sib = proof + r, *path = proof + r + 4;
+            r += 4 + n_path;
+            uint32_t opening[8 + 8 * 32];
+            memcpy(opening + 4 * (il & 1), eval, 16);
+            memcpy(opening + 4 * ((il & 1) ^ 1), sib, 16);
+            memcpy(opening + 8, path, n_path * 4);
+            unsigned lhl = log_len - 1;
+            size_t wl = 8;
+            if (!ora_mmcs_verify(fri_hdr + 9 * l, &lhl, &wl, 1, il >> 1, opening)) { rc = -7; break; }
+            ext_t folded;
+            /* fold_row at index il>>1 of a layer with log height log_len-1 */
+            {
+                uint32_t xx = ora_pow(ora_two_adic_generator(log_len), bitrev(il >> 1, log_len - 1));
+                uint32_t c = ora_sub(0, ora_mul(ora_inv(xx), ora_inv(2)));
+                ext_t d, bx, t;
+                for (int k = 0; k < 4; k++) d[k] = ora_mul(ora_sub(opening[4 + k], opening[k]), c);
+                ext_set(bx, betas[l]);
+                bx[0] = ora_sub(bx[0], xx);
+                ora_ext_mul(bx, d, t);
+                for (int k = 0; k < 4; k++) folded[k] = ora_add(opening[k], t[k]);
+            }
+            ext_set(eval, folded);
+            if (has[log_len - 1]) {
+                ext_t b2, t;
+                ora_ext_mul(betas[l], betas[l], b2);
+                ora_ext_mul(b2, roq[log_len - 1], t);
+                ext_add(eval, t, eval);
+            }
+        }
+        if (rc == 0 && memcmp(eval, fin, 16)) rc = -8;
+    }
+    if (rc == 0 && r != n_words) rc = -3;
+    free(betas), free(lh_main), free(w_main), free(lh_quot), free(w_quot), free(roq), free(has), free(num_reduced);
+    free(pg);
+    return rc;
+}

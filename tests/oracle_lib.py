@@ -182,3 +182,34 @@ def fri_fold(vals, log_n_out, beta):
     b = np.asarray(beta, dtype=np.uint32)
     lib().ora_fri_fold(p32(a), p32(out), log_n_out, p32(b))
     return out
+
+
+def _air_array(airs):
+    """airs: list of dicts {program, log_height, width, trace ([width,n] or None), pvs}."""
+    arr = (OraAir * len(airs))()
+    keep = []
+    for i, a in enumerate(airs):
+        prog = np.ascontiguousarray(a["program"], dtype=np.uint32)
+        pvs = np.ascontiguousarray(a["pvs"], dtype=np.uint32)
+        tr = None if a.get("trace") is None else np.ascontiguousarray(a["trace"], dtype=np.uint32)
+        keep += [prog, pvs, tr]
+        arr[i] = OraAir(p32(prog), prog.size, a["log_height"], a["width"],
+                        p32(tr) if tr is not None else None, p32(pvs) if pvs.size else None, pvs.size)
+    return arr, keep
+
+
+def stark_prove(params, airs, cap_words=1 << 24):
+    prm = OraParams(*params)
+    arr, keep = _air_array(airs)
+    out = np.zeros(cap_words, dtype=np.uint32)
+    n = lib().ora_stark_prove(C.byref(prm), arr, len(airs), p32(out), out.size)
+    if n == 0:
+        raise RuntimeError("oracle prover failed")
+    return out[:n].copy()
+
+
+def stark_verify(params, airs, proof):
+    prm = OraParams(*params)
+    arr, keep = _air_array(airs)
+    pr = np.ascontiguousarray(proof, dtype=np.uint32)
+    return lib().ora_stark_verify(C.byref(prm), arr, len(airs), p32(pr), pr.size)

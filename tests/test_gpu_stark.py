@@ -1,0 +1,117 @@
+"""GPU: the HIP prover's proof bytes equal the CPU oracle's on the same witness (bit-exact), the
+product verifier accepts them, and size-independent properties hold at sizes the oracle cannot reach
+quickly."""
+import numpy as np
+import pytest
+
+import zkvm_prover_amd as z
+from zkvm_prover_amd import air
+
+pytestmark = pytest.mark.gpu
+
+
+def _fib(log_n):
+    fa = air.fibonacci_air()
+    tr, pv = air.fibonacci_trace(log_n)
+    return dict(program=fa.program(), log_height=log_n, width=2, n_pvs=3, trace=tr, pvs=pv)
+
+
+def _syn(log_n, width, n_free, seed, n_bool=4, n_boundary=3):
+    sa = air.SyntheticAir(width=width, n_free=n_free, n_bool=n_bool, n_boundary=n_boundary, seed=seed)
+    tr, pv = sa.gen_trace(log_n, seed=seed + 100)
+    return dict(program=sa.program(), log_height=log_n, width=width, n_pvs=len(pv), trace=tr, pvs=pv)
+
+
+def _prove_gpu(zk, params, airs):
+    pk = z.ProvingKey(zk, params, airs)
+    d_traces = [zk.upload(a["trace"].reshape(-1)) for a in airs]
+    proof = pk.prove(d_traces, [a["pvs"] for a in airs])
+    assert len(proof) == pk.proof_size
+    return proof, pk, d_traces
+
+
+CASES = {
+    "fib_small": lambda: [_fib(5)],
+    "fib_min": lambda: [_fib(1)],
+    "syn_small": lambda: [_syn(6, 24, 8, 1)],
+    "multi_mixed_heights": lambda: [_syn(7, 40, 10, 1), _fib(6), _syn(4, 12, 5, 2, n_bool=2, n_boundary=2)],
+    "same_heights": lambda: [_syn(8, 17, 6, 5), _fib(8)],
+    "tall_fib_short_syn": lambda: [_fib(10), _syn(5, 33, 9, 7)],
+    "syn_12": lambda: [_syn(12, 60, 16, 3)],
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("params", [(1, 0, 10, 4, 5), (1, 0, 3, 0, 8)])
+def test_proof_bytes_equal_oracle(zk, ora, name, params):
+    airs = CASES[name]()
+    for a in airs:
+        assert air.check_trace(a["program"], a["trace"], a["pvs"]) == []
+    exp = ora.stark_prove(params, airs)
+    got, pk, _ = _prove_gpu(zk, params, airs)
+    got_words = np.frombuffer(got, dtype=np.uint32)
+    assert len(got_words) == len(exp)
+    if not (got_words == exp).all():
+        first = int(np.nonzero(got_words != exp)[0][0])
+        pytest.fail("proof differs from oracle at word %d of %d" % (first, len(exp)))
+    assert z.verify(params, airs, [a["pvs"] for a in airs], got) == 0
+    assert ora.stark_verify(params, airs, got_words) == 0
+
+
+def test_reference_parameters_100_queries_pow16(zk, ora):
+    # the reference's parameters: openvm.toml:1-6 (log_blowup 1, 100 queries, PoW 16 + 16)
+    params = z.DEFAULT_PARAMS
+    airs = [_syn(9, 30, 8, 11), _fib(7)]
+    exp = ora.stark_prove(params, airs)
+    got, pk, d_traces = _prove_gpu(zk, params, airs)
+    assert got == exp.tobytes()
+    # proving twice on the same key is deterministic and leaves the traces untouched
+    assert pk.prove(d_traces, [a["pvs"] for a in airs]) == got
+    assert (zk.download(d_traces[0]).reshape(30, -1) == airs[0]["trace"]).all()
+
+
+def test_blowup_4(zk, ora):
+    params = (2, 0, 6, 3, 3)
+    airs = [_syn(6, 20, 7, 13), _fib(5)]
+    exp = ora.stark_prove(params, airs)
+    got, _, _ = _prove_gpu(zk, params, airs)
+    assert got == exp.tobytes()
+    assert z.verify(params, airs, [a["pvs"] for a in airs], got) == 0
+
+
+def test_unsatisfied_witness_fails_verification(zk):
+    params = (1, 0, 8, 2, 2)
+    a = _syn(6, 24, 8, 1)
+    a["trace"] = a["trace"].copy()
+    a["trace"][15, 9] = (int(a["trace"][15, 9]) + 1) % z.P
+    got, _, _ = _prove_gpu(zk, params, [a])
+    assert z.verify(params, [a], [a["pvs"]], got) != 0
+
+
+def test_large_trace_verifies(zk):
+    """2^18 x 64: beyond what the oracle proves in seconds; the independent host verifier must
+    accept, and a flipped witness cell must be rejected (prove -> verify round trip)."""
+    params = (1, 0, 30, 8, 8)
+    sa = air.SyntheticAir(width=64, n_free=16, n_bool=4, n_boundary=4, seed=21)
+    tr, pv = sa.gen_trace(18, seed=5, xp="torch", device="cuda")
+    airs = [dict(program=sa.program(), log_height=18, width=64, n_pvs=len(pv), pvs=pv)]
+    pk = z.ProvingKey(zk, params, airs)
+    d = tr.reshape(-1).contiguous()
+    zk._check(zk.lib.zkhip_to_monty(zk.h, d.data_ptr(), d.numel()))
+    proof = pk.prove([d], [pv])
+    assert z.verify(params, airs, [pv], proof) == 0
+    bad = bytearray(proof)
+    bad[400] ^= 1
+    assert z.verify(params, airs, [pv], bytes(bad)) != 0
+
+
+def test_keygen_rejects_bad_programs(zk):
+    b = air.AirBuilder(2, 0)
+    x = b.var(0)
+    b.assert_zero(x * x * x * x - b.var(1))
+    with pytest.raises(z.ZkhipError):
+        z.ProvingKey(zk, (1, 0, 4, 1, 1), [dict(program=b.program(), log_height=3, width=2, n_pvs=0)])
+    prog = air.fibonacci_air().program().copy()
+    prog[0] = 7
+    with pytest.raises(z.ZkhipError):
+        z.ProvingKey(zk, (1, 0, 4, 1, 1), [dict(program=prog, log_height=3, width=2, n_pvs=3)])

@@ -14,4 +14,8 @@ from ._binding import (  # noqa: F401
     library_path,
     load_library,
     declared_symbols,
+    ProvingKey,
+    verify,
+    DEFAULT_PARAMS,
 )
+from . import air  # noqa: F401

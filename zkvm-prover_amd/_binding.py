@@ -292,3 +292,77 @@ class Transcript:
             self.close()
         except Exception:
             pass
+
+
+DEFAULT_PARAMS = (1, 0, 100, 16, 16)  # crates/circuits/chunk-circuit/openvm.toml:1-6
+
+
+def _air_structs(airs):
+    arr = (_Air * len(airs))()
+    keep = []
+    for i, a in enumerate(airs):
+        prog = np.ascontiguousarray(a["program"], dtype=np.uint32)
+        keep.append(prog)
+        arr[i] = _Air(_u32p(prog), prog.size, a["log_height"], a["width"], a["n_pvs"])
+    return arr, keep
+
+
+def _pvs_array(pvs):
+    keep = [np.ascontiguousarray(p, dtype=np.uint32) for p in pvs]
+    arr = (C.POINTER(C.c_uint32) * len(pvs))(*[_u32p(p) if p.size else None for p in keep])
+    return arr, keep
+
+
+class ProvingKey:
+    """zkhip_pk: compiled AIRs + resident workspace + static proof layout for one set of shapes."""
+
+    def __init__(self, ctx, params, airs):
+        self.ctx, self.params, self.airs = ctx, tuple(params), airs
+        prm = _Params(*self.params)
+        arr, keep = _air_structs(airs)
+        h = C.c_void_p()
+        ctx._check(ctx.lib.zkhip_keygen(ctx.h, C.byref(prm), arr, len(airs), C.byref(h)))
+        self.h = h
+        self.proof_size = ctx.lib.zkhip_proof_size(h)
+
+    def prove_async(self, traces, pvs):
+        tp = (C.c_void_p * len(traces))(*[t.data_ptr() for t in traces])
+        pa, keep = _pvs_array(pvs)
+        self.ctx._check(self.ctx.lib.zkhip_prove_async(self.ctx.h, self.h, tp, pa))
+
+    def fetch(self):
+        buf = np.zeros(self.proof_size, dtype=np.uint8)
+        n = C.c_size_t()
+        self.ctx._check(self.ctx.lib.zkhip_proof_fetch(self.ctx.h, self.h, buf.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                        buf.size, C.byref(n)))
+        return buf[:n.value].tobytes()
+
+    def prove(self, traces, pvs):
+        tp = (C.c_void_p * len(traces))(*[t.data_ptr() for t in traces])
+        pa, keep = _pvs_array(pvs)
+        buf = np.zeros(self.proof_size, dtype=np.uint8)
+        n = C.c_size_t()
+        self.ctx._check(self.ctx.lib.zkhip_prove(self.ctx.h, self.h, tp, pa, buf.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                  buf.size, C.byref(n)))
+        return buf[:n.value].tobytes()
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.zkhip_pk_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def verify(params, airs, pvs, proof_bytes):
+    """Host verifier (needs no GPU).  Returns the zkhip status code (0 = accepted)."""
+    lib = load_library()
+    prm = _Params(*params)
+    arr, keep = _air_structs(airs)
+    pa, keep2 = _pvs_array(pvs)
+    buf = np.frombuffer(proof_bytes, dtype=np.uint8)
+    return lib.zkhip_verify(C.byref(prm), arr, len(airs), pa, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size)

@@ -1,0 +1,275 @@
+"""AIR description for libzkhip: a symbolic-expression builder that serialises to the constraint
+bytecode consumed by zkhip_keygen / zkhip_verify (format: DESIGN.md "AIR bytecode"), plus the
+synthetic AIRs BASELINE.json's configs are measured on (a Fibonacci AIR and a
+~300-column degree-3 AIR standing in for the 42 OpenVM chips of the chunk circuit,
+AGENTS.md:183-185) with their trace generators (numpy for tests, torch for full-size benches).
+
+Host-side product code: no arithmetic of the proving path lives here, only the description of
+WHAT is proven and the synthetic witness data.
+"""
+import numpy as np
+
+P = 2013265921
+AIR_MAGIC = 0x31414B5A
+OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG = range(10)
+
+
+class Expr:
+    __slots__ = ("b", "idx", "deg")
+
+    def __init__(self, b, idx, deg):
+        self.b, self.idx, self.deg = b, idx, deg
+
+    def _lift(self, o):
+        return o if isinstance(o, Expr) else self.b.const(o)
+
+    def __add__(self, o):
+        o = self._lift(o)
+        return self.b._node(OP_ADD, self.idx, o.idx, max(self.deg, o.deg))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        o = self._lift(o)
+        return self.b._node(OP_SUB, self.idx, o.idx, max(self.deg, o.deg))
+
+    def __rsub__(self, o):
+        return self._lift(o) - self
+
+    def __mul__(self, o):
+        o = self._lift(o)
+        return self.b._node(OP_MUL, self.idx, o.idx, self.deg + o.deg)
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return self.b._node(OP_NEG, self.idx, 0, self.deg)
+
+
+class AirBuilder:
+    """Mirrors the shape of p3-air's AirBuilder: main-trace variables with rotation 0/1, public
+    values, is_first_row / is_last_row / is_transition selectors, assert_zero."""
+
+    def __init__(self, width, n_pvs=0):
+        self.width, self.n_pvs = width, n_pvs
+        self.nodes, self.cons, self._cache = [], [], {}
+
+    def _node(self, op, a=0, b=0, deg=0):
+        key = (op, a, b)
+        if key not in self._cache:
+            self.nodes.append(key)
+            self._cache[key] = Expr(self, len(self.nodes) - 1, deg)
+        return self._cache[key]
+
+    def var(self, col, rot=0):
+        assert 0 <= col < self.width and rot in (0, 1)
+        return self._node(OP_VAR, col, rot, 1)
+
+    def next(self, col):
+        return self.var(col, 1)
+
+    def pub(self, i):
+        assert 0 <= i < self.n_pvs
+        return self._node(OP_PUB, i, 0, 0)
+
+    def const(self, v):
+        return self._node(OP_CONST, int(v) % P, 0, 0)
+
+    def is_first_row(self):
+        return self._node(OP_FIRST, 0, 0, 1)
+
+    def is_last_row(self):
+        return self._node(OP_LAST, 0, 0, 1)
+
+    def is_transition(self):
+        return self._node(OP_TRANS, 0, 0, 0)
+
+    def assert_zero(self, e):
+        self.cons.append(e.idx)
+
+    def when_first_row(self, e):
+        self.assert_zero(self.is_first_row() * e)
+
+    def when_last_row(self, e):
+        self.assert_zero(self.is_last_row() * e)
+
+    def when_transition(self, e):
+        self.assert_zero(self.is_transition() * e)
+
+    def max_degree(self):
+        deg = {}
+        for i, (op, a, b) in enumerate(self.nodes):
+            if op == OP_VAR or op in (OP_FIRST, OP_LAST):
+                deg[i] = 1
+            elif op in (OP_PUB, OP_CONST, OP_TRANS):
+                deg[i] = 0
+            elif op in (OP_ADD, OP_SUB):
+                deg[i] = max(deg[a], deg[b])
+            elif op == OP_MUL:
+                deg[i] = deg[a] + deg[b]
+            else:
+                deg[i] = deg[a]
+        return max((deg[c] for c in self.cons), default=0)
+
+    def program(self):
+        words = [AIR_MAGIC, len(self.nodes), len(self.cons), self.n_pvs]
+        for n in self.nodes:
+            words.extend(n)
+        words.extend(self.cons)
+        return np.array(words, dtype=np.uint32)
+
+
+# ---- reference evaluation of a program on a trace (numpy; host-side witness sanity check) ----
+def check_trace(program, trace, pvs):
+    """trace: [width, n] canonical uint32.  Returns the list of violated (constraint, row)."""
+    w = [int(x) for x in program]
+    n_nodes, n_cons = w[1], w[2]
+    nodes = [tuple(w[4 + 3 * i: 7 + 3 * i]) for i in range(n_nodes)]
+    cons = w[4 + 3 * n_nodes:4 + 3 * n_nodes + n_cons]
+    n = trace.shape[1]
+    t = trace.astype(np.int64)
+    rows = np.arange(n)
+    vals = [None] * n_nodes
+    for i, (op, a, b) in enumerate(nodes):
+        if op == OP_VAR:
+            vals[i] = np.roll(t[a], -1) if b else t[a]
+        elif op == OP_PUB:
+            vals[i] = np.full(n, int(pvs[a]), dtype=np.int64)
+        elif op == OP_CONST:
+            vals[i] = np.full(n, a, dtype=np.int64)
+        elif op == OP_FIRST:
+            vals[i] = (rows == 0).astype(np.int64)
+        elif op == OP_LAST:
+            vals[i] = (rows == n - 1).astype(np.int64)
+        elif op == OP_TRANS:
+            vals[i] = (rows != n - 1).astype(np.int64)
+        elif op == OP_ADD:
+            vals[i] = (vals[a] + vals[b]) % P
+        elif op == OP_SUB:
+            vals[i] = (vals[a] - vals[b]) % P
+        elif op == OP_MUL:
+            vals[i] = (vals[a] * vals[b]) % P
+        else:
+            vals[i] = (-vals[a]) % P
+    bad = []
+    for k, c in enumerate(cons):
+        nz = np.nonzero(vals[c])[0]
+        if len(nz):
+            bad.append((k, int(nz[0])))
+    return bad
+
+
+# ---- Fibonacci AIR (SURVEY.md 8(d) cfg #1/#4 (B)) ---------------------------------------------
+def fibonacci_air():
+    """2 columns (a, b); pvs = (a0, b0, b_last)."""
+    b = AirBuilder(2, 3)
+    a0, b0 = b.var(0), b.var(1)
+    b.when_first_row(a0 - b.pub(0))
+    b.when_first_row(b0 - b.pub(1))
+    b.when_transition(b.next(0) - b0)
+    b.when_transition(b.next(1) - (a0 + b0))
+    b.when_last_row(b0 - b.pub(2))
+    return b
+
+
+def fibonacci_trace(log_n, a0=0, b0=1):
+    n = 1 << log_n
+    tr = np.zeros((2, n), dtype=np.uint32)
+    a, bb = a0 % P, b0 % P
+    for i in range(n):
+        tr[0, i], tr[1, i] = a, bb
+        a, bb = bb, (a + bb) % P
+    return tr, np.array([a0 % P, b0 % P, int(tr[1, n - 1])], dtype=np.uint32)
+
+
+# ---- synthetic wide AIR (SURVEY.md 8(d) cfg #4 (A)) --------------------------------------------
+class SyntheticAir:
+    """`width` columns: `n_free` free (random) columns, the rest defined one constraint each from
+    earlier columns, so a satisfying trace can be generated column by column in parallel over rows:
+      local     : col_j(r)   = c1*x*y*z + c2*u*v + c3          (degree 3)
+      transition: col_j(r+1) = c1*x(r)*y(r) + c2*u(r) + c3     (enforced on rows 0..n-2; row 0 = pv)
+    plus booleanity constraints b*(b-1) on the first free columns and first-/last-row boundary
+    constraints against public values.  Deterministic in `seed`."""
+
+    def __init__(self, width=300, n_free=60, n_bool=16, n_boundary=8, seed=0):
+        assert 4 <= n_free < width and n_bool <= n_free
+        rng = np.random.default_rng(seed)
+        self.width, self.n_free, self.n_bool = width, n_free, n_bool
+        self.defs = []  # per derived column: (kind, cols..., coeffs...)
+        n_trans = 0
+        for j in range(n_free, width):
+            kind = "trans" if (j % 4 == 3) else "local"
+            if kind == "local":
+                cols = rng.integers(0, j, size=5).tolist()  # any earlier column
+            else:
+                cols = rng.integers(0, n_free, size=3).tolist()  # free columns only -> row-parallel
+                n_trans += 1
+            coef = rng.integers(1, P, size=3).tolist()
+            self.defs.append((kind, cols, coef))
+        self.trans_cols = [n_free + i for i, d in enumerate(self.defs) if d[0] == "trans"]
+        self.boundary_cols = rng.choice(np.arange(n_free, width), size=n_boundary, replace=False).tolist()
+        self.n_pvs = len(self.trans_cols) + 2 * n_boundary
+        b = AirBuilder(width, self.n_pvs)
+        for c in range(n_bool):
+            x = b.var(c)
+            b.assert_zero(x * (x - 1))
+        pv = 0
+        for j, (kind, cols, coef) in zip(range(n_free, width), self.defs):
+            if kind == "local":
+                x, y, z, u, v = (b.var(c) for c in cols)
+                b.assert_zero(b.var(j) - (b.const(coef[0]) * x * y * z + b.const(coef[1]) * u * v + coef[2]))
+            else:
+                x, y, u = (b.var(c) for c in cols)
+                b.when_transition(b.next(j) - (b.const(coef[0]) * x * y + b.const(coef[1]) * u + coef[2]))
+                b.when_first_row(b.var(j) - b.pub(pv))
+                pv += 1
+        for c in self.boundary_cols:
+            b.when_first_row(b.var(c) - b.pub(pv))
+            b.when_last_row(b.var(c) - b.pub(pv + 1))
+            pv += 2
+        assert pv == self.n_pvs
+        self.builder = b
+
+    def program(self):
+        return self.builder.program()
+
+    def gen_trace(self, log_n, seed=0, xp=None, device=None):
+        """Returns (trace [width, n] canonical, pvs).  xp='torch' generates on `device` with int64
+        tensor ops (full-size benches); default numpy."""
+        n = 1 << log_n
+        if xp == "torch":
+            import torch
+
+            g = torch.Generator(device=device)
+            g.manual_seed(seed)
+            tr = torch.empty((self.width, n), dtype=torch.int64, device=device)
+            tr[:self.n_free] = torch.randint(0, P, (self.n_free, n), generator=g, device=device, dtype=torch.int64)
+            tr[:self.n_bool] %= 2
+            first = torch.randint(0, P, (len(self.trans_cols),), generator=g, device=device, dtype=torch.int64)
+            roll = lambda v: torch.roll(v, 1)
+        else:
+            rng = np.random.default_rng(seed)
+            tr = np.empty((self.width, n), dtype=np.int64)
+            tr[:self.n_free] = rng.integers(0, P, size=(self.n_free, n), dtype=np.int64)
+            tr[:self.n_bool] %= 2
+            first = rng.integers(0, P, size=len(self.trans_cols), dtype=np.int64)
+            roll = lambda v: np.roll(v, 1)
+        ti = 0
+        for j, (kind, cols, coef) in zip(range(self.n_free, self.width), self.defs):
+            if kind == "local":
+                x, y, z, u, v = (tr[c] for c in cols)
+                tr[j] = (coef[0] * (x * y % P * z % P) % P + coef[1] * (u * v % P) % P + coef[2]) % P
+            else:
+                x, y, u = (tr[c] for c in cols)
+                nxt = (coef[0] * (x * y % P) % P + coef[1] * u % P + coef[2]) % P
+                col = roll(nxt)
+                col[0] = first[ti]
+                tr[j] = col
+                ti += 1
+        pvs = [int(first[i]) for i in range(len(self.trans_cols))]
+        for c in self.boundary_cols:
+            pvs += [int(tr[c][0]), int(tr[c][n - 1])]
+        pvs = np.array(pvs, dtype=np.uint32)
+        if xp == "torch":
+            return tr.to(torch.int32), pvs  # values < 2^31: bit pattern == canonical u32
+        return tr.astype(np.uint32), pvs

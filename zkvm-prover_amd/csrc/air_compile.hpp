@@ -1,0 +1,210 @@
+// air_compile.hpp -- host side of the constraint path: parses the AIR bytecode that crosses the
+// ABI (include/zkhip.h, zkhip_air::program; format in DESIGN.md) and lowers the expression DAG
+// to the flat slot program the per-row interpreter kernel executes (K5 of SURVEY.md 2.3).
+//
+// The reference evaluates each chip's SymbolicConstraints DAG on every row of the quotient
+// domain; here the DAG is linearised once at keygen: leaves (trace cells,
+// public values, constants, selectors) become direct operands, every interior node gets a slot
+// chosen by a linear-scan allocator so that the live set stays small enough to sit in LDS
+// ([slot][lane], bank-conflict free).
+#pragma once
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "babybear.hpp"
+
+namespace zk {
+
+constexpr uint32_t AIR_MAGIC = 0x31414B5Au;
+constexpr uint32_t PROOF_MAGIC = 0x31504B5Au;
+constexpr uint32_t PROTO_TAG = 0x5A4B4831u;
+
+enum AirOp : uint32_t { A_VAR, A_PUB, A_CONST, A_FIRST, A_LAST, A_TRANS, A_ADD, A_SUB, A_MUL, A_NEG };
+
+struct AirProgram {
+    uint32_t n_nodes = 0, n_cons = 0, n_pvs = 0;
+    const uint32_t* nodes = nullptr;  // 3 words each
+    const uint32_t* cons = nullptr;
+    unsigned max_degree = 0;
+};
+
+inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p, std::string* err) {
+    auto fail = [&](const char* m) {
+        if (err) *err = m;
+        return -1;
+    };
+    if (!w || len < 4 || w[0] != AIR_MAGIC) return fail("bad AIR magic");
+    p->n_nodes = w[1];
+    p->n_cons = w[2];
+    p->n_pvs = w[3];
+    if ((size_t)4 + 3 * (size_t)p->n_nodes + p->n_cons != len) return fail("AIR program length mismatch");
+    p->nodes = w + 4;
+    p->cons = w + 4 + 3 * (size_t)p->n_nodes;
+    std::vector<unsigned> deg(p->n_nodes, 0);
+    for (uint32_t i = 0; i < p->n_nodes; i++) {
+        uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
+        switch (op) {
+            case A_VAR:
+                if (a >= width || b > 1) return fail("VAR out of range");
+                deg[i] = 1;
+                break;
+            case A_PUB:
+                if (a >= p->n_pvs) return fail("PUB out of range");
+                break;
+            case A_CONST:
+                if (a >= P) return fail("CONST not canonical");
+                break;
+            case A_FIRST:
+            case A_LAST:
+                deg[i] = 1;
+                break;
+            case A_TRANS:
+                break;
+            case A_ADD:
+            case A_SUB:
+                if (a >= i || b >= i) return fail("operand not yet defined");
+                deg[i] = deg[a] > deg[b] ? deg[a] : deg[b];
+                break;
+            case A_MUL:
+                if (a >= i || b >= i) return fail("operand not yet defined");
+                deg[i] = deg[a] + deg[b];
+                break;
+            case A_NEG:
+                if (a >= i) return fail("operand not yet defined");
+                deg[i] = deg[a];
+                break;
+            default:
+                return fail("unknown AIR op");
+        }
+    }
+    p->max_degree = 0;
+    for (uint32_t k = 0; k < p->n_cons; k++) {
+        if (p->cons[k] >= p->n_nodes) return fail("constraint index out of range");
+        if (deg[p->cons[k]] > p->max_degree) p->max_degree = deg[p->cons[k]];
+    }
+    return 0;
+}
+
+// ---- lowered program -------------------------------------------------------------------------
+// instruction = 3 words: w0 = op | (dst << 8), w1 = operand a, w2 = operand b
+// operand = kind << 28 | payload; VAR payload = rot << 27 | column
+enum QOp : uint32_t { Q_ADD, Q_SUB, Q_MUL, Q_NEG, Q_ASSERT };
+enum QKind : uint32_t { K_SLOT, K_VAR, K_PUB, K_CONST, K_SEL };
+constexpr unsigned Q_MAX_SLOTS = 60;
+
+struct CompiledAir {
+    std::vector<uint32_t> code;    // 3 words per instruction
+    std::vector<uint32_t> consts;  // Montgomery
+    unsigned n_slots = 0;
+};
+
+inline int compile_air(const AirProgram& p, CompiledAir* out, std::string* err) {
+    const uint32_t n = p.n_nodes;
+    auto is_leaf = [&](uint32_t i) { return p.nodes[3 * i] <= A_TRANS; };
+    // reachability from the constraints
+    std::vector<char> reach(n, 0);
+    for (uint32_t k = 0; k < p.n_cons; k++) reach[p.cons[k]] = 1;
+    for (uint32_t i = n; i-- > 0;) {
+        if (!reach[i] || is_leaf(i)) continue;
+        uint32_t op = p.nodes[3 * i];
+        reach[p.nodes[3 * i + 1]] = 1;
+        if (op != A_NEG) reach[p.nodes[3 * i + 2]] = 1;
+    }
+    // constraints attached to each node
+    std::vector<std::vector<uint32_t>> cons_of(n);
+    for (uint32_t k = 0; k < p.n_cons; k++) cons_of[p.cons[k]].push_back(k);
+    // event order: node i (if interior & reachable) then its ASSERTs.  last_use in event numbering.
+    std::vector<uint32_t> last_use(n, 0);
+    {
+        uint32_t ev = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            if (!reach[i]) continue;
+            if (!is_leaf(i)) {
+                uint32_t op = p.nodes[3 * i];
+                last_use[p.nodes[3 * i + 1]] = ev;
+                if (op != A_NEG) last_use[p.nodes[3 * i + 2]] = ev;
+                ev++;
+            }
+            for (size_t c = 0; c < cons_of[i].size(); c++) {
+                last_use[i] = ev;
+                ev++;
+            }
+        }
+    }
+    std::map<uint32_t, uint32_t> const_idx;
+    auto leaf_operand = [&](uint32_t i) -> uint32_t {
+        uint32_t op = p.nodes[3 * i], a = p.nodes[3 * i + 1], b = p.nodes[3 * i + 2];
+        switch (op) {
+            case A_VAR:
+                return (K_VAR << 28) | (b << 27) | a;
+            case A_PUB:
+                return (K_PUB << 28) | a;
+            case A_CONST: {
+                auto it = const_idx.find(a);
+                if (it == const_idx.end()) {
+                    it = const_idx.emplace(a, (uint32_t)out->consts.size()).first;
+                    out->consts.push_back(to_monty(a));
+                }
+                return (K_CONST << 28) | it->second;
+            }
+            default:
+                return (K_SEL << 28) | (op - A_FIRST);
+        }
+    };
+    std::vector<int> slot_of(n, -1);
+    std::vector<uint32_t> free_slots;
+    unsigned n_slots = 0;
+    uint32_t ev = 0;
+    auto operand = [&](uint32_t i) -> uint32_t {
+        return is_leaf(i) ? leaf_operand(i) : ((K_SLOT << 28) | (uint32_t)slot_of[i]);
+    };
+    auto release = [&](uint32_t i) {
+        if (!is_leaf(i) && slot_of[i] >= 0 && last_use[i] == ev) {
+            free_slots.push_back((uint32_t)slot_of[i]);
+            slot_of[i] = -2;
+        }
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        if (!reach[i]) continue;
+        if (!is_leaf(i)) {
+            uint32_t op = p.nodes[3 * i], a = p.nodes[3 * i + 1], b = p.nodes[3 * i + 2];
+            uint32_t wa = operand(a), wb = op != A_NEG ? operand(b) : 0;
+            release(a);
+            if (op != A_NEG && b != a) release(b);
+            uint32_t dst;
+            if (!free_slots.empty()) {
+                dst = free_slots.back();
+                free_slots.pop_back();
+            } else {
+                dst = n_slots++;
+            }
+            slot_of[i] = (int)dst;
+            uint32_t qop = op == A_ADD ? Q_ADD : op == A_SUB ? Q_SUB : op == A_MUL ? Q_MUL : Q_NEG;
+            out->code.push_back(qop | (dst << 8));
+            out->code.push_back(wa);
+            out->code.push_back(wb);
+            ev++;
+        }
+        for (size_t c = 0; c < cons_of[i].size(); c++) {
+            out->code.push_back(Q_ASSERT | (cons_of[i][c] << 8));
+            out->code.push_back(operand(i));
+            out->code.push_back(0);
+            release(i);
+            ev++;
+        }
+        // an interior node nobody uses after its definition (only possible if it is unreachable,
+        // which we skipped) cannot occur; a node whose last use is its own ASSERT was released above
+    }
+    if (n_slots > Q_MAX_SLOTS) {
+        if (err) *err = "AIR needs " + std::to_string(n_slots) + " live intermediates (max " + std::to_string(Q_MAX_SLOTS) + ")";
+        return -1;
+    }
+    out->n_slots = n_slots ? n_slots : 1;
+    if (out->consts.empty()) out->consts.push_back(0);
+    return 0;
+}
+
+}  // namespace zk

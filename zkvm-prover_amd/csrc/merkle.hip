@@ -105,8 +105,10 @@ size_t merkle_digest_count(unsigned log_height) { return ((size_t)2 << log_heigh
 //   [ all columns in caller order : total_width pointers ]
 //   [ per level L = log_height .. 0 : pointers of the columns of matrices with that height ]
 //   then u32 shifts[total_width] (log_height - mat.log_height) for the open kernel
-int merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip_tree** out) {
-    if (n_mats == 0) return set_error(ctx, ZKHIP_ERR_INVALID, "merkle_commit: no matrices");
+// Plans a tree over `mats`: builds and uploads the column-pointer tables and reserves the digest
+// store.  `d_digests` may be caller-provided workspace (then the tree does not own it).
+int merkle_plan(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, uint32_t* d_digests, zkhip_tree** out) {
+    if (n_mats == 0) return set_error(ctx, ZKHIP_ERR_INVALID, "merkle: no matrices");
     zkhip_tree* t = new zkhip_tree();
     t->mats.assign(mats, mats + n_mats);
     unsigned lh = 0;
@@ -116,12 +118,11 @@ int merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip
         total_w += mats[m].width;
         if (mats[m].stride < ((size_t)1 << mats[m].log_height)) {
             delete t;
-            return set_error(ctx, ZKHIP_ERR_INVALID, "merkle_commit: stride < height");
+            return set_error(ctx, ZKHIP_ERR_INVALID, "merkle: stride < height");
         }
     }
     t->log_height = lh;
     t->total_width = total_w;
-    // host-side pointer tables
     std::vector<const uint32_t*> ptrs;
     std::vector<uint32_t> shifts;
     for (size_t m = 0; m < n_mats; m++)
@@ -129,21 +130,22 @@ int merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip
             ptrs.push_back(mats[m].data + c * mats[m].stride);
             shifts.push_back(lh - mats[m].log_height);
         }
-    std::vector<size_t> level_off(lh + 1), level_cnt(lh + 1);
+    t->level_off.assign(lh + 1, 0);
+    t->level_cnt.assign(lh + 1, 0);
     for (unsigned level = 0; level <= lh; level++) {
-        level_off[level] = ptrs.size();
+        t->level_off[level] = ptrs.size();
         size_t cnt = 0;
         for (size_t m = 0; m < n_mats; m++)
             if (mats[m].log_height == level)
                 for (size_t c = 0; c < mats[m].width; c++, cnt++) ptrs.push_back(mats[m].data + c * mats[m].stride);
-        level_cnt[level] = cnt;
+        t->level_cnt[level] = cnt;
     }
     size_t ptr_bytes = ptrs.size() * sizeof(void*), shift_bytes = shifts.size() * sizeof(uint32_t);
     if (hipMalloc(&t->d_colptrs, ptr_bytes + shift_bytes + 16) != hipSuccess) {
         delete t;
-        return set_error(ctx, ZKHIP_ERR_NOMEM, "merkle_commit: pointer table alloc");
+        return set_error(ctx, ZKHIP_ERR_NOMEM, "merkle: pointer table alloc");
     }
-    // synchronous small copies (pageable host memory): keeps the host vectors' lifetime simple
+    t->shifts_off = ptr_bytes;
     hipError_t e1 = hipMemcpy(t->d_colptrs, ptrs.data(), ptr_bytes, hipMemcpyHostToDevice);
     hipError_t e2 = shift_bytes ? hipMemcpy((char*)t->d_colptrs + ptr_bytes, shifts.data(), shift_bytes,
                                             hipMemcpyHostToDevice)
@@ -151,13 +153,15 @@ int merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip
     if (e1 != hipSuccess || e2 != hipSuccess) {
         hipFree(t->d_colptrs);
         delete t;
-        return set_error(ctx, ZKHIP_ERR_HIP, "merkle_commit: pointer table upload");
+        return set_error(ctx, ZKHIP_ERR_HIP, "merkle: pointer table upload");
     }
-    size_t n_dig = merkle_digest_count(lh);
-    if (hipMalloc(&t->d_digests, n_dig * 8 * sizeof(uint32_t)) != hipSuccess) {
+    if (d_digests) {
+        t->d_digests = d_digests;
+        t->owns_digests = false;
+    } else if (hipMalloc(&t->d_digests, merkle_digest_count(lh) * 8 * sizeof(uint32_t)) != hipSuccess) {
         hipFree(t->d_colptrs);
         delete t;
-        return set_error(ctx, ZKHIP_ERR_NOMEM, "merkle_commit: digest alloc");
+        return set_error(ctx, ZKHIP_ERR_NOMEM, "merkle: digest alloc");
     }
     t->layer_off.resize(lh + 1);
     size_t off = 0;
@@ -165,12 +169,42 @@ int merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip
         t->layer_off[l] = off;
         off += (size_t)1 << (lh - l);
     }
+    *out = t;
+    return ZKHIP_OK;
+}
+
+// Plans a tree whose leaf digests are produced by the caller (FRI layers): no matrices.
+int merkle_plan_leaves(zkhip_ctx* ctx, unsigned log_height, uint32_t* d_digests, zkhip_tree** out) {
+    zkhip_tree* t = new zkhip_tree();
+    t->log_height = log_height;
+    t->level_off.assign(log_height + 1, 0);
+    t->level_cnt.assign(log_height + 1, 0);
+    if (d_digests) {
+        t->d_digests = d_digests;
+        t->owns_digests = false;
+    } else if (hipMalloc(&t->d_digests, merkle_digest_count(log_height) * 8 * sizeof(uint32_t)) != hipSuccess) {
+        delete t;
+        return set_error(ctx, ZKHIP_ERR_NOMEM, "merkle: digest alloc");
+    }
+    t->layer_off.resize(log_height + 1);
+    size_t off = 0;
+    for (unsigned l = 0; l <= log_height; l++) {
+        t->layer_off[l] = off;
+        off += (size_t)1 << (log_height - l);
+    }
+    *out = t;
+    return ZKHIP_OK;
+}
+
+// Launches the hashing kernels of a planned tree on the ctx stream (asynchronous).
+int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
+    const unsigned lh = t->log_height;
     const uint32_t* const* d_ptrs = (const uint32_t* const*)t->d_colptrs;
     size_t n = (size_t)1 << lh;
-    {
+    if (!leaves_ready) {
         KernelScope ks(ctx, "poseidon2_hash_rows");
         hipLaunchKernelGGL(k_hash_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           d_ptrs + level_off[lh], (uint32_t)level_cnt[lh], n, t->d_digests);
+                           d_ptrs + t->level_off[lh], (uint32_t)t->level_cnt[lh], n, t->d_digests);
     }
     for (unsigned l = 1; l <= lh; l++) {
         unsigned level = lh - l;
@@ -178,13 +212,21 @@ int merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip
         KernelScope ks(ctx, "poseidon2_compress_layer");
         hipLaunchKernelGGL(k_compress_layer, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
                            t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,
-                           d_ptrs + level_off[level], (uint32_t)level_cnt[level]);
+                           d_ptrs ? d_ptrs + t->level_off[level] : nullptr, (uint32_t)t->level_cnt[level]);
     }
-    if (hipGetLastError() != hipSuccess) {
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+int merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip_tree** out) {
+    zkhip_tree* t = nullptr;
+    ZK_TRY(merkle_plan(ctx, mats, n_mats, nullptr, &t));
+    int rc = merkle_build(ctx, t, false);
+    if (rc != ZKHIP_OK) {
         hipFree(t->d_colptrs);
-        hipFree(t->d_digests);
+        if (t->owns_digests) hipFree(t->d_digests);
         delete t;
-        return set_error(ctx, ZKHIP_ERR_HIP, "merkle_commit: launch failed");
+        return rc;
     }
     *out = t;
     return ZKHIP_OK;
@@ -212,9 +254,7 @@ int merkle_open_device(zkhip_ctx* ctx, const zkhip_tree* t, const uint32_t* d_in
     if (n == 0) return ZKHIP_OK;
     KernelScope ks(ctx, "merkle_open");
     const uint32_t* const* d_ptrs = (const uint32_t* const*)t->d_colptrs;
-    // shifts live after ALL pointer tables; recompute the pointer count
-    size_t n_ptrs = t->total_width * 2;  // caller-order table + per-level tables cover each column once more
-    const uint32_t* d_shifts = (const uint32_t*)((const char*)t->d_colptrs + n_ptrs * sizeof(void*));
+    const uint32_t* d_shifts = (const uint32_t*)((const char*)t->d_colptrs + t->shifts_off);
     hipLaunchKernelGGL(k_merkle_open, dim3((unsigned)n), dim3(128), 0, ctx->stream, d_ptrs, d_shifts,
                        (uint32_t)t->total_width, t->d_digests, t->log_height, d_indices, index_shift, d_out,
                        out_pitch_words);

@@ -281,6 +281,13 @@ __global__ void k_gen_coset_powers(uint32_t* pw, uint32_t shift, uint32_t w_big,
         pw[idx] = mmul(n_inv, mpow(s, (uint64_t)(k - (1u << lb)) << lb));
 }
 
+// plain bit-reversal permutation of `width` columns (no scaling), out of place
+int ntt_bitrev_copy(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint32_t* dst, size_t dst_stride,
+                    unsigned log_n, size_t width) {
+    BitrevArgs a{src, src_stride, dst, dst_stride, nullptr, MONTY_ONE, log_n, 0, 0};
+    return launch_bitrev(ctx, a, width);
+}
+
 int ntt_batch(zkhip_ctx* ctx, uint32_t* d_mat, unsigned log_n, size_t width, size_t stride, bool inverse,
               bool bitrev_out) {
     if (width == 0) return ZKHIP_OK;

@@ -1,0 +1,966 @@
+// prover.hip -- the STARK prover behind zkhip_keygen / zkhip_prove (what
+// `sdk.prove(..)` -> `StarkEngine::prove` does for one segment, crates/prover/src/prover/mod.rs:355-357).
+//
+// Pipeline (north_star order): trace commit (coset LDE + Merkle-Poseidon2) -> alpha -> per-row
+// constraint evaluation / quotient -> quotient-chunk LDE + commit -> zeta -> openings ->
+// FRI batching (reduced openings) -> FRI fold loop with per-round commit + PoW -> query PoW ->
+// query openings.  Protocol and proof layout: DESIGN.md; byte-for-byte twin of oracle/stark.c.
+//
+// MI355X design points:
+//  * Everything a proof needs is resident: LDEs, trees, FRI layers live in one workspace sized
+//    at keygen (a 2^22 x 300 chunk trace needs ~17 GB of the 288 GB).
+//  * No host round trip inside a proof: the transcript is a device object (transcript.hip), the
+//    challenges are read by the next kernel straight from HBM, PoW nonces are searched on the
+//    device, and the proof is assembled in a device buffer whose layout is static (FRI proofs
+//    have fixed shape).  One D2H copy at the end.
+//  * Hot kernels are one-row-per-lane over column-major matrices (coalesced 256 B per wave per
+//    column); reductions over rows (openings) are two-stage and deterministic.
+#include <string.h>
+
+#include <algorithm>
+
+#include "air_compile.hpp"
+#include "poseidon2.hpp"
+#include "transcript.hpp"
+#include "zkhip_internal.hpp"
+
+namespace zk {
+
+static constexpr unsigned QBS = 256;  // quotient kernel block size
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+__device__ __forceinline__ Ext ld_ext(const uint32_t* p) { return Ext{{p[0], p[1], p[2], p[3]}}; }
+__device__ __forceinline__ void st_ext(uint32_t* p, const Ext& e) {
+    p[0] = e.c[0], p[1] = e.c[1], p[2] = e.c[2], p[3] = e.c[3];
+}
+// w^i for i < 2^log_m from the half-size table
+__device__ __forceinline__ uint32_t root_pow(const uint32_t* tw, unsigned tw_shift, unsigned log_m, uint32_t i) {
+    uint32_t half = 1u << (log_m - 1);
+    return i < half ? tw[(size_t)i << tw_shift] : mneg(tw[(size_t)(i - half) << tw_shift]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: per-row constraint interpreter.  One LDE row per lane, slots in LDS as [slot][lane].
+struct QuotArgs {
+    const uint32_t* code;
+    uint32_t n_instr;
+    const uint32_t* consts;
+    const uint32_t* pvs;    // Montgomery
+    const uint32_t* apow;   // n_cons extension elements: alpha^(n_cons-1-k)
+    const uint32_t* lde;    // column-major, stride = M
+    uint32_t* q;            // 4 columns of M (quotient values, bit-reversed LDE order)
+    const uint32_t* tw_fwd;
+    const uint32_t* inv_zh; // 2^b values, index = natural index mod 2^b
+    const uint32_t* zh;     // 2^b values
+    uint32_t gen;           // coset shift (Montgomery)
+    uint32_t w_n_inv;       // w_N^-1
+    unsigned lh, b, tw_shift;
+};
+
+__global__ __launch_bounds__(QBS) void k_quotient(QuotArgs a) {
+    extern __shared__ uint32_t slots[];
+    const unsigned tid = threadIdx.x;
+    const unsigned h = a.lh + a.b;
+    const size_t M = (size_t)1 << h;
+    const uint32_t r = blockIdx.x * QBS + tid;
+    if (r >= M) return;
+    const uint32_t i = bitrev32(r, h);
+    const uint32_t rn = bitrev32((i + (1u << a.b)) & (uint32_t)(M - 1), h);
+    const uint32_t x = mmul(a.gen, root_pow(a.tw_fwd, a.tw_shift, h, i));
+    const uint32_t zh = a.zh[i & ((1u << a.b) - 1u)];
+    const uint32_t sel_first = mmul(zh, minv(msub(x, MONTY_ONE)));
+    const uint32_t sel_trans = msub(x, a.w_n_inv);
+    const uint32_t sel_last = mmul(zh, minv(sel_trans));
+    Ext acc = ext_zero();
+    auto fetch = [&](uint32_t w) -> uint32_t {
+        const uint32_t kind = w >> 28, idx = w & 0x0fffffffu;
+        switch (kind) {
+            case K_SLOT:
+                return slots[idx * QBS + tid];
+            case K_VAR: {
+                const uint32_t col = idx & 0x07ffffffu;
+                return a.lde[(size_t)col * M + ((idx >> 27) ? rn : r)];
+            }
+            case K_PUB:
+                return a.pvs[idx];
+            case K_CONST:
+                return a.consts[idx];
+            default:
+                return idx == 0 ? sel_first : (idx == 1 ? sel_last : sel_trans);
+        }
+    };
+    for (uint32_t pc = 0; pc < a.n_instr; pc++) {
+        const uint32_t w0 = a.code[3 * pc], wa = a.code[3 * pc + 1], wb = a.code[3 * pc + 2];
+        const uint32_t op = w0 & 0xffu, dst = w0 >> 8;
+        const uint32_t va = fetch(wa);
+        if (op == Q_ASSERT) {
+            const uint32_t* ap = a.apow + 4 * (size_t)dst;
+            acc.c[0] = madd(acc.c[0], mmul(ap[0], va));
+            acc.c[1] = madd(acc.c[1], mmul(ap[1], va));
+            acc.c[2] = madd(acc.c[2], mmul(ap[2], va));
+            acc.c[3] = madd(acc.c[3], mmul(ap[3], va));
+        } else if (op == Q_NEG) {
+            slots[dst * QBS + tid] = mneg(va);
+        } else {
+            const uint32_t vb = fetch(wb);
+            slots[dst * QBS + tid] = op == Q_ADD ? madd(va, vb) : (op == Q_SUB ? msub(va, vb) : mmul(va, vb));
+        }
+    }
+    const uint32_t izh = a.inv_zh[i & ((1u << a.b) - 1u)];
+#pragma unroll
+    for (int k = 0; k < 4; k++) a.q[(size_t)k * M + r] = mmul(acc.c[k], izh);
+}
+
+// out[k] = base^(reverse ? n-1-k : k) * 1, n extension elements (single lane: n is a few hundred)
+__global__ void k_ext_powers(const uint32_t* base, uint32_t n, int reverse, uint32_t* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Ext bse = ld_ext(base), cur = ext_one();
+    for (uint32_t k = 0; k < n; k++) {
+        st_ext(out + 4 * (size_t)(reverse ? n - 1 - k : k), cur);
+        cur = ext_mul(cur, bse);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// openings: p(z) = (z^N - s^N)/(N s^N) * sum_i p(s w^i) * x_i/(z - x_i), x_i = s w^i (natural order)
+struct PointsArgs {
+    const uint32_t* zeta;  // ext
+    uint32_t w_n;          // generator of H (Montgomery): second point = zeta * w_n
+    uint32_t shift;        // s
+    uint32_t scale_base;   // 1/(N s^N)
+    uint32_t s_pow_n;      // s^N
+    unsigned lh, n_pts;
+    uint32_t* pts;    // n_pts ext
+    uint32_t* scale;  // n_pts ext
+};
+__global__ void k_open_points(PointsArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Ext z = ld_ext(a.zeta);
+    for (unsigned p = 0; p < a.n_pts; p++) {
+        Ext zp = p == 0 ? z : ext_mul_base(z, a.w_n);
+        st_ext(a.pts + 4 * p, zp);
+        Ext t = zp;
+        for (unsigned k = 0; k < a.lh; k++) t = ext_mul(t, t);
+        t.c[0] = msub(t.c[0], a.s_pow_n);
+        st_ext(a.scale + 4 * p, ext_mul_base(t, a.scale_base));
+    }
+}
+
+// weights[pt][i] = x_i / (z_pt - x_i)
+__global__ __launch_bounds__(256) void k_bary_weights(const uint32_t* pts, unsigned n_pts, uint32_t shift,
+                                                      const uint32_t* tw_fwd, unsigned tw_shift, unsigned lh,
+                                                      uint32_t* weights) {
+    const size_t N = (size_t)1 << lh;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    uint32_t x = mmul(shift, lh == 0 ? MONTY_ONE : root_pow(tw_fwd, tw_shift, lh, (uint32_t)i));
+    for (unsigned p = 0; p < n_pts; p++) {
+        Ext d = ld_ext(pts + 4 * p);
+        d.c[0] = msub(d.c[0], x);
+        Ext w = ext_mul_base(ext_inv(d), x);
+        reinterpret_cast<uint4*>(weights)[(size_t)p * N + i] = make_uint4(w.c[0], w.c[1], w.c[2], w.c[3]);
+    }
+}
+
+// partial[tile][col][pt] = sum over the tile's rows of col[r] * w[pt][r].  Rows per tile = 256*RK.
+template <int NPTS, int RK>
+__global__ __launch_bounds__(256) void k_col_reduce(const uint32_t* cols, size_t stride, uint32_t n_cols,
+                                                    unsigned lh, const uint32_t* weights, uint32_t* partial) {
+    __shared__ uint32_t red[4][NPTS * 4];
+    const size_t N = (size_t)1 << lh;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const size_t row0 = (size_t)blockIdx.x * 256 * RK + tid;
+    uint32_t w[RK][NPTS][4];
+#pragma unroll
+    for (int k = 0; k < RK; k++) {
+        size_t r = row0 + (size_t)k * 256;
+#pragma unroll
+        for (int p = 0; p < NPTS; p++) {
+            uint4 v = r < N ? reinterpret_cast<const uint4*>(weights)[(size_t)p * N + r] : make_uint4(0, 0, 0, 0);
+            w[k][p][0] = v.x, w[k][p][1] = v.y, w[k][p][2] = v.z, w[k][p][3] = v.w;
+        }
+    }
+    for (uint32_t c = 0; c < n_cols; c++) {
+        const uint32_t* col = cols + (size_t)c * stride;
+        uint32_t acc[NPTS][4];
+#pragma unroll
+        for (int p = 0; p < NPTS; p++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[p][q] = 0;
+#pragma unroll
+        for (int k = 0; k < RK; k++) {
+            size_t r = row0 + (size_t)k * 256;
+            uint32_t v = r < N ? col[r] : 0u;
+#pragma unroll
+            for (int p = 0; p < NPTS; p++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[p][q] = madd(acc[p][q], mmul(w[k][p][q], v));
+        }
+        // wave reduction (field addition is exact: any order gives the same element)
+#pragma unroll
+        for (int p = 0; p < NPTS; p++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t v = acc[p][q];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v = madd(v, __shfl_xor(v, off, 64));
+                acc[p][q] = v;
+            }
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int p = 0; p < NPTS; p++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) red[wave][p * 4 + q] = acc[p][q];
+        }
+        __syncthreads();
+        if (tid < NPTS * 4) {
+            uint32_t v = madd(madd(red[0][tid], red[1][tid]), madd(red[2][tid], red[3][tid]));
+            partial[((size_t)blockIdx.x * n_cols + c) * (NPTS * 4) + tid] = v;
+        }
+    }
+}
+
+// opened[pt*n_cols + c] = scale[pt] * sum_tiles partial[tile][c][pt]
+__global__ __launch_bounds__(64) void k_open_finish(const uint32_t* partial, uint32_t n_tiles, uint32_t n_cols,
+                                                    unsigned n_pts, const uint32_t* scale, uint32_t* opened) {
+    const uint32_t c = blockIdx.x, p = blockIdx.y, lane = threadIdx.x;
+    uint32_t acc[4] = {0, 0, 0, 0};
+    for (uint32_t t = lane; t < n_tiles; t += 64) {
+        const uint32_t* s = partial + ((size_t)t * n_cols + c) * (n_pts * 4) + p * 4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = madd(acc[q], s[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t v = acc[q];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = madd(v, __shfl_xor(v, off, 64));
+        acc[q] = v;
+    }
+    if (lane == 0) {
+        Ext r = ext_mul(Ext{{acc[0], acc[1], acc[2], acc[3]}}, ld_ext(scale + 4 * p));
+        st_ext(opened + 4 * ((size_t)p * n_cols + c), r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FRI batching: per matrix and point, ro[r] += off_pt * (ry_pt - rrow[r]) / (z_pt - x_r)
+struct ReducePrep {
+    const uint32_t* alpha;   // ext
+    const uint32_t* opened;  // n_pts * width ext (this matrix' opened values)
+    const uint32_t* pts;     // n_pts ext
+    uint32_t width, n_pts;
+    uint64_t num_reduced;    // alpha power offset of the first point
+    uint32_t* apow;          // width ext
+    uint32_t* ry;            // n_pts ext
+    uint32_t* off;           // n_pts ext
+};
+__global__ void k_reduce_prep(ReducePrep a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Ext al = ld_ext(a.alpha), cur = ext_one();
+    Ext ry[2] = {ext_zero(), ext_zero()};
+    for (uint32_t k = 0; k < a.width; k++) {
+        st_ext(a.apow + 4 * (size_t)k, cur);
+        for (uint32_t p = 0; p < a.n_pts; p++)
+            ry[p] = ext_add(ry[p], ext_mul(cur, ld_ext(a.opened + 4 * ((size_t)p * a.width + k))));
+        cur = ext_mul(cur, al);
+    }
+    Ext aw = cur;  // alpha^width
+    Ext off = ext_pow(al, a.num_reduced);
+    for (uint32_t p = 0; p < a.n_pts; p++) {
+        st_ext(a.ry + 4 * p, ry[p]);
+        st_ext(a.off + 4 * p, off);
+        off = ext_mul(off, aw);
+    }
+}
+
+struct ReduceArgs {
+    const uint32_t* mat;  // column-major LDE matrix, stride M
+    const uint32_t* apow;
+    const uint32_t* ry;
+    const uint32_t* off;
+    const uint32_t* pts;
+    uint32_t* ro;  // M ext
+    const uint32_t* tw_fwd;
+    uint32_t gen;
+    uint32_t width, n_pts;
+    unsigned h, tw_shift;
+    int accumulate;  // 0: ro[r] = ..., 1: ro[r] += ...
+};
+__global__ __launch_bounds__(256) void k_reduced_openings(ReduceArgs a) {
+    const size_t M = (size_t)1 << a.h;
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    uint32_t acc[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < a.width; k++) {
+        const uint32_t v = a.mat[(size_t)k * M + r];
+        const uint32_t* ap = a.apow + 4 * (size_t)k;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = madd(acc[q], mmul(ap[q], v));
+    }
+    const Ext rrow{{acc[0], acc[1], acc[2], acc[3]}};
+    const uint32_t x = mmul(a.gen, root_pow(a.tw_fwd, a.tw_shift, a.h, bitrev32((uint32_t)r, a.h)));
+    Ext out = ext_zero();
+    if (a.accumulate) {
+        uint4 v = reinterpret_cast<const uint4*>(a.ro)[r];
+        out = Ext{{v.x, v.y, v.z, v.w}};
+    }
+    for (uint32_t p = 0; p < a.n_pts; p++) {
+        Ext d = ld_ext(a.pts + 4 * p);
+        d.c[0] = msub(d.c[0], x);
+        Ext u = ext_mul(ext_sub(ld_ext(a.ry + 4 * p), rrow), ext_inv(d));
+        out = ext_add(out, ext_mul(u, ld_ext(a.off + 4 * p)));
+    }
+    reinterpret_cast<uint4*>(a.ro)[r] = make_uint4(out.c[0], out.c[1], out.c[2], out.c[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FRI layer leaves: digest i = sponge(layer[2i] || layer[2i+1]) (8 words = one permutation)
+__global__ __launch_bounds__(256) void k_hash_pairs(const uint4* __restrict__ layer, size_t n_leaves,
+                                                    uint32_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves) return;
+    uint4 a = layer[2 * i], b = layer[2 * i + 1];
+    uint32_t s[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, 0, 0, 0, 0, 0, 0, 0, 0};
+    poseidon2_permute(s);
+    uint4* o = reinterpret_cast<uint4*>(out + i * 8);
+    o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+struct FriLayerDesc {
+    const uint32_t* layer;    // 2^log_len ext
+    const uint32_t* digests;  // tree over 2^(log_len-1) leaves
+    uint32_t log_len;
+    uint32_t out_off;         // word offset inside one query's record
+};
+// grid (n_queries, n_layers): sibling value + authentication path, canonical
+__global__ __launch_bounds__(64) void k_fri_query(const FriLayerDesc* layers, const uint32_t* indices,
+                                                  uint32_t* proof_queries, size_t query_pitch) {
+    const FriLayerDesc L = layers[blockIdx.y];
+    const uint32_t il = indices[blockIdx.x] >> blockIdx.y;
+    uint32_t* o = proof_queries + (size_t)blockIdx.x * query_pitch + L.out_off;
+    const unsigned t = threadIdx.x;
+    if (t < 4) o[t] = from_monty(L.layer[4 * (size_t)(il ^ 1u) + t]);
+    const unsigned tree_h = L.log_len - 1;
+    const uint32_t leaf = il >> 1;
+    size_t layer_off = 0;
+    for (unsigned l = 0; l < tree_h; l++) {
+        size_t sib = (leaf >> l) ^ 1u;
+        if (t < 8) o[4 + 8 * l + t] = from_monty(L.digests[(layer_off + sib) * 8 + t]);
+        layer_off += (size_t)1 << (tree_h - l);
+    }
+}
+
+__global__ void k_copy_canon(const uint32_t* src, uint32_t* dst, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = from_monty(src[i]);
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+// ---------------------------------------------------------------------------------------------
+struct AirPlan {
+    unsigned lh = 0, h = 0;
+    size_t width = 0, n_pvs = 0, N = 0, M = 0;
+    AirProgram prog;
+    std::vector<uint32_t> program_words;
+    uint32_t digest[8];  // sponge of the bytecode, canonical
+    // device
+    uint32_t* d_code = nullptr;
+    uint32_t n_instr = 0;
+    uint32_t* d_consts = nullptr;
+    unsigned n_slots = 1;
+    uint32_t* d_zh = nullptr;      // 2^b
+    uint32_t* d_inv_zh = nullptr;  // 2^b
+    uint32_t* d_pvs = nullptr;     // n_pvs (Montgomery), refreshed per proof
+    uint32_t* d_lde = nullptr;     // width columns x M
+    uint32_t* d_q = nullptr;       // 4 columns x M (quotient values, bit-reversed LDE order)
+    uint32_t* d_qnat = nullptr;    // 2^b chunks x 4 columns x N (natural order)
+    uint32_t* d_qlde = nullptr;    // 2^b chunks x 4 columns x M
+    uint32_t* d_apow_q = nullptr;  // n_cons ext
+    size_t opened_main_off = 0, opened_quot_off = 0;  // in ext units inside d_opened
+};
+
+struct zkhip_pk {
+    zkhip_params params;
+    unsigned b = 1, nch = 2, hmax = 0, n_layers = 0;
+    std::vector<AirPlan> airs;
+    std::vector<uint32_t> preamble;  // canonical words observed before anything else (pvs patched in)
+    std::vector<size_t> preamble_pv_off;
+    // workspace
+    void* d_ws = nullptr;
+    size_t ws_bytes = 0;
+    DevTranscript* d_tr = nullptr;
+    uint32_t* d_preamble = nullptr;
+    uint32_t* d_chal = nullptr;     // alpha[4] zeta[4] alpha_f[4] then betas[4*n_layers]
+    uint32_t* d_opened = nullptr;   // n_open ext (Montgomery)
+    size_t n_open = 0;
+    uint32_t* d_pts = nullptr;      // scratch: points / scales / ry / off (ext each)
+    uint32_t* d_weights = nullptr;  // 2 x Nmax ext
+    uint32_t* d_partial = nullptr;
+    uint32_t* d_apow_f = nullptr;   // max width ext
+    std::vector<uint32_t*> d_ro;    // per log height (nullptr if none)
+    std::vector<uint32_t*> d_flayer;  // n_layers+1
+    zkhip_tree* t_main = nullptr;
+    zkhip_tree* t_quot = nullptr;
+    std::vector<zkhip_tree*> t_fri;
+    FriLayerDesc* d_fri_desc = nullptr;
+    uint32_t* d_indices = nullptr;
+    uint32_t* d_proof = nullptr;
+    // proof layout (words)
+    size_t proof_words = 0, off_roots = 0, off_opened = 0, off_fri = 0, off_final = 0, off_qpow = 0, off_queries = 0;
+    size_t query_pitch = 0, q_main_words = 0, q_quot_words = 0;
+};
+
+namespace {
+
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    }
+};
+
+uint32_t host_pow(uint32_t a, uint64_t e) { return mpow(a, e); }
+
+int upload(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return ZKHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* airs, size_t n_airs, zkhip_pk** out) {
+    if (!ctx || !params || !airs || !out || n_airs == 0) return ZKHIP_ERR_INVALID;
+    if (params->log_final_poly_len != 0) return set_error(ctx, ZKHIP_ERR_INVALID, "log_final_poly_len must be 0");
+    if (params->log_blowup < 1 || params->log_blowup > 4) return set_error(ctx, ZKHIP_ERR_INVALID, "log_blowup out of range");
+    if (params->commit_pow_bits > 30 || params->query_pow_bits > 30 || params->num_queries == 0)
+        return set_error(ctx, ZKHIP_ERR_INVALID, "bad FRI parameters");
+    zkhip_pk* pk = new zkhip_pk();
+    pk->params = *params;
+    pk->b = params->log_blowup;
+    pk->nch = 1u << pk->b;
+    pk->airs.resize(n_airs);
+    std::string err;
+    size_t n_open = 0, max_n = 0, max_w = 4, tw_main = 0;
+    for (size_t a = 0; a < n_airs; a++) {
+        AirPlan& A = pk->airs[a];
+        if (airs[a].log_height < 1 || airs[a].log_height + pk->b > 27 || airs[a].width == 0) {
+            delete pk;
+            return set_error(ctx, ZKHIP_ERR_INVALID, "AIR height/width out of range");
+        }
+        A.program_words.assign(airs[a].program, airs[a].program + airs[a].program_len);
+        for (uint32_t w : A.program_words)
+            if (w >= P) {
+                delete pk;
+                return set_error(ctx, ZKHIP_ERR_INVALID, "AIR program word not a field element");
+            }
+        if (parse_air(A.program_words.data(), A.program_words.size(), airs[a].width, &A.prog, &err) != 0 ||
+            A.prog.n_pvs != airs[a].n_pvs) {
+            delete pk;
+            return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + ": " + (err.empty() ? "n_pvs mismatch" : err));
+        }
+        if (A.prog.max_degree > (1u << pk->b) + 1) {
+            delete pk;
+            return set_error(ctx, ZKHIP_ERR_CONSTRAINT, "constraint degree exceeds 2^log_blowup + 1");
+        }
+        A.lh = airs[a].log_height;
+        A.h = A.lh + pk->b;
+        A.width = airs[a].width;
+        A.n_pvs = airs[a].n_pvs;
+        A.N = (size_t)1 << A.lh;
+        A.M = (size_t)1 << A.h;
+        pk->hmax = std::max(pk->hmax, A.h);
+        max_n = std::max(max_n, A.N);
+        max_w = std::max(max_w, A.width);
+        tw_main += A.width;
+        // program digest (binds the proof to the constraint set)
+        std::vector<uint32_t> pm(A.program_words.size());
+        for (size_t i = 0; i < pm.size(); i++) pm[i] = to_monty(A.program_words[i]);
+        uint32_t dg[8];
+        p2_hash_slice(pm.data(), pm.size(), dg);
+        for (int i = 0; i < 8; i++) A.digest[i] = from_monty(dg[i]);
+    }
+    pk->n_layers = pk->hmax - pk->b;
+    // opened-value layout: main (all airs) then quotient (all airs)
+    for (size_t a = 0; a < n_airs; a++) {
+        pk->airs[a].opened_main_off = n_open;
+        n_open += 2 * pk->airs[a].width;
+    }
+    for (size_t a = 0; a < n_airs; a++) {
+        pk->airs[a].opened_quot_off = n_open;
+        n_open += 4 * (size_t)pk->nch;
+    }
+    pk->n_open = n_open;
+    // preamble
+    {
+        auto& pre = pk->preamble;
+        pre = {PROTO_TAG, (uint32_t)n_airs, params->log_blowup, params->log_final_poly_len, params->num_queries,
+               params->commit_pow_bits, params->query_pow_bits};
+        for (size_t a = 0; a < n_airs; a++) {
+            const AirPlan& A = pk->airs[a];
+            pre.push_back(A.lh);
+            pre.push_back((uint32_t)A.width);
+            pre.push_back((uint32_t)A.n_pvs);
+            for (int i = 0; i < 8; i++) pre.push_back(A.digest[i]);
+            pk->preamble_pv_off.push_back(pre.size());
+            for (size_t i = 0; i < A.n_pvs; i++) pre.push_back(0);
+        }
+    }
+    // proof layout
+    {
+        size_t w = 4;
+        pk->off_roots = w;
+        w += 16;
+        pk->off_opened = w;
+        w += 4 * n_open;
+        pk->off_fri = w;
+        w += 9 * (size_t)pk->n_layers;
+        pk->off_final = w;
+        w += 4;
+        pk->off_qpow = w;
+        w += 1;
+        pk->off_queries = w;
+        pk->q_main_words = tw_main + 8 * (size_t)pk->hmax;
+        pk->q_quot_words = 4 * (size_t)pk->nch * n_airs + 8 * (size_t)pk->hmax;
+        size_t pitch = pk->q_main_words + pk->q_quot_words;
+        for (unsigned l = 0; l < pk->n_layers; l++) pitch += 4 + 8 * (size_t)(pk->hmax - l - 1);
+        pk->query_pitch = pitch;
+        w += pitch * params->num_queries;
+        pk->proof_words = w;
+    }
+    // ---- workspace plan ----
+    Bump bp;
+    const unsigned nch = pk->nch;
+    struct AirOff {
+        size_t code, consts, zh, inv_zh, pvs, lde, q, qnat, qlde, apow_q;
+    };
+    std::vector<AirOff> ao(n_airs);
+    std::vector<CompiledAir> comp(n_airs);
+    for (size_t a = 0; a < n_airs; a++) {
+        AirPlan& A = pk->airs[a];
+        if (compile_air(A.prog, &comp[a], &err) != 0) {
+            delete pk;
+            return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + ": " + err);
+        }
+        A.n_instr = (uint32_t)(comp[a].code.size() / 3);
+        A.n_slots = comp[a].n_slots;
+        ao[a].code = bp.take(comp[a].code.size() * 4 + 16);
+        ao[a].consts = bp.take(comp[a].consts.size() * 4);
+        ao[a].zh = bp.take(nch * 4);
+        ao[a].inv_zh = bp.take(nch * 4);
+        ao[a].pvs = bp.take(A.n_pvs * 4 + 16);
+        ao[a].lde = bp.take(A.M * A.width * 4);
+        ao[a].q = bp.take(A.M * 4 * 4);
+        ao[a].qnat = bp.take(A.M * 4 * 4);
+        ao[a].qlde = bp.take((size_t)nch * A.M * 4 * 4);
+        ao[a].apow_q = bp.take((size_t)(A.prog.n_cons + 1) * 16);
+    }
+    size_t o_tr = bp.take(sizeof(DevTranscript));
+    size_t o_pre = bp.take(pk->preamble.size() * 4);
+    size_t o_chal = bp.take((3 + pk->n_layers) * 16);
+    size_t o_opened = bp.take(n_open * 16);
+    size_t o_pts = bp.take(64 * 16);
+    size_t o_weights = bp.take(2 * max_n * 16);
+    const int RK = 8;
+    size_t max_tiles = (max_n + 256 * RK - 1) / (256 * RK);
+    size_t o_partial = bp.take(max_tiles * max_w * 8 * 4);
+    size_t o_apow_f = bp.take(max_w * 16);
+    std::vector<size_t> o_ro(pk->hmax + 1, (size_t)-1);
+    for (size_t a = 0; a < n_airs; a++)
+        if (o_ro[pk->airs[a].h] == (size_t)-1) o_ro[pk->airs[a].h] = bp.take(((size_t)16) << pk->airs[a].h);
+    std::vector<size_t> o_flayer(pk->n_layers + 1);
+    for (unsigned l = 1; l <= pk->n_layers; l++) o_flayer[l] = bp.take((size_t)16 << (pk->hmax - l));
+    size_t o_dig_main = bp.take(merkle_digest_count(pk->hmax) * 32);
+    size_t o_dig_quot = bp.take(merkle_digest_count(pk->hmax) * 32);
+    std::vector<size_t> o_dig_fri(pk->n_layers);
+    for (unsigned l = 0; l < pk->n_layers; l++) o_dig_fri[l] = bp.take(merkle_digest_count(pk->hmax - l - 1) * 32);
+    size_t o_desc = bp.take(sizeof(FriLayerDesc) * (pk->n_layers + 1));
+    size_t o_idx = bp.take(params->num_queries * 4);
+    size_t o_proof = bp.take(pk->proof_words * 4);
+    pk->ws_bytes = bp.off;
+    if (hipMalloc(&pk->d_ws, pk->ws_bytes) != hipSuccess) {
+        delete pk;
+        return set_error(ctx, ZKHIP_ERR_NOMEM, "workspace of " + std::to_string(bp.off) + " bytes");
+    }
+    char* base = (char*)pk->d_ws;
+    int rc = ZKHIP_OK;
+    std::vector<zkhip_matrix> mm, qm;
+    for (size_t a = 0; a < n_airs && rc == ZKHIP_OK; a++) {
+        AirPlan& A = pk->airs[a];
+        A.d_code = (uint32_t*)(base + ao[a].code);
+        A.d_consts = (uint32_t*)(base + ao[a].consts);
+        A.d_zh = (uint32_t*)(base + ao[a].zh);
+        A.d_inv_zh = (uint32_t*)(base + ao[a].inv_zh);
+        A.d_pvs = (uint32_t*)(base + ao[a].pvs);
+        A.d_lde = (uint32_t*)(base + ao[a].lde);
+        A.d_q = (uint32_t*)(base + ao[a].q);
+        A.d_qnat = (uint32_t*)(base + ao[a].qnat);
+        A.d_qlde = (uint32_t*)(base + ao[a].qlde);
+        A.d_apow_q = (uint32_t*)(base + ao[a].apow_q);
+        rc = upload(ctx, A.d_code, comp[a].code.data(), comp[a].code.size() * 4);
+        if (rc == ZKHIP_OK) rc = upload(ctx, A.d_consts, comp[a].consts.data(), comp[a].consts.size() * 4);
+        // vanishing polynomial of H on the LDE coset: x^N = g^N * w_{2^b}^(i mod 2^b)
+        std::vector<uint32_t> zh(nch), izh(nch);
+        uint32_t gN = host_pow(to_monty(FIELD_GEN_CANON), A.N), wb = two_adic_generator(pk->b);
+        for (unsigned j = 0; j < nch; j++) {
+            zh[j] = msub(mmul(gN, host_pow(wb, j)), MONTY_ONE);
+            izh[j] = minv(zh[j]);
+        }
+        if (rc == ZKHIP_OK) rc = upload(ctx, A.d_zh, zh.data(), nch * 4);
+        if (rc == ZKHIP_OK) rc = upload(ctx, A.d_inv_zh, izh.data(), nch * 4);
+        mm.push_back(zkhip_matrix{A.d_lde, A.M, A.h, A.width});
+        for (unsigned j = 0; j < nch; j++) qm.push_back(zkhip_matrix{A.d_qlde + (size_t)j * 4 * A.M, A.M, A.h, 4});
+    }
+    pk->d_tr = (DevTranscript*)(base + o_tr);
+    pk->d_preamble = (uint32_t*)(base + o_pre);
+    pk->d_chal = (uint32_t*)(base + o_chal);
+    pk->d_opened = (uint32_t*)(base + o_opened);
+    pk->d_pts = (uint32_t*)(base + o_pts);
+    pk->d_weights = (uint32_t*)(base + o_weights);
+    pk->d_partial = (uint32_t*)(base + o_partial);
+    pk->d_apow_f = (uint32_t*)(base + o_apow_f);
+    pk->d_ro.assign(pk->hmax + 1, nullptr);
+    for (unsigned h = 0; h <= pk->hmax; h++)
+        if (o_ro[h] != (size_t)-1) pk->d_ro[h] = (uint32_t*)(base + o_ro[h]);
+    pk->d_flayer.assign(pk->n_layers + 1, nullptr);
+    pk->d_flayer[0] = pk->d_ro[pk->hmax];
+    for (unsigned l = 1; l <= pk->n_layers; l++) pk->d_flayer[l] = (uint32_t*)(base + o_flayer[l]);
+    pk->d_indices = (uint32_t*)(base + o_idx);
+    pk->d_proof = (uint32_t*)(base + o_proof);
+    pk->d_fri_desc = (FriLayerDesc*)(base + o_desc);
+    if (rc == ZKHIP_OK) rc = merkle_plan(ctx, mm.data(), mm.size(), (uint32_t*)(base + o_dig_main), &pk->t_main);
+    if (rc == ZKHIP_OK) rc = merkle_plan(ctx, qm.data(), qm.size(), (uint32_t*)(base + o_dig_quot), &pk->t_quot);
+    pk->t_fri.assign(pk->n_layers, nullptr);
+    std::vector<FriLayerDesc> desc(pk->n_layers);
+    size_t qoff = pk->q_main_words + pk->q_quot_words;
+    for (unsigned l = 0; l < pk->n_layers && rc == ZKHIP_OK; l++) {
+        rc = merkle_plan_leaves(ctx, pk->hmax - l - 1, (uint32_t*)(base + o_dig_fri[l]), &pk->t_fri[l]);
+        desc[l].layer = pk->d_flayer[l];
+        desc[l].digests = (uint32_t*)(base + o_dig_fri[l]);
+        desc[l].log_len = pk->hmax - l;
+        desc[l].out_off = (uint32_t)qoff;
+        qoff += 4 + 8 * (size_t)(pk->hmax - l - 1);
+    }
+    if (rc == ZKHIP_OK) rc = upload(ctx, pk->d_fri_desc, desc.data(), desc.size() * sizeof(FriLayerDesc));
+    if (rc == ZKHIP_OK) rc = ensure_twiddles(ctx, pk->hmax);
+    if (rc != ZKHIP_OK) {
+        zkhip_pk_destroy(ctx, pk);
+        return rc;
+    }
+    *out = pk;
+    return ZKHIP_OK;
+}
+
+void zkhip_pk_destroy(zkhip_ctx* ctx, zkhip_pk* pk) {
+    if (!pk) return;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (pk->t_main) zkhip_tree_destroy(ctx, pk->t_main);
+    if (pk->t_quot) zkhip_tree_destroy(ctx, pk->t_quot);
+    for (auto* t : pk->t_fri)
+        if (t) zkhip_tree_destroy(ctx, t);
+    if (pk->d_ws) hipFree(pk->d_ws);
+    delete pk;
+}
+
+size_t zkhip_proof_size(const zkhip_pk* pk) { return pk ? pk->proof_words * 4 : 0; }
+
+int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const* d_traces,
+                      const uint32_t* const* pvs) {
+    if (!ctx || !pkc || !d_traces) return ZKHIP_ERR_INVALID;
+    zkhip_pk* pk = const_cast<zkhip_pk*>(pkc);
+    const unsigned b = pk->b, nch = pk->nch, hmax = pk->hmax;
+    const size_t n_airs = pk->airs.size();
+    hipStream_t st = ctx->stream;
+    ZK_TRY(ensure_twiddles(ctx, hmax));
+    const uint32_t gen = to_monty(FIELD_GEN_CANON);
+    uint32_t* d_alpha = pk->d_chal;
+    uint32_t* d_zeta = pk->d_chal + 4;
+    uint32_t* d_alpha_f = pk->d_chal + 8;
+    uint32_t* d_betas = pk->d_chal + 12;
+
+    // ---- 0. preamble + public values ----
+    {
+        std::vector<uint32_t> pre = pk->preamble;
+        for (size_t a = 0; a < n_airs; a++) {
+            const AirPlan& A = pk->airs[a];
+            if (A.n_pvs && (!pvs || !pvs[a])) return set_error(ctx, ZKHIP_ERR_INVALID, "missing public values");
+            std::vector<uint32_t> pm(A.n_pvs);
+            for (size_t i = 0; i < A.n_pvs; i++) {
+                if (pvs[a][i] >= P) return set_error(ctx, ZKHIP_ERR_INVALID, "public value not canonical");
+                pre[pk->preamble_pv_off[a] + i] = pvs[a][i];
+                pm[i] = to_monty(pvs[a][i]);
+            }
+            if (A.n_pvs) ZK_HIP_CHECK(ctx, hipMemcpyAsync(A.d_pvs, pm.data(), A.n_pvs * 4, hipMemcpyHostToDevice, st));
+            ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));  // pm is a stack temporary
+        }
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_preamble, pre.data(), pre.size() * 4, hipMemcpyHostToDevice, st));
+        uint32_t hdr[4] = {PROOF_MAGIC, (uint32_t)n_airs, hmax, pk->n_layers};
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_proof, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        ZK_TRY(transcript_init(ctx, pk->d_tr));
+        ZK_TRY(transcript_observe(ctx, pk->d_tr, pk->d_preamble, (uint32_t)pre.size(), true));
+    }
+
+    // ---- 1. trace commit: coset LDE + Merkle ----
+    for (size_t a = 0; a < n_airs; a++) {
+        AirPlan& A = pk->airs[a];
+        if (!d_traces[a]) return set_error(ctx, ZKHIP_ERR_INVALID, "missing trace");
+        ZK_TRY(lde_batch(ctx, d_traces[a], A.N, A.d_lde, A.M, A.lh, b, A.width, gen));
+    }
+    ZK_TRY(merkle_build(ctx, pk->t_main, false));
+    const uint32_t* d_root_main = zkhip_tree_root_device(pk->t_main);
+    ZK_TRY(transcript_observe(ctx, pk->d_tr, d_root_main, 8, false));
+    ZK_TRY(transcript_sample(ctx, pk->d_tr, d_alpha, nullptr, 4));
+
+    // ---- 2. quotient ----
+    for (size_t a = 0; a < n_airs; a++) {
+        AirPlan& A = pk->airs[a];
+        {
+            KernelScope ks(ctx, "ext_powers");
+            hipLaunchKernelGGL(k_ext_powers, dim3(1), dim3(64), 0, st, d_alpha, A.prog.n_cons, 1, A.d_apow_q);
+        }
+        QuotArgs qa;
+        qa.code = A.d_code;
+        qa.n_instr = A.n_instr;
+        qa.consts = A.d_consts;
+        qa.pvs = A.d_pvs;
+        qa.apow = A.d_apow_q;
+        qa.lde = A.d_lde;
+        qa.q = A.d_q;
+        qa.tw_fwd = ctx->d_tw_fwd;
+        qa.inv_zh = A.d_inv_zh;
+        qa.zh = A.d_zh;
+        qa.gen = gen;
+        qa.w_n_inv = minv(two_adic_generator(A.lh));
+        qa.lh = A.lh;
+        qa.b = b;
+        qa.tw_shift = ctx->tw_log - A.h;
+        {
+            KernelScope ks(ctx, "quotient_eval");
+            hipLaunchKernelGGL(k_quotient, dim3((unsigned)((A.M + QBS - 1) / QBS)), dim3(QBS),
+                               (size_t)A.n_slots * QBS * 4, st, qa);
+        }
+        ZK_HIP_CHECK(ctx, hipGetLastError());
+        // chunk j = rows [jN,(j+1)N) of q, bit-reversed within the chunk: bring to natural order,
+        // then extend from s_j*H to g*K (shift g/s_j) -- p3's quotient-chunk commitment
+        for (unsigned j = 0; j < nch; j++) {
+            uint32_t* nat = A.d_qnat + (size_t)j * 4 * A.N;
+            // column k of the chunk starts at q + k*M + j*N
+            ZK_TRY(ntt_bitrev_copy(ctx, A.d_q + (size_t)j * A.N, A.M, nat, A.N, A.lh, 4));
+            uint32_t sj = mmul(gen, host_pow(two_adic_generator(A.h), bitrev32(j, b)));
+            ZK_TRY(lde_batch(ctx, nat, A.N, A.d_qlde + (size_t)j * 4 * A.M, A.M, A.lh, b, 4, mmul(gen, minv(sj))));
+        }
+    }
+    ZK_TRY(merkle_build(ctx, pk->t_quot, false));
+    const uint32_t* d_root_quot = zkhip_tree_root_device(pk->t_quot);
+    ZK_TRY(transcript_observe(ctx, pk->d_tr, d_root_quot, 8, false));
+    ZK_TRY(transcript_sample(ctx, pk->d_tr, d_zeta, nullptr, 4));
+
+    // ---- 3. openings at zeta (and zeta*w for the trace) ----
+    const int RK = 8;
+    auto open_matrix = [&](const uint32_t* cols, size_t stride, uint32_t n_cols, unsigned lh, unsigned n_pts,
+                           uint32_t shift, uint32_t* d_out) -> int {
+        const size_t N = (size_t)1 << lh;
+        PointsArgs pa;
+        pa.zeta = d_zeta;
+        pa.w_n = two_adic_generator(lh);
+        pa.shift = shift;
+        pa.s_pow_n = host_pow(shift, N);
+        pa.scale_base = minv(mmul(to_monty((uint32_t)(N % P)), pa.s_pow_n));
+        pa.lh = lh;
+        pa.n_pts = n_pts;
+        pa.pts = pk->d_pts;
+        pa.scale = pk->d_pts + 8;
+        {
+            KernelScope ks(ctx, "open_points");
+            hipLaunchKernelGGL(k_open_points, dim3(1), dim3(64), 0, st, pa);
+        }
+        {
+            KernelScope ks(ctx, "bary_weights");
+            hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pk->d_pts, n_pts,
+                               shift, ctx->d_tw_fwd, lh ? ctx->tw_log - lh : 0, lh, pk->d_weights);
+        }
+        uint32_t n_tiles = (uint32_t)((N + 256 * RK - 1) / (256 * RK));
+        {
+            KernelScope ks(ctx, "open_col_reduce");
+            if (n_pts == 2)
+                hipLaunchKernelGGL((k_col_reduce<2, RK>), dim3(n_tiles), dim3(256), 0, st, cols, stride, n_cols, lh,
+                                   pk->d_weights, pk->d_partial);
+            else
+                hipLaunchKernelGGL((k_col_reduce<1, RK>), dim3(n_tiles), dim3(256), 0, st, cols, stride, n_cols, lh,
+                                   pk->d_weights, pk->d_partial);
+        }
+        {
+            KernelScope ks(ctx, "open_finish");
+            hipLaunchKernelGGL(k_open_finish, dim3(n_cols, n_pts), dim3(64), 0, st, pk->d_partial, n_tiles, n_cols,
+                               n_pts, pk->d_pts + 8, d_out);
+        }
+        ZK_HIP_CHECK(ctx, hipGetLastError());
+        return ZKHIP_OK;
+    };
+    for (size_t a = 0; a < n_airs; a++) {
+        AirPlan& A = pk->airs[a];
+        ZK_TRY(open_matrix(d_traces[a], A.N, (uint32_t)A.width, A.lh, 2, MONTY_ONE,
+                           pk->d_opened + 4 * A.opened_main_off));
+    }
+    for (size_t a = 0; a < n_airs; a++) {
+        AirPlan& A = pk->airs[a];
+        for (unsigned j = 0; j < nch; j++) {
+            uint32_t sj = mmul(gen, host_pow(two_adic_generator(A.h), bitrev32(j, b)));
+            ZK_TRY(open_matrix(A.d_qnat + (size_t)j * 4 * A.N, A.N, 4, A.lh, 1, sj,
+                               pk->d_opened + 4 * (A.opened_quot_off + 4 * (size_t)j)));
+        }
+    }
+    ZK_TRY(transcript_observe(ctx, pk->d_tr, pk->d_opened, (uint32_t)(4 * pk->n_open), false));
+    ZK_TRY(transcript_sample(ctx, pk->d_tr, d_alpha_f, nullptr, 4));
+
+    // ---- 4. FRI batching: reduced openings per LDE height ----
+    {
+        std::vector<uint64_t> num_reduced(hmax + 1, 0);
+        std::vector<char> started(hmax + 1, 0);
+        for (int round = 0; round < 2; round++)
+            for (size_t a = 0; a < n_airs; a++) {
+                AirPlan& A = pk->airs[a];
+                const unsigned n_mats = round == 0 ? 1 : nch;
+                for (unsigned j = 0; j < n_mats; j++) {
+                    const uint32_t W = round == 0 ? (uint32_t)A.width : 4u;
+                    const unsigned n_pts = round == 0 ? 2 : 1;
+                    const uint32_t* mat = round == 0 ? A.d_lde : A.d_qlde + (size_t)j * 4 * A.M;
+                    const uint32_t* opened = pk->d_opened + 4 * (round == 0 ? A.opened_main_off
+                                                                              : A.opened_quot_off + 4 * (size_t)j);
+                    // points of this matrix: zeta (and zeta * w_N)
+                    PointsArgs pa;
+                    pa.zeta = d_zeta;
+                    pa.w_n = two_adic_generator(A.lh);
+                    pa.shift = MONTY_ONE;
+                    pa.s_pow_n = MONTY_ONE;
+                    pa.scale_base = MONTY_ONE;
+                    pa.lh = 0;
+                    pa.n_pts = n_pts;
+                    pa.pts = pk->d_pts;
+                    pa.scale = pk->d_pts + 8;
+                    ReducePrep rp;
+                    rp.alpha = d_alpha_f;
+                    rp.opened = opened;
+                    rp.pts = pk->d_pts;
+                    rp.width = W;
+                    rp.n_pts = n_pts;
+                    rp.num_reduced = num_reduced[A.h];
+                    rp.apow = pk->d_apow_f;
+                    rp.ry = pk->d_pts + 16;
+                    rp.off = pk->d_pts + 24;
+                    {
+                        KernelScope ks(ctx, "reduce_prep");
+                        hipLaunchKernelGGL(k_open_points, dim3(1), dim3(64), 0, st, pa);
+                        hipLaunchKernelGGL(k_reduce_prep, dim3(1), dim3(64), 0, st, rp);
+                    }
+                    ReduceArgs ra;
+                    ra.mat = mat;
+                    ra.apow = pk->d_apow_f;
+                    ra.ry = rp.ry;
+                    ra.off = rp.off;
+                    ra.pts = pk->d_pts;
+                    ra.ro = pk->d_ro[A.h];
+                    ra.tw_fwd = ctx->d_tw_fwd;
+                    ra.gen = gen;
+                    ra.width = W;
+                    ra.n_pts = n_pts;
+                    ra.h = A.h;
+                    ra.tw_shift = ctx->tw_log - A.h;
+                    ra.accumulate = started[A.h] ? 1 : 0;
+                    {
+                        KernelScope ks(ctx, "reduced_openings");
+                        hipLaunchKernelGGL(k_reduced_openings, dim3((unsigned)((A.M + 255) / 256)), dim3(256), 0, st, ra);
+                    }
+                    ZK_HIP_CHECK(ctx, hipGetLastError());
+                    started[A.h] = 1;
+                    num_reduced[A.h] += (uint64_t)W * n_pts;
+                }
+            }
+    }
+
+    // ---- 5. FRI commit phase ----
+    uint32_t* pf = pk->d_proof;
+    for (unsigned l = 0; l < pk->n_layers; l++) {
+        const unsigned log_len = hmax - l;
+        const size_t half = (size_t)1 << (log_len - 1);
+        {
+            KernelScope ks(ctx, "fri_hash_pairs");
+            hipLaunchKernelGGL(k_hash_pairs, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st,
+                               (const uint4*)pk->d_flayer[l], half, pk->t_fri[l]->d_digests);
+        }
+        ZK_TRY(merkle_build(ctx, pk->t_fri[l], true));
+        const uint32_t* d_root = zkhip_tree_root_device(pk->t_fri[l]);
+        ZK_TRY(transcript_observe(ctx, pk->d_tr, d_root, 8, false));
+        {
+            KernelScope ks(ctx, "copy_canon");
+            hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root, pf + pk->off_fri + 9 * (size_t)l, 8u);
+        }
+        ZK_TRY(transcript_grind(ctx, pk->d_tr, pk->params.commit_pow_bits, pf + pk->off_fri + 9 * (size_t)l + 8));
+        ZK_TRY(transcript_sample(ctx, pk->d_tr, d_betas + 4 * l, nullptr, 4));
+        ZK_TRY(fri_fold(ctx, pk->d_flayer[l], pk->d_flayer[l + 1], log_len - 1, d_betas + 4 * l,
+                        pk->d_ro[log_len - 1], pk->d_ro[log_len - 1] != nullptr));
+    }
+    // final polynomial (constant): first value of the last layer
+    ZK_TRY(transcript_observe(ctx, pk->d_tr, pk->d_flayer[pk->n_layers], 4, false));
+    {
+        KernelScope ks(ctx, "copy_canon");
+        hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, pk->d_flayer[pk->n_layers], pf + pk->off_final, 4u);
+        hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_main, pf + pk->off_roots, 8u);
+        hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_quot, pf + pk->off_roots + 8, 8u);
+        uint32_t n = (uint32_t)(4 * pk->n_open);
+        hipLaunchKernelGGL(k_copy_canon, dim3((n + 255) / 256), dim3(256), 0, st, pk->d_opened, pf + pk->off_opened, n);
+    }
+    ZK_TRY(transcript_grind(ctx, pk->d_tr, pk->params.query_pow_bits, pf + pk->off_qpow));
+
+    // ---- 6. queries ----
+    ZK_TRY(transcript_sample_bits(ctx, pk->d_tr, pk->d_indices, pk->params.num_queries, hmax));
+    uint32_t* pq = pf + pk->off_queries;
+    ZK_TRY(merkle_open_device(ctx, pk->t_main, pk->d_indices, 0, pk->params.num_queries, pq, pk->query_pitch));
+    ZK_TRY(merkle_open_device(ctx, pk->t_quot, pk->d_indices, 0, pk->params.num_queries, pq + pk->q_main_words,
+                              pk->query_pitch));
+    if (pk->n_layers) {
+        KernelScope ks(ctx, "fri_query");
+        hipLaunchKernelGGL(k_fri_query, dim3(pk->params.num_queries, pk->n_layers), dim3(64), 0, st, pk->d_fri_desc,
+                           pk->d_indices, pq, pk->query_pitch);
+    }
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+int zkhip_proof_fetch(zkhip_ctx* ctx, const zkhip_pk* pk, uint8_t* out, size_t cap, size_t* out_len) {
+    if (!ctx || !pk || !out) return ZKHIP_ERR_INVALID;
+    size_t bytes = pk->proof_words * 4;
+    if (out_len) *out_len = bytes;
+    if (cap < bytes) return set_error(ctx, ZKHIP_ERR_SMALL_BUFFER, "proof buffer too small");
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(out, pk->d_proof, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    DevTranscript h;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h, pk->d_tr, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h.error) return set_error(ctx, ZKHIP_ERR_POW_FAILED, "proof-of-work search failed");
+    return ZKHIP_OK;
+}
+
+int zkhip_prove(zkhip_ctx* ctx, const zkhip_pk* pk, const uint32_t* const* d_traces, const uint32_t* const* pvs,
+                uint8_t* out, size_t cap, size_t* out_len) {
+    if (!ctx || !pk || !out) return ZKHIP_ERR_INVALID;
+    if (cap < pk->proof_words * 4) {
+        if (out_len) *out_len = pk->proof_words * 4;
+        return set_error(ctx, ZKHIP_ERR_SMALL_BUFFER, "proof buffer too small");
+    }
+    ZK_TRY(zkhip_prove_async(ctx, pk, d_traces, pvs));
+    return zkhip_proof_fetch(ctx, pk, out, cap, out_len);
+}
+
+}  // extern "C"

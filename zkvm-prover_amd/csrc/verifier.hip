@@ -1,0 +1,342 @@
+// verifier.hip -- host-side verifier of libzkhip proofs (no device code; compiled with hipcc only
+// for uniformity).  Replaces, for this backend's proofs, what the reference reaches through
+// `Sdk::verify_proof` (crates/verifier/src/verifier.rs:82) and runs as the prover's self-check
+// (crates/prover/src/prover/mod.rs:407-411).  Written against babybear.hpp / poseidon2.hpp
+// (Montgomery arithmetic); it shares no code with oracle/.
+#include <string.h>
+
+#include <vector>
+
+#include "air_compile.hpp"
+#include "poseidon2.hpp"
+#include "../../include/zkhip.h"
+
+namespace zk {
+namespace {
+
+struct HostChallenger {
+    uint32_t state[16];
+    uint32_t in_buf[8], out_buf[8];
+    unsigned n_in = 0, n_out = 0;
+    HostChallenger() { memset(state, 0, sizeof state); }
+    void duplex() {
+        for (unsigned i = 0; i < n_in; i++) state[i] = in_buf[i];
+        n_in = 0;
+        poseidon2_permute(state);
+        memcpy(out_buf, state, sizeof out_buf);
+        n_out = 8;
+    }
+    void observe(uint32_t v_monty) {
+        n_out = 0;
+        in_buf[n_in++] = v_monty;
+        if (n_in == 8) duplex();
+    }
+    void observe_canon(const uint32_t* v, size_t n) {
+        for (size_t i = 0; i < n; i++) observe(to_monty(v[i]));
+    }
+    uint32_t sample() {
+        if (n_in != 0 || n_out == 0) duplex();
+        return out_buf[--n_out];
+    }
+    Ext sample_ext() {
+        Ext e;
+        for (int i = 0; i < 4; i++) e.c[i] = sample();
+        return e;
+    }
+    uint32_t sample_bits(unsigned bits) { return from_monty(sample()) & (uint32_t)(((uint64_t)1 << bits) - 1); }
+    bool check_witness(unsigned bits, uint32_t w_canon) {
+        observe(to_monty(w_canon));
+        return sample_bits(bits) == 0;
+    }
+};
+
+Ext ext_from_canon(const uint32_t* p) { return Ext{{to_monty(p[0]), to_monty(p[1]), to_monty(p[2]), to_monty(p[3])}}; }
+
+// recompute the root implied by an opening of a mixed-height commitment
+bool verify_opening(const uint32_t root_m[8], const std::vector<unsigned>& lhs, const std::vector<size_t>& ws,
+                    size_t index, const uint32_t* opening_canon) {
+    unsigned lh = 0;
+    size_t total = 0;
+    for (size_t m = 0; m < lhs.size(); m++) {
+        if (lhs[m] > lh) lh = lhs[m];
+        total += ws[m];
+    }
+    std::vector<uint32_t> tmp(total + 1);
+    const uint32_t* path = opening_canon + total;
+    uint32_t cur[8];
+    for (unsigned level = lh;; level--) {
+        size_t len = 0, off = 0;
+        bool any = false;
+        for (size_t m = 0; m < lhs.size(); m++) {
+            if (lhs[m] == level) {
+                for (size_t k = 0; k < ws[m]; k++) tmp[len++] = to_monty(opening_canon[off + k]);
+                any = true;
+            }
+            off += ws[m];
+        }
+        if (level == lh) {
+            p2_hash_slice(tmp.data(), len, cur);
+        } else {
+            unsigned l = lh - level - 1;
+            uint32_t sib[8];
+            for (int k = 0; k < 8; k++) sib[k] = to_monty(path[8 * l + k]);
+            if (((index >> l) & 1) == 0) p2_compress(cur, sib, cur);
+            else p2_compress(sib, cur, cur);
+            if (any) {
+                uint32_t hsh[8];
+                p2_hash_slice(tmp.data(), len, hsh);
+                p2_compress(cur, hsh, cur);
+            }
+        }
+        if (level == 0) break;
+    }
+    return memcmp(cur, root_m, 32) == 0;
+}
+
+}  // namespace
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, const uint32_t* const* pvs,
+                            const uint8_t* proof_bytes, size_t len) {
+    if (!prm || !airs || !proof_bytes || n_airs == 0 || (len & 3)) return ZKHIP_ERR_INVALID;
+    const unsigned b = prm->log_blowup, nch = 1u << b;
+    if (prm->log_final_poly_len != 0 || b < 1 || b > 4) return ZKHIP_ERR_INVALID;
+    const size_t n_words = len / 4;
+    std::vector<uint32_t> pw(n_words);
+    memcpy(pw.data(), proof_bytes, len);
+    const uint32_t* proof = pw.data();
+    for (size_t i = 0; i < n_words; i++)
+        if (proof[i] >= P) return ZKHIP_ERR_VERIFY;
+    std::vector<AirProgram> pg(n_airs);
+    unsigned hmax = 0;
+    size_t n_open = 0;
+    for (size_t a = 0; a < n_airs; a++) {
+        if (parse_air(airs[a].program, airs[a].program_len, airs[a].width, &pg[a], nullptr) != 0) return ZKHIP_ERR_INVALID;
+        if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height < 1) return ZKHIP_ERR_INVALID;
+        if (pg[a].max_degree > nch + 1) return ZKHIP_ERR_CONSTRAINT;
+        if (airs[a].n_pvs && (!pvs || !pvs[a])) return ZKHIP_ERR_INVALID;
+        hmax = std::max(hmax, airs[a].log_height + b);
+        n_open += 2 * airs[a].width + 4 * (size_t)nch;
+    }
+    const unsigned n_layers = hmax - b;
+    size_t r = 0;
+    if (n_words < 4 + 16 + 4 * n_open + 9 * (size_t)n_layers + 5) return ZKHIP_ERR_VERIFY;
+    if (proof[0] != PROOF_MAGIC || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers) return ZKHIP_ERR_VERIFY;
+    r = 4;
+    const uint32_t *root_main = proof + r, *root_quot = proof + r + 8;
+    r += 16;
+    const uint32_t* opened_c = proof + r;
+    r += 4 * n_open;
+    const uint32_t* fri_hdr = proof + r;
+    r += 9 * (size_t)n_layers;
+    const uint32_t* fin_c = proof + r;
+    r += 4;
+    const uint32_t qpow = proof[r++];
+    std::vector<Ext> opened(n_open);
+    for (size_t i = 0; i < n_open; i++) opened[i] = ext_from_canon(opened_c + 4 * i);
+
+    HostChallenger ch;
+    {
+        uint32_t hdr[7] = {PROTO_TAG, (uint32_t)n_airs, prm->log_blowup, prm->log_final_poly_len, prm->num_queries,
+                           prm->commit_pow_bits, prm->query_pow_bits};
+        ch.observe_canon(hdr, 7);
+        for (size_t a = 0; a < n_airs; a++) {
+            std::vector<uint32_t> pm(airs[a].program_len);
+            for (size_t i = 0; i < pm.size(); i++) {
+                if (airs[a].program[i] >= P) return ZKHIP_ERR_INVALID;
+                pm[i] = to_monty(airs[a].program[i]);
+            }
+            uint32_t dg[8];
+            p2_hash_slice(pm.data(), pm.size(), dg);
+            uint32_t meta[3] = {airs[a].log_height, (uint32_t)airs[a].width, (uint32_t)airs[a].n_pvs};
+            ch.observe_canon(meta, 3);
+            for (int i = 0; i < 8; i++) ch.observe(dg[i]);
+            for (size_t i = 0; i < airs[a].n_pvs; i++) {
+                if (pvs[a][i] >= P) return ZKHIP_ERR_INVALID;
+                ch.observe(to_monty(pvs[a][i]));
+            }
+        }
+    }
+    ch.observe_canon(root_main, 8);
+    const Ext alpha = ch.sample_ext();
+    ch.observe_canon(root_quot, 8);
+    const Ext zeta = ch.sample_ext();
+    ch.observe_canon(opened_c, 4 * n_open);
+    const Ext alpha_f = ch.sample_ext();
+    const uint32_t gen = to_monty(FIELD_GEN_CANON);
+
+    // ---- constraints at zeta ----
+    size_t om = 0, oq = 0;
+    for (size_t a = 0; a < n_airs; a++) oq += 2 * airs[a].width;
+    for (size_t a = 0; a < n_airs; a++) {
+        const unsigned lh = airs[a].log_height, h = lh + b;
+        const size_t W = airs[a].width;
+        // selectors of H at zeta
+        Ext zn = zeta;
+        for (unsigned k = 0; k < lh; k++) zn = ext_mul(zn, zn);
+        Ext zh = zn;
+        zh.c[0] = msub(zh.c[0], MONTY_ONE);
+        Ext d1 = zeta;
+        d1.c[0] = msub(d1.c[0], MONTY_ONE);
+        const Ext is_first = ext_mul(zh, ext_inv(d1));
+        Ext is_trans = zeta;
+        is_trans.c[0] = msub(is_trans.c[0], minv(two_adic_generator(lh)));
+        const Ext is_last = ext_mul(zh, ext_inv(is_trans));
+        const Ext inv_zh = ext_inv(zh);
+        std::vector<Ext> vals(pg[a].n_nodes);
+        const Ext* local = &opened[om];
+        const Ext* next = &opened[om + W];
+        for (uint32_t i = 0; i < pg[a].n_nodes; i++) {
+            uint32_t op = pg[a].nodes[3 * i], x = pg[a].nodes[3 * i + 1], y = pg[a].nodes[3 * i + 2];
+            switch (op) {
+                case A_VAR: vals[i] = y ? next[x] : local[x]; break;
+                case A_PUB: vals[i] = ext_from_base(to_monty(pvs[a][x])); break;
+                case A_CONST: vals[i] = ext_from_base(to_monty(x)); break;
+                case A_FIRST: vals[i] = is_first; break;
+                case A_LAST: vals[i] = is_last; break;
+                case A_TRANS: vals[i] = is_trans; break;
+                case A_ADD: vals[i] = ext_add(vals[x], vals[y]); break;
+                case A_SUB: vals[i] = ext_sub(vals[x], vals[y]); break;
+                case A_MUL: vals[i] = ext_mul(vals[x], vals[y]); break;
+                default: vals[i] = ext_neg(vals[x]); break;
+            }
+        }
+        Ext acc = ext_zero();
+        for (uint32_t k = 0; k < pg[a].n_cons; k++) acc = ext_add(ext_mul(acc, alpha), vals[pg[a].cons[k]]);
+        const Ext lhs = ext_mul(acc, inv_zh);
+        // quotient(zeta) from its chunks
+        const uint32_t wM = two_adic_generator(h);
+        Ext rhs = ext_zero();
+        for (unsigned j = 0; j < nch; j++) {
+            const uint32_t sj = mmul(gen, mpow(wM, bitrev32(j, b)));
+            Ext zps = ext_one();
+            for (unsigned k = 0; k < nch; k++) {
+                if (k == j) continue;
+                const uint32_t sk = mmul(gen, mpow(wM, bitrev32(k, b)));
+                Ext t = ext_mul_base(zeta, minv(sk));
+                for (unsigned q = 0; q < lh; q++) t = ext_mul(t, t);
+                t.c[0] = msub(t.c[0], MONTY_ONE);
+                uint32_t den = msub(mpow(mmul(sj, minv(sk)), (uint64_t)1 << lh), MONTY_ONE);
+                zps = ext_mul(zps, ext_mul_base(t, minv(den)));
+            }
+            Ext v = ext_zero();
+            for (int k = 0; k < 4; k++) {
+                Ext e = ext_zero();
+                e.c[k] = MONTY_ONE;
+                v = ext_add(v, ext_mul(e, opened[oq + 4 * j + k]));
+            }
+            rhs = ext_add(rhs, ext_mul(v, zps));
+        }
+        if (!ext_eq(lhs, rhs)) return ZKHIP_ERR_VERIFY;
+        om += 2 * W;
+        oq += 4 * (size_t)nch;
+    }
+
+    // ---- FRI transcript ----
+    std::vector<Ext> betas(n_layers);
+    std::vector<uint32_t> froots_m(8 * (size_t)n_layers);
+    for (unsigned l = 0; l < n_layers; l++) {
+        ch.observe_canon(fri_hdr + 9 * l, 8);
+        for (int k = 0; k < 8; k++) froots_m[8 * l + k] = to_monty(fri_hdr[9 * l + k]);
+        if (!ch.check_witness(prm->commit_pow_bits, fri_hdr[9 * l + 8])) return ZKHIP_ERR_VERIFY;
+        betas[l] = ch.sample_ext();
+    }
+    ch.observe_canon(fin_c, 4);
+    if (!ch.check_witness(prm->query_pow_bits, qpow)) return ZKHIP_ERR_VERIFY;
+    const Ext fin = ext_from_canon(fin_c);
+
+    std::vector<unsigned> lh_main(n_airs), lh_quot(n_airs * nch);
+    std::vector<size_t> w_main(n_airs), w_quot(n_airs * nch);
+    size_t tw_main = 0, tw_quot = 0;
+    for (size_t a = 0; a < n_airs; a++) {
+        lh_main[a] = airs[a].log_height + b;
+        w_main[a] = airs[a].width;
+        tw_main += w_main[a];
+        for (unsigned j = 0; j < nch; j++) {
+            lh_quot[a * nch + j] = lh_main[a];
+            w_quot[a * nch + j] = 4;
+            tw_quot += 4;
+        }
+    }
+    uint32_t root_main_m[8], root_quot_m[8];
+    for (int k = 0; k < 8; k++) {
+        root_main_m[k] = to_monty(root_main[k]);
+        root_quot_m[k] = to_monty(root_quot[k]);
+    }
+    std::vector<Ext> roq(hmax + 1);
+    std::vector<char> has(hmax + 1);
+    std::vector<uint64_t> num_reduced(hmax + 1);
+    for (unsigned qn = 0; qn < prm->num_queries; qn++) {
+        const size_t idx = ch.sample_bits(hmax);
+        const size_t n_main = tw_main + 8 * (size_t)hmax, n_quot = tw_quot + 8 * (size_t)hmax;
+        if (r + n_main + n_quot > n_words) return ZKHIP_ERR_VERIFY;
+        const uint32_t *op_main = proof + r, *op_quot = proof + r + n_main;
+        r += n_main + n_quot;
+        if (!verify_opening(root_main_m, lh_main, w_main, idx, op_main)) return ZKHIP_ERR_VERIFY;
+        if (!verify_opening(root_quot_m, lh_quot, w_quot, idx, op_quot)) return ZKHIP_ERR_VERIFY;
+        std::fill(roq.begin(), roq.end(), ext_zero());
+        std::fill(has.begin(), has.end(), 0);
+        std::fill(num_reduced.begin(), num_reduced.end(), 0);
+        size_t oi = 0;
+        for (int round = 0; round < 2; round++) {
+            const uint32_t* rows = round == 0 ? op_main : op_quot;
+            for (size_t a = 0; a < n_airs; a++) {
+                const unsigned h = airs[a].log_height + b;
+                const unsigned n_mats = round == 0 ? 1 : nch;
+                const size_t W = round == 0 ? airs[a].width : 4;
+                const unsigned n_pts = round == 0 ? 2 : 1;
+                const size_t ih = idx >> (hmax - h);
+                const uint32_t x = mmul(gen, mpow(two_adic_generator(h), bitrev32((uint32_t)ih, h)));
+                has[h] = 1;
+                for (unsigned j = 0; j < n_mats; j++) {
+                    std::vector<Ext> apow(W);
+                    Ext rrow = ext_zero(), cur = ext_one();
+                    for (size_t k = 0; k < W; k++) {
+                        apow[k] = cur;
+                        rrow = ext_add(rrow, ext_mul_base(cur, to_monty(rows[k])));
+                        cur = ext_mul(cur, alpha_f);
+                    }
+                    for (unsigned pt = 0; pt < n_pts; pt++) {
+                        Ext z = pt == 0 ? zeta : ext_mul_base(zeta, two_adic_generator(airs[a].log_height));
+                        Ext ry = ext_zero();
+                        for (size_t k = 0; k < W; k++) ry = ext_add(ry, ext_mul(apow[k], opened[oi + k]));
+                        Ext d = z;
+                        d.c[0] = msub(d.c[0], x);
+                        Ext u = ext_mul(ext_mul(ext_sub(ry, rrow), ext_inv(d)), ext_pow(alpha_f, num_reduced[h]));
+                        roq[h] = ext_add(roq[h], u);
+                        num_reduced[h] += W;
+                        oi += W;
+                    }
+                    rows += W;
+                }
+            }
+        }
+        Ext eval = roq[hmax];
+        for (unsigned l = 0; l < n_layers; l++) {
+            const unsigned log_len = hmax - l;
+            const size_t il = idx >> l, n_path = 8 * (size_t)(log_len - 1);
+            if (r + 4 + n_path > n_words) return ZKHIP_ERR_VERIFY;
+            const uint32_t *sib = proof + r, *path = proof + r + 4;
+            r += 4 + n_path;
+            std::vector<uint32_t> opening(8 + n_path);
+            for (int k = 0; k < 4; k++) {
+                opening[4 * (il & 1) + k] = from_monty(eval.c[k]);
+                opening[4 * ((il & 1) ^ 1) + k] = sib[k];
+            }
+            memcpy(opening.data() + 8, path, n_path * 4);
+            if (!verify_opening(&froots_m[8 * l], {log_len - 1}, {8}, il >> 1, opening.data())) return ZKHIP_ERR_VERIFY;
+            const Ext e0 = ext_from_canon(opening.data()), e1 = ext_from_canon(opening.data() + 4);
+            const uint32_t xx = mpow(two_adic_generator(log_len), bitrev32((uint32_t)(il >> 1), log_len - 1));
+            const uint32_t c = mneg(mmul(minv(xx), minv(to_monty(2))));
+            Ext bx = betas[l];
+            bx.c[0] = msub(bx.c[0], xx);
+            eval = ext_add(e0, ext_mul(bx, ext_mul_base(ext_sub(e1, e0), c)));
+            if (has[log_len - 1]) eval = ext_add(eval, ext_mul(ext_mul(betas[l], betas[l]), roq[log_len - 1]));
+        }
+        if (!ext_eq(eval, fin)) return ZKHIP_ERR_VERIFY;
+    }
+    if (r != n_words) return ZKHIP_ERR_VERIFY;
+    return ZKHIP_OK;
+}

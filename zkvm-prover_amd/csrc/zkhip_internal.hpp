@@ -83,6 +83,8 @@ int ntt_batch(zkhip_ctx* ctx, uint32_t* d_mat, unsigned log_n, size_t width, siz
 int lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* d_out, size_t out_stride,
               unsigned log_n, unsigned added_bits, size_t width, uint32_t shift_monty);
 int convert_repr(zkhip_ctx* ctx, uint32_t* d, size_t n, bool to_monty);
+int ntt_bitrev_copy(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint32_t* dst, size_t dst_stride,
+                    unsigned log_n, size_t width);
 
 // merkle.hip
 struct TreeLevelInject {
@@ -101,10 +103,15 @@ struct zkhip_tree {
     void* d_colptrs = nullptr;             // backing store of the column pointer tables
     bool owns_digests = true;
     size_t total_width = 0;
+    std::vector<size_t> level_off, level_cnt;  // per log-height: slice of the pointer table
+    size_t shifts_off = 0;                     // byte offset of the u32 shift table in d_colptrs
 };
 
 namespace zk {
 int merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip_tree** out);
+int merkle_plan(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, uint32_t* d_digests, zkhip_tree** out);
+int merkle_plan_leaves(zkhip_ctx* ctx, unsigned log_height, uint32_t* d_digests, zkhip_tree** out);
+int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready);
 size_t merkle_digest_count(unsigned log_height);
 // gathers openings for n leaf indices (device array of u32 indices) into a device buffer (canonical)
 int merkle_open_device(zkhip_ctx* ctx, const zkhip_tree* tree, const uint32_t* d_indices, unsigned index_shift,
