@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- chunk STARK proofs/sec on MI355X (BASELINE.json metric).
+
+A "step" is ONE full proof (trace commit -> LDE -> Merkle-Poseidon2 -> constraint/quotient ->
+FRI fold loop -> queries) of the synthetic chunk-shaped workload of SURVEY.md 8(d) cfg #4:
+a 2^22-row x 300-column degree-3 AIR (A) plus a 2^22 x 2 Fibonacci AIR (B), with the reference's
+parameters (crates/circuits/chunk-circuit/openvm.toml:1-6: blow-up 2, 100 queries, PoW 16+16).
+Traces are synthetic and already resident in HBM when the timed region starts.
+
+N GPUs = N independent proofs (segments shard one per GPU); after proving, the
+ranks all-gather their 32-byte trace commitments and rank 0 gathers the proof bytes over RCCL.
+
+Prints ONE JSON line (see the task contract) including `roofline` for the dominant kernel and
+`cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log-rows", type=int, default=22)
+    ap.add_argument("--width", type=int, default=300)
+    ap.add_argument("--cpu-sample-log-rows", type=int, default=15)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, sa_kwargs, params):
+    """Times the CPU oracle (OpenMP, all host cores) on a bounded sample: the same AIR set at
+    2^s rows, then scales by rows (the work is linear in rows up to the log factor of the NTT)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ora
+    from zkvm_prover_amd import air
+
+    s = args.cpu_sample_log_rows
+    sa = air.SyntheticAir(**sa_kwargs)
+    tr, pv = sa.gen_trace(s, seed=1)
+    fa = air.fibonacci_air()
+    ftr, fpv = air.fibonacci_trace(s)
+    airs = [dict(program=sa.program(), log_height=s, width=sa.width, n_pvs=len(pv), trace=tr, pvs=pv),
+            dict(program=fa.program(), log_height=s, width=2, n_pvs=3, trace=ftr, pvs=fpv)]
+    ora.lib()
+    t0 = time.time()
+    proof = ora.stark_prove(params, airs, cap_words=1 << 22)
+    dt = time.time() - t0
+    scale = float(1 << (args.log_rows - s))
+    cores = os.cpu_count() or 1
+    return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": cores, "kind": "port",
+            "sample": "oracle/ (C restatement, OpenMP x%d threads) proving the same AIR set at 2^%d rows in %.2f s, "
+                      "scaled x%d by rows to 2^%d; not the reference Rust binary (unbuildable here)"
+                      % (cores, s, dt, int(scale), args.log_rows)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import zkvm_prover_amd as z
+    from zkvm_prover_amd import air, shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    ctx = z.Context(dev.index)
+
+    params = z.DEFAULT_PARAMS
+    log_n, width = args.log_rows, args.width
+    sa_kwargs = dict(width=width, n_free=max(4, width // 5), n_bool=min(16, max(1, width // 20)),
+                     n_boundary=min(8, max(1, width // 40)), seed=0)
+    sa = air.SyntheticAir(**sa_kwargs)
+    fa = air.fibonacci_air()
+    # independent instance per rank (different witness seed), same AIR set / proving key shape
+    tr, pv = sa.gen_trace(log_n, seed=1000 + rank, xp="torch", device=dev)
+    d_trace = tr.reshape(-1).contiguous()
+    del tr
+    ctx._check(ctx.lib.zkhip_to_monty(ctx.h, d_trace.data_ptr(), d_trace.numel()))
+    ftr_np, fpv = air.fibonacci_trace(log_n, a0=rank, b0=1)
+    d_ftrace = ctx.upload(ftr_np.reshape(-1))
+    airs = [dict(program=sa.program(), log_height=log_n, width=width, n_pvs=len(pv)),
+            dict(program=fa.program(), log_height=log_n, width=2, n_pvs=3)]
+    pvs = [pv, fpv]
+    pk = z.ProvingKey(ctx, params, airs)
+    traces = [d_trace, d_ftrace]
+    torch.cuda.synchronize()
+
+    def step():
+        pk.prove_async(traces, pvs)
+
+    def exchange(proof_bytes):
+        # the one exchange step of the sharded path (zkvm-prover_amd/shard.py): 32-byte trace
+        # commitments to every rank, proofs to rank 0, over RCCL/xGMI
+        if world > 1:
+            shard.exchange(proof_bytes, device=dev)
+
+    for _ in range(args.warmup):
+        step()
+        exchange(pk.fetch())
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        step()
+        last = pk.fetch()  # waits for the proof and copies it to the host (part of the step)
+        exchange(last)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    ctx.profile_enable(False)
+    dt = t1 - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    stats = ctx.profile_read()
+
+    # every rank checks its own last proof with the host verifier (outside the timed region)
+    ok = z.verify(params, airs, pvs, last) == 0
+    if world > 1:
+        okt = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+
+    if rank == 0:
+        n, M = 1 << log_n, 1 << (log_n + 1)
+        # dominant kernel: Poseidon2 row sponge over the main LDE (+ the narrow quotient/FRI trees,
+        # which share the kernel name but are <1% of its time)
+        name = max(stats, key=lambda k: stats[k][1]) if stats else None
+        roof = None
+        if name:
+            launches, total_ms = stats[name]
+            per_step_ms = total_ms / args.steps
+            if name == "poseidon2_hash_rows":
+                # algorithmic bytes per proof: read every committed LDE cell once, write one digest per row
+                alg = 4 * M * (width + 2) + 32 * M + (4 * M * 16 + 32 * M)
+                note = "row sponge, main+quotient commits"
+            elif name.startswith("ntt_dif_pass"):
+                alg = 8 * M * (width + 2 + 16) // (2 if name.endswith("inv") else 1)
+                note = "one read + one write of the transformed matrices"
+            else:
+                alg = None
+                note = ""
+            if alg:
+                ach = alg / (per_step_ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "launches_per_step": launches / args.steps, "ms_per_step": round(per_step_ms, 3),
+                        "algorithmic_bytes_per_step": alg, "note": note}
+                if name == "poseidon2_hash_rows":
+                    perms = M * ((width + 7) // 8 + 1 + 2)
+                    roof["valu"] = {"perms_per_s": round(perms / (per_step_ms * 1e-3), 0),
+                                    "note": "kernel is integer-VALU bound (~600 Montgomery products per permutation)"}
+        out = {
+            "metric": "chunk STARK proofs/sec (2^%d-row trace)" % log_n,
+            "value": round(world * args.steps / dt, 4),
+            "unit": "proofs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "full STARK proof: 2^%d x %d degree-3 AIR + 2^%d x 2 Fibonacci AIR, blow-up 2, "
+                                   "%d queries, PoW %d+%d (SURVEY.md 8(d) cfg #4)"
+                                   % (log_n, width, log_n, params[2], params[3], params[4]),
+                       "proof_bytes": pk.proof_size, "verified": ok,
+                       "parallelism": "1 proof per GPU" + (", RCCL all-gather of commitments + proof gather" if world > 1 else "")},
+            "roofline": roof,
+            "stage_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, sa_kwargs, params)
+            except Exception as e:  # the baseline is a reported number, never a gate
+                out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

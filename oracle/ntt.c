@@ -76,6 +76,7 @@ void ora_dft_batch(uint32_t *mat, unsigned log_n, size_t width, size_t stride, i
     size_t n = (size_t)1 << log_n;
     uint32_t *tw = make_twiddles(log_n, inverse);
     uint32_t ninv = ora_inv((uint32_t)(n % ORA_P));
+#pragma omp parallel for schedule(dynamic) if (width > 1)
     for (size_t c = 0; c < width; c++) {
         uint32_t *col = mat + c * stride;
         dft_col(col, log_n, tw);
@@ -92,8 +93,9 @@ void ora_coset_lde_batch(const uint32_t *in, size_t in_stride, uint32_t *out, si
     unsigned log_m = log_n + added_bits;
     uint32_t *twi = make_twiddles(log_n, 1), *twf = make_twiddles(log_m, 0);
     uint32_t ninv = ora_inv((uint32_t)(n % ORA_P));
-    uint32_t *buf = (uint32_t *)malloc(m * sizeof(uint32_t));
+#pragma omp parallel for schedule(dynamic) if (width > 1)
     for (size_t c = 0; c < width; c++) {
+        uint32_t *buf = (uint32_t *)malloc(m * sizeof(uint32_t));
         memcpy(buf, in + c * in_stride, n * sizeof(uint32_t));
         dft_col(buf, log_n, twi);
         uint32_t sp = ninv;
@@ -108,8 +110,8 @@ void ora_coset_lde_batch(const uint32_t *in, size_t in_stride, uint32_t *out, si
             for (size_t r = 0; r < m; r++) o[r] = buf[bitrev(r, log_m)];
         else
             memcpy(o, buf, m * sizeof(uint32_t));
+        free(buf);
     }
-    free(buf);
     free(twi);
     free(twf);
 }
