@@ -44,7 +44,7 @@ def test_poseidon2_permutation_kat(zk, ora, kat):
 
 
 @pytest.mark.parametrize("log_n,width", [(0, 3), (1, 2), (3, 5), (8, 3), (10, 4), (11, 2), (12, 16), (13, 3),
-                                         (16, 2), (20, 1)])
+                                         (16, 2), (20, 1), (21, 2), (23, 1)])
 def test_ntt_forward_inverse(zk, ora, log_n, width):
     rng = np.random.default_rng(log_n * 100 + width)
     m = ora.rand_field(rng, (width, 1 << log_n))

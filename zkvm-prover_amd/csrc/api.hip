@@ -98,7 +98,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     profile_flush(ctx);
     if (ctx->d_tw_fwd) hipFree(ctx->d_tw_fwd);
     if (ctx->d_tw_inv) hipFree(ctx->d_tw_inv);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
         if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
     delete ctx;
 }

@@ -33,12 +33,20 @@ constexpr uint32_t GEN_2_27_CANON = 0x1a427a41u;  // generator of the 2^27 subgr
 constexpr uint32_t FIELD_GEN_CANON = 31u;          // multiplicative generator (canonical)
 
 // ---- raw Montgomery arithmetic on u32 ------------------------------------------------------
-// reduce x in [0, 2p) to [0, p)
+// reduce x in [0, 2p) to [0, p).  (For x in [p, 2^32) it returns x - p, so inputs slightly above
+// 2p come back slightly above p: the lazy S-box relies on that.)
 ZK_HD uint32_t red_2p(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_sub_co + v_cndmask are full-rate VOP2 (2.3 cycles each); v_min_u32 is half rate (4.1)
+    uint32_t y;
+    asm("v_subrev_co_u32 %0, vcc, %2, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "=&v"(y) : "v"(x), "i"(P) : "vcc");
+    return y;
+#else
     uint32_t y = x - P;
     return y < x ? y : x;  // unsigned min(x, x-p): if x < p, x-p wraps to a huge value
+#endif
 }
-// product in [0, 2p) given a*b < 2^32 * p  (always true for a,b < 2^32 with one of them < p)
+// product in [0, 2p) given a*b < 2.417 p^2  (a*b + 2^32 p must fit 64 bits)
 ZK_HD uint32_t mmul_lazy(uint32_t a, uint32_t b) {
     uint64_t t = (uint64_t)a * b;
     uint32_t m = (uint32_t)t * MONTY_NEG_MU;
@@ -48,9 +56,18 @@ ZK_HD uint32_t mmul_lazy(uint32_t a, uint32_t b) {
 ZK_HD uint32_t mmul(uint32_t a, uint32_t b) { return red_2p(mmul_lazy(a, b)); }
 ZK_HD uint32_t madd(uint32_t a, uint32_t b) { return red_2p(a + b); }
 ZK_HD uint32_t msub(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d, e;
+    asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_add_u32 %1, %4, %0\n\tv_cndmask_b32 %0, %0, %1, vcc"
+        : "=&v"(d), "=&v"(e)
+        : "v"(a), "v"(b), "i"(P)
+        : "vcc");
+    return d;
+#else
     uint32_t d = a - b;
     uint32_t e = d + P;
     return e < d ? e : d;  // if a < b, d wrapped (huge) and d+p wraps back to the small right value
+#endif
 }
 ZK_HD uint32_t mneg(uint32_t a) { return a == 0 ? 0 : P - a; }
 ZK_HD uint32_t to_monty(uint32_t canon) { return mmul(canon, MONTY_R2); }

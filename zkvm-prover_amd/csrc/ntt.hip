@@ -16,6 +16,8 @@
 //    hold coset shift * w_{2^(n+a)}^{bitrev_a(j)} * H in bit-reversed order.
 //  * Twiddles come from one table per direction (w^e, e < 2^(L-1)) kept resident in HBM /
 //    Infinity Cache; exponent arithmetic is shifts only.
+#include <string.h>
+
 #include <algorithm>
 
 #include "zkhip_internal.hpp"
@@ -142,6 +144,212 @@ __global__ __launch_bounds__(1024) void k_ntt_dif_pass(PassArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Four-step pass for transforms larger than one LDS tile (log_m >= 12).
+//
+// A size-M transform, M = R1*R2(*R3), is run as 2 (3) passes.  Pass p performs pure size-R_p DFTs
+// along one index digit with twiddles of w_{R_p} only (a 4 KiB table in LDS, shared by the 16
+// columns of a tile); the inter-digit twiddles w^(k*idx) are applied while the NEXT pass loads its
+// operands, where they form a geometric sequence along the 16 registers of a radix-16 unit (two
+// table look-ups + 15 products per 16 elements).  Each pass reads a tile of [R rows, strided] x
+// [16 contiguous words] (64-byte segments), keeps it in LDS as [row][17] (pad 1: both the row-wise
+// butterfly accesses and the column-wise write-out are bank-conflict free), runs radix-16 / radix-8
+// butterflies in registers (6 LDS touches per element instead of 4 per radix-2 stage) and writes
+// each of its 16 columns as one contiguous run of R words, in the layout the next pass wants
+// (digit-transposed), the last pass producing the standard bit-reversed order.
+struct Pass4Args {
+    const uint32_t* src;
+    uint32_t* dst;
+    size_t src_col_stride, dst_col_stride;
+    const uint32_t* tw;  // w^e, e < 2^(tw_log-1)
+    size_t in_x_stride, in_rs;
+    size_t out_x_stride, out_hi_stride, out_lo_stride;
+    unsigned log_sub, log_m, log_r, log_f, log_lo, tw_log;
+    // input twiddle: element (row r, column F, outer X) *= w_{2^log_tt}^(bitrev(F, log_prev) * (r*tw_a + X*tw_bx))
+    int in_tw;
+    unsigned log_prev, log_tt;
+    uint32_t tw_a, tw_bx;
+};
+
+template <int Q>
+__device__ __forceinline__ void dif_unit(uint32_t (&v)[16], const uint32_t* twl, unsigned j, unsigned log_rq,
+                                         unsigned tshift) {
+#pragma unroll
+    for (int t = 0; t < Q; t++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int half = 1 << (Q - 1 - t);
+#pragma unroll
+        for (int kl = 0; kl < half; kl++) {
+            const uint32_t w = twl[((j + ((unsigned)kl << log_rq)) << t) << tshift];
+#pragma unroll
+            for (int blk = 0; blk < (1 << t); blk++) {
+                const int ka = blk * 2 * half + kl, kb = ka + half;
+                const uint32_t x = v[ka], y = v[kb];
+                v[ka] = madd(x, y);
+                v[kb] = mmul(msub(x, y), w);
+            }
+        }
+    }
+}
+
+template <int Q>
+__device__ __forceinline__ void lds_round(uint32_t* lv, const uint32_t* twl, unsigned log_r, unsigned log_rcur,
+                                          unsigned tid, unsigned nt) {
+    const unsigned log_rq = log_rcur - Q;           // rows between the registers of a unit
+    const unsigned n_units = 1u << (log_r - Q + 4);  // (R >> Q) * 16 columns
+    for (unsigned u = tid; u < n_units; u += nt) {
+        const unsigned c = u & 15u, jj = u >> 4;
+        const unsigned j = jj & ((1u << log_rq) - 1u), blk = jj >> log_rq;
+        const unsigned row0 = (blk << log_rcur) + j;
+        uint32_t v[16];
+#pragma unroll
+        for (int k = 0; k < (1 << Q); k++) v[k] = lv[(row0 + ((unsigned)k << log_rq)) * 17 + c];
+        dif_unit<Q>(v, twl, j, log_rq, log_r - log_rcur);
+#pragma unroll
+        for (int k = 0; k < (1 << Q); k++) lv[(row0 + ((unsigned)k << log_rq)) * 17 + c] = v[k];
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
+    extern __shared__ uint32_t sm[];
+    const unsigned R = 1u << a.log_r;
+    uint32_t* lv = sm;
+    uint32_t* twl = sm + R * 17;
+    const unsigned tid = threadIdx.x, nt = blockDim.x;
+    for (unsigned e = tid; e < (R >> 1); e += nt) twl[e] = a.tw[(size_t)e << (a.tw_log - a.log_r)];
+    const unsigned col = blockIdx.y;
+    const unsigned sub = col & ((1u << a.log_sub) - 1u);
+    const size_t mcol = col >> a.log_sub;
+    const uint32_t* src = a.src + mcol * a.src_col_stride + ((size_t)sub << a.log_m);
+    uint32_t* dst = a.dst + mcol * a.dst_col_stride + ((size_t)sub << a.log_m);
+    const unsigned cg_bits = a.log_f - 4;
+    const unsigned X = blockIdx.x >> cg_bits, F0 = (blockIdx.x & ((1u << cg_bits) - 1u)) << 4;
+    const size_t in_base = (size_t)X * a.in_x_stride + F0;
+    __syncthreads();
+    // ---- round 1: radix-16 straight from HBM ----
+    {
+        const unsigned log_rq = a.log_r - 4;
+        for (unsigned u = tid; u < R; u += nt) {
+            const unsigned c = u & 15u, j = u >> 4;
+            uint32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = src[in_base + (size_t)(j + ((unsigned)k << log_rq)) * a.in_rs + c];
+            if (a.in_tw) {
+                const uint32_t mask = (a.log_tt >= 32) ? 0xffffffffu : ((1u << a.log_tt) - 1u);
+                const uint32_t kc = bitrev32(F0 + c, a.log_prev);
+                const uint32_t e0 = (kc * (j * a.tw_a + X * a.tw_bx)) & mask;
+                const uint32_t de = (kc * ((1u << log_rq) * a.tw_a)) & mask;
+                const unsigned sh = a.tw_log - a.log_tt;
+                const uint32_t half = 1u << (a.log_tt - 1);
+                uint32_t t = e0 < half ? a.tw[(size_t)e0 << sh] : mneg(a.tw[(size_t)(e0 - half) << sh]);
+                const uint32_t rho = de < half ? a.tw[(size_t)de << sh] : mneg(a.tw[(size_t)(de - half) << sh]);
+                v[0] = mmul(v[0], t);
+#pragma unroll
+                for (int k = 1; k < 16; k++) {
+                    t = mmul(t, rho);
+                    v[k] = mmul(v[k], t);
+                }
+            }
+            dif_unit<4>(v, twl, j, log_rq, 0);
+#pragma unroll
+            for (int k = 0; k < 16; k++) lv[(j + ((unsigned)k << log_rq)) * 17 + c] = v[k];
+        }
+    }
+    __syncthreads();
+    // ---- remaining stages out of LDS ----
+    unsigned log_rcur = a.log_r - 4;
+    while (log_rcur > 0) {
+        const unsigned q = log_rcur >= 4 ? 4 : log_rcur;
+        switch (q) {
+            case 4: lds_round<4>(lv, twl, a.log_r, log_rcur, tid, nt); break;
+            case 3: lds_round<3>(lv, twl, a.log_r, log_rcur, tid, nt); break;
+            case 2: lds_round<2>(lv, twl, a.log_r, log_rcur, tid, nt); break;
+            default: lds_round<1>(lv, twl, a.log_r, log_rcur, tid, nt); break;
+        }
+        log_rcur -= q;
+        __syncthreads();
+    }
+    // ---- write-out: each tile column is one contiguous run of R words ----
+    const unsigned lo_mask = (1u << a.log_lo) - 1u;
+    for (unsigned e = tid; e < (R << 4); e += nt) {
+        const unsigned c = e >> a.log_r, p = e & (R - 1u);
+        const unsigned F = F0 + c;
+        const size_t o = (size_t)X * a.out_x_stride + (size_t)(F >> a.log_lo) * a.out_hi_stride +
+                         (size_t)(F & lo_mask) * a.out_lo_stride + p;
+        dst[o] = lv[p * 17 + c];
+    }
+}
+
+static constexpr unsigned P4_MAX_LOG_R = 11;
+static constexpr unsigned P4_MIN_LOG_M = 12;
+
+// src -> dst through tmp (and tmp2 for 3-pass sizes); dst may alias src.  Buffers hold `width`
+// columns of 2^log_sub transforms each, with the given column strides.
+static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint32_t* dst, size_t dst_stride,
+                            uint32_t* tmp, uint32_t* tmp2, size_t tmp_stride, unsigned log_n, size_t width,
+                            unsigned log_sub, bool inverse) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              ((17u << P4_MAX_LOG_R) + (1u << (P4_MAX_LOG_R - 1))) * 4));
+        attr_set = true;
+    }
+    const unsigned n_pass = (log_n + P4_MAX_LOG_R - 1) / P4_MAX_LOG_R;
+    unsigned a[3] = {0, 0, 0};
+    for (unsigned p = 0; p < n_pass; p++) a[p] = log_n / n_pass + (p < log_n % n_pass ? 1 : 0);
+    const uint32_t* tw = inverse ? ctx->d_tw_inv : ctx->d_tw_fwd;
+    auto launch = [&](Pass4Args& pa, const uint32_t* s, size_t ss, uint32_t* d, size_t ds, unsigned n_x) -> int {
+        pa.src = s;
+        pa.src_col_stride = ss;
+        pa.dst = d;
+        pa.dst_col_stride = ds;
+        pa.tw = tw;
+        pa.tw_log = ctx->tw_log;
+        pa.log_sub = log_sub;
+        pa.log_m = log_n;
+        const unsigned R = 1u << pa.log_r;
+        const unsigned threads = std::min(1024u, std::max(64u, R));
+        const size_t lds = ((size_t)R * 17 + (R >> 1)) * 4;
+        dim3 grid(n_x << (pa.log_f - 4), (unsigned)(width << log_sub));
+        KernelScope ks(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd");
+        hipLaunchKernelGGL(k_ntt_pass4, grid, dim3(threads), lds, ctx->stream, pa);
+        ZK_HIP_CHECK(ctx, hipGetLastError());
+        return ZKHIP_OK;
+    };
+    Pass4Args pa;
+    memset(&pa, 0, sizeof pa);
+    if (n_pass == 2) {
+        const unsigned a1 = a[0], a2 = a[1];
+        // pass 1: digit d1 (rows), F = d2
+        pa.log_r = a1, pa.log_f = a2, pa.in_x_stride = 0, pa.in_rs = (size_t)1 << a2;
+        pa.out_x_stride = 0, pa.out_hi_stride = (size_t)1 << a1, pa.out_lo_stride = 0, pa.log_lo = 0, pa.in_tw = 0;
+        ZK_TRY(launch(pa, src, src_stride, tmp, tmp_stride, 1));
+        // pass 2: digit d2 (rows), F = p1; twiddle w_M^(k1 * d2)
+        pa.log_r = a2, pa.log_f = a1, pa.in_rs = (size_t)1 << a1, pa.out_hi_stride = (size_t)1 << a2;
+        pa.in_tw = 1, pa.log_prev = a1, pa.log_tt = log_n, pa.tw_a = 1, pa.tw_bx = 0;
+        ZK_TRY(launch(pa, tmp, tmp_stride, dst, dst_stride, 1));
+    } else {
+        const unsigned a1 = a[0], a2 = a[1], a3 = a[2];
+        // pass 1: rows d1, F = (d2,d3) flat; out (d3, d2, p1)
+        pa.log_r = a1, pa.log_f = a2 + a3, pa.in_x_stride = 0, pa.in_rs = (size_t)1 << (a2 + a3);
+        pa.out_x_stride = 0, pa.log_lo = a3, pa.out_lo_stride = (size_t)1 << (a1 + a2), pa.out_hi_stride = (size_t)1 << a1;
+        pa.in_tw = 0;
+        ZK_TRY(launch(pa, src, src_stride, tmp, tmp_stride, 1));
+        // pass 2: X = d3, rows d2, F = p1; twiddle w_M^(k1 * (d2*R3 + d3)); out (p1, d3, p2)
+        pa.log_r = a2, pa.log_f = a1, pa.in_x_stride = (size_t)1 << (a1 + a2), pa.in_rs = (size_t)1 << a1;
+        pa.out_x_stride = (size_t)1 << a2, pa.log_lo = 0, pa.out_lo_stride = 0, pa.out_hi_stride = (size_t)1 << (a2 + a3);
+        pa.in_tw = 1, pa.log_prev = a1, pa.log_tt = log_n, pa.tw_a = 1u << a3, pa.tw_bx = 1;
+        ZK_TRY(launch(pa, tmp, tmp_stride, tmp2, tmp_stride, 1u << a3));
+        // pass 3: X = p1, rows d3, F = p2; twiddle w_{R2R3}^(k2 * d3); out (p1, p2, q3)
+        pa.log_r = a3, pa.log_f = a2, pa.in_x_stride = (size_t)1 << (a2 + a3), pa.in_rs = (size_t)1 << a2;
+        pa.out_x_stride = (size_t)1 << (a2 + a3), pa.out_hi_stride = (size_t)1 << a3;
+        pa.in_tw = 1, pa.log_prev = a2, pa.log_tt = a2 + a3, pa.tw_a = 1, pa.tw_bx = 0;
+        ZK_TRY(launch(pa, tmp2, tmp_stride, dst, dst_stride, 1u << a1));
+    }
+    return ZKHIP_OK;
+}
+
 static constexpr unsigned MAX_LOG_R = 11;      // stages per pass
 static constexpr unsigned MAX_LOG_TILE = 15;   // 2^15 words = 128 KiB of LDS
 static constexpr unsigned MAX_LOG_C = 7;
@@ -150,6 +358,15 @@ int ntt_dif_inplace(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint
                     unsigned log_n, size_t width, unsigned log_sub, bool inverse) {
     if (width == 0) return ZKHIP_OK;
     ZK_TRY(ensure_twiddles(ctx, log_n));
+    if (log_n >= P4_MIN_LOG_M) {
+        const size_t per_col = (size_t)1 << (log_n + log_sub);
+        const bool three = log_n > 2 * P4_MAX_LOG_R;
+        void* tmp;
+        ZK_TRY(get_scratch(ctx, 4, per_col * width * 4 * (three ? 2 : 1), &tmp));
+        uint32_t* t1 = (uint32_t*)tmp;
+        uint32_t* t2 = three ? t1 + per_col * width : nullptr;
+        return ntt_dif_fourstep(ctx, src, src_stride, dst, dst_stride, t1, t2, per_col, log_n, width, log_sub, inverse);
+    }
     if (log_n == 0) {
         if (src != dst) {
             // height-1 columns: plain strided copy

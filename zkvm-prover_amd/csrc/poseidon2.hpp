@@ -31,11 +31,15 @@ struct Poseidon2Diag {
 ZK_HD uint32_t mdouble(uint32_t x) { return red_2p(x << 1); }
 ZK_HD uint32_t mhalve(uint32_t x) { return (x & 1u) ? ((x >> 1) + ((P + 1u) >> 1)) : (x >> 1); }
 
+// x^7 for x in [0,p).  Lazy Montgomery products keep intermediates in [0, 2.02p) -- bounds, with
+// c = p/2^32 = 0.46875: x2 < 1.469p, x3 < 1.689p, x4 < 2.012p -> one conditional subtraction ->
+// < 1.012p, x7 < 1.801p -> one conditional subtraction -> [0,p).  Every product a*b stays below
+// 2.417 p^2, the overflow limit of the 64-bit accumulate.
 ZK_HD uint32_t sbox7(uint32_t x) {
-    uint32_t x2 = mmul(x, x);
-    uint32_t x3 = mmul(x2, x);
-    uint32_t x4 = mmul(x2, x2);
-    return mmul(x3, x4);
+    uint32_t x2 = mmul_lazy(x, x);
+    uint32_t x3 = mmul_lazy(x2, x);
+    uint32_t x4 = red_2p(mmul_lazy(x2, x2));
+    return red_2p(mmul_lazy(x3, x4));
 }
 
 // M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] on each 4-block, then add column sums.

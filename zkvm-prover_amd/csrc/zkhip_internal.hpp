@@ -35,8 +35,8 @@ struct zkhip_ctx {
     uint32_t* d_tw_inv = nullptr;
     // grow-only scratch buffers (the pool never returns pages to the driver while the ctx lives,
     // like the VPMM pool it replaces -- AGENTS.md:136)
-    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    void* scratch[8] = {};
+    size_t scratch_bytes[8] = {};
     // profiling
     bool profiling = false;
     std::vector<zk::PendingEvent> pending;
