@@ -115,3 +115,16 @@ def test_keygen_rejects_bad_programs(zk):
     prog[0] = 7
     with pytest.raises(z.ZkhipError):
         z.ProvingKey(zk, (1, 0, 4, 1, 1), [dict(program=prog, log_height=3, width=2, n_pvs=3)])
+
+
+def test_jit_constraint_kernel_matches_interpreter_and_oracle(zk, ora, monkeypatch):
+    """The keygen-time hipRTC constraint kernel and the interpreter kernel give the same proof."""
+    params = (1, 0, 6, 3, 3)
+    airs = [_syn(8, 40, 10, 31), _fib(6)]
+    exp = ora.stark_prove(params, airs).tobytes()
+    monkeypatch.setenv("ZKHIP_FORCE_JIT", "1")
+    got_jit, _, _ = _prove_gpu(zk, params, airs)
+    monkeypatch.delenv("ZKHIP_FORCE_JIT")
+    monkeypatch.setenv("ZKHIP_NO_JIT", "1")
+    got_int, _, _ = _prove_gpu(zk, params, airs)
+    assert got_jit == exp and got_int == exp

@@ -15,12 +15,14 @@
 //    have fixed shape).  One D2H copy at the end.
 //  * Hot kernels are one-row-per-lane over column-major matrices (coalesced 256 B per wave per
 //    column); reductions over rows (openings) are two-stage and deterministic.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 
 #include "air_compile.hpp"
 #include "poseidon2.hpp"
+#include "quotient_jit.hpp"
 #include "transcript.hpp"
 #include "zkhip_internal.hpp"
 
@@ -384,6 +386,9 @@ struct AirPlan {
     uint32_t* d_qlde = nullptr;    // 2^b chunks x 4 columns x M
     uint32_t* d_apow_q = nullptr;  // n_cons ext
     size_t opened_main_off = 0, opened_quot_off = 0;  // in ext units inside d_opened
+    hipModule_t jit_mod = nullptr;   // keygen-compiled constraint kernel (null -> interpreter)
+    hipFunction_t jit_fn = nullptr;
+    uint32_t* d_jit_tab = nullptr;   // per-instance leaf parameters of the shape classes
 };
 
 struct zkhip_pk {
@@ -555,6 +560,20 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         }
         A.n_instr = (uint32_t)(comp[a].code.size() / 3);
         A.n_slots = comp[a].n_slots;
+        // keygen-time compiled constraint kernel (ZKHIP_NO_JIT=1 keeps the interpreter)
+        if (!getenv("ZKHIP_NO_JIT")) {
+            std::string msg;
+            std::vector<uint32_t> tab;
+            if (quot_jit_build(A.prog, airs[a].log_height, pk->b, &A.jit_mod, &A.jit_fn, &tab, &msg) &&
+                hipMalloc(&A.d_jit_tab, tab.size() * 4) == hipSuccess &&
+                hipMemcpy(A.d_jit_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) == hipSuccess) {
+            } else {
+                if (A.jit_mod) hipModuleUnload(A.jit_mod);
+                A.jit_mod = nullptr;
+                A.jit_fn = nullptr;
+                ctx->last_error = "constraint JIT unavailable, using the interpreter kernel: " + msg;
+            }
+        }
         ao[a].code = bp.take(comp[a].code.size() * 4 + 16);
         ao[a].consts = bp.take(comp[a].consts.size() * 4);
         ao[a].zh = bp.take(nch * 4);
@@ -669,6 +688,10 @@ void zkhip_pk_destroy(zkhip_ctx* ctx, zkhip_pk* pk) {
     if (pk->t_quot) zkhip_tree_destroy(ctx, pk->t_quot);
     for (auto* t : pk->t_fri)
         if (t) zkhip_tree_destroy(ctx, t);
+    for (auto& A : pk->airs) {
+        if (A.jit_mod) hipModuleUnload(A.jit_mod);
+        if (A.d_jit_tab) hipFree(A.d_jit_tab);
+    }
     if (pk->d_ws) hipFree(pk->d_ws);
     delete pk;
 }
@@ -746,7 +769,14 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         qa.lh = A.lh;
         qa.b = b;
         qa.tw_shift = ctx->tw_log - A.h;
-        {
+        if (A.jit_fn) {
+            KernelScope ks(ctx, "quotient_eval_jit");
+            void* params[] = {(void*)&qa.lde, (void*)&qa.q,      (void*)&qa.pvs,      (void*)&qa.apow,
+                              (void*)&qa.tw_fwd, (void*)&qa.zh,  (void*)&qa.inv_zh,   (void*)&A.d_jit_tab,
+                              (void*)&qa.gen, (void*)&qa.w_n_inv, (void*)&qa.tw_shift};
+            ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, (unsigned)((A.M + 255) / 256), 1, 1, 256, 1, 1, 0, st,
+                                                    params, nullptr));
+        } else {
             KernelScope ks(ctx, "quotient_eval");
             hipLaunchKernelGGL(k_quotient, dim3((unsigned)((A.M + QBS - 1) / QBS)), dim3(QBS),
                                (size_t)A.n_slots * QBS * 4, st, qa);

@@ -1,0 +1,267 @@
+// quotient_jit.hpp -- keygen-time code generation for the constraint kernel (K5).
+//
+// The reference's engines evaluate each chip's constraint DAG with a generic evaluator
+// (SURVEY.md 2.3 K5).  On MI355X the AIR set of a proving key is fixed, so at keygen the DAG is
+// emitted as straight-line HIP (one SSA value per interior node, trace cells / public values /
+// constants / selectors as direct operands) and compiled for gfx950 with hipRTC.  Compared with
+// the per-lane interpreter (k_quotient, kept as the fallback) this removes instruction fetch and
+// decode, keeps every intermediate in a VGPR instead of LDS, and lets the compiler schedule the
+// Montgomery products of independent constraints against each other.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <map>
+#include <sstream>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "air_compile.hpp"
+
+namespace zk {
+
+// Kernel parameters (all geometry that is fixed at keygen is baked into the source as constants):
+//   lde, q, pvs, apow, tw_fwd, zh, inv_zh (pointers), gen, w_n_inv, tw_shift (u32)
+struct QuotJitParams {
+    const uint32_t* lde;
+    uint32_t* q;
+    const uint32_t* pvs;
+    const uint32_t* apow;
+    const uint32_t* tw_fwd;
+    const uint32_t* zh;
+    const uint32_t* inv_zh;
+    uint32_t gen, w_n_inv, tw_shift;
+};
+
+inline const char* quot_jit_preamble() {
+    return R"JIT(
+typedef unsigned int uint32_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long size_t;
+#define P 0x78000001u
+#define NEG_MU 0x77ffffffu
+#define ONE 0x0ffffffeu
+// uniform read-only tables are read through the constant address space so they become scalar loads
+typedef const __attribute__((address_space(4))) uint32_t* cptr;
+__device__ __forceinline__ uint32_t red(uint32_t x) {
+    uint32_t y;
+    asm("v_subrev_co_u32 %0, vcc, %2, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "=&v"(y) : "v"(x), "i"(P) : "vcc");
+    return y;
+}
+__device__ __forceinline__ uint32_t mml(uint32_t a, uint32_t b) {
+    uint64_t t = (uint64_t)a * b;
+    uint32_t m = (uint32_t)t * NEG_MU;
+    uint64_t s = t + (uint64_t)m * P;
+    return (uint32_t)(s >> 32);
+}
+__device__ __forceinline__ uint32_t mmul(uint32_t a, uint32_t b) { return red(mml(a, b)); }
+__device__ __forceinline__ uint32_t madd(uint32_t a, uint32_t b) { return red(a + b); }
+__device__ __forceinline__ uint32_t msub(uint32_t a, uint32_t b) {
+    uint32_t d, e;
+    asm("v_sub_co_u32 %0, vcc, %2, %3\n\tv_add_u32 %1, %4, %0\n\tv_cndmask_b32 %0, %0, %1, vcc"
+        : "=&v"(d), "=&v"(e) : "v"(a), "v"(b), "i"(P) : "vcc");
+    return d;
+}
+__device__ __forceinline__ uint32_t mneg(uint32_t a) { return a == 0 ? 0 : P - a; }
+__device__ __forceinline__ uint32_t minv(uint32_t a) {
+    uint32_t r = ONE; uint32_t e = P - 2;
+    while (e) { if (e & 1) r = mmul(r, a); a = mmul(a, a); e >>= 1; }
+    return r;
+}
+typedef const __attribute__((address_space(1))) uint32_t* gptr;
+// trace cell (column c, this / next row): uniform column base (scalar) + 32-bit per-lane byte offset
+#define LD(c, off) (*(gptr)((const __attribute__((address_space(1))) char*)(ldep + (size_t)(c) * M) + (off)))
+#define PV(i) ((cptr)pvs)[i]
+#define ACC(k, v) { const uint32_t _v = (v); cptr ap = (cptr)apow + 4 * (k); \
+    acc0 = madd(acc0, mmul(ap[0], _v)); acc1 = madd(acc1, mmul(ap[1], _v)); \
+    acc2 = madd(acc2, mmul(ap[2], _v)); acc3 = madd(acc3, mmul(ap[3], _v)); }
+
+)JIT";
+}
+
+// ---- shape classes ----------------------------------------------------------------------------
+// Constraints of real AIRs repeat a handful of expression shapes (one per limb / per column / per
+// bus).  Each constraint is linearised as its own small DAG; constraints whose DAGs are equal up to
+// the identity of their leaves (which column, which constant, which public value) form a class.
+// The kernel has ONE loop per class: the body is straight-line code for the shape, the leaves come
+// from a parameter table read with scalar loads.  Code stays a few KB (instruction-cache resident,
+// unlike one straight-line stream for all constraints) and every trace cell of an instance is loaded
+// before the arithmetic starts.
+struct JitEntry {
+    uint32_t op;     // AirOp
+    uint32_t a, b;   // local indices for interior nodes; rot for VAR
+};
+struct JitClass {
+    std::vector<JitEntry> entries;           // local post-order DAG of the shape
+    std::vector<uint32_t> param_entry;       // entries that take a parameter (VAR col / CONST / PUB)
+    std::vector<std::vector<uint32_t>> inst; // per instance: [constraint index, params...]
+    size_t table_off = 0;                    // word offset of the class in the parameter table
+};
+
+inline bool quot_jit_classify(const AirProgram& p, std::vector<JitClass>* classes, std::string* msg) {
+    std::map<std::string, size_t> by_sig;
+    size_t expanded = 0;
+    for (uint32_t k = 0; k < p.n_cons; k++) {
+        std::vector<JitEntry> ent;
+        std::vector<uint32_t> params, param_entry;
+        std::map<uint32_t, uint32_t> local_of;  // global node -> local index
+        // iterative post-order
+        std::vector<std::pair<uint32_t, int>> stack{{p.cons[k], 0}};
+        while (!stack.empty()) {
+            auto [i, st] = stack.back();
+            stack.pop_back();
+            if (local_of.count(i)) continue;
+            const uint32_t op = p.nodes[3 * i], a = p.nodes[3 * i + 1], b = p.nodes[3 * i + 2];
+            if (op <= A_TRANS) {
+                local_of[i] = (uint32_t)ent.size();
+                ent.push_back({op, op == A_VAR ? b : 0u, 0u});
+                if (op == A_VAR || op == A_CONST || op == A_PUB) {
+                    param_entry.push_back((uint32_t)ent.size() - 1);
+                    params.push_back(op == A_CONST ? to_monty(a) : a);
+                }
+                continue;
+            }
+            if (st == 0) {
+                stack.push_back({i, 1});
+                if (op != A_NEG && !local_of.count(b)) stack.push_back({b, 0});
+                if (!local_of.count(a)) stack.push_back({a, 0});
+            } else {
+                local_of[i] = (uint32_t)ent.size();
+                ent.push_back({op, local_of[a], op != A_NEG ? local_of[b] : 0u});
+            }
+        }
+        expanded += ent.size();
+        std::string sig;
+        sig.reserve(ent.size() * 12);
+        for (const auto& e : ent) sig += std::to_string(e.op) + "," + std::to_string(e.a) + "," + std::to_string(e.b) + ";";
+        auto it = by_sig.find(sig);
+        if (it == by_sig.end()) {
+            it = by_sig.emplace(sig, classes->size()).first;
+            classes->push_back(JitClass());
+            classes->back().entries = ent;
+            classes->back().param_entry = param_entry;
+        }
+        std::vector<uint32_t> row{k};
+        row.insert(row.end(), params.begin(), params.end());
+        (*classes)[it->second].inst.push_back(row);
+    }
+    if (classes->size() > 96 || expanded > 16 * (size_t)p.n_nodes + 1024) {
+        *msg = "AIR does not compress into shape classes (" + std::to_string(classes->size()) + " classes)";
+        return false;
+    }
+    return true;
+}
+
+// Emits the kernel source and the parameter table.
+inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b, std::vector<JitClass>& classes,
+                                   std::vector<uint32_t>* table) {
+    (void)p;
+    std::ostringstream os;
+    os << quot_jit_preamble();
+    os << "#define H " << (lh + b) << "u\n#define B " << b << "u\n#define M ((size_t)1 << H)\n";
+    os << R"JIT(
+extern "C" __global__ __launch_bounds__(256) void quot_jit(const uint32_t* __restrict__ lde, uint32_t* __restrict__ q,
+        const uint32_t* __restrict__ pvs, const uint32_t* __restrict__ apow, const uint32_t* __restrict__ tw_fwd,
+        const uint32_t* __restrict__ zh_t, const uint32_t* __restrict__ inv_zh_t, const uint32_t* __restrict__ tab,
+        uint32_t gen, uint32_t w_n_inv, uint32_t tw_shift) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= (1u << H)) return;
+    const uint32_t i = __brev(r) >> (32 - H);
+    const uint32_t rn = __brev((i + (1u << B)) & ((1u << H) - 1u)) >> (32 - H);
+    const uint32_t halfm = 1u << (H - 1);
+    const uint32_t wi = i < halfm ? tw_fwd[(size_t)i << tw_shift] : mneg(tw_fwd[(size_t)(i - halfm) << tw_shift]);
+    const uint32_t x = mmul(gen, wi);
+    const uint32_t zh = zh_t[i & ((1u << B) - 1u)];
+    const uint32_t sel_first = mmul(zh, minv(msub(x, ONE)));
+    const uint32_t sel_trans = msub(x, w_n_inv);
+    const uint32_t sel_last = mmul(zh, minv(sel_trans));
+    uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    const uint32_t ro = r << 2, rno = rn << 2;
+    const gptr ldep = (gptr)lde;
+)JIT";
+    for (size_t c = 0; c < classes.size(); c++) {
+        JitClass& C = classes[c];
+        C.table_off = table->size();
+        const size_t stride = 1 + C.param_entry.size();
+        for (const auto& row : C.inst) table->insert(table->end(), row.begin(), row.end());
+        os << "    for (uint32_t it = 0; it < " << C.inst.size() << "u; it++) {\n";
+        os << "        cptr pr = (cptr)tab + " << C.table_off << "u + it * " << stride << "u;\n";
+        // parameters first (scalar), then the trace loads back to back, then the arithmetic
+        std::vector<int> pidx(C.entries.size(), -1);
+        for (size_t j = 0; j < C.param_entry.size(); j++) pidx[C.param_entry[j]] = (int)j + 1;
+        for (size_t e = 0; e < C.entries.size(); e++) {
+            const JitEntry& E = C.entries[e];
+            if (E.op == A_VAR)
+                os << "        const uint32_t e" << e << " = LD(pr[" << pidx[e] << "], " << (E.a ? "rno" : "ro") << ");\n";
+        }
+        for (size_t e = 0; e < C.entries.size(); e++) {
+            const JitEntry& E = C.entries[e];
+            switch (E.op) {
+                case A_VAR: break;
+                case A_PUB: os << "        const uint32_t e" << e << " = PV(pr[" << pidx[e] << "]);\n"; break;
+                case A_CONST: os << "        const uint32_t e" << e << " = pr[" << pidx[e] << "];\n"; break;
+                case A_FIRST: os << "        const uint32_t e" << e << " = sel_first;\n"; break;
+                case A_LAST: os << "        const uint32_t e" << e << " = sel_last;\n"; break;
+                case A_TRANS: os << "        const uint32_t e" << e << " = sel_trans;\n"; break;
+                case A_NEG: os << "        const uint32_t e" << e << " = mneg(e" << E.a << ");\n"; break;
+                default:
+                    os << "        const uint32_t e" << e << " = " << (E.op == A_ADD ? "madd" : E.op == A_SUB ? "msub" : "mmul")
+                       << "(e" << E.a << ", e" << E.b << ");\n";
+            }
+        }
+        os << "        ACC(pr[0], e" << (C.entries.size() - 1) << ")\n    }\n";
+    }
+    os << R"JIT(
+    const uint32_t izh = inv_zh_t[i & ((1u << B) - 1u)];
+    q[r] = mmul(acc0, izh);
+    q[M + r] = mmul(acc1, izh);
+    q[2 * M + r] = mmul(acc2, izh);
+    q[3 * M + r] = mmul(acc3, izh);
+}
+)JIT";
+    if (table->empty()) table->push_back(0);
+    return os.str();
+}
+
+// Compiles for gfx950 and loads the module.  Returns false (with a message) on any failure; the
+// caller then keeps the interpreter kernel.
+inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModule_t* mod, hipFunction_t* fn,
+                           std::vector<uint32_t>* table, std::string* msg) {
+    std::vector<JitClass> classes;
+    if (!quot_jit_classify(p, &classes, msg)) return false;
+    std::string src = quot_jit_source(p, lh, b, classes, table);
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "quot_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        *msg = "hiprtcCreateProgram failed";
+        return false;
+    }
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off"};
+    hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, 0);
+        if (ls) hiprtcGetProgramLog(prog, &log[0]);
+        *msg = "hiprtc compile failed: " + log.substr(0, 2000);
+        hiprtcDestroyProgram(&prog);
+        return false;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    if (hipModuleLoadData(mod, code.data()) != hipSuccess) {
+        *msg = "hipModuleLoadData failed";
+        return false;
+    }
+    if (hipModuleGetFunction(fn, *mod, "quot_jit") != hipSuccess) {
+        hipModuleUnload(*mod);
+        *msg = "hipModuleGetFunction failed";
+        return false;
+    }
+    return true;
+}
+
+}  // namespace zk
