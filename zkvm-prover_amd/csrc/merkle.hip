@@ -13,7 +13,7 @@
 // not HBM bound -- see DESIGN.md "Rooflines".
 #include <algorithm>
 
-#include "poseidon2.hpp"
+#include "poseidon2_coop.hpp"
 #include "zkhip_internal.hpp"
 
 namespace zk {
@@ -89,6 +89,35 @@ __global__ void k_permute_batch(uint32_t* states, size_t n) {
     poseidon2_permute(s);
 #pragma unroll
     for (int q = 0; q < 4; q++) p[q] = make_uint4(s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]);
+}
+
+// Top of a tree in ONE launch: from a layer of <= 512 nodes down to the root.  Each 16-lane row
+// computes one compression cooperatively (poseidon2_coop.hpp), the working layer lives in LDS,
+// every produced layer is also written to the tree's digest store for later openings.
+__global__ __launch_bounds__(1024) void k_compress_top(uint32_t* __restrict__ digests, unsigned lh, unsigned l0) {
+    __shared__ uint32_t buf[2][512 * 8];
+    const unsigned tid = threadIdx.x, lane = tid & 15u, grp = tid >> 4;  // 64 groups
+    auto layer_off = [&](unsigned l) -> size_t { return ((size_t)2 << lh) - ((size_t)2 << (lh - l)); };
+    unsigned n = 1u << (lh - l0);
+    for (unsigned e = tid; e < n * 8; e += 1024) buf[0][e] = digests[layer_off(l0) * 8 + e];
+    __syncthreads();
+    unsigned cur = 0;
+    for (unsigned l = l0 + 1; l <= lh; l++) {
+        const unsigned n_next = 1u << (lh - l);
+        uint32_t* out = digests + layer_off(l) * 8;
+        for (unsigned i = grp; i < ((n_next + 63u) & ~63u); i += 64) {
+            // all 16 lanes of a row stay active through the DPP permutation
+            const unsigned ii = i < n_next ? i : 0;
+            uint32_t x = buf[cur][16 * ii + lane];
+            x = coop_permute(x, lane);
+            if (i < n_next && lane < 8) {
+                buf[cur ^ 1][8 * i + lane] = x;
+                out[8 * i + lane] = x;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
 }
 
 int permute_batch(zkhip_ctx* ctx, uint32_t* d_states, size_t n) {
@@ -206,9 +235,18 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
         hipLaunchKernelGGL(k_hash_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                            d_ptrs + t->level_off[lh], (uint32_t)t->level_cnt[lh], n, t->d_digests);
     }
+    // levels at which no shorter matrix is injected, counted from the root
+    unsigned clean_top = 0;
+    while (clean_top < lh && t->level_cnt[clean_top] == 0) clean_top++;  // levels 0..clean_top-1 are plain
     for (unsigned l = 1; l <= lh; l++) {
         unsigned level = lh - l;
         size_t cnt = (size_t)1 << level;
+        if (cnt <= 256 && level < clean_top) {
+            // this and all remaining levels in one launch
+            KernelScope ks(ctx, "poseidon2_compress_top");
+            hipLaunchKernelGGL(k_compress_top, dim3(1), dim3(1024), 0, ctx->stream, t->d_digests, lh, l - 1);
+            break;
+        }
         KernelScope ks(ctx, "poseidon2_compress_layer");
         hipLaunchKernelGGL(k_compress_layer, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
                            t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,

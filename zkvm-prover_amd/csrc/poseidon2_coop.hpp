@@ -1,0 +1,68 @@
+// poseidon2_coop.hpp -- one Poseidon2 permutation spread over 16 lanes (lane i holds state word i).
+//
+// The proving path has strictly serial permutation chains (the Fiat-Shamir sponge, T4; the top
+// levels of every Merkle tree, K3) where one-state-per-lane leaves 63/64 of a wave idle and a
+// permutation costs ~20 us of dependent instructions.  Here the 16 S-boxes of an external round
+// run in parallel lanes and the linear layers use DPP cross-lane moves inside the 16-lane row
+// (quad_perm rotations for the 4x4 MDS block, row_ror for the column / full sums): ~8x shorter
+// dependent chain.  Same arithmetic as poseidon2.hpp (p3-poseidon2 layers, zkhash RC16).
+#pragma once
+#include "poseidon2.hpp"
+
+namespace zk {
+
+#if defined(__HIPCC__)
+__device__ const uint32_t POSEIDON2_RC_DEV[141] = {
+#include "poseidon2_rc.inc"
+};
+// diag V (Montgomery form), see poseidon2.hpp
+__device__ const uint32_t POSEIDON2_DIAG_DEV[16] = {
+    P - 0x1ffffffcu /* -2 */, 0x0ffffffeu /* 1 */, 0x1ffffffcu /* 2 */, 0x07ffffffu /* 1/2 */,
+    0x2ffffffau /* 3 */, 0x3ffffff8u /* 4 */, P - 0x07ffffffu /* -1/2 */, P - 0x2ffffffau /* -3 */,
+    P - 0x3ffffff8u /* -4 */, 1u << 24 /* 2^-8 */, 1u << 30 /* 1/4 */, 1u << 29 /* 1/8 */,
+    1u << 5 /* 2^-27 */, P - (1u << 24), P - (1u << 28) /* -1/16 */, P - (1u << 5)};
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+// rotate within each quad: lane q reads lane (q+k) mod 4
+#define ZK_QROT1 0x39
+#define ZK_QROT2 0x4E
+#define ZK_QROT3 0x93
+// rotate right by n within the 16-lane row: lane i reads lane (i - n) mod 16
+#define ZK_ROR(n) (0x120 + (n))
+
+__device__ __forceinline__ uint32_t coop_external_linear(uint32_t x) {
+    const uint32_t r1 = dpp<ZK_QROT1>(x), r2 = dpp<ZK_QROT2>(x), r3 = dpp<ZK_QROT3>(x);
+    const uint32_t t = madd(madd(x, r1), madd(r2, r3));
+    const uint32_t y = madd(madd(t, x), mdouble(r1));  // 2x_q + 3x_{q+1} + x_{q+2} + x_{q+3}
+    uint32_t s = madd(y, dpp<ZK_ROR(8)>(y));
+    s = madd(s, dpp<ZK_ROR(4)>(s));                    // sum over the four quads, same position
+    return madd(y, s);
+}
+__device__ __forceinline__ uint32_t coop_sum16(uint32_t x) {
+    uint32_t s = madd(x, dpp<ZK_ROR(8)>(x));
+    s = madd(s, dpp<ZK_ROR(4)>(s));
+    s = madd(s, dpp<ZK_ROR(2)>(s));
+    return madd(s, dpp<ZK_ROR(1)>(s));
+}
+// lane = index within the 16-lane row (0..15); all 16 lanes of the row must be active
+__device__ __forceinline__ uint32_t coop_permute(uint32_t x, unsigned lane) {
+    x = coop_external_linear(x);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7(madd(x, POSEIDON2_RC_DEV[r * 16 + lane])));
+    const uint32_t d = POSEIDON2_DIAG_DEV[lane];
+#pragma unroll 1
+    for (int r = 0; r < 13; r++) {
+        const uint32_t sb = sbox7(madd(x, POSEIDON2_RC_DEV[64 + r]));
+        x = lane == 0 ? sb : x;
+        x = madd(mmul(x, d), coop_sum16(x));
+    }
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7(madd(x, POSEIDON2_RC_DEV[77 + r * 16 + lane])));
+    return x;
+}
+#endif
+
+}  // namespace zk

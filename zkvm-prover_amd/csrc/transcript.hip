@@ -10,39 +10,53 @@
 // writing challenges where the next kernel reads them.  The prover therefore never
 // synchronises with the host between stages (the reference's CUDA engine round-trips each
 // commitment through the host transcript).
-#include "poseidon2.hpp"
+#include <algorithm>
+
+#include "poseidon2_coop.hpp"
 #include "transcript.hpp"
 #include "zkhip_internal.hpp"
 
 namespace zk {
 
-__device__ __forceinline__ void tr_duplex(DevTranscript* t) {
-    for (uint32_t i = 0; i < t->n_in; i++) t->state[i] = t->in_buf[i];
-    t->n_in = 0;
-    uint32_t s[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = t->state[i];
-    poseidon2_permute(s);
-#pragma unroll
-    for (int i = 0; i < 16; i++) t->state[i] = s[i];
-#pragma unroll
-    for (int i = 0; i < 8; i++) t->out_buf[i] = s[i];
-    t->n_out = 8;
+// All transcript kernels run one wave; lanes 0..15 hold the sponge state (poseidon2_coop.hpp).
+struct TrRegs {
+    uint32_t s;  // state word of this lane (lane < 16)
+    uint32_t n_in, n_out;
+};
+__device__ __forceinline__ TrRegs tr_load(const DevTranscript* t, unsigned lane) {
+    TrRegs r;
+    r.s = t->state[lane & 15u];
+    r.n_in = t->n_in;
+    r.n_out = t->n_out;
+    return r;
 }
-__device__ __forceinline__ void tr_observe1(DevTranscript* t, uint32_t v) {
-    t->n_out = 0;
-    t->in_buf[t->n_in++] = v;
-    if (t->n_in == 8) tr_duplex(t);
+__device__ __forceinline__ void tr_store(DevTranscript* t, const TrRegs& r, unsigned lane) {
+    if (lane < 16) t->state[lane] = r.s;
+    if (lane == 0) {
+        t->n_in = r.n_in;
+        t->n_out = r.n_out;
+    }
 }
-__device__ __forceinline__ uint32_t tr_sample1(DevTranscript* t) {
-    if (t->n_in != 0 || t->n_out == 0) tr_duplex(t);
-    return t->out_buf[--t->n_out];
+__device__ __forceinline__ void tr_duplex(TrRegs& r, unsigned lane) {
+    r.s = coop_permute(r.s, lane & 15u);
+    r.n_in = 0;
+    r.n_out = 8;
+}
+__device__ __forceinline__ void tr_observe1(TrRegs& r, unsigned lane, uint32_t v) {
+    r.n_out = 0;
+    if ((lane & 15u) == r.n_in) r.s = v;
+    r.n_in++;
+    if (r.n_in == 8) tr_duplex(r, lane);
+}
+__device__ __forceinline__ uint32_t tr_sample1(TrRegs& r, unsigned lane) {
+    if (r.n_in != 0 || r.n_out == 0) tr_duplex(r, lane);
+    r.n_out--;
+    return __shfl(r.s, (int)r.n_out, 64);
 }
 
 __global__ void k_tr_init(DevTranscript* t) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        for (int i = 0; i < 16; i++) t->state[i] = 0;
-        for (int i = 0; i < 8; i++) t->in_buf[i] = t->out_buf[i] = 0;
+    if (threadIdx.x < 16) t->state[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
         t->n_in = t->n_out = 0;
         t->pow_found = 0xffffffffu;
         t->pow_applied = 0;
@@ -51,73 +65,95 @@ __global__ void k_tr_init(DevTranscript* t) {
 }
 
 // src_canonical != 0: src holds canonical words (converted on the fly)
-__global__ void k_tr_observe(DevTranscript* t, const uint32_t* src, uint32_t n, int src_canonical) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (uint32_t i = 0; i < n; i++) tr_observe1(t, src_canonical ? to_monty(src[i]) : src[i]);
+__global__ __launch_bounds__(64) void k_tr_observe(DevTranscript* t, const uint32_t* src, uint32_t n, int src_canonical) {
+    const unsigned lane = threadIdx.x;
+    TrRegs r = tr_load(t, lane);
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t v = src[i];
+        tr_observe1(r, lane, src_canonical ? to_monty(v) : v);
+    }
+    tr_store(t, r, lane);
 }
 
 // dst_monty: optional Montgomery output; dst_canon: optional canonical output (e.g. the proof)
-__global__ void k_tr_sample(DevTranscript* t, uint32_t* dst_monty, uint32_t* dst_canon, uint32_t n) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void k_tr_sample(DevTranscript* t, uint32_t* dst_monty, uint32_t* dst_canon, uint32_t n) {
+    const unsigned lane = threadIdx.x;
+    TrRegs r = tr_load(t, lane);
     for (uint32_t i = 0; i < n; i++) {
-        uint32_t v = tr_sample1(t);
-        if (dst_monty) dst_monty[i] = v;
-        if (dst_canon) dst_canon[i] = from_monty(v);
+        uint32_t v = tr_sample1(r, lane);
+        if (lane == 0) {
+            if (dst_monty) dst_monty[i] = v;
+            if (dst_canon) dst_canon[i] = from_monty(v);
+        }
+    }
+    tr_store(t, r, lane);
+}
+
+__global__ __launch_bounds__(64) void k_tr_sample_bits(DevTranscript* t, uint32_t* dst, uint32_t n, unsigned bits) {
+    const unsigned lane = threadIdx.x;
+    TrRegs r = tr_load(t, lane);
+    uint32_t mask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t v = from_monty(tr_sample1(r, lane)) & mask;
+        if (lane == 0) dst[i] = v;
+    }
+    tr_store(t, r, lane);
+}
+
+// Proof-of-work search, one launch: every lane tests candidates base + gid, base advancing by the
+// grid size.  observe(w); sample_bits(bits) costs exactly one permutation whichever branch of the
+// duplex logic is taken.  A block leaves once a witness below its next candidate window is known;
+// since every block scans its candidates in increasing order, the atomicMin result is the global
+// minimum (= the first witness a sequential scan finds).
+__global__ __launch_bounds__(256) void k_grind(DevTranscript* t, unsigned bits, uint32_t limit) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t s0[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s0[i] = t->state[i];
+    const uint32_t n_in = t->n_in;
+    for (uint32_t base = 0; base < limit; base += stride) {
+        // volatile read: other blocks publish with atomicMin (device scope)
+        const uint32_t found = __hip_atomic_load(&t->pow_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (found < base) return;
+        const uint32_t w = base + gid;
+        if (w >= limit || w < base) continue;
+        uint32_t s[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = s0[i];
+        const uint32_t wm = to_monty(w);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if ((uint32_t)i == n_in) s[i] = wm;
+        poseidon2_permute(s);
+        if ((from_monty(s[7]) & mask) == 0) atomicMin(&t->pow_found, w);
     }
 }
 
-__global__ void k_tr_sample_bits(DevTranscript* t, uint32_t* dst, uint32_t n, unsigned bits) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t mask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
-    for (uint32_t i = 0; i < n; i++) dst[i] = from_monty(tr_sample1(t)) & mask;
-}
-
-// Each lane tests one candidate witness: observe(w) then sample_bits(bits) costs exactly one
-// permutation whichever branch of the duplex logic is taken.
-__global__ __launch_bounds__(256) void k_grind_window(DevTranscript* t, unsigned bits, uint32_t base,
-                                                      uint32_t count) {
-    if (t->pow_applied) return;  // an earlier window already succeeded (set between windows only)
-    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= count) return;
-    uint32_t w = base + gid;
-    if (w >= P) return;
-    uint32_t s[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = t->state[i];
-    uint32_t n_in = t->n_in;
-    // pending inputs overwrite the front of the state, then the witness
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        if ((uint32_t)i < n_in) s[i] = t->in_buf[i];
-    uint32_t wm = to_monty(w);
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        if ((uint32_t)i == n_in) s[i] = wm;
-    poseidon2_permute(s);
-    uint32_t mask = (1u << bits) - 1u;
-    if ((from_monty(s[7]) & mask) == 0) atomicMin(&t->pow_found, w);
-}
-
-// Applies the found witness to the live transcript, stores it (canonical) and re-arms the search.
-__global__ void k_grind_finish(DevTranscript* t, unsigned bits, uint32_t* witness_out, int last_window) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t w = t->pow_found;
+// Applies the found witness to the live transcript and stores it (canonical).
+__global__ __launch_bounds__(64) void k_grind_finish(DevTranscript* t, unsigned bits, uint32_t* witness_out) {
+    const unsigned lane = threadIdx.x;
+    const uint32_t w = t->pow_found;
     if (w == 0xffffffffu) {
-        if (last_window) t->error |= 1u;
+        if (lane == 0) t->error |= 1u;
         return;
     }
-    if (t->pow_applied) return;
-    tr_observe1(t, to_monty(w));
-    uint32_t mask = (1u << bits) - 1u;
-    uint32_t v = from_monty(tr_sample1(t)) & mask;
-    if (v != 0) t->error |= 2u;
-    if (witness_out) *witness_out = w;
-    t->pow_applied = 1;
+    TrRegs r = tr_load(t, lane);
+    tr_observe1(r, lane, to_monty(w));
+    const uint32_t mask = bits ? ((1u << bits) - 1u) : 0u;
+    const uint32_t v = from_monty(tr_sample1(r, lane)) & mask;
+    tr_store(t, r, lane);
+    if (lane == 0) {
+        if (v != 0) t->error |= 2u;
+        if (witness_out) *witness_out = w;
+        t->pow_applied = 1;
+    }
 }
 
-__global__ void k_grind_arm(DevTranscript* t) {
+__global__ void k_grind_arm(DevTranscript* t, uint32_t init) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        t->pow_found = 0xffffffffu;
+        t->pow_found = init;
         t->pow_applied = 0;
     }
 }
@@ -150,35 +186,18 @@ int transcript_sample_bits(zkhip_ctx* ctx, DevTranscript* d_t, uint32_t* d_dst, 
     return ZKHIP_OK;
 }
 
-// Windows of increasing size; a window is a no-op once an earlier one found a witness, so the
-// expected cost is ~2^bits permutations while the sequence never needs the host.
+// One search launch + one finish launch per grind; never needs the host.
 int transcript_grind(zkhip_ctx* ctx, DevTranscript* d_t, unsigned bits, uint32_t* d_witness_out) {
     if (bits > 30) return set_error(ctx, ZKHIP_ERR_INVALID, "pow bits > 30");
     KernelScope ks(ctx, "pow_grind");
-    hipLaunchKernelGGL(k_grind_arm, dim3(1), dim3(64), 0, ctx->stream, d_t);
-    if (bits == 0) {
-        // p3 semantics: grind(0) still observes witness 0 and samples
-        hipLaunchKernelGGL(k_grind_window, dim3(1), dim3(64), 0, ctx->stream, d_t, 0u, 0u, 1u);
-        hipLaunchKernelGGL(k_grind_finish, dim3(1), dim3(64), 0, ctx->stream, d_t, 0u, d_witness_out, 1);
-        ZK_HIP_CHECK(ctx, hipGetLastError());
-        return ZKHIP_OK;
+    // p3 semantics: grind(0) observes witness 0 and samples
+    hipLaunchKernelGGL(k_grind_arm, dim3(1), dim3(64), 0, ctx->stream, d_t, bits == 0 ? 0u : 0xffffffffu);
+    if (bits != 0) {
+        // first sweep covers ~2^(bits+1) candidates when the whole grid is resident
+        unsigned blocks = std::min(4096u, std::max(64u, (2u << bits) / 256u));
+        hipLaunchKernelGGL(k_grind, dim3(blocks), dim3(256), 0, ctx->stream, d_t, bits, (uint32_t)P);
     }
-    uint64_t base = 0;
-    uint64_t window = (uint64_t)1 << (bits + 1);
-    const uint64_t limit = P;
-    int rounds = 0;
-    while (base < limit) {
-        uint64_t cnt = std::min<uint64_t>(window, limit - base);
-        bool last = (base + cnt >= limit) || rounds >= 7;
-        hipLaunchKernelGGL(k_grind_window, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, d_t,
-                           bits, (uint32_t)base, (uint32_t)cnt);
-        hipLaunchKernelGGL(k_grind_finish, dim3(1), dim3(64), 0, ctx->stream, d_t, bits, d_witness_out,
-                           last ? 1 : 0);
-        if (last) break;
-        base += cnt;
-        window <<= 1;
-        rounds++;
-    }
+    hipLaunchKernelGGL(k_grind_finish, dim3(1), dim3(64), 0, ctx->stream, d_t, bits, d_witness_out);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
 }

@@ -7,11 +7,11 @@ struct zkhip_ctx;
 namespace zk {
 
 // Lives in HBM; mutated only by single-lane kernels on the prover's stream.
+// Pending inputs are written straight into the front of `state` (nothing reads the state between
+// an observe and the next duplexing), and the output buffer is state[0..8] itself.
 struct DevTranscript {
     uint32_t state[16];
-    uint32_t in_buf[8];
     uint32_t n_in;
-    uint32_t out_buf[8];
     uint32_t n_out;
     uint32_t pow_found;    // smallest satisfying witness of the current grind, or 0xffffffff
     uint32_t pow_applied;  // set once the witness has been absorbed
