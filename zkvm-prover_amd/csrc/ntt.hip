@@ -16,6 +16,7 @@
 //    hold coset shift * w_{2^(n+a)}^{bitrev_a(j)} * H in bit-reversed order.
 //  * Twiddles come from one table per direction (w^e, e < 2^(L-1)) kept resident in HBM /
 //    Infinity Cache; exponent arithmetic is shifts only.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -164,7 +165,7 @@ struct Pass4Args {
     const uint32_t* tw;  // w^e, e < 2^(tw_log-1)
     size_t in_x_stride, in_rs;
     size_t out_x_stride, out_hi_stride, out_lo_stride;
-    unsigned log_sub, log_m, log_r, log_f, log_lo, tw_log;
+    unsigned log_sub, log_m, log_r, log_f, log_lo, tw_log, log_c;
     // input twiddle: element (row r, column F, outer X) *= w_{2^log_tt}^(bitrev(F, log_prev) * (r*tw_a + X*tw_bx))
     int in_tw;
     unsigned log_prev, log_tt;
@@ -195,27 +196,29 @@ __device__ __forceinline__ void dif_unit(uint32_t (&v)[16], const uint32_t* twl,
 
 template <int Q>
 __device__ __forceinline__ void lds_round(uint32_t* lv, const uint32_t* twl, unsigned log_r, unsigned log_rcur,
-                                          unsigned tid, unsigned nt) {
-    const unsigned log_rq = log_rcur - Q;           // rows between the registers of a unit
-    const unsigned n_units = 1u << (log_r - Q + 4);  // (R >> Q) * 16 columns
+                                          unsigned log_c, unsigned tid, unsigned nt) {
+    const unsigned log_rq = log_rcur - Q;               // rows between the registers of a unit
+    const unsigned n_units = 1u << (log_r - Q + log_c);  // (R >> Q) * C columns
+    const unsigned cmask = (1u << log_c) - 1u, pitch = (1u << log_c) + 1u;
     for (unsigned u = tid; u < n_units; u += nt) {
-        const unsigned c = u & 15u, jj = u >> 4;
+        const unsigned c = u & cmask, jj = u >> log_c;
         const unsigned j = jj & ((1u << log_rq) - 1u), blk = jj >> log_rq;
         const unsigned row0 = (blk << log_rcur) + j;
         uint32_t v[16];
 #pragma unroll
-        for (int k = 0; k < (1 << Q); k++) v[k] = lv[(row0 + ((unsigned)k << log_rq)) * 17 + c];
+        for (int k = 0; k < (1 << Q); k++) v[k] = lv[(row0 + ((unsigned)k << log_rq)) * pitch + c];
         dif_unit<Q>(v, twl, j, log_rq, log_r - log_rcur);
 #pragma unroll
-        for (int k = 0; k < (1 << Q); k++) lv[(row0 + ((unsigned)k << log_rq)) * 17 + c] = v[k];
+        for (int k = 0; k < (1 << Q); k++) lv[(row0 + ((unsigned)k << log_rq)) * pitch + c] = v[k];
     }
 }
 
 __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
     extern __shared__ uint32_t sm[];
     const unsigned R = 1u << a.log_r;
+    const unsigned log_c = a.log_c, C = 1u << log_c, cmask = C - 1u, pitch = C + 1u;
     uint32_t* lv = sm;
-    uint32_t* twl = sm + R * 17;
+    uint32_t* twl = sm + R * pitch;
     const unsigned tid = threadIdx.x, nt = blockDim.x;
     for (unsigned e = tid; e < (R >> 1); e += nt) twl[e] = a.tw[(size_t)e << (a.tw_log - a.log_r)];
     const unsigned col = blockIdx.y;
@@ -223,15 +226,22 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
     const size_t mcol = col >> a.log_sub;
     const uint32_t* src = a.src + mcol * a.src_col_stride + ((size_t)sub << a.log_m);
     uint32_t* dst = a.dst + mcol * a.dst_col_stride + ((size_t)sub << a.log_m);
-    const unsigned cg_bits = a.log_f - 4;
-    const unsigned X = blockIdx.x >> cg_bits, F0 = (blockIdx.x & ((1u << cg_bits) - 1u)) << 4;
+    // tile index; with 8-column tiles the two halves of a 64-byte segment group are given to
+    // workgroups b and b+8, which the dispatcher places on the same XCD (shared L2) -- speed only
+    unsigned tile = blockIdx.x;
+    if (log_c == 3 && (gridDim.x & 15u) == 0) {
+        const unsigned within = tile & 15u;
+        tile = ((((tile >> 4) << 3) + (within & 7u)) << 1) | (within >> 3);
+    }
+    const unsigned cg_bits = a.log_f - log_c;
+    const unsigned X = tile >> cg_bits, F0 = (tile & ((1u << cg_bits) - 1u)) << log_c;
     const size_t in_base = (size_t)X * a.in_x_stride + F0;
     __syncthreads();
     // ---- round 1: radix-16 straight from HBM ----
     {
         const unsigned log_rq = a.log_r - 4;
-        for (unsigned u = tid; u < R; u += nt) {
-            const unsigned c = u & 15u, j = u >> 4;
+        for (unsigned u = tid; u < (R >> 4) * C; u += nt) {
+            const unsigned c = u & cmask, j = u >> log_c;
             uint32_t v[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = src[in_base + (size_t)(j + ((unsigned)k << log_rq)) * a.in_rs + c];
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
             }
             dif_unit<4>(v, twl, j, log_rq, 0);
 #pragma unroll
-            for (int k = 0; k < 16; k++) lv[(j + ((unsigned)k << log_rq)) * 17 + c] = v[k];
+            for (int k = 0; k < 16; k++) lv[(j + ((unsigned)k << log_rq)) * pitch + c] = v[k];
         }
     }
     __syncthreads();
@@ -262,27 +272,38 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
     while (log_rcur > 0) {
         const unsigned q = log_rcur >= 4 ? 4 : log_rcur;
         switch (q) {
-            case 4: lds_round<4>(lv, twl, a.log_r, log_rcur, tid, nt); break;
-            case 3: lds_round<3>(lv, twl, a.log_r, log_rcur, tid, nt); break;
-            case 2: lds_round<2>(lv, twl, a.log_r, log_rcur, tid, nt); break;
-            default: lds_round<1>(lv, twl, a.log_r, log_rcur, tid, nt); break;
+            case 4: lds_round<4>(lv, twl, a.log_r, log_rcur, log_c, tid, nt); break;
+            case 3: lds_round<3>(lv, twl, a.log_r, log_rcur, log_c, tid, nt); break;
+            case 2: lds_round<2>(lv, twl, a.log_r, log_rcur, log_c, tid, nt); break;
+            default: lds_round<1>(lv, twl, a.log_r, log_rcur, log_c, tid, nt); break;
         }
         log_rcur -= q;
         __syncthreads();
     }
     // ---- write-out: each tile column is one contiguous run of R words ----
     const unsigned lo_mask = (1u << a.log_lo) - 1u;
-    for (unsigned e = tid; e < (R << 4); e += nt) {
+    for (unsigned e = tid; e < (R << log_c); e += nt) {
         const unsigned c = e >> a.log_r, p = e & (R - 1u);
         const unsigned F = F0 + c;
         const size_t o = (size_t)X * a.out_x_stride + (size_t)(F >> a.log_lo) * a.out_hi_stride +
                          (size_t)(F & lo_mask) * a.out_lo_stride + p;
-        dst[o] = lv[p * 17 + c];
+        dst[o] = lv[p * pitch + c];
     }
 }
 
 static constexpr unsigned P4_MAX_LOG_R = 11;
 static constexpr unsigned P4_MIN_LOG_M = 12;
+// stages per pass: 11 = two passes up to 2^22 (128 KiB tiles, one workgroup per CU);
+// smaller values trade a third pass for small tiles and full occupancy.  Tunable for experiments.
+static unsigned p4_log_r_limit() {
+    static unsigned v = 0;
+    if (!v) {
+        const char* e = getenv("ZKHIP_NTT_MAX_LOG_R");
+        v = e ? (unsigned)atoi(e) : P4_MAX_LOG_R;
+        if (v < 6 || v > P4_MAX_LOG_R) v = P4_MAX_LOG_R;
+    }
+    return v;
+}
 
 // src -> dst through tmp (and tmp2 for 3-pass sizes); dst may alias src.  Buffers hold `width`
 // columns of 2^log_sub transforms each, with the given column strides.
@@ -295,7 +316,7 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
                                               ((17u << P4_MAX_LOG_R) + (1u << (P4_MAX_LOG_R - 1))) * 4));
         attr_set = true;
     }
-    const unsigned n_pass = (log_n + P4_MAX_LOG_R - 1) / P4_MAX_LOG_R;
+    const unsigned n_pass = std::max(2u, (log_n + p4_log_r_limit() - 1) / p4_log_r_limit());
     unsigned a[3] = {0, 0, 0};
     for (unsigned p = 0; p < n_pass; p++) a[p] = log_n / n_pass + (p < log_n % n_pass ? 1 : 0);
     const uint32_t* tw = inverse ? ctx->d_tw_inv : ctx->d_tw_fwd;
@@ -309,9 +330,21 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         pa.log_sub = log_sub;
         pa.log_m = log_n;
         const unsigned R = 1u << pa.log_r;
-        const unsigned threads = std::min(1024u, std::max(64u, R));
-        const size_t lds = ((size_t)R * 17 + (R >> 1)) * 4;
-        dim3 grid(n_x << (pa.log_f - 4), (unsigned)(width << log_sub));
+        // 2^11-row tiles take 8 columns (70 KiB of LDS, two workgroups per CU so one loads while the
+        // other computes: measured 20 % faster than one 139 KiB / 16-column workgroup per CU);
+        // shorter tiles keep 16 columns (64-byte segments).  ZKHIP_NTT_LOG_C overrides.
+        static int log_c_env = -1;
+        if (log_c_env < 0) {
+            const char* e = getenv("ZKHIP_NTT_LOG_C");
+            log_c_env = e ? atoi(e) : 0;
+            if (log_c_env != 3 && log_c_env != 4) log_c_env = 0;
+        }
+        pa.log_c = log_c_env ? (unsigned)log_c_env : (pa.log_r >= 11 ? 3u : 4u);
+        if (pa.log_c > pa.log_f) pa.log_c = pa.log_f;
+        const unsigned C = 1u << pa.log_c;
+        const unsigned threads = std::min(1024u, std::max(64u, (R >> 4) * C));
+        const size_t lds = ((size_t)R * (C + 1) + (R >> 1)) * 4;
+        dim3 grid(n_x << (pa.log_f - pa.log_c), (unsigned)(width << log_sub));
         KernelScope ks(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd");
         hipLaunchKernelGGL(k_ntt_pass4, grid, dim3(threads), lds, ctx->stream, pa);
         ZK_HIP_CHECK(ctx, hipGetLastError());
@@ -360,7 +393,7 @@ int ntt_dif_inplace(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint
     ZK_TRY(ensure_twiddles(ctx, log_n));
     if (log_n >= P4_MIN_LOG_M) {
         const size_t per_col = (size_t)1 << (log_n + log_sub);
-        const bool three = log_n > 2 * P4_MAX_LOG_R;
+        const bool three = log_n > 2 * p4_log_r_limit();
         void* tmp;
         ZK_TRY(get_scratch(ctx, 4, per_col * width * 4 * (three ? 2 : 1), &tmp));
         uint32_t* t1 = (uint32_t*)tmp;

@@ -165,41 +165,55 @@ __global__ __launch_bounds__(256) void k_bary_weights(const uint32_t* pts, unsig
     }
 }
 
-// partial[tile][col][pt] = sum over the tile's rows of col[r] * w[pt][r].  Rows per tile = 256*RK.
+// partial[tile][col][pt] = sum over the tile's rows of col[r] * w[pt][r].  One tile = one WAVE =
+// 64*RK rows (lane = row, RK rows per lane, their weights held in registers); per column the lane
+// sums are combined with DPP/shuffle adds and lane 0 stores the wave's partial.  No LDS, no
+// barriers, so the loads of the next column are in flight while the current one is multiplied.
 template <int NPTS, int RK>
-__global__ __launch_bounds__(256) void k_col_reduce(const uint32_t* cols, size_t stride, uint32_t n_cols,
-                                                    unsigned lh, const uint32_t* weights, uint32_t* partial) {
-    __shared__ uint32_t red[4][NPTS * 4];
+__global__ __launch_bounds__(256) void k_col_reduce(const uint32_t* __restrict__ cols, size_t stride, uint32_t n_cols,
+                                                    unsigned lh, const uint32_t* __restrict__ weights,
+                                                    uint32_t* __restrict__ partial) {
     const size_t N = (size_t)1 << lh;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const size_t row0 = (size_t)blockIdx.x * 256 * RK + tid;
+    const unsigned lane = threadIdx.x & 63u;
+    const size_t tile = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t row0 = tile * 64 * RK + lane;
+    if (tile * 64 * RK >= N) return;
     uint32_t w[RK][NPTS][4];
 #pragma unroll
     for (int k = 0; k < RK; k++) {
-        size_t r = row0 + (size_t)k * 256;
+        size_t r = row0 + (size_t)k * 64;
 #pragma unroll
         for (int p = 0; p < NPTS; p++) {
             uint4 v = r < N ? reinterpret_cast<const uint4*>(weights)[(size_t)p * N + r] : make_uint4(0, 0, 0, 0);
             w[k][p][0] = v.x, w[k][p][1] = v.y, w[k][p][2] = v.z, w[k][p][3] = v.w;
         }
     }
+    uint32_t x[RK], xn[RK];
+#pragma unroll
+    for (int k = 0; k < RK; k++) {
+        size_t r = row0 + (size_t)k * 64;
+        x[k] = r < N ? cols[r] : 0u;
+    }
     for (uint32_t c = 0; c < n_cols; c++) {
-        const uint32_t* col = cols + (size_t)c * stride;
+        if (c + 1 < n_cols) {
+            const uint32_t* col = cols + (size_t)(c + 1) * stride;
+#pragma unroll
+            for (int k = 0; k < RK; k++) {
+                size_t r = row0 + (size_t)k * 64;
+                xn[k] = r < N ? col[r] : 0u;
+            }
+        }
         uint32_t acc[NPTS][4];
 #pragma unroll
         for (int p = 0; p < NPTS; p++)
 #pragma unroll
             for (int q = 0; q < 4; q++) acc[p][q] = 0;
 #pragma unroll
-        for (int k = 0; k < RK; k++) {
-            size_t r = row0 + (size_t)k * 256;
-            uint32_t v = r < N ? col[r] : 0u;
+        for (int k = 0; k < RK; k++)
 #pragma unroll
             for (int p = 0; p < NPTS; p++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) acc[p][q] = madd(acc[p][q], mmul(w[k][p][q], v));
-        }
-        // wave reduction (field addition is exact: any order gives the same element)
+                for (int q = 0; q < 4; q++) acc[p][q] = madd(acc[p][q], mmul(w[k][p][q], x[k]));
 #pragma unroll
         for (int p = 0; p < NPTS; p++)
 #pragma unroll
@@ -209,18 +223,15 @@ __global__ __launch_bounds__(256) void k_col_reduce(const uint32_t* cols, size_t
                 for (int off = 32; off >= 1; off >>= 1) v = madd(v, __shfl_xor(v, off, 64));
                 acc[p][q] = v;
             }
-        __syncthreads();
         if (lane == 0) {
+            uint32_t* o = partial + (tile * n_cols + c) * (NPTS * 4);
 #pragma unroll
             for (int p = 0; p < NPTS; p++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) red[wave][p * 4 + q] = acc[p][q];
+                for (int q = 0; q < 4; q++) o[p * 4 + q] = acc[p][q];
         }
-        __syncthreads();
-        if (tid < NPTS * 4) {
-            uint32_t v = madd(madd(red[0][tid], red[1][tid]), madd(red[2][tid], red[3][tid]));
-            partial[((size_t)blockIdx.x * n_cols + c) * (NPTS * 4) + tid] = v;
-        }
+#pragma unroll
+        for (int k = 0; k < RK; k++) x[k] = xn[k];
     }
 }
 
@@ -591,8 +602,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     size_t o_opened = bp.take(n_open * 16);
     size_t o_pts = bp.take(64 * 16);
     size_t o_weights = bp.take(2 * max_n * 16);
-    const int RK = 8;
-    size_t max_tiles = (max_n + 256 * RK - 1) / (256 * RK);
+    size_t max_tiles = (max_n + 511) / 512;
     size_t o_partial = bp.take(max_tiles * max_w * 8 * 4);
     size_t o_apow_f = bp.take(max_w * 16);
     std::vector<size_t> o_ro(pk->hmax + 1, (size_t)-1);
@@ -798,7 +808,6 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     ZK_TRY(transcript_sample(ctx, pk->d_tr, d_zeta, nullptr, 4));
 
     // ---- 3. openings at zeta (and zeta*w for the trace) ----
-    const int RK = 8;
     auto open_matrix = [&](const uint32_t* cols, size_t stride, uint32_t n_cols, unsigned lh, unsigned n_pts,
                            uint32_t shift, uint32_t* d_out) -> int {
         const size_t N = (size_t)1 << lh;
@@ -821,14 +830,16 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pk->d_pts, n_pts,
                                shift, ctx->d_tw_fwd, lh ? ctx->tw_log - lh : 0, lh, pk->d_weights);
         }
-        uint32_t n_tiles = (uint32_t)((N + 256 * RK - 1) / (256 * RK));
+        constexpr int RK = 8;
+        uint32_t n_tiles = (uint32_t)((N + 64 * RK - 1) / (64 * RK));
         {
             KernelScope ks(ctx, "open_col_reduce");
+            dim3 grid((n_tiles + 3) / 4);
             if (n_pts == 2)
-                hipLaunchKernelGGL((k_col_reduce<2, RK>), dim3(n_tiles), dim3(256), 0, st, cols, stride, n_cols, lh,
+                hipLaunchKernelGGL((k_col_reduce<2, RK>), grid, dim3(256), 0, st, cols, stride, n_cols, lh,
                                    pk->d_weights, pk->d_partial);
             else
-                hipLaunchKernelGGL((k_col_reduce<1, RK>), dim3(n_tiles), dim3(256), 0, st, cols, stride, n_cols, lh,
+                hipLaunchKernelGGL((k_col_reduce<1, RK>), grid, dim3(256), 0, st, cols, stride, n_cols, lh,
                                    pk->d_weights, pk->d_partial);
         }
         {
