@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--width", type=int, default=300)
     ap.add_argument("--cpu-sample-log-rows", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent proofs in flight per GPU, each on its own HIP stream (segments of a chunk are "
+                         "independent): memory-bound stages of one overlap the VALU-bound hashing of the other")
     return ap.parse_args()
 
 
@@ -83,7 +86,13 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
-    ctx = z.Context(dev.index)
+    n_pipe = max(1, args.inflight)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_pipe)]
+    ctxs = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            ctxs.append(z.Context(dev.index))  # binds the context to this HIP stream
+    ctx = ctxs[0]
 
     params = z.DEFAULT_PARAMS
     log_n, width = args.log_rows, args.width
@@ -91,22 +100,29 @@ def main():
                      n_boundary=min(8, max(1, width // 40)), seed=0)
     sa = air.SyntheticAir(**sa_kwargs)
     fa = air.fibonacci_air()
-    # independent instance per rank (different witness seed), same AIR set / proving key shape
-    tr, pv = sa.gen_trace(log_n, seed=1000 + rank, xp="torch", device=dev)
-    d_trace = tr.reshape(-1).contiguous()
-    del tr
-    ctx._check(ctx.lib.zkhip_to_monty(ctx.h, d_trace.data_ptr(), d_trace.numel()))
-    ftr_np, fpv = air.fibonacci_trace(log_n, a0=rank, b0=1)
-    d_ftrace = ctx.upload(ftr_np.reshape(-1))
-    airs = [dict(program=sa.program(), log_height=log_n, width=width, n_pvs=len(pv)),
+    airs = [dict(program=sa.program(), log_height=log_n, width=width, n_pvs=sa.n_pvs),
             dict(program=fa.program(), log_height=log_n, width=2, n_pvs=3)]
-    pvs = [pv, fpv]
-    pk = z.ProvingKey(ctx, params, airs)
-    traces = [d_trace, d_ftrace]
+    # independent instance per rank and per pipeline (different witness seed), same proving-key shape
+    pipes = []
+    for i, c in enumerate(ctxs):
+        with torch.cuda.stream(streams[i]):
+            tr, pv = sa.gen_trace(log_n, seed=1000 + rank * n_pipe + i, xp="torch", device=dev)
+            d_trace = tr.reshape(-1).contiguous()
+            del tr
+            c._check(c.lib.zkhip_to_monty(c.h, d_trace.data_ptr(), d_trace.numel()))
+            ftr_np, fpv = air.fibonacci_trace(log_n, a0=rank * n_pipe + i, b0=1)
+            d_ftrace = c.upload(ftr_np.reshape(-1))
+            pipes.append(dict(ctx=c, pk=z.ProvingKey(c, params, airs), traces=[d_trace, d_ftrace], pvs=[pv, fpv]))
     torch.cuda.synchronize()
+    pk = pipes[0]["pk"]
 
-    def step():
-        pk.prove_async(traces, pvs)
+    def launch(i):
+        p = pipes[i % n_pipe]
+        p["pk"].prove_async(p["traces"], p["pvs"])
+
+    def collect(i):
+        # waits for proof i and copies it to the host (part of the step)
+        return pipes[i % n_pipe]["pk"].fetch()
 
     def exchange(proof_bytes):
         # the one exchange step of the sharded path (zkvm-prover_amd/shard.py): 32-byte trace
@@ -114,25 +130,34 @@ def main():
         if world > 1:
             shard.exchange(proof_bytes, device=dev)
 
-    for _ in range(args.warmup):
-        step()
-        exchange(pk.fetch())
-    ctx.profile_reset()
-    ctx.profile_enable(True)
+    def run(n_steps):
+        # keep n_pipe proofs in flight: proof i+n_pipe is enqueued as soon as proof i has been fetched
+        last = (0, None)
+        for i in range(min(n_pipe, n_steps)):
+            launch(i)
+        for i in range(n_steps):
+            last = (i, collect(i))
+            exchange(last[1])
+            if i + n_pipe < n_steps:
+                launch(i + n_pipe)
+        return last
+
+    run(args.warmup)
+    for c in ctxs:
+        c.profile_reset()
+    ctx.profile_enable(True)  # per-kernel HIP events on pipeline 0's stream
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        step()
-        last = pk.fetch()  # waits for the proof and copies it to the host (part of the step)
-        exchange(last)
+    last_i, last = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
     ctx.profile_enable(False)
+    pvs = pipes[last_i % n_pipe]["pvs"]
+    steps_profiled = len(range(0, args.steps, n_pipe))  # proofs that ran on pipeline 0
     dt = t1 - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -155,7 +180,7 @@ def main():
         roof = None
         if name:
             launches, total_ms = stats[name]
-            per_step_ms = total_ms / args.steps
+            per_step_ms = total_ms / steps_profiled
             if name == "poseidon2_hash_rows":
                 # algorithmic bytes per proof: read every committed LDE cell once, write one digest per row
                 alg = 4 * M * (width + 2) + 32 * M + (4 * M * 16 + 32 * M)
@@ -170,7 +195,7 @@ def main():
                 ach = alg / (per_step_ms * 1e-3) / 1e9
                 roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                        "launches_per_step": launches / args.steps, "ms_per_step": round(per_step_ms, 3),
+                        "launches_per_step": launches / steps_profiled, "ms_per_step": round(per_step_ms, 3),
                         "algorithmic_bytes_per_step": alg, "note": note}
                 if name == "poseidon2_hash_rows":
                     perms = M * ((width + 7) // 8 + 1 + 2)
@@ -193,9 +218,10 @@ def main():
                                    "%d queries, PoW %d+%d (SURVEY.md 8(d) cfg #4)"
                                    % (log_n, width, log_n, params[2], params[3], params[4]),
                        "proof_bytes": pk.proof_size, "verified": ok,
-                       "parallelism": "1 proof per GPU" + (", RCCL all-gather of commitments + proof gather" if world > 1 else "")},
+                       "inflight_per_gpu": n_pipe,
+                       "parallelism": "%d independent proof(s) in flight per GPU (one HIP stream each)" % n_pipe + (", RCCL all-gather of commitments + proof gather" if world > 1 else "")},
             "roofline": roof,
-            "stage_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
+            "stage_ms_per_step": {k: round(v[1] / steps_profiled, 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
