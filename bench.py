@@ -176,7 +176,7 @@ def main():
         n, M = 1 << log_n, 1 << (log_n + 1)
         # dominant kernel: Poseidon2 row sponge over the main LDE (+ the narrow quotient/FRI trees,
         # which share the kernel name but are <1% of its time)
-        name = max(stats, key=lambda k: stats[k][1]) if stats else None
+        name = "poseidon2_hash_rows" if "poseidon2_hash_rows" in stats else (max(stats, key=lambda k: stats[k][1]) if stats else None)
         roof = None
         if name:
             launches, total_ms = stats[name]
@@ -197,6 +197,18 @@ def main():
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                         "launches_per_step": launches / steps_profiled, "ms_per_step": round(per_step_ms, 3),
                         "algorithmic_bytes_per_step": alg, "note": note}
+                # HBM traffic of this kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+                # corrected as MI355X_MICROARCH.md prescribes; bench.py cannot collect counters itself)
+                try:
+                    with open(os.path.join(ROOT, "profiles", "round01_pmc_traffic.json")) as f:
+                        pmc = json.load(f)["kernels"]
+                    key = {"poseidon2_hash_rows": "zk::k_hash_rows"}.get(name)
+                    if key and log_n == 22 and width == 300:
+                        roof["traffic"] = round(pmc[key]["hbm_bytes_per_proof_corrected"] / pmc[key]["launches_per_proof"])
+                        roof["traffic_note"] = "bytes per launch, profiles/round01_pmc_traffic.json"
+                        roof["algorithmic_bytes_per_launch"] = alg // 2
+                except Exception:
+                    pass
                 if name == "poseidon2_hash_rows":
                     perms = M * ((width + 7) // 8 + 1 + 2)
                     roof["valu"] = {"perms_per_s": round(perms / (per_step_ms * 1e-3), 0),

@@ -63,6 +63,39 @@ int profile_flush(zkhip_ctx* ctx) {
 
 int permute_batch(zkhip_ctx* ctx, uint32_t* d_states, size_t n);
 
+// Power-on self-test of the hand-scheduled field primitives.  red_2p / msub issue
+// v_sub_co + v_cndmask back to back from inline asm (no compiler-inserted wait states between the
+// VCC write and its use: measurably faster in the LDS-bound NTT kernels); this kernel checks them on
+// the running device against plain C arithmetic for boundary and pseudo-random operands, so a part
+// that needed software wait states there would be refused at context creation, not mis-prove.
+__global__ void k_selftest(uint32_t* bad) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x = t * 2654435761u + 12345u;
+    const uint32_t edge[8] = {0u, 1u, P - 1u, P, P + 1u, 2u * P - 1u, 0x7fffffffu, 0x80000000u};
+    if (t < 8) x = edge[t];
+    const uint32_t x2 = x % (2u * P);
+    const uint32_t want_red = x2 >= P ? x2 - P : x2;
+    const uint32_t a = x % P, b = (x * 40503u + 77u) % P;
+    const uint32_t want_sub = a >= b ? a - b : a + P - b;
+    const uint32_t want_add = (uint32_t)(((uint64_t)a + b) % P);
+    const uint32_t want_mul = (uint32_t)(((uint64_t)from_monty(a) * from_monty(b)) % P);
+    if (red_2p(x2) != want_red || msub(a, b) != want_sub || madd(a, b) != want_add ||
+        from_monty(mmul(a, b)) != want_mul)
+        atomicAdd(bad, 1u);
+}
+
+static int selftest(zkhip_ctx* ctx) {
+    uint32_t* d_bad = nullptr;
+    uint32_t h_bad = 0;
+    if (hipMalloc(&d_bad, 4) != hipSuccess) return ZKHIP_ERR_NOMEM;
+    hipMemset(d_bad, 0, 4);
+    hipLaunchKernelGGL(k_selftest, dim3(64), dim3(256), 0, ctx->stream, d_bad);
+    hipError_t e = hipMemcpy(&h_bad, d_bad, 4, hipMemcpyDeviceToHost);
+    hipFree(d_bad);
+    if (e != hipSuccess) return ZKHIP_ERR_HIP;
+    return h_bad == 0 ? ZKHIP_OK : ZKHIP_ERR_HIP;
+}
+
 }  // namespace zk
 
 using namespace zk;
@@ -86,6 +119,10 @@ int zkhip_ctx_create(int device, zkhip_ctx** out) {
         // the code object only carries gfx950 ISA: fail loudly instead of at first launch
         delete ctx;
         return ZKHIP_ERR_NO_DEVICE;
+    }
+    if (selftest(ctx) != ZKHIP_OK) {
+        delete ctx;
+        return ZKHIP_ERR_HIP;
     }
     *out = ctx;
     return ZKHIP_OK;
