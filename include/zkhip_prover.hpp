@@ -1,0 +1,410 @@
+// zkhip_prover.hpp -- host-side C++ mirror of the reference's prover API over the zkhip C ABI.
+//
+// The reference's crate `scroll-zkvm-prover` is Rust (no toolchain in this build environment), so
+// the host side above include/zkhip.h is written in C++ with the same names, argument meaning and
+// error behaviour (INTEGRATION.md shows the Rust shim a maintainer would add instead):
+//
+//   ProverConfig{path_app_exe, path_app_config}   crates/prover/src/prover/mod.rs:83-88
+//   Prover::setup(config, name)                   mod.rs:93-104   (reads files only; keys are lazy)
+//   Prover::reset()                               mod.rs:106-108  (drops device-resident keys)
+//   Prover::gen_proof_universal(task, with_snark) mod.rs:287-309
+//   Prover::gen_proof_stark(..)                   mod.rs:342-413  (prove, encode, SELF-VERIFY)
+//   ProvingTask{serialized_witness, aggregated_proofs, fork_name, vk, identifier, input_commits}
+//                                                 crates/types/src/task.rs:7-23
+//   StarkProof{proof, user_pvs_proof, baseline, deferral_merkle_proofs, stat}, each byte field
+//     carried in JSON as base64(bincode(Vec<u8>))   crates/types/src/proof.rs:52-67, utils.rs:20-39
+//   StarkProofStat{total_cycles, execution_time_mills, proving_time_mills}   proof.rs:41-48
+//   Error::{Io, Setup, Keygen, GenProof, VerifyProof, Custom}               crates/prover/src/error.rs:5-46
+//
+// What differs, because guest execution and trace generation are outside this path (SURVEY.md 8(f)
+// f3): `path_app_exe` is an AIR-set file (the constraint bytecode of every chip) instead
+// of an OpenVM vmexe, and `serialized_witness[i]` carries chip i's public values and trace.
+// `path_app_config` is the reference's own openvm.toml: the five `[app_fri_params.fri_params]` keys
+// are read from it (crates/circuits/chunk-circuit/openvm.toml:1-6).
+#pragma once
+#include <array>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "zkhip.h"
+
+namespace scroll_zkvm_hip {
+
+struct Error : std::runtime_error {
+    enum Kind { Io, Setup, Keygen, GenProof, VerifyProof, Custom } kind;
+    Error(Kind k, const std::string& m) : std::runtime_error(m), kind(k) {}
+};
+
+// ---- wire helpers: base64 + bincode(Vec<u8>) ---------------------------------------------------
+inline std::string base64_encode(const std::vector<uint8_t>& in) {
+    static const char* T = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    std::string out;
+    out.reserve((in.size() + 2) / 3 * 4);
+    size_t i = 0;
+    for (; i + 2 < in.size(); i += 3) {
+        uint32_t v = (in[i] << 16) | (in[i + 1] << 8) | in[i + 2];
+        out += T[v >> 18], out += T[(v >> 12) & 63], out += T[(v >> 6) & 63], out += T[v & 63];
+    }
+    if (i + 1 == in.size()) {
+        uint32_t v = in[i] << 16;
+        out += T[v >> 18], out += T[(v >> 12) & 63], out += "==";
+    } else if (i + 2 == in.size()) {
+        uint32_t v = (in[i] << 16) | (in[i + 1] << 8);
+        out += T[v >> 18], out += T[(v >> 12) & 63], out += T[(v >> 6) & 63], out += '=';
+    }
+    return out;
+}
+inline std::vector<uint8_t> base64_decode(const std::string& s) {
+    auto val = [](char c) -> int {
+        if (c >= 'A' && c <= 'Z') return c - 'A';
+        if (c >= 'a' && c <= 'z') return c - 'a' + 26;
+        if (c >= '0' && c <= '9') return c - '0' + 52;
+        if (c == '+') return 62;
+        if (c == '/') return 63;
+        return -1;
+    };
+    std::vector<uint8_t> out;
+    uint32_t acc = 0;
+    int bits = 0;
+    for (char c : s) {
+        if (c == '=') break;
+        int v = val(c);
+        if (v < 0) throw Error(Error::Custom, "invalid base64");
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) {
+            bits -= 8;
+            out.push_back((uint8_t)(acc >> bits));
+        }
+    }
+    return out;
+}
+// bincode v1 of a Vec<u8>: u64 little-endian length, then the bytes
+inline std::vector<uint8_t> bincode_vec(const std::vector<uint8_t>& v) {
+    std::vector<uint8_t> out(8 + v.size());
+    uint64_t n = v.size();
+    memcpy(out.data(), &n, 8);
+    if (n) memcpy(out.data() + 8, v.data(), v.size());
+    return out;
+}
+inline std::vector<uint8_t> unbincode_vec(const std::vector<uint8_t>& b) {
+    if (b.size() < 8) throw Error(Error::Custom, "bincode: short buffer");
+    uint64_t n;
+    memcpy(&n, b.data(), 8);
+    if (n != b.size() - 8) throw Error(Error::Custom, "bincode: length mismatch");
+    return std::vector<uint8_t>(b.begin() + 8, b.end());
+}
+
+struct StarkProofStat {
+    uint64_t total_cycles = 0, execution_time_mills = 0, proving_time_mills = 0;
+};
+
+struct StarkProof {
+    std::vector<uint8_t> proof, user_pvs_proof, baseline, deferral_merkle_proofs;
+    StarkProofStat stat;
+
+    std::string to_json() const {
+        std::ostringstream os;
+        os << "{\"proof\":\"" << base64_encode(bincode_vec(proof)) << "\",\"user_pvs_proof\":\""
+           << base64_encode(bincode_vec(user_pvs_proof)) << "\",\"baseline\":\"" << base64_encode(bincode_vec(baseline))
+           << "\",\"deferral_merkle_proofs\":\"" << base64_encode(bincode_vec(deferral_merkle_proofs))
+           << "\",\"stat\":{\"total_cycles\":" << stat.total_cycles
+           << ",\"execution_time_mills\":" << stat.execution_time_mills
+           << ",\"proving_time_mills\":" << stat.proving_time_mills << "}}";
+        return os.str();
+    }
+    static StarkProof from_json(const std::string& js) {
+        // position just after `"key" :` (whitespace tolerant), or npos
+        auto after_key = [&](const char* key) -> size_t {
+            std::string k = std::string("\"") + key + "\"";
+            size_t p = js.find(k);
+            if (p == std::string::npos) return p;
+            p += k.size();
+            while (p < js.size() && (js[p] == ' ' || js[p] == '\t' || js[p] == '\n' || js[p] == '\r')) p++;
+            if (p >= js.size() || js[p] != ':') return std::string::npos;
+            p++;
+            while (p < js.size() && (js[p] == ' ' || js[p] == '\t' || js[p] == '\n' || js[p] == '\r')) p++;
+            return p;
+        };
+        auto str_field = [&](const char* key) -> std::vector<uint8_t> {
+            size_t p = after_key(key);
+            if (p == std::string::npos) return {};  // `default` fields may be absent
+            if (js[p] != '"') throw Error(Error::Custom, "malformed proof json");
+            size_t e = js.find('"', p + 1);
+            if (e == std::string::npos) throw Error(Error::Custom, "malformed proof json");
+            return unbincode_vec(base64_decode(js.substr(p + 1, e - p - 1)));
+        };
+        auto num_field = [&](const char* key) -> uint64_t {
+            size_t p = after_key(key);
+            return p == std::string::npos ? 0 : std::stoull(js.substr(p));
+        };
+        StarkProof sp;
+        sp.proof = str_field("proof");
+        sp.user_pvs_proof = str_field("user_pvs_proof");
+        sp.baseline = str_field("baseline");
+        sp.deferral_merkle_proofs = str_field("deferral_merkle_proofs");
+        sp.stat.total_cycles = num_field("total_cycles");
+        sp.stat.execution_time_mills = num_field("execution_time_mills");
+        sp.stat.proving_time_mills = num_field("proving_time_mills");
+        if (sp.proof.empty()) throw Error(Error::Custom, "proof json has no `proof` field");
+        return sp;
+    }
+};
+
+struct ProvingTask {
+    std::vector<std::vector<uint8_t>> serialized_witness;  // one entry per chip (see witness layout below)
+    std::vector<StarkProof> aggregated_proofs;             // unused by leaf (chunk-like) tasks
+    std::string fork_name;
+    std::vector<uint8_t> vk;
+    std::string identifier;
+    std::vector<std::array<uint8_t, 32>> input_commits;
+};
+
+// witness layout of chip i (little-endian u32 words):
+//   [log_height, n_pvs, pvs..., trace column-major (width columns of 2^log_height canonical words)]
+inline std::vector<uint8_t> encode_witness(unsigned log_height, const std::vector<uint32_t>& pvs,
+                                           const std::vector<uint32_t>& trace_colmajor) {
+    std::vector<uint32_t> w{log_height, (uint32_t)pvs.size()};
+    w.insert(w.end(), pvs.begin(), pvs.end());
+    w.insert(w.end(), trace_colmajor.begin(), trace_colmajor.end());
+    std::vector<uint8_t> out(w.size() * 4);
+    memcpy(out.data(), w.data(), out.size());
+    return out;
+}
+
+struct ProverConfig {
+    std::string path_app_exe;     // AIR-set file: [0x58414B5A, n_airs, {width, n_pvs, program_len, program...}...]
+    std::string path_app_config;  // openvm.toml (FRI parameter block)
+};
+
+struct AirDesc {
+    size_t width = 0, n_pvs = 0;
+    std::vector<uint32_t> program;
+};
+constexpr uint32_t AIRSET_MAGIC = 0x58414B5Au;
+
+inline std::vector<uint8_t> encode_app_exe(const std::vector<AirDesc>& airs) {
+    std::vector<uint32_t> w{AIRSET_MAGIC, (uint32_t)airs.size()};
+    for (const auto& a : airs) {
+        w.push_back((uint32_t)a.width), w.push_back((uint32_t)a.n_pvs), w.push_back((uint32_t)a.program.size());
+        w.insert(w.end(), a.program.begin(), a.program.end());
+    }
+    std::vector<uint8_t> out(w.size() * 4);
+    memcpy(out.data(), w.data(), out.size());
+    return out;
+}
+
+// crates/prover/src/setup.rs:16,88 read_app_exe / read_app_config
+inline std::vector<AirDesc> read_app_exe(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw Error(Error::Setup, "failed to read or deserialize " + path + ": cannot open");
+    std::vector<uint8_t> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (b.size() < 8 || b.size() % 4) throw Error(Error::Setup, "failed to read or deserialize " + path + ": truncated");
+    std::vector<uint32_t> w(b.size() / 4);
+    memcpy(w.data(), b.data(), b.size());
+    if (w[0] != AIRSET_MAGIC) throw Error(Error::Setup, "failed to read or deserialize " + path + ": bad magic");
+    std::vector<AirDesc> airs(w[1]);
+    size_t p = 2;
+    for (auto& a : airs) {
+        if (p + 3 > w.size()) throw Error(Error::Setup, "failed to read or deserialize " + path + ": truncated");
+        a.width = w[p], a.n_pvs = w[p + 1];
+        size_t len = w[p + 2];
+        p += 3;
+        if (p + len > w.size()) throw Error(Error::Setup, "failed to read or deserialize " + path + ": truncated");
+        a.program.assign(w.begin() + p, w.begin() + p + len);
+        p += len;
+    }
+    return airs;
+}
+inline zkhip_params read_app_config(const std::string& path) {
+    std::ifstream f(path);
+    if (!f) throw Error(Error::Setup, "failed to read or deserialize " + path + ": cannot open");
+    std::map<std::string, uint32_t> kv;
+    std::string line;
+    while (std::getline(f, line)) {
+        size_t eq = line.find('=');
+        if (eq == std::string::npos || line[0] == '[' || line[0] == '#') continue;
+        std::string k = line.substr(0, eq), v = line.substr(eq + 1);
+        k.erase(0, k.find_first_not_of(" \t")), k.erase(k.find_last_not_of(" \t") + 1);
+        try {
+            kv[k] = (uint32_t)std::stoul(v);
+        } catch (...) {
+        }
+    }
+    auto need = [&](const char* k) -> uint32_t {
+        auto it = kv.find(k);
+        if (it == kv.end()) throw Error(Error::Setup, "failed to read or deserialize " + path + ": missing " + k);
+        return it->second;
+    };
+    zkhip_params p;
+    p.log_blowup = need("log_blowup");
+    p.log_final_poly_len = need("log_final_poly_len");
+    p.num_queries = need("num_queries");
+    p.commit_pow_bits = need("commit_proof_of_work_bits");
+    p.query_pow_bits = need("query_proof_of_work_bits");
+    return p;
+}
+
+class Prover {
+public:
+    std::string prover_name;
+    ProverConfig config;
+
+    // mod.rs:93-104: reads the two files; device keys are built lazily at the first proof
+    static Prover setup(const ProverConfig& cfg, const char* name = nullptr, int device = 0) {
+        Prover p;
+        p.config = cfg;
+        p.prover_name = name ? name : "universal";
+        p.airs_ = read_app_exe(cfg.path_app_exe);
+        p.params_ = read_app_config(cfg.path_app_config);
+        p.device_ = device;
+        return p;
+    }
+    Prover(Prover&& o) noexcept { *this = std::move(o); }
+    Prover& operator=(Prover&& o) noexcept {
+        reset();
+        prover_name = std::move(o.prover_name), config = std::move(o.config), airs_ = std::move(o.airs_);
+        params_ = o.params_, device_ = o.device_, ctx_ = o.ctx_, pk_ = o.pk_, pk_heights_ = std::move(o.pk_heights_);
+        o.ctx_ = nullptr, o.pk_ = nullptr;
+        return *this;
+    }
+    ~Prover() { reset(); }
+
+    // mod.rs:106-108 "Release OpenVM SDK resources": frees the device-resident keys and workspace
+    void reset() {
+        if (pk_) zkhip_pk_destroy(ctx_, pk_), pk_ = nullptr;
+        if (ctx_) zkhip_ctx_destroy(ctx_), ctx_ = nullptr;
+        pk_heights_.clear();
+    }
+
+    // mod.rs:287-309
+    StarkProof gen_proof_universal(const ProvingTask& task, bool with_snark = false) {
+        if (with_snark) throw Error(Error::GenProof, "the SNARK (EVM) wrap is outside the HIP backend's path");
+        return gen_proof_stark(task);
+    }
+
+    // mod.rs:342-413: "execute" (here: decode + upload the witness), prove, encode, self-verify
+    StarkProof gen_proof_stark(const ProvingTask& task) {
+        using clk = std::chrono::steady_clock;
+        auto t0 = clk::now();
+        if (task.serialized_witness.size() != airs_.size())
+            throw Error(Error::GenProof, "task " + task.identifier + ": witness count does not match the app's chips");
+        std::vector<unsigned> heights;
+        std::vector<std::vector<uint32_t>> pvs(airs_.size());
+        std::vector<const uint32_t*> trace_host(airs_.size());
+        uint64_t total_cells = 0;
+        for (size_t a = 0; a < airs_.size(); a++) {
+            const auto& w = task.serialized_witness[a];
+            if (w.size() < 8 || w.size() % 4) throw Error(Error::GenProof, "malformed witness");
+            const uint32_t* words = reinterpret_cast<const uint32_t*>(w.data());
+            unsigned lh = words[0];
+            size_t n_pvs = words[1], have = w.size() / 4;
+            if (lh > 27 || n_pvs != airs_[a].n_pvs || have != 2 + n_pvs + (airs_[a].width << lh))
+                throw Error(Error::GenProof, "witness of chip " + std::to_string(a) + " has the wrong shape");
+            heights.push_back(lh);
+            pvs[a].assign(words + 2, words + 2 + n_pvs);
+            trace_host[a] = words + 2 + n_pvs;
+            total_cells += (uint64_t)airs_[a].width << lh;
+        }
+        ensure_keys(heights);
+        // H2D of the witness (the analogue of execution handing traces to the engine)
+        std::vector<void*> d_traces(airs_.size(), nullptr);
+        auto free_traces = [&]() {
+            for (void* d : d_traces)
+                if (d) zkhip_free(ctx_, d);
+        };
+        try {
+            for (size_t a = 0; a < airs_.size(); a++) {
+                size_t n = airs_[a].width << heights[a];
+                check(zkhip_malloc(ctx_, n * 4, &d_traces[a]), Error::GenProof);
+                check(zkhip_h2d(ctx_, d_traces[a], trace_host[a], n * 4), Error::GenProof);
+                check(zkhip_to_monty(ctx_, (uint32_t*)d_traces[a], n), Error::GenProof);
+            }
+            check(zkhip_sync(ctx_), Error::GenProof);
+            auto t1 = clk::now();
+            StarkProof sp;
+            sp.proof.resize(zkhip_proof_size(pk_));
+            std::vector<const uint32_t*> dt(airs_.size()), pv(airs_.size());
+            for (size_t a = 0; a < airs_.size(); a++) dt[a] = (const uint32_t*)d_traces[a], pv[a] = pvs[a].data();
+            size_t len = 0;
+            check(zkhip_prove(ctx_, pk_, dt.data(), pv.data(), sp.proof.data(), sp.proof.size(), &len), Error::GenProof);
+            sp.proof.resize(len);
+            auto t2 = clk::now();
+            // user public values, chip by chip (canonical LE words)
+            for (auto& p : pvs) {
+                const uint8_t* b = reinterpret_cast<const uint8_t*>(p.data());
+                sp.user_pvs_proof.insert(sp.user_pvs_proof.end(), b, b + p.size() * 4);
+            }
+            // baseline: what a verifier needs besides the app: the per-chip trace heights
+            for (unsigned h : heights) sp.baseline.push_back((uint8_t)h);
+            sp.stat.total_cycles = total_cells;
+            sp.stat.execution_time_mills = std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count();
+            sp.stat.proving_time_mills = std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
+            free_traces();
+            // mandatory self-check, as mod.rs:407-411
+            verify_stark_proof(sp);
+            return sp;
+        } catch (...) {
+            free_traces();
+            throw;
+        }
+    }
+
+    // crates/verifier/src/verifier.rs:38-85 for this backend's proofs; throws Error::VerifyProof
+    void verify_stark_proof(const StarkProof& sp) const {
+        if (sp.baseline.size() != airs_.size()) throw Error(Error::VerifyProof, "baseline does not match the app");
+        std::vector<zkhip_air> za(airs_.size());
+        std::vector<std::vector<uint32_t>> pvs(airs_.size());
+        std::vector<const uint32_t*> pv(airs_.size());
+        size_t off = 0;
+        for (size_t a = 0; a < airs_.size(); a++) {
+            za[a] = zkhip_air{airs_[a].program.data(), airs_[a].program.size(), sp.baseline[a], airs_[a].width, airs_[a].n_pvs};
+            if (off + 4 * airs_[a].n_pvs > sp.user_pvs_proof.size()) throw Error(Error::VerifyProof, "short public values");
+            pvs[a].resize(airs_[a].n_pvs);
+            if (airs_[a].n_pvs) memcpy(pvs[a].data(), sp.user_pvs_proof.data() + off, 4 * airs_[a].n_pvs);
+            off += 4 * airs_[a].n_pvs;
+            pv[a] = pvs[a].data();
+        }
+        int rc = zkhip_verify(&params_, za.data(), za.size(), pv.data(), sp.proof.data(), sp.proof.size());
+        if (rc != ZKHIP_OK) throw Error(Error::VerifyProof, "failed to verify proof: zkhip_verify returned " + std::to_string(rc));
+    }
+
+    const zkhip_params& params() const { return params_; }
+    const std::vector<AirDesc>& airs() const { return airs_; }
+
+private:
+    Prover() = default;
+    std::vector<AirDesc> airs_;
+    zkhip_params params_{};
+    int device_ = 0;
+    zkhip_ctx* ctx_ = nullptr;
+    zkhip_pk* pk_ = nullptr;
+    std::vector<unsigned> pk_heights_;
+
+    void check(int rc, Error::Kind kind) const {
+        if (rc != ZKHIP_OK) throw Error(kind, std::string(kind == Error::Keygen ? "failed to generate STARK proving key: " : "failed to generate proof: ") + zkhip_last_error(ctx_));
+    }
+    // lazily initialised like the reference's OnceLock<Sdk> (mod.rs:78,115-126); keys are per trace shape
+    void ensure_keys(const std::vector<unsigned>& heights) {
+        if (!ctx_) {
+            int rc = zkhip_ctx_create(device_, &ctx_);
+            if (rc != ZKHIP_OK) throw Error(Error::Keygen, "no gfx950 device for the HIP backend (zkhip_ctx_create returned " + std::to_string(rc) + ")");
+        }
+        if (pk_ && pk_heights_ == heights) return;
+        if (pk_) zkhip_pk_destroy(ctx_, pk_), pk_ = nullptr;
+        std::vector<zkhip_air> za(airs_.size());
+        for (size_t a = 0; a < airs_.size(); a++)
+            za[a] = zkhip_air{airs_[a].program.data(), airs_[a].program.size(), heights[a], airs_[a].width, airs_[a].n_pvs};
+        check(zkhip_keygen(ctx_, &params_, za.data(), za.size(), &pk_), Error::Keygen);
+        pk_heights_ = heights;
+    }
+};
+
+}  // namespace scroll_zkvm_hip

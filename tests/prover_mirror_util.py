@@ -1,0 +1,72 @@
+"""Helpers to drive the C++ Prover mirror (include/zkhip_prover.hpp via zkvm-prover_amd/prove_cli)."""
+import base64
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
+AIRSET_MAGIC = 0x58414B5A
+
+# same keys as the reference's circuit config (crates/circuits/chunk-circuit/openvm.toml:1-6)
+TOML = """[app_fri_params.fri_params]
+log_blowup = {0}
+log_final_poly_len = {1}
+num_queries = {2}
+commit_proof_of_work_bits = {3}
+query_proof_of_work_bits = {4}
+
+[app_vm_config.rv32i]
+"""
+
+
+def write_app(tmp, airs, params):
+    words = [AIRSET_MAGIC, len(airs)]
+    for a in airs:
+        prog = np.asarray(a["program"], dtype=np.uint32)
+        words += [a["width"], a["n_pvs"], prog.size] + prog.tolist()
+    exe = os.path.join(tmp, "app.zkair")
+    np.array(words, dtype=np.uint32).tofile(exe)
+    cfg = os.path.join(tmp, "openvm.toml")
+    with open(cfg, "w") as f:
+        f.write(TOML.format(*params))
+    return exe, cfg
+
+
+def write_task(tmp, airs, identifier="chunk-0"):
+    out = os.path.join(tmp, "task.bin")
+    with open(out, "wb") as f:
+        idb = identifier.encode()
+        f.write(struct.pack("<I", len(idb)) + idb + struct.pack("<I", len(airs)))
+        for a in airs:
+            w = np.concatenate([np.array([a["log_height"], len(a["pvs"])], dtype=np.uint32),
+                                np.asarray(a["pvs"], dtype=np.uint32), np.asarray(a["trace"], dtype=np.uint32).reshape(-1)])
+            b = w.tobytes()
+            f.write(struct.pack("<Q", len(b)) + b)
+    return out
+
+
+def b64_bincode(b):
+    return base64.b64encode(struct.pack("<Q", len(b)) + b).decode()
+
+
+def un_b64_bincode(s):
+    raw = base64.b64decode(s)
+    (n,) = struct.unpack("<Q", raw[:8])
+    assert n == len(raw) - 8
+    return raw[8:]
+
+
+def stark_proof_json(proof_bytes, airs, proving_ms=0):
+    pvs = b"".join(np.asarray(a["pvs"], dtype=np.uint32).tobytes() for a in airs)
+    baseline = bytes(a["log_height"] for a in airs)
+    return json.dumps({"proof": b64_bincode(proof_bytes), "user_pvs_proof": b64_bincode(pvs),
+                       "baseline": b64_bincode(baseline), "deferral_merkle_proofs": b64_bincode(b""),
+                       "stat": {"total_cycles": 0, "execution_time_mills": 0, "proving_time_mills": proving_ms}})
+
+
+def run_cli(*args):
+    return subprocess.run([CLI] + list(args), capture_output=True, text=True)

@@ -1,0 +1,47 @@
+"""GPU: Prover::setup -> gen_proof_universal through the C++ mirror produces the reference-shaped
+StarkProof JSON whose proof bytes equal the oracle's, self-verifies, and rejects a bad witness."""
+import json
+
+import numpy as np
+import pytest
+
+import prover_mirror_util as pm
+from zkvm_prover_amd import air
+
+pytestmark = pytest.mark.gpu
+PARAMS = (1, 0, 8, 4, 4)
+
+
+def _airs():
+    sa = air.SyntheticAir(width=20, n_free=7, n_bool=3, n_boundary=2, seed=9)
+    tr, pv = sa.gen_trace(7, seed=1)
+    fa = air.fibonacci_air()
+    ftr, fpv = air.fibonacci_trace(5)
+    return [dict(program=sa.program(), log_height=7, width=20, n_pvs=len(pv), trace=tr, pvs=pv),
+            dict(program=fa.program(), log_height=5, width=2, n_pvs=3, trace=ftr, pvs=fpv)]
+
+
+def test_gen_proof_universal_cli(ora, tmp_path):
+    airs = _airs()
+    exe, cfg = pm.write_app(str(tmp_path), airs, PARAMS)
+    task = pm.write_task(str(tmp_path), airs, identifier="chunk-42")
+    out = tmp_path / "proof.json"
+    r = pm.run_cli("prove", exe, cfg, task, str(out))
+    assert r.returncode == 0 and "proved chunk-42" in r.stdout, r.stderr
+    js = json.loads(out.read_text())
+    assert set(js) == {"proof", "user_pvs_proof", "baseline", "deferral_merkle_proofs", "stat"}
+    assert set(js["stat"]) == {"total_cycles", "execution_time_mills", "proving_time_mills"}
+    proof = pm.un_b64_bincode(js["proof"])
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    assert pm.un_b64_bincode(js["baseline"]) == bytes([7, 5])
+    assert pm.run_cli("verify", exe, cfg, str(out)).returncode == 0
+
+
+def test_unsatisfied_witness_fails_self_verification(tmp_path):
+    airs = _airs()
+    airs[0]["trace"] = airs[0]["trace"].copy()
+    airs[0]["trace"][12, 3] = (int(airs[0]["trace"][12, 3]) + 1) % air.P
+    exe, cfg = pm.write_app(str(tmp_path), airs, PARAMS)
+    task = pm.write_task(str(tmp_path), airs)
+    r = pm.run_cli("prove", exe, cfg, task, str(tmp_path / "o.json"))
+    assert r.returncode == 1 and "kind 4" in r.stderr  # Error::VerifyProof from the mandatory self-check

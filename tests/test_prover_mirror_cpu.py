@@ -1,0 +1,67 @@
+"""CPU: the C++ mirror of the reference's Prover API (include/zkhip_prover.hpp) -- file loading
+(setup), the StarkProof JSON container (base64(bincode(Vec<u8>)) fields, crates/types/src/proof.rs:52-67)
+and verify_stark_proof -- exercised through prove_cli on proofs made by the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import prover_mirror_util as pm
+from zkvm_prover_amd import air
+
+PARAMS = (1, 0, 8, 4, 4)
+
+
+def _airs():
+    sa = air.SyntheticAir(width=20, n_free=7, n_bool=3, n_boundary=2, seed=9)
+    tr, pv = sa.gen_trace(6, seed=1)
+    fa = air.fibonacci_air()
+    ftr, fpv = air.fibonacci_trace(5)
+    return [dict(program=sa.program(), log_height=6, width=20, n_pvs=len(pv), trace=tr, pvs=pv),
+            dict(program=fa.program(), log_height=5, width=2, n_pvs=3, trace=ftr, pvs=fpv)]
+
+
+def test_cli_verifies_oracle_proof_in_reference_container(ora, tmp_path):
+    assert os.path.exists(pm.CLI), "prove_cli not built (python -c 'import __graft_entry__ as g; g.build()')"
+    airs = _airs()
+    proof = ora.stark_prove(PARAMS, airs).tobytes()
+    exe, cfg = pm.write_app(str(tmp_path), airs, PARAMS)
+    pj = tmp_path / "proof.json"
+    pj.write_text(pm.stark_proof_json(proof, airs, proving_ms=12))
+    r = pm.run_cli("verify", exe, cfg, str(pj))
+    assert r.returncode == 0 and "verified" in r.stdout and "proving_time_mills=12" in r.stdout, r.stderr
+    # a flipped proof byte is Error::VerifyProof (kind 4); mismatching public values too
+    bad = bytearray(proof)
+    bad[200] ^= 1
+    pj.write_text(pm.stark_proof_json(bytes(bad), airs))
+    r = pm.run_cli("verify", exe, cfg, str(pj))
+    assert r.returncode == 1 and "kind 4" in r.stderr
+    airs2 = _airs()
+    airs2[1]["pvs"] = airs2[1]["pvs"].copy()
+    airs2[1]["pvs"][2] += 1
+    pj.write_text(pm.stark_proof_json(proof, airs2))
+    assert pm.run_cli("verify", exe, cfg, str(pj)).returncode == 1
+
+
+def test_setup_errors_match_reference_kinds(tmp_path):
+    airs = _airs()
+    exe, cfg = pm.write_app(str(tmp_path), airs, PARAMS)
+    # missing exe / config -> Error::Setup (kind 1), like read_app_exe / read_app_config failures
+    r = pm.run_cli("verify", str(tmp_path / "nope.zkair"), cfg, str(tmp_path / "p.json"))
+    assert r.returncode == 1 and "kind 1" in r.stderr and "failed to read or deserialize" in r.stderr
+    (tmp_path / "bad.toml").write_text("[app_fri_params.fri_params]\nlog_blowup = 1\n")
+    r = pm.run_cli("verify", exe, str(tmp_path / "bad.toml"), str(tmp_path / "p.json"))
+    assert r.returncode == 1 and "kind 1" in r.stderr and "num_queries" in r.stderr or "log_final_poly_len" in r.stderr
+
+
+def test_prove_without_gpu_fails_loudly(tmp_path):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    airs = _airs()
+    exe, cfg = pm.write_app(str(tmp_path), airs, PARAMS)
+    task = pm.write_task(str(tmp_path), airs)
+    r = pm.run_cli("prove", exe, cfg, task, str(tmp_path / "out.json"))
+    assert r.returncode == 1 and "kind 2" in r.stderr and "gfx950" in r.stderr  # Error::Keygen, no CPU fallback

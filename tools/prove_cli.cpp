@@ -1,0 +1,62 @@
+// prove_cli -- command-line driver of the C++ prover mirror (include/zkhip_prover.hpp).
+//   prove_cli prove  <app.zkair> <openvm.toml> <task.bin> <out_proof.json>
+//   prove_cli verify <app.zkair> <openvm.toml> <proof.json>
+// task.bin: [u32 id_len][id][u32 n_witness]{[u64 len][bytes]}  (the fields of ProvingTask that
+// a leaf task uses, crates/types/src/task.rs:7-23)
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+#include "zkhip_prover.hpp"
+
+using namespace scroll_zkvm_hip;
+
+static std::vector<uint8_t> slurp(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw Error(Error::Io, "cannot open " + path);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+int main(int argc, char** argv) {
+    try {
+        if (argc >= 5 && std::string(argv[1]) == "verify") {
+            Prover prover = Prover::setup(ProverConfig{argv[2], argv[3]}, "cli");
+            auto js = slurp(argv[4]);
+            StarkProof sp = StarkProof::from_json(std::string(js.begin(), js.end()));
+            prover.verify_stark_proof(sp);
+            std::printf("verified: %zu proof bytes, proving_time_mills=%llu\n", sp.proof.size(),
+                        (unsigned long long)sp.stat.proving_time_mills);
+            return 0;
+        }
+        if (argc >= 6 && std::string(argv[1]) == "prove") {
+            Prover prover = Prover::setup(ProverConfig{argv[2], argv[3]}, "cli");
+            auto tb = slurp(argv[4]);
+            ProvingTask task;
+            size_t p = 0;
+            auto rd32 = [&]() { uint32_t v; if (p + 4 > tb.size()) throw Error(Error::Io, "short task"); memcpy(&v, &tb[p], 4); p += 4; return v; };
+            auto rd64 = [&]() { uint64_t v; if (p + 8 > tb.size()) throw Error(Error::Io, "short task"); memcpy(&v, &tb[p], 8); p += 8; return v; };
+            uint32_t idl = rd32();
+            task.identifier.assign((const char*)&tb[p], idl);
+            p += idl;
+            uint32_t n = rd32();
+            for (uint32_t i = 0; i < n; i++) {
+                uint64_t len = rd64();
+                if (p + len > tb.size()) throw Error(Error::Io, "short task");
+                task.serialized_witness.emplace_back(tb.begin() + p, tb.begin() + p + len);
+                p += len;
+            }
+            task.fork_name = "hip";
+            StarkProof sp = prover.gen_proof_universal(task, false);
+            std::ofstream(argv[5]) << sp.to_json();
+            std::printf("proved %s: %zu proof bytes, execution %llu ms, proving %llu ms\n", task.identifier.c_str(),
+                        sp.proof.size(), (unsigned long long)sp.stat.execution_time_mills,
+                        (unsigned long long)sp.stat.proving_time_mills);
+            return 0;
+        }
+        std::fprintf(stderr, "usage: prove_cli prove|verify ...\n");
+        return 2;
+    } catch (const Error& e) {
+        std::fprintf(stderr, "error(kind %d): %s\n", (int)e.kind, e.what());
+        return 1;
+    }
+}
