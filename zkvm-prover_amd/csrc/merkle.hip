@@ -19,7 +19,7 @@
 namespace zk {
 
 __device__ __forceinline__ void absorb_rows(uint32_t s[16], const uint32_t* const* __restrict__ cols,
-                                            uint32_t n_cols, size_t row) {
+                                            uint32_t n_cols, uint32_t row) {
     uint32_t j = 0;
     for (; j + 8 <= n_cols; j += 8) {
 #pragma unroll
@@ -36,13 +36,13 @@ __device__ __forceinline__ void absorb_rows(uint32_t s[16], const uint32_t* cons
 
 __global__ __launch_bounds__(256) void k_hash_rows(const uint32_t* const* __restrict__ cols, uint32_t n_cols,
                                                    size_t n_rows, uint32_t* __restrict__ out) {
-    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;  // heights are <= 2^27: 32-bit offsets
     if (row >= n_rows) return;
     uint32_t s[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = 0;
     absorb_rows(s, cols, n_cols, row);
-    uint4* o = reinterpret_cast<uint4*>(out + row * 8);
+    uint4* o = reinterpret_cast<uint4*>(out + (size_t)row * 8);
     o[0] = make_uint4(s[0], s[1], s[2], s[3]);
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_compress_layer(const uint32_t* __restri
         uint32_t h[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) h[k] = 0;
-        absorb_rows(h, inj_cols, n_inj_cols, i);
+        absorb_rows(h, inj_cols, n_inj_cols, (uint32_t)i);
 #pragma unroll
         for (int k = 0; k < 8; k++) s[8 + k] = h[k];
         poseidon2_permute(s);

@@ -306,14 +306,31 @@ __global__ __launch_bounds__(256) void k_reduced_openings(ReduceArgs a) {
     const size_t M = (size_t)1 << a.h;
     size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= M) return;
-    uint32_t acc[4] = {0, 0, 0, 0};
-    for (uint32_t k = 0; k < a.width; k++) {
-        const uint32_t v = a.mat[(size_t)k * M + r];
+    // two independent accumulator sets and an 8-deep unroll keep 8 column loads in flight per lane
+    uint32_t acc[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
+    const uint32_t* col = a.mat + r;
+    uint32_t k = 0;
+    for (; k + 8 <= a.width; k += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = col[(size_t)(k + u) * M];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            const uint32_t* ap = a.apow + 4 * (size_t)(k + u);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                acc[q] = madd(acc[q], mmul(ap[q], v[u]));
+                acc2[q] = madd(acc2[q], mmul(ap[4 + q], v[u + 1]));
+            }
+        }
+    }
+    for (; k < a.width; k++) {
+        const uint32_t v = col[(size_t)k * M];
         const uint32_t* ap = a.apow + 4 * (size_t)k;
 #pragma unroll
         for (int q = 0; q < 4; q++) acc[q] = madd(acc[q], mmul(ap[q], v));
     }
-    const Ext rrow{{acc[0], acc[1], acc[2], acc[3]}};
+    const Ext rrow{{madd(acc[0], acc2[0]), madd(acc[1], acc2[1]), madd(acc[2], acc2[2]), madd(acc[3], acc2[3])}};
     const uint32_t x = mmul(a.gen, root_pow(a.tw_fwd, a.tw_shift, a.h, bitrev32((uint32_t)r, a.h)));
     Ext out = ext_zero();
     if (a.accumulate) {
