@@ -188,7 +188,9 @@ __device__ __forceinline__ void dif_unit(uint32_t (&v)[16], const uint32_t* twl,
                 const int ka = blk * 2 * half + kl, kb = ka + half;
                 const uint32_t x = v[ka], y = v[kb];
                 v[ka] = madd(x, y);
-                v[kb] = mmul(msub(x, y), w);
+                // (x - y + p) is in (0, 2p) without a conditional; times w < p stays below the
+                // 2.417 p^2 limit of the lazy product, one conditional subtraction at the end
+                v[kb] = red_2p(mmul_lazy(x - y + P, w));
             }
         }
     }
@@ -213,14 +215,18 @@ __device__ __forceinline__ void lds_round(uint32_t* lv, const uint32_t* twl, uns
     }
 }
 
+// LOG_R / LOG_C != 0 fix the tile shape at compile time (address arithmetic folds, loops unroll);
+// <0,0> is the generic runtime-shaped variant.
+template <int LOG_R, int LOG_C>
 __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
     extern __shared__ uint32_t sm[];
-    const unsigned R = 1u << a.log_r;
-    const unsigned log_c = a.log_c, C = 1u << log_c, cmask = C - 1u, pitch = C + 1u;
+    const unsigned log_r = LOG_R ? (unsigned)LOG_R : a.log_r;
+    const unsigned R = 1u << log_r;
+    const unsigned log_c = LOG_C ? (unsigned)LOG_C : a.log_c, C = 1u << log_c, cmask = C - 1u, pitch = C + 1u;
     uint32_t* lv = sm;
     uint32_t* twl = sm + R * pitch;
     const unsigned tid = threadIdx.x, nt = blockDim.x;
-    for (unsigned e = tid; e < (R >> 1); e += nt) twl[e] = a.tw[(size_t)e << (a.tw_log - a.log_r)];
+    for (unsigned e = tid; e < (R >> 1); e += nt) twl[e] = a.tw[(size_t)e << (a.tw_log - log_r)];
     const unsigned col = blockIdx.y;
     const unsigned sub = col & ((1u << a.log_sub) - 1u);
     const size_t mcol = col >> a.log_sub;
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
     __syncthreads();
     // ---- round 1: radix-16 straight from HBM ----
     {
-        const unsigned log_rq = a.log_r - 4;
+        const unsigned log_rq = log_r - 4;
         for (unsigned u = tid; u < (R >> 4) * C; u += nt) {
             const unsigned c = u & cmask, j = u >> log_c;
             uint32_t v[16];
@@ -268,14 +274,14 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
     }
     __syncthreads();
     // ---- remaining stages out of LDS ----
-    unsigned log_rcur = a.log_r - 4;
+    unsigned log_rcur = log_r - 4;
     while (log_rcur > 0) {
         const unsigned q = log_rcur >= 4 ? 4 : log_rcur;
         switch (q) {
-            case 4: lds_round<4>(lv, twl, a.log_r, log_rcur, log_c, tid, nt); break;
-            case 3: lds_round<3>(lv, twl, a.log_r, log_rcur, log_c, tid, nt); break;
-            case 2: lds_round<2>(lv, twl, a.log_r, log_rcur, log_c, tid, nt); break;
-            default: lds_round<1>(lv, twl, a.log_r, log_rcur, log_c, tid, nt); break;
+            case 4: lds_round<4>(lv, twl, log_r, log_rcur, log_c, tid, nt); break;
+            case 3: lds_round<3>(lv, twl, log_r, log_rcur, log_c, tid, nt); break;
+            case 2: lds_round<2>(lv, twl, log_r, log_rcur, log_c, tid, nt); break;
+            default: lds_round<1>(lv, twl, log_r, log_rcur, log_c, tid, nt); break;
         }
         log_rcur -= q;
         __syncthreads();
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
     // ---- write-out: each tile column is one contiguous run of R words ----
     const unsigned lo_mask = (1u << a.log_lo) - 1u;
     for (unsigned e = tid; e < (R << log_c); e += nt) {
-        const unsigned c = e >> a.log_r, p = e & (R - 1u);
+        const unsigned c = e >> log_r, p = e & (R - 1u);
         const unsigned F = F0 + c;
         const size_t o = (size_t)X * a.out_x_stride + (size_t)(F >> a.log_lo) * a.out_hi_stride +
                          (size_t)(F & lo_mask) * a.out_lo_stride + p;
@@ -312,8 +318,10 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
                             unsigned log_sub, bool inverse) {
     static bool attr_set = false;
     if (!attr_set) {
-        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              ((17u << P4_MAX_LOG_R) + (1u << (P4_MAX_LOG_R - 1))) * 4));
+        const int lds_max = ((17u << P4_MAX_LOG_R) + (1u << (P4_MAX_LOG_R - 1))) * 4;
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4<11, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         attr_set = true;
     }
     const unsigned n_pass = std::max(2u, (log_n + p4_log_r_limit() - 1) / p4_log_r_limit());
@@ -346,7 +354,12 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         const size_t lds = ((size_t)R * (C + 1) + (R >> 1)) * 4;
         dim3 grid(n_x << (pa.log_f - pa.log_c), (unsigned)(width << log_sub));
         KernelScope ks(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd");
-        hipLaunchKernelGGL(k_ntt_pass4, grid, dim3(threads), lds, ctx->stream, pa);
+        if (pa.log_r == 11 && pa.log_c == 3)
+            hipLaunchKernelGGL((k_ntt_pass4<11, 3>), grid, dim3(threads), lds, ctx->stream, pa);
+        else if (pa.log_r == 10 && pa.log_c == 4)
+            hipLaunchKernelGGL((k_ntt_pass4<10, 4>), grid, dim3(threads), lds, ctx->stream, pa);
+        else
+            hipLaunchKernelGGL((k_ntt_pass4<0, 0>), grid, dim3(threads), lds, ctx->stream, pa);
         ZK_HIP_CHECK(ctx, hipGetLastError());
         return ZKHIP_OK;
     };
