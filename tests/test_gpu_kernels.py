@@ -44,7 +44,7 @@ def test_poseidon2_permutation_kat(zk, ora, kat):
 
 
 @pytest.mark.parametrize("log_n,width", [(0, 3), (1, 2), (3, 5), (8, 3), (10, 4), (11, 2), (12, 16), (13, 3),
-                                         (16, 2), (20, 1), (21, 2), (23, 1)])
+                                         (16, 2), (20, 1), (21, 2), (23, 1), (24, 1)])
 def test_ntt_forward_inverse(zk, ora, log_n, width):
     rng = np.random.default_rng(log_n * 100 + width)
     m = ora.rand_field(rng, (width, 1 << log_n))
@@ -86,7 +86,8 @@ def test_ntt_strided_columns(zk, ora):
 
 
 @pytest.mark.parametrize("log_n,added,width,shift", [(0, 1, 2, 31), (2, 1, 3, 31), (5, 2, 4, 31), (9, 1, 3, 31),
-                                                      (10, 1, 5, 31), (12, 1, 7, 31), (14, 1, 3, 7), (17, 1, 2, 31)])
+                                                      (10, 1, 5, 31), (12, 1, 7, 31), (13, 2, 3, 31), (14, 1, 3, 7), (17, 1, 2, 31),
+                                                      (22, 1, 1, 31), (23, 1, 1, 31)])
 def test_coset_lde(zk, ora, log_n, added, width, shift):
     rng = np.random.default_rng(log_n + 7 * width)
     m = ora.rand_field(rng, (width, 1 << log_n))

@@ -170,6 +170,12 @@ struct Pass4Args {
     int in_tw;
     unsigned log_prev, log_tt;
     uint32_t tw_a, tw_bx;
+    // first pass of an LDE's forward transform: read the coefficients where the inverse transform
+    // left them (bit-reversed order) and scale coefficient i by shift_sub^i / N on the way in
+    int br_src;
+    const uint32_t* scale_col;  // [2^log_sub][2^log_f]   N^-1 * s^F
+    const uint32_t* scale_row;  // [2^log_sub][2^(log_r-4)] s^(L*j), L = 2^log_f
+    const uint32_t* scale_rho;  // [2^log_sub]            s^(L * 2^(log_r-4))
 };
 
 template <int Q>
@@ -249,8 +255,28 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
         for (unsigned u = tid; u < (R >> 4) * C; u += nt) {
             const unsigned c = u & cmask, j = u >> log_c;
             uint32_t v[16];
+            if (a.br_src) {
+                // rows j + k*2^log_rq of tile column c sit in ONE 64-byte chunk of the bit-reversed
+                // coefficient array: run br(F) (2^log_r words), chunk br(j), word br4(k)
+                const uint32_t* run = a.src + mcol * a.src_col_stride + ((size_t)bitrev32(F0 + c, a.log_f) << log_r);
+                const uint4* ch = reinterpret_cast<const uint4*>(run + ((size_t)bitrev32(j, log_rq) << 4));
+                const uint4 q0 = ch[0], q1 = ch[1], q2 = ch[2], q3 = ch[3];
+                const uint32_t w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                                        q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = src[in_base + (size_t)(j + ((unsigned)k << log_rq)) * a.in_rs + c];
+                for (int k = 0; k < 16; k++) v[k] = w[((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3)];
+                uint32_t t = mmul(a.scale_col[((size_t)sub << a.log_f) + F0 + c], a.scale_row[((size_t)sub << log_rq) + j]);
+                const uint32_t rho = a.scale_rho[sub];
+                v[0] = mmul(v[0], t);
+#pragma unroll
+                for (int k = 1; k < 16; k++) {
+                    t = mmul(t, rho);
+                    v[k] = mmul(v[k], t);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) v[k] = src[in_base + (size_t)(j + ((unsigned)k << log_rq)) * a.in_rs + c];
+            }
             if (a.in_tw) {
                 const uint32_t mask = (a.log_tt >= 32) ? 0xffffffffu : ((1u << a.log_tt) - 1u);
                 const uint32_t kc = bitrev32(F0 + c, a.log_prev);
@@ -313,9 +339,20 @@ static unsigned p4_log_r_limit() {
 
 // src -> dst through tmp (and tmp2 for 3-pass sizes); dst may alias src.  Buffers hold `width`
 // columns of 2^log_sub transforms each, with the given column strides.
+struct BrSrc {
+    const uint32_t *scale_col, *scale_row, *scale_rho;
+};
+// stage split of the four-step passes
+static unsigned fourstep_split(unsigned log_n, unsigned a[3]) {
+    const unsigned n_pass = std::max(2u, (log_n + p4_log_r_limit() - 1) / p4_log_r_limit());
+    a[0] = a[1] = a[2] = 0;
+    for (unsigned p = 0; p < n_pass; p++) a[p] = log_n / n_pass + (p < log_n % n_pass ? 1 : 0);
+    return n_pass;
+}
+
 static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint32_t* dst, size_t dst_stride,
                             uint32_t* tmp, uint32_t* tmp2, size_t tmp_stride, unsigned log_n, size_t width,
-                            unsigned log_sub, bool inverse) {
+                            unsigned log_sub, bool inverse, const BrSrc* brsrc = nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
         const int lds_max = ((17u << P4_MAX_LOG_R) + (1u << (P4_MAX_LOG_R - 1))) * 4;
@@ -324,9 +361,8 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         attr_set = true;
     }
-    const unsigned n_pass = std::max(2u, (log_n + p4_log_r_limit() - 1) / p4_log_r_limit());
-    unsigned a[3] = {0, 0, 0};
-    for (unsigned p = 0; p < n_pass; p++) a[p] = log_n / n_pass + (p < log_n % n_pass ? 1 : 0);
+    unsigned a[3];
+    const unsigned n_pass = fourstep_split(log_n, a);
     const uint32_t* tw = inverse ? ctx->d_tw_inv : ctx->d_tw_fwd;
     auto launch = [&](Pass4Args& pa, const uint32_t* s, size_t ss, uint32_t* d, size_t ds, unsigned n_x) -> int {
         pa.src = s;
@@ -365,12 +401,20 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
     };
     Pass4Args pa;
     memset(&pa, 0, sizeof pa);
+    auto first_pass_src = [&]() {
+        if (brsrc) {
+            pa.br_src = 1;
+            pa.scale_col = brsrc->scale_col, pa.scale_row = brsrc->scale_row, pa.scale_rho = brsrc->scale_rho;
+        }
+    };
     if (n_pass == 2) {
         const unsigned a1 = a[0], a2 = a[1];
         // pass 1: digit d1 (rows), F = d2
         pa.log_r = a1, pa.log_f = a2, pa.in_x_stride = 0, pa.in_rs = (size_t)1 << a2;
         pa.out_x_stride = 0, pa.out_hi_stride = (size_t)1 << a1, pa.out_lo_stride = 0, pa.log_lo = 0, pa.in_tw = 0;
+        first_pass_src();
         ZK_TRY(launch(pa, src, src_stride, tmp, tmp_stride, 1));
+        pa.br_src = 0;
         // pass 2: digit d2 (rows), F = p1; twiddle w_M^(k1 * d2)
         pa.log_r = a2, pa.log_f = a1, pa.in_rs = (size_t)1 << a1, pa.out_hi_stride = (size_t)1 << a2;
         pa.in_tw = 1, pa.log_prev = a1, pa.log_tt = log_n, pa.tw_a = 1, pa.tw_bx = 0;
@@ -381,7 +425,9 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         pa.log_r = a1, pa.log_f = a2 + a3, pa.in_x_stride = 0, pa.in_rs = (size_t)1 << (a2 + a3);
         pa.out_x_stride = 0, pa.log_lo = a3, pa.out_lo_stride = (size_t)1 << (a1 + a2), pa.out_hi_stride = (size_t)1 << a1;
         pa.in_tw = 0;
+        first_pass_src();
         ZK_TRY(launch(pa, src, src_stride, tmp, tmp_stride, 1));
+        pa.br_src = 0;
         // pass 2: X = d3, rows d2, F = p1; twiddle w_M^(k1 * (d2*R3 + d3)); out (p1, d3, p2)
         pa.log_r = a2, pa.log_f = a1, pa.in_x_stride = (size_t)1 << (a1 + a2), pa.in_rs = (size_t)1 << a1;
         pa.out_x_stride = (size_t)1 << a2, pa.log_lo = 0, pa.out_lo_stride = 0, pa.out_hi_stride = (size_t)1 << (a2 + a3);
@@ -551,6 +597,32 @@ int ntt_bitrev_copy(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint
     return launch_bitrev(ctx, a, width);
 }
 
+// tables for the fused LDE path: coset c has shift s_c = shift * w_{n+a}^{bitrev_a(c)};
+//   col[c][F] = s_c^F / N (F < 2^log_f), row[c][j] = s_c^(j << log_f) (j < 2^log_rq), rho[c] = s_c^(1 << (log_f+log_rq))
+__global__ void k_gen_lde_scales(uint32_t* col, uint32_t* row, uint32_t* rho, uint32_t shift, uint32_t w_big,
+                                 uint32_t n_inv, unsigned log_cosets, unsigned log_f, unsigned log_rq) {
+    const size_t n_col = (size_t)1 << log_f, n_row = (size_t)1 << log_rq, n_co = (size_t)1 << log_cosets;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n_co * n_col) {
+        const unsigned c = (unsigned)(idx >> log_f);
+        const uint32_t s = mmul(shift, mpow(w_big, bitrev32(c, log_cosets)));
+        col[idx] = mmul(n_inv, mpow(s, idx & (n_col - 1)));
+        return;
+    }
+    idx -= n_co * n_col;
+    if (idx < n_co * n_row) {
+        const unsigned c = (unsigned)(idx >> log_rq);
+        const uint32_t s = mmul(shift, mpow(w_big, bitrev32(c, log_cosets)));
+        row[idx] = mpow(s, (uint64_t)(idx & (n_row - 1)) << log_f);
+        return;
+    }
+    idx -= n_co * n_row;
+    if (idx < n_co) {
+        const uint32_t s = mmul(shift, mpow(w_big, bitrev32((unsigned)idx, log_cosets)));
+        rho[idx] = mpow(s, (uint64_t)1 << (log_f + log_rq));
+    }
+}
+
 int ntt_batch(zkhip_ctx* ctx, uint32_t* d_mat, unsigned log_n, size_t width, size_t stride, bool inverse,
               bool bitrev_out) {
     if (width == 0) return ZKHIP_OK;
@@ -593,6 +665,36 @@ int lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* 
     void* coeffs;
     ZK_TRY(get_scratch(ctx, 0, n * width * 4, &coeffs));
     ZK_TRY(ntt_dif_inplace(ctx, d_in, in_stride, (uint32_t*)coeffs, n, log_n, width, 0, true));
+    if (log_n >= P4_MIN_LOG_M) {
+        // 2'. forward four-step straight from the bit-reversed coefficients: the first pass reads each
+        //     lane's 16 operands as one 64-byte chunk and applies shift_j^i / N as a geometric sequence
+        unsigned a[3];
+        fourstep_split(log_n, a);
+        const unsigned log_f = log_n - a[0], log_rq = a[0] - 4, n_co = 1u << added_bits;
+        const size_t n_col = (size_t)1 << log_f, n_row = (size_t)1 << log_rq;
+        void* tabs;
+        ZK_TRY(get_scratch(ctx, 1, (n_co * (n_col + n_row + 1)) * 4, &tabs));
+        uint32_t* d_col = (uint32_t*)tabs;
+        uint32_t* d_row = d_col + n_co * n_col;
+        uint32_t* d_rho = d_row + n_co * n_row;
+        {
+            KernelScope ks(ctx, "gen_coset_powers");
+            size_t cnt = n_co * (n_col + n_row + 1);
+            uint32_t n_inv = minv(to_monty((uint32_t)(n % P)));
+            hipLaunchKernelGGL(k_gen_lde_scales, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, d_col, d_row,
+                               d_rho, shift_monty, two_adic_generator(log_n + added_bits), n_inv, added_bits, log_f, log_rq);
+        }
+        ZK_HIP_CHECK(ctx, hipGetLastError());
+        BrSrc bs{d_col, d_row, d_rho};
+        const size_t per_col = n << added_bits;
+        const bool three = log_n > 2 * p4_log_r_limit();
+        void* tmp;
+        ZK_TRY(get_scratch(ctx, 4, per_col * width * 4 * (three ? 2 : 1), &tmp));
+        uint32_t* t1 = (uint32_t*)tmp;
+        uint32_t* t2 = three ? t1 + per_col * width : nullptr;
+        return ntt_dif_fourstep(ctx, (const uint32_t*)coeffs, n, d_out, out_stride, t1, t2, per_col, log_n, width, added_bits,
+                                false, &bs);
+    }
     // 2. per-coset power tables
     unsigned lb = (log_n + 1) / 2;
     unsigned per = (1u << lb) + (1u << (log_n - lb));
