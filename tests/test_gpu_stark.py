@@ -128,3 +128,17 @@ def test_jit_constraint_kernel_matches_interpreter_and_oracle(zk, ora, monkeypat
     monkeypatch.setenv("ZKHIP_NO_JIT", "1")
     got_int, _, _ = _prove_gpu(zk, params, airs)
     assert got_jit == exp and got_int == exp
+
+
+def test_tall_trace_three_pass_ntt_verifies(zk):
+    """2^23 rows (LDE height 2^24: the three-pass four-step path in both directions) x 24 columns."""
+    params = (1, 0, 20, 6, 6)
+    sa = air.SyntheticAir(width=24, n_free=8, n_bool=2, n_boundary=2, seed=33)
+    tr, pv = sa.gen_trace(23, seed=7, xp="torch", device="cuda")
+    airs = [dict(program=sa.program(), log_height=23, width=24, n_pvs=len(pv), pvs=pv)]
+    pk = z.ProvingKey(zk, params, airs)
+    d = tr.reshape(-1).contiguous()
+    del tr
+    zk._check(zk.lib.zkhip_to_monty(zk.h, d.data_ptr(), d.numel()))
+    proof = pk.prove([d], [pv])
+    assert z.verify(params, airs, [pv], proof) == 0
