@@ -142,3 +142,40 @@ def test_tall_trace_three_pass_ntt_verifies(zk):
     zk._check(zk.lib.zkhip_to_monty(zk.h, d.data_ptr(), d.numel()))
     proof = pk.prove([d], [pv])
     assert z.verify(params, airs, [pv], proof) == 0
+
+
+def test_full_size_chunk_workload_properties(zk):
+    """BASELINE's full size (2^22 x 300 + 2^22 x 2, reference FRI parameters): too big for the oracle,
+    so check size-independent properties -- the independent host verifier accepts; proving twice is
+    byte-identical; the trace commitment inside the proof equals a stand-alone LDE + Merkle commit of
+    the same traces through the stage-level ABI; a single flipped trace cell is caught."""
+    import torch
+
+    params = z.DEFAULT_PARAMS
+    log_n, width = 22, 300
+    sa = air.SyntheticAir(width=width, n_free=60, n_bool=15, n_boundary=7, seed=0)
+    tr, pv = sa.gen_trace(log_n, seed=77, xp="torch", device="cuda")
+    d = tr.reshape(-1).contiguous()
+    del tr
+    zk._check(zk.lib.zkhip_to_monty(zk.h, d.data_ptr(), d.numel()))
+    ftr, fpv = air.fibonacci_trace(log_n)
+    df = zk.upload(ftr.reshape(-1))
+    fa = air.fibonacci_air()
+    airs = [dict(program=sa.program(), log_height=log_n, width=width, n_pvs=len(pv)),
+            dict(program=fa.program(), log_height=log_n, width=2, n_pvs=3)]
+    pk = z.ProvingKey(zk, params, airs)
+    proof = pk.prove([d, df], [pv, fpv])
+    assert len(proof) == pk.proof_size == 1130012
+    assert z.verify(params, airs, [pv, fpv], proof) == 0
+    assert pk.prove([d, df], [pv, fpv]) == proof
+    # commitment cross-check through zkhip_lde_batch + zkhip_merkle_commit
+    lde_a = zk.lde_batch(d, log_n, 1, width, 31)
+    lde_b = zk.lde_batch(df, log_n, 1, 2, 31)
+    root = zk.merkle_commit([(lde_a, log_n + 1, width), (lde_b, log_n + 1, 2)]).root
+    assert np.frombuffer(proof, dtype=np.uint32)[4:12].tolist() == root.tolist()
+    del lde_a, lde_b
+    # flip one cell of one column in the middle of the trace
+    cell = 137 * (1 << log_n) + 1234567
+    d[cell] = (int(d[cell]) + 1) % z.P
+    bad = pk.prove([d, df], [pv, fpv])
+    assert z.verify(params, airs, [pv, fpv], bad) != 0
