@@ -118,6 +118,25 @@ void zkhip_tree_destroy(zkhip_ctx *ctx, zkhip_tree *tree);
 int zkhip_fri_fold(zkhip_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, unsigned log_n_out,
                    const uint32_t beta[4]);
 
+/* ---- LogUp and sum-check building blocks (K6, K7 of SURVEY.md 2.3; a7.4 of 8(a)): the
+ *      protocol-independent kernels under the pinned backend's LogUp / zero-check / stacking
+ *      sum-checks.  All buffers are device, Montgomery; extension elements are 4 words. ---- */
+/* out[i] = 1 / in[i] for n extension elements (Montgomery batch inversion; no element may be 0) */
+int zkhip_ext_batch_inverse(zkhip_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, size_t n);
+/* LogUp running sum: out[i] = sum_{j<=i} num[j] / den[j]; den = n extension elements, num = n
+ * base-field multiplicities; total (the cumulative sum, 4 canonical words) goes to the HOST
+ * buffer total_out when it is not NULL (synchronises) */
+int zkhip_logup_running_sum(zkhip_ctx *ctx, const uint32_t *d_den, const uint32_t *d_num, size_t n,
+                            uint32_t *d_out, uint32_t *total_out);
+/* Fix the LOWEST variable of a multilinear table of 2n extension evaluations to r:
+ * out[i] = in[2i] + r * (in[2i+1] - in[2i]); r = 4 canonical words (host) */
+int zkhip_mle_fold(zkhip_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, size_t n, const uint32_t r[4]);
+/* One sum-check round for the product of k multilinear tables (each 2*n_half extension
+ * evaluations, lowest variable = adjacent pairs): out[t] = sum_i prod_j (f_j[2i] + t*(f_j[2i+1]-f_j[2i]))
+ * for t = 0..k.  out = (k+1)*4 canonical words on the HOST (synchronises).  1 <= k <= 4. */
+int zkhip_sumcheck_round(zkhip_ctx *ctx, const uint32_t *const *d_tables, size_t k, size_t n_half,
+                         uint32_t *out);
+
 /* ---- transcript (T4) and proof-of-work (K9), device resident ---- */
 typedef struct zkhip_transcript zkhip_transcript;
 int zkhip_transcript_create(zkhip_ctx *ctx, zkhip_transcript **out);

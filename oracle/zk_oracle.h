@@ -116,6 +116,12 @@ int ora_ch_check_witness(ora_challenger *c, unsigned bits, uint32_t witness);
 /* in: 2*n ext elements (bit-reversed domain order), out: n ext elements */
 void ora_fri_fold(const uint32_t *in, uint32_t *out, unsigned log_n_out, const uint32_t beta[4]);
 
+/* ---- LogUp / sum-check building blocks (oracle/sumcheck.c) ---- */
+void ora_ext_batch_inverse(const uint32_t *in, uint32_t *out, size_t n);
+void ora_logup_running_sum(const uint32_t *den, const uint32_t *num, size_t n, uint32_t *out);
+void ora_mle_fold(const uint32_t *in, uint32_t *out, size_t n, const uint32_t r[4]);
+void ora_sumcheck_round(const uint32_t *const *tables, size_t k, size_t n_half, uint32_t *out);
+
 /* ---- full STARK (see oracle/stark.c) ---- */
 typedef struct {
     unsigned log_blowup;        /* 1  (openvm.toml:2) */

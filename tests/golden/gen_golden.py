@@ -71,6 +71,19 @@ for log_n_out in (0, 1, 3, 5):
     beta = rf(4)
     out["fri_fold"].append({"log_n_out": log_n_out, "in": vals, "beta": beta, "out": m.fri_fold(vals, beta)})
 
+# LogUp / sum-check building blocks (appended last so the earlier vectors keep their random stream)
+den = [rf(4) for _ in range(37)]
+num = rf(37)
+out["ext_batch_inverse"] = [[d, m.ext_inv(d)] for d in den[:9]]
+out["logup_running_sum"] = {"den": den, "num": num, "out": m.logup_running_sum(den, num)}
+fv = [rf(4) for _ in range(32)]
+fr = rf(4)
+out["mle_fold"] = {"in": fv, "r": fr, "out": m.mle_fold(fv, fr)}
+out["sumcheck_round"] = []
+for k in (1, 2, 3, 4):
+    tabs = [[rf(4) for _ in range(16)] for _ in range(k)]
+    out["sumcheck_round"].append({"tables": tabs, "out": m.sumcheck_round(tabs)})
+
 with open(os.path.join(HERE, "kat_v1.json"), "w") as f:
     json.dump(out, f, separators=(",", ":"))
 print("wrote kat_v1.json", os.path.getsize(os.path.join(HERE, "kat_v1.json")), "bytes")

@@ -82,6 +82,10 @@ def lib():
         l.ora_ch_grind.restype = C.c_uint32
         l.ora_ch_grind.argtypes = [C.POINTER(OraChallenger), C.c_uint]
         l.ora_fri_fold.argtypes = [u32p, u32p, C.c_uint, u32p]
+        l.ora_ext_batch_inverse.argtypes = [u32p, u32p, sz]
+        l.ora_logup_running_sum.argtypes = [u32p, u32p, sz, u32p]
+        l.ora_mle_fold.argtypes = [u32p, u32p, sz, u32p]
+        l.ora_sumcheck_round.argtypes = [C.POINTER(u32p), sz, sz, u32p]
         if hasattr(l, "ora_stark_prove"):
             l.ora_stark_prove.restype = sz
             l.ora_stark_prove.argtypes = [C.POINTER(OraParams), C.POINTER(OraAir), sz, u32p, sz]
@@ -213,3 +217,34 @@ def stark_verify(params, airs, proof):
     arr, keep = _air_array(airs)
     pr = np.ascontiguousarray(proof, dtype=np.uint32)
     return lib().ora_stark_verify(C.byref(prm), arr, len(airs), p32(pr), pr.size)
+
+
+
+def ext_batch_inverse(vals):
+    a = np.ascontiguousarray(vals, dtype=np.uint32).reshape(-1)
+    out = np.zeros_like(a)
+    lib().ora_ext_batch_inverse(p32(a), p32(out), a.size // 4)
+    return out
+
+
+def logup_running_sum(den, num):
+    d = np.ascontiguousarray(den, dtype=np.uint32).reshape(-1)
+    m = np.ascontiguousarray(num, dtype=np.uint32)
+    out = np.zeros_like(d)
+    lib().ora_logup_running_sum(p32(d), p32(m), m.size, p32(out))
+    return out
+
+
+def mle_fold(vals, r):
+    a = np.ascontiguousarray(vals, dtype=np.uint32).reshape(-1)
+    out = np.zeros(a.size // 2, dtype=np.uint32)
+    lib().ora_mle_fold(p32(a), p32(out), a.size // 8, p32(np.asarray(r, dtype=np.uint32)))
+    return out
+
+
+def sumcheck_round(tables):
+    tabs = [np.ascontiguousarray(t, dtype=np.uint32).reshape(-1) for t in tables]
+    arr = (C.POINTER(C.c_uint32) * len(tabs))(*[p32(t) for t in tabs])
+    out = np.zeros(4 * (len(tabs) + 1), dtype=np.uint32)
+    lib().ora_sumcheck_round(arr, len(tabs), tabs[0].size // 8, p32(out))
+    return out

@@ -235,3 +235,41 @@ def fri_fold(vals, beta):
         t = ext_mul(bx, d)
         out.append([(e0[k] + t[k]) % P for k in range(4)])
     return out
+
+
+# ---- LogUp / sum-check building blocks ------------------------------------------------------------
+def ext_add(a, b):
+    return [(x + y) % P for x, y in zip(a, b)]
+
+
+def logup_running_sum(den, num):
+    acc, out = [0, 0, 0, 0], []
+    for d, m in zip(den, num):
+        inv_d = ext_inv(d)
+        acc = ext_add(acc, [x * m % P for x in inv_d])
+        out.append(acc)
+    return out
+
+
+def mle_fold(vals, r):
+    out = []
+    for i in range(len(vals) // 2):
+        a, b = vals[2 * i], vals[2 * i + 1]
+        t = ext_mul(r, [(y - x) % P for x, y in zip(a, b)])
+        out.append(ext_add(a, t))
+    return out
+
+
+def sumcheck_round(tables):
+    k, n_half = len(tables), len(tables[0]) // 2
+    out = []
+    for t in range(k + 1):
+        acc = [0, 0, 0, 0]
+        for i in range(n_half):
+            prod = [1, 0, 0, 0]
+            for f in tables:
+                a, b = f[2 * i], f[2 * i + 1]
+                prod = ext_mul(prod, [(x + t * (y - x)) % P for x, y in zip(a, b)])
+            acc = ext_add(acc, prod)
+        out.append(acc)
+    return out

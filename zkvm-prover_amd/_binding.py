@@ -81,6 +81,10 @@ def load_library():
         "zkhip_merkle_open": (C.c_int, [vp, vp, C.POINTER(C.c_uint64), sz, u32p, sz]),
         "zkhip_tree_destroy": (None, [vp, vp]),
         "zkhip_fri_fold": (C.c_int, [vp, vp, vp, C.c_uint, u32p]),
+        "zkhip_ext_batch_inverse": (C.c_int, [vp, vp, vp, sz]),
+        "zkhip_logup_running_sum": (C.c_int, [vp, vp, vp, sz, vp, u32p]),
+        "zkhip_mle_fold": (C.c_int, [vp, vp, vp, sz, u32p]),
+        "zkhip_sumcheck_round": (C.c_int, [vp, C.POINTER(vp), sz, sz, u32p]),
         "zkhip_transcript_create": (C.c_int, [vp, C.POINTER(vp)]),
         "zkhip_transcript_destroy": (None, [vp, vp]),
         "zkhip_transcript_observe": (C.c_int, [vp, vp, u32p, sz]),
@@ -203,6 +207,37 @@ class Context:
 
     def transcript(self):
         return Transcript(self)
+
+    # ---- LogUp / sum-check building blocks (K6, K7) ----------------------------------------------
+    def ext_batch_inverse(self, t_in, n):
+        import torch
+
+        out = torch.empty(4 * n, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_ext_batch_inverse(self.h, C.c_void_p(t_in.data_ptr()), C.c_void_p(out.data_ptr()), n))
+        return out
+
+    def logup_running_sum(self, t_den, t_num, n):
+        import torch
+
+        out = torch.empty(4 * n, dtype=torch.int32, device=self.device)
+        total = np.zeros(4, dtype=np.uint32)
+        self._check(self.lib.zkhip_logup_running_sum(self.h, C.c_void_p(t_den.data_ptr()), C.c_void_p(t_num.data_ptr()),
+                                                     n, C.c_void_p(out.data_ptr()), _u32p(total)))
+        return out, total
+
+    def mle_fold(self, t_in, n, r):
+        import torch
+
+        out = torch.empty(4 * n, dtype=torch.int32, device=self.device)
+        rr = np.asarray(r, dtype=np.uint32)
+        self._check(self.lib.zkhip_mle_fold(self.h, C.c_void_p(t_in.data_ptr()), C.c_void_p(out.data_ptr()), n, _u32p(rr)))
+        return out
+
+    def sumcheck_round(self, tables, n_half):
+        arr = (C.c_void_p * len(tables))(*[t.data_ptr() for t in tables])
+        out = np.zeros(4 * (len(tables) + 1), dtype=np.uint32)
+        self._check(self.lib.zkhip_sumcheck_round(self.h, arr, len(tables), n_half, _u32p(out)))
+        return out
 
     # ---- profiling -----------------------------------------------------------------------------
     def profile_enable(self, on=True):
