@@ -306,8 +306,10 @@ __global__ __launch_bounds__(256) void k_reduced_openings(ReduceArgs a) {
     const size_t M = (size_t)1 << a.h;
     size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= M) return;
-    // two independent accumulator sets and an 8-deep unroll keep 8 column loads in flight per lane
-    uint32_t acc[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
+    // sum_k apow[k] * mat[k][r]: products of residues are summed in 64 bits, four at a time
+    // (4 p^2 < 2^64), and Montgomery-reduced once per group -- 4 v_mad_u64_u32 per column instead of
+    // 4 full modular multiply-adds; 8 column loads are in flight per lane
+    uint32_t acc[4] = {0, 0, 0, 0};
     const uint32_t* col = a.mat + r;
     uint32_t k = 0;
     for (; k + 8 <= a.width; k += 8) {
@@ -315,13 +317,16 @@ __global__ __launch_bounds__(256) void k_reduced_openings(ReduceArgs a) {
 #pragma unroll
         for (int u = 0; u < 8; u++) v[u] = col[(size_t)(k + u) * M];
 #pragma unroll
-        for (int u = 0; u < 8; u += 2) {
-            const uint32_t* ap = a.apow + 4 * (size_t)(k + u);
+        for (int g = 0; g < 8; g += 4) {
+            uint64_t t[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                acc[q] = madd(acc[q], mmul(ap[q], v[u]));
-                acc2[q] = madd(acc2[q], mmul(ap[4 + q], v[u + 1]));
+            for (int u = 0; u < 4; u++) {
+                const uint32_t* ap = a.apow + 4 * (size_t)(k + g + u);
+#pragma unroll
+                for (int q = 0; q < 4; q++) t[q] += (uint64_t)ap[q] * v[g + u];
             }
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[q] = madd(acc[q], mred64(t[q]));
         }
     }
     for (; k < a.width; k++) {
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(256) void k_reduced_openings(ReduceArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; q++) acc[q] = madd(acc[q], mmul(ap[q], v));
     }
-    const Ext rrow{{madd(acc[0], acc2[0]), madd(acc[1], acc2[1]), madd(acc[2], acc2[2]), madd(acc[3], acc2[3])}};
+    const Ext rrow{{acc[0], acc[1], acc[2], acc[3]}};
     const uint32_t x = mmul(a.gen, root_pow(a.tw_fwd, a.tw_shift, a.h, bitrev32((uint32_t)r, a.h)));
     Ext out = ext_zero();
     if (a.accumulate) {

@@ -73,10 +73,20 @@ typedef const __attribute__((address_space(1))) uint32_t* gptr;
 // trace cell (column c, this / next row): uniform column base (scalar) + 32-bit per-lane byte offset
 #define LD(c, off) (*(gptr)((const __attribute__((address_space(1))) char*)(ldep + (size_t)(c) * M) + (off)))
 #define PV(i) ((cptr)pvs)[i]
+__device__ __forceinline__ uint32_t mred64(uint64_t t) {
+    uint32_t m = (uint32_t)t * NEG_MU;
+    uint64_t s = (uint64_t)(uint32_t)t + (uint64_t)m * P;
+    uint64_t r = (t >> 32) + (s >> 32);
+    if (r >= 2ull * P) r -= 2ull * P;
+    return red((uint32_t)r);
+}
+// acc += alpha^(n-1-k) * v.  The four coefficient products are summed in 64 bits over four
+// constraints (4 p^2 < 2^64) and Montgomery-reduced once per group.
+#define FLUSH { acc0 = madd(acc0, mred64(w0)); acc1 = madd(acc1, mred64(w1)); acc2 = madd(acc2, mred64(w2)); \
+    acc3 = madd(acc3, mred64(w3)); w0 = w1 = w2 = w3 = 0; cnt = 0; }
 #define ACC(k, v) { const uint32_t _v = (v); cptr ap = (cptr)apow + 4 * (k); \
-    acc0 = madd(acc0, mmul(ap[0], _v)); acc1 = madd(acc1, mmul(ap[1], _v)); \
-    acc2 = madd(acc2, mmul(ap[2], _v)); acc3 = madd(acc3, mmul(ap[3], _v)); }
-
+    w0 += (uint64_t)ap[0] * _v; w1 += (uint64_t)ap[1] * _v; w2 += (uint64_t)ap[2] * _v; w3 += (uint64_t)ap[3] * _v; \
+    if (++cnt == 4) FLUSH }
 )JIT";
 }
 
@@ -177,6 +187,8 @@ extern "C" __global__ __launch_bounds__(256) void quot_jit(const uint32_t* __res
     const uint32_t sel_trans = msub(x, w_n_inv);
     const uint32_t sel_last = mmul(zh, minv(sel_trans));
     uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    uint32_t cnt = 0;
     const uint32_t ro = r << 2, rno = rn << 2;
     const gptr ldep = (gptr)lde;
 )JIT";
@@ -213,6 +225,7 @@ extern "C" __global__ __launch_bounds__(256) void quot_jit(const uint32_t* __res
         os << "        ACC(pr[0], e" << (C.entries.size() - 1) << ")\n    }\n";
     }
     os << R"JIT(
+    FLUSH
     const uint32_t izh = inv_zh_t[i & ((1u << B) - 1u)];
     q[r] = mmul(acc0, izh);
     q[M + r] = mmul(acc1, izh);
