@@ -588,7 +588,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     for (size_t a = 0; a < n_airs; a++) {
         AirPlan& A = pk->airs[a];
         if (compile_air(A.prog, &comp[a], &err) != 0) {
-            delete pk;
+            zkhip_pk_destroy(ctx, pk);  // also unloads the modules of the AIRs already compiled
             return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + ": " + err);
         }
         A.n_instr = (uint32_t)(comp[a].code.size() / 3);
@@ -641,7 +641,8 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     size_t o_proof = bp.take(pk->proof_words * 4);
     pk->ws_bytes = bp.off;
     if (hipMalloc(&pk->d_ws, pk->ws_bytes) != hipSuccess) {
-        delete pk;
+        pk->d_ws = nullptr;
+        zkhip_pk_destroy(ctx, pk);
         return set_error(ctx, ZKHIP_ERR_NOMEM, "workspace of " + std::to_string(bp.off) + " bytes");
     }
     char* base = (char*)pk->d_ws;

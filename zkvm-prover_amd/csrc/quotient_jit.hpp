@@ -12,6 +12,7 @@
 #include <hip/hiprtc.h>
 
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <utility>
@@ -244,27 +245,41 @@ inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModu
     std::vector<JitClass> classes;
     if (!quot_jit_classify(p, &classes, msg)) return false;
     std::string src = quot_jit_source(p, lh, b, classes, table);
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "quot_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
-        *msg = "hiprtcCreateProgram failed";
-        return false;
+    // process-wide cache of compiled code objects keyed by the generated source: several contexts
+    // (one per HIP stream) and repeated keygens of the same AIR share one hipRTC compile
+    static std::mutex cache_mu;
+    static std::map<std::string, std::vector<char>> cache;
+    std::vector<char> code;
+    {
+        std::lock_guard<std::mutex> lk(cache_mu);
+        auto it = cache.find(src);
+        if (it != cache.end()) code = it->second;
     }
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off"};
-    hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
-    if (rc != HIPRTC_SUCCESS) {
-        size_t ls = 0;
-        hiprtcGetProgramLogSize(prog, &ls);
-        std::string log(ls, 0);
-        if (ls) hiprtcGetProgramLog(prog, &log[0]);
-        *msg = "hiprtc compile failed: " + log.substr(0, 2000);
+    if (code.empty()) {
+        hiprtcProgram prog;
+        if (hiprtcCreateProgram(&prog, src.c_str(), "quot_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+            *msg = "hiprtcCreateProgram failed";
+            return false;
+        }
+        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off"};
+        hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
+        if (rc != HIPRTC_SUCCESS) {
+            size_t ls = 0;
+            hiprtcGetProgramLogSize(prog, &ls);
+            std::string log(ls, 0);
+            if (ls) hiprtcGetProgramLog(prog, &log[0]);
+            *msg = "hiprtc compile failed: " + log.substr(0, 2000);
+            hiprtcDestroyProgram(&prog);
+            return false;
+        }
+        size_t cs = 0;
+        hiprtcGetCodeSize(prog, &cs);
+        code.resize(cs);
+        hiprtcGetCode(prog, code.data());
         hiprtcDestroyProgram(&prog);
-        return false;
+        std::lock_guard<std::mutex> lk(cache_mu);
+        cache[src] = code;
     }
-    size_t cs = 0;
-    hiprtcGetCodeSize(prog, &cs);
-    std::vector<char> code(cs);
-    hiprtcGetCode(prog, code.data());
-    hiprtcDestroyProgram(&prog);
     if (hipModuleLoadData(mod, code.data()) != hipSuccess) {
         *msg = "hipModuleLoadData failed";
         return false;
