@@ -45,3 +45,26 @@ def test_unsatisfied_witness_fails_self_verification(tmp_path):
     task = pm.write_task(str(tmp_path), airs)
     r = pm.run_cli("prove", exe, cfg, task, str(tmp_path / "o.json"))
     assert r.returncode == 1 and "kind 4" in r.stderr  # Error::VerifyProof from the mandatory self-check
+
+
+def test_prove_many_reuses_keys_and_survives_reset(ora, tmp_path):
+    """Three tasks through ONE Prover (the reference's multi-chunk test shape): same app, different
+    witnesses and even different trace heights (keys are re-planned), reset() in between."""
+    tasks, all_airs = [], []
+    for i, (lh_a, lh_b) in enumerate([(7, 5), (7, 5), (6, 4)]):
+        sa = air.SyntheticAir(width=20, n_free=7, n_bool=3, n_boundary=2, seed=9)
+        tr, pv = sa.gen_trace(lh_a, seed=10 + i)
+        fa = air.fibonacci_air()
+        ftr, fpv = air.fibonacci_trace(lh_b, a0=i)
+        airs = [dict(program=sa.program(), log_height=lh_a, width=20, n_pvs=len(pv), trace=tr, pvs=pv),
+                dict(program=fa.program(), log_height=lh_b, width=2, n_pvs=3, trace=ftr, pvs=fpv)]
+        all_airs.append(airs)
+        d = tmp_path / ("t%d" % i)
+        d.mkdir()
+        tasks.append(pm.write_task(str(d), airs, identifier="chunk-%d" % i))
+    exe, cfg = pm.write_app(str(tmp_path), all_airs[0], PARAMS)
+    r = pm.run_cli("prove-many", exe, cfg, str(tmp_path), *tasks)
+    assert r.returncode == 0, r.stderr
+    for i, airs in enumerate(all_airs):
+        js = json.loads((tmp_path / ("chunk-%d.json" % i)).read_text())
+        assert pm.un_b64_bincode(js["proof"]) == ora.stark_prove(PARAMS, airs).tobytes()

@@ -53,7 +53,34 @@ int main(int argc, char** argv) {
                         (unsigned long long)sp.stat.proving_time_mills);
             return 0;
         }
-        std::fprintf(stderr, "usage: prove_cli prove|verify ...\n");
+        if (argc >= 6 && std::string(argv[1]) == "prove-many") {
+            // prove-many <app> <cfg> <out_dir> <task.bin>...  : one Prover, keys reused across tasks, like the
+            // reference's multi-chunk test (crates/integration/tests/chunk_circuit.rs:198-208); reset() in between
+            // every second task exercises Prover::reset (mod.rs:106-108)
+            Prover prover = Prover::setup(ProverConfig{argv[2], argv[3]}, "cli");
+            for (int i = 5; i < argc; i++) {
+                auto tb = slurp(argv[i]);
+                ProvingTask task;
+                size_t p = 0;
+                auto rd32 = [&]() { uint32_t v; memcpy(&v, &tb[p], 4); p += 4; return v; };
+                auto rd64 = [&]() { uint64_t v; memcpy(&v, &tb[p], 8); p += 8; return v; };
+                uint32_t idl = rd32();
+                task.identifier.assign((const char*)&tb[p], idl);
+                p += idl;
+                uint32_t n = rd32();
+                for (uint32_t k = 0; k < n; k++) {
+                    uint64_t len = rd64();
+                    task.serialized_witness.emplace_back(tb.begin() + p, tb.begin() + p + len);
+                    p += len;
+                }
+                StarkProof sp = prover.gen_proof_universal(task, false);
+                std::ofstream(std::string(argv[4]) + "/" + task.identifier + ".json") << sp.to_json();
+                std::printf("proved %s: proving %llu ms\n", task.identifier.c_str(), (unsigned long long)sp.stat.proving_time_mills);
+                if ((i - 5) % 2 == 1) prover.reset();
+            }
+            return 0;
+        }
+        std::fprintf(stderr, "usage: prove_cli prove|prove-many|verify ...\n");
         return 2;
     } catch (const Error& e) {
         std::fprintf(stderr, "error(kind %d): %s\n", (int)e.kind, e.what());

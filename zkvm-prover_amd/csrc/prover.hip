@@ -593,8 +593,11 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         }
         A.n_instr = (uint32_t)(comp[a].code.size() / 3);
         A.n_slots = comp[a].n_slots;
-        // keygen-time compiled constraint kernel (ZKHIP_NO_JIT=1 keeps the interpreter)
-        if (!getenv("ZKHIP_NO_JIT")) {
+        // keygen-time compiled constraint kernel when the evaluation is large enough to repay the
+        // ~2-4 s hipRTC compile (2^26 row-instructions ~ a few ms of interpreter time per proof);
+        // ZKHIP_FORCE_JIT=1 / ZKHIP_NO_JIT=1 override
+        const bool big = (double)((size_t)1 << (airs[a].log_height + pk->b)) * (double)A.n_instr >= (double)(1ull << 26);
+        if ((big || getenv("ZKHIP_FORCE_JIT")) && !getenv("ZKHIP_NO_JIT")) {
             std::string msg;
             std::vector<uint32_t> tab;
             if (quot_jit_build(A.prog, airs[a].log_height, pk->b, &A.jit_mod, &A.jit_fn, &tab, &msg) &&
