@@ -179,3 +179,77 @@ def test_full_size_chunk_workload_properties(zk):
     d[cell] = (int(d[cell]) + 1) % z.P
     bad = pk.prove([d, df], [pv, fpv])
     assert z.verify(params, airs, [pv, fpv], bad) != 0
+
+
+def _random_air(rng, width, n_pvs, n_nodes, n_cons):
+    """Random constraint DAG of degree <= 3 using every node kind (shared sub-expressions, NEG,
+    selectors, public values, constants, both rotations).  The trace need not satisfy it: proof
+    bytes are compared with the oracle's, which proves whatever it is given."""
+    b = air.AirBuilder(width, n_pvs)
+    pool = []  # (expr, degree)
+
+    def leaf():
+        k = rng.integers(0, 7)
+        if k <= 2:
+            return b.var(int(rng.integers(0, width)), int(rng.integers(0, 2))), 1
+        if k == 3 and n_pvs:
+            return b.pub(int(rng.integers(0, n_pvs))), 0
+        if k == 4:
+            return b.const(int(rng.integers(0, air.P))), 0
+        if k == 5:
+            return [(b.is_first_row(), 1), (b.is_last_row(), 1), (b.is_transition(), 0)][int(rng.integers(0, 3))]
+        return b.var(int(rng.integers(0, width))), 1
+
+    for _ in range(n_nodes):
+        x, dx = pool[int(rng.integers(0, len(pool)))] if pool and rng.random() < 0.7 else leaf()
+        y, dy = pool[int(rng.integers(0, len(pool)))] if pool and rng.random() < 0.5 else leaf()
+        op = rng.integers(0, 4)
+        if op == 0:
+            pool.append((x + y, max(dx, dy)))
+        elif op == 1:
+            pool.append((x - y, max(dx, dy)))
+        elif op == 2 and dx + dy <= 3:
+            pool.append((x * y, dx + dy))
+        else:
+            pool.append((-x, dx))
+    for _ in range(n_cons):
+        b.assert_zero(pool[int(rng.integers(0, len(pool)))][0])
+    # a leaf used directly as a constraint, and a repeated constraint
+    b.assert_zero(b.var(0))
+    b.assert_zero(pool[-1][0])
+    b.assert_zero(pool[-1][0])
+    assert b.max_degree() <= 3
+    return b
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("jit", ["interpreter", "jit"])
+def test_random_constraint_dags_match_oracle(zk, ora, seed, jit, monkeypatch):
+    rng = np.random.default_rng(seed)
+    width, n_pvs, log_n = int(rng.integers(1, 9)), int(rng.integers(0, 4)), int(rng.integers(2, 7))
+    b = _random_air(rng, width, n_pvs, n_nodes=int(rng.integers(5, 60)), n_cons=int(rng.integers(1, 12)))
+    trace = ora.rand_field(rng, (width, 1 << log_n))
+    pvs = ora.rand_field(rng, n_pvs)
+    airs = [dict(program=b.program(), log_height=log_n, width=width, n_pvs=n_pvs, trace=trace, pvs=pvs), _fib(3)]
+    params = (1, 0, 4, 2, 2)
+    exp = ora.stark_prove(params, airs).tobytes()
+    monkeypatch.setenv("ZKHIP_NO_JIT" if jit == "interpreter" else "ZKHIP_FORCE_JIT", "1")
+    got, _, _ = _prove_gpu(zk, params, airs)
+    assert got == exp
+
+
+def test_many_chips_with_distinct_heights(zk, ora):
+    """Ten AIRs with ten different trace heights (the shape of a real VM segment: 42 chips of
+    very different sizes, AGENTS.md:183-185): every Merkle level from 2^12 down gets an injection,
+    FRI mixes a reduced-opening vector into ten successive layers."""
+    airs = []
+    for i, lh in enumerate([11, 3, 7, 10, 2, 5, 9, 4, 8, 6]):
+        if i % 3 == 2:
+            airs.append(_fib(lh))
+        else:
+            airs.append(_syn(lh, 9 + 5 * (i % 4), 5, 40 + i, n_bool=2, n_boundary=2))
+    params = (1, 0, 12, 3, 4)
+    exp = ora.stark_prove(params, airs).tobytes()
+    got, _, _ = _prove_gpu(zk, params, airs)
+    assert got == exp
+    assert z.verify(params, airs, [a["pvs"] for a in airs], got) == 0
