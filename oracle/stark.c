@@ -5,9 +5,10 @@
  * What it restates: the STARK the reference obtains from `sdk.prove(..)`
  * (crates/prover/src/prover/mod.rs:355-357) in the shape BASELINE.json's
  * north_star names -- trace commit -> coset LDE -> Merkle-Poseidon2 commit ->
+ * [bus interactions: LogUp after-challenge trace + commit] ->
  * constraint/quotient evaluation -> FRI fold loop with PoW and queries -- i.e.
  * the published Plonky3 uni-stark + TwoAdicFriPcs pipeline (multi-matrix,
- * mixed heights) with the FRI parameters of
+ * mixed heights, OpenVM-v1-style LogUp phase) with the FRI parameters of
  * crates/circuits/chunk-circuit/openvm.toml:1-6.  The exact transcript / proof
  * layout of the pinned OpenVM v2 backend (openvm-stark-backend 2.0.0,
  * Cargo.lock:5337) is NOT available offline (SURVEY.md finding 2, 8c); the
@@ -17,20 +18,30 @@
  * AIR bytecode (u32 words, all < p):
  *   [0x31414B5A, n_nodes, n_constraints, n_pvs]
  *   n_nodes x [op, a, b]   ops: 0 VAR(col a, rotation b in {0,1})  1 PUB(a)
- *                               2 CONST(a) 3 IS_FIRST 4 IS_LAST 5 IS_TRANSITION
- *                               6 ADD(a,b) 7 SUB(a,b) 8 MUL(a,b) 9 NEG(a)
+ *        2 CONST(a) 3 IS_FIRST 4 IS_LAST 5 IS_TRANSITION
+ *        6 ADD(a,b) 7 SUB(a,b) 8 MUL(a,b) 9 NEG(a)
+ *        10 PERM(col a, rotation b)  11 CHAL(a)  12 EXPOSED(a)   (LogUp phase leaves)
  *   n_constraints x node index (asserted zero on every row)
+ *   optional: [0x554C4B5A, n_int, n_int x {bus, sign, count leaf[3], n_fields, field leaf[3]...}]
+ * LogUp phase: challenges gamma, beta (extension); chal vector = gamma, beta^1..beta^8 as
+ * 36 base coordinates; interaction j contributes phi_j = (+/-)count / (gamma + bus + 1 +
+ * sum_i beta^(i+1) f_i); the permutation matrix holds phi_j (4 base columns each) and the
+ * running sum of sum_j phi_j over the rows (last 4 columns); the final sum is EXPOSED and the
+ * exposed sums of all AIRs must add up to zero.
  */
 #include <stdlib.h>
 #include <string.h>
 #include "zk_oracle.h"
 
 #define AIR_MAGIC 0x31414B5Au
+#define LOGUP_MAGIC 0x554C4B5Au
 #define PROOF_MAGIC 0x31504B5Au
 #define PROTO_TAG 0x5A4B4831u /* "1HKZ" < p */
 #define GEN 31u
+#define MAX_FIELDS 8
+#define N_CHAL (4 * (1 + MAX_FIELDS))
 
-enum { OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG };
+enum { OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_PERM, OP_CHAL, OP_EXPOSED };
 
 typedef uint32_t ext_t[4];
 
@@ -66,20 +77,62 @@ static void ext_pow(const ext_t a, uint64_t e, ext_t o) {
 
 /* ---------------------------------------------------------------- program */
 typedef struct {
-    const uint32_t *w;
+    uint32_t bus, sign;
+    uint32_t count[3];
+    uint32_t n_fields;
+    uint32_t fields[MAX_FIELDS][3];
+} interaction;
+
+typedef struct {
     uint32_t n_nodes, n_cons, n_pvs;
     const uint32_t *nodes, *cons;
+    uint32_t n_int;
+    interaction *ints;
+    size_t perm_width; /* 4 * (n_int + 1), or 0 */
 } program;
 
+static int leaf_ok(const uint32_t *l, size_t width, uint32_t n_pvs) {
+    if (l[0] == OP_VAR) return l[1] < width && l[2] == 0;
+    if (l[0] == OP_PUB) return l[1] < n_pvs;
+    if (l[0] == OP_CONST) return l[1] < ORA_P;
+    return 0;
+}
+
 static int parse_program(const uint32_t *w, size_t len, size_t width, program *p) {
+    memset(p, 0, sizeof *p);
     if (len < 4 || w[0] != AIR_MAGIC) return -1;
-    p->w = w;
     p->n_nodes = w[1];
     p->n_cons = w[2];
     p->n_pvs = w[3];
-    if ((size_t)4 + 3 * (size_t)p->n_nodes + p->n_cons != len) return -1;
+    size_t base_len = (size_t)4 + 3 * (size_t)p->n_nodes + p->n_cons;
+    if (base_len > len) return -1;
     p->nodes = w + 4;
     p->cons = w + 4 + 3 * (size_t)p->n_nodes;
+    if (base_len != len) {
+        size_t q = base_len;
+        if (q + 2 > len || w[q] != LOGUP_MAGIC) return -1;
+        p->n_int = w[q + 1];
+        q += 2;
+        if (p->n_int == 0 || p->n_int > 4096) return -1;
+        p->ints = (interaction *)calloc(p->n_int, sizeof(interaction));
+        for (uint32_t j = 0; j < p->n_int; j++) {
+            interaction *it = &p->ints[j];
+            if (q + 6 > len) return -1;
+            it->bus = w[q], it->sign = w[q + 1];
+            memcpy(it->count, w + q + 2, 12);
+            it->n_fields = w[q + 5];
+            q += 6;
+            if (it->sign > 1 || it->bus >= ORA_P - 1 || it->n_fields < 1 || it->n_fields > MAX_FIELDS || q + 3 * (size_t)it->n_fields > len) return -1;
+            if (!leaf_ok(it->count, width, p->n_pvs)) return -1;
+            for (uint32_t i = 0; i < it->n_fields; i++) {
+                memcpy(it->fields[i], w + q, 12);
+                if (!leaf_ok(it->fields[i], width, p->n_pvs)) return -1;
+                q += 3;
+            }
+        }
+        if (q != len) return -1;
+        p->perm_width = 4 * ((size_t)p->n_int + 1);
+    }
     for (uint32_t i = 0; i < p->n_nodes; i++) {
         uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
         switch (op) {
@@ -89,6 +142,9 @@ static int parse_program(const uint32_t *w, size_t len, size_t width, program *p
         case OP_FIRST: case OP_LAST: case OP_TRANS: break;
         case OP_ADD: case OP_SUB: case OP_MUL: if (a >= i || b >= i) return -1; break;
         case OP_NEG: if (a >= i) return -1; break;
+        case OP_PERM: if (a >= p->perm_width || b > 1) return -1; break;
+        case OP_CHAL: if (a >= N_CHAL || p->n_int == 0) return -1; break;
+        case OP_EXPOSED: if (a >= 4 || p->n_int == 0) return -1; break;
         default: return -1;
         }
     }
@@ -96,45 +152,60 @@ static int parse_program(const uint32_t *w, size_t len, size_t width, program *p
         if (p->cons[i] >= p->n_nodes) return -1;
     return 0;
 }
+static void free_program(program *p) { free(p->ints); }
+
+typedef struct {
+    const uint32_t *local, *next, *pvs, *perm_local, *perm_next, *chal, *exposed;
+    uint32_t is_first, is_last, is_trans;
+} row_ctx;
 
 /* base-field evaluation of all nodes on one row; vals has n_nodes slots */
-static void eval_nodes_base(const program *p, const uint32_t *local, const uint32_t *next, const uint32_t *pvs,
-                            uint32_t is_first, uint32_t is_last, uint32_t is_trans, uint32_t *vals) {
+static void eval_nodes_base(const program *p, const row_ctx *c, uint32_t *vals) {
     for (uint32_t i = 0; i < p->n_nodes; i++) {
         uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
         switch (op) {
-        case OP_VAR: vals[i] = b ? next[a] : local[a]; break;
-        case OP_PUB: vals[i] = pvs[a]; break;
+        case OP_VAR: vals[i] = b ? c->next[a] : c->local[a]; break;
+        case OP_PUB: vals[i] = c->pvs[a]; break;
         case OP_CONST: vals[i] = a; break;
-        case OP_FIRST: vals[i] = is_first; break;
-        case OP_LAST: vals[i] = is_last; break;
-        case OP_TRANS: vals[i] = is_trans; break;
+        case OP_FIRST: vals[i] = c->is_first; break;
+        case OP_LAST: vals[i] = c->is_last; break;
+        case OP_TRANS: vals[i] = c->is_trans; break;
         case OP_ADD: vals[i] = ora_add(vals[a], vals[b]); break;
         case OP_SUB: vals[i] = ora_sub(vals[a], vals[b]); break;
         case OP_MUL: vals[i] = ora_mul(vals[a], vals[b]); break;
-        default: vals[i] = ora_sub(0, vals[a]); break;
+        case OP_NEG: vals[i] = ora_sub(0, vals[a]); break;
+        case OP_PERM: vals[i] = b ? c->perm_next[a] : c->perm_local[a]; break;
+        case OP_CHAL: vals[i] = c->chal[a]; break;
+        default: vals[i] = c->exposed[a]; break;
         }
     }
 }
+typedef struct {
+    const ext_t *local, *next, *perm_local, *perm_next;
+    const uint32_t *pvs, *chal, *exposed;
+    ext_t is_first, is_last, is_trans;
+} zeta_ctx;
 /* same over the extension (verifier, at zeta) */
-static void eval_nodes_ext(const program *p, const ext_t *local, const ext_t *next, const uint32_t *pvs,
-                           const ext_t is_first, const ext_t is_last, const ext_t is_trans, ext_t *vals) {
+static void eval_nodes_ext(const program *p, const zeta_ctx *c, ext_t *vals) {
     for (uint32_t i = 0; i < p->n_nodes; i++) {
         uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
         switch (op) {
-        case OP_VAR: ext_set(vals[i], b ? next[a] : local[a]); break;
-        case OP_PUB: ext_from(pvs[a], vals[i]); break;
+        case OP_VAR: ext_set(vals[i], b ? c->next[a] : c->local[a]); break;
+        case OP_PUB: ext_from(c->pvs[a], vals[i]); break;
         case OP_CONST: ext_from(a, vals[i]); break;
-        case OP_FIRST: ext_set(vals[i], is_first); break;
-        case OP_LAST: ext_set(vals[i], is_last); break;
-        case OP_TRANS: ext_set(vals[i], is_trans); break;
+        case OP_FIRST: ext_set(vals[i], c->is_first); break;
+        case OP_LAST: ext_set(vals[i], c->is_last); break;
+        case OP_TRANS: ext_set(vals[i], c->is_trans); break;
         case OP_ADD: ext_add(vals[a], vals[b], vals[i]); break;
         case OP_SUB: ext_sub(vals[a], vals[b], vals[i]); break;
         case OP_MUL: ora_ext_mul(vals[a], vals[b], vals[i]); break;
-        default: {
+        case OP_NEG: {
             ext_t z = {0, 0, 0, 0};
             ext_sub(z, vals[a], vals[i]);
         } break;
+        case OP_PERM: ext_set(vals[i], b ? c->perm_next[a] : c->perm_local[a]); break;
+        case OP_CHAL: ext_from(c->chal[a], vals[i]); break;
+        default: ext_from(c->exposed[a], vals[i]); break;
         }
     }
 }
@@ -155,6 +226,17 @@ static void observe_preamble(ora_challenger *ch, const ora_params *prm, const or
     }
 }
 
+/* chal vector: gamma, beta^1 .. beta^MAX_FIELDS as base coordinates */
+static void make_chal(const ext_t gamma, const ext_t beta, uint32_t *chal) {
+    memcpy(chal, gamma, 16);
+    ext_t cur;
+    ext_set(cur, beta);
+    for (int i = 1; i <= MAX_FIELDS; i++) {
+        memcpy(chal + 4 * i, cur, 16);
+        ora_ext_mul(cur, beta, cur);
+    }
+}
+
 /* evaluate the polynomial with the given evaluations over shift*H (natural order) at ext point z */
 static void eval_poly_at(const uint32_t *evals, unsigned log_n, uint32_t shift, const ext_t z, ext_t out) {
     size_t n = (size_t)1 << log_n;
@@ -170,13 +252,6 @@ static void eval_poly_at(const uint32_t *evals, unsigned log_n, uint32_t shift, 
     ext_set(out, acc);
     free(c);
 }
-
-typedef struct {
-    unsigned n_airs;
-    unsigned b;      /* log_blowup */
-    unsigned hmax;   /* max LDE log height */
-    unsigned n_layers;
-} shape;
 
 /* selectors of the trace domain H (size 2^lh) at an extension point */
 static void selectors_ext(unsigned lh, const ext_t x, ext_t is_first, ext_t is_last, ext_t is_trans, ext_t inv_zh) {
@@ -194,14 +269,34 @@ static void selectors_ext(unsigned lh, const ext_t x, ext_t is_first, ext_t is_l
     ora_ext_inv(zh, inv_zh);
 }
 
+static uint32_t leaf_value(const uint32_t *l, const uint32_t *trace, size_t N, size_t row, const uint32_t *pvs) {
+    if (l[0] == OP_VAR) return trace[(size_t)l[1] * N + row];
+    if (l[0] == OP_PUB) return pvs[l[1]];
+    return l[1];
+}
+
 /* ---------------------------------------------------------------- prover */
 typedef struct {
     uint32_t *lde;       /* column-major, height M */
+    uint32_t *perm;      /* permutation trace, column-major height N (NULL if no interactions) */
+    uint32_t *perm_lde;  /* its LDE, height M */
     uint32_t *qlde;      /* 2^b chunk matrices of width 4, each column-major height M, back to back */
     unsigned lh, h;      /* trace / LDE log heights */
     size_t width;
+    uint32_t exposed[4];
     program prog;
 } air_state;
+
+/* one committed matrix as seen by the opening / FRI code */
+typedef struct {
+    const uint32_t *lde;  /* column-major height 2^h */
+    const uint32_t *nat;  /* natural-order evaluations over nat_shift*H (height 2^lh), for the opening at zeta */
+    uint32_t nat_shift;
+    unsigned lh, h;
+    size_t width;
+    unsigned n_pts;       /* 2: zeta and zeta*w_N, 1: zeta */
+    int round;            /* 0 main, 1 perm, 2 quotient */
+} cmat;
 
 size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size_t n_airs, uint32_t *out,
                        size_t cap) {
@@ -209,6 +304,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
     if (prm->log_final_poly_len != 0 || n_airs == 0 || b == 0) return 0;
     air_state *st = (air_state *)calloc(n_airs, sizeof(air_state));
     unsigned hmax = 0;
+    size_t n_lu = 0;
     for (size_t a = 0; a < n_airs; a++) {
         if (airs[a].log_height < 1) return 0;
         if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &st[a].prog)) return 0;
@@ -217,6 +313,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         st[a].h = st[a].lh + b;
         st[a].width = airs[a].width;
         if (st[a].h > hmax) hmax = st[a].h;
+        if (st[a].prog.n_int) n_lu++;
     }
     ora_challenger ch;
     ora_ch_init(&ch);
@@ -230,19 +327,69 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         ora_coset_lde_batch(airs[a].trace, N, st[a].lde, M, st[a].lh, b, st[a].width, GEN, 1);
         mm[a] = (ora_matrix){st[a].lde, M, st[a].h, st[a].width};
     }
-    uint32_t root_main[8], root_quot[8];
-    ora_tree *t_main = ora_mmcs_commit(mm, n_airs, root_main);
+    uint32_t root_main[8], root_perm[8], root_quot[8];
+    ora_tree *t_main = ora_mmcs_commit(mm, n_airs, root_main), *t_perm = NULL;
     ora_ch_observe(&ch, root_main, 8);
+
+    /* 1b. LogUp phase */
+    uint32_t chal[N_CHAL];
+    memset(chal, 0, sizeof chal);
+    ora_matrix *pm = (ora_matrix *)calloc(n_airs, sizeof(ora_matrix));
+    if (n_lu) {
+        ext_t gamma, beta;
+        ora_ch_sample_ext(&ch, gamma);
+        ora_ch_sample_ext(&ch, beta);
+        make_chal(gamma, beta, chal);
+        size_t k = 0;
+        for (size_t a = 0; a < n_airs; a++) {
+            const program *pg = &st[a].prog;
+            if (!pg->n_int) continue;
+            const size_t N = (size_t)1 << st[a].lh, M = N << b, PW = pg->perm_width;
+            st[a].perm = (uint32_t *)calloc(PW * N, sizeof(uint32_t));
+            ext_t run = {0, 0, 0, 0};
+            for (size_t r = 0; r < N; r++) {
+                ext_t rowsum = {0, 0, 0, 0};
+                for (uint32_t j = 0; j < pg->n_int; j++) {
+                    const interaction *it = &pg->ints[j];
+                    ext_t den, inv, phi;
+                    memcpy(den, chal, 16);
+                    den[0] = ora_add(den[0], it->bus + 1);
+                    for (uint32_t i = 0; i < it->n_fields; i++) {
+                        ext_t t;
+                        ext_scale(chal + 4 * (i + 1), leaf_value(it->fields[i], airs[a].trace, N, r, airs[a].pvs), t);
+                        ext_add(den, t, den);
+                    }
+                    ora_ext_inv(den, inv);
+                    uint32_t cnt = leaf_value(it->count, airs[a].trace, N, r, airs[a].pvs);
+                    if (it->sign) cnt = ora_sub(0, cnt);
+                    ext_scale(inv, cnt, phi);
+                    for (int q = 0; q < 4; q++) st[a].perm[(4 * (size_t)j + q) * N + r] = phi[q];
+                    ext_add(rowsum, phi, rowsum);
+                }
+                ext_add(run, rowsum, run);
+                for (int q = 0; q < 4; q++) st[a].perm[(4 * (size_t)pg->n_int + q) * N + r] = run[q];
+            }
+            memcpy(st[a].exposed, run, 16);
+            st[a].perm_lde = (uint32_t *)malloc(M * PW * sizeof(uint32_t));
+            ora_coset_lde_batch(st[a].perm, N, st[a].perm_lde, M, st[a].lh, b, PW, GEN, 1);
+            pm[k++] = (ora_matrix){st[a].perm_lde, M, st[a].h, PW};
+        }
+        t_perm = ora_mmcs_commit(pm, n_lu, root_perm);
+        ora_ch_observe(&ch, root_perm, 8);
+        for (size_t a = 0; a < n_airs; a++)
+            if (st[a].prog.n_int) ora_ch_observe(&ch, st[a].exposed, 4);
+    }
     ext_t alpha;
     ora_ch_sample_ext(&ch, alpha);
 
     /* 2. quotient: evaluate constraints on the LDE domain, divide by Z_H, split, LDE each chunk */
     ora_matrix *qm = (ora_matrix *)calloc(n_airs * nch, sizeof(ora_matrix));
+    uint32_t **qnat = (uint32_t **)calloc(n_airs * nch, sizeof(uint32_t *));
     int ok = 1;
     for (size_t a = 0; a < n_airs; a++) {
         const program *pg = &st[a].prog;
         const unsigned lh = st[a].lh, h = st[a].h;
-        const size_t N = (size_t)1 << lh, M = N << b, W = st[a].width;
+        const size_t N = (size_t)1 << lh, M = N << b, W = st[a].width, PW = pg->perm_width;
         ext_t *ap = (ext_t *)malloc((pg->n_cons + 1) * sizeof(ext_t));
         { /* constraint i is weighted alpha^(n_cons-1-i) (Horner order of p3's folder) */
             ext_t cur = {1, 0, 0, 0};
@@ -256,7 +403,8 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
 #pragma omp parallel
         {
             uint32_t *vals = (uint32_t *)malloc(pg->n_nodes * sizeof(uint32_t));
-            uint32_t *loc = (uint32_t *)malloc(W * sizeof(uint32_t)), *nxt = (uint32_t *)malloc(W * sizeof(uint32_t));
+            uint32_t *loc = (uint32_t *)malloc((W + 1) * sizeof(uint32_t)), *nxt = (uint32_t *)malloc((W + 1) * sizeof(uint32_t));
+            uint32_t *ploc = (uint32_t *)malloc((PW + 1) * sizeof(uint32_t)), *pnxt = (uint32_t *)malloc((PW + 1) * sizeof(uint32_t));
 #pragma omp for schedule(static)
             for (size_t r = 0; r < M; r++) {
                 size_t i = bitrev(r, h), rn = bitrev((i + nch) & (M - 1), h);
@@ -265,11 +413,16 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
                     loc[c] = st[a].lde[c * M + r];
                     nxt[c] = st[a].lde[c * M + rn];
                 }
+                for (size_t c = 0; c < PW; c++) {
+                    ploc[c] = st[a].perm_lde[c * M + r];
+                    pnxt[c] = st[a].perm_lde[c * M + rn];
+                }
                 uint32_t zh = ora_sub(ora_pow(x, N), 1);
-                uint32_t is_first = ora_mul(zh, ora_inv(ora_sub(x, 1)));
-                uint32_t is_trans = ora_sub(x, winv);
-                uint32_t is_last = ora_mul(zh, ora_inv(is_trans));
-                eval_nodes_base(pg, loc, nxt, airs[a].pvs, is_first, is_last, is_trans, vals);
+                row_ctx rc = {loc, nxt, airs[a].pvs, ploc, pnxt, chal, st[a].exposed, 0, 0, 0};
+                rc.is_first = ora_mul(zh, ora_inv(ora_sub(x, 1)));
+                rc.is_trans = ora_sub(x, winv);
+                rc.is_last = ora_mul(zh, ora_inv(rc.is_trans));
+                eval_nodes_base(pg, &rc, vals);
                 ext_t acc = {0, 0, 0, 0}, t;
                 for (uint32_t k = 0; k < pg->n_cons; k++) {
                     ext_scale(ap[k], vals[pg->cons[k]], t);
@@ -277,53 +430,61 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
                 }
                 ext_scale(acc, ora_inv(zh), q + 4 * r);
             }
-            free(vals), free(loc), free(nxt);
+            free(vals), free(loc), free(nxt), free(ploc), free(pnxt);
         }
         /* chunk j = rows [jN,(j+1)N): evaluations over s_j*H (bit-reversed), s_j = g * wM^bitrev_b(j) */
         st[a].qlde = (uint32_t *)malloc((size_t)nch * 4 * M * sizeof(uint32_t));
-        uint32_t *nat = (uint32_t *)malloc(4 * N * sizeof(uint32_t));
         for (unsigned j = 0; j < nch; j++) {
+            uint32_t *nat = (uint32_t *)malloc(4 * N * sizeof(uint32_t));
             for (size_t m = 0; m < N; m++)
                 for (int k = 0; k < 4; k++) nat[k * N + m] = q[4 * (j * N + bitrev(m, lh)) + k];
             uint32_t sj = ora_mul(GEN, ora_pow(wM, bitrev(j, b)));
             uint32_t *dst = st[a].qlde + (size_t)j * 4 * M;
             ora_coset_lde_batch(nat, N, dst, M, lh, b, 4, ora_mul(GEN, ora_inv(sj)), 1);
             qm[a * nch + j] = (ora_matrix){dst, M, h, 4};
+            qnat[a * nch + j] = nat;
         }
-        free(nat), free(q), free(ap);
+        free(q), free(ap);
     }
     ora_tree *t_quot = ora_mmcs_commit(qm, n_airs * nch, root_quot);
     ora_ch_observe(&ch, root_quot, 8);
     ext_t zeta;
     ora_ch_sample_ext(&ch, zeta);
 
+    /* committed matrices in opening order: main (all AIRs), perm (AIRs with interactions), quotient chunks */
+    size_t n_cm = n_airs + n_lu + n_airs * nch;
+    cmat *cm = (cmat *)calloc(n_cm, sizeof(cmat));
+    {
+        size_t k = 0;
+        for (size_t a = 0; a < n_airs; a++)
+            cm[k++] = (cmat){st[a].lde, airs[a].trace, 1, st[a].lh, st[a].h, st[a].width, 2, 0};
+        for (size_t a = 0; a < n_airs; a++)
+            if (st[a].prog.n_int) cm[k++] = (cmat){st[a].perm_lde, st[a].perm, 1, st[a].lh, st[a].h, st[a].prog.perm_width, 2, 1};
+        for (size_t a = 0; a < n_airs; a++) {
+            const uint32_t wM = ora_two_adic_generator(st[a].h);
+            for (unsigned j = 0; j < nch; j++)
+                cm[k++] = (cmat){st[a].qlde + (size_t)j * 4 * ((size_t)1 << st[a].h), qnat[a * nch + j],
+                                 ora_mul(GEN, ora_pow(wM, bitrev(j, b))), st[a].lh, st[a].h, 4, 1, 2};
+        }
+    }
+
     /* 3. openings */
     size_t n_open = 0;
-    for (size_t a = 0; a < n_airs; a++) n_open += 2 * st[a].width + 4 * nch;
-    ext_t *opened = (ext_t *)malloc(n_open * sizeof(ext_t)); /* main(all airs) then quotient(all airs) */
-    size_t oi = 0;
-    for (size_t a = 0; a < n_airs; a++) {
-        const size_t N = (size_t)1 << st[a].lh, W = st[a].width;
-        ext_t zn;
-        ext_scale(zeta, ora_two_adic_generator(st[a].lh), zn);
+    for (size_t m = 0; m < n_cm; m++) n_open += cm[m].width * cm[m].n_pts;
+    ext_t *opened = (ext_t *)malloc(n_open * sizeof(ext_t));
+    {
+        size_t oi = 0;
+        for (size_t m = 0; m < n_cm; m++) {
+            const size_t N = (size_t)1 << cm[m].lh, W = cm[m].width;
+            for (unsigned pt = 0; pt < cm[m].n_pts; pt++) {
+                ext_t z;
+                if (pt == 0) ext_set(z, zeta);
+                else ext_scale(zeta, ora_two_adic_generator(cm[m].lh), z);
 #pragma omp parallel for schedule(dynamic)
-        for (size_t c = 0; c < W; c++) {
-            eval_poly_at(airs[a].trace + c * N, st[a].lh, 1, zeta, opened[oi + c]);
-            eval_poly_at(airs[a].trace + c * N, st[a].lh, 1, zn, opened[oi + W + c]);
-        }
-        oi += 2 * W;
-    }
-    for (size_t a = 0; a < n_airs; a++) {
-        const size_t N = (size_t)1 << st[a].lh, M = N << b;
-        /* chunk polynomial q_j: known on the first N rows of its own LDE = coset g*H, bit-reversed */
-        uint32_t *nat = (uint32_t *)malloc(N * sizeof(uint32_t));
-        for (unsigned j = 0; j < nch; j++)
-            for (int k = 0; k < 4; k++) {
-                const uint32_t *col = st[a].qlde + ((size_t)j * 4 + k) * M;
-                for (size_t m = 0; m < N; m++) nat[m] = col[bitrev(m, st[a].lh)];
-                eval_poly_at(nat, st[a].lh, GEN, zeta, opened[oi++]);
+                for (size_t c = 0; c < W; c++) eval_poly_at(cm[m].nat + c * N, cm[m].lh, cm[m].nat_shift, z, opened[oi + c]);
+                oi += W;
             }
-        free(nat);
+        }
     }
     ora_ch_observe(&ch, (const uint32_t *)opened, 4 * n_open);
     ext_t alpha_f;
@@ -332,63 +493,59 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
     /* 4. reduced openings per LDE log-height */
     ext_t **ro = (ext_t **)calloc(hmax + 1, sizeof(ext_t *));
     size_t *num_reduced = (size_t *)calloc(hmax + 1, sizeof(size_t));
-    oi = 0;
-    for (int round = 0; round < 2; round++)
-        for (size_t a = 0; a < n_airs; a++) {
-            const unsigned h = st[a].h;
-            const size_t M = (size_t)1 << h;
-            const unsigned n_mats = round == 0 ? 1 : nch;
+    {
+        size_t oi = 0;
+        for (size_t m = 0; m < n_cm; m++) {
+            const unsigned h = cm[m].h;
+            const size_t M = (size_t)1 << h, W = cm[m].width;
+            const uint32_t *mat = cm[m].lde;
             if (!ro[h]) ro[h] = (ext_t *)calloc(M, sizeof(ext_t));
-            for (unsigned j = 0; j < n_mats; j++) {
-                const uint32_t *mat = round == 0 ? st[a].lde : st[a].qlde + (size_t)j * 4 * M;
-                const size_t W = round == 0 ? st[a].width : 4;
-                const unsigned n_pts = round == 0 ? 2 : 1;
-                ext_t *apow = (ext_t *)malloc(W * sizeof(ext_t));
-                {
-                    ext_t cur = {1, 0, 0, 0};
-                    for (size_t k = 0; k < W; k++) {
-                        ext_set(apow[k], cur);
-                        ora_ext_mul(cur, alpha_f, cur);
-                    }
+            ext_t *apow = (ext_t *)malloc(W * sizeof(ext_t));
+            {
+                ext_t cur = {1, 0, 0, 0};
+                for (size_t k = 0; k < W; k++) {
+                    ext_set(apow[k], cur);
+                    ora_ext_mul(cur, alpha_f, cur);
                 }
-                ext_t *rrow = (ext_t *)malloc(M * sizeof(ext_t));
+            }
+            ext_t *rrow = (ext_t *)malloc(M * sizeof(ext_t));
+#pragma omp parallel for schedule(static)
+            for (size_t r = 0; r < M; r++) {
+                ext_t acc = {0, 0, 0, 0}, t;
+                for (size_t k = 0; k < W; k++) {
+                    ext_scale(apow[k], mat[k * M + r], t);
+                    ext_add(acc, t, acc);
+                }
+                ext_set(rrow[r], acc);
+            }
+            const uint32_t wM = ora_two_adic_generator(h);
+            for (unsigned pt = 0; pt < cm[m].n_pts; pt++) {
+                ext_t z, ry = {0, 0, 0, 0}, off, t;
+                if (pt == 0) ext_set(z, zeta);
+                else ext_scale(zeta, ora_two_adic_generator(cm[m].lh), z);
+                for (size_t k = 0; k < W; k++) {
+                    ora_ext_mul(apow[k], opened[oi + k], t);
+                    ext_add(ry, t, ry);
+                }
+                ext_pow(alpha_f, num_reduced[h], off);
 #pragma omp parallel for schedule(static)
                 for (size_t r = 0; r < M; r++) {
-                    ext_t acc = {0, 0, 0, 0}, t;
-                    for (size_t k = 0; k < W; k++) {
-                        ext_scale(apow[k], mat[k * M + r], t);
-                        ext_add(acc, t, acc);
-                    }
-                    ext_set(rrow[r], acc);
+                    uint32_t x = ora_mul(GEN, ora_pow(wM, bitrev(r, h)));
+                    ext_t d, di, num, u;
+                    ext_set(d, z);
+                    d[0] = ora_sub(d[0], x);
+                    ora_ext_inv(d, di);
+                    ext_sub(ry, rrow[r], num);
+                    ora_ext_mul(num, di, u);
+                    ora_ext_mul(u, off, u);
+                    ext_add(ro[h][r], u, ro[h][r]);
                 }
-                const uint32_t wM = ora_two_adic_generator(h);
-                for (unsigned pt = 0; pt < n_pts; pt++) {
-                    ext_t z, ry = {0, 0, 0, 0}, off, t;
-                    if (pt == 0) ext_set(z, zeta);
-                    else ext_scale(zeta, ora_two_adic_generator(st[a].lh), z);
-                    for (size_t k = 0; k < W; k++) {
-                        ora_ext_mul(apow[k], opened[oi + k], t);
-                        ext_add(ry, t, ry);
-                    }
-                    ext_pow(alpha_f, num_reduced[h], off);
-#pragma omp parallel for schedule(static)
-                    for (size_t r = 0; r < M; r++) {
-                        uint32_t x = ora_mul(GEN, ora_pow(wM, bitrev(r, h)));
-                        ext_t d, di, num, u;
-                        ext_set(d, z);
-                        d[0] = ora_sub(d[0], x);
-                        ora_ext_inv(d, di);
-                        ext_sub(ry, rrow[r], num);
-                        ora_ext_mul(num, di, u);
-                        ora_ext_mul(u, off, u);
-                        ext_add(ro[h][r], u, ro[h][r]);
-                    }
-                    num_reduced[h] += W;
-                    oi += W;
-                }
-                free(apow), free(rrow);
+                num_reduced[h] += W;
+                oi += W;
             }
+            free(apow), free(rrow);
         }
+    }
 
     /* 5. FRI commit phase */
     const unsigned n_layers = hmax - b;
@@ -412,7 +569,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         ora_ch_sample_ext(&ch, betas[l]);
         flayers[l + 1] = (uint32_t *)malloc(4 * half * sizeof(uint32_t));
         ora_fri_fold(flayers[l], flayers[l + 1], log_len - 1, betas[l]);
-        if (log_len - 1 <= hmax && ro[log_len - 1]) {
+        if (ro[log_len - 1]) {
             ext_t b2;
             ora_ext_mul(betas[l], betas[l], b2);
             for (size_t i = 0; i < half; i++) {
@@ -437,9 +594,14 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         w += (n);                                       \
     } while (0)
     {
-        uint32_t hdr[4] = {PROOF_MAGIC, (uint32_t)n_airs, hmax, n_layers};
+        uint32_t hdr[4] = {PROOF_MAGIC + (n_lu ? 1u : 0u), (uint32_t)n_airs, hmax, n_layers};
         PUT(hdr, 4);
         PUT(root_main, 8);
+        if (n_lu) {
+            PUT(root_perm, 8);
+            for (size_t a = 0; a < n_airs; a++)
+                if (st[a].prog.n_int) PUT(st[a].exposed, 4);
+        }
         PUT(root_quot, 8);
         PUT(opened, 4 * n_open);
         for (unsigned l = 0; l < n_layers; l++) {
@@ -448,14 +610,17 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         }
         PUT(fin, 4);
         PUT(&qpow, 1);
-        size_t tmp_words = 0;
-        for (size_t a = 0; a < n_airs; a++) tmp_words += st[a].width + 4 * nch;
-        tmp_words += 8 * (hmax + 1) + 16;
+        size_t tmp_words = 8 * (hmax + 1) + 16;
+        for (size_t m = 0; m < n_cm; m++) tmp_words += cm[m].width;
         uint32_t *tmp = (uint32_t *)malloc(tmp_words * sizeof(uint32_t));
         for (unsigned qn = 0; qn < prm->num_queries; qn++) {
             size_t idx = ora_ch_sample_bits(&ch, hmax);
             size_t n1 = ora_mmcs_open(t_main, idx >> (hmax - ora_tree_log_height(t_main)), tmp);
             PUT(tmp, n1);
+            if (n_lu) {
+                n1 = ora_mmcs_open(t_perm, idx >> (hmax - ora_tree_log_height(t_perm)), tmp);
+                PUT(tmp, n1);
+            }
             n1 = ora_mmcs_open(t_quot, idx >> (hmax - ora_tree_log_height(t_quot)), tmp);
             PUT(tmp, n1);
             for (unsigned l = 0; l < n_layers; l++) {
@@ -468,7 +633,11 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         free(tmp);
     }
 done:
-    for (size_t a = 0; a < n_airs; a++) free(st[a].lde), free(st[a].qlde);
+    for (size_t a = 0; a < n_airs; a++) {
+        free(st[a].lde), free(st[a].qlde), free(st[a].perm), free(st[a].perm_lde);
+        free_program(&st[a].prog);
+    }
+    for (size_t k = 0; k < n_airs * nch; k++) free(qnat[k]);
     for (unsigned l = 0; l < n_layers; l++) {
         ora_tree_free(ftrees[l]);
         free(fleaves[l]);
@@ -476,24 +645,44 @@ done:
     }
     for (unsigned h = 0; h <= hmax; h++) free(ro[h]);
     ora_tree_free(t_main), ora_tree_free(t_quot);
+    if (t_perm) ora_tree_free(t_perm);
     free(ftrees), free(flayers), free(fleaves), free(froots), free(fpow), free(betas);
-    free(ro), free(num_reduced), free(opened), free(mm), free(qm), free(st);
+    free(ro), free(num_reduced), free(opened), free(mm), free(pm), free(qm), free(qnat), free(cm), free(st);
     return ok ? w : 0;
 }
 
 /* ---------------------------------------------------------------- verifier */
+typedef struct {
+    unsigned lh, h;
+    size_t width;
+    unsigned n_pts;
+} vmat;
+
 int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t n_airs, const uint32_t *proof,
                      size_t n_words) {
     const unsigned b = prm->log_blowup, nch = 1u << b;
     if (prm->log_final_poly_len != 0 || n_airs == 0 || b == 0) return -1;
     program *pg = (program *)calloc(n_airs, sizeof(program));
     unsigned hmax = 0;
-    size_t n_open = 0;
+    size_t n_lu = 0;
     for (size_t a = 0; a < n_airs; a++) {
         if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &pg[a])) return -2;
         if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height < 1) return -2;
         if (airs[a].log_height + b > hmax) hmax = airs[a].log_height + b;
-        n_open += 2 * airs[a].width + 4 * nch;
+        if (pg[a].n_int) n_lu++;
+    }
+    /* committed matrices in opening order */
+    size_t n_cm = n_airs + n_lu + n_airs * nch, n_open = 0;
+    vmat *cm = (vmat *)calloc(n_cm, sizeof(vmat));
+    size_t cm_perm0 = n_airs, cm_quot0 = n_airs + n_lu;
+    {
+        size_t k = 0;
+        for (size_t a = 0; a < n_airs; a++) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, airs[a].width, 2};
+        for (size_t a = 0; a < n_airs; a++)
+            if (pg[a].n_int) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, pg[a].perm_width, 2};
+        for (size_t a = 0; a < n_airs; a++)
+            for (unsigned j = 0; j < nch; j++) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, 4, 1};
+        for (size_t m = 0; m < n_cm; m++) n_open += cm[m].width * cm[m].n_pts;
     }
     const unsigned n_layers = hmax - b;
     size_t r = 0;
@@ -502,13 +691,22 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
         if (r + (n) > n_words) return -3; \
     } while (0)
     for (size_t i = 0; i < n_words; i++)
-        if (proof[i] >= ORA_P && i != 0) return -3; /* all words canonical (magic is < p too) */
+        if (proof[i] >= ORA_P) return -3; /* all words canonical (the magic is < p too) */
     NEED(4);
-    if (proof[0] != PROOF_MAGIC || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers) return -3;
+    if (proof[0] != PROOF_MAGIC + (n_lu ? 1u : 0u) || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers) return -3;
     r = 4;
-    NEED(16);
-    const uint32_t *root_main = proof + r, *root_quot = proof + r + 8;
-    r += 16;
+    NEED(8);
+    const uint32_t *root_main = proof + r, *root_perm = NULL, *exposed_all = NULL;
+    r += 8;
+    if (n_lu) {
+        NEED(8 + 4 * n_lu);
+        root_perm = proof + r;
+        exposed_all = proof + r + 8;
+        r += 8 + 4 * n_lu;
+    }
+    NEED(8);
+    const uint32_t *root_quot = proof + r;
+    r += 8;
     NEED(4 * n_open);
     const ext_t *opened = (const ext_t *)(proof + r);
     r += 4 * n_open;
@@ -523,6 +721,20 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     ora_ch_init(&ch);
     observe_preamble(&ch, prm, airs, n_airs);
     ora_ch_observe(&ch, root_main, 8);
+    uint32_t chal[N_CHAL];
+    memset(chal, 0, sizeof chal);
+    if (n_lu) {
+        ext_t gamma, beta;
+        ora_ch_sample_ext(&ch, gamma);
+        ora_ch_sample_ext(&ch, beta);
+        make_chal(gamma, beta, chal);
+        ora_ch_observe(&ch, root_perm, 8);
+        ora_ch_observe(&ch, exposed_all, 4 * n_lu);
+        /* bus balance: the exposed cumulative sums of all AIRs add up to zero */
+        ext_t tot = {0, 0, 0, 0};
+        for (size_t k = 0; k < n_lu; k++) ext_add(tot, exposed_all + 4 * k, tot);
+        if (tot[0] | tot[1] | tot[2] | tot[3]) return -9;
+    }
     ext_t alpha, zeta, alpha_f;
     ora_ch_sample_ext(&ch, alpha);
     ora_ch_observe(&ch, root_quot, 8);
@@ -530,56 +742,77 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     ora_ch_observe(&ch, (const uint32_t *)opened, 4 * n_open);
     ora_ch_sample_ext(&ch, alpha_f);
 
+    /* offsets of each committed matrix inside `opened` */
+    size_t *open_off = (size_t *)malloc(n_cm * sizeof(size_t));
+    {
+        size_t o = 0;
+        for (size_t m = 0; m < n_cm; m++) {
+            open_off[m] = o;
+            o += cm[m].width * cm[m].n_pts;
+        }
+    }
     /* constraint check at zeta for every AIR */
-    size_t om = 0, oq = 0;
-    for (size_t a = 0; a < n_airs; a++) oq += 2 * airs[a].width;
-    for (size_t a = 0; a < n_airs; a++) {
-        const unsigned lh = airs[a].log_height, h = lh + b;
-        const size_t W = airs[a].width;
-        ext_t is_first, is_last, is_trans, inv_zh;
-        selectors_ext(lh, zeta, is_first, is_last, is_trans, inv_zh);
-        ext_t *vals = (ext_t *)malloc(pg[a].n_nodes * sizeof(ext_t));
-        eval_nodes_ext(&pg[a], opened + om, opened + om + W, airs[a].pvs, is_first, is_last, is_trans, vals);
-        ext_t acc = {0, 0, 0, 0};
-        for (uint32_t k = 0; k < pg[a].n_cons; k++) {
-            ora_ext_mul(acc, alpha, acc);
-            ext_add(acc, vals[pg[a].cons[k]], acc);
-        }
-        free(vals);
-        ext_t lhs;
-        ora_ext_mul(acc, inv_zh, lhs);
-        /* quotient(zeta) = sum_j zps_j * sum_k x^k * chunk_{j,k}(zeta) */
-        const uint32_t wM = ora_two_adic_generator(h);
-        ext_t rhs = {0, 0, 0, 0};
-        for (unsigned j = 0; j < nch; j++) {
-            uint32_t sj = ora_mul(GEN, ora_pow(wM, bitrev(j, b)));
-            ext_t zps = {1, 0, 0, 0};
-            for (unsigned k = 0; k < nch; k++) {
-                if (k == j) continue;
-                uint32_t sk = ora_mul(GEN, ora_pow(wM, bitrev(k, b)));
-                /* Z_{D_k}(x) = (x/s_k)^N - 1 */
-                ext_t t, one = {1, 0, 0, 0}, num;
-                ext_scale(zeta, ora_inv(sk), t);
-                ext_pow(t, (uint64_t)1 << lh, t);
-                ext_sub(t, one, num);
-                uint32_t den = ora_sub(ora_pow(ora_mul(sj, ora_inv(sk)), (uint64_t)1 << lh), 1);
-                ext_scale(num, ora_inv(den), num);
-                ora_ext_mul(zps, num, zps);
+    {
+        size_t k_lu = 0;
+        for (size_t a = 0; a < n_airs; a++) {
+            const unsigned lh = airs[a].log_height, h = lh + b;
+            const size_t W = airs[a].width;
+            zeta_ctx zc;
+            memset(&zc, 0, sizeof zc);
+            ext_t inv_zh;
+            selectors_ext(lh, zeta, zc.is_first, zc.is_last, zc.is_trans, inv_zh);
+            zc.local = opened + open_off[a];
+            zc.next = opened + open_off[a] + W;
+            zc.pvs = airs[a].pvs;
+            zc.chal = chal;
+            if (pg[a].n_int) {
+                zc.perm_local = opened + open_off[cm_perm0 + k_lu];
+                zc.perm_next = zc.perm_local + pg[a].perm_width;
+                zc.exposed = exposed_all + 4 * k_lu;
+                k_lu++;
             }
-            ext_t v = {0, 0, 0, 0};
-            for (int k = 0; k < 4; k++) {
-                /* basis element x^k times an extension value */
-                ext_t e = {0, 0, 0, 0}, t;
-                e[k] = 1;
-                ora_ext_mul(e, opened[oq + 4 * j + k], t);
-                ext_add(v, t, v);
+            ext_t *vals = (ext_t *)malloc(pg[a].n_nodes * sizeof(ext_t));
+            eval_nodes_ext(&pg[a], &zc, vals);
+            ext_t acc = {0, 0, 0, 0};
+            for (uint32_t k = 0; k < pg[a].n_cons; k++) {
+                ora_ext_mul(acc, alpha, acc);
+                ext_add(acc, vals[pg[a].cons[k]], acc);
             }
-            ora_ext_mul(v, zps, v);
-            ext_add(rhs, v, rhs);
+            free(vals);
+            ext_t lhs;
+            ora_ext_mul(acc, inv_zh, lhs);
+            /* quotient(zeta) = sum_j zps_j * sum_k x^k * chunk_{j,k}(zeta) */
+            const uint32_t wM = ora_two_adic_generator(h);
+            ext_t rhs = {0, 0, 0, 0};
+            for (unsigned j = 0; j < nch; j++) {
+                uint32_t sj = ora_mul(GEN, ora_pow(wM, bitrev(j, b)));
+                ext_t zps = {1, 0, 0, 0};
+                for (unsigned k = 0; k < nch; k++) {
+                    if (k == j) continue;
+                    uint32_t sk = ora_mul(GEN, ora_pow(wM, bitrev(k, b)));
+                    /* Z_{D_k}(x) = (x/s_k)^N - 1 */
+                    ext_t t, one = {1, 0, 0, 0}, num;
+                    ext_scale(zeta, ora_inv(sk), t);
+                    ext_pow(t, (uint64_t)1 << lh, t);
+                    ext_sub(t, one, num);
+                    uint32_t den = ora_sub(ora_pow(ora_mul(sj, ora_inv(sk)), (uint64_t)1 << lh), 1);
+                    ext_scale(num, ora_inv(den), num);
+                    ora_ext_mul(zps, num, zps);
+                }
+                const ext_t *chunk = opened + open_off[cm_quot0 + a * nch + j];
+                ext_t v = {0, 0, 0, 0};
+                for (int k = 0; k < 4; k++) {
+                    /* basis element x^k times an extension value */
+                    ext_t e = {0, 0, 0, 0}, t;
+                    e[k] = 1;
+                    ora_ext_mul(e, chunk[k], t);
+                    ext_add(v, t, v);
+                }
+                ora_ext_mul(v, zps, v);
+                ext_add(rhs, v, rhs);
+            }
+            if (memcmp(lhs, rhs, 16)) return -4;
         }
-        if (memcmp(lhs, rhs, 16)) return -4;
-        om += 2 * W;
-        oq += 4 * nch;
     }
 
     /* FRI transcript */
@@ -592,80 +825,86 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     ora_ch_observe(&ch, fin, 4);
     if (!ora_ch_check_witness(&ch, prm->query_pow_bits, qpow)) return -5;
 
-    /* shapes of the two input batches */
-    unsigned *lh_main = (unsigned *)malloc(n_airs * sizeof(unsigned));
-    size_t *w_main = (size_t *)malloc(n_airs * sizeof(size_t));
-    unsigned *lh_quot = (unsigned *)malloc(n_airs * nch * sizeof(unsigned));
-    size_t *w_quot = (size_t *)malloc(n_airs * nch * sizeof(size_t));
-    size_t tw_main = 0, tw_quot = 0;
-    for (size_t a = 0; a < n_airs; a++) {
-        lh_main[a] = airs[a].log_height + b;
-        w_main[a] = airs[a].width;
-        tw_main += w_main[a];
-        for (unsigned j = 0; j < nch; j++) {
-            lh_quot[a * nch + j] = lh_main[a];
-            w_quot[a * nch + j] = 4;
-            tw_quot += 4;
-        }
+    /* shapes of the input batches */
+    const size_t n_batches = n_lu ? 3 : 2;
+    size_t batch_first[3], batch_n[3];
+    const uint32_t *batch_root[3];
+    batch_first[0] = 0, batch_n[0] = n_airs, batch_root[0] = root_main;
+    if (n_lu) {
+        batch_first[1] = cm_perm0, batch_n[1] = n_lu, batch_root[1] = root_perm;
+        batch_first[2] = cm_quot0, batch_n[2] = n_airs * nch, batch_root[2] = root_quot;
+    } else {
+        batch_first[1] = cm_quot0, batch_n[1] = n_airs * nch, batch_root[1] = root_quot;
     }
+    unsigned *lhs_all = (unsigned *)malloc(n_cm * sizeof(unsigned));
+    size_t *ws_all = (size_t *)malloc(n_cm * sizeof(size_t));
+    for (size_t m = 0; m < n_cm; m++) lhs_all[m] = cm[m].h, ws_all[m] = cm[m].width;
     ext_t *roq = (ext_t *)calloc(hmax + 1, sizeof(ext_t));
     int *has = (int *)calloc(hmax + 1, sizeof(int));
     size_t *num_reduced = (size_t *)calloc(hmax + 1, sizeof(size_t));
     int rc = 0;
     for (unsigned qn = 0; qn < prm->num_queries && rc == 0; qn++) {
         size_t idx = ora_ch_sample_bits(&ch, hmax);
-        size_t n_main = tw_main + 8 * (size_t)hmax, n_quot = tw_quot + 8 * (size_t)hmax;
-        if (r + n_main + n_quot > n_words) { rc = -3; break; }
-        const uint32_t *op_main = proof + r, *op_quot = proof + r + n_main;
-        r += n_main + n_quot;
-        if (!ora_mmcs_verify(root_main, lh_main, w_main, n_airs, idx, op_main)) { rc = -6; break; }
-        if (!ora_mmcs_verify(root_quot, lh_quot, w_quot, n_airs * nch, idx, op_quot)) { rc = -6; break; }
+        const uint32_t *rows_of[3];
+        for (size_t bt = 0; bt < n_batches && rc == 0; bt++) {
+            size_t tw = 0;
+            unsigned bh = 0;
+            for (size_t m = 0; m < batch_n[bt]; m++) {
+                tw += ws_all[batch_first[bt] + m];
+                if (lhs_all[batch_first[bt] + m] > bh) bh = lhs_all[batch_first[bt] + m];
+            }
+            size_t n_op = tw + 8 * (size_t)bh;
+            if (r + n_op > n_words) { rc = -3; break; }
+            rows_of[bt] = proof + r;
+            r += n_op;
+            if (!ora_mmcs_verify(batch_root[bt], lhs_all + batch_first[bt], ws_all + batch_first[bt], batch_n[bt],
+                                 idx >> (hmax - bh), rows_of[bt]))
+                rc = -6;
+        }
+        if (rc) break;
         /* reduced openings at this query for every height */
         memset(roq, 0, (hmax + 1) * sizeof(ext_t));
         memset(has, 0, (hmax + 1) * sizeof(int));
         memset(num_reduced, 0, (hmax + 1) * sizeof(size_t));
         size_t oi = 0;
-        for (int round = 0; round < 2; round++) {
-            const uint32_t *rows = round == 0 ? op_main : op_quot;
-            for (size_t a = 0; a < n_airs; a++) {
-                const unsigned h = airs[a].log_height + b;
-                const unsigned n_mats = round == 0 ? 1 : nch;
-                const size_t W = round == 0 ? airs[a].width : 4;
-                const unsigned n_pts = round == 0 ? 2 : 1;
+        for (size_t bt = 0; bt < n_batches; bt++) {
+            const uint32_t *rows = rows_of[bt];
+            for (size_t mi = 0; mi < batch_n[bt]; mi++) {
+                const vmat *M = &cm[batch_first[bt] + mi];
+                const unsigned h = M->h;
+                const size_t W = M->width;
                 size_t ih = idx >> (hmax - h);
                 uint32_t x = ora_mul(GEN, ora_pow(ora_two_adic_generator(h), bitrev(ih, h)));
                 has[h] = 1;
-                for (unsigned j = 0; j < n_mats; j++) {
-                    ext_t rrow = {0, 0, 0, 0}, cur = {1, 0, 0, 0}, t;
-                    ext_t *apow = (ext_t *)malloc(W * sizeof(ext_t));
-                    for (size_t k = 0; k < W; k++) {
-                        ext_set(apow[k], cur);
-                        ext_scale(cur, rows[k], t);
-                        ext_add(rrow, t, rrow);
-                        ora_ext_mul(cur, alpha_f, cur);
-                    }
-                    for (unsigned pt = 0; pt < n_pts; pt++) {
-                        ext_t z, ry = {0, 0, 0, 0}, off, d, di, num, u;
-                        if (pt == 0) ext_set(z, zeta);
-                        else ext_scale(zeta, ora_two_adic_generator(airs[a].log_height), z);
-                        for (size_t k = 0; k < W; k++) {
-                            ora_ext_mul(apow[k], opened[oi + k], t);
-                            ext_add(ry, t, ry);
-                        }
-                        ext_pow(alpha_f, num_reduced[h], off);
-                        ext_set(d, z);
-                        d[0] = ora_sub(d[0], x);
-                        ora_ext_inv(d, di);
-                        ext_sub(ry, rrow, num);
-                        ora_ext_mul(num, di, u);
-                        ora_ext_mul(u, off, u);
-                        ext_add(roq[h], u, roq[h]);
-                        num_reduced[h] += W;
-                        oi += W;
-                    }
-                    free(apow);
-                    rows += W;
+                ext_t rrow = {0, 0, 0, 0}, cur = {1, 0, 0, 0}, t;
+                ext_t *apow = (ext_t *)malloc(W * sizeof(ext_t));
+                for (size_t k = 0; k < W; k++) {
+                    ext_set(apow[k], cur);
+                    ext_scale(cur, rows[k], t);
+                    ext_add(rrow, t, rrow);
+                    ora_ext_mul(cur, alpha_f, cur);
                 }
+                for (unsigned pt = 0; pt < M->n_pts; pt++) {
+                    ext_t z, ry = {0, 0, 0, 0}, off, d, di, num, u;
+                    if (pt == 0) ext_set(z, zeta);
+                    else ext_scale(zeta, ora_two_adic_generator(M->lh), z);
+                    for (size_t k = 0; k < W; k++) {
+                        ora_ext_mul(apow[k], opened[oi + k], t);
+                        ext_add(ry, t, ry);
+                    }
+                    ext_pow(alpha_f, num_reduced[h], off);
+                    ext_set(d, z);
+                    d[0] = ora_sub(d[0], x);
+                    ora_ext_inv(d, di);
+                    ext_sub(ry, rrow, num);
+                    ora_ext_mul(num, di, u);
+                    ora_ext_mul(u, off, u);
+                    ext_add(roq[h], u, roq[h]);
+                    num_reduced[h] += W;
+                    oi += W;
+                }
+                free(apow);
+                rows += W;
             }
         }
         /* fold chain */
@@ -685,8 +924,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
             size_t wl = 8;
             if (!ora_mmcs_verify(fri_hdr + 9 * l, &lhl, &wl, 1, il >> 1, opening)) { rc = -7; break; }
             ext_t folded;
-            /* fold_row at index il>>1 of a layer with log height log_len-1 */
-            {
+            {   /* fold_row at index il>>1 of a layer with log height log_len-1 */
                 uint32_t xx = ora_pow(ora_two_adic_generator(log_len), bitrev(il >> 1, log_len - 1));
                 uint32_t c = ora_sub(0, ora_mul(ora_inv(xx), ora_inv(2)));
                 ext_t d, bx, t;
@@ -707,7 +945,8 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
         if (rc == 0 && memcmp(eval, fin, 16)) rc = -8;
     }
     if (rc == 0 && r != n_words) rc = -3;
-    free(betas), free(lh_main), free(w_main), free(lh_quot), free(w_quot), free(roq), free(has), free(num_reduced);
+    free(betas), free(lhs_all), free(ws_all), free(roq), free(has), free(num_reduced), free(open_off), free(cm);
+    for (size_t a = 0; a < n_airs; a++) free_program(&pg[a]);
     free(pg);
     return rc;
 }

@@ -12,6 +12,13 @@ import numpy as np
 P = 2013265921
 AIR_MAGIC = 0x31414B5A
 OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG = range(10)
+# leaves of the after-challenge (LogUp) phase: a base column of the permutation matrix, a coordinate
+# of the interaction challenges, a coordinate of the AIR's exposed cumulative sum
+OP_PERM, OP_CHAL, OP_EXPOSED = 10, 11, 12
+LOGUP_MAGIC = 0x554C4B5A
+LOGUP_MAX_FIELDS = 8                      # challenge vector = gamma, beta^1 .. beta^8 (4 coordinates each)
+N_CHAL = 4 * (1 + LOGUP_MAX_FIELDS)
+EXT_W = 11                                # x^4 = 11
 
 
 class Expr:
@@ -87,6 +94,72 @@ class AirBuilder:
     def assert_zero(self, e):
         self.cons.append(e.idx)
 
+    # ---- bus interactions (LogUp) ---------------------------------------------------------------
+    def perm(self, col, rot=0):
+        return self._node(OP_PERM, col, rot, 1)
+
+    def chal(self, i):
+        return self._node(OP_CHAL, i, 0, 0)
+
+    def exposed(self, i):
+        return self._node(OP_EXPOSED, i, 0, 0)
+
+    def push_interaction(self, bus, fields, count, kind):
+        """fields / count: leaves only (var of the current row, public value or constant), like most
+        OpenVM chips' buses.  kind 'send' adds count/denominator, 'receive' subtracts it."""
+        assert kind in ("send", "receive") and 0 <= bus < (1 << 20) and 1 <= len(fields) <= LOGUP_MAX_FIELDS
+        fields = [f if isinstance(f, Expr) else self.const(f) for f in fields]
+        count = count if isinstance(count, Expr) else self.const(count)
+        for e in fields + [count]:
+            op, a, b = self.nodes[e.idx]
+            assert op in (OP_VAR, OP_PUB, OP_CONST) and (op != OP_VAR or b == 0), "interaction operands must be leaves"
+        if not hasattr(self, "interactions"):
+            self.interactions = []
+        self.interactions.append((bus, 0 if kind == "send" else 1, count, fields))
+
+    def finalize_interactions(self):
+        """Appends the LogUp constraints (as base-field constraints on the coordinates of the extension
+        values) for the interactions pushed so far.  Permutation matrix layout: interaction j owns base
+        columns 4j..4j+3 (phi_j = sign*count / denominator), the running sum owns the last 4."""
+        ints = getattr(self, "interactions", [])
+        if not ints or getattr(self, "_logup_done", False):
+            return
+        self._logup_done = True
+        n_int = len(ints)
+        for j, (bus, sign, count, fields) in enumerate(ints):
+            # denominator coordinates d_k = gamma_k + [k==0](bus+1) + sum_i beta^(i+1)_k * f_i
+            d = []
+            for k in range(4):
+                e = self.chal(k)
+                if k == 0:
+                    e = e + (bus + 1)
+                for i, f in enumerate(fields):
+                    e = e + self.chal(4 * (i + 1) + k) * f
+                d.append(e)
+            phi = [self.perm(4 * j + k) for k in range(4)]
+            for m in range(4):
+                lo = None
+                for a in range(4):
+                    for b in range(4):
+                        if a + b == m or a + b == m + 4:
+                            t = phi[a] * d[b]
+                            if a + b == m + 4:
+                                t = t * EXT_W
+                            lo = t if lo is None else lo + t
+                if m == 0:
+                    lo = (lo - count) if sign == 0 else (lo + count)
+                self.assert_zero(lo)
+        s_loc = [self.perm(4 * n_int + k) for k in range(4)]
+        s_nxt = [self.perm(4 * n_int + k, 1) for k in range(4)]
+        for k in range(4):
+            row_sum, nxt_sum = None, None
+            for j in range(n_int):
+                row_sum = self.perm(4 * j + k) if row_sum is None else row_sum + self.perm(4 * j + k)
+                nxt_sum = self.perm(4 * j + k, 1) if nxt_sum is None else nxt_sum + self.perm(4 * j + k, 1)
+            self.when_first_row(s_loc[k] - row_sum)
+            self.when_transition(s_nxt[k] - s_loc[k] - nxt_sum)
+            self.when_last_row(s_loc[k] - self.exposed(k))
+
     def when_first_row(self, e):
         self.assert_zero(self.is_first_row() * e)
 
@@ -99,9 +172,9 @@ class AirBuilder:
     def max_degree(self):
         deg = {}
         for i, (op, a, b) in enumerate(self.nodes):
-            if op == OP_VAR or op in (OP_FIRST, OP_LAST):
+            if op in (OP_VAR, OP_PERM, OP_FIRST, OP_LAST):
                 deg[i] = 1
-            elif op in (OP_PUB, OP_CONST, OP_TRANS):
+            elif op in (OP_PUB, OP_CONST, OP_TRANS, OP_CHAL, OP_EXPOSED):
                 deg[i] = 0
             elif op in (OP_ADD, OP_SUB):
                 deg[i] = max(deg[a], deg[b])
@@ -112,10 +185,19 @@ class AirBuilder:
         return max((deg[c] for c in self.cons), default=0)
 
     def program(self):
+        self.finalize_interactions()
         words = [AIR_MAGIC, len(self.nodes), len(self.cons), self.n_pvs]
         for n in self.nodes:
             words.extend(n)
         words.extend(self.cons)
+        ints = getattr(self, "interactions", [])
+        if ints:
+            # trailing section: [LOGUP_MAGIC, n_int, {bus, sign, count leaf (3 words), n_fields, field leaves (3 words each)}]
+            words += [LOGUP_MAGIC, len(ints)]
+            for bus, sign, count, fields in ints:
+                words += [bus, sign] + list(self.nodes[count.idx]) + [len(fields)]
+                for f in fields:
+                    words += list(self.nodes[f.idx])
         return np.array(words, dtype=np.uint32)
 
 
@@ -144,15 +226,19 @@ def check_trace(program, trace, pvs):
         elif op == OP_TRANS:
             vals[i] = (rows != n - 1).astype(np.int64)
         elif op == OP_ADD:
-            vals[i] = (vals[a] + vals[b]) % P
+            vals[i] = None if vals[a] is None or vals[b] is None else (vals[a] + vals[b]) % P
         elif op == OP_SUB:
-            vals[i] = (vals[a] - vals[b]) % P
+            vals[i] = None if vals[a] is None or vals[b] is None else (vals[a] - vals[b]) % P
         elif op == OP_MUL:
-            vals[i] = (vals[a] * vals[b]) % P
+            vals[i] = None if vals[a] is None or vals[b] is None else (vals[a] * vals[b]) % P
+        elif op == OP_NEG:
+            vals[i] = None if vals[a] is None else (-vals[a]) % P
         else:
-            vals[i] = (-vals[a]) % P
+            vals[i] = None  # LogUp-phase leaf: only the main-trace constraints are checked here
     bad = []
     for k, c in enumerate(cons):
+        if vals[c] is None:
+            continue
         nz = np.nonzero(vals[c])[0]
         if len(nz):
             bad.append((k, int(nz[0])))
@@ -273,3 +359,36 @@ class SyntheticAir:
         if xp == "torch":
             return tr.to(torch.int32), pvs  # values < 2^31: bit pattern == canonical u32
         return tr.astype(np.uint32), pvs
+
+
+# ---- lookup demo AIRs for the LogUp phase ----------------------------------------------------------
+def lookup_sender_air(width=3, bus=7):
+    """Every row sends the pair (col0, col1) once on `bus`; col2 is unconstrained filler."""
+    b = AirBuilder(width, 0)
+    b.assert_zero(b.var(0) * (b.var(0) - 1) * 0 + b.var(2) - b.var(2))  # keeps a main-trace constraint around
+    b.push_interaction(bus, [b.var(0), b.var(1)], 1, "send")
+    return b
+
+
+def lookup_table_air(bus=7):
+    """Table of (key, value) pairs with a multiplicity column: receives each pair `mult` times."""
+    b = AirBuilder(3, 0)
+    b.push_interaction(bus, [b.var(0), b.var(1)], b.var(2), "receive")
+    return b
+
+
+def lookup_traces(log_n_sender, log_n_table, seed=0, sender_width=3):
+    """A satisfying pair of traces: the table holds distinct (key, key^2+1) rows, the sender picks rows
+    of the table at random, the multiplicity column counts the picks."""
+    rng = np.random.default_rng(seed)
+    nt, ns = 1 << log_n_table, 1 << log_n_sender
+    keys = rng.permutation(1 << 20)[:nt].astype(np.int64)
+    vals = (keys * keys + 1) % P
+    pick = rng.integers(0, nt, size=ns)
+    sender = np.zeros((sender_width, ns), dtype=np.uint32)
+    sender[0], sender[1] = keys[pick], vals[pick]
+    sender[2:] = rng.integers(0, P, size=(sender_width - 2, ns))
+    table = np.zeros((3, nt), dtype=np.uint32)
+    table[0], table[1] = keys, vals
+    table[2] = np.bincount(pick, minlength=nt)
+    return sender, table

@@ -22,13 +22,29 @@ constexpr uint32_t AIR_MAGIC = 0x31414B5Au;
 constexpr uint32_t PROOF_MAGIC = 0x31504B5Au;
 constexpr uint32_t PROTO_TAG = 0x5A4B4831u;
 
-enum AirOp : uint32_t { A_VAR, A_PUB, A_CONST, A_FIRST, A_LAST, A_TRANS, A_ADD, A_SUB, A_MUL, A_NEG };
+constexpr uint32_t LOGUP_MAGIC = 0x554C4B5Au;
+constexpr unsigned LOGUP_MAX_FIELDS = 8;
+constexpr unsigned N_CHAL = 4 * (1 + LOGUP_MAX_FIELDS);  // gamma, beta^1..beta^8 as base coordinates
+
+// A_PERM / A_CHAL / A_EXPOSED are the leaves of the after-challenge (LogUp) phase: a base column of the
+// permutation matrix, a coordinate of the interaction challenges, a coordinate of the exposed sum.
+enum AirOp : uint32_t { A_VAR, A_PUB, A_CONST, A_FIRST, A_LAST, A_TRANS, A_ADD, A_SUB, A_MUL, A_NEG, A_PERM, A_CHAL, A_EXPOSED };
+
+// one bus interaction: phi = (sign ? -count : count) / (gamma + bus + 1 + sum_i beta^(i+1) * field_i);
+// count and the fields are leaves (VAR of the current row, PUB or CONST), 3 words each as in the node table
+struct Interaction {
+    uint32_t bus = 0, sign = 0, n_fields = 0;
+    uint32_t count[3] = {0, 0, 0};
+    uint32_t fields[LOGUP_MAX_FIELDS][3] = {};
+};
 
 struct AirProgram {
     uint32_t n_nodes = 0, n_cons = 0, n_pvs = 0;
     const uint32_t* nodes = nullptr;  // 3 words each
     const uint32_t* cons = nullptr;
     unsigned max_degree = 0;
+    std::vector<Interaction> ints;
+    size_t perm_width() const { return ints.empty() ? 0 : 4 * (ints.size() + 1); }
 };
 
 inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p, std::string* err) {
@@ -40,9 +56,40 @@ inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p,
     p->n_nodes = w[1];
     p->n_cons = w[2];
     p->n_pvs = w[3];
-    if ((size_t)4 + 3 * (size_t)p->n_nodes + p->n_cons != len) return fail("AIR program length mismatch");
+    const size_t base_len = (size_t)4 + 3 * (size_t)p->n_nodes + p->n_cons;
+    if (base_len > len) return fail("AIR program length mismatch");
     p->nodes = w + 4;
     p->cons = w + 4 + 3 * (size_t)p->n_nodes;
+    p->ints.clear();
+    if (base_len != len) {  // trailing interactions section
+        size_t q = base_len;
+        if (q + 2 > len || w[q] != LOGUP_MAGIC) return fail("AIR program length mismatch");
+        const uint32_t n_int = w[q + 1];
+        q += 2;
+        if (n_int == 0 || n_int > 4096) return fail("bad interaction count");
+        auto leaf_ok = [&](const uint32_t* l) {
+            if (l[0] == A_VAR) return l[1] < width && l[2] == 0;
+            if (l[0] == A_PUB) return l[1] < p->n_pvs;
+            return l[0] == A_CONST && l[1] < P;
+        };
+        p->ints.resize(n_int);
+        for (uint32_t j = 0; j < n_int; j++) {
+            Interaction& it = p->ints[j];
+            if (q + 6 > len) return fail("truncated interaction");
+            it.bus = w[q], it.sign = w[q + 1], it.n_fields = w[q + 5];
+            for (int k = 0; k < 3; k++) it.count[k] = w[q + 2 + k];
+            q += 6;
+            if (it.sign > 1 || it.bus >= P - 1 || it.n_fields < 1 || it.n_fields > LOGUP_MAX_FIELDS || q + 3 * (size_t)it.n_fields > len)
+                return fail("bad interaction");
+            if (!leaf_ok(it.count)) return fail("interaction count is not a leaf");
+            for (uint32_t i = 0; i < it.n_fields; i++, q += 3) {
+                for (int k = 0; k < 3; k++) it.fields[i][k] = w[q + k];
+                if (!leaf_ok(it.fields[i])) return fail("interaction field is not a leaf");
+            }
+        }
+        if (q != len) return fail("AIR program length mismatch");
+    }
+    const size_t perm_w = p->perm_width();
     std::vector<unsigned> deg(p->n_nodes, 0);
     for (uint32_t i = 0; i < p->n_nodes; i++) {
         uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
@@ -76,6 +123,16 @@ inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p,
                 if (a >= i) return fail("operand not yet defined");
                 deg[i] = deg[a];
                 break;
+            case A_PERM:
+                if (a >= perm_w || b > 1) return fail("PERM out of range");
+                deg[i] = 1;
+                break;
+            case A_CHAL:
+                if (a >= N_CHAL || perm_w == 0) return fail("CHAL out of range");
+                break;
+            case A_EXPOSED:
+                if (a >= 4 || perm_w == 0) return fail("EXPOSED out of range");
+                break;
             default:
                 return fail("unknown AIR op");
         }
@@ -92,7 +149,8 @@ inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p,
 // instruction = 3 words: w0 = op | (dst << 8), w1 = operand a, w2 = operand b
 // operand = kind << 28 | payload; VAR payload = rot << 27 | column
 enum QOp : uint32_t { Q_ADD, Q_SUB, Q_MUL, Q_NEG, Q_ASSERT };
-enum QKind : uint32_t { K_SLOT, K_VAR, K_PUB, K_CONST, K_SEL };
+// PERM payload like VAR (column of the permutation LDE); CHAL / EXPO index the per-proof challenge block
+enum QKind : uint32_t { K_SLOT, K_VAR, K_PUB, K_CONST, K_SEL, K_PERM, K_CHAL, K_EXPO };
 constexpr unsigned Q_MAX_SLOTS = 60;
 
 struct CompiledAir {
@@ -103,7 +161,7 @@ struct CompiledAir {
 
 inline int compile_air(const AirProgram& p, CompiledAir* out, std::string* err) {
     const uint32_t n = p.n_nodes;
-    auto is_leaf = [&](uint32_t i) { return p.nodes[3 * i] <= A_TRANS; };
+    auto is_leaf = [&](uint32_t i) { return p.nodes[3 * i] <= A_TRANS || p.nodes[3 * i] >= A_PERM; };
     // reachability from the constraints
     std::vector<char> reach(n, 0);
     for (uint32_t k = 0; k < p.n_cons; k++) reach[p.cons[k]] = 1;
@@ -150,6 +208,12 @@ inline int compile_air(const AirProgram& p, CompiledAir* out, std::string* err) 
                 }
                 return (K_CONST << 28) | it->second;
             }
+            case A_PERM:
+                return (K_PERM << 28) | (b << 27) | a;
+            case A_CHAL:
+                return (K_CHAL << 28) | a;
+            case A_EXPOSED:
+                return (K_EXPO << 28) | a;
             default:
                 return (K_SEL << 28) | (op - A_FIRST);
         }

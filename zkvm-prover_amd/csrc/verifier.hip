@@ -111,22 +111,51 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         if (proof[i] >= P) return ZKHIP_ERR_VERIFY;
     std::vector<AirProgram> pg(n_airs);
     unsigned hmax = 0;
-    size_t n_open = 0;
+    size_t n_lu = 0;
     for (size_t a = 0; a < n_airs; a++) {
         if (parse_air(airs[a].program, airs[a].program_len, airs[a].width, &pg[a], nullptr) != 0) return ZKHIP_ERR_INVALID;
         if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height < 1) return ZKHIP_ERR_INVALID;
         if (pg[a].max_degree > nch + 1) return ZKHIP_ERR_CONSTRAINT;
         if (airs[a].n_pvs && (!pvs || !pvs[a])) return ZKHIP_ERR_INVALID;
         hmax = std::max(hmax, airs[a].log_height + b);
-        n_open += 2 * airs[a].width + 4 * (size_t)nch;
+        if (!pg[a].ints.empty()) n_lu++;
+    }
+    // committed matrices in opening order: main (every AIR), permutation (AIRs with interactions), quotient chunks
+    struct CMat {
+        unsigned lh, h;
+        size_t width;
+        unsigned n_pts;
+        size_t open_off;
+    };
+    std::vector<CMat> cm;
+    for (size_t a = 0; a < n_airs; a++) cm.push_back({airs[a].log_height, airs[a].log_height + b, airs[a].width, 2, 0});
+    for (size_t a = 0; a < n_airs; a++)
+        if (!pg[a].ints.empty()) cm.push_back({airs[a].log_height, airs[a].log_height + b, pg[a].perm_width(), 2, 0});
+    for (size_t a = 0; a < n_airs; a++)
+        for (unsigned j = 0; j < nch; j++) cm.push_back({airs[a].log_height, airs[a].log_height + b, 4, 1, 0});
+    const size_t cm_perm0 = n_airs, cm_quot0 = n_airs + n_lu;
+    size_t n_open = 0;
+    for (auto& m : cm) {
+        m.open_off = n_open;
+        n_open += m.width * m.n_pts;
     }
     const unsigned n_layers = hmax - b;
     size_t r = 0;
-    if (n_words < 4 + 16 + 4 * n_open + 9 * (size_t)n_layers + 5) return ZKHIP_ERR_VERIFY;
-    if (proof[0] != PROOF_MAGIC || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers) return ZKHIP_ERR_VERIFY;
+    const size_t lu_words = n_lu ? 8 + 4 * n_lu : 0;
+    if (n_words < 4 + 16 + lu_words + 4 * n_open + 9 * (size_t)n_layers + 5) return ZKHIP_ERR_VERIFY;
+    if (proof[0] != PROOF_MAGIC + (n_lu ? 1u : 0u) || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers)
+        return ZKHIP_ERR_VERIFY;
     r = 4;
-    const uint32_t *root_main = proof + r, *root_quot = proof + r + 8;
-    r += 16;
+    const uint32_t* root_main = proof + r;
+    r += 8;
+    const uint32_t *root_perm = nullptr, *exposed_c = nullptr;
+    if (n_lu) {
+        root_perm = proof + r;
+        exposed_c = proof + r + 8;
+        r += lu_words;
+    }
+    const uint32_t* root_quot = proof + r;
+    r += 8;
     const uint32_t* opened_c = proof + r;
     r += 4 * n_open;
     const uint32_t* fri_hdr = proof + r;
@@ -160,6 +189,22 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         }
     }
     ch.observe_canon(root_main, 8);
+    // LogUp phase: interaction challenges, permutation commitment, exposed sums (must cancel over all AIRs)
+    uint32_t chal[N_CHAL] = {};
+    if (n_lu) {
+        const Ext gamma = ch.sample_ext(), beta = ch.sample_ext();
+        Ext cur = beta;
+        for (int k = 0; k < 4; k++) chal[k] = gamma.c[k];
+        for (unsigned i = 1; i <= LOGUP_MAX_FIELDS; i++) {
+            for (int k = 0; k < 4; k++) chal[4 * i + k] = cur.c[k];
+            cur = ext_mul(cur, beta);
+        }
+        ch.observe_canon(root_perm, 8);
+        ch.observe_canon(exposed_c, 4 * n_lu);
+        Ext tot = ext_zero();
+        for (size_t k = 0; k < n_lu; k++) tot = ext_add(tot, ext_from_canon(exposed_c + 4 * k));
+        if (!ext_eq(tot, ext_zero())) return ZKHIP_ERR_VERIFY;
+    }
     const Ext alpha = ch.sample_ext();
     ch.observe_canon(root_quot, 8);
     const Ext zeta = ch.sample_ext();
@@ -168,8 +213,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     const uint32_t gen = to_monty(FIELD_GEN_CANON);
 
     // ---- constraints at zeta ----
-    size_t om = 0, oq = 0;
-    for (size_t a = 0; a < n_airs; a++) oq += 2 * airs[a].width;
+    size_t k_lu = 0;
     for (size_t a = 0; a < n_airs; a++) {
         const unsigned lh = airs[a].log_height, h = lh + b;
         const size_t W = airs[a].width;
@@ -186,8 +230,16 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         const Ext is_last = ext_mul(zh, ext_inv(is_trans));
         const Ext inv_zh = ext_inv(zh);
         std::vector<Ext> vals(pg[a].n_nodes);
-        const Ext* local = &opened[om];
-        const Ext* next = &opened[om + W];
+        const Ext* local = &opened[cm[a].open_off];
+        const Ext* next = local + W;
+        const Ext *plocal = nullptr, *pnext = nullptr;
+        const uint32_t* expo = nullptr;
+        if (!pg[a].ints.empty()) {
+            plocal = &opened[cm[cm_perm0 + k_lu].open_off];
+            pnext = plocal + pg[a].perm_width();
+            expo = exposed_c + 4 * k_lu;
+            k_lu++;
+        }
         for (uint32_t i = 0; i < pg[a].n_nodes; i++) {
             uint32_t op = pg[a].nodes[3 * i], x = pg[a].nodes[3 * i + 1], y = pg[a].nodes[3 * i + 2];
             switch (op) {
@@ -200,7 +252,10 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
                 case A_ADD: vals[i] = ext_add(vals[x], vals[y]); break;
                 case A_SUB: vals[i] = ext_sub(vals[x], vals[y]); break;
                 case A_MUL: vals[i] = ext_mul(vals[x], vals[y]); break;
-                default: vals[i] = ext_neg(vals[x]); break;
+                case A_NEG: vals[i] = ext_neg(vals[x]); break;
+                case A_PERM: vals[i] = y ? pnext[x] : plocal[x]; break;
+                case A_CHAL: vals[i] = ext_from_base(chal[x]); break;
+                default: vals[i] = ext_from_base(to_monty(expo[x])); break;
             }
         }
         Ext acc = ext_zero();
@@ -221,17 +276,16 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
                 uint32_t den = msub(mpow(mmul(sj, minv(sk)), (uint64_t)1 << lh), MONTY_ONE);
                 zps = ext_mul(zps, ext_mul_base(t, minv(den)));
             }
+            const Ext* chunk = &opened[cm[cm_quot0 + a * nch + j].open_off];
             Ext v = ext_zero();
             for (int k = 0; k < 4; k++) {
                 Ext e = ext_zero();
                 e.c[k] = MONTY_ONE;
-                v = ext_add(v, ext_mul(e, opened[oq + 4 * j + k]));
+                v = ext_add(v, ext_mul(e, chunk[k]));
             }
             rhs = ext_add(rhs, ext_mul(v, zps));
         }
         if (!ext_eq(lhs, rhs)) return ZKHIP_ERR_VERIFY;
-        om += 2 * W;
-        oq += 4 * (size_t)nch;
     }
 
     // ---- FRI transcript ----
@@ -247,70 +301,77 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     if (!ch.check_witness(prm->query_pow_bits, qpow)) return ZKHIP_ERR_VERIFY;
     const Ext fin = ext_from_canon(fin_c);
 
-    std::vector<unsigned> lh_main(n_airs), lh_quot(n_airs * nch);
-    std::vector<size_t> w_main(n_airs), w_quot(n_airs * nch);
-    size_t tw_main = 0, tw_quot = 0;
-    for (size_t a = 0; a < n_airs; a++) {
-        lh_main[a] = airs[a].log_height + b;
-        w_main[a] = airs[a].width;
-        tw_main += w_main[a];
-        for (unsigned j = 0; j < nch; j++) {
-            lh_quot[a * nch + j] = lh_main[a];
-            w_quot[a * nch + j] = 4;
-            tw_quot += 4;
+    // the input batches (one commitment each) as ranges of `cm`
+    struct Batch {
+        size_t first, n;
+        uint32_t root_m[8];
+        std::vector<unsigned> lhs;
+        std::vector<size_t> ws;
+        size_t tw = 0;
+        unsigned bh = 0;
+    };
+    std::vector<Batch> batches;
+    auto add_batch = [&](size_t first, size_t n, const uint32_t* root_c) {
+        Batch bt;
+        bt.first = first, bt.n = n;
+        for (int k = 0; k < 8; k++) bt.root_m[k] = to_monty(root_c[k]);
+        for (size_t m = first; m < first + n; m++) {
+            bt.lhs.push_back(cm[m].h);
+            bt.ws.push_back(cm[m].width);
+            bt.tw += cm[m].width;
+            bt.bh = std::max(bt.bh, cm[m].h);
         }
-    }
-    uint32_t root_main_m[8], root_quot_m[8];
-    for (int k = 0; k < 8; k++) {
-        root_main_m[k] = to_monty(root_main[k]);
-        root_quot_m[k] = to_monty(root_quot[k]);
-    }
+        batches.push_back(bt);
+    };
+    add_batch(0, n_airs, root_main);
+    if (n_lu) add_batch(cm_perm0, n_lu, root_perm);
+    add_batch(cm_quot0, n_airs * nch, root_quot);
     std::vector<Ext> roq(hmax + 1);
     std::vector<char> has(hmax + 1);
     std::vector<uint64_t> num_reduced(hmax + 1);
+    std::vector<const uint32_t*> rows_of(batches.size());
     for (unsigned qn = 0; qn < prm->num_queries; qn++) {
         const size_t idx = ch.sample_bits(hmax);
-        const size_t n_main = tw_main + 8 * (size_t)hmax, n_quot = tw_quot + 8 * (size_t)hmax;
-        if (r + n_main + n_quot > n_words) return ZKHIP_ERR_VERIFY;
-        const uint32_t *op_main = proof + r, *op_quot = proof + r + n_main;
-        r += n_main + n_quot;
-        if (!verify_opening(root_main_m, lh_main, w_main, idx, op_main)) return ZKHIP_ERR_VERIFY;
-        if (!verify_opening(root_quot_m, lh_quot, w_quot, idx, op_quot)) return ZKHIP_ERR_VERIFY;
+        for (size_t bi = 0; bi < batches.size(); bi++) {
+            const Batch& bt = batches[bi];
+            const size_t n_op = bt.tw + 8 * (size_t)bt.bh;
+            if (r + n_op > n_words) return ZKHIP_ERR_VERIFY;
+            rows_of[bi] = proof + r;
+            r += n_op;
+            if (!verify_opening(bt.root_m, bt.lhs, bt.ws, idx >> (hmax - bt.bh), rows_of[bi])) return ZKHIP_ERR_VERIFY;
+        }
         std::fill(roq.begin(), roq.end(), ext_zero());
         std::fill(has.begin(), has.end(), 0);
         std::fill(num_reduced.begin(), num_reduced.end(), 0);
         size_t oi = 0;
-        for (int round = 0; round < 2; round++) {
-            const uint32_t* rows = round == 0 ? op_main : op_quot;
-            for (size_t a = 0; a < n_airs; a++) {
-                const unsigned h = airs[a].log_height + b;
-                const unsigned n_mats = round == 0 ? 1 : nch;
-                const size_t W = round == 0 ? airs[a].width : 4;
-                const unsigned n_pts = round == 0 ? 2 : 1;
+        for (size_t bi = 0; bi < batches.size(); bi++) {
+            const uint32_t* rows = rows_of[bi];
+            for (size_t mi = 0; mi < batches[bi].n; mi++) {
+                const CMat& M = cm[batches[bi].first + mi];
+                const unsigned h = M.h;
+                const size_t W = M.width;
                 const size_t ih = idx >> (hmax - h);
                 const uint32_t x = mmul(gen, mpow(two_adic_generator(h), bitrev32((uint32_t)ih, h)));
                 has[h] = 1;
-                for (unsigned j = 0; j < n_mats; j++) {
-                    std::vector<Ext> apow(W);
-                    Ext rrow = ext_zero(), cur = ext_one();
-                    for (size_t k = 0; k < W; k++) {
-                        apow[k] = cur;
-                        rrow = ext_add(rrow, ext_mul_base(cur, to_monty(rows[k])));
-                        cur = ext_mul(cur, alpha_f);
-                    }
-                    for (unsigned pt = 0; pt < n_pts; pt++) {
-                        Ext z = pt == 0 ? zeta : ext_mul_base(zeta, two_adic_generator(airs[a].log_height));
-                        Ext ry = ext_zero();
-                        for (size_t k = 0; k < W; k++) ry = ext_add(ry, ext_mul(apow[k], opened[oi + k]));
-                        Ext d = z;
-                        d.c[0] = msub(d.c[0], x);
-                        Ext u = ext_mul(ext_mul(ext_sub(ry, rrow), ext_inv(d)), ext_pow(alpha_f, num_reduced[h]));
-                        roq[h] = ext_add(roq[h], u);
-                        num_reduced[h] += W;
-                        oi += W;
-                    }
-                    rows += W;
+                std::vector<Ext> apow(W);
+                Ext rrow = ext_zero(), cur = ext_one();
+                for (size_t k = 0; k < W; k++) {
+                    apow[k] = cur;
+                    rrow = ext_add(rrow, ext_mul_base(cur, to_monty(rows[k])));
+                    cur = ext_mul(cur, alpha_f);
                 }
+                for (unsigned pt = 0; pt < M.n_pts; pt++) {
+                    Ext z = pt == 0 ? zeta : ext_mul_base(zeta, two_adic_generator(M.lh));
+                    Ext ry = ext_zero();
+                    for (size_t k = 0; k < W; k++) ry = ext_add(ry, ext_mul(apow[k], opened[oi + k]));
+                    Ext d = z;
+                    d.c[0] = msub(d.c[0], x);
+                    Ext u = ext_mul(ext_mul(ext_sub(ry, rrow), ext_inv(d)), ext_pow(alpha_f, num_reduced[h]));
+                    roq[h] = ext_add(roq[h], u);
+                    num_reduced[h] += W;
+                    oi += W;
+                }
+                rows += W;
             }
         }
         Ext eval = roq[hmax];
