@@ -392,3 +392,27 @@ def lookup_traces(log_n_sender, log_n_table, seed=0, sender_width=3):
     table[0], table[1] = keys, vals
     table[2] = np.bincount(pick, minlength=nt)
     return sender, table
+
+
+def bus_mix_air(width=6):
+    """Exercises every interaction operand form in one AIR: a constant field, a public-value field, a
+    constant multiplicity and a column multiplicity; the AIR sends and receives the same messages, so
+    it balances on its own.  pvs = (tag,)."""
+    b = AirBuilder(width, 1)
+    b.assert_zero(b.var(0) * b.var(1) - b.var(2))
+    b.push_interaction(3, [b.var(0), 5, b.pub(0)], b.var(3), "send")
+    b.push_interaction(3, [b.var(0), 5, b.pub(0)], b.var(3), "receive")
+    b.push_interaction(9, [b.var(1)], 1, "send")
+    b.push_interaction(9, [b.var(4)], 1, "receive")
+    b.push_interaction(11, [b.var(0), b.var(1), b.var(2), b.var(3), b.var(4), b.var(5), 7, b.pub(0)], 2, "send")
+    b.push_interaction(11, [b.var(0), b.var(1), b.var(2), b.var(3), b.var(4), b.var(5), 7, b.pub(0)], b.const(2), "receive")
+    return b
+
+
+def bus_mix_trace(log_n, seed=0, width=6):
+    rng = np.random.default_rng(seed)
+    n = 1 << log_n
+    t = rng.integers(0, P, size=(width, n)).astype(np.int64)
+    t[2] = t[0] * t[1] % P
+    t[4] = t[1][rng.permutation(n)]          # bus 9: column 4 is a permutation of column 1
+    return t.astype(np.uint32), np.array([rng.integers(0, P)], dtype=np.uint32)

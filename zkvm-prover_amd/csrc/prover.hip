@@ -51,6 +51,9 @@ struct QuotArgs {
     const uint32_t* pvs;    // Montgomery
     const uint32_t* apow;   // n_cons extension elements: alpha^(n_cons-1-k)
     const uint32_t* lde;    // column-major, stride = M
+    const uint32_t* perm;   // permutation LDE (column-major, stride = M) or null
+    const uint32_t* lchal;  // N_CHAL interaction challenge coordinates or null
+    const uint32_t* expo;   // 4 coordinates of the exposed cumulative sum or null
     uint32_t* q;            // 4 columns of M (quotient values, bit-reversed LDE order)
     const uint32_t* tw_fwd;
     const uint32_t* inv_zh; // 2^b values, index = natural index mod 2^b
@@ -88,6 +91,14 @@ __global__ __launch_bounds__(QBS) void k_quotient(QuotArgs a) {
                 return a.pvs[idx];
             case K_CONST:
                 return a.consts[idx];
+            case K_PERM: {
+                const uint32_t col = idx & 0x07ffffffu;
+                return a.perm[(size_t)col * M + ((idx >> 27) ? rn : r)];
+            }
+            case K_CHAL:
+                return a.lchal[idx];
+            case K_EXPO:
+                return a.expo[idx];
             default:
                 return idx == 0 ? sel_first : (idx == 1 ? sel_last : sel_trans);
         }
@@ -121,6 +132,83 @@ __global__ void k_ext_powers(const uint32_t* base, uint32_t n, int reverse, uint
     for (uint32_t k = 0; k < n; k++) {
         st_ext(out + 4 * (size_t)(reverse ? n - 1 - k : k), cur);
         cur = ext_mul(cur, bse);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LogUp phase (bus interactions; K6).  lchal = gamma, beta^1 .. beta^8 as base coordinates.
+__global__ void k_logup_chal(const uint32_t* gb, uint32_t* lchal) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const Ext gamma = ld_ext(gb), beta = ld_ext(gb + 4);
+    st_ext(lchal, gamma);
+    Ext cur = beta;
+    for (unsigned i = 1; i <= LOGUP_MAX_FIELDS; i++) {
+        st_ext(lchal + 4 * i, cur);
+        cur = ext_mul(cur, beta);
+    }
+}
+
+// interaction table on the device: LU_STRIDE words per interaction
+//   [0] bus+1 (Montgomery)  [1] sign  [2] count kind  [3] count value  [4] n_fields  [5+2i] kind_i  [6+2i] value_i
+// kind 0 = trace column (value = column), 1 = public value (index), 2 = constant (Montgomery)
+constexpr unsigned LU_STRIDE = 5 + 2 * LOGUP_MAX_FIELDS;
+struct LogupArgs {
+    const uint32_t* trace;  // column-major, stride N, Montgomery
+    const uint32_t* pvs;
+    const uint32_t* tab;
+    const uint32_t* lchal;
+    uint32_t* den;   // n_int x N extension elements, [j][r]
+    uint32_t* num;   // n_int x N signed multiplicities
+    uint32_t* perm;  // 4 (n_int + 1) columns x N
+    uint32_t* sums;  // N extension elements: row sums, then (after the scan) the running sum
+    uint32_t* expo;  // 4 words
+    size_t N;
+    uint32_t n_int;
+};
+__device__ __forceinline__ uint32_t lu_leaf(const LogupArgs& a, uint32_t kind, uint32_t val, size_t r) {
+    return kind == 0 ? a.trace[(size_t)val * a.N + r] : (kind == 1 ? a.pvs[val] : val);
+}
+// grid (rows / 256, n_int): denominator gamma + bus + 1 + sum_i beta^(i+1) f_i and numerator +-count of one row
+__global__ __launch_bounds__(256) void k_logup_denoms(LogupArgs a) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.N) return;
+    const uint32_t j = blockIdx.y;
+    const uint32_t* t = a.tab + (size_t)j * LU_STRIDE;
+    Ext den = ld_ext(a.lchal);
+    den.c[0] = madd(den.c[0], t[0]);
+    const uint32_t nf = t[4];
+    for (uint32_t i = 0; i < nf; i++) {
+        const uint32_t f = lu_leaf(a, t[5 + 2 * i], t[6 + 2 * i], r);
+        den = ext_add(den, ext_mul_base(ld_ext(a.lchal + 4 * (i + 1)), f));
+    }
+    reinterpret_cast<uint4*>(a.den)[(size_t)j * a.N + r] = make_uint4(den.c[0], den.c[1], den.c[2], den.c[3]);
+    const uint32_t cnt = lu_leaf(a, t[2], t[3], r);
+    a.num[(size_t)j * a.N + r] = t[1] ? mneg(cnt) : cnt;
+}
+// after the batch inversion den holds phi_j[r]: write the phi columns and the row sums
+__global__ __launch_bounds__(256) void k_logup_rows(LogupArgs a) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.N) return;
+    Ext sum = ext_zero();
+    for (uint32_t j = 0; j < a.n_int; j++) {
+        const uint4 v = reinterpret_cast<const uint4*>(a.den)[(size_t)j * a.N + r];
+        const Ext phi{{v.x, v.y, v.z, v.w}};
+#pragma unroll
+        for (int q = 0; q < 4; q++) a.perm[(size_t)(4 * j + q) * a.N + r] = phi.c[q];
+        sum = ext_add(sum, phi);
+    }
+    reinterpret_cast<uint4*>(a.sums)[r] = make_uint4(sum.c[0], sum.c[1], sum.c[2], sum.c[3]);
+}
+// running-sum columns and the exposed total
+__global__ __launch_bounds__(256) void k_logup_sums(LogupArgs a) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.N) return;
+    const uint4 v = reinterpret_cast<const uint4*>(a.sums)[r];
+    const uint32_t c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        a.perm[(size_t)(4 * a.n_int + q) * a.N + r] = c[q];
+        if (r == a.N - 1) a.expo[q] = c[q];
     }
 }
 
@@ -418,7 +506,16 @@ struct AirPlan {
     uint32_t* d_qnat = nullptr;    // 2^b chunks x 4 columns x N (natural order)
     uint32_t* d_qlde = nullptr;    // 2^b chunks x 4 columns x M
     uint32_t* d_apow_q = nullptr;  // n_cons ext
-    size_t opened_main_off = 0, opened_quot_off = 0;  // in ext units inside d_opened
+    size_t opened_main_off = 0, opened_perm_off = 0, opened_quot_off = 0;  // in ext units inside d_opened
+    // LogUp phase (AIRs with bus interactions)
+    uint32_t n_int = 0;
+    size_t perm_w = 0, lu_index = 0;   // width of the permutation matrix; rank among the AIRs with interactions
+    uint32_t* d_lu_tab = nullptr;      // interaction table (LU_STRIDE words each)
+    uint32_t* d_lu_den = nullptr;      // n_int x N ext
+    uint32_t* d_lu_num = nullptr;      // n_int x N
+    uint32_t* d_lu_sums = nullptr;     // N ext
+    uint32_t* d_perm = nullptr;        // perm_w columns x N (natural order)
+    uint32_t* d_perm_lde = nullptr;    // perm_w columns x M
     hipModule_t jit_mod = nullptr;   // keygen-compiled constraint kernel (null -> interpreter)
     hipFunction_t jit_fn = nullptr;
     uint32_t* d_jit_tab = nullptr;   // per-instance leaf parameters of the shape classes
@@ -444,7 +541,12 @@ struct zkhip_pk {
     uint32_t* d_apow_f = nullptr;   // max width ext
     std::vector<uint32_t*> d_ro;    // per log height (nullptr if none)
     std::vector<uint32_t*> d_flayer;  // n_layers+1
+    size_t n_lu = 0;                // AIRs with bus interactions
+    unsigned h_perm = 0;            // log height of the permutation commitment
+    uint32_t* d_lchal = nullptr;    // N_CHAL challenge coordinates, then the raw gamma, beta (8 words)
+    uint32_t* d_exposed = nullptr;  // 4 x n_lu (Montgomery)
     zkhip_tree* t_main = nullptr;
+    zkhip_tree* t_perm = nullptr;
     zkhip_tree* t_quot = nullptr;
     std::vector<zkhip_tree*> t_fri;
     FriLayerDesc* d_fri_desc = nullptr;
@@ -452,7 +554,8 @@ struct zkhip_pk {
     uint32_t* d_proof = nullptr;
     // proof layout (words)
     size_t proof_words = 0, off_roots = 0, off_opened = 0, off_fri = 0, off_final = 0, off_qpow = 0, off_queries = 0;
-    size_t query_pitch = 0, q_main_words = 0, q_quot_words = 0;
+    size_t off_root_perm = 0, off_exposed = 0, off_root_quot = 0;
+    size_t query_pitch = 0, q_main_words = 0, q_perm_words = 0, q_quot_words = 0;
 };
 
 namespace {
@@ -490,7 +593,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     pk->nch = 1u << pk->b;
     pk->airs.resize(n_airs);
     std::string err;
-    size_t n_open = 0, max_n = 0, max_w = 4, tw_main = 0;
+    size_t n_open = 0, max_n = 0, max_w = 4, tw_main = 0, tw_perm = 0;
     for (size_t a = 0; a < n_airs; a++) {
         AirPlan& A = pk->airs[a];
         if (airs[a].log_height < 1 || airs[a].log_height + pk->b > 27 || airs[a].width == 0) {
@@ -522,6 +625,14 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         max_n = std::max(max_n, A.N);
         max_w = std::max(max_w, A.width);
         tw_main += A.width;
+        A.n_int = (uint32_t)A.prog.ints.size();
+        A.perm_w = A.prog.perm_width();
+        if (A.n_int) {
+            A.lu_index = pk->n_lu++;
+            pk->h_perm = std::max(pk->h_perm, A.h);
+            max_w = std::max(max_w, A.perm_w);
+            tw_perm += A.perm_w;
+        }
         // program digest (binds the proof to the constraint set)
         std::vector<uint32_t> pm(A.program_words.size());
         for (size_t i = 0; i < pm.size(); i++) pm[i] = to_monty(A.program_words[i]);
@@ -530,10 +641,14 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         for (int i = 0; i < 8; i++) A.digest[i] = from_monty(dg[i]);
     }
     pk->n_layers = pk->hmax - pk->b;
-    // opened-value layout: main (all airs) then quotient (all airs)
+    // opened-value layout: main (all airs), permutation (airs with interactions), quotient (all airs)
     for (size_t a = 0; a < n_airs; a++) {
         pk->airs[a].opened_main_off = n_open;
         n_open += 2 * pk->airs[a].width;
+    }
+    for (size_t a = 0; a < n_airs; a++) {
+        pk->airs[a].opened_perm_off = n_open;
+        n_open += 2 * pk->airs[a].perm_w;
     }
     for (size_t a = 0; a < n_airs; a++) {
         pk->airs[a].opened_quot_off = n_open;
@@ -559,7 +674,14 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     {
         size_t w = 4;
         pk->off_roots = w;
-        w += 16;
+        w += 8;
+        if (pk->n_lu) {
+            pk->off_root_perm = w;
+            pk->off_exposed = w + 8;
+            w += 8 + 4 * pk->n_lu;
+        }
+        pk->off_root_quot = w;
+        w += 8;
         pk->off_opened = w;
         w += 4 * n_open;
         pk->off_fri = w;
@@ -570,8 +692,9 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         w += 1;
         pk->off_queries = w;
         pk->q_main_words = tw_main + 8 * (size_t)pk->hmax;
+        pk->q_perm_words = pk->n_lu ? tw_perm + 8 * (size_t)pk->h_perm : 0;
         pk->q_quot_words = 4 * (size_t)pk->nch * n_airs + 8 * (size_t)pk->hmax;
-        size_t pitch = pk->q_main_words + pk->q_quot_words;
+        size_t pitch = pk->q_main_words + pk->q_perm_words + pk->q_quot_words;
         for (unsigned l = 0; l < pk->n_layers; l++) pitch += 4 + 8 * (size_t)(pk->hmax - l - 1);
         pk->query_pitch = pitch;
         w += pitch * params->num_queries;
@@ -582,6 +705,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     const unsigned nch = pk->nch;
     struct AirOff {
         size_t code, consts, zh, inv_zh, pvs, lde, q, qnat, qlde, apow_q;
+        size_t lu_tab, lu_den, lu_num, lu_sums, perm, perm_lde;
     };
     std::vector<AirOff> ao(n_airs);
     std::vector<CompiledAir> comp(n_airs);
@@ -620,7 +744,18 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         ao[a].qnat = bp.take(A.M * 4 * 4);
         ao[a].qlde = bp.take((size_t)nch * A.M * 4 * 4);
         ao[a].apow_q = bp.take((size_t)(A.prog.n_cons + 1) * 16);
+        if (A.n_int) {
+            ao[a].lu_tab = bp.take((size_t)A.n_int * LU_STRIDE * 4);
+            ao[a].lu_den = bp.take((size_t)A.n_int * A.N * 16);
+            ao[a].lu_num = bp.take((size_t)A.n_int * A.N * 4);
+            ao[a].lu_sums = bp.take(A.N * 16);
+            ao[a].perm = bp.take(A.perm_w * A.N * 4);
+            ao[a].perm_lde = bp.take(A.perm_w * A.M * 4);
+        }
     }
+    size_t o_lchal = bp.take((N_CHAL + 8) * 4);
+    size_t o_exposed = bp.take((4 * pk->n_lu + 4) * 4);
+    size_t o_dig_perm = pk->n_lu ? bp.take(merkle_digest_count(pk->h_perm) * 32) : 0;
     size_t o_tr = bp.take(sizeof(DevTranscript));
     size_t o_pre = bp.take(pk->preamble.size() * 4);
     size_t o_chal = bp.take((3 + pk->n_layers) * 16);
@@ -650,7 +785,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     }
     char* base = (char*)pk->d_ws;
     int rc = ZKHIP_OK;
-    std::vector<zkhip_matrix> mm, qm;
+    std::vector<zkhip_matrix> mm, pmm, qm;
     for (size_t a = 0; a < n_airs && rc == ZKHIP_OK; a++) {
         AirPlan& A = pk->airs[a];
         A.d_code = (uint32_t*)(base + ao[a].code);
@@ -674,12 +809,38 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         }
         if (rc == ZKHIP_OK) rc = upload(ctx, A.d_zh, zh.data(), nch * 4);
         if (rc == ZKHIP_OK) rc = upload(ctx, A.d_inv_zh, izh.data(), nch * 4);
+        if (A.n_int) {
+            A.d_lu_tab = (uint32_t*)(base + ao[a].lu_tab);
+            A.d_lu_den = (uint32_t*)(base + ao[a].lu_den);
+            A.d_lu_num = (uint32_t*)(base + ao[a].lu_num);
+            A.d_lu_sums = (uint32_t*)(base + ao[a].lu_sums);
+            A.d_perm = (uint32_t*)(base + ao[a].perm);
+            A.d_perm_lde = (uint32_t*)(base + ao[a].perm_lde);
+            std::vector<uint32_t> tab((size_t)A.n_int * LU_STRIDE, 0);
+            auto leaf = [](const uint32_t* l, uint32_t* kind, uint32_t* val) {
+                *kind = l[0] == A_VAR ? 0u : (l[0] == A_PUB ? 1u : 2u);
+                *val = l[0] == A_CONST ? to_monty(l[1]) : l[1];
+            };
+            for (uint32_t j = 0; j < A.n_int; j++) {
+                const Interaction& it = A.prog.ints[j];
+                uint32_t* t = &tab[(size_t)j * LU_STRIDE];
+                t[0] = to_monty(it.bus + 1);
+                t[1] = it.sign;
+                leaf(it.count, &t[2], &t[3]);
+                t[4] = it.n_fields;
+                for (uint32_t i = 0; i < it.n_fields; i++) leaf(it.fields[i], &t[5 + 2 * i], &t[6 + 2 * i]);
+            }
+            if (rc == ZKHIP_OK) rc = upload(ctx, A.d_lu_tab, tab.data(), tab.size() * 4);
+            pmm.push_back(zkhip_matrix{A.d_perm_lde, A.M, A.h, A.perm_w});
+        }
         mm.push_back(zkhip_matrix{A.d_lde, A.M, A.h, A.width});
         for (unsigned j = 0; j < nch; j++) qm.push_back(zkhip_matrix{A.d_qlde + (size_t)j * 4 * A.M, A.M, A.h, 4});
     }
     pk->d_tr = (DevTranscript*)(base + o_tr);
     pk->d_preamble = (uint32_t*)(base + o_pre);
     pk->d_chal = (uint32_t*)(base + o_chal);
+    pk->d_lchal = (uint32_t*)(base + o_lchal);
+    pk->d_exposed = (uint32_t*)(base + o_exposed);
     pk->d_opened = (uint32_t*)(base + o_opened);
     pk->d_pts = (uint32_t*)(base + o_pts);
     pk->d_weights = (uint32_t*)(base + o_weights);
@@ -695,10 +856,11 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     pk->d_proof = (uint32_t*)(base + o_proof);
     pk->d_fri_desc = (FriLayerDesc*)(base + o_desc);
     if (rc == ZKHIP_OK) rc = merkle_plan(ctx, mm.data(), mm.size(), (uint32_t*)(base + o_dig_main), &pk->t_main);
+    if (rc == ZKHIP_OK && pk->n_lu) rc = merkle_plan(ctx, pmm.data(), pmm.size(), (uint32_t*)(base + o_dig_perm), &pk->t_perm);
     if (rc == ZKHIP_OK) rc = merkle_plan(ctx, qm.data(), qm.size(), (uint32_t*)(base + o_dig_quot), &pk->t_quot);
     pk->t_fri.assign(pk->n_layers, nullptr);
     std::vector<FriLayerDesc> desc(pk->n_layers);
-    size_t qoff = pk->q_main_words + pk->q_quot_words;
+    size_t qoff = pk->q_main_words + pk->q_perm_words + pk->q_quot_words;
     for (unsigned l = 0; l < pk->n_layers && rc == ZKHIP_OK; l++) {
         rc = merkle_plan_leaves(ctx, pk->hmax - l - 1, (uint32_t*)(base + o_dig_fri[l]), &pk->t_fri[l]);
         desc[l].layer = pk->d_flayer[l];
@@ -721,6 +883,7 @@ void zkhip_pk_destroy(zkhip_ctx* ctx, zkhip_pk* pk) {
     if (!pk) return;
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (pk->t_main) zkhip_tree_destroy(ctx, pk->t_main);
+    if (pk->t_perm) zkhip_tree_destroy(ctx, pk->t_perm);
     if (pk->t_quot) zkhip_tree_destroy(ctx, pk->t_quot);
     for (auto* t : pk->t_fri)
         if (t) zkhip_tree_destroy(ctx, t);
@@ -764,7 +927,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));  // pm is a stack temporary
         }
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_preamble, pre.data(), pre.size() * 4, hipMemcpyHostToDevice, st));
-        uint32_t hdr[4] = {PROOF_MAGIC, (uint32_t)n_airs, hmax, pk->n_layers};
+        uint32_t hdr[4] = {PROOF_MAGIC + (pk->n_lu ? 1u : 0u), (uint32_t)n_airs, hmax, pk->n_layers};
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_proof, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
         ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));
         ZK_TRY(transcript_init(ctx, pk->d_tr));
@@ -780,6 +943,55 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     ZK_TRY(merkle_build(ctx, pk->t_main, false));
     const uint32_t* d_root_main = zkhip_tree_root_device(pk->t_main);
     ZK_TRY(transcript_observe(ctx, pk->d_tr, d_root_main, 8, false));
+
+    // ---- 1b. LogUp phase: permutation trace of every AIR with bus interactions, LDE + commit ----
+    const uint32_t* d_root_perm = nullptr;
+    if (pk->n_lu) {
+        uint32_t* d_gb = pk->d_lchal + N_CHAL;
+        ZK_TRY(transcript_sample(ctx, pk->d_tr, d_gb, nullptr, 4));
+        ZK_TRY(transcript_sample(ctx, pk->d_tr, d_gb + 4, nullptr, 4));
+        {
+            KernelScope ks(ctx, "logup_chal");
+            hipLaunchKernelGGL(k_logup_chal, dim3(1), dim3(64), 0, st, d_gb, pk->d_lchal);
+        }
+        for (size_t a = 0; a < n_airs; a++) {
+            AirPlan& A = pk->airs[a];
+            if (!A.n_int) continue;
+            LogupArgs la;
+            la.trace = d_traces[a];
+            la.pvs = A.d_pvs;
+            la.tab = A.d_lu_tab;
+            la.lchal = pk->d_lchal;
+            la.den = A.d_lu_den;
+            la.num = A.d_lu_num;
+            la.perm = A.d_perm;
+            la.sums = A.d_lu_sums;
+            la.expo = pk->d_exposed + 4 * A.lu_index;
+            la.N = A.N;
+            la.n_int = A.n_int;
+            const unsigned rb = (unsigned)((A.N + 255) / 256);
+            {
+                KernelScope ks(ctx, "logup_denoms");
+                hipLaunchKernelGGL(k_logup_denoms, dim3(rb, A.n_int), dim3(256), 0, st, la);
+            }
+            ZK_TRY(launch_batch_inverse(ctx, A.d_lu_den, A.d_lu_den, (size_t)A.n_int * A.N, A.d_lu_num));
+            {
+                KernelScope ks(ctx, "logup_rows");
+                hipLaunchKernelGGL(k_logup_rows, dim3(rb), dim3(256), 0, st, la);
+            }
+            ZK_TRY(ext_inclusive_scan(ctx, A.d_lu_sums, A.N));
+            {
+                KernelScope ks(ctx, "logup_sums");
+                hipLaunchKernelGGL(k_logup_sums, dim3(rb), dim3(256), 0, st, la);
+            }
+            ZK_HIP_CHECK(ctx, hipGetLastError());
+            ZK_TRY(lde_batch(ctx, A.d_perm, A.N, A.d_perm_lde, A.M, A.lh, b, A.perm_w, gen));
+        }
+        ZK_TRY(merkle_build(ctx, pk->t_perm, false));
+        d_root_perm = zkhip_tree_root_device(pk->t_perm);
+        ZK_TRY(transcript_observe(ctx, pk->d_tr, d_root_perm, 8, false));
+        ZK_TRY(transcript_observe(ctx, pk->d_tr, pk->d_exposed, (uint32_t)(4 * pk->n_lu), false));
+    }
     ZK_TRY(transcript_sample(ctx, pk->d_tr, d_alpha, nullptr, 4));
 
     // ---- 2. quotient ----
@@ -796,6 +1008,9 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         qa.pvs = A.d_pvs;
         qa.apow = A.d_apow_q;
         qa.lde = A.d_lde;
+        qa.perm = A.d_perm_lde;
+        qa.lchal = pk->d_lchal;
+        qa.expo = pk->d_exposed + 4 * A.lu_index;
         qa.q = A.d_q;
         qa.tw_fwd = ctx->d_tw_fwd;
         qa.inv_zh = A.d_inv_zh;
@@ -809,7 +1024,8 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             KernelScope ks(ctx, "quotient_eval_jit");
             void* params[] = {(void*)&qa.lde, (void*)&qa.q,      (void*)&qa.pvs,      (void*)&qa.apow,
                               (void*)&qa.tw_fwd, (void*)&qa.zh,  (void*)&qa.inv_zh,   (void*)&A.d_jit_tab,
-                              (void*)&qa.gen, (void*)&qa.w_n_inv, (void*)&qa.tw_shift};
+                              (void*)&qa.gen, (void*)&qa.w_n_inv, (void*)&qa.tw_shift, (void*)&qa.perm,
+                              (void*)&qa.lchal, (void*)&qa.expo};
             ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, (unsigned)((A.M + 255) / 256), 1, 1, 256, 1, 1, 0, st,
                                                     params, nullptr));
         } else {
@@ -883,6 +1099,11 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     }
     for (size_t a = 0; a < n_airs; a++) {
         AirPlan& A = pk->airs[a];
+        if (A.n_int)
+            ZK_TRY(open_matrix(A.d_perm, A.N, (uint32_t)A.perm_w, A.lh, 2, MONTY_ONE, pk->d_opened + 4 * A.opened_perm_off));
+    }
+    for (size_t a = 0; a < n_airs; a++) {
+        AirPlan& A = pk->airs[a];
         for (unsigned j = 0; j < nch; j++) {
             uint32_t sj = mmul(gen, host_pow(two_adic_generator(A.h), bitrev32(j, b)));
             ZK_TRY(open_matrix(A.d_qnat + (size_t)j * 4 * A.N, A.N, 4, A.lh, 1, sj,
@@ -896,15 +1117,17 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     {
         std::vector<uint64_t> num_reduced(hmax + 1, 0);
         std::vector<char> started(hmax + 1, 0);
-        for (int round = 0; round < 2; round++)
+        for (int round = 0; round < 3; round++)  // main, permutation, quotient chunks
             for (size_t a = 0; a < n_airs; a++) {
                 AirPlan& A = pk->airs[a];
-                const unsigned n_mats = round == 0 ? 1 : nch;
+                if (round == 1 && !A.n_int) continue;
+                const unsigned n_mats = round == 2 ? nch : 1;
                 for (unsigned j = 0; j < n_mats; j++) {
-                    const uint32_t W = round == 0 ? (uint32_t)A.width : 4u;
-                    const unsigned n_pts = round == 0 ? 2 : 1;
-                    const uint32_t* mat = round == 0 ? A.d_lde : A.d_qlde + (size_t)j * 4 * A.M;
-                    const uint32_t* opened = pk->d_opened + 4 * (round == 0 ? A.opened_main_off
+                    const uint32_t W = round == 0 ? (uint32_t)A.width : (round == 1 ? (uint32_t)A.perm_w : 4u);
+                    const unsigned n_pts = round == 2 ? 1 : 2;
+                    const uint32_t* mat = round == 0 ? A.d_lde : (round == 1 ? A.d_perm_lde : A.d_qlde + (size_t)j * 4 * A.M);
+                    const uint32_t* opened = pk->d_opened + 4 * (round == 0   ? A.opened_main_off
+                                                                 : round == 1 ? A.opened_perm_off
                                                                               : A.opened_quot_off + 4 * (size_t)j);
                     // points of this matrix: zeta (and zeta * w_N)
                     PointsArgs pa;
@@ -985,7 +1208,12 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         KernelScope ks(ctx, "copy_canon");
         hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, pk->d_flayer[pk->n_layers], pf + pk->off_final, 4u);
         hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_main, pf + pk->off_roots, 8u);
-        hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_quot, pf + pk->off_roots + 8, 8u);
+        hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_quot, pf + pk->off_root_quot, 8u);
+        if (pk->n_lu) {
+            hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_perm, pf + pk->off_root_perm, 8u);
+            hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, pk->d_exposed, pf + pk->off_exposed,
+                               (uint32_t)(4 * pk->n_lu));
+        }
         uint32_t n = (uint32_t)(4 * pk->n_open);
         hipLaunchKernelGGL(k_copy_canon, dim3((n + 255) / 256), dim3(256), 0, st, pk->d_opened, pf + pk->off_opened, n);
     }
@@ -995,8 +1223,11 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     ZK_TRY(transcript_sample_bits(ctx, pk->d_tr, pk->d_indices, pk->params.num_queries, hmax));
     uint32_t* pq = pf + pk->off_queries;
     ZK_TRY(merkle_open_device(ctx, pk->t_main, pk->d_indices, 0, pk->params.num_queries, pq, pk->query_pitch));
-    ZK_TRY(merkle_open_device(ctx, pk->t_quot, pk->d_indices, 0, pk->params.num_queries, pq + pk->q_main_words,
-                              pk->query_pitch));
+    if (pk->n_lu)
+        ZK_TRY(merkle_open_device(ctx, pk->t_perm, pk->d_indices, hmax - pk->h_perm, pk->params.num_queries,
+                                  pq + pk->q_main_words, pk->query_pitch));
+    ZK_TRY(merkle_open_device(ctx, pk->t_quot, pk->d_indices, 0, pk->params.num_queries,
+                              pq + pk->q_main_words + pk->q_perm_words, pk->query_pitch));
     if (pk->n_layers) {
         KernelScope ks(ctx, "fri_query");
         hipLaunchKernelGGL(k_fri_query, dim3(pk->params.num_queries, pk->n_layers), dim3(64), 0, st, pk->d_fri_desc,

@@ -28,8 +28,9 @@ __device__ __forceinline__ void st4(uint32_t* p, size_t i, const Ext& e) {
 
 // ---- batch inversion ---------------------------------------------------------------------------
 constexpr int BI_K = 8;
-__global__ __launch_bounds__(256) void k_ext_batch_inverse(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                           size_t n, const uint32_t* __restrict__ num) {
+// in == out is allowed: a lane reads all of its elements before it writes any of them
+__global__ __launch_bounds__(256) void k_ext_batch_inverse(const uint32_t* in, uint32_t* out, size_t n,
+                                                           const uint32_t* __restrict__ num) {
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Ext x[BI_K], pre[BI_K];
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void k_ext_batch_inverse(const uint32_t* __res
     }
 }
 
-static int launch_batch_inverse(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, const uint32_t* d_num) {
+int launch_batch_inverse(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, const uint32_t* d_num) {
     if (n == 0) return ZKHIP_OK;
     KernelScope ks(ctx, "ext_batch_inverse");
     size_t threads = (n + BI_K - 1) / BI_K;
@@ -144,9 +145,8 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ data, s
         if (base + e < n) st4(data, base + e, ext_add(ld4(data, base + e), off));
 }
 
-int logup_running_sum(zkhip_ctx* ctx, const uint32_t* d_den, const uint32_t* d_num, size_t n, uint32_t* d_out) {
+int ext_inclusive_scan(zkhip_ctx* ctx, uint32_t* d_out, size_t n) {
     if (n == 0) return ZKHIP_OK;
-    ZK_TRY(launch_batch_inverse(ctx, d_den, d_out, n, d_num));
     size_t n_blocks = (n + SC_BLOCK - 1) / SC_BLOCK;
     void* totals;
     ZK_TRY(get_scratch(ctx, 5, n_blocks * 16, &totals));
@@ -158,6 +158,12 @@ int logup_running_sum(zkhip_ctx* ctx, const uint32_t* d_den, const uint32_t* d_n
     }
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
+}
+
+int logup_running_sum(zkhip_ctx* ctx, const uint32_t* d_den, const uint32_t* d_num, size_t n, uint32_t* d_out) {
+    if (n == 0) return ZKHIP_OK;
+    ZK_TRY(launch_batch_inverse(ctx, d_den, d_out, n, d_num));
+    return ext_inclusive_scan(ctx, d_out, n);
 }
 
 // ---- MLE fold ----------------------------------------------------------------------------------

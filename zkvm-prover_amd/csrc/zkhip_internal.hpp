@@ -121,4 +121,10 @@ int merkle_open_device(zkhip_ctx* ctx, const zkhip_tree* tree, const uint32_t* d
 int permute_batch(zkhip_ctx* ctx, uint32_t* d_states, size_t n);
 int fri_fold(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, unsigned log_n_out, const uint32_t* d_beta,
              const uint32_t* d_add, /* optional: out[i] += beta^2 * add[i] */ bool has_add);
+
+// sumcheck.hip
+// out[i] = (num ? num[i] : 1) / in[i] over n extension elements; in == out allowed
+int launch_batch_inverse(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, const uint32_t* d_num);
+// in-place inclusive prefix sum of n extension elements
+int ext_inclusive_scan(zkhip_ctx* ctx, uint32_t* d_data, size_t n);
 }  // namespace zk
