@@ -56,6 +56,29 @@ int main(int argc, char** argv) {
         if (m == proof) continue;
         if (zkhip_verify(&prm, airs.data(), n_airs, pvs.data(), m.data(), m.size()) == 0) accepted++;
     }
+    // mutated AIR programs (the parser sees caller-supplied words too): must neither crash nor accept
+    std::vector<uint32_t> cw(w, w + cb.size() / 4);
+    for (int it = 0; it < iters / 4; it++) {
+        std::vector<uint32_t> m = cw;
+        size_t a = rnd() % n_airs;
+        size_t off = (size_t)(airs[a].program - w), len = airs[a].program_len;
+        size_t i = off + rnd() % len;
+        switch (rnd() % 3) {
+            case 0: m[i] ^= 1u << (rnd() % 31); break;
+            case 1: m[i] = (uint32_t)rnd(); break;
+            default: m[i] = (uint32_t)(rnd() % 64); break;
+        }
+        if (m[i] == cw[i]) continue;
+        std::vector<zkhip_air> airs2 = airs;
+        std::vector<const uint32_t*> pvs2(n_airs);
+        for (size_t k = 0; k < n_airs; k++) {
+            airs2[k].program = m.data() + (airs[k].program - w);
+            pvs2[k] = m.data() + (pvs[k] - w);
+        }
+        size_t plen = airs2[a].program_len;
+        if (rnd() % 8 == 0) airs2[a].program_len = plen - 1 - rnd() % (plen < 9 ? 1 : 8);  // truncated program
+        if (zkhip_verify(&prm, airs2.data(), n_airs, pvs2.data(), proof.data(), proof.size()) == 0) accepted++;
+    }
     // header words that are not bound by the transcript could in principle be mutated harmlessly; none exist
     std::printf("fuzz done: %d iterations, %d mutated proofs accepted\n", iters, accepted);
     return accepted == 0 ? 0 : 1;

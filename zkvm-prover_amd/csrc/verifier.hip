@@ -104,6 +104,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     const unsigned b = prm->log_blowup, nch = 1u << b;
     if (prm->log_final_poly_len != 0 || b < 1 || b > 4) return ZKHIP_ERR_INVALID;
     const size_t n_words = len / 4;
+    if (n_words < 4) return ZKHIP_ERR_VERIFY;
     std::vector<uint32_t> pw(n_words);
     memcpy(pw.data(), proof_bytes, len);
     const uint32_t* proof = pw.data();
