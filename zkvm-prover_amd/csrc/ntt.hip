@@ -323,6 +323,174 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Compile-time shaped variant of the pass kernel for the two tile shapes every transform >= 2^20
+// uses ([2^11 x 8] and [2^10 x 16], 1024 lanes).  Same data flow as k_ntt_pass4 above; what changes
+// is the instruction count (profiles/round01_pmc_valu.json: 1678 VALU instructions per wave, of
+// which only ~900 are butterflies):
+//  * every LDS address is one per-lane base plus an immediate, every HBM address is a uniform
+//    (scalar) base plus one 32-bit per-lane offset -- no per-element 64-bit multiplies;
+//  * the 2^Q - 1 twiddles of a register unit are read from the LDS table before the butterflies
+//    start instead of one dependent read per stage;
+//  * the write-out is unrolled so that the tile column of each store is a compile-time constant.
+template <int Q>
+__device__ __forceinline__ void dif_unit_w(uint32_t (&v)[1 << Q], const uint32_t (&w)[(1 << Q) - 1]) {
+#pragma unroll
+    for (int t = 0; t < Q; t++) {
+        const int half = 1 << (Q - 1 - t);
+        const int woff = (1 << Q) - (1 << (Q - t));
+#pragma unroll
+        for (int kl = 0; kl < half; kl++) {
+#pragma unroll
+            for (int blk = 0; blk < (1 << t); blk++) {
+                const int ka = blk * 2 * half + kl, kb = ka + half;
+                const uint32_t x = v[ka], y = v[kb];
+                v[ka] = madd(x, y);
+                v[kb] = red_2p(mmul_lazy(x - y + P, w[woff + kl]));
+            }
+        }
+    }
+}
+// twiddles of the unit whose first row is j (rows j + k * 2^LOG_RQ), table exponent scaled by 2^TSHIFT
+template <int Q, int LOG_RQ, int TSHIFT>
+__device__ __forceinline__ void load_unit_twiddles(const uint32_t* twl, unsigned j, uint32_t (&w)[(1 << Q) - 1]) {
+#pragma unroll
+    for (int t = 0; t < Q; t++) {
+        const int half = 1 << (Q - 1 - t);
+        const int woff = (1 << Q) - (1 << (Q - t));
+        const uint32_t* tb = twl + (j << (t + TSHIFT));
+#pragma unroll
+        for (int kl = 0; kl < half; kl++) w[woff + kl] = tb[kl << (LOG_RQ + t + TSHIFT)];
+    }
+}
+template <int LOG_R, int LOG_C, int LOG_RCUR>
+__device__ __forceinline__ void lds_rounds_ct(uint32_t* lv, const uint32_t* twl, unsigned tid) {
+    if constexpr (LOG_RCUR > 0) {
+        constexpr int Q = LOG_RCUR >= 4 ? 4 : LOG_RCUR;
+        constexpr int LOG_RQ = LOG_RCUR - Q;
+        constexpr unsigned n_units = 1u << (LOG_R - Q + LOG_C);
+        constexpr unsigned pitch = (1u << LOG_C) + 1u;
+#pragma unroll
+        for (unsigned u0 = 0; u0 < n_units; u0 += 1024) {
+            const unsigned u = u0 + tid;
+            const unsigned c = u & ((1u << LOG_C) - 1u), jj = u >> LOG_C;
+            const unsigned j = jj & ((1u << LOG_RQ) - 1u), blk = jj >> LOG_RQ;
+            uint32_t* base = lv + ((blk << LOG_RCUR) + j) * pitch + c;
+            uint32_t v[1 << Q], w[(1 << Q) - 1];
+#pragma unroll
+            for (int k = 0; k < (1 << Q); k++) v[k] = base[(k << LOG_RQ) * pitch];
+            load_unit_twiddles<Q, LOG_RQ, LOG_R - LOG_RCUR>(twl, j, w);
+#if !defined(NTT_ABL) || NTT_ABL != 1
+            dif_unit_w<Q>(v, w);
+#endif
+#pragma unroll
+            for (int k = 0; k < (1 << Q); k++) base[(k << LOG_RQ) * pitch] = v[k];
+        }
+        __syncthreads();
+        lds_rounds_ct<LOG_R, LOG_C, LOG_RCUR - Q>(lv, twl, tid);
+    }
+}
+
+template <int LOG_R, int LOG_C>
+__global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
+    static_assert(LOG_R >= 10 && LOG_R - 4 + LOG_C == 10, "one radix-16 unit per lane in the first round");
+    extern __shared__ uint32_t sm[];
+    constexpr unsigned R = 1u << LOG_R, C = 1u << LOG_C, pitch = C + 1u;
+    constexpr int LOG_RQ = LOG_R - 4;
+    uint32_t* lv = sm;
+    uint32_t* twl = sm + R * pitch;
+    const unsigned tid = threadIdx.x;
+    if (tid < (R >> 1)) twl[tid] = a.tw[(size_t)tid << (a.tw_log - LOG_R)];
+    const unsigned col = blockIdx.y;
+    const unsigned sub = col & ((1u << a.log_sub) - 1u);
+    const size_t mcol = col >> a.log_sub;
+    unsigned tile = blockIdx.x;
+    if (LOG_C == 3 && (gridDim.x & 15u) == 0) {
+        const unsigned within = tile & 15u;
+        tile = ((((tile >> 4) << 3) + (within & 7u)) << 1) | (within >> 3);
+    }
+    const unsigned cg_bits = a.log_f - LOG_C;
+    const unsigned X = tile >> cg_bits, F0 = (tile & ((1u << cg_bits) - 1u)) << LOG_C;
+    __syncthreads();
+    // ---- round 1: one radix-16 unit per lane straight from HBM ----
+    {
+        const unsigned c = tid & (C - 1u), j = tid >> LOG_C;
+        uint32_t v[16];
+        if (a.br_src) {
+            const uint32_t* run = a.src + mcol * a.src_col_stride + ((size_t)bitrev32(F0 + c, a.log_f) << LOG_R);
+            const uint4* ch = reinterpret_cast<const uint4*>(run + ((size_t)bitrev32(j, LOG_RQ) << 4));
+            const uint4 q0 = ch[0], q1 = ch[1], q2 = ch[2], q3 = ch[3];
+            const uint32_t wv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                                     q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = wv[((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3)];
+            uint32_t t = mmul(a.scale_col[((size_t)sub << a.log_f) + F0 + c], a.scale_row[((size_t)sub << LOG_RQ) + j]);
+            const uint32_t rho = a.scale_rho[sub];
+            v[0] = mmul(v[0], t);
+#pragma unroll
+            for (int k = 1; k < 16; k++) {
+                t = mmul(t, rho);
+                v[k] = mmul(v[k], t);
+            }
+        } else {
+            // uniform base of the tile + one 32-bit lane offset; register k is 2^(LOG_RQ + log_f) words further
+            const uint32_t* tile_src = a.src + mcol * a.src_col_stride + ((size_t)sub << a.log_m) +
+                                       (size_t)X * a.in_x_stride + F0;
+            const uint32_t lane_off = (j << a.log_f) + c;
+#pragma unroll
+#if defined(NTT_ABL) && NTT_ABL == 2
+            for (int k = 0; k < 16; k++) v[k] = lane_off + k;
+#else
+            for (int k = 0; k < 16; k++) v[k] = (tile_src + ((size_t)k << (LOG_RQ + a.log_f)))[lane_off];
+#endif
+        }
+        if (a.in_tw) {
+            const uint32_t mask = (a.log_tt >= 32) ? 0xffffffffu : ((1u << a.log_tt) - 1u);
+            const uint32_t kc = bitrev32(F0 + c, a.log_prev);
+            const uint32_t e0 = (kc * (j * a.tw_a + X * a.tw_bx)) & mask;
+            const uint32_t de = (kc * ((1u << LOG_RQ) * a.tw_a)) & mask;
+            const unsigned sh = a.tw_log - a.log_tt;
+            const uint32_t half = 1u << (a.log_tt - 1);
+            uint32_t t = e0 < half ? a.tw[(size_t)e0 << sh] : mneg(a.tw[(size_t)(e0 - half) << sh]);
+            const uint32_t rho = de < half ? a.tw[(size_t)de << sh] : mneg(a.tw[(size_t)(de - half) << sh]);
+            v[0] = mmul(v[0], t);
+#pragma unroll
+            for (int k = 1; k < 16; k++) {
+                t = mmul(t, rho);
+                v[k] = mmul(v[k], t);
+            }
+        }
+        uint32_t w[15];
+        load_unit_twiddles<4, LOG_RQ, 0>(twl, j, w);
+#if !defined(NTT_ABL) || NTT_ABL != 1
+        dif_unit_w<4>(v, w);
+#endif
+        uint32_t* base = lv + j * pitch + c;
+#pragma unroll
+        for (int k = 0; k < 16; k++) base[(k << LOG_RQ) * pitch] = v[k];
+    }
+    __syncthreads();
+    lds_rounds_ct<LOG_R, LOG_C, LOG_RQ>(lv, twl, tid);
+    // ---- write-out: each tile column is one contiguous run of R words; the column of every store is
+    // a compile-time constant, so its HBM base is scalar and the LDS address an immediate ----
+    const unsigned lo_mask = (1u << a.log_lo) - 1u;
+    uint32_t* dst = a.dst + mcol * a.dst_col_stride + ((size_t)sub << a.log_m) + (size_t)X * a.out_x_stride;
+    const uint32_t* lrow = lv + tid * pitch;
+#pragma unroll
+    for (unsigned i = 0; i < (R * C) / 1024u; i++) {
+        constexpr unsigned dummy = 0;
+        (void)dummy;
+        const unsigned c = (1024u * i) >> LOG_R, p0 = (1024u * i) & (R - 1u);
+        const unsigned F = F0 + c;
+        uint32_t* dcol = dst + (size_t)(F >> a.log_lo) * a.out_hi_stride + (size_t)(F & lo_mask) * a.out_lo_stride + p0;
+#if defined(NTT_ABL) && NTT_ABL == 3
+        if (lrow[p0 * pitch + c] == 0x12345678u) dcol[tid] = 1;
+#else
+        dcol[tid] = lrow[p0 * pitch + c];
+#endif
+    }
+}
+
 static constexpr unsigned P4_MAX_LOG_R = 11;
 static constexpr unsigned P4_MIN_LOG_M = 12;
 // stages per pass: 11 = two passes up to 2^22 (128 KiB tiles, one workgroup per CU);
@@ -358,6 +526,8 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         const int lds_max = ((17u << P4_MAX_LOG_R) + (1u << (P4_MAX_LOG_R - 1))) * 4;
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4<11, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4_ct<11, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4_ct<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         attr_set = true;
     }
@@ -390,7 +560,12 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         const size_t lds = ((size_t)R * (C + 1) + (R >> 1)) * 4;
         dim3 grid(n_x << (pa.log_f - pa.log_c), (unsigned)(width << log_sub));
         KernelScope ks(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd");
-        if (pa.log_r == 11 && pa.log_c == 3)
+        static const bool legacy = getenv("ZKHIP_NTT_LEGACY") != nullptr;  // A/B switch for experiments
+        if (pa.log_r == 11 && pa.log_c == 3 && !legacy)
+            hipLaunchKernelGGL((k_ntt_pass4_ct<11, 3>), grid, dim3(threads), lds, ctx->stream, pa);
+        else if (pa.log_r == 10 && pa.log_c == 4 && !legacy)
+            hipLaunchKernelGGL((k_ntt_pass4_ct<10, 4>), grid, dim3(threads), lds, ctx->stream, pa);
+        else if (pa.log_r == 11 && pa.log_c == 3)
             hipLaunchKernelGGL((k_ntt_pass4<11, 3>), grid, dim3(threads), lds, ctx->stream, pa);
         else if (pa.log_r == 10 && pa.log_c == 4)
             hipLaunchKernelGGL((k_ntt_pass4<10, 4>), grid, dim3(threads), lds, ctx->stream, pa);
