@@ -29,6 +29,16 @@ struct Poseidon2Diag {
 };
 
 ZK_HD uint32_t mdouble(uint32_t x) { return red_2p(x << 1); }
+// x * 2^-K mod p for x in [0,p), 1 <= K <= 27, as a K-bit Montgomery step: p == 1 (mod 2^27), so
+// -p^-1 == -1 (mod 2^K) and m = (-x) mod 2^K makes x + m*p divisible by 2^K; (x + m*p) >> K <= p with
+// equality only for x = 0 (where m = 0 gives 0).  4 VALU instructions (and/sub, one 64-bit mad, one
+// funnel shift) instead of the 5 of a general Montgomery product, and no conditional subtraction.
+template <int K>
+ZK_HD uint32_t mdiv_pow2(uint32_t x) {
+    const uint32_t m = (0u - x) & ((1u << K) - 1u);
+    const uint64_t t = (uint64_t)m * P + x;
+    return (uint32_t)(t >> K);
+}
 ZK_HD uint32_t mhalve(uint32_t x) { return (x & 1u) ? ((x >> 1) + ((P + 1u) >> 1)) : (x >> 1); }
 
 // x^7 for x in [0,p).  Lazy Montgomery products keep intermediates in [0, 2.02p) -- bounds, with
@@ -80,13 +90,13 @@ ZK_HD void p2_internal_linear(uint32_t s[16]) {
     s[6] = msub(sum, mhalve(s[6]));                           // -1/2
     d = mdouble(s[7]); s[7] = msub(sum, madd(d, s[7]));       // -3
     s[8] = msub(sum, mdouble(mdouble(s[8])));                 // -4
-    s[9] = madd(sum, mmul(s[9], Poseidon2Diag::INV_2_8));     //  1/2^8
-    s[10] = madd(sum, mmul(s[10], Poseidon2Diag::INV_4));     //  1/4
-    s[11] = madd(sum, mmul(s[11], Poseidon2Diag::INV_8));     //  1/8
-    s[12] = madd(sum, mmul(s[12], Poseidon2Diag::INV_2_27));  //  1/2^27
-    s[13] = msub(sum, mmul(s[13], Poseidon2Diag::INV_2_8));   // -1/2^8
-    s[14] = msub(sum, mmul(s[14], Poseidon2Diag::INV_16));    // -1/16
-    s[15] = msub(sum, mmul(s[15], Poseidon2Diag::INV_2_27));  // -1/2^27
+    s[9] = madd(sum, mdiv_pow2<8>(s[9]));                     //  1/2^8
+    s[10] = madd(sum, mdiv_pow2<2>(s[10]));                   //  1/4
+    s[11] = madd(sum, mdiv_pow2<3>(s[11]));                   //  1/8
+    s[12] = madd(sum, mdiv_pow2<27>(s[12]));                  //  1/2^27
+    s[13] = msub(sum, mdiv_pow2<8>(s[13]));                   // -1/2^8
+    s[14] = msub(sum, mdiv_pow2<4>(s[14]));                   // -1/16
+    s[15] = msub(sum, mdiv_pow2<27>(s[15]));                  // -1/2^27
 }
 
 ZK_HD void poseidon2_permute(uint32_t s[16]) {
