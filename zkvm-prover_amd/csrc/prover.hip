@@ -21,7 +21,7 @@
 #include <algorithm>
 
 #include "air_compile.hpp"
-#include "poseidon2.hpp"
+#include "poseidon2_coop.hpp"
 #include "quotient_jit.hpp"
 #include "transcript.hpp"
 #include "zkhip_internal.hpp"
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void k_hash_pairs(const uint4* __restrict__ la
     if (i >= n_leaves) return;
     uint4 a = layer[2 * i], b = layer[2 * i + 1];
     uint32_t s[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, 0, 0, 0, 0, 0, 0, 0, 0};
-    poseidon2_permute(s);
+    poseidon2_permute_rolled(s);
     uint4* o = reinterpret_cast<uint4*>(out + i * 8);
     o[0] = make_uint4(s[0], s[1], s[2], s[3]);
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
