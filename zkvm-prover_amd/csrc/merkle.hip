@@ -18,7 +18,9 @@
 
 namespace zk {
 
-// one copy of the permutation per call site: full and ragged 8-column blocks share it
+// one copy of the permutation per call site: full and ragged 8-column blocks share it.  (Requesting the
+// cells of block j+1 before permuting block j changes nothing: 47.17 vs 47.23 ms -- the other resident
+// waves already hide the loads.)
 __device__ __forceinline__ void absorb_rows(uint32_t (&s)[16], const uint32_t* const* __restrict__ cols,
                                             uint32_t n_cols, uint32_t row) {
 #pragma unroll 1
