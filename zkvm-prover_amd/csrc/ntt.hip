@@ -380,7 +380,7 @@ __device__ __forceinline__ void lds_rounds_ct(uint32_t* lv, const uint32_t* twl,
 #pragma unroll
             for (int k = 0; k < (1 << Q); k++) v[k] = base[(k << LOG_RQ) * pitch];
             load_unit_twiddles<Q, LOG_RQ, LOG_R - LOG_RCUR>(twl, j, w);
-#if !defined(NTT_ABL) || NTT_ABL != 1
+#if !defined(NTT_ABL) || (NTT_ABL != 1 && NTT_ABL != 5)
             dif_unit_w<Q>(v, w);
 #endif
 #pragma unroll
@@ -405,16 +405,30 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
     const unsigned sub = col & ((1u << a.log_sub) - 1u);
     const size_t mcol = col >> a.log_sub;
     unsigned tile = blockIdx.x;
-    if (LOG_C == 3 && (gridDim.x & 15u) == 0) {
-        const unsigned within = tile & 15u;
-        tile = ((((tile >> 4) << 3) + (within & 7u)) << 1) | (within >> 3);
+    // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs, so workgroups b, b+8, ...,
+    // b+8(k-1) share an L2.  They are given k ADJACENT tiles, whose 32-byte row segments are neighbours in the
+    // same 128-byte lines and DRAM pages (2^22 x 300 LDE: k = 1 23.7 ms, 2 20.4, 4 19.3, 8 18.6, 16 and 32 18.1).
+    if (LOG_C == 3) {
+        unsigned k = gridDim.x >> 3;
+        if (k > 16u) k = 16u;
+        if (k >= 2u && (k & (k - 1u)) == 0 && (gridDim.x & (8u * k - 1u)) == 0) {
+            const unsigned within = tile & (8u * k - 1u);
+            tile = (tile & ~(8u * k - 1u)) | ((within & 7u) * k) | (within >> 3);
+        }
     }
     const unsigned cg_bits = a.log_f - LOG_C;
     const unsigned X = tile >> cg_bits, F0 = (tile & ((1u << cg_bits) - 1u)) << LOG_C;
     __syncthreads();
     // ---- round 1: one radix-16 unit per lane straight from HBM ----
     {
-        const unsigned c = tid & (C - 1u), j = tid >> LOG_C;
+        // Which unit a lane takes is free in this round (a unit's rows sit 2^LOG_RQ apart, HBM sees the same
+        // 32-byte segments either way), so the rows of one half-wave are placed 8 apart (16 for 16-column tiles):
+        // with the odd pitch their LDS stores then hit 32 distinct banks instead of colliding two-way on
+        // consecutive rows (profiles/round01_ntt_ablation.txt).
+        const unsigned c = tid & (C - 1u), jj = tid >> LOG_C;
+        constexpr unsigned HB = 5 - LOG_C;   // unit-index bits inside a half-wave (2 or 1)
+        constexpr unsigned SP = LOG_C == 3 ? 3 : 4;  // log2 of the row spacing wanted
+        const unsigned j = ((jj & ((1u << HB) - 1u)) << SP) | ((jj >> HB) & ((1u << SP) - 1u)) | (jj & ~((1u << (HB + SP)) - 1u));
         uint32_t v[16];
         if (a.br_src) {
             const uint32_t* run = a.src + mcol * a.src_col_stride + ((size_t)bitrev32(F0 + c, a.log_f) << LOG_R);
@@ -444,7 +458,11 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
             for (int k = 0; k < 16; k++) v[k] = (tile_src + ((size_t)k << (LOG_RQ + a.log_f)))[lane_off];
 #endif
         }
+#if defined(NTT_ABL) && NTT_ABL == 5
+        if (false) {
+#else
         if (a.in_tw) {
+#endif
             const uint32_t mask = (a.log_tt >= 32) ? 0xffffffffu : ((1u << a.log_tt) - 1u);
             const uint32_t kc = bitrev32(F0 + c, a.log_prev);
             const uint32_t e0 = (kc * (j * a.tw_a + X * a.tw_bx)) & mask;
@@ -462,7 +480,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
         }
         uint32_t w[15];
         load_unit_twiddles<4, LOG_RQ, 0>(twl, j, w);
-#if !defined(NTT_ABL) || NTT_ABL != 1
+#if !defined(NTT_ABL) || (NTT_ABL != 1 && NTT_ABL != 5)
         dif_unit_w<4>(v, w);
 #endif
         uint32_t* base = lv + j * pitch + c;
@@ -470,7 +488,9 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
         for (int k = 0; k < 16; k++) base[(k << LOG_RQ) * pitch] = v[k];
     }
     __syncthreads();
+#if !defined(NTT_ABL) || (NTT_ABL != 4 && NTT_ABL != 5)
     lds_rounds_ct<LOG_R, LOG_C, LOG_RQ>(lv, twl, tid);
+#endif
     // ---- write-out: each tile column is one contiguous run of R words; the column of every store is
     // a compile-time constant, so its HBM base is scalar and the LDS address an immediate ----
     const unsigned lo_mask = (1u << a.log_lo) - 1u;
