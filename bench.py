@@ -78,14 +78,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ZKHIP_BENCH_DRYRUN_1GPU=1: exercise the N-rank code path on a box with ONE GPU (every rank on cuda:0, gloo
+    # collectives on host tensors).  A plumbing check only -- never a measurement.
+    dry = world > 1 and os.environ.get("ZKHIP_BENCH_DRYRUN_1GPU") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dry:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    coll_dev = torch.device("cpu") if dry else dev
     n_pipe = max(1, args.inflight)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_pipe)]
     ctxs = []
@@ -128,7 +137,7 @@ def main():
         # the one exchange step of the sharded path (zkvm-prover_amd/shard.py): 32-byte trace
         # commitments to every rank, proofs to rank 0, over RCCL/xGMI
         if world > 1:
-            shard.exchange(proof_bytes, device=dev)
+            shard.exchange(proof_bytes, device=coll_dev)
 
     def run(n_steps):
         # keep n_pipe proofs in flight: proof i+n_pipe is enqueued as soon as proof i has been fetched
@@ -170,7 +179,7 @@ def main():
     steps_profiled = len(range(0, args.steps, n_pipe))  # proofs that ran on pipeline 0
     dt = t1 - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     stats = stats_timed
@@ -178,7 +187,7 @@ def main():
     # every rank checks its own last proof with the host verifier (outside the timed region)
     ok = z.verify(params, airs, pvs, last) == 0
     if world > 1:
-        okt = torch.tensor([1 if ok else 0], device=dev)
+        okt = torch.tensor([1 if ok else 0], device=coll_dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
 
@@ -261,7 +270,8 @@ def main():
                                    % (log_n, width, log_n, params[2], params[3], params[4]),
                        "proof_bytes": pk.proof_size, "verified": ok,
                        "inflight_per_gpu": n_pipe,
-                       "parallelism": "%d independent proof(s) in flight per GPU (one HIP stream each)" % n_pipe + (", RCCL all-gather of commitments + proof gather" if world > 1 else "")},
+                       "parallelism": "%d independent proof(s) in flight per GPU (one HIP stream each)" % n_pipe + (", RCCL all-gather of commitments + proof gather" if world > 1 else "")
+                                      + (" [DRY RUN: all ranks on one GPU, gloo -- not a measurement]" if dry else "")},
             "roofline": roof,
             "roofline_other_kernels": others,
             "stage_ms_single_stream": {k: round(v[1] / 2, 3) for k, v in sorted(stats_alone.items(), key=lambda kv: -kv[1][1])},
