@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--width", type=int, default=300)
     ap.add_argument("--cpu-sample-log-rows", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="independent proofs in flight per GPU, each on its own HIP stream (segments of a chunk are "
                          "independent): memory-bound stages of one overlap the VALU-bound hashing of the other")
     return ap.parse_args()
@@ -151,6 +151,12 @@ def main():
                 launch(i + n_pipe)
         return last
 
+    # setup, not warm-up: the first proof of a proving key grows its context's scratch buffers and loads its code
+    # objects; do that once per pipeline so that the W warm-up steps and the K timed steps see steady state whatever
+    # W is (with 3 pipelines a warm-up of 2 would otherwise leave one of them cold)
+    for i in range(n_pipe):
+        launch(i)
+        collect(i)
     run(args.warmup)
     for c in ctxs:
         c.profile_reset()
