@@ -164,6 +164,12 @@ typedef struct {
     unsigned log_height;
     size_t width;
     size_t n_pvs;
+    /* Preprocessed trace of the AIR (programs with a PREP section; the engine's `preprocessed` columns, fixed at
+     * keygen): zkhip_keygen reads `prep_trace` (HOST, canonical u32, column-major, stride 1<<log_height), extends
+     * and commits it once and keeps it resident; zkhip_verify reads `prep_commit` (8 canonical words, the
+     * verifying-key entry obtained from zkhip_pk_prep_commitment).  NULL when the AIR has none. */
+    const uint32_t *prep_trace;
+    const uint32_t *prep_commit;
 } zkhip_air;
 
 typedef struct zkhip_pk zkhip_pk;
@@ -171,6 +177,8 @@ typedef struct zkhip_pk zkhip_pk;
 int zkhip_keygen(zkhip_ctx *ctx, const zkhip_params *params, const zkhip_air *airs, size_t n_airs,
                  zkhip_pk **out);
 void zkhip_pk_destroy(zkhip_ctx *ctx, zkhip_pk *pk);
+/* commitment (8 canonical words) of AIR `air_index`'s preprocessed trace; ZKHIP_ERR_INVALID if it has none */
+int zkhip_pk_prep_commitment(zkhip_ctx *ctx, const zkhip_pk *pk, size_t air_index, uint32_t out[8]);
 /* exact proof size in bytes for this key (FRI proofs are shape-static) */
 size_t zkhip_proof_size(const zkhip_pk *pk);
 /* d_traces[i]: device, column-major Montgomery trace of AIR i with stride 1<<log_height;

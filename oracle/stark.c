@@ -21,7 +21,10 @@
  *        2 CONST(a) 3 IS_FIRST 4 IS_LAST 5 IS_TRANSITION
  *        6 ADD(a,b) 7 SUB(a,b) 8 MUL(a,b) 9 NEG(a)
  *        10 PERM(col a, rotation b)  11 CHAL(a)  12 EXPOSED(a)   (LogUp phase leaves)
+ *        13 PREP(col a, rotation b)  (preprocessed trace: fixed at keygen, committed per AIR, the
+ *           commitment is observed in the preamble and opened like the main trace)
  *   n_constraints x node index (asserted zero on every row)
+ *   optional: [0x50504B5A, prep_width]
  *   optional: [0x554C4B5A, n_int, n_int x {bus, sign, count leaf[3], n_fields, field leaf[3]...}]
  * LogUp phase: challenges gamma, beta (extension); chal vector = gamma, beta^1..beta^8 as
  * 36 base coordinates; interaction j contributes phi_j = (+/-)count / (gamma + bus + 1 +
@@ -35,13 +38,14 @@
 
 #define AIR_MAGIC 0x31414B5Au
 #define LOGUP_MAGIC 0x554C4B5Au
+#define PREP_MAGIC 0x50504B5Au
 #define PROOF_MAGIC 0x31504B5Au
 #define PROTO_TAG 0x5A4B4831u /* "1HKZ" < p */
 #define GEN 31u
 #define MAX_FIELDS 8
 #define N_CHAL (4 * (1 + MAX_FIELDS))
 
-enum { OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_PERM, OP_CHAL, OP_EXPOSED };
+enum { OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_PERM, OP_CHAL, OP_EXPOSED, OP_PREP };
 
 typedef uint32_t ext_t[4];
 
@@ -89,10 +93,12 @@ typedef struct {
     uint32_t n_int;
     interaction *ints;
     size_t perm_width; /* 4 * (n_int + 1), or 0 */
+    size_t prep_width; /* preprocessed columns, or 0 */
 } program;
 
-static int leaf_ok(const uint32_t *l, size_t width, uint32_t n_pvs) {
+static int leaf_ok(const uint32_t *l, size_t width, uint32_t n_pvs, size_t prep_width) {
     if (l[0] == OP_VAR) return l[1] < width && l[2] == 0;
+    if (l[0] == OP_PREP) return l[1] < prep_width && l[2] == 0;
     if (l[0] == OP_PUB) return l[1] < n_pvs;
     if (l[0] == OP_CONST) return l[1] < ORA_P;
     return 0;
@@ -108,8 +114,14 @@ static int parse_program(const uint32_t *w, size_t len, size_t width, program *p
     if (base_len > len) return -1;
     p->nodes = w + 4;
     p->cons = w + 4 + 3 * (size_t)p->n_nodes;
-    if (base_len != len) {
-        size_t q = base_len;
+    size_t q0 = base_len;
+    if (q0 + 2 <= len && w[q0] == PREP_MAGIC) {
+        p->prep_width = w[q0 + 1];
+        if (p->prep_width == 0 || p->prep_width > (1u << 20)) return -1;
+        q0 += 2;
+    }
+    if (q0 != len) {
+        size_t q = q0;
         if (q + 2 > len || w[q] != LOGUP_MAGIC) return -1;
         p->n_int = w[q + 1];
         q += 2;
@@ -123,10 +135,10 @@ static int parse_program(const uint32_t *w, size_t len, size_t width, program *p
             it->n_fields = w[q + 5];
             q += 6;
             if (it->sign > 1 || it->bus >= ORA_P - 1 || it->n_fields < 1 || it->n_fields > MAX_FIELDS || q + 3 * (size_t)it->n_fields > len) return -1;
-            if (!leaf_ok(it->count, width, p->n_pvs)) return -1;
+            if (!leaf_ok(it->count, width, p->n_pvs, p->prep_width)) return -1;
             for (uint32_t i = 0; i < it->n_fields; i++) {
                 memcpy(it->fields[i], w + q, 12);
-                if (!leaf_ok(it->fields[i], width, p->n_pvs)) return -1;
+                if (!leaf_ok(it->fields[i], width, p->n_pvs, p->prep_width)) return -1;
                 q += 3;
             }
         }
@@ -145,6 +157,7 @@ static int parse_program(const uint32_t *w, size_t len, size_t width, program *p
         case OP_PERM: if (a >= p->perm_width || b > 1) return -1; break;
         case OP_CHAL: if (a >= N_CHAL || p->n_int == 0) return -1; break;
         case OP_EXPOSED: if (a >= 4 || p->n_int == 0) return -1; break;
+        case OP_PREP: if (a >= p->prep_width || b > 1) return -1; break;
         default: return -1;
         }
     }
@@ -157,6 +170,7 @@ static void free_program(program *p) { free(p->ints); }
 typedef struct {
     const uint32_t *local, *next, *pvs, *perm_local, *perm_next, *chal, *exposed;
     uint32_t is_first, is_last, is_trans;
+    const uint32_t *prep_local, *prep_next;
 } row_ctx;
 
 /* base-field evaluation of all nodes on one row; vals has n_nodes slots */
@@ -176,6 +190,7 @@ static void eval_nodes_base(const program *p, const row_ctx *c, uint32_t *vals) 
         case OP_NEG: vals[i] = ora_sub(0, vals[a]); break;
         case OP_PERM: vals[i] = b ? c->perm_next[a] : c->perm_local[a]; break;
         case OP_CHAL: vals[i] = c->chal[a]; break;
+        case OP_PREP: vals[i] = b ? c->prep_next[a] : c->prep_local[a]; break;
         default: vals[i] = c->exposed[a]; break;
         }
     }
@@ -184,6 +199,7 @@ typedef struct {
     const ext_t *local, *next, *perm_local, *perm_next;
     const uint32_t *pvs, *chal, *exposed;
     ext_t is_first, is_last, is_trans;
+    const ext_t *prep_local, *prep_next;
 } zeta_ctx;
 /* same over the extension (verifier, at zeta) */
 static void eval_nodes_ext(const program *p, const zeta_ctx *c, ext_t *vals) {
@@ -205,14 +221,16 @@ static void eval_nodes_ext(const program *p, const zeta_ctx *c, ext_t *vals) {
         } break;
         case OP_PERM: ext_set(vals[i], b ? c->perm_next[a] : c->perm_local[a]); break;
         case OP_CHAL: ext_from(c->chal[a], vals[i]); break;
+        case OP_PREP: ext_set(vals[i], b ? c->prep_next[a] : c->prep_local[a]); break;
         default: ext_from(c->exposed[a], vals[i]); break;
         }
     }
 }
 
 /* ---------------------------------------------------------------- helpers */
+/* prep_commits: n_airs x 8 words, used for the AIRs whose has_prep[a] is set */
 static void observe_preamble(ora_challenger *ch, const ora_params *prm, const ora_air_instance *airs,
-                             size_t n_airs) {
+                             size_t n_airs, const uint32_t *prep_commits, const int *has_prep) {
     uint32_t hdr[7] = {PROTO_TAG, (uint32_t)n_airs, prm->log_blowup, prm->log_final_poly_len,
                        prm->num_queries, prm->commit_pow_bits, prm->query_pow_bits};
     ora_ch_observe(ch, hdr, 7);
@@ -222,6 +240,7 @@ static void observe_preamble(ora_challenger *ch, const ora_params *prm, const or
         uint32_t meta[3] = {airs[a].log_height, (uint32_t)airs[a].width, (uint32_t)airs[a].n_pvs};
         ora_ch_observe(ch, meta, 3);
         ora_ch_observe(ch, dig, 8);
+        if (has_prep[a]) ora_ch_observe(ch, prep_commits + 8 * a, 8);
         ora_ch_observe(ch, airs[a].pvs, airs[a].n_pvs);
     }
 }
@@ -269,8 +288,10 @@ static void selectors_ext(unsigned lh, const ext_t x, ext_t is_first, ext_t is_l
     ora_ext_inv(zh, inv_zh);
 }
 
-static uint32_t leaf_value(const uint32_t *l, const uint32_t *trace, size_t N, size_t row, const uint32_t *pvs) {
+static uint32_t leaf_value(const uint32_t *l, const uint32_t *trace, size_t N, size_t row, const uint32_t *pvs,
+                           const uint32_t *prep) {
     if (l[0] == OP_VAR) return trace[(size_t)l[1] * N + row];
+    if (l[0] == OP_PREP) return prep[(size_t)l[1] * N + row];
     if (l[0] == OP_PUB) return pvs[l[1]];
     return l[1];
 }
@@ -285,6 +306,8 @@ typedef struct {
     size_t width;
     uint32_t exposed[4];
     program prog;
+    uint32_t *prep_lde;  /* preprocessed LDE (height M) and its own commitment */
+    ora_tree *t_prep;
 } air_state;
 
 /* one committed matrix as seen by the opening / FRI code */
@@ -295,8 +318,32 @@ typedef struct {
     unsigned lh, h;
     size_t width;
     unsigned n_pts;       /* 2: zeta and zeta*w_N, 1: zeta */
-    int round;            /* 0 main, 1 perm, 2 quotient */
+    int round;            /* 0 main, 1 perm, 2 quotient, 3 preprocessed */
 } cmat;
+
+/* LDE + commitment of one AIR's preprocessed trace (what keygen stores in the verifying key) */
+static ora_tree *commit_prep(const ora_params *prm, const ora_air_instance *air, size_t prep_width, uint32_t **lde_out,
+                             uint32_t root[8]) {
+    const unsigned lh = air->log_height, b = prm->log_blowup;
+    const size_t N = (size_t)1 << lh, M = N << b;
+    uint32_t *lde = (uint32_t *)malloc(M * prep_width * sizeof(uint32_t));
+    ora_coset_lde_batch(air->prep, N, lde, M, lh, b, prep_width, GEN, 1);
+    ora_matrix m = {lde, M, lh + b, prep_width};
+    ora_tree *t = ora_mmcs_commit(&m, 1, root);
+    *lde_out = lde;
+    return t;
+}
+
+int ora_prep_commit(const ora_params *prm, const ora_air_instance *air, uint32_t root[8]) {
+    program pg;
+    if (parse_program(air->program, air->program_len, air->width, &pg) || !pg.prep_width || !air->prep) return -1;
+    uint32_t *lde;
+    ora_tree *t = commit_prep(prm, air, pg.prep_width, &lde, root);
+    ora_tree_free(t);
+    free(lde);
+    free_program(&pg);
+    return 0;
+}
 
 size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size_t n_airs, uint32_t *out,
                        size_t cap) {
@@ -304,7 +351,9 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
     if (prm->log_final_poly_len != 0 || n_airs == 0 || b == 0) return 0;
     air_state *st = (air_state *)calloc(n_airs, sizeof(air_state));
     unsigned hmax = 0;
-    size_t n_lu = 0;
+    size_t n_lu = 0, n_prep = 0;
+    uint32_t *prep_roots = (uint32_t *)calloc(n_airs, 32);
+    int *has_prep = (int *)calloc(n_airs, sizeof(int));
     for (size_t a = 0; a < n_airs; a++) {
         if (airs[a].log_height < 1) return 0;
         if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &st[a].prog)) return 0;
@@ -314,10 +363,16 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         st[a].width = airs[a].width;
         if (st[a].h > hmax) hmax = st[a].h;
         if (st[a].prog.n_int) n_lu++;
+        if (st[a].prog.prep_width) {
+            if (!airs[a].prep) return 0;
+            st[a].t_prep = commit_prep(prm, &airs[a], st[a].prog.prep_width, &st[a].prep_lde, prep_roots + 8 * a);
+            has_prep[a] = 1;
+            n_prep++;
+        }
     }
     ora_challenger ch;
     ora_ch_init(&ch);
-    observe_preamble(&ch, prm, airs, n_airs);
+    observe_preamble(&ch, prm, airs, n_airs, prep_roots, has_prep);
 
     /* 1. main LDE + commit */
     ora_matrix *mm = (ora_matrix *)calloc(n_airs, sizeof(ora_matrix));
@@ -356,11 +411,11 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
                     den[0] = ora_add(den[0], it->bus + 1);
                     for (uint32_t i = 0; i < it->n_fields; i++) {
                         ext_t t;
-                        ext_scale(chal + 4 * (i + 1), leaf_value(it->fields[i], airs[a].trace, N, r, airs[a].pvs), t);
+                        ext_scale(chal + 4 * (i + 1), leaf_value(it->fields[i], airs[a].trace, N, r, airs[a].pvs, airs[a].prep), t);
                         ext_add(den, t, den);
                     }
                     ora_ext_inv(den, inv);
-                    uint32_t cnt = leaf_value(it->count, airs[a].trace, N, r, airs[a].pvs);
+                    uint32_t cnt = leaf_value(it->count, airs[a].trace, N, r, airs[a].pvs, airs[a].prep);
                     if (it->sign) cnt = ora_sub(0, cnt);
                     ext_scale(inv, cnt, phi);
                     for (int q = 0; q < 4; q++) st[a].perm[(4 * (size_t)j + q) * N + r] = phi[q];
@@ -389,7 +444,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
     for (size_t a = 0; a < n_airs; a++) {
         const program *pg = &st[a].prog;
         const unsigned lh = st[a].lh, h = st[a].h;
-        const size_t N = (size_t)1 << lh, M = N << b, W = st[a].width, PW = pg->perm_width;
+        const size_t N = (size_t)1 << lh, M = N << b, W = st[a].width, PW = pg->perm_width, QW = pg->prep_width;
         ext_t *ap = (ext_t *)malloc((pg->n_cons + 1) * sizeof(ext_t));
         { /* constraint i is weighted alpha^(n_cons-1-i) (Horner order of p3's folder) */
             ext_t cur = {1, 0, 0, 0};
@@ -405,6 +460,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
             uint32_t *vals = (uint32_t *)malloc(pg->n_nodes * sizeof(uint32_t));
             uint32_t *loc = (uint32_t *)malloc((W + 1) * sizeof(uint32_t)), *nxt = (uint32_t *)malloc((W + 1) * sizeof(uint32_t));
             uint32_t *ploc = (uint32_t *)malloc((PW + 1) * sizeof(uint32_t)), *pnxt = (uint32_t *)malloc((PW + 1) * sizeof(uint32_t));
+            uint32_t *qloc = (uint32_t *)malloc((QW + 1) * sizeof(uint32_t)), *qnxt = (uint32_t *)malloc((QW + 1) * sizeof(uint32_t));
 #pragma omp for schedule(static)
             for (size_t r = 0; r < M; r++) {
                 size_t i = bitrev(r, h), rn = bitrev((i + nch) & (M - 1), h);
@@ -417,8 +473,12 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
                     ploc[c] = st[a].perm_lde[c * M + r];
                     pnxt[c] = st[a].perm_lde[c * M + rn];
                 }
+                for (size_t c = 0; c < QW; c++) {
+                    qloc[c] = st[a].prep_lde[c * M + r];
+                    qnxt[c] = st[a].prep_lde[c * M + rn];
+                }
                 uint32_t zh = ora_sub(ora_pow(x, N), 1);
-                row_ctx rc = {loc, nxt, airs[a].pvs, ploc, pnxt, chal, st[a].exposed, 0, 0, 0};
+                row_ctx rc = {loc, nxt, airs[a].pvs, ploc, pnxt, chal, st[a].exposed, 0, 0, 0, qloc, qnxt};
                 rc.is_first = ora_mul(zh, ora_inv(ora_sub(x, 1)));
                 rc.is_trans = ora_sub(x, winv);
                 rc.is_last = ora_mul(zh, ora_inv(rc.is_trans));
@@ -430,7 +490,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
                 }
                 ext_scale(acc, ora_inv(zh), q + 4 * r);
             }
-            free(vals), free(loc), free(nxt), free(ploc), free(pnxt);
+            free(vals), free(loc), free(nxt), free(ploc), free(pnxt), free(qloc), free(qnxt);
         }
         /* chunk j = rows [jN,(j+1)N): evaluations over s_j*H (bit-reversed), s_j = g * wM^bitrev_b(j) */
         st[a].qlde = (uint32_t *)malloc((size_t)nch * 4 * M * sizeof(uint32_t));
@@ -451,13 +511,16 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
     ext_t zeta;
     ora_ch_sample_ext(&ch, zeta);
 
-    /* committed matrices in opening order: main (all AIRs), perm (AIRs with interactions), quotient chunks */
-    size_t n_cm = n_airs + n_lu + n_airs * nch;
+    /* committed matrices in opening order: main (all AIRs), preprocessed (AIRs that have one), perm (AIRs with
+     * interactions), quotient chunks */
+    size_t n_cm = n_airs + n_prep + n_lu + n_airs * nch;
     cmat *cm = (cmat *)calloc(n_cm, sizeof(cmat));
     {
         size_t k = 0;
         for (size_t a = 0; a < n_airs; a++)
             cm[k++] = (cmat){st[a].lde, airs[a].trace, 1, st[a].lh, st[a].h, st[a].width, 2, 0};
+        for (size_t a = 0; a < n_airs; a++)
+            if (has_prep[a]) cm[k++] = (cmat){st[a].prep_lde, airs[a].prep, 1, st[a].lh, st[a].h, st[a].prog.prep_width, 2, 3};
         for (size_t a = 0; a < n_airs; a++)
             if (st[a].prog.n_int) cm[k++] = (cmat){st[a].perm_lde, st[a].perm, 1, st[a].lh, st[a].h, st[a].prog.perm_width, 2, 1};
         for (size_t a = 0; a < n_airs; a++) {
@@ -594,7 +657,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         w += (n);                                       \
     } while (0)
     {
-        uint32_t hdr[4] = {PROOF_MAGIC + (n_lu ? 1u : 0u), (uint32_t)n_airs, hmax, n_layers};
+        uint32_t hdr[4] = {PROOF_MAGIC + (n_lu ? 1u : 0u) + (n_prep ? 2u : 0u), (uint32_t)n_airs, hmax, n_layers};
         PUT(hdr, 4);
         PUT(root_main, 8);
         if (n_lu) {
@@ -617,6 +680,11 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
             size_t idx = ora_ch_sample_bits(&ch, hmax);
             size_t n1 = ora_mmcs_open(t_main, idx >> (hmax - ora_tree_log_height(t_main)), tmp);
             PUT(tmp, n1);
+            for (size_t a = 0; a < n_airs; a++)
+                if (has_prep[a]) {
+                    n1 = ora_mmcs_open(st[a].t_prep, idx >> (hmax - st[a].h), tmp);
+                    PUT(tmp, n1);
+                }
             if (n_lu) {
                 n1 = ora_mmcs_open(t_perm, idx >> (hmax - ora_tree_log_height(t_perm)), tmp);
                 PUT(tmp, n1);
@@ -634,7 +702,8 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
     }
 done:
     for (size_t a = 0; a < n_airs; a++) {
-        free(st[a].lde), free(st[a].qlde), free(st[a].perm), free(st[a].perm_lde);
+        free(st[a].lde), free(st[a].qlde), free(st[a].perm), free(st[a].perm_lde), free(st[a].prep_lde);
+        if (st[a].t_prep) ora_tree_free(st[a].t_prep);
         free_program(&st[a].prog);
     }
     for (size_t k = 0; k < n_airs * nch; k++) free(qnat[k]);
@@ -648,6 +717,7 @@ done:
     if (t_perm) ora_tree_free(t_perm);
     free(ftrees), free(flayers), free(fleaves), free(froots), free(fpow), free(betas);
     free(ro), free(num_reduced), free(opened), free(mm), free(pm), free(qm), free(qnat), free(cm), free(st);
+    free(prep_roots), free(has_prep);
     return ok ? w : 0;
 }
 
@@ -664,20 +734,31 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     if (prm->log_final_poly_len != 0 || n_airs == 0 || b == 0) return -1;
     program *pg = (program *)calloc(n_airs, sizeof(program));
     unsigned hmax = 0;
-    size_t n_lu = 0;
+    size_t n_lu = 0, n_prep = 0;
+    uint32_t *prep_roots = (uint32_t *)calloc(n_airs, 32);
+    int *has_prep = (int *)calloc(n_airs, sizeof(int));
     for (size_t a = 0; a < n_airs; a++) {
         if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &pg[a])) return -2;
         if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height < 1) return -2;
         if (airs[a].log_height + b > hmax) hmax = airs[a].log_height + b;
         if (pg[a].n_int) n_lu++;
+        if (pg[a].prep_width) {
+            /* the verifying key holds the commitment; tests may pass the table itself instead */
+            if (airs[a].prep_commit) memcpy(prep_roots + 8 * a, airs[a].prep_commit, 32);
+            else if (!airs[a].prep || ora_prep_commit(prm, &airs[a], prep_roots + 8 * a)) return -2;
+            has_prep[a] = 1;
+            n_prep++;
+        }
     }
     /* committed matrices in opening order */
-    size_t n_cm = n_airs + n_lu + n_airs * nch, n_open = 0;
+    size_t n_cm = n_airs + n_prep + n_lu + n_airs * nch, n_open = 0;
     vmat *cm = (vmat *)calloc(n_cm, sizeof(vmat));
-    size_t cm_perm0 = n_airs, cm_quot0 = n_airs + n_lu;
+    size_t cm_prep0 = n_airs, cm_perm0 = n_airs + n_prep, cm_quot0 = n_airs + n_prep + n_lu;
     {
         size_t k = 0;
         for (size_t a = 0; a < n_airs; a++) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, airs[a].width, 2};
+        for (size_t a = 0; a < n_airs; a++)
+            if (has_prep[a]) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, pg[a].prep_width, 2};
         for (size_t a = 0; a < n_airs; a++)
             if (pg[a].n_int) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, pg[a].perm_width, 2};
         for (size_t a = 0; a < n_airs; a++)
@@ -693,7 +774,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     for (size_t i = 0; i < n_words; i++)
         if (proof[i] >= ORA_P) return -3; /* all words canonical (the magic is < p too) */
     NEED(4);
-    if (proof[0] != PROOF_MAGIC + (n_lu ? 1u : 0u) || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers) return -3;
+    if (proof[0] != PROOF_MAGIC + (n_lu ? 1u : 0u) + (n_prep ? 2u : 0u) || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers) return -3;
     r = 4;
     NEED(8);
     const uint32_t *root_main = proof + r, *root_perm = NULL, *exposed_all = NULL;
@@ -719,7 +800,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
 
     ora_challenger ch;
     ora_ch_init(&ch);
-    observe_preamble(&ch, prm, airs, n_airs);
+    observe_preamble(&ch, prm, airs, n_airs, prep_roots, has_prep);
     ora_ch_observe(&ch, root_main, 8);
     uint32_t chal[N_CHAL];
     memset(chal, 0, sizeof chal);
@@ -753,7 +834,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     }
     /* constraint check at zeta for every AIR */
     {
-        size_t k_lu = 0;
+        size_t k_lu = 0, k_prep = 0;
         for (size_t a = 0; a < n_airs; a++) {
             const unsigned lh = airs[a].log_height, h = lh + b;
             const size_t W = airs[a].width;
@@ -765,6 +846,11 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
             zc.next = opened + open_off[a] + W;
             zc.pvs = airs[a].pvs;
             zc.chal = chal;
+            if (has_prep[a]) {
+                zc.prep_local = opened + open_off[cm_prep0 + k_prep];
+                zc.prep_next = zc.prep_local + pg[a].prep_width;
+                k_prep++;
+            }
             if (pg[a].n_int) {
                 zc.perm_local = opened + open_off[cm_perm0 + k_lu];
                 zc.perm_next = zc.perm_local + pg[a].perm_width;
@@ -825,16 +911,18 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     ora_ch_observe(&ch, fin, 4);
     if (!ora_ch_check_witness(&ch, prm->query_pow_bits, qpow)) return -5;
 
-    /* shapes of the input batches */
-    const size_t n_batches = n_lu ? 3 : 2;
-    size_t batch_first[3], batch_n[3];
-    const uint32_t *batch_root[3];
-    batch_first[0] = 0, batch_n[0] = n_airs, batch_root[0] = root_main;
-    if (n_lu) {
-        batch_first[1] = cm_perm0, batch_n[1] = n_lu, batch_root[1] = root_perm;
-        batch_first[2] = cm_quot0, batch_n[2] = n_airs * nch, batch_root[2] = root_quot;
-    } else {
-        batch_first[1] = cm_quot0, batch_n[1] = n_airs * nch, batch_root[1] = root_quot;
+    /* shapes of the input batches: main, one per preprocessed trace, perm, quotient */
+    const size_t n_batches = 2 + n_prep + (n_lu ? 1 : 0);
+    size_t *batch_first = (size_t *)malloc(n_batches * sizeof(size_t)), *batch_n = (size_t *)malloc(n_batches * sizeof(size_t));
+    const uint32_t **batch_root = (const uint32_t **)malloc(n_batches * sizeof(uint32_t *));
+    const uint32_t **rows_of = (const uint32_t **)malloc(n_batches * sizeof(uint32_t *));
+    {
+        size_t bt = 0, k = 0;
+        batch_first[bt] = 0, batch_n[bt] = n_airs, batch_root[bt] = root_main, bt++;
+        for (size_t a = 0; a < n_airs; a++)
+            if (has_prep[a]) batch_first[bt] = cm_prep0 + k++, batch_n[bt] = 1, batch_root[bt] = prep_roots + 8 * a, bt++;
+        if (n_lu) batch_first[bt] = cm_perm0, batch_n[bt] = n_lu, batch_root[bt] = root_perm, bt++;
+        batch_first[bt] = cm_quot0, batch_n[bt] = n_airs * nch, batch_root[bt] = root_quot, bt++;
     }
     unsigned *lhs_all = (unsigned *)malloc(n_cm * sizeof(unsigned));
     size_t *ws_all = (size_t *)malloc(n_cm * sizeof(size_t));
@@ -845,7 +933,6 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     int rc = 0;
     for (unsigned qn = 0; qn < prm->num_queries && rc == 0; qn++) {
         size_t idx = ora_ch_sample_bits(&ch, hmax);
-        const uint32_t *rows_of[3];
         for (size_t bt = 0; bt < n_batches && rc == 0; bt++) {
             size_t tw = 0;
             unsigned bh = 0;
@@ -946,6 +1033,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     }
     if (rc == 0 && r != n_words) rc = -3;
     free(betas), free(lhs_all), free(ws_all), free(roq), free(has), free(num_reduced), free(open_off), free(cm);
+    free(batch_first), free(batch_n), free(batch_root), free(rows_of), free(prep_roots), free(has_prep);
     for (size_t a = 0; a < n_airs; a++) free_program(&pg[a]);
     free(pg);
     return rc;

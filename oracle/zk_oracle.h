@@ -139,12 +139,16 @@ typedef struct {
     const uint32_t *trace;   /* column-major, stride = 1<<log_height, canonical */
     const uint32_t *pvs;
     size_t n_pvs;
+    const uint32_t *prep;        /* preprocessed trace (column-major, stride 1<<log_height) or NULL */
+    const uint32_t *prep_commit; /* its 8-word commitment (verifier; NULL -> recomputed from prep) */
 } ora_air_instance;
 
 /* Proves; writes proof words (canonical u32 LE) into out (cap words); returns
  * number of words, or 0 on failure (e.g. constraints unsatisfied when checked). */
 size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size_t n_airs,
                        uint32_t *out, size_t cap);
+/* Commitment of one AIR's preprocessed trace (keygen output, part of the verifying key). 0 = ok. */
+int ora_prep_commit(const ora_params *prm, const ora_air_instance *air, uint32_t root[8]);
 /* Verifies a proof against the AIR programs/public values. 0 = ok, <0 = error code. */
 int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs /* trace ignored */,
                      size_t n_airs, const uint32_t *proof, size_t n_words);

@@ -23,7 +23,7 @@ static uint64_t rnd() {
 
 int main(int argc, char** argv) {
     if (argc < 4) return 2;
-    // case file: [5 params][n_airs]{[log_height][width][n_pvs][prog_len][prog...][pvs...]}
+    // case file: [5 params][n_airs]{[log_height][width][n_pvs][prog_len][prog...][pvs...][has_commit][commit(8) if has_commit]}
     std::vector<uint8_t> cb = slurp(argv[1]), proof = slurp(argv[2]);
     int iters = atoi(argv[3]);
     const uint32_t* w = (const uint32_t*)cb.data();
@@ -37,6 +37,9 @@ int main(int argc, char** argv) {
         p += 4 + airs[a].program_len;
         pvs[a] = w + p;
         p += airs[a].n_pvs;
+        airs[a].prep_trace = nullptr;
+        airs[a].prep_commit = w[p] ? w + p + 1 : nullptr;
+        p += w[p] ? 9 : 1;
     }
     if (zkhip_verify(&prm, airs.data(), n_airs, pvs.data(), proof.data(), proof.size()) != 0) {
         std::printf("valid proof rejected\n");
@@ -74,6 +77,7 @@ int main(int argc, char** argv) {
         for (size_t k = 0; k < n_airs; k++) {
             airs2[k].program = m.data() + (airs[k].program - w);
             pvs2[k] = m.data() + (pvs[k] - w);
+            if (airs[k].prep_commit) airs2[k].prep_commit = m.data() + (airs[k].prep_commit - w);
         }
         size_t plen = airs2[a].program_len;
         if (rnd() % 8 == 0) airs2[a].program_len = plen - 1 - rnd() % (plen < 9 ? 1 : 8);  // truncated program

@@ -29,7 +29,7 @@ class OraParams(C.Structure):
 class OraAir(C.Structure):
     _fields_ = [("program", C.POINTER(C.c_uint32)), ("program_len", C.c_size_t), ("log_height", C.c_uint),
                 ("width", C.c_size_t), ("trace", C.POINTER(C.c_uint32)), ("pvs", C.POINTER(C.c_uint32)),
-                ("n_pvs", C.c_size_t)]
+                ("n_pvs", C.c_size_t), ("prep", C.POINTER(C.c_uint32)), ("prep_commit", C.POINTER(C.c_uint32))]
 
 
 def build():
@@ -93,6 +93,10 @@ def lib():
             l.ora_stark_verify.argtypes = [C.POINTER(OraParams), C.POINTER(OraAir), sz, u32p, sz]
         _LIB = l
     return _LIB
+
+
+def u32p_t():
+    return C.POINTER(C.c_uint32)
 
 
 def p32(a):
@@ -196,9 +200,12 @@ def _air_array(airs):
         prog = np.ascontiguousarray(a["program"], dtype=np.uint32)
         pvs = np.ascontiguousarray(a["pvs"], dtype=np.uint32)
         tr = None if a.get("trace") is None else np.ascontiguousarray(a["trace"], dtype=np.uint32)
-        keep += [prog, pvs, tr]
+        prep = None if a.get("prep") is None else np.ascontiguousarray(a["prep"], dtype=np.uint32)
+        pc = None if a.get("prep_commit") is None else np.ascontiguousarray(a["prep_commit"], dtype=np.uint32)
+        keep += [prog, pvs, tr, prep, pc]
         arr[i] = OraAir(p32(prog), prog.size, a["log_height"], a["width"],
-                        p32(tr) if tr is not None else None, p32(pvs) if pvs.size else None, pvs.size)
+                        p32(tr) if tr is not None else None, p32(pvs) if pvs.size else None, pvs.size,
+                        p32(prep) if prep is not None else None, p32(pc) if pc is not None else None)
     return arr, keep
 
 
@@ -210,6 +217,19 @@ def stark_prove(params, airs, cap_words=1 << 24):
     if n == 0:
         raise RuntimeError("oracle prover failed")
     return out[:n].copy()
+
+
+def prep_commit(params, a):
+    """8-word commitment of one AIR's preprocessed trace (the verifying-key entry)."""
+    prm = OraParams(*params)
+    arr, keep = _air_array([a])
+    out = np.zeros(8, dtype=np.uint32)
+    l = lib()
+    l.ora_prep_commit.restype = C.c_int
+    l.ora_prep_commit.argtypes = [C.POINTER(OraParams), C.POINTER(OraAir), u32p_t()]
+    if l.ora_prep_commit(C.byref(prm), arr, p32(out)) != 0:
+        raise RuntimeError("ora_prep_commit failed")
+    return out
 
 
 def stark_verify(params, airs, proof):

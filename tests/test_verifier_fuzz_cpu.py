@@ -21,6 +21,15 @@ def _logup_airs():
             dict(program=air.lookup_table_air().program(), log_height=3, width=3, n_pvs=0, trace=t, pvs=nopv)]
 
 
+def _prep_airs():
+    u, m, prep = air.range_traces(5, 3, seed=2)
+    nopv = np.zeros(0, np.uint32)
+    ftr, fpv = air.fibonacci_trace(4)
+    return [dict(program=air.range_user_air().program(), log_height=5, width=4, n_pvs=0, trace=u, pvs=nopv),
+            dict(program=air.fibonacci_air().program(), log_height=4, width=2, n_pvs=3, trace=ftr, pvs=fpv),
+            dict(program=air.range_table_air().program(), log_height=3, width=1, n_pvs=0, trace=m, pvs=nopv, prep=prep)]
+
+
 def _plain_airs():
     sa = air.SyntheticAir(width=14, n_free=5, n_bool=2, n_boundary=2, seed=3)
     tr, pv = sa.gen_trace(5, seed=4)
@@ -41,7 +50,7 @@ def fuzz_exe(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("case", [_plain_airs, _logup_airs])
+@pytest.mark.parametrize("case", [_plain_airs, _logup_airs, _prep_airs])
 def test_verifier_asan_ubsan_fuzz(ora, tmp_path, fuzz_exe, case):
     exe = fuzz_exe
     airs = case()
@@ -50,6 +59,7 @@ def test_verifier_asan_ubsan_fuzz(ora, tmp_path, fuzz_exe, case):
     for a in airs:
         prog = np.asarray(a["program"], dtype=np.uint32)
         words += [a["log_height"], a["width"], a["n_pvs"], prog.size] + prog.tolist() + np.asarray(a["pvs"]).tolist()
+        words += [1] + ora.prep_commit(PARAMS, a).tolist() if a.get("prep") is not None else [0]
     np.array(words, dtype=np.uint32).tofile(tmp_path / "case.bin")
     proof.tofile(tmp_path / "proof.bin")
     r = subprocess.run([str(exe), str(tmp_path / "case.bin"), str(tmp_path / "proof.bin"), "2400"],

@@ -39,7 +39,8 @@ class _Params(C.Structure):
 
 class _Air(C.Structure):
     _fields_ = [("program", C.POINTER(C.c_uint32)), ("program_len", C.c_size_t), ("log_height", C.c_uint),
-                ("width", C.c_size_t), ("n_pvs", C.c_size_t)]
+                ("width", C.c_size_t), ("n_pvs", C.c_size_t), ("prep_trace", C.POINTER(C.c_uint32)),
+                ("prep_commit", C.POINTER(C.c_uint32))]
 
 
 class _KernelStat(C.Structure):
@@ -92,6 +93,7 @@ def load_library():
         "zkhip_transcript_grind": (C.c_int, [vp, vp, C.c_uint, u32p]),
         "zkhip_keygen": (C.c_int, [vp, C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(vp)]),
         "zkhip_pk_destroy": (None, [vp, vp]),
+        "zkhip_pk_prep_commitment": (C.c_int, [vp, vp, sz, u32p]),
         "zkhip_proof_size": (sz, [vp]),
         "zkhip_prove": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(u32p), C.POINTER(C.c_uint8), sz, C.POINTER(sz)]),
         "zkhip_prove_async": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(u32p)]),
@@ -337,8 +339,11 @@ def _air_structs(airs):
     keep = []
     for i, a in enumerate(airs):
         prog = np.ascontiguousarray(a["program"], dtype=np.uint32)
-        keep.append(prog)
-        arr[i] = _Air(_u32p(prog), prog.size, a["log_height"], a["width"], a["n_pvs"])
+        prep = None if a.get("prep") is None else np.ascontiguousarray(a["prep"], dtype=np.uint32)
+        pc = None if a.get("prep_commit") is None else np.ascontiguousarray(a["prep_commit"], dtype=np.uint32)
+        keep += [prog, prep, pc]
+        arr[i] = _Air(_u32p(prog), prog.size, a["log_height"], a["width"], a["n_pvs"],
+                      _u32p(prep) if prep is not None else None, _u32p(pc) if pc is not None else None)
     return arr, keep
 
 
@@ -359,6 +364,22 @@ class ProvingKey:
         ctx._check(ctx.lib.zkhip_keygen(ctx.h, C.byref(prm), arr, len(airs), C.byref(h)))
         self.h = h
         self.proof_size = ctx.lib.zkhip_proof_size(h)
+
+    def prep_commitment(self, air_index):
+        """8 canonical words: the verifying-key entry of AIR `air_index`'s preprocessed trace."""
+        out = np.zeros(8, dtype=np.uint32)
+        self.ctx._check(self.ctx.lib.zkhip_pk_prep_commitment(self.ctx.h, self.h, air_index, _u32p(out)))
+        return out
+
+    def verifying_airs(self):
+        """The AIR descriptions a verifier needs: programs + shapes + preprocessed commitments (no tables)."""
+        out = []
+        for i, a in enumerate(self.airs):
+            v = {k: a[k] for k in ("program", "log_height", "width", "n_pvs")}
+            if a.get("prep") is not None:
+                v["prep_commit"] = self.prep_commitment(i)
+            out.append(v)
+        return out
 
     def prove_async(self, traces, pvs):
         tp = (C.c_void_p * len(traces))(*[t.data_ptr() for t in traces])

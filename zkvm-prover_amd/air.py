@@ -15,6 +15,8 @@ OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, O
 # leaves of the after-challenge (LogUp) phase: a base column of the permutation matrix, a coordinate
 # of the interaction challenges, a coordinate of the AIR's exposed cumulative sum
 OP_PERM, OP_CHAL, OP_EXPOSED = 10, 11, 12
+OP_PREP = 13                              # a cell of the AIR's preprocessed trace (committed at keygen)
+PREP_MAGIC = 0x50504B5A                   # section [PREP_MAGIC, prep_width] after the constraints
 LOGUP_MAGIC = 0x554C4B5A
 LOGUP_MAX_FIELDS = 8                      # challenge vector = gamma, beta^1 .. beta^8 (4 coordinates each)
 N_CHAL = 4 * (1 + LOGUP_MAX_FIELDS)
@@ -57,8 +59,8 @@ class AirBuilder:
     """Mirrors the shape of p3-air's AirBuilder: main-trace variables with rotation 0/1, public
     values, is_first_row / is_last_row / is_transition selectors, assert_zero."""
 
-    def __init__(self, width, n_pvs=0):
-        self.width, self.n_pvs = width, n_pvs
+    def __init__(self, width, n_pvs=0, prep_width=0):
+        self.width, self.n_pvs, self.prep_width = width, n_pvs, prep_width
         self.nodes, self.cons, self._cache = [], [], {}
 
     def _node(self, op, a=0, b=0, deg=0):
@@ -74,6 +76,11 @@ class AirBuilder:
 
     def next(self, col):
         return self.var(col, 1)
+
+    def prep(self, col, rot=0):
+        """Cell of the preprocessed trace (fixed at keygen, like p3's `preprocessed` window)."""
+        assert 0 <= col < self.prep_width and rot in (0, 1)
+        return self._node(OP_PREP, col, rot, 1)
 
     def pub(self, i):
         assert 0 <= i < self.n_pvs
@@ -112,7 +119,8 @@ class AirBuilder:
         count = count if isinstance(count, Expr) else self.const(count)
         for e in fields + [count]:
             op, a, b = self.nodes[e.idx]
-            assert op in (OP_VAR, OP_PUB, OP_CONST) and (op != OP_VAR or b == 0), "interaction operands must be leaves"
+            assert op in (OP_VAR, OP_PUB, OP_CONST, OP_PREP) and (op not in (OP_VAR, OP_PREP) or b == 0), \
+                "interaction operands must be leaves"
         if not hasattr(self, "interactions"):
             self.interactions = []
         self.interactions.append((bus, 0 if kind == "send" else 1, count, fields))
@@ -172,7 +180,7 @@ class AirBuilder:
     def max_degree(self):
         deg = {}
         for i, (op, a, b) in enumerate(self.nodes):
-            if op in (OP_VAR, OP_PERM, OP_FIRST, OP_LAST):
+            if op in (OP_VAR, OP_PERM, OP_PREP, OP_FIRST, OP_LAST):
                 deg[i] = 1
             elif op in (OP_PUB, OP_CONST, OP_TRANS, OP_CHAL, OP_EXPOSED):
                 deg[i] = 0
@@ -190,6 +198,8 @@ class AirBuilder:
         for n in self.nodes:
             words.extend(n)
         words.extend(self.cons)
+        if self.prep_width:
+            words += [PREP_MAGIC, self.prep_width]
         ints = getattr(self, "interactions", [])
         if ints:
             # trailing section: [LOGUP_MAGIC, n_int, {bus, sign, count leaf (3 words), n_fields, field leaves (3 words each)}]
@@ -202,8 +212,9 @@ class AirBuilder:
 
 
 # ---- reference evaluation of a program on a trace (numpy; host-side witness sanity check) ----
-def check_trace(program, trace, pvs):
-    """trace: [width, n] canonical uint32.  Returns the list of violated (constraint, row)."""
+def check_trace(program, trace, pvs, prep=None):
+    """trace: [width, n] canonical uint32 (prep: [prep_width, n] or None).  Returns the list of violated
+    (constraint, row)."""
     w = [int(x) for x in program]
     n_nodes, n_cons = w[1], w[2]
     nodes = [tuple(w[4 + 3 * i: 7 + 3 * i]) for i in range(n_nodes)]
@@ -233,6 +244,9 @@ def check_trace(program, trace, pvs):
             vals[i] = None if vals[a] is None or vals[b] is None else (vals[a] * vals[b]) % P
         elif op == OP_NEG:
             vals[i] = None if vals[a] is None else (-vals[a]) % P
+        elif op == OP_PREP and prep is not None:
+            pt = np.asarray(prep).astype(np.int64)
+            vals[i] = np.roll(pt[a], -1) if b else pt[a]
         else:
             vals[i] = None  # LogUp-phase leaf: only the main-trace constraints are checked here
     bad = []
@@ -416,3 +430,34 @@ def bus_mix_trace(log_n, seed=0, width=6):
     t[2] = t[0] * t[1] % P
     t[4] = t[1][rng.permutation(n)]          # bus 9: column 4 is a permutation of column 1
     return t.astype(np.uint32), np.array([rng.integers(0, P)], dtype=np.uint32)
+
+
+# ---- preprocessed-trace demo: a range-check table whose keys are fixed at keygen ---------------
+def range_table_air(bus=5):
+    """Preprocessed column 0 = 0..N-1 (the table); main column 0 = multiplicity.  Receives (key) mult times."""
+    b = AirBuilder(1, 0, prep_width=1)
+    # the table is what it claims to be: first key 0, keys increase by one (checked on the preprocessed column,
+    # which also exercises next-row access to it)
+    b.when_first_row(b.prep(0))
+    b.when_transition(b.prep(0, 1) - b.prep(0) - 1)
+    b.push_interaction(bus, [b.prep(0)], b.var(0), "receive")
+    return b
+
+
+def range_user_air(width=4, bus=5):
+    """Every row sends its column 0 (must lie in the table's range) once; column 1 = column 0 squared."""
+    b = AirBuilder(width, 0)
+    b.assert_zero(b.var(0) * b.var(0) - b.var(1))
+    b.push_interaction(bus, [b.var(0)], 1, "send")
+    return b
+
+
+def range_traces(log_n_user, log_n_table, seed=0, user_width=4):
+    rng = np.random.default_rng(seed)
+    nu, nt = 1 << log_n_user, 1 << log_n_table
+    user = rng.integers(0, P, size=(user_width, nu)).astype(np.int64)
+    user[0] = rng.integers(0, nt, size=nu)
+    user[1] = user[0] * user[0] % P
+    prep = np.arange(nt, dtype=np.uint32).reshape(1, nt)
+    mult = np.bincount(user[0], minlength=nt).astype(np.uint32).reshape(1, nt)
+    return user.astype(np.uint32), mult, prep

@@ -23,12 +23,14 @@ constexpr uint32_t PROOF_MAGIC = 0x31504B5Au;
 constexpr uint32_t PROTO_TAG = 0x5A4B4831u;
 
 constexpr uint32_t LOGUP_MAGIC = 0x554C4B5Au;
+constexpr uint32_t PREP_MAGIC = 0x50504B5Au;  // section [PREP_MAGIC, prep_width]: the AIR has a preprocessed trace
 constexpr unsigned LOGUP_MAX_FIELDS = 8;
 constexpr unsigned N_CHAL = 4 * (1 + LOGUP_MAX_FIELDS);  // gamma, beta^1..beta^8 as base coordinates
 
 // A_PERM / A_CHAL / A_EXPOSED are the leaves of the after-challenge (LogUp) phase: a base column of the
 // permutation matrix, a coordinate of the interaction challenges, a coordinate of the exposed sum.
-enum AirOp : uint32_t { A_VAR, A_PUB, A_CONST, A_FIRST, A_LAST, A_TRANS, A_ADD, A_SUB, A_MUL, A_NEG, A_PERM, A_CHAL, A_EXPOSED };
+// A_PREP is a cell of the preprocessed trace (committed at keygen, opened like the main trace).
+enum AirOp : uint32_t { A_VAR, A_PUB, A_CONST, A_FIRST, A_LAST, A_TRANS, A_ADD, A_SUB, A_MUL, A_NEG, A_PERM, A_CHAL, A_EXPOSED, A_PREP };
 
 // one bus interaction: phi = (sign ? -count : count) / (gamma + bus + 1 + sum_i beta^(i+1) * field_i);
 // count and the fields are leaves (VAR of the current row, PUB or CONST), 3 words each as in the node table
@@ -44,6 +46,7 @@ struct AirProgram {
     const uint32_t* cons = nullptr;
     unsigned max_degree = 0;
     std::vector<Interaction> ints;
+    size_t prep_width = 0;
     size_t perm_width() const { return ints.empty() ? 0 : 4 * (ints.size() + 1); }
 };
 
@@ -61,14 +64,22 @@ inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p,
     p->nodes = w + 4;
     p->cons = w + 4 + 3 * (size_t)p->n_nodes;
     p->ints.clear();
-    if (base_len != len) {  // trailing interactions section
-        size_t q = base_len;
+    p->prep_width = 0;
+    size_t q0 = base_len;
+    if (q0 + 2 <= len && w[q0] == PREP_MAGIC) {
+        p->prep_width = w[q0 + 1];
+        if (p->prep_width == 0 || p->prep_width > (1u << 20)) return fail("bad preprocessed width");
+        q0 += 2;
+    }
+    if (q0 != len) {  // trailing interactions section
+        size_t q = q0;
         if (q + 2 > len || w[q] != LOGUP_MAGIC) return fail("AIR program length mismatch");
         const uint32_t n_int = w[q + 1];
         q += 2;
         if (n_int == 0 || n_int > 4096) return fail("bad interaction count");
         auto leaf_ok = [&](const uint32_t* l) {
             if (l[0] == A_VAR) return l[1] < width && l[2] == 0;
+            if (l[0] == A_PREP) return l[1] < p->prep_width && l[2] == 0;
             if (l[0] == A_PUB) return l[1] < p->n_pvs;
             return l[0] == A_CONST && l[1] < P;
         };
@@ -133,6 +144,10 @@ inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p,
             case A_EXPOSED:
                 if (a >= 4 || perm_w == 0) return fail("EXPOSED out of range");
                 break;
+            case A_PREP:
+                if (a >= p->prep_width || b > 1) return fail("PREP out of range");
+                deg[i] = 1;
+                break;
             default:
                 return fail("unknown AIR op");
         }
@@ -150,7 +165,7 @@ inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p,
 // operand = kind << 28 | payload; VAR payload = rot << 27 | column
 enum QOp : uint32_t { Q_ADD, Q_SUB, Q_MUL, Q_NEG, Q_ASSERT };
 // PERM payload like VAR (column of the permutation LDE); CHAL / EXPO index the per-proof challenge block
-enum QKind : uint32_t { K_SLOT, K_VAR, K_PUB, K_CONST, K_SEL, K_PERM, K_CHAL, K_EXPO };
+enum QKind : uint32_t { K_SLOT, K_VAR, K_PUB, K_CONST, K_SEL, K_PERM, K_CHAL, K_EXPO, K_PREP };
 constexpr unsigned Q_MAX_SLOTS = 60;
 
 struct CompiledAir {
@@ -214,6 +229,8 @@ inline int compile_air(const AirProgram& p, CompiledAir* out, std::string* err) 
                 return (K_CHAL << 28) | a;
             case A_EXPOSED:
                 return (K_EXPO << 28) | a;
+            case A_PREP:
+                return (K_PREP << 28) | (b << 27) | a;
             default:
                 return (K_SEL << 28) | (op - A_FIRST);
         }

@@ -54,6 +54,7 @@ struct QuotArgs {
     const uint32_t* perm;   // permutation LDE (column-major, stride = M) or null
     const uint32_t* lchal;  // N_CHAL interaction challenge coordinates or null
     const uint32_t* expo;   // 4 coordinates of the exposed cumulative sum or null
+    const uint32_t* prep;   // preprocessed LDE (column-major, stride = M) or null
     uint32_t* q;            // 4 columns of M (quotient values, bit-reversed LDE order)
     const uint32_t* tw_fwd;
     const uint32_t* inv_zh; // 2^b values, index = natural index mod 2^b
@@ -99,6 +100,10 @@ __global__ __launch_bounds__(QBS) void k_quotient(QuotArgs a) {
                 return a.lchal[idx];
             case K_EXPO:
                 return a.expo[idx];
+            case K_PREP: {
+                const uint32_t col = idx & 0x07ffffffu;
+                return a.prep[(size_t)col * M + ((idx >> 27) ? rn : r)];
+            }
             default:
                 return idx == 0 ? sel_first : (idx == 1 ? sel_last : sel_trans);
         }
@@ -150,10 +155,11 @@ __global__ void k_logup_chal(const uint32_t* gb, uint32_t* lchal) {
 
 // interaction table on the device: LU_STRIDE words per interaction
 //   [0] bus+1 (Montgomery)  [1] sign  [2] count kind  [3] count value  [4] n_fields  [5+2i] kind_i  [6+2i] value_i
-// kind 0 = trace column (value = column), 1 = public value (index), 2 = constant (Montgomery)
+// kind 0 = trace column (value = column), 1 = public value (index), 2 = constant (Montgomery), 3 = preprocessed column
 constexpr unsigned LU_STRIDE = 5 + 2 * LOGUP_MAX_FIELDS;
 struct LogupArgs {
     const uint32_t* trace;  // column-major, stride N, Montgomery
+    const uint32_t* prep;   // preprocessed trace, same layout (or null)
     const uint32_t* pvs;
     const uint32_t* tab;
     const uint32_t* lchal;
@@ -166,7 +172,7 @@ struct LogupArgs {
     uint32_t n_int;
 };
 __device__ __forceinline__ uint32_t lu_leaf(const LogupArgs& a, uint32_t kind, uint32_t val, size_t r) {
-    return kind == 0 ? a.trace[(size_t)val * a.N + r] : (kind == 1 ? a.pvs[val] : val);
+    return kind == 0 ? a.trace[(size_t)val * a.N + r] : (kind == 1 ? a.pvs[val] : (kind == 3 ? a.prep[(size_t)val * a.N + r] : val));
 }
 // grid (rows / 256, n_int): denominator gamma + bus + 1 + sum_i beta^(i+1) f_i and numerator +-count of one row
 __global__ __launch_bounds__(256) void k_logup_denoms(LogupArgs a) {
@@ -516,6 +522,12 @@ struct AirPlan {
     uint32_t* d_lu_sums = nullptr;     // N ext
     uint32_t* d_perm = nullptr;        // perm_w columns x N (natural order)
     uint32_t* d_perm_lde = nullptr;    // perm_w columns x M
+    // preprocessed trace: uploaded, extended and committed at keygen, resident for the life of the key
+    size_t prep_w = 0, opened_prep_off = 0;
+    uint32_t* d_prep = nullptr;        // prep_w columns x N (natural order, Montgomery)
+    uint32_t* d_prep_lde = nullptr;    // prep_w columns x M
+    zkhip_tree* t_prep = nullptr;
+    uint32_t prep_commit[8] = {};      // canonical
     hipModule_t jit_mod = nullptr;   // keygen-compiled constraint kernel (null -> interpreter)
     hipFunction_t jit_fn = nullptr;
     uint32_t* d_jit_tab = nullptr;   // per-instance leaf parameters of the shape classes
@@ -526,7 +538,7 @@ struct zkhip_pk {
     unsigned b = 1, nch = 2, hmax = 0, n_layers = 0;
     std::vector<AirPlan> airs;
     std::vector<uint32_t> preamble;  // canonical words observed before anything else (pvs patched in)
-    std::vector<size_t> preamble_pv_off;
+    std::vector<size_t> preamble_pv_off, preamble_prep_off;
     // workspace
     void* d_ws = nullptr;
     size_t ws_bytes = 0;
@@ -541,6 +553,7 @@ struct zkhip_pk {
     uint32_t* d_apow_f = nullptr;   // max width ext
     std::vector<uint32_t*> d_ro;    // per log height (nullptr if none)
     std::vector<uint32_t*> d_flayer;  // n_layers+1
+    size_t n_prep = 0;              // AIRs with a preprocessed trace
     size_t n_lu = 0;                // AIRs with bus interactions
     unsigned h_perm = 0;            // log height of the permutation commitment
     uint32_t* d_lchal = nullptr;    // N_CHAL challenge coordinates, then the raw gamma, beta (8 words)
@@ -555,7 +568,7 @@ struct zkhip_pk {
     // proof layout (words)
     size_t proof_words = 0, off_roots = 0, off_opened = 0, off_fri = 0, off_final = 0, off_qpow = 0, off_queries = 0;
     size_t off_root_perm = 0, off_exposed = 0, off_root_quot = 0;
-    size_t query_pitch = 0, q_main_words = 0, q_perm_words = 0, q_quot_words = 0;
+    size_t query_pitch = 0, q_main_words = 0, q_prep_words = 0, q_perm_words = 0, q_quot_words = 0;
 };
 
 namespace {
@@ -625,6 +638,20 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         max_n = std::max(max_n, A.N);
         max_w = std::max(max_w, A.width);
         tw_main += A.width;
+        A.prep_w = A.prog.prep_width;
+        if (A.prep_w) {
+            if (!airs[a].prep_trace) {
+                delete pk;
+                return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + " declares a preprocessed trace but none was given");
+            }
+            for (size_t i = 0; i < A.prep_w * A.N; i++)
+                if (airs[a].prep_trace[i] >= P) {
+                    delete pk;
+                    return set_error(ctx, ZKHIP_ERR_INVALID, "preprocessed trace value not canonical");
+                }
+            pk->n_prep++;
+            max_w = std::max(max_w, A.prep_w);
+        }
         A.n_int = (uint32_t)A.prog.ints.size();
         A.perm_w = A.prog.perm_width();
         if (A.n_int) {
@@ -647,6 +674,10 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         n_open += 2 * pk->airs[a].width;
     }
     for (size_t a = 0; a < n_airs; a++) {
+        pk->airs[a].opened_prep_off = n_open;
+        n_open += 2 * pk->airs[a].prep_w;
+    }
+    for (size_t a = 0; a < n_airs; a++) {
         pk->airs[a].opened_perm_off = n_open;
         n_open += 2 * pk->airs[a].perm_w;
     }
@@ -666,6 +697,9 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             pre.push_back((uint32_t)A.width);
             pre.push_back((uint32_t)A.n_pvs);
             for (int i = 0; i < 8; i++) pre.push_back(A.digest[i]);
+            pk->preamble_prep_off.push_back(pre.size());
+            if (A.prep_w)
+                for (int i = 0; i < 8; i++) pre.push_back(0);  // commitment, known once the table is committed below
             pk->preamble_pv_off.push_back(pre.size());
             for (size_t i = 0; i < A.n_pvs; i++) pre.push_back(0);
         }
@@ -692,9 +726,11 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         w += 1;
         pk->off_queries = w;
         pk->q_main_words = tw_main + 8 * (size_t)pk->hmax;
+        for (size_t a = 0; a < n_airs; a++)
+            if (pk->airs[a].prep_w) pk->q_prep_words += pk->airs[a].prep_w + 8 * (size_t)pk->airs[a].h;
         pk->q_perm_words = pk->n_lu ? tw_perm + 8 * (size_t)pk->h_perm : 0;
         pk->q_quot_words = 4 * (size_t)pk->nch * n_airs + 8 * (size_t)pk->hmax;
-        size_t pitch = pk->q_main_words + pk->q_perm_words + pk->q_quot_words;
+        size_t pitch = pk->q_main_words + pk->q_prep_words + pk->q_perm_words + pk->q_quot_words;
         for (unsigned l = 0; l < pk->n_layers; l++) pitch += 4 + 8 * (size_t)(pk->hmax - l - 1);
         pk->query_pitch = pitch;
         w += pitch * params->num_queries;
@@ -705,7 +741,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     const unsigned nch = pk->nch;
     struct AirOff {
         size_t code, consts, zh, inv_zh, pvs, lde, q, qnat, qlde, apow_q;
-        size_t lu_tab, lu_den, lu_num, lu_sums, perm, perm_lde;
+        size_t lu_tab, lu_den, lu_num, lu_sums, perm, perm_lde, prep, prep_lde, dig_prep;
     };
     std::vector<AirOff> ao(n_airs);
     std::vector<CompiledAir> comp(n_airs);
@@ -744,6 +780,11 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         ao[a].qnat = bp.take(A.M * 4 * 4);
         ao[a].qlde = bp.take((size_t)nch * A.M * 4 * 4);
         ao[a].apow_q = bp.take((size_t)(A.prog.n_cons + 1) * 16);
+        if (A.prep_w) {
+            ao[a].prep = bp.take(A.prep_w * A.N * 4);
+            ao[a].prep_lde = bp.take(A.prep_w * A.M * 4);
+            ao[a].dig_prep = bp.take(merkle_digest_count(A.h) * 32);
+        }
         if (A.n_int) {
             ao[a].lu_tab = bp.take((size_t)A.n_int * LU_STRIDE * 4);
             ao[a].lu_den = bp.take((size_t)A.n_int * A.N * 16);
@@ -809,6 +850,23 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         }
         if (rc == ZKHIP_OK) rc = upload(ctx, A.d_zh, zh.data(), nch * 4);
         if (rc == ZKHIP_OK) rc = upload(ctx, A.d_inv_zh, izh.data(), nch * 4);
+        if (A.prep_w) {
+            A.d_prep = (uint32_t*)(base + ao[a].prep);
+            A.d_prep_lde = (uint32_t*)(base + ao[a].prep_lde);
+            if (rc == ZKHIP_OK) rc = upload(ctx, A.d_prep, airs[a].prep_trace, A.prep_w * A.N * 4);
+            if (rc == ZKHIP_OK) rc = convert_repr(ctx, A.d_prep, A.prep_w * A.N, true);
+            if (rc == ZKHIP_OK) rc = lde_batch(ctx, A.d_prep, A.N, A.d_prep_lde, A.M, A.lh, pk->b, A.prep_w, to_monty(FIELD_GEN_CANON));
+            zkhip_matrix pmx{A.d_prep_lde, A.M, A.h, A.prep_w};
+            if (rc == ZKHIP_OK) rc = merkle_plan(ctx, &pmx, 1, (uint32_t*)(base + ao[a].dig_prep), &A.t_prep);
+            if (rc == ZKHIP_OK) rc = merkle_build(ctx, A.t_prep, false);
+            if (rc == ZKHIP_OK) {
+                uint32_t rm[8];
+                if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+                    hipMemcpy(rm, zkhip_tree_root_device(A.t_prep), 32, hipMemcpyDeviceToHost) != hipSuccess)
+                    rc = set_error(ctx, ZKHIP_ERR_HIP, "reading the preprocessed commitment failed");
+                for (int k = 0; k < 8; k++) A.prep_commit[k] = from_monty(rm[k]);
+            }
+        }
         if (A.n_int) {
             A.d_lu_tab = (uint32_t*)(base + ao[a].lu_tab);
             A.d_lu_den = (uint32_t*)(base + ao[a].lu_den);
@@ -818,7 +876,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             A.d_perm_lde = (uint32_t*)(base + ao[a].perm_lde);
             std::vector<uint32_t> tab((size_t)A.n_int * LU_STRIDE, 0);
             auto leaf = [](const uint32_t* l, uint32_t* kind, uint32_t* val) {
-                *kind = l[0] == A_VAR ? 0u : (l[0] == A_PUB ? 1u : 2u);
+                *kind = l[0] == A_VAR ? 0u : (l[0] == A_PUB ? 1u : (l[0] == A_PREP ? 3u : 2u));
                 *val = l[0] == A_CONST ? to_monty(l[1]) : l[1];
             };
             for (uint32_t j = 0; j < A.n_int; j++) {
@@ -860,7 +918,10 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     if (rc == ZKHIP_OK) rc = merkle_plan(ctx, qm.data(), qm.size(), (uint32_t*)(base + o_dig_quot), &pk->t_quot);
     pk->t_fri.assign(pk->n_layers, nullptr);
     std::vector<FriLayerDesc> desc(pk->n_layers);
-    size_t qoff = pk->q_main_words + pk->q_perm_words + pk->q_quot_words;
+    for (size_t a = 0; a < n_airs; a++)
+        if (pk->airs[a].prep_w)
+            for (int i = 0; i < 8; i++) pk->preamble[pk->preamble_prep_off[a] + i] = pk->airs[a].prep_commit[i];
+    size_t qoff = pk->q_main_words + pk->q_prep_words + pk->q_perm_words + pk->q_quot_words;
     for (unsigned l = 0; l < pk->n_layers && rc == ZKHIP_OK; l++) {
         rc = merkle_plan_leaves(ctx, pk->hmax - l - 1, (uint32_t*)(base + o_dig_fri[l]), &pk->t_fri[l]);
         desc[l].layer = pk->d_flayer[l];
@@ -884,6 +945,8 @@ void zkhip_pk_destroy(zkhip_ctx* ctx, zkhip_pk* pk) {
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (pk->t_main) zkhip_tree_destroy(ctx, pk->t_main);
     if (pk->t_perm) zkhip_tree_destroy(ctx, pk->t_perm);
+    for (auto& A : pk->airs)
+        if (A.t_prep) zkhip_tree_destroy(ctx, A.t_prep);
     if (pk->t_quot) zkhip_tree_destroy(ctx, pk->t_quot);
     for (auto* t : pk->t_fri)
         if (t) zkhip_tree_destroy(ctx, t);
@@ -896,6 +959,13 @@ void zkhip_pk_destroy(zkhip_ctx* ctx, zkhip_pk* pk) {
 }
 
 size_t zkhip_proof_size(const zkhip_pk* pk) { return pk ? pk->proof_words * 4 : 0; }
+
+int zkhip_pk_prep_commitment(zkhip_ctx* ctx, const zkhip_pk* pk, size_t air_index, uint32_t out[8]) {
+    if (!ctx || !pk || !out || air_index >= pk->airs.size()) return ZKHIP_ERR_INVALID;
+    if (!pk->airs[air_index].prep_w) return set_error(ctx, ZKHIP_ERR_INVALID, "AIR has no preprocessed trace");
+    memcpy(out, pk->airs[air_index].prep_commit, 32);
+    return ZKHIP_OK;
+}
 
 int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const* d_traces,
                       const uint32_t* const* pvs) {
@@ -927,7 +997,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));  // pm is a stack temporary
         }
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_preamble, pre.data(), pre.size() * 4, hipMemcpyHostToDevice, st));
-        uint32_t hdr[4] = {PROOF_MAGIC + (pk->n_lu ? 1u : 0u), (uint32_t)n_airs, hmax, pk->n_layers};
+        uint32_t hdr[4] = {PROOF_MAGIC + (pk->n_lu ? 1u : 0u) + (pk->n_prep ? 2u : 0u), (uint32_t)n_airs, hmax, pk->n_layers};
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_proof, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
         ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));
         ZK_TRY(transcript_init(ctx, pk->d_tr));
@@ -959,6 +1029,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             if (!A.n_int) continue;
             LogupArgs la;
             la.trace = d_traces[a];
+            la.prep = A.d_prep;
             la.pvs = A.d_pvs;
             la.tab = A.d_lu_tab;
             la.lchal = pk->d_lchal;
@@ -1011,6 +1082,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         qa.perm = A.d_perm_lde;
         qa.lchal = pk->d_lchal;
         qa.expo = pk->d_exposed + 4 * A.lu_index;
+        qa.prep = A.d_prep_lde;
         qa.q = A.d_q;
         qa.tw_fwd = ctx->d_tw_fwd;
         qa.inv_zh = A.d_inv_zh;
@@ -1025,7 +1097,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             void* params[] = {(void*)&qa.lde, (void*)&qa.q,      (void*)&qa.pvs,      (void*)&qa.apow,
                               (void*)&qa.tw_fwd, (void*)&qa.zh,  (void*)&qa.inv_zh,   (void*)&A.d_jit_tab,
                               (void*)&qa.gen, (void*)&qa.w_n_inv, (void*)&qa.tw_shift, (void*)&qa.perm,
-                              (void*)&qa.lchal, (void*)&qa.expo};
+                              (void*)&qa.lchal, (void*)&qa.expo, (void*)&qa.prep};
             ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, (unsigned)((A.M + 255) / 256), 1, 1, 256, 1, 1, 0, st,
                                                     params, nullptr));
         } else {
@@ -1099,6 +1171,11 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     }
     for (size_t a = 0; a < n_airs; a++) {
         AirPlan& A = pk->airs[a];
+        if (A.prep_w)
+            ZK_TRY(open_matrix(A.d_prep, A.N, (uint32_t)A.prep_w, A.lh, 2, MONTY_ONE, pk->d_opened + 4 * A.opened_prep_off));
+    }
+    for (size_t a = 0; a < n_airs; a++) {
+        AirPlan& A = pk->airs[a];
         if (A.n_int)
             ZK_TRY(open_matrix(A.d_perm, A.N, (uint32_t)A.perm_w, A.lh, 2, MONTY_ONE, pk->d_opened + 4 * A.opened_perm_off));
     }
@@ -1117,17 +1194,20 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     {
         std::vector<uint64_t> num_reduced(hmax + 1, 0);
         std::vector<char> started(hmax + 1, 0);
-        for (int round = 0; round < 3; round++)  // main, permutation, quotient chunks
+        for (int round = 0; round < 4; round++)  // main, preprocessed, permutation, quotient chunks
             for (size_t a = 0; a < n_airs; a++) {
                 AirPlan& A = pk->airs[a];
-                if (round == 1 && !A.n_int) continue;
-                const unsigned n_mats = round == 2 ? nch : 1;
+                if (round == 1 && !A.prep_w) continue;
+                if (round == 2 && !A.n_int) continue;
+                const unsigned n_mats = round == 3 ? nch : 1;
                 for (unsigned j = 0; j < n_mats; j++) {
-                    const uint32_t W = round == 0 ? (uint32_t)A.width : (round == 1 ? (uint32_t)A.perm_w : 4u);
-                    const unsigned n_pts = round == 2 ? 1 : 2;
-                    const uint32_t* mat = round == 0 ? A.d_lde : (round == 1 ? A.d_perm_lde : A.d_qlde + (size_t)j * 4 * A.M);
+                    const uint32_t W = round == 0 ? (uint32_t)A.width : round == 1 ? (uint32_t)A.prep_w : round == 2 ? (uint32_t)A.perm_w : 4u;
+                    const unsigned n_pts = round == 3 ? 1 : 2;
+                    const uint32_t* mat = round == 0 ? A.d_lde : round == 1 ? A.d_prep_lde : round == 2 ? A.d_perm_lde
+                                                                                                        : A.d_qlde + (size_t)j * 4 * A.M;
                     const uint32_t* opened = pk->d_opened + 4 * (round == 0   ? A.opened_main_off
-                                                                 : round == 1 ? A.opened_perm_off
+                                                                 : round == 1 ? A.opened_prep_off
+                                                                 : round == 2 ? A.opened_perm_off
                                                                               : A.opened_quot_off + 4 * (size_t)j);
                     // points of this matrix: zeta (and zeta * w_N)
                     PointsArgs pa;
@@ -1223,11 +1303,20 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     ZK_TRY(transcript_sample_bits(ctx, pk->d_tr, pk->d_indices, pk->params.num_queries, hmax));
     uint32_t* pq = pf + pk->off_queries;
     ZK_TRY(merkle_open_device(ctx, pk->t_main, pk->d_indices, 0, pk->params.num_queries, pq, pk->query_pitch));
+    {
+        size_t off = pk->q_main_words;
+        for (size_t a = 0; a < n_airs; a++) {
+            const AirPlan& A = pk->airs[a];
+            if (!A.prep_w) continue;
+            ZK_TRY(merkle_open_device(ctx, A.t_prep, pk->d_indices, hmax - A.h, pk->params.num_queries, pq + off, pk->query_pitch));
+            off += A.prep_w + 8 * (size_t)A.h;
+        }
+    }
     if (pk->n_lu)
         ZK_TRY(merkle_open_device(ctx, pk->t_perm, pk->d_indices, hmax - pk->h_perm, pk->params.num_queries,
-                                  pq + pk->q_main_words, pk->query_pitch));
+                                  pq + pk->q_main_words + pk->q_prep_words, pk->query_pitch));
     ZK_TRY(merkle_open_device(ctx, pk->t_quot, pk->d_indices, 0, pk->params.num_queries,
-                              pq + pk->q_main_words + pk->q_perm_words, pk->query_pitch));
+                              pq + pk->q_main_words + pk->q_prep_words + pk->q_perm_words, pk->query_pitch));
     if (pk->n_layers) {
         KernelScope ks(ctx, "fri_query");
         hipLaunchKernelGGL(k_fri_query, dim3(pk->params.num_queries, pk->n_layers), dim3(64), 0, st, pk->d_fri_desc,

@@ -24,7 +24,8 @@ namespace zk {
 
 // Kernel parameters (all geometry that is fixed at keygen is baked into the source as constants):
 //   lde, q, pvs, apow, tw_fwd, zh, inv_zh, tab (pointers), gen, w_n_inv, tw_shift (u32),
-//   perm (permutation LDE), lchal (interaction challenges), expo (exposed sum) -- null without interactions
+//   perm (permutation LDE), lchal (interaction challenges), expo (exposed sum) -- null without interactions,
+//   prep (preprocessed LDE) -- null without a preprocessed trace
 struct QuotJitParams {
     const uint32_t* lde;
     uint32_t* q;
@@ -75,6 +76,7 @@ typedef const __attribute__((address_space(1))) uint32_t* gptr;
 // trace cell (column c, this / next row): uniform column base (scalar) + 32-bit per-lane byte offset
 #define LD(c, off) (*(gptr)((const __attribute__((address_space(1))) char*)(ldep + (size_t)(c) * M) + (off)))
 #define LDP(c, off) (*(gptr)((const __attribute__((address_space(1))) char*)(permp + (size_t)(c) * M) + (off)))
+#define LDQ(c, off) (*(gptr)((const __attribute__((address_space(1))) char*)(prepp + (size_t)(c) * M) + (off)))
 #define PV(i) ((cptr)pvs)[i]
 __device__ __forceinline__ uint32_t mred64(uint64_t t) {
     uint32_t m = (uint32_t)t * NEG_MU;
@@ -128,7 +130,7 @@ inline bool quot_jit_classify(const AirProgram& p, std::vector<JitClass>* classe
             const uint32_t op = p.nodes[3 * i], a = p.nodes[3 * i + 1], b = p.nodes[3 * i + 2];
             if (op <= A_TRANS || op >= A_PERM) {
                 local_of[i] = (uint32_t)ent.size();
-                ent.push_back({op, (op == A_VAR || op == A_PERM) ? b : 0u, 0u});
+                ent.push_back({op, (op == A_VAR || op == A_PERM || op == A_PREP) ? b : 0u, 0u});
                 if (op == A_VAR || op == A_CONST || op == A_PUB || op >= A_PERM) {
                     param_entry.push_back((uint32_t)ent.size() - 1);
                     params.push_back(op == A_CONST ? to_monty(a) : a);
@@ -178,7 +180,7 @@ extern "C" __global__ __launch_bounds__(256) void quot_jit(const uint32_t* __res
         const uint32_t* __restrict__ pvs, const uint32_t* __restrict__ apow, const uint32_t* __restrict__ tw_fwd,
         const uint32_t* __restrict__ zh_t, const uint32_t* __restrict__ inv_zh_t, const uint32_t* __restrict__ tab,
         uint32_t gen, uint32_t w_n_inv, uint32_t tw_shift, const uint32_t* __restrict__ perm,
-        const uint32_t* __restrict__ lchal, const uint32_t* __restrict__ expo) {
+        const uint32_t* __restrict__ lchal, const uint32_t* __restrict__ expo, const uint32_t* __restrict__ prep) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= (1u << H)) return;
     const uint32_t i = __brev(r) >> (32 - H);
@@ -196,6 +198,7 @@ extern "C" __global__ __launch_bounds__(256) void quot_jit(const uint32_t* __res
     const uint32_t ro = r << 2, rno = rn << 2;
     const gptr ldep = (gptr)lde;
     const gptr permp = (gptr)perm;
+    const gptr prepp = (gptr)prep;
 )JIT";
     for (size_t c = 0; c < classes.size(); c++) {
         JitClass& C = classes[c];
@@ -209,14 +212,15 @@ extern "C" __global__ __launch_bounds__(256) void quot_jit(const uint32_t* __res
         for (size_t j = 0; j < C.param_entry.size(); j++) pidx[C.param_entry[j]] = (int)j + 1;
         for (size_t e = 0; e < C.entries.size(); e++) {
             const JitEntry& E = C.entries[e];
-            if (E.op == A_VAR || E.op == A_PERM)
-                os << "        const uint32_t e" << e << " = " << (E.op == A_VAR ? "LD" : "LDP") << "(pr[" << pidx[e] << "], "
+            if (E.op == A_VAR || E.op == A_PERM || E.op == A_PREP)
+                os << "        const uint32_t e" << e << " = " << (E.op == A_VAR ? "LD" : E.op == A_PERM ? "LDP" : "LDQ") << "(pr[" << pidx[e] << "], "
                    << (E.a ? "rno" : "ro") << ");\n";
         }
         for (size_t e = 0; e < C.entries.size(); e++) {
             const JitEntry& E = C.entries[e];
             switch (E.op) {
                 case A_VAR:
+                case A_PREP:
                 case A_PERM: break;
                 case A_CHAL: os << "        const uint32_t e" << e << " = ((cptr)lchal)[pr[" << pidx[e] << "]];\n"; break;
                 case A_EXPOSED: os << "        const uint32_t e" << e << " = ((cptr)expo)[pr[" << pidx[e] << "]];\n"; break;

@@ -112,7 +112,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         if (proof[i] >= P) return ZKHIP_ERR_VERIFY;
     std::vector<AirProgram> pg(n_airs);
     unsigned hmax = 0;
-    size_t n_lu = 0;
+    size_t n_lu = 0, n_prep = 0;
     for (size_t a = 0; a < n_airs; a++) {
         if (parse_air(airs[a].program, airs[a].program_len, airs[a].width, &pg[a], nullptr) != 0) return ZKHIP_ERR_INVALID;
         if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height < 1) return ZKHIP_ERR_INVALID;
@@ -120,6 +120,12 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         if (airs[a].n_pvs && (!pvs || !pvs[a])) return ZKHIP_ERR_INVALID;
         hmax = std::max(hmax, airs[a].log_height + b);
         if (!pg[a].ints.empty()) n_lu++;
+        if (pg[a].prep_width) {
+            if (!airs[a].prep_commit) return ZKHIP_ERR_INVALID;  // the verifying key must hold the commitment
+            for (int k = 0; k < 8; k++)
+                if (airs[a].prep_commit[k] >= P) return ZKHIP_ERR_INVALID;
+            n_prep++;
+        }
     }
     // committed matrices in opening order: main (every AIR), permutation (AIRs with interactions), quotient chunks
     struct CMat {
@@ -131,10 +137,12 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     std::vector<CMat> cm;
     for (size_t a = 0; a < n_airs; a++) cm.push_back({airs[a].log_height, airs[a].log_height + b, airs[a].width, 2, 0});
     for (size_t a = 0; a < n_airs; a++)
+        if (pg[a].prep_width) cm.push_back({airs[a].log_height, airs[a].log_height + b, pg[a].prep_width, 2, 0});
+    for (size_t a = 0; a < n_airs; a++)
         if (!pg[a].ints.empty()) cm.push_back({airs[a].log_height, airs[a].log_height + b, pg[a].perm_width(), 2, 0});
     for (size_t a = 0; a < n_airs; a++)
         for (unsigned j = 0; j < nch; j++) cm.push_back({airs[a].log_height, airs[a].log_height + b, 4, 1, 0});
-    const size_t cm_perm0 = n_airs, cm_quot0 = n_airs + n_lu;
+    const size_t cm_prep0 = n_airs, cm_perm0 = n_airs + n_prep, cm_quot0 = n_airs + n_prep + n_lu;
     size_t n_open = 0;
     for (auto& m : cm) {
         m.open_off = n_open;
@@ -144,7 +152,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     size_t r = 0;
     const size_t lu_words = n_lu ? 8 + 4 * n_lu : 0;
     if (n_words < 4 + 16 + lu_words + 4 * n_open + 9 * (size_t)n_layers + 5) return ZKHIP_ERR_VERIFY;
-    if (proof[0] != PROOF_MAGIC + (n_lu ? 1u : 0u) || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers)
+    if (proof[0] != PROOF_MAGIC + (n_lu ? 1u : 0u) + (n_prep ? 2u : 0u) || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers)
         return ZKHIP_ERR_VERIFY;
     r = 4;
     const uint32_t* root_main = proof + r;
@@ -183,6 +191,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
             uint32_t meta[3] = {airs[a].log_height, (uint32_t)airs[a].width, (uint32_t)airs[a].n_pvs};
             ch.observe_canon(meta, 3);
             for (int i = 0; i < 8; i++) ch.observe(dg[i]);
+            if (pg[a].prep_width) ch.observe_canon(airs[a].prep_commit, 8);
             for (size_t i = 0; i < airs[a].n_pvs; i++) {
                 if (pvs[a][i] >= P) return ZKHIP_ERR_INVALID;
                 ch.observe(to_monty(pvs[a][i]));
@@ -214,7 +223,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     const uint32_t gen = to_monty(FIELD_GEN_CANON);
 
     // ---- constraints at zeta ----
-    size_t k_lu = 0;
+    size_t k_lu = 0, k_prep = 0;
     for (size_t a = 0; a < n_airs; a++) {
         const unsigned lh = airs[a].log_height, h = lh + b;
         const size_t W = airs[a].width;
@@ -235,6 +244,12 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         const Ext* next = local + W;
         const Ext *plocal = nullptr, *pnext = nullptr;
         const uint32_t* expo = nullptr;
+        const Ext *qlocal = nullptr, *qnext = nullptr;
+        if (pg[a].prep_width) {
+            qlocal = &opened[cm[cm_prep0 + k_prep].open_off];
+            qnext = qlocal + pg[a].prep_width;
+            k_prep++;
+        }
         if (!pg[a].ints.empty()) {
             plocal = &opened[cm[cm_perm0 + k_lu].open_off];
             pnext = plocal + pg[a].perm_width();
@@ -256,6 +271,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
                 case A_NEG: vals[i] = ext_neg(vals[x]); break;
                 case A_PERM: vals[i] = y ? pnext[x] : plocal[x]; break;
                 case A_CHAL: vals[i] = ext_from_base(chal[x]); break;
+                case A_PREP: vals[i] = y ? qnext[x] : qlocal[x]; break;
                 default: vals[i] = ext_from_base(to_monty(expo[x])); break;
             }
         }
@@ -325,6 +341,11 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         batches.push_back(bt);
     };
     add_batch(0, n_airs, root_main);
+    {
+        size_t k = 0;
+        for (size_t a = 0; a < n_airs; a++)
+            if (pg[a].prep_width) add_batch(cm_prep0 + k++, 1, airs[a].prep_commit);  // each preprocessed trace has its own tree
+    }
     if (n_lu) add_batch(cm_perm0, n_lu, root_perm);
     add_batch(cm_quot0, n_airs * nch, root_quot);
     std::vector<Ext> roq(hmax + 1);
