@@ -25,7 +25,8 @@
  *           commitment is observed in the preamble and opened like the main trace)
  *   n_constraints x node index (asserted zero on every row)
  *   optional: [0x50504B5A, prep_width]
- *   optional: [0x554C4B5A, n_int, n_int x {bus, sign, count leaf[3], n_fields, field leaf[3]...}]
+ *   optional: [0x554C4B5A, n_int, n_int x {bus, sign, count node, n_fields, field node...}]
+ *             (count / fields = nodes that are expressions of the current row only)
  * LogUp phase: challenges gamma, beta (extension); chal vector = gamma, beta^1..beta^8 as
  * 36 base coordinates; interaction j contributes phi_j = (+/-)count / (gamma + bus + 1 +
  * sum_i beta^(i+1) f_i); the permutation matrix holds phi_j (4 base columns each) and the
@@ -82,9 +83,9 @@ static void ext_pow(const ext_t a, uint64_t e, ext_t o) {
 /* ---------------------------------------------------------------- program */
 typedef struct {
     uint32_t bus, sign;
-    uint32_t count[3];
+    uint32_t count; /* node index */
     uint32_t n_fields;
-    uint32_t fields[MAX_FIELDS][3];
+    uint32_t fields[MAX_FIELDS]; /* node indices */
 } interaction;
 
 typedef struct {
@@ -94,15 +95,8 @@ typedef struct {
     interaction *ints;
     size_t perm_width; /* 4 * (n_int + 1), or 0 */
     size_t prep_width; /* preprocessed columns, or 0 */
+    unsigned char *row_local; /* per node: reachable from an interaction operand (evaluated per trace row) */
 } program;
-
-static int leaf_ok(const uint32_t *l, size_t width, uint32_t n_pvs, size_t prep_width) {
-    if (l[0] == OP_VAR) return l[1] < width && l[2] == 0;
-    if (l[0] == OP_PREP) return l[1] < prep_width && l[2] == 0;
-    if (l[0] == OP_PUB) return l[1] < n_pvs;
-    if (l[0] == OP_CONST) return l[1] < ORA_P;
-    return 0;
-}
 
 static int parse_program(const uint32_t *w, size_t len, size_t width, program *p) {
     memset(p, 0, sizeof *p);
@@ -129,17 +123,14 @@ static int parse_program(const uint32_t *w, size_t len, size_t width, program *p
         p->ints = (interaction *)calloc(p->n_int, sizeof(interaction));
         for (uint32_t j = 0; j < p->n_int; j++) {
             interaction *it = &p->ints[j];
-            if (q + 6 > len) return -1;
-            it->bus = w[q], it->sign = w[q + 1];
-            memcpy(it->count, w + q + 2, 12);
-            it->n_fields = w[q + 5];
-            q += 6;
-            if (it->sign > 1 || it->bus >= ORA_P - 1 || it->n_fields < 1 || it->n_fields > MAX_FIELDS || q + 3 * (size_t)it->n_fields > len) return -1;
-            if (!leaf_ok(it->count, width, p->n_pvs, p->prep_width)) return -1;
+            if (q + 4 > len) return -1;
+            it->bus = w[q], it->sign = w[q + 1], it->count = w[q + 2], it->n_fields = w[q + 3];
+            q += 4;
+            if (it->sign > 1 || it->bus >= ORA_P - 1 || it->n_fields < 1 || it->n_fields > MAX_FIELDS || q + it->n_fields > len) return -1;
+            if (it->count >= p->n_nodes) return -1;
             for (uint32_t i = 0; i < it->n_fields; i++) {
-                memcpy(it->fields[i], w + q, 12);
-                if (!leaf_ok(it->fields[i], width, p->n_pvs, p->prep_width)) return -1;
-                q += 3;
+                it->fields[i] = w[q++];
+                if (it->fields[i] >= p->n_nodes) return -1;
             }
         }
         if (q != len) return -1;
@@ -163,9 +154,28 @@ static int parse_program(const uint32_t *w, size_t len, size_t width, program *p
     }
     for (uint32_t i = 0; i < p->n_cons; i++)
         if (p->cons[i] >= p->n_nodes) return -1;
+    if (p->n_int) {
+        /* operands must be expressions of the current row: mark what they reach, reject anything else */
+        p->row_local = (unsigned char *)calloc(p->n_nodes, 1);
+        for (uint32_t j = 0; j < p->n_int; j++) {
+            p->row_local[p->ints[j].count] = 1;
+            for (uint32_t i = 0; i < p->ints[j].n_fields; i++) p->row_local[p->ints[j].fields[i]] = 1;
+        }
+        for (uint32_t i = p->n_nodes; i-- > 0;) {
+            if (!p->row_local[i]) continue;
+            uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
+            switch (op) {
+            case OP_VAR: case OP_PREP: if (b != 0) return -1; break;
+            case OP_PUB: case OP_CONST: break;
+            case OP_ADD: case OP_SUB: case OP_MUL: p->row_local[a] = p->row_local[b] = 1; break;
+            case OP_NEG: p->row_local[a] = 1; break;
+            default: return -1;
+            }
+        }
+    }
     return 0;
 }
-static void free_program(program *p) { free(p->ints); }
+static void free_program(program *p) { free(p->ints), free(p->row_local); }
 
 typedef struct {
     const uint32_t *local, *next, *pvs, *perm_local, *perm_next, *chal, *exposed;
@@ -288,12 +298,23 @@ static void selectors_ext(unsigned lh, const ext_t x, ext_t is_first, ext_t is_l
     ora_ext_inv(zh, inv_zh);
 }
 
-static uint32_t leaf_value(const uint32_t *l, const uint32_t *trace, size_t N, size_t row, const uint32_t *pvs,
-                           const uint32_t *prep) {
-    if (l[0] == OP_VAR) return trace[(size_t)l[1] * N + row];
-    if (l[0] == OP_PREP) return prep[(size_t)l[1] * N + row];
-    if (l[0] == OP_PUB) return pvs[l[1]];
-    return l[1];
+/* values of the row-local nodes (interaction operands) on one trace row */
+static void eval_row_local(const program *p, const uint32_t *trace, const uint32_t *prep, const uint32_t *pvs, size_t N,
+                           size_t row, uint32_t *vals) {
+    for (uint32_t i = 0; i < p->n_nodes; i++) {
+        if (!p->row_local[i]) continue;
+        uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
+        switch (op) {
+        case OP_VAR: vals[i] = trace[(size_t)a * N + row]; break;
+        case OP_PREP: vals[i] = prep[(size_t)a * N + row]; break;
+        case OP_PUB: vals[i] = pvs[a]; break;
+        case OP_CONST: vals[i] = a; break;
+        case OP_ADD: vals[i] = ora_add(vals[a], vals[b]); break;
+        case OP_SUB: vals[i] = ora_sub(vals[a], vals[b]); break;
+        case OP_MUL: vals[i] = ora_mul(vals[a], vals[b]); break;
+        default: vals[i] = ora_sub(0, vals[a]); break;
+        }
+    }
 }
 
 /* ---------------------------------------------------------------- prover */
@@ -402,8 +423,10 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
             const size_t N = (size_t)1 << st[a].lh, M = N << b, PW = pg->perm_width;
             st[a].perm = (uint32_t *)calloc(PW * N, sizeof(uint32_t));
             ext_t run = {0, 0, 0, 0};
+            uint32_t *rv = (uint32_t *)malloc(pg->n_nodes * sizeof(uint32_t));
             for (size_t r = 0; r < N; r++) {
                 ext_t rowsum = {0, 0, 0, 0};
+                eval_row_local(pg, airs[a].trace, airs[a].prep, airs[a].pvs, N, r, rv);
                 for (uint32_t j = 0; j < pg->n_int; j++) {
                     const interaction *it = &pg->ints[j];
                     ext_t den, inv, phi;
@@ -411,11 +434,11 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
                     den[0] = ora_add(den[0], it->bus + 1);
                     for (uint32_t i = 0; i < it->n_fields; i++) {
                         ext_t t;
-                        ext_scale(chal + 4 * (i + 1), leaf_value(it->fields[i], airs[a].trace, N, r, airs[a].pvs, airs[a].prep), t);
+                        ext_scale(chal + 4 * (i + 1), rv[it->fields[i]], t);
                         ext_add(den, t, den);
                     }
                     ora_ext_inv(den, inv);
-                    uint32_t cnt = leaf_value(it->count, airs[a].trace, N, r, airs[a].pvs, airs[a].prep);
+                    uint32_t cnt = rv[it->count];
                     if (it->sign) cnt = ora_sub(0, cnt);
                     ext_scale(inv, cnt, phi);
                     for (int q = 0; q < 4; q++) st[a].perm[(4 * (size_t)j + q) * N + r] = phi[q];
@@ -424,6 +447,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
                 ext_add(run, rowsum, run);
                 for (int q = 0; q < 4; q++) st[a].perm[(4 * (size_t)pg->n_int + q) * N + r] = run[q];
             }
+            free(rv);
             memcpy(st[a].exposed, run, 16);
             st[a].perm_lde = (uint32_t *)malloc(M * PW * sizeof(uint32_t));
             ora_coset_lde_batch(st[a].perm, N, st[a].perm_lde, M, st[a].lh, b, PW, GEN, 1);

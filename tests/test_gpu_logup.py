@@ -28,6 +28,10 @@ def _mix(log_n, seed=3):
     return dict(program=air.bus_mix_air().program(), log_height=log_n, width=6, n_pvs=1, trace=tr, pvs=pv)
 
 
+def _limb(log_n, seed=3):
+    return dict(program=air.limb_air().program(), log_height=log_n, width=4, n_pvs=0, trace=air.limb_trace(log_n, seed), pvs=NOPV)
+
+
 def _prove_gpu(zk, params, airs):
     pk = z.ProvingKey(zk, params, airs)
     d_traces = [zk.upload(a["trace"].reshape(-1)) for a in airs]
@@ -46,6 +50,8 @@ def _cases():
         "mix_only": [_mix(5)],
         "mix_and_lookup": [_mix(7), s2, _fib(4), t2],
         "mix_min_height": [_mix(1)],
+        "compound_messages": [_limb(6), s, t],
+        "compound_and_mix": [_mix(4), _limb(8, seed=5), _fib(6)],
     }
 
 

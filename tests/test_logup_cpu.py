@@ -48,6 +48,37 @@ def test_logup_proofs_verify_and_bind(ora, with_fib):
     assert z.verify(PARAMS, airs, pvs, proof[:-1].tobytes()) != 0
 
 
+def test_logup_compound_messages(ora):
+    """Bus messages that are expressions of the row (lo + 256*hi, is_valid * value, gated multiplicities)."""
+    b = air.limb_air()
+    tr = air.limb_trace(5, seed=3)
+    prog = b.program()
+    assert b.max_degree() == 3
+    assert air.check_trace(prog, tr, NOPV) == []
+    airs = lookup_case() + [dict(program=prog, log_height=5, width=4, n_pvs=0, trace=tr, pvs=NOPV)]
+    pvs = [a["pvs"] for a in airs]
+    proof = ora.stark_prove(PARAMS, airs)
+    assert ora.stark_verify(PARAMS, airs, proof) == 0
+    assert z.verify(PARAMS, airs, pvs, proof.tobytes()) == 0
+    # a wrong limb on a valid row: the AIR's own constraint and the bus both break
+    bad = [dict(a) for a in airs]
+    t2 = tr.copy()
+    row = int(np.nonzero(t2[3])[0][0])
+    t2[0, row] = (int(t2[0, row]) + 1) % 256
+    bad[-1]["trace"] = t2
+    proof = ora.stark_prove(PARAMS, bad)
+    assert ora.stark_verify(PARAMS, bad, proof) != 0
+    assert z.verify(PARAMS, bad, pvs, proof.tobytes()) != 0
+    # operands that look at the next row or at selectors are refused by both parsers
+    bb = air.AirBuilder(2, 0)
+    bb.interactions = [(1, 0, bb.const(1), [bb.var(0, 1)])]
+    prog_bad = bb.program()
+    a_bad = [dict(program=prog_bad, log_height=3, width=2, n_pvs=0, trace=np.zeros((2, 8), np.uint32), pvs=NOPV)]
+    with pytest.raises(RuntimeError):
+        ora.stark_prove(PARAMS, a_bad)
+    assert z.verify(PARAMS, a_bad, [NOPV], proof.tobytes()) != 0
+
+
 def test_logup_unbalanced_bus_is_rejected(ora):
     airs = lookup_case()
     pvs = [a["pvs"] for a in airs]

@@ -111,16 +111,38 @@ class AirBuilder:
     def exposed(self, i):
         return self._node(OP_EXPOSED, i, 0, 0)
 
+    def _row_local(self, idx):
+        """True if node idx is an expression of the CURRENT row only (main / preprocessed cells with rotation 0,
+        public values, constants, + - * neg): what a bus message may be built from."""
+        stack, seen = [idx], set()
+        while stack:
+            i = stack.pop()
+            if i in seen:
+                continue
+            seen.add(i)
+            op, a, b = self.nodes[i]
+            if op in (OP_VAR, OP_PREP):
+                if b != 0:
+                    return False
+            elif op in (OP_PUB, OP_CONST):
+                pass
+            elif op in (OP_ADD, OP_SUB, OP_MUL):
+                stack += [a, b]
+            elif op == OP_NEG:
+                stack.append(a)
+            else:
+                return False
+        return True
+
     def push_interaction(self, bus, fields, count, kind):
-        """fields / count: leaves only (var of the current row, public value or constant), like most
-        OpenVM chips' buses.  kind 'send' adds count/denominator, 'receive' subtracts it."""
+        """fields / count: expressions of the current row (e.g. `b.var(0) + 256 * b.var(1)`, `is_valid * x`),
+        like the bus messages of OpenVM chips.  kind 'send' adds count/denominator, 'receive' subtracts it.
+        Degree budget: 1 + deg(field) and deg(count) must stay <= 2^log_blowup + 1."""
         assert kind in ("send", "receive") and 0 <= bus < (1 << 20) and 1 <= len(fields) <= LOGUP_MAX_FIELDS
         fields = [f if isinstance(f, Expr) else self.const(f) for f in fields]
         count = count if isinstance(count, Expr) else self.const(count)
         for e in fields + [count]:
-            op, a, b = self.nodes[e.idx]
-            assert op in (OP_VAR, OP_PUB, OP_CONST, OP_PREP) and (op not in (OP_VAR, OP_PREP) or b == 0), \
-                "interaction operands must be leaves"
+            assert self._row_local(e.idx), "interaction operands must be expressions of the current row"
         if not hasattr(self, "interactions"):
             self.interactions = []
         self.interactions.append((bus, 0 if kind == "send" else 1, count, fields))
@@ -202,12 +224,10 @@ class AirBuilder:
             words += [PREP_MAGIC, self.prep_width]
         ints = getattr(self, "interactions", [])
         if ints:
-            # trailing section: [LOGUP_MAGIC, n_int, {bus, sign, count leaf (3 words), n_fields, field leaves (3 words each)}]
+            # trailing section: [LOGUP_MAGIC, n_int, {bus, sign, count node, n_fields, field nodes}]
             words += [LOGUP_MAGIC, len(ints)]
             for bus, sign, count, fields in ints:
-                words += [bus, sign] + list(self.nodes[count.idx]) + [len(fields)]
-                for f in fields:
-                    words += list(self.nodes[f.idx])
+                words += [bus, sign, count.idx, len(fields)] + [f.idx for f in fields]
         return np.array(words, dtype=np.uint32)
 
 
@@ -406,6 +426,28 @@ def lookup_traces(log_n_sender, log_n_table, seed=0, sender_width=3):
     table[0], table[1] = keys, vals
     table[2] = np.bincount(pick, minlength=nt)
     return sender, table
+
+
+def limb_air(bus=13):
+    """Compound bus messages: the AIR sends the 16-bit value lo + 256*hi (two byte columns) gated by a boolean
+    `is_valid` column, and receives the recomposed value from a third column -- the shape of OpenVM's
+    byte-decomposition chips.  Columns: lo, hi, value, is_valid."""
+    b = AirBuilder(4, 0)
+    lo, hi, val, ok = b.var(0), b.var(1), b.var(2), b.var(3)
+    b.assert_zero(ok * (ok - 1))
+    b.assert_zero(ok * (lo + hi * 256 - val))
+    b.push_interaction(bus, [lo + hi * 256, ok * val], ok, "send")
+    b.push_interaction(bus, [val, val * ok], ok * 1, "receive")
+    return b
+
+
+def limb_trace(log_n, seed=0):
+    rng = np.random.default_rng(seed)
+    n = 1 << log_n
+    lo, hi = rng.integers(0, 256, n), rng.integers(0, 256, n)
+    ok = rng.integers(0, 2, n)
+    val = np.where(ok == 1, lo + 256 * hi, rng.integers(0, P, n))
+    return np.stack([lo, hi, val, ok]).astype(np.uint32)
 
 
 def bus_mix_air(width=6):

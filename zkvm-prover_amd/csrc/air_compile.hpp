@@ -33,11 +33,12 @@ constexpr unsigned N_CHAL = 4 * (1 + LOGUP_MAX_FIELDS);  // gamma, beta^1..beta^
 enum AirOp : uint32_t { A_VAR, A_PUB, A_CONST, A_FIRST, A_LAST, A_TRANS, A_ADD, A_SUB, A_MUL, A_NEG, A_PERM, A_CHAL, A_EXPOSED, A_PREP };
 
 // one bus interaction: phi = (sign ? -count : count) / (gamma + bus + 1 + sum_i beta^(i+1) * field_i);
-// count and the fields are leaves (VAR of the current row, PUB or CONST), 3 words each as in the node table
+// count and the fields are node indices of expressions of the CURRENT row only (main / preprocessed cells with
+// rotation 0, public values, constants, + - * neg), like the bus messages of OpenVM chips
 struct Interaction {
     uint32_t bus = 0, sign = 0, n_fields = 0;
-    uint32_t count[3] = {0, 0, 0};
-    uint32_t fields[LOGUP_MAX_FIELDS][3] = {};
+    uint32_t count = 0;
+    uint32_t fields[LOGUP_MAX_FIELDS] = {};
 };
 
 struct AirProgram {
@@ -77,25 +78,18 @@ inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p,
         const uint32_t n_int = w[q + 1];
         q += 2;
         if (n_int == 0 || n_int > 4096) return fail("bad interaction count");
-        auto leaf_ok = [&](const uint32_t* l) {
-            if (l[0] == A_VAR) return l[1] < width && l[2] == 0;
-            if (l[0] == A_PREP) return l[1] < p->prep_width && l[2] == 0;
-            if (l[0] == A_PUB) return l[1] < p->n_pvs;
-            return l[0] == A_CONST && l[1] < P;
-        };
         p->ints.resize(n_int);
         for (uint32_t j = 0; j < n_int; j++) {
             Interaction& it = p->ints[j];
-            if (q + 6 > len) return fail("truncated interaction");
-            it.bus = w[q], it.sign = w[q + 1], it.n_fields = w[q + 5];
-            for (int k = 0; k < 3; k++) it.count[k] = w[q + 2 + k];
-            q += 6;
-            if (it.sign > 1 || it.bus >= P - 1 || it.n_fields < 1 || it.n_fields > LOGUP_MAX_FIELDS || q + 3 * (size_t)it.n_fields > len)
+            if (q + 4 > len) return fail("truncated interaction");
+            it.bus = w[q], it.sign = w[q + 1], it.count = w[q + 2], it.n_fields = w[q + 3];
+            q += 4;
+            if (it.sign > 1 || it.bus >= P - 1 || it.n_fields < 1 || it.n_fields > LOGUP_MAX_FIELDS || q + it.n_fields > len)
                 return fail("bad interaction");
-            if (!leaf_ok(it.count)) return fail("interaction count is not a leaf");
-            for (uint32_t i = 0; i < it.n_fields; i++, q += 3) {
-                for (int k = 0; k < 3; k++) it.fields[i][k] = w[q + k];
-                if (!leaf_ok(it.fields[i])) return fail("interaction field is not a leaf");
+            if (it.count >= p->n_nodes) return fail("interaction count node out of range");
+            for (uint32_t i = 0; i < it.n_fields; i++) {
+                it.fields[i] = w[q++];
+                if (it.fields[i] >= p->n_nodes) return fail("interaction field node out of range");
             }
         }
         if (q != len) return fail("AIR program length mismatch");
@@ -152,6 +146,37 @@ inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p,
                 return fail("unknown AIR op");
         }
     }
+    if (!p->ints.empty()) {
+        // interaction operands must be expressions of the current row
+        std::vector<char> mark(p->n_nodes, 0);
+        for (const Interaction& it : p->ints) {
+            mark[it.count] = 1;
+            for (uint32_t i = 0; i < it.n_fields; i++) mark[it.fields[i]] = 1;
+        }
+        for (uint32_t i = p->n_nodes; i-- > 0;) {
+            if (!mark[i]) continue;
+            const uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
+            switch (op) {
+                case A_VAR:
+                case A_PREP:
+                    if (b != 0) return fail("interaction operand reads the next row");
+                    break;
+                case A_PUB:
+                case A_CONST:
+                    break;
+                case A_ADD:
+                case A_SUB:
+                case A_MUL:
+                    mark[a] = mark[b] = 1;
+                    break;
+                case A_NEG:
+                    mark[a] = 1;
+                    break;
+                default:
+                    return fail("interaction operand is not an expression of the current row");
+            }
+        }
+    }
     p->max_degree = 0;
     for (uint32_t k = 0; k < p->n_cons; k++) {
         if (p->cons[k] >= p->n_nodes) return fail("constraint index out of range");
@@ -174,12 +199,16 @@ struct CompiledAir {
     unsigned n_slots = 0;
 };
 
-inline int compile_air(const AirProgram& p, CompiledAir* out, std::string* err) {
+// `roots` (optional): compile these nodes instead of the constraints; the Q_ASSERT of roots[k] carries index k
+// (used for the per-interaction operand programs of the LogUp phase)
+inline int compile_air(const AirProgram& p, CompiledAir* out, std::string* err, const std::vector<uint32_t>* roots = nullptr) {
     const uint32_t n = p.n_nodes;
+    const uint32_t n_roots = roots ? (uint32_t)roots->size() : p.n_cons;
+    auto root_at = [&](uint32_t k) { return roots ? (*roots)[k] : p.cons[k]; };
     auto is_leaf = [&](uint32_t i) { return p.nodes[3 * i] <= A_TRANS || p.nodes[3 * i] >= A_PERM; };
     // reachability from the constraints
     std::vector<char> reach(n, 0);
-    for (uint32_t k = 0; k < p.n_cons; k++) reach[p.cons[k]] = 1;
+    for (uint32_t k = 0; k < n_roots; k++) reach[root_at(k)] = 1;
     for (uint32_t i = n; i-- > 0;) {
         if (!reach[i] || is_leaf(i)) continue;
         uint32_t op = p.nodes[3 * i];
@@ -188,7 +217,7 @@ inline int compile_air(const AirProgram& p, CompiledAir* out, std::string* err) 
     }
     // constraints attached to each node
     std::vector<std::vector<uint32_t>> cons_of(n);
-    for (uint32_t k = 0; k < p.n_cons; k++) cons_of[p.cons[k]].push_back(k);
+    for (uint32_t k = 0; k < n_roots; k++) cons_of[root_at(k)].push_back(k);
     // event order: node i (if interior & reachable) then its ASSERTs.  last_use in event numbering.
     std::vector<uint32_t> last_use(n, 0);
     {

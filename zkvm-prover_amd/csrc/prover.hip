@@ -153,15 +153,19 @@ __global__ void k_logup_chal(const uint32_t* gb, uint32_t* lchal) {
     }
 }
 
-// interaction table on the device: LU_STRIDE words per interaction
-//   [0] bus+1 (Montgomery)  [1] sign  [2] count kind  [3] count value  [4] n_fields  [5+2i] kind_i  [6+2i] value_i
-// kind 0 = trace column (value = column), 1 = public value (index), 2 = constant (Montgomery), 3 = preprocessed column
-constexpr unsigned LU_STRIDE = 5 + 2 * LOGUP_MAX_FIELDS;
+// Interaction operands are expressions of the current row: each interaction has a small slot program (the
+// lowering of air_compile.hpp with the operands as roots: fields first, count last).  Descriptor table on the
+// device, LU_STRIDE words per interaction:
+//   [0] first instruction  [1] n_instr  [2] bus+1 (Montgomery)  [3] sign  [4] n_fields  [5] first constant
+constexpr unsigned LU_STRIDE = 6;
+constexpr unsigned LU_BS = 256;
 struct LogupArgs {
     const uint32_t* trace;  // column-major, stride N, Montgomery
     const uint32_t* prep;   // preprocessed trace, same layout (or null)
     const uint32_t* pvs;
-    const uint32_t* tab;
+    const uint32_t* tab;     // descriptors
+    const uint32_t* code;    // 3 words per instruction, all interactions back to back
+    const uint32_t* consts;  // Montgomery
     const uint32_t* lchal;
     uint32_t* den;   // n_int x N extension elements, [j][r]
     uint32_t* num;   // n_int x N signed multiplicities
@@ -171,25 +175,46 @@ struct LogupArgs {
     size_t N;
     uint32_t n_int;
 };
-__device__ __forceinline__ uint32_t lu_leaf(const LogupArgs& a, uint32_t kind, uint32_t val, size_t r) {
-    return kind == 0 ? a.trace[(size_t)val * a.N + r] : (kind == 1 ? a.pvs[val] : (kind == 3 ? a.prep[(size_t)val * a.N + r] : val));
-}
 // grid (rows / 256, n_int): denominator gamma + bus + 1 + sum_i beta^(i+1) f_i and numerator +-count of one row
-__global__ __launch_bounds__(256) void k_logup_denoms(LogupArgs a) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(LU_BS) void k_logup_denoms(LogupArgs a) {
+    extern __shared__ uint32_t slots[];
+    const unsigned tid = threadIdx.x;
+    const size_t r = (size_t)blockIdx.x * LU_BS + tid;
     if (r >= a.N) return;
     const uint32_t j = blockIdx.y;
     const uint32_t* t = a.tab + (size_t)j * LU_STRIDE;
+    const uint32_t* code = a.code + 3 * (size_t)t[0];
+    const uint32_t n_instr = t[1], n_fields = t[4];
+    const uint32_t* consts = a.consts + t[5];
     Ext den = ld_ext(a.lchal);
-    den.c[0] = madd(den.c[0], t[0]);
-    const uint32_t nf = t[4];
-    for (uint32_t i = 0; i < nf; i++) {
-        const uint32_t f = lu_leaf(a, t[5 + 2 * i], t[6 + 2 * i], r);
-        den = ext_add(den, ext_mul_base(ld_ext(a.lchal + 4 * (i + 1)), f));
+    den.c[0] = madd(den.c[0], t[2]);
+    uint32_t num = 0;
+    auto fetch = [&](uint32_t w) -> uint32_t {
+        const uint32_t kind = w >> 28, idx = w & 0x07ffffffu;
+        switch (kind) {
+            case K_SLOT: return slots[idx * LU_BS + tid];
+            case K_VAR: return a.trace[(size_t)idx * a.N + r];
+            case K_PREP: return a.prep[(size_t)idx * a.N + r];
+            case K_PUB: return a.pvs[idx];
+            default: return consts[idx];
+        }
+    };
+    for (uint32_t pc = 0; pc < n_instr; pc++) {
+        const uint32_t w0 = code[3 * pc], wa = code[3 * pc + 1], wb = code[3 * pc + 2];
+        const uint32_t op = w0 & 0xffu, dst = w0 >> 8;
+        const uint32_t va = fetch(wa);
+        if (op == Q_ASSERT) {
+            if (dst < n_fields) den = ext_add(den, ext_mul_base(ld_ext(a.lchal + 4 * (dst + 1)), va));
+            else num = t[3] ? mneg(va) : va;
+        } else if (op == Q_NEG) {
+            slots[dst * LU_BS + tid] = mneg(va);
+        } else {
+            const uint32_t vb = fetch(wb);
+            slots[dst * LU_BS + tid] = op == Q_ADD ? madd(va, vb) : (op == Q_SUB ? msub(va, vb) : mmul(va, vb));
+        }
     }
     reinterpret_cast<uint4*>(a.den)[(size_t)j * a.N + r] = make_uint4(den.c[0], den.c[1], den.c[2], den.c[3]);
-    const uint32_t cnt = lu_leaf(a, t[2], t[3], r);
-    a.num[(size_t)j * a.N + r] = t[1] ? mneg(cnt) : cnt;
+    a.num[(size_t)j * a.N + r] = num;
 }
 // after the batch inversion den holds phi_j[r]: write the phi columns and the row sums
 __global__ __launch_bounds__(256) void k_logup_rows(LogupArgs a) {
@@ -516,7 +541,10 @@ struct AirPlan {
     // LogUp phase (AIRs with bus interactions)
     uint32_t n_int = 0;
     size_t perm_w = 0, lu_index = 0;   // width of the permutation matrix; rank among the AIRs with interactions
-    uint32_t* d_lu_tab = nullptr;      // interaction table (LU_STRIDE words each)
+    uint32_t* d_lu_tab = nullptr;      // interaction descriptors (LU_STRIDE words each)
+    uint32_t* d_lu_code = nullptr;     // operand programs of all interactions
+    uint32_t* d_lu_consts = nullptr;
+    unsigned lu_slots = 1;             // LDS slots the widest operand program needs
     uint32_t* d_lu_den = nullptr;      // n_int x N ext
     uint32_t* d_lu_num = nullptr;      // n_int x N
     uint32_t* d_lu_sums = nullptr;     // N ext
@@ -741,10 +769,14 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     const unsigned nch = pk->nch;
     struct AirOff {
         size_t code, consts, zh, inv_zh, pvs, lde, q, qnat, qlde, apow_q;
-        size_t lu_tab, lu_den, lu_num, lu_sums, perm, perm_lde, prep, prep_lde, dig_prep;
+        size_t lu_tab, lu_code, lu_consts, lu_den, lu_num, lu_sums, perm, perm_lde, prep, prep_lde, dig_prep;
     };
     std::vector<AirOff> ao(n_airs);
     std::vector<CompiledAir> comp(n_airs);
+    struct LuHost {
+        std::vector<uint32_t> tab, code, consts;
+    };
+    std::vector<LuHost> lu(n_airs);
     for (size_t a = 0; a < n_airs; a++) {
         AirPlan& A = pk->airs[a];
         if (compile_air(A.prog, &comp[a], &err) != 0) {
@@ -786,6 +818,25 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             ao[a].dig_prep = bp.take(merkle_digest_count(A.h) * 32);
         }
         if (A.n_int) {
+            // one operand program per interaction: roots = fields, then count
+            for (uint32_t j = 0; j < A.n_int; j++) {
+                const Interaction& it = A.prog.ints[j];
+                std::vector<uint32_t> roots(it.fields, it.fields + it.n_fields);
+                roots.push_back(it.count);
+                CompiledAir cj;
+                if (compile_air(A.prog, &cj, &err, &roots) != 0) {
+                    zkhip_pk_destroy(ctx, pk);
+                    return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + " interaction " + std::to_string(j) + ": " + err);
+                }
+                const uint32_t desc[LU_STRIDE] = {(uint32_t)(lu[a].code.size() / 3), (uint32_t)(cj.code.size() / 3), to_monty(it.bus + 1),
+                                                  it.sign, it.n_fields, (uint32_t)lu[a].consts.size()};
+                lu[a].tab.insert(lu[a].tab.end(), desc, desc + LU_STRIDE);
+                lu[a].code.insert(lu[a].code.end(), cj.code.begin(), cj.code.end());
+                lu[a].consts.insert(lu[a].consts.end(), cj.consts.begin(), cj.consts.end());
+                A.lu_slots = std::max(A.lu_slots, cj.n_slots);
+            }
+            ao[a].lu_code = bp.take(lu[a].code.size() * 4 + 16);
+            ao[a].lu_consts = bp.take(lu[a].consts.size() * 4 + 16);
             ao[a].lu_tab = bp.take((size_t)A.n_int * LU_STRIDE * 4);
             ao[a].lu_den = bp.take((size_t)A.n_int * A.N * 16);
             ao[a].lu_num = bp.take((size_t)A.n_int * A.N * 4);
@@ -874,21 +925,11 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             A.d_lu_sums = (uint32_t*)(base + ao[a].lu_sums);
             A.d_perm = (uint32_t*)(base + ao[a].perm);
             A.d_perm_lde = (uint32_t*)(base + ao[a].perm_lde);
-            std::vector<uint32_t> tab((size_t)A.n_int * LU_STRIDE, 0);
-            auto leaf = [](const uint32_t* l, uint32_t* kind, uint32_t* val) {
-                *kind = l[0] == A_VAR ? 0u : (l[0] == A_PUB ? 1u : (l[0] == A_PREP ? 3u : 2u));
-                *val = l[0] == A_CONST ? to_monty(l[1]) : l[1];
-            };
-            for (uint32_t j = 0; j < A.n_int; j++) {
-                const Interaction& it = A.prog.ints[j];
-                uint32_t* t = &tab[(size_t)j * LU_STRIDE];
-                t[0] = to_monty(it.bus + 1);
-                t[1] = it.sign;
-                leaf(it.count, &t[2], &t[3]);
-                t[4] = it.n_fields;
-                for (uint32_t i = 0; i < it.n_fields; i++) leaf(it.fields[i], &t[5 + 2 * i], &t[6 + 2 * i]);
-            }
-            if (rc == ZKHIP_OK) rc = upload(ctx, A.d_lu_tab, tab.data(), tab.size() * 4);
+            A.d_lu_code = (uint32_t*)(base + ao[a].lu_code);
+            A.d_lu_consts = (uint32_t*)(base + ao[a].lu_consts);
+            if (rc == ZKHIP_OK) rc = upload(ctx, A.d_lu_tab, lu[a].tab.data(), lu[a].tab.size() * 4);
+            if (rc == ZKHIP_OK) rc = upload(ctx, A.d_lu_code, lu[a].code.data(), lu[a].code.size() * 4);
+            if (rc == ZKHIP_OK) rc = upload(ctx, A.d_lu_consts, lu[a].consts.data(), lu[a].consts.size() * 4);
             pmm.push_back(zkhip_matrix{A.d_perm_lde, A.M, A.h, A.perm_w});
         }
         mm.push_back(zkhip_matrix{A.d_lde, A.M, A.h, A.width});
@@ -1032,6 +1073,8 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             la.prep = A.d_prep;
             la.pvs = A.d_pvs;
             la.tab = A.d_lu_tab;
+            la.code = A.d_lu_code;
+            la.consts = A.d_lu_consts;
             la.lchal = pk->d_lchal;
             la.den = A.d_lu_den;
             la.num = A.d_lu_num;
@@ -1043,7 +1086,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             const unsigned rb = (unsigned)((A.N + 255) / 256);
             {
                 KernelScope ks(ctx, "logup_denoms");
-                hipLaunchKernelGGL(k_logup_denoms, dim3(rb, A.n_int), dim3(256), 0, st, la);
+                hipLaunchKernelGGL(k_logup_denoms, dim3(rb, A.n_int), dim3(LU_BS), (size_t)A.lu_slots * LU_BS * 4, st, la);
             }
             ZK_TRY(launch_batch_inverse(ctx, A.d_lu_den, A.d_lu_den, (size_t)A.n_int * A.N, A.d_lu_num));
             {
