@@ -503,3 +503,47 @@ def range_traces(log_n_user, log_n_table, seed=0, user_width=4):
     prep = np.arange(nt, dtype=np.uint32).reshape(1, nt)
     mult = np.bincount(user[0], minlength=nt).astype(np.uint32).reshape(1, nt)
     return user.astype(np.uint32), mult, prep
+
+
+# ---- a chunk-circuit-shaped AIR set: many chips of different heights that talk over buses ------------
+class ChipSet:
+    """`n_chips` SyntheticAir chips (the reference's chunk circuit has 42 OpenVM chips, AGENTS.md:183-185) of mixed
+    heights whose widths sum to ~`total_width`, each with
+      * a bus of its own on which it sends and receives the compound message (c0 + 2*c1, c2) gated by a boolean column,
+      * one message per row to a shared range table with PREPROCESSED keys (bus 5): the value of a boolean column,
+    plus the range-table chip itself (multiplicities = how often each key was sent).  Deterministic in `seed`."""
+
+    RANGE_BUS = 5
+
+    def __init__(self, n_chips=42, log_max=16, log_min=6, total_width=300, seed=0, log_table=4):
+        rng = np.random.default_rng(seed)
+        w = rng.integers(6, 2 * total_width // n_chips - 5, size=n_chips)
+        self.widths = [int(x) for x in w]
+        # a few tall chips, a long tail of short ones (like CPU / memory chips vs. small ALU chips)
+        hs = np.sort(rng.integers(log_min, log_max + 1, size=n_chips))[::-1].copy()
+        hs[: max(1, n_chips // 10)] = log_max
+        self.heights = [int(h) for h in rng.permutation(hs)]
+        self.log_table = log_table
+        self.chips = []
+        for i, wi in enumerate(self.widths):
+            sa = SyntheticAir(width=wi, n_free=max(4, wi // 3), n_bool=2, n_boundary=1, seed=seed * 1000 + i)
+            b = sa.builder
+            msg = [b.var(2) + b.var(3) * 2, b.var(sa.n_free)]
+            b.push_interaction(100 + i, msg, b.var(0), "send")
+            b.push_interaction(100 + i, msg, b.var(0), "receive")
+            b.push_interaction(self.RANGE_BUS, [b.var(1)], 1, "send")
+            self.chips.append(sa)
+        self.table = range_table_air(self.RANGE_BUS)
+
+    def gen(self, seed=0):
+        """Returns the list of AIR dicts (program, shapes, trace, pvs[, prep]) with balanced buses."""
+        airs, counts = [], np.zeros(1 << self.log_table, dtype=np.int64)
+        for i, (sa, h) in enumerate(zip(self.chips, self.heights)):
+            tr, pv = sa.gen_trace(h, seed=seed * 7919 + i)
+            counts[:2] += np.bincount(tr[1].astype(np.int64), minlength=2)[:2]
+            airs.append(dict(program=sa.program(), log_height=h, width=sa.width, n_pvs=len(pv), trace=tr, pvs=pv))
+        nt = 1 << self.log_table
+        airs.append(dict(program=self.table.program(), log_height=self.log_table, width=1, n_pvs=0,
+                         trace=(counts % P).astype(np.uint32).reshape(1, nt), pvs=np.zeros(0, np.uint32),
+                         prep=np.arange(nt, dtype=np.uint32).reshape(1, nt)))
+        return airs

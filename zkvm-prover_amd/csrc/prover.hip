@@ -1334,8 +1334,8 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_quot, pf + pk->off_root_quot, 8u);
         if (pk->n_lu) {
             hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_perm, pf + pk->off_root_perm, 8u);
-            hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, pk->d_exposed, pf + pk->off_exposed,
-                               (uint32_t)(4 * pk->n_lu));
+            const uint32_t ne = (uint32_t)(4 * pk->n_lu);
+            hipLaunchKernelGGL(k_copy_canon, dim3((ne + 63) / 64), dim3(64), 0, st, pk->d_exposed, pf + pk->off_exposed, ne);
         }
         uint32_t n = (uint32_t)(4 * pk->n_open);
         hipLaunchKernelGGL(k_copy_canon, dim3((n + 255) / 256), dim3(256), 0, st, pk->d_opened, pf + pk->off_opened, n);
