@@ -94,6 +94,29 @@ __global__ void k_permute_batch(uint32_t* states, size_t n) {
     for (int q = 0; q < 4; q++) p[q] = make_uint4(s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]);
 }
 
+// The same layer step with one node per 16-lane row (cooperative permutation, poseidon2_coop.hpp): ~8x shorter
+// dependent chain per node at 16x the lanes.  Used for layers of <= 2^15 nodes, which cannot fill the chip with one
+// lane per node anyway -- there a layer costs one permutation LATENCY, and trees have a dozen such layers (more when
+// matrices of many heights are injected).
+__global__ __launch_bounds__(256) void k_compress_layer_coop(const uint32_t* __restrict__ prev, uint32_t* __restrict__ next,
+                                                             size_t n_next, const uint32_t* const* __restrict__ inj_cols,
+                                                             uint32_t n_inj_cols) {
+    const unsigned lane = threadIdx.x & 15u;
+    const size_t i = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const size_t ii = i < n_next ? i : 0;  // all 16 lanes of every row stay active through the DPP permutation
+    uint32_t x = coop_permute(prev[ii * 16 + lane], lane);
+    if (n_inj_cols) {
+        uint32_t h = 0;  // sponge over the injected row: lane k < 8 absorbs column j + k, lanes 8..15 are the capacity
+        for (uint32_t j = 0; j < n_inj_cols; j += 8) {
+            if (lane < 8 && j + lane < n_inj_cols) h = inj_cols[j + lane][ii];
+            h = coop_permute(h, lane);
+        }
+        const uint32_t hh = dpp<ZK_ROR(8)>(h);  // lane 8 + k reads the digest word k
+        x = coop_permute(lane < 8 ? x : hh, lane);
+    }
+    if (i < n_next && lane < 8) next[i * 8 + lane] = x;
+}
+
 // Top of a tree in ONE launch: from a layer of <= 512 nodes down to the root.  Each 16-lane row
 // computes one compression cooperatively (poseidon2_coop.hpp), the working layer lives in LDS,
 // every produced layer is also written to the tree's digest store for later openings.
@@ -251,9 +274,14 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
             break;
         }
         KernelScope ks(ctx, "poseidon2_compress_layer");
-        hipLaunchKernelGGL(k_compress_layer, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
-                           t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,
-                           d_ptrs ? d_ptrs + t->level_off[level] : nullptr, (uint32_t)t->level_cnt[level]);
+        if (cnt <= ((size_t)1 << 15))
+            hipLaunchKernelGGL(k_compress_layer_coop, dim3((unsigned)((cnt + 15) / 16)), dim3(256), 0, ctx->stream,
+                               t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,
+                               d_ptrs ? d_ptrs + t->level_off[level] : nullptr, (uint32_t)t->level_cnt[level]);
+        else
+            hipLaunchKernelGGL(k_compress_layer, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                               t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,
+                               d_ptrs ? d_ptrs + t->level_off[level] : nullptr, (uint32_t)t->level_cnt[level]);
     }
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
