@@ -38,6 +38,7 @@ CASES = {
     "same_heights": lambda: [_syn(8, 17, 6, 5), _fib(8)],
     "tall_fib_short_syn": lambda: [_fib(10), _syn(5, 33, 9, 7)],
     "syn_12": lambda: [_syn(12, 60, 16, 3)],
+    "wide_short": lambda: [_syn(5, 700, 40, 9), _fib(2)],
 }
 
 
