@@ -37,5 +37,5 @@ for it in range(2):
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
 print("proof %.2f ms (%.2f ns per trace cell)" % (dt * 1e3, dt * 1e9 / cells))
-for k, (cnt, ms) in sorted(ctx.profile_read().items(), key=lambda kv: -kv[1][1])[:14]:
+for k, (cnt, ms) in sorted(ctx.profile_read().items(), key=lambda kv: -kv[1][1])[:40]:
     print("   %-28s x%-4d %9.3f ms" % (k, cnt, ms))
