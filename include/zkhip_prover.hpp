@@ -187,14 +187,28 @@ struct ProverConfig {
 struct AirDesc {
     size_t width = 0, n_pvs = 0;
     std::vector<uint32_t> program;
+    // preprocessed trace of the chip (fixes its height) and its commitment -- the app's verifying-key material,
+    // the analogue of the committed exe / vk the reference checks at crates/verifier/src/verifier.rs:77-80
+    bool has_prep = false;
+    unsigned prep_log_height = 0;
+    std::vector<uint32_t> prep;         // prep_width << prep_log_height canonical words, column-major (may be empty: verify only)
+    std::vector<uint32_t> prep_commit;  // 8 canonical words (may be empty until the first keygen)
 };
-constexpr uint32_t AIRSET_MAGIC = 0x58414B5Au;
+constexpr uint32_t AIRSET_MAGIC = 0x58414B5Au;     // v1: {width, n_pvs, prog_len, prog}
+constexpr uint32_t AIRSET_MAGIC_V2 = 0x58414B5Bu;  // v2: v1 + {has_prep, [log_height, prep_len, prep..., has_commit, commit(8)]}
 
 inline std::vector<uint8_t> encode_app_exe(const std::vector<AirDesc>& airs) {
-    std::vector<uint32_t> w{AIRSET_MAGIC, (uint32_t)airs.size()};
+    std::vector<uint32_t> w{AIRSET_MAGIC_V2, (uint32_t)airs.size()};
     for (const auto& a : airs) {
         w.push_back((uint32_t)a.width), w.push_back((uint32_t)a.n_pvs), w.push_back((uint32_t)a.program.size());
         w.insert(w.end(), a.program.begin(), a.program.end());
+        w.push_back(a.has_prep ? 1u : 0u);
+        if (a.has_prep) {
+            w.push_back(a.prep_log_height), w.push_back((uint32_t)a.prep.size());
+            w.insert(w.end(), a.prep.begin(), a.prep.end());
+            w.push_back(a.prep_commit.size() == 8 ? 1u : 0u);
+            if (a.prep_commit.size() == 8) w.insert(w.end(), a.prep_commit.begin(), a.prep_commit.end());
+        }
     }
     std::vector<uint8_t> out(w.size() * 4);
     memcpy(out.data(), w.data(), out.size());
@@ -209,17 +223,36 @@ inline std::vector<AirDesc> read_app_exe(const std::string& path) {
     if (b.size() < 8 || b.size() % 4) throw Error(Error::Setup, "failed to read or deserialize " + path + ": truncated");
     std::vector<uint32_t> w(b.size() / 4);
     memcpy(w.data(), b.data(), b.size());
-    if (w[0] != AIRSET_MAGIC) throw Error(Error::Setup, "failed to read or deserialize " + path + ": bad magic");
+    if (w[0] != AIRSET_MAGIC && w[0] != AIRSET_MAGIC_V2) throw Error(Error::Setup, "failed to read or deserialize " + path + ": bad magic");
+    const bool v2 = w[0] == AIRSET_MAGIC_V2;
+    auto trunc = [&]() { return Error(Error::Setup, "failed to read or deserialize " + path + ": truncated"); };
+    if (w[1] > w.size()) throw trunc();
     std::vector<AirDesc> airs(w[1]);
     size_t p = 2;
     for (auto& a : airs) {
-        if (p + 3 > w.size()) throw Error(Error::Setup, "failed to read or deserialize " + path + ": truncated");
+        if (p + 3 > w.size()) throw trunc();
         a.width = w[p], a.n_pvs = w[p + 1];
         size_t len = w[p + 2];
         p += 3;
-        if (p + len > w.size()) throw Error(Error::Setup, "failed to read or deserialize " + path + ": truncated");
+        if (len > w.size() || p + len > w.size()) throw trunc();
         a.program.assign(w.begin() + p, w.begin() + p + len);
         p += len;
+        if (!v2) continue;
+        if (p + 1 > w.size()) throw trunc();
+        a.has_prep = w[p++] != 0;
+        if (!a.has_prep) continue;
+        if (p + 2 > w.size()) throw trunc();
+        a.prep_log_height = w[p];
+        size_t plen = w[p + 1];
+        p += 2;
+        if (a.prep_log_height > 27 || plen > w.size() || p + plen + 1 > w.size()) throw trunc();
+        a.prep.assign(w.begin() + p, w.begin() + p + plen);
+        p += plen;
+        if (w[p++]) {
+            if (p + 8 > w.size()) throw trunc();
+            a.prep_commit.assign(w.begin() + p, w.begin() + p + 8);
+            p += 8;
+        }
     }
     return airs;
 }
@@ -308,6 +341,8 @@ public:
             size_t n_pvs = words[1], have = w.size() / 4;
             if (lh > 27 || n_pvs != airs_[a].n_pvs || have != 2 + n_pvs + (airs_[a].width << lh))
                 throw Error(Error::GenProof, "witness of chip " + std::to_string(a) + " has the wrong shape");
+            if (airs_[a].has_prep && lh != airs_[a].prep_log_height)
+                throw Error(Error::GenProof, "witness of chip " + std::to_string(a) + " does not have the height of its preprocessed trace");
             heights.push_back(lh);
             pvs[a].assign(words + 2, words + 2 + n_pvs);
             trace_host[a] = words + 2 + n_pvs;
@@ -365,7 +400,9 @@ public:
         std::vector<const uint32_t*> pv(airs_.size());
         size_t off = 0;
         for (size_t a = 0; a < airs_.size(); a++) {
-            za[a] = zkhip_air{airs_[a].program.data(), airs_[a].program.size(), sp.baseline[a], airs_[a].width, airs_[a].n_pvs};
+            za[a] = make_air(a, sp.baseline[a]);
+            if (airs_[a].has_prep && airs_[a].prep_commit.size() != 8)
+                throw Error(Error::VerifyProof, "the app holds no commitment for the preprocessed trace of chip " + std::to_string(a));
             if (off + 4 * airs_[a].n_pvs > sp.user_pvs_proof.size()) throw Error(Error::VerifyProof, "short public values");
             pvs[a].resize(airs_[a].n_pvs);
             if (airs_[a].n_pvs) memcpy(pvs[a].data(), sp.user_pvs_proof.data() + off, 4 * airs_[a].n_pvs);
@@ -388,6 +425,14 @@ private:
     zkhip_pk* pk_ = nullptr;
     std::vector<unsigned> pk_heights_;
 
+    zkhip_air make_air(size_t a, unsigned lh) const {
+        zkhip_air z{airs_[a].program.data(), airs_[a].program.size(), lh, airs_[a].width, airs_[a].n_pvs, nullptr, nullptr};
+        if (airs_[a].has_prep) {
+            z.prep_trace = airs_[a].prep.empty() ? nullptr : airs_[a].prep.data();
+            z.prep_commit = airs_[a].prep_commit.size() == 8 ? airs_[a].prep_commit.data() : nullptr;
+        }
+        return z;
+    }
     void check(int rc, Error::Kind kind) const {
         if (rc != ZKHIP_OK) throw Error(kind, std::string(kind == Error::Keygen ? "failed to generate STARK proving key: " : "failed to generate proof: ") + zkhip_last_error(ctx_));
     }
@@ -400,10 +445,22 @@ private:
         if (pk_ && pk_heights_ == heights) return;
         if (pk_) zkhip_pk_destroy(ctx_, pk_), pk_ = nullptr;
         std::vector<zkhip_air> za(airs_.size());
-        for (size_t a = 0; a < airs_.size(); a++)
-            za[a] = zkhip_air{airs_[a].program.data(), airs_[a].program.size(), heights[a], airs_[a].width, airs_[a].n_pvs};
+        for (size_t a = 0; a < airs_.size(); a++) za[a] = make_air(a, heights[a]);
         check(zkhip_keygen(ctx_, &params_, za.data(), za.size(), &pk_), Error::Keygen);
         pk_heights_ = heights;
+        // commitments of the preprocessed traces: adopt them, or -- when the app file already carries them -- insist
+        // that the key just generated commits to the same tables (verifier.rs:77-80 does this for the exe commit)
+        for (size_t a = 0; a < airs_.size(); a++) {
+            if (!airs_[a].has_prep) continue;
+            uint32_t c[8];
+            check(zkhip_pk_prep_commitment(ctx_, pk_, a, c), Error::Keygen);
+            if (airs_[a].prep_commit.size() == 8) {
+                if (memcmp(c, airs_[a].prep_commit.data(), 32) != 0)
+                    throw Error(Error::Keygen, "preprocessed trace of chip " + std::to_string(a) + " does not match the app's commitment");
+            } else {
+                airs_[a].prep_commit.assign(c, c + 8);
+            }
+        }
     }
 };
 

@@ -10,6 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
 AIRSET_MAGIC = 0x58414B5A
+AIRSET_MAGIC_V2 = 0x58414B5B   # + per chip {has_prep, [log_height, prep_len, prep..., has_commit, commit(8)]}
 
 # same keys as the reference's circuit config (crates/circuits/chunk-circuit/openvm.toml:1-6)
 TOML = """[app_fri_params.fri_params]
@@ -23,11 +24,23 @@ query_proof_of_work_bits = {4}
 """
 
 
-def write_app(tmp, airs, params):
-    words = [AIRSET_MAGIC, len(airs)]
+def write_app(tmp, airs, params, with_tables=True):
+    """airs: dicts with program/width/n_pvs[/prep/prep_commit/log_height].  with_tables=False writes a verifier's
+    app: commitments of the preprocessed traces but not the tables."""
+    v2 = any(a.get("prep") is not None or a.get("prep_commit") is not None for a in airs)
+    words = [AIRSET_MAGIC_V2 if v2 else AIRSET_MAGIC, len(airs)]
     for a in airs:
         prog = np.asarray(a["program"], dtype=np.uint32)
         words += [a["width"], a["n_pvs"], prog.size] + prog.tolist()
+        if not v2:
+            continue
+        has = a.get("prep") is not None or a.get("prep_commit") is not None
+        words.append(1 if has else 0)
+        if has:
+            prep = np.asarray(a["prep"], dtype=np.uint32).reshape(-1) if (with_tables and a.get("prep") is not None) else np.zeros(0, np.uint32)
+            words += [a["log_height"], prep.size] + prep.tolist()
+            pc = a.get("prep_commit")
+            words += ([1] + np.asarray(pc, dtype=np.uint32).tolist()) if pc is not None else [0]
     exe = os.path.join(tmp, "app.zkair")
     np.array(words, dtype=np.uint32).tofile(exe)
     cfg = os.path.join(tmp, "openvm.toml")

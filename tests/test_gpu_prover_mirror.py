@@ -68,3 +68,35 @@ def test_prove_many_reuses_keys_and_survives_reset(ora, tmp_path):
     for i, airs in enumerate(all_airs):
         js = json.loads((tmp_path / ("chunk-%d.json" % i)).read_text())
         assert pm.un_b64_bincode(js["proof"]) == ora.stark_prove(PARAMS, airs).tobytes()
+
+
+def _range_airs():
+    u, m, prep = air.range_traces(7, 5, seed=3)
+    nopv = np.zeros(0, np.uint32)
+    return [dict(program=air.range_user_air().program(), log_height=7, width=4, n_pvs=0, trace=u, pvs=nopv),
+            dict(program=air.range_table_air().program(), log_height=5, width=1, n_pvs=0, trace=m, pvs=nopv, prep=prep)]
+
+
+def test_app_with_preprocessed_table_and_buses(ora, tmp_path):
+    """The app file carries the range table; keygen commits it; the proof equals the oracle's; a verifier's app file
+    with only the commitment accepts it; an app whose commitment does not match its table fails at keygen."""
+    airs = _range_airs()
+    exe, cfg = pm.write_app(str(tmp_path), airs, PARAMS)
+    task = pm.write_task(str(tmp_path), airs, identifier="chunk-7")
+    out = tmp_path / "proof.json"
+    r = pm.run_cli("prove", exe, cfg, task, str(out))
+    assert r.returncode == 0 and "proved chunk-7" in r.stdout, r.stderr
+    proof = pm.un_b64_bincode(json.loads(out.read_text())["proof"])
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    vk = [dict(a) for a in airs]
+    vk[1]["prep_commit"] = ora.prep_commit(PARAMS, airs[1])
+    (tmp_path / "vk").mkdir()
+    exe_vk, _ = pm.write_app(str(tmp_path / "vk"), vk, PARAMS, with_tables=False)
+    assert pm.run_cli("verify", exe_vk, cfg, str(out)).returncode == 0
+    bad = [dict(a) for a in vk]
+    bad[1]["prep_commit"] = bad[1]["prep_commit"].copy()
+    bad[1]["prep_commit"][5] ^= 4
+    (tmp_path / "bad").mkdir()
+    exe_bad, _ = pm.write_app(str(tmp_path / "bad"), bad, PARAMS)
+    r = pm.run_cli("prove", exe_bad, cfg, task, str(tmp_path / "o2.json"))
+    assert r.returncode == 1 and "does not match the app's commitment" in r.stderr

@@ -44,6 +44,38 @@ def test_cli_verifies_oracle_proof_in_reference_container(ora, tmp_path):
     assert pm.run_cli("verify", exe, cfg, str(pj)).returncode == 1
 
 
+def _range_airs():
+    u, m, prep = air.range_traces(6, 4, seed=3)
+    nopv = np.zeros(0, np.uint32)
+    return [dict(program=air.range_user_air().program(), log_height=6, width=4, n_pvs=0, trace=u, pvs=nopv),
+            dict(program=air.range_table_air().program(), log_height=4, width=1, n_pvs=0, trace=m, pvs=nopv, prep=prep)]
+
+
+def test_cli_verifies_with_the_apps_preprocessed_commitment(ora, tmp_path):
+    """A verifier's app file holds the commitment of the range table, not the table (the exe-commit analogue,
+    crates/verifier/src/verifier.rs:77-80)."""
+    airs = _range_airs()
+    proof = ora.stark_prove(PARAMS, airs).tobytes()
+    vk_airs = [dict(a) for a in airs]
+    vk_airs[1]["prep_commit"] = ora.prep_commit(PARAMS, airs[1])
+    exe, cfg = pm.write_app(str(tmp_path), vk_airs, PARAMS, with_tables=False)
+    pj = tmp_path / "proof.json"
+    pj.write_text(pm.stark_proof_json(proof, airs))
+    r = pm.run_cli("verify", exe, cfg, str(pj))
+    assert r.returncode == 0 and "verified" in r.stdout, r.stderr
+    # another table's commitment, or none at all: Error::VerifyProof
+    vk_airs[1]["prep_commit"] = vk_airs[1]["prep_commit"].copy()
+    vk_airs[1]["prep_commit"][0] ^= 1
+    exe2, _ = pm.write_app(str(tmp_path / "b"), vk_airs, PARAMS, with_tables=False) if os.makedirs(tmp_path / "b") is None else None
+    r = pm.run_cli("verify", exe2, cfg, str(pj))
+    assert r.returncode == 1 and "kind 4" in r.stderr
+    del vk_airs[1]["prep_commit"]
+    os.makedirs(tmp_path / "c")
+    exe3, _ = pm.write_app(str(tmp_path / "c"), vk_airs, PARAMS, with_tables=True)
+    r = pm.run_cli("verify", exe3, cfg, str(pj))
+    assert r.returncode == 1 and "kind 4" in r.stderr and "commitment" in r.stderr
+
+
 def test_setup_errors_match_reference_kinds(tmp_path):
     airs = _airs()
     exe, cfg = pm.write_app(str(tmp_path), airs, PARAMS)
