@@ -56,6 +56,11 @@ def load_library():
     if not os.path.exists(path):
         raise ZkhipError("libzkhip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(or make -C zkvm-prover_amd/csrc)")
+    # torch first: its wheel bundles a HIP runtime, and the process must end up with ONE runtime.  If libzkhip.so
+    # (linked against /opt/rocm) were loaded before torch, two copies of libamdhip64 would be live and the second
+    # one to initialise would not see the GPU.
+    import torch  # noqa: F401
+
     lib = C.CDLL(path)
     vp, sz, u32p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)
     sig = {
