@@ -80,6 +80,16 @@ def test_blowup_4(zk, ora):
     assert z.verify(params, airs, [a["pvs"] for a in airs], got) == 0
 
 
+@pytest.mark.parametrize("b", [3, 4])
+def test_blowup_8_and_16(zk, ora, b):
+    params = (b, 0, 4, 2, 2)
+    airs = [_syn(5, 14, 6, 17, n_bool=2, n_boundary=1), _fib(4)]
+    exp = ora.stark_prove(params, airs)
+    got, _, _ = _prove_gpu(zk, params, airs)
+    assert got == exp.tobytes()
+    assert z.verify(params, airs, [a["pvs"] for a in airs], got) == 0
+
+
 def test_unsatisfied_witness_fails_verification(zk):
     params = (1, 0, 8, 2, 2)
     a = _syn(6, 24, 8, 1)
