@@ -382,25 +382,38 @@ __global__ __launch_bounds__(64) void k_open_finish(const uint32_t* partial, uin
 struct ReducePrep {
     const uint32_t* alpha;   // ext
     const uint32_t* opened;  // n_pts * width ext (this matrix' opened values)
-    const uint32_t* pts;     // n_pts ext
     uint32_t width, n_pts;
     uint64_t num_reduced;    // alpha power offset of the first point
-    uint32_t* apow;          // width ext
+    const uint32_t* apow;    // alpha^k, k <= width (table shared by all matrices of a proof)
     uint32_t* ry;            // n_pts ext
     uint32_t* off;           // n_pts ext
 };
-__global__ void k_reduce_prep(ReducePrep a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Ext al = ld_ext(a.alpha), cur = ext_one();
+// out[k] = base^k for k < n, one lane per power (square-and-multiply: any order of exact field products gives the
+// same element as the serial chain)
+__global__ __launch_bounds__(256) void k_ext_powers_par(const uint32_t* base, uint32_t n, uint32_t* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) st_ext(out + 4 * (size_t)k, ext_pow(ld_ext(base), k));
+}
+// one wave per matrix: ry_pt = sum_k alpha^k * opened[pt][k] (lane-strided partial sums, shuffle reduction),
+// off_pt = alpha^(num_reduced + pt * width)
+__global__ __launch_bounds__(64) void k_reduce_prep(ReducePrep a) {
+    const unsigned lane = threadIdx.x;
     Ext ry[2] = {ext_zero(), ext_zero()};
-    for (uint32_t k = 0; k < a.width; k++) {
-        st_ext(a.apow + 4 * (size_t)k, cur);
-        for (uint32_t p = 0; p < a.n_pts; p++)
-            ry[p] = ext_add(ry[p], ext_mul(cur, ld_ext(a.opened + 4 * ((size_t)p * a.width + k))));
-        cur = ext_mul(cur, al);
+    for (uint32_t k = lane; k < a.width; k += 64) {
+        const Ext ak = ld_ext(a.apow + 4 * (size_t)k);
+        for (uint32_t p = 0; p < a.n_pts; p++) ry[p] = ext_add(ry[p], ext_mul(ak, ld_ext(a.opened + 4 * ((size_t)p * a.width + k))));
     }
-    Ext aw = cur;  // alpha^width
-    Ext off = ext_pow(al, a.num_reduced);
+    for (uint32_t p = 0; p < a.n_pts; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t v = ry[p].c[q];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v = madd(v, __shfl_xor(v, o, 64));
+            ry[p].c[q] = v;
+        }
+    if (lane != 0) return;
+    const Ext aw = ld_ext(a.apow + 4 * (size_t)a.width);  // alpha^width
+    Ext off = ext_pow(ld_ext(a.alpha), a.num_reduced);
     for (uint32_t p = 0; p < a.n_pts; p++) {
         st_ext(a.ry + 4 * p, ry[p]);
         st_ext(a.off + 4 * p, off);
@@ -582,6 +595,7 @@ struct zkhip_pk {
     std::vector<uint32_t*> d_ro;    // per log height (nullptr if none)
     std::vector<uint32_t*> d_flayer;  // n_layers+1
     size_t n_prep = 0;              // AIRs with a preprocessed trace
+    size_t max_w = 0;               // widest committed matrix
     size_t n_lu = 0;                // AIRs with bus interactions
     unsigned h_perm = 0;            // log height of the permutation commitment
     uint32_t* d_lchal = nullptr;    // N_CHAL challenge coordinates, then the raw gamma, beta (8 words)
@@ -856,7 +870,8 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     size_t o_weights = bp.take(2 * max_n * 16);
     size_t max_tiles = (max_n + 511) / 512;
     size_t o_partial = bp.take(max_tiles * max_w * 8 * 4);
-    size_t o_apow_f = bp.take(max_w * 16);
+    size_t o_apow_f = bp.take((max_w + 1) * 16);
+    pk->max_w = max_w;
     std::vector<size_t> o_ro(pk->hmax + 1, (size_t)-1);
     for (size_t a = 0; a < n_airs; a++)
         if (o_ro[pk->airs[a].h] == (size_t)-1) o_ro[pk->airs[a].h] = bp.take(((size_t)16) << pk->airs[a].h);
@@ -1165,9 +1180,19 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     ZK_TRY(transcript_sample(ctx, pk->d_tr, d_zeta, nullptr, 4));
 
     // ---- 3. openings at zeta (and zeta*w for the trace) ----
+    // barycentric weights depend only on (height, coset shift, points): matrices are opened in an order that keeps
+    // equal keys adjacent (AIRs sorted by height; main, preprocessed and permutation matrix of an AIR back to back),
+    // so the two weight kernels run once per distinct key instead of once per matrix
+    unsigned wk_lh = ~0u, wk_pts = 0;
+    uint32_t wk_shift = 0;
+    std::vector<size_t> by_height(n_airs);
+    for (size_t a = 0; a < n_airs; a++) by_height[a] = a;
+    std::stable_sort(by_height.begin(), by_height.end(), [&](size_t x, size_t y) { return pk->airs[x].lh < pk->airs[y].lh; });
     auto open_matrix = [&](const uint32_t* cols, size_t stride, uint32_t n_cols, unsigned lh, unsigned n_pts,
                            uint32_t shift, uint32_t* d_out) -> int {
         const size_t N = (size_t)1 << lh;
+        const bool same_key = lh == wk_lh && shift == wk_shift && n_pts == wk_pts;
+        wk_lh = lh, wk_shift = shift, wk_pts = n_pts;
         PointsArgs pa;
         pa.zeta = d_zeta;
         pa.w_n = two_adic_generator(lh);
@@ -1178,11 +1203,11 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         pa.n_pts = n_pts;
         pa.pts = pk->d_pts;
         pa.scale = pk->d_pts + 8;
-        {
+        if (!same_key) {
             KernelScope ks(ctx, "open_points");
             hipLaunchKernelGGL(k_open_points, dim3(1), dim3(64), 0, st, pa);
         }
-        {
+        if (!same_key) {
             KernelScope ks(ctx, "bary_weights");
             hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pk->d_pts, n_pts,
                                shift, ctx->d_tw_fwd, lh ? ctx->tw_log - lh : 0, lh, pk->d_weights);
@@ -1207,100 +1232,116 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         ZK_HIP_CHECK(ctx, hipGetLastError());
         return ZKHIP_OK;
     };
-    for (size_t a = 0; a < n_airs; a++) {
+    for (size_t a : by_height) {
         AirPlan& A = pk->airs[a];
-        ZK_TRY(open_matrix(d_traces[a], A.N, (uint32_t)A.width, A.lh, 2, MONTY_ONE,
-                           pk->d_opened + 4 * A.opened_main_off));
-    }
-    for (size_t a = 0; a < n_airs; a++) {
-        AirPlan& A = pk->airs[a];
+        ZK_TRY(open_matrix(d_traces[a], A.N, (uint32_t)A.width, A.lh, 2, MONTY_ONE, pk->d_opened + 4 * A.opened_main_off));
         if (A.prep_w)
             ZK_TRY(open_matrix(A.d_prep, A.N, (uint32_t)A.prep_w, A.lh, 2, MONTY_ONE, pk->d_opened + 4 * A.opened_prep_off));
-    }
-    for (size_t a = 0; a < n_airs; a++) {
-        AirPlan& A = pk->airs[a];
         if (A.n_int)
             ZK_TRY(open_matrix(A.d_perm, A.N, (uint32_t)A.perm_w, A.lh, 2, MONTY_ONE, pk->d_opened + 4 * A.opened_perm_off));
     }
-    for (size_t a = 0; a < n_airs; a++) {
-        AirPlan& A = pk->airs[a];
-        for (unsigned j = 0; j < nch; j++) {
+    for (unsigned j = 0; j < nch; j++)
+        for (size_t a : by_height) {
+            AirPlan& A = pk->airs[a];
             uint32_t sj = mmul(gen, host_pow(two_adic_generator(A.h), bitrev32(j, b)));
-            ZK_TRY(open_matrix(A.d_qnat + (size_t)j * 4 * A.N, A.N, 4, A.lh, 1, sj,
-                               pk->d_opened + 4 * (A.opened_quot_off + 4 * (size_t)j)));
+            ZK_TRY(open_matrix(A.d_qnat + (size_t)j * 4 * A.N, A.N, 4, A.lh, 1, sj, pk->d_opened + 4 * (A.opened_quot_off + 4 * (size_t)j)));
         }
-    }
     ZK_TRY(transcript_observe(ctx, pk->d_tr, pk->d_opened, (uint32_t)(4 * pk->n_open), false));
     ZK_TRY(transcript_sample(ctx, pk->d_tr, d_alpha_f, nullptr, 4));
 
     // ---- 4. FRI batching: reduced openings per LDE height ----
     {
+        {
+            KernelScope ks(ctx, "ext_powers");
+            const uint32_t np = (uint32_t)pk->max_w + 1;
+            hipLaunchKernelGGL(k_ext_powers_par, dim3((np + 255) / 256), dim3(256), 0, st, d_alpha_f, np, pk->d_apow_f);
+        }
+        // the matrices in commitment order (main, preprocessed, permutation, quotient chunks) fix every alpha offset;
+        // they are then processed height by height, so the opening points are computed once per height
+        struct RoItem {
+            const uint32_t *mat, *opened;
+            uint32_t W;
+            unsigned n_pts, lh, h;
+            uint64_t num_reduced;
+            int accumulate;
+        };
+        std::vector<RoItem> items;
         std::vector<uint64_t> num_reduced(hmax + 1, 0);
         std::vector<char> started(hmax + 1, 0);
-        for (int round = 0; round < 4; round++)  // main, preprocessed, permutation, quotient chunks
+        for (int round = 0; round < 4; round++)
             for (size_t a = 0; a < n_airs; a++) {
                 AirPlan& A = pk->airs[a];
                 if (round == 1 && !A.prep_w) continue;
                 if (round == 2 && !A.n_int) continue;
                 const unsigned n_mats = round == 3 ? nch : 1;
                 for (unsigned j = 0; j < n_mats; j++) {
-                    const uint32_t W = round == 0 ? (uint32_t)A.width : round == 1 ? (uint32_t)A.prep_w : round == 2 ? (uint32_t)A.perm_w : 4u;
-                    const unsigned n_pts = round == 3 ? 1 : 2;
-                    const uint32_t* mat = round == 0 ? A.d_lde : round == 1 ? A.d_prep_lde : round == 2 ? A.d_perm_lde
-                                                                                                        : A.d_qlde + (size_t)j * 4 * A.M;
-                    const uint32_t* opened = pk->d_opened + 4 * (round == 0   ? A.opened_main_off
-                                                                 : round == 1 ? A.opened_prep_off
-                                                                 : round == 2 ? A.opened_perm_off
-                                                                              : A.opened_quot_off + 4 * (size_t)j);
-                    // points of this matrix: zeta (and zeta * w_N)
-                    PointsArgs pa;
-                    pa.zeta = d_zeta;
-                    pa.w_n = two_adic_generator(A.lh);
-                    pa.shift = MONTY_ONE;
-                    pa.s_pow_n = MONTY_ONE;
-                    pa.scale_base = MONTY_ONE;
-                    pa.lh = 0;
-                    pa.n_pts = n_pts;
-                    pa.pts = pk->d_pts;
-                    pa.scale = pk->d_pts + 8;
-                    ReducePrep rp;
-                    rp.alpha = d_alpha_f;
-                    rp.opened = opened;
-                    rp.pts = pk->d_pts;
-                    rp.width = W;
-                    rp.n_pts = n_pts;
-                    rp.num_reduced = num_reduced[A.h];
-                    rp.apow = pk->d_apow_f;
-                    rp.ry = pk->d_pts + 16;
-                    rp.off = pk->d_pts + 24;
-                    {
-                        KernelScope ks(ctx, "reduce_prep");
-                        hipLaunchKernelGGL(k_open_points, dim3(1), dim3(64), 0, st, pa);
-                        hipLaunchKernelGGL(k_reduce_prep, dim3(1), dim3(64), 0, st, rp);
-                    }
-                    ReduceArgs ra;
-                    ra.mat = mat;
-                    ra.apow = pk->d_apow_f;
-                    ra.ry = rp.ry;
-                    ra.off = rp.off;
-                    ra.pts = pk->d_pts;
-                    ra.ro = pk->d_ro[A.h];
-                    ra.tw_fwd = ctx->d_tw_fwd;
-                    ra.gen = gen;
-                    ra.width = W;
-                    ra.n_pts = n_pts;
-                    ra.h = A.h;
-                    ra.tw_shift = ctx->tw_log - A.h;
-                    ra.accumulate = started[A.h] ? 1 : 0;
-                    {
-                        KernelScope ks(ctx, "reduced_openings");
-                        hipLaunchKernelGGL(k_reduced_openings, dim3((unsigned)((A.M + 255) / 256)), dim3(256), 0, st, ra);
-                    }
-                    ZK_HIP_CHECK(ctx, hipGetLastError());
+                    RoItem it;
+                    it.W = round == 0 ? (uint32_t)A.width : round == 1 ? (uint32_t)A.prep_w : round == 2 ? (uint32_t)A.perm_w : 4u;
+                    it.n_pts = round == 3 ? 1 : 2;
+                    it.mat = round == 0 ? A.d_lde : round == 1 ? A.d_prep_lde : round == 2 ? A.d_perm_lde : A.d_qlde + (size_t)j * 4 * A.M;
+                    it.opened = pk->d_opened + 4 * (round == 0   ? A.opened_main_off
+                                                    : round == 1 ? A.opened_prep_off
+                                                    : round == 2 ? A.opened_perm_off
+                                                                 : A.opened_quot_off + 4 * (size_t)j);
+                    it.lh = A.lh, it.h = A.h;
+                    it.num_reduced = num_reduced[A.h];
+                    it.accumulate = started[A.h] ? 1 : 0;
                     started[A.h] = 1;
-                    num_reduced[A.h] += (uint64_t)W * n_pts;
+                    num_reduced[A.h] += (uint64_t)it.W * it.n_pts;
+                    items.push_back(it);
                 }
             }
+        std::stable_sort(items.begin(), items.end(), [](const RoItem& x, const RoItem& y) { return x.h < y.h; });
+        unsigned pts_lh = ~0u;
+        for (const RoItem& it : items) {
+            if (it.lh != pts_lh) {  // zeta and zeta * w_N
+                PointsArgs pa;
+                pa.zeta = d_zeta;
+                pa.w_n = two_adic_generator(it.lh);
+                pa.shift = MONTY_ONE;
+                pa.s_pow_n = MONTY_ONE;
+                pa.scale_base = MONTY_ONE;
+                pa.lh = 0;
+                pa.n_pts = 2;
+                pa.pts = pk->d_pts;
+                pa.scale = pk->d_pts + 8;
+                KernelScope ks(ctx, "reduce_prep");
+                hipLaunchKernelGGL(k_open_points, dim3(1), dim3(64), 0, st, pa);
+                pts_lh = it.lh;
+            }
+            ReducePrep rp;
+            rp.alpha = d_alpha_f;
+            rp.opened = it.opened;
+            rp.width = it.W;
+            rp.n_pts = it.n_pts;
+            rp.num_reduced = it.num_reduced;
+            rp.apow = pk->d_apow_f;
+            rp.ry = pk->d_pts + 16;
+            rp.off = pk->d_pts + 24;
+            {
+                KernelScope ks(ctx, "reduce_prep");
+                hipLaunchKernelGGL(k_reduce_prep, dim3(1), dim3(64), 0, st, rp);
+            }
+            ReduceArgs ra;
+            ra.mat = it.mat;
+            ra.apow = pk->d_apow_f;
+            ra.ry = rp.ry;
+            ra.off = rp.off;
+            ra.pts = pk->d_pts;
+            ra.ro = pk->d_ro[it.h];
+            ra.tw_fwd = ctx->d_tw_fwd;
+            ra.gen = gen;
+            ra.width = it.W;
+            ra.n_pts = it.n_pts;
+            ra.h = it.h;
+            ra.tw_shift = ctx->tw_log - it.h;
+            ra.accumulate = it.accumulate;
+            {
+                KernelScope ks(ctx, "reduced_openings");
+                hipLaunchKernelGGL(k_reduced_openings, dim3((unsigned)(((size_t)1 << it.h) + 255) / 256), dim3(256), 0, st, ra);
+            }
+            ZK_HIP_CHECK(ctx, hipGetLastError());
+        }
     }
 
     // ---- 5. FRI commit phase ----
