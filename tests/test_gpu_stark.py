@@ -264,3 +264,21 @@ def test_many_chips_with_distinct_heights(zk, ora):
     got, _, _ = _prove_gpu(zk, params, airs)
     assert got == exp
     assert z.verify(params, airs, [a["pvs"] for a in airs], got) == 0
+
+
+def test_gpu_proofs_match_committed_digests(zk):
+    """The HIP prover against the committed fixture alone (tests/golden/proof_digests_v1.json), no oracle in the loop."""
+    import hashlib
+    import importlib.util
+    import json
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("gen_proof_digests", os.path.join(here, "gen_proof_digests.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    want = json.load(open(os.path.join(here, "proof_digests_v1.json")))
+    for name, (params, airs) in gen.cases().items():
+        got, _, _ = _prove_gpu(zk, params, airs)
+        assert len(got) == 4 * want[name]["words"], name
+        assert hashlib.sha256(got).hexdigest() == want[name]["sha256"], name

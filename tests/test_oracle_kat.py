@@ -136,3 +136,18 @@ def test_fri_fold(ora, kat):
         flat = u32(case["in"]).reshape(-1)
         out = ora.fri_fold(flat, case["log_n_out"], case["beta"])
         assert out.reshape(-1, 4).tolist() == case["out"]
+
+
+def test_proof_digests_are_stable(ora):
+    """The oracle's proof bytes for a fixed set of small AIR sets (tests/golden/proof_digests_v1.json)."""
+    import importlib.util
+    import json
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("gen_proof_digests", os.path.join(here, "gen_proof_digests.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    want = json.load(open(os.path.join(here, "proof_digests_v1.json")))
+    got = gen.digests(ora)
+    assert got == want
