@@ -27,8 +27,8 @@
  *   optional: [0x50504B5A, prep_width]
  *   optional: [0x554C4B5A, n_int, n_int x {bus, sign, count node, n_fields, field node...}]
  *             (count / fields = nodes that are expressions of the current row only)
- * LogUp phase: challenges gamma, beta (extension); chal vector = gamma, beta^1..beta^8 as
- * 36 base coordinates; interaction j contributes phi_j = (+/-)count / (gamma + bus + 1 +
+ * LogUp phase: challenges gamma, beta (extension); chal vector = gamma, beta^1..beta^16 as
+ * 68 base coordinates; interaction j contributes phi_j = (+/-)count / (gamma + bus + 1 +
  * sum_i beta^(i+1) f_i); the permutation matrix holds phi_j (4 base columns each) and the
  * running sum of sum_j phi_j over the rows (last 4 columns); the final sum is EXPOSED and the
  * exposed sums of all AIRs must add up to zero.
@@ -43,7 +43,7 @@
 #define PROOF_MAGIC 0x31504B5Au
 #define PROTO_TAG 0x5A4B4831u /* "1HKZ" < p */
 #define GEN 31u
-#define MAX_FIELDS 8
+#define MAX_FIELDS 16
 #define N_CHAL (4 * (1 + MAX_FIELDS))
 
 enum { OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_PERM, OP_CHAL, OP_EXPOSED, OP_PREP };

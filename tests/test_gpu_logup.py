@@ -52,6 +52,8 @@ def _cases():
         "mix_min_height": [_mix(1)],
         "compound_messages": [_limb(6), s, t],
         "compound_and_mix": [_mix(4), _limb(8, seed=5), _fib(6)],
+        "twelve_fields": [dict(program=air.program_bus_air().program(), log_height=5, width=13, n_pvs=0,
+                               trace=air.program_bus_trace(5, 2), pvs=NOPV), _fib(3)],
     }
 
 

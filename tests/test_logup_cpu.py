@@ -79,6 +79,13 @@ def test_logup_compound_messages(ora):
     assert z.verify(PARAMS, a_bad, [NOPV], proof.tobytes()) != 0
 
 
+def test_logup_twelve_field_message(ora):
+    a = [dict(program=air.program_bus_air().program(), log_height=4, width=13, n_pvs=0, trace=air.program_bus_trace(4, 1), pvs=NOPV)]
+    proof = ora.stark_prove(PARAMS, a)
+    assert ora.stark_verify(PARAMS, a, proof) == 0
+    assert z.verify(PARAMS, a, [NOPV], proof.tobytes()) == 0
+
+
 def test_logup_unbalanced_bus_is_rejected(ora):
     airs = lookup_case()
     pvs = [a["pvs"] for a in airs]

@@ -18,7 +18,7 @@ OP_PERM, OP_CHAL, OP_EXPOSED = 10, 11, 12
 OP_PREP = 13                              # a cell of the AIR's preprocessed trace (committed at keygen)
 PREP_MAGIC = 0x50504B5A                   # section [PREP_MAGIC, prep_width] after the constraints
 LOGUP_MAGIC = 0x554C4B5A
-LOGUP_MAX_FIELDS = 8                      # challenge vector = gamma, beta^1 .. beta^8 (4 coordinates each)
+LOGUP_MAX_FIELDS = 16                     # challenge vector = gamma, beta^1 .. beta^16 (4 coordinates each)
 N_CHAL = 4 * (1 + LOGUP_MAX_FIELDS)
 EXT_W = 11                                # x^4 = 11
 
@@ -547,3 +547,22 @@ class ChipSet:
                          trace=(counts % P).astype(np.uint32).reshape(1, nt), pvs=np.zeros(0, np.uint32),
                          prep=np.arange(nt, dtype=np.uint32).reshape(1, nt)))
         return airs
+
+
+def program_bus_air(bus=2):
+    """A 12-field bus message, the width of OpenVM's program / execution buses (pc, opcode, operands a..g, ...):
+    the AIR sends its whole row and receives it back, gated by a boolean."""
+    b = AirBuilder(13, 0)
+    ok = b.var(12)
+    b.assert_zero(ok * (ok - 1))
+    msg = [b.var(i) for i in range(11)] + [b.var(0) + b.var(1) * 3]
+    b.push_interaction(bus, msg, ok, "send")
+    b.push_interaction(bus, msg, ok, "receive")
+    return b
+
+
+def program_bus_trace(log_n, seed=0):
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, P, size=(13, 1 << log_n)).astype(np.uint32)
+    t[12] %= 2
+    return t
