@@ -376,7 +376,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
     uint32_t *prep_roots = (uint32_t *)calloc(n_airs, 32);
     int *has_prep = (int *)calloc(n_airs, sizeof(int));
     for (size_t a = 0; a < n_airs; a++) {
-        if (airs[a].log_height < 1) return 0;
+        if (airs[a].log_height > 27) return 0;
         if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &st[a].prog)) return 0;
         if (st[a].prog.n_pvs != airs[a].n_pvs) return 0;
         st[a].lh = airs[a].log_height;
@@ -763,7 +763,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     int *has_prep = (int *)calloc(n_airs, sizeof(int));
     for (size_t a = 0; a < n_airs; a++) {
         if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &pg[a])) return -2;
-        if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height < 1) return -2;
+        if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height > 27) return -2;
         if (airs[a].log_height + b > hmax) hmax = airs[a].log_height + b;
         if (pg[a].n_int) n_lu++;
         if (pg[a].prep_width) {

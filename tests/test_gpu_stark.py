@@ -266,6 +266,29 @@ def test_many_chips_with_distinct_heights(zk, ora):
     assert z.verify(params, airs, [a["pvs"] for a in airs], got) == 0
 
 
+def test_single_row_traces(zk, ora):
+    """Chips whose trace has ONE row (log_height 0): alone, next to taller chips, and with a bus."""
+    params = (1, 0, 8, 3, 4)
+    one = dict(program=air.fibonacci_air().program(), log_height=0, width=2, n_pvs=3,
+               trace=np.array([[3], [5]], dtype=np.uint32), pvs=np.array([3, 5, 5], dtype=np.uint32))
+    nopv = np.zeros(0, np.uint32)
+    mt, mpv = air.bus_mix_trace(0, 4)
+    mix1 = dict(program=air.bus_mix_air().program(), log_height=0, width=6, n_pvs=1, trace=mt, pvs=mpv)
+    u, m, prep = air.range_traces(4, 0, seed=2)      # a one-entry range table: every user value is 0
+    user = dict(program=air.range_user_air().program(), log_height=4, width=4, n_pvs=0, trace=u, pvs=nopv)
+    rtab = dict(program=air.range_table_air().program(), log_height=0, width=1, n_pvs=0, trace=m, pvs=nopv, prep=prep)
+    for airs in ([one], [_fib(6), one, _syn(4, 12, 5, 2, n_bool=2, n_boundary=2)], [mix1, one], [user, rtab, _fib(3)]):
+        for a in airs:
+            assert air.check_trace(a["program"], a["trace"], a["pvs"], a.get("prep")) == []
+        exp = ora.stark_prove(params, airs)
+        assert ora.stark_verify(params, airs, exp) == 0
+        pk = z.ProvingKey(zk, params, airs)
+        pvs = [a["pvs"] for a in airs]
+        got = pk.prove([zk.upload(a["trace"].reshape(-1)) for a in airs], pvs)
+        assert got == exp.tobytes()
+        assert z.verify(params, pk.verifying_airs(), pvs, got) == 0
+
+
 def test_gpu_proofs_match_committed_digests(zk):
     """The HIP prover against the committed fixture alone (tests/golden/proof_digests_v1.json), no oracle in the loop."""
     import hashlib

@@ -651,7 +651,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     size_t n_open = 0, max_n = 0, max_w = 4, tw_main = 0, tw_perm = 0;
     for (size_t a = 0; a < n_airs; a++) {
         AirPlan& A = pk->airs[a];
-        if (airs[a].log_height < 1 || airs[a].log_height + pk->b > 27 || airs[a].width == 0) {
+        if (airs[a].log_height + pk->b > 27 || airs[a].width == 0) {
             delete pk;
             return set_error(ctx, ZKHIP_ERR_INVALID, "AIR height/width out of range");
         }

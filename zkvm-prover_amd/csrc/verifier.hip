@@ -115,7 +115,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     size_t n_lu = 0, n_prep = 0;
     for (size_t a = 0; a < n_airs; a++) {
         if (parse_air(airs[a].program, airs[a].program_len, airs[a].width, &pg[a], nullptr) != 0) return ZKHIP_ERR_INVALID;
-        if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height < 1) return ZKHIP_ERR_INVALID;
+        if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height > 27) return ZKHIP_ERR_INVALID;
         if (pg[a].max_degree > nch + 1) return ZKHIP_ERR_CONSTRAINT;
         if (airs[a].n_pvs && (!pvs || !pvs[a])) return ZKHIP_ERR_INVALID;
         hmax = std::max(hmax, airs[a].log_height + b);
