@@ -802,7 +802,10 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         // keygen-time compiled constraint kernel when the evaluation is large enough to repay the
         // ~2-4 s hipRTC compile (2^26 row-instructions ~ a few ms of interpreter time per proof);
         // ZKHIP_FORCE_JIT=1 / ZKHIP_NO_JIT=1 override
-        const bool big = (double)((size_t)1 << (airs[a].log_height + pk->b)) * (double)A.n_instr >= (double)(1ull << 26);
+        // ZKHIP_JIT_MIN_LOG_WORK=k moves the threshold to 2^k row-instructions (a fixed app that is proven many times
+        // can afford to compile every chip: ~1.5 s each)
+        static const unsigned jit_log = getenv("ZKHIP_JIT_MIN_LOG_WORK") ? (unsigned)atoi(getenv("ZKHIP_JIT_MIN_LOG_WORK")) : 26u;
+        const bool big = (double)((size_t)1 << (airs[a].log_height + pk->b)) * (double)A.n_instr >= (double)(1ull << std::min(jit_log, 62u));
         if ((big || getenv("ZKHIP_FORCE_JIT")) && !getenv("ZKHIP_NO_JIT")) {
             std::string msg;
             std::vector<uint32_t> tab;
