@@ -393,7 +393,7 @@ __device__ __forceinline__ void lds_rounds_ct(uint32_t* lv, const uint32_t* twl,
 
 template <int LOG_R, int LOG_C>
 __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
-    static_assert(LOG_R >= 10 && LOG_R - 4 + LOG_C == 10, "one radix-16 unit per lane in the first round");
+    static_assert(LOG_R >= 7 && LOG_R - 4 + LOG_C == 10, "one radix-16 unit per lane in the first round");
     extern __shared__ uint32_t sm[];
     constexpr unsigned R = 1u << LOG_R, C = 1u << LOG_C, pitch = C + 1u;
     constexpr int LOG_RQ = LOG_R - 4;
@@ -426,9 +426,12 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
         // with the odd pitch their LDS stores then hit 32 distinct banks instead of colliding two-way on
         // consecutive rows (profiles/round01_ntt_ablation.txt).
         const unsigned c = tid & (C - 1u), jj = tid >> LOG_C;
-        constexpr unsigned HB = 5 - LOG_C;   // unit-index bits inside a half-wave (2 or 1)
-        constexpr unsigned SP = LOG_C == 3 ? 3 : 4;  // log2 of the row spacing wanted
-        const unsigned j = ((jj & ((1u << HB) - 1u)) << SP) | ((jj >> HB) & ((1u << SP) - 1u)) | (jj & ~((1u << (HB + SP)) - 1u));
+        unsigned j = jj;
+        if constexpr (LOG_C <= 4) {
+            constexpr unsigned HB = 5 - LOG_C;           // unit-index bits inside a half-wave (2 or 1)
+            constexpr unsigned SP = LOG_C == 3 ? 3 : 4;  // log2 of the row spacing wanted
+            j = ((jj & ((1u << HB) - 1u)) << SP) | ((jj >> HB) & ((1u << SP) - 1u)) | (jj & ~((1u << (HB + SP)) - 1u));
+        }
         uint32_t v[16];
         if (a.br_src) {
             const uint32_t* run = a.src + mcol * a.src_col_stride + ((size_t)bitrev32(F0 + c, a.log_f) << LOG_R);
@@ -495,19 +498,29 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
     // a compile-time constant, so its HBM base is scalar and the LDS address an immediate ----
     const unsigned lo_mask = (1u << a.log_lo) - 1u;
     uint32_t* dst = a.dst + mcol * a.dst_col_stride + ((size_t)sub << a.log_m) + (size_t)X * a.out_x_stride;
-    const uint32_t* lrow = lv + tid * pitch;
+    if constexpr (LOG_R >= 10) {
+        const uint32_t* lrow = lv + tid * pitch;
 #pragma unroll
-    for (unsigned i = 0; i < (R * C) / 1024u; i++) {
-        constexpr unsigned dummy = 0;
-        (void)dummy;
-        const unsigned c = (1024u * i) >> LOG_R, p0 = (1024u * i) & (R - 1u);
-        const unsigned F = F0 + c;
-        uint32_t* dcol = dst + (size_t)(F >> a.log_lo) * a.out_hi_stride + (size_t)(F & lo_mask) * a.out_lo_stride + p0;
+        for (unsigned i = 0; i < (R * C) / 1024u; i++) {
+            const unsigned c = (1024u * i) >> LOG_R, p0 = (1024u * i) & (R - 1u);
+            const unsigned F = F0 + c;
+            uint32_t* dcol = dst + (size_t)(F >> a.log_lo) * a.out_hi_stride + (size_t)(F & lo_mask) * a.out_lo_stride + p0;
 #if defined(NTT_ABL) && NTT_ABL == 3
-        if (lrow[p0 * pitch + c] == 0x12345678u) dcol[tid] = 1;
+            if (lrow[p0 * pitch + c] == 0x12345678u) dcol[tid] = 1;
 #else
-        dcol[tid] = lrow[p0 * pitch + c];
+            dcol[tid] = lrow[p0 * pitch + c];
 #endif
+        }
+    } else {
+        // short runs: one store instruction covers 1024 / R tile columns, the column is per lane
+        const unsigned p = tid & (R - 1u), c_lane = tid >> LOG_R;
+        const uint32_t* lrow = lv + p * pitch + c_lane;
+#pragma unroll
+        for (unsigned i = 0; i < (R * C) / 1024u; i++) {
+            const unsigned F = F0 + c_lane + i * (1024u >> LOG_R);
+            uint32_t* dcol = dst + (size_t)(F >> a.log_lo) * a.out_hi_stride + (size_t)(F & lo_mask) * a.out_lo_stride + p;
+            *dcol = lrow[i * (1024u >> LOG_R)];
+        }
     }
 }
 
@@ -548,6 +561,9 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4_ct<11, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4_ct<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4_ct<9, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4_ct<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4_ct<7, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         attr_set = true;
     }
@@ -573,7 +589,9 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
             log_c_env = e ? atoi(e) : 0;
             if (log_c_env != 3 && log_c_env != 4) log_c_env = 0;
         }
-        pa.log_c = log_c_env ? (unsigned)log_c_env : (pa.log_r >= 11 ? 3u : 4u);
+        // tiles of 2^14 words (one radix-16 unit per lane): [2^11 x 8], [2^10 x 16], and for the short passes of
+        // three-pass sizes [2^9 x 32], [2^8 x 64], [2^7 x 128]
+        pa.log_c = log_c_env ? (unsigned)log_c_env : (pa.log_r >= 11 ? 3u : (pa.log_r >= 7 ? 14u - pa.log_r : 4u));
         if (pa.log_c > pa.log_f) pa.log_c = pa.log_f;
         const unsigned C = 1u << pa.log_c;
         const unsigned threads = std::min(1024u, std::max(64u, (R >> 4) * C));
@@ -585,6 +603,12 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
             hipLaunchKernelGGL((k_ntt_pass4_ct<11, 3>), grid, dim3(threads), lds, ctx->stream, pa);
         else if (pa.log_r == 10 && pa.log_c == 4 && !legacy)
             hipLaunchKernelGGL((k_ntt_pass4_ct<10, 4>), grid, dim3(threads), lds, ctx->stream, pa);
+        else if (pa.log_r == 9 && pa.log_c == 5 && !legacy)
+            hipLaunchKernelGGL((k_ntt_pass4_ct<9, 5>), grid, dim3(threads), lds, ctx->stream, pa);
+        else if (pa.log_r == 8 && pa.log_c == 6 && !legacy)
+            hipLaunchKernelGGL((k_ntt_pass4_ct<8, 6>), grid, dim3(threads), lds, ctx->stream, pa);
+        else if (pa.log_r == 7 && pa.log_c == 7 && !legacy)
+            hipLaunchKernelGGL((k_ntt_pass4_ct<7, 7>), grid, dim3(threads), lds, ctx->stream, pa);
         else if (pa.log_r == 11 && pa.log_c == 3)
             hipLaunchKernelGGL((k_ntt_pass4<11, 3>), grid, dim3(threads), lds, ctx->stream, pa);
         else if (pa.log_r == 10 && pa.log_c == 4)
