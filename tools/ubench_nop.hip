@@ -34,6 +34,21 @@ __device__ __forceinline__ uint32_t mml(uint32_t a, uint32_t b, uint32_t pp, uin
     uint64_t s = t + (uint64_t)m * pp;
     return (uint32_t)(s >> 32);
 }
+// v9: two independent chains interleaved at the granularity of the (sub, cndmask) pair, both through vcc
+#define B9                                                                          \
+    asm volatile("v_add_u32 %0, %0, %1\n\t"                                         \
+                 "v_add_u32 %2, %2, %3\n\t"                                         \
+                 "v_subrev_co_u32 %4, vcc, 0x78000001, %0\n\t"                      \
+                 "v_cndmask_b32 %0, %4, %0, vcc\n\t"                                \
+                 "v_subrev_co_u32 %5, vcc, 0x78000001, %2\n\t"                      \
+                 "v_cndmask_b32 %2, %5, %2, vcc\n\t"                                \
+                 "v_add_u32 %1, %1, %0\n\t"                                         \
+                 "v_add_u32 %3, %3, %2\n\t"                                         \
+                 "v_subrev_co_u32 %4, vcc, 0x78000001, %1\n\t"                      \
+                 "v_cndmask_b32 %1, %4, %1, vcc\n\t"                                \
+                 "v_subrev_co_u32 %5, vcc, 0x78000001, %3\n\t"                      \
+                 "v_cndmask_b32 %3, %5, %3, vcc\n\t"                                \
+                 : "+v"(x), "+v"(y), "+v"(z), "+v"(w), "=&v"(t), "=&v"(u)::"vcc");
 // two chains (x,y) and (z,w): x += y, z += w then y += x, w += z
 #define B2                                                                          \
     asm volatile("v_add_u32 %0, %0, %1\n\t"                                         \
@@ -79,6 +94,7 @@ __global__ __launch_bounds__(256) void k(uint32_t* o, int iters) {
         if (V == 3) { B3 B3 B3 B3 B3 B3 B3 B3 }
         if (V == 5) { B5 B5 B5 B5 B5 B5 B5 B5 }
         if (V == 6) { B6 B6 B6 B6 B6 B6 B6 B6 }
+        if (V == 9) { B9 B9 B9 B9 }
         if (V == 7 || V == 8) {
 #pragma unroll
             for (int q = 0; q < 8; q++) {
@@ -117,6 +133,9 @@ int main() {
     run<6>("v6 one value, vcc, P in an SGPR", d);
     run<0>("v0 again", d);
     run<6>("v6 again", d);
+    run<9>("v9 two chains interleaved, vcc", d);
+    run<0>("v0 again", d);
+    run<9>("v9 again", d);
     run<7>("v7 Montgomery product, constants in SGPRs", d);
     run<8>("v8 Montgomery product, constants in VGPRs", d);
     run<7>("v7 again", d);
