@@ -114,3 +114,69 @@ def test_logup_large_lookup_verifies(zk):
         bad = words.copy()
         bad[pos] = (int(bad[pos]) + 1) % air.P
         assert z.verify(params, airs, pvs, bad.tobytes()) != 0
+
+
+def _random_bus_air(seed, log_n):
+    """A SyntheticAir with a random preprocessed matrix and random bus messages: every message is sent and received
+    by the same chip (balanced by construction), its fields and multiplicity are random expressions of the row --
+    sums, products, negations of main / preprocessed cells, public values and constants up to degree 2."""
+    rng = np.random.default_rng(seed)
+    width = int(rng.integers(8, 20))
+    sa = air.SyntheticAir(width=width, n_free=max(4, width // 3), n_bool=2, n_boundary=1, seed=seed)
+    b = sa.builder
+    prep_w = int(rng.integers(0, 4))
+    b.prep_width = prep_w
+
+    def leaf():
+        k = int(rng.integers(0, 4 if prep_w else 3))
+        if k == 0:
+            return b.var(int(rng.integers(0, width)))
+        if k == 1:
+            return b.pub(int(rng.integers(0, sa.n_pvs)))
+        if k == 2:
+            return b.const(int(rng.integers(0, air.P)))
+        return b.prep(int(rng.integers(0, prep_w)))
+
+    def expr(deg):
+        e = leaf()
+        for _ in range(int(rng.integers(0, 4))):
+            op = int(rng.integers(0, 4))
+            o = leaf()
+            if op == 0:
+                e = e + o
+            elif op == 1:
+                e = e - o
+            elif op == 2 and deg > 1 and e.deg + o.deg <= deg:
+                e = e * o
+            else:
+                e = -e
+        return e
+
+    for j in range(int(rng.integers(1, 5))):
+        msg = [expr(2) for _ in range(int(rng.integers(1, 7)))]
+        cnt = expr(2)
+        bus = int(rng.integers(0, 50))
+        b.push_interaction(bus, msg, cnt, "send")
+        b.push_interaction(bus, msg, cnt, "receive")
+    if prep_w:
+        b.assert_zero(b.prep(0) * b.var(0) - b.var(0) * b.prep(0))
+    tr, pv = sa.gen_trace(log_n, seed=seed + 7)
+    d = dict(program=sa.program(), log_height=log_n, width=width, n_pvs=len(pv), trace=tr, pvs=pv)
+    if prep_w:
+        d["prep"] = rng.integers(0, air.P, size=(prep_w, 1 << log_n)).astype(np.uint32)
+    return d
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_bus_expressions_match_oracle(zk, ora, seed):
+    params = (1, 0, 6, 3, 3)
+    airs = [_random_bus_air(seed, 5 + seed % 3), _random_bus_air(100 + seed, 3 + seed % 4), _fib(4)]
+    for a in airs:
+        assert air.check_trace(a["program"], a["trace"], a["pvs"], a.get("prep")) == []
+    exp = ora.stark_prove(params, airs)
+    assert ora.stark_verify(params, airs, exp) == 0
+    pk = z.ProvingKey(zk, params, airs)
+    pvs = [a["pvs"] for a in airs]
+    got = pk.prove([zk.upload(a["trace"].reshape(-1)) for a in airs], pvs)
+    assert got == exp.tobytes()
+    assert z.verify(params, pk.verifying_airs(), pvs, got) == 0
