@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-rows", type=int, default=22)
     ap.add_argument("--width", type=int, default=300)
-    ap.add_argument("--cpu-sample-log-rows", type=int, default=15)
+    ap.add_argument("--cpu-sample-log-rows", type=int, default=0,
+                    help="rows of the CPU-baseline sample (0 = by host core count: about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent proofs in flight per GPU, each on its own HIP stream (segments of a chunk are "
@@ -47,7 +48,8 @@ def cpu_baseline(args, sa_kwargs, params):
     import oracle_lib as ora
     from zkvm_prover_amd import air
 
-    s = args.cpu_sample_log_rows
+    cores_avail = os.cpu_count() or 1
+    s = args.cpu_sample_log_rows or (18 if cores_avail >= 128 else 16 if cores_avail >= 32 else 14)
     sa = air.SyntheticAir(**sa_kwargs)
     tr, pv = sa.gen_trace(s, seed=1)
     fa = air.fibonacci_air()
