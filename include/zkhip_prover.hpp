@@ -464,4 +464,28 @@ private:
     }
 };
 
+// crates/verifier/src/verifier.rs:20-85 UniversalVerifier: holds only verifying material (the app's AIR programs,
+// FRI parameters and preprocessed commitments -- no tables, no device) and checks StarkProofs.
+class UniversalVerifier {
+public:
+    // verifier.rs:28-36 setup(path_vm_config, path_root_committed_exe ...): here the app file + openvm.toml
+    static UniversalVerifier setup(const std::string& path_app_exe, const std::string& path_app_config) {
+        return UniversalVerifier(Prover::setup(ProverConfig{path_app_exe, path_app_config}, "verifier"));
+    }
+    // verifier.rs:38-85 verify_stark_proof_with_vk: throws Error::VerifyProof
+    void verify_stark_proof(const StarkProof& sp) const { p_.verify_stark_proof(sp); }
+    bool verify(const StarkProof& sp) const noexcept {
+        try {
+            p_.verify_stark_proof(sp);
+            return true;
+        } catch (...) {
+            return false;
+        }
+    }
+
+private:
+    explicit UniversalVerifier(Prover&& p) : p_(std::move(p)) {}
+    Prover p_;
+};
+
 }  // namespace scroll_zkvm_hip

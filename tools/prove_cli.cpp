@@ -20,10 +20,10 @@ static std::vector<uint8_t> slurp(const std::string& path) {
 int main(int argc, char** argv) {
     try {
         if (argc >= 5 && std::string(argv[1]) == "verify") {
-            Prover prover = Prover::setup(ProverConfig{argv[2], argv[3]}, "cli");
+            UniversalVerifier verifier = UniversalVerifier::setup(argv[2], argv[3]);  // no device needed
             auto js = slurp(argv[4]);
             StarkProof sp = StarkProof::from_json(std::string(js.begin(), js.end()));
-            prover.verify_stark_proof(sp);
+            verifier.verify_stark_proof(sp);
             std::printf("verified: %zu proof bytes, proving_time_mills=%llu\n", sp.proof.size(),
                         (unsigned long long)sp.stat.proving_time_mills);
             return 0;
