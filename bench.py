@@ -260,6 +260,22 @@ def main():
                 others[k] = {"algorithmic_bytes_per_step": alg_b, "ms_per_step": round(ms, 3),
                              "achieved_GBps": round(alg_b / (ms * 1e-3) / 1e9, 1),
                              "frac_of_hbm_peak": round(alg_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # whole-proof VALU roofline from the committed counter pass (tools/pmc_valu.py): the time one proof's VALU
+        # instructions take at the issue rate of the best-utilised kernel, against the measured time per proof
+        valu_roof = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "round01_pmc_valu.json")) as f:
+                pv = json.load(f)
+            if log_n == 22 and width == 300:
+                ms = dt / args.steps * 1e3  # every rank proves `steps` proofs in dt
+                valu_roof = {"valu_wave_instr_per_proof": pv["total_valu_wave_instr_per_proof"],
+                             "ms_at_best_issue_rate": pv["total_ms_at_hash_issue_rate"],
+                             "ms_per_proof_per_gpu": round(ms, 2),
+                             "frac": round(pv["total_ms_at_hash_issue_rate"] / ms, 3),
+                             "note": "profiles/round01_pmc_valu.json: SQ_INSTS_VALU summed over the kernels of one proof, "
+                                     "priced at the row-hash kernel's measured issue rate"}
+        except Exception:
+            pass
         out = {
             "metric": "chunk STARK proofs/sec (2^%d-row trace)" % log_n,
             "value": round(world * args.steps / dt, 4),
@@ -282,6 +298,7 @@ def main():
                                       + (" [DRY RUN: all ranks on one GPU, gloo -- not a measurement]" if dry else "")},
             "roofline": roof,
             "roofline_other_kernels": others,
+            "roofline_valu_whole_proof": valu_roof,
             "stage_ms_single_stream": {k: round(v[1] / 2, 3) for k, v in sorted(stats_alone.items(), key=lambda kv: -kv[1][1])},
             "stage_note": "per-kernel HIP-event times of one proof running alone (measured after the timed region); "
                           "`roofline` is from the timed region itself",

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
 // ---------------------------------------------------------------------------------------------
 // Compile-time shaped variant of the pass kernel for the two tile shapes every transform >= 2^20
 // uses ([2^11 x 8] and [2^10 x 16], 1024 lanes).  Same data flow as k_ntt_pass4 above; what changes
-// is the instruction count (profiles/round01_pmc_valu.json: 1678 VALU instructions per wave, of
+// is the instruction count (1678 VALU instructions per wave before, 1106 now -- profiles/round01_pmc_valu.json --, of
 // which only ~900 are butterflies):
 //  * every LDS address is one per-lane base plus an immediate, every HBM address is a uniform
 //    (scalar) base plus one 32-bit per-lane offset -- no per-element 64-bit multiplies;
