@@ -427,6 +427,7 @@ struct ReduceArgs {
     const uint32_t* ry;
     const uint32_t* off;
     const uint32_t* pts;
+    const uint32_t* inv;  // [row][2] ext: 1 / (z_p - x_row)
     uint32_t* ro;  // M ext
     const uint32_t* tw_fwd;
     uint32_t gen;
@@ -468,19 +469,33 @@ __global__ __launch_bounds__(256) void k_reduced_openings(ReduceArgs a) {
         for (int q = 0; q < 4; q++) acc[q] = madd(acc[q], mmul(ap[q], v));
     }
     const Ext rrow{{acc[0], acc[1], acc[2], acc[3]}};
-    const uint32_t x = mmul(a.gen, root_pow(a.tw_fwd, a.tw_shift, a.h, bitrev32((uint32_t)r, a.h)));
     Ext out = ext_zero();
     if (a.accumulate) {
         uint4 v = reinterpret_cast<const uint4*>(a.ro)[r];
         out = Ext{{v.x, v.y, v.z, v.w}};
     }
     for (uint32_t p = 0; p < a.n_pts; p++) {
-        Ext d = ld_ext(a.pts + 4 * p);
-        d.c[0] = msub(d.c[0], x);
-        Ext u = ext_mul(ext_sub(ld_ext(a.ry + 4 * p), rrow), ext_inv(d));
+        const uint4 iv = reinterpret_cast<const uint4*>(a.inv)[2 * r + p];  // 1 / (z_p - x_r), shared by all matrices of this height
+        Ext u = ext_mul(ext_sub(ld_ext(a.ry + 4 * p), rrow), Ext{{iv.x, iv.y, iv.z, iv.w}});
         out = ext_add(out, ext_mul(u, ld_ext(a.off + 4 * p)));
     }
     reinterpret_cast<uint4*>(a.ro)[r] = make_uint4(out.c[0], out.c[1], out.c[2], out.c[3]);
+}
+
+// inv[r][p] = 1 / (z_p - x_r) for the two opening points of a height, x_r = g * w^bitrev(r): one extension inversion
+// per row (Montgomery's trick on the pair) instead of one per row per matrix per point
+__global__ __launch_bounds__(256) void k_ro_denoms(const uint32_t* pts, const uint32_t* tw_fwd, uint32_t gen, unsigned h,
+                                                   unsigned tw_shift, uint32_t* inv) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ((size_t)1 << h)) return;
+    const uint32_t x = mmul(gen, root_pow(tw_fwd, tw_shift, h, bitrev32((uint32_t)r, h)));
+    Ext d0 = ld_ext(pts), d1 = ld_ext(pts + 4);
+    d0.c[0] = msub(d0.c[0], x);
+    d1.c[0] = msub(d1.c[0], x);
+    const Ext ip = ext_inv(ext_mul(d0, d1));
+    const Ext i0 = ext_mul(ip, d1), i1 = ext_mul(ip, d0);
+    reinterpret_cast<uint4*>(inv)[2 * r] = make_uint4(i0.c[0], i0.c[1], i0.c[2], i0.c[3]);
+    reinterpret_cast<uint4*>(inv)[2 * r + 1] = make_uint4(i1.c[0], i1.c[1], i1.c[2], i1.c[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -593,6 +608,7 @@ struct zkhip_pk {
     uint32_t* d_partial = nullptr;
     uint32_t* d_apow_f = nullptr;   // max width ext
     std::vector<uint32_t*> d_ro;    // per log height (nullptr if none)
+    uint32_t* d_ro_inv = nullptr;   // 2 x 2^hmax ext: inverse denominators of the height being reduced
     std::vector<uint32_t*> d_flayer;  // n_layers+1
     size_t n_prep = 0;              // AIRs with a preprocessed trace
     size_t max_w = 0;               // widest committed matrix
@@ -875,6 +891,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     size_t o_partial = bp.take(max_tiles * max_w * 8 * 4);
     size_t o_apow_f = bp.take((max_w + 1) * 16);
     pk->max_w = max_w;
+    size_t o_ro_inv = bp.take(((size_t)32) << pk->hmax);
     std::vector<size_t> o_ro(pk->hmax + 1, (size_t)-1);
     for (size_t a = 0; a < n_airs; a++)
         if (o_ro[pk->airs[a].h] == (size_t)-1) o_ro[pk->airs[a].h] = bp.take(((size_t)16) << pk->airs[a].h);
@@ -963,6 +980,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     pk->d_weights = (uint32_t*)(base + o_weights);
     pk->d_partial = (uint32_t*)(base + o_partial);
     pk->d_apow_f = (uint32_t*)(base + o_apow_f);
+    pk->d_ro_inv = (uint32_t*)(base + o_ro_inv);
     pk->d_ro.assign(pk->hmax + 1, nullptr);
     for (unsigned h = 0; h <= pk->hmax; h++)
         if (o_ro[h] != (size_t)-1) pk->d_ro[h] = (uint32_t*)(base + o_ro[h]);
@@ -1310,6 +1328,8 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
                 pa.scale = pk->d_pts + 8;
                 KernelScope ks(ctx, "reduce_prep");
                 hipLaunchKernelGGL(k_open_points, dim3(1), dim3(64), 0, st, pa);
+                hipLaunchKernelGGL(k_ro_denoms, dim3((unsigned)((((size_t)1 << it.h) + 255) / 256)), dim3(256), 0, st, pk->d_pts,
+                                   ctx->d_tw_fwd, gen, it.h, ctx->tw_log - it.h, pk->d_ro_inv);
                 pts_lh = it.lh;
             }
             ReducePrep rp;
@@ -1331,6 +1351,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             ra.ry = rp.ry;
             ra.off = rp.off;
             ra.pts = pk->d_pts;
+            ra.inv = pk->d_ro_inv;
             ra.ro = pk->d_ro[it.h];
             ra.tw_fwd = ctx->d_tw_fwd;
             ra.gen = gen;
