@@ -1,0 +1,55 @@
+"""Randomised parity campaign: HIP prover vs CPU oracle on random AIR sets (random constraint DAGs, random bus
+expressions, random preprocessed matrices, random heights / blow-ups / query counts).  Test infrastructure
+(uses oracle/ as the checker).  Usage: python tools/parity_fuzz.py [n_cases] [first_seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import oracle_lib as ora
+import zkvm_prover_amd as z
+from zkvm_prover_amd import air
+
+import test_gpu_logup as tl
+import test_gpu_stark as ts
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+zk = z.Context(0)
+bad, t0 = 0, time.time()
+for case in range(n_cases):
+    seed = seed0 + case
+    rng = np.random.default_rng(seed)
+    params = (int(rng.integers(1, 4)), 0, int(rng.integers(1, 12)), int(rng.integers(0, 6)), int(rng.integers(0, 6)))
+    airs = []
+    for k in range(int(rng.integers(1, 5))):
+        kind = int(rng.integers(0, 4))
+        lh = int(rng.integers(0, 9))
+        if kind == 0:
+            airs.append(tl._random_bus_air(seed * 10 + k, lh))
+        elif kind == 1:
+            airs.append(ts._syn(max(lh, 1), int(rng.integers(8, 40)), 5, seed * 10 + k, n_bool=2, n_boundary=1))
+        elif kind == 2:
+            airs.append(ts._fib(max(lh, 1)))
+        else:
+            airs.append(tl._limb(lh, seed=seed + k))
+    # constraint degree 3 needs blow-up >= 2^1: all our AIRs have degree <= 3
+    try:
+        exp = ora.stark_prove(params, airs)
+        pk = z.ProvingKey(zk, params, airs)
+        pvs = [a["pvs"] for a in airs]
+        got = pk.prove([zk.upload(a["trace"].reshape(-1)) for a in airs], pvs)
+        ok = got == exp.tobytes() and z.verify(params, pk.verifying_airs(), pvs, got) == 0
+        pk.close()
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        print("seed", seed, "exception", repr(e)[:200])
+    if not ok:
+        bad += 1
+        print("MISMATCH seed", seed, params, [(a["log_height"], a["width"]) for a in airs])
+print("%d cases, %d mismatches, %.1f s" % (n_cases, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
