@@ -1,6 +1,6 @@
 """Randomised parity campaign: HIP prover vs CPU oracle on random AIR sets (random constraint DAGs, random bus
 expressions, random preprocessed matrices, random heights / blow-ups / query counts).  Test infrastructure
-(uses oracle/ as the checker).  Usage: python tools/parity_fuzz.py [n_cases] [first_seed]"""
+(uses oracle/ as the checker).  Usage: python tools/parity_fuzz.py [n_cases] [first_seed] [min_log_height] [max_log_height]"""
 import os
 import sys
 import time
@@ -19,6 +19,8 @@ import test_gpu_stark as ts
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+lh_lo = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # log2 of the smallest / largest trace height drawn
+lh_hi = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 zk = z.Context(0)
 bad, t0 = 0, time.time()
 for case in range(n_cases):
@@ -28,7 +30,7 @@ for case in range(n_cases):
     airs = []
     for k in range(int(rng.integers(1, 5))):
         kind = int(rng.integers(0, 4))
-        lh = int(rng.integers(0, 9))
+        lh = int(rng.integers(lh_lo, lh_hi + 1))
         if kind == 0:
             airs.append(tl._random_bus_air(seed * 10 + k, lh))
         elif kind == 1:
