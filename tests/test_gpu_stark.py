@@ -305,3 +305,40 @@ def test_gpu_proofs_match_committed_digests(zk):
         got, _, _ = _prove_gpu(zk, params, airs)
         assert len(got) == 4 * want[name]["words"], name
         assert hashlib.sha256(got).hexdigest() == want[name]["sha256"], name
+
+
+def test_two_contexts_prove_concurrently_from_two_threads(ora):
+    """one context per Prover, different contexts may run concurrently.  Two host threads, each with
+    its own context, stream and proving key, prove different AIR sets at the same time; every proof equals the oracle's."""
+    import threading
+
+    import torch
+
+    params = (1, 0, 8, 3, 4)
+    jobs = [[_syn(10, 40, 10, 21), _fib(8)], [_syn(9, 24, 8, 22), _fib(11), _syn(6, 12, 5, 23, n_bool=2, n_boundary=2)]]
+    want = [ora.stark_prove(params, airs).tobytes() for airs in jobs]
+    errors = []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                ctx = z.Context(0)
+                airs = jobs[i]
+                pk = z.ProvingKey(ctx, params, airs)
+                d = [ctx.upload(a["trace"].reshape(-1)) for a in airs]
+                for _ in range(6):
+                    got = pk.prove(d, [a["pvs"] for a in airs])
+                    if got != want[i]:
+                        errors.append("thread %d: proof differs" % i)
+                pk.close()
+                ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (i, e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []
