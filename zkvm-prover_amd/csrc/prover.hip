@@ -379,14 +379,13 @@ __global__ __launch_bounds__(64) void k_open_finish(const uint32_t* partial, uin
 
 // ---------------------------------------------------------------------------------------------
 // FRI batching: per matrix and point, ro[r] += off_pt * (ry_pt - rrow[r]) / (z_pt - x_r)
-struct ReducePrep {
-    const uint32_t* alpha;   // ext
-    const uint32_t* opened;  // n_pts * width ext (this matrix' opened values)
+// One committed matrix as the FRI-batching kernels see it (static per proving key, commitment order within a height)
+struct RoItem {
+    const uint32_t* mat;   // column-major LDE matrix, stride 2^h
+    uint32_t opened_off;   // ext offset of its opened values: [pt][width]
     uint32_t width, n_pts;
-    uint64_t num_reduced;    // alpha power offset of the first point
-    const uint32_t* apow;    // alpha^k, k <= width (table shared by all matrices of a proof)
-    uint32_t* ry;            // n_pts ext
-    uint32_t* off;           // n_pts ext
+    uint32_t pad;
+    uint64_t num_reduced;  // alpha power offset of its first point
 };
 // out[k] = base^k for k < n, one lane per power (square-and-multiply: any order of exact field products gives the
 // same element as the serial chain)
@@ -394,16 +393,19 @@ __global__ __launch_bounds__(256) void k_ext_powers_par(const uint32_t* base, ui
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) st_ext(out + 4 * (size_t)k, ext_pow(ld_ext(base), k));
 }
-// one wave per matrix: ry_pt = sum_k alpha^k * opened[pt][k] (lane-strided partial sums, shuffle reduction),
-// off_pt = alpha^(num_reduced + pt * width)
-__global__ __launch_bounds__(64) void k_reduce_prep(ReducePrep a) {
+// one wave per matrix (grid = all matrices of the proof): ry_pt = sum_k alpha^k * opened[pt][k] (lane-strided partial
+// sums, shuffle reduction), off_pt = alpha^(num_reduced + pt * width); slot[item] = {ry0, ry1, off0, off1}
+__global__ __launch_bounds__(64) void k_reduce_prep(const RoItem* items, const uint32_t* alpha, const uint32_t* apow,
+                                                    const uint32_t* opened, uint32_t* slots) {
+    const RoItem it = items[blockIdx.x];
     const unsigned lane = threadIdx.x;
+    const uint32_t* op = opened + 4 * (size_t)it.opened_off;
     Ext ry[2] = {ext_zero(), ext_zero()};
-    for (uint32_t k = lane; k < a.width; k += 64) {
-        const Ext ak = ld_ext(a.apow + 4 * (size_t)k);
-        for (uint32_t p = 0; p < a.n_pts; p++) ry[p] = ext_add(ry[p], ext_mul(ak, ld_ext(a.opened + 4 * ((size_t)p * a.width + k))));
+    for (uint32_t k = lane; k < it.width; k += 64) {
+        const Ext ak = ld_ext(apow + 4 * (size_t)k);
+        for (uint32_t p = 0; p < it.n_pts; p++) ry[p] = ext_add(ry[p], ext_mul(ak, ld_ext(op + 4 * ((size_t)p * it.width + k))));
     }
-    for (uint32_t p = 0; p < a.n_pts; p++)
+    for (uint32_t p = 0; p < 2; p++)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             uint32_t v = ry[p].c[q];
@@ -412,72 +414,75 @@ __global__ __launch_bounds__(64) void k_reduce_prep(ReducePrep a) {
             ry[p].c[q] = v;
         }
     if (lane != 0) return;
-    const Ext aw = ld_ext(a.apow + 4 * (size_t)a.width);  // alpha^width
-    Ext off = ext_pow(ld_ext(a.alpha), a.num_reduced);
-    for (uint32_t p = 0; p < a.n_pts; p++) {
-        st_ext(a.ry + 4 * p, ry[p]);
-        st_ext(a.off + 4 * p, off);
+    const Ext aw = ld_ext(apow + 4 * (size_t)it.width);  // alpha^width
+    Ext off = ext_pow(ld_ext(alpha), it.num_reduced);
+    uint32_t* sl = slots + 16 * (size_t)blockIdx.x;
+    for (uint32_t p = 0; p < 2; p++) {
+        st_ext(sl + 4 * p, ry[p]);
+        st_ext(sl + 8 + 4 * p, off);
         off = ext_mul(off, aw);
     }
 }
 
 struct ReduceArgs {
-    const uint32_t* mat;  // column-major LDE matrix, stride M
+    const RoItem* items;   // the matrices of this height, commitment order
+    const uint32_t* slots; // {ry0, ry1, off0, off1} per item (same indexing as items)
+    uint32_t n_items;
     const uint32_t* apow;
-    const uint32_t* ry;
-    const uint32_t* off;
-    const uint32_t* pts;
-    const uint32_t* inv;  // [row][2] ext: 1 / (z_p - x_row)
-    uint32_t* ro;  // M ext
-    const uint32_t* tw_fwd;
-    uint32_t gen;
-    uint32_t width, n_pts;
-    unsigned h, tw_shift;
-    int accumulate;  // 0: ro[r] = ..., 1: ro[r] += ...
+    const uint32_t* inv;   // [row][2] ext: 1 / (z_p - x_row)
+    uint32_t* ro;          // 2^h ext
+    unsigned h;
 };
+// ro[r] = sum over the matrices m of this height and their points p of  off_{m,p} * (ry_{m,p} - rrow_m[r]) / (z_p - x_r),
+// rrow_m[r] = sum_k alpha^k M_m[r][k].  One launch per height: every matrix row is read once, ro is written once.
 __global__ __launch_bounds__(256) void k_reduced_openings(ReduceArgs a) {
     const size_t M = (size_t)1 << a.h;
     size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= M) return;
-    // sum_k apow[k] * mat[k][r]: products of residues are summed in 64 bits, four at a time
-    // (4 p^2 < 2^64), and Montgomery-reduced once per group -- 4 v_mad_u64_u32 per column instead of
-    // 4 full modular multiply-adds; 8 column loads are in flight per lane
-    uint32_t acc[4] = {0, 0, 0, 0};
-    const uint32_t* col = a.mat + r;
-    uint32_t k = 0;
-    for (; k + 8 <= a.width; k += 8) {
-        uint32_t v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = col[(size_t)(k + u) * M];
-#pragma unroll
-        for (int g = 0; g < 8; g += 4) {
-            uint64_t t[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t* ap = a.apow + 4 * (size_t)(k + g + u);
-#pragma unroll
-                for (int q = 0; q < 4; q++) t[q] += (uint64_t)ap[q] * v[g + u];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) acc[q] = madd(acc[q], mred64(t[q]));
-        }
+    Ext inv[2];
+    {
+        const uint4 i0 = reinterpret_cast<const uint4*>(a.inv)[2 * r], i1 = reinterpret_cast<const uint4*>(a.inv)[2 * r + 1];
+        inv[0] = Ext{{i0.x, i0.y, i0.z, i0.w}};
+        inv[1] = Ext{{i1.x, i1.y, i1.z, i1.w}};
     }
-    for (; k < a.width; k++) {
-        const uint32_t v = col[(size_t)k * M];
-        const uint32_t* ap = a.apow + 4 * (size_t)k;
-#pragma unroll
-        for (int q = 0; q < 4; q++) acc[q] = madd(acc[q], mmul(ap[q], v));
-    }
-    const Ext rrow{{acc[0], acc[1], acc[2], acc[3]}};
     Ext out = ext_zero();
-    if (a.accumulate) {
-        uint4 v = reinterpret_cast<const uint4*>(a.ro)[r];
-        out = Ext{{v.x, v.y, v.z, v.w}};
-    }
-    for (uint32_t p = 0; p < a.n_pts; p++) {
-        const uint4 iv = reinterpret_cast<const uint4*>(a.inv)[2 * r + p];  // 1 / (z_p - x_r), shared by all matrices of this height
-        Ext u = ext_mul(ext_sub(ld_ext(a.ry + 4 * p), rrow), Ext{{iv.x, iv.y, iv.z, iv.w}});
-        out = ext_add(out, ext_mul(u, ld_ext(a.off + 4 * p)));
+    for (uint32_t m = 0; m < a.n_items; m++) {
+        const RoItem it = a.items[m];
+        // sum_k apow[k] * mat[k][r]: products of residues are summed in 64 bits, four at a time
+        // (4 p^2 < 2^64), and Montgomery-reduced once per group -- 4 v_mad_u64_u32 per column instead of
+        // 4 full modular multiply-adds; 8 column loads are in flight per lane
+        uint32_t acc[4] = {0, 0, 0, 0};
+        const uint32_t* col = it.mat + r;
+        uint32_t k = 0;
+        for (; k + 8 <= it.width; k += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = col[(size_t)(k + u) * M];
+#pragma unroll
+            for (int g = 0; g < 8; g += 4) {
+                uint64_t t[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t* ap = a.apow + 4 * (size_t)(k + g + u);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) t[q] += (uint64_t)ap[q] * v[g + u];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[q] = madd(acc[q], mred64(t[q]));
+            }
+        }
+        for (; k < it.width; k++) {
+            const uint32_t v = col[(size_t)k * M];
+            const uint32_t* ap = a.apow + 4 * (size_t)k;
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[q] = madd(acc[q], mmul(ap[q], v));
+        }
+        const Ext rrow{{acc[0], acc[1], acc[2], acc[3]}};
+        const uint32_t* sl = a.slots + 16 * (size_t)m;
+        for (uint32_t p = 0; p < it.n_pts; p++) {
+            const Ext u = ext_mul(ext_sub(ld_ext(sl + 4 * p), rrow), inv[p]);
+            out = ext_add(out, ext_mul(u, ld_ext(sl + 8 + 4 * p)));
+        }
     }
     reinterpret_cast<uint4*>(a.ro)[r] = make_uint4(out.c[0], out.c[1], out.c[2], out.c[3]);
 }
@@ -609,6 +614,14 @@ struct zkhip_pk {
     uint32_t* d_apow_f = nullptr;   // max width ext
     std::vector<uint32_t*> d_ro;    // per log height (nullptr if none)
     uint32_t* d_ro_inv = nullptr;   // 2 x 2^hmax ext: inverse denominators of the height being reduced
+    RoItem* d_ro_items = nullptr;   // every committed matrix, grouped by height (ascending), commitment order inside
+    uint32_t* d_ro_slots = nullptr; // 16 words per item
+    struct RoGroup {
+        unsigned lh, h;
+        uint32_t first, n;
+    };
+    std::vector<RoGroup> ro_groups;
+    uint32_t n_ro_items = 0;
     std::vector<uint32_t*> d_flayer;  // n_layers+1
     size_t n_prep = 0;              // AIRs with a preprocessed trace
     size_t max_w = 0;               // widest committed matrix
@@ -892,6 +905,9 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     size_t o_apow_f = bp.take((max_w + 1) * 16);
     pk->max_w = max_w;
     size_t o_ro_inv = bp.take(((size_t)32) << pk->hmax);
+    pk->n_ro_items = (uint32_t)(n_airs + pk->n_prep + pk->n_lu + n_airs * nch);
+    size_t o_ro_items = bp.take(pk->n_ro_items * sizeof(RoItem));
+    size_t o_ro_slots = bp.take((size_t)pk->n_ro_items * 64);
     std::vector<size_t> o_ro(pk->hmax + 1, (size_t)-1);
     for (size_t a = 0; a < n_airs; a++)
         if (o_ro[pk->airs[a].h] == (size_t)-1) o_ro[pk->airs[a].h] = bp.take(((size_t)16) << pk->airs[a].h);
@@ -981,6 +997,49 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     pk->d_partial = (uint32_t*)(base + o_partial);
     pk->d_apow_f = (uint32_t*)(base + o_apow_f);
     pk->d_ro_inv = (uint32_t*)(base + o_ro_inv);
+    pk->d_ro_items = (RoItem*)(base + o_ro_items);
+    pk->d_ro_slots = (uint32_t*)(base + o_ro_slots);
+    {
+        // the matrices in commitment order (main, preprocessed, permutation, quotient chunks) fix every alpha offset;
+        // they are then grouped by height so that one launch reduces a whole height
+        struct HostItem {
+            RoItem it;
+            unsigned lh, h;
+        };
+        std::vector<HostItem> items;
+        std::vector<uint64_t> num_reduced(pk->hmax + 1, 0);
+        for (int round = 0; round < 4; round++)
+            for (size_t a = 0; a < n_airs; a++) {
+                AirPlan& A = pk->airs[a];
+                if (round == 1 && !A.prep_w) continue;
+                if (round == 2 && !A.n_int) continue;
+                const unsigned n_mats = round == 3 ? nch : 1;
+                for (unsigned j = 0; j < n_mats; j++) {
+                    HostItem hi;
+                    hi.it.width = round == 0 ? (uint32_t)A.width : round == 1 ? (uint32_t)A.prep_w : round == 2 ? (uint32_t)A.perm_w : 4u;
+                    hi.it.n_pts = round == 3 ? 1 : 2;
+                    hi.it.mat = round == 0 ? A.d_lde : round == 1 ? A.d_prep_lde : round == 2 ? A.d_perm_lde : A.d_qlde + (size_t)j * 4 * A.M;
+                    hi.it.opened_off = (uint32_t)(round == 0   ? A.opened_main_off
+                                                  : round == 1 ? A.opened_prep_off
+                                                  : round == 2 ? A.opened_perm_off
+                                                               : A.opened_quot_off + 4 * (size_t)j);
+                    hi.it.pad = 0;
+                    hi.it.num_reduced = num_reduced[A.h];
+                    hi.lh = A.lh, hi.h = A.h;
+                    num_reduced[A.h] += (uint64_t)hi.it.width * hi.it.n_pts;
+                    items.push_back(hi);
+                }
+            }
+        std::stable_sort(items.begin(), items.end(), [](const HostItem& x, const HostItem& y) { return x.h < y.h; });
+        std::vector<RoItem> flat;
+        for (size_t i = 0; i < items.size(); i++) {
+            if (pk->ro_groups.empty() || pk->ro_groups.back().h != items[i].h)
+                pk->ro_groups.push_back({items[i].lh, items[i].h, (uint32_t)i, 0u});
+            pk->ro_groups.back().n++;
+            flat.push_back(items[i].it);
+        }
+        if (rc == ZKHIP_OK) rc = upload(ctx, pk->d_ro_items, flat.data(), flat.size() * sizeof(RoItem));
+    }
     pk->d_ro.assign(pk->hmax + 1, nullptr);
     for (unsigned h = 0; h <= pk->hmax; h++)
         if (o_ro[h] != (size_t)-1) pk->d_ro[h] = (uint32_t*)(base + o_ro[h]);
@@ -1277,92 +1336,39 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             const uint32_t np = (uint32_t)pk->max_w + 1;
             hipLaunchKernelGGL(k_ext_powers_par, dim3((np + 255) / 256), dim3(256), 0, st, d_alpha_f, np, pk->d_apow_f);
         }
-        // the matrices in commitment order (main, preprocessed, permutation, quotient chunks) fix every alpha offset;
-        // they are then processed height by height, so the opening points are computed once per height
-        struct RoItem {
-            const uint32_t *mat, *opened;
-            uint32_t W;
-            unsigned n_pts, lh, h;
-            uint64_t num_reduced;
-            int accumulate;
-        };
-        std::vector<RoItem> items;
-        std::vector<uint64_t> num_reduced(hmax + 1, 0);
-        std::vector<char> started(hmax + 1, 0);
-        for (int round = 0; round < 4; round++)
-            for (size_t a = 0; a < n_airs; a++) {
-                AirPlan& A = pk->airs[a];
-                if (round == 1 && !A.prep_w) continue;
-                if (round == 2 && !A.n_int) continue;
-                const unsigned n_mats = round == 3 ? nch : 1;
-                for (unsigned j = 0; j < n_mats; j++) {
-                    RoItem it;
-                    it.W = round == 0 ? (uint32_t)A.width : round == 1 ? (uint32_t)A.prep_w : round == 2 ? (uint32_t)A.perm_w : 4u;
-                    it.n_pts = round == 3 ? 1 : 2;
-                    it.mat = round == 0 ? A.d_lde : round == 1 ? A.d_prep_lde : round == 2 ? A.d_perm_lde : A.d_qlde + (size_t)j * 4 * A.M;
-                    it.opened = pk->d_opened + 4 * (round == 0   ? A.opened_main_off
-                                                    : round == 1 ? A.opened_prep_off
-                                                    : round == 2 ? A.opened_perm_off
-                                                                 : A.opened_quot_off + 4 * (size_t)j);
-                    it.lh = A.lh, it.h = A.h;
-                    it.num_reduced = num_reduced[A.h];
-                    it.accumulate = started[A.h] ? 1 : 0;
-                    started[A.h] = 1;
-                    num_reduced[A.h] += (uint64_t)it.W * it.n_pts;
-                    items.push_back(it);
-                }
-            }
-        std::stable_sort(items.begin(), items.end(), [](const RoItem& x, const RoItem& y) { return x.h < y.h; });
-        unsigned pts_lh = ~0u;
-        for (const RoItem& it : items) {
-            if (it.lh != pts_lh) {  // zeta and zeta * w_N
-                PointsArgs pa;
-                pa.zeta = d_zeta;
-                pa.w_n = two_adic_generator(it.lh);
-                pa.shift = MONTY_ONE;
-                pa.s_pow_n = MONTY_ONE;
-                pa.scale_base = MONTY_ONE;
-                pa.lh = 0;
-                pa.n_pts = 2;
-                pa.pts = pk->d_pts;
-                pa.scale = pk->d_pts + 8;
+        {
+            KernelScope ks(ctx, "reduce_prep");
+            hipLaunchKernelGGL(k_reduce_prep, dim3(pk->n_ro_items), dim3(64), 0, st, pk->d_ro_items, d_alpha_f, pk->d_apow_f,
+                               pk->d_opened, pk->d_ro_slots);
+        }
+        for (const auto& g : pk->ro_groups) {
+            PointsArgs pa;  // zeta and zeta * w_N
+            pa.zeta = d_zeta;
+            pa.w_n = two_adic_generator(g.lh);
+            pa.shift = MONTY_ONE;
+            pa.s_pow_n = MONTY_ONE;
+            pa.scale_base = MONTY_ONE;
+            pa.lh = 0;
+            pa.n_pts = 2;
+            pa.pts = pk->d_pts;
+            pa.scale = pk->d_pts + 8;
+            {
                 KernelScope ks(ctx, "reduce_prep");
                 hipLaunchKernelGGL(k_open_points, dim3(1), dim3(64), 0, st, pa);
-                hipLaunchKernelGGL(k_ro_denoms, dim3((unsigned)((((size_t)1 << it.h) + 255) / 256)), dim3(256), 0, st, pk->d_pts,
-                                   ctx->d_tw_fwd, gen, it.h, ctx->tw_log - it.h, pk->d_ro_inv);
-                pts_lh = it.lh;
-            }
-            ReducePrep rp;
-            rp.alpha = d_alpha_f;
-            rp.opened = it.opened;
-            rp.width = it.W;
-            rp.n_pts = it.n_pts;
-            rp.num_reduced = it.num_reduced;
-            rp.apow = pk->d_apow_f;
-            rp.ry = pk->d_pts + 16;
-            rp.off = pk->d_pts + 24;
-            {
-                KernelScope ks(ctx, "reduce_prep");
-                hipLaunchKernelGGL(k_reduce_prep, dim3(1), dim3(64), 0, st, rp);
+                hipLaunchKernelGGL(k_ro_denoms, dim3((unsigned)((((size_t)1 << g.h) + 255) / 256)), dim3(256), 0, st, pk->d_pts,
+                                   ctx->d_tw_fwd, gen, g.h, ctx->tw_log - g.h, pk->d_ro_inv);
             }
             ReduceArgs ra;
-            ra.mat = it.mat;
+            ra.items = pk->d_ro_items + g.first;
+            ra.slots = pk->d_ro_slots + 16 * (size_t)g.first;
+            ra.n_items = g.n;
             ra.apow = pk->d_apow_f;
-            ra.ry = rp.ry;
-            ra.off = rp.off;
-            ra.pts = pk->d_pts;
             ra.inv = pk->d_ro_inv;
-            ra.ro = pk->d_ro[it.h];
-            ra.tw_fwd = ctx->d_tw_fwd;
-            ra.gen = gen;
-            ra.width = it.W;
-            ra.n_pts = it.n_pts;
-            ra.h = it.h;
-            ra.tw_shift = ctx->tw_log - it.h;
-            ra.accumulate = it.accumulate;
+            ra.ro = pk->d_ro[g.h];
+            ra.h = g.h;
             {
                 KernelScope ks(ctx, "reduced_openings");
-                hipLaunchKernelGGL(k_reduced_openings, dim3((unsigned)(((size_t)1 << it.h) + 255) / 256), dim3(256), 0, st, ra);
+                hipLaunchKernelGGL(k_reduced_openings, dim3((unsigned)((((size_t)1 << g.h) + 255) / 256)), dim3(256), 0, st, ra);
             }
             ZK_HIP_CHECK(ctx, hipGetLastError());
         }
