@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void k_bary_weights(const uint32_t* pts, unsig
 // sums are combined with DPP/shuffle adds and lane 0 stores the wave's partial.  No LDS, no
 // barriers, so the loads of the next column are in flight while the current one is multiplied.
 template <int NPTS, int RK>
-__global__ __launch_bounds__(256) void k_col_reduce(const uint32_t* __restrict__ cols, size_t stride, uint32_t n_cols,
+__global__ __launch_bounds__(256) void k_col_reduce(const uint32_t* const* __restrict__ col_ptrs, uint32_t n_cols,
                                                     unsigned lh, const uint32_t* __restrict__ weights,
                                                     uint32_t* __restrict__ partial) {
     const size_t N = (size_t)1 << lh;
@@ -311,11 +311,11 @@ __global__ __launch_bounds__(256) void k_col_reduce(const uint32_t* __restrict__
 #pragma unroll
     for (int k = 0; k < RK; k++) {
         size_t r = row0 + (size_t)k * 64;
-        x[k] = r < N ? cols[r] : 0u;
+        x[k] = r < N ? col_ptrs[0][r] : 0u;
     }
     for (uint32_t c = 0; c < n_cols; c++) {
         if (c + 1 < n_cols) {
-            const uint32_t* col = cols + (size_t)(c + 1) * stride;
+            const uint32_t* col = col_ptrs[c + 1];  // columns of every matrix of this height: wave-uniform pointer table
 #pragma unroll
             for (int k = 0; k < RK; k++) {
                 size_t r = row0 + (size_t)k * 64;
@@ -354,9 +354,10 @@ __global__ __launch_bounds__(256) void k_col_reduce(const uint32_t* __restrict__
     }
 }
 
-// opened[pt*n_cols + c] = scale[pt] * sum_tiles partial[tile][c][pt]
+// opened[dst[c][pt]] = scale[pt] * sum_tiles partial[tile][c][pt]
 __global__ __launch_bounds__(64) void k_open_finish(const uint32_t* partial, uint32_t n_tiles, uint32_t n_cols,
-                                                    unsigned n_pts, const uint32_t* scale, uint32_t* opened) {
+                                                    unsigned n_pts, const uint32_t* scale, const uint32_t* dst,
+                                                    uint32_t* opened) {
     const uint32_t c = blockIdx.x, p = blockIdx.y, lane = threadIdx.x;
     uint32_t acc[4] = {0, 0, 0, 0};
     for (uint32_t t = lane; t < n_tiles; t += 64) {
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(64) void k_open_finish(const uint32_t* partial, uin
     }
     if (lane == 0) {
         Ext r = ext_mul(Ext{{acc[0], acc[1], acc[2], acc[3]}}, ld_ext(scale + 4 * p));
-        st_ext(opened + 4 * ((size_t)p * n_cols + c), r);
+        st_ext(opened + 4 * (size_t)dst[2 * c + p], r);  // dst: ext index of (column, point) inside the opened-value array
     }
 }
 
@@ -614,6 +615,23 @@ struct zkhip_pk {
     uint32_t* d_apow_f = nullptr;   // max width ext
     std::vector<uint32_t*> d_ro;    // per log height (nullptr if none)
     uint32_t* d_ro_inv = nullptr;   // 2 x 2^hmax ext: inverse denominators of the height being reduced
+    // openings: the columns of all matrices that share barycentric weights (same height, same coset shift) are reduced
+    // by one launch; main-trace columns are patched into the pointer table per proof
+    struct OpenGroup {
+        unsigned lh, n_pts;
+        int chunk;  // -1: trace-like matrices (shift 1, two points), j: quotient chunk j of every AIR of this height
+        uint32_t first, n_cols;
+    };
+    std::vector<OpenGroup> open_groups;
+    std::vector<const uint32_t*> open_ptrs_host;          // pointer table (host copy)
+    struct MainCol {
+        uint32_t index, air, col;
+    };
+    std::vector<MainCol> open_main_cols;                   // table entries that point into the caller's traces
+    const uint32_t** d_open_ptrs = nullptr;
+    const uint32_t** h_open_ptrs_pinned = nullptr;
+    uint32_t* d_open_dst = nullptr;
+    size_t open_total_cols = 0;
     RoItem* d_ro_items = nullptr;   // every committed matrix, grouped by height (ascending), commitment order inside
     uint32_t* d_ro_slots = nullptr; // 16 words per item
     struct RoGroup {
@@ -900,8 +918,33 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     size_t o_opened = bp.take(n_open * 16);
     size_t o_pts = bp.take(64 * 16);
     size_t o_weights = bp.take(2 * max_n * 16);
-    size_t max_tiles = (max_n + 511) / 512;
-    size_t o_partial = bp.take(max_tiles * max_w * 8 * 4);
+    // opening groups (sizes only here; the pointer tables are filled once the workspace is laid out)
+    size_t partial_words = 16;
+    {
+        std::vector<unsigned> lhs;
+        for (size_t a = 0; a < n_airs; a++) lhs.push_back(pk->airs[a].lh);
+        std::sort(lhs.begin(), lhs.end());
+        lhs.erase(std::unique(lhs.begin(), lhs.end()), lhs.end());
+        uint32_t first = 0;
+        for (unsigned lh : lhs)
+            for (int chunk = -1; chunk < (int)nch; chunk++) {
+                uint32_t nc = 0;
+                for (size_t a = 0; a < n_airs; a++) {
+                    const AirPlan& A = pk->airs[a];
+                    if (A.lh != lh) continue;
+                    nc += chunk < 0 ? (uint32_t)(A.width + A.prep_w + A.perm_w) : 4u;
+                }
+                const unsigned n_pts = chunk < 0 ? 2 : 1;
+                pk->open_groups.push_back({lh, n_pts, chunk, first, nc});
+                first += nc;
+                const size_t n_tiles = (((size_t)1 << lh) + 511) / 512;
+                partial_words = std::max(partial_words, n_tiles * nc * n_pts * 4);
+            }
+        pk->open_total_cols = first;
+    }
+    size_t o_partial = bp.take(partial_words * 4);
+    size_t o_open_ptrs = bp.take(pk->open_total_cols * sizeof(uint32_t*) + 16);
+    size_t o_open_dst = bp.take(pk->open_total_cols * 8 + 16);
     size_t o_apow_f = bp.take((max_w + 1) * 16);
     pk->max_w = max_w;
     size_t o_ro_inv = bp.take(((size_t)32) << pk->hmax);
@@ -997,6 +1040,37 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     pk->d_partial = (uint32_t*)(base + o_partial);
     pk->d_apow_f = (uint32_t*)(base + o_apow_f);
     pk->d_ro_inv = (uint32_t*)(base + o_ro_inv);
+    pk->d_open_ptrs = (const uint32_t**)(base + o_open_ptrs);
+    pk->d_open_dst = (uint32_t*)(base + o_open_dst);
+    {
+        std::vector<uint32_t> dst(2 * pk->open_total_cols + 2, 0);
+        pk->open_ptrs_host.assign(pk->open_total_cols + 1, nullptr);
+        for (const auto& g : pk->open_groups) {
+            uint32_t c = g.first;
+            for (size_t a = 0; a < n_airs; a++) {
+                AirPlan& A = pk->airs[a];
+                if (A.lh != g.lh) continue;
+                auto put = [&](const uint32_t* base_ptr, size_t width, size_t opened_off, bool is_main) {
+                    for (size_t k = 0; k < width; k++, c++) {
+                        pk->open_ptrs_host[c] = base_ptr ? base_ptr + k * A.N : nullptr;
+                        if (is_main) pk->open_main_cols.push_back({c, (uint32_t)a, (uint32_t)k});
+                        dst[2 * c] = (uint32_t)(opened_off + k);
+                        dst[2 * c + 1] = (uint32_t)(opened_off + width + k);
+                    }
+                };
+                if (g.chunk < 0) {
+                    put(nullptr, A.width, A.opened_main_off, true);
+                    if (A.prep_w) put(A.d_prep, A.prep_w, A.opened_prep_off, false);
+                    if (A.n_int) put(A.d_perm, A.perm_w, A.opened_perm_off, false);
+                } else {
+                    put(A.d_qnat + (size_t)g.chunk * 4 * A.N, 4, A.opened_quot_off + 4 * (size_t)g.chunk, false);
+                }
+            }
+        }
+        if (rc == ZKHIP_OK) rc = upload(ctx, pk->d_open_dst, dst.data(), 2 * pk->open_total_cols * 4);
+        if (rc == ZKHIP_OK && hipHostMalloc((void**)&pk->h_open_ptrs_pinned, (pk->open_total_cols + 1) * sizeof(uint32_t*), 0) != hipSuccess)
+            rc = set_error(ctx, ZKHIP_ERR_NOMEM, "pinned pointer table");
+    }
     pk->d_ro_items = (RoItem*)(base + o_ro_items);
     pk->d_ro_slots = (uint32_t*)(base + o_ro_slots);
     {
@@ -1080,6 +1154,7 @@ void zkhip_pk_destroy(zkhip_ctx* ctx, zkhip_pk* pk) {
     if (!pk) return;
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (pk->t_main) zkhip_tree_destroy(ctx, pk->t_main);
+    if (pk->h_open_ptrs_pinned) hipHostFree(pk->h_open_ptrs_pinned);
     if (pk->t_perm) zkhip_tree_destroy(ctx, pk->t_perm);
     for (auto& A : pk->airs)
         if (A.t_prep) zkhip_tree_destroy(ctx, A.t_prep);
@@ -1259,20 +1334,33 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     ZK_TRY(transcript_observe(ctx, pk->d_tr, d_root_quot, 8, false));
     ZK_TRY(transcript_sample(ctx, pk->d_tr, d_zeta, nullptr, 4));
 
-    // ---- 3. openings at zeta (and zeta*w for the trace) ----
-    // barycentric weights depend only on (height, coset shift, points): matrices are opened in an order that keeps
-    // equal keys adjacent (AIRs sorted by height; main, preprocessed and permutation matrix of an AIR back to back),
-    // so the two weight kernels run once per distinct key instead of once per matrix
-    unsigned wk_lh = ~0u, wk_pts = 0;
-    uint32_t wk_shift = 0;
-    std::vector<size_t> by_height(n_airs);
-    for (size_t a = 0; a < n_airs; a++) by_height[a] = a;
-    std::stable_sort(by_height.begin(), by_height.end(), [&](size_t x, size_t y) { return pk->airs[x].lh < pk->airs[y].lh; });
-    auto open_matrix = [&](const uint32_t* cols, size_t stride, uint32_t n_cols, unsigned lh, unsigned n_pts,
-                           uint32_t shift, uint32_t* d_out) -> int {
+    // ---- 3. openings at zeta (and zeta*w for the trace-like matrices) ----
+    // Barycentric weights depend only on (height, coset shift, points), so the columns of ALL matrices that share them
+    // -- main, preprocessed and permutation matrices of every AIR of one height; chunk j of every AIR of one height --
+    // are reduced by one launch over a pointer table.  Main-trace columns live in the caller's buffers: their table
+    // entries are refreshed when the caller passes other buffers than last time.
+    {
+        bool changed = false;
+        for (const auto& mc : pk->open_main_cols) {
+            const uint32_t* ptr = d_traces[mc.air] + (size_t)mc.col * pk->airs[mc.air].N;
+            if (pk->open_ptrs_host[mc.index] != ptr) {
+                pk->open_ptrs_host[mc.index] = ptr;
+                changed = true;
+            }
+        }
+        if (changed) {
+            // the pinned staging buffer may still feed the previous proof's copy
+            ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            memcpy(pk->h_open_ptrs_pinned, pk->open_ptrs_host.data(), pk->open_total_cols * sizeof(uint32_t*));
+            ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_open_ptrs, pk->h_open_ptrs_pinned, pk->open_total_cols * sizeof(uint32_t*),
+                                             hipMemcpyHostToDevice, st));
+        }
+    }
+    for (const auto& g : pk->open_groups) {
+        if (g.n_cols == 0) continue;
+        const unsigned lh = g.lh, n_pts = g.n_pts;
         const size_t N = (size_t)1 << lh;
-        const bool same_key = lh == wk_lh && shift == wk_shift && n_pts == wk_pts;
-        wk_lh = lh, wk_shift = shift, wk_pts = n_pts;
+        const uint32_t shift = g.chunk < 0 ? MONTY_ONE : mmul(gen, host_pow(two_adic_generator(lh + b), bitrev32((uint32_t)g.chunk, b)));
         PointsArgs pa;
         pa.zeta = d_zeta;
         pa.w_n = two_adic_generator(lh);
@@ -1283,49 +1371,34 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         pa.n_pts = n_pts;
         pa.pts = pk->d_pts;
         pa.scale = pk->d_pts + 8;
-        if (!same_key) {
+        {
             KernelScope ks(ctx, "open_points");
             hipLaunchKernelGGL(k_open_points, dim3(1), dim3(64), 0, st, pa);
         }
-        if (!same_key) {
+        {
             KernelScope ks(ctx, "bary_weights");
             hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pk->d_pts, n_pts,
                                shift, ctx->d_tw_fwd, lh ? ctx->tw_log - lh : 0, lh, pk->d_weights);
         }
         constexpr int RK = 8;
-        uint32_t n_tiles = (uint32_t)((N + 64 * RK - 1) / (64 * RK));
+        const uint32_t n_tiles = (uint32_t)((N + 64 * RK - 1) / (64 * RK));
         {
             KernelScope ks(ctx, "open_col_reduce");
             dim3 grid((n_tiles + 3) / 4);
             if (n_pts == 2)
-                hipLaunchKernelGGL((k_col_reduce<2, RK>), grid, dim3(256), 0, st, cols, stride, n_cols, lh,
+                hipLaunchKernelGGL((k_col_reduce<2, RK>), grid, dim3(256), 0, st, pk->d_open_ptrs + g.first, g.n_cols, lh,
                                    pk->d_weights, pk->d_partial);
             else
-                hipLaunchKernelGGL((k_col_reduce<1, RK>), grid, dim3(256), 0, st, cols, stride, n_cols, lh,
+                hipLaunchKernelGGL((k_col_reduce<1, RK>), grid, dim3(256), 0, st, pk->d_open_ptrs + g.first, g.n_cols, lh,
                                    pk->d_weights, pk->d_partial);
         }
         {
             KernelScope ks(ctx, "open_finish");
-            hipLaunchKernelGGL(k_open_finish, dim3(n_cols, n_pts), dim3(64), 0, st, pk->d_partial, n_tiles, n_cols,
-                               n_pts, pk->d_pts + 8, d_out);
+            hipLaunchKernelGGL(k_open_finish, dim3(g.n_cols, n_pts), dim3(64), 0, st, pk->d_partial, n_tiles, g.n_cols, n_pts,
+                               pk->d_pts + 8, pk->d_open_dst + 2 * (size_t)g.first, pk->d_opened);
         }
         ZK_HIP_CHECK(ctx, hipGetLastError());
-        return ZKHIP_OK;
-    };
-    for (size_t a : by_height) {
-        AirPlan& A = pk->airs[a];
-        ZK_TRY(open_matrix(d_traces[a], A.N, (uint32_t)A.width, A.lh, 2, MONTY_ONE, pk->d_opened + 4 * A.opened_main_off));
-        if (A.prep_w)
-            ZK_TRY(open_matrix(A.d_prep, A.N, (uint32_t)A.prep_w, A.lh, 2, MONTY_ONE, pk->d_opened + 4 * A.opened_prep_off));
-        if (A.n_int)
-            ZK_TRY(open_matrix(A.d_perm, A.N, (uint32_t)A.perm_w, A.lh, 2, MONTY_ONE, pk->d_opened + 4 * A.opened_perm_off));
     }
-    for (unsigned j = 0; j < nch; j++)
-        for (size_t a : by_height) {
-            AirPlan& A = pk->airs[a];
-            uint32_t sj = mmul(gen, host_pow(two_adic_generator(A.h), bitrev32(j, b)));
-            ZK_TRY(open_matrix(A.d_qnat + (size_t)j * 4 * A.N, A.N, 4, A.lh, 1, sj, pk->d_opened + 4 * (A.opened_quot_off + 4 * (size_t)j)));
-        }
     ZK_TRY(transcript_observe(ctx, pk->d_tr, pk->d_opened, (uint32_t)(4 * pk->n_open), false));
     ZK_TRY(transcript_sample(ctx, pk->d_tr, d_alpha_f, nullptr, 4));
 
