@@ -295,6 +295,7 @@ def main():
                                    "%d queries, PoW %d+%d (SURVEY.md 8(d) cfg #4)"
                                    % (log_n, width, log_n, params[2], params[3], params[4]),
                        "proof_bytes": pk.proof_size, "verified": ok,
+                       "resident_key_bytes_per_pipeline": pk.workspace_bytes,
                        "inflight_per_gpu": n_pipe,
                        "parallelism": "%d independent proof(s) in flight per GPU (one HIP stream each)" % n_pipe + (", RCCL all-gather of commitments + proof gather" if world > 1 else "")
                                       + (" [DRY RUN: all ranks on one GPU, gloo -- not a measurement]" if dry else "")},

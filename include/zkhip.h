@@ -181,6 +181,9 @@ void zkhip_pk_destroy(zkhip_ctx *ctx, zkhip_pk *pk);
 int zkhip_pk_prep_commitment(zkhip_ctx *ctx, const zkhip_pk *pk, size_t air_index, uint32_t out[8]);
 /* exact proof size in bytes for this key (FRI proofs are shape-static) */
 size_t zkhip_proof_size(const zkhip_pk *pk);
+/* bytes of device memory the key keeps resident (LDEs, trees, FRI layers, tables): capacity planning for several
+ * keys / several proofs in flight on one 288 GB device */
+size_t zkhip_pk_workspace_bytes(const zkhip_pk *pk);
 /* d_traces[i]: device, column-major Montgomery trace of AIR i with stride 1<<log_height;
  * pvs[i]: host canonical public values.  Proof bytes (canonical LE u32) are written to the
  * HOST buffer `out`.  Runs entirely on the ctx stream; returns after the final D2H. */

@@ -100,6 +100,7 @@ def load_library():
         "zkhip_pk_destroy": (None, [vp, vp]),
         "zkhip_pk_prep_commitment": (C.c_int, [vp, vp, sz, u32p]),
         "zkhip_proof_size": (sz, [vp]),
+        "zkhip_pk_workspace_bytes": (sz, [vp]),
         "zkhip_prove": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(u32p), C.POINTER(C.c_uint8), sz, C.POINTER(sz)]),
         "zkhip_prove_async": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(u32p)]),
         "zkhip_proof_fetch": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), sz, C.POINTER(sz)]),
@@ -369,6 +370,7 @@ class ProvingKey:
         ctx._check(ctx.lib.zkhip_keygen(ctx.h, C.byref(prm), arr, len(airs), C.byref(h)))
         self.h = h
         self.proof_size = ctx.lib.zkhip_proof_size(h)
+        self.workspace_bytes = ctx.lib.zkhip_pk_workspace_bytes(h)
 
     def prep_commitment(self, air_index):
         """8 canonical words: the verifying-key entry of AIR `air_index`'s preprocessed trace."""

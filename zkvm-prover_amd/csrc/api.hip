@@ -102,7 +102,7 @@ using namespace zk;
 
 extern "C" {
 
-uint32_t zkhip_version(void) { return (0u << 16) | 1u; }
+uint32_t zkhip_version(void) { return (0u << 16) | 2u; }  // 0.2: zkhip_air gained prep_trace / prep_commit
 
 int zkhip_ctx_create(int device, zkhip_ctx** out) {
     if (!out) return ZKHIP_ERR_INVALID;

@@ -1170,6 +1170,7 @@ void zkhip_pk_destroy(zkhip_ctx* ctx, zkhip_pk* pk) {
 }
 
 size_t zkhip_proof_size(const zkhip_pk* pk) { return pk ? pk->proof_words * 4 : 0; }
+size_t zkhip_pk_workspace_bytes(const zkhip_pk* pk) { return pk ? pk->ws_bytes : 0; }
 
 int zkhip_pk_prep_commitment(zkhip_ctx* ctx, const zkhip_pk* pk, size_t air_index, uint32_t out[8]) {
     if (!ctx || !pk || !out || air_index >= pk->airs.size()) return ZKHIP_ERR_INVALID;
