@@ -8,7 +8,7 @@
 //
 // MI355X design points:
 //  * Everything a proof needs is resident: LDEs, trees, FRI layers live in one workspace sized
-//    at keygen (a 2^22 x 300 chunk trace needs ~17 GB of the 288 GB).
+//    at keygen (a 2^22 x 300 chunk trace needs 13.6 GB of the 288 GB; zkhip_pk_workspace_bytes).
 //  * No host round trip inside a proof: the transcript is a device object (transcript.hip), the
 //    challenges are read by the next kernel straight from HBM, PoW nonces are searched on the
 //    device, and the proof is assembled in a device buffer whose layout is static (FRI proofs
