@@ -176,6 +176,10 @@ struct Pass4Args {
     const uint32_t* scale_col;  // [2^log_sub][2^log_f]   N^-1 * s^F
     const uint32_t* scale_row;  // [2^log_sub][2^(log_r-4)] s^(L*j), L = 2^log_f
     const uint32_t* scale_rho;  // [2^log_sub]            s^(L * 2^(log_r-4))
+    // optional per-column base pointers (columns of several matrices transformed as one batch): when set they replace
+    // src + col * src_col_stride (first pass of a transform) / dst + col * dst_col_stride (last pass)
+    const uint32_t* const* src_cols;
+    uint32_t* const* dst_cols;
 };
 
 template <int Q>
@@ -236,8 +240,8 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
     const unsigned col = blockIdx.y;
     const unsigned sub = col & ((1u << a.log_sub) - 1u);
     const size_t mcol = col >> a.log_sub;
-    const uint32_t* src = a.src + mcol * a.src_col_stride + ((size_t)sub << a.log_m);
-    uint32_t* dst = a.dst + mcol * a.dst_col_stride + ((size_t)sub << a.log_m);
+    const uint32_t* src = (a.src_cols ? a.src_cols[mcol] : a.src + mcol * a.src_col_stride) + ((size_t)sub << a.log_m);
+    uint32_t* dst = (a.dst_cols ? a.dst_cols[mcol] : a.dst + mcol * a.dst_col_stride) + ((size_t)sub << a.log_m);
     // tile index; with 8-column tiles the two halves of a 64-byte segment group are given to
     // workgroups b and b+8, which the dispatcher places on the same XCD (shared L2) -- speed only
     unsigned tile = blockIdx.x;
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
             }
         } else {
             // uniform base of the tile + one 32-bit lane offset; register k is 2^(LOG_RQ + log_f) words further
-            const uint32_t* tile_src = a.src + mcol * a.src_col_stride + ((size_t)sub << a.log_m) +
+            const uint32_t* tile_src = (a.src_cols ? a.src_cols[mcol] : a.src + mcol * a.src_col_stride) + ((size_t)sub << a.log_m) +
                                        (size_t)X * a.in_x_stride + F0;
             const uint32_t lane_off = (j << a.log_f) + c;
 #pragma unroll
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
     // ---- write-out: each tile column is one contiguous run of R words; the column of every store is
     // a compile-time constant, so its HBM base is scalar and the LDS address an immediate ----
     const unsigned lo_mask = (1u << a.log_lo) - 1u;
-    uint32_t* dst = a.dst + mcol * a.dst_col_stride + ((size_t)sub << a.log_m) + (size_t)X * a.out_x_stride;
+    uint32_t* dst = (a.dst_cols ? a.dst_cols[mcol] : a.dst + mcol * a.dst_col_stride) + ((size_t)sub << a.log_m) + (size_t)X * a.out_x_stride;
     if constexpr (LOG_R >= 10) {
         const uint32_t* lrow = lv + tid * pitch;
 #pragma unroll
@@ -553,7 +557,8 @@ static unsigned fourstep_split(unsigned log_n, unsigned a[3]) {
 
 static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint32_t* dst, size_t dst_stride,
                             uint32_t* tmp, uint32_t* tmp2, size_t tmp_stride, unsigned log_n, size_t width,
-                            unsigned log_sub, bool inverse, const BrSrc* brsrc = nullptr) {
+                            unsigned log_sub, bool inverse, const BrSrc* brsrc = nullptr,
+                            const uint32_t* const* src_cols = nullptr, uint32_t* const* dst_cols = nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
         const int lds_max = ((17u << P4_MAX_LOG_R) + (1u << (P4_MAX_LOG_R - 1))) * 4;
@@ -632,12 +637,16 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         pa.log_r = a1, pa.log_f = a2, pa.in_x_stride = 0, pa.in_rs = (size_t)1 << a2;
         pa.out_x_stride = 0, pa.out_hi_stride = (size_t)1 << a1, pa.out_lo_stride = 0, pa.log_lo = 0, pa.in_tw = 0;
         first_pass_src();
+        pa.src_cols = src_cols;
         ZK_TRY(launch(pa, src, src_stride, tmp, tmp_stride, 1));
+        pa.src_cols = nullptr, pa.dst_cols = nullptr;
         pa.br_src = 0;
         // pass 2: digit d2 (rows), F = p1; twiddle w_M^(k1 * d2)
         pa.log_r = a2, pa.log_f = a1, pa.in_rs = (size_t)1 << a1, pa.out_hi_stride = (size_t)1 << a2;
         pa.in_tw = 1, pa.log_prev = a1, pa.log_tt = log_n, pa.tw_a = 1, pa.tw_bx = 0;
+        pa.dst_cols = dst_cols;
         ZK_TRY(launch(pa, tmp, tmp_stride, dst, dst_stride, 1));
+        pa.src_cols = nullptr, pa.dst_cols = nullptr;
     } else {
         const unsigned a1 = a[0], a2 = a[1], a3 = a[2];
         // pass 1: rows d1, F = (d2,d3) flat; out (d3, d2, p1)
@@ -645,7 +654,9 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         pa.out_x_stride = 0, pa.log_lo = a3, pa.out_lo_stride = (size_t)1 << (a1 + a2), pa.out_hi_stride = (size_t)1 << a1;
         pa.in_tw = 0;
         first_pass_src();
+        pa.src_cols = src_cols;
         ZK_TRY(launch(pa, src, src_stride, tmp, tmp_stride, 1));
+        pa.src_cols = nullptr, pa.dst_cols = nullptr;
         pa.br_src = 0;
         // pass 2: X = d3, rows d2, F = p1; twiddle w_M^(k1 * (d2*R3 + d3)); out (p1, d3, p2)
         pa.log_r = a2, pa.log_f = a1, pa.in_x_stride = (size_t)1 << (a1 + a2), pa.in_rs = (size_t)1 << a1;
@@ -656,7 +667,9 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         pa.log_r = a3, pa.log_f = a2, pa.in_x_stride = (size_t)1 << (a2 + a3), pa.in_rs = (size_t)1 << a2;
         pa.out_x_stride = (size_t)1 << (a2 + a3), pa.out_hi_stride = (size_t)1 << a3;
         pa.in_tw = 1, pa.log_prev = a2, pa.log_tt = a2 + a3, pa.tw_a = 1, pa.tw_bx = 0;
+        pa.dst_cols = dst_cols;
         ZK_TRY(launch(pa, tmp2, tmp_stride, dst, dst_stride, 1u << a1));
+        pa.src_cols = nullptr, pa.dst_cols = nullptr;
     }
     return ZKHIP_OK;
 }
@@ -933,6 +946,54 @@ int lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* 
     // 4. forward DIF of every coset block in place -> bit-reversed evaluations
     ZK_TRY(ntt_dif_inplace(ctx, d_out, out_stride, d_out, out_stride, log_n, width, added_bits, false));
     return ZKHIP_OK;
+}
+
+// LDE of `n_cols` columns that live in different matrices (per-column device pointer tables) as ONE batch: the
+// chips of a proof that share a height are extended by the same launches.  Four-step sizes only (log_n >= 12).
+int lde_batch_cols(zkhip_ctx* ctx, const uint32_t* const* d_src_cols, uint32_t* const* d_dst_cols, size_t n_cols,
+                   unsigned log_n, unsigned added_bits, uint32_t shift_monty) {
+    if (n_cols == 0) return ZKHIP_OK;
+    if (log_n < P4_MIN_LOG_M) return set_error(ctx, ZKHIP_ERR_INVALID, "lde_batch_cols: transform too small");
+    if (log_n + added_bits > 27) return set_error(ctx, ZKHIP_ERR_INVALID, "LDE size exceeds two-adicity");
+    const size_t n = (size_t)1 << log_n;
+    ZK_TRY(ensure_twiddles(ctx, log_n + added_bits));
+    void* coeffs;
+    ZK_TRY(get_scratch(ctx, 0, n * n_cols * 4, &coeffs));
+    {
+        // inverse transform: columns come from the table, coefficients go to contiguous scratch
+        const bool three = log_n > 2 * p4_log_r_limit();
+        void* tmp;
+        ZK_TRY(get_scratch(ctx, 4, (n << added_bits) * n_cols * 4 * (three ? 2 : 1), &tmp));
+        uint32_t* t1 = (uint32_t*)tmp;
+        uint32_t* t2 = three ? t1 + n * n_cols : nullptr;
+        ZK_TRY(ntt_dif_fourstep(ctx, nullptr, 0, (uint32_t*)coeffs, n, t1, t2, n, log_n, n_cols, 0, true, nullptr, d_src_cols, nullptr));
+    }
+    unsigned a[3];
+    fourstep_split(log_n, a);
+    const unsigned log_f = log_n - a[0], log_rq = a[0] - 4, n_co = 1u << added_bits;
+    const size_t n_col = (size_t)1 << log_f, n_row = (size_t)1 << log_rq;
+    void* tabs;
+    ZK_TRY(get_scratch(ctx, 1, (n_co * (n_col + n_row + 1)) * 4, &tabs));
+    uint32_t* d_col = (uint32_t*)tabs;
+    uint32_t* d_row = d_col + n_co * n_col;
+    uint32_t* d_rho = d_row + n_co * n_row;
+    {
+        KernelScope ks(ctx, "gen_coset_powers");
+        size_t cnt = n_co * (n_col + n_row + 1);
+        uint32_t n_inv = minv(to_monty((uint32_t)(n % P)));
+        hipLaunchKernelGGL(k_gen_lde_scales, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, d_col, d_row,
+                           d_rho, shift_monty, two_adic_generator(log_n + added_bits), n_inv, added_bits, log_f, log_rq);
+    }
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    BrSrc bs{d_col, d_row, d_rho};
+    const size_t per_col = n << added_bits;
+    const bool three = log_n > 2 * p4_log_r_limit();
+    void* tmp;
+    ZK_TRY(get_scratch(ctx, 4, per_col * n_cols * 4 * (three ? 2 : 1), &tmp));
+    uint32_t* t1 = (uint32_t*)tmp;
+    uint32_t* t2 = three ? t1 + per_col * n_cols : nullptr;
+    return ntt_dif_fourstep(ctx, (const uint32_t*)coeffs, n, nullptr, 0, t1, t2, per_col, log_n, n_cols, added_bits, false, &bs,
+                            nullptr, d_dst_cols);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -628,6 +628,17 @@ struct zkhip_pk {
         uint32_t index, air, col;
     };
     std::vector<MainCol> open_main_cols;                   // table entries that point into the caller's traces
+    // coset LDEs: chips of one height (>= 2^12 rows) are extended together; kind 0 = main traces (sources patched per
+    // proof), 1 = permutation traces, 2 + j = quotient chunk j.  The source pointers follow the opening pointers in the
+    // same table; the destination pointers are static.
+    struct LdeGroup {
+        unsigned lh;
+        int kind;
+        uint32_t first, n_cols;  // slice of the pointer tables (sources: after open_total_cols)
+    };
+    std::vector<LdeGroup> lde_groups;
+    size_t lde_total_cols = 0;
+    uint32_t** d_lde_dst = nullptr;
     const uint32_t** d_open_ptrs = nullptr;
     const uint32_t** h_open_ptrs_pinned = nullptr;
     uint32_t* d_open_dst = nullptr;
@@ -941,9 +952,25 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
                 partial_words = std::max(partial_words, n_tiles * nc * n_pts * 4);
             }
         pk->open_total_cols = first;
+        uint32_t lfirst = 0;
+        for (unsigned lh : lhs) {
+            if (lh < 12) continue;  // smaller transforms are single-tile kernels, extended per matrix
+            for (int kind = 0; kind < 2 + (int)nch; kind++) {
+                uint32_t nc = 0;
+                for (size_t a = 0; a < n_airs; a++) {
+                    const AirPlan& A = pk->airs[a];
+                    if (A.lh != lh) continue;
+                    nc += kind == 0 ? (uint32_t)A.width : kind == 1 ? (uint32_t)A.perm_w : 4u;
+                }
+                if (nc) pk->lde_groups.push_back({lh, kind, lfirst, nc});
+                lfirst += nc;
+            }
+        }
+        pk->lde_total_cols = lfirst;
     }
     size_t o_partial = bp.take(partial_words * 4);
-    size_t o_open_ptrs = bp.take(pk->open_total_cols * sizeof(uint32_t*) + 16);
+    size_t o_open_ptrs = bp.take((pk->open_total_cols + pk->lde_total_cols) * sizeof(uint32_t*) + 16);
+    size_t o_lde_dst = bp.take(pk->lde_total_cols * sizeof(uint32_t*) + 16);
     size_t o_open_dst = bp.take(pk->open_total_cols * 8 + 16);
     size_t o_apow_f = bp.take((max_w + 1) * 16);
     pk->max_w = max_w;
@@ -1044,7 +1071,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     pk->d_open_dst = (uint32_t*)(base + o_open_dst);
     {
         std::vector<uint32_t> dst(2 * pk->open_total_cols + 2, 0);
-        pk->open_ptrs_host.assign(pk->open_total_cols + 1, nullptr);
+        pk->open_ptrs_host.assign(pk->open_total_cols + pk->lde_total_cols + 1, nullptr);
         for (const auto& g : pk->open_groups) {
             uint32_t c = g.first;
             for (size_t a = 0; a < n_airs; a++) {
@@ -1068,7 +1095,33 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             }
         }
         if (rc == ZKHIP_OK) rc = upload(ctx, pk->d_open_dst, dst.data(), 2 * pk->open_total_cols * 4);
-        if (rc == ZKHIP_OK && hipHostMalloc((void**)&pk->h_open_ptrs_pinned, (pk->open_total_cols + 1) * sizeof(uint32_t*), 0) != hipSuccess)
+        // LDE groups: sources behind the opening pointers, destinations in their own static table
+        pk->d_lde_dst = (uint32_t**)(base + o_lde_dst);
+        std::vector<uint32_t*> ldst(pk->lde_total_cols + 1, nullptr);
+        for (const auto& g : pk->lde_groups) {
+            uint32_t c = g.first;
+            for (size_t a = 0; a < n_airs; a++) {
+                AirPlan& A = pk->airs[a];
+                if (A.lh != g.lh) continue;
+                const size_t w = g.kind == 0 ? A.width : g.kind == 1 ? A.perm_w : 4;
+                for (size_t k = 0; k < w; k++, c++) {
+                    const uint32_t idx = (uint32_t)(pk->open_total_cols + c);
+                    if (g.kind == 0) {
+                        pk->open_main_cols.push_back({idx, (uint32_t)a, (uint32_t)k});
+                        ldst[c] = A.d_lde + k * A.M;
+                    } else if (g.kind == 1) {
+                        pk->open_ptrs_host[idx] = A.d_perm + k * A.N;
+                        ldst[c] = A.d_perm_lde + k * A.M;
+                    } else {
+                        const size_t j = (size_t)g.kind - 2;
+                        pk->open_ptrs_host[idx] = A.d_qnat + (j * 4 + k) * A.N;
+                        ldst[c] = A.d_qlde + (j * 4 + k) * A.M;
+                    }
+                }
+            }
+        }
+        if (rc == ZKHIP_OK) rc = upload(ctx, pk->d_lde_dst, ldst.data(), pk->lde_total_cols * sizeof(uint32_t*));
+        if (rc == ZKHIP_OK && hipHostMalloc((void**)&pk->h_open_ptrs_pinned, (pk->open_total_cols + pk->lde_total_cols + 1) * sizeof(uint32_t*), 0) != hipSuccess)
             rc = set_error(ctx, ZKHIP_ERR_NOMEM, "pinned pointer table");
     }
     pk->d_ro_items = (RoItem*)(base + o_ro_items);
@@ -1216,11 +1269,46 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         ZK_TRY(transcript_observe(ctx, pk->d_tr, pk->d_preamble, (uint32_t)pre.size(), true));
     }
 
+    for (size_t a = 0; a < n_airs; a++)
+        if (!d_traces[a]) return set_error(ctx, ZKHIP_ERR_INVALID, "missing trace");
+    // pointer tables: main-trace columns live in the caller's buffers; their entries (for the batched LDEs and for the
+    // batched openings) are refreshed when the caller passes other buffers than last time
+    {
+        bool changed = false;
+        for (const auto& mc : pk->open_main_cols) {
+            const uint32_t* ptr = d_traces[mc.air] + (size_t)mc.col * pk->airs[mc.air].N;
+            if (pk->open_ptrs_host[mc.index] != ptr) {
+                pk->open_ptrs_host[mc.index] = ptr;
+                changed = true;
+            }
+        }
+        if (changed) {
+            // the pinned staging buffer may still feed the previous proof's copy
+            const size_t n_ptrs = pk->open_total_cols + pk->lde_total_cols;
+            ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            memcpy(pk->h_open_ptrs_pinned, pk->open_ptrs_host.data(), n_ptrs * sizeof(uint32_t*));
+            ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_open_ptrs, pk->h_open_ptrs_pinned, n_ptrs * sizeof(uint32_t*),
+                                             hipMemcpyHostToDevice, st));
+        }
+    }
+    auto lde_groups_of = [&](int kind_lo, int kind_hi) -> int {
+        for (const auto& g : pk->lde_groups) {
+            if (g.kind < kind_lo || g.kind > kind_hi) continue;
+            uint32_t shift = gen;
+            if (g.kind >= 2) {
+                const uint32_t sj = mmul(gen, host_pow(two_adic_generator(g.lh + b), bitrev32((uint32_t)(g.kind - 2), b)));
+                shift = mmul(gen, minv(sj));
+            }
+            ZK_TRY(lde_batch_cols(ctx, pk->d_open_ptrs + pk->open_total_cols + g.first, pk->d_lde_dst + g.first, g.n_cols, g.lh, b, shift));
+        }
+        return ZKHIP_OK;
+    };
+
     // ---- 1. trace commit: coset LDE + Merkle ----
+    ZK_TRY(lde_groups_of(0, 0));  // chips of >= 2^12 rows, one batch per height
     for (size_t a = 0; a < n_airs; a++) {
         AirPlan& A = pk->airs[a];
-        if (!d_traces[a]) return set_error(ctx, ZKHIP_ERR_INVALID, "missing trace");
-        ZK_TRY(lde_batch(ctx, d_traces[a], A.N, A.d_lde, A.M, A.lh, b, A.width, gen));
+        if (A.lh < 12) ZK_TRY(lde_batch(ctx, d_traces[a], A.N, A.d_lde, A.M, A.lh, b, A.width, gen));
     }
     ZK_TRY(merkle_build(ctx, pk->t_main, false));
     const uint32_t* d_root_main = zkhip_tree_root_device(pk->t_main);
@@ -1270,8 +1358,9 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
                 hipLaunchKernelGGL(k_logup_sums, dim3(rb), dim3(256), 0, st, la);
             }
             ZK_HIP_CHECK(ctx, hipGetLastError());
-            ZK_TRY(lde_batch(ctx, A.d_perm, A.N, A.d_perm_lde, A.M, A.lh, b, A.perm_w, gen));
+            if (A.lh < 12) ZK_TRY(lde_batch(ctx, A.d_perm, A.N, A.d_perm_lde, A.M, A.lh, b, A.perm_w, gen));
         }
+        ZK_TRY(lde_groups_of(1, 1));
         ZK_TRY(merkle_build(ctx, pk->t_perm, false));
         d_root_perm = zkhip_tree_root_device(pk->t_perm);
         ZK_TRY(transcript_observe(ctx, pk->d_tr, d_root_perm, 8, false));
@@ -1326,10 +1415,13 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             uint32_t* nat = A.d_qnat + (size_t)j * 4 * A.N;
             // column k of the chunk starts at q + k*M + j*N
             ZK_TRY(ntt_bitrev_copy(ctx, A.d_q + (size_t)j * A.N, A.M, nat, A.N, A.lh, 4));
-            uint32_t sj = mmul(gen, host_pow(two_adic_generator(A.h), bitrev32(j, b)));
-            ZK_TRY(lde_batch(ctx, nat, A.N, A.d_qlde + (size_t)j * 4 * A.M, A.M, A.lh, b, 4, mmul(gen, minv(sj))));
+            if (A.lh < 12) {
+                uint32_t sj = mmul(gen, host_pow(two_adic_generator(A.h), bitrev32(j, b)));
+                ZK_TRY(lde_batch(ctx, nat, A.N, A.d_qlde + (size_t)j * 4 * A.M, A.M, A.lh, b, 4, mmul(gen, minv(sj))));
+            }
         }
     }
+    ZK_TRY(lde_groups_of(2, 2 + (int)nch - 1));  // chunk j of every chip of one height in one batch
     ZK_TRY(merkle_build(ctx, pk->t_quot, false));
     const uint32_t* d_root_quot = zkhip_tree_root_device(pk->t_quot);
     ZK_TRY(transcript_observe(ctx, pk->d_tr, d_root_quot, 8, false));
@@ -1340,23 +1432,6 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     // -- main, preprocessed and permutation matrices of every AIR of one height; chunk j of every AIR of one height --
     // are reduced by one launch over a pointer table.  Main-trace columns live in the caller's buffers: their table
     // entries are refreshed when the caller passes other buffers than last time.
-    {
-        bool changed = false;
-        for (const auto& mc : pk->open_main_cols) {
-            const uint32_t* ptr = d_traces[mc.air] + (size_t)mc.col * pk->airs[mc.air].N;
-            if (pk->open_ptrs_host[mc.index] != ptr) {
-                pk->open_ptrs_host[mc.index] = ptr;
-                changed = true;
-            }
-        }
-        if (changed) {
-            // the pinned staging buffer may still feed the previous proof's copy
-            ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));
-            memcpy(pk->h_open_ptrs_pinned, pk->open_ptrs_host.data(), pk->open_total_cols * sizeof(uint32_t*));
-            ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_open_ptrs, pk->h_open_ptrs_pinned, pk->open_total_cols * sizeof(uint32_t*),
-                                             hipMemcpyHostToDevice, st));
-        }
-    }
     for (const auto& g : pk->open_groups) {
         if (g.n_cols == 0) continue;
         const unsigned lh = g.lh, n_pts = g.n_pts;

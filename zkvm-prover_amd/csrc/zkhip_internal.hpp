@@ -82,6 +82,9 @@ int ntt_batch(zkhip_ctx* ctx, uint32_t* d_mat, unsigned log_n, size_t width, siz
               bool bitrev_out);
 int lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* d_out, size_t out_stride,
               unsigned log_n, unsigned added_bits, size_t width, uint32_t shift_monty);
+// the same for n_cols columns given by per-column device pointer tables (columns of several matrices, log_n >= 12)
+int lde_batch_cols(zkhip_ctx* ctx, const uint32_t* const* d_src_cols, uint32_t* const* d_dst_cols, size_t n_cols,
+                   unsigned log_n, unsigned added_bits, uint32_t shift_monty);
 int convert_repr(zkhip_ctx* ctx, uint32_t* d, size_t n, bool to_monty);
 int ntt_bitrev_copy(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint32_t* dst, size_t dst_stride,
                     unsigned log_n, size_t width);
