@@ -52,9 +52,7 @@ __global__ __launch_bounds__(256) void k_hash_rows(const uint32_t* const* __rest
 
 // next[i] = compress(prev[2i], prev[2i+1]); with injected matrices: compress(that, sponge(row i))
 __global__ __launch_bounds__(256) void k_compress_layer(const uint32_t* __restrict__ prev,
-                                                        uint32_t* __restrict__ next, size_t n_next,
-                                                        const uint32_t* const* __restrict__ inj_cols,
-                                                        uint32_t n_inj_cols) {
+                                                        uint32_t* __restrict__ next, size_t n_next) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_next) return;
     uint32_t s[16];
@@ -64,19 +62,58 @@ __global__ __launch_bounds__(256) void k_compress_layer(const uint32_t* __restri
         uint4 v = p[q];
         s[4 * q] = v.x, s[4 * q + 1] = v.y, s[4 * q + 2] = v.z, s[4 * q + 3] = v.w;
     }
-    poseidon2_permute(s);  // the unrolled form is 5 % faster here (short kernel, no second call site on the hot path)
-    if (n_inj_cols) {
-        uint32_t h[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) h[k] = 0;
-        absorb_rows(h, inj_cols, n_inj_cols, (uint32_t)i);
-#pragma unroll
-        for (int k = 0; k < 8; k++) s[8 + k] = h[k];
-        poseidon2_permute_rolled(s);
-    }
+    poseidon2_permute(s);  // the unrolled form is 5 % faster here (short kernel, one call site)
     uint4* o = reinterpret_cast<uint4*>(next + i * 8);
     o[0] = make_uint4(s[0], s[1], s[2], s[3]);
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// The layer step with shorter matrices injected: node = compress(compress(left, right), sponge(row i)).  ONE call site
+// of the rolled permutation serves the compression, every 8-column block of the row sponge and the final compression
+// (three inlined copies are ~80 KB of code, more than the instruction cache; with many chips of many heights most rows
+// of a proof are hashed here, not in k_hash_rows).
+__global__ __launch_bounds__(256) void k_compress_layer_inj(const uint32_t* __restrict__ prev, uint32_t* __restrict__ next,
+                                                            size_t n_next, const uint32_t* const* __restrict__ inj_cols,
+                                                            uint32_t n_inj_cols) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_next) return;
+    uint32_t cur[16], node[8];
+    const uint4* p = reinterpret_cast<const uint4*>(prev + i * 16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint4 v = p[q];
+        cur[4 * q] = v.x, cur[4 * q + 1] = v.y, cur[4 * q + 2] = v.z, cur[4 * q + 3] = v.w;
+    }
+    const uint32_t n_blocks = (n_inj_cols + 7) / 8;
+#pragma unroll 1
+    for (uint32_t step = 0; step < n_blocks + 2; step++) {
+        if (step >= 1 && step <= n_blocks) {
+            if (step == 1) {  // the pair is compressed: keep its digest, start the row sponge
+#pragma unroll
+                for (int k = 0; k < 8; k++) node[k] = cur[k];
+#pragma unroll
+                for (int k = 0; k < 16; k++) cur[k] = 0;
+            }
+            const uint32_t j = 8 * (step - 1);
+            if (j + 8 <= n_inj_cols) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) cur[k] = inj_cols[j + k][i];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (j + k < n_inj_cols) cur[k] = inj_cols[j + k][i];
+            }
+        } else if (step == n_blocks + 1) {  // compress(node digest, row digest)
+#pragma unroll
+            for (int k = 0; k < 8; k++) cur[8 + k] = cur[k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) cur[k] = node[k];
+        }
+        poseidon2_permute_rolled(cur);
+    }
+    uint4* o = reinterpret_cast<uint4*>(next + i * 8);
+    o[0] = make_uint4(cur[0], cur[1], cur[2], cur[3]);
+    o[1] = make_uint4(cur[4], cur[5], cur[6], cur[7]);
 }
 
 __global__ void k_permute_batch(uint32_t* states, size_t n) {
@@ -278,10 +315,13 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
             hipLaunchKernelGGL(k_compress_layer_coop, dim3((unsigned)((cnt + 15) / 16)), dim3(256), 0, ctx->stream,
                                t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,
                                d_ptrs ? d_ptrs + t->level_off[level] : nullptr, (uint32_t)t->level_cnt[level]);
+        else if (t->level_cnt[level])
+            hipLaunchKernelGGL(k_compress_layer_inj, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                               t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,
+                               d_ptrs + t->level_off[level], (uint32_t)t->level_cnt[level]);
         else
             hipLaunchKernelGGL(k_compress_layer, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
-                               t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,
-                               d_ptrs ? d_ptrs + t->level_off[level] : nullptr, (uint32_t)t->level_cnt[level]);
+                               t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt);
     }
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
