@@ -25,8 +25,9 @@
  *           commitment is observed in the preamble and opened like the main trace)
  *   n_constraints x node index (asserted zero on every row)
  *   optional: [0x50504B5A, prep_width]
- *   optional: [0x554C4B5A, n_int, n_int x {bus, sign, count node, n_fields, field node...}]
- *             (count / fields = nodes that are expressions of the current row only)
+ *   optional: [0x554C4B5A, n_int, n_int x {bus, sign, count node, n_fields, field node..., group}]
+ *             (count / fields = nodes that are expressions of the current row only; interactions of one group share
+ *              a permutation column group: phi_g = sum of their terms; groups are numbered 0.. in order)
  * LogUp phase: challenges gamma, beta (extension); chal vector = gamma, beta^1..beta^16 as
  * 68 base coordinates; interaction j contributes phi_j = (+/-)count / (gamma + bus + 1 +
  * sum_i beta^(i+1) f_i); the permutation matrix holds phi_j (4 base columns each) and the
@@ -86,6 +87,7 @@ typedef struct {
     uint32_t count; /* node index */
     uint32_t n_fields;
     uint32_t fields[MAX_FIELDS]; /* node indices */
+    uint32_t group;              /* permutation column group */
 } interaction;
 
 typedef struct {
@@ -93,7 +95,8 @@ typedef struct {
     const uint32_t *nodes, *cons;
     uint32_t n_int;
     interaction *ints;
-    size_t perm_width; /* 4 * (n_int + 1), or 0 */
+    uint32_t n_groups;
+    size_t perm_width; /* 4 * (n_groups + 1), or 0 */
     size_t prep_width; /* preprocessed columns, or 0 */
     unsigned char *row_local; /* per node: reachable from an interaction operand (evaluated per trace row) */
 } program;
@@ -132,9 +135,13 @@ static int parse_program(const uint32_t *w, size_t len, size_t width, program *p
                 it->fields[i] = w[q++];
                 if (it->fields[i] >= p->n_nodes) return -1;
             }
+            if (q + 1 > len) return -1;
+            it->group = w[q++];
+            if (it->group != (j == 0 ? 0 : p->ints[j - 1].group) && it->group != (j == 0 ? 0 : p->ints[j - 1].group + 1)) return -1;
         }
+        p->n_groups = p->ints[p->n_int - 1].group + 1;
         if (q != len) return -1;
-        p->perm_width = 4 * ((size_t)p->n_int + 1);
+        p->perm_width = 4 * ((size_t)p->n_groups + 1);
     }
     for (uint32_t i = 0; i < p->n_nodes; i++) {
         uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
@@ -441,11 +448,14 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
                     uint32_t cnt = rv[it->count];
                     if (it->sign) cnt = ora_sub(0, cnt);
                     ext_scale(inv, cnt, phi);
-                    for (int q = 0; q < 4; q++) st[a].perm[(4 * (size_t)j + q) * N + r] = phi[q];
+                    for (int q = 0; q < 4; q++) {  /* the column group accumulates the terms of its interactions */
+                        uint32_t *cell = &st[a].perm[(4 * (size_t)it->group + q) * N + r];
+                        *cell = ora_add(*cell, phi[q]);
+                    }
                     ext_add(rowsum, phi, rowsum);
                 }
                 ext_add(run, rowsum, run);
-                for (int q = 0; q < 4; q++) st[a].perm[(4 * (size_t)pg->n_int + q) * N + r] = run[q];
+                for (int q = 0; q < 4; q++) st[a].perm[(4 * (size_t)pg->n_groups + q) * N + r] = run[q];
             }
             free(rv);
             memcpy(st[a].exposed, run, 16);

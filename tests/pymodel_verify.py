@@ -75,6 +75,7 @@ class Program:
             need(q + 2 <= len(w) and w[q] == LOGUP_MAGIC, "trailing words")
             n_int = w[q + 1]
             q += 2
+            groups = []
             need(n_int > 0, "empty interaction section")
             for _ in range(n_int):
                 need(q + 4 <= len(w), "short interaction")
@@ -83,8 +84,13 @@ class Program:
                 need(sign <= 1 and 1 <= nf <= MAX_FIELDS and q + nf <= len(w) and bus < P - 1, "bad interaction")
                 self.ints.append((bus, sign, count, w[q:q + nf]))
                 q += nf
+                need(q < len(w), "short interaction")
+                prev = groups[-1] if groups else 0
+                need(w[q] == prev or (groups and w[q] == prev + 1), "group order")
+                groups.append(w[q])
+                q += 1
             need(q == len(w), "trailing words")
-        self.perm_width = 4 * (len(self.ints) + 1) if self.ints else 0
+        self.perm_width = 4 * (groups[-1] + 2) if self.ints else 0
         deg = []
         for i, (op, a, b) in enumerate(self.nodes):
             if op == VAR:

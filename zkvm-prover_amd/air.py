@@ -147,16 +147,38 @@ class AirBuilder:
             self.interactions = []
         self.interactions.append((bus, 0 if kind == "send" else 1, count, fields))
 
+    # extension-field expressions: 4 base coordinates (None = zero), x^4 = 11
+    def _ext_mul(self, a, b):
+        out = [None] * 4
+        for i in range(4):
+            for j in range(4):
+                if a[i] is None or b[j] is None:
+                    continue
+                t = a[i] * b[j]
+                if i + j >= 4:
+                    t = t * EXT_W
+                m = (i + j) % 4
+                out[m] = t if out[m] is None else out[m] + t
+        return out
+
+    def _ext_add(self, a, b):
+        return [x if y is None else (y if x is None else x + y) for x, y in zip(a, b)]
+
     def finalize_interactions(self):
-        """Appends the LogUp constraints (as base-field constraints on the coordinates of the extension
-        values) for the interactions pushed so far.  Permutation matrix layout: interaction j owns base
-        columns 4j..4j+3 (phi_j = sign*count / denominator), the running sum owns the last 4."""
+        """Appends the LogUp constraints (as base-field constraints on the coordinates of the extension values) for
+        the interactions pushed so far.  Interactions are packed greedily into GROUPS as far as the constraint-degree
+        budget allows (like OpenVM's interaction chunking): group g owns base columns 4g..4g+3 of the permutation
+        matrix and holds phi_g = sum_{j in g} sign_j*count_j / den_j, constrained by
+            phi_g * prod_j den_j = sum_j sign_j*count_j * prod_{k != j} den_k;
+        the running sum of all phi_g owns the last 4 columns.  With degree-1 message fields and a degree budget of 3
+        two interactions share a column group: half the permutation columns to extend, hash and open."""
         ints = getattr(self, "interactions", [])
         if not ints or getattr(self, "_logup_done", False):
             return
         self._logup_done = True
-        n_int = len(ints)
-        for j, (bus, sign, count, fields) in enumerate(ints):
+        budget = getattr(self, "max_constraint_degree", 3)
+        dens, dds = [], []
+        for (bus, sign, count, fields) in ints:
             # denominator coordinates d_k = gamma_k + [k==0](bus+1) + sum_i beta^(i+1)_k * f_i
             d = []
             for k in range(4):
@@ -166,26 +188,47 @@ class AirBuilder:
                 for i, f in enumerate(fields):
                     e = e + self.chal(4 * (i + 1) + k) * f
                 d.append(e)
-            phi = [self.perm(4 * j + k) for k in range(4)]
+            dens.append(d)
+            dds.append(max([f.deg for f in fields] + [0]))
+        groups = []
+        for j in range(len(ints)):
+            placed = False
+            if groups and len(groups[-1]) < 4:
+                g = groups[-1] + [j]
+                dsum = sum(dds[k] for k in g)
+                if 1 + dsum <= budget and all(ints[k][2].deg + dsum - dds[k] <= budget for k in g):
+                    groups[-1] = g
+                    placed = True
+            if not placed:
+                groups.append([j])
+        self.interaction_groups = [0] * len(ints)
+        for gi, g in enumerate(groups):
+            for j in g:
+                self.interaction_groups[j] = gi
+        n_grp = len(groups)
+        for gi, g in enumerate(groups):
+            phi = [self.perm(4 * gi + k) for k in range(4)]
+            lhs = phi
+            for j in g:
+                lhs = self._ext_mul(lhs, dens[j])
+            rhs = [None] * 4
+            for j in g:
+                bus, sign, count, fields = ints[j]
+                term = [count if sign == 0 else -count, None, None, None]
+                for k in g:
+                    if k != j:
+                        term = self._ext_mul(term, dens[k])
+                rhs = self._ext_add(rhs, term)
             for m in range(4):
-                lo = None
-                for a in range(4):
-                    for b in range(4):
-                        if a + b == m or a + b == m + 4:
-                            t = phi[a] * d[b]
-                            if a + b == m + 4:
-                                t = t * EXT_W
-                            lo = t if lo is None else lo + t
-                if m == 0:
-                    lo = (lo - count) if sign == 0 else (lo + count)
-                self.assert_zero(lo)
-        s_loc = [self.perm(4 * n_int + k) for k in range(4)]
-        s_nxt = [self.perm(4 * n_int + k, 1) for k in range(4)]
+                e = lhs[m] if rhs[m] is None else lhs[m] - rhs[m]
+                self.assert_zero(e)
+        s_loc = [self.perm(4 * n_grp + k) for k in range(4)]
+        s_nxt = [self.perm(4 * n_grp + k, 1) for k in range(4)]
         for k in range(4):
             row_sum, nxt_sum = None, None
-            for j in range(n_int):
-                row_sum = self.perm(4 * j + k) if row_sum is None else row_sum + self.perm(4 * j + k)
-                nxt_sum = self.perm(4 * j + k, 1) if nxt_sum is None else nxt_sum + self.perm(4 * j + k, 1)
+            for gi in range(n_grp):
+                row_sum = self.perm(4 * gi + k) if row_sum is None else row_sum + self.perm(4 * gi + k)
+                nxt_sum = self.perm(4 * gi + k, 1) if nxt_sum is None else nxt_sum + self.perm(4 * gi + k, 1)
             self.when_first_row(s_loc[k] - row_sum)
             self.when_transition(s_nxt[k] - s_loc[k] - nxt_sum)
             self.when_last_row(s_loc[k] - self.exposed(k))
@@ -224,10 +267,11 @@ class AirBuilder:
             words += [PREP_MAGIC, self.prep_width]
         ints = getattr(self, "interactions", [])
         if ints:
-            # trailing section: [LOGUP_MAGIC, n_int, {bus, sign, count node, n_fields, field nodes}]
+            # trailing section: [LOGUP_MAGIC, n_int, {bus, sign, count node, n_fields, field nodes, group}]
+            # (groups are numbered 0.. in order; interaction j adds its term to permutation column group `group`)
             words += [LOGUP_MAGIC, len(ints)]
-            for bus, sign, count, fields in ints:
-                words += [bus, sign, count.idx, len(fields)] + [f.idx for f in fields]
+            for j, (bus, sign, count, fields) in enumerate(ints):
+                words += [bus, sign, count.idx, len(fields)] + [f.idx for f in fields] + [self.interaction_groups[j]]
         return np.array(words, dtype=np.uint32)
 
 

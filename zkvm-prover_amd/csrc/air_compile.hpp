@@ -39,6 +39,7 @@ struct Interaction {
     uint32_t bus = 0, sign = 0, n_fields = 0;
     uint32_t count = 0;
     uint32_t fields[LOGUP_MAX_FIELDS] = {};
+    uint32_t group = 0;  // permutation column group: phi_group = sum of the terms of its interactions
 };
 
 struct AirProgram {
@@ -48,7 +49,8 @@ struct AirProgram {
     unsigned max_degree = 0;
     std::vector<Interaction> ints;
     size_t prep_width = 0;
-    size_t perm_width() const { return ints.empty() ? 0 : 4 * (ints.size() + 1); }
+    size_t n_groups() const { return ints.empty() ? 0 : (size_t)ints.back().group + 1; }
+    size_t perm_width() const { return ints.empty() ? 0 : 4 * (n_groups() + 1); }
 };
 
 inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p, std::string* err) {
@@ -91,6 +93,10 @@ inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p,
                 it.fields[i] = w[q++];
                 if (it.fields[i] >= p->n_nodes) return fail("interaction field node out of range");
             }
+            if (q + 1 > len) return fail("truncated interaction");
+            it.group = w[q++];
+            const uint32_t prev = j ? p->ints[j - 1].group : 0;
+            if (it.group != prev && (j == 0 || it.group != prev + 1)) return fail("interaction groups must be numbered in order");
         }
         if (q != len) return fail("AIR program length mismatch");
     }

@@ -157,7 +157,8 @@ __global__ void k_logup_chal(const uint32_t* gb, uint32_t* lchal) {
 // lowering of air_compile.hpp with the operands as roots: fields first, count last).  Descriptor table on the
 // device, LU_STRIDE words per interaction:
 //   [0] first instruction  [1] n_instr  [2] bus+1 (Montgomery)  [3] sign  [4] n_fields  [5] first constant
-constexpr unsigned LU_STRIDE = 6;
+//   [6] permutation column group (consecutive interactions of one group share a phi column: their terms add)
+constexpr unsigned LU_STRIDE = 7;
 constexpr unsigned LU_BS = 256;
 struct LogupArgs {
     const uint32_t* trace;  // column-major, stride N, Montgomery
@@ -169,11 +170,11 @@ struct LogupArgs {
     const uint32_t* lchal;
     uint32_t* den;   // n_int x N extension elements, [j][r]
     uint32_t* num;   // n_int x N signed multiplicities
-    uint32_t* perm;  // 4 (n_int + 1) columns x N
+    uint32_t* perm;  // 4 (n_groups + 1) columns x N
     uint32_t* sums;  // N extension elements: row sums, then (after the scan) the running sum
     uint32_t* expo;  // 4 words
     size_t N;
-    uint32_t n_int;
+    uint32_t n_int, n_groups;
 };
 // grid (rows / 256, n_int): denominator gamma + bus + 1 + sum_i beta^(i+1) f_i and numerator +-count of one row
 __global__ __launch_bounds__(LU_BS) void k_logup_denoms(LogupArgs a) {
@@ -220,13 +221,17 @@ __global__ __launch_bounds__(LU_BS) void k_logup_denoms(LogupArgs a) {
 __global__ __launch_bounds__(256) void k_logup_rows(LogupArgs a) {
     const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= a.N) return;
-    Ext sum = ext_zero();
+    Ext sum = ext_zero(), grp = ext_zero();
     for (uint32_t j = 0; j < a.n_int; j++) {
         const uint4 v = reinterpret_cast<const uint4*>(a.den)[(size_t)j * a.N + r];
-        const Ext phi{{v.x, v.y, v.z, v.w}};
+        grp = ext_add(grp, Ext{{v.x, v.y, v.z, v.w}});
+        const uint32_t g = a.tab[(size_t)j * LU_STRIDE + 6];
+        if (j + 1 == a.n_int || a.tab[(size_t)(j + 1) * LU_STRIDE + 6] != g) {  // last interaction of its group
 #pragma unroll
-        for (int q = 0; q < 4; q++) a.perm[(size_t)(4 * j + q) * a.N + r] = phi.c[q];
-        sum = ext_add(sum, phi);
+            for (int q = 0; q < 4; q++) a.perm[(size_t)(4 * g + q) * a.N + r] = grp.c[q];
+            sum = ext_add(sum, grp);
+            grp = ext_zero();
+        }
     }
     reinterpret_cast<uint4*>(a.sums)[r] = make_uint4(sum.c[0], sum.c[1], sum.c[2], sum.c[3]);
 }
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256) void k_logup_sums(LogupArgs a) {
     const uint32_t c[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        a.perm[(size_t)(4 * a.n_int + q) * a.N + r] = c[q];
+        a.perm[(size_t)(4 * a.n_groups + q) * a.N + r] = c[q];
         if (r == a.N - 1) a.expo[q] = c[q];
     }
 }
@@ -904,7 +909,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
                     return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + " interaction " + std::to_string(j) + ": " + err);
                 }
                 const uint32_t desc[LU_STRIDE] = {(uint32_t)(lu[a].code.size() / 3), (uint32_t)(cj.code.size() / 3), to_monty(it.bus + 1),
-                                                  it.sign, it.n_fields, (uint32_t)lu[a].consts.size()};
+                                                  it.sign, it.n_fields, (uint32_t)lu[a].consts.size(), it.group};
                 lu[a].tab.insert(lu[a].tab.end(), desc, desc + LU_STRIDE);
                 lu[a].code.insert(lu[a].code.end(), cj.code.begin(), cj.code.end());
                 lu[a].consts.insert(lu[a].consts.end(), cj.consts.begin(), cj.consts.end());
@@ -1342,6 +1347,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             la.expo = pk->d_exposed + 4 * A.lu_index;
             la.N = A.N;
             la.n_int = A.n_int;
+            la.n_groups = (uint32_t)A.prog.n_groups();
             const unsigned rb = (unsigned)((A.N + 255) / 256);
             {
                 KernelScope ks(ctx, "logup_denoms");
