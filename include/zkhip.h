@@ -87,6 +87,19 @@ int zkhip_lde_batch(zkhip_ctx *ctx, const uint32_t *d_in, size_t in_stride, uint
 /* permutes n independent 16-word states, laid out state-major [n][16] */
 int zkhip_poseidon2_permute_batch(zkhip_ctx *ctx, uint32_t *d_states, size_t n);
 
+/* ---- device-side trace generation (the reference's GPU backend fills chip traces on the
+ *      device, AGENTS.md:183-187) ---- */
+/* Trace of the Poseidon2 AIR (one permutation per row; the structure of p3-poseidon2-air 0.4.3 as OpenVM instantiates
+ * it: one committed x^3 register per S-box, every constraint of degree <= 3; Cargo.lock p3-poseidon2-air /
+ * openvm-poseidon2-air).  Columns: inputs[16] | 4 x {sbox[16], post[16]} | 13 x {sbox, post_sbox} | 4 x {sbox[16],
+ * post[16]}; the last 16 columns are the permutation's output.  d_inputs: device, [n_perms][16] Montgomery;
+ * d_trace: device, ZKHIP_POSEIDON2_AIR_WIDTH columns with stride 1<<log_height, Montgomery -- the layout zkhip_prove
+ * takes.  Rows >= n_perms hold the permutation of the zero state (valid rows).  The matching constraint program is
+ * zkvm-prover_amd/air.py poseidon2_air(). */
+#define ZKHIP_POSEIDON2_AIR_WIDTH 298
+int zkhip_poseidon2_air_tracegen(zkhip_ctx *ctx, const uint32_t *d_inputs, size_t n_perms, unsigned log_height,
+                                 uint32_t *d_trace);
+
 typedef struct {
     const uint32_t *data; /* device, column-major, Montgomery */
     size_t stride;

@@ -151,3 +151,47 @@ void ora_compress(const uint32_t l[8], const uint32_t r[8], uint32_t out[8]) {
     ora_poseidon2_permute(s);
     memcpy(out, s, 32);
 }
+
+/* Trace of the Poseidon2 AIR (one permutation per row; the structure of p3-poseidon2-air 0.4.3 with one S-box register,
+ * Cargo.lock: p3-poseidon2-air / openvm-poseidon2-air): columns
+ *   inputs[16] | 4 x { sbox[16] = (s+rc)^3, post[16] } | 13 x { sbox, post_sbox } | 4 x { sbox[16], post[16] }
+ * column-major, stride N = 2^log_height, canonical.  Rows >= n_perms hold the permutation of the zero state (valid rows).
+ * The last 16 columns are the permutation's output. */
+void ora_poseidon2_air_trace(const uint32_t *inputs, size_t n_perms, unsigned log_height, uint32_t *trace) {
+    const uint32_t *rc = ora_poseidon2_round_constants();
+    if (!g_diag_ready) gen_diag();
+    const size_t N = (size_t)1 << log_height;
+    for (size_t r = 0; r < N; r++) {
+        uint32_t s[16];
+        size_t col = 0;
+        for (int i = 0; i < 16; i++) {
+            s[i] = r < n_perms ? inputs[r * 16 + i] : 0;
+            trace[(col++) * N + r] = s[i];
+        }
+        external_linear(s);
+        for (int half = 0; half < 2; half++) {
+            for (int rd = 0; rd < RF_HALF; rd++) {
+                const uint32_t *k = rc + (half ? RF_HALF * 16 + RP : 0) + rd * 16;
+                for (int i = 0; i < 16; i++) {
+                    uint32_t y = ora_add(s[i], k[i]);
+                    uint32_t y3 = ora_mul(ora_mul(y, y), y);
+                    trace[(col + i) * N + r] = y3;
+                    s[i] = ora_mul(ora_mul(y3, y3), y);
+                }
+                external_linear(s);
+                for (int i = 0; i < 16; i++) trace[(col + 16 + i) * N + r] = s[i];
+                col += 32;
+            }
+            if (half == 0) {
+                for (int rd = 0; rd < RP; rd++) {
+                    uint32_t y = ora_add(s[0], rc[RF_HALF * 16 + rd]);
+                    uint32_t y3 = ora_mul(ora_mul(y, y), y);
+                    s[0] = ora_mul(ora_mul(y3, y3), y);
+                    trace[(col++) * N + r] = y3;
+                    trace[(col++) * N + r] = s[0];
+                    internal_linear(s);
+                }
+            }
+        }
+    }
+}

@@ -72,6 +72,10 @@ void ora_poseidon2_permute(uint32_t state[16]);
 void ora_hash_slice(const uint32_t *in, size_t len, uint32_t out[8]);
 /* TruncatedPermutation<_,2,8,16> */
 void ora_compress(const uint32_t l[8], const uint32_t r[8], uint32_t out[8]);
+/* trace of the Poseidon2 AIR (298 columns, one permutation per row; p3-poseidon2-air layout with one S-box register):
+ * inputs [n_perms][16] canonical, trace column-major with stride 2^log_height, rows >= n_perms permute the zero state */
+#define ORA_POSEIDON2_AIR_WIDTH 298
+void ora_poseidon2_air_trace(const uint32_t *inputs, size_t n_perms, unsigned log_height, uint32_t *trace);
 
 /* ---- MerkleTreeMmcs over column-major matrices of (possibly) mixed heights ---- */
 typedef struct {

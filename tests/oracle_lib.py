@@ -12,6 +12,14 @@ _LIB = None
 P = 2013265921
 
 
+def poseidon2_air_trace(inputs, log_height):
+    """Oracle trace (298 x 2^log_height, canonical, column-major) of the Poseidon2 AIR for inputs [n][16]."""
+    inputs = np.ascontiguousarray(inputs, dtype=np.uint32).reshape(-1, 16)
+    out = np.zeros((298, 1 << log_height), dtype=np.uint32)
+    lib().ora_poseidon2_air_trace(p32(inputs), inputs.shape[0], log_height, p32(out))
+    return out
+
+
 class OraMatrix(C.Structure):
     _fields_ = [("data", C.c_void_p), ("stride", C.c_size_t), ("log_height", C.c_uint), ("width", C.c_size_t)]
 
@@ -62,6 +70,7 @@ def lib():
         l.ora_poseidon2_permute.argtypes = [u32p]
         l.ora_hash_slice.argtypes = [u32p, sz, u32p]
         l.ora_compress.argtypes = [u32p, u32p, u32p]
+        l.ora_poseidon2_air_trace.argtypes = [u32p, sz, C.c_uint, u32p]
         l.ora_mmcs_commit.restype = C.c_void_p
         l.ora_mmcs_commit.argtypes = [C.POINTER(OraMatrix), sz, u32p]
         l.ora_tree_log_height.restype = C.c_uint

@@ -1,0 +1,78 @@
+"""GPU: device-side trace generation of the Poseidon2 AIR (zkhip_poseidon2_air_tracegen) -- the trace equals the
+oracle's cell for cell, proofs made from the device-resident trace equal the oracle's byte for byte, and at a size
+the oracle does not reach the trace is checked through the permutation kernel and sampled rows of the AIR."""
+import numpy as np
+import pytest
+
+import zkvm_prover_amd as z
+from zkvm_prover_amd import air
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+NOPV = np.zeros(0, np.uint32)
+
+
+@pytest.mark.parametrize("log_n,n_perms", [(0, 1), (0, 0), (3, 8), (6, 50), (9, 512), (12, 4000), (10, 0)])
+def test_device_trace_equals_oracle(zk, log_n, n_perms):
+    rng = np.random.default_rng(100 + log_n)
+    inputs = O.rand_field(rng, (n_perms, 16))
+    exp = O.poseidon2_air_trace(inputs, log_n)
+    d_in = zk.upload(inputs.reshape(-1)) if n_perms else zk.upload(np.zeros(16, np.uint32))[:0]
+    d_tr = zk.poseidon2_air_tracegen(d_in, log_n)
+    got = zk.download(d_tr).reshape(298, 1 << log_n)
+    assert (got == exp).all()
+
+
+@pytest.mark.parametrize("jit", ["interpreter", "jit"])
+def test_proof_from_device_trace_equals_oracle(zk, ora, jit, monkeypatch):
+    monkeypatch.setenv("ZKHIP_NO_JIT" if jit == "interpreter" else "ZKHIP_FORCE_JIT", "1")
+    params = (1, 0, 8, 3, 4)
+    rng = np.random.default_rng(5)
+    inputs = O.rand_field(rng, (200, 16))
+    tr = O.poseidon2_air_trace(inputs, 8)
+    ftr, fpv = air.fibonacci_trace(5)
+    airs = [dict(program=air.poseidon2_air().program(), log_height=8, width=298, n_pvs=0, trace=tr, pvs=NOPV),
+            dict(program=air.fibonacci_air().program(), log_height=5, width=2, n_pvs=3, trace=ftr, pvs=fpv)]
+    pvs = [a["pvs"] for a in airs]
+    exp = ora.stark_prove(params, airs)
+    pk = z.ProvingKey(zk, params, airs)
+    d_traces = [zk.poseidon2_air_tracegen(zk.upload(inputs.reshape(-1)), 8), zk.upload(ftr.reshape(-1))]
+    zk.profile_reset()
+    zk.profile_enable(True)
+    got = pk.prove(d_traces, pvs)
+    zk.profile_enable(False)
+    assert got == exp.tobytes()
+    assert z.verify(params, airs, pvs, got) == 0
+    # the Poseidon2 AIR does not compress into shape classes: the straight-line form of the whole DAG must have been
+    # compiled (no silent fall-back to the interpreter)
+    labels = zk.profile_read()
+    assert ("quotient_eval_jit" in labels) == (jit == "jit"), sorted(labels)
+
+
+def test_large_device_trace_properties_and_proof(zk):
+    import torch
+
+    log_n = 16
+    n = (1 << log_n) - 77
+    rng = np.random.default_rng(8)
+    inputs = O.rand_field(rng, (n, 16))
+    d_in = zk.upload(inputs.reshape(-1))
+    d_tr = zk.poseidon2_air_tracegen(d_in, log_n)
+    tr = d_tr.view(298, 1 << log_n)
+    # inputs and outputs: the first / last 16 columns against the batch permutation kernel
+    d_st = torch.zeros((1 << log_n, 16), dtype=torch.int32, device=d_in.device)
+    d_st[:n] = d_in.view(n, 16)
+    assert torch.equal(tr[:16].t().contiguous(), d_st)
+    zk.poseidon2_permute_batch(d_st, 1 << log_n)
+    zk.sync()
+    assert torch.equal(tr[-16:].t().contiguous(), d_st)
+    # sampled rows satisfy every constraint (rows are independent: no transition constraints)
+    rows = np.concatenate([[0, n - 1, n, (1 << log_n) - 1], rng.integers(0, 1 << log_n, 12)])
+    sample = zk.download(tr[:, torch.from_numpy(rows).to(d_in.device)].contiguous().view(-1)).reshape(298, len(rows))
+    prog = air.poseidon2_air().program()
+    assert air.check_trace(prog, sample, NOPV) == []
+    params = z.DEFAULT_PARAMS
+    airs = [dict(program=prog, log_height=log_n, width=298, n_pvs=0)]
+    pk = z.ProvingKey(zk, params, airs)
+    proof = pk.prove([d_tr], [NOPV])
+    assert z.verify(params, airs, [NOPV], proof) == 0

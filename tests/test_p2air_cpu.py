@@ -1,0 +1,66 @@
+"""CPU: the Poseidon2 AIR (one permutation per row, p3-poseidon2-air shape with one S-box register).  The oracle's
+trace generator satisfies the constraint program row by row, its output columns are the permutation, any flipped
+cell breaks a constraint, and oracle proofs of the AIR are accepted by the product's host verifier and by the
+independent Python verifier."""
+import numpy as np
+
+import zkvm_prover_amd as z
+from zkvm_prover_amd import air
+import oracle_lib as O
+import pymodel_verify
+
+PARAMS = (1, 0, 10, 4, 5)
+NOPV = np.zeros(0, np.uint32)
+
+
+def _case(log_n, n_perms, seed=0):
+    rng = np.random.default_rng(seed)
+    inputs = O.rand_field(rng, (n_perms, 16))
+    return inputs, O.poseidon2_air_trace(inputs, log_n)
+
+
+def test_round_constants_and_shape():
+    rc = air.poseidon2_round_constants()
+    assert len(rc) == 141 and rc == np.ctypeslib.as_array(O.lib().ora_poseidon2_round_constants(), shape=(141,)).tolist()
+    b = air.poseidon2_air()
+    b.program()
+    assert b.width == air.POSEIDON2_AIR_WIDTH == 298 and len(b.cons) == 282 and b.max_degree() == 3
+
+
+def test_oracle_trace_satisfies_the_air_and_outputs_the_permutation():
+    prog = air.poseidon2_air().program()
+    for log_n, n in [(0, 1), (3, 8), (4, 11), (5, 0)]:
+        inputs, tr = _case(log_n, n, seed=log_n)
+        assert air.check_trace(prog, tr, NOPV) == []
+        for r in range(1 << log_n):
+            s = inputs[r].copy() if r < n else np.zeros(16, np.uint32)
+            assert (tr[:16, r] == s).all()
+            assert (tr[-16:, r] == O.permute(s)).all()
+
+
+def test_every_column_is_constrained():
+    prog = air.poseidon2_air().program()
+    _, tr = _case(2, 3, seed=9)
+    for col in range(16, 298):  # inputs are free; every other cell is pinned by a constraint
+        bad = tr.copy()
+        bad[col, 1] = (int(bad[col, 1]) + 1) % air.P
+        assert air.check_trace(prog, bad, NOPV) != [], "column %d unconstrained" % col
+
+
+def test_oracle_proofs_verify_everywhere(ora):
+    prog = air.poseidon2_air().program()
+    _, tr = _case(4, 13, seed=2)
+    ftr, fpv = air.fibonacci_trace(6)
+    airs = [dict(program=prog, log_height=4, width=298, n_pvs=0, trace=tr, pvs=NOPV),
+            dict(program=air.fibonacci_air().program(), log_height=6, width=2, n_pvs=3, trace=ftr, pvs=fpv)]
+    pvs = [a["pvs"] for a in airs]
+    proof = ora.stark_prove(PARAMS, airs)
+    assert ora.stark_verify(PARAMS, airs, proof) == 0
+    assert z.verify(PARAMS, airs, pvs, proof.tobytes()) == 0
+    assert pymodel_verify.verify(PARAMS, airs, proof) is True
+    # a wrong S-box register anywhere makes the (self-consistent) proof unverifiable
+    bad = [dict(a) for a in airs]
+    bad[0]["trace"] = tr.copy()
+    bad[0]["trace"][200, 7] ^= 1
+    p2 = ora.stark_prove(PARAMS, bad)
+    assert ora.stark_verify(PARAMS, bad, p2) != 0 and z.verify(PARAMS, airs, pvs, p2.tobytes()) != 0

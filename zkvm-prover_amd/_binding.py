@@ -79,6 +79,7 @@ def load_library():
         "zkhip_ntt_batch": (C.c_int, [vp, vp, C.c_uint, sz, sz, C.c_int, C.c_int]),
         "zkhip_lde_batch": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint, C.c_uint, sz, C.c_uint32]),
         "zkhip_poseidon2_permute_batch": (C.c_int, [vp, vp, sz]),
+        "zkhip_poseidon2_air_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
         "zkhip_merkle_commit": (C.c_int, [vp, C.POINTER(_Matrix), sz, C.POINTER(vp), u32p]),
         "zkhip_tree_root_device": (vp, [vp]),
         "zkhip_tree_log_height": (C.c_uint, [vp]),
@@ -199,6 +200,18 @@ class Context:
 
     def poseidon2_permute_batch(self, t, n):
         self._check(self.lib.zkhip_poseidon2_permute_batch(self.h, C.c_void_p(t.data_ptr()), n))
+
+    def poseidon2_air_tracegen(self, t_inputs, log_height, t_out=None):
+        """Device trace (298 columns x 2^log_height, column-major, Montgomery) of the Poseidon2 AIR for the
+        Montgomery input states t_inputs ([n][16], device)."""
+        import torch
+
+        n = t_inputs.numel() // 16
+        if t_out is None:
+            t_out = torch.empty(298 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_poseidon2_air_tracegen(self.h, C.c_void_p(t_inputs.data_ptr()), n, log_height,
+                                                          C.c_void_p(t_out.data_ptr())))
+        return t_out
 
     def merkle_commit(self, mats, want_root=True):
         """mats: list of (tensor, log_height, width[, stride])."""

@@ -610,3 +610,111 @@ def program_bus_trace(log_n, seed=0):
     t = rng.integers(0, P, size=(13, 1 << log_n)).astype(np.uint32)
     t[12] %= 2
     return t
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Poseidon2 AIR: one permutation per row (the shape of p3-poseidon2-air 0.4.3 as OpenVM instantiates it for BabyBear:
+# width 16, S-box degree 7 with ONE committed register x^3 per S-box so that every constraint has degree <= 3;
+# Cargo.lock: openvm-poseidon2-air / p3-poseidon2-air).  The reference stack uses this AIR wherever the VM hashes
+# (memory Merkle tree, recursion transcript); here it is the first chip whose TRACE IS GENERATED ON THE DEVICE
+# (zkhip_poseidon2_air_tracegen).
+#
+# Columns (298): inputs[16] | 4 x { sbox[16] (= (state+rc)^3), post[16] } | 13 x { sbox, post_sbox } | 4 x { sbox[16], post[16] }
+# A full round constrains  sbox_i = (s_i + rc_i)^3  and  post = M_ext(sbox_i^2 * (s_i + rc_i));  a partial round constrains
+# sbox = (s_0 + rc)^3, post_sbox = sbox^2 * (s_0 + rc), then applies the internal linear layer to EXPRESSIONS (lanes 1..15 stay
+# uncommitted linear combinations until the next full round).  The initial external layer acts on the inputs as expressions.
+POSEIDON2_AIR_WIDTH = 16 + 4 * 32 + 13 * 2 + 4 * 32
+
+
+def poseidon2_round_constants():
+    """The 141 canonical round constants (Grain LFSR for field=prime, x^7, n=31, t=16, R_F=8, R_P=13: SURVEY.md A.3;
+    the same generator as csrc/gen_poseidon2_rc.py, which emits them in Montgomery form for the kernels)."""
+    bits = []
+    for v, n in ((1, 2), (0, 4), (31, 12), (16, 12), (8, 10), (13, 10)):
+        bits += [(v >> (n - 1 - i)) & 1 for i in range(n)]
+    bits += [1] * 30
+
+    def step():
+        nb = bits[62] ^ bits[51] ^ bits[38] ^ bits[23] ^ bits[13] ^ bits[0]
+        del bits[0]
+        bits.append(nb)
+        return nb
+
+    def next_bit():
+        while True:
+            a, c = step(), step()
+            if a:
+                return c
+
+    for _ in range(160):
+        step()
+    out = []
+    while len(out) < 141:
+        v = 0
+        for _ in range(31):
+            v = (v << 1) | next_bit()
+        if v < P:
+            out.append(v)
+    return out
+
+
+def poseidon2_internal_diag():
+    i2 = pow(2, P - 2, P)
+    v = [-2, 1, 2, i2, 3, 4, -i2, -3, -4, pow(i2, 8, P), pow(i2, 2, P), pow(i2, 3, P), pow(i2, 27, P),
+         -pow(i2, 8, P), -pow(i2, 4, P), -pow(i2, 27, P)]
+    return [x % P for x in v]
+
+
+def _p2_external(s):
+    """circ(2 M4, M4, M4, M4) with M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] on a list of 16 expressions."""
+    out = [None] * 16
+    for blk in range(0, 16, 4):
+        x0, x1, x2, x3 = s[blk:blk + 4]
+        t01, t23 = x0 + x1, x2 + x3
+        t0123 = t01 + t23
+        t01123, t01233 = t0123 + x1, t0123 + x3
+        out[blk + 3] = t01233 + x0 * 2
+        out[blk + 1] = t01123 + x2 * 2
+        out[blk + 0] = t01123 + t01
+        out[blk + 2] = t01233 + t23
+    sums = [(out[k] + out[4 + k]) + (out[8 + k] + out[12 + k]) for k in range(4)]
+    return [out[i] + sums[i % 4] for i in range(16)]
+
+
+def poseidon2_air():
+    """AirBuilder of the Poseidon2 AIR above: 298 columns, 282 constraints of degree 3, no public values."""
+    b = AirBuilder(POSEIDON2_AIR_WIDTH, 0)
+    rc, diag = poseidon2_round_constants(), poseidon2_internal_diag()
+    col = 16
+    state = _p2_external([b.var(i) for i in range(16)])
+
+    def full_round(state, rcs, col):
+        outs = []
+        for i in range(16):
+            y = state[i] + rcs[i]
+            reg = b.var(col + i)
+            b.assert_zero(reg - y * y * y)
+            outs.append(reg * reg * y)
+        lin = _p2_external(outs)
+        post = [b.var(col + 16 + i) for i in range(16)]
+        for i in range(16):
+            b.assert_zero(post[i] - lin[i])
+        return post, col + 32
+
+    for r in range(4):
+        state, col = full_round(state, rc[16 * r:16 * r + 16], col)
+    for r in range(13):
+        y = state[0] + rc[64 + r]
+        reg, post = b.var(col), b.var(col + 1)
+        b.assert_zero(reg - y * y * y)
+        b.assert_zero(post - reg * reg * y)
+        col += 2
+        state = [post] + state[1:]
+        total = state[0]
+        for i in range(1, 16):
+            total = total + state[i]
+        state = [state[i] * diag[i] + total for i in range(16)]
+    for r in range(4):
+        state, col = full_round(state, rc[77 + 16 * r:77 + 16 * r + 16], col)
+    assert col == POSEIDON2_AIR_WIDTH
+    return b

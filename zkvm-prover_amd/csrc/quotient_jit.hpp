@@ -168,11 +168,7 @@ inline bool quot_jit_classify(const AirProgram& p, std::vector<JitClass>* classe
     return true;
 }
 
-// Emits the kernel source and the parameter table.
-inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b, std::vector<JitClass>& classes,
-                                   std::vector<uint32_t>* table) {
-    (void)p;
-    std::ostringstream os;
+inline void quot_jit_prologue(std::ostringstream& os, unsigned lh, unsigned b) {
     os << quot_jit_preamble();
     os << "#define H " << (lh + b) << "u\n#define B " << b << "u\n#define M ((size_t)1 << H)\n";
     os << R"JIT(
@@ -200,6 +196,25 @@ extern "C" __global__ __launch_bounds__(256) void quot_jit(const uint32_t* __res
     const gptr permp = (gptr)perm;
     const gptr prepp = (gptr)prep;
 )JIT";
+}
+inline void quot_jit_epilogue(std::ostringstream& os) {
+    os << R"JIT(
+    FLUSH
+    const uint32_t izh = inv_zh_t[i & ((1u << B) - 1u)];
+    q[r] = mmul(acc0, izh);
+    q[M + r] = mmul(acc1, izh);
+    q[2 * M + r] = mmul(acc2, izh);
+    q[3 * M + r] = mmul(acc3, izh);
+}
+)JIT";
+}
+
+// Emits the kernel source and the parameter table.
+inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b, std::vector<JitClass>& classes,
+                                   std::vector<uint32_t>* table) {
+    (void)p;
+    std::ostringstream os;
+    quot_jit_prologue(os, lh, b);
     for (size_t c = 0; c < classes.size(); c++) {
         JitClass& C = classes[c];
         C.table_off = table->size();
@@ -237,17 +252,70 @@ extern "C" __global__ __launch_bounds__(256) void quot_jit(const uint32_t* __res
         }
         os << "        ACC(pr[0], e" << (C.entries.size() - 1) << ")\n    }\n";
     }
-    os << R"JIT(
-    FLUSH
-    const uint32_t izh = inv_zh_t[i & ((1u << B) - 1u)];
-    q[r] = mmul(acc0, izh);
-    q[M + r] = mmul(acc1, izh);
-    q[2 * M + r] = mmul(acc2, izh);
-    q[3 * M + r] = mmul(acc3, izh);
-}
-)JIT";
+    quot_jit_epilogue(os);
     if (table->empty()) table->push_back(0);
     return os.str();
+}
+
+// Second code shape, for AIRs whose constraints SHARE large sub-expressions instead of repeating small shapes (the
+// Poseidon2 AIR: 282 constraints over one 2701-node DAG in which every round's S-box outputs feed 16 constraints and the
+// partial rounds' lanes are linear expressions that grow for 13 rounds -- expanded per constraint that is 30x the DAG):
+// the whole DAG as ONE straight-line block, one SSA value per reachable node, columns / constants / indices as literals,
+// each constraint accumulated as soon as its root exists.  The code is larger than the instruction cache, but it is
+// fetched strictly sequentially and every wave of a CU walks the same stream.
+constexpr size_t QUOT_JIT_FLAT_MAX_NODES = 24576;
+inline bool quot_jit_source_flat(const AirProgram& p, unsigned lh, unsigned b, std::string* src, std::string* msg) {
+    std::vector<uint8_t> live(p.n_nodes, 0);
+    for (uint32_t k = 0; k < p.n_cons; k++) live[p.cons[k]] = 1;
+    size_t n_live = 0;
+    for (uint32_t i = p.n_nodes; i-- > 0;) {  // operands precede their users
+        if (!live[i]) continue;
+        n_live++;
+        const uint32_t op = p.nodes[3 * i], a = p.nodes[3 * i + 1], bb = p.nodes[3 * i + 2];
+        if (op == A_ADD || op == A_SUB || op == A_MUL) live[a] = live[bb] = 1;
+        else if (op == A_NEG) live[a] = 1;
+    }
+    if (n_live > QUOT_JIT_FLAT_MAX_NODES) {
+        *msg += "; flat form too large (" + std::to_string(n_live) + " nodes)";
+        return false;
+    }
+    std::vector<std::vector<uint32_t>> cons_of(p.n_nodes);
+    for (uint32_t k = 0; k < p.n_cons; k++) cons_of[p.cons[k]].push_back(k);
+    std::ostringstream os;
+    quot_jit_prologue(os, lh, b);
+    os << "    (void)tab;\n";
+    for (uint32_t i = 0; i < p.n_nodes; i++) {
+        if (!live[i]) continue;
+        const uint32_t op = p.nodes[3 * i], a = p.nodes[3 * i + 1], bb = p.nodes[3 * i + 2];
+        os << "    const uint32_t e" << i << " = ";
+        switch (op) {
+            case A_VAR: os << "LD(" << a << "u, " << (bb ? "rno" : "ro") << ")"; break;
+            case A_PERM: os << "LDP(" << a << "u, " << (bb ? "rno" : "ro") << ")"; break;
+            case A_PREP: os << "LDQ(" << a << "u, " << (bb ? "rno" : "ro") << ")"; break;
+            case A_CHAL: os << "((cptr)lchal)[" << a << "]"; break;
+            case A_EXPOSED: os << "((cptr)expo)[" << a << "]"; break;
+            case A_PUB: os << "PV(" << a << ")"; break;
+            case A_CONST: os << to_monty(a) << "u"; break;
+            case A_FIRST: os << "sel_first"; break;
+            case A_LAST: os << "sel_last"; break;
+            case A_TRANS: os << "sel_trans"; break;
+            case A_NEG: os << "mneg(e" << a << ")"; break;
+            default: {
+                auto is_two = [&](uint32_t n) { return p.nodes[3 * n] == A_CONST && p.nodes[3 * n + 1] == 2u; };
+                if (op == A_MUL && (is_two(a) || is_two(bb))) {  // doubling is an addition, not a Montgomery product
+                    const uint32_t x = is_two(a) ? bb : a;
+                    os << "madd(e" << x << ", e" << x << ")";
+                } else {
+                    os << (op == A_ADD ? "madd" : op == A_SUB ? "msub" : "mmul") << "(e" << a << ", e" << bb << ")";
+                }
+            }
+        }
+        os << ";\n";
+        for (uint32_t k : cons_of[i]) os << "    ACC(" << k << "u, e" << i << ")\n";
+    }
+    quot_jit_epilogue(os);
+    *src = os.str();
+    return true;
 }
 
 // Compiles for gfx950 and loads the module.  Returns false (with a message) on any failure; the
@@ -255,8 +323,13 @@ extern "C" __global__ __launch_bounds__(256) void quot_jit(const uint32_t* __res
 inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModule_t* mod, hipFunction_t* fn,
                            std::vector<uint32_t>* table, std::string* msg) {
     std::vector<JitClass> classes;
-    if (!quot_jit_classify(p, &classes, msg)) return false;
-    std::string src = quot_jit_source(p, lh, b, classes, table);
+    std::string src;
+    if (quot_jit_classify(p, &classes, msg)) {
+        src = quot_jit_source(p, lh, b, classes, table);
+    } else {
+        if (!quot_jit_source_flat(p, lh, b, &src, msg)) return false;
+        table->assign(1, 0u);
+    }
     // process-wide cache of compiled code objects keyed by the generated source: several contexts
     // (one per HIP stream) and repeated keygens of the same AIR share one hipRTC compile
     static std::mutex cache_mu;
