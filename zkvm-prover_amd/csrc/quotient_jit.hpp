@@ -264,7 +264,12 @@ inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b,
 // each constraint accumulated as soon as its root exists.  The code is larger than the instruction cache, but it is
 // fetched strictly sequentially and every wave of a CU walks the same stream.
 constexpr size_t QUOT_JIT_FLAT_MAX_NODES = 24576;
-inline bool quot_jit_source_flat(const AirProgram& p, unsigned lh, unsigned b, std::string* src, std::string* msg) {
+// Column indices are read from an identity table with scalar loads rather than written as literals: with a literal
+// LLVM rewrites base + c*M + lane_offset as (base + lane_offset) + c*M, i.e. one 64-bit per-lane address per column,
+// all of them live at once (309 VGPRs, one wave per SIMD, 11.9 ms for the Poseidon2 AIR at 2^23 rows); through the
+// table the column base stays a scalar pair (61 VGPRs).
+inline bool quot_jit_source_flat(const AirProgram& p, unsigned lh, unsigned b, std::string* src, std::vector<uint32_t>* table,
+                                 std::string* msg) {
     std::vector<uint8_t> live(p.n_nodes, 0);
     for (uint32_t k = 0; k < p.n_cons; k++) live[p.cons[k]] = 1;
     size_t n_live = 0;
@@ -283,15 +288,23 @@ inline bool quot_jit_source_flat(const AirProgram& p, unsigned lh, unsigned b, s
     for (uint32_t k = 0; k < p.n_cons; k++) cons_of[p.cons[k]].push_back(k);
     std::ostringstream os;
     quot_jit_prologue(os, lh, b);
-    os << "    (void)tab;\n";
+    uint32_t max_col = 0;
+    for (uint32_t i = 0; i < p.n_nodes; i++) {
+        if (!live[i]) continue;
+        const uint32_t op0 = p.nodes[3 * i];
+        if (op0 == A_VAR || op0 == A_PERM || op0 == A_PREP) max_col = std::max(max_col, p.nodes[3 * i + 1]);
+    }
+    table->resize((size_t)max_col + 1);
+    for (uint32_t c = 0; c <= max_col; c++) (*table)[c] = c;
+    os << "    const cptr colv = (cptr)tab;\n";
     for (uint32_t i = 0; i < p.n_nodes; i++) {
         if (!live[i]) continue;
         const uint32_t op = p.nodes[3 * i], a = p.nodes[3 * i + 1], bb = p.nodes[3 * i + 2];
         os << "    const uint32_t e" << i << " = ";
         switch (op) {
-            case A_VAR: os << "LD(" << a << "u, " << (bb ? "rno" : "ro") << ")"; break;
-            case A_PERM: os << "LDP(" << a << "u, " << (bb ? "rno" : "ro") << ")"; break;
-            case A_PREP: os << "LDQ(" << a << "u, " << (bb ? "rno" : "ro") << ")"; break;
+            case A_VAR: os << "LD(colv[" << a << "], " << (bb ? "rno" : "ro") << ")"; break;
+            case A_PERM: os << "LDP(colv[" << a << "], " << (bb ? "rno" : "ro") << ")"; break;
+            case A_PREP: os << "LDQ(colv[" << a << "], " << (bb ? "rno" : "ro") << ")"; break;
             case A_CHAL: os << "((cptr)lchal)[" << a << "]"; break;
             case A_EXPOSED: os << "((cptr)expo)[" << a << "]"; break;
             case A_PUB: os << "PV(" << a << ")"; break;
@@ -327,8 +340,7 @@ inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModu
     if (quot_jit_classify(p, &classes, msg)) {
         src = quot_jit_source(p, lh, b, classes, table);
     } else {
-        if (!quot_jit_source_flat(p, lh, b, &src, msg)) return false;
-        table->assign(1, 0u);
+        if (!quot_jit_source_flat(p, lh, b, &src, table, msg)) return false;
     }
     // process-wide cache of compiled code objects keyed by the generated source: several contexts
     // (one per HIP stream) and repeated keygens of the same AIR share one hipRTC compile
