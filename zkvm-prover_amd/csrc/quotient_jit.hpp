@@ -11,6 +11,10 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -352,6 +356,38 @@ inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModu
         auto it = cache.find(src);
         if (it != cache.end()) code = it->second;
     }
+    // optional on-disk cache (ZKHIP_JIT_CACHE_DIR): code objects keyed by a 128-bit hash of the source, so that a
+    // service restarting with the same application skips hipRTC altogether (42 chips: ~90 s of compiles)
+    std::string disk_path;
+    if (code.empty()) {
+        if (const char* dir = getenv("ZKHIP_JIT_CACHE_DIR")) {
+            uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull;
+            for (unsigned char ch : src) {
+                h1 = (h1 ^ ch) * 0x100000001b3ull;
+                h2 = (h2 + ch) * 0x9e3779b97f4a7c15ull + (h2 >> 29);
+            }
+            char name[64];
+            snprintf(name, sizeof name, "/quot_%016llx%016llx.hsaco", (unsigned long long)h1, (unsigned long long)h2);
+            disk_path = std::string(dir) + name;
+            if (FILE* f = fopen(disk_path.c_str(), "rb")) {
+                // file = [source length u64][source][code]: the source is compared, a hash collision cannot mis-load
+                uint64_t sl = 0;
+                if (fread(&sl, 8, 1, f) == 1 && sl == src.size()) {
+                    std::string stored(sl, 0);
+                    if (fread(&stored[0], 1, sl, f) == sl && stored == src) {
+                        char buf[65536];
+                        size_t n;
+                        while ((n = fread(buf, 1, sizeof buf, f)) > 0) code.insert(code.end(), buf, buf + n);
+                    }
+                }
+                fclose(f);
+                if (!code.empty()) {
+                    std::lock_guard<std::mutex> lk(cache_mu);
+                    cache[src] = code;
+                }
+            }
+        }
+    }
     if (code.empty()) {
         hiprtcProgram prog;
         if (hiprtcCreateProgram(&prog, src.c_str(), "quot_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -374,6 +410,16 @@ inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModu
         code.resize(cs);
         hiprtcGetCode(prog, code.data());
         hiprtcDestroyProgram(&prog);
+        if (!disk_path.empty()) {  // write to a temporary name, then rename: concurrent keygens never see a partial file
+            const std::string tmp = disk_path + ".tmp" + std::to_string((unsigned long long)getpid());
+            if (FILE* f = fopen(tmp.c_str(), "wb")) {
+                const uint64_t sl = src.size();
+                const bool ok = fwrite(&sl, 8, 1, f) == 1 && fwrite(src.data(), 1, src.size(), f) == src.size() &&
+                                fwrite(code.data(), 1, code.size(), f) == code.size();
+                fclose(f);
+                if (!ok || rename(tmp.c_str(), disk_path.c_str()) != 0) remove(tmp.c_str());
+            }
+        }
         std::lock_guard<std::mutex> lk(cache_mu);
         cache[src] = code;
     }
