@@ -44,7 +44,7 @@
 #define PROOF_MAGIC 0x31504B5Au
 #define PROTO_TAG 0x5A4B4831u /* "1HKZ" < p */
 #define GEN 31u
-#define MAX_FIELDS 16
+#define MAX_FIELDS 32
 #define N_CHAL (4 * (1 + MAX_FIELDS))
 
 enum { OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_PERM, OP_CHAL, OP_EXPOSED, OP_PREP };

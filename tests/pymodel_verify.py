@@ -10,7 +10,7 @@ import pymodel as m
 P = m.P
 AIR_MAGIC, PREP_MAGIC, LOGUP_MAGIC = 0x31414B5A, 0x50504B5A, 0x554C4B5A
 PROOF_MAGIC, PROTO_TAG, GEN = 0x31504B5A, 0x5A4B4831, 31
-MAX_FIELDS = 16
+MAX_FIELDS = 32
 (VAR, PUB, CONST, FIRST, LAST, TRANS, ADD, SUB, MUL, NEG, PERM, CHAL, EXPOSED, PREP) = range(14)
 
 

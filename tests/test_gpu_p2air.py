@@ -76,3 +76,27 @@ def test_large_device_trace_properties_and_proof(zk):
     pk = z.ProvingKey(zk, params, airs)
     proof = pk.prove([d_tr], [NOPV])
     assert z.verify(params, airs, [NOPV], proof) == 0
+
+
+@pytest.mark.parametrize("jit", ["interpreter", "jit"])
+def test_poseidon2_chip_on_a_bus_device_trace_equals_oracle(zk, ora, jit, monkeypatch):
+    """Requester + Poseidon2 chip over a 24-field bus: the chip's 298 permutation columns come from the device
+    generator, the multiplicity column is the caller's; proof bytes equal the oracle's."""
+    import torch
+    from test_p2air_cpu import hasher_pair
+
+    monkeypatch.setenv("ZKHIP_NO_JIT" if jit == "interpreter" else "ZKHIP_FORCE_JIT", "1")
+    params = (1, 0, 8, 3, 4)
+    airs, uniq = hasher_pair(log_user=6, n_req=40, log_chip=7, seed=11)
+    pvs = [NOPV, NOPV]
+    exp = ora.stark_prove(params, airs)
+    assert ora.stark_verify(params, airs, exp) == 0
+    N = 1 << 7
+    d_chip = torch.empty(299 * N, dtype=torch.int32, device="cuda:0")
+    zk.poseidon2_air_tracegen(zk.upload(uniq.reshape(-1)), 7, d_chip)
+    d_chip[298 * N:] = zk.upload(airs[1]["trace"][298])
+    assert (zk.download(d_chip).reshape(299, N) == airs[1]["trace"]).all()
+    pk = z.ProvingKey(zk, params, airs)
+    got = pk.prove([zk.upload(airs[0]["trace"].reshape(-1)), d_chip], pvs)
+    assert got == exp.tobytes()
+    assert z.verify(params, airs, pvs, got) == 0

@@ -64,3 +64,45 @@ def test_oracle_proofs_verify_everywhere(ora):
     bad[0]["trace"][200, 7] ^= 1
     p2 = ora.stark_prove(PARAMS, bad)
     assert ora.stark_verify(PARAMS, bad, p2) != 0 and z.verify(PARAMS, airs, pvs, p2.tobytes()) != 0
+
+
+def hasher_pair(log_user=4, n_req=11, log_chip=4, seed=3, bus=9):
+    """A requester chip and the Poseidon2 chip on one bus with 24-field messages; one request is made twice
+    (multiplicity 2 on the chip's side)."""
+    rng = np.random.default_rng(seed)
+    left, right = O.rand_field(rng, (n_req, 8)), O.rand_field(rng, (n_req, 8))
+    left[1], right[1] = left[0], right[0]
+    states = np.concatenate([left, right], axis=1)
+    out = np.stack([O.permute(s.copy())[:8] for s in states])
+    user = air.hasher_user_trace(log_user, left, right, out)
+    uniq = states[1:]                                   # request 0 == request 1: served by one row
+    chip = np.zeros((299, 1 << log_chip), np.uint32)
+    chip[:298] = O.poseidon2_air_trace(uniq, log_chip)
+    chip[298, :len(uniq)] = 1
+    chip[298, 0] = 2
+    return [dict(program=air.hasher_user_air(bus).program(), log_height=log_user, width=25, n_pvs=0, trace=user, pvs=NOPV),
+            dict(program=air.poseidon2_air(bus).program(), log_height=log_chip, width=299, n_pvs=0, trace=chip, pvs=NOPV)], uniq
+
+
+def test_poseidon2_chip_serves_a_requester_over_a_24_field_bus(ora):
+    airs, _ = hasher_pair()
+    pvs = [NOPV, NOPV]
+    for a in airs:
+        assert air.check_trace(a["program"], a["trace"], a["pvs"]) == []
+    proof = ora.stark_prove(PARAMS, airs)
+    assert ora.stark_verify(PARAMS, airs, proof) == 0
+    assert z.verify(PARAMS, airs, pvs, proof.tobytes()) == 0
+    assert pymodel_verify.verify(PARAMS, airs, proof) is True
+    # a requester claiming a wrong digest word: every AIR is satisfied row by row, but the bus does not balance
+    bad = [dict(a) for a in airs]
+    bad[0]["trace"] = airs[0]["trace"].copy()
+    bad[0]["trace"][19, 2] ^= 1
+    assert air.check_trace(bad[0]["program"], bad[0]["trace"], NOPV) == []
+    p2 = ora.stark_prove(PARAMS, bad)
+    assert ora.stark_verify(PARAMS, bad, p2) != 0 and z.verify(PARAMS, airs, pvs, p2.tobytes()) != 0
+    # so does a multiplicity that is off by one
+    bad = [dict(a) for a in airs]
+    bad[1]["trace"] = airs[1]["trace"].copy()
+    bad[1]["trace"][298, 0] = 1
+    p3 = ora.stark_prove(PARAMS, bad)
+    assert ora.stark_verify(PARAMS, bad, p3) != 0 and z.verify(PARAMS, airs, pvs, p3.tobytes()) != 0

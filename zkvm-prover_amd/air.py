@@ -18,7 +18,7 @@ OP_PERM, OP_CHAL, OP_EXPOSED = 10, 11, 12
 OP_PREP = 13                              # a cell of the AIR's preprocessed trace (committed at keygen)
 PREP_MAGIC = 0x50504B5A                   # section [PREP_MAGIC, prep_width] after the constraints
 LOGUP_MAGIC = 0x554C4B5A
-LOGUP_MAX_FIELDS = 16                     # challenge vector = gamma, beta^1 .. beta^16 (4 coordinates each)
+LOGUP_MAX_FIELDS = 32                     # challenge vector = gamma, beta^1 .. beta^32 (4 coordinates each)
 N_CHAL = 4 * (1 + LOGUP_MAX_FIELDS)
 EXT_W = 11                                # x^4 = 11
 
@@ -681,9 +681,11 @@ def _p2_external(s):
     return [out[i] + sums[i % 4] for i in range(16)]
 
 
-def poseidon2_air():
-    """AirBuilder of the Poseidon2 AIR above: 298 columns, 282 constraints of degree 3, no public values."""
-    b = AirBuilder(POSEIDON2_AIR_WIDTH, 0)
+def poseidon2_air(bus=None):
+    """AirBuilder of the Poseidon2 AIR above: 298 columns, 282 constraints of degree 3, no public values.
+    With `bus` the chip serves compression requests like OpenVM's Poseidon2 periphery chip: one more column `mult`
+    (column 298) and the interaction receive(bus, inputs[0..16] ++ outputs[0..8], mult) -- a 24-field message."""
+    b = AirBuilder(POSEIDON2_AIR_WIDTH + (1 if bus is not None else 0), 0)
     rc, diag = poseidon2_round_constants(), poseidon2_internal_diag()
     col = 16
     state = _p2_external([b.var(i) for i in range(16)])
@@ -717,4 +719,27 @@ def poseidon2_air():
     for r in range(4):
         state, col = full_round(state, rc[77 + 16 * r:77 + 16 * r + 16], col)
     assert col == POSEIDON2_AIR_WIDTH
+    if bus is not None:
+        msg = [b.var(i) for i in range(16)] + state[:8]
+        b.push_interaction(bus, msg, b.var(POSEIDON2_AIR_WIDTH), "receive")
     return b
+
+
+def hasher_user_air(bus):
+    """A chip that needs 2-to-1 compressions (a Merkle-path checker, say): columns left[8] | right[8] | out[8] | is_real;
+    it sends (left, right, out) on `bus` when is_real = 1 and relies on the Poseidon2 chip to receive it, i.e. to
+    have a row whose permutation maps left ++ right to out ++ (anything)."""
+    b = AirBuilder(25, 0)
+    real = b.var(24)
+    b.assert_zero(real * (real - 1))
+    b.push_interaction(bus, [b.var(i) for i in range(24)], real, "send")
+    return b
+
+
+def hasher_user_trace(log_n, left, right, out):
+    """Trace of hasher_user_air: rows 0..len(left) are real requests (canonical uint32 arrays [n][8]), the rest padding."""
+    n = len(left)
+    t = np.zeros((25, 1 << log_n), dtype=np.uint32)
+    t[0:8, :n], t[8:16, :n], t[16:24, :n] = np.asarray(left).T, np.asarray(right).T, np.asarray(out).T
+    t[24, :n] = 1
+    return t

@@ -24,8 +24,8 @@ constexpr uint32_t PROTO_TAG = 0x5A4B4831u;
 
 constexpr uint32_t LOGUP_MAGIC = 0x554C4B5Au;
 constexpr uint32_t PREP_MAGIC = 0x50504B5Au;  // section [PREP_MAGIC, prep_width]: the AIR has a preprocessed trace
-constexpr unsigned LOGUP_MAX_FIELDS = 16;
-constexpr unsigned N_CHAL = 4 * (1 + LOGUP_MAX_FIELDS);  // gamma, beta^1..beta^16 as base coordinates
+constexpr unsigned LOGUP_MAX_FIELDS = 32;
+constexpr unsigned N_CHAL = 4 * (1 + LOGUP_MAX_FIELDS);  // gamma, beta^1..beta^32 as base coordinates
 
 // A_PERM / A_CHAL / A_EXPOSED are the leaves of the after-challenge (LogUp) phase: a base column of the
 // permutation matrix, a coordinate of the interaction challenges, a coordinate of the exposed sum.

@@ -141,7 +141,7 @@ __global__ void k_ext_powers(const uint32_t* base, uint32_t n, int reverse, uint
 }
 
 // ---------------------------------------------------------------------------------------------
-// LogUp phase (bus interactions; K6).  lchal = gamma, beta^1 .. beta^8 as base coordinates.
+// LogUp phase (bus interactions; K6).  lchal = gamma, beta^1 .. beta^LOGUP_MAX_FIELDS as base coordinates.
 __global__ void k_logup_chal(const uint32_t* gb, uint32_t* lchal) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const Ext gamma = ld_ext(gb), beta = ld_ext(gb + 4);
