@@ -100,6 +100,15 @@ int zkhip_poseidon2_permute_batch(zkhip_ctx *ctx, uint32_t *d_states, size_t n);
 int zkhip_poseidon2_air_tracegen(zkhip_ctx *ctx, const uint32_t *d_inputs, size_t n_perms, unsigned log_height,
                                  uint32_t *d_trace);
 
+/* Multiplicity column of a range-check / lookup table -- the whole trace of OpenVM's VariableRangeChecker-style
+ * chips (their tracegen counts requests with atomics while the other chips fill their rows).
+ * d_counts[v] = #{ i < n : d_values[i] == v } for v < 2^log_table; d_values: n Montgomery words on the device (e.g. a
+ * trace column that is sent to the table's bus); d_counts: 2^log_table Montgomery words = the table chip's trace.
+ * accumulate != 0 adds to the counts already there (one call per requesting column).  Synchronises; returns
+ * ZKHIP_ERR_INVALID (and leaves the in-range counts) if a value lies outside the table. */
+int zkhip_range_counts_tracegen(zkhip_ctx *ctx, const uint32_t *d_values, size_t n, unsigned log_table,
+                                uint32_t *d_counts, int accumulate);
+
 typedef struct {
     const uint32_t *data; /* device, column-major, Montgomery */
     size_t stride;

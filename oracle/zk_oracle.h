@@ -76,6 +76,8 @@ void ora_compress(const uint32_t l[8], const uint32_t r[8], uint32_t out[8]);
  * inputs [n_perms][16] canonical, trace column-major with stride 2^log_height, rows >= n_perms permute the zero state */
 #define ORA_POSEIDON2_AIR_WIDTH 298
 void ora_poseidon2_air_trace(const uint32_t *inputs, size_t n_perms, unsigned log_height, uint32_t *trace);
+/* multiplicity column of a range-check table: counts[v] (+)= #{i : values[i] == v}, canonical; returns #values out of range */
+size_t ora_range_counts(const uint32_t *values, size_t n, unsigned log_table, uint32_t *counts, int accumulate);
 
 /* ---- MerkleTreeMmcs over column-major matrices of (possibly) mixed heights ---- */
 typedef struct {

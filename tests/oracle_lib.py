@@ -12,6 +12,15 @@ _LIB = None
 P = 2013265921
 
 
+def range_counts(values, log_table, counts=None):
+    """(counts, n_out_of_range): multiplicity column of a range table for the canonical values."""
+    values = np.ascontiguousarray(values, dtype=np.uint32).reshape(-1)
+    acc = counts is not None
+    counts = np.ascontiguousarray(counts, dtype=np.uint32).copy() if acc else np.zeros(1 << log_table, np.uint32)
+    bad = lib().ora_range_counts(p32(values), len(values), log_table, p32(counts), 1 if acc else 0)
+    return counts, int(bad)
+
+
 def poseidon2_air_trace(inputs, log_height):
     """Oracle trace (298 x 2^log_height, canonical, column-major) of the Poseidon2 AIR for inputs [n][16]."""
     inputs = np.ascontiguousarray(inputs, dtype=np.uint32).reshape(-1, 16)
@@ -71,6 +80,8 @@ def lib():
         l.ora_hash_slice.argtypes = [u32p, sz, u32p]
         l.ora_compress.argtypes = [u32p, u32p, u32p]
         l.ora_poseidon2_air_trace.argtypes = [u32p, sz, C.c_uint, u32p]
+        l.ora_range_counts.argtypes = [u32p, sz, C.c_uint, u32p, C.c_int]
+        l.ora_range_counts.restype = sz
         l.ora_mmcs_commit.restype = C.c_void_p
         l.ora_mmcs_commit.argtypes = [C.POINTER(OraMatrix), sz, u32p]
         l.ora_tree_log_height.restype = C.c_uint

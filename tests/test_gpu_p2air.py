@@ -100,3 +100,41 @@ def test_poseidon2_chip_on_a_bus_device_trace_equals_oracle(zk, ora, jit, monkey
     got = pk.prove([zk.upload(airs[0]["trace"].reshape(-1)), d_chip], pvs)
     assert got == exp.tobytes()
     assert z.verify(params, airs, pvs, got) == 0
+
+
+@pytest.mark.parametrize("log_table,n", [(0, 5), (4, 1000), (13, 100000), (14, 100000), (20, 300000), (6, 0)])
+def test_range_counts_tracegen_equals_oracle(zk, log_table, n):
+    rng = np.random.default_rng(log_table)
+    vals = rng.integers(0, 1 << log_table, n).astype(np.uint32)
+    if n > 10:
+        vals[: n // 3] = vals[0]                      # a heavy hitter (atomic contention)
+    exp, bad = O.range_counts(vals, log_table)
+    assert bad == 0
+    d_vals = zk.upload(vals) if n else zk.upload(np.zeros(1, np.uint32))[:0]
+    d_c = zk.range_counts_tracegen(d_vals, log_table)
+    assert (zk.download(d_c) == exp).all()
+    # accumulate a second requesting column
+    more = rng.integers(0, 1 << log_table, 777).astype(np.uint32)
+    exp2, _ = O.range_counts(more, log_table, counts=exp)
+    zk.range_counts_tracegen(zk.upload(more), log_table, d_c, accumulate=True)
+    assert (zk.download(d_c) == exp2).all()
+
+
+def test_range_counts_rejects_out_of_range_values(zk):
+    vals = np.array([1, 2, 3, 16, 5], np.uint32)
+    with pytest.raises(Exception, match="outside the table"):
+        zk.range_counts_tracegen(zk.upload(vals), 4)
+
+
+def test_range_table_trace_from_device_counts_proves(zk, ora):
+    """The range-table chip's trace generated on the device from the user chip's resident column: proof == oracle."""
+    params = (1, 0, 8, 3, 4)
+    u, m, prep = air.range_traces(9, 6, seed=5)
+    airs = [dict(program=air.range_user_air().program(), log_height=9, width=4, n_pvs=0, trace=u, pvs=NOPV),
+            dict(program=air.range_table_air().program(), log_height=6, width=1, n_pvs=0, trace=m, pvs=NOPV, prep=prep)]
+    exp = ora.stark_prove(params, airs)
+    d_user = zk.upload(u.reshape(-1))
+    d_table = zk.range_counts_tracegen(d_user[: 1 << 9], 6)      # column 0 of the user trace
+    pk = z.ProvingKey(zk, params, airs)
+    got = pk.prove([d_user, d_table], [NOPV, NOPV])
+    assert got == exp.tobytes()

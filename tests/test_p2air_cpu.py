@@ -106,3 +106,16 @@ def test_poseidon2_chip_serves_a_requester_over_a_24_field_bus(ora):
     bad[1]["trace"][298, 0] = 1
     p3 = ora.stark_prove(PARAMS, bad)
     assert ora.stark_verify(PARAMS, bad, p3) != 0 and z.verify(PARAMS, airs, pvs, p3.tobytes()) != 0
+
+
+def test_range_counts_oracle_matches_numpy_and_balances_the_range_bus(ora):
+    rng = np.random.default_rng(4)
+    vals = rng.integers(0, 1 << 6, 500).astype(np.uint32)
+    c, bad = O.range_counts(vals, 6)
+    assert bad == 0 and (c == np.bincount(vals, minlength=64)).all()
+    c2, bad = O.range_counts(np.array([3, 64, 3, 2**31 - 5], np.uint32), 6, counts=c)
+    assert bad == 2 and c2[3] == c[3] + 2 and c2.sum() == c.sum() + 2
+    # the table chip's trace of air.range_traces is exactly this histogram of the user's column
+    u, m, prep = air.range_traces(6, 4, seed=2)
+    c3, bad = O.range_counts(u[0], 4)
+    assert bad == 0 and (c3 == m[0]).all()

@@ -80,6 +80,7 @@ def load_library():
         "zkhip_lde_batch": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint, C.c_uint, sz, C.c_uint32]),
         "zkhip_poseidon2_permute_batch": (C.c_int, [vp, vp, sz]),
         "zkhip_poseidon2_air_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
+        "zkhip_range_counts_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, C.c_int]),
         "zkhip_merkle_commit": (C.c_int, [vp, C.POINTER(_Matrix), sz, C.POINTER(vp), u32p]),
         "zkhip_tree_root_device": (vp, [vp]),
         "zkhip_tree_log_height": (C.c_uint, [vp]),
@@ -212,6 +213,16 @@ class Context:
         self._check(self.lib.zkhip_poseidon2_air_tracegen(self.h, C.c_void_p(t_inputs.data_ptr()), n, log_height,
                                                           C.c_void_p(t_out.data_ptr())))
         return t_out
+
+    def range_counts_tracegen(self, t_values, log_table, t_counts=None, accumulate=False):
+        """Multiplicity column (2^log_table Montgomery words, device) of the Montgomery values in t_values."""
+        import torch
+
+        if t_counts is None:
+            t_counts = torch.empty(1 << log_table, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_range_counts_tracegen(self.h, C.c_void_p(t_values.data_ptr()), t_values.numel(), log_table,
+                                                         C.c_void_p(t_counts.data_ptr()), 1 if accumulate else 0))
+        return t_counts
 
     def merkle_commit(self, mats, want_root=True):
         """mats: list of (tensor, log_height, width[, stride])."""

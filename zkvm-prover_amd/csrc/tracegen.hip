@@ -14,6 +14,8 @@
 #include "poseidon2_coop.hpp"
 #include "zkhip_internal.hpp"
 
+#include <algorithm>
+
 namespace zk {
 
 static_assert(ZKHIP_POSEIDON2_AIR_WIDTH == 16 + 8 * 32 + 13 * 2, "column layout");
@@ -85,9 +87,77 @@ int poseidon2_air_tracegen(zkhip_ctx* ctx, const uint32_t* d_inputs, size_t n_pe
     return ZKHIP_OK;
 }
 
+// Second chip: the multiplicity column of a range-check / lookup table (the whole trace of OpenVM's
+// VariableRangeChecker-style chips: how often each table entry was requested; the reference's CPU tracegen bumps
+// atomic counters while the other chips fill their rows, its GPU backend does the same with device atomics).
+// counts[v] (+)= #{ i : values[i] == v } for v < 2^log_table; values and counts are Montgomery residues.
+// Tables of <= 2^13 entries are counted in a per-workgroup LDS histogram (32 KiB) and merged with one atomic per
+// non-zero bin; larger tables count straight into HBM.  `bad` receives the number of out-of-range values.
+constexpr unsigned RC_LDS_LOG = 13;
+__global__ __launch_bounds__(256) void k_range_counts(const uint32_t* __restrict__ values, size_t n, unsigned log_table,
+                                                      uint32_t* __restrict__ hist, uint32_t* __restrict__ bad) {
+    extern __shared__ uint32_t bins[];
+    const uint32_t T = 1u << log_table;
+    const bool use_lds = log_table <= RC_LDS_LOG;
+    if (use_lds) {
+        for (uint32_t i = threadIdx.x; i < T; i += 256) bins[i] = 0;
+        __syncthreads();
+    }
+    uint32_t n_bad = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t v = from_monty(values[i]);
+        if (v >= T) {
+            n_bad++;
+            continue;
+        }
+        atomicAdd(use_lds ? &bins[v] : &hist[v], 1u);
+    }
+    if (n_bad) atomicAdd(bad, n_bad);
+    if (use_lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < T; i += 256)
+            if (bins[i]) atomicAdd(&hist[i], bins[i]);
+    }
+}
+// integer histogram <-> Montgomery counts (counts stay far below p: at most 2^27 rows x a few hundred columns per call,
+// and the sum is reduced mod p, which is what the bus argument needs anyway)
+__global__ void k_counts_repr(uint32_t* c, size_t n, int to_m) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) c[i] = to_m ? to_monty(c[i] % P) : from_monty(c[i]);
+}
+
+int range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d_values, size_t n, unsigned log_table, uint32_t* d_counts, int accumulate) {
+    if (log_table > 27) return set_error(ctx, ZKHIP_ERR_INVALID, "range_counts_tracegen: log_table > 27");
+    const size_t T = (size_t)1 << log_table;
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "range_counts_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const unsigned tb = (unsigned)((T + 255) / 256);
+    if (accumulate) hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
+    else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
+    if (n) {
+        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 16 - 1) / (256 * 16), 4096);
+        hipLaunchKernelGGL(k_range_counts, dim3(blocks), dim3(256), log_table <= RC_LDS_LOG ? T * 4 : 0, ctx->stream, d_values, n,
+                           log_table, d_counts, (uint32_t*)flag);
+    }
+    hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    uint32_t h_bad = 0;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_bad) return set_error(ctx, ZKHIP_ERR_INVALID, "range_counts_tracegen: " + std::to_string(h_bad) + " values outside the table");
+    return ZKHIP_OK;
+}
+
 }  // namespace zk
 
 using namespace zk;
+extern "C" int zkhip_range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d_values, size_t n, unsigned log_table,
+                                           uint32_t* d_counts, int accumulate) {
+    if (!ctx || !d_counts || (n && !d_values)) return ZKHIP_ERR_INVALID;
+    return range_counts_tracegen(ctx, d_values, n, log_table, d_counts, accumulate);
+}
 extern "C" int zkhip_poseidon2_air_tracegen(zkhip_ctx* ctx, const uint32_t* d_inputs, size_t n_perms, unsigned log_height,
                                             uint32_t* d_trace) {
     if (!ctx || !d_trace) return ZKHIP_ERR_INVALID;
