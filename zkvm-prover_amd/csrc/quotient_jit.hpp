@@ -341,7 +341,8 @@ inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModu
                            std::vector<uint32_t>* table, std::string* msg) {
     std::vector<JitClass> classes;
     std::string src;
-    if (quot_jit_classify(p, &classes, msg)) {
+    // ZKHIP_JIT_FLAT=1 prefers the flat form for every AIR (experiments)
+    if (!getenv("ZKHIP_JIT_FLAT") && quot_jit_classify(p, &classes, msg)) {
         src = quot_jit_source(p, lh, b, classes, table);
     } else {
         if (!quot_jit_source_flat(p, lh, b, &src, table, msg)) return false;
