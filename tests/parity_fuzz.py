@@ -1,6 +1,6 @@
 """Randomised parity campaign: HIP prover vs CPU oracle on random AIR sets (random constraint DAGs, random bus
 expressions, random preprocessed matrices, random heights / blow-ups / query counts).  Test infrastructure
-(uses oracle/ as the checker).  Usage: python tools/parity_fuzz.py [n_cases] [first_seed] [min_log_height] [max_log_height]"""
+(uses oracle/ as the checker).  Usage: python tests/parity_fuzz.py [n_cases] [first_seed] [min_log_height] [max_log_height]"""
 import os
 import sys
 import time

@@ -30,12 +30,13 @@ def test_version_and_no_cpu_fallback():
 
 
 def test_product_never_touches_oracle():
-    """The product tree (package + include) must not reference oracle/ in any way."""
+    """The product tree (package + include) and the measurement tools must not reference oracle/ in any way
+    (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may)."""
     import os
     import re
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for base in ("zkvm-prover_amd", "zkvm_prover_amd", "include"):
+    for base in ("zkvm-prover_amd", "zkvm_prover_amd", "include", "tools"):
         for dp, _, fs in os.walk(os.path.join(root, base)):
             for f in fs:
                 if f.endswith((".so", ".o", ".pyc")):
