@@ -1,0 +1,139 @@
+// Builds the demo AIRs of zkvm-prover_amd/air.py with the C++ builder (include/zkhip_air.hpp) and prints their
+// programs; tests/test_air_builder_cpp.py compares them word for word with the Python builder's.
+// (Leaves are bound to variables in the Python creation order: C++ leaves the evaluation order of a binary
+// operator's operands unspecified, and node numbering follows creation order.)
+#include <cstdio>
+
+#include "zkhip_air.hpp"
+
+using namespace zkhip::air;
+
+static void dump(const char* name, AirBuilder& b) {
+    const std::vector<uint32_t> w = b.program();
+    std::printf("%s %u", name, b.max_degree());
+    for (uint32_t x : w) std::printf(" %u", x);
+    std::printf("\n");
+}
+
+int main() {
+    {   // fibonacci_air
+        AirBuilder b(2, 3);
+        const Expr a0 = b.var(0), b0 = b.var(1);
+        b.when_first_row(a0 - b.pub(0));
+        b.when_first_row(b0 - b.pub(1));
+        b.when_transition(b.next(0) - b0);
+        const Expr n1 = b.next(1);
+        b.when_transition(n1 - (a0 + b0));
+        b.when_last_row(b0 - b.pub(2));
+        dump("fibonacci", b);
+    }
+    {   // lookup_sender_air(3, 7)
+        AirBuilder b(3, 0);
+        const Expr v0 = b.var(0);
+        const Expr t = v0 * (v0 - 1);
+        const Expr t0 = t * 0;
+        const Expr v2 = b.var(2);
+        b.assert_zero(t0 + v2 - v2);
+        const Expr f0 = b.var(0), f1 = b.var(1);
+        b.push_interaction(7, {f0, f1}, b.constant(1), Kind::Send);
+        dump("lookup_sender", b);
+    }
+    {   // lookup_table_air(7)
+        AirBuilder b(3, 0);
+        const Expr f0 = b.var(0), f1 = b.var(1), c = b.var(2);
+        b.push_interaction(7, {f0, f1}, c, Kind::Receive);
+        dump("lookup_table", b);
+    }
+    {   // limb_air(13)
+        AirBuilder b(4, 0);
+        const Expr lo = b.var(0), hi = b.var(1), val = b.var(2), ok = b.var(3);
+        b.assert_zero(ok * (ok - 1));
+        const Expr h256 = hi * 256;
+        b.assert_zero(ok * (lo + h256 - val));
+        const Expr f0 = lo + hi * 256;
+        const Expr f1 = ok * val;
+        b.push_interaction(13, {f0, f1}, ok, Kind::Send);
+        const Expr g1 = val * ok;
+        const Expr c = ok * 1;
+        b.push_interaction(13, {val, g1}, c, Kind::Receive);
+        dump("limb", b);
+    }
+    {   // bus_mix_air(6)
+        AirBuilder b(6, 1);
+        const Expr v0 = b.var(0), v1 = b.var(1);
+        const Expr m = v0 * v1;
+        b.assert_zero(m - b.var(2));
+        for (int rep = 0; rep < 2; rep++) {
+            const Expr f0 = b.var(0), f2 = b.pub(0), c = b.var(3), f1 = b.constant(5);  // Python lifts the literal 5 last
+            b.push_interaction(3, {f0, f1, f2}, c, rep == 0 ? Kind::Send : Kind::Receive);
+        }
+        {
+            const Expr f = b.var(1), c = b.constant(1);
+            b.push_interaction(9, {f}, c, Kind::Send);
+        }
+        {
+            const Expr f = b.var(4), c = b.constant(1);
+            b.push_interaction(9, {f}, c, Kind::Receive);
+        }
+        for (int rep = 0; rep < 2; rep++) {
+            std::vector<Expr> f;
+            for (int i = 0; i < 6; i++) f.push_back(b.var(i));
+            f.push_back(b.constant(7));
+            f.push_back(b.pub(0));
+            const Expr c = b.constant(2);
+            b.push_interaction(11, f, c, rep == 0 ? Kind::Send : Kind::Receive);
+        }
+        dump("bus_mix", b);
+    }
+    {   // range_table_air(5)
+        AirBuilder b(1, 0, 1);
+        b.when_first_row(b.prep(0));
+        const Expr p1 = b.prep(0, 1);
+        const Expr d = p1 - b.prep(0);
+        b.when_transition(d - 1);
+        const Expr f = b.prep(0), c = b.var(0);
+        b.push_interaction(5, {f}, c, Kind::Receive);
+        dump("range_table", b);
+    }
+    {   // range_user_air(4, 5)
+        AirBuilder b(4, 0);
+        const Expr v0 = b.var(0);
+        const Expr sq = v0 * v0;
+        b.assert_zero(sq - b.var(1));
+        b.push_interaction(5, {v0}, b.constant(1), Kind::Send);
+        dump("range_user", b);
+    }
+    {   // program_bus_air(2)
+        AirBuilder b(13, 0);
+        const Expr ok = b.var(12);
+        b.assert_zero(ok * (ok - 1));
+        std::vector<Expr> msg;
+        for (int i = 0; i < 11; i++) msg.push_back(b.var(i));
+        const Expr v0 = b.var(0);
+        const Expr v13 = b.var(1) * 3;
+        msg.push_back(v0 + v13);
+        b.push_interaction(2, msg, ok, Kind::Send);
+        b.push_interaction(2, msg, ok, Kind::Receive);
+        dump("program_bus", b);
+    }
+    {
+        AirBuilder b(POSEIDON2_AIR_WIDTH, 0);
+        poseidon2_air(b);
+        dump("poseidon2", b);
+    }
+    {
+        AirBuilder b(POSEIDON2_AIR_WIDTH + 1, 0);
+        poseidon2_air(b, 9);
+        dump("poseidon2_bus", b);
+    }
+    {   // hasher_user_air(9)
+        AirBuilder b(25, 0);
+        const Expr real = b.var(24);
+        b.assert_zero(real * (real - 1));
+        std::vector<Expr> msg;
+        for (int i = 0; i < 24; i++) msg.push_back(b.var(i));
+        b.push_interaction(9, msg, real, Kind::Send);
+        dump("hasher_user", b);
+    }
+    return 0;
+}
