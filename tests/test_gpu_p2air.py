@@ -138,3 +138,16 @@ def test_range_table_trace_from_device_counts_proves(zk, ora):
     pk = z.ProvingKey(zk, params, airs)
     got = pk.prove([d_user, d_table], [NOPV, NOPV])
     assert got == exp.tobytes()
+
+
+def test_all_cpp_hasher_demo_proves_and_rejects_tampering():
+    """tools/hasher_demo.cpp: AIRs from include/zkhip_air.hpp, device tracegen, keygen / prove / verify through the
+    C ABI only -- no Python in the loop."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zkvm-prover_amd", "hasher_demo")
+    assert os.path.exists(exe), "hasher_demo not built (python -c 'import __graft_entry__ as g; g.build()')"
+    out = subprocess.run([exe, "10"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "verified" in out.stdout and "tampered digest: rejected" in out.stdout
