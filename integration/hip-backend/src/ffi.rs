@@ -1,0 +1,149 @@
+//! Raw bindings, one to one with `include/zkhip.h` (every entry point; checked by
+//! `tests/test_rust_ffi_matches_header.py`).  All functions return `0` or a negative `ZKHIP_ERR_*`.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_double, c_int, c_uint, c_void};
+
+pub const ZKHIP_OK: c_int = 0;
+pub const ZKHIP_ERR_NO_DEVICE: c_int = -1;
+pub const ZKHIP_ERR_HIP: c_int = -2;
+pub const ZKHIP_ERR_INVALID: c_int = -3;
+pub const ZKHIP_ERR_NOMEM: c_int = -4;
+pub const ZKHIP_ERR_SMALL_BUFFER: c_int = -5;
+pub const ZKHIP_ERR_POW_FAILED: c_int = -6;
+pub const ZKHIP_ERR_VERIFY: c_int = -7;
+pub const ZKHIP_ERR_CONSTRAINT: c_int = -8;
+pub const ZKHIP_DIGEST_WORDS: usize = 8;
+pub const ZKHIP_POSEIDON2_AIR_WIDTH: usize = 298;
+
+#[repr(C)]
+pub struct zkhip_ctx {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct zkhip_tree {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct zkhip_transcript {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct zkhip_pk {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkhip_matrix {
+    pub data: *const u32, // device, column-major, Montgomery
+    pub stride: usize,
+    pub log_height: c_uint,
+    pub width: usize,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkhip_params {
+    pub log_blowup: u32,
+    pub log_final_poly_len: u32,
+    pub num_queries: u32,
+    pub commit_pow_bits: u32,
+    pub query_pow_bits: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkhip_air {
+    pub program: *const u32, // host, AIR constraint bytecode
+    pub program_len: usize,  // words
+    pub log_height: c_uint,
+    pub width: usize,
+    pub n_pvs: usize,
+    pub prep_trace: *const u32,  // host, canonical, column-major; null when the AIR has no preprocessed trace
+    pub prep_commit: *const u32, // 8 canonical words (verifying-key entry); null when none
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkhip_kernel_stat {
+    pub name: [c_char; 48],
+    pub launches: u64,
+    pub total_ms: c_double,
+}
+
+extern "C" {
+    pub fn zkhip_version() -> u32;
+
+    // context
+    pub fn zkhip_ctx_create(device: c_int, out: *mut *mut zkhip_ctx) -> c_int;
+    pub fn zkhip_ctx_destroy(ctx: *mut zkhip_ctx);
+    pub fn zkhip_last_error(ctx: *const zkhip_ctx) -> *const c_char;
+    pub fn zkhip_set_stream(ctx: *mut zkhip_ctx, hip_stream: *mut c_void) -> c_int;
+    pub fn zkhip_sync(ctx: *mut zkhip_ctx) -> c_int;
+
+    // device memory
+    pub fn zkhip_malloc(ctx: *mut zkhip_ctx, bytes: usize, dptr: *mut *mut c_void) -> c_int;
+    pub fn zkhip_free(ctx: *mut zkhip_ctx, dptr: *mut c_void) -> c_int;
+    pub fn zkhip_h2d(ctx: *mut zkhip_ctx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+    pub fn zkhip_d2h(ctx: *mut zkhip_ctx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+    pub fn zkhip_to_monty(ctx: *mut zkhip_ctx, d: *mut u32, n: usize) -> c_int;
+    pub fn zkhip_from_monty(ctx: *mut zkhip_ctx, d: *mut u32, n: usize) -> c_int;
+
+    // NTT / LDE
+    pub fn zkhip_ntt_batch(ctx: *mut zkhip_ctx, d_mat: *mut u32, log_n: c_uint, width: usize, stride: usize,
+                           inverse: c_int, bitrev_out: c_int) -> c_int;
+    pub fn zkhip_lde_batch(ctx: *mut zkhip_ctx, d_in: *const u32, in_stride: usize, d_out: *mut u32, out_stride: usize,
+                           log_n: c_uint, added_bits: c_uint, width: usize, shift: u32) -> c_int;
+
+    // Poseidon2, trace generators
+    pub fn zkhip_poseidon2_permute_batch(ctx: *mut zkhip_ctx, d_states: *mut u32, n: usize) -> c_int;
+    pub fn zkhip_poseidon2_air_tracegen(ctx: *mut zkhip_ctx, d_inputs: *const u32, n_perms: usize, log_height: c_uint,
+                                        d_trace: *mut u32) -> c_int;
+    pub fn zkhip_range_counts_tracegen(ctx: *mut zkhip_ctx, d_values: *const u32, n: usize, log_table: c_uint,
+                                       d_counts: *mut u32, accumulate: c_int) -> c_int;
+
+    // Merkle
+    pub fn zkhip_merkle_commit(ctx: *mut zkhip_ctx, mats: *const zkhip_matrix, n_mats: usize, tree: *mut *mut zkhip_tree,
+                               root_out: *mut u32) -> c_int;
+    pub fn zkhip_tree_root_device(tree: *const zkhip_tree) -> *const u32;
+    pub fn zkhip_tree_log_height(tree: *const zkhip_tree) -> c_uint;
+    pub fn zkhip_tree_layer(ctx: *mut zkhip_ctx, tree: *const zkhip_tree, layer: c_uint, out: *mut u32) -> c_int;
+    pub fn zkhip_merkle_opening_words(tree: *const zkhip_tree) -> usize;
+    pub fn zkhip_merkle_open(ctx: *mut zkhip_ctx, tree: *const zkhip_tree, indices: *const u64, n: usize, out: *mut u32,
+                             cap_words: usize) -> c_int;
+    pub fn zkhip_tree_destroy(ctx: *mut zkhip_ctx, tree: *mut zkhip_tree);
+
+    // FRI fold, LogUp / sum-check blocks
+    pub fn zkhip_fri_fold(ctx: *mut zkhip_ctx, d_in: *const u32, d_out: *mut u32, log_n_out: c_uint, beta: *const u32) -> c_int;
+    pub fn zkhip_ext_batch_inverse(ctx: *mut zkhip_ctx, d_in: *const u32, d_out: *mut u32, n: usize) -> c_int;
+    pub fn zkhip_logup_running_sum(ctx: *mut zkhip_ctx, d_den: *const u32, d_num: *const u32, n: usize, d_out: *mut u32,
+                                   total_out: *mut u32) -> c_int;
+    pub fn zkhip_mle_fold(ctx: *mut zkhip_ctx, d_in: *const u32, d_out: *mut u32, n: usize, r: *const u32) -> c_int;
+    pub fn zkhip_sumcheck_round(ctx: *mut zkhip_ctx, d_tables: *const *const u32, k: usize, n_half: usize, out: *mut u32) -> c_int;
+
+    // transcript
+    pub fn zkhip_transcript_create(ctx: *mut zkhip_ctx, out: *mut *mut zkhip_transcript) -> c_int;
+    pub fn zkhip_transcript_destroy(ctx: *mut zkhip_ctx, t: *mut zkhip_transcript);
+    pub fn zkhip_transcript_observe(ctx: *mut zkhip_ctx, t: *mut zkhip_transcript, vals: *const u32, n: usize) -> c_int;
+    pub fn zkhip_transcript_sample(ctx: *mut zkhip_ctx, t: *mut zkhip_transcript, out: *mut u32, n: usize) -> c_int;
+    pub fn zkhip_transcript_grind(ctx: *mut zkhip_ctx, t: *mut zkhip_transcript, bits: c_uint, witness: *mut u32) -> c_int;
+
+    // STARK
+    pub fn zkhip_keygen(ctx: *mut zkhip_ctx, params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize,
+                        out: *mut *mut zkhip_pk) -> c_int;
+    pub fn zkhip_pk_destroy(ctx: *mut zkhip_ctx, pk: *mut zkhip_pk);
+    pub fn zkhip_pk_prep_commitment(ctx: *mut zkhip_ctx, pk: *const zkhip_pk, air_index: usize, out: *mut u32) -> c_int;
+    pub fn zkhip_proof_size(pk: *const zkhip_pk) -> usize;
+    pub fn zkhip_pk_workspace_bytes(pk: *const zkhip_pk) -> usize;
+    pub fn zkhip_prove(ctx: *mut zkhip_ctx, pk: *const zkhip_pk, d_traces: *const *const u32, pvs: *const *const u32,
+                       out: *mut u8, cap: usize, out_len: *mut usize) -> c_int;
+    pub fn zkhip_prove_async(ctx: *mut zkhip_ctx, pk: *const zkhip_pk, d_traces: *const *const u32, pvs: *const *const u32) -> c_int;
+    pub fn zkhip_proof_fetch(ctx: *mut zkhip_ctx, pk: *const zkhip_pk, out: *mut u8, cap: usize, out_len: *mut usize) -> c_int;
+    pub fn zkhip_verify(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize, pvs: *const *const u32,
+                        proof: *const u8, len: usize) -> c_int;
+
+    // per-kernel timing
+    pub fn zkhip_profile_enable(ctx: *mut zkhip_ctx, on: c_int) -> c_int;
+    pub fn zkhip_profile_read(ctx: *mut zkhip_ctx, out: *mut zkhip_kernel_stat, cap: usize) -> c_int;
+    pub fn zkhip_profile_reset(ctx: *mut zkhip_ctx) -> c_int;
+}
