@@ -290,7 +290,7 @@ def test_single_row_traces(zk, ora):
 
 
 def test_gpu_proofs_match_committed_digests(zk):
-    """The HIP prover against the committed fixture alone (tests/golden/proof_digests_v1.json), no oracle in the loop."""
+    """The HIP prover against the committed fixture alone (tests/golden/proof_digests_v2.json), no oracle in the loop."""
     import hashlib
     import importlib.util
     import json
@@ -300,7 +300,7 @@ def test_gpu_proofs_match_committed_digests(zk):
     spec = importlib.util.spec_from_file_location("gen_proof_digests", os.path.join(here, "gen_proof_digests.py"))
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
-    want = json.load(open(os.path.join(here, "proof_digests_v1.json")))
+    want = json.load(open(os.path.join(here, "proof_digests_v2.json")))
     for name, (params, airs) in gen.cases().items():
         got, _, _ = _prove_gpu(zk, params, airs)
         assert len(got) == 4 * want[name]["words"], name
