@@ -342,3 +342,38 @@ def test_two_contexts_prove_concurrently_from_two_threads(ora):
     for t in threads:
         t.join()
     assert errors == []
+
+
+def test_no_device_memory_leak_over_key_and_context_lifecycles():
+    """A proving service creates and drops keys (per trace shape) and contexts for days: device memory must return."""
+    import gc
+    import torch
+
+    tr, pv = air.fibonacci_trace(10)
+    airs = [dict(program=air.fibonacci_air().program(), log_height=10, width=2, n_pvs=3)]
+    u, m, prep = air.range_traces(9, 6, seed=5)
+    airs2 = [dict(program=air.range_user_air().program(), log_height=9, width=4, n_pvs=0),
+             dict(program=air.range_table_air().program(), log_height=6, width=1, n_pvs=0, prep=prep)]
+    nopv = np.zeros(0, np.uint32)
+
+    def cycle():
+        ctx = z.Context(0)
+        for _ in range(3):
+            pk = z.ProvingKey(ctx, (1, 0, 8, 3, 4), airs)
+            proof = pk.prove([ctx.upload(tr.reshape(-1))], [pv])
+            assert z.verify((1, 0, 8, 3, 4), airs, [pv], proof) == 0
+            pk.close()
+            pk2 = z.ProvingKey(ctx, (1, 0, 8, 3, 4), airs2)       # preprocessed tree + LogUp buffers
+            pk2.prove([ctx.upload(u.reshape(-1)), ctx.upload(m.reshape(-1))], [nopv, nopv])
+            pk2.close()
+        ctx.close()
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    cycle()                                    # first cycle: code objects, allocator pools
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(4):
+        cycle()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), "device memory shrank by %d bytes over 4 lifecycles" % (free0 - free1)
