@@ -58,8 +58,9 @@ int main() {
         b.push_interaction(13, {val, g1}, c, Kind::Receive);
         dump("limb", b);
     }
-    {   // bus_mix_air(6)
+    for (int budget : {3, 5}) {   // bus_mix_air(6); with a degree budget of 5 (blow-up 4) four interactions share a column group
         AirBuilder b(6, 1);
+        b.max_constraint_degree = (unsigned)budget;
         const Expr v0 = b.var(0), v1 = b.var(1);
         const Expr m = v0 * v1;
         b.assert_zero(m - b.var(2));
@@ -83,7 +84,7 @@ int main() {
             const Expr c = b.constant(2);
             b.push_interaction(11, f, c, rep == 0 ? Kind::Send : Kind::Receive);
         }
-        dump("bus_mix", b);
+        dump(budget == 3 ? "bus_mix" : "bus_mix_budget5", b);
     }
     {   // range_table_air(5)
         AirBuilder b(1, 0, 1);

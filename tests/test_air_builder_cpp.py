@@ -25,12 +25,18 @@ def cpp_programs(tmp_path_factory):
     return progs
 
 
+def _with_budget(b, budget):
+    b.max_constraint_degree = budget
+    return b
+
+
 PY = {
     "fibonacci": lambda: air.fibonacci_air(),
     "lookup_sender": lambda: air.lookup_sender_air(3, 7),
     "lookup_table": lambda: air.lookup_table_air(7),
     "limb": lambda: air.limb_air(13),
     "bus_mix": lambda: air.bus_mix_air(6),
+    "bus_mix_budget5": lambda: _with_budget(air.bus_mix_air(6), 5),
     "range_table": lambda: air.range_table_air(5),
     "range_user": lambda: air.range_user_air(4, 5),
     "program_bus": lambda: air.program_bus_air(2),
@@ -49,3 +55,5 @@ def test_cpp_builder_emits_the_same_program(cpp_programs, name):
     if not (got == want).all():
         pytest.fail("first difference at word %d" % int(np.nonzero(got != want)[0][0]))
     assert deg == b.max_degree()
+    if name == "bus_mix_budget5":
+        assert b.interaction_groups == [0, 0, 0, 0, 1, 1] and deg == 5

@@ -180,3 +180,28 @@ def test_random_bus_expressions_match_oracle(zk, ora, seed):
     got = pk.prove([zk.upload(a["trace"].reshape(-1)) for a in airs], pvs)
     assert got == exp.tobytes()
     assert z.verify(params, pk.verifying_airs(), pvs, got) == 0
+
+
+@pytest.mark.parametrize("jit", ["interpreter", "jit"])
+def test_four_interactions_per_column_group_at_blowup_4(zk, ora, jit, monkeypatch):
+    """With blow-up 4 the degree budget is 5: four degree-1 interactions share one group of permutation columns
+    (constraint phi * d1 d2 d3 d4 = sum +-count * prod of the other three, degree 5).  Proof bytes equal the oracle's."""
+    monkeypatch.setenv("ZKHIP_NO_JIT" if jit == "interpreter" else "ZKHIP_FORCE_JIT", "1")
+    b = air.bus_mix_air()
+    b.max_constraint_degree = 5
+    prog = b.program()
+    assert b.interaction_groups == [0, 0, 0, 0, 1, 1] and b.max_degree() == 5
+    tr, pv = air.bus_mix_trace(7, seed=3)
+    ftr, fpv = air.fibonacci_trace(5)
+    airs = [dict(program=prog, log_height=7, width=6, n_pvs=1, trace=tr, pvs=pv),
+            dict(program=air.fibonacci_air().program(), log_height=5, width=2, n_pvs=3, trace=ftr, pvs=fpv)]
+    params = (2, 0, 6, 2, 3)
+    exp = ora.stark_prove(params, airs)
+    assert ora.stark_verify(params, airs, exp) == 0
+    pk = z.ProvingKey(zk, params, airs)
+    got = pk.prove([zk.upload(a["trace"].reshape(-1)) for a in airs], [a["pvs"] for a in airs])
+    assert got == exp.tobytes()
+    assert z.verify(params, airs, [a["pvs"] for a in airs], got) == 0
+    # the same program is over the budget of blow-up 2 and must be refused there
+    with pytest.raises(Exception):
+        z.ProvingKey(zk, (1, 0, 6, 2, 3), airs)
