@@ -278,6 +278,16 @@ def main():
                                      "priced at the row-hash kernel's measured issue rate"}
         except Exception:
             pass
+        # whole-proof HBM roofline (SURVEY.md 8(d) cfg #4: unfused per-stage algorithmic bytes of one proof): the LDE reads
+        # the trace and writes the codeword, the row hash and the constraint kernel each read the codeword once, the
+        # quotient is written once, the fold loop moves ~2 x 2 x M ext elements.  The proof is integer-VALU bound, so
+        # this fraction is small by nature; it is reported because BASELINE.json asks for it.
+        Wt = width + 2
+        alg_proof = 4 * n * Wt + 4 * M * Wt + 4 * M * Wt + 4 * M * Wt + 16 * M + 2 * 2 * 16 * M
+        per_gpu_s = dt / args.steps
+        hbm_whole = {"bound": "hbm", "algorithmic_bytes_per_proof": alg_proof, "achieved": round(alg_proof / per_gpu_s / 1e9, 1),
+                     "peak": 8000.0, "unit": "GB/s", "frac": round(alg_proof / per_gpu_s / 8e12, 4),
+                     "floor_ms_at_6.3TBps": round(alg_proof / 6.3e12 * 1e3, 2)}
         out = {
             "metric": "chunk STARK proofs/sec (2^%d-row trace)" % log_n,
             "value": round(world * args.steps / dt, 4),
@@ -302,6 +312,7 @@ def main():
             "roofline": roof,
             "roofline_other_kernels": others,
             "roofline_valu_whole_proof": valu_roof,
+            "roofline_hbm_whole_proof": hbm_whole,
             "stage_ms_single_stream": {k: round(v[1] / 2, 3) for k, v in sorted(stats_alone.items(), key=lambda kv: -kv[1][1])},
             "stage_note": "per-kernel HIP-event times of one proof running alone (measured after the timed region); "
                           "`roofline` is from the timed region itself",
