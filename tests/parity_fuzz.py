@@ -39,12 +39,31 @@ for case in range(n_cases):
             airs.append(ts._fib(max(lh, 1)))
         else:
             airs.append(tl._limb(lh, seed=seed + k))
+    # every 8th case adds a requester + the Poseidon2 chip on a 24-field bus; the chip's 298 permutation columns are
+    # generated ON THE DEVICE (zkhip_poseidon2_air_tracegen), the oracle generates its own
+    dev_chip = None
+    if case % 8 == 7:
+        import torch
+        import test_p2air_cpu as tp
+
+        lu, lc = int(rng.integers(max(lh_lo, 1), lh_hi + 1)), int(rng.integers(max(lh_lo, 1), lh_hi + 1))
+        n_req = int(rng.integers(2, min(1 << lu, 1 << lc) + 1))
+        pair, uniq = tp.hasher_pair(log_user=lu, n_req=n_req, log_chip=lc, seed=seed, bus=int(rng.integers(20, 200)))
+        airs += pair
+        N = 1 << lc
+        d_chip = torch.empty(299 * N, dtype=torch.int32, device="cuda:0")
+        zk.poseidon2_air_tracegen(zk.upload(uniq.reshape(-1)), lc, d_chip)
+        d_chip[298 * N:] = zk.upload(pair[1]["trace"][298])
+        dev_chip = (len(airs) - 1, d_chip)
     # constraint degree 3 needs blow-up >= 2^1: all our AIRs have degree <= 3
     try:
         exp = ora.stark_prove(params, airs)
         pk = z.ProvingKey(zk, params, airs)
         pvs = [a["pvs"] for a in airs]
-        got = pk.prove([zk.upload(a["trace"].reshape(-1)) for a in airs], pvs)
+        d_traces = [zk.upload(a["trace"].reshape(-1)) for a in airs]
+        if dev_chip is not None:
+            d_traces[dev_chip[0]] = dev_chip[1]
+        got = pk.prove(d_traces, pvs)
         ok = got == exp.tobytes() and z.verify(params, pk.verifying_airs(), pvs, got) == 0
         pk.close()
     except Exception as e:  # noqa: BLE001
