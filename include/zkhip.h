@@ -221,6 +221,28 @@ int zkhip_proof_fetch(zkhip_ctx *ctx, const zkhip_pk *pk, uint8_t *out, size_t c
 int zkhip_verify(const zkhip_params *params, const zkhip_air *airs, size_t n_airs,
                  const uint32_t *const *pvs, const uint8_t *proof, size_t len);
 
+/* Field offsets of a proof, in 32-bit words from its start (the layout is static for given parameters and AIR shapes:
+ * DESIGN.md section 4).  The counterpart of `Proof::<SC>::decode_from_bytes` (crates/verifier/src/verifier.rs:62) for this
+ * backend's proofs: commitments, opened values, FRI layers and query openings are read in place.  Needs no device. */
+typedef struct {
+    size_t n_words;      /* whole proof; n_words * 4 == zkhip_proof_size */
+    size_t root_main;    /* 8 words */
+    size_t root_perm;    /* 8 words; 0 = no AIR has bus interactions */
+    size_t exposed;      /* n_exposed x 4 words: the LogUp sums of the AIRs with interactions, in AIR order */
+    size_t n_exposed;
+    size_t root_quot;    /* 8 words */
+    size_t opened;       /* n_opened extension elements (4 words each): main, preprocessed, permutation, quotient */
+    size_t n_opened;
+    size_t fri_layers;   /* n_fri_layers x { root(8), proof-of-work witness(1) } */
+    size_t n_fri_layers;
+    size_t final_poly;   /* 4 words */
+    size_t query_pow;    /* 1 word */
+    size_t queries;      /* query i occupies [queries + i * query_words, +query_words) */
+    size_t query_words;
+    size_t n_queries;
+} zkhip_proof_layout;
+int zkhip_proof_layout_of(const zkhip_params *params, const zkhip_air *airs, size_t n_airs, zkhip_proof_layout *out);
+
 /* ---- per-kernel timing (HIP events on the ctx stream), for bench.py's roofline ---- */
 int zkhip_profile_enable(zkhip_ctx *ctx, int on);
 /* copies up to cap entries; returns number of distinct kernel names recorded */

@@ -64,6 +64,26 @@ pub struct zkhip_air {
 }
 
 #[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct zkhip_proof_layout {
+    pub n_words: usize,
+    pub root_main: usize,
+    pub root_perm: usize,
+    pub exposed: usize,
+    pub n_exposed: usize,
+    pub root_quot: usize,
+    pub opened: usize,
+    pub n_opened: usize,
+    pub fri_layers: usize,
+    pub n_fri_layers: usize,
+    pub final_poly: usize,
+    pub query_pow: usize,
+    pub queries: usize,
+    pub query_words: usize,
+    pub n_queries: usize,
+}
+
+#[repr(C)]
 #[derive(Clone, Copy)]
 pub struct zkhip_kernel_stat {
     pub name: [c_char; 48],
@@ -141,6 +161,9 @@ extern "C" {
     pub fn zkhip_proof_fetch(ctx: *mut zkhip_ctx, pk: *const zkhip_pk, out: *mut u8, cap: usize, out_len: *mut usize) -> c_int;
     pub fn zkhip_verify(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize, pvs: *const *const u32,
                         proof: *const u8, len: usize) -> c_int;
+
+    pub fn zkhip_proof_layout_of(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize,
+                                 out: *mut zkhip_proof_layout) -> c_int;
 
     // per-kernel timing
     pub fn zkhip_profile_enable(ctx: *mut zkhip_ctx, on: c_int) -> c_int;

@@ -65,3 +65,37 @@ def test_degree_bound_enforced():
     b.assert_zero(x * x * x * x - b.var(1))
     airs = [dict(program=b.program(), log_height=3, width=2, n_pvs=0)]
     assert z.verify(PARAMS, airs, [np.zeros(0, np.uint32)], np.zeros(64, np.uint32).tobytes()) == -8
+
+
+def test_proof_layout_matches_the_proofs(ora):
+    """zkhip_proof_layout_of: the static field offsets agree with oracle proofs of AIR sets with every feature
+    (mixed heights, preprocessed tree, LogUp phase) -- size, magic-dependent sections, commitments, exposed sums."""
+    import zkvm_prover_amd as z
+    from zkvm_prover_amd import air
+    from test_prep_cpu import range_case, verifying_airs, PARAMS as PP
+
+    nopv = np.zeros(0, np.uint32)
+    ftr, fpv = air.fibonacci_trace(6)
+    fib = dict(program=air.fibonacci_air().program(), log_height=6, width=2, n_pvs=3, trace=ftr, pvs=fpv)
+    tr, pv = air.bus_mix_trace(4, seed=1)
+    mix = dict(program=air.bus_mix_air().program(), log_height=4, width=6, n_pvs=1, trace=tr, pvs=pv)
+    for params, airs in [((1, 0, 7, 2, 3), [fib]), ((2, 0, 5, 1, 1), [mix, fib]), (PP, range_case())]:
+        proof = ora.stark_prove(params, airs)
+        lay = z.proof_layout(params, airs)
+        assert lay["n_words"] == len(proof)
+        assert lay["queries"] + lay["n_queries"] * lay["query_words"] == len(proof) and lay["n_queries"] == params[2]
+        assert lay["root_main"] == 4 and lay["n_fri_layers"] == int(proof[3])
+        has_lu = any(air.LOGUP_MAGIC in [int(w) for w in a["program"]] for a in airs)
+        assert (lay["root_perm"] != 0) == has_lu == bool((int(proof[0]) - 0x31504B5A) & 1)
+        if has_lu:
+            # the exposed sums of all AIRs with interactions cancel (each is an extension element)
+            ex = proof[lay["exposed"]: lay["exposed"] + 4 * lay["n_exposed"]].astype(np.int64).reshape(-1, 4)
+            assert (ex.sum(axis=0) % ora.P == 0).all()
+        # tampering with the word just before / at the located fields is caught by the verifier
+        vk = verifying_airs(ora, airs) if any(a.get("prep") is not None for a in airs) else airs
+        pvs = [a["pvs"] for a in airs]
+        assert z.verify(params, vk, pvs, proof.tobytes()) == 0
+        for field in ("root_main", "root_quot", "opened", "fri_layers", "final_poly", "query_pow", "queries"):
+            bad = proof.copy()
+            bad[lay[field]] = (int(bad[lay[field]]) + 1) % ora.P
+            assert z.verify(params, vk, pvs, bad.tobytes()) != 0, field

@@ -16,6 +16,7 @@ from ._binding import (  # noqa: F401
     declared_symbols,
     ProvingKey,
     verify,
+    proof_layout,
     DEFAULT_PARAMS,
 )
 from . import air  # noqa: F401

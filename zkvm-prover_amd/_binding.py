@@ -43,6 +43,12 @@ class _Air(C.Structure):
                 ("prep_commit", C.POINTER(C.c_uint32))]
 
 
+class _ProofLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("n_words", "root_main", "root_perm", "exposed", "n_exposed", "root_quot", "opened",
+                                          "n_opened", "fri_layers", "n_fri_layers", "final_poly", "query_pow", "queries",
+                                          "query_words", "n_queries")]
+
+
 class _KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -107,6 +113,7 @@ def load_library():
         "zkhip_prove_async": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(u32p)]),
         "zkhip_proof_fetch": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), sz, C.POINTER(sz)]),
         "zkhip_verify": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(u32p), C.POINTER(C.c_uint8), sz]),
+        "zkhip_proof_layout_of": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(_ProofLayout)]),
         "zkhip_profile_enable": (C.c_int, [vp, C.c_int]),
         "zkhip_profile_read": (C.c_int, [vp, C.POINTER(_KernelStat), sz]),
         "zkhip_profile_reset": (C.c_int, [vp]),
@@ -443,6 +450,18 @@ class ProvingKey:
             self.close()
         except Exception:
             pass
+
+
+def proof_layout(params, airs):
+    """Word offsets of the fields of a proof for these parameters / AIR shapes (dict; needs no GPU)."""
+    lib = load_library()
+    prm = _Params(*params)
+    arr, keep = _air_structs(airs)
+    out = _ProofLayout()
+    rc = lib.zkhip_proof_layout_of(C.byref(prm), arr, len(airs), C.byref(out))
+    if rc != 0:
+        raise ZkhipError("zkhip_proof_layout_of returned %d" % rc)
+    return {name: int(getattr(out, name)) for name, _ in _ProofLayout._fields_}
 
 
 def verify(params, airs, pvs, proof_bytes):

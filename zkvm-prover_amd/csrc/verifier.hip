@@ -98,6 +98,59 @@ bool verify_opening(const uint32_t root_m[8], const std::vector<unsigned>& lhs, 
 
 using namespace zk;
 
+// Word offsets of the fields of a proof: what Proof::<SC>::decode_from_bytes gives the reference's
+// verifier (crates/verifier/src/verifier.rs:62) -- here the layout is static, so "decoding" is a table of offsets.
+extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, zkhip_proof_layout* out) {
+    if (!prm || !airs || !out || n_airs == 0) return ZKHIP_ERR_INVALID;
+    const unsigned b = prm->log_blowup, nch = 1u << b;
+    if (prm->log_final_poly_len != 0 || b < 1 || b > 4) return ZKHIP_ERR_INVALID;
+    unsigned hmax = 0;
+    size_t n_lu = 0, n_open = 0;
+    size_t main_w = 0, perm_w = 0, quot_w = 0, prep_words = 0;   // opened row words per query, per input commitment
+    unsigned main_h = 0, perm_h = 0;
+    for (size_t a = 0; a < n_airs; a++) {
+        AirProgram pg;
+        if (parse_air(airs[a].program, airs[a].program_len, airs[a].width, &pg, nullptr) != 0) return ZKHIP_ERR_INVALID;
+        if (airs[a].log_height > 27) return ZKHIP_ERR_INVALID;
+        const unsigned h = airs[a].log_height + b;
+        hmax = std::max(hmax, h);
+        main_h = std::max(main_h, h);
+        main_w += airs[a].width;
+        quot_w += 4 * (size_t)nch;
+        n_open += 2 * airs[a].width + 4 * (size_t)nch;
+        if (pg.prep_width) {
+            prep_words += pg.prep_width + 8 * (size_t)h;
+            n_open += 2 * pg.prep_width;
+        }
+        if (!pg.ints.empty()) {
+            n_lu++;
+            perm_w += pg.perm_width();
+            perm_h = std::max(perm_h, h);
+            n_open += 2 * pg.perm_width();
+        }
+    }
+    const unsigned n_layers = hmax - b;
+    memset(out, 0, sizeof *out);
+    size_t r = 4;
+    out->root_main = r, r += 8;
+    if (n_lu) {
+        out->root_perm = r, r += 8;
+        out->exposed = r, out->n_exposed = n_lu, r += 4 * n_lu;
+    }
+    out->root_quot = r, r += 8;
+    out->opened = r, out->n_opened = n_open, r += 4 * n_open;
+    out->fri_layers = r, out->n_fri_layers = n_layers, r += 9 * (size_t)n_layers;
+    out->final_poly = r, r += 4;
+    out->query_pow = r, r += 1;
+    out->queries = r;
+    size_t qw = main_w + 8 * (size_t)main_h + prep_words + (n_lu ? perm_w + 8 * (size_t)perm_h : 0) + quot_w + 8 * (size_t)main_h;
+    for (unsigned l = 0; l < n_layers; l++) qw += 4 + 8 * (size_t)(hmax - l - 1);
+    out->query_words = qw;
+    out->n_queries = prm->num_queries;
+    out->n_words = r + qw * prm->num_queries;
+    return ZKHIP_OK;
+}
+
 extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, const uint32_t* const* pvs,
                             const uint8_t* proof_bytes, size_t len) {
     if (!prm || !airs || !proof_bytes || n_airs == 0 || (len & 3)) return ZKHIP_ERR_INVALID;
