@@ -75,11 +75,25 @@ ZK_HD void p2_external_linear(uint32_t s[16]) {
 
 ZK_HD void p2_internal_linear(uint32_t s[16]) {
     uint32_t sum = 0;
+#ifdef ZK_P2_MODULAR_SUM
     {
         uint32_t a0 = madd(s[0], s[1]), a1 = madd(s[2], s[3]), a2 = madd(s[4], s[5]), a3 = madd(s[6], s[7]);
         uint32_t a4 = madd(s[8], s[9]), a5 = madd(s[10], s[11]), a6 = madd(s[12], s[13]), a7 = madd(s[14], s[15]);
         sum = madd(madd(madd(a0, a1), madd(a2, a3)), madd(madd(a4, a5), madd(a6, a7)));
     }
+#else
+    {
+        // Lazy sum of the 16 lanes: pairs fit 32 bits (2p < 2^32), the eight pair sums are added in 64 bits (< 16p < 2^35)
+        // and folded once with 2^32 == 2^28 - 2 (mod p): 30 instructions instead of the 45 of fifteen modular additions.
+        const uint32_t a0 = s[0] + s[1], a1 = s[2] + s[3], a2 = s[4] + s[5], a3 = s[6] + s[7];
+        const uint32_t a4 = s[8] + s[9], a5 = s[10] + s[11], a6 = s[12] + s[13], a7 = s[14] + s[15];
+        const uint64_t t = (uint64_t)a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+        const uint64_t x = (uint64_t)(uint32_t)(t >> 32) * 0x0FFFFFFEu + (uint32_t)t;  // < 7 * 2^28 + 2^32 < 2^33
+        // x >= 2^32 leaves a low word below 2^31, so adding 2^28 - 2 cannot wrap
+        const uint32_t y = (uint32_t)x + ((uint32_t)(x >> 32) ? 0x0FFFFFFEu : 0u);     // < 2^32 < 3p
+        sum = red_2p(red_2p(y));
+    }
+#endif
     uint32_t d;
     s[0] = msub(sum, mdouble(s[0]));                          // -2
     s[1] = madd(sum, s[1]);                                   //  1
