@@ -129,6 +129,25 @@ ZK_HD uint32_t mred64(uint64_t t) {
     if (r >= 2ull * P) r -= 2ull * P;
     return red_2p((uint32_t)r);
 }
+// Split accumulator for long sums of Montgomery products (sum_k a_k * b_k with hundreds of terms): groups of four
+// products are summed in 64 bits (4 p^2 < 2^64) and the group sum is banked as two halves -- hi += t >> 32,
+// lo += t & (2^32 - 1), four full-rate instructions -- instead of being Montgomery-reduced and added modularly (13).
+// One reduction at the end: sum * 2^-32 = hi + lo * 2^-32 (mod p).  Good for < 2^31 groups (hi, lo < 2^63).
+struct LazyAcc {
+    uint64_t hi = 0, lo = 0;
+    ZK_HD void add_group(uint64_t t) {
+        hi += t >> 32;
+        lo += (uint32_t)t;
+    }
+    // the Montgomery-form value of the banked sum: (hi * 2^32 + lo) * 2^-32 mod p
+    ZK_HD uint32_t reduce() const {
+        // hi < 2^63: split once more so that every piece satisfies mred64's bound (< 0.94 * 2^64)
+        const uint32_t h = mmul(mred64(hi & 0xffffffffull), MONTY_R2);                     // (hi mod 2^32) mod p
+        const uint32_t hh = mmul(mmul(mred64(hi >> 32), MONTY_R2), MONTY_R2);              // (hi >> 32) * 2^32 mod p
+        const uint32_t l = madd(mred64(lo & 0xffffffffull), mmul(mred64(lo >> 32), MONTY_R2));  // lo * 2^-32 mod p
+        return madd(madd(h, hh), l);
+    }
+};
 constexpr uint32_t EXT_W_MONTY = 939524073u;  // 11 * 2^32 mod p
 ZK_HD Ext ext_mul(const Ext& a, const Ext& b) {
     // schoolbook, delayed reduction: every coefficient sums <= 4 products in 64 bits.

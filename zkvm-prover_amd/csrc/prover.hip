@@ -455,8 +455,10 @@ __global__ __launch_bounds__(256) void k_reduced_openings(ReduceArgs a) {
     for (uint32_t m = 0; m < a.n_items; m++) {
         const RoItem it = a.items[m];
         // sum_k apow[k] * mat[k][r]: products of residues are summed in 64 bits, four at a time
-        // (4 p^2 < 2^64), and Montgomery-reduced once per group -- 4 v_mad_u64_u32 per column instead of
-        // 4 full modular multiply-adds; 8 column loads are in flight per lane
+        // (4 p^2 < 2^64), the group sums are banked in split 64-bit accumulators (LazyAcc) and reduced once per
+        // matrix row -- 4 v_mad_u64_u32 + 4 adds per column instead of 4 full modular multiply-adds; 8 column loads are
+        // in flight per lane
+        LazyAcc lz[4];
         uint32_t acc[4] = {0, 0, 0, 0};
         const uint32_t* col = it.mat + r;
         uint32_t k = 0;
@@ -474,8 +476,12 @@ __global__ __launch_bounds__(256) void k_reduced_openings(ReduceArgs a) {
                     for (int q = 0; q < 4; q++) t[q] += (uint64_t)ap[q] * v[g + u];
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) acc[q] = madd(acc[q], mred64(t[q]));
+                for (int q = 0; q < 4; q++) lz[q].add_group(t[q]);
             }
+        }
+        if (it.width >= 8) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[q] = lz[q].reduce();
         }
         for (; k < it.width; k++) {
             const uint32_t v = col[(size_t)k * M];
