@@ -172,9 +172,10 @@ int zkhip_transcript_grind(zkhip_ctx *ctx, zkhip_transcript *t, unsigned bits, u
 
 /* ---- STARK proving / verification (a7 of SURVEY.md 8(a)): the `StarkEngine::prove`
  *      replacement.  See DESIGN.md for protocol, AIR bytecode and proof layout. ---- */
+#define ZKHIP_MAX_LOG_FINAL_POLY 8
 typedef struct {
     uint32_t log_blowup;         /* openvm.toml:2  */
-    uint32_t log_final_poly_len; /* openvm.toml:3  */
+    uint32_t log_final_poly_len; /* openvm.toml:3; <= ZKHIP_MAX_LOG_FINAL_POLY, and no trace shorter than 2^log_final_poly_len rows */
     uint32_t num_queries;        /* openvm.toml:4  */
     uint32_t commit_pow_bits;    /* openvm.toml:5  */
     uint32_t query_pow_bits;     /* openvm.toml:6  */
@@ -235,7 +236,8 @@ typedef struct {
     size_t n_opened;
     size_t fri_layers;   /* n_fri_layers x { root(8), proof-of-work witness(1) } */
     size_t n_fri_layers;
-    size_t final_poly;   /* 4 words */
+    size_t final_poly;   /* n_final_poly = 2^log_final_poly_len coefficients, 4 words each */
+    size_t n_final_poly;
     size_t query_pow;    /* 1 word */
     size_t queries;      /* query i occupies [queries + i * query_words, +query_words) */
     size_t query_words;

@@ -14,6 +14,7 @@ pub const ZKHIP_ERR_VERIFY: c_int = -7;
 pub const ZKHIP_ERR_CONSTRAINT: c_int = -8;
 pub const ZKHIP_DIGEST_WORDS: usize = 8;
 pub const ZKHIP_POSEIDON2_AIR_WIDTH: usize = 298;
+pub const ZKHIP_MAX_LOG_FINAL_POLY: u32 = 8;
 
 #[repr(C)]
 pub struct zkhip_ctx {
@@ -77,6 +78,7 @@ pub struct zkhip_proof_layout {
     pub fri_layers: usize,
     pub n_fri_layers: usize,
     pub final_poly: usize,
+    pub n_final_poly: usize,
     pub query_pow: usize,
     pub queries: usize,
     pub query_words: usize,

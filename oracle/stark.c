@@ -45,6 +45,7 @@
 #define PROTO_TAG 0x5A4B4831u /* "1HKZ" < p */
 #define GEN 31u
 #define MAX_FIELDS 32
+#define MAX_LOG_FINAL_POLY 8
 #define N_CHAL (4 * (1 + MAX_FIELDS))
 
 enum { OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_PERM, OP_CHAL, OP_EXPOSED, OP_PREP };
@@ -376,7 +377,8 @@ int ora_prep_commit(const ora_params *prm, const ora_air_instance *air, uint32_t
 size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size_t n_airs, uint32_t *out,
                        size_t cap) {
     const unsigned b = prm->log_blowup, nch = 1u << b;
-    if (prm->log_final_poly_len != 0 || n_airs == 0 || b == 0) return 0;
+    const unsigned lfp = prm->log_final_poly_len; /* the fold loop stops at 2^(b+lfp) values = a polynomial of degree < 2^lfp */
+    if (lfp > MAX_LOG_FINAL_POLY || n_airs == 0 || b == 0) return 0;
     air_state *st = (air_state *)calloc(n_airs, sizeof(air_state));
     unsigned hmax = 0;
     size_t n_lu = 0, n_prep = 0;
@@ -384,6 +386,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
     int *has_prep = (int *)calloc(n_airs, sizeof(int));
     for (size_t a = 0; a < n_airs; a++) {
         if (airs[a].log_height > 27) return 0;
+        if (airs[a].log_height < lfp) return 0; /* shorter than the final polynomial: its openings would never join the fold */
         if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &st[a].prog)) return 0;
         if (st[a].prog.n_pvs != airs[a].n_pvs) return 0;
         st[a].lh = airs[a].log_height;
@@ -645,7 +648,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
     }
 
     /* 5. FRI commit phase */
-    const unsigned n_layers = hmax - b;
+    const unsigned n_layers = hmax - b - lfp;
     ora_tree **ftrees = (ora_tree **)calloc(n_layers, sizeof(ora_tree *));
     uint32_t **flayers = (uint32_t **)calloc(n_layers + 1, sizeof(uint32_t *)); /* [len][4] each */
     uint32_t **fleaves = (uint32_t **)calloc(n_layers, sizeof(uint32_t *));      /* column-major 8 x len/2 */
@@ -676,10 +679,30 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
             }
         }
     }
-    const uint32_t *fin = flayers[n_layers]; /* 2^b values, all equal for a valid proof */
-    for (size_t i = 1; i < ((size_t)1 << b); i++)
-        if (memcmp(fin, fin + 4 * i, 16)) ok = 0;
-    ora_ch_observe(&ch, fin, 4);
+    /* final polynomial: the last layer holds 2^(b+lfp) evaluations (bit-reversed) over the subgroup of that size of a
+     * polynomial of degree < 2^lfp; its 2^lfp coefficients are sent.  lfp = 0: a constant (all values equal). */
+    const size_t n_fin = (size_t)1 << lfp, n_last = (size_t)1 << (b + lfp);
+    uint32_t *fin = (uint32_t *)calloc(4 * n_fin, sizeof(uint32_t));
+    {
+        const uint32_t *last = flayers[n_layers];
+        if (lfp == 0) {
+            for (size_t i = 1; i < n_last; i++)
+                if (memcmp(last, last + 4 * i, 16)) ok = 0;
+            memcpy(fin, last, 16);
+        } else {
+            uint32_t *mat = (uint32_t *)malloc(4 * n_last * sizeof(uint32_t)); /* 4 coordinate columns, natural order */
+            for (size_t i = 0; i < n_last; i++)
+                for (int q = 0; q < 4; q++) mat[(size_t)q * n_last + i] = last[4 * bitrev(i, b + lfp) + q];
+            ora_dft_batch(mat, b + lfp, 4, n_last, 1);
+            for (size_t j = 0; j < n_last; j++)
+                for (int q = 0; q < 4; q++) {
+                    if (j < n_fin) fin[4 * j + q] = mat[(size_t)q * n_last + j];
+                    else if (mat[(size_t)q * n_last + j]) ok = 0; /* not low-degree: unsatisfied witness */
+                }
+            free(mat);
+        }
+    }
+    ora_ch_observe(&ch, fin, 4 * n_fin);
     uint32_t qpow = ora_ch_grind(&ch, prm->query_pow_bits);
 
     /* 6. assemble the proof */
@@ -705,7 +728,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
             PUT(froots[l], 8);
             PUT(&fpow[l], 1);
         }
-        PUT(fin, 4);
+        PUT(fin, 4 * n_fin);
         PUT(&qpow, 1);
         size_t tmp_words = 8 * (hmax + 1) + 16;
         for (size_t m = 0; m < n_cm; m++) tmp_words += cm[m].width;
@@ -751,7 +774,7 @@ done:
     if (t_perm) ora_tree_free(t_perm);
     free(ftrees), free(flayers), free(fleaves), free(froots), free(fpow), free(betas);
     free(ro), free(num_reduced), free(opened), free(mm), free(pm), free(qm), free(qnat), free(cm), free(st);
-    free(prep_roots), free(has_prep);
+    free(prep_roots), free(has_prep), free(fin);
     return ok ? w : 0;
 }
 
@@ -765,7 +788,8 @@ typedef struct {
 int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t n_airs, const uint32_t *proof,
                      size_t n_words) {
     const unsigned b = prm->log_blowup, nch = 1u << b;
-    if (prm->log_final_poly_len != 0 || n_airs == 0 || b == 0) return -1;
+    const unsigned lfp = prm->log_final_poly_len;
+    if (lfp > MAX_LOG_FINAL_POLY || n_airs == 0 || b == 0) return -1;
     program *pg = (program *)calloc(n_airs, sizeof(program));
     unsigned hmax = 0;
     size_t n_lu = 0, n_prep = 0;
@@ -773,7 +797,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     int *has_prep = (int *)calloc(n_airs, sizeof(int));
     for (size_t a = 0; a < n_airs; a++) {
         if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &pg[a])) return -2;
-        if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height > 27) return -2;
+        if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height > 27 || airs[a].log_height < lfp) return -2;
         if (airs[a].log_height + b > hmax) hmax = airs[a].log_height + b;
         if (pg[a].n_int) n_lu++;
         if (pg[a].prep_width) {
@@ -799,7 +823,8 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
             for (unsigned j = 0; j < nch; j++) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, 4, 1};
         for (size_t m = 0; m < n_cm; m++) n_open += cm[m].width * cm[m].n_pts;
     }
-    const unsigned n_layers = hmax - b;
+    const unsigned n_layers = hmax - b - lfp;
+    const size_t n_fin = (size_t)1 << lfp;
     size_t r = 0;
 #define NEED(n)                         \
     do {                                \
@@ -825,11 +850,11 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     NEED(4 * n_open);
     const ext_t *opened = (const ext_t *)(proof + r);
     r += 4 * n_open;
-    NEED(9 * (size_t)n_layers + 5);
+    NEED(9 * (size_t)n_layers + 4 * n_fin + 1);
     const uint32_t *fri_hdr = proof + r;
     r += 9 * (size_t)n_layers;
-    const uint32_t *fin = proof + r;
-    r += 4;
+    const uint32_t *fin = proof + r; /* 2^lfp coefficients */
+    r += 4 * n_fin;
     const uint32_t qpow = proof[r++];
 
     ora_challenger ch;
@@ -942,7 +967,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
         if (!ora_ch_check_witness(&ch, prm->commit_pow_bits, fri_hdr[9 * l + 8])) return -5;
         ora_ch_sample_ext(&ch, betas[l]);
     }
-    ora_ch_observe(&ch, fin, 4);
+    ora_ch_observe(&ch, fin, 4 * n_fin);
     if (!ora_ch_check_witness(&ch, prm->query_pow_bits, qpow)) return -5;
 
     /* shapes of the input batches: main, one per preprocessed trace, perm, quotient */
@@ -1063,7 +1088,14 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
                 ext_add(eval, t, eval);
             }
         }
-        if (rc == 0 && memcmp(eval, fin, 16)) rc = -8;
+        if (rc == 0) { /* the folded value must be the final polynomial at this query's point of the last domain (Horner) */
+            ext_t want = {0, 0, 0, 0};
+            const uint32_t xf = lfp ? ora_pow(ora_two_adic_generator(b + lfp), bitrev(idx >> n_layers, b + lfp)) : 0;
+            for (size_t j = n_fin; j-- > 0;) {
+                for (int k = 0; k < 4; k++) want[k] = ora_add(ora_mul(want[k], xf), fin[4 * j + k]);
+            }
+            if (memcmp(eval, want, 16)) rc = -8;
+        }
     }
     if (rc == 0 && r != n_words) rc = -3;
     free(betas), free(lhs_all), free(ws_all), free(roq), free(has), free(num_reduced), free(open_off), free(cm);

@@ -55,6 +55,10 @@ for case in range(n_cases):
         zk.poseidon2_air_tracegen(zk.upload(uniq.reshape(-1)), lc, d_chip)
         d_chip[298 * N:] = zk.upload(pair[1]["trace"][298])
         dev_chip = (len(airs) - 1, d_chip)
+    # final polynomial length: any value up to the shortest trace of the set (every second case; 0 = a constant)
+    if case % 2 == 1:
+        lfp_max = min(4, min(a["log_height"] for a in airs))
+        params = (params[0], int(rng.integers(0, lfp_max + 1)), params[2], params[3], params[4])
     # constraint degree 3 needs blow-up >= 2^1: all our AIRs have degree <= 3
     try:
         exp = ora.stark_prove(params, airs)

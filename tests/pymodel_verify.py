@@ -174,7 +174,7 @@ def verify(params, airs, proof_words):
     """params = (log_blowup, log_final_poly_len, num_queries, commit_pow_bits, query_pow_bits);
     airs: dicts with program, log_height, width, n_pvs, pvs[, prep_commit].  Raises Reject, returns True."""
     b, lfp, n_queries, cpow, qpow = params
-    need(lfp == 0 and b >= 1, "parameters")
+    need(0 <= lfp <= 8 and b >= 1, "parameters")
     nch = 1 << b
     pr = [int(x) for x in proof_words]
     need(all(x < P for x in pr), "non-canonical word")
@@ -185,7 +185,8 @@ def verify(params, airs, proof_words):
         if pg.prep_width:
             need(a.get("prep_commit") is not None, "missing preprocessed commitment")
     hmax = max(a["log_height"] + b for a in airs)
-    n_layers = hmax - b
+    need(all(a["log_height"] >= lfp for a in airs), "a trace shorter than the final polynomial")
+    n_layers = hmax - b - lfp
     lu = [i for i, pg in enumerate(progs) if pg.ints]
     pp = [i for i, pg in enumerate(progs) if pg.prep_width]
     # committed matrices in opening order: (air, kind, log_height(trace), width, n_pts)
@@ -217,7 +218,7 @@ def verify(params, airs, proof_words):
     for _ in range(n_layers):
         fri_roots.append(take(8))
         fri_pows.append(take(1)[0])
-    fin = take(4)
+    fin = [take(4) for _ in range(1 << lfp)]          # coefficients of the final polynomial (degree < 2^lfp)
     qpow_w = take(1)[0]
 
     # ---- transcript ----
@@ -326,7 +327,7 @@ def verify(params, airs, proof_words):
         ch.observe([fri_pows[l]])
         need(ch.sample_bits(cpow) == 0, "commit-phase proof of work")
         betas.append(ch.sample_ext())
-    ch.observe(fin)
+    ch.observe([w for c in fin for w in c])
     ch.observe([qpow_w])
     need(ch.sample_bits(qpow) == 0, "query proof of work")
 
@@ -380,6 +381,11 @@ def verify(params, airs, proof_words):
             ev = e_add(pair[0], e_mul(e_sub(betas[l], e_from(xx)), d))
             if (log_len - 1) in ro:
                 ev = e_add(ev, e_mul(e_mul(betas[l], betas[l]), ro[log_len - 1]))
-        need(ev == fin, "final value")
+        # the folded value is the final polynomial at this query's point of the last domain (size 2^(b + lfp))
+        xf = pow(m.two_adic_generator(b + lfp), m.bitrev(idx >> n_layers, b + lfp), P) if lfp else 0
+        want = ZERO
+        for c in reversed(fin):
+            want = e_add(e_scale(want, xf), c)
+        need(ev == want, "final value")
     need(pos[0] == len(pr), "trailing proof words")
     return True

@@ -377,3 +377,28 @@ def test_no_device_memory_leak_over_key_and_context_lifecycles():
         cycle()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), "device memory shrank by %d bytes over 4 lifecycles" % (free0 - free1)
+
+
+@pytest.mark.parametrize("lfp", [1, 2, 3, 5])
+def test_final_polynomial_of_positive_length_equals_oracle(zk, ora, lfp):
+    """log_final_poly_len > 0 (openvm.toml:3): fewer FRI layers, 2^lfp final coefficients interpolated on the device.
+    Proof bytes equal the oracle's for mixed heights, LogUp and preprocessed AIRs; the tallest trace may be as short as
+    the final polynomial itself (no fold layers beyond the blow-up)."""
+    from test_gpu_logup import _mix
+    from test_gpu_prep import _range
+
+    u, t = _range(7, 5, seed=4)
+    cases = [[_syn(8, 12, 5, 3), _fib(6)], [_mix(6, 2), _fib(5), u, t]]
+    if lfp <= 3:
+        cases.append([_fib(lfp)])            # h_max = b + lfp: the reduced-openings vector is the final layer
+    for airs in cases:
+        for params in [(1, lfp, 7, 2, 3), (2, lfp, 4, 1, 2)]:
+            exp = ora.stark_prove(params, airs)
+            pk = z.ProvingKey(zk, params, airs)
+            pvs = [a["pvs"] for a in airs]
+            got = pk.prove([zk.upload(a["trace"].reshape(-1)) for a in airs], pvs)
+            assert got == exp.tobytes(), (lfp, params, [a["log_height"] for a in airs])
+            assert z.verify(params, pk.verifying_airs(), pvs, got) == 0
+            assert len(got) == 4 * z.proof_layout(params, pk.verifying_airs())["n_words"]
+    with pytest.raises(Exception, match="shorter than the final polynomial"):
+        z.ProvingKey(zk, (1, lfp, 7, 2, 3), [_fib(lfp - 1)] if lfp > 1 else [dict(_fib(1), log_height=0)])

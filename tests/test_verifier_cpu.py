@@ -99,3 +99,41 @@ def test_proof_layout_matches_the_proofs(ora):
             bad = proof.copy()
             bad[lay[field]] = (int(bad[lay[field]]) + 1) % ora.P
             assert z.verify(params, vk, pvs, bad.tobytes()) != 0, field
+
+
+@pytest.mark.parametrize("lfp", [1, 2, 3, 4])
+def test_final_polynomial_of_positive_length(ora, lfp):
+    """log_final_poly_len > 0: the fold loop stops at 2^(b+lfp) values and the proof carries 2^lfp coefficients.  The
+    oracle's proofs are accepted by the product's host verifier and by the Python verifier, shrink with lfp, and every
+    coefficient is bound (tampering is rejected); an AIR shorter than the final polynomial is refused."""
+    import zkvm_prover_amd as z
+    from zkvm_prover_amd import air
+    import pymodel_verify
+
+    ftr, fpv = air.fibonacci_trace(6)
+    fib = dict(program=air.fibonacci_air().program(), log_height=6, width=2, n_pvs=3, trace=ftr, pvs=fpv)
+    tr, pv = air.bus_mix_trace(4, seed=1)
+    mix = dict(program=air.bus_mix_air().program(), log_height=4, width=6, n_pvs=1, trace=tr, pvs=pv)
+    airs, pvs = [mix, fib], [pv, fpv]
+    params, params0 = (1, lfp, 6, 2, 3), (1, 0, 6, 2, 3)
+    proof = ora.stark_prove(params, airs)
+    assert 0 < len(proof) < len(ora.stark_prove(params0, airs))
+    assert ora.stark_verify(params, airs, proof) == 0
+    assert z.verify(params, airs, pvs, proof.tobytes()) == 0
+    assert pymodel_verify.verify(params, airs, proof) is True
+    lay = z.proof_layout(params, airs)
+    assert lay["n_words"] == len(proof) and lay["n_final_poly"] == 1 << lfp and int(proof[3]) == lay["n_fri_layers"] == 6 + 1 - 1 - lfp
+    for j in range(1 << lfp):
+        bad = proof.copy()
+        w = lay["final_poly"] + 4 * j + (j % 4)
+        bad[w] = (int(bad[w]) + 1) % ora.P
+        assert ora.stark_verify(params, airs, bad) != 0 and z.verify(params, airs, pvs, bad.tobytes()) != 0
+    # a proof for one lfp does not verify under another
+    assert z.verify(params0, airs, pvs, proof.tobytes()) != 0
+    # a trace shorter than the final polynomial cannot be part of the set
+    tiny = dict(program=air.fibonacci_air().program(), log_height=lfp - 1, width=2, n_pvs=3)
+    tt, tp = air.fibonacci_trace(lfp - 1) if lfp > 1 else (np.array([[0], [1]], np.uint32), np.array([0, 1, 1], np.uint32))
+    tiny.update(trace=tt, pvs=tp)
+    with pytest.raises(RuntimeError):
+        ora.stark_prove(params, airs + [tiny])
+    assert z.verify(params, airs + [tiny], pvs + [tp], proof.tobytes()) != 0

@@ -553,6 +553,22 @@ __global__ __launch_bounds__(64) void k_fri_query(const FriLayerDesc* layers, co
     }
 }
 
+// Coefficients of the final polynomial (log_final_poly_len > 0): the last FRI layer holds n_last = 2^(b+lfp) evaluations,
+// bit-reversed, over the subgroup of that size; thread j computes c_j = 1/n_last * sum_i F[bitrev(i)] * w^(-ij) for
+// j < 2^lfp (a naive inverse DFT: n_last <= 4096 values, once per proof).  One block.
+__global__ void k_fri_final_poly(const uint32_t* last, unsigned log_last, unsigned n_fin, uint32_t w_inv, uint32_t inv_n, uint32_t* out) {
+    const unsigned j = threadIdx.x;
+    if (j >= n_fin) return;
+    const uint32_t wj = mpow(w_inv, j);
+    uint32_t cur = MONTY_ONE;
+    Ext acc = ext_zero();
+    for (uint32_t i = 0; i < (1u << log_last); i++) {
+        acc = ext_add(acc, ext_mul_base(ld_ext(last + 4 * (size_t)bitrev32(i, log_last)), cur));
+        cur = mmul(cur, wj);
+    }
+    st_ext(out + 4 * (size_t)j, ext_mul_base(acc, inv_n));
+}
+
 __global__ void k_copy_canon(const uint32_t* src, uint32_t* dst, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = from_monty(src[i]);
@@ -608,7 +624,7 @@ struct AirPlan {
 
 struct zkhip_pk {
     zkhip_params params;
-    unsigned b = 1, nch = 2, hmax = 0, n_layers = 0;
+    unsigned b = 1, nch = 2, hmax = 0, n_layers = 0, lfp = 0;
     std::vector<AirPlan> airs;
     std::vector<uint32_t> preamble;  // canonical words observed before anything else (pvs patched in)
     std::vector<size_t> preamble_pv_off, preamble_prep_off;
@@ -707,7 +723,10 @@ extern "C" {
 
 int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* airs, size_t n_airs, zkhip_pk** out) {
     if (!ctx || !params || !airs || !out || n_airs == 0) return ZKHIP_ERR_INVALID;
-    if (params->log_final_poly_len != 0) return set_error(ctx, ZKHIP_ERR_INVALID, "log_final_poly_len must be 0");
+    if (params->log_final_poly_len > ZKHIP_MAX_LOG_FINAL_POLY) return set_error(ctx, ZKHIP_ERR_INVALID, "log_final_poly_len out of range");
+    for (size_t a = 0; a < n_airs; a++)
+        if (airs[a].log_height < params->log_final_poly_len)  // its reduced openings would never join the fold loop
+            return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + ": trace shorter than the final polynomial (2^log_final_poly_len rows)");
     if (params->log_blowup < 1 || params->log_blowup > 4) return set_error(ctx, ZKHIP_ERR_INVALID, "log_blowup out of range");
     if (params->commit_pow_bits > 30 || params->query_pow_bits > 30 || params->num_queries == 0)
         return set_error(ctx, ZKHIP_ERR_INVALID, "bad FRI parameters");
@@ -778,7 +797,8 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         p2_hash_slice(pm.data(), pm.size(), dg);
         for (int i = 0; i < 8; i++) A.digest[i] = from_monty(dg[i]);
     }
-    pk->n_layers = pk->hmax - pk->b;
+    pk->lfp = params->log_final_poly_len;
+    pk->n_layers = pk->hmax - pk->b - pk->lfp;
     // opened-value layout: main (all airs), permutation (airs with interactions), quotient (all airs)
     for (size_t a = 0; a < n_airs; a++) {
         pk->airs[a].opened_main_off = n_open;
@@ -832,7 +852,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         pk->off_fri = w;
         w += 9 * (size_t)pk->n_layers;
         pk->off_final = w;
-        w += 4;
+        w += (size_t)4 << pk->lfp;
         pk->off_qpow = w;
         w += 1;
         pk->off_queries = w;
@@ -936,7 +956,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     size_t o_dig_perm = pk->n_lu ? bp.take(merkle_digest_count(pk->h_perm) * 32) : 0;
     size_t o_tr = bp.take(sizeof(DevTranscript));
     size_t o_pre = bp.take(pk->preamble.size() * 4);
-    size_t o_chal = bp.take((3 + pk->n_layers) * 16);
+    size_t o_chal = bp.take((3 + pk->n_layers + ((size_t)1 << pk->lfp)) * 16);  // + the final polynomial's coefficients
     size_t o_opened = bp.take(n_open * 16);
     size_t o_pts = bp.take(64 * 16);
     size_t o_weights = bp.take(2 * max_n * 16);
@@ -1557,11 +1577,23 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         ZK_TRY(fri_fold(ctx, pk->d_flayer[l], pk->d_flayer[l + 1], log_len - 1, d_betas + 4 * l,
                         pk->d_ro[log_len - 1], pk->d_ro[log_len - 1] != nullptr));
     }
-    // final polynomial (constant): first value of the last layer
-    ZK_TRY(transcript_observe(ctx, pk->d_tr, pk->d_flayer[pk->n_layers], 4, false));
+    // final polynomial: a constant (first value of the last layer) for log_final_poly_len = 0, else the 2^lfp coefficients
+    // interpolated from the last layer's 2^(b+lfp) evaluations
+    const uint32_t* d_final = pk->d_flayer[pk->n_layers];
+    const uint32_t n_fin_words = 4u << pk->lfp;
+    if (pk->lfp) {
+        uint32_t* d_coef = d_betas + 4 * (size_t)pk->n_layers;
+        const unsigned log_last = pk->b + pk->lfp;
+        const uint32_t w_inv = minv(two_adic_generator(log_last));
+        const uint32_t inv_n = minv(to_monty(1u << log_last));
+        KernelScope ks(ctx, "fri_final_poly");
+        hipLaunchKernelGGL(k_fri_final_poly, dim3(1), dim3(256), 0, st, d_final, log_last, 1u << pk->lfp, w_inv, inv_n, d_coef);
+        d_final = d_coef;
+    }
+    ZK_TRY(transcript_observe(ctx, pk->d_tr, d_final, n_fin_words, false));
     {
         KernelScope ks(ctx, "copy_canon");
-        hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, pk->d_flayer[pk->n_layers], pf + pk->off_final, 4u);
+        hipLaunchKernelGGL(k_copy_canon, dim3((n_fin_words + 63) / 64), dim3(64), 0, st, d_final, pf + pk->off_final, n_fin_words);
         hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_main, pf + pk->off_roots, 8u);
         hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_quot, pf + pk->off_root_quot, 8u);
         if (pk->n_lu) {

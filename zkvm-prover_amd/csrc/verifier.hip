@@ -103,7 +103,8 @@ using namespace zk;
 extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, zkhip_proof_layout* out) {
     if (!prm || !airs || !out || n_airs == 0) return ZKHIP_ERR_INVALID;
     const unsigned b = prm->log_blowup, nch = 1u << b;
-    if (prm->log_final_poly_len != 0 || b < 1 || b > 4) return ZKHIP_ERR_INVALID;
+    const unsigned lfp = prm->log_final_poly_len;
+    if (lfp > ZKHIP_MAX_LOG_FINAL_POLY || b < 1 || b > 4) return ZKHIP_ERR_INVALID;
     unsigned hmax = 0;
     size_t n_lu = 0, n_open = 0;
     size_t main_w = 0, perm_w = 0, quot_w = 0, prep_words = 0;   // opened row words per query, per input commitment
@@ -111,7 +112,7 @@ extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* a
     for (size_t a = 0; a < n_airs; a++) {
         AirProgram pg;
         if (parse_air(airs[a].program, airs[a].program_len, airs[a].width, &pg, nullptr) != 0) return ZKHIP_ERR_INVALID;
-        if (airs[a].log_height > 27) return ZKHIP_ERR_INVALID;
+        if (airs[a].log_height > 27 || airs[a].log_height < lfp) return ZKHIP_ERR_INVALID;
         const unsigned h = airs[a].log_height + b;
         hmax = std::max(hmax, h);
         main_h = std::max(main_h, h);
@@ -129,7 +130,7 @@ extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* a
             n_open += 2 * pg.perm_width();
         }
     }
-    const unsigned n_layers = hmax - b;
+    const unsigned n_layers = hmax - b - lfp;
     memset(out, 0, sizeof *out);
     size_t r = 4;
     out->root_main = r, r += 8;
@@ -140,7 +141,7 @@ extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* a
     out->root_quot = r, r += 8;
     out->opened = r, out->n_opened = n_open, r += 4 * n_open;
     out->fri_layers = r, out->n_fri_layers = n_layers, r += 9 * (size_t)n_layers;
-    out->final_poly = r, r += 4;
+    out->final_poly = r, out->n_final_poly = (size_t)1 << lfp, r += (size_t)4 << lfp;
     out->query_pow = r, r += 1;
     out->queries = r;
     size_t qw = main_w + 8 * (size_t)main_h + prep_words + (n_lu ? perm_w + 8 * (size_t)perm_h : 0) + quot_w + 8 * (size_t)main_h;
@@ -155,7 +156,9 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
                             const uint8_t* proof_bytes, size_t len) {
     if (!prm || !airs || !proof_bytes || n_airs == 0 || (len & 3)) return ZKHIP_ERR_INVALID;
     const unsigned b = prm->log_blowup, nch = 1u << b;
-    if (prm->log_final_poly_len != 0 || b < 1 || b > 4) return ZKHIP_ERR_INVALID;
+    const unsigned lfp = prm->log_final_poly_len;  // the fold loop stops at 2^(b+lfp) values: a polynomial of degree < 2^lfp
+    if (lfp > ZKHIP_MAX_LOG_FINAL_POLY || b < 1 || b > 4) return ZKHIP_ERR_INVALID;
+    const size_t n_fin = (size_t)1 << lfp;
     const size_t n_words = len / 4;
     if (n_words < 4) return ZKHIP_ERR_VERIFY;
     std::vector<uint32_t> pw(n_words);
@@ -168,7 +171,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     size_t n_lu = 0, n_prep = 0;
     for (size_t a = 0; a < n_airs; a++) {
         if (parse_air(airs[a].program, airs[a].program_len, airs[a].width, &pg[a], nullptr) != 0) return ZKHIP_ERR_INVALID;
-        if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height > 27) return ZKHIP_ERR_INVALID;
+        if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height > 27 || airs[a].log_height < lfp) return ZKHIP_ERR_INVALID;
         if (pg[a].max_degree > nch + 1) return ZKHIP_ERR_CONSTRAINT;
         if (airs[a].n_pvs && (!pvs || !pvs[a])) return ZKHIP_ERR_INVALID;
         hmax = std::max(hmax, airs[a].log_height + b);
@@ -201,10 +204,10 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         m.open_off = n_open;
         n_open += m.width * m.n_pts;
     }
-    const unsigned n_layers = hmax - b;
+    const unsigned n_layers = hmax - b - lfp;
     size_t r = 0;
     const size_t lu_words = n_lu ? 8 + 4 * n_lu : 0;
-    if (n_words < 4 + 16 + lu_words + 4 * n_open + 9 * (size_t)n_layers + 5) return ZKHIP_ERR_VERIFY;
+    if (n_words < 4 + 16 + lu_words + 4 * n_open + 9 * (size_t)n_layers + 4 * n_fin + 1) return ZKHIP_ERR_VERIFY;
     if (proof[0] != PROOF_MAGIC + (n_lu ? 1u : 0u) + (n_prep ? 2u : 0u) || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers)
         return ZKHIP_ERR_VERIFY;
     r = 4;
@@ -222,8 +225,8 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     r += 4 * n_open;
     const uint32_t* fri_hdr = proof + r;
     r += 9 * (size_t)n_layers;
-    const uint32_t* fin_c = proof + r;
-    r += 4;
+    const uint32_t* fin_c = proof + r;  // 2^lfp coefficients of the final polynomial
+    r += 4 * n_fin;
     const uint32_t qpow = proof[r++];
     std::vector<Ext> opened(n_open);
     for (size_t i = 0; i < n_open; i++) opened[i] = ext_from_canon(opened_c + 4 * i);
@@ -367,9 +370,10 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         if (!ch.check_witness(prm->commit_pow_bits, fri_hdr[9 * l + 8])) return ZKHIP_ERR_VERIFY;
         betas[l] = ch.sample_ext();
     }
-    ch.observe_canon(fin_c, 4);
+    ch.observe_canon(fin_c, 4 * n_fin);
     if (!ch.check_witness(prm->query_pow_bits, qpow)) return ZKHIP_ERR_VERIFY;
-    const Ext fin = ext_from_canon(fin_c);
+    std::vector<Ext> fin(n_fin);
+    for (size_t j = 0; j < n_fin; j++) fin[j] = ext_from_canon(fin_c + 4 * j);
 
     // the input batches (one commitment each) as ranges of `cm`
     struct Batch {
@@ -471,7 +475,13 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
             eval = ext_add(e0, ext_mul(bx, ext_mul_base(ext_sub(e1, e0), c)));
             if (has[log_len - 1]) eval = ext_add(eval, ext_mul(ext_mul(betas[l], betas[l]), roq[log_len - 1]));
         }
-        if (!ext_eq(eval, fin)) return ZKHIP_ERR_VERIFY;
+        // the folded value must be the final polynomial at this query's point of the last domain (Horner)
+        Ext want = fin[n_fin - 1];
+        if (lfp) {
+            const uint32_t xf = mpow(two_adic_generator(b + lfp), bitrev32((uint32_t)(idx >> n_layers), b + lfp));
+            for (size_t j = n_fin - 1; j-- > 0;) want = ext_add(ext_mul_base(want, xf), fin[j]);
+        }
+        if (!ext_eq(eval, want)) return ZKHIP_ERR_VERIFY;
     }
     if (r != n_words) return ZKHIP_ERR_VERIFY;
     return ZKHIP_OK;
