@@ -222,6 +222,20 @@ int zkhip_proof_fetch(zkhip_ctx *ctx, const zkhip_pk *pk, uint8_t *out, size_t c
 int zkhip_verify(const zkhip_params *params, const zkhip_air *airs, size_t n_airs,
                  const uint32_t *const *pvs, const uint8_t *proof, size_t len);
 
+/* The verifier's primitives on the HOST (no device, canonical words in and out).  They are what p3's permutation,
+ * `Mmcs::verify_batch` (MerkleTreeMmcs over PaddingFreeSponge / TruncatedPermutation) and p3-fri's `fold_row` are to
+ * `Sdk::verify_proof` (crates/verifier/src/verifier.rs:82), usable on any BabyBear-Poseidon2 v1 proof -- including the
+ * reference's own stored proofs (tests/test_ref_vectors_cpu.py pins them to those).
+ * zkhip_mmcs_verify: `opening` = the opened rows in matrix order (widths[m] words each) followed by max(log_heights)
+ * sibling digests bottom-up; matrix m's row index is index >> (max - log_heights[m]).  ZKHIP_OK / ZKHIP_ERR_VERIFY.
+ * zkhip_fri_fold_row: pair `index` of a layer that folds 2^(log_height+1) values (bit-reversed order) to 2^log_height:
+ * out = e0 + (beta - x)(e1 - e0)/(-2x), x = two_adic_generator(log_height+1)^bitrev(index, log_height). */
+int zkhip_poseidon2_permute_host(uint32_t state[16]);
+int zkhip_mmcs_verify(const uint32_t root[8], const unsigned *log_heights, const size_t *widths, size_t n_mats,
+                      uint64_t index, const uint32_t *opening);
+int zkhip_fri_fold_row(uint64_t index, unsigned log_height, const uint32_t beta[4], const uint32_t e0[4],
+                       const uint32_t e1[4], uint32_t out[4]);
+
 /* Field offsets of a proof, in 32-bit words from its start (the layout is static for given parameters and AIR shapes:
  * DESIGN.md section 4).  The counterpart of `Proof::<SC>::decode_from_bytes` (crates/verifier/src/verifier.rs:62) for this
  * backend's proofs: commitments, opened values, FRI layers and query openings are read in place.  Needs no device. */

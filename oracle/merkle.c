@@ -152,3 +152,33 @@ void ora_tree_free(ora_tree *t) {
     free(t->mats);
     free(t);
 }
+
+/* Test utility for tests/golden/gen_ref_vectors.py: the query index is not part of a reference proof (it comes from
+ * the transcript), so it is recovered by trying every leaf position of a single-matrix opening.  Walks the path
+ * bottom-up keeping the node of every candidate prefix (2^(l) candidates after l siblings): 2^(log_height+1)
+ * compressions in all.  Returns how many indices verify; the first goes to *index_out. */
+size_t ora_mmcs_find_index(const uint32_t root[8], unsigned log_height, size_t width, const uint32_t *opening,
+                           size_t *index_out) {
+    size_t n = (size_t)1 << log_height;
+    uint32_t *cur = (uint32_t *)malloc(n * 8 * sizeof(uint32_t)), *nxt = (uint32_t *)malloc(n * 8 * sizeof(uint32_t));
+    const uint32_t *path = opening + width;
+    ora_hash_slice(opening, width, cur);
+    for (unsigned l = 0; l < log_height; l++) {
+        size_t cnt = (size_t)1 << l;
+        const uint32_t *sib = path + 8 * l;
+#pragma omp parallel for schedule(static)
+        for (size_t c = 0; c < cnt; c++) {
+            ora_compress(cur + 8 * c, sib, nxt + 8 * c);         /* bit l of the index = 0 */
+            ora_compress(sib, cur + 8 * c, nxt + 8 * (c + cnt)); /* bit l of the index = 1 */
+        }
+        uint32_t *t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    size_t found = 0;
+    for (size_t c = 0; c < n; c++)
+        if (memcmp(cur + 8 * c, root, 32) == 0 && found++ == 0) *index_out = c;
+    free(cur);
+    free(nxt);
+    return found;
+}

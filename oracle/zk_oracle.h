@@ -100,6 +100,9 @@ size_t ora_mmcs_open(const ora_tree *t, size_t index, uint32_t *out);
 int ora_mmcs_verify(const uint32_t root[8], const unsigned *log_heights, const size_t *widths,
                     size_t n_mats, size_t index, const uint32_t *opening);
 void ora_tree_free(ora_tree *t);
+/* test utility (fixture generation): number of leaf indices at which a single-matrix opening verifies; first -> *index_out */
+size_t ora_mmcs_find_index(const uint32_t root[8], unsigned log_height, size_t width, const uint32_t *opening,
+                           size_t *index_out);
 
 /* ---- DuplexChallenger<BabyBear, Perm, 16, 8> ---- */
 typedef struct {

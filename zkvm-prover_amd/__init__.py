@@ -18,5 +18,8 @@ from ._binding import (  # noqa: F401
     verify,
     proof_layout,
     DEFAULT_PARAMS,
+    poseidon2_permute_host,
+    mmcs_verify,
+    fri_fold_row,
 )
 from . import air  # noqa: F401

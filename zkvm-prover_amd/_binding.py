@@ -113,6 +113,9 @@ def load_library():
         "zkhip_prove_async": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(u32p)]),
         "zkhip_proof_fetch": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), sz, C.POINTER(sz)]),
         "zkhip_verify": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(u32p), C.POINTER(C.c_uint8), sz]),
+        "zkhip_poseidon2_permute_host": (C.c_int, [u32p]),
+        "zkhip_mmcs_verify": (C.c_int, [u32p, C.POINTER(C.c_uint), C.POINTER(sz), sz, C.c_uint64, u32p]),
+        "zkhip_fri_fold_row": (C.c_int, [C.c_uint64, C.c_uint, u32p, u32p, u32p, u32p]),
         "zkhip_proof_layout_of": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(_ProofLayout)]),
         "zkhip_profile_enable": (C.c_int, [vp, C.c_int]),
         "zkhip_profile_read": (C.c_int, [vp, C.POINTER(_KernelStat), sz]),
@@ -472,3 +475,32 @@ def verify(params, airs, pvs, proof_bytes):
     pa, keep2 = _pvs_array(pvs)
     buf = np.frombuffer(proof_bytes, dtype=np.uint8)
     return lib.zkhip_verify(C.byref(prm), arr, len(airs), pa, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size)
+
+
+# ---- the verifier's primitives on the host (need no GPU) ---------------------------------------------
+def poseidon2_permute_host(state):
+    """Poseidon2 permutation of 16 canonical words on the host (the verifier's copy of the permutation)."""
+    s = np.ascontiguousarray(state, dtype=np.uint32).copy()
+    rc = load_library().zkhip_poseidon2_permute_host(_u32p(s))
+    if rc != 0:
+        raise ZkhipError("zkhip_poseidon2_permute_host returned %d" % rc)
+    return s
+
+
+def mmcs_verify(root, log_heights, widths, index, opening):
+    """p3 `Mmcs::verify_batch` for MerkleTreeMmcs<Poseidon2>: status code (0 = the opening leads to `root`)."""
+    r = np.ascontiguousarray(root, dtype=np.uint32)
+    op = np.ascontiguousarray(opening, dtype=np.uint32)
+    lhs = (C.c_uint * len(log_heights))(*log_heights)
+    ws = (C.c_size_t * len(widths))(*widths)
+    return load_library().zkhip_mmcs_verify(_u32p(r), lhs, ws, len(log_heights), int(index), _u32p(op))
+
+
+def fri_fold_row(index, log_height, beta, e0, e1):
+    """p3-fri `fold_row` (arity 2) on canonical extension elements; returns 4 canonical words."""
+    b, a0, a1 = (np.ascontiguousarray(v, dtype=np.uint32) for v in (beta, e0, e1))
+    out = np.zeros(4, dtype=np.uint32)
+    rc = load_library().zkhip_fri_fold_row(int(index), log_height, _u32p(b), _u32p(a0), _u32p(a1), _u32p(out))
+    if rc != 0:
+        raise ZkhipError("zkhip_fri_fold_row returned %d" % rc)
+    return out

@@ -93,10 +93,69 @@ bool verify_opening(const uint32_t root_m[8], const std::vector<unsigned>& lhs, 
     return memcmp(cur, root_m, 32) == 0;
 }
 
+// p3-fri `fold_row` for arity 2: pair k of a layer of 2^(log_n_out+1) values in bit-reversed order sits on the points
+// +-x, x = g^bitrev(k) with g the generator of that size; the line through (x, e0), (-x, e1) is evaluated at beta.
+Ext fold_row(size_t k, unsigned log_n_out, const Ext& beta, const Ext& e0, const Ext& e1) {
+    const uint32_t xx = mpow(two_adic_generator(log_n_out + 1), bitrev32((uint32_t)k, log_n_out));
+    const uint32_t c = mneg(mmul(minv(xx), minv(to_monty(2))));
+    Ext bx = beta;
+    bx.c[0] = msub(bx.c[0], xx);
+    return ext_add(e0, ext_mul(bx, ext_mul_base(ext_sub(e1, e0), c)));
+}
+
 }  // namespace
 }  // namespace zk
 
 using namespace zk;
+
+// ---- the verifier's primitives as host entry points (no device): what p3's `Mmcs::verify_batch`, `fold_row` and the
+//      permutation are to the reference's verifier (crates/verifier/src/verifier.rs:82 -> Sdk::verify_proof).  They let a
+//      consumer -- and tests/test_ref_vectors_cpu.py, against the reference's own stored proofs -- check openings and
+//      fold steps of ANY BabyBear-Poseidon2 v1 proof, not only the ones this backend writes. ----
+extern "C" int zkhip_poseidon2_permute_host(uint32_t state[16]) {
+    if (!state) return ZKHIP_ERR_INVALID;
+    uint32_t s[16];
+    for (int i = 0; i < 16; i++) {
+        if (state[i] >= P) return ZKHIP_ERR_INVALID;
+        s[i] = to_monty(state[i]);
+    }
+    poseidon2_permute(s);
+    for (int i = 0; i < 16; i++) state[i] = from_monty(s[i]);
+    return ZKHIP_OK;
+}
+
+extern "C" int zkhip_mmcs_verify(const uint32_t root[8], const unsigned* log_heights, const size_t* widths, size_t n_mats,
+                                 uint64_t index, const uint32_t* opening) {
+    if (!root || !log_heights || !widths || !opening || n_mats == 0) return ZKHIP_ERR_INVALID;
+    std::vector<unsigned> lhs(log_heights, log_heights + n_mats);
+    std::vector<size_t> ws(widths, widths + n_mats);
+    unsigned lh = 0;
+    size_t total = 0;
+    for (size_t m = 0; m < n_mats; m++) {
+        if (lhs[m] > 27) return ZKHIP_ERR_INVALID;
+        lh = std::max(lh, lhs[m]);
+        total += ws[m];
+    }
+    if (index >> lh) return ZKHIP_ERR_INVALID;
+    for (size_t i = 0; i < total + 8 * (size_t)lh; i++)
+        if (opening[i] >= P) return ZKHIP_ERR_VERIFY;
+    uint32_t root_m[8];
+    for (int k = 0; k < 8; k++) {
+        if (root[k] >= P) return ZKHIP_ERR_VERIFY;
+        root_m[k] = to_monty(root[k]);
+    }
+    return verify_opening(root_m, lhs, ws, (size_t)index, opening) ? ZKHIP_OK : ZKHIP_ERR_VERIFY;
+}
+
+extern "C" int zkhip_fri_fold_row(uint64_t index, unsigned log_height, const uint32_t beta[4], const uint32_t e0[4],
+                                  const uint32_t e1[4], uint32_t out[4]) {
+    if (!beta || !e0 || !e1 || !out || log_height > 26 || (index >> log_height)) return ZKHIP_ERR_INVALID;
+    for (int k = 0; k < 4; k++)
+        if (beta[k] >= P || e0[k] >= P || e1[k] >= P) return ZKHIP_ERR_INVALID;
+    const Ext r = fold_row((size_t)index, log_height, ext_from_canon(beta), ext_from_canon(e0), ext_from_canon(e1));
+    for (int k = 0; k < 4; k++) out[k] = from_monty(r.c[k]);
+    return ZKHIP_OK;
+}
 
 // Word offsets of the fields of a proof: what Proof::<SC>::decode_from_bytes gives the reference's
 // verifier (crates/verifier/src/verifier.rs:62) -- here the layout is static, so "decoding" is a table of offsets.
@@ -468,11 +527,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
             memcpy(opening.data() + 8, path, n_path * 4);
             if (!verify_opening(&froots_m[8 * l], {log_len - 1}, {8}, il >> 1, opening.data())) return ZKHIP_ERR_VERIFY;
             const Ext e0 = ext_from_canon(opening.data()), e1 = ext_from_canon(opening.data() + 4);
-            const uint32_t xx = mpow(two_adic_generator(log_len), bitrev32((uint32_t)(il >> 1), log_len - 1));
-            const uint32_t c = mneg(mmul(minv(xx), minv(to_monty(2))));
-            Ext bx = betas[l];
-            bx.c[0] = msub(bx.c[0], xx);
-            eval = ext_add(e0, ext_mul(bx, ext_mul_base(ext_sub(e1, e0), c)));
+            eval = fold_row(il >> 1, log_len - 1, betas[l], e0, e1);
             if (has[log_len - 1]) eval = ext_add(eval, ext_mul(ext_mul(betas[l], betas[l]), roq[log_len - 1]));
         }
         // the folded value must be the final polynomial at this query's point of the last domain (Horner)
