@@ -7,8 +7,11 @@ a 2^22-row x 300-column degree-3 AIR (A) plus a 2^22 x 2 Fibonacci AIR (B), with
 parameters (crates/circuits/chunk-circuit/openvm.toml:1-6: blow-up 2, 100 queries, PoW 16+16).
 Traces are synthetic and already resident in HBM when the timed region starts.
 
-N GPUs = N independent proofs (segments shard one per GPU); after proving, the
-ranks all-gather their 32-byte trace commitments and rank 0 gathers the proof bytes over RCCL.
+N GPUs = N independent proof streams (segments shard across GPUs); every finished proof's 32-byte
+trace commitment is all-gathered and its bytes gathered on rank 0 over RCCL -- posted ASYNCHRONOUSLY on a side stream
+(zkvm-prover_amd/shard.py AsyncExchange), so ranks never run in lockstep; the timed region ends when every proof has
+been proven AND exchanged.  `python bench.py --gpus N` without a launcher starts the N ranks itself (one child process
+per GPU, before the parent touches the GPU); under `torch.distributed.run` it uses the ranks it is given.
 
 Prints ONE JSON line (see the task contract) including `roofline` for the dominant kernel and
 `cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload, rank 0, N=1).
@@ -41,6 +44,68 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher: start one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    in its environment, as torch.distributed.run would), relay rank 0's JSON line, exit with the first non-zero code.
+    The parent has not initialised the GPU (torch.cuda.device_count() does not), and it never execs."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    plumbing = os.environ.get("ZKHIP_BENCH_PLUMBING_ONLY") == "1"
+    if not plumbing and os.environ.get("ZKHIP_BENCH_DRYRUN_1GPU") != "1":
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible (ZKHIP_BENCH_DRYRUN_1GPU=1 runs all ranks on one "
+                             "GPU as a plumbing check)\n" % (n, have))
+            return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            code = p.wait()
+            if code != 0 and rc == 0:
+                rc = code
+                for q in procs:  # a failed rank would leave the others waiting in a collective
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
+class StubProver:
+    """ZKHIP_BENCH_PLUMBING_ONLY=1 (CPU test of the launcher / exchange / JSON plumbing; no GPU, no proving, no
+    measurement): stands in for the device pipelines with fixed-size byte strings."""
+
+    proof_size = 4096
+    workspace_bytes = 0
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def launch(self, i):
+        pass
+
+    def collect(self, i):
+        import hashlib
+
+        seed = hashlib.sha256(b"%d/%d" % (self.rank, i)).digest()
+        return (seed * (self.proof_size // len(seed)))[:self.proof_size]
+
+
 def cpu_baseline(args, sa_kwargs, params):
     """Times the CPU oracle (OpenMP, all host cores) on a bounded sample: the same AIR set at
     2^s rows, then scales by rows (the work is linear in rows up to the log factor of the NTT)."""
@@ -70,6 +135,9 @@ def cpu_baseline(args, sa_kwargs, params):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    plumbing = os.environ.get("ZKHIP_BENCH_PLUMBING_ONLY") == "1"
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -83,6 +151,8 @@ def main():
     # ZKHIP_BENCH_DRYRUN_1GPU=1: exercise the N-rank code path on a box with ONE GPU (every rank on cuda:0, gloo
     # collectives on host tensors).  A plumbing check only -- never a measurement.
     dry = world > 1 and os.environ.get("ZKHIP_BENCH_DRYRUN_1GPU") == "1"
+    if plumbing:
+        return plumbing_run(args, world, rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -135,11 +205,10 @@ def main():
         # waits for proof i and copies it to the host (part of the step)
         return pipes[i % n_pipe]["pk"].fetch()
 
-    def exchange(proof_bytes):
-        # the one exchange step of the sharded path (zkvm-prover_amd/shard.py): 32-byte trace
-        # commitments to every rank, proofs to rank 0, over RCCL/xGMI
-        if world > 1:
-            shard.exchange(proof_bytes, device=coll_dev)
+    # the one exchange step of the sharded path (zkvm-prover_amd/shard.py): 32-byte trace commitments to every
+    # rank, proofs to rank 0, over RCCL/xGMI -- posted asynchronously per proof, completed before the clock stops
+    xch = shard.AsyncExchange(device=coll_dev)
+    xstat = {"wait_s": 0.0, "posted": 0}
 
     def run(n_steps):
         # keep n_pipe proofs in flight: proof i+n_pipe is enqueued as soon as proof i has been fetched
@@ -148,9 +217,16 @@ def main():
             launch(i)
         for i in range(n_steps):
             last = (i, collect(i))
-            exchange(last[1])
             if i + n_pipe < n_steps:
                 launch(i + n_pipe)
+            if world > 1:
+                xch.post(last[1])
+                xstat["posted"] += 1
+        if world > 1:
+            tw = time.perf_counter()
+            commits, proofs = xch.wait()
+            xstat["wait_s"] = time.perf_counter() - tw
+            assert all(len(c) == world for c in commits) and (rank != 0 or all(len(pr) == world for pr in proofs))
         return last
 
     # setup, not warm-up: the first proof of a proving key grows its context's scratch buffers and loads its code
@@ -183,6 +259,14 @@ def main():
         collect(0)
     ctx.profile_enable(False)
     stats_alone = {k: (v[0], v[1]) for k, v in ctx.profile_read().items()}
+    # the exchange alone (outside the timed region): one blocking all-gather + gather of a finished proof
+    exchange_alone_ms = None
+    if world > 1:
+        dist.barrier()
+        te = time.perf_counter()
+        for _ in range(4):
+            shard.exchange(last, device=coll_dev)
+        exchange_alone_ms = (time.perf_counter() - te) / 4 * 1e3
     pvs = pipes[last_i % n_pipe]["pvs"]
     steps_profiled = len(range(0, args.steps, n_pipe))  # proofs that ran on pipeline 0
     dt = t1 - t0
@@ -307,6 +391,11 @@ def main():
                        "proof_bytes": pk.proof_size, "verified": ok,
                        "resident_key_bytes_per_pipeline": pk.workspace_bytes,
                        "inflight_per_gpu": n_pipe,
+                       "exchange": None if world == 1 else {
+                           "posted_per_rank": xstat["posted"], "mode": "asynchronous per proof (side stream), completed inside the timed region",
+                           "ms_blocked_at_end_of_timed_region": round(xstat["wait_s"] * 1e3, 3),
+                           "ms_one_blocking_exchange_alone": round(exchange_alone_ms, 3),
+                           "bytes_per_proof": "32 x %d all-gather + %d gather to rank 0" % (world, pk.proof_size)},
                        "parallelism": "%d independent proof(s) in flight per GPU (one HIP stream each)" % n_pipe + (", RCCL all-gather of commitments + proof gather" if world > 1 else "")
                                       + (" [DRY RUN: all ranks on one GPU, gloo -- not a measurement]" if dry else "")},
             "roofline": roof,
@@ -326,6 +415,44 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def plumbing_run(args, world, rank):
+    """ZKHIP_BENCH_PLUMBING_ONLY=1: the launcher, the rendezvous, the asynchronous exchange and the JSON line with stub
+    proofs over gloo -- what a box without a GPU can check (tests/test_bench_launcher_cpu.py).  Not a measurement."""
+    import torch.distributed as dist
+
+    from zkvm_prover_amd import shard
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    pr = StubProver(rank)
+    xch = shard.AsyncExchange()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        xch.post(pr.collect(i))
+    commits, proofs = xch.wait()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = all(len(c) == world for c in commits)
+    if rank == 0:
+        for i, prs in enumerate(proofs):
+            ok &= [bytes(b) for b in prs] == [StubProver(r).collect(i) for r in range(world)]
+            ok &= [bytes(c) for c in commits[i]] == [shard.commitment_of(b) for b in prs]
+        print(json.dumps({"metric": "chunk STARK proofs/sec (2^%d-row trace)" % args.log_rows, "value": None,
+                          "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                          "config": {"workload": "PLUMBING ONLY: stub proofs, gloo, no GPU -- not a measurement",
+                                     "exchange_ok": bool(ok)}}))
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

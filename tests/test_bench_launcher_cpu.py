@@ -1,0 +1,52 @@
+"""CPU: `python bench.py --gpus 2` starts its own two ranks (no torch.distributed.run), they rendezvous on 127.0.0.1,
+run the asynchronous exchange of zkvm-prover_amd/shard.py end to end and rank 0 prints ONE JSON line with n_gpus = 2.
+ZKHIP_BENCH_PLUMBING_ONLY=1 replaces the device pipelines with stub byte strings (there is no GPU here): this checks the
+launcher and the N>1 data path, not the prover.  The same path with real proofs on one GPU:
+`ZKHIP_BENCH_DRYRUN_1GPU=1 python bench.py --gpus 2` (tests/test_gpu_bench_ranks.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, *argv):
+    env = dict(os.environ, ZKHIP_BENCH_PLUMBING_ONLY="1", **extra_env)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                       timeout=300)
+    return r
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_spawns_its_own_ranks(n):
+    r = _run({}, "--gpus", str(n), "--steps", "5", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["steps"] == 5 and out["config"]["exchange_ok"] is True
+    assert out["scaling"] == "weak" and out["value"] is None  # plumbing only: no measurement is claimed
+
+
+def test_bench_under_a_launcher_uses_the_given_ranks():
+    """torch.distributed.run-style environment: bench.py must NOT spawn again."""
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, ZKHIP_BENCH_PLUMBING_ONLY="1", RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][0])["n_gpus"] == 2
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]
