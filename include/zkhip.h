@@ -259,6 +259,37 @@ typedef struct {
 } zkhip_proof_layout;
 int zkhip_proof_layout_of(const zkhip_params *params, const zkhip_air *airs, size_t n_airs, zkhip_proof_layout *out);
 
+/* ---- the reference's stored-proof container: OpenVM-v1 `Proof<SC>`, bincode (C++ codec in
+ *      include/zkhip_codec.hpp).  Replaces `Proof::<SC>::decode_from_bytes` (crates/verifier/src/verifier.rs:62) /
+ *      `encode_to_vec` (crates/prover/src/prover/mod.rs:375-378) for v1-format proofs such as the ones under
+ *      crates/verifier/testdata/proofs/.  Host only.  Words inside the container are Montgomery (p3's in-memory form). ---- */
+#define ZKHIP_V1_SINGLE 0 /* bincode(Proof<SC>) */
+#define ZKHIP_V1_VEC 1    /* bincode(Vec<Proof<SC>>): the `proofs` field of VmInternalStarkProof (crates/types/src/proof.rs:69-74) */
+#define ZKHIP_V1_MAX_AIRS 64
+typedef struct {
+    size_t n_proofs; /* the fields below describe proof 0 */
+    size_t n_airs, n_queries, n_fri_layers, n_final_poly;
+    size_t n_main_commits, n_after_challenge_commits, n_preprocessed, n_input_batches;
+    unsigned log_max_height; /* longest input-batch Merkle path = log2 of the tallest LDE */
+    unsigned log_blowup;     /* log_max_height - max log2(degree) */
+    int has_logup_pow;
+    unsigned log_degree[ZKHIP_V1_MAX_AIRS];
+} zkhip_v1_summary;
+/* parses and structurally validates (lengths, field elements < p, uniform query shapes); ZKHIP_ERR_VERIFY if malformed */
+int zkhip_proof_decode_v1(const uint8_t *bytes, size_t len, int kind, zkhip_v1_summary *out);
+/* decode -> encode; for a well-formed input the output equals the input byte for byte */
+int zkhip_proof_reencode_v1(const uint8_t *bytes, size_t len, int kind, uint8_t *out, size_t cap, size_t *out_len);
+/* a proof of zkhip_prove (params, AIR shapes and public values as given to it) as bincode(Proof<SC>): commitments
+ * {main_trace: [main], after_challenge: [permutation]?, quotient}, FRI proof (input batches in the reference's order:
+ * preprocessed, main, after-challenge, quotient), opened values, per-AIR data.  Needs commit_pow_bits == 0: the v1 container
+ * has no field for per-layer commit-phase witnesses.  *out_len is set even when the buffer is too small. */
+int zkhip_proof_to_v1(const zkhip_params *params, const zkhip_air *airs, size_t n_airs, const uint32_t *const *pvs,
+                      const uint8_t *proof, size_t len, uint8_t *out, size_t cap, size_t *out_len);
+/* the inverse: checks the container against the key's shapes and writes this backend's layout (zkhip_verify's input);
+ * pvs_out (may be NULL): per AIR a buffer of n_pvs canonical words */
+int zkhip_proof_from_v1(const zkhip_params *params, const zkhip_air *airs, size_t n_airs, const uint8_t *v1, size_t v1_len,
+                        uint8_t *out, size_t cap, size_t *out_len, uint32_t *const *pvs_out);
+
 /* ---- per-kernel timing (HIP events on the ctx stream), for bench.py's roofline ---- */
 int zkhip_profile_enable(zkhip_ctx *ctx, int on);
 /* copies up to cap entries; returns number of distinct kernel names recorded */

@@ -21,5 +21,11 @@ from ._binding import (  # noqa: F401
     poseidon2_permute_host,
     mmcs_verify,
     fri_fold_row,
+    proof_decode_v1,
+    proof_reencode_v1,
+    proof_to_v1,
+    proof_from_v1,
+    V1_SINGLE,
+    V1_VEC,
 )
 from . import air  # noqa: F401

@@ -49,6 +49,12 @@ class _ProofLayout(C.Structure):
                                           "query_words", "n_queries")]
 
 
+class _V1Summary(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("n_proofs", "n_airs", "n_queries", "n_fri_layers", "n_final_poly", "n_main_commits",
+                                          "n_after_challenge_commits", "n_preprocessed", "n_input_batches")] + \
+               [("log_max_height", C.c_uint), ("log_blowup", C.c_uint), ("has_logup_pow", C.c_int), ("log_degree", C.c_uint * 64)]
+
+
 class _KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -116,6 +122,12 @@ def load_library():
         "zkhip_poseidon2_permute_host": (C.c_int, [u32p]),
         "zkhip_mmcs_verify": (C.c_int, [u32p, C.POINTER(C.c_uint), C.POINTER(sz), sz, C.c_uint64, u32p]),
         "zkhip_fri_fold_row": (C.c_int, [C.c_uint64, C.c_uint, u32p, u32p, u32p, u32p]),
+        "zkhip_proof_decode_v1": (C.c_int, [C.POINTER(C.c_uint8), sz, C.c_int, C.POINTER(_V1Summary)]),
+        "zkhip_proof_reencode_v1": (C.c_int, [C.POINTER(C.c_uint8), sz, C.c_int, C.POINTER(C.c_uint8), sz, C.POINTER(sz)]),
+        "zkhip_proof_to_v1": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(u32p), C.POINTER(C.c_uint8), sz,
+                                        C.POINTER(C.c_uint8), sz, C.POINTER(sz)]),
+        "zkhip_proof_from_v1": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(C.c_uint8), sz,
+                                          C.POINTER(C.c_uint8), sz, C.POINTER(sz), C.POINTER(u32p)]),
         "zkhip_proof_layout_of": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(_ProofLayout)]),
         "zkhip_profile_enable": (C.c_int, [vp, C.c_int]),
         "zkhip_profile_read": (C.c_int, [vp, C.POINTER(_KernelStat), sz]),
@@ -504,3 +516,71 @@ def fri_fold_row(index, log_height, beta, e0, e1):
     if rc != 0:
         raise ZkhipError("zkhip_fri_fold_row returned %d" % rc)
     return out
+
+
+# ---- the reference's stored-proof container (OpenVM-v1 Proof<SC>, bincode): include/zkhip_codec.hpp ----
+V1_SINGLE, V1_VEC = 0, 1
+
+
+def _bytes_ptr(b):
+    a = np.frombuffer(b, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def proof_decode_v1(blob, kind=V1_VEC):
+    """Parses + validates a v1 container; returns the summary as a dict (raises ZkhipError when malformed)."""
+    a, ptr = _bytes_ptr(blob)
+    out = _V1Summary()
+    rc = load_library().zkhip_proof_decode_v1(ptr, a.size, kind, C.byref(out))
+    if rc != 0:
+        raise ZkhipError("zkhip_proof_decode_v1 returned %d" % rc)
+    d = {n: int(getattr(out, n)) for n, _ in _V1Summary._fields_ if n != "log_degree"}
+    d["log_degree"] = [int(out.log_degree[i]) for i in range(min(d["n_airs"], 64))]
+    return d
+
+
+def proof_reencode_v1(blob, kind=V1_VEC):
+    a, ptr = _bytes_ptr(blob)
+    out = np.zeros(a.size + 64, dtype=np.uint8)
+    n = C.c_size_t()
+    rc = load_library().zkhip_proof_reencode_v1(ptr, a.size, kind, out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size, C.byref(n))
+    if rc != 0:
+        raise ZkhipError("zkhip_proof_reencode_v1 returned %d" % rc)
+    return out[:n.value].tobytes()
+
+
+def proof_to_v1(params, airs, pvs, proof_bytes):
+    """zkhip proof -> bincode(Proof<SC>) bytes."""
+    lib = load_library()
+    prm = _Params(*params)
+    arr, keep = _air_structs(airs)
+    pa, keep2 = _pvs_array(pvs)
+    a, ptr = _bytes_ptr(proof_bytes)
+    n = C.c_size_t()
+    rc = lib.zkhip_proof_to_v1(C.byref(prm), arr, len(airs), pa, ptr, a.size, None, 0, C.byref(n))
+    if rc != -5:
+        raise ZkhipError("zkhip_proof_to_v1 returned %d" % rc)
+    out = np.zeros(n.value, dtype=np.uint8)
+    rc = lib.zkhip_proof_to_v1(C.byref(prm), arr, len(airs), pa, ptr, a.size, out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size,
+                               C.byref(n))
+    if rc != 0:
+        raise ZkhipError("zkhip_proof_to_v1 returned %d" % rc)
+    return out.tobytes()
+
+
+def proof_from_v1(params, airs, v1_bytes):
+    """bincode(Proof<SC>) -> (zkhip proof bytes, public values per AIR)."""
+    lib = load_library()
+    prm = _Params(*params)
+    arr, keep = _air_structs(airs)
+    a, ptr = _bytes_ptr(v1_bytes)
+    size = proof_layout(params, airs)["n_words"] * 4
+    out = np.zeros(size, dtype=np.uint8)
+    pvs = [np.zeros(max(1, x["n_pvs"]), dtype=np.uint32) for x in airs]
+    pv_arr = (C.POINTER(C.c_uint32) * len(airs))(*[_u32p(p) for p in pvs])
+    n = C.c_size_t()
+    rc = lib.zkhip_proof_from_v1(C.byref(prm), arr, len(airs), ptr, a.size, out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size,
+                                 C.byref(n), pv_arr)
+    if rc != 0:
+        raise ZkhipError("zkhip_proof_from_v1 returned %d" % rc)
+    return out[:n.value].tobytes(), [p[:x["n_pvs"]] for p, x in zip(pvs, airs)]
