@@ -400,6 +400,11 @@ public:
         std::vector<const uint32_t*> pv(airs_.size());
         size_t off = 0;
         for (size_t a = 0; a < airs_.size(); a++) {
+            // heights are prover-chosen data: a chip with a preprocessed trace has the height of its table, and no
+            // height may leave the field's two-adicity (zkhip_verify re-checks the LogUp bus bound over all of them)
+            if (airs_[a].has_prep && sp.baseline[a] != airs_[a].prep_log_height)
+                throw Error(Error::VerifyProof, "baseline height of chip " + std::to_string(a) + " does not match its preprocessed trace");
+            if (sp.baseline[a] + params_.log_blowup > 27) throw Error(Error::VerifyProof, "baseline height out of range");
             za[a] = make_air(a, sp.baseline[a]);
             if (airs_[a].has_prep && airs_[a].prep_commit.size() != 8)
                 throw Error(Error::VerifyProof, "the app holds no commitment for the preprocessed trace of chip " + std::to_string(a));

@@ -15,6 +15,9 @@ pub const ZKHIP_ERR_CONSTRAINT: c_int = -8;
 pub const ZKHIP_DIGEST_WORDS: usize = 8;
 pub const ZKHIP_POSEIDON2_AIR_WIDTH: usize = 298;
 pub const ZKHIP_MAX_LOG_FINAL_POLY: u32 = 8;
+pub const ZKHIP_V1_SINGLE: c_int = 0;
+pub const ZKHIP_V1_VEC: c_int = 1;
+pub const ZKHIP_V1_MAX_AIRS: usize = 64;
 
 #[repr(C)]
 pub struct zkhip_ctx {
@@ -83,6 +86,25 @@ pub struct zkhip_proof_layout {
     pub queries: usize,
     pub query_words: usize,
     pub n_queries: usize,
+}
+
+/// summary of a decoded OpenVM-v1 `Proof<SC>` container (zkhip_proof_decode_v1)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkhip_v1_summary {
+    pub n_proofs: usize,
+    pub n_airs: usize,
+    pub n_queries: usize,
+    pub n_fri_layers: usize,
+    pub n_final_poly: usize,
+    pub n_main_commits: usize,
+    pub n_after_challenge_commits: usize,
+    pub n_preprocessed: usize,
+    pub n_input_batches: usize,
+    pub log_max_height: c_uint,
+    pub log_blowup: c_uint,
+    pub has_logup_pow: c_int,
+    pub log_degree: [c_uint; ZKHIP_V1_MAX_AIRS],
 }
 
 #[repr(C)]
@@ -166,6 +188,20 @@ extern "C" {
 
     pub fn zkhip_proof_layout_of(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize,
                                  out: *mut zkhip_proof_layout) -> c_int;
+
+    // the verifier's primitives on the host (no device)
+    pub fn zkhip_poseidon2_permute_host(state: *mut u32) -> c_int;
+    pub fn zkhip_mmcs_verify(root: *const u32, log_heights: *const c_uint, widths: *const usize, n_mats: usize, index: u64,
+                             opening: *const u32) -> c_int;
+    pub fn zkhip_fri_fold_row(index: u64, log_height: c_uint, beta: *const u32, e0: *const u32, e1: *const u32, out: *mut u32) -> c_int;
+
+    // the reference's stored-proof container (OpenVM-v1 Proof<SC>, bincode)
+    pub fn zkhip_proof_decode_v1(bytes: *const u8, len: usize, kind: c_int, out: *mut zkhip_v1_summary) -> c_int;
+    pub fn zkhip_proof_reencode_v1(bytes: *const u8, len: usize, kind: c_int, out: *mut u8, cap: usize, out_len: *mut usize) -> c_int;
+    pub fn zkhip_proof_to_v1(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize, pvs: *const *const u32,
+                             proof: *const u8, len: usize, out: *mut u8, cap: usize, out_len: *mut usize) -> c_int;
+    pub fn zkhip_proof_from_v1(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize, v1: *const u8, v1_len: usize,
+                               out: *mut u8, cap: usize, out_len: *mut usize, pvs_out: *const *mut u32) -> c_int;
 
     // per-kernel timing
     pub fn zkhip_profile_enable(ctx: *mut zkhip_ctx, on: c_int) -> c_int;

@@ -40,9 +40,10 @@ def test_error_codes_and_constants_match():
 
 def test_struct_fields_match_in_order():
     body = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
-    for cname in ("zkhip_matrix", "zkhip_params", "zkhip_air", "zkhip_proof_layout", "zkhip_kernel_stat"):
+    for cname in ("zkhip_matrix", "zkhip_params", "zkhip_air", "zkhip_proof_layout", "zkhip_kernel_stat", "zkhip_v1_summary"):
         cdef = re.search(r"typedef struct \{([^{}]*)\} %s;" % cname, body).group(1)
-        cfields = [re.search(r"([a-z_0-9]+)(?:\[\d+\])?\s*$", f.strip()).group(1) for f in cdef.split(";") if f.strip()]
+        cfields = [re.search(r"([a-z_0-9]+)(?:\[[A-Z0-9_]+\])?\s*$", part.strip()).group(1)
+                   for f in cdef.split(";") if f.strip() for part in f.split(",")]  # `size_t a, b;` declares two fields
         rdef = re.search(r"pub struct %s \{(.*?)\n\}" % cname, FFI, flags=re.S).group(1)
         rfields = re.findall(r"pub ([a-z_0-9]+):", rdef)
         assert cfields == rfields, (cname, cfields, rfields)

@@ -137,3 +137,36 @@ def test_final_polynomial_of_positive_length(ora, lfp):
     with pytest.raises(RuntimeError):
         ora.stark_prove(params, airs + [tiny])
     assert z.verify(params, airs + [tiny], pvs + [tp], proof.tobytes()) != 0
+
+
+def test_logup_bus_row_bound_and_parameter_validation():
+    """multiplicities live in characteristic p, so a bus must carry fewer than p interaction rows in total
+    (prover-chosen heights!); and the verifier validates parameters like keygen does."""
+    import zkvm_prover_amd as z
+    from zkvm_prover_amd import air
+
+    b = air.AirBuilder(2, 0)
+    for _ in range(16):
+        b.push_interaction(3, [b.var(0)], b.var(1), "send")
+        b.push_interaction(3, [b.var(0)], b.var(1), "receive")
+    b.finalize_interactions()
+    prog = b.program()
+    dummy = np.zeros(64, dtype=np.uint32).tobytes()
+    params = (1, 0, 4, 0, 0)
+    # 32 interactions x 2^26 rows = 2^31 >= p: refused outright, whatever the proof says
+    a = [dict(program=prog, log_height=26, width=2, n_pvs=0)]
+    assert z.verify(params, a, [np.zeros(0, np.uint32)], dummy) == -3
+    # 2^25 rows: below the bound; the (garbage) proof is then rejected as a proof
+    a = [dict(program=prog, log_height=25, width=2, n_pvs=0)]
+    assert z.verify(params, a, [np.zeros(0, np.uint32)], dummy) == -7
+    # the same total spread over two AIRs on the same bus is also refused
+    a = [dict(program=prog, log_height=25, width=2, n_pvs=0)] * 2
+    assert z.verify(params, a, [np.zeros(0, np.uint32)] * 2, dummy) == -3
+    fib = [dict(program=air.fibonacci_air().program(), log_height=4, width=2, n_pvs=3)]
+    pv = [np.array([0, 1, 1], dtype=np.uint32)]
+    for bad in [(1, 0, 0, 0, 0), (1, 0, 4, 31, 0), (1, 0, 4, 0, 31), (5, 0, 4, 0, 0), (0, 0, 4, 0, 0)]:
+        assert z.verify(bad, fib, pv, dummy) == -3, bad
+    tall = [dict(program=air.fibonacci_air().program(), log_height=27, width=2, n_pvs=3)]
+    assert z.verify((1, 0, 4, 0, 0), tall, pv, dummy) == -3   # log_height + log_blowup > 27
+    with pytest.raises(z.ZkhipError):
+        z.proof_layout((1, 0, 4, 0, 0), tall)

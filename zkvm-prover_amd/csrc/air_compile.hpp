@@ -53,6 +53,21 @@ struct AirProgram {
     size_t perm_width() const { return ints.empty() ? 0 : 4 * (n_groups() + 1); }
 };
 
+// LogUp soundness bound (the trace-height constraint the reference's stark-backend carries in its verifying key):
+// multiplicities live in characteristic p, so a bus whose total number of interaction rows reaches p can be balanced
+// by ~p copies of a bogus message.  Sum over the AIRs of (interactions on the bus) << log_height must stay below p.
+// `progs[a]` / `log_heights[a]` describe the AIRs of one proof.
+inline bool logup_bus_counts_bounded(const AirProgram* progs, const unsigned* log_heights, size_t n_airs) {
+    std::map<uint32_t, uint64_t> rows_on_bus;
+    for (size_t a = 0; a < n_airs; a++)
+        for (const auto& it : progs[a].ints) {
+            uint64_t& t = rows_on_bus[it.bus];
+            t += (uint64_t)1 << log_heights[a];
+            if (t >= P) return false;
+        }
+    return true;
+}
+
 inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p, std::string* err) {
     auto fail = [&](const char* m) {
         if (err) *err = m;

@@ -143,23 +143,27 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
 const char* zkhip_last_error(const zkhip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "no context"; }
 
 int zkhip_set_stream(zkhip_ctx* ctx, void* hip_stream) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx) return ZKHIP_ERR_INVALID;
     ctx->stream = (hipStream_t)hip_stream;
     return ZKHIP_OK;
 }
 int zkhip_sync(zkhip_ctx* ctx) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx) return ZKHIP_ERR_INVALID;
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
 }
 
 int zkhip_malloc(zkhip_ctx* ctx, size_t bytes, void** dptr) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !dptr) return ZKHIP_ERR_INVALID;
     if (hipMalloc(dptr, bytes ? bytes : 16) != hipSuccess)
         return set_error(ctx, ZKHIP_ERR_NOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
     return ZKHIP_OK;
 }
 int zkhip_free(zkhip_ctx* ctx, void* dptr) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx) return ZKHIP_ERR_INVALID;
     if (!dptr) return ZKHIP_OK;
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -167,45 +171,53 @@ int zkhip_free(zkhip_ctx* ctx, void* dptr) {
     return ZKHIP_OK;
 }
 int zkhip_h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx) return ZKHIP_ERR_INVALID;
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // src may be pageable and freed by the caller
     return ZKHIP_OK;
 }
 int zkhip_d2h(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx) return ZKHIP_ERR_INVALID;
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
 }
 int zkhip_to_monty(zkhip_ctx* ctx, uint32_t* d, size_t n) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx) return ZKHIP_ERR_INVALID;
     return convert_repr(ctx, d, n, true);
 }
 int zkhip_from_monty(zkhip_ctx* ctx, uint32_t* d, size_t n) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx) return ZKHIP_ERR_INVALID;
     return convert_repr(ctx, d, n, false);
 }
 
 int zkhip_ntt_batch(zkhip_ctx* ctx, uint32_t* d_mat, unsigned log_n, size_t width, size_t stride, int inverse,
                     int bitrev_out) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_mat) return ZKHIP_ERR_INVALID;
     return ntt_batch(ctx, d_mat, log_n, width, stride, inverse != 0, bitrev_out != 0);
 }
 int zkhip_lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* d_out, size_t out_stride,
                     unsigned log_n, unsigned added_bits, size_t width, uint32_t shift) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_in || !d_out) return ZKHIP_ERR_INVALID;
     if (shift == 0 || shift >= P) return set_error(ctx, ZKHIP_ERR_INVALID, "shift must be in [1,p)");
     return lde_batch(ctx, d_in, in_stride, d_out, out_stride, log_n, added_bits, width, to_monty(shift));
 }
 
 int zkhip_poseidon2_permute_batch(zkhip_ctx* ctx, uint32_t* d_states, size_t n) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_states) return ZKHIP_ERR_INVALID;
     return permute_batch(ctx, d_states, n);
 }
 
 int zkhip_merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip_tree** tree,
                         uint32_t* root_out) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !mats || !tree) return ZKHIP_ERR_INVALID;
     ZK_TRY(merkle_commit(ctx, mats, n_mats, tree));
     if (root_out) {
@@ -220,6 +232,7 @@ const uint32_t* zkhip_tree_root_device(const zkhip_tree* t) {
 }
 unsigned zkhip_tree_log_height(const zkhip_tree* t) { return t ? t->log_height : 0; }
 int zkhip_tree_layer(zkhip_ctx* ctx, const zkhip_tree* t, unsigned layer, uint32_t* out) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !t || !out || layer > t->log_height) return ZKHIP_ERR_INVALID;
     size_t words = (size_t)8 << (t->log_height - layer);
     ZK_TRY(zkhip_d2h(ctx, out, t->d_digests + t->layer_off[layer] * 8, words * 4));
@@ -229,6 +242,7 @@ int zkhip_tree_layer(zkhip_ctx* ctx, const zkhip_tree* t, unsigned layer, uint32
 size_t zkhip_merkle_opening_words(const zkhip_tree* t) { return t ? t->total_width + 8 * (size_t)t->log_height : 0; }
 int zkhip_merkle_open(zkhip_ctx* ctx, const zkhip_tree* t, const uint64_t* indices, size_t n, uint32_t* out,
                       size_t cap_words) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !t || !indices || !out) return ZKHIP_ERR_INVALID;
     size_t pitch = zkhip_merkle_opening_words(t);
     if (cap_words < pitch * n) return set_error(ctx, ZKHIP_ERR_SMALL_BUFFER, "merkle_open: output too small");
@@ -245,6 +259,7 @@ int zkhip_merkle_open(zkhip_ctx* ctx, const zkhip_tree* t, const uint64_t* indic
     return zkhip_d2h(ctx, out, d_out, pitch * n * 4);
 }
 void zkhip_tree_destroy(zkhip_ctx* ctx, zkhip_tree* t) {
+    ZK_BIND_DEVICE(ctx);
     if (!t) return;
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (t->d_colptrs) hipFree(t->d_colptrs);
@@ -253,6 +268,7 @@ void zkhip_tree_destroy(zkhip_ctx* ctx, zkhip_tree* t) {
 }
 
 int zkhip_fri_fold(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, unsigned log_n_out, const uint32_t beta[4]) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_in || !d_out || !beta) return ZKHIP_ERR_INVALID;
     uint32_t bm[4];
     for (int i = 0; i < 4; i++) {
@@ -285,6 +301,7 @@ static int tr_buf(zkhip_ctx* ctx, zkhip_transcript* t, size_t words) {
 }
 
 int zkhip_transcript_create(zkhip_ctx* ctx, zkhip_transcript** out) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !out) return ZKHIP_ERR_INVALID;
     zkhip_transcript* t = new zkhip_transcript();
     if (hipMalloc(&t->d, sizeof(DevTranscript)) != hipSuccess) {
@@ -301,6 +318,7 @@ int zkhip_transcript_create(zkhip_ctx* ctx, zkhip_transcript** out) {
     return ZKHIP_OK;
 }
 void zkhip_transcript_destroy(zkhip_ctx* ctx, zkhip_transcript* t) {
+    ZK_BIND_DEVICE(ctx);
     if (!t) return;
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (t->d) hipFree(t->d);
@@ -308,6 +326,7 @@ void zkhip_transcript_destroy(zkhip_ctx* ctx, zkhip_transcript* t) {
     delete t;
 }
 int zkhip_transcript_observe(zkhip_ctx* ctx, zkhip_transcript* t, const uint32_t* vals, size_t n) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !t || (!vals && n)) return ZKHIP_ERR_INVALID;
     if (n == 0) return ZKHIP_OK;
     for (size_t i = 0; i < n; i++)
@@ -317,6 +336,7 @@ int zkhip_transcript_observe(zkhip_ctx* ctx, zkhip_transcript* t, const uint32_t
     return transcript_observe(ctx, t->d, t->d_buf, (uint32_t)n, true);
 }
 int zkhip_transcript_sample(zkhip_ctx* ctx, zkhip_transcript* t, uint32_t* out, size_t n) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !t || (!out && n)) return ZKHIP_ERR_INVALID;
     if (n == 0) return ZKHIP_OK;
     ZK_TRY(tr_buf(ctx, t, n));
@@ -324,6 +344,7 @@ int zkhip_transcript_sample(zkhip_ctx* ctx, zkhip_transcript* t, uint32_t* out, 
     return zkhip_d2h(ctx, out, t->d_buf, n * 4);
 }
 int zkhip_transcript_grind(zkhip_ctx* ctx, zkhip_transcript* t, unsigned bits, uint32_t* witness) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !t || !witness) return ZKHIP_ERR_INVALID;
     ZK_TRY(tr_buf(ctx, t, 1));
     ZK_TRY(transcript_grind(ctx, t->d, bits, t->d_buf));
@@ -336,12 +357,14 @@ int zkhip_transcript_grind(zkhip_ctx* ctx, zkhip_transcript* t, unsigned bits, u
 
 // ---- profiling ----------------------------------------------------------------------------------
 int zkhip_profile_enable(zkhip_ctx* ctx, int on) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx) return ZKHIP_ERR_INVALID;
     if (!on) profile_flush(ctx);
     ctx->profiling = on != 0;
     return ZKHIP_OK;
 }
 int zkhip_profile_read(zkhip_ctx* ctx, zkhip_kernel_stat* out, size_t cap) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx) return ZKHIP_ERR_INVALID;
     profile_flush(ctx);
     size_t i = 0;
@@ -357,6 +380,7 @@ int zkhip_profile_read(zkhip_ctx* ctx, zkhip_kernel_stat* out, size_t cap) {
     return (int)i;
 }
 int zkhip_profile_reset(zkhip_ctx* ctx) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx) return ZKHIP_ERR_INVALID;
     profile_flush(ctx);
     ctx->stats.clear();

@@ -668,6 +668,11 @@ struct zkhip_pk {
     uint32_t** d_lde_dst = nullptr;
     const uint32_t** d_open_ptrs = nullptr;
     const uint32_t** h_open_ptrs_pinned = nullptr;
+    // per-proof host->device staging (pinned): [preamble | 4 header words | Montgomery public values of every AIR]; the
+    // event marks the last copy that reads it, so a second prove_async waits only if those copies are still pending
+    uint32_t* h_stage_pinned = nullptr;
+    size_t stage_words = 0;
+    hipEvent_t stage_ev = nullptr;
     uint32_t* d_open_dst = nullptr;
     size_t open_total_cols = 0;
     RoItem* d_ro_items = nullptr;   // every committed matrix, grouped by height (ascending), commitment order inside
@@ -722,6 +727,7 @@ int upload(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
 extern "C" {
 
 int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* airs, size_t n_airs, zkhip_pk** out) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !params || !airs || !out || n_airs == 0) return ZKHIP_ERR_INVALID;
     if (params->log_final_poly_len > ZKHIP_MAX_LOG_FINAL_POLY) return set_error(ctx, ZKHIP_ERR_INVALID, "log_final_poly_len out of range");
     for (size_t a = 0; a < n_airs; a++)
@@ -867,6 +873,15 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         w += pitch * params->num_queries;
         pk->proof_words = w;
     }
+    {
+        std::vector<AirProgram> progs(n_airs);
+        std::vector<unsigned> lhs(n_airs);
+        for (size_t a = 0; a < n_airs; a++) progs[a] = pk->airs[a].prog, lhs[a] = pk->airs[a].lh;
+        if (!logup_bus_counts_bounded(progs.data(), lhs.data(), n_airs)) {
+            delete pk;
+            return set_error(ctx, ZKHIP_ERR_INVALID, "a bus carries >= p interaction rows: the LogUp argument is unsound at these trace heights");
+        }
+    }
     // ---- workspace plan ----
     Bump bp;
     const unsigned nch = pk->nch;
@@ -882,10 +897,12 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     std::vector<LuHost> lu(n_airs);
     for (size_t a = 0; a < n_airs; a++) {
         AirPlan& A = pk->airs[a];
-        if (compile_air(A.prog, &comp[a], &err) != 0) {
-            zkhip_pk_destroy(ctx, pk);  // also unloads the modules of the AIRs already compiled
-            return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + ": " + err);
-        }
+        // The interpreter lowering can refuse a valid AIR (more live intermediates than its LDS slots); the compiled
+        // kernel keeps intermediates in registers and has no such limit, so the refusal is fatal only if the JIT is
+        // unavailable too.
+        const bool interp_ok = compile_air(A.prog, &comp[a], &err) == 0;
+        const std::string interp_err = err;
+        if (!interp_ok) comp[a] = CompiledAir();
         A.n_instr = (uint32_t)(comp[a].code.size() / 3);
         A.n_slots = comp[a].n_slots;
         // keygen-time compiled constraint kernel when the evaluation is large enough to repay the
@@ -895,7 +912,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         // can afford to compile every chip: ~1.5 s each)
         static const unsigned jit_log = getenv("ZKHIP_JIT_MIN_LOG_WORK") ? (unsigned)atoi(getenv("ZKHIP_JIT_MIN_LOG_WORK")) : 26u;
         const bool big = (double)((size_t)1 << (airs[a].log_height + pk->b)) * (double)A.n_instr >= (double)(1ull << std::min(jit_log, 62u));
-        if ((big || getenv("ZKHIP_FORCE_JIT")) && !getenv("ZKHIP_NO_JIT")) {
+        if ((big || !interp_ok || getenv("ZKHIP_FORCE_JIT")) && !getenv("ZKHIP_NO_JIT")) {
             std::string msg;
             std::vector<uint32_t> tab;
             if (quot_jit_build(A.prog, airs[a].log_height, pk->b, &A.jit_mod, &A.jit_fn, &tab, &msg) &&
@@ -907,6 +924,10 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
                 A.jit_fn = nullptr;
                 ctx->last_error = "constraint JIT unavailable, using the interpreter kernel: " + msg;
             }
+        }
+        if (!interp_ok && !A.jit_fn) {
+            zkhip_pk_destroy(ctx, pk);  // also unloads the modules of the AIRs already compiled
+            return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + ": " + interp_err + " (interpreter form; no compiled form available either)");
         }
         ao[a].code = bp.take(comp[a].code.size() * 4 + 16);
         ao[a].consts = bp.take(comp[a].consts.size() * 4);
@@ -1226,6 +1247,14 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     }
     if (rc == ZKHIP_OK) rc = upload(ctx, pk->d_fri_desc, desc.data(), desc.size() * sizeof(FriLayerDesc));
     if (rc == ZKHIP_OK) rc = ensure_twiddles(ctx, pk->hmax);
+    if (rc == ZKHIP_OK) {
+        size_t n_pv = 0;
+        for (const auto& A : pk->airs) n_pv += A.n_pvs;
+        pk->stage_words = pk->preamble.size() + 4 + n_pv;
+        if (hipHostMalloc((void**)&pk->h_stage_pinned, pk->stage_words * 4, 0) != hipSuccess ||
+            hipEventCreateWithFlags(&pk->stage_ev, hipEventDisableTiming) != hipSuccess)
+            rc = set_error(ctx, ZKHIP_ERR_NOMEM, "pinned staging buffer");
+    }
     if (rc != ZKHIP_OK) {
         zkhip_pk_destroy(ctx, pk);
         return rc;
@@ -1235,10 +1264,13 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
 }
 
 void zkhip_pk_destroy(zkhip_ctx* ctx, zkhip_pk* pk) {
+    ZK_BIND_DEVICE(ctx);
     if (!pk) return;
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (pk->t_main) zkhip_tree_destroy(ctx, pk->t_main);
     if (pk->h_open_ptrs_pinned) hipHostFree(pk->h_open_ptrs_pinned);
+    if (pk->h_stage_pinned) hipHostFree(pk->h_stage_pinned);
+    if (pk->stage_ev) hipEventDestroy(pk->stage_ev);
     if (pk->t_perm) zkhip_tree_destroy(ctx, pk->t_perm);
     for (auto& A : pk->airs)
         if (A.t_prep) zkhip_tree_destroy(ctx, A.t_prep);
@@ -1257,6 +1289,7 @@ size_t zkhip_proof_size(const zkhip_pk* pk) { return pk ? pk->proof_words * 4 : 
 size_t zkhip_pk_workspace_bytes(const zkhip_pk* pk) { return pk ? pk->ws_bytes : 0; }
 
 int zkhip_pk_prep_commitment(zkhip_ctx* ctx, const zkhip_pk* pk, size_t air_index, uint32_t out[8]) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !pk || !out || air_index >= pk->airs.size()) return ZKHIP_ERR_INVALID;
     if (!pk->airs[air_index].prep_w) return set_error(ctx, ZKHIP_ERR_INVALID, "AIR has no preprocessed trace");
     memcpy(out, pk->airs[air_index].prep_commit, 32);
@@ -1265,6 +1298,7 @@ int zkhip_pk_prep_commitment(zkhip_ctx* ctx, const zkhip_pk* pk, size_t air_inde
 
 int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const* d_traces,
                       const uint32_t* const* pvs) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !pkc || !d_traces) return ZKHIP_ERR_INVALID;
     zkhip_pk* pk = const_cast<zkhip_pk*>(pkc);
     const unsigned b = pk->b, nch = pk->nch, hmax = pk->hmax;
@@ -1277,27 +1311,35 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     uint32_t* d_alpha_f = pk->d_chal + 8;
     uint32_t* d_betas = pk->d_chal + 12;
 
-    // ---- 0. preamble + public values ----
+    // ---- 0. preamble + public values: one pinned staging buffer, no host synchronisation ----
     {
-        std::vector<uint32_t> pre = pk->preamble;
         for (size_t a = 0; a < n_airs; a++) {
             const AirPlan& A = pk->airs[a];
             if (A.n_pvs && (!pvs || !pvs[a])) return set_error(ctx, ZKHIP_ERR_INVALID, "missing public values");
-            std::vector<uint32_t> pm(A.n_pvs);
-            for (size_t i = 0; i < A.n_pvs; i++) {
+            for (size_t i = 0; i < A.n_pvs; i++)
                 if (pvs[a][i] >= P) return set_error(ctx, ZKHIP_ERR_INVALID, "public value not canonical");
+        }
+        ZK_HIP_CHECK(ctx, hipEventSynchronize(pk->stage_ev));  // returns at once unless the previous proof's copies are pending
+        const size_t n_pre = pk->preamble.size();
+        uint32_t* pre = pk->h_stage_pinned;
+        uint32_t* hdr = pre + n_pre;
+        uint32_t* pm = hdr + 4;
+        memcpy(pre, pk->preamble.data(), n_pre * 4);
+        hdr[0] = PROOF_MAGIC + (pk->n_lu ? 1u : 0u) + (pk->n_prep ? 2u : 0u), hdr[1] = (uint32_t)n_airs, hdr[2] = hmax, hdr[3] = pk->n_layers;
+        for (size_t a = 0; a < n_airs; a++) {
+            const AirPlan& A = pk->airs[a];
+            for (size_t i = 0; i < A.n_pvs; i++) {
                 pre[pk->preamble_pv_off[a] + i] = pvs[a][i];
                 pm[i] = to_monty(pvs[a][i]);
             }
-            if (A.n_pvs) ZK_HIP_CHECK(ctx, hipMemcpyAsync(A.d_pvs, pm.data(), A.n_pvs * 4, hipMemcpyHostToDevice, st));
-            ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));  // pm is a stack temporary
+            if (A.n_pvs) ZK_HIP_CHECK(ctx, hipMemcpyAsync(A.d_pvs, pm, A.n_pvs * 4, hipMemcpyHostToDevice, st));
+            pm += A.n_pvs;
         }
-        ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_preamble, pre.data(), pre.size() * 4, hipMemcpyHostToDevice, st));
-        uint32_t hdr[4] = {PROOF_MAGIC + (pk->n_lu ? 1u : 0u) + (pk->n_prep ? 2u : 0u), (uint32_t)n_airs, hmax, pk->n_layers};
-        ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_proof, hdr, sizeof hdr, hipMemcpyHostToDevice, st));
-        ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_preamble, pre, n_pre * 4, hipMemcpyHostToDevice, st));
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_proof, hdr, 16, hipMemcpyHostToDevice, st));
+        ZK_HIP_CHECK(ctx, hipEventRecord(pk->stage_ev, st));
         ZK_TRY(transcript_init(ctx, pk->d_tr));
-        ZK_TRY(transcript_observe(ctx, pk->d_tr, pk->d_preamble, (uint32_t)pre.size(), true));
+        ZK_TRY(transcript_observe(ctx, pk->d_tr, pk->d_preamble, (uint32_t)n_pre, true));
     }
 
     for (size_t a = 0; a < n_airs; a++)
@@ -1634,6 +1676,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
 }
 
 int zkhip_proof_fetch(zkhip_ctx* ctx, const zkhip_pk* pk, uint8_t* out, size_t cap, size_t* out_len) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !pk || !out) return ZKHIP_ERR_INVALID;
     size_t bytes = pk->proof_words * 4;
     if (out_len) *out_len = bytes;
@@ -1648,6 +1691,7 @@ int zkhip_proof_fetch(zkhip_ctx* ctx, const zkhip_pk* pk, uint8_t* out, size_t c
 
 int zkhip_prove(zkhip_ctx* ctx, const zkhip_pk* pk, const uint32_t* const* d_traces, const uint32_t* const* pvs,
                 uint8_t* out, size_t cap, size_t* out_len) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !pk || !out) return ZKHIP_ERR_INVALID;
     if (cap < pk->proof_words * 4) {
         if (out_len) *out_len = pk->proof_words * 4;

@@ -246,12 +246,14 @@ using namespace zk;
 extern "C" {
 
 int zkhip_ext_batch_inverse(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_in || !d_out) return ZKHIP_ERR_INVALID;
     return launch_batch_inverse(ctx, d_in, d_out, n, nullptr);
 }
 
 int zkhip_logup_running_sum(zkhip_ctx* ctx, const uint32_t* d_den, const uint32_t* d_num, size_t n, uint32_t* d_out,
                             uint32_t* total_out) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_den || !d_num || !d_out) return ZKHIP_ERR_INVALID;
     ZK_TRY(logup_running_sum(ctx, d_den, d_num, n, d_out));
     if (total_out) {
@@ -263,6 +265,7 @@ int zkhip_logup_running_sum(zkhip_ctx* ctx, const uint32_t* d_den, const uint32_
 }
 
 int zkhip_mle_fold(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, const uint32_t r[4]) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_in || !d_out || !r) return ZKHIP_ERR_INVALID;
     if (n == 0) return ZKHIP_OK;
     uint32_t rm[4];
@@ -281,6 +284,7 @@ int zkhip_mle_fold(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t
 }
 
 int zkhip_sumcheck_round(zkhip_ctx* ctx, const uint32_t* const* d_tables, size_t k, size_t n_half, uint32_t* out) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_tables || !out || k < 1 || k > SCR_MAXK) return ZKHIP_ERR_INVALID;
     SumcheckArgs a;
     for (size_t j = 0; j < SCR_MAXK; j++) a.tab[j] = j < k ? d_tables[j] : nullptr;

@@ -155,11 +155,13 @@ int range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d_values, size_t n, un
 using namespace zk;
 extern "C" int zkhip_range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d_values, size_t n, unsigned log_table,
                                            uint32_t* d_counts, int accumulate) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_counts || (n && !d_values)) return ZKHIP_ERR_INVALID;
     return range_counts_tracegen(ctx, d_values, n, log_table, d_counts, accumulate);
 }
 extern "C" int zkhip_poseidon2_air_tracegen(zkhip_ctx* ctx, const uint32_t* d_inputs, size_t n_perms, unsigned log_height,
                                             uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_trace) return ZKHIP_ERR_INVALID;
     return poseidon2_air_tracegen(ctx, d_inputs, n_perms, log_height, d_trace);
 }

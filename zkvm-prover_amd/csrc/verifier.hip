@@ -171,7 +171,7 @@ extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* a
     for (size_t a = 0; a < n_airs; a++) {
         AirProgram pg;
         if (parse_air(airs[a].program, airs[a].program_len, airs[a].width, &pg, nullptr) != 0) return ZKHIP_ERR_INVALID;
-        if (airs[a].log_height > 27 || airs[a].log_height < lfp) return ZKHIP_ERR_INVALID;
+        if (airs[a].log_height + b > 27 || airs[a].log_height < lfp) return ZKHIP_ERR_INVALID;
         const unsigned h = airs[a].log_height + b;
         hmax = std::max(hmax, h);
         main_h = std::max(main_h, h);
@@ -217,6 +217,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     const unsigned b = prm->log_blowup, nch = 1u << b;
     const unsigned lfp = prm->log_final_poly_len;  // the fold loop stops at 2^(b+lfp) values: a polynomial of degree < 2^lfp
     if (lfp > ZKHIP_MAX_LOG_FINAL_POLY || b < 1 || b > 4) return ZKHIP_ERR_INVALID;
+    if (prm->num_queries == 0 || prm->commit_pow_bits > 30 || prm->query_pow_bits > 30) return ZKHIP_ERR_INVALID;  // as zkhip_keygen
     const size_t n_fin = (size_t)1 << lfp;
     const size_t n_words = len / 4;
     if (n_words < 4) return ZKHIP_ERR_VERIFY;
@@ -230,7 +231,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     size_t n_lu = 0, n_prep = 0;
     for (size_t a = 0; a < n_airs; a++) {
         if (parse_air(airs[a].program, airs[a].program_len, airs[a].width, &pg[a], nullptr) != 0) return ZKHIP_ERR_INVALID;
-        if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height > 27 || airs[a].log_height < lfp) return ZKHIP_ERR_INVALID;
+        if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height + b > 27 || airs[a].log_height < lfp || airs[a].width == 0) return ZKHIP_ERR_INVALID;
         if (pg[a].max_degree > nch + 1) return ZKHIP_ERR_CONSTRAINT;
         if (airs[a].n_pvs && (!pvs || !pvs[a])) return ZKHIP_ERR_INVALID;
         hmax = std::max(hmax, airs[a].log_height + b);
@@ -262,6 +263,11 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     for (auto& m : cm) {
         m.open_off = n_open;
         n_open += m.width * m.n_pts;
+    }
+    {
+        std::vector<unsigned> lhs(n_airs);
+        for (size_t a = 0; a < n_airs; a++) lhs[a] = airs[a].log_height;
+        if (!logup_bus_counts_bounded(pg.data(), lhs.data(), n_airs)) return ZKHIP_ERR_INVALID;
     }
     const unsigned n_layers = hmax - b - lfp;
     size_t r = 0;

@@ -53,6 +53,13 @@ void profile_begin(zkhip_ctx* ctx, const char* name);
 void profile_end(zkhip_ctx* ctx);
 int profile_flush(zkhip_ctx* ctx);
 
+// every entry point that takes a context runs on the context's device, whatever device the calling thread had current
+// (two contexts on different GPUs in one process; a context handed to another thread)
+#define ZK_BIND_DEVICE(ctx)                            \
+    do {                                               \
+        if (ctx) (void)hipSetDevice((ctx)->device);    \
+    } while (0)
+
 #define ZK_HIP_CHECK(ctx, expr)                                                              \
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \
