@@ -213,6 +213,7 @@ def main():
     def run(n_steps):
         # keep n_pipe proofs in flight: proof i+n_pipe is enqueued as soon as proof i has been fetched
         last = (0, None)
+        xstat["posted"] = 0
         for i in range(min(n_pipe, n_steps)):
             launch(i)
         for i in range(n_steps):
