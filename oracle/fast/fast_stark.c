@@ -1,0 +1,1260 @@
+/*
+ * oracle/fast/fast_stark.c -- an OPTIMISED CPU prover for the same proofs as oracle/stark.c.
+ *
+ * TEST / BENCH INFRASTRUCTURE ONLY (like everything under oracle/): it is the `cpu_baseline` leg of bench.py and the
+ * checker of the full-size bit-exactness tests; the product never links or loads it.
+ *
+ * Why it exists: oracle/stark.c is written to be obviously right (64-bit `% p`, Fermat inversions per row, one
+ * column at a time) and is one to two orders of magnitude slower than a competent CPU prover, so timing it says
+ * nothing about "the reference CPU path" that BASELINE.json's north_star compares against.  The reference's CPU
+ * engine (openvm-stark-backend on Plonky3: packed Montgomery arithmetic in AVX2/AVX-512 lanes, rayon over rows /
+ * columns; un-vendored, unbuildable here -- no Rust) does what this file does:
+ *   - BabyBear in Montgomery form, 16 (AVX-512) or 8 (AVX2) lanes per instruction: two vpmuludq per product half,
+ *     like p3-monty-31's packed types;
+ *   - Poseidon2 with one ROW per lane: 16 independent sponges advance together (p3's packed permutation);
+ *   - cache-oblivious recursive radix-2 DIF NTTs with the last log2(lanes) stages done inside a register;
+ *   - batch (Montgomery-trick) inversions instead of per-row Fermat inversions;
+ *   - barycentric openings and the reduced openings as (extension x base) dot products over vectors of rows;
+ *   - proof-of-work grinding over lanes x threads, smallest witness kept;
+ *   - OpenMP over columns / row blocks in every stage.
+ * It is checked BIT-EXACT against oracle/stark.c (tests/test_fast_oracle_cpu.py): same proof bytes for every supported
+ * AIR set.  Scope: the AIR sets of the bench workload family (any number of AIRs, mixed heights, public values, any FRI
+ * parameters); AIRs with preprocessed traces or bus interactions are refused (returns 0) -- the headline workload
+ * (SURVEY.md 8(d) cfg #4) has neither.
+ *
+ * Protocol, layout and every formula: oracle/stark.c (its header cites the reference call sites).  Values crossing
+ * this API are canonical u32, as in zk_oracle.h.
+ */
+#include <immintrin.h>
+#include <omp.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../zk_oracle.h"
+
+#define P ORA_P
+#define MU 0x88000001u /* P * MU == 1 (mod 2^32) */
+#define GEN 31u
+#define AIR_MAGIC 0x31414B5Au
+#define PROOF_MAGIC 0x31504B5Au
+#define PROTO_TAG 0x5A4B4831u
+#define MAX_LOG_FINAL_POLY 8
+
+static void *xalloc(size_t bytes) { return aligned_alloc(64, (bytes + 63) / 64 * 64 + 64); }
+
+/* ------------------------------------------------------------------ scalar Montgomery */
+static uint32_t R1, R2; /* 2^32 mod p, 2^64 mod p */
+static inline uint32_t mm(uint32_t a, uint32_t b) {
+    uint64_t x = (uint64_t)a * b;
+    uint32_t t = (uint32_t)x * MU;
+    uint64_t u = (uint64_t)t * P;
+    uint32_t r = (uint32_t)((x - u) >> 32);
+    return x < u ? r + P : r;
+}
+static inline uint32_t madd(uint32_t a, uint32_t b) {
+    uint32_t s = a + b;
+    return s >= P ? s - P : s;
+}
+static inline uint32_t msub(uint32_t a, uint32_t b) { return a >= b ? a - b : a + P - b; }
+static inline uint32_t to_m(uint32_t c) { return mm(c, R2); }
+static inline uint32_t from_m(uint32_t m) { return mm(m, 1); }
+static uint32_t mpow(uint32_t a, uint64_t e) {
+    uint32_t r = R1;
+    while (e) {
+        if (e & 1) r = mm(r, a);
+        a = mm(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+static uint32_t minv(uint32_t a) { return mpow(a, P - 2); }
+static uint32_t two_adic_m(unsigned bits) { return to_m(ora_two_adic_generator(bits)); }
+static inline size_t bitrev(size_t x, unsigned bits) {
+    size_t r = 0;
+    for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+/* extension F[x]/(x^4 - 11), Montgomery coordinates */
+typedef struct {
+    uint32_t c[4];
+} ext;
+static uint32_t W11; /* to_m(11) */
+static inline ext eadd(ext a, ext b) {
+    ext r;
+    for (int k = 0; k < 4; k++) r.c[k] = madd(a.c[k], b.c[k]);
+    return r;
+}
+static inline ext esub(ext a, ext b) {
+    ext r;
+    for (int k = 0; k < 4; k++) r.c[k] = msub(a.c[k], b.c[k]);
+    return r;
+}
+static inline ext escale(ext a, uint32_t s) {
+    ext r;
+    for (int k = 0; k < 4; k++) r.c[k] = mm(a.c[k], s);
+    return r;
+}
+static inline ext emul(ext a, ext b) {
+    uint32_t t[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) t[i + j] = madd(t[i + j], mm(a.c[i], b.c[j]));
+    ext r;
+    for (int k = 0; k < 4; k++) r.c[k] = k < 3 ? madd(t[k], mm(W11, t[k + 4])) : t[k];
+    return r;
+}
+static ext eone(void) {
+    ext r = {{R1, 0, 0, 0}};
+    return r;
+}
+static ext ezero(void) {
+    ext r = {{0, 0, 0, 0}};
+    return r;
+}
+static ext epow(ext a, uint64_t e) {
+    ext r = eone();
+    while (e) {
+        if (e & 1) r = emul(r, a);
+        a = emul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+static uint32_t FROB[4]; /* 11^((p-1)/4 * i) */
+static ext efrob(ext a) {
+    ext r;
+    for (int i = 0; i < 4; i++) r.c[i] = mm(a.c[i], FROB[i]);
+    return r;
+}
+static ext einv(ext a) {
+    ext f1 = efrob(a), f2 = efrob(f1), f3 = efrob(f2);
+    ext t = emul(emul(f1, f2), f3);
+    ext n = emul(t, a); /* the norm: lies in the base field */
+    return escale(t, minv(n.c[0]));
+}
+static ext ext_from_canon(const uint32_t *c) {
+    ext r;
+    for (int k = 0; k < 4; k++) r.c[k] = to_m(c[k]);
+    return r;
+}
+static void ext_to_canon(ext a, uint32_t *o) {
+    for (int k = 0; k < 4; k++) o[k] = from_m(a.c[k]);
+}
+/* in-place batch inversion of n extension elements (Montgomery's trick), one true inversion */
+static void ebatch_inv(ext *a, size_t n, ext *scratch) {
+    if (!n) return;
+    ext acc = eone();
+    for (size_t i = 0; i < n; i++) {
+        scratch[i] = acc;
+        acc = emul(acc, a[i]);
+    }
+    acc = einv(acc);
+    for (size_t i = n; i-- > 0;) {
+        ext t = emul(acc, scratch[i]);
+        acc = emul(acc, a[i]);
+        a[i] = t;
+    }
+}
+static void batch_inv(uint32_t *a, size_t n, uint32_t *scratch) {
+    if (!n) return;
+    uint32_t acc = R1;
+    for (size_t i = 0; i < n; i++) {
+        scratch[i] = acc;
+        acc = mm(acc, a[i]);
+    }
+    acc = minv(acc);
+    for (size_t i = n; i-- > 0;) {
+        uint32_t t = mm(acc, scratch[i]);
+        acc = mm(acc, a[i]);
+        a[i] = t;
+    }
+}
+
+/* ------------------------------------------------------------------ vector layer */
+#if defined(__AVX512F__)
+#define VL 16
+#define LOG_VL 4
+typedef __m512i vec;
+static inline vec vload(const void *p) { return _mm512_loadu_si512(p); }
+static inline void vstore(void *p, vec v) { _mm512_storeu_si512(p, v); }
+static inline vec vset1(uint32_t x) { return _mm512_set1_epi32((int)x); }
+static inline vec vzero(void) { return _mm512_setzero_si512(); }
+static inline vec vadd32(vec a, vec b) { return _mm512_add_epi32(a, b); }
+static inline vec vsub32(vec a, vec b) { return _mm512_sub_epi32(a, b); }
+static inline vec vminu(vec a, vec b) { return _mm512_min_epu32(a, b); }
+static inline vec vmul64(vec a, vec b) { return _mm512_mul_epu32(a, b); }
+static inline vec vsub64(vec a, vec b) { return _mm512_sub_epi64(a, b); }
+static inline vec vsrl64_32(vec a) { return _mm512_srli_epi64(a, 32); }
+static inline vec vhdup(vec a) { return _mm512_castps_si512(_mm512_movehdup_ps(_mm512_castsi512_ps(a))); }
+static inline vec vblend_odd(vec even, vec odd) { return _mm512_mask_blend_epi32(0xAAAA, even, odd); }
+static inline vec vperm(vec x, vec idx) { return _mm512_permutexvar_epi32(idx, x); }
+static inline vec vselect(vec mask, vec a, vec b) { return _mm512_ternarylogic_epi32(mask, b, a, 0xCA); } /* mask ? b : a */
+static inline vec vgather(const uint32_t *base, vec idx) { return _mm512_i32gather_epi32(idx, base, 4); }
+#elif defined(__AVX2__)
+#define VL 8
+#define LOG_VL 3
+typedef __m256i vec;
+static inline vec vload(const void *p) { return _mm256_loadu_si256((const __m256i *)p); }
+static inline void vstore(void *p, vec v) { _mm256_storeu_si256((__m256i *)p, v); }
+static inline vec vset1(uint32_t x) { return _mm256_set1_epi32((int)x); }
+static inline vec vzero(void) { return _mm256_setzero_si256(); }
+static inline vec vadd32(vec a, vec b) { return _mm256_add_epi32(a, b); }
+static inline vec vsub32(vec a, vec b) { return _mm256_sub_epi32(a, b); }
+static inline vec vminu(vec a, vec b) { return _mm256_min_epu32(a, b); }
+static inline vec vmul64(vec a, vec b) { return _mm256_mul_epu32(a, b); }
+static inline vec vsub64(vec a, vec b) { return _mm256_sub_epi64(a, b); }
+static inline vec vsrl64_32(vec a) { return _mm256_srli_epi64(a, 32); }
+static inline vec vhdup(vec a) { return _mm256_castps_si256(_mm256_movehdup_ps(_mm256_castsi256_ps(a))); }
+static inline vec vblend_odd(vec even, vec odd) { return _mm256_blend_epi32(even, odd, 0xAA); }
+static inline vec vperm(vec x, vec idx) { return _mm256_permutevar8x32_epi32(x, idx); }
+static inline vec vselect(vec mask, vec a, vec b) { return _mm256_blendv_epi8(a, b, mask); }
+static inline vec vgather(const uint32_t *base, vec idx) { return _mm256_i32gather_epi32((const int *)base, idx, 4); }
+#else
+#error "oracle/fast needs AVX2 or AVX-512 (build with -march=native on an x86-64-v3 or newer host)"
+#endif
+
+static vec VP, VMU;
+static inline vec vaddm(vec a, vec b) {
+    vec s = vadd32(a, b);
+    return vminu(s, vsub32(s, VP));
+}
+static inline vec vsubm(vec a, vec b) {
+    vec d = vsub32(a, b);
+    return vminu(d, vadd32(d, VP));
+}
+/* Montgomery product of every lane, result in [0, p) */
+static inline vec vmm(vec a, vec b) {
+    vec ao = vhdup(a), bo = vhdup(b);
+    vec pe = vmul64(a, b), po = vmul64(ao, bo);
+    vec qe = vmul64(pe, VMU), qo = vmul64(po, VMU);
+    vec me = vmul64(qe, VP), mo = vmul64(qo, VP);
+    vec de = vsub64(pe, me), dod = vsub64(po, mo); /* multiples of 2^32: the quotient sits in the high half */
+    vec r = vblend_odd(vsrl64_32(de), dod);
+    return vminu(r, vadd32(r, VP));
+}
+static vec vload_tail(const uint32_t *p, size_t n_valid) { /* n_valid < VL lanes from p, zeros after */
+    uint32_t t[VL];
+    memset(t, 0, sizeof t);
+    memcpy(t, p, n_valid * 4);
+    return vload(t);
+}
+
+typedef struct {
+    vec c[4];
+} vext;
+static inline vext veaddm(vext a, vext b) {
+    vext r;
+    for (int k = 0; k < 4; k++) r.c[k] = vaddm(a.c[k], b.c[k]);
+    return r;
+}
+static inline vext vemul(vext a, vext b) {
+    vec t[7];
+    for (int k = 0; k < 7; k++) t[k] = vzero();
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) t[i + j] = vaddm(t[i + j], vmm(a.c[i], b.c[j]));
+    vext r;
+    vec w = vset1(W11);
+    for (int k = 0; k < 4; k++) r.c[k] = k < 3 ? vaddm(t[k], vmm(w, t[k + 4])) : t[k];
+    return r;
+}
+
+/* ------------------------------------------------------------------ Poseidon2, one state per lane */
+static uint32_t RCM[141], DIAGM[16];
+static inline void p2_external_v(vec s[16]) {
+    for (int b = 0; b < 16; b += 4) {
+        vec x0 = s[b], x1 = s[b + 1], x2 = s[b + 2], x3 = s[b + 3];
+        vec sum = vaddm(vaddm(x0, x1), vaddm(x2, x3));
+        vec d0 = vaddm(x0, x0), d1 = vaddm(x1, x1), d2 = vaddm(x2, x2), d3 = vaddm(x3, x3);
+        s[b] = vaddm(vaddm(sum, x0), d1);     /* 2x0 + 3x1 + x2 + x3 */
+        s[b + 1] = vaddm(vaddm(sum, x1), d2); /* x0 + 2x1 + 3x2 + x3 */
+        s[b + 2] = vaddm(vaddm(sum, x2), d3);
+        s[b + 3] = vaddm(vaddm(sum, x3), d0);
+    }
+    for (int k = 0; k < 4; k++) {
+        vec sm = vaddm(vaddm(s[k], s[4 + k]), vaddm(s[8 + k], s[12 + k]));
+        for (int b = 0; b < 16; b += 4) s[b + k] = vaddm(s[b + k], sm);
+    }
+}
+static inline vec sbox7_v(vec x) {
+    vec x2 = vmm(x, x), x3 = vmm(x2, x), x4 = vmm(x2, x2);
+    return vmm(x3, x4);
+}
+static void p2_permute_v(vec s[16]) {
+    p2_external_v(s);
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 16; i++) s[i] = sbox7_v(vaddm(s[i], vset1(RCM[r * 16 + i])));
+        p2_external_v(s);
+    }
+    for (int r = 0; r < 13; r++) {
+        s[0] = sbox7_v(vaddm(s[0], vset1(RCM[64 + r])));
+        vec sum = s[0];
+        for (int i = 1; i < 16; i++) sum = vaddm(sum, s[i]);
+        for (int i = 0; i < 16; i++) s[i] = vaddm(vmm(s[i], vset1(DIAGM[i])), sum);
+    }
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 16; i++) s[i] = sbox7_v(vaddm(s[i], vset1(RCM[77 + r * 16 + i])));
+        p2_external_v(s);
+    }
+}
+
+/* Montgomery column-major matrix */
+typedef struct {
+    const uint32_t *data;
+    size_t stride;
+    unsigned log_height;
+    size_t width;
+} fmat;
+
+/* digests[row][8] (Montgomery) = sponge over the concatenated rows of `cols` (nc column pointers of `rows` words) */
+static void hash_rows(const uint32_t *const *cols, size_t nc, size_t rows, uint32_t *dig) {
+    const size_t groups = (rows + VL - 1) / VL;
+#pragma omp parallel for schedule(static)
+    for (size_t g = 0; g < groups; g++) {
+        const size_t r = g * VL, valid = rows - r < VL ? rows - r : VL;
+        vec s[16];
+        for (int k = 0; k < 16; k++) s[k] = vzero();
+        for (size_t c = 0; c < nc; c += 8) {
+            const size_t n = nc - c < 8 ? nc - c : 8;
+            if (valid == VL)
+                for (size_t k = 0; k < n; k++) s[k] = vload(cols[c + k] + r);
+            else
+                for (size_t k = 0; k < n; k++) s[k] = vload_tail(cols[c + k] + r, valid);
+            p2_permute_v(s);
+        }
+        uint32_t t[8][VL];
+        for (int k = 0; k < 8; k++) vstore(t[k], s[k]);
+        for (size_t l = 0; l < valid; l++)
+            for (int k = 0; k < 8; k++) dig[(r + l) * 8 + k] = t[k][l];
+    }
+}
+/* out[i] = compress(L[i*sl .. +8], Rt[i*sr .. +8]) for i < cnt (TruncatedPermutation) */
+static void compress_many(const uint32_t *L, size_t sl, const uint32_t *Rt, size_t sr, uint32_t *out, size_t cnt) {
+    const size_t groups = (cnt + VL - 1) / VL;
+#pragma omp parallel for schedule(static) if (cnt > 4 * VL)
+    for (size_t g = 0; g < groups; g++) {
+        const size_t i0 = g * VL, valid = cnt - i0 < VL ? cnt - i0 : VL;
+        uint32_t il[VL], ir[VL];
+        for (size_t l = 0; l < VL; l++) {
+            size_t i = i0 + (l < valid ? l : valid - 1);
+            il[l] = (uint32_t)((i - i0) * sl), ir[l] = (uint32_t)((i - i0) * sr);
+        }
+        vec vil = vload(il), vir = vload(ir);
+        vec s[16];
+        for (int k = 0; k < 8; k++) {
+            s[k] = vgather(L + i0 * sl + k, vil);
+            s[8 + k] = vgather(Rt + i0 * sr + k, vir);
+        }
+        p2_permute_v(s);
+        uint32_t t[8][VL];
+        for (int k = 0; k < 8; k++) vstore(t[k], s[k]);
+        for (size_t l = 0; l < valid; l++)
+            for (int k = 0; k < 8; k++) out[(i0 + l) * 8 + k] = t[k][l];
+    }
+}
+
+typedef struct {
+    unsigned lh;
+    size_t n_mats;
+    fmat *mats;
+    uint32_t **layers; /* layers[l]: 8 * 2^(lh-l) Montgomery words */
+} ftree;
+
+static void group_hash(const fmat *mats, size_t n_mats, unsigned log_h, uint32_t *dig) {
+    size_t nc = 0;
+    for (size_t m = 0; m < n_mats; m++)
+        if (mats[m].log_height == log_h) nc += mats[m].width;
+    const uint32_t **cols = (const uint32_t **)malloc((nc + 1) * sizeof(uint32_t *));
+    size_t k = 0;
+    for (size_t m = 0; m < n_mats; m++)
+        if (mats[m].log_height == log_h)
+            for (size_t c = 0; c < mats[m].width; c++) cols[k++] = mats[m].data + c * mats[m].stride;
+    hash_rows(cols, nc, (size_t)1 << log_h, dig);
+    free(cols);
+}
+static ftree *tree_commit(const fmat *mats, size_t n_mats, uint32_t root_canon[8]) {
+    ftree *t = (ftree *)calloc(1, sizeof *t);
+    for (size_t m = 0; m < n_mats; m++)
+        if (mats[m].log_height > t->lh) t->lh = mats[m].log_height;
+    t->n_mats = n_mats;
+    t->mats = (fmat *)malloc(n_mats * sizeof(fmat));
+    memcpy(t->mats, mats, n_mats * sizeof(fmat));
+    t->layers = (uint32_t **)calloc(t->lh + 1, sizeof(uint32_t *));
+    t->layers[0] = (uint32_t *)malloc(((size_t)8 << t->lh) * 4);
+    group_hash(mats, n_mats, t->lh, t->layers[0]);
+    for (unsigned l = 1; l <= t->lh; l++) {
+        const size_t cnt = (size_t)1 << (t->lh - l);
+        t->layers[l] = (uint32_t *)malloc(cnt * 32);
+        compress_many(t->layers[l - 1], 16, t->layers[l - 1] + 8, 16, t->layers[l], cnt);
+        int inject = 0;
+        for (size_t m = 0; m < n_mats; m++)
+            if (mats[m].log_height == t->lh - l) inject = 1;
+        if (inject) {
+            uint32_t *h = (uint32_t *)malloc(cnt * 32);
+            group_hash(mats, n_mats, t->lh - l, h);
+            compress_many(t->layers[l], 8, h, 8, t->layers[l], cnt);
+            free(h);
+        }
+    }
+    for (int k = 0; k < 8; k++) root_canon[k] = from_m(t->layers[t->lh][k]);
+    return t;
+}
+/* canonical opening in oracle/merkle.c's format: rows of every matrix (caller order), then lh sibling digests */
+static size_t tree_open(const ftree *t, size_t index, uint32_t *out) {
+    size_t w = 0;
+    for (size_t m = 0; m < t->n_mats; m++) {
+        const fmat *M = &t->mats[m];
+        const size_t row = index >> (t->lh - M->log_height);
+        for (size_t c = 0; c < M->width; c++) out[w++] = from_m(M->data[c * M->stride + row]);
+    }
+    for (unsigned l = 0; l < t->lh; l++) {
+        const uint32_t *sib = t->layers[l] + 8 * ((index >> l) ^ 1);
+        for (int k = 0; k < 8; k++) out[w++] = from_m(sib[k]);
+    }
+    return w;
+}
+static void tree_free(ftree *t) {
+    if (!t) return;
+    for (unsigned l = 0; l <= t->lh; l++) free(t->layers[l]);
+    free(t->layers), free(t->mats), free(t);
+}
+
+/* ------------------------------------------------------------------ NTT (radix-2 DIF, natural in -> bit-reversed out) */
+#define MAX_LOG 27
+static uint32_t *TWF[MAX_LOG + 1], *TWI[MAX_LOG + 1]; /* TW?[log][j] = w_{2^log}^(+-j), j < 2^(log-1), Montgomery */
+static unsigned tw_ready = 0;
+static uint32_t TWV_F[LOG_VL][VL], TWV_I[LOG_VL][VL], PERMV[LOG_VL][VL], MASKV[LOG_VL][VL];
+static void ensure_twiddles(unsigned log_max) {
+    if (log_max <= tw_ready) return;
+    for (unsigned l = 1; l <= MAX_LOG; l++) free(TWF[l]), free(TWI[l]), TWF[l] = TWI[l] = NULL;
+    if (log_max < LOG_VL + 1) log_max = LOG_VL + 1;
+    for (int inv = 0; inv < 2; inv++) {
+        uint32_t **T = inv ? TWI : TWF;
+        const size_t half = (size_t)1 << (log_max - 1);
+        uint32_t g = two_adic_m(log_max);
+        if (inv) g = minv(g);
+        T[log_max] = (uint32_t *)malloc(half * 4);
+        const int nt = omp_get_max_threads();
+#pragma omp parallel for schedule(static)
+        for (int t = 0; t < nt; t++) {
+            size_t lo = half * t / nt, hi = half * (t + 1) / nt;
+            uint32_t w = mpow(g, lo);
+            for (size_t i = lo; i < hi; i++) T[log_max][i] = w, w = mm(w, g);
+        }
+        for (unsigned l = log_max - 1; l >= 1; l--) {
+            const size_t h = (size_t)1 << (l - 1);
+            T[l] = (uint32_t *)malloc((h > VL ? h : VL) * 4);
+            for (size_t j = 0; j < h; j++) T[l][j] = T[l + 1][2 * j];
+        }
+    }
+    /* in-register stages: sub-transform of size 2*hf inside one vector, hf = VL/2 .. 1 */
+    for (unsigned s = 0; s < LOG_VL; s++) {
+        const unsigned hf = VL >> (s + 1);
+        for (unsigned i = 0; i < VL; i++) {
+            PERMV[s][i] = i ^ hf;
+            MASKV[s][i] = (i & hf) ? 0xFFFFFFFFu : 0;
+            unsigned lg = 0;
+            while ((1u << lg) < 2 * hf) lg++;
+            TWV_F[s][i] = hf > 1 ? TWF[lg][i % hf] : R1;
+            TWV_I[s][i] = hf > 1 ? TWI[lg][i % hf] : R1;
+        }
+    }
+    tw_ready = log_max;
+}
+static inline vec dif_in_register(vec x, int inverse) {
+    for (unsigned s = 0; s < LOG_VL; s++) {
+        vec xs = vperm(x, vload(PERMV[s]));
+        vec sum = vaddm(x, xs), diff = vsubm(xs, x);
+        if (s + 1 < LOG_VL) diff = vmm(diff, vload(inverse ? TWV_I[s] : TWV_F[s]));
+        x = vselect(vload(MASKV[s]), sum, diff);
+    }
+    return x;
+}
+static void dif(uint32_t *a, unsigned log_n, int inverse) {
+    uint32_t *const *T = inverse ? TWI : TWF;
+    if (log_n < LOG_VL) { /* scalar: tiny transforms only */
+        for (unsigned s = log_n; s >= 1; s--) {
+            const size_t m = (size_t)1 << s, half = m >> 1;
+            for (size_t k = 0; k < ((size_t)1 << log_n); k += m)
+                for (size_t j = 0; j < half; j++) {
+                    uint32_t u = a[k + j], v = a[k + j + half];
+                    a[k + j] = madd(u, v);
+                    a[k + j + half] = mm(msub(u, v), T[s][j]);
+                }
+        }
+        return;
+    }
+    if (log_n == LOG_VL) {
+        vstore(a, dif_in_register(vload(a), inverse));
+        return;
+    }
+    if (log_n > 14) { /* one streaming stage, then the halves (each ends up cache resident) */
+        const size_t half = (size_t)1 << (log_n - 1);
+        const uint32_t *tw = T[log_n];
+        for (size_t j = 0; j < half; j += VL) {
+            vec u = vload(a + j), v = vload(a + j + half);
+            vstore(a + j, vaddm(u, v));
+            vstore(a + j + half, vmm(vsubm(u, v), vload(tw + j)));
+        }
+        dif(a, log_n - 1, inverse);
+        dif(a + half, log_n - 1, inverse);
+        return;
+    }
+    const size_t n = (size_t)1 << log_n;
+    for (unsigned s = log_n; s > LOG_VL; s--) {
+        const size_t m = (size_t)1 << s, half = m >> 1;
+        const uint32_t *tw = T[s];
+        for (size_t k = 0; k < n; k += m)
+            for (size_t j = 0; j < half; j += VL) {
+                vec u = vload(a + k + j), v = vload(a + k + j + half);
+                vstore(a + k + j, vaddm(u, v));
+                vstore(a + k + j + half, vmm(vsubm(u, v), vload(tw + j)));
+            }
+    }
+    for (size_t k = 0; k < n; k += VL) vstore(a + k, dif_in_register(vload(a + k), inverse));
+}
+/* coset LDE of `width` columns: evaluations over H (natural order; canonical if in_canon else Montgomery) -> evaluations over
+ * shift*K, bit-reversed rows, Montgomery.  shift_m is Montgomery. */
+static void lde_cols(const uint32_t *in, size_t in_stride, int in_canon, uint32_t *out, size_t out_stride, unsigned lh,
+                     unsigned added, size_t width, uint32_t shift_m) {
+    const size_t N = (size_t)1 << lh, M = N << added;
+    ensure_twiddles(lh + added);
+    const uint32_t ninv = minv(to_m((uint32_t)(N % P)));
+    uint32_t *sp = (uint32_t *)malloc(N * 4); /* ninv * shift^k */
+    {
+        const int nt = omp_get_max_threads();
+#pragma omp parallel for schedule(static)
+        for (int t = 0; t < nt; t++) {
+            size_t lo = N * t / nt, hi = N * (t + 1) / nt;
+            uint32_t w = mm(ninv, mpow(shift_m, lo));
+            for (size_t i = lo; i < hi; i++) sp[i] = w, w = mm(w, shift_m);
+        }
+    }
+    uint32_t *brv = NULL; /* bitrev table for the permutation between the transforms */
+    if (lh <= 24) {
+        brv = (uint32_t *)malloc(N * 4);
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < N; i++) brv[i] = (uint32_t)bitrev(i, lh);
+    }
+#pragma omp parallel
+    {
+        uint32_t *buf = (uint32_t *)xalloc((N < VL ? VL : N) * 4);
+#pragma omp for schedule(dynamic)
+        for (size_t c = 0; c < width; c++) {
+            const uint32_t *src = in + c * in_stride;
+            uint32_t *dst = out + c * out_stride;
+            if (in_canon) {
+                const vec r2 = vset1(R2);
+                size_t i = 0;
+                for (; i + VL <= N; i += VL) vstore(buf + i, vmm(vload(src + i), r2));
+                for (; i < N; i++) buf[i] = to_m(src[i]);
+            } else {
+                memcpy(buf, src, N * 4);
+            }
+            dif(buf, lh, 1); /* buf[p] = N * coefficient bitrev(p) */
+            if (brv)
+                for (size_t k = 0; k < N; k++) dst[k] = mm(buf[brv[k]], sp[k]);
+            else
+                for (size_t k = 0; k < N; k++) dst[k] = mm(buf[bitrev(k, lh)], sp[k]);
+            memset(dst + N, 0, (M - N) * 4);
+            dif(dst, lh + added, 0); /* dst[p] = evaluation bitrev(p): the committed layout */
+        }
+        free(buf);
+    }
+    free(sp), free(brv);
+}
+
+/* ------------------------------------------------------------------ AIR programs (the bytecode of oracle/stark.c) */
+enum { OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, OP_NEG };
+typedef struct {
+    uint32_t n_nodes, n_cons, n_pvs;
+    const uint32_t *nodes, *cons;
+} program;
+static int parse_program(const uint32_t *w, size_t len, size_t width, program *p) {
+    if (len < 4 || w[0] != AIR_MAGIC) return -1;
+    p->n_nodes = w[1], p->n_cons = w[2], p->n_pvs = w[3];
+    const size_t base_len = (size_t)4 + 3 * (size_t)p->n_nodes + p->n_cons;
+    if (base_len != len) return -1; /* preprocessed / interaction sections: not supported by the fast prover */
+    p->nodes = w + 4;
+    p->cons = w + 4 + 3 * (size_t)p->n_nodes;
+    for (uint32_t i = 0; i < p->n_nodes; i++) {
+        const uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
+        switch (op) {
+        case OP_VAR: if (a >= width || b > 1) return -1; break;
+        case OP_PUB: if (a >= p->n_pvs) return -1; break;
+        case OP_CONST: if (a >= P) return -1; break;
+        case OP_FIRST: case OP_LAST: case OP_TRANS: break;
+        case OP_ADD: case OP_SUB: case OP_MUL: if (a >= i || b >= i) return -1; break;
+        case OP_NEG: if (a >= i) return -1; break;
+        default: return -1;
+        }
+    }
+    for (uint32_t i = 0; i < p->n_cons; i++)
+        if (p->cons[i] >= p->n_nodes) return -1;
+    return 0;
+}
+
+typedef struct {
+    program prog;
+    unsigned lh, h;
+    size_t width, N, M;
+    uint32_t *nat;  /* Montgomery copy of the trace, natural order (for the openings) */
+    uint32_t *lde;  /* width columns x M */
+    uint32_t *qnat; /* nch x 4 columns x N: quotient chunks, natural order over s_j*H */
+    uint32_t *qlde; /* nch x 4 columns x M */
+} air_state;
+
+typedef struct {
+    const uint32_t *lde, *nat;
+    uint32_t nat_shift; /* Montgomery */
+    unsigned lh, h;
+    size_t width;
+    unsigned n_pts;
+} cmat;
+
+/* ------------------------------------------------------------------ proof-of-work over lanes x threads */
+static uint32_t grind(ora_challenger *ch, unsigned bits) {
+    uint32_t found = 0xFFFFFFFFu;
+    const uint32_t mask = (uint32_t)(((uint64_t)1 << bits) - 1);
+    if (bits) {
+        uint32_t st[16];
+        for (int i = 0; i < 16; i++) st[i] = to_m(ch->state[i]);
+        for (unsigned i = 0; i < ch->n_in; i++) st[i] = to_m(ch->in_buf[i]);
+        const unsigned slot = ch->n_in;
+        const int nt = omp_get_max_threads();
+        const uint32_t per_thread = 256, round = (uint32_t)nt * per_thread;
+        uint32_t lane_id[VL];
+        for (uint32_t l = 0; l < VL; l++) lane_id[l] = l;
+        for (uint64_t base = 0; base < P && found == 0xFFFFFFFFu; base += round) {
+#pragma omp parallel for schedule(static)
+            for (int t = 0; t < nt; t++) {
+                uint32_t best = 0xFFFFFFFFu;
+                for (uint32_t o = 0; o < per_thread && best == 0xFFFFFFFFu; o += VL) {
+                    const uint64_t w0 = base + (uint64_t)t * per_thread + o;
+                    if (w0 >= P) break;
+                    vec s[16];
+                    for (int i = 0; i < 16; i++) s[i] = vset1(st[i]);
+                    vec wv = vadd32(vset1((uint32_t)w0), vload(lane_id)); /* canonical candidates (w0 + lane < 2^32) */
+                    s[slot] = vmm(vminu(wv, vset1(P - 1)), vset1(R2));
+                    p2_permute_v(s);
+                    uint32_t o7[VL];
+                    vstore(o7, vmm(s[7], vset1(1))); /* canonical */
+                    for (uint32_t l = 0; l < VL; l++)
+                        if (w0 + l < P && (o7[l] & mask) == 0) {
+                            best = (uint32_t)(w0 + l);
+                            break;
+                        }
+                }
+#pragma omp critical
+                if (best < found) found = best;
+            }
+        }
+    } else {
+        found = 0;
+    }
+    if (!ora_ch_check_witness(ch, bits, found)) return 0xFFFFFFFFu;
+    return found;
+}
+
+/* ------------------------------------------------------------------ the prover */
+static int g_init = 0;
+static void init_once(void) {
+    if (g_init) return;
+    R1 = (uint32_t)(((uint64_t)1 << 32) % P);
+    R2 = (uint32_t)(((uint64_t)R1 * R1) % P);
+    VP = vset1(P), VMU = vset1(MU);
+    W11 = to_m(11);
+    const uint32_t *rc = ora_poseidon2_round_constants();
+    for (int i = 0; i < 141; i++) RCM[i] = to_m(rc[i]);
+    {
+        const uint32_t i2 = ora_inv(2);
+        const uint32_t i2_8 = ora_pow(i2, 8), i2_27 = ora_pow(i2, 27);
+        const uint32_t v[16] = {P - 2, 1, 2, i2, 3, 4, P - i2, P - 3, P - 4, i2_8, ora_pow(i2, 2), ora_pow(i2, 3), i2_27,
+                                P - i2_8, P - ora_pow(i2, 4), P - i2_27};
+        for (int i = 0; i < 16; i++) DIAGM[i] = to_m(v[i]);
+    }
+    const uint32_t z = ora_pow(11, (P - 1) / 4);
+    uint32_t zp = 1;
+    for (int i = 0; i < 4; i++) FROB[i] = to_m(zp), zp = ora_mul(zp, z);
+    g_init = 1;
+}
+
+static double now_s(void) { return omp_get_wtime(); }
+
+size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, size_t n_airs, uint32_t *out, size_t cap) {
+    init_once();
+    const int timing = getenv("FAST_ORACLE_TIMING") != NULL;
+    double t_last = now_s();
+#define STAGE(name)                                                      \
+    do {                                                                 \
+        if (timing) {                                                    \
+            double t_now = now_s();                                      \
+            fprintf(stderr, "  fast: %-22s %8.3f s\n", name, t_now - t_last); \
+            t_last = t_now;                                              \
+        }                                                                \
+    } while (0)
+    const unsigned b = prm->log_blowup, nch = 1u << b, lfp = prm->log_final_poly_len;
+    if (lfp > MAX_LOG_FINAL_POLY || n_airs == 0 || b == 0) return 0;
+    air_state *st = (air_state *)calloc(n_airs, sizeof(air_state));
+    unsigned hmax = 0;
+    for (size_t a = 0; a < n_airs; a++) {
+        if (airs[a].log_height > 27 || airs[a].log_height < lfp || airs[a].prep) return 0;
+        if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &st[a].prog)) return 0;
+        if (st[a].prog.n_pvs != airs[a].n_pvs) return 0;
+        st[a].lh = airs[a].log_height, st[a].h = st[a].lh + b, st[a].width = airs[a].width;
+        st[a].N = (size_t)1 << st[a].lh, st[a].M = st[a].N << b;
+        if (st[a].h > hmax) hmax = st[a].h;
+    }
+    ensure_twiddles(hmax);
+    const uint32_t gen = to_m(GEN);
+    ora_challenger ch;
+    ora_ch_init(&ch);
+    { /* preamble, as oracle/stark.c observe_preamble */
+        uint32_t hdr[7] = {PROTO_TAG, (uint32_t)n_airs, prm->log_blowup, prm->log_final_poly_len, prm->num_queries,
+                           prm->commit_pow_bits, prm->query_pow_bits};
+        ora_ch_observe(&ch, hdr, 7);
+        for (size_t a = 0; a < n_airs; a++) {
+            uint32_t dig[8], meta[3] = {airs[a].log_height, (uint32_t)airs[a].width, (uint32_t)airs[a].n_pvs};
+            ora_hash_slice(airs[a].program, airs[a].program_len, dig);
+            ora_ch_observe(&ch, meta, 3);
+            ora_ch_observe(&ch, dig, 8);
+            ora_ch_observe(&ch, airs[a].pvs, airs[a].n_pvs);
+        }
+    }
+
+    /* 1. main LDE + commit */
+    fmat *mm_ = (fmat *)calloc(n_airs, sizeof(fmat));
+    for (size_t a = 0; a < n_airs; a++) {
+        const size_t N = st[a].N, M = st[a].M, W = st[a].width;
+        st[a].nat = (uint32_t *)xalloc(N * W * 4);
+        st[a].lde = (uint32_t *)xalloc(M * W * 4);
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < N * W; i++) st[a].nat[i] = to_m(airs[a].trace[i]);
+        lde_cols(st[a].nat, N, 0, st[a].lde, M, st[a].lh, b, W, gen);
+        mm_[a] = (fmat){st[a].lde, M, st[a].h, W};
+    }
+    STAGE("main LDE");
+    uint32_t root_main[8], root_quot[8];
+    ftree *t_main = tree_commit(mm_, n_airs, root_main);
+    ora_ch_observe(&ch, root_main, 8);
+    STAGE("main commit");
+    uint32_t alpha_c[4];
+    ora_ch_sample_ext(&ch, alpha_c);
+    const ext alpha = ext_from_canon(alpha_c);
+
+    /* 2. quotient */
+    fmat *qm = (fmat *)calloc(n_airs * nch, sizeof(fmat));
+    int ok = 1;
+    for (size_t a = 0; a < n_airs; a++) {
+        const program *pg = &st[a].prog;
+        const unsigned lh = st[a].lh, h = st[a].h;
+        const size_t N = st[a].N, M = st[a].M;
+        ext *ap = (ext *)malloc((pg->n_cons + 1) * sizeof(ext));
+        {
+            ext cur = eone();
+            for (uint32_t i = pg->n_cons; i-- > 0;) ap[i] = cur, cur = emul(cur, alpha);
+        }
+        const uint32_t wM = two_adic_m(h), winv = minv(two_adic_m(lh));
+        /* x_r = g * wM^bitrev(r); 1/(x-1), 1/(x-winv) by chunked batch inversion */
+        uint32_t *xs = (uint32_t *)malloc(M * 4), *i1 = (uint32_t *)malloc(M * 4), *i2 = (uint32_t *)malloc(M * 4);
+        {
+            uint32_t pw[32];
+            pw[0] = wM;
+            for (unsigned k = 1; k < h; k++) pw[k] = mm(pw[k - 1], pw[k - 1]);
+#pragma omp parallel for schedule(static)
+            for (size_t r = 0; r < M; r++) {
+                uint32_t x = gen; /* exponent bitrev(r): bit k of r selects wM^(2^(h-1-k)) */
+                for (unsigned k = 0; k < h; k++)
+                    if ((r >> k) & 1) x = mm(x, pw[h - 1 - k]);
+                xs[r] = x, i1[r] = msub(x, R1), i2[r] = msub(x, winv);
+            }
+            const size_t CH = 4096, nchunk = (M + CH - 1) / CH;
+#pragma omp parallel
+            {
+                uint32_t *scr = (uint32_t *)malloc(CH * 4);
+#pragma omp for schedule(static)
+                for (size_t c = 0; c < nchunk; c++) {
+                    size_t lo = c * CH, n = M - lo < CH ? M - lo : CH;
+                    batch_inv(i1 + lo, n, scr);
+                    batch_inv(i2 + lo, n, scr);
+                }
+                free(scr);
+            }
+        }
+        /* x^N - 1 depends only on bitrev(r) mod nch = r >> lh: the coset chunk the row lies in */
+        uint32_t zh_tab[16], zhi_tab[16];
+        for (unsigned j = 0; j < nch; j++) {
+            zh_tab[j] = msub(mpow(xs[(size_t)j << lh], N), R1);
+            zhi_tab[j] = minv(zh_tab[j]);
+        }
+        uint32_t *q = (uint32_t *)malloc(M * 16); /* [r][4] */
+        uint32_t *cm_ = (uint32_t *)malloc((pg->n_nodes + 1) * 4);
+        for (uint32_t i = 0; i < pg->n_nodes; i++) {
+            const uint32_t op = pg->nodes[3 * i], av = pg->nodes[3 * i + 1];
+            cm_[i] = op == OP_CONST ? to_m(av) : op == OP_PUB ? to_m(airs[a].pvs[av]) : 0;
+        }
+        const size_t groups = (M + VL - 1) / VL;
+#pragma omp parallel
+        {
+            vec *vals = (vec *)xalloc((size_t)(pg->n_nodes + 1) * sizeof(vec));
+#pragma omp for schedule(static)
+            for (size_t g = 0; g < groups; g++) {
+                const size_t r0 = g * VL, valid = M - r0 < VL ? M - r0 : VL;
+                uint32_t rn[VL];
+                int contiguous = valid == VL;
+                for (size_t l = 0; l < VL; l++) {
+                    size_t r = r0 + (l < valid ? l : 0);
+                    rn[l] = (uint32_t)bitrev((bitrev(r, h) + nch) & (M - 1), h);
+                    if (rn[l] != rn[0] + l) contiguous = 0;
+                }
+                vec vx, vi1, vi2, vzh, vzhi;
+                {
+                    uint32_t tx[VL], t1[VL], t2[VL], tz[VL], tzi[VL];
+                    for (size_t l = 0; l < VL; l++) {
+                        size_t r = r0 + (l < valid ? l : 0);
+                        tx[l] = xs[r], t1[l] = i1[r], t2[l] = i2[r];
+                        tz[l] = zh_tab[r >> lh], tzi[l] = zhi_tab[r >> lh];
+                    }
+                    vx = vload(tx), vi1 = vload(t1), vi2 = vload(t2), vzh = vload(tz), vzhi = vload(tzi);
+                }
+                const vec is_trans = vsubm(vx, vset1(winv));
+                const vec is_first = vmm(vzh, vi1), is_last = vmm(vzh, vi2);
+                for (uint32_t i = 0; i < pg->n_nodes; i++) {
+                    const uint32_t op = pg->nodes[3 * i], x = pg->nodes[3 * i + 1], y = pg->nodes[3 * i + 2];
+                    switch (op) {
+                    case OP_VAR: {
+                        const uint32_t *col = st[a].lde + (size_t)x * M;
+                        if (!y) {
+                            vals[i] = valid == VL ? vload(col + r0) : vload_tail(col + r0, valid);
+                        } else if (contiguous) {
+                            vals[i] = vload(col + rn[0]);
+                        } else {
+                            uint32_t t[VL];
+                            for (size_t l = 0; l < VL; l++) t[l] = col[rn[l]];
+                            vals[i] = vload(t);
+                        }
+                    } break;
+                    case OP_PUB: case OP_CONST: vals[i] = vset1(cm_[i]); break;
+                    case OP_FIRST: vals[i] = is_first; break;
+                    case OP_LAST: vals[i] = is_last; break;
+                    case OP_TRANS: vals[i] = is_trans; break;
+                    case OP_ADD: vals[i] = vaddm(vals[x], vals[y]); break;
+                    case OP_SUB: vals[i] = vsubm(vals[x], vals[y]); break;
+                    case OP_MUL: vals[i] = vmm(vals[x], vals[y]); break;
+                    default: vals[i] = vsubm(vzero(), vals[x]); break;
+                    }
+                }
+                vec acc[4] = {vzero(), vzero(), vzero(), vzero()};
+                for (uint32_t k = 0; k < pg->n_cons; k++) {
+                    const vec v = vals[pg->cons[k]];
+                    for (int j = 0; j < 4; j++) acc[j] = vaddm(acc[j], vmm(v, vset1(ap[k].c[j])));
+                }
+                uint32_t t[4][VL];
+                for (int j = 0; j < 4; j++) vstore(t[j], vmm(acc[j], vzhi));
+                for (size_t l = 0; l < valid; l++)
+                    for (int j = 0; j < 4; j++) q[4 * (r0 + l) + j] = t[j][l];
+            }
+            free(vals);
+        }
+        free(xs), free(i1), free(i2), free(cm_), free(ap);
+        /* chunk j = rows [jN, (j+1)N) = evaluations over s_j*H (bit-reversed), s_j = g * wM^bitrev_b(j) */
+        st[a].qnat = (uint32_t *)xalloc((size_t)nch * 4 * N * 4);
+        st[a].qlde = (uint32_t *)xalloc((size_t)nch * 4 * M * 4);
+        for (unsigned j = 0; j < nch; j++) {
+            uint32_t *nat = st[a].qnat + (size_t)j * 4 * N;
+#pragma omp parallel for schedule(static)
+            for (size_t m = 0; m < N; m++) {
+                const size_t src = j * N + bitrev(m, lh);
+                for (int k = 0; k < 4; k++) nat[k * N + m] = q[4 * src + k];
+            }
+            const uint32_t sj = mm(gen, mpow(wM, bitrev(j, b)));
+            uint32_t *dst = st[a].qlde + (size_t)j * 4 * M;
+            lde_cols(nat, N, 0, dst, M, lh, b, 4, mm(gen, minv(sj)));
+            qm[a * nch + j] = (fmat){dst, M, h, 4};
+        }
+        free(q);
+    }
+    STAGE("quotient + chunk LDEs");
+    ftree *t_quot = tree_commit(qm, n_airs * nch, root_quot);
+    ora_ch_observe(&ch, root_quot, 8);
+    STAGE("quotient commit");
+    uint32_t zeta_c[4];
+    ora_ch_sample_ext(&ch, zeta_c);
+    const ext zeta = ext_from_canon(zeta_c);
+
+    /* committed matrices in opening order: main (all AIRs), quotient chunks */
+    const size_t n_cm = n_airs + n_airs * nch;
+    cmat *cm = (cmat *)calloc(n_cm, sizeof(cmat));
+    {
+        size_t k = 0;
+        for (size_t a = 0; a < n_airs; a++) cm[k++] = (cmat){st[a].lde, st[a].nat, R1, st[a].lh, st[a].h, st[a].width, 2};
+        for (size_t a = 0; a < n_airs; a++) {
+            const uint32_t wM = two_adic_m(st[a].h);
+            for (unsigned j = 0; j < nch; j++)
+                cm[k++] = (cmat){st[a].qlde + (size_t)j * 4 * st[a].M, st[a].qnat + (size_t)j * 4 * st[a].N,
+                                 mm(gen, mpow(wM, bitrev(j, b))), st[a].lh, st[a].h, 4, 1};
+        }
+    }
+
+    /* 3. openings: p(z) = (z^N - s^N)/(N s^N) * sum_i p_i * x_i/(z - x_i), x_i = s w^i; at z*w the weights rotate by one */
+    size_t n_open = 0;
+    for (size_t m = 0; m < n_cm; m++) n_open += cm[m].width * cm[m].n_pts;
+    ext *opened = (ext *)malloc(n_open * sizeof(ext));
+    {
+        size_t oi = 0;
+        for (size_t m = 0; m < n_cm;) {
+            /* all matrices with the same (lh, shift) share the weights */
+            size_t m2 = m;
+            while (m2 < n_cm && cm[m2].lh == cm[m].lh && cm[m2].nat_shift == cm[m].nat_shift && cm[m2].n_pts == cm[m].n_pts) m2++;
+            const unsigned lh = cm[m].lh;
+            const size_t N = (size_t)1 << lh;
+            const uint32_t s = cm[m].nat_shift, w = two_adic_m(lh);
+            uint32_t *pl[4];
+            for (int k = 0; k < 4; k++) pl[k] = (uint32_t *)xalloc((N + 1 + VL) * 4) + 1;
+            {
+                const size_t CH = 2048, nchunk = (N + CH - 1) / CH;
+#pragma omp parallel
+                {
+                    ext *d = (ext *)malloc(CH * sizeof(ext)), *scr = (ext *)malloc(CH * sizeof(ext));
+                    uint32_t *xv = (uint32_t *)malloc(CH * 4);
+#pragma omp for schedule(static)
+                    for (size_t c = 0; c < nchunk; c++) {
+                        const size_t lo = c * CH, n = N - lo < CH ? N - lo : CH;
+                        uint32_t x = mm(s, mpow(w, lo));
+                        for (size_t i = 0; i < n; i++) {
+                            xv[i] = x;
+                            d[i] = zeta;
+                            d[i].c[0] = msub(d[i].c[0], x);
+                            x = mm(x, w);
+                        }
+                        ebatch_inv(d, n, scr);
+                        for (size_t i = 0; i < n; i++)
+                            for (int k = 0; k < 4; k++) pl[k][lo + i] = mm(d[i].c[k], xv[i]);
+                    }
+                    free(d), free(scr), free(xv);
+                }
+                for (int k = 0; k < 4; k++) pl[k][-1] = pl[k][N - 1];
+            }
+            /* scale Z(z)/(N s^N) */
+            ext zn = epow(zeta, N);
+            const uint32_t sN = mpow(s, N);
+            zn.c[0] = msub(zn.c[0], sN);
+            const ext scale = escale(zn, minv(mm(to_m((uint32_t)(N % P)), sN)));
+            /* columns of the group, flattened */
+            size_t ncols = 0;
+            for (size_t k = m; k < m2; k++) ncols += cm[k].width;
+            const uint32_t **cols = (const uint32_t **)malloc(ncols * sizeof(uint32_t *));
+            size_t *dst0 = (size_t *)malloc(ncols * sizeof(size_t)), *dst1 = (size_t *)malloc(ncols * sizeof(size_t));
+            {
+                size_t c = 0, o = oi;
+                for (size_t k = m; k < m2; k++) {
+                    for (size_t j = 0; j < cm[k].width; j++) {
+                        cols[c] = cm[k].nat + j * N;
+                        dst0[c] = o + j;
+                        dst1[c] = o + cm[k].width + j;
+                        c++;
+                    }
+                    o += cm[k].width * cm[k].n_pts;
+                }
+                oi = o;
+            }
+            const unsigned n_pts = cm[m].n_pts;
+#pragma omp parallel for schedule(dynamic)
+            for (size_t c = 0; c < ncols; c++) {
+                const uint32_t *p = cols[c];
+                vec a0[4] = {vzero(), vzero(), vzero(), vzero()}, a1[4] = {vzero(), vzero(), vzero(), vzero()};
+                ext s0 = ezero(), s1 = ezero();
+                size_t i = 0;
+                for (; i + VL <= N; i += VL) {
+                    const vec v = vload(p + i);
+                    for (int k = 0; k < 4; k++) a0[k] = vaddm(a0[k], vmm(v, vload(pl[k] + i)));
+                    if (n_pts == 2)
+                        for (int k = 0; k < 4; k++) a1[k] = vaddm(a1[k], vmm(v, vload(pl[k] + i - 1)));
+                }
+                for (; i < N; i++)
+                    for (int k = 0; k < 4; k++) {
+                        s0.c[k] = madd(s0.c[k], mm(p[i], pl[k][i]));
+                        if (n_pts == 2) s1.c[k] = madd(s1.c[k], mm(p[i], pl[k][(ptrdiff_t)i - 1]));
+                    }
+                for (int k = 0; k < 4; k++) {
+                    uint32_t t[VL];
+                    vstore(t, a0[k]);
+                    for (size_t l = 0; l < VL; l++) s0.c[k] = madd(s0.c[k], t[l]);
+                    vstore(t, a1[k]);
+                    for (size_t l = 0; l < VL; l++) s1.c[k] = madd(s1.c[k], t[l]);
+                }
+                opened[dst0[c]] = emul(s0, scale);
+                if (n_pts == 2) opened[dst1[c]] = emul(s1, scale);
+            }
+            for (int k = 0; k < 4; k++) free(pl[k] - 1);
+            free(cols), free(dst0), free(dst1);
+            m = m2;
+        }
+    }
+    uint32_t *opened_c = (uint32_t *)malloc(n_open * 16);
+    for (size_t i = 0; i < n_open; i++) ext_to_canon(opened[i], opened_c + 4 * i);
+    ora_ch_observe(&ch, opened_c, 4 * n_open);
+    STAGE("openings");
+    uint32_t af_c[4];
+    ora_ch_sample_ext(&ch, af_c);
+    const ext alpha_f = ext_from_canon(af_c);
+
+    /* 4. reduced openings per LDE log-height: ro[r] = sum_pt (C_pt - sum_cols coef_pt[col] * cell[col][r]) / (z_pt - x_r) */
+    uint32_t **ro = (uint32_t **)calloc(hmax + 1, sizeof(uint32_t *)); /* [r][4] Montgomery */
+    for (unsigned h = 0; h <= hmax; h++) {
+        size_t ncols = 0;
+        for (size_t m = 0; m < n_cm; m++)
+            if (cm[m].h == h) ncols += cm[m].width;
+        if (!ncols) continue;
+        const size_t M = (size_t)1 << h;
+        const unsigned lh = h - b;
+        const uint32_t **cols = (const uint32_t **)malloc(ncols * sizeof(uint32_t *));
+        ext *coef0 = (ext *)malloc(ncols * sizeof(ext)), *coef1 = (ext *)malloc(ncols * sizeof(ext));
+        ext C0 = ezero(), C1 = ezero();
+        {
+            size_t c = 0, oi = 0, nr = 0;
+            ext apw = eone(); /* alpha_f^nr */
+            for (size_t m = 0; m < n_cm; m++) {
+                const size_t Wm = cm[m].width;
+                if (cm[m].h != h) {
+                    oi += Wm * cm[m].n_pts;
+                    continue;
+                }
+                for (unsigned pt = 0; pt < cm[m].n_pts; pt++) {
+                    for (size_t k = 0; k < Wm; k++) {
+                        if (pt == 0) {
+                            cols[c + k] = cm[m].lde + k * M;
+                            coef0[c + k] = apw;
+                            coef1[c + k] = ezero();
+                            C0 = eadd(C0, emul(apw, opened[oi + k]));
+                        } else {
+                            coef1[c + k] = apw;
+                            C1 = eadd(C1, emul(apw, opened[oi + k]));
+                        }
+                        apw = emul(apw, alpha_f);
+                    }
+                    oi += Wm, nr += Wm;
+                }
+                c += Wm;
+            }
+            (void)nr;
+        }
+        ro[h] = (uint32_t *)malloc(M * 16);
+        const uint32_t wM = two_adic_m(h);
+        const ext z0 = zeta, z1 = escale(zeta, two_adic_m(lh));
+        uint32_t pw[32];
+        pw[0] = wM;
+        for (unsigned k = 1; k < h; k++) pw[k] = mm(pw[k - 1], pw[k - 1]);
+        const size_t CH = 1024, nchunk = (M + CH - 1) / CH; /* CH is a multiple of VL */
+#pragma omp parallel
+        {
+            ext *d0 = (ext *)malloc(CH * sizeof(ext)), *d1 = (ext *)malloc(CH * sizeof(ext)), *scr = (ext *)malloc(CH * sizeof(ext));
+#pragma omp for schedule(static)
+            for (size_t cnk = 0; cnk < nchunk; cnk++) {
+                const size_t lo = cnk * CH, n = M - lo < CH ? M - lo : CH;
+                for (size_t i = 0; i < n; i++) {
+                    const size_t r = lo + i;
+                    uint32_t x = gen;
+                    for (unsigned k = 0; k < h; k++)
+                        if ((r >> k) & 1) x = mm(x, pw[h - 1 - k]);
+                    d0[i] = z0, d1[i] = z1;
+                    d0[i].c[0] = msub(d0[i].c[0], x);
+                    d1[i].c[0] = msub(d1[i].c[0], x);
+                }
+                ebatch_inv(d0, n, scr);
+                ebatch_inv(d1, n, scr);
+                for (size_t i0 = 0; i0 < n; i0 += VL) {
+                    const size_t valid = n - i0 < VL ? n - i0 : VL;
+                    vec t0[4] = {vzero(), vzero(), vzero(), vzero()}, t1[4] = {vzero(), vzero(), vzero(), vzero()};
+                    for (size_t c = 0; c < ncols; c++) {
+                        const vec v = valid == VL ? vload(cols[c] + lo + i0) : vload_tail(cols[c] + lo + i0, valid);
+                        for (int k = 0; k < 4; k++) t0[k] = vaddm(t0[k], vmm(v, vset1(coef0[c].c[k])));
+                        if (coef1[c].c[0] | coef1[c].c[1] | coef1[c].c[2] | coef1[c].c[3])
+                            for (int k = 0; k < 4; k++) t1[k] = vaddm(t1[k], vmm(v, vset1(coef1[c].c[k])));
+                    }
+                    uint32_t s0[4][VL], s1[4][VL];
+                    for (int k = 0; k < 4; k++) vstore(s0[k], t0[k]), vstore(s1[k], t1[k]);
+                    for (size_t l = 0; l < valid; l++) {
+                        ext e0, e1;
+                        for (int k = 0; k < 4; k++) e0.c[k] = s0[k][l], e1.c[k] = s1[k][l];
+                        const ext u = eadd(emul(esub(C0, e0), d0[i0 + l]), emul(esub(C1, e1), d1[i0 + l]));
+                        memcpy(ro[h] + 4 * (lo + i0 + l), u.c, 16);
+                    }
+                }
+            }
+            free(d0), free(d1), free(scr);
+        }
+        free(cols), free(coef0), free(coef1);
+    }
+    STAGE("reduced openings");
+
+    /* 5. FRI commit phase */
+    const unsigned n_layers = hmax - b - lfp;
+    ftree **ftrees = (ftree **)calloc(n_layers + 1, sizeof(ftree *));
+    uint32_t **flayers = (uint32_t **)calloc(n_layers + 1, sizeof(uint32_t *));
+    uint32_t **fleaves = (uint32_t **)calloc(n_layers + 1, sizeof(uint32_t *));
+    uint32_t(*froots)[8] = (uint32_t(*)[8])calloc(n_layers + 1, 32);
+    uint32_t *fpow = (uint32_t *)calloc(n_layers + 1, sizeof(uint32_t));
+    const uint32_t inv2 = minv(to_m(2));
+    flayers[0] = ro[hmax];
+    for (unsigned l = 0; l < n_layers; l++) {
+        const unsigned log_len = hmax - l;
+        const size_t half = (size_t)1 << (log_len - 1);
+        fleaves[l] = (uint32_t *)xalloc(8 * half * 4);
+#pragma omp parallel for schedule(static) if (half > 4096)
+        for (size_t i = 0; i < half; i++)
+            for (int k = 0; k < 8; k++) fleaves[l][k * half + i] = flayers[l][8 * i + k];
+        fmat lm = {fleaves[l], half, log_len - 1, 8};
+        ftrees[l] = tree_commit(&lm, 1, froots[l]);
+        ora_ch_observe(&ch, froots[l], 8);
+        fpow[l] = grind(&ch, prm->commit_pow_bits);
+        uint32_t beta_c[4];
+        ora_ch_sample_ext(&ch, beta_c);
+        const ext beta = ext_from_canon(beta_c);
+        flayers[l + 1] = (uint32_t *)malloc(half * 16);
+        const uint32_t ginv = minv(two_adic_m(log_len));
+        uint32_t pwi[32], pwf[32];
+        pwf[0] = two_adic_m(log_len), pwi[0] = ginv;
+        for (unsigned k = 1; k < log_len; k++) pwf[k] = mm(pwf[k - 1], pwf[k - 1]), pwi[k] = mm(pwi[k - 1], pwi[k - 1]);
+        const ext b2 = emul(beta, beta);
+        const uint32_t *rj = ro[log_len - 1];
+        const uint32_t *in = flayers[l];
+        uint32_t *o = flayers[l + 1];
+        const unsigned lo_bits = log_len - 1;
+#pragma omp parallel for schedule(static) if (half > 1024)
+        for (size_t i = 0; i < half; i++) {
+            uint32_t x = R1, xi = R1; /* x = g^bitrev(i), xi = 1/x */
+            for (unsigned k = 0; k < lo_bits; k++)
+                if ((i >> k) & 1) x = mm(x, pwf[lo_bits - 1 - k]), xi = mm(xi, pwi[lo_bits - 1 - k]);
+            const uint32_t c = msub(0, mm(xi, inv2)); /* 1/(-2x) */
+            ext e0, e1, bx = beta;
+            memcpy(e0.c, in + 8 * i, 16), memcpy(e1.c, in + 8 * i + 4, 16);
+            bx.c[0] = msub(bx.c[0], x);
+            ext r = eadd(e0, emul(bx, escale(esub(e1, e0), c)));
+            if (rj) {
+                ext t;
+                memcpy(t.c, rj + 4 * i, 16);
+                r = eadd(r, emul(b2, t));
+            }
+            memcpy(o + 4 * i, r.c, 16);
+        }
+    }
+    const size_t n_fin = (size_t)1 << lfp, n_last = (size_t)1 << (b + lfp);
+    uint32_t *fin = (uint32_t *)calloc(4 * n_fin, sizeof(uint32_t)); /* canonical */
+    {
+        uint32_t *last = (uint32_t *)malloc(n_last * 16);
+        for (size_t i = 0; i < 4 * n_last; i++) last[i] = from_m(flayers[n_layers][i]);
+        if (lfp == 0) {
+            for (size_t i = 1; i < n_last; i++)
+                if (memcmp(last, last + 4 * i, 16)) ok = 0;
+            memcpy(fin, last, 16);
+        } else {
+            uint32_t *mat = (uint32_t *)malloc(4 * n_last * sizeof(uint32_t));
+            for (size_t i = 0; i < n_last; i++)
+                for (int qd = 0; qd < 4; qd++) mat[(size_t)qd * n_last + i] = last[4 * bitrev(i, b + lfp) + qd];
+            ora_dft_batch(mat, b + lfp, 4, n_last, 1);
+            for (size_t j = 0; j < n_last; j++)
+                for (int qd = 0; qd < 4; qd++) {
+                    if (j < n_fin) fin[4 * j + qd] = mat[(size_t)qd * n_last + j];
+                    else if (mat[(size_t)qd * n_last + j]) ok = 0;
+                }
+            free(mat);
+        }
+        free(last);
+    }
+    ora_ch_observe(&ch, fin, 4 * n_fin);
+    const uint32_t qpow = grind(&ch, prm->query_pow_bits);
+    STAGE("FRI commit phase + PoW");
+
+    /* 6. assemble the proof (oracle/stark.c section 6) */
+    size_t w = 0;
+#define PUT(ptr, n)                                  \
+    do {                                             \
+        if (w + (n) > cap) { ok = 0; goto done; }    \
+        memcpy(out + w, (ptr), (size_t)(n) * 4);     \
+        w += (n);                                    \
+    } while (0)
+    {
+        uint32_t hdr[4] = {PROOF_MAGIC, (uint32_t)n_airs, hmax, n_layers};
+        PUT(hdr, 4);
+        PUT(root_main, 8);
+        PUT(root_quot, 8);
+        PUT(opened_c, 4 * n_open);
+        for (unsigned l = 0; l < n_layers; l++) {
+            PUT(froots[l], 8);
+            PUT(&fpow[l], 1);
+        }
+        PUT(fin, 4 * n_fin);
+        PUT(&qpow, 1);
+        size_t tmp_words = 8 * (hmax + 1) + 16;
+        for (size_t m = 0; m < n_cm; m++) tmp_words += cm[m].width;
+        uint32_t *tmp = (uint32_t *)malloc(tmp_words * sizeof(uint32_t));
+        for (unsigned qn = 0; qn < prm->num_queries; qn++) {
+            const size_t idx = ora_ch_sample_bits(&ch, hmax);
+            size_t n1 = tree_open(t_main, idx >> (hmax - t_main->lh), tmp);
+            PUT(tmp, n1);
+            n1 = tree_open(t_quot, idx >> (hmax - t_quot->lh), tmp);
+            PUT(tmp, n1);
+            for (unsigned l = 0; l < n_layers; l++) {
+                const size_t il = idx >> l;
+                uint32_t sib[4];
+                for (int k = 0; k < 4; k++) sib[k] = from_m(flayers[l][4 * (il ^ 1) + k]);
+                PUT(sib, 4);
+                n1 = tree_open(ftrees[l], il >> 1, tmp);
+                PUT(tmp + 8, n1 - 8);
+            }
+        }
+        free(tmp);
+    }
+done:
+    for (size_t a = 0; a < n_airs; a++) free(st[a].nat), free(st[a].lde), free(st[a].qnat), free(st[a].qlde);
+    for (unsigned l = 0; l < n_layers; l++) tree_free(ftrees[l]), free(fleaves[l]), free(flayers[l + 1]);
+    for (unsigned h = 0; h <= hmax; h++) free(ro[h]);
+    tree_free(t_main), tree_free(t_quot);
+    free(ftrees), free(flayers), free(fleaves), free(froots), free(fpow), free(ro), free(opened), free(opened_c);
+    free(mm_), free(qm), free(cm), free(st), free(fin);
+    STAGE("queries");
+    return ok ? w : 0;
+}
+
+/* ---- pieces exported for the unit checks of tests/test_fast_oracle_cpu.py (canonical in / out) ---- */
+int fast_vector_lanes(void) { return VL; }
+void fast_poseidon2_permute_many(uint32_t *states, size_t n) { /* [n][16] canonical */
+    init_once();
+    for (size_t i0 = 0; i0 < n; i0 += VL) {
+        vec s[16];
+        uint32_t t[16][VL];
+        memset(t, 0, sizeof t);
+        for (size_t l = 0; l < VL && i0 + l < n; l++)
+            for (int k = 0; k < 16; k++) t[k][l] = to_m(states[(i0 + l) * 16 + k]);
+        for (int k = 0; k < 16; k++) s[k] = vload(t[k]);
+        p2_permute_v(s);
+        for (int k = 0; k < 16; k++) vstore(t[k], s[k]);
+        for (size_t l = 0; l < VL && i0 + l < n; l++)
+            for (int k = 0; k < 16; k++) states[(i0 + l) * 16 + k] = from_m(t[k][l]);
+    }
+}
+void fast_coset_lde_batch(const uint32_t *in, size_t in_stride, uint32_t *out, size_t out_stride, unsigned log_n,
+                          unsigned added_bits, size_t width, uint32_t shift) {
+    init_once();
+    lde_cols(in, in_stride, 1, out, out_stride, log_n, added_bits, width, to_m(shift));
+    const size_t M = (size_t)1 << (log_n + added_bits);
+    for (size_t c = 0; c < width; c++)
+        for (size_t i = 0; i < M; i++) out[c * out_stride + i] = from_m(out[c * out_stride + i]);
+}
+void fast_mmcs_root(const ora_matrix *mats, size_t n_mats, uint32_t root[8]) {
+    init_once();
+    fmat *fm = (fmat *)calloc(n_mats, sizeof(fmat));
+    uint32_t **copies = (uint32_t **)calloc(n_mats, sizeof(uint32_t *));
+    for (size_t m = 0; m < n_mats; m++) {
+        const size_t H = (size_t)1 << mats[m].log_height;
+        copies[m] = (uint32_t *)malloc((H * mats[m].width + VL) * 4);
+        for (size_t c = 0; c < mats[m].width; c++)
+            for (size_t i = 0; i < H; i++) copies[m][c * H + i] = to_m(mats[m].data[c * mats[m].stride + i]);
+        fm[m] = (fmat){copies[m], H, mats[m].log_height, mats[m].width};
+    }
+    ftree *t = tree_commit(fm, n_mats, root);
+    tree_free(t);
+    for (size_t m = 0; m < n_mats; m++) free(copies[m]);
+    free(copies), free(fm);
+}

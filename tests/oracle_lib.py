@@ -288,3 +288,53 @@ def sumcheck_round(tables):
     out = np.zeros(4 * (len(tabs) + 1), dtype=np.uint32)
     lib().ora_sumcheck_round(arr, len(tabs), tabs[0].size // 8, p32(out))
     return out
+
+
+# ---- oracle/fast: the optimised CPU prover (same proofs; bench baseline + full-size checks) ----
+_FAST = None
+
+
+def fast_lib():
+    """Builds (with -march=native, on this machine) and loads oracle/fast/libfastoracle.so."""
+    global _FAST
+    if _FAST is None:
+        lib()  # builds liboracle.so, which the fast library links
+        d = os.path.join(_ORA_DIR, "fast")
+        so = os.path.join(d, "libfastoracle.so")
+        srcs = [os.path.join(d, "fast_stark.c"), os.path.join(d, "Makefile"), os.path.join(_ORA_DIR, "liboracle.so")]
+        # -march=native: a library built on another machine (it travels with the repository snapshot) may use
+        # instructions this host lacks, so the build is stamped with the host's CPU flags and redone when they differ
+        import hashlib
+
+        try:
+            with open("/proc/cpuinfo") as f:
+                flags = next((ln for ln in f if ln.startswith("flags")), "")
+        except OSError:
+            flags = ""
+        stamp, stamp_path = hashlib.sha256(flags.encode()).hexdigest(), so + ".host"
+        have = open(stamp_path).read().strip() if os.path.exists(stamp_path) else ""
+        if not os.path.exists(so) or have != stamp or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["make", "-C", d, "clean"], stdout=subprocess.DEVNULL)
+            subprocess.check_call(["make", "-C", d], stdout=subprocess.DEVNULL)
+            with open(stamp_path, "w") as f:
+                f.write(stamp)
+        l = C.CDLL(so)
+        u32p, sz = C.POINTER(C.c_uint32), C.c_size_t
+        l.fast_stark_prove.restype = sz
+        l.fast_stark_prove.argtypes = [C.POINTER(OraParams), C.POINTER(OraAir), sz, u32p, sz]
+        l.fast_vector_lanes.restype = C.c_int
+        l.fast_poseidon2_permute_many.argtypes = [u32p, sz]
+        l.fast_coset_lde_batch.argtypes = [u32p, sz, u32p, sz, C.c_uint, C.c_uint, sz, C.c_uint32]
+        l.fast_mmcs_root.argtypes = [C.POINTER(OraMatrix), sz, u32p]
+        _FAST = l
+    return _FAST
+
+
+def fast_stark_prove(params, airs, cap_words=1 << 24):
+    prm = OraParams(*params)
+    arr, keep = _air_array(airs)
+    out = np.zeros(cap_words, dtype=np.uint32)
+    n = fast_lib().fast_stark_prove(C.byref(prm), arr, len(airs), p32(out), out.size)
+    if n == 0:
+        raise RuntimeError("fast oracle prover failed (unsupported AIR set or unsatisfied constraints)")
+    return out[:n].copy()
