@@ -1219,6 +1219,10 @@ done:
 
 /* ---- pieces exported for the unit checks of tests/test_fast_oracle_cpu.py (canonical in / out) ---- */
 int fast_vector_lanes(void) { return VL; }
+void fast_warmup(unsigned log_max) { /* constants + twiddle tables up to 2^log_max (setup, not proving) */
+    init_once();
+    ensure_twiddles(log_max);
+}
 void fast_poseidon2_permute_many(uint32_t *states, size_t n) { /* [n][16] canonical */
     init_once();
     for (size_t i0 = 0; i0 < n; i0 += VL) {

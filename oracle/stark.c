@@ -533,6 +533,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         st[a].qlde = (uint32_t *)malloc((size_t)nch * 4 * M * sizeof(uint32_t));
         for (unsigned j = 0; j < nch; j++) {
             uint32_t *nat = (uint32_t *)malloc(4 * N * sizeof(uint32_t));
+#pragma omp parallel for schedule(static)
             for (size_t m = 0; m < N; m++)
                 for (int k = 0; k < 4; k++) nat[k * N + m] = q[4 * (j * N + bitrev(m, lh)) + k];
             uint32_t sj = ora_mul(GEN, ora_pow(wM, bitrev(j, b)));
@@ -660,6 +661,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         const unsigned log_len = hmax - l;
         const size_t half = (size_t)1 << (log_len - 1);
         fleaves[l] = (uint32_t *)malloc(8 * half * sizeof(uint32_t));
+#pragma omp parallel for schedule(static) if (half > 4096)
         for (size_t i = 0; i < half; i++)
             for (int k = 0; k < 8; k++) fleaves[l][k * half + i] = flayers[l][8 * i + k];
         ora_matrix lm = {fleaves[l], half, log_len - 1, 8};
@@ -672,6 +674,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         if (ro[log_len - 1]) {
             ext_t b2;
             ora_ext_mul(betas[l], betas[l], b2);
+#pragma omp parallel for schedule(static) if (half > 4096)
             for (size_t i = 0; i < half; i++) {
                 ext_t t;
                 ora_ext_mul(b2, ro[log_len - 1][i], t);

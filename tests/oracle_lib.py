@@ -323,6 +323,7 @@ def fast_lib():
         l.fast_stark_prove.restype = sz
         l.fast_stark_prove.argtypes = [C.POINTER(OraParams), C.POINTER(OraAir), sz, u32p, sz]
         l.fast_vector_lanes.restype = C.c_int
+        l.fast_warmup.argtypes = [C.c_uint]
         l.fast_poseidon2_permute_many.argtypes = [u32p, sz]
         l.fast_coset_lde_batch.argtypes = [u32p, sz, u32p, sz, C.c_uint, C.c_uint, sz, C.c_uint32]
         l.fast_mmcs_root.argtypes = [C.POINTER(OraMatrix), sz, u32p]
