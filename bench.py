@@ -118,14 +118,19 @@ def cpu_baseline(args, params, airs, host_traces, pvs, gpu_proof):
     inst = [dict(a, trace=t, pvs=np.ascontiguousarray(pv, dtype=np.uint32)) for a, t, pv in zip(airs, host_traces, pvs)]
     cap = len(gpu_proof) // 4 + 16
     ora.fast_lib().fast_warmup(max(a["log_height"] for a in airs) + params[0])  # twiddle tables: setup, like the GPU's keygen
+    # first proof = warm-up (its workspace arena is mapped and page-faulted once, like the GPU key's workspace at keygen);
+    # the second, steady-state proof is the one timed -- the GPU side is timed after warm-up too
+    t0 = time.time()
+    ora.fast_stark_prove(params, inst, cap_words=cap)
+    dt_first = time.time() - t0
     t0 = time.time()
     proof = ora.fast_stark_prove(params, inst, cap_words=cap)
     dt = time.time() - t0
     same = proof.tobytes() == bytes(gpu_proof)
     return {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": cores, "kind": "port",
-            "seconds_per_proof": round(dt, 3), "proof_bytes_equal_gpu": bool(same),
+            "seconds_per_proof": round(dt, 3), "seconds_first_proof": round(dt_first, 3), "proof_bytes_equal_gpu": bool(same),
             "sample": "2^%d rows, measured: oracle/fast (optimised C restatement: %d-lane %s Montgomery, OpenMP x%d threads) "
-                      "proved the full bench instance of pipeline 0 in %.2f s; proof bytes %s the GPU's; not the reference "
+                      "proved the full bench instance of pipeline 0 in %.2f s (second proof; workspace warm); proof bytes %s the GPU's; not the reference "
                       "Rust binary (unbuildable here)"
                       % (args.log_rows, lanes, "AVX-512" if lanes == 16 else "AVX2", cores, dt,
                          "EQUAL" if same else "DIFFER FROM")}
@@ -411,7 +416,8 @@ def main():
                 p0 = pipes[0]
                 p0["pk"].prove_async(p0["traces"], p0["pvs"])
                 gpu_proof0 = p0["pk"].fetch()
-                host_traces = [p0["ctx"].download(t).reshape(a["width"], -1) for t, a in zip(p0["traces"], airs)]
+                with torch.cuda.stream(streams[0]):  # the context issues on this stream: clone and conversion must share it
+                    host_traces = [p0["ctx"].download(t).reshape(a["width"], -1) for t, a in zip(p0["traces"], airs)]
                 out["cpu_baseline"] = cpu_baseline(args, params, airs, host_traces, p0["pvs"], gpu_proof0)
                 out["config"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
             except Exception as e:  # the baseline is a reported number, never a gate

@@ -41,7 +41,41 @@
 #define PROTO_TAG 0x5A4B4831u
 #define MAX_LOG_FINAL_POLY 8
 
+#include <sys/mman.h>
 static void *xalloc(size_t bytes) { return aligned_alloc(64, (bytes + 63) / 64 * 64 + 64); }
+
+/* Workspace arena: the big buffers of a proof (LDEs, trees, weights) come from a few huge mappings that persist across
+ * proofs -- like the GPU prover's per-key workspace -- so that only the first proof pays the page faults (with 256
+ * threads they cost more than the arithmetic) and the pages can be transparent huge pages (the column-major passes
+ * touch hundreds of columns per row block: 4 KiB pages thrash the TLB). */
+#define ARENA_SLABS 64
+static struct {
+    char *base[ARENA_SLABS];
+    size_t size[ARENA_SLABS], used[ARENA_SLABS];
+    int n;
+} g_arena;
+static void arena_reset(void) {
+    for (int i = 0; i < g_arena.n; i++) g_arena.used[i] = 0;
+}
+static void *arena_alloc(size_t bytes) {
+    bytes = (bytes + 4095) / 4096 * 4096 + 4096;
+    for (int i = 0; i < g_arena.n; i++)
+        if (g_arena.size[i] - g_arena.used[i] >= bytes) {
+            void *p = g_arena.base[i] + g_arena.used[i];
+            g_arena.used[i] += bytes;
+            return p;
+        }
+    if (g_arena.n == ARENA_SLABS) return NULL;
+    size_t sz = bytes > ((size_t)1 << 30) ? bytes : ((size_t)1 << 30);
+    sz = (sz + (1u << 21) - 1) >> 21 << 21;
+    char *p = (char *)mmap(NULL, sz + (1u << 21), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return NULL;
+    p = (char *)(((uintptr_t)p + (1u << 21) - 1) >> 21 << 21);
+    madvise(p, sz, MADV_HUGEPAGE);
+    const int i = g_arena.n++;
+    g_arena.base[i] = p, g_arena.size[i] = sz, g_arena.used[i] = bytes;
+    return p;
+}
 
 /* ------------------------------------------------------------------ scalar Montgomery */
 static uint32_t R1, R2; /* 2^32 mod p, 2^64 mod p */
@@ -306,26 +340,39 @@ typedef struct {
     size_t width;
 } fmat;
 
-/* digests[row][8] (Montgomery) = sponge over the concatenated rows of `cols` (nc column pointers of `rows` words) */
+/* digests[row][8] (Montgomery) = sponge over the concatenated rows of `cols` (nc column pointers of `rows` words).
+ * A thread keeps the sponge states of HB row groups and walks the columns 8 at a time: each column is then read as one
+ * contiguous run of HB * VL words (prefetcher- and TLB-friendly) instead of one vector per column per row group. */
+#define HB 16
 static void hash_rows(const uint32_t *const *cols, size_t nc, size_t rows, uint32_t *dig) {
-    const size_t groups = (rows + VL - 1) / VL;
+    const size_t groups = (rows + VL - 1) / VL, blocks = (groups + HB - 1) / HB;
 #pragma omp parallel for schedule(static)
-    for (size_t g = 0; g < groups; g++) {
-        const size_t r = g * VL, valid = rows - r < VL ? rows - r : VL;
-        vec s[16];
-        for (int k = 0; k < 16; k++) s[k] = vzero();
+    for (size_t blk = 0; blk < blocks; blk++) {
+        vec st[HB][16];
+        const size_t g0 = blk * HB, ng = groups - g0 < HB ? groups - g0 : HB;
+        for (size_t g = 0; g < ng; g++)
+            for (int k = 0; k < 16; k++) st[g][k] = vzero();
         for (size_t c = 0; c < nc; c += 8) {
             const size_t n = nc - c < 8 ? nc - c : 8;
-            if (valid == VL)
-                for (size_t k = 0; k < n; k++) s[k] = vload(cols[c + k] + r);
-            else
-                for (size_t k = 0; k < n; k++) s[k] = vload_tail(cols[c + k] + r, valid);
-            p2_permute_v(s);
+            for (size_t g = 0; g < ng; g++) {
+                const size_t r = (g0 + g) * VL, valid = rows - r < VL ? rows - r : VL;
+                vec s[16];
+                for (int k = 0; k < 16; k++) s[k] = st[g][k];
+                if (valid == VL)
+                    for (size_t k = 0; k < n; k++) s[k] = vload(cols[c + k] + r);
+                else
+                    for (size_t k = 0; k < n; k++) s[k] = vload_tail(cols[c + k] + r, valid);
+                p2_permute_v(s);
+                for (int k = 0; k < 16; k++) st[g][k] = s[k];
+            }
         }
-        uint32_t t[8][VL];
-        for (int k = 0; k < 8; k++) vstore(t[k], s[k]);
-        for (size_t l = 0; l < valid; l++)
-            for (int k = 0; k < 8; k++) dig[(r + l) * 8 + k] = t[k][l];
+        for (size_t g = 0; g < ng; g++) {
+            const size_t r = (g0 + g) * VL, valid = rows - r < VL ? rows - r : VL;
+            uint32_t t[8][VL];
+            for (int k = 0; k < 8; k++) vstore(t[k], st[g][k]);
+            for (size_t l = 0; l < valid; l++)
+                for (int k = 0; k < 8; k++) dig[(r + l) * 8 + k] = t[k][l];
+        }
     }
 }
 /* out[i] = compress(L[i*sl .. +8], Rt[i*sr .. +8]) for i < cnt (TruncatedPermutation) */
@@ -380,17 +427,17 @@ static ftree *tree_commit(const fmat *mats, size_t n_mats, uint32_t root_canon[8
     t->mats = (fmat *)malloc(n_mats * sizeof(fmat));
     memcpy(t->mats, mats, n_mats * sizeof(fmat));
     t->layers = (uint32_t **)calloc(t->lh + 1, sizeof(uint32_t *));
-    t->layers[0] = (uint32_t *)malloc(((size_t)8 << t->lh) * 4);
+    t->layers[0] = (uint32_t *)arena_alloc(((size_t)8 << t->lh) * 4);
     group_hash(mats, n_mats, t->lh, t->layers[0]);
     for (unsigned l = 1; l <= t->lh; l++) {
         const size_t cnt = (size_t)1 << (t->lh - l);
-        t->layers[l] = (uint32_t *)malloc(cnt * 32);
+        t->layers[l] = (uint32_t *)arena_alloc(cnt * 32);
         compress_many(t->layers[l - 1], 16, t->layers[l - 1] + 8, 16, t->layers[l], cnt);
         int inject = 0;
         for (size_t m = 0; m < n_mats; m++)
             if (mats[m].log_height == t->lh - l) inject = 1;
         if (inject) {
-            uint32_t *h = (uint32_t *)malloc(cnt * 32);
+            uint32_t *h = (uint32_t *)xalloc(cnt * 32);
             group_hash(mats, n_mats, t->lh - l, h);
             compress_many(t->layers[l], 8, h, 8, t->layers[l], cnt);
             free(h);
@@ -415,8 +462,7 @@ static size_t tree_open(const ftree *t, size_t index, uint32_t *out) {
 }
 static void tree_free(ftree *t) {
     if (!t) return;
-    for (unsigned l = 0; l <= t->lh; l++) free(t->layers[l]);
-    free(t->layers), free(t->mats), free(t);
+    free(t->layers), free(t->mats), free(t); /* the digest layers live in the arena */
 }
 
 /* ------------------------------------------------------------------ NTT (radix-2 DIF, natural in -> bit-reversed out) */
@@ -513,6 +559,29 @@ static void dif(uint32_t *a, unsigned log_n, int inverse) {
     }
     for (size_t k = 0; k < n; k += VL) vstore(a + k, dif_in_register(vload(a + k), inverse));
 }
+/* the same transform with all threads on ONE column (narrow batches: the quotient chunks are 4 columns wide): the top
+ * stages stream over the whole array in parallel, then the 2^k independent sub-transforms run one per thread */
+static void dif_par(uint32_t *a, unsigned log_n, int inverse) {
+    uint32_t *const *T = inverse ? TWI : TWF;
+    const int nt = omp_get_max_threads();
+    unsigned k = 0;
+    while (((size_t)1 << k) < 2 * (size_t)nt && log_n - k > 14) k++;
+    for (unsigned s = 0; s < k; s++) {
+        const size_t half = (size_t)1 << (log_n - s - 1), per = half / VL, total = per << s;
+        const uint32_t *tw = T[log_n - s];
+#pragma omp parallel for schedule(static)
+        for (size_t t = 0; t < total; t++) {
+            const size_t blk = t / per, j = (t % per) * VL;
+            uint32_t *p = a + (blk << (log_n - s)) + j;
+            vec u = vload(p), v = vload(p + half);
+            vstore(p, vaddm(u, v));
+            vstore(p + half, vmm(vsubm(u, v), vload(tw + j)));
+        }
+    }
+#pragma omp parallel for schedule(dynamic)
+    for (size_t blk = 0; blk < ((size_t)1 << k); blk++) dif(a + (blk << (log_n - k)), log_n - k, inverse);
+}
+
 /* coset LDE of `width` columns: evaluations over H (natural order; canonical if in_canon else Montgomery) -> evaluations over
  * shift*K, bit-reversed rows, Montgomery.  shift_m is Montgomery. */
 static void lde_cols(const uint32_t *in, size_t in_stride, int in_canon, uint32_t *out, size_t out_stride, unsigned lh,
@@ -535,6 +604,21 @@ static void lde_cols(const uint32_t *in, size_t in_stride, int in_canon, uint32_
         brv = (uint32_t *)malloc(N * 4);
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < N; i++) brv[i] = (uint32_t)bitrev(i, lh);
+    }
+    if (lh >= 16 && 2 * width <= (size_t)omp_get_max_threads() && brv) {
+        uint32_t *buf = (uint32_t *)arena_alloc(N * 4);
+        for (size_t c = 0; c < width; c++) {
+            const uint32_t *src = in + c * in_stride;
+            uint32_t *dst = out + c * out_stride;
+#pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < N; i++) buf[i] = in_canon ? to_m(src[i]) : src[i];
+            dif_par(buf, lh, 1);
+#pragma omp parallel for schedule(static)
+            for (size_t k = 0; k < M; k++) dst[k] = k < N ? mm(buf[brv[k]], sp[k]) : 0;
+            dif_par(dst, lh + added, 0);
+        }
+        free(sp), free(brv);
+        return;
     }
 #pragma omp parallel
     {
@@ -683,6 +767,7 @@ static double now_s(void) { return omp_get_wtime(); }
 
 size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, size_t n_airs, uint32_t *out, size_t cap) {
     init_once();
+    arena_reset();
     const int timing = getenv("FAST_ORACLE_TIMING") != NULL;
     double t_last = now_s();
 #define STAGE(name)                                                      \
@@ -726,8 +811,8 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
     fmat *mm_ = (fmat *)calloc(n_airs, sizeof(fmat));
     for (size_t a = 0; a < n_airs; a++) {
         const size_t N = st[a].N, M = st[a].M, W = st[a].width;
-        st[a].nat = (uint32_t *)xalloc(N * W * 4);
-        st[a].lde = (uint32_t *)xalloc(M * W * 4);
+        st[a].nat = (uint32_t *)arena_alloc(N * W * 4);
+        st[a].lde = (uint32_t *)arena_alloc(M * W * 4);
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < N * W; i++) st[a].nat[i] = to_m(airs[a].trace[i]);
         lde_cols(st[a].nat, N, 0, st[a].lde, M, st[a].lh, b, W, gen);
@@ -756,7 +841,7 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
         }
         const uint32_t wM = two_adic_m(h), winv = minv(two_adic_m(lh));
         /* x_r = g * wM^bitrev(r); 1/(x-1), 1/(x-winv) by chunked batch inversion */
-        uint32_t *xs = (uint32_t *)malloc(M * 4), *i1 = (uint32_t *)malloc(M * 4), *i2 = (uint32_t *)malloc(M * 4);
+        uint32_t *xs = (uint32_t *)arena_alloc(M * 4), *i1 = (uint32_t *)arena_alloc(M * 4), *i2 = (uint32_t *)arena_alloc(M * 4);
         {
             uint32_t pw[32];
             pw[0] = wM;
@@ -787,7 +872,7 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
             zh_tab[j] = msub(mpow(xs[(size_t)j << lh], N), R1);
             zhi_tab[j] = minv(zh_tab[j]);
         }
-        uint32_t *q = (uint32_t *)malloc(M * 16); /* [r][4] */
+        uint32_t *q = (uint32_t *)arena_alloc(M * 16); /* [r][4] */
         uint32_t *cm_ = (uint32_t *)malloc((pg->n_nodes + 1) * 4);
         for (uint32_t i = 0; i < pg->n_nodes; i++) {
             const uint32_t op = pg->nodes[3 * i], av = pg->nodes[3 * i + 1];
@@ -856,10 +941,10 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
             }
             free(vals);
         }
-        free(xs), free(i1), free(i2), free(cm_), free(ap);
+        free(cm_), free(ap);
         /* chunk j = rows [jN, (j+1)N) = evaluations over s_j*H (bit-reversed), s_j = g * wM^bitrev_b(j) */
-        st[a].qnat = (uint32_t *)xalloc((size_t)nch * 4 * N * 4);
-        st[a].qlde = (uint32_t *)xalloc((size_t)nch * 4 * M * 4);
+        st[a].qnat = (uint32_t *)arena_alloc((size_t)nch * 4 * N * 4);
+        st[a].qlde = (uint32_t *)arena_alloc((size_t)nch * 4 * M * 4);
         for (unsigned j = 0; j < nch; j++) {
             uint32_t *nat = st[a].qnat + (size_t)j * 4 * N;
 #pragma omp parallel for schedule(static)
@@ -872,7 +957,6 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
             lde_cols(nat, N, 0, dst, M, lh, b, 4, mm(gen, minv(sj)));
             qm[a * nch + j] = (fmat){dst, M, h, 4};
         }
-        free(q);
     }
     STAGE("quotient + chunk LDEs");
     ftree *t_quot = tree_commit(qm, n_airs * nch, root_quot);
@@ -910,7 +994,7 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
             const size_t N = (size_t)1 << lh;
             const uint32_t s = cm[m].nat_shift, w = two_adic_m(lh);
             uint32_t *pl[4];
-            for (int k = 0; k < 4; k++) pl[k] = (uint32_t *)xalloc((N + 1 + VL) * 4) + 1;
+            for (int k = 0; k < 4; k++) pl[k] = (uint32_t *)arena_alloc((N + 1 + VL) * 4 + 64) + 16;
             {
                 const size_t CH = 2048, nchunk = (N + CH - 1) / CH;
 #pragma omp parallel
@@ -986,7 +1070,6 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
                 opened[dst0[c]] = emul(s0, scale);
                 if (n_pts == 2) opened[dst1[c]] = emul(s1, scale);
             }
-            for (int k = 0; k < 4; k++) free(pl[k] - 1);
             free(cols), free(dst0), free(dst1);
             m = m2;
         }
@@ -1039,7 +1122,7 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
             }
             (void)nr;
         }
-        ro[h] = (uint32_t *)malloc(M * 16);
+        ro[h] = (uint32_t *)arena_alloc(M * 16);
         const uint32_t wM = two_adic_m(h);
         const ext z0 = zeta, z1 = escale(zeta, two_adic_m(lh));
         uint32_t pw[32];
@@ -1049,6 +1132,7 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
 #pragma omp parallel
         {
             ext *d0 = (ext *)malloc(CH * sizeof(ext)), *d1 = (ext *)malloc(CH * sizeof(ext)), *scr = (ext *)malloc(CH * sizeof(ext));
+            vec(*acc0)[4] = (vec(*)[4])xalloc((CH / VL + 1) * 4 * sizeof(vec)), (*acc1)[4] = (vec(*)[4])xalloc((CH / VL + 1) * 4 * sizeof(vec));
 #pragma omp for schedule(static)
             for (size_t cnk = 0; cnk < nchunk; cnk++) {
                 const size_t lo = cnk * CH, n = M - lo < CH ? M - lo : CH;
@@ -1063,17 +1147,27 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
                 }
                 ebatch_inv(d0, n, scr);
                 ebatch_inv(d1, n, scr);
-                for (size_t i0 = 0; i0 < n; i0 += VL) {
-                    const size_t valid = n - i0 < VL ? n - i0 : VL;
-                    vec t0[4] = {vzero(), vzero(), vzero(), vzero()}, t1[4] = {vzero(), vzero(), vzero(), vzero()};
-                    for (size_t c = 0; c < ncols; c++) {
-                        const vec v = valid == VL ? vload(cols[c] + lo + i0) : vload_tail(cols[c] + lo + i0, valid);
-                        for (int k = 0; k < 4; k++) t0[k] = vaddm(t0[k], vmm(v, vset1(coef0[c].c[k])));
-                        if (coef1[c].c[0] | coef1[c].c[1] | coef1[c].c[2] | coef1[c].c[3])
-                            for (int k = 0; k < 4; k++) t1[k] = vaddm(t1[k], vmm(v, vset1(coef1[c].c[k])));
+                /* column-outer: every column is read as one contiguous run of the chunk's rows */
+                const size_t ngr = (n + VL - 1) / VL;
+                for (size_t g = 0; g < ngr; g++)
+                    for (int k = 0; k < 4; k++) acc0[g][k] = vzero(), acc1[g][k] = vzero();
+                for (size_t c = 0; c < ncols; c++) {
+                    const uint32_t *colp = cols[c] + lo;
+                    vec k0[4], k1[4];
+                    for (int k = 0; k < 4; k++) k0[k] = vset1(coef0[c].c[k]), k1[k] = vset1(coef1[c].c[k]);
+                    const int two = (coef1[c].c[0] | coef1[c].c[1] | coef1[c].c[2] | coef1[c].c[3]) != 0;
+                    for (size_t g = 0; g < ngr; g++) {
+                        const size_t i0 = g * VL, valid = n - i0 < VL ? n - i0 : VL;
+                        const vec v = valid == VL ? vload(colp + i0) : vload_tail(colp + i0, valid);
+                        for (int k = 0; k < 4; k++) acc0[g][k] = vaddm(acc0[g][k], vmm(v, k0[k]));
+                        if (two)
+                            for (int k = 0; k < 4; k++) acc1[g][k] = vaddm(acc1[g][k], vmm(v, k1[k]));
                     }
+                }
+                for (size_t g = 0; g < ngr; g++) {
+                    const size_t i0 = g * VL, valid = n - i0 < VL ? n - i0 : VL;
                     uint32_t s0[4][VL], s1[4][VL];
-                    for (int k = 0; k < 4; k++) vstore(s0[k], t0[k]), vstore(s1[k], t1[k]);
+                    for (int k = 0; k < 4; k++) vstore(s0[k], acc0[g][k]), vstore(s1[k], acc1[g][k]);
                     for (size_t l = 0; l < valid; l++) {
                         ext e0, e1;
                         for (int k = 0; k < 4; k++) e0.c[k] = s0[k][l], e1.c[k] = s1[k][l];
@@ -1082,7 +1176,7 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
                     }
                 }
             }
-            free(d0), free(d1), free(scr);
+            free(d0), free(d1), free(scr), free(acc0), free(acc1);
         }
         free(cols), free(coef0), free(coef1);
     }
@@ -1100,7 +1194,7 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
     for (unsigned l = 0; l < n_layers; l++) {
         const unsigned log_len = hmax - l;
         const size_t half = (size_t)1 << (log_len - 1);
-        fleaves[l] = (uint32_t *)xalloc(8 * half * 4);
+        fleaves[l] = (uint32_t *)arena_alloc(8 * half * 4);
 #pragma omp parallel for schedule(static) if (half > 4096)
         for (size_t i = 0; i < half; i++)
             for (int k = 0; k < 8; k++) fleaves[l][k * half + i] = flayers[l][8 * i + k];
@@ -1111,7 +1205,7 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
         uint32_t beta_c[4];
         ora_ch_sample_ext(&ch, beta_c);
         const ext beta = ext_from_canon(beta_c);
-        flayers[l + 1] = (uint32_t *)malloc(half * 16);
+        flayers[l + 1] = (uint32_t *)arena_alloc(half * 16);
         const uint32_t ginv = minv(two_adic_m(log_len));
         uint32_t pwi[32], pwf[32];
         pwf[0] = two_adic_m(log_len), pwi[0] = ginv;
@@ -1207,9 +1301,7 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
         free(tmp);
     }
 done:
-    for (size_t a = 0; a < n_airs; a++) free(st[a].nat), free(st[a].lde), free(st[a].qnat), free(st[a].qlde);
-    for (unsigned l = 0; l < n_layers; l++) tree_free(ftrees[l]), free(fleaves[l]), free(flayers[l + 1]);
-    for (unsigned h = 0; h <= hmax; h++) free(ro[h]);
+    for (unsigned l = 0; l < n_layers; l++) tree_free(ftrees[l]);
     tree_free(t_main), tree_free(t_quot);
     free(ftrees), free(flayers), free(fleaves), free(froots), free(fpow), free(ro), free(opened), free(opened_c);
     free(mm_), free(qm), free(cm), free(st), free(fin);
@@ -1248,6 +1340,7 @@ void fast_coset_lde_batch(const uint32_t *in, size_t in_stride, uint32_t *out, s
 }
 void fast_mmcs_root(const ora_matrix *mats, size_t n_mats, uint32_t root[8]) {
     init_once();
+    arena_reset();
     fmat *fm = (fmat *)calloc(n_mats, sizeof(fmat));
     uint32_t **copies = (uint32_t **)calloc(n_mats, sizeof(uint32_t *));
     for (size_t m = 0; m < n_mats; m++) {
