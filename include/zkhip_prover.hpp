@@ -15,6 +15,9 @@
 //     carried in JSON as base64(bincode(Vec<u8>))   crates/types/src/proof.rs:52-67, utils.rs:20-39
 //   StarkProofStat{total_cycles, execution_time_mills, proving_time_mills}   proof.rs:41-48
 //   Error::{Io, Setup, Keygen, GenProof, VerifyProof, Custom}               crates/prover/src/error.rs:5-46
+//   BatchProver (below Prover): what replaces the reference's SEQUENTIAL loop over the chunks of a batch
+//     (crates/integration/src/testers/batch.rs:97-107): a queue of tasks over `inflight` Provers per GPU on every
+//     listed GPU, each Prover still proving one task at a time (mod.rs:287 `&mut self`).
 //
 // What differs, because guest execution and trace generation are outside this path (SURVEY.md 8(f)
 // f3): `path_app_exe` is an AIR-set file (the constraint bytecode of every chip) instead
@@ -23,6 +26,7 @@
 // are read from it (crates/circuits/chunk-circuit/openvm.toml:1-6).
 #pragma once
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstring>
@@ -31,6 +35,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "zkhip.h"
@@ -323,16 +328,27 @@ public:
         return gen_proof_stark(task);
     }
 
-    // mod.rs:342-413: "execute" (here: decode + upload the witness), prove, encode, self-verify
-    StarkProof gen_proof_stark(const ProvingTask& task) {
+    // A task whose traces are resident on this Prover's device (the form trace generation on the device produces,
+    // SURVEY.md 8(f) f3; also what `upload_witness` returns for a host-side ProvingTask)
+    struct DeviceWitness {
+        std::string identifier;
+        std::vector<unsigned> heights;
+        std::vector<std::vector<uint32_t>> pvs;
+        std::vector<void*> d_traces;  // column-major Montgomery traces, one per chip
+        uint64_t total_cells = 0;
+        uint64_t upload_mills = 0;
+    };
+
+    // "execute" half of mod.rs:342-413: decode the witness, build keys for its shape, copy the traces to the device
+    DeviceWitness upload_witness(const ProvingTask& task) {
         using clk = std::chrono::steady_clock;
         auto t0 = clk::now();
         if (task.serialized_witness.size() != airs_.size())
             throw Error(Error::GenProof, "task " + task.identifier + ": witness count does not match the app's chips");
-        std::vector<unsigned> heights;
-        std::vector<std::vector<uint32_t>> pvs(airs_.size());
+        DeviceWitness dw;
+        dw.identifier = task.identifier;
+        dw.pvs.resize(airs_.size());
         std::vector<const uint32_t*> trace_host(airs_.size());
-        uint64_t total_cells = 0;
         for (size_t a = 0; a < airs_.size(); a++) {
             const auto& w = task.serialized_witness[a];
             if (w.size() < 8 || w.size() % 4) throw Error(Error::GenProof, "malformed witness");
@@ -343,51 +359,70 @@ public:
                 throw Error(Error::GenProof, "witness of chip " + std::to_string(a) + " has the wrong shape");
             if (airs_[a].has_prep && lh != airs_[a].prep_log_height)
                 throw Error(Error::GenProof, "witness of chip " + std::to_string(a) + " does not have the height of its preprocessed trace");
-            heights.push_back(lh);
-            pvs[a].assign(words + 2, words + 2 + n_pvs);
+            dw.heights.push_back(lh);
+            dw.pvs[a].assign(words + 2, words + 2 + n_pvs);
             trace_host[a] = words + 2 + n_pvs;
-            total_cells += (uint64_t)airs_[a].width << lh;
+            dw.total_cells += (uint64_t)airs_[a].width << lh;
         }
-        ensure_keys(heights);
-        // H2D of the witness (the analogue of execution handing traces to the engine)
-        std::vector<void*> d_traces(airs_.size(), nullptr);
-        auto free_traces = [&]() {
-            for (void* d : d_traces)
-                if (d) zkhip_free(ctx_, d);
-        };
+        ensure_keys(dw.heights);
+        dw.d_traces.assign(airs_.size(), nullptr);
         try {
             for (size_t a = 0; a < airs_.size(); a++) {
-                size_t n = airs_[a].width << heights[a];
-                check(zkhip_malloc(ctx_, n * 4, &d_traces[a]), Error::GenProof);
-                check(zkhip_h2d(ctx_, d_traces[a], trace_host[a], n * 4), Error::GenProof);
-                check(zkhip_to_monty(ctx_, (uint32_t*)d_traces[a], n), Error::GenProof);
+                size_t n = airs_[a].width << dw.heights[a];
+                check(zkhip_malloc(ctx_, n * 4, &dw.d_traces[a]), Error::GenProof);
+                check(zkhip_h2d(ctx_, dw.d_traces[a], trace_host[a], n * 4), Error::GenProof);
+                check(zkhip_to_monty(ctx_, (uint32_t*)dw.d_traces[a], n), Error::GenProof);
             }
             check(zkhip_sync(ctx_), Error::GenProof);
-            auto t1 = clk::now();
-            StarkProof sp;
-            sp.proof.resize(zkhip_proof_size(pk_));
-            std::vector<const uint32_t*> dt(airs_.size()), pv(airs_.size());
-            for (size_t a = 0; a < airs_.size(); a++) dt[a] = (const uint32_t*)d_traces[a], pv[a] = pvs[a].data();
-            size_t len = 0;
-            check(zkhip_prove(ctx_, pk_, dt.data(), pv.data(), sp.proof.data(), sp.proof.size(), &len), Error::GenProof);
-            sp.proof.resize(len);
-            auto t2 = clk::now();
-            // user public values, chip by chip (canonical LE words)
-            for (auto& p : pvs) {
-                const uint8_t* b = reinterpret_cast<const uint8_t*>(p.data());
-                sp.user_pvs_proof.insert(sp.user_pvs_proof.end(), b, b + p.size() * 4);
-            }
-            // baseline: what a verifier needs besides the app: the per-chip trace heights
-            for (unsigned h : heights) sp.baseline.push_back((uint8_t)h);
-            sp.stat.total_cycles = total_cells;
-            sp.stat.execution_time_mills = std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count();
-            sp.stat.proving_time_mills = std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
-            free_traces();
-            // mandatory self-check, as mod.rs:407-411
-            verify_stark_proof(sp);
+        } catch (...) {
+            free_witness(dw);
+            throw;
+        }
+        dw.upload_mills = std::chrono::duration_cast<std::chrono::milliseconds>(clk::now() - t0).count();
+        return dw;
+    }
+    void free_witness(DeviceWitness& dw) {
+        for (void*& d : dw.d_traces)
+            if (d) zkhip_free(ctx_, d), d = nullptr;
+    }
+
+    // "prove" half: sdk.prove -> encode -> mandatory self-verify (mod.rs:355-411) from device-resident traces
+    StarkProof prove_resident(const DeviceWitness& dw, bool self_verify = true) {
+        using clk = std::chrono::steady_clock;
+        if (dw.d_traces.size() != airs_.size()) throw Error(Error::GenProof, "device witness does not match the app's chips");
+        ensure_keys(dw.heights);
+        auto t1 = clk::now();
+        StarkProof sp;
+        sp.proof.resize(zkhip_proof_size(pk_));
+        std::vector<const uint32_t*> dt(airs_.size()), pv(airs_.size());
+        for (size_t a = 0; a < airs_.size(); a++) dt[a] = (const uint32_t*)dw.d_traces[a], pv[a] = dw.pvs[a].data();
+        size_t len = 0;
+        check(zkhip_prove(ctx_, pk_, dt.data(), pv.data(), sp.proof.data(), sp.proof.size(), &len), Error::GenProof);
+        sp.proof.resize(len);
+        auto t2 = clk::now();
+        // user public values, chip by chip (canonical LE words)
+        for (const auto& p : dw.pvs) {
+            const uint8_t* b = reinterpret_cast<const uint8_t*>(p.data());
+            sp.user_pvs_proof.insert(sp.user_pvs_proof.end(), b, b + p.size() * 4);
+        }
+        // baseline: what a verifier needs besides the app: the per-chip trace heights
+        for (unsigned h : dw.heights) sp.baseline.push_back((uint8_t)h);
+        sp.stat.total_cycles = dw.total_cells;
+        sp.stat.execution_time_mills = dw.upload_mills;
+        sp.stat.proving_time_mills = std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
+        if (self_verify) verify_stark_proof(sp);  // mandatory self-check, as mod.rs:407-411
+        return sp;
+    }
+
+    // mod.rs:342-413: "execute" (here: decode + upload the witness), prove, encode, self-verify
+    StarkProof gen_proof_stark(const ProvingTask& task) {
+        DeviceWitness dw = upload_witness(task);
+        try {
+            StarkProof sp = prove_resident(dw);
+            free_witness(dw);
             return sp;
         } catch (...) {
-            free_traces();
+            free_witness(dw);
             throw;
         }
     }
@@ -466,6 +501,109 @@ private:
                 airs_[a].prep_commit.assign(c, c + 8);
             }
         }
+    }
+};
+
+// Task queue over several Provers: `inflight` per GPU on every GPU of `devices`.  Each lane is an ordinary Prover (own
+// zkhip context = own HIP stream, own key + workspace) driven by its own host thread, so that the memory-bound stages
+// of one proof overlap the VALU-bound hashing of another on the same GPU (bench.py measures the same arrangement) and
+// independent segments / chunks spread over the GPUs of a node.  The reference proves the chunks of a
+// batch one after another on one device (crates/integration/src/testers/batch.rs:97-107); results keep task order.
+class BatchProver {
+public:
+    struct Stats {
+        size_t proofs = 0;
+        double seconds = 0, proofs_per_second = 0;
+        std::vector<double> lane_seconds;
+    };
+
+    static BatchProver setup(const ProverConfig& cfg, unsigned inflight_per_gpu = 3, std::vector<int> devices = {0}) {
+        if (inflight_per_gpu == 0 || devices.empty()) throw Error(Error::Setup, "BatchProver needs at least one lane");
+        BatchProver b;
+        for (int dev : devices)
+            for (unsigned k = 0; k < inflight_per_gpu; k++)
+                b.lanes_.push_back(Prover::setup(cfg, ("lane-" + std::to_string(dev) + "." + std::to_string(k)).c_str(), dev));
+        return b;
+    }
+    size_t lanes() const { return lanes_.size(); }
+    void reset() {
+        for (auto& l : lanes_) l.reset();
+    }
+
+    // proves every task (witnesses are uploaded by the lane that takes the task); result i belongs to task i
+    std::vector<StarkProof> prove_many(const std::vector<ProvingTask>& tasks, Stats* stats = nullptr) {
+        std::vector<StarkProof> out(tasks.size());
+        run(tasks.size(), stats, [&](Prover& p, size_t i) { out[i] = p.gen_proof_universal(tasks[i], false); });
+        return out;
+    }
+
+    // throughput form (what bench.py times): the witness is uploaded ONCE per lane -- traces resident in HBM, as they are
+    // when trace generation runs on the device -- and proven `n` times in total; every proof is self-verified
+    Stats prove_repeated(const ProvingTask& task, size_t n, std::vector<uint8_t>* last_proof = nullptr) {
+        std::vector<Prover::DeviceWitness> dws(lanes_.size());
+        parallel_lanes([&](size_t l) { dws[l] = lanes_[l].upload_witness(task); });
+        for (size_t l = 0; l < lanes_.size(); l++) (void)lanes_[l].prove_resident(dws[l]);  // first proof: scratch growth, code objects
+        Stats st;
+        std::vector<StarkProof> last(lanes_.size());
+        std::atomic<size_t> next{0};
+        std::vector<size_t> lane_of(n);
+        run_indexed(n, &st, [&](Prover& p, size_t lane, size_t i) {
+            last[lane] = p.prove_resident(dws[lane]);
+            lane_of[i] = lane;
+        });
+        for (size_t l = 0; l < lanes_.size(); l++) lanes_[l].free_witness(dws[l]);
+        if (last_proof && n) *last_proof = last[lane_of[n - 1]].proof;
+        return st;
+    }
+
+private:
+    BatchProver() = default;
+    std::vector<Prover> lanes_;
+
+    template <class F>
+    void parallel_lanes(F&& f) {
+        std::vector<std::thread> th;
+        std::vector<std::string> errs(lanes_.size());
+        std::vector<int> kinds(lanes_.size(), -1);
+        for (size_t l = 0; l < lanes_.size(); l++)
+            th.emplace_back([&, l]() {
+                try {
+                    f(l);
+                } catch (const Error& e) {
+                    errs[l] = e.what(), kinds[l] = (int)e.kind;
+                } catch (const std::exception& e) {
+                    errs[l] = e.what(), kinds[l] = (int)Error::Custom;
+                }
+            });
+        for (auto& t : th) t.join();
+        for (size_t l = 0; l < lanes_.size(); l++)
+            if (kinds[l] >= 0) throw Error((Error::Kind)kinds[l], errs[l]);
+    }
+    template <class F>
+    void run_indexed(size_t n, Stats* stats, F&& f) {
+        using clk = std::chrono::steady_clock;
+        std::atomic<size_t> next{0};
+        std::vector<double> lane_s(lanes_.size(), 0.0);
+        auto t0 = clk::now();
+        parallel_lanes([&](size_t l) {
+            auto tl = clk::now();
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= n) break;
+                f(lanes_[l], l, i);
+            }
+            lane_s[l] = std::chrono::duration<double>(clk::now() - tl).count();
+        });
+        if (stats) {
+            stats->proofs = n;
+            stats->seconds = std::chrono::duration<double>(clk::now() - t0).count();
+            stats->proofs_per_second = stats->seconds > 0 ? n / stats->seconds : 0;
+            stats->lane_seconds = lane_s;
+        }
+    }
+    template <class F>
+    void run(size_t n, Stats* stats, F&& f) {
+        run_indexed(n, stats, [&](Prover& p, size_t, size_t i) { f(p, i); });
     }
 };
 

@@ -100,3 +100,38 @@ def test_app_with_preprocessed_table_and_buses(ora, tmp_path):
     exe_bad, _ = pm.write_app(str(tmp_path / "bad"), bad, PARAMS)
     r = pm.run_cli("prove", exe_bad, cfg, task, str(tmp_path / "o2.json"))
     assert r.returncode == 1 and "does not match the app's commitment" in r.stderr
+
+
+def test_batch_prover_queue_and_api_throughput(ora, tmp_path):
+    """BatchProver: five tasks queued over 2 Provers in flight on one GPU (the replacement of the reference's sequential
+    chunk loop, crates/integration/src/testers/batch.rs:97-107) -- every proof byte-equal to the oracle's, results in task
+    order; and the throughput form (witness resident, n proofs, self-verified) reports through the same API."""
+    tasks, all_airs = [], []
+    for i in range(5):
+        sa = air.SyntheticAir(width=20, n_free=7, n_bool=3, n_boundary=2, seed=9)
+        tr, pv = sa.gen_trace(8, seed=30 + i)
+        ftr, fpv = air.fibonacci_trace(6, a0=i)
+        airs = [dict(program=sa.program(), log_height=8, width=20, n_pvs=len(pv), trace=tr, pvs=pv),
+                dict(program=air.fibonacci_air().program(), log_height=6, width=2, n_pvs=3, trace=ftr, pvs=fpv)]
+        all_airs.append(airs)
+        d = tmp_path / ("t%d" % i)
+        d.mkdir()
+        tasks.append(pm.write_task(str(d), airs, identifier="seg-%d" % i))
+    exe, cfg = pm.write_app(str(tmp_path), all_airs[0], PARAMS)
+    r = pm.run_cli("prove-batch", exe, cfg, str(tmp_path), "2", *tasks)
+    assert r.returncode == 0 and "batch: 5 proofs on 2 lanes" in r.stdout, r.stderr
+    for i, airs in enumerate(all_airs):
+        js = json.loads((tmp_path / ("seg-%d.json" % i)).read_text())
+        assert pm.un_b64_bincode(js["proof"]) == ora.stark_prove(PARAMS, airs).tobytes()
+    r = pm.run_cli("bench-many", exe, cfg, tasks[0], "12", "3")
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["proofs"] == 12 and out["inflight_per_gpu"] == 3 and out["proofs_per_s"] > 0 and out["self_verified"] is True
+    # a bad witness in the queue surfaces as the reference's error kind (VerifyProof from the self-check)
+    bad = [dict(a) for a in all_airs[1]]
+    bad[0]["trace"] = bad[0]["trace"].copy()
+    bad[0]["trace"][12, 3] = (int(bad[0]["trace"][12, 3]) + 1) % air.P
+    (tmp_path / "bad").mkdir()
+    tbad = pm.write_task(str(tmp_path / "bad"), bad, identifier="seg-bad")
+    r = pm.run_cli("prove-batch", exe, cfg, str(tmp_path), "2", tasks[0], tbad, tasks[2])
+    assert r.returncode == 1 and "kind 4" in r.stderr

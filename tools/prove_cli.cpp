@@ -17,6 +17,27 @@ static std::vector<uint8_t> slurp(const std::string& path) {
     return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 }
 
+static ProvingTask read_task(const std::string& path) {
+    auto tb = slurp(path);
+    ProvingTask task;
+    size_t p = 0;
+    auto rd32 = [&]() { uint32_t v; if (p + 4 > tb.size()) throw Error(Error::Io, "short task"); memcpy(&v, &tb[p], 4); p += 4; return v; };
+    auto rd64 = [&]() { uint64_t v; if (p + 8 > tb.size()) throw Error(Error::Io, "short task"); memcpy(&v, &tb[p], 8); p += 8; return v; };
+    uint32_t idl = rd32();
+    if (p + idl > tb.size()) throw Error(Error::Io, "short task");
+    task.identifier.assign((const char*)&tb[p], idl);
+    p += idl;
+    uint32_t n = rd32();
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t len = rd64();
+        if (p + len > tb.size()) throw Error(Error::Io, "short task");
+        task.serialized_witness.emplace_back(tb.begin() + p, tb.begin() + p + len);
+        p += len;
+    }
+    task.fork_name = "hip";
+    return task;
+}
+
 int main(int argc, char** argv) {
     try {
         if (argc >= 5 && std::string(argv[1]) == "verify") {
@@ -80,7 +101,41 @@ int main(int argc, char** argv) {
             }
             return 0;
         }
-        std::fprintf(stderr, "usage: prove_cli prove|prove-many|verify ...\n");
+        if (argc >= 7 && std::string(argv[1]) == "prove-batch") {
+            // prove-batch <app> <cfg> <out_dir> <inflight> <task.bin>... : BatchProver::prove_many -- the tasks are queued
+            // over `inflight` Provers on GPU 0 (the replacement of the sequential chunk loop, batch.rs:97-107)
+            BatchProver bp = BatchProver::setup(ProverConfig{argv[2], argv[3]}, (unsigned)std::stoul(argv[5]));
+            std::vector<ProvingTask> tasks;
+            for (int i = 6; i < argc; i++) tasks.push_back(read_task(argv[i]));
+            BatchProver::Stats st;
+            std::vector<StarkProof> proofs = bp.prove_many(tasks, &st);
+            for (size_t i = 0; i < tasks.size(); i++) {
+                std::ofstream(std::string(argv[4]) + "/" + tasks[i].identifier + ".json") << proofs[i].to_json();
+                std::printf("proved %s: proving %llu ms\n", tasks[i].identifier.c_str(), (unsigned long long)proofs[i].stat.proving_time_mills);
+            }
+            std::printf("batch: %zu proofs on %zu lanes in %.3f s\n", st.proofs, bp.lanes(), st.seconds);
+            return 0;
+        }
+        if (argc >= 7 && std::string(argv[1]) == "bench-many") {
+            // bench-many <app> <cfg> <task.bin> <n_proofs> <inflight> [n_gpus]: BatchProver::prove_repeated -- the witness is
+            // uploaded once per lane (traces resident in HBM), then n proofs are proven and self-verified through the
+            // Prover API with `inflight` Provers per GPU; prints one JSON line.  The API-level twin of bench.py.
+            const size_t n = std::stoul(argv[5]);
+            const unsigned inflight = (unsigned)std::stoul(argv[6]);
+            const int n_gpus = argc >= 8 ? std::stoi(argv[7]) : 1;
+            std::vector<int> devs;
+            for (int d = 0; d < n_gpus; d++) devs.push_back(d);
+            BatchProver bp = BatchProver::setup(ProverConfig{argv[2], argv[3]}, inflight, devs);
+            ProvingTask task = read_task(argv[4]);
+            std::vector<uint8_t> last;
+            BatchProver::Stats st = bp.prove_repeated(task, n, &last);
+            std::printf("{\"api\": \"BatchProver::prove_repeated\", \"proofs\": %zu, \"seconds\": %.4f, \"proofs_per_s\": %.4f, "
+                        "\"ms_per_proof\": %.2f, \"inflight_per_gpu\": %u, \"n_gpus\": %d, \"proof_bytes\": %zu, \"self_verified\": true}\n",
+                        st.proofs, st.seconds, st.proofs_per_second, st.proofs ? 1e3 * st.seconds / st.proofs : 0.0, inflight, n_gpus,
+                        last.size());
+            return 0;
+        }
+        std::fprintf(stderr, "usage: prove_cli prove|prove-many|prove-batch|bench-many|verify ...\n");
         return 2;
     } catch (const Error& e) {
         std::fprintf(stderr, "error(kind %d): %s\n", (int)e.kind, e.what());
