@@ -1,6 +1,8 @@
 /*
  * oracle/challenger.c -- Fiat-Shamir duplex challenger, PoW grinding and the
- * arity-2 FRI fold.  TEST INFRASTRUCTURE.  PARITY UNPINNED vs p3 0.4.3.
+ * arity-2 FRI fold.  TEST INFRASTRUCTURE.  The fold is PINNED to the reference (55 fold triples of its stored proofs,
+ * tests/test_ref_vectors_cpu.py); the challenger (observe / sample order, grinding) is PARITY UNPINNED vs p3 0.4.3:
+ * a transcript cannot be replayed without the verifying key pre-hash.
  *
  * Restates p3-challenger 0.4.3 DuplexChallenger<F, Perm, 16, 8>
  * (Cargo.lock:5576): observe() buffers up to RATE inputs and duplexes when

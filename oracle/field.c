@@ -1,6 +1,7 @@
 /*
  * oracle/field.c -- BabyBear and its quartic extension, canonical form.
- * TEST INFRASTRUCTURE (see zk_oracle.h).  PARITY UNPINNED against p3 0.4.3.
+ * TEST INFRASTRUCTURE (see zk_oracle.h).  The extension arithmetic is pinned by the FRI fold triples of the
+ * reference's stored proofs (tests/test_ref_vectors_cpu.py).
  *
  * Follows the published definitions of p3-baby-bear / p3-monty-31 / p3-field
  * 0.4.3 (Cargo.lock:5545,5605,5685): p = 2^31 - 2^27 + 1

@@ -1,6 +1,7 @@
 /*
  * oracle/merkle.c -- Poseidon2 Merkle commitment over column-major matrices
- * of mixed power-of-two heights.  TEST INFRASTRUCTURE.  PARITY UNPINNED.
+ * of mixed power-of-two heights.  TEST INFRASTRUCTURE.  Pinned to the reference's stored proofs (72 batch openings
+ * incl. 17-matrix mixed-height batches, tests/test_ref_vectors_cpu.py).
  *
  * Restates the published p3 MerkleTreeMmcs algorithm (the MMCS the
  * north_star's "Merkle-Poseidon2 commit" refers to; the crate itself is not

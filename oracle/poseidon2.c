@@ -1,6 +1,7 @@
 /*
  * oracle/poseidon2.c -- Poseidon2-BabyBear, width 16, and the two hash
- * constructions built on it.  TEST INFRASTRUCTURE.  PARITY UNPINNED vs p3.
+ * constructions built on it.  TEST INFRASTRUCTURE.  PINNED to the reference: 193 commitments of its stored proofs
+ * are reproduced by the permutation / compress, 72 openings by the sponge (tests/test_ref_vectors_cpu.py).
  *
  * Restates p3-poseidon2 0.4.3 (external/internal layer structure, MDSMat4),
  * p3-baby-bear 0.4.3 (internal diagonal for width 16) and zkhash-axiom 0.2.0

@@ -1,6 +1,7 @@
 /*
  * oracle/stark.c -- CPU restatement of the whole proving path and its verifier.
- * TEST INFRASTRUCTURE (see zk_oracle.h).  PARITY UNPINNED.
+ * TEST INFRASTRUCTURE (see zk_oracle.h).  Primitives pinned to the reference (zk_oracle.h); the protocol flow of this
+ * file (transcript order, quotient, reduced openings, proof layout) is PARITY UNPINNED.
  *
  * What it restates: the STARK the reference obtains from `sdk.prove(..)`
  * (crates/prover/src/prover/mod.rs:355-357) in the shape BASELINE.json's

@@ -6,7 +6,7 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and
  * only as the checker / the timed CPU baseline.
  *
- * PARITY UNPINNED: the arithmetic of this path is not in /root/reference.  It
+ * PARITY: the arithmetic of this path is not in /root/reference.  It
  * lives in un-vendored dependencies pinned by the reference's Cargo.lock:
  *   p3-baby-bear / p3-monty-31 / p3-field / p3-dft / p3-poseidon2 /
  *   p3-symmetric / p3-challenger 0.4.3   (Cargo.lock:5535-5750)
@@ -17,12 +17,22 @@
  * DFT / coset LDE, Poseidon2-BabyBear-16 with Grain-LFSR constants,
  * PaddingFreeSponge / TruncatedPermutation, MerkleTreeMmcs, DuplexChallenger,
  * and the uni-stark + two-adic-FRI pipeline named by BASELINE.json
- * north_star).  It is pinned only against (i) the constants the reference tree
- * itself holds (p = 2013265921, scripts/compress_bn254.py:10; DIGEST_SIZE = 8,
- * crates/types/src/proof.rs:209; FRI parameters,
- * crates/circuits/chunk-circuit/openvm.toml:1-6), (ii) the Poseidon2 round
- * constant anchors and permutation self-consistency vectors of SURVEY.md A.3,
- * and (iii) an independent big-int Python model (tests/golden/gen_golden.py).
+ * north_star).
+ * PINNED to the reference's own data (tests/golden/ref_v1_vectors.json, taken
+ * by tests/golden/gen_ref_vectors.py from the eight OpenVM-v1 proofs under
+ * /root/reference/crates/{verifier/testdata/proofs,prover/testdata};
+ * tests/test_ref_vectors_cpu.py): the Poseidon2 permutation and
+ * ora_compress (193 commitments), ora_hash_slice + ora_mmcs_verify incl. mixed
+ * heights (72 batch openings, 20 FRI-layer leaves), ora_fri_fold and the
+ * extension arithmetic (55 fold triples).
+ * PARITY UNPINNED (not extractable without the verifying key's pre-hash, which
+ * the tree does not hold): the transcript order (challenger.c's use in
+ * stark.c), proof-of-work, the quotient identity and the reduced openings.
+ * Those rest on (i) the constants the reference tree holds (p = 2013265921,
+ * scripts/compress_bn254.py:10; DIGEST_SIZE = 8, crates/types/src/proof.rs:209;
+ * FRI parameters, crates/circuits/chunk-circuit/openvm.toml:1-6), (ii) the
+ * round-constant anchors of SURVEY.md A.3 and (iii) the independent big-int
+ * Python model (tests/pymodel.py, tests/golden/gen_golden.py).
  *
  * All values crossing this API are CANONICAL u32 in [0, p).  Internally the
  * oracle computes with 64-bit integers and `% p` (deliberately not the
