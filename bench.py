@@ -113,7 +113,8 @@ def cpu_baseline(args, params, airs, host_traces, pvs, gpu_proof):
     import numpy as np
     import oracle_lib as ora
 
-    cores = os.cpu_count() or 1
+    cores = ora.effective_cpus()  # min(visible CPUs, cgroup quota); oracle_lib has set OMP_NUM_THREADS to it
+    threads = int(os.environ.get("OMP_NUM_THREADS", cores))
     lanes = ora.fast_lib().fast_vector_lanes()
     inst = [dict(a, trace=t, pvs=np.ascontiguousarray(pv, dtype=np.uint32)) for a, t, pv in zip(airs, host_traces, pvs)]
     cap = len(gpu_proof) // 4 + 16
@@ -127,12 +128,14 @@ def cpu_baseline(args, params, airs, host_traces, pvs, gpu_proof):
     proof = ora.fast_stark_prove(params, inst, cap_words=cap)
     dt = time.time() - t0
     same = proof.tobytes() == bytes(gpu_proof)
-    return {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": min(cores, threads), "kind": "port",
+            "threads": threads, "host_cpus_visible": os.cpu_count(),
             "seconds_per_proof": round(dt, 3), "seconds_first_proof": round(dt_first, 3), "proof_bytes_equal_gpu": bool(same),
-            "sample": "2^%d rows, measured: oracle/fast (optimised C restatement: %d-lane %s Montgomery, OpenMP x%d threads) "
+            "sample": "2^%d rows, measured: oracle/fast (optimised C restatement: %d-lane %s Montgomery, OpenMP x%d threads = the CPUs "
+                      "this container's cgroup grants; the host shows more) "
                       "proved the full bench instance of pipeline 0 in %.2f s (second proof; workspace warm); proof bytes %s the GPU's; not the reference "
                       "Rust binary (unbuildable here)"
-                      % (args.log_rows, lanes, "AVX-512" if lanes == 16 else "AVX2", cores, dt,
+                      % (args.log_rows, lanes, "AVX-512" if lanes == 16 else "AVX2", threads, dt,
                          "EQUAL" if same else "DIFFER FROM")}
 
 

@@ -143,7 +143,8 @@ int zkhip_fri_fold(zkhip_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, unsign
 /* ---- LogUp and sum-check building blocks (K6, K7 of SURVEY.md 2.3; a7.4 of 8(a)): the
  *      protocol-independent kernels under the pinned backend's LogUp / zero-check / stacking
  *      sum-checks.  All buffers are device, Montgomery; extension elements are 4 words. ---- */
-/* out[i] = 1 / in[i] for n extension elements (Montgomery batch inversion; no element may be 0) */
+/* out[i] = 1 / in[i] for n extension elements (Montgomery batch inversion); a zero element gives 0 (= 0^(p^4-2), what
+ * an element-wise Fermat inversion returns) and does not disturb its neighbours */
 int zkhip_ext_batch_inverse(zkhip_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, size_t n);
 /* LogUp running sum: out[i] = sum_{j<=i} num[j] / den[j]; den = n extension elements, num = n
  * base-field multiplicities; total (the cumulative sum, 4 canonical words) goes to the HOST

@@ -6,6 +6,33 @@ import subprocess
 
 import numpy as np
 
+def effective_cpus():
+    """CPUs this process may actually use: min(affinity, cgroup CPU quota).  A container can SEE every host thread
+    (nproc = 256 on the GPU box) while its cgroup grants far fewer (cpu.max = 16 CPUs there): OpenMP's default of one
+    thread per visible CPU then spends its time being throttled (measured: 2^19-row proof 0.52 s with 16 threads, 58 s
+    with 256)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+# must happen before libgomp starts (first dlopen of an OpenMP library in this process)
+os.environ.setdefault("OMP_NUM_THREADS", str(effective_cpus()))
+
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ORA_DIR = os.path.join(_ROOT, "oracle")
 _LIB = None

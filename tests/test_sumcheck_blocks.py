@@ -119,3 +119,22 @@ def test_sumcheck_protocol_invariant_large(zk, ora):
     for f in finals:
         prod = ext_mul(prod, [int(x) for x in f])
     assert prod == claim
+
+
+@pytest.mark.gpu
+def test_hip_batch_inverse_with_zero_elements(zk, ora):
+    """A vanishing LogUp denominator must not poison its batch-inversion group: zero -> zero (what the oracle's
+    element-wise Fermat inversion gives), every other element still inverted exactly."""
+    rng = np.random.default_rng(9)
+    n = 5000
+    den = ora.rand_field(rng, (n, 4))
+    for i in (0, 1, 7, 8, 2047, 2048, 3333, n - 1):
+        den[i] = 0
+    den[100:120] = 0  # a whole run of zeros, several per lane group
+    got = zk.download(zk.ext_batch_inverse(zk.upload(den.reshape(-1)), n)).reshape(-1, 4)
+    exp = ora.ext_batch_inverse(den.reshape(-1)).reshape(-1, 4)
+    assert (got == exp).all()
+    assert (got[100:120] == 0).all() and (got[50] != 0).any()
+    num = ora.rand_field(rng, n)
+    out, total = zk.logup_running_sum(zk.upload(den.reshape(-1)), zk.upload(num), n)
+    assert (zk.download(out) == ora.logup_running_sum(den.reshape(-1), num)).all()

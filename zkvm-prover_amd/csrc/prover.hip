@@ -176,13 +176,35 @@ struct LogupArgs {
     size_t N;
     uint32_t n_int, n_groups;
 };
-// grid (rows / 256, n_int): denominator gamma + bus + 1 + sum_i beta^(i+1) f_i and numerator +-count of one row
-__global__ __launch_bounds__(LU_BS) void k_logup_denoms(LogupArgs a) {
+// All chips with bus interactions of a proof go through each LogUp kernel in ONE launch: the descriptors of the chips sit
+// in a device array, the grid is the concatenation of the chips' block ranges and a block finds its chip by a binary
+// search over the (scalar) prefix table.  42 chips used to cost 42 launches per kernel, each far too small to fill the GPU.
+struct LogupMulti {
+    const LogupArgs* args;       // n chips
+    const uint32_t* rows_first;  // n + 1: first 256-row block of each chip in the flattened row grid
+    const uint32_t* den_first;   // n + 1: first block in the flattened denominator grid (row blocks x n_int)
+    uint32_t n;
+};
+__device__ __forceinline__ uint32_t chip_of_block(const uint32_t* first, uint32_t n, uint32_t b) {
+    uint32_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+// denominator gamma + bus + 1 + sum_i beta^(i+1) f_i and numerator +-count of one row of one interaction
+__global__ __launch_bounds__(LU_BS) void k_logup_denoms(LogupMulti m) {
     extern __shared__ uint32_t slots[];
+    const uint32_t chip = chip_of_block(m.den_first, m.n, blockIdx.x);
+    const LogupArgs& a = m.args[chip];
+    const uint32_t lb = blockIdx.x - m.den_first[chip];
+    const uint32_t rb = (uint32_t)((a.N + LU_BS - 1) / LU_BS);
     const unsigned tid = threadIdx.x;
-    const size_t r = (size_t)blockIdx.x * LU_BS + tid;
+    const size_t r = (size_t)(lb % rb) * LU_BS + tid;
     if (r >= a.N) return;
-    const uint32_t j = blockIdx.y;
+    const uint32_t j = lb / rb;
     const uint32_t* t = a.tab + (size_t)j * LU_STRIDE;
     const uint32_t* code = a.code + 3 * (size_t)t[0];
     const uint32_t n_instr = t[1], n_fields = t[4];
@@ -190,13 +212,17 @@ __global__ __launch_bounds__(LU_BS) void k_logup_denoms(LogupArgs a) {
     Ext den = ld_ext(a.lchal);
     den.c[0] = madd(den.c[0], t[2]);
     uint32_t num = 0;
+    const uint32_t* trace = a.trace;
+    const uint32_t* prep = a.prep;
+    const uint32_t* pvs = a.pvs;
+    const size_t N = a.N;
     auto fetch = [&](uint32_t w) -> uint32_t {
         const uint32_t kind = w >> 28, idx = w & 0x07ffffffu;
         switch (kind) {
             case K_SLOT: return slots[idx * LU_BS + tid];
-            case K_VAR: return a.trace[(size_t)idx * a.N + r];
-            case K_PREP: return a.prep[(size_t)idx * a.N + r];
-            case K_PUB: return a.pvs[idx];
+            case K_VAR: return trace[(size_t)idx * N + r];
+            case K_PREP: return prep[(size_t)idx * N + r];
+            case K_PUB: return pvs[idx];
             default: return consts[idx];
         }
     };
@@ -214,12 +240,14 @@ __global__ __launch_bounds__(LU_BS) void k_logup_denoms(LogupArgs a) {
             slots[dst * LU_BS + tid] = op == Q_ADD ? madd(va, vb) : (op == Q_SUB ? msub(va, vb) : mmul(va, vb));
         }
     }
-    reinterpret_cast<uint4*>(a.den)[(size_t)j * a.N + r] = make_uint4(den.c[0], den.c[1], den.c[2], den.c[3]);
-    a.num[(size_t)j * a.N + r] = num;
+    reinterpret_cast<uint4*>(a.den)[(size_t)j * N + r] = make_uint4(den.c[0], den.c[1], den.c[2], den.c[3]);
+    a.num[(size_t)j * N + r] = num;
 }
 // after the batch inversion den holds phi_j[r]: write the phi columns and the row sums
-__global__ __launch_bounds__(256) void k_logup_rows(LogupArgs a) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_logup_rows(LogupMulti m) {
+    const uint32_t chip = chip_of_block(m.rows_first, m.n, blockIdx.x);
+    const LogupArgs& a = m.args[chip];
+    const size_t r = (size_t)(blockIdx.x - m.rows_first[chip]) * 256 + threadIdx.x;
     if (r >= a.N) return;
     Ext sum = ext_zero(), grp = ext_zero();
     for (uint32_t j = 0; j < a.n_int; j++) {
@@ -236,8 +264,10 @@ __global__ __launch_bounds__(256) void k_logup_rows(LogupArgs a) {
     reinterpret_cast<uint4*>(a.sums)[r] = make_uint4(sum.c[0], sum.c[1], sum.c[2], sum.c[3]);
 }
 // running-sum columns and the exposed total
-__global__ __launch_bounds__(256) void k_logup_sums(LogupArgs a) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_logup_sums(LogupMulti m) {
+    const uint32_t chip = chip_of_block(m.rows_first, m.n, blockIdx.x);
+    const LogupArgs& a = m.args[chip];
+    const size_t r = (size_t)(blockIdx.x - m.rows_first[chip]) * 256 + threadIdx.x;
     if (r >= a.N) return;
     const uint4 v = reinterpret_cast<const uint4*>(a.sums)[r];
     const uint32_t c[4] = {v.x, v.y, v.z, v.w};
@@ -672,6 +702,16 @@ struct zkhip_pk {
     // event marks the last copy that reads it, so a second prove_async waits only if those copies are still pending
     uint32_t* h_stage_pinned = nullptr;
     size_t stage_words = 0;
+    // LogUp phase of all chips as one batch: descriptor array (main-trace pointers patched per proof through the staging
+    // buffer), block prefix tables, the shared denominator / numerator regions, the segmented-scan table
+    LogupArgs* d_lu_args = nullptr;
+    std::vector<LogupArgs> lu_args_host;
+    uint32_t *d_lu_rows_first = nullptr, *d_lu_den_first = nullptr;
+    uint32_t lu_rows_blocks = 0, lu_den_blocks = 0, lu_scan_blocks = 0, lu_max_slots = 1;
+    bool lu_scan_multi = false;
+    uint32_t *d_lu_den_all = nullptr, *d_lu_num_all = nullptr;
+    size_t lu_den_elems = 0;
+    ScanSeg* d_lu_scan = nullptr;
     hipEvent_t stage_ev = nullptr;
     uint32_t* d_open_dst = nullptr;
     size_t open_total_cols = 0;
@@ -887,7 +927,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     const unsigned nch = pk->nch;
     struct AirOff {
         size_t code, consts, zh, inv_zh, pvs, lde, q, qnat, qlde, apow_q;
-        size_t lu_tab, lu_code, lu_consts, lu_den, lu_num, lu_sums, perm, perm_lde, prep, prep_lde, dig_prep;
+        size_t lu_tab, lu_code, lu_consts, lu_den, lu_totals, lu_sums, perm, perm_lde, prep, prep_lde, dig_prep;
     };
     std::vector<AirOff> ao(n_airs);
     std::vector<CompiledAir> comp(n_airs);
@@ -895,6 +935,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         std::vector<uint32_t> tab, code, consts;
     };
     std::vector<LuHost> lu(n_airs);
+    size_t lu_den_elems = 0, lu_tot_elems = 0;
     for (size_t a = 0; a < n_airs; a++) {
         AirPlan& A = pk->airs[a];
         // The interpreter lowering can refuse a valid AIR (more live intermediates than its LDS slots); the compiled
@@ -965,13 +1006,19 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             ao[a].lu_code = bp.take(lu[a].code.size() * 4 + 16);
             ao[a].lu_consts = bp.take(lu[a].consts.size() * 4 + 16);
             ao[a].lu_tab = bp.take((size_t)A.n_int * LU_STRIDE * 4);
-            ao[a].lu_den = bp.take((size_t)A.n_int * A.N * 16);
-            ao[a].lu_num = bp.take((size_t)A.n_int * A.N * 4);
+            ao[a].lu_den = lu_den_elems;  // element offset into the shared regions (one batch inversion for all chips)
+            lu_den_elems += (size_t)A.n_int * A.N;
             ao[a].lu_sums = bp.take(A.N * 16);
+            ao[a].lu_totals = lu_tot_elems;
+            lu_tot_elems += scan_blocks_of(A.N);
             ao[a].perm = bp.take(A.perm_w * A.N * 4);
             ao[a].perm_lde = bp.take(A.perm_w * A.M * 4);
         }
     }
+    const size_t o_lu_den_all = bp.take(lu_den_elems * 16 + 16), o_lu_num_all = bp.take(lu_den_elems * 4 + 16);
+    const size_t o_lu_totals = bp.take(lu_tot_elems * 16 + 16), o_lu_args = bp.take((pk->n_lu + 1) * sizeof(LogupArgs));
+    const size_t o_lu_rows_first = bp.take((pk->n_lu + 2) * 4), o_lu_den_first = bp.take((pk->n_lu + 2) * 4);
+    const size_t o_lu_scan = bp.take((pk->n_lu + 1) * sizeof(ScanSeg));
     size_t o_lchal = bp.take((N_CHAL + 8) * 4);
     size_t o_exposed = bp.take((4 * pk->n_lu + 4) * 4);
     size_t o_dig_perm = pk->n_lu ? bp.take(merkle_digest_count(pk->h_perm) * 32) : 0;
@@ -1093,8 +1140,8 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         }
         if (A.n_int) {
             A.d_lu_tab = (uint32_t*)(base + ao[a].lu_tab);
-            A.d_lu_den = (uint32_t*)(base + ao[a].lu_den);
-            A.d_lu_num = (uint32_t*)(base + ao[a].lu_num);
+            A.d_lu_den = (uint32_t*)(base + o_lu_den_all) + 4 * ao[a].lu_den;
+            A.d_lu_num = (uint32_t*)(base + o_lu_num_all) + ao[a].lu_den;
             A.d_lu_sums = (uint32_t*)(base + ao[a].lu_sums);
             A.d_perm = (uint32_t*)(base + ao[a].perm);
             A.d_perm_lde = (uint32_t*)(base + ao[a].perm_lde);
@@ -1113,6 +1160,14 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     pk->d_chal = (uint32_t*)(base + o_chal);
     pk->d_lchal = (uint32_t*)(base + o_lchal);
     pk->d_exposed = (uint32_t*)(base + o_exposed);
+    // LogUp batch tables (all chips with interactions, in AIR order = lu_index order)
+    pk->d_lu_den_all = (uint32_t*)(base + o_lu_den_all);
+    pk->d_lu_num_all = (uint32_t*)(base + o_lu_num_all);
+    pk->lu_den_elems = lu_den_elems;
+    pk->d_lu_args = (LogupArgs*)(base + o_lu_args);
+    pk->d_lu_rows_first = (uint32_t*)(base + o_lu_rows_first);
+    pk->d_lu_den_first = (uint32_t*)(base + o_lu_den_first);
+    pk->d_lu_scan = (ScanSeg*)(base + o_lu_scan);
     pk->d_opened = (uint32_t*)(base + o_opened);
     pk->d_pts = (uint32_t*)(base + o_pts);
     pk->d_weights = (uint32_t*)(base + o_weights);
@@ -1247,10 +1302,48 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     }
     if (rc == ZKHIP_OK) rc = upload(ctx, pk->d_fri_desc, desc.data(), desc.size() * sizeof(FriLayerDesc));
     if (rc == ZKHIP_OK) rc = ensure_twiddles(ctx, pk->hmax);
+    if (rc == ZKHIP_OK && pk->n_lu) {
+        std::vector<uint32_t> rows_first, den_first;
+        std::vector<ScanSeg> segs;
+        uint32_t rb_acc = 0, den_acc = 0, scan_acc = 0;
+        for (size_t a = 0; a < n_airs; a++) {
+            AirPlan& A = pk->airs[a];
+            if (!A.n_int) continue;
+            LogupArgs la;
+            la.trace = nullptr;  // the caller's buffer: patched per proof
+            la.prep = A.d_prep;
+            la.pvs = A.d_pvs;
+            la.tab = A.d_lu_tab;
+            la.code = A.d_lu_code;
+            la.consts = A.d_lu_consts;
+            la.lchal = pk->d_lchal;
+            la.den = A.d_lu_den;
+            la.num = A.d_lu_num;
+            la.perm = A.d_perm;
+            la.sums = A.d_lu_sums;
+            la.expo = pk->d_exposed + 4 * A.lu_index;
+            la.N = A.N;
+            la.n_int = A.n_int;
+            la.n_groups = (uint32_t)A.prog.n_groups();
+            pk->lu_args_host.push_back(la);
+            const uint32_t rb = (uint32_t)((A.N + 255) / 256), sb = scan_blocks_of(A.N);
+            rows_first.push_back(rb_acc), den_first.push_back(den_acc);
+            segs.push_back(ScanSeg{A.d_lu_sums, (uint32_t*)(base + o_lu_totals) + 4 * ao[a].lu_totals, (uint64_t)A.N, scan_acc, sb});
+            rb_acc += rb, den_acc += rb * A.n_int, scan_acc += sb;
+            if (sb > 1) pk->lu_scan_multi = true;
+            pk->lu_max_slots = std::max(pk->lu_max_slots, (uint32_t)A.lu_slots);
+        }
+        rows_first.push_back(rb_acc), den_first.push_back(den_acc);
+        pk->lu_rows_blocks = rb_acc, pk->lu_den_blocks = den_acc, pk->lu_scan_blocks = scan_acc;
+        rc = upload(ctx, pk->d_lu_rows_first, rows_first.data(), rows_first.size() * 4);
+        if (rc == ZKHIP_OK) rc = upload(ctx, pk->d_lu_den_first, den_first.data(), den_first.size() * 4);
+        if (rc == ZKHIP_OK) rc = upload(ctx, pk->d_lu_scan, segs.data(), segs.size() * sizeof(ScanSeg));
+    }
     if (rc == ZKHIP_OK) {
         size_t n_pv = 0;
         for (const auto& A : pk->airs) n_pv += A.n_pvs;
-        pk->stage_words = pk->preamble.size() + 4 + n_pv;
+        // [LogupArgs x n_lu (8-byte aligned: first)] [preamble] [4 header words] [public values]
+        pk->stage_words = pk->n_lu * (sizeof(LogupArgs) / 4) + pk->preamble.size() + 4 + n_pv;
         if (hipHostMalloc((void**)&pk->h_stage_pinned, pk->stage_words * 4, 0) != hipSuccess ||
             hipEventCreateWithFlags(&pk->stage_ev, hipEventDisableTiming) != hipSuccess)
             rc = set_error(ctx, ZKHIP_ERR_NOMEM, "pinned staging buffer");
@@ -1321,7 +1414,19 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         }
         ZK_HIP_CHECK(ctx, hipEventSynchronize(pk->stage_ev));  // returns at once unless the previous proof's copies are pending
         const size_t n_pre = pk->preamble.size();
-        uint32_t* pre = pk->h_stage_pinned;
+        LogupArgs* lu_stage = reinterpret_cast<LogupArgs*>(pk->h_stage_pinned);
+        uint32_t* pre = pk->h_stage_pinned + pk->n_lu * (sizeof(LogupArgs) / 4);
+        if (pk->n_lu) {
+            size_t k = 0;
+            for (size_t a = 0; a < n_airs; a++)
+                if (pk->airs[a].n_int) {
+                    if (!d_traces[a]) return set_error(ctx, ZKHIP_ERR_INVALID, "missing trace");
+                    lu_stage[k] = pk->lu_args_host[k];
+                    lu_stage[k].trace = d_traces[a];
+                    k++;
+                }
+            ZK_HIP_CHECK(ctx, hipMemcpyAsync(pk->d_lu_args, lu_stage, pk->n_lu * sizeof(LogupArgs), hipMemcpyHostToDevice, st));
+        }
         uint32_t* hdr = pre + n_pre;
         uint32_t* pm = hdr + 4;
         memcpy(pre, pk->preamble.data(), n_pre * 4);
@@ -1397,42 +1502,28 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             KernelScope ks(ctx, "logup_chal");
             hipLaunchKernelGGL(k_logup_chal, dim3(1), dim3(64), 0, st, d_gb, pk->d_lchal);
         }
-        for (size_t a = 0; a < n_airs; a++) {
-            AirPlan& A = pk->airs[a];
-            if (!A.n_int) continue;
-            LogupArgs la;
-            la.trace = d_traces[a];
-            la.prep = A.d_prep;
-            la.pvs = A.d_pvs;
-            la.tab = A.d_lu_tab;
-            la.code = A.d_lu_code;
-            la.consts = A.d_lu_consts;
-            la.lchal = pk->d_lchal;
-            la.den = A.d_lu_den;
-            la.num = A.d_lu_num;
-            la.perm = A.d_perm;
-            la.sums = A.d_lu_sums;
-            la.expo = pk->d_exposed + 4 * A.lu_index;
-            la.N = A.N;
-            la.n_int = A.n_int;
-            la.n_groups = (uint32_t)A.prog.n_groups();
-            const unsigned rb = (unsigned)((A.N + 255) / 256);
+        {
+            const LogupMulti lm{pk->d_lu_args, pk->d_lu_rows_first, pk->d_lu_den_first, (uint32_t)pk->n_lu};
             {
                 KernelScope ks(ctx, "logup_denoms");
-                hipLaunchKernelGGL(k_logup_denoms, dim3(rb, A.n_int), dim3(LU_BS), (size_t)A.lu_slots * LU_BS * 4, st, la);
+                hipLaunchKernelGGL(k_logup_denoms, dim3(pk->lu_den_blocks), dim3(LU_BS), (size_t)pk->lu_max_slots * LU_BS * 4, st, lm);
             }
-            ZK_TRY(launch_batch_inverse(ctx, A.d_lu_den, A.d_lu_den, (size_t)A.n_int * A.N, A.d_lu_num));
+            // one batch inversion over the denominators of every chip (numerators fused)
+            ZK_TRY(launch_batch_inverse(ctx, pk->d_lu_den_all, pk->d_lu_den_all, pk->lu_den_elems, pk->d_lu_num_all));
             {
                 KernelScope ks(ctx, "logup_rows");
-                hipLaunchKernelGGL(k_logup_rows, dim3(rb), dim3(256), 0, st, la);
+                hipLaunchKernelGGL(k_logup_rows, dim3(pk->lu_rows_blocks), dim3(256), 0, st, lm);
             }
-            ZK_TRY(ext_inclusive_scan(ctx, A.d_lu_sums, A.N));
+            ZK_TRY(ext_inclusive_scan_multi(ctx, pk->d_lu_scan, (uint32_t)pk->n_lu, pk->lu_scan_blocks, pk->lu_scan_multi));
             {
                 KernelScope ks(ctx, "logup_sums");
-                hipLaunchKernelGGL(k_logup_sums, dim3(rb), dim3(256), 0, st, la);
+                hipLaunchKernelGGL(k_logup_sums, dim3(pk->lu_rows_blocks), dim3(256), 0, st, lm);
             }
             ZK_HIP_CHECK(ctx, hipGetLastError());
-            if (A.lh < 12) ZK_TRY(lde_batch(ctx, A.d_perm, A.N, A.d_perm_lde, A.M, A.lh, b, A.perm_w, gen));
+        }
+        for (size_t a = 0; a < n_airs; a++) {
+            AirPlan& A = pk->airs[a];
+            if (A.n_int && A.lh < 12) ZK_TRY(lde_batch(ctx, A.d_perm, A.N, A.d_perm_lde, A.M, A.lh, b, A.perm_w, gen));
         }
         ZK_TRY(lde_groups_of(1, 1));
         ZK_TRY(merkle_build(ctx, pk->t_perm, false));

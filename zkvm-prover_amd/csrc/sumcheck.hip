@@ -33,11 +33,20 @@ __global__ __launch_bounds__(256) void k_ext_batch_inverse(const uint32_t* in, u
                                                            const uint32_t* __restrict__ num) {
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // A zero element (a LogUp denominator vanishes with probability ~2^-120 per row) must not poison the other seven of
+    // its group: it takes part in the running product as 1 and its own "inverse" is 0 -- what Fermat's a^(p^4-2) gives,
+    // i.e. what the oracle computes element by element.  (The row's LogUp constraint then fails unless its count is 0,
+    // exactly as with the reference's per-element inversion.)
     Ext x[BI_K], pre[BI_K];
+    unsigned zero_mask = 0;
 #pragma unroll
     for (int k = 0; k < BI_K; k++) {
         size_t i = gid + (size_t)k * nthreads;
         x[k] = i < n ? ld4(in, i) : ext_one();
+        if ((x[k].c[0] | x[k].c[1] | x[k].c[2] | x[k].c[3]) == 0) {
+            zero_mask |= 1u << k;
+            x[k] = ext_one();
+        }
         pre[k] = k == 0 ? x[0] : ext_mul(pre[k - 1], x[k]);
     }
     Ext inv = ext_inv(pre[BI_K - 1]);
@@ -47,6 +56,7 @@ __global__ __launch_bounds__(256) void k_ext_batch_inverse(const uint32_t* in, u
         inv = ext_mul(inv, x[k]);
         size_t i = gid + (size_t)k * nthreads;
         if (i < n) {
+            if (zero_mask & (1u << k)) o = ext_zero();
             if (num) o = ext_mul_base(o, num[i]);  // LogUp term num/den
             st4(out, i, o);
         }
@@ -155,6 +165,103 @@ int ext_inclusive_scan(zkhip_ctx* ctx, uint32_t* d_out, size_t n) {
     if (n_blocks > 1) {
         hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, ctx->stream, (uint32_t*)totals, n_blocks);
         hipLaunchKernelGGL(k_scan_add, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, d_out, n, (const uint32_t*)totals);
+    }
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+// ---- the same scan over several independent arrays in three launches (the LogUp running sums of every chip of a proof:
+//      42 chips used to cost 42 x 3 launches, each a few microseconds of work) ----
+// block b of the flattened grid belongs to the segment whose [first_block, first_block + n_blocks) holds it
+__device__ __forceinline__ uint32_t seg_of_block(const ScanSeg* segs, uint32_t n_seg, uint32_t b) {
+    uint32_t lo = 0, hi = n_seg - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (segs[mid].first_block <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_scan_local_multi(const ScanSeg* __restrict__ segs, uint32_t n_seg) {
+    __shared__ uint32_t wave_tot[4][4];
+    const ScanSeg sg = segs[seg_of_block(segs, n_seg, blockIdx.x)];
+    const uint32_t lb = blockIdx.x - sg.first_block;
+    uint32_t* data = sg.data;
+    const size_t n = sg.n;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const size_t base = (size_t)lb * SC_BLOCK + (size_t)tid * SC_K;
+    Ext v[SC_K];
+    Ext run = ext_zero();
+#pragma unroll
+    for (int k = 0; k < SC_K; k++) {
+        v[k] = base + k < n ? ld4(data, base + k) : ext_zero();
+        run = ext_add(run, v[k]);
+        v[k] = run;
+    }
+    Ext incl = wave_inclusive_scan(run, lane);
+    if (lane == 63) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) wave_tot[wave][q] = incl.c[q];
+    }
+    __syncthreads();
+    Ext off = ext_sub(incl, run);
+    for (unsigned w = 0; w < wave; w++)
+        off = ext_add(off, Ext{{wave_tot[w][0], wave_tot[w][1], wave_tot[w][2], wave_tot[w][3]}});
+#pragma unroll
+    for (int k = 0; k < SC_K; k++)
+        if (base + k < n) st4(data, base + k, ext_add(v[k], off));
+    if (tid == 255) st4(sg.totals, lb, ext_add(off, run));
+}
+// one workgroup per segment scans that segment's workgroup totals
+__global__ __launch_bounds__(1024) void k_scan_totals_multi(const ScanSeg* __restrict__ segs) {
+    __shared__ uint32_t wave_tot[16][4];
+    __shared__ uint32_t carry[4];
+    const ScanSeg sg = segs[blockIdx.x];
+    const size_t n_blocks = sg.n_blocks;
+    if (n_blocks <= 1) return;
+    uint32_t* totals = sg.totals;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid < 4) carry[tid] = 0;
+    __syncthreads();
+    for (size_t start = 0; start < n_blocks; start += 1024) {
+        size_t i = start + tid;
+        Ext v = i < n_blocks ? ld4(totals, i) : ext_zero();
+        Ext incl = wave_inclusive_scan(v, lane);
+        if (lane == 63) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) wave_tot[wave][q] = incl.c[q];
+        }
+        __syncthreads();
+        Ext off{{carry[0], carry[1], carry[2], carry[3]}};
+        for (unsigned w = 0; w < wave; w++)
+            off = ext_add(off, Ext{{wave_tot[w][0], wave_tot[w][1], wave_tot[w][2], wave_tot[w][3]}});
+        Ext r = ext_add(incl, off);
+        if (i < n_blocks) st4(totals, i, r);
+        __syncthreads();
+        if (tid == 1023) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) carry[q] = r.c[q];
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_add_multi(const ScanSeg* __restrict__ segs, uint32_t n_seg) {
+    const ScanSeg sg = segs[seg_of_block(segs, n_seg, blockIdx.x)];
+    const uint32_t lb = blockIdx.x - sg.first_block;
+    if (lb == 0) return;
+    const Ext off = ld4(sg.totals, lb - 1);
+    const size_t base = (size_t)lb * SC_BLOCK;
+    for (unsigned e = threadIdx.x; e < SC_BLOCK; e += 256)
+        if (base + e < sg.n) st4(sg.data, base + e, ext_add(ld4(sg.data, base + e), off));
+}
+uint32_t scan_blocks_of(size_t n) { return (uint32_t)((n + SC_BLOCK - 1) / SC_BLOCK); }
+int ext_inclusive_scan_multi(zkhip_ctx* ctx, const ScanSeg* d_segs, uint32_t n_seg, uint32_t total_blocks, bool any_multi_block) {
+    if (n_seg == 0 || total_blocks == 0) return ZKHIP_OK;
+    KernelScope ks(ctx, "logup_scan");
+    hipLaunchKernelGGL(k_scan_local_multi, dim3(total_blocks), dim3(256), 0, ctx->stream, d_segs, n_seg);
+    if (any_multi_block) {
+        hipLaunchKernelGGL(k_scan_totals_multi, dim3(n_seg), dim3(1024), 0, ctx->stream, d_segs);
+        hipLaunchKernelGGL(k_scan_add_multi, dim3(total_blocks), dim3(256), 0, ctx->stream, d_segs, n_seg);
     }
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;

@@ -137,4 +137,14 @@ int fri_fold(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, unsigned log
 int launch_batch_inverse(zkhip_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, size_t n, const uint32_t* d_num);
 // in-place inclusive prefix sum of n extension elements
 int ext_inclusive_scan(zkhip_ctx* ctx, uint32_t* d_data, size_t n);
+// several independent scans in three launches: segment i = n extension elements at `data`, its workgroup totals at `totals`
+// (scan_blocks_of(n) extension elements), occupying blocks [first_block, first_block + n_blocks) of the flattened grid
+struct ScanSeg {
+    uint32_t* data;
+    uint32_t* totals;
+    uint64_t n;
+    uint32_t first_block, n_blocks;
+};
+uint32_t scan_blocks_of(size_t n);
+int ext_inclusive_scan_multi(zkhip_ctx* ctx, const ScanSeg* d_segs, uint32_t n_seg, uint32_t total_blocks, bool any_multi_block);
 }  // namespace zk
