@@ -822,6 +822,61 @@ __global__ void k_gen_coset_powers(uint32_t* pw, uint32_t shift, uint32_t w_big,
         pw[idx] = mmul(n_inv, mpow(s, (uint64_t)(k - (1u << lb)) << lb));
 }
 
+// The same plain permutation for MANY small matrices in one launch per kernel form (the quotient chunks of every chip of a
+// proof): segment = `width` columns of 2^log_n words; the flattened grid is searched like the LogUp kernels' (prover.hip).
+__device__ __forceinline__ uint32_t bitrev_seg_of(const BitrevSeg* segs, uint32_t n, uint32_t b) {
+    uint32_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (segs[mid].first_block <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_bitrev_copy_tiled_multi(const BitrevSeg* __restrict__ segs, uint32_t n_seg) {
+    __shared__ uint32_t tile[32][33];
+    const BitrevSeg sg = segs[bitrev_seg_of(segs, n_seg, blockIdx.x)];
+    const uint32_t lb = blockIdx.x - sg.first_block, log_mid = sg.log_n - 10;
+    const unsigned mid = lb & ((1u << log_mid) - 1u), colx = lb >> log_mid;
+    const unsigned tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;
+    const uint32_t* src = sg.src + (size_t)colx * sg.src_stride;
+    uint32_t* dst = sg.dst + (size_t)colx * sg.dst_stride;
+#pragma unroll
+    for (unsigned rr = 0; rr < 4; rr++) {
+        unsigned hi5 = ty + 8 * rr;
+        tile[hi5][tx] = src[((size_t)hi5 << (sg.log_n - 5)) + ((size_t)mid << 5) + tx];
+    }
+    __syncthreads();
+    const unsigned brmid = bitrev32(mid, log_mid);
+#pragma unroll
+    for (unsigned rr = 0; rr < 4; rr++) {
+        unsigned B = ty + 8 * rr, A = tx;
+        dst[(B << (sg.log_n - 5)) + (brmid << 5) + A] = tile[bitrev32(A, 5)][bitrev32(B, 5)];
+    }
+}
+__global__ __launch_bounds__(256) void k_bitrev_copy_small_multi(const BitrevSeg* __restrict__ segs, uint32_t n_seg) {
+    const BitrevSeg sg = segs[bitrev_seg_of(segs, n_seg, blockIdx.x)];
+    const uint32_t lb = blockIdx.x - sg.first_block;
+    const uint32_t n = 1u << sg.log_n, bpc = (n + 255u) / 256u;  // blocks per column
+    const uint32_t colx = lb / bpc, i = (lb % bpc) * 256u + threadIdx.x;
+    if (i >= n) return;
+    sg.dst[(size_t)colx * sg.dst_stride + i] = sg.src[(size_t)colx * sg.src_stride + bitrev32(i, sg.log_n)];
+}
+uint32_t ntt_bitrev_copy_blocks(unsigned log_n, uint32_t width) {
+    return log_n >= 10 ? (width << (log_n - 10)) : width * (((1u << log_n) + 255u) / 256u);
+}
+// d_tiled: segments with log_n >= 10, d_small: the others (first_block counted separately in each table)
+int ntt_bitrev_copy_multi(zkhip_ctx* ctx, const BitrevSeg* d_tiled, uint32_t n_tiled, uint32_t blocks_tiled,
+                          const BitrevSeg* d_small, uint32_t n_small, uint32_t blocks_small) {
+    KernelScope ks(ctx, "bitrev_scale");
+    if (n_tiled && blocks_tiled)
+        hipLaunchKernelGGL(k_bitrev_copy_tiled_multi, dim3(blocks_tiled), dim3(256), 0, ctx->stream, d_tiled, n_tiled);
+    if (n_small && blocks_small)
+        hipLaunchKernelGGL(k_bitrev_copy_small_multi, dim3(blocks_small), dim3(256), 0, ctx->stream, d_small, n_small);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
 // plain bit-reversal permutation of `width` columns (no scaling), out of place
 int ntt_bitrev_copy(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint32_t* dst, size_t dst_stride,
                     unsigned log_n, size_t width) {

@@ -56,24 +56,43 @@ struct QuotArgs {
     const uint32_t* expo;   // 4 coordinates of the exposed cumulative sum or null
     const uint32_t* prep;   // preprocessed LDE (column-major, stride = M) or null
     uint32_t* q;            // 4 columns of M (quotient values, bit-reversed LDE order)
-    const uint32_t* tw_fwd;
     const uint32_t* inv_zh; // 2^b values, index = natural index mod 2^b
     const uint32_t* zh;     // 2^b values
     uint32_t gen;           // coset shift (Montgomery)
     uint32_t w_n_inv;       // w_N^-1
-    unsigned lh, b, tw_shift;
+    unsigned lh, b;
+};
+// every chip that runs the interpreter, in ONE launch: descriptor array + block prefix table (the twiddle table belongs
+// to the context, not to the key, so it is a launch parameter)
+struct QuotMulti {
+    const QuotArgs* args;
+    const uint32_t* first;  // n + 1
+    uint32_t n;
+    const uint32_t* tw_fwd;
+    unsigned tw_log;
 };
 
-__global__ __launch_bounds__(QBS) void k_quotient(QuotArgs a) {
+__global__ __launch_bounds__(QBS) void k_quotient(QuotMulti m) {
     extern __shared__ uint32_t slots[];
+    uint32_t chip = 0;
+    {
+        uint32_t lo = 0, hi = m.n - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (m.first[mid] <= blockIdx.x) lo = mid;
+            else hi = mid - 1;
+        }
+        chip = lo;
+    }
+    const QuotArgs& a = m.args[chip];
     const unsigned tid = threadIdx.x;
     const unsigned h = a.lh + a.b;
     const size_t M = (size_t)1 << h;
-    const uint32_t r = blockIdx.x * QBS + tid;
+    const uint32_t r = (blockIdx.x - m.first[chip]) * QBS + tid;
     if (r >= M) return;
     const uint32_t i = bitrev32(r, h);
     const uint32_t rn = bitrev32((i + (1u << a.b)) & (uint32_t)(M - 1), h);
-    const uint32_t x = mmul(a.gen, root_pow(a.tw_fwd, a.tw_shift, h, i));
+    const uint32_t x = mmul(a.gen, root_pow(m.tw_fwd, m.tw_log - h, h, i));
     const uint32_t zh = a.zh[i & ((1u << a.b) - 1u)];
     const uint32_t sel_first = mmul(zh, minv(msub(x, MONTY_ONE)));
     const uint32_t sel_trans = msub(x, a.w_n_inv);
@@ -130,6 +149,20 @@ __global__ __launch_bounds__(QBS) void k_quotient(QuotArgs a) {
     for (int k = 0; k < 4; k++) a.q[(size_t)k * M + r] = mmul(acc.c[k], izh);
 }
 
+// alpha^(n_cons-1-k) for every chip at once: block = chip, one lane each (n_cons is a few hundred at most)
+struct PowDesc {
+    uint32_t* out;
+    uint32_t n, pad;
+};
+__global__ void k_ext_powers_multi(const uint32_t* base, const PowDesc* __restrict__ descs) {
+    if (threadIdx.x != 0) return;
+    const PowDesc d = descs[blockIdx.x];
+    Ext bse = ld_ext(base), cur = ext_one();
+    for (uint32_t k = 0; k < d.n; k++) {
+        st_ext(d.out + 4 * (size_t)(d.n - 1 - k), cur);
+        cur = ext_mul(cur, bse);
+    }
+}
 // out[k] = base^(reverse ? n-1-k : k) * 1, n extension elements (single lane: n is a few hundred)
 __global__ void k_ext_powers(const uint32_t* base, uint32_t n, int reverse, uint32_t* out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -712,6 +745,15 @@ struct zkhip_pk {
     uint32_t *d_lu_den_all = nullptr, *d_lu_num_all = nullptr;
     size_t lu_den_elems = 0;
     ScanSeg* d_lu_scan = nullptr;
+    // quotient phase as batches: interpreter descriptors of the chips without a compiled kernel, the alpha-power
+    // descriptors of every chip, the bit-reversal copies of every quotient chunk
+    std::vector<QuotArgs> quot_args_host;  // one per AIR (the compiled kernels take their fields as parameters)
+    QuotArgs* d_quot_args = nullptr;
+    uint32_t* d_quot_first = nullptr;
+    uint32_t quot_n = 0, quot_blocks = 0, quot_max_slots = 1;
+    PowDesc* d_pow_desc = nullptr;
+    BitrevSeg *d_br_tiled = nullptr, *d_br_small = nullptr;
+    uint32_t br_n_tiled = 0, br_n_small = 0, br_blocks_tiled = 0, br_blocks_small = 0;
     hipEvent_t stage_ev = nullptr;
     uint32_t* d_open_dst = nullptr;
     size_t open_total_cols = 0;
@@ -1015,6 +1057,9 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             ao[a].perm_lde = bp.take(A.perm_w * A.M * 4);
         }
     }
+    const size_t o_quot_args = bp.take((n_airs + 1) * sizeof(QuotArgs)), o_quot_first = bp.take((n_airs + 2) * 4);
+    const size_t o_pow_desc = bp.take((n_airs + 1) * sizeof(PowDesc));
+    const size_t o_br_tiled = bp.take((n_airs * nch + 1) * sizeof(BitrevSeg)), o_br_small = bp.take((n_airs * nch + 1) * sizeof(BitrevSeg));
     const size_t o_lu_den_all = bp.take(lu_den_elems * 16 + 16), o_lu_num_all = bp.take(lu_den_elems * 4 + 16);
     const size_t o_lu_totals = bp.take(lu_tot_elems * 16 + 16), o_lu_args = bp.take((pk->n_lu + 1) * sizeof(LogupArgs));
     const size_t o_lu_rows_first = bp.take((pk->n_lu + 2) * 4), o_lu_den_first = bp.take((pk->n_lu + 2) * 4);
@@ -1302,6 +1347,65 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     }
     if (rc == ZKHIP_OK) rc = upload(ctx, pk->d_fri_desc, desc.data(), desc.size() * sizeof(FriLayerDesc));
     if (rc == ZKHIP_OK) rc = ensure_twiddles(ctx, pk->hmax);
+    if (rc == ZKHIP_OK) {
+        pk->d_quot_args = (QuotArgs*)(base + o_quot_args);
+        pk->d_quot_first = (uint32_t*)(base + o_quot_first);
+        pk->d_pow_desc = (PowDesc*)(base + o_pow_desc);
+        pk->d_br_tiled = (BitrevSeg*)(base + o_br_tiled);
+        pk->d_br_small = (BitrevSeg*)(base + o_br_small);
+        std::vector<QuotArgs> interp;
+        std::vector<uint32_t> first;
+        std::vector<PowDesc> pows;
+        std::vector<BitrevSeg> tiled, small;
+        uint32_t acc = 0;
+        const uint32_t gen_m = to_monty(FIELD_GEN_CANON);
+        for (size_t a = 0; a < n_airs; a++) {
+            AirPlan& A = pk->airs[a];
+            QuotArgs qa;
+            qa.code = A.d_code;
+            qa.n_instr = A.n_instr;
+            qa.consts = A.d_consts;
+            qa.pvs = A.d_pvs;
+            qa.apow = A.d_apow_q;
+            qa.lde = A.d_lde;
+            qa.perm = A.d_perm_lde;
+            qa.lchal = pk->d_lchal;
+            qa.expo = pk->d_exposed + 4 * A.lu_index;
+            qa.prep = A.d_prep_lde;
+            qa.q = A.d_q;
+            qa.inv_zh = A.d_inv_zh;
+            qa.zh = A.d_zh;
+            qa.gen = gen_m;
+            qa.w_n_inv = minv(two_adic_generator(A.lh));
+            qa.lh = A.lh;
+            qa.b = pk->b;
+            pk->quot_args_host.push_back(qa);
+            pows.push_back(PowDesc{A.d_apow_q, A.prog.n_cons, 0});
+            if (!A.jit_fn) {
+                interp.push_back(qa);
+                first.push_back(acc);
+                acc += (uint32_t)((A.M + QBS - 1) / QBS);
+                pk->quot_max_slots = std::max(pk->quot_max_slots, (uint32_t)A.n_slots);
+            }
+            for (unsigned j = 0; j < nch; j++) {
+                // column k of chunk j starts at q + k*M + j*N and goes to qnat + (4j + k)*N
+                BitrevSeg sg{A.d_q + (size_t)j * A.N, A.d_qnat + (size_t)j * 4 * A.N, A.M, A.N, A.lh, 4, 0, 0};
+                auto& v = A.lh >= 10 ? tiled : small;
+                uint32_t& blocks = A.lh >= 10 ? pk->br_blocks_tiled : pk->br_blocks_small;
+                sg.first_block = blocks;
+                blocks += ntt_bitrev_copy_blocks(A.lh, 4);
+                v.push_back(sg);
+            }
+        }
+        first.push_back(acc);
+        pk->quot_n = (uint32_t)interp.size(), pk->quot_blocks = acc;
+        pk->br_n_tiled = (uint32_t)tiled.size(), pk->br_n_small = (uint32_t)small.size();
+        if (!interp.empty()) rc = upload(ctx, pk->d_quot_args, interp.data(), interp.size() * sizeof(QuotArgs));
+        if (rc == ZKHIP_OK) rc = upload(ctx, pk->d_quot_first, first.data(), first.size() * 4);
+        if (rc == ZKHIP_OK) rc = upload(ctx, pk->d_pow_desc, pows.data(), pows.size() * sizeof(PowDesc));
+        if (rc == ZKHIP_OK && !tiled.empty()) rc = upload(ctx, pk->d_br_tiled, tiled.data(), tiled.size() * sizeof(BitrevSeg));
+        if (rc == ZKHIP_OK && !small.empty()) rc = upload(ctx, pk->d_br_small, small.data(), small.size() * sizeof(BitrevSeg));
+    }
     if (rc == ZKHIP_OK && pk->n_lu) {
         std::vector<uint32_t> rows_first, den_first;
         std::vector<ScanSeg> segs;
@@ -1534,56 +1638,41 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     ZK_TRY(transcript_sample(ctx, pk->d_tr, d_alpha, nullptr, 4));
 
     // ---- 2. quotient ----
+    {
+        KernelScope ks(ctx, "ext_powers");  // alpha powers of every chip: one launch, one lane per chip
+        hipLaunchKernelGGL(k_ext_powers_multi, dim3((unsigned)n_airs), dim3(64), 0, st, d_alpha, pk->d_pow_desc);
+    }
+    // chips without a compiled kernel: the interpreter runs over all of them in one launch
+    if (pk->quot_n) {
+        KernelScope ks(ctx, "quotient_eval");
+        const QuotMulti qm{pk->d_quot_args, pk->d_quot_first, pk->quot_n, ctx->d_tw_fwd, ctx->tw_log};
+        hipLaunchKernelGGL(k_quotient, dim3(pk->quot_blocks), dim3(QBS), (size_t)pk->quot_max_slots * QBS * 4, st, qm);
+        ZK_HIP_CHECK(ctx, hipGetLastError());
+    }
     for (size_t a = 0; a < n_airs; a++) {
         AirPlan& A = pk->airs[a];
-        {
-            KernelScope ks(ctx, "ext_powers");
-            hipLaunchKernelGGL(k_ext_powers, dim3(1), dim3(64), 0, st, d_alpha, A.prog.n_cons, 1, A.d_apow_q);
-        }
-        QuotArgs qa;
-        qa.code = A.d_code;
-        qa.n_instr = A.n_instr;
-        qa.consts = A.d_consts;
-        qa.pvs = A.d_pvs;
-        qa.apow = A.d_apow_q;
-        qa.lde = A.d_lde;
-        qa.perm = A.d_perm_lde;
-        qa.lchal = pk->d_lchal;
-        qa.expo = pk->d_exposed + 4 * A.lu_index;
-        qa.prep = A.d_prep_lde;
-        qa.q = A.d_q;
-        qa.tw_fwd = ctx->d_tw_fwd;
-        qa.inv_zh = A.d_inv_zh;
-        qa.zh = A.d_zh;
-        qa.gen = gen;
-        qa.w_n_inv = minv(two_adic_generator(A.lh));
-        qa.lh = A.lh;
-        qa.b = b;
-        qa.tw_shift = ctx->tw_log - A.h;
-        if (A.jit_fn) {
-            KernelScope ks(ctx, "quotient_eval_jit");
-            void* params[] = {(void*)&qa.lde, (void*)&qa.q,      (void*)&qa.pvs,      (void*)&qa.apow,
-                              (void*)&qa.tw_fwd, (void*)&qa.zh,  (void*)&qa.inv_zh,   (void*)&A.d_jit_tab,
-                              (void*)&qa.gen, (void*)&qa.w_n_inv, (void*)&qa.tw_shift, (void*)&qa.perm,
-                              (void*)&qa.lchal, (void*)&qa.expo, (void*)&qa.prep};
-            ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, (unsigned)((A.M + 255) / 256), 1, 1, 256, 1, 1, 0, st,
-                                                    params, nullptr));
-        } else {
-            KernelScope ks(ctx, "quotient_eval");
-            hipLaunchKernelGGL(k_quotient, dim3((unsigned)((A.M + QBS - 1) / QBS)), dim3(QBS),
-                               (size_t)A.n_slots * QBS * 4, st, qa);
-        }
-        ZK_HIP_CHECK(ctx, hipGetLastError());
-        // chunk j = rows [jN,(j+1)N) of q, bit-reversed within the chunk: bring to natural order,
-        // then extend from s_j*H to g*K (shift g/s_j) -- p3's quotient-chunk commitment
+        if (!A.jit_fn) continue;
+        QuotArgs qa = pk->quot_args_host[a];
+        const uint32_t* tw_fwd = ctx->d_tw_fwd;
+        unsigned tw_shift = ctx->tw_log - A.h;
+        KernelScope ks(ctx, "quotient_eval_jit");
+        void* params[] = {(void*)&qa.lde, (void*)&qa.q,      (void*)&qa.pvs,      (void*)&qa.apow,
+                          (void*)&tw_fwd, (void*)&qa.zh,  (void*)&qa.inv_zh,   (void*)&A.d_jit_tab,
+                          (void*)&qa.gen, (void*)&qa.w_n_inv, (void*)&tw_shift, (void*)&qa.perm,
+                          (void*)&qa.lchal, (void*)&qa.expo, (void*)&qa.prep};
+        ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, (unsigned)((A.M + 255) / 256), 1, 1, 256, 1, 1, 0, st,
+                                                params, nullptr));
+    }
+    // chunk j = rows [jN,(j+1)N) of q, bit-reversed within the chunk: bring to natural order (all chips, all chunks: one
+    // launch per kernel form), then extend from s_j*H to g*K (shift g/s_j) -- p3's quotient-chunk commitment
+    ZK_TRY(ntt_bitrev_copy_multi(ctx, pk->d_br_tiled, pk->br_n_tiled, pk->br_blocks_tiled, pk->d_br_small, pk->br_n_small,
+                                 pk->br_blocks_small));
+    for (size_t a = 0; a < n_airs; a++) {
+        AirPlan& A = pk->airs[a];
+        if (A.lh >= 12) continue;
         for (unsigned j = 0; j < nch; j++) {
-            uint32_t* nat = A.d_qnat + (size_t)j * 4 * A.N;
-            // column k of the chunk starts at q + k*M + j*N
-            ZK_TRY(ntt_bitrev_copy(ctx, A.d_q + (size_t)j * A.N, A.M, nat, A.N, A.lh, 4));
-            if (A.lh < 12) {
-                uint32_t sj = mmul(gen, host_pow(two_adic_generator(A.h), bitrev32(j, b)));
-                ZK_TRY(lde_batch(ctx, nat, A.N, A.d_qlde + (size_t)j * 4 * A.M, A.M, A.lh, b, 4, mmul(gen, minv(sj))));
-            }
+            uint32_t sj = mmul(gen, host_pow(two_adic_generator(A.h), bitrev32(j, b)));
+            ZK_TRY(lde_batch(ctx, A.d_qnat + (size_t)j * 4 * A.N, A.N, A.d_qlde + (size_t)j * 4 * A.M, A.M, A.lh, b, 4, mmul(gen, minv(sj))));
         }
     }
     ZK_TRY(lde_groups_of(2, 2 + (int)nch - 1));  // chunk j of every chip of one height in one batch

@@ -93,6 +93,15 @@ int lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* 
 int lde_batch_cols(zkhip_ctx* ctx, const uint32_t* const* d_src_cols, uint32_t* const* d_dst_cols, size_t n_cols,
                    unsigned log_n, unsigned added_bits, uint32_t shift_monty);
 int convert_repr(zkhip_ctx* ctx, uint32_t* d, size_t n, bool to_monty);
+struct BitrevSeg {
+    const uint32_t* src;
+    uint32_t* dst;
+    size_t src_stride, dst_stride;
+    uint32_t log_n, width, first_block, pad;
+};
+uint32_t ntt_bitrev_copy_blocks(unsigned log_n, uint32_t width);
+int ntt_bitrev_copy_multi(zkhip_ctx* ctx, const BitrevSeg* d_tiled, uint32_t n_tiled, uint32_t blocks_tiled,
+                          const BitrevSeg* d_small, uint32_t n_small, uint32_t blocks_small);
 int ntt_bitrev_copy(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint32_t* dst, size_t dst_stride,
                     unsigned log_n, size_t width);
 
