@@ -59,6 +59,12 @@ const char *zkhip_last_error(const zkhip_ctx *ctx);
 /* hipStream_t of the caller (e.g. the stream that produced the trace); NULL = default stream */
 int zkhip_set_stream(zkhip_ctx *ctx, void *hip_stream);
 int zkhip_sync(zkhip_ctx *ctx);
+/* Trace commit of zkhip_prove as a pipeline of `parts` column blocks (2..8; 0 or 1 = off, the default unless the
+ * environment sets ZKHIP_COMMIT_PARTS): the coset LDE of block k+1 runs on a second stream of the context while the row
+ * sponge absorbs block k.  Shortens the latency of ONE proof on an otherwise idle GPU (the LDE is memory-bound, the
+ * sponge VALU-bound); with several proofs in flight the same overlap already happens across proofs.  Proof bytes are
+ * identical either way. */
+int zkhip_set_commit_pipeline(zkhip_ctx *ctx, unsigned parts);
 
 /* ---- device memory (replaces openvm-cuda-common DeviceBuffer / VPMM pool, AGENTS.md:136) ---- */
 int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr);

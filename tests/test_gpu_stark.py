@@ -402,3 +402,33 @@ def test_final_polynomial_of_positive_length_equals_oracle(zk, ora, lfp):
             assert len(got) == 4 * z.proof_layout(params, pk.verifying_airs())["n_words"]
     with pytest.raises(Exception, match="shorter than the final polynomial"):
         z.ProvingKey(zk, (1, lfp, 7, 2, 3), [_fib(lfp - 1)] if lfp > 1 else [dict(_fib(1), log_height=0)])
+
+
+@pytest.mark.parametrize("parts", [2, 3, 4, 7])
+def test_pipelined_commit_gives_identical_proofs(zk, ora, parts):
+    """zkhip_set_commit_pipeline: the LDE of column block k+1 on the side stream beside the sponge step of block k
+    (state parked in HBM) changes nothing in the proof -- bytes equal the oracle's, back to back with the plain form."""
+    params = (1, 0, 20, 6, 6)
+    log_n, width = 16, 130
+    sa = air.SyntheticAir(width=width, n_free=30, n_bool=6, n_boundary=3, seed=2)
+    tr, pv = sa.gen_trace(log_n, seed=4)
+    ftr, fpv = air.fibonacci_trace(log_n)
+    s, t = air.lookup_traces(12, 6, seed=2)   # shorter chips with a bus: extended on the main stream first
+    nopv = np.zeros(0, np.uint32)
+    airs = [dict(program=sa.program(), log_height=log_n, width=width, n_pvs=len(pv), trace=tr, pvs=pv),
+            dict(program=air.lookup_sender_air().program(), log_height=12, width=3, n_pvs=0, trace=s, pvs=nopv),
+            dict(program=air.fibonacci_air().program(), log_height=log_n, width=2, n_pvs=3, trace=ftr, pvs=fpv),
+            dict(program=air.lookup_table_air().program(), log_height=6, width=3, n_pvs=0, trace=t, pvs=nopv)]
+    pk = z.ProvingKey(zk, params, airs)
+    d = [zk.upload(a["trace"].reshape(-1)) for a in airs]
+    pvs = [a["pvs"] for a in airs]
+    plain = pk.prove(d, pvs)
+    try:
+        zk.set_commit_pipeline(parts)
+        piped = pk.prove(d, pvs)
+        again = pk.prove(d, pvs)
+    finally:
+        zk.set_commit_pipeline(0)
+    assert piped == plain and again == plain
+    assert plain == ora.stark_prove(params, airs, cap_words=len(plain) // 4 + 16).tobytes()
+    pk.close()

@@ -82,6 +82,7 @@ def load_library():
         "zkhip_last_error": (C.c_char_p, [vp]),
         "zkhip_set_stream": (C.c_int, [vp, vp]),
         "zkhip_sync": (C.c_int, [vp]),
+        "zkhip_set_commit_pipeline": (C.c_int, [vp, C.c_uint]),
         "zkhip_malloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
         "zkhip_free": (C.c_int, [vp, vp]),
         "zkhip_h2d": (C.c_int, [vp, vp, vp, sz]),
@@ -185,6 +186,10 @@ class Context:
 
     def sync(self):
         self._check(self.lib.zkhip_sync(self.h))
+
+    def set_commit_pipeline(self, parts):
+        """Trace commit as a pipeline of `parts` column blocks (LDE of block k+1 beside the sponge of block k); 0 = off."""
+        self._check(self.lib.zkhip_set_commit_pipeline(self.h, parts))
 
     # ---- data movement -----------------------------------------------------------------------
     def upload(self, arr_canonical):

@@ -124,6 +124,9 @@ int zkhip_ctx_create(int device, zkhip_ctx** out) {
         delete ctx;
         return ZKHIP_ERR_HIP;
     }
+    // pipelined trace commit (prover.hip): ZKHIP_COMMIT_PARTS=k column blocks, 0 / 1 = off; zkhip_set_commit_pipeline overrides
+    ctx->commit_parts = getenv("ZKHIP_COMMIT_PARTS") ? (unsigned)atoi(getenv("ZKHIP_COMMIT_PARTS")) : 0u;
+    if (ctx->commit_parts > 8) ctx->commit_parts = 8;
     *out = ctx;
     return ZKHIP_OK;
 }
@@ -137,7 +140,17 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     if (ctx->d_tw_inv) hipFree(ctx->d_tw_inv);
     for (int i = 0; i < 8; i++)
         if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
+    if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
+    for (auto& e : ctx->pipe_ev)
+        if (e) hipEventDestroy(e);
     delete ctx;
+}
+
+int zkhip_set_commit_pipeline(zkhip_ctx* ctx, unsigned parts) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || parts > 8) return ZKHIP_ERR_INVALID;
+    ctx->commit_parts = parts;
+    return ZKHIP_OK;
 }
 
 const char* zkhip_last_error(const zkhip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "no context"; }

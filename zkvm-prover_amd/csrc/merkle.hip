@@ -50,6 +50,33 @@ __global__ __launch_bounds__(256) void k_hash_rows(const uint32_t* const* __rest
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
+// One step of the same sponge over a block of columns, the 16-word state parked in HBM between steps ([16][rows]: a
+// lane's loads and stores are coalesced with its neighbours').  Lets the trace commit run as a pipeline: while the
+// sponge absorbs block k the LDE of block k+1 is computed on another stream.
+__global__ __launch_bounds__(256) void k_hash_rows_part(const uint32_t* const* __restrict__ cols, uint32_t n_cols, size_t n_rows,
+                                                        uint32_t* __restrict__ state, int first, int last,
+                                                        uint32_t* __restrict__ out) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    uint32_t s[16];
+    if (first) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = 0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = state[(size_t)i * n_rows + row];
+    }
+    absorb_rows(s, cols, n_cols, row);
+    if (last) {
+        uint4* o = reinterpret_cast<uint4*>(out + (size_t)row * 8);
+        o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+        o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) state[(size_t)i * n_rows + row] = s[i];
+    }
+}
+
 // next[i] = compress(prev[2i], prev[2i+1]); with injected matrices: compress(that, sponge(row i))
 __global__ __launch_bounds__(256) void k_compress_layer(const uint32_t* __restrict__ prev,
                                                         uint32_t* __restrict__ next, size_t n_next) {
@@ -285,6 +312,19 @@ int merkle_plan_leaves(zkhip_ctx* ctx, unsigned log_height, uint32_t* d_digests,
         off += (size_t)1 << (log_height - l);
     }
     *out = t;
+    return ZKHIP_OK;
+}
+
+int merkle_leaves_part(zkhip_ctx* ctx, zkhip_tree* t, size_t col_begin, size_t col_end, bool first, bool last, uint32_t* d_state) {
+    const unsigned lh = t->log_height;
+    const size_t n = (size_t)1 << lh;
+    if (col_begin % 8 || col_end > t->level_cnt[lh] || col_begin >= col_end || (!last && (col_end % 8))) return ZKHIP_ERR_INVALID;
+    const uint32_t* const* d_ptrs = (const uint32_t* const*)t->d_colptrs;
+    KernelScope ks(ctx, "poseidon2_hash_rows");
+    hipLaunchKernelGGL(k_hash_rows_part, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d_ptrs + t->level_off[lh] + col_begin, (uint32_t)(col_end - col_begin), n, d_state, first ? 1 : 0,
+                       last ? 1 : 0, t->d_digests);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
 }
 

@@ -1587,12 +1587,55 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     };
 
     // ---- 1. trace commit: coset LDE + Merkle ----
-    ZK_TRY(lde_groups_of(0, 0));  // chips of >= 2^12 rows, one batch per height
-    for (size_t a = 0; a < n_airs; a++) {
-        AirPlan& A = pk->airs[a];
-        if (A.lh < 12) ZK_TRY(lde_batch(ctx, d_traces[a], A.N, A.d_lde, A.M, A.lh, b, A.width, gen));
+    // Pipelined form (zkhip_set_commit_pipeline): the tallest chips' columns are extended block by block on the side stream
+    // while the main stream's row sponge absorbs the blocks already done (state parked in HBM between blocks).
+    const zkhip_pk::LdeGroup* top = nullptr;
+    if (ctx->commit_parts >= 2)
+        for (const auto& g : pk->lde_groups)
+            if (g.kind == 0 && g.lh + b == hmax && g.lh >= 16 && g.n_cols >= 16 * ctx->commit_parts) top = &g;
+    bool leaves_ready = false;
+    if (top) {
+        if (!ctx->side_stream) {
+            ZK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            for (auto& e : ctx->pipe_ev) ZK_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        const unsigned parts = ctx->commit_parts;
+        const uint32_t per = ((top->n_cols + parts - 1) / parts + 7u) & ~7u;  // block boundaries on sponge-rate multiples
+        void* d_state = nullptr;
+        ZK_TRY(get_scratch(ctx, 6, ((size_t)16 << hmax) * 4, &d_state));
+        // the shorter chips first, on the main stream (the NTT scratch buffers of the context serve one stream at a time)
+        for (const auto& g : pk->lde_groups)
+            if (g.kind == 0 && &g != top)
+                ZK_TRY(lde_batch_cols(ctx, pk->d_open_ptrs + pk->open_total_cols + g.first, pk->d_lde_dst + g.first, g.n_cols, g.lh, b, gen));
+        for (size_t a = 0; a < n_airs; a++) {
+            AirPlan& A = pk->airs[a];
+            if (A.lh < 12) ZK_TRY(lde_batch(ctx, d_traces[a], A.N, A.d_lde, A.M, A.lh, b, A.width, gen));
+        }
+        // the side stream starts after everything already queued on the main stream (pointer tables, previous proof)
+        ZK_HIP_CHECK(ctx, hipEventRecord(ctx->pipe_ev[8], st));
+        ZK_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->pipe_ev[8], 0));
+        unsigned k = 0;
+        for (uint32_t c0 = 0; c0 < top->n_cols; c0 += per, k++) {
+            const uint32_t c1 = std::min(top->n_cols, c0 + per);
+            ctx->stream = ctx->side_stream;
+            int rc = lde_batch_cols(ctx, pk->d_open_ptrs + pk->open_total_cols + top->first + c0, pk->d_lde_dst + top->first + c0,
+                                    c1 - c0, top->lh, b, gen);
+            hipError_t he = hipEventRecord(ctx->pipe_ev[k], ctx->side_stream);
+            ctx->stream = st;
+            if (rc != ZKHIP_OK) return rc;
+            ZK_HIP_CHECK(ctx, he);
+            ZK_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->pipe_ev[k], 0));
+            ZK_TRY(merkle_leaves_part(ctx, pk->t_main, c0, c1, c0 == 0, c1 == top->n_cols, (uint32_t*)d_state));
+        }
+        leaves_ready = true;
+    } else {
+        ZK_TRY(lde_groups_of(0, 0));  // chips of >= 2^12 rows, one batch per height
+        for (size_t a = 0; a < n_airs; a++) {
+            AirPlan& A = pk->airs[a];
+            if (A.lh < 12) ZK_TRY(lde_batch(ctx, d_traces[a], A.N, A.d_lde, A.M, A.lh, b, A.width, gen));
+        }
     }
-    ZK_TRY(merkle_build(ctx, pk->t_main, false));
+    ZK_TRY(merkle_build(ctx, pk->t_main, leaves_ready));
     const uint32_t* d_root_main = zkhip_tree_root_device(pk->t_main);
     ZK_TRY(transcript_observe(ctx, pk->d_tr, d_root_main, 8, false));
 

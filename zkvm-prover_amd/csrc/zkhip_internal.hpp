@@ -42,6 +42,11 @@ struct zkhip_ctx {
     std::vector<zk::PendingEvent> pending;
     std::map<std::string, zk::ProfileEntry> stats;
     int cu_count = 256;
+    // trace commit as a pipeline (prover.hip): the LDE of column block k+1 runs on `side_stream` while the row sponge
+    // absorbs block k on the main stream.  commit_parts = number of column blocks (0/1 = off).
+    hipStream_t side_stream = nullptr;
+    hipEvent_t pipe_ev[10] = {};
+    unsigned commit_parts = 0;
 };
 
 namespace zk {
@@ -131,6 +136,10 @@ int merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip
 int merkle_plan(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, uint32_t* d_digests, zkhip_tree** out);
 int merkle_plan_leaves(zkhip_ctx* ctx, unsigned log_height, uint32_t* d_digests, zkhip_tree** out);
 int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready);
+// one step of the leaf sponge over columns [col_begin, col_end) of the tallest matrices (col_begin a multiple of 8):
+// `first` starts from the zero state, otherwise the 16-word state of every row is read from d_state ([16][rows]);
+// `last` writes the leaf digests, otherwise the state goes back to d_state
+int merkle_leaves_part(zkhip_ctx* ctx, zkhip_tree* t, size_t col_begin, size_t col_end, bool first, bool last, uint32_t* d_state);
 size_t merkle_digest_count(unsigned log_height);
 // gathers openings for n leaf indices (device array of u32 indices) into a device buffer (canonical)
 int merkle_open_device(zkhip_ctx* ctx, const zkhip_tree* tree, const uint32_t* d_indices, unsigned index_shift,
