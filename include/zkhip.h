@@ -115,6 +115,31 @@ int zkhip_poseidon2_air_tracegen(zkhip_ctx *ctx, const uint32_t *d_inputs, size_
 int zkhip_range_counts_tracegen(zkhip_ctx *ctx, const uint32_t *d_values, size_t n, unsigned log_table,
                                 uint32_t *d_counts, int accumulate);
 
+/* Multiplicity column of a range-TUPLE table (OpenVM RangeTupleCheckerChip<2>; the chunk circuit's rv32m / bigint
+ * extensions use sizes [256, 8192], crates/circuits/chunk-circuit/openvm.toml `range_tuple_checker_sizes`): d_counts[x * size_y
+ * + y] = #{ i < n : (d_x[i], d_y[i]) == (x, y) }.  d_x / d_y: n Montgomery words each (requesting trace columns);
+ * d_counts: size_x * size_y Montgomery words (a power of two <= 2^27) = the chip's whole trace.  Synchronises;
+ * ZKHIP_ERR_INVALID if a request lies outside the table. */
+int zkhip_range_tuple_counts_tracegen(zkhip_ctx *ctx, const uint32_t *d_x, const uint32_t *d_y, size_t n, uint32_t size_x,
+                                      uint32_t size_y, uint32_t *d_counts, int accumulate);
+/* The two multiplicity columns of a bitwise-operation lookup table (OpenVM BitwiseOperationLookupChip<num_bits>, 8 in the
+ * reference's circuits): rows = all (x, y) with x, y < 2^num_bits, row (x << num_bits) + y; column 0 counts the range requests
+ * (d_op[i] == 0), column 1 the XOR requests (d_op[i] == 1; the requester's z = x ^ y is what the table's preprocessed column holds).
+ * d_x, d_y, d_op: n Montgomery words; d_trace: 2 columns of 2^(2 num_bits) Montgomery words. */
+int zkhip_bitwise_lookup_tracegen(zkhip_ctx *ctx, const uint32_t *d_x, const uint32_t *d_y, const uint32_t *d_op, size_t n,
+                                  unsigned num_bits, uint32_t *d_trace, int accumulate);
+/* Trace of a volatile memory boundary chip (OpenVM VolatileBoundaryChip): one row per touched address, SORTED by
+ * (address space, pointer) on the device (radix sort), then zero rows up to 2^log_height.  Columns
+ * (ZKHIP_MEMORY_BOUNDARY_WIDTH = 8, stride 2^log_height, Montgomery): address space, pointer, initial data, final data,
+ * final timestamp, is_valid, gap_lo, gap_hi -- (key_next - key - 1) split at 16 bits with key = as * 2^pointer_bits + pointer,
+ * the sortedness witness the range checker receives (0 on the last valid row).  d_addr_space / d_pointer / d_timestamp:
+ * n plain integers (addr_space < 2^as_bits, pointer < 2^pointer_bits); d_initial / d_final: n Montgomery words.
+ * ZKHIP_ERR_INVALID for out-of-range or duplicate addresses or n > 2^log_height. */
+#define ZKHIP_MEMORY_BOUNDARY_WIDTH 8
+int zkhip_memory_boundary_tracegen(zkhip_ctx *ctx, const uint32_t *d_addr_space, const uint32_t *d_pointer, const uint32_t *d_initial,
+                                   const uint32_t *d_final, const uint32_t *d_timestamp, size_t n, unsigned as_bits,
+                                   unsigned pointer_bits, unsigned log_height, uint32_t *d_trace);
+
 typedef struct {
     const uint32_t *data; /* device, column-major, Montgomery */
     size_t stride;

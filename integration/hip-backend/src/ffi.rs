@@ -14,6 +14,7 @@ pub const ZKHIP_ERR_VERIFY: c_int = -7;
 pub const ZKHIP_ERR_CONSTRAINT: c_int = -8;
 pub const ZKHIP_DIGEST_WORDS: usize = 8;
 pub const ZKHIP_POSEIDON2_AIR_WIDTH: usize = 298;
+pub const ZKHIP_MEMORY_BOUNDARY_WIDTH: usize = 8;
 pub const ZKHIP_MAX_LOG_FINAL_POLY: u32 = 8;
 pub const ZKHIP_V1_SINGLE: c_int = 0;
 pub const ZKHIP_V1_VEC: c_int = 1;
@@ -146,6 +147,14 @@ extern "C" {
                                         d_trace: *mut u32) -> c_int;
     pub fn zkhip_range_counts_tracegen(ctx: *mut zkhip_ctx, d_values: *const u32, n: usize, log_table: c_uint,
                                        d_counts: *mut u32, accumulate: c_int) -> c_int;
+
+    pub fn zkhip_range_tuple_counts_tracegen(ctx: *mut zkhip_ctx, d_x: *const u32, d_y: *const u32, n: usize, size_x: u32, size_y: u32,
+                                             d_counts: *mut u32, accumulate: c_int) -> c_int;
+    pub fn zkhip_bitwise_lookup_tracegen(ctx: *mut zkhip_ctx, d_x: *const u32, d_y: *const u32, d_op: *const u32, n: usize,
+                                         num_bits: c_uint, d_trace: *mut u32, accumulate: c_int) -> c_int;
+    pub fn zkhip_memory_boundary_tracegen(ctx: *mut zkhip_ctx, d_addr_space: *const u32, d_pointer: *const u32, d_initial: *const u32,
+                                          d_final: *const u32, d_timestamp: *const u32, n: usize, as_bits: c_uint, pointer_bits: c_uint,
+                                          log_height: c_uint, d_trace: *mut u32) -> c_int;
 
     // Merkle
     pub fn zkhip_merkle_commit(ctx: *mut zkhip_ctx, mats: *const zkhip_matrix, n_mats: usize, tree: *mut *mut zkhip_tree,

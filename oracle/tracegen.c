@@ -21,3 +21,85 @@ size_t ora_range_counts(const uint32_t *values, size_t n, unsigned log_table, ui
     }
     return bad;
 }
+
+/* range-tuple table (OpenVM RangeTupleCheckerChip<2>): counts[x * size_y + y], canonical; returns the requests out of range */
+size_t ora_range_tuple_counts(const uint32_t *xs, const uint32_t *ys, size_t n, uint32_t size_x, uint32_t size_y, uint32_t *counts,
+                              int accumulate) {
+    const size_t T = (size_t)size_x * size_y;
+    size_t bad = 0;
+    if (!accumulate)
+        for (size_t v = 0; v < T; v++) counts[v] = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (xs[i] >= size_x || ys[i] >= size_y) {
+            bad++;
+            continue;
+        }
+        uint32_t *c = &counts[(size_t)xs[i] * size_y + ys[i]];
+        *c = ora_add(*c, 1);
+    }
+    return bad;
+}
+
+/* bitwise-operation lookup table (OpenVM BitwiseOperationLookupChip<bits>): trace = 2 columns of 2^(2 bits) rows,
+ * row (x << bits) + y; column op (0 range, 1 xor) counts the requests */
+size_t ora_bitwise_lookup_counts(const uint32_t *xs, const uint32_t *ys, const uint32_t *ops, size_t n, unsigned bits, uint32_t *trace,
+                                 int accumulate) {
+    const size_t R = (size_t)1 << (2 * bits);
+    size_t bad = 0;
+    if (!accumulate)
+        for (size_t v = 0; v < 2 * R; v++) trace[v] = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (xs[i] >> bits || ys[i] >> bits || ops[i] > 1) {
+            bad++;
+            continue;
+        }
+        uint32_t *c = &trace[ops[i] * R + ((size_t)xs[i] << bits) + ys[i]];
+        *c = ora_add(*c, 1);
+    }
+    return bad;
+}
+
+/* volatile memory boundary chip (OpenVM VolatileBoundaryChip): rows sorted by (address space, pointer); 8 columns with
+ * stride 2^log_height: as, ptr, initial, final, final timestamp, is_valid, gap_lo, gap_hi (gap = key_next - key - 1, key =
+ * as * 2^ptr_bits + ptr, 16-bit low limb); returns the number of out-of-range or duplicated addresses */
+#include <stdlib.h>
+typedef struct {
+    uint64_t key;
+    uint32_t idx;
+} ora_bkey;
+static int ora_bkey_cmp(const void *a, const void *b) {
+    const ora_bkey *x = (const ora_bkey *)a, *y = (const ora_bkey *)b;
+    return x->key < y->key ? -1 : x->key > y->key ? 1 : (x->idx < y->idx ? -1 : x->idx > y->idx);
+}
+size_t ora_memory_boundary_trace(const uint32_t *as, const uint32_t *ptr, const uint32_t *init, const uint32_t *fin, const uint32_t *ts,
+                                 size_t n, unsigned as_bits, unsigned ptr_bits, unsigned log_height, uint32_t *trace) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    ora_bkey *k = (ora_bkey *)malloc((n + 1) * sizeof(ora_bkey));
+    for (size_t i = 0; i < n; i++) {
+        if ((as_bits < 32 && (as[i] >> as_bits)) || (ptr_bits < 32 && (ptr[i] >> ptr_bits))) bad++;
+        k[i].key = ((uint64_t)as[i] << 32) | ptr[i];
+        k[i].idx = (uint32_t)i;
+    }
+    qsort(k, n, sizeof(ora_bkey), ora_bkey_cmp);
+    for (size_t q = 0; q < 8; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n; r++) {
+        const uint32_t j = k[r].idx;
+        trace[0 * N + r] = (uint32_t)(k[r].key >> 32) % ORA_P;
+        trace[1 * N + r] = (uint32_t)k[r].key % ORA_P;
+        trace[2 * N + r] = init[j];
+        trace[3 * N + r] = fin[j];
+        trace[4 * N + r] = ts[j] % ORA_P;
+        trace[5 * N + r] = 1;
+        if (r + 1 < n) {
+            if (k[r + 1].key == k[r].key) bad++;
+            const uint64_t a = ((k[r].key >> 32) << ptr_bits) + (uint32_t)k[r].key, b = ((k[r + 1].key >> 32) << ptr_bits) + (uint32_t)k[r + 1].key;
+            const uint64_t gap = b - a - 1;
+            trace[6 * N + r] = (uint32_t)(gap & 0xffffu);
+            trace[7 * N + r] = (uint32_t)((gap >> 16) % ORA_P);
+        }
+    }
+    free(k);
+    return bad;
+}

@@ -89,6 +89,14 @@ void ora_poseidon2_air_trace(const uint32_t *inputs, size_t n_perms, unsigned lo
 /* multiplicity column of a range-check table: counts[v] (+)= #{i : values[i] == v}, canonical; returns #values out of range */
 size_t ora_range_counts(const uint32_t *values, size_t n, unsigned log_table, uint32_t *counts, int accumulate);
 
+/* three more periphery chips' traces (oracle/tracegen.c): range-tuple table, bitwise-operation lookup, volatile memory boundary */
+size_t ora_range_tuple_counts(const uint32_t *xs, const uint32_t *ys, size_t n, uint32_t size_x, uint32_t size_y, uint32_t *counts,
+                              int accumulate);
+size_t ora_bitwise_lookup_counts(const uint32_t *xs, const uint32_t *ys, const uint32_t *ops, size_t n, unsigned bits, uint32_t *trace,
+                                 int accumulate);
+size_t ora_memory_boundary_trace(const uint32_t *as, const uint32_t *ptr, const uint32_t *init, const uint32_t *fin, const uint32_t *ts,
+                                 size_t n, unsigned as_bits, unsigned ptr_bits, unsigned log_height, uint32_t *trace);
+
 /* ---- MerkleTreeMmcs over column-major matrices of (possibly) mixed heights ---- */
 typedef struct {
     const uint32_t *data; /* column-major */

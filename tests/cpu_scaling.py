@@ -5,7 +5,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ may drive the oracle; tools/ may not
 CHILD = r"""
 import sys, time, os
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))

@@ -48,6 +48,37 @@ def range_counts(values, log_table, counts=None):
     return counts, int(bad)
 
 
+def range_tuple_counts(xs, ys, size_x, size_y, counts=None):
+    xs, ys = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (xs, ys))
+    acc = counts is not None
+    counts = np.ascontiguousarray(counts, dtype=np.uint32).copy() if acc else np.zeros(size_x * size_y, np.uint32)
+    l = lib()
+    l.ora_range_tuple_counts.restype = C.c_size_t
+    l.ora_range_tuple_counts.argtypes = [u32p_t(), u32p_t(), C.c_size_t, C.c_uint32, C.c_uint32, u32p_t(), C.c_int]
+    bad = l.ora_range_tuple_counts(p32(xs), p32(ys), len(xs), size_x, size_y, p32(counts), 1 if acc else 0)
+    return counts, int(bad)
+
+
+def bitwise_lookup_counts(xs, ys, ops, bits=8):
+    xs, ys, ops = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (xs, ys, ops))
+    tr = np.zeros((2, 1 << (2 * bits)), np.uint32)
+    l = lib()
+    l.ora_bitwise_lookup_counts.restype = C.c_size_t
+    l.ora_bitwise_lookup_counts.argtypes = [u32p_t(), u32p_t(), u32p_t(), C.c_size_t, C.c_uint, u32p_t(), C.c_int]
+    bad = l.ora_bitwise_lookup_counts(p32(xs), p32(ys), p32(ops), len(xs), bits, p32(tr), 0)
+    return tr, int(bad)
+
+
+def memory_boundary_trace(as_, ptr, init, fin, ts, as_bits, ptr_bits, log_height):
+    as_, ptr, init, fin, ts = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (as_, ptr, init, fin, ts))
+    tr = np.zeros((8, 1 << log_height), np.uint32)
+    l = lib()
+    l.ora_memory_boundary_trace.restype = C.c_size_t
+    l.ora_memory_boundary_trace.argtypes = [u32p_t()] * 5 + [C.c_size_t, C.c_uint, C.c_uint, C.c_uint, u32p_t()]
+    bad = l.ora_memory_boundary_trace(p32(as_), p32(ptr), p32(init), p32(fin), p32(ts), len(as_), as_bits, ptr_bits, log_height, p32(tr))
+    return tr, int(bad)
+
+
 def poseidon2_air_trace(inputs, log_height):
     """Oracle trace (298 x 2^log_height, canonical, column-major) of the Poseidon2 AIR for inputs [n][16]."""
     inputs = np.ascontiguousarray(inputs, dtype=np.uint32).reshape(-1, 16)

@@ -1,0 +1,120 @@
+"""GPU: three more device-side trace generators (csrc/tracegen_tables.hip) -- range-tuple table, bitwise-operation lookup,
+volatile memory boundary -- cell for cell against oracle/tracegen.c, and proven end to end from the device-resident traces
+(proof bytes == the oracle's for the same AIR set)."""
+import numpy as np
+import pytest
+import torch
+
+import zkvm_prover_amd as z
+from zkvm_prover_amd import air
+
+pytestmark = pytest.mark.gpu
+P = 2013265921
+NOPV = np.zeros(0, np.uint32)
+PARAMS = (1, 0, 12, 4, 4)
+
+
+def test_range_tuple_counts(zk, ora):
+    rng = np.random.default_rng(0)
+    for size_x, size_y, n in [(256, 8192, 300000), (4, 8, 1000), (16, 16, 0)]:
+        xs = rng.integers(0, size_x, n).astype(np.uint32)
+        ys = rng.integers(0, size_y, n).astype(np.uint32)
+        exp, bad = ora.range_tuple_counts(xs, ys, size_x, size_y)
+        assert bad == 0
+        dx, dy = zk.upload(xs), zk.upload(ys)
+        got = zk.download(zk.range_tuple_counts_tracegen(dx, dy, size_x, size_y))
+        assert (got == exp).all() and int(exp.astype(np.int64).sum()) == n
+        # accumulate a second batch of requests on top
+        got2 = zk.download(zk.range_tuple_counts_tracegen(dy % size_x if False else dx, dy, size_x, size_y,
+                                                          t_counts=zk.upload(exp), accumulate=True))
+        assert (got2 == ora.range_tuple_counts(xs, ys, size_x, size_y, counts=exp)[0]).all()
+    with pytest.raises(z.ZkhipError):
+        zk.range_tuple_counts_tracegen(zk.upload(np.array([3, 256], np.uint32)), zk.upload(np.array([1, 1], np.uint32)), 256, 8192)
+
+
+def test_bitwise_lookup_counts(zk, ora):
+    rng = np.random.default_rng(1)
+    n = 200000
+    xs, ys = rng.integers(0, 256, n).astype(np.uint32), rng.integers(0, 256, n).astype(np.uint32)
+    ops = rng.integers(0, 2, n).astype(np.uint32)
+    exp, bad = ora.bitwise_lookup_counts(xs, ys, ops, 8)
+    assert bad == 0
+    got = zk.download(zk.bitwise_lookup_tracegen(zk.upload(xs), zk.upload(ys), zk.upload(ops), 8)).reshape(2, -1)
+    assert (got == exp).all()
+    assert int(got[1].astype(np.int64).sum()) == int(ops.sum())
+    with pytest.raises(z.ZkhipError):
+        zk.bitwise_lookup_tracegen(zk.upload(np.array([256], np.uint32)), zk.upload(np.array([0], np.uint32)),
+                                   zk.upload(np.array([0], np.uint32)), 8)
+
+
+@pytest.mark.parametrize("n,log_height", [(0, 3), (1, 0), (5, 3), (1000, 10), (70000, 17)])
+def test_memory_boundary_trace_sorted_on_device(zk, ora, n, log_height):
+    rng = np.random.default_rng(n)
+    keys = rng.choice(1 << 22, size=n, replace=False) if n else np.zeros(0, np.int64)
+    as_ = (keys >> 20).astype(np.uint32) + 1           # address spaces 1..4
+    ptr = ((keys & ((1 << 20) - 1)) * 37 % (1 << 29)).astype(np.uint32)
+    # distinct (as, ptr) pairs are guaranteed by distinct keys only if the map is injective per address space
+    _, first = np.unique((as_.astype(np.int64) << 32) | ptr, return_index=True)
+    keep = np.sort(first)
+    as_, ptr = as_[keep], ptr[keep]
+    n = len(as_)
+    init, fin = ora.rand_field(rng, n), ora.rand_field(rng, n)
+    ts = rng.integers(0, 1 << 29, n).astype(np.uint32)
+    exp, bad = ora.memory_boundary_trace(as_, ptr, init, fin, ts, 3, 29, log_height)
+    assert bad == 0
+    dev = zk.device
+    t_as = torch.from_numpy(as_.view(np.int32)).to(dev)
+    t_ptr = torch.from_numpy(ptr.view(np.int32)).to(dev)
+    t_ts = torch.from_numpy(ts.view(np.int32)).to(dev)
+    got = zk.download(zk.memory_boundary_tracegen(t_as, t_ptr, zk.upload(init), zk.upload(fin), t_ts, 3, 29, log_height))
+    got = got.reshape(8, -1)
+    assert (got == exp).all()
+    # rows are sorted and the AIR's own constraints hold on the generated trace
+    k = got[0, :n].astype(np.int64) * (1 << 29) + got[1, :n]
+    assert (np.diff(k) > 0).all() and (got[5, :n] == 1).all() and (got[:, n:] == 0).all()
+    if log_height <= 10:
+        assert air.check_trace(air.memory_boundary_air(29).program(), got, NOPV) == []
+
+
+def test_memory_boundary_rejects_duplicates_and_overflow(zk):
+    dev = zk.device
+    as_ = torch.tensor([1, 1], dtype=torch.int32, device=dev)
+    ptr = torch.tensor([8, 8], dtype=torch.int32, device=dev)
+    v = zk.upload(np.array([1, 2], np.uint32))
+    with pytest.raises(z.ZkhipError):
+        zk.memory_boundary_tracegen(as_, ptr, v, v, ptr, 3, 29, 2)
+    with pytest.raises(z.ZkhipError):   # more records than rows
+        zk.memory_boundary_tracegen(as_, torch.tensor([8, 9], dtype=torch.int32, device=dev), v, v, ptr, 3, 29, 0)
+
+
+def test_tables_proven_from_device_generated_traces(zk, ora):
+    """Requester chips + the two lookup tables, the tables' traces generated on the device from the requesters' columns where
+    they lie: the proof equals the oracle's proof of the same AIR set with host-generated tables."""
+    rng = np.random.default_rng(5)
+    sx, sy, bits = 16, 64, 4
+    nu = 1 << 9
+    u = np.zeros((3, nu), np.uint32)
+    u[0], u[1] = rng.integers(0, sx, nu), rng.integers(0, sy, nu)
+    u[2] = (u[0].astype(np.int64) * u[1] % P).astype(np.uint32)
+    w = np.zeros((4, nu), np.uint32)
+    w[0], w[1], w[3] = rng.integers(0, 1 << bits, nu), rng.integers(0, 1 << bits, nu), rng.integers(0, 2, nu)
+    w[2] = (w[0] ^ w[1]) * w[3]
+    tuple_prep, bw_prep = air.range_tuple_prep(sx, sy), air.bitwise_lookup_prep(bits)
+    d_u, d_w = zk.upload(u.reshape(-1)), zk.upload(w.reshape(-1))
+    d_tuple = zk.range_tuple_counts_tracegen(d_u[0:nu], d_u[nu:2 * nu], sx, sy)
+    d_bw = zk.bitwise_lookup_tracegen(d_w[0:nu], d_w[nu:2 * nu], d_w[3 * nu:4 * nu], bits)
+    t_tuple = zk.download(d_tuple).reshape(1, -1)
+    t_bw = zk.download(d_bw).reshape(2, -1)
+    assert (t_tuple == ora.range_tuple_counts(u[0], u[1], sx, sy)[0]).all()
+    assert (t_bw == ora.bitwise_lookup_counts(w[0], w[1], w[3], bits)[0]).all()
+    airs = [dict(program=air.range_tuple_user_air().program(), log_height=9, width=3, n_pvs=0, trace=u, pvs=NOPV),
+            dict(program=air.range_tuple_table_air(sx, sy).program(), log_height=10, width=1, n_pvs=0, trace=t_tuple, pvs=NOPV, prep=tuple_prep),
+            dict(program=air.bitwise_user_air().program(), log_height=9, width=4, n_pvs=0, trace=w, pvs=NOPV),
+            dict(program=air.bitwise_lookup_air(bits).program(), log_height=2 * bits, width=2, n_pvs=0, trace=t_bw, pvs=NOPV, prep=bw_prep)]
+    for a in airs:
+        assert air.check_trace(a["program"], a["trace"], a["pvs"], a.get("prep")) == []
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    proof = pk.prove([d_u, d_tuple, d_w, d_bw], [NOPV] * 4)
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 4, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    pk.close()

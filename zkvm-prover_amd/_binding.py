@@ -94,6 +94,9 @@ def load_library():
         "zkhip_poseidon2_permute_batch": (C.c_int, [vp, vp, sz]),
         "zkhip_poseidon2_air_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
         "zkhip_range_counts_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, C.c_int]),
+        "zkhip_range_tuple_counts_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_int]),
+        "zkhip_bitwise_lookup_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, C.c_int]),
+        "zkhip_memory_boundary_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint, C.c_uint, vp]),
         "zkhip_merkle_commit": (C.c_int, [vp, C.POINTER(_Matrix), sz, C.POINTER(vp), u32p]),
         "zkhip_tree_root_device": (vp, [vp]),
         "zkhip_tree_log_height": (C.c_uint, [vp]),
@@ -250,6 +253,39 @@ class Context:
         self._check(self.lib.zkhip_range_counts_tracegen(self.h, C.c_void_p(t_values.data_ptr()), t_values.numel(), log_table,
                                                          C.c_void_p(t_counts.data_ptr()), 1 if accumulate else 0))
         return t_counts
+
+    def range_tuple_counts_tracegen(self, t_x, t_y, size_x, size_y, t_counts=None, accumulate=False):
+        """Multiplicity column (size_x * size_y Montgomery words) of a range-tuple table for the requests (t_x[i], t_y[i])."""
+        import torch
+
+        if t_counts is None:
+            t_counts = torch.empty(size_x * size_y, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_range_tuple_counts_tracegen(self.h, C.c_void_p(t_x.data_ptr()), C.c_void_p(t_y.data_ptr()), t_x.numel(),
+                                                               size_x, size_y, C.c_void_p(t_counts.data_ptr()), 1 if accumulate else 0))
+        return t_counts
+
+    def bitwise_lookup_tracegen(self, t_x, t_y, t_op, num_bits=8, t_trace=None, accumulate=False):
+        """The two multiplicity columns (range, xor) of a bitwise-operation lookup table: 2 x 2^(2 num_bits) words."""
+        import torch
+
+        if t_trace is None:
+            t_trace = torch.empty(2 << (2 * num_bits), dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_bitwise_lookup_tracegen(self.h, C.c_void_p(t_x.data_ptr()), C.c_void_p(t_y.data_ptr()),
+                                                           C.c_void_p(t_op.data_ptr()), t_x.numel(), num_bits,
+                                                           C.c_void_p(t_trace.data_ptr()), 1 if accumulate else 0))
+        return t_trace
+
+    def memory_boundary_tracegen(self, t_as, t_ptr, t_init, t_final, t_ts, as_bits, pointer_bits, log_height):
+        """8-column trace of the volatile memory boundary chip, rows sorted by address on the device.
+        t_as / t_ptr / t_ts: plain integers (int32 tensors); t_init / t_final: Montgomery words."""
+        import torch
+
+        out = torch.empty(8 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_memory_boundary_tracegen(self.h, C.c_void_p(t_as.data_ptr()), C.c_void_p(t_ptr.data_ptr()),
+                                                            C.c_void_p(t_init.data_ptr()), C.c_void_p(t_final.data_ptr()),
+                                                            C.c_void_p(t_ts.data_ptr()), t_as.numel(), as_bits, pointer_bits, log_height,
+                                                            C.c_void_p(out.data_ptr())))
+        return out
 
     def merkle_commit(self, mats, want_root=True):
         """mats: list of (tensor, log_height, width[, stride])."""

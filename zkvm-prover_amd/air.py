@@ -549,6 +549,81 @@ def range_traces(log_n_user, log_n_table, seed=0, user_width=4):
     return user.astype(np.uint32), mult, prep
 
 
+# ---- three more periphery chips whose traces are generated on the device (csrc/tracegen_tables.hip) ----
+def range_tuple_table_air(size_x=256, size_y=8192, bus=6):
+    """OpenVM RangeTupleCheckerChip<2> (sizes [256, 8192] in crates/circuits/chunk-circuit/openvm.toml): preprocessed columns
+    (x, y) enumerate all tuples, row x * size_y + y; the main trace is the multiplicity column.  Receives (x, y) mult times."""
+    b = AirBuilder(1, 0, prep_width=2)
+    b.when_first_row(b.prep(0))
+    b.when_first_row(b.prep(1))
+    # y counts up and wraps to 0 when x steps: (y' - y - 1) * y' = 0 and x' = x + [y' == 0]
+    b.when_transition((b.prep(1, 1) - b.prep(1) - 1) * b.prep(1, 1))
+    b.when_transition((b.prep(0, 1) - b.prep(0)) * (b.prep(0, 1) - b.prep(0) - 1))
+    b.push_interaction(bus, [b.prep(0), b.prep(1)], b.var(0), "receive")
+    return b
+
+
+def range_tuple_prep(size_x=256, size_y=8192):
+    i = np.arange(size_x * size_y, dtype=np.uint32)
+    return np.stack([i // size_y, i % size_y]).astype(np.uint32)
+
+
+def range_tuple_user_air(bus=6):
+    """Every row sends the tuple (col0, col1) once; col2 = col0 * col1 keeps a main constraint around."""
+    b = AirBuilder(3, 0)
+    b.assert_zero(b.var(0) * b.var(1) - b.var(2))
+    b.push_interaction(bus, [b.var(0), b.var(1)], 1, "send")
+    return b
+
+
+def bitwise_lookup_air(bits=8, bus=9):
+    """OpenVM BitwiseOperationLookupChip<bits>: preprocessed (x, y, x ^ y) over all pairs, row (x << bits) + y; main trace =
+    two multiplicity columns.  Receives (x, y, 0, 0) for range requests and (x, y, x ^ y, 1) for XOR requests."""
+    b = AirBuilder(2, 0, prep_width=3)
+    b.push_interaction(bus, [b.prep(0), b.prep(1), 0, 0], b.var(0), "receive")
+    b.push_interaction(bus, [b.prep(0), b.prep(1), b.prep(2), 1], b.var(1), "receive")
+    return b
+
+
+def bitwise_lookup_prep(bits=8):
+    i = np.arange(1 << (2 * bits), dtype=np.uint32)
+    x, y = i >> bits, i & ((1 << bits) - 1)
+    return np.stack([x, y, x ^ y]).astype(np.uint32)
+
+
+def bitwise_user_air(bus=9):
+    """Columns x, y, z, op (boolean): op = 1 rows claim z = x ^ y, op = 0 rows range-check (x, y) and hold z = 0."""
+    b = AirBuilder(4, 0)
+    op = b.var(3)
+    b.assert_zero(op * (op - 1))
+    b.assert_zero((1 - op) * b.var(2))
+    b.push_interaction(bus, [b.var(0), b.var(1), b.var(2), op], 1, "send")
+    return b
+
+
+MEMORY_BOUNDARY_WIDTH = 8
+
+
+def memory_boundary_air(pointer_bits=29, range_bus=5, memory_bus=1):
+    """OpenVM VolatileBoundaryChip: columns as, ptr, initial, final, final_ts, is_valid, gap_lo, gap_hi.  Valid rows come
+    first and are strictly sorted by key = as * 2^pointer_bits + ptr: key' - key - 1 = gap_lo + 2^16 gap_hi with both limbs
+    sent to the range checker; each valid row sends (as, ptr, initial, 0) and receives (as, ptr, final, final_ts) on the
+    memory bus (the initial / final memory states of the offline-checking argument)."""
+    b = AirBuilder(MEMORY_BOUNDARY_WIDTH, 0)
+    as_, ptr, init, fin, ts, ok, lo, hi = (b.var(i) for i in range(8))
+    ok_n = b.var(5, 1)
+    b.assert_zero(ok * (ok - 1))
+    b.when_transition(ok_n * (1 - ok))  # no valid row after an invalid one
+    key = as_ * (1 << pointer_bits) + ptr
+    key_n = b.var(0, 1) * (1 << pointer_bits) + b.var(1, 1)
+    b.when_transition(ok_n * (key_n - key - 1 - lo - hi * (1 << 16)))
+    b.push_interaction(range_bus, [lo], ok, "send")
+    b.push_interaction(range_bus, [hi], ok, "send")
+    b.push_interaction(memory_bus, [as_, ptr, init, 0], ok, "send")
+    b.push_interaction(memory_bus, [as_, ptr, fin, ts], ok, "receive")
+    return b
+
+
 # ---- a chunk-circuit-shaped AIR set: many chips of different heights that talk over buses ------------
 class ChipSet:
     """`n_chips` SyntheticAir chips (the reference's chunk circuit has 42 OpenVM chips, AGENTS.md:183-185) of mixed

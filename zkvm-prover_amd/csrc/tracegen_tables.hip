@@ -1,0 +1,201 @@
+// tracegen_tables.hip -- device-side trace generation for three more periphery chips of the
+// reference's chunk circuit (crates/circuits/chunk-circuit/openvm.toml:8-59: rv32i/rv32m/bigint/... all lean on them):
+//
+//  * range-tuple checker  (OpenVM RangeTupleCheckerChip<2>, sizes [256, 8192] under `[app_vm_config.rv32m]
+//    range_tuple_checker_sizes`, openvm.toml): the whole trace is ONE multiplicity column over the table of all tuples
+//    (x, y), row x * size_y + y -- counted with atomics from the requesting columns where they lie;
+//  * bitwise-operation lookup (OpenVM BitwiseOperationLookupChip<8>): table of all (x, y), x, y < 2^bits, row
+//    (x << bits) + y; TWO multiplicity columns: range requests (x, y) and XOR requests (x, y, x ^ y);
+//  * volatile memory boundary (OpenVM VolatileBoundaryChip): one row per touched address, SORTED by (address space,
+//    pointer), carrying initial / final data and the final timestamp, plus the sortedness witness (the gap to the
+//    next key split into 16-bit limbs for the range checker).  The sort is rocPRIM's device radix sort (through the
+//    hipCUB front end shipped with ROCm), the fill one coalesced pass.
+//
+// The un-vendored OpenVM crates hold the reference generators (`generate_proving_ctx` of each chip's GPU twin,
+// AGENTS.md:183-187); the layouts below restate the published chip structure and are matched cell for cell by
+// oracle/tracegen.c (tests/test_gpu_tracegen_tables.py), the AIRs are in zkvm-prover_amd/air.py.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <string>
+
+#include "../../include/zkhip.h"
+#include "babybear.hpp"
+#include "zkhip_internal.hpp"
+
+namespace zk {
+namespace {
+
+__global__ void k_tab_repr(uint32_t* c, size_t n, int to_m) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) c[i] = to_m ? to_monty(c[i] % P) : from_monty(c[i]);
+}
+
+// hist[x * size_y + y] += 1 for every request; x / y Montgomery words of the requesting trace columns
+__global__ __launch_bounds__(256) void k_tuple_counts(const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, size_t n,
+                                                      uint32_t size_x, uint32_t size_y, uint32_t* __restrict__ hist,
+                                                      uint32_t* __restrict__ bad) {
+    uint32_t n_bad = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t x = from_monty(xs[i]), y = from_monty(ys[i]);
+        if (x >= size_x || y >= size_y) {
+            n_bad++;
+            continue;
+        }
+        atomicAdd(&hist[(size_t)x * size_y + y], 1u);
+    }
+    if (n_bad) atomicAdd(bad, n_bad);
+}
+
+// column 0 (range requests) / column 1 (xor requests) of the table of all (x, y): row (x << bits) + y
+__global__ __launch_bounds__(256) void k_bitwise_counts(const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+                                                        const uint32_t* __restrict__ ops, size_t n, unsigned bits,
+                                                        uint32_t* __restrict__ hist, uint32_t* __restrict__ bad) {
+    uint32_t n_bad = 0;
+    const uint32_t lim = 1u << bits;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t x = from_monty(xs[i]), y = from_monty(ys[i]), op = from_monty(ops[i]);
+        if (x >= lim || y >= lim || op > 1) {
+            n_bad++;
+            continue;
+        }
+        atomicAdd(&hist[((size_t)op << (2 * bits)) + ((size_t)x << bits) + y], 1u);
+    }
+    if (n_bad) atomicAdd(bad, n_bad);
+}
+
+__global__ void k_boundary_keys(const uint32_t* __restrict__ as, const uint32_t* __restrict__ ptr, size_t n, uint64_t* keys,
+                                uint32_t* idx, uint32_t* bad, unsigned as_bits, unsigned ptr_bits) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if ((as_bits < 32 && (as[i] >> as_bits)) || (ptr_bits < 32 && (ptr[i] >> ptr_bits))) atomicAdd(bad, 1u);
+    keys[i] = ((uint64_t)as[i] << 32) | ptr[i];
+    idx[i] = (uint32_t)i;
+}
+// row r < n: record idx[r] of the sorted order; gap to the next key minus one in 16-bit limbs (0 on the last valid row);
+// rows >= n are zero (is_valid = 0).  Columns: as, ptr, initial, final, final_ts, is_valid, gap_lo, gap_hi.
+__global__ __launch_bounds__(256) void k_boundary_fill(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
+                                                       const uint32_t* __restrict__ init, const uint32_t* __restrict__ fin,
+                                                       const uint32_t* __restrict__ ts, size_t n, size_t N, unsigned ptr_bits,
+                                                       uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t c[ZKHIP_MEMORY_BOUNDARY_WIDTH] = {};
+    if (r < n) {
+        const uint64_t k = keys[r];
+        const uint32_t j = idx[r];
+        c[0] = to_monty((uint32_t)(k >> 32)), c[1] = to_monty((uint32_t)k);
+        c[2] = init[j], c[3] = fin[j];
+        c[4] = to_monty(ts[j] % P);
+        c[5] = MONTY_ONE;
+        if (r + 1 < n) {
+            const uint64_t kn = keys[r + 1];
+            if (kn == k) atomicAdd(bad, 1u);  // an address listed twice
+            // the AIR's key: as * 2^ptr_bits + ptr
+            const uint64_t a = ((k >> 32) << ptr_bits) + (uint32_t)k, b = ((kn >> 32) << ptr_bits) + (uint32_t)kn;
+            const uint64_t gap = b - a - 1;
+            c[6] = to_monty((uint32_t)(gap & 0xffffu));
+            c[7] = to_monty((uint32_t)((gap >> 16) % P));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_MEMORY_BOUNDARY_WIDTH; q++) trace[(size_t)q * N + r] = c[q];
+}
+
+int finish_counts(zkhip_ctx* ctx, void* flag, const char* what) {
+    uint32_t h_bad = 0;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_bad) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": " + std::to_string(h_bad) + " requests outside the table");
+    return ZKHIP_OK;
+}
+
+}  // namespace
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" int zkhip_range_tuple_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d_x, const uint32_t* d_y, size_t n, uint32_t size_x,
+                                                 uint32_t size_y, uint32_t* d_counts, int accumulate) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_counts || (n && (!d_x || !d_y)) || size_x == 0 || size_y == 0) return ZKHIP_ERR_INVALID;
+    const size_t T = (size_t)size_x * size_y;
+    if (T > ((size_t)1 << 27) || (T & (T - 1))) return set_error(ctx, ZKHIP_ERR_INVALID, "range tuple table: size_x * size_y must be a power of two <= 2^27");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "range_tuple_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const unsigned tb = (unsigned)((T + 255) / 256);
+    if (accumulate) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
+    else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
+    if (n) {
+        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), 8192);
+        hipLaunchKernelGGL(k_tuple_counts, dim3(blocks), dim3(256), 0, ctx->stream, d_x, d_y, n, size_x, size_y, d_counts, (uint32_t*)flag);
+    }
+    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "range_tuple_counts_tracegen");
+}
+
+extern "C" int zkhip_bitwise_lookup_tracegen(zkhip_ctx* ctx, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_op, size_t n,
+                                             unsigned num_bits, uint32_t* d_trace, int accumulate) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || (n && (!d_x || !d_y || !d_op)) || num_bits == 0 || num_bits > 12) return ZKHIP_ERR_INVALID;
+    const size_t T = (size_t)2 << (2 * num_bits);  // two columns
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "bitwise_lookup_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const unsigned tb = (unsigned)((T + 255) / 256);
+    if (accumulate) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_trace, T, 0);
+    else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_trace, 0, T * 4, ctx->stream));
+    if (n) {
+        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), 8192);
+        hipLaunchKernelGGL(k_bitwise_counts, dim3(blocks), dim3(256), 0, ctx->stream, d_x, d_y, d_op, n, num_bits, d_trace, (uint32_t*)flag);
+    }
+    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_trace, T, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "bitwise_lookup_tracegen");
+}
+
+extern "C" int zkhip_memory_boundary_tracegen(zkhip_ctx* ctx, const uint32_t* d_addr_space, const uint32_t* d_pointer,
+                                              const uint32_t* d_initial, const uint32_t* d_final, const uint32_t* d_timestamp, size_t n,
+                                              unsigned as_bits, unsigned pointer_bits, unsigned log_height, uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || log_height > 27 || as_bits == 0 || pointer_bits == 0 || as_bits + pointer_bits > 44 || pointer_bits > 32 || as_bits > 32)
+        return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N || (n && (!d_addr_space || !d_pointer || !d_initial || !d_final || !d_timestamp)))
+        return set_error(ctx, ZKHIP_ERR_INVALID, "memory_boundary_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "memory_boundary_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    uint64_t* keys_sorted = nullptr;
+    uint32_t* idx_sorted = nullptr;
+    if (n) {
+        // scratch: keys in / out (u64), indices in / out (u32), radix-sort workspace
+        size_t tmp_bytes = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                           (uint32_t*)nullptr, (int)n, 0, 64, ctx->stream);
+        const size_t kb = (n * 8 + 255) & ~(size_t)255, ib = (n * 4 + 255) & ~(size_t)255;
+        void* buf = nullptr;
+        ZK_TRY(get_scratch(ctx, 3, 2 * kb + 2 * ib + tmp_bytes + 256, &buf));
+        uint64_t* keys = (uint64_t*)buf;
+        keys_sorted = (uint64_t*)((char*)buf + kb);
+        uint32_t* idx = (uint32_t*)((char*)buf + 2 * kb);
+        idx_sorted = (uint32_t*)((char*)buf + 2 * kb + ib);
+        void* tmp = (char*)buf + 2 * kb + 2 * ib;
+        hipLaunchKernelGGL(k_boundary_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_addr_space, d_pointer, n, keys,
+                           idx, (uint32_t*)flag, as_bits, pointer_bits);
+        ZK_HIP_CHECK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_sorted, idx, idx_sorted, (int)n, 0, 64, ctx->stream));
+    }
+    hipLaunchKernelGGL(k_boundary_fill, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, keys_sorted, idx_sorted, d_initial,
+                       d_final, d_timestamp, n, N, pointer_bits, d_trace, (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    uint32_t h_bad = 0;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_bad) return set_error(ctx, ZKHIP_ERR_INVALID, "memory_boundary_tracegen: " + std::to_string(h_bad) + " records out of range or duplicated");
+    return ZKHIP_OK;
+}
