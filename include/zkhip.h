@@ -273,7 +273,9 @@ int zkhip_fri_fold_row(uint64_t index, unsigned log_height, const uint32_t beta[
  * backend's proofs: commitments, opened values, FRI layers and query openings are read in place.  Needs no device. */
 typedef struct {
     size_t n_words;      /* whole proof; n_words * 4 == zkhip_proof_size */
-    size_t root_main;    /* 8 words */
+    size_t root_main;    /* 8 words: the COMMON main commitment */
+    size_t roots_cached; /* n_cached x 8 words (0 = none): the cached main partitions' commitments, AIR order */
+    size_t n_cached;
     size_t root_perm;    /* 8 words; 0 = no AIR has bus interactions */
     size_t exposed;      /* n_exposed x 4 words: the LogUp sums of the AIRs with interactions, in AIR order */
     size_t n_exposed;

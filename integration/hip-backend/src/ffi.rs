@@ -73,6 +73,8 @@ pub struct zkhip_air {
 pub struct zkhip_proof_layout {
     pub n_words: usize,
     pub root_main: usize,
+    pub roots_cached: usize,
+    pub n_cached: usize,
     pub root_perm: usize,
     pub exposed: usize,
     pub n_exposed: usize,

@@ -26,6 +26,10 @@
  *           commitment is observed in the preamble and opened like the main trace)
  *   n_constraints x node index (asserted zero on every row)
  *   optional: [0x50504B5A, prep_width]
+ *   optional: [0x43414B5A, cached_width]  (cached main partition, OpenVM-v1 `cached_mains`: the first cached_width columns
+ *             of the main trace are committed in a tree of their own -- e.g. the program ROM, whose commitment is reused
+ *             across proofs -- and the rest joins the common main commitment; `commitments.main_trace` of the reference's
+ *             stored proofs holds [cached..., common])
  *   optional: [0x554C4B5A, n_int, n_int x {bus, sign, count node, n_fields, field node..., group}]
  *             (count / fields = nodes that are expressions of the current row only; interactions of one group share
  *              a permutation column group: phi_g = sum of their terms; groups are numbered 0.. in order)
@@ -42,6 +46,7 @@
 #define AIR_MAGIC 0x31414B5Au
 #define LOGUP_MAGIC 0x554C4B5Au
 #define PREP_MAGIC 0x50504B5Au
+#define CACHED_MAGIC 0x43414B5Au
 #define PROOF_MAGIC 0x31504B5Au
 #define PROTO_TAG 0x5A4B4831u /* "1HKZ" < p */
 #define GEN 31u
@@ -100,6 +105,7 @@ typedef struct {
     uint32_t n_groups;
     size_t perm_width; /* 4 * (n_groups + 1), or 0 */
     size_t prep_width; /* preprocessed columns, or 0 */
+    size_t cached_width; /* leading main columns committed on their own (cached main partition), or 0 */
     unsigned char *row_local; /* per node: reachable from an interaction operand (evaluated per trace row) */
 } program;
 
@@ -117,6 +123,11 @@ static int parse_program(const uint32_t *w, size_t len, size_t width, program *p
     if (q0 + 2 <= len && w[q0] == PREP_MAGIC) {
         p->prep_width = w[q0 + 1];
         if (p->prep_width == 0 || p->prep_width > (1u << 20)) return -1;
+        q0 += 2;
+    }
+    if (q0 + 2 <= len && w[q0] == CACHED_MAGIC) {
+        p->cached_width = w[q0 + 1];
+        if (p->cached_width == 0 || p->cached_width >= width) return -1; /* a common part must remain */
         q0 += 2;
     }
     if (q0 != len) {
@@ -338,6 +349,9 @@ typedef struct {
     program prog;
     uint32_t *prep_lde;  /* preprocessed LDE (height M) and its own commitment */
     ora_tree *t_prep;
+    size_t cw;           /* cached main partition: columns [0, cw) have their own tree */
+    ora_tree *t_cached;
+    uint32_t root_cached[8];
 } air_state;
 
 /* one committed matrix as seen by the opening / FRI code */
@@ -348,7 +362,7 @@ typedef struct {
     unsigned lh, h;
     size_t width;
     unsigned n_pts;       /* 2: zeta and zeta*w_N, 1: zeta */
-    int round;            /* 0 main, 1 perm, 2 quotient, 3 preprocessed */
+    int round;            /* 0 main, 1 perm, 2 quotient, 3 preprocessed, 4 cached main partition */
 } cmat;
 
 /* LDE + commitment of one AIR's preprocessed trace (what keygen stores in the verifying key) */
@@ -382,7 +396,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
     if (lfp > MAX_LOG_FINAL_POLY || n_airs == 0 || b == 0) return 0;
     air_state *st = (air_state *)calloc(n_airs, sizeof(air_state));
     unsigned hmax = 0;
-    size_t n_lu = 0, n_prep = 0;
+    size_t n_lu = 0, n_prep = 0, n_cached = 0;
     uint32_t *prep_roots = (uint32_t *)calloc(n_airs, 32);
     int *has_prep = (int *)calloc(n_airs, sizeof(int));
     for (size_t a = 0; a < n_airs; a++) {
@@ -395,6 +409,8 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         st[a].width = airs[a].width;
         if (st[a].h > hmax) hmax = st[a].h;
         if (st[a].prog.n_int) n_lu++;
+        st[a].cw = st[a].prog.cached_width;
+        if (st[a].cw) n_cached++;
         if (st[a].prog.prep_width) {
             if (!airs[a].prep) return 0;
             st[a].t_prep = commit_prep(prm, &airs[a], st[a].prog.prep_width, &st[a].prep_lde, prep_roots + 8 * a);
@@ -412,10 +428,17 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         size_t N = (size_t)1 << st[a].lh, M = N << b;
         st[a].lde = (uint32_t *)malloc(M * st[a].width * sizeof(uint32_t));
         ora_coset_lde_batch(airs[a].trace, N, st[a].lde, M, st[a].lh, b, st[a].width, GEN, 1);
-        mm[a] = (ora_matrix){st[a].lde, M, st[a].h, st[a].width};
+        /* a cached partition gets its own tree; only the remaining columns join the common main commitment */
+        mm[a] = (ora_matrix){st[a].lde + st[a].cw * M, M, st[a].h, st[a].width - st[a].cw};
+        if (st[a].cw) {
+            ora_matrix cmx = {st[a].lde, M, st[a].h, st[a].cw};
+            st[a].t_cached = ora_mmcs_commit(&cmx, 1, st[a].root_cached);
+        }
     }
     uint32_t root_main[8], root_perm[8], root_quot[8];
     ora_tree *t_main = ora_mmcs_commit(mm, n_airs, root_main), *t_perm = NULL;
+    for (size_t a = 0; a < n_airs; a++) /* main-trace commitments in the reference's order: cached..., common */
+        if (st[a].cw) ora_ch_observe(&ch, st[a].root_cached, 8);
     ora_ch_observe(&ch, root_main, 8);
 
     /* 1b. LogUp phase */
@@ -552,12 +575,15 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
 
     /* committed matrices in opening order: main (all AIRs), preprocessed (AIRs that have one), perm (AIRs with
      * interactions), quotient chunks */
-    size_t n_cm = n_airs + n_prep + n_lu + n_airs * nch;
+    size_t n_cm = n_airs + n_cached + n_prep + n_lu + n_airs * nch;
     cmat *cm = (cmat *)calloc(n_cm, sizeof(cmat));
     {
         size_t k = 0;
         for (size_t a = 0; a < n_airs; a++)
-            cm[k++] = (cmat){st[a].lde, airs[a].trace, 1, st[a].lh, st[a].h, st[a].width, 2, 0};
+            cm[k++] = (cmat){st[a].lde + st[a].cw * ((size_t)1 << st[a].h), airs[a].trace + st[a].cw * ((size_t)1 << st[a].lh), 1,
+                             st[a].lh, st[a].h, st[a].width - st[a].cw, 2, 0};
+        for (size_t a = 0; a < n_airs; a++)
+            if (st[a].cw) cm[k++] = (cmat){st[a].lde, airs[a].trace, 1, st[a].lh, st[a].h, st[a].cw, 2, 4};
         for (size_t a = 0; a < n_airs; a++)
             if (has_prep[a]) cm[k++] = (cmat){st[a].prep_lde, airs[a].prep, 1, st[a].lh, st[a].h, st[a].prog.prep_width, 2, 3};
         for (size_t a = 0; a < n_airs; a++)
@@ -718,9 +744,11 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
         w += (n);                                       \
     } while (0)
     {
-        uint32_t hdr[4] = {PROOF_MAGIC + (n_lu ? 1u : 0u) + (n_prep ? 2u : 0u), (uint32_t)n_airs, hmax, n_layers};
+        uint32_t hdr[4] = {PROOF_MAGIC + (n_lu ? 1u : 0u) + (n_prep ? 2u : 0u) + (n_cached ? 4u : 0u), (uint32_t)n_airs, hmax, n_layers};
         PUT(hdr, 4);
         PUT(root_main, 8);
+        for (size_t a = 0; a < n_airs; a++)
+            if (st[a].cw) PUT(st[a].root_cached, 8);
         if (n_lu) {
             PUT(root_perm, 8);
             for (size_t a = 0; a < n_airs; a++)
@@ -741,6 +769,11 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
             size_t idx = ora_ch_sample_bits(&ch, hmax);
             size_t n1 = ora_mmcs_open(t_main, idx >> (hmax - ora_tree_log_height(t_main)), tmp);
             PUT(tmp, n1);
+            for (size_t a = 0; a < n_airs; a++)
+                if (st[a].cw) {
+                    n1 = ora_mmcs_open(st[a].t_cached, idx >> (hmax - st[a].h), tmp);
+                    PUT(tmp, n1);
+                }
             for (size_t a = 0; a < n_airs; a++)
                 if (has_prep[a]) {
                     n1 = ora_mmcs_open(st[a].t_prep, idx >> (hmax - st[a].h), tmp);
@@ -765,6 +798,7 @@ done:
     for (size_t a = 0; a < n_airs; a++) {
         free(st[a].lde), free(st[a].qlde), free(st[a].perm), free(st[a].perm_lde), free(st[a].prep_lde);
         if (st[a].t_prep) ora_tree_free(st[a].t_prep);
+        if (st[a].t_cached) ora_tree_free(st[a].t_cached);
         free_program(&st[a].prog);
     }
     for (size_t k = 0; k < n_airs * nch; k++) free(qnat[k]);
@@ -796,11 +830,12 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     if (lfp > MAX_LOG_FINAL_POLY || n_airs == 0 || b == 0) return -1;
     program *pg = (program *)calloc(n_airs, sizeof(program));
     unsigned hmax = 0;
-    size_t n_lu = 0, n_prep = 0;
+    size_t n_lu = 0, n_prep = 0, n_cached = 0;
     uint32_t *prep_roots = (uint32_t *)calloc(n_airs, 32);
     int *has_prep = (int *)calloc(n_airs, sizeof(int));
     for (size_t a = 0; a < n_airs; a++) {
         if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &pg[a])) return -2;
+        if (pg[a].cached_width) n_cached++;
         if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height > 27 || airs[a].log_height < lfp) return -2;
         if (airs[a].log_height + b > hmax) hmax = airs[a].log_height + b;
         if (pg[a].n_int) n_lu++;
@@ -813,12 +848,15 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
         }
     }
     /* committed matrices in opening order */
-    size_t n_cm = n_airs + n_prep + n_lu + n_airs * nch, n_open = 0;
+    size_t n_cm = n_airs + n_cached + n_prep + n_lu + n_airs * nch, n_open = 0;
     vmat *cm = (vmat *)calloc(n_cm, sizeof(vmat));
-    size_t cm_prep0 = n_airs, cm_perm0 = n_airs + n_prep, cm_quot0 = n_airs + n_prep + n_lu;
+    size_t cm_cached0 = n_airs, cm_prep0 = n_airs + n_cached, cm_perm0 = cm_prep0 + n_prep, cm_quot0 = cm_perm0 + n_lu;
     {
         size_t k = 0;
-        for (size_t a = 0; a < n_airs; a++) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, airs[a].width, 2};
+        for (size_t a = 0; a < n_airs; a++)
+            cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, airs[a].width - pg[a].cached_width, 2};
+        for (size_t a = 0; a < n_airs; a++)
+            if (pg[a].cached_width) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, pg[a].cached_width, 2};
         for (size_t a = 0; a < n_airs; a++)
             if (has_prep[a]) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, pg[a].prep_width, 2};
         for (size_t a = 0; a < n_airs; a++)
@@ -837,11 +875,13 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     for (size_t i = 0; i < n_words; i++)
         if (proof[i] >= ORA_P) return -3; /* all words canonical (the magic is < p too) */
     NEED(4);
-    if (proof[0] != PROOF_MAGIC + (n_lu ? 1u : 0u) + (n_prep ? 2u : 0u) || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers) return -3;
+    if (proof[0] != PROOF_MAGIC + (n_lu ? 1u : 0u) + (n_prep ? 2u : 0u) + (n_cached ? 4u : 0u) || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers) return -3;
     r = 4;
-    NEED(8);
+    NEED(8 + 8 * n_cached);
     const uint32_t *root_main = proof + r, *root_perm = NULL, *exposed_all = NULL;
     r += 8;
+    const uint32_t *roots_cached = proof + r; /* one per AIR with a cached partition, AIR order */
+    r += 8 * n_cached;
     if (n_lu) {
         NEED(8 + 4 * n_lu);
         root_perm = proof + r;
@@ -864,6 +904,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     ora_challenger ch;
     ora_ch_init(&ch);
     observe_preamble(&ch, prm, airs, n_airs, prep_roots, has_prep);
+    ora_ch_observe(&ch, roots_cached, 8 * n_cached);
     ora_ch_observe(&ch, root_main, 8);
     uint32_t chal[N_CHAL];
     memset(chal, 0, sizeof chal);
@@ -897,16 +938,25 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     }
     /* constraint check at zeta for every AIR */
     {
-        size_t k_lu = 0, k_prep = 0;
+        size_t k_lu = 0, k_prep = 0, k_cached = 0;
         for (size_t a = 0; a < n_airs; a++) {
             const unsigned lh = airs[a].log_height, h = lh + b;
-            const size_t W = airs[a].width;
+            const size_t W = airs[a].width, CW = pg[a].cached_width;
             zeta_ctx zc;
             memset(&zc, 0, sizeof zc);
             ext_t inv_zh;
             selectors_ext(lh, zeta, zc.is_first, zc.is_last, zc.is_trans, inv_zh);
-            zc.local = opened + open_off[a];
-            zc.next = opened + open_off[a] + W;
+            /* the AIR's main row = cached partition columns, then the common columns */
+            ext_t *mrow = (ext_t *)malloc(2 * W * sizeof(ext_t));
+            if (CW) {
+                const ext_t *co = opened + open_off[cm_cached0 + k_cached++];
+                memcpy(mrow, co, CW * sizeof(ext_t));
+                memcpy(mrow + W, co + CW, CW * sizeof(ext_t));
+            }
+            memcpy(mrow + CW, opened + open_off[a], (W - CW) * sizeof(ext_t));
+            memcpy(mrow + W + CW, opened + open_off[a] + (W - CW), (W - CW) * sizeof(ext_t));
+            zc.local = (const ext_t *)mrow;
+            zc.next = (const ext_t *)(mrow + W);
             zc.pvs = airs[a].pvs;
             zc.chal = chal;
             if (has_prep[a]) {
@@ -922,6 +972,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
             }
             ext_t *vals = (ext_t *)malloc(pg[a].n_nodes * sizeof(ext_t));
             eval_nodes_ext(&pg[a], &zc, vals);
+            free(mrow);
             ext_t acc = {0, 0, 0, 0};
             for (uint32_t k = 0; k < pg[a].n_cons; k++) {
                 ora_ext_mul(acc, alpha, acc);
@@ -975,13 +1026,15 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
     if (!ora_ch_check_witness(&ch, prm->query_pow_bits, qpow)) return -5;
 
     /* shapes of the input batches: main, one per preprocessed trace, perm, quotient */
-    const size_t n_batches = 2 + n_prep + (n_lu ? 1 : 0);
+    const size_t n_batches = 2 + n_cached + n_prep + (n_lu ? 1 : 0);
     size_t *batch_first = (size_t *)malloc(n_batches * sizeof(size_t)), *batch_n = (size_t *)malloc(n_batches * sizeof(size_t));
     const uint32_t **batch_root = (const uint32_t **)malloc(n_batches * sizeof(uint32_t *));
     const uint32_t **rows_of = (const uint32_t **)malloc(n_batches * sizeof(uint32_t *));
     {
         size_t bt = 0, k = 0;
         batch_first[bt] = 0, batch_n[bt] = n_airs, batch_root[bt] = root_main, bt++;
+        for (size_t a = 0, kc = 0; a < n_airs; a++)
+            if (pg[a].cached_width) batch_first[bt] = cm_cached0 + kc, batch_n[bt] = 1, batch_root[bt] = roots_cached + 8 * kc, kc++, bt++;
         for (size_t a = 0; a < n_airs; a++)
             if (has_prep[a]) batch_first[bt] = cm_prep0 + k++, batch_n[bt] = 1, batch_root[bt] = prep_roots + 8 * a, bt++;
         if (n_lu) batch_first[bt] = cm_perm0, batch_n[bt] = n_lu, batch_root[bt] = root_perm, bt++;

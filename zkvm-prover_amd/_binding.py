@@ -44,7 +44,7 @@ class _Air(C.Structure):
 
 
 class _ProofLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("n_words", "root_main", "root_perm", "exposed", "n_exposed", "root_quot", "opened",
+    _fields_ = [(n, C.c_size_t) for n in ("n_words", "root_main", "roots_cached", "n_cached", "root_perm", "exposed", "n_exposed", "root_quot", "opened",
                                           "n_opened", "fri_layers", "n_fri_layers", "final_poly", "n_final_poly", "query_pow", "queries",
                                           "query_words", "n_queries")]
 

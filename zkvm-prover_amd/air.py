@@ -16,6 +16,7 @@ OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP_MUL, O
 # of the interaction challenges, a coordinate of the AIR's exposed cumulative sum
 OP_PERM, OP_CHAL, OP_EXPOSED = 10, 11, 12
 OP_PREP = 13                              # a cell of the AIR's preprocessed trace (committed at keygen)
+CACHED_MAGIC = 0x43414B5A                 # section [CACHED_MAGIC, cached_width]: leading main columns committed on their own
 PREP_MAGIC = 0x50504B5A                   # section [PREP_MAGIC, prep_width] after the constraints
 LOGUP_MAGIC = 0x554C4B5A
 LOGUP_MAX_FIELDS = 32                     # challenge vector = gamma, beta^1 .. beta^32 (4 coordinates each)
@@ -59,8 +60,12 @@ class AirBuilder:
     """Mirrors the shape of p3-air's AirBuilder: main-trace variables with rotation 0/1, public
     values, is_first_row / is_last_row / is_transition selectors, assert_zero."""
 
-    def __init__(self, width, n_pvs=0, prep_width=0):
-        self.width, self.n_pvs, self.prep_width = width, n_pvs, prep_width
+    def __init__(self, width, n_pvs=0, prep_width=0, cached_width=0):
+        """cached_width: the first cached_width main columns form a CACHED main partition (OpenVM-v1 `cached_mains`): they
+        are committed in a tree of their own (e.g. the program ROM, whose commitment is reused), the rest joins the common
+        main commitment.  Constraints address the main trace as before."""
+        self.width, self.n_pvs, self.prep_width, self.cached_width = width, n_pvs, prep_width, cached_width
+        assert 0 <= cached_width < width
         self.nodes, self.cons, self._cache = [], [], {}
 
     def _node(self, op, a=0, b=0, deg=0):
@@ -265,6 +270,8 @@ class AirBuilder:
         words.extend(self.cons)
         if self.prep_width:
             words += [PREP_MAGIC, self.prep_width]
+        if self.cached_width:
+            words += [CACHED_MAGIC, self.cached_width]
         ints = getattr(self, "interactions", [])
         if ints:
             # trailing section: [LOGUP_MAGIC, n_int, {bus, sign, count node, n_fields, field nodes, group}]

@@ -24,6 +24,7 @@ constexpr uint32_t PROTO_TAG = 0x5A4B4831u;
 
 constexpr uint32_t LOGUP_MAGIC = 0x554C4B5Au;
 constexpr uint32_t PREP_MAGIC = 0x50504B5Au;  // section [PREP_MAGIC, prep_width]: the AIR has a preprocessed trace
+constexpr uint32_t CACHED_MAGIC = 0x43414B5Au;  // section [CACHED_MAGIC, cached_width]: cached main partition (own commitment)
 constexpr unsigned LOGUP_MAX_FIELDS = 32;
 constexpr unsigned N_CHAL = 4 * (1 + LOGUP_MAX_FIELDS);  // gamma, beta^1..beta^32 as base coordinates
 
@@ -49,6 +50,7 @@ struct AirProgram {
     unsigned max_degree = 0;
     std::vector<Interaction> ints;
     size_t prep_width = 0;
+    size_t cached_width = 0;  // leading main columns committed in a tree of their own (OpenVM-v1 cached main)
     size_t n_groups() const { return ints.empty() ? 0 : (size_t)ints.back().group + 1; }
     size_t perm_width() const { return ints.empty() ? 0 : 4 * (n_groups() + 1); }
 };
@@ -83,10 +85,16 @@ inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p,
     p->cons = w + 4 + 3 * (size_t)p->n_nodes;
     p->ints.clear();
     p->prep_width = 0;
+    p->cached_width = 0;
     size_t q0 = base_len;
     if (q0 + 2 <= len && w[q0] == PREP_MAGIC) {
         p->prep_width = w[q0 + 1];
         if (p->prep_width == 0 || p->prep_width > (1u << 20)) return fail("bad preprocessed width");
+        q0 += 2;
+    }
+    if (q0 + 2 <= len && w[q0] == CACHED_MAGIC) {
+        p->cached_width = w[q0 + 1];
+        if (p->cached_width == 0 || p->cached_width >= width) return fail("bad cached main width (a common part must remain)");
         q0 += 2;
     }
     if (q0 != len) {  // trailing interactions section

@@ -58,7 +58,7 @@ void summarize(const std::vector<cd::ProofV1>& ps, zkhip_v1_summary* s) {
 struct Shape {
     std::vector<AirProgram> pg;
     unsigned b = 0, nch = 0, lfp = 0, hmax = 0, n_layers = 0;
-    size_t n_airs = 0, n_lu = 0, n_prep = 0, n_open = 0, n_fin = 0;
+    size_t n_airs = 0, n_lu = 0, n_prep = 0, n_cached = 0, n_open = 0, n_fin = 0;
     unsigned main_h = 0, perm_h = 0;
 };
 
@@ -76,6 +76,7 @@ int shape_of(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, Shap
         s->hmax = std::max(s->hmax, h);
         s->n_open += 2 * airs[a].width + 4 * (size_t)s->nch;
         if (s->pg[a].prep_width) s->n_prep++, s->n_open += 2 * s->pg[a].prep_width;
+        if (s->pg[a].cached_width) s->n_cached++;
         if (!s->pg[a].ints.empty()) s->n_lu++, s->perm_h = std::max(s->perm_h, h), s->n_open += 2 * s->pg[a].perm_width();
     }
     s->main_h = s->hmax;
@@ -152,10 +153,12 @@ extern "C" int zkhip_proof_to_v1(const zkhip_params* prm, const zkhip_air* airs,
     memcpy(w.data(), proof_bytes, len);
     for (uint32_t v : w)
         if (v >= P) return ZKHIP_ERR_VERIFY;
-    if (w[0] != PROOF_MAGIC + (s.n_lu ? 1u : 0u) + (s.n_prep ? 2u : 0u) || w[1] != n_airs || w[2] != s.hmax || w[3] != s.n_layers)
+    if (w[0] != PROOF_MAGIC + (s.n_lu ? 1u : 0u) + (s.n_prep ? 2u : 0u) + (s.n_cached ? 4u : 0u) || w[1] != n_airs || w[2] != s.hmax || w[3] != s.n_layers)
         return ZKHIP_ERR_VERIFY;
     try {
         cd::ProofV1 p;
+        // main-trace commitments in the reference's order: cached partitions (AIR order), then the common main
+        for (size_t k = 0; k < s.n_cached; k++) p.main_trace.push_back(digest_m(&w[lay.roots_cached + 8 * k]));
         p.main_trace.push_back(digest_m(&w[lay.root_main]));
         if (s.n_lu) p.after_challenge.push_back(digest_m(&w[lay.root_perm]));
         p.quotient = digest_m(&w[lay.root_quot]);
@@ -166,11 +169,21 @@ extern "C" int zkhip_proof_to_v1(const zkhip_params* prm, const zkhip_air* airs,
             for (size_t i = 0; i < n; i++, o += 4) v[i] = ext_m(&w[o]);
             return v;
         };
-        p.values.main.resize(1);
-        for (size_t a = 0; a < n_airs; a++) {
+        p.values.main.resize(s.n_cached + 1);
+        for (size_t a = 0; a < n_airs; a++) {  // zkhip order: the common parts of every AIR first ...
             cd::AdjacentOpenedValues adj;
-            adj.local = take(airs[a].width), adj.next = take(airs[a].width);
-            p.values.main[0].push_back(std::move(adj));
+            const size_t wc = airs[a].width - s.pg[a].cached_width;
+            adj.local = take(wc), adj.next = take(wc);
+            p.values.main[s.n_cached].push_back(std::move(adj));
+        }
+        {
+            size_t k = 0;  // ... then the cached partitions, one commitment each
+            for (size_t a = 0; a < n_airs; a++)
+                if (s.pg[a].cached_width) {
+                    cd::AdjacentOpenedValues adj;
+                    adj.local = take(s.pg[a].cached_width), adj.next = take(s.pg[a].cached_width);
+                    p.values.main[k++].push_back(std::move(adj));
+                }
         }
         for (size_t a = 0; a < n_airs; a++)
             if (s.pg[a].prep_width) {
@@ -209,9 +222,16 @@ extern "C" int zkhip_proof_to_v1(const zkhip_params* prm, const zkhip_air* airs,
                 return v;
             };
             cd::BatchOpening bmain, bperm, bquot;
-            std::vector<cd::BatchOpening> bprep;
-            for (size_t a = 0; a < n_airs; a++) bmain.opened_values.push_back(rows(airs[a].width));
+            std::vector<cd::BatchOpening> bprep, bcached;
+            for (size_t a = 0; a < n_airs; a++) bmain.opened_values.push_back(rows(airs[a].width - s.pg[a].cached_width));
             bmain.opening_proof = path(s.main_h);
+            for (size_t a = 0; a < n_airs; a++)
+                if (s.pg[a].cached_width) {
+                    cd::BatchOpening bc;
+                    bc.opened_values.push_back(rows(s.pg[a].cached_width));
+                    bc.opening_proof = path(airs[a].log_height + s.b);
+                    bcached.push_back(std::move(bc));
+                }
             for (size_t a = 0; a < n_airs; a++)
                 if (s.pg[a].prep_width) {
                     cd::BatchOpening bp;
@@ -228,7 +248,8 @@ extern "C" int zkhip_proof_to_v1(const zkhip_params* prm, const zkhip_air* airs,
                 for (unsigned j = 0; j < s.nch; j++) bquot.opened_values.push_back(rows(4));
             bquot.opening_proof = path(s.main_h);
             auto& q = p.fri.query_proofs[qi];
-            for (auto& bp : bprep) q.input_proof.push_back(std::move(bp));  // v1 order: preprocessed, main, after-challenge, quotient
+            for (auto& bp : bprep) q.input_proof.push_back(std::move(bp));  // v1 order: preprocessed, main (cached..., common), after-challenge, quotient
+            for (auto& bc : bcached) q.input_proof.push_back(std::move(bc));
             q.input_proof.push_back(std::move(bmain));
             if (s.n_lu) q.input_proof.push_back(std::move(bperm));
             q.input_proof.push_back(std::move(bquot));
@@ -275,17 +296,18 @@ extern "C" int zkhip_proof_from_v1(const zkhip_params* prm, const zkhip_air* air
         const cd::ProofV1 p = cd::decode_proof(v1, v1_len);
         if (!cd::well_formed(p, P)) return ZKHIP_ERR_VERIFY;
         // shape checks against the key
-        if (p.main_trace.size() != 1 || p.after_challenge.size() != (s.n_lu ? 1u : 0u) || p.per_air.size() != n_airs ||
+        if (p.main_trace.size() != s.n_cached + 1 || p.after_challenge.size() != (s.n_lu ? 1u : 0u) || p.per_air.size() != n_airs ||
             p.fri.commit_phase_commits.size() != s.n_layers || p.fri.final_poly.size() != s.n_fin ||
-            p.fri.query_proofs.size() != lay.n_queries || p.values.main.size() != 1 || p.values.main[0].size() != n_airs ||
+            p.fri.query_proofs.size() != lay.n_queries || p.values.main.size() != s.n_cached + 1 || p.values.main[s.n_cached].size() != n_airs ||
             p.values.preprocessed.size() != s.n_prep || p.values.after_challenge.size() != (s.n_lu ? 1u : 0u) ||
             p.values.quotient.size() != n_airs)
             return ZKHIP_ERR_VERIFY;
         std::vector<uint32_t> w;
         w.reserve(lay.n_words);
-        w.push_back(PROOF_MAGIC + (s.n_lu ? 1u : 0u) + (s.n_prep ? 2u : 0u));
+        w.push_back(PROOF_MAGIC + (s.n_lu ? 1u : 0u) + (s.n_prep ? 2u : 0u) + (s.n_cached ? 4u : 0u));
         w.push_back((uint32_t)n_airs), w.push_back(s.hmax), w.push_back(s.n_layers);
-        put_canon(w, p.main_trace[0].data(), 8);
+        put_canon(w, p.main_trace[s.n_cached].data(), 8);
+        for (size_t k = 0; k < s.n_cached; k++) put_canon(w, p.main_trace[k].data(), 8);
         if (s.n_lu) {
             put_canon(w, p.after_challenge[0].data(), 8);
             for (size_t a = 0; a < n_airs; a++)
@@ -303,9 +325,15 @@ extern "C" int zkhip_proof_from_v1(const zkhip_params* prm, const zkhip_air* air
             return true;
         };
         for (size_t a = 0; a < n_airs; a++)
-            if (!put_adj(p.values.main[0][a], airs[a].width)) return ZKHIP_ERR_VERIFY;
+            if (!put_adj(p.values.main[s.n_cached][a], airs[a].width - s.pg[a].cached_width)) return ZKHIP_ERR_VERIFY;
         {
             size_t k = 0;
+            for (size_t a = 0; a < n_airs; a++)
+                if (s.pg[a].cached_width) {
+                    if (p.values.main[k].size() != 1 || !put_adj(p.values.main[k][0], s.pg[a].cached_width)) return ZKHIP_ERR_VERIFY;
+                    k++;
+                }
+            k = 0;
             for (size_t a = 0; a < n_airs; a++)
                 if (s.pg[a].prep_width && !put_adj(p.values.preprocessed[k++], s.pg[a].prep_width)) return ZKHIP_ERR_VERIFY;
             k = 0;
@@ -326,7 +354,7 @@ extern "C" int zkhip_proof_from_v1(const zkhip_params* prm, const zkhip_air* air
         }
         for (const auto& e : p.fri.final_poly) put_canon(w, e.data(), 4);
         w.push_back(from_monty(p.fri.pow_witness));
-        const size_t n_batches = s.n_prep + 2 + (s.n_lu ? 1 : 0);
+        const size_t n_batches = s.n_prep + s.n_cached + 2 + (s.n_lu ? 1 : 0);
         for (const auto& q : p.fri.query_proofs) {
             if (q.input_proof.size() != n_batches || q.commit_phase_openings.size() != s.n_layers) return ZKHIP_ERR_VERIFY;
             auto put_batch = [&](const cd::BatchOpening& b, const std::vector<size_t>& widths, unsigned h) {
@@ -340,15 +368,18 @@ extern "C" int zkhip_proof_from_v1(const zkhip_params* prm, const zkhip_air* air
             };
             std::vector<size_t> wmain, wperm, wquot;
             for (size_t a = 0; a < n_airs; a++) {
-                wmain.push_back(airs[a].width);
+                wmain.push_back(airs[a].width - s.pg[a].cached_width);
                 if (!s.pg[a].ints.empty()) wperm.push_back(s.pg[a].perm_width());
                 for (unsigned j = 0; j < s.nch; j++) wquot.push_back(4);
             }
-            if (!put_batch(q.input_proof[s.n_prep], wmain, s.main_h)) return ZKHIP_ERR_VERIFY;
+            if (!put_batch(q.input_proof[s.n_prep + s.n_cached], wmain, s.main_h)) return ZKHIP_ERR_VERIFY;
             size_t k = 0;
             for (size_t a = 0; a < n_airs; a++)
+                if (s.pg[a].cached_width && !put_batch(q.input_proof[s.n_prep + k++], {s.pg[a].cached_width}, airs[a].log_height + s.b)) return ZKHIP_ERR_VERIFY;
+            k = 0;
+            for (size_t a = 0; a < n_airs; a++)
                 if (s.pg[a].prep_width && !put_batch(q.input_proof[k++], {s.pg[a].prep_width}, airs[a].log_height + s.b)) return ZKHIP_ERR_VERIFY;
-            if (s.n_lu && !put_batch(q.input_proof[s.n_prep + 1], wperm, s.perm_h)) return ZKHIP_ERR_VERIFY;
+            if (s.n_lu && !put_batch(q.input_proof[s.n_prep + s.n_cached + 1], wperm, s.perm_h)) return ZKHIP_ERR_VERIFY;
             if (!put_batch(q.input_proof[n_batches - 1], wquot, s.main_h)) return ZKHIP_ERR_VERIFY;
             for (unsigned l = 0; l < s.n_layers; l++) {
                 const auto& st = q.commit_phase_openings[l];

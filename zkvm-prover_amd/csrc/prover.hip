@@ -674,6 +674,10 @@ struct AirPlan {
     uint32_t* d_lu_sums = nullptr;     // N ext
     uint32_t* d_perm = nullptr;        // perm_w columns x N (natural order)
     uint32_t* d_perm_lde = nullptr;    // perm_w columns x M
+    // cached main partition (OpenVM-v1 cached main): the first cw columns of the main trace are committed in a tree of
+    // their own at prove time; the other columns join the common main commitment
+    size_t cw = 0, opened_cached_off = 0;
+    zkhip_tree* t_cached = nullptr;
     // preprocessed trace: uploaded, extended and committed at keygen, resident for the life of the key
     size_t prep_w = 0, opened_prep_off = 0;
     uint32_t* d_prep = nullptr;        // prep_w columns x N (natural order, Montgomery)
@@ -767,6 +771,8 @@ struct zkhip_pk {
     uint32_t n_ro_items = 0;
     std::vector<uint32_t*> d_flayer;  // n_layers+1
     size_t n_prep = 0;              // AIRs with a preprocessed trace
+    size_t n_cached = 0;            // AIRs with a cached main partition
+    size_t off_roots_cached = 0, q_cached_words = 0;
     size_t max_w = 0;               // widest committed matrix
     size_t n_lu = 0;                // AIRs with bus interactions
     unsigned h_perm = 0;            // log height of the permutation commitment
@@ -855,7 +861,9 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         pk->hmax = std::max(pk->hmax, A.h);
         max_n = std::max(max_n, A.N);
         max_w = std::max(max_w, A.width);
-        tw_main += A.width;
+        A.cw = A.prog.cached_width;
+        if (A.cw) pk->n_cached++;
+        tw_main += A.width - A.cw;
         A.prep_w = A.prog.prep_width;
         if (A.prep_w) {
             if (!airs[a].prep_trace) {
@@ -889,8 +897,12 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     pk->n_layers = pk->hmax - pk->b - pk->lfp;
     // opened-value layout: main (all airs), permutation (airs with interactions), quotient (all airs)
     for (size_t a = 0; a < n_airs; a++) {
-        pk->airs[a].opened_main_off = n_open;
-        n_open += 2 * pk->airs[a].width;
+        pk->airs[a].opened_main_off = n_open;  // the COMMON part of the main trace
+        n_open += 2 * (pk->airs[a].width - pk->airs[a].cw);
+    }
+    for (size_t a = 0; a < n_airs; a++) {
+        pk->airs[a].opened_cached_off = n_open;
+        n_open += 2 * pk->airs[a].cw;
     }
     for (size_t a = 0; a < n_airs; a++) {
         pk->airs[a].opened_prep_off = n_open;
@@ -928,6 +940,8 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         size_t w = 4;
         pk->off_roots = w;
         w += 8;
+        pk->off_roots_cached = w;
+        w += 8 * pk->n_cached;
         if (pk->n_lu) {
             pk->off_root_perm = w;
             pk->off_exposed = w + 8;
@@ -945,11 +959,13 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         w += 1;
         pk->off_queries = w;
         pk->q_main_words = tw_main + 8 * (size_t)pk->hmax;
-        for (size_t a = 0; a < n_airs; a++)
+        for (size_t a = 0; a < n_airs; a++) {
+            if (pk->airs[a].cw) pk->q_cached_words += pk->airs[a].cw + 8 * (size_t)pk->airs[a].h;
             if (pk->airs[a].prep_w) pk->q_prep_words += pk->airs[a].prep_w + 8 * (size_t)pk->airs[a].h;
+        }
         pk->q_perm_words = pk->n_lu ? tw_perm + 8 * (size_t)pk->h_perm : 0;
         pk->q_quot_words = 4 * (size_t)pk->nch * n_airs + 8 * (size_t)pk->hmax;
-        size_t pitch = pk->q_main_words + pk->q_prep_words + pk->q_perm_words + pk->q_quot_words;
+        size_t pitch = pk->q_main_words + pk->q_cached_words + pk->q_prep_words + pk->q_perm_words + pk->q_quot_words;
         for (unsigned l = 0; l < pk->n_layers; l++) pitch += 4 + 8 * (size_t)(pk->hmax - l - 1);
         pk->query_pitch = pitch;
         w += pitch * params->num_queries;
@@ -969,7 +985,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     const unsigned nch = pk->nch;
     struct AirOff {
         size_t code, consts, zh, inv_zh, pvs, lde, q, qnat, qlde, apow_q;
-        size_t lu_tab, lu_code, lu_consts, lu_den, lu_totals, lu_sums, perm, perm_lde, prep, prep_lde, dig_prep;
+        size_t lu_tab, lu_code, lu_consts, lu_den, lu_totals, lu_sums, perm, perm_lde, prep, prep_lde, dig_prep, dig_cached;
     };
     std::vector<AirOff> ao(n_airs);
     std::vector<CompiledAir> comp(n_airs);
@@ -1022,6 +1038,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         ao[a].qnat = bp.take(A.M * 4 * 4);
         ao[a].qlde = bp.take((size_t)nch * A.M * 4 * 4);
         ao[a].apow_q = bp.take((size_t)(A.prog.n_cons + 1) * 16);
+        if (A.cw) ao[a].dig_cached = bp.take(merkle_digest_count(A.h) * 32);
         if (A.prep_w) {
             ao[a].prep = bp.take(A.prep_w * A.N * 4);
             ao[a].prep_lde = bp.take(A.prep_w * A.M * 4);
@@ -1119,7 +1136,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     size_t o_apow_f = bp.take((max_w + 1) * 16);
     pk->max_w = max_w;
     size_t o_ro_inv = bp.take(((size_t)32) << pk->hmax);
-    pk->n_ro_items = (uint32_t)(n_airs + pk->n_prep + pk->n_lu + n_airs * nch);
+    pk->n_ro_items = (uint32_t)(n_airs + pk->n_cached + pk->n_prep + pk->n_lu + n_airs * nch);
     size_t o_ro_items = bp.take(pk->n_ro_items * sizeof(RoItem));
     size_t o_ro_slots = bp.take((size_t)pk->n_ro_items * 64);
     std::vector<size_t> o_ro(pk->hmax + 1, (size_t)-1);
@@ -1197,7 +1214,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             if (rc == ZKHIP_OK) rc = upload(ctx, A.d_lu_consts, lu[a].consts.data(), lu[a].consts.size() * 4);
             pmm.push_back(zkhip_matrix{A.d_perm_lde, A.M, A.h, A.perm_w});
         }
-        mm.push_back(zkhip_matrix{A.d_lde, A.M, A.h, A.width});
+        mm.push_back(zkhip_matrix{A.d_lde + A.cw * A.M, A.M, A.h, A.width - A.cw});  // common part
         for (unsigned j = 0; j < nch; j++) qm.push_back(zkhip_matrix{A.d_qlde + (size_t)j * 4 * A.M, A.M, A.h, 4});
     }
     pk->d_tr = (DevTranscript*)(base + o_tr);
@@ -1229,16 +1246,17 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             for (size_t a = 0; a < n_airs; a++) {
                 AirPlan& A = pk->airs[a];
                 if (A.lh != g.lh) continue;
-                auto put = [&](const uint32_t* base_ptr, size_t width, size_t opened_off, bool is_main) {
+                auto put = [&](const uint32_t* base_ptr, size_t width, size_t opened_off, bool is_main, size_t col0 = 0) {
                     for (size_t k = 0; k < width; k++, c++) {
                         pk->open_ptrs_host[c] = base_ptr ? base_ptr + k * A.N : nullptr;
-                        if (is_main) pk->open_main_cols.push_back({c, (uint32_t)a, (uint32_t)k});
+                        if (is_main) pk->open_main_cols.push_back({c, (uint32_t)a, (uint32_t)(col0 + k)});
                         dst[2 * c] = (uint32_t)(opened_off + k);
                         dst[2 * c + 1] = (uint32_t)(opened_off + width + k);
                     }
                 };
                 if (g.chunk < 0) {
-                    put(nullptr, A.width, A.opened_main_off, true);
+                    if (A.cw) put(nullptr, A.cw, A.opened_cached_off, true);  // trace columns stay in order: cached, then common
+                    put(nullptr, A.width - A.cw, A.opened_main_off, true, A.cw);
                     if (A.prep_w) put(A.d_prep, A.prep_w, A.opened_prep_off, false);
                     if (A.n_int) put(A.d_perm, A.perm_w, A.opened_perm_off, false);
                 } else {
@@ -1287,18 +1305,29 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         };
         std::vector<HostItem> items;
         std::vector<uint64_t> num_reduced(pk->hmax + 1, 0);
-        for (int round = 0; round < 4; round++)
+        // rounds: 0 common main, 4 cached main partitions (right after the main batch), 1 preprocessed, 2 permutation, 3 quotient
+        for (int round : {0, 4, 1, 2, 3})
             for (size_t a = 0; a < n_airs; a++) {
                 AirPlan& A = pk->airs[a];
                 if (round == 1 && !A.prep_w) continue;
                 if (round == 2 && !A.n_int) continue;
+                if (round == 4 && !A.cw) continue;
                 const unsigned n_mats = round == 3 ? nch : 1;
                 for (unsigned j = 0; j < n_mats; j++) {
                     HostItem hi;
-                    hi.it.width = round == 0 ? (uint32_t)A.width : round == 1 ? (uint32_t)A.prep_w : round == 2 ? (uint32_t)A.perm_w : 4u;
+                    hi.it.width = round == 0   ? (uint32_t)(A.width - A.cw)
+                                  : round == 4 ? (uint32_t)A.cw
+                                  : round == 1 ? (uint32_t)A.prep_w
+                                  : round == 2 ? (uint32_t)A.perm_w
+                                               : 4u;
                     hi.it.n_pts = round == 3 ? 1 : 2;
-                    hi.it.mat = round == 0 ? A.d_lde : round == 1 ? A.d_prep_lde : round == 2 ? A.d_perm_lde : A.d_qlde + (size_t)j * 4 * A.M;
+                    hi.it.mat = round == 0   ? A.d_lde + A.cw * A.M
+                                : round == 4 ? A.d_lde
+                                : round == 1 ? A.d_prep_lde
+                                : round == 2 ? A.d_perm_lde
+                                             : A.d_qlde + (size_t)j * 4 * A.M;
                     hi.it.opened_off = (uint32_t)(round == 0   ? A.opened_main_off
+                                                  : round == 4 ? A.opened_cached_off
                                                   : round == 1 ? A.opened_prep_off
                                                   : round == 2 ? A.opened_perm_off
                                                                : A.opened_quot_off + 4 * (size_t)j);
@@ -1329,6 +1358,12 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     pk->d_proof = (uint32_t*)(base + o_proof);
     pk->d_fri_desc = (FriLayerDesc*)(base + o_desc);
     if (rc == ZKHIP_OK) rc = merkle_plan(ctx, mm.data(), mm.size(), (uint32_t*)(base + o_dig_main), &pk->t_main);
+    for (size_t a = 0; a < n_airs && rc == ZKHIP_OK; a++) {
+        AirPlan& A = pk->airs[a];
+        if (!A.cw) continue;
+        zkhip_matrix cmx{A.d_lde, A.M, A.h, A.cw};
+        rc = merkle_plan(ctx, &cmx, 1, (uint32_t*)(base + ao[a].dig_cached), &A.t_cached);
+    }
     if (rc == ZKHIP_OK && pk->n_lu) rc = merkle_plan(ctx, pmm.data(), pmm.size(), (uint32_t*)(base + o_dig_perm), &pk->t_perm);
     if (rc == ZKHIP_OK) rc = merkle_plan(ctx, qm.data(), qm.size(), (uint32_t*)(base + o_dig_quot), &pk->t_quot);
     pk->t_fri.assign(pk->n_layers, nullptr);
@@ -1336,7 +1371,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     for (size_t a = 0; a < n_airs; a++)
         if (pk->airs[a].prep_w)
             for (int i = 0; i < 8; i++) pk->preamble[pk->preamble_prep_off[a] + i] = pk->airs[a].prep_commit[i];
-    size_t qoff = pk->q_main_words + pk->q_prep_words + pk->q_perm_words + pk->q_quot_words;
+    size_t qoff = pk->q_main_words + pk->q_cached_words + pk->q_prep_words + pk->q_perm_words + pk->q_quot_words;
     for (unsigned l = 0; l < pk->n_layers && rc == ZKHIP_OK; l++) {
         rc = merkle_plan_leaves(ctx, pk->hmax - l - 1, (uint32_t*)(base + o_dig_fri[l]), &pk->t_fri[l]);
         desc[l].layer = pk->d_flayer[l];
@@ -1469,8 +1504,10 @@ void zkhip_pk_destroy(zkhip_ctx* ctx, zkhip_pk* pk) {
     if (pk->h_stage_pinned) hipHostFree(pk->h_stage_pinned);
     if (pk->stage_ev) hipEventDestroy(pk->stage_ev);
     if (pk->t_perm) zkhip_tree_destroy(ctx, pk->t_perm);
-    for (auto& A : pk->airs)
+    for (auto& A : pk->airs) {
         if (A.t_prep) zkhip_tree_destroy(ctx, A.t_prep);
+        if (A.t_cached) zkhip_tree_destroy(ctx, A.t_cached);
+    }
     if (pk->t_quot) zkhip_tree_destroy(ctx, pk->t_quot);
     for (auto* t : pk->t_fri)
         if (t) zkhip_tree_destroy(ctx, t);
@@ -1534,7 +1571,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         uint32_t* hdr = pre + n_pre;
         uint32_t* pm = hdr + 4;
         memcpy(pre, pk->preamble.data(), n_pre * 4);
-        hdr[0] = PROOF_MAGIC + (pk->n_lu ? 1u : 0u) + (pk->n_prep ? 2u : 0u), hdr[1] = (uint32_t)n_airs, hdr[2] = hmax, hdr[3] = pk->n_layers;
+        hdr[0] = PROOF_MAGIC + (pk->n_lu ? 1u : 0u) + (pk->n_prep ? 2u : 0u) + (pk->n_cached ? 4u : 0u), hdr[1] = (uint32_t)n_airs, hdr[2] = hmax, hdr[3] = pk->n_layers;
         for (size_t a = 0; a < n_airs; a++) {
             const AirPlan& A = pk->airs[a];
             for (size_t i = 0; i < A.n_pvs; i++) {
@@ -1590,7 +1627,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     // Pipelined form (zkhip_set_commit_pipeline): the tallest chips' columns are extended block by block on the side stream
     // while the main stream's row sponge absorbs the blocks already done (state parked in HBM between blocks).
     const zkhip_pk::LdeGroup* top = nullptr;
-    if (ctx->commit_parts >= 2)
+    if (ctx->commit_parts >= 2 && pk->n_cached == 0)  // with cached partitions the leaf columns are not the LDE group's
         for (const auto& g : pk->lde_groups)
             if (g.kind == 0 && g.lh + b == hmax && g.lh >= 16 && g.n_cols >= 16 * ctx->commit_parts) top = &g;
     bool leaves_ready = false;
@@ -1637,6 +1674,13 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     }
     ZK_TRY(merkle_build(ctx, pk->t_main, leaves_ready));
     const uint32_t* d_root_main = zkhip_tree_root_device(pk->t_main);
+    // main-trace commitments in the reference's order: cached partitions (AIR order), then the common main
+    for (size_t a = 0; a < n_airs; a++) {
+        AirPlan& A = pk->airs[a];
+        if (!A.cw) continue;
+        ZK_TRY(merkle_build(ctx, A.t_cached, false));
+        ZK_TRY(transcript_observe(ctx, pk->d_tr, zkhip_tree_root_device(A.t_cached), 8, false));
+    }
     ZK_TRY(transcript_observe(ctx, pk->d_tr, d_root_main, 8, false));
 
     // ---- 1b. LogUp phase: permutation trace of every AIR with bus interactions, LDE + commit ----
@@ -1860,6 +1904,13 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         KernelScope ks(ctx, "copy_canon");
         hipLaunchKernelGGL(k_copy_canon, dim3((n_fin_words + 63) / 64), dim3(64), 0, st, d_final, pf + pk->off_final, n_fin_words);
         hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_main, pf + pk->off_roots, 8u);
+        {
+            size_t k = 0;
+            for (size_t a = 0; a < n_airs; a++)
+                if (pk->airs[a].cw)
+                    hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, zkhip_tree_root_device(pk->airs[a].t_cached),
+                                       pf + pk->off_roots_cached + 8 * k++, 8u);
+        }
         hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_quot, pf + pk->off_root_quot, 8u);
         if (pk->n_lu) {
             hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root_perm, pf + pk->off_root_perm, 8u);
@@ -1879,6 +1930,12 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         size_t off = pk->q_main_words;
         for (size_t a = 0; a < n_airs; a++) {
             const AirPlan& A = pk->airs[a];
+            if (!A.cw) continue;
+            ZK_TRY(merkle_open_device(ctx, A.t_cached, pk->d_indices, hmax - A.h, pk->params.num_queries, pq + off, pk->query_pitch));
+            off += A.cw + 8 * (size_t)A.h;
+        }
+        for (size_t a = 0; a < n_airs; a++) {
+            const AirPlan& A = pk->airs[a];
             if (!A.prep_w) continue;
             ZK_TRY(merkle_open_device(ctx, A.t_prep, pk->d_indices, hmax - A.h, pk->params.num_queries, pq + off, pk->query_pitch));
             off += A.prep_w + 8 * (size_t)A.h;
@@ -1886,9 +1943,9 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     }
     if (pk->n_lu)
         ZK_TRY(merkle_open_device(ctx, pk->t_perm, pk->d_indices, hmax - pk->h_perm, pk->params.num_queries,
-                                  pq + pk->q_main_words + pk->q_prep_words, pk->query_pitch));
+                                  pq + pk->q_main_words + pk->q_cached_words + pk->q_prep_words, pk->query_pitch));
     ZK_TRY(merkle_open_device(ctx, pk->t_quot, pk->d_indices, 0, pk->params.num_queries,
-                              pq + pk->q_main_words + pk->q_prep_words + pk->q_perm_words, pk->query_pitch));
+                              pq + pk->q_main_words + pk->q_cached_words + pk->q_prep_words + pk->q_perm_words, pk->query_pitch));
     if (pk->n_layers) {
         KernelScope ks(ctx, "fri_query");
         hipLaunchKernelGGL(k_fri_query, dim3(pk->params.num_queries, pk->n_layers), dim3(64), 0, st, pk->d_fri_desc,

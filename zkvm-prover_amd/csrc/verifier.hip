@@ -165,8 +165,8 @@ extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* a
     const unsigned lfp = prm->log_final_poly_len;
     if (lfp > ZKHIP_MAX_LOG_FINAL_POLY || b < 1 || b > 4) return ZKHIP_ERR_INVALID;
     unsigned hmax = 0;
-    size_t n_lu = 0, n_open = 0;
-    size_t main_w = 0, perm_w = 0, quot_w = 0, prep_words = 0;   // opened row words per query, per input commitment
+    size_t n_lu = 0, n_open = 0, n_cached = 0;
+    size_t main_w = 0, perm_w = 0, quot_w = 0, prep_words = 0, cached_words = 0;   // opened row words per query, per input commitment
     unsigned main_h = 0, perm_h = 0;
     for (size_t a = 0; a < n_airs; a++) {
         AirProgram pg;
@@ -175,7 +175,8 @@ extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* a
         const unsigned h = airs[a].log_height + b;
         hmax = std::max(hmax, h);
         main_h = std::max(main_h, h);
-        main_w += airs[a].width;
+        main_w += airs[a].width - pg.cached_width;
+        if (pg.cached_width) n_cached++, cached_words += pg.cached_width + 8 * (size_t)h;
         quot_w += 4 * (size_t)nch;
         n_open += 2 * airs[a].width + 4 * (size_t)nch;
         if (pg.prep_width) {
@@ -193,6 +194,7 @@ extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* a
     memset(out, 0, sizeof *out);
     size_t r = 4;
     out->root_main = r, r += 8;
+    out->roots_cached = n_cached ? r : 0, out->n_cached = n_cached, r += 8 * n_cached;
     if (n_lu) {
         out->root_perm = r, r += 8;
         out->exposed = r, out->n_exposed = n_lu, r += 4 * n_lu;
@@ -203,7 +205,7 @@ extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* a
     out->final_poly = r, out->n_final_poly = (size_t)1 << lfp, r += (size_t)4 << lfp;
     out->query_pow = r, r += 1;
     out->queries = r;
-    size_t qw = main_w + 8 * (size_t)main_h + prep_words + (n_lu ? perm_w + 8 * (size_t)perm_h : 0) + quot_w + 8 * (size_t)main_h;
+    size_t qw = main_w + 8 * (size_t)main_h + cached_words + prep_words + (n_lu ? perm_w + 8 * (size_t)perm_h : 0) + quot_w + 8 * (size_t)main_h;
     for (unsigned l = 0; l < n_layers; l++) qw += 4 + 8 * (size_t)(hmax - l - 1);
     out->query_words = qw;
     out->n_queries = prm->num_queries;
@@ -228,9 +230,10 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         if (proof[i] >= P) return ZKHIP_ERR_VERIFY;
     std::vector<AirProgram> pg(n_airs);
     unsigned hmax = 0;
-    size_t n_lu = 0, n_prep = 0;
+    size_t n_lu = 0, n_prep = 0, n_cached = 0;
     for (size_t a = 0; a < n_airs; a++) {
         if (parse_air(airs[a].program, airs[a].program_len, airs[a].width, &pg[a], nullptr) != 0) return ZKHIP_ERR_INVALID;
+        if (pg[a].cached_width) n_cached++;
         if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height + b > 27 || airs[a].log_height < lfp || airs[a].width == 0) return ZKHIP_ERR_INVALID;
         if (pg[a].max_degree > nch + 1) return ZKHIP_ERR_CONSTRAINT;
         if (airs[a].n_pvs && (!pvs || !pvs[a])) return ZKHIP_ERR_INVALID;
@@ -251,14 +254,17 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         size_t open_off;
     };
     std::vector<CMat> cm;
-    for (size_t a = 0; a < n_airs; a++) cm.push_back({airs[a].log_height, airs[a].log_height + b, airs[a].width, 2, 0});
+    // a cached main partition (leading columns of an AIR's main trace) is a matrix of its own, in a tree of its own
+    for (size_t a = 0; a < n_airs; a++) cm.push_back({airs[a].log_height, airs[a].log_height + b, airs[a].width - pg[a].cached_width, 2, 0});
+    for (size_t a = 0; a < n_airs; a++)
+        if (pg[a].cached_width) cm.push_back({airs[a].log_height, airs[a].log_height + b, pg[a].cached_width, 2, 0});
     for (size_t a = 0; a < n_airs; a++)
         if (pg[a].prep_width) cm.push_back({airs[a].log_height, airs[a].log_height + b, pg[a].prep_width, 2, 0});
     for (size_t a = 0; a < n_airs; a++)
         if (!pg[a].ints.empty()) cm.push_back({airs[a].log_height, airs[a].log_height + b, pg[a].perm_width(), 2, 0});
     for (size_t a = 0; a < n_airs; a++)
         for (unsigned j = 0; j < nch; j++) cm.push_back({airs[a].log_height, airs[a].log_height + b, 4, 1, 0});
-    const size_t cm_prep0 = n_airs, cm_perm0 = n_airs + n_prep, cm_quot0 = n_airs + n_prep + n_lu;
+    const size_t cm_cached0 = n_airs, cm_prep0 = n_airs + n_cached, cm_perm0 = cm_prep0 + n_prep, cm_quot0 = cm_perm0 + n_lu;
     size_t n_open = 0;
     for (auto& m : cm) {
         m.open_off = n_open;
@@ -272,12 +278,15 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     const unsigned n_layers = hmax - b - lfp;
     size_t r = 0;
     const size_t lu_words = n_lu ? 8 + 4 * n_lu : 0;
-    if (n_words < 4 + 16 + lu_words + 4 * n_open + 9 * (size_t)n_layers + 4 * n_fin + 1) return ZKHIP_ERR_VERIFY;
-    if (proof[0] != PROOF_MAGIC + (n_lu ? 1u : 0u) + (n_prep ? 2u : 0u) || proof[1] != n_airs || proof[2] != hmax || proof[3] != n_layers)
+    if (n_words < 4 + 16 + 8 * n_cached + lu_words + 4 * n_open + 9 * (size_t)n_layers + 4 * n_fin + 1) return ZKHIP_ERR_VERIFY;
+    if (proof[0] != PROOF_MAGIC + (n_lu ? 1u : 0u) + (n_prep ? 2u : 0u) + (n_cached ? 4u : 0u) || proof[1] != n_airs || proof[2] != hmax ||
+        proof[3] != n_layers)
         return ZKHIP_ERR_VERIFY;
     r = 4;
     const uint32_t* root_main = proof + r;
     r += 8;
+    const uint32_t* roots_cached = proof + r;  // one per AIR with a cached partition, AIR order
+    r += 8 * n_cached;
     const uint32_t *root_perm = nullptr, *exposed_c = nullptr;
     if (n_lu) {
         root_perm = proof + r;
@@ -319,6 +328,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
             }
         }
     }
+    ch.observe_canon(roots_cached, 8 * n_cached);  // main-trace commitments in the reference's order: cached..., common
     ch.observe_canon(root_main, 8);
     // LogUp phase: interaction challenges, permutation commitment, exposed sums (must cancel over all AIRs)
     uint32_t chal[N_CHAL] = {};
@@ -344,10 +354,10 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     const uint32_t gen = to_monty(FIELD_GEN_CANON);
 
     // ---- constraints at zeta ----
-    size_t k_lu = 0, k_prep = 0;
+    size_t k_lu = 0, k_prep = 0, k_cached = 0;
     for (size_t a = 0; a < n_airs; a++) {
         const unsigned lh = airs[a].log_height, h = lh + b;
-        const size_t W = airs[a].width;
+        const size_t W = airs[a].width, CW = pg[a].cached_width;
         // selectors of H at zeta
         Ext zn = zeta;
         for (unsigned k = 0; k < lh; k++) zn = ext_mul(zn, zn);
@@ -361,7 +371,14 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         const Ext is_last = ext_mul(zh, ext_inv(is_trans));
         const Ext inv_zh = ext_inv(zh);
         std::vector<Ext> vals(pg[a].n_nodes);
-        const Ext* local = &opened[cm[a].open_off];
+        // the AIR's main row = the cached partition's columns, then the common columns
+        std::vector<Ext> mrow(2 * W);
+        if (CW) {
+            const Ext* co = &opened[cm[cm_cached0 + k_cached++].open_off];
+            for (size_t k = 0; k < CW; k++) mrow[k] = co[k], mrow[W + k] = co[CW + k];
+        }
+        for (size_t k = 0; k < W - CW; k++) mrow[CW + k] = opened[cm[a].open_off + k], mrow[W + CW + k] = opened[cm[a].open_off + (W - CW) + k];
+        const Ext* local = mrow.data();
         const Ext* next = local + W;
         const Ext *plocal = nullptr, *pnext = nullptr;
         const uint32_t* expo = nullptr;
@@ -463,6 +480,11 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         batches.push_back(bt);
     };
     add_batch(0, n_airs, root_main);
+    {
+        size_t k = 0;
+        for (size_t a = 0; a < n_airs; a++)
+            if (pg[a].cached_width) add_batch(cm_cached0 + k, 1, roots_cached + 8 * k), k++;
+    }
     {
         size_t k = 0;
         for (size_t a = 0; a < n_airs; a++)
