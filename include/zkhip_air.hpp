@@ -21,7 +21,7 @@ namespace zkhip {
 namespace air {
 
 constexpr uint32_t P = 2013265921u;
-constexpr uint32_t AIR_MAGIC = 0x31414B5Au, PREP_MAGIC = 0x50504B5Au, LOGUP_MAGIC = 0x554C4B5Au;
+constexpr uint32_t AIR_MAGIC = 0x31414B5Au, PREP_MAGIC = 0x50504B5Au, LOGUP_MAGIC = 0x554C4B5Au, CACHED_MAGIC = 0x43414B5Au;
 enum Op : uint32_t { VAR, PUB, CONST, FIRST, LAST, TRANS, ADD, SUB, MUL, NEG, PERM, CHAL, EXPOSED, PREP };
 constexpr unsigned LOGUP_MAX_FIELDS = 32;  // challenge vector = gamma, beta^1 .. beta^32
 constexpr uint32_t EXT_W = 11;             // x^4 = 11
@@ -38,6 +38,12 @@ struct Expr {
 class AirBuilder {
   public:
     AirBuilder(size_t width, size_t n_pvs = 0, size_t prep_width = 0) : width_(width), n_pvs_(n_pvs), prep_width_(prep_width) {}
+    // cached main partition (OpenVM-v1 cached main): the first `cw` main columns are committed in a tree of their own
+    void set_cached_width(size_t cw) {
+        if (cw >= width_) throw std::out_of_range("cached_width must leave a common part");
+        cached_width_ = cw;
+    }
+    size_t cached_width() const { return cached_width_; }
     AirBuilder(const AirBuilder&) = delete;  // expressions point at their builder
     AirBuilder& operator=(const AirBuilder&) = delete;
 
@@ -152,7 +158,7 @@ class AirBuilder {
     inline Ext ext_add(const Ext& a, const Ext& b);
     inline void finalize_interactions();
 
-    size_t width_, n_pvs_, prep_width_;
+    size_t width_, n_pvs_, prep_width_, cached_width_ = 0;
     std::vector<std::tuple<uint32_t, uint32_t, uint32_t>> nodes_;
     std::vector<uint32_t> cons_;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::pair<uint32_t, unsigned>> cache_;
@@ -283,6 +289,10 @@ inline std::vector<uint32_t> AirBuilder::program() {
     if (prep_width_) {
         w.push_back(PREP_MAGIC);
         w.push_back((uint32_t)prep_width_);
+    }
+    if (cached_width_) {
+        w.push_back(CACHED_MAGIC);
+        w.push_back((uint32_t)cached_width_);
     }
     if (!ints_.empty()) {
         w.push_back(LOGUP_MAGIC);

@@ -38,6 +38,18 @@ int main() {
         b.push_interaction(7, {f0, f1}, b.constant(1), Kind::Send);
         dump("lookup_sender", b);
     }
+    {   // lookup_sender_air(3, 7) with a cached main partition of 2 columns
+        AirBuilder b(3, 0);
+        b.set_cached_width(2);
+        const Expr v0 = b.var(0);
+        const Expr t = v0 * (v0 - 1);
+        const Expr t0 = t * 0;
+        const Expr v2 = b.var(2);
+        b.assert_zero(t0 + v2 - v2);
+        const Expr f0 = b.var(0), f1 = b.var(1);
+        b.push_interaction(7, {f0, f1}, b.constant(1), Kind::Send);
+        dump("lookup_sender_cached", b);
+    }
     {   // lookup_table_air(7)
         AirBuilder b(3, 0);
         const Expr f0 = b.var(0), f1 = b.var(1), c = b.var(2);

@@ -25,6 +25,11 @@ def cpp_programs(tmp_path_factory):
     return progs
 
 
+def _with_cached(b, cw):
+    b.cached_width = cw
+    return b
+
+
 def _with_budget(b, budget):
     b.max_constraint_degree = budget
     return b
@@ -33,6 +38,7 @@ def _with_budget(b, budget):
 PY = {
     "fibonacci": lambda: air.fibonacci_air(),
     "lookup_sender": lambda: air.lookup_sender_air(3, 7),
+    "lookup_sender_cached": lambda: _with_cached(air.lookup_sender_air(3, 7), 2),
     "lookup_table": lambda: air.lookup_table_air(7),
     "limb": lambda: air.limb_air(13),
     "bus_mix": lambda: air.bus_mix_air(6),
