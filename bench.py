@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--width", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--commit-parts", type=int, default=-1,
-                    help="pipelined trace commit: column blocks per commit (0 = off; default: 4 when --inflight 1, else off)")
+                    help="pipelined trace commit: column blocks per commit (default 0 = off: it gains ~1 ms on one proof alone and loses 4 ms with three in flight, DESIGN.md 5)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent proofs in flight per GPU, each on its own HIP stream (segments of a chunk are "
                          "independent): memory-bound stages of one overlap the VALU-bound hashing of the other")
@@ -181,7 +181,7 @@ def main():
     for st in streams:
         with torch.cuda.stream(st):
             ctxs.append(z.Context(dev.index))  # binds the context to this HIP stream
-            cp = args.commit_parts if args.commit_parts >= 0 else (4 if n_pipe == 1 else 0)
+            cp = max(0, args.commit_parts)
             ctxs[-1].set_commit_pipeline(cp)
     ctx = ctxs[0]
 
@@ -402,7 +402,7 @@ def main():
                        "proof_bytes": pk.proof_size, "verified": ok,
                        "resident_key_bytes_per_pipeline": pk.workspace_bytes,
                        "inflight_per_gpu": n_pipe,
-                       "commit_pipeline_parts": args.commit_parts if args.commit_parts >= 0 else (4 if n_pipe == 1 else 0),
+                       "commit_pipeline_parts": max(0, args.commit_parts),
                        "exchange": None if world == 1 else {
                            "posted_per_rank": xstat["posted"], "mode": "asynchronous per proof (side stream), completed inside the timed region",
                            "ms_blocked_at_end_of_timed_region": round(xstat["wait_s"] * 1e3, 3),

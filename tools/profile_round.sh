@@ -11,7 +11,8 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES -d $O/v -o v --output-form
 find $O -name "*.csv" | head -30
 FC=$(find $O/f -name "*counter_collection.csv" | head -1); WC=$(find $O/w -name "*counter_collection.csv" | head -1); VC=$(find $O/v -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_traffic.py $FC $WC 4 $O/pmc_traffic.json
-python3 tools/pmc_valu.py $VC 4 $O/pmc_valu.json 2>&1 | tail -12
+VT=$(find $O/v -name "*kernel_trace.csv" | head -1)
+python3 tools/pmc_valu.py $VC $VT 4 $O/pmc_valu.json 2>&1 | tail -12
 cp $(find $O/a -name "*kernel_stats.csv" | head -1) $O/a_kernel_stats.csv
 cp $(find $O/b -name "*kernel_stats.csv" | head -1) $O/b_kernel_stats.csv
 # keep the merge small: drop the raw traces
