@@ -607,6 +607,71 @@ private:
     }
 };
 
+// ---- aggregation-tree scheduling (the part that does not need the recursion AIRs) -----------------------
+// crates/prover/src/prover/mod.rs:57-60 DEFAULT_AGG_TREE_CONFIG: leaf nodes verify up to 4 segment proofs, internal nodes up to 3
+// children, until one root remains.  The recursion (verifier) circuits themselves live in un-vendored OpenVM crates; what can
+// be built here is the SHAPE and the SCHEDULE: which node consumes which proofs, and the nodes of a level proven as
+// independent tasks over the lanes / GPUs of a BatchProver as soon as the level below is complete.
+struct AggregationTreeConfig {
+    unsigned num_children_internal = 3, num_children_leaf = 4;
+};
+struct AggregationPlan {
+    struct Node {
+        std::vector<size_t> children;  // level 0: indices of segment proofs; level l > 0: indices of nodes of level l - 1
+    };
+    size_t n_segments = 0;
+    std::vector<std::vector<Node>> levels;  // levels.back() has exactly one node: the root
+
+    static AggregationPlan build(size_t n_segments, AggregationTreeConfig cfg = {}) {
+        if (n_segments == 0 || cfg.num_children_leaf == 0 || cfg.num_children_internal < 2)
+            throw Error(Error::Setup, "aggregation plan needs segments, a leaf arity >= 1 and an internal arity >= 2");
+        AggregationPlan p;
+        p.n_segments = n_segments;
+        auto group = [](size_t n, unsigned arity) {
+            std::vector<Node> lv;
+            for (size_t i = 0; i < n; i += arity) {
+                Node nd;
+                for (size_t k = i; k < n && k < i + arity; k++) nd.children.push_back(k);
+                lv.push_back(std::move(nd));
+            }
+            return lv;
+        };
+        p.levels.push_back(group(n_segments, cfg.num_children_leaf));
+        while (p.levels.back().size() > 1) p.levels.push_back(group(p.levels.back().size(), cfg.num_children_internal));
+        return p;
+    }
+    size_t n_nodes() const {
+        size_t n = 0;
+        for (const auto& l : levels) n += l.size();
+        return n;
+    }
+};
+
+// Proves an aggregation plan on a BatchProver set up with the AGGREGATION app: `make_task(level, node, child_proofs)` builds
+// the ProvingTask of a node from its children's proofs (for the reference that is the leaf / internal verifier circuit's
+// input, crates/integration/src/lib.rs:461-514); the nodes of one level are queued over the lanes like independent
+// segments, a level starts when the previous one is complete.  Returns the root proof; `all` (optional) receives every
+// level's proofs.
+template <class MakeTask>
+inline StarkProof prove_aggregation(BatchProver& agg, const AggregationPlan& plan, const std::vector<StarkProof>& segment_proofs,
+                                    MakeTask&& make_task, std::vector<std::vector<StarkProof>>* all = nullptr) {
+    if (segment_proofs.size() != plan.n_segments) throw Error(Error::GenProof, "aggregation: segment proof count does not match the plan");
+    std::vector<StarkProof> below = segment_proofs;
+    for (size_t l = 0; l < plan.levels.size(); l++) {
+        std::vector<ProvingTask> tasks;
+        for (size_t n = 0; n < plan.levels[l].size(); n++) {
+            std::vector<const StarkProof*> kids;
+            for (size_t c : plan.levels[l][n].children) kids.push_back(&below.at(c));
+            ProvingTask t = make_task(l, n, kids);
+            if (t.identifier.empty()) t.identifier = "agg-" + std::to_string(l) + "-" + std::to_string(n);
+            tasks.push_back(std::move(t));
+        }
+        below = agg.prove_many(tasks);
+        if (all) all->push_back(below);
+    }
+    return below.at(0);
+}
+
 // crates/verifier/src/verifier.rs:20-85 UniversalVerifier: holds only verifying material (the app's AIR programs,
 // FRI parameters and preprocessed commitments -- no tables, no device) and checks StarkProofs.
 class UniversalVerifier {

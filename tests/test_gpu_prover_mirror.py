@@ -135,3 +135,48 @@ def test_batch_prover_queue_and_api_throughput(ora, tmp_path):
     tbad = pm.write_task(str(tmp_path / "bad"), bad, identifier="seg-bad")
     r = pm.run_cli("prove-batch", exe, cfg, str(tmp_path), "2", tasks[0], tbad, tasks[2])
     assert r.returncode == 1 and "kind 4" in r.stderr
+
+
+def test_aggregation_tree_schedule(ora, tmp_path):
+    """Six segments proven through a BatchProver, then the reference's aggregation tree shape (leaf arity 4, internal 3:
+    2 leaf nodes + 1 root) through another, every node bound to its children's commitments by a stand-in circuit (the
+    recursion AIRs are not available): node proofs verify, and their public inputs are what the children's proofs dictate."""
+    import struct
+
+    tasks, all_airs = [], []
+    for i in range(6):
+        sa = air.SyntheticAir(width=20, n_free=7, n_bool=3, n_boundary=2, seed=9)
+        tr, pv = sa.gen_trace(7, seed=50 + i)
+        ftr, fpv = air.fibonacci_trace(5, a0=i)
+        airs = [dict(program=sa.program(), log_height=7, width=20, n_pvs=len(pv), trace=tr, pvs=pv),
+                dict(program=air.fibonacci_air().program(), log_height=5, width=2, n_pvs=3, trace=ftr, pvs=fpv)]
+        all_airs.append(airs)
+        d = tmp_path / ("t%d" % i)
+        d.mkdir()
+        tasks.append(pm.write_task(str(d), airs, identifier="seg-%d" % i))
+    seg_exe, cfg = pm.write_app(str(tmp_path), all_airs[0], PARAMS)
+    (tmp_path / "agg").mkdir()
+    fib = [dict(program=air.fibonacci_air().program(), log_height=6, width=2, n_pvs=3)]
+    agg_exe, _ = pm.write_app(str(tmp_path / "agg"), fib, PARAMS)
+    r = pm.run_cli("prove-agg", seg_exe, agg_exe, cfg, str(tmp_path), "2", *tasks)
+    assert r.returncode == 0 and "aggregated 6 segments through 3 nodes in 2 levels" in r.stdout, r.stderr
+    seg_commit = [np.frombuffer(ora.stark_prove(PARAMS, a).tobytes(), np.uint32)[4:12] for a in all_airs]
+
+    def fold(level, node, commits):
+        a0, b0 = 1 + level, 1 + node
+        for c in commits:
+            for v in c:
+                a0 = (a0 * 31 + int(v)) % air.P
+                b0 = (b0 * 37 + int(v) + a0) % air.P
+        return a0, b0
+
+    node_commit = []
+    for n, kids in enumerate([[0, 1, 2, 3], [4, 5]]):
+        js = json.loads((tmp_path / ("agg-0-%d.json" % n)).read_text())
+        pvs = struct.unpack("<3I", pm.un_b64_bincode(js["user_pvs_proof"]))
+        assert pvs[:2] == fold(0, n, [seg_commit[k] for k in kids])
+        node_commit.append(np.frombuffer(pm.un_b64_bincode(js["proof"]), np.uint32)[4:12])
+        assert pm.run_cli("verify", agg_exe, cfg, str(tmp_path / ("agg-0-%d.json" % n))).returncode == 0
+    root = json.loads((tmp_path / "root.json").read_text())
+    assert struct.unpack("<3I", pm.un_b64_bincode(root["user_pvs_proof"]))[:2] == fold(1, 0, node_commit)
+    assert pm.run_cli("verify", agg_exe, cfg, str(tmp_path / "root.json")).returncode == 0

@@ -97,3 +97,25 @@ def test_prove_without_gpu_fails_loudly(tmp_path):
     task = pm.write_task(str(tmp_path), airs)
     r = pm.run_cli("prove", exe, cfg, task, str(tmp_path / "out.json"))
     assert r.returncode == 1 and "kind 2" in r.stderr and "gfx950" in r.stderr  # Error::Keygen, no CPU fallback
+
+
+def test_aggregation_plan_shape():
+    """AggregationPlan::build with the reference's tree (crates/prover/src/prover/mod.rs:57-60: leaf arity 4, internal 3):
+    every segment is consumed exactly once, every node of a level exactly once by the level above, one root."""
+    import json
+
+    import prover_mirror_util as pm
+
+    for n in (1, 2, 4, 5, 12, 13, 37, 100):
+        r = pm.run_cli("agg-plan", str(n))
+        assert r.returncode == 0, r.stderr
+        plan = json.loads(r.stdout)
+        lv = plan["levels"]
+        assert sorted(c for node in lv[0] for c in node) == list(range(n))
+        assert all(1 <= len(node) <= 4 for node in lv[0]) and all(len(node) == 4 for node in lv[0][:-1])
+        for below, above in zip(lv, lv[1:]):
+            assert sorted(c for node in above for c in node) == list(range(len(below)))
+            assert all(1 <= len(node) <= 3 for node in above)
+        assert len(lv[-1]) == 1 and plan["n_nodes"] == sum(len(l) for l in lv)
+    r = pm.run_cli("agg-plan", "9", "2", "2")
+    assert [len(l) for l in json.loads(r.stdout)["levels"]] == [5, 3, 2, 1]

@@ -116,6 +116,65 @@ int main(int argc, char** argv) {
             std::printf("batch: %zu proofs on %zu lanes in %.3f s\n", st.proofs, bp.lanes(), st.seconds);
             return 0;
         }
+        if (argc >= 3 && std::string(argv[1]) == "agg-plan") {
+            // agg-plan <n_segments> [leaf_arity internal_arity]: prints the aggregation tree (mod.rs:57-60 defaults 4 / 3), no device
+            AggregationTreeConfig cfg;
+            if (argc >= 5) cfg.num_children_leaf = (unsigned)std::stoul(argv[3]), cfg.num_children_internal = (unsigned)std::stoul(argv[4]);
+            AggregationPlan plan = AggregationPlan::build(std::stoul(argv[2]), cfg);
+            std::printf("{\"n_segments\": %zu, \"n_nodes\": %zu, \"levels\": [", plan.n_segments, plan.n_nodes());
+            for (size_t l = 0; l < plan.levels.size(); l++) {
+                std::printf("%s[", l ? ", " : "");
+                for (size_t n = 0; n < plan.levels[l].size(); n++) {
+                    std::printf("%s[", n ? ", " : "");
+                    for (size_t k = 0; k < plan.levels[l][n].children.size(); k++) std::printf("%s%zu", k ? ", " : "", plan.levels[l][n].children[k]);
+                    std::printf("]");
+                }
+                std::printf("]");
+            }
+            std::printf("]}\n");
+            return 0;
+        }
+        if (argc >= 8 && std::string(argv[1]) == "prove-agg") {
+            // prove-agg <seg_app> <agg_app> <cfg> <out_dir> <inflight> <segment task.bin>...: segments through one BatchProver, then
+            // the aggregation tree through another.  STAND-IN node circuit (the recursion AIRs are not available): the agg app
+            // is a Fibonacci chip whose public inputs (a0, b0) are folded from the children's trace commitments, so a node proof
+            // is bound to exactly its children; shape and schedule are the reference's (leaf arity 4, internal 3).
+            BatchProver seg = BatchProver::setup(ProverConfig{argv[2], argv[4]}, (unsigned)std::stoul(argv[6]));
+            BatchProver agg = BatchProver::setup(ProverConfig{argv[3], argv[4]}, (unsigned)std::stoul(argv[6]));
+            std::vector<ProvingTask> tasks;
+            for (int i = 7; i < argc; i++) tasks.push_back(read_task(argv[i]));
+            std::vector<StarkProof> seg_proofs = seg.prove_many(tasks);
+            AggregationPlan plan = AggregationPlan::build(seg_proofs.size());
+            const unsigned lh = 6;
+            auto make_task = [&](size_t level, size_t node, const std::vector<const StarkProof*>& kids) {
+                const uint32_t Pm = 2013265921u;
+                uint64_t a0 = 1 + level, b0 = 1 + node;
+                for (const StarkProof* k : kids)
+                    for (int w = 0; w < 8; w++) {  // words 4..11 of a proof: its main-trace commitment
+                        uint32_t v;
+                        memcpy(&v, k->proof.data() + 16 + 4 * w, 4);
+                        a0 = (a0 * 31 + v) % Pm, b0 = (b0 * 37 + v + a0) % Pm;
+                    }
+                std::vector<uint32_t> tr(2u << lh);
+                uint64_t x = a0, y = b0;
+                for (unsigned r = 0; r < (1u << lh); r++) {
+                    tr[r] = (uint32_t)x, tr[(1u << lh) + r] = (uint32_t)y;
+                    uint64_t z = (x + y) % Pm;
+                    x = y, y = z;
+                }
+                ProvingTask t;
+                t.serialized_witness.push_back(encode_witness(lh, {(uint32_t)a0, (uint32_t)b0, tr[(2u << lh) - 1]}, tr));
+                return t;
+            };
+            std::vector<std::vector<StarkProof>> all;
+            StarkProof root = prove_aggregation(agg, plan, seg_proofs, make_task, &all);
+            std::ofstream(std::string(argv[5]) + "/root.json") << root.to_json();
+            for (size_t l = 0; l < all.size(); l++)
+                for (size_t n = 0; n < all[l].size(); n++)
+                    std::ofstream(std::string(argv[5]) + "/agg-" + std::to_string(l) + "-" + std::to_string(n) + ".json") << all[l][n].to_json();
+            std::printf("aggregated %zu segments through %zu nodes in %zu levels\n", seg_proofs.size(), plan.n_nodes(), plan.levels.size());
+            return 0;
+        }
         if (argc >= 7 && std::string(argv[1]) == "bench-many") {
             // bench-many <app> <cfg> <task.bin> <n_proofs> <inflight> [n_gpus]: BatchProver::prove_repeated -- the witness is
             // uploaded once per lane (traces resident in HBM), then n proofs are proven and self-verified through the
@@ -135,7 +194,7 @@ int main(int argc, char** argv) {
                         last.size());
             return 0;
         }
-        std::fprintf(stderr, "usage: prove_cli prove|prove-many|prove-batch|bench-many|verify ...\n");
+        std::fprintf(stderr, "usage: prove_cli prove|prove-many|prove-batch|prove-agg|agg-plan|bench-many|verify ...\n");
         return 2;
     } catch (const Error& e) {
         std::fprintf(stderr, "error(kind %d): %s\n", (int)e.kind, e.what());
