@@ -28,6 +28,9 @@
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -538,21 +541,73 @@ public:
     }
 
     // throughput form (what bench.py times): the witness is uploaded ONCE per lane -- traces resident in HBM, as they are
-    // when trace generation runs on the device -- and proven `n` times in total; every proof is self-verified
+    // when trace generation runs on the device -- and proven `n` times in total.  Every proof is self-verified (mod.rs:407-411)
+    // by a pool of host threads BESIDE the lanes: a lane hands its finished proof over and starts the next one at once, so the
+    // host-side check (tens of ms of scalar Poseidon2 per 1.1 MB proof) never leaves that lane's GPU stream idle.  The clock
+    // stops when the last proof has been verified.
     Stats prove_repeated(const ProvingTask& task, size_t n, std::vector<uint8_t>* last_proof = nullptr) {
+        using clk = std::chrono::steady_clock;
         std::vector<Prover::DeviceWitness> dws(lanes_.size());
         parallel_lanes([&](size_t l) { dws[l] = lanes_[l].upload_witness(task); });
         for (size_t l = 0; l < lanes_.size(); l++) (void)lanes_[l].prove_resident(dws[l]);  // first proof: scratch growth, code objects
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<StarkProof> queue;
+        bool done = false;
+        std::string verr;
+        size_t verified = 0;
+        StarkProof last;
+        const Prover& checker = lanes_[0];
+        std::vector<std::thread> pool;
+        for (size_t v = 0; v < lanes_.size(); v++)
+            pool.emplace_back([&]() {
+                for (;;) {
+                    StarkProof sp;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return done || !queue.empty(); });
+                        if (queue.empty()) return;
+                        sp = std::move(queue.front());
+                        queue.pop_front();
+                    }
+                    try {
+                        checker.verify_stark_proof(sp);
+                        std::lock_guard<std::mutex> lk(mu);
+                        verified++;
+                    } catch (const std::exception& e) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (verr.empty()) verr = e.what();
+                    }
+                }
+            });
         Stats st;
-        std::vector<StarkProof> last(lanes_.size());
-        std::atomic<size_t> next{0};
-        std::vector<size_t> lane_of(n);
-        run_indexed(n, &st, [&](Prover& p, size_t lane, size_t i) {
-            last[lane] = p.prove_resident(dws[lane]);
-            lane_of[i] = lane;
-        });
+        auto t0 = clk::now();
+        std::string perr;
+        try {
+            run_indexed(n, &st, [&](Prover& p, size_t lane, size_t i) {
+                StarkProof sp = p.prove_resident(dws[lane], /*self_verify=*/false);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (i + 1 == n) last = sp;
+                    queue.push_back(std::move(sp));
+                }
+                cv.notify_one();
+            });
+        } catch (const std::exception& e) {
+            perr = e.what();
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            done = true;
+        }
+        cv.notify_all();
+        for (auto& t : pool) t.join();
+        st.seconds = std::chrono::duration<double>(clk::now() - t0).count();
+        st.proofs_per_second = st.seconds > 0 ? n / st.seconds : 0;
         for (size_t l = 0; l < lanes_.size(); l++) lanes_[l].free_witness(dws[l]);
-        if (last_proof && n) *last_proof = last[lane_of[n - 1]].proof;
+        if (!perr.empty()) throw Error(Error::GenProof, perr);
+        if (!verr.empty() || verified != n) throw Error(Error::VerifyProof, verr.empty() ? "not every proof was verified" : verr);
+        if (last_proof && n) *last_proof = last.proof;
         return st;
     }
 

@@ -313,38 +313,81 @@ __global__ __launch_bounds__(256) void k_logup_sums(LogupMulti m) {
 
 // ---------------------------------------------------------------------------------------------
 // openings: p(z) = (z^N - s^N)/(N s^N) * sum_i p(s w^i) * x_i/(z - x_i), x_i = s w^i (natural order)
-struct PointsArgs {
-    const uint32_t* zeta;  // ext
-    uint32_t w_n;          // generator of H (Montgomery): second point = zeta * w_n
-    uint32_t shift;        // s
-    uint32_t scale_base;   // 1/(N s^N)
-    uint32_t s_pow_n;      // s^N
-    unsigned lh, n_pts;
-    uint32_t* pts;    // n_pts ext
-    uint32_t* scale;  // n_pts ext
+// One opening group = the columns of all matrices that share barycentric weights (a height, a coset shift, 1 or 2 points).
+// All groups of a proof are processed by ONE launch per kernel over this descriptor table (static per key).
+struct OpenGroupDev {
+    uint32_t lh, n_pts;
+    uint32_t shift, w_n, s_pow_n, scale_base;  // Montgomery: coset shift s, generator of H, s^N, 1/(N s^N)
+    uint32_t col_first, n_cols;                // slice of the column pointer / destination tables
+    uint32_t n_tiles;                          // 512-row tiles (one wave each)
+    uint32_t tile_first;                       // first tile inside the flattened tile grid of ITS point-count class
+    uint32_t wblk_first;                       // first 256-row block inside the flattened weights grid
+    uint32_t fin_first;                        // first (column, point) block inside the flattened finish grid
+    uint64_t weights_off;                      // ext offset of weights[pt][i] inside d_weights
+    uint64_t partial_off;                      // word offset of partial[tile][col][pt][4] inside d_partial
 };
-__global__ void k_open_points(PointsArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Ext z = ld_ext(a.zeta);
+struct OpenMulti {
+    const OpenGroupDev* g;
+    uint32_t n;
+    const uint32_t* idx2;  // indices of the groups with two points (trace-like matrices), tile_first ascending
+    uint32_t n2;
+    const uint32_t* idx1;  // one point (quotient chunks)
+    uint32_t n1;
+    const uint32_t* zeta;
+    uint32_t* pts;         // per group: pts[2] then scale[2] (ext each)
+    uint32_t* weights;
+    uint32_t* partial;
+    const uint32_t* const* col_ptrs;
+    const uint32_t* dst;
+    uint32_t* opened;
+    const uint32_t* tw_fwd;
+    unsigned tw_log;
+};
+// points z, z*w and the scales (z_pt^N - s^N)/(N s^N) of every group: block = group, one lane
+__global__ void k_open_points(OpenMulti m) {
+    if (threadIdx.x != 0) return;
+    const OpenGroupDev a = m.g[blockIdx.x];
+    uint32_t* pts = m.pts + 16 * (size_t)blockIdx.x;
+    Ext z = ld_ext(m.zeta);
     for (unsigned p = 0; p < a.n_pts; p++) {
         Ext zp = p == 0 ? z : ext_mul_base(z, a.w_n);
-        st_ext(a.pts + 4 * p, zp);
+        st_ext(pts + 4 * p, zp);
         Ext t = zp;
         for (unsigned k = 0; k < a.lh; k++) t = ext_mul(t, t);
         t.c[0] = msub(t.c[0], a.s_pow_n);
-        st_ext(a.scale + 4 * p, ext_mul_base(t, a.scale_base));
+        st_ext(pts + 8 + 4 * p, ext_mul_base(t, a.scale_base));
     }
 }
 
+// pts[0] = z, pts[1] = z * w (the two opening points of a height, for the FRI batching denominators)
+__global__ void k_two_points(const uint32_t* zeta, uint32_t w_n, uint32_t* pts) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const Ext z = ld_ext(zeta);
+    st_ext(pts, z);
+    st_ext(pts + 4, ext_mul_base(z, w_n));
+}
+
 // weights[pt][i] = x_i / (z_pt - x_i)
-__global__ __launch_bounds__(256) void k_bary_weights(const uint32_t* pts, unsigned n_pts, uint32_t shift,
-                                                      const uint32_t* tw_fwd, unsigned tw_shift, unsigned lh,
-                                                      uint32_t* weights) {
+__global__ __launch_bounds__(256) void k_bary_weights(OpenMulti m) {
+    uint32_t gi = 0;
+    {
+        uint32_t lo = 0, hi = m.n - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (m.g[mid].wblk_first <= blockIdx.x) lo = mid;
+            else hi = mid - 1;
+        }
+        gi = lo;
+    }
+    const OpenGroupDev& a = m.g[gi];
+    const unsigned lh = a.lh;
     const size_t N = (size_t)1 << lh;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = (size_t)(blockIdx.x - a.wblk_first) * 256 + threadIdx.x;
     if (i >= N) return;
-    uint32_t x = mmul(shift, lh == 0 ? MONTY_ONE : root_pow(tw_fwd, tw_shift, lh, (uint32_t)i));
-    for (unsigned p = 0; p < n_pts; p++) {
+    const uint32_t* pts = m.pts + 16 * (size_t)gi;
+    uint32_t* weights = m.weights + 4 * a.weights_off;
+    uint32_t x = mmul(a.shift, lh == 0 ? MONTY_ONE : root_pow(m.tw_fwd, m.tw_log - lh, lh, (uint32_t)i));
+    for (unsigned p = 0; p < a.n_pts; p++) {
         Ext d = ld_ext(pts + 4 * p);
         d.c[0] = msub(d.c[0], x);
         Ext w = ext_mul_base(ext_inv(d), x);
@@ -356,15 +399,32 @@ __global__ __launch_bounds__(256) void k_bary_weights(const uint32_t* pts, unsig
 // 64*RK rows (lane = row, RK rows per lane, their weights held in registers); per column the lane
 // sums are combined with DPP/shuffle adds and lane 0 stores the wave's partial.  No LDS, no
 // barriers, so the loads of the next column are in flight while the current one is multiplied.
+// The flattened tile grid covers every group with NPTS points; a wave finds its group by its tile index.
 template <int NPTS, int RK>
-__global__ __launch_bounds__(256) void k_col_reduce(const uint32_t* const* __restrict__ col_ptrs, uint32_t n_cols,
-                                                    unsigned lh, const uint32_t* __restrict__ weights,
-                                                    uint32_t* __restrict__ partial) {
-    const size_t N = (size_t)1 << lh;
+__global__ __launch_bounds__(256) void k_col_reduce(OpenMulti m) {
+    const uint32_t* idx = NPTS == 2 ? m.idx2 : m.idx1;
+    const uint32_t n_idx = NPTS == 2 ? m.n2 : m.n1;
     const unsigned lane = threadIdx.x & 63u;
-    const size_t tile = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t gtile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint32_t gi;
+    {
+        uint32_t lo = 0, hi = n_idx - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (m.g[idx[mid]].tile_first <= gtile) lo = mid;
+            else hi = mid - 1;
+        }
+        gi = idx[lo];
+    }
+    const OpenGroupDev& a = m.g[gi];
+    const size_t tile = gtile - a.tile_first;
+    if (tile >= a.n_tiles) return;  // beyond the last group's tiles (grid rounded up to 4 waves per block)
+    const size_t N = (size_t)1 << a.lh;
+    const uint32_t n_cols = a.n_cols;
+    const uint32_t* const* __restrict__ col_ptrs = m.col_ptrs + a.col_first;
+    const uint32_t* __restrict__ weights = m.weights + 4 * a.weights_off;
+    uint32_t* __restrict__ partial = m.partial + a.partial_off;
     const size_t row0 = tile * 64 * RK + lane;
-    if (tile * 64 * RK >= N) return;
     uint32_t w[RK][NPTS][4];
 #pragma unroll
     for (int k = 0; k < RK; k++) {
@@ -422,11 +482,24 @@ __global__ __launch_bounds__(256) void k_col_reduce(const uint32_t* const* __res
     }
 }
 
-// opened[dst[c][pt]] = scale[pt] * sum_tiles partial[tile][c][pt]
-__global__ __launch_bounds__(64) void k_open_finish(const uint32_t* partial, uint32_t n_tiles, uint32_t n_cols,
-                                                    unsigned n_pts, const uint32_t* scale, const uint32_t* dst,
-                                                    uint32_t* opened) {
-    const uint32_t c = blockIdx.x, p = blockIdx.y, lane = threadIdx.x;
+// opened[dst[c][pt]] = scale[pt] * sum_tiles partial[tile][c][pt]; block = one (column, point) of one group
+__global__ __launch_bounds__(64) void k_open_finish(OpenMulti m) {
+    uint32_t gi = 0;
+    {
+        uint32_t lo = 0, hi = m.n - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (m.g[mid].fin_first <= blockIdx.x) lo = mid;
+            else hi = mid - 1;
+        }
+        gi = lo;
+    }
+    const OpenGroupDev& a = m.g[gi];
+    const uint32_t lb = blockIdx.x - a.fin_first, n_pts = a.n_pts, n_cols = a.n_cols, n_tiles = a.n_tiles;
+    const uint32_t c = lb / n_pts, p = lb % n_pts, lane = threadIdx.x;
+    const uint32_t* partial = m.partial + a.partial_off;
+    const uint32_t* scale = m.pts + 16 * (size_t)gi + 8;
+    const uint32_t* dst = m.dst + 2 * (size_t)a.col_first;
     uint32_t acc[4] = {0, 0, 0, 0};
     for (uint32_t t = lane; t < n_tiles; t += 64) {
         const uint32_t* s = partial + ((size_t)t * n_cols + c) * (n_pts * 4) + p * 4;
@@ -442,7 +515,7 @@ __global__ __launch_bounds__(64) void k_open_finish(const uint32_t* partial, uin
     }
     if (lane == 0) {
         Ext r = ext_mul(Ext{{acc[0], acc[1], acc[2], acc[3]}}, ld_ext(scale + 4 * p));
-        st_ext(opened + 4 * (size_t)dst[2 * c + p], r);  // dst: ext index of (column, point) inside the opened-value array
+        st_ext(m.opened + 4 * (size_t)dst[2 * c + p], r);  // dst: ext index of (column, point) inside the opened-value array
     }
 }
 
@@ -717,6 +790,9 @@ struct zkhip_pk {
         uint32_t first, n_cols;
     };
     std::vector<OpenGroup> open_groups;
+    OpenGroupDev* d_og = nullptr;  // the groups as device descriptors (all groups of a proof: one launch per kernel)
+    uint32_t *d_og2_idx = nullptr, *d_og1_idx = nullptr;
+    uint32_t og_n = 0, og2_n = 0, og1_n = 0, og2_tiles = 0, og1_tiles = 0, og_wblocks = 0, og_fin_blocks = 0;
     std::vector<const uint32_t*> open_ptrs_host;          // pointer table (host copy)
     struct MainCol {
         uint32_t index, air, col;
@@ -1088,8 +1164,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     size_t o_pre = bp.take(pk->preamble.size() * 4);
     size_t o_chal = bp.take((3 + pk->n_layers + ((size_t)1 << pk->lfp)) * 16);  // + the final polynomial's coefficients
     size_t o_opened = bp.take(n_open * 16);
-    size_t o_pts = bp.take(64 * 16);
-    size_t o_weights = bp.take(2 * max_n * 16);
+    size_t o_pts = 0, o_weights = 0;  // sized once the opening groups are known (below)
     // opening groups (sizes only here; the pointer tables are filled once the workspace is laid out)
     size_t partial_words = 16;
     {
@@ -1129,7 +1204,18 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         }
         pk->lde_total_cols = lfirst;
     }
-    size_t o_partial = bp.take(partial_words * 4);
+    // every group keeps its own weights / partial sums / points: all groups run in one launch per kernel
+    size_t og_weights_ext = 0, og_partial_words = 16;
+    for (const auto& g : pk->open_groups) {
+        og_weights_ext += (size_t)g.n_pts << g.lh;
+        og_partial_words += ((((size_t)1 << g.lh) + 511) / 512) * g.n_cols * g.n_pts * 4;
+    }
+    (void)partial_words;
+    o_pts = bp.take((pk->open_groups.size() + 1) * 16 * 4);
+    o_weights = bp.take(og_weights_ext * 16 + 16);
+    size_t o_partial = bp.take(og_partial_words * 4);
+    const size_t o_og = bp.take((pk->open_groups.size() + 1) * sizeof(OpenGroupDev));
+    const size_t o_og2 = bp.take((pk->open_groups.size() + 1) * 4), o_og1 = bp.take((pk->open_groups.size() + 1) * 4);
     size_t o_open_ptrs = bp.take((pk->open_total_cols + pk->lde_total_cols) * sizeof(uint32_t*) + 16);
     size_t o_lde_dst = bp.take(pk->lde_total_cols * sizeof(uint32_t*) + 16);
     size_t o_open_dst = bp.take(pk->open_total_cols * 8 + 16);
@@ -1234,6 +1320,42 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     pk->d_pts = (uint32_t*)(base + o_pts);
     pk->d_weights = (uint32_t*)(base + o_weights);
     pk->d_partial = (uint32_t*)(base + o_partial);
+    {
+        pk->d_og = (OpenGroupDev*)(base + o_og);
+        pk->d_og2_idx = (uint32_t*)(base + o_og2);
+        pk->d_og1_idx = (uint32_t*)(base + o_og1);
+        std::vector<OpenGroupDev> ogs;
+        std::vector<uint32_t> i2, i1;
+        uint64_t w_off = 0, p_off = 0;
+        const uint32_t gen_m = to_monty(FIELD_GEN_CANON);
+        for (const auto& g : pk->open_groups) {
+            if (g.n_cols == 0) continue;
+            const size_t N = (size_t)1 << g.lh;
+            OpenGroupDev d;
+            d.lh = g.lh, d.n_pts = g.n_pts;
+            d.shift = g.chunk < 0 ? MONTY_ONE : mmul(gen_m, host_pow(two_adic_generator(g.lh + pk->b), bitrev32((uint32_t)g.chunk, pk->b)));
+            d.w_n = two_adic_generator(g.lh);
+            d.s_pow_n = host_pow(d.shift, N);
+            d.scale_base = minv(mmul(to_monty((uint32_t)(N % P)), d.s_pow_n));
+            d.col_first = g.first, d.n_cols = g.n_cols;
+            d.n_tiles = (uint32_t)((N + 511) / 512);
+            uint32_t& tiles = g.n_pts == 2 ? pk->og2_tiles : pk->og1_tiles;
+            d.tile_first = tiles;
+            tiles += d.n_tiles;
+            d.wblk_first = pk->og_wblocks;
+            pk->og_wblocks += (uint32_t)((N + 255) / 256);
+            d.fin_first = pk->og_fin_blocks;
+            pk->og_fin_blocks += g.n_cols * g.n_pts;
+            d.weights_off = w_off, w_off += (uint64_t)g.n_pts * N;
+            d.partial_off = p_off, p_off += (uint64_t)d.n_tiles * g.n_cols * g.n_pts * 4;
+            (g.n_pts == 2 ? i2 : i1).push_back((uint32_t)ogs.size());
+            ogs.push_back(d);
+        }
+        pk->og_n = (uint32_t)ogs.size(), pk->og2_n = (uint32_t)i2.size(), pk->og1_n = (uint32_t)i1.size();
+        if (rc == ZKHIP_OK && !ogs.empty()) rc = upload(ctx, pk->d_og, ogs.data(), ogs.size() * sizeof(OpenGroupDev));
+        if (rc == ZKHIP_OK && !i2.empty()) rc = upload(ctx, pk->d_og2_idx, i2.data(), i2.size() * 4);
+        if (rc == ZKHIP_OK && !i1.empty()) rc = upload(ctx, pk->d_og1_idx, i1.data(), i1.size() * 4);
+    }
     pk->d_apow_f = (uint32_t*)(base + o_apow_f);
     pk->d_ro_inv = (uint32_t*)(base + o_ro_inv);
     pk->d_open_ptrs = (const uint32_t**)(base + o_open_ptrs);
@@ -1773,46 +1895,27 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     // -- main, preprocessed and permutation matrices of every AIR of one height; chunk j of every AIR of one height --
     // are reduced by one launch over a pointer table.  Main-trace columns live in the caller's buffers: their table
     // entries are refreshed when the caller passes other buffers than last time.
-    for (const auto& g : pk->open_groups) {
-        if (g.n_cols == 0) continue;
-        const unsigned lh = g.lh, n_pts = g.n_pts;
-        const size_t N = (size_t)1 << lh;
-        const uint32_t shift = g.chunk < 0 ? MONTY_ONE : mmul(gen, host_pow(two_adic_generator(lh + b), bitrev32((uint32_t)g.chunk, b)));
-        PointsArgs pa;
-        pa.zeta = d_zeta;
-        pa.w_n = two_adic_generator(lh);
-        pa.shift = shift;
-        pa.s_pow_n = host_pow(shift, N);
-        pa.scale_base = minv(mmul(to_monty((uint32_t)(N % P)), pa.s_pow_n));
-        pa.lh = lh;
-        pa.n_pts = n_pts;
-        pa.pts = pk->d_pts;
-        pa.scale = pk->d_pts + 8;
+    // every (height, chunk) group in one launch per kernel: points + scales, barycentric weights, column reduction (one
+    // launch per point count), final sums
+    if (pk->og_n) {
+        const OpenMulti om{pk->d_og, pk->og_n, pk->d_og2_idx, pk->og2_n, pk->d_og1_idx, pk->og1_n, d_zeta, pk->d_pts, pk->d_weights,
+                           pk->d_partial, pk->d_open_ptrs, pk->d_open_dst, pk->d_opened, ctx->d_tw_fwd, ctx->tw_log};
         {
             KernelScope ks(ctx, "open_points");
-            hipLaunchKernelGGL(k_open_points, dim3(1), dim3(64), 0, st, pa);
+            hipLaunchKernelGGL(k_open_points, dim3(pk->og_n), dim3(64), 0, st, om);
         }
         {
             KernelScope ks(ctx, "bary_weights");
-            hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pk->d_pts, n_pts,
-                               shift, ctx->d_tw_fwd, lh ? ctx->tw_log - lh : 0, lh, pk->d_weights);
+            hipLaunchKernelGGL(k_bary_weights, dim3(pk->og_wblocks), dim3(256), 0, st, om);
         }
-        constexpr int RK = 8;
-        const uint32_t n_tiles = (uint32_t)((N + 64 * RK - 1) / (64 * RK));
         {
             KernelScope ks(ctx, "open_col_reduce");
-            dim3 grid((n_tiles + 3) / 4);
-            if (n_pts == 2)
-                hipLaunchKernelGGL((k_col_reduce<2, RK>), grid, dim3(256), 0, st, pk->d_open_ptrs + g.first, g.n_cols, lh,
-                                   pk->d_weights, pk->d_partial);
-            else
-                hipLaunchKernelGGL((k_col_reduce<1, RK>), grid, dim3(256), 0, st, pk->d_open_ptrs + g.first, g.n_cols, lh,
-                                   pk->d_weights, pk->d_partial);
+            if (pk->og2_n) hipLaunchKernelGGL((k_col_reduce<2, 8>), dim3((pk->og2_tiles + 3) / 4), dim3(256), 0, st, om);
+            if (pk->og1_n) hipLaunchKernelGGL((k_col_reduce<1, 8>), dim3((pk->og1_tiles + 3) / 4), dim3(256), 0, st, om);
         }
         {
             KernelScope ks(ctx, "open_finish");
-            hipLaunchKernelGGL(k_open_finish, dim3(g.n_cols, n_pts), dim3(64), 0, st, pk->d_partial, n_tiles, g.n_cols, n_pts,
-                               pk->d_pts + 8, pk->d_open_dst + 2 * (size_t)g.first, pk->d_opened);
+            hipLaunchKernelGGL(k_open_finish, dim3(pk->og_fin_blocks), dim3(64), 0, st, om);
         }
         ZK_HIP_CHECK(ctx, hipGetLastError());
     }
@@ -1832,19 +1935,9 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
                                pk->d_opened, pk->d_ro_slots);
         }
         for (const auto& g : pk->ro_groups) {
-            PointsArgs pa;  // zeta and zeta * w_N
-            pa.zeta = d_zeta;
-            pa.w_n = two_adic_generator(g.lh);
-            pa.shift = MONTY_ONE;
-            pa.s_pow_n = MONTY_ONE;
-            pa.scale_base = MONTY_ONE;
-            pa.lh = 0;
-            pa.n_pts = 2;
-            pa.pts = pk->d_pts;
-            pa.scale = pk->d_pts + 8;
             {
                 KernelScope ks(ctx, "reduce_prep");
-                hipLaunchKernelGGL(k_open_points, dim3(1), dim3(64), 0, st, pa);
+                hipLaunchKernelGGL(k_two_points, dim3(1), dim3(64), 0, st, d_zeta, two_adic_generator(g.lh), pk->d_pts);  // zeta, zeta * w_N
                 hipLaunchKernelGGL(k_ro_denoms, dim3((unsigned)((((size_t)1 << g.h) + 255) / 256)), dim3(256), 0, st, pk->d_pts,
                                    ctx->d_tw_fwd, gen, g.h, ctx->tw_log - g.h, pk->d_ro_inv);
             }
