@@ -30,6 +30,18 @@ def _prep_airs():
             dict(program=air.range_table_air().program(), log_height=3, width=1, n_pvs=0, trace=m, pvs=nopv, prep=prep)]
 
 
+def _cached_airs():
+    """cached main partitions next to a bus and a preprocessed table"""
+    airs = _prep_airs() + _logup_airs()[:1] + _logup_airs()[2:]
+    sa = air.SyntheticAir(width=14, n_free=5, n_bool=2, n_boundary=2, seed=3)
+    sa.builder.cached_width = 6
+    tr, pv = sa.gen_trace(5, seed=4)
+    lb = air.lookup_sender_air()
+    lb.cached_width = 1
+    airs[3] = dict(airs[3], program=lb.program())
+    return [dict(program=sa.program(), log_height=5, width=14, n_pvs=len(pv), trace=tr, pvs=pv)] + airs
+
+
 def _plain_airs():
     sa = air.SyntheticAir(width=14, n_free=5, n_bool=2, n_boundary=2, seed=3)
     tr, pv = sa.gen_trace(5, seed=4)
@@ -50,7 +62,7 @@ def fuzz_exe(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("case", [_plain_airs, _logup_airs, _prep_airs])
+@pytest.mark.parametrize("case", [_plain_airs, _logup_airs, _prep_airs, _cached_airs])
 def test_verifier_asan_ubsan_fuzz(ora, tmp_path, fuzz_exe, case):
     exe = fuzz_exe
     airs = case()
@@ -66,3 +78,18 @@ def test_verifier_asan_ubsan_fuzz(ora, tmp_path, fuzz_exe, case):
                        capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 mutated proofs accepted" in r.stdout
+
+
+def test_codec_asan_ubsan_fuzz(tmp_path):
+    """The v1 proof-container codec parses untrusted bytes too: the reference's stored proof and 3000 mutated variants under
+    ASan + UBSan; whatever still parses must re-encode to exactly its input."""
+    exe = tmp_path / "fuzz_codec"
+    csrc = os.path.join(ROOT, "zkvm-prover_amd", "csrc")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-I", os.path.join(ROOT, "include"), "-I", csrc, "-x", "c++", os.path.join(csrc, "codec.hip"),
+           os.path.join(csrc, "verifier.hip"), os.path.join(ROOT, "tests", "fuzz_codec.cpp"), "-o", str(exe)]
+    subprocess.check_call(cmd)
+    blob = os.path.join(ROOT, "tests", "golden", "ref_proofs", "chunk-proof-feynman.proofs.bin")
+    r = subprocess.run([str(exe), blob, "3000"], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 round-trip mismatches" in r.stdout
