@@ -56,7 +56,9 @@ uint32_t zkhip_version(void);
 int zkhip_ctx_create(int device, zkhip_ctx **out);
 void zkhip_ctx_destroy(zkhip_ctx *ctx);
 const char *zkhip_last_error(const zkhip_ctx *ctx);
-/* hipStream_t of the caller (e.g. the stream that produced the trace); NULL = default stream */
+/* A context issues all its work on ONE stream: its own (created with the context, non-blocking -- several contexts on one GPU
+ * overlap) unless the caller hands in another hipStream_t here (e.g. the stream that produced the trace); NULL = the legacy
+ * default stream.  Synchronises with the stream used so far. */
 int zkhip_set_stream(zkhip_ctx *ctx, void *hip_stream);
 int zkhip_sync(zkhip_ctx *ctx);
 /* Trace commit of zkhip_prove as a pipeline of `parts` column blocks (2..8; 0 or 1 = off, the default unless the

@@ -88,9 +88,11 @@ static int selftest(zkhip_ctx* ctx) {
     uint32_t* d_bad = nullptr;
     uint32_t h_bad = 0;
     if (hipMalloc(&d_bad, 4) != hipSuccess) return ZKHIP_ERR_NOMEM;
-    hipMemset(d_bad, 0, 4);
+    // everything on the context's stream (a non-blocking stream is not ordered against the legacy default stream)
+    hipMemsetAsync(d_bad, 0, 4, ctx->stream);
     hipLaunchKernelGGL(k_selftest, dim3(64), dim3(256), 0, ctx->stream, d_bad);
-    hipError_t e = hipMemcpy(&h_bad, d_bad, 4, hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(d_bad);
     if (e != hipSuccess) return ZKHIP_ERR_HIP;
     return h_bad == 0 ? ZKHIP_OK : ZKHIP_ERR_HIP;
@@ -120,7 +122,15 @@ int zkhip_ctx_create(int device, zkhip_ctx** out) {
         delete ctx;
         return ZKHIP_ERR_NO_DEVICE;
     }
+    // one stream per context: work of different contexts on one GPU (several proofs in flight) must not serialise on the
+    // legacy default stream
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return ZKHIP_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
     if (selftest(ctx) != ZKHIP_OK) {
+        hipStreamDestroy(ctx->own_stream);
         delete ctx;
         return ZKHIP_ERR_HIP;
     }
@@ -141,6 +151,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     for (int i = 0; i < 8; i++)
         if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     for (auto& e : ctx->pipe_ev)
         if (e) hipEventDestroy(e);
     delete ctx;
@@ -158,6 +169,8 @@ const char* zkhip_last_error(const zkhip_ctx* ctx) { return ctx ? ctx->last_erro
 int zkhip_set_stream(zkhip_ctx* ctx, void* hip_stream) {
     ZK_BIND_DEVICE(ctx);
     if (!ctx) return ZKHIP_ERR_INVALID;
+    // work already queued on the previous stream stays ordered before what follows on the new one
+    if (ctx->stream != (hipStream_t)hip_stream) ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = (hipStream_t)hip_stream;
     return ZKHIP_OK;
 }

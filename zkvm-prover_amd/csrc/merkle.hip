@@ -265,10 +265,11 @@ int merkle_plan(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, uint32_
         return set_error(ctx, ZKHIP_ERR_NOMEM, "merkle: pointer table alloc");
     }
     t->shifts_off = ptr_bytes;
-    hipError_t e1 = hipMemcpy(t->d_colptrs, ptrs.data(), ptr_bytes, hipMemcpyHostToDevice);
-    hipError_t e2 = shift_bytes ? hipMemcpy((char*)t->d_colptrs + ptr_bytes, shifts.data(), shift_bytes,
-                                            hipMemcpyHostToDevice)
+    hipError_t e1 = hipMemcpyAsync(t->d_colptrs, ptrs.data(), ptr_bytes, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e2 = shift_bytes ? hipMemcpyAsync((char*)t->d_colptrs + ptr_bytes, shifts.data(), shift_bytes,
+                                                 hipMemcpyHostToDevice, ctx->stream)
                                 : hipSuccess;
+    if (e1 == hipSuccess && e2 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);  // host vectors are temporaries
     if (e1 != hipSuccess || e2 != hipSuccess) {
         hipFree(t->d_colptrs);
         delete t;

@@ -882,7 +882,10 @@ uint32_t host_pow(uint32_t a, uint64_t e) { return mpow(a, e); }
 
 int upload(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return ZKHIP_OK;
-    ZK_HIP_CHECK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    // on the context's stream, then wait: ordered before every later kernel of this context (a blocking hipMemcpy runs on
+    // the legacy default stream, which a non-blocking stream does not wait for), and `src` may be a temporary
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return ZKHIP_OK;
 }
 
@@ -1092,7 +1095,8 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             std::vector<uint32_t> tab;
             if (quot_jit_build(A.prog, airs[a].log_height, pk->b, &A.jit_mod, &A.jit_fn, &tab, &msg) &&
                 hipMalloc(&A.d_jit_tab, tab.size() * 4) == hipSuccess &&
-                hipMemcpy(A.d_jit_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) == hipSuccess) {
+                hipMemcpyAsync(A.d_jit_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                hipStreamSynchronize(ctx->stream) == hipSuccess) {
             } else {
                 if (A.jit_mod) hipModuleUnload(A.jit_mod);
                 A.jit_mod = nullptr;
@@ -1281,7 +1285,8 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             if (rc == ZKHIP_OK) {
                 uint32_t rm[8];
                 if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
-                    hipMemcpy(rm, zkhip_tree_root_device(A.t_prep), 32, hipMemcpyDeviceToHost) != hipSuccess)
+                    hipMemcpyAsync(rm, zkhip_tree_root_device(A.t_prep), 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                    hipStreamSynchronize(ctx->stream) != hipSuccess)
                     rc = set_error(ctx, ZKHIP_ERR_HIP, "reading the preprocessed commitment failed");
                 for (int k = 0; k < 8; k++) A.prep_commit[k] = from_monty(rm[k]);
             }

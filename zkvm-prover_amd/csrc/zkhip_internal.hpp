@@ -27,7 +27,8 @@ struct PendingEvent {
 
 struct zkhip_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // where all work is issued: the context's own stream unless zkhip_set_stream gave another
+    hipStream_t own_stream = nullptr;   // created with the context (non-blocking): several contexts on one GPU overlap by default
     std::string last_error;
     // twiddle tables: w^e (fwd) and w^-e (inv) for w = two_adic_generator(tw_log), e < 2^(tw_log-1)
     unsigned tw_log = 0;
