@@ -160,3 +160,21 @@ def test_to_v1_refuses_commit_phase_pow(ora):
     vk = [{k: a[k] for k in ("program", "log_height", "width", "n_pvs")} for a in airs]
     with pytest.raises(z.ZkhipError):
         z.proof_to_v1(params, vk, [a["pvs"] for a in airs], proof)
+
+
+def test_cli_decodes_a_reference_proof_file(tmp_path):
+    """`prove_cli decode-v1` on a proof file shaped like the reference's (JSON with base64 `proofs` / `public_values`)."""
+    import subprocess
+
+    blob = _committed_blob()
+    with open(os.path.join(HERE, "golden", "ref_proofs", "chunk-proof-feynman.public_values.bin"), "rb") as f:
+        pv = f.read()
+    path = tmp_path / "chunk-proof.json"
+    path.write_text(json.dumps({"metadata": {}, "proof": {"proofs": base64.b64encode(blob).decode(),
+                                                          "public_values": base64.b64encode(pv).decode()}, "vk": "", "git_version": "x"}))
+    cli = os.path.join(os.path.dirname(HERE), "zkvm-prover_amd", "prove_cli")
+    r = subprocess.run([cli, "decode-v1", str(path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["roundtrip_exact"] is True and out["n_airs"] == 17 and out["n_queries"] == 44 and out["n_main_commits"] == 2
+    assert out["log_blowup"] == 2 and out["user_public_values"] == 32 and out["log_max_height"] == 23

@@ -116,6 +116,41 @@ int main(int argc, char** argv) {
             std::printf("batch: %zu proofs on %zu lanes in %.3f s\n", st.proofs, bp.lanes(), st.seconds);
             return 0;
         }
+        if (argc >= 3 && std::string(argv[1]) == "decode-v1") {
+            // decode-v1 <proof.json>: a proof file as the reference stores them (crates/verifier/testdata/proofs/*.json:
+            // {"proof": {"proofs": base64(bincode Vec<Proof<SC>>), "public_values": base64(bincode Vec<BabyBear>)}, "vk": ..}):
+            // decodes the OpenVM-v1 container (include/zkhip_codec.hpp), checks the byte-exact round trip, prints its shape.  No device.
+            auto js = slurp(argv[2]);
+            std::string text(js.begin(), js.end());
+            auto field = [&](const char* key) -> std::string {
+                std::string k = std::string("\"") + key + "\"";
+                size_t p = text.find(k);
+                if (p == std::string::npos) throw Error(Error::Custom, std::string("no field ") + key);
+                p = text.find('"', text.find(':', p + k.size()) + 1);
+                size_t e = text.find('"', p + 1);
+                if (p == std::string::npos || e == std::string::npos) throw Error(Error::Custom, "malformed json");
+                return text.substr(p + 1, e - p - 1);
+            };
+            std::vector<uint8_t> blob = base64_decode(field("proofs")), pvs = base64_decode(field("public_values"));
+            zkhip_v1_summary sm;
+            int rc = zkhip_proof_decode_v1(blob.data(), blob.size(), ZKHIP_V1_VEC, &sm);
+            if (rc != ZKHIP_OK) throw Error(Error::Custom, "not a well-formed v1 proof container (zkhip_proof_decode_v1 returned " + std::to_string(rc) + ")");
+            std::vector<uint8_t> again(blob.size() + 64);
+            size_t n = 0;
+            rc = zkhip_proof_reencode_v1(blob.data(), blob.size(), ZKHIP_V1_VEC, again.data(), again.size(), &n);
+            const bool same = rc == ZKHIP_OK && n == blob.size() && memcmp(again.data(), blob.data(), n) == 0;
+            uint64_t n_pv = 0;
+            if (pvs.size() >= 8) memcpy(&n_pv, pvs.data(), 8);
+            std::printf("{\"bytes\": %zu, \"roundtrip_exact\": %s, \"n_proofs\": %zu, \"n_airs\": %zu, \"n_queries\": %zu, \"n_fri_layers\": %zu, "
+                        "\"n_main_commits\": %zu, \"n_after_challenge_commits\": %zu, \"n_preprocessed\": %zu, \"n_input_batches\": %zu, "
+                        "\"log_max_height\": %u, \"log_blowup\": %u, \"user_public_values\": %llu, \"log_degrees\": [",
+                        blob.size(), same ? "true" : "false", sm.n_proofs, sm.n_airs, sm.n_queries, sm.n_fri_layers, sm.n_main_commits,
+                        sm.n_after_challenge_commits, sm.n_preprocessed, sm.n_input_batches, sm.log_max_height, sm.log_blowup,
+                        (unsigned long long)n_pv);
+            for (size_t a = 0; a < sm.n_airs && a < ZKHIP_V1_MAX_AIRS; a++) std::printf("%s%u", a ? ", " : "", sm.log_degree[a]);
+            std::printf("]}\n");
+            return same ? 0 : 1;
+        }
         if (argc >= 3 && std::string(argv[1]) == "agg-plan") {
             // agg-plan <n_segments> [leaf_arity internal_arity]: prints the aggregation tree (mod.rs:57-60 defaults 4 / 3), no device
             AggregationTreeConfig cfg;
@@ -194,7 +229,7 @@ int main(int argc, char** argv) {
                         last.size());
             return 0;
         }
-        std::fprintf(stderr, "usage: prove_cli prove|prove-many|prove-batch|prove-agg|agg-plan|bench-many|verify ...\n");
+        std::fprintf(stderr, "usage: prove_cli prove|prove-many|prove-batch|prove-agg|agg-plan|bench-many|decode-v1|verify ...\n");
         return 2;
     } catch (const Error& e) {
         std::fprintf(stderr, "error(kind %d): %s\n", (int)e.kind, e.what());
