@@ -324,12 +324,14 @@ def main():
                 # HBM traffic of this kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
                 # corrected as MI355X_MICROARCH.md prescribes; bench.py cannot collect counters itself)
                 try:
-                    with open(os.path.join(ROOT, "profiles", "round01_pmc_traffic.json")) as f:
+                    pmc_file = next(n for n in ("round02_pmc_traffic.json", "round01_pmc_traffic.json")
+                                    if os.path.exists(os.path.join(ROOT, "profiles", n)))
+                    with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                         pmc = json.load(f)["kernels"]
                     key = {"poseidon2_hash_rows": "zk::k_hash_rows"}.get(name)
                     if key and log_n == 22 and width == 300:
                         roof["traffic"] = round(pmc[key]["hbm_bytes_per_proof_corrected"] / pmc[key]["launches_per_proof"])
-                        roof["traffic_note"] = "bytes per launch, profiles/round01_pmc_traffic.json"
+                        roof["traffic_note"] = "bytes per launch, profiles/" + pmc_file
                         roof["algorithmic_bytes_per_launch"] = alg // 2
                 except Exception:
                     pass
@@ -361,7 +363,9 @@ def main():
         # instructions take at the issue rate of the best-utilised kernel, against the measured time per proof
         valu_roof = None
         try:
-            with open(os.path.join(ROOT, "profiles", "round01_pmc_valu.json")) as f:
+            valu_file = next(n for n in ("round02_pmc_valu.json", "round01_pmc_valu.json")
+                             if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            with open(os.path.join(ROOT, "profiles", valu_file)) as f:
                 pv = json.load(f)
             if log_n == 22 and width == 300:
                 ms = dt / args.steps * 1e3  # every rank proves `steps` proofs in dt
@@ -369,7 +373,7 @@ def main():
                              "ms_at_best_issue_rate": pv["total_ms_at_hash_issue_rate"],
                              "ms_per_proof_per_gpu": round(ms, 2),
                              "frac": round(pv["total_ms_at_hash_issue_rate"] / ms, 3),
-                             "note": "profiles/round01_pmc_valu.json: SQ_INSTS_VALU summed over the kernels of one proof, "
+                             "note": "profiles/" + valu_file + ": SQ_INSTS_VALU summed over the kernels of one proof, "
                                      "priced at the row-hash kernel's measured issue rate"}
         except Exception:
             pass
