@@ -537,7 +537,10 @@ static unsigned p4_log_r_limit() {
     if (!v) {
         const char* e = getenv("ZKHIP_NTT_MAX_LOG_R");
         v = e ? (unsigned)atoi(e) : P4_MAX_LOG_R;
-        if (v < 6 || v > P4_MAX_LOG_R) v = P4_MAX_LOG_R;
+        // at most three passes exist (fourstep_split writes a[0..2]): 3 * limit must cover the field's two-adicity (27).
+        // A smaller value used to be accepted and made 2^22 transforms silently wrong (4 "passes" of 7 stages, the 4th
+        // written past the array) -- found by tools/ntt_shape_sweep.sh.
+        if (v < 9 || v > P4_MAX_LOG_R) v = P4_MAX_LOG_R;
     }
     return v;
 }
