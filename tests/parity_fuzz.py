@@ -59,6 +59,10 @@ for case in range(n_cases):
     if case % 2 == 1:
         lfp_max = min(4, min(a["log_height"] for a in airs))
         params = (params[0], int(rng.integers(0, lfp_max + 1)), params[2], params[3], params[4])
+    # every third AIR with at least two columns gets a cached main partition of random width
+    for a in airs:
+        if a["width"] >= 2 and rng.integers(0, 3) == 0:
+            a["program"] = air.with_cached_width(a["program"], int(rng.integers(1, a["width"])))
     # constraint degree 3 needs blow-up >= 2^1: all our AIRs have degree <= 3
     try:
         exp = ora.stark_prove(params, airs)
@@ -67,8 +71,13 @@ for case in range(n_cases):
         d_traces = [zk.upload(a["trace"].reshape(-1)) for a in airs]
         if dev_chip is not None:
             d_traces[dev_chip[0]] = dev_chip[1]
+        zk.set_commit_pipeline(int(rng.integers(0, 5)))  # 0 / 1 = plain, 2..4 = pipelined trace commit (tall, wide chips only)
         got = pk.prove(d_traces, pvs)
-        ok = got == exp.tobytes() and z.verify(params, pk.verifying_airs(), pvs, got) == 0
+        vk = pk.verifying_airs()
+        ok = got == exp.tobytes() and z.verify(params, vk, pvs, got) == 0
+        if ok and params[3] == 0:  # no commit-phase proof-of-work: the proof fits the reference's v1 container
+            back, pvs_back = z.proof_from_v1(params, vk, z.proof_to_v1(params, vk, pvs, got))
+            ok = back == got and all(list(map(int, x)) == list(map(int, y)) for x, y in zip(pvs_back, pvs))
         pk.close()
     except Exception as e:  # noqa: BLE001
         ok = False

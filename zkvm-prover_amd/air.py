@@ -282,6 +282,17 @@ class AirBuilder:
         return np.array(words, dtype=np.uint32)
 
 
+def with_cached_width(program, cached_width):
+    """The same AIR program with its first `cached_width` main columns declared a cached main partition (inserted after the
+    constraints / the preprocessed section, before the interactions)."""
+    w = [int(x) for x in program]
+    pos = 4 + 3 * w[1] + w[2]
+    if pos + 2 <= len(w) and w[pos] == PREP_MAGIC:
+        pos += 2
+    assert not (pos + 2 <= len(w) and w[pos] == CACHED_MAGIC), "program already has a cached partition"
+    return np.array(w[:pos] + [CACHED_MAGIC, cached_width] + w[pos:], dtype=np.uint32)
+
+
 # ---- reference evaluation of a program on a trace (numpy; host-side witness sanity check) ----
 def check_trace(program, trace, pvs, prep=None):
     """trace: [width, n] canonical uint32 (prep: [prep_width, n] or None).  Returns the list of violated
