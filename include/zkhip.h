@@ -142,6 +142,17 @@ int zkhip_memory_boundary_tracegen(zkhip_ctx *ctx, const uint32_t *d_addr_space,
                                    const uint32_t *d_final, const uint32_t *d_timestamp, size_t n, unsigned as_bits,
                                    unsigned pointer_bits, unsigned log_height, uint32_t *d_trace);
 
+/* Trace of an INSTRUCTION chip from execution records: the core of OpenVM's RV32 base ALU chip (rv32im BaseAluCoreAir: ADD, SUB,
+ * XOR, OR, AND on 4 x 8-bit limbs; the `rv32i` extension of crates/circuits/chunk-circuit/openvm.toml).  Record i = (d_opcode[i] in
+ * 0..4 = add, sub, xor, or, and; d_b[i], d_c[i]: the 32-bit operands) -- plain integers.  Fills d_trace (ZKHIP_RV32_ALU_WIDTH = 18
+ * columns, stride 2^log_height, Montgomery: a[4] | b[4] | c[4] | 5 opcode flags | is_valid; rows >= n zero) and, in the same pass,
+ * adds the bitwise-lookup requests of every row (4 per record: (b_i, c_i) for the bitwise opcodes, (a_i, a_i) for ADD / SUB) to the
+ * XOR multiplicity column of d_bitwise_trace, the 2 x 2^16 trace of the 8-bit bitwise-operation lookup table
+ * (zkhip_bitwise_lookup_tracegen's layout; zero it first or pass a table other chips already counted into). */
+#define ZKHIP_RV32_ALU_WIDTH 18
+int zkhip_rv32_alu_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_b, const uint32_t *d_c, size_t n,
+                            unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
+
 typedef struct {
     const uint32_t *data; /* device, column-major, Montgomery */
     size_t stride;

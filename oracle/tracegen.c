@@ -103,3 +103,31 @@ size_t ora_memory_boundary_trace(const uint32_t *as, const uint32_t *ptr, const 
     free(k);
     return bad;
 }
+
+/* RV32 base ALU core chip (OpenVM BaseAluCoreAir) from records (opcode 0..4 = add, sub, xor, or, and; operands b, c): 18 columns with
+ * stride 2^log_height: a[4] | b[4] | c[4] | 5 opcode flags | is_valid; xor_counts[(x << 8) | y] (+)= the bitwise-lookup requests of
+ * the rows ((b_i, c_i) for bitwise opcodes, (a_i, a_i) for add / sub), canonical mod p.  Returns the number of bad opcodes. */
+size_t ora_rv32_alu_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace,
+                          uint32_t *xor_counts) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 18; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t op = opc[r], b = bs[r], c = cs[r];
+        if (op > 4) {
+            bad++;
+            continue;
+        }
+        const uint32_t a = op == 0 ? b + c : op == 1 ? b - c : op == 2 ? (b ^ c) : op == 3 ? (b | c) : (b & c);
+        for (int i = 0; i < 4; i++) {
+            const uint32_t ai = (a >> (8 * i)) & 255u, bi = (b >> (8 * i)) & 255u, ci = (c >> (8 * i)) & 255u;
+            trace[(size_t)i * N + r] = ai, trace[(size_t)(4 + i) * N + r] = bi, trace[(size_t)(8 + i) * N + r] = ci;
+            const uint32_t x = op >= 2 ? bi : ai, y = op >= 2 ? ci : ai;
+            xor_counts[(x << 8) | y] = ora_add(xor_counts[(x << 8) | y], 1);
+        }
+        trace[(size_t)(12 + op) * N + r] = 1;
+        trace[(size_t)17 * N + r] = 1;
+    }
+    return bad;
+}

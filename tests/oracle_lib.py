@@ -69,6 +69,17 @@ def bitwise_lookup_counts(xs, ys, ops, bits=8):
     return tr, int(bad)
 
 
+def rv32_alu_trace(opc, bs, cs, log_height, xor_counts=None):
+    opc, bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, bs, cs))
+    tr = np.zeros((18, 1 << log_height), np.uint32)
+    xc = np.zeros(1 << 16, np.uint32) if xor_counts is None else np.ascontiguousarray(xor_counts, dtype=np.uint32).copy()
+    l = lib()
+    l.ora_rv32_alu_trace.restype = C.c_size_t
+    l.ora_rv32_alu_trace.argtypes = [u32p_t()] * 3 + [C.c_size_t, C.c_uint, u32p_t(), u32p_t()]
+    bad = l.ora_rv32_alu_trace(p32(opc), p32(bs), p32(cs), len(opc), log_height, p32(tr), p32(xc))
+    return tr, xc, int(bad)
+
+
 def memory_boundary_trace(as_, ptr, init, fin, ts, as_bits, ptr_bits, log_height):
     as_, ptr, init, fin, ts = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (as_, ptr, init, fin, ts))
     tr = np.zeros((8, 1 << log_height), np.uint32)

@@ -96,6 +96,7 @@ def load_library():
         "zkhip_range_counts_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, C.c_int]),
         "zkhip_range_tuple_counts_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_int]),
         "zkhip_bitwise_lookup_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, C.c_int]),
+        "zkhip_rv32_alu_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_memory_boundary_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint, C.c_uint, vp]),
         "zkhip_merkle_commit": (C.c_int, [vp, C.POINTER(_Matrix), sz, C.POINTER(vp), u32p]),
         "zkhip_tree_root_device": (vp, [vp]),
@@ -274,6 +275,17 @@ class Context:
                                                            C.c_void_p(t_op.data_ptr()), t_x.numel(), num_bits,
                                                            C.c_void_p(t_trace.data_ptr()), 1 if accumulate else 0))
         return t_trace
+
+    def rv32_alu_tracegen(self, t_opcode, t_b, t_c, log_height, t_bitwise_trace):
+        """18-column trace of the RV32 base ALU core chip from records (int32 tensors: opcode 0..4, operands b, c); the rows'
+        bitwise-lookup requests are added to the XOR column of t_bitwise_trace (2 x 2^16 Montgomery words)."""
+        import torch
+
+        out = torch.empty(18 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_rv32_alu_tracegen(self.h, C.c_void_p(t_opcode.data_ptr()), C.c_void_p(t_b.data_ptr()),
+                                                     C.c_void_p(t_c.data_ptr()), t_opcode.numel(), log_height, C.c_void_p(out.data_ptr()),
+                                                     C.c_void_p(t_bitwise_trace.data_ptr())))
+        return out
 
     def memory_boundary_tracegen(self, t_as, t_ptr, t_init, t_final, t_ts, as_bits, pointer_bits, log_height):
         """8-column trace of the volatile memory boundary chip, rows sorted by address on the device.

@@ -619,6 +619,38 @@ def bitwise_user_air(bus=9):
     return b
 
 
+RV32_ALU_WIDTH = 18
+
+
+def rv32_alu_core_air(bus=9):
+    """The core of OpenVM's RV32 base ALU chip (rv32im `BaseAluCoreAir`): columns a[4] | b[4] | c[4] | is_add is_sub is_xor is_or
+    is_and | is_valid, 8-bit limbs, a = result.  ADD / SUB are checked through their carry chains (carry_i = (b_i + c_i + carry_{i-1}
+    - a_i) / 256 must be boolean; SUB with a and b exchanged); the bitwise opcodes -- and the range of every result limb -- through the
+    bitwise-operation lookup: per limb the row sends (x, y, x ^ y, 1) with (x, y) = (b_i, c_i) for XOR / OR / AND and (a_i, a_i) for
+    ADD / SUB, where x ^ y = a_i (XOR), 2 a_i - b_i - c_i (OR), b_i + c_i - 2 a_i (AND), 0 (ADD / SUB)."""
+    b = AirBuilder(RV32_ALU_WIDTH, 0)
+    a_, b_, c_ = [b.var(i) for i in range(4)], [b.var(4 + i) for i in range(4)], [b.var(8 + i) for i in range(4)]
+    f_add, f_sub, f_xor, f_or, f_and = (b.var(12 + i) for i in range(5))
+    ok = b.var(17)
+    for f in (f_add, f_sub, f_xor, f_or, f_and, ok):
+        b.assert_zero(f * (f - 1))
+    b.assert_zero(f_add + f_sub + f_xor + f_or + f_and - ok)
+    inv256 = pow(256, -1, P)
+    carry_add, carry_sub = None, None
+    for i in range(4):
+        carry_add = (b_[i] + c_[i] - a_[i] + (carry_add if carry_add is not None else 0)) * inv256
+        carry_sub = (a_[i] + c_[i] - b_[i] + (carry_sub if carry_sub is not None else 0)) * inv256
+        b.assert_zero(f_add * (carry_add * (carry_add - 1)))
+        b.assert_zero(f_sub * (carry_sub * (carry_sub - 1)))
+    bitwise = f_xor + f_or + f_and
+    for i in range(4):
+        x = bitwise * b_[i] + (1 - bitwise) * a_[i]
+        y = bitwise * c_[i] + (1 - bitwise) * a_[i]
+        z = f_xor * a_[i] + f_or * (a_[i] * 2 - b_[i] - c_[i]) + f_and * (b_[i] + c_[i] - a_[i] * 2)
+        b.push_interaction(bus, [x, y, z, 1], ok, "send")
+    return b
+
+
 MEMORY_BOUNDARY_WIDTH = 8
 
 

@@ -199,3 +199,61 @@ extern "C" int zkhip_memory_boundary_tracegen(zkhip_ctx* ctx, const uint32_t* d_
     if (h_bad) return set_error(ctx, ZKHIP_ERR_INVALID, "memory_boundary_tracegen: " + std::to_string(h_bad) + " records out of range or duplicated");
     return ZKHIP_OK;
 }
+
+// ---- an instruction chip: RV32 base ALU core (OpenVM rv32im BaseAluCoreAir: ADD / SUB / XOR / OR / AND on 4 x 8-bit limbs) --------
+// From execution records (opcode, rs1 value b, rs2 / immediate value c) the kernel fills one trace row per record AND counts, with
+// atomics, the bitwise-lookup requests the row's interactions make -- the way the reference's GPU chips fill their traces and bump
+// the periphery tables in one pass (AGENTS.md:183-187).  Columns (ZKHIP_RV32_ALU_WIDTH = 18, stride 2^log_height, Montgomery):
+//   a[4] | b[4] | c[4] | is_add is_sub is_xor is_or is_and | is_valid        (little-endian limbs; a = result)
+// Per limb the chip sends (x, y, x ^ y, 1) to the bitwise lookup bus: (b_i, c_i) for the bitwise opcodes, (a_i, a_i) for ADD / SUB
+// (a ^ a = 0: a range check of the result limb).  The AIR is air.py rv32_alu_core_air(); rows >= n are zero.
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_rv32_alu(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ bs,
+                                                  const uint32_t* __restrict__ cs, size_t n, size_t N, uint32_t* __restrict__ trace,
+                                                  uint32_t* __restrict__ xor_counts, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_RV32_ALU_WIDTH] = {};
+    if (r < n) {
+        const uint32_t op = opc[r], b = bs[r], c = cs[r];
+        if (op > 4) {
+            atomicAdd(bad, 1u);
+        } else {
+            const uint32_t a = op == 0 ? b + c : op == 1 ? b - c : op == 2 ? (b ^ c) : op == 3 ? (b | c) : (b & c);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t ai = (a >> (8 * i)) & 255u, bi = (b >> (8 * i)) & 255u, ci = (c >> (8 * i)) & 255u;
+                col[i] = to_monty(ai), col[4 + i] = to_monty(bi), col[8 + i] = to_monty(ci);
+                const uint32_t x = op >= 2 ? bi : ai, y = op >= 2 ? ci : ai;
+                atomicAdd(&xor_counts[(x << 8) | y], 1u);
+            }
+            col[12 + op] = MONTY_ONE;
+            col[17] = MONTY_ONE;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_RV32_ALU_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_rv32_alu_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, const uint32_t* d_b, const uint32_t* d_c, size_t n,
+                                       unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 27 || (n && (!d_opcode || !d_b || !d_c))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_alu_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "rv32_alu_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    // the XOR multiplicity column of the 8-bit bitwise lookup table (column 1 of its 2 x 2^16 trace): Montgomery -> counts -> Montgomery
+    uint32_t* xor_col = d_bitwise_trace + (1u << 16);
+    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 0);
+    hipLaunchKernelGGL(k_rv32_alu, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, xor_col,
+                       (uint32_t*)flag);
+    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "rv32_alu_tracegen (opcode > 4)");
+}
