@@ -153,6 +153,15 @@ int zkhip_memory_boundary_tracegen(zkhip_ctx *ctx, const uint32_t *d_addr_space,
 int zkhip_rv32_alu_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_b, const uint32_t *d_c, size_t n,
                             unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
 
+/* RV32 multiplication core (OpenVM rv32im MultiplicationCoreAir; the `rv32m` extension of the chunk circuit): record i = operands
+ * (d_b[i], d_c[i]), plain integers.  d_trace: ZKHIP_RV32_MUL_WIDTH = 13 columns (a[4] = low word of b * c | b[4] | c[4] | is_valid),
+ * stride 2^log_height, Montgomery, rows >= n zero.  The four (result limb, carry) pairs of every record are added to
+ * d_tuple_counts, the multiplicity column of the range-tuple table (size_x x size_y Montgomery words, row limb * size_y + carry;
+ * the reference's sizes are [256, 8192]). */
+#define ZKHIP_RV32_MUL_WIDTH 13
+int zkhip_rv32_mul_tracegen(zkhip_ctx *ctx, const uint32_t *d_b, const uint32_t *d_c, size_t n, unsigned log_height, uint32_t *d_trace,
+                            uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+
 typedef struct {
     const uint32_t *data; /* device, column-major, Montgomery */
     size_t stride;

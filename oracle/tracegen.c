@@ -131,3 +131,26 @@ size_t ora_rv32_alu_trace(const uint32_t *opc, const uint32_t *bs, const uint32_
     }
     return bad;
 }
+
+/* RV32 multiplication core chip (OpenVM MultiplicationCoreAir): 13 columns a[4] | b[4] | c[4] | is_valid; tuple_counts[a_i * size_y +
+ * carry_i] (+)= 1 for the four (limb, carry) pairs of every record */
+void ora_rv32_mul_trace(const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace, uint32_t *tuple_counts,
+                        uint32_t size_y) {
+    const size_t N = (size_t)1 << log_height;
+    for (size_t q = 0; q < 13; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        uint32_t bl[4], cl[4], carry = 0;
+        for (int i = 0; i < 4; i++) bl[i] = (bs[r] >> (8 * i)) & 255u, cl[i] = (cs[r] >> (8 * i)) & 255u;
+        for (int i = 0; i < 4; i++) {
+            uint32_t acc = carry;
+            for (int k = 0; k <= i; k++) acc += bl[k] * cl[i - k];
+            const uint32_t ai = acc & 255u;
+            carry = acc >> 8;
+            trace[(size_t)i * N + r] = ai, trace[(size_t)(4 + i) * N + r] = bl[i], trace[(size_t)(8 + i) * N + r] = cl[i];
+            uint32_t *t = &tuple_counts[(size_t)ai * size_y + carry];
+            *t = ora_add(*t, 1);
+        }
+        trace[(size_t)12 * N + r] = 1;
+    }
+}

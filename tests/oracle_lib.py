@@ -80,6 +80,17 @@ def rv32_alu_trace(opc, bs, cs, log_height, xor_counts=None):
     return tr, xc, int(bad)
 
 
+def rv32_mul_trace(bs, cs, log_height, size_x=256, size_y=8192, tuple_counts=None):
+    bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (bs, cs))
+    tr = np.zeros((13, 1 << log_height), np.uint32)
+    tc = np.zeros(size_x * size_y, np.uint32) if tuple_counts is None else np.ascontiguousarray(tuple_counts, dtype=np.uint32).copy()
+    l = lib()
+    l.ora_rv32_mul_trace.restype = None
+    l.ora_rv32_mul_trace.argtypes = [u32p_t(), u32p_t(), C.c_size_t, C.c_uint, u32p_t(), u32p_t(), C.c_uint32]
+    l.ora_rv32_mul_trace(p32(bs), p32(cs), len(bs), log_height, p32(tr), p32(tc), size_y)
+    return tr, tc
+
+
 def memory_boundary_trace(as_, ptr, init, fin, ts, as_bits, ptr_bits, log_height):
     as_, ptr, init, fin, ts = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (as_, ptr, init, fin, ts))
     tr = np.zeros((8, 1 << log_height), np.uint32)

@@ -161,3 +161,35 @@ def test_rv32_alu_chip_from_execution_records(zk, ora):
     assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 3, proof) == 0
     assert proof == ora.stark_prove(PARAMS, airs).tobytes()
     pk.close()
+
+
+def test_rv32_mul_chip_with_the_range_tuple_table(zk, ora):
+    """RV32 multiplication core (OpenVM MultiplicationCoreAir) from records on the device, its (limb, carry) requests counted into
+    the range-tuple table in the same pass: cells == oracle with the reference's table sizes [256, 8192]; MUL chip + table proven end
+    to end from the device-resident traces (proof bytes == oracle) with a smaller table."""
+    rng = np.random.default_rng(11)
+    n, lh = 5000, 13
+    b = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    c = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    b[:3], c[:3] = [0xFFFFFFFF, 0, 0x10001], [0xFFFFFFFF, 5, 0xFFFF]
+    dev = zk.device
+    as_dev = lambda v: torch.from_numpy(v.view(np.int32)).to(dev)  # noqa: E731
+    for sx, sy in ((256, 8192), (256, 2048)):
+        exp, tc = ora.rv32_mul_trace(b, c, lh, sx, sy)
+        d_tab = torch.zeros(sx * sy, dtype=torch.int32, device=dev)
+        d_mul = zk.rv32_mul_tracegen(as_dev(b), as_dev(c), lh, d_tab, sx, sy)
+        assert (zk.download(d_mul).reshape(13, -1) == exp).all()
+        assert (zk.download(d_tab) == tc).all() and int(tc.astype(np.int64).sum()) == 4 * n
+    prog = air.rv32_mul_core_air().program()
+    assert air.check_trace(prog, exp, NOPV) == []
+    airs = [dict(program=prog, log_height=lh, width=13, n_pvs=0, trace=exp, pvs=NOPV),
+            dict(program=air.range_tuple_table_air(256, 2048).program(), log_height=19, width=1, n_pvs=0, trace=tc.reshape(1, -1), pvs=NOPV,
+                 prep=air.range_tuple_prep(256, 2048))]
+    params = (1, 0, 6, 2, 2)
+    pk = z.ProvingKey(zk, params, airs)
+    proof = pk.prove([d_mul, d_tab], [NOPV] * 2)
+    assert z.verify(params, pk.verifying_airs(), [NOPV] * 2, proof) == 0
+    assert proof == ora.stark_prove(params, airs).tobytes()
+    pk.close()
+    with pytest.raises(z.ZkhipError):   # a table that cannot hold the carries
+        zk.rv32_mul_tracegen(as_dev(b), as_dev(c), lh, d_tab, 256, 512)

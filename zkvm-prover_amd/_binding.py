@@ -97,6 +97,7 @@ def load_library():
         "zkhip_range_tuple_counts_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint32, C.c_uint32, vp, C.c_int]),
         "zkhip_bitwise_lookup_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, C.c_int]),
         "zkhip_rv32_alu_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_rv32_mul_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_memory_boundary_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint, C.c_uint, vp]),
         "zkhip_merkle_commit": (C.c_int, [vp, C.POINTER(_Matrix), sz, C.POINTER(vp), u32p]),
         "zkhip_tree_root_device": (vp, [vp]),
@@ -285,6 +286,16 @@ class Context:
         self._check(self.lib.zkhip_rv32_alu_tracegen(self.h, C.c_void_p(t_opcode.data_ptr()), C.c_void_p(t_b.data_ptr()),
                                                      C.c_void_p(t_c.data_ptr()), t_opcode.numel(), log_height, C.c_void_p(out.data_ptr()),
                                                      C.c_void_p(t_bitwise_trace.data_ptr())))
+        return out
+
+    def rv32_mul_tracegen(self, t_b, t_c, log_height, t_tuple_counts, size_x=256, size_y=8192):
+        """13-column trace of the RV32 multiplication core chip from records (int32 tensors: operands); the (limb, carry) requests of
+        every row are added to t_tuple_counts (size_x * size_y Montgomery words: the range-tuple table's trace)."""
+        import torch
+
+        out = torch.empty(13 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_rv32_mul_tracegen(self.h, C.c_void_p(t_b.data_ptr()), C.c_void_p(t_c.data_ptr()), t_b.numel(), log_height,
+                                                     C.c_void_p(out.data_ptr()), C.c_void_p(t_tuple_counts.data_ptr()), size_x, size_y))
         return out
 
     def memory_boundary_tracegen(self, t_as, t_ptr, t_init, t_final, t_ts, as_bits, pointer_bits, log_height):

@@ -651,6 +651,29 @@ def rv32_alu_core_air(bus=9):
     return b
 
 
+RV32_MUL_WIDTH = 13
+
+
+def rv32_mul_core_air(bus=6):
+    """The core of OpenVM's RV32 multiplication chip (rv32im `MultiplicationCoreAir`): columns a[4] | b[4] | c[4] | is_valid, 8-bit
+    limbs, a = low 32 bits of b * c.  carry_i = (sum_{k<=i} b_k c_{i-k} + carry_{i-1} - a_i) / 256 is an EXPRESSION (degree 2); the row
+    sends (a_i, carry_i) to the range-tuple checker (limb < 256, carry < 8192 with the reference's sizes), which is what makes a the
+    product's limbs."""
+    b = AirBuilder(RV32_MUL_WIDTH, 0)
+    a_, b_, c_ = [b.var(i) for i in range(4)], [b.var(4 + i) for i in range(4)], [b.var(8 + i) for i in range(4)]
+    ok = b.var(12)
+    b.assert_zero(ok * (ok - 1))
+    inv256 = pow(256, -1, P)
+    carry = None
+    for i in range(4):
+        acc = carry if carry is not None else 0
+        for k in range(i + 1):
+            acc = b_[k] * c_[i - k] + acc
+        carry = (acc - a_[i]) * inv256
+        b.push_interaction(bus, [a_[i], carry], ok, "send")
+    return b
+
+
 MEMORY_BOUNDARY_WIDTH = 8
 
 

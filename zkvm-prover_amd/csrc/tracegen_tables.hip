@@ -257,3 +257,56 @@ extern "C" int zkhip_rv32_alu_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode,
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_alu_tracegen (opcode > 4)");
 }
+
+// ---- RV32 multiplication core (OpenVM rv32im MultiplicationCoreAir: MUL on 4 x 8-bit limbs) ----------------------------------------
+// Record = the two 32-bit operands.  Row: a[4] (low 32 bits of b * c) | b[4] | c[4] | is_valid  (ZKHIP_RV32_MUL_WIDTH = 13).  The
+// carries carry_i = (sum_{k<=i} b_k c_{i-k} + carry_{i-1} - a_i) / 256 are not columns: the AIR recomputes them as expressions and
+// sends (a_i, carry_i) to the range-TUPLE checker -- sizes [256, 8192] in the reference's config exist for exactly this pair
+// (crates/circuits/chunk-circuit/openvm.toml `range_tuple_checker_sizes`).  The kernel counts those four requests per record into
+// the tuple table's trace while it fills the row.
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_rv32_mul(const uint32_t* __restrict__ bs, const uint32_t* __restrict__ cs, size_t n, size_t N,
+                                                  uint32_t* __restrict__ trace, uint32_t* __restrict__ tuple_counts, uint32_t size_y) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_RV32_MUL_WIDTH] = {};
+    if (r < n) {
+        const uint32_t b = bs[r], c = cs[r];
+        uint32_t bl[4], cl[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) bl[i] = (b >> (8 * i)) & 255u, cl[i] = (c >> (8 * i)) & 255u;
+        uint32_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t acc = carry;
+#pragma unroll
+            for (int k = 0; k <= i; k++) acc += bl[k] * cl[i - k];
+            const uint32_t ai = acc & 255u;
+            carry = acc >> 8;  // < 4 * 255 * 255 / 256 + ... < 1024
+            col[i] = to_monty(ai), col[4 + i] = to_monty(bl[i]), col[8 + i] = to_monty(cl[i]);
+            atomicAdd(&tuple_counts[(size_t)ai * size_y + carry], 1u);
+        }
+        col[12] = MONTY_ONE;
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_RV32_MUL_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_rv32_mul_tracegen(zkhip_ctx* ctx, const uint32_t* d_b, const uint32_t* d_c, size_t n, unsigned log_height,
+                                       uint32_t* d_trace, uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_tuple_counts || log_height > 27 || (n && (!d_b || !d_c))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height, T = (size_t)size_x * size_y;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_mul_tracegen: more records than rows");
+    if (size_x < 256 || size_y < 1024 || T > ((size_t)1 << 27)) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_mul_tracegen: the tuple table must cover (limb < 256, carry < 1024)");
+    KernelScope ks(ctx, "rv32_mul_tracegen");
+    const unsigned tb = (unsigned)((T + 255) / 256);
+    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
+    hipLaunchKernelGGL(k_rv32_mul, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_b, d_c, n, N, d_trace, d_tuple_counts, size_y);
+    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
