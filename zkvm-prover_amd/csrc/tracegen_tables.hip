@@ -276,14 +276,15 @@ __global__ __launch_bounds__(256) void k_rv32_mul(const uint32_t* __restrict__ b
         uint32_t bl[4], cl[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) bl[i] = (b >> (8 * i)) & 255u, cl[i] = (c >> (8 * i)) & 255u;
+        // schoolbook columns of the low word: sums stay below 4 * 255^2 + 1024 < 2^19
+        const uint32_t s[4] = {bl[0] * cl[0], bl[0] * cl[1] + bl[1] * cl[0], bl[0] * cl[2] + bl[1] * cl[1] + bl[2] * cl[0],
+                               bl[0] * cl[3] + bl[1] * cl[2] + bl[2] * cl[1] + bl[3] * cl[0]};
         uint32_t carry = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            uint32_t acc = carry;
-#pragma unroll
-            for (int k = 0; k <= i; k++) acc += bl[k] * cl[i - k];
+            const uint32_t acc = s[i] + carry;
             const uint32_t ai = acc & 255u;
-            carry = acc >> 8;  // < 4 * 255 * 255 / 256 + ... < 1024
+            carry = acc >> 8;  // < 1024
             col[i] = to_monty(ai), col[4 + i] = to_monty(bl[i]), col[8 + i] = to_monty(cl[i]);
             atomicAdd(&tuple_counts[(size_t)ai * size_y + carry], 1u);
         }
