@@ -188,6 +188,14 @@ int zkhip_merkle_open(zkhip_ctx *ctx, const zkhip_tree *tree, const uint64_t *in
                       uint32_t *out, size_t cap_words);
 void zkhip_tree_destroy(zkhip_ctx *ctx, zkhip_tree *tree);
 
+/* ---- constraint evaluation (K5) on its own: quotient values q(x) = (sum_i alpha^(n-1-i) c_i(x)) / Z_H(x) of ONE AIR on its LDE
+ *      domain (what the engine's quotient / constraint prover computes per chip).  program: AIR bytecode (host);
+ *      d_lde: the committed LDE of the main trace, `width` columns of 2^(log_height+log_blowup) rows in the committed (bit-reversed,
+ *      coset shift 31) layout, Montgomery; pvs: host canonical; alpha: 4 canonical words; d_q: 4 columns (extension coordinates) of
+ *      2^(log_height+log_blowup) Montgomery words, same row order.  AIRs with buses / preprocessed traces go through zkhip_prove. ---- */
+int zkhip_constraint_eval(zkhip_ctx *ctx, const uint32_t *program, size_t program_len, unsigned log_height, unsigned log_blowup,
+                          size_t width, const uint32_t *d_lde, const uint32_t *pvs, size_t n_pvs, const uint32_t alpha[4], uint32_t *d_q);
+
 /* ---- FRI fold (K8): d_in = 2n extension elements in bit-reversed domain order,
  *      d_out = n; beta = 4 canonical words (host) ---- */
 int zkhip_fri_fold(zkhip_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, unsigned log_n_out,

@@ -175,6 +175,10 @@ extern "C" {
                              cap_words: usize) -> c_int;
     pub fn zkhip_tree_destroy(ctx: *mut zkhip_ctx, tree: *mut zkhip_tree);
 
+    // constraint evaluation (K5) as a stage
+    pub fn zkhip_constraint_eval(ctx: *mut zkhip_ctx, program: *const u32, program_len: usize, log_height: c_uint, log_blowup: c_uint,
+                                 width: usize, d_lde: *const u32, pvs: *const u32, n_pvs: usize, alpha: *const u32, d_q: *mut u32) -> c_int;
+
     // FRI fold, LogUp / sum-check blocks
     pub fn zkhip_fri_fold(ctx: *mut zkhip_ctx, d_in: *const u32, d_out: *mut u32, log_n_out: c_uint, beta: *const u32) -> c_int;
     pub fn zkhip_ext_batch_inverse(ctx: *mut zkhip_ctx, d_in: *const u32, d_out: *mut u32, n: usize) -> c_int;

@@ -816,6 +816,55 @@ done:
     return ok ? w : 0;
 }
 
+/* K5 on its own (the checker of zkhip_constraint_eval): quotient values of one AIR over its LDE domain.  lde: `width` columns of
+ * 2^(lh+b) canonical values in the committed layout (bit-reversed rows, coset shift GEN); q: 4 columns (extension coordinates) of
+ * 2^(lh+b), same row order.  AIRs with interactions / preprocessed traces are not handled here.  Returns 0, or -1 on a bad program. */
+int ora_constraint_eval(const uint32_t *prog_words, size_t prog_len, unsigned lh, unsigned b, size_t width, const uint32_t *lde,
+                        const uint32_t *pvs, size_t n_pvs, const uint32_t alpha[4], uint32_t *q) {
+    program pgm;
+    if (parse_program(prog_words, prog_len, width, &pgm) || pgm.n_int || pgm.prep_width || pgm.n_pvs != n_pvs) return -1;
+    const program *pg = &pgm;
+    const unsigned h = lh + b, nch = 1u << b;
+    const size_t N = (size_t)1 << lh, M = N << b, W = width;
+    ext_t *ap = (ext_t *)malloc((pg->n_cons + 1) * sizeof(ext_t));
+    {
+        ext_t cur = {1, 0, 0, 0};
+        for (uint32_t i = pg->n_cons; i-- > 0;) {
+            ext_set(ap[i], cur);
+            ora_ext_mul(cur, alpha, cur);
+        }
+    }
+    const uint32_t wM = ora_two_adic_generator(h), winv = ora_inv(ora_two_adic_generator(lh));
+#pragma omp parallel
+    {
+        uint32_t *vals = (uint32_t *)malloc((pg->n_nodes + 1) * sizeof(uint32_t));
+        uint32_t *loc = (uint32_t *)malloc((W + 1) * sizeof(uint32_t)), *nxt = (uint32_t *)malloc((W + 1) * sizeof(uint32_t));
+#pragma omp for schedule(static)
+        for (size_t r = 0; r < M; r++) {
+            size_t i = bitrev(r, h), rn = bitrev((i + nch) & (M - 1), h);
+            uint32_t x = ora_mul(GEN, ora_pow(wM, i));
+            for (size_t c = 0; c < W; c++) loc[c] = lde[c * M + r], nxt[c] = lde[c * M + rn];
+            uint32_t zh = ora_sub(ora_pow(x, N), 1);
+            row_ctx rc = {loc, nxt, pvs, NULL, NULL, NULL, NULL, 0, 0, 0, NULL, NULL};
+            rc.is_first = ora_mul(zh, ora_inv(ora_sub(x, 1)));
+            rc.is_trans = ora_sub(x, winv);
+            rc.is_last = ora_mul(zh, ora_inv(rc.is_trans));
+            eval_nodes_base(pg, &rc, vals);
+            ext_t acc = {0, 0, 0, 0}, t, out;
+            for (uint32_t k = 0; k < pg->n_cons; k++) {
+                ext_scale(ap[k], vals[pg->cons[k]], t);
+                ext_add(acc, t, acc);
+            }
+            ext_scale(acc, ora_inv(zh), out);
+            for (int k = 0; k < 4; k++) q[(size_t)k * M + r] = out[k];
+        }
+        free(vals), free(loc), free(nxt);
+    }
+    free(ap);
+    free_program(&pgm);
+    return 0;
+}
+
 /* ---------------------------------------------------------------- verifier */
 typedef struct {
     unsigned lh, h;

@@ -174,6 +174,9 @@ typedef struct {
     const uint32_t *prep_commit; /* its 8-word commitment (verifier; NULL -> recomputed from prep) */
 } ora_air_instance;
 
+/* K5 on its own: quotient values (4 extension-coordinate columns of 2^(lh+b) rows) of one AIR over its committed LDE */
+int ora_constraint_eval(const uint32_t *program, size_t program_len, unsigned log_height, unsigned log_blowup, size_t width,
+                        const uint32_t *lde, const uint32_t *pvs, size_t n_pvs, const uint32_t alpha[4], uint32_t *q);
 /* Proves; writes proof words (canonical u32 LE) into out (cap words); returns
  * number of words, or 0 on failure (e.g. constraints unsatisfied when checked). */
 size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size_t n_airs,

@@ -319,6 +319,21 @@ def stark_prove(params, airs, cap_words=1 << 24):
     return out[:n].copy()
 
 
+def constraint_eval(program, log_height, log_blowup, width, lde, pvs, alpha):
+    """Quotient values [4, 2^(lh+b)] (canonical) of one AIR on its committed LDE ([width, 2^(lh+b)] canonical)."""
+    prog = np.ascontiguousarray(program, dtype=np.uint32)
+    l_ = np.ascontiguousarray(lde, dtype=np.uint32)
+    pv = np.ascontiguousarray(pvs, dtype=np.uint32)
+    al = np.ascontiguousarray(alpha, dtype=np.uint32)
+    q = np.zeros((4, 1 << (log_height + log_blowup)), np.uint32)
+    l = lib()
+    l.ora_constraint_eval.restype = C.c_int
+    l.ora_constraint_eval.argtypes = [u32p_t(), C.c_size_t, C.c_uint, C.c_uint, C.c_size_t, u32p_t(), u32p_t(), C.c_size_t, u32p_t(), u32p_t()]
+    if l.ora_constraint_eval(p32(prog), prog.size, log_height, log_blowup, width, p32(l_), p32(pv) if pv.size else None, pv.size, p32(al), p32(q)) != 0:
+        raise RuntimeError("ora_constraint_eval refused the program")
+    return q
+
+
 def prep_commit(params, a):
     """8-word commitment of one AIR's preprocessed trace (the verifying-key entry)."""
     prm = OraParams(*params)

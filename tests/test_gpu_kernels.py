@@ -203,3 +203,28 @@ def test_fri_fold_golden(zk, kat):
         flat = np.array(case["in"], dtype=np.uint32).reshape(-1)
         got = zk.download(zk.fri_fold(zk.upload(flat), case["log_n_out"], case["beta"]))
         assert got.reshape(-1, 4).tolist() == case["out"]
+
+
+@pytest.mark.parametrize("log_n,log_blowup,width", [(1, 1, 6), (6, 1, 12), (10, 2, 30), (13, 1, 40), (12, 3, 9)])
+def test_constraint_eval_stage(zk, ora, log_n, log_blowup, width):
+    """K5 as a stage through the C ABI (zkhip_constraint_eval): quotient values of one AIR over its committed LDE == oracle; on
+    a satisfying trace the quotient is a polynomial of degree < 2^b * N - N (its chunks' LDEs are what zkhip_prove commits)."""
+    from zkvm_prover_amd import air
+
+    sa = air.SyntheticAir(width=width, n_free=max(4, width // 3), n_bool=2, n_boundary=1, seed=log_n)
+    tr, pv = sa.gen_trace(log_n, seed=3)
+    lde = ora.coset_lde_batch(tr, log_n, log_blowup, 31)
+    alpha = ora.rand_field(np.random.default_rng(5), 4)
+    exp = ora.constraint_eval(sa.program(), log_n, log_blowup, width, lde, pv, alpha)
+    d_lde = zk.lde_batch(zk.upload(tr.reshape(-1)), log_n, log_blowup, width, 31)
+    got = zk.download(zk.constraint_eval(sa.program(), log_n, log_blowup, width, d_lde, pv, alpha)).reshape(4, -1)
+    assert (got == exp).all()
+    # an unsatisfying trace still evaluates (to something else); a bus AIR is refused
+    tr2 = tr.copy()
+    tr2[0, 0] = (int(tr2[0, 0]) + 1) % P
+    got2 = zk.download(zk.constraint_eval(sa.program(), log_n, log_blowup, width, zk.lde_batch(zk.upload(tr2.reshape(-1)), log_n, log_blowup, width, 31), pv, alpha))
+    assert (got2.reshape(4, -1) == ora.constraint_eval(sa.program(), log_n, log_blowup, width, ora.coset_lde_batch(tr2, log_n, log_blowup, 31), pv, alpha)).all()
+    import zkvm_prover_amd as z
+
+    with pytest.raises(z.ZkhipError):
+        zk.constraint_eval(air.lookup_sender_air().program(), log_n, log_blowup, 3, d_lde, np.zeros(0, np.uint32), alpha)

@@ -106,6 +106,7 @@ def load_library():
         "zkhip_merkle_opening_words": (sz, [vp]),
         "zkhip_merkle_open": (C.c_int, [vp, vp, C.POINTER(C.c_uint64), sz, u32p, sz]),
         "zkhip_tree_destroy": (None, [vp, vp]),
+        "zkhip_constraint_eval": (C.c_int, [vp, u32p, sz, C.c_uint, C.c_uint, sz, vp, u32p, sz, u32p, vp]),
         "zkhip_fri_fold": (C.c_int, [vp, vp, vp, C.c_uint, u32p]),
         "zkhip_ext_batch_inverse": (C.c_int, [vp, vp, vp, sz]),
         "zkhip_logup_running_sum": (C.c_int, [vp, vp, vp, sz, vp, u32p]),
@@ -313,6 +314,18 @@ class Context:
     def merkle_commit(self, mats, want_root=True):
         """mats: list of (tensor, log_height, width[, stride])."""
         return MerkleTree(self, mats, want_root)
+
+    def constraint_eval(self, program, log_height, log_blowup, width, t_lde, pvs, alpha):
+        """Quotient values (4 x 2^(log_height+log_blowup) Montgomery words, device) of one AIR on its committed LDE."""
+        import torch
+
+        prog = np.ascontiguousarray(program, dtype=np.uint32)
+        pv = np.ascontiguousarray(pvs, dtype=np.uint32)
+        al = np.ascontiguousarray(alpha, dtype=np.uint32)
+        out = torch.empty(4 << (log_height + log_blowup), dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_constraint_eval(self.h, _u32p(prog), prog.size, log_height, log_blowup, width, C.c_void_p(t_lde.data_ptr()),
+                                                   _u32p(pv) if pv.size else None, pv.size, _u32p(al), C.c_void_p(out.data_ptr())))
+        return out
 
     def fri_fold(self, t_in, log_n_out, beta):
         import torch

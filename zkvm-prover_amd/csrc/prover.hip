@@ -2053,6 +2053,74 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     return ZKHIP_OK;
 }
 
+// K5 on its own: the quotient values of ONE AIR over its LDE domain, through the interpreter kernel.  Stage-level entry like
+// zkhip_lde_batch / zkhip_merkle_commit (SURVEY.md 8(b) `zkhip_constraint_eval`); zkhip_prove runs the same kernel over all chips.
+int zkhip_constraint_eval(zkhip_ctx* ctx, const uint32_t* program, size_t program_len, unsigned log_height, unsigned log_blowup,
+                          size_t width, const uint32_t* d_lde, const uint32_t* pvs, size_t n_pvs, const uint32_t alpha[4], uint32_t* d_q) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !program || !d_lde || !alpha || !d_q || width == 0 || log_blowup < 1 || log_blowup > 4 || log_height + log_blowup > 27)
+        return ZKHIP_ERR_INVALID;
+    AirProgram prog;
+    std::string err;
+    if (parse_air(program, program_len, width, &prog, &err) != 0) return set_error(ctx, ZKHIP_ERR_INVALID, "constraint_eval: " + err);
+    if (prog.n_pvs != n_pvs || (n_pvs && !pvs)) return set_error(ctx, ZKHIP_ERR_INVALID, "constraint_eval: public values do not match the program");
+    if (!prog.ints.empty() || prog.prep_width) return set_error(ctx, ZKHIP_ERR_INVALID, "constraint_eval: AIRs with bus interactions or preprocessed traces are proven through zkhip_prove");
+    if (prog.max_degree > (1u << log_blowup) + 1) return set_error(ctx, ZKHIP_ERR_CONSTRAINT, "constraint degree exceeds 2^log_blowup + 1");
+    CompiledAir comp;
+    if (compile_air(prog, &comp, &err) != 0) return set_error(ctx, ZKHIP_ERR_INVALID, "constraint_eval: " + err);
+    const unsigned b = log_blowup, nch = 1u << b, h = log_height + b;
+    const size_t N = (size_t)1 << log_height, M = (size_t)1 << h;
+    ZK_TRY(ensure_twiddles(ctx, h));
+    // small tables: code | consts | pvs | alpha (1 ext) | apow (n_cons ext) | zh | inv_zh | descriptor | prefix
+    std::vector<uint32_t> pm(n_pvs + 1), zh(nch), izh(nch), am(4);
+    for (size_t i = 0; i < n_pvs; i++) {
+        if (pvs[i] >= P) return set_error(ctx, ZKHIP_ERR_INVALID, "public value not canonical");
+        pm[i] = to_monty(pvs[i]);
+    }
+    for (int k = 0; k < 4; k++) {
+        if (alpha[k] >= P) return set_error(ctx, ZKHIP_ERR_INVALID, "alpha not canonical");
+        am[k] = to_monty(alpha[k]);
+    }
+    const uint32_t gN = host_pow(to_monty(FIELD_GEN_CANON), N), wb = two_adic_generator(b);
+    for (unsigned j = 0; j < nch; j++) zh[j] = msub(mmul(gN, host_pow(wb, j)), MONTY_ONE), izh[j] = minv(zh[j]);
+    Bump bp;
+    const size_t o_code = bp.take(comp.code.size() * 4 + 16), o_consts = bp.take(comp.consts.size() * 4 + 16), o_pvs = bp.take(n_pvs * 4 + 16);
+    const size_t o_alpha = bp.take(16), o_apow = bp.take((size_t)(prog.n_cons + 1) * 16), o_zh = bp.take(nch * 4), o_izh = bp.take(nch * 4);
+    const size_t o_args = bp.take(sizeof(QuotArgs)), o_first = bp.take(16), o_pow = bp.take(sizeof(PowDesc));
+    void* buf = nullptr;
+    ZK_TRY(get_scratch(ctx, 7, bp.off, &buf));
+    char* base = (char*)buf;
+    ZK_TRY(upload(ctx, base + o_code, comp.code.data(), comp.code.size() * 4));
+    ZK_TRY(upload(ctx, base + o_consts, comp.consts.data(), comp.consts.size() * 4));
+    ZK_TRY(upload(ctx, base + o_pvs, pm.data(), n_pvs * 4));
+    ZK_TRY(upload(ctx, base + o_alpha, am.data(), 16));
+    ZK_TRY(upload(ctx, base + o_zh, zh.data(), nch * 4));
+    ZK_TRY(upload(ctx, base + o_izh, izh.data(), nch * 4));
+    QuotArgs qa;
+    memset(&qa, 0, sizeof qa);
+    qa.code = (uint32_t*)(base + o_code), qa.n_instr = (uint32_t)(comp.code.size() / 3), qa.consts = (uint32_t*)(base + o_consts);
+    qa.pvs = (uint32_t*)(base + o_pvs), qa.apow = (uint32_t*)(base + o_apow), qa.lde = d_lde, qa.q = d_q;
+    qa.inv_zh = (uint32_t*)(base + o_izh), qa.zh = (uint32_t*)(base + o_zh), qa.gen = to_monty(FIELD_GEN_CANON);
+    qa.w_n_inv = minv(two_adic_generator(log_height)), qa.lh = log_height, qa.b = b;
+    const uint32_t first[2] = {0, (uint32_t)((M + QBS - 1) / QBS)};
+    const PowDesc pd{(uint32_t*)(base + o_apow), prog.n_cons, 0};
+    ZK_TRY(upload(ctx, base + o_args, &qa, sizeof qa));
+    ZK_TRY(upload(ctx, base + o_first, first, 8));
+    ZK_TRY(upload(ctx, base + o_pow, &pd, sizeof pd));
+    {
+        KernelScope ks(ctx, "ext_powers");
+        hipLaunchKernelGGL(k_ext_powers_multi, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)(base + o_alpha), (const PowDesc*)(base + o_pow));
+    }
+    {
+        KernelScope ks(ctx, "quotient_eval");
+        const QuotMulti qm{(const QuotArgs*)(base + o_args), (const uint32_t*)(base + o_first), 1u, ctx->d_tw_fwd, ctx->tw_log};
+        hipLaunchKernelGGL(k_quotient, dim3(first[1]), dim3(QBS), (size_t)comp.n_slots * QBS * 4, ctx->stream, qm);
+    }
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the scratch tables may be reused by the next call
+    return ZKHIP_OK;
+}
+
 int zkhip_proof_fetch(zkhip_ctx* ctx, const zkhip_pk* pk, uint8_t* out, size_t cap, size_t* out_len) {
     ZK_BIND_DEVICE(ctx);
     if (!ctx || !pk || !out) return ZKHIP_ERR_INVALID;
