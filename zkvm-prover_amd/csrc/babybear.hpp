@@ -56,6 +56,27 @@ ZK_HD uint32_t mmul_lazy(uint32_t a, uint32_t b) {
     return (uint32_t)(s >> 32);
 }
 ZK_HD uint32_t mmul(uint32_t a, uint32_t b) { return red_2p(mmul_lazy(a, b)); }
+// Signed Montgomery product: d == a * b * 2^-32 (mod p) with |d| <= |a*b| / 2^32 + p/2, for any int32 a, b (|a*b| <= 2^62 keeps
+// t - m*p inside 64 bits).  Operands in [-p, p] give |d| < 0.97 p: a chain of products needs NO conditional step between
+// them, where the unsigned form (result in [0, 2p)) has to be brought below the 2.417 p^2 product bound again.  Same three
+// instructions (v_mad_i64_i32, v_mul_lo_u32, v_mad_i64_i32).  Sums of two such values do not fit 32 bits (2p > 2^31), so
+// everything additive stays in the unsigned [0, p) form; canon_signed() is the way back (2 full-rate instructions).
+ZK_HD int32_t smml(int32_t a, int32_t b) {
+    const int64_t t = (int64_t)a * b;
+    const int32_t m = (int32_t)((uint32_t)t * MONTY_MU);
+    const int64_t s = t - (int64_t)m * (int32_t)P;  // low word == 0
+    return (int32_t)(s >> 32);
+}
+// d in (-p, p) -> [0, p)
+ZK_HD uint32_t canon_signed(int32_t d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t y;
+    asm("v_add_co_u32 %0, vcc, %2, %1\n\tv_cndmask_b32 %0, %1, %0, vcc" : "=&v"(y) : "v"(d), "i"(P) : "vcc");
+    return y;
+#else
+    return d < 0 ? (uint32_t)(d + (int32_t)P) : (uint32_t)d;
+#endif
+}
 ZK_HD uint32_t madd(uint32_t a, uint32_t b) { return red_2p(a + b); }
 ZK_HD uint32_t msub(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -198,9 +198,9 @@ __device__ __forceinline__ void dif_unit(uint32_t (&v)[16], const uint32_t* twl,
                 const int ka = blk * 2 * half + kl, kb = ka + half;
                 const uint32_t x = v[ka], y = v[kb];
                 v[ka] = madd(x, y);
-                // (x - y + p) is in (0, 2p) without a conditional; times w < p stays below the
-                // 2.417 p^2 limit of the lazy product, one conditional subtraction at the end
-                v[kb] = red_2p(mmul_lazy(x - y + P, w));
+                // x - y lies in (-p, p) as a signed word: the signed Montgomery product takes it as it is (no + p),
+                // result in (-p, p), one conditional addition at the end
+                v[kb] = canon_signed(smml((int32_t)(x - y), (int32_t)w));
             }
         }
     }
@@ -350,7 +350,7 @@ __device__ __forceinline__ void dif_unit_w(uint32_t (&v)[1 << Q], const uint32_t
                 const int ka = blk * 2 * half + kl, kb = ka + half;
                 const uint32_t x = v[ka], y = v[kb];
                 v[ka] = madd(x, y);
-                v[kb] = red_2p(mmul_lazy(x - y + P, w[woff + kl]));
+                v[kb] = canon_signed(smml((int32_t)(x - y), (int32_t)w[woff + kl]));
             }
         }
     }

@@ -38,18 +38,18 @@ __device__ __forceinline__ void poseidon2_permute_rolled(uint32_t (&s)[16]) {
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = sbox7(madd(s[i], rc[r * 16 + i]));
+        for (int i = 0; i < 16; i++) s[i] = sbox7_rc(s[i], rc[r * 16 + i]);
         p2_external_linear(s);
     }
 #pragma unroll 1
     for (int r = 0; r < 13; r++) {
-        s[0] = sbox7(madd(s[0], rc[64 + r]));
+        s[0] = sbox7_rc(s[0], rc[64 + r]);
         p2_internal_linear(s);
     }
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = sbox7(madd(s[i], rc[77 + r * 16 + i]));
+        for (int i = 0; i < 16; i++) s[i] = sbox7_rc(s[i], rc[77 + r * 16 + i]);
         p2_external_linear(s);
     }
 }
@@ -83,16 +83,16 @@ __device__ __forceinline__ uint32_t coop_sum16(uint32_t x) {
 __device__ __forceinline__ uint32_t coop_permute(uint32_t x, unsigned lane) {
     x = coop_external_linear(x);
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7(madd(x, POSEIDON2_RC_DEV[r * 16 + lane])));
+    for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7_rc(x, POSEIDON2_RC_DEV[r * 16 + lane]));
     const uint32_t d = POSEIDON2_DIAG_DEV[lane];
 #pragma unroll 1
     for (int r = 0; r < 13; r++) {
-        const uint32_t sb = sbox7(madd(x, POSEIDON2_RC_DEV[64 + r]));
+        const uint32_t sb = sbox7_rc(x, POSEIDON2_RC_DEV[64 + r]);
         x = lane == 0 ? sb : x;
         x = madd(mmul(x, d), coop_sum16(x));
     }
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7(madd(x, POSEIDON2_RC_DEV[77 + r * 16 + lane])));
+    for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7_rc(x, POSEIDON2_RC_DEV[77 + r * 16 + lane]));
     return x;
 }
 #endif
