@@ -49,11 +49,13 @@ ZK_HD uint32_t mhalve(uint32_t x) { return (x & 1u) ? ((x >> 1) + ((P + 1u) >> 1
 // (one addition, the constant's half is uniform), and signed Montgomery products of values that small stay below 0.97 p in
 // magnitude: x2, x3, x4, x7 need no conditional step until the final canon_signed -- 1 + 12 + 2 instructions against the
 // 3 + 12 + 4 of sbox7(madd(s, rc)).
-ZK_HD uint32_t sbox7_rc(uint32_t s, uint32_t rc) {
-    const int32_t x = (int32_t)(s + (rc - P));
+// rcs = rc - p (mod 2^32), a constant prepared once: s + rcs is the signed word s + rc - p
+ZK_HD uint32_t sbox7_rcs(uint32_t s, uint32_t rcs) {
+    const int32_t x = (int32_t)(s + rcs);
     const int32_t x2 = smml(x, x), x3 = smml(x2, x), x4 = smml(x2, x2);
     return canon_signed(smml(x3, x4));
 }
+ZK_HD uint32_t sbox7_rc(uint32_t s, uint32_t rc) { return sbox7_rcs(s, rc - P); }
 ZK_HD uint32_t sbox7(uint32_t x) {
     uint32_t x2 = mmul_lazy(x, x);
     uint32_t x3 = mmul_lazy(x2, x);
@@ -69,8 +71,8 @@ ZK_HD void p2_external_linear(uint32_t s[16]) {
         uint32_t t01 = madd(x0, x1), t23 = madd(x2, x3);
         uint32_t t0123 = madd(t01, t23);
         uint32_t t01123 = madd(t0123, x1), t01233 = madd(t0123, x3);
-        s[b + 3] = madd(t01233, mdouble(x0));
-        s[b + 1] = madd(t01123, mdouble(x2));
+        s[b + 3] = madd(madd(t01233, x0), x0);  // + 2 x0 as two additions: one instruction fewer than doubling first
+        s[b + 1] = madd(madd(t01123, x2), x2);
         s[b + 0] = madd(t01123, t01);
         s[b + 2] = madd(t01233, t23);
     }
@@ -106,9 +108,9 @@ ZK_HD void p2_internal_linear(uint32_t s[16]) {
     uint32_t d;
     s[0] = msub(sum, mdouble(s[0]));                          // -2
     s[1] = madd(sum, s[1]);                                   //  1
-    s[2] = madd(sum, mdouble(s[2]));                          //  2
+    s[2] = madd(madd(sum, s[2]), s[2]);                       //  2
     s[3] = madd(sum, mhalve(s[3]));                           //  1/2
-    d = mdouble(s[4]); s[4] = madd(sum, madd(d, s[4]));       //  3
+    d = madd(sum, s[4]); s[4] = madd(madd(d, s[4]), s[4]);    //  3
     s[5] = madd(sum, mdouble(mdouble(s[5])));                 //  4
     s[6] = msub(sum, mhalve(s[6]));                           // -1/2
     d = mdouble(s[7]); s[7] = msub(sum, madd(d, s[7]));       // -3

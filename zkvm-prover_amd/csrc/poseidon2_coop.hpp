@@ -12,9 +12,6 @@
 namespace zk {
 
 #if defined(__HIPCC__)
-__device__ const uint32_t POSEIDON2_RC_DEV[141] = {
-#include "poseidon2_rc.inc"
-};
 // diag V (Montgomery form), see poseidon2.hpp
 __device__ const uint32_t POSEIDON2_DIAG_DEV[16] = {
     P - 0x1ffffffcu /* -2 */, 0x0ffffffeu /* 1 */, 0x1ffffffcu /* 2 */, 0x07ffffffu /* 1/2 */,
@@ -31,25 +28,41 @@ __device__ const uint32_t POSEIDON2_DIAG_DEV[16] = {
 static __constant__ const uint32_t POSEIDON2_RC_CONST[144] = {
 #include "poseidon2_rc.inc"
 };
+// The bulk kernels add rc - p (mod 2^32), the form sbox7_rcs takes: the compiler would otherwise reassociate
+// s + (rc - p) into two vector additions (2^23 x 300 row hash: 45.2 - 46.0 ms against 46.2 - 46.8).  One scalar load per
+// constant, each just ahead of its S-box: fetching the 16 constants of an external round as one s_load_dwordx16 makes
+// the compiler interleave all 16 S-boxes (84 VGPRs, 5 waves per SIMD, or spills at 8) and measured 1 - 3 % SLOWER.
+struct Poseidon2RcShifted {
+    uint32_t v[144];
+};
+constexpr Poseidon2RcShifted poseidon2_rc_shifted() {
+    Poseidon2RcShifted t{};
+    // [0,64) initial external rounds, [64,77) internal rounds, [80,144) final external rounds
+    for (int i = 0; i < 77; i++) t.v[i] = Poseidon2Consts::RC[i] - P;
+    for (int i = 0; i < 64; i++) t.v[80 + i] = Poseidon2Consts::RC[77 + i] - P;
+    return t;
+}
+static __constant__ const Poseidon2RcShifted POSEIDON2_RCS_CONST = poseidon2_rc_shifted();
+__device__ const Poseidon2RcShifted POSEIDON2_RCS_DEV = poseidon2_rc_shifted();
 __device__ __forceinline__ void poseidon2_permute_rolled(uint32_t (&s)[16]) {
     typedef const __attribute__((address_space(4))) uint32_t* cptr;
-    cptr rc = (cptr)POSEIDON2_RC_CONST;
+    cptr rc = (cptr)POSEIDON2_RCS_CONST.v;
     p2_external_linear(s);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = sbox7_rc(s[i], rc[r * 16 + i]);
+        for (int i = 0; i < 16; i++) s[i] = sbox7_rcs(s[i], rc[r * 16 + i]);
         p2_external_linear(s);
     }
 #pragma unroll 1
     for (int r = 0; r < 13; r++) {
-        s[0] = sbox7_rc(s[0], rc[64 + r]);
+        s[0] = sbox7_rcs(s[0], rc[64 + r]);
         p2_internal_linear(s);
     }
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = sbox7_rc(s[i], rc[77 + r * 16 + i]);
+        for (int i = 0; i < 16; i++) s[i] = sbox7_rcs(s[i], rc[80 + r * 16 + i]);
         p2_external_linear(s);
     }
 }
@@ -83,16 +96,16 @@ __device__ __forceinline__ uint32_t coop_sum16(uint32_t x) {
 __device__ __forceinline__ uint32_t coop_permute(uint32_t x, unsigned lane) {
     x = coop_external_linear(x);
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7_rc(x, POSEIDON2_RC_DEV[r * 16 + lane]));
+    for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7_rcs(x, POSEIDON2_RCS_DEV.v[r * 16 + lane]));
     const uint32_t d = POSEIDON2_DIAG_DEV[lane];
 #pragma unroll 1
     for (int r = 0; r < 13; r++) {
-        const uint32_t sb = sbox7_rc(x, POSEIDON2_RC_DEV[64 + r]);
+        const uint32_t sb = sbox7_rcs(x, POSEIDON2_RCS_DEV.v[64 + r]);
         x = lane == 0 ? sb : x;
         x = madd(mmul(x, d), coop_sum16(x));
     }
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7_rc(x, POSEIDON2_RC_DEV[77 + r * 16 + lane]));
+    for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7_rcs(x, POSEIDON2_RCS_DEV.v[80 + r * 16 + lane]));
     return x;
 }
 #endif
