@@ -337,7 +337,9 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
 //  * the 2^Q - 1 twiddles of a register unit are read from the LDS table before the butterflies
 //    start instead of one dependent read per stage;
 //  * the write-out is unrolled so that the tile column of each store is a compile-time constant.
-template <int Q>
+// LAST: the unit ends the tile's transform (rows 1 apart, first row 0): the twiddle of its last stage and the first
+// twiddle of the stage before are w^0 = 1 -- no product
+template <int Q, bool LAST = false>
 __device__ __forceinline__ void dif_unit_w(uint32_t (&v)[1 << Q], const uint32_t (&w)[(1 << Q) - 1]) {
 #pragma unroll
     for (int t = 0; t < Q; t++) {
@@ -350,7 +352,10 @@ __device__ __forceinline__ void dif_unit_w(uint32_t (&v)[1 << Q], const uint32_t
                 const int ka = blk * 2 * half + kl, kb = ka + half;
                 const uint32_t x = v[ka], y = v[kb];
                 v[ka] = madd(x, y);
-                v[kb] = canon_signed(smml((int32_t)(x - y), (int32_t)w[woff + kl]));
+                if (LAST && kl == 0)
+                    v[kb] = msub(x, y);
+                else
+                    v[kb] = canon_signed(smml((int32_t)(x - y), (int32_t)w[woff + kl]));
             }
         }
     }
@@ -385,7 +390,7 @@ __device__ __forceinline__ void lds_rounds_ct(uint32_t* lv, const uint32_t* twl,
             for (int k = 0; k < (1 << Q); k++) v[k] = base[(k << LOG_RQ) * pitch];
             load_unit_twiddles<Q, LOG_RQ, LOG_R - LOG_RCUR>(twl, j, w);
 #if !defined(NTT_ABL) || (NTT_ABL != 1 && NTT_ABL != 5)
-            dif_unit_w<Q>(v, w);
+            dif_unit_w<Q, LOG_RQ == 0>(v, w);
 #endif
 #pragma unroll
             for (int k = 0; k < (1 << Q); k++) base[(k << LOG_RQ) * pitch] = v[k];
@@ -447,11 +452,13 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
             for (int k = 0; k < 16; k++) v[k] = wv[((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3)];
             uint32_t t = mmul(a.scale_col[((size_t)sub << a.log_f) + F0 + c], a.scale_row[((size_t)sub << LOG_RQ) + j]);
             const uint32_t rho = a.scale_rho[sub];
+            // the running power stays a signed word (|t| < p needs no conditional step between products)
+            int32_t ts = (int32_t)t;
             v[0] = mmul(v[0], t);
 #pragma unroll
             for (int k = 1; k < 16; k++) {
-                t = mmul(t, rho);
-                v[k] = mmul(v[k], t);
+                ts = smml(ts, (int32_t)rho);
+                v[k] = canon_signed(smml((int32_t)v[k], ts));
             }
         } else {
             // uniform base of the tile + one 32-bit lane offset; register k is 2^(LOG_RQ + log_f) words further
@@ -478,11 +485,13 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
             const uint32_t half = 1u << (a.log_tt - 1);
             uint32_t t = e0 < half ? a.tw[(size_t)e0 << sh] : mneg(a.tw[(size_t)(e0 - half) << sh]);
             const uint32_t rho = de < half ? a.tw[(size_t)de << sh] : mneg(a.tw[(size_t)(de - half) << sh]);
+            // the running power stays a signed word (|t| < p needs no conditional step between products)
+            int32_t ts = (int32_t)t;
             v[0] = mmul(v[0], t);
 #pragma unroll
             for (int k = 1; k < 16; k++) {
-                t = mmul(t, rho);
-                v[k] = mmul(v[k], t);
+                ts = smml(ts, (int32_t)rho);
+                v[k] = canon_signed(smml((int32_t)v[k], ts));
             }
         }
         uint32_t w[15];
