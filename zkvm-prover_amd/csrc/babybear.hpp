@@ -92,6 +92,21 @@ ZK_HD uint32_t msub(uint32_t a, uint32_t b) {
     return e < d ? e : d;  // if a < b, d wrapped (huge) and d+p wraps back to the small right value
 #endif
 }
+// [0, p) -> the representative in (-p/2, p/2]
+ZK_HD int32_t center_signed(uint32_t x) { return x > (P >> 1) ? (int32_t)(x - P) : (int32_t)x; }
+// signed Montgomery step of a 64-bit sum of products: d == t * 2^-32 (mod p), |d| <= |t| / 2^32 + p/2 (|t| < 1.21 p^2 keeps it in 32 bits)
+ZK_HD int32_t smred64(int64_t t) {
+    const int32_t m = (int32_t)((uint32_t)t * MONTY_MU);
+    const int64_t s = t - (int64_t)m * (int32_t)P;
+    return (int32_t)(s >> 32);
+}
+// d in (-2p, 2p) as far as it fits a signed word -> [0, p)
+ZK_HD uint32_t canon_signed_wide(int32_t d) {
+    if (d < 0) d += (int32_t)P;
+    if (d < 0) d += (int32_t)P;
+    if (d >= (int32_t)P) d -= (int32_t)P;
+    return (uint32_t)d;
+}
 ZK_HD uint32_t mneg(uint32_t a) { return a == 0 ? 0 : P - a; }
 ZK_HD uint32_t to_monty(uint32_t canon) { return mmul(canon, MONTY_R2); }
 ZK_HD uint32_t from_monty(uint32_t m) { return mmul(m, 1u); }

@@ -425,14 +425,19 @@ __global__ __launch_bounds__(256) void k_col_reduce(OpenMulti m) {
     const uint32_t* __restrict__ weights = m.weights + 4 * a.weights_off;
     uint32_t* __restrict__ partial = m.partial + a.partial_off;
     const size_t row0 = tile * 64 * RK + lane;
-    uint32_t w[RK][NPTS][4];
+    // Weights and cells are centred to (-p/2, p/2] and multiplied as signed words: four products fit one 64-bit
+    // accumulator under the bound of the signed Montgomery step (|t| < 1.21 p^2 keeps the result inside 32 bits), so a
+    // lane's RK = 8 rows cost 8 v_mad_i64_i32 + one extra product that carries the first group's residue into the second
+    // (d1 * (2^32 mod p) * 2^-32 == d1) + two 2-instruction reductions per coordinate, instead of 8 x (product + modular add).
+    static_assert(RK == 8, "two groups of four rows");
+    int32_t w[RK][NPTS][4];
 #pragma unroll
     for (int k = 0; k < RK; k++) {
         size_t r = row0 + (size_t)k * 64;
 #pragma unroll
         for (int p = 0; p < NPTS; p++) {
             uint4 v = r < N ? reinterpret_cast<const uint4*>(weights)[(size_t)p * N + r] : make_uint4(0, 0, 0, 0);
-            w[k][p][0] = v.x, w[k][p][1] = v.y, w[k][p][2] = v.z, w[k][p][3] = v.w;
+            w[k][p][0] = center_signed(v.x), w[k][p][1] = center_signed(v.y), w[k][p][2] = center_signed(v.z), w[k][p][3] = center_signed(v.w);
         }
     }
     uint32_t x[RK], xn[RK];
@@ -450,32 +455,53 @@ __global__ __launch_bounds__(256) void k_col_reduce(OpenMulti m) {
                 xn[k] = r < N ? col[r] : 0u;
             }
         }
-        uint32_t acc[NPTS][4];
+        int32_t xs[RK];
 #pragma unroll
-        for (int p = 0; p < NPTS; p++)
+        for (int k = 0; k < RK; k++) xs[k] = center_signed(x[k]);
+        uint32_t acc[8];  // [p][q] for two points; the second half is unused (zero) with one point
 #pragma unroll
-            for (int q = 0; q < 4; q++) acc[p][q] = 0;
-#pragma unroll
-        for (int k = 0; k < RK; k++)
-#pragma unroll
-            for (int p = 0; p < NPTS; p++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) acc[p][q] = madd(acc[p][q], mmul(w[k][p][q], x[k]));
-#pragma unroll
-        for (int p = 0; p < NPTS; p++)
+        for (int p = 0; p < 2; p++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                uint32_t v = acc[p][q];
+                if (p >= NPTS) {
+                    acc[p * 4 + q] = 0;
+                    continue;
+                }
+                int64_t t = 0;
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) v = madd(v, __shfl_xor(v, off, 64));
-                acc[p][q] = v;
+                for (int k = 0; k < 4; k++) t += (int64_t)w[k][p][q] * xs[k];
+                const int32_t d1 = smred64(t);                       // |d1| < 0.97 p
+                t = (int64_t)d1 * (int32_t)MONTY_ONE;                // 0.13 p^2 at most
+#pragma unroll
+                for (int k = 4; k < 8; k++) t += (int64_t)w[k][p][q] * xs[k];
+                acc[p * 4 + q] = canon_signed_wide(smred64(t));      // |.| < 1.03 p
             }
-        if (lane == 0) {
-            uint32_t* o = partial + (tile * n_cols + c) * (NPTS * 4);
+        // Sum over the 64 lanes, all eight values at once: each exchange step halves the number of values a lane
+        // carries (v_permlane32_swap / v_permlane16_swap move the halves that change hands, then one select + row
+        // rotation), three more steps finish the one value left: 10 modular additions instead of 48.
+        uint32_t u4[4], u2[2], u1;
 #pragma unroll
-            for (int p = 0; p < NPTS; p++)
+        for (int j = 0; j < 4; j++) {
+            const auto r = __builtin_amdgcn_permlane32_swap(acc[j], acc[j + 4], false, false);
+            u4[j] = madd(r[0], r[1]);  // lanes 0-31: value j, lanes 32-63: value j + 4
+        }
 #pragma unroll
-                for (int q = 0; q < 4; q++) o[p * 4 + q] = acc[p][q];
+        for (int j = 0; j < 2; j++) {
+            const auto r = __builtin_amdgcn_permlane16_swap(u4[j], u4[j + 2], false, false);
+            u2[j] = madd(r[0], r[1]);  // 16-lane rows 0 / 1: values j, j + 2 (rows 2 / 3: + 4)
+        }
+        {
+            const bool up = (lane & 8u) != 0;
+            const uint32_t keep = up ? u2[1] : u2[0], send = up ? u2[0] : u2[1];
+            u1 = madd(keep, dpp<ZK_ROR(8)>(send));  // lanes 0-7 of a row: value + 0, lanes 8-15: value + 1
+        }
+        u1 = madd(u1, dpp<0x141>(u1));        // row_half_mirror: lane i <-> 7 - i inside each group of 8
+        u1 = madd(u1, dpp<0xB1>(u1));         // quad_perm [1,0,3,2]
+        u1 = madd(u1, dpp<ZK_QROT2>(u1));     // quad_perm [2,3,0,1]
+        if ((lane & 7u) == 0) {
+            // value index = 4 * (lane >> 5) + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1)
+            const unsigned vi = ((lane >> 5) << 2) | (((lane >> 4) & 1u) << 1) | ((lane >> 3) & 1u);
+            if (vi < NPTS * 4) partial[(tile * n_cols + c) * (NPTS * 4) + vi] = u1;
         }
 #pragma unroll
         for (int k = 0; k < RK; k++) x[k] = xn[k];
