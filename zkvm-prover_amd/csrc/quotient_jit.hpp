@@ -64,6 +64,22 @@ __device__ __forceinline__ uint32_t mml(uint32_t a, uint32_t b) {
     return (uint32_t)(s >> 32);
 }
 __device__ __forceinline__ uint32_t mmul(uint32_t a, uint32_t b) { return red(mml(a, b)); }
+// signed Montgomery product (babybear.hpp): operands in (-p, p), result in (-0.97 p, 0.97 p), no conditional step; a
+// product whose only users are products stays in this form, SC() brings one back to [0, p)
+#define MU 0x88000001u
+typedef int int32_t;
+typedef long long int64_t;
+__device__ __forceinline__ int32_t sml(int32_t a, int32_t b) {
+    int64_t t = (int64_t)a * b;
+    int32_t m = (int32_t)((uint32_t)t * MU);
+    int64_t s = t - (int64_t)m * (int32_t)P;
+    return (int32_t)(s >> 32);
+}
+__device__ __forceinline__ uint32_t SC(int32_t d) {
+    uint32_t y;
+    asm("v_add_co_u32 %0, vcc, %2, %1\n\tv_cndmask_b32 %0, %1, %0, vcc" : "=&v"(y) : "v"(d), "i"(P) : "vcc");
+    return y;
+}
 __device__ __forceinline__ uint32_t madd(uint32_t a, uint32_t b) { return red(a + b); }
 __device__ __forceinline__ uint32_t msub(uint32_t a, uint32_t b) {
     uint32_t d, e;
@@ -246,6 +262,18 @@ inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b,
                 os << "        const uint32_t e" << e << " = " << (E.op == A_VAR ? "LD" : E.op == A_PERM ? "LDP" : "LDQ") << "(pr[" << pidx[e] << "], "
                    << (E.a ? "rno" : "ro") << ");\n";
         }
+        // a product used only by other products keeps the signed form (2 instructions fewer than a reduced one)
+        std::vector<uint8_t> only_mul(C.entries.size(), 1), used(C.entries.size(), 0);
+        for (size_t e = 0; e < C.entries.size(); e++) {
+            const JitEntry& E = C.entries[e];
+            if (E.op == A_ADD || E.op == A_SUB || E.op == A_MUL) {
+                used[E.a] = used[E.b] = 1;
+                if (E.op != A_MUL) only_mul[E.a] = only_mul[E.b] = 0;
+            } else if (E.op == A_NEG) {
+                used[E.a] = 1, only_mul[E.a] = 0;
+            }
+        }
+        auto stays_signed = [&](size_t e) { return C.entries[e].op == A_MUL && used[e] && only_mul[e] && e + 1 != C.entries.size(); };
         for (size_t e = 0; e < C.entries.size(); e++) {
             const JitEntry& E = C.entries[e];
             switch (E.op) {
@@ -260,9 +288,14 @@ inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b,
                 case A_LAST: os << "        const uint32_t e" << e << " = sel_last;\n"; break;
                 case A_TRANS: os << "        const uint32_t e" << e << " = sel_trans;\n"; break;
                 case A_NEG: os << "        const uint32_t e" << e << " = mneg(e" << E.a << ");\n"; break;
+                case A_MUL:
+                    if (stays_signed(e))
+                        os << "        const int32_t e" << e << " = sml((int32_t)e" << E.a << ", (int32_t)e" << E.b << ");\n";
+                    else
+                        os << "        const uint32_t e" << e << " = SC(sml((int32_t)e" << E.a << ", (int32_t)e" << E.b << "));\n";
+                    break;
                 default:
-                    os << "        const uint32_t e" << e << " = " << (E.op == A_ADD ? "madd" : E.op == A_SUB ? "msub" : "mmul")
-                       << "(e" << E.a << ", e" << E.b << ");\n";
+                    os << "        const uint32_t e" << e << " = " << (E.op == A_ADD ? "madd" : "msub") << "(e" << E.a << ", e" << E.b << ");\n";
             }
         }
         os << "        ACC(pr[0], e" << (C.entries.size() - 1) << ")\n    }\n";
@@ -312,10 +345,25 @@ inline bool quot_jit_source_flat(const AirProgram& p, unsigned lh, unsigned b, s
     table->resize((size_t)max_col + 1);
     for (uint32_t c = 0; c <= max_col; c++) (*table)[c] = c;
     os << "    const cptr colv = (cptr)tab;\n";
+    auto is_two = [&](uint32_t n) { return p.nodes[3 * n] == A_CONST && p.nodes[3 * n + 1] == 2u; };
+    auto is_doubling = [&](uint32_t n) { return p.nodes[3 * n] == A_MUL && (is_two(p.nodes[3 * n + 1]) || is_two(p.nodes[3 * n + 2])); };
+    // a product used only by other (true) products keeps the signed form
+    std::vector<uint8_t> only_mul(p.n_nodes, 1), used(p.n_nodes, 0);
     for (uint32_t i = 0; i < p.n_nodes; i++) {
         if (!live[i]) continue;
         const uint32_t op = p.nodes[3 * i], a = p.nodes[3 * i + 1], bb = p.nodes[3 * i + 2];
-        os << "    const uint32_t e" << i << " = ";
+        if (op == A_ADD || op == A_SUB || op == A_MUL) {
+            used[a] = used[bb] = 1;
+            if (op != A_MUL || is_doubling(i)) only_mul[a] = only_mul[bb] = 0;
+        } else if (op == A_NEG) {
+            used[a] = 1, only_mul[a] = 0;
+        }
+    }
+    auto stays_signed = [&](uint32_t n) { return p.nodes[3 * n] == A_MUL && !is_doubling(n) && used[n] && only_mul[n] && cons_of[n].empty(); };
+    for (uint32_t i = 0; i < p.n_nodes; i++) {
+        if (!live[i]) continue;
+        const uint32_t op = p.nodes[3 * i], a = p.nodes[3 * i + 1], bb = p.nodes[3 * i + 2];
+        os << "    const " << (stays_signed(i) ? "int32_t" : "uint32_t") << " e" << i << " = ";
         switch (op) {
             case A_VAR: os << "LD(colv[" << a << "], " << (bb ? "rno" : "ro") << ")"; break;
             case A_PERM: os << "LDP(colv[" << a << "], " << (bb ? "rno" : "ro") << ")"; break;
@@ -329,12 +377,14 @@ inline bool quot_jit_source_flat(const AirProgram& p, unsigned lh, unsigned b, s
             case A_TRANS: os << "sel_trans"; break;
             case A_NEG: os << "mneg(e" << a << ")"; break;
             default: {
-                auto is_two = [&](uint32_t n) { return p.nodes[3 * n] == A_CONST && p.nodes[3 * n + 1] == 2u; };
                 if (op == A_MUL && (is_two(a) || is_two(bb))) {  // doubling is an addition, not a Montgomery product
                     const uint32_t x = is_two(a) ? bb : a;
                     os << "madd(e" << x << ", e" << x << ")";
+                } else if (op == A_MUL) {
+                    if (stays_signed(i)) os << "sml((int32_t)e" << a << ", (int32_t)e" << bb << ")";
+                    else os << "SC(sml((int32_t)e" << a << ", (int32_t)e" << bb << "))";
                 } else {
-                    os << (op == A_ADD ? "madd" : op == A_SUB ? "msub" : "mmul") << "(e" << a << ", e" << bb << ")";
+                    os << (op == A_ADD ? "madd" : "msub") << "(e" << a << ", e" << bb << ")";
                 }
             }
         }
