@@ -153,7 +153,11 @@ def _u32p(arr):
 
 
 class Context:
-    """One per GPU (zkhip_ctx).  Work is issued on the current torch stream of `device`."""
+    """One per GPU (zkhip_ctx).  Work is issued on the torch stream that is CURRENT WHEN THE CONTEXT IS CREATED (so that it
+    is ordered with the torch copies that fill its buffers).  Several contexts meant to run side by side must therefore be
+    created under different streams (`with torch.cuda.stream(s): Context(0)`, as bench.py and tools/refshape_bench.py do):
+    created under torch's default stream they all share it and their proofs run one after the other.  (The C++ side has no
+    such coupling: zkhip_ctx_create gives every context a non-blocking stream of its own.)"""
 
     def __init__(self, device=0):
         import torch

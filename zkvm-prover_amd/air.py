@@ -741,6 +741,74 @@ class ChipSet:
         return airs
 
 
+class ReferenceShapedSet:
+    """An AIR set with the SHAPE of the chunk proof the reference stores (crates/verifier/testdata/proofs/chunk-proof-feynman.json,
+    decoded by tests/refproof_v1.py; the shape is in tests/golden/ref_v1_vectors.json): 17 AIRs of 2^1 .. 2^21 rows, common main
+    widths 1 .. 398, one cached main partition of width 9 (the program chip), two preprocessed traces (widths 1 and 2), and as
+    many interactions per AIR as give the reference's after-challenge widths (two interactions share a permutation column group,
+    so an after-challenge matrix of 4 * (g + 1) base columns takes g send / receive pairs).  The chips' CONSTRAINTS are
+    synthetic (SyntheticAir); what is real is every dimension a prover's cost depends on.  `shrink` subtracts from every
+    log-height (tests).  Quotient: this prover splits every AIR's quotient into 2^log_blowup chunks (68 matrices at blow-up 4),
+    the reference's engine into next_pow2(max_degree - 1) per AIR (62 in that proof)."""
+
+    LOG_DEGREES = [17, 1, 6, 18, 19, 18, 13, 17, 19, 18, 21, 17, 18, 17, 19, 15, 18]
+    MAIN_WIDTHS = [1, 5, 23, 12, 11, 13, 17, 398, 27, 38, 29, 12, 23, 27, 21, 6, 1]
+    AFTER_CHALLENGE_WIDTHS = [8, 12, 16, 12, 12, 12, 12, 160, 44, 20, 20, 16, 16, 24, 24, 8, 8]
+    CACHED = {0: 9}          # AIR index -> cached main width
+    PREP = {1: 1, 16: 2}     # AIR index -> preprocessed width
+    TABLE, TABLE_USER, TABLE_BUS = 16, 10, 6
+
+    def __init__(self, shrink=0, seed=0):
+        self.heights = [max(1, d - shrink) for d in self.LOG_DEGREES]
+        self.heights[1] = 1
+        self.chips = []
+        for i, (w, acw) in enumerate(zip(self.MAIN_WIDTHS, self.AFTER_CHALLENGE_WIDTHS)):
+            groups = acw // 4 - 1
+            if i == self.TABLE:
+                lh = self.heights[i]
+                self.table_sizes = (1 << (lh // 2), 1 << (lh - lh // 2))
+                self.chips.append(range_tuple_table_air(self.table_sizes[0], self.table_sizes[1], bus=self.TABLE_BUS))
+                continue
+            width = w + self.CACHED.get(i, 0)
+            sa = SyntheticAir(width=width, n_free=max(4, width // 3), n_bool=2, n_boundary=1, seed=seed * 1000 + i)
+            b = sa.builder
+            b.cached_width = self.CACHED.get(i, 0)
+            if i in self.PREP:
+                b.prep_width = self.PREP[i]
+                for c in range(b.prep_width):
+                    b.assert_zero(b.prep(c) * (b.prep(c) - 1))
+            rng = np.random.default_rng(seed * 7 + i)
+            n_pairs = groups - 1 if i == self.TABLE_USER else groups
+            for k in range(n_pairs):
+                c = [int(x) for x in rng.integers(0, width, size=3)]
+                msg = [b.var(c[0]) + b.var(c[1]) * (k + 2), b.var(c[2])]
+                b.push_interaction(100 + i, msg, b.var(0), "send")
+                b.push_interaction(100 + i, msg, b.var(0), "receive")
+            if i == self.TABLE_USER:
+                b.push_interaction(self.TABLE_BUS, [b.var(0), b.var(1)], 1, "send")  # (bool, bool): always in the table
+            self.chips.append(sa)
+
+    def gen(self, seed=0):
+        airs, counts = [], None
+        for i, (chip, h) in enumerate(zip(self.chips, self.heights)):
+            if i == self.TABLE:
+                airs.append(None)
+                continue
+            tr, pv = chip.gen_trace(h, seed=seed * 7919 + i)
+            a = dict(program=chip.program(), log_height=h, width=chip.width, n_pvs=len(pv), trace=tr, pvs=pv)
+            if i in self.PREP:
+                a["prep"] = (np.arange(self.PREP[i] << h, dtype=np.uint32).reshape(self.PREP[i], 1 << h) % 2).astype(np.uint32)
+            if i == self.TABLE_USER:
+                sx, sy = self.table_sizes
+                counts = np.bincount(tr[0].astype(np.int64) * sy + tr[1].astype(np.int64), minlength=sx * sy)
+            airs.append(a)
+        sx, sy = self.table_sizes
+        airs[self.TABLE] = dict(program=self.chips[self.TABLE].program(), log_height=self.heights[self.TABLE], width=1, n_pvs=0,
+                                trace=(counts % P).astype(np.uint32).reshape(1, sx * sy), pvs=np.zeros(0, np.uint32),
+                                prep=range_tuple_prep(sx, sy))
+        return airs
+
+
 def program_bus_air(bus=2):
     """A 12-field bus message, the width of OpenVM's program / execution buses (pc, opcode, operands a..g, ...):
     the AIR sends its whole row and receives it back, gated by a boolean."""
