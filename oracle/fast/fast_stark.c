@@ -653,6 +653,7 @@ enum { OP_VAR, OP_PUB, OP_CONST, OP_FIRST, OP_LAST, OP_TRANS, OP_ADD, OP_SUB, OP
 typedef struct {
     uint32_t n_nodes, n_cons, n_pvs;
     const uint32_t *nodes, *cons;
+    unsigned log_qd; /* quotient chunks = 2^log_qd = next_pow2(max(constraint degree, 2) - 1), as oracle/stark.c */
 } program;
 static int parse_program(const uint32_t *w, size_t len, size_t width, program *p) {
     if (len < 4 || w[0] != AIR_MAGIC) return -1;
@@ -675,6 +676,22 @@ static int parse_program(const uint32_t *w, size_t len, size_t width, program *p
     }
     for (uint32_t i = 0; i < p->n_cons; i++)
         if (p->cons[i] >= p->n_nodes) return -1;
+    {
+        uint32_t *deg = (uint32_t *)calloc(p->n_nodes + 1, 4), maxd = 0;
+        for (uint32_t i = 0; i < p->n_nodes; i++) {
+            const uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
+            deg[i] = op == OP_VAR || op == OP_FIRST || op == OP_LAST ? 1
+                     : op == OP_ADD || op == OP_SUB               ? (deg[a] > deg[b] ? deg[a] : deg[b])
+                     : op == OP_MUL                               ? (deg[a] + deg[b] > 64 ? 64 : deg[a] + deg[b])
+                     : op == OP_NEG                               ? deg[a]
+                                                                  : 0;
+        }
+        for (uint32_t i = 0; i < p->n_cons; i++)
+            if (deg[p->cons[i]] > maxd) maxd = deg[p->cons[i]];
+        free(deg);
+        p->log_qd = 0;
+        while (((uint32_t)1 << p->log_qd) + 1 < (maxd < 2 ? 2 : maxd)) p->log_qd++;
+    }
     return 0;
 }
 
@@ -778,7 +795,7 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
             t_last = t_now;                                              \
         }                                                                \
     } while (0)
-    const unsigned b = prm->log_blowup, nch = 1u << b, lfp = prm->log_final_poly_len;
+    const unsigned b = prm->log_blowup, nch_lde = 1u << b, lfp = prm->log_final_poly_len;
     if (lfp > MAX_LOG_FINAL_POLY || n_airs == 0 || b == 0) return 0;
     air_state *st = (air_state *)calloc(n_airs, sizeof(air_state));
     unsigned hmax = 0;
@@ -828,12 +845,20 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
     const ext alpha = ext_from_canon(alpha_c);
 
     /* 2. quotient */
-    fmat *qm = (fmat *)calloc(n_airs * nch, sizeof(fmat));
+    size_t *qoff = (size_t *)calloc(n_airs + 1, sizeof(size_t)); /* AIR a's chunk j is quotient matrix qoff[a] + j */
+    for (size_t a = 0; a < n_airs; a++) {
+        if (st[a].prog.log_qd > b) return 0;
+        qoff[a + 1] = qoff[a] + ((size_t)1 << st[a].prog.log_qd);
+    }
+    const size_t n_quot = qoff[n_airs];
+    fmat *qm = (fmat *)calloc(n_quot, sizeof(fmat));
     int ok = 1;
     for (size_t a = 0; a < n_airs; a++) {
         const program *pg = &st[a].prog;
         const unsigned lh = st[a].lh, h = st[a].h;
         const size_t N = st[a].N, M = st[a].M;
+        const unsigned nch = 1u << pg->log_qd;
+        const size_t MQ = N << pg->log_qd; /* the quotient domain: the first N * qd rows of the bit-reversed LDE */
         ext *ap = (ext *)malloc((pg->n_cons + 1) * sizeof(ext));
         {
             ext cur = eone();
@@ -841,25 +866,25 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
         }
         const uint32_t wM = two_adic_m(h), winv = minv(two_adic_m(lh));
         /* x_r = g * wM^bitrev(r); 1/(x-1), 1/(x-winv) by chunked batch inversion */
-        uint32_t *xs = (uint32_t *)arena_alloc(M * 4), *i1 = (uint32_t *)arena_alloc(M * 4), *i2 = (uint32_t *)arena_alloc(M * 4);
+        uint32_t *xs = (uint32_t *)arena_alloc(MQ * 4), *i1 = (uint32_t *)arena_alloc(MQ * 4), *i2 = (uint32_t *)arena_alloc(MQ * 4);
         {
             uint32_t pw[32];
             pw[0] = wM;
             for (unsigned k = 1; k < h; k++) pw[k] = mm(pw[k - 1], pw[k - 1]);
 #pragma omp parallel for schedule(static)
-            for (size_t r = 0; r < M; r++) {
+            for (size_t r = 0; r < MQ; r++) {
                 uint32_t x = gen; /* exponent bitrev(r): bit k of r selects wM^(2^(h-1-k)) */
                 for (unsigned k = 0; k < h; k++)
                     if ((r >> k) & 1) x = mm(x, pw[h - 1 - k]);
                 xs[r] = x, i1[r] = msub(x, R1), i2[r] = msub(x, winv);
             }
-            const size_t CH = 4096, nchunk = (M + CH - 1) / CH;
+            const size_t CH = 4096, nchunk = (MQ + CH - 1) / CH;
 #pragma omp parallel
             {
                 uint32_t *scr = (uint32_t *)malloc(CH * 4);
 #pragma omp for schedule(static)
                 for (size_t c = 0; c < nchunk; c++) {
-                    size_t lo = c * CH, n = M - lo < CH ? M - lo : CH;
+                    size_t lo = c * CH, n = MQ - lo < CH ? MQ - lo : CH;
                     batch_inv(i1 + lo, n, scr);
                     batch_inv(i2 + lo, n, scr);
                 }
@@ -872,24 +897,24 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
             zh_tab[j] = msub(mpow(xs[(size_t)j << lh], N), R1);
             zhi_tab[j] = minv(zh_tab[j]);
         }
-        uint32_t *q = (uint32_t *)arena_alloc(M * 16); /* [r][4] */
+        uint32_t *q = (uint32_t *)arena_alloc(MQ * 16); /* [r][4] */
         uint32_t *cm_ = (uint32_t *)malloc((pg->n_nodes + 1) * 4);
         for (uint32_t i = 0; i < pg->n_nodes; i++) {
             const uint32_t op = pg->nodes[3 * i], av = pg->nodes[3 * i + 1];
             cm_[i] = op == OP_CONST ? to_m(av) : op == OP_PUB ? to_m(airs[a].pvs[av]) : 0;
         }
-        const size_t groups = (M + VL - 1) / VL;
+        const size_t groups = (MQ + VL - 1) / VL;
 #pragma omp parallel
         {
             vec *vals = (vec *)xalloc((size_t)(pg->n_nodes + 1) * sizeof(vec));
 #pragma omp for schedule(static)
             for (size_t g = 0; g < groups; g++) {
-                const size_t r0 = g * VL, valid = M - r0 < VL ? M - r0 : VL;
+                const size_t r0 = g * VL, valid = MQ - r0 < VL ? MQ - r0 : VL;
                 uint32_t rn[VL];
                 int contiguous = valid == VL;
                 for (size_t l = 0; l < VL; l++) {
                     size_t r = r0 + (l < valid ? l : 0);
-                    rn[l] = (uint32_t)bitrev((bitrev(r, h) + nch) & (M - 1), h);
+                    rn[l] = (uint32_t)bitrev((bitrev(r, h) + nch_lde) & (M - 1), h);
                     if (rn[l] != rn[0] + l) contiguous = 0;
                 }
                 vec vx, vi1, vi2, vzh, vzhi;
@@ -955,11 +980,11 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
             const uint32_t sj = mm(gen, mpow(wM, bitrev(j, b)));
             uint32_t *dst = st[a].qlde + (size_t)j * 4 * M;
             lde_cols(nat, N, 0, dst, M, lh, b, 4, mm(gen, minv(sj)));
-            qm[a * nch + j] = (fmat){dst, M, h, 4};
+            qm[qoff[a] + j] = (fmat){dst, M, h, 4};
         }
     }
     STAGE("quotient + chunk LDEs");
-    ftree *t_quot = tree_commit(qm, n_airs * nch, root_quot);
+    ftree *t_quot = tree_commit(qm, n_quot, root_quot);
     ora_ch_observe(&ch, root_quot, 8);
     STAGE("quotient commit");
     uint32_t zeta_c[4];
@@ -967,14 +992,14 @@ size_t fast_stark_prove(const ora_params *prm, const ora_air_instance *airs, siz
     const ext zeta = ext_from_canon(zeta_c);
 
     /* committed matrices in opening order: main (all AIRs), quotient chunks */
-    const size_t n_cm = n_airs + n_airs * nch;
+    const size_t n_cm = n_airs + n_quot;
     cmat *cm = (cmat *)calloc(n_cm, sizeof(cmat));
     {
         size_t k = 0;
         for (size_t a = 0; a < n_airs; a++) cm[k++] = (cmat){st[a].lde, st[a].nat, R1, st[a].lh, st[a].h, st[a].width, 2};
         for (size_t a = 0; a < n_airs; a++) {
             const uint32_t wM = two_adic_m(st[a].h);
-            for (unsigned j = 0; j < nch; j++)
+            for (unsigned j = 0; j < (1u << st[a].prog.log_qd); j++)
                 cm[k++] = (cmat){st[a].qlde + (size_t)j * 4 * st[a].M, st[a].qnat + (size_t)j * 4 * st[a].N,
                                  mm(gen, mpow(wM, bitrev(j, b))), st[a].lh, st[a].h, 4, 1};
         }
@@ -1304,7 +1329,7 @@ done:
     for (unsigned l = 0; l < n_layers; l++) tree_free(ftrees[l]);
     tree_free(t_main), tree_free(t_quot);
     free(ftrees), free(flayers), free(fleaves), free(froots), free(fpow), free(ro), free(opened), free(opened_c);
-    free(mm_), free(qm), free(cm), free(st), free(fin);
+    free(mm_), free(qm), free(qoff), free(cm), free(st), free(fin);
     STAGE("queries");
     return ok ? w : 0;
 }

@@ -104,6 +104,8 @@ typedef struct {
     interaction *ints;
     uint32_t n_groups;
     size_t perm_width; /* 4 * (n_groups + 1), or 0 */
+    uint32_t max_degree; /* of the constraints, in units of the trace length */
+    unsigned log_qd;     /* quotient chunks = 2^log_qd */
     size_t prep_width; /* preprocessed columns, or 0 */
     size_t cached_width; /* leading main columns committed on their own (cached main partition), or 0 */
     unsigned char *row_local; /* per node: reachable from an interaction operand (evaluated per trace row) */
@@ -174,6 +176,28 @@ static int parse_program(const uint32_t *w, size_t len, size_t width, program *p
     }
     for (uint32_t i = 0; i < p->n_cons; i++)
         if (p->cons[i] >= p->n_nodes) return -1;
+    { /* Degree of every constraint in units of the trace length (a trace cell, is_first, is_last: 1; is_transition = X - w^-1,
+       * constants, public values, challenges: 0).  The quotient of an AIR of constraint degree d has degree < (d - 1) N: it is
+       * split into qd = 2^ceil(log2(max(d, 2) - 1)) chunks (the rule of the reference's engine; the stored v1 proofs have
+       * 1 or 4 chunks per AIR at blow-up 4). */
+        uint32_t *deg = (uint32_t *)calloc(p->n_nodes + 1, sizeof(uint32_t));
+        for (uint32_t i = 0; i < p->n_nodes; i++) {
+            uint32_t op = p->nodes[3 * i], a = p->nodes[3 * i + 1], b = p->nodes[3 * i + 2];
+            switch (op) {
+            case OP_VAR: case OP_PERM: case OP_PREP: case OP_FIRST: case OP_LAST: deg[i] = 1; break;
+            case OP_ADD: case OP_SUB: deg[i] = deg[a] > deg[b] ? deg[a] : deg[b]; break;
+            case OP_MUL: deg[i] = deg[a] + deg[b]; if (deg[i] > 64) deg[i] = 64; break;
+            case OP_NEG: deg[i] = deg[a]; break;
+            default: deg[i] = 0;
+            }
+        }
+        p->max_degree = 0;
+        for (uint32_t i = 0; i < p->n_cons; i++)
+            if (deg[p->cons[i]] > p->max_degree) p->max_degree = deg[p->cons[i]];
+        free(deg);
+        p->log_qd = 0;
+        while (((uint32_t)1 << p->log_qd) + 1 < (p->max_degree < 2 ? 2 : p->max_degree)) p->log_qd++;
+    }
     if (p->n_int) {
         /* operands must be expressions of the current row: mark what they reach, reject anything else */
         p->row_local = (unsigned char *)calloc(p->n_nodes, 1);
@@ -391,7 +415,7 @@ int ora_prep_commit(const ora_params *prm, const ora_air_instance *air, uint32_t
 
 size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size_t n_airs, uint32_t *out,
                        size_t cap) {
-    const unsigned b = prm->log_blowup, nch = 1u << b;
+    const unsigned b = prm->log_blowup, nch_lde = 1u << b; /* rows of the LDE per trace row */
     const unsigned lfp = prm->log_final_poly_len; /* the fold loop stops at 2^(b+lfp) values = a polynomial of degree < 2^lfp */
     if (lfp > MAX_LOG_FINAL_POLY || n_airs == 0 || b == 0) return 0;
     air_state *st = (air_state *)calloc(n_airs, sizeof(air_state));
@@ -499,13 +523,23 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
     ora_ch_sample_ext(&ch, alpha);
 
     /* 2. quotient: evaluate constraints on the LDE domain, divide by Z_H, split, LDE each chunk */
-    ora_matrix *qm = (ora_matrix *)calloc(n_airs * nch, sizeof(ora_matrix));
-    uint32_t **qnat = (uint32_t **)calloc(n_airs * nch, sizeof(uint32_t *));
+    /* AIR a has qd_a = 2^log_qd chunks (parse_program); its chunk j is quotient matrix qoff[a] + j */
+    size_t *qoff = (size_t *)calloc(n_airs + 1, sizeof(size_t));
+    for (size_t a = 0; a < n_airs; a++) {
+        if (st[a].prog.log_qd > b) return 0; /* constraint degree needs a larger blow-up */
+        qoff[a + 1] = qoff[a] + ((size_t)1 << st[a].prog.log_qd);
+    }
+    const size_t n_quot = qoff[n_airs];
+    ora_matrix *qm = (ora_matrix *)calloc(n_quot, sizeof(ora_matrix));
+    uint32_t **qnat = (uint32_t **)calloc(n_quot, sizeof(uint32_t *));
     int ok = 1;
     for (size_t a = 0; a < n_airs; a++) {
         const program *pg = &st[a].prog;
         const unsigned lh = st[a].lh, h = st[a].h;
         const size_t N = (size_t)1 << lh, M = N << b, W = st[a].width, PW = pg->perm_width, QW = pg->prep_width;
+        /* the quotient domain g * H_{N qd} is the first N * qd rows of the bit-reversed LDE */
+        const unsigned nch = 1u << pg->log_qd;
+        const size_t MQ = N << pg->log_qd;
         ext_t *ap = (ext_t *)malloc((pg->n_cons + 1) * sizeof(ext_t));
         { /* constraint i is weighted alpha^(n_cons-1-i) (Horner order of p3's folder) */
             ext_t cur = {1, 0, 0, 0};
@@ -514,7 +548,7 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
                 ora_ext_mul(cur, alpha, cur);
             }
         }
-        uint32_t *q = (uint32_t *)malloc(M * 4 * sizeof(uint32_t)); /* [r][4] */
+        uint32_t *q = (uint32_t *)malloc(MQ * 4 * sizeof(uint32_t)); /* [r][4] */
         const uint32_t wM = ora_two_adic_generator(h), winv = ora_inv(ora_two_adic_generator(lh));
 #pragma omp parallel
         {
@@ -523,8 +557,8 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
             uint32_t *ploc = (uint32_t *)malloc((PW + 1) * sizeof(uint32_t)), *pnxt = (uint32_t *)malloc((PW + 1) * sizeof(uint32_t));
             uint32_t *qloc = (uint32_t *)malloc((QW + 1) * sizeof(uint32_t)), *qnxt = (uint32_t *)malloc((QW + 1) * sizeof(uint32_t));
 #pragma omp for schedule(static)
-            for (size_t r = 0; r < M; r++) {
-                size_t i = bitrev(r, h), rn = bitrev((i + nch) & (M - 1), h);
+            for (size_t r = 0; r < MQ; r++) {
+                size_t i = bitrev(r, h), rn = bitrev((i + nch_lde) & (M - 1), h);
                 uint32_t x = ora_mul(GEN, ora_pow(wM, i));
                 for (size_t c = 0; c < W; c++) {
                     loc[c] = st[a].lde[c * M + r];
@@ -563,19 +597,19 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
             uint32_t sj = ora_mul(GEN, ora_pow(wM, bitrev(j, b)));
             uint32_t *dst = st[a].qlde + (size_t)j * 4 * M;
             ora_coset_lde_batch(nat, N, dst, M, lh, b, 4, ora_mul(GEN, ora_inv(sj)), 1);
-            qm[a * nch + j] = (ora_matrix){dst, M, h, 4};
-            qnat[a * nch + j] = nat;
+            qm[qoff[a] + j] = (ora_matrix){dst, M, h, 4};
+            qnat[qoff[a] + j] = nat;
         }
         free(q), free(ap);
     }
-    ora_tree *t_quot = ora_mmcs_commit(qm, n_airs * nch, root_quot);
+    ora_tree *t_quot = ora_mmcs_commit(qm, n_quot, root_quot);
     ora_ch_observe(&ch, root_quot, 8);
     ext_t zeta;
     ora_ch_sample_ext(&ch, zeta);
 
     /* committed matrices in opening order: main (all AIRs), preprocessed (AIRs that have one), perm (AIRs with
      * interactions), quotient chunks */
-    size_t n_cm = n_airs + n_cached + n_prep + n_lu + n_airs * nch;
+    size_t n_cm = n_airs + n_cached + n_prep + n_lu + n_quot;
     cmat *cm = (cmat *)calloc(n_cm, sizeof(cmat));
     {
         size_t k = 0;
@@ -590,8 +624,8 @@ size_t ora_stark_prove(const ora_params *prm, const ora_air_instance *airs, size
             if (st[a].prog.n_int) cm[k++] = (cmat){st[a].perm_lde, st[a].perm, 1, st[a].lh, st[a].h, st[a].prog.perm_width, 2, 1};
         for (size_t a = 0; a < n_airs; a++) {
             const uint32_t wM = ora_two_adic_generator(st[a].h);
-            for (unsigned j = 0; j < nch; j++)
-                cm[k++] = (cmat){st[a].qlde + (size_t)j * 4 * ((size_t)1 << st[a].h), qnat[a * nch + j],
+            for (unsigned j = 0; j < (1u << st[a].prog.log_qd); j++)
+                cm[k++] = (cmat){st[a].qlde + (size_t)j * 4 * ((size_t)1 << st[a].h), qnat[qoff[a] + j],
                                  ora_mul(GEN, ora_pow(wM, bitrev(j, b))), st[a].lh, st[a].h, 4, 1, 2};
         }
     }
@@ -801,7 +835,8 @@ done:
         if (st[a].t_cached) ora_tree_free(st[a].t_cached);
         free_program(&st[a].prog);
     }
-    for (size_t k = 0; k < n_airs * nch; k++) free(qnat[k]);
+    for (size_t k = 0; k < n_quot; k++) free(qnat[k]);
+    free(qoff);
     for (unsigned l = 0; l < n_layers; l++) {
         ora_tree_free(ftrees[l]);
         free(fleaves[l]);
@@ -874,7 +909,7 @@ typedef struct {
 
 int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t n_airs, const uint32_t *proof,
                      size_t n_words) {
-    const unsigned b = prm->log_blowup, nch = 1u << b;
+    const unsigned b = prm->log_blowup;
     const unsigned lfp = prm->log_final_poly_len;
     if (lfp > MAX_LOG_FINAL_POLY || n_airs == 0 || b == 0) return -1;
     program *pg = (program *)calloc(n_airs, sizeof(program));
@@ -886,6 +921,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
         if (parse_program(airs[a].program, airs[a].program_len, airs[a].width, &pg[a])) return -2;
         if (pg[a].cached_width) n_cached++;
         if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height > 27 || airs[a].log_height < lfp) return -2;
+        if (pg[a].log_qd > b) return -2; /* constraint degree above 2^log_blowup + 1 */
         if (airs[a].log_height + b > hmax) hmax = airs[a].log_height + b;
         if (pg[a].n_int) n_lu++;
         if (pg[a].prep_width) {
@@ -897,7 +933,10 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
         }
     }
     /* committed matrices in opening order */
-    size_t n_cm = n_airs + n_cached + n_prep + n_lu + n_airs * nch, n_open = 0;
+    size_t *qoff = (size_t *)calloc(n_airs + 1, sizeof(size_t)); /* quotient chunks per AIR: 2^log_qd (parse_program) */
+    for (size_t a = 0; a < n_airs; a++) qoff[a + 1] = qoff[a] + ((size_t)1 << pg[a].log_qd);
+    const size_t n_quot = qoff[n_airs];
+    size_t n_cm = n_airs + n_cached + n_prep + n_lu + n_quot, n_open = 0;
     vmat *cm = (vmat *)calloc(n_cm, sizeof(vmat));
     size_t cm_cached0 = n_airs, cm_prep0 = n_airs + n_cached, cm_perm0 = cm_prep0 + n_prep, cm_quot0 = cm_perm0 + n_lu;
     {
@@ -911,7 +950,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
         for (size_t a = 0; a < n_airs; a++)
             if (pg[a].n_int) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, pg[a].perm_width, 2};
         for (size_t a = 0; a < n_airs; a++)
-            for (unsigned j = 0; j < nch; j++) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, 4, 1};
+            for (unsigned j = 0; j < (1u << pg[a].log_qd); j++) cm[k++] = (vmat){airs[a].log_height, airs[a].log_height + b, 4, 1};
         for (size_t m = 0; m < n_cm; m++) n_open += cm[m].width * cm[m].n_pts;
     }
     const unsigned n_layers = hmax - b - lfp;
@@ -1033,6 +1072,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
             /* quotient(zeta) = sum_j zps_j * sum_k x^k * chunk_{j,k}(zeta) */
             const uint32_t wM = ora_two_adic_generator(h);
             ext_t rhs = {0, 0, 0, 0};
+            const unsigned nch = 1u << pg[a].log_qd;
             for (unsigned j = 0; j < nch; j++) {
                 uint32_t sj = ora_mul(GEN, ora_pow(wM, bitrev(j, b)));
                 ext_t zps = {1, 0, 0, 0};
@@ -1048,7 +1088,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
                     ext_scale(num, ora_inv(den), num);
                     ora_ext_mul(zps, num, zps);
                 }
-                const ext_t *chunk = opened + open_off[cm_quot0 + a * nch + j];
+                const ext_t *chunk = opened + open_off[cm_quot0 + qoff[a] + j];
                 ext_t v = {0, 0, 0, 0};
                 for (int k = 0; k < 4; k++) {
                     /* basis element x^k times an extension value */
@@ -1087,7 +1127,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
         for (size_t a = 0; a < n_airs; a++)
             if (has_prep[a]) batch_first[bt] = cm_prep0 + k++, batch_n[bt] = 1, batch_root[bt] = prep_roots + 8 * a, bt++;
         if (n_lu) batch_first[bt] = cm_perm0, batch_n[bt] = n_lu, batch_root[bt] = root_perm, bt++;
-        batch_first[bt] = cm_quot0, batch_n[bt] = n_airs * nch, batch_root[bt] = root_quot, bt++;
+        batch_first[bt] = cm_quot0, batch_n[bt] = n_quot, batch_root[bt] = root_quot, bt++;
     }
     unsigned *lhs_all = (unsigned *)malloc(n_cm * sizeof(unsigned));
     size_t *ws_all = (size_t *)malloc(n_cm * sizeof(size_t));
@@ -1204,7 +1244,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
         }
     }
     if (rc == 0 && r != n_words) rc = -3;
-    free(betas), free(lhs_all), free(ws_all), free(roq), free(has), free(num_reduced), free(open_off), free(cm);
+    free(betas), free(lhs_all), free(ws_all), free(roq), free(has), free(num_reduced), free(open_off), free(cm), free(qoff);
     free(batch_first), free(batch_n), free(batch_root), free(rows_of), free(prep_roots), free(has_prep);
     for (size_t a = 0; a < n_airs; a++) free_program(&pg[a]);
     free(pg);

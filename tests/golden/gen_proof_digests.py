@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/proof_digests_v2.json: SHA-256 of the oracle's proof bytes for a fixed set of small AIR
+"""Generates tests/golden/proof_digests_v3.json: SHA-256 of the oracle's proof bytes for a fixed set of small AIR
 sets (plain, mixed heights, bus interactions, compound messages, preprocessed tables, a small chip set).
 
 These are REGRESSION pins produced by this repository's own oracle (no upstream vectors exist offline, SURVEY.md
@@ -65,6 +65,6 @@ def digests(ora):
 if __name__ == "__main__":
     import oracle_lib as ora
 
-    path = os.path.join(HERE, "proof_digests_v2.json")
+    path = os.path.join(HERE, "proof_digests_v3.json")
     json.dump(digests(ora), open(path, "w"), indent=1, sort_keys=True)
     print(open(path).read())

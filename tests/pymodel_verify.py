@@ -131,6 +131,10 @@ class Program:
                 raise Reject("unknown op")
         need(all(c < self.n_nodes for c in self.cons), "constraint index")
         self.max_degree = max([deg[c] for c in self.cons], default=0)
+        # quotient chunks: the quotient of degree-d constraints has degree < (d - 1) N -> next power of two of max(d, 2) - 1
+        self.qd = 1
+        while self.qd + 1 < max(self.max_degree, 2):
+            self.qd *= 2
         # bus operands are expressions of the current row only
         for (_, _, count, fields) in self.ints:
             stack = [count] + list(fields)
@@ -175,13 +179,12 @@ def verify(params, airs, proof_words):
     airs: dicts with program, log_height, width, n_pvs, pvs[, prep_commit].  Raises Reject, returns True."""
     b, lfp, n_queries, cpow, qpow = params
     need(0 <= lfp <= 8 and b >= 1, "parameters")
-    nch = 1 << b
     pr = [int(x) for x in proof_words]
     need(all(x < P for x in pr), "non-canonical word")
     progs = [Program(a["program"], a["width"]) for a in airs]
     for a, pg in zip(airs, progs):
         need(pg.n_pvs == a["n_pvs"] == len(a["pvs"]), "public values")
-        need(pg.max_degree <= nch + 1, "degree")
+        need(pg.qd <= (1 << b), "degree")
         if pg.prep_width:
             need(a.get("prep_commit") is not None, "missing preprocessed commitment")
     hmax = max(a["log_height"] + b for a in airs)
@@ -193,7 +196,7 @@ def verify(params, airs, proof_words):
     cm = [(i, "main", a["log_height"], a["width"], 2) for i, a in enumerate(airs)]
     cm += [(i, "prep", airs[i]["log_height"], progs[i].prep_width, 2) for i in pp]
     cm += [(i, "perm", airs[i]["log_height"], progs[i].perm_width, 2) for i in lu]
-    cm += [(i, "quot%d" % j, a["log_height"], 4, 1) for i, a in enumerate(airs) for j in range(nch)]
+    cm += [(i, "quot%d" % j, a["log_height"], 4, 1) for i, a in enumerate(airs) for j in range(progs[i].qd)]
     pos = [0]
 
     def take(n):
@@ -299,7 +302,8 @@ def verify(params, airs, proof_words):
         for c in pg.cons:
             acc = e_add(e_mul(acc, alpha), vals[c])
         lhs = e_mul(acc, e_inv(zh))
-        # the quotient is split over the 2^b cosets s_j * H of the LDE domain; chunk j is opened as 4 base polynomials
+        # the quotient lives on the first qd of the 2^b cosets s_j * H of the LDE domain; chunk j is opened as 4 base polynomials
+        nch = pg.qd
         w_m = m.two_adic_generator(lh + b)
         shifts = [GEN * pow(w_m, m.bitrev(j, b), P) % P for j in range(nch)]
         rhs = ZERO

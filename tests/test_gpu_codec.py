@@ -34,7 +34,9 @@ def test_hip_proof_into_v1_container_and_back(zk, params):
     sh = rp.shape_of(p)
     assert sh["n_airs"] == 5 and sh["n_queries"] == params[2] and sh["log_degrees"] == [12, 10, 6, 9, 5]
     # batches in the reference's order: preprocessed tree, main, after-challenge (LogUp permutation), quotient chunks
-    assert [len(b["widths"]) for b in sh["batches"]] == [1, 5, 4, 5 << params[0]]
+    n_chunks = [air.quotient_chunks(a["program"]) for a in airs]   # next_pow2(max(degree, 2) - 1) per AIR
+    assert [len(q) for q in p["opened"]["quotient"]] == n_chunks and max(n_chunks) <= (1 << params[0])
+    assert [len(b["widths"]) for b in sh["batches"]] == [1, 5, 4, sum(n_chunks)]
     assert sh["batches"][1]["log_height"] == 12 + params[0]
     s1 = z.proof_decode_v1(v1, z.V1_SINGLE)
     assert s1["log_blowup"] == params[0] and s1["n_preprocessed"] == 1 and s1["n_after_challenge_commits"] == 1

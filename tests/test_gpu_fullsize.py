@@ -94,11 +94,11 @@ def test_three_way_parity_mid_size(zk, ora):
 
 def test_cfg4_full_chunk_proof_bit_exact(zk, ora):
     """cfg #4 at full size: 2^22 x 300 (+ 2^22 x 2), reference FRI parameters (100 queries, PoW 16 + 16): the HIP
-    prover's 1,130,012 proof bytes equal the CPU prover's, and the host verifier accepts them."""
+    prover's 1,128,348 proof bytes equal the CPU prover's, and the host verifier accepts them."""
     params = z.DEFAULT_PARAMS
     sa, airs = _workload(22)
     proof, host, pvs = _prove_on_device(zk, sa, airs, 22, params, seed=1000)
-    assert len(proof) == 1130012
+    assert len(proof) == 1128348
     import torch
 
     torch.cuda.empty_cache()

@@ -176,7 +176,7 @@ def test_full_size_chunk_workload_properties(zk):
             dict(program=fa.program(), log_height=log_n, width=2, n_pvs=3)]
     pk = z.ProvingKey(zk, params, airs)
     proof = pk.prove([d, df], [pv, fpv])
-    assert len(proof) == pk.proof_size == 1130012
+    assert len(proof) == pk.proof_size == 1128348
     assert z.verify(params, airs, [pv, fpv], proof) == 0
     assert pk.prove([d, df], [pv, fpv]) == proof
     # commitment cross-check through zkhip_lde_batch + zkhip_merkle_commit
@@ -290,7 +290,7 @@ def test_single_row_traces(zk, ora):
 
 
 def test_gpu_proofs_match_committed_digests(zk):
-    """The HIP prover against the committed fixture alone (tests/golden/proof_digests_v2.json), no oracle in the loop."""
+    """The HIP prover against the committed fixture alone (tests/golden/proof_digests_v3.json), no oracle in the loop."""
     import hashlib
     import importlib.util
     import json
@@ -300,7 +300,7 @@ def test_gpu_proofs_match_committed_digests(zk):
     spec = importlib.util.spec_from_file_location("gen_proof_digests", os.path.join(here, "gen_proof_digests.py"))
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
-    want = json.load(open(os.path.join(here, "proof_digests_v2.json")))
+    want = json.load(open(os.path.join(here, "proof_digests_v3.json")))
     for name, (params, airs) in gen.cases().items():
         got, _, _ = _prove_gpu(zk, params, airs)
         assert len(got) == 4 * want[name]["words"], name

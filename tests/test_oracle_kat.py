@@ -139,7 +139,7 @@ def test_fri_fold(ora, kat):
 
 
 def test_proof_digests_are_stable(ora):
-    """The oracle's proof bytes for a fixed set of small AIR sets (tests/golden/proof_digests_v2.json)."""
+    """The oracle's proof bytes for a fixed set of small AIR sets (tests/golden/proof_digests_v3.json)."""
     import importlib.util
     import json
     import os
@@ -148,6 +148,6 @@ def test_proof_digests_are_stable(ora):
     spec = importlib.util.spec_from_file_location("gen_proof_digests", os.path.join(here, "gen_proof_digests.py"))
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
-    want = json.load(open(os.path.join(here, "proof_digests_v2.json")))
+    want = json.load(open(os.path.join(here, "proof_digests_v3.json")))
     got = gen.digests(ora)
     assert got == want

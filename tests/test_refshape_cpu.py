@@ -1,7 +1,7 @@
 """An AIR set with the dimensions of the chunk proof the reference stores (air.ReferenceShapedSet: 17 AIRs, cached main, two
 preprocessed traces, the reference's after-challenge widths), heights shrunk for the CPU: the oracle proves it, the host
 verifier accepts it, and converted into the reference's v1 container the proof has the reference proof's own STRUCTURE --
-every vector length a decoder meets, batch by batch -- up to the heights and the documented quotient-chunk count."""
+every vector length a decoder meets, batch by batch -- up to the heights."""
 import json
 import os
 import sys
@@ -53,9 +53,8 @@ def check_against_reference_shape(shape, shrink):
     # preprocessed (2 trees), cached main, common main, after-challenge: the same matrices of the same widths in the same order
     for g, e in zip(got[:5], exp[:5]):
         assert g["widths"] == e["widths"]
-    # quotient: width-4 chunk matrices; 2^log_blowup per AIR here, next_pow2(max_degree - 1) per AIR in the reference's engine
-    assert set(got[5]["widths"]) == set(exp[5]["widths"]) == {4}
-    assert len(got[5]["widths"]) == 17 * 4 and len(exp[5]["widths"]) == 62
+    # quotient: 62 width-4 chunk matrices (next_pow2(max_degree - 1) per AIR: 1 + 15 x 4 + 1)
+    assert got[5]["widths"] == exp[5]["widths"] == [4] * 62
 
 
 def test_reference_shaped_set_oracle_to_v1(ora):
@@ -70,6 +69,7 @@ def test_reference_shaped_set_oracle_to_v1(ora):
     p = rp.decode_proofs((1).to_bytes(8, "little") + v1)[0]
     assert rp.encode_proofs([p])[8:] == v1
     check_against_reference_shape(rp.shape_of(p), SHRINK)
+    assert [len(q) for q in p["opened"]["quotient"]] == [1] + [4] * 15 + [1]   # chunks per AIR, as in the stored proof
     assert len(p["main_trace"]) == 2 and len(p["opened"]["preprocessed"]) == 2   # [cached, common]; two preprocessed AIRs
     back, pvs_back = z.proof_from_v1(PARAMS, vk, v1)
     assert back == proof

@@ -293,6 +293,32 @@ def with_cached_width(program, cached_width):
     return np.array(w[:pos] + [CACHED_MAGIC, cached_width] + w[pos:], dtype=np.uint32)
 
 
+def quotient_chunks(program):
+    """Number of quotient chunk matrices of an AIR program: next_pow2(max(constraint degree, 2) - 1), the rule of the
+    reference's engine (its stored v1 proofs have 1 or 4 chunks per AIR at blow-up 4).  Degrees in units of the trace length:
+    trace / permutation / preprocessed cells, is_first, is_last 1; is_transition, constants, public values, challenges 0."""
+    w = [int(x) for x in program]
+    n_nodes, n_cons = w[1], w[2]
+    deg = []
+    for i in range(n_nodes):
+        op, a, b = w[4 + 3 * i: 7 + 3 * i]
+        if op in (OP_VAR, OP_PERM, OP_PREP, OP_FIRST, OP_LAST):
+            deg.append(1)
+        elif op in (OP_ADD, OP_SUB):
+            deg.append(max(deg[a], deg[b]))
+        elif op == OP_MUL:
+            deg.append(deg[a] + deg[b])
+        elif op == OP_NEG:
+            deg.append(deg[a])
+        else:
+            deg.append(0)
+    d = max([deg[c] for c in w[4 + 3 * n_nodes: 4 + 3 * n_nodes + n_cons]], default=0)
+    qd = 1
+    while qd + 1 < max(d, 2):
+        qd *= 2
+    return qd
+
+
 # ---- reference evaluation of a program on a trace (numpy; host-side witness sanity check) ----
 def check_trace(program, trace, pvs, prep=None):
     """trace: [width, n] canonical uint32 (prep: [prep_width, n] or None).  Returns the list of violated
@@ -373,10 +399,12 @@ class SyntheticAir:
     plus booleanity constraints b*(b-1) on the first free columns and first-/last-row boundary
     constraints against public values.  Deterministic in `seed`."""
 
-    def __init__(self, width=300, n_free=60, n_bool=16, n_boundary=8, seed=0):
-        assert 4 <= n_free < width and n_bool <= n_free
+    def __init__(self, width=300, n_free=60, n_bool=16, n_boundary=8, seed=0, degree=3):
+        """degree=5: the local definitions read c1*x*y*z*u*v + c2*u*v + c3 (constraint degree 5: four quotient chunks, what
+        most chips of the reference's stored proofs have at blow-up 4)."""
+        assert 4 <= n_free < width and n_bool <= n_free and degree in (3, 5)
         rng = np.random.default_rng(seed)
-        self.width, self.n_free, self.n_bool = width, n_free, n_bool
+        self.width, self.n_free, self.n_bool, self.degree = width, n_free, n_bool, degree
         self.defs = []  # per derived column: (kind, cols..., coeffs...)
         n_trans = 0
         for j in range(n_free, width):
@@ -399,7 +427,8 @@ class SyntheticAir:
         for j, (kind, cols, coef) in zip(range(n_free, width), self.defs):
             if kind == "local":
                 x, y, z, u, v = (b.var(c) for c in cols)
-                b.assert_zero(b.var(j) - (b.const(coef[0]) * x * y * z + b.const(coef[1]) * u * v + coef[2]))
+                top = x * y * z * u * v if degree == 5 else x * y * z
+                b.assert_zero(b.var(j) - (b.const(coef[0]) * top + b.const(coef[1]) * u * v + coef[2]))
             else:
                 x, y, u = (b.var(c) for c in cols)
                 b.when_transition(b.next(j) - (b.const(coef[0]) * x * y + b.const(coef[1]) * u + coef[2]))
@@ -440,7 +469,10 @@ class SyntheticAir:
         for j, (kind, cols, coef) in zip(range(self.n_free, self.width), self.defs):
             if kind == "local":
                 x, y, z, u, v = (tr[c] for c in cols)
-                tr[j] = (coef[0] * (x * y % P * z % P) % P + coef[1] * (u * v % P) % P + coef[2]) % P
+                top = x * y % P * z % P
+                if self.degree == 5:
+                    top = top * u % P * v % P
+                tr[j] = (coef[0] * top % P + coef[1] * (u * v % P) % P + coef[2]) % P
             else:
                 x, y, u = (tr[c] for c in cols)
                 nxt = (coef[0] * (x * y % P) % P + coef[1] * u % P + coef[2]) % P
@@ -747,9 +779,10 @@ class ReferenceShapedSet:
     widths 1 .. 398, one cached main partition of width 9 (the program chip), two preprocessed traces (widths 1 and 2), and as
     many interactions per AIR as give the reference's after-challenge widths (two interactions share a permutation column group,
     so an after-challenge matrix of 4 * (g + 1) base columns takes g send / receive pairs).  The chips' CONSTRAINTS are
-    synthetic (SyntheticAir); what is real is every dimension a prover's cost depends on.  `shrink` subtracts from every
-    log-height (tests).  Quotient: this prover splits every AIR's quotient into 2^log_blowup chunks (68 matrices at blow-up 4),
-    the reference's engine into next_pow2(max_degree - 1) per AIR (62 in that proof)."""
+    synthetic (SyntheticAir with degree-5 definitions: four quotient chunks per AIR, as in the stored proof); the first AIR
+    is program-chip-like (nine cached columns received on a bus with the frequency column as multiplicity, degree 2: one
+    chunk) and the last a preprocessed tuple table (one chunk): 62 quotient matrices in all, the stored proof's count.
+    What is real is every dimension a prover's cost depends on.  `shrink` subtracts from every log-height (tests)."""
 
     LOG_DEGREES = [17, 1, 6, 18, 19, 18, 13, 17, 19, 18, 21, 17, 18, 17, 19, 15, 18]
     MAIN_WIDTHS = [1, 5, 23, 12, 11, 13, 17, 398, 27, 38, 29, 12, 23, 27, 21, 6, 1]
@@ -769,8 +802,15 @@ class ReferenceShapedSet:
                 self.table_sizes = (1 << (lh // 2), 1 << (lh - lh // 2))
                 self.chips.append(range_tuple_table_air(self.table_sizes[0], self.table_sizes[1], bus=self.TABLE_BUS))
                 continue
+            if i == 0:
+                # program chip: the cached partition holds the program, the common column its execution frequencies
+                b = AirBuilder(w + self.CACHED[0], 0, cached_width=self.CACHED[0])
+                b.push_interaction(100, [b.var(c) for c in range(self.CACHED[0])], b.var(self.CACHED[0]), "receive")
+                b.width_total = w + self.CACHED[0]
+                self.chips.append(b)
+                continue
             width = w + self.CACHED.get(i, 0)
-            sa = SyntheticAir(width=width, n_free=max(4, width // 3), n_bool=2, n_boundary=1, seed=seed * 1000 + i)
+            sa = SyntheticAir(width=width, n_free=max(4, width // 3), n_bool=2, n_boundary=1, seed=seed * 1000 + i, degree=5)
             b = sa.builder
             b.cached_width = self.CACHED.get(i, 0)
             if i in self.PREP:
@@ -793,6 +833,12 @@ class ReferenceShapedSet:
         for i, (chip, h) in enumerate(zip(self.chips, self.heights)):
             if i == self.TABLE:
                 airs.append(None)
+                continue
+            if i == 0:
+                # nothing sends on the program bus here: every frequency is zero (the bus balances trivially)
+                tr = np.random.default_rng(seed * 7919).integers(0, P, size=(chip.width_total, 1 << h)).astype(np.uint32)
+                tr[chip.width_total - 1] = 0
+                airs.append(dict(program=chip.program(), log_height=h, width=chip.width_total, n_pvs=0, trace=tr, pvs=np.zeros(0, np.uint32)))
                 continue
             tr, pv = chip.gen_trace(h, seed=seed * 7919 + i)
             a = dict(program=chip.program(), log_height=h, width=chip.width, n_pvs=len(pv), trace=tr, pvs=pv)

@@ -48,6 +48,14 @@ struct AirProgram {
     const uint32_t* nodes = nullptr;  // 3 words each
     const uint32_t* cons = nullptr;
     unsigned max_degree = 0;
+    // quotient chunks = 2^log_qd: the quotient of degree-d constraints has degree < (d - 1) N (the reference engine's rule;
+    // its stored v1 proofs have 1 or 4 chunks per AIR at blow-up 4)
+    unsigned log_qd() const {
+        unsigned l = 0;
+        while ((1u << l) + 1u < (max_degree < 2u ? 2u : max_degree)) l++;
+        return l;
+    }
+    unsigned qd() const { return 1u << log_qd(); }
     std::vector<Interaction> ints;
     size_t prep_width = 0;
     size_t cached_width = 0;  // leading main columns committed in a tree of their own (OpenVM-v1 cached main)

@@ -57,14 +57,14 @@ void summarize(const std::vector<cd::ProofV1>& ps, zkhip_v1_summary* s) {
 // the committed matrices of a zkhip proof, in ITS opening order: main (every AIR), preprocessed, permutation, quotient chunks
 struct Shape {
     std::vector<AirProgram> pg;
-    unsigned b = 0, nch = 0, lfp = 0, hmax = 0, n_layers = 0;
+    unsigned b = 0, lfp = 0, hmax = 0, n_layers = 0;  // AIR a has pg[a].qd() quotient chunks
     size_t n_airs = 0, n_lu = 0, n_prep = 0, n_cached = 0, n_open = 0, n_fin = 0;
     unsigned main_h = 0, perm_h = 0;
 };
 
 int shape_of(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, Shape* s) {
     if (!prm || !airs || n_airs == 0) return ZKHIP_ERR_INVALID;
-    s->b = prm->log_blowup, s->nch = 1u << s->b, s->lfp = prm->log_final_poly_len;
+    s->b = prm->log_blowup, s->lfp = prm->log_final_poly_len;
     if (s->lfp > ZKHIP_MAX_LOG_FINAL_POLY || s->b < 1 || s->b > 4) return ZKHIP_ERR_INVALID;
     s->n_airs = n_airs;
     s->n_fin = (size_t)1 << s->lfp;
@@ -74,7 +74,8 @@ int shape_of(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, Shap
         if (airs[a].log_height + s->b > 27 || airs[a].log_height < s->lfp) return ZKHIP_ERR_INVALID;
         const unsigned h = airs[a].log_height + s->b;
         s->hmax = std::max(s->hmax, h);
-        s->n_open += 2 * airs[a].width + 4 * (size_t)s->nch;
+        if (s->pg[a].log_qd() > s->b) return ZKHIP_ERR_CONSTRAINT;
+        s->n_open += 2 * airs[a].width + 4 * (size_t)s->pg[a].qd();
         if (s->pg[a].prep_width) s->n_prep++, s->n_open += 2 * s->pg[a].prep_width;
         if (s->pg[a].cached_width) s->n_cached++;
         if (!s->pg[a].ints.empty()) s->n_lu++, s->perm_h = std::max(s->perm_h, h), s->n_open += 2 * s->pg[a].perm_width();
@@ -200,7 +201,7 @@ extern "C" int zkhip_proof_to_v1(const zkhip_params* prm, const zkhip_air* airs,
             }
         p.values.quotient.resize(n_airs);
         for (size_t a = 0; a < n_airs; a++)
-            for (unsigned j = 0; j < s.nch; j++) p.values.quotient[a].push_back(take(4));
+            for (unsigned j = 0; j < s.pg[a].qd(); j++) p.values.quotient[a].push_back(take(4));
         // FRI
         for (size_t l = 0; l < s.n_layers; l++) {
             p.fri.commit_phase_commits.push_back(digest_m(&w[lay.fri_layers + 9 * l]));
@@ -245,7 +246,7 @@ extern "C" int zkhip_proof_to_v1(const zkhip_params* prm, const zkhip_air* airs,
                 bperm.opening_proof = path(s.perm_h);
             }
             for (size_t a = 0; a < n_airs; a++)
-                for (unsigned j = 0; j < s.nch; j++) bquot.opened_values.push_back(rows(4));
+                for (unsigned j = 0; j < s.pg[a].qd(); j++) bquot.opened_values.push_back(rows(4));
             bquot.opening_proof = path(s.main_h);
             auto& q = p.fri.query_proofs[qi];
             for (auto& bp : bprep) q.input_proof.push_back(std::move(bp));  // v1 order: preprocessed, main (cached..., common), after-challenge, quotient
@@ -342,7 +343,7 @@ extern "C" int zkhip_proof_from_v1(const zkhip_params* prm, const zkhip_air* air
                 if (!s.pg[a].ints.empty() && !put_adj(p.values.after_challenge[0][k++], s.pg[a].perm_width())) return ZKHIP_ERR_VERIFY;
         }
         for (size_t a = 0; a < n_airs; a++) {
-            if (p.values.quotient[a].size() != s.nch) return ZKHIP_ERR_VERIFY;
+            if (p.values.quotient[a].size() != s.pg[a].qd()) return ZKHIP_ERR_VERIFY;
             for (const auto& c : p.values.quotient[a]) {
                 if (c.size() != 4) return ZKHIP_ERR_VERIFY;
                 for (const auto& e : c) put_canon(w, e.data(), 4);
@@ -370,7 +371,7 @@ extern "C" int zkhip_proof_from_v1(const zkhip_params* prm, const zkhip_air* air
             for (size_t a = 0; a < n_airs; a++) {
                 wmain.push_back(airs[a].width - s.pg[a].cached_width);
                 if (!s.pg[a].ints.empty()) wperm.push_back(s.pg[a].perm_width());
-                for (unsigned j = 0; j < s.nch; j++) wquot.push_back(4);
+                for (unsigned j = 0; j < s.pg[a].qd(); j++) wquot.push_back(4);
             }
             if (!put_batch(q.input_proof[s.n_prep + s.n_cached], wmain, s.main_h)) return ZKHIP_ERR_VERIFY;
             size_t k = 0;

@@ -61,6 +61,7 @@ struct QuotArgs {
     uint32_t gen;           // coset shift (Montgomery)
     uint32_t w_n_inv;       // w_N^-1
     unsigned lh, b;
+    uint32_t n_rows;        // rows to evaluate: the first N * (quotient chunks) of the M LDE rows (M for the stage-level entry)
 };
 // every chip that runs the interpreter, in ONE launch: descriptor array + block prefix table (the twiddle table belongs
 // to the context, not to the key, so it is a launch parameter)
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(QBS) void k_quotient(QuotMulti m) {
     const unsigned h = a.lh + a.b;
     const size_t M = (size_t)1 << h;
     const uint32_t r = (blockIdx.x - m.first[chip]) * QBS + tid;
-    if (r >= M) return;
+    if (r >= a.n_rows) return;
     const uint32_t i = bitrev32(r, h);
     const uint32_t rn = bitrev32((i + (1u << a.b)) & (uint32_t)(M - 1), h);
     const uint32_t x = mmul(a.gen, root_pow(m.tw_fwd, m.tw_log - h, h, i));
@@ -744,6 +745,9 @@ using namespace zk;
 struct AirPlan {
     unsigned lh = 0, h = 0;
     size_t width = 0, n_pvs = 0, N = 0, M = 0;
+    unsigned nq = 1;   // quotient chunks (AirProgram::qd()); the quotient is evaluated on the first MQ = N * nq rows of the LDE
+    size_t MQ = 0;
+    size_t quot_first = 0;  // rank of chunk 0 among the quotient matrices of the proof
     AirProgram prog;
     std::vector<uint32_t> program_words;
     uint32_t digest[8];  // sponge of the bytecode, canonical
@@ -757,8 +761,8 @@ struct AirPlan {
     uint32_t* d_pvs = nullptr;     // n_pvs (Montgomery), refreshed per proof
     uint32_t* d_lde = nullptr;     // width columns x M
     uint32_t* d_q = nullptr;       // 4 columns x M (quotient values, bit-reversed LDE order)
-    uint32_t* d_qnat = nullptr;    // 2^b chunks x 4 columns x N (natural order)
-    uint32_t* d_qlde = nullptr;    // 2^b chunks x 4 columns x M
+    uint32_t* d_qnat = nullptr;    // nq chunks x 4 columns x N (natural order)
+    uint32_t* d_qlde = nullptr;    // nq chunks x 4 columns x M
     uint32_t* d_apow_q = nullptr;  // n_cons ext
     size_t opened_main_off = 0, opened_perm_off = 0, opened_quot_off = 0;  // in ext units inside d_opened
     // LogUp phase (AIRs with bus interactions)
@@ -790,7 +794,8 @@ struct AirPlan {
 
 struct zkhip_pk {
     zkhip_params params;
-    unsigned b = 1, nch = 2, hmax = 0, n_layers = 0, lfp = 0;
+    unsigned b = 1, nch = 2, hmax = 0, n_layers = 0, lfp = 0;  // nch = 2^b cosets of the LDE (AIR a uses the first airs[a].nq of them for its quotient)
+    size_t n_quot = 0;                                            // quotient matrices of a proof = sum of nq
     std::vector<AirPlan> airs;
     std::vector<uint32_t> preamble;  // canonical words observed before anything else (pvs patched in)
     std::vector<size_t> preamble_pv_off, preamble_prep_off;
@@ -953,7 +958,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             delete pk;
             return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + ": " + (err.empty() ? "n_pvs mismatch" : err));
         }
-        if (A.prog.max_degree > (1u << pk->b) + 1) {
+        if (A.prog.log_qd() > pk->b) {
             delete pk;
             return set_error(ctx, ZKHIP_ERR_CONSTRAINT, "constraint degree exceeds 2^log_blowup + 1");
         }
@@ -963,6 +968,10 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         A.n_pvs = airs[a].n_pvs;
         A.N = (size_t)1 << A.lh;
         A.M = (size_t)1 << A.h;
+        A.nq = A.prog.qd();
+        A.MQ = A.N * A.nq;
+        A.quot_first = pk->n_quot;
+        pk->n_quot += A.nq;
         pk->hmax = std::max(pk->hmax, A.h);
         max_n = std::max(max_n, A.N);
         max_w = std::max(max_w, A.width);
@@ -1019,7 +1028,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     }
     for (size_t a = 0; a < n_airs; a++) {
         pk->airs[a].opened_quot_off = n_open;
-        n_open += 4 * (size_t)pk->nch;
+        n_open += 4 * (size_t)pk->airs[a].nq;
     }
     pk->n_open = n_open;
     // preamble
@@ -1069,7 +1078,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             if (pk->airs[a].prep_w) pk->q_prep_words += pk->airs[a].prep_w + 8 * (size_t)pk->airs[a].h;
         }
         pk->q_perm_words = pk->n_lu ? tw_perm + 8 * (size_t)pk->h_perm : 0;
-        pk->q_quot_words = 4 * (size_t)pk->nch * n_airs + 8 * (size_t)pk->hmax;
+        pk->q_quot_words = 4 * pk->n_quot + 8 * (size_t)pk->hmax;
         size_t pitch = pk->q_main_words + pk->q_cached_words + pk->q_prep_words + pk->q_perm_words + pk->q_quot_words;
         for (unsigned l = 0; l < pk->n_layers; l++) pitch += 4 + 8 * (size_t)(pk->hmax - l - 1);
         pk->query_pitch = pitch;
@@ -1141,8 +1150,8 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         ao[a].pvs = bp.take(A.n_pvs * 4 + 16);
         ao[a].lde = bp.take(A.M * A.width * 4);
         ao[a].q = bp.take(A.M * 4 * 4);
-        ao[a].qnat = bp.take(A.M * 4 * 4);
-        ao[a].qlde = bp.take((size_t)nch * A.M * 4 * 4);
+        ao[a].qnat = bp.take(A.MQ * 4 * 4);
+        ao[a].qlde = bp.take((size_t)A.nq * A.M * 4 * 4);
         ao[a].apow_q = bp.take((size_t)(A.prog.n_cons + 1) * 16);
         if (A.cw) ao[a].dig_cached = bp.take(merkle_digest_count(A.h) * 32);
         if (A.prep_w) {
@@ -1182,7 +1191,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     }
     const size_t o_quot_args = bp.take((n_airs + 1) * sizeof(QuotArgs)), o_quot_first = bp.take((n_airs + 2) * 4);
     const size_t o_pow_desc = bp.take((n_airs + 1) * sizeof(PowDesc));
-    const size_t o_br_tiled = bp.take((n_airs * nch + 1) * sizeof(BitrevSeg)), o_br_small = bp.take((n_airs * nch + 1) * sizeof(BitrevSeg));
+    const size_t o_br_tiled = bp.take((pk->n_quot + 1) * sizeof(BitrevSeg)), o_br_small = bp.take((pk->n_quot + 1) * sizeof(BitrevSeg));
     const size_t o_lu_den_all = bp.take(lu_den_elems * 16 + 16), o_lu_num_all = bp.take(lu_den_elems * 4 + 16);
     const size_t o_lu_totals = bp.take(lu_tot_elems * 16 + 16), o_lu_args = bp.take((pk->n_lu + 1) * sizeof(LogupArgs));
     const size_t o_lu_rows_first = bp.take((pk->n_lu + 2) * 4), o_lu_den_first = bp.take((pk->n_lu + 2) * 4);
@@ -1208,9 +1217,10 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
                 uint32_t nc = 0;
                 for (size_t a = 0; a < n_airs; a++) {
                     const AirPlan& A = pk->airs[a];
-                    if (A.lh != lh) continue;
+                    if (A.lh != lh || chunk >= (int)A.nq) continue;
                     nc += chunk < 0 ? (uint32_t)(A.width + A.prep_w + A.perm_w) : 4u;
                 }
+                if (!nc) continue;  // no AIR of this height has that many chunks
                 const unsigned n_pts = chunk < 0 ? 2 : 1;
                 pk->open_groups.push_back({lh, n_pts, chunk, first, nc});
                 first += nc;
@@ -1225,7 +1235,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
                 uint32_t nc = 0;
                 for (size_t a = 0; a < n_airs; a++) {
                     const AirPlan& A = pk->airs[a];
-                    if (A.lh != lh) continue;
+                    if (A.lh != lh || kind - 2 >= (int)A.nq) continue;
                     nc += kind == 0 ? (uint32_t)A.width : kind == 1 ? (uint32_t)A.perm_w : 4u;
                 }
                 if (nc) pk->lde_groups.push_back({lh, kind, lfirst, nc});
@@ -1252,7 +1262,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     size_t o_apow_f = bp.take((max_w + 1) * 16);
     pk->max_w = max_w;
     size_t o_ro_inv = bp.take(((size_t)32) << pk->hmax);
-    pk->n_ro_items = (uint32_t)(n_airs + pk->n_cached + pk->n_prep + pk->n_lu + n_airs * nch);
+    pk->n_ro_items = (uint32_t)(n_airs + pk->n_cached + pk->n_prep + pk->n_lu + pk->n_quot);
     size_t o_ro_items = bp.take(pk->n_ro_items * sizeof(RoItem));
     size_t o_ro_slots = bp.take((size_t)pk->n_ro_items * 64);
     std::vector<size_t> o_ro(pk->hmax + 1, (size_t)-1);
@@ -1332,7 +1342,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             pmm.push_back(zkhip_matrix{A.d_perm_lde, A.M, A.h, A.perm_w});
         }
         mm.push_back(zkhip_matrix{A.d_lde + A.cw * A.M, A.M, A.h, A.width - A.cw});  // common part
-        for (unsigned j = 0; j < nch; j++) qm.push_back(zkhip_matrix{A.d_qlde + (size_t)j * 4 * A.M, A.M, A.h, 4});
+        for (unsigned j = 0; j < A.nq; j++) qm.push_back(zkhip_matrix{A.d_qlde + (size_t)j * 4 * A.M, A.M, A.h, 4});
     }
     pk->d_tr = (DevTranscript*)(base + o_tr);
     pk->d_preamble = (uint32_t*)(base + o_pre);
@@ -1398,7 +1408,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             uint32_t c = g.first;
             for (size_t a = 0; a < n_airs; a++) {
                 AirPlan& A = pk->airs[a];
-                if (A.lh != g.lh) continue;
+                if (A.lh != g.lh || g.chunk >= (int)A.nq) continue;
                 auto put = [&](const uint32_t* base_ptr, size_t width, size_t opened_off, bool is_main, size_t col0 = 0) {
                     for (size_t k = 0; k < width; k++, c++) {
                         pk->open_ptrs_host[c] = base_ptr ? base_ptr + k * A.N : nullptr;
@@ -1425,7 +1435,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             uint32_t c = g.first;
             for (size_t a = 0; a < n_airs; a++) {
                 AirPlan& A = pk->airs[a];
-                if (A.lh != g.lh) continue;
+                if (A.lh != g.lh || g.kind - 2 >= (int)A.nq) continue;
                 const size_t w = g.kind == 0 ? A.width : g.kind == 1 ? A.perm_w : 4;
                 for (size_t k = 0; k < w; k++, c++) {
                     const uint32_t idx = (uint32_t)(pk->open_total_cols + c);
@@ -1465,7 +1475,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
                 if (round == 1 && !A.prep_w) continue;
                 if (round == 2 && !A.n_int) continue;
                 if (round == 4 && !A.cw) continue;
-                const unsigned n_mats = round == 3 ? nch : 1;
+                const unsigned n_mats = round == 3 ? A.nq : 1;
                 for (unsigned j = 0; j < n_mats; j++) {
                     HostItem hi;
                     hi.it.width = round == 0   ? (uint32_t)(A.width - A.cw)
@@ -1567,15 +1577,16 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             qa.w_n_inv = minv(two_adic_generator(A.lh));
             qa.lh = A.lh;
             qa.b = pk->b;
+            qa.n_rows = (uint32_t)A.MQ;
             pk->quot_args_host.push_back(qa);
             pows.push_back(PowDesc{A.d_apow_q, A.prog.n_cons, 0});
             if (!A.jit_fn) {
                 interp.push_back(qa);
                 first.push_back(acc);
-                acc += (uint32_t)((A.M + QBS - 1) / QBS);
+                acc += (uint32_t)((A.MQ + QBS - 1) / QBS);
                 pk->quot_max_slots = std::max(pk->quot_max_slots, (uint32_t)A.n_slots);
             }
-            for (unsigned j = 0; j < nch; j++) {
+            for (unsigned j = 0; j < A.nq; j++) {
                 // column k of chunk j starts at q + k*M + j*N and goes to qnat + (4j + k)*N
                 BitrevSeg sg{A.d_q + (size_t)j * A.N, A.d_qnat + (size_t)j * 4 * A.N, A.M, A.N, A.lh, 4, 0, 0};
                 auto& v = A.lh >= 10 ? tiled : small;
@@ -1900,7 +1911,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
                           (void*)&tw_fwd, (void*)&qa.zh,  (void*)&qa.inv_zh,   (void*)&A.d_jit_tab,
                           (void*)&qa.gen, (void*)&qa.w_n_inv, (void*)&tw_shift, (void*)&qa.perm,
                           (void*)&qa.lchal, (void*)&qa.expo, (void*)&qa.prep};
-        ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, (unsigned)((A.M + 255) / 256), 1, 1, 256, 1, 1, 0, st,
+        ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, (unsigned)((A.MQ + 255) / 256), 1, 1, 256, 1, 1, 0, st,
                                                 params, nullptr));
     }
     // chunk j = rows [jN,(j+1)N) of q, bit-reversed within the chunk: bring to natural order (all chips, all chunks: one
@@ -1910,7 +1921,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     for (size_t a = 0; a < n_airs; a++) {
         AirPlan& A = pk->airs[a];
         if (A.lh >= 12) continue;
-        for (unsigned j = 0; j < nch; j++) {
+        for (unsigned j = 0; j < A.nq; j++) {
             uint32_t sj = mmul(gen, host_pow(two_adic_generator(A.h), bitrev32(j, b)));
             ZK_TRY(lde_batch(ctx, A.d_qnat + (size_t)j * 4 * A.N, A.N, A.d_qlde + (size_t)j * 4 * A.M, A.M, A.lh, b, 4, mmul(gen, minv(sj))));
         }
@@ -2127,7 +2138,7 @@ int zkhip_constraint_eval(zkhip_ctx* ctx, const uint32_t* program, size_t progra
     qa.code = (uint32_t*)(base + o_code), qa.n_instr = (uint32_t)(comp.code.size() / 3), qa.consts = (uint32_t*)(base + o_consts);
     qa.pvs = (uint32_t*)(base + o_pvs), qa.apow = (uint32_t*)(base + o_apow), qa.lde = d_lde, qa.q = d_q;
     qa.inv_zh = (uint32_t*)(base + o_izh), qa.zh = (uint32_t*)(base + o_zh), qa.gen = to_monty(FIELD_GEN_CANON);
-    qa.w_n_inv = minv(two_adic_generator(log_height)), qa.lh = log_height, qa.b = b;
+    qa.w_n_inv = minv(two_adic_generator(log_height)), qa.lh = log_height, qa.b = b, qa.n_rows = (uint32_t)M;
     const uint32_t first[2] = {0, (uint32_t)((M + QBS - 1) / QBS)};
     const PowDesc pd{(uint32_t*)(base + o_apow), prog.n_cons, 0};
     ZK_TRY(upload(ctx, base + o_args, &qa, sizeof qa));

@@ -199,9 +199,10 @@ inline bool quot_jit_classify(const AirProgram& p, std::vector<JitClass>* classe
     return true;
 }
 
-inline void quot_jit_prologue(std::ostringstream& os, unsigned lh, unsigned b) {
+inline void quot_jit_prologue(std::ostringstream& os, unsigned lh, unsigned b, unsigned qd) {
     os << quot_jit_preamble();
-    os << "#define H " << (lh + b) << "u\n#define B " << b << "u\n#define M ((size_t)1 << H)\n";
+    // the quotient lives on the first N * qd rows of the LDE (qd = AirProgram::qd() chunks)
+    os << "#define H " << (lh + b) << "u\n#define B " << b << "u\n#define M ((size_t)1 << H)\n#define NQROWS " << ((1u << lh) * qd) << "u\n";
     os << R"JIT(
 extern "C" __global__ __launch_bounds__(256) void quot_jit(const uint32_t* __restrict__ lde, uint32_t* __restrict__ q,
         const uint32_t* __restrict__ pvs, const uint32_t* __restrict__ apow, const uint32_t* __restrict__ tw_fwd,
@@ -209,7 +210,7 @@ extern "C" __global__ __launch_bounds__(256) void quot_jit(const uint32_t* __res
         uint32_t gen, uint32_t w_n_inv, uint32_t tw_shift, const uint32_t* __restrict__ perm,
         const uint32_t* __restrict__ lchal, const uint32_t* __restrict__ expo, const uint32_t* __restrict__ prep) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= (1u << H)) return;
+    if (r >= NQROWS) return;
     const uint32_t i = __brev(r) >> (32 - H);
     const uint32_t rn = __brev((i + (1u << B)) & ((1u << H) - 1u)) >> (32 - H);
     const uint32_t halfm = 1u << (H - 1);
@@ -245,7 +246,7 @@ inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b,
                                    std::vector<uint32_t>* table) {
     (void)p;
     std::ostringstream os;
-    quot_jit_prologue(os, lh, b);
+    quot_jit_prologue(os, lh, b, p.qd());
     for (size_t c = 0; c < classes.size(); c++) {
         JitClass& C = classes[c];
         C.table_off = table->size();
@@ -335,7 +336,7 @@ inline bool quot_jit_source_flat(const AirProgram& p, unsigned lh, unsigned b, s
     std::vector<std::vector<uint32_t>> cons_of(p.n_nodes);
     for (uint32_t k = 0; k < p.n_cons; k++) cons_of[p.cons[k]].push_back(k);
     std::ostringstream os;
-    quot_jit_prologue(os, lh, b);
+    quot_jit_prologue(os, lh, b, p.qd());
     uint32_t max_col = 0;
     for (uint32_t i = 0; i < p.n_nodes; i++) {
         if (!live[i]) continue;

@@ -161,7 +161,7 @@ extern "C" int zkhip_fri_fold_row(uint64_t index, unsigned log_height, const uin
 // verifier (crates/verifier/src/verifier.rs:62) -- here the layout is static, so "decoding" is a table of offsets.
 extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, zkhip_proof_layout* out) {
     if (!prm || !airs || !out || n_airs == 0) return ZKHIP_ERR_INVALID;
-    const unsigned b = prm->log_blowup, nch = 1u << b;
+    const unsigned b = prm->log_blowup;
     const unsigned lfp = prm->log_final_poly_len;
     if (lfp > ZKHIP_MAX_LOG_FINAL_POLY || b < 1 || b > 4) return ZKHIP_ERR_INVALID;
     unsigned hmax = 0;
@@ -177,6 +177,8 @@ extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* a
         main_h = std::max(main_h, h);
         main_w += airs[a].width - pg.cached_width;
         if (pg.cached_width) n_cached++, cached_words += pg.cached_width + 8 * (size_t)h;
+        if (pg.log_qd() > b) return ZKHIP_ERR_CONSTRAINT;
+        const unsigned nch = pg.qd();
         quot_w += 4 * (size_t)nch;
         n_open += 2 * airs[a].width + 4 * (size_t)nch;
         if (pg.prep_width) {
@@ -216,7 +218,7 @@ extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* a
 extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, const uint32_t* const* pvs,
                             const uint8_t* proof_bytes, size_t len) {
     if (!prm || !airs || !proof_bytes || n_airs == 0 || (len & 3)) return ZKHIP_ERR_INVALID;
-    const unsigned b = prm->log_blowup, nch = 1u << b;
+    const unsigned b = prm->log_blowup;
     const unsigned lfp = prm->log_final_poly_len;  // the fold loop stops at 2^(b+lfp) values: a polynomial of degree < 2^lfp
     if (lfp > ZKHIP_MAX_LOG_FINAL_POLY || b < 1 || b > 4) return ZKHIP_ERR_INVALID;
     if (prm->num_queries == 0 || prm->commit_pow_bits > 30 || prm->query_pow_bits > 30) return ZKHIP_ERR_INVALID;  // as zkhip_keygen
@@ -235,7 +237,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         if (parse_air(airs[a].program, airs[a].program_len, airs[a].width, &pg[a], nullptr) != 0) return ZKHIP_ERR_INVALID;
         if (pg[a].cached_width) n_cached++;
         if (pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height + b > 27 || airs[a].log_height < lfp || airs[a].width == 0) return ZKHIP_ERR_INVALID;
-        if (pg[a].max_degree > nch + 1) return ZKHIP_ERR_CONSTRAINT;
+        if (pg[a].log_qd() > b) return ZKHIP_ERR_CONSTRAINT;
         if (airs[a].n_pvs && (!pvs || !pvs[a])) return ZKHIP_ERR_INVALID;
         hmax = std::max(hmax, airs[a].log_height + b);
         if (!pg[a].ints.empty()) n_lu++;
@@ -263,8 +265,10 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     for (size_t a = 0; a < n_airs; a++)
         if (!pg[a].ints.empty()) cm.push_back({airs[a].log_height, airs[a].log_height + b, pg[a].perm_width(), 2, 0});
     for (size_t a = 0; a < n_airs; a++)
-        for (unsigned j = 0; j < nch; j++) cm.push_back({airs[a].log_height, airs[a].log_height + b, 4, 1, 0});
+        for (unsigned j = 0; j < pg[a].qd(); j++) cm.push_back({airs[a].log_height, airs[a].log_height + b, 4, 1, 0});
     const size_t cm_cached0 = n_airs, cm_prep0 = n_airs + n_cached, cm_perm0 = cm_prep0 + n_prep, cm_quot0 = cm_perm0 + n_lu;
+    std::vector<size_t> qoff(n_airs + 1, 0);  // AIR a's chunk j is quotient matrix qoff[a] + j
+    for (size_t a = 0; a < n_airs; a++) qoff[a + 1] = qoff[a] + pg[a].qd();
     size_t n_open = 0;
     for (auto& m : cm) {
         m.open_off = n_open;
@@ -419,6 +423,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         // quotient(zeta) from its chunks
         const uint32_t wM = two_adic_generator(h);
         Ext rhs = ext_zero();
+        const unsigned nch = pg[a].qd();
         for (unsigned j = 0; j < nch; j++) {
             const uint32_t sj = mmul(gen, mpow(wM, bitrev32(j, b)));
             Ext zps = ext_one();
@@ -431,7 +436,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
                 uint32_t den = msub(mpow(mmul(sj, minv(sk)), (uint64_t)1 << lh), MONTY_ONE);
                 zps = ext_mul(zps, ext_mul_base(t, minv(den)));
             }
-            const Ext* chunk = &opened[cm[cm_quot0 + a * nch + j].open_off];
+            const Ext* chunk = &opened[cm[cm_quot0 + qoff[a] + j].open_off];
             Ext v = ext_zero();
             for (int k = 0; k < 4; k++) {
                 Ext e = ext_zero();
@@ -491,7 +496,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
             if (pg[a].prep_width) add_batch(cm_prep0 + k++, 1, airs[a].prep_commit);  // each preprocessed trace has its own tree
     }
     if (n_lu) add_batch(cm_perm0, n_lu, root_perm);
-    add_batch(cm_quot0, n_airs * nch, root_quot);
+    add_batch(cm_quot0, qoff[n_airs], root_quot);
     std::vector<Ext> roq(hmax + 1);
     std::vector<char> has(hmax + 1);
     std::vector<uint64_t> num_reduced(hmax + 1);
