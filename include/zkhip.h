@@ -142,6 +142,22 @@ int zkhip_memory_boundary_tracegen(zkhip_ctx *ctx, const uint32_t *d_addr_space,
                                    const uint32_t *d_final, const uint32_t *d_timestamp, size_t n, unsigned as_bits,
                                    unsigned pointer_bits, unsigned log_height, uint32_t *d_trace);
 
+/* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
+ * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
+ * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the
+ * reference's stored proofs has exactly this shape: cached width 9, common width 1).  From the list of executed instruction
+ * indices (d_pc_index: n plain integers, row numbers of the program):
+ *   zkhip_program_freq_tracegen  the frequency column: 2^log_height Montgomery words, the chip's whole common trace;
+ *   zkhip_exec_frame_tracegen    one row per executed instruction, [9 program fields | is_valid] (ZKHIP_PROGRAM_FIELDS + 1 columns,
+ *                                stride 2^log_height, rows >= n zero), gathered from d_program (9 columns of n_program Montgomery
+ *                                words, column-major: the program chip's cached partition as uploaded) -- the rows that SEND the
+ *                                instruction on the program bus.
+ * ZKHIP_ERR_INVALID if an index is not a row of the program.  AIRs: air.py program_air() / exec_frame_air(). */
+#define ZKHIP_PROGRAM_FIELDS 9
+int zkhip_program_freq_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc_index, size_t n, unsigned log_height, uint32_t *d_freq);
+int zkhip_exec_frame_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc_index, size_t n, const uint32_t *d_program, size_t n_program,
+                              unsigned log_height, uint32_t *d_trace);
+
 /* Trace of an INSTRUCTION chip from execution records: the core of OpenVM's RV32 base ALU chip (rv32im BaseAluCoreAir: ADD, SUB,
  * XOR, OR, AND on 4 x 8-bit limbs; the `rv32i` extension of crates/circuits/chunk-circuit/openvm.toml).  Record i = (d_opcode[i] in
  * 0..4 = add, sub, xor, or, and; d_b[i], d_c[i]: the 32-bit operands) -- plain integers.  Fills d_trace (ZKHIP_RV32_ALU_WIDTH = 18

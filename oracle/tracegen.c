@@ -154,3 +154,32 @@ void ora_rv32_mul_trace(const uint32_t *bs, const uint32_t *cs, size_t n, unsign
         trace[(size_t)12 * N + r] = 1;
     }
 }
+
+/* Program chip / execution frames (zkhip_program_freq_tracegen, zkhip_exec_frame_tracegen): freq[k] = how often instruction k was
+ * executed; frame row r = the 9 program fields of instruction idx[r] and is_valid.  Canonical values.  Returns the number of
+ * indices that are not rows of the program. */
+size_t ora_program_freq_trace(const uint32_t *idx, size_t n, unsigned log_height, uint32_t *freq) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t r = 0; r < N; r++) freq[r] = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (idx[i] >= N) bad++;
+        else freq[idx[i]] = ora_add(freq[idx[i]], 1);
+    }
+    return bad;
+}
+size_t ora_exec_frame_trace(const uint32_t *idx, size_t n, const uint32_t *program, size_t n_program, unsigned log_height, uint32_t *trace) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 10; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        if (idx[r] >= n_program) {
+            bad++;
+            continue;
+        }
+        for (size_t q = 0; q < 9; q++) trace[q * N + r] = program[q * n_program + idx[r]];
+        trace[9 * N + r] = 1;
+    }
+    return bad;
+}

@@ -91,6 +91,28 @@ def rv32_mul_trace(bs, cs, log_height, size_x=256, size_y=8192, tuple_counts=Non
     return tr, tc
 
 
+def program_freq_trace(idx, log_height):
+    idx = np.ascontiguousarray(idx, dtype=np.uint32).reshape(-1)
+    out = np.zeros(1 << log_height, np.uint32)
+    l = lib()
+    l.ora_program_freq_trace.restype = C.c_size_t
+    l.ora_program_freq_trace.argtypes = [u32p_t(), C.c_size_t, C.c_uint, u32p_t()]
+    bad = l.ora_program_freq_trace(p32(idx), idx.size, log_height, p32(out))
+    return out, bad
+
+
+def exec_frame_trace(idx, program, log_height):
+    """program: [9, n_program] canonical; returns ([10, 2^log_height] canonical, bad)"""
+    idx = np.ascontiguousarray(idx, dtype=np.uint32).reshape(-1)
+    prog = np.ascontiguousarray(program, dtype=np.uint32)
+    out = np.zeros((10, 1 << log_height), np.uint32)
+    l = lib()
+    l.ora_exec_frame_trace.restype = C.c_size_t
+    l.ora_exec_frame_trace.argtypes = [u32p_t(), C.c_size_t, u32p_t(), C.c_size_t, C.c_uint, u32p_t()]
+    bad = l.ora_exec_frame_trace(p32(idx), idx.size, p32(prog), prog.shape[1], log_height, p32(out))
+    return out, bad
+
+
 def memory_boundary_trace(as_, ptr, init, fin, ts, as_bits, ptr_bits, log_height):
     as_, ptr, init, fin, ts = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (as_, ptr, init, fin, ts))
     tr = np.zeros((8, 1 << log_height), np.uint32)

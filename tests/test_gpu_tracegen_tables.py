@@ -193,3 +193,50 @@ def test_rv32_mul_chip_with_the_range_tuple_table(zk, ora):
     pk.close()
     with pytest.raises(z.ZkhipError):   # a table that cannot hold the carries
         zk.rv32_mul_tracegen(as_dev(b), as_dev(c), lh, d_tab, 256, 512)
+
+
+def _program(n_program, seed=0):
+    """[9, n_program] canonical: pc = 4 * row, the other fields random."""
+    rng = np.random.default_rng(seed)
+    prog = rng.integers(0, P, size=(air.PROGRAM_FIELDS, n_program)).astype(np.uint32)
+    prog[0] = 4 * np.arange(n_program, dtype=np.uint32)
+    return prog
+
+
+@pytest.mark.parametrize("log_program,log_frames,n", [(3, 4, 11), (10, 12, 4096), (12, 16, 60001), (5, 5, 0)])
+def test_program_chip_and_execution_frames(zk, ora, log_program, log_frames, n):
+    """Program chip (cached program of width 9 + frequency column) and the execution frames that send each executed instruction:
+    both traces generated on the device from the list of executed instruction indices == oracle/tracegen.c; the pair proves from
+    the device-resident traces with the program as a cached main partition, bytes == oracle."""
+    rng = np.random.default_rng(log_frames)
+    n_program = 1 << log_program
+    prog = _program(n_program, seed=log_program)
+    # a skewed execution profile: loops revisit a few instructions
+    idx = (rng.integers(0, n_program, n) * rng.integers(0, 2, n) + rng.integers(0, min(8, n_program), n)) % n_program
+    idx = idx.astype(np.uint32)
+    exp_freq, bad = ora.program_freq_trace(idx, log_program)
+    exp_frames, bad2 = ora.exec_frame_trace(idx, prog, log_frames)
+    assert bad == 0 and bad2 == 0 and int(exp_freq.astype(np.int64).sum()) == n
+    d_idx = torch.from_numpy(idx.astype(np.int32)).cuda()   # plain integers (zk.upload would convert to Montgomery form)
+    d_prog = zk.upload(prog.reshape(-1))            # canonical -> Montgomery on upload: the cached partition as the prover reads it
+    d_freq = zk.program_freq_tracegen(d_idx, log_program)
+    d_frames = zk.exec_frame_tracegen(d_idx, d_prog, n_program, log_frames)
+    assert (zk.download(d_freq) == exp_freq).all()
+    assert (zk.download(d_frames).reshape(10, -1) == exp_frames).all()
+    airs = [dict(program=air.program_air().program(), log_height=log_program, width=10, n_pvs=0,
+                 trace=np.concatenate([prog, exp_freq.reshape(1, -1)]), pvs=NOPV),
+            dict(program=air.exec_frame_air().program(), log_height=log_frames, width=10, n_pvs=0, trace=exp_frames, pvs=NOPV)]
+    assert air.quotient_chunks(airs[0]["program"]) == 1   # degree 2, like the stored proofs' program chip
+    exp = ora.stark_prove(PARAMS, airs).tobytes()
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    d_program_trace = torch.cat([d_prog, d_freq])   # [cached 9 columns | frequency]
+    got = pk.prove([d_program_trace, d_frames], [NOPV, NOPV])
+    assert got == exp and z.verify(PARAMS, pk.verifying_airs(), [NOPV, NOPV], got) == 0
+    lay = z.proof_layout(PARAMS, pk.verifying_airs())
+    assert lay["n_cached"] == 1
+    pk.close()
+    if n:
+        with pytest.raises(z.ZkhipError):
+            zk.program_freq_tracegen(torch.tensor([n_program], dtype=torch.int32, device="cuda"), log_program)
+        with pytest.raises(z.ZkhipError):
+            zk.exec_frame_tracegen(torch.tensor([0, n_program], dtype=torch.int32, device="cuda"), d_prog, n_program, log_frames)

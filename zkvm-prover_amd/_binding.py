@@ -99,6 +99,8 @@ def load_library():
         "zkhip_rv32_alu_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_mul_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_memory_boundary_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint, C.c_uint, vp]),
+        "zkhip_program_freq_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
+        "zkhip_exec_frame_tracegen": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint, vp]),
         "zkhip_merkle_commit": (C.c_int, [vp, C.POINTER(_Matrix), sz, C.POINTER(vp), u32p]),
         "zkhip_tree_root_device": (vp, [vp]),
         "zkhip_tree_log_height": (C.c_uint, [vp]),
@@ -301,6 +303,25 @@ class Context:
         out = torch.empty(13 << log_height, dtype=torch.int32, device=self.device)
         self._check(self.lib.zkhip_rv32_mul_tracegen(self.h, C.c_void_p(t_b.data_ptr()), C.c_void_p(t_c.data_ptr()), t_b.numel(), log_height,
                                                      C.c_void_p(out.data_ptr()), C.c_void_p(t_tuple_counts.data_ptr()), size_x, size_y))
+        return out
+
+    def program_freq_tracegen(self, t_pc_index, log_height):
+        """Frequency column of the program chip (2^log_height Montgomery words) from the executed instruction indices (int32 tensor)."""
+        import torch
+
+        out = torch.empty(1 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_program_freq_tracegen(self.h, C.c_void_p(t_pc_index.data_ptr()), t_pc_index.numel(), log_height,
+                                                         C.c_void_p(out.data_ptr())))
+        return out
+
+    def exec_frame_tracegen(self, t_pc_index, t_program, n_program, log_height):
+        """10-column trace of the execution-frame chip: row i = the 9 fields of instruction t_pc_index[i] (gathered from t_program:
+        9 columns of n_program Montgomery words) and is_valid."""
+        import torch
+
+        out = torch.empty(10 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_exec_frame_tracegen(self.h, C.c_void_p(t_pc_index.data_ptr()), t_pc_index.numel(),
+                                                       C.c_void_p(t_program.data_ptr()), n_program, log_height, C.c_void_p(out.data_ptr())))
         return out
 
     def memory_boundary_tracegen(self, t_as, t_ptr, t_init, t_final, t_ts, as_bits, pointer_bits, log_height):

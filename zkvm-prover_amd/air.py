@@ -706,6 +706,29 @@ def rv32_mul_core_air(bus=6):
     return b
 
 
+PROGRAM_FIELDS = 9
+PROGRAM_BUS = 8
+
+
+def program_air(bus=PROGRAM_BUS):
+    """OpenVM ProgramAir: the program (pc, opcode, operands a..g) is a CACHED main partition of width 9, the common main is the
+    execution-frequency column; every instruction is received `frequency` times on the program bus.  Degree 2: one quotient chunk
+    (the first AIR of the reference's stored proofs: cached width 9, common width 1, after-challenge width 8, one chunk)."""
+    b = AirBuilder(PROGRAM_FIELDS + 1, 0, cached_width=PROGRAM_FIELDS)
+    b.push_interaction(bus, [b.var(c) for c in range(PROGRAM_FIELDS)], b.var(PROGRAM_FIELDS), "receive")
+    return b
+
+
+def exec_frame_air(bus=PROGRAM_BUS):
+    """One row per executed instruction: its nine program fields and is_valid; a valid row sends the instruction on the program
+    bus (in OpenVM every instruction chip's adapter does; this stand-alone chip keeps the pair self-contained)."""
+    b = AirBuilder(PROGRAM_FIELDS + 1, 0)
+    ok = b.var(PROGRAM_FIELDS)
+    b.assert_zero(ok * (ok - 1))
+    b.push_interaction(bus, [b.var(c) for c in range(PROGRAM_FIELDS)], ok, "send")
+    return b
+
+
 MEMORY_BOUNDARY_WIDTH = 8
 
 

@@ -311,3 +311,67 @@ extern "C" int zkhip_rv32_mul_tracegen(zkhip_ctx* ctx, const uint32_t* d_b, cons
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
 }
+
+// ---- system chips: the program chip and the execution frames that look instructions up in it ----------------------------------
+// OpenVM's ProgramAir keeps the program (pc, opcode, operands a..g: 9 fields per instruction) as a CACHED main partition -- its
+// commitment is part of the verifying key's identity and is reused by every segment proof -- and one common column, the number
+// of times each instruction was executed; it RECEIVES each instruction that often on the program bus.  The reference's stored
+// proofs have exactly this shape for their first AIR (cached width 9, common width 1).  The execution side here is one row
+// per executed instruction that SENDS the instruction's nine fields (in OpenVM every instruction chip's adapter does that; a
+// stand-alone frame chip keeps the pair self-contained).  From the list of executed instruction indices:
+//   k_program_freq  : histogram -> the frequency column (the program chip's whole common trace)
+//   k_exec_frames   : gather    -> frame rows [9 program fields | is_valid]
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_program_freq(const uint32_t* __restrict__ idx, size_t n, size_t N, uint32_t* __restrict__ freq,
+                                                      uint32_t* __restrict__ bad) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = idx[i];
+    if (k >= N) atomicAdd(bad, 1u);
+    else atomicAdd(&freq[k], 1u);
+}
+__global__ __launch_bounds__(256) void k_exec_frames(const uint32_t* __restrict__ idx, size_t n, const uint32_t* __restrict__ program,
+                                                     size_t n_program, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t k = 0;
+    const bool valid = r < n && (k = idx[r]) < n_program;
+    if (r < n && !valid) atomicAdd(bad, 1u);
+#pragma unroll
+    for (int q = 0; q < ZKHIP_PROGRAM_FIELDS; q++) trace[(size_t)q * N + r] = valid ? program[(size_t)q * n_program + k] : 0u;
+    trace[(size_t)ZKHIP_PROGRAM_FIELDS * N + r] = valid ? MONTY_ONE : 0u;
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_program_freq_tracegen(zkhip_ctx* ctx, const uint32_t* d_pc_index, size_t n, unsigned log_height, uint32_t* d_freq) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_freq || log_height > 27 || (n && !d_pc_index)) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "program_freq_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(d_freq, 0, N * 4, ctx->stream));
+    if (n) hipLaunchKernelGGL(k_program_freq, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_pc_index, n, N, d_freq, (uint32_t*)flag);
+    hipLaunchKernelGGL(k_tab_repr, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_freq, N, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "program_freq_tracegen (instruction index beyond the program)");
+}
+
+extern "C" int zkhip_exec_frame_tracegen(zkhip_ctx* ctx, const uint32_t* d_pc_index, size_t n, const uint32_t* d_program, size_t n_program,
+                                         unsigned log_height, uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_program || log_height > 27 || (n && !d_pc_index)) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "exec_frame_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "exec_frame_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_exec_frames, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_pc_index, n, d_program, n_program, N, d_trace,
+                       (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "exec_frame_tracegen (instruction index beyond the program)");
+}
