@@ -142,6 +142,15 @@ int zkhip_memory_boundary_tracegen(zkhip_ctx *ctx, const uint32_t *d_addr_space,
                                    const uint32_t *d_final, const uint32_t *d_timestamp, size_t n, unsigned as_bits,
                                    unsigned pointer_bits, unsigned log_height, uint32_t *d_trace);
 
+/* RV32 less-than core (rv32im LessThanCoreAir<4, 8>: SLT / SLTU).  Record i = (d_opcode[i]: 0 = SLT signed, 1 = SLTU unsigned;
+ * d_b[i], d_c[i]) -- plain integers.  Fills d_trace (ZKHIP_RV32_LT_WIDTH = 18 columns, stride 2^log_height, Montgomery:
+ * b[4] | c[4] | cmp | is_slt is_sltu | b_msb_f c_msb_f | marker[4] | diff_val; rows >= n zero) and adds the row's two RANGE
+ * requests -- (b_msb_f + 128 is_slt, c_msb_f + 128 is_slt) and, when the operands differ, (diff_val - 1, 0) -- to the range column
+ * (column 0) of d_bitwise_trace, the 2 x 2^16 trace of the 8-bit bitwise-operation lookup table.  AIR: air.py rv32_lt_core_air(). */
+#define ZKHIP_RV32_LT_WIDTH 18
+int zkhip_rv32_lt_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_b, const uint32_t *d_c, size_t n,
+                           unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

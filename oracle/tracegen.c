@@ -183,3 +183,47 @@ size_t ora_exec_frame_trace(const uint32_t *idx, size_t n, const uint32_t *progr
     }
     return bad;
 }
+
+/* RV32 less-than core (zkhip_rv32_lt_tracegen): 18 columns b[4] | c[4] | cmp | is_slt is_sltu | b_msb_f c_msb_f | marker[4] | diff_val,
+ * canonical; range_counts[(x << 8) | y] (+)= 1 for the row's range requests.  Returns the number of records with opcode > 1. */
+size_t ora_rv32_lt_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace,
+                         uint32_t *range_counts) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 18; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t op = opc[r];
+        if (op > 1) {
+            bad++;
+            continue;
+        }
+        long bl[4], cl[4];
+        for (int i = 0; i < 4; i++) bl[i] = (bs[r] >> (8 * i)) & 255u, cl[i] = (cs[r] >> (8 * i)) & 255u;
+        const int is_slt = op == 0;
+        /* the operands as integers, most significant limb signed for SLT */
+        const long bm = is_slt && bl[3] >= 128 ? bl[3] - 256 : bl[3], cm = is_slt && cl[3] >= 128 ? cl[3] - 256 : cl[3];
+        long bv = bm, cv = cm;
+        for (int i = 2; i >= 0; i--) bv = bv * 256 + bl[i], cv = cv * 256 + cl[i];
+        int mark = -1;
+        for (int i = 3; i >= 0 && mark < 0; i--)
+            if ((i == 3 ? bm : bl[i]) != (i == 3 ? cm : cl[i])) mark = i;
+        for (int i = 0; i < 4; i++) trace[(size_t)i * N + r] = (uint32_t)bl[i], trace[(size_t)(4 + i) * N + r] = (uint32_t)cl[i];
+        trace[(size_t)8 * N + r] = bv < cv;
+        trace[(size_t)(9 + op) * N + r] = 1;
+        trace[(size_t)11 * N + r] = (uint32_t)(bm < 0 ? (long)ORA_P + bm : bm);
+        trace[(size_t)12 * N + r] = (uint32_t)(cm < 0 ? (long)ORA_P + cm : cm);
+        const long sh = is_slt ? 128 : 0;
+        uint32_t *t = &range_counts[((bm + sh) << 8) | (cm + sh)];
+        *t = ora_add(*t, 1);
+        if (mark >= 0) {
+            long d = (mark == 3 ? cm - bm : cl[mark] - bl[mark]);
+            if (d < 0) d = -d;
+            trace[(size_t)(13 + mark) * N + r] = 1;
+            trace[(size_t)17 * N + r] = (uint32_t)d;
+            t = &range_counts[(d - 1) << 8];
+            *t = ora_add(*t, 1);
+        }
+    }
+    return bad;
+}

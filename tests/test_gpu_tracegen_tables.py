@@ -240,3 +240,53 @@ def test_program_chip_and_execution_frames(zk, ora, log_program, log_frames, n):
             zk.program_freq_tracegen(torch.tensor([n_program], dtype=torch.int32, device="cuda"), log_program)
         with pytest.raises(z.ZkhipError):
             zk.exec_frame_tracegen(torch.tensor([0, n_program], dtype=torch.int32, device="cuda"), d_prog, n_program, log_frames)
+
+
+def test_rv32_less_than_chip(zk, ora):
+    """RV32 less-than core (SLT / SLTU, OpenVM LessThanCoreAir<4, 8>) filled on the device from execution records, its range
+    requests counted into the bitwise lookup table's range column in the same pass: cells == oracle, cmp == the integers'
+    comparison, the oracle's trace satisfies the AIR, and chip + table prove from the device-resident traces (bytes == oracle)."""
+    rng = np.random.default_rng(13)
+    n, lh = 6000, 13
+    opc = rng.integers(0, 2, n).astype(np.uint32)
+    b = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    c = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    b[:8] = [0, 5, 0x80000000, 0x7FFFFFFF, 0xFFFFFFFF, 0x80000000, 7, 0x12345678]
+    c[:8] = [0, 5, 0x7FFFFFFF, 0x80000000, 0, 0x80000001, 7, 0x12345679]
+    c[100:200] = b[100:200]                 # equal operands: no marker, cmp = 0
+    c[200:300] = b[200:300] ^ 0x100         # first difference in limb 1
+    c[300:400] = b[300:400] ^ 0x80000000    # sign flips
+    exp, rc, bad = ora.rv32_lt_trace(opc, b, c, lh)
+    assert bad == 0
+    want = np.where(opc == 0, b.view(np.int32) < c.view(np.int32), b < c).astype(np.uint32)
+    assert (exp[8][:n] == want).all()
+    prog = air.rv32_lt_core_air().program()
+    assert air.check_trace(prog, exp, NOPV) == []
+    dev = zk.device
+    as_dev = lambda v: torch.from_numpy(v.view(np.int32)).to(dev)  # noqa: E731
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=dev)
+    d_lt = zk.rv32_lt_tracegen(as_dev(opc), as_dev(b), as_dev(c), lh, d_bw)
+    assert (zk.download(d_lt).reshape(18, -1) == exp).all()
+    bw = zk.download(d_bw).reshape(2, -1)
+    assert (bw[0] == rc).all() and (bw[1] == 0).all() and int(rc.astype(np.int64).sum()) == n + int((b != c).sum())
+    with pytest.raises(z.ZkhipError):
+        zk.rv32_lt_tracegen(as_dev(np.array([2], np.uint32)), as_dev(b[:1]), as_dev(c[:1]), 0, d_bw)
+    # a cheating witness (cmp flipped on one row) violates the AIR
+    bad_tr = exp.copy()
+    bad_tr[8][3] ^= 1
+    assert air.check_trace(prog, bad_tr, NOPV) != []
+    # the ALU chip counts into the XOR column of the same table: both instruction chips + the table in one proof
+    opa = rng.integers(0, 5, 1000).astype(np.uint32)
+    d_alu = zk.rv32_alu_tracegen(as_dev(opa), as_dev(b[:1000]), as_dev(c[:1000]), 10, d_bw)
+    exp_alu, xc, _ = ora.rv32_alu_trace(opa, b[:1000], c[:1000], 10)
+    bw = zk.download(d_bw).reshape(2, -1)
+    assert (bw[0] == rc).all() and (bw[1] == xc).all()
+    airs = [dict(program=prog, log_height=lh, width=18, n_pvs=0, trace=exp, pvs=NOPV),
+            dict(program=air.rv32_alu_core_air().program(), log_height=10, width=18, n_pvs=0, trace=exp_alu, pvs=NOPV),
+            dict(program=air.bitwise_lookup_air(8).program(), log_height=16, width=2, n_pvs=0, trace=bw, pvs=NOPV,
+                 prep=air.bitwise_lookup_prep(8))]
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    proof = pk.prove([d_lt, d_alu, d_bw], [NOPV] * 3)
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 3, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    pk.close()

@@ -683,6 +683,42 @@ def rv32_alu_core_air(bus=9):
     return b
 
 
+RV32_LT_WIDTH = 18
+
+
+def rv32_lt_core_air(bus=9):
+    """The core of OpenVM's RV32 less-than chip (rv32im `LessThanCoreAir<4, 8>`: SLT / SLTU): columns b[4] | c[4] | cmp | is_slt
+    is_sltu | b_msb_f c_msb_f | marker[4] | diff_val.  b_msb_f / c_msb_f are the top limbs as field elements (limb, or limb - 256
+    for a negative SLT operand: the difference to the limb is 0 or 256, and 0 for SLTU); scanning from the top, limbs are equal
+    until the marked one, where (c_i - b_i) * (2 cmp - 1) = diff_val; no marker means b = c and cmp = 0.  Two RANGE requests go to
+    the bitwise lookup: (b_msb_f + 128 is_slt, c_msb_f + 128 is_slt) puts the signed limbs into [-128, 127] (the unsigned ones into
+    [0, 255]), (diff_val - 1, 0) makes the marked difference 1..255, i.e. of the claimed sign."""
+    b = AirBuilder(RV32_LT_WIDTH, 0)
+    bl, cl = [b.var(i) for i in range(4)], [b.var(4 + i) for i in range(4)]
+    cmp, slt, sltu, bm, cm = b.var(8), b.var(9), b.var(10), b.var(11), b.var(12)
+    mk, dv = [b.var(13 + i) for i in range(4)], b.var(17)
+    ok = slt + sltu
+    for f in (slt, sltu, ok, cmp) + tuple(mk):
+        b.assert_zero(f * (f - 1))
+    for limb, f in ((bl[3], bm), (cl[3], cm)):
+        d = limb - f
+        b.assert_zero(d * (d - 256))
+        b.assert_zero((1 - slt) * d)
+    sign = cmp * 2 - 1
+    prefix = None
+    for i in (3, 2, 1, 0):
+        diff = ((cm if i == 3 else cl[i]) - (bm if i == 3 else bl[i])) * sign
+        prefix = mk[i] if prefix is None else prefix + mk[i]
+        b.assert_zero((1 - prefix) * diff)
+        b.assert_zero(mk[i] * (dv - diff))
+    b.assert_zero(prefix * (prefix - 1))
+    b.assert_zero((1 - prefix) * cmp)
+    b.assert_zero((1 - ok) * prefix)   # padding rows carry no marker (and no request)
+    b.push_interaction(bus, [bm + slt * 128, cm + slt * 128, 0, 0], ok, "send")
+    b.push_interaction(bus, [dv - 1, 0, 0, 0], prefix, "send")
+    return b
+
+
 RV32_MUL_WIDTH = 13
 
 

@@ -375,3 +375,74 @@ extern "C" int zkhip_exec_frame_tracegen(zkhip_ctx* ctx, const uint32_t* d_pc_in
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "exec_frame_tracegen (instruction index beyond the program)");
 }
+
+// ---- RV32 less-than core (OpenVM rv32im LessThanCoreAir<4, 8>: SLT / SLTU) -------------------------------------------------------
+// Record = (opcode 0 = SLT signed, 1 = SLTU unsigned; operands b, c).  Row (ZKHIP_RV32_LT_WIDTH = 18 columns):
+//   b[4] | c[4] | cmp | is_slt is_sltu | b_msb_f c_msb_f | marker[4] | diff_val
+// b_msb_f / c_msb_f are the most significant limbs as FIELD elements: the limb itself for SLTU, limb - 256 for a negative SLT
+// operand; marker[i] = 1 at the most significant limb where b and c differ (none if b = c), diff_val = |c_i - b_i| there (1..255).
+// The row sends two RANGE requests to the bitwise lookup: (b_msb_f + 128 is_slt, c_msb_f + 128 is_slt) -- which is what makes the
+// signed limbs lie in [-128, 127] -- and (diff_val - 1, 0) when a marker is set; both are counted here into the range column of
+// the lookup table's trace.
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_rv32_lt(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ bs,
+                                                 const uint32_t* __restrict__ cs, size_t n, size_t N, uint32_t* __restrict__ trace,
+                                                 uint32_t* __restrict__ range_counts, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_RV32_LT_WIDTH] = {};
+    if (r < n) {
+        const uint32_t op = opc[r], b = bs[r], c = cs[r];
+        if (op > 1) {
+            atomicAdd(bad, 1u);
+        } else {
+            const bool is_slt = op == 0;
+            int bl[4], cl[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) bl[i] = (int)((b >> (8 * i)) & 255u), cl[i] = (int)((c >> (8 * i)) & 255u);
+            const int bm = is_slt && bl[3] >= 128 ? bl[3] - 256 : bl[3], cm = is_slt && cl[3] >= 128 ? cl[3] - 256 : cl[3];
+            int mark = -1, diff = 0;
+#pragma unroll
+            for (int i = 3; i >= 0; i--) {
+                const int x = i == 3 ? bm : bl[i], y = i == 3 ? cm : cl[i];
+                if (mark < 0 && x != y) mark = i, diff = y - x;
+            }
+            const uint32_t cmp = mark >= 0 && diff > 0;
+            const int dv = diff > 0 ? diff : -diff;
+#pragma unroll
+            for (int i = 0; i < 4; i++) col[i] = to_monty((uint32_t)bl[i]), col[4 + i] = to_monty((uint32_t)cl[i]);
+            col[8] = cmp ? MONTY_ONE : 0u;
+            col[9 + op] = MONTY_ONE;
+            col[11] = to_monty(bm < 0 ? P - (uint32_t)(-bm) : (uint32_t)bm);
+            col[12] = to_monty(cm < 0 ? P - (uint32_t)(-cm) : (uint32_t)cm);
+            if (mark >= 0) col[13 + mark] = MONTY_ONE, col[17] = to_monty((uint32_t)dv);
+            const uint32_t sh = is_slt ? 128u : 0u;
+            atomicAdd(&range_counts[((uint32_t)(bm + (int)sh) << 8) | (uint32_t)(cm + (int)sh)], 1u);
+            if (mark >= 0) atomicAdd(&range_counts[(uint32_t)(dv - 1) << 8], 1u);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_RV32_LT_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_rv32_lt_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, const uint32_t* d_b, const uint32_t* d_c, size_t n,
+                                      unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 27 || (n && (!d_opcode || !d_b || !d_c))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_lt_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "rv32_lt_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    // the RANGE multiplicity column of the 8-bit bitwise lookup table (column 0 of its 2 x 2^16 trace)
+    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
+    hipLaunchKernelGGL(k_rv32_lt, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_bitwise_trace,
+                       (uint32_t*)flag);
+    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "rv32_lt_tracegen (opcode > 1)");
+}
