@@ -170,11 +170,32 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            # RCCL for device tensors, gloo for host tensors in the same group: the exchange (32-byte commitments, ~1 MB
+            # proofs) runs over RCCL/xGMI; should RCCL not come up on this node the same exchange runs over gloo on host
+            # copies and the JSON line says so (the proofs are independent: the exchange is not on the proving path).
+            import datetime
+
+            dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     coll_dev = torch.device("cpu") if dry else dev
+    coll_note = None
+    if world > 1 and not dry:
+        ok_flag = torch.ones(1, device="cpu")
+        try:
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError("RCCL all-reduce returned %r" % probe.item())
+        except Exception as e:  # noqa: BLE001
+            ok_flag[0] = 0
+            coll_note = "gloo on host copies (RCCL unavailable on this node: %s)" % (repr(e)[:120])
+        dist.all_reduce(ok_flag, op=dist.ReduceOp.MIN)  # gloo: every rank takes the same path
+        if int(ok_flag.item()) == 0:
+            coll_dev = torch.device("cpu")
+            coll_note = coll_note or "gloo on host copies (RCCL unavailable on another rank)"
     n_pipe = max(1, args.inflight)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_pipe)]
     ctxs = []
@@ -246,18 +267,25 @@ def main():
     for i in range(n_pipe):
         launch(i)
         collect(i)
+    def barrier():
+        # on the backend the exchange uses (dist.barrier() would pick RCCL even when the exchange fell back to gloo)
+        t = torch.zeros(1, device=coll_dev)
+        dist.all_reduce(t)
+        if t.is_cuda:
+            torch.cuda.synchronize()
+
     run(args.warmup)
     for c in ctxs:
         c.profile_reset()
     ctx.profile_enable(True)  # per-kernel HIP events on pipeline 0's stream
     if world > 1:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last_i, last = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        barrier()
     t1 = time.perf_counter()
     ctx.profile_enable(False)
     stats_timed = ctx.profile_read()
@@ -273,7 +301,7 @@ def main():
     # the exchange alone (outside the timed region): one blocking all-gather + gather of a finished proof
     exchange_alone_ms = None
     if world > 1:
-        dist.barrier()
+        barrier()
         te = time.perf_counter()
         for _ in range(4):
             shard.exchange(last, device=coll_dev)
@@ -414,7 +442,8 @@ def main():
                            "posted_per_rank": xstat["posted"], "mode": "asynchronous per proof (side stream), completed inside the timed region",
                            "ms_blocked_at_end_of_timed_region": round(xstat["wait_s"] * 1e3, 3),
                            "ms_one_blocking_exchange_alone": round(exchange_alone_ms, 3),
-                           "bytes_per_proof": "32 x %d all-gather + %d gather to rank 0" % (world, pk.proof_size)},
+                           "bytes_per_proof": "32 x %d all-gather + %d gather to rank 0" % (world, pk.proof_size),
+                           "backend": "gloo (dry run)" if dry else (coll_note or "RCCL (nccl backend), device tensors")},
                        "parallelism": "%d independent proof(s) in flight per GPU (one HIP stream each)" % n_pipe + (", RCCL all-gather of commitments + proof gather" if world > 1 else "")
                                       + (" [DRY RUN: all ranks on one GPU, gloo -- not a measurement]" if dry else "")},
             "roofline": roof,
