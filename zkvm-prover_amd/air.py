@@ -850,8 +850,10 @@ class ReferenceShapedSet:
     PREP = {1: 1, 16: 2}     # AIR index -> preprocessed width
     TABLE, TABLE_USER, TABLE_BUS = 16, 10, 6
 
-    def __init__(self, shrink=0, seed=0):
-        self.heights = [max(1, d - shrink) for d in self.LOG_DEGREES]
+    def __init__(self, shrink=0, seed=0, log_degrees=None):
+        """log_degrees: the heights of another of the eight stored proofs (they are proofs of one circuit, 17 AIRs of the same widths,
+        at different heights; tests/golden/ref_v1_vectors.json `shapes`)."""
+        self.heights = [max(1, d - shrink) for d in (log_degrees or self.LOG_DEGREES)]
         self.heights[1] = 1
         self.chips = []
         for i, (w, acw) in enumerate(zip(self.MAIN_WIDTHS, self.AFTER_CHALLENGE_WIDTHS)):
