@@ -42,6 +42,7 @@
 #include <vector>
 
 #include "zkhip.h"
+#include "zkhip_vm.hpp"
 
 namespace scroll_zkvm_hip {
 
@@ -417,12 +418,37 @@ public:
         return sp;
     }
 
-    // mod.rs:342-413: "execute" (here: decode + upload the witness), prove, encode, self-verify
-    StarkProof gen_proof_stark(const ProvingTask& task) {
+    // mod.rs:312-338: execute the guest to get the cycle count (and check its public values); errors become Error::GenProof
+    // as in mod.rs:318-319.  `records` receives the per-chip execution records the device trace generators take.
+    zkhip_vm::ExecutionResult execute_and_check_with_full_result(const zkhip_vm::Exe& exe, const zkhip_vm::StdIn& stdin_,
+                                                                 zkhip_vm::ExecRecords* records = nullptr, uint64_t max_cost = 0) const {
+        try {
+            const auto t = std::chrono::steady_clock::now();
+            zkhip_vm::ExecutionResult r = zkhip_vm::execute_guest(exe, stdin_, max_cost, records);
+            last_execution_time_mills_ = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t).count();
+            return r;
+        } catch (const zkhip_vm::Error& e) {
+            throw Error(Error::GenProof, e.what());
+        }
+    }
+    uint64_t execute_and_check(const zkhip_vm::Exe& exe, const zkhip_vm::StdIn& stdin_) const {
+        return execute_and_check_with_full_result(exe, stdin_).total_cycle;
+    }
+
+    // mod.rs:342-413: execute (when the task comes with its guest: the cycle count and execution time go into the proof's
+    // stat, mod.rs:398-404), decode + upload the witness, prove, encode, self-verify
+    StarkProof gen_proof_stark(const ProvingTask& task, const zkhip_vm::Exe* guest = nullptr, const zkhip_vm::StdIn* guest_stdin = nullptr) {
+        uint64_t cycles = 0, exec_mills = 0;
+        if (guest) {
+            static const zkhip_vm::StdIn no_input;
+            cycles = execute_and_check_with_full_result(*guest, guest_stdin ? *guest_stdin : no_input).total_cycle;
+            exec_mills = last_execution_time_mills_;
+        }
         DeviceWitness dw = upload_witness(task);
         try {
             StarkProof sp = prove_resident(dw);
             free_witness(dw);
+            if (guest) sp.stat.total_cycles = cycles, sp.stat.execution_time_mills = exec_mills;
             return sp;
         } catch (...) {
             free_witness(dw);
@@ -465,6 +491,7 @@ private:
     zkhip_params params_{};
     int device_ = 0;
     zkhip_ctx* ctx_ = nullptr;
+    mutable uint64_t last_execution_time_mills_ = 0;
     zkhip_pk* pk_ = nullptr;
     std::vector<unsigned> pk_heights_;
 

@@ -1,0 +1,295 @@
+// zkhip_vm.hpp -- host-side mirror of the reference's guest execution step:
+//   crates/prover/src/utils/vm.rs:13-48  execute_guest(sdk, exe, inputs) -> ExecutionResult { total_cycle, public_values }
+// a metered run first (instruction count + cost, bounded by a maximum cost), the plain executor as the fall-back when the
+// metered one gives up (total_cycle = u64::MAX then, as in the reference), and the same sanity check on the public values
+// ("public_values are all 0s ...").  Called by Prover::gen_proof_stark before proving (crates/prover/src/prover/mod.rs:318).
+//
+// What runs here is an RV32IM interpreter (the reference's guests are rv32im ELFs transpiled for OpenVM; its executor and
+// transpiler live in un-vendored crates, so the instruction set is the public RISC-V one, not OpenVM's opcode numbering).
+// Besides the result it produces what the step AFTER execution needs on this backend: per-chip EXECUTION RECORDS in the
+// layout the device trace generators take (include/zkhip.h: zkhip_program_freq_tracegen / zkhip_exec_frame_tracegen /
+// zkhip_rv32_alu_tracegen / zkhip_rv32_lt_tracegen / zkhip_rv32_mul_tracegen) -- the execution -> trace hand-off of
+// SURVEY.md 8(f) f3.  Chips that have no device generator yet (shifts, branches, loads / stores, jumps, division) are
+// counted, so that the cost model sees them, but leave no records.
+//
+// Environment calls (a7): 93 = exit(a0) (non-zero = guest failure), 1 = reveal the word a0 as public-value bytes
+// [4 a1, 4 a1 + 4), 2 = read the next word of the input stream into a0.  Header-only; no GPU code.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace zkhip_vm {
+
+struct Exe {
+    uint32_t pc_base = 0x00200000u;       // address of program[0]
+    std::vector<uint32_t> program;        // RV32IM instruction words
+    uint32_t data_base = 0x00400000u;
+    std::vector<uint8_t> data;            // initial read-write memory at data_base
+    uint32_t memory_bytes = 1u << 20;     // size of the read-write region (stack at its top)
+};
+struct StdIn {
+    std::vector<uint8_t> bytes;           // the hint stream, consumed one little-endian word per read
+};
+struct ExecutionResult {                  // crates/prover/src/utils/vm.rs:3-8
+    uint64_t total_cycle = 0;
+    std::vector<uint8_t> public_values;
+};
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// Per-chip records, in the argument layout of the device trace generators (plain integers).
+struct ExecRecords {
+    std::vector<uint32_t> pc_index;                   // every executed instruction: its row in the program
+    std::vector<uint32_t> alu_op, alu_b, alu_c;       // 0 add 1 sub 2 xor 3 or 4 and (register and immediate forms)
+    std::vector<uint32_t> lt_op, lt_b, lt_c;          // 0 slt 1 sltu
+    std::vector<uint32_t> mul_b, mul_c;               // mul (low word)
+    uint64_t n_shift = 0, n_branch = 0, n_jump = 0, n_load_store = 0, n_mulh = 0, n_divrem = 0, n_lui_auipc = 0, n_ecall = 0;
+};
+
+constexpr unsigned NUM_PUBLIC_VALUE_BYTES = 32;
+// trace widths used by the cost model (cells per record): the device generators' widths where they exist, OpenVM-like
+// figures for the rest; program chip rows are counted once per program instruction
+constexpr uint64_t W_ALU = 18, W_LT = 18, W_MUL = 13, W_FRAME = 10, W_SHIFT = 53, W_BRANCH = 26, W_JUMP = 18, W_LOAD_STORE = 41,
+                   W_MULH = 39, W_DIVREM = 59, W_LUI_AUIPC = 20;
+
+inline uint64_t next_pow2(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+// metered cost = main-trace cells of the segment (rows padded to powers of two), the quantity OpenVM's metered executor bounds
+inline uint64_t trace_cells(const ExecRecords& r, size_t program_len) {
+    auto cells = [](uint64_t n, uint64_t w) { return n ? next_pow2(n) * w : 0; };
+    return cells(r.alu_op.size(), W_ALU) + cells(r.lt_op.size(), W_LT) + cells(r.mul_b.size(), W_MUL) + cells(r.pc_index.size(), W_FRAME) +
+           cells(program_len, 10) + cells(r.n_shift, W_SHIFT) + cells(r.n_branch, W_BRANCH) + cells(r.n_jump, W_JUMP) +
+           cells(r.n_load_store, W_LOAD_STORE) + cells(r.n_mulh, W_MULH) + cells(r.n_divrem, W_DIVREM) + cells(r.n_lui_auipc, W_LUI_AUIPC);
+}
+
+class Machine {
+public:
+    Machine(const Exe& exe, const StdIn& in) : exe_(exe), in_(in), mem_(exe.memory_bytes, 0), pv_(NUM_PUBLIC_VALUE_BYTES, 0) {
+        if (exe.data.size() > mem_.size()) throw Error("initial data larger than memory");
+        if (!exe.data.empty()) memcpy(mem_.data(), exe.data.data(), exe.data.size());
+        memset(x_, 0, sizeof x_);
+        x_[2] = exe.data_base + exe.memory_bytes;  // sp
+        pc_ = exe.pc_base;
+    }
+    // Runs until exit.  max_instr / max_cost == 0: unbounded.  Returns false if a bound was hit (state stays valid).
+    bool run(uint64_t max_instr, uint64_t max_cost, ExecRecords* rec) {
+        while (!done_) {
+            if (max_instr && instret_ >= max_instr) return false;
+            if (max_cost && rec && (instret_ & 1023u) == 0 && trace_cells(*rec, exe_.program.size()) > max_cost) return false;
+            step(rec);
+        }
+        return true;
+    }
+    uint64_t instret() const { return instret_; }
+    const std::vector<uint8_t>& public_values() const { return pv_; }
+    uint32_t exit_code() const { return exit_code_; }
+    uint32_t reg(unsigned i) const { return x_[i & 31]; }
+
+private:
+    const Exe& exe_;
+    const StdIn& in_;
+    std::vector<uint8_t> mem_, pv_;
+    uint32_t x_[32], pc_ = 0, exit_code_ = 0;
+    uint64_t instret_ = 0;
+    size_t in_pos_ = 0;
+    bool done_ = false;
+
+    uint8_t* at(uint32_t addr, unsigned n) {
+        const uint64_t off = (uint64_t)addr - exe_.data_base;
+        if (addr < exe_.data_base || off + n > mem_.size()) throw Error("memory access out of range at pc " + std::to_string(pc_));
+        return mem_.data() + off;
+    }
+    uint32_t load(uint32_t addr, unsigned n) {
+        if (addr % n) throw Error("misaligned load");
+        uint32_t v = 0;
+        memcpy(&v, at(addr, n), n);
+        return v;
+    }
+    void store(uint32_t addr, uint32_t v, unsigned n) {
+        if (addr % n) throw Error("misaligned store");
+        memcpy(at(addr, n), &v, n);
+    }
+    void step(ExecRecords* rec) {
+        const uint64_t idx64 = ((uint64_t)pc_ - exe_.pc_base) / 4;
+        if (pc_ < exe_.pc_base || (pc_ & 3u) || idx64 >= exe_.program.size()) throw Error("pc outside the program: " + std::to_string(pc_));
+        const uint32_t w = exe_.program[idx64];
+        const uint32_t op = w & 0x7f, rd = (w >> 7) & 31, f3 = (w >> 12) & 7, rs1 = (w >> 15) & 31, rs2 = (w >> 20) & 31, f7 = w >> 25;
+        const uint32_t a = x_[rs1], b = x_[rs2];
+        const int32_t imm_i = (int32_t)w >> 20;
+        const int32_t imm_s = (((int32_t)w >> 25) << 5) | (int32_t)((w >> 7) & 31);
+        const int32_t imm_b = (((int32_t)w >> 31) << 12) | (int32_t)(((w >> 7) & 1) << 11) | (int32_t)(((w >> 25) & 63) << 5) | (int32_t)(((w >> 8) & 15) << 1);
+        const int32_t imm_j = (((int32_t)w >> 31) << 20) | (int32_t)(((w >> 12) & 255) << 12) | (int32_t)(((w >> 20) & 1) << 11) | (int32_t)(((w >> 21) & 1023) << 1);
+        uint32_t next = pc_ + 4, val = 0;
+        bool wr = false;
+        if (rec) rec->pc_index.push_back((uint32_t)idx64);
+        auto alu = [&](uint32_t o, uint32_t x, uint32_t y) {
+            if (rec) rec->alu_op.push_back(o), rec->alu_b.push_back(x), rec->alu_c.push_back(y);
+            return o == 0 ? x + y : o == 1 ? x - y : o == 2 ? (x ^ y) : o == 3 ? (x | y) : (x & y);
+        };
+        auto lt = [&](uint32_t o, uint32_t x, uint32_t y) {
+            if (rec) rec->lt_op.push_back(o), rec->lt_b.push_back(x), rec->lt_c.push_back(y);
+            return (uint32_t)(o == 0 ? (int32_t)x < (int32_t)y : x < y);
+        };
+        auto shift = [&](uint32_t kind, uint32_t x, uint32_t s) {
+            if (rec) rec->n_shift++;
+            s &= 31;
+            return kind == 0 ? x << s : kind == 1 ? x >> s : (uint32_t)((int32_t)x >> s);
+        };
+        switch (op) {
+            case 0x37: val = w & 0xfffff000u, wr = true; if (rec) rec->n_lui_auipc++; break;               // LUI
+            case 0x17: val = pc_ + (w & 0xfffff000u), wr = true; if (rec) rec->n_lui_auipc++; break;        // AUIPC
+            case 0x6f: val = pc_ + 4, wr = true, next = pc_ + (uint32_t)imm_j; if (rec) rec->n_jump++; break;  // JAL
+            case 0x67: val = pc_ + 4, wr = true, next = (a + (uint32_t)imm_i) & ~1u; if (rec) rec->n_jump++; break;  // JALR
+            case 0x63: {
+                bool t;
+                switch (f3) {
+                    case 0: t = a == b; break;
+                    case 1: t = a != b; break;
+                    case 4: t = (int32_t)a < (int32_t)b; break;
+                    case 5: t = (int32_t)a >= (int32_t)b; break;
+                    case 6: t = a < b; break;
+                    case 7: t = a >= b; break;
+                    default: throw Error("illegal branch");
+                }
+                if (t) next = pc_ + (uint32_t)imm_b;
+                if (rec) rec->n_branch++;
+                break;
+            }
+            case 0x03: {
+                const uint32_t addr = a + (uint32_t)imm_i;
+                switch (f3) {
+                    case 0: val = (uint32_t)(int32_t)(int8_t)load(addr, 1); break;
+                    case 1: val = (uint32_t)(int32_t)(int16_t)load(addr, 2); break;
+                    case 2: val = load(addr, 4); break;
+                    case 4: val = load(addr, 1); break;
+                    case 5: val = load(addr, 2); break;
+                    default: throw Error("illegal load");
+                }
+                wr = true;
+                if (rec) rec->n_load_store++;
+                break;
+            }
+            case 0x23: {
+                const uint32_t addr = a + (uint32_t)imm_s;
+                if (f3 > 2) throw Error("illegal store");
+                store(addr, b, 1u << f3);
+                if (rec) rec->n_load_store++;
+                break;
+            }
+            case 0x13: {
+                const uint32_t c = (uint32_t)imm_i;
+                wr = true;
+                switch (f3) {
+                    case 0: val = alu(0, a, c); break;
+                    case 2: val = lt(0, a, c); break;
+                    case 3: val = lt(1, a, c); break;
+                    case 4: val = alu(2, a, c); break;
+                    case 6: val = alu(3, a, c); break;
+                    case 7: val = alu(4, a, c); break;
+                    case 1: if (f7) throw Error("illegal slli"); val = shift(0, a, rs2); break;
+                    default: if (f7 != 0 && f7 != 0x20) throw Error("illegal shift"); val = shift(f7 ? 2 : 1, a, rs2); break;
+                }
+                break;
+            }
+            case 0x33: {
+                wr = true;
+                if (f7 == 1) {
+                    const int64_t sa = (int32_t)a, sb = (int32_t)b;
+                    const uint64_t ua = a, ub = b;
+                    switch (f3) {
+                        case 0: val = a * b; if (rec) rec->mul_b.push_back(a), rec->mul_c.push_back(b); break;
+                        case 1: val = (uint32_t)((uint64_t)(sa * sb) >> 32); if (rec) rec->n_mulh++; break;
+                        case 2: val = (uint32_t)((uint64_t)(sa * (int64_t)ub) >> 32); if (rec) rec->n_mulh++; break;
+                        case 3: val = (uint32_t)((ua * ub) >> 32); if (rec) rec->n_mulh++; break;
+                        case 4: val = b == 0 ? 0xffffffffu : (a == 0x80000000u && b == 0xffffffffu) ? a : (uint32_t)((int32_t)a / (int32_t)b); break;
+                        case 5: val = b == 0 ? 0xffffffffu : a / b; break;
+                        case 6: val = b == 0 ? a : (a == 0x80000000u && b == 0xffffffffu) ? 0 : (uint32_t)((int32_t)a % (int32_t)b); break;
+                        default: val = b == 0 ? a : a % b; break;
+                    }
+                    if (f3 >= 4 && rec) rec->n_divrem++;
+                } else if (f7 == 0 || f7 == 0x20) {
+                    switch (f3) {
+                        case 0: val = alu(f7 ? 1 : 0, a, b); break;
+                        case 1: if (f7) throw Error("illegal sll"); val = shift(0, a, b); break;
+                        case 2: if (f7) throw Error("illegal slt"); val = lt(0, a, b); break;
+                        case 3: if (f7) throw Error("illegal sltu"); val = lt(1, a, b); break;
+                        case 4: if (f7) throw Error("illegal xor"); val = alu(2, a, b); break;
+                        case 5: val = shift(f7 ? 2 : 1, a, b); break;
+                        case 6: if (f7) throw Error("illegal or"); val = alu(3, a, b); break;
+                        default: if (f7) throw Error("illegal and"); val = alu(4, a, b); break;
+                    }
+                } else {
+                    throw Error("illegal op");
+                }
+                break;
+            }
+            case 0x73: {
+                if (w != 0x00000073u) throw Error("unsupported system instruction");
+                if (rec) rec->n_ecall++;
+                const uint32_t call = x_[17];
+                if (call == 93) {
+                    done_ = true, exit_code_ = x_[10];
+                } else if (call == 1) {
+                    const uint64_t off = 4ull * x_[11];
+                    if (off + 4 > pv_.size()) throw Error("public value index out of range");
+                    memcpy(pv_.data() + off, &x_[10], 4);
+                } else if (call == 2) {
+                    if (in_pos_ + 4 > in_.bytes.size()) throw Error("input stream exhausted");
+                    memcpy(&val, in_.bytes.data() + in_pos_, 4);
+                    in_pos_ += 4;
+                    x_[10] = val;
+                } else {
+                    throw Error("unknown environment call " + std::to_string(call));
+                }
+                break;
+            }
+            default: throw Error("illegal instruction " + std::to_string(w) + " at pc " + std::to_string(pc_));
+        }
+        if (wr && rd) x_[rd] = val;
+        pc_ = next;
+        instret_++;
+    }
+};
+
+// crates/prover/src/utils/vm.rs:13-48.  `records`, when given, receives the per-chip execution records of the run that
+// produced the result (the metered run, or the fall-back run).
+inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64_t max_cost = 0, ExecRecords* records = nullptr) {
+    auto all_zero = [](const std::vector<uint8_t>& v) {
+        for (uint8_t b : v)
+            if (b) return false;
+        return true;
+    };
+    ExecRecords local;
+    ExecRecords* rec = records ? records : &local;
+    {
+        *rec = ExecRecords();
+        Machine m(exe, inputs);
+        bool finished = false;
+        try {
+            finished = m.run(0, max_cost, rec);
+        } catch (const Error&) {
+            finished = false;  // "Metered execution failed: {e}, falling back to execute"
+        }
+        if (finished) {
+            if (m.exit_code()) throw Error("guest exited with code " + std::to_string(m.exit_code()));
+            if (all_zero(m.public_values())) throw Error("public_values are all 0s for unexpected reason");
+            return ExecutionResult{m.instret(), m.public_values()};
+        }
+    }
+    // the plain executor: no cost bound, and -- like the reference's -- no instruction count (u64::MAX as the sentinel)
+    *rec = ExecRecords();
+    Machine m(exe, inputs);
+    m.run(0, 0, rec);
+    if (m.exit_code()) throw Error("guest exited with code " + std::to_string(m.exit_code()));
+    if (all_zero(m.public_values())) throw Error("public_values are all 0s upon execute");
+    return ExecutionResult{UINT64_MAX, m.public_values()};
+}
+
+}  // namespace zkhip_vm

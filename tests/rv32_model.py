@@ -1,0 +1,259 @@
+"""A tiny RV32IM assembler and an independent Python interpreter (test infrastructure): the checker of include/zkhip_vm.hpp.
+Follows the RISC-V unprivileged specification (RV32I base + M); environment calls as documented in zkhip_vm.hpp
+(a7 = 93 exit, 1 reveal, 2 read input word)."""
+import struct
+
+M32 = 0xFFFFFFFF
+
+
+def _r(op, f3, f7, rd, rs1, rs2):
+    return (f7 << 25) | (rs2 << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | op
+
+
+def _i(op, f3, rd, rs1, imm):
+    return ((imm & 0xFFF) << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | op
+
+
+def _s(f3, rs1, rs2, imm):
+    return (((imm >> 5) & 0x7F) << 25) | (rs2 << 20) | (rs1 << 15) | (f3 << 12) | ((imm & 31) << 7) | 0x23
+
+
+def _b(f3, rs1, rs2, imm):
+    return (((imm >> 12) & 1) << 31) | (((imm >> 5) & 63) << 25) | (rs2 << 20) | (rs1 << 15) | (f3 << 12) | (((imm >> 1) & 15) << 8) | (((imm >> 11) & 1) << 7) | 0x63
+
+
+def _j(rd, imm):
+    return (((imm >> 20) & 1) << 31) | (((imm >> 1) & 1023) << 21) | (((imm >> 11) & 1) << 20) | (((imm >> 12) & 255) << 12) | (rd << 7) | 0x6F
+
+
+R_OPS = {"add": (0, 0), "sub": (0, 0x20), "sll": (1, 0), "slt": (2, 0), "sltu": (3, 0), "xor": (4, 0), "srl": (5, 0), "sra": (5, 0x20),
+         "or": (6, 0), "and": (7, 0), "mul": (0, 1), "mulh": (1, 1), "mulhsu": (2, 1), "mulhu": (3, 1), "div": (4, 1), "divu": (5, 1),
+         "rem": (6, 1), "remu": (7, 1)}
+I_OPS = {"addi": 0, "slti": 2, "sltiu": 3, "xori": 4, "ori": 6, "andi": 7}
+B_OPS = {"beq": 0, "bne": 1, "blt": 4, "bge": 5, "bltu": 6, "bgeu": 7}
+L_OPS = {"lb": 0, "lh": 1, "lw": 2, "lbu": 4, "lhu": 5}
+S_OPS = {"sb": 0, "sh": 1, "sw": 2}
+
+
+def assemble(lines):
+    """lines: tuples like ("addi", rd, rs1, imm), ("beq", rs1, rs2, "label"), ("label", "name"), ("jal", rd, "label"),
+    ("lw", rd, rs1, imm), ("sw", rs2, rs1, imm), ("lui", rd, imm20), ("ecall",).  Returns the instruction words."""
+    labels, pc = {}, 0
+    for ln in lines:
+        if ln[0] == "label":
+            labels[ln[1]] = pc
+        else:
+            pc += 4
+    out, pc = [], 0
+    for ln in lines:
+        op = ln[0]
+        if op == "label":
+            continue
+        tgt = lambda v: (labels[v] - pc) if isinstance(v, str) else v  # noqa: E731
+        if op in R_OPS:
+            f3, f7 = R_OPS[op]
+            w = _r(0x33, f3, f7, ln[1], ln[2], ln[3])
+        elif op in I_OPS:
+            w = _i(0x13, I_OPS[op], ln[1], ln[2], ln[3])
+        elif op in ("slli", "srli", "srai"):
+            w = _r(0x13, 1 if op == "slli" else 5, 0x20 if op == "srai" else 0, ln[1], ln[2], ln[3] & 31)
+        elif op in B_OPS:
+            w = _b(B_OPS[op], ln[1], ln[2], tgt(ln[3]))
+        elif op in L_OPS:
+            w = _i(0x03, L_OPS[op], ln[1], ln[2], ln[3])
+        elif op in S_OPS:
+            w = _s(S_OPS[op], ln[2], ln[1], ln[3])
+        elif op == "lui":
+            w = ((ln[2] & 0xFFFFF) << 12) | (ln[1] << 7) | 0x37
+        elif op == "auipc":
+            w = ((ln[2] & 0xFFFFF) << 12) | (ln[1] << 7) | 0x17
+        elif op == "jal":
+            w = _j(ln[1], tgt(ln[2]))
+        elif op == "jalr":
+            w = _i(0x67, 0, ln[1], ln[2], ln[3])
+        elif op == "ecall":
+            w = 0x73
+        else:
+            raise ValueError(op)
+        out.append(w & M32)
+        pc += 4
+    return out
+
+
+def li(rd, value):
+    """load a 32-bit constant: lui + addi"""
+    value &= M32
+    lo = value & 0xFFF
+    if lo >= 0x800:
+        lo -= 0x1000
+    hi = ((value - lo) >> 12) & 0xFFFFF
+    return [("lui", rd, hi), ("addi", rd, rd, lo)]
+
+
+def sdiv(a, b):
+    q = abs(a) // abs(b)   # RISC-V division truncates towards zero
+    return q if (a < 0) == (b < 0) else -q
+
+
+def srem(a, b):
+    r = abs(a) % abs(b)    # the remainder has the sign of the dividend
+    return r if a >= 0 else -r
+
+
+def sx(v, bits):
+    v &= (1 << bits) - 1
+    return v - (1 << bits) if v >> (bits - 1) else v
+
+
+def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_bytes=1 << 20, data=b"", max_instr=10**7):
+    """Independent interpreter.  Returns dict(instret, pvs (32 bytes), exit_code, records)."""
+    x = [0] * 32
+    x[2] = data_base + memory_bytes
+    mem = bytearray(memory_bytes)
+    mem[:len(data)] = data
+    pvs = bytearray(32)
+    pc, n, pos = pc_base, 0, 0
+    rec = dict(pc_index=[], alu=[], lt=[], mul=[], shift=0, branch=0, jump=0, load_store=0, mulh=0, divrem=0, lui_auipc=0, ecall=0)
+    s32 = lambda v: sx(v, 32)  # noqa: E731
+    while True:
+        assert n < max_instr
+        idx = (pc - pc_base) // 4
+        w = program[idx]
+        rec["pc_index"].append(idx)
+        op, rd, f3, rs1, rs2, f7 = w & 0x7F, (w >> 7) & 31, (w >> 12) & 7, (w >> 15) & 31, (w >> 20) & 31, w >> 25
+        a, b = x[rs1], x[rs2]
+        imm_i = sx(w >> 20, 12)
+        nxt, val, wr = pc + 4, 0, False
+
+        def alu(o, p, q):
+            rec["alu"].append((o, p, q))
+            return [p + q, p - q, p ^ q, p | q, p & q][o] & M32
+
+        def lt(o, p, q):
+            rec["lt"].append((o, p, q))
+            return int(s32(p) < s32(q)) if o == 0 else int(p < q)
+
+        def shift(k, p, s):
+            rec["shift"] += 1
+            s &= 31
+            return [(p << s) & M32, p >> s, (s32(p) >> s) & M32][k]
+
+        if op == 0x37:
+            val, wr = w & 0xFFFFF000, True
+            rec["lui_auipc"] += 1
+        elif op == 0x17:
+            val, wr = (pc + (w & 0xFFFFF000)) & M32, True
+            rec["lui_auipc"] += 1
+        elif op == 0x6F:
+            imm = sx(((w >> 31) << 20) | (((w >> 12) & 255) << 12) | (((w >> 20) & 1) << 11) | (((w >> 21) & 1023) << 1), 21)
+            val, wr, nxt = pc + 4, True, (pc + imm) & M32
+            rec["jump"] += 1
+        elif op == 0x67:
+            val, wr, nxt = pc + 4, True, (a + imm_i) & M32 & ~1
+            rec["jump"] += 1
+        elif op == 0x63:
+            imm = sx(((w >> 31) << 12) | (((w >> 7) & 1) << 11) | (((w >> 25) & 63) << 5) | (((w >> 8) & 15) << 1), 13)
+            t = {0: a == b, 1: a != b, 4: s32(a) < s32(b), 5: s32(a) >= s32(b), 6: a < b, 7: a >= b}[f3]
+            if t:
+                nxt = (pc + imm) & M32
+            rec["branch"] += 1
+        elif op == 0x03:
+            addr = (a + imm_i) & M32
+            o = addr - data_base
+            size = {0: 1, 1: 2, 2: 4, 4: 1, 5: 2}[f3]
+            v = int.from_bytes(mem[o:o + size], "little")
+            val = (sx(v, 8 * size) & M32) if f3 in (0, 1) else v
+            wr = True
+            rec["load_store"] += 1
+        elif op == 0x23:
+            imm = sx(((w >> 25) << 5) | ((w >> 7) & 31), 12)
+            o = ((a + imm) & M32) - data_base
+            size = 1 << f3
+            mem[o:o + size] = (b & ((1 << (8 * size)) - 1)).to_bytes(size, "little")
+            rec["load_store"] += 1
+        elif op == 0x13:
+            c = imm_i & M32
+            wr = True
+            if f3 == 0:
+                val = alu(0, a, c)
+            elif f3 == 2:
+                val = lt(0, a, c)
+            elif f3 == 3:
+                val = lt(1, a, c)
+            elif f3 == 4:
+                val = alu(2, a, c)
+            elif f3 == 6:
+                val = alu(3, a, c)
+            elif f3 == 7:
+                val = alu(4, a, c)
+            elif f3 == 1:
+                val = shift(0, a, rs2)
+            else:
+                val = shift(2 if f7 else 1, a, rs2)
+        elif op == 0x33:
+            wr = True
+            if f7 == 1:
+                sa, sb = s32(a), s32(b)
+                if f3 == 0:
+                    val = (a * b) & M32
+                    rec["mul"].append((a, b))
+                elif f3 == 1:
+                    val = ((sa * sb) >> 32) & M32
+                elif f3 == 2:
+                    val = ((sa * b) >> 32) & M32
+                elif f3 == 3:
+                    val = ((a * b) >> 32) & M32
+                elif f3 == 4:
+                    val = M32 if b == 0 else (a if (a == 0x80000000 and b == M32) else sdiv(sa, sb) & M32)
+                elif f3 == 5:
+                    val = M32 if b == 0 else a // b
+                elif f3 == 6:
+                    val = a if b == 0 else (0 if (a == 0x80000000 and b == M32) else srem(sa, sb) & M32)
+                else:
+                    val = a if b == 0 else a % b
+                if 1 <= f3 <= 3:
+                    rec["mulh"] += 1
+                if f3 >= 4:
+                    rec["divrem"] += 1
+            else:
+                if f3 == 0:
+                    val = alu(1 if f7 else 0, a, b)
+                elif f3 == 1:
+                    val = shift(0, a, b)
+                elif f3 == 2:
+                    val = lt(0, a, b)
+                elif f3 == 3:
+                    val = lt(1, a, b)
+                elif f3 == 4:
+                    val = alu(2, a, b)
+                elif f3 == 5:
+                    val = shift(2 if f7 else 1, a, b)
+                elif f3 == 6:
+                    val = alu(3, a, b)
+                else:
+                    val = alu(4, a, b)
+        elif op == 0x73:
+            rec["ecall"] += 1
+            call = x[17]
+            if call == 93:
+                n += 1
+                return dict(instret=n, pvs=bytes(pvs), exit_code=x[10], records=rec)
+            if call == 1:
+                pvs[4 * x[11]:4 * x[11] + 4] = struct.pack("<I", x[10])
+            elif call == 2:
+                x[10] = struct.unpack_from("<I", stdin, pos)[0]
+                pos += 4
+            else:
+                raise ValueError("ecall %d" % call)
+        else:
+            raise ValueError("illegal instruction %08x" % w)
+        if wr and rd:
+            x[rd] = val & M32
+        pc = nxt
+        n += 1
+
+
+def exe_bytes(program, pc_base=0x00200000, data_base=0x00400000, memory_bytes=1 << 20, data=b""):
+    """the vm_cli exe format"""
+    return struct.pack("<III", 0x58455A4B, pc_base, len(program)) + struct.pack("<%dI" % len(program), *program) + \
+        struct.pack("<III", data_base, memory_bytes, len(data)) + bytes(data)

@@ -1,0 +1,92 @@
+"""Execution -> trace hand-off -> proof (SURVEY.md 8(a) a4 + 8(f) f3): an RV32IM guest runs in the host executor
+(include/zkhip_vm.hpp via vm_cli), its per-chip execution records go to the device trace generators -- program chip
+(cached program + execution frequencies), execution frames, base ALU, less-than, multiplication, and the two lookup tables
+they count into -- and the seven AIRs are proven in one proof from the device-resident traces.  Every trace equals the
+oracle's trace from the same records, the proof bytes equal the oracle's, the host verifier accepts."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import rv32_model as rv  # noqa: E402
+from test_vm_cpu import mixed_program, fib_program, run_cli  # noqa: E402
+
+import zkvm_prover_amd as z  # noqa: E402
+from zkvm_prover_amd import air  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+NOPV = np.zeros(0, np.uint32)
+PARAMS = (1, 0, 12, 4, 4)
+P = 2013265921
+
+
+def program_table(words, log_program):
+    """[9, 2^log_program] canonical: pc index, opcode, rd, funct3, rs1, rs2, funct7, and the instruction word split in two halves
+    (rows beyond the program are zero: never executed)."""
+    n = 1 << log_program
+    t = np.zeros((9, n), np.uint32)
+    w = np.array(words, dtype=np.uint32)
+    k = len(w)
+    t[0, :k] = np.arange(k)
+    t[1, :k], t[2, :k], t[3, :k] = w & 0x7F, (w >> 7) & 31, (w >> 12) & 7
+    t[4, :k], t[5, :k], t[6, :k] = (w >> 15) & 31, (w >> 20) & 31, w >> 25
+    t[7, :k], t[8, :k] = w & 0xFFFF, w >> 16
+    return t
+
+
+def log2_ceil(n):
+    return max(1, int(np.ceil(np.log2(max(n, 2)))))
+
+
+@pytest.mark.parametrize("which,seed", [("mixed", 7), ("fib", 300)])
+def test_guest_execution_to_proof(zk, ora, tmp_path, which, seed):
+    words = mixed_program() if which == "mixed" else fib_program()
+    r, js, rec = run_cli(tmp_path, words, int(seed).to_bytes(4, "little"))
+    assert r.returncode == 0, r.stderr
+    assert js["total_cycle"] == rv.run(words, int(seed).to_bytes(4, "little"))["instret"]
+    dev = zk.device
+    as_dev = lambda v: torch.from_numpy(np.ascontiguousarray(v).view(np.int32)).to(dev)  # noqa: E731
+    lp, lf = log2_ceil(len(words)), log2_ceil(len(rec["pc_index"]))
+    prog = program_table(words, lp)
+    # ---- device trace generation from the records
+    d_prog = zk.upload(prog.reshape(-1))
+    d_idx = as_dev(rec["pc_index"])
+    d_freq = zk.program_freq_tracegen(d_idx, lp)
+    d_frames = zk.exec_frame_tracegen(d_idx, d_prog, 1 << lp, lf)
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=dev)
+    la, ll, lm = log2_ceil(len(rec["alu_op"])), log2_ceil(len(rec["lt_op"])), log2_ceil(len(rec["mul_b"]))
+    d_alu = zk.rv32_alu_tracegen(as_dev(rec["alu_op"]), as_dev(rec["alu_b"]), as_dev(rec["alu_c"]), la, d_bw)
+    d_lt = zk.rv32_lt_tracegen(as_dev(rec["lt_op"]), as_dev(rec["lt_b"]), as_dev(rec["lt_c"]), ll, d_bw)
+    sx, sy = 256, 2048
+    d_tab = torch.zeros(sx * sy, dtype=torch.int32, device=dev)
+    d_mul = zk.rv32_mul_tracegen(as_dev(rec["mul_b"]), as_dev(rec["mul_c"]), lm, d_tab, sx, sy)
+    # ---- the oracle's traces from the same records
+    freq, _ = ora.program_freq_trace(rec["pc_index"], lp)
+    frames, _ = ora.exec_frame_trace(rec["pc_index"], prog, lf)
+    alu, xc, _ = ora.rv32_alu_trace(rec["alu_op"], rec["alu_b"], rec["alu_c"], la)
+    lt, rc, _ = ora.rv32_lt_trace(rec["lt_op"], rec["lt_b"], rec["lt_c"], ll)
+    mul, tc = ora.rv32_mul_trace(rec["mul_b"], rec["mul_c"], lm, sx, sy)
+    bw = np.stack([rc, xc])
+    assert (zk.download(d_freq) == freq).all() and (zk.download(d_frames).reshape(10, -1) == frames).all()
+    assert (zk.download(d_alu).reshape(18, -1) == alu).all() and (zk.download(d_lt).reshape(18, -1) == lt).all()
+    assert (zk.download(d_mul).reshape(13, -1) == mul).all()
+    assert (zk.download(d_bw).reshape(2, -1) == bw).all() and (zk.download(d_tab) == tc).all()
+    assert int(freq.astype(np.int64).sum()) == js["total_cycle"]
+    # ---- one proof over the seven chips
+    airs = [dict(program=air.program_air().program(), log_height=lp, width=10, n_pvs=0, trace=np.concatenate([prog, freq.reshape(1, -1)]), pvs=NOPV),
+            dict(program=air.exec_frame_air().program(), log_height=lf, width=10, n_pvs=0, trace=frames, pvs=NOPV),
+            dict(program=air.rv32_alu_core_air().program(), log_height=la, width=18, n_pvs=0, trace=alu, pvs=NOPV),
+            dict(program=air.rv32_lt_core_air().program(), log_height=ll, width=18, n_pvs=0, trace=lt, pvs=NOPV),
+            dict(program=air.rv32_mul_core_air().program(), log_height=lm, width=13, n_pvs=0, trace=mul, pvs=NOPV),
+            dict(program=air.bitwise_lookup_air(8).program(), log_height=16, width=2, n_pvs=0, trace=bw, pvs=NOPV, prep=air.bitwise_lookup_prep(8)),
+            dict(program=air.range_tuple_table_air(sx, sy).program(), log_height=19, width=1, n_pvs=0, trace=tc.reshape(1, -1), pvs=NOPV,
+                 prep=air.range_tuple_prep(sx, sy))]
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    pvs = [NOPV] * len(airs)
+    proof = pk.prove([torch.cat([d_prog, d_freq]), d_frames, d_alu, d_lt, d_mul, d_bw, d_tab], pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    pk.close()

@@ -1,0 +1,73 @@
+// vm_cli -- the guest execution step (include/zkhip_vm.hpp: the mirror of crates/prover/src/utils/vm.rs execute_guest) as a
+// command-line tool: runs an RV32IM guest and writes the per-chip execution records the device trace generators take.
+//   vm_cli exec <exe.bin> <stdin.bin | -> <out_dir | -> [max_cost]
+// exe.bin: u32 words  [0x58455A4B "KZEX", pc_base, n_program, program..., data_base, memory_bytes, n_data_bytes, data bytes...]
+// Prints one JSON line {"total_cycle", "public_values", "records": {...counts}, "trace_cells"}; with an out_dir, writes
+// pc_index.u32, alu_{op,b,c}.u32, lt_{op,b,c}.u32, mul_{b,c}.u32 (raw little-endian arrays).
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "zkhip_vm.hpp"
+
+static std::vector<uint8_t> read_file(const std::string& p) {
+    std::ifstream f(p, std::ios::binary);
+    if (!f) throw zkhip_vm::Error("cannot read " + p);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+static void write_u32(const std::string& p, const std::vector<uint32_t>& v) {
+    std::ofstream f(p, std::ios::binary);
+    f.write((const char*)v.data(), (std::streamsize)(v.size() * 4));
+}
+
+int main(int argc, char** argv) {
+    try {
+        if (argc < 5 || std::string(argv[1]) != "exec") {
+            fprintf(stderr, "usage: vm_cli exec <exe.bin> <stdin.bin|-> <out_dir|-> [max_cost]\n");
+            return 2;
+        }
+        const std::vector<uint8_t> raw = read_file(argv[2]);
+        if (raw.size() < 24 || raw.size() % 4 > 3) throw zkhip_vm::Error("exe too short");
+        auto word = [&](size_t i) {
+            if (4 * i + 4 > raw.size()) throw zkhip_vm::Error("exe truncated");
+            uint32_t v;
+            memcpy(&v, raw.data() + 4 * i, 4);
+            return v;
+        };
+        if (word(0) != 0x58455A4Bu) throw zkhip_vm::Error("bad exe magic");
+        zkhip_vm::Exe exe;
+        exe.pc_base = word(1);
+        const size_t n_prog = word(2);
+        for (size_t i = 0; i < n_prog; i++) exe.program.push_back(word(3 + i));
+        exe.data_base = word(3 + n_prog), exe.memory_bytes = word(4 + n_prog);
+        const size_t n_data = word(5 + n_prog), off = 4 * (6 + n_prog);
+        if (off + n_data > raw.size()) throw zkhip_vm::Error("exe data truncated");
+        exe.data.assign(raw.begin() + (long)off, raw.begin() + (long)(off + n_data));
+        zkhip_vm::StdIn in;
+        if (std::string(argv[3]) != "-") in.bytes = read_file(argv[3]);
+        const uint64_t max_cost = argc > 5 ? strtoull(argv[5], nullptr, 10) : 0;
+        zkhip_vm::ExecRecords rec;
+        const zkhip_vm::ExecutionResult r = zkhip_vm::execute_guest(exe, in, max_cost, &rec);
+        const std::string out = argv[4];
+        if (out != "-") {
+            write_u32(out + "/pc_index.u32", rec.pc_index);
+            write_u32(out + "/alu_op.u32", rec.alu_op), write_u32(out + "/alu_b.u32", rec.alu_b), write_u32(out + "/alu_c.u32", rec.alu_c);
+            write_u32(out + "/lt_op.u32", rec.lt_op), write_u32(out + "/lt_b.u32", rec.lt_b), write_u32(out + "/lt_c.u32", rec.lt_c);
+            write_u32(out + "/mul_b.u32", rec.mul_b), write_u32(out + "/mul_c.u32", rec.mul_c);
+        }
+        std::ostringstream js;
+        js << "{\"total_cycle\": " << r.total_cycle << ", \"public_values\": [";
+        for (size_t i = 0; i < r.public_values.size(); i++) js << (i ? ", " : "") << (unsigned)r.public_values[i];
+        js << "], \"records\": {\"executed\": " << rec.pc_index.size() << ", \"alu\": " << rec.alu_op.size() << ", \"lt\": " << rec.lt_op.size()
+           << ", \"mul\": " << rec.mul_b.size() << ", \"shift\": " << rec.n_shift << ", \"branch\": " << rec.n_branch << ", \"jump\": " << rec.n_jump
+           << ", \"load_store\": " << rec.n_load_store << ", \"mulh\": " << rec.n_mulh << ", \"divrem\": " << rec.n_divrem
+           << ", \"lui_auipc\": " << rec.n_lui_auipc << ", \"ecall\": " << rec.n_ecall << "}, \"trace_cells\": "
+           << zkhip_vm::trace_cells(rec, exe.program.size()) << "}";
+        std::cout << js.str() << std::endl;
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "vm_cli: %s\n", e.what());
+        return 1;
+    }
+}
