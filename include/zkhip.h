@@ -167,6 +167,19 @@ int zkhip_program_freq_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc_index, size
 int zkhip_exec_frame_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc_index, size_t n, const uint32_t *d_program, size_t n_program,
                               unsigned log_height, uint32_t *d_trace);
 
+/* Per-access rows of the offline memory-checking argument (OpenVM's memory bus; the access adapters of its chips): record i =
+ * one access of a 16-bit memory cell -- (d_addr_space[i], d_pointer[i]) the cell, (d_prev_data[i], d_prev_ts[i]) the state the
+ * previous access left (the initial state with timestamp 0 for the first), (d_data[i], d_ts[i]) the state this access leaves,
+ * d_is_read[i] = 1 for reads (data == prev_data) -- plain integers, as include/zkhip_vm.hpp ExecRecords::acc_* holds them.  Fills
+ * d_trace (ZKHIP_MEMORY_ACCESS_WIDTH = 10 columns, stride 2^log_height, Montgomery): as | ptr | prev_data | prev_ts | data | ts |
+ * is_read | is_valid | gap_lo | gap_hi with ts - prev_ts - 1 = gap_lo + 2^16 gap_hi; rows >= n zero.  With the boundary chip
+ * (zkhip_memory_boundary_tracegen over the touched cells) the memory bus balances exactly when the log is a consistent history.
+ * ZKHIP_ERR_INVALID for a value above 16 bits, ts <= prev_ts, or a read that changes its cell.  AIR: air.py memory_access_air(). */
+#define ZKHIP_MEMORY_ACCESS_WIDTH 10
+int zkhip_memory_access_tracegen(zkhip_ctx *ctx, const uint32_t *d_addr_space, const uint32_t *d_pointer, const uint32_t *d_prev_data,
+                                 const uint32_t *d_prev_ts, const uint32_t *d_data, const uint32_t *d_ts, const uint32_t *d_is_read, size_t n,
+                                 unsigned log_height, uint32_t *d_trace);
+
 /* Trace of an INSTRUCTION chip from execution records: the core of OpenVM's RV32 base ALU chip (rv32im BaseAluCoreAir: ADD, SUB,
  * XOR, OR, AND on 4 x 8-bit limbs; the `rv32i` extension of crates/circuits/chunk-circuit/openvm.toml).  Record i = (d_opcode[i] in
  * 0..4 = add, sub, xor, or, and; d_b[i], d_c[i]: the 32-bit operands) -- plain integers.  Fills d_trace (ZKHIP_RV32_ALU_WIDTH = 18

@@ -18,7 +18,9 @@
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace zkhip_vm {
@@ -48,6 +50,14 @@ struct ExecRecords {
     std::vector<uint32_t> lt_op, lt_b, lt_c;          // 0 slt 1 sltu
     std::vector<uint32_t> mul_b, mul_c;               // mul (low word)
     uint64_t n_shift = 0, n_branch = 0, n_jump = 0, n_load_store = 0, n_mulh = 0, n_divrem = 0, n_lui_auipc = 0, n_ecall = 0;
+    // Memory log for the offline memory-checking argument (OpenVM's memory bus): state is kept in 16-bit CELLS -- address space
+    // 1 = registers (cell 2 i + half of x_i), 2 = read-write memory (cell = halfword index from data_base) -- so that a cell's
+    // value is a field element.  One entry per cell access, in execution order, timestamps 1, 2, 3, ...:
+    //   (as, ptr, prev_data, prev_ts) is what the access consumes, (as, ptr, data, ts) what it leaves; reads have data == prev_data.
+    std::vector<uint32_t> acc_as, acc_ptr, acc_prev_data, acc_prev_ts, acc_data, acc_ts, acc_is_read;
+    // and per touched cell, once the run is over: initial value (before the first access), final value, timestamp of the last
+    // access -- the records of the memory boundary chip (zkhip_memory_boundary_tracegen)
+    std::vector<uint32_t> bnd_as, bnd_ptr, bnd_initial, bnd_final, bnd_final_ts;
 };
 
 constexpr unsigned NUM_PUBLIC_VALUE_BYTES = 32;
@@ -85,6 +95,17 @@ public:
             if (max_cost && rec && (instret_ & 1023u) == 0 && trace_cells(*rec, exe_.program.size()) > max_cost) return false;
             step(rec);
         }
+        if (rec) {  // boundary records, sorted by (address space, pointer)
+            std::vector<uint64_t> keys;
+            keys.reserve(cells_.size());
+            for (const auto& kv : cells_) keys.push_back(kv.first);
+            std::sort(keys.begin(), keys.end());
+            for (uint64_t k : keys) {
+                const Cell& c = cells_[k];
+                rec->bnd_as.push_back((uint32_t)(k >> 32)), rec->bnd_ptr.push_back((uint32_t)k);
+                rec->bnd_initial.push_back(c.initial), rec->bnd_final.push_back(c.data), rec->bnd_final_ts.push_back(c.ts);
+            }
+        }
         return true;
     }
     uint64_t instret() const { return instret_; }
@@ -100,28 +121,68 @@ private:
     uint64_t instret_ = 0;
     size_t in_pos_ = 0;
     bool done_ = false;
+    struct Cell {
+        uint32_t initial, data, ts;
+    };
+    std::unordered_map<uint64_t, Cell> cells_;
+    uint32_t clock_ = 0;
 
+    // one access of a 16-bit cell: `write` replaces its value by `value`
+    void touch(ExecRecords* rec, uint32_t as, uint32_t ptr, uint32_t current, bool write, uint32_t value) {
+        if (!rec) return;
+        const uint64_t key = ((uint64_t)as << 32) | ptr;
+        auto it = cells_.find(key);
+        if (it == cells_.end()) it = cells_.emplace(key, Cell{current, current, 0}).first;
+        Cell& c = it->second;
+        if (++clock_ == 0) throw Error("memory clock overflow");
+        rec->acc_as.push_back(as), rec->acc_ptr.push_back(ptr), rec->acc_prev_data.push_back(c.data), rec->acc_prev_ts.push_back(c.ts);
+        c.data = write ? value : c.data, c.ts = clock_;
+        rec->acc_data.push_back(c.data), rec->acc_ts.push_back(clock_), rec->acc_is_read.push_back(write ? 0u : 1u);
+    }
+    uint32_t reg_read(ExecRecords* rec, unsigned i) {
+        touch(rec, 1, 2 * i, x_[i] & 0xffffu, false, 0), touch(rec, 1, 2 * i + 1, x_[i] >> 16, false, 0);
+        return x_[i];
+    }
+    void reg_write(ExecRecords* rec, unsigned i, uint32_t v) {
+        if (i == 0) v = 0;  // x0 is a cell that only ever holds zero
+        touch(rec, 1, 2 * i, x_[i] & 0xffffu, true, v & 0xffffu), touch(rec, 1, 2 * i + 1, x_[i] >> 16, true, v >> 16);
+        x_[i] = v;
+    }
     uint8_t* at(uint32_t addr, unsigned n) {
         const uint64_t off = (uint64_t)addr - exe_.data_base;
         if (addr < exe_.data_base || off + n > mem_.size()) throw Error("memory access out of range at pc " + std::to_string(pc_));
         return mem_.data() + off;
     }
-    uint32_t load(uint32_t addr, unsigned n) {
+    uint16_t cell_value(uint32_t cidx) const {
+        uint16_t v;
+        memcpy(&v, mem_.data() + 2 * (size_t)cidx, 2);
+        return v;
+    }
+    uint32_t load(ExecRecords* rec, uint32_t addr, unsigned n) {
         if (addr % n) throw Error("misaligned load");
         uint32_t v = 0;
         memcpy(&v, at(addr, n), n);
+        const uint32_t first = (addr - exe_.data_base) >> 1, last = (addr - exe_.data_base + n - 1) >> 1;
+        for (uint32_t c = first; c <= last; c++) touch(rec, 2, c, cell_value(c), false, 0);
         return v;
     }
-    void store(uint32_t addr, uint32_t v, unsigned n) {
+    void store(ExecRecords* rec, uint32_t addr, uint32_t v, unsigned n) {
         if (addr % n) throw Error("misaligned store");
-        memcpy(at(addr, n), &v, n);
+        uint8_t* p = at(addr, n);
+        const uint32_t first = (addr - exe_.data_base) >> 1, last = (addr - exe_.data_base + n - 1) >> 1;
+        const uint16_t before[2] = {cell_value(first), cell_value(last)};
+        memcpy(p, &v, n);
+        for (uint32_t c = first; c <= last; c++) touch(rec, 2, c, before[c - first], true, cell_value(c));  // a byte store rewrites its cell
     }
     void step(ExecRecords* rec) {
         const uint64_t idx64 = ((uint64_t)pc_ - exe_.pc_base) / 4;
         if (pc_ < exe_.pc_base || (pc_ & 3u) || idx64 >= exe_.program.size()) throw Error("pc outside the program: " + std::to_string(pc_));
         const uint32_t w = exe_.program[idx64];
         const uint32_t op = w & 0x7f, rd = (w >> 7) & 31, f3 = (w >> 12) & 7, rs1 = (w >> 15) & 31, rs2 = (w >> 20) & 31, f7 = w >> 25;
-        const uint32_t a = x_[rs1], b = x_[rs2];
+        // registers the instruction reads, in the order rs1, rs2 (logged for the memory argument)
+        const bool uses_rs1 = op == 0x67 || op == 0x63 || op == 0x03 || op == 0x23 || op == 0x13 || op == 0x33;
+        const bool uses_rs2 = op == 0x63 || op == 0x23 || op == 0x33;
+        const uint32_t a = uses_rs1 ? reg_read(rec, rs1) : 0, b = uses_rs2 ? reg_read(rec, rs2) : 0;
         const int32_t imm_i = (int32_t)w >> 20;
         const int32_t imm_s = (((int32_t)w >> 25) << 5) | (int32_t)((w >> 7) & 31);
         const int32_t imm_b = (((int32_t)w >> 31) << 12) | (int32_t)(((w >> 7) & 1) << 11) | (int32_t)(((w >> 25) & 63) << 5) | (int32_t)(((w >> 8) & 15) << 1);
@@ -165,11 +226,11 @@ private:
             case 0x03: {
                 const uint32_t addr = a + (uint32_t)imm_i;
                 switch (f3) {
-                    case 0: val = (uint32_t)(int32_t)(int8_t)load(addr, 1); break;
-                    case 1: val = (uint32_t)(int32_t)(int16_t)load(addr, 2); break;
-                    case 2: val = load(addr, 4); break;
-                    case 4: val = load(addr, 1); break;
-                    case 5: val = load(addr, 2); break;
+                    case 0: val = (uint32_t)(int32_t)(int8_t)load(rec, addr, 1); break;
+                    case 1: val = (uint32_t)(int32_t)(int16_t)load(rec, addr, 2); break;
+                    case 2: val = load(rec, addr, 4); break;
+                    case 4: val = load(rec, addr, 1); break;
+                    case 5: val = load(rec, addr, 2); break;
                     default: throw Error("illegal load");
                 }
                 wr = true;
@@ -179,7 +240,7 @@ private:
             case 0x23: {
                 const uint32_t addr = a + (uint32_t)imm_s;
                 if (f3 > 2) throw Error("illegal store");
-                store(addr, b, 1u << f3);
+                store(rec, addr, b, 1u << f3);
                 if (rec) rec->n_load_store++;
                 break;
             }
@@ -233,18 +294,19 @@ private:
             case 0x73: {
                 if (w != 0x00000073u) throw Error("unsupported system instruction");
                 if (rec) rec->n_ecall++;
-                const uint32_t call = x_[17];
+                const uint32_t call = reg_read(rec, 17);
                 if (call == 93) {
-                    done_ = true, exit_code_ = x_[10];
+                    done_ = true, exit_code_ = reg_read(rec, 10);
                 } else if (call == 1) {
-                    const uint64_t off = 4ull * x_[11];
+                    const uint32_t word = reg_read(rec, 10);
+                    const uint64_t off = 4ull * reg_read(rec, 11);
                     if (off + 4 > pv_.size()) throw Error("public value index out of range");
-                    memcpy(pv_.data() + off, &x_[10], 4);
+                    memcpy(pv_.data() + off, &word, 4);
                 } else if (call == 2) {
                     if (in_pos_ + 4 > in_.bytes.size()) throw Error("input stream exhausted");
                     memcpy(&val, in_.bytes.data() + in_pos_, 4);
                     in_pos_ += 4;
-                    x_[10] = val;
+                    reg_write(rec, 10, val);
                 } else {
                     throw Error("unknown environment call " + std::to_string(call));
                 }
@@ -252,7 +314,7 @@ private:
             }
             default: throw Error("illegal instruction " + std::to_string(w) + " at pc " + std::to_string(pc_));
         }
-        if (wr && rd) x_[rd] = val;
+        if (wr) reg_write(rec, rd, val);
         pc_ = next;
         instret_++;
     }

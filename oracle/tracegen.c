@@ -227,3 +227,24 @@ size_t ora_rv32_lt_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t
     }
     return bad;
 }
+
+/* Memory access chip (zkhip_memory_access_tracegen): 10 columns as | ptr | prev_data | prev_ts | data | ts | is_read | is_valid | gap_lo |
+ * gap_hi, canonical.  Returns the number of refused records. */
+size_t ora_memory_access_trace(const uint32_t *as, const uint32_t *ptr, const uint32_t *prev_data, const uint32_t *prev_ts, const uint32_t *data,
+                               const uint32_t *ts, const uint32_t *is_read, size_t n, unsigned log_height, uint32_t *trace) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 10; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        if (as[r] >= ORA_P || ptr[r] >= ORA_P || prev_data[r] > 0xffff || data[r] > 0xffff || ts[r] >= ORA_P || prev_ts[r] >= ts[r] || is_read[r] > 1 ||
+            (is_read[r] && data[r] != prev_data[r])) {
+            bad++;
+            continue;
+        }
+        const uint32_t gap = ts[r] - prev_ts[r] - 1;
+        const uint32_t row[10] = {as[r], ptr[r], prev_data[r], prev_ts[r], data[r], ts[r], is_read[r], 1, gap & 0xffff, gap >> 16};
+        for (size_t q = 0; q < 10; q++) trace[q * N + r] = row[q];
+    }
+    return bad;
+}

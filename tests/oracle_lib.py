@@ -80,6 +80,16 @@ def rv32_alu_trace(opc, bs, cs, log_height, xor_counts=None):
     return tr, xc, int(bad)
 
 
+def memory_access_trace(as_, ptr, prev_data, prev_ts, data, ts, is_read, log_height):
+    cols = [np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (as_, ptr, prev_data, prev_ts, data, ts, is_read)]
+    tr = np.zeros((10, 1 << log_height), np.uint32)
+    l = lib()
+    l.ora_memory_access_trace.restype = C.c_size_t
+    l.ora_memory_access_trace.argtypes = [u32p_t()] * 7 + [C.c_size_t, C.c_uint, u32p_t()]
+    bad = l.ora_memory_access_trace(*[p32(c) for c in cols], cols[0].size, log_height, p32(tr))
+    return tr, int(bad)
+
+
 def rv32_lt_trace(opc, bs, cs, log_height, range_counts=None):
     opc, bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, bs, cs))
     tr = np.zeros((18, 1 << log_height), np.uint32)

@@ -113,15 +113,48 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
     mem[:len(data)] = data
     pvs = bytearray(32)
     pc, n, pos = pc_base, 0, 0
-    rec = dict(pc_index=[], alu=[], lt=[], mul=[], shift=0, branch=0, jump=0, load_store=0, mulh=0, divrem=0, lui_auipc=0, ecall=0)
+    rec = dict(pc_index=[], alu=[], lt=[], mul=[], shift=0, branch=0, jump=0, load_store=0, mulh=0, divrem=0, lui_auipc=0, ecall=0,
+               acc=[], bnd=[])
     s32 = lambda v: sx(v, 32)  # noqa: E731
+    # memory log over 16-bit cells: address space 1 = registers (cell 2 i + half), 2 = memory (halfword index); entries
+    # (as, ptr, prev_data, prev_ts, data, ts, is_read), timestamps 1, 2, ...
+    cells, clock = {}, [0]
+
+    def touch(as_, ptr, current, write, value):
+        c = cells.setdefault((as_, ptr), [current, current, 0])   # initial, data, ts
+        clock[0] += 1
+        prev = (c[1], c[2])
+        if write:
+            c[1] = value
+        c[2] = clock[0]
+        rec["acc"].append((as_, ptr, prev[0], prev[1], c[1], clock[0], 0 if write else 1))
+
+    def rr(i):
+        touch(1, 2 * i, x[i] & 0xFFFF, False, 0)
+        touch(1, 2 * i + 1, x[i] >> 16, False, 0)
+        return x[i]
+
+    def rw(i, v):
+        v = 0 if i == 0 else v & M32
+        touch(1, 2 * i, x[i] & 0xFFFF, True, v & 0xFFFF)
+        touch(1, 2 * i + 1, x[i] >> 16, True, v >> 16)
+        x[i] = v
+
+    def cellv(c):
+        return int.from_bytes(mem[2 * c:2 * c + 2], "little")
+
+    def finish():
+        for (as_, ptr) in sorted(cells):
+            c = cells[(as_, ptr)]
+            rec["bnd"].append((as_, ptr, c[0], c[1], c[2]))
     while True:
         assert n < max_instr
         idx = (pc - pc_base) // 4
         w = program[idx]
         rec["pc_index"].append(idx)
         op, rd, f3, rs1, rs2, f7 = w & 0x7F, (w >> 7) & 31, (w >> 12) & 7, (w >> 15) & 31, (w >> 20) & 31, w >> 25
-        a, b = x[rs1], x[rs2]
+        a = rr(rs1) if op in (0x67, 0x63, 0x03, 0x23, 0x13, 0x33) else 0
+        b = rr(rs2) if op in (0x63, 0x23, 0x33) else 0
         imm_i = sx(w >> 20, 12)
         nxt, val, wr = pc + 4, 0, False
 
@@ -162,6 +195,8 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
             o = addr - data_base
             size = {0: 1, 1: 2, 2: 4, 4: 1, 5: 2}[f3]
             v = int.from_bytes(mem[o:o + size], "little")
+            for c in range(o >> 1, ((o + size - 1) >> 1) + 1):
+                touch(2, c, cellv(c), False, 0)
             val = (sx(v, 8 * size) & M32) if f3 in (0, 1) else v
             wr = True
             rec["load_store"] += 1
@@ -169,7 +204,11 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
             imm = sx(((w >> 25) << 5) | ((w >> 7) & 31), 12)
             o = ((a + imm) & M32) - data_base
             size = 1 << f3
+            cs = list(range(o >> 1, ((o + size - 1) >> 1) + 1))
+            before = [cellv(c) for c in cs]
             mem[o:o + size] = (b & ((1 << (8 * size)) - 1)).to_bytes(size, "little")
+            for c, bv in zip(cs, before):
+                touch(2, c, bv, True, cellv(c))
             rec["load_store"] += 1
         elif op == 0x13:
             c = imm_i & M32
@@ -234,21 +273,25 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                     val = alu(4, a, b)
         elif op == 0x73:
             rec["ecall"] += 1
-            call = x[17]
+            call = rr(17)
             if call == 93:
+                code = rr(10)
                 n += 1
-                return dict(instret=n, pvs=bytes(pvs), exit_code=x[10], records=rec)
+                finish()
+                return dict(instret=n, pvs=bytes(pvs), exit_code=code, records=rec)
             if call == 1:
-                pvs[4 * x[11]:4 * x[11] + 4] = struct.pack("<I", x[10])
+                word = rr(10)
+                k = rr(11)
+                pvs[4 * k:4 * k + 4] = struct.pack("<I", word)
             elif call == 2:
-                x[10] = struct.unpack_from("<I", stdin, pos)[0]
+                rw(10, struct.unpack_from("<I", stdin, pos)[0])
                 pos += 4
             else:
                 raise ValueError("ecall %d" % call)
         else:
             raise ValueError("illegal instruction %08x" % w)
-        if wr and rd:
-            x[rd] = val & M32
+        if wr:
+            rw(rd, val)
         pc = nxt
         n += 1
 

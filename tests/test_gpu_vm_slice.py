@@ -90,3 +90,62 @@ def test_guest_execution_to_proof(zk, ora, tmp_path, which, seed):
     assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
     assert proof == ora.stark_prove(PARAMS, airs).tobytes()
     pk.close()
+
+
+def _memory_chips(zk, ora, rec, tamper=None):
+    """Device + oracle traces of the memory access chip, the boundary chip and the 16-bit range table they send to."""
+    dev = zk.device
+    as_dev = lambda v: torch.from_numpy(np.ascontiguousarray(v).view(np.int32)).to(dev)  # noqa: E731
+    acc = {k: rec["acc_" + k].copy() for k in ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read")}
+    if tamper is not None:
+        acc["data"][tamper] ^= 1          # a write that leaves another value than the next access of the cell consumes
+    n, nb = len(acc["ts"]), len(rec["bnd_ptr"])
+    la, lb = log2_ceil(n), log2_ceil(nb)
+    order = ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read")
+    d_acc = zk.memory_access_tracegen(*[as_dev(acc[k]) for k in order], la)
+    exp_acc, bad = ora.memory_access_trace(*[acc[k] for k in order], la)
+    assert bad == 0 and (zk.download(d_acc).reshape(10, -1) == exp_acc).all()
+    d_bnd = zk.memory_boundary_tracegen(as_dev(rec["bnd_as"]), as_dev(rec["bnd_ptr"]), zk.upload(rec["bnd_initial"]), zk.upload(rec["bnd_final"]),
+                                        as_dev(rec["bnd_final_ts"]), 2, 29, lb)
+    exp_bnd, bad = ora.memory_boundary_trace(rec["bnd_as"], rec["bnd_ptr"], rec["bnd_initial"], rec["bnd_final"], rec["bnd_final_ts"], 2, 29, lb)
+    assert bad == 0 and (zk.download(d_bnd).reshape(8, -1) == exp_bnd).all()
+    # the range table's multiplicities, counted on the device from the requesting columns (valid rows only)
+    NA, NB = 1 << la, 1 << lb
+    d_rng = None
+    for col in (8, 9, 4):
+        d_rng = zk.range_counts_tracegen(d_acc[col * NA: col * NA + n], 16, t_counts=d_rng, accumulate=d_rng is not None)
+    for col in (6, 7):
+        d_rng = zk.range_counts_tracegen(d_bnd[col * NB: col * NB + nb], 16, t_counts=d_rng, accumulate=True)
+    cnt = np.zeros(1 << 16, np.int64)
+    for v in (exp_acc[8][:n], exp_acc[9][:n], exp_acc[4][:n], exp_bnd[6][:nb], exp_bnd[7][:nb]):
+        cnt += np.bincount(v.astype(np.int64), minlength=1 << 16)
+    assert (zk.download(d_rng) == (cnt % P).astype(np.uint32)).all()
+    airs = [dict(program=air.memory_access_air().program(), log_height=la, width=10, n_pvs=0, trace=exp_acc, pvs=NOPV),
+            dict(program=air.memory_boundary_air().program(), log_height=lb, width=8, n_pvs=0, trace=exp_bnd, pvs=NOPV),
+            dict(program=air.range_table_air(5).program(), log_height=16, width=1, n_pvs=0, trace=(cnt % P).astype(np.uint32).reshape(1, -1), pvs=NOPV,
+                 prep=np.arange(1 << 16, dtype=np.uint32).reshape(1, -1))]
+    return airs, [d_acc, d_bnd, d_rng]
+
+
+@pytest.mark.parametrize("which,seed", [("mixed", 9), ("fib", 40)])
+def test_memory_consistency_of_the_execution(zk, ora, tmp_path, which, seed):
+    """The execution's memory log (register file and read-write memory as 16-bit cells) through the offline memory-checking
+    argument: access chip + boundary chip + range table, traces generated on the device, balance the memory bus exactly because
+    the log is a consistent history -- proof bytes == oracle, verifier accepts; one tampered write and the verifier refuses."""
+    words = mixed_program() if which == "mixed" else fib_program()
+    r, js, rec = run_cli(tmp_path, words, int(seed).to_bytes(4, "little"))
+    assert r.returncode == 0, r.stderr
+    assert air.check_trace(air.memory_access_air().program(), ora.memory_access_trace(
+        *[rec["acc_" + k] for k in ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read")], log2_ceil(len(rec["acc_ts"])))[0], NOPV) == []
+    airs, d_traces = _memory_chips(zk, ora, rec)
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    pvs = [NOPV] * 3
+    proof = pk.prove(d_traces, pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    # a write whose value is not what the next access of that cell consumes: the buses no longer balance
+    k = int(np.nonzero(rec["acc_is_read"] == 0)[0][3])
+    bad_airs, bad_traces = _memory_chips(zk, ora, rec, tamper=k)
+    bad_proof = pk.prove(bad_traces, pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, bad_proof) != 0
+    pk.close()

@@ -69,9 +69,22 @@ def run_cli(tmp_path, program, stdin=b"", max_cost=0, data=b""):
     r = subprocess.run([VM, "exec", str(exe), str(inp), str(out)] + ([str(max_cost)] if max_cost else []), capture_output=True, text=True)
     rec = {}
     if r.returncode == 0:
-        for name in ("pc_index", "alu_op", "alu_b", "alu_c", "lt_op", "lt_b", "lt_c", "mul_b", "mul_c"):
+        for name in ("pc_index", "alu_op", "alu_b", "alu_c", "lt_op", "lt_b", "lt_c", "mul_b", "mul_c", "acc_as", "acc_ptr", "acc_prev_data",
+                     "acc_prev_ts", "acc_data", "acc_ts", "acc_is_read", "bnd_as", "bnd_ptr", "bnd_initial", "bnd_final", "bnd_final_ts"):
             rec[name] = np.fromfile(out / (name + ".u32"), dtype=np.uint32)
     return r, (json.loads(r.stdout) if r.returncode == 0 else None), rec
+
+
+def check_memory_log(acc, bnd):
+    """The offline memory-checking property itself: replaying the log from the boundary's initial values, every access consumes
+    exactly the state the previous access of its cell left, and the last state of every cell is the boundary's final one."""
+    state = {(a, p): (init, 0) for a, p, init, fin, ts in bnd}
+    for k, (a, p, pd, pts, d, ts, is_read) in enumerate(acc):
+        assert ts == k + 1 and state[(a, p)] == (pd, pts) and pts < ts and d < 65536
+        if is_read:
+            assert d == pd
+        state[(a, p)] = (d, ts)
+    assert all(state[(a, p)] == (fin, ts) for a, p, init, fin, ts in bnd)
 
 
 def check_against_model(js, rec, model):
@@ -85,6 +98,12 @@ def check_against_model(js, rec, model):
     for k in ("shift", "branch", "jump", "load_store", "mulh", "divrem", "lui_auipc", "ecall"):
         assert js["records"][k] == m[k], k
     assert js["records"]["executed"] == model["instret"]
+    # the memory log and the boundary records
+    acc = list(zip(*(rec["acc_" + k].tolist() for k in ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read"))))
+    assert acc == m["acc"] and js["records"]["memory_accesses"] == len(acc)
+    bnd = list(zip(*(rec["bnd_" + k].tolist() for k in ("as", "ptr", "initial", "final", "final_ts"))))
+    assert bnd == m["bnd"] and js["records"]["cells_touched"] == len(bnd)
+    check_memory_log(acc, bnd)
 
 
 @pytest.mark.parametrize("n", [0, 1, 10, 47, 1000])

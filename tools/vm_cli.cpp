@@ -3,7 +3,8 @@
 //   vm_cli exec <exe.bin> <stdin.bin | -> <out_dir | -> [max_cost]
 // exe.bin: u32 words  [0x58455A4B "KZEX", pc_base, n_program, program..., data_base, memory_bytes, n_data_bytes, data bytes...]
 // Prints one JSON line {"total_cycle", "public_values", "records": {...counts}, "trace_cells"}; with an out_dir, writes
-// pc_index.u32, alu_{op,b,c}.u32, lt_{op,b,c}.u32, mul_{b,c}.u32 (raw little-endian arrays).
+// pc_index.u32, alu_{op,b,c}.u32, lt_{op,b,c}.u32, mul_{b,c}.u32, the memory log acc_{as,ptr,prev_data,prev_ts,data,ts,is_read}.u32 and
+// the boundary records bnd_{as,ptr,initial,final,final_ts}.u32 (raw little-endian arrays).
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -55,6 +56,11 @@ int main(int argc, char** argv) {
             write_u32(out + "/alu_op.u32", rec.alu_op), write_u32(out + "/alu_b.u32", rec.alu_b), write_u32(out + "/alu_c.u32", rec.alu_c);
             write_u32(out + "/lt_op.u32", rec.lt_op), write_u32(out + "/lt_b.u32", rec.lt_b), write_u32(out + "/lt_c.u32", rec.lt_c);
             write_u32(out + "/mul_b.u32", rec.mul_b), write_u32(out + "/mul_c.u32", rec.mul_c);
+            write_u32(out + "/acc_as.u32", rec.acc_as), write_u32(out + "/acc_ptr.u32", rec.acc_ptr);
+            write_u32(out + "/acc_prev_data.u32", rec.acc_prev_data), write_u32(out + "/acc_prev_ts.u32", rec.acc_prev_ts);
+            write_u32(out + "/acc_data.u32", rec.acc_data), write_u32(out + "/acc_ts.u32", rec.acc_ts), write_u32(out + "/acc_is_read.u32", rec.acc_is_read);
+            write_u32(out + "/bnd_as.u32", rec.bnd_as), write_u32(out + "/bnd_ptr.u32", rec.bnd_ptr), write_u32(out + "/bnd_initial.u32", rec.bnd_initial);
+            write_u32(out + "/bnd_final.u32", rec.bnd_final), write_u32(out + "/bnd_final_ts.u32", rec.bnd_final_ts);
         }
         std::ostringstream js;
         js << "{\"total_cycle\": " << r.total_cycle << ", \"public_values\": [";
@@ -62,7 +68,8 @@ int main(int argc, char** argv) {
         js << "], \"records\": {\"executed\": " << rec.pc_index.size() << ", \"alu\": " << rec.alu_op.size() << ", \"lt\": " << rec.lt_op.size()
            << ", \"mul\": " << rec.mul_b.size() << ", \"shift\": " << rec.n_shift << ", \"branch\": " << rec.n_branch << ", \"jump\": " << rec.n_jump
            << ", \"load_store\": " << rec.n_load_store << ", \"mulh\": " << rec.n_mulh << ", \"divrem\": " << rec.n_divrem
-           << ", \"lui_auipc\": " << rec.n_lui_auipc << ", \"ecall\": " << rec.n_ecall << "}, \"trace_cells\": "
+           << ", \"lui_auipc\": " << rec.n_lui_auipc << ", \"ecall\": " << rec.n_ecall << ", \"memory_accesses\": " << rec.acc_ts.size() << ", \"cells_touched\": " << rec.bnd_ptr.size()
+           << "}, \"trace_cells\": "
            << zkhip_vm::trace_cells(rec, exe.program.size()) << "}";
         std::cout << js.str() << std::endl;
         return 0;

@@ -100,6 +100,7 @@ def load_library():
         "zkhip_rv32_lt_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_mul_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_memory_boundary_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint, C.c_uint, vp]),
+        "zkhip_memory_access_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_program_freq_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
         "zkhip_exec_frame_tracegen": (C.c_int, [vp, vp, sz, vp, sz, C.c_uint, vp]),
         "zkhip_merkle_commit": (C.c_int, [vp, C.POINTER(_Matrix), sz, C.POINTER(vp), u32p]),
@@ -315,6 +316,15 @@ class Context:
         out = torch.empty(13 << log_height, dtype=torch.int32, device=self.device)
         self._check(self.lib.zkhip_rv32_mul_tracegen(self.h, C.c_void_p(t_b.data_ptr()), C.c_void_p(t_c.data_ptr()), t_b.numel(), log_height,
                                                      C.c_void_p(out.data_ptr()), C.c_void_p(t_tuple_counts.data_ptr()), size_x, size_y))
+        return out
+
+    def memory_access_tracegen(self, t_as, t_ptr, t_prev_data, t_prev_ts, t_data, t_ts, t_is_read, log_height):
+        """10-column trace of the memory access chip from the memory log (int32 tensors of plain integers, one entry per cell access)."""
+        import torch
+
+        out = torch.empty(10 << log_height, dtype=torch.int32, device=self.device)
+        args = [C.c_void_p(t.data_ptr()) for t in (t_as, t_ptr, t_prev_data, t_prev_ts, t_data, t_ts, t_is_read)]
+        self._check(self.lib.zkhip_memory_access_tracegen(self.h, *args, t_as.numel(), log_height, C.c_void_p(out.data_ptr())))
         return out
 
     def program_freq_tracegen(self, t_pc_index, log_height):

@@ -742,6 +742,29 @@ def rv32_mul_core_air(bus=6):
     return b
 
 
+MEMORY_ACCESS_WIDTH = 10
+
+
+def memory_access_air(range_bus=5, memory_bus=1):
+    """One row per access of a 16-bit memory cell (the access side of OpenVM's offline memory checking; memory_boundary_air() is
+    the other side): columns as | ptr | prev_data | prev_ts | data | ts | is_read | is_valid | gap_lo | gap_hi.  A valid row
+    receives (as, ptr, prev_data, prev_ts) and sends (as, ptr, data, ts) on the memory bus; a read leaves the value as it was;
+    time moves forward: ts - prev_ts - 1 = gap_lo + 2^16 gap_hi, the limbs and the cell value range-checked to 16 bits."""
+    b = AirBuilder(MEMORY_ACCESS_WIDTH, 0)
+    as_, ptr, pd, pts, d, ts, rd, ok, lo, hi = (b.var(i) for i in range(10))
+    b.assert_zero(ok * (ok - 1))
+    b.assert_zero(rd * (rd - 1))
+    b.assert_zero((1 - ok) * rd)
+    b.assert_zero(rd * (d - pd))
+    b.assert_zero(ok * (ts - pts - 1 - lo - hi * (1 << 16)))
+    b.push_interaction(range_bus, [lo], ok, "send")
+    b.push_interaction(range_bus, [hi], ok, "send")
+    b.push_interaction(range_bus, [d], ok, "send")
+    b.push_interaction(memory_bus, [as_, ptr, pd, pts], ok, "receive")
+    b.push_interaction(memory_bus, [as_, ptr, d, ts], ok, "send")
+    return b
+
+
 PROGRAM_FIELDS = 9
 PROGRAM_BUS = 8
 

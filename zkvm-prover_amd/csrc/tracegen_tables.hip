@@ -446,3 +446,54 @@ extern "C" int zkhip_rv32_lt_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, 
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_lt_tracegen (opcode > 1)");
 }
+
+// ---- memory access chip: the offline memory-checking argument's per-access rows ---------------------------------------------------
+// One row per cell access of the execution's memory log (include/zkhip_vm.hpp ExecRecords::acc_*): the row RECEIVES the state the
+// previous access of the cell left, (as, ptr, prev_data, prev_ts), and SENDS the state it leaves, (as, ptr, data, ts), on the memory
+// bus; the boundary chip (zkhip_memory_boundary_tracegen) sends every touched cell's initial state and receives its final one, so the
+// bus balances exactly when the log is a consistent history of the memory.  Time moves forward: ts - prev_ts - 1 = gap_lo + 2^16
+// gap_hi with both limbs (and the 16-bit cell value) sent to the range checker.  Columns (ZKHIP_MEMORY_ACCESS_WIDTH = 10):
+//   as | ptr | prev_data | prev_ts | data | ts | is_read | is_valid | gap_lo | gap_hi
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_memory_access(const uint32_t* __restrict__ as, const uint32_t* __restrict__ ptr,
+                                                       const uint32_t* __restrict__ prev_data, const uint32_t* __restrict__ prev_ts,
+                                                       const uint32_t* __restrict__ data, const uint32_t* __restrict__ ts,
+                                                       const uint32_t* __restrict__ is_read, size_t n, size_t N, uint32_t* __restrict__ trace,
+                                                       uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_MEMORY_ACCESS_WIDTH] = {};
+    if (r < n) {
+        const uint32_t pd = prev_data[r], pt = prev_ts[r], d = data[r], t = ts[r], rd = is_read[r];
+        if (as[r] >= P || ptr[r] >= P || pd >= 65536u || d >= 65536u || t >= P || pt >= t || rd > 1u || (rd && d != pd)) {
+            atomicAdd(bad, 1u);
+        } else {
+            const uint32_t gap = t - pt - 1u;
+            col[0] = to_monty(as[r]), col[1] = to_monty(ptr[r]), col[2] = to_monty(pd), col[3] = to_monty(pt), col[4] = to_monty(d);
+            col[5] = to_monty(t), col[6] = rd ? MONTY_ONE : 0u, col[7] = MONTY_ONE, col[8] = to_monty(gap & 0xffffu), col[9] = to_monty(gap >> 16);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_MEMORY_ACCESS_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_memory_access_tracegen(zkhip_ctx* ctx, const uint32_t* d_addr_space, const uint32_t* d_pointer, const uint32_t* d_prev_data,
+                                            const uint32_t* d_prev_ts, const uint32_t* d_data, const uint32_t* d_ts, const uint32_t* d_is_read,
+                                            size_t n, unsigned log_height, uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || log_height > 27 || (n && (!d_addr_space || !d_pointer || !d_prev_data || !d_prev_ts || !d_data || !d_ts || !d_is_read)))
+        return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "memory_access_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "memory_access_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_memory_access, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_addr_space, d_pointer, d_prev_data, d_prev_ts,
+                       d_data, d_ts, d_is_read, n, N, d_trace, (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "memory_access_tracegen (value above 16 bits, time not moving forward, or a read that changes its cell)");
+}
