@@ -29,8 +29,15 @@ for case in range(n_cases):
     params = (int(rng.integers(1, 4)), 0, int(rng.integers(1, 12)), int(rng.integers(0, 6)), int(rng.integers(0, 6)))
     airs = []
     for k in range(int(rng.integers(1, 5))):
-        kind = int(rng.integers(0, 4))
+        kind = int(rng.integers(0, 5))
         lh = int(rng.integers(lh_lo, lh_hi + 1))
+        if kind == 4:
+            # degree-5 definitions (four quotient chunks) need blow-up >= 4; otherwise a degree-3 chip
+            w = int(rng.integers(8, 30))
+            sa = air.SyntheticAir(width=w, n_free=5, n_bool=2, n_boundary=1, seed=seed * 10 + k, degree=5 if params[0] >= 2 else 3)
+            tr, pv = sa.gen_trace(max(lh, 1), seed=seed + k)
+            airs.append(dict(program=sa.program(), log_height=max(lh, 1), width=w, n_pvs=len(pv), trace=tr, pvs=pv))
+            continue
         if kind == 0:
             airs.append(tl._random_bus_air(seed * 10 + k, lh))
         elif kind == 1:
