@@ -31,6 +31,7 @@ struct Exe {
     uint32_t data_base = 0x00400000u;
     std::vector<uint8_t> data;            // initial read-write memory at data_base
     uint32_t memory_bytes = 1u << 20;     // size of the read-write region (stack at its top)
+    uint32_t entry = 0;                   // first pc; 0 = pc_base
 };
 struct StdIn {
     std::vector<uint8_t> bytes;           // the hint stream, consumed one little-endian word per read
@@ -86,7 +87,7 @@ public:
         if (!exe.data.empty()) memcpy(mem_.data(), exe.data.data(), exe.data.size());
         memset(x_, 0, sizeof x_);
         x_[2] = exe.data_base + exe.memory_bytes;  // sp
-        pc_ = exe.pc_base;
+        pc_ = exe.entry ? exe.entry : exe.pc_base;
     }
     // Runs until exit.  max_instr / max_cost == 0: unbounded.  Returns false if a bound was hit (state stays valid).
     bool run(uint64_t max_instr, uint64_t max_cost, ExecRecords* rec) {
@@ -319,6 +320,60 @@ private:
         instret_++;
     }
 };
+
+// An RV32 ELF image as an Exe (the reference passes `exe: impl Into<ExecutableFormat>`, an ELF or a transpiled VmExe,
+// crates/prover/src/utils/vm.rs:15): ELF32 little-endian, e_machine = EM_RISCV; the executable PT_LOAD segment becomes the
+// program, the other PT_LOAD segments the initial image of the read-write region (zero-filled up to p_memsz), which extends
+// `stack_bytes` beyond the highest loaded address.
+inline Exe load_elf(const std::vector<uint8_t>& f, uint32_t stack_bytes = 1u << 20) {
+    auto u16 = [&](size_t o) -> uint32_t {
+        if (o + 2 > f.size()) throw Error("ELF truncated");
+        return (uint32_t)f[o] | ((uint32_t)f[o + 1] << 8);
+    };
+    auto u32 = [&](size_t o) -> uint32_t { return u16(o) | (u16(o + 2) << 16); };
+    if (f.size() < 52 || f[0] != 0x7f || f[1] != 'E' || f[2] != 'L' || f[3] != 'F') throw Error("not an ELF file");
+    if (f[4] != 1 || f[5] != 1) throw Error("not a 32-bit little-endian ELF");
+    if (u16(18) != 243) throw Error("not a RISC-V ELF");
+    const uint32_t entry = u32(24), phoff = u32(28), phentsize = u16(42), phnum = u16(44);
+    if (phentsize < 32) throw Error("bad program header size");
+    Exe exe;
+    exe.entry = entry;
+    bool have_text = false;
+    uint64_t lo = UINT64_MAX, hi = 0;
+    struct Seg {
+        uint32_t off, vaddr, filesz, memsz;
+    };
+    std::vector<Seg> data;
+    for (uint32_t i = 0; i < phnum; i++) {
+        const size_t ph = (size_t)phoff + (size_t)i * phentsize;
+        if (u32(ph) != 1) continue;  // PT_LOAD
+        const Seg sg{u32(ph + 4), u32(ph + 8), u32(ph + 16), u32(ph + 20)};
+        const uint32_t flags = u32(ph + 24);
+        if ((uint64_t)sg.off + sg.filesz > f.size() || sg.filesz > sg.memsz) throw Error("ELF segment outside the file");
+        if (flags & 1u) {  // PF_X
+            if (have_text) throw Error("more than one executable segment");
+            if ((sg.vaddr & 3u) || (sg.filesz & 3u)) throw Error("misaligned text segment");
+            have_text = true;
+            exe.pc_base = sg.vaddr;
+            exe.program.resize(sg.filesz / 4);
+            if (sg.filesz) memcpy(exe.program.data(), f.data() + sg.off, sg.filesz);
+        } else {
+            data.push_back(sg);
+            lo = std::min<uint64_t>(lo, sg.vaddr), hi = std::max<uint64_t>(hi, (uint64_t)sg.vaddr + sg.memsz);
+        }
+    }
+    if (!have_text) throw Error("no executable segment");
+    if (entry < exe.pc_base || entry >= exe.pc_base + 4 * (uint64_t)exe.program.size()) throw Error("entry point outside the text segment");
+    if (data.empty()) lo = hi = exe.data_base;
+    lo &= ~3ull;
+    if (hi - lo + stack_bytes > (1ull << 30)) throw Error("data image too large");
+    exe.data_base = (uint32_t)lo;
+    exe.data.assign((size_t)(hi - lo), 0);
+    for (const Seg& sg : data)
+        if (sg.filesz) memcpy(exe.data.data() + (sg.vaddr - lo), f.data() + sg.off, sg.filesz);
+    exe.memory_bytes = (uint32_t)(((hi - lo + 3) & ~3ull) + stack_bytes);
+    return exe;
+}
 
 // crates/prover/src/utils/vm.rs:13-48.  `records`, when given, receives the per-chip execution records of the run that
 // produced the result (the metered run, or the fall-back run).

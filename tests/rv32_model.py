@@ -300,3 +300,18 @@ def exe_bytes(program, pc_base=0x00200000, data_base=0x00400000, memory_bytes=1 
     """the vm_cli exe format"""
     return struct.pack("<III", 0x58455A4B, pc_base, len(program)) + struct.pack("<%dI" % len(program), *program) + \
         struct.pack("<III", data_base, memory_bytes, len(data)) + bytes(data)
+
+
+def elf_bytes(program, text_vaddr=0x00200000, data=b"", data_vaddr=0x00400000, bss=0, entry_offset=0):
+    """A minimal ELF32 little-endian RISC-V executable: one PF_X PT_LOAD segment (the program), one PF_R|PF_W segment (data + bss)."""
+    text = struct.pack("<%dI" % len(program), *program)
+    n_ph = 2 if (data or bss) else 1
+    ehsize, phsize = 52, 32
+    off_text = ehsize + n_ph * phsize
+    off_data = off_text + len(text)
+    eh = b"\x7fELF" + bytes([1, 1, 1, 0]) + bytes(8) + struct.pack("<HHIIIIIHHHHHH", 2, 243, 1, text_vaddr + entry_offset, ehsize, 0, 0,
+                                                                  ehsize, phsize, n_ph, 40, 0, 0)
+    ph = struct.pack("<IIIIIIII", 1, off_text, text_vaddr, text_vaddr, len(text), len(text), 5, 4)
+    if n_ph == 2:
+        ph += struct.pack("<IIIIIIII", 1, off_data, data_vaddr, data_vaddr, len(data), len(data) + bss, 6, 4)
+    return eh + ph + text + bytes(data)

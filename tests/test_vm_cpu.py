@@ -149,3 +149,38 @@ def test_metered_fallback_and_guest_failure(tmp_path):
     # a jump out of the program
     r, _, _ = run_cli(tmp_path, rv.assemble([("jal", 0, 64)]))
     assert r.returncode != 0 and "pc outside the program" in r.stderr
+
+
+def test_elf_guest(tmp_path):
+    """The same guest as an ELF image (what the reference's `exe` is before transpilation): text and data segments, bss, an entry
+    point that is not the first instruction."""
+    table = bytes(range(1, 33))
+    prog = [("jal", 0, "start"),                                  # never executed: the entry point skips it
+            ("label", "start")] + rv.li(S1, 0x00400000) + [
+        ("addi", T2, 0, 0), ("addi", T0, 0, 0),
+        ("label", "loop"), ("slti", T3, T2, 32), ("beq", T3, 0, "done"),
+        ("add", T3, S1, T2), ("lbu", T1, T3, 0), ("add", T0, T0, T1), ("sb", T0, T3, 64),   # running sums into the bss
+        ("addi", T2, T2, 1), ("jal", 0, "loop"),
+        ("label", "done"), ("lw", A0, S1, 92), ("addi", A1, 0, 0), ("addi", A7, 0, 1), ("ecall",),
+        ("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    words = rv.assemble(prog)
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words, data=table, bss=64, entry_offset=4))
+    out = tmp_path / "rec"
+    out.mkdir()
+    r = subprocess.run([VM, "exec", str(exe), "-", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    js = json.loads(r.stdout)
+    model = rv.run(words[1:], pc_base=0x00200004, data=table + bytes(64))
+    assert js["total_cycle"] == model["instret"] and bytes(js["public_values"]) == model["pvs"]
+    sums = np.cumsum(np.frombuffer(table, np.uint8).astype(np.int64)) & 255
+    assert bytes(js["public_values"][:4]) == bytes(int(v) for v in sums[28:32])
+    # not RISC-V / truncated
+    bad = bytearray(exe.read_bytes())
+    bad[18] = 3
+    (tmp_path / "x86.elf").write_bytes(bad)
+    r = subprocess.run([VM, "exec", str(tmp_path / "x86.elf"), "-", "-"], capture_output=True, text=True)
+    assert r.returncode != 0 and "RISC-V" in r.stderr
+    (tmp_path / "cut.elf").write_bytes(exe.read_bytes()[:100])
+    r = subprocess.run([VM, "exec", str(tmp_path / "cut.elf"), "-", "-"], capture_output=True, text=True)
+    assert r.returncode != 0

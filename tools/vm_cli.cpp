@@ -1,7 +1,7 @@
 // vm_cli -- the guest execution step (include/zkhip_vm.hpp: the mirror of crates/prover/src/utils/vm.rs execute_guest) as a
 // command-line tool: runs an RV32IM guest and writes the per-chip execution records the device trace generators take.
 //   vm_cli exec <exe.bin> <stdin.bin | -> <out_dir | -> [max_cost]
-// exe.bin: u32 words  [0x58455A4B "KZEX", pc_base, n_program, program..., data_base, memory_bytes, n_data_bytes, data bytes...]
+// exe.bin: an RV32 ELF file, or u32 words  [0x58455A4B "KZEX", pc_base, n_program, program..., data_base, memory_bytes, n_data_bytes, data bytes...]
 // Prints one JSON line {"total_cycle", "public_values", "records": {...counts}, "trace_cells"}; with an out_dir, writes
 // pc_index.u32, alu_{op,b,c}.u32, lt_{op,b,c}.u32, mul_{b,c}.u32, the memory log acc_{as,ptr,prev_data,prev_ts,data,ts,is_read}.u32 and
 // the boundary records bnd_{as,ptr,initial,final,final_ts}.u32 (raw little-endian arrays).
@@ -36,15 +36,19 @@ int main(int argc, char** argv) {
             memcpy(&v, raw.data() + 4 * i, 4);
             return v;
         };
-        if (word(0) != 0x58455A4Bu) throw zkhip_vm::Error("bad exe magic");
         zkhip_vm::Exe exe;
-        exe.pc_base = word(1);
-        const size_t n_prog = word(2);
-        for (size_t i = 0; i < n_prog; i++) exe.program.push_back(word(3 + i));
-        exe.data_base = word(3 + n_prog), exe.memory_bytes = word(4 + n_prog);
-        const size_t n_data = word(5 + n_prog), off = 4 * (6 + n_prog);
-        if (off + n_data > raw.size()) throw zkhip_vm::Error("exe data truncated");
-        exe.data.assign(raw.begin() + (long)off, raw.begin() + (long)(off + n_data));
+        if (raw[0] == 0x7f && raw[1] == 'E') {
+            exe = zkhip_vm::load_elf(raw);  // an RV32 ELF image
+        } else {
+            if (word(0) != 0x58455A4Bu) throw zkhip_vm::Error("bad exe magic");
+            exe.pc_base = word(1);
+            const size_t n_prog = word(2);
+            for (size_t i = 0; i < n_prog; i++) exe.program.push_back(word(3 + i));
+            exe.data_base = word(3 + n_prog), exe.memory_bytes = word(4 + n_prog);
+            const size_t n_data = word(5 + n_prog), off = 4 * (6 + n_prog);
+            if (off + n_data > raw.size()) throw zkhip_vm::Error("exe data truncated");
+            exe.data.assign(raw.begin() + (long)off, raw.begin() + (long)(off + n_data));
+        }
         zkhip_vm::StdIn in;
         if (std::string(argv[3]) != "-") in.bytes = read_file(argv[3]);
         const uint64_t max_cost = argc > 5 ? strtoull(argv[5], nullptr, 10) : 0;
