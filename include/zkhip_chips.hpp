@@ -1,0 +1,334 @@
+// zkhip_chips.hpp -- the AIRs of the VM chips whose traces the device generates (include/zkhip.h: zkhip_*_tracegen), built with
+// the C++ AIR builder (include/zkhip_air.hpp).  Each function emits WORD FOR WORD the program of its Python twin in
+// zkvm-prover_amd/air.py (tests/test_air_builder_cpp.py compares them), so a proving key made from these programs is the key the
+// Python-driven tests make.  What the chips are, and which OpenVM chip each follows, is documented at the Python definitions and
+// at the generators in include/zkhip.h; here only the construction order matters: node numbers follow creation order, and C++
+// leaves the evaluation order of a binary operator's operands unspecified, so every sub-expression is bound to a name in the
+// order Python evaluates it.
+#pragma once
+#include "zkhip_air.hpp"
+
+namespace zkhip {
+namespace chips {
+using air::AirBuilder;
+using air::Expr;
+using air::Kind;
+
+constexpr uint32_t RANGE_BUS = 5, RANGE_TUPLE_BUS = 6, PROGRAM_BUS = 8, BITWISE_BUS = 9, MEMORY_BUS = 1;
+constexpr int64_t INV_256 = 2005401601;  // 256^-1 mod p
+
+// air.range_table_air(bus)
+inline void range_table_air(AirBuilder& b, uint32_t bus = RANGE_BUS) {
+    b.when_first_row(b.prep(0));
+    const Expr p1 = b.prep(0, 1);
+    const Expr p0 = b.prep(0);
+    const Expr d = p1 - p0;
+    b.when_transition(d - 1);
+    const Expr f = b.prep(0);
+    const Expr c = b.var(0);
+    b.push_interaction(bus, {f}, c, Kind::Receive);
+}
+
+// air.range_tuple_table_air(size_x, size_y, bus): the sizes only shape the preprocessed trace, not the constraints
+inline void range_tuple_table_air(AirBuilder& b, uint32_t bus = RANGE_TUPLE_BUS) {
+    b.when_first_row(b.prep(0));
+    b.when_first_row(b.prep(1));
+    {
+        const Expr y1 = b.prep(1, 1);
+        const Expr y0 = b.prep(1);
+        const Expr d = y1 - y0;
+        const Expr d1 = d - 1;
+        const Expr y1b = b.prep(1, 1);
+        b.when_transition(d1 * y1b);
+    }
+    {
+        const Expr x1 = b.prep(0, 1);
+        const Expr x0 = b.prep(0);
+        const Expr l = x1 - x0;
+        const Expr x1b = b.prep(0, 1);
+        const Expr x0b = b.prep(0);
+        const Expr r0 = x1b - x0b;
+        const Expr r = r0 - 1;
+        b.when_transition(l * r);
+    }
+    const Expr f0 = b.prep(0);
+    const Expr f1 = b.prep(1);
+    const Expr c = b.var(0);
+    b.push_interaction(bus, {f0, f1}, c, Kind::Receive);
+}
+
+// air.bitwise_lookup_air(bits, bus): AirBuilder(2, 0, prep_width = 3)
+inline void bitwise_lookup_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
+    {   // (Python evaluates the count argument before push_interaction lifts the integer fields)
+        const Expr x = b.prep(0);
+        const Expr y = b.prep(1);
+        const Expr c = b.var(0);
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {x, y, z0, z0}, c, Kind::Receive);
+    }
+    {
+        const Expr x = b.prep(0);
+        const Expr y = b.prep(1);
+        const Expr z = b.prep(2);
+        const Expr c = b.var(1);
+        const Expr one = b.constant(1);
+        b.push_interaction(bus, {x, y, z, one}, c, Kind::Receive);
+    }
+}
+
+// air.program_air(bus): AirBuilder(10, 0) with set_cached_width(9)
+inline void program_air(AirBuilder& b, uint32_t bus = PROGRAM_BUS) {
+    std::vector<Expr> f;
+    for (size_t c = 0; c < 9; c++) f.push_back(b.var(c));
+    const Expr cnt = b.var(9);
+    b.push_interaction(bus, f, cnt, Kind::Receive);
+}
+
+// air.exec_frame_air(bus): AirBuilder(10, 0)
+inline void exec_frame_air(AirBuilder& b, uint32_t bus = PROGRAM_BUS) {
+    const Expr ok = b.var(9);
+    const Expr t = ok - 1;
+    b.assert_zero(ok * t);
+    std::vector<Expr> f;
+    for (size_t c = 0; c < 9; c++) f.push_back(b.var(c));
+    b.push_interaction(bus, f, ok, Kind::Send);
+}
+
+// air.rv32_alu_core_air(bus): AirBuilder(18, 0)
+inline void rv32_alu_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
+    Expr a_[4], b_[4], c_[4], fl[5];
+    for (int i = 0; i < 4; i++) a_[i] = b.var(i);
+    for (int i = 0; i < 4; i++) b_[i] = b.var(4 + i);
+    for (int i = 0; i < 4; i++) c_[i] = b.var(8 + i);
+    for (int i = 0; i < 5; i++) fl[i] = b.var(12 + i);
+    const Expr f_add = fl[0], f_sub = fl[1], f_xor = fl[2], f_or = fl[3], f_and = fl[4];
+    const Expr ok = b.var(17);
+    for (const Expr& f : {f_add, f_sub, f_xor, f_or, f_and, ok}) {
+        const Expr t = f - 1;
+        b.assert_zero(f * t);
+    }
+    {
+        const Expr s1 = f_add + f_sub;
+        const Expr s2 = s1 + f_xor;
+        const Expr s3 = s2 + f_or;
+        const Expr s4 = s3 + f_and;
+        b.assert_zero(s4 - ok);
+    }
+    Expr carry_add, carry_sub;
+    for (int i = 0; i < 4; i++) {
+        {
+            const Expr s = b_[i] + c_[i];
+            const Expr d = s - a_[i];
+            const Expr prev = i == 0 ? b.constant(0) : carry_add;
+            const Expr t = d + prev;
+            carry_add = t * INV_256;
+        }
+        {
+            const Expr s = a_[i] + c_[i];
+            const Expr d = s - b_[i];
+            const Expr prev = i == 0 ? b.constant(0) : carry_sub;
+            const Expr t = d + prev;
+            carry_sub = t * INV_256;
+        }
+        {
+            const Expr t = carry_add - 1;
+            const Expr m = carry_add * t;
+            b.assert_zero(f_add * m);
+        }
+        {
+            const Expr t = carry_sub - 1;
+            const Expr m = carry_sub * t;
+            b.assert_zero(f_sub * m);
+        }
+    }
+    const Expr bw0 = f_xor + f_or;
+    const Expr bitwise = bw0 + f_and;
+    for (int i = 0; i < 4; i++) {
+        const Expr x1 = bitwise * b_[i];
+        const Expr nb = 1 - bitwise;
+        const Expr x2 = nb * a_[i];
+        const Expr x = x1 + x2;
+        const Expr y1 = bitwise * c_[i];
+        const Expr nb2 = 1 - bitwise;
+        const Expr y2 = nb2 * a_[i];
+        const Expr y = y1 + y2;
+        const Expr z1 = f_xor * a_[i];
+        const Expr a2 = a_[i] * 2;
+        const Expr o1 = a2 - b_[i];
+        const Expr o2 = o1 - c_[i];
+        const Expr z2 = f_or * o2;
+        const Expr z12 = z1 + z2;
+        const Expr bc = b_[i] + c_[i];
+        const Expr a2b = a_[i] * 2;
+        const Expr n1 = bc - a2b;
+        const Expr z3 = f_and * n1;
+        const Expr z = z12 + z3;
+        const Expr one = b.constant(1);
+        b.push_interaction(bus, {x, y, z, one}, ok, Kind::Send);
+    }
+}
+
+// air.rv32_lt_core_air(bus): AirBuilder(18, 0)
+inline void rv32_lt_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
+    Expr bl[4], cl[4], mk[4];
+    for (int i = 0; i < 4; i++) bl[i] = b.var(i);
+    for (int i = 0; i < 4; i++) cl[i] = b.var(4 + i);
+    const Expr cmp = b.var(8), slt = b.var(9), sltu = b.var(10), bm = b.var(11), cm = b.var(12);
+    for (int i = 0; i < 4; i++) mk[i] = b.var(13 + i);
+    const Expr dv = b.var(17);
+    const Expr ok = slt + sltu;
+    for (const Expr& f : {slt, sltu, ok, cmp, mk[0], mk[1], mk[2], mk[3]}) {
+        const Expr t = f - 1;
+        b.assert_zero(f * t);
+    }
+    for (int k = 0; k < 2; k++) {
+        const Expr limb = k == 0 ? bl[3] : cl[3], f = k == 0 ? bm : cm;
+        const Expr d = limb - f;
+        const Expr d256 = d - 256;
+        b.assert_zero(d * d256);
+        const Expr ns = 1 - slt;
+        b.assert_zero(ns * d);
+    }
+    const Expr c2 = cmp * 2;
+    const Expr sign = c2 - 1;
+    Expr prefix;
+    for (int i = 3; i >= 0; i--) {
+        const Expr hi = i == 3 ? cm : cl[i], lo = i == 3 ? bm : bl[i];
+        const Expr d0 = hi - lo;
+        const Expr diff = d0 * sign;
+        prefix = i == 3 ? mk[i] : prefix + mk[i];
+        const Expr np = 1 - prefix;
+        b.assert_zero(np * diff);
+        const Expr dd = dv - diff;
+        b.assert_zero(mk[i] * dd);
+    }
+    {
+        const Expr t = prefix - 1;
+        b.assert_zero(prefix * t);
+    }
+    {
+        const Expr np = 1 - prefix;
+        b.assert_zero(np * cmp);
+    }
+    {
+        const Expr nok = 1 - ok;
+        b.assert_zero(nok * prefix);
+    }
+    {
+        const Expr s1 = slt * 128;
+        const Expr x = bm + s1;
+        const Expr s2 = slt * 128;
+        const Expr y = cm + s2;
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {x, y, z0, z0}, ok, Kind::Send);
+    }
+    {
+        const Expr x = dv - 1;
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {x, z0, z0, z0}, prefix, Kind::Send);
+    }
+}
+
+// air.rv32_mul_core_air(bus): AirBuilder(13, 0)
+inline void rv32_mul_core_air(AirBuilder& b, uint32_t bus = RANGE_TUPLE_BUS) {
+    Expr a_[4], b_[4], c_[4];
+    for (int i = 0; i < 4; i++) a_[i] = b.var(i);
+    for (int i = 0; i < 4; i++) b_[i] = b.var(4 + i);
+    for (int i = 0; i < 4; i++) c_[i] = b.var(8 + i);
+    const Expr ok = b.var(12);
+    {
+        const Expr t = ok - 1;
+        b.assert_zero(ok * t);
+    }
+    Expr carry;
+    for (int i = 0; i < 4; i++) {
+        // acc = carry (or 0); for k: acc = b_k * c_{i-k} + acc
+        Expr acc;
+        bool have = i > 0;
+        if (have) acc = carry;
+        for (int k = 0; k <= i; k++) {
+            const Expr m = b_[k] * c_[i - k];
+            acc = have ? m + acc : m + 0;
+            have = true;
+        }
+        const Expr d = acc - a_[i];
+        carry = d * INV_256;
+        b.push_interaction(bus, {a_[i], carry}, ok, Kind::Send);
+    }
+}
+
+// air.memory_access_air(range_bus, memory_bus): AirBuilder(10, 0)
+inline void memory_access_air(AirBuilder& b, uint32_t range_bus = RANGE_BUS, uint32_t memory_bus = MEMORY_BUS) {
+    Expr v[10];
+    for (int i = 0; i < 10; i++) v[i] = b.var(i);
+    const Expr as_ = v[0], ptr = v[1], pd = v[2], pts = v[3], d = v[4], ts = v[5], rd = v[6], ok = v[7], lo = v[8], hi = v[9];
+    {
+        const Expr t = ok - 1;
+        b.assert_zero(ok * t);
+    }
+    {
+        const Expr t = rd - 1;
+        b.assert_zero(rd * t);
+    }
+    {
+        const Expr nok = 1 - ok;
+        b.assert_zero(nok * rd);
+    }
+    {
+        const Expr t = d - pd;
+        b.assert_zero(rd * t);
+    }
+    {
+        const Expr t1 = ts - pts;
+        const Expr t2 = t1 - 1;
+        const Expr t3 = t2 - lo;
+        const Expr h = hi * (int64_t)(1 << 16);
+        const Expr t4 = t3 - h;
+        b.assert_zero(ok * t4);
+    }
+    b.push_interaction(range_bus, {lo}, ok, Kind::Send);
+    b.push_interaction(range_bus, {hi}, ok, Kind::Send);
+    b.push_interaction(range_bus, {d}, ok, Kind::Send);
+    b.push_interaction(memory_bus, {as_, ptr, pd, pts}, ok, Kind::Receive);
+    b.push_interaction(memory_bus, {as_, ptr, d, ts}, ok, Kind::Send);
+}
+
+// air.memory_boundary_air(pointer_bits, range_bus, memory_bus): AirBuilder(8, 0)
+inline void memory_boundary_air(AirBuilder& b, unsigned pointer_bits = 29, uint32_t range_bus = RANGE_BUS, uint32_t memory_bus = MEMORY_BUS) {
+    Expr v[8];
+    for (int i = 0; i < 8; i++) v[i] = b.var(i);
+    const Expr as_ = v[0], ptr = v[1], init = v[2], fin = v[3], ts = v[4], ok = v[5], lo = v[6], hi = v[7];
+    const Expr ok_n = b.var(5, 1);
+    {
+        const Expr t = ok - 1;
+        b.assert_zero(ok * t);
+    }
+    {
+        const Expr nok = 1 - ok;
+        b.when_transition(ok_n * nok);
+    }
+    const Expr k1 = as_ * (int64_t)(1ll << pointer_bits);
+    const Expr key = k1 + ptr;
+    const Expr a1 = b.var(0, 1);
+    const Expr kn1 = a1 * (int64_t)(1ll << pointer_bits);
+    const Expr p1 = b.var(1, 1);
+    const Expr key_n = kn1 + p1;
+    {
+        const Expr t1 = key_n - key;
+        const Expr t2 = t1 - 1;
+        const Expr t3 = t2 - lo;
+        const Expr h = hi * (int64_t)(1 << 16);
+        const Expr t4 = t3 - h;
+        b.when_transition(ok_n * t4);
+    }
+    b.push_interaction(range_bus, {lo}, ok, Kind::Send);
+    b.push_interaction(range_bus, {hi}, ok, Kind::Send);
+    {
+        const Expr z0 = b.constant(0);
+        b.push_interaction(memory_bus, {as_, ptr, init, z0}, ok, Kind::Send);
+    }
+    b.push_interaction(memory_bus, {as_, ptr, fin, ts}, ok, Kind::Receive);
+}
+
+}  // namespace chips
+}  // namespace zkhip

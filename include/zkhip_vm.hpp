@@ -375,6 +375,29 @@ inline Exe load_elf(const std::vector<uint8_t>& f, uint32_t stack_bytes = 1u << 
     return exe;
 }
 
+// An executable file: an RV32 ELF image, or the flat test format  u32 words [0x58455A4B "KZEX", pc_base, n_program, program...,
+// data_base, memory_bytes, n_data_bytes] followed by the data bytes.
+inline Exe parse_exe(const std::vector<uint8_t>& raw) {
+    if (raw.size() >= 4 && raw[0] == 0x7f && raw[1] == 'E' && raw[2] == 'L' && raw[3] == 'F') return load_elf(raw);
+    auto word = [&](size_t i) {
+        if (4 * i + 4 > raw.size()) throw Error("exe truncated");
+        uint32_t v;
+        memcpy(&v, raw.data() + 4 * i, 4);
+        return v;
+    };
+    if (word(0) != 0x58455A4Bu) throw Error("bad exe magic");
+    Exe exe;
+    exe.pc_base = word(1);
+    const size_t n_prog = word(2);
+    if (n_prog > raw.size() / 4) throw Error("exe truncated");
+    for (size_t i = 0; i < n_prog; i++) exe.program.push_back(word(3 + i));
+    exe.data_base = word(3 + n_prog), exe.memory_bytes = word(4 + n_prog);
+    const size_t n_data = word(5 + n_prog), off = 4 * (6 + n_prog);
+    if (off + n_data > raw.size()) throw Error("exe data truncated");
+    exe.data.assign(raw.begin() + (long)off, raw.begin() + (long)(off + n_data));
+    return exe;
+}
+
 // crates/prover/src/utils/vm.rs:13-48.  `records`, when given, receives the per-chip execution records of the run that
 // produced the result (the metered run, or the fall-back run).
 inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64_t max_cost = 0, ExecRecords* records = nullptr) {

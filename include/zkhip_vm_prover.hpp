@@ -1,0 +1,214 @@
+// zkhip_vm_prover.hpp -- guest in, proof out: the reference's Prover::gen_proof_stark flow (crates/prover/src/prover/mod.rs:342-413:
+// execute the guest, prove, encode, self-verify) over this backend, in C++ on the C ABI alone:
+//   1. zkhip_vm::execute_guest (include/zkhip_vm.hpp)            -> cycle count, public values, per-chip execution records
+//   2. records -> device buffers -> the device trace generators   (include/zkhip.h: zkhip_*_tracegen; no trace ever exists on the host)
+//   3. zkhip_keygen over the chips' AIRs (include/zkhip_chips.hpp), zkhip_prove, zkhip_verify
+// The AIR set (order fixed, it is part of the verifying key): program (cached program + execution frequencies), execution
+// frames, RV32 base ALU / less-than / multiplication cores, 8-bit bitwise lookup, range-tuple checker, memory access rows, memory
+// boundary, 16-bit range checker.  What these ten AIRs prove together is stated in DESIGN.md 8: every bus balances (program,
+// memory, lookups) -- the chips are not yet tied to each other by an execution bus.
+#pragma once
+#include <chrono>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "zkhip.h"
+#include "zkhip_chips.hpp"
+#include "zkhip_vm.hpp"
+
+namespace zkhip_vm {
+
+constexpr uint32_t TUPLE_SIZE_X = 256, TUPLE_SIZE_Y = 2048;  // covers (limb < 256, carry < 1024): a 2^19-row table
+constexpr unsigned N_VM_AIRS = 10;
+
+struct GuestProof {
+    ExecutionResult exec;
+    uint64_t execution_time_mills = 0, tracegen_time_mills = 0, proving_time_mills = 0;
+    std::vector<uint8_t> proof;               // zkhip proof bytes
+    std::vector<unsigned> log_heights;        // per AIR (the proof's baseline)
+    std::vector<std::vector<uint32_t>> programs;
+    std::vector<std::array<uint32_t, 8>> prep_commits;  // for the AIRs with a preprocessed trace (else zeros)
+    std::vector<uint8_t> has_prep;
+};
+
+inline unsigned log2_ceil_min1(size_t n) {
+    unsigned l = 1;
+    while (((size_t)1 << l) < n) l++;
+    return l;
+}
+
+// The program chip's cached partition: 9 fields per instruction (row index, opcode, rd, funct3, rs1, rs2, funct7, low and high
+// half of the instruction word), column-major over 2^log_program rows; rows beyond the program are zero (never executed).
+inline std::vector<uint32_t> program_table(const std::vector<uint32_t>& words, unsigned log_program) {
+    const size_t n = (size_t)1 << log_program;
+    std::vector<uint32_t> t(9 * n, 0);
+    for (size_t k = 0; k < words.size(); k++) {
+        const uint32_t w = words[k];
+        const uint32_t f[9] = {(uint32_t)k, w & 0x7f, (w >> 7) & 31, (w >> 12) & 7, (w >> 15) & 31, (w >> 20) & 31, w >> 25, w & 0xffff, w >> 16};
+        for (size_t q = 0; q < 9; q++) t[q * n + k] = f[q];
+    }
+    return t;
+}
+
+class VmProver {
+public:
+    explicit VmProver(int device = 0) {
+        if (zkhip_ctx_create(device, &ctx_) != ZKHIP_OK) throw Error("zkhip_ctx_create failed (needs a gfx950 device)");
+    }
+    ~VmProver() {
+        for (void* p : bufs_) zkhip_free(ctx_, p);
+        if (ctx_) zkhip_ctx_destroy(ctx_);
+    }
+    VmProver(const VmProver&) = delete;
+    VmProver& operator=(const VmProver&) = delete;
+
+    GuestProof prove_guest(const zkhip_params& params, const Exe& exe, const StdIn& in, uint64_t max_cost = 0) {
+        using clk = std::chrono::steady_clock;
+        auto ms = [](clk::time_point a, clk::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(b - a).count(); };
+        GuestProof gp;
+        // ---- 1. execute
+        const auto t0 = clk::now();
+        ExecRecords rec;
+        gp.exec = execute_guest(exe, in, max_cost, &rec);
+        const auto t1 = clk::now();
+        gp.execution_time_mills = ms(t0, t1);
+        // ---- 2. heights, device records, device traces
+        const unsigned lp = log2_ceil_min1(exe.program.size()), lf = log2_ceil_min1(rec.pc_index.size());
+        const unsigned la = log2_ceil_min1(rec.alu_op.size()), ll = log2_ceil_min1(rec.lt_op.size()), lm = log2_ceil_min1(rec.mul_b.size());
+        const unsigned lacc = log2_ceil_min1(rec.acc_ts.size()), lbnd = log2_ceil_min1(rec.bnd_ptr.size());
+        unsigned ltup = 0;
+        while ((1u << ltup) < TUPLE_SIZE_X * TUPLE_SIZE_Y) ltup++;
+        gp.log_heights = {lp, lf, la, ll, lm, 16, ltup, lacc, lbnd, 16};
+        const std::vector<uint32_t> prog = program_table(exe.program, lp);
+        const size_t NP = (size_t)1 << lp;
+        uint32_t* d_program_trace = dmalloc(10 * NP);  // [9 cached columns | frequency]
+        h2d(d_program_trace, prog.data(), 9 * NP);
+        check(zkhip_to_monty(ctx_, d_program_trace, 9 * NP));
+        const uint32_t* d_idx = up(rec.pc_index);
+        check(zkhip_program_freq_tracegen(ctx_, d_idx, rec.pc_index.size(), lp, d_program_trace + 9 * NP));
+        uint32_t* d_frames = dmalloc((size_t)10 << lf);
+        check(zkhip_exec_frame_tracegen(ctx_, d_idx, rec.pc_index.size(), d_program_trace, NP, lf, d_frames));
+        uint32_t* d_bw = dzeros(2u << 16);
+        uint32_t* d_alu = dmalloc((size_t)ZKHIP_RV32_ALU_WIDTH << la);
+        check(zkhip_rv32_alu_tracegen(ctx_, up(rec.alu_op), up(rec.alu_b), up(rec.alu_c), rec.alu_op.size(), la, d_alu, d_bw));
+        uint32_t* d_lt = dmalloc((size_t)ZKHIP_RV32_LT_WIDTH << ll);
+        check(zkhip_rv32_lt_tracegen(ctx_, up(rec.lt_op), up(rec.lt_b), up(rec.lt_c), rec.lt_op.size(), ll, d_lt, d_bw));
+        uint32_t* d_tup = dzeros((size_t)1 << ltup);
+        uint32_t* d_mul = dmalloc((size_t)ZKHIP_RV32_MUL_WIDTH << lm);
+        check(zkhip_rv32_mul_tracegen(ctx_, up(rec.mul_b), up(rec.mul_c), rec.mul_b.size(), lm, d_mul, d_tup, TUPLE_SIZE_X, TUPLE_SIZE_Y));
+        uint32_t* d_acc = dmalloc((size_t)ZKHIP_MEMORY_ACCESS_WIDTH << lacc);
+        const size_t n_acc = rec.acc_ts.size(), n_bnd = rec.bnd_ptr.size();
+        check(zkhip_memory_access_tracegen(ctx_, up(rec.acc_as), up(rec.acc_ptr), up(rec.acc_prev_data), up(rec.acc_prev_ts), up(rec.acc_data),
+                                           up(rec.acc_ts), up(rec.acc_is_read), n_acc, lacc, d_acc));
+        uint32_t* d_bnd = dmalloc((size_t)ZKHIP_MEMORY_BOUNDARY_WIDTH << lbnd);
+        uint32_t* d_init = const_cast<uint32_t*>(up(rec.bnd_initial));
+        uint32_t* d_fin = const_cast<uint32_t*>(up(rec.bnd_final));
+        if (n_bnd) check(zkhip_to_monty(ctx_, d_init, n_bnd)), check(zkhip_to_monty(ctx_, d_fin, n_bnd));
+        check(zkhip_memory_boundary_tracegen(ctx_, up(rec.bnd_as), up(rec.bnd_ptr), d_init, d_fin, up(rec.bnd_final_ts), n_bnd, 2, 29, lbnd, d_bnd));
+        // the 16-bit range checker's multiplicities, counted where the requesting columns lie (valid rows only)
+        uint32_t* d_rng = dzeros(1u << 16);
+        const size_t NA = (size_t)1 << lacc, NB = (size_t)1 << lbnd;
+        bool first = true;
+        auto count = [&](const uint32_t* col, size_t n) {
+            check(zkhip_range_counts_tracegen(ctx_, col, n, 16, d_rng, first ? 0 : 1));
+            first = false;
+        };
+        count(d_acc + 8 * NA, n_acc), count(d_acc + 9 * NA, n_acc), count(d_acc + 4 * NA, n_acc);
+        count(d_bnd + 6 * NB, n_bnd), count(d_bnd + 7 * NB, n_bnd);
+        const auto t2 = clk::now();
+        gp.tracegen_time_mills = ms(t1, t2);
+        // ---- 3. the AIR set and its preprocessed tables
+        namespace ch = zkhip::chips;
+        using zkhip::air::AirBuilder;
+        const size_t widths[N_VM_AIRS] = {10, 10, 18, 18, 13, 2, 1, 10, 8, 1};
+        const size_t prep_w[N_VM_AIRS] = {0, 0, 0, 0, 0, 3, 2, 0, 0, 1};
+        gp.programs.resize(N_VM_AIRS);
+        for (unsigned a = 0; a < N_VM_AIRS; a++) {
+            AirBuilder b(widths[a], 0, prep_w[a]);
+            switch (a) {
+                case 0: b.set_cached_width(9); ch::program_air(b); break;
+                case 1: ch::exec_frame_air(b); break;
+                case 2: ch::rv32_alu_core_air(b); break;
+                case 3: ch::rv32_lt_core_air(b); break;
+                case 4: ch::rv32_mul_core_air(b); break;
+                case 5: ch::bitwise_lookup_air(b); break;
+                case 6: ch::range_tuple_table_air(b); break;
+                case 7: ch::memory_access_air(b); break;
+                case 8: ch::memory_boundary_air(b); break;
+                default: ch::range_table_air(b); break;
+            }
+            gp.programs[a] = b.program();
+        }
+        std::vector<uint32_t> prep_bw(3u << 16), prep_tup((size_t)2 << ltup), prep_rng(1u << 16);
+        for (uint32_t i = 0; i < (1u << 16); i++) prep_bw[i] = i >> 8, prep_bw[(1u << 16) + i] = i & 255u, prep_bw[(2u << 16) + i] = (i >> 8) ^ (i & 255u);
+        for (uint32_t i = 0; i < (1u << ltup); i++) prep_tup[i] = i / TUPLE_SIZE_Y, prep_tup[((size_t)1 << ltup) + i] = i % TUPLE_SIZE_Y;
+        std::iota(prep_rng.begin(), prep_rng.end(), 0u);
+        const uint32_t* preps[N_VM_AIRS] = {nullptr, nullptr, nullptr, nullptr, nullptr, prep_bw.data(), prep_tup.data(), nullptr, nullptr, prep_rng.data()};
+        std::vector<zkhip_air> airs(N_VM_AIRS);
+        for (unsigned a = 0; a < N_VM_AIRS; a++)
+            airs[a] = zkhip_air{gp.programs[a].data(), gp.programs[a].size(), gp.log_heights[a], widths[a], 0, preps[a], nullptr};
+        zkhip_pk* pk = nullptr;
+        check(zkhip_keygen(ctx_, &params, airs.data(), airs.size(), &pk));
+        gp.prep_commits.assign(N_VM_AIRS, std::array<uint32_t, 8>{});
+        gp.has_prep.assign(N_VM_AIRS, 0);
+        for (unsigned a = 0; a < N_VM_AIRS; a++)
+            if (preps[a]) gp.has_prep[a] = 1, check(zkhip_pk_prep_commitment(ctx_, pk, a, gp.prep_commits[a].data()));
+        // ---- 4. prove from the device-resident traces, then the mandatory self-check (mod.rs:407-411)
+        const uint32_t* d_traces[N_VM_AIRS] = {d_program_trace, d_frames, d_alu, d_lt, d_mul, d_bw, d_tup, d_acc, d_bnd, d_rng};
+        const uint32_t* pvs[N_VM_AIRS] = {};
+        gp.proof.resize(zkhip_proof_size(pk));
+        size_t len = 0;
+        const int rc = zkhip_prove(ctx_, pk, d_traces, pvs, gp.proof.data(), gp.proof.size(), &len);
+        const std::string err = rc == ZKHIP_OK ? "" : zkhip_last_error(ctx_);
+        zkhip_pk_destroy(ctx_, pk);
+        if (rc != ZKHIP_OK) throw Error("zkhip_prove: " + err);
+        gp.proof.resize(len);
+        gp.proving_time_mills = ms(t2, clk::now());
+        if (verify(params, gp) != ZKHIP_OK) throw Error("the proof does not verify");
+        return gp;
+    }
+
+    // host only: what a verifier needs is the programs, heights and preprocessed commitments of the proof
+    static int verify(const zkhip_params& params, const GuestProof& gp) {
+        const size_t widths[N_VM_AIRS] = {10, 10, 18, 18, 13, 2, 1, 10, 8, 1};
+        std::vector<zkhip_air> airs(N_VM_AIRS);
+        for (unsigned a = 0; a < N_VM_AIRS; a++)
+            airs[a] = zkhip_air{gp.programs[a].data(), gp.programs[a].size(), gp.log_heights[a], widths[a], 0, nullptr,
+                                gp.has_prep[a] ? gp.prep_commits[a].data() : nullptr};
+        const uint32_t* pvs[N_VM_AIRS] = {};
+        return zkhip_verify(&params, airs.data(), airs.size(), pvs, gp.proof.data(), gp.proof.size());
+    }
+
+private:
+    zkhip_ctx* ctx_ = nullptr;
+    std::vector<void*> bufs_;
+
+    void check(int rc) {
+        if (rc != ZKHIP_OK) throw Error(std::string("zkhip: ") + zkhip_last_error(ctx_));
+    }
+    uint32_t* dmalloc(size_t words) {
+        void* p = nullptr;
+        check(zkhip_malloc(ctx_, (words ? words : 1) * 4, &p));
+        bufs_.push_back(p);
+        return (uint32_t*)p;
+    }
+    void h2d(uint32_t* d, const uint32_t* h, size_t words) {
+        if (words) check(zkhip_h2d(ctx_, d, h, words * 4));
+    }
+    uint32_t* dzeros(size_t words) {
+        uint32_t* d = dmalloc(words);
+        const std::vector<uint32_t> z(words, 0);
+        h2d(d, z.data(), words);
+        return d;
+    }
+    const uint32_t* up(const std::vector<uint32_t>& v) {  // plain integers, as the generators take them
+        uint32_t* d = dmalloc(v.size());
+        h2d(d, v.data(), v.size());
+        return d;
+    }
+};
+
+}  // namespace zkhip_vm

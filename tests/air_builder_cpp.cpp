@@ -5,6 +5,7 @@
 #include <cstdio>
 
 #include "zkhip_air.hpp"
+#include "zkhip_chips.hpp"
 
 using namespace zkhip::air;
 
@@ -147,6 +148,19 @@ int main() {
         for (int i = 0; i < 24; i++) msg.push_back(b.var(i));
         b.push_interaction(9, msg, real, Kind::Send);
         dump("hasher_user", b);
+    }
+    {   // the VM chips (include/zkhip_chips.hpp)
+        namespace ch = zkhip::chips;
+        { AirBuilder b(1, 0, 1); ch::range_table_air(b); dump("chip_range_table", b); }
+        { AirBuilder b(1, 0, 2); ch::range_tuple_table_air(b); dump("chip_range_tuple_table", b); }
+        { AirBuilder b(2, 0, 3); ch::bitwise_lookup_air(b); dump("chip_bitwise_lookup", b); }
+        { AirBuilder b(10, 0); b.set_cached_width(9); ch::program_air(b); dump("chip_program", b); }
+        { AirBuilder b(10, 0); ch::exec_frame_air(b); dump("chip_exec_frame", b); }
+        { AirBuilder b(18, 0); ch::rv32_alu_core_air(b); dump("chip_rv32_alu", b); }
+        { AirBuilder b(18, 0); ch::rv32_lt_core_air(b); dump("chip_rv32_lt", b); }
+        { AirBuilder b(13, 0); ch::rv32_mul_core_air(b); dump("chip_rv32_mul", b); }
+        { AirBuilder b(10, 0); ch::memory_access_air(b); dump("chip_memory_access", b); }
+        { AirBuilder b(8, 0); ch::memory_boundary_air(b); dump("chip_memory_boundary", b); }
     }
     return 0;
 }

@@ -49,6 +49,17 @@ PY = {
     "poseidon2": lambda: air.poseidon2_air(),
     "poseidon2_bus": lambda: air.poseidon2_air(9),
     "hasher_user": lambda: air.hasher_user_air(9),
+    # the VM chips: include/zkhip_chips.hpp against their Python definitions
+    "chip_range_table": lambda: air.range_table_air(5),
+    "chip_range_tuple_table": lambda: air.range_tuple_table_air(256, 8192, 6),
+    "chip_bitwise_lookup": lambda: air.bitwise_lookup_air(8, 9),
+    "chip_program": lambda: air.program_air(),
+    "chip_exec_frame": lambda: air.exec_frame_air(),
+    "chip_rv32_alu": lambda: air.rv32_alu_core_air(),
+    "chip_rv32_lt": lambda: air.rv32_lt_core_air(),
+    "chip_rv32_mul": lambda: air.rv32_mul_core_air(),
+    "chip_memory_access": lambda: air.memory_access_air(),
+    "chip_memory_boundary": lambda: air.memory_boundary_air(),
 }
 
 

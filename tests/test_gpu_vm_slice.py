@@ -149,3 +149,67 @@ def test_memory_consistency_of_the_execution(zk, ora, tmp_path, which, seed):
     bad_proof = pk.prove(bad_traces, pvs)
     assert z.verify(PARAMS, pk.verifying_airs(), pvs, bad_proof) != 0
     pk.close()
+
+
+def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
+    """`prove_cli prove-guest`: the gen_proof_stark flow of the reference (mod.rs:342-413 -- execute, prove, encode, self-verify)
+    from a guest image, all in C++ on the C ABI (include/zkhip_vm_prover.hpp): the ten-chip proof it writes equals, byte for byte,
+    the oracle's proof over the oracle's traces of the same execution records; the JSON carries the cycle count and the public
+    values like the reference's StarkProof."""
+    import base64
+    import json
+    import subprocess
+
+    from prover_mirror_util import CLI
+
+    words = mixed_program()
+    stdin = (77).to_bytes(4, "little")
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words))
+    inp = tmp_path / "stdin.bin"
+    inp.write_bytes(stdin)
+    out = tmp_path / "proof.json"
+    r = subprocess.run([CLI, "prove-guest", str(exe), str(inp), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    model = rv.run(words, stdin)
+    assert line["verified"] and line["total_cycles"] == model["instret"]
+    sp = json.loads(out.read_text())
+    unb64 = lambda s: base64.b64decode(s)   # noqa: E731  (fields are base64(bincode(Vec<u8>)): 8-byte length + bytes)
+    proof = unb64(sp["proof"])[8:]
+    assert unb64(sp["user_pvs_proof"])[8:] == model["pvs"] and sp["stat"]["total_cycles"] == model["instret"]
+    heights = list(unb64(sp["baseline"])[8:])
+    # the same proof from the Python side: records of the same run, the oracle's traces, the oracle's prover
+    r2, js, rec = run_cli(tmp_path, words, stdin)
+    assert r2.returncode == 0
+    lp, lf = log2_ceil(len(words)), log2_ceil(len(rec["pc_index"]))
+    la, ll, lm = log2_ceil(len(rec["alu_op"])), log2_ceil(len(rec["lt_op"])), log2_ceil(len(rec["mul_b"]))
+    lacc, lbnd = log2_ceil(len(rec["acc_ts"])), log2_ceil(len(rec["bnd_ptr"]))
+    assert heights == [lp, lf, la, ll, lm, 16, 19, lacc, lbnd, 16]
+    prog = program_table(words, lp)
+    freq, _ = ora.program_freq_trace(rec["pc_index"], lp)
+    frames, _ = ora.exec_frame_trace(rec["pc_index"], prog, lf)
+    alu, xc, _ = ora.rv32_alu_trace(rec["alu_op"], rec["alu_b"], rec["alu_c"], la)
+    lt, rc, _ = ora.rv32_lt_trace(rec["lt_op"], rec["lt_b"], rec["lt_c"], ll)
+    sx, sy = 256, 2048
+    mul, tc = ora.rv32_mul_trace(rec["mul_b"], rec["mul_c"], lm, sx, sy)
+    order = ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read")
+    acc, _ = ora.memory_access_trace(*[rec["acc_" + k] for k in order], lacc)
+    bnd, _ = ora.memory_boundary_trace(rec["bnd_as"], rec["bnd_ptr"], rec["bnd_initial"], rec["bnd_final"], rec["bnd_final_ts"], 2, 29, lbnd)
+    n, nb = len(rec["acc_ts"]), len(rec["bnd_ptr"])
+    cnt = np.zeros(1 << 16, np.int64)
+    for v in (acc[8][:n], acc[9][:n], acc[4][:n], bnd[6][:nb], bnd[7][:nb]):
+        cnt += np.bincount(v.astype(np.int64), minlength=1 << 16)
+    A = lambda program, lh, w, tr, prep=None: dict(program=program, log_height=lh, width=w, n_pvs=0, trace=tr, pvs=NOPV, **({"prep": prep} if prep is not None else {}))  # noqa: E731
+    airs = [A(air.program_air().program(), lp, 10, np.concatenate([prog, freq.reshape(1, -1)])),
+            A(air.exec_frame_air().program(), lf, 10, frames),
+            A(air.rv32_alu_core_air().program(), la, 18, alu),
+            A(air.rv32_lt_core_air().program(), ll, 18, lt),
+            A(air.rv32_mul_core_air().program(), lm, 13, mul),
+            A(air.bitwise_lookup_air(8).program(), 16, 2, np.stack([rc, xc]), air.bitwise_lookup_prep(8)),
+            A(air.range_tuple_table_air(sx, sy).program(), 19, 1, tc.reshape(1, -1), air.range_tuple_prep(sx, sy)),
+            A(air.memory_access_air().program(), lacc, 10, acc),
+            A(air.memory_boundary_air().program(), lbnd, 8, bnd),
+            A(air.range_table_air(5).program(), 16, 1, (cnt % P).astype(np.uint32).reshape(1, -1), np.arange(1 << 16, dtype=np.uint32).reshape(1, -1))]
+    params = (1, 0, 100, 16, 16)
+    assert proof == ora.stark_prove(params, airs).tobytes()

@@ -1,6 +1,8 @@
 // prove_cli -- command-line driver of the C++ prover mirror (include/zkhip_prover.hpp).
 //   prove_cli prove  <app.zkair> <openvm.toml> <task.bin> <out_proof.json>
 //   prove_cli verify <app.zkair> <openvm.toml> <proof.json>
+//   prove_cli prove-guest <guest.elf | exe.bin> <stdin.bin | -> <out_proof.json> [openvm.toml | -] [max_cost]
+//       guest image in, proof out (include/zkhip_vm_prover.hpp): execute, device trace generation, prove, self-verify
 // task.bin: [u32 id_len][id][u32 n_witness]{[u64 len][bytes]}  (the fields of ProvingTask that
 // a leaf task uses, crates/types/src/task.rs:7-23)
 #include <cstdio>
@@ -8,6 +10,7 @@
 #include <iostream>
 
 #include "zkhip_prover.hpp"
+#include "zkhip_vm_prover.hpp"
 
 using namespace scroll_zkvm_hip;
 
@@ -40,6 +43,40 @@ static ProvingTask read_task(const std::string& path) {
 
 int main(int argc, char** argv) {
     try {
+        if (argc >= 5 && std::string(argv[1]) == "prove-guest") {
+            // prove-guest <guest.elf | exe.bin> <stdin.bin | -> <out.json> [openvm.toml] [max_cost]: the whole gen_proof_stark flow
+            // (mod.rs:342-413) from a guest image: execute, generate the chips' traces on the device, prove, self-verify
+            std::ifstream f(argv[2], std::ios::binary);
+            if (!f) throw Error(Error::Io, std::string("cannot read ") + argv[2]);
+            const std::vector<uint8_t> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            zkhip_vm::StdIn in;
+            if (std::string(argv[3]) != "-") {
+                std::ifstream g(argv[3], std::ios::binary);
+                if (!g) throw Error(Error::Io, std::string("cannot read ") + argv[3]);
+                in.bytes.assign((std::istreambuf_iterator<char>(g)), std::istreambuf_iterator<char>());
+            }
+            zkhip_params params{1, 0, 100, 16, 16};
+            if (argc >= 6 && std::string(argv[5]) != "-") params = read_app_config(argv[5]);
+            const uint64_t max_cost = argc >= 7 ? strtoull(argv[6], nullptr, 10) : 0;
+            try {
+                zkhip_vm::VmProver vp(0);
+                const zkhip_vm::GuestProof gp = vp.prove_guest(params, zkhip_vm::parse_exe(raw), in, max_cost);
+                StarkProof sp;
+                sp.proof = gp.proof;
+                sp.user_pvs_proof = gp.exec.public_values;
+                for (unsigned h : gp.log_heights) sp.baseline.push_back((uint8_t)h);
+                sp.stat.total_cycles = gp.exec.total_cycle;
+                sp.stat.execution_time_mills = gp.execution_time_mills;
+                sp.stat.proving_time_mills = gp.proving_time_mills;
+                std::ofstream(argv[4]) << sp.to_json();
+                printf("{\"total_cycles\": %llu, \"proof_bytes\": %zu, \"execution_ms\": %llu, \"tracegen_ms\": %llu, \"proving_ms\": %llu, \"verified\": true}\n",
+                       (unsigned long long)gp.exec.total_cycle, gp.proof.size(), (unsigned long long)gp.execution_time_mills,
+                       (unsigned long long)gp.tracegen_time_mills, (unsigned long long)gp.proving_time_mills);
+            } catch (const zkhip_vm::Error& e) {
+                throw Error(Error::GenProof, e.what());
+            }
+            return 0;
+        }
         if (argc >= 5 && std::string(argv[1]) == "verify") {
             UniversalVerifier verifier = UniversalVerifier::setup(argv[2], argv[3]);  // no device needed
             auto js = slurp(argv[4]);

@@ -29,26 +29,7 @@ int main(int argc, char** argv) {
             return 2;
         }
         const std::vector<uint8_t> raw = read_file(argv[2]);
-        if (raw.size() < 24 || raw.size() % 4 > 3) throw zkhip_vm::Error("exe too short");
-        auto word = [&](size_t i) {
-            if (4 * i + 4 > raw.size()) throw zkhip_vm::Error("exe truncated");
-            uint32_t v;
-            memcpy(&v, raw.data() + 4 * i, 4);
-            return v;
-        };
-        zkhip_vm::Exe exe;
-        if (raw[0] == 0x7f && raw[1] == 'E') {
-            exe = zkhip_vm::load_elf(raw);  // an RV32 ELF image
-        } else {
-            if (word(0) != 0x58455A4Bu) throw zkhip_vm::Error("bad exe magic");
-            exe.pc_base = word(1);
-            const size_t n_prog = word(2);
-            for (size_t i = 0; i < n_prog; i++) exe.program.push_back(word(3 + i));
-            exe.data_base = word(3 + n_prog), exe.memory_bytes = word(4 + n_prog);
-            const size_t n_data = word(5 + n_prog), off = 4 * (6 + n_prog);
-            if (off + n_data > raw.size()) throw zkhip_vm::Error("exe data truncated");
-            exe.data.assign(raw.begin() + (long)off, raw.begin() + (long)(off + n_data));
-        }
+        const zkhip_vm::Exe exe = zkhip_vm::parse_exe(raw);
         zkhip_vm::StdIn in;
         if (std::string(argv[3]) != "-") in.bytes = read_file(argv[3]);
         const uint64_t max_cost = argc > 5 ? strtoull(argv[5], nullptr, 10) : 0;
