@@ -96,18 +96,17 @@ public:
             if (max_cost && rec && (instret_ & 1023u) == 0 && trace_cells(*rec, exe_.program.size()) > max_cost) return false;
             step(rec);
         }
-        if (rec) {  // boundary records, sorted by (address space, pointer)
-            std::vector<uint64_t> keys;
-            keys.reserve(cells_.size());
-            for (const auto& kv : cells_) keys.push_back(kv.first);
-            std::sort(keys.begin(), keys.end());
-            for (uint64_t k : keys) {
-                const Cell& c = cells_[k];
-                rec->bnd_as.push_back((uint32_t)(k >> 32)), rec->bnd_ptr.push_back((uint32_t)k);
-                rec->bnd_initial.push_back(c.initial), rec->bnd_final.push_back(c.data), rec->bnd_final_ts.push_back(c.ts);
-            }
-        }
+        close_segment(rec);
         return true;
+    }
+    // Continuation: executes at most `max_instr` further instructions into `rec` and closes the SEGMENT -- boundary records of the
+    // cells it touched (initial = their value when the segment began), memory log restarted at timestamp 1.  Consecutive
+    // segments are independent proofs; what chains them is that a cell's final value in one segment is its
+    // initial value in the next one that touches it.  Returns true once the guest has exited.
+    bool run_segment(uint64_t max_instr, ExecRecords* rec) {
+        for (uint64_t k = 0; !done_ && (max_instr == 0 || k < max_instr); k++) step(rec);
+        close_segment(rec);
+        return done_;
     }
     uint64_t instret() const { return instret_; }
     const std::vector<uint8_t>& public_values() const { return pv_; }
@@ -128,6 +127,21 @@ private:
     std::unordered_map<uint64_t, Cell> cells_;
     uint32_t clock_ = 0;
 
+    void close_segment(ExecRecords* rec) {
+        if (rec) {  // boundary records, sorted by (address space, pointer)
+            std::vector<uint64_t> keys;
+            keys.reserve(cells_.size());
+            for (const auto& kv : cells_) keys.push_back(kv.first);
+            std::sort(keys.begin(), keys.end());
+            for (uint64_t k : keys) {
+                const Cell& c = cells_[k];
+                rec->bnd_as.push_back((uint32_t)(k >> 32)), rec->bnd_ptr.push_back((uint32_t)k);
+                rec->bnd_initial.push_back(c.initial), rec->bnd_final.push_back(c.data), rec->bnd_final_ts.push_back(c.ts);
+            }
+        }
+        cells_.clear();
+        clock_ = 0;
+    }
     // one access of a 16-bit cell: `write` replaces its value by `value`
     void touch(ExecRecords* rec, uint32_t as, uint32_t ptr, uint32_t current, bool write, uint32_t value) {
         if (!rec) return;
@@ -373,6 +387,29 @@ inline Exe load_elf(const std::vector<uint8_t>& f, uint32_t stack_bytes = 1u << 
         if (sg.filesz) memcpy(exe.data.data() + (sg.vaddr - lo), f.data() + sg.off, sg.filesz);
     exe.memory_bytes = (uint32_t)(((hi - lo + 3) & ~3ull) + stack_bytes);
     return exe;
+}
+
+// The run cut into continuation segments of at most `max_instr` instructions: one ExecRecords per segment (each proven on its
+// own: VmProver::prove_segments), the public values and the total instruction count of the whole run.
+struct SegmentedExecution {
+    ExecutionResult result;
+    std::vector<ExecRecords> segments;
+};
+inline SegmentedExecution execute_segments(const Exe& exe, const StdIn& inputs, uint64_t max_instr) {
+    if (max_instr == 0) throw Error("segment length must be positive");
+    SegmentedExecution se;
+    Machine m(exe, inputs);
+    bool done = false;
+    while (!done) {
+        se.segments.emplace_back();
+        done = m.run_segment(max_instr, &se.segments.back());
+    }
+    if (m.exit_code()) throw Error("guest exited with code " + std::to_string(m.exit_code()));
+    bool all_zero = true;
+    for (uint8_t b : m.public_values()) all_zero = all_zero && b == 0;
+    if (all_zero) throw Error("public_values are all 0s for unexpected reason");
+    se.result = ExecutionResult{m.instret(), m.public_values()};
+    return se;
 }
 
 // An executable file: an RV32 ELF image, or the flat test format  u32 words [0x58455A4B "KZEX", pc_base, n_program, program...,

@@ -12,7 +12,9 @@
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "zkhip.h"
@@ -66,15 +68,23 @@ public:
     VmProver& operator=(const VmProver&) = delete;
 
     GuestProof prove_guest(const zkhip_params& params, const Exe& exe, const StdIn& in, uint64_t max_cost = 0) {
+        // ---- 1. execute
+        const auto t0 = std::chrono::steady_clock::now();
+        ExecRecords rec;
+        const ExecutionResult er = execute_guest(exe, in, max_cost, &rec);
+        const uint64_t exec_ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        GuestProof gp = prove_records(params, exe, rec);
+        gp.exec = er, gp.execution_time_mills = exec_ms;
+        return gp;
+    }
+
+    // One segment's (or a whole run's) records -> device traces -> proof.  gp.exec.total_cycle = the segment's instruction count.
+    GuestProof prove_records(const zkhip_params& params, const Exe& exe, const ExecRecords& rec) {
         using clk = std::chrono::steady_clock;
         auto ms = [](clk::time_point a, clk::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(b - a).count(); };
         GuestProof gp;
-        // ---- 1. execute
-        const auto t0 = clk::now();
-        ExecRecords rec;
-        gp.exec = execute_guest(exe, in, max_cost, &rec);
+        gp.exec.total_cycle = rec.pc_index.size();
         const auto t1 = clk::now();
-        gp.execution_time_mills = ms(t0, t1);
         // ---- 2. heights, device records, device traces
         const unsigned lp = log2_ceil_min1(exe.program.size()), lf = log2_ceil_min1(rec.pc_index.size());
         const unsigned la = log2_ceil_min1(rec.alu_op.size()), ll = log2_ceil_min1(rec.lt_op.size()), lm = log2_ceil_min1(rec.mul_b.size());
@@ -168,6 +178,8 @@ public:
         gp.proof.resize(len);
         gp.proving_time_mills = ms(t2, clk::now());
         if (verify(params, gp) != ZKHIP_OK) throw Error("the proof does not verify");
+        for (void* p : bufs_) zkhip_free(ctx_, p);  // the records and traces of this segment
+        bufs_.clear();
         return gp;
     }
 
@@ -210,5 +222,46 @@ private:
         return d;
     }
 };
+
+// Continuation: the run is cut into segments of at most `segment_instr` instructions (zkhip_vm::execute_segments) and every
+// segment is proven on its own -- independent STARKs spread over `inflight` provers per listed GPU, each
+// with a context of its own, like BatchProver's lanes (include/zkhip_prover.hpp).  What chains the segment proofs is the memory
+// boundary: a cell's final value in one segment is its initial value in the next segment that touches it (the aggregation layer
+// of the reference checks that link; here tests do).
+struct SegmentedProof {
+    ExecutionResult exec;
+    uint64_t execution_time_mills = 0, proving_wall_mills = 0;
+    std::vector<GuestProof> segments;
+};
+inline SegmentedProof prove_segments(const zkhip_params& params, const Exe& exe, const StdIn& in, uint64_t segment_instr,
+                                     unsigned inflight = 1, std::vector<int> devices = {0}) {
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    const SegmentedExecution se = execute_segments(exe, in, segment_instr);
+    const auto t1 = clk::now();
+    SegmentedProof sp;
+    sp.exec = se.result;
+    sp.execution_time_mills = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count();
+    sp.segments.resize(se.segments.size());
+    if (devices.empty() || inflight == 0) throw Error("no prover lanes");
+    const size_t n_lanes = std::min<size_t>(devices.size() * inflight, se.segments.size());
+    std::vector<std::thread> lanes;
+    std::vector<std::string> errors(n_lanes);
+    std::atomic<size_t> next{0};
+    for (size_t l = 0; l < n_lanes; l++)
+        lanes.emplace_back([&, l] {
+            try {
+                VmProver vp(devices[l % devices.size()]);
+                for (size_t k = next++; k < se.segments.size(); k = next++) sp.segments[k] = vp.prove_records(params, exe, se.segments[k]);
+            } catch (const std::exception& e) {
+                errors[l] = e.what();
+            }
+        });
+    for (auto& t : lanes) t.join();
+    for (const auto& e : errors)
+        if (!e.empty()) throw Error("segment prover: " + e);
+    sp.proving_wall_mills = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(clk::now() - t1).count();
+    return sp;
+}
 
 }  // namespace zkhip_vm

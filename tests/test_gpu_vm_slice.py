@@ -213,3 +213,39 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
             A(air.range_table_air(5).program(), 16, 1, (cnt % P).astype(np.uint32).reshape(1, -1), np.arange(1 << 16, dtype=np.uint32).reshape(1, -1))]
     params = (1, 0, 100, 16, 16)
     assert proof == ora.stark_prove(params, airs).tobytes()
+
+
+def test_continuation_segments_proven_over_lanes(tmp_path):
+    """`prove_cli prove-guest ... <segment_instr> <inflight>`: the run is cut into segments, each proven on its own (self-verified)
+    over `inflight` prover lanes on the GPU; the cycle counts add up and the last segment carries the public values."""
+    import base64
+    import json
+    import subprocess
+
+    from prover_mirror_util import CLI
+
+    words = mixed_program()
+    stdin = (99).to_bytes(4, "little")
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words))
+    inp = tmp_path / "stdin.bin"
+    inp.write_bytes(stdin)
+    out = tmp_path / "segments"
+    out.mkdir()
+    toml = tmp_path / "openvm.toml"
+    toml.write_text("[app_fri_params.fri_params]\nlog_blowup = 1\nlog_final_poly_len = 0\nnum_queries = 30\n"
+                    "commit_proof_of_work_bits = 4\nquery_proof_of_work_bits = 8\n")
+    r = subprocess.run([CLI, "prove-guest", str(exe), str(inp), str(out), str(toml), "0", "700", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    model = rv.run(words, stdin)
+    n_seg = (model["instret"] + 699) // 700
+    assert line["verified"] and line["total_cycles"] == model["instret"] and line["segments"] == n_seg and line["inflight"] == 3
+    cycles = 0
+    for k in range(n_seg):
+        sp = json.loads((out / ("segment-%d.json" % k)).read_text())
+        cycles += sp["stat"]["total_cycles"]
+        pv = base64.b64decode(sp["user_pvs_proof"])[8:]
+        assert pv == (model["pvs"] if k == n_seg - 1 else b"")
+        assert len(base64.b64decode(sp["proof"])) > 1000
+    assert cycles == model["instret"]

@@ -184,3 +184,50 @@ def test_elf_guest(tmp_path):
     (tmp_path / "cut.elf").write_bytes(exe.read_bytes()[:100])
     r = subprocess.run([VM, "exec", str(tmp_path / "cut.elf"), "-", "-"], capture_output=True, text=True)
     assert r.returncode != 0
+
+
+REC_NAMES = ("pc_index", "alu_op", "alu_b", "alu_c", "lt_op", "lt_b", "lt_c", "mul_b", "mul_c", "acc_as", "acc_ptr", "acc_prev_data",
+             "acc_prev_ts", "acc_data", "acc_ts", "acc_is_read", "bnd_as", "bnd_ptr", "bnd_initial", "bnd_final", "bnd_final_ts")
+
+
+def run_segments(tmp_path, program, stdin, segment_instr, max_segments=64):
+    exe = tmp_path / "exe.bin"
+    exe.write_bytes(rv.exe_bytes(program))
+    inp = tmp_path / "stdin.bin"
+    inp.write_bytes(stdin)
+    out = tmp_path / "segs"
+    out.mkdir(exist_ok=True)
+    for k in range(max_segments):
+        (out / ("seg-%d" % k)).mkdir(exist_ok=True)
+    r = subprocess.run([VM, "exec-segments", str(exe), str(inp), str(out), str(segment_instr)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    js = json.loads(r.stdout)
+    segs = [{n: np.fromfile(out / ("seg-%d" % k) / (n + ".u32"), dtype=np.uint32) for n in REC_NAMES} for k in range(len(js["segments"]))]
+    return js, segs
+
+
+@pytest.mark.parametrize("segment_instr", [100, 1000, 10**6])
+def test_continuation_segments(tmp_path, segment_instr):
+    """The run cut into segments: the segments' instruction streams concatenate to the whole run's, every segment's memory log is a
+    consistent history from ITS boundary's initial values, and a cell's final value in one segment is its initial value in the next
+    segment that touches it."""
+    prog = mixed_program()
+    stdin = (4242).to_bytes(4, "little")
+    js, segs = run_segments(tmp_path, prog, stdin, segment_instr)
+    model = rv.run(prog, stdin)
+    assert js["total_cycle"] == model["instret"] == sum(js["segments"]) and bytes(js["public_values"]) == model["pvs"]
+    assert all(n == segment_instr for n in js["segments"][:-1]) and 0 < js["segments"][-1] <= segment_instr
+    assert np.concatenate([s["pc_index"] for s in segs]).tolist() == model["records"]["pc_index"]
+    assert sum(len(s["alu_op"]) for s in segs) == len(model["records"]["alu"])
+    state = {}
+    for s in segs:
+        acc = list(zip(*(s["acc_" + k].tolist() for k in ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read"))))
+        bnd = list(zip(*(s["bnd_" + k].tolist() for k in ("as", "ptr", "initial", "final", "final_ts"))))
+        check_memory_log(acc, bnd)
+        for a, p, init, fin, ts in bnd:
+            if (a, p) in state:
+                assert state[(a, p)] == init      # the link between consecutive segment proofs
+            state[(a, p)] = fin
+    # the last values agree with the un-segmented run's boundary
+    whole = {(a, p): fin for a, p, init, fin, ts in model["records"]["bnd"]}
+    assert state == whole

@@ -1,7 +1,7 @@
 // prove_cli -- command-line driver of the C++ prover mirror (include/zkhip_prover.hpp).
 //   prove_cli prove  <app.zkair> <openvm.toml> <task.bin> <out_proof.json>
 //   prove_cli verify <app.zkair> <openvm.toml> <proof.json>
-//   prove_cli prove-guest <guest.elf | exe.bin> <stdin.bin | -> <out_proof.json> [openvm.toml | -] [max_cost]
+//   prove_cli prove-guest <guest.elf | exe.bin> <stdin.bin | -> <out_proof.json | out_dir> [openvm.toml | -] [max_cost] [segment_instr] [inflight]
 //       guest image in, proof out (include/zkhip_vm_prover.hpp): execute, device trace generation, prove, self-verify
 // task.bin: [u32 id_len][id][u32 n_witness]{[u64 len][bytes]}  (the fields of ProvingTask that
 // a leaf task uses, crates/types/src/task.rs:7-23)
@@ -58,6 +58,34 @@ int main(int argc, char** argv) {
             zkhip_params params{1, 0, 100, 16, 16};
             if (argc >= 6 && std::string(argv[5]) != "-") params = read_app_config(argv[5]);
             const uint64_t max_cost = argc >= 7 ? strtoull(argv[6], nullptr, 10) : 0;
+            const uint64_t segment_instr = argc >= 8 ? strtoull(argv[7], nullptr, 10) : 0;
+            const unsigned inflight = argc >= 9 ? (unsigned)atoi(argv[8]) : 1;
+            if (segment_instr) {
+                // continuation: <out_proof.json> is a directory; one StarkProof per segment, proven over `inflight` lanes
+                try {
+                    const zkhip_vm::SegmentedProof sg = zkhip_vm::prove_segments(params, zkhip_vm::parse_exe(raw), in, segment_instr, inflight);
+                    uint64_t cycles = 0, ms_sum = 0;
+                    for (size_t k = 0; k < sg.segments.size(); k++) {
+                        const zkhip_vm::GuestProof& gp = sg.segments[k];
+                        StarkProof sp;
+                        sp.proof = gp.proof;
+                        if (k + 1 == sg.segments.size()) sp.user_pvs_proof = sg.exec.public_values;
+                        for (unsigned h : gp.log_heights) sp.baseline.push_back((uint8_t)h);
+                        sp.stat.total_cycles = gp.exec.total_cycle;
+                        sp.stat.proving_time_mills = gp.proving_time_mills;
+                        std::ofstream(std::string(argv[4]) + "/segment-" + std::to_string(k) + ".json") << sp.to_json();
+                        cycles += gp.exec.total_cycle, ms_sum += gp.proving_time_mills + gp.tracegen_time_mills;
+                    }
+                    printf("{\"total_cycles\": %llu, \"segments\": %zu, \"inflight\": %u, \"execution_ms\": %llu, \"proving_wall_ms\": %llu, "
+                           "\"sum_of_segment_ms\": %llu, \"verified\": true}\n",
+                           (unsigned long long)cycles, sg.segments.size(), inflight, (unsigned long long)sg.execution_time_mills,
+                           (unsigned long long)sg.proving_wall_mills, (unsigned long long)ms_sum);
+                    if (cycles != sg.exec.total_cycle) throw Error(Error::GenProof, "segment cycle counts do not add up");
+                } catch (const zkhip_vm::Error& e) {
+                    throw Error(Error::GenProof, e.what());
+                }
+                return 0;
+            }
             try {
                 zkhip_vm::VmProver vp(0);
                 const zkhip_vm::GuestProof gp = vp.prove_guest(params, zkhip_vm::parse_exe(raw), in, max_cost);

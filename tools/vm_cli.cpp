@@ -21,9 +21,38 @@ static void write_u32(const std::string& p, const std::vector<uint32_t>& v) {
     std::ofstream f(p, std::ios::binary);
     f.write((const char*)v.data(), (std::streamsize)(v.size() * 4));
 }
+static void write_records(const std::string& out, const zkhip_vm::ExecRecords& rec) {
+    write_u32(out + "/pc_index.u32", rec.pc_index);
+    write_u32(out + "/alu_op.u32", rec.alu_op), write_u32(out + "/alu_b.u32", rec.alu_b), write_u32(out + "/alu_c.u32", rec.alu_c);
+    write_u32(out + "/lt_op.u32", rec.lt_op), write_u32(out + "/lt_b.u32", rec.lt_b), write_u32(out + "/lt_c.u32", rec.lt_c);
+    write_u32(out + "/mul_b.u32", rec.mul_b), write_u32(out + "/mul_c.u32", rec.mul_c);
+    write_u32(out + "/acc_as.u32", rec.acc_as), write_u32(out + "/acc_ptr.u32", rec.acc_ptr);
+    write_u32(out + "/acc_prev_data.u32", rec.acc_prev_data), write_u32(out + "/acc_prev_ts.u32", rec.acc_prev_ts);
+    write_u32(out + "/acc_data.u32", rec.acc_data), write_u32(out + "/acc_ts.u32", rec.acc_ts), write_u32(out + "/acc_is_read.u32", rec.acc_is_read);
+    write_u32(out + "/bnd_as.u32", rec.bnd_as), write_u32(out + "/bnd_ptr.u32", rec.bnd_ptr), write_u32(out + "/bnd_initial.u32", rec.bnd_initial);
+    write_u32(out + "/bnd_final.u32", rec.bnd_final), write_u32(out + "/bnd_final_ts.u32", rec.bnd_final_ts);
+}
 
 int main(int argc, char** argv) {
     try {
+        if (argc >= 6 && std::string(argv[1]) == "exec-segments") {
+            // vm_cli exec-segments <exe> <stdin|-> <out_dir> <segment_instr>: the continuation split; out_dir/seg-<k>/ must exist
+            const zkhip_vm::Exe exe = zkhip_vm::parse_exe(read_file(argv[2]));
+            zkhip_vm::StdIn in;
+            if (std::string(argv[3]) != "-") in.bytes = read_file(argv[3]);
+            const zkhip_vm::SegmentedExecution se = zkhip_vm::execute_segments(exe, in, strtoull(argv[5], nullptr, 10));
+            std::ostringstream js;
+            js << "{\"total_cycle\": " << se.result.total_cycle << ", \"segments\": [";
+            for (size_t k = 0; k < se.segments.size(); k++) {
+                write_records(std::string(argv[4]) + "/seg-" + std::to_string(k), se.segments[k]);
+                js << (k ? ", " : "") << se.segments[k].pc_index.size();
+            }
+            js << "], \"public_values\": [";
+            for (size_t i = 0; i < se.result.public_values.size(); i++) js << (i ? ", " : "") << (unsigned)se.result.public_values[i];
+            js << "]}";
+            std::cout << js.str() << std::endl;
+            return 0;
+        }
         if (argc < 5 || std::string(argv[1]) != "exec") {
             fprintf(stderr, "usage: vm_cli exec <exe.bin> <stdin.bin|-> <out_dir|-> [max_cost]\n");
             return 2;
@@ -36,17 +65,7 @@ int main(int argc, char** argv) {
         zkhip_vm::ExecRecords rec;
         const zkhip_vm::ExecutionResult r = zkhip_vm::execute_guest(exe, in, max_cost, &rec);
         const std::string out = argv[4];
-        if (out != "-") {
-            write_u32(out + "/pc_index.u32", rec.pc_index);
-            write_u32(out + "/alu_op.u32", rec.alu_op), write_u32(out + "/alu_b.u32", rec.alu_b), write_u32(out + "/alu_c.u32", rec.alu_c);
-            write_u32(out + "/lt_op.u32", rec.lt_op), write_u32(out + "/lt_b.u32", rec.lt_b), write_u32(out + "/lt_c.u32", rec.lt_c);
-            write_u32(out + "/mul_b.u32", rec.mul_b), write_u32(out + "/mul_c.u32", rec.mul_c);
-            write_u32(out + "/acc_as.u32", rec.acc_as), write_u32(out + "/acc_ptr.u32", rec.acc_ptr);
-            write_u32(out + "/acc_prev_data.u32", rec.acc_prev_data), write_u32(out + "/acc_prev_ts.u32", rec.acc_prev_ts);
-            write_u32(out + "/acc_data.u32", rec.acc_data), write_u32(out + "/acc_ts.u32", rec.acc_ts), write_u32(out + "/acc_is_read.u32", rec.acc_is_read);
-            write_u32(out + "/bnd_as.u32", rec.bnd_as), write_u32(out + "/bnd_ptr.u32", rec.bnd_ptr), write_u32(out + "/bnd_initial.u32", rec.bnd_initial);
-            write_u32(out + "/bnd_final.u32", rec.bnd_final), write_u32(out + "/bnd_final_ts.u32", rec.bnd_final_ts);
-        }
+        if (out != "-") write_records(out, rec);
         std::ostringstream js;
         js << "{\"total_cycle\": " << r.total_cycle << ", \"public_values\": [";
         for (size_t i = 0; i < r.public_values.size(); i++) js << (i ? ", " : "") << (unsigned)r.public_values[i];
