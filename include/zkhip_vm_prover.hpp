@@ -10,6 +10,7 @@
 #pragma once
 #include <chrono>
 #include <cstring>
+#include <map>
 #include <numeric>
 #include <stdexcept>
 #include <atomic>
@@ -61,6 +62,8 @@ public:
         if (zkhip_ctx_create(device, &ctx_) != ZKHIP_OK) throw Error("zkhip_ctx_create failed (needs a gfx950 device)");
     }
     ~VmProver() {
+        for (auto& kv : keys_)
+            if (kv.second.pk) zkhip_pk_destroy(ctx_, kv.second.pk);
         for (void* p : bufs_) zkhip_free(ctx_, p);
         if (ctx_) zkhip_ctx_destroy(ctx_);
     }
@@ -79,7 +82,7 @@ public:
     }
 
     // One segment's (or a whole run's) records -> device traces -> proof.  gp.exec.total_cycle = the segment's instruction count.
-    GuestProof prove_records(const zkhip_params& params, const Exe& exe, const ExecRecords& rec) {
+    GuestProof prove_records(const zkhip_params& params, const Exe& exe, const ExecRecords& rec, bool self_verify = true) {
         using clk = std::chrono::steady_clock;
         auto ms = [](clk::time_point a, clk::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(b - a).count(); };
         GuestProof gp;
@@ -160,24 +163,32 @@ public:
         std::vector<zkhip_air> airs(N_VM_AIRS);
         for (unsigned a = 0; a < N_VM_AIRS; a++)
             airs[a] = zkhip_air{gp.programs[a].data(), gp.programs[a].size(), gp.log_heights[a], widths[a], 0, preps[a], nullptr};
-        zkhip_pk* pk = nullptr;
-        check(zkhip_keygen(ctx_, &params, airs.data(), airs.size(), &pk));
-        gp.prep_commits.assign(N_VM_AIRS, std::array<uint32_t, 8>{});
+        // proving keys are kept per height set: consecutive segments of one run have the same heights, and a key holds the
+        // committed lookup tables and the compiled constraint kernels (keys live until the prover is destroyed, like the
+        // reference's keys until Prover::reset)
+        if (have_params_ && memcmp(&params_, &params, sizeof params) != 0) throw Error("one VmProver proves with one set of FRI parameters");
+        params_ = params, have_params_ = true;
+        Key& key = keys_[gp.log_heights];
+        if (!key.pk) {
+            check(zkhip_keygen(ctx_, &params, airs.data(), airs.size(), &key.pk));
+            key.prep_commits.assign(N_VM_AIRS, std::array<uint32_t, 8>{});
+            for (unsigned a = 0; a < N_VM_AIRS; a++)
+                if (preps[a]) check(zkhip_pk_prep_commitment(ctx_, key.pk, a, key.prep_commits[a].data()));
+        }
+        zkhip_pk* pk = key.pk;
+        gp.prep_commits = key.prep_commits;
         gp.has_prep.assign(N_VM_AIRS, 0);
-        for (unsigned a = 0; a < N_VM_AIRS; a++)
-            if (preps[a]) gp.has_prep[a] = 1, check(zkhip_pk_prep_commitment(ctx_, pk, a, gp.prep_commits[a].data()));
+        for (unsigned a = 0; a < N_VM_AIRS; a++) gp.has_prep[a] = preps[a] ? 1 : 0;
         // ---- 4. prove from the device-resident traces, then the mandatory self-check (mod.rs:407-411)
         const uint32_t* d_traces[N_VM_AIRS] = {d_program_trace, d_frames, d_alu, d_lt, d_mul, d_bw, d_tup, d_acc, d_bnd, d_rng};
         const uint32_t* pvs[N_VM_AIRS] = {};
         gp.proof.resize(zkhip_proof_size(pk));
         size_t len = 0;
         const int rc = zkhip_prove(ctx_, pk, d_traces, pvs, gp.proof.data(), gp.proof.size(), &len);
-        const std::string err = rc == ZKHIP_OK ? "" : zkhip_last_error(ctx_);
-        zkhip_pk_destroy(ctx_, pk);
-        if (rc != ZKHIP_OK) throw Error("zkhip_prove: " + err);
+        if (rc != ZKHIP_OK) throw Error(std::string("zkhip_prove: ") + zkhip_last_error(ctx_));
         gp.proof.resize(len);
         gp.proving_time_mills = ms(t2, clk::now());
-        if (verify(params, gp) != ZKHIP_OK) throw Error("the proof does not verify");
+        if (self_verify && verify(params, gp) != ZKHIP_OK) throw Error("the proof does not verify");
         for (void* p : bufs_) zkhip_free(ctx_, p);  // the records and traces of this segment
         bufs_.clear();
         return gp;
@@ -197,6 +208,13 @@ public:
 private:
     zkhip_ctx* ctx_ = nullptr;
     std::vector<void*> bufs_;
+    struct Key {
+        zkhip_pk* pk = nullptr;
+        std::vector<std::array<uint32_t, 8>> prep_commits;
+    };
+    std::map<std::vector<unsigned>, Key> keys_;
+    zkhip_params params_{};
+    bool have_params_ = false;
 
     void check(int rc) {
         if (rc != ZKHIP_OK) throw Error(std::string("zkhip: ") + zkhip_last_error(ctx_));
@@ -252,7 +270,8 @@ inline SegmentedProof prove_segments(const zkhip_params& params, const Exe& exe,
         lanes.emplace_back([&, l] {
             try {
                 VmProver vp(devices[l % devices.size()]);
-                for (size_t k = next++; k < se.segments.size(); k = next++) sp.segments[k] = vp.prove_records(params, exe, se.segments[k]);
+                // the mandatory self-check (mod.rs:407-411) runs on host threads after the lanes are done, not on a lane
+                for (size_t k = next++; k < se.segments.size(); k = next++) sp.segments[k] = vp.prove_records(params, exe, se.segments[k], false);
             } catch (const std::exception& e) {
                 errors[l] = e.what();
             }
@@ -260,6 +279,19 @@ inline SegmentedProof prove_segments(const zkhip_params& params, const Exe& exe,
     for (auto& t : lanes) t.join();
     for (const auto& e : errors)
         if (!e.empty()) throw Error("segment prover: " + e);
+    {
+        const size_t n_ver = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), sp.segments.size());
+        std::vector<std::thread> vt;
+        std::atomic<size_t> nv{0};
+        std::atomic<int> bad{0};
+        for (size_t t = 0; t < n_ver; t++)
+            vt.emplace_back([&] {
+                for (size_t k = nv++; k < sp.segments.size(); k = nv++)
+                    if (VmProver::verify(params, sp.segments[k]) != ZKHIP_OK) bad++;
+            });
+        for (auto& t : vt) t.join();
+        if (bad) throw Error("a segment proof does not verify");
+    }
     sp.proving_wall_mills = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(clk::now() - t1).count();
     return sp;
 }

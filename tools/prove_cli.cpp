@@ -76,10 +76,12 @@ int main(int argc, char** argv) {
                         std::ofstream(std::string(argv[4]) + "/segment-" + std::to_string(k) + ".json") << sp.to_json();
                         cycles += gp.exec.total_cycle, ms_sum += gp.proving_time_mills + gp.tracegen_time_mills;
                     }
+                    std::string per;
+                    for (const auto& gp : sg.segments) per += (per.empty() ? "[" : ", [") + std::to_string(gp.tracegen_time_mills) + ", " + std::to_string(gp.proving_time_mills) + "]";
                     printf("{\"total_cycles\": %llu, \"segments\": %zu, \"inflight\": %u, \"execution_ms\": %llu, \"proving_wall_ms\": %llu, "
-                           "\"sum_of_segment_ms\": %llu, \"verified\": true}\n",
+                           "\"sum_of_segment_ms\": %llu, \"segment_tracegen_and_proving_ms\": [%s], \"verified\": true}\n",
                            (unsigned long long)cycles, sg.segments.size(), inflight, (unsigned long long)sg.execution_time_mills,
-                           (unsigned long long)sg.proving_wall_mills, (unsigned long long)ms_sum);
+                           (unsigned long long)sg.proving_wall_mills, (unsigned long long)ms_sum, per.c_str());
                     if (cycles != sg.exec.total_cycle) throw Error(Error::GenProof, "segment cycle counts do not add up");
                 } catch (const zkhip_vm::Error& e) {
                     throw Error(Error::GenProof, e.what());
