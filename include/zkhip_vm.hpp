@@ -198,10 +198,12 @@ private:
         const bool uses_rs1 = op == 0x67 || op == 0x63 || op == 0x03 || op == 0x23 || op == 0x13 || op == 0x33;
         const bool uses_rs2 = op == 0x63 || op == 0x23 || op == 0x33;
         const uint32_t a = uses_rs1 ? reg_read(rec, rs1) : 0, b = uses_rs2 ? reg_read(rec, rs2) : 0;
-        const int32_t imm_i = (int32_t)w >> 20;
-        const int32_t imm_s = (((int32_t)w >> 25) << 5) | (int32_t)((w >> 7) & 31);
-        const int32_t imm_b = (((int32_t)w >> 31) << 12) | (int32_t)(((w >> 7) & 1) << 11) | (int32_t)(((w >> 25) & 63) << 5) | (int32_t)(((w >> 8) & 15) << 1);
-        const int32_t imm_j = (((int32_t)w >> 31) << 20) | (int32_t)(((w >> 12) & 255) << 12) | (int32_t)(((w >> 20) & 1) << 11) | (int32_t)(((w >> 21) & 1023) << 1);
+        // immediates: assembled as unsigned fields, sign-extended once (shifting a negative value left is undefined before C++20)
+        auto sext = [](uint32_t v, unsigned bits) { const uint32_t m = 1u << (bits - 1); return (int32_t)((v ^ m) - m); };
+        const int32_t imm_i = sext(w >> 20, 12);
+        const int32_t imm_s = sext(((w >> 25) << 5) | ((w >> 7) & 31u), 12);
+        const int32_t imm_b = sext(((w >> 31) << 12) | (((w >> 7) & 1u) << 11) | (((w >> 25) & 63u) << 5) | (((w >> 8) & 15u) << 1), 13);
+        const int32_t imm_j = sext(((w >> 31) << 20) | (((w >> 12) & 255u) << 12) | (((w >> 20) & 1u) << 11) | (((w >> 21) & 1023u) << 1), 21);
         uint32_t next = pc_ + 4, val = 0;
         bool wr = false;
         if (rec) rec->pc_index.push_back((uint32_t)idx64);
@@ -437,7 +439,8 @@ inline Exe parse_exe(const std::vector<uint8_t>& raw) {
 
 // crates/prover/src/utils/vm.rs:13-48.  `records`, when given, receives the per-chip execution records of the run that
 // produced the result (the metered run, or the fall-back run).
-inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64_t max_cost = 0, ExecRecords* records = nullptr) {
+inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64_t max_cost = 0, ExecRecords* records = nullptr,
+                                     uint64_t max_instr = 0) {
     auto all_zero = [](const std::vector<uint8_t>& v) {
         for (uint8_t b : v)
             if (b) return false;
@@ -450,7 +453,7 @@ inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64
         Machine m(exe, inputs);
         bool finished = false;
         try {
-            finished = m.run(0, max_cost, rec);
+            finished = m.run(max_instr, max_cost, rec);
         } catch (const Error&) {
             finished = false;  // "Metered execution failed: {e}, falling back to execute"
         }
@@ -463,7 +466,7 @@ inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64
     // the plain executor: no cost bound, and -- like the reference's -- no instruction count (u64::MAX as the sentinel)
     *rec = ExecRecords();
     Machine m(exe, inputs);
-    m.run(0, 0, rec);
+    if (!m.run(max_instr, 0, rec)) throw Error("instruction limit reached");  // max_instr: a service-side bound, 0 = none
     if (m.exit_code()) throw Error("guest exited with code " + std::to_string(m.exit_code()));
     if (all_zero(m.public_values())) throw Error("public_values are all 0s upon execute");
     return ExecutionResult{UINT64_MAX, m.public_values()};

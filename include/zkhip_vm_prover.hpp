@@ -13,6 +13,7 @@
 #include <map>
 #include <numeric>
 #include <stdexcept>
+#include <array>
 #include <atomic>
 #include <string>
 #include <thread>

@@ -231,3 +231,42 @@ def test_continuation_segments(tmp_path, segment_instr):
     # the last values agree with the un-segmented run's boundary
     whole = {(a, p): fin for a, p, init, fin, ts in model["records"]["bnd"]}
     assert state == whole
+
+
+def test_interpreter_survives_arbitrary_programs(tmp_path):
+    """Random instruction words, random mutations of a real program, truncated / corrupt images: under AddressSanitizer + UBSan the
+    interpreter either finishes or reports an error -- it never crashes, reads out of bounds or hangs (instruction limit)."""
+    exe_san = str(tmp_path / "vm_cli_san")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tools", "vm_cli.cpp"), "-o", exe_san], check=True)
+    rng = np.random.default_rng(2024)
+    base = mixed_program()
+    env = dict(os.environ, ZKHIP_VM_MAX_INSTR="20000", ASAN_OPTIONS="detect_leaks=0")
+    outcomes = {0: 0, 1: 0}
+    for case in range(250):
+        kind = case % 5
+        if kind == 0:
+            words = [int(x) for x in rng.integers(0, 1 << 32, size=int(rng.integers(1, 40)), dtype=np.uint64)]
+        elif kind == 1:   # valid opcodes, random fields
+            ops = [0x37, 0x17, 0x6F, 0x67, 0x63, 0x03, 0x23, 0x13, 0x33, 0x73]
+            words = [(int(rng.integers(0, 1 << 25)) << 7) | int(rng.choice(ops)) for _ in range(int(rng.integers(1, 60)))]
+        else:             # a real program with a few words / bits changed
+            words = list(base)
+            for _ in range(int(rng.integers(1, 6))):
+                k = int(rng.integers(0, len(words)))
+                words[k] = (words[k] ^ (1 << int(rng.integers(0, 32)))) if kind < 4 else int(rng.integers(0, 1 << 32, dtype=np.uint64))
+        raw = rv.exe_bytes(words) if case % 7 else rv.elf_bytes(words)
+        if case % 11 == 0:
+            raw = raw[:int(rng.integers(1, len(raw)))]           # truncated image
+        elif case % 13 == 0:
+            raw = bytearray(raw)
+            raw[int(rng.integers(0, min(60, len(raw))))] ^= 0xFF   # corrupt header
+        f = tmp_path / "fuzz.bin"
+        f.write_bytes(bytes(raw))
+        inp = tmp_path / "in.bin"
+        inp.write_bytes(rng.integers(0, 256, size=64, dtype=np.uint8).tobytes())
+        r = subprocess.run([exe_san, "exec", str(f), str(inp), "-"], capture_output=True, text=True, env=env, timeout=60)
+        assert r.returncode in (0, 1), (case, r.returncode, r.stderr[-2000:])
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (case, r.stderr[-2000:])
+        outcomes[r.returncode] += 1
+    assert outcomes[1] > 50   # most mutants fail cleanly; some still finish

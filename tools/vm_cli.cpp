@@ -63,7 +63,8 @@ int main(int argc, char** argv) {
         if (std::string(argv[3]) != "-") in.bytes = read_file(argv[3]);
         const uint64_t max_cost = argc > 5 ? strtoull(argv[5], nullptr, 10) : 0;
         zkhip_vm::ExecRecords rec;
-        const zkhip_vm::ExecutionResult r = zkhip_vm::execute_guest(exe, in, max_cost, &rec);
+        const uint64_t max_instr = getenv("ZKHIP_VM_MAX_INSTR") ? strtoull(getenv("ZKHIP_VM_MAX_INSTR"), nullptr, 10) : 0;
+        const zkhip_vm::ExecutionResult r = zkhip_vm::execute_guest(exe, in, max_cost, &rec, max_instr);
         const std::string out = argv[4];
         if (out != "-") write_records(out, rec);
         std::ostringstream js;
