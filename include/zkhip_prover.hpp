@@ -174,6 +174,30 @@ struct ProvingTask {
     std::vector<uint8_t> vk;
     std::string identifier;
     std::vector<std::array<uint8_t, 32>> input_commits;
+
+    // crates/prover/src/task/mod.rs:13-17,27-38: the guest's input (hint) stream -- every serialized witness as one
+    // `write_bytes` item, then the input commitments when there are any.  The stream a zkhip_vm guest reads word by word
+    // (environment call 2) frames an item as [byte length][bytes, zero-padded to a word boundary]; the commitments follow as
+    // [count][8 words each].
+    zkhip_vm::StdIn build_guest_input() const {
+        zkhip_vm::StdIn in;
+        build_guest_input_inner(in);
+        return in;
+    }
+    void build_guest_input_inner(zkhip_vm::StdIn& in) const {
+        auto word = [&](uint32_t v) {
+            for (int k = 0; k < 4; k++) in.bytes.push_back((uint8_t)(v >> (8 * k)));
+        };
+        for (const auto& w : serialized_witness) {
+            word((uint32_t)w.size());
+            in.bytes.insert(in.bytes.end(), w.begin(), w.end());
+            while (in.bytes.size() % 4) in.bytes.push_back(0);
+        }
+        if (!input_commits.empty()) {
+            word((uint32_t)input_commits.size());
+            for (const auto& c : input_commits) in.bytes.insert(in.bytes.end(), c.begin(), c.end());
+        }
+    }
 };
 
 // witness layout of chip i (little-endian u32 words):

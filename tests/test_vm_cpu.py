@@ -270,3 +270,39 @@ def test_interpreter_survives_arbitrary_programs(tmp_path):
         assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (case, r.stderr[-2000:])
         outcomes[r.returncode] += 1
     assert outcomes[1] > 50   # most mutants fail cleanly; some still finish
+
+
+def test_build_guest_input_stream(tmp_path):
+    """ProvingTask::build_guest_input (crates/prover/src/task/mod.rs:13-38) in the C++ mirror: witnesses as length-framed items,
+    then the input commitments; a guest that walks the whole stream (sum of all words, number of items) sees what the Python
+    model sees on the same bytes."""
+    exe = str(tmp_path / "guest_input_cpp")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "guest_input_cpp.cpp"), "-o", exe,
+                    "-L", os.path.join(ROOT, "zkvm-prover_amd"), "-lzkhip", "-Wl,-rpath," + os.path.join(ROOT, "zkvm-prover_amd"), "-pthread"], check=True)
+    # guest: read 3 items [len][words...], then the commitments [count][8 words each]; checksum += every word read
+    p = [("addi", S0, 0, 0), ("addi", S1, 0, 0),                       # s0 = checksum, s1 = items seen
+         ("label", "item"), ("slti", T3, S1, 3), ("beq", T3, 0, "commits"),
+         ("addi", A7, 0, 2), ("ecall",), ("add", S0, S0, A0),          # length
+         ("addi", T0, A0, 3), ("srli", T0, T0, 2),                     # words to read
+         ("label", "w"), ("beq", T0, 0, "next"), ("ecall",), ("add", S0, S0, A0), ("addi", T0, T0, -1), ("jal", 0, "w"),
+         ("label", "next"), ("addi", S1, S1, 1), ("jal", 0, "item"),
+         ("label", "commits"), ("addi", A7, 0, 2), ("ecall",), ("add", S0, S0, A0), ("slli", T0, A0, 3),
+         ("label", "cw"), ("beq", T0, 0, "out"), ("ecall",), ("add", S0, S0, A0), ("addi", T0, T0, -1), ("jal", 0, "cw"),
+         ("label", "out"), ("add", A0, S0, 0), ("addi", A1, 0, 0), ("addi", A7, 0, 1), ("ecall",),
+         ("addi", A0, S1, 0), ("addi", A1, 0, 1), ("ecall",),
+         ("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    words = rv.assemble(p)
+    guest = tmp_path / "guest.bin"
+    guest.write_bytes(rv.exe_bytes(words))
+    r = subprocess.run([exe, str(guest)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    stream_hex, pv_hex, cycles = r.stdout.split()
+    stream = bytes.fromhex(stream_hex)
+    w1, w3 = bytes([1, 2, 3, 4, 5]), bytes([0xFF, 0xFE, 0xFD, 0xFC, 0xFB, 0xFA, 0xF9, 0xF8])
+    commit = bytes((3 * i + 1) & 255 for i in range(32))
+    expect = (5).to_bytes(4, "little") + w1 + bytes(3) + (0).to_bytes(4, "little") + (8).to_bytes(4, "little") + w3 + (2).to_bytes(4, "little") + commit * 2
+    assert stream == expect
+    model = rv.run(words, stream)
+    assert bytes.fromhex(pv_hex) == model["pvs"] and int(cycles) == model["instret"]
+    total = sum(int.from_bytes(stream[i:i + 4], "little") for i in range(0, len(stream), 4)) & 0xFFFFFFFF
+    assert int.from_bytes(model["pvs"][:4], "little") == total and model["pvs"][4] == 3
