@@ -19,7 +19,7 @@ airs = cs.gen(2)
 cells = sum(a["width"] << a["log_height"] for a in airs)
 print("42 chips + range table: widths sum %d, heights %s, %.1f M trace cells (trace generation %.1f s)"
       % (sum(cs.widths), sorted(cs.heights, reverse=True)[:8], cells / 1e6, time.time() - t0))
-torch.cuda.set_stream(torch.cuda.Stream(device=0))  # a real stream (ZKHIP_GRAPH=1 cannot capture the legacy default stream)
+torch.cuda.set_stream(torch.cuda.Stream(device=0))  # a stream of its own, not the legacy default stream
 ctx = z.Context(0)
 t0 = time.time()
 pk = z.ProvingKey(ctx, z.DEFAULT_PARAMS, airs)
@@ -39,12 +39,12 @@ for it in range(2):
     ctx.profile_enable(False)
 print("proof %.2f ms (%.2f ns per trace cell)" % (dt * 1e3, dt * 1e9 / cells))
 best = 1e9
-for it in range(5):  # without the per-kernel events (and, with ZKHIP_GRAPH=1, replayed as one hipGraph)
+for it in range(5):  # without the per-kernel events
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pk.prove(d, pvs)
     torch.cuda.synchronize()
     best = min(best, time.perf_counter() - t0)
-print("proof without profiling events %.2f ms%s" % (best * 1e3, " (ZKHIP_GRAPH=1)" if os.environ.get("ZKHIP_GRAPH") else ""))
+print("proof without profiling events %.2f ms" % (best * 1e3))
 for k, (cnt, ms) in sorted(ctx.profile_read().items(), key=lambda kv: -kv[1][1])[:40]:
     print("   %-28s x%-4d %9.3f ms" % (k, cnt, ms))

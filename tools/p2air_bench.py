@@ -13,7 +13,7 @@ from zkvm_prover_amd import air
 
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 N = 1 << log_n
-torch.cuda.set_stream(torch.cuda.Stream(device=0))  # a real stream (ZKHIP_GRAPH=1 cannot capture the legacy default stream)
+torch.cuda.set_stream(torch.cuda.Stream(device=0))  # a stream of its own, not the legacy default stream
 ctx = z.Context(0)
 prog = air.poseidon2_air().program()
 airs = [dict(program=prog, log_height=log_n, width=298, n_pvs=0)]
