@@ -290,3 +290,25 @@ def test_rv32_less_than_chip(zk, ora):
     assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 3, proof) == 0
     assert proof == ora.stark_prove(PARAMS, airs).tobytes()
     pk.close()
+
+
+def test_memory_access_tracegen_refuses_inconsistent_records(zk, ora):
+    """The generator's own checks (a 16-bit cell, time moving forward, a read that leaves its cell alone) and parity with the oracle
+    on a hand-made log, including an empty one."""
+    dev = zk.device
+    t = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)  # noqa: E731
+    good = dict(as_=[1, 1, 2], ptr=[4, 4, 9], pd=[0, 7, 65535], pts=[0, 1, 0], d=[7, 7, 1], ts=[1, 2, 3], rd=[0, 1, 0])
+    tr = zk.memory_access_tracegen(*[t(good[k]) for k in ("as_", "ptr", "pd", "pts", "d", "ts", "rd")], 2)
+    exp, bad = ora.memory_access_trace(*[np.array(good[k], np.uint32) for k in ("as_", "ptr", "pd", "pts", "d", "ts", "rd")], 2)
+    assert bad == 0 and (zk.download(tr).reshape(10, -1) == exp).all()
+    assert air.check_trace(air.memory_access_air().program(), exp, NOPV) == []
+    empty = zk.memory_access_tracegen(*[torch.empty(0, dtype=torch.int32, device=dev)] * 7, 1)
+    assert (zk.download(empty) == 0).all()
+    for key, val in (("d", [7, 7, 65536]), ("ts", [1, 1, 3]), ("d", [7, 8, 1]), ("rd", [0, 2, 0]), ("pts", [0, 5, 0])):
+        rec = dict(good)
+        rec[key] = val
+        with pytest.raises(z.ZkhipError):
+            zk.memory_access_tracegen(*[t(rec[k]) for k in ("as_", "ptr", "pd", "pts", "d", "ts", "rd")], 2)
+        assert ora.memory_access_trace(*[np.array(rec[k], np.uint32) for k in ("as_", "ptr", "pd", "pts", "d", "ts", "rd")], 2)[1] >= 1
+    with pytest.raises(z.ZkhipError):   # more records than rows
+        zk.memory_access_tracegen(*[t(good[k]) for k in ("as_", "ptr", "pd", "pts", "d", "ts", "rd")], 1)

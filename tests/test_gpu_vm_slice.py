@@ -249,3 +249,23 @@ def test_continuation_segments_proven_over_lanes(tmp_path):
         assert pv == (model["pvs"] if k == n_seg - 1 else b"")
         assert len(base64.b64decode(sp["proof"])) > 1000
     assert cycles == model["instret"]
+
+
+def test_prove_guest_reports_guest_failures(tmp_path):
+    """Errors of the execution step surface as the reference's Error::GenProof (mod.rs:318-319): a guest that exits non-zero, one
+    whose public values stay zero, an image that is not an executable."""
+    import subprocess
+
+    from prover_mirror_util import CLI
+
+    cases = {"exit3": (rv.assemble([("addi", 10, 0, 3), ("addi", 17, 0, 93), ("ecall",)]), "exited with code 3"),
+             "zero_pvs": (rv.assemble([("addi", 10, 0, 0), ("addi", 17, 0, 93), ("ecall",)]), "public_values are all 0s")}
+    for name, (words, msg) in cases.items():
+        exe = tmp_path / (name + ".elf")
+        exe.write_bytes(rv.elf_bytes(words))
+        r = subprocess.run([CLI, "prove-guest", str(exe), "-", str(tmp_path / "out.json")], capture_output=True, text=True)
+        assert r.returncode != 0 and msg in r.stderr and "kind 3" in r.stderr, r.stderr   # kind 3 = Error::GenProof
+    junk = tmp_path / "junk.bin"
+    junk.write_bytes(b"not an executable at all")
+    r = subprocess.run([CLI, "prove-guest", str(junk), "-", str(tmp_path / "out.json")], capture_output=True, text=True)
+    assert r.returncode != 0
