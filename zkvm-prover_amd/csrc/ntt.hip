@@ -926,8 +926,18 @@ int ntt_batch(zkhip_ctx* ctx, uint32_t* d_mat, unsigned log_n, size_t width, siz
               bool bitrev_out) {
     if (width == 0) return ZKHIP_OK;
     if (stride < ((size_t)1 << log_n)) return set_error(ctx, ZKHIP_ERR_INVALID, "stride < height");
-    ZK_TRY(ntt_dif_inplace(ctx, d_mat, stride, d_mat, stride, log_n, width, 0, inverse));
     uint32_t n_inv = minv(to_monty((uint32_t)(((uint64_t)1 << log_n) % P)));
+    if (!bitrev_out) {
+        // natural order in and out: the transform writes its bit-reversed result into scratch and the bit-reversal pass
+        // brings it home (round 1 transformed in place, permuted into scratch and copied back: one pass over memory more)
+        const size_t n = (size_t)1 << log_n;
+        void* tmp;
+        ZK_TRY(get_scratch(ctx, 0, n * width * 4, &tmp));
+        ZK_TRY(ntt_dif_inplace(ctx, d_mat, stride, (uint32_t*)tmp, n, log_n, width, 0, inverse));
+        BitrevArgs a{(uint32_t*)tmp, n, d_mat, stride, nullptr, inverse ? n_inv : MONTY_ONE, log_n, 0, 0};
+        return launch_bitrev(ctx, a, width);
+    }
+    ZK_TRY(ntt_dif_inplace(ctx, d_mat, stride, d_mat, stride, log_n, width, 0, inverse));
     if (bitrev_out) {
         if (inverse) {
             // scale in place by 1/n
@@ -943,13 +953,6 @@ int ntt_batch(zkhip_ctx* ctx, uint32_t* d_mat, unsigned log_n, size_t width, siz
         }
         return ZKHIP_OK;
     }
-    size_t n = (size_t)1 << log_n;
-    void* tmp;
-    ZK_TRY(get_scratch(ctx, 0, n * width * 4, &tmp));
-    BitrevArgs a{d_mat, stride, (uint32_t*)tmp, n, nullptr, inverse ? n_inv : MONTY_ONE, log_n, 0, 0};
-    ZK_TRY(launch_bitrev(ctx, a, width));
-    ZK_HIP_CHECK(ctx, hipMemcpy2DAsync(d_mat, stride * 4, tmp, n * 4, n * 4, width, hipMemcpyDeviceToDevice,
-                                       ctx->stream));
     return ZKHIP_OK;
 }
 
