@@ -6,11 +6,15 @@
 //
 // What runs here is an RV32IM interpreter (the reference's guests are rv32im ELFs transpiled for OpenVM; its executor and
 // transpiler live in un-vendored crates, so the instruction set is the public RISC-V one, not OpenVM's opcode numbering).
-// Besides the result it produces what the step AFTER execution needs on this backend: per-chip EXECUTION RECORDS in the
-// layout the device trace generators take (include/zkhip.h: zkhip_program_freq_tracegen / zkhip_exec_frame_tracegen /
-// zkhip_rv32_alu_tracegen / zkhip_rv32_lt_tracegen / zkhip_rv32_mul_tracegen) -- the execution -> trace hand-off of
-// SURVEY.md 8(f) f3.  Chips that have no device generator yet (shifts, branches, loads / stores, jumps, division) are
-// counted, so that the cost model sees them, but leave no records.
+// Besides the result it produces what the step AFTER execution needs on this backend -- the execution -> trace hand-off of
+// SURVEY.md 8(f) f3 -- in the layout the device trace generators take (include/zkhip.h):
+//   * per-chip EXECUTION RECORDS: executed instruction indices (zkhip_program_freq_tracegen / zkhip_exec_frame_tracegen), ALU,
+//     less-than and multiplication operands (zkhip_rv32_{alu,lt,mul}_tracegen); instruction classes without a device generator
+//     yet (shifts, branches, loads / stores, jumps, division) are counted, so that the cost model sees them;
+//   * the MEMORY LOG over 16-bit cells of the register file and the read-write memory (zkhip_memory_access_tracegen) and the
+//     boundary records of the touched cells (zkhip_memory_boundary_tracegen): the offline memory-checking argument;
+//   * CONTINUATION: execute_segments cuts the run into independently provable segments chained by their memory boundaries.
+// load_elf / parse_exe read an ELF32 RISC-V image (or the flat test format).
 //
 // Environment calls (a7): 93 = exit(a0) (non-zero = guest failure), 1 = reveal the word a0 as public-value bytes
 // [4 a1, 4 a1 + 4), 2 = read the next word of the input stream into a0.  Header-only; no GPU code.
