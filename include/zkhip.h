@@ -151,6 +151,16 @@ int zkhip_memory_boundary_tracegen(zkhip_ctx *ctx, const uint32_t *d_addr_space,
 int zkhip_rv32_lt_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_b, const uint32_t *d_c, size_t n,
                            unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
 
+/* RV32 shift core (rv32im ShiftCoreAir<4, 8>: SLL / SRL / SRA).  Record i = (d_opcode[i]: 0 = SLL, 1 = SRL, 2 = SRA; d_b[i] the
+ * value; d_c[i] the shift operand, of which the low five bits count) -- plain integers.  Fills d_trace (ZKHIP_RV32_SHIFT_WIDTH = 32
+ * columns, stride 2^log_height, Montgomery: a[4] | b[4] | c0 | is_sll is_srl is_sra | bit_marker[8] | limb_marker[4] | carry[4] |
+ * sign | q | mult_left | mult_right; rows >= n zero) and adds the row's lookup requests to d_bitwise_trace (2 x 2^16): seven range
+ * pairs -- (carry_i, 2^bit_shift - 1 - carry_i) x 4, (a0, a1), (a2, a3), (q, 32 q) -- and for SRA the XOR request (b3, 128).
+ * AIR: air.py rv32_shift_core_air(). */
+#define ZKHIP_RV32_SHIFT_WIDTH 32
+int zkhip_rv32_shift_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_b, const uint32_t *d_c, size_t n,
+                              unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

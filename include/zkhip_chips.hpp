@@ -229,6 +229,129 @@ inline void rv32_lt_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
     }
 }
 
+// air.rv32_shift_core_air(bus): AirBuilder(32, 0)
+inline void rv32_shift_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
+    Expr a_[4], b_[4], bm[8], lm[4], cy[4];
+    for (int i = 0; i < 4; i++) a_[i] = b.var(i);
+    for (int i = 0; i < 4; i++) b_[i] = b.var(4 + i);
+    const Expr c0 = b.var(8), sll = b.var(9), srl = b.var(10), sra = b.var(11);
+    for (int i = 0; i < 8; i++) bm[i] = b.var(12 + i);
+    for (int i = 0; i < 4; i++) lm[i] = b.var(20 + i);
+    for (int i = 0; i < 4; i++) cy[i] = b.var(24 + i);
+    const Expr sign = b.var(28), q = b.var(29), ml = b.var(30), mr = b.var(31);
+    const Expr ok0 = sll + srl;
+    const Expr ok = ok0 + sra;
+    const Expr right = srl + sra;
+    {
+        std::vector<Expr> fs{sll, srl, sra, ok, sign};
+        for (int i = 0; i < 8; i++) fs.push_back(bm[i]);
+        for (int i = 0; i < 4; i++) fs.push_back(lm[i]);
+        for (const Expr& f : fs) {
+            const Expr t = f - 1;
+            b.assert_zero(f * t);
+        }
+    }
+    Expr sbm = bm[0], slm = lm[0], mult = bm[0], bs, ls;
+    for (int i = 1; i < 8; i++) {
+        sbm = sbm + bm[i];
+        const Expr m2 = bm[i] * (int64_t)(1 << i);
+        mult = mult + m2;
+        const Expr mi = bm[i] * (int64_t)i;
+        bs = i == 1 ? mi : bs + mi;
+    }
+    for (int j = 1; j < 4; j++) {
+        slm = slm + lm[j];
+        const Expr mj = lm[j] * (int64_t)j;
+        ls = j == 1 ? mj : ls + mj;
+    }
+    b.assert_zero(sbm - ok);
+    b.assert_zero(slm - ok);
+    {
+        const Expr t1 = c0 - bs;
+        const Expr l8 = ls * 8;
+        const Expr t2 = t1 - l8;
+        const Expr q32 = q * 32;
+        b.assert_zero(t2 - q32);
+    }
+    {
+        const Expr m = sll * mult;
+        b.assert_zero(ml - m);
+    }
+    {
+        const Expr m = right * mult;
+        b.assert_zero(mr - m);
+    }
+    {
+        const Expr ns = 1 - sra;
+        b.assert_zero(sign * ns);
+    }
+    for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 4; i++) {
+            if (i < j) {
+                const Expr m = a_[i] * sll;
+                b.assert_zero(lm[j] * m);
+            } else {
+                const int k = i - j;
+                const Expr e1 = b_[k] * ml;
+                const Expr e2 = cy[k] * sll;
+                const Expr e3 = e2 * 256;
+                Expr exp = e1 - e3;
+                if (k > 0) {
+                    const Expr e4 = cy[k - 1] * sll;
+                    exp = exp + e4;
+                }
+                const Expr as = a_[i] * sll;
+                const Expr d = as - exp;
+                b.assert_zero(lm[j] * d);
+            }
+            if (i + j > 3) {
+                const Expr ar = a_[i] * right;
+                const Expr sr = sign * right;
+                const Expr s255 = sr * 255;
+                const Expr d = ar - s255;
+                b.assert_zero(lm[j] * d);
+            } else {
+                const int k = i + j;
+                Expr nxt;
+                if (k == 3) {
+                    const Expr t = mr - right;
+                    nxt = sign * t;
+                } else {
+                    nxt = cy[k + 1] * right;
+                }
+                const Expr am = a_[i] * mr;
+                const Expr n256 = nxt * 256;
+                const Expr d1 = am - n256;
+                const Expr bc = b_[k] - cy[k];
+                const Expr br = bc * right;
+                const Expr d2 = d1 - br;
+                b.assert_zero(lm[j] * d2);
+            }
+        }
+    for (int i = 0; i < 4; i++) {
+        const Expr m = ml + mr;
+        const Expr m1 = m - 1;
+        const Expr y = m1 - cy[i];
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {cy[i], y, z0, z0}, ok, Kind::Send);
+    }
+    {
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {a_[0], a_[1], z0, z0}, ok, Kind::Send);
+        b.push_interaction(bus, {a_[2], a_[3], z0, z0}, ok, Kind::Send);
+        const Expr q32 = q * 32;
+        b.push_interaction(bus, {q, q32, z0, z0}, ok, Kind::Send);
+    }
+    {
+        const Expr s1 = b_[3] + 128;
+        const Expr s256 = sign * 256;
+        const Expr z = s1 - s256;
+        const Expr c128 = b.constant(128);
+        const Expr one = b.constant(1);
+        b.push_interaction(bus, {b_[3], c128, z, one}, sra, Kind::Send);
+    }
+}
+
 // air.rv32_mul_core_air(bus): AirBuilder(13, 0)
 inline void rv32_mul_core_air(AirBuilder& b, uint32_t bus = RANGE_TUPLE_BUS) {
     Expr a_[4], b_[4], c_[4];

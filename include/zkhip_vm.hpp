@@ -9,8 +9,8 @@
 // Besides the result it produces what the step AFTER execution needs on this backend -- the execution -> trace hand-off of
 // SURVEY.md 8(f) f3 -- in the layout the device trace generators take (include/zkhip.h):
 //   * per-chip EXECUTION RECORDS: executed instruction indices (zkhip_program_freq_tracegen / zkhip_exec_frame_tracegen), ALU,
-//     less-than and multiplication operands (zkhip_rv32_{alu,lt,mul}_tracegen); instruction classes without a device generator
-//     yet (shifts, branches, loads / stores, jumps, division) are counted, so that the cost model sees them;
+//     less-than, multiplication and shift operands (zkhip_rv32_{alu,lt,mul,shift}_tracegen); instruction classes without a device
+//     generator yet (branches, loads / stores, jumps, division) are counted, so that the cost model sees them;
 //   * the MEMORY LOG over 16-bit cells of the register file and the read-write memory (zkhip_memory_access_tracegen) and the
 //     boundary records of the touched cells (zkhip_memory_boundary_tracegen): the offline memory-checking argument;
 //   * CONTINUATION: execute_segments cuts the run into independently provable segments chained by their memory boundaries.
@@ -54,6 +54,7 @@ struct ExecRecords {
     std::vector<uint32_t> alu_op, alu_b, alu_c;       // 0 add 1 sub 2 xor 3 or 4 and (register and immediate forms)
     std::vector<uint32_t> lt_op, lt_b, lt_c;          // 0 slt 1 sltu
     std::vector<uint32_t> mul_b, mul_c;               // mul (low word)
+    std::vector<uint32_t> shift_op, shift_b, shift_c; // 0 sll 1 srl 2 sra; c = the shift operand (register value or shamt)
     uint64_t n_shift = 0, n_branch = 0, n_jump = 0, n_load_store = 0, n_mulh = 0, n_divrem = 0, n_lui_auipc = 0, n_ecall = 0;
     // Memory log for the offline memory-checking argument (OpenVM's memory bus): state is kept in 16-bit CELLS -- address space
     // 1 = registers (cell 2 i + half of x_i), 2 = read-write memory (cell = halfword index from data_base) -- so that a cell's
@@ -220,7 +221,7 @@ private:
             return (uint32_t)(o == 0 ? (int32_t)x < (int32_t)y : x < y);
         };
         auto shift = [&](uint32_t kind, uint32_t x, uint32_t s) {
-            if (rec) rec->n_shift++;
+            if (rec) rec->n_shift++, rec->shift_op.push_back(kind), rec->shift_b.push_back(x), rec->shift_c.push_back(s);
             s &= 31;
             return kind == 0 ? x << s : kind == 1 ? x >> s : (uint32_t)((int32_t)x >> s);
         };

@@ -248,3 +248,51 @@ size_t ora_memory_access_trace(const uint32_t *as, const uint32_t *ptr, const ui
     }
     return bad;
 }
+
+/* RV32 shift core (zkhip_rv32_shift_tracegen): 32 columns a[4] | b[4] | c0 | is_sll is_srl is_sra | bit_marker[8] | limb_marker[4] |
+ * carry[4] | sign | q | mult_left | mult_right, canonical; range_counts / xor_counts[(x << 8) | y] (+)= 1 per lookup request.
+ * The result limbs come from a limb-wise restatement of the shift (not from the C shift operators the device kernel uses). */
+size_t ora_rv32_shift_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace,
+                            uint32_t *range_counts, uint32_t *xor_counts) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 32; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t op = opc[r];
+        if (op > 2) {
+            bad++;
+            continue;
+        }
+        const uint32_t s = cs[r] & 31u, bsh = s & 7u, lsh = s >> 3, c0 = cs[r] & 255u, q = c0 >> 5, mult = 1u << bsh;
+        uint32_t bl[4], t[4], cy[4], al[4];
+        for (int i = 0; i < 4; i++) bl[i] = (bs[r] >> (8 * i)) & 255u;
+        const uint32_t sign = op == 2 ? bl[3] >> 7 : 0;
+        if (op == 0) { /* bit shift limb by limb towards the top, then move up by whole limbs */
+            uint32_t carry = 0;
+            for (int k = 0; k < 4; k++) {
+                const uint32_t v = bl[k] * mult + carry;
+                t[k] = v & 255u, carry = cy[k] = v >> 8;
+            }
+            for (int i = 0; i < 4; i++) al[i] = (uint32_t)i < lsh ? 0 : t[i - lsh];
+        } else { /* towards the bottom: limb k keeps its high bits and takes the bits falling out of limb k + 1 (or the sign fill) */
+            for (int k = 0; k < 4; k++) cy[k] = bl[k] & (mult - 1u);
+            for (int k = 0; k < 4; k++) {
+                const uint32_t in = k == 3 ? sign * (mult - 1u) : cy[k + 1];
+                t[k] = (bl[k] >> bsh) + in * (256u / mult);
+            }
+            for (int i = 0; i < 4; i++) al[i] = i + lsh > 3 ? 255u * sign : t[i + lsh];
+        }
+        uint32_t row[32] = {0};
+        for (int i = 0; i < 4; i++) row[i] = al[i], row[4 + i] = bl[i], row[24 + i] = cy[i];
+        row[8] = c0, row[9 + op] = 1, row[12 + bsh] = 1, row[20 + lsh] = 1, row[28] = sign, row[29] = q, row[op == 0 ? 30 : 31] = mult;
+        for (size_t c = 0; c < 32; c++) trace[c * N + r] = row[c];
+        uint32_t *p;
+        for (int i = 0; i < 4; i++) p = &range_counts[(cy[i] << 8) | (mult - 1u - cy[i])], *p = ora_add(*p, 1);
+        p = &range_counts[(al[0] << 8) | al[1]], *p = ora_add(*p, 1);
+        p = &range_counts[(al[2] << 8) | al[3]], *p = ora_add(*p, 1);
+        p = &range_counts[(q << 8) | (32u * q)], *p = ora_add(*p, 1);
+        if (op == 2) p = &xor_counts[(bl[3] << 8) | 128u], *p = ora_add(*p, 1);
+    }
+    return bad;
+}

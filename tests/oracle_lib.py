@@ -90,6 +90,18 @@ def memory_access_trace(as_, ptr, prev_data, prev_ts, data, ts, is_read, log_hei
     return tr, int(bad)
 
 
+def rv32_shift_trace(opc, bs, cs, log_height, range_counts=None, xor_counts=None):
+    opc, bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, bs, cs))
+    tr = np.zeros((32, 1 << log_height), np.uint32)
+    rc = np.zeros(1 << 16, np.uint32) if range_counts is None else np.ascontiguousarray(range_counts, dtype=np.uint32).copy()
+    xc = np.zeros(1 << 16, np.uint32) if xor_counts is None else np.ascontiguousarray(xor_counts, dtype=np.uint32).copy()
+    l = lib()
+    l.ora_rv32_shift_trace.restype = C.c_size_t
+    l.ora_rv32_shift_trace.argtypes = [u32p_t()] * 3 + [C.c_size_t, C.c_uint, u32p_t(), u32p_t(), u32p_t()]
+    bad = l.ora_rv32_shift_trace(p32(opc), p32(bs), p32(cs), len(opc), log_height, p32(tr), p32(rc), p32(xc))
+    return tr, rc, xc, int(bad)
+
+
 def rv32_lt_trace(opc, bs, cs, log_height, range_counts=None):
     opc, bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, bs, cs))
     tr = np.zeros((18, 1 << log_height), np.uint32)

@@ -98,6 +98,7 @@ def load_library():
         "zkhip_bitwise_lookup_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, C.c_int]),
         "zkhip_rv32_alu_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_lt_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_rv32_shift_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_mul_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_memory_boundary_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint, C.c_uint, vp]),
         "zkhip_memory_access_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
@@ -306,6 +307,17 @@ class Context:
         self._check(self.lib.zkhip_rv32_lt_tracegen(self.h, C.c_void_p(t_opcode.data_ptr()), C.c_void_p(t_b.data_ptr()),
                                                     C.c_void_p(t_c.data_ptr()), t_opcode.numel(), log_height, C.c_void_p(out.data_ptr()),
                                                     C.c_void_p(t_bitwise_trace.data_ptr())))
+        return out
+
+    def rv32_shift_tracegen(self, t_opcode, t_b, t_c, log_height, t_bitwise_trace):
+        """32-column trace of the RV32 shift core chip from records (int32 tensors: opcode 0 = SLL, 1 = SRL, 2 = SRA; value b; shift
+        operand c); the rows' lookup requests are added to both columns of t_bitwise_trace (2 x 2^16 Montgomery words)."""
+        import torch
+
+        out = torch.empty(32 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_rv32_shift_tracegen(self.h, C.c_void_p(t_opcode.data_ptr()), C.c_void_p(t_b.data_ptr()),
+                                                       C.c_void_p(t_c.data_ptr()), t_opcode.numel(), log_height, C.c_void_p(out.data_ptr()),
+                                                       C.c_void_p(t_bitwise_trace.data_ptr())))
         return out
 
     def rv32_mul_tracegen(self, t_b, t_c, log_height, t_tuple_counts, size_x=256, size_y=8192):

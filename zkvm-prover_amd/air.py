@@ -719,6 +719,67 @@ def rv32_lt_core_air(bus=9):
     return b
 
 
+RV32_SHIFT_WIDTH = 32
+
+
+def rv32_shift_core_air(bus=9):
+    """The core of OpenVM's RV32 shift chip (rv32im `ShiftCoreAir<4, 8>`: SLL / SRL / SRA), 8-bit limbs.  Columns
+    a[4] | b[4] | c0 | is_sll is_srl is_sra | bit_marker[8] | limb_marker[4] | carry[4] | sign | q | mult_left | mult_right.
+    The shift amount is c0 mod 32 = bit_shift + 8 limb_shift (one-hot markers; q = c0 >> 5).  With mult = 2^bit_shift:
+      left :  a[i] + 256 carry[k] = b[k] mult + carry[k - 1]           (k = i - limb_shift; a[i] = 0 below the limb shift)
+      right:  a[i] mult + carry[k] = b[k] + 256 carry[k + 1]           (k = i + limb_shift; carry[4] = sign (mult - 1); a[i] = 255 sign above)
+    mult_left / mult_right are columns (mult gated by the opcode) so that every constraint stays of degree 3.  Lookups (bitwise
+    table): carry[i] < mult as the range pair (carry[i], mult - 1 - carry[i]); the result limbs pairwise; (q, 32 q); and for SRA the
+    sign bit of b[3] as the XOR (b[3], 128, b[3] + 128 - 256 sign)."""
+    b = AirBuilder(RV32_SHIFT_WIDTH, 0)
+    a_, b_ = [b.var(i) for i in range(4)], [b.var(4 + i) for i in range(4)]
+    c0, sll, srl, sra = b.var(8), b.var(9), b.var(10), b.var(11)
+    bm, lm = [b.var(12 + i) for i in range(8)], [b.var(20 + i) for i in range(4)]
+    cy = [b.var(24 + i) for i in range(4)]
+    sign, q, ml, mr = b.var(28), b.var(29), b.var(30), b.var(31)
+    ok = sll + srl + sra
+    right = srl + sra
+    for f in [sll, srl, sra, ok, sign] + bm + lm:
+        b.assert_zero(f * (f - 1))
+    sbm, slm, mult, bs, ls = bm[0], lm[0], bm[0], None, None
+    for i in range(1, 8):
+        sbm = sbm + bm[i]
+        mult = mult + bm[i] * (1 << i)
+        bs = bm[i] * i if bs is None else bs + bm[i] * i
+    for j in range(1, 4):
+        slm = slm + lm[j]
+        ls = lm[j] * j if ls is None else ls + lm[j] * j
+    b.assert_zero(sbm - ok)
+    b.assert_zero(slm - ok)
+    b.assert_zero(c0 - bs - ls * 8 - q * 32)
+    b.assert_zero(ml - sll * mult)
+    b.assert_zero(mr - right * mult)
+    b.assert_zero(sign * (1 - sra))
+    for j in range(4):
+        for i in range(4):
+            if i < j:
+                b.assert_zero(lm[j] * (a_[i] * sll))
+            else:
+                k = i - j
+                exp = b_[k] * ml - cy[k] * sll * 256
+                if k > 0:
+                    exp = exp + cy[k - 1] * sll
+                b.assert_zero(lm[j] * (a_[i] * sll - exp))
+            if i + j > 3:
+                b.assert_zero(lm[j] * (a_[i] * right - sign * right * 255))
+            else:
+                k = i + j
+                nxt = sign * (mr - right) if k == 3 else cy[k + 1] * right
+                b.assert_zero(lm[j] * (a_[i] * mr - nxt * 256 - (b_[k] - cy[k]) * right))
+    for i in range(4):
+        b.push_interaction(bus, [cy[i], ml + mr - 1 - cy[i], 0, 0], ok, "send")
+    b.push_interaction(bus, [a_[0], a_[1], 0, 0], ok, "send")
+    b.push_interaction(bus, [a_[2], a_[3], 0, 0], ok, "send")
+    b.push_interaction(bus, [q, q * 32, 0, 0], ok, "send")
+    b.push_interaction(bus, [b_[3], 128, b_[3] + 128 - sign * 256, 1], sra, "send")
+    return b
+
+
 RV32_MUL_WIDTH = 13
 
 

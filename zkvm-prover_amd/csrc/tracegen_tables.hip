@@ -497,3 +497,77 @@ extern "C" int zkhip_memory_access_tracegen(zkhip_ctx* ctx, const uint32_t* d_ad
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "memory_access_tracegen (value above 16 bits, time not moving forward, or a read that changes its cell)");
 }
+
+// ---- RV32 shift core (OpenVM rv32im ShiftCoreAir<4, 8>: SLL / SRL / SRA) -----------------------------------------------------------
+// Record = (opcode 0 = SLL, 1 = SRL, 2 = SRA; value b; shift operand c, of which c mod 32 counts).  Row (ZKHIP_RV32_SHIFT_WIDTH = 32):
+//   a[4] | b[4] | c0 | is_sll is_srl is_sra | bit_marker[8] | limb_marker[4] | carry[4] | sign | q | mult_left | mult_right
+// (air.py rv32_shift_core_air()).  Lookup requests counted into the 8-bit bitwise table's trace in the same pass: range pairs
+// (carry[i], mult - 1 - carry[i]) x 4, (a0, a1), (a2, a3), (q, 32 q); for SRA the XOR request (b[3], 128).
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_rv32_shift(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ bs,
+                                                    const uint32_t* __restrict__ cs, size_t n, size_t N, uint32_t* __restrict__ trace,
+                                                    uint32_t* __restrict__ range_counts, uint32_t* __restrict__ xor_counts,
+                                                    uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_RV32_SHIFT_WIDTH] = {};
+    if (r < n) {
+        const uint32_t op = opc[r], b = bs[r], c = cs[r];
+        if (op > 2) {
+            atomicAdd(bad, 1u);
+        } else {
+            const uint32_t s = c & 31u, bsh = s & 7u, lsh = s >> 3, c0 = c & 255u, q = c0 >> 5, mult = 1u << bsh;
+            const uint32_t a = op == 0 ? b << s : op == 1 ? b >> s : (uint32_t)((int32_t)b >> s);
+            const uint32_t sign = op == 2 ? b >> 31 : 0u;
+            uint32_t bl[4], al[4], cy[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) bl[i] = (b >> (8 * i)) & 255u, al[i] = (a >> (8 * i)) & 255u;
+            if (op == 0) {
+                uint32_t carry = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) carry = cy[k] = (bl[k] * mult + carry) >> 8;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) cy[k] = bl[k] & (mult - 1u);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) col[i] = to_monty(al[i]), col[4 + i] = to_monty(bl[i]), col[24 + i] = to_monty(cy[i]);
+            col[8] = to_monty(c0);
+            col[9 + op] = MONTY_ONE;
+            col[12 + bsh] = MONTY_ONE;
+            col[20 + lsh] = MONTY_ONE;
+            col[28] = sign ? MONTY_ONE : 0u;
+            col[29] = to_monty(q);
+            col[op == 0 ? 30 : 31] = to_monty(mult);
+#pragma unroll
+            for (int i = 0; i < 4; i++) atomicAdd(&range_counts[(cy[i] << 8) | (mult - 1u - cy[i])], 1u);
+            atomicAdd(&range_counts[(al[0] << 8) | al[1]], 1u);
+            atomicAdd(&range_counts[(al[2] << 8) | al[3]], 1u);
+            atomicAdd(&range_counts[(q << 8) | (32u * q)], 1u);
+            if (op == 2) atomicAdd(&xor_counts[(bl[3] << 8) | 128u], 1u);
+        }
+    }
+#pragma unroll
+    for (int qq = 0; qq < ZKHIP_RV32_SHIFT_WIDTH; qq++) trace[(size_t)qq * N + r] = col[qq];
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_rv32_shift_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, const uint32_t* d_b, const uint32_t* d_c, size_t n,
+                                         unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 27 || (n && (!d_opcode || !d_b || !d_c))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_shift_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "rv32_shift_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_tab_repr, dim3(512), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 0);  // both columns
+    hipLaunchKernelGGL(k_rv32_shift, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace,
+                       d_bitwise_trace, d_bitwise_trace + (1u << 16), (uint32_t*)flag);
+    hipLaunchKernelGGL(k_tab_repr, dim3(512), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "rv32_shift_tracegen (opcode > 2)");
+}
