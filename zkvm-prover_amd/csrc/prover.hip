@@ -1907,10 +1907,11 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         const uint32_t* tw_fwd = ctx->d_tw_fwd;
         unsigned tw_shift = ctx->tw_log - A.h;
         KernelScope ks(ctx, "quotient_eval_jit");
+        uint32_t h_bits = A.h, nq_rows = (uint32_t)A.MQ;
         void* params[] = {(void*)&qa.lde, (void*)&qa.q,      (void*)&qa.pvs,      (void*)&qa.apow,
                           (void*)&tw_fwd, (void*)&qa.zh,  (void*)&qa.inv_zh,   (void*)&A.d_jit_tab,
                           (void*)&qa.gen, (void*)&qa.w_n_inv, (void*)&tw_shift, (void*)&qa.perm,
-                          (void*)&qa.lchal, (void*)&qa.expo, (void*)&qa.prep};
+                          (void*)&qa.lchal, (void*)&qa.expo, (void*)&qa.prep, (void*)&h_bits, (void*)&nq_rows};
         ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, (unsigned)((A.MQ + 255) / 256), 1, 1, 256, 1, 1, 0, st,
                                                 params, nullptr));
     }

@@ -201,14 +201,18 @@ inline bool quot_jit_classify(const AirProgram& p, std::vector<JitClass>* classe
 
 inline void quot_jit_prologue(std::ostringstream& os, unsigned lh, unsigned b, unsigned qd) {
     os << quot_jit_preamble();
-    // the quotient lives on the first N * qd rows of the LDE (qd = AirProgram::qd() chunks)
-    os << "#define H " << (lh + b) << "u\n#define B " << b << "u\n#define M ((size_t)1 << H)\n#define NQROWS " << ((1u << lh) * qd) << "u\n";
+    // The trace height is a launch parameter (H = log2 of the LDE height, NQROWS = the first N * qd rows of the LDE, where the
+    // quotient lives): one compiled kernel serves an AIR at every height -- continuation segments, tasks of different sizes and
+    // re-keying after a reset pay the hipRTC compile once per (AIR, blow-up), not once per height.
+    (void)lh, (void)qd;
+    os << "#define B " << b << "u\n#define M ((size_t)1 << H)\n";
     os << R"JIT(
 extern "C" __global__ __launch_bounds__(256) void quot_jit(const uint32_t* __restrict__ lde, uint32_t* __restrict__ q,
         const uint32_t* __restrict__ pvs, const uint32_t* __restrict__ apow, const uint32_t* __restrict__ tw_fwd,
         const uint32_t* __restrict__ zh_t, const uint32_t* __restrict__ inv_zh_t, const uint32_t* __restrict__ tab,
         uint32_t gen, uint32_t w_n_inv, uint32_t tw_shift, const uint32_t* __restrict__ perm,
-        const uint32_t* __restrict__ lchal, const uint32_t* __restrict__ expo, const uint32_t* __restrict__ prep) {
+        const uint32_t* __restrict__ lchal, const uint32_t* __restrict__ expo, const uint32_t* __restrict__ prep,
+        uint32_t H, uint32_t NQROWS) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= NQROWS) return;
     const uint32_t i = __brev(r) >> (32 - H);
