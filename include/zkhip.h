@@ -161,6 +161,15 @@ int zkhip_rv32_lt_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint3
 int zkhip_rv32_shift_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_b, const uint32_t *d_c, size_t n,
                               unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
 
+/* RV32 branch-equal core (rv32im BranchEqualCoreAir<4>: BEQ / BNE).  Record i = (d_opcode[i]: 0 = BEQ, 1 = BNE; d_a[i], d_b[i] the
+ * operands; d_imm[i] the branch offset as a canonical field element, p - |offset| for a backward branch) -- plain integers.  Fills
+ * d_trace (ZKHIP_RV32_BRANCH_EQ_WIDTH = 17 columns, stride 2^log_height, Montgomery: a[4] | b[4] | taken | imm | is_beq is_bne |
+ * diff_inv_marker[4] | pc_inc; rows >= n zero); the marker of the first differing limb pair holds (a_i - b_i)^-1, inverted on the
+ * device.  AIR: air.py rv32_branch_eq_core_air() (no bus interactions). */
+#define ZKHIP_RV32_BRANCH_EQ_WIDTH 17
+int zkhip_rv32_branch_eq_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_a, const uint32_t *d_b, const uint32_t *d_imm,
+                                  size_t n, unsigned log_height, uint32_t *d_trace);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

@@ -296,3 +296,32 @@ size_t ora_rv32_shift_trace(const uint32_t *opc, const uint32_t *bs, const uint3
     }
     return bad;
 }
+
+/* RV32 branch-equal core (zkhip_rv32_branch_eq_tracegen): 17 columns a[4] | b[4] | taken | imm | is_beq is_bne | diff_inv_marker[4] |
+ * pc_inc, canonical; imm is the offset as a canonical field element.  Returns the number of refused records. */
+size_t ora_rv32_branch_eq_trace(const uint32_t *opc, const uint32_t *as, const uint32_t *bs, const uint32_t *imms, size_t n, unsigned log_height,
+                                uint32_t *trace) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 17; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t op = opc[r];
+        if (op > 1 || imms[r] >= ORA_P) {
+            bad++;
+            continue;
+        }
+        const int equal = as[r] == bs[r], taken = op == 0 ? equal : !equal;
+        int first = -1;
+        for (int i = 0; i < 4; i++) {
+            const uint32_t ai = (as[r] >> (8 * i)) & 255u, bi = (bs[r] >> (8 * i)) & 255u;
+            trace[(size_t)i * N + r] = ai, trace[(size_t)(4 + i) * N + r] = bi;
+            if (first < 0 && ai != bi) first = i, trace[(size_t)(12 + i) * N + r] = ora_inv(ora_sub(ai, bi));
+        }
+        trace[(size_t)8 * N + r] = (uint32_t)taken;
+        trace[(size_t)9 * N + r] = imms[r];
+        trace[(size_t)(10 + op) * N + r] = 1;
+        trace[(size_t)16 * N + r] = taken ? imms[r] : 4;
+    }
+    return bad;
+}

@@ -357,3 +357,42 @@ def test_rv32_shift_chip(zk, ora):
     assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, proof) == 0
     assert proof == ora.stark_prove(PARAMS, airs).tobytes()
     pk.close()
+
+
+def test_rv32_branch_equal_chip(zk, ora):
+    """RV32 branch-equal core (BEQ / BNE, OpenVM BranchEqualCoreAir<4>) filled on the device from execution records, the inverse of
+    the first limb difference computed on the device: cells == oracle, `taken` == the integers' comparison, the oracle's trace
+    satisfies the AIR and tampered decisions do not; the chip proves from the device-resident trace (bytes == oracle)."""
+    rng = np.random.default_rng(23)
+    n, lh = 4000, 12
+    opc = rng.integers(0, 2, n).astype(np.uint32)
+    a = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    b = a.copy()
+    kind = rng.integers(0, 3, n)
+    b[kind == 0] = rng.integers(0, 1 << 32, int((kind == 0).sum()), dtype=np.uint64).astype(np.uint32)
+    b[kind == 1] ^= (1 << rng.integers(0, 32, int((kind == 1).sum()))).astype(np.uint32)    # differ in exactly one bit
+    off = rng.integers(-2048, 2048, n) * 2
+    imm = np.where(off < 0, P + off, off).astype(np.uint32)
+    exp, bad = ora.rv32_branch_eq_trace(opc, a, b, imm, lh)
+    assert bad == 0
+    taken = np.where(opc == 0, a == b, a != b)
+    assert (exp[8][:n] == taken).all() and (exp[16][:n] == np.where(taken, imm, 4)).all()
+    prog = air.rv32_branch_eq_core_air().program()
+    assert air.check_trace(prog, exp, NOPV) == []
+    for col, row in ((8, 0), (16, 5), (12, int(np.nonzero(a != b)[0][0]))):
+        w = exp.copy()
+        w[col][row] = (int(w[col][row]) + 1) % P
+        assert air.check_trace(prog, w, NOPV) != []
+    as_dev = lambda v: torch.from_numpy(v.view(np.int32)).to(zk.device)  # noqa: E731
+    d_tr = zk.rv32_branch_eq_tracegen(as_dev(opc), as_dev(a), as_dev(b), as_dev(imm), lh)
+    assert (zk.download(d_tr).reshape(17, -1) == exp).all()
+    with pytest.raises(z.ZkhipError):
+        zk.rv32_branch_eq_tracegen(as_dev(np.array([2], np.uint32)), as_dev(a[:1]), as_dev(b[:1]), as_dev(imm[:1]), 0)
+    with pytest.raises(z.ZkhipError):   # an offset that is not a field element
+        zk.rv32_branch_eq_tracegen(as_dev(opc[:1]), as_dev(a[:1]), as_dev(b[:1]), as_dev(np.array([P], np.uint32)), 0)
+    airs = [dict(program=prog, log_height=lh, width=17, n_pvs=0, trace=exp, pvs=NOPV)]
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    proof = pk.prove([d_tr], [NOPV])
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV], proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    pk.close()

@@ -69,7 +69,7 @@ def run_cli(tmp_path, program, stdin=b"", max_cost=0, data=b""):
     r = subprocess.run([VM, "exec", str(exe), str(inp), str(out)] + ([str(max_cost)] if max_cost else []), capture_output=True, text=True)
     rec = {}
     if r.returncode == 0:
-        for name in ("pc_index", "alu_op", "alu_b", "alu_c", "lt_op", "lt_b", "lt_c", "mul_b", "mul_c", "shift_op", "shift_b", "shift_c", "acc_as", "acc_ptr", "acc_prev_data",
+        for name in ("pc_index", "alu_op", "alu_b", "alu_c", "lt_op", "lt_b", "lt_c", "mul_b", "mul_c", "shift_op", "shift_b", "shift_c", "beq_op", "beq_a", "beq_b", "beq_imm", "acc_as", "acc_ptr", "acc_prev_data",
                      "acc_prev_ts", "acc_data", "acc_ts", "acc_is_read", "bnd_as", "bnd_ptr", "bnd_initial", "bnd_final", "bnd_final_ts"):
             rec[name] = np.fromfile(out / (name + ".u32"), dtype=np.uint32)
     return r, (json.loads(r.stdout) if r.returncode == 0 else None), rec
@@ -96,6 +96,7 @@ def check_against_model(js, rec, model):
     assert list(zip(rec["lt_op"].tolist(), rec["lt_b"].tolist(), rec["lt_c"].tolist())) == m["lt"]
     assert list(zip(rec["mul_b"].tolist(), rec["mul_c"].tolist())) == m["mul"]
     assert list(zip(rec["shift_op"].tolist(), rec["shift_b"].tolist(), rec["shift_c"].tolist())) == m["shifts"]
+    assert list(zip(rec["beq_op"].tolist(), rec["beq_a"].tolist(), rec["beq_b"].tolist(), rec["beq_imm"].tolist())) == m["beq"]
     for k in ("shift", "branch", "jump", "load_store", "mulh", "divrem", "lui_auipc", "ecall"):
         assert js["records"][k] == m[k], k
     assert js["records"]["executed"] == model["instret"]
@@ -187,7 +188,7 @@ def test_elf_guest(tmp_path):
     assert r.returncode != 0
 
 
-REC_NAMES = ("pc_index", "alu_op", "alu_b", "alu_c", "lt_op", "lt_b", "lt_c", "mul_b", "mul_c", "shift_op", "shift_b", "shift_c", "acc_as", "acc_ptr", "acc_prev_data",
+REC_NAMES = ("pc_index", "alu_op", "alu_b", "alu_c", "lt_op", "lt_b", "lt_c", "mul_b", "mul_c", "shift_op", "shift_b", "shift_c", "beq_op", "beq_a", "beq_b", "beq_imm", "acc_as", "acc_ptr", "acc_prev_data",
              "acc_prev_ts", "acc_data", "acc_ts", "acc_is_read", "bnd_as", "bnd_ptr", "bnd_initial", "bnd_final", "bnd_final_ts")
 
 

@@ -719,6 +719,33 @@ def rv32_lt_core_air(bus=9):
     return b
 
 
+RV32_BRANCH_EQ_WIDTH = 17
+
+
+def rv32_branch_eq_core_air():
+    """The core of OpenVM's RV32 branch-equal chip (rv32im `BranchEqualCoreAir<4>`: BEQ / BNE): columns a[4] | b[4] | taken | imm |
+    is_beq is_bne | diff_inv_marker[4] | pc_inc.  eq := taken for BEQ, 1 - taken for BNE; eq forces every limb pair equal, and
+    eq + sum_i (a_i - b_i) marker_i = 1 forces a difference somewhere when eq = 0 (the prover puts the inverse of the first non-zero
+    difference into its marker).  pc_inc = imm if the branch is taken, else 4.  No lookups: the operand limbs come range-checked
+    from memory in OpenVM's design."""
+    b = AirBuilder(RV32_BRANCH_EQ_WIDTH, 0)
+    a_, b_ = [b.var(i) for i in range(4)], [b.var(4 + i) for i in range(4)]
+    taken, imm, beq, bne = b.var(8), b.var(9), b.var(10), b.var(11)
+    mk, inc = [b.var(12 + i) for i in range(4)], b.var(16)
+    ok = beq + bne
+    for f in (beq, bne, ok, taken):
+        b.assert_zero(f * (f - 1))
+    eq = taken * beq + (1 - taken) * bne
+    total = eq
+    for i in range(4):
+        d = a_[i] - b_[i]
+        b.assert_zero(eq * d)
+        total = total + d * mk[i]
+    b.assert_zero(ok * (total - 1))
+    b.assert_zero(ok * (inc - taken * imm - (1 - taken) * 4))
+    return b
+
+
 RV32_SHIFT_WIDTH = 32
 
 

@@ -571,3 +571,60 @@ extern "C" int zkhip_rv32_shift_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcod
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_shift_tracegen (opcode > 2)");
 }
+
+// ---- RV32 branch-equal core (OpenVM rv32im BranchEqualCoreAir<4>: BEQ / BNE) ------------------------------------------------------
+// Record = (opcode 0 = BEQ, 1 = BNE; operands a, b; the branch offset imm as a field element's canonical value, i.e. p - |imm| for a
+// backward branch).  Row (ZKHIP_RV32_BRANCH_EQ_WIDTH = 17): a[4] | b[4] | taken | imm | is_beq is_bne | diff_inv_marker[4] | pc_inc;
+// the marker of the first differing limb pair holds (a_i - b_i)^-1 -- one field inversion per unequal row, on the device.
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_rv32_branch_eq(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ as, const uint32_t* __restrict__ bs,
+                                                        const uint32_t* __restrict__ imms, size_t n, size_t N, uint32_t* __restrict__ trace,
+                                                        uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_RV32_BRANCH_EQ_WIDTH] = {};
+    if (r < n) {
+        const uint32_t op = opc[r], a = as[r], b = bs[r], imm = imms[r];
+        if (op > 1 || imm >= P) {
+            atomicAdd(bad, 1u);
+        } else {
+            const bool taken = op == 0 ? a == b : a != b;
+            int first = -1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t ai = (a >> (8 * i)) & 255u, bi = (b >> (8 * i)) & 255u;
+                col[i] = to_monty(ai), col[4 + i] = to_monty(bi);
+                if (first < 0 && ai != bi) first = i;
+            }
+            if (first >= 0) {
+                const uint32_t ai = (a >> (8 * first)) & 255u, bi = (b >> (8 * first)) & 255u;
+                col[12 + first] = minv(msub(to_monty(ai), to_monty(bi)));
+            }
+            col[8] = taken ? MONTY_ONE : 0u;
+            col[9] = to_monty(imm);
+            col[10 + op] = MONTY_ONE;
+            col[16] = taken ? to_monty(imm) : to_monty(4u);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_RV32_BRANCH_EQ_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_rv32_branch_eq_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, const uint32_t* d_a, const uint32_t* d_b, const uint32_t* d_imm,
+                                             size_t n, unsigned log_height, uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || log_height > 27 || (n && (!d_opcode || !d_a || !d_b || !d_imm))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_branch_eq_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "rv32_branch_eq_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_rv32_branch_eq, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_a, d_b, d_imm, n, N, d_trace,
+                       (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "rv32_branch_eq_tracegen (opcode > 1 or offset not a field element)");
+}
