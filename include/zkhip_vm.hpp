@@ -24,7 +24,6 @@
 #include <stdexcept>
 #include <algorithm>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 namespace zkhip_vm {
@@ -127,34 +126,36 @@ private:
     uint64_t instret_ = 0;
     size_t in_pos_ = 0;
     bool done_ = false;
+    // Per-cell state of the memory log for the CURRENT segment, kept in flat tables (register cells, then memory cells) instead
+    // of a hash map: a slot belongs to the segment whose number its `seg` field holds, so closing a segment costs nothing
+    // per untouched cell; `touched_` lists the slots of this segment for the boundary records.
     struct Cell {
-        uint32_t initial, data, ts;
+        uint32_t initial, data, ts, seg;
     };
-    std::unordered_map<uint64_t, Cell> cells_;
-    uint32_t clock_ = 0;
+    std::vector<Cell> reg_cells_ = std::vector<Cell>(64, Cell{0, 0, 0, 0});
+    std::vector<Cell> mem_cells_;          // memory_bytes / 2 slots, allocated at the first logged access
+    std::vector<uint64_t> touched_;        // (address space << 32) | pointer
+    uint32_t clock_ = 0, segment_ = 1;
 
     void close_segment(ExecRecords* rec) {
         if (rec) {  // boundary records, sorted by (address space, pointer)
-            std::vector<uint64_t> keys;
-            keys.reserve(cells_.size());
-            for (const auto& kv : cells_) keys.push_back(kv.first);
-            std::sort(keys.begin(), keys.end());
-            for (uint64_t k : keys) {
-                const Cell& c = cells_[k];
+            std::sort(touched_.begin(), touched_.end());
+            for (uint64_t k : touched_) {
+                const Cell& c = (k >> 32) == 1 ? reg_cells_[(uint32_t)k] : mem_cells_[(uint32_t)k];
                 rec->bnd_as.push_back((uint32_t)(k >> 32)), rec->bnd_ptr.push_back((uint32_t)k);
                 rec->bnd_initial.push_back(c.initial), rec->bnd_final.push_back(c.data), rec->bnd_final_ts.push_back(c.ts);
             }
         }
-        cells_.clear();
+        touched_.clear();
         clock_ = 0;
+        segment_++;
     }
     // one access of a 16-bit cell: `write` replaces its value by `value`
     void touch(ExecRecords* rec, uint32_t as, uint32_t ptr, uint32_t current, bool write, uint32_t value) {
         if (!rec) return;
-        const uint64_t key = ((uint64_t)as << 32) | ptr;
-        auto it = cells_.find(key);
-        if (it == cells_.end()) it = cells_.emplace(key, Cell{current, current, 0}).first;
-        Cell& c = it->second;
+        if (as == 2 && mem_cells_.empty()) mem_cells_.assign(mem_.size() / 2 + 1, Cell{0, 0, 0, 0});
+        Cell& c = as == 1 ? reg_cells_[ptr] : mem_cells_[ptr];
+        if (c.seg != segment_) c = Cell{current, current, 0, segment_}, touched_.push_back(((uint64_t)as << 32) | ptr);
         if (++clock_ == 0) throw Error("memory clock overflow");
         rec->acc_as.push_back(as), rec->acc_ptr.push_back(ptr), rec->acc_prev_data.push_back(c.data), rec->acc_prev_ts.push_back(c.ts);
         c.data = write ? value : c.data, c.ts = clock_;
