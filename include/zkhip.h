@@ -170,6 +170,15 @@ int zkhip_rv32_shift_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const ui
 int zkhip_rv32_branch_eq_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_a, const uint32_t *d_b, const uint32_t *d_imm,
                                   size_t n, unsigned log_height, uint32_t *d_trace);
 
+/* RV32 branch-less-than core (rv32im BranchLessThanCoreAir<4, 8>: BLT / BLTU / BGE / BGEU).  Record i = (d_opcode[i]: 0 = BLT, 1 = BLTU,
+ * 2 = BGE, 3 = BGEU; operands d_a[i], d_b[i]; d_imm[i] the offset as a canonical field element) -- plain integers.  Fills d_trace
+ * (ZKHIP_RV32_BRANCH_LT_WIDTH = 23 columns, stride 2^log_height, Montgomery: a[4] | b[4] | cmp_lt | taken | imm | 4 opcode flags |
+ * a_msb_f b_msb_f | marker[4] | diff_val | pc_inc; rows >= n zero) and adds the two range requests of the comparison (as
+ * zkhip_rv32_lt_tracegen) to column 0 of d_bitwise_trace.  AIR: air.py rv32_branch_lt_core_air(). */
+#define ZKHIP_RV32_BRANCH_LT_WIDTH 23
+int zkhip_rv32_branch_lt_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_a, const uint32_t *d_b, const uint32_t *d_imm,
+                                  size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

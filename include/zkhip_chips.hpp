@@ -229,6 +229,126 @@ inline void rv32_lt_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
     }
 }
 
+// air.rv32_branch_eq_core_air(): AirBuilder(17, 0)
+inline void rv32_branch_eq_core_air(AirBuilder& b) {
+    Expr al[4], bl[4], mk[4];
+    for (int i = 0; i < 4; i++) al[i] = b.var(i);
+    for (int i = 0; i < 4; i++) bl[i] = b.var(4 + i);
+    const Expr taken = b.var(8), imm = b.var(9), beq = b.var(10), bne = b.var(11);
+    for (int i = 0; i < 4; i++) mk[i] = b.var(12 + i);
+    const Expr inc = b.var(16);
+    const Expr ok = beq + bne;
+    for (const Expr& f : {beq, bne, ok, taken}) {
+        const Expr t = f - 1;
+        b.assert_zero(f * t);
+    }
+    const Expr e0 = taken * beq;
+    const Expr nt = 1 - taken;
+    const Expr e1 = nt * bne;
+    const Expr eq = e0 + e1;
+    Expr total = eq;
+    for (int i = 0; i < 4; i++) {
+        const Expr d = al[i] - bl[i];
+        b.assert_zero(eq * d);
+        const Expr dm = d * mk[i];
+        total = total + dm;
+    }
+    {
+        const Expr t = total - 1;
+        b.assert_zero(ok * t);
+    }
+    {
+        const Expr ti = taken * imm;
+        const Expr x = inc - ti;
+        const Expr nt2 = 1 - taken;
+        const Expr f = nt2 * 4;
+        const Expr y = x - f;
+        b.assert_zero(ok * y);
+    }
+}
+
+// air.rv32_branch_lt_core_air(bus): AirBuilder(23, 0)
+inline void rv32_branch_lt_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
+    Expr al[4], bl[4], mk[4];
+    for (int i = 0; i < 4; i++) al[i] = b.var(i);
+    for (int i = 0; i < 4; i++) bl[i] = b.var(4 + i);
+    const Expr cmp = b.var(8), taken = b.var(9), imm = b.var(10);
+    const Expr blt = b.var(11), bltu = b.var(12), bge = b.var(13), bgeu = b.var(14);
+    const Expr am = b.var(15), bm = b.var(16);
+    for (int i = 0; i < 4; i++) mk[i] = b.var(17 + i);
+    const Expr dv = b.var(21), inc = b.var(22);
+    const Expr sgn = blt + bge;
+    const Expr ge = bge + bgeu;
+    const Expr ok0 = blt + bltu;
+    const Expr ok1 = ok0 + bge;
+    const Expr ok = ok1 + bgeu;
+    for (const Expr& f : {blt, bltu, bge, bgeu, ok, cmp, taken, mk[0], mk[1], mk[2], mk[3]}) {
+        const Expr t = f - 1;
+        b.assert_zero(f * t);
+    }
+    {
+        const Expr s = cmp + ge;
+        const Expr cg = cmp * ge;
+        const Expr cg2 = cg * 2;
+        const Expr r = s - cg2;
+        b.assert_zero(taken - r);
+    }
+    for (int k = 0; k < 2; k++) {
+        const Expr limb = k == 0 ? al[3] : bl[3], f = k == 0 ? am : bm;
+        const Expr d = limb - f;
+        const Expr d256 = d - 256;
+        b.assert_zero(d * d256);
+        const Expr ns = 1 - sgn;
+        b.assert_zero(ns * d);
+    }
+    const Expr c2 = cmp * 2;
+    const Expr sign = c2 - 1;
+    Expr prefix;
+    for (int i = 3; i >= 0; i--) {
+        const Expr hi = i == 3 ? bm : bl[i], lo = i == 3 ? am : al[i];
+        const Expr d0 = hi - lo;
+        const Expr diff = d0 * sign;
+        prefix = i == 3 ? mk[i] : prefix + mk[i];
+        const Expr np = 1 - prefix;
+        b.assert_zero(np * diff);
+        const Expr dd = dv - diff;
+        b.assert_zero(mk[i] * dd);
+    }
+    {
+        const Expr t = prefix - 1;
+        b.assert_zero(prefix * t);
+    }
+    {
+        const Expr np = 1 - prefix;
+        b.assert_zero(np * cmp);
+    }
+    {
+        const Expr nok = 1 - ok;
+        b.assert_zero(nok * prefix);
+    }
+    {
+        const Expr ti = taken * imm;
+        const Expr x = inc - ti;
+        const Expr nt = 1 - taken;
+        const Expr f = nt * 4;
+        const Expr y = x - f;
+        b.assert_zero(ok * y);
+    }
+    {
+        const Expr s1 = sgn * 128;
+        const Expr x = am + s1;
+        const Expr s2 = sgn * 128;
+        const Expr y = bm + s2;
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {x, y, z0, z0}, ok, Kind::Send);
+    }
+    {
+        const Expr x = dv - 1;
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {x, z0, z0, z0}, prefix, Kind::Send);
+    }
+}
+
 // air.rv32_shift_core_air(bus): AirBuilder(32, 0)
 inline void rv32_shift_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
     Expr a_[4], b_[4], bm[8], lm[4], cy[4];

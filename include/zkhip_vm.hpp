@@ -55,6 +55,7 @@ struct ExecRecords {
     std::vector<uint32_t> mul_b, mul_c;               // mul (low word)
     std::vector<uint32_t> shift_op, shift_b, shift_c; // 0 sll 1 srl 2 sra; c = the shift operand (register value or shamt)
     std::vector<uint32_t> beq_op, beq_a, beq_b, beq_imm;  // 0 beq 1 bne; imm = the offset as a canonical BabyBear element
+    std::vector<uint32_t> blt_op, blt_a, blt_b, blt_imm;  // 0 blt 1 bltu 2 bge 3 bgeu; imm as above
     uint64_t n_shift = 0, n_branch = 0, n_jump = 0, n_load_store = 0, n_mulh = 0, n_divrem = 0, n_lui_auipc = 0, n_ecall = 0;
     // Memory log for the offline memory-checking argument (OpenVM's memory bus): state is kept in 16-bit CELLS -- address space
     // 1 = registers (cell 2 i + half of x_i), 2 = read-write memory (cell = halfword index from data_base) -- so that a cell's
@@ -245,9 +246,14 @@ private:
                 }
                 if (t) next = pc_ + (uint32_t)imm_b;
                 if (rec) rec->n_branch++;
-                if (rec && f3 < 2) {
-                    rec->beq_op.push_back(f3), rec->beq_a.push_back(a), rec->beq_b.push_back(b);
-                    rec->beq_imm.push_back(imm_b < 0 ? 2013265921u - (uint32_t)(-imm_b) : (uint32_t)imm_b);
+                if (rec) {
+                    const uint32_t off = imm_b < 0 ? 2013265921u - (uint32_t)(-imm_b) : (uint32_t)imm_b;
+                    if (f3 < 2) {
+                        rec->beq_op.push_back(f3), rec->beq_a.push_back(a), rec->beq_b.push_back(b), rec->beq_imm.push_back(off);
+                    } else {   // funct3 4 blt, 5 bge, 6 bltu, 7 bgeu -> the chip's opcode order blt, bltu, bge, bgeu
+                        rec->blt_op.push_back(((f3 & 1u) << 1) | ((f3 >> 1) & 1u));
+                        rec->blt_a.push_back(a), rec->blt_b.push_back(b), rec->blt_imm.push_back(off);
+                    }
                 }
                 break;
             }

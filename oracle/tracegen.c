@@ -325,3 +325,49 @@ size_t ora_rv32_branch_eq_trace(const uint32_t *opc, const uint32_t *as, const u
     }
     return bad;
 }
+
+/* RV32 branch-less-than core (zkhip_rv32_branch_lt_tracegen): 23 columns a[4] | b[4] | cmp_lt | taken | imm | is_blt is_bltu is_bge is_bgeu |
+ * a_msb_f b_msb_f | marker[4] | diff_val | pc_inc, canonical; range_counts as in ora_rv32_lt_trace.  cmp_lt comes from the operands
+ * as integers (signed for BLT / BGE), the marker scan from the limbs. */
+size_t ora_rv32_branch_lt_trace(const uint32_t *opc, const uint32_t *as, const uint32_t *bs, const uint32_t *imms, size_t n, unsigned log_height,
+                                uint32_t *trace, uint32_t *range_counts) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 23; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t op = opc[r];
+        if (op > 3 || imms[r] >= ORA_P) {
+            bad++;
+            continue;
+        }
+        const int is_signed = (op & 1) == 0, is_ge = op >= 2;
+        long al[4], bl[4];
+        for (int i = 0; i < 4; i++) al[i] = (as[r] >> (8 * i)) & 255u, bl[i] = (bs[r] >> (8 * i)) & 255u;
+        const long am = is_signed && al[3] >= 128 ? al[3] - 256 : al[3], bm = is_signed && bl[3] >= 128 ? bl[3] - 256 : bl[3];
+        long av = am, bv = bm;
+        for (int i = 2; i >= 0; i--) av = av * 256 + al[i], bv = bv * 256 + bl[i];
+        const int lt = av < bv, taken = lt != is_ge;
+        int mark = -1;
+        for (int i = 3; i >= 0 && mark < 0; i--)
+            if ((i == 3 ? am : al[i]) != (i == 3 ? bm : bl[i])) mark = i;
+        for (int i = 0; i < 4; i++) trace[(size_t)i * N + r] = (uint32_t)al[i], trace[(size_t)(4 + i) * N + r] = (uint32_t)bl[i];
+        trace[(size_t)8 * N + r] = (uint32_t)lt, trace[(size_t)9 * N + r] = (uint32_t)taken, trace[(size_t)10 * N + r] = imms[r];
+        trace[(size_t)(11 + op) * N + r] = 1;
+        trace[(size_t)15 * N + r] = (uint32_t)(am < 0 ? (long)ORA_P + am : am);
+        trace[(size_t)16 * N + r] = (uint32_t)(bm < 0 ? (long)ORA_P + bm : bm);
+        trace[(size_t)22 * N + r] = taken ? imms[r] : 4;
+        const long sh = is_signed ? 128 : 0;
+        uint32_t *t = &range_counts[((am + sh) << 8) | (bm + sh)];
+        *t = ora_add(*t, 1);
+        if (mark >= 0) {
+            long d = mark == 3 ? bm - am : bl[mark] - al[mark];
+            if (d < 0) d = -d;
+            trace[(size_t)(17 + mark) * N + r] = 1;
+            trace[(size_t)21 * N + r] = (uint32_t)d;
+            t = &range_counts[(d - 1) << 8];
+            *t = ora_add(*t, 1);
+        }
+    }
+    return bad;
+}

@@ -160,6 +160,8 @@ int main() {
         { AirBuilder b(18, 0); ch::rv32_lt_core_air(b); dump("chip_rv32_lt", b); }
         { AirBuilder b(13, 0); ch::rv32_mul_core_air(b); dump("chip_rv32_mul", b); }
         { AirBuilder b(32, 0); ch::rv32_shift_core_air(b); dump("chip_rv32_shift", b); }
+        { AirBuilder b(17, 0); ch::rv32_branch_eq_core_air(b); dump("chip_rv32_branch_eq", b); }
+        { AirBuilder b(23, 0); ch::rv32_branch_lt_core_air(b); dump("chip_rv32_branch_lt", b); }
         { AirBuilder b(10, 0); ch::memory_access_air(b); dump("chip_memory_access", b); }
         { AirBuilder b(8, 0); ch::memory_boundary_air(b); dump("chip_memory_boundary", b); }
     }

@@ -112,6 +112,17 @@ def rv32_branch_eq_trace(opc, a, b, imm, log_height):
     return tr, int(bad)
 
 
+def rv32_branch_lt_trace(opc, a, b, imm, log_height, range_counts=None):
+    opc, a, b, imm = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, a, b, imm))
+    tr = np.zeros((23, 1 << log_height), np.uint32)
+    rc = np.zeros(1 << 16, np.uint32) if range_counts is None else np.ascontiguousarray(range_counts, dtype=np.uint32).copy()
+    l = lib()
+    l.ora_rv32_branch_lt_trace.restype = C.c_size_t
+    l.ora_rv32_branch_lt_trace.argtypes = [u32p_t()] * 4 + [C.c_size_t, C.c_uint, u32p_t(), u32p_t()]
+    bad = l.ora_rv32_branch_lt_trace(p32(opc), p32(a), p32(b), p32(imm), len(opc), log_height, p32(tr), p32(rc))
+    return tr, rc, int(bad)
+
+
 def rv32_lt_trace(opc, bs, cs, log_height, range_counts=None):
     opc, bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, bs, cs))
     tr = np.zeros((18, 1 << log_height), np.uint32)

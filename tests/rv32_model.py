@@ -114,7 +114,7 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
     pvs = bytearray(32)
     pc, n, pos = pc_base, 0, 0
     rec = dict(pc_index=[], alu=[], lt=[], mul=[], shift=0, branch=0, jump=0, load_store=0, mulh=0, divrem=0, lui_auipc=0, ecall=0,
-               acc=[], bnd=[], shifts=[], beq=[])
+               acc=[], bnd=[], shifts=[], beq=[], blt=[])
     s32 = lambda v: sx(v, 32)  # noqa: E731
     # memory log over 16-bit cells: address space 1 = registers (cell 2 i + half), 2 = memory (halfword index); entries
     # (as, ptr, prev_data, prev_ts, data, ts, is_read), timestamps 1, 2, ...
@@ -193,6 +193,8 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
             rec["branch"] += 1
             if f3 < 2:
                 rec["beq"].append((f3, a, b, imm % 2013265921))
+            else:
+                rec["blt"].append(({4: 0, 6: 1, 5: 2, 7: 3}[f3], a, b, imm % 2013265921))
         elif op == 0x03:
             addr = (a + imm_i) & M32
             o = addr - data_base

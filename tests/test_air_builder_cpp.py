@@ -59,6 +59,8 @@ PY = {
     "chip_rv32_lt": lambda: air.rv32_lt_core_air(),
     "chip_rv32_mul": lambda: air.rv32_mul_core_air(),
     "chip_rv32_shift": lambda: air.rv32_shift_core_air(),
+    "chip_rv32_branch_eq": lambda: air.rv32_branch_eq_core_air(),
+    "chip_rv32_branch_lt": lambda: air.rv32_branch_lt_core_air(),
     "chip_memory_access": lambda: air.memory_access_air(),
     "chip_memory_boundary": lambda: air.memory_boundary_air(),
 }

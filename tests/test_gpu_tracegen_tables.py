@@ -396,3 +396,51 @@ def test_rv32_branch_equal_chip(zk, ora):
     assert z.verify(PARAMS, pk.verifying_airs(), [NOPV], proof) == 0
     assert proof == ora.stark_prove(PARAMS, airs).tobytes()
     pk.close()
+
+
+def test_rv32_branch_less_than_chip(zk, ora):
+    """RV32 branch-less-than core (BLT / BLTU / BGE / BGEU, OpenVM BranchLessThanCoreAir<4, 8>) filled on the device from execution
+    records, its range requests counted into the bitwise table in the same pass: cells == oracle (whose comparison is on the
+    integers, its marker scan on the limbs), `taken` == the integers' comparison incl. equal operands and operands that differ
+    only in the sign bit, the oracle's trace satisfies the AIR and tampered decisions do not; chip + table prove from the
+    device-resident traces (bytes == oracle)."""
+    rng = np.random.default_rng(29)
+    n, lh = 4000, 12
+    opc = rng.integers(0, 4, n).astype(np.uint32)
+    a = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    b[:500] = a[:500]
+    b[500:900] = a[500:900] ^ 0x80000000
+    b[900:1200] = a[900:1200] ^ 0x100
+    off = rng.integers(-2048, 2048, n) * 2
+    imm = np.where(off < 0, P + off, off).astype(np.uint32)
+    exp, rc, bad = ora.rv32_branch_lt_trace(opc, a, b, imm, lh)
+    assert bad == 0
+    lt = np.where(opc % 2 == 0, a.view(np.int32) < b.view(np.int32), a < b)
+    taken = np.where(opc >= 2, ~lt, lt)
+    assert (exp[8][:n] == lt).all() and (exp[9][:n] == taken).all() and (exp[22][:n] == np.where(taken, imm, 4)).all()
+    assert int(rc.astype(np.int64).sum()) == n + int((a != b).sum())
+    prog = air.rv32_branch_lt_core_air().program()
+    assert air.check_trace(prog, exp, NOPV) == []
+    for col, row in ((9, 0), (8, 600), (22, 5), (21, 1000)):
+        w = exp.copy()
+        w[col][row] = (int(w[col][row]) + 1) % P
+        assert air.check_trace(prog, w, NOPV) != []
+    as_dev = lambda v: torch.from_numpy(v.view(np.int32)).to(zk.device)  # noqa: E731
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
+    d_tr = zk.rv32_branch_lt_tracegen(as_dev(opc), as_dev(a), as_dev(b), as_dev(imm), lh, d_bw)
+    assert (zk.download(d_tr).reshape(23, -1) == exp).all()
+    bw = zk.download(d_bw).reshape(2, -1)
+    assert (bw[0] == rc).all() and (bw[1] == 0).all()
+    with pytest.raises(z.ZkhipError):
+        zk.rv32_branch_lt_tracegen(as_dev(np.array([4], np.uint32)), as_dev(a[:1]), as_dev(b[:1]), as_dev(imm[:1]), 0, d_bw)
+    with pytest.raises(z.ZkhipError):   # an offset that is not a field element
+        zk.rv32_branch_lt_tracegen(as_dev(opc[:1]), as_dev(a[:1]), as_dev(b[:1]), as_dev(np.array([P], np.uint32)), 0, d_bw)
+    airs = [dict(program=prog, log_height=lh, width=23, n_pvs=0, trace=exp, pvs=NOPV),
+            dict(program=air.bitwise_lookup_air(8).program(), log_height=16, width=2, n_pvs=0, trace=bw, pvs=NOPV,
+                 prep=air.bitwise_lookup_prep(8))]
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    proof = pk.prove([d_tr, d_bw], [NOPV] * 2)
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    pk.close()

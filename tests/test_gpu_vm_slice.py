@@ -153,7 +153,7 @@ def test_memory_consistency_of_the_execution(zk, ora, tmp_path, which, seed):
 
 def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     """`prove_cli prove-guest`: the gen_proof_stark flow of the reference (mod.rs:342-413 -- execute, prove, encode, self-verify)
-    from a guest image, all in C++ on the C ABI (include/zkhip_vm_prover.hpp): the eleven-chip proof it writes equals, byte for byte,
+    from a guest image, all in C++ on the C ABI (include/zkhip_vm_prover.hpp): the thirteen-chip proof it writes equals, byte for byte,
     the oracle's proof over the oracle's traces of the same execution records; the JSON carries the cycle count and the public
     values like the reference's StarkProof."""
     import base64
@@ -185,8 +185,9 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     lp, lf = log2_ceil(len(words)), log2_ceil(len(rec["pc_index"]))
     la, ll, lm = log2_ceil(len(rec["alu_op"])), log2_ceil(len(rec["lt_op"])), log2_ceil(len(rec["mul_b"]))
     lacc, lbnd = log2_ceil(len(rec["acc_ts"])), log2_ceil(len(rec["bnd_ptr"]))
-    lsh = log2_ceil(len(rec["shift_op"]))
-    assert heights == [lp, lf, la, ll, lm, lsh, 16, 19, lacc, lbnd, 16]
+    lsh, lbe, lbl = log2_ceil(len(rec["shift_op"])), log2_ceil(len(rec["beq_op"])), log2_ceil(len(rec["blt_op"]))
+    assert len(rec["blt_op"]) > 100 and set(rec["blt_op"].tolist()) == {0, 1, 2, 3} and set(rec["beq_op"].tolist()) == {0, 1}
+    assert heights == [lp, lf, la, ll, lm, lsh, lbe, lbl, 16, 19, lacc, lbnd, 16]
     prog = program_table(words, lp)
     freq, _ = ora.program_freq_trace(rec["pc_index"], lp)
     frames, _ = ora.exec_frame_trace(rec["pc_index"], prog, lf)
@@ -195,6 +196,8 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     sx, sy = 256, 2048
     mul, tc = ora.rv32_mul_trace(rec["mul_b"], rec["mul_c"], lm, sx, sy)
     sh, rc, xc, _ = ora.rv32_shift_trace(rec["shift_op"], rec["shift_b"], rec["shift_c"], lsh, range_counts=rc, xor_counts=xc)
+    beq, _ = ora.rv32_branch_eq_trace(rec["beq_op"], rec["beq_a"], rec["beq_b"], rec["beq_imm"], lbe)
+    blt, rc, _ = ora.rv32_branch_lt_trace(rec["blt_op"], rec["blt_a"], rec["blt_b"], rec["blt_imm"], lbl, range_counts=rc)
     order = ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read")
     acc, _ = ora.memory_access_trace(*[rec["acc_" + k] for k in order], lacc)
     bnd, _ = ora.memory_boundary_trace(rec["bnd_as"], rec["bnd_ptr"], rec["bnd_initial"], rec["bnd_final"], rec["bnd_final_ts"], 2, 29, lbnd)
@@ -209,6 +212,8 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
             A(air.rv32_lt_core_air().program(), ll, 18, lt),
             A(air.rv32_mul_core_air().program(), lm, 13, mul),
             A(air.rv32_shift_core_air().program(), lsh, 32, sh),
+            A(air.rv32_branch_eq_core_air().program(), lbe, 17, beq),
+            A(air.rv32_branch_lt_core_air().program(), lbl, 23, blt),
             A(air.bitwise_lookup_air(8).program(), 16, 2, np.stack([rc, xc]), air.bitwise_lookup_prep(8)),
             A(air.range_tuple_table_air(sx, sy).program(), 19, 1, tc.reshape(1, -1), air.range_tuple_prep(sx, sy)),
             A(air.memory_access_air().program(), lacc, 10, acc),

@@ -29,6 +29,8 @@ static void write_records(const std::string& out, const zkhip_vm::ExecRecords& r
     write_u32(out + "/shift_op.u32", rec.shift_op), write_u32(out + "/shift_b.u32", rec.shift_b), write_u32(out + "/shift_c.u32", rec.shift_c);
     write_u32(out + "/beq_op.u32", rec.beq_op), write_u32(out + "/beq_a.u32", rec.beq_a), write_u32(out + "/beq_b.u32", rec.beq_b);
     write_u32(out + "/beq_imm.u32", rec.beq_imm);
+    write_u32(out + "/blt_op.u32", rec.blt_op), write_u32(out + "/blt_a.u32", rec.blt_a), write_u32(out + "/blt_b.u32", rec.blt_b);
+    write_u32(out + "/blt_imm.u32", rec.blt_imm);
     write_u32(out + "/acc_as.u32", rec.acc_as), write_u32(out + "/acc_ptr.u32", rec.acc_ptr);
     write_u32(out + "/acc_prev_data.u32", rec.acc_prev_data), write_u32(out + "/acc_prev_ts.u32", rec.acc_prev_ts);
     write_u32(out + "/acc_data.u32", rec.acc_data), write_u32(out + "/acc_ts.u32", rec.acc_ts), write_u32(out + "/acc_is_read.u32", rec.acc_is_read);

@@ -100,6 +100,7 @@ def load_library():
         "zkhip_rv32_lt_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_shift_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_branch_eq_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
+        "zkhip_rv32_branch_lt_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_mul_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_memory_boundary_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint, C.c_uint, vp]),
         "zkhip_memory_access_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
@@ -308,6 +309,17 @@ class Context:
         self._check(self.lib.zkhip_rv32_lt_tracegen(self.h, C.c_void_p(t_opcode.data_ptr()), C.c_void_p(t_b.data_ptr()),
                                                     C.c_void_p(t_c.data_ptr()), t_opcode.numel(), log_height, C.c_void_p(out.data_ptr()),
                                                     C.c_void_p(t_bitwise_trace.data_ptr())))
+        return out
+
+    def rv32_branch_lt_tracegen(self, t_opcode, t_a, t_b, t_imm, log_height, t_bitwise_trace):
+        """23-column trace of the RV32 branch-less-than core chip from records (int32 tensors: opcode 0 = BLT, 1 = BLTU, 2 = BGE, 3 = BGEU;
+        operands; the offset as a canonical field element); range requests go to column 0 of t_bitwise_trace."""
+        import torch
+
+        out = torch.empty(23 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_rv32_branch_lt_tracegen(self.h, C.c_void_p(t_opcode.data_ptr()), C.c_void_p(t_a.data_ptr()),
+                                                           C.c_void_p(t_b.data_ptr()), C.c_void_p(t_imm.data_ptr()), t_opcode.numel(), log_height,
+                                                           C.c_void_p(out.data_ptr()), C.c_void_p(t_bitwise_trace.data_ptr())))
         return out
 
     def rv32_branch_eq_tracegen(self, t_opcode, t_a, t_b, t_imm, log_height):

@@ -746,6 +746,46 @@ def rv32_branch_eq_core_air():
     return b
 
 
+RV32_BRANCH_LT_WIDTH = 23
+
+
+def rv32_branch_lt_core_air(bus=9):
+    """The core of OpenVM's RV32 branch-less-than chip (rv32im `BranchLessThanCoreAir<4, 8>`: BLT / BLTU / BGE / BGEU): columns
+    a[4] | b[4] | cmp_lt | taken | imm | is_blt is_bltu is_bge is_bgeu | a_msb_f b_msb_f | marker[4] | diff_val | pc_inc.  cmp_lt is
+    a < b by the comparison of rv32_lt_core_air() (signed for BLT / BGE); taken = cmp_lt for the less-than opcodes, 1 - cmp_lt for
+    the greater-or-equal ones; pc_inc = imm if taken else 4.  The same two range requests as the less-than chip."""
+    b = AirBuilder(RV32_BRANCH_LT_WIDTH, 0)
+    al, bl = [b.var(i) for i in range(4)], [b.var(4 + i) for i in range(4)]
+    cmp, taken, imm = b.var(8), b.var(9), b.var(10)
+    blt, bltu, bge, bgeu = (b.var(11 + i) for i in range(4))
+    am, bm = b.var(15), b.var(16)
+    mk, dv, inc = [b.var(17 + i) for i in range(4)], b.var(21), b.var(22)
+    signed = blt + bge
+    ge = bge + bgeu
+    ok = blt + bltu + bge + bgeu
+    for f in (blt, bltu, bge, bgeu, ok, cmp, taken) + tuple(mk):
+        b.assert_zero(f * (f - 1))
+    b.assert_zero(taken - (cmp + ge - cmp * ge * 2))
+    for limb, f in ((al[3], am), (bl[3], bm)):
+        d = limb - f
+        b.assert_zero(d * (d - 256))
+        b.assert_zero((1 - signed) * d)
+    sign = cmp * 2 - 1
+    prefix = None
+    for i in (3, 2, 1, 0):
+        diff = ((bm if i == 3 else bl[i]) - (am if i == 3 else al[i])) * sign
+        prefix = mk[i] if prefix is None else prefix + mk[i]
+        b.assert_zero((1 - prefix) * diff)
+        b.assert_zero(mk[i] * (dv - diff))
+    b.assert_zero(prefix * (prefix - 1))
+    b.assert_zero((1 - prefix) * cmp)
+    b.assert_zero((1 - ok) * prefix)
+    b.assert_zero(ok * (inc - taken * imm - (1 - taken) * 4))
+    b.push_interaction(bus, [am + signed * 128, bm + signed * 128, 0, 0], ok, "send")
+    b.push_interaction(bus, [dv - 1, 0, 0, 0], prefix, "send")
+    return b
+
+
 RV32_SHIFT_WIDTH = 32
 
 

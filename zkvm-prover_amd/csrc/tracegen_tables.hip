@@ -628,3 +628,70 @@ extern "C" int zkhip_rv32_branch_eq_tracegen(zkhip_ctx* ctx, const uint32_t* d_o
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_branch_eq_tracegen (opcode > 1 or offset not a field element)");
 }
+
+// ---- RV32 branch-less-than core (OpenVM rv32im BranchLessThanCoreAir<4, 8>: BLT / BLTU / BGE / BGEU) -------------------------------
+// Record = (opcode 0 = BLT, 1 = BLTU, 2 = BGE, 3 = BGEU; operands a, b; the offset as a canonical field element).  Row
+// (ZKHIP_RV32_BRANCH_LT_WIDTH = 23): a[4] | b[4] | cmp_lt | taken | imm | 4 opcode flags | a_msb_f b_msb_f | marker[4] | diff_val | pc_inc;
+// the comparison columns are those of the less-than chip, and so are the two range requests counted into the bitwise table.
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_rv32_branch_lt(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ as, const uint32_t* __restrict__ bs,
+                                                        const uint32_t* __restrict__ imms, size_t n, size_t N, uint32_t* __restrict__ trace,
+                                                        uint32_t* __restrict__ range_counts, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_RV32_BRANCH_LT_WIDTH] = {};
+    if (r < n) {
+        const uint32_t op = opc[r], a = as[r], b = bs[r], imm = imms[r];
+        if (op > 3 || imm >= P) {
+            atomicAdd(bad, 1u);
+        } else {
+            const bool is_signed = (op & 1u) == 0, is_ge = op >= 2;
+            int al[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) al[i] = (int)((a >> (8 * i)) & 255u), bl[i] = (int)((b >> (8 * i)) & 255u);
+            const int am = is_signed && al[3] >= 128 ? al[3] - 256 : al[3], bm = is_signed && bl[3] >= 128 ? bl[3] - 256 : bl[3];
+            int mark = -1, diff = 0;
+#pragma unroll
+            for (int i = 3; i >= 0; i--) {
+                const int x = i == 3 ? am : al[i], y = i == 3 ? bm : bl[i];
+                if (mark < 0 && x != y) mark = i, diff = y - x;
+            }
+            const bool lt = mark >= 0 && diff > 0, taken = lt != is_ge;
+            const int dv = diff > 0 ? diff : -diff;
+#pragma unroll
+            for (int i = 0; i < 4; i++) col[i] = to_monty((uint32_t)al[i]), col[4 + i] = to_monty((uint32_t)bl[i]);
+            col[8] = lt ? MONTY_ONE : 0u, col[9] = taken ? MONTY_ONE : 0u, col[10] = to_monty(imm);
+            col[11 + op] = MONTY_ONE;
+            col[15] = to_monty(am < 0 ? P - (uint32_t)(-am) : (uint32_t)am);
+            col[16] = to_monty(bm < 0 ? P - (uint32_t)(-bm) : (uint32_t)bm);
+            if (mark >= 0) col[17 + mark] = MONTY_ONE, col[21] = to_monty((uint32_t)dv);
+            col[22] = taken ? to_monty(imm) : to_monty(4u);
+            const int sh = is_signed ? 128 : 0;
+            atomicAdd(&range_counts[((uint32_t)(am + sh) << 8) | (uint32_t)(bm + sh)], 1u);
+            if (mark >= 0) atomicAdd(&range_counts[(uint32_t)(dv - 1) << 8], 1u);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_RV32_BRANCH_LT_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_rv32_branch_lt_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, const uint32_t* d_a, const uint32_t* d_b, const uint32_t* d_imm,
+                                             size_t n, unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 27 || (n && (!d_opcode || !d_a || !d_b || !d_imm))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_branch_lt_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "rv32_branch_lt_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
+    hipLaunchKernelGGL(k_rv32_branch_lt, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_a, d_b, d_imm, n, N, d_trace,
+                       d_bitwise_trace, (uint32_t*)flag);
+    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "rv32_branch_lt_tracegen (opcode > 3 or offset not a field element)");
+}
