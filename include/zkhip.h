@@ -179,6 +179,29 @@ int zkhip_rv32_branch_eq_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, cons
 int zkhip_rv32_branch_lt_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_a, const uint32_t *d_b, const uint32_t *d_imm,
                                   size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
 
+/* RV32 JAL / LUI core (rv32im Rv32JalLuiCoreAir).  Record i = (d_opcode[i]: 0 = JAL, 1 = LUI; d_pc[i] the instruction's pc, < 2^30 - 4 for
+ * JAL; d_imm[i]: JAL's offset as a canonical field element, LUI's 20-bit immediate) -- plain integers.  Fills d_trace
+ * (ZKHIP_RV32_JAL_LUI_WIDTH = 9 columns, stride 2^log_height, Montgomery: pc | imm | rd[4] | is_jal is_lui | pc_inc; rows >= n zero) and
+ * adds the rows' range requests ((rd0, rd1), (rd2, rd3), JAL: (4 rd3, 0)) to column 0 of d_bitwise_trace.  AIR: air.py
+ * rv32_jal_lui_core_air().  ZKHIP_ERR_INVALID for a record outside those ranges. */
+#define ZKHIP_RV32_JAL_LUI_WIDTH 9
+int zkhip_rv32_jal_lui_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_pc, const uint32_t *d_imm, size_t n,
+                                unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
+
+/* RV32 AUIPC core (rv32im Rv32AuipcCoreAir).  Record i = (d_pc[i] < p, d_imm[i] the 20-bit immediate).  ZKHIP_RV32_AUIPC_WIDTH = 14
+ * columns: pc | imm | pc_limb[4] | imm_limb[3] (bytes of 16 imm) | rd[4] = pc + (imm << 12) mod 2^32 | is_valid; five range requests
+ * per row.  AIR: air.py rv32_auipc_core_air(). */
+#define ZKHIP_RV32_AUIPC_WIDTH 14
+int zkhip_rv32_auipc_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc, const uint32_t *d_imm, size_t n, unsigned log_height, uint32_t *d_trace,
+                              uint32_t *d_bitwise_trace);
+
+/* RV32 JALR core (rv32im Rv32JalrCoreAir).  Record i = (d_pc[i] < 2^30 - 4, d_rs1[i], d_imm[i] the raw 12-bit immediate).
+ * ZKHIP_RV32_JALR_WIDTH = 20 columns: pc | imm | imm_limb[2] | imm_sign | rs1[4] | rd[4] = pc + 4 | t[4] = rs1 + sext(imm) mod 2^32 | lsb of
+ * t | to_pc = t - lsb (must be < p) | is_valid; five range requests per row.  AIR: air.py rv32_jalr_core_air(). */
+#define ZKHIP_RV32_JALR_WIDTH 20
+int zkhip_rv32_jalr_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc, const uint32_t *d_rs1, const uint32_t *d_imm, size_t n, unsigned log_height,
+                             uint32_t *d_trace, uint32_t *d_bitwise_trace);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

@@ -16,6 +16,7 @@ using air::Kind;
 
 constexpr uint32_t RANGE_BUS = 5, RANGE_TUPLE_BUS = 6, PROGRAM_BUS = 8, BITWISE_BUS = 9, MEMORY_BUS = 1;
 constexpr int64_t INV_256 = 2005401601;  // 256^-1 mod p
+constexpr int64_t INV_2 = 1006632961;     // 2^-1 mod p
 
 // air.range_table_air(bus)
 inline void range_table_air(AirBuilder& b, uint32_t bus = RANGE_BUS) {
@@ -346,6 +347,201 @@ inline void rv32_branch_lt_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
         const Expr x = dv - 1;
         const Expr z0 = b.constant(0);
         b.push_interaction(bus, {x, z0, z0, z0}, prefix, Kind::Send);
+    }
+}
+
+// air.rv32_jal_lui_core_air(bus): AirBuilder(9, 0)
+inline void rv32_jal_lui_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
+    const Expr pc = b.var(0), imm = b.var(1);
+    Expr rd[4];
+    for (int i = 0; i < 4; i++) rd[i] = b.var(2 + i);
+    const Expr jal = b.var(6), lui = b.var(7), inc = b.var(8);
+    const Expr ok = jal + lui;
+    for (const Expr& f : {jal, lui, ok}) {
+        const Expr t = f - 1;
+        b.assert_zero(f * t);
+    }
+    b.assert_zero(lui * rd[0]);
+    {
+        const Expr t1 = rd[2] * 256;
+        const Expr t2 = rd[1] + t1;
+        const Expr t3 = rd[3] * 65536;
+        const Expr t4 = t2 + t3;
+        const Expr t5 = imm * 16;
+        const Expr t6 = t4 - t5;
+        b.assert_zero(lui * t6);
+    }
+    {
+        const Expr u1 = rd[1] * 256;
+        const Expr u2 = rd[0] + u1;
+        const Expr u3 = rd[2] * 65536;
+        const Expr u4 = u2 + u3;
+        const Expr u5 = rd[3] * 16777216;
+        const Expr u6 = u4 + u5;
+        const Expr u7 = u6 - pc;
+        const Expr u8 = u7 - 4;
+        b.assert_zero(jal * u8);
+    }
+    {
+        const Expr v1 = jal * imm;
+        const Expr v2 = inc - v1;
+        const Expr v3 = lui * 4;
+        const Expr v4 = v2 - v3;
+        b.assert_zero(ok * v4);
+    }
+    {
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {rd[0], rd[1], z0, z0}, ok, Kind::Send);
+    }
+    {
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {rd[2], rd[3], z0, z0}, ok, Kind::Send);
+    }
+    {
+        const Expr x = rd[3] * 4;
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {x, z0, z0, z0}, jal, Kind::Send);
+    }
+}
+
+// air.rv32_auipc_core_air(bus): AirBuilder(14, 0)
+inline void rv32_auipc_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
+    const Expr pc = b.var(0), imm = b.var(1);
+    Expr pl[4], il[3], rd[4];
+    for (int i = 0; i < 4; i++) pl[i] = b.var(2 + i);
+    for (int i = 0; i < 3; i++) il[i] = b.var(6 + i);
+    for (int i = 0; i < 4; i++) rd[i] = b.var(9 + i);
+    const Expr ok = b.var(13);
+    {
+        const Expr t = ok - 1;
+        b.assert_zero(ok * t);
+    }
+    {
+        const Expr u1 = pl[1] * 256;
+        const Expr u2 = pl[0] + u1;
+        const Expr u3 = pl[2] * 65536;
+        const Expr u4 = u2 + u3;
+        const Expr u5 = pl[3] * 16777216;
+        const Expr u6 = u4 + u5;
+        const Expr u7 = u6 - pc;
+        b.assert_zero(ok * u7);
+    }
+    {
+        const Expr u1 = il[1] * 256;
+        const Expr u2 = il[0] + u1;
+        const Expr u3 = il[2] * 65536;
+        const Expr u4 = u2 + u3;
+        const Expr u5 = imm * 16;
+        const Expr u6 = u4 - u5;
+        b.assert_zero(ok * u6);
+    }
+    {
+        const Expr d = rd[0] - pl[0];
+        b.assert_zero(ok * d);
+    }
+    Expr carry;
+    for (int i = 1; i < 4; i++) {
+        const Expr s = pl[i] + il[i - 1];
+        const Expr d = s - rd[i];
+        const Expr prev = i == 1 ? b.constant(0) : carry;
+        const Expr t = d + prev;
+        carry = t * INV_256;
+        const Expr c1 = carry - 1;
+        const Expr m = carry * c1;
+        b.assert_zero(ok * m);
+    }
+    const Expr xs[5] = {pl[0], pl[2], il[0], il[2], rd[2]}, ys[5] = {pl[1], pl[3], il[1], rd[1], rd[3]};
+    for (int k = 0; k < 5; k++) {
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {xs[k], ys[k], z0, z0}, ok, Kind::Send);
+    }
+}
+
+// air.rv32_jalr_core_air(bus): AirBuilder(20, 0)
+inline void rv32_jalr_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
+    const Expr pc = b.var(0), imm = b.var(1);
+    const Expr il0 = b.var(2), il1 = b.var(3), sign = b.var(4);
+    Expr rs[4], rd[4], t[4];
+    for (int i = 0; i < 4; i++) rs[i] = b.var(5 + i);
+    for (int i = 0; i < 4; i++) rd[i] = b.var(9 + i);
+    for (int i = 0; i < 4; i++) t[i] = b.var(13 + i);
+    const Expr lsb = b.var(17), to_pc = b.var(18), ok = b.var(19);
+    for (const Expr& f : {ok, sign, lsb}) {
+        const Expr m = f - 1;
+        b.assert_zero(f * m);
+    }
+    {
+        const Expr u1 = il1 * 256;
+        const Expr u2 = il0 + u1;
+        const Expr u3 = u2 - imm;
+        b.assert_zero(ok * u3);
+    }
+    Expr ext[4];
+    ext[0] = il0;
+    {
+        const Expr s240 = sign * 240;
+        ext[1] = il1 + s240;
+    }
+    ext[2] = sign * 255;
+    ext[3] = sign * 255;
+    Expr carry;
+    for (int i = 0; i < 4; i++) {
+        const Expr s = rs[i] + ext[i];
+        const Expr d = s - t[i];
+        const Expr prev = i == 0 ? b.constant(0) : carry;
+        const Expr e = d + prev;
+        carry = e * INV_256;
+        const Expr c1 = carry - 1;
+        const Expr m = carry * c1;
+        b.assert_zero(ok * m);
+    }
+    {
+        const Expr u1 = t[1] * 256;
+        const Expr u2 = t[0] + u1;
+        const Expr u3 = t[2] * 65536;
+        const Expr u4 = u2 + u3;
+        const Expr u5 = t[3] * 16777216;
+        const Expr u6 = u4 + u5;
+        const Expr u7 = u6 - lsb;
+        const Expr u8 = u7 - to_pc;
+        b.assert_zero(ok * u8);
+    }
+    {
+        const Expr u1 = rd[1] * 256;
+        const Expr u2 = rd[0] + u1;
+        const Expr u3 = rd[2] * 65536;
+        const Expr u4 = u2 + u3;
+        const Expr u5 = rd[3] * 16777216;
+        const Expr u6 = u4 + u5;
+        const Expr u7 = u6 - pc;
+        const Expr u8 = u7 - 4;
+        b.assert_zero(ok * u8);
+    }
+    {
+        const Expr s8 = sign * 8;
+        const Expr d = il1 - s8;
+        const Expr y = d * 32;
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {il0, y, z0, z0}, ok, Kind::Send);
+    }
+    {
+        const Expr d = t[0] - lsb;
+        const Expr x = d * INV_2;
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {x, t[1], z0, z0}, ok, Kind::Send);
+    }
+    {
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {t[2], t[3], z0, z0}, ok, Kind::Send);
+    }
+    {
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {rd[0], rd[1], z0, z0}, ok, Kind::Send);
+    }
+    {
+        const Expr y = rd[3] * 4;
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {rd[2], y, z0, z0}, ok, Kind::Send);
     }
 }
 

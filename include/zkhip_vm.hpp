@@ -56,6 +56,9 @@ struct ExecRecords {
     std::vector<uint32_t> shift_op, shift_b, shift_c; // 0 sll 1 srl 2 sra; c = the shift operand (register value or shamt)
     std::vector<uint32_t> beq_op, beq_a, beq_b, beq_imm;  // 0 beq 1 bne; imm = the offset as a canonical BabyBear element
     std::vector<uint32_t> blt_op, blt_a, blt_b, blt_imm;  // 0 blt 1 bltu 2 bge 3 bgeu; imm as above
+    std::vector<uint32_t> jal_op, jal_pc, jal_imm;        // 0 jal (imm = the offset as a field element) 1 lui (imm = the 20-bit immediate)
+    std::vector<uint32_t> auipc_pc, auipc_imm;            // imm = the 20-bit immediate
+    std::vector<uint32_t> jalr_pc, jalr_rs1, jalr_imm;    // imm = the raw 12-bit immediate
     uint64_t n_shift = 0, n_branch = 0, n_jump = 0, n_load_store = 0, n_mulh = 0, n_divrem = 0, n_lui_auipc = 0, n_ecall = 0;
     // Memory log for the offline memory-checking argument (OpenVM's memory bus): state is kept in 16-bit CELLS -- address space
     // 1 = registers (cell 2 i + half of x_i), 2 = read-write memory (cell = halfword index from data_base) -- so that a cell's
@@ -229,10 +232,25 @@ private:
             return kind == 0 ? x << s : kind == 1 ? x >> s : (uint32_t)((int32_t)x >> s);
         };
         switch (op) {
-            case 0x37: val = w & 0xfffff000u, wr = true; if (rec) rec->n_lui_auipc++; break;               // LUI
-            case 0x17: val = pc_ + (w & 0xfffff000u), wr = true; if (rec) rec->n_lui_auipc++; break;        // AUIPC
-            case 0x6f: val = pc_ + 4, wr = true, next = pc_ + (uint32_t)imm_j; if (rec) rec->n_jump++; break;  // JAL
-            case 0x67: val = pc_ + 4, wr = true, next = (a + (uint32_t)imm_i) & ~1u; if (rec) rec->n_jump++; break;  // JALR
+            case 0x37:  // LUI
+                val = w & 0xfffff000u, wr = true;
+                if (rec) rec->n_lui_auipc++, rec->jal_op.push_back(1), rec->jal_pc.push_back(pc_), rec->jal_imm.push_back(w >> 12);
+                break;
+            case 0x17:  // AUIPC
+                val = pc_ + (w & 0xfffff000u), wr = true;
+                if (rec) rec->n_lui_auipc++, rec->auipc_pc.push_back(pc_), rec->auipc_imm.push_back(w >> 12);
+                break;
+            case 0x6f:  // JAL
+                val = pc_ + 4, wr = true, next = pc_ + (uint32_t)imm_j;
+                if (rec) {
+                    rec->n_jump++, rec->jal_op.push_back(0), rec->jal_pc.push_back(pc_);
+                    rec->jal_imm.push_back(imm_j < 0 ? 2013265921u - (uint32_t)(-imm_j) : (uint32_t)imm_j);
+                }
+                break;
+            case 0x67:  // JALR
+                val = pc_ + 4, wr = true, next = (a + (uint32_t)imm_i) & ~1u;
+                if (rec) rec->n_jump++, rec->jalr_pc.push_back(pc_), rec->jalr_rs1.push_back(a), rec->jalr_imm.push_back(w >> 20);
+                break;
             case 0x63: {
                 bool t;
                 switch (f3) {

@@ -21,6 +21,9 @@ pub const ZKHIP_RV32_LT_WIDTH: usize = 18;
 pub const ZKHIP_RV32_SHIFT_WIDTH: usize = 32;
 pub const ZKHIP_RV32_BRANCH_EQ_WIDTH: usize = 17;
 pub const ZKHIP_RV32_BRANCH_LT_WIDTH: usize = 23;
+pub const ZKHIP_RV32_JAL_LUI_WIDTH: usize = 9;
+pub const ZKHIP_RV32_AUIPC_WIDTH: usize = 14;
+pub const ZKHIP_RV32_JALR_WIDTH: usize = 20;
 pub const ZKHIP_MEMORY_ACCESS_WIDTH: usize = 10;
 pub const ZKHIP_PROGRAM_FIELDS: usize = 9;
 pub const ZKHIP_MAX_LOG_FINAL_POLY: u32 = 8;
@@ -171,6 +174,12 @@ extern "C" {
                                      d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_rv32_branch_lt_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_a: *const u32, d_b: *const u32, d_imm: *const u32, n: usize,
                                          log_height: c_uint, d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_rv32_jal_lui_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_pc: *const u32, d_imm: *const u32, n: usize, log_height: c_uint,
+                                       d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_rv32_auipc_tracegen(ctx: *mut zkhip_ctx, d_pc: *const u32, d_imm: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
+                                     d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_rv32_jalr_tracegen(ctx: *mut zkhip_ctx, d_pc: *const u32, d_rs1: *const u32, d_imm: *const u32, n: usize, log_height: c_uint,
+                                    d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_rv32_branch_eq_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_a: *const u32, d_b: *const u32, d_imm: *const u32, n: usize,
                                          log_height: c_uint, d_trace: *mut u32) -> c_int;
     pub fn zkhip_rv32_lt_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_b: *const u32, d_c: *const u32, n: usize, log_height: c_uint,

@@ -371,3 +371,96 @@ size_t ora_rv32_branch_lt_trace(const uint32_t *opc, const uint32_t *as, const u
     }
     return bad;
 }
+
+/* RV32 JAL / LUI core (zkhip_rv32_jal_lui_tracegen): 9 columns pc | imm | rd[4] | is_jal is_lui | pc_inc, canonical.  Record = (opcode
+ * 0 = JAL, 1 = LUI; pc; imm = the offset as a field element for JAL, the 20-bit immediate for LUI).  Range requests as the AIR
+ * sends them: (rd0, rd1), (rd2, rd3), and (4 rd3, 0) for JAL. */
+static void ora_bump(uint32_t *range_counts, uint32_t x, uint32_t y) {
+    uint32_t *t = &range_counts[(x << 8) | y];
+    *t = ora_add(*t, 1);
+}
+size_t ora_rv32_jal_lui_trace(const uint32_t *opc, const uint32_t *pcs, const uint32_t *imms, size_t n, unsigned log_height, uint32_t *trace,
+                              uint32_t *range_counts) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 9; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t op = opc[r], pc = pcs[r], imm = imms[r];
+        if (op > 1 || (op == 0 ? (imm >= ORA_P || pc >= (1u << 30) - 4) : (imm >> 20) != 0) || pc >= ORA_P) {
+            bad++;
+            continue;
+        }
+        const uint32_t rd = op == 0 ? pc + 4 : imm << 12;
+        trace[0 * N + r] = pc, trace[1 * N + r] = imm;
+        for (int i = 0; i < 4; i++) trace[(size_t)(2 + i) * N + r] = (rd >> (8 * i)) & 255u;
+        trace[(size_t)(6 + op) * N + r] = 1;
+        trace[8 * N + r] = op == 0 ? imm : 4;
+        ora_bump(range_counts, rd & 255u, (rd >> 8) & 255u);
+        ora_bump(range_counts, (rd >> 16) & 255u, rd >> 24);
+        if (op == 0) ora_bump(range_counts, (rd >> 24) * 4, 0);
+    }
+    return bad;
+}
+
+/* RV32 AUIPC core (zkhip_rv32_auipc_tracegen): 14 columns pc | imm | pc_limb[4] | imm_limb[3] | rd[4] | is_valid; record = (pc, the
+ * 20-bit immediate); rd = pc + (imm << 12) mod 2^32 from 64-bit integer arithmetic. */
+size_t ora_rv32_auipc_trace(const uint32_t *pcs, const uint32_t *imms, size_t n, unsigned log_height, uint32_t *trace, uint32_t *range_counts) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 14; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t pc = pcs[r], imm = imms[r];
+        if (pc >= ORA_P || (imm >> 20) != 0) {
+            bad++;
+            continue;
+        }
+        const uint32_t rd = (uint32_t)(((uint64_t)pc + ((uint64_t)imm << 12)) & 0xffffffffu), im16 = imm << 4;
+        uint32_t pl[4], il[3], dl[4];
+        for (int i = 0; i < 4; i++) pl[i] = (pc >> (8 * i)) & 255u, dl[i] = (rd >> (8 * i)) & 255u;
+        for (int i = 0; i < 3; i++) il[i] = (im16 >> (8 * i)) & 255u;
+        trace[0 * N + r] = pc, trace[1 * N + r] = imm;
+        for (int i = 0; i < 4; i++) trace[(size_t)(2 + i) * N + r] = pl[i], trace[(size_t)(9 + i) * N + r] = dl[i];
+        for (int i = 0; i < 3; i++) trace[(size_t)(6 + i) * N + r] = il[i];
+        trace[13 * N + r] = 1;
+        ora_bump(range_counts, pl[0], pl[1]), ora_bump(range_counts, pl[2], pl[3]), ora_bump(range_counts, il[0], il[1]);
+        ora_bump(range_counts, il[2], dl[1]), ora_bump(range_counts, dl[2], dl[3]);
+    }
+    return bad;
+}
+
+/* RV32 JALR core (zkhip_rv32_jalr_tracegen): 20 columns pc | imm | imm_limb[2] | imm_sign | rs1[4] | rd[4] | t[4] | lsb | to_pc | is_valid;
+ * record = (pc, rs1, the raw 12-bit immediate).  t = rs1 + sext(imm) from integer arithmetic, to_pc = t & ~1, rd = pc + 4. */
+size_t ora_rv32_jalr_trace(const uint32_t *pcs, const uint32_t *rs1s, const uint32_t *imms, size_t n, unsigned log_height, uint32_t *trace,
+                           uint32_t *range_counts) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 20; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t pc = pcs[r], rs1 = rs1s[r], imm = imms[r];
+        if (pc >= (1u << 30) - 4 || (imm >> 12) != 0) {
+            bad++;
+            continue;
+        }
+        const uint32_t sign = imm >> 11, ext = sign ? imm | 0xfffff000u : imm, t = rs1 + ext, rd = pc + 4, to_pc = t & ~1u;
+        if (to_pc >= ORA_P) {   /* not a program counter this field can hold */
+            bad++;
+            continue;
+        }
+        trace[0 * N + r] = pc, trace[1 * N + r] = imm, trace[2 * N + r] = imm & 255u, trace[3 * N + r] = imm >> 8, trace[4 * N + r] = sign;
+        for (int i = 0; i < 4; i++) {
+            trace[(size_t)(5 + i) * N + r] = (rs1 >> (8 * i)) & 255u;
+            trace[(size_t)(9 + i) * N + r] = (rd >> (8 * i)) & 255u;
+            trace[(size_t)(13 + i) * N + r] = (t >> (8 * i)) & 255u;
+        }
+        trace[17 * N + r] = t & 1u, trace[18 * N + r] = to_pc, trace[19 * N + r] = 1;
+        ora_bump(range_counts, imm & 255u, ((imm >> 8) - 8 * sign) * 32);
+        ora_bump(range_counts, (t & 255u) >> 1, (t >> 8) & 255u);
+        ora_bump(range_counts, (t >> 16) & 255u, t >> 24);
+        ora_bump(range_counts, rd & 255u, (rd >> 8) & 255u);
+        ora_bump(range_counts, (rd >> 16) & 255u, (rd >> 24) * 4);
+    }
+    return bad;
+}

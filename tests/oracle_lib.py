@@ -123,6 +123,29 @@ def rv32_branch_lt_trace(opc, a, b, imm, log_height, range_counts=None):
     return tr, rc, int(bad)
 
 
+def _records_trace(fn, width, cols, log_height, range_counts):
+    cols = [np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in cols]
+    tr = np.zeros((width, 1 << log_height), np.uint32)
+    rc = np.zeros(1 << 16, np.uint32) if range_counts is None else np.ascontiguousarray(range_counts, dtype=np.uint32).copy()
+    f = getattr(lib(), fn)
+    f.restype = C.c_size_t
+    f.argtypes = [u32p_t()] * len(cols) + [C.c_size_t, C.c_uint, u32p_t(), u32p_t()]
+    bad = f(*[p32(c) for c in cols], len(cols[0]), log_height, p32(tr), p32(rc))
+    return tr, rc, int(bad)
+
+
+def rv32_jal_lui_trace(opc, pc, imm, log_height, range_counts=None):
+    return _records_trace("ora_rv32_jal_lui_trace", 9, (opc, pc, imm), log_height, range_counts)
+
+
+def rv32_auipc_trace(pc, imm, log_height, range_counts=None):
+    return _records_trace("ora_rv32_auipc_trace", 14, (pc, imm), log_height, range_counts)
+
+
+def rv32_jalr_trace(pc, rs1, imm, log_height, range_counts=None):
+    return _records_trace("ora_rv32_jalr_trace", 20, (pc, rs1, imm), log_height, range_counts)
+
+
 def rv32_lt_trace(opc, bs, cs, log_height, range_counts=None):
     opc, bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, bs, cs))
     tr = np.zeros((18, 1 << log_height), np.uint32)

@@ -114,7 +114,7 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
     pvs = bytearray(32)
     pc, n, pos = pc_base, 0, 0
     rec = dict(pc_index=[], alu=[], lt=[], mul=[], shift=0, branch=0, jump=0, load_store=0, mulh=0, divrem=0, lui_auipc=0, ecall=0,
-               acc=[], bnd=[], shifts=[], beq=[], blt=[])
+               acc=[], bnd=[], shifts=[], beq=[], blt=[], jal=[], auipc=[], jalr=[])
     s32 = lambda v: sx(v, 32)  # noqa: E731
     # memory log over 16-bit cells: address space 1 = registers (cell 2 i + half), 2 = memory (halfword index); entries
     # (as, ptr, prev_data, prev_ts, data, ts, is_read), timestamps 1, 2, ...
@@ -175,16 +175,20 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
         if op == 0x37:
             val, wr = w & 0xFFFFF000, True
             rec["lui_auipc"] += 1
+            rec["jal"].append((1, pc, w >> 12))
         elif op == 0x17:
             val, wr = (pc + (w & 0xFFFFF000)) & M32, True
             rec["lui_auipc"] += 1
+            rec["auipc"].append((pc, w >> 12))
         elif op == 0x6F:
             imm = sx(((w >> 31) << 20) | (((w >> 12) & 255) << 12) | (((w >> 20) & 1) << 11) | (((w >> 21) & 1023) << 1), 21)
             val, wr, nxt = pc + 4, True, (pc + imm) & M32
             rec["jump"] += 1
+            rec["jal"].append((0, pc, imm % 2013265921))
         elif op == 0x67:
             val, wr, nxt = pc + 4, True, (a + imm_i) & M32 & ~1
             rec["jump"] += 1
+            rec["jalr"].append((pc, a, w >> 20))
         elif op == 0x63:
             imm = sx(((w >> 31) << 12) | (((w >> 7) & 1) << 11) | (((w >> 25) & 63) << 5) | (((w >> 8) & 15) << 1), 13)
             t = {0: a == b, 1: a != b, 4: s32(a) < s32(b), 5: s32(a) >= s32(b), 6: a < b, 7: a >= b}[f3]

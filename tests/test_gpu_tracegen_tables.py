@@ -444,3 +444,109 @@ def test_rv32_branch_less_than_chip(zk, ora):
     assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, proof) == 0
     assert proof == ora.stark_prove(PARAMS, airs).tobytes()
     pk.close()
+
+
+def _prove_chip_with_bitwise_table(zk, ora, prog, width, lh, exp, d_tr, d_bw, rc):
+    bw = zk.download(d_bw).reshape(2, -1)
+    assert (bw[0] == rc).all() and (bw[1] == 0).all()
+    airs = [dict(program=prog, log_height=lh, width=width, n_pvs=0, trace=exp, pvs=NOPV),
+            dict(program=air.bitwise_lookup_air(8).program(), log_height=16, width=2, n_pvs=0, trace=bw, pvs=NOPV,
+                 prep=air.bitwise_lookup_prep(8))]
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    proof = pk.prove([d_tr, d_bw], [NOPV] * 2)
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    pk.close()
+
+
+def test_rv32_jal_lui_chip(zk, ora):
+    """RV32 JAL / LUI core (OpenVM Rv32JalLuiCoreAir) from (opcode, pc, immediate) records: cells == oracle, rd == pc + 4 resp.
+    imm << 12 as integers, the oracle's trace satisfies the AIR and tampered cells do not, records out of range are refused;
+    chip + bitwise table prove from the device-resident traces (bytes == oracle)."""
+    rng = np.random.default_rng(31)
+    n, lh = 3000, 12
+    opc = rng.integers(0, 2, n).astype(np.uint32)
+    pc = (rng.integers(0, 1 << 28, n) * 4).astype(np.uint32)
+    pc[:2] = [0, (1 << 30) - 8]
+    off = rng.integers(-(1 << 19), 1 << 19, n) * 2
+    imm = np.where(opc == 0, np.where(off < 0, P + off, off), rng.integers(0, 1 << 20, n)).astype(np.uint32)
+    exp, rc, bad = ora.rv32_jal_lui_trace(opc, pc, imm, lh)
+    assert bad == 0 and int(rc.astype(np.int64).sum()) == 2 * n + int((opc == 0).sum())
+    rd = sum(exp[2 + i][:n].astype(np.uint64) << (8 * i) for i in range(4))
+    assert (rd == np.where(opc == 0, pc.astype(np.uint64) + 4, (imm.astype(np.uint64) << 12) & 0xFFFFFFFF)).all()
+    prog = air.rv32_jal_lui_core_air().program()
+    assert air.check_trace(prog, exp, NOPV) == []
+    for col, row in ((2, 0), (8, 1), (5, 2)):
+        w = exp.copy()
+        w[col][row] = (int(w[col][row]) + 1) % P
+        assert air.check_trace(prog, w, NOPV) != []
+    as_dev = lambda v: torch.from_numpy(np.ascontiguousarray(v).view(np.int32)).to(zk.device)  # noqa: E731
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
+    d_tr = zk.rv32_jal_lui_tracegen(as_dev(opc), as_dev(pc), as_dev(imm), lh, d_bw)
+    assert (zk.download(d_tr).reshape(9, -1) == exp).all()
+    one = lambda v: as_dev(np.array([v], np.uint32))   # noqa: E731
+    for o, p_, i_ in ((2, 0, 0), (1, 0, 1 << 20), (0, (1 << 30) - 4, 8), (0, 0, P)):
+        with pytest.raises(z.ZkhipError):
+            zk.rv32_jal_lui_tracegen(one(o), one(p_), one(i_), 0, torch.zeros(2 << 16, dtype=torch.int32, device=zk.device))
+        assert ora.rv32_jal_lui_trace([o], [p_], [i_], 0)[2] == 1
+    _prove_chip_with_bitwise_table(zk, ora, prog, 9, lh, exp, d_tr, d_bw, rc)
+
+
+def test_rv32_auipc_chip(zk, ora):
+    """RV32 AUIPC core (OpenVM Rv32AuipcCoreAir) from (pc, 20-bit immediate) records: cells == oracle, rd == pc + (imm << 12)
+    mod 2^32 as integers incl. wrap-around, AIR satisfied / tampering caught; proves with the bitwise table (bytes == oracle)."""
+    rng = np.random.default_rng(37)
+    n, lh = 3000, 12
+    pc = rng.integers(0, P, n).astype(np.uint32)
+    imm = rng.integers(0, 1 << 20, n).astype(np.uint32)
+    pc[:10], imm[:10] = P - 1, (1 << 20) - 1
+    exp, rc, bad = ora.rv32_auipc_trace(pc, imm, lh)
+    assert bad == 0 and int(rc.astype(np.int64).sum()) == 5 * n
+    rd = sum(exp[9 + i][:n].astype(np.uint64) << (8 * i) for i in range(4))
+    assert (rd == (pc.astype(np.uint64) + (imm.astype(np.uint64) << 12)) & 0xFFFFFFFF).all()
+    prog = air.rv32_auipc_core_air().program()
+    assert air.check_trace(prog, exp, NOPV) == []
+    for col, row in ((9, 0), (10, 1), (12, 2), (6, 3)):
+        w = exp.copy()
+        w[col][row] = (int(w[col][row]) + 1) % P
+        assert air.check_trace(prog, w, NOPV) != []
+    as_dev = lambda v: torch.from_numpy(np.ascontiguousarray(v).view(np.int32)).to(zk.device)  # noqa: E731
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
+    d_tr = zk.rv32_auipc_tracegen(as_dev(pc), as_dev(imm), lh, d_bw)
+    assert (zk.download(d_tr).reshape(14, -1) == exp).all()
+    with pytest.raises(z.ZkhipError):
+        zk.rv32_auipc_tracegen(as_dev(pc[:1]), as_dev(np.array([1 << 20], np.uint32)), 0, torch.zeros(2 << 16, dtype=torch.int32, device=zk.device))
+    _prove_chip_with_bitwise_table(zk, ora, prog, 14, lh, exp, d_tr, d_bw, rc)
+
+
+def test_rv32_jalr_chip(zk, ora):
+    """RV32 JALR core (OpenVM Rv32JalrCoreAir) from (pc, rs1, raw 12-bit immediate) records: cells == oracle, to_pc ==
+    (rs1 + sext(imm)) & ~1 as integers incl. negative immediates and wrap-around, AIR satisfied / tampering caught, a target
+    that is not a field element refused; proves with the bitwise table (bytes == oracle)."""
+    rng = np.random.default_rng(41)
+    n, lh = 3000, 12
+    pc = (rng.integers(0, 1 << 28, n) * 4).astype(np.uint32)
+    rs1 = rng.integers(0, 1 << 30, n).astype(np.uint32)
+    imm = rng.integers(0, 1 << 12, n).astype(np.uint32)
+    rs1[:5] = [4096, 1, 0x7FF, 0xFFFFFFFF, 0x800]
+    imm[:5] = [0xFFF, 0x001, 0x7FF, 1, 0x800]
+    exp, rc, bad = ora.rv32_jalr_trace(pc, rs1, imm, lh)
+    assert bad == 0 and int(rc.astype(np.int64).sum()) == 5 * n
+    ext = np.where(imm >= 2048, imm.astype(np.int64) - 4096, imm.astype(np.int64))
+    assert (exp[18][:n] == ((rs1.astype(np.int64) + ext) & 0xFFFFFFFF) & ~1).all()
+    prog = air.rv32_jalr_core_air().program()
+    assert air.check_trace(prog, exp, NOPV) == []
+    for col, row in ((18, 5), (17, 6), (9, 7), (4, 8), (13, 9)):
+        w = exp.copy()
+        w[col][row] = (int(w[col][row]) + 1) % P
+        assert air.check_trace(prog, w, NOPV) != []
+    as_dev = lambda v: torch.from_numpy(np.ascontiguousarray(v).view(np.int32)).to(zk.device)  # noqa: E731
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
+    d_tr = zk.rv32_jalr_tracegen(as_dev(pc), as_dev(rs1), as_dev(imm), lh, d_bw)
+    assert (zk.download(d_tr).reshape(20, -1) == exp).all()
+    one = lambda v: as_dev(np.array([v], np.uint32))   # noqa: E731
+    for p_, r_, i_ in ((0, 0, 0xFFF), (0, 0, 1 << 12), ((1 << 30) - 4, 0, 0)):   # target 0xffffffff & ~1 >= p; immediate too wide; pc too large
+        with pytest.raises(z.ZkhipError):
+            zk.rv32_jalr_tracegen(one(p_), one(r_), one(i_), 0, torch.zeros(2 << 16, dtype=torch.int32, device=zk.device))
+        assert ora.rv32_jalr_trace([p_], [r_], [i_], 0)[2] == 1
+    _prove_chip_with_bitwise_table(zk, ora, prog, 20, lh, exp, d_tr, d_bw, rc)

@@ -153,7 +153,7 @@ def test_memory_consistency_of_the_execution(zk, ora, tmp_path, which, seed):
 
 def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     """`prove_cli prove-guest`: the gen_proof_stark flow of the reference (mod.rs:342-413 -- execute, prove, encode, self-verify)
-    from a guest image, all in C++ on the C ABI (include/zkhip_vm_prover.hpp): the thirteen-chip proof it writes equals, byte for byte,
+    from a guest image, all in C++ on the C ABI (include/zkhip_vm_prover.hpp): the sixteen-chip proof it writes equals, byte for byte,
     the oracle's proof over the oracle's traces of the same execution records; the JSON carries the cycle count and the public
     values like the reference's StarkProof."""
     import base64
@@ -187,7 +187,9 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     lacc, lbnd = log2_ceil(len(rec["acc_ts"])), log2_ceil(len(rec["bnd_ptr"]))
     lsh, lbe, lbl = log2_ceil(len(rec["shift_op"])), log2_ceil(len(rec["beq_op"])), log2_ceil(len(rec["blt_op"]))
     assert len(rec["blt_op"]) > 100 and set(rec["blt_op"].tolist()) == {0, 1, 2, 3} and set(rec["beq_op"].tolist()) == {0, 1}
-    assert heights == [lp, lf, la, ll, lm, lsh, lbe, lbl, 16, 19, lacc, lbnd, 16]
+    ljl, lau, ljr = log2_ceil(len(rec["jal_op"])), log2_ceil(len(rec["auipc_pc"])), log2_ceil(len(rec["jalr_pc"]))
+    assert set(rec["jal_op"].tolist()) == {0, 1} and len(rec["auipc_pc"]) > 100 and len(rec["jalr_pc"]) > 100
+    assert heights == [lp, lf, la, ll, lm, lsh, lbe, lbl, ljl, lau, ljr, 16, 19, lacc, lbnd, 16]
     prog = program_table(words, lp)
     freq, _ = ora.program_freq_trace(rec["pc_index"], lp)
     frames, _ = ora.exec_frame_trace(rec["pc_index"], prog, lf)
@@ -198,6 +200,9 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     sh, rc, xc, _ = ora.rv32_shift_trace(rec["shift_op"], rec["shift_b"], rec["shift_c"], lsh, range_counts=rc, xor_counts=xc)
     beq, _ = ora.rv32_branch_eq_trace(rec["beq_op"], rec["beq_a"], rec["beq_b"], rec["beq_imm"], lbe)
     blt, rc, _ = ora.rv32_branch_lt_trace(rec["blt_op"], rec["blt_a"], rec["blt_b"], rec["blt_imm"], lbl, range_counts=rc)
+    jal, rc, _ = ora.rv32_jal_lui_trace(rec["jal_op"], rec["jal_pc"], rec["jal_imm"], ljl, range_counts=rc)
+    auipc, rc, _ = ora.rv32_auipc_trace(rec["auipc_pc"], rec["auipc_imm"], lau, range_counts=rc)
+    jalr, rc, _ = ora.rv32_jalr_trace(rec["jalr_pc"], rec["jalr_rs1"], rec["jalr_imm"], ljr, range_counts=rc)
     order = ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read")
     acc, _ = ora.memory_access_trace(*[rec["acc_" + k] for k in order], lacc)
     bnd, _ = ora.memory_boundary_trace(rec["bnd_as"], rec["bnd_ptr"], rec["bnd_initial"], rec["bnd_final"], rec["bnd_final_ts"], 2, 29, lbnd)
@@ -214,6 +219,9 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
             A(air.rv32_shift_core_air().program(), lsh, 32, sh),
             A(air.rv32_branch_eq_core_air().program(), lbe, 17, beq),
             A(air.rv32_branch_lt_core_air().program(), lbl, 23, blt),
+            A(air.rv32_jal_lui_core_air().program(), ljl, 9, jal),
+            A(air.rv32_auipc_core_air().program(), lau, 14, auipc),
+            A(air.rv32_jalr_core_air().program(), ljr, 20, jalr),
             A(air.bitwise_lookup_air(8).program(), 16, 2, np.stack([rc, xc]), air.bitwise_lookup_prep(8)),
             A(air.range_tuple_table_air(sx, sy).program(), 19, 1, tc.reshape(1, -1), air.range_tuple_prep(sx, sy)),
             A(air.memory_access_air().program(), lacc, 10, acc),

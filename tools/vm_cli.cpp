@@ -31,6 +31,9 @@ static void write_records(const std::string& out, const zkhip_vm::ExecRecords& r
     write_u32(out + "/beq_imm.u32", rec.beq_imm);
     write_u32(out + "/blt_op.u32", rec.blt_op), write_u32(out + "/blt_a.u32", rec.blt_a), write_u32(out + "/blt_b.u32", rec.blt_b);
     write_u32(out + "/blt_imm.u32", rec.blt_imm);
+    write_u32(out + "/jal_op.u32", rec.jal_op), write_u32(out + "/jal_pc.u32", rec.jal_pc), write_u32(out + "/jal_imm.u32", rec.jal_imm);
+    write_u32(out + "/auipc_pc.u32", rec.auipc_pc), write_u32(out + "/auipc_imm.u32", rec.auipc_imm);
+    write_u32(out + "/jalr_pc.u32", rec.jalr_pc), write_u32(out + "/jalr_rs1.u32", rec.jalr_rs1), write_u32(out + "/jalr_imm.u32", rec.jalr_imm);
     write_u32(out + "/acc_as.u32", rec.acc_as), write_u32(out + "/acc_ptr.u32", rec.acc_ptr);
     write_u32(out + "/acc_prev_data.u32", rec.acc_prev_data), write_u32(out + "/acc_prev_ts.u32", rec.acc_prev_ts);
     write_u32(out + "/acc_data.u32", rec.acc_data), write_u32(out + "/acc_ts.u32", rec.acc_ts), write_u32(out + "/acc_is_read.u32", rec.acc_is_read);

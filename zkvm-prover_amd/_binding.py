@@ -101,6 +101,9 @@ def load_library():
         "zkhip_rv32_shift_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_branch_eq_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_rv32_branch_lt_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_rv32_jal_lui_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_rv32_auipc_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_rv32_jalr_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_mul_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_memory_boundary_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, C.c_uint, C.c_uint, vp]),
         "zkhip_memory_access_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
@@ -321,6 +324,27 @@ class Context:
                                                            C.c_void_p(t_b.data_ptr()), C.c_void_p(t_imm.data_ptr()), t_opcode.numel(), log_height,
                                                            C.c_void_p(out.data_ptr()), C.c_void_p(t_bitwise_trace.data_ptr())))
         return out
+
+    def _records_tracegen(self, fn, width, records, log_height, t_bitwise_trace):
+        import torch
+
+        out = torch.empty(width << log_height, dtype=torch.int32, device=self.device)
+        self._check(fn(self.h, *[C.c_void_p(t.data_ptr()) for t in records], records[0].numel(), log_height, C.c_void_p(out.data_ptr()),
+                       C.c_void_p(t_bitwise_trace.data_ptr())))
+        return out
+
+    def rv32_jal_lui_tracegen(self, t_opcode, t_pc, t_imm, log_height, t_bitwise_trace):
+        """9-column trace of the RV32 JAL / LUI core chip from records (int32 tensors: opcode 0 = JAL, 1 = LUI; pc; JAL's offset as a
+        field element or LUI's 20-bit immediate); range requests go to column 0 of t_bitwise_trace."""
+        return self._records_tracegen(self.lib.zkhip_rv32_jal_lui_tracegen, 9, (t_opcode, t_pc, t_imm), log_height, t_bitwise_trace)
+
+    def rv32_auipc_tracegen(self, t_pc, t_imm, log_height, t_bitwise_trace):
+        """14-column trace of the RV32 AUIPC core chip from records (pc, 20-bit immediate)."""
+        return self._records_tracegen(self.lib.zkhip_rv32_auipc_tracegen, 14, (t_pc, t_imm), log_height, t_bitwise_trace)
+
+    def rv32_jalr_tracegen(self, t_pc, t_rs1, t_imm, log_height, t_bitwise_trace):
+        """20-column trace of the RV32 JALR core chip from records (pc, rs1, raw 12-bit immediate)."""
+        return self._records_tracegen(self.lib.zkhip_rv32_jalr_tracegen, 20, (t_pc, t_rs1, t_imm), log_height, t_bitwise_trace)
 
     def rv32_branch_eq_tracegen(self, t_opcode, t_a, t_b, t_imm, log_height):
         """17-column trace of the RV32 branch-equal core chip from records (int32 tensors: opcode 0 = BEQ, 1 = BNE; operands; the

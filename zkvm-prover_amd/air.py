@@ -786,6 +786,91 @@ def rv32_branch_lt_core_air(bus=9):
     return b
 
 
+RV32_JAL_LUI_WIDTH = 9
+
+
+def rv32_jal_lui_core_air(bus=9):
+    """The core of OpenVM's RV32 JAL / LUI chip (rv32im `Rv32JalLuiCoreAir`): columns pc | imm | rd[4] | is_jal is_lui | pc_inc.
+    LUI: rd = imm << 12 with the 20-bit immediate, i.e. rd_0 = 0 and rd_1 + 2^8 rd_2 + 2^16 rd_3 = 16 imm.  JAL: rd = pc + 4
+    (composed from the limbs; the top limb below 2^6 as pc < 2^30), pc_inc = imm (the offset as a field element); LUI steps by 4.
+    Range requests to the bitwise lookup: (rd_0, rd_1), (rd_2, rd_3) per row and (4 rd_3, 0) for JAL."""
+    b = AirBuilder(RV32_JAL_LUI_WIDTH, 0)
+    pc, imm = b.var(0), b.var(1)
+    rd = [b.var(2 + i) for i in range(4)]
+    jal, lui, inc = b.var(6), b.var(7), b.var(8)
+    ok = jal + lui
+    for f in (jal, lui, ok):
+        b.assert_zero(f * (f - 1))
+    b.assert_zero(lui * rd[0])
+    b.assert_zero(lui * (rd[1] + rd[2] * 256 + rd[3] * 65536 - imm * 16))
+    b.assert_zero(jal * (rd[0] + rd[1] * 256 + rd[2] * 65536 + rd[3] * 16777216 - pc - 4))
+    b.assert_zero(ok * (inc - jal * imm - lui * 4))
+    b.push_interaction(bus, [rd[0], rd[1], 0, 0], ok, "send")
+    b.push_interaction(bus, [rd[2], rd[3], 0, 0], ok, "send")
+    b.push_interaction(bus, [rd[3] * 4, 0, 0, 0], jal, "send")
+    return b
+
+
+RV32_AUIPC_WIDTH = 14
+
+
+def rv32_auipc_core_air(bus=9):
+    """The core of OpenVM's RV32 AUIPC chip (rv32im `Rv32AuipcCoreAir`): columns pc | imm | pc_limb[4] | imm_limb[3] | rd[4] | is_valid.
+    rd = pc + (imm << 12) mod 2^32: the pc and 16 imm (= bytes 1..3 of imm << 12) are decomposed into 8-bit limbs, rd_0 = pc_limb_0,
+    and limbs 1..3 add with boolean carries.  Five range requests: (pc_0, pc_1), (pc_2, pc_3), (imm_0, imm_1), (imm_2, rd_1),
+    (rd_2, rd_3)."""
+    b = AirBuilder(RV32_AUIPC_WIDTH, 0)
+    pc, imm = b.var(0), b.var(1)
+    pl, il, rd = [b.var(2 + i) for i in range(4)], [b.var(6 + i) for i in range(3)], [b.var(9 + i) for i in range(4)]
+    ok = b.var(13)
+    b.assert_zero(ok * (ok - 1))
+    b.assert_zero(ok * (pl[0] + pl[1] * 256 + pl[2] * 65536 + pl[3] * 16777216 - pc))
+    b.assert_zero(ok * (il[0] + il[1] * 256 + il[2] * 65536 - imm * 16))
+    b.assert_zero(ok * (rd[0] - pl[0]))
+    inv256 = pow(256, -1, P)
+    carry = None
+    for i in range(1, 4):
+        carry = (pl[i] + il[i - 1] - rd[i] + (carry if carry is not None else 0)) * inv256
+        b.assert_zero(ok * (carry * (carry - 1)))
+    for x, y in ((pl[0], pl[1]), (pl[2], pl[3]), (il[0], il[1]), (il[2], rd[1]), (rd[2], rd[3])):
+        b.push_interaction(bus, [x, y, 0, 0], ok, "send")
+    return b
+
+
+RV32_JALR_WIDTH = 20
+
+
+def rv32_jalr_core_air(bus=9):
+    """The core of OpenVM's RV32 JALR chip (rv32im `Rv32JalrCoreAir`): columns pc | imm | imm_limb[2] | imm_sign | rs1[4] | rd[4] |
+    t[4] | lsb | to_pc | is_valid.  imm is the raw 12-bit immediate = imm_limb_0 + 2^8 imm_limb_1 with imm_sign its bit 11
+    (imm_limb_1 - 8 imm_sign in [0, 8)); t = rs1 + sign-extended imm mod 2^32, limb by limb with boolean carries; to_pc = t with its
+    lowest bit (lsb) cleared; rd = pc + 4.  Five range requests: (imm_0, 32 (imm_1 - 8 sign)), ((t_0 - lsb) / 2, t_1), (t_2, t_3),
+    (rd_0, rd_1), (rd_2, 4 rd_3)."""
+    b = AirBuilder(RV32_JALR_WIDTH, 0)
+    pc, imm = b.var(0), b.var(1)
+    il, sign = [b.var(2), b.var(3)], b.var(4)
+    rs, rd, t = [b.var(5 + i) for i in range(4)], [b.var(9 + i) for i in range(4)], [b.var(13 + i) for i in range(4)]
+    lsb, to_pc, ok = b.var(17), b.var(18), b.var(19)
+    for f in (ok, sign, lsb):
+        b.assert_zero(f * (f - 1))
+    b.assert_zero(ok * (il[0] + il[1] * 256 - imm))
+    ext = [il[0], il[1] + sign * 240, sign * 255, sign * 255]
+    inv256 = pow(256, -1, P)
+    carry = None
+    for i in range(4):
+        carry = (rs[i] + ext[i] - t[i] + (carry if carry is not None else 0)) * inv256
+        b.assert_zero(ok * (carry * (carry - 1)))
+    b.assert_zero(ok * (t[0] + t[1] * 256 + t[2] * 65536 + t[3] * 16777216 - lsb - to_pc))
+    b.assert_zero(ok * (rd[0] + rd[1] * 256 + rd[2] * 65536 + rd[3] * 16777216 - pc - 4))
+    inv2 = pow(2, -1, P)
+    b.push_interaction(bus, [il[0], (il[1] - sign * 8) * 32, 0, 0], ok, "send")
+    b.push_interaction(bus, [(t[0] - lsb) * inv2, t[1], 0, 0], ok, "send")
+    b.push_interaction(bus, [t[2], t[3], 0, 0], ok, "send")
+    b.push_interaction(bus, [rd[0], rd[1], 0, 0], ok, "send")
+    b.push_interaction(bus, [rd[2], rd[3] * 4, 0, 0], ok, "send")
+    return b
+
+
 RV32_SHIFT_WIDTH = 32
 
 

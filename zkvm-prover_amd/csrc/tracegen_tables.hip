@@ -695,3 +695,142 @@ extern "C" int zkhip_rv32_branch_lt_tracegen(zkhip_ctx* ctx, const uint32_t* d_o
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_branch_lt_tracegen (opcode > 3 or offset not a field element)");
 }
+
+// ---- RV32 JAL / LUI, AUIPC and JALR cores (OpenVM rv32im Rv32JalLuiCoreAir, Rv32AuipcCoreAir, Rv32JalrCoreAir) ---------------------
+// One thread per record / row as the chips above; the rows' range requests are counted into column 0 of the bitwise table.
+namespace zk {
+namespace {
+__device__ __forceinline__ void bump_range(uint32_t* range_counts, uint32_t x, uint32_t y) { atomicAdd(&range_counts[(x << 8) | y], 1u); }
+
+__global__ __launch_bounds__(256) void k_rv32_jal_lui(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ pcs, const uint32_t* __restrict__ imms,
+                                                      size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ range_counts,
+                                                      uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_RV32_JAL_LUI_WIDTH] = {};
+    if (r < n) {
+        const uint32_t op = opc[r], pc = pcs[r], imm = imms[r];
+        const bool ok = op == 0 ? (imm < P && pc < (1u << 30) - 4) : (op == 1 && (imm >> 20) == 0 && pc < P);
+        if (!ok) {
+            atomicAdd(bad, 1u);
+        } else {
+            const uint32_t rd = op == 0 ? pc + 4 : imm << 12;
+            col[0] = to_monty(pc), col[1] = to_monty(imm);
+#pragma unroll
+            for (int i = 0; i < 4; i++) col[2 + i] = to_monty((rd >> (8 * i)) & 255u);
+            col[6 + op] = MONTY_ONE;
+            col[8] = op == 0 ? to_monty(imm) : to_monty(4u);
+            bump_range(range_counts, rd & 255u, (rd >> 8) & 255u);
+            bump_range(range_counts, (rd >> 16) & 255u, rd >> 24);
+            if (op == 0) bump_range(range_counts, (rd >> 24) * 4, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_RV32_JAL_LUI_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+
+__global__ __launch_bounds__(256) void k_rv32_auipc(const uint32_t* __restrict__ pcs, const uint32_t* __restrict__ imms, size_t n, size_t N,
+                                                    uint32_t* __restrict__ trace, uint32_t* __restrict__ range_counts, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_RV32_AUIPC_WIDTH] = {};
+    if (r < n) {
+        const uint32_t pc = pcs[r], imm = imms[r];
+        if (pc >= P || (imm >> 20) != 0) {
+            atomicAdd(bad, 1u);
+        } else {
+            const uint32_t rd = pc + (imm << 12), im16 = imm << 4;
+            uint32_t pl[4], il[3], dl[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) pl[i] = (pc >> (8 * i)) & 255u, dl[i] = (rd >> (8 * i)) & 255u;
+#pragma unroll
+            for (int i = 0; i < 3; i++) il[i] = (im16 >> (8 * i)) & 255u;
+            col[0] = to_monty(pc), col[1] = to_monty(imm);
+#pragma unroll
+            for (int i = 0; i < 4; i++) col[2 + i] = to_monty(pl[i]), col[9 + i] = to_monty(dl[i]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) col[6 + i] = to_monty(il[i]);
+            col[13] = MONTY_ONE;
+            bump_range(range_counts, pl[0], pl[1]), bump_range(range_counts, pl[2], pl[3]), bump_range(range_counts, il[0], il[1]);
+            bump_range(range_counts, il[2], dl[1]), bump_range(range_counts, dl[2], dl[3]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_RV32_AUIPC_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+
+__global__ __launch_bounds__(256) void k_rv32_jalr(const uint32_t* __restrict__ pcs, const uint32_t* __restrict__ rs1s, const uint32_t* __restrict__ imms,
+                                                   size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ range_counts,
+                                                   uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_RV32_JALR_WIDTH] = {};
+    if (r < n) {
+        const uint32_t pc = pcs[r], rs1 = rs1s[r], imm = imms[r];
+        const uint32_t sign = (imm >> 11) & 1u, t = rs1 + (sign ? imm | 0xfffff000u : imm), rd = pc + 4, to_pc = t & ~1u;
+        if (pc >= (1u << 30) - 4 || (imm >> 12) != 0 || to_pc >= P) {
+            atomicAdd(bad, 1u);
+        } else {
+            col[0] = to_monty(pc), col[1] = to_monty(imm), col[2] = to_monty(imm & 255u), col[3] = to_monty(imm >> 8), col[4] = sign ? MONTY_ONE : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                col[5 + i] = to_monty((rs1 >> (8 * i)) & 255u);
+                col[9 + i] = to_monty((rd >> (8 * i)) & 255u);
+                col[13 + i] = to_monty((t >> (8 * i)) & 255u);
+            }
+            col[17] = (t & 1u) ? MONTY_ONE : 0u, col[18] = to_monty(to_pc), col[19] = MONTY_ONE;
+            bump_range(range_counts, imm & 255u, ((imm >> 8) - 8 * sign) * 32);
+            bump_range(range_counts, (t & 255u) >> 1, (t >> 8) & 255u);
+            bump_range(range_counts, (t >> 16) & 255u, t >> 24);
+            bump_range(range_counts, rd & 255u, (rd >> 8) & 255u);
+            bump_range(range_counts, (rd >> 16) & 255u, (rd >> 24) * 4);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_RV32_JALR_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+
+// shared launch frame of the three: flag, table to counts, the chip's kernel, table back to Montgomery form
+template <typename Launch>
+int jump_chip_tracegen(zkhip_ctx* ctx, const char* name, size_t n, unsigned log_height, uint32_t* d_bitwise_trace, Launch&& launch) {
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, name);
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
+    launch(dim3((unsigned)((N + 255) / 256)), N, (uint32_t*)flag);
+    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, name);
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_rv32_jal_lui_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, const uint32_t* d_pc, const uint32_t* d_imm, size_t n,
+                                           unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 27 || (n && (!d_opcode || !d_pc || !d_imm))) return ZKHIP_ERR_INVALID;
+    return jump_chip_tracegen(ctx, "rv32_jal_lui_tracegen", n, log_height, d_bitwise_trace, [&](dim3 grid, size_t N, uint32_t* flag) {
+        hipLaunchKernelGGL(k_rv32_jal_lui, grid, dim3(256), 0, ctx->stream, d_opcode, d_pc, d_imm, n, N, d_trace, d_bitwise_trace, flag);
+    });
+}
+
+extern "C" int zkhip_rv32_auipc_tracegen(zkhip_ctx* ctx, const uint32_t* d_pc, const uint32_t* d_imm, size_t n, unsigned log_height, uint32_t* d_trace,
+                                         uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 27 || (n && (!d_pc || !d_imm))) return ZKHIP_ERR_INVALID;
+    return jump_chip_tracegen(ctx, "rv32_auipc_tracegen", n, log_height, d_bitwise_trace, [&](dim3 grid, size_t N, uint32_t* flag) {
+        hipLaunchKernelGGL(k_rv32_auipc, grid, dim3(256), 0, ctx->stream, d_pc, d_imm, n, N, d_trace, d_bitwise_trace, flag);
+    });
+}
+
+extern "C" int zkhip_rv32_jalr_tracegen(zkhip_ctx* ctx, const uint32_t* d_pc, const uint32_t* d_rs1, const uint32_t* d_imm, size_t n,
+                                        unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 27 || (n && (!d_pc || !d_rs1 || !d_imm))) return ZKHIP_ERR_INVALID;
+    return jump_chip_tracegen(ctx, "rv32_jalr_tracegen", n, log_height, d_bitwise_trace, [&](dim3 grid, size_t N, uint32_t* flag) {
+        hipLaunchKernelGGL(k_rv32_jalr, grid, dim3(256), 0, ctx->stream, d_pc, d_rs1, d_imm, n, N, d_trace, d_bitwise_trace, flag);
+    });
+}
