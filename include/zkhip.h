@@ -202,6 +202,15 @@ int zkhip_rv32_auipc_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc, const uint32
 int zkhip_rv32_jalr_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc, const uint32_t *d_rs1, const uint32_t *d_imm, size_t n, unsigned log_height,
                              uint32_t *d_trace, uint32_t *d_bitwise_trace);
 
+/* RV32 high-multiplication core (rv32im MulHCoreAir<4, 8>: MULH / MULHSU / MULHU).  Record i = (d_opcode[i]: 0 = MULH, 1 = MULHSU,
+ * 2 = MULHU; operands d_b[i], d_c[i]).  Fills d_trace (ZKHIP_RV32_MULH_WIDTH = 21 columns, stride 2^log_height, Montgomery: a[4] = high
+ * word | b[4] | c[4] | a_mul[4] = low word | b_sign c_sign | 3 opcode flags; rows >= n zero), adds the eight (limb, carry) requests of
+ * every row to d_tuple_counts (the range-tuple table's trace, size_x >= 256, size_y >= 2048) and the sign requests to column 0 of
+ * d_bitwise_trace.  AIR: air.py rv32_mulh_core_air(). */
+#define ZKHIP_RV32_MULH_WIDTH 21
+int zkhip_rv32_mulh_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_b, const uint32_t *d_c, size_t n, unsigned log_height,
+                             uint32_t *d_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y, uint32_t *d_bitwise_trace);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

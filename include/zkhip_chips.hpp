@@ -696,6 +696,74 @@ inline void rv32_mul_core_air(AirBuilder& b, uint32_t bus = RANGE_TUPLE_BUS) {
     }
 }
 
+// air.rv32_mulh_core_air(tuple_bus, bitwise_bus): AirBuilder(21, 0)
+inline void rv32_mulh_core_air(AirBuilder& b, uint32_t tuple_bus = RANGE_TUPLE_BUS, uint32_t bitwise_bus = BITWISE_BUS) {
+    Expr a_[4], b_[4], c_[4], am[4];
+    for (int i = 0; i < 4; i++) a_[i] = b.var(i);
+    for (int i = 0; i < 4; i++) b_[i] = b.var(4 + i);
+    for (int i = 0; i < 4; i++) c_[i] = b.var(8 + i);
+    for (int i = 0; i < 4; i++) am[i] = b.var(12 + i);
+    const Expr bs = b.var(16), cs = b.var(17), mulh = b.var(18), mulhsu = b.var(19), mulhu = b.var(20);
+    const Expr ok0 = mulh + mulhsu;
+    const Expr ok = ok0 + mulhu;
+    for (const Expr& f : {mulh, mulhsu, mulhu, ok, bs, cs}) {
+        const Expr t = f - 1;
+        b.assert_zero(f * t);
+    }
+    b.assert_zero(mulhu * bs);
+    {
+        const Expr u = mulhu + mulhsu;
+        b.assert_zero(u * cs);
+    }
+    const Expr b_ext = bs * 255;
+    const Expr c_ext = cs * 255;
+    Expr carry;
+    for (int i = 0; i < 4; i++) {
+        Expr acc;
+        bool have = i > 0;
+        if (have) acc = carry;
+        for (int k = 0; k <= i; k++) {
+            const Expr m = b_[k] * c_[i - k];
+            acc = have ? m + acc : m + 0;
+            have = true;
+        }
+        const Expr d = acc - am[i];
+        carry = d * INV_256;
+        b.push_interaction(tuple_bus, {am[i], carry}, ok, Kind::Send);
+    }
+    for (int j = 0; j < 4; j++) {
+        Expr acc = carry;
+        for (int k = j + 1; k < 4; k++) {
+            const Expr m = b_[k] * c_[4 + j - k];
+            acc = m + acc;
+        }
+        for (int k = 0; k <= j; k++) {
+            const Expr m1 = b_[k] * c_ext;
+            const Expr m2 = c_[k] * b_ext;
+            const Expr m = m1 + m2;
+            acc = m + acc;
+        }
+        const Expr d = acc - a_[j];
+        carry = d * INV_256;
+        b.push_interaction(tuple_bus, {a_[j], carry}, ok, Kind::Send);
+    }
+    {
+        const Expr s = bs * 128;
+        const Expr d = b_[3] - s;
+        const Expr x = d * 2;
+        const Expr z0 = b.constant(0);
+        const Expr cnt = mulh + mulhsu;
+        b.push_interaction(bitwise_bus, {x, z0, z0, z0}, cnt, Kind::Send);
+    }
+    {
+        const Expr s = cs * 128;
+        const Expr d = c_[3] - s;
+        const Expr x = d * 2;
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bitwise_bus, {x, z0, z0, z0}, mulh, Kind::Send);
+    }
+}
+
 // air.memory_access_air(range_bus, memory_bus): AirBuilder(10, 0)
 inline void memory_access_air(AirBuilder& b, uint32_t range_bus = RANGE_BUS, uint32_t memory_bus = MEMORY_BUS) {
     Expr v[10];

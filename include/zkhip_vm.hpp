@@ -53,6 +53,7 @@ struct ExecRecords {
     std::vector<uint32_t> alu_op, alu_b, alu_c;       // 0 add 1 sub 2 xor 3 or 4 and (register and immediate forms)
     std::vector<uint32_t> lt_op, lt_b, lt_c;          // 0 slt 1 sltu
     std::vector<uint32_t> mul_b, mul_c;               // mul (low word)
+    std::vector<uint32_t> mulh_op, mulh_b, mulh_c;    // 0 mulh 1 mulhsu 2 mulhu
     std::vector<uint32_t> shift_op, shift_b, shift_c; // 0 sll 1 srl 2 sra; c = the shift operand (register value or shamt)
     std::vector<uint32_t> beq_op, beq_a, beq_b, beq_imm;  // 0 beq 1 bne; imm = the offset as a canonical BabyBear element
     std::vector<uint32_t> blt_op, blt_a, blt_b, blt_imm;  // 0 blt 1 bltu 2 bge 3 bgeu; imm as above
@@ -318,14 +319,15 @@ private:
                     const uint64_t ua = a, ub = b;
                     switch (f3) {
                         case 0: val = a * b; if (rec) rec->mul_b.push_back(a), rec->mul_c.push_back(b); break;
-                        case 1: val = (uint32_t)((uint64_t)(sa * sb) >> 32); if (rec) rec->n_mulh++; break;
-                        case 2: val = (uint32_t)((uint64_t)(sa * (int64_t)ub) >> 32); if (rec) rec->n_mulh++; break;
-                        case 3: val = (uint32_t)((ua * ub) >> 32); if (rec) rec->n_mulh++; break;
+                        case 1: val = (uint32_t)((uint64_t)(sa * sb) >> 32); break;
+                        case 2: val = (uint32_t)((uint64_t)(sa * (int64_t)ub) >> 32); break;
+                        case 3: val = (uint32_t)((ua * ub) >> 32); break;
                         case 4: val = b == 0 ? 0xffffffffu : (a == 0x80000000u && b == 0xffffffffu) ? a : (uint32_t)((int32_t)a / (int32_t)b); break;
                         case 5: val = b == 0 ? 0xffffffffu : a / b; break;
                         case 6: val = b == 0 ? a : (a == 0x80000000u && b == 0xffffffffu) ? 0 : (uint32_t)((int32_t)a % (int32_t)b); break;
                         default: val = b == 0 ? a : a % b; break;
                     }
+                    if (rec && f3 >= 1 && f3 <= 3) rec->n_mulh++, rec->mulh_op.push_back(f3 - 1), rec->mulh_b.push_back(a), rec->mulh_c.push_back(b);
                     if (f3 >= 4 && rec) rec->n_divrem++;
                 } else if (f7 == 0 || f7 == 0x20) {
                     switch (f3) {

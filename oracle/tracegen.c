@@ -464,3 +464,49 @@ size_t ora_rv32_jalr_trace(const uint32_t *pcs, const uint32_t *rs1s, const uint
     }
     return bad;
 }
+
+/* RV32 high-multiplication core (zkhip_rv32_mulh_tracegen): 21 columns a[4] | b[4] | c[4] | a_mul[4] | b_sign c_sign | is_mulh is_mulhsu
+ * is_mulhu, canonical; record = (opcode 0 = MULH, 1 = MULHSU, 2 = MULHU; operands).  a and a_mul are the halves of the 64-bit
+ * product from INTEGER arithmetic; the carries sent to the tuple table come from the limb sums the AIR states, and the function
+ * returns the number of records (there must be none) where the two disagree or a carry leaves the table. */
+size_t ora_rv32_mulh_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace,
+                           uint32_t *tuple_counts, uint32_t size_y, uint32_t *range_counts) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 21; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t op = opc[r], bv = bs[r], cv = cs[r];
+        if (op > 2) {
+            bad++;
+            continue;
+        }
+        const uint32_t b_sign = op != 2 ? bv >> 31 : 0, c_sign = op == 0 ? cv >> 31 : 0;
+        const int64_t sb = b_sign ? (int64_t)(int32_t)bv : (int64_t)bv, sc = c_sign ? (int64_t)(int32_t)cv : (int64_t)cv;
+        const uint64_t prod = (uint64_t)(sb * sc);   /* |sb|, |sc| < 2^32 and not both 2^32 - 1 signed: fits */
+        uint32_t l[8], m[8];
+        for (int i = 0; i < 4; i++) l[i] = (bv >> (8 * i)) & 255u, m[i] = (cv >> (8 * i)) & 255u;
+        for (int i = 4; i < 8; i++) l[i] = b_sign * 255u, m[i] = c_sign * 255u;
+        uint32_t carry = 0;
+        int ok = 1;
+        for (int i = 0; i < 8; i++) {
+            uint32_t acc = carry;
+            for (int k = 0; k <= i; k++) acc += l[k] * m[i - k];
+            const uint32_t limb = acc & 255u;
+            carry = acc >> 8;
+            if (limb != ((prod >> (8 * i)) & 255u) || carry >= size_y) ok = 0;
+            trace[(size_t)(i < 4 ? 12 + i : i - 4) * N + r] = limb;
+            if (carry < size_y) {
+                uint32_t *t = &tuple_counts[(size_t)limb * size_y + carry];
+                *t = ora_add(*t, 1);
+            }
+        }
+        if (!ok) bad++;
+        for (int i = 0; i < 4; i++) trace[(size_t)(4 + i) * N + r] = l[i], trace[(size_t)(8 + i) * N + r] = m[i];
+        trace[(size_t)16 * N + r] = b_sign, trace[(size_t)17 * N + r] = c_sign;
+        trace[(size_t)(18 + op) * N + r] = 1;
+        if (op != 2) ora_bump(range_counts, 2 * (l[3] - 128 * b_sign), 0);
+        if (op == 0) ora_bump(range_counts, 2 * (m[3] - 128 * c_sign), 0);
+    }
+    return bad;
+}

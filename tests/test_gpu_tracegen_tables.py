@@ -550,3 +550,58 @@ def test_rv32_jalr_chip(zk, ora):
             zk.rv32_jalr_tracegen(one(p_), one(r_), one(i_), 0, torch.zeros(2 << 16, dtype=torch.int32, device=zk.device))
         assert ora.rv32_jalr_trace([p_], [r_], [i_], 0)[2] == 1
     _prove_chip_with_bitwise_table(zk, ora, prog, 20, lh, exp, d_tr, d_bw, rc)
+
+
+def test_rv32_mulh_chip(zk, ora):
+    """RV32 high-multiplication core (OpenVM MulHCoreAir<4, 8>: MULH / MULHSU / MULHU) from records on the device, its eight
+    (limb, carry) requests counted into the range-tuple table and its sign requests into the bitwise table in the same pass:
+    cells == oracle (whose result limbs come from the 64-bit integer product), high word == the integers' product for every
+    signedness incl. the extreme operands; chip + both tables prove from the device-resident traces (bytes == oracle); a wrong
+    result limb leaves the tuple bus unbalanced and the verifier refuses."""
+    rng = np.random.default_rng(43)
+    n, lh = 4000, 12
+    opc = rng.integers(0, 3, n).astype(np.uint32)
+    b = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    c = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    ext = np.array([0xFFFFFFFF, 0x80000000, 0x7FFFFFFF, 0, 1], np.uint32)
+    k = 0
+    for o in range(3):
+        for x in ext:
+            for y in ext:
+                opc[k], b[k], c[k] = o, x, y
+                k += 1
+    sx, sy = 256, 2048
+    exp, tc, rc, bad = ora.rv32_mulh_trace(opc, b, c, lh, sx, sy)
+    assert bad == 0 and int(tc.astype(np.int64).sum()) == 8 * n and int(rc.astype(np.int64).sum()) == int((opc != 2).sum() + (opc == 0).sum())
+    sb = np.where(opc != 2, b.view(np.int32).astype(object), b.astype(object))
+    sc = np.where(opc == 0, c.view(np.int32).astype(object), c.astype(object))
+    want = np.array([((int(x) * int(y)) >> 32) & 0xFFFFFFFF for x, y in zip(sb, sc)], dtype=np.uint64)
+    assert (sum(exp[i][:n].astype(np.uint64) << (8 * i) for i in range(4)) == want).all()
+    prog = air.rv32_mulh_core_air().program()
+    assert air.check_trace(prog, exp, NOPV) == []
+    dev = zk.device
+    as_dev = lambda v: torch.from_numpy(np.ascontiguousarray(v).view(np.int32)).to(dev)  # noqa: E731
+    d_tab = torch.zeros(sx * sy, dtype=torch.int32, device=dev)
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=dev)
+    d_tr = zk.rv32_mulh_tracegen(as_dev(opc), as_dev(b), as_dev(c), lh, d_tab, d_bw, sx, sy)
+    assert (zk.download(d_tr).reshape(21, -1) == exp).all()
+    assert (zk.download(d_tab) == tc).all()
+    bw = zk.download(d_bw).reshape(2, -1)
+    assert (bw[0] == rc).all() and (bw[1] == 0).all()
+    with pytest.raises(z.ZkhipError):
+        zk.rv32_mulh_tracegen(as_dev(np.array([3], np.uint32)), as_dev(b[:1]), as_dev(c[:1]), 0, d_tab.clone(), d_bw.clone(), sx, sy)
+    with pytest.raises(z.ZkhipError):   # a table that cannot hold the carries
+        zk.rv32_mulh_tracegen(as_dev(opc), as_dev(b), as_dev(c), lh, d_tab.clone(), d_bw.clone(), 256, 1024)
+    airs = [dict(program=prog, log_height=lh, width=21, n_pvs=0, trace=exp, pvs=NOPV),
+            dict(program=air.range_tuple_table_air(sx, sy).program(), log_height=19, width=1, n_pvs=0, trace=tc.reshape(1, -1), pvs=NOPV,
+                 prep=air.range_tuple_prep(sx, sy)),
+            dict(program=air.bitwise_lookup_air(8).program(), log_height=16, width=2, n_pvs=0, trace=bw, pvs=NOPV, prep=air.bitwise_lookup_prep(8))]
+    params = (1, 0, 6, 2, 2)
+    pk = z.ProvingKey(zk, params, airs)
+    proof = pk.prove([d_tr, d_tab, d_bw], [NOPV] * 3)
+    assert z.verify(params, pk.verifying_airs(), [NOPV] * 3, proof) == 0
+    assert proof == ora.stark_prove(params, airs).tobytes()
+    wrong = exp.copy()
+    wrong[0][7] = (int(wrong[0][7]) + 1) % 256
+    assert z.verify(params, pk.verifying_airs(), [NOPV] * 3, pk.prove([zk.upload(wrong.reshape(-1)), d_tab, d_bw], [NOPV] * 3)) != 0
+    pk.close()

@@ -101,6 +101,7 @@ def load_library():
         "zkhip_rv32_shift_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_branch_eq_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_rv32_branch_lt_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_rv32_mulh_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp]),
         "zkhip_rv32_jal_lui_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_auipc_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_jalr_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
@@ -376,6 +377,17 @@ class Context:
         out = torch.empty(13 << log_height, dtype=torch.int32, device=self.device)
         self._check(self.lib.zkhip_rv32_mul_tracegen(self.h, C.c_void_p(t_b.data_ptr()), C.c_void_p(t_c.data_ptr()), t_b.numel(), log_height,
                                                      C.c_void_p(out.data_ptr()), C.c_void_p(t_tuple_counts.data_ptr()), size_x, size_y))
+        return out
+
+    def rv32_mulh_tracegen(self, t_opcode, t_b, t_c, log_height, t_tuple_counts, t_bitwise_trace, size_x=256, size_y=2048):
+        """21-column trace of the RV32 high-multiplication core chip from records (int32 tensors: opcode 0 = MULH, 1 = MULHSU,
+        2 = MULHU; operands); the (limb, carry) requests go to t_tuple_counts, the sign requests to column 0 of t_bitwise_trace."""
+        import torch
+
+        out = torch.empty(21 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_rv32_mulh_tracegen(self.h, C.c_void_p(t_opcode.data_ptr()), C.c_void_p(t_b.data_ptr()), C.c_void_p(t_c.data_ptr()),
+                                                      t_opcode.numel(), log_height, C.c_void_p(out.data_ptr()), C.c_void_p(t_tuple_counts.data_ptr()),
+                                                      size_x, size_y, C.c_void_p(t_bitwise_trace.data_ptr())))
         return out
 
     def memory_access_tracegen(self, t_as, t_ptr, t_prev_data, t_prev_ts, t_data, t_ts, t_is_read, log_height):

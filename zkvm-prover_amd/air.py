@@ -955,6 +955,47 @@ def rv32_mul_core_air(bus=6):
     return b
 
 
+RV32_MULH_WIDTH = 21
+
+
+def rv32_mulh_core_air(tuple_bus=6, bitwise_bus=9):
+    """The core of OpenVM's RV32 high-multiplication chip (rv32im `MulHCoreAir<4, 8>`: MULH / MULHSU / MULHU): columns a[4] | b[4] |
+    c[4] | a_mul[4] | b_sign c_sign | is_mulh is_mulhsu is_mulhu.  The operands are extended to eight limbs by their sign limbs
+    (255 sign) and multiplied schoolbook-wise: limbs 0..3 of the product are a_mul, limbs 4..7 the result a; all eight carries are
+    expressions, and the row sends (limb, carry) to the range-tuple checker (carry < 2048) as the multiplication chip does.  Signs:
+    MULHU has none, MULHSU only b's; 2 (x_3 - 128 sign) in byte range ties a sign to its operand's top limb (bitwise lookup)."""
+    b = AirBuilder(RV32_MULH_WIDTH, 0)
+    a_, b_, c_ = [b.var(i) for i in range(4)], [b.var(4 + i) for i in range(4)], [b.var(8 + i) for i in range(4)]
+    am = [b.var(12 + i) for i in range(4)]
+    bs, cs = b.var(16), b.var(17)
+    mulh, mulhsu, mulhu = b.var(18), b.var(19), b.var(20)
+    ok = mulh + mulhsu + mulhu
+    for f in (mulh, mulhsu, mulhu, ok, bs, cs):
+        b.assert_zero(f * (f - 1))
+    b.assert_zero(mulhu * bs)
+    b.assert_zero((mulhu + mulhsu) * cs)
+    b_ext, c_ext = bs * 255, cs * 255
+    inv256 = pow(256, -1, P)
+    carry = None
+    for i in range(4):
+        acc = carry if carry is not None else 0
+        for k in range(i + 1):
+            acc = b_[k] * c_[i - k] + acc
+        carry = (acc - am[i]) * inv256
+        b.push_interaction(tuple_bus, [am[i], carry], ok, "send")
+    for j in range(4):
+        acc = carry
+        for k in range(j + 1, 4):
+            acc = b_[k] * c_[4 + j - k] + acc
+        for k in range(j + 1):
+            acc = b_[k] * c_ext + c_[k] * b_ext + acc
+        carry = (acc - a_[j]) * inv256
+        b.push_interaction(tuple_bus, [a_[j], carry], ok, "send")
+    b.push_interaction(bitwise_bus, [(b_[3] - bs * 128) * 2, 0, 0, 0], mulh + mulhsu, "send")
+    b.push_interaction(bitwise_bus, [(c_[3] - cs * 128) * 2, 0, 0, 0], mulh, "send")
+    return b
+
+
 MEMORY_ACCESS_WIDTH = 10
 
 

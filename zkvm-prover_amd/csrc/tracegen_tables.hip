@@ -276,6 +276,8 @@ __global__ __launch_bounds__(256) void k_rv32_mul(const uint32_t* __restrict__ b
         uint32_t bl[4], cl[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) bl[i] = (b >> (8 * i)) & 255u, cl[i] = (c >> (8 * i)) & 255u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) asm volatile("" : "+v"(bl[i]), "+v"(cl[i]));   // no v_dot4_u32_u8 rewrite: see k_rv32_mulh
         // schoolbook columns of the low word: sums stay below 4 * 255^2 + 1024 < 2^19
         const uint32_t s[4] = {bl[0] * cl[0], bl[0] * cl[1] + bl[1] * cl[0], bl[0] * cl[2] + bl[1] * cl[1] + bl[2] * cl[0],
                                bl[0] * cl[3] + bl[1] * cl[2] + bl[2] * cl[1] + bl[3] * cl[0]};
@@ -833,4 +835,79 @@ extern "C" int zkhip_rv32_jalr_tracegen(zkhip_ctx* ctx, const uint32_t* d_pc, co
     return jump_chip_tracegen(ctx, "rv32_jalr_tracegen", n, log_height, d_bitwise_trace, [&](dim3 grid, size_t N, uint32_t* flag) {
         hipLaunchKernelGGL(k_rv32_jalr, grid, dim3(256), 0, ctx->stream, d_pc, d_rs1, d_imm, n, N, d_trace, d_bitwise_trace, flag);
     });
+}
+
+// ---- RV32 high-multiplication core (OpenVM rv32im MulHCoreAir<4, 8>: MULH / MULHSU / MULHU) ------------------------------------------
+// Record = (opcode 0 = MULH, 1 = MULHSU, 2 = MULHU; operands).  Row (ZKHIP_RV32_MULH_WIDTH = 21): a[4] | b[4] | c[4] | a_mul[4] | b_sign c_sign |
+// 3 opcode flags.  The operands are extended by their sign limbs and multiplied limb by limb as the AIR states it; the eight
+// (limb, carry) pairs go to the range-tuple table, the two sign requests to the bitwise table's range column.
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_rv32_mulh(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ bs, const uint32_t* __restrict__ cs,
+                                                   size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ tuple_counts, uint32_t size_y,
+                                                   uint32_t* __restrict__ range_counts, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_RV32_MULH_WIDTH] = {};
+    if (r < n) {
+        const uint32_t op = opc[r], b = bs[r], c = cs[r];
+        if (op > 2) {
+            atomicAdd(bad, 1u);
+        } else {
+            const uint32_t b_sign = op != 2 ? b >> 31 : 0u, c_sign = op == 0 ? c >> 31 : 0u;
+            uint32_t l[8], m[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) l[i] = (b >> (8 * i)) & 255u, m[i] = (c >> (8 * i)) & 255u;
+#pragma unroll
+            for (int i = 4; i < 8; i++) l[i] = b_sign * 255u, m[i] = c_sign * 255u;
+            // The limbs are made opaque to the optimiser: knowing them to be bytes, LLVM (ROCm 7.2) rewrites the column sums into
+            // v_perm_b32 + v_dot4_u32_u8 and gets product limbs 1 and 2 wrong on gfx950 (found by the oracle parity test).
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("" : "+v"(l[i]), "+v"(m[i]));
+            uint32_t carry = 0;   // sums stay below 8 * 255^2 + 2048 < 2^20
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                uint32_t acc = carry;
+#pragma unroll
+                for (int k = 0; k <= i; k++) acc += l[k] * m[i - k];
+                const uint32_t limb = acc & 255u;
+                carry = acc >> 8;   // < 2048
+                col[i < 4 ? 12 + i : i - 4] = to_monty(limb);
+                atomicAdd(&tuple_counts[(size_t)limb * size_y + carry], 1u);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) col[4 + i] = to_monty(l[i]), col[8 + i] = to_monty(m[i]);
+            col[16] = b_sign ? MONTY_ONE : 0u, col[17] = c_sign ? MONTY_ONE : 0u;
+            col[18 + op] = MONTY_ONE;
+            if (op != 2) bump_range(range_counts, 2 * (l[3] - 128 * b_sign), 0);
+            if (op == 0) bump_range(range_counts, 2 * (m[3] - 128 * c_sign), 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_RV32_MULH_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_rv32_mulh_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, const uint32_t* d_b, const uint32_t* d_c, size_t n, unsigned log_height,
+                                        uint32_t* d_trace, uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_tuple_counts || !d_bitwise_trace || log_height > 27 || (n && (!d_opcode || !d_b || !d_c))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height, T = (size_t)size_x * size_y;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_mulh_tracegen: more records than rows");
+    if (size_x < 256 || size_y < 2048 || T > ((size_t)1 << 27))
+        return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_mulh_tracegen: the tuple table must cover (limb < 256, carry < 2048)");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "rv32_mulh_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const unsigned tb = (unsigned)((T + 255) / 256);
+    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
+    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
+    hipLaunchKernelGGL(k_rv32_mulh, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_tuple_counts, size_y,
+                       d_bitwise_trace, (uint32_t*)flag);
+    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
+    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "rv32_mulh_tracegen (opcode > 2)");
 }
