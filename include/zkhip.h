@@ -211,6 +211,16 @@ int zkhip_rv32_jalr_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc, const uint32_
 int zkhip_rv32_mulh_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_b, const uint32_t *d_c, size_t n, unsigned log_height,
                              uint32_t *d_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y, uint32_t *d_bitwise_trace);
 
+/* RV32 load/store cores (rv32im LoadStoreCoreAir<4> and LoadSignExtendCoreAir<4, 8> in one chip).  Record i = (d_case[i] in 0..19:
+ * LW, LHU@0 LHU@2, LBU@0..3, SW, SH@0 SH@2, SB@0..3, LH@0 LH@2, LB@0..3 -- @k = byte offset inside the aligned word; d_read[i]: the
+ * aligned memory word for loads, the source register for stores; d_prev[i]: what the destination (register / aligned word) held).
+ * Fills d_trace (ZKHIP_RV32_LOADSTORE_WIDTH = 33 columns, stride 2^log_height, Montgomery: read[4] | prev[4] | write[4] | case flag[20] |
+ * sign; rows >= n zero) and adds the sign request of LH / LB rows to column 0 of d_bitwise_trace.  AIR: air.py
+ * rv32_loadstore_core_air(). */
+#define ZKHIP_RV32_LOADSTORE_WIDTH 33
+int zkhip_rv32_loadstore_tracegen(zkhip_ctx *ctx, const uint32_t *d_case, const uint32_t *d_read, const uint32_t *d_prev, size_t n,
+                                  unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

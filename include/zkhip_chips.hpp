@@ -764,6 +764,75 @@ inline void rv32_mulh_core_air(AirBuilder& b, uint32_t tuple_bus = RANGE_TUPLE_B
     }
 }
 
+// air.rv32_loadstore_core_air(bus): AirBuilder(33, 0); cases in the order of air.RV32_LOADSTORE_CASES
+inline void rv32_loadstore_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
+    enum Kind_ { LW, LHU, LBU, SW, SH, SB, LH, LB };
+    static const struct { Kind_ kind; int s; } CASES[20] = {{LW, 0}, {LHU, 0}, {LHU, 2}, {LBU, 0}, {LBU, 1}, {LBU, 2}, {LBU, 3}, {SW, 0}, {SH, 0}, {SH, 2},
+                                                           {SB, 0}, {SB, 1}, {SB, 2}, {SB, 3}, {LH, 0}, {LH, 2}, {LB, 0}, {LB, 1}, {LB, 2}, {LB, 3}};
+    Expr rd[4], pv[4], wr[4], fl[20];
+    for (int i = 0; i < 4; i++) rd[i] = b.var(i);
+    for (int i = 0; i < 4; i++) pv[i] = b.var(4 + i);
+    for (int i = 0; i < 4; i++) wr[i] = b.var(8 + i);
+    for (int i = 0; i < 20; i++) fl[i] = b.var(12 + i);
+    const Expr sign = b.var(32);
+    Expr ok = fl[0];
+    for (int i = 1; i < 20; i++) ok = ok + fl[i];
+    for (int i = 0; i < 22; i++) {
+        const Expr f = i < 20 ? fl[i] : i == 20 ? ok : sign;
+        const Expr t = f - 1;
+        b.assert_zero(f * t);
+    }
+    Expr sgn = fl[14];
+    for (int i = 15; i < 20; i++) sgn = sgn + fl[i];
+    {
+        const Expr ns = 1 - sgn;
+        b.assert_zero(sign * ns);
+    }
+    const Expr ext = sign * 255;
+    for (int i = 0; i < 4; i++) {
+        Expr acc;
+        bool have = false;
+        for (int c = 0; c < 20; c++) {
+            const Kind_ kind = CASES[c].kind;
+            const int s = CASES[c].s;
+            Expr t;
+            bool term = true;
+            switch (kind) {
+                case LW: case SW: t = rd[i]; break;
+                case LHU: case LH:
+                    if (i < 2) t = rd[s + i];
+                    else if (kind == LH) t = ext;
+                    else term = false;
+                    break;
+                case LBU: case LB:
+                    if (i == 0) t = rd[s];
+                    else if (kind == LB) t = ext;
+                    else term = false;
+                    break;
+                case SH: t = (s <= i && i < s + 2) ? rd[i - s] : pv[i]; break;
+                default: t = i == s ? rd[0] : pv[i]; break;
+            }
+            if (!term) continue;
+            const Expr m = fl[c] * t;
+            acc = have ? acc + m : m;
+            have = true;
+        }
+        b.assert_zero(wr[i] - acc);
+    }
+    Expr top;
+    for (int c = 14; c < 20; c++) {
+        const Expr t = fl[c] * rd[CASES[c].kind == LH ? CASES[c].s + 1 : CASES[c].s];
+        top = c == 14 ? t : top + t;
+    }
+    {
+        const Expr s128 = sign * 128;
+        const Expr d = top - s128;
+        const Expr x = d * 2;
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bus, {x, z0, z0, z0}, sgn, Kind::Send);
+    }
+}
+
 // air.memory_access_air(range_bus, memory_bus): AirBuilder(10, 0)
 inline void memory_access_air(AirBuilder& b, uint32_t range_bus = RANGE_BUS, uint32_t memory_bus = MEMORY_BUS) {
     Expr v[10];

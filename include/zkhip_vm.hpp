@@ -60,6 +60,10 @@ struct ExecRecords {
     std::vector<uint32_t> jal_op, jal_pc, jal_imm;        // 0 jal (imm = the offset as a field element) 1 lui (imm = the 20-bit immediate)
     std::vector<uint32_t> auipc_pc, auipc_imm;            // imm = the 20-bit immediate
     std::vector<uint32_t> jalr_pc, jalr_rs1, jalr_imm;    // imm = the raw 12-bit immediate
+    // loads and stores: case 0..19 (LW, LHU@0 LHU@2, LBU@0..3, SW, SH@0 SH@2, SB@0..3, LH@0 LH@2, LB@0..3; @k = byte offset inside the
+    // word, words aligned from data_base), read = the aligned memory word (loads) / the stored register (stores), prev = what the
+    // destination register (loads) / the aligned memory word (stores) held before
+    std::vector<uint32_t> ls_case, ls_read, ls_prev;
     uint64_t n_shift = 0, n_branch = 0, n_jump = 0, n_load_store = 0, n_mulh = 0, n_divrem = 0, n_lui_auipc = 0, n_ecall = 0;
     // Memory log for the offline memory-checking argument (OpenVM's memory bus): state is kept in 16-bit CELLS -- address space
     // 1 = registers (cell 2 i + half of x_i), 2 = read-write memory (cell = halfword index from data_base) -- so that a cell's
@@ -180,6 +184,12 @@ private:
         if (addr < exe_.data_base || off + n > mem_.size()) throw Error("memory access out of range at pc " + std::to_string(pc_));
         return mem_.data() + off;
     }
+    uint32_t word_around(uint32_t addr) const {   // the aligned word (from data_base) holding addr, zero beyond the end of memory
+        const size_t wo = ((size_t)addr - exe_.data_base) & ~(size_t)3;
+        uint32_t v = 0;
+        if (wo < mem_.size()) memcpy(&v, mem_.data() + wo, std::min<size_t>(4, mem_.size() - wo));
+        return v;
+    }
     uint16_t cell_value(uint32_t cidx) const {
         uint16_t v;
         memcpy(&v, mem_.data() + 2 * (size_t)cidx, 2);
@@ -287,14 +297,23 @@ private:
                     default: throw Error("illegal load");
                 }
                 wr = true;
-                if (rec) rec->n_load_store++;
+                if (rec) {
+                    const uint32_t off = (addr - exe_.data_base) & 3u;
+                    const uint32_t cs = f3 == 2 ? 0 : f3 == 5 ? 1 + off / 2 : f3 == 4 ? 3 + off : f3 == 1 ? 14 + off / 2 : 16 + off;
+                    rec->n_load_store++, rec->ls_case.push_back(cs), rec->ls_read.push_back(word_around(addr)), rec->ls_prev.push_back(x_[rd]);
+                }
                 break;
             }
             case 0x23: {
                 const uint32_t addr = a + (uint32_t)imm_s;
                 if (f3 > 2) throw Error("illegal store");
+                if (rec) {
+                    at(addr, 1u << f3);   // range check before the word is read
+                    const uint32_t off = (addr - exe_.data_base) & 3u;
+                    rec->n_load_store++, rec->ls_case.push_back(f3 == 2 ? 7 : f3 == 1 ? 8 + off / 2 : 10 + off);
+                    rec->ls_read.push_back(b), rec->ls_prev.push_back(word_around(addr));
+                }
                 store(rec, addr, b, 1u << f3);
-                if (rec) rec->n_load_store++;
                 break;
             }
             case 0x13: {

@@ -4,8 +4,8 @@
 //   2. records -> device buffers -> the device trace generators   (include/zkhip.h: zkhip_*_tracegen; no trace ever exists on the host)
 //   3. zkhip_keygen over the chips' AIRs (include/zkhip_chips.hpp), zkhip_prove, zkhip_verify
 // The AIR set (order fixed, it is part of the verifying key): program (cached program + execution frequencies), execution
-// frames, RV32 base ALU / less-than / multiplication / high multiplication / shift / branch-equal / branch-less-than / JAL-LUI / AUIPC / JALR cores, 8-bit bitwise lookup, range-tuple checker, memory access rows, memory
-// boundary, 16-bit range checker.  What these seventeen AIRs prove together is stated in DESIGN.md 8: every bus balances (program,
+// frames, RV32 base ALU / less-than / multiplication / high multiplication / shift / branch-equal / branch-less-than / JAL-LUI / AUIPC / JALR / load-store cores, 8-bit bitwise lookup, range-tuple checker, memory access rows, memory
+// boundary, 16-bit range checker.  What these eighteen AIRs prove together is stated in DESIGN.md 8: every bus balances (program,
 // memory, lookups) -- the chips are not yet tied to each other by an execution bus.
 #pragma once
 #include <chrono>
@@ -26,7 +26,7 @@
 namespace zkhip_vm {
 
 constexpr uint32_t TUPLE_SIZE_X = 256, TUPLE_SIZE_Y = 2048;  // covers (limb < 256, carry < 1024): a 2^19-row table
-constexpr unsigned N_VM_AIRS = 17;
+constexpr unsigned N_VM_AIRS = 18;
 
 struct GuestProof {
     ExecutionResult exec;
@@ -95,10 +95,11 @@ public:
         const unsigned lacc = log2_ceil_min1(rec.acc_ts.size()), lbnd = log2_ceil_min1(rec.bnd_ptr.size());
         const unsigned lsh = log2_ceil_min1(rec.shift_op.size()), lmh = log2_ceil_min1(rec.mulh_op.size());
         const unsigned lbe = log2_ceil_min1(rec.beq_op.size()), lbl = log2_ceil_min1(rec.blt_op.size());
+        const unsigned lls = log2_ceil_min1(rec.ls_case.size());
         const unsigned ljl = log2_ceil_min1(rec.jal_op.size()), lau = log2_ceil_min1(rec.auipc_pc.size()), ljr = log2_ceil_min1(rec.jalr_pc.size());
         unsigned ltup = 0;
         while ((1u << ltup) < TUPLE_SIZE_X * TUPLE_SIZE_Y) ltup++;
-        gp.log_heights = {lp, lf, la, ll, lm, lmh, lsh, lbe, lbl, ljl, lau, ljr, 16, ltup, lacc, lbnd, 16};
+        gp.log_heights = {lp, lf, la, ll, lm, lmh, lsh, lbe, lbl, ljl, lau, ljr, lls, 16, ltup, lacc, lbnd, 16};
         const std::vector<uint32_t> prog = program_table(exe.program, lp);
         const size_t NP = (size_t)1 << lp;
         uint32_t* d_program_trace = dmalloc(10 * NP);  // [9 cached columns | frequency]
@@ -125,6 +126,8 @@ public:
         check(zkhip_rv32_auipc_tracegen(ctx_, up(rec.auipc_pc), up(rec.auipc_imm), rec.auipc_pc.size(), lau, d_auipc, d_bw));
         uint32_t* d_jalr = dmalloc((size_t)ZKHIP_RV32_JALR_WIDTH << ljr);
         check(zkhip_rv32_jalr_tracegen(ctx_, up(rec.jalr_pc), up(rec.jalr_rs1), up(rec.jalr_imm), rec.jalr_pc.size(), ljr, d_jalr, d_bw));
+        uint32_t* d_ls = dmalloc((size_t)ZKHIP_RV32_LOADSTORE_WIDTH << lls);
+        check(zkhip_rv32_loadstore_tracegen(ctx_, up(rec.ls_case), up(rec.ls_read), up(rec.ls_prev), rec.ls_case.size(), lls, d_ls, d_bw));
         uint32_t* d_tup = dzeros((size_t)1 << ltup);
         uint32_t* d_mul = dmalloc((size_t)ZKHIP_RV32_MUL_WIDTH << lm);
         check(zkhip_rv32_mul_tracegen(ctx_, up(rec.mul_b), up(rec.mul_c), rec.mul_b.size(), lm, d_mul, d_tup, TUPLE_SIZE_X, TUPLE_SIZE_Y));
@@ -154,8 +157,8 @@ public:
         // ---- 3. the AIR set and its preprocessed tables
         namespace ch = zkhip::chips;
         using zkhip::air::AirBuilder;
-        const size_t widths[N_VM_AIRS] = {10, 10, 18, 18, 13, 21, 32, 17, 23, 9, 14, 20, 2, 1, 10, 8, 1};
-        const size_t prep_w[N_VM_AIRS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 2, 0, 0, 1};
+        const size_t widths[N_VM_AIRS] = {10, 10, 18, 18, 13, 21, 32, 17, 23, 9, 14, 20, 33, 2, 1, 10, 8, 1};
+        const size_t prep_w[N_VM_AIRS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 2, 0, 0, 1};
         gp.programs.resize(N_VM_AIRS);
         for (unsigned a = 0; a < N_VM_AIRS; a++) {
             AirBuilder b(widths[a], 0, prep_w[a]);
@@ -172,10 +175,11 @@ public:
                 case 9: ch::rv32_jal_lui_core_air(b); break;
                 case 10: ch::rv32_auipc_core_air(b); break;
                 case 11: ch::rv32_jalr_core_air(b); break;
-                case 12: ch::bitwise_lookup_air(b); break;
-                case 13: ch::range_tuple_table_air(b); break;
-                case 14: ch::memory_access_air(b); break;
-                case 15: ch::memory_boundary_air(b); break;
+                case 12: ch::rv32_loadstore_core_air(b); break;
+                case 13: ch::bitwise_lookup_air(b); break;
+                case 14: ch::range_tuple_table_air(b); break;
+                case 15: ch::memory_access_air(b); break;
+                case 16: ch::memory_boundary_air(b); break;
                 default: ch::range_table_air(b); break;
             }
             gp.programs[a] = b.program();
@@ -184,7 +188,7 @@ public:
         for (uint32_t i = 0; i < (1u << 16); i++) prep_bw[i] = i >> 8, prep_bw[(1u << 16) + i] = i & 255u, prep_bw[(2u << 16) + i] = (i >> 8) ^ (i & 255u);
         for (uint32_t i = 0; i < (1u << ltup); i++) prep_tup[i] = i / TUPLE_SIZE_Y, prep_tup[((size_t)1 << ltup) + i] = i % TUPLE_SIZE_Y;
         std::iota(prep_rng.begin(), prep_rng.end(), 0u);
-        const uint32_t* preps[N_VM_AIRS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, prep_bw.data(), prep_tup.data(), nullptr, nullptr, prep_rng.data()};
+        const uint32_t* preps[N_VM_AIRS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, prep_bw.data(), prep_tup.data(), nullptr, nullptr, prep_rng.data()};
         std::vector<zkhip_air> airs(N_VM_AIRS);
         for (unsigned a = 0; a < N_VM_AIRS; a++)
             airs[a] = zkhip_air{gp.programs[a].data(), gp.programs[a].size(), gp.log_heights[a], widths[a], 0, preps[a], nullptr};
@@ -205,7 +209,7 @@ public:
         gp.has_prep.assign(N_VM_AIRS, 0);
         for (unsigned a = 0; a < N_VM_AIRS; a++) gp.has_prep[a] = preps[a] ? 1 : 0;
         // ---- 4. prove from the device-resident traces, then the mandatory self-check (mod.rs:407-411)
-        const uint32_t* d_traces[N_VM_AIRS] = {d_program_trace, d_frames, d_alu, d_lt, d_mul, d_mulh, d_shift, d_beq, d_blt, d_jal, d_auipc, d_jalr, d_bw, d_tup, d_acc, d_bnd, d_rng};
+        const uint32_t* d_traces[N_VM_AIRS] = {d_program_trace, d_frames, d_alu, d_lt, d_mul, d_mulh, d_shift, d_beq, d_blt, d_jal, d_auipc, d_jalr, d_ls, d_bw, d_tup, d_acc, d_bnd, d_rng};
         const uint32_t* pvs[N_VM_AIRS] = {};
         gp.proof.resize(zkhip_proof_size(pk));
         size_t len = 0;
@@ -221,7 +225,7 @@ public:
 
     // host only: what a verifier needs is the programs, heights and preprocessed commitments of the proof
     static int verify(const zkhip_params& params, const GuestProof& gp) {
-        const size_t widths[N_VM_AIRS] = {10, 10, 18, 18, 13, 21, 32, 17, 23, 9, 14, 20, 2, 1, 10, 8, 1};
+        const size_t widths[N_VM_AIRS] = {10, 10, 18, 18, 13, 21, 32, 17, 23, 9, 14, 20, 33, 2, 1, 10, 8, 1};
         std::vector<zkhip_air> airs(N_VM_AIRS);
         for (unsigned a = 0; a < N_VM_AIRS; a++)
             airs[a] = zkhip_air{gp.programs[a].data(), gp.programs[a].size(), gp.log_heights[a], widths[a], 0, nullptr,

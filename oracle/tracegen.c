@@ -510,3 +510,45 @@ size_t ora_rv32_mulh_trace(const uint32_t *opc, const uint32_t *bs, const uint32
     }
     return bad;
 }
+
+/* RV32 load/store cores (zkhip_rv32_loadstore_tracegen): 33 columns read[4] | prev[4] | write[4] | case flag[20] | sign, canonical.
+ * Record = (case 0..19 in the order LW, LHU@0 LHU@2, LBU@0..3, SW, SH@0 SH@2, SB@0..3, LH@0 LH@2, LB@0..3; read word; prev word).
+ * write comes from integer shifts and masks of the words (loads extract and extend, stores merge into prev). */
+size_t ora_rv32_loadstore_trace(const uint32_t *cases, const uint32_t *reads, const uint32_t *prevs, size_t n, unsigned log_height, uint32_t *trace,
+                                uint32_t *range_counts) {
+    static const uint8_t SHIFT[20] = {0, 0, 2, 0, 1, 2, 3, 0, 0, 2, 0, 1, 2, 3, 0, 2, 0, 1, 2, 3};
+    static const uint8_t BYTES[20] = {4, 2, 2, 1, 1, 1, 1, 4, 2, 2, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1};
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 33; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t cs = cases[r], rd = reads[r], pv = prevs[r];
+        if (cs > 19) {
+            bad++;
+            continue;
+        }
+        const unsigned sh = 8u * SHIFT[cs], nb = BYTES[cs];
+        const uint32_t mask = nb == 4 ? 0xffffffffu : (1u << (8 * nb)) - 1;
+        const int is_store = cs >= 7 && cs <= 13, is_signed = cs >= 14;
+        uint32_t wr, sign = 0;
+        if (is_store) {
+            wr = (pv & ~(mask << sh)) | ((rd & mask) << sh);
+        } else {
+            wr = (rd >> sh) & mask;
+            if (is_signed) {
+                sign = (wr >> (8 * nb - 1)) & 1u;
+                if (sign) wr |= ~mask;
+                ora_bump(range_counts, 2 * (((wr >> (8 * (nb - 1))) & 255u) - 128 * sign), 0);
+            }
+        }
+        for (int i = 0; i < 4; i++) {
+            trace[(size_t)i * N + r] = (rd >> (8 * i)) & 255u;
+            trace[(size_t)(4 + i) * N + r] = (pv >> (8 * i)) & 255u;
+            trace[(size_t)(8 + i) * N + r] = (wr >> (8 * i)) & 255u;
+        }
+        trace[(size_t)(12 + cs) * N + r] = 1;
+        trace[(size_t)32 * N + r] = sign;
+    }
+    return bad;
+}

@@ -142,6 +142,10 @@ def rv32_auipc_trace(pc, imm, log_height, range_counts=None):
     return _records_trace("ora_rv32_auipc_trace", 14, (pc, imm), log_height, range_counts)
 
 
+def rv32_loadstore_trace(case, read, prev, log_height, range_counts=None):
+    return _records_trace("ora_rv32_loadstore_trace", 33, (case, read, prev), log_height, range_counts)
+
+
 def rv32_jalr_trace(pc, rs1, imm, log_height, range_counts=None):
     return _records_trace("ora_rv32_jalr_trace", 20, (pc, rs1, imm), log_height, range_counts)
 

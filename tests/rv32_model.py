@@ -114,7 +114,7 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
     pvs = bytearray(32)
     pc, n, pos = pc_base, 0, 0
     rec = dict(pc_index=[], alu=[], lt=[], mul=[], shift=0, branch=0, jump=0, load_store=0, mulh=0, divrem=0, lui_auipc=0, ecall=0,
-               acc=[], bnd=[], shifts=[], beq=[], blt=[], jal=[], auipc=[], jalr=[], mulhs=[])
+               acc=[], bnd=[], shifts=[], beq=[], blt=[], jal=[], auipc=[], jalr=[], mulhs=[], ls=[])
     s32 = lambda v: sx(v, 32)  # noqa: E731
     # memory log over 16-bit cells: address space 1 = registers (cell 2 i + half), 2 = memory (halfword index); entries
     # (as, ptr, prev_data, prev_ts, data, ts, is_read), timestamps 1, 2, ...
@@ -209,12 +209,17 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
             val = (sx(v, 8 * size) & M32) if f3 in (0, 1) else v
             wr = True
             rec["load_store"] += 1
+            wo, off = o & ~3, o & 3
+            case = {2: 0, 5: 1 + off // 2, 4: 3 + off, 1: 14 + off // 2, 0: 16 + off}[f3]
+            rec["ls"].append((case, int.from_bytes(bytes(mem[wo:wo + 4]).ljust(4, b"\0"), "little"), x[rd]))
         elif op == 0x23:
             imm = sx(((w >> 25) << 5) | ((w >> 7) & 31), 12)
             o = ((a + imm) & M32) - data_base
             size = 1 << f3
             cs = list(range(o >> 1, ((o + size - 1) >> 1) + 1))
             before = [cellv(c) for c in cs]
+            wo, off = o & ~3, o & 3
+            rec["ls"].append(({2: 7, 1: 8 + off // 2, 0: 10 + off}[f3], b, int.from_bytes(bytes(mem[wo:wo + 4]).ljust(4, b"\0"), "little")))
             mem[o:o + size] = (b & ((1 << (8 * size)) - 1)).to_bytes(size, "little")
             for c, bv in zip(cs, before):
                 touch(2, c, bv, True, cellv(c))

@@ -605,3 +605,48 @@ def test_rv32_mulh_chip(zk, ora):
     wrong[0][7] = (int(wrong[0][7]) + 1) % 256
     assert z.verify(params, pk.verifying_airs(), [NOPV] * 3, pk.prove([zk.upload(wrong.reshape(-1)), d_tab, d_bw], [NOPV] * 3)) != 0
     pk.close()
+
+
+def test_rv32_loadstore_chip(zk, ora):
+    """RV32 load/store cores (OpenVM LoadStoreCoreAir<4> + LoadSignExtendCoreAir<4, 8> in one chip) from (case, read word, prev
+    word) records: cells == oracle, the written word == the Python statement of each of the 20 (opcode, byte offset) cases, the
+    oracle's trace satisfies the AIR and tampered cells do not; proves with the bitwise table (bytes == oracle)."""
+    rng = np.random.default_rng(47)
+    n, lh = 4000, 12
+    cs = rng.integers(0, 20, n).astype(np.uint32)
+    cs[:20] = np.arange(20)
+    rd = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    pv = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    rd[20:40] = 0x80FF7F00
+    cs[20:40] = np.arange(20)
+    exp, rc, bad = ora.rv32_loadstore_trace(cs, rd, pv, lh)
+    assert bad == 0 and int(rc.astype(np.int64).sum()) == int((cs >= 14).sum())
+    for i in range(n):
+        kind, s = air.RV32_LOADSTORE_CASES[cs[i]]
+        r, p_ = int(rd[i]), int(pv[i])
+        if kind in ("lw", "sw"):
+            w = r
+        elif kind in ("lhu", "lh"):
+            w = (r >> (8 * s)) & 0xFFFF
+            w |= 0xFFFF0000 if kind == "lh" and w & 0x8000 else 0
+        elif kind in ("lbu", "lb"):
+            w = (r >> (8 * s)) & 0xFF
+            w |= 0xFFFFFF00 if kind == "lb" and w & 0x80 else 0
+        elif kind == "sh":
+            w = (p_ & ~(0xFFFF << (8 * s)) & 0xFFFFFFFF) | ((r & 0xFFFF) << (8 * s))
+        else:
+            w = (p_ & ~(0xFF << (8 * s)) & 0xFFFFFFFF) | ((r & 0xFF) << (8 * s))
+        assert sum(int(exp[8 + k][i]) << (8 * k) for k in range(4)) == w, (i, kind, s)
+    prog = air.rv32_loadstore_core_air().program()
+    assert air.check_trace(prog, exp, NOPV) == []
+    for col, row in ((8, 0), (9, 1), (11, 14), (32, 16), (10, 9), (12, 5)):
+        w = exp.copy()
+        w[col][row] = (int(w[col][row]) + 1) % P
+        assert air.check_trace(prog, w, NOPV) != []
+    as_dev = lambda v: torch.from_numpy(np.ascontiguousarray(v).view(np.int32)).to(zk.device)  # noqa: E731
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
+    d_tr = zk.rv32_loadstore_tracegen(as_dev(cs), as_dev(rd), as_dev(pv), lh, d_bw)
+    assert (zk.download(d_tr).reshape(33, -1) == exp).all()
+    with pytest.raises(z.ZkhipError):
+        zk.rv32_loadstore_tracegen(as_dev(np.array([20], np.uint32)), as_dev(rd[:1]), as_dev(pv[:1]), 0, torch.zeros(2 << 16, dtype=torch.int32, device=zk.device))
+    _prove_chip_with_bitwise_table(zk, ora, prog, 33, lh, exp, d_tr, d_bw, rc)

@@ -153,7 +153,7 @@ def test_memory_consistency_of_the_execution(zk, ora, tmp_path, which, seed):
 
 def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     """`prove_cli prove-guest`: the gen_proof_stark flow of the reference (mod.rs:342-413 -- execute, prove, encode, self-verify)
-    from a guest image, all in C++ on the C ABI (include/zkhip_vm_prover.hpp): the seventeen-chip proof it writes equals, byte for byte,
+    from a guest image, all in C++ on the C ABI (include/zkhip_vm_prover.hpp): the eighteen-chip proof it writes equals, byte for byte,
     the oracle's proof over the oracle's traces of the same execution records; the JSON carries the cycle count and the public
     values like the reference's StarkProof."""
     import base64
@@ -191,7 +191,9 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     assert set(rec["jal_op"].tolist()) == {0, 1} and len(rec["auipc_pc"]) > 100 and len(rec["jalr_pc"]) > 100
     lmh = log2_ceil(len(rec["mulh_op"]))
     assert set(rec["mulh_op"].tolist()) == {0, 1, 2}
-    assert heights == [lp, lf, la, ll, lm, lmh, lsh, lbe, lbl, ljl, lau, ljr, 16, 19, lacc, lbnd, 16]
+    lls = log2_ceil(len(rec["ls_case"]))
+    assert len(set(rec["ls_case"].tolist())) >= 8
+    assert heights == [lp, lf, la, ll, lm, lmh, lsh, lbe, lbl, ljl, lau, ljr, lls, 16, 19, lacc, lbnd, 16]
     prog = program_table(words, lp)
     freq, _ = ora.program_freq_trace(rec["pc_index"], lp)
     frames, _ = ora.exec_frame_trace(rec["pc_index"], prog, lf)
@@ -206,6 +208,7 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     jal, rc, _ = ora.rv32_jal_lui_trace(rec["jal_op"], rec["jal_pc"], rec["jal_imm"], ljl, range_counts=rc)
     auipc, rc, _ = ora.rv32_auipc_trace(rec["auipc_pc"], rec["auipc_imm"], lau, range_counts=rc)
     jalr, rc, _ = ora.rv32_jalr_trace(rec["jalr_pc"], rec["jalr_rs1"], rec["jalr_imm"], ljr, range_counts=rc)
+    ls, rc, _ = ora.rv32_loadstore_trace(rec["ls_case"], rec["ls_read"], rec["ls_prev"], lls, range_counts=rc)
     order = ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read")
     acc, _ = ora.memory_access_trace(*[rec["acc_" + k] for k in order], lacc)
     bnd, _ = ora.memory_boundary_trace(rec["bnd_as"], rec["bnd_ptr"], rec["bnd_initial"], rec["bnd_final"], rec["bnd_final_ts"], 2, 29, lbnd)
@@ -226,6 +229,7 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
             A(air.rv32_jal_lui_core_air().program(), ljl, 9, jal),
             A(air.rv32_auipc_core_air().program(), lau, 14, auipc),
             A(air.rv32_jalr_core_air().program(), ljr, 20, jalr),
+            A(air.rv32_loadstore_core_air().program(), lls, 33, ls),
             A(air.bitwise_lookup_air(8).program(), 16, 2, np.stack([rc, xc]), air.bitwise_lookup_prep(8)),
             A(air.range_tuple_table_air(sx, sy).program(), 19, 1, tc.reshape(1, -1), air.range_tuple_prep(sx, sy)),
             A(air.memory_access_air().program(), lacc, 10, acc),

@@ -102,6 +102,7 @@ def load_library():
         "zkhip_rv32_branch_eq_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_rv32_branch_lt_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_mulh_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp]),
+        "zkhip_rv32_loadstore_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_jal_lui_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_auipc_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_jalr_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
@@ -338,6 +339,11 @@ class Context:
         """9-column trace of the RV32 JAL / LUI core chip from records (int32 tensors: opcode 0 = JAL, 1 = LUI; pc; JAL's offset as a
         field element or LUI's 20-bit immediate); range requests go to column 0 of t_bitwise_trace."""
         return self._records_tracegen(self.lib.zkhip_rv32_jal_lui_tracegen, 9, (t_opcode, t_pc, t_imm), log_height, t_bitwise_trace)
+
+    def rv32_loadstore_tracegen(self, t_case, t_read, t_prev, log_height, t_bitwise_trace):
+        """33-column trace of the RV32 load/store core chip from records (int32 tensors: case 0..19 as air.RV32_LOADSTORE_CASES,
+        read word, prev word); the sign requests of LH / LB go to column 0 of t_bitwise_trace."""
+        return self._records_tracegen(self.lib.zkhip_rv32_loadstore_tracegen, 33, (t_case, t_read, t_prev), log_height, t_bitwise_trace)
 
     def rv32_auipc_tracegen(self, t_pc, t_imm, log_height, t_bitwise_trace):
         """14-column trace of the RV32 AUIPC core chip from records (pc, 20-bit immediate)."""

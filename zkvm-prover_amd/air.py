@@ -996,6 +996,58 @@ def rv32_mulh_core_air(tuple_bus=6, bitwise_bus=9):
     return b
 
 
+RV32_LOADSTORE_WIDTH = 33
+# (kind, shift) of the 20 cases of the load/store chip, in flag order: LW, LHU x2, LBU x4, SW, SH x2, SB x4, LH x2, LB x4
+RV32_LOADSTORE_CASES = ([("lw", 0), ("lhu", 0), ("lhu", 2)] + [("lbu", s) for s in range(4)] + [("sw", 0), ("sh", 0), ("sh", 2)] +
+                        [("sb", s) for s in range(4)] + [("lh", 0), ("lh", 2)] + [("lb", s) for s in range(4)])
+
+
+def rv32_loadstore_core_air(bus=9):
+    """The cores of OpenVM's RV32 load/store chips in one AIR (rv32im `LoadStoreCoreAir<4>`: LW LHU LBU SW SH SB, and
+    `LoadSignExtendCoreAir<4, 8>`: LH LB): columns read[4] | prev[4] | write[4] | case flag[20] | sign.  One flag per (opcode, byte
+    offset inside the aligned word) in the order of RV32_LOADSTORE_CASES; read = the aligned memory word (loads) or the register
+    (stores), prev = what the destination held, write = what it holds afterwards: each limb of write is the flag-selected limb of
+    read / prev, 0, or 255 sign.  For LH / LB, sign is the top bit of the loaded value: 2 (top limb - 128 sign) goes to the
+    bitwise lookup's range column."""
+    b = AirBuilder(RV32_LOADSTORE_WIDTH, 0)
+    rd_, pv, wr = [b.var(i) for i in range(4)], [b.var(4 + i) for i in range(4)], [b.var(8 + i) for i in range(4)]
+    fl = [b.var(12 + i) for i in range(20)]
+    sign = b.var(32)
+    ok = fl[0]
+    for f in fl[1:]:
+        ok = ok + f
+    for f in fl + [ok, sign]:
+        b.assert_zero(f * (f - 1))
+    signed = fl[14]
+    for f in fl[15:]:
+        signed = signed + f
+    b.assert_zero(sign * (1 - signed))
+    ext = sign * 255
+    for i in range(4):
+        acc = None
+        for f, (kind, s) in zip(fl, RV32_LOADSTORE_CASES):
+            if kind in ("lw", "sw"):
+                t = rd_[i]
+            elif kind in ("lhu", "lh"):
+                t = rd_[s + i] if i < 2 else (ext if kind == "lh" else None)
+            elif kind in ("lbu", "lb"):
+                t = rd_[s] if i == 0 else (ext if kind == "lb" else None)
+            elif kind == "sh":
+                t = rd_[i - s] if s <= i < s + 2 else pv[i]
+            else:
+                t = rd_[0] if i == s else pv[i]
+            if t is None:
+                continue
+            acc = f * t if acc is None else acc + f * t
+        b.assert_zero(wr[i] - acc)
+    top = None
+    for f, (kind, s) in zip(fl[14:], RV32_LOADSTORE_CASES[14:]):
+        t = f * rd_[s + 1 if kind == "lh" else s]
+        top = t if top is None else top + t
+    b.push_interaction(bus, [(top - sign * 128) * 2, 0, 0, 0], signed, "send")
+    return b
+
+
 MEMORY_ACCESS_WIDTH = 10
 
 

@@ -911,3 +911,61 @@ extern "C" int zkhip_rv32_mulh_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_mulh_tracegen (opcode > 2)");
 }
+
+// ---- RV32 load/store cores (OpenVM rv32im LoadStoreCoreAir<4> + LoadSignExtendCoreAir<4, 8>) in one chip -------------------------------
+// Record = (case 0..19: LW, LHU@0 LHU@2, LBU@0..3, SW, SH@0 SH@2, SB@0..3, LH@0 LH@2, LB@0..3 -- the number after @ is the byte offset
+// inside the aligned word; read word: memory for loads, the register for stores; prev word: what the destination held).
+// Row (ZKHIP_RV32_LOADSTORE_WIDTH = 33): read[4] | prev[4] | write[4] | case flag[20] | sign.
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_rv32_loadstore(const uint32_t* __restrict__ cases, const uint32_t* __restrict__ reads,
+                                                        const uint32_t* __restrict__ prevs, size_t n, size_t N, uint32_t* __restrict__ trace,
+                                                        uint32_t* __restrict__ range_counts, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t rd = 0, pv = 0, wr = 0, cs = 0xffffffffu, sign = 0;
+    if (r < n) {
+        cs = cases[r], rd = reads[r], pv = prevs[r];
+        if (cs > 19) {
+            atomicAdd(bad, 1u);
+            cs = 0xffffffffu, rd = pv = 0;
+        } else {
+            // bytes and byte offset of the case: words (4, offset 0) at 0 and 7, halves at 1, 2, 8, 9, 14, 15, bytes elsewhere
+            const bool word = cs == 0 || cs == 7, half = cs == 1 || cs == 2 || cs == 8 || cs == 9 || cs == 14 || cs == 15;
+            const unsigned nb = word ? 4 : half ? 2 : 1;
+            const unsigned base = cs < 1 ? 0 : cs < 3 ? 1 : cs < 7 ? 3 : cs < 8 ? 7 : cs < 10 ? 8 : cs < 14 ? 10 : cs < 16 ? 14 : 16;
+            const unsigned sh = 8u * (half ? 2 * (cs - base) : (cs - base));
+            const uint32_t mask = nb == 4 ? 0xffffffffu : (1u << (8 * nb)) - 1;
+            if (cs >= 7 && cs <= 13) {
+                wr = (pv & ~(mask << sh)) | ((rd & mask) << sh);
+            } else {
+                wr = (rd >> sh) & mask;
+                if (cs >= 14) {
+                    sign = (wr >> (8 * nb - 1)) & 1u;
+                    if (sign) wr |= ~mask;
+                    bump_range(range_counts, 2 * (((wr >> (8 * (nb - 1))) & 255u) - 128 * sign), 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        trace[(size_t)i * N + r] = to_monty((rd >> (8 * i)) & 255u);
+        trace[(size_t)(4 + i) * N + r] = to_monty((pv >> (8 * i)) & 255u);
+        trace[(size_t)(8 + i) * N + r] = to_monty((wr >> (8 * i)) & 255u);
+    }
+#pragma unroll
+    for (unsigned q = 0; q < 20; q++) trace[(size_t)(12 + q) * N + r] = q == cs ? MONTY_ONE : 0u;
+    trace[(size_t)32 * N + r] = sign ? MONTY_ONE : 0u;
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_rv32_loadstore_tracegen(zkhip_ctx* ctx, const uint32_t* d_case, const uint32_t* d_read, const uint32_t* d_prev, size_t n,
+                                             unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 27 || (n && (!d_case || !d_read || !d_prev))) return ZKHIP_ERR_INVALID;
+    return jump_chip_tracegen(ctx, "rv32_loadstore_tracegen", n, log_height, d_bitwise_trace, [&](dim3 grid, size_t N, uint32_t* flag) {
+        hipLaunchKernelGGL(k_rv32_loadstore, grid, dim3(256), 0, ctx->stream, d_case, d_read, d_prev, n, N, d_trace, d_bitwise_trace, flag);
+    });
+}
