@@ -221,6 +221,16 @@ int zkhip_rv32_mulh_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uin
 int zkhip_rv32_loadstore_tracegen(zkhip_ctx *ctx, const uint32_t *d_case, const uint32_t *d_read, const uint32_t *d_prev, size_t n,
                                   unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
 
+/* RV32 division core (the job of rv32im DivRemCoreAir<4, 8>: DIV / DIVU / REM / REMU).  Record i = (d_opcode[i]: 0 = DIV, 1 = DIVU, 2 = REM,
+ * 3 = REMU; dividend d_b[i]; divisor d_c[i]).  Fills d_trace (ZKHIP_RV32_DIVREM_WIDTH = 41 columns, stride 2^log_height, Montgomery:
+ * b[4] | c[4] | q[4] | r[4] | c_abs[4] | r_abs[4] | b_sign c_sign q_sign r_sign | k_c k_r | zero_divisor c_sum_inv | marker[4] | diff | 4 opcode
+ * flags; rows >= n zero), adds the eight (limb, carry) requests of every row to d_tuple_counts (size_x >= 256, size_y >= 2048) and
+ * its range requests to column 0 of d_bitwise_trace.  RISC-V's exceptional results (division by zero, -2^31 / -1) included.
+ * AIR: air.py rv32_divrem_core_air(). */
+#define ZKHIP_RV32_DIVREM_WIDTH 41
+int zkhip_rv32_divrem_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_b, const uint32_t *d_c, size_t n, unsigned log_height,
+                               uint32_t *d_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y, uint32_t *d_bitwise_trace);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

@@ -764,6 +764,161 @@ inline void rv32_mulh_core_air(AirBuilder& b, uint32_t tuple_bus = RANGE_TUPLE_B
     }
 }
 
+// air.rv32_divrem_core_air(tuple_bus, bitwise_bus): AirBuilder(41, 0)
+inline void rv32_divrem_core_air(AirBuilder& b, uint32_t tuple_bus = RANGE_TUPLE_BUS, uint32_t bitwise_bus = BITWISE_BUS) {
+    Expr bl[4], cl[4], ql[4], rl[4], ca[4], ra[4], mk[4];
+    for (int i = 0; i < 4; i++) bl[i] = b.var(i);
+    for (int i = 0; i < 4; i++) cl[i] = b.var(4 + i);
+    for (int i = 0; i < 4; i++) ql[i] = b.var(8 + i);
+    for (int i = 0; i < 4; i++) rl[i] = b.var(12 + i);
+    for (int i = 0; i < 4; i++) ca[i] = b.var(16 + i);
+    for (int i = 0; i < 4; i++) ra[i] = b.var(20 + i);
+    const Expr b_sign = b.var(24), c_sign = b.var(25), q_sign = b.var(26), r_sign = b.var(27);
+    const Expr kc = b.var(28), kr = b.var(29), zd = b.var(30), cinv = b.var(31);
+    for (int i = 0; i < 4; i++) mk[i] = b.var(32 + i);
+    const Expr diff = b.var(36);
+    const Expr div = b.var(37), divu = b.var(38), rem = b.var(39), remu = b.var(40);
+    const Expr ok0 = div + divu;
+    const Expr ok1 = ok0 + rem;
+    const Expr ok = ok1 + remu;
+    const Expr sgn = div + rem;
+    for (const Expr& f : {div, divu, rem, remu, ok, b_sign, c_sign, q_sign, r_sign, kc, kr, zd, mk[0], mk[1], mk[2], mk[3]}) {
+        const Expr t = f - 1;
+        b.assert_zero(f * t);
+    }
+    for (const Expr& f : {b_sign, c_sign, q_sign, r_sign}) {
+        const Expr ns = 1 - sgn;
+        b.assert_zero(ns * f);
+    }
+    {
+        const Expr nok = 1 - ok;
+        b.assert_zero(nok * zd);
+    }
+    const Expr cs0 = cl[0] + cl[1];
+    const Expr cs1 = cs0 + cl[2];
+    const Expr csum = cs1 + cl[3];
+    for (int i = 0; i < 4; i++) {
+        b.assert_zero(zd * cl[i]);
+        const Expr d = ql[i] - 255;
+        b.assert_zero(zd * d);
+    }
+    {
+        const Expr nz = ok - zd;
+        const Expr pr = csum * cinv;
+        const Expr m1 = pr - 1;
+        b.assert_zero(nz * m1);
+    }
+    const Expr b_ext = b_sign * 255;
+    const Expr c_ext = c_sign * 255;
+    const Expr q_ext = q_sign * 255;
+    const Expr r_ext = r_sign * 255;
+    Expr carry;
+    for (int i = 0; i < 4; i++) {
+        Expr acc;
+        bool have = i > 0;
+        if (have) acc = carry;
+        for (int k = 0; k <= i; k++) {
+            const Expr m = cl[k] * ql[i - k];
+            acc = have ? m + acc : m + 0;
+            have = true;
+        }
+        const Expr s = acc + rl[i];
+        const Expr d = s - bl[i];
+        carry = d * INV_256;
+        b.push_interaction(tuple_bus, {ql[i], carry}, ok, Kind::Send);
+    }
+    for (int j = 0; j < 4; j++) {
+        Expr acc = carry;
+        for (int k = j + 1; k < 4; k++) {
+            const Expr m = cl[k] * ql[4 + j - k];
+            acc = m + acc;
+        }
+        for (int k = 0; k <= j; k++) {
+            const Expr m1 = cl[k] * q_ext;
+            const Expr m2 = ql[k] * c_ext;
+            const Expr m = m1 + m2;
+            acc = m + acc;
+        }
+        const Expr s = acc + r_ext;
+        const Expr d = s - b_ext;
+        carry = d * INV_256;
+        b.push_interaction(tuple_bus, {rl[j], carry}, ok, Kind::Send);
+    }
+    for (int g = 0; g < 2; g++) {
+        const Expr* x = g == 0 ? cl : rl;
+        const Expr* xa = g == 0 ? ca : ra;
+        const Expr sg = g == 0 ? c_sign : r_sign, k = g == 0 ? kc : kr;
+        for (int i = 0; i < 4; i++) {
+            const Expr ns = 1 - sg;
+            const Expr d = x[i] - xa[i];
+            b.assert_zero(ns * d);
+        }
+        {
+            const Expr t1 = x[1] * 256;
+            const Expr t2 = x[0] + t1;
+            const Expr t3 = t2 + xa[0];
+            const Expr t4 = xa[1] * 256;
+            const Expr t5 = t3 + t4;
+            const Expr t6 = k * 65536;
+            const Expr t7 = t5 - t6;
+            b.assert_zero(sg * t7);
+        }
+        {
+            const Expr t1 = x[3] * 256;
+            const Expr t2 = x[2] + t1;
+            const Expr t3 = t2 + xa[2];
+            const Expr t4 = xa[3] * 256;
+            const Expr t5 = t3 + t4;
+            const Expr t6 = t5 + k;
+            const Expr t7 = t6 - 65536;
+            b.assert_zero(sg * t7);
+        }
+    }
+    {
+        const Expr nb = 1 - b_sign;
+        b.assert_zero(r_sign * nb);
+    }
+    for (int i = 0; i < 4; i++) {
+        const Expr nr = 1 - r_sign;
+        const Expr m = b_sign * nr;
+        b.assert_zero(m * rl[i]);
+    }
+    Expr prefix;
+    for (int i = 3; i >= 0; i--) {
+        const Expr d = ca[i] - ra[i];
+        prefix = i == 3 ? mk[i] : prefix + mk[i];
+        const Expr nz = 1 - zd;
+        const Expr np = nz - prefix;
+        b.assert_zero(np * d);
+        const Expr dd = diff - d;
+        b.assert_zero(mk[i] * dd);
+    }
+    {
+        const Expr nz = ok - zd;
+        b.assert_zero(prefix - nz);
+    }
+    {
+        const Expr s1 = b_sign * 128;
+        const Expr d1 = bl[3] - s1;
+        const Expr x = d1 * 2;
+        const Expr s2 = c_sign * 128;
+        const Expr d2 = cl[3] - s2;
+        const Expr y = d2 * 2;
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bitwise_bus, {x, y, z0, z0}, sgn, Kind::Send);
+    }
+    const Expr xs[4] = {ca[0], ca[2], ra[0], ra[2]}, ys[4] = {ca[1], ca[3], ra[1], ra[3]};
+    for (int k = 0; k < 4; k++) {
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bitwise_bus, {xs[k], ys[k], z0, z0}, ok, Kind::Send);
+    }
+    {
+        const Expr x = diff - 1;
+        const Expr z0 = b.constant(0);
+        b.push_interaction(bitwise_bus, {x, z0, z0, z0}, prefix, Kind::Send);
+    }
+}
+
 // air.rv32_loadstore_core_air(bus): AirBuilder(33, 0); cases in the order of air.RV32_LOADSTORE_CASES
 inline void rv32_loadstore_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
     enum Kind_ { LW, LHU, LBU, SW, SH, SB, LH, LB };

@@ -54,6 +54,7 @@ struct ExecRecords {
     std::vector<uint32_t> lt_op, lt_b, lt_c;          // 0 slt 1 sltu
     std::vector<uint32_t> mul_b, mul_c;               // mul (low word)
     std::vector<uint32_t> mulh_op, mulh_b, mulh_c;    // 0 mulh 1 mulhsu 2 mulhu
+    std::vector<uint32_t> div_op, div_b, div_c;       // 0 div 1 divu 2 rem 3 remu; b = dividend, c = divisor
     std::vector<uint32_t> shift_op, shift_b, shift_c; // 0 sll 1 srl 2 sra; c = the shift operand (register value or shamt)
     std::vector<uint32_t> beq_op, beq_a, beq_b, beq_imm;  // 0 beq 1 bne; imm = the offset as a canonical BabyBear element
     std::vector<uint32_t> blt_op, blt_a, blt_b, blt_imm;  // 0 blt 1 bltu 2 bge 3 bgeu; imm as above
@@ -76,10 +77,10 @@ struct ExecRecords {
 };
 
 constexpr unsigned NUM_PUBLIC_VALUE_BYTES = 32;
-// trace widths used by the cost model (cells per record): the device generators' widths where they exist, OpenVM-like
-// figures for the rest; program chip rows are counted once per program instruction
-constexpr uint64_t W_ALU = 18, W_LT = 18, W_MUL = 13, W_FRAME = 10, W_SHIFT = 53, W_BRANCH = 26, W_JUMP = 18, W_LOAD_STORE = 41,
-                   W_MULH = 39, W_DIVREM = 59, W_LUI_AUIPC = 20;
+// trace widths used by the cost model (cells per record) = the widths of the device trace generators (include/zkhip.h
+// ZKHIP_*_WIDTH); program chip rows are counted once per program instruction, memory rows once per cell access
+constexpr uint64_t W_ALU = 18, W_LT = 18, W_MUL = 13, W_MULH = 21, W_DIVREM = 41, W_FRAME = 10, W_SHIFT = 32, W_BRANCH_EQ = 17, W_BRANCH_LT = 23,
+                   W_JAL_LUI = 9, W_AUIPC = 14, W_JALR = 20, W_LOAD_STORE = 33, W_MEM_ACCESS = 10;
 
 inline uint64_t next_pow2(uint64_t x) {
     uint64_t p = 1;
@@ -89,9 +90,11 @@ inline uint64_t next_pow2(uint64_t x) {
 // metered cost = main-trace cells of the segment (rows padded to powers of two), the quantity OpenVM's metered executor bounds
 inline uint64_t trace_cells(const ExecRecords& r, size_t program_len) {
     auto cells = [](uint64_t n, uint64_t w) { return n ? next_pow2(n) * w : 0; };
-    return cells(r.alu_op.size(), W_ALU) + cells(r.lt_op.size(), W_LT) + cells(r.mul_b.size(), W_MUL) + cells(r.pc_index.size(), W_FRAME) +
-           cells(program_len, 10) + cells(r.n_shift, W_SHIFT) + cells(r.n_branch, W_BRANCH) + cells(r.n_jump, W_JUMP) +
-           cells(r.n_load_store, W_LOAD_STORE) + cells(r.n_mulh, W_MULH) + cells(r.n_divrem, W_DIVREM) + cells(r.n_lui_auipc, W_LUI_AUIPC);
+    return cells(r.alu_op.size(), W_ALU) + cells(r.lt_op.size(), W_LT) + cells(r.mul_b.size(), W_MUL) + cells(r.mulh_op.size(), W_MULH) +
+           cells(r.div_op.size(), W_DIVREM) + cells(r.pc_index.size(), W_FRAME) + cells(program_len, 10) + cells(r.shift_op.size(), W_SHIFT) +
+           cells(r.beq_op.size(), W_BRANCH_EQ) + cells(r.blt_op.size(), W_BRANCH_LT) + cells(r.jal_op.size(), W_JAL_LUI) +
+           cells(r.auipc_pc.size(), W_AUIPC) + cells(r.jalr_pc.size(), W_JALR) + cells(r.ls_case.size(), W_LOAD_STORE) +
+           cells(r.acc_ts.size(), W_MEM_ACCESS);
 }
 
 class Machine {
@@ -346,6 +349,7 @@ private:
                         case 6: val = b == 0 ? a : (a == 0x80000000u && b == 0xffffffffu) ? 0 : (uint32_t)((int32_t)a % (int32_t)b); break;
                         default: val = b == 0 ? a : a % b; break;
                     }
+                    if (rec && f3 >= 4) rec->div_op.push_back(f3 - 4), rec->div_b.push_back(a), rec->div_c.push_back(b);
                     if (rec && f3 >= 1 && f3 <= 3) rec->n_mulh++, rec->mulh_op.push_back(f3 - 1), rec->mulh_b.push_back(a), rec->mulh_c.push_back(b);
                     if (f3 >= 4 && rec) rec->n_divrem++;
                 } else if (f7 == 0 || f7 == 0x20) {

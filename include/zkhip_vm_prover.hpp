@@ -4,8 +4,8 @@
 //   2. records -> device buffers -> the device trace generators   (include/zkhip.h: zkhip_*_tracegen; no trace ever exists on the host)
 //   3. zkhip_keygen over the chips' AIRs (include/zkhip_chips.hpp), zkhip_prove, zkhip_verify
 // The AIR set (order fixed, it is part of the verifying key): program (cached program + execution frequencies), execution
-// frames, RV32 base ALU / less-than / multiplication / high multiplication / shift / branch-equal / branch-less-than / JAL-LUI / AUIPC / JALR / load-store cores, 8-bit bitwise lookup, range-tuple checker, memory access rows, memory
-// boundary, 16-bit range checker.  What these eighteen AIRs prove together is stated in DESIGN.md 8: every bus balances (program,
+// frames, RV32 base ALU / less-than / multiplication / high multiplication / division / shift / branch-equal / branch-less-than / JAL-LUI / AUIPC / JALR / load-store cores, 8-bit bitwise lookup, range-tuple checker, memory access rows, memory
+// boundary, 16-bit range checker.  What these nineteen AIRs prove together is stated in DESIGN.md 8: every bus balances (program,
 // memory, lookups) -- the chips are not yet tied to each other by an execution bus.
 #pragma once
 #include <chrono>
@@ -26,7 +26,7 @@
 namespace zkhip_vm {
 
 constexpr uint32_t TUPLE_SIZE_X = 256, TUPLE_SIZE_Y = 2048;  // covers (limb < 256, carry < 1024): a 2^19-row table
-constexpr unsigned N_VM_AIRS = 18;
+constexpr unsigned N_VM_AIRS = 19;
 
 struct GuestProof {
     ExecutionResult exec;
@@ -93,13 +93,13 @@ public:
         const unsigned lp = log2_ceil_min1(exe.program.size()), lf = log2_ceil_min1(rec.pc_index.size());
         const unsigned la = log2_ceil_min1(rec.alu_op.size()), ll = log2_ceil_min1(rec.lt_op.size()), lm = log2_ceil_min1(rec.mul_b.size());
         const unsigned lacc = log2_ceil_min1(rec.acc_ts.size()), lbnd = log2_ceil_min1(rec.bnd_ptr.size());
-        const unsigned lsh = log2_ceil_min1(rec.shift_op.size()), lmh = log2_ceil_min1(rec.mulh_op.size());
+        const unsigned lsh = log2_ceil_min1(rec.shift_op.size()), lmh = log2_ceil_min1(rec.mulh_op.size()), ldv = log2_ceil_min1(rec.div_op.size());
         const unsigned lbe = log2_ceil_min1(rec.beq_op.size()), lbl = log2_ceil_min1(rec.blt_op.size());
         const unsigned lls = log2_ceil_min1(rec.ls_case.size());
         const unsigned ljl = log2_ceil_min1(rec.jal_op.size()), lau = log2_ceil_min1(rec.auipc_pc.size()), ljr = log2_ceil_min1(rec.jalr_pc.size());
         unsigned ltup = 0;
         while ((1u << ltup) < TUPLE_SIZE_X * TUPLE_SIZE_Y) ltup++;
-        gp.log_heights = {lp, lf, la, ll, lm, lmh, lsh, lbe, lbl, ljl, lau, ljr, lls, 16, ltup, lacc, lbnd, 16};
+        gp.log_heights = {lp, lf, la, ll, lm, lmh, ldv, lsh, lbe, lbl, ljl, lau, ljr, lls, 16, ltup, lacc, lbnd, 16};
         const std::vector<uint32_t> prog = program_table(exe.program, lp);
         const size_t NP = (size_t)1 << lp;
         uint32_t* d_program_trace = dmalloc(10 * NP);  // [9 cached columns | frequency]
@@ -133,6 +133,8 @@ public:
         check(zkhip_rv32_mul_tracegen(ctx_, up(rec.mul_b), up(rec.mul_c), rec.mul_b.size(), lm, d_mul, d_tup, TUPLE_SIZE_X, TUPLE_SIZE_Y));
         uint32_t* d_mulh = dmalloc((size_t)ZKHIP_RV32_MULH_WIDTH << lmh);
         check(zkhip_rv32_mulh_tracegen(ctx_, up(rec.mulh_op), up(rec.mulh_b), up(rec.mulh_c), rec.mulh_op.size(), lmh, d_mulh, d_tup, TUPLE_SIZE_X, TUPLE_SIZE_Y, d_bw));
+        uint32_t* d_div = dmalloc((size_t)ZKHIP_RV32_DIVREM_WIDTH << ldv);
+        check(zkhip_rv32_divrem_tracegen(ctx_, up(rec.div_op), up(rec.div_b), up(rec.div_c), rec.div_op.size(), ldv, d_div, d_tup, TUPLE_SIZE_X, TUPLE_SIZE_Y, d_bw));
         uint32_t* d_acc = dmalloc((size_t)ZKHIP_MEMORY_ACCESS_WIDTH << lacc);
         const size_t n_acc = rec.acc_ts.size(), n_bnd = rec.bnd_ptr.size();
         check(zkhip_memory_access_tracegen(ctx_, up(rec.acc_as), up(rec.acc_ptr), up(rec.acc_prev_data), up(rec.acc_prev_ts), up(rec.acc_data),
@@ -157,8 +159,8 @@ public:
         // ---- 3. the AIR set and its preprocessed tables
         namespace ch = zkhip::chips;
         using zkhip::air::AirBuilder;
-        const size_t widths[N_VM_AIRS] = {10, 10, 18, 18, 13, 21, 32, 17, 23, 9, 14, 20, 33, 2, 1, 10, 8, 1};
-        const size_t prep_w[N_VM_AIRS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 2, 0, 0, 1};
+        const size_t widths[N_VM_AIRS] = {10, 10, 18, 18, 13, 21, 41, 32, 17, 23, 9, 14, 20, 33, 2, 1, 10, 8, 1};
+        const size_t prep_w[N_VM_AIRS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 2, 0, 0, 1};
         gp.programs.resize(N_VM_AIRS);
         for (unsigned a = 0; a < N_VM_AIRS; a++) {
             AirBuilder b(widths[a], 0, prep_w[a]);
@@ -169,17 +171,18 @@ public:
                 case 3: ch::rv32_lt_core_air(b); break;
                 case 4: ch::rv32_mul_core_air(b); break;
                 case 5: ch::rv32_mulh_core_air(b); break;
-                case 6: ch::rv32_shift_core_air(b); break;
-                case 7: ch::rv32_branch_eq_core_air(b); break;
-                case 8: ch::rv32_branch_lt_core_air(b); break;
-                case 9: ch::rv32_jal_lui_core_air(b); break;
-                case 10: ch::rv32_auipc_core_air(b); break;
-                case 11: ch::rv32_jalr_core_air(b); break;
-                case 12: ch::rv32_loadstore_core_air(b); break;
-                case 13: ch::bitwise_lookup_air(b); break;
-                case 14: ch::range_tuple_table_air(b); break;
-                case 15: ch::memory_access_air(b); break;
-                case 16: ch::memory_boundary_air(b); break;
+                case 6: ch::rv32_divrem_core_air(b); break;
+                case 7: ch::rv32_shift_core_air(b); break;
+                case 8: ch::rv32_branch_eq_core_air(b); break;
+                case 9: ch::rv32_branch_lt_core_air(b); break;
+                case 10: ch::rv32_jal_lui_core_air(b); break;
+                case 11: ch::rv32_auipc_core_air(b); break;
+                case 12: ch::rv32_jalr_core_air(b); break;
+                case 13: ch::rv32_loadstore_core_air(b); break;
+                case 14: ch::bitwise_lookup_air(b); break;
+                case 15: ch::range_tuple_table_air(b); break;
+                case 16: ch::memory_access_air(b); break;
+                case 17: ch::memory_boundary_air(b); break;
                 default: ch::range_table_air(b); break;
             }
             gp.programs[a] = b.program();
@@ -188,7 +191,7 @@ public:
         for (uint32_t i = 0; i < (1u << 16); i++) prep_bw[i] = i >> 8, prep_bw[(1u << 16) + i] = i & 255u, prep_bw[(2u << 16) + i] = (i >> 8) ^ (i & 255u);
         for (uint32_t i = 0; i < (1u << ltup); i++) prep_tup[i] = i / TUPLE_SIZE_Y, prep_tup[((size_t)1 << ltup) + i] = i % TUPLE_SIZE_Y;
         std::iota(prep_rng.begin(), prep_rng.end(), 0u);
-        const uint32_t* preps[N_VM_AIRS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, prep_bw.data(), prep_tup.data(), nullptr, nullptr, prep_rng.data()};
+        const uint32_t* preps[N_VM_AIRS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, prep_bw.data(), prep_tup.data(), nullptr, nullptr, prep_rng.data()};
         std::vector<zkhip_air> airs(N_VM_AIRS);
         for (unsigned a = 0; a < N_VM_AIRS; a++)
             airs[a] = zkhip_air{gp.programs[a].data(), gp.programs[a].size(), gp.log_heights[a], widths[a], 0, preps[a], nullptr};
@@ -209,7 +212,7 @@ public:
         gp.has_prep.assign(N_VM_AIRS, 0);
         for (unsigned a = 0; a < N_VM_AIRS; a++) gp.has_prep[a] = preps[a] ? 1 : 0;
         // ---- 4. prove from the device-resident traces, then the mandatory self-check (mod.rs:407-411)
-        const uint32_t* d_traces[N_VM_AIRS] = {d_program_trace, d_frames, d_alu, d_lt, d_mul, d_mulh, d_shift, d_beq, d_blt, d_jal, d_auipc, d_jalr, d_ls, d_bw, d_tup, d_acc, d_bnd, d_rng};
+        const uint32_t* d_traces[N_VM_AIRS] = {d_program_trace, d_frames, d_alu, d_lt, d_mul, d_mulh, d_div, d_shift, d_beq, d_blt, d_jal, d_auipc, d_jalr, d_ls, d_bw, d_tup, d_acc, d_bnd, d_rng};
         const uint32_t* pvs[N_VM_AIRS] = {};
         gp.proof.resize(zkhip_proof_size(pk));
         size_t len = 0;
@@ -225,7 +228,7 @@ public:
 
     // host only: what a verifier needs is the programs, heights and preprocessed commitments of the proof
     static int verify(const zkhip_params& params, const GuestProof& gp) {
-        const size_t widths[N_VM_AIRS] = {10, 10, 18, 18, 13, 21, 32, 17, 23, 9, 14, 20, 33, 2, 1, 10, 8, 1};
+        const size_t widths[N_VM_AIRS] = {10, 10, 18, 18, 13, 21, 41, 32, 17, 23, 9, 14, 20, 33, 2, 1, 10, 8, 1};
         std::vector<zkhip_air> airs(N_VM_AIRS);
         for (unsigned a = 0; a < N_VM_AIRS; a++)
             airs[a] = zkhip_air{gp.programs[a].data(), gp.programs[a].size(), gp.log_heights[a], widths[a], 0, nullptr,

@@ -22,6 +22,7 @@ pub const ZKHIP_RV32_SHIFT_WIDTH: usize = 32;
 pub const ZKHIP_RV32_BRANCH_EQ_WIDTH: usize = 17;
 pub const ZKHIP_RV32_BRANCH_LT_WIDTH: usize = 23;
 pub const ZKHIP_RV32_MULH_WIDTH: usize = 21;
+pub const ZKHIP_RV32_DIVREM_WIDTH: usize = 41;
 pub const ZKHIP_RV32_LOADSTORE_WIDTH: usize = 33;
 pub const ZKHIP_RV32_JAL_LUI_WIDTH: usize = 9;
 pub const ZKHIP_RV32_AUIPC_WIDTH: usize = 14;
@@ -176,6 +177,8 @@ extern "C" {
                                      d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_rv32_branch_lt_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_a: *const u32, d_b: *const u32, d_imm: *const u32, n: usize,
                                          log_height: c_uint, d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_rv32_divrem_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_b: *const u32, d_c: *const u32, n: usize, log_height: c_uint,
+                                      d_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_rv32_mulh_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_b: *const u32, d_c: *const u32, n: usize, log_height: c_uint,
                                     d_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_rv32_loadstore_tracegen(ctx: *mut zkhip_ctx, d_case: *const u32, d_read: *const u32, d_prev: *const u32, n: usize, log_height: c_uint,

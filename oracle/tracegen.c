@@ -552,3 +552,87 @@ size_t ora_rv32_loadstore_trace(const uint32_t *cases, const uint32_t *reads, co
     }
     return bad;
 }
+
+/* RV32 division core (zkhip_rv32_divrem_tracegen): 41 columns b[4] | c[4] | q[4] | r[4] | c_abs[4] | r_abs[4] | b_sign c_sign q_sign r_sign |
+ * k_c k_r | zero_divisor c_sum_inv | marker[4] | diff | is_div is_divu is_rem is_remu, canonical.  Record = (opcode 0 = DIV, 1 = DIVU,
+ * 2 = REM, 3 = REMU; dividend b; divisor c).  q and r come from C's integer division with RISC-V's two exceptions (c = 0: q = all
+ * ones, r = b; DIV/REM of -2^31 by -1: q = -2^31, r = 0); the carries sent to the tuple table come from the limb sums the AIR
+ * states.  Returns the number of records (there must be none) with an opcode > 3, a limb sum that is not a multiple of 256 or a
+ * carry outside the table. */
+size_t ora_rv32_divrem_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace,
+                             uint32_t *tuple_counts, uint32_t size_y, uint32_t *range_counts) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 41; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t row = 0; row < n && row < N; row++) {
+        const uint32_t op = opc[row], b = bs[row], c = cs[row];
+        if (op > 3) {
+            bad++;
+            continue;
+        }
+        const int is_signed = (op & 1) == 0;
+        uint32_t q, r;
+        int overflow = 0;
+        if (c == 0) {
+            q = 0xffffffffu, r = b;
+        } else if (is_signed && b == 0x80000000u && c == 0xffffffffu) {
+            q = b, r = 0, overflow = 1;
+        } else if (is_signed) {
+            q = (uint32_t)((int32_t)b / (int32_t)c), r = (uint32_t)((int32_t)b % (int32_t)c);
+        } else {
+            q = b / c, r = b % c;
+        }
+        const uint32_t b_sign = is_signed ? b >> 31 : 0, c_sign = is_signed ? c >> 31 : 0, r_sign = is_signed ? r >> 31 : 0;
+        const uint32_t q_sign = is_signed && !overflow ? q >> 31 : 0;
+        const uint32_t ca = c_sign ? 0u - c : c, ra = r_sign ? 0u - r : r;
+        const uint32_t kc = c_sign && (c & 0xffffu) ? 1 : 0, kr = r_sign && (r & 0xffffu) ? 1 : 0;
+        uint32_t w[4] = {b, c, q, r};
+        for (int g = 0; g < 4; g++)
+            for (int i = 0; i < 4; i++) trace[(size_t)(4 * g + i) * N + row] = (w[g] >> (8 * i)) & 255u;
+        for (int i = 0; i < 4; i++) trace[(size_t)(16 + i) * N + row] = (ca >> (8 * i)) & 255u, trace[(size_t)(20 + i) * N + row] = (ra >> (8 * i)) & 255u;
+        trace[(size_t)24 * N + row] = b_sign, trace[(size_t)25 * N + row] = c_sign, trace[(size_t)26 * N + row] = q_sign, trace[(size_t)27 * N + row] = r_sign;
+        trace[(size_t)28 * N + row] = kc, trace[(size_t)29 * N + row] = kr;
+        trace[(size_t)30 * N + row] = c == 0;
+        uint32_t csum = 0;
+        for (int i = 0; i < 4; i++) csum += (c >> (8 * i)) & 255u;
+        trace[(size_t)31 * N + row] = c == 0 ? 0 : ora_inv(csum);
+        trace[(size_t)(37 + op) * N + row] = 1;
+        int ok = 1;
+        if (c != 0) {   /* |r| < |c|: the most significant differing limb of the magnitudes */
+            int mark = -1;
+            for (int i = 3; i >= 0 && mark < 0; i--)
+                if (((ca >> (8 * i)) & 255u) != ((ra >> (8 * i)) & 255u)) mark = i;
+            if (mark < 0 || ra >= ca) {
+                ok = 0;
+            } else {
+                const uint32_t d = ((ca >> (8 * mark)) & 255u) - ((ra >> (8 * mark)) & 255u);
+                trace[(size_t)(32 + mark) * N + row] = 1, trace[(size_t)36 * N + row] = d;
+                ora_bump(range_counts, d - 1, 0);
+            }
+        }
+        /* c q + r - b over eight sign-extended limbs */
+        int64_t l[8], m[8], rr[8], bb[8], carry = 0;
+        for (int i = 0; i < 8; i++) {
+            l[i] = i < 4 ? (c >> (8 * i)) & 255u : 255 * c_sign, m[i] = i < 4 ? (q >> (8 * i)) & 255u : 255 * q_sign;
+            rr[i] = i < 4 ? (r >> (8 * i)) & 255u : 255 * r_sign, bb[i] = i < 4 ? (b >> (8 * i)) & 255u : 255 * b_sign;
+        }
+        for (int i = 0; i < 8; i++) {
+            int64_t acc = carry + rr[i] - bb[i];
+            for (int k = 0; k <= i; k++) acc += l[k] * m[i - k];
+            if (acc < 0 || (acc & 255) != 0 || (acc >> 8) >= size_y) {
+                ok = 0;
+                break;
+            }
+            carry = acc >> 8;
+            const uint32_t limb = (uint32_t)(i < 4 ? m[i] : rr[i - 4]);
+            uint32_t *t = &tuple_counts[(size_t)limb * size_y + (uint32_t)carry];
+            *t = ora_add(*t, 1);
+        }
+        if (!ok) bad++;
+        if (is_signed) ora_bump(range_counts, 2 * (((b >> 24) & 255u) - 128 * b_sign), 2 * (((c >> 24) & 255u) - 128 * c_sign));
+        ora_bump(range_counts, ca & 255u, (ca >> 8) & 255u), ora_bump(range_counts, (ca >> 16) & 255u, ca >> 24);
+        ora_bump(range_counts, ra & 255u, (ra >> 8) & 255u), ora_bump(range_counts, (ra >> 16) & 255u, ra >> 24);
+    }
+    return bad;
+}

@@ -113,6 +113,8 @@ size_t ora_rv32_mulh_trace(const uint32_t *opc, const uint32_t *bs, const uint32
                            uint32_t *tuple_counts, uint32_t size_y, uint32_t *range_counts);
 size_t ora_rv32_loadstore_trace(const uint32_t *cases, const uint32_t *reads, const uint32_t *prevs, size_t n, unsigned log_height, uint32_t *trace,
                                 uint32_t *range_counts);
+size_t ora_rv32_divrem_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace,
+                             uint32_t *tuple_counts, uint32_t size_y, uint32_t *range_counts);
 size_t ora_rv32_lt_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace,
                          uint32_t *range_counts);
 size_t ora_program_freq_trace(const uint32_t *idx, size_t n, unsigned log_height, uint32_t *freq);

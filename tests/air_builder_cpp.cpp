@@ -167,6 +167,7 @@ int main() {
         { AirBuilder b(20, 0); ch::rv32_jalr_core_air(b); dump("chip_rv32_jalr", b); }
         { AirBuilder b(21, 0); ch::rv32_mulh_core_air(b); dump("chip_rv32_mulh", b); }
         { AirBuilder b(33, 0); ch::rv32_loadstore_core_air(b); dump("chip_rv32_loadstore", b); }
+        { AirBuilder b(41, 0); ch::rv32_divrem_core_air(b); dump("chip_rv32_divrem", b); }
         { AirBuilder b(10, 0); ch::memory_access_air(b); dump("chip_memory_access", b); }
         { AirBuilder b(8, 0); ch::memory_boundary_air(b); dump("chip_memory_boundary", b); }
     }

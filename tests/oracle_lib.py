@@ -162,6 +162,18 @@ def rv32_mulh_trace(opc, bs, cs, log_height, size_x=256, size_y=2048, tuple_coun
     return tr, tc, rc, int(bad)
 
 
+def rv32_divrem_trace(opc, bs, cs, log_height, size_x=256, size_y=2048, tuple_counts=None, range_counts=None):
+    opc, bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, bs, cs))
+    tr = np.zeros((41, 1 << log_height), np.uint32)
+    tc = np.zeros(size_x * size_y, np.uint32) if tuple_counts is None else np.ascontiguousarray(tuple_counts, dtype=np.uint32).copy()
+    rc = np.zeros(1 << 16, np.uint32) if range_counts is None else np.ascontiguousarray(range_counts, dtype=np.uint32).copy()
+    l = lib()
+    l.ora_rv32_divrem_trace.restype = C.c_size_t
+    l.ora_rv32_divrem_trace.argtypes = [u32p_t()] * 3 + [C.c_size_t, C.c_uint, u32p_t(), u32p_t(), C.c_uint32, u32p_t()]
+    bad = l.ora_rv32_divrem_trace(p32(opc), p32(bs), p32(cs), len(opc), log_height, p32(tr), p32(tc), size_y, p32(rc))
+    return tr, tc, rc, int(bad)
+
+
 def rv32_lt_trace(opc, bs, cs, log_height, range_counts=None):
     opc, bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, bs, cs))
     tr = np.zeros((18, 1 << log_height), np.uint32)

@@ -114,7 +114,7 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
     pvs = bytearray(32)
     pc, n, pos = pc_base, 0, 0
     rec = dict(pc_index=[], alu=[], lt=[], mul=[], shift=0, branch=0, jump=0, load_store=0, mulh=0, divrem=0, lui_auipc=0, ecall=0,
-               acc=[], bnd=[], shifts=[], beq=[], blt=[], jal=[], auipc=[], jalr=[], mulhs=[], ls=[])
+               acc=[], bnd=[], shifts=[], beq=[], blt=[], jal=[], auipc=[], jalr=[], mulhs=[], ls=[], divs=[])
     s32 = lambda v: sx(v, 32)  # noqa: E731
     # memory log over 16-bit cells: address space 1 = registers (cell 2 i + half), 2 = memory (halfword index); entries
     # (as, ptr, prev_data, prev_ts, data, ts, is_read), timestamps 1, 2, ...
@@ -269,6 +269,7 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                     rec["mulhs"].append((f3 - 1, a, b))
                 if f3 >= 4:
                     rec["divrem"] += 1
+                    rec["divs"].append((f3 - 4, a, b))
             else:
                 if f3 == 0:
                     val = alu(1 if f7 else 0, a, b)

@@ -66,6 +66,7 @@ PY = {
     "chip_rv32_jalr": lambda: air.rv32_jalr_core_air(),
     "chip_rv32_mulh": lambda: air.rv32_mulh_core_air(),
     "chip_rv32_loadstore": lambda: air.rv32_loadstore_core_air(),
+    "chip_rv32_divrem": lambda: air.rv32_divrem_core_air(),
     "chip_memory_access": lambda: air.memory_access_air(),
     "chip_memory_boundary": lambda: air.memory_boundary_air(),
 }

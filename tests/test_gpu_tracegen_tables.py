@@ -650,3 +650,77 @@ def test_rv32_loadstore_chip(zk, ora):
     with pytest.raises(z.ZkhipError):
         zk.rv32_loadstore_tracegen(as_dev(np.array([20], np.uint32)), as_dev(rd[:1]), as_dev(pv[:1]), 0, torch.zeros(2 << 16, dtype=torch.int32, device=zk.device))
     _prove_chip_with_bitwise_table(zk, ora, prog, 33, lh, exp, d_tr, d_bw, rc)
+
+
+def test_rv32_divrem_chip(zk, ora):
+    """RV32 division core (DIV / DIVU / REM / REMU, the job of OpenVM's DivRemCoreAir<4, 8>) from records on the device: cells ==
+    oracle (quotient and remainder from C's division with RISC-V's two exceptions), q and r == Python's integers for every
+    opcode incl. division by zero, -2^31 / -1 and the extreme operands; the oracle's trace satisfies the AIR and tampered cells do
+    not; chip + tuple table + bitwise table prove from the device-resident traces (bytes == oracle); a wrong quotient limb leaves
+    the tuple bus unbalanced and the verifier refuses."""
+    rng = np.random.default_rng(53)
+    n, lh = 4000, 12
+    opc = rng.integers(0, 4, n).astype(np.uint32)
+    b = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    c = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    c[500:1500] = rng.integers(0, 1 << 16, 1000).astype(np.uint32)
+    c[1500:2000] = (0 - rng.integers(1, 1 << 12, 500)).astype(np.uint32)
+    c[2000:2200] = rng.integers(0, 4, 200).astype(np.uint32)
+    ext = np.array([0xFFFFFFFF, 0x80000000, 0x7FFFFFFF, 0, 1, 2, 0xFFFFFFFE, 0x80000001], np.uint32)
+    k = 0
+    for o in range(4):
+        for x in ext:
+            for y in ext:
+                opc[k], b[k], c[k] = o, x, y
+                k += 1
+    sx, sy = 256, 2048
+    exp, tc, rc, bad = ora.rv32_divrem_trace(opc, b, c, lh, sx, sy)
+    assert bad == 0 and int(tc.astype(np.int64).sum()) == 8 * n
+    s32 = lambda v: v - (1 << 32) if v >= 1 << 31 else v   # noqa: E731
+    for i in range(n):
+        o, bv, cv = int(opc[i]), int(b[i]), int(c[i])
+        if cv == 0:
+            q, r = 0xFFFFFFFF, bv
+        elif o in (0, 2):
+            sb, sc = s32(bv), s32(cv)
+            if sb == -(1 << 31) and sc == -1:
+                q, r = bv, 0
+            else:
+                q = abs(sb) // abs(sc)
+                q = -q if (sb < 0) != (sc < 0) else q
+                r = (sb - q * sc) & 0xFFFFFFFF
+                q &= 0xFFFFFFFF
+        else:
+            q, r = bv // cv, bv % cv
+        assert sum(int(exp[8 + j][i]) << (8 * j) for j in range(4)) == q and sum(int(exp[12 + j][i]) << (8 * j) for j in range(4)) == r, (o, bv, cv)
+    prog = air.rv32_divrem_core_air().program()
+    assert air.check_trace(prog, exp, NOPV) == []
+    for col, row in ((12, 301), (30, 303), (36, 304), (16, 1600), (27, 305)):   # b_sign, q_sign and the q limbs are held by the lookups alone
+        w = exp.copy()
+        w[col][row] = (int(w[col][row]) + 1) % P
+        assert air.check_trace(prog, w, NOPV) != []
+    dev = zk.device
+    as_dev = lambda v: torch.from_numpy(np.ascontiguousarray(v).view(np.int32)).to(dev)  # noqa: E731
+    d_tab = torch.zeros(sx * sy, dtype=torch.int32, device=dev)
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=dev)
+    d_tr = zk.rv32_divrem_tracegen(as_dev(opc), as_dev(b), as_dev(c), lh, d_tab, d_bw, sx, sy)
+    got = zk.download(d_tr).reshape(41, -1)
+    assert (got == exp).all(), [int(q) for q in range(41) if (got[q] != exp[q]).any()]
+    assert (zk.download(d_tab) == tc).all()
+    bw = zk.download(d_bw).reshape(2, -1)
+    assert (bw[0] == rc).all() and (bw[1] == 0).all()
+    with pytest.raises(z.ZkhipError):
+        zk.rv32_divrem_tracegen(as_dev(np.array([4], np.uint32)), as_dev(b[:1]), as_dev(c[:1]), 0, d_tab.clone(), d_bw.clone(), sx, sy)
+    airs = [dict(program=prog, log_height=lh, width=41, n_pvs=0, trace=exp, pvs=NOPV),
+            dict(program=air.range_tuple_table_air(sx, sy).program(), log_height=19, width=1, n_pvs=0, trace=tc.reshape(1, -1), pvs=NOPV,
+                 prep=air.range_tuple_prep(sx, sy)),
+            dict(program=air.bitwise_lookup_air(8).program(), log_height=16, width=2, n_pvs=0, trace=bw, pvs=NOPV, prep=air.bitwise_lookup_prep(8))]
+    params = (1, 0, 6, 2, 2)
+    pk = z.ProvingKey(zk, params, airs)
+    proof = pk.prove([d_tr, d_tab, d_bw], [NOPV] * 3)
+    assert z.verify(params, pk.verifying_airs(), [NOPV] * 3, proof) == 0
+    assert proof == ora.stark_prove(params, airs).tobytes()
+    wrong = exp.copy()
+    wrong[8][300] = (int(wrong[8][300]) + 1) % 256
+    assert z.verify(params, pk.verifying_airs(), [NOPV] * 3, pk.prove([zk.upload(wrong.reshape(-1)), d_tab, d_bw], [NOPV] * 3)) != 0
+    pk.close()

@@ -153,7 +153,7 @@ def test_memory_consistency_of_the_execution(zk, ora, tmp_path, which, seed):
 
 def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     """`prove_cli prove-guest`: the gen_proof_stark flow of the reference (mod.rs:342-413 -- execute, prove, encode, self-verify)
-    from a guest image, all in C++ on the C ABI (include/zkhip_vm_prover.hpp): the eighteen-chip proof it writes equals, byte for byte,
+    from a guest image, all in C++ on the C ABI (include/zkhip_vm_prover.hpp): the nineteen-chip proof it writes equals, byte for byte,
     the oracle's proof over the oracle's traces of the same execution records; the JSON carries the cycle count and the public
     values like the reference's StarkProof."""
     import base64
@@ -193,7 +193,9 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     assert set(rec["mulh_op"].tolist()) == {0, 1, 2}
     lls = log2_ceil(len(rec["ls_case"]))
     assert len(set(rec["ls_case"].tolist())) >= 8
-    assert heights == [lp, lf, la, ll, lm, lmh, lsh, lbe, lbl, ljl, lau, ljr, lls, 16, 19, lacc, lbnd, 16]
+    ldv = log2_ceil(len(rec["div_op"]))
+    assert set(rec["div_op"].tolist()) == {0, 1, 2, 3}
+    assert heights == [lp, lf, la, ll, lm, lmh, ldv, lsh, lbe, lbl, ljl, lau, ljr, lls, 16, 19, lacc, lbnd, 16]
     prog = program_table(words, lp)
     freq, _ = ora.program_freq_trace(rec["pc_index"], lp)
     frames, _ = ora.exec_frame_trace(rec["pc_index"], prog, lf)
@@ -203,6 +205,7 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     mul, tc = ora.rv32_mul_trace(rec["mul_b"], rec["mul_c"], lm, sx, sy)
     sh, rc, xc, _ = ora.rv32_shift_trace(rec["shift_op"], rec["shift_b"], rec["shift_c"], lsh, range_counts=rc, xor_counts=xc)
     mulh, tc, rc, _ = ora.rv32_mulh_trace(rec["mulh_op"], rec["mulh_b"], rec["mulh_c"], lmh, sx, sy, tuple_counts=tc, range_counts=rc)
+    dv, tc, rc, _ = ora.rv32_divrem_trace(rec["div_op"], rec["div_b"], rec["div_c"], ldv, sx, sy, tuple_counts=tc, range_counts=rc)
     beq, _ = ora.rv32_branch_eq_trace(rec["beq_op"], rec["beq_a"], rec["beq_b"], rec["beq_imm"], lbe)
     blt, rc, _ = ora.rv32_branch_lt_trace(rec["blt_op"], rec["blt_a"], rec["blt_b"], rec["blt_imm"], lbl, range_counts=rc)
     jal, rc, _ = ora.rv32_jal_lui_trace(rec["jal_op"], rec["jal_pc"], rec["jal_imm"], ljl, range_counts=rc)
@@ -223,6 +226,7 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
             A(air.rv32_lt_core_air().program(), ll, 18, lt),
             A(air.rv32_mul_core_air().program(), lm, 13, mul),
             A(air.rv32_mulh_core_air().program(), lmh, 21, mulh),
+            A(air.rv32_divrem_core_air().program(), ldv, 41, dv),
             A(air.rv32_shift_core_air().program(), lsh, 32, sh),
             A(air.rv32_branch_eq_core_air().program(), lbe, 17, beq),
             A(air.rv32_branch_lt_core_air().program(), lbl, 23, blt),

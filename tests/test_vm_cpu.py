@@ -48,7 +48,7 @@ def mixed_program():
           ("sltu", 12, T1, T0), ("slt", 13, T1, T0), ("sub", T0, T0, 12), ("add", T0, T0, 13),
           ("and", 14, T1, T4), ("or", 15, T1, T3), ("xor", T0, T0, 14), ("add", T0, T0, 15),
           ("srli", 14, T1, 7), ("sra", 15, T1, T3), ("add", T0, T0, 14), ("sub", T0, T0, 15),
-          ("ori", 16, T3, 1), ("divu", 14, T1, 16), ("rem", 15, T1, 16), ("mulhu", 16, T1, T4), ("mulh", 18, T1, T4), ("mulhsu", 19, T1, T4), ("xor", 16, 16, 19),
+          ("ori", 16, T3, 1), ("divu", 14, T1, 16), ("rem", 15, T1, 16), ("div", 19, T1, 13), ("remu", 20, T1, 12), ("xor", 14, 14, 19), ("add", 15, 15, 20), ("mulhu", 16, T1, T4), ("mulh", 18, T1, T4), ("mulhsu", 19, T1, T4), ("xor", 16, 16, 19),
           ("add", T0, T0, 14), ("add", T0, T0, 15), ("xor", T0, T0, 16), ("add", T0, T0, 18),
           ("sb", T0, S1, 3), ("lh", 14, S1, 2), ("add", T0, T0, 14),
           ("sh", T0, S1, 6), ("lhu", 15, S1, 6), ("lb", 16, S1, 7), ("add", T0, T0, 15), ("xor", T0, T0, 16),
@@ -76,7 +76,7 @@ def run_cli(tmp_path, program, stdin=b"", max_cost=0, data=b""):
     r = subprocess.run([VM, "exec", str(exe), str(inp), str(out)] + ([str(max_cost)] if max_cost else []), capture_output=True, text=True)
     rec = {}
     if r.returncode == 0:
-        for name in ("pc_index", "alu_op", "alu_b", "alu_c", "lt_op", "lt_b", "lt_c", "mul_b", "mul_c", "shift_op", "shift_b", "shift_c", "beq_op", "beq_a", "beq_b", "beq_imm", "blt_op", "blt_a", "blt_b", "blt_imm", "mulh_op", "mulh_b", "mulh_c", "ls_case", "ls_read", "ls_prev", "jal_op", "jal_pc", "jal_imm", "auipc_pc", "auipc_imm", "jalr_pc", "jalr_rs1", "jalr_imm", "acc_as", "acc_ptr", "acc_prev_data",
+        for name in ("pc_index", "alu_op", "alu_b", "alu_c", "lt_op", "lt_b", "lt_c", "mul_b", "mul_c", "shift_op", "shift_b", "shift_c", "beq_op", "beq_a", "beq_b", "beq_imm", "blt_op", "blt_a", "blt_b", "blt_imm", "mulh_op", "mulh_b", "mulh_c", "div_op", "div_b", "div_c", "ls_case", "ls_read", "ls_prev", "jal_op", "jal_pc", "jal_imm", "auipc_pc", "auipc_imm", "jalr_pc", "jalr_rs1", "jalr_imm", "acc_as", "acc_ptr", "acc_prev_data",
                      "acc_prev_ts", "acc_data", "acc_ts", "acc_is_read", "bnd_as", "bnd_ptr", "bnd_initial", "bnd_final", "bnd_final_ts"):
             rec[name] = np.fromfile(out / (name + ".u32"), dtype=np.uint32)
     return r, (json.loads(r.stdout) if r.returncode == 0 else None), rec
@@ -106,6 +106,7 @@ def check_against_model(js, rec, model):
     assert list(zip(rec["beq_op"].tolist(), rec["beq_a"].tolist(), rec["beq_b"].tolist(), rec["beq_imm"].tolist())) == m["beq"]
     assert list(zip(rec["blt_op"].tolist(), rec["blt_a"].tolist(), rec["blt_b"].tolist(), rec["blt_imm"].tolist())) == m["blt"]
     assert list(zip(rec["mulh_op"].tolist(), rec["mulh_b"].tolist(), rec["mulh_c"].tolist())) == m["mulhs"]
+    assert list(zip(rec["div_op"].tolist(), rec["div_b"].tolist(), rec["div_c"].tolist())) == m["divs"]
     assert list(zip(rec["ls_case"].tolist(), rec["ls_read"].tolist(), rec["ls_prev"].tolist())) == m["ls"]
     assert list(zip(rec["jal_op"].tolist(), rec["jal_pc"].tolist(), rec["jal_imm"].tolist())) == m["jal"]
     assert list(zip(rec["auipc_pc"].tolist(), rec["auipc_imm"].tolist())) == m["auipc"]
@@ -148,7 +149,7 @@ def test_mixed_guest_every_instruction_class(tmp_path, seed):
     assert r.returncode == 0, r.stderr
     model = rv.run(prog, stdin)
     check_against_model(js, rec, model)
-    assert js["records"]["mul"] == 64 and js["records"]["divrem"] == 128 and js["records"]["mulh"] == 192 and js["records"]["load_store"] > 300
+    assert js["records"]["mul"] == 64 and js["records"]["divrem"] == 256 and js["records"]["mulh"] == 192 and js["records"]["load_store"] > 300
 
 
 def test_metered_fallback_and_guest_failure(tmp_path):
@@ -201,7 +202,7 @@ def test_elf_guest(tmp_path):
     assert r.returncode != 0
 
 
-REC_NAMES = ("pc_index", "alu_op", "alu_b", "alu_c", "lt_op", "lt_b", "lt_c", "mul_b", "mul_c", "shift_op", "shift_b", "shift_c", "beq_op", "beq_a", "beq_b", "beq_imm", "blt_op", "blt_a", "blt_b", "blt_imm", "mulh_op", "mulh_b", "mulh_c", "ls_case", "ls_read", "ls_prev", "jal_op", "jal_pc", "jal_imm", "auipc_pc", "auipc_imm", "jalr_pc", "jalr_rs1", "jalr_imm", "acc_as", "acc_ptr", "acc_prev_data",
+REC_NAMES = ("pc_index", "alu_op", "alu_b", "alu_c", "lt_op", "lt_b", "lt_c", "mul_b", "mul_c", "shift_op", "shift_b", "shift_c", "beq_op", "beq_a", "beq_b", "beq_imm", "blt_op", "blt_a", "blt_b", "blt_imm", "mulh_op", "mulh_b", "mulh_c", "div_op", "div_b", "div_c", "ls_case", "ls_read", "ls_prev", "jal_op", "jal_pc", "jal_imm", "auipc_pc", "auipc_imm", "jalr_pc", "jalr_rs1", "jalr_imm", "acc_as", "acc_ptr", "acc_prev_data",
              "acc_prev_ts", "acc_data", "acc_ts", "acc_is_read", "bnd_as", "bnd_ptr", "bnd_initial", "bnd_final", "bnd_final_ts")
 
 

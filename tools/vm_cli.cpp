@@ -32,6 +32,7 @@ static void write_records(const std::string& out, const zkhip_vm::ExecRecords& r
     write_u32(out + "/blt_op.u32", rec.blt_op), write_u32(out + "/blt_a.u32", rec.blt_a), write_u32(out + "/blt_b.u32", rec.blt_b);
     write_u32(out + "/blt_imm.u32", rec.blt_imm);
     write_u32(out + "/mulh_op.u32", rec.mulh_op), write_u32(out + "/mulh_b.u32", rec.mulh_b), write_u32(out + "/mulh_c.u32", rec.mulh_c);
+    write_u32(out + "/div_op.u32", rec.div_op), write_u32(out + "/div_b.u32", rec.div_b), write_u32(out + "/div_c.u32", rec.div_c);
     write_u32(out + "/ls_case.u32", rec.ls_case), write_u32(out + "/ls_read.u32", rec.ls_read), write_u32(out + "/ls_prev.u32", rec.ls_prev);
     write_u32(out + "/jal_op.u32", rec.jal_op), write_u32(out + "/jal_pc.u32", rec.jal_pc), write_u32(out + "/jal_imm.u32", rec.jal_imm);
     write_u32(out + "/auipc_pc.u32", rec.auipc_pc), write_u32(out + "/auipc_imm.u32", rec.auipc_imm);

@@ -101,6 +101,7 @@ def load_library():
         "zkhip_rv32_shift_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_branch_eq_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_rv32_branch_lt_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_rv32_divrem_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp]),
         "zkhip_rv32_mulh_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp]),
         "zkhip_rv32_loadstore_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_jal_lui_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
@@ -383,6 +384,17 @@ class Context:
         out = torch.empty(13 << log_height, dtype=torch.int32, device=self.device)
         self._check(self.lib.zkhip_rv32_mul_tracegen(self.h, C.c_void_p(t_b.data_ptr()), C.c_void_p(t_c.data_ptr()), t_b.numel(), log_height,
                                                      C.c_void_p(out.data_ptr()), C.c_void_p(t_tuple_counts.data_ptr()), size_x, size_y))
+        return out
+
+    def rv32_divrem_tracegen(self, t_opcode, t_b, t_c, log_height, t_tuple_counts, t_bitwise_trace, size_x=256, size_y=2048):
+        """41-column trace of the RV32 division core chip from records (int32 tensors: opcode 0 = DIV, 1 = DIVU, 2 = REM, 3 = REMU;
+        dividend; divisor); the (limb, carry) requests go to t_tuple_counts, the range requests to column 0 of t_bitwise_trace."""
+        import torch
+
+        out = torch.empty(41 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_rv32_divrem_tracegen(self.h, C.c_void_p(t_opcode.data_ptr()), C.c_void_p(t_b.data_ptr()), C.c_void_p(t_c.data_ptr()),
+                                                        t_opcode.numel(), log_height, C.c_void_p(out.data_ptr()), C.c_void_p(t_tuple_counts.data_ptr()),
+                                                        size_x, size_y, C.c_void_p(t_bitwise_trace.data_ptr())))
         return out
 
     def rv32_mulh_tracegen(self, t_opcode, t_b, t_c, log_height, t_tuple_counts, t_bitwise_trace, size_x=256, size_y=2048):

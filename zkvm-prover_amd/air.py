@@ -996,6 +996,88 @@ def rv32_mulh_core_air(tuple_bus=6, bitwise_bus=9):
     return b
 
 
+RV32_DIVREM_WIDTH = 41
+
+
+def rv32_divrem_core_air(tuple_bus=6, bitwise_bus=9):
+    """The core of an RV32 division chip (the job of rv32im `DivRemCoreAir<4, 8>`: DIV / DIVU / REM / REMU), columns
+    b[4] | c[4] | q[4] | r[4] | c_abs[4] | r_abs[4] | b_sign c_sign q_sign r_sign | k_c k_r | zero_divisor c_sum_inv | marker[4] | diff |
+    is_div is_divu is_rem is_remu.  Three statements:
+      * b = c q + r over the integers: the four values are sign-extended to eight limbs by their sign columns and
+        c q + r - b is multiplied out limb by limb; each of the eight carries is an expression sent with a limb of q (low half) or
+        of r (high half) to the range-tuple checker, which also makes those limbs bytes.  q_sign is free: the identity together
+        with the bound below admits exactly one value of q, and in the overflow case DIV(-2^31, -1) that value is +2^31
+        (limbs 0x80000000 with q_sign = 0), the result RISC-V prescribes;
+      * |r| < |c| unless c = 0, and r has b's sign or is zero: c_abs, r_abs are the magnitudes (x + x_abs = 2^32 in two 16-bit
+        halves with a carry bit when the sign is set, equal limbs otherwise), compared like the less-than chip (marker at the
+        most significant differing limb, diff = c_abs_i - r_abs_i in 1..255); b_sign (1 - r_sign) r_i = 0;
+      * c = 0 (zero_divisor, with c_sum_inv witnessing a non-zero limb sum otherwise) forces q = 0xffffffff; r = b then follows
+        from the identity.
+    b_sign / c_sign are tied to the top limbs through the bitwise lookup (signed opcodes), the unsigned opcodes have no signs."""
+    b = AirBuilder(RV32_DIVREM_WIDTH, 0)
+    bl, cl, ql, rl = ([b.var(4 * g + i) for i in range(4)] for g in range(4))
+    ca, ra = [b.var(16 + i) for i in range(4)], [b.var(20 + i) for i in range(4)]
+    b_sign, c_sign, q_sign, r_sign = (b.var(24 + i) for i in range(4))
+    kc, kr, zd, cinv = b.var(28), b.var(29), b.var(30), b.var(31)
+    mk, diff = [b.var(32 + i) for i in range(4)], b.var(36)
+    div, divu, rem, remu = (b.var(37 + i) for i in range(4))
+    ok = div + divu + rem + remu
+    signed = div + rem
+    for f in (div, divu, rem, remu, ok, b_sign, c_sign, q_sign, r_sign, kc, kr, zd) + tuple(mk):
+        b.assert_zero(f * (f - 1))
+    for f in (b_sign, c_sign, q_sign, r_sign):
+        b.assert_zero((1 - signed) * f)
+    b.assert_zero((1 - ok) * zd)
+    # ---- c = 0
+    csum = cl[0] + cl[1] + cl[2] + cl[3]
+    for i in range(4):
+        b.assert_zero(zd * cl[i])
+        b.assert_zero(zd * (ql[i] - 255))
+    b.assert_zero((ok - zd) * (csum * cinv - 1))
+    # ---- b = c q + r
+    b_ext, c_ext, q_ext, r_ext = b_sign * 255, c_sign * 255, q_sign * 255, r_sign * 255
+    inv256 = pow(256, -1, P)
+    carry = None
+    for i in range(4):
+        acc = carry if carry is not None else 0
+        for k in range(i + 1):
+            acc = cl[k] * ql[i - k] + acc
+        carry = (acc + rl[i] - bl[i]) * inv256
+        b.push_interaction(tuple_bus, [ql[i], carry], ok, "send")
+    for j in range(4):
+        acc = carry
+        for k in range(j + 1, 4):
+            acc = cl[k] * ql[4 + j - k] + acc
+        for k in range(j + 1):
+            acc = cl[k] * q_ext + ql[k] * c_ext + acc
+        carry = (acc + r_ext - b_ext) * inv256
+        b.push_interaction(tuple_bus, [rl[j], carry], ok, "send")
+    # ---- magnitudes
+    for x, xa, sg, k in ((cl, ca, c_sign, kc), (rl, ra, r_sign, kr)):
+        for i in range(4):
+            b.assert_zero((1 - sg) * (x[i] - xa[i]))
+        b.assert_zero(sg * (x[0] + x[1] * 256 + xa[0] + xa[1] * 256 - k * 65536))
+        b.assert_zero(sg * (x[2] + x[3] * 256 + xa[2] + xa[3] * 256 + k - 65536))
+    b.assert_zero(r_sign * (1 - b_sign))
+    for i in range(4):
+        b.assert_zero(b_sign * (1 - r_sign) * rl[i])
+    # ---- |r| < |c|
+    prefix = None
+    for i in (3, 2, 1, 0):
+        d = ca[i] - ra[i]
+        prefix = mk[i] if prefix is None else prefix + mk[i]
+        b.assert_zero((1 - zd - prefix) * d)
+        b.assert_zero(mk[i] * (diff - d))
+    b.assert_zero(prefix - (ok - zd))
+    b.push_interaction(bitwise_bus, [(bl[3] - b_sign * 128) * 2, (cl[3] - c_sign * 128) * 2, 0, 0], signed, "send")
+    b.push_interaction(bitwise_bus, [ca[0], ca[1], 0, 0], ok, "send")
+    b.push_interaction(bitwise_bus, [ca[2], ca[3], 0, 0], ok, "send")
+    b.push_interaction(bitwise_bus, [ra[0], ra[1], 0, 0], ok, "send")
+    b.push_interaction(bitwise_bus, [ra[2], ra[3], 0, 0], ok, "send")
+    b.push_interaction(bitwise_bus, [diff - 1, 0, 0, 0], prefix, "send")
+    return b
+
+
 RV32_LOADSTORE_WIDTH = 33
 # (kind, shift) of the 20 cases of the load/store chip, in flag order: LW, LHU x2, LBU x4, SW, SH x2, SB x4, LH x2, LB x4
 RV32_LOADSTORE_CASES = ([("lw", 0), ("lhu", 0), ("lhu", 2)] + [("lbu", s) for s in range(4)] + [("sw", 0), ("sh", 0), ("sh", 2)] +

@@ -969,3 +969,105 @@ extern "C" int zkhip_rv32_loadstore_tracegen(zkhip_ctx* ctx, const uint32_t* d_c
         hipLaunchKernelGGL(k_rv32_loadstore, grid, dim3(256), 0, ctx->stream, d_case, d_read, d_prev, n, N, d_trace, d_bitwise_trace, flag);
     });
 }
+
+// ---- RV32 division core (the job of OpenVM rv32im DivRemCoreAir<4, 8>: DIV / DIVU / REM / REMU) ---------------------------------------
+// Record = (opcode 0 = DIV, 1 = DIVU, 2 = REM, 3 = REMU; dividend b; divisor c).  Row (ZKHIP_RV32_DIVREM_WIDTH = 41): b[4] | c[4] | q[4] | r[4] |
+// c_abs[4] | r_abs[4] | b_sign c_sign q_sign r_sign | k_c k_r | zero_divisor c_sum_inv | marker[4] | diff | 4 opcode flags (air.py
+// rv32_divrem_core_air() states what they prove).  One hardware division per row, one field inversion per non-zero divisor; the
+// eight (limb, carry) pairs of c q + r - b go to the range-tuple table, six range requests to the bitwise table.
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_rv32_divrem(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ bs, const uint32_t* __restrict__ cs,
+                                                     size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ tuple_counts, uint32_t size_y,
+                                                     uint32_t* __restrict__ range_counts, uint32_t* __restrict__ bad) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    uint32_t col[ZKHIP_RV32_DIVREM_WIDTH] = {};
+    if (row < n) {
+        const uint32_t op = opc[row], b = bs[row], c = cs[row];
+        if (op > 3) {
+            atomicAdd(bad, 1u);
+        } else {
+            const bool is_signed = (op & 1u) == 0, overflow = is_signed && b == 0x80000000u && c == 0xffffffffu;
+            uint32_t q, r;
+            if (c == 0) q = 0xffffffffu, r = b;
+            else if (overflow) q = b, r = 0;
+            else if (is_signed) q = (uint32_t)((int32_t)b / (int32_t)c), r = (uint32_t)((int32_t)b % (int32_t)c);
+            else q = b / c, r = b % c;
+            const uint32_t b_sign = is_signed ? b >> 31 : 0u, c_sign = is_signed ? c >> 31 : 0u, r_sign = is_signed ? r >> 31 : 0u;
+            const uint32_t q_sign = is_signed && !overflow ? q >> 31 : 0u;
+            const uint32_t ca = c_sign ? 0u - c : c, ra = r_sign ? 0u - r : r;
+            const uint32_t w[6] = {b, c, q, r, ca, ra};
+#pragma unroll
+            for (int g = 0; g < 6; g++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) col[4 * g + i] = to_monty((w[g] >> (8 * i)) & 255u);
+            col[24] = b_sign ? MONTY_ONE : 0u, col[25] = c_sign ? MONTY_ONE : 0u, col[26] = q_sign ? MONTY_ONE : 0u, col[27] = r_sign ? MONTY_ONE : 0u;
+            col[28] = c_sign && (c & 0xffffu) ? MONTY_ONE : 0u, col[29] = r_sign && (r & 0xffffu) ? MONTY_ONE : 0u;
+            col[37 + op] = MONTY_ONE;
+            if (c == 0) {
+                col[30] = MONTY_ONE;
+            } else {
+                col[31] = minv(to_monty((c & 255u) + ((c >> 8) & 255u) + ((c >> 16) & 255u) + (c >> 24)));
+                int mark = 0;   // ra < ca: the magnitudes differ somewhere
+#pragma unroll
+                for (int i = 3; i >= 0; i--)
+                    if (((ca ^ ra) >> (8 * i)) & 255u) {
+                        mark = i;
+                        break;
+                    }
+                const uint32_t d = ((ca >> (8 * mark)) & 255u) - ((ra >> (8 * mark)) & 255u);
+                col[32 + mark] = MONTY_ONE, col[36] = to_monty(d);
+                bump_range(range_counts, d - 1, 0);
+            }
+            // c q + r - b over eight sign-extended limbs; the limbs are opaque to the optimiser (see k_rv32_mulh)
+            uint32_t l[8], m[8];
+            int rr[8], bb[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                l[i] = i < 4 ? (c >> (8 * i)) & 255u : 255u * c_sign, m[i] = i < 4 ? (q >> (8 * i)) & 255u : 255u * q_sign;
+                rr[i] = (int)(i < 4 ? (r >> (8 * i)) & 255u : 255u * r_sign), bb[i] = (int)(i < 4 ? (b >> (8 * i)) & 255u : 255u * b_sign);
+                asm volatile("" : "+v"(l[i]), "+v"(m[i]));
+            }
+            int carry = 0;   // sums are multiples of 256 in [0, 2^19)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int acc = carry + rr[i] - bb[i];
+#pragma unroll
+                for (int k = 0; k <= i; k++) acc += (int)(l[k] * m[i - k]);
+                carry = acc >> 8;
+                atomicAdd(&tuple_counts[(size_t)(i < 4 ? m[i] : (uint32_t)rr[i - 4]) * size_y + (uint32_t)carry], 1u);
+            }
+            if (is_signed) bump_range(range_counts, 2 * ((b >> 24) - 128 * b_sign), 2 * ((c >> 24) - 128 * c_sign));
+            bump_range(range_counts, ca & 255u, (ca >> 8) & 255u), bump_range(range_counts, (ca >> 16) & 255u, ca >> 24);
+            bump_range(range_counts, ra & 255u, (ra >> 8) & 255u), bump_range(range_counts, (ra >> 16) & 255u, ra >> 24);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_RV32_DIVREM_WIDTH; q++) trace[(size_t)q * N + row] = col[q];
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_rv32_divrem_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, const uint32_t* d_b, const uint32_t* d_c, size_t n, unsigned log_height,
+                                          uint32_t* d_trace, uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_tuple_counts || !d_bitwise_trace || log_height > 27 || (n && (!d_opcode || !d_b || !d_c))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height, T = (size_t)size_x * size_y;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_divrem_tracegen: more records than rows");
+    if (size_x < 256 || size_y < 2048 || T > ((size_t)1 << 27))
+        return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_divrem_tracegen: the tuple table must cover (limb < 256, carry < 2048)");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "rv32_divrem_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const unsigned tb = (unsigned)((T + 255) / 256);
+    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
+    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
+    hipLaunchKernelGGL(k_rv32_divrem, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_tuple_counts,
+                       size_y, d_bitwise_trace, (uint32_t*)flag);
+    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
+    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "rv32_divrem_tracegen (opcode > 3)");
+}
