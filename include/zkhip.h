@@ -73,6 +73,15 @@ int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr);
 int zkhip_free(zkhip_ctx *ctx, void *dptr);
 int zkhip_h2d(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int zkhip_d2h(zkhip_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronises */
+/* Pinned host staging: zkhip_host_alloc returns page-locked memory; zkhip_h2d_async enqueues the copy on the context's stream and
+ * returns at once -- the source must be pinned and stay untouched until work enqueued after it has completed (any synchronising
+ * call: zkhip_d2h, zkhip_prove, ...).  zkhip_zero clears device memory in stream order.  (A caller that uploads many record
+ * arrays per proof -- include/zkhip_vm_prover.hpp -- stages them in one pinned buffer instead of one synchronous pageable copy
+ * each.) */
+int zkhip_host_alloc(zkhip_ctx *ctx, size_t bytes, void **hptr);
+int zkhip_host_free(zkhip_ctx *ctx, void *hptr);
+int zkhip_h2d_async(zkhip_ctx *ctx, void *dst, const void *src_pinned, size_t bytes);
+int zkhip_zero(zkhip_ctx *ctx, void *dptr, size_t bytes);
 /* in-place canonical <-> Montgomery on a device buffer of n words */
 int zkhip_to_monty(zkhip_ctx *ctx, uint32_t *d, size_t n);
 int zkhip_from_monty(zkhip_ctx *ctx, uint32_t *d, size_t n);

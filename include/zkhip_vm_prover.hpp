@@ -8,6 +8,7 @@
 // boundary, 16-bit range checker.  What these nineteen AIRs prove together is stated in DESIGN.md 8: every bus balances (program,
 // memory, lookups) -- the chips are not yet tied to each other by an execution bus.
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <map>
@@ -65,7 +66,8 @@ public:
     ~VmProver() {
         for (auto& kv : keys_)
             if (kv.second.pk) zkhip_pk_destroy(ctx_, kv.second.pk);
-        for (void* p : bufs_) zkhip_free(ctx_, p);
+        for (Chunk& c : dev_) zkhip_free(ctx_, c.base);
+        for (Chunk& c : pin_) zkhip_host_free(ctx_, c.base);
         if (ctx_) zkhip_ctx_destroy(ctx_);
     }
     VmProver(const VmProver&) = delete;
@@ -88,6 +90,10 @@ public:
         auto ms = [](clk::time_point a, clk::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(b - a).count(); };
         GuestProof gp;
         gp.exec.total_cycle = rec.pc_index.size();
+        if (!dev_.empty() && dev_[0].used) {   // a previous segment ended in an exception: let its copies drain, then reuse the arenas
+            zkhip_sync(ctx_);
+            release_segment_buffers();
+        }
         const auto t1 = clk::now();
         // ---- 2. heights, device records, device traces
         const unsigned lp = log2_ceil_min1(exe.program.size()), lf = log2_ceil_min1(rec.pc_index.size());
@@ -221,8 +227,7 @@ public:
         gp.proof.resize(len);
         gp.proving_time_mills = ms(t2, clk::now());
         if (self_verify && verify(params, gp) != ZKHIP_OK) throw Error("the proof does not verify");
-        for (void* p : bufs_) zkhip_free(ctx_, p);  // the records and traces of this segment
-        bufs_.clear();
+        release_segment_buffers();  // the records and traces of this segment (the proof is out: nothing in flight reads them)
         return gp;
     }
 
@@ -239,7 +244,15 @@ public:
 
 private:
     zkhip_ctx* ctx_ = nullptr;
-    std::vector<void*> bufs_;
+    // Device memory and pinned staging of a segment come from chunked arenas that live as long as the prover: after the first
+    // segment a lane neither allocates nor frees (hipFree synchronises the whole device, which serialised the lanes), and the
+    // ~50 record arrays of a segment go up as asynchronous copies from ONE pinned buffer instead of 50 synchronous pageable ones.
+    struct Chunk {
+        char* base = nullptr;
+        size_t cap = 0, used = 0;
+    };
+    std::vector<Chunk> dev_, pin_;
+    static constexpr size_t DEV_CHUNK = (size_t)256 << 20, PIN_CHUNK = (size_t)64 << 20;
     struct Key {
         zkhip_pk* pk = nullptr;
         std::vector<std::array<uint32_t, 8>> prep_commits;
@@ -251,19 +264,39 @@ private:
     void check(int rc) {
         if (rc != ZKHIP_OK) throw Error(std::string("zkhip: ") + zkhip_last_error(ctx_));
     }
-    uint32_t* dmalloc(size_t words) {
+    template <typename Alloc>
+    char* carve(std::vector<Chunk>& chunks, size_t bytes, size_t chunk_bytes, Alloc&& alloc) {
+        bytes = (std::max<size_t>(bytes, 4) + 255) & ~(size_t)255;
+        for (Chunk& c : chunks)
+            if (c.cap - c.used >= bytes) {
+                char* p = c.base + c.used;
+                c.used += bytes;
+                return p;
+            }
+        Chunk c;
+        c.cap = std::max(bytes, chunk_bytes);
         void* p = nullptr;
-        check(zkhip_malloc(ctx_, (words ? words : 1) * 4, &p));
-        bufs_.push_back(p);
-        return (uint32_t*)p;
+        check(alloc(c.cap, &p));
+        c.base = (char*)p, c.used = bytes;
+        chunks.push_back(c);
+        return c.base;
     }
-    void h2d(uint32_t* d, const uint32_t* h, size_t words) {
-        if (words) check(zkhip_h2d(ctx_, d, h, words * 4));
+    void release_segment_buffers() {
+        for (Chunk& c : dev_) c.used = 0;
+        for (Chunk& c : pin_) c.used = 0;
+    }
+    uint32_t* dmalloc(size_t words) {
+        return (uint32_t*)carve(dev_, words * 4, DEV_CHUNK, [&](size_t n, void** p) { return zkhip_malloc(ctx_, n, p); });
+    }
+    void h2d(uint32_t* d, const uint32_t* h, size_t words) {   // through the pinned staging buffer, stream-ordered
+        if (!words) return;
+        char* stage = carve(pin_, words * 4, PIN_CHUNK, [&](size_t n, void** p) { return zkhip_host_alloc(ctx_, n, p); });
+        memcpy(stage, h, words * 4);
+        check(zkhip_h2d_async(ctx_, d, stage, words * 4));
     }
     uint32_t* dzeros(size_t words) {
         uint32_t* d = dmalloc(words);
-        const std::vector<uint32_t> z(words, 0);
-        h2d(d, z.data(), words);
+        check(zkhip_zero(ctx_, d, words * 4));
         return d;
     }
     const uint32_t* up(const std::vector<uint32_t>& v) {  // plain integers, as the generators take them

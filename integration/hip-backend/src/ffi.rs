@@ -148,6 +148,10 @@ extern "C" {
     pub fn zkhip_free(ctx: *mut zkhip_ctx, dptr: *mut c_void) -> c_int;
     pub fn zkhip_h2d(ctx: *mut zkhip_ctx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
     pub fn zkhip_d2h(ctx: *mut zkhip_ctx, dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+    pub fn zkhip_host_alloc(ctx: *mut zkhip_ctx, bytes: usize, hptr: *mut *mut c_void) -> c_int;
+    pub fn zkhip_host_free(ctx: *mut zkhip_ctx, hptr: *mut c_void) -> c_int;
+    pub fn zkhip_h2d_async(ctx: *mut zkhip_ctx, dst: *mut c_void, src_pinned: *const c_void, bytes: usize) -> c_int;
+    pub fn zkhip_zero(ctx: *mut zkhip_ctx, dptr: *mut c_void, bytes: usize) -> c_int;
     pub fn zkhip_to_monty(ctx: *mut zkhip_ctx, d: *mut u32, n: usize) -> c_int;
     pub fn zkhip_from_monty(ctx: *mut zkhip_ctx, d: *mut u32, n: usize) -> c_int;
 

@@ -203,6 +203,33 @@ int zkhip_h2d(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // src may be pageable and freed by the caller
     return ZKHIP_OK;
 }
+int zkhip_host_alloc(zkhip_ctx* ctx, size_t bytes, void** hptr) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !hptr) return ZKHIP_ERR_INVALID;
+    if (hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess)
+        return set_error(ctx, ZKHIP_ERR_NOMEM, "hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
+    return ZKHIP_OK;
+}
+int zkhip_host_free(zkhip_ctx* ctx, void* hptr) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    if (!hptr) return ZKHIP_OK;
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP_CHECK(ctx, hipHostFree(hptr));
+    return ZKHIP_OK;
+}
+int zkhip_h2d_async(zkhip_ctx* ctx, void* dst, const void* src_pinned, size_t bytes) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || (bytes && (!dst || !src_pinned))) return ZKHIP_ERR_INVALID;
+    if (bytes) ZK_HIP_CHECK(ctx, hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return ZKHIP_OK;
+}
+int zkhip_zero(zkhip_ctx* ctx, void* dptr, size_t bytes) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || (bytes && !dptr)) return ZKHIP_ERR_INVALID;
+    if (bytes) ZK_HIP_CHECK(ctx, hipMemsetAsync(dptr, 0, bytes, ctx->stream));
+    return ZKHIP_OK;
+}
 int zkhip_d2h(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
     ZK_BIND_DEVICE(ctx);
     if (!ctx) return ZKHIP_ERR_INVALID;

@@ -11,6 +11,7 @@
 // One row per lane: the 298 stores of a wave are 298 contiguous 256-byte runs (column-major trace), the 16 input words
 // of a row are four 16-byte loads.  HBM-bound on the writes: 1192 B per row written, 64 B read.
 #include "poseidon2.hpp"
+#include "hist.hpp"
 #include "poseidon2_coop.hpp"
 #include "zkhip_internal.hpp"
 
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void k_range_counts(const uint32_t* __restrict
             n_bad++;
             continue;
         }
-        atomicAdd(use_lds ? &bins[v] : &hist[v], 1u);
+        hist_add(use_lds ? bins : hist, v);
     }
     if (n_bad) atomicAdd(bad, n_bad);
     if (use_lds) {

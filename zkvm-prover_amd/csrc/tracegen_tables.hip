@@ -20,6 +20,7 @@
 #include <string>
 
 #include "../../include/zkhip.h"
+#include "hist.hpp"
 #include "babybear.hpp"
 #include "zkhip_internal.hpp"
 
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void k_tuple_counts(const uint32_t* __restrict
             n_bad++;
             continue;
         }
-        atomicAdd(&hist[(size_t)x * size_y + y], 1u);
+        hist_add(hist, (uint32_t)((size_t)x * size_y + y));
     }
     if (n_bad) atomicAdd(bad, n_bad);
 }
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void k_bitwise_counts(const uint32_t* __restri
             n_bad++;
             continue;
         }
-        atomicAdd(&hist[((size_t)op << (2 * bits)) + ((size_t)x << bits) + y], 1u);
+        hist_add(hist, (uint32_t)(((size_t)op << (2 * bits)) + ((size_t)x << bits) + y));
     }
     if (n_bad) atomicAdd(bad, n_bad);
 }
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void k_rv32_alu(const uint32_t* __restrict__ o
                 const uint32_t ai = (a >> (8 * i)) & 255u, bi = (b >> (8 * i)) & 255u, ci = (c >> (8 * i)) & 255u;
                 col[i] = to_monty(ai), col[4 + i] = to_monty(bi), col[8 + i] = to_monty(ci);
                 const uint32_t x = op >= 2 ? bi : ai, y = op >= 2 ? ci : ai;
-                atomicAdd(&xor_counts[(x << 8) | y], 1u);
+                hist_add(xor_counts, (x << 8) | y);
             }
             col[12 + op] = MONTY_ONE;
             col[17] = MONTY_ONE;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256) void k_rv32_mul(const uint32_t* __restrict__ b
             const uint32_t ai = acc & 255u;
             carry = acc >> 8;  // < 1024
             col[i] = to_monty(ai), col[4 + i] = to_monty(bl[i]), col[8 + i] = to_monty(cl[i]);
-            atomicAdd(&tuple_counts[(size_t)ai * size_y + carry], 1u);
+            hist_add(tuple_counts, ai * size_y + carry);
         }
         col[12] = MONTY_ONE;
     }
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void k_program_freq(const uint32_t* __restrict
     if (i >= n) return;
     const uint32_t k = idx[i];
     if (k >= N) atomicAdd(bad, 1u);
-    else atomicAdd(&freq[k], 1u);
+    else hist_add(freq, k);
 }
 __global__ __launch_bounds__(256) void k_exec_frames(const uint32_t* __restrict__ idx, size_t n, const uint32_t* __restrict__ program,
                                                      size_t n_program, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
@@ -420,8 +421,8 @@ __global__ __launch_bounds__(256) void k_rv32_lt(const uint32_t* __restrict__ op
             col[12] = to_monty(cm < 0 ? P - (uint32_t)(-cm) : (uint32_t)cm);
             if (mark >= 0) col[13 + mark] = MONTY_ONE, col[17] = to_monty((uint32_t)dv);
             const uint32_t sh = is_slt ? 128u : 0u;
-            atomicAdd(&range_counts[((uint32_t)(bm + (int)sh) << 8) | (uint32_t)(cm + (int)sh)], 1u);
-            if (mark >= 0) atomicAdd(&range_counts[(uint32_t)(dv - 1) << 8], 1u);
+            hist_add(range_counts, ((uint32_t)(bm + (int)sh) << 8) | (uint32_t)(cm + (int)sh));
+            if (mark >= 0) hist_add(range_counts, (uint32_t)(dv - 1) << 8);
         }
     }
 #pragma unroll
@@ -543,11 +544,11 @@ __global__ __launch_bounds__(256) void k_rv32_shift(const uint32_t* __restrict__
             col[29] = to_monty(q);
             col[op == 0 ? 30 : 31] = to_monty(mult);
 #pragma unroll
-            for (int i = 0; i < 4; i++) atomicAdd(&range_counts[(cy[i] << 8) | (mult - 1u - cy[i])], 1u);
-            atomicAdd(&range_counts[(al[0] << 8) | al[1]], 1u);
-            atomicAdd(&range_counts[(al[2] << 8) | al[3]], 1u);
-            atomicAdd(&range_counts[(q << 8) | (32u * q)], 1u);
-            if (op == 2) atomicAdd(&xor_counts[(bl[3] << 8) | 128u], 1u);
+            for (int i = 0; i < 4; i++) hist_add(range_counts, (cy[i] << 8) | (mult - 1u - cy[i]));
+            hist_add(range_counts, (al[0] << 8) | al[1]);
+            hist_add(range_counts, (al[2] << 8) | al[3]);
+            hist_add(range_counts, (q << 8) | (32u * q));
+            if (op == 2) hist_add(xor_counts, (bl[3] << 8) | 128u);
         }
     }
 #pragma unroll
@@ -670,8 +671,8 @@ __global__ __launch_bounds__(256) void k_rv32_branch_lt(const uint32_t* __restri
             if (mark >= 0) col[17 + mark] = MONTY_ONE, col[21] = to_monty((uint32_t)dv);
             col[22] = taken ? to_monty(imm) : to_monty(4u);
             const int sh = is_signed ? 128 : 0;
-            atomicAdd(&range_counts[((uint32_t)(am + sh) << 8) | (uint32_t)(bm + sh)], 1u);
-            if (mark >= 0) atomicAdd(&range_counts[(uint32_t)(dv - 1) << 8], 1u);
+            hist_add(range_counts, ((uint32_t)(am + sh) << 8) | (uint32_t)(bm + sh));
+            if (mark >= 0) hist_add(range_counts, (uint32_t)(dv - 1) << 8);
         }
     }
 #pragma unroll
@@ -702,7 +703,7 @@ extern "C" int zkhip_rv32_branch_lt_tracegen(zkhip_ctx* ctx, const uint32_t* d_o
 // One thread per record / row as the chips above; the rows' range requests are counted into column 0 of the bitwise table.
 namespace zk {
 namespace {
-__device__ __forceinline__ void bump_range(uint32_t* range_counts, uint32_t x, uint32_t y) { atomicAdd(&range_counts[(x << 8) | y], 1u); }
+__device__ __forceinline__ void bump_range(uint32_t* range_counts, uint32_t x, uint32_t y) { hist_add(range_counts, (x << 8) | y); }
 
 __global__ __launch_bounds__(256) void k_rv32_jal_lui(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ pcs, const uint32_t* __restrict__ imms,
                                                       size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ range_counts,
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(256) void k_rv32_mulh(const uint32_t* __restrict__ 
                 const uint32_t limb = acc & 255u;
                 carry = acc >> 8;   // < 2048
                 col[i < 4 ? 12 + i : i - 4] = to_monty(limb);
-                atomicAdd(&tuple_counts[(size_t)limb * size_y + carry], 1u);
+                hist_add(tuple_counts, limb * size_y + carry);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) col[4 + i] = to_monty(l[i]), col[8 + i] = to_monty(m[i]);
@@ -1036,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_rv32_divrem(const uint32_t* __restrict_
 #pragma unroll
                 for (int k = 0; k <= i; k++) acc += (int)(l[k] * m[i - k]);
                 carry = acc >> 8;
-                atomicAdd(&tuple_counts[(size_t)(i < 4 ? m[i] : (uint32_t)rr[i - 4]) * size_y + (uint32_t)carry], 1u);
+                hist_add(tuple_counts, (i < 4 ? m[i] : (uint32_t)rr[i - 4]) * size_y + (uint32_t)carry);
             }
             if (is_signed) bump_range(range_counts, 2 * ((b >> 24) - 128 * b_sign), 2 * ((c >> 24) - 128 * c_sign));
             bump_range(range_counts, ca & 255u, (ca >> 8) & 255u), bump_range(range_counts, (ca >> 16) & 255u, ca >> 24);
