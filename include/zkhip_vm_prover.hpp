@@ -10,6 +10,9 @@
 #pragma once
 #include <algorithm>
 #include <chrono>
+#include <mutex>
+#include <deque>
+#include <condition_variable>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -313,37 +316,96 @@ private:
 // of the reference checks that link; here tests do).
 struct SegmentedProof {
     ExecutionResult exec;
-    uint64_t execution_time_mills = 0, proving_wall_mills = 0;
+    uint64_t execution_time_mills = 0;   // time the executor spent executing (it overlaps the proving)
+    uint64_t proving_wall_mills = 0;     // wall time from the start of the execution to the last segment proof verified
     std::vector<GuestProof> segments;
 };
 inline SegmentedProof prove_segments(const zkhip_params& params, const Exe& exe, const StdIn& in, uint64_t segment_instr,
                                      unsigned inflight = 1, std::vector<int> devices = {0}) {
     using clk = std::chrono::steady_clock;
-    const auto t0 = clk::now();
-    const SegmentedExecution se = execute_segments(exe, in, segment_instr);
-    const auto t1 = clk::now();
-    SegmentedProof sp;
-    sp.exec = se.result;
-    sp.execution_time_mills = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count();
-    sp.segments.resize(se.segments.size());
+    auto ms = [](clk::duration d) { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(d).count(); };
+    if (segment_instr == 0) throw Error("segment length must be positive");
     if (devices.empty() || inflight == 0) throw Error("no prover lanes");
-    const size_t n_lanes = std::min<size_t>(devices.size() * inflight, se.segments.size());
-    std::vector<std::thread> lanes;
+    const auto t0 = clk::now();
+    SegmentedProof sp;
+    // The executor (this thread) streams segments into a bounded queue while the lanes prove: execution overlaps proving, and
+    // at most 2 * lanes segments of records (168 B per instruction) are alive at once instead of the whole run's.
+    const size_t n_lanes = devices.size() * inflight;
+    struct Item {
+        size_t index;
+        ExecRecords rec;
+    };
+    std::deque<Item> queue;
+    std::mutex mu;
+    std::condition_variable cv_push, cv_pop;
+    bool closed = false;
     std::vector<std::string> errors(n_lanes);
-    std::atomic<size_t> next{0};
+    std::atomic<bool> lane_failed{false};
+    std::vector<std::thread> lanes;
     for (size_t l = 0; l < n_lanes; l++)
         lanes.emplace_back([&, l] {
             try {
                 VmProver vp(devices[l % devices.size()]);
-                // the mandatory self-check (mod.rs:407-411) runs on host threads after the lanes are done, not on a lane
-                for (size_t k = next++; k < se.segments.size(); k = next++) sp.segments[k] = vp.prove_records(params, exe, se.segments[k], false);
+                for (;;) {
+                    Item it;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_pop.wait(lk, [&] { return !queue.empty() || closed; });
+                        if (queue.empty()) return;
+                        it = std::move(queue.front());
+                        queue.pop_front();
+                    }
+                    cv_push.notify_one();
+                    // the mandatory self-check (mod.rs:407-411) runs on host threads after the lanes are done, not on a lane
+                    GuestProof gp = vp.prove_records(params, exe, it.rec, false);
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (sp.segments.size() <= it.index) sp.segments.resize(it.index + 1);
+                    sp.segments[it.index] = std::move(gp);
+                }
             } catch (const std::exception& e) {
                 errors[l] = e.what();
+                lane_failed = true;
+                cv_push.notify_all();
             }
         });
-    for (auto& t : lanes) t.join();
+    auto close_queue = [&] {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            closed = true;
+        }
+        cv_pop.notify_all();
+        for (auto& t : lanes) t.join();
+    };
+    clk::duration exec_time{};
+    size_t n_segments = 0;
+    try {
+        Machine m(exe, in);
+        for (bool done = false; !done && !lane_failed;) {
+            Item it;
+            it.index = n_segments++;
+            const auto a = clk::now();
+            done = m.run_segment(segment_instr, &it.rec);
+            exec_time += clk::now() - a;
+            std::unique_lock<std::mutex> lk(mu);
+            cv_push.wait(lk, [&] { return queue.size() < 2 * n_lanes || lane_failed; });
+            queue.push_back(std::move(it));
+            lk.unlock();
+            cv_pop.notify_one();
+        }
+        if (m.exit_code()) throw Error("guest exited with code " + std::to_string(m.exit_code()));
+        bool all_zero = true;
+        for (uint8_t b : m.public_values()) all_zero = all_zero && b == 0;
+        if (all_zero) throw Error("public_values are all 0s for unexpected reason");
+        sp.exec = ExecutionResult{m.instret(), m.public_values()};
+    } catch (...) {
+        close_queue();
+        throw;
+    }
+    close_queue();
     for (const auto& e : errors)
         if (!e.empty()) throw Error("segment prover: " + e);
+    if (sp.segments.size() != n_segments) throw Error("segment prover: proofs missing");
+    sp.execution_time_mills = ms(exec_time);
     {
         const size_t n_ver = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), sp.segments.size());
         std::vector<std::thread> vt;
@@ -357,7 +419,7 @@ inline SegmentedProof prove_segments(const zkhip_params& params, const Exe& exe,
         for (auto& t : vt) t.join();
         if (bad) throw Error("a segment proof does not verify");
     }
-    sp.proving_wall_mills = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(clk::now() - t1).count();
+    sp.proving_wall_mills = ms(clk::now() - t0);   // execution included: it runs under the proving
     return sp;
 }
 

@@ -1,6 +1,6 @@
 """Guest in, proofs out at scale: a Fibonacci guest of ~1 M instructions through `prove_cli prove-guest` with continuation
-segments (include/zkhip_vm_prover.hpp: execute, per-segment device trace generation for ten chips, prove, self-verify) --
-reports executed MHz and PROVEN instructions per second.  Usage: python tools/guest_bench.py [n_iterations] [segment_instr] [inflight]"""
+segments (include/zkhip_vm_prover.hpp: execute, per-segment device trace generation for nineteen chips, prove, self-verify; the
+execution streams under the proving) -- reports executed MHz and instructions per second from ELF to verified proofs.  Usage: python tools/guest_bench.py [n_iterations] [segment_instr] [inflight]"""
 import json
 import os
 import subprocess
