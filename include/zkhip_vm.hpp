@@ -74,7 +74,19 @@ struct ExecRecords {
     // and per touched cell, once the run is over: initial value (before the first access), final value, timestamp of the last
     // access -- the records of the memory boundary chip (zkhip_memory_boundary_tracegen)
     std::vector<uint32_t> bnd_as, bnd_ptr, bnd_initial, bnd_final, bnd_final_ts;
+
+    // empties every array but keeps its storage: a recycled ExecRecords spares the next segment ~25 MB of fresh pages
+    void clear() {
+        for (std::vector<uint32_t>* v :
+             {&pc_index, &alu_op, &alu_b, &alu_c, &lt_op, &lt_b, &lt_c, &mul_b, &mul_c, &mulh_op, &mulh_b, &mulh_c, &div_op, &div_b, &div_c, &shift_op,
+              &shift_b, &shift_c, &beq_op, &beq_a, &beq_b, &beq_imm, &blt_op, &blt_a, &blt_b, &blt_imm, &jal_op, &jal_pc, &jal_imm, &auipc_pc, &auipc_imm,
+              &jalr_pc, &jalr_rs1, &jalr_imm, &ls_case, &ls_read, &ls_prev, &acc_as, &acc_ptr, &acc_prev_data, &acc_prev_ts, &acc_data, &acc_ts,
+              &acc_is_read, &bnd_as, &bnd_ptr, &bnd_initial, &bnd_final, &bnd_final_ts})
+            v->clear();
+        n_shift = n_branch = n_jump = n_load_store = n_mulh = n_divrem = n_lui_auipc = n_ecall = 0;
+    }
 };
+static_assert(sizeof(ExecRecords) == 49 * sizeof(std::vector<uint32_t>) + 8 * sizeof(uint64_t), "ExecRecords::clear() must list every array");
 
 constexpr unsigned NUM_PUBLIC_VALUE_BYTES = 32;
 // trace widths used by the cost model (cells per record) = the widths of the device trace generators (include/zkhip.h
@@ -121,6 +133,11 @@ public:
     // segments are independent proofs; what chains them is that a cell's final value in one segment is its
     // initial value in the next one that touches it.  Returns true once the guest has exited.
     bool run_segment(uint64_t max_instr, ExecRecords* rec) {
+        if (rec && max_instr && max_instr <= ((uint64_t)1 << 24)) {   // the memory log grows by about five entries per instruction
+            rec->pc_index.reserve(max_instr);
+            for (auto* v : {&rec->acc_as, &rec->acc_ptr, &rec->acc_prev_data, &rec->acc_prev_ts, &rec->acc_data, &rec->acc_ts, &rec->acc_is_read})
+                v->reserve(5 * max_instr);
+        }
         for (uint64_t k = 0; !done_ && (max_instr == 0 || k < max_instr); k++) step(rec);
         close_segment(rec);
         return done_;

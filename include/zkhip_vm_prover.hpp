@@ -336,6 +336,7 @@ inline SegmentedProof prove_segments(const zkhip_params& params, const Exe& exe,
         ExecRecords rec;
     };
     std::deque<Item> queue;
+    std::vector<ExecRecords> pool;   // proven segments' records, emptied: the executor refills them instead of faulting in fresh pages
     std::mutex mu;
     std::condition_variable cv_push, cv_pop;
     bool closed = false;
@@ -358,9 +359,11 @@ inline SegmentedProof prove_segments(const zkhip_params& params, const Exe& exe,
                     cv_push.notify_one();
                     // the mandatory self-check (mod.rs:407-411) runs on host threads after the lanes are done, not on a lane
                     GuestProof gp = vp.prove_records(params, exe, it.rec, false);
+                    it.rec.clear();
                     std::lock_guard<std::mutex> lk(mu);
                     if (sp.segments.size() <= it.index) sp.segments.resize(it.index + 1);
                     sp.segments[it.index] = std::move(gp);
+                    pool.push_back(std::move(it.rec));
                 }
             } catch (const std::exception& e) {
                 errors[l] = e.what();
@@ -383,6 +386,10 @@ inline SegmentedProof prove_segments(const zkhip_params& params, const Exe& exe,
         for (bool done = false; !done && !lane_failed;) {
             Item it;
             it.index = n_segments++;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!pool.empty()) it.rec = std::move(pool.back()), pool.pop_back();
+            }
             const auto a = clk::now();
             done = m.run_segment(segment_instr, &it.rec);
             exec_time += clk::now() - a;
