@@ -197,7 +197,7 @@ int zkhip_rv32_branch_lt_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, cons
 int zkhip_rv32_jal_lui_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_pc, const uint32_t *d_imm, size_t n,
                                 unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
 
-/* RV32 AUIPC core (rv32im Rv32AuipcCoreAir).  Record i = (d_pc[i] < p, d_imm[i] the 20-bit immediate).  ZKHIP_RV32_AUIPC_WIDTH = 14
+/* RV32 AUIPC core (rv32im Rv32AuipcCoreAir).  Record i = (d_pc[i] < 2^30, d_imm[i] the 20-bit immediate).  ZKHIP_RV32_AUIPC_WIDTH = 14
  * columns: pc | imm | pc_limb[4] | imm_limb[3] (bytes of 16 imm) | rd[4] = pc + (imm << 12) mod 2^32 | is_valid; five range requests
  * per row.  AIR: air.py rv32_auipc_core_air(). */
 #define ZKHIP_RV32_AUIPC_WIDTH 14

@@ -452,8 +452,9 @@ inline void rv32_auipc_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
     }
     const Expr xs[5] = {pl[0], pl[2], il[0], il[2], rd[2]}, ys[5] = {pl[1], pl[3], il[1], rd[1], rd[3]};
     for (int k = 0; k < 5; k++) {
+        const Expr y = k == 1 ? ys[k] * 4 : ys[k];   // the top pc limb below 2^6
         const Expr z0 = b.constant(0);
-        b.push_interaction(bus, {xs[k], ys[k], z0, z0}, ok, Kind::Send);
+        b.push_interaction(bus, {xs[k], y, z0, z0}, ok, Kind::Send);
     }
 }
 

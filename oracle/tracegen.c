@@ -412,7 +412,7 @@ size_t ora_rv32_auipc_trace(const uint32_t *pcs, const uint32_t *imms, size_t n,
         for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
     for (size_t r = 0; r < n && r < N; r++) {
         const uint32_t pc = pcs[r], imm = imms[r];
-        if (pc >= ORA_P || (imm >> 20) != 0) {
+        if (pc >= (1u << 30) || (imm >> 20) != 0) {
             bad++;
             continue;
         }
@@ -424,7 +424,7 @@ size_t ora_rv32_auipc_trace(const uint32_t *pcs, const uint32_t *imms, size_t n,
         for (int i = 0; i < 4; i++) trace[(size_t)(2 + i) * N + r] = pl[i], trace[(size_t)(9 + i) * N + r] = dl[i];
         for (int i = 0; i < 3; i++) trace[(size_t)(6 + i) * N + r] = il[i];
         trace[13 * N + r] = 1;
-        ora_bump(range_counts, pl[0], pl[1]), ora_bump(range_counts, pl[2], pl[3]), ora_bump(range_counts, il[0], il[1]);
+        ora_bump(range_counts, pl[0], pl[1]), ora_bump(range_counts, pl[2], 4 * pl[3]), ora_bump(range_counts, il[0], il[1]);
         ora_bump(range_counts, il[2], dl[1]), ora_bump(range_counts, dl[2], dl[3]);
     }
     return bad;

@@ -497,9 +497,9 @@ def test_rv32_auipc_chip(zk, ora):
     mod 2^32 as integers incl. wrap-around, AIR satisfied / tampering caught; proves with the bitwise table (bytes == oracle)."""
     rng = np.random.default_rng(37)
     n, lh = 3000, 12
-    pc = rng.integers(0, P, n).astype(np.uint32)
+    pc = rng.integers(0, 1 << 30, n).astype(np.uint32)
     imm = rng.integers(0, 1 << 20, n).astype(np.uint32)
-    pc[:10], imm[:10] = P - 1, (1 << 20) - 1
+    pc[:10], imm[:10] = (1 << 30) - 1, (1 << 20) - 1
     exp, rc, bad = ora.rv32_auipc_trace(pc, imm, lh)
     assert bad == 0 and int(rc.astype(np.int64).sum()) == 5 * n
     rd = sum(exp[9 + i][:n].astype(np.uint64) << (8 * i) for i in range(4))
@@ -514,8 +514,11 @@ def test_rv32_auipc_chip(zk, ora):
     d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
     d_tr = zk.rv32_auipc_tracegen(as_dev(pc), as_dev(imm), lh, d_bw)
     assert (zk.download(d_tr).reshape(14, -1) == exp).all()
-    with pytest.raises(z.ZkhipError):
-        zk.rv32_auipc_tracegen(as_dev(pc[:1]), as_dev(np.array([1 << 20], np.uint32)), 0, torch.zeros(2 << 16, dtype=torch.int32, device=zk.device))
+    for p_, i_ in ((0, 1 << 20), (1 << 30, 0)):   # an immediate or a pc too wide
+        with pytest.raises(z.ZkhipError):
+            zk.rv32_auipc_tracegen(as_dev(np.array([p_], np.uint32)), as_dev(np.array([i_], np.uint32)), 0,
+                                   torch.zeros(2 << 16, dtype=torch.int32, device=zk.device))
+        assert ora.rv32_auipc_trace([p_], [i_], 0)[2] == 1
     _prove_chip_with_bitwise_table(zk, ora, prog, 14, lh, exp, d_tr, d_bw, rc)
 
 

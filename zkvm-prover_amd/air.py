@@ -817,8 +817,8 @@ RV32_AUIPC_WIDTH = 14
 def rv32_auipc_core_air(bus=9):
     """The core of OpenVM's RV32 AUIPC chip (rv32im `Rv32AuipcCoreAir`): columns pc | imm | pc_limb[4] | imm_limb[3] | rd[4] | is_valid.
     rd = pc + (imm << 12) mod 2^32: the pc and 16 imm (= bytes 1..3 of imm << 12) are decomposed into 8-bit limbs, rd_0 = pc_limb_0,
-    and limbs 1..3 add with boolean carries.  Five range requests: (pc_0, pc_1), (pc_2, pc_3), (imm_0, imm_1), (imm_2, rd_1),
-    (rd_2, rd_3)."""
+    and limbs 1..3 add with boolean carries.  Five range requests: (pc_0, pc_1), (pc_2, 4 pc_3), (imm_0, imm_1), (imm_2, rd_1),
+    (rd_2, rd_3); the second keeps the pc limbs below 2^30, so that their sum cannot be pc + p."""
     b = AirBuilder(RV32_AUIPC_WIDTH, 0)
     pc, imm = b.var(0), b.var(1)
     pl, il, rd = [b.var(2 + i) for i in range(4)], [b.var(6 + i) for i in range(3)], [b.var(9 + i) for i in range(4)]
@@ -832,7 +832,7 @@ def rv32_auipc_core_air(bus=9):
     for i in range(1, 4):
         carry = (pl[i] + il[i - 1] - rd[i] + (carry if carry is not None else 0)) * inv256
         b.assert_zero(ok * (carry * (carry - 1)))
-    for x, y in ((pl[0], pl[1]), (pl[2], pl[3]), (il[0], il[1]), (il[2], rd[1]), (rd[2], rd[3])):
+    for x, y in ((pl[0], pl[1]), (pl[2], pl[3] * 4), (il[0], il[1]), (il[2], rd[1]), (rd[2], rd[3])):
         b.push_interaction(bus, [x, y, 0, 0], ok, "send")
     return b
 

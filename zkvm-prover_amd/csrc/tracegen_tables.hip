@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256) void k_rv32_auipc(const uint32_t* __restrict__
     uint32_t col[ZKHIP_RV32_AUIPC_WIDTH] = {};
     if (r < n) {
         const uint32_t pc = pcs[r], imm = imms[r];
-        if (pc >= P || (imm >> 20) != 0) {
+        if (pc >= (1u << 30) || (imm >> 20) != 0) {
             atomicAdd(bad, 1u);
         } else {
             const uint32_t rd = pc + (imm << 12), im16 = imm << 4;
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void k_rv32_auipc(const uint32_t* __restrict__
 #pragma unroll
             for (int i = 0; i < 3; i++) col[6 + i] = to_monty(il[i]);
             col[13] = MONTY_ONE;
-            bump_range(range_counts, pl[0], pl[1]), bump_range(range_counts, pl[2], pl[3]), bump_range(range_counts, il[0], il[1]);
+            bump_range(range_counts, pl[0], pl[1]), bump_range(range_counts, pl[2], 4 * pl[3]), bump_range(range_counts, il[0], il[1]);
             bump_range(range_counts, il[2], dl[1]), bump_range(range_counts, dl[2], dl[3]);
         }
     }
