@@ -240,6 +240,20 @@ int zkhip_rv32_loadstore_tracegen(zkhip_ctx *ctx, const uint32_t *d_case, const 
 int zkhip_rv32_divrem_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_b, const uint32_t *d_c, size_t n, unsigned log_height,
                                uint32_t *d_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y, uint32_t *d_bitwise_trace);
 
+/* MMCS path chip: in-circuit verification of mixed-height Merkle openings, a piece of the recursion circuit the reference's
+ * aggregation nodes run.  Path p = (leaf digest d_leaf[8 p ..], index d_index[p], steps d_path_start[p] ..
+ * d_path_start[p + 1] bottom-up: d_step_kind 0 = sibling digest (consumes the next index bit, least significant first), 1 = injected
+ * row digest of the shorter matrices joining there; d_step_digest[8 s ..]) -- canonical words.  Fills d_trace
+ * (ZKHIP_MMCS_PATH_WIDTH = 39 columns, stride 2^log_height, Montgomery: root[8] | parent[8] | a[8] | b[8] | bit | is_inj | is_first | is_last |
+ * is_real | idx | lvl; path p occupies rows d_path_start[p] .., written from the root down; other rows zero) and d_hash_inputs
+ * ([2^log_height][16] Montgomery: a || b of every row, the input of zkhip_poseidon2_air_tracegen for the Poseidon2 chip that
+ * serves the chip's hash bus).  AIR: air.py mmcs_path_air().  ZKHIP_ERR_INVALID if a path does not fit or does not end in a sibling
+ * step. */
+#define ZKHIP_MMCS_PATH_WIDTH 39
+int zkhip_mmcs_path_tracegen(zkhip_ctx *ctx, const uint32_t *d_leaf, const uint32_t *d_index, const uint32_t *d_path_start,
+                             const uint32_t *d_step_kind, const uint32_t *d_step_digest, size_t n_paths, unsigned log_height, uint32_t *d_trace,
+                             uint32_t *d_hash_inputs);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

@@ -765,6 +765,119 @@ inline void rv32_mulh_core_air(AirBuilder& b, uint32_t tuple_bus = RANGE_TUPLE_B
     }
 }
 
+// air.mmcs_path_air(hash_bus, claims_bus): AirBuilder(39, 0) -- in-circuit verification of mixed-height Merkle openings
+inline void mmcs_path_air(AirBuilder& b, uint32_t hash_bus, uint32_t claims_bus) {
+    Expr root[8], par[8], a_[8], b_[8], n_root[8], n_par[8];
+    for (int i = 0; i < 8; i++) root[i] = b.var(i);
+    for (int i = 0; i < 8; i++) par[i] = b.var(8 + i);
+    for (int i = 0; i < 8; i++) a_[i] = b.var(16 + i);
+    for (int i = 0; i < 8; i++) b_[i] = b.var(24 + i);
+    const Expr bit = b.var(32), inj = b.var(33), first = b.var(34), last = b.var(35), real = b.var(36), idx = b.var(37), lvl = b.var(38);
+    for (int i = 0; i < 8; i++) n_root[i] = b.next(i);
+    for (int i = 0; i < 8; i++) n_par[i] = b.next(8 + i);
+    const Expr n_bit = b.next(32), n_inj = b.next(33), n_first = b.next(34), n_real = b.next(36), n_idx = b.next(37), n_lvl = b.next(38);
+    for (const Expr& f : {bit, inj, first, last, real}) {
+        const Expr t = f - 1;
+        b.assert_zero(f * t);
+    }
+    b.assert_zero(inj * bit);
+    {
+        const Expr nr = 1 - real;
+        b.assert_zero(first * nr);
+    }
+    {
+        const Expr nr = 1 - real;
+        b.assert_zero(last * nr);
+    }
+    b.assert_zero(last * inj);
+    const Expr link = real - last;
+    b.when_first_row(real - first);
+    b.when_last_row(link);
+    {
+        const Expr nn = 1 - n_real;
+        b.when_transition(link * nn);
+    }
+    b.when_transition(link * n_first);
+    {
+        const Expr m = last * n_real;
+        const Expr nf = 1 - n_first;
+        b.when_transition(m * nf);
+    }
+    {
+        const Expr nr = 1 - real;
+        b.when_transition(nr * n_real);
+    }
+    for (int i = 0; i < 8; i++) {
+        {
+            const Expr d = par[i] - root[i];
+            b.assert_zero(first * d);
+        }
+        {
+            const Expr d = n_root[i] - root[i];
+            b.when_transition(link * d);
+        }
+        {
+            const Expr t1 = n_par[i] - a_[i];
+            const Expr t2 = b_[i] - a_[i];
+            const Expr t3 = bit * t2;
+            const Expr t4 = t1 - t3;
+            b.when_transition(link * t4);
+        }
+    }
+    {
+        const Expr d = idx - bit;
+        b.assert_zero(first * d);
+    }
+    {
+        const Expr d = lvl - 1;
+        const Expr e = d + inj;
+        b.assert_zero(first * e);
+    }
+    {
+        const Expr w = 2 - n_inj;
+        const Expr m = idx * w;
+        const Expr d = n_idx - m;
+        const Expr e = d - n_bit;
+        b.when_transition(link * e);
+    }
+    {
+        const Expr d = n_lvl - lvl;
+        const Expr e = d - 1;
+        const Expr f = e + n_inj;
+        b.when_transition(link * f);
+    }
+    {
+        std::vector<Expr> msg;
+        for (int i = 0; i < 8; i++) msg.push_back(a_[i]);
+        for (int i = 0; i < 8; i++) msg.push_back(b_[i]);
+        for (int i = 0; i < 8; i++) msg.push_back(par[i]);
+        b.push_interaction(hash_bus, msg, real, Kind::Send);
+    }
+    {
+        std::vector<Expr> msg(root, root + 8);
+        msg.push_back(lvl), msg.push_back(idx);
+        for (int i = 0; i < 8; i++) msg.push_back(b_[i]);
+        b.push_interaction(claims_bus, msg, inj, Kind::Send);
+    }
+    {
+        std::vector<Expr> msg(root, root + 8);
+        msg.push_back(lvl), msg.push_back(idx);
+        for (int i = 0; i < 8; i++) {
+            const Expr t = b_[i] - a_[i];
+            const Expr m = bit * t;
+            msg.push_back(a_[i] + m);
+        }
+        b.push_interaction(claims_bus, msg, last, Kind::Send);
+    }
+}
+
+// air.mmcs_claims_air(claims_bus): AirBuilder(19, 0)
+inline void mmcs_claims_air(AirBuilder& b, uint32_t claims_bus) {
+    std::vector<Expr> msg;
+    for (int i = 0; i < 18; i++) msg.push_back(b.var(i));
+    b.push_interaction(claims_bus, msg, b.var(18), Kind::Receive);
+}
+
 // air.rv32_divrem_core_air(tuple_bus, bitwise_bus): AirBuilder(41, 0)
 inline void rv32_divrem_core_air(AirBuilder& b, uint32_t tuple_bus = RANGE_TUPLE_BUS, uint32_t bitwise_bus = BITWISE_BUS) {
     Expr bl[4], cl[4], ql[4], rl[4], ca[4], ra[4], mk[4];

@@ -21,6 +21,7 @@ pub const ZKHIP_RV32_LT_WIDTH: usize = 18;
 pub const ZKHIP_RV32_SHIFT_WIDTH: usize = 32;
 pub const ZKHIP_RV32_BRANCH_EQ_WIDTH: usize = 17;
 pub const ZKHIP_RV32_BRANCH_LT_WIDTH: usize = 23;
+pub const ZKHIP_MMCS_PATH_WIDTH: usize = 39;
 pub const ZKHIP_RV32_MULH_WIDTH: usize = 21;
 pub const ZKHIP_RV32_DIVREM_WIDTH: usize = 41;
 pub const ZKHIP_RV32_LOADSTORE_WIDTH: usize = 33;
@@ -181,6 +182,8 @@ extern "C" {
                                      d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_rv32_branch_lt_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_a: *const u32, d_b: *const u32, d_imm: *const u32, n: usize,
                                          log_height: c_uint, d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_mmcs_path_tracegen(ctx: *mut zkhip_ctx, d_leaf: *const u32, d_index: *const u32, d_path_start: *const u32, d_step_kind: *const u32,
+                                    d_step_digest: *const u32, n_paths: usize, log_height: c_uint, d_trace: *mut u32, d_hash_inputs: *mut u32) -> c_int;
     pub fn zkhip_rv32_divrem_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_b: *const u32, d_c: *const u32, n: usize, log_height: c_uint,
                                       d_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_rv32_mulh_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_b: *const u32, d_c: *const u32, n: usize, log_height: c_uint,

@@ -636,3 +636,57 @@ size_t ora_rv32_divrem_trace(const uint32_t *opc, const uint32_t *bs, const uint
     }
     return bad;
 }
+
+/* MMCS path chip (zkhip_mmcs_path_tracegen; air.py mmcs_path_air): 39 columns root[8] | parent[8] | a[8] | b[8] | bit | is_inj | is_first |
+ * is_last | is_real | idx | lvl, canonical.  Path p: leaf digest leaf[8 p ..], index index[p], steps path_start[p] .. path_start[p+1]
+ * BOTTOM-UP (step_kind 0 = sibling digest, consuming the next index bit from the least significant end; 1 = injected row digest
+ * of shorter matrices; step_digest[8 s ..]).  The digests are compressed bottom-up with ora_compress, the rows written top-down
+ * (row path_start[p] is the compression that yields the root).  hash_inputs[16 r ..] = a || b of row r (what the Poseidon2 chip
+ * must permute), claims[18 c ..] = (root, lvl, idx, digest) in row order (injections, then the leaf of each path).  Returns the
+ * number of paths that do not fit the trace or do not end in a sibling step. */
+size_t ora_mmcs_path_trace(const uint32_t *leaf, const uint32_t *index, const uint32_t *path_start, const uint32_t *step_kind,
+                           const uint32_t *step_digest, size_t n_paths, unsigned log_height, uint32_t *trace, uint32_t *hash_inputs,
+                           uint32_t *claims, size_t *n_claims) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0, nc = 0;
+    for (size_t q = 0; q < 39; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t p = 0; p < n_paths; p++) {
+        const size_t s0 = path_start[p], s1 = path_start[p + 1], ns = s1 - s0;
+        if (s1 > N || ns == 0 || ns > 64 || step_kind[s0] != 0) {
+            bad++;
+            continue;
+        }
+        uint32_t a[64][8], b[64][8], par[64][8], bits[64], node[8];
+        unsigned sibs = 0;
+        for (int i = 0; i < 8; i++) node[i] = leaf[8 * p + i];
+        for (size_t j = 0; j < ns; j++) {
+            const uint32_t *d = &step_digest[8 * (s0 + j)];
+            bits[j] = step_kind[s0 + j] == 0 ? (index[p] >> sibs) & 1u : 0;
+            if (step_kind[s0 + j] == 0) sibs++;
+            for (int i = 0; i < 8; i++) a[j][i] = bits[j] ? d[i] : node[i], b[j][i] = bits[j] ? node[i] : d[i];
+            ora_compress(a[j], b[j], par[j]);
+            for (int i = 0; i < 8; i++) node[i] = par[j][i];
+        }
+        uint32_t idx = 0, lvl = 0;
+        for (size_t k = 0; k < ns; k++) {   /* top-down */
+            const size_t j = ns - 1 - k, r = s0 + k;
+            const uint32_t inj = step_kind[s0 + j] != 0;
+            idx = idx * (2 - inj) + bits[j], lvl += 1 - inj;
+            for (int i = 0; i < 8; i++) {
+                trace[(size_t)i * N + r] = node[i], trace[(size_t)(8 + i) * N + r] = par[j][i];
+                trace[(size_t)(16 + i) * N + r] = a[j][i], trace[(size_t)(24 + i) * N + r] = b[j][i];
+                hash_inputs[16 * r + i] = a[j][i], hash_inputs[16 * r + 8 + i] = b[j][i];
+            }
+            trace[(size_t)32 * N + r] = bits[j], trace[(size_t)33 * N + r] = inj, trace[(size_t)34 * N + r] = k == 0, trace[(size_t)35 * N + r] = j == 0;
+            trace[(size_t)36 * N + r] = 1, trace[(size_t)37 * N + r] = idx, trace[(size_t)38 * N + r] = lvl;
+            if (inj || j == 0) {
+                uint32_t *c = &claims[18 * nc++];
+                for (int i = 0; i < 8; i++) c[i] = node[i], c[10 + i] = inj ? b[j][i] : (bits[j] ? b[j][i] : a[j][i]);
+                c[8] = lvl, c[9] = idx;
+            }
+        }
+    }
+    *n_claims = nc;
+    return bad;
+}

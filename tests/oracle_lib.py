@@ -174,6 +174,23 @@ def rv32_divrem_trace(opc, bs, cs, log_height, size_x=256, size_y=2048, tuple_co
     return tr, tc, rc, int(bad)
 
 
+def mmcs_path_trace(leaf, index, path_start, step_kind, step_digest, log_height):
+    """-> (trace [39, N], hash_inputs [rows, 16], claims [n_claims, 18], bad)"""
+    leaf, index, path_start, step_kind, step_digest = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1)
+                                                       for v in (leaf, index, path_start, step_kind, step_digest))
+    n_paths, rows = len(index), int(path_start[-1]) if len(path_start) else 0
+    tr = np.zeros((39, 1 << log_height), np.uint32)
+    hin = np.zeros((max(rows, 1), 16), np.uint32)
+    claims = np.zeros((len(step_kind) + n_paths + 1, 18), np.uint32)
+    nc = C.c_size_t(0)
+    l = lib()
+    l.ora_mmcs_path_trace.restype = C.c_size_t
+    l.ora_mmcs_path_trace.argtypes = [u32p_t()] * 5 + [C.c_size_t, C.c_uint, u32p_t(), u32p_t(), u32p_t(), C.POINTER(C.c_size_t)]
+    bad = l.ora_mmcs_path_trace(p32(leaf), p32(index), p32(path_start), p32(step_kind), p32(step_digest), n_paths, log_height, p32(tr), p32(hin),
+                                p32(claims), C.byref(nc))
+    return tr, hin[:rows], claims[:nc.value], int(bad)
+
+
 def rv32_lt_trace(opc, bs, cs, log_height, range_counts=None):
     opc, bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, bs, cs))
     tr = np.zeros((18, 1 << log_height), np.uint32)

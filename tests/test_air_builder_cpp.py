@@ -67,6 +67,8 @@ PY = {
     "chip_rv32_mulh": lambda: air.rv32_mulh_core_air(),
     "chip_rv32_loadstore": lambda: air.rv32_loadstore_core_air(),
     "chip_rv32_divrem": lambda: air.rv32_divrem_core_air(),
+    "chip_mmcs_path": lambda: air.mmcs_path_air(9, 10),
+    "chip_mmcs_claims": lambda: air.mmcs_claims_air(10),
     "chip_memory_access": lambda: air.memory_access_air(),
     "chip_memory_boundary": lambda: air.memory_boundary_air(),
 }

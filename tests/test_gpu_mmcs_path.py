@@ -1,0 +1,91 @@
+"""GPU: the MMCS path chip -- in-circuit verification of the Merkle openings stored in the REFERENCE'S OWN proofs (a piece of
+the recursion circuit).  Path rows and the Poseidon2 chip's 298 permutation columns are generated on the
+device; path chip + Poseidon2 chip + claims table prove together: every opening of the fixture leads to the commitment its proof
+carries, and the chip's claims are exactly the digests of the opened rows.  Proof bytes == oracle."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import mmcs_path_util as mu  # noqa: E402
+
+import zkvm_prover_amd as z  # noqa: E402
+from zkvm_prover_amd import air  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+NOPV = np.zeros(0, np.uint32)
+PARAMS = (1, 0, 12, 4, 4)
+P = 2013265921
+
+
+@pytest.fixture(scope="module")
+def vec():
+    with open(os.path.join(HERE, "golden", "ref_v1_vectors.json")) as f:
+        return json.load(f)
+
+
+def _airs(ora, leaf, idx, starts, kinds, digs, claims_rows=None):
+    rows = int(starts[-1])
+    lh = max(1, int(np.ceil(np.log2(max(rows, 2)))))
+    tr, hin, claims, bad = ora.mmcs_path_trace(leaf, idx, starts, kinds, digs, lh)
+    assert bad == 0
+    chip = np.zeros((299, 1 << lh), np.uint32)
+    full = np.zeros((1 << lh, 16), np.uint32)
+    full[:rows] = hin
+    chip[:298] = ora.poseidon2_air_trace(full, lh)
+    chip[298, :rows] = 1
+    table = mu.claims_table(claims if claims_rows is None else claims_rows, int(np.ceil(np.log2(max(len(claims), 2)))))
+    A = lambda prog, w, t: dict(program=prog, log_height=int(np.log2(t.shape[1])), width=w, n_pvs=0, trace=t, pvs=NOPV)  # noqa: E731
+    return [A(air.mmcs_path_air(9, 10).program(), 39, tr), A(air.poseidon2_air(9).program(), 299, chip),
+            A(air.mmcs_claims_air(10).program(), 19, table)], lh, rows, claims
+
+
+def test_reference_openings_verified_in_circuit(zk, ora, vec):
+    leaf, idx, starts, kinds, digs, want = mu.records_of_fixture(ora, vec)
+    airs, lh, rows, claims = _airs(ora, leaf, idx, starts, kinds, digs)
+    assert sorted((tuple(c[:8].tolist()), int(c[8]), int(c[9]), tuple(c[10:].tolist())) for c in claims) == sorted(want)
+    dev = zk.device
+    as_dev = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.uint32).view(np.int32)).to(dev)  # noqa: E731
+    d_tr, d_hin = zk.mmcs_path_tracegen(as_dev(leaf), as_dev(idx), as_dev(starts), as_dev(kinds), as_dev(digs), lh)
+    assert (zk.download(d_tr).reshape(39, -1) == airs[0]["trace"]).all()
+    N = 1 << lh
+    d_chip = torch.empty(299 * N, dtype=torch.int32, device=dev)
+    zk.poseidon2_air_tracegen(d_hin, lh, d_chip)
+    d_chip[298 * N:] = zk.upload(airs[1]["trace"][298])
+    assert (zk.download(d_chip).reshape(299, N) == airs[1]["trace"]).all()
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    proof = pk.prove([d_tr, d_chip, zk.upload(airs[2]["trace"].reshape(-1))], [NOPV] * 3)
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 3, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    # one flipped word in one sibling digest: the walk ends in another root, the claims no longer match the table
+    bad = digs.copy()
+    bad[5][0] = (int(bad[5][0]) + 1) % P
+    d_tr2, d_hin2 = zk.mmcs_path_tracegen(as_dev(leaf), as_dev(idx), as_dev(starts), as_dev(kinds), as_dev(bad), lh)
+    zk.poseidon2_air_tracegen(d_hin2, lh, d_chip)
+    d_chip[298 * N:] = zk.upload(airs[1]["trace"][298])
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 3, pk.prove([d_tr2, d_chip, zk.upload(airs[2]["trace"].reshape(-1))], [NOPV] * 3)) != 0
+    pk.close()
+
+
+def test_generator_edge_cases(zk, ora):
+    dev = zk.device
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.uint32).view(np.int32)).to(dev)  # noqa: E731
+    leaf = np.arange(8, dtype=np.uint32).reshape(1, 8)
+    digs = np.arange(16, dtype=np.uint32).reshape(2, 8) + 100
+    # one path of two sibling steps at index 2 into a 4-row trace: rows 0..1 used
+    tr, hin, claims, bad = ora.mmcs_path_trace(leaf, [2], [0, 2], [0, 0], digs, 2)
+    d_tr, d_hin = zk.mmcs_path_tracegen(t(leaf), t([2]), t([0, 2]), t([0, 0]), t(digs), 2)
+    assert bad == 0 and (zk.download(d_tr).reshape(39, -1) == tr).all()
+    assert (zk.download(d_hin).reshape(-1, 16)[:2] == hin).all() and (zk.download(d_hin).reshape(-1, 16)[2:] == 0).all()
+    assert claims[0][8] == 2 and claims[0][9] == 2
+    for starts, kinds in (([0, 2], [1, 0]), ([0, 5], [0] * 5)):   # bottom step an injection; more steps than rows
+        with pytest.raises(z.ZkhipError):
+            zk.mmcs_path_tracegen(t(leaf), t([0]), t(starts), t(kinds), t(np.zeros((len(kinds), 8), np.uint32)), 2)
+    e = torch.empty(0, dtype=torch.int32, device=dev)
+    d_tr, _ = zk.mmcs_path_tracegen(e, e, t([0]), e, e, 1)
+    assert (zk.download(d_tr) == 0).all()

@@ -101,6 +101,7 @@ def load_library():
         "zkhip_rv32_shift_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_branch_eq_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_rv32_branch_lt_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_mmcs_path_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_divrem_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp]),
         "zkhip_rv32_mulh_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp]),
         "zkhip_rv32_loadstore_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
@@ -385,6 +386,17 @@ class Context:
         self._check(self.lib.zkhip_rv32_mul_tracegen(self.h, C.c_void_p(t_b.data_ptr()), C.c_void_p(t_c.data_ptr()), t_b.numel(), log_height,
                                                      C.c_void_p(out.data_ptr()), C.c_void_p(t_tuple_counts.data_ptr()), size_x, size_y))
         return out
+
+    def mmcs_path_tracegen(self, t_leaf, t_index, t_path_start, t_step_kind, t_step_digest, log_height):
+        """(39-column trace of the MMCS path chip, [2^log_height][16] hash inputs for the Poseidon2 chip) from path records (int32
+        tensors of canonical words: leaf digests [n][8], indices [n], step offsets [n + 1], step kinds, step digests [steps][8])."""
+        import torch
+
+        tr = torch.empty(39 << log_height, dtype=torch.int32, device=self.device)
+        hin = torch.empty(16 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_mmcs_path_tracegen(self.h, *[C.c_void_p(t.data_ptr()) for t in (t_leaf, t_index, t_path_start, t_step_kind, t_step_digest)],
+                                                      t_index.numel(), log_height, C.c_void_p(tr.data_ptr()), C.c_void_p(hin.data_ptr())))
+        return tr, hin
 
     def rv32_divrem_tracegen(self, t_opcode, t_b, t_c, log_height, t_tuple_counts, t_bitwise_trace, size_x=256, size_y=2048):
         """41-column trace of the RV32 division core chip from records (int32 tensors: opcode 0 = DIV, 1 = DIVU, 2 = REM, 3 = REMU;

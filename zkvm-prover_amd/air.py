@@ -1459,6 +1459,62 @@ def poseidon2_air(bus=None):
     return b
 
 
+MMCS_PATH_WIDTH = 39
+
+
+def mmcs_path_air(hash_bus, claims_bus):
+    """In-circuit verification of mixed-height Merkle (MMCS) openings -- a piece of the recursion circuit (the aggregation nodes
+    of the reference verify their children's openings this way): columns root[8] | parent[8] | a[8] | b[8] | bit | is_inj |
+    is_first | is_last | is_real | idx | lvl.  A path is walked from the ROOT down, one row per compression:
+      * every row claims parent = compress(a, b) on `hash_bus` (the Poseidon2 chip receives it, air.poseidon2_air(bus));
+      * a sibling row (is_inj = 0) descends into a (bit = 0) or b (bit = 1): the next row's parent; idx' = 2 idx + bit, lvl' = lvl + 1;
+      * an injection row (is_inj = 1, where shorter matrices join the tree: node = compress(inner, digest of their rows))
+        descends into a and reports b on `claims_bus` as (root, lvl, idx, digest) -- the row digest of the matrices of height
+        2^lvl at row idx;
+      * the last row of a path reports the child it would descend into: the leaf digest, at (lvl, idx) = (tree height, index).
+    is_first rows start from parent = root; root is carried down the path, so every claim names its commitment."""
+    b = AirBuilder(MMCS_PATH_WIDTH, 0)
+    root, par = [b.var(i) for i in range(8)], [b.var(8 + i) for i in range(8)]
+    a_, b_ = [b.var(16 + i) for i in range(8)], [b.var(24 + i) for i in range(8)]
+    bit, inj, first, last, real, idx, lvl = (b.var(32 + i) for i in range(7))
+    n_root, n_par = [b.next(i) for i in range(8)], [b.next(8 + i) for i in range(8)]
+    n_bit, n_inj, n_first, n_real, n_idx, n_lvl = b.next(32), b.next(33), b.next(34), b.next(36), b.next(37), b.next(38)
+    for f in (bit, inj, first, last, real):
+        b.assert_zero(f * (f - 1))
+    b.assert_zero(inj * bit)
+    b.assert_zero(first * (1 - real))
+    b.assert_zero(last * (1 - real))
+    b.assert_zero(last * inj)
+    link = real - last                      # 1 where the next row continues this path
+    b.when_first_row(real - first)
+    b.when_last_row(link)
+    b.when_transition(link * (1 - n_real))
+    b.when_transition(link * n_first)
+    b.when_transition(last * n_real * (1 - n_first))
+    b.when_transition((1 - real) * n_real)
+    for i in range(8):
+        b.assert_zero(first * (par[i] - root[i]))
+        b.when_transition(link * (n_root[i] - root[i]))
+        b.when_transition(link * (n_par[i] - a_[i] - bit * (b_[i] - a_[i])))
+    b.assert_zero(first * (idx - bit))
+    b.assert_zero(first * (lvl - 1 + inj))
+    b.when_transition(link * (n_idx - idx * (2 - n_inj) - n_bit))
+    b.when_transition(link * (n_lvl - lvl - 1 + n_inj))
+    b.push_interaction(hash_bus, a_ + b_ + par, real, "send")
+    b.push_interaction(claims_bus, root + [lvl, idx] + b_, inj, "send")
+    b.push_interaction(claims_bus, root + [lvl, idx] + [a_[i] + bit * (b_[i] - a_[i]) for i in range(8)], last, "send")
+    return b
+
+
+def mmcs_claims_air(claims_bus):
+    """The receiving side of mmcs_path_air's claims, as a table: columns root[8] | lvl | idx | digest[8] | mult -- row = "the matrices
+    of height 2^lvl committed under root have digest `digest` at row idx", received mult times.  (In a recursion circuit the
+    sponge over the opened values produces these; as a table it lets the claims be stated and checked.)"""
+    b = AirBuilder(19, 0)
+    b.push_interaction(claims_bus, [b.var(i) for i in range(18)], b.var(18), "receive")
+    return b
+
+
 def hasher_user_air(bus):
     """A chip that needs 2-to-1 compressions (a Merkle-path checker, say): columns left[8] | right[8] | out[8] | is_real;
     it sends (left, right, out) on `bus` when is_real = 1 and relies on the Poseidon2 chip to receive it, i.e. to

@@ -151,9 +151,83 @@ int range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d_values, size_t n, un
     return ZKHIP_OK;
 }
 
+// ---- MMCS path chip: in-circuit verification of mixed-height Merkle openings (air.py mmcs_path_air) ------------------------------
+// One thread per path.  Pass 1 climbs from the leaf (the compressions are the hashes this chip asks the Poseidon2 chip to
+// prove, so the generator computes them once and hands a || b of every row to zkhip_poseidon2_air_tracegen) and writes each
+// row at its final place -- rows run from the root DOWN --; pass 2 descends again with the root and the position counters.
+__global__ __launch_bounds__(64) void k_mmcs_path(const uint32_t* __restrict__ leaf, const uint32_t* __restrict__ index,
+                                                  const uint32_t* __restrict__ path_start, const uint32_t* __restrict__ step_kind,
+                                                  const uint32_t* __restrict__ step_digest, size_t n_paths, size_t N, uint32_t* __restrict__ trace,
+                                                  uint32_t* __restrict__ hash_inputs, uint32_t* __restrict__ bad) {
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (p >= n_paths) return;
+    const size_t s0 = path_start[p], s1 = path_start[p + 1], ns = s1 - s0;
+    if (s1 > N || s1 <= s0 || step_kind[s0] != 0) {
+        atomicAdd(bad, 1u);
+        return;
+    }
+    const uint32_t q = index[p];
+    uint32_t st[16], node[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) node[i] = to_monty(leaf[8 * p + i]);
+    unsigned sibs = 0;
+    for (size_t j = 0; j < ns; j++) {
+        const bool inj = step_kind[s0 + j] != 0;
+        const uint32_t bit = inj ? 0u : (q >> sibs) & 1u;
+        sibs += inj ? 0 : 1;
+        const size_t r = s0 + (ns - 1 - j);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t d = to_monty(step_digest[8 * (s0 + j) + i]);
+            st[i] = bit ? d : node[i], st[8 + i] = bit ? node[i] : d;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) trace[(size_t)(16 + i) * N + r] = st[i], hash_inputs[16 * r + i] = st[i];
+        poseidon2_permute_rolled(st);
+#pragma unroll
+        for (int i = 0; i < 8; i++) node[i] = st[i], trace[(size_t)(8 + i) * N + r] = st[i];
+    }
+    uint32_t idx = 0, lvl = 0;
+    for (size_t k = 0; k < ns; k++) {
+        const size_t j = ns - 1 - k, r = s0 + k;
+        const bool inj = step_kind[s0 + j] != 0;
+        sibs -= inj ? 0 : 1;
+        const uint32_t bit = inj ? 0u : (q >> sibs) & 1u;
+        idx = idx * (inj ? 1u : 2u) + bit, lvl += inj ? 0u : 1u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) trace[(size_t)i * N + r] = node[i];
+        trace[(size_t)32 * N + r] = bit ? MONTY_ONE : 0u, trace[(size_t)33 * N + r] = inj ? MONTY_ONE : 0u;
+        trace[(size_t)34 * N + r] = k == 0 ? MONTY_ONE : 0u, trace[(size_t)35 * N + r] = j == 0 ? MONTY_ONE : 0u;
+        trace[(size_t)36 * N + r] = MONTY_ONE, trace[(size_t)37 * N + r] = to_monty(idx), trace[(size_t)38 * N + r] = to_monty(lvl);
+    }
+}
+
 }  // namespace zk
 
 using namespace zk;
+extern "C" int zkhip_mmcs_path_tracegen(zkhip_ctx* ctx, const uint32_t* d_leaf, const uint32_t* d_index, const uint32_t* d_path_start,
+                                        const uint32_t* d_step_kind, const uint32_t* d_step_digest, size_t n_paths, unsigned log_height,
+                                        uint32_t* d_trace, uint32_t* d_hash_inputs) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_hash_inputs || log_height > 27 || (n_paths && (!d_leaf || !d_index || !d_path_start || !d_step_kind || !d_step_digest)))
+        return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "mmcs_path_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(d_trace, 0, (size_t)ZKHIP_MMCS_PATH_WIDTH * N * 4, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(d_hash_inputs, 0, 16 * N * 4, ctx->stream));
+    if (n_paths)
+        hipLaunchKernelGGL(k_mmcs_path, dim3((unsigned)((n_paths + 63) / 64)), dim3(64), 0, ctx->stream, d_leaf, d_index, d_path_start, d_step_kind,
+                           d_step_digest, n_paths, N, d_trace, d_hash_inputs, (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    uint32_t h_bad = 0;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_bad) return set_error(ctx, ZKHIP_ERR_INVALID, "mmcs_path_tracegen: " + std::to_string(h_bad) + " paths do not fit the trace or do not end in a sibling step");
+    return ZKHIP_OK;
+}
 extern "C" int zkhip_range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d_values, size_t n, unsigned log_table,
                                            uint32_t* d_counts, int accumulate) {
     ZK_BIND_DEVICE(ctx);
