@@ -871,6 +871,70 @@ inline void mmcs_path_air(AirBuilder& b, uint32_t hash_bus, uint32_t claims_bus)
     }
 }
 
+// air.fri_fold_air(): AirBuilder(18, 0) -- one arity-2 FRI folding step per row
+inline void fri_fold_air(AirBuilder& b) {
+    Expr e0[4], e1[4], beta[4], folded[4], d[4];
+    for (int i = 0; i < 4; i++) e0[i] = b.var(i);
+    for (int i = 0; i < 4; i++) e1[i] = b.var(4 + i);
+    for (int i = 0; i < 4; i++) beta[i] = b.var(8 + i);
+    const Expr xinv = b.var(12);
+    for (int i = 0; i < 4; i++) folded[i] = b.var(13 + i);
+    const Expr real = b.var(17);
+    {
+        const Expr t = real - 1;
+        b.assert_zero(real * t);
+    }
+    for (int i = 0; i < 4; i++) d[i] = e0[i] - e1[i];
+    auto mul = [&](int i, int j) { return beta[i] * d[j]; };
+    Expr prod[4];
+    {
+        const Expr t0 = mul(0, 0);
+        const Expr t1 = mul(1, 3);
+        const Expr t2 = mul(2, 2);
+        const Expr s1 = t1 + t2;
+        const Expr t3 = mul(3, 1);
+        const Expr s2 = s1 + t3;
+        const Expr w = s2 * 11;
+        prod[0] = t0 + w;
+    }
+    {
+        const Expr t0 = mul(0, 1);
+        const Expr t1 = mul(1, 0);
+        const Expr s0 = t0 + t1;
+        const Expr t2 = mul(2, 3);
+        const Expr t3 = mul(3, 2);
+        const Expr s1 = t2 + t3;
+        const Expr w = s1 * 11;
+        prod[1] = s0 + w;
+    }
+    {
+        const Expr t0 = mul(0, 2);
+        const Expr t1 = mul(1, 1);
+        const Expr s0 = t0 + t1;
+        const Expr t2 = mul(2, 0);
+        const Expr s1 = s0 + t2;
+        const Expr t3 = mul(3, 3);
+        const Expr w = t3 * 11;
+        prod[2] = s1 + w;
+    }
+    {
+        const Expr t0 = mul(0, 3);
+        const Expr t1 = mul(1, 2);
+        const Expr s0 = t0 + t1;
+        const Expr t2 = mul(2, 1);
+        const Expr s1 = s0 + t2;
+        const Expr t3 = mul(3, 0);
+        prod[3] = s1 + t3;
+    }
+    for (int i = 0; i < 4; i++) {
+        const Expr f2 = folded[i] * 2;
+        const Expr a = f2 - e0[i];
+        const Expr c = a - e1[i];
+        const Expr xp = xinv * prod[i];
+        b.assert_zero(c - xp);
+    }
+}
+
 // air.mmcs_claims_air(claims_bus): AirBuilder(19, 0)
 inline void mmcs_claims_air(AirBuilder& b, uint32_t claims_bus) {
     std::vector<Expr> msg;

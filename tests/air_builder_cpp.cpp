@@ -170,6 +170,7 @@ int main() {
         { AirBuilder b(41, 0); ch::rv32_divrem_core_air(b); dump("chip_rv32_divrem", b); }
         { AirBuilder b(39, 0); ch::mmcs_path_air(b, 9, 10); dump("chip_mmcs_path", b); }
         { AirBuilder b(19, 0); ch::mmcs_claims_air(b, 10); dump("chip_mmcs_claims", b); }
+        { AirBuilder b(18, 0); ch::fri_fold_air(b); dump("chip_fri_fold", b); }
         { AirBuilder b(10, 0); ch::memory_access_air(b); dump("chip_memory_access", b); }
         { AirBuilder b(8, 0); ch::memory_boundary_air(b); dump("chip_memory_boundary", b); }
     }

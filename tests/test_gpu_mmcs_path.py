@@ -89,3 +89,20 @@ def test_generator_edge_cases(zk, ora):
     e = torch.empty(0, dtype=torch.int32, device=dev)
     d_tr, _ = zk.mmcs_path_tracegen(e, e, t([0]), e, e, 1)
     assert (zk.download(d_tr) == 0).all()
+
+
+def test_reference_fri_fold_steps_proven(zk, ora, vec):
+    """The FRI fold chip (air.fri_fold_air) on the sibling pairs stored in the reference's proofs: the rows prove (JIT and
+    interpreter paths alike: bytes == oracle) and a wrong folded value is refused at keygen-free proving time by the verifier."""
+    from test_fri_fold_chip_cpu import fold_trace
+
+    tr, n, lh = fold_trace(vec)
+    airs = [dict(program=air.fri_fold_air().program(), log_height=lh, width=18, n_pvs=0, trace=tr, pvs=NOPV)]
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    proof = pk.prove([zk.upload(tr.reshape(-1))], [NOPV])
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV], proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    w = tr.copy()
+    w[13][0] = (int(w[13][0]) + 1) % P
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV], pk.prove([zk.upload(w.reshape(-1))], [NOPV])) != 0
+    pk.close()

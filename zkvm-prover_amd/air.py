@@ -1515,6 +1515,29 @@ def mmcs_claims_air(claims_bus):
     return b
 
 
+FRI_FOLD_WIDTH = 18
+
+
+def fri_fold_air():
+    """One FRI folding step per row, in-circuit (p3 `TwoAdicFriFolding::fold_row`, arity 2) -- another piece of the recursion
+    circuit: columns e0[4] | e1[4] | beta[4] | x_inv | folded[4] | is_real.  e0, e1 are the sibling evaluations at x and -x,
+    x_inv = 1 / x in the base field; folded = (e0 + e1) / 2 + beta (e0 - e1) x_inv / 2 in the quartic extension (X^4 = 11),
+    stated as 2 folded = (e0 + e1) + x_inv (beta * (e0 - e1)), coordinate by coordinate (degree 3)."""
+    b = AirBuilder(FRI_FOLD_WIDTH, 0)
+    e0, e1, beta = [b.var(i) for i in range(4)], [b.var(4 + i) for i in range(4)], [b.var(8 + i) for i in range(4)]
+    xinv, folded, real = b.var(12), [b.var(13 + i) for i in range(4)], b.var(17)
+    b.assert_zero(real * (real - 1))
+    d = [e0[i] - e1[i] for i in range(4)]
+    W = 11
+    prod = [beta[0] * d[0] + (beta[1] * d[3] + beta[2] * d[2] + beta[3] * d[1]) * W,
+            beta[0] * d[1] + beta[1] * d[0] + (beta[2] * d[3] + beta[3] * d[2]) * W,
+            beta[0] * d[2] + beta[1] * d[1] + beta[2] * d[0] + beta[3] * d[3] * W,
+            beta[0] * d[3] + beta[1] * d[2] + beta[2] * d[1] + beta[3] * d[0]]
+    for i in range(4):
+        b.assert_zero(folded[i] * 2 - e0[i] - e1[i] - xinv * prod[i])    # all-zero padding rows satisfy it as they are
+    return b
+
+
 def hasher_user_air(bus):
     """A chip that needs 2-to-1 compressions (a Merkle-path checker, say): columns left[8] | right[8] | out[8] | is_real;
     it sends (left, right, out) on `bus` when is_real = 1 and relies on the Poseidon2 chip to receive it, i.e. to
