@@ -457,6 +457,8 @@ inline Exe load_elf(const std::vector<uint8_t>& f, uint32_t stack_bytes = 1u << 
     }
     if (!have_text) throw Error("no executable segment");
     if (entry < exe.pc_base || entry >= exe.pc_base + 4 * (uint64_t)exe.program.size()) throw Error("entry point outside the text segment");
+    // the chips hold a pc as one BabyBear element and compose pc + 4 from limbs of 30 bits (OpenVM's PC_BITS): link the guest low
+    if ((uint64_t)exe.pc_base + 4 * (uint64_t)exe.program.size() >= (1ull << 30)) throw Error("text segment must lie below 2^30");
     if (data.empty()) lo = hi = exe.data_base;
     lo &= ~3ull;
     if (hi - lo + stack_bytes > (1ull << 30)) throw Error("data image too large");
@@ -504,6 +506,7 @@ inline Exe parse_exe(const std::vector<uint8_t>& raw) {
     if (word(0) != 0x58455A4Bu) throw Error("bad exe magic");
     Exe exe;
     exe.pc_base = word(1);
+    if ((uint64_t)exe.pc_base + 4 * (uint64_t)word(2) >= (1ull << 30)) throw Error("text segment must lie below 2^30");
     const size_t n_prog = word(2);
     if (n_prog > raw.size() / 4) throw Error("exe truncated");
     for (size_t i = 0; i < n_prog; i++) exe.program.push_back(word(3 + i));

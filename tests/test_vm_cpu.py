@@ -322,3 +322,14 @@ def test_build_guest_input_stream(tmp_path):
     assert bytes.fromhex(pv_hex) == model["pvs"] and int(cycles) == model["instret"]
     total = sum(int.from_bytes(stream[i:i + 4], "little") for i in range(0, len(stream), 4)) & 0xFFFFFFFF
     assert int.from_bytes(model["pvs"][:4], "little") == total and model["pvs"][4] == 3
+
+
+def test_text_segment_must_lie_below_two_to_the_30(tmp_path):
+    """The chips hold a pc as one BabyBear element (and compose pc + 4 from 30 bits of limbs, OpenVM's PC_BITS): an image linked
+    at the usual bare-metal 0x80000000 is refused by the loader with a clear message instead of by a trace generator later."""
+    exe = tmp_path / "high.elf"
+    exe.write_bytes(rv.elf_bytes(fib_program(), text_vaddr=0x80000000))
+    inp = tmp_path / "stdin.bin"
+    inp.write_bytes((5).to_bytes(4, "little"))
+    r = subprocess.run([VM, "exec", str(exe), str(inp), "-"], capture_output=True, text=True)
+    assert r.returncode != 0 and "below 2^30" in r.stderr
