@@ -95,15 +95,17 @@ int poseidon2_air_tracegen(zkhip_ctx* ctx, const uint32_t* d_inputs, size_t n_pe
 // Tables of <= 2^13 entries are counted in a per-workgroup LDS histogram (32 KiB) and merged with one atomic per
 // non-zero bin; larger tables count straight into HBM.  `bad` receives the number of out-of-range values.
 constexpr unsigned RC_LDS_LOG = 13;
+// Every workgroup counts the values below 2^13 in an LDS histogram (32 KiB) and merges it with one atomic per non-zero bin;
+// larger values go straight to HBM through the wave-aggregated increment.  The split is by VALUE, not by table size: what
+// makes a global histogram slow is a hot bin, and the hot bins of range-check columns are the small values (timestamp gaps,
+// carries, high limbs) -- a 2^16-entry table fed with a guest's memory log took 0.83 ms per 2.8 M values while all 11 k waves
+// sent their aggregated increments to the same few addresses.
 __global__ __launch_bounds__(256) void k_range_counts(const uint32_t* __restrict__ values, size_t n, unsigned log_table,
                                                       uint32_t* __restrict__ hist, uint32_t* __restrict__ bad) {
-    extern __shared__ uint32_t bins[];
-    const uint32_t T = 1u << log_table;
-    const bool use_lds = log_table <= RC_LDS_LOG;
-    if (use_lds) {
-        for (uint32_t i = threadIdx.x; i < T; i += 256) bins[i] = 0;
-        __syncthreads();
-    }
+    __shared__ uint32_t bins[1u << RC_LDS_LOG];
+    const uint32_t T = 1u << log_table, L = T < (1u << RC_LDS_LOG) ? T : (1u << RC_LDS_LOG);
+    for (uint32_t i = threadIdx.x; i < L; i += 256) bins[i] = 0;
+    __syncthreads();
     uint32_t n_bad = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const uint32_t v = from_monty(values[i]);
@@ -111,14 +113,13 @@ __global__ __launch_bounds__(256) void k_range_counts(const uint32_t* __restrict
             n_bad++;
             continue;
         }
-        hist_add(use_lds ? bins : hist, v);
+        if (v < L) atomicAdd(&bins[v], 1u);
+        else hist_add(hist, v);
     }
     if (n_bad) atomicAdd(bad, n_bad);
-    if (use_lds) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < T; i += 256)
-            if (bins[i]) atomicAdd(&hist[i], bins[i]);
-    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < L; i += 256)
+        if (bins[i]) atomicAdd(&hist[i], bins[i]);
 }
 // integer histogram <-> Montgomery counts (counts stay far below p: at most 2^27 rows x a few hundred columns per call,
 // and the sum is reduced mod p, which is what the bus argument needs anyway)
@@ -138,9 +139,8 @@ int range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d_values, size_t n, un
     if (accumulate) hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
     else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
     if (n) {
-        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 16 - 1) / (256 * 16), 4096);
-        hipLaunchKernelGGL(k_range_counts, dim3(blocks), dim3(256), log_table <= RC_LDS_LOG ? T * 4 : 0, ctx->stream, d_values, n,
-                           log_table, d_counts, (uint32_t*)flag);
+        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 32 - 1) / (256 * 32), 1024);
+        hipLaunchKernelGGL(k_range_counts, dim3(blocks), dim3(256), 0, ctx->stream, d_values, n, log_table, d_counts, (uint32_t*)flag);
     }
     hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <string>
 
 #include "../../include/zkhip.h"
@@ -326,13 +327,23 @@ extern "C" int zkhip_rv32_mul_tracegen(zkhip_ctx* ctx, const uint32_t* d_b, cons
 //   k_exec_frames   : gather    -> frame rows [9 program fields | is_valid]
 namespace zk {
 namespace {
+// a loop's instructions are the hot bins of this histogram: the workgroup counts the program's first 2^13 rows in LDS and merges
+// once (k_range_counts in tracegen.hip has the measurements), rows beyond that go to HBM through the wave-aggregated increment
 __global__ __launch_bounds__(256) void k_program_freq(const uint32_t* __restrict__ idx, size_t n, size_t N, uint32_t* __restrict__ freq,
                                                       uint32_t* __restrict__ bad) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = idx[i];
-    if (k >= N) atomicAdd(bad, 1u);
-    else hist_add(freq, k);
+    __shared__ uint32_t bins[1u << 13];
+    const uint32_t L = N < (1u << 13) ? (uint32_t)N : (1u << 13);
+    for (uint32_t i = threadIdx.x; i < L; i += 256) bins[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t k = idx[i];
+        if (k >= N) atomicAdd(bad, 1u);
+        else if (k < L) atomicAdd(&bins[k], 1u);
+        else hist_add(freq, k);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < L; i += 256)
+        if (bins[i]) atomicAdd(&freq[i], bins[i]);
 }
 __global__ __launch_bounds__(256) void k_exec_frames(const uint32_t* __restrict__ idx, size_t n, const uint32_t* __restrict__ program,
                                                      size_t n_program, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
@@ -357,7 +368,9 @@ extern "C" int zkhip_program_freq_tracegen(zkhip_ctx* ctx, const uint32_t* d_pc_
     KernelScope ks(ctx, "program_freq_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     ZK_HIP_CHECK(ctx, hipMemsetAsync(d_freq, 0, N * 4, ctx->stream));
-    if (n) hipLaunchKernelGGL(k_program_freq, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_pc_index, n, N, d_freq, (uint32_t*)flag);
+    if (n)
+        hipLaunchKernelGGL(k_program_freq, dim3((unsigned)std::min<size_t>((n + 256 * 32 - 1) / (256 * 32), 1024)), dim3(256), 0, ctx->stream, d_pc_index, n, N,
+                           d_freq, (uint32_t*)flag);
     hipLaunchKernelGGL(k_tab_repr, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_freq, N, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "program_freq_tracegen (instruction index beyond the program)");
