@@ -254,6 +254,19 @@ int zkhip_mmcs_path_tracegen(zkhip_ctx *ctx, const uint32_t *d_leaf, const uint3
                              const uint32_t *d_step_kind, const uint32_t *d_step_digest, size_t n_paths, unsigned log_height, uint32_t *d_trace,
                              uint32_t *d_hash_inputs);
 
+/* NATIVE chips -- the arithmetic of the recursion programs the aggregation circuits run (native FieldArithmeticCoreAir,
+ * FieldExtensionCoreAir).  Records are canonical field elements: (d_opcode[i]: 0 = ADD, 1 = SUB, 2 = MUL, 3 = DIV; operands).
+ * zkhip_field_arith_tracegen: ZKHIP_FIELD_ARITH_WIDTH = 8 columns a = b op c | b | c | 4 opcode flags | divisor_inv.
+ * zkhip_field_ext_tracegen: operands are quartic-extension elements, four words per record in d_x / d_y (16-byte aligned);
+ * ZKHIP_FIELD_EXT_WIDTH = 20 columns x[4] | y[4] | z[4] = x op y | 4 opcode flags | divisor_inv[4].  Rows >= n zero; Montgomery;
+ * ZKHIP_ERR_INVALID on an opcode > 3, an operand >= p or a division by zero.  AIRs: air.py field_arith_air(), field_ext_air(). */
+#define ZKHIP_FIELD_ARITH_WIDTH 8
+#define ZKHIP_FIELD_EXT_WIDTH 20
+int zkhip_field_arith_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_b, const uint32_t *d_c, size_t n, unsigned log_height,
+                               uint32_t *d_trace);
+int zkhip_field_ext_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_x, const uint32_t *d_y, size_t n, unsigned log_height,
+                             uint32_t *d_trace);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

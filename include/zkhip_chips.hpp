@@ -871,6 +871,130 @@ inline void mmcs_path_air(AirBuilder& b, uint32_t hash_bus, uint32_t claims_bus)
     }
 }
 
+// air._ext_mul_exprs(x, y): coordinates of x * y in F[X] / (X^4 - 11), node for node as the Python helper builds them
+inline void ext_mul_exprs(const Expr x[4], const Expr y[4], Expr out[4]) {
+    {
+        const Expr t0 = x[0] * y[0];
+        const Expr t1 = x[1] * y[3];
+        const Expr t2 = x[2] * y[2];
+        const Expr s1 = t1 + t2;
+        const Expr t3 = x[3] * y[1];
+        const Expr s2 = s1 + t3;
+        const Expr w = s2 * 11;
+        out[0] = t0 + w;
+    }
+    {
+        const Expr t0 = x[0] * y[1];
+        const Expr t1 = x[1] * y[0];
+        const Expr s0 = t0 + t1;
+        const Expr t2 = x[2] * y[3];
+        const Expr t3 = x[3] * y[2];
+        const Expr s1 = t2 + t3;
+        const Expr w = s1 * 11;
+        out[1] = s0 + w;
+    }
+    {
+        const Expr t0 = x[0] * y[2];
+        const Expr t1 = x[1] * y[1];
+        const Expr s0 = t0 + t1;
+        const Expr t2 = x[2] * y[0];
+        const Expr s1 = s0 + t2;
+        const Expr t3 = x[3] * y[3];
+        const Expr w = t3 * 11;
+        out[2] = s1 + w;
+    }
+    {
+        const Expr t0 = x[0] * y[3];
+        const Expr t1 = x[1] * y[2];
+        const Expr s0 = t0 + t1;
+        const Expr t2 = x[2] * y[1];
+        const Expr s1 = s0 + t2;
+        const Expr t3 = x[3] * y[0];
+        out[3] = s1 + t3;
+    }
+}
+
+// air.field_arith_air(): AirBuilder(8, 0) -- native base-field ADD / SUB / MUL / DIV
+inline void field_arith_air(AirBuilder& b) {
+    const Expr a_ = b.var(0), b_ = b.var(1), c_ = b.var(2), add = b.var(3), sub = b.var(4), mul = b.var(5), div = b.var(6), inv = b.var(7);
+    const Expr ok0 = add + sub;
+    const Expr ok1 = ok0 + mul;
+    const Expr ok = ok1 + div;
+    for (const Expr& f : {add, sub, mul, div, ok}) {
+        const Expr t = f - 1;
+        b.assert_zero(f * t);
+    }
+    {
+        const Expr d = a_ - b_;
+        const Expr e = d - c_;
+        b.assert_zero(add * e);
+    }
+    {
+        const Expr d = a_ - b_;
+        const Expr e = d + c_;
+        b.assert_zero(sub * e);
+    }
+    {
+        const Expr m = b_ * c_;
+        const Expr e = a_ - m;
+        b.assert_zero(mul * e);
+    }
+    {
+        const Expr m = a_ * c_;
+        const Expr e = b_ - m;
+        b.assert_zero(div * e);
+    }
+    {
+        const Expr m = c_ * inv;
+        const Expr e = m - 1;
+        b.assert_zero(div * e);
+    }
+}
+
+// air.field_ext_air(): AirBuilder(20, 0) -- native extension-field ADD / SUB / MUL / DIV
+inline void field_ext_air(AirBuilder& b) {
+    Expr x[4], y[4], z[4], inv[4], xy[4], xi[4], yi[4];
+    for (int i = 0; i < 4; i++) x[i] = b.var(i);
+    for (int i = 0; i < 4; i++) y[i] = b.var(4 + i);
+    for (int i = 0; i < 4; i++) z[i] = b.var(8 + i);
+    const Expr add = b.var(12), sub = b.var(13), mul = b.var(14), div = b.var(15);
+    for (int i = 0; i < 4; i++) inv[i] = b.var(16 + i);
+    const Expr ok0 = add + sub;
+    const Expr ok1 = ok0 + mul;
+    const Expr ok = ok1 + div;
+    for (const Expr& f : {add, sub, mul, div, ok}) {
+        const Expr t = f - 1;
+        b.assert_zero(f * t);
+    }
+    ext_mul_exprs(x, y, xy);
+    ext_mul_exprs(x, inv, xi);
+    ext_mul_exprs(y, inv, yi);
+    for (int i = 0; i < 4; i++) {
+        {
+            const Expr d = z[i] - x[i];
+            const Expr e = d - y[i];
+            b.assert_zero(add * e);
+        }
+        {
+            const Expr d = z[i] - x[i];
+            const Expr e = d + y[i];
+            b.assert_zero(sub * e);
+        }
+        {
+            const Expr e = z[i] - xy[i];
+            b.assert_zero(mul * e);
+        }
+        {
+            const Expr e = z[i] - xi[i];
+            b.assert_zero(div * e);
+        }
+        {
+            const Expr e = yi[i] - (i == 0 ? 1 : 0);
+            b.assert_zero(div * e);
+        }
+    }
+}
+
 // air.fri_fold_air(): AirBuilder(18, 0) -- one arity-2 FRI folding step per row
 inline void fri_fold_air(AirBuilder& b) {
     Expr e0[4], e1[4], beta[4], folded[4], d[4];

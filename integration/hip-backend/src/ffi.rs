@@ -21,6 +21,8 @@ pub const ZKHIP_RV32_LT_WIDTH: usize = 18;
 pub const ZKHIP_RV32_SHIFT_WIDTH: usize = 32;
 pub const ZKHIP_RV32_BRANCH_EQ_WIDTH: usize = 17;
 pub const ZKHIP_RV32_BRANCH_LT_WIDTH: usize = 23;
+pub const ZKHIP_FIELD_ARITH_WIDTH: usize = 8;
+pub const ZKHIP_FIELD_EXT_WIDTH: usize = 20;
 pub const ZKHIP_MMCS_PATH_WIDTH: usize = 39;
 pub const ZKHIP_RV32_MULH_WIDTH: usize = 21;
 pub const ZKHIP_RV32_DIVREM_WIDTH: usize = 41;
@@ -182,6 +184,10 @@ extern "C" {
                                      d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_rv32_branch_lt_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_a: *const u32, d_b: *const u32, d_imm: *const u32, n: usize,
                                          log_height: c_uint, d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_field_arith_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_b: *const u32, d_c: *const u32, n: usize, log_height: c_uint,
+                                      d_trace: *mut u32) -> c_int;
+    pub fn zkhip_field_ext_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_x: *const u32, d_y: *const u32, n: usize, log_height: c_uint,
+                                    d_trace: *mut u32) -> c_int;
     pub fn zkhip_mmcs_path_tracegen(ctx: *mut zkhip_ctx, d_leaf: *const u32, d_index: *const u32, d_path_start: *const u32, d_step_kind: *const u32,
                                     d_step_digest: *const u32, n_paths: usize, log_height: c_uint, d_trace: *mut u32, d_hash_inputs: *mut u32) -> c_int;
     pub fn zkhip_rv32_divrem_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_b: *const u32, d_c: *const u32, n: usize, log_height: c_uint,

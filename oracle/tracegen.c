@@ -690,3 +690,52 @@ size_t ora_mmcs_path_trace(const uint32_t *leaf, const uint32_t *index, const ui
     *n_claims = nc;
     return bad;
 }
+
+/* Native field-arithmetic core (zkhip_field_arith_tracegen): 8 columns a | b | c | is_add is_sub is_mul is_div | divisor_inv, canonical.
+ * Record = (opcode 0 = ADD, 1 = SUB, 2 = MUL, 3 = DIV; b; c) field elements.  Returns the number of bad records (opcode > 3,
+ * operand >= p, division by zero). */
+size_t ora_field_arith_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 8; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t op = opc[r], b = bs[r], c = cs[r];
+        if (op > 3 || b >= ORA_P || c >= ORA_P || (op == 3 && c == 0)) {
+            bad++;
+            continue;
+        }
+        const uint32_t inv = op == 3 ? ora_inv(c) : 0;
+        trace[0 * N + r] = op == 0 ? ora_add(b, c) : op == 1 ? ora_sub(b, c) : op == 2 ? ora_mul(b, c) : ora_mul(b, inv);
+        trace[1 * N + r] = b, trace[2 * N + r] = c, trace[(size_t)(3 + op) * N + r] = 1, trace[7 * N + r] = inv;
+    }
+    return bad;
+}
+
+/* Native field-extension core (zkhip_field_ext_tracegen): 20 columns x[4] | y[4] | z[4] | is_add is_sub is_mul is_div | divisor_inv[4];
+ * record = (opcode 0..3; x[4]; y[4]) with xs / ys holding four words per record. */
+size_t ora_field_ext_trace(const uint32_t *opc, const uint32_t *xs, const uint32_t *ys, size_t n, unsigned log_height, uint32_t *trace) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 20; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t op = opc[r], *x = xs + 4 * r, *y = ys + 4 * r;
+        int ok = op <= 3;
+        for (int i = 0; i < 4; i++) ok = ok && x[i] < ORA_P && y[i] < ORA_P;
+        if (ok && op == 3 && !(y[0] | y[1] | y[2] | y[3])) ok = 0;
+        if (!ok) {
+            bad++;
+            continue;
+        }
+        uint32_t z[4], inv[4] = {0, 0, 0, 0};
+        if (op == 0) for (int i = 0; i < 4; i++) z[i] = ora_add(x[i], y[i]);
+        else if (op == 1) for (int i = 0; i < 4; i++) z[i] = ora_sub(x[i], y[i]);
+        else if (op == 2) ora_ext_mul(x, y, z);
+        else ora_ext_inv(y, inv), ora_ext_mul(x, inv, z);
+        for (int i = 0; i < 4; i++)
+            trace[(size_t)i * N + r] = x[i], trace[(size_t)(4 + i) * N + r] = y[i], trace[(size_t)(8 + i) * N + r] = z[i], trace[(size_t)(16 + i) * N + r] = inv[i];
+        trace[(size_t)(12 + op) * N + r] = 1;
+    }
+    return bad;
+}

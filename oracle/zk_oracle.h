@@ -118,6 +118,8 @@ size_t ora_rv32_divrem_trace(const uint32_t *opc, const uint32_t *bs, const uint
 size_t ora_mmcs_path_trace(const uint32_t *leaf, const uint32_t *index, const uint32_t *path_start, const uint32_t *step_kind,
                            const uint32_t *step_digest, size_t n_paths, unsigned log_height, uint32_t *trace, uint32_t *hash_inputs,
                            uint32_t *claims, size_t *n_claims);
+size_t ora_field_arith_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace);
+size_t ora_field_ext_trace(const uint32_t *opc, const uint32_t *xs, const uint32_t *ys, size_t n, unsigned log_height, uint32_t *trace);
 size_t ora_rv32_lt_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace,
                          uint32_t *range_counts);
 size_t ora_program_freq_trace(const uint32_t *idx, size_t n, unsigned log_height, uint32_t *freq);

@@ -171,6 +171,8 @@ int main() {
         { AirBuilder b(39, 0); ch::mmcs_path_air(b, 9, 10); dump("chip_mmcs_path", b); }
         { AirBuilder b(19, 0); ch::mmcs_claims_air(b, 10); dump("chip_mmcs_claims", b); }
         { AirBuilder b(18, 0); ch::fri_fold_air(b); dump("chip_fri_fold", b); }
+        { AirBuilder b(8, 0); ch::field_arith_air(b); dump("chip_field_arith", b); }
+        { AirBuilder b(20, 0); ch::field_ext_air(b); dump("chip_field_ext", b); }
         { AirBuilder b(10, 0); ch::memory_access_air(b); dump("chip_memory_access", b); }
         { AirBuilder b(8, 0); ch::memory_boundary_air(b); dump("chip_memory_boundary", b); }
     }

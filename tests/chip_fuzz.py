@@ -130,5 +130,18 @@ for r in range(n_rounds):
     exp, rc, _ = ora.rv32_loadstore_trace(cs, a, b, lh)
     check("loadstore", dl(zk.rv32_loadstore_tracegen(as_dev(cs), as_dev(a), as_dev(b), lh, d), 33), exp)
     check("loadstore range", dl(d, 2)[0], rc)
-    rows += 13 * n
+    # native field chips (operands are field elements; divisors non-zero)
+    op = rng.integers(0, 4, n).astype(np.uint32)
+    fb, fc = (a % P).astype(np.uint32), (b % (P - 1) + 1).astype(np.uint32)
+    exp, bad = ora.field_arith_trace(op, fb, fc, lh)
+    assert bad == 0
+    check("field_arith", dl(zk.field_arith_tracegen(as_dev(op), as_dev(fb), as_dev(fc), lh), 8), exp)
+    if n:
+        fx = rng.integers(0, P, (n, 4)).astype(np.uint32)
+        fy = rng.integers(0, P, (n, 4)).astype(np.uint32)
+        fy[:, 0] |= 1
+        exp, bad = ora.field_ext_trace(op, fx, fy, lh)
+        assert bad == 0
+        check("field_ext", dl(zk.field_ext_tracegen(as_dev(op), as_dev(fx), as_dev(fy), lh), 20), exp)
+    rows += 15 * n
 print(f"{n_rounds} rounds, {rows} records, 0 mismatches, {time.time() - t0:.1f} s")

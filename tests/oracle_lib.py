@@ -191,6 +191,24 @@ def mmcs_path_trace(leaf, index, path_start, step_kind, step_digest, log_height)
     return tr, hin[:rows], claims[:nc.value], int(bad)
 
 
+def _plain_trace(fn, width, cols, n, log_height):
+    cols = [np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in cols]
+    tr = np.zeros((width, 1 << log_height), np.uint32)
+    f = getattr(lib(), fn)
+    f.restype = C.c_size_t
+    f.argtypes = [u32p_t()] * len(cols) + [C.c_size_t, C.c_uint, u32p_t()]
+    bad = f(*[p32(c) for c in cols], n, log_height, p32(tr))
+    return tr, int(bad)
+
+
+def field_arith_trace(opc, b, c, log_height):
+    return _plain_trace("ora_field_arith_trace", 8, (opc, b, c), len(np.asarray(opc).reshape(-1)), log_height)
+
+
+def field_ext_trace(opc, x, y, log_height):
+    return _plain_trace("ora_field_ext_trace", 20, (opc, x, y), len(np.asarray(opc).reshape(-1)), log_height)
+
+
 def rv32_lt_trace(opc, bs, cs, log_height, range_counts=None):
     opc, bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, bs, cs))
     tr = np.zeros((18, 1 << log_height), np.uint32)

@@ -727,3 +727,57 @@ def test_rv32_divrem_chip(zk, ora):
     wrong[8][300] = (int(wrong[8][300]) + 1) % 256
     assert z.verify(params, pk.verifying_airs(), [NOPV] * 3, pk.prove([zk.upload(wrong.reshape(-1)), d_tab, d_bw], [NOPV] * 3)) != 0
     pk.close()
+
+
+def test_native_field_chips(zk, ora):
+    """The native field-arithmetic and field-extension chips (OpenVM native FieldArithmeticCoreAir / FieldExtensionCoreAir: what
+    the recursion programs of the aggregation circuits compute with) from records on the device, one field inversion per division:
+    cells == oracle, results == Python's modular arithmetic, the AIRs hold and catch a wrong result, division by zero is refused;
+    both chips prove from the device-resident traces (bytes == oracle)."""
+    rng = np.random.default_rng(59)
+    n, lh = 3000, 12
+    op = rng.integers(0, 4, n).astype(np.uint32)
+    b = rng.integers(0, P, n).astype(np.uint32)
+    c = rng.integers(1, P, n).astype(np.uint32)
+    b[:4], c[:4] = [0, P - 1, 1, P - 1], [1, P - 1, P - 1, 2]
+    as_dev = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.uint32).view(np.int32)).to(zk.device)  # noqa: E731
+    exp, bad = ora.field_arith_trace(op, b, c, lh)
+    want = [(int(x) + int(y)) % P if o == 0 else (int(x) - int(y)) % P if o == 1 else int(x) * int(y) % P if o == 2 else int(x) * pow(int(y), P - 2, P) % P
+            for o, x, y in zip(op, b, c)]
+    assert bad == 0 and (exp[0][:n] == np.array(want, np.uint32)).all()
+    prog_a = air.field_arith_air().program()
+    assert air.check_trace(prog_a, exp, NOPV) == []
+    w = exp.copy()
+    w[0][7] = (int(w[0][7]) + 1) % P
+    assert air.check_trace(prog_a, w, NOPV) != []
+    d_a = zk.field_arith_tracegen(as_dev(op), as_dev(b), as_dev(c), lh)
+    assert (zk.download(d_a).reshape(8, -1) == exp).all()
+    with pytest.raises(z.ZkhipError):
+        zk.field_arith_tracegen(as_dev([3]), as_dev([5]), as_dev([0]), 0)
+    with pytest.raises(z.ZkhipError):
+        zk.field_arith_tracegen(as_dev([0]), as_dev([P]), as_dev([1]), 0)
+    x = rng.integers(0, P, (n, 4)).astype(np.uint32)
+    y = rng.integers(0, P, (n, 4)).astype(np.uint32)
+    y[:3] = [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, P - 1]]
+    exp_e, bad = ora.field_ext_trace(op, x, y, lh)
+    prog_e = air.field_ext_air().program()
+    assert bad == 0 and air.check_trace(prog_e, exp_e, NOPV) == []
+    # division really is the inverse of multiplication: (x / y) * y == x through the oracle's own extension product
+    k = int(np.nonzero(op == 3)[0][0])
+    back = np.zeros(4, np.uint32)
+    ora.lib().ora_ext_mul(ora.p32(np.ascontiguousarray(exp_e[8:12, k])), ora.p32(np.ascontiguousarray(y[k])), ora.p32(back))
+    assert back.tolist() == x[k].tolist()
+    w = exp_e.copy()
+    w[9][k] = (int(w[9][k]) + 1) % P
+    assert air.check_trace(prog_e, w, NOPV) != []
+    d_e = zk.field_ext_tracegen(as_dev(op), as_dev(x), as_dev(y), lh)
+    assert (zk.download(d_e).reshape(20, -1) == exp_e).all()
+    with pytest.raises(z.ZkhipError):
+        zk.field_ext_tracegen(as_dev([3]), as_dev([[1, 2, 3, 4]]), as_dev([[0, 0, 0, 0]]), 0)
+    airs = [dict(program=prog_a, log_height=lh, width=8, n_pvs=0, trace=exp, pvs=NOPV),
+            dict(program=prog_e, log_height=lh, width=20, n_pvs=0, trace=exp_e, pvs=NOPV)]
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    proof = pk.prove([d_a, d_e], [NOPV] * 2)
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    pk.close()

@@ -101,6 +101,8 @@ def load_library():
         "zkhip_rv32_shift_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_branch_eq_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_rv32_branch_lt_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_field_arith_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp]),
+        "zkhip_field_ext_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_mmcs_path_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_divrem_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp]),
         "zkhip_rv32_mulh_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp]),
@@ -385,6 +387,24 @@ class Context:
         out = torch.empty(13 << log_height, dtype=torch.int32, device=self.device)
         self._check(self.lib.zkhip_rv32_mul_tracegen(self.h, C.c_void_p(t_b.data_ptr()), C.c_void_p(t_c.data_ptr()), t_b.numel(), log_height,
                                                      C.c_void_p(out.data_ptr()), C.c_void_p(t_tuple_counts.data_ptr()), size_x, size_y))
+        return out
+
+    def field_arith_tracegen(self, t_opcode, t_b, t_c, log_height):
+        """8-column trace of the native field-arithmetic chip from records (int32 tensors: opcode 0 = ADD .. 3 = DIV, canonical operands)."""
+        import torch
+
+        out = torch.empty(8 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_field_arith_tracegen(self.h, C.c_void_p(t_opcode.data_ptr()), C.c_void_p(t_b.data_ptr()), C.c_void_p(t_c.data_ptr()),
+                                                        t_opcode.numel(), log_height, C.c_void_p(out.data_ptr())))
+        return out
+
+    def field_ext_tracegen(self, t_opcode, t_x, t_y, log_height):
+        """20-column trace of the native field-extension chip from records (opcode, x [n][4], y [n][4] canonical)."""
+        import torch
+
+        out = torch.empty(20 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_field_ext_tracegen(self.h, C.c_void_p(t_opcode.data_ptr()), C.c_void_p(t_x.data_ptr()), C.c_void_p(t_y.data_ptr()),
+                                                      t_opcode.numel(), log_height, C.c_void_p(out.data_ptr())))
         return out
 
     def mmcs_path_tracegen(self, t_leaf, t_index, t_path_start, t_step_kind, t_step_digest, log_height):

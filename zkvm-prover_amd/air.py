@@ -1515,6 +1515,58 @@ def mmcs_claims_air(claims_bus):
     return b
 
 
+FIELD_ARITH_WIDTH = 8
+FIELD_EXT_WIDTH = 20
+
+
+def _ext_mul_exprs(x, y):
+    """coordinates of x * y in F[X] / (X^4 - 11) for lists of four expressions"""
+    W = 11
+    return [x[0] * y[0] + (x[1] * y[3] + x[2] * y[2] + x[3] * y[1]) * W,
+            x[0] * y[1] + x[1] * y[0] + (x[2] * y[3] + x[3] * y[2]) * W,
+            x[0] * y[2] + x[1] * y[1] + x[2] * y[0] + x[3] * y[3] * W,
+            x[0] * y[3] + x[1] * y[2] + x[2] * y[1] + x[3] * y[0]]
+
+
+def field_arith_air():
+    """The core of OpenVM's NATIVE field-arithmetic chip (native `FieldArithmeticCoreAir`: the base-field ADD / SUB / MUL / DIV of the
+    recursion programs the aggregation circuits run): columns a | b | c | is_add is_sub is_mul is_div | divisor_inv, a = b op c;
+    division is a c = b with c divisor_inv = 1."""
+    b = AirBuilder(FIELD_ARITH_WIDTH, 0)
+    a_, b_, c_ = b.var(0), b.var(1), b.var(2)
+    add, sub, mul, div, inv = b.var(3), b.var(4), b.var(5), b.var(6), b.var(7)
+    ok = add + sub + mul + div
+    for f in (add, sub, mul, div, ok):
+        b.assert_zero(f * (f - 1))
+    b.assert_zero(add * (a_ - b_ - c_))
+    b.assert_zero(sub * (a_ - b_ + c_))
+    b.assert_zero(mul * (a_ - b_ * c_))
+    b.assert_zero(div * (b_ - a_ * c_))
+    b.assert_zero(div * (c_ * inv - 1))
+    return b
+
+
+def field_ext_air():
+    """The core of OpenVM's native field-extension chip (native `FieldExtensionCoreAir`: FE4ADD / FE4SUB / BBE4MUL / BBE4DIV over
+    F[X] / (X^4 - 11)): columns x[4] | y[4] | z[4] | is_add is_sub is_mul is_div | divisor_inv[4], z = x op y; division is
+    z = x * divisor_inv with y * divisor_inv = 1."""
+    b = AirBuilder(FIELD_EXT_WIDTH, 0)
+    x, y, z = [b.var(i) for i in range(4)], [b.var(4 + i) for i in range(4)], [b.var(8 + i) for i in range(4)]
+    add, sub, mul, div = b.var(12), b.var(13), b.var(14), b.var(15)
+    inv = [b.var(16 + i) for i in range(4)]
+    ok = add + sub + mul + div
+    for f in (add, sub, mul, div, ok):
+        b.assert_zero(f * (f - 1))
+    xy, xi, yi = _ext_mul_exprs(x, y), _ext_mul_exprs(x, inv), _ext_mul_exprs(y, inv)
+    for i in range(4):
+        b.assert_zero(add * (z[i] - x[i] - y[i]))
+        b.assert_zero(sub * (z[i] - x[i] + y[i]))
+        b.assert_zero(mul * (z[i] - xy[i]))
+        b.assert_zero(div * (z[i] - xi[i]))
+        b.assert_zero(div * (yi[i] - (1 if i == 0 else 0)))
+    return b
+
+
 FRI_FOLD_WIDTH = 18
 
 

@@ -1085,3 +1085,93 @@ extern "C" int zkhip_rv32_divrem_tracegen(zkhip_ctx* ctx, const uint32_t* d_opco
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_divrem_tracegen (opcode > 3)");
 }
+
+// ---- NATIVE chips: base-field and extension-field arithmetic (OpenVM native FieldArithmeticCoreAir / FieldExtensionCoreAir) -----------
+// The recursion programs the reference's aggregation circuits run execute on these: a = b op c over BabyBear,
+// z = x op y over F[X] / (X^4 - 11).  Records are field elements; one field inversion per division, on the device.
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_field_arith(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ bs, const uint32_t* __restrict__ cs,
+                                                     size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_FIELD_ARITH_WIDTH] = {};
+    if (r < n) {
+        const uint32_t op = opc[r], bc = bs[r], cc = cs[r];
+        if (op > 3 || bc >= P || cc >= P || (op == 3 && cc == 0)) {
+            atomicAdd(bad, 1u);
+        } else {
+            const uint32_t b = to_monty(bc), c = to_monty(cc);
+            const uint32_t inv = op == 3 ? minv(c) : 0u;
+            col[0] = op == 0 ? madd(b, c) : op == 1 ? msub(b, c) : op == 2 ? mmul(b, c) : mmul(b, inv);
+            col[1] = b, col[2] = c, col[3 + op] = MONTY_ONE, col[7] = inv;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_FIELD_ARITH_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+
+__global__ __launch_bounds__(256) void k_field_ext(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+                                                   size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_FIELD_EXT_WIDTH] = {};
+    if (r < n) {
+        const uint32_t op = opc[r];
+        const uint4 xv = reinterpret_cast<const uint4*>(xs)[r], yv = reinterpret_cast<const uint4*>(ys)[r];
+        const uint32_t xc[4] = {xv.x, xv.y, xv.z, xv.w}, yc[4] = {yv.x, yv.y, yv.z, yv.w};
+        bool ok = op <= 3;
+#pragma unroll
+        for (int i = 0; i < 4; i++) ok = ok && xc[i] < P && yc[i] < P;
+        if (ok && op == 3 && !(yc[0] | yc[1] | yc[2] | yc[3])) ok = false;
+        if (!ok) {
+            atomicAdd(bad, 1u);
+        } else {
+            Ext x, y, z, inv = ext_zero();
+#pragma unroll
+            for (int i = 0; i < 4; i++) x.c[i] = to_monty(xc[i]), y.c[i] = to_monty(yc[i]);
+            if (op == 0) z = ext_add(x, y);
+            else if (op == 1) z = ext_sub(x, y);
+            else if (op == 2) z = ext_mul(x, y);
+            else inv = ext_inv(y), z = ext_mul(x, inv);
+#pragma unroll
+            for (int i = 0; i < 4; i++) col[i] = x.c[i], col[4 + i] = y.c[i], col[8 + i] = z.c[i], col[16 + i] = inv.c[i];
+            col[12 + op] = MONTY_ONE;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_FIELD_EXT_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_field_arith_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, const uint32_t* d_b, const uint32_t* d_c, size_t n, unsigned log_height,
+                                          uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || log_height > 27 || (n && (!d_opcode || !d_b || !d_c))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "field_arith_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "field_arith_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_field_arith, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "field_arith_tracegen (opcode > 3, operand not a field element, or division by zero)");
+}
+
+extern "C" int zkhip_field_ext_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, const uint32_t* d_x, const uint32_t* d_y, size_t n, unsigned log_height,
+                                        uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || log_height > 27 || (n && (!d_opcode || !d_x || !d_y))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "field_ext_tracegen: more records than rows");
+    if (((uintptr_t)d_x | (uintptr_t)d_y) & 15u) return set_error(ctx, ZKHIP_ERR_INVALID, "field_ext_tracegen: operands must be 16-byte aligned");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "field_ext_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_field_ext, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_x, d_y, n, N, d_trace, (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "field_ext_tracegen (opcode > 3, operand not a field element, or division by zero)");
+}
