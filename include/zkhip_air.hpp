@@ -387,7 +387,7 @@ inline std::vector<Expr> p2_external(const std::vector<Expr>& s) {
 }  // namespace detail
 
 // Fills `b` (constructed with width POSEIDON2_AIR_WIDTH, or +1 with a bus) with the constraints of the Poseidon2 AIR.
-inline void poseidon2_air(AirBuilder& b, int bus = -1) {
+inline void poseidon2_air(AirBuilder& b, int bus = -1, int out_lanes = 8) {   // out_lanes: 8 serve compressions, 16 a sponge (chips::duplex_air)
     if (b.width() != POSEIDON2_AIR_WIDTH + (bus >= 0 ? 1 : 0)) throw std::invalid_argument("poseidon2_air: builder width");
     const std::vector<uint32_t> rc = poseidon2_round_constants();
     const std::array<uint32_t, 16> diag = poseidon2_internal_diag();
@@ -429,7 +429,7 @@ inline void poseidon2_air(AirBuilder& b, int bus = -1) {
     for (int r = 0; r < 4; r++) full_round(&rc[77 + 16 * r]);
     if (bus >= 0) {
         std::vector<Expr> msg = in;
-        msg.insert(msg.end(), state.begin(), state.begin() + 8);
+        msg.insert(msg.end(), state.begin(), state.begin() + out_lanes);
         b.push_interaction((uint32_t)bus, msg, b.var(POSEIDON2_AIR_WIDTH), Kind::Receive);
     }
 }

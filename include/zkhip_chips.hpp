@@ -871,6 +871,94 @@ inline void mmcs_path_air(AirBuilder& b, uint32_t hash_bus, uint32_t claims_bus)
     }
 }
 
+// air.duplex_air(hash_bus, io_bus): AirBuilder(50, 0) -- the DuplexChallenger in-circuit, one row per duplexing
+inline void duplex_air(AirBuilder& b, uint32_t hash_bus, uint32_t io_bus) {
+    Expr st_in[16], st_out[16], f[8], s_[8], n_in[16], n_f[8];
+    for (int i = 0; i < 16; i++) st_in[i] = b.var(i);
+    for (int i = 0; i < 16; i++) st_out[i] = b.var(16 + i);
+    for (int i = 0; i < 8; i++) f[i] = b.var(32 + i);
+    for (int i = 0; i < 8; i++) s_[i] = b.var(40 + i);
+    const Expr seq = b.var(48), real = b.var(49);
+    for (int i = 0; i < 16; i++) n_in[i] = b.next(i);
+    for (int i = 0; i < 8; i++) n_f[i] = b.next(32 + i);
+    const Expr n_seq = b.next(48), n_real = b.next(49);
+    for (int i = 0; i < 17; i++) {
+        const Expr x = i < 8 ? f[i] : i < 16 ? s_[i - 8] : real;
+        const Expr t = x - 1;
+        b.assert_zero(x * t);
+    }
+    for (int j = 0; j < 8; j++) {
+        {
+            const Expr nr = 1 - real;
+            b.assert_zero(nr * f[j]);
+        }
+        {
+            const Expr nr = 1 - real;
+            b.assert_zero(nr * s_[j]);
+        }
+    }
+    for (int j = 0; j < 7; j++) {
+        {
+            const Expr nf = 1 - f[j];
+            b.assert_zero(f[j + 1] * nf);
+        }
+        {
+            const Expr ns = 1 - s_[j + 1];
+            b.assert_zero(s_[j] * ns);
+        }
+    }
+    {
+        const Expr nr = 1 - real;
+        b.when_transition(nr * n_real);
+    }
+    b.when_first_row(seq);
+    {
+        const Expr d = n_seq - seq;
+        const Expr e = d - 1;
+        b.when_transition(n_real * e);
+    }
+    for (int j = 0; j < 16; j++) {
+        if (j < 8) {
+            {
+                const Expr nf = 1 - f[j];
+                b.when_first_row(nf * st_in[j]);
+            }
+            {
+                const Expr nf = 1 - n_f[j];
+                const Expr m = n_real * nf;
+                const Expr d = n_in[j] - st_out[j];
+                b.when_transition(m * d);
+            }
+        } else {
+            b.when_first_row(st_in[j]);
+            const Expr d = n_in[j] - st_out[j];
+            b.when_transition(n_real * d);
+        }
+    }
+    {
+        std::vector<Expr> msg(st_in, st_in + 16);
+        msg.insert(msg.end(), st_out, st_out + 16);
+        b.push_interaction(hash_bus, msg, real, Kind::Send);
+    }
+    for (int j = 0; j < 8; j++) {
+        const Expr lane = b.constant(j);
+        const Expr kind = b.constant(0);
+        b.push_interaction(io_bus, {seq, lane, st_in[j], kind}, f[j], Kind::Send);
+    }
+    for (int j = 0; j < 8; j++) {
+        const Expr lane = b.constant(j);
+        const Expr kind = b.constant(1);
+        b.push_interaction(io_bus, {seq, lane, st_out[j], kind}, s_[j], Kind::Send);
+    }
+}
+
+// air.duplex_io_air(io_bus): AirBuilder(5, 0)
+inline void duplex_io_air(AirBuilder& b, uint32_t io_bus) {
+    std::vector<Expr> msg;
+    for (int i = 0; i < 4; i++) msg.push_back(b.var(i));
+    b.push_interaction(io_bus, msg, b.var(4), Kind::Receive);
+}
+
 // air._ext_mul_exprs(x, y): coordinates of x * y in F[X] / (X^4 - 11), node for node as the Python helper builds them
 inline void ext_mul_exprs(const Expr x[4], const Expr y[4], Expr out[4]) {
     {

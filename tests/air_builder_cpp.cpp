@@ -173,6 +173,9 @@ int main() {
         { AirBuilder b(18, 0); ch::fri_fold_air(b); dump("chip_fri_fold", b); }
         { AirBuilder b(8, 0); ch::field_arith_air(b); dump("chip_field_arith", b); }
         { AirBuilder b(20, 0); ch::field_ext_air(b); dump("chip_field_ext", b); }
+        { AirBuilder b(50, 0); ch::duplex_air(b, 9, 10); dump("chip_duplex", b); }
+        { AirBuilder b(5, 0); ch::duplex_io_air(b, 10); dump("chip_duplex_io", b); }
+        { AirBuilder b(299, 0); poseidon2_air(b, 9, 16); dump("poseidon2_bus16", b); }
         { AirBuilder b(10, 0); ch::memory_access_air(b); dump("chip_memory_access", b); }
         { AirBuilder b(8, 0); ch::memory_boundary_air(b); dump("chip_memory_boundary", b); }
     }

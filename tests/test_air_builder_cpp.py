@@ -72,6 +72,9 @@ PY = {
     "chip_fri_fold": lambda: air.fri_fold_air(),
     "chip_field_arith": lambda: air.field_arith_air(),
     "chip_field_ext": lambda: air.field_ext_air(),
+    "chip_duplex": lambda: air.duplex_air(9, 10),
+    "chip_duplex_io": lambda: air.duplex_io_air(10),
+    "poseidon2_bus16": lambda: air.poseidon2_air(9, out_lanes=16),
     "chip_memory_access": lambda: air.memory_access_air(),
     "chip_memory_boundary": lambda: air.memory_boundary_air(),
 }

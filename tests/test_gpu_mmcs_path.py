@@ -106,3 +106,42 @@ def test_reference_fri_fold_steps_proven(zk, ora, vec):
     w[13][0] = (int(w[13][0]) + 1) % P
     assert z.verify(PARAMS, pk.verifying_airs(), [NOPV], pk.prove([zk.upload(w.reshape(-1))], [NOPV])) != 0
     pk.close()
+
+
+def test_transcript_chip_over_the_poseidon2_chip(zk, ora):
+    """The transcript chip (air.duplex_air: the DuplexChallenger in-circuit) with the Poseidon2 chip serving its 32-field hash bus
+    and a table stating what was observed and sampled: the Poseidon2 chip's 298 columns are generated on the device from the
+    duplexing inputs, the three AIRs prove together (bytes == oracle), and a table that claims a different sample is refused."""
+    from test_duplex_chip_cpu import random_script
+    import duplex_util as du
+
+    rng = np.random.default_rng(9)
+    script = random_script(rng, 80)
+    tr, io, samples = du.run_script(ora, script)
+    rows = len(tr)
+    lh = int(np.ceil(np.log2(rows + 1)))
+    N = 1 << lh
+    t = du.padded(tr, lh)
+    inputs = np.zeros((N, 16), np.uint32)
+    inputs[:rows] = tr[:, :16]
+    chip = np.zeros((299, N), np.uint32)
+    chip[:298] = ora.poseidon2_air_trace(inputs, lh)
+    chip[298, :rows] = 1
+    lio = int(np.ceil(np.log2(len(set(io)) + 1)))
+    table = du.io_table(io, lio)
+    A = lambda prog, w, x: dict(program=prog, log_height=int(np.log2(x.shape[1])), width=w, n_pvs=0, trace=x, pvs=NOPV)  # noqa: E731
+    airs = [A(air.duplex_air(9, 10).program(), 50, t), A(air.poseidon2_air(9, out_lanes=16).program(), 299, chip),
+            A(air.duplex_io_air(10).program(), 5, table)]
+    d_chip = torch.empty(299 * N, dtype=torch.int32, device=zk.device)
+    zk.poseidon2_air_tracegen(zk.upload(inputs.reshape(-1)), lh, d_chip)
+    d_chip[298 * N:] = zk.upload(chip[298])
+    assert (zk.download(d_chip).reshape(299, N) == chip).all()
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    proof = pk.prove([zk.upload(t.reshape(-1)), d_chip, zk.upload(table.reshape(-1))], [NOPV] * 3)
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 3, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    wrong = table.copy()
+    r = int(np.nonzero(table[3] == 1)[0][0])     # a sampled value
+    wrong[2][r] = (int(wrong[2][r]) + 1) % P
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 3, pk.prove([zk.upload(t.reshape(-1)), d_chip, zk.upload(wrong.reshape(-1))], [NOPV] * 3)) != 0
+    pk.close()

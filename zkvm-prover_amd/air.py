@@ -1415,7 +1415,7 @@ def _p2_external(s):
     return [out[i] + sums[i % 4] for i in range(16)]
 
 
-def poseidon2_air(bus=None):
+def poseidon2_air(bus=None, out_lanes=8):
     """AirBuilder of the Poseidon2 AIR above: 298 columns, 282 constraints of degree 3, no public values.
     With `bus` the chip serves compression requests like OpenVM's Poseidon2 periphery chip: one more column `mult`
     (column 298) and the interaction receive(bus, inputs[0..16] ++ outputs[0..8], mult) -- a 24-field message."""
@@ -1454,7 +1454,7 @@ def poseidon2_air(bus=None):
         state, col = full_round(state, rc[77 + 16 * r:77 + 16 * r + 16], col)
     assert col == POSEIDON2_AIR_WIDTH
     if bus is not None:
-        msg = [b.var(i) for i in range(16)] + state[:8]
+        msg = [b.var(i) for i in range(16)] + state[:out_lanes]   # 8 lanes serve compressions, 16 a sponge (duplex_air)
         b.push_interaction(bus, msg, b.var(POSEIDON2_AIR_WIDTH), "receive")
     return b
 
@@ -1512,6 +1512,55 @@ def mmcs_claims_air(claims_bus):
     sponge over the opened values produces these; as a table it lets the claims be stated and checked.)"""
     b = AirBuilder(19, 0)
     b.push_interaction(claims_bus, [b.var(i) for i in range(18)], b.var(18), "receive")
+    return b
+
+
+DUPLEX_WIDTH = 50
+
+
+def duplex_air(hash_bus, io_bus):
+    """The Fiat-Shamir transcript in-circuit (p3 `DuplexChallenger<F, Poseidon2, 16, 8>`, the challenger of the reference's STARK
+    configuration) -- a third piece of the recursion circuit: one row per duplexing, columns st_in[16] | st_out[16] | f[8] | s[8] |
+    seq | is_real.  f is the prefix of rate lanes the observed values overwrote before the permutation, the other lanes carry
+    over from the previous row's st_out (zero in the first row); st_out = Poseidon2(st_in) is requested from the Poseidon2 chip
+    over `hash_bus` (a 32-field message: air.poseidon2_air(bus, out_lanes=16)); s is the suffix of output lanes that were
+    sampled afterwards (the challenger pops from the end).  Every observed value goes out on `io_bus` as (seq, lane, value, 0),
+    every sampled one as (seq, lane, value, 1): whoever feeds or uses the transcript is bound to it there."""
+    b = AirBuilder(DUPLEX_WIDTH, 0)
+    st_in, st_out = [b.var(i) for i in range(16)], [b.var(16 + i) for i in range(16)]
+    f, s_ = [b.var(32 + i) for i in range(8)], [b.var(40 + i) for i in range(8)]
+    seq, real = b.var(48), b.var(49)
+    n_in, n_f, n_seq, n_real = [b.next(i) for i in range(16)], [b.next(32 + i) for i in range(8)], b.next(48), b.next(49)
+    for x in f + s_ + [real]:
+        b.assert_zero(x * (x - 1))
+    for j in range(8):
+        b.assert_zero((1 - real) * f[j])
+        b.assert_zero((1 - real) * s_[j])
+    for j in range(7):
+        b.assert_zero(f[j + 1] * (1 - f[j]))
+        b.assert_zero(s_[j] * (1 - s_[j + 1]))
+    b.when_transition((1 - real) * n_real)
+    b.when_first_row(seq)
+    b.when_transition(n_real * (n_seq - seq - 1))
+    for j in range(16):
+        if j < 8:
+            b.when_first_row((1 - f[j]) * st_in[j])
+            b.when_transition(n_real * (1 - n_f[j]) * (n_in[j] - st_out[j]))
+        else:
+            b.when_first_row(st_in[j])
+            b.when_transition(n_real * (n_in[j] - st_out[j]))
+    b.push_interaction(hash_bus, st_in + st_out, real, "send")
+    for j in range(8):
+        b.push_interaction(io_bus, [seq, j, st_in[j], 0], f[j], "send")
+    for j in range(8):
+        b.push_interaction(io_bus, [seq, j, st_out[j], 1], s_[j], "send")
+    return b
+
+
+def duplex_io_air(io_bus):
+    """The other side of duplex_air's io bus as a table: columns seq | lane | value | kind | mult."""
+    b = AirBuilder(5, 0)
+    b.push_interaction(io_bus, [b.var(i) for i in range(4)], b.var(4), "receive")
     return b
 
 
