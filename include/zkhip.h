@@ -267,6 +267,13 @@ int zkhip_field_arith_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const u
 int zkhip_field_ext_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uint32_t *d_x, const uint32_t *d_y, size_t n, unsigned log_height,
                              uint32_t *d_trace);
 
+/* Variable range checker (OpenVM VariableRangeCheckerChip): the multiplicity column of the table that serves every check
+ * value < 2^bits with bits <= max_bits (2^(max_bits + 1) rows: row 2^bits - 1 + value; air.py var_range_table_air / var_range_prep).
+ * d_values: a requesting trace column (Montgomery); d_bits: the column of the bit counts, or NULL to use const_bits for every
+ * request.  accumulate as in zkhip_range_counts_tracegen.  ZKHIP_ERR_INVALID for a request outside the table. */
+int zkhip_var_range_counts_tracegen(zkhip_ctx *ctx, const uint32_t *d_values, const uint32_t *d_bits, uint32_t const_bits, size_t n, unsigned max_bits,
+                                    uint32_t *d_counts, int accumulate);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

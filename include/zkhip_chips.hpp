@@ -871,6 +871,12 @@ inline void mmcs_path_air(AirBuilder& b, uint32_t hash_bus, uint32_t claims_bus)
     }
 }
 
+// air.var_range_table_air(bus): AirBuilder(1, 0, prep_width = 2) -- OpenVM VariableRangeCheckerChip
+inline void var_range_table_air(AirBuilder& b, uint32_t bus = 7) {
+    const Expr v = b.prep(0), bits = b.prep(1);
+    b.push_interaction(bus, {v, bits}, b.var(0), Kind::Receive);
+}
+
 // air.duplex_air(hash_bus, io_bus): AirBuilder(50, 0) -- the DuplexChallenger in-circuit, one row per duplexing
 inline void duplex_air(AirBuilder& b, uint32_t hash_bus, uint32_t io_bus) {
     Expr st_in[16], st_out[16], f[8], s_[8], n_in[16], n_f[8];

@@ -184,6 +184,8 @@ extern "C" {
                                      d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_rv32_branch_lt_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_a: *const u32, d_b: *const u32, d_imm: *const u32, n: usize,
                                          log_height: c_uint, d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_var_range_counts_tracegen(ctx: *mut zkhip_ctx, d_values: *const u32, d_bits: *const u32, const_bits: u32, n: usize, max_bits: c_uint,
+                                           d_counts: *mut u32, accumulate: c_int) -> c_int;
     pub fn zkhip_field_arith_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_b: *const u32, d_c: *const u32, n: usize, log_height: c_uint,
                                       d_trace: *mut u32) -> c_int;
     pub fn zkhip_field_ext_tracegen(ctx: *mut zkhip_ctx, d_opcode: *const u32, d_x: *const u32, d_y: *const u32, n: usize, log_height: c_uint,

@@ -739,3 +739,20 @@ size_t ora_field_ext_trace(const uint32_t *opc, const uint32_t *xs, const uint32
     }
     return bad;
 }
+
+/* Variable range checker multiplicities (zkhip_var_range_counts_tracegen): counts[2^bits - 1 + value] (+)= 1 per request
+ * (value, bits), bits <= max_bits, value < 2^bits; bits == NULL means const_bits for every request.  Canonical inputs.
+ * Returns the number of requests outside the table. */
+size_t ora_var_range_counts(const uint32_t *values, const uint32_t *bits, uint32_t const_bits, size_t n, unsigned max_bits, uint32_t *counts) {
+    size_t bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t b = bits ? bits[i] : const_bits, v = values[i];
+        if (b > max_bits || (b < 32 && v >= (1u << b))) {
+            bad++;
+            continue;
+        }
+        uint32_t *t = &counts[((size_t)1 << b) - 1 + v];
+        *t = ora_add(*t, 1);
+    }
+    return bad;
+}

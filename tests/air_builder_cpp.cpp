@@ -176,6 +176,7 @@ int main() {
         { AirBuilder b(50, 0); ch::duplex_air(b, 9, 10); dump("chip_duplex", b); }
         { AirBuilder b(5, 0); ch::duplex_io_air(b, 10); dump("chip_duplex_io", b); }
         { AirBuilder b(299, 0); poseidon2_air(b, 9, 16); dump("poseidon2_bus16", b); }
+        { AirBuilder b(1, 0, 2); ch::var_range_table_air(b); dump("chip_var_range_table", b); }
         { AirBuilder b(10, 0); ch::memory_access_air(b); dump("chip_memory_access", b); }
         { AirBuilder b(8, 0); ch::memory_boundary_air(b); dump("chip_memory_boundary", b); }
     }

@@ -209,6 +209,21 @@ def field_ext_trace(opc, x, y, log_height):
     return _plain_trace("ora_field_ext_trace", 20, (opc, x, y), len(np.asarray(opc).reshape(-1)), log_height)
 
 
+def var_range_counts(values, bits, max_bits, counts=None):
+    """bits: an array (one per request) or an int (the same for every request)"""
+    values = np.ascontiguousarray(values, dtype=np.uint32).reshape(-1)
+    c = np.zeros(1 << (max_bits + 1), np.uint32) if counts is None else np.ascontiguousarray(counts, dtype=np.uint32).copy()
+    l = lib()
+    l.ora_var_range_counts.restype = C.c_size_t
+    l.ora_var_range_counts.argtypes = [u32p_t(), u32p_t(), C.c_uint32, C.c_size_t, C.c_uint, u32p_t()]
+    if isinstance(bits, (int, np.integer)):
+        bad = l.ora_var_range_counts(p32(values), None, int(bits), len(values), max_bits, p32(c))
+    else:
+        bits = np.ascontiguousarray(bits, dtype=np.uint32).reshape(-1)
+        bad = l.ora_var_range_counts(p32(values), p32(bits), 0, len(values), max_bits, p32(c))
+    return c, int(bad)
+
+
 def rv32_lt_trace(opc, bs, cs, log_height, range_counts=None):
     opc, bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, bs, cs))
     tr = np.zeros((18, 1 << log_height), np.uint32)

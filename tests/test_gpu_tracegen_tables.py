@@ -781,3 +781,42 @@ def test_native_field_chips(zk, ora):
     assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, proof) == 0
     assert proof == ora.stark_prove(PARAMS, airs).tobytes()
     pk.close()
+
+
+def test_variable_range_checker(zk, ora):
+    """OpenVM's VariableRangeCheckerChip: one table for every check value < 2^bits, bits <= max_bits.  Multiplicities counted on
+    the device from the requesting columns (a column of bit counts, or one constant) == oracle; requests outside the table are
+    refused; a user chip sending (value, bits) pairs and the table prove from the device-resident traces (bytes == oracle)."""
+    rng = np.random.default_rng(61)
+    B, lh = 12, 11
+    n = 1 << lh
+    bits = rng.integers(0, B + 1, n).astype(np.uint32)
+    vals = (rng.integers(0, 1 << 30, n) % (1 << bits.astype(np.uint64))).astype(np.uint32)
+    vals[:40], bits[:40] = 0, 0                      # a hot entry
+    prep = air.var_range_prep(B)
+    assert prep.shape == (2, 1 << (B + 1)) and (prep[0] < (1 << prep[1].astype(np.uint64))).all()
+    assert prep[:, 0].tolist() == [0, 0] and prep[:, 1].tolist() == [0, 1] and prep[:, 2].tolist() == [1, 1] and prep[:, -1].tolist() == [0, B + 1]
+    cnt, bad = ora.var_range_counts(vals, bits, B)
+    assert bad == 0 and int(cnt.astype(np.int64).sum()) == n
+    for i in (0, 77, 500):
+        assert cnt[(1 << int(bits[i])) - 1 + int(vals[i])] >= 1
+    user = np.stack([vals, bits, (vals.astype(np.uint64) * bits % P).astype(np.uint32)])
+    d_user = zk.upload(user.reshape(-1))
+    d_cnt = zk.var_range_counts_tracegen(d_user[:n], d_user[n:2 * n], B)
+    assert (zk.download(d_cnt) == cnt).all()
+    # a second requesting column with one constant bit count, accumulated
+    more = rng.integers(0, 1 << 7, 999).astype(np.uint32)
+    cnt2, _ = ora.var_range_counts(more, 7, B, counts=cnt)
+    d_cnt2 = zk.var_range_counts_tracegen(zk.upload(more), 7, B, d_cnt.clone(), accumulate=True)
+    assert (zk.download(d_cnt2) == cnt2).all()
+    for v, b_ in ((4, 2), (0, B + 1)):
+        with pytest.raises(z.ZkhipError):
+            zk.var_range_counts_tracegen(zk.upload(np.array([v], np.uint32)), b_, B)
+        assert ora.var_range_counts([v], b_, B)[1] == 1
+    airs = [dict(program=air.var_range_user_air(7).program(), log_height=lh, width=3, n_pvs=0, trace=user, pvs=NOPV),
+            dict(program=air.var_range_table_air(7).program(), log_height=B + 1, width=1, n_pvs=0, trace=cnt.reshape(1, -1), pvs=NOPV, prep=prep)]
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    proof = pk.prove([d_user, d_cnt], [NOPV] * 2)
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    pk.close()

@@ -101,6 +101,7 @@ def load_library():
         "zkhip_rv32_shift_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_rv32_branch_eq_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_rv32_branch_lt_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_var_range_counts_tracegen": (C.c_int, [vp, vp, vp, C.c_uint32, sz, C.c_uint, vp, C.c_int]),
         "zkhip_field_arith_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_field_ext_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_mmcs_path_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
@@ -388,6 +389,19 @@ class Context:
         self._check(self.lib.zkhip_rv32_mul_tracegen(self.h, C.c_void_p(t_b.data_ptr()), C.c_void_p(t_c.data_ptr()), t_b.numel(), log_height,
                                                      C.c_void_p(out.data_ptr()), C.c_void_p(t_tuple_counts.data_ptr()), size_x, size_y))
         return out
+
+    def var_range_counts_tracegen(self, t_values, bits, max_bits, t_counts=None, accumulate=False):
+        """Multiplicity column (2^(max_bits + 1) Montgomery words) of the variable range checker for the Montgomery column t_values;
+        bits: a Montgomery column of bit counts (tensor) or one int for every request."""
+        import torch
+
+        if t_counts is None:
+            t_counts = torch.zeros(1 << (max_bits + 1), dtype=torch.int32, device=self.device)
+        col = isinstance(bits, torch.Tensor)
+        self._check(self.lib.zkhip_var_range_counts_tracegen(self.h, C.c_void_p(t_values.data_ptr()), C.c_void_p(bits.data_ptr()) if col else None,
+                                                             0 if col else int(bits), t_values.numel(), max_bits, C.c_void_p(t_counts.data_ptr()),
+                                                             1 if accumulate else 0))
+        return t_counts
 
     def field_arith_tracegen(self, t_opcode, t_b, t_c, log_height):
         """8-column trace of the native field-arithmetic chip from records (int32 tensors: opcode 0 = ADD .. 3 = DIV, canonical operands)."""

@@ -618,6 +618,31 @@ def range_tuple_prep(size_x=256, size_y=8192):
     return np.stack([i // size_y, i % size_y]).astype(np.uint32)
 
 
+def var_range_table_air(bus=7):
+    """OpenVM VariableRangeCheckerChip: one table for every range check x < 2^bits with bits <= max_bits.  Preprocessed columns
+    (value, bits), row 2^bits - 1 + value (var_range_prep); the main trace is the multiplicity column.  Receives (value, bits)."""
+    b = AirBuilder(1, 0, prep_width=2)
+    b.push_interaction(bus, [b.prep(0), b.prep(1)], b.var(0), "receive")
+    return b
+
+
+def var_range_prep(max_bits):
+    """[2, 2^(max_bits + 1)]: rows (value, bits) for bits = 0 .. max_bits in order, then one row (0, max_bits + 1) that pads the
+    height to a power of two (as the reference chip's table does)."""
+    r = np.arange(1 << (max_bits + 1), dtype=np.uint64) + 1
+    bits = np.floor(np.log2(r)).astype(np.uint32)
+    value = (r - (np.uint64(1) << bits.astype(np.uint64))).astype(np.uint32)
+    return np.stack([value, bits]).astype(np.uint32)
+
+
+def var_range_user_air(bus=7):
+    """Every row sends (col0, col1): col0 < 2^col1; col2 = col0 * col1 keeps a main constraint around."""
+    b = AirBuilder(3, 0)
+    b.assert_zero(b.var(0) * b.var(1) - b.var(2))
+    b.push_interaction(bus, [b.var(0), b.var(1)], 1, "send")
+    return b
+
+
 def range_tuple_user_air(bus=6):
     """Every row sends the tuple (col0, col1) once; col2 = col0 * col1 keeps a main constraint around."""
     b = AirBuilder(3, 0)

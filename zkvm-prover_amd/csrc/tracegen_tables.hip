@@ -1175,3 +1175,44 @@ extern "C" int zkhip_field_ext_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "field_ext_tracegen (opcode > 3, operand not a field element, or division by zero)");
 }
+
+// ---- variable range checker (OpenVM VariableRangeCheckerChip): one table for x < 2^bits, bits <= max_bits ------------------------------
+// Row 2^bits - 1 + value.  The requesting columns are Montgomery words where they lie; `bits` may be a column or one constant.
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_var_range_counts(const uint32_t* __restrict__ values, const uint32_t* __restrict__ bits, uint32_t const_bits,
+                                                          size_t n, unsigned max_bits, uint32_t* __restrict__ hist, uint32_t* __restrict__ bad) {
+    uint32_t n_bad = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t b = bits ? from_monty(bits[i]) : const_bits, v = from_monty(values[i]);
+        if (b > max_bits || v >= (1u << b)) {
+            n_bad++;
+            continue;
+        }
+        hist_add(hist, (1u << b) - 1 + v);
+    }
+    if (n_bad) atomicAdd(bad, n_bad);
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_var_range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d_values, const uint32_t* d_bits, uint32_t const_bits, size_t n,
+                                               unsigned max_bits, uint32_t* d_counts, int accumulate) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_counts || (n && !d_values) || max_bits > 26) return ZKHIP_ERR_INVALID;
+    const size_t T = (size_t)1 << (max_bits + 1);
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "var_range_counts_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const unsigned tb = (unsigned)((T + 255) / 256);
+    if (accumulate) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
+    else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
+    if (n) {
+        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), 8192);
+        hipLaunchKernelGGL(k_var_range_counts, dim3(blocks), dim3(256), 0, ctx->stream, d_values, d_bits, const_bits, n, max_bits, d_counts, (uint32_t*)flag);
+    }
+    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "var_range_counts_tracegen (bits > max_bits or value >= 2^bits)");
+}
