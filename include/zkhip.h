@@ -274,6 +274,13 @@ int zkhip_field_ext_tracegen(zkhip_ctx *ctx, const uint32_t *d_opcode, const uin
 int zkhip_var_range_counts_tracegen(zkhip_ctx *ctx, const uint32_t *d_values, const uint32_t *d_bits, uint32_t const_bits, size_t n, unsigned max_bits,
                                     uint32_t *d_counts, int accumulate);
 
+/* Native CASTF core (native CastFCoreAir): record i = d_x[i] < 2^30 (plain integer).  Fills d_trace (ZKHIP_CASTF_WIDTH = 6 columns,
+ * stride 2^log_height, Montgomery: x | limb[4] of 8, 8, 8, 6 bits | is_valid; rows >= n zero) and adds the four limb checks of
+ * every row to d_var_range_counts (the variable range checker's trace for max_bits >= 8).  AIR: air.py castf_air(). */
+#define ZKHIP_CASTF_WIDTH 6
+int zkhip_castf_tracegen(zkhip_ctx *ctx, const uint32_t *d_x, size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_var_range_counts,
+                         unsigned max_bits);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

@@ -877,6 +877,32 @@ inline void var_range_table_air(AirBuilder& b, uint32_t bus = 7) {
     b.push_interaction(bus, {v, bits}, b.var(0), Kind::Receive);
 }
 
+// air.castf_air(bus): AirBuilder(6, 0) -- native CASTF: x to limbs of 8, 8, 8, 6 bits through the variable range checker
+inline void castf_air(AirBuilder& b, uint32_t bus = 7) {
+    const Expr x = b.var(0);
+    Expr limb[4];
+    for (int i = 0; i < 4; i++) limb[i] = b.var(1 + i);
+    const Expr ok = b.var(5);
+    {
+        const Expr t = ok - 1;
+        b.assert_zero(ok * t);
+    }
+    {
+        const Expr u1 = limb[1] * 256;
+        const Expr u2 = limb[0] + u1;
+        const Expr u3 = limb[2] * 65536;
+        const Expr u4 = u2 + u3;
+        const Expr u5 = limb[3] * 16777216;
+        const Expr u6 = u4 + u5;
+        const Expr u7 = u6 - x;
+        b.assert_zero(ok * u7);
+    }
+    for (int i = 0; i < 4; i++) {
+        const Expr bits = b.constant(i < 3 ? 8 : 6);
+        b.push_interaction(bus, {limb[i], bits}, ok, Kind::Send);
+    }
+}
+
 // air.duplex_air(hash_bus, io_bus): AirBuilder(50, 0) -- the DuplexChallenger in-circuit, one row per duplexing
 inline void duplex_air(AirBuilder& b, uint32_t hash_bus, uint32_t io_bus) {
     Expr st_in[16], st_out[16], f[8], s_[8], n_in[16], n_f[8];

@@ -756,3 +756,27 @@ size_t ora_var_range_counts(const uint32_t *values, const uint32_t *bits, uint32
     }
     return bad;
 }
+
+/* Native CASTF core (zkhip_castf_tracegen): 6 columns x | limb[4] | is_valid, canonical; record = x < 2^30.  The four limb checks
+ * are counted into the variable range checker's table (max_bits >= 8): counts[2^bits - 1 + limb] with bits 8, 8, 8, 6. */
+size_t ora_castf_trace(const uint32_t *xs, size_t n, unsigned log_height, uint32_t *trace, uint32_t *var_range_counts) {
+    const size_t N = (size_t)1 << log_height;
+    size_t bad = 0;
+    for (size_t q = 0; q < 6; q++)
+        for (size_t r = 0; r < N; r++) trace[q * N + r] = 0;
+    for (size_t r = 0; r < n && r < N; r++) {
+        const uint32_t x = xs[r];
+        if (x >> 30) {
+            bad++;
+            continue;
+        }
+        trace[r] = x, trace[5 * N + r] = 1;
+        for (int i = 0; i < 4; i++) {
+            const uint32_t limb = (x >> (8 * i)) & 255u, bits = i < 3 ? 8 : 6;
+            trace[(size_t)(1 + i) * N + r] = limb;
+            uint32_t *t = &var_range_counts[(1u << bits) - 1 + limb];
+            *t = ora_add(*t, 1);
+        }
+    }
+    return bad;
+}

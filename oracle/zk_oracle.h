@@ -121,6 +121,7 @@ size_t ora_mmcs_path_trace(const uint32_t *leaf, const uint32_t *index, const ui
 size_t ora_field_arith_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace);
 size_t ora_field_ext_trace(const uint32_t *opc, const uint32_t *xs, const uint32_t *ys, size_t n, unsigned log_height, uint32_t *trace);
 size_t ora_var_range_counts(const uint32_t *values, const uint32_t *bits, uint32_t const_bits, size_t n, unsigned max_bits, uint32_t *counts);
+size_t ora_castf_trace(const uint32_t *xs, size_t n, unsigned log_height, uint32_t *trace, uint32_t *var_range_counts);
 size_t ora_rv32_lt_trace(const uint32_t *opc, const uint32_t *bs, const uint32_t *cs, size_t n, unsigned log_height, uint32_t *trace,
                          uint32_t *range_counts);
 size_t ora_program_freq_trace(const uint32_t *idx, size_t n, unsigned log_height, uint32_t *freq);

@@ -177,6 +177,7 @@ int main() {
         { AirBuilder b(5, 0); ch::duplex_io_air(b, 10); dump("chip_duplex_io", b); }
         { AirBuilder b(299, 0); poseidon2_air(b, 9, 16); dump("poseidon2_bus16", b); }
         { AirBuilder b(1, 0, 2); ch::var_range_table_air(b); dump("chip_var_range_table", b); }
+        { AirBuilder b(6, 0); ch::castf_air(b); dump("chip_castf", b); }
         { AirBuilder b(10, 0); ch::memory_access_air(b); dump("chip_memory_access", b); }
         { AirBuilder b(8, 0); ch::memory_boundary_air(b); dump("chip_memory_boundary", b); }
     }

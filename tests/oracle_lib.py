@@ -224,6 +224,17 @@ def var_range_counts(values, bits, max_bits, counts=None):
     return c, int(bad)
 
 
+def castf_trace(xs, log_height, max_bits, counts=None):
+    xs = np.ascontiguousarray(xs, dtype=np.uint32).reshape(-1)
+    tr = np.zeros((6, 1 << log_height), np.uint32)
+    c = np.zeros(1 << (max_bits + 1), np.uint32) if counts is None else np.ascontiguousarray(counts, dtype=np.uint32).copy()
+    l = lib()
+    l.ora_castf_trace.restype = C.c_size_t
+    l.ora_castf_trace.argtypes = [u32p_t(), C.c_size_t, C.c_uint, u32p_t(), u32p_t()]
+    bad = l.ora_castf_trace(p32(xs), len(xs), log_height, p32(tr), p32(c))
+    return tr, c, int(bad)
+
+
 def rv32_lt_trace(opc, bs, cs, log_height, range_counts=None):
     opc, bs, cs = (np.ascontiguousarray(v, dtype=np.uint32).reshape(-1) for v in (opc, bs, cs))
     tr = np.zeros((18, 1 << log_height), np.uint32)

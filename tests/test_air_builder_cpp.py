@@ -76,6 +76,7 @@ PY = {
     "chip_duplex_io": lambda: air.duplex_io_air(10),
     "poseidon2_bus16": lambda: air.poseidon2_air(9, out_lanes=16),
     "chip_var_range_table": lambda: air.var_range_table_air(7),
+    "chip_castf": lambda: air.castf_air(7),
     "chip_memory_access": lambda: air.memory_access_air(),
     "chip_memory_boundary": lambda: air.memory_boundary_air(),
 }

@@ -820,3 +820,37 @@ def test_variable_range_checker(zk, ora):
     assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, proof) == 0
     assert proof == ora.stark_prove(PARAMS, airs).tobytes()
     pk.close()
+
+
+def test_native_castf_chip_with_the_variable_range_checker(zk, ora):
+    """Native CASTF (a field element below 2^30 to limbs of 8, 8, 8, 6 bits) filled on the device, its four limb checks counted
+    into the variable range checker's table in the same pass: cells and counts == oracle, the AIR holds, a value >= 2^30 is
+    refused; chip + table prove from the device-resident traces (bytes == oracle); a limb moved between positions leaves the bus
+    unbalanced."""
+    rng = np.random.default_rng(67)
+    n, lh, B = 3000, 12, 10
+    xs = rng.integers(0, 1 << 30, n).astype(np.uint32)
+    xs[:4] = [0, (1 << 30) - 1, 255, 1 << 24]
+    exp, cnt, bad = ora.castf_trace(xs, lh, B)
+    assert bad == 0 and int(cnt.astype(np.int64).sum()) == 4 * n
+    assert (sum(exp[1 + i][:n].astype(np.uint64) << (8 * i) for i in range(4)) == xs).all() and exp[4][:n].max() < 64
+    prog = air.castf_air(7).program()
+    assert air.check_trace(prog, exp, NOPV) == []
+    as_dev = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.uint32).view(np.int32)).to(zk.device)  # noqa: E731
+    d_cnt = torch.zeros(1 << (B + 1), dtype=torch.int32, device=zk.device)
+    d_tr = zk.castf_tracegen(as_dev(xs), lh, d_cnt, B)
+    assert (zk.download(d_tr).reshape(6, -1) == exp).all() and (zk.download(d_cnt) == cnt).all()
+    with pytest.raises(z.ZkhipError):
+        zk.castf_tracegen(as_dev([1 << 30]), 0, d_cnt.clone(), B)
+    airs = [dict(program=prog, log_height=lh, width=6, n_pvs=0, trace=exp, pvs=NOPV),
+            dict(program=air.var_range_table_air(7).program(), log_height=B + 1, width=1, n_pvs=0, trace=cnt.reshape(1, -1), pvs=NOPV,
+                 prep=air.var_range_prep(B))]
+    pk = z.ProvingKey(zk, PARAMS, airs)
+    proof = pk.prove([d_tr, d_cnt], [NOPV] * 2)
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, airs).tobytes()
+    wrong = exp.copy()     # 2^24 as limbs (0, 0, 256, 0) instead of (0, 0, 0, 1): the sum still holds, the range check does not
+    wrong[3][3], wrong[4][3] = 256, 0
+    assert air.check_trace(prog, wrong, NOPV) == []
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, pk.prove([zk.upload(wrong.reshape(-1)), d_cnt], [NOPV] * 2)) != 0
+    pk.close()

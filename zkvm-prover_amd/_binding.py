@@ -102,6 +102,7 @@ def load_library():
         "zkhip_rv32_branch_eq_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_rv32_branch_lt_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_var_range_counts_tracegen": (C.c_int, [vp, vp, vp, C.c_uint32, sz, C.c_uint, vp, C.c_int]),
+        "zkhip_castf_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp, C.c_uint]),
         "zkhip_field_arith_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_field_ext_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_mmcs_path_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
@@ -402,6 +403,16 @@ class Context:
                                                              0 if col else int(bits), t_values.numel(), max_bits, C.c_void_p(t_counts.data_ptr()),
                                                              1 if accumulate else 0))
         return t_counts
+
+    def castf_tracegen(self, t_x, log_height, t_var_range_counts, max_bits):
+        """6-column trace of the native CASTF chip from records (int32 tensor of values < 2^30); the limb checks are added to
+        t_var_range_counts (the variable range checker's trace)."""
+        import torch
+
+        out = torch.empty(6 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_castf_tracegen(self.h, C.c_void_p(t_x.data_ptr()), t_x.numel(), log_height, C.c_void_p(out.data_ptr()),
+                                                  C.c_void_p(t_var_range_counts.data_ptr()), max_bits))
+        return out
 
     def field_arith_tracegen(self, t_opcode, t_b, t_c, log_height):
         """8-column trace of the native field-arithmetic chip from records (int32 tensors: opcode 0 = ADD .. 3 = DIV, canonical operands)."""

@@ -643,6 +643,22 @@ def var_range_user_air(bus=7):
     return b
 
 
+CASTF_WIDTH = 6
+
+
+def castf_air(bus=7):
+    """The core of OpenVM's native CASTF chip (native `CastFCoreAir`: a field element to four little-endian limbs of 8, 8, 8 and 6
+    bits): columns x | limb[4] | is_valid; x = sum limb_i 2^(8 i), every limb range-checked through the variable range checker
+    ((limb, 8) three times, (limb_3, 6)) -- below 2^30 the decomposition is unique."""
+    b = AirBuilder(CASTF_WIDTH, 0)
+    x, limb, ok = b.var(0), [b.var(1 + i) for i in range(4)], b.var(5)
+    b.assert_zero(ok * (ok - 1))
+    b.assert_zero(ok * (limb[0] + limb[1] * 256 + limb[2] * 65536 + limb[3] * 16777216 - x))
+    for i in range(4):
+        b.push_interaction(bus, [limb[i], 8 if i < 3 else 6], ok, "send")
+    return b
+
+
 def range_tuple_user_air(bus=6):
     """Every row sends the tuple (col0, col1) once; col2 = col0 * col1 keeps a main constraint around."""
     b = AirBuilder(3, 0)

@@ -1216,3 +1216,49 @@ extern "C" int zkhip_var_range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "var_range_counts_tracegen (bits > max_bits or value >= 2^bits)");
 }
+
+// ---- native CASTF core (OpenVM native CastFCoreAir): a field element below 2^30 to limbs of 8, 8, 8, 6 bits -----------------------------
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_castf(const uint32_t* __restrict__ xs, size_t n, size_t N, uint32_t* __restrict__ trace,
+                                               uint32_t* __restrict__ var_range_counts, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_CASTF_WIDTH] = {};
+    if (r < n) {
+        const uint32_t x = xs[r];
+        if (x >> 30) {
+            atomicAdd(bad, 1u);
+        } else {
+            col[0] = to_monty(x), col[5] = MONTY_ONE;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t limb = (x >> (8 * i)) & 255u;
+                col[1 + i] = to_monty(limb);
+                hist_add(var_range_counts, (i < 3 ? 255u : 63u) + limb);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_CASTF_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_castf_tracegen(zkhip_ctx* ctx, const uint32_t* d_x, size_t n, unsigned log_height, uint32_t* d_trace, uint32_t* d_var_range_counts,
+                                    unsigned max_bits) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_var_range_counts || log_height > 27 || max_bits < 8 || max_bits > 26 || (n && !d_x)) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height, T = (size_t)1 << (max_bits + 1);
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "castf_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "castf_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const unsigned tb = (unsigned)((T + 255) / 256);
+    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_var_range_counts, T, 0);
+    hipLaunchKernelGGL(k_castf, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_x, n, N, d_trace, d_var_range_counts, (uint32_t*)flag);
+    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_var_range_counts, T, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "castf_tracegen (value >= 2^30)");
+}
