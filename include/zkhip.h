@@ -281,6 +281,14 @@ int zkhip_var_range_counts_tracegen(zkhip_ctx *ctx, const uint32_t *d_values, co
 int zkhip_castf_tracegen(zkhip_ctx *ctx, const uint32_t *d_x, size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_var_range_counts,
                          unsigned max_bits);
 
+/* FRI fold chip (a piece of the recursion circuit, air.py fri_fold_air): record i = (d_e0[4 i ..], d_e1[4 i ..], d_beta[4 i ..] canonical
+ * extension elements; pair index d_k[i] < 2^d_log_n_out[i]; d_log_n_out[i] <= 26).  Fills d_trace (ZKHIP_FRI_FOLD_WIDTH = 18 columns,
+ * stride 2^log_height, Montgomery: e0[4] | e1[4] | beta[4] | x_inv | folded[4] | is_real) with x = g^bitrev(k) in the subgroup of order
+ * 2^(log_n_out + 1) and folded = (e0 + e1) / 2 + beta (e0 - e1) x_inv / 2 (p3 TwoAdicFriFolding::fold_row, arity 2). */
+#define ZKHIP_FRI_FOLD_WIDTH 18
+int zkhip_fri_fold_chip_tracegen(zkhip_ctx *ctx, const uint32_t *d_e0, const uint32_t *d_e1, const uint32_t *d_beta, const uint32_t *d_k,
+                                 const uint32_t *d_log_n_out, size_t n, unsigned log_height, uint32_t *d_trace);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

@@ -97,9 +97,17 @@ def test_reference_fri_fold_steps_proven(zk, ora, vec):
     from test_fri_fold_chip_cpu import fold_trace
 
     tr, n, lh = fold_trace(vec)
+    # the rows from the device generator: records = the sibling pairs, the layer's beta, the pair's index and layer size
+    recs = [(t["e0"], t["e1"], lay["beta"], t["k"], lay["log_n_out"]) for lay in vec["fri_layers"] for t in lay["triples"]]
+    t32 = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.uint32).view(np.int32)).to(zk.device)  # noqa: E731
+    d_tr = zk.fri_fold_chip_tracegen(t32([r[0] for r in recs]), t32([r[1] for r in recs]), t32([r[2] for r in recs]), t32([r[3] for r in recs]),
+                                     t32([r[4] for r in recs]), lh)
+    assert (zk.download(d_tr).reshape(18, -1) == tr).all()       # incl. folded == the value the reference's proof holds
+    with pytest.raises(z.ZkhipError):                            # an index outside its layer
+        zk.fri_fold_chip_tracegen(t32([[1, 2, 3, 4]]), t32([[1, 2, 3, 4]]), t32([[1, 0, 0, 0]]), t32([8]), t32([3]), 0)
     airs = [dict(program=air.fri_fold_air().program(), log_height=lh, width=18, n_pvs=0, trace=tr, pvs=NOPV)]
     pk = z.ProvingKey(zk, PARAMS, airs)
-    proof = pk.prove([zk.upload(tr.reshape(-1))], [NOPV])
+    proof = pk.prove([d_tr], [NOPV])
     assert z.verify(PARAMS, pk.verifying_airs(), [NOPV], proof) == 0
     assert proof == ora.stark_prove(PARAMS, airs).tobytes()
     w = tr.copy()

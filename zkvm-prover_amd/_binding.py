@@ -102,6 +102,7 @@ def load_library():
         "zkhip_rv32_branch_eq_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_rv32_branch_lt_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_var_range_counts_tracegen": (C.c_int, [vp, vp, vp, C.c_uint32, sz, C.c_uint, vp, C.c_int]),
+        "zkhip_fri_fold_chip_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_castf_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp, C.c_uint]),
         "zkhip_field_arith_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_field_ext_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp]),
@@ -403,6 +404,16 @@ class Context:
                                                              0 if col else int(bits), t_values.numel(), max_bits, C.c_void_p(t_counts.data_ptr()),
                                                              1 if accumulate else 0))
         return t_counts
+
+    def fri_fold_chip_tracegen(self, t_e0, t_e1, t_beta, t_k, t_log_n_out, log_height):
+        """18-column trace of the FRI fold chip from records (int32 tensors: e0, e1, beta [n][4] canonical; pair indices; log2 of the
+        folded layer's size)."""
+        import torch
+
+        out = torch.empty(18 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_fri_fold_chip_tracegen(self.h, *[C.c_void_p(t.data_ptr()) for t in (t_e0, t_e1, t_beta, t_k, t_log_n_out)], t_k.numel(),
+                                                          log_height, C.c_void_p(out.data_ptr())))
+        return out
 
     def castf_tracegen(self, t_x, log_height, t_var_range_counts, max_bits):
         """6-column trace of the native CASTF chip from records (int32 tensor of values < 2^30); the limb checks are added to

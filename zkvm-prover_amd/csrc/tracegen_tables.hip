@@ -1262,3 +1262,58 @@ extern "C" int zkhip_castf_tracegen(zkhip_ctx* ctx, const uint32_t* d_x, size_t 
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "castf_tracegen (value >= 2^30)");
 }
+
+// ---- FRI fold chip (air.py fri_fold_air): one arity-2 folding step per row, generated from the step's data -----------------------------
+// Record = (e0[4], e1[4], beta[4] canonical, pair index k, log_n_out): x = g^bitrev(k) in the subgroup of order 2^(log_n_out + 1),
+// the row holds x^-1 and folded = (e0 + e1) / 2 + beta (e0 - e1) x^-1 / 2 -- the arithmetic a verifier circuit re-does for every
+// query and layer of a child proof.
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_fri_fold_chip(const uint32_t* __restrict__ e0s, const uint32_t* __restrict__ e1s, const uint32_t* __restrict__ betas,
+                                                       const uint32_t* __restrict__ ks, const uint32_t* __restrict__ log_n_outs, size_t n, size_t N,
+                                                       uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[ZKHIP_FRI_FOLD_WIDTH] = {};
+    if (r < n) {
+        const uint32_t k = ks[r], lo = log_n_outs[r];
+        bool ok = lo <= 26 && (lo == 32 || (k >> lo) == 0);
+        Ext e0, e1, beta;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t a = e0s[4 * r + i], b = e1s[4 * r + i], c = betas[4 * r + i];
+            ok = ok && a < P && b < P && c < P;
+            e0.c[i] = to_monty(a), e1.c[i] = to_monty(b), beta.c[i] = to_monty(c);
+        }
+        if (!ok) {
+            atomicAdd(bad, 1u);
+        } else {
+            const uint32_t xinv = minv(mpow(two_adic_generator(lo + 1), bitrev32(k, lo)));
+            const uint32_t half = to_monty((P + 1) / 2);
+            const Ext folded = ext_mul_base(ext_add(ext_add(e0, e1), ext_mul_base(ext_mul(beta, ext_sub(e0, e1)), xinv)), half);
+#pragma unroll
+            for (int i = 0; i < 4; i++) col[i] = e0.c[i], col[4 + i] = e1.c[i], col[8 + i] = beta.c[i], col[13 + i] = folded.c[i];
+            col[12] = xinv, col[17] = MONTY_ONE;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ZKHIP_FRI_FOLD_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_fri_fold_chip_tracegen(zkhip_ctx* ctx, const uint32_t* d_e0, const uint32_t* d_e1, const uint32_t* d_beta, const uint32_t* d_k,
+                                            const uint32_t* d_log_n_out, size_t n, unsigned log_height, uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || log_height > 27 || (n && (!d_e0 || !d_e1 || !d_beta || !d_k || !d_log_n_out))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "fri_fold_chip_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "fri_fold_chip_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_fri_fold_chip, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_e0, d_e1, d_beta, d_k, d_log_n_out, n, N, d_trace,
+                       (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "fri_fold_chip_tracegen (a value that is not a field element, or an index outside its layer)");
+}
