@@ -38,24 +38,24 @@ void profile_begin(zkhip_ctx* ctx, const char* name) {
     PendingEvent pe;
     pe.name = name;
     if (hipEventCreate(&pe.start) != hipSuccess || hipEventCreate(&pe.stop) != hipSuccess) return;
-    hipEventRecord(pe.start, ctx->stream);
+    (void)hipEventRecord(pe.start, ctx->stream);
     ctx->pending.push_back(pe);
 }
 void profile_end(zkhip_ctx* ctx) {
     if (!ctx->profiling || ctx->pending.empty()) return;
-    hipEventRecord(ctx->pending.back().stop, ctx->stream);
+    (void)hipEventRecord(ctx->pending.back().stop, ctx->stream);
 }
 int profile_flush(zkhip_ctx* ctx) {
     for (auto& pe : ctx->pending) {
-        hipEventSynchronize(pe.stop);
+        (void)hipEventSynchronize(pe.stop);
         float ms = 0;
         if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
             auto& st = ctx->stats[pe.name];
             st.launches++;
             st.total_ms += ms;
         }
-        hipEventDestroy(pe.start);
-        hipEventDestroy(pe.stop);
+        (void)hipEventDestroy(pe.start);
+        (void)hipEventDestroy(pe.stop);
     }
     ctx->pending.clear();
     return ZKHIP_OK;
@@ -89,11 +89,11 @@ static int selftest(zkhip_ctx* ctx) {
     uint32_t h_bad = 0;
     if (hipMalloc(&d_bad, 4) != hipSuccess) return ZKHIP_ERR_NOMEM;
     // everything on the context's stream (a non-blocking stream is not ordered against the legacy default stream)
-    hipMemsetAsync(d_bad, 0, 4, ctx->stream);
+    hipError_t e = hipMemsetAsync(d_bad, 0, 4, ctx->stream);
     hipLaunchKernelGGL(k_selftest, dim3(64), dim3(256), 0, ctx->stream, d_bad);
-    hipError_t e = hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    hipFree(d_bad);
+    (void)hipFree(d_bad);
     if (e != hipSuccess) return ZKHIP_ERR_HIP;
     return h_bad == 0 ? ZKHIP_OK : ZKHIP_ERR_HIP;
 }
@@ -130,7 +130,7 @@ int zkhip_ctx_create(int device, zkhip_ctx** out) {
     }
     ctx->stream = ctx->own_stream;
     if (selftest(ctx) != ZKHIP_OK) {
-        hipStreamDestroy(ctx->own_stream);
+        (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;
         return ZKHIP_ERR_HIP;
     }
@@ -143,17 +143,17 @@ int zkhip_ctx_create(int device, zkhip_ctx** out) {
 
 void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
     profile_flush(ctx);
-    if (ctx->d_tw_fwd) hipFree(ctx->d_tw_fwd);
-    if (ctx->d_tw_inv) hipFree(ctx->d_tw_inv);
+    if (ctx->d_tw_fwd) (void)hipFree(ctx->d_tw_fwd);
+    if (ctx->d_tw_inv) (void)hipFree(ctx->d_tw_inv);
     for (int i = 0; i < 8; i++)
-        if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
-    if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
-    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     for (auto& e : ctx->pipe_ev)
-        if (e) hipEventDestroy(e);
+        if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -314,9 +314,9 @@ int zkhip_merkle_open(zkhip_ctx* ctx, const zkhip_tree* t, const uint64_t* indic
 void zkhip_tree_destroy(zkhip_ctx* ctx, zkhip_tree* t) {
     ZK_BIND_DEVICE(ctx);
     if (!t) return;
-    if (ctx) hipStreamSynchronize(ctx->stream);
-    if (t->d_colptrs) hipFree(t->d_colptrs);
-    if (t->d_digests && t->owns_digests) hipFree(t->d_digests);
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (t->d_colptrs) (void)hipFree(t->d_colptrs);
+    if (t->d_digests && t->owns_digests) (void)hipFree(t->d_digests);
     delete t;
 }
 
@@ -363,7 +363,7 @@ int zkhip_transcript_create(zkhip_ctx* ctx, zkhip_transcript** out) {
     }
     int rc = transcript_init(ctx, t->d);
     if (rc != ZKHIP_OK) {
-        hipFree(t->d);
+        (void)hipFree(t->d);
         delete t;
         return rc;
     }
@@ -373,9 +373,9 @@ int zkhip_transcript_create(zkhip_ctx* ctx, zkhip_transcript** out) {
 void zkhip_transcript_destroy(zkhip_ctx* ctx, zkhip_transcript* t) {
     ZK_BIND_DEVICE(ctx);
     if (!t) return;
-    if (ctx) hipStreamSynchronize(ctx->stream);
-    if (t->d) hipFree(t->d);
-    if (t->d_buf) hipFree(t->d_buf);
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (t->d) (void)hipFree(t->d);
+    if (t->d_buf) (void)hipFree(t->d_buf);
     delete t;
 }
 int zkhip_transcript_observe(zkhip_ctx* ctx, zkhip_transcript* t, const uint32_t* vals, size_t n) {

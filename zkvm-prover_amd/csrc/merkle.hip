@@ -271,7 +271,7 @@ int merkle_plan(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, uint32_
                                 : hipSuccess;
     if (e1 == hipSuccess && e2 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);  // host vectors are temporaries
     if (e1 != hipSuccess || e2 != hipSuccess) {
-        hipFree(t->d_colptrs);
+        (void)hipFree(t->d_colptrs);
         delete t;
         return set_error(ctx, ZKHIP_ERR_HIP, "merkle: pointer table upload");
     }
@@ -279,7 +279,7 @@ int merkle_plan(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, uint32_
         t->d_digests = d_digests;
         t->owns_digests = false;
     } else if (hipMalloc(&t->d_digests, merkle_digest_count(lh) * 8 * sizeof(uint32_t)) != hipSuccess) {
-        hipFree(t->d_colptrs);
+        (void)hipFree(t->d_colptrs);
         delete t;
         return set_error(ctx, ZKHIP_ERR_NOMEM, "merkle: digest alloc");
     }
@@ -373,8 +373,8 @@ int merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats, zkhip
     ZK_TRY(merkle_plan(ctx, mats, n_mats, nullptr, &t));
     int rc = merkle_build(ctx, t, false);
     if (rc != ZKHIP_OK) {
-        hipFree(t->d_colptrs);
-        if (t->owns_digests) hipFree(t->d_digests);
+        (void)hipFree(t->d_colptrs);
+        if (t->owns_digests) (void)hipFree(t->d_digests);
         delete t;
         return rc;
     }

@@ -1133,7 +1133,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
                 hipMemcpyAsync(A.d_jit_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
                 hipStreamSynchronize(ctx->stream) == hipSuccess) {
             } else {
-                if (A.jit_mod) hipModuleUnload(A.jit_mod);
+                if (A.jit_mod) (void)hipModuleUnload(A.jit_mod);
                 A.jit_mod = nullptr;
                 A.jit_fn = nullptr;
                 ctx->last_error = "constraint JIT unavailable, using the interpreter kernel: " + msg;
@@ -1662,11 +1662,11 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
 void zkhip_pk_destroy(zkhip_ctx* ctx, zkhip_pk* pk) {
     ZK_BIND_DEVICE(ctx);
     if (!pk) return;
-    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
     if (pk->t_main) zkhip_tree_destroy(ctx, pk->t_main);
-    if (pk->h_open_ptrs_pinned) hipHostFree(pk->h_open_ptrs_pinned);
-    if (pk->h_stage_pinned) hipHostFree(pk->h_stage_pinned);
-    if (pk->stage_ev) hipEventDestroy(pk->stage_ev);
+    if (pk->h_open_ptrs_pinned) (void)hipHostFree(pk->h_open_ptrs_pinned);
+    if (pk->h_stage_pinned) (void)hipHostFree(pk->h_stage_pinned);
+    if (pk->stage_ev) (void)hipEventDestroy(pk->stage_ev);
     if (pk->t_perm) zkhip_tree_destroy(ctx, pk->t_perm);
     for (auto& A : pk->airs) {
         if (A.t_prep) zkhip_tree_destroy(ctx, A.t_prep);
@@ -1676,10 +1676,10 @@ void zkhip_pk_destroy(zkhip_ctx* ctx, zkhip_pk* pk) {
     for (auto* t : pk->t_fri)
         if (t) zkhip_tree_destroy(ctx, t);
     for (auto& A : pk->airs) {
-        if (A.jit_mod) hipModuleUnload(A.jit_mod);
-        if (A.d_jit_tab) hipFree(A.d_jit_tab);
+        if (A.jit_mod) (void)hipModuleUnload(A.jit_mod);
+        if (A.d_jit_tab) (void)hipFree(A.d_jit_tab);
     }
-    if (pk->d_ws) hipFree(pk->d_ws);
+    if (pk->d_ws) (void)hipFree(pk->d_ws);
     delete pk;
 }
 

@@ -495,7 +495,7 @@ inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModu
         return false;
     }
     if (hipModuleGetFunction(fn, *mod, "quot_jit") != hipSuccess) {
-        hipModuleUnload(*mod);
+        (void)hipModuleUnload(*mod);
         *msg = "hipModuleGetFunction failed";
         return false;
     }

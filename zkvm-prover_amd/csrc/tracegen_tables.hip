@@ -178,8 +178,8 @@ extern "C" int zkhip_memory_boundary_tracegen(zkhip_ctx* ctx, const uint32_t* d_
     if (n) {
         // scratch: keys in / out (u64), indices in / out (u32), radix-sort workspace
         size_t tmp_bytes = 0;
-        hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
-                                           (uint32_t*)nullptr, (int)n, 0, 64, ctx->stream);
+        ZK_HIP_CHECK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                                             (uint32_t*)nullptr, (int)n, 0, 64, ctx->stream));   // size query
         const size_t kb = (n * 8 + 255) & ~(size_t)255, ib = (n * 4 + 255) & ~(size_t)255;
         void* buf = nullptr;
         ZK_TRY(get_scratch(ctx, 3, 2 * kb + 2 * ib + tmp_bytes + 256, &buf));
