@@ -289,6 +289,15 @@ int zkhip_castf_tracegen(zkhip_ctx *ctx, const uint32_t *d_x, size_t n, unsigned
 int zkhip_fri_fold_chip_tracegen(zkhip_ctx *ctx, const uint32_t *d_e0, const uint32_t *d_e1, const uint32_t *d_beta, const uint32_t *d_k,
                                  const uint32_t *d_log_n_out, size_t n, unsigned log_height, uint32_t *d_trace);
 
+/* Transcript chip (a piece of the recursion circuit, air.py duplex_air: the DuplexChallenger in-circuit).  Record r = one
+ * duplexing: d_n_observed[r] <= 8 values d_observed[8 r ..] (canonical) overwrite the first rate lanes of the running state, the
+ * state is permuted, d_n_sampled[r] <= 8 output lanes are popped from the end.  Fills d_trace (ZKHIP_DUPLEX_WIDTH = 50 columns, stride
+ * 2^log_height, Montgomery: st_in[16] | st_out[16] | f[8] | s[8] | seq | is_real; rows >= n zero) and d_hash_inputs
+ * ([2^log_height][16]: st_in of every row, the input of zkhip_poseidon2_air_tracegen for the chip serving the 32-field hash bus). */
+#define ZKHIP_DUPLEX_WIDTH 50
+int zkhip_duplex_tracegen(zkhip_ctx *ctx, const uint32_t *d_n_observed, const uint32_t *d_observed, const uint32_t *d_n_sampled, size_t n,
+                          unsigned log_height, uint32_t *d_trace, uint32_t *d_hash_inputs);
+
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,
  * the execution frequency of each instruction; it receives every instruction that often on the program bus (the first AIR of the

@@ -140,12 +140,20 @@ def test_transcript_chip_over_the_poseidon2_chip(zk, ora):
     A = lambda prog, w, x: dict(program=prog, log_height=int(np.log2(x.shape[1])), width=w, n_pvs=0, trace=x, pvs=NOPV)  # noqa: E731
     airs = [A(air.duplex_air(9, 10).program(), 50, t), A(air.poseidon2_air(9, out_lanes=16).program(), 299, chip),
             A(air.duplex_io_air(10).program(), 5, table)]
+    # the chip's rows from the device: one record per duplexing (observed values, how many lanes were sampled afterwards)
+    t32 = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.uint32).view(np.int32)).to(zk.device)  # noqa: E731
+    n_obs = tr[:, 32:40].sum(axis=1).astype(np.uint32)
+    obs = np.where(tr[:, 32:40] == 1, tr[:, 0:8], 0).astype(np.uint32)
+    d_t, d_hin = zk.duplex_tracegen(t32(n_obs), t32(obs), t32(tr[:, 40:48].sum(axis=1)), lh)
+    assert (zk.download(d_t).reshape(50, N) == t).all() and (zk.download(d_hin).reshape(N, 16) == inputs).all()
+    with pytest.raises(z.ZkhipError):
+        zk.duplex_tracegen(t32([9]), t32(np.zeros((1, 8))), t32([0]), 0)
     d_chip = torch.empty(299 * N, dtype=torch.int32, device=zk.device)
-    zk.poseidon2_air_tracegen(zk.upload(inputs.reshape(-1)), lh, d_chip)
+    zk.poseidon2_air_tracegen(d_hin, lh, d_chip)
     d_chip[298 * N:] = zk.upload(chip[298])
     assert (zk.download(d_chip).reshape(299, N) == chip).all()
     pk = z.ProvingKey(zk, PARAMS, airs)
-    proof = pk.prove([zk.upload(t.reshape(-1)), d_chip, zk.upload(table.reshape(-1))], [NOPV] * 3)
+    proof = pk.prove([d_t, d_chip, zk.upload(table.reshape(-1))], [NOPV] * 3)
     assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 3, proof) == 0
     assert proof == ora.stark_prove(PARAMS, airs).tobytes()
     wrong = table.copy()

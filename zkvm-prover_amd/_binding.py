@@ -102,6 +102,7 @@ def load_library():
         "zkhip_rv32_branch_eq_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_rv32_branch_lt_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_var_range_counts_tracegen": (C.c_int, [vp, vp, vp, C.c_uint32, sz, C.c_uint, vp, C.c_int]),
+        "zkhip_duplex_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_fri_fold_chip_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_castf_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp, C.c_uint]),
         "zkhip_field_arith_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp]),
@@ -404,6 +405,18 @@ class Context:
                                                              0 if col else int(bits), t_values.numel(), max_bits, C.c_void_p(t_counts.data_ptr()),
                                                              1 if accumulate else 0))
         return t_counts
+
+    def duplex_tracegen(self, t_n_observed, t_observed, t_n_sampled, log_height):
+        """(50-column trace of the transcript chip, [2^log_height][16] permutation inputs for the Poseidon2 chip) from duplexing
+        records (int32 tensors: observed count per row, observed values [n][8] canonical, sampled count per row)."""
+        import torch
+
+        tr = torch.empty(50 << log_height, dtype=torch.int32, device=self.device)
+        hin = torch.empty(16 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_duplex_tracegen(self.h, C.c_void_p(t_n_observed.data_ptr()), C.c_void_p(t_observed.data_ptr()),
+                                                   C.c_void_p(t_n_sampled.data_ptr()), t_n_observed.numel(), log_height, C.c_void_p(tr.data_ptr()),
+                                                   C.c_void_p(hin.data_ptr())))
+        return tr, hin
 
     def fri_fold_chip_tracegen(self, t_e0, t_e1, t_beta, t_k, t_log_n_out, log_height):
         """18-column trace of the FRI fold chip from records (int32 tensors: e0, e1, beta [n][4] canonical; pair indices; log2 of the

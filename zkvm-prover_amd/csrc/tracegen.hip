@@ -202,9 +202,66 @@ __global__ __launch_bounds__(64) void k_mmcs_path(const uint32_t* __restrict__ l
     }
 }
 
+// ---- transcript chip (air.py duplex_air): the rows of a DuplexChallenger run -----------------------------------------------------
+// Record r = one duplexing: n_observed[r] values (observed[8 r ..], canonical) overwrite the first rate lanes, then the state is
+// permuted; n_sampled[r] output lanes are popped from the end afterwards.  The sponge is a chain, so one lane walks it (a rolled
+// permutation per row); the inputs of every permutation are handed to zkhip_poseidon2_air_tracegen, which is where the width is.
+__global__ void k_duplex_rows(const uint32_t* __restrict__ n_observed, const uint32_t* __restrict__ observed, const uint32_t* __restrict__ n_sampled,
+                              size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ hash_inputs, uint32_t* __restrict__ bad) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint32_t st[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) st[i] = 0;
+    for (size_t r = 0; r < n; r++) {
+        const uint32_t k = n_observed[r], ns = n_sampled[r];
+        if (k > 8 || ns > 8) {
+            atomicAdd(bad, 1u);
+            return;
+        }
+        for (uint32_t j = 0; j < k; j++) {
+            const uint32_t v = observed[8 * r + j];
+            if (v >= P) {
+                atomicAdd(bad, 1u);
+                return;
+            }
+            st[j] = to_monty(v);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) trace[(size_t)i * N + r] = st[i], hash_inputs[16 * r + i] = st[i];
+        poseidon2_permute_rolled(st);
+#pragma unroll
+        for (int i = 0; i < 16; i++) trace[(size_t)(16 + i) * N + r] = st[i];
+        for (uint32_t j = 0; j < 8; j++) {
+            trace[(size_t)(32 + j) * N + r] = j < k ? MONTY_ONE : 0u;
+            trace[(size_t)(40 + j) * N + r] = j >= 8 - ns ? MONTY_ONE : 0u;
+        }
+        trace[(size_t)48 * N + r] = to_monty((uint32_t)r), trace[(size_t)49 * N + r] = MONTY_ONE;
+    }
+}
+
 }  // namespace zk
 
 using namespace zk;
+extern "C" int zkhip_duplex_tracegen(zkhip_ctx* ctx, const uint32_t* d_n_observed, const uint32_t* d_observed, const uint32_t* d_n_sampled, size_t n,
+                                     unsigned log_height, uint32_t* d_trace, uint32_t* d_hash_inputs) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_hash_inputs || log_height > 27 || (n && (!d_n_observed || !d_observed || !d_n_sampled))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "duplex_tracegen: more duplexings than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "duplex_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(d_trace, 0, (size_t)ZKHIP_DUPLEX_WIDTH * N * 4, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(d_hash_inputs, 0, 16 * N * 4, ctx->stream));
+    if (n) hipLaunchKernelGGL(k_duplex_rows, dim3(1), dim3(64), 0, ctx->stream, d_n_observed, d_observed, d_n_sampled, n, N, d_trace, d_hash_inputs, (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    uint32_t h_bad = 0;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_bad) return set_error(ctx, ZKHIP_ERR_INVALID, "duplex_tracegen: a record with more than 8 observed / sampled lanes or a value that is not a field element");
+    return ZKHIP_OK;
+}
 extern "C" int zkhip_mmcs_path_tracegen(zkhip_ctx* ctx, const uint32_t* d_leaf, const uint32_t* d_index, const uint32_t* d_path_start,
                                         const uint32_t* d_step_kind, const uint32_t* d_step_digest, size_t n_paths, unsigned log_height,
                                         uint32_t* d_trace, uint32_t* d_hash_inputs) {
