@@ -46,6 +46,23 @@ timed("rv32_mul (13 cols)", lambda: zk.rv32_mul_tracegen(b, c, lh, d_tab, 256, 8
 timed("exec_frame (10 cols)", lambda: zk.exec_frame_tracegen(idx, d_prog, n_prog, lh), n * (4 + 40))
 timed("program_freq", lambda: zk.program_freq_tracegen(idx, 16), n * 4)
 timed("memory_access (10 cols)", lambda: zk.memory_access_tracegen(as3, ptr, data, pts, data, ts, ones, lh), n * (28 + 40))
+P = 2013265921
+d_tab2 = torch.zeros(256 * 2048, dtype=torch.int32, device=dev)
+op3, op4, imm, pc = b % 3, b % 4, ri(P), (ri(1 << 27) << 2)
+timed("rv32_shift (32 cols)", lambda: zk.rv32_shift_tracegen(op3, b, c, lh, d_bw), n * (12 + 128))
+timed("rv32_mulh (21 cols)", lambda: zk.rv32_mulh_tracegen(op3, b, c, lh, d_tab2, d_bw, 256, 2048), n * (12 + 84))
+timed("rv32_divrem (41 cols)", lambda: zk.rv32_divrem_tracegen(op4, b, c, lh, d_tab2, d_bw, 256, 2048), n * (12 + 164))
+timed("rv32_branch_eq (17 cols)", lambda: zk.rv32_branch_eq_tracegen(op2, b, c, imm, lh), n * (16 + 68))
+timed("rv32_branch_lt (23 cols)", lambda: zk.rv32_branch_lt_tracegen(op4, b, c, imm, lh, d_bw), n * (16 + 92))
+timed("rv32_jal_lui (9 cols)", lambda: zk.rv32_jal_lui_tracegen(op2, pc, torch.where(op2 == 0, imm, imm & 0xFFFFF), lh, d_bw), n * (12 + 36))
+timed("rv32_auipc (14 cols)", lambda: zk.rv32_auipc_tracegen(pc, imm & 0xFFFFF, lh, d_bw), n * (8 + 56))
+timed("rv32_jalr (20 cols)", lambda: zk.rv32_jalr_tracegen(pc, (b >> 2) + 4096, imm & 0xFFF, lh, d_bw), n * (12 + 80))
+timed("rv32_loadstore (33 cols)", lambda: zk.rv32_loadstore_tracegen(b % 20, b, c, lh, d_bw), n * (12 + 132))
+fb, fc = b % P, (c % (P - 1)) + 1
+timed("field_arith (8 cols)", lambda: zk.field_arith_tracegen(op4, fb, fc, lh), n * (12 + 32))
+if lh <= 22:
+    fx, fy = ri(P, 4 * n), ri(P - 1, 4 * n) + 1
+    timed("field_ext (20 cols)", lambda: zk.field_ext_tracegen(op4, fx, fy, lh), n * (36 + 80))
 perm_in = ri(2013265921, 16 * n)
 out = torch.empty(299 * n, dtype=torch.int32, device=dev) if lh <= 22 else None
 if out is not None:
