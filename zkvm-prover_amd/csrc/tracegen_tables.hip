@@ -214,8 +214,9 @@ namespace {
 __global__ __launch_bounds__(256) void k_rv32_alu(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ bs,
                                                   const uint32_t* __restrict__ cs, size_t n, size_t N, uint32_t* __restrict__ trace,
                                                   uint32_t* __restrict__ xor_counts, uint32_t* __restrict__ bad) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
+    __shared__ uint32_t hk_x[HOT_SLOTS], hc_x[HOT_SLOTS];
+    hot_init(hk_x, hc_x);
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (size_t)gridDim.x * 256) {
     uint32_t col[ZKHIP_RV32_ALU_WIDTH] = {};
     if (r < n) {
         const uint32_t op = opc[r], b = bs[r], c = cs[r];
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void k_rv32_alu(const uint32_t* __restrict__ o
                 const uint32_t ai = (a >> (8 * i)) & 255u, bi = (b >> (8 * i)) & 255u, ci = (c >> (8 * i)) & 255u;
                 col[i] = to_monty(ai), col[4 + i] = to_monty(bi), col[8 + i] = to_monty(ci);
                 const uint32_t x = op >= 2 ? bi : ai, y = op >= 2 ? ci : ai;
-                hist_add(xor_counts, (x << 8) | y);
+                hot_add(hk_x, hc_x, xor_counts, (x << 8) | y);
             }
             col[12 + op] = MONTY_ONE;
             col[17] = MONTY_ONE;
@@ -236,6 +237,8 @@ __global__ __launch_bounds__(256) void k_rv32_alu(const uint32_t* __restrict__ o
     }
 #pragma unroll
     for (int q = 0; q < ZKHIP_RV32_ALU_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+    }
+    hot_flush(hk_x, hc_x, xor_counts);
 }
 }  // namespace
 }  // namespace zk
@@ -253,7 +256,7 @@ extern "C" int zkhip_rv32_alu_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode,
     // the XOR multiplicity column of the 8-bit bitwise lookup table (column 1 of its 2 x 2^16 trace): Montgomery -> counts -> Montgomery
     uint32_t* xor_col = d_bitwise_trace + (1u << 16);
     hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 0);
-    hipLaunchKernelGGL(k_rv32_alu, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, xor_col,
+    hipLaunchKernelGGL(k_rv32_alu, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, xor_col,
                        (uint32_t*)flag);
     hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
@@ -270,8 +273,9 @@ namespace zk {
 namespace {
 __global__ __launch_bounds__(256) void k_rv32_mul(const uint32_t* __restrict__ bs, const uint32_t* __restrict__ cs, size_t n, size_t N,
                                                   uint32_t* __restrict__ trace, uint32_t* __restrict__ tuple_counts, uint32_t size_y) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
+    __shared__ uint32_t hk_t[HOT_SLOTS], hc_t[HOT_SLOTS];
+    hot_init(hk_t, hc_t);
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (size_t)gridDim.x * 256) {
     uint32_t col[ZKHIP_RV32_MUL_WIDTH] = {};
     if (r < n) {
         const uint32_t b = bs[r], c = cs[r];
@@ -290,12 +294,14 @@ __global__ __launch_bounds__(256) void k_rv32_mul(const uint32_t* __restrict__ b
             const uint32_t ai = acc & 255u;
             carry = acc >> 8;  // < 1024
             col[i] = to_monty(ai), col[4 + i] = to_monty(bl[i]), col[8 + i] = to_monty(cl[i]);
-            hist_add(tuple_counts, ai * size_y + carry);
+            hot_add(hk_t, hc_t, tuple_counts, ai * size_y + carry);
         }
         col[12] = MONTY_ONE;
     }
 #pragma unroll
     for (int q = 0; q < ZKHIP_RV32_MUL_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+    }
+    hot_flush(hk_t, hc_t, tuple_counts);
 }
 }  // namespace
 }  // namespace zk
@@ -310,7 +316,7 @@ extern "C" int zkhip_rv32_mul_tracegen(zkhip_ctx* ctx, const uint32_t* d_b, cons
     KernelScope ks(ctx, "rv32_mul_tracegen");
     const unsigned tb = (unsigned)((T + 255) / 256);
     hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
-    hipLaunchKernelGGL(k_rv32_mul, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_b, d_c, n, N, d_trace, d_tuple_counts, size_y);
+    hipLaunchKernelGGL(k_rv32_mul, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_b, d_c, n, N, d_trace, d_tuple_counts, size_y);
     hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
@@ -405,8 +411,9 @@ namespace {
 __global__ __launch_bounds__(256) void k_rv32_lt(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ bs,
                                                  const uint32_t* __restrict__ cs, size_t n, size_t N, uint32_t* __restrict__ trace,
                                                  uint32_t* __restrict__ range_counts, uint32_t* __restrict__ bad) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
+    __shared__ uint32_t hk_r[HOT_SLOTS], hc_r[HOT_SLOTS];
+    hot_init(hk_r, hc_r);
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (size_t)gridDim.x * 256) {
     uint32_t col[ZKHIP_RV32_LT_WIDTH] = {};
     if (r < n) {
         const uint32_t op = opc[r], b = bs[r], c = cs[r];
@@ -434,12 +441,14 @@ __global__ __launch_bounds__(256) void k_rv32_lt(const uint32_t* __restrict__ op
             col[12] = to_monty(cm < 0 ? P - (uint32_t)(-cm) : (uint32_t)cm);
             if (mark >= 0) col[13 + mark] = MONTY_ONE, col[17] = to_monty((uint32_t)dv);
             const uint32_t sh = is_slt ? 128u : 0u;
-            hist_add(range_counts, ((uint32_t)(bm + (int)sh) << 8) | (uint32_t)(cm + (int)sh));
-            if (mark >= 0) hist_add(range_counts, (uint32_t)(dv - 1) << 8);
+            hot_add(hk_r, hc_r, range_counts, ((uint32_t)(bm + (int)sh) << 8) | (uint32_t)(cm + (int)sh));
+            if (mark >= 0) hot_add(hk_r, hc_r, range_counts, (uint32_t)(dv - 1) << 8);
         }
     }
 #pragma unroll
     for (int q = 0; q < ZKHIP_RV32_LT_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+    }
+    hot_flush(hk_r, hc_r, range_counts);
 }
 }  // namespace
 }  // namespace zk
@@ -456,7 +465,7 @@ extern "C" int zkhip_rv32_lt_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, 
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     // the RANGE multiplicity column of the 8-bit bitwise lookup table (column 0 of its 2 x 2^16 trace)
     hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
-    hipLaunchKernelGGL(k_rv32_lt, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_bitwise_trace,
+    hipLaunchKernelGGL(k_rv32_lt, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_bitwise_trace,
                        (uint32_t*)flag);
     hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
@@ -525,8 +534,10 @@ __global__ __launch_bounds__(256) void k_rv32_shift(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ cs, size_t n, size_t N, uint32_t* __restrict__ trace,
                                                     uint32_t* __restrict__ range_counts, uint32_t* __restrict__ xor_counts,
                                                     uint32_t* __restrict__ bad) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
+    __shared__ uint32_t hot_k[HOT_SLOTS], hot_c[HOT_SLOTS];   // one cache for both columns of the bitwise table (xor = range + 2^16)
+    hot_init(hot_k, hot_c);
+    const uint32_t xor_off = (uint32_t)(xor_counts - range_counts);
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (size_t)gridDim.x * 256) {
     uint32_t col[ZKHIP_RV32_SHIFT_WIDTH] = {};
     if (r < n) {
         const uint32_t op = opc[r], b = bs[r], c = cs[r];
@@ -557,15 +568,17 @@ __global__ __launch_bounds__(256) void k_rv32_shift(const uint32_t* __restrict__
             col[29] = to_monty(q);
             col[op == 0 ? 30 : 31] = to_monty(mult);
 #pragma unroll
-            for (int i = 0; i < 4; i++) hist_add(range_counts, (cy[i] << 8) | (mult - 1u - cy[i]));
-            hist_add(range_counts, (al[0] << 8) | al[1]);
-            hist_add(range_counts, (al[2] << 8) | al[3]);
-            hist_add(range_counts, (q << 8) | (32u * q));
-            if (op == 2) hist_add(xor_counts, (bl[3] << 8) | 128u);
+            for (int i = 0; i < 4; i++) hot_add(hot_k, hot_c, range_counts, (cy[i] << 8) | (mult - 1u - cy[i]));
+            hot_add(hot_k, hot_c, range_counts, (al[0] << 8) | al[1]);
+            hot_add(hot_k, hot_c, range_counts, (al[2] << 8) | al[3]);
+            hot_add(hot_k, hot_c, range_counts, (q << 8) | (32u * q));
+            if (op == 2) hot_add(hot_k, hot_c, range_counts, xor_off + ((bl[3] << 8) | 128u));
         }
     }
 #pragma unroll
     for (int qq = 0; qq < ZKHIP_RV32_SHIFT_WIDTH; qq++) trace[(size_t)qq * N + r] = col[qq];
+    }
+    hot_flush(hot_k, hot_c, range_counts);
 }
 }  // namespace
 }  // namespace zk
@@ -581,7 +594,7 @@ extern "C" int zkhip_rv32_shift_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcod
     KernelScope ks(ctx, "rv32_shift_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_tab_repr, dim3(512), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 0);  // both columns
-    hipLaunchKernelGGL(k_rv32_shift, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace,
+    hipLaunchKernelGGL(k_rv32_shift, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace,
                        d_bitwise_trace, d_bitwise_trace + (1u << 16), (uint32_t*)flag);
     hipLaunchKernelGGL(k_tab_repr, dim3(512), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
@@ -654,8 +667,9 @@ namespace {
 __global__ __launch_bounds__(256) void k_rv32_branch_lt(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ as, const uint32_t* __restrict__ bs,
                                                         const uint32_t* __restrict__ imms, size_t n, size_t N, uint32_t* __restrict__ trace,
                                                         uint32_t* __restrict__ range_counts, uint32_t* __restrict__ bad) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
+    __shared__ uint32_t hk_r[HOT_SLOTS], hc_r[HOT_SLOTS];
+    hot_init(hk_r, hc_r);
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (size_t)gridDim.x * 256) {
     uint32_t col[ZKHIP_RV32_BRANCH_LT_WIDTH] = {};
     if (r < n) {
         const uint32_t op = opc[r], a = as[r], b = bs[r], imm = imms[r];
@@ -684,12 +698,14 @@ __global__ __launch_bounds__(256) void k_rv32_branch_lt(const uint32_t* __restri
             if (mark >= 0) col[17 + mark] = MONTY_ONE, col[21] = to_monty((uint32_t)dv);
             col[22] = taken ? to_monty(imm) : to_monty(4u);
             const int sh = is_signed ? 128 : 0;
-            hist_add(range_counts, ((uint32_t)(am + sh) << 8) | (uint32_t)(bm + sh));
-            if (mark >= 0) hist_add(range_counts, (uint32_t)(dv - 1) << 8);
+            hot_add(hk_r, hc_r, range_counts, ((uint32_t)(am + sh) << 8) | (uint32_t)(bm + sh));
+            if (mark >= 0) hot_add(hk_r, hc_r, range_counts, (uint32_t)(dv - 1) << 8);
         }
     }
 #pragma unroll
     for (int q = 0; q < ZKHIP_RV32_BRANCH_LT_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+    }
+    hot_flush(hk_r, hc_r, range_counts);
 }
 }  // namespace
 }  // namespace zk
@@ -705,7 +721,7 @@ extern "C" int zkhip_rv32_branch_lt_tracegen(zkhip_ctx* ctx, const uint32_t* d_o
     KernelScope ks(ctx, "rv32_branch_lt_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
-    hipLaunchKernelGGL(k_rv32_branch_lt, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_a, d_b, d_imm, n, N, d_trace,
+    hipLaunchKernelGGL(k_rv32_branch_lt, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_a, d_b, d_imm, n, N, d_trace,
                        d_bitwise_trace, (uint32_t*)flag);
     hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
@@ -717,12 +733,16 @@ extern "C" int zkhip_rv32_branch_lt_tracegen(zkhip_ctx* ctx, const uint32_t* d_o
 namespace zk {
 namespace {
 __device__ __forceinline__ void bump_range(uint32_t* range_counts, uint32_t x, uint32_t y) { hist_add(range_counts, (x << 8) | y); }
+__device__ __forceinline__ void bump_range_hot(uint32_t* keys, uint32_t* cnts, uint32_t* range_counts, uint32_t x, uint32_t y) {
+    hot_add(keys, cnts, range_counts, (x << 8) | y);
+}
 
 __global__ __launch_bounds__(256) void k_rv32_jal_lui(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ pcs, const uint32_t* __restrict__ imms,
                                                       size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ range_counts,
                                                       uint32_t* __restrict__ bad) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
+    __shared__ uint32_t hk_r[HOT_SLOTS], hc_r[HOT_SLOTS];
+    hot_init(hk_r, hc_r);
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (size_t)gridDim.x * 256) {
     uint32_t col[ZKHIP_RV32_JAL_LUI_WIDTH] = {};
     if (r < n) {
         const uint32_t op = opc[r], pc = pcs[r], imm = imms[r];
@@ -736,19 +756,22 @@ __global__ __launch_bounds__(256) void k_rv32_jal_lui(const uint32_t* __restrict
             for (int i = 0; i < 4; i++) col[2 + i] = to_monty((rd >> (8 * i)) & 255u);
             col[6 + op] = MONTY_ONE;
             col[8] = op == 0 ? to_monty(imm) : to_monty(4u);
-            bump_range(range_counts, rd & 255u, (rd >> 8) & 255u);
-            bump_range(range_counts, (rd >> 16) & 255u, rd >> 24);
-            if (op == 0) bump_range(range_counts, (rd >> 24) * 4, 0);
+            bump_range_hot(hk_r, hc_r, range_counts, rd & 255u, (rd >> 8) & 255u);
+            bump_range_hot(hk_r, hc_r, range_counts, (rd >> 16) & 255u, rd >> 24);
+            if (op == 0) bump_range_hot(hk_r, hc_r, range_counts, (rd >> 24) * 4, 0);
         }
     }
 #pragma unroll
     for (int q = 0; q < ZKHIP_RV32_JAL_LUI_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+    }
+    hot_flush(hk_r, hc_r, range_counts);
 }
 
 __global__ __launch_bounds__(256) void k_rv32_auipc(const uint32_t* __restrict__ pcs, const uint32_t* __restrict__ imms, size_t n, size_t N,
                                                     uint32_t* __restrict__ trace, uint32_t* __restrict__ range_counts, uint32_t* __restrict__ bad) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
+    __shared__ uint32_t hk_r[HOT_SLOTS], hc_r[HOT_SLOTS];
+    hot_init(hk_r, hc_r);
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (size_t)gridDim.x * 256) {
     uint32_t col[ZKHIP_RV32_AUIPC_WIDTH] = {};
     if (r < n) {
         const uint32_t pc = pcs[r], imm = imms[r];
@@ -767,19 +790,22 @@ __global__ __launch_bounds__(256) void k_rv32_auipc(const uint32_t* __restrict__
 #pragma unroll
             for (int i = 0; i < 3; i++) col[6 + i] = to_monty(il[i]);
             col[13] = MONTY_ONE;
-            bump_range(range_counts, pl[0], pl[1]), bump_range(range_counts, pl[2], 4 * pl[3]), bump_range(range_counts, il[0], il[1]);
-            bump_range(range_counts, il[2], dl[1]), bump_range(range_counts, dl[2], dl[3]);
+            bump_range_hot(hk_r, hc_r, range_counts, pl[0], pl[1]), bump_range_hot(hk_r, hc_r, range_counts, pl[2], 4 * pl[3]), bump_range_hot(hk_r, hc_r, range_counts, il[0], il[1]);
+            bump_range_hot(hk_r, hc_r, range_counts, il[2], dl[1]), bump_range_hot(hk_r, hc_r, range_counts, dl[2], dl[3]);
         }
     }
 #pragma unroll
     for (int q = 0; q < ZKHIP_RV32_AUIPC_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+    }
+    hot_flush(hk_r, hc_r, range_counts);
 }
 
 __global__ __launch_bounds__(256) void k_rv32_jalr(const uint32_t* __restrict__ pcs, const uint32_t* __restrict__ rs1s, const uint32_t* __restrict__ imms,
                                                    size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ range_counts,
                                                    uint32_t* __restrict__ bad) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
+    __shared__ uint32_t hk_r[HOT_SLOTS], hc_r[HOT_SLOTS];
+    hot_init(hk_r, hc_r);
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (size_t)gridDim.x * 256) {
     uint32_t col[ZKHIP_RV32_JALR_WIDTH] = {};
     if (r < n) {
         const uint32_t pc = pcs[r], rs1 = rs1s[r], imm = imms[r];
@@ -795,15 +821,17 @@ __global__ __launch_bounds__(256) void k_rv32_jalr(const uint32_t* __restrict__ 
                 col[13 + i] = to_monty((t >> (8 * i)) & 255u);
             }
             col[17] = (t & 1u) ? MONTY_ONE : 0u, col[18] = to_monty(to_pc), col[19] = MONTY_ONE;
-            bump_range(range_counts, imm & 255u, ((imm >> 8) - 8 * sign) * 32);
-            bump_range(range_counts, (t & 255u) >> 1, (t >> 8) & 255u);
-            bump_range(range_counts, (t >> 16) & 255u, t >> 24);
-            bump_range(range_counts, rd & 255u, (rd >> 8) & 255u);
-            bump_range(range_counts, (rd >> 16) & 255u, (rd >> 24) * 4);
+            bump_range_hot(hk_r, hc_r, range_counts, imm & 255u, ((imm >> 8) - 8 * sign) * 32);
+            bump_range_hot(hk_r, hc_r, range_counts, (t & 255u) >> 1, (t >> 8) & 255u);
+            bump_range_hot(hk_r, hc_r, range_counts, (t >> 16) & 255u, t >> 24);
+            bump_range_hot(hk_r, hc_r, range_counts, rd & 255u, (rd >> 8) & 255u);
+            bump_range_hot(hk_r, hc_r, range_counts, (rd >> 16) & 255u, (rd >> 24) * 4);
         }
     }
 #pragma unroll
     for (int q = 0; q < ZKHIP_RV32_JALR_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+    }
+    hot_flush(hk_r, hc_r, range_counts);
 }
 
 // shared launch frame of the three: flag, table to counts, the chip's kernel, table back to Montgomery form
@@ -816,7 +844,7 @@ int jump_chip_tracegen(zkhip_ctx* ctx, const char* name, size_t n, unsigned log_
     KernelScope ks(ctx, name);
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
-    launch(dim3((unsigned)((N + 255) / 256)), N, (uint32_t*)flag);
+    launch(dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), N, (uint32_t*)flag);
     hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, name);
@@ -860,8 +888,11 @@ namespace {
 __global__ __launch_bounds__(256) void k_rv32_mulh(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ bs, const uint32_t* __restrict__ cs,
                                                    size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ tuple_counts, uint32_t size_y,
                                                    uint32_t* __restrict__ range_counts, uint32_t* __restrict__ bad) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
+    __shared__ uint32_t hk_t[HOT_SLOTS], hc_t[HOT_SLOTS];
+    hot_init(hk_t, hc_t);
+    __shared__ uint32_t hk_r[HOT_SLOTS], hc_r[HOT_SLOTS];
+    hot_init(hk_r, hc_r);
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (size_t)gridDim.x * 256) {
     uint32_t col[ZKHIP_RV32_MULH_WIDTH] = {};
     if (r < n) {
         const uint32_t op = opc[r], b = bs[r], c = cs[r];
@@ -887,18 +918,21 @@ __global__ __launch_bounds__(256) void k_rv32_mulh(const uint32_t* __restrict__ 
                 const uint32_t limb = acc & 255u;
                 carry = acc >> 8;   // < 2048
                 col[i < 4 ? 12 + i : i - 4] = to_monty(limb);
-                hist_add(tuple_counts, limb * size_y + carry);
+                hot_add(hk_t, hc_t, tuple_counts, limb * size_y + carry);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) col[4 + i] = to_monty(l[i]), col[8 + i] = to_monty(m[i]);
             col[16] = b_sign ? MONTY_ONE : 0u, col[17] = c_sign ? MONTY_ONE : 0u;
             col[18 + op] = MONTY_ONE;
-            if (op != 2) bump_range(range_counts, 2 * (l[3] - 128 * b_sign), 0);
-            if (op == 0) bump_range(range_counts, 2 * (m[3] - 128 * c_sign), 0);
+            if (op != 2) bump_range_hot(hk_r, hc_r, range_counts, 2 * (l[3] - 128 * b_sign), 0);
+            if (op == 0) bump_range_hot(hk_r, hc_r, range_counts, 2 * (m[3] - 128 * c_sign), 0);
         }
     }
 #pragma unroll
     for (int q = 0; q < ZKHIP_RV32_MULH_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+    }
+    hot_flush(hk_t, hc_t, tuple_counts);
+    hot_flush(hk_r, hc_r, range_counts);
 }
 }  // namespace
 }  // namespace zk
@@ -918,7 +952,7 @@ extern "C" int zkhip_rv32_mulh_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode
     const unsigned tb = (unsigned)((T + 255) / 256);
     hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
     hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
-    hipLaunchKernelGGL(k_rv32_mulh, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_tuple_counts, size_y,
+    hipLaunchKernelGGL(k_rv32_mulh, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_tuple_counts, size_y,
                        d_bitwise_trace, (uint32_t*)flag);
     hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
     hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
@@ -935,8 +969,9 @@ namespace {
 __global__ __launch_bounds__(256) void k_rv32_loadstore(const uint32_t* __restrict__ cases, const uint32_t* __restrict__ reads,
                                                         const uint32_t* __restrict__ prevs, size_t n, size_t N, uint32_t* __restrict__ trace,
                                                         uint32_t* __restrict__ range_counts, uint32_t* __restrict__ bad) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
+    __shared__ uint32_t hk_r[HOT_SLOTS], hc_r[HOT_SLOTS];
+    hot_init(hk_r, hc_r);
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (size_t)gridDim.x * 256) {
     uint32_t rd = 0, pv = 0, wr = 0, cs = 0xffffffffu, sign = 0;
     if (r < n) {
         cs = cases[r], rd = reads[r], pv = prevs[r];
@@ -957,7 +992,7 @@ __global__ __launch_bounds__(256) void k_rv32_loadstore(const uint32_t* __restri
                 if (cs >= 14) {
                     sign = (wr >> (8 * nb - 1)) & 1u;
                     if (sign) wr |= ~mask;
-                    bump_range(range_counts, 2 * (((wr >> (8 * (nb - 1))) & 255u) - 128 * sign), 0);
+                    bump_range_hot(hk_r, hc_r, range_counts, 2 * (((wr >> (8 * (nb - 1))) & 255u) - 128 * sign), 0);
                 }
             }
         }
@@ -971,6 +1006,8 @@ __global__ __launch_bounds__(256) void k_rv32_loadstore(const uint32_t* __restri
 #pragma unroll
     for (unsigned q = 0; q < 20; q++) trace[(size_t)(12 + q) * N + r] = q == cs ? MONTY_ONE : 0u;
     trace[(size_t)32 * N + r] = sign ? MONTY_ONE : 0u;
+    }
+    hot_flush(hk_r, hc_r, range_counts);
 }
 }  // namespace
 }  // namespace zk
@@ -994,8 +1031,11 @@ namespace {
 __global__ __launch_bounds__(256) void k_rv32_divrem(const uint32_t* __restrict__ opc, const uint32_t* __restrict__ bs, const uint32_t* __restrict__ cs,
                                                      size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ tuple_counts, uint32_t size_y,
                                                      uint32_t* __restrict__ range_counts, uint32_t* __restrict__ bad) {
-    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (row >= N) return;
+    __shared__ uint32_t hk_t[HOT_SLOTS], hc_t[HOT_SLOTS];
+    hot_init(hk_t, hc_t);
+    __shared__ uint32_t hk_r[HOT_SLOTS], hc_r[HOT_SLOTS];
+    hot_init(hk_r, hc_r);
+    for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < N; row += (size_t)gridDim.x * 256) {
     uint32_t col[ZKHIP_RV32_DIVREM_WIDTH] = {};
     if (row < n) {
         const uint32_t op = opc[row], b = bs[row], c = cs[row];
@@ -1032,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_rv32_divrem(const uint32_t* __restrict_
                     }
                 const uint32_t d = ((ca >> (8 * mark)) & 255u) - ((ra >> (8 * mark)) & 255u);
                 col[32 + mark] = MONTY_ONE, col[36] = to_monty(d);
-                bump_range(range_counts, d - 1, 0);
+                bump_range_hot(hk_r, hc_r, range_counts, d - 1, 0);
             }
             // c q + r - b over eight sign-extended limbs; the limbs are opaque to the optimiser (see k_rv32_mulh)
             uint32_t l[8], m[8];
@@ -1050,15 +1090,18 @@ __global__ __launch_bounds__(256) void k_rv32_divrem(const uint32_t* __restrict_
 #pragma unroll
                 for (int k = 0; k <= i; k++) acc += (int)(l[k] * m[i - k]);
                 carry = acc >> 8;
-                hist_add(tuple_counts, (i < 4 ? m[i] : (uint32_t)rr[i - 4]) * size_y + (uint32_t)carry);
+                hot_add(hk_t, hc_t, tuple_counts, (i < 4 ? m[i] : (uint32_t)rr[i - 4]) * size_y + (uint32_t)carry);
             }
-            if (is_signed) bump_range(range_counts, 2 * ((b >> 24) - 128 * b_sign), 2 * ((c >> 24) - 128 * c_sign));
-            bump_range(range_counts, ca & 255u, (ca >> 8) & 255u), bump_range(range_counts, (ca >> 16) & 255u, ca >> 24);
-            bump_range(range_counts, ra & 255u, (ra >> 8) & 255u), bump_range(range_counts, (ra >> 16) & 255u, ra >> 24);
+            if (is_signed) bump_range_hot(hk_r, hc_r, range_counts, 2 * ((b >> 24) - 128 * b_sign), 2 * ((c >> 24) - 128 * c_sign));
+            bump_range_hot(hk_r, hc_r, range_counts, ca & 255u, (ca >> 8) & 255u), bump_range_hot(hk_r, hc_r, range_counts, (ca >> 16) & 255u, ca >> 24);
+            bump_range_hot(hk_r, hc_r, range_counts, ra & 255u, (ra >> 8) & 255u), bump_range_hot(hk_r, hc_r, range_counts, (ra >> 16) & 255u, ra >> 24);
         }
     }
 #pragma unroll
     for (int q = 0; q < ZKHIP_RV32_DIVREM_WIDTH; q++) trace[(size_t)q * N + row] = col[q];
+    }
+    hot_flush(hk_t, hc_t, tuple_counts);
+    hot_flush(hk_r, hc_r, range_counts);
 }
 }  // namespace
 }  // namespace zk
@@ -1078,7 +1121,7 @@ extern "C" int zkhip_rv32_divrem_tracegen(zkhip_ctx* ctx, const uint32_t* d_opco
     const unsigned tb = (unsigned)((T + 255) / 256);
     hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
     hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
-    hipLaunchKernelGGL(k_rv32_divrem, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_tuple_counts,
+    hipLaunchKernelGGL(k_rv32_divrem, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_tuple_counts,
                        size_y, d_bitwise_trace, (uint32_t*)flag);
     hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
     hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
@@ -1222,8 +1265,9 @@ namespace zk {
 namespace {
 __global__ __launch_bounds__(256) void k_castf(const uint32_t* __restrict__ xs, size_t n, size_t N, uint32_t* __restrict__ trace,
                                                uint32_t* __restrict__ var_range_counts, uint32_t* __restrict__ bad) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= N) return;
+    __shared__ uint32_t hk_v[HOT_SLOTS], hc_v[HOT_SLOTS];
+    hot_init(hk_v, hc_v);
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < N; r += (size_t)gridDim.x * 256) {
     uint32_t col[ZKHIP_CASTF_WIDTH] = {};
     if (r < n) {
         const uint32_t x = xs[r];
@@ -1235,12 +1279,14 @@ __global__ __launch_bounds__(256) void k_castf(const uint32_t* __restrict__ xs, 
             for (int i = 0; i < 4; i++) {
                 const uint32_t limb = (x >> (8 * i)) & 255u;
                 col[1 + i] = to_monty(limb);
-                hist_add(var_range_counts, (i < 3 ? 255u : 63u) + limb);
+                hot_add(hk_v, hc_v, var_range_counts, (i < 3 ? 255u : 63u) + limb);
             }
         }
     }
 #pragma unroll
     for (int q = 0; q < ZKHIP_CASTF_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+    }
+    hot_flush(hk_v, hc_v, var_range_counts);
 }
 }  // namespace
 }  // namespace zk
@@ -1257,7 +1303,7 @@ extern "C" int zkhip_castf_tracegen(zkhip_ctx* ctx, const uint32_t* d_x, size_t 
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
     hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_var_range_counts, T, 0);
-    hipLaunchKernelGGL(k_castf, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_x, n, N, d_trace, d_var_range_counts, (uint32_t*)flag);
+    hipLaunchKernelGGL(k_castf, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_x, n, N, d_trace, d_var_range_counts, (uint32_t*)flag);
     hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_var_range_counts, T, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "castf_tracegen (value >= 2^30)");
