@@ -37,6 +37,8 @@ __global__ void k_tab_repr(uint32_t* c, size_t n, int to_m) {
 __global__ __launch_bounds__(256) void k_tuple_counts(const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, size_t n,
                                                       uint32_t size_x, uint32_t size_y, uint32_t* __restrict__ hist,
                                                       uint32_t* __restrict__ bad) {
+    __shared__ uint32_t hk[HOT_SLOTS], hc[HOT_SLOTS];   // hot entries counted in LDS, merged once per workgroup (csrc/hist.hpp)
+    hot_init(hk, hc);
     uint32_t n_bad = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const uint32_t x = from_monty(xs[i]), y = from_monty(ys[i]);
@@ -44,15 +46,18 @@ __global__ __launch_bounds__(256) void k_tuple_counts(const uint32_t* __restrict
             n_bad++;
             continue;
         }
-        hist_add(hist, (uint32_t)((size_t)x * size_y + y));
+        hot_add(hk, hc, hist, (uint32_t)((size_t)x * size_y + y));
     }
     if (n_bad) atomicAdd(bad, n_bad);
+    hot_flush(hk, hc, hist);
 }
 
 // column 0 (range requests) / column 1 (xor requests) of the table of all (x, y): row (x << bits) + y
 __global__ __launch_bounds__(256) void k_bitwise_counts(const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
                                                         const uint32_t* __restrict__ ops, size_t n, unsigned bits,
                                                         uint32_t* __restrict__ hist, uint32_t* __restrict__ bad) {
+    __shared__ uint32_t hk[HOT_SLOTS], hc[HOT_SLOTS];   // hot entries counted in LDS, merged once per workgroup (csrc/hist.hpp)
+    hot_init(hk, hc);
     uint32_t n_bad = 0;
     const uint32_t lim = 1u << bits;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -61,9 +66,10 @@ __global__ __launch_bounds__(256) void k_bitwise_counts(const uint32_t* __restri
             n_bad++;
             continue;
         }
-        hist_add(hist, (uint32_t)(((size_t)op << (2 * bits)) + ((size_t)x << bits) + y));
+        hot_add(hk, hc, hist, (uint32_t)(((size_t)op << (2 * bits)) + ((size_t)x << bits) + y));
     }
     if (n_bad) atomicAdd(bad, n_bad);
+    hot_flush(hk, hc, hist);
 }
 
 __global__ void k_boundary_keys(const uint32_t* __restrict__ as, const uint32_t* __restrict__ ptr, size_t n, uint64_t* keys,
@@ -131,7 +137,7 @@ extern "C" int zkhip_range_tuple_counts_tracegen(zkhip_ctx* ctx, const uint32_t*
     if (accumulate) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
     else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
     if (n) {
-        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), 8192);
+        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), HOT_MAX_BLOCKS);
         hipLaunchKernelGGL(k_tuple_counts, dim3(blocks), dim3(256), 0, ctx->stream, d_x, d_y, n, size_x, size_y, d_counts, (uint32_t*)flag);
     }
     hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
@@ -152,7 +158,7 @@ extern "C" int zkhip_bitwise_lookup_tracegen(zkhip_ctx* ctx, const uint32_t* d_x
     if (accumulate) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_trace, T, 0);
     else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_trace, 0, T * 4, ctx->stream));
     if (n) {
-        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), 8192);
+        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), HOT_MAX_BLOCKS);
         hipLaunchKernelGGL(k_bitwise_counts, dim3(blocks), dim3(256), 0, ctx->stream, d_x, d_y, d_op, n, num_bits, d_trace, (uint32_t*)flag);
     }
     hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_trace, T, 1);
@@ -1225,6 +1231,8 @@ namespace zk {
 namespace {
 __global__ __launch_bounds__(256) void k_var_range_counts(const uint32_t* __restrict__ values, const uint32_t* __restrict__ bits, uint32_t const_bits,
                                                           size_t n, unsigned max_bits, uint32_t* __restrict__ hist, uint32_t* __restrict__ bad) {
+    __shared__ uint32_t hk[HOT_SLOTS], hc[HOT_SLOTS];   // hot entries counted in LDS, merged once per workgroup (csrc/hist.hpp)
+    hot_init(hk, hc);
     uint32_t n_bad = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const uint32_t b = bits ? from_monty(bits[i]) : const_bits, v = from_monty(values[i]);
@@ -1232,9 +1240,10 @@ __global__ __launch_bounds__(256) void k_var_range_counts(const uint32_t* __rest
             n_bad++;
             continue;
         }
-        hist_add(hist, (1u << b) - 1 + v);
+        hot_add(hk, hc, hist, (1u << b) - 1 + v);
     }
     if (n_bad) atomicAdd(bad, n_bad);
+    hot_flush(hk, hc, hist);
 }
 }  // namespace
 }  // namespace zk
@@ -1252,7 +1261,7 @@ extern "C" int zkhip_var_range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d
     if (accumulate) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
     else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
     if (n) {
-        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), 8192);
+        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), HOT_MAX_BLOCKS);
         hipLaunchKernelGGL(k_var_range_counts, dim3(blocks), dim3(256), 0, ctx->stream, d_values, d_bits, const_bits, n, max_bits, d_counts, (uint32_t*)flag);
     }
     hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
