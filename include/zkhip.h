@@ -282,10 +282,10 @@ int zkhip_castf_tracegen(zkhip_ctx *ctx, const uint32_t *d_x, size_t n, unsigned
                          unsigned max_bits);
 
 /* FRI fold chip (a piece of the recursion circuit, air.py fri_fold_air): record i = (d_e0[4 i ..], d_e1[4 i ..], d_beta[4 i ..] canonical
- * extension elements; pair index d_k[i] < 2^d_log_n_out[i]; d_log_n_out[i] <= 26).  Fills d_trace (ZKHIP_FRI_FOLD_WIDTH = 18 columns,
- * stride 2^log_height, Montgomery: e0[4] | e1[4] | beta[4] | x_inv | folded[4] | is_real) with x = g^bitrev(k) in the subgroup of order
+ * extension elements; pair index d_k[i] < 2^d_log_n_out[i]; d_log_n_out[i] <= 26).  Fills d_trace (ZKHIP_FRI_FOLD_WIDTH = 19 columns,
+ * stride 2^log_height, Montgomery: e0[4] | e1[4] | beta[4] | x_inv | folded[4] | is_real | k) with x = g^bitrev(k) in the subgroup of order
  * 2^(log_n_out + 1) and folded = (e0 + e1) / 2 + beta (e0 - e1) x_inv / 2 (p3 TwoAdicFriFolding::fold_row, arity 2). */
-#define ZKHIP_FRI_FOLD_WIDTH 18
+#define ZKHIP_FRI_FOLD_WIDTH 19
 int zkhip_fri_fold_chip_tracegen(zkhip_ctx *ctx, const uint32_t *d_e0, const uint32_t *d_e1, const uint32_t *d_beta, const uint32_t *d_k,
                                  const uint32_t *d_log_n_out, size_t n, unsigned log_height, uint32_t *d_trace);
 
@@ -297,6 +297,13 @@ int zkhip_fri_fold_chip_tracegen(zkhip_ctx *ctx, const uint32_t *d_e0, const uin
 #define ZKHIP_DUPLEX_WIDTH 50
 int zkhip_duplex_tracegen(zkhip_ctx *ctx, const uint32_t *d_n_observed, const uint32_t *d_observed, const uint32_t *d_n_sampled, size_t n,
                           unsigned log_height, uint32_t *d_trace, uint32_t *d_hash_inputs);
+
+/* Domain-point chip (air.py domain_point_air): row i = pair index d_k[i] (< 2^26), its bits, the running product that ends in
+ * x^-1 for x = g^bitrev(k) (the same per-bit constants for a layer of any size), and the multiplicity d_mult[i] with which rows of
+ * the FRI fold chip use the pair.  ZKHIP_DOMAIN_POINT_WIDTH = 54 columns: k | bit[26] | acc[26] | mult; rows >= n: k = 0, mult = 0. */
+#define ZKHIP_DOMAIN_POINT_BITS 26
+#define ZKHIP_DOMAIN_POINT_WIDTH 54
+int zkhip_domain_point_tracegen(zkhip_ctx *ctx, const uint32_t *d_k, const uint32_t *d_mult, size_t n, unsigned log_height, uint32_t *d_trace);
 
 /* System chips: the PROGRAM chip and the execution frames that look instructions up in it.  OpenVM's ProgramAir keeps the program
  * (ZKHIP_PROGRAM_FIELDS = 9 fields per instruction: pc, opcode, operands a..g) as a CACHED main partition and one common column,

@@ -1116,14 +1116,14 @@ inline void field_ext_air(AirBuilder& b) {
 }
 
 // air.fri_fold_air(): AirBuilder(18, 0) -- one arity-2 FRI folding step per row
-inline void fri_fold_air(AirBuilder& b) {
+inline void fri_fold_air(AirBuilder& b, int point_bus = -1) {   // AirBuilder(19, 0); with point_bus the row sends (k, x_inv) there
     Expr e0[4], e1[4], beta[4], folded[4], d[4];
     for (int i = 0; i < 4; i++) e0[i] = b.var(i);
     for (int i = 0; i < 4; i++) e1[i] = b.var(4 + i);
     for (int i = 0; i < 4; i++) beta[i] = b.var(8 + i);
     const Expr xinv = b.var(12);
     for (int i = 0; i < 4; i++) folded[i] = b.var(13 + i);
-    const Expr real = b.var(17);
+    const Expr real = b.var(17), k = b.var(18);
     {
         const Expr t = real - 1;
         b.assert_zero(real * t);
@@ -1177,6 +1177,45 @@ inline void fri_fold_air(AirBuilder& b) {
         const Expr xp = xinv * prod[i];
         b.assert_zero(c - xp);
     }
+    if (point_bus >= 0) b.push_interaction((uint32_t)point_bus, {k, xinv}, real, Kind::Send);
+}
+
+// air.domain_point_air(point_bus): AirBuilder(54, 0) -- x^-1 of a FRI pair from the bits of its index
+inline void domain_point_air(AirBuilder& b, uint32_t point_bus) {
+    constexpr int NB = 26;
+    constexpr uint64_t P = zkhip::air::P;
+    // W_j^-1, W_j = the generator of the subgroup of order 2^(j + 2) (air.domain_point_inverse_roots)
+    auto powmod = [](uint64_t base, uint64_t e) {
+        uint64_t r = 1;
+        for (base %= P; e; e >>= 1, base = base * base % P)
+            if (e & 1) r = r * base % P;
+        return r;
+    };
+    const Expr k = b.var(0);
+    Expr bit[NB], acc[NB];
+    for (int j = 0; j < NB; j++) bit[j] = b.var(1 + j);
+    for (int j = 0; j < NB; j++) acc[j] = b.var(1 + NB + j);
+    const Expr mult = b.var(1 + 2 * NB);
+    Expr total;
+    for (int j = 0; j < NB; j++) {
+        {
+            const Expr t = bit[j] - 1;
+            b.assert_zero(bit[j] * t);
+        }
+        const Expr term = bit[j] * (int64_t)(1u << j);
+        total = j == 0 ? term : total + term;
+        const int64_t winv = (int64_t)powmod(powmod(0x1A427A41ull, 1ull << (27 - (j + 2))), P - 2);
+        const Expr f0 = bit[j] * (winv - 1);
+        const Expr factor = f0 + 1;
+        if (j == 0) {
+            b.assert_zero(acc[j] - factor);
+        } else {
+            const Expr m = acc[j - 1] * factor;
+            b.assert_zero(acc[j] - m);
+        }
+    }
+    b.assert_zero(k - total);
+    b.push_interaction(point_bus, {k, acc[NB - 1]}, mult, Kind::Receive);
 }
 
 // air.mmcs_claims_air(claims_bus): AirBuilder(19, 0)

@@ -22,7 +22,9 @@ pub const ZKHIP_RV32_SHIFT_WIDTH: usize = 32;
 pub const ZKHIP_RV32_BRANCH_EQ_WIDTH: usize = 17;
 pub const ZKHIP_RV32_BRANCH_LT_WIDTH: usize = 23;
 pub const ZKHIP_DUPLEX_WIDTH: usize = 50;
-pub const ZKHIP_FRI_FOLD_WIDTH: usize = 18;
+pub const ZKHIP_FRI_FOLD_WIDTH: usize = 19;
+pub const ZKHIP_DOMAIN_POINT_BITS: usize = 26;
+pub const ZKHIP_DOMAIN_POINT_WIDTH: usize = 54;
 pub const ZKHIP_CASTF_WIDTH: usize = 6;
 pub const ZKHIP_FIELD_ARITH_WIDTH: usize = 8;
 pub const ZKHIP_FIELD_EXT_WIDTH: usize = 20;
@@ -189,6 +191,7 @@ extern "C" {
                                          log_height: c_uint, d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_var_range_counts_tracegen(ctx: *mut zkhip_ctx, d_values: *const u32, d_bits: *const u32, const_bits: u32, n: usize, max_bits: c_uint,
                                            d_counts: *mut u32, accumulate: c_int) -> c_int;
+    pub fn zkhip_domain_point_tracegen(ctx: *mut zkhip_ctx, d_k: *const u32, d_mult: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;
     pub fn zkhip_duplex_tracegen(ctx: *mut zkhip_ctx, d_n_observed: *const u32, d_observed: *const u32, d_n_sampled: *const u32, n: usize,
                                  log_height: c_uint, d_trace: *mut u32, d_hash_inputs: *mut u32) -> c_int;
     pub fn zkhip_fri_fold_chip_tracegen(ctx: *mut zkhip_ctx, d_e0: *const u32, d_e1: *const u32, d_beta: *const u32, d_k: *const u32,

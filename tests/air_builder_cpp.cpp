@@ -170,7 +170,9 @@ int main() {
         { AirBuilder b(41, 0); ch::rv32_divrem_core_air(b); dump("chip_rv32_divrem", b); }
         { AirBuilder b(39, 0); ch::mmcs_path_air(b, 9, 10); dump("chip_mmcs_path", b); }
         { AirBuilder b(19, 0); ch::mmcs_claims_air(b, 10); dump("chip_mmcs_claims", b); }
-        { AirBuilder b(18, 0); ch::fri_fold_air(b); dump("chip_fri_fold", b); }
+        { AirBuilder b(19, 0); ch::fri_fold_air(b); dump("chip_fri_fold", b); }
+        { AirBuilder b(19, 0); ch::fri_fold_air(b, 11); dump("chip_fri_fold_bus", b); }
+        { AirBuilder b(54, 0); ch::domain_point_air(b, 11); dump("chip_domain_point", b); }
         { AirBuilder b(8, 0); ch::field_arith_air(b); dump("chip_field_arith", b); }
         { AirBuilder b(20, 0); ch::field_ext_air(b); dump("chip_field_ext", b); }
         { AirBuilder b(50, 0); ch::duplex_air(b, 9, 10); dump("chip_duplex", b); }

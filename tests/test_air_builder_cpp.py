@@ -70,6 +70,8 @@ PY = {
     "chip_mmcs_path": lambda: air.mmcs_path_air(9, 10),
     "chip_mmcs_claims": lambda: air.mmcs_claims_air(10),
     "chip_fri_fold": lambda: air.fri_fold_air(),
+    "chip_fri_fold_bus": lambda: air.fri_fold_air(11),
+    "chip_domain_point": lambda: air.domain_point_air(11),
     "chip_field_arith": lambda: air.field_arith_air(),
     "chip_field_ext": lambda: air.field_ext_air(),
     "chip_duplex": lambda: air.duplex_air(9, 10),

@@ -20,14 +20,14 @@ def bitrev(k, bits):
 
 
 def fold_rows(vec):
-    """[18, n] canonical rows from the fixture's FRI layers: x = g^bitrev(k) in the subgroup of order 2 * 2^log_n_out"""
+    """[19, n] canonical rows from the fixture's FRI layers: x = g^bitrev(k) in the subgroup of order 2 * 2^log_n_out"""
     rows = []
     for lay in vec["fri_layers"]:
         lo = lay["log_n_out"]
         g = pow(G27, 1 << (27 - (lo + 1)), P)
         for t in lay["triples"]:
             xinv = pow(pow(g, bitrev(t["k"], lo), P), P - 2, P)
-            rows.append(t["e0"] + t["e1"] + lay["beta"] + [xinv] + t["folded"] + [1])
+            rows.append(t["e0"] + t["e1"] + lay["beta"] + [xinv] + t["folded"] + [1, t["k"]])
     return np.array(rows, np.uint32).T
 
 
@@ -40,7 +40,7 @@ def vec():
 def fold_trace(vec):
     rows = fold_rows(vec)
     lh = int(np.ceil(np.log2(rows.shape[1])))
-    tr = np.zeros((18, 1 << lh), np.uint32)
+    tr = np.zeros((19, 1 << lh), np.uint32)
     tr[:, :rows.shape[1]] = rows
     return tr, rows.shape[1], lh
 
@@ -56,4 +56,40 @@ def test_reference_fold_steps_satisfy_the_air(vec):
         assert air.check_trace(prog, w, NOPV) != []
     w = tr.copy()
     w[0:4, 3], w[4:8, 3] = tr[4:8, 3], tr[0:4, 3]    # siblings swapped: the fold at x is not the fold at -x
+    assert air.check_trace(prog, w, NOPV) != []
+
+
+def point_table(tr, n):
+    """domain_point_air trace for the distinct pair indices of the fold rows (with how often each is used)"""
+    from collections import Counter
+
+    cnt = Counter(int(k) for k in tr[18][:n])
+    lh = max(1, int(np.ceil(np.log2(len(cnt)))))
+    w = air.domain_point_inverse_roots()
+    t = np.zeros((air.DOMAIN_POINT_WIDTH, 1 << lh), np.uint32)
+    t[1 + air.DOMAIN_POINT_BITS:1 + 2 * air.DOMAIN_POINT_BITS, :] = 1      # padding rows: k = 0, x = 1, multiplicity 0
+    for r, (k, m) in enumerate(sorted(cnt.items())):
+        acc = 1
+        t[0, r] = k
+        for j in range(air.DOMAIN_POINT_BITS):
+            bit = (k >> j) & 1
+            acc = acc * w[j] % P if bit else acc
+            t[1 + j, r], t[1 + air.DOMAIN_POINT_BITS + j, r] = bit, acc
+        t[1 + 2 * air.DOMAIN_POINT_BITS, r] = m
+    return t
+
+
+def test_fold_points_follow_from_the_pair_indices(vec):
+    """x^-1 of every fold row of the fixture equals the product the domain-point chip builds from the bits of the pair index --
+    for every layer size with the same per-bit constants -- and its trace satisfies the AIR."""
+    tr, n, lh = fold_trace(vec)
+    t = point_table(tr, n)
+    prog = air.domain_point_air(11).program()
+    assert air.check_trace(prog, t, NOPV) == []
+    last = t[2 * air.DOMAIN_POINT_BITS]
+    by_k = {int(k): int(x) for k, x in zip(t[0], last)}
+    assert all(by_k[int(tr[18][i])] == int(tr[12][i]) for i in range(n))
+    assert len({lay["log_n_out"] for lay in vec["fri_layers"]}) >= 3         # several layer sizes, one table
+    w = t.copy()
+    w[1 + 3][0] ^= 1                                                         # a flipped bit: k no longer matches
     assert air.check_trace(prog, w, NOPV) != []

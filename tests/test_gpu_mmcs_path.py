@@ -102,17 +102,31 @@ def test_reference_fri_fold_steps_proven(zk, ora, vec):
     t32 = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.uint32).view(np.int32)).to(zk.device)  # noqa: E731
     d_tr = zk.fri_fold_chip_tracegen(t32([r[0] for r in recs]), t32([r[1] for r in recs]), t32([r[2] for r in recs]), t32([r[3] for r in recs]),
                                      t32([r[4] for r in recs]), lh)
-    assert (zk.download(d_tr).reshape(18, -1) == tr).all()       # incl. folded == the value the reference's proof holds
+    assert (zk.download(d_tr).reshape(19, -1) == tr).all()       # incl. folded == the value the reference's proof holds
     with pytest.raises(z.ZkhipError):                            # an index outside its layer
         zk.fri_fold_chip_tracegen(t32([[1, 2, 3, 4]]), t32([[1, 2, 3, 4]]), t32([[1, 0, 0, 0]]), t32([8]), t32([3]), 0)
-    airs = [dict(program=air.fri_fold_air().program(), log_height=lh, width=18, n_pvs=0, trace=tr, pvs=NOPV)]
+    # the evaluation points come from the pair indices: the domain-point chip (device-generated) holds every (k, x^-1) the fold rows send
+    from test_fri_fold_chip_cpu import point_table
+    pt = point_table(tr, n)
+    cnt = sorted({int(k): 0 for k in tr[18][:n]})
+    mult = [int((tr[18][:n] == k).sum()) for k in cnt]
+    lpt = int(np.log2(pt.shape[1]))
+    d_pt = zk.domain_point_tracegen(t32(cnt), t32(mult), lpt)
+    assert (zk.download(d_pt).reshape(air.DOMAIN_POINT_WIDTH, -1) == pt).all()
+    with pytest.raises(z.ZkhipError):
+        zk.domain_point_tracegen(t32([1 << 26]), t32([1]), 0)
+    airs = [dict(program=air.fri_fold_air(11).program(), log_height=lh, width=19, n_pvs=0, trace=tr, pvs=NOPV),
+            dict(program=air.domain_point_air(11).program(), log_height=lpt, width=air.DOMAIN_POINT_WIDTH, n_pvs=0, trace=pt, pvs=NOPV)]
     pk = z.ProvingKey(zk, PARAMS, airs)
-    proof = pk.prove([d_tr], [NOPV])
-    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV], proof) == 0
+    proof = pk.prove([d_tr, d_pt], [NOPV] * 2)
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, proof) == 0
     assert proof == ora.stark_prove(PARAMS, airs).tobytes()
     w = tr.copy()
-    w[13][0] = (int(w[13][0]) + 1) % P
-    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV], pk.prove([zk.upload(w.reshape(-1))], [NOPV])) != 0
+    w[13][0] = (int(w[13][0]) + 1) % P                       # a wrong folded value: the fold constraint
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, pk.prove([zk.upload(w.reshape(-1)), d_pt], [NOPV] * 2)) != 0
+    w = tr.copy()
+    w[18][0] = int(w[18][0]) ^ 1                             # a fold row that claims another pair's point: the point bus
+    assert z.verify(PARAMS, pk.verifying_airs(), [NOPV] * 2, pk.prove([zk.upload(w.reshape(-1)), d_pt], [NOPV] * 2)) != 0
     pk.close()
 
 

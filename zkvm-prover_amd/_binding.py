@@ -102,6 +102,7 @@ def load_library():
         "zkhip_rv32_branch_eq_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_rv32_branch_lt_tracegen": (C.c_int, [vp, vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_var_range_counts_tracegen": (C.c_int, [vp, vp, vp, C.c_uint32, sz, C.c_uint, vp, C.c_int]),
+        "zkhip_domain_point_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_duplex_tracegen": (C.c_int, [vp, vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_fri_fold_chip_tracegen": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_castf_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp, C.c_uint]),
@@ -406,6 +407,15 @@ class Context:
                                                              1 if accumulate else 0))
         return t_counts
 
+    def domain_point_tracegen(self, t_k, t_mult, log_height):
+        """54-column trace of the domain-point chip from (pair index, multiplicity) records (int32 tensors)."""
+        import torch
+
+        out = torch.empty(54 << log_height, dtype=torch.int32, device=self.device)
+        self._check(self.lib.zkhip_domain_point_tracegen(self.h, C.c_void_p(t_k.data_ptr()), C.c_void_p(t_mult.data_ptr()), t_k.numel(), log_height,
+                                                         C.c_void_p(out.data_ptr())))
+        return out
+
     def duplex_tracegen(self, t_n_observed, t_observed, t_n_sampled, log_height):
         """(50-column trace of the transcript chip, [2^log_height][16] permutation inputs for the Poseidon2 chip) from duplexing
         records (int32 tensors: observed count per row, observed values [n][8] canonical, sampled count per row)."""
@@ -419,11 +429,11 @@ class Context:
         return tr, hin
 
     def fri_fold_chip_tracegen(self, t_e0, t_e1, t_beta, t_k, t_log_n_out, log_height):
-        """18-column trace of the FRI fold chip from records (int32 tensors: e0, e1, beta [n][4] canonical; pair indices; log2 of the
+        """19-column trace of the FRI fold chip from records (int32 tensors: e0, e1, beta [n][4] canonical; pair indices; log2 of the
         folded layer's size)."""
         import torch
 
-        out = torch.empty(18 << log_height, dtype=torch.int32, device=self.device)
+        out = torch.empty(19 << log_height, dtype=torch.int32, device=self.device)
         self._check(self.lib.zkhip_fri_fold_chip_tracegen(self.h, *[C.c_void_p(t.data_ptr()) for t in (t_e0, t_e1, t_beta, t_k, t_log_n_out)], t_k.numel(),
                                                           log_height, C.c_void_p(out.data_ptr())))
         return out

@@ -1657,17 +1657,20 @@ def field_ext_air():
     return b
 
 
-FRI_FOLD_WIDTH = 18
+FRI_FOLD_WIDTH = 19
+DOMAIN_POINT_BITS = 26
+DOMAIN_POINT_WIDTH = 2 + 2 * DOMAIN_POINT_BITS
 
 
-def fri_fold_air():
+def fri_fold_air(point_bus=None):
     """One FRI folding step per row, in-circuit (p3 `TwoAdicFriFolding::fold_row`, arity 2) -- another piece of the recursion
-    circuit: columns e0[4] | e1[4] | beta[4] | x_inv | folded[4] | is_real.  e0, e1 are the sibling evaluations at x and -x,
+    circuit: columns e0[4] | e1[4] | beta[4] | x_inv | folded[4] | is_real | k.  e0, e1 are the sibling evaluations at x and -x,
     x_inv = 1 / x in the base field; folded = (e0 + e1) / 2 + beta (e0 - e1) x_inv / 2 in the quartic extension (X^4 = 11),
-    stated as 2 folded = (e0 + e1) + x_inv (beta * (e0 - e1)), coordinate by coordinate (degree 3)."""
+    stated as 2 folded = (e0 + e1) + x_inv (beta * (e0 - e1)), coordinate by coordinate (degree 3).  k is the pair's index in
+    its layer; with `point_bus` the row sends (k, x_inv) there and domain_point_air() must hold that pair: x = g^bitrev(k)."""
     b = AirBuilder(FRI_FOLD_WIDTH, 0)
     e0, e1, beta = [b.var(i) for i in range(4)], [b.var(4 + i) for i in range(4)], [b.var(8 + i) for i in range(4)]
-    xinv, folded, real = b.var(12), [b.var(13 + i) for i in range(4)], b.var(17)
+    xinv, folded, real, k = b.var(12), [b.var(13 + i) for i in range(4)], b.var(17), b.var(18)
     b.assert_zero(real * (real - 1))
     d = [e0[i] - e1[i] for i in range(4)]
     W = 11
@@ -1677,6 +1680,38 @@ def fri_fold_air():
             beta[0] * d[3] + beta[1] * d[2] + beta[2] * d[1] + beta[3] * d[0]]
     for i in range(4):
         b.assert_zero(folded[i] * 2 - e0[i] - e1[i] - xinv * prod[i])    # all-zero padding rows satisfy it as they are
+    if point_bus is not None:
+        b.push_interaction(point_bus, [k, xinv], real, "send")
+    return b
+
+
+def domain_point_inverse_roots():
+    """W_j^-1 for j = 0 .. 25 with W_j the generator of the subgroup of order 2^(j + 2): bit j of a pair index k contributes W_j
+    to x = g^bitrev(k) WHATEVER the layer's size is (g_{m+1}^(2^(m-1-j)) has order 2^(j+2) for every m > j)."""
+    g27 = 0x1A427A41
+    return [pow(pow(g27, 1 << (27 - (j + 2)), P), P - 2, P) for j in range(DOMAIN_POINT_BITS)]
+
+
+def domain_point_air(point_bus):
+    """The evaluation point of a FRI pair from its index, in-circuit: columns k | bit[26] | acc[26] | mult.  k = sum bit_j 2^j;
+    acc_j = acc_(j-1) (1 + bit_j (W_j^-1 - 1)) runs through the bits (degree 2), acc_25 = x^-1 for x = g^bitrev(k) (a pair index has at most 26 bits: the largest layer has 2^27 points).  The row
+    receives (k, x^-1) `mult` times from the rows of fri_fold_air(point_bus) that fold the pair k (of any layer: see
+    domain_point_inverse_roots)."""
+    b = AirBuilder(DOMAIN_POINT_WIDTH, 0)
+    k = b.var(0)
+    bit = [b.var(1 + j) for j in range(DOMAIN_POINT_BITS)]
+    acc = [b.var(1 + DOMAIN_POINT_BITS + j) for j in range(DOMAIN_POINT_BITS)]
+    mult = b.var(1 + 2 * DOMAIN_POINT_BITS)
+    winv = domain_point_inverse_roots()
+    total = None
+    for j in range(DOMAIN_POINT_BITS):
+        b.assert_zero(bit[j] * (bit[j] - 1))
+        term = bit[j] * (1 << j)
+        total = term if total is None else total + term
+        factor = bit[j] * (winv[j] - 1) + 1
+        b.assert_zero(acc[j] - (factor if j == 0 else acc[j - 1] * factor))
+    b.assert_zero(k - total)
+    b.push_interaction(point_bus, [k, acc[DOMAIN_POINT_BITS - 1]], mult, "receive")
     return b
 
 

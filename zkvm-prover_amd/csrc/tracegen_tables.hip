@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(256) void k_fri_fold_chip(const uint32_t* __restric
             const Ext folded = ext_mul_base(ext_add(ext_add(e0, e1), ext_mul_base(ext_mul(beta, ext_sub(e0, e1)), xinv)), half);
 #pragma unroll
             for (int i = 0; i < 4; i++) col[i] = e0.c[i], col[4 + i] = e1.c[i], col[8 + i] = beta.c[i], col[13 + i] = folded.c[i];
-            col[12] = xinv, col[17] = MONTY_ONE;
+            col[12] = xinv, col[17] = MONTY_ONE, col[18] = to_monty(k);
         }
     }
 #pragma unroll
@@ -1371,4 +1371,44 @@ extern "C" int zkhip_fri_fold_chip_tracegen(zkhip_ctx* ctx, const uint32_t* d_e0
                        (uint32_t*)flag);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "fri_fold_chip_tracegen (a value that is not a field element, or an index outside its layer)");
+}
+
+// ---- domain-point chip (air.py domain_point_air): x^-1 of a FRI pair from the bits of its index ------------------------------------------
+// Row = (k, its 26 bits, the running product acc_j = prod_{i <= j} (W_i^-1)^bit_i, multiplicity); W_i generates the subgroup of
+// order 2^(i + 2), so the product is 1 / g^bitrev(k) for the layer of ANY size that holds pair k.
+namespace zk {
+namespace {
+__global__ __launch_bounds__(256) void k_domain_point(const uint32_t* __restrict__ ks, const uint32_t* __restrict__ mults, size_t n, size_t N,
+                                                      uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    const bool real = r < n;
+    const uint32_t k = real ? ks[r] : 0u, m = real ? mults[r] : 0u;
+    if (real && ((k >> ZKHIP_DOMAIN_POINT_BITS) || m >= P)) atomicAdd(bad, 1u);
+    trace[r] = to_monty(k & ((1u << ZKHIP_DOMAIN_POINT_BITS) - 1));
+    uint32_t acc = MONTY_ONE;
+#pragma unroll 1
+    for (unsigned j = 0; j < ZKHIP_DOMAIN_POINT_BITS; j++) {
+        const uint32_t bit = (k >> j) & 1u;
+        if (bit) acc = mmul(acc, minv(two_adic_generator(j + 2)));
+        trace[(size_t)(1 + j) * N + r] = bit ? MONTY_ONE : 0u;
+        trace[(size_t)(1 + ZKHIP_DOMAIN_POINT_BITS + j) * N + r] = acc;
+    }
+    trace[(size_t)(1 + 2 * ZKHIP_DOMAIN_POINT_BITS) * N + r] = m < P ? to_monty(m) : 0u;
+}
+}  // namespace
+}  // namespace zk
+
+extern "C" int zkhip_domain_point_tracegen(zkhip_ctx* ctx, const uint32_t* d_k, const uint32_t* d_mult, size_t n, unsigned log_height, uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || log_height > 27 || (n && (!d_k || !d_mult))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "domain_point_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "domain_point_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_domain_point, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_k, d_mult, n, N, d_trace, (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return finish_counts(ctx, flag, "domain_point_tracegen (a pair index of more than 26 bits or a multiplicity that is not a field element)");
 }
