@@ -45,23 +45,50 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT touching the HIP runtime (a launcher that has initialised the GPU must not
+    fork+exec its ranks on this pool): KFD topology nodes that have SIMDs (CPU nodes have simd_count 0), cut down by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  ZKHIP_BENCH_DEVICE_COUNT overrides (tests)."""
+    forced = os.environ.get("ZKHIP_BENCH_DEVICE_COUNT")
+    if forced is not None:
+        return int(forced)
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    n = 0
+    try:
+        for node in os.listdir(base):
+            try:
+                with open(os.path.join(base, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        return 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no launcher: start one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
     in its environment, as torch.distributed.run would), relay rank 0's JSON line, exit with the first non-zero code.
-    The parent has not initialised the GPU (torch.cuda.device_count() does not), and it never execs."""
+    The parent never imports torch and never calls into HIP (devices are counted from the KFD topology in sysfs), so the
+    fork+exec of the ranks happens in a process that has not initialised the GPU."""
     import socket
     import subprocess
 
     n = args.gpus
     plumbing = os.environ.get("ZKHIP_BENCH_PLUMBING_ONLY") == "1"
     if not plumbing and os.environ.get("ZKHIP_BENCH_DRYRUN_1GPU") != "1":
-        import torch
-
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()
         if have < n:
             sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible (ZKHIP_BENCH_DRYRUN_1GPU=1 runs all ranks on one "
                              "GPU as a plumbing check)\n" % (n, have))
             return 2
+    assert "torch" not in sys.modules, "the launcher must not load torch / HIP before it starts its ranks"
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]

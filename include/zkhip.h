@@ -67,6 +67,11 @@ int zkhip_sync(zkhip_ctx *ctx);
  * sponge VALU-bound); with several proofs in flight the same overlap already happens across proofs.  Proof bytes are
  * identical either way. */
 int zkhip_set_commit_pipeline(zkhip_ctx *ctx, unsigned parts);
+/* CU partition of that pipeline: with side_cus > 0 the LDE stream is created with a CU mask of `side_cus` compute units
+ * (hipExtStreamCreateWithCUMask; an even slice of every XCD) and the pipeline's row sponge runs on a stream masked to the
+ * remaining CUs, so the memory-bound LDE never queues behind hash workgroups.  0 = unmasked streams (the default unless the
+ * environment sets ZKHIP_SIDE_CUS).  Measured effect: DESIGN.md section 5.  Proof bytes are identical either way. */
+int zkhip_set_cu_partition(zkhip_ctx *ctx, unsigned side_cus);
 
 /* ---- device memory (replaces openvm-cuda-common DeviceBuffer / VPMM pool, AGENTS.md:136) ---- */
 int zkhip_malloc(zkhip_ctx *ctx, size_t bytes, void **dptr);

@@ -150,6 +150,7 @@ extern "C" {
     pub fn zkhip_set_stream(ctx: *mut zkhip_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn zkhip_sync(ctx: *mut zkhip_ctx) -> c_int;
     pub fn zkhip_set_commit_pipeline(ctx: *mut zkhip_ctx, parts: c_uint) -> c_int;
+    pub fn zkhip_set_cu_partition(ctx: *mut zkhip_ctx, side_cus: c_uint) -> c_int;
 
     // device memory
     pub fn zkhip_malloc(ctx: *mut zkhip_ctx, bytes: usize, dptr: *mut *mut c_void) -> c_int;

@@ -50,3 +50,41 @@ def test_bench_under_a_launcher_uses_the_given_ranks():
     assert [p.returncode for p in procs] == [0, 0], outs
     assert json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][0])["n_gpus"] == 2
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+
+
+def _run_real(extra_env, *argv):
+    env = dict(os.environ, **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "ZKHIP_BENCH_PLUMBING_ONLY", "ZKHIP_BENCH_DRYRUN_1GPU"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                          timeout=600)
+
+
+def test_launcher_counts_devices_without_touching_hip():
+    """The NON-dry launcher branch: devices are counted from the KFD topology (stubbed here), torch is never imported in
+    the parent (bench.py asserts it), and too few devices is refused before any rank starts."""
+    r = _run_real({"ZKHIP_BENCH_DEVICE_COUNT": "1"}, "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode == 2 and "1 GPU(s) visible" in r.stderr, (r.returncode, r.stderr[-500:])
+
+
+def test_launcher_real_branch_starts_fresh_ranks_that_fail_loudly_without_a_gpu():
+    """With enough (stubbed) devices the launcher starts its ranks as fresh processes; on this GPU-less box each rank
+    fails on its own (no CPU fallback) and the launcher returns that failure instead of hanging."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: this is the no-GPU failure path")
+    r = _run_real({"ZKHIP_BENCH_DEVICE_COUNT": "2"}, "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert r.returncode not in (0, 2), (r.returncode, r.stderr[-800:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_visible_gpu_count_reads_sysfs_only(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import importlib
+
+    bench = importlib.import_module("bench")
+    monkeypatch.setenv("ZKHIP_BENCH_DEVICE_COUNT", "5")
+    assert bench.visible_gpu_count() == 5
+    monkeypatch.delenv("ZKHIP_BENCH_DEVICE_COUNT")
+    assert bench.visible_gpu_count() >= 0   # whatever this box has; must not raise and must not need torch

@@ -83,6 +83,7 @@ def load_library():
         "zkhip_set_stream": (C.c_int, [vp, vp]),
         "zkhip_sync": (C.c_int, [vp]),
         "zkhip_set_commit_pipeline": (C.c_int, [vp, C.c_uint]),
+        "zkhip_set_cu_partition": (C.c_int, [vp, C.c_uint]),
         "zkhip_malloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
         "zkhip_free": (C.c_int, [vp, vp]),
         "zkhip_h2d": (C.c_int, [vp, vp, vp, sz]),
@@ -221,6 +222,10 @@ class Context:
     def set_commit_pipeline(self, parts):
         """Trace commit as a pipeline of `parts` column blocks (LDE of block k+1 beside the sponge of block k); 0 = off."""
         self._check(self.lib.zkhip_set_commit_pipeline(self.h, parts))
+
+    def set_cu_partition(self, side_cus):
+        """CU partition of the pipelined commit: `side_cus` CUs for the LDE stream, the rest for the sponge; 0 = off."""
+        self._check(self.lib.zkhip_set_cu_partition(self.h, side_cus))
 
     # ---- data movement -----------------------------------------------------------------------
     def upload(self, arr_canonical):

@@ -137,6 +137,8 @@ int zkhip_ctx_create(int device, zkhip_ctx** out) {
     // pipelined trace commit (prover.hip): ZKHIP_COMMIT_PARTS=k column blocks, 0 / 1 = off; zkhip_set_commit_pipeline overrides
     ctx->commit_parts = getenv("ZKHIP_COMMIT_PARTS") ? (unsigned)atoi(getenv("ZKHIP_COMMIT_PARTS")) : 0u;
     if (ctx->commit_parts > 8) ctx->commit_parts = 8;
+    ctx->side_cus = getenv("ZKHIP_SIDE_CUS") ? (unsigned)atoi(getenv("ZKHIP_SIDE_CUS")) : 0u;
+    if (ctx->side_cus >= (unsigned)ctx->cu_count) ctx->side_cus = 0;
     *out = ctx;
     return ZKHIP_OK;
 }
@@ -151,6 +153,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     for (int i = 0; i < 8; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->hash_stream) (void)hipStreamDestroy(ctx->hash_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     for (auto& e : ctx->pipe_ev)
         if (e) (void)hipEventDestroy(e);
@@ -161,6 +164,23 @@ int zkhip_set_commit_pipeline(zkhip_ctx* ctx, unsigned parts) {
     ZK_BIND_DEVICE(ctx);
     if (!ctx || parts > 8) return ZKHIP_ERR_INVALID;
     ctx->commit_parts = parts;
+    return ZKHIP_OK;
+}
+
+int zkhip_set_cu_partition(zkhip_ctx* ctx, unsigned side_cus) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || side_cus >= (unsigned)ctx->cu_count) return ZKHIP_ERR_INVALID;
+    if (side_cus != ctx->side_cus) {
+        // the masked streams are created lazily by the next pipelined commit
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (hipStream_t* s : {&ctx->side_stream, &ctx->hash_stream}) {
+            if (!*s) continue;
+            ZK_HIP_CHECK(ctx, hipStreamSynchronize(*s));
+            (void)hipStreamDestroy(*s);
+            *s = nullptr;
+        }
+        ctx->side_cus = side_cus;
+    }
     return ZKHIP_OK;
 }
 

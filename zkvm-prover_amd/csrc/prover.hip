@@ -1797,8 +1797,19 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     bool leaves_ready = false;
     if (top) {
         if (!ctx->side_stream) {
-            ZK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-            for (auto& e : ctx->pipe_ev) ZK_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            if (ctx->side_cus) {
+                // CU partition: bit i of a CU mask is CU i, numbered round-robin over the XCDs and then over their shader
+                // engines, so the low `side_cus` bits are an even slice of every XCD (its L2 and its share of the HBM channels)
+                const unsigned words = ((unsigned)ctx->cu_count + 31) / 32;
+                std::vector<uint32_t> m_side(words, 0), m_hash(words, 0);
+                for (unsigned i = 0; i < (unsigned)ctx->cu_count; i++) (i < ctx->side_cus ? m_side : m_hash)[i / 32] |= 1u << (i % 32);
+                ZK_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ctx->side_stream, words, m_side.data()));
+                ZK_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ctx->hash_stream, words, m_hash.data()));
+            } else {
+                ZK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            }
+            for (auto& e : ctx->pipe_ev)
+                if (!e) ZK_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
         const unsigned parts = ctx->commit_parts;
         const uint32_t per = ((top->n_cols + parts - 1) / parts + 7u) & ~7u;  // block boundaries on sponge-rate multiples
@@ -1813,8 +1824,10 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             if (A.lh < 12) ZK_TRY(lde_batch(ctx, d_traces[a], A.N, A.d_lde, A.M, A.lh, b, A.width, gen));
         }
         // the side stream starts after everything already queued on the main stream (pointer tables, previous proof)
+        hipStream_t hs = ctx->hash_stream ? ctx->hash_stream : st;  // where the sponge of the pipeline runs
         ZK_HIP_CHECK(ctx, hipEventRecord(ctx->pipe_ev[8], st));
         ZK_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->pipe_ev[8], 0));
+        if (hs != st) ZK_HIP_CHECK(ctx, hipStreamWaitEvent(hs, ctx->pipe_ev[8], 0));
         unsigned k = 0;
         for (uint32_t c0 = 0; c0 < top->n_cols; c0 += per, k++) {
             const uint32_t c1 = std::min(top->n_cols, c0 + per);
@@ -1825,8 +1838,15 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
             ctx->stream = st;
             if (rc != ZKHIP_OK) return rc;
             ZK_HIP_CHECK(ctx, he);
-            ZK_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->pipe_ev[k], 0));
-            ZK_TRY(merkle_leaves_part(ctx, pk->t_main, c0, c1, c0 == 0, c1 == top->n_cols, (uint32_t*)d_state));
+            ZK_HIP_CHECK(ctx, hipStreamWaitEvent(hs, ctx->pipe_ev[k], 0));
+            ctx->stream = hs;
+            rc = merkle_leaves_part(ctx, pk->t_main, c0, c1, c0 == 0, c1 == top->n_cols, (uint32_t*)d_state);
+            ctx->stream = st;
+            if (rc != ZKHIP_OK) return rc;
+        }
+        if (hs != st) {
+            ZK_HIP_CHECK(ctx, hipEventRecord(ctx->pipe_ev[9], hs));
+            ZK_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->pipe_ev[9], 0));
         }
         leaves_ready = true;
     } else {

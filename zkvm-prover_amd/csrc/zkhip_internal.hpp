@@ -46,8 +46,13 @@ struct zkhip_ctx {
     // trace commit as a pipeline (prover.hip): the LDE of column block k+1 runs on `side_stream` while the row sponge
     // absorbs block k on the main stream.  commit_parts = number of column blocks (0/1 = off).
     hipStream_t side_stream = nullptr;
-    hipEvent_t pipe_ev[10] = {};
+    hipEvent_t pipe_ev[12] = {};
     unsigned commit_parts = 0;
+    // CU partition of the pipelined commit (zkhip_set_cu_partition): with side_cus > 0 the side stream is created with a CU
+    // mask of `side_cus` CUs (the memory-bound LDE) and the row sponge of the pipeline runs on `hash_stream`, masked to the
+    // remaining CUs, so that neither queue waits behind the other's workgroups.  0 = unmasked streams.
+    unsigned side_cus = 0;
+    hipStream_t hash_stream = nullptr;
 };
 
 namespace zk {
