@@ -551,6 +551,52 @@ int zkhip_proof_to_v1(const zkhip_params *params, const zkhip_air *airs, size_t 
 int zkhip_proof_from_v1(const zkhip_params *params, const zkhip_air *airs, size_t n_airs, const uint8_t *v1, size_t v1_len,
                         uint8_t *out, size_t cap, size_t *out_len, uint32_t *const *pvs_out);
 
+/* ---- aggregation layer: the verifier circuit.  Replaces, for this backend's proofs, the leaf /
+ *      internal verifier programs the reference's SDK proves at the nodes of its aggregation tree and `commit_child_vk`
+ *      (crates/prover/src/prover/mod.rs:47-60, 200-282; crates/integration/src/lib.rs:461-514).  A circuit is built for ONE
+ *      child verifying key -- FRI parameters, AIR programs, trace heights, preprocessed commitments -- and up to `max_children`
+ *      proofs of it; it is an AIR set of three chips (gate chip, Poseidon2 chip, public-value chip; zkvm-prover_amd/csrc/
+ *      recursion.hip) whose preprocessed traces hold the whole wiring, so the node's preprocessed commitments are the committed
+ *      child vk.  A satisfying witness exists exactly when zkhip_verify accepts every present child.
+ *      Public values of a node: [child-vk digest at the leaf level (8) | start state (K) | end state (K) | accumulator (8)]:
+ *      the children's states are chained (end of child i = start of child i + 1), the accumulator is a Poseidon2 chain over the
+ *      children's public values (leaf level) or accumulators (above). ---- */
+typedef struct zkhip_recursion zkhip_recursion;
+typedef struct {
+    /* leaf level (child_is_node = 0): state word k of a child's START state is public value start_idx[k] of its AIR
+     * start_air[k], of its END state public value end_idx[k] of AIR end_air[k]; n_state <= 16 (0 = no chained state).
+     * child_is_node = 1: the children are proofs of a node circuit (their last AIR is its public-value chip); the layout
+     * above is read from there and the arrays are ignored. */
+    size_t n_state;
+    const uint32_t *start_air, *start_idx, *end_air, *end_idx;
+    int child_is_node;
+} zkhip_recursion_stmt;
+/* `airs[a].log_height` and `airs[a].prep_commit` are part of the child verifying key; program pointers are copied. */
+int zkhip_recursion_build(const zkhip_params *child_params, const zkhip_air *child_airs, size_t n_child_airs, size_t max_children,
+                          const zkhip_recursion_stmt *stmt, zkhip_recursion **out);
+void zkhip_recursion_destroy(zkhip_recursion *r);
+const char *zkhip_recursion_last_error(const zkhip_recursion *r); /* r = NULL: why the last zkhip_recursion_build of this thread failed */
+size_t zkhip_recursion_n_airs(const zkhip_recursion *r);            /* 3 */
+size_t zkhip_recursion_n_pvs(const zkhip_recursion *r);             /* 16 + 2 K */
+size_t zkhip_recursion_n_state(const zkhip_recursion *r);           /* K */
+size_t zkhip_recursion_max_children(const zkhip_recursion *r);
+size_t zkhip_recursion_child_proof_bytes(const zkhip_recursion *r);
+int zkhip_recursion_stats(const zkhip_recursion *r, size_t out[4]); /* wires, gate rows, permutations, public values */
+int zkhip_recursion_child_vk_digest(const zkhip_recursion *r, uint32_t out[8]);
+/* chip i of the node circuit as a zkhip_air (program, height, width, preprocessed trace; pointers stay owned by `r`):
+ * 0 = gate chip, 1 = Poseidon2 chip, 2 = public-value chip (the node's public values are its public values) */
+int zkhip_recursion_air(const zkhip_recursion *r, size_t i, zkhip_air *out);
+/* Runs the circuit on n_present child proofs (proofs[c] with child_pvs[c][a] = the public values of AIR a of child c, canonical);
+ * absent slots repeat child 0 without entering the statement.  node_pvs_out (zkhip_recursion_n_pvs words, may be NULL) receives
+ * the node's public values.  ZKHIP_ERR_VERIFY: an assertion of the circuit fails (some child does not verify) -- the wire
+ * values are kept, so the traces can still be generated (and their proof will not verify). */
+int zkhip_recursion_witness(zkhip_recursion *r, const uint8_t *const *proofs, const size_t *proof_lens, const uint32_t *const *const *child_pvs,
+                            size_t n_present, uint32_t *node_pvs_out);
+/* wire values of the last witness, canonical [n_wires + 1][4]; out = NULL: only the size */
+int zkhip_recursion_wires(const zkhip_recursion *r, uint32_t *out, size_t cap_words, size_t *n_words);
+/* device traces of the three chips from the last witness (Montgomery, column-major, stride = 2^log_height of the chip) */
+int zkhip_recursion_tracegen(zkhip_ctx *ctx, zkhip_recursion *r, uint32_t *d_gate_trace, uint32_t *d_p2_trace, uint32_t *d_pv_trace);
+
 /* ---- per-kernel timing (HIP events on the ctx stream), for bench.py's roofline ---- */
 int zkhip_profile_enable(zkhip_ctx *ctx, int on);
 /* copies up to cap entries; returns number of distinct kernel names recorded */

@@ -1,0 +1,271 @@
+// zkhip_aggregation.hpp -- the aggregation layer over the verifier circuit of the C ABI (zkhip_recursion_*): what the
+// reference does with its leaf / internal aggregation provers.
+//
+//   crates/prover/src/prover/mod.rs:47-60    leaf / internal parameter sets, DEFAULT_AGG_TREE_CONFIG (arity 4 / 3)
+//   crates/prover/src/prover/mod.rs:200-282  `commit_child_vk` -> VerifyProver: a node proves "my children verify under the child vk"
+//   crates/integration/src/lib.rs:461-514    the data handed from one level to the next
+//
+// Here a node circuit is built for ONE child verifying key (zkhip_recursion_build) and its whole wiring is preprocessed, so
+// the chain of commitments is: app vk -> leaf circuit (verifies <= 4 segment proofs) -> internal circuit of level 1 (verifies
+// <= 3 leaf proofs) -> internal circuit of level 2 (verifies <= 3 level-1 proofs) -> ...  The verifying key of level l is
+// (three AIR programs, three heights, three preprocessed commitments); it pins everything below it.  A node's public values are
+// [app-vk digest (8) | start state (K) | end state (K) | accumulator (8)]; the children's states are chained in-circuit.
+// Every node proof is self-verified (crates/prover/src/prover/mod.rs:407-411 does that for every proof it returns).
+#pragma once
+#include <chrono>
+#include <memory>
+#include <thread>
+
+#include "zkhip_prover.hpp"
+
+namespace scroll_zkvm_hip {
+
+struct StatementSpec {
+    std::vector<std::pair<uint32_t, uint32_t>> start, end;  // (AIR, public-value index) of the state words of a segment proof
+};
+
+// a verified unit entering a node: proof bytes + the public values of every AIR of its verifying key
+struct ChildProof {
+    std::vector<uint8_t> proof;
+    std::vector<std::vector<uint32_t>> pvs;
+};
+
+// verifying key of a node circuit (or of the app): everything zkhip_verify needs
+struct VerifyingKey {
+    zkhip_params params{};
+    std::vector<AirDesc> airs;      // program, width, n_pvs, prep_commit (no tables)
+    std::vector<unsigned> heights;  // fixed trace heights
+
+    std::vector<zkhip_air> as_airs() const {
+        std::vector<zkhip_air> za(airs.size());
+        for (size_t a = 0; a < airs.size(); a++) {
+            za[a] = zkhip_air{airs[a].program.data(), airs[a].program.size(), heights[a], airs[a].width, airs[a].n_pvs, nullptr, nullptr};
+            if (airs[a].has_prep) za[a].prep_commit = airs[a].prep_commit.size() == 8 ? airs[a].prep_commit.data() : nullptr;
+        }
+        return za;
+    }
+    bool verify(const ChildProof& p) const {
+        if (p.pvs.size() != airs.size()) return false;
+        std::vector<zkhip_air> za = as_airs();
+        std::vector<const uint32_t*> pv(airs.size());
+        for (size_t a = 0; a < airs.size(); a++) {
+            if (p.pvs[a].size() != airs[a].n_pvs) return false;
+            pv[a] = p.pvs[a].data();
+        }
+        return zkhip_verify(&params, za.data(), za.size(), pv.data(), p.proof.data(), p.proof.size()) == ZKHIP_OK;
+    }
+    // the app-file form (encode_app_exe, tables omitted): UniversalVerifier::setup reads it back
+    std::vector<uint8_t> to_app_exe() const {
+        std::vector<AirDesc> a = airs;
+        for (size_t i = 0; i < a.size(); i++) {
+            a[i].prep.clear();
+            if (a[i].has_prep) a[i].prep_log_height = heights[i];
+        }
+        return encode_app_exe(a);
+    }
+};
+
+class AggregationProver {
+public:
+    struct Stats {
+        size_t nodes = 0;
+        double witness_seconds = 0, tracegen_prove_seconds = 0, verify_seconds = 0, keygen_seconds = 0, build_seconds = 0;
+    };
+
+    static AggregationProver setup(const VerifyingKey& app, const StatementSpec& spec, AggregationTreeConfig cfg = {}, int device = 0) {
+        AggregationProver p;
+        p.app_ = app, p.spec_ = spec, p.cfg_ = cfg, p.device_ = device;
+        if (app.airs.size() != app.heights.size() || app.airs.empty()) throw Error(Error::Setup, "aggregation: the app verifying key needs one height per AIR");
+        if (spec.start.size() != spec.end.size()) throw Error(Error::Setup, "aggregation: start and end state must have the same length");
+        return p;
+    }
+    AggregationProver(AggregationProver&& o) noexcept { *this = std::move(o); }
+    AggregationProver& operator=(AggregationProver&& o) noexcept {
+        reset();
+        app_ = std::move(o.app_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, device_ = o.device_, ctx_ = o.ctx_, levels_ = std::move(o.levels_), stats = o.stats;
+        o.ctx_ = nullptr;
+        return *this;
+    }
+    ~AggregationProver() { reset(); }
+    void reset() {
+        for (auto& L : levels_) {
+            for (void* d : L.d_traces)
+                if (d) zkhip_free(ctx_, d);
+            if (L.pk) zkhip_pk_destroy(ctx_, L.pk);
+            if (L.circ) zkhip_recursion_destroy(L.circ);
+        }
+        levels_.clear();
+        if (ctx_) zkhip_ctx_destroy(ctx_), ctx_ = nullptr;
+    }
+
+    Stats stats;
+
+    // verifying key of the node circuit of `level` (0 = leaf): the root vk of a tree with level + 1 levels
+    const VerifyingKey& node_vk(size_t level) {
+        ensure_level(level);
+        return levels_[level].vk;
+    }
+    size_t arity(size_t level) const { return level == 0 ? cfg_.num_children_leaf : cfg_.num_children_internal; }
+
+    // proves one node: level 0 verifies up to 4 proofs of the app, level l > 0 up to 3 proofs of level l - 1
+    ChildProof prove_node(size_t level, const std::vector<const ChildProof*>& kids) {
+        using clk = std::chrono::steady_clock;
+        ensure_level(level);
+        Level& L = levels_[level];
+        if (kids.empty() || kids.size() > arity(level)) throw Error(Error::GenProof, "aggregation: a node of level " + std::to_string(level) + " takes 1.." + std::to_string(arity(level)) + " children");
+        const VerifyingKey& cvk = level == 0 ? app_ : levels_[level - 1].vk;
+        std::vector<const uint8_t*> proofs;
+        std::vector<size_t> lens;
+        std::vector<std::vector<const uint32_t*>> pv_rows(kids.size());
+        std::vector<const uint32_t* const*> pv_ptrs;
+        for (size_t c = 0; c < kids.size(); c++) {
+            if (kids[c]->pvs.size() != cvk.airs.size()) throw Error(Error::GenProof, "aggregation: child public values do not match the child verifying key");
+            proofs.push_back(kids[c]->proof.data()), lens.push_back(kids[c]->proof.size());
+            for (size_t a = 0; a < cvk.airs.size(); a++) {
+                if (kids[c]->pvs[a].size() != cvk.airs[a].n_pvs) throw Error(Error::GenProof, "aggregation: child public values do not match the child verifying key");
+                pv_rows[c].push_back(kids[c]->pvs[a].data());
+            }
+            pv_ptrs.push_back(pv_rows[c].data());
+        }
+        auto t0 = clk::now();
+        ChildProof out;
+        out.pvs.resize(3);
+        out.pvs[2].resize(zkhip_recursion_n_pvs(L.circ));
+        int rc = zkhip_recursion_witness(L.circ, proofs.data(), lens.data(), pv_ptrs.data(), kids.size(), out.pvs[2].data());
+        if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_recursion_last_error(L.circ));
+        auto t1 = clk::now();
+        check(zkhip_recursion_tracegen(ctx_, L.circ, (uint32_t*)L.d_traces[0], (uint32_t*)L.d_traces[1], (uint32_t*)L.d_traces[2]));
+        out.proof.resize(zkhip_proof_size(L.pk));
+        const uint32_t* dt[3] = {(const uint32_t*)L.d_traces[0], (const uint32_t*)L.d_traces[1], (const uint32_t*)L.d_traces[2]};
+        const uint32_t* pv[3] = {nullptr, nullptr, out.pvs[2].data()};
+        size_t len = 0;
+        check(zkhip_prove(ctx_, L.pk, dt, pv, out.proof.data(), out.proof.size(), &len));
+        out.proof.resize(len);
+        auto t2 = clk::now();
+        if (!L.vk.verify(out)) throw Error(Error::VerifyProof, "aggregation: the node proof does not verify");
+        auto t3 = clk::now();
+        stats.nodes++;
+        stats.witness_seconds += std::chrono::duration<double>(t1 - t0).count();
+        stats.tracegen_prove_seconds += std::chrono::duration<double>(t2 - t1).count();
+        stats.verify_seconds += std::chrono::duration<double>(t3 - t2).count();
+        return out;
+    }
+
+    // the whole tree of `plan` over the segment proofs; returns the root, `all` (optional) receives every level
+    ChildProof prove_tree(const AggregationPlan& plan, const std::vector<ChildProof>& segments, std::vector<std::vector<ChildProof>>* all = nullptr) {
+        if (segments.size() != plan.n_segments) throw Error(Error::GenProof, "aggregation: segment proof count does not match the plan");
+        std::vector<ChildProof> below = segments;
+        for (size_t l = 0; l < plan.levels.size(); l++) {
+            std::vector<ChildProof> cur;
+            for (const auto& nd : plan.levels[l]) {
+                std::vector<const ChildProof*> kids;
+                for (size_t c : nd.children) kids.push_back(&below.at(c));
+                cur.push_back(prove_node(l, kids));
+            }
+            below = std::move(cur);
+            if (all) all->push_back(below);
+        }
+        return below.at(0);
+    }
+
+    // ---- StarkProof container <-> ChildProof ----
+    static ChildProof from_stark_proof(const StarkProof& sp, const VerifyingKey& vk) {
+        ChildProof c;
+        c.proof = sp.proof;
+        size_t off = 0;
+        for (const auto& a : vk.airs) {
+            if (off + 4 * a.n_pvs > sp.user_pvs_proof.size()) throw Error(Error::GenProof, "aggregation: short public values in a child proof");
+            std::vector<uint32_t> v(a.n_pvs);
+            if (a.n_pvs) memcpy(v.data(), sp.user_pvs_proof.data() + off, 4 * a.n_pvs);
+            off += 4 * a.n_pvs;
+            c.pvs.push_back(std::move(v));
+        }
+        if (sp.baseline.size() != vk.heights.size()) throw Error(Error::GenProof, "aggregation: a child proof's heights do not match the fixed heights of the child verifying key");
+        for (size_t a = 0; a < vk.heights.size(); a++)
+            if (sp.baseline[a] != vk.heights[a]) throw Error(Error::GenProof, "aggregation: a child proof's heights do not match the fixed heights of the child verifying key");
+        return c;
+    }
+    static StarkProof to_stark_proof(const ChildProof& c, const VerifyingKey& vk) {
+        StarkProof sp;
+        sp.proof = c.proof;
+        for (const auto& p : c.pvs) {
+            const uint8_t* b = reinterpret_cast<const uint8_t*>(p.data());
+            sp.user_pvs_proof.insert(sp.user_pvs_proof.end(), b, b + 4 * p.size());
+        }
+        for (unsigned h : vk.heights) sp.baseline.push_back((uint8_t)h);
+        return sp;
+    }
+
+private:
+    AggregationProver() = default;
+    struct Level {
+        zkhip_recursion* circ = nullptr;
+        zkhip_pk* pk = nullptr;
+        VerifyingKey vk;
+        std::vector<void*> d_traces;
+    };
+    VerifyingKey app_;
+    StatementSpec spec_;
+    AggregationTreeConfig cfg_;
+    int device_ = 0;
+    zkhip_ctx* ctx_ = nullptr;
+    std::vector<Level> levels_;
+
+    void check(int rc) const {
+        if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_last_error(ctx_));
+    }
+    void ensure_level(size_t level) {
+        using clk = std::chrono::steady_clock;
+        while (levels_.size() <= level) {
+            const size_t l = levels_.size();
+            if (!ctx_) {
+                int rc = zkhip_ctx_create(device_, &ctx_);
+                if (rc != ZKHIP_OK) throw Error(Error::Keygen, "no gfx950 device for the HIP backend (zkhip_ctx_create returned " + std::to_string(rc) + ")");
+            }
+            const VerifyingKey& cvk = l == 0 ? app_ : levels_[l - 1].vk;
+            std::vector<zkhip_air> za = cvk.as_airs();
+            zkhip_recursion_stmt st{};
+            std::vector<uint32_t> sa, si, ea, ei;
+            if (l == 0) {
+                for (auto& p : spec_.start) sa.push_back(p.first), si.push_back(p.second);
+                for (auto& p : spec_.end) ea.push_back(p.first), ei.push_back(p.second);
+                st.n_state = sa.size(), st.start_air = sa.data(), st.start_idx = si.data(), st.end_air = ea.data(), st.end_idx = ei.data();
+            } else {
+                st.child_is_node = 1;
+            }
+            Level L;
+            auto t0 = clk::now();
+            int rc = zkhip_recursion_build(&cvk.params, za.data(), za.size(), arity(l), &st, &L.circ);
+            if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the verifier circuit of level ") + std::to_string(l) + ": " + zkhip_recursion_last_error(nullptr));
+            auto t1 = clk::now();
+            L.vk.params = app_.params;
+            std::vector<zkhip_air> na(3);
+            for (size_t i = 0; i < 3; i++) {
+                if (zkhip_recursion_air(L.circ, i, &na[i]) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_air");
+                AirDesc d;
+                d.width = na[i].width, d.n_pvs = na[i].n_pvs, d.program.assign(na[i].program, na[i].program + na[i].program_len);
+                d.has_prep = true, d.prep_log_height = na[i].log_height;
+                L.vk.airs.push_back(std::move(d));
+                L.vk.heights.push_back(na[i].log_height);
+            }
+            rc = zkhip_keygen(ctx_, &L.vk.params, na.data(), 3, &L.pk);
+            if (rc != ZKHIP_OK) {
+                zkhip_recursion_destroy(L.circ);
+                throw Error(Error::Keygen, std::string("failed to generate STARK proving key: ") + zkhip_last_error(ctx_));
+            }
+            for (size_t i = 0; i < 3; i++) {
+                uint32_t c[8];
+                check(zkhip_pk_prep_commitment(ctx_, L.pk, i, c));
+                L.vk.airs[i].prep_commit.assign(c, c + 8);
+                void* d = nullptr;
+                check(zkhip_malloc(ctx_, (na[i].width << na[i].log_height) * 4, &d));
+                L.d_traces.push_back(d);
+            }
+            stats.build_seconds += std::chrono::duration<double>(t1 - t0).count();
+            stats.keygen_seconds += std::chrono::duration<double>(clk::now() - t1).count();
+            levels_.push_back(std::move(L));
+        }
+    }
+};
+
+}  // namespace scroll_zkvm_hip

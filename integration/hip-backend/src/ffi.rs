@@ -133,6 +133,23 @@ pub struct zkhip_v1_summary {
 }
 
 #[repr(C)]
+pub struct zkhip_recursion {
+    _private: [u8; 0],
+}
+
+/// include/zkhip.h `zkhip_recursion_stmt`: where the chained state of a child proof lives in its public values.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkhip_recursion_stmt {
+    pub n_state: usize,
+    pub start_air: *const u32,
+    pub start_idx: *const u32,
+    pub end_air: *const u32,
+    pub end_idx: *const u32,
+    pub child_is_node: c_int,
+}
+
+#[repr(C)]
 #[derive(Clone, Copy)]
 pub struct zkhip_kernel_stat {
     pub name: [c_char; 48],
@@ -290,6 +307,25 @@ extern "C" {
                              proof: *const u8, len: usize, out: *mut u8, cap: usize, out_len: *mut usize) -> c_int;
     pub fn zkhip_proof_from_v1(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize, v1: *const u8, v1_len: usize,
                                out: *mut u8, cap: usize, out_len: *mut usize, pvs_out: *const *mut u32) -> c_int;
+
+    // aggregation layer: the verifier circuit of a node (commit_child_vk / VerifyProver of the reference)
+    pub fn zkhip_recursion_build(child_params: *const zkhip_params, child_airs: *const zkhip_air, n_child_airs: usize, max_children: usize,
+                                 stmt: *const zkhip_recursion_stmt, out: *mut *mut zkhip_recursion) -> c_int;
+    pub fn zkhip_recursion_destroy(r: *mut zkhip_recursion);
+    pub fn zkhip_recursion_last_error(r: *const zkhip_recursion) -> *const c_char;
+    pub fn zkhip_recursion_n_airs(r: *const zkhip_recursion) -> usize;
+    pub fn zkhip_recursion_n_pvs(r: *const zkhip_recursion) -> usize;
+    pub fn zkhip_recursion_n_state(r: *const zkhip_recursion) -> usize;
+    pub fn zkhip_recursion_max_children(r: *const zkhip_recursion) -> usize;
+    pub fn zkhip_recursion_child_proof_bytes(r: *const zkhip_recursion) -> usize;
+    pub fn zkhip_recursion_stats(r: *const zkhip_recursion, out: *mut usize) -> c_int;
+    pub fn zkhip_recursion_child_vk_digest(r: *const zkhip_recursion, out: *mut u32) -> c_int;
+    pub fn zkhip_recursion_air(r: *const zkhip_recursion, i: usize, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_recursion_witness(r: *mut zkhip_recursion, proofs: *const *const u8, proof_lens: *const usize,
+                                   child_pvs: *const *const *const u32, n_present: usize, node_pvs_out: *mut u32) -> c_int;
+    pub fn zkhip_recursion_wires(r: *const zkhip_recursion, out: *mut u32, cap_words: usize, n_words: *mut usize) -> c_int;
+    pub fn zkhip_recursion_tracegen(ctx: *mut zkhip_ctx, r: *mut zkhip_recursion, d_gate_trace: *mut u32, d_p2_trace: *mut u32,
+                                    d_pv_trace: *mut u32) -> c_int;
 
     // per-kernel timing
     pub fn zkhip_profile_enable(ctx: *mut zkhip_ctx, on: c_int) -> c_int;

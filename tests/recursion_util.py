@@ -1,0 +1,97 @@
+"""Shared helpers of the verifier-circuit tests: small child AIR sets with a chained state, the node circuit's traces
+restated in numpy (the CPU twin of zkhip_recursion_tracegen: a gather of the wire values; the Poseidon2 chip through the
+oracle's trace generator) and the node statement recomputed independently with the oracle's Poseidon2."""
+import numpy as np
+
+import oracle_lib as ora
+from zkvm_prover_amd import air
+
+NOPV = np.zeros(0, np.uint32)
+P = ora.P
+
+
+def counter_air():
+    """1 column x, x' = x + 1; public values (first, last): a segment whose state is a counter."""
+    b = air.AirBuilder(1, 2)
+    x = b.var(0)
+    b.when_first_row(x - b.pub(0))
+    b.when_transition(b.next(0) - x - 1)
+    b.when_last_row(x - b.pub(1))
+    return b
+
+
+def counter_segment(start, log_n=3, seed=0):
+    """One 'segment' = a counter chip (state start -> start + 2^log_n - 1), a lookup pair (bus traffic) and a Fibonacci chip
+    (unchained public values).  The NEXT segment starts where this one ends."""
+    n = 1 << log_n
+    tr = ((start + np.arange(n, dtype=np.int64)) % P).astype(np.uint32).reshape(1, n)
+    pv = np.array([start % P, (start + n - 1) % P], np.uint32)
+    s, t = air.lookup_traces(4, 3, seed=seed)
+    ftr, fpv = air.fibonacci_trace(3, a0=seed, b0=1)
+    return [dict(program=counter_air().program(), log_height=log_n, width=1, n_pvs=2, trace=tr, pvs=pv),
+            dict(program=air.lookup_sender_air().program(), log_height=4, width=3, n_pvs=0, trace=s, pvs=NOPV),
+            dict(program=air.fibonacci_air().program(), log_height=3, width=2, n_pvs=3, trace=ftr, pvs=fpv),
+            dict(program=air.lookup_table_air().program(), log_height=3, width=3, n_pvs=0, trace=t, pvs=NOPV)]
+
+
+COUNTER_STMT = dict(start=[(0, 0)], end=[(0, 1)])
+
+
+def verifying(params, airs):
+    out = []
+    for a in airs:
+        v = {k: a[k] for k in ("program", "log_height", "width", "n_pvs")}
+        if a.get("prep") is not None:
+            v["prep_commit"] = a["prep_commit"] if a.get("prep_commit") is not None else ora.prep_commit(params, a)
+        out.append(v)
+    return out
+
+
+def node_traces(rc):
+    """The three chips' traces (canonical) from the circuit's last witness: what zkhip_recursion_tracegen writes."""
+    W = rc.wires()
+    na = rc.airs()
+    g, p2 = na[0], na[1]
+    gt = np.zeros((16, 1 << g["log_height"]), np.uint32)
+    for s in range(4):
+        gt[4 * s:4 * s + 4] = W[g["prep"][s]].T
+    inp = np.zeros((rc.n_perms, 16), np.uint32)
+    for j in range(4):
+        inp[:, 4 * j:4 * j + 4] = W[p2["prep"][j][:rc.n_perms]]
+    pt = ora.poseidon2_air_trace(inp, p2["log_height"])
+    return na, [gt, pt, np.zeros((1, 1), np.uint32)]
+
+
+def node_instance(rc, node_pvs):
+    na, traces = node_traces(rc)
+    return [dict(a, trace=t, pvs=v) for a, t, v in zip(na, traces, [NOPV, NOPV, node_pvs])]
+
+
+def sponge(vals):
+    st = np.zeros(16, np.uint32)
+    vals = [int(v) for v in vals]
+    for i in range(0, len(vals), 8):
+        chunk = vals[i:i + 8]
+        st[:len(chunk)] = chunk
+        st = ora.permute(st)
+    return st[:8].copy()
+
+
+def compress(l, r):
+    return ora.permute(np.concatenate([np.asarray(l, np.uint32), np.asarray(r, np.uint32)]))[:8].copy()
+
+
+def leaf_accumulator(children_pvs):
+    """acc = compress(... compress(compress(0, H(pvs_0)), H(pvs_1)) ...), H = the sponge over all public values of a child."""
+    acc = np.zeros(8, np.uint32)
+    for pvs in children_pvs:
+        flat = [int(x) for p in pvs for x in p]
+        acc = compress(acc, sponge(flat) if flat else np.zeros(8, np.uint32))
+    return acc
+
+
+def internal_accumulator(child_accs):
+    acc = np.zeros(8, np.uint32)
+    for a in child_accs:
+        acc = compress(acc, a)
+    return acc

@@ -1,0 +1,111 @@
+"""GPU: the aggregation layer on the device.
+  * zkhip_recursion_tracegen == the numpy / oracle restatement of the node's traces, cell for cell; the HIP proof of a node
+    equals the oracle's proof of the same instance byte for byte;
+  * `prove_cli prove-agg`: 69 segment proofs -> 18 leaf nodes (arity 4) -> 6 -> 2 -> 1 root, every node a REAL verifier
+    circuit; the root verifies under root.vk alone; its statement is the chained state of all 69 segments; node proofs equal
+    the oracle's; one flipped byte in one segment proof and the node's witness is unsatisfiable."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import zkvm_prover_amd as z
+
+import prover_mirror_util as pm
+import recursion_util as ru
+
+pytestmark = pytest.mark.gpu
+PARAMS = (1, 0, 4, 3, 3)
+NOPV = ru.NOPV
+
+
+def test_device_traces_and_node_proof_match_the_oracle(zk, ora):
+    kids = [ru.counter_segment(s, seed=i) for i, s in enumerate([3, 10, 17, 24])]
+    vk = ru.verifying(PARAMS, kids[0])
+    pk = z.ProvingKey(zk, PARAMS, kids[0])
+    proofs = []
+    for k in kids:
+        tr = [zk.upload(a["trace"].reshape(-1)) for a in k]
+        proofs.append(pk.prove(tr, [a["pvs"] for a in k]))
+        assert proofs[-1] == ora.stark_prove(PARAMS, k).tobytes()
+    pvs = [[a["pvs"] for a in k] for k in kids]
+    rc = z.RecursionCircuit(PARAMS, vk, 4, stmt=ru.COUNTER_STMT)
+    st, npv = rc.witness(proofs, pvs)
+    assert st == 0, rc.last_error()
+    assert int(npv[8]) == 3 and int(npv[9]) == 31
+    node = ru.node_instance(rc, npv)
+    d_traces = rc.tracegen(zk)
+    for a, d in zip(node, d_traces):
+        assert (zk.download(d).reshape(a["width"], -1) == a["trace"]).all()
+    npk = z.ProvingKey(zk, PARAMS, node)
+    proof = npk.prove(d_traces, [NOPV, NOPV, npv])
+    assert proof == ora.stark_prove(PARAMS, node).tobytes()
+    assert z.verify(PARAMS, npk.verifying_airs(), [NOPV, NOPV, npv], proof) == 0
+    # a tampered child: the traces are still generated, and their proof is refused
+    bad = bytearray(proofs[2])
+    bad[4 * 200] ^= 1
+    st, npv2 = rc.witness([proofs[0], proofs[1], bytes(bad)], pvs[:3])
+    assert st == -7
+    proof2 = npk.prove(rc.tracegen(zk), [NOPV, NOPV, npv2])
+    assert z.verify(PARAMS, npk.verifying_airs(), [NOPV, NOPV, npv2], proof2) != 0
+
+
+def test_prove_agg_cli_69_segments_to_one_root(ora, tmp_path):
+    n_seg = 69
+    start, tasks, segs = 1000, [], []
+    for i in range(n_seg):
+        k = ru.counter_segment(start, seed=i)
+        segs.append(k)
+        d = tmp_path / ("s%d" % i)
+        d.mkdir()
+        tasks.append(pm.write_task(str(d), k, identifier="seg-%d" % i))
+        start += 7
+    exe, cfg = pm.write_app(str(tmp_path), segs[0], PARAMS)
+    out = tmp_path / "out"
+    out.mkdir()
+    r = pm.run_cli("prove-agg", exe, cfg, str(out), "2", "0:0/0:1", *tasks)
+    assert r.returncode == 0, r.stderr[-3000:]
+    info = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert info["segments"] == 69 and info["nodes"] == 18 + 6 + 2 + 1 and info["levels"] == 4
+    # the root verifies with the root vk alone
+    assert pm.run_cli("verify", str(out / "root.vk"), cfg, str(out / "root.json")).returncode == 0
+    root = json.loads((out / "root.json").read_text())
+    rpv = np.frombuffer(pm.un_b64_bincode(root["user_pvs_proof"]), dtype=np.uint32)
+    assert rpv.tolist() == info["root_public_values"]
+    assert int(rpv[8]) == 1000 and int(rpv[9]) == 1000 + 7 * n_seg        # start of segment 0, end of segment 68
+    # the accumulator, recomputed from the segments' public values through the tree's shape
+    accs = [ru.leaf_accumulator([[a["pvs"] for a in s] for s in segs[i:i + 4]]) for i in range(0, n_seg, 4)]
+    while len(accs) > 1:
+        accs = [ru.internal_accumulator(accs[i:i + 3]) for i in range(0, len(accs), 3)]
+    assert rpv[10:].tolist() == accs[0].tolist()
+    # a leaf node's proof against the oracle: same circuit, same witness -> same bytes
+    vk = ru.verifying(PARAMS, segs[0])
+    rc = z.RecursionCircuit(PARAMS, vk, 4, stmt=ru.COUNTER_STMT)
+    assert rpv[:8].tolist() == rc.child_vk_digest().tolist()
+    seg_proofs = [ora.stark_prove(PARAMS, s).tobytes() for s in segs[4:8]]
+    st, npv = rc.witness(seg_proofs, [[a["pvs"] for a in s] for s in segs[4:8]])
+    assert st == 0
+    leaf1 = json.loads((out / "agg-0-1.json").read_text())
+    assert pm.un_b64_bincode(leaf1["proof"]) == ora.stark_prove(PARAMS, ru.node_instance(rc, npv)).tobytes()
+    # a proof of another level does not verify under the root vk; a flipped public value neither
+    assert pm.run_cli("verify", str(out / "root.vk"), cfg, str(out / "agg-2-0.json")).returncode != 0
+    lie = dict(root)
+    w = bytearray(pm.un_b64_bincode(root["user_pvs_proof"]))
+    w[4 * 9] ^= 1
+    lie["user_pvs_proof"] = pm.b64_bincode(bytes(w))
+    (out / "lie.json").write_text(json.dumps(lie))
+    assert pm.run_cli("verify", str(out / "root.vk"), cfg, str(out / "lie.json")).returncode != 0
+
+
+def test_prove_agg_refuses_a_broken_hand_over(tmp_path):
+    tasks, segs = [], []
+    for i, s in enumerate([10, 17, 25, 32, 39]):   # segment 2 does not start where segment 1 ends
+        k = ru.counter_segment(s, seed=i)
+        segs.append(k)
+        d = tmp_path / ("s%d" % i)
+        d.mkdir()
+        tasks.append(pm.write_task(str(d), k, identifier="seg-%d" % i))
+    exe, cfg = pm.write_app(str(tmp_path), segs[0], PARAMS)
+    r = pm.run_cli("prove-agg", exe, cfg, str(tmp_path), "1", "0:0/0:1", *tasks)
+    assert r.returncode == 1 and "not satisfied" in r.stderr, r.stderr[-2000:]

@@ -1,0 +1,180 @@
+"""CPU: the verifier circuit of the aggregation layer (zkhip_recursion_*, zkvm-prover_amd/csrc/recursion.hip).  Child proofs
+come from the oracle prover (their bytes equal the HIP prover's: tests/test_gpu_stark.py); building the circuit and running
+its witness need no GPU.
+  * the circuit's assertions hold exactly when the product's verifier accepts (every word of a proof tampered in turn);
+  * the wire values, gathered into the three chips' traces, satisfy every constraint, and the oracle proves the node and both
+    verifiers accept it -- while the traces of a tampered child do NOT give a verifying proof;
+  * the node statement (state chain, accumulator, child-vk digest) against an independent restatement;
+  * a second level: an internal circuit verifies proofs of the leaf circuit."""
+import numpy as np
+import pytest
+
+import zkvm_prover_amd as z
+from zkvm_prover_amd import air
+
+import recursion_util as ru
+
+PARAMS = (1, 0, 4, 3, 3)
+NOPV = ru.NOPV
+
+
+def prove_children(ora, starts, params=PARAMS):
+    kids = [ru.counter_segment(s, seed=i) for i, s in enumerate(starts)]
+    proofs = [ora.stark_prove(params, k) for k in kids]
+    pvs = [[a["pvs"] for a in k] for k in kids]
+    return kids, proofs, pvs
+
+
+@pytest.fixture(scope="module")
+def leaf(ora):
+    kids, proofs, pvs = prove_children(ora, [5, 12, 19])
+    vk = ru.verifying(PARAMS, kids[0])
+    for k, p, pv in zip(kids, proofs, pvs):
+        assert z.verify(PARAMS, vk, pv, p.tobytes()) == 0
+    rc = z.RecursionCircuit(PARAMS, vk, 4, stmt=ru.COUNTER_STMT)
+    return dict(kids=kids, proofs=proofs, pvs=pvs, vk=vk, rc=rc)
+
+
+def test_circuit_accepts_exactly_what_the_verifier_accepts(ora, leaf):
+    rc, proofs, pvs, vk = leaf["rc"], leaf["proofs"], leaf["pvs"], leaf["vk"]
+    st, _ = rc.witness([p.tobytes() for p in proofs], pvs)
+    assert st == 0, rc.last_error()
+    base = [p.tobytes() for p in proofs]
+    for pos in range(len(proofs[1])):
+        bad = proofs[1].copy()
+        bad[pos] = (int(bad[pos]) + 1) % ora.P
+        v = z.verify(PARAMS, vk, pvs[1], bad.tobytes())
+        st, _ = rc.witness([base[0], bad.tobytes(), base[2]], pvs)
+        assert (v == 0) == (st == 0), "word %d: verifier %d, circuit %d" % (pos, v, st)
+        assert st != 0
+    # a public value of a child that is not part of the chained state (the Fibonacci chip's)
+    pv2 = [[x.copy() for x in c] for c in pvs]
+    pv2[2][2][1] = (int(pv2[2][2][1]) + 1) % ora.P
+    assert rc.witness(base, pv2)[0] == -7
+    # wrong size / non-canonical word
+    assert rc.witness([base[0][:-4]], pvs[:1])[0] == -3
+    bad = proofs[0].copy()
+    bad[100] = ora.P
+    assert rc.witness([bad.tobytes()], pvs[:1])[0] == -7
+
+
+def test_statement_chain_flags_and_accumulator(ora, leaf):
+    rc, proofs, pvs = leaf["rc"], leaf["proofs"], leaf["pvs"]
+    base = [p.tobytes() for p in proofs]
+    assert rc.n_pvs == 8 + 1 + 1 + 8 and rc.n_state == 1
+    for n in (1, 2, 3):
+        st, npv = rc.witness(base[:n], pvs[:n])
+        assert st == 0, rc.last_error()
+        assert npv[:8].tolist() == rc.child_vk_digest().tolist()
+        assert int(npv[8]) == 5 and int(npv[9]) == 5 + 7 * n   # start of child 0, end of the last PRESENT child
+        assert npv[10:].tolist() == ru.leaf_accumulator(pvs[:n]).tolist()
+    # a broken hand-over: child 1 does not start where child 0 ends
+    kids, proofs2, pvs2 = prove_children(ora, [5, 13])
+    st, _ = rc.witness([p.tobytes() for p in proofs2], pvs2)
+    assert st == -7
+    # the same two proofs are fine on their own
+    assert rc.witness([proofs2[1].tobytes()], pvs2[1:])[0] == 0
+    # more children than the circuit was built for
+    assert rc.witness(base + base[:2], pvs + pvs[:2])[0] == -3
+
+
+def test_node_traces_satisfy_the_airs_and_prove(ora, leaf):
+    rc, proofs, pvs = leaf["rc"], leaf["proofs"], leaf["pvs"]
+    st, npv = rc.witness([p.tobytes() for p in proofs], pvs)
+    assert st == 0
+    node = ru.node_instance(rc, npv)
+    for a in node[:2]:
+        assert air.check_trace(a["program"], a["trace"], a["pvs"], a["prep"]) == []
+    # the Poseidon2 chip's outputs are the wires the circuit says they are
+    W, p2 = rc.wires(), node[1]
+    for j in range(4):
+        assert (p2["trace"][282 + 4 * j:286 + 4 * j, :rc.n_perms].T == W[p2["prep"][4 + j][:rc.n_perms]]).all()
+    proof = ora.stark_prove(PARAMS, node)
+    assert ora.stark_verify(PARAMS, node, proof) == 0
+    nvk = ru.verifying(PARAMS, node)
+    assert z.verify(PARAMS, nvk, [a["pvs"] for a in node], proof.tobytes()) == 0
+    # other public values than the circuit computed: refused (the public-value chip binds them to the wires)
+    wrong = npv.copy()
+    wrong[9] = (int(wrong[9]) + 1) % ora.P
+    assert z.verify(PARAMS, nvk, [NOPV, NOPV, wrong], proof.tobytes()) != 0
+    leaf["node"] = dict(instance=node, proof=proof, vk=nvk, pvs=npv)
+
+
+def test_traces_of_a_tampered_child_do_not_prove(ora, leaf):
+    rc, proofs, pvs = leaf["rc"], leaf["proofs"], leaf["pvs"]
+    bad = proofs[0].copy()
+    lay = z.proof_layout(PARAMS, leaf["vk"])
+    bad[lay["opened"] + 5] = (int(bad[lay["opened"] + 5]) + 1) % ora.P
+    st, npv = rc.witness([bad.tobytes(), proofs[1].tobytes()], pvs[:2])
+    assert st == -7
+    node = ru.node_instance(rc, npv)
+    assert any(air.check_trace(a["program"], a["trace"], a["pvs"], a["prep"]) for a in node[:2])
+    proof = ora.stark_prove(PARAMS, node)
+    assert ora.stark_verify(PARAMS, node, proof) != 0
+    assert z.verify(PARAMS, ru.verifying(PARAMS, node), [a["pvs"] for a in node], proof.tobytes()) != 0
+
+
+def test_internal_level_verifies_leaf_proofs(ora, leaf):
+    """Two leaf proofs (3 + 2 segments) under an internal circuit: the state chain and the vk digest go up, a leaf proof with
+    another child-vk digest or a broken chain is refused."""
+    if "node" not in leaf:
+        test_node_traces_satisfy_the_airs_and_prove(ora, leaf)
+    rc = leaf["rc"]
+    n0 = leaf["node"]
+    kids, proofs, pvs = prove_children(ora, [26, 33])
+    st, npv1 = rc.witness([p.tobytes() for p in proofs], pvs)
+    assert st == 0
+    node1 = ru.node_instance(rc, npv1)
+    proof1 = ora.stark_prove(PARAMS, node1)
+    irc = z.RecursionCircuit(PARAMS, n0["vk"], 3, stmt="node")
+    assert irc.n_state == 1 and irc.n_pvs == 18
+    child_pvs = [[NOPV, NOPV, n0["pvs"]], [NOPV, NOPV, npv1]]
+    st, top = irc.witness([n0["proof"].tobytes(), proof1.tobytes()], child_pvs)
+    assert st == 0, irc.last_error()
+    assert top[:8].tolist() == rc.child_vk_digest().tolist()          # still the APP's digest
+    assert int(top[8]) == 5 and int(top[9]) == 40
+    assert top[10:].tolist() == ru.internal_accumulator([n0["pvs"][10:], npv1[10:]]).tolist()
+    inode = ru.node_instance(irc, top)
+    for a in inode[:2]:
+        assert air.check_trace(a["program"], a["trace"], a["pvs"], a["prep"]) == []
+    # children in the wrong order: the chain breaks
+    st, _ = irc.witness([proof1.tobytes(), n0["proof"].tobytes()], child_pvs[::-1])
+    assert st == -7
+    # a child claiming other public values than its proof binds
+    lie = n0["pvs"].copy()
+    lie[9] = 25
+    assert irc.witness([n0["proof"].tobytes(), proof1.tobytes()], [[NOPV, NOPV, lie], child_pvs[1]])[0] == -7
+
+
+def test_circuit_covers_cached_preprocessed_and_final_poly(ora):
+    """A child AIR set with cached main partitions, a preprocessed table, blow-up 4 and a final polynomial of 4 coefficients."""
+    from test_cached_main_cpu import cached_case
+
+    params = (2, 2, 3, 2, 2)
+    airs = cached_case()
+    proof = ora.stark_prove(params, airs)
+    pvs = [a["pvs"] for a in airs]
+    vk = ru.verifying(params, airs)
+    assert z.verify(params, vk, pvs, proof.tobytes()) == 0
+    rc = z.RecursionCircuit(params, vk, 1)
+    st, _ = rc.witness([proof.tobytes()], [pvs])
+    assert st == 0, rc.last_error()
+    rng = np.random.default_rng(1)
+    for pos in sorted(set(range(4, 80)) | set(rng.integers(4, len(proof), 150).tolist())):
+        bad = proof.copy()
+        bad[pos] = (int(bad[pos]) + 1) % ora.P
+        assert rc.witness([bad.tobytes()], [pvs])[0] == -7, pos
+    node = ru.node_instance(rc, rc.witness([proof.tobytes()], [pvs])[1])
+    for a in node[:2]:
+        assert air.check_trace(a["program"], a["trace"], a["pvs"], a["prep"]) == []
+
+
+def test_build_refuses_inconsistent_keys(ora, leaf):
+    vk = [dict(v) for v in leaf["vk"]]
+    vk[0]["log_height"] = 27
+    with pytest.raises(z.ZkhipError):
+        z.RecursionCircuit(PARAMS, vk, 2)
+    with pytest.raises(z.ZkhipError):
+        z.RecursionCircuit(PARAMS, leaf["vk"], 2, stmt=dict(start=[(0, 5)], end=[(0, 1)]))   # no such public value
+    with pytest.raises(z.ZkhipError):
+        z.RecursionCircuit(PARAMS, leaf["vk"], 2, stmt="node")                                # last AIR is not a public-value chip

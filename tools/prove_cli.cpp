@@ -9,7 +9,7 @@
 #include <fstream>
 #include <iostream>
 
-#include "zkhip_prover.hpp"
+#include "zkhip_aggregation.hpp"
 #include "zkhip_vm_prover.hpp"
 
 using namespace scroll_zkvm_hip;
@@ -237,44 +237,75 @@ int main(int argc, char** argv) {
             return 0;
         }
         if (argc >= 8 && std::string(argv[1]) == "prove-agg") {
-            // prove-agg <seg_app> <agg_app> <cfg> <out_dir> <inflight> <segment task.bin>...: segments through one BatchProver, then
-            // the aggregation tree through another.  STAND-IN node circuit (the recursion AIRs are not available): the agg app
-            // is a Fibonacci chip whose public inputs (a0, b0) are folded from the children's trace commitments, so a node proof
-            // is bound to exactly its children; shape and schedule are the reference's (leaf arity 4, internal 3).
-            BatchProver seg = BatchProver::setup(ProverConfig{argv[2], argv[4]}, (unsigned)std::stoul(argv[6]));
-            BatchProver agg = BatchProver::setup(ProverConfig{argv[3], argv[4]}, (unsigned)std::stoul(argv[6]));
+            // prove-agg <seg_app> <cfg> <out_dir> <inflight> <state> <segment task.bin>...: the segments through a BatchProver,
+            // then the aggregation tree (leaf arity 4, internal 3: mod.rs:57-60) through REAL node circuits -- every node proves
+            // that its children verify under the child verifying key (zkhip_aggregation.hpp).  <state> = where a segment's chained
+            // state lives in its public values: "air:idx,air:idx/air:idx,air:idx" (start words / end words), or "-" for none.
+            // Writes root.json, root.vk (the root circuit's verifying key in app-file form: `prove_cli verify root.vk cfg root.json`)
+            // and every node proof.
+            BatchProver seg = BatchProver::setup(ProverConfig{argv[2], argv[3]}, (unsigned)std::stoul(argv[5]));
+            StatementSpec spec;
+            {
+                const std::string st = argv[6];
+                if (st != "-") {
+                    const size_t slash = st.find('/');
+                    if (slash == std::string::npos) throw Error(Error::Setup, "state spec: start/end");
+                    auto parse = [](const std::string& part) {
+                        std::vector<std::pair<uint32_t, uint32_t>> v;
+                        std::stringstream ss(part);
+                        std::string item;
+                        while (std::getline(ss, item, ',')) {
+                            const size_t c = item.find(':');
+                            if (c == std::string::npos) throw Error(Error::Setup, "state spec: air:idx");
+                            v.push_back({(uint32_t)std::stoul(item.substr(0, c)), (uint32_t)std::stoul(item.substr(c + 1))});
+                        }
+                        return v;
+                    };
+                    spec.start = parse(st.substr(0, slash)), spec.end = parse(st.substr(slash + 1));
+                }
+            }
             std::vector<ProvingTask> tasks;
             for (int i = 7; i < argc; i++) tasks.push_back(read_task(argv[i]));
+            const auto t0 = std::chrono::steady_clock::now();
             std::vector<StarkProof> seg_proofs = seg.prove_many(tasks);
+            const auto t1 = std::chrono::steady_clock::now();
+            // the app verifying key: the segment app's AIRs with the (fixed) heights of the segment proofs
+            Prover app = Prover::setup(ProverConfig{argv[2], argv[3]}, "app-vk");
+            VerifyingKey avk;
+            avk.params = app.params(), avk.airs = app.airs();
+            for (uint8_t h : seg_proofs.at(0).baseline) avk.heights.push_back(h);
+            for (auto& a : avk.airs) {
+                if (a.has_prep && a.prep_commit.size() != 8) throw Error(Error::Setup, "the segment app file must carry its preprocessed commitments (prove once with `prove`, or use an app without tables)");
+                a.prep.clear();
+            }
+            seg.reset();
+            AggregationProver agg = AggregationProver::setup(avk, spec);
             AggregationPlan plan = AggregationPlan::build(seg_proofs.size());
-            const unsigned lh = 6;
-            auto make_task = [&](size_t level, size_t node, const std::vector<const StarkProof*>& kids) {
-                const uint32_t Pm = 2013265921u;
-                uint64_t a0 = 1 + level, b0 = 1 + node;
-                for (const StarkProof* k : kids)
-                    for (int w = 0; w < 8; w++) {  // words 4..11 of a proof: its main-trace commitment
-                        uint32_t v;
-                        memcpy(&v, k->proof.data() + 16 + 4 * w, 4);
-                        a0 = (a0 * 31 + v) % Pm, b0 = (b0 * 37 + v + a0) % Pm;
-                    }
-                std::vector<uint32_t> tr(2u << lh);
-                uint64_t x = a0, y = b0;
-                for (unsigned r = 0; r < (1u << lh); r++) {
-                    tr[r] = (uint32_t)x, tr[(1u << lh) + r] = (uint32_t)y;
-                    uint64_t z = (x + y) % Pm;
-                    x = y, y = z;
-                }
-                ProvingTask t;
-                t.serialized_witness.push_back(encode_witness(lh, {(uint32_t)a0, (uint32_t)b0, tr[(2u << lh) - 1]}, tr));
-                return t;
-            };
-            std::vector<std::vector<StarkProof>> all;
-            StarkProof root = prove_aggregation(agg, plan, seg_proofs, make_task, &all);
-            std::ofstream(std::string(argv[5]) + "/root.json") << root.to_json();
+            std::vector<ChildProof> segs;
+            for (const auto& sp : seg_proofs) segs.push_back(AggregationProver::from_stark_proof(sp, avk));
+            (void)agg.node_vk(plan.levels.size() - 1);  // circuits + keys of every level: setup, not proving
+            const auto t2 = std::chrono::steady_clock::now();
+            std::vector<std::vector<ChildProof>> all;
+            ChildProof root = agg.prove_tree(plan, segs, &all);
+            const auto t3 = std::chrono::steady_clock::now();
+            const VerifyingKey& rvk = agg.node_vk(plan.levels.size() - 1);
+            const std::string dir = argv[4];
+            std::ofstream(dir + "/root.json") << AggregationProver::to_stark_proof(root, rvk).to_json();
+            {
+                const std::vector<uint8_t> vkb = rvk.to_app_exe();
+                std::ofstream(dir + "/root.vk", std::ios::binary).write((const char*)vkb.data(), (std::streamsize)vkb.size());
+            }
             for (size_t l = 0; l < all.size(); l++)
                 for (size_t n = 0; n < all[l].size(); n++)
-                    std::ofstream(std::string(argv[5]) + "/agg-" + std::to_string(l) + "-" + std::to_string(n) + ".json") << all[l][n].to_json();
-            std::printf("aggregated %zu segments through %zu nodes in %zu levels\n", seg_proofs.size(), plan.n_nodes(), plan.levels.size());
+                    std::ofstream(dir + "/agg-" + std::to_string(l) + "-" + std::to_string(n) + ".json") << AggregationProver::to_stark_proof(all[l][n], agg.node_vk(l)).to_json();
+            auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+            std::printf("{\"segments\": %zu, \"nodes\": %zu, \"levels\": %zu, \"segment_seconds\": %.4f, \"setup_seconds\": %.4f, \"tree_seconds\": %.4f, "
+                        "\"proofs_folded_per_s\": %.2f, \"witness_seconds\": %.4f, \"tracegen_prove_seconds\": %.4f, \"self_verify_seconds\": %.4f, "
+                        "\"root_proof_bytes\": %zu, \"root_public_values\": [",
+                        seg_proofs.size(), plan.n_nodes(), plan.levels.size(), secs(t0, t1), secs(t1, t2), secs(t2, t3), seg_proofs.size() / secs(t2, t3),
+                        agg.stats.witness_seconds, agg.stats.tracegen_prove_seconds, agg.stats.verify_seconds, root.proof.size());
+            for (size_t i = 0; i < root.pvs[2].size(); i++) std::printf("%s%u", i ? ", " : "", root.pvs[2][i]);
+            std::printf("]}\n");
             return 0;
         }
         if (argc >= 7 && std::string(argv[1]) == "bench-many") {

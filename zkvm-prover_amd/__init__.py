@@ -15,6 +15,7 @@ from ._binding import (  # noqa: F401
     load_library,
     declared_symbols,
     ProvingKey,
+    RecursionCircuit,
     verify,
     proof_layout,
     DEFAULT_PARAMS,

@@ -55,6 +55,11 @@ class _V1Summary(C.Structure):
                [("log_max_height", C.c_uint), ("log_blowup", C.c_uint), ("has_logup_pow", C.c_int), ("log_degree", C.c_uint * 64)]
 
 
+class _RecursionStmt(C.Structure):
+    _fields_ = [("n_state", C.c_size_t), ("start_air", C.POINTER(C.c_uint32)), ("start_idx", C.POINTER(C.c_uint32)),
+                ("end_air", C.POINTER(C.c_uint32)), ("end_idx", C.POINTER(C.c_uint32)), ("child_is_node", C.c_int)]
+
+
 class _KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -158,6 +163,20 @@ def load_library():
         "zkhip_proof_from_v1": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(C.c_uint8), sz,
                                           C.POINTER(C.c_uint8), sz, C.POINTER(sz), C.POINTER(u32p)]),
         "zkhip_proof_layout_of": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(_ProofLayout)]),
+        "zkhip_recursion_build": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, sz, C.POINTER(_RecursionStmt), C.POINTER(vp)]),
+        "zkhip_recursion_destroy": (None, [vp]),
+        "zkhip_recursion_last_error": (C.c_char_p, [vp]),
+        "zkhip_recursion_n_airs": (sz, [vp]),
+        "zkhip_recursion_n_pvs": (sz, [vp]),
+        "zkhip_recursion_n_state": (sz, [vp]),
+        "zkhip_recursion_max_children": (sz, [vp]),
+        "zkhip_recursion_child_proof_bytes": (sz, [vp]),
+        "zkhip_recursion_stats": (C.c_int, [vp, C.POINTER(sz)]),
+        "zkhip_recursion_child_vk_digest": (C.c_int, [vp, u32p]),
+        "zkhip_recursion_air": (C.c_int, [vp, sz, C.POINTER(_Air)]),
+        "zkhip_recursion_witness": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(C.POINTER(u32p)), sz, u32p]),
+        "zkhip_recursion_wires": (C.c_int, [vp, u32p, sz, C.POINTER(sz)]),
+        "zkhip_recursion_tracegen": (C.c_int, [vp, vp, vp, vp, vp]),
         "zkhip_profile_enable": (C.c_int, [vp, C.c_int]),
         "zkhip_profile_read": (C.c_int, [vp, C.POINTER(_KernelStat), sz]),
         "zkhip_profile_reset": (C.c_int, [vp]),
@@ -797,6 +816,103 @@ def verify(params, airs, pvs, proof_bytes):
     pa, keep2 = _pvs_array(pvs)
     buf = np.frombuffer(proof_bytes, dtype=np.uint8)
     return lib.zkhip_verify(C.byref(prm), arr, len(airs), pa, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size)
+
+
+class RecursionCircuit:
+    """zkhip_recursion: the verifier circuit of an aggregation node for ONE child verifying key (params + verifying AIRs with
+    heights and preprocessed commitments) and up to `max_children` child proofs.  Building it and running the witness need no
+    GPU.  stmt: None (no chained state), "node" (the children are node proofs) or dict(start=[(air, idx)..], end=[(air, idx)..])."""
+
+    def __init__(self, params, child_airs, max_children, stmt=None):
+        self.lib = load_library()
+        self.params, self.child_airs = tuple(params), child_airs
+        prm = _Params(*self.params)
+        arr, keep = _air_structs(child_airs)
+        st = _RecursionStmt()
+        keep2 = []
+        if stmt == "node":
+            st.child_is_node = 1
+        elif stmt:
+            cols = [np.ascontiguousarray([x[k] for x in stmt[side]], dtype=np.uint32) for side in ("start", "end") for k in (0, 1)]
+            keep2 = cols
+            st.n_state = len(stmt["start"])
+            st.start_air, st.start_idx, st.end_air, st.end_idx = (_u32p(c) for c in cols)
+        h = C.c_void_p()
+        rc = self.lib.zkhip_recursion_build(C.byref(prm), arr, len(child_airs), max_children, C.byref(st), C.byref(h))
+        if rc != 0:
+            raise ZkhipError("zkhip_recursion_build returned %d: %s" % (rc, self.lib.zkhip_recursion_last_error(None).decode()))
+        self.h = h
+        self.max_children = max_children
+        self.n_pvs = self.lib.zkhip_recursion_n_pvs(h)
+        self.n_state = self.lib.zkhip_recursion_n_state(h)
+        out = (C.c_size_t * 4)()
+        self.lib.zkhip_recursion_stats(h, out)
+        self.n_wires, self.n_gates, self.n_perms = int(out[0]), int(out[1]), int(out[2])
+
+    def airs(self):
+        """The node circuit as AIR dicts (program, log_height, width, n_pvs, prep) for ProvingKey / the oracle prover."""
+        out = []
+        for i in range(3):
+            a = _Air()
+            rc = self.lib.zkhip_recursion_air(self.h, i, C.byref(a))
+            assert rc == 0
+            prog = np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy()
+            pw = [18, 13, (self.n_pvs + 3) // 4][i]
+            prep = np.ctypeslib.as_array(a.prep_trace, shape=(pw << a.log_height,)).copy().reshape(pw, -1)
+            out.append(dict(program=prog, log_height=int(a.log_height), width=int(a.width), n_pvs=int(a.n_pvs), prep=prep))
+        return out
+
+    def child_vk_digest(self):
+        out = np.zeros(8, dtype=np.uint32)
+        self.lib.zkhip_recursion_child_vk_digest(self.h, _u32p(out))
+        return out
+
+    def witness(self, proofs, child_pvs):
+        """proofs: list of bytes; child_pvs[c][a]: public values of AIR a of child c.  Returns (status, node public values)."""
+        n = len(proofs)
+        bufs = [np.frombuffer(p, dtype=np.uint8) for p in proofs]
+        pp = (C.POINTER(C.c_uint8) * n)(*[b.ctypes.data_as(C.POINTER(C.c_uint8)) for b in bufs])
+        lens = (C.c_size_t * n)(*[b.size for b in bufs])
+        keep, rows = [], []
+        for c in range(n):
+            pa, k = _pvs_array(child_pvs[c])
+            keep += [pa, k]
+            rows.append(C.cast(pa, C.POINTER(C.POINTER(C.c_uint32))))
+        pv = (C.POINTER(C.POINTER(C.c_uint32)) * n)(*rows)
+        out = np.zeros(self.n_pvs, dtype=np.uint32)
+        rc = self.lib.zkhip_recursion_witness(self.h, pp, lens, pv, n, _u32p(out))
+        return rc, out
+
+    def last_error(self):
+        return self.lib.zkhip_recursion_last_error(self.h).decode()
+
+    def wires(self):
+        n = C.c_size_t()
+        self.lib.zkhip_recursion_wires(self.h, None, 0, C.byref(n))
+        out = np.zeros(n.value, dtype=np.uint32)
+        rc = self.lib.zkhip_recursion_wires(self.h, _u32p(out), out.size, C.byref(n))
+        assert rc == 0
+        return out.reshape(-1, 4)
+
+    def tracegen(self, ctx):
+        """Device traces of the three chips from the last witness (torch int32 tensors, Montgomery)."""
+        import torch
+
+        airs = self.airs()
+        ts = [torch.empty(a["width"] << a["log_height"], dtype=torch.int32, device=ctx.device) for a in airs]
+        ctx._check(self.lib.zkhip_recursion_tracegen(ctx.h, self.h, ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr()))
+        return ts
+
+    def close(self):
+        if self.h:
+            self.lib.zkhip_recursion_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- the verifier's primitives on the host (need no GPU) ---------------------------------------------
