@@ -110,6 +110,22 @@ public:
     // proves one node: level 0 verifies up to 4 proofs of the app, level l > 0 up to 3 proofs of level l - 1
     ChildProof prove_node(size_t level, const std::vector<const ChildProof*>& kids) {
         using clk = std::chrono::steady_clock;
+        auto t0 = clk::now();
+        std::vector<uint32_t> npv = witness_node(level, kids);
+        auto t1 = clk::now();
+        ChildProof out = prove_witnessed(level, std::move(npv));
+        auto t2 = clk::now();
+        if (!levels_[level].vk.verify(out)) throw Error(Error::VerifyProof, "aggregation: the node proof does not verify");
+        stats.nodes++;
+        stats.witness_seconds += std::chrono::duration<double>(t1 - t0).count();
+        stats.tracegen_prove_seconds += std::chrono::duration<double>(t2 - t1).count();
+        stats.verify_seconds += std::chrono::duration<double>(clk::now() - t2).count();
+        return out;
+    }
+
+    // "execution" of a node: runs the verifier circuit on the children (host; one thread per child inside the library) and
+    // returns the node's public values.  Throws if a child does not verify or the states do not chain.
+    std::vector<uint32_t> witness_node(size_t level, const std::vector<const ChildProof*>& kids) {
         ensure_level(level);
         Level& L = levels_[level];
         if (kids.empty() || kids.size() > arity(level)) throw Error(Error::GenProof, "aggregation: a node of level " + std::to_string(level) + " takes 1.." + std::to_string(arity(level)) + " children");
@@ -127,41 +143,90 @@ public:
             }
             pv_ptrs.push_back(pv_rows[c].data());
         }
-        auto t0 = clk::now();
-        ChildProof out;
-        out.pvs.resize(3);
-        out.pvs[2].resize(zkhip_recursion_n_pvs(L.circ));
-        int rc = zkhip_recursion_witness(L.circ, proofs.data(), lens.data(), pv_ptrs.data(), kids.size(), out.pvs[2].data());
+        std::vector<uint32_t> npv(zkhip_recursion_n_pvs(L.circ));
+        int rc = zkhip_recursion_witness(L.circ, proofs.data(), lens.data(), pv_ptrs.data(), kids.size(), npv.data());
         if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_recursion_last_error(L.circ));
-        auto t1 = clk::now();
-        check(zkhip_recursion_tracegen(ctx_, L.circ, (uint32_t*)L.d_traces[0], (uint32_t*)L.d_traces[1], (uint32_t*)L.d_traces[2]));
-        out.proof.resize(zkhip_proof_size(L.pk));
-        const uint32_t* dt[3] = {(const uint32_t*)L.d_traces[0], (const uint32_t*)L.d_traces[1], (const uint32_t*)L.d_traces[2]};
-        const uint32_t* pv[3] = {nullptr, nullptr, out.pvs[2].data()};
-        size_t len = 0;
-        check(zkhip_prove(ctx_, L.pk, dt, pv, out.proof.data(), out.proof.size(), &len));
-        out.proof.resize(len);
-        auto t2 = clk::now();
-        if (!L.vk.verify(out)) throw Error(Error::VerifyProof, "aggregation: the node proof does not verify");
-        auto t3 = clk::now();
-        stats.nodes++;
-        stats.witness_seconds += std::chrono::duration<double>(t1 - t0).count();
-        stats.tracegen_prove_seconds += std::chrono::duration<double>(t2 - t1).count();
-        stats.verify_seconds += std::chrono::duration<double>(t3 - t2).count();
-        return out;
+        return npv;
+    }
+    // device trace generation + proof of the node whose witness was computed last on this level
+    ChildProof prove_witnessed(size_t level, std::vector<uint32_t> node_pvs) {
+        Level& L = levels_[level];
+        upload_witness(level);
+        return prove_uploaded(level, std::move(node_pvs));
     }
 
-    // the whole tree of `plan` over the segment proofs; returns the root, `all` (optional) receives every level
+    // The whole tree of `plan` over the segment proofs; returns the root, `all` (optional) receives every level.  Within a
+    // level the three stages of consecutive nodes overlap: the host runs the circuit of node n + 1 (witness) and the
+    // self-verification of node n - 1 while the device generates the traces of node n and proves it.
     ChildProof prove_tree(const AggregationPlan& plan, const std::vector<ChildProof>& segments, std::vector<std::vector<ChildProof>>* all = nullptr) {
+        using clk = std::chrono::steady_clock;
         if (segments.size() != plan.n_segments) throw Error(Error::GenProof, "aggregation: segment proof count does not match the plan");
         std::vector<ChildProof> below = segments;
         for (size_t l = 0; l < plan.levels.size(); l++) {
-            std::vector<ChildProof> cur;
-            for (const auto& nd : plan.levels[l]) {
+            ensure_level(l);
+            const auto& nodes = plan.levels[l];
+            std::vector<ChildProof> cur(nodes.size());
+            auto kids_of = [&](size_t n) {
                 std::vector<const ChildProof*> kids;
-                for (size_t c : nd.children) kids.push_back(&below.at(c));
-                cur.push_back(prove_node(l, kids));
+                for (size_t c : nodes[n].children) kids.push_back(&below.at(c));
+                return kids;
+            };
+            struct Job {
+                std::thread th;
+                std::string err;
+                std::vector<uint32_t> npv;
+                double seconds = 0;
+            };
+            auto start_witness = [&](size_t n) {
+                auto j = std::make_unique<Job>();
+                Job* jp = j.get();
+                jp->th = std::thread([this, jp, l, kids = kids_of(n)]() {
+                    auto t = clk::now();
+                    try {
+                        jp->npv = witness_node(l, kids);
+                    } catch (const std::exception& e) {
+                        jp->err = e.what();
+                    }
+                    jp->seconds = std::chrono::duration<double>(clk::now() - t).count();
+                });
+                return j;
+            };
+            std::vector<std::unique_ptr<Job>> verifies;
+            auto start_verify = [&](size_t n) {
+                auto j = std::make_unique<Job>();
+                Job* jp = j.get();
+                jp->th = std::thread([this, jp, l, &cur, n]() {
+                    auto t = clk::now();
+                    if (!levels_[l].vk.verify(cur[n])) jp->err = "aggregation: the proof of node " + std::to_string(n) + " of level " + std::to_string(l) + " does not verify";
+                    jp->seconds = std::chrono::duration<double>(clk::now() - t).count();
+                });
+                verifies.push_back(std::move(j));
+            };
+            std::unique_ptr<Job> wit = start_witness(0);
+            std::string err;
+            for (size_t n = 0; n < nodes.size(); n++) {
+                wit->th.join();
+                stats.witness_seconds += wit->seconds;
+                if (!wit->err.empty()) {
+                    err = wit->err;
+                    break;
+                }
+                std::vector<uint32_t> npv = std::move(wit->npv);
+                auto t = clk::now();
+                upload_witness(l);  // after this the circuit's witness buffer is free for the next node
+                if (n + 1 < nodes.size()) wit = start_witness(n + 1);
+                cur[n] = prove_uploaded(l, std::move(npv));
+                stats.tracegen_prove_seconds += std::chrono::duration<double>(clk::now() - t).count();
+                stats.nodes++;
+                start_verify(n);
             }
+            if (wit && wit->th.joinable()) wit->th.join();
+            for (auto& v : verifies) {
+                v->th.join();
+                stats.verify_seconds += v->seconds;
+                if (err.empty() && !v->err.empty()) err = v->err;
+            }
+            if (!err.empty()) throw Error(err.find("does not verify") != std::string::npos && err.find("node ") != std::string::npos ? Error::VerifyProof : Error::GenProof, err);
             below = std::move(cur);
             if (all) all->push_back(below);
         }
@@ -213,6 +278,23 @@ private:
 
     void check(int rc) const {
         if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_last_error(ctx_));
+    }
+    void upload_witness(size_t level) {
+        Level& L = levels_[level];
+        check(zkhip_recursion_tracegen(ctx_, L.circ, (uint32_t*)L.d_traces[0], (uint32_t*)L.d_traces[1], (uint32_t*)L.d_traces[2]));
+    }
+    ChildProof prove_uploaded(size_t level, std::vector<uint32_t> node_pvs) {
+        Level& L = levels_[level];
+        ChildProof out;
+        out.pvs.resize(3);
+        out.pvs[2] = std::move(node_pvs);
+        out.proof.resize(zkhip_proof_size(L.pk));
+        const uint32_t* dt[3] = {(const uint32_t*)L.d_traces[0], (const uint32_t*)L.d_traces[1], (const uint32_t*)L.d_traces[2]};
+        const uint32_t* pv[3] = {nullptr, nullptr, out.pvs[2].data()};
+        size_t len = 0;
+        check(zkhip_prove(ctx_, L.pk, dt, pv, out.proof.data(), out.proof.size(), &len));
+        out.proof.resize(len);
+        return out;
     }
     void ensure_level(size_t level) {
         using clk = std::chrono::steady_clock;

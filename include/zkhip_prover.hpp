@@ -580,6 +580,7 @@ public:
         return b;
     }
     size_t lanes() const { return lanes_.size(); }
+    const Prover& lane(size_t i) const { return lanes_.at(i); }
     void reset() {
         for (auto& l : lanes_) l.reset();
     }

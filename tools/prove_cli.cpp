@@ -270,12 +270,20 @@ int main(int argc, char** argv) {
             std::vector<StarkProof> seg_proofs = seg.prove_many(tasks);
             const auto t1 = std::chrono::steady_clock::now();
             // the app verifying key: the segment app's AIRs with the (fixed) heights of the segment proofs
-            Prover app = Prover::setup(ProverConfig{argv[2], argv[3]}, "app-vk");
+            // (a lane that has proven holds the commitments of the app's preprocessed tables, adopted at its keygen)
             VerifyingKey avk;
-            avk.params = app.params(), avk.airs = app.airs();
+            {
+                size_t best = 0;
+                for (size_t l = 0; l < seg.lanes(); l++) {
+                    bool ok = true;
+                    for (const auto& a : seg.lane(l).airs()) ok = ok && (!a.has_prep || a.prep_commit.size() == 8);
+                    if (ok) best = l;
+                }
+                avk.params = seg.lane(best).params(), avk.airs = seg.lane(best).airs();
+            }
             for (uint8_t h : seg_proofs.at(0).baseline) avk.heights.push_back(h);
             for (auto& a : avk.airs) {
-                if (a.has_prep && a.prep_commit.size() != 8) throw Error(Error::Setup, "the segment app file must carry its preprocessed commitments (prove once with `prove`, or use an app without tables)");
+                if (a.has_prep && a.prep_commit.size() != 8) throw Error(Error::Setup, "no lane holds the commitments of the app's preprocessed tables");
                 a.prep.clear();
             }
             seg.reset();

@@ -30,6 +30,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "air_compile.hpp"
@@ -98,6 +99,9 @@ struct Circuit {
     std::vector<Op> order;
     std::vector<uint32_t> pv_wires;  // groups of 4 public values bound to one wire each
     size_t n_pvs = 0;
+    // order[sections[i] .. sections[i + 1]) verifies child i and touches only that child's wires and constant wires: the
+    // sections can be evaluated side by side once the constant rows are done
+    std::vector<size_t> sections;
 };
 
 struct BuildError {
@@ -157,6 +161,7 @@ class Builder {
         in_fill_[t]++;
         return v;
     }
+    void close_input_rows() { in_gate_[0] = in_gate_[1] = SIZE_MAX; }  // the next input opens a fresh row (section boundary)
     V in_base(const Src& s) { return input(s, true); }
     V in_ext(const Src& s) { return input(s, false); }
 
@@ -1170,7 +1175,13 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
         Builder b;
         const size_t K = R->n_state;
         std::vector<ChildValues> kids;
-        for (size_t ci = 0; ci < max_children; ci++) kids.push_back(verify_child_sym(b, vk, (uint32_t)ci));
+        for (size_t ci = 0; ci < max_children; ci++) {
+            b.close_input_rows();
+            b.c.sections.push_back(b.c.order.size());
+            kids.push_back(verify_child_sym(b, vk, (uint32_t)ci));
+        }
+        b.close_input_rows();
+        b.c.sections.push_back(b.c.order.size());
         // presence flags: child 0 is present, present children form a prefix
         std::vector<V> flag(max_children);
         flag[0] = cst(ext_one());
@@ -1311,7 +1322,6 @@ int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, co
     }
     std::vector<Ext>& vals = R->vals;
     vals.assign((size_t)c.n_wires + 1, ext_zero());
-    long first_bad = -1;
     auto lin_value = [&](const Gate& G) {
         Ext r = G.qK;
         const Ext &a = vals[G.w[0]], &bq = vals[G.w[1]], &d = vals[G.w[3]];
@@ -1321,63 +1331,90 @@ int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, co
         if (G.qD) r = ext_add(r, ext_mul_base(d, G.qD));
         return r;
     };
-    for (const Op& op : c.order) {
-        if (op.is_perm) {
-            const Perm& p = c.perms[op.idx];
-            uint32_t s[16];
-            for (int j = 0; j < 4; j++)
-                for (int k = 0; k < 4; k++) s[4 * j + k] = vals[p.in[j]].c[k];
-            poseidon2_permute(s);
-            for (int j = 0; j < 4; j++) vals[p.out[j]] = Ext{{s[4 * j], s[4 * j + 1], s[4 * j + 2], s[4 * j + 3]}};
-            continue;
-        }
-        const Gate& G = c.gates[op.idx];
-        switch (G.kind) {
-            case K_INPUT:
-                for (int s = 0; s < 4; s++) {
-                    if (G.role[s] != 2) continue;
-                    const Src& sr = G.src[s];
-                    Ext v = ext_zero();
-                    switch (sr.kind) {
-                        case S_PROOF_BASE: v.c[0] = to_monty(pw[sr.child][sr.a]); break;
-                        case S_PROOF_EXT:
-                            for (int k = 0; k < 4; k++) v.c[k] = to_monty(pw[sr.child][sr.a + k]);
-                            break;
-                        case S_PV: v.c[0] = to_monty(child_pvs[sr.child < n_present ? sr.child : 0][sr.a][sr.b]); break;
-                        case S_FLAG: v.c[0] = sr.child < n_present ? MONTY_ONE : 0; break;
-                        case S_HINT_BIT: v.c[0] = ((from_monty(vals[sr.a].c[0]) >> sr.b) & 1) ? MONTY_ONE : 0; break;
-                        case S_HINT_COORD: v.c[0] = vals[sr.a].c[sr.b]; break;
-                        default: break;
+    auto is_const_row = [](const Gate& G) { return G.kind == K_LIN && !G.role[0] && !G.role[1] && !G.role[3]; };
+    // evaluates order[lo, hi); returns the first failing gate or -1
+    auto run = [&](size_t lo, size_t hi, bool skip_const) -> long {
+        long first_bad = -1;
+        for (size_t oi = lo; oi < hi; oi++) {
+            const Op& op = c.order[oi];
+            if (op.is_perm) {
+                const Perm& p = c.perms[op.idx];
+                uint32_t s[16];
+                for (int j = 0; j < 4; j++)
+                    for (int k = 0; k < 4; k++) s[4 * j + k] = vals[p.in[j]].c[k];
+                poseidon2_permute(s);
+                for (int j = 0; j < 4; j++) vals[p.out[j]] = Ext{{s[4 * j], s[4 * j + 1], s[4 * j + 2], s[4 * j + 3]}};
+                continue;
+            }
+            const Gate& G = c.gates[op.idx];
+            switch (G.kind) {
+                case K_INPUT:
+                    for (int s = 0; s < 4; s++) {
+                        if (G.role[s] != 2) continue;
+                        const Src& sr = G.src[s];
+                        Ext v = ext_zero();
+                        switch (sr.kind) {
+                            case S_PROOF_BASE: v.c[0] = to_monty(pw[sr.child][sr.a]); break;
+                            case S_PROOF_EXT:
+                                for (int k = 0; k < 4; k++) v.c[k] = to_monty(pw[sr.child][sr.a + k]);
+                                break;
+                            case S_PV: v.c[0] = to_monty(child_pvs[sr.child < n_present ? sr.child : 0][sr.a][sr.b]); break;
+                            case S_FLAG: v.c[0] = sr.child < n_present ? MONTY_ONE : 0; break;
+                            case S_HINT_BIT: v.c[0] = ((from_monty(vals[sr.a].c[0]) >> sr.b) & 1) ? MONTY_ONE : 0; break;
+                            case S_HINT_COORD: v.c[0] = vals[sr.a].c[sr.b]; break;
+                            default: break;
+                        }
+                        vals[G.w[s]] = v;
                     }
-                    vals[G.w[s]] = v;
+                    break;
+                case K_LIN:
+                    if (skip_const && is_const_row(G)) break;
+                    vals[G.w[2]] = lin_value(G);
+                    break;
+                case K_INV: {
+                    const Ext& a = vals[G.w[0]];
+                    if (is_zero(a)) {
+                        if (first_bad < 0) first_bad = (long)op.idx;
+                        vals[G.w[1]] = ext_zero();
+                    } else {
+                        vals[G.w[1]] = ext_inv(a);
+                    }
+                    break;
                 }
-                break;
-            case K_LIN: vals[G.w[2]] = lin_value(G); break;
-            case K_INV: {
-                const Ext& a = vals[G.w[0]];
-                if (is_zero(a)) {
-                    if (first_bad < 0) first_bad = (long)op.idx;
-                    vals[G.w[1]] = ext_zero();
-                } else {
-                    vals[G.w[1]] = ext_inv(a);
+                case K_DIV: {
+                    const Ext& d = vals[G.w[1]];
+                    const Ext n = G.qD ? vals[G.w[3]] : ext_neg(G.qK);
+                    if (is_zero(d)) {
+                        if (first_bad < 0 && !is_zero(n)) first_bad = (long)op.idx;
+                        vals[G.w[0]] = ext_zero();
+                    } else {
+                        vals[G.w[0]] = ext_mul(n, ext_inv(d));
+                    }
+                    break;
                 }
-                break;
+                default:
+                    if (!is_zero(lin_value(G)) && first_bad < 0) first_bad = (long)op.idx;
+                    break;
             }
-            case K_DIV: {
-                const Ext& d = vals[G.w[1]];
-                const Ext n = G.qD ? vals[G.w[3]] : ext_neg(G.qK);
-                if (is_zero(d)) {
-                    if (first_bad < 0 && !is_zero(n)) first_bad = (long)op.idx;
-                    vals[G.w[0]] = ext_zero();
-                } else {
-                    vals[G.w[0]] = ext_mul(n, ext_inv(d));
-                }
-                break;
-            }
-            default:
-                if (!is_zero(lin_value(G)) && first_bad < 0) first_bad = (long)op.idx;
-                break;
         }
+        return first_bad;
+    };
+    // constant rows first (a constant's row sits in whichever section used it first), then one thread per child section,
+    // then the statement logic behind them
+    for (const Gate& G : c.gates)
+        if (is_const_row(G)) vals[G.w[2]] = G.qK;
+    long first_bad = -1;
+    {
+        const size_t n_sec = c.sections.size() - 1;
+        std::vector<long> bad(n_sec, -1);
+        std::vector<std::thread> th;
+        for (size_t i = 1; i < n_sec; i++) th.emplace_back([&, i]() { bad[i] = run(c.sections[i], c.sections[i + 1], true); });
+        bad[0] = run(c.sections[0], c.sections[1], true);
+        for (auto& t : th) t.join();
+        for (long b : bad)
+            if (b >= 0 && (first_bad < 0 || b < first_bad)) first_bad = b;
+        const long tail = run(c.sections[n_sec], c.order.size(), true);
+        if (first_bad < 0) first_bad = tail;
     }
     R->node_pvs.assign(c.n_pvs, 0);
     for (size_t i = 0; i < c.n_pvs; i++) R->node_pvs[i] = from_monty(vals[c.pv_wires[i / 4]].c[i % 4]);
