@@ -551,6 +551,40 @@ int zkhip_proof_to_v1(const zkhip_params *params, const zkhip_air *airs, size_t 
 int zkhip_proof_from_v1(const zkhip_params *params, const zkhip_air *airs, size_t n_airs, const uint8_t *v1, size_t v1_len,
                         uint8_t *out, size_t cap, size_t *out_len, uint32_t *const *pvs_out);
 
+/* ---- the ONE-STATEMENT VM circuit (include/zkhip_vm_circuit.hpp; SURVEY.md 8(f) f3 adapters / execution bus / connector /
+ *      persistent memory -- OpenVM's openvm-circuit and openvm-rv32im-circuit crates, un-vendored; reached by the reference through
+ *      sdk.prove, crates/prover/src/prover/mod.rs:355-357).  The AIR set of a segment is defined ONCE, in C++; these entry points
+ *      hand its programs, the instruction decode and the program table to any host language. ---- */
+size_t zkhip_vm_n_airs(void);
+/* AIR `id` (order of zkhip::vmc::AirId): program words, width, public-value count; log_height and the preprocessed fields are
+ * left zero (heights come from the segment configuration, tables from zkhip_vm_program_table / the lookup tables); *prep_width
+ * receives the width of its preprocessed trace.  Pointers stay valid for the life of the process. */
+int zkhip_vm_air(unsigned id, zkhip_air *out, size_t *prep_width);
+int zkhip_vm_decode(uint32_t word, uint32_t pc, uint32_t out[17], int *legal);
+/* preprocessed trace of the program chip: 17 columns x 2^log_program rows, column-major, canonical */
+int zkhip_vm_program_table(const uint32_t *words, size_t n_words, uint32_t pc_base, unsigned log_program, uint32_t *out);
+/* Frame chip (34 columns): record r = (program row d_pc_index[r], operands d_x / d_y, result d_z, previous value of rd d_rd_prev --
+ * plain 32-bit words --, pc step d_pc_inc as a canonical field element); its timestamp is 1 + 16 r.  d_program: the program table on the
+ * device, Montgomery, stride n_program. */
+int zkhip_vm_frame_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc_index, const uint32_t *d_x, const uint32_t *d_y, const uint32_t *d_z,
+                            const uint32_t *d_rd_prev, const uint32_t *d_pc_inc, size_t n, const uint32_t *d_program, size_t n_program, unsigned log_height,
+                            uint32_t *d_trace);
+/* Load/store chip (45 columns): the core's records (zkhip_rv32_loadstore_tracegen) + per record the instruction's timestamp, base
+ * register value and 32-bit immediate. */
+int zkhip_vm_loadstore_tracegen(zkhip_ctx *ctx, const uint32_t *d_case, const uint32_t *d_read, const uint32_t *d_prev, const uint32_t *d_ts,
+                                const uint32_t *d_base, const uint32_t *d_imm, size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
+/* Memory-access chip (11 columns): zkhip_memory_access_tracegen's ten + 8 * gap_hi. */
+int zkhip_vm_access_tracegen(zkhip_ctx *ctx, const uint32_t *d_addr_space, const uint32_t *d_pointer, const uint32_t *d_prev_data, const uint32_t *d_prev_ts,
+                             const uint32_t *d_data, const uint32_t *d_ts, const uint32_t *d_is_read, size_t n, unsigned log_height, uint32_t *d_trace);
+/* Poseidon2 chip serving the hash bus (299 columns): zkhip_poseidon2_air_tracegen + multiplicity 1 on the first n rows. */
+int zkhip_vm_poseidon2_tracegen(zkhip_ctx *ctx, const uint32_t *d_inputs, size_t n, unsigned log_height, uint32_t *d_trace);
+/* n rows of `width` canonical words (row-major, device) -> column-major Montgomery trace of 2^log_height rows; the other rows get
+ * pad_row (HOST, `width` words; NULL = zeros).  For chips whose rows the executor writes itself (ecall, leaf, merkle, connector). */
+int zkhip_rows_tracegen(zkhip_ctx *ctx, const uint32_t *d_rows, size_t n, size_t width, unsigned log_height, uint32_t *d_trace, const uint32_t *pad_row);
+/* multiplicities of the requests scale * value (value = Montgomery words of a trace column) in a range table of 2^log_table entries */
+int zkhip_range_counts_scaled_tracegen(zkhip_ctx *ctx, const uint32_t *d_values, size_t n, uint32_t scale, unsigned log_table, uint32_t *d_counts,
+                                       int accumulate);
+
 /* ---- aggregation layer: the verifier circuit.  Replaces, for this backend's proofs, the leaf /
  *      internal verifier programs the reference's SDK proves at the nodes of its aggregation tree and `commit_child_vk`
  *      (crates/prover/src/prover/mod.rs:47-60, 200-282; crates/integration/src/lib.rs:461-514).  A circuit is built for ONE

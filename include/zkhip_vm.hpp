@@ -142,6 +142,17 @@ public:
         close_segment(rec);
         return done_;
     }
+    // one instruction (the segmenting executor of include/zkhip_vm_exec.hpp drives the machine step by step and keeps the memory
+    // log of its own: set_memory_log(false) stops this class from writing acc_* / bnd_* records)
+    void step_one(ExecRecords* rec) {
+        if (!done_) step(rec);
+    }
+    void set_memory_log(bool on) { log_memory_ = on; }
+    bool done() const { return done_; }
+    uint32_t pc() const { return pc_; }
+    uint32_t last_result() const { return last_val_; }   // the value the last instruction computed for rd (also when rd = x0)
+    uint32_t peek_word(uint32_t addr) const { return word_around(addr); }
+    const Exe& exe() const { return exe_; }
     uint64_t instret() const { return instret_; }
     const std::vector<uint8_t>& public_values() const { return pv_; }
     uint32_t exit_code() const { return exit_code_; }
@@ -151,7 +162,8 @@ private:
     const Exe& exe_;
     const StdIn& in_;
     std::vector<uint8_t> mem_, pv_;
-    uint32_t x_[32], pc_ = 0, exit_code_ = 0;
+    uint32_t x_[32], pc_ = 0, exit_code_ = 0, last_val_ = 0;
+    bool log_memory_ = true;
     uint64_t instret_ = 0;
     size_t in_pos_ = 0;
     bool done_ = false;
@@ -167,7 +179,7 @@ private:
     uint32_t clock_ = 0, segment_ = 1;
 
     void close_segment(ExecRecords* rec) {
-        if (rec) {  // boundary records, sorted by (address space, pointer)
+        if (rec && log_memory_) {  // boundary records, sorted by (address space, pointer)
             std::sort(touched_.begin(), touched_.end());
             for (uint64_t k : touched_) {
                 const Cell& c = (k >> 32) == 1 ? reg_cells_[(uint32_t)k] : mem_cells_[(uint32_t)k];
@@ -181,7 +193,7 @@ private:
     }
     // one access of a 16-bit cell: `write` replaces its value by `value`
     void touch(ExecRecords* rec, uint32_t as, uint32_t ptr, uint32_t current, bool write, uint32_t value) {
-        if (!rec) return;
+        if (!rec || !log_memory_) return;
         if (as == 2 && mem_cells_.empty()) mem_cells_.assign(mem_.size() / 2 + 1, Cell{0, 0, 0, 0});
         Cell& c = as == 1 ? reg_cells_[ptr] : mem_cells_[ptr];
         if (c.seg != segment_) c = Cell{current, current, 0, segment_}, touched_.push_back(((uint64_t)as << 32) | ptr);
@@ -406,8 +418,10 @@ private:
                 }
                 break;
             }
+            case 0x0f: break;  // FENCE: a single hart with one memory -- no operation (ordinary rv32im toolchains emit it)
             default: throw Error("illegal instruction " + std::to_string(w) + " at pc " + std::to_string(pc_));
         }
+        last_val_ = val;
         if (wr) reg_write(rec, rd, val);
         pc_ = next;
         instret_++;

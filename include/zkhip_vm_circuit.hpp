@@ -1,0 +1,502 @@
+// zkhip_vm_circuit.hpp -- ONE STATEMENT PER SEGMENT: the chips that tie the instruction cores of include/zkhip_chips.hpp to the
+// executed program, to each other and to memory -- the job of OpenVM's adapters, execution bus, connector and persistent-memory
+// chips (un-vendored crates openvm-circuit / openvm-rv32im-circuit; the reference reaches them through
+// sdk.prove, crates/prover/src/prover/mod.rs:355-357).
+//
+//   program chip   the decoded program as a PREPROCESSED trace (its commitment is part of the verifying key = the committed
+//                  executable, crates/verifier/src/verifier.rs:77-80), one row per instruction: 17 decode fields; the main trace is
+//                  the execution frequency; every executed instruction is looked up here.
+//   frame chip     one row per executed instruction: receives (pc, timestamp) on the EXECUTION BUS and sends (pc + pc_inc,
+//                  timestamp + 16); reads rs1 / rs2 and writes rd through the ACCESS BUS at fixed timestamp slots; range-checks
+//                  the operand bytes; hands (class, opcode, operands, result, pc_inc ...) to the instruction's core chip on the
+//                  OPERAND BUS.  A core chip (ALU, less-than, mul, mulh, div, shift, branches, jumps) is the core of
+//                  include/zkhip_chips.hpp plus ONE receive on that bus: its columns are unchanged, so are its trace generators.
+//   load/store     the load/store core plus its memory adapter: address = rs1 + immediate, the aligned word's two 16-bit cells
+//                  accessed at slots 4, 5.
+//   ecall chip     exit (pc becomes 0: the end of the execution), reveal (writes a public-value word into address space 3), hint read.
+//   memory access  one row per cell access (include/zkhip_chips.hpp memory_access_air + the ACCESS BUS receive + a timestamp-gap
+//                  bound that cannot wrap around the field): offline memory checking inside the segment.
+//   leaf chip      one row per touched memory BLOCK of 8 cells: initial / final cell values against the memory bus, their Poseidon2
+//                  digests, strictly increasing block labels.
+//   merkle chip    one row per node on the path from a touched block to the root: the same path hashed over the initial and the
+//                  final blocks; untouched siblings are equal in both; the root row's digests are PUBLIC VALUES: the segment's
+//                  initial and final memory root.
+//   connector      public values (pc_start, pc_end): starts and ends the execution-bus chain.
+// A segment proof therefore states: "the committed program, started at pc_start on the memory with root R0, runs to pc_end and
+// leaves the memory with root R1".  Consecutive segments chain by (pc_end, R1) = (pc_start', R0') -- exactly the (start, end)
+// state the aggregation circuit chains (include/zkhip_aggregation.hpp) -- and pc_end = 0 means the guest has exited with code 0.
+// Registers are address space 1 (cell 2 i + half of x_i), memory address space 2 (cell = byte address / 2, addresses below 2^30),
+// the 32 public-value bytes address space 3 (cells 0..15).  Header-only, no device code.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <vector>
+
+#include "zkhip_chips.hpp"
+
+namespace zkhip {
+namespace vmc {
+using air::AirBuilder;
+using air::Expr;
+using air::Kind;
+
+constexpr uint32_t MEMORY_BUS = 1, EXEC_BUS = 2, OPERAND_BUS = 3, ACCESS_BUS = 4, RANGE_BUS = 5, RANGE_TUPLE_BUS = 6, PROGRAM_BUS = 8, BITWISE_BUS = 9,
+                   MERKLE_BUS = 10, HASH_BUS = 11;
+constexpr uint32_t TS_STEP = 16;   // timestamps per instruction: rs1 at +0, +1; rs2 at +2, +3; the core's own accesses at +4 ..; rd at +12, +13
+constexpr uint32_t BLOCK_CELLS = 8, LABEL_BITS = 26, LEAF_LEVEL = LABEL_BITS + 2;  // block label = as * 2^26 + (cell >> 3); the tree has 28 levels above the blocks
+enum Cls : uint32_t { C_ALU, C_LT, C_MUL, C_MULH, C_DIVREM, C_SHIFT, C_BEQ, C_BLT, C_JAL_LUI, C_AUIPC, C_JALR, C_LS, C_ECALL, N_CLS };
+constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 34, LS_WIDTH = 45, ECALL_WIDTH = 21, ACCESS_WIDTH = 11, LEAF_WIDTH = 47, MERKLE_WIDTH = 54,
+                 CONNECTOR_WIDTH = 2;
+constexpr uint32_t P = air::P;
+
+// ---- decode: the 17 fields of a program row -------------------------------------------------------------------------------------
+struct Decoded {
+    uint32_t pc = 0, cls = 0, op = 0, rd = 0, rs1 = 0, rs2 = 0, imm_lo = 0, imm_hi = 0, imm_f = 0;
+    uint32_t use_rs1 = 0, use_rs2 = 0, y_is_imm = 0, wr_rd = 0, need_pc = 0, need_immf = 0, need_ts = 0, y_byte = 0;
+    bool legal = true;
+    std::array<uint32_t, PROGRAM_FIELDS> fields() const {
+        return {pc, cls, op, rd, rs1, rs2, imm_lo, imm_hi, imm_f, use_rs1, use_rs2, y_is_imm, wr_rd, need_pc, need_immf, need_ts, y_byte};
+    }
+};
+inline uint32_t field_of(int32_t v) { return v < 0 ? P - (uint32_t)(-(int64_t)v) : (uint32_t)v; }
+inline Decoded decode(uint32_t w, uint32_t pc) {
+    Decoded d;
+    d.pc = pc;
+    const uint32_t opc = w & 0x7f, rd = (w >> 7) & 31, f3 = (w >> 12) & 7, rs1 = (w >> 15) & 31, rs2 = (w >> 20) & 31, f7 = w >> 25;
+    auto sext = [](uint32_t v, unsigned bits) { const uint32_t m = 1u << (bits - 1); return (int32_t)((v ^ m) - m); };
+    const int32_t imm_i = sext(w >> 20, 12), imm_s = sext(((w >> 25) << 5) | ((w >> 7) & 31u), 12);
+    const int32_t imm_b = sext(((w >> 31) << 12) | (((w >> 7) & 1u) << 11) | (((w >> 25) & 63u) << 5) | (((w >> 8) & 15u) << 1), 13);
+    const int32_t imm_j = sext(((w >> 31) << 20) | (((w >> 12) & 255u) << 12) | (((w >> 20) & 1u) << 11) | (((w >> 21) & 1023u) << 1), 21);
+    auto imm32 = [&](int32_t v) { d.imm_lo = (uint32_t)v & 0xffffu, d.imm_hi = (uint32_t)v >> 16; };
+    auto dest = [&]() { d.rd = rd, d.wr_rd = rd != 0; };
+    switch (opc) {
+        case 0x37: d.cls = C_JAL_LUI, d.op = 1, dest(), d.imm_f = w >> 12, d.need_pc = d.need_immf = 1; break;
+        case 0x17: d.cls = C_AUIPC, dest(), d.imm_f = w >> 12, d.need_pc = d.need_immf = 1; break;
+        case 0x6f: d.cls = C_JAL_LUI, d.op = 0, dest(), d.imm_f = field_of(imm_j), d.need_pc = d.need_immf = 1; break;
+        case 0x67: d.cls = C_JALR, dest(), d.rs1 = rs1, d.use_rs1 = 1, d.imm_f = w >> 20, d.need_pc = d.need_immf = 1; break;
+        case 0x63:
+            if (f3 == 2 || f3 == 3) d.legal = false;
+            d.cls = f3 < 2 ? C_BEQ : C_BLT, d.op = f3 < 2 ? f3 : (((f3 & 1u) << 1) | ((f3 >> 1) & 1u));
+            d.rs1 = rs1, d.rs2 = rs2, d.use_rs1 = d.use_rs2 = 1, d.imm_f = field_of(imm_b), d.need_immf = 1;
+            break;
+        case 0x03: {
+            static const int kind[8] = {7, 6, 0, -1, 2, 1, -1, -1};  // lb lh lw - lbu lhu
+            if (kind[f3] < 0) d.legal = false;
+            d.cls = C_LS, d.op = (uint32_t)std::max(kind[f3], 0), dest(), d.rs1 = rs1, d.use_rs1 = 1, imm32(imm_i), d.need_ts = 1;
+            break;
+        }
+        case 0x23:
+            if (f3 > 2) d.legal = false;
+            d.cls = C_LS, d.op = f3 == 2 ? 3 : f3 == 1 ? 4 : 5, d.rs1 = rs1, d.rs2 = rs2, d.use_rs1 = d.use_rs2 = 1, imm32(imm_s), d.need_ts = 1;
+            break;
+        case 0x13:
+            dest(), d.rs1 = rs1, d.use_rs1 = 1, d.y_is_imm = 1;
+            switch (f3) {
+                case 0: d.cls = C_ALU, d.op = 0, imm32(imm_i); break;
+                case 2: d.cls = C_LT, d.op = 0, imm32(imm_i); break;
+                case 3: d.cls = C_LT, d.op = 1, imm32(imm_i); break;
+                case 4: d.cls = C_ALU, d.op = 2, imm32(imm_i); break;
+                case 6: d.cls = C_ALU, d.op = 3, imm32(imm_i); break;
+                case 7: d.cls = C_ALU, d.op = 4, imm32(imm_i); break;
+                case 1: d.cls = C_SHIFT, d.op = 0, d.imm_lo = rs2, d.y_byte = 1, d.legal = f7 == 0; break;
+                default: d.cls = C_SHIFT, d.op = f7 ? 2 : 1, d.imm_lo = rs2, d.y_byte = 1, d.legal = f7 == 0 || f7 == 0x20; break;
+            }
+            break;
+        case 0x33:
+            dest(), d.rs1 = rs1, d.rs2 = rs2, d.use_rs1 = d.use_rs2 = 1;
+            if (f7 == 1) {
+                if (f3 == 0) d.cls = C_MUL;
+                else if (f3 < 4) d.cls = C_MULH, d.op = f3 - 1;
+                else d.cls = C_DIVREM, d.op = f3 - 4;
+            } else if (f7 == 0 || f7 == 0x20) {
+                switch (f3) {
+                    case 0: d.cls = C_ALU, d.op = f7 ? 1 : 0; break;
+                    case 1: d.cls = C_SHIFT, d.op = 0, d.y_byte = 1, d.legal = f7 == 0; break;
+                    case 2: d.cls = C_LT, d.op = 0, d.legal = f7 == 0; break;
+                    case 3: d.cls = C_LT, d.op = 1, d.legal = f7 == 0; break;
+                    case 4: d.cls = C_ALU, d.op = 2, d.legal = f7 == 0; break;
+                    case 5: d.cls = C_SHIFT, d.op = f7 ? 2 : 1, d.y_byte = 1; break;
+                    case 6: d.cls = C_ALU, d.op = 3, d.legal = f7 == 0; break;
+                    default: d.cls = C_ALU, d.op = 4, d.legal = f7 == 0; break;
+                }
+            } else {
+                d.legal = false;
+            }
+            break;
+        case 0x73:
+            d.legal = w == 0x00000073u;
+            d.cls = C_ECALL, d.rs1 = 17, d.rs2 = 10, d.rd = 10, d.use_rs1 = d.use_rs2 = d.wr_rd = 1, d.need_pc = d.need_ts = 1;
+            break;
+        case 0x0f: d.cls = C_ALU, d.op = 0, d.y_is_imm = 1; break;  // FENCE: no operation (add x0, x0, 0)
+        default: d.legal = false; break;
+    }
+    return d;
+}
+
+// The program chip's preprocessed trace: PROGRAM_FIELDS columns (column-major over 2^log_program rows, canonical); rows beyond the
+// program are zero and never executed.  An illegal word gets a row nothing can use (class N_CLS): executing it cannot be proven.
+inline std::vector<uint32_t> program_table(const std::vector<uint32_t>& words, uint32_t pc_base, unsigned log_program) {
+    const size_t n = (size_t)1 << log_program;
+    std::vector<uint32_t> t(PROGRAM_FIELDS * n, 0);
+    for (size_t k = 0; k < words.size(); k++) {
+        Decoded d = decode(words[k], pc_base + 4 * (uint32_t)k);
+        if (!d.legal) d = Decoded(), d.pc = pc_base + 4 * (uint32_t)k, d.cls = N_CLS;
+        const auto f = d.fields();
+        for (size_t q = 0; q < PROGRAM_FIELDS; q++) t[q * n + k] = f[q];
+    }
+    return t;
+}
+
+// ---- chips -------------------------------------------------------------------------------------------------------------------------
+// program chip: AirBuilder(1, 0, prep_width = PROGRAM_FIELDS); main column 0 = execution frequency
+inline void program_air(AirBuilder& b) {
+    std::vector<Expr> f;
+    for (size_t c = 0; c < PROGRAM_FIELDS; c++) f.push_back(b.prep(c));
+    b.push_interaction(PROGRAM_BUS, f, b.var(0), Kind::Receive);
+}
+
+// frame chip: AirBuilder(FRAME_WIDTH, 0).  Columns: pc ts | cls op rd rs1 rs2 imm_lo imm_hi imm_f use_rs1 use_rs2 y_is_imm wr_rd need_pc
+// need_immf need_ts y_byte | x[4] y[4] z[4] | rd_prev_lo rd_prev_hi | pc_inc | ok
+inline void frame_air(AirBuilder& b) {
+    const Expr pc = b.var(0), ts = b.var(1), cls = b.var(2), op = b.var(3), rd = b.var(4), rs1 = b.var(5), rs2 = b.var(6), imm_lo = b.var(7),
+               imm_hi = b.var(8), imm_f = b.var(9), use_rs1 = b.var(10), use_rs2 = b.var(11), y_is_imm = b.var(12), wr_rd = b.var(13), need_pc = b.var(14),
+               need_immf = b.var(15), need_ts = b.var(16), y_byte = b.var(17);
+    Expr x[4], y[4], z[4];
+    for (int i = 0; i < 4; i++) x[i] = b.var(18 + i), y[i] = b.var(22 + i), z[i] = b.var(26 + i);
+    const Expr rdp_lo = b.var(30), rdp_hi = b.var(31), pc_inc = b.var(32), ok = b.var(33);
+    const Expr x_lo = x[0] + x[1] * 256, x_hi = x[2] + x[3] * 256, y_lo = y[0] + y[1] * 256, y_hi = y[2] + y[3] * 256, z_lo = z[0] + z[1] * 256,
+               z_hi = z[2] + z[3] * 256;
+    b.assert_zero(ok * (ok - 1));
+    // operands that do not come from a register: zero, or the immediate
+    b.assert_zero((1 - use_rs1) * x_lo);
+    b.assert_zero((1 - use_rs1) * x_hi);
+    b.assert_zero(y_is_imm * (y_lo - imm_lo));
+    b.assert_zero(y_is_imm * (y_hi - imm_hi));
+    b.assert_zero((1 - use_rs2 - y_is_imm) * y_lo);
+    b.assert_zero((1 - use_rs2 - y_is_imm) * y_hi);
+    std::vector<Expr> prog{pc, cls, op, rd, rs1, rs2, imm_lo, imm_hi, imm_f, use_rs1, use_rs2, y_is_imm, wr_rd, need_pc, need_immf, need_ts, y_byte};
+    b.push_interaction(PROGRAM_BUS, prog, ok, Kind::Send);
+    b.push_interaction(EXEC_BUS, {pc, ts}, ok, Kind::Receive);
+    b.push_interaction(EXEC_BUS, {pc + pc_inc, ts + (int64_t)TS_STEP}, ok, Kind::Send);
+    {
+        const Expr wide = 1 - y_byte;
+        std::vector<Expr> m{cls, op, x[0], x[1], x[2], x[3], y[0], wide * y[1], wide * y[2], wide * y[3], z[0], z[1], z[2], z[3],
+                            need_pc * pc, need_immf * imm_f, pc_inc, need_ts * ts, need_ts * imm_lo, need_ts * imm_hi};
+        b.push_interaction(OPERAND_BUS, m, ok, Kind::Send);
+    }
+    const Expr one = b.constant(1), zero = b.constant(0);
+    b.push_interaction(ACCESS_BUS, {one, rs1 * 2, x_lo, x_lo, ts, one}, use_rs1, Kind::Send);
+    b.push_interaction(ACCESS_BUS, {one, rs1 * 2 + 1, x_hi, x_hi, ts + 1, one}, use_rs1, Kind::Send);
+    b.push_interaction(ACCESS_BUS, {one, rs2 * 2, y_lo, y_lo, ts + 2, one}, use_rs2, Kind::Send);
+    b.push_interaction(ACCESS_BUS, {one, rs2 * 2 + 1, y_hi, y_hi, ts + 3, one}, use_rs2, Kind::Send);
+    b.push_interaction(ACCESS_BUS, {one, rd * 2, rdp_lo, z_lo, ts + 12, zero}, wr_rd, Kind::Send);
+    b.push_interaction(ACCESS_BUS, {one, rd * 2 + 1, rdp_hi, z_hi, ts + 13, zero}, wr_rd, Kind::Send);
+    b.push_interaction(BITWISE_BUS, {x[0], x[1], zero, zero}, ok, Kind::Send);
+    b.push_interaction(BITWISE_BUS, {x[2], x[3], zero, zero}, ok, Kind::Send);
+    b.push_interaction(BITWISE_BUS, {y[0], y[1], zero, zero}, ok, Kind::Send);
+    b.push_interaction(BITWISE_BUS, {y[2], y[3], zero, zero}, ok, Kind::Send);
+}
+
+// The operand-bus message as a core chip states it: 20 fields (class, opcode, x[4], y[4], z[4], pc, imm_f, pc_inc, ts, imm_lo, imm_hi);
+// fields a class does not use are zero on both sides (the frame masks them with the program's need_* flags).
+struct OperandMsg {
+    Expr op, x[4], y[4], z[4], pc, imm_f, pc_inc, ts, imm_lo, imm_hi;
+};
+inline void receive_operands(AirBuilder& b, uint32_t cls, const OperandMsg& m, Expr count) {
+    std::vector<Expr> f{b.constant(cls), m.op};
+    for (int i = 0; i < 4; i++) f.push_back(m.x[i]);
+    for (int i = 0; i < 4; i++) f.push_back(m.y[i]);
+    for (int i = 0; i < 4; i++) f.push_back(m.z[i]);
+    for (const Expr& e : {m.pc, m.imm_f, m.pc_inc, m.ts, m.imm_lo, m.imm_hi}) f.push_back(e);
+    b.push_interaction(OPERAND_BUS, f, count, Kind::Receive);
+}
+inline OperandMsg blank_msg(AirBuilder& b) {
+    OperandMsg m;
+    const Expr z = b.constant(0);
+    m.op = z, m.pc = z, m.imm_f = z, m.pc_inc = b.constant(4), m.ts = z, m.imm_lo = z, m.imm_hi = z;
+    for (int i = 0; i < 4; i++) m.x[i] = m.y[i] = m.z[i] = z;
+    return m;
+}
+// The instruction cores of include/zkhip_chips.hpp, each with its receive on the operand bus (columns unchanged).
+inline void core_air(AirBuilder& b, uint32_t cls) {
+    OperandMsg m = blank_msg(b);
+    auto cols = [&](Expr* dst, size_t first) { for (int i = 0; i < 4; i++) dst[i] = b.var(first + i); };
+    Expr count;
+    switch (cls) {
+        case C_ALU:
+            chips::rv32_alu_core_air(b);
+            cols(m.z, 0), cols(m.x, 4), cols(m.y, 8);
+            m.op = b.var(13) + b.var(14) * 2 + b.var(15) * 3 + b.var(16) * 4, count = b.var(17);
+            break;
+        case C_LT:
+            chips::rv32_lt_core_air(b);
+            cols(m.x, 0), cols(m.y, 4), m.z[0] = b.var(8), m.op = b.var(10), count = b.var(9) + b.var(10);
+            break;
+        case C_MUL:
+            chips::rv32_mul_core_air(b);
+            cols(m.z, 0), cols(m.x, 4), cols(m.y, 8), count = b.var(12);
+            break;
+        case C_MULH:
+            chips::rv32_mulh_core_air(b);
+            cols(m.z, 0), cols(m.x, 4), cols(m.y, 8), m.op = b.var(19) + b.var(20) * 2, count = b.var(18) + b.var(19) + b.var(20);
+            break;
+        case C_DIVREM: {
+            chips::rv32_divrem_core_air(b);
+            cols(m.x, 0), cols(m.y, 4);
+            const Expr quot = b.var(37) + b.var(38), rem = b.var(39) + b.var(40);
+            for (int i = 0; i < 4; i++) m.z[i] = quot * b.var(8 + i) + rem * b.var(12 + i);
+            m.op = b.var(38) + b.var(39) * 2 + b.var(40) * 3, count = quot + rem;
+            break;
+        }
+        case C_SHIFT:
+            chips::rv32_shift_core_air(b);
+            cols(m.z, 0), cols(m.x, 4), m.y[0] = b.var(8), m.op = b.var(10) + b.var(11) * 2, count = b.var(9) + b.var(10) + b.var(11);
+            break;
+        case C_BEQ:
+            chips::rv32_branch_eq_core_air(b);
+            cols(m.x, 0), cols(m.y, 4), m.imm_f = b.var(9), m.pc_inc = b.var(16), m.op = b.var(11), count = b.var(10) + b.var(11);
+            break;
+        case C_BLT:
+            chips::rv32_branch_lt_core_air(b);
+            cols(m.x, 0), cols(m.y, 4), m.imm_f = b.var(10), m.pc_inc = b.var(22), m.op = b.var(12) + b.var(13) * 2 + b.var(14) * 3;
+            count = b.var(11) + b.var(12) + b.var(13) + b.var(14);
+            break;
+        case C_JAL_LUI:
+            chips::rv32_jal_lui_core_air(b);
+            cols(m.z, 2), m.pc = b.var(0), m.imm_f = b.var(1), m.pc_inc = b.var(8), m.op = b.var(7), count = b.var(6) + b.var(7);
+            break;
+        case C_AUIPC:
+            chips::rv32_auipc_core_air(b);
+            cols(m.z, 9), m.pc = b.var(0), m.imm_f = b.var(1), count = b.var(13);
+            break;
+        case C_JALR:
+            chips::rv32_jalr_core_air(b);
+            cols(m.x, 5), cols(m.z, 9), m.pc = b.var(0), m.imm_f = b.var(1), m.pc_inc = b.var(18) - b.var(0), count = b.var(19);
+            break;
+        default: throw std::invalid_argument("core_air: not a plain core class");
+    }
+    receive_operands(b, cls, m, count);
+}
+inline size_t core_width(uint32_t cls) {
+    static const size_t w[11] = {18, 18, 13, 21, 41, 32, 17, 23, 9, 14, 20};
+    return w[cls];
+}
+
+// load/store chip: AirBuilder(LS_WIDTH, 0).  Columns 0..32 are the core's (read[4] prev[4] write[4] flag[20] sign); then
+// ts | base[4] | imm_lo imm_hi | addr_lo addr_hi | carry0 carry1 | word_lo (= addr_lo >> 2)
+inline void loadstore_air(AirBuilder& b) {
+    chips::rv32_loadstore_core_air(b);
+    Expr rdv[4], pv[4], wr[4], fl[20], base[4];
+    for (int i = 0; i < 4; i++) rdv[i] = b.var(i), pv[i] = b.var(4 + i), wr[i] = b.var(8 + i), base[i] = b.var(34 + i);
+    for (int i = 0; i < 20; i++) fl[i] = b.var(12 + i);
+    const Expr ts = b.var(33), imm_lo = b.var(38), imm_hi = b.var(39), a_lo = b.var(40), a_hi = b.var(41), c0 = b.var(42), c1 = b.var(43), w_lo = b.var(44);
+    static const int KIND[20] = {0, 1, 1, 2, 2, 2, 2, 3, 4, 4, 5, 5, 5, 5, 6, 6, 7, 7, 7, 7};
+    static const int SHIFT[20] = {0, 0, 2, 0, 1, 2, 3, 0, 0, 2, 0, 1, 2, 3, 0, 2, 0, 1, 2, 3};
+    Expr ok = fl[0], kind = fl[0] * KIND[0], shift = fl[0] * SHIFT[0], is_store = fl[7], m0 = fl[0], m1 = fl[0];
+    for (int c = 1; c < 20; c++) {
+        ok = ok + fl[c], kind = kind + fl[c] * KIND[c], shift = shift + fl[c] * SHIFT[c];
+        if (KIND[c] >= 3 && KIND[c] <= 5 && c != 7) is_store = is_store + fl[c];
+        const bool word = KIND[c] == 0 || KIND[c] == 3;
+        if (word || SHIFT[c] < 2) m0 = m0 + fl[c];
+        if (word || SHIFT[c] >= 2) m1 = m1 + fl[c];
+    }
+    const Expr is_load = ok - is_store;
+    b.assert_zero(c0 * (c0 - 1));
+    b.assert_zero(c1 * (c1 - 1));
+    // address = base + immediate (mod 2^32), in 16-bit halves; byte offset inside the aligned word = the case's shift
+    b.assert_zero(ok * (a_lo + c0 * 65536 - (base[0] + base[1] * 256) - imm_lo));
+    b.assert_zero(ok * (a_hi + c1 * 65536 - (base[2] + base[3] * 256) - imm_hi - c0));
+    b.assert_zero(ok * (a_lo - w_lo * 4 - shift));
+    OperandMsg m = blank_msg(b);
+    m.op = kind, m.ts = ts, m.imm_lo = imm_lo, m.imm_hi = imm_hi;
+    for (int i = 0; i < 4; i++) m.x[i] = base[i], m.y[i] = is_store * rdv[i], m.z[i] = is_load * wr[i];
+    receive_operands(b, C_LS, m, ok);
+    // the aligned word's cells: cell = address / 2; values before / after the access
+    const Expr cell0 = w_lo * 2 + a_hi * 32768;
+    const Expr two = b.constant(2);
+    const Expr r0 = rdv[0] + rdv[1] * 256, r1 = rdv[2] + rdv[3] * 256, p0 = pv[0] + pv[1] * 256, p1 = pv[2] + pv[3] * 256, n0 = wr[0] + wr[1] * 256,
+               n1 = wr[2] + wr[3] * 256;
+    b.push_interaction(ACCESS_BUS, {two, cell0, is_load * r0 + is_store * p0, is_load * r0 + is_store * n0, ts + 4, is_load}, m0, Kind::Send);
+    b.push_interaction(ACCESS_BUS, {two, cell0 + 1, is_load * r1 + is_store * p1, is_load * r1 + is_store * n1, ts + 5, is_load}, m1, Kind::Send);
+    const Expr zero = b.constant(0);
+    b.push_interaction(BITWISE_BUS, {rdv[0], rdv[1], zero, zero}, ok, Kind::Send);
+    b.push_interaction(BITWISE_BUS, {rdv[2], rdv[3], zero, zero}, ok, Kind::Send);
+    b.push_interaction(BITWISE_BUS, {pv[0], pv[1], zero, zero}, ok, Kind::Send);
+    b.push_interaction(BITWISE_BUS, {pv[2], pv[3], zero, zero}, ok, Kind::Send);
+    b.push_interaction(RANGE_BUS, {a_lo}, ok, Kind::Send);
+    b.push_interaction(RANGE_BUS, {a_hi * 4}, ok, Kind::Send);   // address below 2^30
+    b.push_interaction(RANGE_BUS, {w_lo * 4}, ok, Kind::Send);   // with the next one: word_lo below 2^14
+    b.push_interaction(RANGE_BUS, {w_lo}, ok, Kind::Send);
+    b.push_interaction(RANGE_BUS, {a_hi}, ok, Kind::Send);
+}
+
+// ecall chip: AirBuilder(ECALL_WIDTH, 0).  Columns: pc ts | x[4] (a7) | y[4] (a0) | z[4] (a0 afterwards) | is_exit is_reveal is_read |
+// idx (a1 low cell, the public-value word index) | pv_prev_lo pv_prev_hi | pc_inc
+inline void ecall_air(AirBuilder& b) {
+    const Expr pc = b.var(0), ts = b.var(1);
+    Expr x[4], y[4], z[4];
+    for (int i = 0; i < 4; i++) x[i] = b.var(2 + i), y[i] = b.var(6 + i), z[i] = b.var(10 + i);
+    const Expr is_exit = b.var(14), is_reveal = b.var(15), is_read = b.var(16), idx = b.var(17), pvp_lo = b.var(18), pvp_hi = b.var(19), pc_inc = b.var(20);
+    const Expr ok = is_exit + is_reveal + is_read;
+    for (const Expr& f : {is_exit, is_reveal, is_read, ok}) b.assert_zero(f * (f - 1));
+    b.assert_zero(x[0] - is_exit * 93 - is_reveal - is_read * 2);
+    for (int i = 1; i < 4; i++) b.assert_zero(x[i]);
+    for (int i = 0; i < 4; i++) {
+        b.assert_zero(is_exit * y[i]);                 // exit code 0: a failing guest has no proof
+        b.assert_zero((ok - is_read) * (z[i] - y[i]));  // only the hint read changes a0
+    }
+    b.assert_zero(is_exit * (pc_inc + pc));             // the execution ends at pc = 0
+    b.assert_zero((ok - is_exit) * (pc_inc - 4));
+    OperandMsg m = blank_msg(b);
+    m.pc = pc, m.pc_inc = pc_inc, m.ts = ts;
+    for (int i = 0; i < 4; i++) m.x[i] = x[i], m.y[i] = y[i], m.z[i] = z[i];
+    receive_operands(b, C_ECALL, m, ok);
+    const Expr one = b.constant(1), zero = b.constant(0), three = b.constant(3);
+    // reveal: a1's low cell (register 11) is the word index, below 8; the word a0 goes to cells 2 idx, 2 idx + 1 of address space 3
+    b.push_interaction(ACCESS_BUS, {one, b.constant(22), idx, idx, ts + 4, one}, is_reveal, Kind::Send);
+    b.push_interaction(ACCESS_BUS, {three, idx * 2, pvp_lo, y[0] + y[1] * 256, ts + 5, zero}, is_reveal, Kind::Send);
+    b.push_interaction(ACCESS_BUS, {three, idx * 2 + 1, pvp_hi, y[2] + y[3] * 256, ts + 6, zero}, is_reveal, Kind::Send);
+    b.push_interaction(RANGE_BUS, {idx * 8192}, is_reveal, Kind::Send);
+    b.push_interaction(RANGE_BUS, {idx}, is_reveal, Kind::Send);
+}
+
+// memory access chip: AirBuilder(ACCESS_WIDTH, 0).  chips::memory_access_air's ten columns + hi8 = 8 gap_hi: the gap
+// ts - prev_ts - 1 = gap_lo + 2^16 gap_hi stays below 2^29, so a timestamp cannot run backwards modulo p (timestamps themselves
+// are bounded by the execution-bus chain: 1 + 16 per instruction).  Every row is one access requested on the access bus.
+inline void access_air(AirBuilder& b) {
+    chips::memory_access_air(b, RANGE_BUS, MEMORY_BUS);
+    const Expr as_ = b.var(0), ptr = b.var(1), pd = b.var(2), d = b.var(4), ts = b.var(5), rd = b.var(6), ok = b.var(7), hi = b.var(9), hi8 = b.var(10);
+    b.assert_zero(hi8 - hi * 8);
+    b.push_interaction(RANGE_BUS, {hi8}, ok, Kind::Send);
+    b.push_interaction(ACCESS_BUS, {as_, ptr, pd, d, ts, rd}, ok, Kind::Receive);
+}
+
+// leaf chip: AirBuilder(LEAF_WIDTH, 0).  Columns: as blk | init[8] | fin[8] | fin_ts[8] | h_init[8] | h_fin[8] | ok | gap_lo gap_hi |
+// blk_lo blk_hi.  One row per touched block of 8 cells, strictly increasing label = as 2^26 + blk; padding rows carry as = 1.
+inline void leaf_air(AirBuilder& b) {
+    const Expr as_ = b.var(0), blk = b.var(1), ok = b.var(42), gap_lo = b.var(43), gap_hi = b.var(44), blk_lo = b.var(45), blk_hi = b.var(46);
+    Expr init[8], fin[8], fts[8], hi[8], hf[8];
+    for (int j = 0; j < 8; j++) init[j] = b.var(2 + j), fin[j] = b.var(10 + j), fts[j] = b.var(18 + j), hi[j] = b.var(26 + j), hf[j] = b.var(34 + j);
+    const Expr ok_n = b.var(42, 1);
+    b.assert_zero(ok * (ok - 1));
+    b.when_transition(ok_n * (1 - ok));                              // valid rows come first
+    b.assert_zero((as_ - 1) * (as_ - 2) * (as_ - 3));                // address space 1, 2 or 3 (padding rows: 1)
+    const Expr label = as_ * (int64_t)(1u << LABEL_BITS) + blk, label_n = b.var(0, 1) * (int64_t)(1u << LABEL_BITS) + b.var(1, 1);
+    b.when_transition(ok_n * (label_n - label - 1 - gap_lo - gap_hi * 65536));
+    b.assert_zero(blk - blk_lo - blk_hi * 65536);
+    const Expr zero = b.constant(0);
+    for (int j = 0; j < 8; j++) {
+        b.push_interaction(MEMORY_BUS, {as_, blk * 8 + j, init[j], zero}, ok, Kind::Send);
+        b.push_interaction(MEMORY_BUS, {as_, blk * 8 + j, fin[j], fts[j]}, ok, Kind::Receive);
+    }
+    std::vector<Expr> hin, hfn;
+    for (int j = 0; j < 8; j++) hin.push_back(init[j]), hfn.push_back(fin[j]);
+    for (int j = 0; j < 8; j++) hin.push_back(zero), hfn.push_back(zero);
+    for (int j = 0; j < 8; j++) hin.push_back(hi[j]), hfn.push_back(hf[j]);
+    b.push_interaction(HASH_BUS, hin, ok, Kind::Send);
+    b.push_interaction(HASH_BUS, hfn, ok, Kind::Send);
+    std::vector<Expr> mk{b.constant(LEAF_LEVEL), label};
+    for (int j = 0; j < 8; j++) mk.push_back(hi[j]);
+    for (int j = 0; j < 8; j++) mk.push_back(hf[j]);
+    b.push_interaction(MERKLE_BUS, mk, ok, Kind::Send);
+    b.push_interaction(RANGE_BUS, {gap_lo}, ok, Kind::Send);
+    b.push_interaction(RANGE_BUS, {gap_hi * 16}, ok, Kind::Send);     // gap below 2^28: labels cannot wrap
+    b.push_interaction(RANGE_BUS, {gap_hi}, ok, Kind::Send);
+    b.push_interaction(RANGE_BUS, {blk_lo}, ok, Kind::Send);
+    b.push_interaction(RANGE_BUS, {blk_hi * 64}, ok, Kind::Send);     // blk below 2^26
+    b.push_interaction(RANGE_BUS, {blk_hi}, ok, Kind::Send);
+}
+
+// merkle chip: AirBuilder(MERKLE_WIDTH, 16).  Columns: level idx | left_init[8] right_init[8] | left_fin[8] right_fin[8] | parent_init[8]
+// parent_fin[8] | left_on right_on | ok | is_root.  Public values: the initial root (8), the final root (8).
+inline void merkle_air(AirBuilder& b) {
+    const Expr level = b.var(0), idx = b.var(1), l_on = b.var(50), r_on = b.var(51), ok = b.var(52), is_root = b.var(53);
+    Expr li[8], ri[8], lf[8], rf[8], pi[8], pf[8];
+    for (int k = 0; k < 8; k++) li[k] = b.var(2 + k), ri[k] = b.var(10 + k), lf[k] = b.var(18 + k), rf[k] = b.var(26 + k), pi[k] = b.var(34 + k), pf[k] = b.var(42 + k);
+    for (const Expr& f : {l_on, r_on, ok, is_root}) b.assert_zero(f * (f - 1));
+    b.assert_zero((1 - ok) * l_on);
+    b.assert_zero((1 - ok) * r_on);
+    b.assert_zero((1 - ok) * is_root);
+    b.assert_zero(ok * ((1 - l_on) * (1 - r_on)));   // at least one child lies on a touched path
+    for (int k = 0; k < 8; k++) {
+        b.assert_zero((ok - l_on) * (li[k] - lf[k]));   // an untouched subtree is the same before and after
+        b.assert_zero((ok - r_on) * (ri[k] - rf[k]));
+        b.assert_zero(is_root * (pi[k] - b.pub(k)));
+        b.assert_zero(is_root * (pf[k] - b.pub(8 + k)));
+    }
+    b.assert_zero(is_root * level);
+    b.assert_zero(is_root * idx);
+    b.when_transition(b.var(53, 1));                    // only the first row can be the root
+    b.when_first_row(ok - is_root);                     // and if there is any row at all, the first one is
+    auto cat = [](const Expr* a, const Expr* c, const Expr* o) {
+        std::vector<Expr> v(a, a + 8);
+        v.insert(v.end(), c, c + 8);
+        v.insert(v.end(), o, o + 8);
+        return v;
+    };
+    b.push_interaction(HASH_BUS, cat(li, ri, pi), ok, Kind::Send);
+    b.push_interaction(HASH_BUS, cat(lf, rf, pf), ok, Kind::Send);
+    auto node = [&](Expr lv, Expr ix, const Expr* a, const Expr* c) {
+        std::vector<Expr> v{lv, ix};
+        v.insert(v.end(), a, a + 8);
+        v.insert(v.end(), c, c + 8);
+        return v;
+    };
+    b.push_interaction(MERKLE_BUS, node(level + 1, idx * 2, li, lf), l_on, Kind::Receive);
+    b.push_interaction(MERKLE_BUS, node(level + 1, idx * 2 + 1, ri, rf), r_on, Kind::Receive);
+    b.push_interaction(MERKLE_BUS, node(level, idx, pi, pf), ok - is_root, Kind::Send);
+}
+
+// connector: AirBuilder(CONNECTOR_WIDTH, 2), ONE row.  Public values (pc_start, pc_end); columns = the 16-bit halves of the final
+// timestamp (bounded below 2^29, which bounds every timestamp of the segment).
+inline void connector_air(AirBuilder& b) {
+    const Expr te_lo = b.var(0), te_hi = b.var(1), one = b.constant(1);
+    b.push_interaction(EXEC_BUS, {b.pub(0), one}, one, Kind::Send);
+    b.push_interaction(EXEC_BUS, {b.pub(1), te_lo + te_hi * 65536}, one, Kind::Receive);
+    b.push_interaction(RANGE_BUS, {te_lo}, one, Kind::Send);
+    b.push_interaction(RANGE_BUS, {te_hi * 8}, one, Kind::Send);
+    b.push_interaction(RANGE_BUS, {te_hi}, one, Kind::Send);
+}
+
+// ---- the segment's AIR set (order fixed: it is part of the verifying key) ----
+enum AirId : unsigned {
+    A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_ACCESS, A_LEAF,
+    A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, N_AIRS
+};
+struct AirShape {
+    size_t width = 0, n_pvs = 0, prep_width = 0, cached_width = 0;
+    std::vector<uint32_t> program;
+};
+inline AirShape build_air(unsigned id) {
+    AirShape s;
+    auto make = [&](size_t width, size_t n_pvs, size_t prep, auto&& fill) {
+        AirBuilder b(width, n_pvs, prep);
+        fill(b);
+        s.width = width, s.n_pvs = n_pvs, s.prep_width = prep, s.cached_width = b.cached_width(), s.program = b.program();
+    };
+    switch (id) {
+        case A_PROGRAM: make(1, 0, PROGRAM_FIELDS, program_air); break;
+        case A_FRAME: make(FRAME_WIDTH, 0, 0, frame_air); break;
+        case A_LS: make(LS_WIDTH, 0, 0, loadstore_air); break;
+        case A_ECALL: make(ECALL_WIDTH, 0, 0, ecall_air); break;
+        case A_ACCESS: make(ACCESS_WIDTH, 0, 0, access_air); break;
+        case A_LEAF: make(LEAF_WIDTH, 0, 0, leaf_air); break;
+        case A_MERKLE: make(MERKLE_WIDTH, 16, 0, merkle_air); break;
+        case A_POSEIDON2: make(air::POSEIDON2_AIR_WIDTH + 1, 0, 0, [](AirBuilder& b) { air::poseidon2_air(b, (int)HASH_BUS, 8); }); break;
+        case A_CONNECTOR: make(CONNECTOR_WIDTH, 2, 0, connector_air); break;
+        case A_BITWISE: make(2, 0, 3, [](AirBuilder& b) { chips::bitwise_lookup_air(b, BITWISE_BUS); }); break;
+        case A_RANGE_TUPLE: make(1, 0, 2, [](AirBuilder& b) { chips::range_tuple_table_air(b, RANGE_TUPLE_BUS); }); break;
+        case A_RANGE: make(1, 0, 1, [](AirBuilder& b) { chips::range_table_air(b, RANGE_BUS); }); break;
+        default:
+            if (id >= A_ALU && id <= A_JALR) {
+                const uint32_t cls = id - A_ALU;
+                make(core_width(cls), 0, 0, [cls](AirBuilder& b) { core_air(b, cls); });
+            } else {
+                throw std::invalid_argument("build_air: unknown AIR");
+            }
+    }
+    return s;
+}
+
+}  // namespace vmc
+}  // namespace zkhip

@@ -1,0 +1,400 @@
+// zkhip_vm_exec.hpp -- the SEGMENTING executor of the one-statement flow: runs the guest (the interpreter of include/zkhip_vm.hpp)
+// and produces, segment by segment, everything the chips of include/zkhip_vm_circuit.hpp are generated from:
+//   * the per-class core records of include/zkhip_vm.hpp (unchanged), the frame records (operands, result, pc step of every
+//     instruction), the load/store adapter records, the ecall rows;
+//   * the memory log with the circuit's timestamps (1 + 16 k + slot for instruction k of the segment; cells: registers = address
+//     space 1, memory = 2 with cell = byte address / 2, public values = 3);
+//   * the PERSISTENT MEMORY: a sparse Merkle tree (Poseidon2, blocks of 8 cells) over all three address spaces that lives across
+//     segments; per segment the touched blocks (leaf rows) and the nodes of their paths (merkle rows) with digests before and after.
+// A segment ends when the guest exits or when one more instruction could overflow a chip's fixed height (SegmentCaps): heights are
+// part of the verifying key, so every segment of every run of one app is proven under ONE key -- what the aggregation layer needs
+// (include/zkhip_aggregation.hpp).  This is the role of OpenVM's metered execution + segmentation + preflight (un-vendored; reached by the
+// reference through sdk.prove, crates/prover/src/prover/mod.rs:355-357, and execute_guest, crates/prover/src/utils/vm.rs:13-48).
+// Host only; Poseidon2 through the library's host entry point (zkhip_poseidon2_permute_host).
+#pragma once
+#include <array>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "zkhip.h"
+#include "zkhip_vm.hpp"
+#include "zkhip_vm_circuit.hpp"
+
+namespace zkhip_vm {
+namespace vmc = zkhip::vmc;
+using Digest = std::array<uint32_t, 8>;
+
+inline Digest p2_block(const uint32_t cells[8]) {
+    uint32_t st[16] = {};
+    for (int i = 0; i < 8; i++) st[i] = cells[i];
+    zkhip_poseidon2_permute_host(st);
+    Digest d;
+    for (int i = 0; i < 8; i++) d[i] = st[i];
+    return d;
+}
+inline Digest p2_compress(const Digest& l, const Digest& r) {
+    uint32_t st[16];
+    for (int i = 0; i < 8; i++) st[i] = l[i], st[8 + i] = r[i];
+    zkhip_poseidon2_permute_host(st);
+    Digest d;
+    for (int i = 0; i < 8; i++) d[i] = st[i];
+    return d;
+}
+
+// Sparse Merkle tree over block labels (vmc::LEAF_LEVEL levels above the blocks); absent nodes are all-zero subtrees.
+class MemoryTree {
+public:
+    MemoryTree() {
+        const uint32_t z[8] = {};
+        zero_[vmc::LEAF_LEVEL] = p2_block(z);
+        for (int l = (int)vmc::LEAF_LEVEL - 1; l >= 0; l--) zero_[l] = p2_compress(zero_[l + 1], zero_[l + 1]);
+    }
+    Digest get(unsigned level, uint32_t idx) const {
+        auto it = nodes_.find(key(level, idx));
+        return it == nodes_.end() ? zero_[level] : it->second;
+    }
+    void set(unsigned level, uint32_t idx, const Digest& d) { nodes_[key(level, idx)] = d; }
+    Digest root() const { return get(0, 0); }
+    // sets the given blocks and rehashes their paths (used for the initial image)
+    void set_blocks(const std::vector<std::pair<uint32_t, std::array<uint32_t, 8>>>& blocks) {
+        std::vector<uint32_t> cur;
+        for (const auto& b : blocks) set(vmc::LEAF_LEVEL, b.first, p2_block(b.second.data())), cur.push_back(b.first >> 1);
+        for (int l = (int)vmc::LEAF_LEVEL - 1; l >= 0; l--) {
+            std::sort(cur.begin(), cur.end());
+            cur.erase(std::unique(cur.begin(), cur.end()), cur.end());
+            std::vector<uint32_t> up;
+            for (uint32_t i : cur) set(l, i, p2_compress(get(l + 1, 2 * i), get(l + 1, 2 * i + 1))), up.push_back(i >> 1);
+            cur = std::move(up);
+        }
+    }
+    static uint64_t key(unsigned level, uint32_t idx) { return ((uint64_t)level << 32) | idx; }
+
+private:
+    std::unordered_map<uint64_t, Digest> nodes_;
+    Digest zero_[vmc::LEAF_LEVEL + 1];
+};
+
+// fixed trace heights of a segment = part of its verifying key
+struct SegmentCaps {
+    unsigned log_height[vmc::N_AIRS] = {};
+    // heights for segments of about 2^log_frame instructions of an ordinary instruction mix
+    static SegmentCaps for_frame(unsigned log_frame, unsigned log_program) {
+        SegmentCaps c;
+        auto sub = [&](unsigned d) { return log_frame > d + 2 ? log_frame - d : 2u; };
+        c.log_height[vmc::A_PROGRAM] = log_program, c.log_height[vmc::A_FRAME] = log_frame;
+        c.log_height[vmc::A_ALU] = sub(1), c.log_height[vmc::A_LT] = sub(3), c.log_height[vmc::A_MUL] = sub(3), c.log_height[vmc::A_MULH] = sub(5);
+        c.log_height[vmc::A_DIVREM] = sub(5), c.log_height[vmc::A_SHIFT] = sub(3), c.log_height[vmc::A_BEQ] = sub(2), c.log_height[vmc::A_BLT] = sub(2);
+        c.log_height[vmc::A_JAL_LUI] = sub(3), c.log_height[vmc::A_AUIPC] = sub(5), c.log_height[vmc::A_JALR] = sub(4), c.log_height[vmc::A_LS] = sub(1);
+        c.log_height[vmc::A_ECALL] = sub(7), c.log_height[vmc::A_ACCESS] = log_frame + 3, c.log_height[vmc::A_LEAF] = sub(5), c.log_height[vmc::A_MERKLE] = sub(3);
+        c.log_height[vmc::A_POSEIDON2] = sub(1), c.log_height[vmc::A_CONNECTOR] = 0, c.log_height[vmc::A_BITWISE] = 16;
+        c.log_height[vmc::A_RANGE_TUPLE] = 19, c.log_height[vmc::A_RANGE] = 16;
+        return c;
+    }
+    size_t rows(unsigned air) const { return (size_t)1 << log_height[air]; }
+};
+constexpr uint32_t TUPLE_X = 256, TUPLE_Y = 2048;
+
+struct SegmentRecords {
+    ExecRecords core;                                        // per-class core records; core.pc_index = the frame rows' program indices
+    std::vector<uint32_t> f_x, f_y, f_z, f_rdprev, f_pcinc;  // frame: operands, result, previous rd, pc step (field element)
+    std::vector<uint32_t> ls_ts, ls_base, ls_imm;            // load/store adapter, aligned with core.ls_*
+    std::vector<uint32_t> ecall_rows;                        // row-major canonical rows of the ecall / leaf / merkle chips
+    std::vector<uint32_t> acc_as, acc_ptr, acc_prev_data, acc_prev_ts, acc_data, acc_ts, acc_is_read;
+    std::vector<uint32_t> leaf_rows, merkle_rows, p2_inputs; // p2_inputs: [n][16] canonical, one row per hash-bus request
+    uint32_t pc_start = 0, pc_end = 0, ts_end = 0;
+    Digest root_init{}, root_final{};
+    size_t n_instr = 0;
+    size_t n_ecall() const { return ecall_rows.size() / vmc::ECALL_WIDTH; }
+    size_t n_leaf() const { return leaf_rows.size() / vmc::LEAF_WIDTH; }
+    size_t n_merkle() const { return merkle_rows.size() / vmc::MERKLE_WIDTH; }
+    size_t n_p2() const { return p2_inputs.size() / 16; }
+    void clear() {
+        core.clear();
+        for (auto* v : {&f_x, &f_y, &f_z, &f_rdprev, &f_pcinc, &ls_ts, &ls_base, &ls_imm, &ecall_rows, &acc_as, &acc_ptr, &acc_prev_data, &acc_prev_ts,
+                        &acc_data, &acc_ts, &acc_is_read, &leaf_rows, &merkle_rows, &p2_inputs})
+            v->clear();
+        n_instr = 0;
+    }
+};
+
+class SegmentExecutor {
+public:
+    SegmentExecutor(const Exe& exe, const StdIn& in, const SegmentCaps& caps) : exe_(exe), m_(exe, in), caps_(caps) {
+        if (exe.data_base % 16) throw Error("the one-statement flow needs a 16-byte aligned data base");
+        if ((uint64_t)exe.data_base + exe.memory_bytes > (1ull << 30) || (uint64_t)exe.pc_base + 4 * exe.program.size() > (1ull << 30))
+            throw Error("guest addresses must lie below 2^30");
+        m_.set_memory_log(false);
+        // the initial memory image: registers (sp), the data segment
+        std::vector<std::pair<uint32_t, std::array<uint32_t, 8>>> blocks;
+        for (uint32_t blk = 0; blk < 8; blk++) push_nonzero(blocks, 1, blk);
+        const uint32_t first = exe.data_base / 16, last = (uint32_t)(((uint64_t)exe.data_base + exe.data.size() + 15) / 16);
+        for (uint32_t blk = first; blk < last; blk++) push_nonzero(blocks, 2, blk);
+        tree_.set_blocks(blocks);
+        image_root_ = tree_.root();
+    }
+    const Digest& image_root() const { return image_root_; }
+    const MemoryTree& tree() const { return tree_; }
+    bool done() const { return m_.done(); }
+    uint64_t instret() const { return m_.instret(); }
+    uint32_t exit_code() const { return m_.exit_code(); }
+    const std::vector<uint8_t>& public_values() const { return m_.public_values(); }
+
+    // Executes the next segment into `r`.  Returns true once the guest has exited (then r.pc_end = 0).
+    bool run_segment(SegmentRecords& r) {
+        r.clear();
+        blocks_.clear(), path_nodes_.clear();
+        r.pc_start = m_.pc();
+        r.root_init = tree_.root();
+        size_t n_cls[vmc::N_CLS] = {};
+        while (!m_.done()) {
+            const uint32_t pc = m_.pc();
+            const uint64_t k = ((uint64_t)pc - exe_.pc_base) / 4;
+            if (pc < exe_.pc_base || (pc & 3u) || k >= exe_.program.size()) throw Error("pc outside the program: " + std::to_string(pc));
+            const vmc::Decoded d = vmc::decode(exe_.program[k], pc);
+            if (!d.legal) throw Error("illegal instruction at pc " + std::to_string(pc));
+            // would one more instruction overflow a chip?  (the blocks and path nodes it would add are counted exactly)
+            size_t new_blocks = 0, new_nodes = 0;
+            {
+                uint32_t labels[5];
+                unsigned nl = 0;
+                auto want = [&](uint32_t as, uint32_t cell) { labels[nl++] = (as << vmc::LABEL_BITS) | (cell >> 3); };
+                if (d.use_rs1) want(1, 2 * d.rs1);
+                if (d.use_rs2) want(1, 2 * d.rs2);
+                if (d.wr_rd) want(1, 2 * d.rd);
+                if (d.cls == vmc::C_LS) want(2, (((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) & ~3u) >> 1);
+                if (d.cls == vmc::C_ECALL) want(1, 22), want(3, 2 * (m_.reg(11) & 7u));
+                std::unordered_set<uint64_t> fresh;
+                for (unsigned i = 0; i < nl; i++) {
+                    if (blocks_.count(labels[i]) || !fresh.insert(MemoryTree::key(vmc::LEAF_LEVEL, labels[i])).second) continue;
+                    new_blocks++;
+                    uint32_t idx = labels[i];
+                    for (int l = (int)vmc::LEAF_LEVEL - 1; l >= 0; l--) {
+                        idx >>= 1;
+                        const uint64_t kk = MemoryTree::key((unsigned)l, idx);
+                        if (path_nodes_.count(kk) || !fresh.insert(kk).second) break;
+                        new_nodes++;
+                    }
+                }
+            }
+            if (r.n_instr + 1 > caps_.rows(vmc::A_FRAME) || n_cls[d.cls] + 1 > caps_.rows(vmc::A_ALU + d.cls) ||
+                r.acc_ts.size() + 9 > caps_.rows(vmc::A_ACCESS) || blocks_.size() + new_blocks > caps_.rows(vmc::A_LEAF) ||
+                path_nodes_.size() + new_nodes > caps_.rows(vmc::A_MERKLE) ||
+                2 * (blocks_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
+                if (r.n_instr == 0) throw Error("segment heights too small for a single instruction");
+                break;
+            }
+            const uint32_t ts = 1 + vmc::TS_STEP * (uint32_t)r.n_instr;
+            const uint32_t x = d.use_rs1 ? m_.reg(d.rs1) : 0;
+            const uint32_t imm32 = d.imm_lo | (d.imm_hi << 16);
+            const uint32_t y = d.use_rs2 ? m_.reg(d.rs2) : d.y_is_imm ? imm32 : 0;
+            const uint32_t rd_prev = m_.reg(d.rd);
+            // memory cells of a load / store, before the instruction
+            uint32_t addr = 0, word_before = 0;
+            if (d.cls == vmc::C_LS) addr = x + imm32, word_before = mem_word(addr & ~3u);
+            if (d.use_rs1) read_cell(r, 1, 2 * d.rs1, x & 0xffffu, ts), read_cell(r, 1, 2 * d.rs1 + 1, x >> 16, ts + 1);
+            if (d.use_rs2) read_cell(r, 1, 2 * d.rs2, y & 0xffffu, ts + 2), read_cell(r, 1, 2 * d.rs2 + 1, y >> 16, ts + 3);
+            uint32_t a1 = 0, pv_before = 0;
+            if (d.cls == vmc::C_ECALL && x == 1) {
+                a1 = m_.reg(11) & 0xffffu;
+                if (a1 >= 8 || (m_.reg(11) >> 16)) throw Error("public value index out of range");
+                memcpy(&pv_before, m_.public_values().data() + 4 * a1, 4);
+            }
+            // snapshot the blocks this instruction is going to change
+            if (d.wr_rd) (void)block_of(1, 2 * d.rd);
+            if (d.cls == vmc::C_LS) (void)block_of(2, (addr & ~3u) >> 1);
+            if (d.cls == vmc::C_ECALL && x == 1) (void)block_of(3, 2 * a1);
+            const size_t n_ls_before = r.core.ls_case.size();
+            m_.step_one(&r.core);
+            uint32_t z = 0, pc_inc;
+            if (d.cls == vmc::C_ECALL) {
+                z = x == 2 ? m_.last_result() : y;
+                pc_inc = m_.done() ? vmc::field_of(-(int32_t)pc) : 4;
+                if (m_.done() && m_.exit_code()) throw Error("guest exited with code " + std::to_string(m_.exit_code()));
+                uint32_t row[vmc::ECALL_WIDTH] = {};
+                row[0] = pc, row[1] = ts;
+                for (int i = 0; i < 4; i++) row[2 + i] = (x >> (8 * i)) & 255u, row[6 + i] = (y >> (8 * i)) & 255u, row[10 + i] = (z >> (8 * i)) & 255u;
+                row[14] = x == 93, row[15] = x == 1, row[16] = x == 2, row[20] = pc_inc;
+                if (x == 1) {
+                    row[17] = a1, row[18] = pv_before & 0xffffu, row[19] = pv_before >> 16;
+                    read_cell(r, 1, 22, a1, ts + 4);
+                    write_cell(r, 3, 2 * a1, y & 0xffffu, ts + 5), write_cell(r, 3, 2 * a1 + 1, y >> 16, ts + 6);
+                }
+                r.ecall_rows.insert(r.ecall_rows.end(), row, row + vmc::ECALL_WIDTH);
+            } else {
+                const bool has_result = d.cls != vmc::C_BEQ && d.cls != vmc::C_BLT && !(d.cls == vmc::C_LS && d.op >= 3 && d.op <= 5);
+                z = has_result ? m_.last_result() : 0;
+                pc_inc = vmc::field_of((int32_t)(m_.pc() - pc));
+            }
+            if (d.cls == vmc::C_LS) {
+                if (r.core.ls_case.size() != n_ls_before + 1) throw Error("internal: load/store record missing");
+                r.ls_ts.push_back(ts), r.ls_base.push_back(x), r.ls_imm.push_back(imm32);
+                const uint32_t cs = r.core.ls_case.back(), word_after = mem_word(addr & ~3u), cell0 = (addr & ~3u) >> 1;
+                const bool store = d.op >= 3 && d.op <= 5, word = d.op == 0 || d.op == 3;
+                const unsigned s = addr & 3u;
+                (void)cs;
+                for (unsigned c = 0; c < 2; c++) {
+                    if (!(word || (s >> 1) == c)) continue;
+                    const uint32_t before = (word_before >> (16 * c)) & 0xffffu, after = (word_after >> (16 * c)) & 0xffffu;
+                    if (store) write_cell(r, 2, cell0 + c, after, ts + 4 + c);
+                    else read_cell(r, 2, cell0 + c, before, ts + 4 + c);
+                }
+            }
+            if (d.wr_rd) write_cell(r, 1, 2 * d.rd, z & 0xffffu, ts + 12), write_cell(r, 1, 2 * d.rd + 1, z >> 16, ts + 13);
+            r.f_x.push_back(x), r.f_y.push_back(y), r.f_z.push_back(z), r.f_rdprev.push_back(d.wr_rd ? rd_prev : 0), r.f_pcinc.push_back(pc_inc);
+            n_cls[d.cls]++;
+            r.n_instr++;
+        }
+        r.pc_end = m_.done() ? 0 : m_.pc();
+        r.ts_end = 1 + vmc::TS_STEP * (uint32_t)r.n_instr;
+        close_memory(r);
+        return m_.done();
+    }
+
+private:
+    const Exe& exe_;
+    Machine m_;
+    SegmentCaps caps_;
+    MemoryTree tree_;
+    Digest image_root_{};
+    struct Block {
+        uint32_t init[8], cur[8], ts[8];
+    };
+    std::unordered_map<uint32_t, Block> blocks_;     // touched blocks of the current segment, by label
+    std::unordered_set<uint64_t> path_nodes_;        // internal nodes above them
+
+    uint32_t mem_word(uint32_t addr) const { return m_.peek_word(addr); }
+    // value of a cell in the machine's CURRENT state
+    uint32_t cell_now(uint32_t as, uint32_t cell) const {
+        if (as == 1) return cell < 64 ? (m_.reg(cell >> 1) >> (16 * (cell & 1))) & 0xffffu : 0;
+        if (as == 3) {
+            if (cell >= 16) return 0;
+            uint16_t v;
+            memcpy(&v, m_.public_values().data() + 2 * cell, 2);
+            return v;
+        }
+        return (mem_word((cell << 1) & ~3u) >> (16 * (cell & 1))) & 0xffffu;
+    }
+    void push_nonzero(std::vector<std::pair<uint32_t, std::array<uint32_t, 8>>>& out, uint32_t as, uint32_t blk) const {
+        std::array<uint32_t, 8> c;
+        bool any = false;
+        for (uint32_t j = 0; j < 8; j++) c[j] = cell_now(as, 8 * blk + j), any = any || c[j];
+        if (any) out.push_back({(as << vmc::LABEL_BITS) | blk, c});
+    }
+    Block& block_of(uint32_t as, uint32_t cell) {
+        const uint32_t label = (as << vmc::LABEL_BITS) | (cell >> 3);
+        auto it = blocks_.find(label);
+        if (it != blocks_.end()) return it->second;
+        // first touch in this segment: the block's cells still have their values from the segment's start
+        Block b;
+        for (uint32_t j = 0; j < 8; j++) b.init[j] = b.cur[j] = cell_now(as, (cell & ~7u) + j), b.ts[j] = 0;
+        uint32_t idx = label;
+        for (int l = (int)vmc::LEAF_LEVEL - 1; l >= 0; l--) {
+            idx >>= 1;
+            if (!path_nodes_.insert(MemoryTree::key((unsigned)l, idx)).second) break;
+        }
+        return blocks_.emplace(label, b).first->second;
+    }
+    void log(SegmentRecords& r, uint32_t as, uint32_t cell, uint32_t prev, uint32_t prev_ts, uint32_t data, uint32_t ts, bool read) {
+        r.acc_as.push_back(as), r.acc_ptr.push_back(cell), r.acc_prev_data.push_back(prev), r.acc_prev_ts.push_back(prev_ts);
+        r.acc_data.push_back(data), r.acc_ts.push_back(ts), r.acc_is_read.push_back(read ? 1u : 0u);
+    }
+    // A block is snapshotted at its first touch in the segment, which must happen BEFORE the machine executes an instruction that
+    // changes it: run_segment calls block_of for every cell an instruction will write before step_one.
+    void read_cell(SegmentRecords& r, uint32_t as, uint32_t cell, uint32_t value, uint32_t ts) {
+        Block& b = block_of(as, cell);
+        const unsigned j = cell & 7u;
+        if (b.cur[j] != value) throw Error("internal: memory log out of step with the machine");
+        log(r, as, cell, value, b.ts[j], value, ts, true);
+        b.ts[j] = ts;
+    }
+    void write_cell(SegmentRecords& r, uint32_t as, uint32_t cell, uint32_t value, uint32_t ts) {
+        auto it = blocks_.find((as << vmc::LABEL_BITS) | (cell >> 3));
+        if (it == blocks_.end()) throw Error("internal: write to a block that was not snapshotted");
+        Block& b = it->second;
+        const unsigned j = cell & 7u;
+        log(r, as, cell, b.cur[j], b.ts[j], value, ts, false);
+        b.cur[j] = value, b.ts[j] = ts;
+    }
+
+    // leaf rows, merkle rows, Poseidon2 requests; commits the segment's final memory to the tree
+    void close_memory(SegmentRecords& r) {
+        std::vector<uint32_t> labels;
+        for (const auto& kv : blocks_) labels.push_back(kv.first);
+        std::sort(labels.begin(), labels.end());
+        std::unordered_map<uint64_t, Digest> fin;   // final digests of the touched blocks and path nodes
+        auto add_p2 = [&](const uint32_t* a, const uint32_t* b8) {
+            for (int i = 0; i < 8; i++) r.p2_inputs.push_back(a[i]);
+            for (int i = 0; i < 8; i++) r.p2_inputs.push_back(b8 ? b8[i] : 0u);
+        };
+        std::vector<Digest> h_fin(labels.size());
+        parallel_for(labels.size(), [&](size_t i) { h_fin[i] = p2_block(blocks_[labels[i]].cur); });
+        for (size_t i = 0; i < labels.size(); i++) {
+            const uint32_t label = labels[i];
+            const Block& b = blocks_[label];
+            const Digest hi = tree_.get(vmc::LEAF_LEVEL, label);
+            fin[MemoryTree::key(vmc::LEAF_LEVEL, label)] = h_fin[i];
+            uint32_t row[vmc::LEAF_WIDTH] = {};
+            row[0] = label >> vmc::LABEL_BITS, row[1] = label & ((1u << vmc::LABEL_BITS) - 1);
+            for (int j = 0; j < 8; j++) row[2 + j] = b.init[j], row[10 + j] = b.cur[j], row[18 + j] = b.ts[j], row[26 + j] = hi[j], row[34 + j] = h_fin[i][j];
+            row[42] = 1;
+            const uint32_t gap = i + 1 < labels.size() ? labels[i + 1] - label - 1 : 0;
+            row[43] = gap & 0xffffu, row[44] = gap >> 16, row[45] = row[1] & 0xffffu, row[46] = row[1] >> 16;
+            r.leaf_rows.insert(r.leaf_rows.end(), row, row + vmc::LEAF_WIDTH);
+            add_p2(b.init, nullptr), add_p2(b.cur, nullptr);
+        }
+        // path nodes level by level, bottom-up; the root's row goes first in the chip
+        std::vector<std::vector<uint32_t>> by_level(vmc::LEAF_LEVEL);
+        for (uint64_t k : path_nodes_) by_level[k >> 32].push_back((uint32_t)k);
+        std::vector<std::vector<uint32_t>> rows_by_level(vmc::LEAF_LEVEL);
+        for (int l = (int)vmc::LEAF_LEVEL - 1; l >= 0; l--) {
+            auto& idxs = by_level[l];
+            std::sort(idxs.begin(), idxs.end());
+            std::vector<Digest> pf(idxs.size());
+            auto child_fin = [&](uint32_t ci, bool* on) {
+                auto it = fin.find(MemoryTree::key((unsigned)l + 1, ci));
+                *on = it != fin.end();
+                return *on ? it->second : tree_.get((unsigned)l + 1, ci);
+            };
+            parallel_for(idxs.size(), [&](size_t i) {
+                bool a, b;
+                pf[i] = p2_compress(child_fin(2 * idxs[i], &a), child_fin(2 * idxs[i] + 1, &b));
+            });
+            for (size_t i = 0; i < idxs.size(); i++) {
+                const uint32_t idx = idxs[i];
+                bool l_on, r_on;
+                const Digest lf = child_fin(2 * idx, &l_on), rf = child_fin(2 * idx + 1, &r_on);
+                const Digest li = tree_.get((unsigned)l + 1, 2 * idx), ri = tree_.get((unsigned)l + 1, 2 * idx + 1), pi = tree_.get((unsigned)l, idx);
+                uint32_t row[vmc::MERKLE_WIDTH] = {};
+                row[0] = (uint32_t)l, row[1] = idx;
+                for (int q = 0; q < 8; q++) row[2 + q] = li[q], row[10 + q] = ri[q], row[18 + q] = lf[q], row[26 + q] = rf[q], row[34 + q] = pi[q], row[42 + q] = pf[i][q];
+                row[50] = l_on, row[51] = r_on, row[52] = 1, row[53] = l == 0;
+                rows_by_level[l].insert(rows_by_level[l].end(), row, row + vmc::MERKLE_WIDTH);
+            }
+            for (size_t i = 0; i < idxs.size(); i++) fin[MemoryTree::key((unsigned)l, idxs[i])] = pf[i];
+        }
+        for (unsigned l = 0; l < vmc::LEAF_LEVEL; l++) r.merkle_rows.insert(r.merkle_rows.end(), rows_by_level[l].begin(), rows_by_level[l].end());
+        for (size_t i = 0; i < r.n_merkle(); i++) {
+            const uint32_t* row = &r.merkle_rows[i * vmc::MERKLE_WIDTH];
+            add_p2(row + 2, row + 10), add_p2(row + 18, row + 26);
+        }
+        for (const auto& kv : fin) tree_.set((unsigned)(kv.first >> 32), (uint32_t)kv.first, kv.second);
+        r.root_final = tree_.root();
+    }
+    template <class F>
+    static void parallel_for(size_t n, F&& f) {
+        const size_t nt = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), n / 256);
+        if (nt <= 1) {
+            for (size_t i = 0; i < n; i++) f(i);
+            return;
+        }
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                for (size_t i = t; i < n; i += nt) f(i);
+            });
+        for (auto& t : th) t.join();
+    }
+};
+
+}  // namespace zkhip_vm

@@ -1,0 +1,375 @@
+// zkhip_vm_flow.hpp -- ONE FLOW PER TASK: guest ELF + witness bytes in, ONE proof out.  The reference's
+//   Prover::gen_proof_universal -> gen_proof_stark  (crates/prover/src/prover/mod.rs:287-309, 342-413):
+//   task.build_guest_input() (crates/prover/src/task/mod.rs:27-38) -> execute_guest (crates/prover/src/utils/vm.rs:13-48) -> sdk.prove
+//   (app segments, then the leaf / internal aggregation tree, mod.rs:47-60) -> encode -> mandatory self-verification
+// over this backend:
+//   1. SegmentExecutor (include/zkhip_vm_exec.hpp) runs the guest and cuts it into segments of fixed heights;
+//   2. SegmentProver uploads a segment's records, generates the 23 chips' traces on the device (include/zkhip.h zkhip_*_tracegen) and
+//      proves them as ONE statement (include/zkhip_vm_circuit.hpp): (pc_start, memory root) -> (pc_end, memory root');
+//   3. AggregationProver (include/zkhip_aggregation.hpp) folds the segment proofs: leaf nodes verify <= 4 segments, internal
+//      nodes <= 3 nodes, chaining (pc, root) in-circuit, until one root proof remains;
+//   4. verify_guest_proof: the root proof under the root verifying key + the statement checks a verifier makes outside the circuit
+//      (initial pc and memory root = the guest image's; final pc = 0 = exited with code 0; the public values' Merkle openings in the
+//      final root -- the `user_pvs_proof` of crates/types/src/proof.rs:52-67).
+#pragma once
+#include <chrono>
+#include <map>
+#include <numeric>
+
+#include "zkhip_aggregation.hpp"
+#include "zkhip_vm_exec.hpp"
+
+namespace zkhip_vm {
+using scroll_zkvm_hip::AirDesc;
+using scroll_zkvm_hip::ChildProof;
+using scroll_zkvm_hip::VerifyingKey;
+
+// the segment's verifying key material that does not need a device: programs, shapes, heights (commitments come from keygen)
+struct SegmentAirs {
+    std::vector<zkhip_air> airs;                 // program / width / n_pvs / log_height; prep_trace set for the AIRs with tables
+    std::vector<size_t> prep_width;
+    std::vector<uint32_t> program_prep, bitwise_prep, tuple_prep, range_prep;
+};
+inline unsigned vm_log2_ceil(size_t n) {
+    unsigned l = 1;
+    while (((size_t)1 << l) < n) l++;
+    return l;
+}
+inline SegmentAirs segment_airs(const Exe& exe, const SegmentCaps& caps) {
+    SegmentAirs s;
+    s.airs.resize(vmc::N_AIRS), s.prep_width.resize(vmc::N_AIRS);
+    for (unsigned a = 0; a < vmc::N_AIRS; a++) {
+        if (zkhip_vm_air(a, &s.airs[a], &s.prep_width[a]) != ZKHIP_OK) throw Error("zkhip_vm_air failed");
+        s.airs[a].log_height = caps.log_height[a];
+    }
+    const unsigned lp = caps.log_height[vmc::A_PROGRAM];
+    s.program_prep = vmc::program_table(exe.program, exe.pc_base, lp);
+    s.bitwise_prep.resize(3u << 16), s.tuple_prep.resize((size_t)2 << 19), s.range_prep.resize(1u << 16);
+    for (uint32_t i = 0; i < (1u << 16); i++) s.bitwise_prep[i] = i >> 8, s.bitwise_prep[(1u << 16) + i] = i & 255u, s.bitwise_prep[(2u << 16) + i] = (i >> 8) ^ (i & 255u);
+    for (uint32_t i = 0; i < (1u << 19); i++) s.tuple_prep[i] = i / TUPLE_Y, s.tuple_prep[((size_t)1 << 19) + i] = i % TUPLE_Y;
+    std::iota(s.range_prep.begin(), s.range_prep.end(), 0u);
+    s.airs[vmc::A_PROGRAM].prep_trace = s.program_prep.data(), s.airs[vmc::A_BITWISE].prep_trace = s.bitwise_prep.data();
+    s.airs[vmc::A_RANGE_TUPLE].prep_trace = s.tuple_prep.data(), s.airs[vmc::A_RANGE].prep_trace = s.range_prep.data();
+    return s;
+}
+
+struct SegmentProof {
+    ChildProof proof;               // proof bytes + public values per AIR (merkle chip: roots; connector: pc_start, pc_end)
+    uint64_t n_instr = 0, tracegen_mills = 0, proving_mills = 0;
+};
+
+// where the chained state of a segment proof lives: (pc, memory root) -- the StatementSpec of the aggregation layer
+inline scroll_zkvm_hip::StatementSpec segment_statement() {
+    scroll_zkvm_hip::StatementSpec sp;
+    sp.start.push_back({vmc::A_CONNECTOR, 0}), sp.end.push_back({vmc::A_CONNECTOR, 1});
+    for (uint32_t k = 0; k < 8; k++) sp.start.push_back({vmc::A_MERKLE, k}), sp.end.push_back({vmc::A_MERKLE, 8 + k});
+    return sp;
+}
+
+class SegmentProver {
+public:
+    SegmentProver(const zkhip_params& params, const Exe& exe, const SegmentCaps& caps, int device = 0) : params_(params), caps_(caps), sa_(segment_airs(exe, caps)) {
+        if (zkhip_ctx_create(device, &ctx_) != ZKHIP_OK) throw Error("zkhip_ctx_create failed (needs a gfx950 device)");
+        check(zkhip_keygen(ctx_, &params_, sa_.airs.data(), sa_.airs.size(), &pk_));
+        vk_.params = params_;
+        for (unsigned a = 0; a < vmc::N_AIRS; a++) {
+            AirDesc d;
+            d.width = sa_.airs[a].width, d.n_pvs = sa_.airs[a].n_pvs;
+            d.program.assign(sa_.airs[a].program, sa_.airs[a].program + sa_.airs[a].program_len);
+            if (sa_.prep_width[a]) {
+                uint32_t c[8];
+                check(zkhip_pk_prep_commitment(ctx_, pk_, a, c));
+                d.has_prep = true, d.prep_log_height = caps.log_height[a], d.prep_commit.assign(c, c + 8);
+            }
+            vk_.airs.push_back(std::move(d));
+            vk_.heights.push_back(caps.log_height[a]);
+        }
+        // device-resident tables: the program (for the frame chip's gather), zeros for the bitwise "op" argument
+        const size_t NP = caps_.rows(vmc::A_PROGRAM);
+        check(zkhip_malloc(ctx_, vmc::PROGRAM_FIELDS * NP * 4, (void**)&d_program_));
+        check(zkhip_h2d(ctx_, d_program_, sa_.program_prep.data(), vmc::PROGRAM_FIELDS * NP * 4));
+        check(zkhip_to_monty(ctx_, d_program_, vmc::PROGRAM_FIELDS * NP));
+        size_t max_rows = 0;
+        for (unsigned a = 0; a < vmc::N_AIRS; a++) {
+            const size_t words = sa_.airs[a].width << caps_.log_height[a];
+            void* d = nullptr;
+            check(zkhip_malloc(ctx_, words * 4, &d));
+            d_traces_.push_back((uint32_t*)d);
+            max_rows = std::max(max_rows, caps_.rows(a));
+        }
+        check(zkhip_malloc(ctx_, max_rows * 4, (void**)&d_zeros_));
+        check(zkhip_zero(ctx_, d_zeros_, max_rows * 4));
+    }
+    ~SegmentProver() {
+        for (uint32_t* d : d_traces_) zkhip_free(ctx_, d);
+        for (auto& c : dev_) zkhip_free(ctx_, c.base);
+        for (auto& c : pin_) zkhip_host_free(ctx_, c.base);
+        if (d_program_) zkhip_free(ctx_, d_program_);
+        if (d_zeros_) zkhip_free(ctx_, d_zeros_);
+        if (pk_) zkhip_pk_destroy(ctx_, pk_);
+        if (ctx_) zkhip_ctx_destroy(ctx_);
+    }
+    SegmentProver(const SegmentProver&) = delete;
+    SegmentProver& operator=(const SegmentProver&) = delete;
+    const VerifyingKey& vk() const { return vk_; }
+
+    SegmentProof prove(const SegmentRecords& r, bool self_verify = true) {
+        using clk = std::chrono::steady_clock;
+        auto ms = [](clk::time_point a, clk::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(b - a).count(); };
+        const auto t0 = clk::now();
+        release();
+        const ExecRecords& c = r.core;
+        auto H = [&](unsigned a) { return caps_.log_height[a]; };
+        auto T = [&](unsigned a) { return d_traces_[a]; };
+        auto N = [&](unsigned a) { return caps_.rows(a); };
+        // ---- tables start empty
+        check(zkhip_zero(ctx_, T(vmc::A_BITWISE), (2u << 16) * 4)), check(zkhip_zero(ctx_, T(vmc::A_RANGE_TUPLE), (1u << 19) * 4));
+        uint32_t *d_bw = T(vmc::A_BITWISE), *d_tup = T(vmc::A_RANGE_TUPLE), *d_rng = T(vmc::A_RANGE);
+        // ---- program frequencies, frame
+        const uint32_t* d_idx = up(c.pc_index);
+        check(zkhip_program_freq_tracegen(ctx_, d_idx, c.pc_index.size(), H(vmc::A_PROGRAM), T(vmc::A_PROGRAM)));
+        check(zkhip_vm_frame_tracegen(ctx_, d_idx, up(r.f_x), up(r.f_y), up(r.f_z), up(r.f_rdprev), up(r.f_pcinc), r.n_instr, d_program_, N(vmc::A_PROGRAM),
+                                      H(vmc::A_FRAME), T(vmc::A_FRAME)));
+        // ---- instruction cores (include/zkhip_chips.hpp: unchanged generators)
+        check(zkhip_rv32_alu_tracegen(ctx_, up(c.alu_op), up(c.alu_b), up(c.alu_c), c.alu_op.size(), H(vmc::A_ALU), T(vmc::A_ALU), d_bw));
+        check(zkhip_rv32_lt_tracegen(ctx_, up(c.lt_op), up(c.lt_b), up(c.lt_c), c.lt_op.size(), H(vmc::A_LT), T(vmc::A_LT), d_bw));
+        check(zkhip_rv32_mul_tracegen(ctx_, up(c.mul_b), up(c.mul_c), c.mul_b.size(), H(vmc::A_MUL), T(vmc::A_MUL), d_tup, TUPLE_X, TUPLE_Y));
+        check(zkhip_rv32_mulh_tracegen(ctx_, up(c.mulh_op), up(c.mulh_b), up(c.mulh_c), c.mulh_op.size(), H(vmc::A_MULH), T(vmc::A_MULH), d_tup, TUPLE_X, TUPLE_Y, d_bw));
+        check(zkhip_rv32_divrem_tracegen(ctx_, up(c.div_op), up(c.div_b), up(c.div_c), c.div_op.size(), H(vmc::A_DIVREM), T(vmc::A_DIVREM), d_tup, TUPLE_X, TUPLE_Y, d_bw));
+        check(zkhip_rv32_shift_tracegen(ctx_, up(c.shift_op), up(c.shift_b), up(c.shift_c), c.shift_op.size(), H(vmc::A_SHIFT), T(vmc::A_SHIFT), d_bw));
+        check(zkhip_rv32_branch_eq_tracegen(ctx_, up(c.beq_op), up(c.beq_a), up(c.beq_b), up(c.beq_imm), c.beq_op.size(), H(vmc::A_BEQ), T(vmc::A_BEQ)));
+        check(zkhip_rv32_branch_lt_tracegen(ctx_, up(c.blt_op), up(c.blt_a), up(c.blt_b), up(c.blt_imm), c.blt_op.size(), H(vmc::A_BLT), T(vmc::A_BLT), d_bw));
+        check(zkhip_rv32_jal_lui_tracegen(ctx_, up(c.jal_op), up(c.jal_pc), up(c.jal_imm), c.jal_op.size(), H(vmc::A_JAL_LUI), T(vmc::A_JAL_LUI), d_bw));
+        check(zkhip_rv32_auipc_tracegen(ctx_, up(c.auipc_pc), up(c.auipc_imm), c.auipc_pc.size(), H(vmc::A_AUIPC), T(vmc::A_AUIPC), d_bw));
+        check(zkhip_rv32_jalr_tracegen(ctx_, up(c.jalr_pc), up(c.jalr_rs1), up(c.jalr_imm), c.jalr_pc.size(), H(vmc::A_JALR), T(vmc::A_JALR), d_bw));
+        check(zkhip_vm_loadstore_tracegen(ctx_, up(c.ls_case), up(c.ls_read), up(c.ls_prev), up(r.ls_ts), up(r.ls_base), up(r.ls_imm), c.ls_case.size(), H(vmc::A_LS),
+                                          T(vmc::A_LS), d_bw));
+        // ---- the chips whose rows the executor wrote
+        const uint32_t leaf_pad[vmc::LEAF_WIDTH] = {1};   // padding rows of the leaf chip carry address space 1
+        check(zkhip_rows_tracegen(ctx_, up(r.ecall_rows), r.n_ecall(), vmc::ECALL_WIDTH, H(vmc::A_ECALL), T(vmc::A_ECALL), nullptr));
+        check(zkhip_rows_tracegen(ctx_, up(r.leaf_rows), r.n_leaf(), vmc::LEAF_WIDTH, H(vmc::A_LEAF), T(vmc::A_LEAF), leaf_pad));
+        check(zkhip_rows_tracegen(ctx_, up(r.merkle_rows), r.n_merkle(), vmc::MERKLE_WIDTH, H(vmc::A_MERKLE), T(vmc::A_MERKLE), nullptr));
+        const std::vector<uint32_t> conn{r.ts_end & 0xffffu, r.ts_end >> 16};
+        check(zkhip_rows_tracegen(ctx_, up(conn), 1, vmc::CONNECTOR_WIDTH, 0, T(vmc::A_CONNECTOR), nullptr));
+        uint32_t* d_p2in = const_cast<uint32_t*>(up(r.p2_inputs));
+        if (r.n_p2()) check(zkhip_to_monty(ctx_, d_p2in, r.p2_inputs.size()));
+        check(zkhip_vm_poseidon2_tracegen(ctx_, d_p2in, r.n_p2(), H(vmc::A_POSEIDON2), T(vmc::A_POSEIDON2)));
+        // ---- memory accesses
+        const size_t n_acc = r.acc_ts.size();
+        check(zkhip_vm_access_tracegen(ctx_, up(r.acc_as), up(r.acc_ptr), up(r.acc_prev_data), up(r.acc_prev_ts), up(r.acc_data), up(r.acc_ts), up(r.acc_is_read), n_acc,
+                                       H(vmc::A_ACCESS), T(vmc::A_ACCESS)));
+        // ---- lookup multiplicities of the new chips, counted from the requesting columns
+        auto pairs = [&](unsigned a, size_t cx, size_t cy, size_t n) {
+            if (n) check(zkhip_bitwise_lookup_tracegen(ctx_, T(a) + cx * N(a), T(a) + cy * N(a), d_zeros_, n, 8, d_bw, 1));
+        };
+        for (size_t q : {18, 20, 22, 24}) pairs(vmc::A_FRAME, q, q + 1, r.n_instr);
+        for (size_t q : {0, 2, 4, 6}) pairs(vmc::A_LS, q, q + 1, c.ls_case.size());
+        bool first = true;
+        auto count = [&](const uint32_t* col, size_t n, uint32_t scale = 1) {
+            if (scale == 1) check(zkhip_range_counts_tracegen(ctx_, col, n, 16, d_rng, first ? 0 : 1));
+            else check(zkhip_range_counts_scaled_tracegen(ctx_, col, n, scale, 16, d_rng, first ? 0 : 1));
+            first = false;
+        };
+        const size_t NA = N(vmc::A_ACCESS), NL = N(vmc::A_LS), n_ls = c.ls_case.size();
+        for (size_t q : {8, 9, 4, 10}) count(T(vmc::A_ACCESS) + q * NA, n_acc);
+        count(T(vmc::A_LS) + 40 * NL, n_ls), count(T(vmc::A_LS) + 41 * NL, n_ls, 4), count(T(vmc::A_LS) + 44 * NL, n_ls, 4);
+        count(T(vmc::A_LS) + 44 * NL, n_ls), count(T(vmc::A_LS) + 41 * NL, n_ls);
+        {
+            // the few range requests of the ecall, leaf and connector chips, listed on the host
+            std::vector<uint32_t> misc{r.ts_end & 0xffffu, 8 * (r.ts_end >> 16), r.ts_end >> 16};
+            for (size_t i = 0; i < r.n_ecall(); i++) {
+                const uint32_t* row = &r.ecall_rows[i * vmc::ECALL_WIDTH];
+                if (row[15]) misc.push_back(row[17] * 8192), misc.push_back(row[17]);
+            }
+            for (size_t i = 0; i < r.n_leaf(); i++) {
+                const uint32_t* row = &r.leaf_rows[i * vmc::LEAF_WIDTH];
+                for (uint32_t v : {row[43], row[44] * 16, row[44], row[45], row[46] * 64, row[46]}) misc.push_back(v);
+            }
+            uint32_t* d_misc = const_cast<uint32_t*>(up(misc));
+            check(zkhip_to_monty(ctx_, d_misc, misc.size()));
+            count(d_misc, misc.size());
+        }
+        const auto t1 = clk::now();
+        // ---- prove
+        SegmentProof sp;
+        sp.n_instr = r.n_instr;
+        sp.proof.pvs.resize(vmc::N_AIRS);
+        for (int k = 0; k < 8; k++) sp.proof.pvs[vmc::A_MERKLE].push_back(r.root_init[k]);
+        for (int k = 0; k < 8; k++) sp.proof.pvs[vmc::A_MERKLE].push_back(r.root_final[k]);
+        sp.proof.pvs[vmc::A_CONNECTOR] = {r.pc_start, r.pc_end};
+        std::vector<const uint32_t*> dt(d_traces_.begin(), d_traces_.end()), pv(vmc::N_AIRS, nullptr);
+        pv[vmc::A_MERKLE] = sp.proof.pvs[vmc::A_MERKLE].data(), pv[vmc::A_CONNECTOR] = sp.proof.pvs[vmc::A_CONNECTOR].data();
+        sp.proof.proof.resize(zkhip_proof_size(pk_));
+        size_t len = 0;
+        check(zkhip_prove(ctx_, pk_, dt.data(), pv.data(), sp.proof.proof.data(), sp.proof.proof.size(), &len));
+        sp.proof.proof.resize(len);
+        sp.tracegen_mills = ms(t0, t1), sp.proving_mills = ms(t1, clk::now());
+        if (self_verify && !vk_.verify(sp.proof)) throw Error("the segment proof does not verify");
+        return sp;
+    }
+
+private:
+    zkhip_params params_;
+    SegmentCaps caps_;
+    SegmentAirs sa_;
+    zkhip_ctx* ctx_ = nullptr;
+    zkhip_pk* pk_ = nullptr;
+    VerifyingKey vk_;
+    uint32_t *d_program_ = nullptr, *d_zeros_ = nullptr;
+    std::vector<uint32_t*> d_traces_;
+    struct Chunk {
+        char* base = nullptr;
+        size_t cap = 0, used = 0;
+    };
+    std::vector<Chunk> dev_, pin_;
+    void check(int rc) {
+        if (rc != ZKHIP_OK) throw Error(std::string("zkhip: ") + zkhip_last_error(ctx_));
+    }
+    template <typename Alloc>
+    char* carve(std::vector<Chunk>& chunks, size_t bytes, size_t chunk_bytes, Alloc&& alloc) {
+        bytes = (std::max<size_t>(bytes, 4) + 255) & ~(size_t)255;
+        for (Chunk& c : chunks)
+            if (c.cap - c.used >= bytes) {
+                char* p = c.base + c.used;
+                c.used += bytes;
+                return p;
+            }
+        Chunk c;
+        c.cap = std::max(bytes, chunk_bytes);
+        void* p = nullptr;
+        check(alloc(c.cap, &p));
+        c.base = (char*)p, c.used = bytes;
+        chunks.push_back(c);
+        return c.base;
+    }
+    void release() {
+        zkhip_sync(ctx_);
+        for (Chunk& c : dev_) c.used = 0;
+        for (Chunk& c : pin_) c.used = 0;
+    }
+    const uint32_t* up(const std::vector<uint32_t>& v) {
+        uint32_t* d = (uint32_t*)carve(dev_, v.size() * 4, (size_t)64 << 20, [&](size_t n, void** p) { return zkhip_malloc(ctx_, n, p); });
+        if (v.empty()) return d;
+        char* stage = carve(pin_, v.size() * 4, (size_t)32 << 20, [&](size_t n, void** p) { return zkhip_host_alloc(ctx_, n, p); });
+        memcpy(stage, v.data(), v.size() * 4);
+        check(zkhip_h2d_async(ctx_, d, stage, v.size() * 4));
+        return d;
+    }
+};
+
+// ---- the whole flow ---------------------------------------------------------------------------------------------------------------------
+struct GuestStark {
+    ChildProof root;                       // the root node's proof + public values [app-vk digest | (pc, root) start | (pc, root) end | accumulator]
+    VerifyingKey root_vk;
+    size_t levels = 0, segments = 0;
+    ExecutionResult exec;
+    Digest image_root{};
+    uint32_t entry_pc = 0;
+    // openings of the two public-value blocks (address space 3) in the final memory root: sibling digests bottom-up, per block
+    std::vector<uint32_t> pv_openings;
+    uint64_t execution_mills = 0, segment_proving_mills = 0, aggregation_mills = 0;
+    std::vector<SegmentProof> segment_proofs;   // kept when asked for
+};
+
+// the public-value cells' Merkle openings in the executor's final tree
+inline std::vector<uint32_t> open_public_values(const MemoryTree& tree) {
+    std::vector<uint32_t> out;
+    for (uint32_t blk = 0; blk < 2; blk++) {
+        uint32_t idx = (3u << vmc::LABEL_BITS) | blk;
+        for (int l = (int)vmc::LEAF_LEVEL; l > 0; l--) {
+            const Digest sib = tree.get((unsigned)l, idx ^ 1u);
+            out.insert(out.end(), sib.begin(), sib.end());
+            idx >>= 1;
+        }
+    }
+    return out;
+}
+// what a verifier recomputes: the final memory root from the claimed public values and their openings
+inline bool check_public_values(const std::vector<uint8_t>& pv, const std::vector<uint32_t>& openings, const uint32_t root[8]) {
+    if (pv.size() != NUM_PUBLIC_VALUE_BYTES || openings.size() != 2 * 8 * vmc::LEAF_LEVEL) return false;
+    for (uint32_t blk = 0; blk < 2; blk++) {
+        uint32_t cells[8];
+        for (int j = 0; j < 8; j++) cells[j] = pv[16 * blk + 2 * j] | ((uint32_t)pv[16 * blk + 2 * j + 1] << 8);
+        Digest cur = p2_block(cells);
+        uint32_t idx = (3u << vmc::LABEL_BITS) | blk;
+        const uint32_t* sib = &openings[(size_t)blk * 8 * vmc::LEAF_LEVEL];
+        for (int l = (int)vmc::LEAF_LEVEL; l > 0; l--, sib += 8, idx >>= 1) {
+            Digest s;
+            std::copy(sib, sib + 8, s.begin());
+            cur = (idx & 1u) ? p2_compress(s, cur) : p2_compress(cur, s);
+        }
+        if (!std::equal(cur.begin(), cur.end(), root)) return false;
+    }
+    return true;
+}
+
+// root of the initial memory of a guest image (what a verifier derives from the ELF)
+inline Digest guest_image_root(const Exe& exe) {
+    StdIn none;
+    SegmentCaps caps = SegmentCaps::for_frame(4, 2);
+    SegmentExecutor ex(exe, none, caps);
+    return ex.image_root();
+}
+
+// execute -> segment proofs -> aggregation tree -> root.  `keep_segments`: also return the segment proofs.
+inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
+                                        bool keep_segments = false) {
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::duration d) { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(d).count(); };
+    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()));
+    GuestStark g;
+    SegmentExecutor ex(exe, in, caps);
+    g.image_root = ex.image_root(), g.entry_pc = exe.entry ? exe.entry : exe.pc_base;
+    std::vector<ChildProof> seg_proofs;
+    VerifyingKey seg_vk;
+    {
+        SegmentProver sp(params, exe, caps, device);
+        seg_vk = sp.vk();
+        SegmentRecords rec;
+        clk::duration t_exec{}, t_prove{};
+        for (bool done = false; !done;) {
+            const auto a = clk::now();
+            done = ex.run_segment(rec);
+            const auto b = clk::now();
+            SegmentProof p = sp.prove(rec);
+            t_exec += b - a, t_prove += clk::now() - b;
+            seg_proofs.push_back(p.proof);
+            if (keep_segments) g.segment_proofs.push_back(std::move(p));
+        }
+        g.execution_mills = ms(t_exec), g.segment_proving_mills = ms(t_prove);
+    }
+    bool all_zero = true;
+    for (uint8_t b : ex.public_values()) all_zero = all_zero && b == 0;
+    if (all_zero) throw Error("public_values are all 0s for unexpected reason");   // crates/prover/src/utils/vm.rs:34-46
+    g.exec = ExecutionResult{ex.instret(), ex.public_values()};
+    g.pv_openings = open_public_values(ex.tree());
+    g.segments = seg_proofs.size();
+    const auto t0 = clk::now();
+    scroll_zkvm_hip::AggregationProver agg = scroll_zkvm_hip::AggregationProver::setup(seg_vk, segment_statement(), {}, device);
+    const scroll_zkvm_hip::AggregationPlan plan = scroll_zkvm_hip::AggregationPlan::build(seg_proofs.size());
+    g.root = agg.prove_tree(plan, seg_proofs);
+    g.levels = plan.levels.size();
+    g.root_vk = agg.node_vk(plan.levels.size() - 1);
+    g.aggregation_mills = ms(clk::now() - t0);
+    return g;
+}
+
+// The verifier's side: the root proof under the root verifying key, then the statement: the run starts at the guest's entry on the
+// guest's image, ends with pc = 0 (exit code 0), and the claimed public values open in the final memory root.
+inline bool verify_guest_proof(const VerifyingKey& root_vk, const ChildProof& root, uint32_t entry_pc, const Digest& image_root,
+                               const std::vector<uint8_t>& public_values, const std::vector<uint32_t>& pv_openings, std::string* why = nullptr) {
+    auto fail = [&](const char* m) {
+        if (why) *why = m;
+        return false;
+    };
+    if (!root_vk.verify(root)) return fail("the root proof does not verify under the root verifying key");
+    const std::vector<uint32_t>& pv = root.pvs.at(2);
+    if (pv.size() != 8 + 9 + 9 + 8) return fail("the root statement does not have the (pc, memory root) layout");
+    if (pv[8] != entry_pc) return fail("the run does not start at the guest's entry point");
+    if (!std::equal(image_root.begin(), image_root.end(), pv.begin() + 9)) return fail("the run does not start on the guest's memory image");
+    if (pv[17] != 0) return fail("the run does not end with exit code 0");
+    if (!check_public_values(public_values, pv_openings, &pv[18])) return fail("the public values do not open in the final memory root");
+    return true;
+}
+
+}  // namespace zkhip_vm

@@ -308,6 +308,26 @@ extern "C" {
     pub fn zkhip_proof_from_v1(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize, v1: *const u8, v1_len: usize,
                                out: *mut u8, cap: usize, out_len: *mut usize, pvs_out: *const *mut u32) -> c_int;
 
+    // the one-statement VM circuit: AIR set, decode, program table, trace generators of the adapter-side chips
+    pub fn zkhip_vm_n_airs() -> usize;
+    pub fn zkhip_vm_air(id: c_uint, out: *mut zkhip_air, prep_width: *mut usize) -> c_int;
+    pub fn zkhip_vm_decode(word: u32, pc: u32, out: *mut u32, legal: *mut c_int) -> c_int;
+    pub fn zkhip_vm_program_table(words: *const u32, n_words: usize, pc_base: u32, log_program: c_uint, out: *mut u32) -> c_int;
+    pub fn zkhip_vm_frame_tracegen(ctx: *mut zkhip_ctx, d_pc_index: *const u32, d_x: *const u32, d_y: *const u32, d_z: *const u32,
+                                   d_rd_prev: *const u32, d_pc_inc: *const u32, n: usize, d_program: *const u32, n_program: usize,
+                                   log_height: c_uint, d_trace: *mut u32) -> c_int;
+    pub fn zkhip_vm_loadstore_tracegen(ctx: *mut zkhip_ctx, d_case: *const u32, d_read: *const u32, d_prev: *const u32, d_ts: *const u32,
+                                       d_base: *const u32, d_imm: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
+                                       d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_vm_access_tracegen(ctx: *mut zkhip_ctx, d_addr_space: *const u32, d_pointer: *const u32, d_prev_data: *const u32,
+                                    d_prev_ts: *const u32, d_data: *const u32, d_ts: *const u32, d_is_read: *const u32, n: usize,
+                                    log_height: c_uint, d_trace: *mut u32) -> c_int;
+    pub fn zkhip_vm_poseidon2_tracegen(ctx: *mut zkhip_ctx, d_inputs: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;
+    pub fn zkhip_rows_tracegen(ctx: *mut zkhip_ctx, d_rows: *const u32, n: usize, width: usize, log_height: c_uint, d_trace: *mut u32,
+                               pad_row: *const u32) -> c_int;
+    pub fn zkhip_range_counts_scaled_tracegen(ctx: *mut zkhip_ctx, d_values: *const u32, n: usize, scale: u32, log_table: c_uint,
+                                              d_counts: *mut u32, accumulate: c_int) -> c_int;
+
     // aggregation layer: the verifier circuit of a node (commit_child_vk / VerifyProver of the reference)
     pub fn zkhip_recursion_build(child_params: *const zkhip_params, child_airs: *const zkhip_air, n_child_airs: usize, max_children: usize,
                                  stmt: *const zkhip_recursion_stmt, out: *mut *mut zkhip_recursion) -> c_int;

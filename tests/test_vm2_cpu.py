@@ -1,0 +1,171 @@
+"""CPU: the one-statement VM circuit (include/zkhip_vm_circuit.hpp) -- adapters, execution bus, connector, persistent memory -- on
+the segmenting executor's records (include/zkhip_vm_exec.hpp, `prove_cli dump-segments`):
+  * the run agrees with the independent Python interpreter; segments chain by (pc, memory root); the first root is the guest image's,
+    the last pc is 0, the public values open in the final root;
+  * every one of the 23 traces (CPU twins of the device generators, tests/vm2_util.py) satisfies its AIR, and every bus balances
+    exactly: program, execution, operand, access, memory, merkle, hash and the three lookup buses;
+  * the oracle proves a whole segment and both verifiers accept;
+  * a tampered instruction result, swapped operands, a forged memory value, a skipped instruction, a wrong next pc: some bus no
+    longer balances (what makes the proof fail);
+  * the decode table against an independent decoder."""
+import numpy as np
+import pytest
+
+import zkvm_prover_amd as z
+from zkvm_prover_amd import air
+
+import recursion_util as ru
+import rv32_model as rv
+import vm2_util as v2
+from test_vm_cpu import fib_program, mixed_program
+
+PARAMS = (1, 0, 4, 3, 3)
+PC_BASE = 0x00200000
+
+
+@pytest.fixture(scope="module")
+def mixed(tmp_path_factory):
+    words = mixed_program()
+    stdin = (7).to_bytes(4, "little")
+    info, heights, segs, image_root, pv_open = v2.dump_segments(tmp_path_factory.mktemp("mixed"), rv.exe_bytes(words), stdin, 9)
+    return dict(words=words, stdin=stdin, info=info, heights=heights, segs=segs, image_root=image_root, pv_open=pv_open)
+
+
+def test_segments_chain_and_agree_with_the_model(mixed):
+    model = rv.run(mixed["words"], mixed["stdin"])
+    info, segs = mixed["info"], mixed["segs"]
+    assert info["total_cycle"] == model["instret"] and bytes.fromhex(info["public_values"]) == bytes(model["pvs"])
+    assert len(segs) > 5 and sum(int(s["meta"][3]) for s in segs) == model["instret"]
+    meta = [s["meta"] for s in segs]
+    assert int(meta[0][0]) == PC_BASE and meta[0][4:12].tolist() == mixed["image_root"].tolist()
+    for a, b in zip(meta, meta[1:]):
+        assert int(a[1]) == int(b[0]) != 0 and a[12:20].tolist() == b[4:12].tolist()
+    assert int(meta[-1][1]) == 0                       # exited
+    for m, s in zip(meta, segs):
+        assert int(m[2]) == 1 + 16 * int(m[3]) and s["f_x"].size == int(m[3])
+    # the public values open in the final root: two blocks of address space 3, 28 siblings each
+    pv = bytes(model["pvs"])
+    final_root = meta[-1][12:20]
+    for blk in range(2):
+        cells = [pv[16 * blk + 2 * j] | (pv[16 * blk + 2 * j + 1] << 8) for j in range(8)]
+        cur = ru.sponge(cells)
+        idx = (3 << 26) | blk
+        sib = mixed["pv_open"][blk * 8 * 28:(blk + 1) * 8 * 28].reshape(28, 8)
+        for lvl in range(28):
+            cur = ru.compress(sib[lvl], cur) if idx & 1 else ru.compress(cur, sib[lvl])
+            idx >>= 1
+        assert cur.tolist() == final_root.tolist()
+
+
+@pytest.mark.parametrize("k", [0, 7, -1])
+def test_every_trace_satisfies_its_air_and_every_bus_balances(mixed, k):
+    inst = v2.segment_instance(mixed["segs"][k], mixed["words"], PC_BASE, mixed["heights"])
+    assert len(inst) == 23
+    for a, d in enumerate(inst):
+        assert air.quotient_chunks(d["program"]) <= 2, a                     # degree <= 3: blow-up 2 suffices
+        assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], a
+    assert v2.bus_imbalance(inst) == {}
+
+
+def test_a_segment_proves_and_verifies(ora, mixed):
+    inst = v2.segment_instance(mixed["segs"][2], mixed["words"], PC_BASE, mixed["heights"])
+    proof = ora.stark_prove(PARAMS, inst)
+    assert ora.stark_verify(PARAMS, inst, proof) == 0
+    vk = ru.verifying(PARAMS, inst)
+    pvs = [d["pvs"] for d in inst]
+    assert z.verify(PARAMS, vk, pvs, proof.tobytes()) == 0
+    # the statement is bound: another pc_end, another final root
+    for a, i in ((v2.A_CONNECTOR, 1), (v2.A_MERKLE, 9)):
+        bad = [p.copy() for p in pvs]
+        bad[a][i] = (int(bad[a][i]) + 1) % ora.P
+        assert z.verify(PARAMS, vk, bad, proof.tobytes()) != 0
+
+
+def _tampered(mixed, k, edit):
+    rec = {n: v.copy() for n, v in mixed["segs"][k].items()}
+    edit(rec)
+    inst = v2.segment_instance(rec, mixed["words"], PC_BASE, mixed["heights"])
+    local = [a for a, d in enumerate(inst) if air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep"))]
+    return local, v2.bus_imbalance(inst)
+
+
+def test_tampering_breaks_a_bus(mixed):
+    seg = mixed["segs"][4]
+    prog = v2.program_table(mixed["words"], PC_BASE, mixed["heights"][0])
+    cls = prog[1][seg["pc_index"]]
+    alu_rows = np.nonzero(cls == 0)[0]
+    sub_row = next(int(r) for r in alu_rows if prog[2][seg["pc_index"][r]] == 1 and seg["f_x"][r] != seg["f_y"][r])
+
+    # 1. a wrong instruction result in the frame (the core still holds the true one): operand + access bus
+    def wrong_result(rec):
+        rec["f_z"][int(alu_rows[3])] ^= 4
+    assert _tampered(mixed, 4, wrong_result)[1].keys() >= {3, 4}
+
+    # 2. swapped operands of a SUB: the registers say otherwise
+    def swapped(rec):
+        r = sub_row
+        rec["f_x"][r], rec["f_y"][r] = rec["f_y"][r], rec["f_x"][r]
+    local, bad = _tampered(mixed, 4, swapped)
+    assert 3 in bad and 4 in bad
+
+    # 3. the core is made consistent with a forged operand (b + 1): the core row is valid, but no register holds that value
+    def forged_operand(rec):
+        j = 2
+        rec["alu_b"][j] = (int(rec["alu_b"][j]) + 1) & 0xFFFFFFFF
+    local, bad = _tampered(mixed, 4, forged_operand)
+    assert local == [] and 3 in bad
+
+    # 4. a skipped instruction: the execution-bus chain has a hole
+    def skipped(rec):
+        for n in ("pc_index", "f_x", "f_y", "f_z", "f_rdprev", "f_pcinc"):
+            rec[n] = np.delete(rec[n], 10)
+    assert 2 in _tampered(mixed, 4, skipped)[1]
+
+    # 5. a branch that goes elsewhere
+    def wrong_pc(rec):
+        rec["f_pcinc"][20] = (int(rec["f_pcinc"][20]) + 4) % v2.P
+    assert {2, 3} <= _tampered(mixed, 4, wrong_pc)[1].keys()
+
+    # 6. a memory cell that changes between two accesses: the access log no longer is a history
+    def forged_memory(rec):
+        w = int(np.nonzero(rec["acc_is_read"] == 1)[0][40])
+        rec["acc_data"][w] ^= 1
+        rec["acc_prev_data"][w] ^= 1
+    assert 4 in _tampered(mixed, 4, forged_memory)[1] or 1 in _tampered(mixed, 4, forged_memory)[1]
+
+    # 7. another initial memory root than the blocks hash to
+    def wrong_root(rec):
+        rec["meta"][5] = (int(rec["meta"][5]) + 1) % v2.P
+    local, bad = _tampered(mixed, 4, wrong_root)
+    assert v2.A_MERKLE in local
+
+
+def test_decode_table_against_an_independent_decoder(mixed):
+    """cls / op / registers / immediates of every instruction of both test programs, re-derived from the RISC-V encoding here."""
+    for words in (mixed["words"], fib_program()):
+        t = v2.program_table(words, PC_BASE, max(1, int(np.ceil(np.log2(len(words))))))
+        for k, w in enumerate(words):
+            f = t[:, k].tolist()
+            opc, rd, f3, rs1, rs2, f7 = w & 0x7F, (w >> 7) & 31, (w >> 12) & 7, (w >> 15) & 31, (w >> 20) & 31, w >> 25
+            assert f[0] == PC_BASE + 4 * k
+            sext = lambda v, bits: v - (1 << bits) if v >> (bits - 1) else v   # noqa: E731
+            if opc == 0x33:
+                assert f[3:6] == [rd, rs1, rs2] and f[9:12] == [1, 1, 0] and f[12] == (rd != 0)
+                exp = {(0, 0): (0, 0), (0x20, 0): (0, 1), (0, 4): (0, 2), (0, 6): (0, 3), (0, 7): (0, 4), (0, 2): (1, 0), (0, 3): (1, 1), (0, 1): (5, 0),
+                       (0, 5): (5, 1), (0x20, 5): (5, 2), (1, 0): (2, 0), (1, 1): (3, 0), (1, 2): (3, 1), (1, 3): (3, 2), (1, 4): (4, 0), (1, 5): (4, 1),
+                       (1, 6): (4, 2), (1, 7): (4, 3)}[(f7, f3)]
+                assert tuple(f[1:3]) == exp
+            elif opc == 0x13:
+                imm = sext(w >> 20, 12) & 0xFFFFFFFF
+                if f3 in (1, 5):
+                    assert f[1] == 5 and f[6:8] == [rs2, 0] and f[16] == 1
+                else:
+                    assert f[6:8] == [imm & 0xFFFF, imm >> 16]
+                assert f[9:12] == [1, 0, 1]
+            elif opc == 0x63:
+                off = sext(((w >> 31) << 12) | (((w >> 7) & 1) << 11) | (((w >> 25) & 63) << 5) | (((w >> 8) & 15) << 1), 13)
+                assert f[8] == off % v2.P and f[9:13] == [1, 1, 0, 0] and f[1] == (6 if f3 < 2 else 7)
+            elif opc in (0x03, 0x23):
+                assert f[1] == 11 and f[15] == 1
+            elif opc == 0x73:
+                assert f[1] == 12 and f[3:6] == [10, 17, 10]

@@ -1,0 +1,268 @@
+"""CPU twins of the one-statement VM circuit's trace generators (include/zkhip_vm_circuit.hpp, zkvm-prover_amd/csrc/vm_chips.hip):
+the segment records the C++ executor dumps (`prove_cli dump-segments`) -> the 23 traces, in numpy and through the oracle's
+existing core-chip generators.  TEST INFRASTRUCTURE.  The AIR programs themselves come from the library (zkhip_vm_air): they have
+ONE definition, the C++ one."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import oracle_lib as ora
+import zkvm_prover_amd as z
+from zkvm_prover_amd import _binding as zb
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
+P = ora.P
+NOPV = np.zeros(0, np.uint32)
+(A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_ACCESS, A_LEAF,
+ A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, N_AIRS) = range(24)
+PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, ACCESS_WIDTH, LEAF_WIDTH, MERKLE_WIDTH = 17, 34, 45, 21, 11, 47, 54
+TS_STEP = 16
+SX, SY = 256, 2048
+
+
+def vm_airs():
+    """[(program, width, n_pvs, prep_width)] of the segment's AIR set, from the library."""
+    lib = z.load_library()
+    lib.zkhip_vm_n_airs.restype = C.c_size_t
+    lib.zkhip_vm_air.restype = C.c_int
+    lib.zkhip_vm_air.argtypes = [C.c_uint, C.POINTER(zb._Air), C.POINTER(C.c_size_t)]
+    out = []
+    for i in range(lib.zkhip_vm_n_airs()):
+        a, pw = zb._Air(), C.c_size_t()
+        assert lib.zkhip_vm_air(i, C.byref(a), C.byref(pw)) == 0
+        out.append((np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width), int(a.n_pvs), int(pw.value)))
+    return out
+
+
+def program_table(words, pc_base, log_program):
+    lib = z.load_library()
+    lib.zkhip_vm_program_table.restype = C.c_int
+    lib.zkhip_vm_program_table.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_uint32, C.c_uint, C.POINTER(C.c_uint32)]
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    out = np.zeros((PROGRAM_FIELDS, 1 << log_program), np.uint32)
+    assert lib.zkhip_vm_program_table(zb._u32p(w), w.size, pc_base, log_program, zb._u32p(out)) == 0
+    return out
+
+
+def dump_segments(tmp, exe_bytes, stdin, log_frame):
+    """Runs the C++ segmenting executor; returns (info json, heights, [segment record dicts], image root, pv openings)."""
+    import json
+
+    d = str(tmp)
+    open(os.path.join(d, "exe.bin"), "wb").write(exe_bytes)
+    open(os.path.join(d, "stdin.bin"), "wb").write(stdin)
+    r = subprocess.run([CLI, "dump-segments", os.path.join(d, "exe.bin"), os.path.join(d, "stdin.bin"), d, str(log_frame)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    heights = np.fromfile(os.path.join(d, "heights.u32"), dtype=np.uint32).tolist()
+    segs = []
+    for k in range(info["segments"]):
+        sd = os.path.join(d, "seg-%d" % k)
+        segs.append({f[:-4]: np.fromfile(os.path.join(sd, f), dtype=np.uint32) for f in os.listdir(sd) if f.endswith(".u32")})
+    extra = np.fromfile(os.path.join(d, "image_root_and_pv_openings.u32"), dtype=np.uint32)
+    return info, heights, segs, extra[:8], extra[8:]
+
+
+def _bytes4(v):
+    v = np.asarray(v, dtype=np.uint32)
+    return [(v >> (8 * i)) & 255 for i in range(4)]
+
+
+def frame_trace(rec, prog, log_height):
+    n, N = len(rec["pc_index"]), 1 << log_height
+    t = np.zeros((FRAME_WIDTH, N), np.uint32)
+    k = rec["pc_index"].astype(np.int64)
+    t[0, :n] = prog[0][k]
+    t[1, :n] = 1 + TS_STEP * np.arange(n)
+    for q in range(1, PROGRAM_FIELDS):
+        t[1 + q, :n] = prog[q][k]
+    for base, name in ((18, "f_x"), (22, "f_y"), (26, "f_z")):
+        for i, b in enumerate(_bytes4(rec[name])):
+            t[base + i, :n] = b
+    t[30, :n], t[31, :n] = rec["f_rdprev"] & 0xFFFF, rec["f_rdprev"] >> 16
+    t[32, :n], t[33, :n] = rec["f_pcinc"], 1
+    return t
+
+
+def loadstore_trace(rec, log_height, rc):
+    core, rc, bad = ora.rv32_loadstore_trace(rec["ls_case"], rec["ls_read"], rec["ls_prev"], log_height, range_counts=rc)
+    assert bad == 0
+    n, N = len(rec["ls_case"]), 1 << log_height
+    t = np.zeros((LS_WIDTH, N), np.uint32)
+    t[:33] = core
+    base, imm = rec["ls_base"].astype(np.int64), rec["ls_imm"].astype(np.int64)
+    lo = (base & 0xFFFF) + (imm & 0xFFFF)
+    hi = (base >> 16) + (imm >> 16) + (lo >> 16)
+    t[33, :n] = rec["ls_ts"]
+    for i, b in enumerate(_bytes4(rec["ls_base"])):
+        t[34 + i, :n] = b
+    t[38, :n], t[39, :n] = imm & 0xFFFF, imm >> 16
+    t[40, :n], t[41, :n], t[42, :n], t[43, :n] = lo & 0xFFFF, hi & 0xFFFF, lo >> 16, hi >> 16
+    t[44, :n] = (lo & 0xFFFF) >> 2
+    return t, rc
+
+
+def rows_trace(rows, width, log_height, pad=None):
+    rows = np.asarray(rows, dtype=np.uint32).reshape(-1, width)
+    t = np.zeros((width, 1 << log_height), np.uint32)
+    if pad is not None:
+        t[:] = np.asarray(pad, dtype=np.uint32).reshape(-1, 1)
+    t[:, :len(rows)] = rows.T
+    return t
+
+
+def segment_instance(rec, words, pc_base, heights):
+    """The 23 AIR dicts (program, shapes, trace, pvs[, prep]) of one segment, traces from the CPU twins."""
+    H = heights
+    shapes = vm_airs()
+    prog = program_table(words, pc_base, H[A_PROGRAM])
+    tr = [None] * N_AIRS
+    freq, bad = ora.program_freq_trace(rec["pc_index"], H[A_PROGRAM])
+    assert bad == 0
+    tr[A_PROGRAM] = freq.reshape(1, -1)
+    tr[A_FRAME] = frame_trace(rec, prog, H[A_FRAME])
+    tr[A_ALU], xc, _ = ora.rv32_alu_trace(rec["alu_op"], rec["alu_b"], rec["alu_c"], H[A_ALU])
+    tr[A_LT], rc, _ = ora.rv32_lt_trace(rec["lt_op"], rec["lt_b"], rec["lt_c"], H[A_LT])
+    tr[A_MUL], tc = ora.rv32_mul_trace(rec["mul_b"], rec["mul_c"], H[A_MUL], SX, SY)
+    tr[A_SHIFT], rc, xc, _ = ora.rv32_shift_trace(rec["shift_op"], rec["shift_b"], rec["shift_c"], H[A_SHIFT], range_counts=rc, xor_counts=xc)
+    tr[A_MULH], tc, rc, _ = ora.rv32_mulh_trace(rec["mulh_op"], rec["mulh_b"], rec["mulh_c"], H[A_MULH], SX, SY, tuple_counts=tc, range_counts=rc)
+    tr[A_DIVREM], tc, rc, _ = ora.rv32_divrem_trace(rec["div_op"], rec["div_b"], rec["div_c"], H[A_DIVREM], SX, SY, tuple_counts=tc, range_counts=rc)
+    tr[A_BEQ], _ = ora.rv32_branch_eq_trace(rec["beq_op"], rec["beq_a"], rec["beq_b"], rec["beq_imm"], H[A_BEQ])
+    tr[A_BLT], rc, _ = ora.rv32_branch_lt_trace(rec["blt_op"], rec["blt_a"], rec["blt_b"], rec["blt_imm"], H[A_BLT], range_counts=rc)
+    tr[A_JAL_LUI], rc, _ = ora.rv32_jal_lui_trace(rec["jal_op"], rec["jal_pc"], rec["jal_imm"], H[A_JAL_LUI], range_counts=rc)
+    tr[A_AUIPC], rc, _ = ora.rv32_auipc_trace(rec["auipc_pc"], rec["auipc_imm"], H[A_AUIPC], range_counts=rc)
+    tr[A_JALR], rc, _ = ora.rv32_jalr_trace(rec["jalr_pc"], rec["jalr_rs1"], rec["jalr_imm"], H[A_JALR], range_counts=rc)
+    tr[A_LS], rc = loadstore_trace(rec, H[A_LS], rc)
+    tr[A_ECALL] = rows_trace(rec["ecall_rows"], ECALL_WIDTH, H[A_ECALL])
+    leaf_pad = np.zeros(LEAF_WIDTH, np.uint32)
+    leaf_pad[0] = 1
+    tr[A_LEAF] = rows_trace(rec["leaf_rows"], LEAF_WIDTH, H[A_LEAF], leaf_pad)
+    tr[A_MERKLE] = rows_trace(rec["merkle_rows"], MERKLE_WIDTH, H[A_MERKLE])
+    p2in = rec["p2_inputs"].reshape(-1, 16)
+    p2 = np.zeros((299, 1 << H[A_POSEIDON2]), np.uint32)
+    p2[:298] = ora.poseidon2_air_trace(p2in, H[A_POSEIDON2])
+    p2[298, :len(p2in)] = 1
+    tr[A_POSEIDON2] = p2
+    meta = rec["meta"]
+    pc_start, pc_end, ts_end, n_instr = (int(x) for x in meta[:4])
+    tr[A_CONNECTOR] = np.array([[ts_end & 0xFFFF], [ts_end >> 16]], np.uint32)
+    order = ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read")
+    acc10, bad = ora.memory_access_trace(*[rec["acc_" + k] for k in order], H[A_ACCESS])
+    assert bad == 0
+    acc = np.zeros((ACCESS_WIDTH, 1 << H[A_ACCESS]), np.uint32)
+    acc[:10] = acc10
+    acc[10] = (acc10[9].astype(np.int64) * 8) % P
+    tr[A_ACCESS] = acc
+    # lookup multiplicities of the new chips
+    rc = rc.astype(np.int64)
+    n, nls, nacc = n_instr, len(rec["ls_case"]), len(rec["acc_ts"])
+    fr, ls = tr[A_FRAME].astype(np.int64), tr[A_LS].astype(np.int64)
+    for q in (18, 20, 22, 24):
+        rc += np.bincount(fr[q][:n] * 256 + fr[q + 1][:n], minlength=1 << 16)
+    for q in (0, 2, 4, 6):
+        rc += np.bincount(ls[q][:nls] * 256 + ls[q + 1][:nls], minlength=1 << 16)
+    cnt = np.zeros(1 << 16, np.int64)
+    for q in (8, 9, 4, 10):
+        cnt += np.bincount(acc[q][:nacc].astype(np.int64), minlength=1 << 16)
+    for q, s in ((40, 1), (41, 4), (44, 4), (44, 1), (41, 1)):
+        cnt += np.bincount(ls[q][:nls] * s, minlength=1 << 16)
+    misc = [ts_end & 0xFFFF, 8 * (ts_end >> 16), ts_end >> 16]
+    for row in rec["ecall_rows"].reshape(-1, ECALL_WIDTH):
+        if row[15]:
+            misc += [int(row[17]) * 8192, int(row[17])]
+    for row in rec["leaf_rows"].reshape(-1, LEAF_WIDTH):
+        misc += [int(row[43]), int(row[44]) * 16, int(row[44]), int(row[45]), int(row[46]) * 64, int(row[46])]
+    cnt += np.bincount(np.array(misc, dtype=np.int64), minlength=1 << 16)
+    tr[A_BITWISE] = np.stack([(rc % P).astype(np.uint32), xc])
+    tr[A_RANGE_TUPLE] = tc.reshape(1, -1)
+    tr[A_RANGE] = (cnt % P).astype(np.uint32).reshape(1, -1)
+    from zkvm_prover_amd import air
+
+    preps = {A_PROGRAM: prog, A_BITWISE: air.bitwise_lookup_prep(8), A_RANGE_TUPLE: air.range_tuple_prep(SX, SY),
+             A_RANGE: np.arange(1 << 16, dtype=np.uint32).reshape(1, -1)}
+    pvs = {A_MERKLE: np.concatenate([meta[4:12], meta[12:20]]).astype(np.uint32), A_CONNECTOR: np.array([pc_start, pc_end], np.uint32)}
+    out = []
+    for a, (program, width, n_pvs, pw) in enumerate(shapes):
+        d = dict(program=program, log_height=H[a], width=width, n_pvs=n_pvs, trace=tr[a], pvs=pvs.get(a, NOPV))
+        assert tr[a].shape == (width, 1 << H[a]), (a, tr[a].shape, width, H[a])
+        if pw:
+            d["prep"] = preps[a]
+        out.append(d)
+    return out
+
+
+# ---- exact bus accounting (what the LogUp argument enforces cryptographically): per bus, the multiset of sent messages equals the
+# ---- multiset of received ones -------------------------------------------------------------------------------------------------
+def _eval_nodes(program, trace, pvs, prep):
+    from zkvm_prover_amd import air
+
+    w = [int(x) for x in program]
+    n_nodes, n_cons = w[1], w[2]
+    nodes = [tuple(w[4 + 3 * i: 7 + 3 * i]) for i in range(n_nodes)]
+    n = trace.shape[1]
+    t = trace.astype(np.int64)
+    pt = None if prep is None else np.asarray(prep).astype(np.int64)
+    vals = [None] * n_nodes
+    for i, (op, a, b) in enumerate(nodes):
+        if op == air.OP_VAR:
+            vals[i] = np.roll(t[a], -1) if b else t[a]
+        elif op == air.OP_PREP:
+            vals[i] = np.roll(pt[a], -1) if b else pt[a]
+        elif op == air.OP_PUB:
+            vals[i] = np.full(n, int(pvs[a]), dtype=np.int64)
+        elif op == air.OP_CONST:
+            vals[i] = np.full(n, a, dtype=np.int64)
+        elif op in (air.OP_ADD, air.OP_SUB, air.OP_MUL):
+            x, y = vals[a], vals[b]
+            if x is None or y is None:
+                continue
+            vals[i] = (x + y) % P if op == air.OP_ADD else (x - y) % P if op == air.OP_SUB else (x * y) % P
+        elif op == air.OP_NEG:
+            vals[i] = None if vals[a] is None else (-vals[a]) % P
+    pos = 4 + 3 * n_nodes + n_cons
+    if pos + 2 <= len(w) and w[pos] == air.PREP_MAGIC:
+        pos += 2
+    if pos + 2 <= len(w) and w[pos] == air.CACHED_MAGIC:
+        pos += 2
+    ints = []
+    if pos < len(w):
+        assert w[pos] == air.LOGUP_MAGIC
+        n_int = w[pos + 1]
+        pos += 2
+        for _ in range(n_int):
+            bus, sign, count, nf = w[pos:pos + 4]
+            fields = w[pos + 4:pos + 4 + nf]
+            pos += 4 + nf + 1
+            ints.append((bus, sign, count, fields))
+    return vals, ints
+
+
+def bus_imbalance(instance):
+    """{bus: number of distinct messages whose sends and receives do not cancel (mod p)}; {} = every bus balances."""
+    per_bus = {}
+    for d in instance:
+        vals, ints = _eval_nodes(d["program"], d["trace"], d["pvs"], d.get("prep"))
+        for bus, sign, count, fields in ints:
+            c = vals[count]
+            nz = np.nonzero(c)[0]
+            if not len(nz):
+                continue
+            msg = np.stack([vals[f][nz] for f in fields], axis=1)
+            cnt = c[nz] if sign == 0 else (-c[nz]) % P
+            per_bus.setdefault(bus, []).append((msg, cnt))
+    bad = {}
+    for bus, parts in per_bus.items():
+        width = max(m.shape[1] for m, _ in parts)
+        assert all(m.shape[1] == width for m, _ in parts), "bus %d carries messages of different lengths" % bus
+        msg = np.concatenate([m for m, _ in parts])
+        cnt = np.concatenate([c for _, c in parts])
+        uniq, inv = np.unique(msg, axis=0, return_inverse=True)
+        tot = np.zeros(len(uniq), dtype=np.int64)
+        np.add.at(tot, inv.reshape(-1), cnt)
+        n_bad = int(np.count_nonzero(tot % P))
+        if n_bad:
+            bad[bus] = n_bad
+    return bad

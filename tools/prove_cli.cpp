@@ -10,6 +10,7 @@
 #include <iostream>
 
 #include "zkhip_aggregation.hpp"
+#include "zkhip_vm_flow.hpp"
 #include "zkhip_vm_prover.hpp"
 
 using namespace scroll_zkvm_hip;
@@ -43,6 +44,107 @@ static ProvingTask read_task(const std::string& path) {
 
 int main(int argc, char** argv) {
     try {
+        if (argc >= 6 && std::string(argv[1]) == "dump-segments") {
+            // dump-segments <guest.elf | exe.bin> <stdin.bin | -> <out_dir> <log_frame>: the segmenting executor's records (include/zkhip_vm_exec.hpp)
+            // as raw u32 arrays, one directory per segment -- what the tests' CPU twins of the trace generators read
+            const std::vector<uint8_t> raw = slurp(argv[2]);
+            zkhip_vm::StdIn in;
+            if (std::string(argv[3]) != "-") in.bytes = slurp(argv[3]);
+            try {
+                const zkhip_vm::Exe exe = zkhip_vm::parse_exe(raw);
+                const zkhip_vm::SegmentCaps caps = zkhip_vm::SegmentCaps::for_frame((unsigned)atoi(argv[5]), zkhip_vm::vm_log2_ceil(exe.program.size()));
+                zkhip_vm::SegmentExecutor ex(exe, in, caps);
+                zkhip_vm::SegmentRecords r;
+                size_t k = 0;
+                std::string roots;
+                auto put = [](const std::string& path, const std::vector<uint32_t>& v) {
+                    std::ofstream f(path, std::ios::binary);
+                    f.write((const char*)v.data(), (std::streamsize)(v.size() * 4));
+                };
+                for (bool done = false; !done; k++) {
+                    done = ex.run_segment(r);
+                    const std::string d = std::string(argv[4]) + "/seg-" + std::to_string(k);
+                    if (system(("mkdir -p '" + d + "'").c_str()) != 0) throw Error(Error::Io, "cannot create " + d);
+                    const zkhip_vm::ExecRecords& c = r.core;
+#define PUT(name, vec) put(d + "/" name ".u32", vec)
+                    PUT("pc_index", c.pc_index), PUT("alu_op", c.alu_op), PUT("alu_b", c.alu_b), PUT("alu_c", c.alu_c), PUT("lt_op", c.lt_op), PUT("lt_b", c.lt_b), PUT("lt_c", c.lt_c);
+                    PUT("mul_b", c.mul_b), PUT("mul_c", c.mul_c), PUT("mulh_op", c.mulh_op), PUT("mulh_b", c.mulh_b), PUT("mulh_c", c.mulh_c);
+                    PUT("div_op", c.div_op), PUT("div_b", c.div_b), PUT("div_c", c.div_c), PUT("shift_op", c.shift_op), PUT("shift_b", c.shift_b), PUT("shift_c", c.shift_c);
+                    PUT("beq_op", c.beq_op), PUT("beq_a", c.beq_a), PUT("beq_b", c.beq_b), PUT("beq_imm", c.beq_imm), PUT("blt_op", c.blt_op), PUT("blt_a", c.blt_a), PUT("blt_b", c.blt_b), PUT("blt_imm", c.blt_imm);
+                    PUT("jal_op", c.jal_op), PUT("jal_pc", c.jal_pc), PUT("jal_imm", c.jal_imm), PUT("auipc_pc", c.auipc_pc), PUT("auipc_imm", c.auipc_imm);
+                    PUT("jalr_pc", c.jalr_pc), PUT("jalr_rs1", c.jalr_rs1), PUT("jalr_imm", c.jalr_imm), PUT("ls_case", c.ls_case), PUT("ls_read", c.ls_read), PUT("ls_prev", c.ls_prev);
+                    PUT("f_x", r.f_x), PUT("f_y", r.f_y), PUT("f_z", r.f_z), PUT("f_rdprev", r.f_rdprev), PUT("f_pcinc", r.f_pcinc), PUT("ls_ts", r.ls_ts), PUT("ls_base", r.ls_base), PUT("ls_imm", r.ls_imm);
+                    PUT("ecall_rows", r.ecall_rows), PUT("leaf_rows", r.leaf_rows), PUT("merkle_rows", r.merkle_rows), PUT("p2_inputs", r.p2_inputs);
+                    PUT("acc_as", r.acc_as), PUT("acc_ptr", r.acc_ptr), PUT("acc_prev_data", r.acc_prev_data), PUT("acc_prev_ts", r.acc_prev_ts), PUT("acc_data", r.acc_data), PUT("acc_ts", r.acc_ts), PUT("acc_is_read", r.acc_is_read);
+#undef PUT
+                    std::vector<uint32_t> meta{r.pc_start, r.pc_end, r.ts_end, (uint32_t)r.n_instr};
+                    meta.insert(meta.end(), r.root_init.begin(), r.root_init.end());
+                    meta.insert(meta.end(), r.root_final.begin(), r.root_final.end());
+                    put(d + "/meta.u32", meta);
+                }
+                std::vector<uint32_t> heights(caps.log_height, caps.log_height + zkhip::vmc::N_AIRS);
+                put(std::string(argv[4]) + "/heights.u32", heights);
+                std::vector<uint32_t> fin(ex.image_root().begin(), ex.image_root().end());
+                const std::vector<uint32_t> op = zkhip_vm::open_public_values(ex.tree());
+                fin.insert(fin.end(), op.begin(), op.end());
+                put(std::string(argv[4]) + "/image_root_and_pv_openings.u32", fin);
+                std::printf("{\"segments\": %zu, \"total_cycle\": %llu, \"public_values\": \"", k, (unsigned long long)ex.instret());
+                for (uint8_t b : ex.public_values()) std::printf("%02x", b);
+                std::printf("\"}\n");
+            } catch (const zkhip_vm::Error& e) {
+                throw Error(Error::GenProof, e.what());
+            }
+            return 0;
+        }
+        if (argc >= 5 && std::string(argv[1]) == "prove-elf") {
+            // prove-elf <guest.elf | exe.bin> <stdin.bin | -> <out_dir> [openvm.toml | -] [log_frame]: ONE FLOW (include/zkhip_vm_flow.hpp):
+            // execute -> segments (one statement each) -> aggregation tree -> root.json + root.vk; prints a JSON line
+            const std::vector<uint8_t> raw = slurp(argv[2]);
+            zkhip_vm::StdIn in;
+            if (std::string(argv[3]) != "-") in.bytes = slurp(argv[3]);
+            zkhip_params params{1, 0, 100, 16, 16};
+            if (argc >= 6 && std::string(argv[5]) != "-") params = read_app_config(argv[5]);
+            const unsigned log_frame = argc >= 7 ? (unsigned)atoi(argv[6]) : 17;
+            try {
+                const zkhip_vm::Exe exe = zkhip_vm::parse_exe(raw);
+                const auto t0 = std::chrono::steady_clock::now();
+                const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, exe, in, log_frame, 0, true);
+                const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                std::string why;
+                if (!zkhip_vm::verify_guest_proof(g.root_vk, g.root, g.entry_pc, g.image_root, g.exec.public_values, g.pv_openings, &why))
+                    throw Error(Error::VerifyProof, "failed to verify proof: " + why);   // the mandatory self-check (mod.rs:407-411)
+                StarkProof sp = AggregationProver::to_stark_proof(g.root, g.root_vk);
+                // user_pvs_proof (crates/types/src/proof.rs:52-67): the public values and their Merkle openings in the final memory root
+                sp.user_pvs_proof = g.exec.public_values;
+                const uint8_t* ob = reinterpret_cast<const uint8_t*>(g.pv_openings.data());
+                sp.user_pvs_proof.insert(sp.user_pvs_proof.end(), ob, ob + 4 * g.pv_openings.size());
+                const uint8_t* nb = reinterpret_cast<const uint8_t*>(g.root.pvs[2].data());
+                sp.deferral_merkle_proofs.assign(nb, nb + 4 * g.root.pvs[2].size());   // the root node's public values (its statement)
+                sp.stat.total_cycles = g.exec.total_cycle, sp.stat.execution_time_mills = g.execution_mills;
+                sp.stat.proving_time_mills = g.segment_proving_mills + g.aggregation_mills;
+                const std::string dir = argv[4];
+                std::ofstream(dir + "/root.json") << sp.to_json();
+                const std::vector<uint8_t> vkb = g.root_vk.to_app_exe();
+                std::ofstream(dir + "/root.vk", std::ios::binary).write((const char*)vkb.data(), (std::streamsize)vkb.size());
+                for (size_t k = 0; k < g.segment_proofs.size(); k++) {
+                    StarkProof s2;
+                    s2.proof = g.segment_proofs[k].proof.proof;
+                    for (const auto& p : g.segment_proofs[k].proof.pvs) {
+                        const uint8_t* b = reinterpret_cast<const uint8_t*>(p.data());
+                        s2.user_pvs_proof.insert(s2.user_pvs_proof.end(), b, b + 4 * p.size());
+                    }
+                    s2.stat.total_cycles = g.segment_proofs[k].n_instr, s2.stat.proving_time_mills = g.segment_proofs[k].proving_mills;
+                    std::ofstream(dir + "/segment-" + std::to_string(k) + ".json") << s2.to_json();
+                }
+                std::printf("{\"total_cycles\": %llu, \"segments\": %zu, \"levels\": %zu, \"execution_ms\": %llu, \"segment_tracegen_and_proving_ms\": %llu, "
+                            "\"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, \"verified\": true}\n",
+                            (unsigned long long)g.exec.total_cycle, g.segments, g.levels, (unsigned long long)g.execution_mills,
+                            (unsigned long long)g.segment_proving_mills, (unsigned long long)g.aggregation_mills, wall, g.root.proof.size());
+            } catch (const zkhip_vm::Error& e) {
+                throw Error(Error::GenProof, e.what());
+            }
+            return 0;
+        }
         if (argc >= 5 && std::string(argv[1]) == "prove-guest") {
             // prove-guest <guest.elf | exe.bin> <stdin.bin | -> <out.json> [openvm.toml] [max_cost]: the whole gen_proof_stark flow
             // (mod.rs:342-413) from a guest image: execute, generate the chips' traces on the device, prove, self-verify

@@ -163,6 +163,16 @@ def load_library():
         "zkhip_proof_from_v1": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(C.c_uint8), sz,
                                           C.POINTER(C.c_uint8), sz, C.POINTER(sz), C.POINTER(u32p)]),
         "zkhip_proof_layout_of": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(_ProofLayout)]),
+        "zkhip_vm_n_airs": (sz, []),
+        "zkhip_vm_air": (C.c_int, [C.c_uint, C.POINTER(_Air), C.POINTER(sz)]),
+        "zkhip_vm_decode": (C.c_int, [C.c_uint32, C.c_uint32, u32p, C.POINTER(C.c_int)]),
+        "zkhip_vm_program_table": (C.c_int, [u32p, sz, C.c_uint32, C.c_uint, u32p]),
+        "zkhip_vm_frame_tracegen": (C.c_int, [vp] * 7 + [sz, vp, sz, C.c_uint, vp]),
+        "zkhip_vm_loadstore_tracegen": (C.c_int, [vp] * 7 + [sz, C.c_uint, vp, vp]),
+        "zkhip_vm_access_tracegen": (C.c_int, [vp] * 8 + [sz, C.c_uint, vp]),
+        "zkhip_vm_poseidon2_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
+        "zkhip_rows_tracegen": (C.c_int, [vp, vp, sz, sz, C.c_uint, vp, u32p]),
+        "zkhip_range_counts_scaled_tracegen": (C.c_int, [vp, vp, sz, C.c_uint32, C.c_uint, vp, C.c_int]),
         "zkhip_recursion_build": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, sz, C.POINTER(_RecursionStmt), C.POINTER(vp)]),
         "zkhip_recursion_destroy": (None, [vp]),
         "zkhip_recursion_last_error": (C.c_char_p, [vp]),
@@ -562,6 +572,47 @@ class Context:
                                                             C.c_void_p(t_ts.data_ptr()), t_as.numel(), as_bits, pointer_bits, log_height,
                                                             C.c_void_p(out.data_ptr())))
         return out
+
+    # ---- the one-statement VM circuit (include/zkhip_vm_circuit.hpp): generators of the adapter-side chips ----
+    def _new(self, words):
+        import torch
+
+        return torch.empty(words, dtype=torch.int32, device=self.device)
+
+    def vm_frame_tracegen(self, t_idx, t_x, t_y, t_z, t_rdprev, t_pcinc, t_program, n_program, log_height):
+        out = self._new(34 << log_height)
+        self._check(self.lib.zkhip_vm_frame_tracegen(self.h, t_idx.data_ptr(), t_x.data_ptr(), t_y.data_ptr(), t_z.data_ptr(), t_rdprev.data_ptr(),
+                                                     t_pcinc.data_ptr(), t_idx.numel(), t_program.data_ptr(), n_program, log_height, out.data_ptr()))
+        return out
+
+    def vm_loadstore_tracegen(self, t_case, t_read, t_prev, t_ts, t_base, t_imm, log_height, t_bitwise_trace):
+        out = self._new(45 << log_height)
+        self._check(self.lib.zkhip_vm_loadstore_tracegen(self.h, t_case.data_ptr(), t_read.data_ptr(), t_prev.data_ptr(), t_ts.data_ptr(), t_base.data_ptr(),
+                                                         t_imm.data_ptr(), t_case.numel(), log_height, out.data_ptr(), t_bitwise_trace.data_ptr()))
+        return out
+
+    def vm_access_tracegen(self, t_as, t_ptr, t_prev_data, t_prev_ts, t_data, t_ts, t_is_read, log_height):
+        out = self._new(11 << log_height)
+        self._check(self.lib.zkhip_vm_access_tracegen(self.h, t_as.data_ptr(), t_ptr.data_ptr(), t_prev_data.data_ptr(), t_prev_ts.data_ptr(), t_data.data_ptr(),
+                                                      t_ts.data_ptr(), t_is_read.data_ptr(), t_as.numel(), log_height, out.data_ptr()))
+        return out
+
+    def vm_poseidon2_tracegen(self, t_inputs_monty, n, log_height):
+        out = self._new(299 << log_height)
+        self._check(self.lib.zkhip_vm_poseidon2_tracegen(self.h, t_inputs_monty.data_ptr() if n else None, n, log_height, out.data_ptr()))
+        return out
+
+    def rows_tracegen(self, t_rows, n, width, log_height, pad_row=None):
+        out = self._new(width << log_height)
+        pad = None if pad_row is None else np.ascontiguousarray(pad_row, dtype=np.uint32)
+        self._check(self.lib.zkhip_rows_tracegen(self.h, t_rows.data_ptr() if n else None, n, width, log_height, out.data_ptr(),
+                                                 _u32p(pad) if pad is not None else None))
+        return out
+
+    def range_counts_scaled_tracegen(self, t_values, scale, log_table, t_counts, accumulate=True):
+        self._check(self.lib.zkhip_range_counts_scaled_tracegen(self.h, t_values.data_ptr(), t_values.numel(), scale, log_table, t_counts.data_ptr(),
+                                                                1 if accumulate else 0))
+        return t_counts
 
     def merkle_commit(self, mats, want_root=True):
         """mats: list of (tensor, log_height, width[, stride])."""

@@ -1,0 +1,274 @@
+// vm_chips.hip -- the one-statement VM circuit on the device and across the ABI (include/zkhip_vm_circuit.hpp):
+//   * zkhip_vm_air / zkhip_vm_program_table / zkhip_vm_decode: the segment's AIR set (programs built once, by the C++ definitions --
+//     there is no second definition of these chips anywhere), its decode and program table;
+//   * trace generators of the new chips: frame (gathers the program row of every executed instruction and splits operands into
+//     bytes), the load/store adapter columns, the memory-access chip with its bounded gap, the Poseidon2 chip with multiplicities,
+//     and a transposer for the small chips whose rows the segmenting executor writes itself (ecall, leaf, merkle, connector);
+//   * range-table multiplicities of scaled columns (requests like 4 * addr_hi).
+// Replaces, for this backend, the trace generation of OpenVM's adapter / connector / persistent-memory chips (un-vendored;
+// AGENTS.md:183-187 says the reference's GPU backend fills chip traces on the device).
+#include <algorithm>
+#include <mutex>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/zkhip.h"
+#include "../../include/zkhip_vm_circuit.hpp"
+#include "babybear.hpp"
+#include "hist.hpp"
+#include "zkhip_internal.hpp"
+
+namespace zk {
+int poseidon2_air_tracegen(zkhip_ctx* ctx, const uint32_t* d_inputs, size_t n_perms, unsigned log_height, uint32_t* d_trace);
+namespace {
+
+namespace vmc = zkhip::vmc;
+
+std::once_flag g_airs_once;
+vmc::AirShape g_airs[vmc::N_AIRS];
+
+__global__ __launch_bounds__(256) void k_vm_frame(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+                                                  const uint32_t* __restrict__ zs, const uint32_t* __restrict__ rdp, const uint32_t* __restrict__ pcinc,
+                                                  size_t n, const uint32_t* __restrict__ program, size_t n_program, size_t N,
+                                                  uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t k = 0;
+    const bool valid = r < n && (k = idx[r]) < n_program;
+    if (r < n && !valid) atomicAdd(bad, 1u);
+    uint32_t col[vmc::FRAME_WIDTH];
+#pragma unroll
+    for (unsigned q = 0; q < vmc::FRAME_WIDTH; q++) col[q] = 0;
+    if (valid) {
+        col[0] = program[k];                                             // pc
+        col[1] = to_monty(1u + vmc::TS_STEP * (uint32_t)r);              // timestamp of the instruction's first slot
+#pragma unroll
+        for (unsigned q = 1; q < vmc::PROGRAM_FIELDS; q++) col[1 + q] = program[(size_t)q * n_program + k];
+        const uint32_t x = xs[r], y = ys[r], z = zs[r], p = rdp[r];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            col[18 + i] = to_monty((x >> (8 * i)) & 255u), col[22 + i] = to_monty((y >> (8 * i)) & 255u), col[26 + i] = to_monty((z >> (8 * i)) & 255u);
+        }
+        col[30] = to_monty(p & 0xffffu), col[31] = to_monty(p >> 16);
+        const uint32_t inc = pcinc[r];
+        if (inc >= P) atomicAdd(bad, 1u);
+        col[32] = to_monty(inc % P), col[33] = MONTY_ONE;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < vmc::FRAME_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+
+// load/store adapter columns 33..44: ts | base[4] | imm_lo imm_hi | addr_lo addr_hi | carry0 carry1 | word_lo
+__global__ __launch_bounds__(256) void k_vm_ls_adapter(const uint32_t* __restrict__ tss, const uint32_t* __restrict__ bases, const uint32_t* __restrict__ imms,
+                                                       size_t n, size_t N, uint32_t* __restrict__ trace) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) col[q] = 0;
+    if (r < n) {
+        const uint32_t base = bases[r], imm = imms[r];
+        const uint32_t lo = (base & 0xffffu) + (imm & 0xffffu), c0 = lo >> 16;
+        const uint32_t hi = (base >> 16) + (imm >> 16) + c0, c1 = hi >> 16;
+        col[0] = to_monty(tss[r]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) col[1 + i] = to_monty((base >> (8 * i)) & 255u);
+        col[5] = to_monty(imm & 0xffffu), col[6] = to_monty(imm >> 16);
+        col[7] = to_monty(lo & 0xffffu), col[8] = to_monty(hi & 0xffffu), col[9] = to_monty(c0), col[10] = to_monty(c1);
+        col[11] = to_monty((lo & 0xffffu) >> 2);
+    }
+#pragma unroll
+    for (int q = 0; q < 12; q++) trace[(size_t)(33 + q) * N + r] = col[q];
+}
+
+__global__ __launch_bounds__(256) void k_col_scale(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n, uint32_t scale_monty) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = mmul(src[i], scale_monty);
+}
+
+__global__ __launch_bounds__(256) void k_fill_prefix(uint32_t* __restrict__ col, size_t n_ones, size_t N) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) col[i] = i < n_ones ? MONTY_ONE : 0u;
+}
+
+// rows (row-major, canonical) -> column-major Montgomery trace; rows >= n get the padding row
+__global__ __launch_bounds__(256) void k_rows_to_trace(const uint32_t* __restrict__ rows, size_t n, uint32_t width, size_t N, const uint32_t* __restrict__ pad,
+                                                       uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * width) return;
+    const size_t q = i / N, r = i % N;
+    uint32_t v = r < n ? rows[r * width + q] : (pad ? pad[q] : 0u);
+    if (v >= P) {
+        atomicAdd(bad, 1u);
+        v %= P;
+    }
+    trace[i] = to_monty(v);
+}
+
+__global__ void k_counts_repr(uint32_t* c, size_t n, int to_m) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) c[i] = to_m ? to_monty(c[i] % P) : from_monty(c[i]);
+}
+__global__ __launch_bounds__(256) void k_range_counts_scaled(const uint32_t* __restrict__ values, size_t n, uint32_t scale, uint32_t T,
+                                                             uint32_t* __restrict__ hist, uint32_t* __restrict__ bad) {
+    __shared__ uint32_t hk[HOT_SLOTS], hc[HOT_SLOTS];
+    hot_init(hk, hc);
+    uint32_t n_bad = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint64_t v = (uint64_t)from_monty(values[i]) * scale;
+        if (v >= T) {
+            n_bad++;
+            continue;
+        }
+        hot_add(hk, hc, hist, (uint32_t)v);
+    }
+    if (n_bad) atomicAdd(bad, n_bad);
+    hot_flush(hk, hc, hist);
+}
+
+int check_flag(zkhip_ctx* ctx, void* flag, const char* what) {
+    uint32_t h_bad = 0;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_bad) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": " + std::to_string(h_bad) + " bad records");
+    return ZKHIP_OK;
+}
+
+}  // namespace
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+size_t zkhip_vm_n_airs(void) { return vmc::N_AIRS; }
+
+int zkhip_vm_air(unsigned id, zkhip_air* out, size_t* prep_width) {
+    if (id >= vmc::N_AIRS || !out) return ZKHIP_ERR_INVALID;
+    try {
+        std::call_once(g_airs_once, [] {
+            for (unsigned i = 0; i < vmc::N_AIRS; i++) g_airs[i] = vmc::build_air(i);
+        });
+    } catch (const std::exception&) {
+        return ZKHIP_ERR_INVALID;
+    }
+    const vmc::AirShape& s = g_airs[id];
+    out->program = s.program.data(), out->program_len = s.program.size(), out->log_height = 0, out->width = s.width, out->n_pvs = s.n_pvs;
+    out->prep_trace = nullptr, out->prep_commit = nullptr;
+    if (prep_width) *prep_width = s.prep_width;
+    return ZKHIP_OK;
+}
+
+int zkhip_vm_decode(uint32_t word, uint32_t pc, uint32_t out[17], int* legal) {
+    if (!out) return ZKHIP_ERR_INVALID;
+    const vmc::Decoded d = vmc::decode(word, pc);
+    const auto f = d.fields();
+    for (size_t i = 0; i < vmc::PROGRAM_FIELDS; i++) out[i] = f[i];
+    if (legal) *legal = d.legal ? 1 : 0;
+    return ZKHIP_OK;
+}
+
+int zkhip_vm_program_table(const uint32_t* words, size_t n_words, uint32_t pc_base, unsigned log_program, uint32_t* out) {
+    if (!out || (n_words && !words) || log_program > 27 || n_words > ((size_t)1 << log_program)) return ZKHIP_ERR_INVALID;
+    const std::vector<uint32_t> t = vmc::program_table(std::vector<uint32_t>(words, words + n_words), pc_base, log_program);
+    memcpy(out, t.data(), t.size() * 4);
+    return ZKHIP_OK;
+}
+
+int zkhip_vm_frame_tracegen(zkhip_ctx* ctx, const uint32_t* d_pc_index, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_z,
+                            const uint32_t* d_rd_prev, const uint32_t* d_pc_inc, size_t n, const uint32_t* d_program, size_t n_program, unsigned log_height,
+                            uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_program || log_height > 25 || (n && (!d_pc_index || !d_x || !d_y || !d_z || !d_rd_prev || !d_pc_inc))) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "vm_frame_tracegen: more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "vm_frame_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_vm_frame, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_pc_index, d_x, d_y, d_z, d_rd_prev, d_pc_inc, n, d_program,
+                       n_program, N, d_trace, (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return check_flag(ctx, flag, "vm_frame_tracegen (instruction index beyond the program, or a pc step that is not a field element)");
+}
+
+int zkhip_vm_loadstore_tracegen(zkhip_ctx* ctx, const uint32_t* d_case, const uint32_t* d_read, const uint32_t* d_prev, const uint32_t* d_ts,
+                                const uint32_t* d_base, const uint32_t* d_imm, size_t n, unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 27 || (n && (!d_case || !d_read || !d_prev || !d_ts || !d_base || !d_imm))) return ZKHIP_ERR_INVALID;
+    // the core's 33 columns (same stride: they are the first 33 columns of this chip), then the adapter's
+    ZK_TRY(zkhip_rv32_loadstore_tracegen(ctx, d_case, d_read, d_prev, n, log_height, d_trace, d_bitwise_trace));
+    const size_t N = (size_t)1 << log_height;
+    KernelScope ks(ctx, "vm_loadstore_adapter_tracegen");
+    hipLaunchKernelGGL(k_vm_ls_adapter, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_ts, d_base, d_imm, n, N, d_trace);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+int zkhip_vm_access_tracegen(zkhip_ctx* ctx, const uint32_t* d_addr_space, const uint32_t* d_pointer, const uint32_t* d_prev_data, const uint32_t* d_prev_ts,
+                             const uint32_t* d_data, const uint32_t* d_ts, const uint32_t* d_is_read, size_t n, unsigned log_height, uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace) return ZKHIP_ERR_INVALID;
+    ZK_TRY(zkhip_memory_access_tracegen(ctx, d_addr_space, d_pointer, d_prev_data, d_prev_ts, d_data, d_ts, d_is_read, n, log_height, d_trace));
+    const size_t N = (size_t)1 << log_height;
+    KernelScope ks(ctx, "vm_access_gap_bound");
+    hipLaunchKernelGGL(k_col_scale, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_trace + 9 * N, d_trace + 10 * N, N, to_monty(8));
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+int zkhip_vm_poseidon2_tracegen(zkhip_ctx* ctx, const uint32_t* d_inputs, size_t n, unsigned log_height, uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || log_height > 27) return ZKHIP_ERR_INVALID;
+    ZK_TRY(poseidon2_air_tracegen(ctx, d_inputs, n, log_height, d_trace));
+    const size_t N = (size_t)1 << log_height;
+    KernelScope ks(ctx, "vm_poseidon2_multiplicities");
+    hipLaunchKernelGGL(k_fill_prefix, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_trace + (size_t)ZKHIP_POSEIDON2_AIR_WIDTH * N, n, N);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+int zkhip_rows_tracegen(zkhip_ctx* ctx, const uint32_t* d_rows, size_t n, size_t width, unsigned log_height, uint32_t* d_trace, const uint32_t* pad_row) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || width == 0 || width > 4096 || log_height > 27 || (n && !d_rows)) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rows_tracegen: more rows than the trace height");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16 + 4 * 4096, &flag));
+    uint32_t* d_pad = nullptr;
+    KernelScope ks(ctx, "rows_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    if (pad_row) {
+        d_pad = (uint32_t*)flag + 4;
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_pad, pad_row, width * 4, hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // pad_row may be a temporary of the caller
+    }
+    hipLaunchKernelGGL(k_rows_to_trace, dim3((unsigned)((N * width + 255) / 256)), dim3(256), 0, ctx->stream, d_rows, n, (uint32_t)width, N, d_pad, d_trace,
+                       (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return check_flag(ctx, flag, "rows_tracegen (a word is not a canonical field element)");
+}
+
+int zkhip_range_counts_scaled_tracegen(zkhip_ctx* ctx, const uint32_t* d_values, size_t n, uint32_t scale, unsigned log_table, uint32_t* d_counts,
+                                       int accumulate) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_counts || log_table > 27 || scale == 0 || (n && !d_values)) return ZKHIP_ERR_INVALID;
+    const size_t T = (size_t)1 << log_table;
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "range_counts_scaled_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const unsigned tb = (unsigned)((T + 255) / 256);
+    if (accumulate) hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
+    else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
+    if (n) {
+        const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), HOT_MAX_BLOCKS);
+        hipLaunchKernelGGL(k_range_counts_scaled, dim3(blocks), dim3(256), 0, ctx->stream, d_values, n, scale, (uint32_t)T, d_counts, (uint32_t*)flag);
+    }
+    hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return check_flag(ctx, flag, "range_counts_scaled_tracegen (scaled value outside the table)");
+}
+
+}  // extern "C"
