@@ -1,0 +1,156 @@
+"""GPU: the one-statement VM flow (include/zkhip_vm_flow.hpp).
+  * device trace generation of a segment == the CPU twins, cell for cell, for all 23 chips; the HIP proof == the oracle's, byte
+    for byte; tampered records (a wrong instruction result, swapped operands) give proofs the verifier refuses;
+  * `prove_cli prove-elf`: ELF + input bytes -> execution -> segment proofs -> aggregation tree -> ONE root proof, self-verified:
+    the root statement starts at the guest's entry pc on the guest image's memory root, ends at pc = 0, and the public values open
+    in the final root; segments that do not chain are refused by the aggregation circuit."""
+import json
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import zkvm_prover_amd as z
+
+import prover_mirror_util as pm
+import recursion_util as ru
+import rv32_model as rv
+import vm2_util as v2
+from test_vm_cpu import fib_program, mixed_program
+
+pytestmark = pytest.mark.gpu
+PARAMS = (1, 0, 4, 3, 3)
+PC_BASE = 0x00200000
+
+
+def device_traces(zk, rec, prog, H):
+    """The segment's traces through the device generators, as SegmentProver::prove drives them."""
+    dev = zk.device
+    D = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.uint32).view(np.int32)).to(dev)  # noqa: E731
+    T = [None] * v2.N_AIRS
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=dev)
+    d_tup = torch.zeros(1 << 19, dtype=torch.int32, device=dev)
+    d_prog = zk.upload(prog.reshape(-1))
+    idx = D(rec["pc_index"])
+    T[v2.A_PROGRAM] = zk.program_freq_tracegen(idx, H[v2.A_PROGRAM])
+    T[v2.A_FRAME] = zk.vm_frame_tracegen(idx, D(rec["f_x"]), D(rec["f_y"]), D(rec["f_z"]), D(rec["f_rdprev"]), D(rec["f_pcinc"]), d_prog,
+                                         1 << H[v2.A_PROGRAM], H[v2.A_FRAME])
+    T[v2.A_ALU] = zk.rv32_alu_tracegen(D(rec["alu_op"]), D(rec["alu_b"]), D(rec["alu_c"]), H[v2.A_ALU], d_bw)
+    T[v2.A_LT] = zk.rv32_lt_tracegen(D(rec["lt_op"]), D(rec["lt_b"]), D(rec["lt_c"]), H[v2.A_LT], d_bw)
+    T[v2.A_MUL] = zk.rv32_mul_tracegen(D(rec["mul_b"]), D(rec["mul_c"]), H[v2.A_MUL], d_tup, v2.SX, v2.SY)
+    T[v2.A_MULH] = zk.rv32_mulh_tracegen(D(rec["mulh_op"]), D(rec["mulh_b"]), D(rec["mulh_c"]), H[v2.A_MULH], d_tup, d_bw, v2.SX, v2.SY)
+    T[v2.A_DIVREM] = zk.rv32_divrem_tracegen(D(rec["div_op"]), D(rec["div_b"]), D(rec["div_c"]), H[v2.A_DIVREM], d_tup, d_bw, v2.SX, v2.SY)
+    T[v2.A_SHIFT] = zk.rv32_shift_tracegen(D(rec["shift_op"]), D(rec["shift_b"]), D(rec["shift_c"]), H[v2.A_SHIFT], d_bw)
+    T[v2.A_BEQ] = zk.rv32_branch_eq_tracegen(D(rec["beq_op"]), D(rec["beq_a"]), D(rec["beq_b"]), D(rec["beq_imm"]), H[v2.A_BEQ])
+    T[v2.A_BLT] = zk.rv32_branch_lt_tracegen(D(rec["blt_op"]), D(rec["blt_a"]), D(rec["blt_b"]), D(rec["blt_imm"]), H[v2.A_BLT], d_bw)
+    T[v2.A_JAL_LUI] = zk.rv32_jal_lui_tracegen(D(rec["jal_op"]), D(rec["jal_pc"]), D(rec["jal_imm"]), H[v2.A_JAL_LUI], d_bw)
+    T[v2.A_AUIPC] = zk.rv32_auipc_tracegen(D(rec["auipc_pc"]), D(rec["auipc_imm"]), H[v2.A_AUIPC], d_bw)
+    T[v2.A_JALR] = zk.rv32_jalr_tracegen(D(rec["jalr_pc"]), D(rec["jalr_rs1"]), D(rec["jalr_imm"]), H[v2.A_JALR], d_bw)
+    T[v2.A_LS] = zk.vm_loadstore_tracegen(D(rec["ls_case"]), D(rec["ls_read"]), D(rec["ls_prev"]), D(rec["ls_ts"]), D(rec["ls_base"]), D(rec["ls_imm"]),
+                                          H[v2.A_LS], d_bw)
+    n_ec, n_leaf, n_mk = len(rec["ecall_rows"]) // v2.ECALL_WIDTH, len(rec["leaf_rows"]) // v2.LEAF_WIDTH, len(rec["merkle_rows"]) // v2.MERKLE_WIDTH
+    leaf_pad = np.zeros(v2.LEAF_WIDTH, np.uint32)
+    leaf_pad[0] = 1
+    T[v2.A_ECALL] = zk.rows_tracegen(D(rec["ecall_rows"]), n_ec, v2.ECALL_WIDTH, H[v2.A_ECALL])
+    T[v2.A_LEAF] = zk.rows_tracegen(D(rec["leaf_rows"]), n_leaf, v2.LEAF_WIDTH, H[v2.A_LEAF], leaf_pad)
+    T[v2.A_MERKLE] = zk.rows_tracegen(D(rec["merkle_rows"]), n_mk, v2.MERKLE_WIDTH, H[v2.A_MERKLE])
+    ts_end = int(rec["meta"][2])
+    T[v2.A_CONNECTOR] = zk.rows_tracegen(D(np.array([ts_end & 0xFFFF, ts_end >> 16], np.uint32)), 1, 2, 0)
+    p2in = zk.upload(rec["p2_inputs"])
+    T[v2.A_POSEIDON2] = zk.vm_poseidon2_tracegen(p2in, len(rec["p2_inputs"]) // 16, H[v2.A_POSEIDON2])
+    order = ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read")
+    T[v2.A_ACCESS] = zk.vm_access_tracegen(*[D(rec["acc_" + k]) for k in order], H[v2.A_ACCESS])
+    n, nls, nacc = len(rec["f_x"]), len(rec["ls_case"]), len(rec["acc_ts"])
+    zeros = torch.zeros(max(n, nls, 1), dtype=torch.int32, device=dev)
+    NF, NL, NA = 1 << H[v2.A_FRAME], 1 << H[v2.A_LS], 1 << H[v2.A_ACCESS]
+    for q in (18, 20, 22, 24):
+        zk.bitwise_lookup_tracegen(T[v2.A_FRAME][q * NF:q * NF + n], T[v2.A_FRAME][(q + 1) * NF:(q + 1) * NF + n], zeros[:n], 8, d_bw, accumulate=True)
+    for q in (0, 2, 4, 6):
+        if nls:
+            zk.bitwise_lookup_tracegen(T[v2.A_LS][q * NL:q * NL + nls], T[v2.A_LS][(q + 1) * NL:(q + 1) * NL + nls], zeros[:nls], 8, d_bw, accumulate=True)
+    d_rng = None
+    for q in (8, 9, 4, 10):
+        d_rng = zk.range_counts_tracegen(T[v2.A_ACCESS][q * NA:q * NA + nacc], 16, t_counts=d_rng, accumulate=d_rng is not None)
+    for q, s in ((40, 1), (41, 4), (44, 4), (44, 1), (41, 1)):
+        col = T[v2.A_LS][q * NL:q * NL + nls]
+        if not nls:
+            continue
+        d_rng = zk.range_counts_tracegen(col, 16, t_counts=d_rng, accumulate=True) if s == 1 else zk.range_counts_scaled_tracegen(col, s, 16, d_rng)
+    misc = [ts_end & 0xFFFF, 8 * (ts_end >> 16), ts_end >> 16]
+    for row in rec["ecall_rows"].reshape(-1, v2.ECALL_WIDTH):
+        if row[15]:
+            misc += [int(row[17]) * 8192, int(row[17])]
+    for row in rec["leaf_rows"].reshape(-1, v2.LEAF_WIDTH):
+        misc += [int(row[43]), int(row[44]) * 16, int(row[44]), int(row[45]), int(row[46]) * 64, int(row[46])]
+    d_rng = zk.range_counts_tracegen(zk.upload(np.array(misc, np.uint32)), 16, t_counts=d_rng, accumulate=True)
+    T[v2.A_BITWISE], T[v2.A_RANGE_TUPLE], T[v2.A_RANGE] = d_bw, d_tup, d_rng
+    return T
+
+
+@pytest.fixture(scope="module")
+def mixed(tmp_path_factory):
+    words = mixed_program()
+    info, heights, segs, image_root, pv_open = v2.dump_segments(tmp_path_factory.mktemp("mixed"), rv.exe_bytes(words), (7).to_bytes(4, "little"), 9)
+    return dict(words=words, heights=heights, segs=segs)
+
+
+def test_device_traces_equal_the_twins_and_the_proof_equals_the_oracles(zk, ora, mixed):
+    rec, H = mixed["segs"][3], mixed["heights"]
+    inst = v2.segment_instance(rec, mixed["words"], PC_BASE, H)
+    prog = v2.program_table(mixed["words"], PC_BASE, H[0])
+    T = device_traces(zk, rec, prog, H)
+    for a, d in enumerate(inst):
+        assert (zk.download(T[a]).reshape(d["width"], -1) == d["trace"]).all(), "chip %d" % a
+    pk = z.ProvingKey(zk, PARAMS, inst)
+    pvs = [d["pvs"] for d in inst]
+    proof = pk.prove(T, pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, inst).tobytes()
+    # tampered records: the device generates the traces all the same; their proofs are refused
+    cls = prog[1][rec["pc_index"]]
+    alu_rows = np.nonzero(cls == 0)[0]
+
+    def wrong_result(r):
+        r["f_z"][int(alu_rows[3])] ^= 4
+
+    def swapped(r):
+        k = next(int(q) for q in alu_rows if prog[2][rec["pc_index"][q]] == 1 and rec["f_x"][q] != rec["f_y"][q])
+        r["f_x"][k], r["f_y"][k] = r["f_y"][k], r["f_x"][k]
+
+    for edit in (wrong_result, swapped):
+        bad = {n: v.copy() for n, v in rec.items()}
+        edit(bad)
+        proof = pk.prove(device_traces(zk, bad, prog, H), pvs)
+        assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) != 0
+    pk.close()
+
+
+@pytest.mark.parametrize("which,seed", [("mixed", 21), ("fib", 500)])
+def test_prove_elf_one_flow_one_proof(tmp_path, which, seed):
+    words = mixed_program() if which == "mixed" else fib_program()
+    stdin = int(seed).to_bytes(4, "little")
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words))
+    (tmp_path / "stdin.bin").write_bytes(stdin)
+    (tmp_path / "openvm.toml").write_text(pm.TOML.format(*PARAMS))
+    r = subprocess.run([pm.CLI, "prove-elf", str(exe), str(tmp_path / "stdin.bin"), str(tmp_path), str(tmp_path / "openvm.toml"), "9"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    model = rv.run(words, stdin)
+    assert info["verified"] and info["total_cycles"] == model["instret"] and info["segments"] >= 3 and info["levels"] >= 2
+    root = json.loads((tmp_path / "root.json").read_text())
+    upv = pm.un_b64_bincode(root["user_pvs_proof"])
+    assert upv[:32] == bytes(model["pvs"])
+    stmt = np.frombuffer(pm.un_b64_bincode(root["deferral_merkle_proofs"]), dtype=np.uint32)
+    assert len(stmt) == 8 + 9 + 9 + 8 and int(stmt[8]) == PC_BASE and int(stmt[17]) == 0          # from the entry point to the exit
+    # the root proof verifies under the root verifying key alone (the node's public values = its statement)
+    sp = dict(root)
+    sp["user_pvs_proof"] = pm.b64_bincode(stmt.tobytes())
+    (tmp_path / "root_as_node.json").write_text(json.dumps(sp))
+    assert pm.run_cli("verify", str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root_as_node.json")).returncode == 0
+    lie = stmt.copy()
+    lie[20] ^= 1                                                                                    # another final memory root
+    sp["user_pvs_proof"] = pm.b64_bincode(lie.tobytes())
+    (tmp_path / "lie.json").write_text(json.dumps(sp))
+    assert pm.run_cli("verify", str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "lie.json")).returncode != 0
