@@ -494,6 +494,9 @@ int zkhip_mmcs_verify(const uint32_t root[8], const unsigned *log_heights, const
                       uint64_t index, const uint32_t *opening);
 int zkhip_fri_fold_row(uint64_t index, unsigned log_height, const uint32_t beta[4], const uint32_t e0[4],
                        const uint32_t e1[4], uint32_t out[4]);
+/* the LogUp bus check: n exposed cumulative sums (4 canonical words each, one per AIR with interactions) must add up to zero in
+ * F_p[X]/(X^4 - 11); ZKHIP_OK = balanced, ZKHIP_ERR_VERIFY = not */
+int zkhip_logup_exposed_check(const uint32_t *exposed, size_t n);
 
 /* Field offsets of a proof, in 32-bit words from its start (the layout is static for given parameters and AIR shapes:
  * DESIGN.md section 4).  The counterpart of `Proof::<SC>::decode_from_bytes` (crates/verifier/src/verifier.rs:62) for this

@@ -311,33 +311,28 @@ inline Digest guest_image_root(const Exe& exe) {
     return ex.image_root();
 }
 
-// execute -> segment proofs -> aggregation tree -> root.  `keep_segments`: also return the segment proofs.
-inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
-                                        bool keep_segments = false) {
+// execute -> segment proofs -> aggregation tree -> root, with the provers handed in (their keys and circuits are reused from task
+// to task: the reference keeps its Sdk in a OnceLock, crates/prover/src/prover/mod.rs:78,115-126).
+inline GuestStark prove_guest_with(SegmentProver& sp, scroll_zkvm_hip::AggregationProver& agg, const Exe& exe, const StdIn& in, const SegmentCaps& caps,
+                                   bool keep_segments = false) {
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::duration d) { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(d).count(); };
-    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()));
     GuestStark g;
     SegmentExecutor ex(exe, in, caps);
     g.image_root = ex.image_root(), g.entry_pc = exe.entry ? exe.entry : exe.pc_base;
     std::vector<ChildProof> seg_proofs;
-    VerifyingKey seg_vk;
-    {
-        SegmentProver sp(params, exe, caps, device);
-        seg_vk = sp.vk();
-        SegmentRecords rec;
-        clk::duration t_exec{}, t_prove{};
-        for (bool done = false; !done;) {
-            const auto a = clk::now();
-            done = ex.run_segment(rec);
-            const auto b = clk::now();
-            SegmentProof p = sp.prove(rec);
-            t_exec += b - a, t_prove += clk::now() - b;
-            seg_proofs.push_back(p.proof);
-            if (keep_segments) g.segment_proofs.push_back(std::move(p));
-        }
-        g.execution_mills = ms(t_exec), g.segment_proving_mills = ms(t_prove);
+    SegmentRecords rec;
+    clk::duration t_exec{}, t_prove{};
+    for (bool done = false; !done;) {
+        const auto a = clk::now();
+        done = ex.run_segment(rec);
+        const auto b = clk::now();
+        SegmentProof p = sp.prove(rec);
+        t_exec += b - a, t_prove += clk::now() - b;
+        seg_proofs.push_back(p.proof);
+        if (keep_segments) g.segment_proofs.push_back(std::move(p));
     }
+    g.execution_mills = ms(t_exec), g.segment_proving_mills = ms(t_prove);
     bool all_zero = true;
     for (uint8_t b : ex.public_values()) all_zero = all_zero && b == 0;
     if (all_zero) throw Error("public_values are all 0s for unexpected reason");   // crates/prover/src/utils/vm.rs:34-46
@@ -345,13 +340,19 @@ inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& e
     g.pv_openings = open_public_values(ex.tree());
     g.segments = seg_proofs.size();
     const auto t0 = clk::now();
-    scroll_zkvm_hip::AggregationProver agg = scroll_zkvm_hip::AggregationProver::setup(seg_vk, segment_statement(), {}, device);
     const scroll_zkvm_hip::AggregationPlan plan = scroll_zkvm_hip::AggregationPlan::build(seg_proofs.size());
     g.root = agg.prove_tree(plan, seg_proofs);
     g.levels = plan.levels.size();
     g.root_vk = agg.node_vk(plan.levels.size() - 1);
     g.aggregation_mills = ms(clk::now() - t0);
     return g;
+}
+inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
+                                        bool keep_segments = false) {
+    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()));
+    SegmentProver sp(params, exe, caps, device);
+    scroll_zkvm_hip::AggregationProver agg = scroll_zkvm_hip::AggregationProver::setup(sp.vk(), segment_statement(), {}, device);
+    return prove_guest_with(sp, agg, exe, in, caps, keep_segments);
 }
 
 // The verifier's side: the root proof under the root verifying key, then the statement: the run starts at the guest's entry on the
@@ -373,3 +374,121 @@ inline bool verify_guest_proof(const VerifyingKey& root_vk, const ChildProof& ro
 }
 
 }  // namespace zkhip_vm
+
+// ---- the reference's Prover API over the one-statement flow ------------------------------------------------------------------------------
+namespace scroll_zkvm_hip {
+
+// crates/prover/src/prover/mod.rs:83-413 for guests: ProverConfig::path_app_exe is the guest ELF (the reference: the app's vmexe),
+// path_app_config its openvm.toml.  gen_proof_universal(task) = task.build_guest_input() -> execute -> segments -> aggregation ->
+// ONE StarkProof, self-verified.  StarkProof.user_pvs_proof = [the root node's statement (34 words) | the guest's 32 public-value
+// bytes | their Merkle openings in the final memory root]; baseline = the root circuit's heights: `UniversalVerifier` over the
+// root verifying key accepts it as it is, verify_guest_stark checks the whole statement.
+class UniversalProver {
+public:
+    std::string prover_name;
+    ProverConfig config;
+
+    static UniversalProver setup(const ProverConfig& cfg, const char* name = nullptr, int device = 0, unsigned log_frame = 17) {
+        UniversalProver p;
+        p.config = cfg, p.prover_name = name ? name : "universal", p.device_ = device;
+        std::ifstream f(cfg.path_app_exe, std::ios::binary);
+        if (!f) throw Error(Error::Setup, "failed to read or deserialize " + cfg.path_app_exe + ": cannot open");
+        const std::vector<uint8_t> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        try {
+            p.exe_ = zkhip_vm::parse_exe(raw);
+        } catch (const zkhip_vm::Error& e) {
+            throw Error(Error::Setup, "failed to read or deserialize " + cfg.path_app_exe + ": " + e.what());
+        }
+        p.params_ = read_app_config(cfg.path_app_config);
+        p.caps_ = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(p.exe_.program.size()));
+        return p;
+    }
+    void reset() {   // mod.rs:106-108: releases the device-resident keys, circuits and workspaces
+        agg_.reset(), seg_.reset();
+    }
+    // mod.rs:312-338
+    uint64_t execute_and_check(const ProvingTask& task) const {
+        try {
+            return zkhip_vm::execute_guest(exe_, task.build_guest_input()).total_cycle;
+        } catch (const zkhip_vm::Error& e) {
+            throw Error(Error::GenProof, e.what());
+        }
+    }
+    StarkProof gen_proof_universal(const ProvingTask& task, bool with_snark = false) {
+        if (with_snark) throw Error(Error::GenProof, "the SNARK (EVM) wrap is outside the HIP backend's path");
+        return gen_proof_stark(task);
+    }
+    StarkProof gen_proof_stark(const ProvingTask& task) {
+        try {
+            ensure();
+            const zkhip_vm::StdIn in = task.build_guest_input();
+            last_ = zkhip_vm::prove_guest_with(*seg_, *agg_, exe_, in, caps_);
+        } catch (const zkhip_vm::Error& e) {
+            throw Error(Error::GenProof, std::string("failed to generate proof: ") + e.what());
+        }
+        StarkProof sp = encode(last_);
+        std::string why;
+        if (!verify_guest_stark(sp, last_.root_vk, exe_, &why)) throw Error(Error::VerifyProof, "failed to verify proof: " + why);   // mod.rs:407-411
+        return sp;
+    }
+    const zkhip_vm::GuestStark& last() const { return last_; }
+    const zkhip_vm::Exe& exe() const { return exe_; }
+
+    static StarkProof encode(const zkhip_vm::GuestStark& g) {
+        StarkProof sp = AggregationProver::to_stark_proof(g.root, g.root_vk);   // proof, the node's public values, heights
+        sp.user_pvs_proof.insert(sp.user_pvs_proof.end(), g.exec.public_values.begin(), g.exec.public_values.end());
+        const uint8_t* ob = reinterpret_cast<const uint8_t*>(g.pv_openings.data());
+        sp.user_pvs_proof.insert(sp.user_pvs_proof.end(), ob, ob + 4 * g.pv_openings.size());
+        sp.stat.total_cycles = g.exec.total_cycle, sp.stat.execution_time_mills = g.execution_mills;
+        sp.stat.proving_time_mills = g.segment_proving_mills + g.aggregation_mills;
+        return sp;
+    }
+    // crates/verifier/src/verifier.rs:38-85 for this flow: the root proof under the root verifying key and the statement about THIS guest
+    static bool verify_guest_stark(const StarkProof& sp, const VerifyingKey& root_vk, const zkhip_vm::Exe& exe, std::string* why = nullptr) {
+        const size_t n_stmt = 34, n_open = 2 * 8 * zkhip::vmc::LEAF_LEVEL;
+        if (sp.user_pvs_proof.size() != 4 * n_stmt + zkhip_vm::NUM_PUBLIC_VALUE_BYTES + 4 * n_open) {
+            if (why) *why = "user_pvs_proof has the wrong size";
+            return false;
+        }
+        ChildProof root;
+        root.proof = sp.proof;
+        root.pvs.resize(3);
+        root.pvs[2].resize(n_stmt);
+        memcpy(root.pvs[2].data(), sp.user_pvs_proof.data(), 4 * n_stmt);
+        const std::vector<uint8_t> pv(sp.user_pvs_proof.begin() + 4 * n_stmt, sp.user_pvs_proof.begin() + 4 * n_stmt + zkhip_vm::NUM_PUBLIC_VALUE_BYTES);
+        std::vector<uint32_t> openings(n_open);
+        memcpy(openings.data(), sp.user_pvs_proof.data() + 4 * n_stmt + zkhip_vm::NUM_PUBLIC_VALUE_BYTES, 4 * n_open);
+        if (sp.baseline.size() != root_vk.heights.size()) {
+            if (why) *why = "baseline does not match the root verifying key";
+            return false;
+        }
+        for (size_t a = 0; a < root_vk.heights.size(); a++)
+            if (sp.baseline[a] != root_vk.heights[a]) {
+                if (why) *why = "baseline does not match the root verifying key";
+                return false;
+            }
+        try {
+            return zkhip_vm::verify_guest_proof(root_vk, root, exe.entry ? exe.entry : exe.pc_base, zkhip_vm::guest_image_root(exe), pv, openings, why);
+        } catch (const zkhip_vm::Error& e) {
+            if (why) *why = e.what();
+            return false;
+        }
+    }
+
+private:
+    UniversalProver() = default;
+    zkhip_vm::Exe exe_;
+    zkhip_params params_{};
+    zkhip_vm::SegmentCaps caps_;
+    int device_ = 0;
+    std::unique_ptr<zkhip_vm::SegmentProver> seg_;
+    std::unique_ptr<AggregationProver> agg_;
+    zkhip_vm::GuestStark last_;
+    void ensure() {
+        if (seg_) return;
+        seg_.reset(new zkhip_vm::SegmentProver(params_, exe_, caps_, device_));
+        agg_.reset(new AggregationProver(AggregationProver::setup(seg_->vk(), zkhip_vm::segment_statement(), {}, device_)));
+    }
+};
+
+}  // namespace scroll_zkvm_hip

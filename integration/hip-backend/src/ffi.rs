@@ -299,6 +299,7 @@ extern "C" {
     pub fn zkhip_mmcs_verify(root: *const u32, log_heights: *const c_uint, widths: *const usize, n_mats: usize, index: u64,
                              opening: *const u32) -> c_int;
     pub fn zkhip_fri_fold_row(index: u64, log_height: c_uint, beta: *const u32, e0: *const u32, e1: *const u32, out: *mut u32) -> c_int;
+    pub fn zkhip_logup_exposed_check(exposed: *const u32, n: usize) -> c_int;
 
     // the reference's stored-proof container (OpenVM-v1 Proof<SC>, bincode)
     pub fn zkhip_proof_decode_v1(bytes: *const u8, len: usize, kind: c_int, out: *mut zkhip_v1_summary) -> c_int;

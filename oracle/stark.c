@@ -907,6 +907,19 @@ typedef struct {
     unsigned n_pts;
 } vmat;
 
+/* The verifier's bus check on its own (OpenVM-v1 LogUp: every AIR with interactions exposes the cumulative sum of its
+ * permutation column; the buses balance iff the sums of all AIRs add up to zero in the quartic extension).  Pinned to the reference:
+ * the `exposed_values_after_challenge` of its eight stored proofs sum to zero (tests/test_ref_vectors_cpu.py). */
+int ora_logup_exposed_check(const uint32_t *exposed, size_t n) {
+    ext_t tot = {0, 0, 0, 0};
+    for (size_t k = 0; k < n; k++) {
+        for (int q = 0; q < 4; q++)
+            if (exposed[4 * k + q] >= ORA_P) return -1;
+        ext_add(tot, exposed + 4 * k, tot);
+    }
+    return (tot[0] | tot[1] | tot[2] | tot[3]) ? -9 : 0;
+}
+
 int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t n_airs, const uint32_t *proof,
                      size_t n_words) {
     const unsigned b = prm->log_blowup;
@@ -1004,9 +1017,7 @@ int ora_stark_verify(const ora_params *prm, const ora_air_instance *airs, size_t
         ora_ch_observe(&ch, root_perm, 8);
         ora_ch_observe(&ch, exposed_all, 4 * n_lu);
         /* bus balance: the exposed cumulative sums of all AIRs add up to zero */
-        ext_t tot = {0, 0, 0, 0};
-        for (size_t k = 0; k < n_lu; k++) ext_add(tot, exposed_all + 4 * k, tot);
-        if (tot[0] | tot[1] | tot[2] | tot[3]) return -9;
+        if (ora_logup_exposed_check(exposed_all, n_lu) != 0) return -9;
     }
     ext_t alpha, zeta, alpha_f;
     ora_ch_sample_ext(&ch, alpha);

@@ -177,6 +177,9 @@ int ora_ch_check_witness(ora_challenger *c, unsigned bits, uint32_t witness);
 /* in: 2*n ext elements (bit-reversed domain order), out: n ext elements */
 void ora_fri_fold(const uint32_t *in, uint32_t *out, unsigned log_n_out, const uint32_t beta[4]);
 
+/* the verifier's bus check: n exposed cumulative sums (4 canonical words each) must add up to zero; 0 = balanced */
+int ora_logup_exposed_check(const uint32_t *exposed, size_t n);
+
 /* ---- LogUp / sum-check building blocks (oracle/sumcheck.c) ---- */
 void ora_ext_batch_inverse(const uint32_t *in, uint32_t *out, size_t n);
 void ora_logup_running_sum(const uint32_t *den, const uint32_t *num, size_t n, uint32_t *out);

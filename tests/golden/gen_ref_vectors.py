@@ -315,7 +315,7 @@ def fri_analysis(fname, p, idxs, H, lay):
 
 def main():
     out = {"about": "canonical field elements taken / solved from the reference's stored OpenVM-v1 proofs; see gen_ref_vectors.py",
-           "sources": [], "compress": [], "openings": [], "fri_layers": [], "fri_leaves": [], "shapes": {}}
+           "sources": [], "compress": [], "openings": [], "fri_layers": [], "fri_leaves": [], "shapes": {}, "logup_exposed": []}
     for rel in FILES:
         fname = os.path.basename(rel) if "prover/" not in rel else "prover-" + os.path.basename(rel)
         d, blob, p = load(rel)
@@ -323,6 +323,10 @@ def main():
         out["sources"].append({"file": rel, "name": fname, "proof_bytes": len(blob), "sha256": hashlib.sha256(blob).hexdigest(),
                                "git_version": d.get("git_version")})
         out["shapes"][fname] = rp.shape_of(p)
+        # 4. LogUp exposed sums: per AIR with interactions the cumulative sum of its after-challenge column (one phase); the
+        #    verifier's bus check is that they cancel over all AIRs of the proof.
+        out["logup_exposed"].append({"file": fname, "air_ids": [a["air_id"] for a in p["per_air"] if a["exposed"] and a["exposed"][0]],
+                                     "exposed": [canon(a["exposed"][0][0]) for a in p["per_air"] if a["exposed"] and a["exposed"][0]]})
         trips = compress_triples(fname, p)
         print("  compress triples: %d" % len(trips))
         out["compress"] += trips

@@ -123,3 +123,21 @@ def test_device_fri_fold_reproduces_reference_layers(zk, vec):
             assert out[t["k"]].tolist() == t["folded"], (lay["file"], lay["layer"], t["k"])
             n += 1
     assert n >= 50
+
+
+def test_device_running_sum_over_the_reference_exposed_sums_is_zero(zk):
+    """The LogUp accumulation kernel (zkhip_logup_running_sum: prefix sums of num / den in the quartic extension) over the exposed
+    cumulative sums the reference's stored proofs carry, with unit denominators: the total is the verifier's bus check, zero."""
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_v1_vectors.json")) as f:
+        vec = json.load(f)
+    for e in vec["logup_exposed"]:
+        ex = np.array(e["exposed"], dtype=np.uint32)
+        den = np.zeros_like(ex)
+        den[:, 0] = 1
+        out, total = zk.logup_running_sum(zk.upload(den.reshape(-1)), zk.upload(ex.reshape(-1)), len(ex))
+        assert np.asarray(total).tolist() == [0, 0, 0, 0], e["file"]
+        run = zk.download(out).reshape(-1, 4)
+        assert (run[-1] == 0).all() and (run[0] == ex[0]).all()

@@ -141,16 +141,99 @@ def test_prove_elf_one_flow_one_proof(tmp_path, which, seed):
     assert info["verified"] and info["total_cycles"] == model["instret"] and info["segments"] >= 3 and info["levels"] >= 2
     root = json.loads((tmp_path / "root.json").read_text())
     upv = pm.un_b64_bincode(root["user_pvs_proof"])
-    assert upv[:32] == bytes(model["pvs"])
-    stmt = np.frombuffer(pm.un_b64_bincode(root["deferral_merkle_proofs"]), dtype=np.uint32)
-    assert len(stmt) == 8 + 9 + 9 + 8 and int(stmt[8]) == PC_BASE and int(stmt[17]) == 0          # from the entry point to the exit
-    # the root proof verifies under the root verifying key alone (the node's public values = its statement)
-    sp = dict(root)
-    sp["user_pvs_proof"] = pm.b64_bincode(stmt.tobytes())
-    (tmp_path / "root_as_node.json").write_text(json.dumps(sp))
-    assert pm.run_cli("verify", str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root_as_node.json")).returncode == 0
-    lie = stmt.copy()
-    lie[20] ^= 1                                                                                    # another final memory root
-    sp["user_pvs_proof"] = pm.b64_bincode(lie.tobytes())
-    (tmp_path / "lie.json").write_text(json.dumps(sp))
-    assert pm.run_cli("verify", str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "lie.json")).returncode != 0
+    stmt = np.frombuffer(upv[:4 * 34], dtype=np.uint32)
+    assert upv[4 * 34:4 * 34 + 32] == bytes(model["pvs"]) and len(upv) == 4 * 34 + 32 + 4 * 2 * 8 * 28
+    assert int(stmt[8]) == PC_BASE and int(stmt[17]) == 0                                           # from the entry point to the exit
+    cfg = str(tmp_path / "openvm.toml")
+    # the root proof verifies under the root verifying key alone; the whole statement about this guest with verify-guest
+    assert pm.run_cli("verify", str(tmp_path / "root.vk"), cfg, str(tmp_path / "root.json")).returncode == 0
+    r = pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), cfg, str(tmp_path / "root.json"))
+    assert r.returncode == 0 and bytes(model["pvs"]).hex() in r.stdout, r.stderr
+
+    def variant(edit, name):
+        b = bytearray(upv)
+        edit(b)
+        sp = dict(root)
+        sp["user_pvs_proof"] = pm.b64_bincode(bytes(b))
+        (tmp_path / name).write_text(json.dumps(sp))
+        return str(tmp_path / name)
+
+    lie = variant(lambda b: b.__setitem__(4 * 20, b[4 * 20] ^ 1), "lie_root.json")                    # another final memory root
+    assert pm.run_cli("verify", str(tmp_path / "root.vk"), cfg, lie).returncode != 0
+    lie = variant(lambda b: b.__setitem__(4 * 34, b[4 * 34] ^ 1), "lie_pv.json")                      # other public values
+    assert pm.run_cli("verify", str(tmp_path / "root.vk"), cfg, lie).returncode == 0                  # (the node proof does not see them)
+    assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), cfg, lie).returncode != 0  # the openings do
+    # another initial memory image: the statement starts elsewhere (the PROGRAM is pinned by root.vk: the segment key holds the
+    # commitment of the decoded program table, and every circuit above holds its child's key)
+    other = tmp_path / "other.elf"
+    other.write_bytes(rv.elf_bytes(words, data=b"\x01\x02\x03\x04"))
+    assert pm.run_cli("verify-guest", str(other), str(tmp_path / "root.vk"), cfg, str(tmp_path / "root.json")).returncode != 0
+
+
+def test_gen_proof_universal_from_an_elf_and_witness_bytes(tmp_path):
+    """Prover::gen_proof_universal (mod.rs:287-309) over the one-statement flow: the task's serialized witnesses reach the guest
+    through ProvingTask::build_guest_input (length-framed items), the guest folds them into its public values, ONE proof comes out."""
+    import struct
+    from test_vm_cpu import A0, A1, A7, S0, S1, T0, T3
+
+    p = [("addi", S0, 0, 0), ("addi", S1, 0, 0),
+         ("label", "item"), ("slti", T3, S1, 3), ("beq", T3, 0, "out"),
+         ("addi", A7, 0, 2), ("ecall",), ("add", S0, S0, A0), ("addi", T0, A0, 3), ("srli", T0, T0, 2),
+         ("label", "w"), ("beq", T0, 0, "next"), ("ecall",), ("add", S0, S0, A0), ("addi", T0, T0, -1), ("jal", 0, "w"),
+         ("label", "next"), ("addi", S1, S1, 1), ("jal", 0, "item"),
+         ("label", "out"), ("add", A0, S0, 0), ("addi", A1, 0, 0), ("addi", A7, 0, 1), ("ecall",),
+         ("addi", A0, S1, 0), ("addi", A1, 0, 1), ("ecall",), ("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    words = rv.assemble(p)
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words))
+    wit = [bytes(range(1, 6)), b"", bytes(range(200, 216))]
+    with open(tmp_path / "task.bin", "wb") as f:
+        f.write(struct.pack("<I", 7) + b"chunk-7" + struct.pack("<I", len(wit)))
+        for w in wit:
+            f.write(struct.pack("<Q", len(w)) + w)
+    (tmp_path / "openvm.toml").write_text(pm.TOML.format(*PARAMS))
+    r = pm.run_cli("prove-task", str(exe), str(tmp_path / "task.bin"), str(tmp_path), str(tmp_path / "openvm.toml"), "8")
+    assert r.returncode == 0, r.stderr[-3000:]
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    stream = b"".join(struct.pack("<I", len(w)) + w + bytes(-len(w) % 4) for w in wit)
+    model = rv.run(words, stream)
+    assert info["identifier"] == "chunk-7" and info["verified"] and info["total_cycles"] == model["instret"]
+    root = json.loads((tmp_path / "root.json").read_text())
+    assert set(root) == {"proof", "user_pvs_proof", "baseline", "deferral_merkle_proofs", "stat"}
+    assert root["stat"]["total_cycles"] == model["instret"]
+    upv = pm.un_b64_bincode(root["user_pvs_proof"])
+    assert upv[4 * 34:4 * 34 + 32] == bytes(model["pvs"])
+    total = sum(int.from_bytes(stream[i:i + 4], "little") for i in range(0, len(stream), 4)) & 0xFFFFFFFF
+    assert int.from_bytes(upv[4 * 34:4 * 34 + 4], "little") == total and upv[4 * 34 + 4] == 3
+    assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
+    # a guest that fails (exit code 1) has no proof; neither has one whose public values stay zero
+    bad = rv.assemble([("addi", A0, 0, 1), ("addi", A7, 0, 93), ("ecall",)])
+    exe.write_bytes(rv.elf_bytes(bad))
+    r = pm.run_cli("prove-task", str(exe), str(tmp_path / "task.bin"), str(tmp_path), str(tmp_path / "openvm.toml"), "8")
+    assert r.returncode == 1 and "exited with code 1" in r.stderr
+    silent = rv.assemble([("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)])
+    exe.write_bytes(rv.elf_bytes(silent))
+    r = pm.run_cli("prove-task", str(exe), str(tmp_path / "task.bin"), str(tmp_path), str(tmp_path / "openvm.toml"), "8")
+    assert r.returncode == 1 and "public_values are all 0s" in r.stderr
+
+
+def test_segments_that_do_not_chain_are_refused_in_circuit(zk, mixed):
+    """The aggregation circuit chains (pc, memory root): segment k followed by segment k + 2 has no witness."""
+    H, words = mixed["heights"], mixed["words"]
+    insts = [v2.segment_instance(mixed["segs"][k], words, PC_BASE, H) for k in (1, 2, 3)]
+    prog = v2.program_table(words, PC_BASE, H[0])
+    pk = z.ProvingKey(zk, PARAMS, insts[0])
+    proofs, pvs = [], []
+    for k, inst in zip((1, 2, 3), insts):
+        pv = [d["pvs"] for d in inst]
+        proofs.append(pk.prove(device_traces(zk, mixed["segs"][k], prog, H), pv))
+        pvs.append(pv)
+    stmt = dict(start=[(v2.A_CONNECTOR, 0)] + [(v2.A_MERKLE, k) for k in range(8)], end=[(v2.A_CONNECTOR, 1)] + [(v2.A_MERKLE, 8 + k) for k in range(8)])
+    rc = z.RecursionCircuit(PARAMS, pk.verifying_airs(), 4, stmt=stmt)
+    st, npv = rc.witness(proofs, pvs)
+    assert st == 0, rc.last_error()
+    assert int(npv[8]) == int(mixed["segs"][1]["meta"][0]) and int(npv[17]) == int(mixed["segs"][3]["meta"][1])
+    assert npv[9:17].tolist() == mixed["segs"][1]["meta"][4:12].tolist() and npv[18:26].tolist() == mixed["segs"][3]["meta"][12:20].tolist()
+    assert rc.witness([proofs[0], proofs[2]], [pvs[0], pvs[2]])[0] == -7
+    assert rc.witness([proofs[1], proofs[0]], [pvs[1], pvs[0]])[0] == -7
+    pk.close()

@@ -135,3 +135,27 @@ def test_fixture_matches_reference_files(vec):
         assert rp.shape_of(proofs[0])["n_queries"] == vec["shapes"][s["name"]]["n_queries"]
         pv = rp.decode_public_values(base64.b64decode(d["proof"]["public_values"]))
         assert len(pv) == 32 and all(rp.from_monty(v) < 256 for v in pv)  # 32 user public values, one byte each
+
+
+def test_logup_exposed_sums_of_the_reference_proofs_cancel(ora, vec):
+    """The verifier's bus check on the reference's own data: in every stored proof the `exposed_values_after_challenge` of the AIRs
+    with interactions add up to zero in F_p[X]/(X^4 - 11) -- through the oracle's check and through the product's
+    (zkhip_logup_exposed_check, the function zkhip_verify calls); one changed coordinate and both refuse."""
+    import zkvm_prover_amd as z
+
+    lib = z.load_library()
+    assert len(vec["logup_exposed"]) == 8
+    o = ora.lib()
+    o.ora_logup_exposed_check.restype = C.c_int
+    o.ora_logup_exposed_check.argtypes = [C.POINTER(C.c_uint32), C.c_size_t]
+    for e in vec["logup_exposed"]:
+        ex = _u32(e["exposed"])
+        assert ex.shape == (len(e["air_ids"]), 4) and len(e["air_ids"]) >= 15
+        assert (ex.astype(np.int64).sum(axis=0) % P).tolist() == [0, 0, 0, 0]      # coordinate-wise: ext addition is
+        assert o.ora_logup_exposed_check(ora.p32(ex), len(ex)) == 0, e["file"]
+        assert lib.zkhip_logup_exposed_check(ex.ctypes.data_as(C.POINTER(C.c_uint32)), len(ex)) == 0, e["file"]
+        bad = ex.copy()
+        bad[3, 2] = (int(bad[3, 2]) + 1) % P
+        assert o.ora_logup_exposed_check(ora.p32(bad), len(bad)) != 0
+        assert lib.zkhip_logup_exposed_check(bad.ctypes.data_as(C.POINTER(C.c_uint32)), len(bad)) == -7
+        assert lib.zkhip_logup_exposed_check(ex[:-1].copy().ctypes.data_as(C.POINTER(C.c_uint32)), len(ex) - 1) == -7

@@ -96,53 +96,88 @@ int main(int argc, char** argv) {
             }
             return 0;
         }
-        if (argc >= 5 && std::string(argv[1]) == "prove-elf") {
-            // prove-elf <guest.elf | exe.bin> <stdin.bin | -> <out_dir> [openvm.toml | -] [log_frame]: ONE FLOW (include/zkhip_vm_flow.hpp):
-            // execute -> segments (one statement each) -> aggregation tree -> root.json + root.vk; prints a JSON line
-            const std::vector<uint8_t> raw = slurp(argv[2]);
-            zkhip_vm::StdIn in;
-            if (std::string(argv[3]) != "-") in.bytes = slurp(argv[3]);
-            zkhip_params params{1, 0, 100, 16, 16};
-            if (argc >= 6 && std::string(argv[5]) != "-") params = read_app_config(argv[5]);
-            const unsigned log_frame = argc >= 7 ? (unsigned)atoi(argv[6]) : 17;
-            try {
-                const zkhip_vm::Exe exe = zkhip_vm::parse_exe(raw);
-                const auto t0 = std::chrono::steady_clock::now();
-                const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, exe, in, log_frame, 0, true);
-                const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                std::string why;
-                if (!zkhip_vm::verify_guest_proof(g.root_vk, g.root, g.entry_pc, g.image_root, g.exec.public_values, g.pv_openings, &why))
-                    throw Error(Error::VerifyProof, "failed to verify proof: " + why);   // the mandatory self-check (mod.rs:407-411)
-                StarkProof sp = AggregationProver::to_stark_proof(g.root, g.root_vk);
-                // user_pvs_proof (crates/types/src/proof.rs:52-67): the public values and their Merkle openings in the final memory root
-                sp.user_pvs_proof = g.exec.public_values;
-                const uint8_t* ob = reinterpret_cast<const uint8_t*>(g.pv_openings.data());
-                sp.user_pvs_proof.insert(sp.user_pvs_proof.end(), ob, ob + 4 * g.pv_openings.size());
-                const uint8_t* nb = reinterpret_cast<const uint8_t*>(g.root.pvs[2].data());
-                sp.deferral_merkle_proofs.assign(nb, nb + 4 * g.root.pvs[2].size());   // the root node's public values (its statement)
-                sp.stat.total_cycles = g.exec.total_cycle, sp.stat.execution_time_mills = g.execution_mills;
-                sp.stat.proving_time_mills = g.segment_proving_mills + g.aggregation_mills;
-                const std::string dir = argv[4];
-                std::ofstream(dir + "/root.json") << sp.to_json();
-                const std::vector<uint8_t> vkb = g.root_vk.to_app_exe();
-                std::ofstream(dir + "/root.vk", std::ios::binary).write((const char*)vkb.data(), (std::streamsize)vkb.size());
-                for (size_t k = 0; k < g.segment_proofs.size(); k++) {
-                    StarkProof s2;
-                    s2.proof = g.segment_proofs[k].proof.proof;
-                    for (const auto& p : g.segment_proofs[k].proof.pvs) {
-                        const uint8_t* b = reinterpret_cast<const uint8_t*>(p.data());
-                        s2.user_pvs_proof.insert(s2.user_pvs_proof.end(), b, b + 4 * p.size());
-                    }
-                    s2.stat.total_cycles = g.segment_proofs[k].n_instr, s2.stat.proving_time_mills = g.segment_proofs[k].proving_mills;
-                    std::ofstream(dir + "/segment-" + std::to_string(k) + ".json") << s2.to_json();
-                }
-                std::printf("{\"total_cycles\": %llu, \"segments\": %zu, \"levels\": %zu, \"execution_ms\": %llu, \"segment_tracegen_and_proving_ms\": %llu, "
-                            "\"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, \"verified\": true}\n",
-                            (unsigned long long)g.exec.total_cycle, g.segments, g.levels, (unsigned long long)g.execution_mills,
-                            (unsigned long long)g.segment_proving_mills, (unsigned long long)g.aggregation_mills, wall, g.root.proof.size());
-            } catch (const zkhip_vm::Error& e) {
-                throw Error(Error::GenProof, e.what());
+        if (argc >= 5 && (std::string(argv[1]) == "prove-elf" || std::string(argv[1]) == "prove-task")) {
+            // prove-elf  <guest.elf | exe.bin> <stdin.bin | -> <out_dir> [openvm.toml | -] [log_frame]
+            // prove-task <guest.elf | exe.bin> <task.bin>     <out_dir> [openvm.toml | -] [log_frame]
+            // ONE FLOW (include/zkhip_vm_flow.hpp UniversalProver = the reference's Prover::gen_proof_universal, mod.rs:287-309): the
+            // task's witnesses become the guest's input stream (ProvingTask::build_guest_input; prove-elf: the raw bytes are one
+            // input stream), the guest is executed in segments, every segment is ONE statement, the aggregation tree folds them
+            // into root.json (+ root.vk, the root circuit's verifying key); self-verified.  Prints a JSON line.
+            const bool is_task = std::string(argv[1]) == "prove-task";
+            std::string cfg_path = argc >= 6 && std::string(argv[5]) != "-" ? argv[5] : "";
+            const std::string dir = argv[4];
+            if (cfg_path.empty()) {
+                cfg_path = dir + "/openvm.toml";
+                std::ofstream(cfg_path) << "[app_fri_params.fri_params]\nlog_blowup = 1\nlog_final_poly_len = 0\nnum_queries = 100\n"
+                                           "commit_proof_of_work_bits = 16\nquery_proof_of_work_bits = 16\n";
             }
+            const unsigned log_frame = argc >= 7 ? (unsigned)atoi(argv[6]) : 17;
+            UniversalProver up = UniversalProver::setup(ProverConfig{argv[2], cfg_path}, nullptr, 0, log_frame);
+            ProvingTask task;
+            if (is_task) {
+                task = read_task(argv[3]);
+            } else if (std::string(argv[3]) != "-") {
+                // a raw input stream: handed to the guest as it is (one "witness" that IS the stream has no framing: bypass the task)
+                task.identifier = "raw-stdin";
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            StarkProof sp;
+            if (is_task) {
+                sp = up.gen_proof_universal(task);
+            } else {
+                // same flow, the stream given directly
+                zkhip_vm::StdIn in;
+                if (std::string(argv[3]) != "-") in.bytes = slurp(argv[3]);
+                struct RawTask : ProvingTask {};
+                try {
+                    const zkhip_vm::SegmentCaps caps = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(up.exe().program.size()));
+                    const zkhip_params params = read_app_config(cfg_path);
+                    const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false);
+                    (void)caps;
+                    sp = UniversalProver::encode(g);
+                    std::string why;
+                    if (!UniversalProver::verify_guest_stark(sp, g.root_vk, up.exe(), &why)) throw Error(Error::VerifyProof, "failed to verify proof: " + why);
+                    const std::vector<uint8_t> vkb = g.root_vk.to_app_exe();
+                    std::ofstream(dir + "/root.vk", std::ios::binary).write((const char*)vkb.data(), (std::streamsize)vkb.size());
+                    std::ofstream(dir + "/root.json") << sp.to_json();
+                    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    std::printf("{\"total_cycles\": %llu, \"segments\": %zu, \"levels\": %zu, \"execution_ms\": %llu, \"segment_tracegen_and_proving_ms\": %llu, "
+                                "\"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, \"verified\": true}\n",
+                                (unsigned long long)g.exec.total_cycle, g.segments, g.levels, (unsigned long long)g.execution_mills,
+                                (unsigned long long)g.segment_proving_mills, (unsigned long long)g.aggregation_mills, wall, g.root.proof.size());
+                } catch (const zkhip_vm::Error& e) {
+                    throw Error(Error::GenProof, e.what());
+                }
+                return 0;
+            }
+            const zkhip_vm::GuestStark& g = up.last();
+            const std::vector<uint8_t> vkb = g.root_vk.to_app_exe();
+            std::ofstream(dir + "/root.vk", std::ios::binary).write((const char*)vkb.data(), (std::streamsize)vkb.size());
+            std::ofstream(dir + "/root.json") << sp.to_json();
+            const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("{\"identifier\": \"%s\", \"total_cycles\": %llu, \"segments\": %zu, \"levels\": %zu, \"execution_ms\": %llu, "
+                        "\"segment_tracegen_and_proving_ms\": %llu, \"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, \"verified\": true}\n",
+                        task.identifier.c_str(), (unsigned long long)g.exec.total_cycle, g.segments, g.levels, (unsigned long long)g.execution_mills,
+                        (unsigned long long)g.segment_proving_mills, (unsigned long long)g.aggregation_mills, wall, g.root.proof.size());
+            return 0;
+        }
+        if (argc >= 6 && std::string(argv[1]) == "verify-guest") {
+            // verify-guest <guest.elf | exe.bin> <root.vk> <openvm.toml> <root.json>: the root proof under the root verifying key AND the
+            // statement about this guest: entry pc, memory image, exit code 0, public values opened in the final memory root (host only)
+            const zkhip_vm::Exe exe = zkhip_vm::parse_exe(slurp(argv[2]));
+            VerifyingKey vk;
+            vk.params = read_app_config(argv[4]);
+            vk.airs = read_app_exe(argv[3]);
+            for (const auto& a : vk.airs) vk.heights.push_back(a.prep_log_height);
+            std::ifstream f(argv[5]);
+            std::stringstream ss;
+            ss << f.rdbuf();
+            const StarkProof sp = StarkProof::from_json(ss.str());
+            std::string why;
+            if (!UniversalProver::verify_guest_stark(sp, vk, exe, &why)) throw Error(Error::VerifyProof, "failed to verify proof: " + why);
+            std::printf("verified: public values ");
+            for (size_t i = 0; i < 32; i++) std::printf("%02x", sp.user_pvs_proof[4 * 34 + i]);
+            std::printf("\n");
             return 0;
         }
         if (argc >= 5 && std::string(argv[1]) == "prove-guest") {

@@ -156,6 +156,7 @@ def load_library():
         "zkhip_poseidon2_permute_host": (C.c_int, [u32p]),
         "zkhip_mmcs_verify": (C.c_int, [u32p, C.POINTER(C.c_uint), C.POINTER(sz), sz, C.c_uint64, u32p]),
         "zkhip_fri_fold_row": (C.c_int, [C.c_uint64, C.c_uint, u32p, u32p, u32p, u32p]),
+        "zkhip_logup_exposed_check": (C.c_int, [u32p, sz]),
         "zkhip_proof_decode_v1": (C.c_int, [C.POINTER(C.c_uint8), sz, C.c_int, C.POINTER(_V1Summary)]),
         "zkhip_proof_reencode_v1": (C.c_int, [C.POINTER(C.c_uint8), sz, C.c_int, C.POINTER(C.c_uint8), sz, C.POINTER(sz)]),
         "zkhip_proof_to_v1": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(u32p), C.POINTER(C.c_uint8), sz,

@@ -157,6 +157,20 @@ extern "C" int zkhip_fri_fold_row(uint64_t index, unsigned log_height, const uin
     return ZKHIP_OK;
 }
 
+// The bus check of the verifier on its own: the exposed cumulative sums of the AIRs with interactions cancel (crates/verifier/src/
+// verifier.rs:82 -> Sdk::verify_proof does this inside the engine; the `exposed_values_after_challenge` of the reference's stored
+// proofs are the vectors, tests/test_ref_vectors_cpu.py).
+extern "C" int zkhip_logup_exposed_check(const uint32_t* exposed, size_t n) {
+    if (n && !exposed) return ZKHIP_ERR_INVALID;
+    Ext tot = ext_zero();
+    for (size_t k = 0; k < n; k++) {
+        for (int q = 0; q < 4; q++)
+            if (exposed[4 * k + q] >= P) return ZKHIP_ERR_INVALID;
+        tot = ext_add(tot, ext_from_canon(exposed + 4 * k));
+    }
+    return ext_eq(tot, ext_zero()) ? ZKHIP_OK : ZKHIP_ERR_VERIFY;
+}
+
 // Word offsets of the fields of a proof: what Proof::<SC>::decode_from_bytes gives the reference's
 // verifier (crates/verifier/src/verifier.rs:62) -- here the layout is static, so "decoding" is a table of offsets.
 extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, zkhip_proof_layout* out) {
@@ -346,9 +360,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         }
         ch.observe_canon(root_perm, 8);
         ch.observe_canon(exposed_c, 4 * n_lu);
-        Ext tot = ext_zero();
-        for (size_t k = 0; k < n_lu; k++) tot = ext_add(tot, ext_from_canon(exposed_c + 4 * k));
-        if (!ext_eq(tot, ext_zero())) return ZKHIP_ERR_VERIFY;
+        if (zkhip_logup_exposed_check(exposed_c, n_lu) != ZKHIP_OK) return ZKHIP_ERR_VERIFY;
     }
     const Ext alpha = ch.sample_ext();
     ch.observe_canon(root_quot, 8);
