@@ -126,18 +126,20 @@ def test_device_fri_fold_reproduces_reference_layers(zk, vec):
 
 
 def test_device_running_sum_over_the_reference_exposed_sums_is_zero(zk):
-    """The LogUp accumulation kernel (zkhip_logup_running_sum: prefix sums of num / den in the quartic extension) over the exposed
-    cumulative sums the reference's stored proofs carry, with unit denominators: the total is the verifier's bus check, zero."""
+    """The LogUp kernels (zkhip_ext_batch_inverse, zkhip_logup_running_sum: prefix sums of multiplicity / denominator in the quartic
+    extension) over the exposed cumulative sums the reference's stored proofs carry: with denominators 1 / S_k and unit
+    multiplicities the running total is S_1 + ... + S_n -- the verifier's bus check -- and must end at zero."""
     import json
     import os
 
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_v1_vectors.json")) as f:
         vec = json.load(f)
     for e in vec["logup_exposed"]:
-        ex = np.array(e["exposed"], dtype=np.uint32)
-        den = np.zeros_like(ex)
-        den[:, 0] = 1
-        out, total = zk.logup_running_sum(zk.upload(den.reshape(-1)), zk.upload(ex.reshape(-1)), len(ex))
+        ex = np.array([v for v in e["exposed"] if any(v)], dtype=np.uint32)
+        n = len(ex)
+        den = zk.ext_batch_inverse(zk.upload(ex.reshape(-1)), n)
+        out, total = zk.logup_running_sum(den, zk.upload(np.ones(n, np.uint32)), n)
         assert np.asarray(total).tolist() == [0, 0, 0, 0], e["file"]
         run = zk.download(out).reshape(-1, 4)
         assert (run[-1] == 0).all() and (run[0] == ex[0]).all()
+        assert (run[1] == (ex[0].astype(np.int64) + ex[1]) % P).all()
