@@ -88,8 +88,8 @@ struct SegmentCaps {
         c.log_height[vmc::A_JAL_LUI] = sub(3), c.log_height[vmc::A_AUIPC] = sub(5), c.log_height[vmc::A_JALR] = sub(4), c.log_height[vmc::A_LS] = sub(1);
         // (floors: a handful of touched blocks already needs ~28 path nodes each and two permutations per row)
         c.log_height[vmc::A_ECALL] = std::max(sub(7), 3u), c.log_height[vmc::A_ACCESS] = log_frame + 3, c.log_height[vmc::A_LEAF] = std::max(sub(5), 4u);
-        c.log_height[vmc::A_MERKLE] = std::max(sub(3), 8u);
-        c.log_height[vmc::A_POSEIDON2] = std::max(sub(1), c.log_height[vmc::A_MERKLE] + 2), c.log_height[vmc::A_CONNECTOR] = 0, c.log_height[vmc::A_BITWISE] = 16;
+        c.log_height[vmc::A_MERKLE] = std::max(sub(4), 8u);
+        c.log_height[vmc::A_POSEIDON2] = std::max(sub(2), c.log_height[vmc::A_MERKLE] + 2), c.log_height[vmc::A_CONNECTOR] = 0, c.log_height[vmc::A_BITWISE] = 16;
         c.log_height[vmc::A_RANGE_TUPLE] = 19, c.log_height[vmc::A_RANGE] = 16;
         return c;
     }

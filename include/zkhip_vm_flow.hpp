@@ -13,7 +13,10 @@
 //      final root -- the `user_pvs_proof` of crates/types/src/proof.rs:52-67).
 #pragma once
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <numeric>
 
 #include "zkhip_aggregation.hpp"
@@ -312,33 +315,131 @@ inline Digest guest_image_root(const Exe& exe) {
 }
 
 // execute -> segment proofs -> aggregation tree -> root, with the provers handed in (their keys and circuits are reused from task
-// to task: the reference keeps its Sdk in a OnceLock, crates/prover/src/prover/mod.rs:78,115-126).
-inline GuestStark prove_guest_with(SegmentProver& sp, scroll_zkvm_hip::AggregationProver& agg, const Exe& exe, const StdIn& in, const SegmentCaps& caps,
-                                   bool keep_segments = false) {
+// to task: the reference keeps its Sdk in a OnceLock, crates/prover/src/prover/mod.rs:78,115-126).  The executor (this thread)
+// streams segments into a bounded queue; every lane (a SegmentProver with a context = HIP stream of its own) proves the segments it
+// takes, so the launch gaps and host-side pauses of one lane are filled by the other; the mandatory self-verification of the segment
+// proofs runs on host threads beside the lanes.  Segments are independent proofs; their order is restored.
+inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scroll_zkvm_hip::AggregationProver& agg, const Exe& exe, const StdIn& in,
+                                   const SegmentCaps& caps, bool keep_segments = false) {
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::duration d) { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(d).count(); };
+    if (lanes.empty()) throw Error("no segment prover lanes");
     GuestStark g;
     SegmentExecutor ex(exe, in, caps);
     g.image_root = ex.image_root(), g.entry_pc = exe.entry ? exe.entry : exe.pc_base;
-    std::vector<ChildProof> seg_proofs;
-    SegmentRecords rec;
-    clk::duration t_exec{}, t_prove{};
-    for (bool done = false; !done;) {
-        const auto a = clk::now();
-        done = ex.run_segment(rec);
-        const auto b = clk::now();
-        SegmentProof p = sp.prove(rec);
-        t_exec += b - a, t_prove += clk::now() - b;
-        seg_proofs.push_back(p.proof);
-        if (keep_segments) g.segment_proofs.push_back(std::move(p));
+    struct Item {
+        size_t index;
+        SegmentRecords rec;
+    };
+    std::deque<Item> queue;
+    std::vector<SegmentRecords> pool;
+    std::mutex mu;
+    std::condition_variable cv_push, cv_pop;
+    bool closed = false, failed = false;
+    std::string error;
+    std::vector<SegmentProof> proofs;
+    std::vector<std::thread> workers, verifiers;
+    std::deque<size_t> to_verify;
+    bool proving_done = false;
+    const auto t_start = clk::now();
+    for (SegmentProver* lane : lanes)
+        workers.emplace_back([&, lane] {
+            try {
+                for (;;) {
+                    Item it;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_pop.wait(lk, [&] { return !queue.empty() || closed || failed; });
+                        if (failed || queue.empty()) return;
+                        it = std::move(queue.front());
+                        queue.pop_front();
+                    }
+                    cv_push.notify_one();
+                    SegmentProof p = lane->prove(it.rec, /*self_verify=*/false);
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (proofs.size() <= it.index) proofs.resize(it.index + 1);
+                    proofs[it.index] = std::move(p);
+                    to_verify.push_back(it.index);
+                    pool.push_back(std::move(it.rec));
+                    cv_pop.notify_all();
+                }
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (error.empty()) error = e.what();
+                failed = true;
+                cv_push.notify_all(), cv_pop.notify_all();
+            }
+        });
+    const VerifyingKey& seg_vk = lanes[0]->vk();
+    for (size_t v = 0; v < std::max<size_t>(2, lanes.size()); v++)
+        verifiers.emplace_back([&] {
+            for (;;) {
+                size_t k;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_pop.wait(lk, [&] { return !to_verify.empty() || proving_done || failed; });
+                    if (to_verify.empty()) return;
+                    k = to_verify.front();
+                    to_verify.pop_front();
+                }
+                if (!seg_vk.verify(proofs[k].proof)) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (error.empty()) error = "the proof of segment " + std::to_string(k) + " does not verify";
+                    failed = true;
+                    cv_push.notify_all(), cv_pop.notify_all();
+                }
+            }
+        });
+    clk::duration t_exec{};
+    size_t n_seg = 0;
+    std::string exec_error;
+    try {
+        for (bool done = false; !done;) {
+            Item it;
+            it.index = n_seg++;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (failed) break;
+                if (!pool.empty()) it.rec = std::move(pool.back()), pool.pop_back();
+            }
+            const auto a = clk::now();
+            done = ex.run_segment(it.rec);
+            t_exec += clk::now() - a;
+            std::unique_lock<std::mutex> lk(mu);
+            cv_push.wait(lk, [&] { return queue.size() < 2 * lanes.size() || failed; });
+            queue.push_back(std::move(it));
+            lk.unlock();
+            cv_pop.notify_all();
+        }
+    } catch (const std::exception& e) {
+        exec_error = e.what();
     }
-    g.execution_mills = ms(t_exec), g.segment_proving_mills = ms(t_prove);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        closed = true;
+        if (!exec_error.empty()) failed = true;
+    }
+    cv_pop.notify_all();
+    for (auto& t : workers) t.join();
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        proving_done = true;
+    }
+    cv_pop.notify_all();
+    for (auto& t : verifiers) t.join();
+    if (!exec_error.empty()) throw Error(exec_error);
+    if (!error.empty()) throw Error("segment prover: " + error);
+    if (proofs.size() != n_seg) throw Error("segment prover: proofs missing");
+    g.execution_mills = ms(t_exec), g.segment_proving_mills = ms(clk::now() - t_start);   // wall: the execution runs under the proving
     bool all_zero = true;
     for (uint8_t b : ex.public_values()) all_zero = all_zero && b == 0;
     if (all_zero) throw Error("public_values are all 0s for unexpected reason");   // crates/prover/src/utils/vm.rs:34-46
     g.exec = ExecutionResult{ex.instret(), ex.public_values()};
     g.pv_openings = open_public_values(ex.tree());
-    g.segments = seg_proofs.size();
+    g.segments = n_seg;
+    std::vector<ChildProof> seg_proofs;
+    for (auto& p : proofs) seg_proofs.push_back(p.proof);
+    if (keep_segments) g.segment_proofs = std::move(proofs);
     const auto t0 = clk::now();
     const scroll_zkvm_hip::AggregationPlan plan = scroll_zkvm_hip::AggregationPlan::build(seg_proofs.size());
     g.root = agg.prove_tree(plan, seg_proofs);
@@ -348,11 +449,14 @@ inline GuestStark prove_guest_with(SegmentProver& sp, scroll_zkvm_hip::Aggregati
     return g;
 }
 inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
-                                        bool keep_segments = false) {
+                                        bool keep_segments = false, unsigned inflight = 2) {
     const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()));
-    SegmentProver sp(params, exe, caps, device);
-    scroll_zkvm_hip::AggregationProver agg = scroll_zkvm_hip::AggregationProver::setup(sp.vk(), segment_statement(), {}, device);
-    return prove_guest_with(sp, agg, exe, in, caps, keep_segments);
+    std::vector<std::unique_ptr<SegmentProver>> own;
+    std::vector<SegmentProver*> lanes;
+    for (unsigned l = 0; l < std::max(1u, inflight); l++) own.emplace_back(new SegmentProver(params, exe, caps, device)), lanes.push_back(own.back().get());
+    scroll_zkvm_hip::AggregationProver agg = scroll_zkvm_hip::AggregationProver::setup(lanes[0]->vk(), segment_statement(), {}, device);
+    (void)agg.node_vk(0);   // the leaf circuit and its key: setup, like the segment keys
+    return prove_guest_with(lanes, agg, exe, in, caps, keep_segments);
 }
 
 // The verifier's side: the root proof under the root verifying key, then the statement: the run starts at the guest's entry on the
@@ -404,7 +508,7 @@ public:
         return p;
     }
     void reset() {   // mod.rs:106-108: releases the device-resident keys, circuits and workspaces
-        agg_.reset(), seg_.reset();
+        agg_.reset(), seg_.clear();
     }
     // mod.rs:312-338
     uint64_t execute_and_check(const ProvingTask& task) const {
@@ -422,7 +526,9 @@ public:
         try {
             ensure();
             const zkhip_vm::StdIn in = task.build_guest_input();
-            last_ = zkhip_vm::prove_guest_with(*seg_, *agg_, exe_, in, caps_);
+            std::vector<zkhip_vm::SegmentProver*> lanes;
+            for (auto& l : seg_) lanes.push_back(l.get());
+            last_ = zkhip_vm::prove_guest_with(lanes, *agg_, exe_, in, caps_);
         } catch (const zkhip_vm::Error& e) {
             throw Error(Error::GenProof, std::string("failed to generate proof: ") + e.what());
         }
@@ -481,13 +587,14 @@ private:
     zkhip_params params_{};
     zkhip_vm::SegmentCaps caps_;
     int device_ = 0;
-    std::unique_ptr<zkhip_vm::SegmentProver> seg_;
+    unsigned inflight_ = 2;
+    std::vector<std::unique_ptr<zkhip_vm::SegmentProver>> seg_;   // lanes: segment provers in flight on the device
     std::unique_ptr<AggregationProver> agg_;
     zkhip_vm::GuestStark last_;
     void ensure() {
-        if (seg_) return;
-        seg_.reset(new zkhip_vm::SegmentProver(params_, exe_, caps_, device_));
-        agg_.reset(new AggregationProver(AggregationProver::setup(seg_->vk(), zkhip_vm::segment_statement(), {}, device_)));
+        if (!seg_.empty()) return;
+        for (unsigned l = 0; l < inflight_; l++) seg_.emplace_back(new zkhip_vm::SegmentProver(params_, exe_, caps_, device_));
+        agg_.reset(new AggregationProver(AggregationProver::setup(seg_[0]->vk(), zkhip_vm::segment_statement(), {}, device_)));
     }
 };
 

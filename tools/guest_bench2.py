@@ -1,0 +1,37 @@
+"""ONE FLOW at scale: a Fibonacci guest of ~n instructions through `prove_cli prove-elf` (include/zkhip_vm_flow.hpp): execution in
+segments of fixed heights, every segment ONE statement (23 chips, adapters + execution bus + persistent memory), aggregation tree
+to ONE root proof, self-verified, at the reference's FRI parameters.  Prints the CLI's JSON line + instructions per second.
+Usage: python tools/guest_bench2.py [n_iterations] [log_frame]"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import rv32_model as rv  # noqa: E402
+from test_vm_cpu import fib_program  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+    log_frame = sys.argv[2] if len(sys.argv) > 2 else "17"
+    tmp = tempfile.mkdtemp(prefix="zkhip_guest2_")
+    exe, inp = os.path.join(tmp, "fib.elf"), os.path.join(tmp, "stdin.bin")
+    open(exe, "wb").write(rv.elf_bytes(fib_program()))
+    open(inp, "wb").write(n.to_bytes(4, "little"))
+    cli = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
+    r = subprocess.run([cli, "prove-elf", exe, inp, tmp, "-", log_frame], capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr[-3000:])
+        sys.exit(r.returncode)
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    info["instr_per_s_wall"] = round(info["total_cycles"] / info["wall_s"])
+    info["instr_per_s_segments_only"] = round(info["total_cycles"] / max(1e-9, (info["execution_ms"] + info["segment_tracegen_and_proving_ms"]) / 1e3))
+    info["log_frame"] = int(log_frame)
+    print(json.dumps(info))
+
+
+if __name__ == "__main__":
+    main()
