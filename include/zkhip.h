@@ -211,7 +211,7 @@ int zkhip_rv32_auipc_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc, const uint32
 
 /* RV32 JALR core (rv32im Rv32JalrCoreAir).  Record i = (d_pc[i] < 2^30 - 4, d_rs1[i], d_imm[i] the raw 12-bit immediate).
  * ZKHIP_RV32_JALR_WIDTH = 20 columns: pc | imm | imm_limb[2] | imm_sign | rs1[4] | rd[4] = pc + 4 | t[4] = rs1 + sext(imm) mod 2^32 | lsb of
- * t | to_pc = t - lsb (must be < p) | is_valid; five range requests per row.  AIR: air.py rv32_jalr_core_air(). */
+ * t | to_pc = t - lsb (must be < 2^30: the top limb is range-checked as 4 t_3) | is_valid; five range requests per row.  AIR: air.py rv32_jalr_core_air(). */
 #define ZKHIP_RV32_JALR_WIDTH 20
 int zkhip_rv32_jalr_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc, const uint32_t *d_rs1, const uint32_t *d_imm, size_t n, unsigned log_height,
                              uint32_t *d_trace, uint32_t *d_bitwise_trace);

@@ -532,8 +532,9 @@ inline void rv32_jalr_core_air(AirBuilder& b, uint32_t bus = BITWISE_BUS) {
         b.push_interaction(bus, {x, t[1], z0, z0}, ok, Kind::Send);
     }
     {
+        const Expr y = t[3] * 4;
         const Expr z0 = b.constant(0);
-        b.push_interaction(bus, {t[2], t[3], z0, z0}, ok, Kind::Send);
+        b.push_interaction(bus, {t[2], y, z0, z0}, ok, Kind::Send);
     }
     {
         const Expr z0 = b.constant(0);

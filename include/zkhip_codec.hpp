@@ -329,7 +329,31 @@ inline bool well_formed(const ProofV1& p, uint32_t modulus = 2013265921u) {
         if (a.degree == 0 || (a.degree & (a.degree - 1))) return false;
         for (uint32_t v : a.public_values)
             if (!okw(v)) return false;
+        for (const auto& ph : a.exposed_values_after_challenge)
+            for (const auto& e : ph)
+                if (!oke(e)) return false;
     }
+    // every opened value, the proof-of-work witnesses: a word w + p would decode to the same field element as w
+    auto oka = [&](const AdjacentOpenedValues& v) {
+        for (const auto& e : v.local)
+            if (!oke(e)) return false;
+        for (const auto& e : v.next)
+            if (!oke(e)) return false;
+        return true;
+    };
+    for (const auto& v : p.values.preprocessed)
+        if (!oka(v)) return false;
+    for (const auto& c : p.values.main)
+        for (const auto& v : c)
+            if (!oka(v)) return false;
+    for (const auto& c : p.values.after_challenge)
+        for (const auto& v : c)
+            if (!oka(v)) return false;
+    for (const auto& a : p.values.quotient)
+        for (const auto& ch : a)
+            for (const auto& e : ch)
+                if (!oke(e)) return false;
+    if (!okw(p.fri.pow_witness) || (p.has_logup_pow && !okw(p.logup_pow_witness))) return false;
     const QueryProof* q0 = p.fri.query_proofs.empty() ? nullptr : &p.fri.query_proofs[0];
     for (const auto& q : p.fri.query_proofs) {
         if (q.input_proof.size() != q0->input_proof.size() || q.commit_phase_openings.size() != p.fri.commit_phase_commits.size())

@@ -133,10 +133,11 @@ public:
     // segments are independent proofs; what chains them is that a cell's final value in one segment is its
     // initial value in the next one that touches it.  Returns true once the guest has exited.
     bool run_segment(uint64_t max_instr, ExecRecords* rec) {
-        if (rec && max_instr && max_instr <= ((uint64_t)1 << 24)) {   // the memory log grows by about five entries per instruction
-            rec->pc_index.reserve(max_instr);
+        if (rec && max_instr && log_memory_) {   // the memory log grows by about five entries per instruction; a hint, capped at 2^20 instructions
+            const uint64_t hint = std::min<uint64_t>(max_instr, (uint64_t)1 << 20);
+            rec->pc_index.reserve(hint);
             for (auto* v : {&rec->acc_as, &rec->acc_ptr, &rec->acc_prev_data, &rec->acc_prev_ts, &rec->acc_data, &rec->acc_ts, &rec->acc_is_read})
-                v->reserve(5 * max_instr);
+                v->reserve(5 * hint);
         }
         for (uint64_t k = 0; !done_ && (max_instr == 0 || k < max_instr); k++) step(rec);
         close_segment(rec);
@@ -525,6 +526,7 @@ inline Exe parse_exe(const std::vector<uint8_t>& raw) {
     if (n_prog > raw.size() / 4) throw Error("exe truncated");
     for (size_t i = 0; i < n_prog; i++) exe.program.push_back(word(3 + i));
     exe.data_base = word(3 + n_prog), exe.memory_bytes = word(4 + n_prog);
+    if ((uint64_t)exe.data_base + exe.memory_bytes > (1ull << 30)) throw Error("the read-write region must lie below 2^30");   // as load_elf
     const size_t n_data = word(5 + n_prog), off = 4 * (6 + n_prog);
     if (off + n_data > raw.size()) throw Error("exe data truncated");
     exe.data.assign(raw.begin() + (long)off, raw.begin() + (long)(off + n_data));

@@ -366,8 +366,11 @@ inline SegmentedProof prove_segments(const zkhip_params& params, const Exe& exe,
                     pool.push_back(std::move(it.rec));
                 }
             } catch (const std::exception& e) {
-                errors[l] = e.what();
-                lane_failed = true;
+                {
+                    std::lock_guard<std::mutex> lk(mu);   // under the queue's mutex: the executor cannot miss the notification
+                    errors[l] = e.what();
+                    lane_failed = true;
+                }
                 cv_push.notify_all();
             }
         });
@@ -377,7 +380,8 @@ inline SegmentedProof prove_segments(const zkhip_params& params, const Exe& exe,
             closed = true;
         }
         cv_pop.notify_all();
-        for (auto& t : lanes) t.join();
+        for (auto& t : lanes)
+            if (t.joinable()) t.join();
     };
     clk::duration exec_time{};
     size_t n_segments = 0;
@@ -398,6 +402,12 @@ inline SegmentedProof prove_segments(const zkhip_params& params, const Exe& exe,
             queue.push_back(std::move(it));
             lk.unlock();
             cv_pop.notify_one();
+        }
+        if (lane_failed) {   // the run was cut short by a failed lane: that error, not a verdict on an unfinished guest
+            close_queue();
+            for (const auto& e : errors)
+                if (!e.empty()) throw Error("segment prover: " + e);
+            throw Error("segment prover: a lane failed");
         }
         if (m.exit_code()) throw Error("guest exited with code " + std::to_string(m.exit_code()));
         bool all_zero = true;

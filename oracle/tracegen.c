@@ -445,7 +445,7 @@ size_t ora_rv32_jalr_trace(const uint32_t *pcs, const uint32_t *rs1s, const uint
             continue;
         }
         const uint32_t sign = imm >> 11, ext = sign ? imm | 0xfffff000u : imm, t = rs1 + ext, rd = pc + 4, to_pc = t & ~1u;
-        if (to_pc >= ORA_P) {   /* not a program counter this field can hold */
+        if (to_pc >= (1u << 30)) {   /* program counters are 30-bit values (the top limb of t is range-checked as 4 t_3) */
             bad++;
             continue;
         }
@@ -458,7 +458,7 @@ size_t ora_rv32_jalr_trace(const uint32_t *pcs, const uint32_t *rs1s, const uint
         trace[17 * N + r] = t & 1u, trace[18 * N + r] = to_pc, trace[19 * N + r] = 1;
         ora_bump(range_counts, imm & 255u, ((imm >> 8) - 8 * sign) * 32);
         ora_bump(range_counts, (t & 255u) >> 1, (t >> 8) & 255u);
-        ora_bump(range_counts, (t >> 16) & 255u, t >> 24);
+        ora_bump(range_counts, (t >> 16) & 255u, (t >> 24) * 4);
         ora_bump(range_counts, rd & 255u, (rd >> 8) & 255u);
         ora_bump(range_counts, (rd >> 16) & 255u, (rd >> 24) * 4);
     }

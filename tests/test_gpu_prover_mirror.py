@@ -180,3 +180,35 @@ def test_aggregation_tree_schedule(ora, tmp_path):
     root = json.loads((tmp_path / "root.json").read_text())
     assert struct.unpack("<3I", pm.un_b64_bincode(root["user_pvs_proof"]))[:2] == fold(1, 0, node_commit)
     assert pm.run_cli("verify", agg_exe, cfg, str(tmp_path / "root.json")).returncode == 0
+
+
+def test_batch_prover_multi_device_queue_on_one_gpu(ora, tmp_path):
+    """BatchProver over a device LIST (segments spread over the GPUs of a node): ZKHIP_BATCH_DEVICES=0,0,0 builds
+    three lane groups as if there were three GPUs -- all mapped onto this box's one device -- so the cross-device queue (contexts
+    bound per call, one host thread per lane, results in task order) runs in the GPU suite.  Seven tasks, six lanes: every proof
+    equals the oracle's."""
+    import os
+    import subprocess
+
+    tasks, all_airs = [], []
+    for i in range(7):
+        sa = air.SyntheticAir(width=20, n_free=7, n_bool=3, n_boundary=2, seed=9)
+        tr, pv = sa.gen_trace(7, seed=60 + i)
+        ftr, fpv = air.fibonacci_trace(5, a0=i)
+        airs = [dict(program=sa.program(), log_height=7, width=20, n_pvs=len(pv), trace=tr, pvs=pv),
+                dict(program=air.fibonacci_air().program(), log_height=5, width=2, n_pvs=3, trace=ftr, pvs=fpv)]
+        all_airs.append(airs)
+        d = tmp_path / ("t%d" % i)
+        d.mkdir()
+        tasks.append(pm.write_task(str(d), airs, identifier="seg-%d" % i))
+    exe, cfg = pm.write_app(str(tmp_path), all_airs[0], PARAMS)
+    env = dict(os.environ, ZKHIP_BATCH_DEVICES="0,0,0")
+    r = subprocess.run([pm.CLI, "prove-batch", exe, cfg, str(tmp_path), "2", *tasks], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "7 proofs on 6 lanes" in r.stdout, r.stderr
+    for i, airs in enumerate(all_airs):
+        js = json.loads((tmp_path / ("seg-%d.json" % i)).read_text())
+        assert pm.un_b64_bincode(js["proof"]) == ora.stark_prove(PARAMS, airs).tobytes()
+    # a device that does not exist is refused by that lane, and the whole batch reports it
+    env = dict(os.environ, ZKHIP_BATCH_DEVICES="0,63")
+    r = subprocess.run([pm.CLI, "prove-batch", exe, cfg, str(tmp_path), "1", *tasks[:2]], capture_output=True, text=True, env=env)
+    assert r.returncode == 1 and "gfx950" in r.stderr

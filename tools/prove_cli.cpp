@@ -308,7 +308,18 @@ int main(int argc, char** argv) {
         if (argc >= 7 && std::string(argv[1]) == "prove-batch") {
             // prove-batch <app> <cfg> <out_dir> <inflight> <task.bin>... : BatchProver::prove_many -- the tasks are queued
             // over `inflight` Provers on GPU 0 (the replacement of the sequential chunk loop, batch.rs:97-107)
-            BatchProver bp = BatchProver::setup(ProverConfig{argv[2], argv[3]}, (unsigned)std::stoul(argv[5]));
+            // ZKHIP_BATCH_DEVICES="0,0,1": the device of every lane group (default "0").  Listing one device several times maps the
+            // multi-device queue (one lane group per entry, tasks spread over all of them) onto a single GPU: the self-test of the
+            // cross-device path on a one-GPU box (tests/test_gpu_prover_mirror.py).
+            std::vector<int> devs{0};
+            if (const char* e = getenv("ZKHIP_BATCH_DEVICES")) {
+                devs.clear();
+                std::stringstream ss(e);
+                std::string item;
+                while (std::getline(ss, item, ',')) devs.push_back(std::stoi(item));
+                if (devs.empty()) throw Error(Error::Setup, "ZKHIP_BATCH_DEVICES is empty");
+            }
+            BatchProver bp = BatchProver::setup(ProverConfig{argv[2], argv[3]}, (unsigned)std::stoul(argv[5]), devs);
             std::vector<ProvingTask> tasks;
             for (int i = 6; i < argc; i++) tasks.push_back(read_task(argv[i]));
             BatchProver::Stats st;

@@ -885,7 +885,7 @@ def rv32_jalr_core_air(bus=9):
     """The core of OpenVM's RV32 JALR chip (rv32im `Rv32JalrCoreAir`): columns pc | imm | imm_limb[2] | imm_sign | rs1[4] | rd[4] |
     t[4] | lsb | to_pc | is_valid.  imm is the raw 12-bit immediate = imm_limb_0 + 2^8 imm_limb_1 with imm_sign its bit 11
     (imm_limb_1 - 8 imm_sign in [0, 8)); t = rs1 + sign-extended imm mod 2^32, limb by limb with boolean carries; to_pc = t with its
-    lowest bit (lsb) cleared; rd = pc + 4.  Five range requests: (imm_0, 32 (imm_1 - 8 sign)), ((t_0 - lsb) / 2, t_1), (t_2, t_3),
+    lowest bit (lsb) cleared; rd = pc + 4.  Five range requests: (imm_0, 32 (imm_1 - 8 sign)), ((t_0 - lsb) / 2, t_1), (t_2, 4 t_3),
     (rd_0, rd_1), (rd_2, 4 rd_3)."""
     b = AirBuilder(RV32_JALR_WIDTH, 0)
     pc, imm = b.var(0), b.var(1)
@@ -906,7 +906,7 @@ def rv32_jalr_core_air(bus=9):
     inv2 = pow(2, -1, P)
     b.push_interaction(bus, [il[0], (il[1] - sign * 8) * 32, 0, 0], ok, "send")
     b.push_interaction(bus, [(t[0] - lsb) * inv2, t[1], 0, 0], ok, "send")
-    b.push_interaction(bus, [t[2], t[3], 0, 0], ok, "send")
+    b.push_interaction(bus, [t[2], t[3] * 4, 0, 0], ok, "send")     # t below 2^30: to_pc cannot alias a target beyond the field
     b.push_interaction(bus, [rd[0], rd[1], 0, 0], ok, "send")
     b.push_interaction(bus, [rd[2], rd[3] * 4, 0, 0], ok, "send")
     return b

@@ -296,6 +296,8 @@ extern "C" int zkhip_proof_from_v1(const zkhip_params* prm, const zkhip_air* air
     try {
         const cd::ProofV1 p = cd::decode_proof(v1, v1_len);
         if (!cd::well_formed(p, P)) return ZKHIP_ERR_VERIFY;
+        for (size_t a = 0; a < p.per_air.size(); a++)
+            if (p.per_air[a].air_id != a) return ZKHIP_ERR_VERIFY;   // this backend's proofs carry every AIR of the key, in key order
         // shape checks against the key
         if (p.main_trace.size() != s.n_cached + 1 || p.after_challenge.size() != (s.n_lu ? 1u : 0u) || p.per_air.size() != n_airs ||
             p.fri.commit_phase_commits.size() != s.n_layers || p.fri.final_poly.size() != s.n_fin ||

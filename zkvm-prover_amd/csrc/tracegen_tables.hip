@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256) void k_rv32_jalr(const uint32_t* __restrict__ 
     if (r < n) {
         const uint32_t pc = pcs[r], rs1 = rs1s[r], imm = imms[r];
         const uint32_t sign = (imm >> 11) & 1u, t = rs1 + (sign ? imm | 0xfffff000u : imm), rd = pc + 4, to_pc = t & ~1u;
-        if (pc >= (1u << 30) - 4 || (imm >> 12) != 0 || to_pc >= P) {
+        if (pc >= (1u << 30) - 4 || (imm >> 12) != 0 || to_pc >= (1u << 30)) {   // program counters are 30-bit values
             atomicAdd(bad, 1u);
         } else {
             col[0] = to_monty(pc), col[1] = to_monty(imm), col[2] = to_monty(imm & 255u), col[3] = to_monty(imm >> 8), col[4] = sign ? MONTY_ONE : 0u;
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256) void k_rv32_jalr(const uint32_t* __restrict__ 
             col[17] = (t & 1u) ? MONTY_ONE : 0u, col[18] = to_monty(to_pc), col[19] = MONTY_ONE;
             bump_range_hot(hk_r, hc_r, range_counts, imm & 255u, ((imm >> 8) - 8 * sign) * 32);
             bump_range_hot(hk_r, hc_r, range_counts, (t & 255u) >> 1, (t >> 8) & 255u);
-            bump_range_hot(hk_r, hc_r, range_counts, (t >> 16) & 255u, t >> 24);
+            bump_range_hot(hk_r, hc_r, range_counts, (t >> 16) & 255u, (t >> 24) * 4);
             bump_range_hot(hk_r, hc_r, range_counts, rd & 255u, (rd >> 8) & 255u);
             bump_range_hot(hk_r, hc_r, range_counts, (rd >> 16) & 255u, (rd >> 24) * 4);
         }
