@@ -379,7 +379,7 @@ def main():
                 # HBM traffic of this kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
                 # corrected as MI355X_MICROARCH.md prescribes; bench.py cannot collect counters itself)
                 try:
-                    pmc_file = next(n for n in ("round02_pmc_traffic.json", "round01_pmc_traffic.json")
+                    pmc_file = next(n for n in ("round03_pmc_traffic.json", "round02_pmc_traffic.json", "round01_pmc_traffic.json")
                                     if os.path.exists(os.path.join(ROOT, "profiles", n)))
                     with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                         pmc = json.load(f)["kernels"]
@@ -392,16 +392,32 @@ def main():
                     pass
                 if name == "poseidon2_hash_rows":
                     perms = M * ((width + 7) // 8 + 1 + 2)
-                    # issue-cycle model from the kernel's ISA with the measured issue costs (4.2 - 4.4
-                    # cycles per wave64 multiply-class instruction, 2.3 per full-rate one): external round 192 + 280
-                    # instructions = 1.46k cycles (x 8), internal round 20 + 145 = 0.42k (x 13), first linear layer
-                    # 0.5k: ~17.7k VALU issue cycles per wave64 permutation (19.0k before the signed S-box), 1024
-                    # SIMDs at the 2.4 GHz peak clock
                     rate = perms / (per_step_ms * 1e-3)
                     roof["valu"] = {"perms_per_s": round(rate, 0),
-                                    "issue_frac_of_peak_clock": round(rate / 64 * 17.7e3 / (1024 * 2.4e9), 3),
-                                    "note": "the kernel is integer-VALU bound (~570 Montgomery products and ~1300 modular "
-                                            "add/sub per permutation, 6.0k VALU instructions), not HBM bound; frac above is vs HBM as BASELINE asks"}
+                                    "note": "the kernel is integer-VALU bound (~570 Montgomery products and ~1300 modular add/sub per "
+                                            "permutation, 6.1k VALU instructions), not HBM bound; frac above is vs HBM as BASELINE asks"}
+                    # ABSOLUTE VALU roofline from the committed counter pass (profiles/round03_pmc_valu.json, tools/pmc_valu3.py):
+                    # SQ_INSTS_VALU per launch x cycles per wave-instruction of the kernel's ISA mix (tools/isa_mix.py: multiply-class
+                    # share x 4.2 + the rest x 2.2 cycles, costs measured by tools/ubench_valu.hip) / (1024 SIMDs x 2.4 GHz), against
+                    # THIS run's HIP-event time per launch -- no rate of the kernel itself enters the floor
+                    try:
+                        with open(os.path.join(ROOT, "profiles", "round03_pmc_valu.json")) as f:
+                            pv3 = json.load(f)
+                        kv = pv3["kernels"]["zk::k_hash_rows"]
+                        if log_n == 22 and width == 300:
+                            ms_launch = per_step_ms / (launches / steps_profiled)
+                            roof["valu"].update({
+                                "wave_instr_per_launch": kv["valu_wave_instr_per_launch"],
+                                "cycles_per_wave_instr_model": kv["isa_mix"]["cycles_per_wave_instruction_model"],
+                                "multiply_class_fraction": kv["isa_mix"]["multiply_class_fraction"],
+                                "floor_ms_per_launch": kv["valu_roofline_ms_per_launch"],
+                                "measured_ms_per_launch": round(ms_launch, 3),
+                                "frac_of_valu_peak": round(kv["valu_roofline_ms_per_launch"] / ms_launch, 4),
+                                "clock_ghz_under_pmc": kv.get("clock_ghz_from_grbm_gui_active"),
+                                "issue_efficiency_at_measured_clock_under_pmc": kv.get("issue_efficiency_at_measured_clock"),
+                                "source": "profiles/round03_pmc_valu.json + profiles/round03_isa_mix_hash_rows.json"})
+                    except Exception:
+                        pass
         # the memory-side kernels against the same HBM peak (algorithmic bytes / measured time)
         others = {}
         cols_all = width + 2 + 16  # trace columns + quotient-chunk columns that go through the LDE
@@ -417,22 +433,20 @@ def main():
                 others[k] = {"algorithmic_bytes_per_step": alg_b, "ms_per_step": round(ms, 3),
                              "achieved_GBps": round(alg_b / (ms * 1e-3) / 1e9, 1),
                              "frac_of_hbm_peak": round(alg_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        # whole-proof VALU roofline from the committed counter pass (tools/pmc_valu.py): the time one proof's VALU
-        # instructions take at the issue rate of the best-utilised kernel, against the measured time per proof
+        # whole-proof VALU roofline from the committed counter pass (tools/pmc_valu3.py): one proof's VALU wave-instructions priced at
+        # the cycles per instruction of the row-hash kernel's ISA mix on 1024 SIMDs at 2.4 GHz, against the measured time per proof
         valu_roof = None
         try:
-            valu_file = next(n for n in ("round02_pmc_valu.json", "round01_pmc_valu.json")
-                             if os.path.exists(os.path.join(ROOT, "profiles", n)))
-            with open(os.path.join(ROOT, "profiles", valu_file)) as f:
+            with open(os.path.join(ROOT, "profiles", "round03_pmc_valu.json")) as f:
                 pv = json.load(f)
             if log_n == 22 and width == 300:
                 ms = dt / args.steps * 1e3  # every rank proves `steps` proofs in dt
                 valu_roof = {"valu_wave_instr_per_proof": pv["total_valu_wave_instr_per_proof"],
-                             "ms_at_best_issue_rate": pv["total_ms_at_hash_issue_rate"],
+                             "floor_ms_per_proof": pv["total_valu_roofline_ms_per_proof"],
                              "ms_per_proof_per_gpu": round(ms, 2),
-                             "frac": round(pv["total_ms_at_hash_issue_rate"] / ms, 3),
-                             "note": "profiles/" + valu_file + ": SQ_INSTS_VALU summed over the kernels of one proof, "
-                                     "priced at the row-hash kernel's measured issue rate"}
+                             "frac": round(pv["total_valu_roofline_ms_per_proof"] / ms, 3),
+                             "note": "profiles/round03_pmc_valu.json: SQ_INSTS_VALU summed over the kernels of one proof x 2.82 cycles per "
+                                     "wave-instruction (ISA mix of the row-hash kernel, which issues 69 % of them) / (1024 SIMDs x 2.4 GHz)"}
         except Exception:
             pass
         # whole-proof HBM roofline (SURVEY.md 8(d) cfg #4: unfused per-stage algorithmic bytes of one proof): the LDE reads
