@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import prover_mirror_util as pm
+import zkvm_prover_amd as z
 from zkvm_prover_amd import air
 
 pytestmark = pytest.mark.gpu
@@ -137,11 +138,11 @@ def test_batch_prover_queue_and_api_throughput(ora, tmp_path):
     assert r.returncode == 1 and "kind 4" in r.stderr
 
 
-def test_aggregation_tree_schedule(ora, tmp_path):
-    """Six segments proven through a BatchProver, then the reference's aggregation tree shape (leaf arity 4, internal 3:
-    2 leaf nodes + 1 root) through another, every node bound to its children's commitments by a stand-in circuit (the
-    recursion AIRs are not available): node proofs verify, and their public inputs are what the children's proofs dictate."""
-    import struct
+def test_aggregation_tree_over_a_batch(ora, tmp_path):
+    """Six independent segment proofs (no chained state) through a BatchProver, then the reference's aggregation tree shape (leaf
+    arity 4, internal 3: 2 leaf nodes + 1 root) on REAL node circuits (tests/test_gpu_recursion.py covers the circuit itself): the
+    root verifies under root.vk alone and its accumulator is the Poseidon2 chain over the segments' public values."""
+    import recursion_util as ru
 
     tasks, all_airs = [], []
     for i in range(6):
@@ -155,31 +156,23 @@ def test_aggregation_tree_schedule(ora, tmp_path):
         d.mkdir()
         tasks.append(pm.write_task(str(d), airs, identifier="seg-%d" % i))
     seg_exe, cfg = pm.write_app(str(tmp_path), all_airs[0], PARAMS)
-    (tmp_path / "agg").mkdir()
-    fib = [dict(program=air.fibonacci_air().program(), log_height=6, width=2, n_pvs=3)]
-    agg_exe, _ = pm.write_app(str(tmp_path / "agg"), fib, PARAMS)
-    r = pm.run_cli("prove-agg", seg_exe, agg_exe, cfg, str(tmp_path), "2", *tasks)
-    assert r.returncode == 0 and "aggregated 6 segments through 3 nodes in 2 levels" in r.stdout, r.stderr
-    seg_commit = [np.frombuffer(ora.stark_prove(PARAMS, a).tobytes(), np.uint32)[4:12] for a in all_airs]
-
-    def fold(level, node, commits):
-        a0, b0 = 1 + level, 1 + node
-        for c in commits:
-            for v in c:
-                a0 = (a0 * 31 + int(v)) % air.P
-                b0 = (b0 * 37 + int(v) + a0) % air.P
-        return a0, b0
-
-    node_commit = []
-    for n, kids in enumerate([[0, 1, 2, 3], [4, 5]]):
-        js = json.loads((tmp_path / ("agg-0-%d.json" % n)).read_text())
-        pvs = struct.unpack("<3I", pm.un_b64_bincode(js["user_pvs_proof"]))
-        assert pvs[:2] == fold(0, n, [seg_commit[k] for k in kids])
-        node_commit.append(np.frombuffer(pm.un_b64_bincode(js["proof"]), np.uint32)[4:12])
-        assert pm.run_cli("verify", agg_exe, cfg, str(tmp_path / ("agg-0-%d.json" % n))).returncode == 0
-    root = json.loads((tmp_path / "root.json").read_text())
-    assert struct.unpack("<3I", pm.un_b64_bincode(root["user_pvs_proof"]))[:2] == fold(1, 0, node_commit)
-    assert pm.run_cli("verify", agg_exe, cfg, str(tmp_path / "root.json")).returncode == 0
+    out = tmp_path / "out"
+    out.mkdir()
+    r = pm.run_cli("prove-agg", seg_exe, cfg, str(out), "2", "-", *tasks)
+    assert r.returncode == 0, r.stderr[-2000:]
+    info = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert info["segments"] == 6 and info["nodes"] == 3 and info["levels"] == 2
+    assert pm.run_cli("verify", str(out / "root.vk"), cfg, str(out / "root.json")).returncode == 0
+    accs = [ru.leaf_accumulator([[a["pvs"] for a in s] for s in all_airs[i:i + 4]]) for i in (0, 4)]
+    assert info["root_public_values"][8:] == ru.internal_accumulator(accs).tolist()
+    # the first leaf node's proof, re-derived: same circuit, same witness, the oracle's prover
+    rc = z.RecursionCircuit(PARAMS, [{k: a[k] for k in ("program", "log_height", "width", "n_pvs")} for a in all_airs[0]], 4)
+    st, npv = rc.witness([ora.stark_prove(PARAMS, a).tobytes() for a in all_airs[:4]], [[a["pvs"] for a in s] for s in all_airs[:4]])
+    assert st == 0
+    leaf0 = json.loads((out / "agg-0-0.json").read_text())
+    assert pm.un_b64_bincode(leaf0["proof"]) == ora.stark_prove(PARAMS, ru.node_instance(rc, npv)).tobytes()
+    # bad command lines are errors, not crashes
+    assert pm.run_cli("prove-agg", seg_exe, cfg, str(out), "two", "-", *tasks).returncode in (1, 2)
 
 
 def test_batch_prover_multi_device_queue_on_one_gpu(ora, tmp_path):

@@ -488,5 +488,8 @@ int main(int argc, char** argv) {
     } catch (const Error& e) {
         std::fprintf(stderr, "error(kind %d): %s\n", (int)e.kind, e.what());
         return 1;
+    } catch (const std::exception& e) {   // a malformed number on the command line, an allocation failure: an error, not a crash
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 2;
     }
 }
