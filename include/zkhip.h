@@ -588,6 +588,16 @@ int zkhip_rows_tracegen(zkhip_ctx *ctx, const uint32_t *d_rows, size_t n, size_t
 int zkhip_range_counts_scaled_tracegen(zkhip_ctx *ctx, const uint32_t *d_values, size_t n, uint32_t scale, unsigned log_table, uint32_t *d_counts,
                                        int accumulate);
 
+/* ---- Keccak-f[1600] chip (include/zkhip_keccak.hpp: one round per row, 24 rows per permutation, 2633 columns, degree 3 -- the
+ *      shape of Plonky3's p3-keccak-air that OpenVM's keccak extension wraps; crates/circuits/chunk-circuit/openvm.toml:8-59 lists
+ *      `keccak` among the chunk circuit's extensions).  Pinned to FIPS 202 / hashlib (tests/golden/keccak_kat.json). ---- */
+#define ZKHIP_KECCAK_F_WIDTH 2633
+int zkhip_keccak_f_air(zkhip_air *out);            /* the AIR program (pointer valid for the life of the process), width, no public values */
+int zkhip_keccak_f1600_host(uint64_t state[25]);   /* the permutation on lanes state[x + 5 y] (host) */
+/* d_states: n_perms x 50 words (lane x + 5 y = words 2 i, 2 i + 1, low word first; plain integers); fills 2^log_height rows: rows
+ * 24 p .. 24 p + 23 = the rounds of permutation p, the rest permutations of the zero state (valid padding) */
+int zkhip_keccak_f_tracegen(zkhip_ctx *ctx, const uint32_t *d_states, size_t n_perms, unsigned log_height, uint32_t *d_trace);
+
 /* ---- aggregation layer: the verifier circuit.  Replaces, for this backend's proofs, the leaf /
  *      internal verifier programs the reference's SDK proves at the nodes of its aggregation tree and `commit_child_vk`
  *      (crates/prover/src/prover/mod.rs:47-60, 200-282; crates/integration/src/lib.rs:461-514).  A circuit is built for ONE

@@ -13,6 +13,7 @@ pub const ZKHIP_ERR_POW_FAILED: c_int = -6;
 pub const ZKHIP_ERR_VERIFY: c_int = -7;
 pub const ZKHIP_ERR_CONSTRAINT: c_int = -8;
 pub const ZKHIP_DIGEST_WORDS: usize = 8;
+pub const ZKHIP_KECCAK_F_WIDTH: usize = 2633;
 pub const ZKHIP_POSEIDON2_AIR_WIDTH: usize = 298;
 pub const ZKHIP_MEMORY_BOUNDARY_WIDTH: usize = 8;
 pub const ZKHIP_RV32_ALU_WIDTH: usize = 18;
@@ -328,6 +329,11 @@ extern "C" {
                                pad_row: *const u32) -> c_int;
     pub fn zkhip_range_counts_scaled_tracegen(ctx: *mut zkhip_ctx, d_values: *const u32, n: usize, scale: u32, log_table: c_uint,
                                               d_counts: *mut u32, accumulate: c_int) -> c_int;
+
+    // Keccak-f[1600] chip
+    pub fn zkhip_keccak_f_air(out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_keccak_f1600_host(state: *mut u64) -> c_int;
+    pub fn zkhip_keccak_f_tracegen(ctx: *mut zkhip_ctx, d_states: *const u32, n_perms: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;
 
     // aggregation layer: the verifier circuit of a node (commit_child_vk / VerifyProver of the reference)
     pub fn zkhip_recursion_build(child_params: *const zkhip_params, child_airs: *const zkhip_air, n_child_airs: usize, max_children: usize,

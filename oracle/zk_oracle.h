@@ -177,6 +177,11 @@ int ora_ch_check_witness(ora_challenger *c, unsigned bits, uint32_t witness);
 /* in: 2*n ext elements (bit-reversed domain order), out: n ext elements */
 void ora_fri_fold(const uint32_t *in, uint32_t *out, unsigned log_n_out, const uint32_t beta[4]);
 
+/* ---- Keccak (oracle/keccak.c): the permutation, the FIPS 202 sponge at rate 136, the Keccak-f chip's trace ---- */
+void ora_keccak_f1600(uint64_t st[25]);
+void ora_sha3_256(const uint8_t *msg, size_t len, uint8_t out[32], int keccak_padding);
+void ora_keccak_f_trace(const uint64_t *inputs, size_t n_perms, unsigned log_height, uint32_t *trace);
+
 /* the verifier's bus check: n exposed cumulative sums (4 canonical words each) must add up to zero; 0 = balanced */
 int ora_logup_exposed_check(const uint32_t *exposed, size_t n);
 

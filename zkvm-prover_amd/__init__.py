@@ -16,6 +16,8 @@ from ._binding import (  # noqa: F401
     declared_symbols,
     ProvingKey,
     RecursionCircuit,
+    keccak_f_air,
+    keccak_f1600_host,
     verify,
     proof_layout,
     DEFAULT_PARAMS,

@@ -164,6 +164,9 @@ def load_library():
         "zkhip_proof_from_v1": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(C.c_uint8), sz,
                                           C.POINTER(C.c_uint8), sz, C.POINTER(sz), C.POINTER(u32p)]),
         "zkhip_proof_layout_of": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(_ProofLayout)]),
+        "zkhip_keccak_f_air": (C.c_int, [C.POINTER(_Air)]),
+        "zkhip_keccak_f1600_host": (C.c_int, [C.POINTER(C.c_uint64)]),
+        "zkhip_keccak_f_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
         "zkhip_vm_n_airs": (sz, []),
         "zkhip_vm_air": (C.c_int, [C.c_uint, C.POINTER(_Air), C.POINTER(sz)]),
         "zkhip_vm_decode": (C.c_int, [C.c_uint32, C.c_uint32, u32p, C.POINTER(C.c_int)]),
@@ -615,6 +618,11 @@ class Context:
                                                                 1 if accumulate else 0))
         return t_counts
 
+    def keccak_f_tracegen(self, t_states, n_perms, log_height):
+        out = self._new(2633 << log_height)
+        self._check(self.lib.zkhip_keccak_f_tracegen(self.h, t_states.data_ptr() if n_perms else None, n_perms, log_height, out.data_ptr()))
+        return out
+
     def merkle_commit(self, mats, want_root=True):
         """mats: list of (tensor, log_height, width[, stride])."""
         return MerkleTree(self, mats, want_root)
@@ -868,6 +876,20 @@ def verify(params, airs, pvs, proof_bytes):
     pa, keep2 = _pvs_array(pvs)
     buf = np.frombuffer(proof_bytes, dtype=np.uint8)
     return lib.zkhip_verify(C.byref(prm), arr, len(airs), pa, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size)
+
+
+def keccak_f_air():
+    """The Keccak-f[1600] chip's AIR (program, width) from the library; its one definition is include/zkhip_keccak.hpp."""
+    lib = load_library()
+    a = _Air()
+    assert lib.zkhip_keccak_f_air(C.byref(a)) == 0
+    return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
+
+
+def keccak_f1600_host(lanes):
+    st = np.ascontiguousarray(lanes, dtype=np.uint64).copy()
+    assert st.size == 25 and load_library().zkhip_keccak_f1600_host(st.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+    return st
 
 
 class RecursionCircuit:
