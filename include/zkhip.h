@@ -554,6 +554,12 @@ int zkhip_proof_to_v1(const zkhip_params *params, const zkhip_air *airs, size_t 
 int zkhip_proof_from_v1(const zkhip_params *params, const zkhip_air *airs, size_t n_airs, const uint8_t *v1, size_t v1_len,
                         uint8_t *out, size_t cap, size_t *out_len, uint32_t *const *pvs_out);
 
+/* Trace generators check their records on the device and report at once: one stream synchronisation per call.  A caller that
+ * issues dozens of generators per proof turns the immediate reports off (on = 1): bad-record counts are then summed on the device,
+ * and zkhip_tracegen_check synchronises once, returns ZKHIP_ERR_INVALID if anything was refused since the last check, and resets. */
+int zkhip_tracegen_defer_checks(zkhip_ctx *ctx, int on);
+int zkhip_tracegen_check(zkhip_ctx *ctx);
+
 /* ---- the ONE-STATEMENT VM circuit (include/zkhip_vm_circuit.hpp; SURVEY.md 8(f) f3 adapters / execution bus / connector /
  *      persistent memory -- OpenVM's openvm-circuit and openvm-rv32im-circuit crates, un-vendored; reached by the reference through
  *      sdk.prove, crates/prover/src/prover/mod.rs:355-357).  The AIR set of a segment is defined ONCE, in C++; these entry points

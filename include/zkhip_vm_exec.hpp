@@ -127,6 +127,10 @@ public:
         if ((uint64_t)exe.data_base + exe.memory_bytes > (1ull << 30) || (uint64_t)exe.pc_base + 4 * exe.program.size() > (1ull << 30))
             throw Error("guest addresses must lie below 2^30");
         m_.set_memory_log(false);
+        dec_.reserve(exe.program.size());
+        for (size_t k = 0; k < exe.program.size(); k++) dec_.push_back(vmc::decode(exe.program[k], exe.pc_base + 4 * (uint32_t)k));
+        mem_lo_blk_ = exe.data_base / 16;
+        mem_slot_.assign(((size_t)exe.memory_bytes + 15) / 16 + 1, 0);
         // the initial memory image: registers (sp), the data segment
         std::vector<std::pair<uint32_t, std::array<uint32_t, 8>>> blocks;
         for (uint32_t blk = 0; blk < 8; blk++) push_nonzero(blocks, 1, blk);
@@ -145,7 +149,11 @@ public:
     // Executes the next segment into `r`.  Returns true once the guest has exited (then r.pc_end = 0).
     bool run_segment(SegmentRecords& r) {
         r.clear();
-        blocks_.clear(), path_nodes_.clear();
+        reset_blocks();
+        acc_.clear();
+        if (acc_.capacity() < caps_.rows(vmc::A_ACCESS)) acc_.reserve(caps_.rows(vmc::A_ACCESS));
+        for (auto* v : {&r.f_x, &r.f_y, &r.f_z, &r.f_rdprev, &r.f_pcinc, &r.core.pc_index})
+            if (v->capacity() < caps_.rows(vmc::A_FRAME)) v->reserve(caps_.rows(vmc::A_FRAME));
         r.pc_start = m_.pc();
         r.root_init = tree_.root();
         size_t n_cls[vmc::N_CLS] = {};
@@ -153,36 +161,43 @@ public:
             const uint32_t pc = m_.pc();
             const uint64_t k = ((uint64_t)pc - exe_.pc_base) / 4;
             if (pc < exe_.pc_base || (pc & 3u) || k >= exe_.program.size()) throw Error("pc outside the program: " + std::to_string(pc));
-            const vmc::Decoded d = vmc::decode(exe_.program[k], pc);
+            const vmc::Decoded& d = dec_[k];
             if (!d.legal) throw Error("illegal instruction at pc " + std::to_string(pc));
             // would one more instruction overflow a chip?  (the blocks and path nodes it would add are counted exactly)
             size_t new_blocks = 0, new_nodes = 0;
             {
                 uint32_t labels[5];
                 unsigned nl = 0;
-                auto want = [&](uint32_t as, uint32_t cell) { labels[nl++] = (as << vmc::LABEL_BITS) | (cell >> 3); };
+                bool all_known = true;
+                auto want = [&](uint32_t as, uint32_t cell) {
+                    labels[nl] = (as << vmc::LABEL_BITS) | (cell >> 3);
+                    all_known = all_known && find_block(labels[nl]) != nullptr;
+                    nl++;
+                };
                 if (d.use_rs1) want(1, 2 * d.rs1);
                 if (d.use_rs2) want(1, 2 * d.rs2);
                 if (d.wr_rd) want(1, 2 * d.rd);
                 if (d.cls == vmc::C_LS) want(2, (((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) & ~3u) >> 1);
                 if (d.cls == vmc::C_ECALL) want(1, 22), want(3, 2 * (m_.reg(11) & 7u));
-                std::unordered_set<uint64_t> fresh;
-                for (unsigned i = 0; i < nl; i++) {
-                    if (blocks_.count(labels[i]) || !fresh.insert(MemoryTree::key(vmc::LEAF_LEVEL, labels[i])).second) continue;
-                    new_blocks++;
-                    uint32_t idx = labels[i];
-                    for (int l = (int)vmc::LEAF_LEVEL - 1; l >= 0; l--) {
-                        idx >>= 1;
-                        const uint64_t kk = MemoryTree::key((unsigned)l, idx);
-                        if (path_nodes_.count(kk) || !fresh.insert(kk).second) break;
-                        new_nodes++;
+                if (!all_known) {   // rare: count exactly what the instruction would add
+                    std::unordered_set<uint64_t> fresh;
+                    for (unsigned i = 0; i < nl; i++) {
+                        if (find_block(labels[i]) || !fresh.insert(MemoryTree::key(vmc::LEAF_LEVEL, labels[i])).second) continue;
+                        new_blocks++;
+                        uint32_t idx = labels[i];
+                        for (int l = (int)vmc::LEAF_LEVEL - 1; l >= 0; l--) {
+                            idx >>= 1;
+                            const uint64_t kk = MemoryTree::key((unsigned)l, idx);
+                            if (path_nodes_.count(kk) || !fresh.insert(kk).second) break;
+                            new_nodes++;
+                        }
                     }
                 }
             }
             if (r.n_instr + 1 > caps_.rows(vmc::A_FRAME) || n_cls[d.cls] + 1 > caps_.rows(vmc::A_ALU + d.cls) ||
-                r.acc_ts.size() + 9 > caps_.rows(vmc::A_ACCESS) || blocks_.size() + new_blocks > caps_.rows(vmc::A_LEAF) ||
+                acc_.size() + 9 > caps_.rows(vmc::A_ACCESS) || blk_.size() + new_blocks > caps_.rows(vmc::A_LEAF) ||
                 path_nodes_.size() + new_nodes > caps_.rows(vmc::A_MERKLE) ||
-                2 * (blocks_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
+                2 * (blk_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
                 if (r.n_instr == 0) throw Error("segment heights too small for a single instruction");
                 break;
             }
@@ -249,6 +264,7 @@ public:
         }
         r.pc_end = m_.done() ? 0 : m_.pc();
         r.ts_end = 1 + vmc::TS_STEP * (uint32_t)r.n_instr;
+        flush_access_log(r);
         close_memory(r);
         return m_.done();
     }
@@ -262,8 +278,37 @@ private:
     struct Block {
         uint32_t init[8], cur[8], ts[8];
     };
-    std::unordered_map<uint32_t, Block> blocks_;     // touched blocks of the current segment, by label
+    // touched blocks of the current segment: dense storage + direct-mapped slot tables (registers, public values, the guest's
+    // read-write region) so that the common lookup is an array access; anything else (addresses outside the region) goes through a map
+    std::vector<Block> blk_;
+    std::vector<uint32_t> blk_label_;
+    uint32_t reg_slot_[8] = {}, pv_slot_[2] = {}, mem_lo_blk_ = 0;
+    std::vector<uint32_t> mem_slot_;                 // index + 1 into blk_, 0 = untouched
+    std::unordered_map<uint32_t, uint32_t> other_slot_;
     std::unordered_set<uint64_t> path_nodes_;        // internal nodes above them
+    std::vector<vmc::Decoded> dec_;
+
+    uint32_t* slot_of(uint32_t label, bool create) {
+        const uint32_t as = label >> vmc::LABEL_BITS, blk = label & ((1u << vmc::LABEL_BITS) - 1);
+        if (as == 1 && blk < 8) return &reg_slot_[blk];
+        if (as == 3 && blk < 2) return &pv_slot_[blk];
+        if (as == 2 && blk >= mem_lo_blk_ && blk - mem_lo_blk_ < mem_slot_.size()) return &mem_slot_[blk - mem_lo_blk_];
+        if (create) return &other_slot_[label];
+        auto it = other_slot_.find(label);
+        return it == other_slot_.end() ? nullptr : &it->second;
+    }
+    Block* find_block(uint32_t label) {
+        const uint32_t* s = slot_of(label, false);
+        return s && *s ? &blk_[*s - 1] : nullptr;
+    }
+    void reset_blocks() {
+        for (uint32_t label : blk_label_) {
+            uint32_t* s = slot_of(label, false);
+            if (s) *s = 0;
+        }
+        other_slot_.clear();
+        blk_.clear(), blk_label_.clear(), path_nodes_.clear();
+    }
 
     uint32_t mem_word(uint32_t addr) const { return m_.peek_word(addr); }
     // value of a cell in the machine's CURRENT state
@@ -285,8 +330,7 @@ private:
     }
     Block& block_of(uint32_t as, uint32_t cell) {
         const uint32_t label = (as << vmc::LABEL_BITS) | (cell >> 3);
-        auto it = blocks_.find(label);
-        if (it != blocks_.end()) return it->second;
+        if (Block* known = find_block(label)) return *known;
         // first touch in this segment: the block's cells still have their values from the segment's start
         Block b;
         for (uint32_t j = 0; j < 8; j++) b.init[j] = b.cur[j] = cell_now(as, (cell & ~7u) + j), b.ts[j] = 0;
@@ -295,11 +339,28 @@ private:
             idx >>= 1;
             if (!path_nodes_.insert(MemoryTree::key((unsigned)l, idx)).second) break;
         }
-        return blocks_.emplace(label, b).first->second;
+        blk_.push_back(b), blk_label_.push_back(label);
+        *slot_of(label, true) = (uint32_t)blk_.size();
+        return blk_.back();
     }
-    void log(SegmentRecords& r, uint32_t as, uint32_t cell, uint32_t prev, uint32_t prev_ts, uint32_t data, uint32_t ts, bool read) {
-        r.acc_as.push_back(as), r.acc_ptr.push_back(cell), r.acc_prev_data.push_back(prev), r.acc_prev_ts.push_back(prev_ts);
-        r.acc_data.push_back(data), r.acc_ts.push_back(ts), r.acc_is_read.push_back(read ? 1u : 0u);
+    // the access log is kept as one array of records while the segment runs (one store per access) and split into the seven
+    // columns the device generator takes when the segment closes
+    struct Acc {
+        uint32_t as, ptr, prev_data, prev_ts, data, ts, is_read;
+    };
+    std::vector<Acc> acc_;
+    void log(SegmentRecords&, uint32_t as, uint32_t cell, uint32_t prev, uint32_t prev_ts, uint32_t data, uint32_t ts, bool read) {
+        acc_.push_back(Acc{as, cell, prev, prev_ts, data, ts, read ? 1u : 0u});
+    }
+    void flush_access_log(SegmentRecords& r) {
+        const size_t n = acc_.size();
+        for (auto* v : {&r.acc_as, &r.acc_ptr, &r.acc_prev_data, &r.acc_prev_ts, &r.acc_data, &r.acc_ts, &r.acc_is_read}) v->resize(n);
+        for (size_t i = 0; i < n; i++) {
+            const Acc& a = acc_[i];
+            r.acc_as[i] = a.as, r.acc_ptr[i] = a.ptr, r.acc_prev_data[i] = a.prev_data, r.acc_prev_ts[i] = a.prev_ts;
+            r.acc_data[i] = a.data, r.acc_ts[i] = a.ts, r.acc_is_read[i] = a.is_read;
+        }
+        acc_.clear();
     }
     // A block is snapshotted at its first touch in the segment, which must happen BEFORE the machine executes an instruction that
     // changes it: run_segment calls block_of for every cell an instruction will write before step_one.
@@ -311,9 +372,9 @@ private:
         b.ts[j] = ts;
     }
     void write_cell(SegmentRecords& r, uint32_t as, uint32_t cell, uint32_t value, uint32_t ts) {
-        auto it = blocks_.find((as << vmc::LABEL_BITS) | (cell >> 3));
-        if (it == blocks_.end()) throw Error("internal: write to a block that was not snapshotted");
-        Block& b = it->second;
+        Block* known = find_block((as << vmc::LABEL_BITS) | (cell >> 3));
+        if (!known) throw Error("internal: write to a block that was not snapshotted");
+        Block& b = *known;
         const unsigned j = cell & 7u;
         log(r, as, cell, b.cur[j], b.ts[j], value, ts, false);
         b.cur[j] = value, b.ts[j] = ts;
@@ -321,8 +382,7 @@ private:
 
     // leaf rows, merkle rows, Poseidon2 requests; commits the segment's final memory to the tree
     void close_memory(SegmentRecords& r) {
-        std::vector<uint32_t> labels;
-        for (const auto& kv : blocks_) labels.push_back(kv.first);
+        std::vector<uint32_t> labels(blk_label_);
         std::sort(labels.begin(), labels.end());
         std::unordered_map<uint64_t, Digest> fin;   // final digests of the touched blocks and path nodes
         auto add_p2 = [&](const uint32_t* a, const uint32_t* b8) {
@@ -330,10 +390,10 @@ private:
             for (int i = 0; i < 8; i++) r.p2_inputs.push_back(b8 ? b8[i] : 0u);
         };
         std::vector<Digest> h_fin(labels.size());
-        parallel_for(labels.size(), [&](size_t i) { h_fin[i] = p2_block(blocks_[labels[i]].cur); });
+        parallel_for(labels.size(), [&](size_t i) { h_fin[i] = p2_block(find_block(labels[i])->cur); });
         for (size_t i = 0; i < labels.size(); i++) {
             const uint32_t label = labels[i];
-            const Block& b = blocks_[label];
+            const Block& b = *find_block(label);
             const Digest hi = tree_.get(vmc::LEAF_LEVEL, label);
             fin[MemoryTree::key(vmc::LEAF_LEVEL, label)] = h_fin[i];
             uint32_t row[vmc::LEAF_WIDTH] = {};

@@ -102,6 +102,7 @@ public:
         }
         check(zkhip_malloc(ctx_, max_rows * 4, (void**)&d_zeros_));
         check(zkhip_zero(ctx_, d_zeros_, max_rows * 4));
+        check(zkhip_tracegen_defer_checks(ctx_, 1));   // ~60 generator calls per segment: one check at the end instead of one sync each
     }
     ~SegmentProver() {
         for (uint32_t* d : d_traces_) zkhip_free(ctx_, d);
@@ -192,6 +193,7 @@ public:
             check(zkhip_to_monty(ctx_, d_misc, misc.size()));
             count(d_misc, misc.size());
         }
+        check(zkhip_tracegen_check(ctx_));
         const auto t1 = clk::now();
         // ---- prove
         SegmentProof sp;
@@ -271,6 +273,8 @@ struct GuestStark {
     // openings of the two public-value blocks (address space 3) in the final memory root: sibling digests bottom-up, per block
     std::vector<uint32_t> pv_openings;
     uint64_t execution_mills = 0, segment_proving_mills = 0, aggregation_mills = 0;
+    uint64_t aggregation_setup_wait_mills = 0;   // waiting for the aggregation circuits / keys of this app to be built (first task only)
+    uint64_t sum_segment_tracegen_mills = 0, sum_segment_prove_mills = 0;   // summed over the segments (lanes run side by side)
     std::vector<SegmentProof> segment_proofs;   // kept when asked for
 };
 
@@ -390,6 +394,14 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
                 }
             }
         });
+    // the aggregation circuits and keys of the first levels are built beside the segment proving (nothing else uses the
+    // aggregation prover until the tree starts); deeper trees build their levels when they get there
+    std::thread warm_agg([&agg] {
+        try {
+            (void)agg.node_vk(3);
+        } catch (...) {
+        }
+    });
     clk::duration t_exec{};
     size_t n_seg = 0;
     std::string exec_error;
@@ -427,10 +439,13 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     }
     cv_pop.notify_all();
     for (auto& t : verifiers) t.join();
+    const auto t_segments_done = clk::now();
+    warm_agg.join();   // (a one-time cost per app: a prover that lives on keeps the circuits and keys)
+    g.aggregation_setup_wait_mills = ms(clk::now() - t_segments_done);
     if (!exec_error.empty()) throw Error(exec_error);
     if (!error.empty()) throw Error("segment prover: " + error);
     if (proofs.size() != n_seg) throw Error("segment prover: proofs missing");
-    g.execution_mills = ms(t_exec), g.segment_proving_mills = ms(clk::now() - t_start);   // wall: the execution runs under the proving
+    g.execution_mills = ms(t_exec), g.segment_proving_mills = ms(t_segments_done - t_start);   // wall: the execution runs under the proving
     bool all_zero = true;
     for (uint8_t b : ex.public_values()) all_zero = all_zero && b == 0;
     if (all_zero) throw Error("public_values are all 0s for unexpected reason");   // crates/prover/src/utils/vm.rs:34-46
@@ -438,7 +453,7 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     g.pv_openings = open_public_values(ex.tree());
     g.segments = n_seg;
     std::vector<ChildProof> seg_proofs;
-    for (auto& p : proofs) seg_proofs.push_back(p.proof);
+    for (auto& p : proofs) seg_proofs.push_back(p.proof), g.sum_segment_tracegen_mills += p.tracegen_mills, g.sum_segment_prove_mills += p.proving_mills;
     if (keep_segments) g.segment_proofs = std::move(proofs);
     const auto t0 = clk::now();
     const scroll_zkvm_hip::AggregationPlan plan = scroll_zkvm_hip::AggregationPlan::build(seg_proofs.size());

@@ -310,6 +310,9 @@ extern "C" {
     pub fn zkhip_proof_from_v1(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize, v1: *const u8, v1_len: usize,
                                out: *mut u8, cap: usize, out_len: *mut usize, pvs_out: *const *mut u32) -> c_int;
 
+    pub fn zkhip_tracegen_defer_checks(ctx: *mut zkhip_ctx, on: c_int) -> c_int;
+    pub fn zkhip_tracegen_check(ctx: *mut zkhip_ctx) -> c_int;
+
     // the one-statement VM circuit: AIR set, decode, program table, trace generators of the adapter-side chips
     pub fn zkhip_vm_n_airs() -> usize;
     pub fn zkhip_vm_air(id: c_uint, out: *mut zkhip_air, prep_width: *mut usize) -> c_int;

@@ -132,7 +132,8 @@ int main(int argc, char** argv) {
                 try {
                     const zkhip_vm::SegmentCaps caps = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(up.exe().program.size()));
                     const zkhip_params params = read_app_config(cfg_path);
-                    const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false);
+                    const unsigned lanes = getenv("ZKHIP_LANES") ? (unsigned)atoi(getenv("ZKHIP_LANES")) : 2u;   // segment provers in flight
+                    const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false, lanes);
                     (void)caps;
                     sp = UniversalProver::encode(g);
                     std::string why;
@@ -141,10 +142,13 @@ int main(int argc, char** argv) {
                     std::ofstream(dir + "/root.vk", std::ios::binary).write((const char*)vkb.data(), (std::streamsize)vkb.size());
                     std::ofstream(dir + "/root.json") << sp.to_json();
                     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                    std::printf("{\"total_cycles\": %llu, \"segments\": %zu, \"levels\": %zu, \"execution_ms\": %llu, \"segment_tracegen_and_proving_ms\": %llu, "
-                                "\"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, \"verified\": true}\n",
-                                (unsigned long long)g.exec.total_cycle, g.segments, g.levels, (unsigned long long)g.execution_mills,
-                                (unsigned long long)g.segment_proving_mills, (unsigned long long)g.aggregation_mills, wall, g.root.proof.size());
+                    std::printf("{\"total_cycles\": %llu, \"segments\": %zu, \"levels\": %zu, \"lanes\": %u, \"execution_ms\": %llu, \"segment_tracegen_and_proving_ms\": %llu, "
+                                "\"sum_over_segments_tracegen_ms\": %llu, \"sum_over_segments_prove_ms\": %llu, "
+                                "\"aggregation_setup_wait_ms\": %llu, \"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, \"verified\": true}\n",
+                                (unsigned long long)g.exec.total_cycle, g.segments, g.levels, lanes, (unsigned long long)g.execution_mills,
+                                (unsigned long long)g.segment_proving_mills, (unsigned long long)g.sum_segment_tracegen_mills,
+                                (unsigned long long)g.sum_segment_prove_mills, (unsigned long long)g.aggregation_setup_wait_mills,
+                                (unsigned long long)g.aggregation_mills, wall, g.root.proof.size());
                 } catch (const zkhip_vm::Error& e) {
                     throw Error(Error::GenProof, e.what());
                 }

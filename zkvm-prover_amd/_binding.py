@@ -164,6 +164,8 @@ def load_library():
         "zkhip_proof_from_v1": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(C.c_uint8), sz,
                                           C.POINTER(C.c_uint8), sz, C.POINTER(sz), C.POINTER(u32p)]),
         "zkhip_proof_layout_of": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(_ProofLayout)]),
+        "zkhip_tracegen_defer_checks": (C.c_int, [vp, C.c_int]),
+        "zkhip_tracegen_check": (C.c_int, [vp]),
         "zkhip_keccak_f_air": (C.c_int, [C.POINTER(_Air)]),
         "zkhip_keccak_f1600_host": (C.c_int, [C.POINTER(C.c_uint64)]),
         "zkhip_keccak_f_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),

@@ -98,6 +98,22 @@ static int selftest(zkhip_ctx* ctx) {
     return h_bad == 0 ? ZKHIP_OK : ZKHIP_ERR_HIP;
 }
 
+__global__ void k_accumulate_flag(const uint32_t* flag, uint32_t* total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && *flag) atomicAdd(total, *flag);
+}
+int tracegen_finish(zkhip_ctx* ctx, void* flag, const std::string& what) {
+    if (ctx->defer_tracegen_checks && ctx->d_deferred_bad) {
+        hipLaunchKernelGGL(k_accumulate_flag, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)flag, ctx->d_deferred_bad);
+        ZK_HIP_CHECK(ctx, hipGetLastError());
+        return ZKHIP_OK;
+    }
+    uint32_t h_bad = 0;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_bad) return set_error(ctx, ZKHIP_ERR_INVALID, what + ": " + std::to_string(h_bad) + " bad records");
+    return ZKHIP_OK;
+}
+
 }  // namespace zk
 
 using namespace zk;
@@ -154,6 +170,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->hash_stream) (void)hipStreamDestroy(ctx->hash_stream);
+    if (ctx->d_deferred_bad) (void)hipFree(ctx->d_deferred_bad);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     for (auto& e : ctx->pipe_ev)
         if (e) (void)hipEventDestroy(e);
@@ -164,6 +181,29 @@ int zkhip_set_commit_pipeline(zkhip_ctx* ctx, unsigned parts) {
     ZK_BIND_DEVICE(ctx);
     if (!ctx || parts > 8) return ZKHIP_ERR_INVALID;
     ctx->commit_parts = parts;
+    return ZKHIP_OK;
+}
+
+int zkhip_tracegen_defer_checks(zkhip_ctx* ctx, int on) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    if (on && !ctx->d_deferred_bad) {
+        ZK_HIP_CHECK(ctx, hipMalloc(&ctx->d_deferred_bad, 4));
+        ZK_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_deferred_bad, 0, 4, ctx->stream));
+    }
+    ctx->defer_tracegen_checks = on != 0;
+    return ZKHIP_OK;
+}
+
+int zkhip_tracegen_check(zkhip_ctx* ctx) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    if (!ctx->d_deferred_bad) return ZKHIP_OK;
+    uint32_t h_bad = 0;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, ctx->d_deferred_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_deferred_bad, 0, 4, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_bad) return set_error(ctx, ZKHIP_ERR_INVALID, "trace generation: " + std::to_string(h_bad) + " bad records since the last check (run without deferred checks to see which generator refuses them)");
     return ZKHIP_OK;
 }
 

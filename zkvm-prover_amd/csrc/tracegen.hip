@@ -144,11 +144,7 @@ int range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d_values, size_t n, un
     }
     hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
-    uint32_t h_bad = 0;
-    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (h_bad) return set_error(ctx, ZKHIP_ERR_INVALID, "range_counts_tracegen: " + std::to_string(h_bad) + " values outside the table");
-    return ZKHIP_OK;
+    return tracegen_finish(ctx, flag, "range_counts_tracegen (values outside the table)");
 }
 
 // ---- MMCS path chip: in-circuit verification of mixed-height Merkle openings (air.py mmcs_path_air) ------------------------------

@@ -110,13 +110,7 @@ __global__ __launch_bounds__(256) void k_boundary_fill(const uint64_t* __restric
     for (int q = 0; q < ZKHIP_MEMORY_BOUNDARY_WIDTH; q++) trace[(size_t)q * N + r] = c[q];
 }
 
-int finish_counts(zkhip_ctx* ctx, void* flag, const char* what) {
-    uint32_t h_bad = 0;
-    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (h_bad) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": " + std::to_string(h_bad) + " requests outside the table");
-    return ZKHIP_OK;
-}
+int finish_counts(zkhip_ctx* ctx, void* flag, const char* what) { return tracegen_finish(ctx, flag, std::string(what) + " (requests outside the table)"); }
 
 }  // namespace
 }  // namespace zk

@@ -127,13 +127,7 @@ __global__ __launch_bounds__(256) void k_range_counts_scaled(const uint32_t* __r
     hot_flush(hk, hc, hist);
 }
 
-int check_flag(zkhip_ctx* ctx, void* flag, const char* what) {
-    uint32_t h_bad = 0;
-    ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (h_bad) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": " + std::to_string(h_bad) + " bad records");
-    return ZKHIP_OK;
-}
+int check_flag(zkhip_ctx* ctx, void* flag, const char* what) { return tracegen_finish(ctx, flag, what); }
 
 }  // namespace
 }  // namespace zk

@@ -53,6 +53,10 @@ struct zkhip_ctx {
     // remaining CUs, so that neither queue waits behind the other's workgroups.  0 = unmasked streams.
     unsigned side_cus = 0;
     hipStream_t hash_stream = nullptr;
+    // trace generators check their records on the device and normally report at once (one stream synchronisation per call); with
+    // deferred checks (zkhip_tracegen_defer_checks) the bad-record counts are summed on the device and read once (zkhip_tracegen_check)
+    bool defer_tracegen_checks = false;
+    uint32_t* d_deferred_bad = nullptr;
 };
 
 namespace zk {
@@ -63,6 +67,8 @@ int get_scratch(zkhip_ctx* ctx, int slot, size_t bytes, void** out);
 void profile_begin(zkhip_ctx* ctx, const char* name);
 void profile_end(zkhip_ctx* ctx);
 int profile_flush(zkhip_ctx* ctx);
+// end of a trace generator: `flag` = device counter of bad records of this call; reports now, or adds it to the deferred total
+int tracegen_finish(zkhip_ctx* ctx, void* flag, const std::string& what);
 
 // every entry point that takes a context runs on the context's device, whatever device the calling thread had current
 // (two contexts on different GPUs in one process; a context handed to another thread)
