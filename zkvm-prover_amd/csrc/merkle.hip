@@ -168,15 +168,16 @@ __global__ __launch_bounds__(256) void k_compress_layer_coop(const uint32_t* __r
     const unsigned lane = threadIdx.x & 15u;
     const size_t i = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const size_t ii = i < n_next ? i : 0;  // all 16 lanes of every row stay active through the DPP permutation
-    uint32_t x = coop_permute(prev[ii * 16 + lane], lane);
+    const CoopConsts cc = coop_load_consts(lane);
+    uint32_t x = coop_permute_regs(prev[ii * 16 + lane], lane, cc);
     if (n_inj_cols) {
         uint32_t h = 0;  // sponge over the injected row: lane k < 8 absorbs column j + k, lanes 8..15 are the capacity
         for (uint32_t j = 0; j < n_inj_cols; j += 8) {
             if (lane < 8 && j + lane < n_inj_cols) h = inj_cols[j + lane][ii];
-            h = coop_permute(h, lane);
+            h = coop_permute_regs(h, lane, cc);
         }
         const uint32_t hh = dpp<ZK_ROR(8)>(h);  // lane 8 + k reads the digest word k
-        x = coop_permute(lane < 8 ? x : hh, lane);
+        x = coop_permute_regs(lane < 8 ? x : hh, lane, cc);
     }
     if (i < n_next && lane < 8) next[i * 8 + lane] = x;
 }
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(1024) void k_compress_top(uint32_t* __restrict__ di
     const unsigned tid = threadIdx.x, lane = tid & 15u, grp = tid >> 4;  // 64 groups
     auto layer_off = [&](unsigned l) -> size_t { return ((size_t)2 << lh) - ((size_t)2 << (lh - l)); };
     unsigned n = 1u << (lh - l0);
+    const CoopConsts cc = coop_load_consts(lane);
     for (unsigned e = tid; e < n * 8; e += 1024) buf[0][e] = digests[layer_off(l0) * 8 + e];
     __syncthreads();
     unsigned cur = 0;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(1024) void k_compress_top(uint32_t* __restrict__ di
             // all 16 lanes of a row stay active through the DPP permutation
             const unsigned ii = i < n_next ? i : 0;
             uint32_t x = buf[cur][16 * ii + lane];
-            x = coop_permute(x, lane);
+            x = coop_permute_regs(x, lane, cc);
             if (i < n_next && lane < 8) {
                 buf[cur ^ 1][8 * i + lane] = x;
                 out[8 * i + lane] = x;

@@ -108,6 +108,34 @@ __device__ __forceinline__ uint32_t coop_permute(uint32_t x, unsigned lane) {
     for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7_rcs(x, POSEIDON2_RCS_DEV.v[80 + r * 16 + lane]));
     return x;
 }
+// The same permutation with the round constants of this lane held in registers: for kernels that chain many permutations on one
+// wave (the transcript), where the constant loads of the rolled form sit on the dependent chain of every round.
+struct CoopConsts {
+    uint32_t ext[8], in[13], diag;
+};
+__device__ __forceinline__ CoopConsts coop_load_consts(unsigned lane) {
+    CoopConsts c;
+#pragma unroll
+    for (int r = 0; r < 4; r++) c.ext[r] = POSEIDON2_RCS_DEV.v[r * 16 + lane], c.ext[4 + r] = POSEIDON2_RCS_DEV.v[80 + r * 16 + lane];
+#pragma unroll
+    for (int r = 0; r < 13; r++) c.in[r] = POSEIDON2_RCS_DEV.v[64 + r];
+    c.diag = POSEIDON2_DIAG_DEV[lane];
+    return c;
+}
+__device__ __forceinline__ uint32_t coop_permute_regs(uint32_t x, unsigned lane, const CoopConsts& c) {
+    x = coop_external_linear(x);
+#pragma unroll
+    for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7_rcs(x, c.ext[r]));
+#pragma unroll
+    for (int r = 0; r < 13; r++) {
+        const uint32_t sb = sbox7_rcs(x, c.in[r]);
+        x = lane == 0 ? sb : x;
+        x = madd(mmul(x, c.diag), coop_sum16(x));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) x = coop_external_linear(sbox7_rcs(x, c.ext[4 + r]));
+    return x;
+}
 #endif
 
 }  // namespace zk

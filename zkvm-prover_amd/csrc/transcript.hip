@@ -64,11 +64,32 @@ __global__ void k_tr_init(DevTranscript* t) {
     }
 }
 
-// src_canonical != 0: src holds canonical words (converted on the fly)
+// src_canonical != 0: src holds canonical words (converted on the fly).  The sponge is serial by construction (one
+// permutation per 8 words), so the latency of a block is what counts: once the input buffer is aligned, lanes 0..7 fetch a
+// whole block with ONE load and the next block is already in flight while this one is permuted (word-by-word uniform loads cost
+// more than the permutation itself; a chunk proof observes ~12 k opened words here).
 __global__ __launch_bounds__(64) void k_tr_observe(DevTranscript* t, const uint32_t* src, uint32_t n, int src_canonical) {
     const unsigned lane = threadIdx.x;
     TrRegs r = tr_load(t, lane);
-    for (uint32_t i = 0; i < n; i++) {
+    uint32_t i = 0;
+    for (; i < n && r.n_in != 0; i++) {
+        uint32_t v = src[i];
+        tr_observe1(r, lane, src_canonical ? to_monty(v) : v);
+    }
+    if (i + 8 <= n) {
+        const unsigned l8 = lane & 7u;
+        const CoopConsts cc = coop_load_consts(lane & 15u);
+        uint32_t nxt = src[i + l8];
+        while (i + 8 <= n) {
+            uint32_t cur = src_canonical ? to_monty(nxt) : nxt;
+            i += 8;
+            if (i + 8 <= n) nxt = src[i + l8];
+            if ((lane & 15u) < 8) r.s = cur;
+            r.s = coop_permute_regs(r.s, lane & 15u, cc);
+        }
+        r.n_in = 0, r.n_out = 8;
+    }
+    for (; i < n; i++) {
         uint32_t v = src[i];
         tr_observe1(r, lane, src_canonical ? to_monty(v) : v);
     }
