@@ -604,6 +604,21 @@ int zkhip_keccak_f1600_host(uint64_t state[25]);   /* the permutation on lanes s
  * 24 p .. 24 p + 23 = the rounds of permutation p, the rest permutations of the zero state (valid padding) */
 int zkhip_keccak_f_tracegen(zkhip_ctx *ctx, const uint32_t *d_states, size_t n_perms, unsigned log_height, uint32_t *d_trace);
 
+/* ---- SHA-256 compression chip (include/zkhip_sha256.hpp: one round per row, 65 rows per block, 433 main + 6 preprocessed columns,
+ *      degree 3, no lookups; crates/circuits/chunk-circuit/openvm.toml:8-59 lists `sha256` among the chunk circuit's extensions;
+ *      OpenVM's chip is openvm-sha256-circuit, un-vendored).  Pinned to FIPS 180-4 / hashlib (tests/golden/sha256_kat.json). ---- */
+#define ZKHIP_SHA256_WIDTH 433
+#define ZKHIP_SHA256_PREP_WIDTH 6
+#define ZKHIP_SHA256_ROWS_PER_BLOCK 65
+/* the AIR for a trace of 2^log_height rows (7 <= log_height <= 24): program, width, and `prep_trace` = the round constants and the
+ * round / final / first / schedule gates of floor(2^log_height / 65) blocks (HOST, column-major; pointers valid for the life of the process) */
+int zkhip_sha256_air(unsigned log_height, zkhip_air *out);
+/* the compression function (host): state[8] <- compress(state, block), block = sixteen big-endian message words (FIPS 180-4 6.2.2) */
+int zkhip_sha256_compress_host(uint32_t state[8], const uint32_t block[16]);
+/* d_blocks: n_blocks x 24 words (H_in[8], then the sixteen message words; plain integers); rows 65 b .. 65 b + 63 = the rounds of block
+ * b, row 65 b + 64 = H_out (state columns), further whole blocks = compressions of the zero record with real = 0, the tail rows zero */
+int zkhip_sha256_tracegen(zkhip_ctx *ctx, const uint32_t *d_blocks, size_t n_blocks, unsigned log_height, uint32_t *d_trace);
+
 /* ---- aggregation layer: the verifier circuit.  Replaces, for this backend's proofs, the leaf /
  *      internal verifier programs the reference's SDK proves at the nodes of its aggregation tree and `commit_child_vk`
  *      (crates/prover/src/prover/mod.rs:47-60, 200-282; crates/integration/src/lib.rs:461-514).  A circuit is built for ONE

@@ -337,6 +337,9 @@ extern "C" {
     pub fn zkhip_keccak_f_air(out: *mut zkhip_air) -> c_int;
     pub fn zkhip_keccak_f1600_host(state: *mut u64) -> c_int;
     pub fn zkhip_keccak_f_tracegen(ctx: *mut zkhip_ctx, d_states: *const u32, n_perms: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;
+    pub fn zkhip_sha256_air(log_height: c_uint, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_sha256_compress_host(state: *mut u32, block: *const u32) -> c_int;
+    pub fn zkhip_sha256_tracegen(ctx: *mut zkhip_ctx, d_blocks: *const u32, n_blocks: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;
 
     // aggregation layer: the verifier circuit of a node (commit_child_vk / VerifyProver of the reference)
     pub fn zkhip_recursion_build(child_params: *const zkhip_params, child_airs: *const zkhip_air, n_child_airs: usize, max_children: usize,

@@ -181,6 +181,10 @@ void ora_fri_fold(const uint32_t *in, uint32_t *out, unsigned log_n_out, const u
 void ora_keccak_f1600(uint64_t st[25]);
 void ora_sha3_256(const uint8_t *msg, size_t len, uint8_t out[32], int keccak_padding);
 void ora_keccak_f_trace(const uint64_t *inputs, size_t n_perms, unsigned log_height, uint32_t *trace);
+/* ---- SHA-256 (oracle/sha256.c): compression function, padded hash, the compression chip's trace ---- */
+void ora_sha256_compress(uint32_t h[8], const uint32_t m[16]);
+void ora_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
+void ora_sha256_trace(const uint32_t *blocks, size_t n_blocks, unsigned log_height, uint32_t *trace);
 
 /* the verifier's bus check: n exposed cumulative sums (4 canonical words each) must add up to zero; 0 = balanced */
 int ora_logup_exposed_check(const uint32_t *exposed, size_t n);

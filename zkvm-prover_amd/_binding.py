@@ -169,6 +169,9 @@ def load_library():
         "zkhip_keccak_f_air": (C.c_int, [C.POINTER(_Air)]),
         "zkhip_keccak_f1600_host": (C.c_int, [C.POINTER(C.c_uint64)]),
         "zkhip_keccak_f_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
+        "zkhip_sha256_air": (C.c_int, [C.c_uint, C.POINTER(_Air)]),
+        "zkhip_sha256_compress_host": (C.c_int, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+        "zkhip_sha256_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
         "zkhip_vm_n_airs": (sz, []),
         "zkhip_vm_air": (C.c_int, [C.c_uint, C.POINTER(_Air), C.POINTER(sz)]),
         "zkhip_vm_decode": (C.c_int, [C.c_uint32, C.c_uint32, u32p, C.POINTER(C.c_int)]),
@@ -625,6 +628,11 @@ class Context:
         self._check(self.lib.zkhip_keccak_f_tracegen(self.h, t_states.data_ptr() if n_perms else None, n_perms, log_height, out.data_ptr()))
         return out
 
+    def sha256_tracegen(self, t_blocks, n_blocks, log_height):
+        out = self._new(433 << log_height)
+        self._check(self.lib.zkhip_sha256_tracegen(self.h, t_blocks.data_ptr() if n_blocks else None, n_blocks, log_height, out.data_ptr()))
+        return out
+
     def merkle_commit(self, mats, want_root=True):
         """mats: list of (tensor, log_height, width[, stride])."""
         return MerkleTree(self, mats, want_root)
@@ -891,6 +899,23 @@ def keccak_f_air():
 def keccak_f1600_host(lanes):
     st = np.ascontiguousarray(lanes, dtype=np.uint64).copy()
     assert st.size == 25 and load_library().zkhip_keccak_f1600_host(st.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+    return st
+
+
+def sha256_air(log_height):
+    """The SHA-256 compression chip's AIR for 2^log_height rows: (program, width, prep) -- prep = its preprocessed trace (6 columns,
+    column-major, canonical); the one definition is include/zkhip_sha256.hpp."""
+    lib = load_library()
+    a = _Air()
+    assert lib.zkhip_sha256_air(log_height, C.byref(a)) == 0
+    prep = np.ctypeslib.as_array(a.prep_trace, shape=(6 << log_height,)).copy().reshape(6, 1 << log_height)
+    return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width), prep
+
+
+def sha256_compress_host(state, block):
+    st = np.ascontiguousarray(state, dtype=np.uint32).copy()
+    blk = np.ascontiguousarray(block, dtype=np.uint32)
+    assert st.size == 8 and blk.size == 16 and load_library().zkhip_sha256_compress_host(_u32p(st), _u32p(blk)) == 0
     return st
 
 
