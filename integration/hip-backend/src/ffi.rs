@@ -14,6 +14,9 @@ pub const ZKHIP_ERR_VERIFY: c_int = -7;
 pub const ZKHIP_ERR_CONSTRAINT: c_int = -8;
 pub const ZKHIP_DIGEST_WORDS: usize = 8;
 pub const ZKHIP_KECCAK_F_WIDTH: usize = 2633;
+pub const ZKHIP_SHA256_WIDTH: usize = 433;
+pub const ZKHIP_SHA256_PREP_WIDTH: usize = 6;
+pub const ZKHIP_SHA256_ROWS_PER_BLOCK: usize = 65;
 pub const ZKHIP_POSEIDON2_AIR_WIDTH: usize = 298;
 pub const ZKHIP_MEMORY_BOUNDARY_WIDTH: usize = 8;
 pub const ZKHIP_RV32_ALU_WIDTH: usize = 18;
