@@ -572,19 +572,18 @@ int zkhip_vm_air(unsigned id, zkhip_air *out, size_t *prep_width);
 int zkhip_vm_decode(uint32_t word, uint32_t pc, uint32_t out[17], int *legal);
 /* preprocessed trace of the program chip: 17 columns x 2^log_program rows, column-major, canonical */
 int zkhip_vm_program_table(const uint32_t *words, size_t n_words, uint32_t pc_base, unsigned log_program, uint32_t *out);
-/* Frame chip (34 columns): record r = (program row d_pc_index[r], operands d_x / d_y, result d_z, previous value of rd d_rd_prev --
- * plain 32-bit words --, pc step d_pc_inc as a canonical field element); its timestamp is 1 + 16 r.  d_program: the program table on the
- * device, Montgomery, stride n_program. */
+/* Frame chip (43 columns): record r = (program row d_pc_index[r], operands d_x / d_y, result d_z, previous value of rd d_rd_prev --
+ * plain 32-bit words --, pc step d_pc_inc as a canonical field element, and the timestamps of the previous accesses of the rs1 / rs2 /
+ * rd words -- its register adapter; ignored where the instruction skips the access); its timestamp is 1 + 16 r.  d_program: the program
+ * table on the device, Montgomery, stride n_program. */
 int zkhip_vm_frame_tracegen(zkhip_ctx *ctx, const uint32_t *d_pc_index, const uint32_t *d_x, const uint32_t *d_y, const uint32_t *d_z,
-                            const uint32_t *d_rd_prev, const uint32_t *d_pc_inc, size_t n, const uint32_t *d_program, size_t n_program, unsigned log_height,
-                            uint32_t *d_trace);
-/* Load/store chip (45 columns): the core's records (zkhip_rv32_loadstore_tracegen) + per record the instruction's timestamp, base
- * register value and 32-bit immediate. */
+                            const uint32_t *d_rd_prev, const uint32_t *d_pc_inc, const uint32_t *d_prev_ts_rs1, const uint32_t *d_prev_ts_rs2,
+                            const uint32_t *d_prev_ts_rd, size_t n, const uint32_t *d_program, size_t n_program, unsigned log_height, uint32_t *d_trace);
+/* Load/store chip (48 columns): the core's records (zkhip_rv32_loadstore_tracegen) + per record the instruction's timestamp, base
+ * register value, 32-bit immediate and the timestamp of the previous access of the memory word (its memory adapter). */
 int zkhip_vm_loadstore_tracegen(zkhip_ctx *ctx, const uint32_t *d_case, const uint32_t *d_read, const uint32_t *d_prev, const uint32_t *d_ts,
-                                const uint32_t *d_base, const uint32_t *d_imm, size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
-/* Memory-access chip (11 columns): zkhip_memory_access_tracegen's ten + 8 * gap_hi. */
-int zkhip_vm_access_tracegen(zkhip_ctx *ctx, const uint32_t *d_addr_space, const uint32_t *d_pointer, const uint32_t *d_prev_data, const uint32_t *d_prev_ts,
-                             const uint32_t *d_data, const uint32_t *d_ts, const uint32_t *d_is_read, size_t n, unsigned log_height, uint32_t *d_trace);
+                                const uint32_t *d_base, const uint32_t *d_imm, const uint32_t *d_prev_ts, size_t n, unsigned log_height, uint32_t *d_trace,
+                                uint32_t *d_bitwise_trace);
 /* Poseidon2 chip serving the hash bus (299 columns): zkhip_poseidon2_air_tracegen + multiplicity 1 on the first n rows. */
 int zkhip_vm_poseidon2_tracegen(zkhip_ctx *ctx, const uint32_t *d_inputs, size_t n, unsigned log_height, uint32_t *d_trace);
 /* n rows of `width` canonical words (row-major, device) -> column-major Montgomery trace of 2^log_height rows; the other rows get

@@ -13,7 +13,10 @@
 // Every node proof is self-verified (crates/prover/src/prover/mod.rs:407-411 does that for every proof it returns).
 #pragma once
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "zkhip_prover.hpp"
@@ -75,6 +78,7 @@ public:
     static AggregationProver setup(const VerifyingKey& app, const StatementSpec& spec, AggregationTreeConfig cfg = {}, int device = 0) {
         AggregationProver p;
         p.app_ = app, p.spec_ = spec, p.cfg_ = cfg, p.device_ = device;
+        p.levels_mu_.reset(new std::mutex), p.dev_mu_.reset(new std::mutex), p.build_mu_.reset(new std::mutex);
         if (app.airs.size() != app.heights.size() || app.airs.empty()) throw Error(Error::Setup, "aggregation: the app verifying key needs one height per AIR");
         if (spec.start.size() != spec.end.size()) throw Error(Error::Setup, "aggregation: start and end state must have the same length");
         return p;
@@ -83,6 +87,7 @@ public:
     AggregationProver& operator=(AggregationProver&& o) noexcept {
         reset();
         app_ = std::move(o.app_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, device_ = o.device_, ctx_ = o.ctx_, levels_ = std::move(o.levels_), stats = o.stats;
+        levels_mu_ = std::move(o.levels_mu_), dev_mu_ = std::move(o.dev_mu_), build_mu_ = std::move(o.build_mu_);
         o.ctx_ = nullptr;
         return *this;
     }
@@ -103,7 +108,7 @@ public:
     // verifying key of the node circuit of `level` (0 = leaf): the root vk of a tree with level + 1 levels
     const VerifyingKey& node_vk(size_t level) {
         ensure_level(level);
-        return levels_[level].vk;
+        return lv(level).vk;
     }
     size_t arity(size_t level) const { return level == 0 ? cfg_.num_children_leaf : cfg_.num_children_internal; }
 
@@ -115,7 +120,7 @@ public:
         auto t1 = clk::now();
         ChildProof out = prove_witnessed(level, std::move(npv));
         auto t2 = clk::now();
-        if (!levels_[level].vk.verify(out)) throw Error(Error::VerifyProof, "aggregation: the node proof does not verify");
+        if (!lv(level).vk.verify(out)) throw Error(Error::VerifyProof, "aggregation: the node proof does not verify");
         stats.nodes++;
         stats.witness_seconds += std::chrono::duration<double>(t1 - t0).count();
         stats.tracegen_prove_seconds += std::chrono::duration<double>(t2 - t1).count();
@@ -127,9 +132,9 @@ public:
     // returns the node's public values.  Throws if a child does not verify or the states do not chain.
     std::vector<uint32_t> witness_node(size_t level, const std::vector<const ChildProof*>& kids) {
         ensure_level(level);
-        Level& L = levels_[level];
+        Level& L = lv(level);
         if (kids.empty() || kids.size() > arity(level)) throw Error(Error::GenProof, "aggregation: a node of level " + std::to_string(level) + " takes 1.." + std::to_string(arity(level)) + " children");
-        const VerifyingKey& cvk = level == 0 ? app_ : levels_[level - 1].vk;
+        const VerifyingKey& cvk = level == 0 ? app_ : lv(level - 1).vk;
         std::vector<const uint8_t*> proofs;
         std::vector<size_t> lens;
         std::vector<std::vector<const uint32_t*>> pv_rows(kids.size());
@@ -150,87 +155,248 @@ public:
     }
     // device trace generation + proof of the node whose witness was computed last on this level
     ChildProof prove_witnessed(size_t level, std::vector<uint32_t> node_pvs) {
-        Level& L = levels_[level];
+        std::lock_guard<std::mutex> dev(*dev_mu_);
         upload_witness(level);
         return prove_uploaded(level, std::move(node_pvs));
     }
 
-    // The whole tree of `plan` over the segment proofs; returns the root, `all` (optional) receives every level.  Within a
-    // level the three stages of consecutive nodes overlap: the host runs the circuit of node n + 1 (witness) and the
-    // self-verification of node n - 1 while the device generates the traces of node n and proves it.
-    ChildProof prove_tree(const AggregationPlan& plan, const std::vector<ChildProof>& segments, std::vector<std::vector<ChildProof>>* all = nullptr) {
-        using clk = std::chrono::steady_clock;
-        if (segments.size() != plan.n_segments) throw Error(Error::GenProof, "aggregation: segment proof count does not match the plan");
-        std::vector<ChildProof> below = segments;
-        for (size_t l = 0; l < plan.levels.size(); l++) {
-            ensure_level(l);
-            const auto& nodes = plan.levels[l];
-            std::vector<ChildProof> cur(nodes.size());
-            auto kids_of = [&](size_t n) {
-                std::vector<const ChildProof*> kids;
-                for (size_t c : nodes[n].children) kids.push_back(&below.at(c));
-                return kids;
-            };
-            struct Job {
-                std::thread th;
-                std::string err;
-                std::vector<uint32_t> npv;
-                double seconds = 0;
-            };
-            auto start_witness = [&](size_t n) {
-                auto j = std::make_unique<Job>();
-                Job* jp = j.get();
-                jp->th = std::thread([this, jp, l, kids = kids_of(n)]() {
-                    auto t = clk::now();
-                    try {
-                        jp->npv = witness_node(l, kids);
-                    } catch (const std::exception& e) {
-                        jp->err = e.what();
-                    }
-                    jp->seconds = std::chrono::duration<double>(clk::now() - t).count();
-                });
-                return j;
-            };
-            std::vector<std::unique_ptr<Job>> verifies;
-            auto start_verify = [&](size_t n) {
-                auto j = std::make_unique<Job>();
-                Job* jp = j.get();
-                jp->th = std::thread([this, jp, l, &cur, n]() {
-                    auto t = clk::now();
-                    if (!levels_[l].vk.verify(cur[n])) jp->err = "aggregation: the proof of node " + std::to_string(n) + " of level " + std::to_string(l) + " does not verify";
-                    jp->seconds = std::chrono::duration<double>(clk::now() - t).count();
-                });
-                verifies.push_back(std::move(j));
-            };
-            std::unique_ptr<Job> wit = start_witness(0);
-            std::string err;
-            for (size_t n = 0; n < nodes.size(); n++) {
-                wit->th.join();
-                stats.witness_seconds += wit->seconds;
-                if (!wit->err.empty()) {
-                    err = wit->err;
-                    break;
-                }
-                std::vector<uint32_t> npv = std::move(wit->npv);
-                auto t = clk::now();
-                upload_witness(l);  // after this the circuit's witness buffer is free for the next node
-                if (n + 1 < nodes.size()) wit = start_witness(n + 1);
-                cur[n] = prove_uploaded(l, std::move(npv));
-                stats.tracegen_prove_seconds += std::chrono::duration<double>(clk::now() - t).count();
-                stats.nodes++;
-                start_verify(n);
-            }
-            if (wit && wit->th.joinable()) wit->th.join();
-            for (auto& v : verifies) {
-                v->th.join();
-                stats.verify_seconds += v->seconds;
-                if (err.empty() && !v->err.empty()) err = v->err;
-            }
-            if (!err.empty()) throw Error(err.find("does not verify") != std::string::npos && err.find("node ") != std::string::npos ? Error::VerifyProof : Error::GenProof, err);
-            below = std::move(cur);
-            if (all) all->push_back(below);
+    // The aggregation tree as a STREAM: segment proofs are pushed as they complete (any order, any thread) and every node starts as
+    // soon as its children exist -- leaf nodes while later segments are still being executed and proven, internal nodes while other
+    // nodes of the level below are still in flight.  The grouping is AggregationPlan's (node k of a level = children [a k, a k + a) of
+    // the level below), so full groups are known before the number of segments is; finish(n) fixes the partial ones and returns the
+    // root.  Per level two host threads: one runs the verifier circuit of the next node (witness, host cores), one generates its
+    // traces on the device and proves it (the levels share the prover's context: device sections are serialised, while the segment
+    // lanes keep proving on contexts of their own); every node proof is self-verified on a thread of its own.
+    class TreeStream {
+    public:
+        explicit TreeStream(AggregationProver& agg) : agg_(agg) {
+            layers_.emplace_back();
+            start_level(0);
         }
-        return below.at(0);
+        TreeStream(const TreeStream&) = delete;
+        TreeStream& operator=(const TreeStream&) = delete;
+        ~TreeStream() {
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                stop_ = true;
+            }
+            cv_.notify_all();
+            join_all();
+        }
+        void push(size_t index, ChildProof seg) { put(0, index, std::move(seg)); }
+        // all `n_segments` proofs have been (or will be) pushed: waits for the root.  `all` (optional) receives every level's proofs.
+        ChildProof finish(size_t n_segments, std::vector<std::vector<ChildProof>>* all = nullptr) {
+            if (n_segments == 0) throw Error(Error::GenProof, "aggregation: no segment proofs");
+            std::unique_lock<std::mutex> lk(mu_);
+            layers_[0].total = n_segments;
+            cv_.notify_all();
+            size_t root_layer = 0;
+            cv_.wait(lk, [&] {
+                if (!err_.empty()) return true;
+                for (size_t i = 1; i < layers_.size(); i++)
+                    if (layers_[i].total == 1 && !layers_[i].items.empty() && layers_[i].items[0]) {
+                        root_layer = i;
+                        return true;
+                    }
+                return false;
+            });
+            if (!err_.empty()) {
+                const std::string e = err_;
+                stop_ = true;
+                lk.unlock();
+                cv_.notify_all();
+                join_all();
+                throw Error(e.find("does not verify") != std::string::npos && e.find("node ") != std::string::npos ? Error::VerifyProof : Error::GenProof, e);
+            }
+            stop_ = true;
+            lk.unlock();
+            cv_.notify_all();
+            join_all();   // the self-verification of the last nodes
+            if (!err_.empty()) throw Error(Error::VerifyProof, err_);
+            if (all)
+                for (size_t i = 1; i <= root_layer; i++) {
+                    all->emplace_back();
+                    for (auto& it : layers_[i].items) all->back().push_back(*it);
+                }
+            return *layers_[root_layer].items[0];
+        }
+        size_t levels() const {
+            size_t n = 0;
+            for (size_t i = 1; i < layers_.size(); i++) n += !layers_[i].items.empty();
+            return n;
+        }
+
+    private:
+        struct Layer {
+            std::deque<std::unique_ptr<ChildProof>> items;   // layer 0 = segment proofs, layer l + 1 = node proofs of level l
+            size_t total = SIZE_MAX;                          // number of items once known
+            bool started = false;                             // the threads of the level that consumes this layer exist
+        };
+        AggregationProver& agg_;
+        std::mutex mu_;
+        std::condition_variable cv_;
+        std::deque<Layer> layers_;
+        std::vector<std::thread> threads_, verifiers_;
+        std::string err_;
+        bool stop_ = false;
+
+        void join_all() {
+            for (;;) {   // threads may start further threads until stop_ is seen
+                std::vector<std::thread> t;
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    t.swap(threads_);
+                    for (auto& v : verifiers_) t.push_back(std::move(v));
+                    verifiers_.clear();
+                }
+                if (t.empty()) return;
+                for (auto& th : t)
+                    if (th.joinable()) th.join();
+            }
+        }
+        void fail(const std::string& e) {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (err_.empty()) err_ = e;
+            cv_.notify_all();
+        }
+        void put(size_t layer, size_t index, ChildProof p) {
+            std::lock_guard<std::mutex> lk(mu_);
+            while (layers_.size() <= layer) layers_.emplace_back();
+            Layer& L = layers_[layer];
+            if (L.items.size() <= index) L.items.resize(index + 1);
+            L.items[index].reset(new ChildProof(std::move(p)));
+            if (layer > 0 && !L.started && !stop_) start_level_locked(layer);
+            cv_.notify_all();
+        }
+        void start_level(size_t level) {
+            std::lock_guard<std::mutex> lk(mu_);
+            start_level_locked(level);
+        }
+        // level `level` consumes layer `level` and produces layer `level + 1`
+        void start_level_locked(size_t level) {
+            while (layers_.size() <= level + 1) layers_.emplace_back();
+            layers_[level].started = true;
+            struct Shared {
+                std::mutex m;
+                std::condition_variable c;
+                bool witness_ready = false, buffer_free = true, done = false;
+                size_t node = 0;
+                std::vector<uint32_t> npv;
+            };
+            auto sh = std::make_shared<Shared>();
+            // witness thread: runs the circuit of node k once its children exist and the level's witness buffer is free
+            threads_.emplace_back([this, level, sh] {
+                const size_t a = agg_.arity(level);
+                try {
+                    for (size_t k = 0;; k++) {
+                        std::vector<const ChildProof*> kids;
+                        {
+                            std::unique_lock<std::mutex> lk(mu_);
+                            bool end = false;
+                            cv_.wait(lk, [&] {
+                                if (stop_ || !err_.empty()) return true;
+                                const Layer& in = layers_[level];
+                                const size_t lo = a * k, hi = in.total == SIZE_MAX ? lo + a : std::min(lo + a, in.total);
+                                if (in.total != SIZE_MAX && (lo >= in.total || (level > 0 && in.total == 1))) {
+                                    end = true;   // no further node on this level (a single item above the segments is the root)
+                                    return true;
+                                }
+                                if (in.items.size() < hi) return false;
+                                for (size_t c = lo; c < hi; c++)
+                                    if (!in.items[c]) return false;
+                                return true;
+                            });
+                            if (end) {
+                                layers_[level + 1].total = (level > 0 && layers_[level].total == 1) ? 0 : k;
+                                cv_.notify_all();
+                            }
+                            if (end || stop_ || !err_.empty()) break;
+                            const Layer& in = layers_[level];
+                            const size_t lo = a * k, hi = in.total == SIZE_MAX ? lo + a : std::min(lo + a, in.total);
+                            for (size_t c = lo; c < hi; c++) kids.push_back(in.items[c].get());
+                        }
+                        {
+                            std::unique_lock<std::mutex> lk(sh->m);
+                            sh->c.wait(lk, [&] { return sh->buffer_free; });
+                        }
+                        const auto t = std::chrono::steady_clock::now();
+                        std::vector<uint32_t> npv = agg_.witness_node(level, kids);
+                        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+                        {
+                            std::lock_guard<std::mutex> lk(mu_);
+                            agg_.stats.witness_seconds += dt;
+                        }
+                        std::lock_guard<std::mutex> lk(sh->m);
+                        sh->npv = std::move(npv), sh->node = k, sh->witness_ready = true, sh->buffer_free = false;
+                        sh->c.notify_all();
+                    }
+                } catch (const std::exception& e) {
+                    fail(e.what());
+                }
+                std::lock_guard<std::mutex> lk(sh->m);
+                sh->done = true;
+                sh->c.notify_all();
+            });
+            // device thread: trace generation (frees the witness buffer) and proof of the node, then its self-verification elsewhere
+            threads_.emplace_back([this, level, sh] {
+                try {
+                    for (;;) {
+                        std::vector<uint32_t> npv;
+                        size_t k;
+                        {
+                            std::unique_lock<std::mutex> lk(sh->m);
+                            sh->c.wait(lk, [&] { return sh->witness_ready || sh->done; });
+                            if (!sh->witness_ready) return;
+                            npv = std::move(sh->npv), k = sh->node, sh->witness_ready = false;
+                        }
+                        const auto t = std::chrono::steady_clock::now();
+                        ChildProof out;
+                        {
+                            std::lock_guard<std::mutex> dev(*agg_.dev_mu_);
+                            agg_.upload_witness(level);
+                            {
+                                std::lock_guard<std::mutex> lk(sh->m);
+                                sh->buffer_free = true;
+                                sh->c.notify_all();
+                            }
+                            out = agg_.prove_uploaded(level, std::move(npv));
+                        }
+                        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+                        {
+                            std::lock_guard<std::mutex> lk(mu_);
+                            agg_.stats.tracegen_prove_seconds += dt, agg_.stats.nodes++;
+                        }
+                        put(level + 1, k, std::move(out));
+                        std::lock_guard<std::mutex> lk(mu_);
+                        const ChildProof* made = layers_[level + 1].items[k].get();
+                        verifiers_.emplace_back([this, level, k, made] {
+                            const auto tv = std::chrono::steady_clock::now();
+                            const bool ok = agg_.level_vk(level).verify(*made);
+                            const double dv = std::chrono::duration<double>(std::chrono::steady_clock::now() - tv).count();
+                            std::lock_guard<std::mutex> lk(mu_);
+                            agg_.stats.verify_seconds += dv;
+                            if (!ok && err_.empty()) {
+                                err_ = "aggregation: the proof of node " + std::to_string(k) + " of level " + std::to_string(level) + " does not verify";
+                                cv_.notify_all();
+                            }
+                        });
+                    }
+                } catch (const std::exception& e) {
+                    fail(e.what());
+                    std::lock_guard<std::mutex> lk(sh->m);
+                    sh->buffer_free = true;
+                    sh->c.notify_all();
+                }
+            });
+        }
+    };
+
+    // The whole tree of `plan` over the segment proofs; returns the root, `all` (optional) receives every level.
+    ChildProof prove_tree(const AggregationPlan& plan, const std::vector<ChildProof>& segments, std::vector<std::vector<ChildProof>>* all = nullptr) {
+        if (segments.size() != plan.n_segments) throw Error(Error::GenProof, "aggregation: segment proof count does not match the plan");
+        TreeStream ts(*this);
+        for (size_t i = 0; i < segments.size(); i++) ts.push(i, segments[i]);
+        return ts.finish(segments.size(), all);
     }
 
     // ---- StarkProof container <-> ChildProof ----
@@ -262,7 +428,7 @@ public:
     }
 
 private:
-    AggregationProver() = default;
+    AggregationProver() : levels_mu_(new std::mutex), dev_mu_(new std::mutex), build_mu_(new std::mutex) {}
     struct Level {
         zkhip_recursion* circ = nullptr;
         zkhip_pk* pk = nullptr;
@@ -274,17 +440,29 @@ private:
     AggregationTreeConfig cfg_;
     int device_ = 0;
     zkhip_ctx* ctx_ = nullptr;
-    std::vector<Level> levels_;
+    std::deque<Level> levels_;                       // (stable references: levels are added while others are in use)
+    // levels_mu_: the container (brief); build_mu_: one level is built at a time; dev_mu_: any call on ctx_.  Order: build -> dev;
+    // levels_mu_ is never held while another one is taken.
+    std::unique_ptr<std::mutex> levels_mu_, dev_mu_, build_mu_;
+    Level& lv(size_t level) {
+        std::lock_guard<std::mutex> lk(*levels_mu_);
+        return levels_.at(level);
+    }
+    size_t n_levels() {
+        std::lock_guard<std::mutex> lk(*levels_mu_);
+        return levels_.size();
+    }
+    const VerifyingKey& level_vk(size_t level) { return lv(level).vk; }
 
     void check(int rc) const {
         if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_last_error(ctx_));
     }
     void upload_witness(size_t level) {
-        Level& L = levels_[level];
+        Level& L = lv(level);
         check(zkhip_recursion_tracegen(ctx_, L.circ, (uint32_t*)L.d_traces[0], (uint32_t*)L.d_traces[1], (uint32_t*)L.d_traces[2]));
     }
     ChildProof prove_uploaded(size_t level, std::vector<uint32_t> node_pvs) {
-        Level& L = levels_[level];
+        Level& L = lv(level);
         ChildProof out;
         out.pvs.resize(3);
         out.pvs[2] = std::move(node_pvs);
@@ -298,13 +476,16 @@ private:
     }
     void ensure_level(size_t level) {
         using clk = std::chrono::steady_clock;
-        while (levels_.size() <= level) {
-            const size_t l = levels_.size();
+        while (n_levels() <= level) {
+            std::lock_guard<std::mutex> build_lock(*build_mu_);   // per level: a thread that needs level 1 gets in between levels 1 and 2 of a warm-up
+            const size_t l = n_levels();
+            if (l > level) break;
             if (!ctx_) {
+                std::lock_guard<std::mutex> dev(*dev_mu_);
                 int rc = zkhip_ctx_create(device_, &ctx_);
                 if (rc != ZKHIP_OK) throw Error(Error::Keygen, "no gfx950 device for the HIP backend (zkhip_ctx_create returned " + std::to_string(rc) + ")");
             }
-            const VerifyingKey& cvk = l == 0 ? app_ : levels_[l - 1].vk;
+            const VerifyingKey& cvk = l == 0 ? app_ : lv(l - 1).vk;
             std::vector<zkhip_air> za = cvk.as_airs();
             zkhip_recursion_stmt st{};
             std::vector<uint32_t> sa, si, ea, ei;
@@ -330,6 +511,7 @@ private:
                 L.vk.airs.push_back(std::move(d));
                 L.vk.heights.push_back(na[i].log_height);
             }
+            std::lock_guard<std::mutex> dev(*dev_mu_);
             rc = zkhip_keygen(ctx_, &L.vk.params, na.data(), 3, &L.pk);
             if (rc != ZKHIP_OK) {
                 zkhip_recursion_destroy(L.circ);
@@ -345,6 +527,7 @@ private:
             }
             stats.build_seconds += std::chrono::duration<double>(t1 - t0).count();
             stats.keygen_seconds += std::chrono::duration<double>(clk::now() - t1).count();
+            std::lock_guard<std::mutex> lk(*levels_mu_);
             levels_.push_back(std::move(L));
         }
     }

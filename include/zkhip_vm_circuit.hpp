@@ -7,17 +7,18 @@
 //                  executable, crates/verifier/src/verifier.rs:77-80), one row per instruction: 17 decode fields; the main trace is
 //                  the execution frequency; every executed instruction is looked up here.
 //   frame chip     one row per executed instruction: receives (pc, timestamp) on the EXECUTION BUS and sends (pc + pc_inc,
-//                  timestamp + 16); reads rs1 / rs2 and writes rd through the ACCESS BUS at fixed timestamp slots; range-checks
-//                  the operand bytes; hands (class, opcode, operands, result, pc_inc ...) to the instruction's core chip on the
-//                  OPERAND BUS.  A core chip (ALU, less-than, mul, mulh, div, shift, branches, jumps) is the core of
+//                  timestamp + 16); its REGISTER ADAPTER reads rs1 / rs2 and writes rd on the MEMORY BUS at fixed timestamp slots (a word
+//                  access = receive the word's previous state, send the new one, previous timestamp strictly smaller); range-checks
+//                  the operand and result bytes; hands (class, opcode, operands, result, pc_inc ...) to the instruction's core chip
+//                  on the OPERAND BUS.  A core chip (ALU, less-than, mul, mulh, div, shift, branches, jumps) is the core of
 //                  include/zkhip_chips.hpp plus ONE receive on that bus: its columns are unchanged, so are its trace generators.
-//   load/store     the load/store core plus its memory adapter: address = rs1 + immediate, the aligned word's two 16-bit cells
-//                  accessed at slots 4, 5.
+//   load/store     the load/store core plus its memory adapter: address = rs1 + immediate, the aligned word accessed at slot 4.
 //   ecall chip     exit (pc becomes 0: the end of the execution), reveal (writes a public-value word into address space 3), hint read.
-//   memory access  one row per cell access (include/zkhip_chips.hpp memory_access_air + the ACCESS BUS receive + a timestamp-gap
-//                  bound that cannot wrap around the field): offline memory checking inside the segment.
-//   leaf chip      one row per touched memory BLOCK of 8 cells: initial / final cell values against the memory bus, their Poseidon2
-//                  digests, strictly increasing block labels.
+//   (memory)       offline memory checking inside the segment lives in the chips that access memory (as in OpenVM's adapters): a memory
+//                  word is (address space, word pointer, low half, high half, timestamp) on the memory bus; there is no separate
+//                  access chip.
+//   leaf chip      one row per touched memory BLOCK of 4 words (8 sixteen-bit cells): initial / final values against the memory bus,
+//                  their Poseidon2 digests, strictly increasing block labels.
 //   merkle chip    one row per node on the path from a touched block to the root: the same path hashed over the initial and the
 //                  final blocks; untouched siblings are equal in both; the root row's digests are PUBLIC VALUES: the segment's
 //                  initial and final memory root.
@@ -25,8 +26,8 @@
 // A segment proof therefore states: "the committed program, started at pc_start on the memory with root R0, runs to pc_end and
 // leaves the memory with root R1".  Consecutive segments chain by (pc_end, R1) = (pc_start', R0') -- exactly the (start, end)
 // state the aggregation circuit chains (include/zkhip_aggregation.hpp) -- and pc_end = 0 means the guest has exited with code 0.
-// Registers are address space 1 (cell 2 i + half of x_i), memory address space 2 (cell = byte address / 2, addresses below 2^30),
-// the 32 public-value bytes address space 3 (cells 0..15).  Header-only, no device code.
+// Registers are address space 1 (word i = x_i), memory address space 2 (word = byte address / 4, addresses below 2^30), the 32
+// public-value bytes address space 3 (words 0..7).  Header-only, no device code.
 #pragma once
 #include <array>
 #include <cstdint>
@@ -40,12 +41,13 @@ using air::AirBuilder;
 using air::Expr;
 using air::Kind;
 
-constexpr uint32_t MEMORY_BUS = 1, EXEC_BUS = 2, OPERAND_BUS = 3, ACCESS_BUS = 4, RANGE_BUS = 5, RANGE_TUPLE_BUS = 6, PROGRAM_BUS = 8, BITWISE_BUS = 9,
+constexpr uint32_t MEMORY_BUS = 1, EXEC_BUS = 2, OPERAND_BUS = 3, RANGE_BUS = 5, RANGE_TUPLE_BUS = 6, PROGRAM_BUS = 8, BITWISE_BUS = 9,
                    MERKLE_BUS = 10, HASH_BUS = 11;
-constexpr uint32_t TS_STEP = 16;   // timestamps per instruction: rs1 at +0, +1; rs2 at +2, +3; the core's own accesses at +4 ..; rd at +12, +13
-constexpr uint32_t BLOCK_CELLS = 8, LABEL_BITS = 26, LEAF_LEVEL = LABEL_BITS + 2;  // block label = as * 2^26 + (cell >> 3); the tree has 28 levels above the blocks
+constexpr uint32_t TS_STEP = 16;   // timestamps per instruction: rs1 at +0; rs2 at +2; the core's own accesses at +4 ..; rd at +12
+constexpr uint32_t BLOCK_CELLS = 8, BLOCK_WORDS = 4, LABEL_BITS = 26, LEAF_LEVEL = LABEL_BITS + 2;  // block label = as * 2^26 + (word >> 2); the tree has 28 levels above the blocks
+constexpr uint32_t GAP_HI_BITS = 11;  // a timestamp gap is gap_lo + 2^16 gap_hi with gap_hi below 2^11 (one range-tuple lookup (0, gap_hi))
 enum Cls : uint32_t { C_ALU, C_LT, C_MUL, C_MULH, C_DIVREM, C_SHIFT, C_BEQ, C_BLT, C_JAL_LUI, C_AUIPC, C_JALR, C_LS, C_ECALL, N_CLS };
-constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 34, LS_WIDTH = 45, ECALL_WIDTH = 21, ACCESS_WIDTH = 11, LEAF_WIDTH = 47, MERKLE_WIDTH = 54,
+constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 27, LEAF_WIDTH = 43, MERKLE_WIDTH = 54,
                  CONNECTOR_WIDTH = 2;
 constexpr uint32_t P = air::P;
 
@@ -155,8 +157,22 @@ inline void program_air(AirBuilder& b) {
     b.push_interaction(PROGRAM_BUS, f, b.var(0), Kind::Receive);
 }
 
+// One WORD ACCESS inside a chip's row (the memory side of an adapter): the word's previous state (p_lo, p_hi, prev_ts) is received
+// from the memory bus and its new state (n_lo, n_hi, ts) sent, `count` times (0 or 1).  ts - prev_ts - 1 = gap_lo + 2^16 gap_hi with
+// gap_lo in the range table and (0, gap_hi) in the range-tuple table (gap_hi < 2^11): timestamps stay below 2^29 (connector), so the
+// difference cannot wrap around the field and the previous access is strictly earlier.  The two lookups are made `looked_up` times
+// (the row's validity flag: rows that skip the access carry a zero gap), so their multiplicities are plain column histograms.
+inline void word_access(AirBuilder& b, Expr count, Expr looked_up, Expr as_, Expr ptr, Expr p_lo, Expr p_hi, Expr n_lo, Expr n_hi, Expr ts, Expr prev_ts,
+                        Expr gap_lo, Expr gap_hi) {
+    b.assert_zero(count * (ts - prev_ts - 1 - gap_lo - gap_hi * 65536));
+    b.push_interaction(MEMORY_BUS, {as_, ptr, p_lo, p_hi, prev_ts}, count, Kind::Receive);
+    b.push_interaction(MEMORY_BUS, {as_, ptr, n_lo, n_hi, ts}, count, Kind::Send);
+    b.push_interaction(RANGE_BUS, {gap_lo}, looked_up, Kind::Send);
+    b.push_interaction(RANGE_TUPLE_BUS, {b.constant(0), gap_hi}, looked_up, Kind::Send);
+}
+
 // frame chip: AirBuilder(FRAME_WIDTH, 0).  Columns: pc ts | cls op rd rs1 rs2 imm_lo imm_hi imm_f use_rs1 use_rs2 y_is_imm wr_rd need_pc
-// need_immf need_ts y_byte | x[4] y[4] z[4] | rd_prev_lo rd_prev_hi | pc_inc | ok
+// need_immf need_ts y_byte | x[4] y[4] z[4] | rd_prev_lo rd_prev_hi | pc_inc | ok | (prev_ts gap_lo gap_hi) of the rs1, rs2, rd accesses
 inline void frame_air(AirBuilder& b) {
     const Expr pc = b.var(0), ts = b.var(1), cls = b.var(2), op = b.var(3), rd = b.var(4), rs1 = b.var(5), rs2 = b.var(6), imm_lo = b.var(7),
                imm_hi = b.var(8), imm_f = b.var(9), use_rs1 = b.var(10), use_rs2 = b.var(11), y_is_imm = b.var(12), wr_rd = b.var(13), need_pc = b.var(14),
@@ -185,16 +201,16 @@ inline void frame_air(AirBuilder& b) {
         b.push_interaction(OPERAND_BUS, m, ok, Kind::Send);
     }
     const Expr one = b.constant(1), zero = b.constant(0);
-    b.push_interaction(ACCESS_BUS, {one, rs1 * 2, x_lo, x_lo, ts, one}, use_rs1, Kind::Send);
-    b.push_interaction(ACCESS_BUS, {one, rs1 * 2 + 1, x_hi, x_hi, ts + 1, one}, use_rs1, Kind::Send);
-    b.push_interaction(ACCESS_BUS, {one, rs2 * 2, y_lo, y_lo, ts + 2, one}, use_rs2, Kind::Send);
-    b.push_interaction(ACCESS_BUS, {one, rs2 * 2 + 1, y_hi, y_hi, ts + 3, one}, use_rs2, Kind::Send);
-    b.push_interaction(ACCESS_BUS, {one, rd * 2, rdp_lo, z_lo, ts + 12, zero}, wr_rd, Kind::Send);
-    b.push_interaction(ACCESS_BUS, {one, rd * 2 + 1, rdp_hi, z_hi, ts + 13, zero}, wr_rd, Kind::Send);
+    // register adapter: rs1 and rs2 are read (the word stays), rd is written
+    word_access(b, use_rs1, ok, one, rs1, x_lo, x_hi, x_lo, x_hi, ts, b.var(34), b.var(35), b.var(36));
+    word_access(b, use_rs2, ok, one, rs2, y_lo, y_hi, y_lo, y_hi, ts + 2, b.var(37), b.var(38), b.var(39));
+    word_access(b, wr_rd, ok, one, rd, rdp_lo, rdp_hi, z_lo, z_hi, ts + 12, b.var(40), b.var(41), b.var(42));
     b.push_interaction(BITWISE_BUS, {x[0], x[1], zero, zero}, ok, Kind::Send);
     b.push_interaction(BITWISE_BUS, {x[2], x[3], zero, zero}, ok, Kind::Send);
     b.push_interaction(BITWISE_BUS, {y[0], y[1], zero, zero}, ok, Kind::Send);
     b.push_interaction(BITWISE_BUS, {y[2], y[3], zero, zero}, ok, Kind::Send);
+    b.push_interaction(BITWISE_BUS, {z[0], z[1], zero, zero}, ok, Kind::Send);   // what is written to a register is a word of bytes
+    b.push_interaction(BITWISE_BUS, {z[2], z[3], zero, zero}, ok, Kind::Send);
 }
 
 // The operand-bus message as a core chip states it: 20 fields (class, opcode, x[4], y[4], z[4], pc, imm_f, pc_inc, ts, imm_lo, imm_hi);
@@ -283,7 +299,7 @@ inline size_t core_width(uint32_t cls) {
 }
 
 // load/store chip: AirBuilder(LS_WIDTH, 0).  Columns 0..32 are the core's (read[4] prev[4] write[4] flag[20] sign); then
-// ts | base[4] | imm_lo imm_hi | addr_lo addr_hi | carry0 carry1 | word_lo (= addr_lo >> 2)
+// ts | base[4] | imm_lo imm_hi | addr_lo addr_hi | carry0 carry1 | word_lo (= addr_lo >> 2) | prev_ts gap_lo gap_hi of the word access
 inline void loadstore_air(AirBuilder& b) {
     chips::rv32_loadstore_core_air(b);
     Expr rdv[4], pv[4], wr[4], fl[20], base[4];
@@ -292,13 +308,10 @@ inline void loadstore_air(AirBuilder& b) {
     const Expr ts = b.var(33), imm_lo = b.var(38), imm_hi = b.var(39), a_lo = b.var(40), a_hi = b.var(41), c0 = b.var(42), c1 = b.var(43), w_lo = b.var(44);
     static const int KIND[20] = {0, 1, 1, 2, 2, 2, 2, 3, 4, 4, 5, 5, 5, 5, 6, 6, 7, 7, 7, 7};
     static const int SHIFT[20] = {0, 0, 2, 0, 1, 2, 3, 0, 0, 2, 0, 1, 2, 3, 0, 2, 0, 1, 2, 3};
-    Expr ok = fl[0], kind = fl[0] * KIND[0], shift = fl[0] * SHIFT[0], is_store = fl[7], m0 = fl[0], m1 = fl[0];
+    Expr ok = fl[0], kind = fl[0] * KIND[0], shift = fl[0] * SHIFT[0], is_store = fl[7];
     for (int c = 1; c < 20; c++) {
         ok = ok + fl[c], kind = kind + fl[c] * KIND[c], shift = shift + fl[c] * SHIFT[c];
         if (KIND[c] >= 3 && KIND[c] <= 5 && c != 7) is_store = is_store + fl[c];
-        const bool word = KIND[c] == 0 || KIND[c] == 3;
-        if (word || SHIFT[c] < 2) m0 = m0 + fl[c];
-        if (word || SHIFT[c] >= 2) m1 = m1 + fl[c];
     }
     const Expr is_load = ok - is_store;
     b.assert_zero(c0 * (c0 - 1));
@@ -311,13 +324,14 @@ inline void loadstore_air(AirBuilder& b) {
     m.op = kind, m.ts = ts, m.imm_lo = imm_lo, m.imm_hi = imm_hi;
     for (int i = 0; i < 4; i++) m.x[i] = base[i], m.y[i] = is_store * rdv[i], m.z[i] = is_load * wr[i];
     receive_operands(b, C_LS, m, ok);
-    // the aligned word's cells: cell = address / 2; values before / after the access
-    const Expr cell0 = w_lo * 2 + a_hi * 32768;
+    // the aligned word: word pointer = address / 4; a load leaves it as it is (read = the memory word), a store replaces the previous
+    // word by the core's merged word (the bytes a narrow store does not touch are the previous word's, by the core's constraints)
+    const Expr word = w_lo + a_hi * 16384;
     const Expr two = b.constant(2);
     const Expr r0 = rdv[0] + rdv[1] * 256, r1 = rdv[2] + rdv[3] * 256, p0 = pv[0] + pv[1] * 256, p1 = pv[2] + pv[3] * 256, n0 = wr[0] + wr[1] * 256,
                n1 = wr[2] + wr[3] * 256;
-    b.push_interaction(ACCESS_BUS, {two, cell0, is_load * r0 + is_store * p0, is_load * r0 + is_store * n0, ts + 4, is_load}, m0, Kind::Send);
-    b.push_interaction(ACCESS_BUS, {two, cell0 + 1, is_load * r1 + is_store * p1, is_load * r1 + is_store * n1, ts + 5, is_load}, m1, Kind::Send);
+    word_access(b, ok, ok, two, word, is_load * r0 + is_store * p0, is_load * r1 + is_store * p1, is_load * r0 + is_store * n0, is_load * r1 + is_store * n1, ts + 4,
+                b.var(45), b.var(46), b.var(47));
     const Expr zero = b.constant(0);
     b.push_interaction(BITWISE_BUS, {rdv[0], rdv[1], zero, zero}, ok, Kind::Send);
     b.push_interaction(BITWISE_BUS, {rdv[2], rdv[3], zero, zero}, ok, Kind::Send);
@@ -331,7 +345,7 @@ inline void loadstore_air(AirBuilder& b) {
 }
 
 // ecall chip: AirBuilder(ECALL_WIDTH, 0).  Columns: pc ts | x[4] (a7) | y[4] (a0) | z[4] (a0 afterwards) | is_exit is_reveal is_read |
-// idx (a1 low cell, the public-value word index) | pv_prev_lo pv_prev_hi | pc_inc
+// idx (a1, the public-value word index) | pv_prev_lo pv_prev_hi | pc_inc | (prev_ts gap_lo gap_hi) of the a1 read and the public-value write
 inline void ecall_air(AirBuilder& b) {
     const Expr pc = b.var(0), ts = b.var(1);
     Expr x[4], y[4], z[4];
@@ -352,32 +366,25 @@ inline void ecall_air(AirBuilder& b) {
     for (int i = 0; i < 4; i++) m.x[i] = x[i], m.y[i] = y[i], m.z[i] = z[i];
     receive_operands(b, C_ECALL, m, ok);
     const Expr one = b.constant(1), zero = b.constant(0), three = b.constant(3);
-    // reveal: a1's low cell (register 11) is the word index, below 8; the word a0 goes to cells 2 idx, 2 idx + 1 of address space 3
-    b.push_interaction(ACCESS_BUS, {one, b.constant(22), idx, idx, ts + 4, one}, is_reveal, Kind::Send);
-    b.push_interaction(ACCESS_BUS, {three, idx * 2, pvp_lo, y[0] + y[1] * 256, ts + 5, zero}, is_reveal, Kind::Send);
-    b.push_interaction(ACCESS_BUS, {three, idx * 2 + 1, pvp_hi, y[2] + y[3] * 256, ts + 6, zero}, is_reveal, Kind::Send);
+    // reveal: a1 (register 11) is the word index, below 8; the word a0 goes to word idx of address space 3
+    word_access(b, is_reveal, is_reveal, one, b.constant(11), idx, zero, idx, zero, ts + 4, b.var(21), b.var(22), b.var(23));
+    word_access(b, is_reveal, is_reveal, three, idx, pvp_lo, pvp_hi, y[0] + y[1] * 256, y[2] + y[3] * 256, ts + 5, b.var(24), b.var(25), b.var(26));
     b.push_interaction(RANGE_BUS, {idx * 8192}, is_reveal, Kind::Send);
     b.push_interaction(RANGE_BUS, {idx}, is_reveal, Kind::Send);
+    // the hinted word is a word of bytes (the other cases copy a0, whose bytes the frame chip checks)
+    b.push_interaction(BITWISE_BUS, {z[0], z[1], zero, zero}, is_read, Kind::Send);
+    b.push_interaction(BITWISE_BUS, {z[2], z[3], zero, zero}, is_read, Kind::Send);
 }
 
-// memory access chip: AirBuilder(ACCESS_WIDTH, 0).  chips::memory_access_air's ten columns + hi8 = 8 gap_hi: the gap
-// ts - prev_ts - 1 = gap_lo + 2^16 gap_hi stays below 2^29, so a timestamp cannot run backwards modulo p (timestamps themselves
-// are bounded by the execution-bus chain: 1 + 16 per instruction).  Every row is one access requested on the access bus.
-inline void access_air(AirBuilder& b) {
-    chips::memory_access_air(b, RANGE_BUS, MEMORY_BUS);
-    const Expr as_ = b.var(0), ptr = b.var(1), pd = b.var(2), d = b.var(4), ts = b.var(5), rd = b.var(6), ok = b.var(7), hi = b.var(9), hi8 = b.var(10);
-    b.assert_zero(hi8 - hi * 8);
-    b.push_interaction(RANGE_BUS, {hi8}, ok, Kind::Send);
-    b.push_interaction(ACCESS_BUS, {as_, ptr, pd, d, ts, rd}, ok, Kind::Receive);
-}
-
-// leaf chip: AirBuilder(LEAF_WIDTH, 0).  Columns: as blk | init[8] | fin[8] | fin_ts[8] | h_init[8] | h_fin[8] | ok | gap_lo gap_hi |
-// blk_lo blk_hi.  One row per touched block of 8 cells, strictly increasing label = as 2^26 + blk; padding rows carry as = 1.
+// leaf chip: AirBuilder(LEAF_WIDTH, 0).  Columns: as blk | init[8] | fin[8] | fin_ts[4] | h_init[8] | h_fin[8] | ok | gap_lo gap_hi |
+// blk_lo blk_hi.  One row per touched block of 4 words (cells 2 j, 2 j + 1 = the halves of word j), strictly increasing
+// label = as 2^26 + blk; padding rows carry as = 1.
 inline void leaf_air(AirBuilder& b) {
-    const Expr as_ = b.var(0), blk = b.var(1), ok = b.var(42), gap_lo = b.var(43), gap_hi = b.var(44), blk_lo = b.var(45), blk_hi = b.var(46);
-    Expr init[8], fin[8], fts[8], hi[8], hf[8];
-    for (int j = 0; j < 8; j++) init[j] = b.var(2 + j), fin[j] = b.var(10 + j), fts[j] = b.var(18 + j), hi[j] = b.var(26 + j), hf[j] = b.var(34 + j);
-    const Expr ok_n = b.var(42, 1);
+    const Expr as_ = b.var(0), blk = b.var(1), ok = b.var(38), gap_lo = b.var(39), gap_hi = b.var(40), blk_lo = b.var(41), blk_hi = b.var(42);
+    Expr init[8], fin[8], fts[4], hi[8], hf[8];
+    for (int j = 0; j < 8; j++) init[j] = b.var(2 + j), fin[j] = b.var(10 + j), hi[j] = b.var(22 + j), hf[j] = b.var(30 + j);
+    for (int j = 0; j < 4; j++) fts[j] = b.var(18 + j);
+    const Expr ok_n = b.var(38, 1);
     b.assert_zero(ok * (ok - 1));
     b.when_transition(ok_n * (1 - ok));                              // valid rows come first
     b.assert_zero((as_ - 1) * (as_ - 2) * (as_ - 3));                // address space 1, 2 or 3 (padding rows: 1)
@@ -385,9 +392,9 @@ inline void leaf_air(AirBuilder& b) {
     b.when_transition(ok_n * (label_n - label - 1 - gap_lo - gap_hi * 65536));
     b.assert_zero(blk - blk_lo - blk_hi * 65536);
     const Expr zero = b.constant(0);
-    for (int j = 0; j < 8; j++) {
-        b.push_interaction(MEMORY_BUS, {as_, blk * 8 + j, init[j], zero}, ok, Kind::Send);
-        b.push_interaction(MEMORY_BUS, {as_, blk * 8 + j, fin[j], fts[j]}, ok, Kind::Receive);
+    for (int j = 0; j < 4; j++) {
+        b.push_interaction(MEMORY_BUS, {as_, blk * 4 + j, init[2 * j], init[2 * j + 1], zero}, ok, Kind::Send);
+        b.push_interaction(MEMORY_BUS, {as_, blk * 4 + j, fin[2 * j], fin[2 * j + 1], fts[j]}, ok, Kind::Receive);
     }
     std::vector<Expr> hin, hfn;
     for (int j = 0; j < 8; j++) hin.push_back(init[j]), hfn.push_back(fin[j]);
@@ -460,7 +467,7 @@ inline void connector_air(AirBuilder& b) {
 
 // ---- the segment's AIR set (order fixed: it is part of the verifying key) ----
 enum AirId : unsigned {
-    A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_ACCESS, A_LEAF,
+    A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
     A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, N_AIRS
 };
 struct AirShape {
@@ -479,7 +486,6 @@ inline AirShape build_air(unsigned id) {
         case A_FRAME: make(FRAME_WIDTH, 0, 0, frame_air); break;
         case A_LS: make(LS_WIDTH, 0, 0, loadstore_air); break;
         case A_ECALL: make(ECALL_WIDTH, 0, 0, ecall_air); break;
-        case A_ACCESS: make(ACCESS_WIDTH, 0, 0, access_air); break;
         case A_LEAF: make(LEAF_WIDTH, 0, 0, leaf_air); break;
         case A_MERKLE: make(MERKLE_WIDTH, 16, 0, merkle_air); break;
         case A_POSEIDON2: make(air::POSEIDON2_AIR_WIDTH + 1, 0, 0, [](AirBuilder& b) { air::poseidon2_air(b, (int)HASH_BUS, 8); }); break;

@@ -2,8 +2,8 @@
 // and produces, segment by segment, everything the chips of include/zkhip_vm_circuit.hpp are generated from:
 //   * the per-class core records of include/zkhip_vm.hpp (unchanged), the frame records (operands, result, pc step of every
 //     instruction), the load/store adapter records, the ecall rows;
-//   * the memory log with the circuit's timestamps (1 + 16 k + slot for instruction k of the segment; cells: registers = address
-//     space 1, memory = 2 with cell = byte address / 2, public values = 3);
+//   * for every word access of every chip the timestamp of the word's previous access (the circuit's timestamps are 1 + 16 k + slot
+//     for instruction k of the segment; words: registers = address space 1, memory = 2 with word = byte address / 4, public values = 3);
 //   * the PERSISTENT MEMORY: a sparse Merkle tree (Poseidon2, blocks of 8 cells) over all three address spaces that lives across
 //     segments; per segment the touched blocks (leaf rows) and the nodes of their paths (merkle rows) with digests before and after.
 // A segment ends when the guest exits or when one more instruction could overflow a chip's fixed height (SegmentCaps): heights are
@@ -87,7 +87,7 @@ struct SegmentCaps {
         c.log_height[vmc::A_DIVREM] = sub(5), c.log_height[vmc::A_SHIFT] = sub(3), c.log_height[vmc::A_BEQ] = sub(2), c.log_height[vmc::A_BLT] = sub(2);
         c.log_height[vmc::A_JAL_LUI] = sub(3), c.log_height[vmc::A_AUIPC] = sub(5), c.log_height[vmc::A_JALR] = sub(4), c.log_height[vmc::A_LS] = sub(1);
         // (floors: a handful of touched blocks already needs ~28 path nodes each and two permutations per row)
-        c.log_height[vmc::A_ECALL] = std::max(sub(7), 3u), c.log_height[vmc::A_ACCESS] = log_frame + 3, c.log_height[vmc::A_LEAF] = std::max(sub(5), 4u);
+        c.log_height[vmc::A_ECALL] = std::max(sub(7), 3u), c.log_height[vmc::A_LEAF] = std::max(sub(5), 4u);
         c.log_height[vmc::A_MERKLE] = std::max(sub(4), 8u);
         c.log_height[vmc::A_POSEIDON2] = std::max(sub(2), c.log_height[vmc::A_MERKLE] + 2), c.log_height[vmc::A_CONNECTOR] = 0, c.log_height[vmc::A_BITWISE] = 16;
         c.log_height[vmc::A_RANGE_TUPLE] = 19, c.log_height[vmc::A_RANGE] = 16;
@@ -100,9 +100,9 @@ constexpr uint32_t TUPLE_X = 256, TUPLE_Y = 2048;
 struct SegmentRecords {
     ExecRecords core;                                        // per-class core records; core.pc_index = the frame rows' program indices
     std::vector<uint32_t> f_x, f_y, f_z, f_rdprev, f_pcinc;  // frame: operands, result, previous rd, pc step (field element)
-    std::vector<uint32_t> ls_ts, ls_base, ls_imm;            // load/store adapter, aligned with core.ls_*
+    std::vector<uint32_t> f_pts1, f_pts2, f_pts3;            // frame: timestamps of the previous accesses of rs1, rs2, rd (0 where unused)
+    std::vector<uint32_t> ls_ts, ls_base, ls_imm, ls_pts;    // load/store adapter, aligned with core.ls_*; ls_pts = the word's previous access
     std::vector<uint32_t> ecall_rows;                        // row-major canonical rows of the ecall / leaf / merkle chips
-    std::vector<uint32_t> acc_as, acc_ptr, acc_prev_data, acc_prev_ts, acc_data, acc_ts, acc_is_read;
     std::vector<uint32_t> leaf_rows, merkle_rows, p2_inputs; // p2_inputs: [n][16] canonical, one row per hash-bus request
     uint32_t pc_start = 0, pc_end = 0, ts_end = 0;
     Digest root_init{}, root_final{};
@@ -113,8 +113,8 @@ struct SegmentRecords {
     size_t n_p2() const { return p2_inputs.size() / 16; }
     void clear() {
         core.clear();
-        for (auto* v : {&f_x, &f_y, &f_z, &f_rdprev, &f_pcinc, &ls_ts, &ls_base, &ls_imm, &ecall_rows, &acc_as, &acc_ptr, &acc_prev_data, &acc_prev_ts,
-                        &acc_data, &acc_ts, &acc_is_read, &leaf_rows, &merkle_rows, &p2_inputs})
+        for (auto* v : {&f_x, &f_y, &f_z, &f_rdprev, &f_pcinc, &f_pts1, &f_pts2, &f_pts3, &ls_ts, &ls_base, &ls_imm, &ls_pts, &ecall_rows, &leaf_rows, &merkle_rows,
+                        &p2_inputs})
             v->clear();
         n_instr = 0;
     }
@@ -150,9 +150,7 @@ public:
     bool run_segment(SegmentRecords& r) {
         r.clear();
         reset_blocks();
-        acc_.clear();
-        if (acc_.capacity() < caps_.rows(vmc::A_ACCESS)) acc_.reserve(caps_.rows(vmc::A_ACCESS));
-        for (auto* v : {&r.f_x, &r.f_y, &r.f_z, &r.f_rdprev, &r.f_pcinc, &r.core.pc_index})
+        for (auto* v : {&r.f_x, &r.f_y, &r.f_z, &r.f_rdprev, &r.f_pcinc, &r.f_pts1, &r.f_pts2, &r.f_pts3, &r.core.pc_index})
             if (v->capacity() < caps_.rows(vmc::A_FRAME)) v->reserve(caps_.rows(vmc::A_FRAME));
         r.pc_start = m_.pc();
         r.root_init = tree_.root();
@@ -169,16 +167,16 @@ public:
                 uint32_t labels[5];
                 unsigned nl = 0;
                 bool all_known = true;
-                auto want = [&](uint32_t as, uint32_t cell) {
-                    labels[nl] = (as << vmc::LABEL_BITS) | (cell >> 3);
+                auto want = [&](uint32_t as, uint32_t word) {
+                    labels[nl] = (as << vmc::LABEL_BITS) | (word >> 2);
                     all_known = all_known && find_block(labels[nl]) != nullptr;
                     nl++;
                 };
-                if (d.use_rs1) want(1, 2 * d.rs1);
-                if (d.use_rs2) want(1, 2 * d.rs2);
-                if (d.wr_rd) want(1, 2 * d.rd);
-                if (d.cls == vmc::C_LS) want(2, (((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) & ~3u) >> 1);
-                if (d.cls == vmc::C_ECALL) want(1, 22), want(3, 2 * (m_.reg(11) & 7u));
+                if (d.use_rs1) want(1, d.rs1);
+                if (d.use_rs2) want(1, d.rs2);
+                if (d.wr_rd) want(1, d.rd);
+                if (d.cls == vmc::C_LS) want(2, ((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) >> 2);
+                if (d.cls == vmc::C_ECALL) want(1, 11), want(3, m_.reg(11) & 7u);
                 if (!all_known) {   // rare: count exactly what the instruction would add
                     std::unordered_set<uint64_t> fresh;
                     for (unsigned i = 0; i < nl; i++) {
@@ -195,7 +193,7 @@ public:
                 }
             }
             if (r.n_instr + 1 > caps_.rows(vmc::A_FRAME) || n_cls[d.cls] + 1 > caps_.rows(vmc::A_ALU + d.cls) ||
-                acc_.size() + 9 > caps_.rows(vmc::A_ACCESS) || blk_.size() + new_blocks > caps_.rows(vmc::A_LEAF) ||
+                blk_.size() + new_blocks > caps_.rows(vmc::A_LEAF) ||
                 path_nodes_.size() + new_nodes > caps_.rows(vmc::A_MERKLE) ||
                 2 * (blk_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
                 if (r.n_instr == 0) throw Error("segment heights too small for a single instruction");
@@ -209,18 +207,18 @@ public:
             // memory cells of a load / store, before the instruction
             uint32_t addr = 0, word_before = 0;
             if (d.cls == vmc::C_LS) addr = x + imm32, word_before = mem_word(addr & ~3u);
-            if (d.use_rs1) read_cell(r, 1, 2 * d.rs1, x & 0xffffu, ts), read_cell(r, 1, 2 * d.rs1 + 1, x >> 16, ts + 1);
-            if (d.use_rs2) read_cell(r, 1, 2 * d.rs2, y & 0xffffu, ts + 2), read_cell(r, 1, 2 * d.rs2 + 1, y >> 16, ts + 3);
+            const uint32_t pts1 = d.use_rs1 ? read_word(1, d.rs1, x, ts) : 0;
+            const uint32_t pts2 = d.use_rs2 ? read_word(1, d.rs2, y, ts + 2) : 0;
             uint32_t a1 = 0, pv_before = 0;
             if (d.cls == vmc::C_ECALL && x == 1) {
-                a1 = m_.reg(11) & 0xffffu;
-                if (a1 >= 8 || (m_.reg(11) >> 16)) throw Error("public value index out of range");
+                a1 = m_.reg(11);
+                if (a1 >= 8) throw Error("public value index out of range");
                 memcpy(&pv_before, m_.public_values().data() + 4 * a1, 4);
             }
             // snapshot the blocks this instruction is going to change
-            if (d.wr_rd) (void)block_of(1, 2 * d.rd);
-            if (d.cls == vmc::C_LS) (void)block_of(2, (addr & ~3u) >> 1);
-            if (d.cls == vmc::C_ECALL && x == 1) (void)block_of(3, 2 * a1);
+            if (d.wr_rd) (void)block_of(1, d.rd);
+            if (d.cls == vmc::C_LS) (void)block_of(2, addr >> 2);
+            if (d.cls == vmc::C_ECALL && x == 1) (void)block_of(3, a1);
             const size_t n_ls_before = r.core.ls_case.size();
             m_.step_one(&r.core);
             uint32_t z = 0, pc_inc;
@@ -234,8 +232,11 @@ public:
                 row[14] = x == 93, row[15] = x == 1, row[16] = x == 2, row[20] = pc_inc;
                 if (x == 1) {
                     row[17] = a1, row[18] = pv_before & 0xffffu, row[19] = pv_before >> 16;
-                    read_cell(r, 1, 22, a1, ts + 4);
-                    write_cell(r, 3, 2 * a1, y & 0xffffu, ts + 5), write_cell(r, 3, 2 * a1 + 1, y >> 16, ts + 6);
+                    auto gap = [&](uint32_t* dst, uint32_t pts, uint32_t at) {
+                        dst[0] = pts, dst[1] = (at - pts - 1) & 0xffffu, dst[2] = (at - pts - 1) >> 16;
+                    };
+                    gap(row + 21, read_word(1, 11, a1, ts + 4), ts + 4);
+                    gap(row + 24, write_word(3, a1, y, ts + 5), ts + 5);
                 }
                 r.ecall_rows.insert(r.ecall_rows.end(), row, row + vmc::ECALL_WIDTH);
             } else {
@@ -246,25 +247,17 @@ public:
             if (d.cls == vmc::C_LS) {
                 if (r.core.ls_case.size() != n_ls_before + 1) throw Error("internal: load/store record missing");
                 r.ls_ts.push_back(ts), r.ls_base.push_back(x), r.ls_imm.push_back(imm32);
-                const uint32_t cs = r.core.ls_case.back(), word_after = mem_word(addr & ~3u), cell0 = (addr & ~3u) >> 1;
-                const bool store = d.op >= 3 && d.op <= 5, word = d.op == 0 || d.op == 3;
-                const unsigned s = addr & 3u;
-                (void)cs;
-                for (unsigned c = 0; c < 2; c++) {
-                    if (!(word || (s >> 1) == c)) continue;
-                    const uint32_t before = (word_before >> (16 * c)) & 0xffffu, after = (word_after >> (16 * c)) & 0xffffu;
-                    if (store) write_cell(r, 2, cell0 + c, after, ts + 4 + c);
-                    else read_cell(r, 2, cell0 + c, before, ts + 4 + c);
-                }
+                const bool store = d.op >= 3 && d.op <= 5;
+                r.ls_pts.push_back(store ? write_word(2, addr >> 2, mem_word(addr & ~3u), ts + 4) : read_word(2, addr >> 2, word_before, ts + 4));
             }
-            if (d.wr_rd) write_cell(r, 1, 2 * d.rd, z & 0xffffu, ts + 12), write_cell(r, 1, 2 * d.rd + 1, z >> 16, ts + 13);
+            const uint32_t pts3 = d.wr_rd ? write_word(1, d.rd, z, ts + 12) : 0;
+            r.f_pts1.push_back(pts1), r.f_pts2.push_back(pts2), r.f_pts3.push_back(pts3);
             r.f_x.push_back(x), r.f_y.push_back(y), r.f_z.push_back(z), r.f_rdprev.push_back(d.wr_rd ? rd_prev : 0), r.f_pcinc.push_back(pc_inc);
             n_cls[d.cls]++;
             r.n_instr++;
         }
         r.pc_end = m_.done() ? 0 : m_.pc();
         r.ts_end = 1 + vmc::TS_STEP * (uint32_t)r.n_instr;
-        flush_access_log(r);
         close_memory(r);
         return m_.done();
     }
@@ -276,7 +269,7 @@ private:
     MemoryTree tree_;
     Digest image_root_{};
     struct Block {
-        uint32_t init[8], cur[8], ts[8];
+        uint32_t init[8], cur[8], ts[4];   // cells 2 j, 2 j + 1 = the halves of word j; ts[j] = the word's last access in this segment
     };
     // touched blocks of the current segment: dense storage + direct-mapped slot tables (registers, public values, the guest's
     // read-write region) so that the common lookup is an array access; anything else (addresses outside the region) goes through a map
@@ -311,29 +304,35 @@ private:
     }
 
     uint32_t mem_word(uint32_t addr) const { return m_.peek_word(addr); }
-    // value of a cell in the machine's CURRENT state
-    uint32_t cell_now(uint32_t as, uint32_t cell) const {
-        if (as == 1) return cell < 64 ? (m_.reg(cell >> 1) >> (16 * (cell & 1))) & 0xffffu : 0;
+    // value of a word in the machine's CURRENT state
+    uint32_t word_now(uint32_t as, uint32_t word) const {
+        if (as == 1) return word < 32 ? m_.reg(word) : 0;
         if (as == 3) {
-            if (cell >= 16) return 0;
-            uint16_t v;
-            memcpy(&v, m_.public_values().data() + 2 * cell, 2);
+            if (word >= 8) return 0;
+            uint32_t v;
+            memcpy(&v, m_.public_values().data() + 4 * word, 4);
             return v;
         }
-        return (mem_word((cell << 1) & ~3u) >> (16 * (cell & 1))) & 0xffffu;
+        return mem_word(word << 2);
     }
     void push_nonzero(std::vector<std::pair<uint32_t, std::array<uint32_t, 8>>>& out, uint32_t as, uint32_t blk) const {
         std::array<uint32_t, 8> c;
         bool any = false;
-        for (uint32_t j = 0; j < 8; j++) c[j] = cell_now(as, 8 * blk + j), any = any || c[j];
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t w = word_now(as, 4 * blk + j);
+            c[2 * j] = w & 0xffffu, c[2 * j + 1] = w >> 16, any = any || w;
+        }
         if (any) out.push_back({(as << vmc::LABEL_BITS) | blk, c});
     }
-    Block& block_of(uint32_t as, uint32_t cell) {
-        const uint32_t label = (as << vmc::LABEL_BITS) | (cell >> 3);
+    Block& block_of(uint32_t as, uint32_t word) {
+        const uint32_t label = (as << vmc::LABEL_BITS) | (word >> 2);
         if (Block* known = find_block(label)) return *known;
-        // first touch in this segment: the block's cells still have their values from the segment's start
+        // first touch in this segment: the block's words still have their values from the segment's start
         Block b;
-        for (uint32_t j = 0; j < 8; j++) b.init[j] = b.cur[j] = cell_now(as, (cell & ~7u) + j), b.ts[j] = 0;
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t w = word_now(as, (word & ~3u) + j);
+            b.init[2 * j] = b.cur[2 * j] = w & 0xffffu, b.init[2 * j + 1] = b.cur[2 * j + 1] = w >> 16, b.ts[j] = 0;
+        }
         uint32_t idx = label;
         for (int l = (int)vmc::LEAF_LEVEL - 1; l >= 0; l--) {
             idx >>= 1;
@@ -343,41 +342,24 @@ private:
         *slot_of(label, true) = (uint32_t)blk_.size();
         return blk_.back();
     }
-    // the access log is kept as one array of records while the segment runs (one store per access) and split into the seven
-    // columns the device generator takes when the segment closes
-    struct Acc {
-        uint32_t as, ptr, prev_data, prev_ts, data, ts, is_read;
-    };
-    std::vector<Acc> acc_;
-    void log(SegmentRecords&, uint32_t as, uint32_t cell, uint32_t prev, uint32_t prev_ts, uint32_t data, uint32_t ts, bool read) {
-        acc_.push_back(Acc{as, cell, prev, prev_ts, data, ts, read ? 1u : 0u});
-    }
-    void flush_access_log(SegmentRecords& r) {
-        const size_t n = acc_.size();
-        for (auto* v : {&r.acc_as, &r.acc_ptr, &r.acc_prev_data, &r.acc_prev_ts, &r.acc_data, &r.acc_ts, &r.acc_is_read}) v->resize(n);
-        for (size_t i = 0; i < n; i++) {
-            const Acc& a = acc_[i];
-            r.acc_as[i] = a.as, r.acc_ptr[i] = a.ptr, r.acc_prev_data[i] = a.prev_data, r.acc_prev_ts[i] = a.prev_ts;
-            r.acc_data[i] = a.data, r.acc_ts[i] = a.ts, r.acc_is_read[i] = a.is_read;
-        }
-        acc_.clear();
-    }
     // A block is snapshotted at its first touch in the segment, which must happen BEFORE the machine executes an instruction that
-    // changes it: run_segment calls block_of for every cell an instruction will write before step_one.
-    void read_cell(SegmentRecords& r, uint32_t as, uint32_t cell, uint32_t value, uint32_t ts) {
-        Block& b = block_of(as, cell);
-        const unsigned j = cell & 7u;
-        if (b.cur[j] != value) throw Error("internal: memory log out of step with the machine");
-        log(r, as, cell, value, b.ts[j], value, ts, true);
+    // changes it: run_segment calls block_of for every word an instruction will write before step_one.  Both return the timestamp of
+    // the word's previous access (0 = untouched in this segment: the leaf chip's initial state).
+    uint32_t read_word(uint32_t as, uint32_t word, uint32_t value, uint32_t ts) {
+        Block& b = block_of(as, word);
+        const unsigned j = word & 3u;
+        if ((b.cur[2 * j] | (b.cur[2 * j + 1] << 16)) != value) throw Error("internal: memory log out of step with the machine");
+        const uint32_t prev = b.ts[j];
         b.ts[j] = ts;
+        return prev;
     }
-    void write_cell(SegmentRecords& r, uint32_t as, uint32_t cell, uint32_t value, uint32_t ts) {
-        Block* known = find_block((as << vmc::LABEL_BITS) | (cell >> 3));
+    uint32_t write_word(uint32_t as, uint32_t word, uint32_t value, uint32_t ts) {
+        Block* known = find_block((as << vmc::LABEL_BITS) | (word >> 2));
         if (!known) throw Error("internal: write to a block that was not snapshotted");
-        Block& b = *known;
-        const unsigned j = cell & 7u;
-        log(r, as, cell, b.cur[j], b.ts[j], value, ts, false);
-        b.cur[j] = value, b.ts[j] = ts;
+        const unsigned j = word & 3u;
+        const uint32_t prev = known->ts[j];
+        known->cur[2 * j] = value & 0xffffu, known->cur[2 * j + 1] = value >> 16, known->ts[j] = ts;
+        return prev;
     }
 
     // leaf rows, merkle rows, Poseidon2 requests; commits the segment's final memory to the tree
@@ -398,10 +380,11 @@ private:
             fin[MemoryTree::key(vmc::LEAF_LEVEL, label)] = h_fin[i];
             uint32_t row[vmc::LEAF_WIDTH] = {};
             row[0] = label >> vmc::LABEL_BITS, row[1] = label & ((1u << vmc::LABEL_BITS) - 1);
-            for (int j = 0; j < 8; j++) row[2 + j] = b.init[j], row[10 + j] = b.cur[j], row[18 + j] = b.ts[j], row[26 + j] = hi[j], row[34 + j] = h_fin[i][j];
-            row[42] = 1;
+            for (int j = 0; j < 8; j++) row[2 + j] = b.init[j], row[10 + j] = b.cur[j], row[22 + j] = hi[j], row[30 + j] = h_fin[i][j];
+            for (int j = 0; j < 4; j++) row[18 + j] = b.ts[j];
+            row[38] = 1;
             const uint32_t gap = i + 1 < labels.size() ? labels[i + 1] - label - 1 : 0;
-            row[43] = gap & 0xffffu, row[44] = gap >> 16, row[45] = row[1] & 0xffffu, row[46] = row[1] >> 16;
+            row[39] = gap & 0xffffu, row[40] = gap >> 16, row[41] = row[1] & 0xffffu, row[42] = row[1] >> 16;
             r.leaf_rows.insert(r.leaf_rows.end(), row, row + vmc::LEAF_WIDTH);
             add_p2(b.init, nullptr), add_p2(b.cur, nullptr);
         }

@@ -4,7 +4,7 @@
 //   (app segments, then the leaf / internal aggregation tree, mod.rs:47-60) -> encode -> mandatory self-verification
 // over this backend:
 //   1. SegmentExecutor (include/zkhip_vm_exec.hpp) runs the guest and cuts it into segments of fixed heights;
-//   2. SegmentProver uploads a segment's records, generates the 23 chips' traces on the device (include/zkhip.h zkhip_*_tracegen) and
+//   2. SegmentProver uploads a segment's records, generates the 22 chips' traces on the device (include/zkhip.h zkhip_*_tracegen) and
 //      proves them as ONE statement (include/zkhip_vm_circuit.hpp): (pc_start, memory root) -> (pc_end, memory root');
 //   3. AggregationProver (include/zkhip_aggregation.hpp) folds the segment proofs: leaf nodes verify <= 4 segments, internal
 //      nodes <= 3 nodes, chaining (pc, root) in-circuit, until one root proof remains;
@@ -132,8 +132,8 @@ public:
         // ---- program frequencies, frame
         const uint32_t* d_idx = up(c.pc_index);
         check(zkhip_program_freq_tracegen(ctx_, d_idx, c.pc_index.size(), H(vmc::A_PROGRAM), T(vmc::A_PROGRAM)));
-        check(zkhip_vm_frame_tracegen(ctx_, d_idx, up(r.f_x), up(r.f_y), up(r.f_z), up(r.f_rdprev), up(r.f_pcinc), r.n_instr, d_program_, N(vmc::A_PROGRAM),
-                                      H(vmc::A_FRAME), T(vmc::A_FRAME)));
+        check(zkhip_vm_frame_tracegen(ctx_, d_idx, up(r.f_x), up(r.f_y), up(r.f_z), up(r.f_rdprev), up(r.f_pcinc), up(r.f_pts1), up(r.f_pts2), up(r.f_pts3), r.n_instr,
+                                      d_program_, N(vmc::A_PROGRAM), H(vmc::A_FRAME), T(vmc::A_FRAME)));
         // ---- instruction cores (include/zkhip_chips.hpp: unchanged generators)
         check(zkhip_rv32_alu_tracegen(ctx_, up(c.alu_op), up(c.alu_b), up(c.alu_c), c.alu_op.size(), H(vmc::A_ALU), T(vmc::A_ALU), d_bw));
         check(zkhip_rv32_lt_tracegen(ctx_, up(c.lt_op), up(c.lt_b), up(c.lt_c), c.lt_op.size(), H(vmc::A_LT), T(vmc::A_LT), d_bw));
@@ -146,8 +146,8 @@ public:
         check(zkhip_rv32_jal_lui_tracegen(ctx_, up(c.jal_op), up(c.jal_pc), up(c.jal_imm), c.jal_op.size(), H(vmc::A_JAL_LUI), T(vmc::A_JAL_LUI), d_bw));
         check(zkhip_rv32_auipc_tracegen(ctx_, up(c.auipc_pc), up(c.auipc_imm), c.auipc_pc.size(), H(vmc::A_AUIPC), T(vmc::A_AUIPC), d_bw));
         check(zkhip_rv32_jalr_tracegen(ctx_, up(c.jalr_pc), up(c.jalr_rs1), up(c.jalr_imm), c.jalr_pc.size(), H(vmc::A_JALR), T(vmc::A_JALR), d_bw));
-        check(zkhip_vm_loadstore_tracegen(ctx_, up(c.ls_case), up(c.ls_read), up(c.ls_prev), up(r.ls_ts), up(r.ls_base), up(r.ls_imm), c.ls_case.size(), H(vmc::A_LS),
-                                          T(vmc::A_LS), d_bw));
+        check(zkhip_vm_loadstore_tracegen(ctx_, up(c.ls_case), up(c.ls_read), up(c.ls_prev), up(r.ls_ts), up(r.ls_base), up(r.ls_imm), up(r.ls_pts), c.ls_case.size(),
+                                          H(vmc::A_LS), T(vmc::A_LS), d_bw));
         // ---- the chips whose rows the executor wrote
         const uint32_t leaf_pad[vmc::LEAF_WIDTH] = {1};   // padding rows of the leaf chip carry address space 1
         check(zkhip_rows_tracegen(ctx_, up(r.ecall_rows), r.n_ecall(), vmc::ECALL_WIDTH, H(vmc::A_ECALL), T(vmc::A_ECALL), nullptr));
@@ -158,15 +158,11 @@ public:
         uint32_t* d_p2in = const_cast<uint32_t*>(up(r.p2_inputs));
         if (r.n_p2()) check(zkhip_to_monty(ctx_, d_p2in, r.p2_inputs.size()));
         check(zkhip_vm_poseidon2_tracegen(ctx_, d_p2in, r.n_p2(), H(vmc::A_POSEIDON2), T(vmc::A_POSEIDON2)));
-        // ---- memory accesses
-        const size_t n_acc = r.acc_ts.size();
-        check(zkhip_vm_access_tracegen(ctx_, up(r.acc_as), up(r.acc_ptr), up(r.acc_prev_data), up(r.acc_prev_ts), up(r.acc_data), up(r.acc_ts), up(r.acc_is_read), n_acc,
-                                       H(vmc::A_ACCESS), T(vmc::A_ACCESS)));
         // ---- lookup multiplicities of the new chips, counted from the requesting columns
         auto pairs = [&](unsigned a, size_t cx, size_t cy, size_t n) {
             if (n) check(zkhip_bitwise_lookup_tracegen(ctx_, T(a) + cx * N(a), T(a) + cy * N(a), d_zeros_, n, 8, d_bw, 1));
         };
-        for (size_t q : {18, 20, 22, 24}) pairs(vmc::A_FRAME, q, q + 1, r.n_instr);
+        for (size_t q : {18, 20, 22, 24, 26, 28}) pairs(vmc::A_FRAME, q, q + 1, r.n_instr);
         for (size_t q : {0, 2, 4, 6}) pairs(vmc::A_LS, q, q + 1, c.ls_case.size());
         bool first = true;
         auto count = [&](const uint32_t* col, size_t n, uint32_t scale = 1) {
@@ -174,24 +170,43 @@ public:
             else check(zkhip_range_counts_scaled_tracegen(ctx_, col, n, scale, 16, d_rng, first ? 0 : 1));
             first = false;
         };
-        const size_t NA = N(vmc::A_ACCESS), NL = N(vmc::A_LS), n_ls = c.ls_case.size();
-        for (size_t q : {8, 9, 4, 10}) count(T(vmc::A_ACCESS) + q * NA, n_acc);
+        const size_t NF = N(vmc::A_FRAME), NL = N(vmc::A_LS), n_ls = c.ls_case.size();
+        // timestamp gaps of the register and memory adapters: gap_lo in the range table, (0, gap_hi) in the range-tuple table
+        for (size_t q : {35, 38, 41}) count(T(vmc::A_FRAME) + q * NF, r.n_instr);
+        count(T(vmc::A_LS) + 46 * NL, n_ls);
+        for (size_t q : {36, 39, 42})
+            if (r.n_instr) check(zkhip_range_tuple_counts_tracegen(ctx_, d_zeros_, T(vmc::A_FRAME) + q * NF, r.n_instr, TUPLE_X, TUPLE_Y, d_tup, 1));
+        if (n_ls) check(zkhip_range_tuple_counts_tracegen(ctx_, d_zeros_, T(vmc::A_LS) + 47 * NL, n_ls, TUPLE_X, TUPLE_Y, d_tup, 1));
         count(T(vmc::A_LS) + 40 * NL, n_ls), count(T(vmc::A_LS) + 41 * NL, n_ls, 4), count(T(vmc::A_LS) + 44 * NL, n_ls, 4);
         count(T(vmc::A_LS) + 44 * NL, n_ls), count(T(vmc::A_LS) + 41 * NL, n_ls);
         {
             // the few range requests of the ecall, leaf and connector chips, listed on the host
-            std::vector<uint32_t> misc{r.ts_end & 0xffffu, 8 * (r.ts_end >> 16), r.ts_end >> 16};
+            std::vector<uint32_t> misc{r.ts_end & 0xffffu, 8 * (r.ts_end >> 16), r.ts_end >> 16}, tup_y, bw_x, bw_y;
             for (size_t i = 0; i < r.n_ecall(); i++) {
                 const uint32_t* row = &r.ecall_rows[i * vmc::ECALL_WIDTH];
-                if (row[15]) misc.push_back(row[17] * 8192), misc.push_back(row[17]);
+                if (row[15]) {
+                    for (uint32_t v : {row[17] * 8192, row[17], row[22], row[25]}) misc.push_back(v);
+                    tup_y.push_back(row[23]), tup_y.push_back(row[26]);
+                }
+                if (row[16]) bw_x.push_back(row[10]), bw_y.push_back(row[11]), bw_x.push_back(row[12]), bw_y.push_back(row[13]);
             }
             for (size_t i = 0; i < r.n_leaf(); i++) {
                 const uint32_t* row = &r.leaf_rows[i * vmc::LEAF_WIDTH];
-                for (uint32_t v : {row[43], row[44] * 16, row[44], row[45], row[46] * 64, row[46]}) misc.push_back(v);
+                for (uint32_t v : {row[39], row[40] * 16, row[40], row[41], row[42] * 64, row[42]}) misc.push_back(v);
             }
             uint32_t* d_misc = const_cast<uint32_t*>(up(misc));
             check(zkhip_to_monty(ctx_, d_misc, misc.size()));
             count(d_misc, misc.size());
+            if (!tup_y.empty()) {   // the ecall chip's two word accesses: (0, gap_hi)
+                uint32_t* d_y = const_cast<uint32_t*>(up(tup_y));
+                check(zkhip_to_monty(ctx_, d_y, tup_y.size()));
+                check(zkhip_range_tuple_counts_tracegen(ctx_, d_zeros_, d_y, tup_y.size(), TUPLE_X, TUPLE_Y, d_tup, 1));
+            }
+            if (!bw_x.empty()) {    // the hinted words' bytes
+                uint32_t *d_x = const_cast<uint32_t*>(up(bw_x)), *d_y = const_cast<uint32_t*>(up(bw_y));
+                check(zkhip_to_monty(ctx_, d_x, bw_x.size())), check(zkhip_to_monty(ctx_, d_y, bw_y.size()));
+                check(zkhip_bitwise_lookup_tracegen(ctx_, d_x, d_y, d_zeros_, bw_x.size(), 8, d_bw, 1));
+            }
         }
         check(zkhip_tracegen_check(ctx_));
         const auto t1 = clk::now();
@@ -346,6 +361,8 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     std::deque<size_t> to_verify;
     bool proving_done = false;
     const auto t_start = clk::now();
+    // the aggregation tree runs as a stream beside the segment proving: a leaf node starts when its four segment proofs exist
+    scroll_zkvm_hip::AggregationProver::TreeStream tree(agg);
     for (SegmentProver* lane : lanes)
         workers.emplace_back([&, lane] {
             try {
@@ -360,6 +377,7 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
                     }
                     cv_push.notify_one();
                     SegmentProof p = lane->prove(it.rec, /*self_verify=*/false);
+                    tree.push(it.index, p.proof);
                     std::lock_guard<std::mutex> lk(mu);
                     if (proofs.size() <= it.index) proofs.resize(it.index + 1);
                     proofs[it.index] = std::move(p);
@@ -375,7 +393,7 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
             }
         });
     const VerifyingKey& seg_vk = lanes[0]->vk();
-    for (size_t v = 0; v < std::max<size_t>(2, lanes.size()); v++)
+    for (size_t v = 0; v < std::max<size_t>(4, 2 * lanes.size()); v++)
         verifiers.emplace_back([&] {
             for (;;) {
                 size_t k;
@@ -398,7 +416,7 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     // aggregation prover until the tree starts); deeper trees build their levels when they get there
     std::thread warm_agg([&agg] {
         try {
-            (void)agg.node_vk(3);
+            for (size_t l = 1; l <= 3; l++) (void)agg.node_vk(l);
         } catch (...) {
         }
     });
@@ -457,7 +475,7 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     if (keep_segments) g.segment_proofs = std::move(proofs);
     const auto t0 = clk::now();
     const scroll_zkvm_hip::AggregationPlan plan = scroll_zkvm_hip::AggregationPlan::build(seg_proofs.size());
-    g.root = agg.prove_tree(plan, seg_proofs);
+    g.root = tree.finish(seg_proofs.size());   // (what is left of the tree once the last segment proof exists)
     g.levels = plan.levels.size();
     g.root_vk = agg.node_vk(plan.levels.size() - 1);
     g.aggregation_mills = ms(clk::now() - t0);

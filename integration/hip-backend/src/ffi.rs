@@ -322,14 +322,12 @@ extern "C" {
     pub fn zkhip_vm_decode(word: u32, pc: u32, out: *mut u32, legal: *mut c_int) -> c_int;
     pub fn zkhip_vm_program_table(words: *const u32, n_words: usize, pc_base: u32, log_program: c_uint, out: *mut u32) -> c_int;
     pub fn zkhip_vm_frame_tracegen(ctx: *mut zkhip_ctx, d_pc_index: *const u32, d_x: *const u32, d_y: *const u32, d_z: *const u32,
-                                   d_rd_prev: *const u32, d_pc_inc: *const u32, n: usize, d_program: *const u32, n_program: usize,
-                                   log_height: c_uint, d_trace: *mut u32) -> c_int;
+                                   d_rd_prev: *const u32, d_pc_inc: *const u32, d_prev_ts_rs1: *const u32, d_prev_ts_rs2: *const u32,
+                                   d_prev_ts_rd: *const u32, n: usize, d_program: *const u32, n_program: usize, log_height: c_uint,
+                                   d_trace: *mut u32) -> c_int;
     pub fn zkhip_vm_loadstore_tracegen(ctx: *mut zkhip_ctx, d_case: *const u32, d_read: *const u32, d_prev: *const u32, d_ts: *const u32,
-                                       d_base: *const u32, d_imm: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
-                                       d_bitwise_trace: *mut u32) -> c_int;
-    pub fn zkhip_vm_access_tracegen(ctx: *mut zkhip_ctx, d_addr_space: *const u32, d_pointer: *const u32, d_prev_data: *const u32,
-                                    d_prev_ts: *const u32, d_data: *const u32, d_ts: *const u32, d_is_read: *const u32, n: usize,
-                                    log_height: c_uint, d_trace: *mut u32) -> c_int;
+                                       d_base: *const u32, d_imm: *const u32, d_prev_ts: *const u32, n: usize, log_height: c_uint,
+                                       d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_vm_poseidon2_tracegen(ctx: *mut zkhip_ctx, d_inputs: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;
     pub fn zkhip_rows_tracegen(ctx: *mut zkhip_ctx, d_rows: *const u32, n: usize, width: usize, log_height: c_uint, d_trace: *mut u32,
                                pad_row: *const u32) -> c_int;

@@ -1,5 +1,5 @@
 """GPU: the one-statement VM flow (include/zkhip_vm_flow.hpp).
-  * device trace generation of a segment == the CPU twins, cell for cell, for all 23 chips; the HIP proof == the oracle's, byte
+  * device trace generation of a segment == the CPU twins, cell for cell, for all 22 chips; the HIP proof == the oracle's, byte
     for byte; tampered records (a wrong instruction result, swapped operands) give proofs the verifier refuses;
   * `prove_cli prove-elf`: ELF + input bytes -> execution -> segment proofs -> aggregation tree -> ONE root proof, self-verified:
     the root statement starts at the guest's entry pc on the guest image's memory root, ends at pc = 0, and the public values open
@@ -34,8 +34,8 @@ def device_traces(zk, rec, prog, H):
     d_prog = zk.upload(prog.reshape(-1))
     idx = D(rec["pc_index"])
     T[v2.A_PROGRAM] = zk.program_freq_tracegen(idx, H[v2.A_PROGRAM])
-    T[v2.A_FRAME] = zk.vm_frame_tracegen(idx, D(rec["f_x"]), D(rec["f_y"]), D(rec["f_z"]), D(rec["f_rdprev"]), D(rec["f_pcinc"]), d_prog,
-                                         1 << H[v2.A_PROGRAM], H[v2.A_FRAME])
+    T[v2.A_FRAME] = zk.vm_frame_tracegen(idx, D(rec["f_x"]), D(rec["f_y"]), D(rec["f_z"]), D(rec["f_rdprev"]), D(rec["f_pcinc"]), D(rec["f_pts1"]),
+                                         D(rec["f_pts2"]), D(rec["f_pts3"]), d_prog, 1 << H[v2.A_PROGRAM], H[v2.A_FRAME])
     T[v2.A_ALU] = zk.rv32_alu_tracegen(D(rec["alu_op"]), D(rec["alu_b"]), D(rec["alu_c"]), H[v2.A_ALU], d_bw)
     T[v2.A_LT] = zk.rv32_lt_tracegen(D(rec["lt_op"]), D(rec["lt_b"]), D(rec["lt_c"]), H[v2.A_LT], d_bw)
     T[v2.A_MUL] = zk.rv32_mul_tracegen(D(rec["mul_b"]), D(rec["mul_c"]), H[v2.A_MUL], d_tup, v2.SX, v2.SY)
@@ -48,7 +48,7 @@ def device_traces(zk, rec, prog, H):
     T[v2.A_AUIPC] = zk.rv32_auipc_tracegen(D(rec["auipc_pc"]), D(rec["auipc_imm"]), H[v2.A_AUIPC], d_bw)
     T[v2.A_JALR] = zk.rv32_jalr_tracegen(D(rec["jalr_pc"]), D(rec["jalr_rs1"]), D(rec["jalr_imm"]), H[v2.A_JALR], d_bw)
     T[v2.A_LS] = zk.vm_loadstore_tracegen(D(rec["ls_case"]), D(rec["ls_read"]), D(rec["ls_prev"]), D(rec["ls_ts"]), D(rec["ls_base"]), D(rec["ls_imm"]),
-                                          H[v2.A_LS], d_bw)
+                                          D(rec["ls_pts"]), H[v2.A_LS], d_bw)
     n_ec, n_leaf, n_mk = len(rec["ecall_rows"]) // v2.ECALL_WIDTH, len(rec["leaf_rows"]) // v2.LEAF_WIDTH, len(rec["merkle_rows"]) // v2.MERKLE_WIDTH
     leaf_pad = np.zeros(v2.LEAF_WIDTH, np.uint32)
     leaf_pad[0] = 1
@@ -59,31 +59,42 @@ def device_traces(zk, rec, prog, H):
     T[v2.A_CONNECTOR] = zk.rows_tracegen(D(np.array([ts_end & 0xFFFF, ts_end >> 16], np.uint32)), 1, 2, 0)
     p2in = zk.upload(rec["p2_inputs"])
     T[v2.A_POSEIDON2] = zk.vm_poseidon2_tracegen(p2in, len(rec["p2_inputs"]) // 16, H[v2.A_POSEIDON2])
-    order = ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read")
-    T[v2.A_ACCESS] = zk.vm_access_tracegen(*[D(rec["acc_" + k]) for k in order], H[v2.A_ACCESS])
-    n, nls, nacc = len(rec["f_x"]), len(rec["ls_case"]), len(rec["acc_ts"])
-    zeros = torch.zeros(max(n, nls, 1), dtype=torch.int32, device=dev)
-    NF, NL, NA = 1 << H[v2.A_FRAME], 1 << H[v2.A_LS], 1 << H[v2.A_ACCESS]
-    for q in (18, 20, 22, 24):
+    n, nls = len(rec["f_x"]), len(rec["ls_case"])
+    zeros = torch.zeros(max(n, nls, 8), dtype=torch.int32, device=dev)
+    NF, NL = 1 << H[v2.A_FRAME], 1 << H[v2.A_LS]
+    for q in (18, 20, 22, 24, 26, 28):
         zk.bitwise_lookup_tracegen(T[v2.A_FRAME][q * NF:q * NF + n], T[v2.A_FRAME][(q + 1) * NF:(q + 1) * NF + n], zeros[:n], 8, d_bw, accumulate=True)
     for q in (0, 2, 4, 6):
         if nls:
             zk.bitwise_lookup_tracegen(T[v2.A_LS][q * NL:q * NL + nls], T[v2.A_LS][(q + 1) * NL:(q + 1) * NL + nls], zeros[:nls], 8, d_bw, accumulate=True)
     d_rng = None
-    for q in (8, 9, 4, 10):
-        d_rng = zk.range_counts_tracegen(T[v2.A_ACCESS][q * NA:q * NA + nacc], 16, t_counts=d_rng, accumulate=d_rng is not None)
+    for q in (35, 38, 41):   # the adapters' timestamp gaps: gap_lo in the range table, (0, gap_hi) in the range-tuple table
+        d_rng = zk.range_counts_tracegen(T[v2.A_FRAME][q * NF:q * NF + n], 16, t_counts=d_rng, accumulate=d_rng is not None)
+        zk.range_tuple_counts_tracegen(zeros[:n], T[v2.A_FRAME][(q + 1) * NF:(q + 1) * NF + n], v2.SX, v2.SY, t_counts=d_tup, accumulate=True)
+    if nls:
+        d_rng = zk.range_counts_tracegen(T[v2.A_LS][46 * NL:46 * NL + nls], 16, t_counts=d_rng, accumulate=True)
+        zk.range_tuple_counts_tracegen(zeros[:nls], T[v2.A_LS][47 * NL:47 * NL + nls], v2.SX, v2.SY, t_counts=d_tup, accumulate=True)
     for q, s in ((40, 1), (41, 4), (44, 4), (44, 1), (41, 1)):
         col = T[v2.A_LS][q * NL:q * NL + nls]
         if not nls:
             continue
         d_rng = zk.range_counts_tracegen(col, 16, t_counts=d_rng, accumulate=True) if s == 1 else zk.range_counts_scaled_tracegen(col, s, 16, d_rng)
     misc = [ts_end & 0xFFFF, 8 * (ts_end >> 16), ts_end >> 16]
+    tup_y, bw_x, bw_y = [], [], []
     for row in rec["ecall_rows"].reshape(-1, v2.ECALL_WIDTH):
         if row[15]:
-            misc += [int(row[17]) * 8192, int(row[17])]
+            misc += [int(row[17]) * 8192, int(row[17]), int(row[22]), int(row[25])]
+            tup_y += [int(row[23]), int(row[26])]
+        if row[16]:
+            bw_x += [int(row[10]), int(row[12])]
+            bw_y += [int(row[11]), int(row[13])]
     for row in rec["leaf_rows"].reshape(-1, v2.LEAF_WIDTH):
-        misc += [int(row[43]), int(row[44]) * 16, int(row[44]), int(row[45]), int(row[46]) * 64, int(row[46])]
+        misc += [int(row[39]), int(row[40]) * 16, int(row[40]), int(row[41]), int(row[42]) * 64, int(row[42])]
     d_rng = zk.range_counts_tracegen(zk.upload(np.array(misc, np.uint32)), 16, t_counts=d_rng, accumulate=True)
+    if tup_y:
+        zk.range_tuple_counts_tracegen(zeros[:len(tup_y)], zk.upload(np.array(tup_y, np.uint32)), v2.SX, v2.SY, t_counts=d_tup, accumulate=True)
+    if bw_x:
+        zk.bitwise_lookup_tracegen(zk.upload(np.array(bw_x, np.uint32)), zk.upload(np.array(bw_y, np.uint32)), zeros[:len(bw_x)], 8, d_bw, accumulate=True)
     T[v2.A_BITWISE], T[v2.A_RANGE_TUPLE], T[v2.A_RANGE] = d_bw, d_tup, d_rng
     return T
 

@@ -2,7 +2,7 @@
 the segmenting executor's records (include/zkhip_vm_exec.hpp, `prove_cli dump-segments`):
   * the run agrees with the independent Python interpreter; segments chain by (pc, memory root); the first root is the guest image's,
     the last pc is 0, the public values open in the final root;
-  * every one of the 23 traces (CPU twins of the device generators, tests/vm2_util.py) satisfies its AIR, and every bus balances
+  * every one of the 22 traces (CPU twins of the device generators, tests/vm2_util.py) satisfies its AIR, and every bus balances
     exactly: program, execution, operand, access, memory, merkle, hash and the three lookup buses;
   * the oracle proves a whole segment and both verifiers accept;
   * a tampered instruction result, swapped operands, a forged memory value, a skipped instruction, a wrong next pc: some bus no
@@ -60,7 +60,7 @@ def test_segments_chain_and_agree_with_the_model(mixed):
 @pytest.mark.parametrize("k", [0, 7, -1])
 def test_every_trace_satisfies_its_air_and_every_bus_balances(mixed, k):
     inst = v2.segment_instance(mixed["segs"][k], mixed["words"], PC_BASE, mixed["heights"])
-    assert len(inst) == 23
+    assert len(inst) == 22
     for a, d in enumerate(inst):
         assert air.quotient_chunks(d["program"]) <= 2, a                     # degree <= 3: blow-up 2 suffices
         assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], a
@@ -96,17 +96,17 @@ def test_tampering_breaks_a_bus(mixed):
     alu_rows = np.nonzero(cls == 0)[0]
     sub_row = next(int(r) for r in alu_rows if prog[2][seg["pc_index"][r]] == 1 and seg["f_x"][r] != seg["f_y"][r])
 
-    # 1. a wrong instruction result in the frame (the core still holds the true one): operand + access bus
+    # 1. a wrong instruction result in the frame (the core still holds the true one): operand + memory bus
     def wrong_result(rec):
         rec["f_z"][int(alu_rows[3])] ^= 4
-    assert _tampered(mixed, 4, wrong_result)[1].keys() >= {3, 4}
+    assert _tampered(mixed, 4, wrong_result)[1].keys() >= {3, 1}
 
     # 2. swapped operands of a SUB: the registers say otherwise
     def swapped(rec):
         r = sub_row
         rec["f_x"][r], rec["f_y"][r] = rec["f_y"][r], rec["f_x"][r]
     local, bad = _tampered(mixed, 4, swapped)
-    assert 3 in bad and 4 in bad
+    assert 3 in bad and 1 in bad
 
     # 3. the core is made consistent with a forged operand (b + 1): the core row is valid, but no register holds that value
     def forged_operand(rec):
@@ -117,7 +117,7 @@ def test_tampering_breaks_a_bus(mixed):
 
     # 4. a skipped instruction: the execution-bus chain has a hole
     def skipped(rec):
-        for n in ("pc_index", "f_x", "f_y", "f_z", "f_rdprev", "f_pcinc"):
+        for n in ("pc_index", "f_x", "f_y", "f_z", "f_rdprev", "f_pcinc", "f_pts1", "f_pts2", "f_pts3"):
             rec[n] = np.delete(rec[n], 10)
     assert 2 in _tampered(mixed, 4, skipped)[1]
 
@@ -126,12 +126,17 @@ def test_tampering_breaks_a_bus(mixed):
         rec["f_pcinc"][20] = (int(rec["f_pcinc"][20]) + 4) % v2.P
     assert {2, 3} <= _tampered(mixed, 4, wrong_pc)[1].keys()
 
-    # 6. a memory cell that changes between two accesses: the access log no longer is a history
+    # 6. a register that changes between two accesses (the value a write claims to replace), and an access that claims an older
+    #    predecessor than the word's last access: the memory bus no longer is a history
+    writes = np.nonzero(prog[12][seg["pc_index"]] == 1)[0]
     def forged_memory(rec):
-        w = int(np.nonzero(rec["acc_is_read"] == 1)[0][40])
-        rec["acc_data"][w] ^= 1
-        rec["acc_prev_data"][w] ^= 1
-    assert 4 in _tampered(mixed, 4, forged_memory)[1] or 1 in _tampered(mixed, 4, forged_memory)[1]
+        rec["f_rdprev"][int(writes[40])] ^= 1
+    assert 1 in _tampered(mixed, 4, forged_memory)[1]
+    reads = np.nonzero((prog[9][seg["pc_index"]] == 1) & (seg["f_pts1"] > 16))[0]
+    def forged_history(rec):
+        rec["f_pts1"][int(reads[5])] -= 16
+    local, bad = _tampered(mixed, 4, forged_history)
+    assert local == [] and 1 in bad
 
     # 7. another initial memory root than the blocks hash to
     def wrong_root(rec):

@@ -1,5 +1,5 @@
 """CPU twins of the one-statement VM circuit's trace generators (include/zkhip_vm_circuit.hpp, zkvm-prover_amd/csrc/vm_chips.hip):
-the segment records the C++ executor dumps (`prove_cli dump-segments`) -> the 23 traces, in numpy and through the oracle's
+the segment records the C++ executor dumps (`prove_cli dump-segments`) -> the 22 traces, in numpy and through the oracle's
 existing core-chip generators.  TEST INFRASTRUCTURE.  The AIR programs themselves come from the library (zkhip_vm_air): they have
 ONE definition, the C++ one."""
 import ctypes as C
@@ -16,10 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
 P = ora.P
 NOPV = np.zeros(0, np.uint32)
-(A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_ACCESS, A_LEAF,
- A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, N_AIRS) = range(24)
-PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, ACCESS_WIDTH, LEAF_WIDTH, MERKLE_WIDTH = 17, 34, 45, 21, 11, 47, 54
-TS_STEP = 16
+(A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
+ A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, N_AIRS) = range(23)
+PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH = 17, 43, 48, 27, 43, 54
+TS_STEP, GAP_HI_BITS = 16, 11
 SX, SY = 256, 2048
 
 
@@ -84,6 +84,13 @@ def frame_trace(rec, prog, log_height):
             t[base + i, :n] = b
     t[30, :n], t[31, :n] = rec["f_rdprev"] & 0xFFFF, rec["f_rdprev"] >> 16
     t[32, :n], t[33, :n] = rec["f_pcinc"], 1
+    # register adapter: (prev_ts, gap_lo, gap_hi) of the rs1 / rs2 / rd accesses at slots 0, 2, 12; zero where the access is skipped
+    ts = t[1, :n].astype(np.int64)
+    for a, (flag_col, slot, name) in enumerate(((10, 0, "f_pts1"), (11, 2, "f_pts2"), (13, 12, "f_pts3"))):
+        used = t[flag_col, :n].astype(np.int64)
+        prev = rec[name].astype(np.int64)
+        gap = ((ts + slot - prev - 1) * used) & ((1 << (16 + GAP_HI_BITS)) - 1)   # (an honest log never wraps; tampered ones are tests)
+        t[34 + 3 * a, :n], t[35 + 3 * a, :n], t[36 + 3 * a, :n] = prev * used, gap & 0xFFFF, gap >> 16
     return t
 
 
@@ -102,6 +109,9 @@ def loadstore_trace(rec, log_height, rc):
     t[38, :n], t[39, :n] = imm & 0xFFFF, imm >> 16
     t[40, :n], t[41, :n], t[42, :n], t[43, :n] = lo & 0xFFFF, hi & 0xFFFF, lo >> 16, hi >> 16
     t[44, :n] = (lo & 0xFFFF) >> 2
+    prev = rec["ls_pts"].astype(np.int64)
+    gap = (rec["ls_ts"].astype(np.int64) + 4 - prev - 1) & ((1 << (16 + GAP_HI_BITS)) - 1)
+    t[45, :n], t[46, :n], t[47, :n] = prev, gap & 0xFFFF, gap >> 16
     return t, rc
 
 
@@ -115,7 +125,7 @@ def rows_trace(rows, width, log_height, pad=None):
 
 
 def segment_instance(rec, words, pc_base, heights):
-    """The 23 AIR dicts (program, shapes, trace, pvs[, prep]) of one segment, traces from the CPU twins."""
+    """The 22 AIR dicts (program, shapes, trace, pvs[, prep]) of one segment, traces from the CPU twins."""
     H = heights
     shapes = vm_airs()
     prog = program_table(words, pc_base, H[A_PROGRAM])
@@ -149,33 +159,36 @@ def segment_instance(rec, words, pc_base, heights):
     meta = rec["meta"]
     pc_start, pc_end, ts_end, n_instr = (int(x) for x in meta[:4])
     tr[A_CONNECTOR] = np.array([[ts_end & 0xFFFF], [ts_end >> 16]], np.uint32)
-    order = ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read")
-    acc10, bad = ora.memory_access_trace(*[rec["acc_" + k] for k in order], H[A_ACCESS])
-    assert bad == 0
-    acc = np.zeros((ACCESS_WIDTH, 1 << H[A_ACCESS]), np.uint32)
-    acc[:10] = acc10
-    acc[10] = (acc10[9].astype(np.int64) * 8) % P
-    tr[A_ACCESS] = acc
     # lookup multiplicities of the new chips
     rc = rc.astype(np.int64)
-    n, nls, nacc = n_instr, len(rec["ls_case"]), len(rec["acc_ts"])
+    tc = tc.astype(np.int64)
+    n, nls = n_instr, len(rec["ls_case"])
     fr, ls = tr[A_FRAME].astype(np.int64), tr[A_LS].astype(np.int64)
-    for q in (18, 20, 22, 24):
+    for q in (18, 20, 22, 24, 26, 28):
         rc += np.bincount(fr[q][:n] * 256 + fr[q + 1][:n], minlength=1 << 16)
     for q in (0, 2, 4, 6):
         rc += np.bincount(ls[q][:nls] * 256 + ls[q + 1][:nls], minlength=1 << 16)
     cnt = np.zeros(1 << 16, np.int64)
-    for q in (8, 9, 4, 10):
-        cnt += np.bincount(acc[q][:nacc].astype(np.int64), minlength=1 << 16)
+    for q in (35, 38, 41):                              # timestamp gaps: gap_lo in the range table, (0, gap_hi) in the range-tuple table
+        cnt += np.bincount(fr[q][:n], minlength=1 << 16)
+        tc += np.bincount(fr[q + 1][:n], minlength=SX * SY)
+    cnt += np.bincount(ls[46][:nls], minlength=1 << 16)
+    tc += np.bincount(ls[47][:nls], minlength=SX * SY)
     for q, s in ((40, 1), (41, 4), (44, 4), (44, 1), (41, 1)):
         cnt += np.bincount(ls[q][:nls] * s, minlength=1 << 16)
     misc = [ts_end & 0xFFFF, 8 * (ts_end >> 16), ts_end >> 16]
     for row in rec["ecall_rows"].reshape(-1, ECALL_WIDTH):
         if row[15]:
-            misc += [int(row[17]) * 8192, int(row[17])]
+            misc += [int(row[17]) * 8192, int(row[17]), int(row[22]), int(row[25])]
+            tc[int(row[23])] += 1
+            tc[int(row[26])] += 1
+        if row[16]:
+            rc[int(row[10]) * 256 + int(row[11])] += 1
+            rc[int(row[12]) * 256 + int(row[13])] += 1
     for row in rec["leaf_rows"].reshape(-1, LEAF_WIDTH):
-        misc += [int(row[43]), int(row[44]) * 16, int(row[44]), int(row[45]), int(row[46]) * 64, int(row[46])]
+        misc += [int(row[39]), int(row[40]) * 16, int(row[40]), int(row[41]), int(row[42]) * 64, int(row[42])]
     cnt += np.bincount(np.array(misc, dtype=np.int64), minlength=1 << 16)
+    tc = (tc % P).astype(np.uint32)
     tr[A_BITWISE] = np.stack([(rc % P).astype(np.uint32), xc])
     tr[A_RANGE_TUPLE] = tc.reshape(1, -1)
     tr[A_RANGE] = (cnt % P).astype(np.uint32).reshape(1, -1)

@@ -1,5 +1,5 @@
 """ONE FLOW at scale: a Fibonacci guest of ~n instructions through `prove_cli prove-elf` (include/zkhip_vm_flow.hpp): execution in
-segments of fixed heights, every segment ONE statement (23 chips, adapters + execution bus + persistent memory), aggregation tree
+segments of fixed heights, every segment ONE statement (22 chips, adapters + execution bus + persistent memory), aggregation tree
 to ONE root proof, self-verified, at the reference's FRI parameters.  Prints the CLI's JSON line + instructions per second.
 Usage: python tools/guest_bench2.py [n_iterations] [log_frame]"""
 import json

@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
                     PUT("jalr_pc", c.jalr_pc), PUT("jalr_rs1", c.jalr_rs1), PUT("jalr_imm", c.jalr_imm), PUT("ls_case", c.ls_case), PUT("ls_read", c.ls_read), PUT("ls_prev", c.ls_prev);
                     PUT("f_x", r.f_x), PUT("f_y", r.f_y), PUT("f_z", r.f_z), PUT("f_rdprev", r.f_rdprev), PUT("f_pcinc", r.f_pcinc), PUT("ls_ts", r.ls_ts), PUT("ls_base", r.ls_base), PUT("ls_imm", r.ls_imm);
                     PUT("ecall_rows", r.ecall_rows), PUT("leaf_rows", r.leaf_rows), PUT("merkle_rows", r.merkle_rows), PUT("p2_inputs", r.p2_inputs);
-                    PUT("acc_as", r.acc_as), PUT("acc_ptr", r.acc_ptr), PUT("acc_prev_data", r.acc_prev_data), PUT("acc_prev_ts", r.acc_prev_ts), PUT("acc_data", r.acc_data), PUT("acc_ts", r.acc_ts), PUT("acc_is_read", r.acc_is_read);
+                    PUT("f_pts1", r.f_pts1), PUT("f_pts2", r.f_pts2), PUT("f_pts3", r.f_pts3), PUT("ls_pts", r.ls_pts);
 #undef PUT
                     std::vector<uint32_t> meta{r.pc_start, r.pc_end, r.ts_end, (uint32_t)r.n_instr};
                     meta.insert(meta.end(), r.root_init.begin(), r.root_init.end());

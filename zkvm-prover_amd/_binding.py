@@ -176,9 +176,8 @@ def load_library():
         "zkhip_vm_air": (C.c_int, [C.c_uint, C.POINTER(_Air), C.POINTER(sz)]),
         "zkhip_vm_decode": (C.c_int, [C.c_uint32, C.c_uint32, u32p, C.POINTER(C.c_int)]),
         "zkhip_vm_program_table": (C.c_int, [u32p, sz, C.c_uint32, C.c_uint, u32p]),
-        "zkhip_vm_frame_tracegen": (C.c_int, [vp] * 7 + [sz, vp, sz, C.c_uint, vp]),
-        "zkhip_vm_loadstore_tracegen": (C.c_int, [vp] * 7 + [sz, C.c_uint, vp, vp]),
-        "zkhip_vm_access_tracegen": (C.c_int, [vp] * 8 + [sz, C.c_uint, vp]),
+        "zkhip_vm_frame_tracegen": (C.c_int, [vp] * 10 + [sz, vp, sz, C.c_uint, vp]),
+        "zkhip_vm_loadstore_tracegen": (C.c_int, [vp] * 8 + [sz, C.c_uint, vp, vp]),
         "zkhip_vm_poseidon2_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
         "zkhip_rows_tracegen": (C.c_int, [vp, vp, sz, sz, C.c_uint, vp, u32p]),
         "zkhip_range_counts_scaled_tracegen": (C.c_int, [vp, vp, sz, C.c_uint32, C.c_uint, vp, C.c_int]),
@@ -588,22 +587,18 @@ class Context:
 
         return torch.empty(words, dtype=torch.int32, device=self.device)
 
-    def vm_frame_tracegen(self, t_idx, t_x, t_y, t_z, t_rdprev, t_pcinc, t_program, n_program, log_height):
-        out = self._new(34 << log_height)
+    def vm_frame_tracegen(self, t_idx, t_x, t_y, t_z, t_rdprev, t_pcinc, t_pts1, t_pts2, t_pts3, t_program, n_program, log_height):
+        out = self._new(43 << log_height)
         self._check(self.lib.zkhip_vm_frame_tracegen(self.h, t_idx.data_ptr(), t_x.data_ptr(), t_y.data_ptr(), t_z.data_ptr(), t_rdprev.data_ptr(),
-                                                     t_pcinc.data_ptr(), t_idx.numel(), t_program.data_ptr(), n_program, log_height, out.data_ptr()))
+                                                     t_pcinc.data_ptr(), t_pts1.data_ptr(), t_pts2.data_ptr(), t_pts3.data_ptr(), t_idx.numel(),
+                                                     t_program.data_ptr(), n_program, log_height, out.data_ptr()))
         return out
 
-    def vm_loadstore_tracegen(self, t_case, t_read, t_prev, t_ts, t_base, t_imm, log_height, t_bitwise_trace):
-        out = self._new(45 << log_height)
+    def vm_loadstore_tracegen(self, t_case, t_read, t_prev, t_ts, t_base, t_imm, t_pts, log_height, t_bitwise_trace):
+        out = self._new(48 << log_height)
         self._check(self.lib.zkhip_vm_loadstore_tracegen(self.h, t_case.data_ptr(), t_read.data_ptr(), t_prev.data_ptr(), t_ts.data_ptr(), t_base.data_ptr(),
-                                                         t_imm.data_ptr(), t_case.numel(), log_height, out.data_ptr(), t_bitwise_trace.data_ptr()))
-        return out
-
-    def vm_access_tracegen(self, t_as, t_ptr, t_prev_data, t_prev_ts, t_data, t_ts, t_is_read, log_height):
-        out = self._new(11 << log_height)
-        self._check(self.lib.zkhip_vm_access_tracegen(self.h, t_as.data_ptr(), t_ptr.data_ptr(), t_prev_data.data_ptr(), t_prev_ts.data_ptr(), t_data.data_ptr(),
-                                                      t_ts.data_ptr(), t_is_read.data_ptr(), t_as.numel(), log_height, out.data_ptr()))
+                                                         t_imm.data_ptr(), t_pts.data_ptr(), t_case.numel(), log_height, out.data_ptr(),
+                                                         t_bitwise_trace.data_ptr()))
         return out
 
     def vm_poseidon2_tracegen(self, t_inputs_monty, n, log_height):

@@ -2,7 +2,7 @@
 //   * zkhip_vm_air / zkhip_vm_program_table / zkhip_vm_decode: the segment's AIR set (programs built once, by the C++ definitions --
 //     there is no second definition of these chips anywhere), its decode and program table;
 //   * trace generators of the new chips: frame (gathers the program row of every executed instruction and splits operands into
-//     bytes), the load/store adapter columns, the memory-access chip with its bounded gap, the Poseidon2 chip with multiplicities,
+//     bytes), the load/store adapter columns, the Poseidon2 chip with multiplicities,
 //     and a transposer for the small chips whose rows the segmenting executor writes itself (ecall, leaf, merkle, connector);
 //   * range-table multiplicities of scaled columns (requests like 4 * addr_hi).
 // Replaces, for this backend, the trace generation of OpenVM's adapter / connector / persistent-memory chips (un-vendored;
@@ -30,7 +30,7 @@ vmc::AirShape g_airs[vmc::N_AIRS];
 
 __global__ __launch_bounds__(256) void k_vm_frame(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
                                                   const uint32_t* __restrict__ zs, const uint32_t* __restrict__ rdp, const uint32_t* __restrict__ pcinc,
-                                                  size_t n, const uint32_t* __restrict__ program, size_t n_program, size_t N,
+                                                  const uint32_t* __restrict__ pts1, const uint32_t* __restrict__ pts2, const uint32_t* __restrict__ pts3, size_t n, const uint32_t* __restrict__ program, size_t n_program, size_t N,
                                                   uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
     const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= N) return;
@@ -54,19 +54,29 @@ __global__ __launch_bounds__(256) void k_vm_frame(const uint32_t* __restrict__ i
         const uint32_t inc = pcinc[r];
         if (inc >= P) atomicAdd(bad, 1u);
         col[32] = to_monty(inc % P), col[33] = MONTY_ONE;
+        // register adapter: previous timestamps and gaps of the rs1 / rs2 / rd accesses (zero where the instruction skips the access)
+        const uint32_t ts = 1u + vmc::TS_STEP * (uint32_t)r;
+        const uint32_t used[3] = {col[10], col[11], col[13]}, at[3] = {ts, ts + 2, ts + 12}, prev[3] = {pts1[r], pts2[r], pts3[r]};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            if (!used[a]) continue;
+            const uint32_t gap = at[a] - prev[a] - 1;
+            if (prev[a] >= at[a] || (gap >> (16 + vmc::GAP_HI_BITS))) atomicAdd(bad, 1u);
+            col[34 + 3 * a] = to_monty(prev[a] % P), col[35 + 3 * a] = to_monty(gap & 0xffffu), col[36 + 3 * a] = to_monty((gap >> 16) & ((1u << vmc::GAP_HI_BITS) - 1));
+        }
     }
 #pragma unroll
     for (unsigned q = 0; q < vmc::FRAME_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
 }
 
-// load/store adapter columns 33..44: ts | base[4] | imm_lo imm_hi | addr_lo addr_hi | carry0 carry1 | word_lo
+// load/store adapter columns 33..47: ts | base[4] | imm_lo imm_hi | addr_lo addr_hi | carry0 carry1 | word_lo | prev_ts gap_lo gap_hi
 __global__ __launch_bounds__(256) void k_vm_ls_adapter(const uint32_t* __restrict__ tss, const uint32_t* __restrict__ bases, const uint32_t* __restrict__ imms,
-                                                       size_t n, size_t N, uint32_t* __restrict__ trace) {
+                                                       const uint32_t* __restrict__ ptss, size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
     const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= N) return;
-    uint32_t col[12];
+    uint32_t col[15];
 #pragma unroll
-    for (int q = 0; q < 12; q++) col[q] = 0;
+    for (int q = 0; q < 15; q++) col[q] = 0;
     if (r < n) {
         const uint32_t base = bases[r], imm = imms[r];
         const uint32_t lo = (base & 0xffffu) + (imm & 0xffffu), c0 = lo >> 16;
@@ -77,14 +87,12 @@ __global__ __launch_bounds__(256) void k_vm_ls_adapter(const uint32_t* __restric
         col[5] = to_monty(imm & 0xffffu), col[6] = to_monty(imm >> 16);
         col[7] = to_monty(lo & 0xffffu), col[8] = to_monty(hi & 0xffffu), col[9] = to_monty(c0), col[10] = to_monty(c1);
         col[11] = to_monty((lo & 0xffffu) >> 2);
+        const uint32_t at = tss[r] + 4, prev = ptss[r], gap = at - prev - 1;
+        if (prev >= at || (gap >> (16 + vmc::GAP_HI_BITS))) atomicAdd(bad, 1u);
+        col[12] = to_monty(prev % P), col[13] = to_monty(gap & 0xffffu), col[14] = to_monty((gap >> 16) & ((1u << vmc::GAP_HI_BITS) - 1));
     }
 #pragma unroll
-    for (int q = 0; q < 12; q++) trace[(size_t)(33 + q) * N + r] = col[q];
-}
-
-__global__ __launch_bounds__(256) void k_col_scale(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n, uint32_t scale_monty) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = mmul(src[i], scale_monty);
+    for (int q = 0; q < 15; q++) trace[(size_t)(33 + q) * N + r] = col[q];
 }
 
 __global__ __launch_bounds__(256) void k_fill_prefix(uint32_t* __restrict__ col, size_t n_ones, size_t N) {
@@ -171,45 +179,40 @@ int zkhip_vm_program_table(const uint32_t* words, size_t n_words, uint32_t pc_ba
 }
 
 int zkhip_vm_frame_tracegen(zkhip_ctx* ctx, const uint32_t* d_pc_index, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_z,
-                            const uint32_t* d_rd_prev, const uint32_t* d_pc_inc, size_t n, const uint32_t* d_program, size_t n_program, unsigned log_height,
-                            uint32_t* d_trace) {
+                            const uint32_t* d_rd_prev, const uint32_t* d_pc_inc, const uint32_t* d_prev_ts_rs1, const uint32_t* d_prev_ts_rs2,
+                            const uint32_t* d_prev_ts_rd, size_t n, const uint32_t* d_program, size_t n_program, unsigned log_height, uint32_t* d_trace) {
     ZK_BIND_DEVICE(ctx);
-    if (!ctx || !d_trace || !d_program || log_height > 25 || (n && (!d_pc_index || !d_x || !d_y || !d_z || !d_rd_prev || !d_pc_inc))) return ZKHIP_ERR_INVALID;
+    if (!ctx || !d_trace || !d_program || log_height > 25 ||
+        (n && (!d_pc_index || !d_x || !d_y || !d_z || !d_rd_prev || !d_pc_inc || !d_prev_ts_rs1 || !d_prev_ts_rs2 || !d_prev_ts_rd)))
+        return ZKHIP_ERR_INVALID;
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "vm_frame_tracegen: more records than rows");
     void* flag = nullptr;
     ZK_TRY(get_scratch(ctx, 2, 16, &flag));
     KernelScope ks(ctx, "vm_frame_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_vm_frame, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_pc_index, d_x, d_y, d_z, d_rd_prev, d_pc_inc, n, d_program,
-                       n_program, N, d_trace, (uint32_t*)flag);
+    hipLaunchKernelGGL(k_vm_frame, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_pc_index, d_x, d_y, d_z, d_rd_prev, d_pc_inc,
+                       d_prev_ts_rs1, d_prev_ts_rs2, d_prev_ts_rd, n, d_program, n_program, N, d_trace, (uint32_t*)flag);
     ZK_HIP_CHECK(ctx, hipGetLastError());
-    return check_flag(ctx, flag, "vm_frame_tracegen (instruction index beyond the program, or a pc step that is not a field element)");
+    return check_flag(ctx, flag, "vm_frame_tracegen (instruction index beyond the program, a pc step that is not a field element, or a timestamp gap out of range)");
 }
 
 int zkhip_vm_loadstore_tracegen(zkhip_ctx* ctx, const uint32_t* d_case, const uint32_t* d_read, const uint32_t* d_prev, const uint32_t* d_ts,
-                                const uint32_t* d_base, const uint32_t* d_imm, size_t n, unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
+                                const uint32_t* d_base, const uint32_t* d_imm, const uint32_t* d_prev_ts, size_t n, unsigned log_height, uint32_t* d_trace,
+                                uint32_t* d_bitwise_trace) {
     ZK_BIND_DEVICE(ctx);
-    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 27 || (n && (!d_case || !d_read || !d_prev || !d_ts || !d_base || !d_imm))) return ZKHIP_ERR_INVALID;
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 27 || (n && (!d_case || !d_read || !d_prev || !d_ts || !d_base || !d_imm || !d_prev_ts)))
+        return ZKHIP_ERR_INVALID;
     // the core's 33 columns (same stride: they are the first 33 columns of this chip), then the adapter's
     ZK_TRY(zkhip_rv32_loadstore_tracegen(ctx, d_case, d_read, d_prev, n, log_height, d_trace, d_bitwise_trace));
     const size_t N = (size_t)1 << log_height;
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
     KernelScope ks(ctx, "vm_loadstore_adapter_tracegen");
-    hipLaunchKernelGGL(k_vm_ls_adapter, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_ts, d_base, d_imm, n, N, d_trace);
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_vm_ls_adapter, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_ts, d_base, d_imm, d_prev_ts, n, N, d_trace, (uint32_t*)flag);
     ZK_HIP_CHECK(ctx, hipGetLastError());
-    return ZKHIP_OK;
-}
-
-int zkhip_vm_access_tracegen(zkhip_ctx* ctx, const uint32_t* d_addr_space, const uint32_t* d_pointer, const uint32_t* d_prev_data, const uint32_t* d_prev_ts,
-                             const uint32_t* d_data, const uint32_t* d_ts, const uint32_t* d_is_read, size_t n, unsigned log_height, uint32_t* d_trace) {
-    ZK_BIND_DEVICE(ctx);
-    if (!ctx || !d_trace) return ZKHIP_ERR_INVALID;
-    ZK_TRY(zkhip_memory_access_tracegen(ctx, d_addr_space, d_pointer, d_prev_data, d_prev_ts, d_data, d_ts, d_is_read, n, log_height, d_trace));
-    const size_t N = (size_t)1 << log_height;
-    KernelScope ks(ctx, "vm_access_gap_bound");
-    hipLaunchKernelGGL(k_col_scale, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_trace + 9 * N, d_trace + 10 * N, N, to_monty(8));
-    ZK_HIP_CHECK(ctx, hipGetLastError());
-    return ZKHIP_OK;
+    return check_flag(ctx, flag, "vm_loadstore_tracegen (a timestamp gap out of range)");
 }
 
 int zkhip_vm_poseidon2_tracegen(zkhip_ctx* ctx, const uint32_t* d_inputs, size_t n, unsigned log_height, uint32_t* d_trace) {
