@@ -150,5 +150,21 @@ inline void keccak_f_air(AirBuilder& b) {
             }
 }
 
+// The chip inside the VM (include/zkhip_vm_circuit.hpp): the same AIR plus a timestamp column; on its export row every lane's
+// (timestamp, lane index, preimage limbs, output limbs) is received from the keccak adapter on `lane_bus` -- 25 receives that tie
+// the permutation to the 50 memory words the adapter reads and writes.  AirBuilder(VM_WIDTH, 0)
+constexpr size_t COL_TS = WIDTH, VM_WIDTH = WIDTH + 1;
+inline void keccak_vm_air(AirBuilder& b, uint32_t lane_bus) {
+    keccak_f_air(b);
+    const Expr exp = b.var(COL_EXPORT), ts = b.var(COL_TS);
+    for (size_t y = 0; y < 5; y++)
+        for (size_t x = 0; x < 5; x++) {
+            std::vector<Expr> m{ts, b.constant((uint32_t)(x + 5 * y))};
+            for (size_t l = 0; l < U64_LIMBS; l++) m.push_back(b.var(col_preimage(y, x, l)));
+            for (size_t l = 0; l < U64_LIMBS; l++) m.push_back((x == 0 && y == 0) ? b.var(COL_A_PPP_00 + l) : b.var(col_a_pp(y, x, l)));
+            b.push_interaction(lane_bus, m, exp, air::Kind::Receive);
+        }
+}
+
 }  // namespace keccak
 }  // namespace zkhip

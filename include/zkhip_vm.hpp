@@ -26,6 +26,8 @@
 #include <string>
 #include <vector>
 
+#include "zkhip_keccak.hpp"
+
 namespace zkhip_vm {
 
 struct Exe {
@@ -414,6 +416,17 @@ private:
                     memcpy(&val, in_.bytes.data() + in_pos_, 4);
                     in_pos_ += 4;
                     reg_write(rec, 10, val);
+                } else if (call == 3) {
+                    // Keccak-f[1600] in place on the 200 bytes at a0 (25 little-endian lanes): the intrinsic behind OpenVM's keccak
+                    // extension; proven by the keccak chips of the one-statement circuit (include/zkhip_vm_circuit.hpp)
+                    if (rec && log_memory_) throw Error("the keccak intrinsic is proven by the one-statement flow only");
+                    const uint32_t addr = reg_read(rec, 10);
+                    if (addr & 3u) throw Error("keccak state must be word-aligned");
+                    uint8_t* p = at(addr, 200);
+                    uint64_t st[25];
+                    memcpy(st, p, 200);
+                    zkhip::keccak::keccak_f1600(st);
+                    memcpy(p, st, 200);
                 } else {
                     throw Error("unknown environment call " + std::to_string(call));
                 }

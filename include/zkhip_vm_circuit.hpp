@@ -13,7 +13,12 @@
 //                  on the OPERAND BUS.  A core chip (ALU, less-than, mul, mulh, div, shift, branches, jumps) is the core of
 //                  include/zkhip_chips.hpp plus ONE receive on that bus: its columns are unchanged, so are its trace generators.
 //   load/store     the load/store core plus its memory adapter: address = rs1 + immediate, the aligned word accessed at slot 4.
-//   ecall chip     exit (pc becomes 0: the end of the execution), reveal (writes a public-value word into address space 3), hint read.
+//   ecall chip     exit (pc becomes 0: the end of the execution), reveal (writes a public-value word into address space 3), hint read,
+//                  keccak (a7 = 3: Keccak-f[1600] in place on the 200 bytes at a0 -- the intrinsic the reference's guests reach through
+//                  OpenVM's keccak extension, crates/circuits/chunk-circuit/openvm.toml).
+//   keccak adapter one row per LANE of a permutation call (25 rows): the lane's two memory words are read and replaced by the output
+//                  lane's (word accesses at the call's timestamp), and (timestamp, lane, input limbs, output limbs) goes to the
+//                  Keccak-f chip (include/zkhip_keccak.hpp, one round per row) on the lane bus.
 //   (memory)       offline memory checking inside the segment lives in the chips that access memory (as in OpenVM's adapters): a memory
 //                  word is (address space, word pointer, low half, high half, timestamp) on the memory bus; there is no separate
 //                  access chip.
@@ -34,6 +39,7 @@
 #include <vector>
 
 #include "zkhip_chips.hpp"
+#include "zkhip_keccak.hpp"
 
 namespace zkhip {
 namespace vmc {
@@ -42,12 +48,12 @@ using air::Expr;
 using air::Kind;
 
 constexpr uint32_t MEMORY_BUS = 1, EXEC_BUS = 2, OPERAND_BUS = 3, RANGE_BUS = 5, RANGE_TUPLE_BUS = 6, PROGRAM_BUS = 8, BITWISE_BUS = 9,
-                   MERKLE_BUS = 10, HASH_BUS = 11;
+                   MERKLE_BUS = 10, HASH_BUS = 11, KECCAK_REQ_BUS = 12, KECCAK_LANE_BUS = 13;
 constexpr uint32_t TS_STEP = 16;   // timestamps per instruction: rs1 at +0; rs2 at +2; the core's own accesses at +4 ..; rd at +12
 constexpr uint32_t BLOCK_CELLS = 8, BLOCK_WORDS = 4, LABEL_BITS = 26, LEAF_LEVEL = LABEL_BITS + 2;  // block label = as * 2^26 + (word >> 2); the tree has 28 levels above the blocks
 constexpr uint32_t GAP_HI_BITS = 11;  // a timestamp gap is gap_lo + 2^16 gap_hi with gap_hi below 2^11 (one range-tuple lookup (0, gap_hi))
 enum Cls : uint32_t { C_ALU, C_LT, C_MUL, C_MULH, C_DIVREM, C_SHIFT, C_BEQ, C_BLT, C_JAL_LUI, C_AUIPC, C_JALR, C_LS, C_ECALL, N_CLS };
-constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 27, LEAF_WIDTH = 43, MERKLE_WIDTH = 54,
+constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 29, LEAF_WIDTH = 43, MERKLE_WIDTH = 54, KECCAK_IO_WIDTH = 42,
                  CONNECTOR_WIDTH = 2;
 constexpr uint32_t P = air::P;
 
@@ -345,15 +351,17 @@ inline void loadstore_air(AirBuilder& b) {
 }
 
 // ecall chip: AirBuilder(ECALL_WIDTH, 0).  Columns: pc ts | x[4] (a7) | y[4] (a0) | z[4] (a0 afterwards) | is_exit is_reveal is_read |
-// idx (a1, the public-value word index) | pv_prev_lo pv_prev_hi | pc_inc | (prev_ts gap_lo gap_hi) of the a1 read and the public-value write
+// idx (a1, the public-value word index) | pv_prev_lo pv_prev_hi | pc_inc | (prev_ts gap_lo gap_hi) of the a1 read and the public-value write |
+// is_keccak | q (= a0's low byte / 4: the state must be word-aligned)
 inline void ecall_air(AirBuilder& b) {
     const Expr pc = b.var(0), ts = b.var(1);
     Expr x[4], y[4], z[4];
     for (int i = 0; i < 4; i++) x[i] = b.var(2 + i), y[i] = b.var(6 + i), z[i] = b.var(10 + i);
     const Expr is_exit = b.var(14), is_reveal = b.var(15), is_read = b.var(16), idx = b.var(17), pvp_lo = b.var(18), pvp_hi = b.var(19), pc_inc = b.var(20);
-    const Expr ok = is_exit + is_reveal + is_read;
-    for (const Expr& f : {is_exit, is_reveal, is_read, ok}) b.assert_zero(f * (f - 1));
-    b.assert_zero(x[0] - is_exit * 93 - is_reveal - is_read * 2);
+    const Expr is_keccak = b.var(27), q = b.var(28);
+    const Expr ok = is_exit + is_reveal + is_read + is_keccak;
+    for (const Expr& f : {is_exit, is_reveal, is_read, is_keccak, ok}) b.assert_zero(f * (f - 1));
+    b.assert_zero(x[0] - is_exit * 93 - is_reveal - is_read * 2 - is_keccak * 3);
     for (int i = 1; i < 4; i++) b.assert_zero(x[i]);
     for (int i = 0; i < 4; i++) {
         b.assert_zero(is_exit * y[i]);                 // exit code 0: a failing guest has no proof
@@ -371,9 +379,40 @@ inline void ecall_air(AirBuilder& b) {
     word_access(b, is_reveal, is_reveal, three, idx, pvp_lo, pvp_hi, y[0] + y[1] * 256, y[2] + y[3] * 256, ts + 5, b.var(24), b.var(25), b.var(26));
     b.push_interaction(RANGE_BUS, {idx * 8192}, is_reveal, Kind::Send);
     b.push_interaction(RANGE_BUS, {idx}, is_reveal, Kind::Send);
+    // keccak: the state's word pointer = a0 / 4 (a0 word-aligned, below 2^30) goes to the keccak adapter with the call's timestamp
+    b.assert_zero(is_keccak * (y[0] - q * 4));
+    b.push_interaction(KECCAK_REQ_BUS, {ts, q + y[1] * 64 + y[2] * 16384 + y[3] * 4194304}, is_keccak, Kind::Send);
+    b.push_interaction(RANGE_BUS, {q * 1024}, is_keccak, Kind::Send);
+    b.push_interaction(RANGE_BUS, {q}, is_keccak, Kind::Send);
+    b.push_interaction(RANGE_BUS, {y[3] * 1024}, is_keccak, Kind::Send);
     // the hinted word is a word of bytes (the other cases copy a0, whose bytes the frame chip checks)
     b.push_interaction(BITWISE_BUS, {z[0], z[1], zero, zero}, is_read, Kind::Send);
     b.push_interaction(BITWISE_BUS, {z[2], z[3], zero, zero}, is_read, Kind::Send);
+}
+
+// keccak adapter: AirBuilder(KECCAK_IO_WIDTH, 0).  Columns: lane[25] (one-hot: the row's lane index x + 5 y) | ts | ptr (word pointer of
+// the state) | in[4] | out[4] (the lane's 16-bit limbs before / after) | (prev_ts gap_lo gap_hi) of its two word accesses | ok.  A call
+// occupies 25 consecutive rows: lane k is followed by lane k + 1 with the same (ts, ptr); lane 0 receives the call from the ecall chip.
+inline void keccak_io_air(AirBuilder& b) {
+    Expr lane[25], in[4], out[4];
+    for (int k = 0; k < 25; k++) lane[k] = b.var(k);
+    const Expr ts = b.var(25), ptr = b.var(26), ok = b.var(41);
+    for (int l = 0; l < 4; l++) in[l] = b.var(27 + l), out[l] = b.var(31 + l);
+    Expr sum = lane[0], idx = b.constant(0);
+    for (int k = 1; k < 25; k++) sum = sum + lane[k], idx = idx + lane[k] * k;
+    for (int k = 0; k < 25; k++) b.assert_zero(lane[k] * (lane[k] - 1));
+    b.assert_zero(ok * (ok - 1));
+    b.assert_zero(sum - ok);
+    for (int k = 0; k < 24; k++) b.when_transition(b.var(k + 1, 1) - lane[k]);   // a started call runs through all 25 lanes
+    b.when_first_row(sum - lane[0]);                                              // no call starts in the middle
+    const Expr cont = b.var(41, 1) - b.var(0, 1);                                 // the next row continues this call
+    b.when_transition(cont * (b.var(25, 1) - ts));
+    b.when_transition(cont * (b.var(26, 1) - ptr));
+    b.push_interaction(KECCAK_REQ_BUS, {ts, ptr}, lane[0], Kind::Receive);
+    const Expr two = b.constant(2), w0 = ptr + idx * 2;
+    word_access(b, ok, ok, two, w0, in[0], in[1], out[0], out[1], ts + 4, b.var(35), b.var(36), b.var(37));
+    word_access(b, ok, ok, two, w0 + 1, in[2], in[3], out[2], out[3], ts + 4, b.var(38), b.var(39), b.var(40));
+    b.push_interaction(KECCAK_LANE_BUS, {ts, idx, in[0], in[1], in[2], in[3], out[0], out[1], out[2], out[3]}, ok, Kind::Send);
 }
 
 // leaf chip: AirBuilder(LEAF_WIDTH, 0).  Columns: as blk | init[8] | fin[8] | fin_ts[4] | h_init[8] | h_fin[8] | ok | gap_lo gap_hi |
@@ -468,8 +507,9 @@ inline void connector_air(AirBuilder& b) {
 // ---- the segment's AIR set (order fixed: it is part of the verifying key) ----
 enum AirId : unsigned {
     A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
-    A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, N_AIRS
+    A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, N_AIRS
 };
+constexpr unsigned N_BASE_AIRS = A_KECCAK;   // the extension chips come last: an app without the keccak extension has the first N_BASE_AIRS only
 struct AirShape {
     size_t width = 0, n_pvs = 0, prep_width = 0, cached_width = 0;
     std::vector<uint32_t> program;
@@ -493,6 +533,8 @@ inline AirShape build_air(unsigned id) {
         case A_BITWISE: make(2, 0, 3, [](AirBuilder& b) { chips::bitwise_lookup_air(b, BITWISE_BUS); }); break;
         case A_RANGE_TUPLE: make(1, 0, 2, [](AirBuilder& b) { chips::range_tuple_table_air(b, RANGE_TUPLE_BUS); }); break;
         case A_RANGE: make(1, 0, 1, [](AirBuilder& b) { chips::range_table_air(b, RANGE_BUS); }); break;
+        case A_KECCAK: make(keccak::VM_WIDTH, 0, 0, [](AirBuilder& b) { keccak::keccak_vm_air(b, KECCAK_LANE_BUS); }); break;
+        case A_KECCAK_IO: make(KECCAK_IO_WIDTH, 0, 0, keccak_io_air); break;
         default:
             if (id >= A_ALU && id <= A_JALR) {
                 const uint32_t cls = id - A_ALU;

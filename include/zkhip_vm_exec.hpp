@@ -78,8 +78,13 @@ private:
 // fixed trace heights of a segment = part of its verifying key
 struct SegmentCaps {
     unsigned log_height[vmc::N_AIRS] = {};
+    unsigned n_airs = vmc::N_BASE_AIRS;   // N_AIRS with the keccak extension (the reference enables it per app in openvm.toml)
+    bool keccak() const { return n_airs > vmc::A_KECCAK; }
     // heights for segments of about 2^log_frame instructions of an ordinary instruction mix
-    static SegmentCaps for_frame(unsigned log_frame, unsigned log_program) {
+    // log_keccak: 0 = the app has no keccak extension (22 chips); otherwise the rows of the Keccak-f chip (24 per permutation call,
+    // at least 32).  A wide chip costs every segment proof and every leaf circuit its 2634 openings per query, used or not, so it is
+    // part of the key only where openvm.toml asks for it (crates/circuits/chunk-circuit/openvm.toml `[app_vm_config.keccak]`).
+    static SegmentCaps for_frame(unsigned log_frame, unsigned log_program, unsigned log_keccak = 0) {
         SegmentCaps c;
         auto sub = [&](unsigned d) { return log_frame > d + 2 ? log_frame - d : 2u; };
         c.log_height[vmc::A_PROGRAM] = log_program, c.log_height[vmc::A_FRAME] = log_frame;
@@ -91,6 +96,10 @@ struct SegmentCaps {
         c.log_height[vmc::A_MERKLE] = std::max(sub(4), 8u);
         c.log_height[vmc::A_POSEIDON2] = std::max(sub(2), c.log_height[vmc::A_MERKLE] + 2), c.log_height[vmc::A_CONNECTOR] = 0, c.log_height[vmc::A_BITWISE] = 16;
         c.log_height[vmc::A_RANGE_TUPLE] = 19, c.log_height[vmc::A_RANGE] = 16;
+        if (log_keccak) {
+            c.n_airs = vmc::N_AIRS;
+            c.log_height[vmc::A_KECCAK] = std::max(log_keccak, 5u), c.log_height[vmc::A_KECCAK_IO] = c.log_height[vmc::A_KECCAK] + 1;   // 25 adapter rows per 24 chip rows
+        }
         return c;
     }
     size_t rows(unsigned air) const { return (size_t)1 << log_height[air]; }
@@ -104,6 +113,7 @@ struct SegmentRecords {
     std::vector<uint32_t> ls_ts, ls_base, ls_imm, ls_pts;    // load/store adapter, aligned with core.ls_*; ls_pts = the word's previous access
     std::vector<uint32_t> ecall_rows;                        // row-major canonical rows of the ecall / leaf / merkle chips
     std::vector<uint32_t> leaf_rows, merkle_rows, p2_inputs; // p2_inputs: [n][16] canonical, one row per hash-bus request
+    std::vector<uint32_t> kk_states, kk_ts, kio_rows;        // keccak calls: 50 input words and the timestamp per call; the adapter's rows
     uint32_t pc_start = 0, pc_end = 0, ts_end = 0;
     Digest root_init{}, root_final{};
     size_t n_instr = 0;
@@ -111,10 +121,11 @@ struct SegmentRecords {
     size_t n_leaf() const { return leaf_rows.size() / vmc::LEAF_WIDTH; }
     size_t n_merkle() const { return merkle_rows.size() / vmc::MERKLE_WIDTH; }
     size_t n_p2() const { return p2_inputs.size() / 16; }
+    size_t n_keccak() const { return kk_ts.size(); }
     void clear() {
         core.clear();
         for (auto* v : {&f_x, &f_y, &f_z, &f_rdprev, &f_pcinc, &f_pts1, &f_pts2, &f_pts3, &ls_ts, &ls_base, &ls_imm, &ls_pts, &ecall_rows, &leaf_rows, &merkle_rows,
-                        &p2_inputs})
+                        &p2_inputs, &kk_states, &kk_ts, &kio_rows})
             v->clear();
         n_instr = 0;
     }
@@ -164,7 +175,7 @@ public:
             // would one more instruction overflow a chip?  (the blocks and path nodes it would add are counted exactly)
             size_t new_blocks = 0, new_nodes = 0;
             {
-                uint32_t labels[5];
+                uint32_t labels[5 + 14];
                 unsigned nl = 0;
                 bool all_known = true;
                 auto want = [&](uint32_t as, uint32_t word) {
@@ -177,6 +188,8 @@ public:
                 if (d.wr_rd) want(1, d.rd);
                 if (d.cls == vmc::C_LS) want(2, ((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) >> 2);
                 if (d.cls == vmc::C_ECALL) want(1, 11), want(3, m_.reg(11) & 7u);
+                if (d.cls == vmc::C_ECALL && m_.reg(17) == 3)
+                    for (uint32_t w = m_.reg(10) >> 2; w < (m_.reg(10) >> 2) + 50; w += (w & 3u) ? 4 - (w & 3u) : 4) want(2, w);
                 if (!all_known) {   // rare: count exactly what the instruction would add
                     std::unordered_set<uint64_t> fresh;
                     for (unsigned i = 0; i < nl; i++) {
@@ -192,8 +205,11 @@ public:
                     }
                 }
             }
+            if (d.cls == vmc::C_ECALL && m_.reg(17) == 3 && !caps_.keccak())
+                throw Error("the guest calls the keccak intrinsic but the app's openvm.toml does not enable the keccak extension");
             if (r.n_instr + 1 > caps_.rows(vmc::A_FRAME) || n_cls[d.cls] + 1 > caps_.rows(vmc::A_ALU + d.cls) ||
                 blk_.size() + new_blocks > caps_.rows(vmc::A_LEAF) ||
+                (d.cls == vmc::C_ECALL && m_.reg(17) == 3 && 24 * (r.n_keccak() + 1) > caps_.rows(vmc::A_KECCAK)) ||
                 path_nodes_.size() + new_nodes > caps_.rows(vmc::A_MERKLE) ||
                 2 * (blk_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
                 if (r.n_instr == 0) throw Error("segment heights too small for a single instruction");
@@ -219,6 +235,11 @@ public:
             if (d.wr_rd) (void)block_of(1, d.rd);
             if (d.cls == vmc::C_LS) (void)block_of(2, addr >> 2);
             if (d.cls == vmc::C_ECALL && x == 1) (void)block_of(3, a1);
+            uint32_t kk_in[50];
+            if (d.cls == vmc::C_ECALL && x == 3) {
+                if ((y & 3u) || (uint64_t)y + 200 > (1ull << 30)) throw Error("keccak state must be word-aligned and below 2^30");
+                for (uint32_t j = 0; j < 50; j++) kk_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
+            }
             const size_t n_ls_before = r.core.ls_case.size();
             m_.step_one(&r.core);
             uint32_t z = 0, pc_inc;
@@ -229,7 +250,23 @@ public:
                 uint32_t row[vmc::ECALL_WIDTH] = {};
                 row[0] = pc, row[1] = ts;
                 for (int i = 0; i < 4; i++) row[2 + i] = (x >> (8 * i)) & 255u, row[6 + i] = (y >> (8 * i)) & 255u, row[10 + i] = (z >> (8 * i)) & 255u;
-                row[14] = x == 93, row[15] = x == 1, row[16] = x == 2, row[20] = pc_inc;
+                row[14] = x == 93, row[15] = x == 1, row[16] = x == 2, row[20] = pc_inc, row[27] = x == 3;
+                if (x == 3) {
+                    row[28] = (y & 255u) >> 2;
+                    r.kk_ts.push_back(ts);
+                    r.kk_states.insert(r.kk_states.end(), kk_in, kk_in + 50);
+                    for (uint32_t lane = 0; lane < 25; lane++) {   // the adapter's rows: both words of every lane replaced at ts + 4
+                        uint32_t kr[vmc::KECCAK_IO_WIDTH] = {};
+                        kr[lane] = 1, kr[25] = ts, kr[26] = y >> 2, kr[41] = 1;
+                        for (uint32_t h = 0; h < 2; h++) {
+                            const uint32_t w = (y >> 2) + 2 * lane + h, before = kk_in[2 * lane + h], after = mem_word(y + 4 * (2 * lane + h));
+                            kr[27 + 2 * h] = before & 0xffffu, kr[28 + 2 * h] = before >> 16, kr[31 + 2 * h] = after & 0xffffu, kr[32 + 2 * h] = after >> 16;
+                            const uint32_t pts = write_word(2, w, after, ts + 4), gap = ts + 4 - pts - 1;
+                            kr[35 + 3 * h] = pts, kr[36 + 3 * h] = gap & 0xffffu, kr[37 + 3 * h] = gap >> 16;
+                        }
+                        r.kio_rows.insert(r.kio_rows.end(), kr, kr + vmc::KECCAK_IO_WIDTH);
+                    }
+                }
                 if (x == 1) {
                     row[17] = a1, row[18] = pv_before & 0xffffu, row[19] = pv_before >> 16;
                     auto gap = [&](uint32_t* dst, uint32_t pts, uint32_t at) {

@@ -12,6 +12,7 @@
 //      (initial pc and memory root = the guest image's; final pc = 0 = exited with code 0; the public values' Merkle openings in the
 //      final root -- the `user_pvs_proof` of crates/types/src/proof.rs:52-67).
 #pragma once
+#include <fstream>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -40,8 +41,8 @@ inline unsigned vm_log2_ceil(size_t n) {
 }
 inline SegmentAirs segment_airs(const Exe& exe, const SegmentCaps& caps) {
     SegmentAirs s;
-    s.airs.resize(vmc::N_AIRS), s.prep_width.resize(vmc::N_AIRS);
-    for (unsigned a = 0; a < vmc::N_AIRS; a++) {
+    s.airs.resize(caps.n_airs), s.prep_width.resize(caps.n_airs);
+    for (unsigned a = 0; a < caps.n_airs; a++) {
         if (zkhip_vm_air(a, &s.airs[a], &s.prep_width[a]) != ZKHIP_OK) throw Error("zkhip_vm_air failed");
         s.airs[a].log_height = caps.log_height[a];
     }
@@ -75,7 +76,7 @@ public:
         if (zkhip_ctx_create(device, &ctx_) != ZKHIP_OK) throw Error("zkhip_ctx_create failed (needs a gfx950 device)");
         check(zkhip_keygen(ctx_, &params_, sa_.airs.data(), sa_.airs.size(), &pk_));
         vk_.params = params_;
-        for (unsigned a = 0; a < vmc::N_AIRS; a++) {
+        for (unsigned a = 0; a < caps.n_airs; a++) {
             AirDesc d;
             d.width = sa_.airs[a].width, d.n_pvs = sa_.airs[a].n_pvs;
             d.program.assign(sa_.airs[a].program, sa_.airs[a].program + sa_.airs[a].program_len);
@@ -93,7 +94,7 @@ public:
         check(zkhip_h2d(ctx_, d_program_, sa_.program_prep.data(), vmc::PROGRAM_FIELDS * NP * 4));
         check(zkhip_to_monty(ctx_, d_program_, vmc::PROGRAM_FIELDS * NP));
         size_t max_rows = 0;
-        for (unsigned a = 0; a < vmc::N_AIRS; a++) {
+        for (unsigned a = 0; a < caps_.n_airs; a++) {
             const size_t words = sa_.airs[a].width << caps_.log_height[a];
             void* d = nullptr;
             check(zkhip_malloc(ctx_, words * 4, &d));
@@ -158,6 +159,11 @@ public:
         uint32_t* d_p2in = const_cast<uint32_t*>(up(r.p2_inputs));
         if (r.n_p2()) check(zkhip_to_monty(ctx_, d_p2in, r.p2_inputs.size()));
         check(zkhip_vm_poseidon2_tracegen(ctx_, d_p2in, r.n_p2(), H(vmc::A_POSEIDON2), T(vmc::A_POSEIDON2)));
+        // ---- keccak calls: the Keccak-f chip on the device, its adapter's rows from the executor
+        if (caps_.keccak()) {
+            check(zkhip_vm_keccak_tracegen(ctx_, up(r.kk_states), up(r.kk_ts), r.n_keccak(), H(vmc::A_KECCAK), T(vmc::A_KECCAK)));
+            check(zkhip_rows_tracegen(ctx_, up(r.kio_rows), r.kio_rows.size() / vmc::KECCAK_IO_WIDTH, vmc::KECCAK_IO_WIDTH, H(vmc::A_KECCAK_IO), T(vmc::A_KECCAK_IO), nullptr));
+        }
         // ---- lookup multiplicities of the new chips, counted from the requesting columns
         auto pairs = [&](unsigned a, size_t cx, size_t cy, size_t n) {
             if (n) check(zkhip_bitwise_lookup_tracegen(ctx_, T(a) + cx * N(a), T(a) + cy * N(a), d_zeros_, n, 8, d_bw, 1));
@@ -189,6 +195,12 @@ public:
                     tup_y.push_back(row[23]), tup_y.push_back(row[26]);
                 }
                 if (row[16]) bw_x.push_back(row[10]), bw_y.push_back(row[11]), bw_x.push_back(row[12]), bw_y.push_back(row[13]);
+                if (row[27])
+                    for (uint32_t v : {row[28] * 1024, row[28], row[9] * 1024}) misc.push_back(v);
+            }
+            for (size_t i = 0; i < r.kio_rows.size() / vmc::KECCAK_IO_WIDTH; i++) {
+                const uint32_t* row = &r.kio_rows[i * vmc::KECCAK_IO_WIDTH];
+                misc.push_back(row[36]), misc.push_back(row[39]), tup_y.push_back(row[37]), tup_y.push_back(row[40]);
             }
             for (size_t i = 0; i < r.n_leaf(); i++) {
                 const uint32_t* row = &r.leaf_rows[i * vmc::LEAF_WIDTH];
@@ -213,11 +225,11 @@ public:
         // ---- prove
         SegmentProof sp;
         sp.n_instr = r.n_instr;
-        sp.proof.pvs.resize(vmc::N_AIRS);
+        sp.proof.pvs.resize(caps_.n_airs);
         for (int k = 0; k < 8; k++) sp.proof.pvs[vmc::A_MERKLE].push_back(r.root_init[k]);
         for (int k = 0; k < 8; k++) sp.proof.pvs[vmc::A_MERKLE].push_back(r.root_final[k]);
         sp.proof.pvs[vmc::A_CONNECTOR] = {r.pc_start, r.pc_end};
-        std::vector<const uint32_t*> dt(d_traces_.begin(), d_traces_.end()), pv(vmc::N_AIRS, nullptr);
+        std::vector<const uint32_t*> dt(d_traces_.begin(), d_traces_.end()), pv(caps_.n_airs, nullptr);
         pv[vmc::A_MERKLE] = sp.proof.pvs[vmc::A_MERKLE].data(), pv[vmc::A_CONNECTOR] = sp.proof.pvs[vmc::A_CONNECTOR].data();
         sp.proof.proof.resize(zkhip_proof_size(pk_));
         size_t len = 0;
@@ -481,9 +493,18 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     g.aggregation_mills = ms(clk::now() - t0);
     return g;
 }
+// Rows of the Keccak-f chip for an app: the reference enables the intrinsic per app in openvm.toml (`[app_vm_config.keccak]`,
+// crates/circuits/chunk-circuit/openvm.toml); with it the chip holds 2^(log_frame - 6) rows (at least 32), without it the app has no keccak chips (0).
+inline unsigned keccak_log_rows(const std::string& path_app_config, unsigned log_frame) {
+    std::ifstream f(path_app_config);
+    std::string line;
+    while (std::getline(f, line))
+        if (line.find("[app_vm_config.keccak]") != std::string::npos) return std::max(5u, log_frame > 6 ? log_frame - 6 : 0u);
+    return 0;
+}
 inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
-                                        bool keep_segments = false, unsigned inflight = 2) {
-    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()));
+                                        bool keep_segments = false, unsigned inflight = 2, unsigned log_keccak = 0) {
+    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak);
     std::vector<std::unique_ptr<SegmentProver>> own;
     std::vector<SegmentProver*> lanes;
     for (unsigned l = 0; l < std::max(1u, inflight); l++) own.emplace_back(new SegmentProver(params, exe, caps, device)), lanes.push_back(own.back().get());
@@ -537,7 +558,7 @@ public:
             throw Error(Error::Setup, "failed to read or deserialize " + cfg.path_app_exe + ": " + e.what());
         }
         p.params_ = read_app_config(cfg.path_app_config);
-        p.caps_ = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(p.exe_.program.size()));
+        p.caps_ = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(p.exe_.program.size()), zkhip_vm::keccak_log_rows(cfg.path_app_config, log_frame));
         return p;
     }
     void reset() {   // mod.rs:106-108: releases the device-resident keys, circuits and workspaces

@@ -328,6 +328,8 @@ extern "C" {
     pub fn zkhip_vm_loadstore_tracegen(ctx: *mut zkhip_ctx, d_case: *const u32, d_read: *const u32, d_prev: *const u32, d_ts: *const u32,
                                        d_base: *const u32, d_imm: *const u32, d_prev_ts: *const u32, n: usize, log_height: c_uint,
                                        d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_vm_keccak_tracegen(ctx: *mut zkhip_ctx, d_states: *const u32, d_ts: *const u32, n_perms: usize, log_height: c_uint,
+                                    d_trace: *mut u32) -> c_int;
     pub fn zkhip_vm_poseidon2_tracegen(ctx: *mut zkhip_ctx, d_inputs: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;
     pub fn zkhip_rows_tracegen(ctx: *mut zkhip_ctx, d_rows: *const u32, n: usize, width: usize, log_height: c_uint, d_trace: *mut u32,
                                pad_row: *const u32) -> c_int;

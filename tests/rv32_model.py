@@ -302,6 +302,10 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
             elif call == 2:
                 rw(10, struct.unpack_from("<I", stdin, pos)[0])
                 pos += 4
+            elif call == 3:   # Keccak-f[1600] in place on the 200 bytes at a0 (the memory log of this model does not cover it)
+                off = rr(10) - data_base
+                assert off % 4 == 0 and 0 <= off and off + 200 <= len(mem)
+                mem[off:off + 200] = keccak_f1600_bytes(bytes(mem[off:off + 200]))
             else:
                 raise ValueError("ecall %d" % call)
         else:
@@ -310,6 +314,38 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
             rw(rd, val)
         pc = nxt
         n += 1
+
+
+def keccak_f1600_bytes(state200):
+    """Keccak-f[1600] on 200 bytes (25 little-endian lanes, lane x + 5 y), written from FIPS 202 section 3 for this model."""
+    rc = []
+    r = 1
+    for _ in range(24):               # round constants from the LFSR of section 3.2.5
+        c = 0
+        for j in range(7):
+            if r & 1:
+                c |= 1 << ((1 << j) - 1)
+            r = ((r << 1) ^ (0x71 if r & 0x80 else 0)) & 0xFF
+        rc.append(c)
+    rot = [[0] * 5 for _ in range(5)]
+    xx, yy = 1, 0
+    for t in range(24):               # rotation offsets (t + 1)(t + 2) / 2 along the walk (x, y) -> (y, 2 x + 3 y)
+        rot[xx][yy] = ((t + 1) * (t + 2) // 2) % 64
+        xx, yy = yy, (2 * xx + 3 * yy) % 5
+    m64 = (1 << 64) - 1
+    rol = lambda v, k: ((v << k) | (v >> (64 - k))) & m64 if k else v  # noqa: E731
+    a = [[int.from_bytes(state200[8 * (x + 5 * y):8 * (x + 5 * y) + 8], "little") for y in range(5)] for x in range(5)]
+    for rnd in range(24):
+        c = [a[x][0] ^ a[x][1] ^ a[x][2] ^ a[x][3] ^ a[x][4] for x in range(5)]
+        d = [c[(x - 1) % 5] ^ rol(c[(x + 1) % 5], 1) for x in range(5)]
+        a = [[a[x][y] ^ d[x] for y in range(5)] for x in range(5)]
+        b = [[0] * 5 for _ in range(5)]
+        for x in range(5):
+            for y in range(5):
+                b[y][(2 * x + 3 * y) % 5] = rol(a[x][y], rot[x][y])
+        a = [[b[x][y] ^ (~b[(x + 1) % 5][y] & m64 & b[(x + 2) % 5][y]) for y in range(5)] for x in range(5)]
+        a[0][0] ^= rc[rnd]
+    return b"".join(a[x][y].to_bytes(8, "little") for y in range(5) for x in range(5))
 
 
 def exe_bytes(program, pc_base=0x00200000, data_base=0x00400000, memory_bytes=1 << 20, data=b""):

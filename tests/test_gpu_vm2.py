@@ -1,5 +1,5 @@
 """GPU: the one-statement VM flow (include/zkhip_vm_flow.hpp).
-  * device trace generation of a segment == the CPU twins, cell for cell, for all 22 chips; the HIP proof == the oracle's, byte
+  * device trace generation of a segment == the CPU twins, cell for cell, for all 22 chips (24 with the keccak extension); the HIP proof == the oracle's, byte
     for byte; tampered records (a wrong instruction result, swapped operands) give proofs the verifier refuses;
   * `prove_cli prove-elf`: ELF + input bytes -> execution -> segment proofs -> aggregation tree -> ONE root proof, self-verified:
     the root statement starts at the guest's entry pc on the guest image's memory root, ends at pc = 0, and the public values open
@@ -17,7 +17,7 @@ import prover_mirror_util as pm
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import fib_program, mixed_program
+from test_vm_cpu import fib_program, keccak_data, keccak_program, mixed_program
 
 pytestmark = pytest.mark.gpu
 PARAMS = (1, 0, 4, 3, 3)
@@ -28,7 +28,7 @@ def device_traces(zk, rec, prog, H):
     """The segment's traces through the device generators, as SegmentProver::prove drives them."""
     dev = zk.device
     D = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.uint32).view(np.int32)).to(dev)  # noqa: E731
-    T = [None] * v2.N_AIRS
+    T = [None] * len(H)
     d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=dev)
     d_tup = torch.zeros(1 << 19, dtype=torch.int32, device=dev)
     d_prog = zk.upload(prog.reshape(-1))
@@ -59,8 +59,12 @@ def device_traces(zk, rec, prog, H):
     T[v2.A_CONNECTOR] = zk.rows_tracegen(D(np.array([ts_end & 0xFFFF, ts_end >> 16], np.uint32)), 1, 2, 0)
     p2in = zk.upload(rec["p2_inputs"])
     T[v2.A_POSEIDON2] = zk.vm_poseidon2_tracegen(p2in, len(rec["p2_inputs"]) // 16, H[v2.A_POSEIDON2])
+    if len(H) > v2.A_KECCAK:
+        n_kk = len(rec["kk_ts"])
+        T[v2.A_KECCAK] = zk.vm_keccak_tracegen(D(rec["kk_states"]) if n_kk else None, D(rec["kk_ts"]) if n_kk else None, n_kk, H[v2.A_KECCAK])
+        T[v2.A_KECCAK_IO] = zk.rows_tracegen(D(rec["kio_rows"]), len(rec["kio_rows"]) // v2.KECCAK_IO_WIDTH, v2.KECCAK_IO_WIDTH, H[v2.A_KECCAK_IO])
     n, nls = len(rec["f_x"]), len(rec["ls_case"])
-    zeros = torch.zeros(max(n, nls, 8), dtype=torch.int32, device=dev)
+    zeros = torch.zeros(max(n, nls, 64), dtype=torch.int32, device=dev)
     NF, NL = 1 << H[v2.A_FRAME], 1 << H[v2.A_LS]
     for q in (18, 20, 22, 24, 26, 28):
         zk.bitwise_lookup_tracegen(T[v2.A_FRAME][q * NF:q * NF + n], T[v2.A_FRAME][(q + 1) * NF:(q + 1) * NF + n], zeros[:n], 8, d_bw, accumulate=True)
@@ -88,6 +92,11 @@ def device_traces(zk, rec, prog, H):
         if row[16]:
             bw_x += [int(row[10]), int(row[12])]
             bw_y += [int(row[11]), int(row[13])]
+        if row[27]:
+            misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
+    for row in rec["kio_rows"].reshape(-1, v2.KECCAK_IO_WIDTH):
+        misc += [int(row[36]), int(row[39])]
+        tup_y += [int(row[37]), int(row[40])]
     for row in rec["leaf_rows"].reshape(-1, v2.LEAF_WIDTH):
         misc += [int(row[39]), int(row[40]) * 16, int(row[40]), int(row[41]), int(row[42]) * 64, int(row[42])]
     d_rng = zk.range_counts_tracegen(zk.upload(np.array(misc, np.uint32)), 16, t_counts=d_rng, accumulate=True)
@@ -179,6 +188,41 @@ def test_prove_elf_one_flow_one_proof(tmp_path, which, seed):
     other = tmp_path / "other.elf"
     other.write_bytes(rv.elf_bytes(words, data=b"\x01\x02\x03\x04"))
     assert pm.run_cli("verify-guest", str(other), str(tmp_path / "root.vk"), cfg, str(tmp_path / "root.json")).returncode != 0
+
+
+def test_keccak_guest_device_traces_and_one_proof(zk, ora, tmp_path):
+    """A guest hashing with the keccak intrinsic: the segment with the calls on the device (24 chips) == the CPU twins, proof bytes ==
+    the oracle's; then the whole flow from the ELF (openvm.toml enables the keccak extension): the root's public values carry hashlib's
+    SHA3-256 digest."""
+    import hashlib
+
+    msg = b"one block of a message for the keccak intrinsic"
+    words, data = keccak_program(2), keccak_data(msg)
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 6)
+    k = next(i for i, s in enumerate(segs) if len(s["kk_ts"]))
+    inst = v2.segment_instance(segs[k], words, PC_BASE, H)
+    prog = v2.program_table(words, PC_BASE, H[0])
+    T = device_traces(zk, segs[k], prog, H)
+    for a, d in enumerate(inst):
+        assert (zk.download(T[a]).reshape(d["width"], -1) == d["trace"]).all(), "chip %d" % a
+    pk = z.ProvingKey(zk, PARAMS, inst)
+    pvs = [d["pvs"] for d in inst]
+    proof = pk.prove(T, pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, inst).tobytes()
+    pk.close()
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words, data=data))
+    (tmp_path / "openvm.toml").write_text(pm.TOML.format(*PARAMS) + "\n[app_vm_config.keccak]\n")
+    r = subprocess.run([pm.CLI, "prove-elf", str(exe), "-", str(tmp_path), str(tmp_path / "openvm.toml"), "8"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    model = rv.run(words, b"", data=data)
+    assert out["verified"] and out["total_cycles"] == model["instret"]
+    root = json.loads((tmp_path / "root.json").read_text())
+    upv = pm.un_b64_bincode(root["user_pvs_proof"])
+    assert upv[4 * 34:4 * 34 + 28] == hashlib.sha3_256(msg).digest()[:28] and upv[4 * 34:4 * 34 + 32] == bytes(model["pvs"])
+    assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
 
 
 def test_gen_proof_universal_from_an_elf_and_witness_bytes(tmp_path):

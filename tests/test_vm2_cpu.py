@@ -2,7 +2,7 @@
 the segmenting executor's records (include/zkhip_vm_exec.hpp, `prove_cli dump-segments`):
   * the run agrees with the independent Python interpreter; segments chain by (pc, memory root); the first root is the guest image's,
     the last pc is 0, the public values open in the final root;
-  * every one of the 22 traces (CPU twins of the device generators, tests/vm2_util.py) satisfies its AIR, and every bus balances
+  * every one of the 22 traces (24 with the keccak extension) (CPU twins of the device generators, tests/vm2_util.py) satisfies its AIR, and every bus balances
     exactly: program, execution, operand, access, memory, merkle, hash and the three lookup buses;
   * the oracle proves a whole segment and both verifiers accept;
   * a tampered instruction result, swapped operands, a forged memory value, a skipped instruction, a wrong next pc: some bus no
@@ -17,7 +17,7 @@ from zkvm_prover_amd import air
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import fib_program, mixed_program
+from test_vm_cpu import fib_program, keccak_data, keccak_program, mixed_program
 
 PARAMS = (1, 0, 4, 3, 3)
 PC_BASE = 0x00200000
@@ -143,6 +143,39 @@ def test_tampering_breaks_a_bus(mixed):
         rec["meta"][5] = (int(rec["meta"][5]) + 1) % v2.P
     local, bad = _tampered(mixed, 4, wrong_root)
     assert v2.A_MERKLE in local
+
+
+def test_keccak_intrinsic_is_part_of_the_statement(tmp_path):
+    """A guest that computes SHA3-256 with the keccak intrinsic: the revealed digest is hashlib's (FIPS 202 -- parity anchored outside
+    this repository), the calls' 50 memory words go through the keccak adapter, the permutation through the Keccak-f chip: all traces
+    satisfy their AIRs, every bus balances, and a forged output lane breaks the lane bus."""
+    import hashlib
+
+    msg = b"one block of a message for the keccak intrinsic"
+    words, data = keccak_program(2), keccak_data(msg)
+    model = rv.run(words, b"", data=data)
+    digest = hashlib.sha3_256(msg).digest()
+    assert bytes(model["pvs"])[:28] == digest[:28]                       # (word 7 is folded with the second permutation's output)
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 6)   # room for two calls per segment
+    assert bytes.fromhex(info["public_values"]) == bytes(model["pvs"]) and info["total_cycle"] == model["instret"]
+    assert sum(len(s["kk_ts"]) for s in segs) == 2 and len(H) == 24
+    with pytest.raises(AssertionError, match="does not enable the keccak extension"):   # the same guest under an app without it
+        v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)
+    for k, rec in enumerate(segs):
+        inst = v2.segment_instance(rec, words, PC_BASE, H)
+        for a, d in enumerate(inst):
+            assert air.quotient_chunks(d["program"]) <= 2, a
+            assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], (k, a)
+        assert v2.bus_imbalance(inst) == {}
+    k = next(i for i, s in enumerate(segs) if len(s["kk_ts"]))
+    rec = {n: v.copy() for n, v in segs[k].items()}
+    rec["kio_rows"].reshape(-1, v2.KECCAK_IO_WIDTH)[3, 31] ^= 1           # an output limb of lane 3 that the permutation does not produce
+    inst = v2.segment_instance(rec, words, PC_BASE, H)
+    bad = v2.bus_imbalance(inst)
+    assert 13 in bad and 1 in bad                                         # the lane bus and (the next reader of that word) the memory bus
+    rec = {n: v.copy() for n, v in segs[k].items()}
+    rec["kk_states"][5] ^= 1                                              # the chip permutes another state than the memory holds
+    assert 13 in v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
 
 
 def test_decode_table_against_an_independent_decoder(mixed):

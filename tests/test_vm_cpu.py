@@ -33,6 +33,34 @@ def fib_program():
         ("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)])
 
 
+def keccak_program(n_calls=2):
+    """SHA3-256 of a one-block message through the keccak intrinsic (a7 = 3): the padded block sits in the data segment (keccak_data),
+    the guest permutes it in place `n_calls` times (the digest of the FIRST permutation is saved before) and reveals eight digest words."""
+    p = rv.li(S0, 0x00400000)
+    p += [("add", A0, S0, 0), ("addi", A7, 0, 3), ("ecall",)]
+    for k in range(8):                                                    # keep the digest: the next call overwrites the state
+        p += [("lw", T0, S0, 4 * k), ("sw", T0, S0, 256 + 4 * k)]
+    for _ in range(n_calls - 1):
+        p += [("add", A0, S0, 0), ("addi", A7, 0, 3), ("ecall",)]
+    p += [("lw", T1, S0, 0)]                                              # a word of the twice-permuted state, folded into word 7
+    for k in range(8):
+        p += [("lw", A0, S0, 256 + 4 * k)]
+        if k == 7:
+            p += [("xor", A0, A0, T1)]
+        p += [("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
+def keccak_data(msg):
+    assert len(msg) < 136
+    blk = bytearray(200)
+    blk[:len(msg)] = msg
+    blk[len(msg)] ^= 0x06
+    blk[135] ^= 0x80
+    return bytes(blk)
+
+
 def mixed_program():
     """every instruction class: a checksum over a table in memory with multiplies, comparisons, shifts, division, bytes"""
     p = [("addi", A7, 0, 2), ("ecall",), ("add", S0, A0, 0)]          # seed

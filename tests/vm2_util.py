@@ -1,5 +1,5 @@
 """CPU twins of the one-statement VM circuit's trace generators (include/zkhip_vm_circuit.hpp, zkvm-prover_amd/csrc/vm_chips.hip):
-the segment records the C++ executor dumps (`prove_cli dump-segments`) -> the 22 traces, in numpy and through the oracle's
+the segment records the C++ executor dumps (`prove_cli dump-segments`) -> the 24 traces, in numpy and through the oracle's
 existing core-chip generators.  TEST INFRASTRUCTURE.  The AIR programs themselves come from the library (zkhip_vm_air): they have
 ONE definition, the C++ one."""
 import ctypes as C
@@ -17,8 +17,8 @@ CLI = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
 P = ora.P
 NOPV = np.zeros(0, np.uint32)
 (A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
- A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, N_AIRS) = range(23)
-PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH = 17, 43, 48, 27, 43, 54
+ A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, N_AIRS) = range(25)
+PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 29, 43, 54, 42, 2634
 TS_STEP, GAP_HI_BITS = 16, 11
 SX, SY = 256, 2048
 
@@ -47,14 +47,15 @@ def program_table(words, pc_base, log_program):
     return out
 
 
-def dump_segments(tmp, exe_bytes, stdin, log_frame):
+def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0):
     """Runs the C++ segmenting executor; returns (info json, heights, [segment record dicts], image root, pv openings)."""
     import json
 
     d = str(tmp)
     open(os.path.join(d, "exe.bin"), "wb").write(exe_bytes)
     open(os.path.join(d, "stdin.bin"), "wb").write(stdin)
-    r = subprocess.run([CLI, "dump-segments", os.path.join(d, "exe.bin"), os.path.join(d, "stdin.bin"), d, str(log_frame)], capture_output=True, text=True)
+    r = subprocess.run([CLI, "dump-segments", os.path.join(d, "exe.bin"), os.path.join(d, "stdin.bin"), d, str(log_frame), str(log_keccak)],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
     heights = np.fromfile(os.path.join(d, "heights.u32"), dtype=np.uint32).tolist()
@@ -124,12 +125,27 @@ def rows_trace(rows, width, log_height, pad=None):
     return t
 
 
+def keccak_traces(rec, H):
+    """keccak calls: the oracle's Keccak-f trace + the call's timestamp on its rows; the adapter's rows as the executor wrote them"""
+    n_kk = len(rec["kk_ts"])
+    kk = np.zeros((KECCAK_WIDTH, 1 << H[A_KECCAK]), np.uint32)
+    lib = ora.lib()
+    lib.ora_keccak_f_trace.restype = None
+    lib.ora_keccak_f_trace.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, C.c_uint, C.POINTER(C.c_uint32)]
+    states = np.ascontiguousarray(rec["kk_states"], dtype=np.uint32).view(np.uint64).reshape(-1, 25) if n_kk else np.zeros((0, 25), np.uint64)
+    body = np.zeros((KECCAK_WIDTH - 1, 1 << H[A_KECCAK]), np.uint32)
+    lib.ora_keccak_f_trace(states.ctypes.data_as(C.POINTER(C.c_uint64)), n_kk, H[A_KECCAK], ora.p32(body))
+    kk[:KECCAK_WIDTH - 1] = body
+    kk[KECCAK_WIDTH - 1, :24 * n_kk] = np.repeat(rec["kk_ts"], 24)
+    return kk, rows_trace(rec["kio_rows"], KECCAK_IO_WIDTH, H[A_KECCAK_IO])
+
+
 def segment_instance(rec, words, pc_base, heights):
-    """The 22 AIR dicts (program, shapes, trace, pvs[, prep]) of one segment, traces from the CPU twins."""
+    """The 24 AIR dicts (program, shapes, trace, pvs[, prep]) of one segment, traces from the CPU twins."""
     H = heights
-    shapes = vm_airs()
+    shapes = vm_airs()[:len(H)]   # 22 chips, or 24 with the keccak extension
     prog = program_table(words, pc_base, H[A_PROGRAM])
-    tr = [None] * N_AIRS
+    tr = [None] * len(H)
     freq, bad = ora.program_freq_trace(rec["pc_index"], H[A_PROGRAM])
     assert bad == 0
     tr[A_PROGRAM] = freq.reshape(1, -1)
@@ -156,6 +172,8 @@ def segment_instance(rec, words, pc_base, heights):
     p2[:298] = ora.poseidon2_air_trace(p2in, H[A_POSEIDON2])
     p2[298, :len(p2in)] = 1
     tr[A_POSEIDON2] = p2
+    if len(H) > A_KECCAK:
+        tr[A_KECCAK], tr[A_KECCAK_IO] = keccak_traces(rec, H)
     meta = rec["meta"]
     pc_start, pc_end, ts_end, n_instr = (int(x) for x in meta[:4])
     tr[A_CONNECTOR] = np.array([[ts_end & 0xFFFF], [ts_end >> 16]], np.uint32)
@@ -185,6 +203,12 @@ def segment_instance(rec, words, pc_base, heights):
         if row[16]:
             rc[int(row[10]) * 256 + int(row[11])] += 1
             rc[int(row[12]) * 256 + int(row[13])] += 1
+        if row[27]:
+            misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
+    for row in rec["kio_rows"].reshape(-1, KECCAK_IO_WIDTH):
+        misc += [int(row[36]), int(row[39])]
+        tc[int(row[37])] += 1
+        tc[int(row[40])] += 1
     for row in rec["leaf_rows"].reshape(-1, LEAF_WIDTH):
         misc += [int(row[39]), int(row[40]) * 16, int(row[40]), int(row[41]), int(row[42]) * 64, int(row[42])]
     cnt += np.bincount(np.array(misc, dtype=np.int64), minlength=1 << 16)

@@ -179,6 +179,7 @@ def load_library():
         "zkhip_vm_frame_tracegen": (C.c_int, [vp] * 10 + [sz, vp, sz, C.c_uint, vp]),
         "zkhip_vm_loadstore_tracegen": (C.c_int, [vp] * 8 + [sz, C.c_uint, vp, vp]),
         "zkhip_vm_poseidon2_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
+        "zkhip_vm_keccak_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_rows_tracegen": (C.c_int, [vp, vp, sz, sz, C.c_uint, vp, u32p]),
         "zkhip_range_counts_scaled_tracegen": (C.c_int, [vp, vp, sz, C.c_uint32, C.c_uint, vp, C.c_int]),
         "zkhip_recursion_build": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, sz, C.POINTER(_RecursionStmt), C.POINTER(vp)]),
@@ -599,6 +600,12 @@ class Context:
         self._check(self.lib.zkhip_vm_loadstore_tracegen(self.h, t_case.data_ptr(), t_read.data_ptr(), t_prev.data_ptr(), t_ts.data_ptr(), t_base.data_ptr(),
                                                          t_imm.data_ptr(), t_pts.data_ptr(), t_case.numel(), log_height, out.data_ptr(),
                                                          t_bitwise_trace.data_ptr()))
+        return out
+
+    def vm_keccak_tracegen(self, t_states, t_ts, n_perms, log_height):
+        out = self._new(2634 << log_height)
+        self._check(self.lib.zkhip_vm_keccak_tracegen(self.h, t_states.data_ptr() if n_perms else None, t_ts.data_ptr() if n_perms else None, n_perms,
+                                                      log_height, out.data_ptr()))
         return out
 
     def vm_poseidon2_tracegen(self, t_inputs_monty, n, log_height):

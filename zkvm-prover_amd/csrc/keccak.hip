@@ -88,6 +88,14 @@ __global__ __launch_bounds__(256) void k_keccak_trace(const uint32_t* __restrict
     for (int l = 0; l < 4; l++) put(kk::COL_A_PPP_00 + l, (uint32_t)(out00 >> (16 * l)) & 0xffffu);
 }
 
+// the VM chip's timestamp column: every row of call p carries the call's timestamp, the padding permutations zero
+__global__ __launch_bounds__(256) void k_keccak_ts(const uint32_t* __restrict__ ts, size_t n_perms, size_t N, uint32_t* __restrict__ col) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    const size_t p = row / 24;
+    col[row] = p < n_perms ? to_monty(ts[p] % P) : 0u;
+}
+
 std::once_flag g_once;
 std::vector<uint32_t> g_program;
 
@@ -127,6 +135,17 @@ int zkhip_keccak_f_tracegen(zkhip_ctx* ctx, const uint32_t* d_states, size_t n_p
     if (24 * n_perms > N) return set_error(ctx, ZKHIP_ERR_INVALID, "keccak_f_tracegen: 24 rows per permutation do not fit the trace");
     KernelScope ks(ctx, "keccak_f_tracegen");
     hipLaunchKernelGGL(k_keccak_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_states, n_perms, N, d_trace);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+int zkhip_vm_keccak_tracegen(zkhip_ctx* ctx, const uint32_t* d_states, const uint32_t* d_ts, size_t n_perms, unsigned log_height, uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || (n_perms && !d_ts)) return ZKHIP_ERR_INVALID;
+    ZK_TRY(zkhip_keccak_f_tracegen(ctx, d_states, n_perms, log_height, d_trace));
+    const size_t N = (size_t)1 << log_height;
+    KernelScope ks(ctx, "vm_keccak_timestamps");
+    hipLaunchKernelGGL(k_keccak_ts, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_ts, n_perms, N, d_trace + (size_t)kk::COL_TS * N);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
 }
