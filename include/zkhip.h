@@ -587,6 +587,10 @@ int zkhip_vm_loadstore_tracegen(zkhip_ctx *ctx, const uint32_t *d_case, const ui
 /* Keccak-f chip inside the VM (2634 columns): zkhip_keccak_f_tracegen + the timestamp of call p on its 24 rows (d_ts: n_perms plain
  * integers).  Its adapter's rows (vmc::KECCAK_IO_WIDTH) are written by the executor and transposed with zkhip_rows_tracegen. */
 int zkhip_vm_keccak_tracegen(zkhip_ctx *ctx, const uint32_t *d_states, const uint32_t *d_ts, size_t n_perms, unsigned log_height, uint32_t *d_trace);
+/* SHA-256 compression chip inside the VM (434 columns, 9 preprocessed): zkhip_sha256_tracegen + the timestamp of call b on its 65 rows;
+ * zkhip_vm_sha256_prep writes its preprocessed trace (the standalone chip's six columns + input / digest / round-index). */
+int zkhip_vm_sha256_tracegen(zkhip_ctx *ctx, const uint32_t *d_blocks, const uint32_t *d_ts, size_t n_blocks, unsigned log_height, uint32_t *d_trace);
+int zkhip_vm_sha256_prep(unsigned log_height, uint32_t *out);
 /* Poseidon2 chip serving the hash bus (299 columns): zkhip_poseidon2_air_tracegen + multiplicity 1 on the first n rows. */
 int zkhip_vm_poseidon2_tracegen(zkhip_ctx *ctx, const uint32_t *d_inputs, size_t n, unsigned log_height, uint32_t *d_trace);
 /* n rows of `width` canonical words (row-major, device) -> column-major Montgomery trace of 2^log_height rows; the other rows get

@@ -168,5 +168,39 @@ inline void compress_air(AirBuilder& b) {
     }
 }
 
+// The chip inside the VM (include/zkhip_vm_circuit.hpp): the same AIR plus a timestamp column (constant through a block) and three
+// more preprocessed columns (input: t < 16, digest: t = 64, tidx: t).  The sixteen message words are received from the SHA-256
+// adapter on `msg_bus` as (timestamp, t, W_t limbs) on the rows that hold them, the eight state words as (timestamp, k, H_in[k]
+// limbs, H_out[k] limbs) on the digest row -- which ties the block to the 24 memory words the adapter reads and the 8 it rewrites.
+// AirBuilder(VM_WIDTH, 0, VM_PREP_WIDTH)
+constexpr size_t COL_TS = WIDTH, VM_WIDTH = WIDTH + 1;
+constexpr size_t PREP_INPUT = PREP_WIDTH, PREP_DIGEST = PREP_WIDTH + 1, PREP_TIDX = PREP_WIDTH + 2, VM_PREP_WIDTH = PREP_WIDTH + 3;
+inline std::vector<uint32_t> prep_trace_vm(unsigned log_height) {
+    const size_t N = (size_t)1 << log_height, blocks = N / ROWS_PER_BLOCK;
+    const std::vector<uint32_t> base = prep_trace(log_height);
+    std::vector<uint32_t> p(VM_PREP_WIDTH * N, 0);
+    std::copy(base.begin(), base.end(), p.begin());
+    for (size_t b = 0; b < blocks; b++)
+        for (size_t t = 0; t < ROWS_PER_BLOCK; t++) {
+            const size_t row = b * ROWS_PER_BLOCK + t;
+            p[PREP_INPUT * N + row] = t < 16, p[PREP_DIGEST * N + row] = t == 64, p[PREP_TIDX * N + row] = (uint32_t)t;
+        }
+    return p;
+}
+inline void compress_vm_air(AirBuilder& b, uint32_t msg_bus, uint32_t state_bus) {
+    compress_air(b);
+    const Expr ts = b.var(COL_TS), real = b.var(COL_REAL), gate = b.prep(PREP_ROUND) + b.prep(PREP_FINAL);
+    b.when_transition(gate * (b.next(COL_TS) - ts));
+    auto limb = [&](size_t base, size_t l) {
+        Expr s = b.constant(0);
+        for (size_t k = 0; k < 16; k++) s = s + b.var(base + 16 * l + k) * (int64_t)(1u << k);
+        return s;
+    };
+    b.push_interaction(msg_bus, {ts, b.prep(PREP_TIDX), limb(COL_W15_BITS, 0), limb(COL_W15_BITS, 1)}, real * b.prep(PREP_INPUT), air::Kind::Receive);
+    for (size_t k = 0; k < 8; k++)
+        b.push_interaction(state_bus, {ts, b.constant((uint32_t)k), b.var(COL_HIN + 2 * k), b.var(COL_HIN + 2 * k + 1), limb(COL_STATE + 32 * k, 0), limb(COL_STATE + 32 * k, 1)},
+                           real * b.prep(PREP_DIGEST), air::Kind::Receive);
+}
+
 }  // namespace sha256
 }  // namespace zkhip

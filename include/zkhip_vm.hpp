@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "zkhip_keccak.hpp"
+#include "zkhip_sha256.hpp"
 
 namespace zkhip_vm {
 
@@ -427,6 +428,17 @@ private:
                     memcpy(st, p, 200);
                     zkhip::keccak::keccak_f1600(st);
                     memcpy(p, st, 200);
+                } else if (call == 4) {
+                    // SHA-256 compression on the 24 words at a0: words 0..7 the state, words 8..23 the block's message words (plain
+                    // 32-bit values: the guest does the byte order); the state becomes compress(state, block) (OpenVM's sha256 extension)
+                    if (rec && log_memory_) throw Error("the sha256 intrinsic is proven by the one-statement flow only");
+                    const uint32_t addr = reg_read(rec, 10);
+                    if (addr & 3u) throw Error("sha256 buffer must be word-aligned");
+                    uint8_t* p = at(addr, 96);
+                    uint32_t buf[24];
+                    memcpy(buf, p, 96);
+                    zkhip::sha256::compress(buf, buf + 8);
+                    memcpy(p, buf, 32);
                 } else {
                     throw Error("unknown environment call " + std::to_string(call));
                 }

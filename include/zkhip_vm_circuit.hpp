@@ -16,6 +16,10 @@
 //   ecall chip     exit (pc becomes 0: the end of the execution), reveal (writes a public-value word into address space 3), hint read,
 //                  keccak (a7 = 3: Keccak-f[1600] in place on the 200 bytes at a0 -- the intrinsic the reference's guests reach through
 //                  OpenVM's keccak extension, crates/circuits/chunk-circuit/openvm.toml).
+//                  sha256 (a7 = 4: the SHA-256 compression function on the 24 words at a0 -- eight state words, then the sixteen message
+//                  words of a block; the state is replaced by compress(state, block); OpenVM's sha256 extension).
+//   sha256 adapter one row per WORD of a call (24 rows): state words are read and replaced, message words read; (timestamp, index, limbs)
+//                  goes to the SHA-256 compression chip (include/zkhip_sha256.hpp, one round per row) on the message / state buses.
 //   keccak adapter one row per LANE of a permutation call (25 rows): the lane's two memory words are read and replaced by the output
 //                  lane's (word accesses at the call's timestamp), and (timestamp, lane, input limbs, output limbs) goes to the
 //                  Keccak-f chip (include/zkhip_keccak.hpp, one round per row) on the lane bus.
@@ -40,6 +44,7 @@
 
 #include "zkhip_chips.hpp"
 #include "zkhip_keccak.hpp"
+#include "zkhip_sha256.hpp"
 
 namespace zkhip {
 namespace vmc {
@@ -48,12 +53,12 @@ using air::Expr;
 using air::Kind;
 
 constexpr uint32_t MEMORY_BUS = 1, EXEC_BUS = 2, OPERAND_BUS = 3, RANGE_BUS = 5, RANGE_TUPLE_BUS = 6, PROGRAM_BUS = 8, BITWISE_BUS = 9,
-                   MERKLE_BUS = 10, HASH_BUS = 11, KECCAK_REQ_BUS = 12, KECCAK_LANE_BUS = 13;
+                   MERKLE_BUS = 10, HASH_BUS = 11, KECCAK_REQ_BUS = 12, KECCAK_LANE_BUS = 13, SHA_REQ_BUS = 14, SHA_MSG_BUS = 15, SHA_STATE_BUS = 16;
 constexpr uint32_t TS_STEP = 16;   // timestamps per instruction: rs1 at +0; rs2 at +2; the core's own accesses at +4 ..; rd at +12
 constexpr uint32_t BLOCK_CELLS = 8, BLOCK_WORDS = 4, LABEL_BITS = 26, LEAF_LEVEL = LABEL_BITS + 2;  // block label = as * 2^26 + (word >> 2); the tree has 28 levels above the blocks
 constexpr uint32_t GAP_HI_BITS = 11;  // a timestamp gap is gap_lo + 2^16 gap_hi with gap_hi below 2^11 (one range-tuple lookup (0, gap_hi))
 enum Cls : uint32_t { C_ALU, C_LT, C_MUL, C_MULH, C_DIVREM, C_SHIFT, C_BEQ, C_BLT, C_JAL_LUI, C_AUIPC, C_JALR, C_LS, C_ECALL, N_CLS };
-constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 29, LEAF_WIDTH = 43, MERKLE_WIDTH = 54, KECCAK_IO_WIDTH = 42,
+constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 30, LEAF_WIDTH = 43, MERKLE_WIDTH = 54, KECCAK_IO_WIDTH = 42, SHA_IO_WIDTH = 34,
                  CONNECTOR_WIDTH = 2;
 constexpr uint32_t P = air::P;
 
@@ -352,16 +357,16 @@ inline void loadstore_air(AirBuilder& b) {
 
 // ecall chip: AirBuilder(ECALL_WIDTH, 0).  Columns: pc ts | x[4] (a7) | y[4] (a0) | z[4] (a0 afterwards) | is_exit is_reveal is_read |
 // idx (a1, the public-value word index) | pv_prev_lo pv_prev_hi | pc_inc | (prev_ts gap_lo gap_hi) of the a1 read and the public-value write |
-// is_keccak | q (= a0's low byte / 4: the state must be word-aligned)
+// is_keccak | q (= a0's low byte / 4: the state must be word-aligned) | is_sha
 inline void ecall_air(AirBuilder& b) {
     const Expr pc = b.var(0), ts = b.var(1);
     Expr x[4], y[4], z[4];
     for (int i = 0; i < 4; i++) x[i] = b.var(2 + i), y[i] = b.var(6 + i), z[i] = b.var(10 + i);
     const Expr is_exit = b.var(14), is_reveal = b.var(15), is_read = b.var(16), idx = b.var(17), pvp_lo = b.var(18), pvp_hi = b.var(19), pc_inc = b.var(20);
-    const Expr is_keccak = b.var(27), q = b.var(28);
-    const Expr ok = is_exit + is_reveal + is_read + is_keccak;
-    for (const Expr& f : {is_exit, is_reveal, is_read, is_keccak, ok}) b.assert_zero(f * (f - 1));
-    b.assert_zero(x[0] - is_exit * 93 - is_reveal - is_read * 2 - is_keccak * 3);
+    const Expr is_keccak = b.var(27), q = b.var(28), is_sha = b.var(29), is_hash = is_keccak + is_sha;
+    const Expr ok = is_exit + is_reveal + is_read + is_keccak + is_sha;
+    for (const Expr& f : {is_exit, is_reveal, is_read, is_keccak, is_sha, ok}) b.assert_zero(f * (f - 1));
+    b.assert_zero(x[0] - is_exit * 93 - is_reveal - is_read * 2 - is_keccak * 3 - is_sha * 4);
     for (int i = 1; i < 4; i++) b.assert_zero(x[i]);
     for (int i = 0; i < 4; i++) {
         b.assert_zero(is_exit * y[i]);                 // exit code 0: a failing guest has no proof
@@ -380,11 +385,14 @@ inline void ecall_air(AirBuilder& b) {
     b.push_interaction(RANGE_BUS, {idx * 8192}, is_reveal, Kind::Send);
     b.push_interaction(RANGE_BUS, {idx}, is_reveal, Kind::Send);
     // keccak: the state's word pointer = a0 / 4 (a0 word-aligned, below 2^30) goes to the keccak adapter with the call's timestamp
-    b.assert_zero(is_keccak * (y[0] - q * 4));
-    b.push_interaction(KECCAK_REQ_BUS, {ts, q + y[1] * 64 + y[2] * 16384 + y[3] * 4194304}, is_keccak, Kind::Send);
-    b.push_interaction(RANGE_BUS, {q * 1024}, is_keccak, Kind::Send);
-    b.push_interaction(RANGE_BUS, {q}, is_keccak, Kind::Send);
-    b.push_interaction(RANGE_BUS, {y[3] * 1024}, is_keccak, Kind::Send);
+    // (sha256: the same with the 24-word state-and-block buffer and the SHA-256 adapter)
+    b.assert_zero(is_hash * (y[0] - q * 4));
+    const Expr wptr = q + y[1] * 64 + y[2] * 16384 + y[3] * 4194304;
+    b.push_interaction(KECCAK_REQ_BUS, {ts, wptr}, is_keccak, Kind::Send);
+    b.push_interaction(SHA_REQ_BUS, {ts, wptr}, is_sha, Kind::Send);
+    b.push_interaction(RANGE_BUS, {q * 1024}, is_hash, Kind::Send);
+    b.push_interaction(RANGE_BUS, {q}, is_hash, Kind::Send);
+    b.push_interaction(RANGE_BUS, {y[3] * 1024}, is_hash, Kind::Send);
     // the hinted word is a word of bytes (the other cases copy a0, whose bytes the frame chip checks)
     b.push_interaction(BITWISE_BUS, {z[0], z[1], zero, zero}, is_read, Kind::Send);
     b.push_interaction(BITWISE_BUS, {z[2], z[3], zero, zero}, is_read, Kind::Send);
@@ -413,6 +421,35 @@ inline void keccak_io_air(AirBuilder& b) {
     word_access(b, ok, ok, two, w0, in[0], in[1], out[0], out[1], ts + 4, b.var(35), b.var(36), b.var(37));
     word_access(b, ok, ok, two, w0 + 1, in[2], in[3], out[2], out[3], ts + 4, b.var(38), b.var(39), b.var(40));
     b.push_interaction(KECCAK_LANE_BUS, {ts, idx, in[0], in[1], in[2], in[3], out[0], out[1], out[2], out[3]}, ok, Kind::Send);
+}
+
+// sha256 adapter: AirBuilder(SHA_IO_WIDTH, 0).  Columns: word[24] (one-hot: 0..7 the state words, 8..23 the message words) | ts | base
+// (word pointer of the buffer) | v_lo v_hi (the word before) | n_lo n_hi (after: H_out for a state word, unchanged for a message
+// word) | prev_ts gap_lo gap_hi | ok.  A call occupies 24 consecutive rows, like the keccak adapter's 25.
+inline void sha256_io_air(AirBuilder& b) {
+    Expr sel[24];
+    for (int k = 0; k < 24; k++) sel[k] = b.var(k);
+    const Expr ts = b.var(24), base = b.var(25), v_lo = b.var(26), v_hi = b.var(27), n_lo = b.var(28), n_hi = b.var(29), ok = b.var(33);
+    Expr sum = sel[0], idx = b.constant(0), is_state = sel[0];
+    for (int k = 1; k < 24; k++) {
+        sum = sum + sel[k], idx = idx + sel[k] * k;
+        if (k < 8) is_state = is_state + sel[k];
+    }
+    const Expr is_msg = ok - is_state;
+    for (int k = 0; k < 24; k++) b.assert_zero(sel[k] * (sel[k] - 1));
+    b.assert_zero(ok * (ok - 1));
+    b.assert_zero(sum - ok);
+    for (int k = 0; k < 23; k++) b.when_transition(b.var(k + 1, 1) - sel[k]);
+    b.when_first_row(sum - sel[0]);
+    const Expr cont = b.var(33, 1) - b.var(0, 1);
+    b.when_transition(cont * (b.var(24, 1) - ts));
+    b.when_transition(cont * (b.var(25, 1) - base));
+    b.assert_zero(is_msg * (n_lo - v_lo));
+    b.assert_zero(is_msg * (n_hi - v_hi));
+    b.push_interaction(SHA_REQ_BUS, {ts, base}, sel[0], Kind::Receive);
+    word_access(b, ok, ok, b.constant(2), base + idx, v_lo, v_hi, n_lo, n_hi, ts + 4, b.var(30), b.var(31), b.var(32));
+    b.push_interaction(SHA_MSG_BUS, {ts, idx - 8, v_lo, v_hi}, is_msg, Kind::Send);
+    b.push_interaction(SHA_STATE_BUS, {ts, idx, v_lo, v_hi, n_lo, n_hi}, is_state, Kind::Send);
 }
 
 // leaf chip: AirBuilder(LEAF_WIDTH, 0).  Columns: as blk | init[8] | fin[8] | fin_ts[4] | h_init[8] | h_fin[8] | ok | gap_lo gap_hi |
@@ -507,9 +544,9 @@ inline void connector_air(AirBuilder& b) {
 // ---- the segment's AIR set (order fixed: it is part of the verifying key) ----
 enum AirId : unsigned {
     A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
-    A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, N_AIRS
+    A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, N_AIRS
 };
-constexpr unsigned N_BASE_AIRS = A_KECCAK;   // the extension chips come last: an app without the keccak extension has the first N_BASE_AIRS only
+constexpr unsigned N_BASE_AIRS = A_KECCAK;   // the extension chips come last: an app has the base chips + the extensions its openvm.toml enables
 struct AirShape {
     size_t width = 0, n_pvs = 0, prep_width = 0, cached_width = 0;
     std::vector<uint32_t> program;
@@ -535,6 +572,8 @@ inline AirShape build_air(unsigned id) {
         case A_RANGE: make(1, 0, 1, [](AirBuilder& b) { chips::range_table_air(b, RANGE_BUS); }); break;
         case A_KECCAK: make(keccak::VM_WIDTH, 0, 0, [](AirBuilder& b) { keccak::keccak_vm_air(b, KECCAK_LANE_BUS); }); break;
         case A_KECCAK_IO: make(KECCAK_IO_WIDTH, 0, 0, keccak_io_air); break;
+        case A_SHA256: make(sha256::VM_WIDTH, 0, sha256::VM_PREP_WIDTH, [](AirBuilder& b) { sha256::compress_vm_air(b, SHA_MSG_BUS, SHA_STATE_BUS); }); break;
+        case A_SHA256_IO: make(SHA_IO_WIDTH, 0, 0, sha256_io_air); break;
         default:
             if (id >= A_ALU && id <= A_JALR) {
                 const uint32_t cls = id - A_ALU;

@@ -78,14 +78,24 @@ private:
 // fixed trace heights of a segment = part of its verifying key
 struct SegmentCaps {
     unsigned log_height[vmc::N_AIRS] = {};
-    unsigned n_airs = vmc::N_BASE_AIRS;   // N_AIRS with the keccak extension (the reference enables it per app in openvm.toml)
-    bool keccak() const { return n_airs > vmc::A_KECCAK; }
+    // the chips of this app, in proof order: the base chips, then the extensions its openvm.toml enables (ids of vmc::AirId)
+    std::vector<unsigned> ids;
+    unsigned n_airs = 0;
+    int pos(unsigned id) const {
+        for (size_t p = 0; p < ids.size(); p++)
+            if (ids[p] == id) return (int)p;
+        return -1;
+    }
+    bool keccak() const { return pos(vmc::A_KECCAK) >= 0; }
+    bool sha256() const { return pos(vmc::A_SHA256) >= 0; }
     // heights for segments of about 2^log_frame instructions of an ordinary instruction mix
     // log_keccak: 0 = the app has no keccak extension (22 chips); otherwise the rows of the Keccak-f chip (24 per permutation call,
     // at least 32).  A wide chip costs every segment proof and every leaf circuit its 2634 openings per query, used or not, so it is
     // part of the key only where openvm.toml asks for it (crates/circuits/chunk-circuit/openvm.toml `[app_vm_config.keccak]`).
-    static SegmentCaps for_frame(unsigned log_frame, unsigned log_program, unsigned log_keccak = 0) {
+    // log_sha256: likewise for the SHA-256 compression chip (65 rows per block, at least 128; `[app_vm_config.sha256]`).
+    static SegmentCaps for_frame(unsigned log_frame, unsigned log_program, unsigned log_keccak = 0, unsigned log_sha256 = 0) {
         SegmentCaps c;
+        for (unsigned a = 0; a < vmc::N_BASE_AIRS; a++) c.ids.push_back(a);
         auto sub = [&](unsigned d) { return log_frame > d + 2 ? log_frame - d : 2u; };
         c.log_height[vmc::A_PROGRAM] = log_program, c.log_height[vmc::A_FRAME] = log_frame;
         c.log_height[vmc::A_ALU] = sub(1), c.log_height[vmc::A_LT] = sub(3), c.log_height[vmc::A_MUL] = sub(3), c.log_height[vmc::A_MULH] = sub(5);
@@ -97,9 +107,14 @@ struct SegmentCaps {
         c.log_height[vmc::A_POSEIDON2] = std::max(sub(2), c.log_height[vmc::A_MERKLE] + 2), c.log_height[vmc::A_CONNECTOR] = 0, c.log_height[vmc::A_BITWISE] = 16;
         c.log_height[vmc::A_RANGE_TUPLE] = 19, c.log_height[vmc::A_RANGE] = 16;
         if (log_keccak) {
-            c.n_airs = vmc::N_AIRS;
+            c.ids.push_back(vmc::A_KECCAK), c.ids.push_back(vmc::A_KECCAK_IO);
             c.log_height[vmc::A_KECCAK] = std::max(log_keccak, 5u), c.log_height[vmc::A_KECCAK_IO] = c.log_height[vmc::A_KECCAK] + 1;   // 25 adapter rows per 24 chip rows
         }
+        if (log_sha256) {
+            c.ids.push_back(vmc::A_SHA256), c.ids.push_back(vmc::A_SHA256_IO);
+            c.log_height[vmc::A_SHA256] = std::max(log_sha256, 7u), c.log_height[vmc::A_SHA256_IO] = c.log_height[vmc::A_SHA256] - 1;       // 24 adapter rows per 65 chip rows
+        }
+        c.n_airs = (unsigned)c.ids.size();
         return c;
     }
     size_t rows(unsigned air) const { return (size_t)1 << log_height[air]; }
@@ -114,6 +129,7 @@ struct SegmentRecords {
     std::vector<uint32_t> ecall_rows;                        // row-major canonical rows of the ecall / leaf / merkle chips
     std::vector<uint32_t> leaf_rows, merkle_rows, p2_inputs; // p2_inputs: [n][16] canonical, one row per hash-bus request
     std::vector<uint32_t> kk_states, kk_ts, kio_rows;        // keccak calls: 50 input words and the timestamp per call; the adapter's rows
+    std::vector<uint32_t> sha_blocks, sha_ts, shaio_rows;    // sha256 calls: 24 words (state, block) and the timestamp per call; the adapter's rows
     uint32_t pc_start = 0, pc_end = 0, ts_end = 0;
     Digest root_init{}, root_final{};
     size_t n_instr = 0;
@@ -122,10 +138,11 @@ struct SegmentRecords {
     size_t n_merkle() const { return merkle_rows.size() / vmc::MERKLE_WIDTH; }
     size_t n_p2() const { return p2_inputs.size() / 16; }
     size_t n_keccak() const { return kk_ts.size(); }
+    size_t n_sha256() const { return sha_ts.size(); }
     void clear() {
         core.clear();
         for (auto* v : {&f_x, &f_y, &f_z, &f_rdprev, &f_pcinc, &f_pts1, &f_pts2, &f_pts3, &ls_ts, &ls_base, &ls_imm, &ls_pts, &ecall_rows, &leaf_rows, &merkle_rows,
-                        &p2_inputs, &kk_states, &kk_ts, &kio_rows})
+                        &p2_inputs, &kk_states, &kk_ts, &kio_rows, &sha_blocks, &sha_ts, &shaio_rows})
             v->clear();
         n_instr = 0;
     }
@@ -188,8 +205,10 @@ public:
                 if (d.wr_rd) want(1, d.rd);
                 if (d.cls == vmc::C_LS) want(2, ((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) >> 2);
                 if (d.cls == vmc::C_ECALL) want(1, 11), want(3, m_.reg(11) & 7u);
-                if (d.cls == vmc::C_ECALL && m_.reg(17) == 3)
-                    for (uint32_t w = m_.reg(10) >> 2; w < (m_.reg(10) >> 2) + 50; w += (w & 3u) ? 4 - (w & 3u) : 4) want(2, w);
+                if (d.cls == vmc::C_ECALL && (m_.reg(17) == 3 || m_.reg(17) == 4)) {
+                    const uint32_t n_words = m_.reg(17) == 3 ? 50 : 24;
+                    for (uint32_t w = m_.reg(10) >> 2; w < (m_.reg(10) >> 2) + n_words; w += (w & 3u) ? 4 - (w & 3u) : 4) want(2, w);
+                }
                 if (!all_known) {   // rare: count exactly what the instruction would add
                     std::unordered_set<uint64_t> fresh;
                     for (unsigned i = 0; i < nl; i++) {
@@ -207,9 +226,12 @@ public:
             }
             if (d.cls == vmc::C_ECALL && m_.reg(17) == 3 && !caps_.keccak())
                 throw Error("the guest calls the keccak intrinsic but the app's openvm.toml does not enable the keccak extension");
+            if (d.cls == vmc::C_ECALL && m_.reg(17) == 4 && !caps_.sha256())
+                throw Error("the guest calls the sha256 intrinsic but the app's openvm.toml does not enable the sha256 extension");
             if (r.n_instr + 1 > caps_.rows(vmc::A_FRAME) || n_cls[d.cls] + 1 > caps_.rows(vmc::A_ALU + d.cls) ||
                 blk_.size() + new_blocks > caps_.rows(vmc::A_LEAF) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 3 && 24 * (r.n_keccak() + 1) > caps_.rows(vmc::A_KECCAK)) ||
+                (d.cls == vmc::C_ECALL && m_.reg(17) == 4 && 65 * (r.n_sha256() + 1) > caps_.rows(vmc::A_SHA256)) ||
                 path_nodes_.size() + new_nodes > caps_.rows(vmc::A_MERKLE) ||
                 2 * (blk_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
                 if (r.n_instr == 0) throw Error("segment heights too small for a single instruction");
@@ -239,6 +261,11 @@ public:
             if (d.cls == vmc::C_ECALL && x == 3) {
                 if ((y & 3u) || (uint64_t)y + 200 > (1ull << 30)) throw Error("keccak state must be word-aligned and below 2^30");
                 for (uint32_t j = 0; j < 50; j++) kk_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
+            }
+            uint32_t sha_in[24];
+            if (d.cls == vmc::C_ECALL && x == 4) {
+                if ((y & 3u) || (uint64_t)y + 96 > (1ull << 30)) throw Error("sha256 buffer must be word-aligned and below 2^30");
+                for (uint32_t j = 0; j < 24; j++) sha_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
             }
             const size_t n_ls_before = r.core.ls_case.size();
             m_.step_one(&r.core);
@@ -274,6 +301,20 @@ public:
                     };
                     gap(row + 21, read_word(1, 11, a1, ts + 4), ts + 4);
                     gap(row + 24, write_word(3, a1, y, ts + 5), ts + 5);
+                }
+                if (x == 4) {
+                    row[29] = 1, row[28] = (y & 255u) >> 2;
+                    r.sha_ts.push_back(ts);
+                    r.sha_blocks.insert(r.sha_blocks.end(), sha_in, sha_in + 24);
+                    for (uint32_t k = 0; k < 24; k++) {   // the adapter's rows: state words replaced, message words read, all at ts + 4
+                        uint32_t sr[vmc::SHA_IO_WIDTH] = {};
+                        const uint32_t w = (y >> 2) + k, before = sha_in[k], after = mem_word(y + 4 * k);
+                        sr[k] = 1, sr[24] = ts, sr[25] = y >> 2, sr[33] = 1;
+                        sr[26] = before & 0xffffu, sr[27] = before >> 16, sr[28] = after & 0xffffu, sr[29] = after >> 16;
+                        const uint32_t pts = k < 8 ? write_word(2, w, after, ts + 4) : read_word(2, w, before, ts + 4), gap = ts + 4 - pts - 1;
+                        sr[30] = pts, sr[31] = gap & 0xffffu, sr[32] = gap >> 16;
+                        r.shaio_rows.insert(r.shaio_rows.end(), sr, sr + vmc::SHA_IO_WIDTH);
+                    }
                 }
                 r.ecall_rows.insert(r.ecall_rows.end(), row, row + vmc::ECALL_WIDTH);
             } else {

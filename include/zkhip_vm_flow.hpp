@@ -32,7 +32,7 @@ using scroll_zkvm_hip::VerifyingKey;
 struct SegmentAirs {
     std::vector<zkhip_air> airs;                 // program / width / n_pvs / log_height; prep_trace set for the AIRs with tables
     std::vector<size_t> prep_width;
-    std::vector<uint32_t> program_prep, bitwise_prep, tuple_prep, range_prep;
+    std::vector<uint32_t> program_prep, bitwise_prep, tuple_prep, range_prep, sha_prep;
 };
 inline unsigned vm_log2_ceil(size_t n) {
     unsigned l = 1;
@@ -42,9 +42,9 @@ inline unsigned vm_log2_ceil(size_t n) {
 inline SegmentAirs segment_airs(const Exe& exe, const SegmentCaps& caps) {
     SegmentAirs s;
     s.airs.resize(caps.n_airs), s.prep_width.resize(caps.n_airs);
-    for (unsigned a = 0; a < caps.n_airs; a++) {
-        if (zkhip_vm_air(a, &s.airs[a], &s.prep_width[a]) != ZKHIP_OK) throw Error("zkhip_vm_air failed");
-        s.airs[a].log_height = caps.log_height[a];
+    for (unsigned p = 0; p < caps.n_airs; p++) {   // position p of the proof holds chip caps.ids[p] (base chips: p = id)
+        if (zkhip_vm_air(caps.ids[p], &s.airs[p], &s.prep_width[p]) != ZKHIP_OK) throw Error("zkhip_vm_air failed");
+        s.airs[p].log_height = caps.log_height[caps.ids[p]];
     }
     const unsigned lp = caps.log_height[vmc::A_PROGRAM];
     s.program_prep = vmc::program_table(exe.program, exe.pc_base, lp);
@@ -54,6 +54,10 @@ inline SegmentAirs segment_airs(const Exe& exe, const SegmentCaps& caps) {
     std::iota(s.range_prep.begin(), s.range_prep.end(), 0u);
     s.airs[vmc::A_PROGRAM].prep_trace = s.program_prep.data(), s.airs[vmc::A_BITWISE].prep_trace = s.bitwise_prep.data();
     s.airs[vmc::A_RANGE_TUPLE].prep_trace = s.tuple_prep.data(), s.airs[vmc::A_RANGE].prep_trace = s.range_prep.data();
+    if (caps.sha256()) {
+        s.sha_prep = zkhip::sha256::prep_trace_vm(caps.log_height[vmc::A_SHA256]);
+        s.airs[caps.pos(vmc::A_SHA256)].prep_trace = s.sha_prep.data();
+    }
     return s;
 }
 
@@ -83,10 +87,10 @@ public:
             if (sa_.prep_width[a]) {
                 uint32_t c[8];
                 check(zkhip_pk_prep_commitment(ctx_, pk_, a, c));
-                d.has_prep = true, d.prep_log_height = caps.log_height[a], d.prep_commit.assign(c, c + 8);
+                d.has_prep = true, d.prep_log_height = sa_.airs[a].log_height, d.prep_commit.assign(c, c + 8);
             }
             vk_.airs.push_back(std::move(d));
-            vk_.heights.push_back(caps.log_height[a]);
+            vk_.heights.push_back(sa_.airs[a].log_height);
         }
         // device-resident tables: the program (for the frame chip's gather), zeros for the bitwise "op" argument
         const size_t NP = caps_.rows(vmc::A_PROGRAM);
@@ -95,11 +99,11 @@ public:
         check(zkhip_to_monty(ctx_, d_program_, vmc::PROGRAM_FIELDS * NP));
         size_t max_rows = 0;
         for (unsigned a = 0; a < caps_.n_airs; a++) {
-            const size_t words = sa_.airs[a].width << caps_.log_height[a];
+            const size_t words = sa_.airs[a].width << sa_.airs[a].log_height;
             void* d = nullptr;
             check(zkhip_malloc(ctx_, words * 4, &d));
             d_traces_.push_back((uint32_t*)d);
-            max_rows = std::max(max_rows, caps_.rows(a));
+            max_rows = std::max(max_rows, (size_t)1 << sa_.airs[a].log_height);
         }
         check(zkhip_malloc(ctx_, max_rows * 4, (void**)&d_zeros_));
         check(zkhip_zero(ctx_, d_zeros_, max_rows * 4));
@@ -125,7 +129,7 @@ public:
         release();
         const ExecRecords& c = r.core;
         auto H = [&](unsigned a) { return caps_.log_height[a]; };
-        auto T = [&](unsigned a) { return d_traces_[a]; };
+        auto T = [&](unsigned a) { return d_traces_[(size_t)caps_.pos(a)]; };
         auto N = [&](unsigned a) { return caps_.rows(a); };
         // ---- tables start empty
         check(zkhip_zero(ctx_, T(vmc::A_BITWISE), (2u << 16) * 4)), check(zkhip_zero(ctx_, T(vmc::A_RANGE_TUPLE), (1u << 19) * 4));
@@ -164,6 +168,10 @@ public:
             check(zkhip_vm_keccak_tracegen(ctx_, up(r.kk_states), up(r.kk_ts), r.n_keccak(), H(vmc::A_KECCAK), T(vmc::A_KECCAK)));
             check(zkhip_rows_tracegen(ctx_, up(r.kio_rows), r.kio_rows.size() / vmc::KECCAK_IO_WIDTH, vmc::KECCAK_IO_WIDTH, H(vmc::A_KECCAK_IO), T(vmc::A_KECCAK_IO), nullptr));
         }
+        if (caps_.sha256()) {
+            check(zkhip_vm_sha256_tracegen(ctx_, up(r.sha_blocks), up(r.sha_ts), r.n_sha256(), H(vmc::A_SHA256), T(vmc::A_SHA256)));
+            check(zkhip_rows_tracegen(ctx_, up(r.shaio_rows), r.shaio_rows.size() / vmc::SHA_IO_WIDTH, vmc::SHA_IO_WIDTH, H(vmc::A_SHA256_IO), T(vmc::A_SHA256_IO), nullptr));
+        }
         // ---- lookup multiplicities of the new chips, counted from the requesting columns
         auto pairs = [&](unsigned a, size_t cx, size_t cy, size_t n) {
             if (n) check(zkhip_bitwise_lookup_tracegen(ctx_, T(a) + cx * N(a), T(a) + cy * N(a), d_zeros_, n, 8, d_bw, 1));
@@ -195,7 +203,7 @@ public:
                     tup_y.push_back(row[23]), tup_y.push_back(row[26]);
                 }
                 if (row[16]) bw_x.push_back(row[10]), bw_y.push_back(row[11]), bw_x.push_back(row[12]), bw_y.push_back(row[13]);
-                if (row[27])
+                if (row[27] || row[29])
                     for (uint32_t v : {row[28] * 1024, row[28], row[9] * 1024}) misc.push_back(v);
             }
             for (size_t i = 0; i < r.kio_rows.size() / vmc::KECCAK_IO_WIDTH; i++) {
@@ -205,6 +213,10 @@ public:
             for (size_t i = 0; i < r.n_leaf(); i++) {
                 const uint32_t* row = &r.leaf_rows[i * vmc::LEAF_WIDTH];
                 for (uint32_t v : {row[39], row[40] * 16, row[40], row[41], row[42] * 64, row[42]}) misc.push_back(v);
+            }
+            for (size_t i = 0; i < r.shaio_rows.size() / vmc::SHA_IO_WIDTH; i++) {
+                const uint32_t* row = &r.shaio_rows[i * vmc::SHA_IO_WIDTH];
+                misc.push_back(row[31]), tup_y.push_back(row[32]);
             }
             uint32_t* d_misc = const_cast<uint32_t*>(up(misc));
             check(zkhip_to_monty(ctx_, d_misc, misc.size()));
@@ -495,16 +507,23 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
 }
 // Rows of the Keccak-f chip for an app: the reference enables the intrinsic per app in openvm.toml (`[app_vm_config.keccak]`,
 // crates/circuits/chunk-circuit/openvm.toml); with it the chip holds 2^(log_frame - 6) rows (at least 32), without it the app has no keccak chips (0).
-inline unsigned keccak_log_rows(const std::string& path_app_config, unsigned log_frame) {
+inline bool config_has_section(const std::string& path_app_config, const char* section) {
     std::ifstream f(path_app_config);
     std::string line;
     while (std::getline(f, line))
-        if (line.find("[app_vm_config.keccak]") != std::string::npos) return std::max(5u, log_frame > 6 ? log_frame - 6 : 0u);
-    return 0;
+        if (line.find(section) != std::string::npos) return true;
+    return false;
+}
+inline unsigned keccak_log_rows(const std::string& path_app_config, unsigned log_frame) {
+    return config_has_section(path_app_config, "[app_vm_config.keccak]") ? std::max(5u, log_frame > 6 ? log_frame - 6 : 0u) : 0u;
+}
+// likewise `[app_vm_config.sha256]`: 2^(log_frame - 5) rows of the SHA-256 compression chip (65 per block, at least 128)
+inline unsigned sha256_log_rows(const std::string& path_app_config, unsigned log_frame) {
+    return config_has_section(path_app_config, "[app_vm_config.sha256]") ? std::max(7u, log_frame > 5 ? log_frame - 5 : 0u) : 0u;
 }
 inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
-                                        bool keep_segments = false, unsigned inflight = 2, unsigned log_keccak = 0) {
-    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak);
+                                        bool keep_segments = false, unsigned inflight = 2, unsigned log_keccak = 0, unsigned log_sha256 = 0) {
+    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak, log_sha256);
     std::vector<std::unique_ptr<SegmentProver>> own;
     std::vector<SegmentProver*> lanes;
     for (unsigned l = 0; l < std::max(1u, inflight); l++) own.emplace_back(new SegmentProver(params, exe, caps, device)), lanes.push_back(own.back().get());
@@ -558,7 +577,8 @@ public:
             throw Error(Error::Setup, "failed to read or deserialize " + cfg.path_app_exe + ": " + e.what());
         }
         p.params_ = read_app_config(cfg.path_app_config);
-        p.caps_ = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(p.exe_.program.size()), zkhip_vm::keccak_log_rows(cfg.path_app_config, log_frame));
+        p.caps_ = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(p.exe_.program.size()), zkhip_vm::keccak_log_rows(cfg.path_app_config, log_frame),
+                                                   zkhip_vm::sha256_log_rows(cfg.path_app_config, log_frame));
         return p;
     }
     void reset() {   // mod.rs:106-108: releases the device-resident keys, circuits and workspaces

@@ -330,6 +330,9 @@ extern "C" {
                                        d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_vm_keccak_tracegen(ctx: *mut zkhip_ctx, d_states: *const u32, d_ts: *const u32, n_perms: usize, log_height: c_uint,
                                     d_trace: *mut u32) -> c_int;
+    pub fn zkhip_vm_sha256_tracegen(ctx: *mut zkhip_ctx, d_blocks: *const u32, d_ts: *const u32, n_blocks: usize, log_height: c_uint,
+                                    d_trace: *mut u32) -> c_int;
+    pub fn zkhip_vm_sha256_prep(log_height: c_uint, out: *mut u32) -> c_int;
     pub fn zkhip_vm_poseidon2_tracegen(ctx: *mut zkhip_ctx, d_inputs: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;
     pub fn zkhip_rows_tracegen(ctx: *mut zkhip_ctx, d_rows: *const u32, n: usize, width: usize, log_height: c_uint, d_trace: *mut u32,
                                pad_row: *const u32) -> c_int;

@@ -306,6 +306,11 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                 off = rr(10) - data_base
                 assert off % 4 == 0 and 0 <= off and off + 200 <= len(mem)
                 mem[off:off + 200] = keccak_f1600_bytes(bytes(mem[off:off + 200]))
+            elif call == 4:   # SHA-256 compression on the 24 words at a0: state[8] <- compress(state, block[16])
+                off = rr(10) - data_base
+                assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem)
+                buf = list(struct.unpack_from("<24I", mem, off))
+                struct.pack_into("<8I", mem, off, *sha256_compress(buf[:8], buf[8:]))
             else:
                 raise ValueError("ecall %d" % call)
         else:
@@ -314,6 +319,41 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
             rw(rd, val)
         pc = nxt
         n += 1
+
+
+def sha256_constants():
+    """K_t = the first 32 bits of the fractional parts of the cube roots of the first 64 primes (FIPS 180-4 4.2.2), derived here."""
+    primes, c = [], 2
+    while len(primes) < 64:
+        if all(c % q for q in primes):
+            primes.append(c)
+        c += 1
+
+    def icbrt(n):
+        x = int(round(n ** (1 / 3)))
+        while x ** 3 > n:
+            x -= 1
+        while (x + 1) ** 3 <= n:
+            x += 1
+        return x
+    return [icbrt(q << 96) & 0xFFFFFFFF for q in primes]
+
+
+def sha256_compress(h, m):
+    """FIPS 180-4 6.2.2 on words"""
+    k = sha256_constants()
+    rr_ = lambda v, n: ((v >> n) | (v << (32 - n))) & M32  # noqa: E731
+    w = list(m)
+    for t in range(16, 64):
+        s0 = rr_(w[t - 15], 7) ^ rr_(w[t - 15], 18) ^ (w[t - 15] >> 3)
+        s1 = rr_(w[t - 2], 17) ^ rr_(w[t - 2], 19) ^ (w[t - 2] >> 10)
+        w.append((w[t - 16] + s0 + w[t - 7] + s1) & M32)
+    a, b, c, d, e, f, g, hh = h
+    for t in range(64):
+        t1 = (hh + (rr_(e, 6) ^ rr_(e, 11) ^ rr_(e, 25)) + ((e & f) ^ (~e & M32 & g)) + k[t] + w[t]) & M32
+        t2 = ((rr_(a, 2) ^ rr_(a, 13) ^ rr_(a, 22)) + ((a & b) ^ (a & c) ^ (b & c))) & M32
+        a, b, c, d, e, f, g, hh = (t1 + t2) & M32, a, b, c, (d + t1) & M32, e, f, g
+    return [(x + y) & M32 for x, y in zip(h, (a, b, c, d, e, f, g, hh))]
 
 
 def keccak_f1600_bytes(state200):

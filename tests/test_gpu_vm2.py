@@ -17,7 +17,7 @@ import prover_mirror_util as pm
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import fib_program, keccak_data, keccak_program, mixed_program
+from test_vm_cpu import fib_program, keccak_data, keccak_program, mixed_program, sha256_data, sha256_program
 
 pytestmark = pytest.mark.gpu
 PARAMS = (1, 0, 4, 3, 3)
@@ -28,7 +28,7 @@ def device_traces(zk, rec, prog, H):
     """The segment's traces through the device generators, as SegmentProver::prove drives them."""
     dev = zk.device
     D = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.uint32).view(np.int32)).to(dev)  # noqa: E731
-    T = [None] * len(H)
+    T = [None] * v2.N_AIRS
     d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=dev)
     d_tup = torch.zeros(1 << 19, dtype=torch.int32, device=dev)
     d_prog = zk.upload(prog.reshape(-1))
@@ -59,7 +59,11 @@ def device_traces(zk, rec, prog, H):
     T[v2.A_CONNECTOR] = zk.rows_tracegen(D(np.array([ts_end & 0xFFFF, ts_end >> 16], np.uint32)), 1, 2, 0)
     p2in = zk.upload(rec["p2_inputs"])
     T[v2.A_POSEIDON2] = zk.vm_poseidon2_tracegen(p2in, len(rec["p2_inputs"]) // 16, H[v2.A_POSEIDON2])
-    if len(H) > v2.A_KECCAK:
+    if v2.A_SHA256 in H.ids:
+        n_sh = len(rec["sha_ts"])
+        T[v2.A_SHA256] = zk.vm_sha256_tracegen(D(rec["sha_blocks"]) if n_sh else None, D(rec["sha_ts"]) if n_sh else None, n_sh, H[v2.A_SHA256])
+        T[v2.A_SHA256_IO] = zk.rows_tracegen(D(rec["shaio_rows"]), len(rec["shaio_rows"]) // v2.SHA_IO_WIDTH, v2.SHA_IO_WIDTH, H[v2.A_SHA256_IO])
+    if v2.A_KECCAK in H.ids:
         n_kk = len(rec["kk_ts"])
         T[v2.A_KECCAK] = zk.vm_keccak_tracegen(D(rec["kk_states"]) if n_kk else None, D(rec["kk_ts"]) if n_kk else None, n_kk, H[v2.A_KECCAK])
         T[v2.A_KECCAK_IO] = zk.rows_tracegen(D(rec["kio_rows"]), len(rec["kio_rows"]) // v2.KECCAK_IO_WIDTH, v2.KECCAK_IO_WIDTH, H[v2.A_KECCAK_IO])
@@ -92,11 +96,14 @@ def device_traces(zk, rec, prog, H):
         if row[16]:
             bw_x += [int(row[10]), int(row[12])]
             bw_y += [int(row[11]), int(row[13])]
-        if row[27]:
+        if row[27] or row[29]:
             misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
     for row in rec["kio_rows"].reshape(-1, v2.KECCAK_IO_WIDTH):
         misc += [int(row[36]), int(row[39])]
         tup_y += [int(row[37]), int(row[40])]
+    for row in rec["shaio_rows"].reshape(-1, v2.SHA_IO_WIDTH):
+        misc += [int(row[31])]
+        tup_y += [int(row[32])]
     for row in rec["leaf_rows"].reshape(-1, v2.LEAF_WIDTH):
         misc += [int(row[39]), int(row[40]) * 16, int(row[40]), int(row[41]), int(row[42]) * 64, int(row[42])]
     d_rng = zk.range_counts_tracegen(zk.upload(np.array(misc, np.uint32)), 16, t_counts=d_rng, accumulate=True)
@@ -105,7 +112,7 @@ def device_traces(zk, rec, prog, H):
     if bw_x:
         zk.bitwise_lookup_tracegen(zk.upload(np.array(bw_x, np.uint32)), zk.upload(np.array(bw_y, np.uint32)), zeros[:len(bw_x)], 8, d_bw, accumulate=True)
     T[v2.A_BITWISE], T[v2.A_RANGE_TUPLE], T[v2.A_RANGE] = d_bw, d_tup, d_rng
-    return T
+    return [T[a] for a in H.ids]   # proof order
 
 
 @pytest.fixture(scope="module")
@@ -223,6 +230,45 @@ def test_keccak_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     upv = pm.un_b64_bincode(root["user_pvs_proof"])
     assert upv[4 * 34:4 * 34 + 28] == hashlib.sha3_256(msg).digest()[:28] and upv[4 * 34:4 * 34 + 32] == bytes(model["pvs"])
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
+
+
+def test_sha256_guest_device_traces_and_one_proof(zk, ora, tmp_path):
+    """A guest hashing a three-block message with the sha256 intrinsic under an app with both hash extensions (26 chips): device traces
+    == CPU twins, proof bytes == the oracle's; the whole flow from the ELF: the root's public values carry hashlib's SHA-256 digest."""
+    import hashlib
+
+    msg = bytes(range(150))
+    data, n_blocks = sha256_data(msg)
+    words = sha256_program(n_blocks)
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 5, 8)
+    k = next(i for i, s in enumerate(segs) if len(s["sha_ts"]))
+    inst = v2.segment_instance(segs[k], words, PC_BASE, H)
+    T = device_traces(zk, segs[k], v2.program_table(words, PC_BASE, H[0]), H)
+    assert len(inst) == len(T) == 26
+    for a, d in enumerate(inst):
+        assert (zk.download(T[a]).reshape(d["width"], -1) == d["trace"]).all(), "position %d" % a
+    pk = z.ProvingKey(zk, PARAMS, inst)
+    pvs = [d["pvs"] for d in inst]
+    proof = pk.prove(T, pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, inst).tobytes()
+    pk.close()
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words, data=data))
+    (tmp_path / "openvm.toml").write_text(pm.TOML.format(*PARAMS) + "\n[app_vm_config.sha256]\n")
+    r = subprocess.run([pm.CLI, "prove-elf", str(exe), "-", str(tmp_path), str(tmp_path / "openvm.toml"), "8"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    model = rv.run(words, b"", data=data)
+    assert out["verified"] and out["total_cycles"] == model["instret"]
+    upv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])
+    pv = upv[4 * 34:4 * 34 + 32]
+    assert b"".join(int.from_bytes(pv[4 * k:4 * k + 4], "little").to_bytes(4, "big") for k in range(8)) == hashlib.sha256(msg).digest()
+    assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
+    # the same guest under an app without the extension has no proof
+    (tmp_path / "plain.toml").write_text(pm.TOML.format(*PARAMS))
+    r = subprocess.run([pm.CLI, "prove-elf", str(exe), "-", str(tmp_path), str(tmp_path / "plain.toml"), "8"], capture_output=True, text=True)
+    assert r.returncode != 0 and "does not enable the sha256 extension" in r.stderr
 
 
 def test_gen_proof_universal_from_an_elf_and_witness_bytes(tmp_path):

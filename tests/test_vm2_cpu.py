@@ -17,7 +17,7 @@ from zkvm_prover_amd import air
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import fib_program, keccak_data, keccak_program, mixed_program
+from test_vm_cpu import fib_program, keccak_data, keccak_program, mixed_program, sha256_data, sha256_program
 
 PARAMS = (1, 0, 4, 3, 3)
 PC_BASE = 0x00200000
@@ -158,7 +158,7 @@ def test_keccak_intrinsic_is_part_of_the_statement(tmp_path):
     assert bytes(model["pvs"])[:28] == digest[:28]                       # (word 7 is folded with the second permutation's output)
     info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 6)   # room for two calls per segment
     assert bytes.fromhex(info["public_values"]) == bytes(model["pvs"]) and info["total_cycle"] == model["instret"]
-    assert sum(len(s["kk_ts"]) for s in segs) == 2 and len(H) == 24
+    assert sum(len(s["kk_ts"]) for s in segs) == 2 and len(H.ids) == 24
     with pytest.raises(AssertionError, match="does not enable the keccak extension"):   # the same guest under an app without it
         v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)
     for k, rec in enumerate(segs):
@@ -176,6 +176,41 @@ def test_keccak_intrinsic_is_part_of_the_statement(tmp_path):
     rec = {n: v.copy() for n, v in segs[k].items()}
     rec["kk_states"][5] ^= 1                                              # the chip permutes another state than the memory holds
     assert 13 in v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
+
+
+def test_sha256_intrinsic_is_part_of_the_statement(tmp_path):
+    """A guest that hashes a three-block message with the sha256 intrinsic under an app with BOTH hash extensions (26 chips): the
+    revealed digest is hashlib's (FIPS 180-4), every trace satisfies its AIR, every bus balances; forged words break the buses."""
+    import hashlib
+
+    msg = bytes(range(150))
+    data, n_blocks = sha256_data(msg)
+    words = sha256_program(n_blocks)
+    model = rv.run(words, b"", data=data)
+    digest = hashlib.sha256(msg).digest()
+    assert b"".join(int.from_bytes(bytes(model["pvs"])[4 * k:4 * k + 4], "little").to_bytes(4, "big") for k in range(8)) == digest
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 5, 8)
+    assert bytes.fromhex(info["public_values"]) == bytes(model["pvs"]) and info["total_cycle"] == model["instret"]
+    assert sum(len(s["sha_ts"]) for s in segs) == n_blocks == 3 and len(H.ids) == 26
+    for k, rec in enumerate(segs):
+        inst = v2.segment_instance(rec, words, PC_BASE, H)
+        for d in inst:
+            assert air.quotient_chunks(d["program"]) <= 2
+            assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], k
+        assert v2.bus_imbalance(inst) == {}
+    k = next(i for i, s in enumerate(segs) if len(s["sha_ts"]))
+    rec = {n: v.copy() for n, v in segs[k].items()}
+    rec["shaio_rows"].reshape(-1, v2.SHA_IO_WIDTH)[2, 28] ^= 1            # a state word written that the compression does not produce
+    bad = v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
+    assert 16 in bad and 1 in bad                                         # state bus, memory bus
+    rec = {n: v.copy() for n, v in segs[k].items()}
+    rec["sha_blocks"][8 + 3] ^= 1                                         # the chip compresses another message word than the memory holds
+    assert 15 in v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
+    # sha256 alone (24 chips: the extension chips follow the base chips in the order of their ids)
+    info, H2, segs2, _, _ = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 8)
+    assert H2.ids[-2:] == (v2.A_SHA256, v2.A_SHA256_IO) and len(H2.ids) == 24
+    inst = v2.segment_instance(segs2[0], words, PC_BASE, H2)
+    assert all(air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [] for d in inst) and v2.bus_imbalance(inst) == {}
 
 
 def test_decode_table_against_an_independent_decoder(mixed):

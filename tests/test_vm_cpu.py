@@ -61,6 +61,32 @@ def keccak_data(msg):
     return bytes(blk)
 
 
+def sha256_program(n_blocks):
+    """SHA-256 of a padded message through the sha256 intrinsic (a7 = 4): the buffer at the data base holds the state (IV) and one
+    block; the following blocks sit behind it and are copied into the buffer's block slot one after the other (sha256_data); the eight
+    digest words are revealed."""
+    p = rv.li(S0, 0x00400000)
+    for b in range(n_blocks):
+        if b:
+            for k in range(16):                                            # next block into the buffer's message slot
+                p += [("lw", T0, S0, 96 + 64 * (b - 1) + 4 * k), ("sw", T0, S0, 32 + 4 * k)]
+        p += [("add", A0, S0, 0), ("addi", A7, 0, 4), ("ecall",)]
+    for k in range(8):
+        p += [("lw", A0, S0, 4 * k), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
+def sha256_data(msg):
+    """IV | first block | further blocks: words as plain little-endian u32 values of the big-endian message words (FIPS 180-4 5.1.1, 5.2.1)"""
+    import struct
+
+    iv = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+    data = msg + b"\x80" + b"\x00" * ((55 - len(msg)) % 64) + (8 * len(msg)).to_bytes(8, "big")
+    words = struct.unpack(">%dI" % (len(data) // 4), data)
+    return struct.pack("<8I", *iv) + struct.pack("<%dI" % len(words), *words), len(data) // 64
+
+
 def mixed_program():
     """every instruction class: a checksum over a table in memory with multiplies, comparisons, shifts, division, bytes"""
     p = [("addi", A7, 0, 2), ("ecall",), ("add", S0, A0, 0)]          # seed

@@ -17,8 +17,9 @@ CLI = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
 P = ora.P
 NOPV = np.zeros(0, np.uint32)
 (A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
- A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, N_AIRS) = range(25)
-PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 29, 43, 54, 42, 2634
+ A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, N_AIRS) = range(27)
+PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 30, 43, 54, 42, 2634
+SHA_IO_WIDTH, SHA_WIDTH = 34, 434
 TS_STEP, GAP_HI_BITS = 16, 11
 SX, SY = 256, 2048
 
@@ -47,18 +48,28 @@ def program_table(words, pc_base, log_program):
     return out
 
 
-def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0):
+class Heights(list):
+    """heights[AirId] of the app's chips (None for an absent extension chip); .ids = the chips in proof order"""
+    ids = ()
+
+
+def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0):
     """Runs the C++ segmenting executor; returns (info json, heights, [segment record dicts], image root, pv openings)."""
     import json
 
     d = str(tmp)
     open(os.path.join(d, "exe.bin"), "wb").write(exe_bytes)
     open(os.path.join(d, "stdin.bin"), "wb").write(stdin)
-    r = subprocess.run([CLI, "dump-segments", os.path.join(d, "exe.bin"), os.path.join(d, "stdin.bin"), d, str(log_frame), str(log_keccak)],
+    r = subprocess.run([CLI, "dump-segments", os.path.join(d, "exe.bin"), os.path.join(d, "stdin.bin"), d, str(log_frame), str(log_keccak), str(log_sha256)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
-    heights = np.fromfile(os.path.join(d, "heights.u32"), dtype=np.uint32).tolist()
+    by_pos = np.fromfile(os.path.join(d, "heights.u32"), dtype=np.uint32).tolist()
+    ids = np.fromfile(os.path.join(d, "air_ids.u32"), dtype=np.uint32).tolist()
+    heights = Heights([None] * N_AIRS)
+    heights.ids = tuple(ids)
+    for i, h in zip(ids, by_pos):
+        heights[i] = h
     segs = []
     for k in range(info["segments"]):
         sd = os.path.join(d, "seg-%d" % k)
@@ -140,12 +151,45 @@ def keccak_traces(rec, H):
     return kk, rows_trace(rec["kio_rows"], KECCAK_IO_WIDTH, H[A_KECCAK_IO])
 
 
+def sha256_vm_prep(log_height):
+    """the VM SHA-256 chip's nine preprocessed columns (K_t limbs, round / final / first / schedule / input / digest gates, round index),
+    written here from the chip's description with K_t derived in tests/rv32_model.py"""
+    import rv32_model as rv
+
+    k = rv.sha256_constants()
+    n = 1 << log_height
+    p = np.zeros((9, n), np.uint32)
+    for b in range(n // 65):
+        for t in range(65):
+            row = 65 * b + t
+            if t < 64:
+                p[0, row], p[1, row] = k[t] & 0xFFFF, k[t] >> 16
+            p[2, row], p[3, row], p[4, row], p[5, row] = t < 63, t == 63, t == 0, 15 <= t < 63
+            p[6, row], p[7, row], p[8, row] = t < 16, t == 64, t
+    return p
+
+
+def sha256_traces(rec, H):
+    """sha256 calls: the oracle's compression-chip trace + the call's timestamp on its rows; the adapter's rows as the executor wrote them"""
+    n = len(rec["sha_ts"])
+    tr = np.zeros((SHA_WIDTH, 1 << H[A_SHA256]), np.uint32)
+    lib = ora.lib()
+    lib.ora_sha256_trace.restype = None
+    lib.ora_sha256_trace.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_uint, C.POINTER(C.c_uint32)]
+    body = np.zeros((SHA_WIDTH - 1, 1 << H[A_SHA256]), np.uint32)
+    blocks = np.ascontiguousarray(rec["sha_blocks"], dtype=np.uint32)
+    lib.ora_sha256_trace(ora.p32(blocks) if n else None, n, H[A_SHA256], ora.p32(body))
+    tr[:SHA_WIDTH - 1] = body
+    tr[SHA_WIDTH - 1, :65 * n] = np.repeat(rec["sha_ts"], 65)
+    return tr, rows_trace(rec["shaio_rows"], SHA_IO_WIDTH, H[A_SHA256_IO])
+
+
 def segment_instance(rec, words, pc_base, heights):
     """The 24 AIR dicts (program, shapes, trace, pvs[, prep]) of one segment, traces from the CPU twins."""
     H = heights
-    shapes = vm_airs()[:len(H)]   # 22 chips, or 24 with the keccak extension
+    all_shapes = vm_airs()
     prog = program_table(words, pc_base, H[A_PROGRAM])
-    tr = [None] * len(H)
+    tr = [None] * N_AIRS
     freq, bad = ora.program_freq_trace(rec["pc_index"], H[A_PROGRAM])
     assert bad == 0
     tr[A_PROGRAM] = freq.reshape(1, -1)
@@ -172,8 +216,10 @@ def segment_instance(rec, words, pc_base, heights):
     p2[:298] = ora.poseidon2_air_trace(p2in, H[A_POSEIDON2])
     p2[298, :len(p2in)] = 1
     tr[A_POSEIDON2] = p2
-    if len(H) > A_KECCAK:
+    if A_KECCAK in H.ids:
         tr[A_KECCAK], tr[A_KECCAK_IO] = keccak_traces(rec, H)
+    if A_SHA256 in H.ids:
+        tr[A_SHA256], tr[A_SHA256_IO] = sha256_traces(rec, H)
     meta = rec["meta"]
     pc_start, pc_end, ts_end, n_instr = (int(x) for x in meta[:4])
     tr[A_CONNECTOR] = np.array([[ts_end & 0xFFFF], [ts_end >> 16]], np.uint32)
@@ -203,12 +249,15 @@ def segment_instance(rec, words, pc_base, heights):
         if row[16]:
             rc[int(row[10]) * 256 + int(row[11])] += 1
             rc[int(row[12]) * 256 + int(row[13])] += 1
-        if row[27]:
+        if row[27] or row[29]:
             misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
     for row in rec["kio_rows"].reshape(-1, KECCAK_IO_WIDTH):
         misc += [int(row[36]), int(row[39])]
         tc[int(row[37])] += 1
         tc[int(row[40])] += 1
+    for row in rec["shaio_rows"].reshape(-1, SHA_IO_WIDTH):
+        misc += [int(row[31])]
+        tc[int(row[32])] += 1
     for row in rec["leaf_rows"].reshape(-1, LEAF_WIDTH):
         misc += [int(row[39]), int(row[40]) * 16, int(row[40]), int(row[41]), int(row[42]) * 64, int(row[42])]
     cnt += np.bincount(np.array(misc, dtype=np.int64), minlength=1 << 16)
@@ -220,9 +269,12 @@ def segment_instance(rec, words, pc_base, heights):
 
     preps = {A_PROGRAM: prog, A_BITWISE: air.bitwise_lookup_prep(8), A_RANGE_TUPLE: air.range_tuple_prep(SX, SY),
              A_RANGE: np.arange(1 << 16, dtype=np.uint32).reshape(1, -1)}
+    if A_SHA256 in H.ids:
+        preps[A_SHA256] = sha256_vm_prep(H[A_SHA256])
     pvs = {A_MERKLE: np.concatenate([meta[4:12], meta[12:20]]).astype(np.uint32), A_CONNECTOR: np.array([pc_start, pc_end], np.uint32)}
     out = []
-    for a, (program, width, n_pvs, pw) in enumerate(shapes):
+    for a in H.ids:   # proof order
+        program, width, n_pvs, pw = all_shapes[a]
         d = dict(program=program, log_height=H[a], width=width, n_pvs=n_pvs, trace=tr[a], pvs=pvs.get(a, NOPV))
         assert tr[a].shape == (width, 1 << H[a]), (a, tr[a].shape, width, H[a])
         if pw:

@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
             try {
                 const zkhip_vm::Exe exe = zkhip_vm::parse_exe(raw);
                 const zkhip_vm::SegmentCaps caps = zkhip_vm::SegmentCaps::for_frame((unsigned)atoi(argv[5]), zkhip_vm::vm_log2_ceil(exe.program.size()),
-                                                                                    argc >= 7 ? (unsigned)atoi(argv[6]) : 0u);
+                                                                                    argc >= 7 ? (unsigned)atoi(argv[6]) : 0u, argc >= 8 ? (unsigned)atoi(argv[7]) : 0u);
                 zkhip_vm::SegmentExecutor ex(exe, in, caps);
                 zkhip_vm::SegmentRecords r;
                 size_t k = 0;
@@ -78,13 +78,16 @@ int main(int argc, char** argv) {
                     PUT("ecall_rows", r.ecall_rows), PUT("leaf_rows", r.leaf_rows), PUT("merkle_rows", r.merkle_rows), PUT("p2_inputs", r.p2_inputs);
                     PUT("f_pts1", r.f_pts1), PUT("f_pts2", r.f_pts2), PUT("f_pts3", r.f_pts3), PUT("ls_pts", r.ls_pts);
                     PUT("kk_states", r.kk_states), PUT("kk_ts", r.kk_ts), PUT("kio_rows", r.kio_rows);
+                    PUT("sha_blocks", r.sha_blocks), PUT("sha_ts", r.sha_ts), PUT("shaio_rows", r.shaio_rows);
 #undef PUT
                     std::vector<uint32_t> meta{r.pc_start, r.pc_end, r.ts_end, (uint32_t)r.n_instr};
                     meta.insert(meta.end(), r.root_init.begin(), r.root_init.end());
                     meta.insert(meta.end(), r.root_final.begin(), r.root_final.end());
                     put(d + "/meta.u32", meta);
                 }
-                std::vector<uint32_t> heights(caps.log_height, caps.log_height + caps.n_airs);
+                std::vector<uint32_t> heights;
+                for (unsigned id : caps.ids) heights.push_back(caps.log_height[id]);
+                put(std::string(argv[4]) + "/air_ids.u32", std::vector<uint32_t>(caps.ids.begin(), caps.ids.end()));
                 put(std::string(argv[4]) + "/heights.u32", heights);
                 std::vector<uint32_t> fin(ex.image_root().begin(), ex.image_root().end());
                 const std::vector<uint32_t> op = zkhip_vm::open_public_values(ex.tree());
@@ -134,9 +137,9 @@ int main(int argc, char** argv) {
                 try {
                     const zkhip_vm::SegmentCaps caps = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(up.exe().program.size()));
                     const zkhip_params params = read_app_config(cfg_path);
-                    const unsigned log_keccak = zkhip_vm::keccak_log_rows(cfg_path, log_frame);
+                    const unsigned log_keccak = zkhip_vm::keccak_log_rows(cfg_path, log_frame), log_sha256 = zkhip_vm::sha256_log_rows(cfg_path, log_frame);
                     const unsigned lanes = getenv("ZKHIP_LANES") ? (unsigned)atoi(getenv("ZKHIP_LANES")) : 2u;   // segment provers in flight
-                    const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false, lanes, log_keccak);
+                    const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false, lanes, log_keccak, log_sha256);
                     (void)caps;
                     sp = UniversalProver::encode(g);
                     std::string why;

@@ -180,6 +180,8 @@ def load_library():
         "zkhip_vm_loadstore_tracegen": (C.c_int, [vp] * 8 + [sz, C.c_uint, vp, vp]),
         "zkhip_vm_poseidon2_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
         "zkhip_vm_keccak_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp]),
+        "zkhip_vm_sha256_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp]),
+        "zkhip_vm_sha256_prep": (C.c_int, [C.c_uint, u32p]),
         "zkhip_rows_tracegen": (C.c_int, [vp, vp, sz, sz, C.c_uint, vp, u32p]),
         "zkhip_range_counts_scaled_tracegen": (C.c_int, [vp, vp, sz, C.c_uint32, C.c_uint, vp, C.c_int]),
         "zkhip_recursion_build": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, sz, C.POINTER(_RecursionStmt), C.POINTER(vp)]),
@@ -605,6 +607,12 @@ class Context:
     def vm_keccak_tracegen(self, t_states, t_ts, n_perms, log_height):
         out = self._new(2634 << log_height)
         self._check(self.lib.zkhip_vm_keccak_tracegen(self.h, t_states.data_ptr() if n_perms else None, t_ts.data_ptr() if n_perms else None, n_perms,
+                                                      log_height, out.data_ptr()))
+        return out
+
+    def vm_sha256_tracegen(self, t_blocks, t_ts, n_blocks, log_height):
+        out = self._new(434 << log_height)
+        self._check(self.lib.zkhip_vm_sha256_tracegen(self.h, t_blocks.data_ptr() if n_blocks else None, t_ts.data_ptr() if n_blocks else None, n_blocks,
                                                       log_height, out.data_ptr()))
         return out
 

@@ -119,6 +119,14 @@ __global__ __launch_bounds__(256) void k_sha256_trace(const uint32_t* __restrict
     put(sh::COL_CARRY_W + 2, (cwh & 1u) ? ONE : 0u), put(sh::COL_CARRY_W + 3, (cwh & 2u) ? ONE : 0u);
 }
 
+// the VM chip's timestamp column: every row of block b carries the call's timestamp, the padding blocks and the tail zero
+__global__ __launch_bounds__(256) void k_sha256_ts(const uint32_t* __restrict__ ts, size_t n_blocks, size_t N, uint32_t* __restrict__ col) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    const size_t blk = row / sh::ROWS_PER_BLOCK;
+    col[row] = blk < n_blocks ? to_monty(ts[blk] % P) : 0u;
+}
+
 std::mutex g_mu;
 std::vector<uint32_t> g_program;
 std::map<unsigned, std::vector<uint32_t>> g_prep;   // log_height -> preprocessed trace (kept for the life of the process)
@@ -163,6 +171,25 @@ int zkhip_sha256_tracegen(zkhip_ctx* ctx, const uint32_t* d_blocks, size_t n_blo
     KernelScope ks(ctx, "sha256_tracegen");
     hipLaunchKernelGGL(k_sha256_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_blocks, n_blocks, N, d_trace);
     ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+int zkhip_vm_sha256_tracegen(zkhip_ctx* ctx, const uint32_t* d_blocks, const uint32_t* d_ts, size_t n_blocks, unsigned log_height, uint32_t* d_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || (n_blocks && !d_ts)) return ZKHIP_ERR_INVALID;
+    ZK_TRY(zkhip_sha256_tracegen(ctx, d_blocks, n_blocks, log_height, d_trace));
+    const size_t N = (size_t)1 << log_height;
+    KernelScope ks(ctx, "vm_sha256_timestamps");
+    hipLaunchKernelGGL(k_sha256_ts, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_ts, n_blocks, N, d_trace + (size_t)sh::COL_TS * N);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+/* preprocessed trace of the VM chip (9 columns x 2^log_height rows, column-major, canonical) */
+int zkhip_vm_sha256_prep(unsigned log_height, uint32_t* out) {
+    if (!out || log_height < 7 || log_height > 24) return ZKHIP_ERR_INVALID;
+    const std::vector<uint32_t> p = sh::prep_trace_vm(log_height);
+    memcpy(out, p.data(), p.size() * 4);
     return ZKHIP_OK;
 }
 
