@@ -380,9 +380,9 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     std::condition_variable cv_push, cv_pop;
     bool closed = false, failed = false;
     std::string error;
-    std::vector<SegmentProof> proofs;
+    std::deque<SegmentProof> proofs;   // (a deque: verifier threads read finished proofs while later ones are still being added)
     std::vector<std::thread> workers, verifiers;
-    std::deque<size_t> to_verify;
+    std::deque<std::pair<size_t, const SegmentProof*>> to_verify;   // (element addresses of a deque stay put while it grows)
     bool proving_done = false;
     const auto t_start = clk::now();
     // the aggregation tree runs as a stream beside the segment proving: a leaf node starts when its four segment proofs exist
@@ -405,7 +405,7 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
                     std::lock_guard<std::mutex> lk(mu);
                     if (proofs.size() <= it.index) proofs.resize(it.index + 1);
                     proofs[it.index] = std::move(p);
-                    to_verify.push_back(it.index);
+                    to_verify.push_back({it.index, &proofs[it.index]});
                     pool.push_back(std::move(it.rec));
                     cv_pop.notify_all();
                 }
@@ -421,14 +421,15 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
         verifiers.emplace_back([&] {
             for (;;) {
                 size_t k;
+                const SegmentProof* made;
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     cv_pop.wait(lk, [&] { return !to_verify.empty() || proving_done || failed; });
                     if (to_verify.empty()) return;
-                    k = to_verify.front();
+                    k = to_verify.front().first, made = to_verify.front().second;
                     to_verify.pop_front();
                 }
-                if (!seg_vk.verify(proofs[k].proof)) {
+                if (!seg_vk.verify(made->proof)) {
                     std::lock_guard<std::mutex> lk(mu);
                     if (error.empty()) error = "the proof of segment " + std::to_string(k) + " does not verify";
                     failed = true;
@@ -496,7 +497,7 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     g.segments = n_seg;
     std::vector<ChildProof> seg_proofs;
     for (auto& p : proofs) seg_proofs.push_back(p.proof), g.sum_segment_tracegen_mills += p.tracegen_mills, g.sum_segment_prove_mills += p.proving_mills;
-    if (keep_segments) g.segment_proofs = std::move(proofs);
+    if (keep_segments) g.segment_proofs.assign(std::make_move_iterator(proofs.begin()), std::make_move_iterator(proofs.end()));
     const auto t0 = clk::now();
     const scroll_zkvm_hip::AggregationPlan plan = scroll_zkvm_hip::AggregationPlan::build(seg_proofs.size());
     g.root = tree.finish(seg_proofs.size());   // (what is left of the tree once the last segment proof exists)
