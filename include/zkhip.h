@@ -625,6 +625,20 @@ int zkhip_sha256_compress_host(uint32_t state[8], const uint32_t block[16]);
  * b, row 65 b + 64 = H_out (state columns), further whole blocks = compressions of the zero record with real = 0, the tail rows zero */
 int zkhip_sha256_tracegen(zkhip_ctx *ctx, const uint32_t *d_blocks, size_t n_blocks, unsigned log_height, uint32_t *d_trace);
 
+/* ---- modular multiplication chip (include/zkhip_modular.hpp: r = a b mod P for a 256-bit modulus on byte limbs, one multiplication per
+ *      row, 286 columns, degree 3; byte pairs looked up in the 8-bit bitwise table, carries in the range-tuple table;
+ *      crates/circuits/chunk-circuit/openvm.toml:8-59 lists `modular` with the secp256k1 / bn254 / bls12-381 moduli; OpenVM's chip is
+ *      openvm-algebra-circuit's ModularMulDiv, un-vendored).  Pinned to Python's integers (tests/golden/modular_kat.json). ---- */
+#define ZKHIP_MODMUL_WIDTH 286
+/* the AIR for one modulus (32 little-endian bytes, non-zero) sending on the given buses; pointers valid for the life of the process */
+int zkhip_modmul_air(const uint8_t modulus[32], uint32_t bitwise_bus, uint32_t tuple_bus, zkhip_air *out);
+/* (q, r) = divmod(a b, modulus) on little-endian 32-bit words (host); ZKHIP_ERR_INVALID if q does not fit 256 bits */
+int zkhip_modmul_host(const uint32_t a[8], const uint32_t b[8], const uint32_t modulus[8], uint32_t q[8], uint32_t r[8]);
+/* d_records: n x 16 words (a[8] | b[8], little-endian words, plain integers); fills 2^log_height rows and adds the rows' lookups to
+ * the bitwise table's range column (d_bitwise_trace, 8-bit table) and to the range-tuple table d_tuple_counts (size_x >= 256) */
+int zkhip_modmul_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace,
+                          uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+
 /* ---- aggregation layer: the verifier circuit.  Replaces, for this backend's proofs, the leaf /
  *      internal verifier programs the reference's SDK proves at the nodes of its aggregation tree and `commit_child_vk`
  *      (crates/prover/src/prover/mod.rs:47-60, 200-282; crates/integration/src/lib.rs:461-514).  A circuit is built for ONE

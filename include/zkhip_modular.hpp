@@ -1,0 +1,123 @@
+// zkhip_modular.hpp -- modular multiplication over a 256-bit modulus (crates/circuits/chunk-circuit/openvm.toml:8-59
+// lists `modular` with the secp256k1 / bn254 / bls12-381 field and scalar moduli: the arithmetic under the EVM guest's ecrecover and pairing
+// precompiles).  OpenVM's chips (openvm-algebra-circuit ModularMulDiv over its mod-builder, un-vendored) state r = a b mod P as an integer
+// identity on byte limbs with range-checked carries; this is the same statement in this repository's own columns, ONE multiplication
+// per row:
+//   a[32] b[32] q[32] r[32]   byte limbs (little-endian), each looked up pairwise in the 8-bit bitwise table
+//   carry (cx, cy)[62]        limb position k of a b - q P - r sums to 256 c_k - c_{k-1} with c_k = cx_k + 256 cy_k - 2^14, (cx_k, cy_k) in the
+//                             range-tuple table (cx < 256, cy < 2048): every quantity stays far below the field's characteristic, so the 63
+//                             limb equations hold over the integers and a b = q P + r exactly (the last carry is zero)
+//   marker[32], diff          r < P: the most significant limb where r and P differ is marked, P - r there is in 1..255
+//   real                      rows beyond the records are zero
+// The modulus is a constant of the AIR (one chip per modulus, as OpenVM instantiates one per configured modulus).  a and b are bytes
+// but not required to be reduced; r is the canonical residue.  Every constraint has degree <= 3.
+// External parity: Python's integers (tests/golden/modular_kat.json: random and edge operands for the secp256k1 and bn254 field and
+// scalar moduli) and the secp256k1 generator's curve equation.  Header-only; device generator: csrc/modular.hip.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <vector>
+
+#include "zkhip_air.hpp"
+
+namespace zkhip {
+namespace modular {
+using air::AirBuilder;
+using air::Expr;
+using air::Kind;
+
+constexpr size_t LIMBS = 32, N_CARRY = 2 * LIMBS - 2;
+constexpr size_t COL_A = 0, COL_B = 32, COL_Q = 64, COL_R = 96, COL_CX = 128, COL_CY = COL_CX + N_CARRY, COL_MARK = COL_CY + N_CARRY, COL_DIFF = COL_MARK + LIMBS,
+                 COL_REAL = COL_DIFF + 1, WIDTH = COL_REAL + 1;
+constexpr int64_t CARRY_OFFSET = 1 << 14;
+using Modulus = std::array<uint8_t, LIMBS>;   // little-endian bytes
+
+// AirBuilder(WIDTH, 0); bitwise_bus: (x, y, 0, 0) byte pairs; tuple_bus: (cx, cy)
+inline void modmul_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus, uint32_t tuple_bus) {
+    const Expr real = b.var(COL_REAL), zero = b.constant(0);
+    b.assert_zero(real * (real - 1));
+    auto carry = [&](size_t k) { return b.var(COL_CX + k) + b.var(COL_CY + k) * 256 - CARRY_OFFSET; };
+    for (size_t k = 0; k <= N_CARRY; k++) {   // limb positions 0 .. 62
+        Expr s = b.constant(0);
+        for (size_t i = 0; i < LIMBS; i++) {
+            if (k < i || k - i >= LIMBS) continue;
+            const size_t j = k - i;
+            s = s + b.var(COL_A + i) * b.var(COL_B + j);
+            if (P[j]) s = s - b.var(COL_Q + i) * (int64_t)P[j];
+        }
+        if (k < LIMBS) s = s - b.var(COL_R + k);
+        if (k > 0) s = s + carry(k - 1);
+        if (k < N_CARRY) s = s - carry(k) * 256;   // the carry out of position 62 is zero
+        b.assert_zero(real * s);
+    }
+    // r < P
+    Expr n_marked = b.constant(0), diff = b.constant(0);
+    for (size_t i = 0; i < LIMBS; i++) {
+        const Expr m = b.var(COL_MARK + i);
+        b.assert_zero(m * (m - 1));
+        n_marked = n_marked + m;
+        diff = diff + m * (b.constant(P[i]) - b.var(COL_R + i));
+    }
+    b.assert_zero(n_marked - real);
+    Expr above = b.constant(0);   // markers at limbs above i
+    for (size_t ii = LIMBS; ii-- > 0;) {
+        b.assert_zero((real - above - b.var(COL_MARK + ii)) * (b.var(COL_R + ii) - b.constant(P[ii])));   // equal below no marker yet
+        above = above + b.var(COL_MARK + ii);
+    }
+    b.assert_zero(b.var(COL_DIFF) - diff);
+    b.push_interaction(bitwise_bus, {b.var(COL_DIFF) - real, zero, zero, zero}, real, Kind::Send);   // P - r at the marked limb is 1..255
+    for (size_t base : {COL_A, COL_B, COL_Q, COL_R})
+        for (size_t i = 0; i < LIMBS; i += 2) b.push_interaction(bitwise_bus, {b.var(base + i), b.var(base + i + 1), zero, zero}, real, Kind::Send);
+    for (size_t k = 0; k < N_CARRY; k++) b.push_interaction(tuple_bus, {b.var(COL_CX + k), b.var(COL_CY + k)}, real, Kind::Send);
+}
+
+// 256-bit helpers on little-endian 32-bit words (host; the tests' expected values come from Python, not from here)
+struct U256 {
+    uint32_t w[8];
+};
+inline Modulus modulus_bytes(const U256& p) {
+    Modulus m;
+    for (size_t i = 0; i < LIMBS; i++) m[i] = (uint8_t)(p.w[i / 4] >> (8 * (i % 4)));
+    return m;
+}
+// (q, r) = divmod(a b, p) by binary long division: r < p; q fits 256 bits when a, b < p (returns false otherwise)
+inline bool mulmod(const U256& a, const U256& b, const U256& p, U256* q, U256* r) {
+    uint32_t prod[16] = {};
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+        for (int j = 0; j < 8; j++) {
+            c += (uint64_t)a.w[i] * b.w[j] + prod[i + j];
+            prod[i + j] = (uint32_t)c, c >>= 32;
+        }
+        prod[i + 8] = (uint32_t)c;
+    }
+    uint32_t rem[9] = {}, quo[16] = {};
+    for (int bit = 511; bit >= 0; bit--) {
+        for (int k = 8; k > 0; k--) rem[k] = (rem[k] << 1) | (rem[k - 1] >> 31);
+        rem[0] = (rem[0] << 1) | ((prod[bit / 32] >> (bit % 32)) & 1u);
+        bool ge = rem[8] != 0;
+        if (!ge) {
+            ge = true;
+            for (int k = 7; k >= 0; k--)
+                if (rem[k] != p.w[k]) {
+                    ge = rem[k] > p.w[k];
+                    break;
+                }
+        }
+        if (ge) {
+            uint64_t br = 0;
+            for (int k = 0; k < 9; k++) {
+                const uint64_t d = (uint64_t)rem[k] - (k < 8 ? p.w[k] : 0u) - br;
+                rem[k] = (uint32_t)d, br = (d >> 32) & 1u;
+            }
+            quo[bit / 32] |= 1u << (bit % 32);
+        }
+    }
+    bool fits = true;
+    for (int k = 8; k < 16; k++) fits = fits && quo[k] == 0;
+    for (int k = 0; k < 8; k++) q->w[k] = quo[k], r->w[k] = rem[k];
+    return fits;
+}
+
+}  // namespace modular
+}  // namespace zkhip

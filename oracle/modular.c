@@ -1,0 +1,104 @@
+/* modular.c -- CPU restatement (TEST INFRASTRUCTURE) of the modular-multiplication chip's trace (include/zkhip_modular.hpp;
+ * zkhip_modmul_tracegen): r = a b mod P on byte limbs.  The reference's chip is un-vendored (openvm-algebra-circuit ModularMulDiv,
+ * Cargo.lock); parity is anchored OUTSIDE this repository: Python's integers (tests/golden/modular_kat.json, tests/test_modular_cpu.py).
+ * Written on BYTES (schoolbook product, byte-wise long division with trial subtraction): shares no code with the product. */
+#include <stdint.h>
+#include <string.h>
+
+#include "zk_oracle.h"
+
+/* out[0..63] = a[0..31] * b[0..31], little-endian bytes */
+static void mul_bytes(const uint8_t *a, const uint8_t *b, uint8_t *out) {
+    uint32_t acc[64] = {0};
+    for (int i = 0; i < 32; i++)
+        for (int j = 0; j < 32; j++) acc[i + j] += (uint32_t)a[i] * b[j];
+    uint32_t c = 0;
+    for (int k = 0; k < 64; k++) {
+        c += acc[k];
+        out[k] = (uint8_t)c, c >>= 8;
+    }
+}
+/* does rem (33 bytes) >= p (32 bytes)? */
+static int ge33(const uint8_t *rem, const uint8_t *p) {
+    if (rem[32]) return 1;
+    for (int k = 31; k >= 0; k--)
+        if (rem[k] != p[k]) return rem[k] > p[k];
+    return 1;
+}
+/* (q[64], r[32]) = divmod(x[64], p[32]): one byte of the dividend at a time, the quotient byte by repeated subtraction */
+static void divmod_bytes(const uint8_t *x, const uint8_t *p, uint8_t *q, uint8_t *r) {
+    uint8_t rem[33] = {0};
+    for (int k = 63; k >= 0; k--) {
+        memmove(rem + 1, rem, 32);
+        rem[0] = x[k];
+        unsigned d = 0;
+        while (ge33(rem, p)) {
+            int br = 0;
+            for (int i = 0; i < 33; i++) {
+                const int v = (int)rem[i] - (i < 32 ? p[i] : 0) - br;
+                rem[i] = (uint8_t)(v & 255), br = v < 0;
+            }
+            d++;
+        }
+        q[k] = (uint8_t)d;
+    }
+    memcpy(r, rem, 32);
+}
+
+/* q, r of one product (bytes); returns 0 if the quotient fits 32 bytes */
+int ora_modmul(const uint8_t a[32], const uint8_t b[32], const uint8_t p[32], uint8_t q[32], uint8_t r[32]) {
+    uint8_t x[64], qq[64];
+    mul_bytes(a, b, x);
+    divmod_bytes(x, p, qq, r);
+    memcpy(q, qq, 32);
+    for (int k = 32; k < 64; k++)
+        if (qq[k]) return 1;
+    return 0;
+}
+
+/* trace: 286 columns x 2^log_height rows, column-major, canonical; records[64 i] = a bytes | b bytes; adds the rows' lookups to
+ * bitwise_range[65536] (index 256 x + y) and tuple[256 * size_y] (index x * size_y + y); returns the number of bad records */
+size_t ora_modmul_trace(const uint8_t *records, size_t n, const uint8_t p[32], unsigned log_height, uint32_t *trace, uint32_t *bitwise_range, uint32_t *tuple,
+                        uint32_t size_y) {
+    const size_t N = (size_t)1 << log_height;
+    enum { A = 0, B = 32, Q = 64, R = 96, CX = 128, CY = 190, MARK = 252, DIFF = 284, REAL = 285, WIDTH = 286 };
+    memset(trace, 0, (size_t)WIDTH * N * sizeof(uint32_t));
+    size_t bad = 0;
+    for (size_t row = 0; row < n && row < N; row++) {
+        const uint8_t *a = records + 64 * row, *b = a + 32;
+        uint8_t q[32], r[32];
+        if (ora_modmul(a, b, p, q, r)) bad++;
+#define PUT(col, v) trace[(size_t)(col) * N + row] = (uint32_t)(v)
+        for (int i = 0; i < 32; i++) PUT(A + i, a[i]), PUT(B + i, b[i]), PUT(Q + i, q[i]), PUT(R + i, r[i]);
+        for (int i = 0; i < 32; i += 2)
+            bitwise_range[256 * a[i] + a[i + 1]]++, bitwise_range[256 * b[i] + b[i + 1]]++, bitwise_range[256 * q[i] + q[i + 1]]++, bitwise_range[256 * r[i] + r[i + 1]]++;
+        long long c = 0;
+        for (int k = 0; k <= 62; k++) {
+            long long s = c;
+            for (int i = 0; i < 32; i++) {
+                const int j = k - i;
+                if (j < 0 || j >= 32) continue;
+                s += (long long)a[i] * b[j] - (long long)q[i] * p[j];
+            }
+            if (k < 32) s -= r[k];
+            c = s >> 8; /* exact: a b = q p + r */
+            if (k < 62) {
+                const long long v = c + (1 << 14);
+                PUT(CX + k, v & 255), PUT(CY + k, v >> 8);
+                tuple[(size_t)(v & 255) * size_y + (size_t)(v >> 8)]++;
+            }
+        }
+        int mark = -1;
+        for (int i = 31; i >= 0; i--)
+            if (r[i] != p[i]) {
+                mark = i;
+                break;
+            }
+        if (mark >= 0) PUT(MARK + mark, 1);
+        const unsigned diff = mark >= 0 ? (unsigned)(p[mark] - r[mark]) : 0;
+        PUT(DIFF, diff), PUT(REAL, 1);
+        bitwise_range[256 * ((diff - 1) & 255)]++;
+#undef PUT
+    }
+    return bad;
+}

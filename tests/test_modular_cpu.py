@@ -1,0 +1,101 @@
+"""CPU: the modular-multiplication chip (include/zkhip_modular.hpp) -- parity anchored OUTSIDE this repository.
+  * the oracle's byte-wise divmod (oracle/modular.c) and the product's host function (zkhip_modmul_host) against Python's integers for the
+    secp256k1 / bn254 field and scalar moduli (tests/golden/modular_kat.json); the published secp256k1 generator satisfies the curve
+    equation when computed through them;
+  * the chip's trace (oracle twin of zkhip_modmul_tracegen) with its lookup tables satisfies the AIRs and balances both buses; r and q in
+    the trace are Python's; a changed cell breaks a constraint or a bus; a non-canonical residue (r + P) has no trace; the oracle proves
+    the set and both verifiers accept."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import zkvm_prover_amd as z
+from zkvm_prover_amd import air
+
+import modular_util as mu
+import vm2_util as v2
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PARAMS = (1, 0, 4, 3, 3)
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(os.path.join(HERE, "golden", "modular_kat.json")) as f:
+        return json.load(f)
+
+
+def test_divmod_against_python_integers(ora, kat):
+    mod = {k: int(v, 16) for k, v in kat["moduli"].items()}
+    for c in kat["cases"]:
+        p, a, b, q, r = mod[c["modulus"]], int(c["a"], 16), int(c["b"], 16), int(c["q"], 16), int(c["r"], 16)
+        assert (q, r) == divmod(a * b, p)
+        assert mu.ora_modmul(ora, a, b, p) == (0, q, r)
+        assert z.modmul_host(a, b, p) == (q, r)
+    # the published generator of secp256k1 lies on y^2 = x^3 + 7
+    p = mod["secp256k1_p"]
+    gx, gy = int(kat["secp256k1_generator"]["x"], 16), int(kat["secp256k1_generator"]["y"], 16)
+    y2 = z.modmul_host(gy, gy, p)[1]
+    x3 = z.modmul_host(z.modmul_host(gx, gx, p)[1], gx, p)[1]
+    assert y2 == (x3 + 7) % p and mu.ora_modmul(ora, gy, gy, p)[2] == y2
+
+
+@pytest.mark.parametrize("name", ["secp256k1_p", "bn254_r"])
+def test_trace_satisfies_the_air_and_the_buses_balance(ora, kat, name):
+    p = int(kat["moduli"][name], 16)
+    pairs = [(int(c["a"], 16), int(c["b"], 16)) for c in kat["cases"] if c["modulus"] == name][:13]
+    tr, bw, tup, bad = mu.ora_trace(ora, pairs, p, 4)
+    assert bad == 0
+    inst = mu.instance(p, tr, bw, tup, 4)
+    for d in inst:
+        assert air.quotient_chunks(d["program"]) <= 2
+        assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == []
+    assert v2.bus_imbalance(inst) == {}
+    for row, (a, b) in enumerate(pairs):
+        q, r = divmod(a * b, p)
+        assert bytes(tr[64:96, row].astype(np.uint8)) == q.to_bytes(32, "little") and bytes(tr[96:128, row].astype(np.uint8)) == r.to_bytes(32, "little")
+    rng = np.random.default_rng(3)
+    for _ in range(60):   # any changed cell of a real row: a constraint fails or a lookup has no table entry
+        t2 = tr.copy()
+        c, r_ = int(rng.integers(0, mu.WIDTH)), int(rng.integers(0, len(pairs)))
+        t2[c, r_] = (int(t2[c, r_]) + 1) % 2013265921
+        i2 = mu.instance(p, t2, bw, tup, 4)
+        assert air.check_trace(i2[0]["program"], t2, mu.NOPV) != [] or v2.bus_imbalance(i2) != {}, (c, r_)
+    # the residue r + P with the quotient q - 1 satisfies the integer identity but not r < P
+    a, b = pairs[8]
+    q, r = divmod(a * b, p)
+    if r + p < 1 << 256 and q > 0:
+        forged, _, _, _ = mu.ora_trace(ora, [(a, b)], p, 4)
+        forged[64:96, 0] = np.frombuffer((q - 1).to_bytes(32, "little"), dtype=np.uint8)
+        forged[96:128, 0] = np.frombuffer((r + p).to_bytes(32, "little"), dtype=np.uint8)
+        # (carries recomputed for the forged limbs so that only the range argument is left to object)
+        pb = p.to_bytes(32, "little")
+        c = 0
+        for k in range(63):
+            s = c + sum(int(forged[i, 0]) * int(forged[32 + k - i, 0]) - int(forged[64 + i, 0]) * pb[k - i] for i in range(32) if 0 <= k - i < 32)
+            s -= int(forged[96 + k, 0]) if k < 32 else 0
+            assert s % 256 == 0
+            c = s // 256
+            if k < 62:
+                forged[128 + k, 0], forged[190 + k, 0] = (c + (1 << 14)) & 255, (c + (1 << 14)) >> 8
+        assert c == 0
+        assert air.check_trace(inst[0]["program"], forged, mu.NOPV) != []
+
+
+def test_oracle_proves_the_chip_with_its_tables(ora, kat):
+    p = int(kat["moduli"]["bn254_p"], 16)
+    rng = np.random.default_rng(5)
+    pairs = [(int.from_bytes(rng.bytes(32), "little") % p, int.from_bytes(rng.bytes(32), "little") % p) for _ in range(6)]
+    tr, bw, tup, bad = mu.ora_trace(ora, pairs, p, 3)
+    inst = mu.instance(p, tr, bw, tup, 3)
+    proof = ora.stark_prove(PARAMS, inst)
+    assert ora.stark_verify(PARAMS, inst, proof) == 0
+    vk = []
+    for d in inst:
+        v = {k: d[k] for k in ("program", "log_height", "width", "n_pvs")}
+        if d.get("prep") is not None:
+            v["prep_commit"] = ora.prep_commit(PARAMS, d)
+        vk.append(v)
+    assert z.verify(PARAMS, vk, [mu.NOPV] * 3, proof.tobytes()) == 0

@@ -18,6 +18,8 @@ from ._binding import (  # noqa: F401
     RecursionCircuit,
     keccak_f_air,
     keccak_f1600_host,
+    modmul_air,
+    modmul_host,
     sha256_air,
     sha256_compress_host,
     verify,

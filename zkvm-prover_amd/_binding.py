@@ -169,6 +169,9 @@ def load_library():
         "zkhip_keccak_f_air": (C.c_int, [C.POINTER(_Air)]),
         "zkhip_keccak_f1600_host": (C.c_int, [C.POINTER(C.c_uint64)]),
         "zkhip_keccak_f_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
+        "zkhip_modmul_air": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
+        "zkhip_modmul_host": (C.c_int, [u32p, u32p, u32p, u32p, u32p]),
+        "zkhip_modmul_tracegen": (C.c_int, [vp, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_sha256_air": (C.c_int, [C.c_uint, C.POINTER(_Air)]),
         "zkhip_sha256_compress_host": (C.c_int, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "zkhip_sha256_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
@@ -638,6 +641,13 @@ class Context:
         self._check(self.lib.zkhip_keccak_f_tracegen(self.h, t_states.data_ptr() if n_perms else None, n_perms, log_height, out.data_ptr()))
         return out
 
+    def modmul_tracegen(self, modulus, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
+        out = self._new(286 << log_height)
+        m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
+        self._check(self.lib.zkhip_modmul_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr(),
+                                                   t_tuple_counts.data_ptr(), size_x, size_y))
+        return out
+
     def sha256_tracegen(self, t_blocks, n_blocks, log_height):
         out = self._new(433 << log_height)
         self._check(self.lib.zkhip_sha256_tracegen(self.h, t_blocks.data_ptr() if n_blocks else None, n_blocks, log_height, out.data_ptr()))
@@ -910,6 +920,29 @@ def keccak_f1600_host(lanes):
     st = np.ascontiguousarray(lanes, dtype=np.uint64).copy()
     assert st.size == 25 and load_library().zkhip_keccak_f1600_host(st.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
     return st
+
+
+def _int_words(v):
+    """a non-negative integer below 2^256 as eight little-endian 32-bit words"""
+    return [(int(v) >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+
+
+def modmul_air(modulus, bitwise_bus, tuple_bus):
+    """The modular-multiplication chip's AIR for `modulus` (an integer): (program, width); its one definition is include/zkhip_modular.hpp."""
+    lib = load_library()
+    a = _Air()
+    m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
+    assert lib.zkhip_modmul_air(m, bitwise_bus, tuple_bus, C.byref(a)) == 0
+    return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
+
+
+def modmul_host(a, b, modulus):
+    """(q, r) = divmod(a * b, modulus) through the library's host function (integers in, integers out)"""
+    wa, wb, wm = (np.array(_int_words(v), dtype=np.uint32) for v in (a, b, modulus))
+    q, r = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
+    rc = load_library().zkhip_modmul_host(_u32p(wa), _u32p(wb), _u32p(wm), _u32p(q), _u32p(r))
+    assert rc == 0
+    return sum(int(x) << (32 * i) for i, x in enumerate(q)), sum(int(x) << (32 * i) for i, x in enumerate(r))
 
 
 def sha256_air(log_height):

@@ -1,0 +1,196 @@
+// modular.hip -- the modular-multiplication chip on the device (include/zkhip_modular.hpp: r = a b mod P on byte limbs, one multiplication
+// per row, 286 columns).  Record = a[8] | b[8] (little-endian 32-bit words).  One lane per row: schoolbook product, binary long division
+// by the modulus (512 shift-compare-subtract steps on nine words: ~20 k integer operations next to 286 stores and 127 table increments),
+// then the carries of the limb equations; the row's lookups (65 byte pairs, 62 carry tuples) are counted into the bitwise and range-tuple
+// tables in the same pass (wave-merged atomics, csrc/hist.hpp).  Replaces the trace generation of OpenVM's ModularMulDiv chip
+// (openvm-algebra-circuit, un-vendored).
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/zkhip.h"
+#include "../../include/zkhip_modular.hpp"
+#include "babybear.hpp"
+#include "hist.hpp"
+#include "zkhip_internal.hpp"
+
+namespace zk {
+namespace {
+namespace md = zkhip::modular;
+
+struct ModWords {
+    uint32_t w[8];
+};
+
+__global__ void k_mod_repr(uint32_t* c, size_t n, int to_m) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) c[i] = to_m ? to_monty(c[i] % P) : from_monty(c[i]);
+}
+
+__global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict__ recs, size_t n, size_t N, ModWords pm, uint32_t* __restrict__ trace,
+                                                      uint32_t* __restrict__ bitwise_range, uint32_t* __restrict__ tuple, uint32_t tuple_y,
+                                                      uint32_t* __restrict__ bad) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    if (row >= n) {
+        for (size_t c = 0; c < md::WIDTH; c++) trace[c * N + row] = 0u;
+        return;
+    }
+    uint32_t a[8], b[8], prod[16], rem[9], quo[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = recs[16 * row + i], b[i] = recs[16 * row + 8 + i];
+#pragma unroll
+    for (int i = 0; i < 16; i++) prod[i] = 0;
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+        for (int j = 0; j < 8; j++) {
+            c += (uint64_t)a[i] * b[j] + prod[i + j];
+            prod[i + j] = (uint32_t)c, c >>= 32;
+        }
+        prod[i + 8] = (uint32_t)c;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) rem[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) quo[i] = 0;
+    bool overflow = false;
+    for (int bit = 511; bit >= 0; bit--) {
+        for (int k = 8; k > 0; k--) rem[k] = (rem[k] << 1) | (rem[k - 1] >> 31);
+        rem[0] = (rem[0] << 1) | ((prod[bit >> 5] >> (bit & 31)) & 1u);
+        bool ge = rem[8] != 0;
+        if (!ge) {
+            ge = true;
+            for (int k = 7; k >= 0; k--)
+                if (rem[k] != pm.w[k]) {
+                    ge = rem[k] > pm.w[k];
+                    break;
+                }
+        }
+        if (ge) {
+            uint32_t br = 0;
+            for (int k = 0; k < 9; k++) {
+                const uint64_t d = (uint64_t)rem[k] - (k < 8 ? pm.w[k] : 0u) - br;
+                rem[k] = (uint32_t)d, br = (uint32_t)(d >> 32) & 1u;
+            }
+            if (bit >= 256) overflow = true;
+            else quo[bit >> 5] |= 1u << (bit & 31);
+        }
+    }
+    if (overflow) atomicAdd(bad, 1u);   // the quotient does not fit 256 bits: operands far above the modulus
+    auto byte_of = [](const uint32_t* w, int i) -> uint32_t { return (w[i >> 2] >> (8 * (i & 3))) & 255u; };
+    auto put = [&](size_t col, uint32_t v) { trace[col * N + row] = to_monty(v); };
+    for (int i = 0; i < 32; i++) {
+        put(md::COL_A + i, byte_of(a, i)), put(md::COL_B + i, byte_of(b, i)), put(md::COL_Q + i, byte_of(quo, i)), put(md::COL_R + i, byte_of(rem, i));
+    }
+    for (int i = 0; i < 32; i += 2) {
+        hist_add(bitwise_range, byte_of(a, i) * 256 + byte_of(a, i + 1)), hist_add(bitwise_range, byte_of(b, i) * 256 + byte_of(b, i + 1));
+        hist_add(bitwise_range, byte_of(quo, i) * 256 + byte_of(quo, i + 1)), hist_add(bitwise_range, byte_of(rem, i) * 256 + byte_of(rem, i + 1));
+    }
+    // carries of the limb equations: position k of a b - q P - r, plus the carry in, is 256 times the carry out
+    int64_t c = 0;
+    for (int k = 0; k <= (int)md::N_CARRY; k++) {
+        int64_t s = c;
+        for (int i = 0; i < 32; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= 32) continue;
+            s += (int64_t)byte_of(a, i) * byte_of(b, j) - (int64_t)byte_of(quo, i) * byte_of(pm.w, j);
+        }
+        if (k < 32) s -= byte_of(rem, k);
+        if ((s & 255) != 0 && !overflow) atomicAdd(bad, 1u);   // (cannot happen: a b = q P + r)
+        c = s >> 8;
+        if (k < (int)md::N_CARRY) {
+            const int64_t shifted = c + md::CARRY_OFFSET;
+            const uint32_t v = shifted < 0 || shifted >= (int64_t)256 * tuple_y ? 0u : (uint32_t)shifted;
+            if ((int64_t)v != shifted) atomicAdd(bad, 1u);
+            put(md::COL_CX + k, v & 255u), put(md::COL_CY + k, v >> 8);
+            hist_add(tuple, (v & 255u) * tuple_y + (v >> 8));
+        } else if (c != 0 && !overflow) {
+            atomicAdd(bad, 1u);
+        }
+    }
+    // r < P: the most significant differing limb
+    int mark = -1;
+    for (int i = 31; i >= 0; i--)
+        if (byte_of(rem, i) != byte_of(pm.w, i)) {
+            mark = i;
+            break;
+        }
+    for (int i = 0; i < 32; i++) put(md::COL_MARK + i, i == mark ? 1u : 0u);
+    const uint32_t diff = mark >= 0 ? byte_of(pm.w, mark) - byte_of(rem, mark) : 0u;
+    put(md::COL_DIFF, diff), put(md::COL_REAL, 1u);
+    hist_add(bitwise_range, ((diff - 1u) & 255u) * 256);
+}
+
+std::mutex g_mu;
+std::map<md::Modulus, std::vector<uint32_t>> g_programs;   // per modulus, kept for the life of the process
+
+}  // namespace
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+int zkhip_modmul_air(const uint8_t modulus[32], uint32_t bitwise_bus, uint32_t tuple_bus, zkhip_air* out) {
+    if (!modulus || !out) return ZKHIP_ERR_INVALID;
+    md::Modulus m;
+    memcpy(m.data(), modulus, 32);
+    bool zero = true;
+    for (uint8_t v : m) zero = zero && v == 0;
+    if (zero) return ZKHIP_ERR_INVALID;
+    try {
+        std::lock_guard<std::mutex> lk(g_mu);
+        md::Modulus key = m;   // (the buses are part of the program: one entry per (modulus, buses) in practice = per modulus)
+        auto it = g_programs.find(key);
+        if (it == g_programs.end()) {
+            zkhip::air::AirBuilder b(md::WIDTH, 0);
+            md::modmul_air(b, m, bitwise_bus, tuple_bus);
+            it = g_programs.emplace(key, b.program()).first;
+        }
+        out->program = it->second.data(), out->program_len = it->second.size(), out->log_height = 0, out->width = md::WIDTH, out->n_pvs = 0;
+        out->prep_trace = nullptr, out->prep_commit = nullptr;
+    } catch (const std::exception&) {
+        return ZKHIP_ERR_INVALID;
+    }
+    return ZKHIP_OK;
+}
+
+int zkhip_modmul_host(const uint32_t a[8], const uint32_t b[8], const uint32_t modulus[8], uint32_t q[8], uint32_t r[8]) {
+    if (!a || !b || !modulus || !q || !r) return ZKHIP_ERR_INVALID;
+    md::U256 A, B, M, Q, R;
+    memcpy(A.w, a, 32), memcpy(B.w, b, 32), memcpy(M.w, modulus, 32);
+    bool zero = true;
+    for (uint32_t v : M.w) zero = zero && v == 0;
+    if (zero) return ZKHIP_ERR_INVALID;
+    const bool fits = md::mulmod(A, B, M, &Q, &R);
+    memcpy(q, Q.w, 32), memcpy(r, R.w, 32);
+    return fits ? ZKHIP_OK : ZKHIP_ERR_INVALID;
+}
+
+int zkhip_modmul_tracegen(zkhip_ctx* ctx, const uint32_t modulus[8], const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace,
+                          uint32_t* d_bitwise_trace, uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !modulus || !d_trace || !d_bitwise_trace || !d_tuple_counts || log_height > 24 || (n && !d_records)) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height, T = (size_t)size_x * size_y;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "modmul_tracegen: more records than rows");
+    if (size_x < 256 || size_y < 128 || T > ((size_t)1 << 27)) return set_error(ctx, ZKHIP_ERR_INVALID, "modmul_tracegen: the tuple table must cover (x < 256, y < 128)");
+    ModWords pm;
+    memcpy(pm.w, modulus, 32);
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, "modmul_tracegen");
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const unsigned tb = (unsigned)((T + 255) / 256), bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
+    hipLaunchKernelGGL(k_mod_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
+    hipLaunchKernelGGL(k_mod_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);   // the range column of the 8-bit table
+    hipLaunchKernelGGL(k_modmul_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, n, N, pm, d_trace, d_bitwise_trace, d_tuple_counts, size_y,
+                       (uint32_t*)flag);
+    hipLaunchKernelGGL(k_mod_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
+    hipLaunchKernelGGL(k_mod_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return tracegen_finish(ctx, flag, "modmul_tracegen (a quotient beyond 256 bits: operands far above the modulus)");
+}
+
+}  // extern "C"
