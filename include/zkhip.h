@@ -565,7 +565,7 @@ int zkhip_tracegen_check(zkhip_ctx *ctx);
  *      sdk.prove, crates/prover/src/prover/mod.rs:355-357).  The AIR set of a segment is defined ONCE, in C++; these entry points
  *      hand its programs, the instruction decode and the program table to any host language. ---- */
 size_t zkhip_vm_n_airs(void);
-/* AIR `id` (order of zkhip::vmc::AirId): program words, width, public-value count; log_height and the preprocessed fields are
+/* AIR `id` < zkhip_vm_n_airs() (order of zkhip::vmc::AirId; the modular extension's chips come from zkhip_vm_modmul_air): program words, width, public-value count; log_height and the preprocessed fields are
  * left zero (heights come from the segment configuration, tables from zkhip_vm_program_table / the lookup tables); *prep_width
  * receives the width of its preprocessed trace.  Pointers stay valid for the life of the process. */
 int zkhip_vm_air(unsigned id, zkhip_air *out, size_t *prep_width);
@@ -591,6 +591,12 @@ int zkhip_vm_keccak_tracegen(zkhip_ctx *ctx, const uint32_t *d_states, const uin
  * zkhip_vm_sha256_prep writes its preprocessed trace (the standalone chip's six columns + input / digest / round-index). */
 int zkhip_vm_sha256_tracegen(zkhip_ctx *ctx, const uint32_t *d_blocks, const uint32_t *d_ts, size_t n_blocks, unsigned log_height, uint32_t *d_trace);
 int zkhip_vm_sha256_prep(unsigned log_height, uint32_t *out);
+/* The two chips of modulus `index` (< 8) of an app with the modular extension: adapter == 0 the multiplication chip inside the VM (287
+ * columns: zkhip_modmul_air + a timestamp column + the 24 word receives), adapter != 0 its adapter; zkhip_vm_modmul_tracegen =
+ * zkhip_modmul_tracegen + the timestamp of call i on row i. */
+int zkhip_vm_modmul_air(const uint8_t modulus[32], unsigned index, int adapter, zkhip_air *out);
+int zkhip_vm_modmul_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height,
+                             uint32_t *d_trace, uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
 /* Poseidon2 chip serving the hash bus (299 columns): zkhip_poseidon2_air_tracegen + multiplicity 1 on the first n rows. */
 int zkhip_vm_poseidon2_tracegen(zkhip_ctx *ctx, const uint32_t *d_inputs, size_t n, unsigned log_height, uint32_t *d_trace);
 /* n rows of `width` canonical words (row-major, device) -> column-major Montgomery trace of 2^log_height rows; the other rows get

@@ -71,6 +71,21 @@ inline void modmul_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus, ui
     for (size_t k = 0; k < N_CARRY; k++) b.push_interaction(tuple_bus, {b.var(COL_CX + k), b.var(COL_CY + k)}, real, Kind::Send);
 }
 
+// The chip inside the VM (include/zkhip_vm_circuit.hpp): the same AIR plus a timestamp column; the 24 words of a call -- a, b (read) and
+// r (written) -- are received from the modular adapter on `word_bus` as (timestamp, word index 0..23, low half, high half).
+// AirBuilder(VM_WIDTH, 0)
+constexpr size_t COL_TS = WIDTH, VM_WIDTH = WIDTH + 1;
+inline void modmul_vm_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus, uint32_t tuple_bus, uint32_t word_bus) {
+    modmul_air(b, P, bitwise_bus, tuple_bus);
+    const Expr ts = b.var(COL_TS), real = b.var(COL_REAL);
+    const size_t base[3] = {COL_A, COL_B, COL_R};
+    for (size_t o = 0; o < 3; o++)
+        for (size_t k = 0; k < 8; k++) {
+            const size_t c = base[o] + 4 * k;
+            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(8 * o + k)), b.var(c) + b.var(c + 1) * 256, b.var(c + 2) + b.var(c + 3) * 256}, real, Kind::Receive);
+        }
+}
+
 // 256-bit helpers on little-endian 32-bit words (host; the tests' expected values come from Python, not from here)
 struct U256 {
     uint32_t w[8];

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "zkhip_keccak.hpp"
+#include "zkhip_modular.hpp"
 #include "zkhip_sha256.hpp"
 
 namespace zkhip_vm {
@@ -152,6 +153,7 @@ public:
         if (!done_) step(rec);
     }
     void set_memory_log(bool on) { log_memory_ = on; }
+    void set_moduli(const std::vector<zkhip::modular::U256>& m) { moduli_ = m; }   // the modular extension's moduli (ecall 5)
     bool done() const { return done_; }
     uint32_t pc() const { return pc_; }
     uint32_t last_result() const { return last_val_; }   // the value the last instruction computed for rd (also when rd = x0)
@@ -168,6 +170,7 @@ private:
     std::vector<uint8_t> mem_, pv_;
     uint32_t x_[32], pc_ = 0, exit_code_ = 0, last_val_ = 0;
     bool log_memory_ = true;
+    std::vector<zkhip::modular::U256> moduli_;
     uint64_t instret_ = 0;
     size_t in_pos_ = 0;
     bool done_ = false;
@@ -439,6 +442,18 @@ private:
                     memcpy(buf, p, 96);
                     zkhip::sha256::compress(buf, buf + 8);
                     memcpy(p, buf, 32);
+                } else if (call == 5) {
+                    // r = a b mod P_i on the 24 words at a0 (a[8] | b[8] | r[8], little-endian words), i = a1: one of the moduli the
+                    // app's openvm.toml lists (OpenVM's modular extension)
+                    if (rec && log_memory_) throw Error("the modmul intrinsic is proven by the one-statement flow only");
+                    const uint32_t addr = reg_read(rec, 10), which = reg_read(rec, 11);
+                    if (which >= moduli_.size()) throw Error("modmul: the app's openvm.toml lists no modulus " + std::to_string(which));
+                    if (addr & 3u) throw Error("modmul buffer must be word-aligned");
+                    uint8_t* p = at(addr, 96);
+                    zkhip::modular::U256 a, b, q, r;
+                    memcpy(a.w, p, 32), memcpy(b.w, p + 32, 32);
+                    if (!zkhip::modular::mulmod(a, b, moduli_[which], &q, &r)) throw Error("modmul: operands far above the modulus (the quotient needs more than 256 bits)");
+                    memcpy(p + 64, r.w, 32);
                 } else {
                     throw Error("unknown environment call " + std::to_string(call));
                 }

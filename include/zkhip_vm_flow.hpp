@@ -43,8 +43,16 @@ inline SegmentAirs segment_airs(const Exe& exe, const SegmentCaps& caps) {
     SegmentAirs s;
     s.airs.resize(caps.n_airs), s.prep_width.resize(caps.n_airs);
     for (unsigned p = 0; p < caps.n_airs; p++) {   // position p of the proof holds chip caps.ids[p] (base chips: p = id)
-        if (zkhip_vm_air(caps.ids[p], &s.airs[p], &s.prep_width[p]) != ZKHIP_OK) throw Error("zkhip_vm_air failed");
-        s.airs[p].log_height = caps.log_height[caps.ids[p]];
+        const unsigned id = caps.ids[p];
+        if (id >= vmc::N_STATIC_AIRS) {   // the modular extension: chip / adapter of modulus i
+            const unsigned i = (id - vmc::N_STATIC_AIRS) / 2;
+            const zkhip::modular::Modulus m = zkhip::modular::modulus_bytes(caps.moduli.at(i));
+            if (zkhip_vm_modmul_air(m.data(), i, (id - vmc::N_STATIC_AIRS) & 1, &s.airs[p]) != ZKHIP_OK) throw Error("zkhip_vm_modmul_air failed");
+            s.prep_width[p] = 0;
+        } else if (zkhip_vm_air(id, &s.airs[p], &s.prep_width[p]) != ZKHIP_OK) {
+            throw Error("zkhip_vm_air failed");
+        }
+        s.airs[p].log_height = caps.log_height[id];
     }
     const unsigned lp = caps.log_height[vmc::A_PROGRAM];
     s.program_prep = vmc::program_table(exe.program, exe.pc_base, lp);
@@ -172,6 +180,12 @@ public:
             check(zkhip_vm_sha256_tracegen(ctx_, up(r.sha_blocks), up(r.sha_ts), r.n_sha256(), H(vmc::A_SHA256), T(vmc::A_SHA256)));
             check(zkhip_rows_tracegen(ctx_, up(r.shaio_rows), r.shaio_rows.size() / vmc::SHA_IO_WIDTH, vmc::SHA_IO_WIDTH, H(vmc::A_SHA256_IO), T(vmc::A_SHA256_IO), nullptr));
         }
+        for (unsigned i = 0; i < caps_.moduli.size(); i++) {   // modular extension: the chip's lookups are counted by its generator
+            check(zkhip_vm_modmul_tracegen(ctx_, caps_.moduli[i].w, up(r.mm_records[i]), up(r.mm_ts[i]), r.mm_ts[i].size(), H(vmc::A_MODMUL(i)), T(vmc::A_MODMUL(i)), d_bw,
+                                           d_tup, TUPLE_X, TUPLE_Y));
+            check(zkhip_rows_tracegen(ctx_, up(r.mmio_rows[i]), r.mmio_rows[i].size() / vmc::MODMUL_IO_WIDTH, vmc::MODMUL_IO_WIDTH, H(vmc::A_MODMUL_IO(i)),
+                                      T(vmc::A_MODMUL_IO(i)), nullptr));
+        }
         // ---- lookup multiplicities of the new chips, counted from the requesting columns
         auto pairs = [&](unsigned a, size_t cx, size_t cy, size_t n) {
             if (n) check(zkhip_bitwise_lookup_tracegen(ctx_, T(a) + cx * N(a), T(a) + cy * N(a), d_zeros_, n, 8, d_bw, 1));
@@ -202,8 +216,9 @@ public:
                     for (uint32_t v : {row[17] * 8192, row[17], row[22], row[25]}) misc.push_back(v);
                     tup_y.push_back(row[23]), tup_y.push_back(row[26]);
                 }
+                if (row[30]) misc.push_back(row[22]), tup_y.push_back(row[23]);   // modmul: the a1 read
                 if (row[16]) bw_x.push_back(row[10]), bw_y.push_back(row[11]), bw_x.push_back(row[12]), bw_y.push_back(row[13]);
-                if (row[27] || row[29])
+                if (row[27] || row[29] || row[30])
                     for (uint32_t v : {row[28] * 1024, row[28], row[9] * 1024}) misc.push_back(v);
             }
             for (size_t i = 0; i < r.kio_rows.size() / vmc::KECCAK_IO_WIDTH; i++) {
@@ -218,6 +233,11 @@ public:
                 const uint32_t* row = &r.shaio_rows[i * vmc::SHA_IO_WIDTH];
                 misc.push_back(row[31]), tup_y.push_back(row[32]);
             }
+            for (unsigned m = 0; m < caps_.moduli.size(); m++)
+                for (size_t i = 0; i < r.mmio_rows[m].size() / vmc::MODMUL_IO_WIDTH; i++) {
+                    const uint32_t* row = &r.mmio_rows[m][i * vmc::MODMUL_IO_WIDTH];
+                    misc.push_back(row[31]), tup_y.push_back(row[32]);
+                }
             uint32_t* d_misc = const_cast<uint32_t*>(up(misc));
             check(zkhip_to_monty(ctx_, d_misc, misc.size()));
             count(d_misc, misc.size());
@@ -520,11 +540,47 @@ inline unsigned keccak_log_rows(const std::string& path_app_config, unsigned log
 }
 // likewise `[app_vm_config.sha256]`: 2^(log_frame - 5) rows of the SHA-256 compression chip (65 per block, at least 128)
 inline unsigned sha256_log_rows(const std::string& path_app_config, unsigned log_frame) {
-    return config_has_section(path_app_config, "[app_vm_config.sha256]") ? std::max(7u, log_frame > 5 ? log_frame - 5 : 0u) : 0u;
+    const bool on = config_has_section(path_app_config, "[app_vm_config.sha256]") || config_has_section(path_app_config, "[app_vm_config.sha2]");   // (the reference's name)
+    return on ? std::max(7u, log_frame > 5 ? log_frame - 5 : 0u) : 0u;
+}
+// `[app_vm_config.modular] supported_moduli = ["<decimal>", ...]` (the reference's chunk circuit lists six): the moduli as 256-bit words
+inline std::vector<zkhip::modular::U256> config_moduli(const std::string& path_app_config) {
+    std::ifstream f(path_app_config);
+    std::string line, body;
+    bool in_section = false, in_list = false;
+    while (std::getline(f, line)) {
+        const size_t b0 = line.find('[');
+        if (!in_list && b0 != std::string::npos && line.find_first_not_of(" \t") == b0) in_section = line.find("[app_vm_config.modular]") != std::string::npos;
+        if (!in_section) continue;
+        if (line.find("supported_moduli") != std::string::npos) in_list = true;
+        if (in_list) {
+            body += line;
+            if (line.find(']') != std::string::npos && line.find("[app_vm_config") == std::string::npos) break;
+        }
+    }
+    std::vector<zkhip::modular::U256> out;
+    for (size_t p = body.find('"'); p != std::string::npos;) {
+        const size_t e = body.find('"', p + 1);
+        if (e == std::string::npos) break;
+        zkhip::modular::U256 v{};
+        for (size_t k = p + 1; k < e; k++) {   // decimal -> words
+            if (body[k] < '0' || body[k] > '9') throw Error("openvm.toml: a modulus is not a decimal number");
+            uint64_t c = (uint64_t)(body[k] - '0');
+            for (int w = 0; w < 8; w++) {
+                c += (uint64_t)v.w[w] * 10u;
+                v.w[w] = (uint32_t)c, c >>= 32;
+            }
+            if (c) throw Error("openvm.toml: a modulus does not fit 256 bits");
+        }
+        out.push_back(v);
+        p = body.find('"', e + 1);
+    }
+    return out;
 }
 inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
-                                        bool keep_segments = false, unsigned inflight = 2, unsigned log_keccak = 0, unsigned log_sha256 = 0) {
-    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak, log_sha256);
+                                        bool keep_segments = false, unsigned inflight = 2, unsigned log_keccak = 0, unsigned log_sha256 = 0,
+                                        const std::vector<zkhip::modular::U256>& moduli = {}) {
+    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak, log_sha256, moduli, log_frame > 8 ? log_frame - 8 : 1);
     std::vector<std::unique_ptr<SegmentProver>> own;
     std::vector<SegmentProver*> lanes;
     for (unsigned l = 0; l < std::max(1u, inflight); l++) own.emplace_back(new SegmentProver(params, exe, caps, device)), lanes.push_back(own.back().get());
@@ -579,7 +635,8 @@ public:
         }
         p.params_ = read_app_config(cfg.path_app_config);
         p.caps_ = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(p.exe_.program.size()), zkhip_vm::keccak_log_rows(cfg.path_app_config, log_frame),
-                                                   zkhip_vm::sha256_log_rows(cfg.path_app_config, log_frame));
+                                                   zkhip_vm::sha256_log_rows(cfg.path_app_config, log_frame), zkhip_vm::config_moduli(cfg.path_app_config),
+                                                   log_frame > 8 ? log_frame - 8 : 1);
         return p;
     }
     void reset() {   // mod.rs:106-108: releases the device-resident keys, circuits and workspaces

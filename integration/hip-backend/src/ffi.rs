@@ -334,6 +334,9 @@ extern "C" {
     pub fn zkhip_vm_sha256_tracegen(ctx: *mut zkhip_ctx, d_blocks: *const u32, d_ts: *const u32, n_blocks: usize, log_height: c_uint,
                                     d_trace: *mut u32) -> c_int;
     pub fn zkhip_vm_sha256_prep(log_height: c_uint, out: *mut u32) -> c_int;
+    pub fn zkhip_vm_modmul_air(modulus: *const u8, index: c_uint, adapter: c_int, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_vm_modmul_tracegen(ctx: *mut zkhip_ctx, modulus: *const u32, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint,
+                                    d_trace: *mut u32, d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
     pub fn zkhip_vm_poseidon2_tracegen(ctx: *mut zkhip_ctx, d_inputs: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;
     pub fn zkhip_rows_tracegen(ctx: *mut zkhip_ctx, d_rows: *const u32, n: usize, width: usize, log_height: c_uint, d_trace: *mut u32,
                                pad_row: *const u32) -> c_int;

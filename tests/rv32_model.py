@@ -105,7 +105,7 @@ def sx(v, bits):
     return v - (1 << bits) if v >> (bits - 1) else v
 
 
-def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_bytes=1 << 20, data=b"", max_instr=10**7):
+def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_bytes=1 << 20, data=b"", max_instr=10**7, moduli=()):
     """Independent interpreter.  Returns dict(instret, pvs (32 bytes), exit_code, records)."""
     x = [0] * 32
     x[2] = data_base + memory_bytes
@@ -306,6 +306,12 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                 off = rr(10) - data_base
                 assert off % 4 == 0 and 0 <= off and off + 200 <= len(mem)
                 mem[off:off + 200] = keccak_f1600_bytes(bytes(mem[off:off + 200]))
+            elif call == 5:   # r = a b mod moduli[a1] on the 24 words at a0 (a | b | r, little-endian)
+                off = rr(10) - data_base
+                p_ = moduli[rr(11)]
+                assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem)
+                a_, b_ = int.from_bytes(mem[off:off + 32], "little"), int.from_bytes(mem[off + 32:off + 64], "little")
+                mem[off + 64:off + 96] = (a_ * b_ % p_).to_bytes(32, "little")
             elif call == 4:   # SHA-256 compression on the 24 words at a0: state[8] <- compress(state, block[16])
                 off = rr(10) - data_base
                 assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem)

@@ -17,7 +17,8 @@ from zkvm_prover_amd import air
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import fib_program, keccak_data, keccak_program, mixed_program, sha256_data, sha256_program
+from test_vm_cpu import (SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, keccak_data, keccak_program, mixed_program, modmul_data,
+                         modmul_program, sha256_data, sha256_program)
 
 PARAMS = (1, 0, 4, 3, 3)
 PC_BASE = 0x00200000
@@ -211,6 +212,38 @@ def test_sha256_intrinsic_is_part_of_the_statement(tmp_path):
     assert H2.ids[-2:] == (v2.A_SHA256, v2.A_SHA256_IO) and len(H2.ids) == 24
     inst = v2.segment_instance(segs2[0], words, PC_BASE, H2)
     assert all(air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [] for d in inst) and v2.bus_imbalance(inst) == {}
+
+
+def test_modmul_intrinsic_is_part_of_the_statement(tmp_path):
+    """A guest that evaluates both sides of the secp256k1 curve equation at the published generator with the modmul intrinsic, under an app
+    with two moduli (26 chips: a multiplication chip and an adapter per modulus): the revealed y^2 and x^3 are Python's and differ by 7
+    modulo p; every trace satisfies its AIR, every bus balances; a forged product breaks the word bus."""
+    moduli = (SECP256K1_P, SECP256K1_N)
+    words, data = modmul_program(), modmul_data()
+    model = rv.run(words, b"", data=data, moduli=moduli)
+    pv = bytes(model["pvs"])
+    y2, x3 = SECP256K1_GY ** 2 % SECP256K1_P, SECP256K1_GX ** 3 % SECP256K1_P
+    assert (y2 - x3 - 7) % SECP256K1_P == 0
+    other = (SECP256K1_N - 2) * (SECP256K1_N - 3) % SECP256K1_N
+    assert pv[:16] == y2.to_bytes(32, "little")[:16] and pv[16:28] == x3.to_bytes(32, "little")[:12]
+    assert int.from_bytes(pv[28:32], "little") == (x3 >> 96 & 0xFFFFFFFF) ^ (other & 0xFFFFFFFF)
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, moduli)
+    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"]
+    assert len(H.ids) == 26 and sum(len(s["mm_ts_0"]) for s in segs) == 3 and sum(len(s["mm_ts_1"]) for s in segs) == 1
+    for k, rec in enumerate(segs):
+        inst = v2.segment_instance(rec, words, PC_BASE, H)
+        for d in inst:
+            assert air.quotient_chunks(d["program"]) <= 2
+            assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], k
+        assert v2.bus_imbalance(inst) == {}
+    k = next(i for i, s in enumerate(segs) if len(s["mm_ts_0"]))
+    rec = {n: v.copy() for n, v in segs[k].items()}
+    rec["mmio_rows_0"].reshape(-1, v2.MODMUL_IO_WIDTH)[17, 28] ^= 1        # a result word that is not the product's
+    bad = v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
+    assert 18 in bad and 1 in bad                                         # modulus 0's word bus, memory bus
+    # without the extension the guest has no proof
+    with pytest.raises(AssertionError, match="lists 0 moduli"):
+        v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)
 
 
 def test_decode_table_against_an_independent_decoder(mixed):

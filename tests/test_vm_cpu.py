@@ -87,6 +87,43 @@ def sha256_data(msg):
     return struct.pack("<8I", *iv) + struct.pack("<%dI" % len(words), *words), len(data) // 64
 
 
+def modmul_program():
+    """The secp256k1 generator's curve equation through the modmul intrinsic (a7 = 5, a1 = modulus index): buffer 0 = (Gy, Gy, .),
+    buffer 1 = (Gx, Gx, .), buffer 2 = (Gx^2, Gx, .) at the data base (modmul_data); reveals the low words of y^2 and x^3 (words 0..3 and
+    4..7) -- they differ by 7 modulo p -- and one product modulo the second modulus folded into word 7."""
+    p = rv.li(S0, 0x00400000)
+    def call(buf, which):
+        return [("addi", A0, S0, 96 * buf), ("addi", A1, 0, which), ("addi", A7, 0, 5), ("ecall",)]
+    p += call(0, 0) + call(1, 0)
+    for k in range(8):                                                     # x^2 into buffer 2's first operand
+        p += [("lw", T0, S0, 96 + 64 + 4 * k), ("sw", T0, S0, 192 + 4 * k)]
+    p += call(2, 0)
+    p += call(3, 1)                                                        # buffer 3 under the other modulus
+    p += [("lw", T1, S0, 288 + 64)]
+    for k in range(4):
+        p += [("lw", A0, S0, 64 + 4 * k), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+    for k in range(4):
+        p += [("lw", A0, S0, 192 + 64 + 4 * k)]
+        if k == 3:
+            p += [("xor", A0, A0, T1)]
+        p += [("addi", A1, 0, 4 + k), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
+SECP256K1_P = 2**256 - 2**32 - 977
+SECP256K1_N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+SECP256K1_GX = 0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798
+SECP256K1_GY = 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8
+
+
+def modmul_data():
+    b32 = lambda v: int(v).to_bytes(32, "little")  # noqa: E731
+    z32 = bytes(32)
+    return (b32(SECP256K1_GY) + b32(SECP256K1_GY) + z32 + b32(SECP256K1_GX) + b32(SECP256K1_GX) + z32 + z32 + b32(SECP256K1_GX) + z32 +
+            b32(SECP256K1_N - 2) + b32(SECP256K1_N - 3) + z32)
+
+
 def mixed_program():
     """every instruction class: a checksum over a table in memory with multiplies, comparisons, shifts, division, bytes"""
     p = [("addi", A7, 0, 2), ("ecall",), ("add", S0, A0, 0)]          # seed

@@ -17,9 +17,12 @@ CLI = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
 P = ora.P
 NOPV = np.zeros(0, np.uint32)
 (A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
- A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, N_AIRS) = range(27)
-PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 30, 43, 54, 42, 2634
+ A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, N_STATIC_AIRS) = range(27)
+MAX_MODULI = 8
+N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI   # the modular extension: chips N_STATIC_AIRS + 2 i (multiplication), + 2 i + 1 (adapter) of modulus i
+PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 31, 43, 54, 42, 2634
 SHA_IO_WIDTH, SHA_WIDTH = 34, 434
+MODMUL_IO_WIDTH, MODMUL_WIDTH = 34, 287
 TS_STEP, GAP_HI_BITS = 16, 11
 SX, SY = 256, 2048
 
@@ -49,25 +52,38 @@ def program_table(words, pc_base, log_program):
 
 
 class Heights(list):
-    """heights[AirId] of the app's chips (None for an absent extension chip); .ids = the chips in proof order"""
+    """heights[AirId] of the app's chips (None for an absent extension chip); .ids = the chips in proof order; .moduli = the modular
+    extension's moduli (integers)"""
     ids = ()
+    moduli = ()
 
 
-def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0):
+def A_MODMUL(i):
+    return N_STATIC_AIRS + 2 * i
+
+
+def A_MODMUL_IO(i):
+    return N_STATIC_AIRS + 2 * i + 1
+
+
+def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0, moduli=()):
     """Runs the C++ segmenting executor; returns (info json, heights, [segment record dicts], image root, pv openings)."""
     import json
 
     d = str(tmp)
     open(os.path.join(d, "exe.bin"), "wb").write(exe_bytes)
     open(os.path.join(d, "stdin.bin"), "wb").write(stdin)
-    r = subprocess.run([CLI, "dump-segments", os.path.join(d, "exe.bin"), os.path.join(d, "stdin.bin"), d, str(log_frame), str(log_keccak), str(log_sha256)],
-                       capture_output=True, text=True)
+    cmd = [CLI, "dump-segments", os.path.join(d, "exe.bin"), os.path.join(d, "stdin.bin"), d, str(log_frame), str(log_keccak), str(log_sha256)]
+    if moduli:
+        open(os.path.join(d, "moduli.toml"), "w").write("[app_vm_config.modular]\nsupported_moduli = [\n" + ",\n".join('    "%d"' % m for m in moduli) + "\n]\n")
+        cmd.append(os.path.join(d, "moduli.toml"))
+    r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
     by_pos = np.fromfile(os.path.join(d, "heights.u32"), dtype=np.uint32).tolist()
     ids = np.fromfile(os.path.join(d, "air_ids.u32"), dtype=np.uint32).tolist()
     heights = Heights([None] * N_AIRS)
-    heights.ids = tuple(ids)
+    heights.ids, heights.moduli = tuple(ids), tuple(moduli)
     for i, h in zip(ids, by_pos):
         heights[i] = h
     segs = []
@@ -169,6 +185,27 @@ def sha256_vm_prep(log_height):
     return p
 
 
+def modmul_traces(rec, H, i, p):
+    """modmul calls of modulus i: the oracle's chip trace (and its lookup counts) + the call's timestamp; the adapter's rows"""
+    n = len(rec["mm_ts_%d" % i])
+    l = ora.lib()
+    l.ora_modmul_trace.restype = C.c_size_t
+    l.ora_modmul_trace.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8), C.c_uint, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint32), C.c_uint32]
+    lh = H[A_MODMUL(i)]
+    body = np.zeros((MODMUL_WIDTH - 1, 1 << lh), np.uint32)
+    bw, tup = np.zeros(1 << 16, np.uint32), np.zeros(SX * SY, np.uint32)
+    recs = np.ascontiguousarray(rec["mm_records_%d" % i], dtype=np.uint32).view(np.uint8)
+    pb = np.frombuffer(int(p).to_bytes(32, "little"), dtype=np.uint8).copy()
+    bad = l.ora_modmul_trace(recs.ctypes.data_as(C.POINTER(C.c_uint8)) if n else None, n, pb.ctypes.data_as(C.POINTER(C.c_uint8)), lh, ora.p32(body), ora.p32(bw),
+                             ora.p32(tup), SY)
+    assert bad == 0
+    tr = np.zeros((MODMUL_WIDTH, 1 << lh), np.uint32)
+    tr[:MODMUL_WIDTH - 1] = body
+    tr[MODMUL_WIDTH - 1, :n] = rec["mm_ts_%d" % i]
+    return tr, rows_trace(rec["mmio_rows_%d" % i], MODMUL_IO_WIDTH, H[A_MODMUL_IO(i)]), bw.astype(np.int64), tup.astype(np.int64)
+
+
 def sha256_traces(rec, H):
     """sha256 calls: the oracle's compression-chip trace + the call's timestamp on its rows; the adapter's rows as the executor wrote them"""
     n = len(rec["sha_ts"])
@@ -220,12 +257,19 @@ def segment_instance(rec, words, pc_base, heights):
         tr[A_KECCAK], tr[A_KECCAK_IO] = keccak_traces(rec, H)
     if A_SHA256 in H.ids:
         tr[A_SHA256], tr[A_SHA256_IO] = sha256_traces(rec, H)
+    mm_counts = []
+    for i, p_ in enumerate(H.moduli):
+        tr[A_MODMUL(i)], tr[A_MODMUL_IO(i)], bw_i, tup_i = modmul_traces(rec, H, i, p_)
+        mm_counts.append((bw_i, tup_i))
     meta = rec["meta"]
     pc_start, pc_end, ts_end, n_instr = (int(x) for x in meta[:4])
     tr[A_CONNECTOR] = np.array([[ts_end & 0xFFFF], [ts_end >> 16]], np.uint32)
     # lookup multiplicities of the new chips
     rc = rc.astype(np.int64)
     tc = tc.astype(np.int64)
+    for bw_i, tup_i in mm_counts:   # the multiplication chips' own lookups (byte pairs, carries)
+        rc += bw_i
+        tc += tup_i
     n, nls = n_instr, len(rec["ls_case"])
     fr, ls = tr[A_FRAME].astype(np.int64), tr[A_LS].astype(np.int64)
     for q in (18, 20, 22, 24, 26, 28):
@@ -249,7 +293,10 @@ def segment_instance(rec, words, pc_base, heights):
         if row[16]:
             rc[int(row[10]) * 256 + int(row[11])] += 1
             rc[int(row[12]) * 256 + int(row[13])] += 1
-        if row[27] or row[29]:
+        if row[30]:
+            misc += [int(row[22])]
+            tc[int(row[23])] += 1
+        if row[27] or row[29] or row[30]:
             misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
     for row in rec["kio_rows"].reshape(-1, KECCAK_IO_WIDTH):
         misc += [int(row[36]), int(row[39])]
@@ -258,6 +305,10 @@ def segment_instance(rec, words, pc_base, heights):
     for row in rec["shaio_rows"].reshape(-1, SHA_IO_WIDTH):
         misc += [int(row[31])]
         tc[int(row[32])] += 1
+    for i in range(len(H.moduli)):
+        for row in rec["mmio_rows_%d" % i].reshape(-1, MODMUL_IO_WIDTH):
+            misc += [int(row[31])]
+            tc[int(row[32])] += 1
     for row in rec["leaf_rows"].reshape(-1, LEAF_WIDTH):
         misc += [int(row[39]), int(row[40]) * 16, int(row[40]), int(row[41]), int(row[42]) * 64, int(row[42])]
     cnt += np.bincount(np.array(misc, dtype=np.int64), minlength=1 << 16)
@@ -274,7 +325,12 @@ def segment_instance(rec, words, pc_base, heights):
     pvs = {A_MERKLE: np.concatenate([meta[4:12], meta[12:20]]).astype(np.uint32), A_CONNECTOR: np.array([pc_start, pc_end], np.uint32)}
     out = []
     for a in H.ids:   # proof order
-        program, width, n_pvs, pw = all_shapes[a]
+        if a >= N_STATIC_AIRS:
+            i = (a - N_STATIC_AIRS) // 2
+            program, width = z.vm_modmul_air(H.moduli[i], i, (a - N_STATIC_AIRS) & 1)
+            n_pvs, pw = 0, 0
+        else:
+            program, width, n_pvs, pw = all_shapes[a]
         d = dict(program=program, log_height=H[a], width=width, n_pvs=n_pvs, trace=tr[a], pvs=pvs.get(a, NOPV))
         assert tr[a].shape == (width, 1 << H[a]), (a, tr[a].shape, width, H[a])
         if pw:

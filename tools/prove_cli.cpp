@@ -53,7 +53,8 @@ int main(int argc, char** argv) {
             try {
                 const zkhip_vm::Exe exe = zkhip_vm::parse_exe(raw);
                 const zkhip_vm::SegmentCaps caps = zkhip_vm::SegmentCaps::for_frame((unsigned)atoi(argv[5]), zkhip_vm::vm_log2_ceil(exe.program.size()),
-                                                                                    argc >= 7 ? (unsigned)atoi(argv[6]) : 0u, argc >= 8 ? (unsigned)atoi(argv[7]) : 0u);
+                                                                                    argc >= 7 ? (unsigned)atoi(argv[6]) : 0u, argc >= 8 ? (unsigned)atoi(argv[7]) : 0u,
+                                                                                    argc >= 9 ? zkhip_vm::config_moduli(argv[8]) : std::vector<zkhip::modular::U256>(), 3);
                 zkhip_vm::SegmentExecutor ex(exe, in, caps);
                 zkhip_vm::SegmentRecords r;
                 size_t k = 0;
@@ -79,6 +80,10 @@ int main(int argc, char** argv) {
                     PUT("f_pts1", r.f_pts1), PUT("f_pts2", r.f_pts2), PUT("f_pts3", r.f_pts3), PUT("ls_pts", r.ls_pts);
                     PUT("kk_states", r.kk_states), PUT("kk_ts", r.kk_ts), PUT("kio_rows", r.kio_rows);
                     PUT("sha_blocks", r.sha_blocks), PUT("sha_ts", r.sha_ts), PUT("shaio_rows", r.shaio_rows);
+                    for (unsigned i = 0; i < caps.moduli.size(); i++) {
+                        const std::string t = std::to_string(i);
+                        put(d + "/mm_records_" + t + ".u32", r.mm_records[i]), put(d + "/mm_ts_" + t + ".u32", r.mm_ts[i]), put(d + "/mmio_rows_" + t + ".u32", r.mmio_rows[i]);
+                    }
 #undef PUT
                     std::vector<uint32_t> meta{r.pc_start, r.pc_end, r.ts_end, (uint32_t)r.n_instr};
                     meta.insert(meta.end(), r.root_init.begin(), r.root_init.end());
@@ -139,7 +144,7 @@ int main(int argc, char** argv) {
                     const zkhip_params params = read_app_config(cfg_path);
                     const unsigned log_keccak = zkhip_vm::keccak_log_rows(cfg_path, log_frame), log_sha256 = zkhip_vm::sha256_log_rows(cfg_path, log_frame);
                     const unsigned lanes = getenv("ZKHIP_LANES") ? (unsigned)atoi(getenv("ZKHIP_LANES")) : 2u;   // segment provers in flight
-                    const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false, lanes, log_keccak, log_sha256);
+                    const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false, lanes, log_keccak, log_sha256, zkhip_vm::config_moduli(cfg_path));
                     (void)caps;
                     sp = UniversalProver::encode(g);
                     std::string why;

@@ -20,6 +20,7 @@ from ._binding import (  # noqa: F401
     keccak_f1600_host,
     modmul_air,
     modmul_host,
+    vm_modmul_air,
     sha256_air,
     sha256_compress_host,
     verify,

@@ -184,6 +184,8 @@ def load_library():
         "zkhip_vm_poseidon2_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
         "zkhip_vm_keccak_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp]),
         "zkhip_vm_sha256_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp]),
+        "zkhip_vm_modmul_air": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint, C.c_int, C.POINTER(_Air)]),
+        "zkhip_vm_modmul_tracegen": (C.c_int, [vp, u32p, vp, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_vm_sha256_prep": (C.c_int, [C.c_uint, u32p]),
         "zkhip_rows_tracegen": (C.c_int, [vp, vp, sz, sz, C.c_uint, vp, u32p]),
         "zkhip_range_counts_scaled_tracegen": (C.c_int, [vp, vp, sz, C.c_uint32, C.c_uint, vp, C.c_int]),
@@ -613,6 +615,13 @@ class Context:
                                                       log_height, out.data_ptr()))
         return out
 
+    def vm_modmul_tracegen(self, modulus, t_records, t_ts, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
+        out = self._new(287 << log_height)
+        m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
+        self._check(self.lib.zkhip_vm_modmul_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height,
+                                                      out.data_ptr(), t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
+        return out
+
     def vm_sha256_tracegen(self, t_blocks, t_ts, n_blocks, log_height):
         out = self._new(434 << log_height)
         self._check(self.lib.zkhip_vm_sha256_tracegen(self.h, t_blocks.data_ptr() if n_blocks else None, t_ts.data_ptr() if n_blocks else None, n_blocks,
@@ -933,6 +942,15 @@ def modmul_air(modulus, bitwise_bus, tuple_bus):
     a = _Air()
     m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
     assert lib.zkhip_modmul_air(m, bitwise_bus, tuple_bus, C.byref(a)) == 0
+    return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
+
+
+def vm_modmul_air(modulus, index, adapter):
+    """(program, width) of the VM's multiplication chip (adapter False) or adapter chip (True) of modulus `index`"""
+    lib = load_library()
+    a = _Air()
+    m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
+    assert lib.zkhip_vm_modmul_air(m, index, 1 if adapter else 0, C.byref(a)) == 0
     return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
 
 

@@ -255,12 +255,48 @@ inline int compile_air(const AirProgram& p, CompiledAir* out, std::string* err, 
     // constraints attached to each node
     std::vector<std::vector<uint32_t>> cons_of(n);
     for (uint32_t k = 0; k < n_roots; k++) cons_of[root_at(k)].push_back(k);
-    // event order: node i (if interior & reachable) then its ASSERTs.  last_use in event numbering.
+    // Evaluation order: a post-order walk from each constraint in turn, so that a subexpression is computed right before its first
+    // use (node-index order keeps everything a builder created early -- e.g. the denominators of ALL bus interactions, which the
+    // LogUp section builds before the first group constraint -- live until its last use: 516 live values for a 127-interaction chip
+    // where this order needs a dozen).  Constraints keep their numbers (an ASSERT carries its constraint index), so the quotient is
+    // the same polynomial.  event order: node (if interior) then its ASSERTs; last_use in event numbering.
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    {
+        std::vector<char> done(n, 0);
+        std::vector<std::pair<uint32_t, unsigned>> stack;
+        for (uint32_t k = 0; k < n_roots; k++) {
+            if (done[root_at(k)]) continue;
+            stack.push_back({root_at(k), 0});
+            while (!stack.empty()) {
+                auto& top = stack.back();
+                const uint32_t i = top.first;
+                if (done[i]) {
+                    stack.pop_back();
+                    continue;
+                }
+                if (is_leaf(i)) {
+                    done[i] = 1, order.push_back(i);
+                    stack.pop_back();
+                    continue;
+                }
+                const uint32_t op = p.nodes[3 * i];
+                const unsigned n_kids = op == A_NEG ? 1 : 2;
+                if (top.second < n_kids) {
+                    const uint32_t kid = p.nodes[3 * i + 1 + top.second];
+                    top.second++;
+                    if (!done[kid]) stack.push_back({kid, 0});
+                    continue;
+                }
+                done[i] = 1, order.push_back(i);
+                stack.pop_back();
+            }
+        }
+    }
     std::vector<uint32_t> last_use(n, 0);
     {
         uint32_t ev = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            if (!reach[i]) continue;
+        for (uint32_t i : order) {
             if (!is_leaf(i)) {
                 uint32_t op = p.nodes[3 * i];
                 last_use[p.nodes[3 * i + 1]] = ev;
@@ -314,8 +350,7 @@ inline int compile_air(const AirProgram& p, CompiledAir* out, std::string* err, 
             slot_of[i] = -2;
         }
     };
-    for (uint32_t i = 0; i < n; i++) {
-        if (!reach[i]) continue;
+    for (uint32_t i : order) {
         if (!is_leaf(i)) {
             uint32_t op = p.nodes[3 * i], a = p.nodes[3 * i + 1], b = p.nodes[3 * i + 2];
             uint32_t wa = operand(a), wb = op != A_NEG ? operand(b) : 0;

@@ -123,6 +123,12 @@ __global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict
     hist_add(bitwise_range, ((diff - 1u) & 255u) * 256);
 }
 
+// the VM chip's timestamp column: row i carries the timestamp of call i
+__global__ __launch_bounds__(256) void k_modmul_ts(const uint32_t* __restrict__ ts, size_t n, size_t N, uint32_t* __restrict__ col) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row < N) col[row] = row < n ? to_monty(ts[row] % P) : 0u;
+}
+
 std::mutex g_mu;
 std::map<md::Modulus, std::vector<uint32_t>> g_programs;   // per modulus, kept for the life of the process
 
@@ -191,6 +197,18 @@ int zkhip_modmul_tracegen(zkhip_ctx* ctx, const uint32_t modulus[8], const uint3
     hipLaunchKernelGGL(k_mod_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return tracegen_finish(ctx, flag, "modmul_tracegen (a quotient beyond 256 bits: operands far above the modulus)");
+}
+
+int zkhip_vm_modmul_tracegen(zkhip_ctx* ctx, const uint32_t modulus[8], const uint32_t* d_records, const uint32_t* d_ts, size_t n, unsigned log_height,
+                             uint32_t* d_trace, uint32_t* d_bitwise_trace, uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || (n && !d_ts)) return ZKHIP_ERR_INVALID;
+    ZK_TRY(zkhip_modmul_tracegen(ctx, modulus, d_records, n, log_height, d_trace, d_bitwise_trace, d_tuple_counts, size_x, size_y));
+    const size_t N = (size_t)1 << log_height;
+    KernelScope ks(ctx, "vm_modmul_timestamps");
+    hipLaunchKernelGGL(k_modmul_ts, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_ts, n, N, d_trace + (size_t)md::COL_TS * N);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
 }
 
 }  // extern "C"

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include "air_compile.hpp"
 #include "poseidon2_coop.hpp"
@@ -1128,6 +1129,17 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         if ((big || !interp_ok || getenv("ZKHIP_FORCE_JIT")) && !getenv("ZKHIP_NO_JIT")) {
             std::string msg;
             std::vector<uint32_t> tab;
+            const auto jit_t0 = std::chrono::steady_clock::now();
+            struct JitTimer {   // ZKHIP_KEYGEN_TIMING=1: what each chip's compiled constraint kernel cost (hipRTC or the on-disk cache)
+                std::chrono::steady_clock::time_point t0;
+                size_t air, n_nodes;
+                bool forced;
+                ~JitTimer() {
+                    if (getenv("ZKHIP_KEYGEN_TIMING"))
+                        fprintf(stderr, "[zkhip keygen] AIR %zu: constraint kernel %.2f s (%zu nodes%s)\n", air,
+                                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n_nodes, forced ? ", interpreter form refused" : "");
+                }
+            } jit_timer{jit_t0, a, (size_t)A.prog.n_nodes, !interp_ok};
             if (quot_jit_build(A.prog, airs[a].log_height, pk->b, &A.jit_mod, &A.jit_fn, &tab, &msg) &&
                 hipMalloc(&A.d_jit_tab, tab.size() * 4) == hipSuccess &&
                 hipMemcpyAsync(A.d_jit_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&

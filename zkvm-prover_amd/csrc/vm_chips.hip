@@ -8,6 +8,7 @@
 // Replaces, for this backend, the trace generation of OpenVM's adapter / connector / persistent-memory chips (un-vendored;
 // AGENTS.md:183-187 says the reference's GPU backend fills chip traces on the device).
 #include <algorithm>
+#include <map>
 #include <mutex>
 #include <string.h>
 #include <string>
@@ -26,7 +27,9 @@ namespace {
 namespace vmc = zkhip::vmc;
 
 std::once_flag g_airs_once;
-vmc::AirShape g_airs[vmc::N_AIRS];
+vmc::AirShape g_airs[vmc::N_STATIC_AIRS];
+std::mutex g_mod_mu;
+std::map<std::pair<zkhip::modular::Modulus, unsigned>, vmc::AirShape> g_mod_airs;   // (modulus, 2 index + adapter) -> program
 
 __global__ __launch_bounds__(256) void k_vm_frame(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
                                                   const uint32_t* __restrict__ zs, const uint32_t* __restrict__ rdp, const uint32_t* __restrict__ pcinc,
@@ -144,13 +147,13 @@ using namespace zk;
 
 extern "C" {
 
-size_t zkhip_vm_n_airs(void) { return vmc::N_AIRS; }
+size_t zkhip_vm_n_airs(void) { return vmc::N_STATIC_AIRS; }
 
 int zkhip_vm_air(unsigned id, zkhip_air* out, size_t* prep_width) {
-    if (id >= vmc::N_AIRS || !out) return ZKHIP_ERR_INVALID;
+    if (id >= vmc::N_STATIC_AIRS || !out) return ZKHIP_ERR_INVALID;
     try {
         std::call_once(g_airs_once, [] {
-            for (unsigned i = 0; i < vmc::N_AIRS; i++) g_airs[i] = vmc::build_air(i);
+            for (unsigned i = 0; i < vmc::N_STATIC_AIRS; i++) g_airs[i] = vmc::build_air(i);
         });
     } catch (const std::exception&) {
         return ZKHIP_ERR_INVALID;
@@ -159,6 +162,24 @@ int zkhip_vm_air(unsigned id, zkhip_air* out, size_t* prep_width) {
     out->program = s.program.data(), out->program_len = s.program.size(), out->log_height = 0, out->width = s.width, out->n_pvs = s.n_pvs;
     out->prep_trace = nullptr, out->prep_commit = nullptr;
     if (prep_width) *prep_width = s.prep_width;
+    return ZKHIP_OK;
+}
+
+int zkhip_vm_modmul_air(const uint8_t modulus[32], unsigned index, int adapter, zkhip_air* out) {
+    if (!modulus || !out || index >= vmc::MAX_MODULI) return ZKHIP_ERR_INVALID;
+    zkhip::modular::Modulus m;
+    memcpy(m.data(), modulus, 32);
+    try {
+        std::lock_guard<std::mutex> lk(g_mod_mu);
+        const auto key = std::make_pair(m, 2 * index + (adapter ? 1u : 0u));
+        auto it = g_mod_airs.find(key);
+        if (it == g_mod_airs.end()) it = g_mod_airs.emplace(key, vmc::build_modmul_air(m, index, adapter != 0)).first;
+        const vmc::AirShape& s = it->second;
+        out->program = s.program.data(), out->program_len = s.program.size(), out->log_height = 0, out->width = s.width, out->n_pvs = 0;
+        out->prep_trace = nullptr, out->prep_commit = nullptr;
+    } catch (const std::exception&) {
+        return ZKHIP_ERR_INVALID;
+    }
     return ZKHIP_OK;
 }
 
