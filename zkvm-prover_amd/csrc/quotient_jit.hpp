@@ -401,10 +401,11 @@ inline bool quot_jit_source_flat(const AirProgram& p, unsigned lh, unsigned b, s
     return true;
 }
 
-// Compiles for gfx950 and loads the module.  Returns false (with a message) on any failure; the
-// caller then keeps the interpreter kernel.
-inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModule_t* mod, hipFunction_t* fn,
-                           std::vector<uint32_t>* table, std::string* msg) {
+// Generates the kernel of an AIR and compiles it for gfx950 (or finds its code object in the process-wide / on-disk cache).  No HIP
+// call.  (Compiling the chips of an AIR set on several host threads was tried: hipRTC of ROCm 7.2 serialises the compiles of one
+// process -- five kernels took 24.1 s on five threads and 24.9 s in sequence -- and -O1 / -O2 compile as long as -O3: the time is the
+// backend's on these long basic blocks.)
+inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vector<uint32_t>* table, std::vector<char>* code_out, std::string* msg) {
     std::vector<JitClass> classes;
     std::string src;
     // ZKHIP_JIT_FLAT=1 prefers the flat form for every AIR (experiments)
@@ -461,7 +462,8 @@ inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModu
             *msg = "hiprtcCreateProgram failed";
             return false;
         }
-        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off"};
+        static const char* opt_level = getenv("ZKHIP_JIT_OPT") ? getenv("ZKHIP_JIT_OPT") : "-O3";   // (experiments: compile time against kernel time)
+        const char* opts[] = {"--offload-arch=gfx950", opt_level, "-ffp-contract=off"};
         hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
         if (rc != HIPRTC_SUCCESS) {
             size_t ls = 0;
@@ -490,6 +492,16 @@ inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModu
         std::lock_guard<std::mutex> lk(cache_mu);
         cache[src] = code;
     }
+    *code_out = std::move(code);
+    return true;
+}
+
+// Compiles (or finds) and loads the module.  Returns false (with a message) on any failure; the caller then keeps the interpreter
+// kernel.
+inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModule_t* mod, hipFunction_t* fn,
+                           std::vector<uint32_t>* table, std::string* msg) {
+    std::vector<char> code;
+    if (!quot_jit_code(p, lh, b, table, &code, msg)) return false;
     if (hipModuleLoadData(mod, code.data()) != hipSuccess) {
         *msg = "hipModuleLoadData failed";
         return false;
