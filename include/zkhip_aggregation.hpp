@@ -68,6 +68,29 @@ struct VerifyingKey {
     }
 };
 
+// FRI parameters of the node proofs: `leaf` for the nodes over segment proofs, `internal` for every level above
+// (crates/prover/src/prover/mod.rs:47-52 `default_agg_params`: leaf_params_with_100_bits_security / internal_params_with_100_bits_security
+// of the un-vendored SDK).  A node circuit is built for its CHILD's parameters and proven under its own, and a level's verifying key
+// carries its parameters (VerifyingKey::params).  By default every level uses the app's parameters: the file form of a verifying key
+// (`root.vk`) does not carry parameters and the command-line verifier reads them from the app's openvm.toml.  with_100_bits_security()
+// is the pair that follows the rule the reference's own parameters obey (openvm.toml: blow-up 2 with 100 queries; its stored proofs:
+// blow-up 4 with 44 queries; 16 + 16 proof-of-work bits): an internal proof costs more to make and less than half to verify in the
+// next circuit.
+struct AggregationSystemParams {
+    zkhip_params leaf{}, internal{};
+    static AggregationSystemParams defaults_for(const zkhip_params& app) {
+        AggregationSystemParams a;
+        a.leaf = a.internal = app;
+        return a;
+    }
+    static AggregationSystemParams with_100_bits_security() {
+        AggregationSystemParams a;
+        a.leaf = zkhip_params{1, 0, 100, 16, 16};
+        a.internal = zkhip_params{2, 0, 44, 16, 16};
+        return a;
+    }
+};
+
 class AggregationProver {
 public:
     struct Stats {
@@ -75,9 +98,11 @@ public:
         double witness_seconds = 0, tracegen_prove_seconds = 0, verify_seconds = 0, keygen_seconds = 0, build_seconds = 0;
     };
 
-    static AggregationProver setup(const VerifyingKey& app, const StatementSpec& spec, AggregationTreeConfig cfg = {}, int device = 0) {
+    static AggregationProver setup(const VerifyingKey& app, const StatementSpec& spec, AggregationTreeConfig cfg = {}, int device = 0,
+                                   const AggregationSystemParams* agg_params = nullptr) {
         AggregationProver p;
         p.app_ = app, p.spec_ = spec, p.cfg_ = cfg, p.device_ = device;
+        p.agg_params_ = agg_params ? *agg_params : AggregationSystemParams::defaults_for(app.params);
         p.levels_mu_.reset(new std::mutex), p.dev_mu_.reset(new std::mutex), p.build_mu_.reset(new std::mutex);
         if (app.airs.size() != app.heights.size() || app.airs.empty()) throw Error(Error::Setup, "aggregation: the app verifying key needs one height per AIR");
         if (spec.start.size() != spec.end.size()) throw Error(Error::Setup, "aggregation: start and end state must have the same length");
@@ -86,7 +111,7 @@ public:
     AggregationProver(AggregationProver&& o) noexcept { *this = std::move(o); }
     AggregationProver& operator=(AggregationProver&& o) noexcept {
         reset();
-        app_ = std::move(o.app_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, device_ = o.device_, ctx_ = o.ctx_, levels_ = std::move(o.levels_), stats = o.stats;
+        app_ = std::move(o.app_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, agg_params_ = o.agg_params_, device_ = o.device_, ctx_ = o.ctx_, levels_ = std::move(o.levels_), stats = o.stats;
         levels_mu_ = std::move(o.levels_mu_), dev_mu_ = std::move(o.dev_mu_), build_mu_ = std::move(o.build_mu_);
         o.ctx_ = nullptr;
         return *this;
@@ -438,6 +463,7 @@ private:
     VerifyingKey app_;
     StatementSpec spec_;
     AggregationTreeConfig cfg_;
+    AggregationSystemParams agg_params_;
     int device_ = 0;
     zkhip_ctx* ctx_ = nullptr;
     std::deque<Level> levels_;                       // (stable references: levels are added while others are in use)
@@ -501,7 +527,7 @@ private:
             int rc = zkhip_recursion_build(&cvk.params, za.data(), za.size(), arity(l), &st, &L.circ);
             if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the verifier circuit of level ") + std::to_string(l) + ": " + zkhip_recursion_last_error(nullptr));
             auto t1 = clk::now();
-            L.vk.params = app_.params;
+            L.vk.params = l == 0 ? agg_params_.leaf : agg_params_.internal;
             std::vector<zkhip_air> na(3);
             for (size_t i = 0; i < 3; i++) {
                 if (zkhip_recursion_air(L.circ, i, &na[i]) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_air");

@@ -584,7 +584,11 @@ inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& e
     std::vector<std::unique_ptr<SegmentProver>> own;
     std::vector<SegmentProver*> lanes;
     for (unsigned l = 0; l < std::max(1u, inflight); l++) own.emplace_back(new SegmentProver(params, exe, caps, device)), lanes.push_back(own.back().get());
-    scroll_zkvm_hip::AggregationProver agg = scroll_zkvm_hip::AggregationProver::setup(lanes[0]->vk(), segment_statement(), {}, device);
+    // ZKHIP_AGG_100BIT=1 (measurements): the leaf / internal pair of AggregationSystemParams::with_100_bits_security() instead of the app's
+    // parameters on every level (the root then verifies under ITS level's parameters: in-process through GuestStark::root_vk)
+    const scroll_zkvm_hip::AggregationSystemParams pair = scroll_zkvm_hip::AggregationSystemParams::with_100_bits_security();
+    scroll_zkvm_hip::AggregationProver agg =
+        scroll_zkvm_hip::AggregationProver::setup(lanes[0]->vk(), segment_statement(), {}, device, getenv("ZKHIP_AGG_100BIT") ? &pair : nullptr);
     (void)agg.node_vk(0);   // the leaf circuit and its key: setup, like the segment keys
     return prove_guest_with(lanes, agg, exe, in, caps, keep_segments);
 }

@@ -51,6 +51,43 @@ def test_device_traces_and_node_proof_match_the_oracle(zk, ora):
     assert z.verify(PARAMS, npk.verifying_airs(), [NOPV, NOPV, npv2], proof2) != 0
 
 
+def test_leaf_and_internal_parameter_sets(zk, ora):
+    """The reference proves its aggregation levels under parameter sets of their own (crates/prover/src/prover/mod.rs:47-52: leaf /
+    internal).  A circuit is built for its CHILD's parameters and proven under its own: segments under PARAMS, the leaf node under
+    blow-up 2 with 6 queries, the internal node (built for THAT child) under blow-up 4 with 3 queries; every proof == the oracle's."""
+    LEAF, INTERNAL = (1, 0, 6, 2, 2), (2, 0, 3, 1, 2)
+    kids = [ru.counter_segment(s, seed=i) for i, s in enumerate([3, 10, 17])]
+    vk = ru.verifying(PARAMS, kids[0])
+    pk = z.ProvingKey(zk, PARAMS, kids[0])
+    proofs = [pk.prove([zk.upload(a["trace"].reshape(-1)) for a in k], [a["pvs"] for a in k]) for k in kids]
+    pvs = [[a["pvs"] for a in k] for k in kids]
+    leaf_rc = z.RecursionCircuit(PARAMS, vk, 4, stmt=ru.COUNTER_STMT)          # verifies proofs made under PARAMS
+    leaf_proofs, leaf_pvs, leaf_vk = [], [], None
+    for group in ([0, 1], [2]):
+        st, npv = leaf_rc.witness([proofs[i] for i in group], [pvs[i] for i in group])
+        assert st == 0, leaf_rc.last_error()
+        node = ru.node_instance(leaf_rc, npv)
+        npk = z.ProvingKey(zk, LEAF, node)                                      # ... and is proven under the leaf set
+        proof = npk.prove(leaf_rc.tracegen(zk), [NOPV, NOPV, npv])
+        assert proof == ora.stark_prove(LEAF, node).tobytes()
+        assert z.verify(LEAF, npk.verifying_airs(), [NOPV, NOPV, npv], proof) == 0
+        assert z.verify(PARAMS, npk.verifying_airs(), [NOPV, NOPV, npv], proof) != 0   # (not a proof under the app's parameters)
+        leaf_proofs.append(proof), leaf_pvs.append([NOPV, NOPV, npv])
+        leaf_vk = npk.verifying_airs()
+    top_rc = z.RecursionCircuit(LEAF, leaf_vk, 3, stmt="node")                   # built for children proven under the leaf set
+    st, rpv = top_rc.witness(leaf_proofs, leaf_pvs)
+    assert st == 0, top_rc.last_error()
+    assert int(rpv[8]) == 3 and int(rpv[9]) == 24                               # the chained state: from segment 0's start to segment 2's end
+    root = ru.node_instance(top_rc, rpv)
+    rpk = z.ProvingKey(zk, INTERNAL, root)
+    proof = rpk.prove(top_rc.tracegen(zk), [NOPV, NOPV, rpv])
+    assert proof == ora.stark_prove(INTERNAL, root).tobytes()
+    assert z.verify(INTERNAL, rpk.verifying_airs(), [NOPV, NOPV, rpv], proof) == 0
+    # a circuit built for other child parameters than the proofs were made under has no witness
+    wrong = z.RecursionCircuit(PARAMS, leaf_vk, 3, stmt="node")
+    assert wrong.witness(leaf_proofs, leaf_pvs)[0] != 0
+
+
 def test_prove_agg_cli_69_segments_to_one_root(ora, tmp_path):
     n_seg = 69
     start, tasks, segs = 1000, [], []
