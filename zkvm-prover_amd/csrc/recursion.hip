@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <map>
 #include <memory>
@@ -102,6 +103,11 @@ struct Circuit {
     // order[sections[i] .. sections[i + 1]) verifies child i and touches only that child's wires and constant wires: the
     // sections can be evaluated side by side once the constant rows are done
     std::vector<size_t> sections;
+    // inside child i: order[sub[i][q] .. sub[i][q + 1]) checks query q (its openings, reduced openings, folds) and reads only the
+    // child's part before the queries and constants: once that part is done the queries run side by side (a hundred per child), then
+    // whatever follows them.  `query_parallel` is set by a dependency check over the finished circuit, not assumed.
+    std::vector<std::vector<size_t>> sub;
+    bool query_parallel = false;
 };
 
 struct BuildError {
@@ -865,8 +871,15 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci) 
 
     // ---- queries ----
     const uint32_t half = minv(to_monty(2));
+    // the query indices first (the challenger is a chain: nothing else touches it from here on), then the queries, each a part of the
+    // circuit of its own
+    std::vector<std::vector<V>> idx_of(prm.num_queries);
+    for (unsigned qn = 0; qn < prm.num_queries; qn++) idx_of[qn] = ch.sample_bits(hmax);  // least significant first
+    b.c.sub.emplace_back();
     for (unsigned qn = 0; qn < prm.num_queries; qn++) {
-        const std::vector<V> idx = ch.sample_bits(hmax);  // least significant first
+        b.close_input_rows();
+        b.c.sub.back().push_back(b.c.order.size());
+        const std::vector<V>& idx = idx_of[qn];
         std::vector<std::vector<V>> rows_of(batches.size());
         for (size_t bi = 0; bi < batches.size(); bi++) {
             const Batch& bt = batches[bi];
@@ -957,6 +970,8 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci) 
         }
         b.assert_eq(eval, want);
     }
+    b.close_input_rows();
+    b.c.sub.back().push_back(b.c.order.size());
     if (r != vk.proof_words) throw BuildError{"internal: the circuit's walk over the proof does not end at its last word"};
     return out;
 }
@@ -1238,6 +1253,51 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
         b.c.n_pvs = pvl.size();
         while (pvl.size() % 4) pvl.push_back(Lane{cst(ext_zero()), -1});
         for (size_t g = 0; g < pvl.size(); g += 4) b.c.pv_wires.push_back(b.use(b.pack_lanes(&pvl[g])));
+        // May the queries of a child run side by side?  Every wire a query part reads must be written by a constant row, by the child's
+        // part before its queries, or by the same query part (roles: 2 = written here, 1 = read here; a permutation reads in, writes out).
+        {
+            Circuit& c = b.c;
+            const size_t n_children = c.sections.size() - 1;
+            bool ok = c.sub.size() == n_children;
+            auto is_const_row = [](const Gate& G) { return G.kind == K_LIN && !G.role[0] && !G.role[1] && !G.role[3]; };
+            std::vector<uint32_t> part_of_wire(c.n_wires + 1, 0);   // 0 = constant, else 1 + part id
+            // part ids: child i: pre = 3 i (n_q + 2) ... keep it simple: id = (i, k) -> i * stride + k, k = 0 pre, 1 .. n_q queries, n_q + 1 post
+            size_t stride = 0;
+            for (const auto& sb : c.sub) stride = std::max(stride, sb.size() + 2);
+            auto part_at = [&](size_t oi) -> uint32_t {
+                size_t i = std::upper_bound(c.sections.begin(), c.sections.end(), oi) - c.sections.begin() - 1;
+                if (i >= n_children) return (uint32_t)(n_children * stride + 1);   // the statement logic behind the children
+                const auto& sb = c.sub[i];
+                const size_t k = std::upper_bound(sb.begin(), sb.end(), oi) - sb.begin();   // 0 = before the queries
+                return (uint32_t)(i * stride + k + 1);
+            };
+            for (size_t pass = 0; pass < 2 && ok; pass++)
+                for (size_t oi = 0; oi < c.order.size() && ok; oi++) {
+                    const Op& op = c.order[oi];
+                    const uint32_t part = part_at(oi);
+                    const size_t i = (part - 1) / stride, k = (part - 1) % stride;
+                    const bool is_query = i < n_children && k >= 1 && k + 1 < c.sub[i].size() + 1 && k <= c.sub[i].size() - 1;
+                    auto wr = [&](uint32_t w, bool constant) {
+                        if (pass == 0) part_of_wire[w] = constant ? 0 : part;
+                    };
+                    auto rd = [&](uint32_t w) {
+                        if (pass == 0 || !is_query || !w) return;
+                        const uint32_t src = part_of_wire[w];
+                        if (src != 0 && src != part && src != (uint32_t)(i * stride + 1)) ok = false;   // not constant, not own, not the child's part before the queries
+                    };
+                    if (op.is_perm) {
+                        for (int j = 0; j < 4; j++) rd(c.perms[op.idx].in[j]), wr(c.perms[op.idx].out[j], false);
+                    } else {
+                        const Gate& G = c.gates[op.idx];
+                        for (int sl = 0; sl < 4; sl++) {
+                            if (G.role[sl] == 2) wr(G.w[sl], is_const_row(G));
+                            else if (G.role[sl] == 1) rd(G.w[sl]);
+                            if (G.kind == K_INPUT && G.role[sl] == 2 && (G.src[sl].kind == S_HINT_BIT || G.src[sl].kind == S_HINT_COORD)) rd(G.src[sl].a);
+                        }
+                    }
+                }
+            c.query_parallel = ok && !getenv("ZKHIP_RECURSION_SERIAL_QUERIES");
+        }
         R->c = std::move(b.c);
     } catch (const BuildError& e) {
         g_build_error = e.msg;
@@ -1407,10 +1467,43 @@ int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, co
     {
         const size_t n_sec = c.sections.size() - 1;
         std::vector<long> bad(n_sec, -1);
-        std::vector<std::thread> th;
-        for (size_t i = 1; i < n_sec; i++) th.emplace_back([&, i]() { bad[i] = run(c.sections[i], c.sections[i + 1], true); });
-        bad[0] = run(c.sections[0], c.sections[1], true);
-        for (auto& t : th) t.join();
+        auto keep_first = [](long& acc, long b) {
+            if (b >= 0 && (acc < 0 || b < acc)) acc = b;
+        };
+        if (!c.query_parallel) {
+            std::vector<std::thread> th;
+            for (size_t i = 1; i < n_sec; i++) th.emplace_back([&, i]() { bad[i] = run(c.sections[i], c.sections[i + 1], true); });
+            bad[0] = run(c.sections[0], c.sections[1], true);
+            for (auto& t : th) t.join();
+        } else {
+            // the children's parts before their queries side by side, then every (child, query) part from a shared counter, then what
+            // follows the queries
+            auto each_child = [&](auto&& f) {
+                std::vector<std::thread> th;
+                for (size_t i = 1; i < n_sec; i++) th.emplace_back([&, i]() { f(i); });
+                f(0);
+                for (auto& t : th) t.join();
+            };
+            each_child([&](size_t i) { keep_first(bad[i], run(c.sections[i], c.sub[i].front(), true)); });
+            std::vector<std::pair<size_t, size_t>> tasks;
+            for (size_t i = 0; i < n_sec; i++)
+                for (size_t q = 0; q + 1 < c.sub[i].size(); q++) tasks.push_back({i, q});
+            const size_t n_threads = std::min<size_t>(tasks.size(), std::max(1u, std::thread::hardware_concurrency()));
+            std::atomic<size_t> next{0};
+            std::vector<std::vector<long>> tb(n_threads, std::vector<long>(n_sec, -1));
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < n_threads; t++)
+                th.emplace_back([&, t]() {
+                    for (size_t k; (k = next.fetch_add(1)) < tasks.size();) {
+                        const size_t i = tasks[k].first, q = tasks[k].second;
+                        keep_first(tb[t][i], run(c.sub[i][q], c.sub[i][q + 1], true));
+                    }
+                });
+            for (auto& t : th) t.join();
+            for (size_t t = 0; t < n_threads; t++)
+                for (size_t i = 0; i < n_sec; i++) keep_first(bad[i], tb[t][i]);
+            each_child([&](size_t i) { keep_first(bad[i], run(c.sub[i].back(), c.sections[i + 1], true)); });
+        }
         for (long b : bad)
             if (b >= 0 && (first_bad < 0 || b < first_bad)) first_bad = b;
         const long tail = run(c.sections[n_sec], c.order.size(), true);
