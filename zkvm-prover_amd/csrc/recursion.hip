@@ -1000,6 +1000,7 @@ struct zkhip_recursion {
     // device copies of the wiring (ids per slot) for the trace generators
     int dev_ready_device = -1;
     uint32_t *d_gate_ids = nullptr, *d_perm_ids = nullptr, *d_wires = nullptr, *d_p2_inputs = nullptr;
+    void* pinned_vals = nullptr;   // vals.data() while it is registered as page-locked memory (42 MB of wire values cross PCIe per node)
 };
 
 namespace {
@@ -1312,6 +1313,7 @@ void zkhip_recursion_destroy(zkhip_recursion* R) {
     if (!R) return;
     for (uint32_t* p : {R->d_gate_ids, R->d_perm_ids, R->d_wires, R->d_p2_inputs})
         if (p) (void)hipFree(p);
+    if (R->pinned_vals) (void)hipHostUnregister(R->pinned_vals);
     delete R;
 }
 
@@ -1381,7 +1383,7 @@ int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, co
                 if (child_pvs[ci][a][i] >= P) return ZKHIP_ERR_INVALID;
     }
     std::vector<Ext>& vals = R->vals;
-    vals.assign((size_t)c.n_wires + 1, ext_zero());
+    if (vals.size() != (size_t)c.n_wires + 1) vals.assign((size_t)c.n_wires + 1, ext_zero());   // (every wire has exactly one defining row: nothing stale survives a run)
     auto lin_value = [&](const Gate& G) {
         Ext r = G.qK;
         const Ext &a = vals[G.w[0]], &bq = vals[G.w[1]], &d = vals[G.w[3]];
@@ -1488,7 +1490,10 @@ int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, co
             std::vector<std::pair<size_t, size_t>> tasks;
             for (size_t i = 0; i < n_sec; i++)
                 for (size_t q = 0; q + 1 < c.sub[i].size(); q++) tasks.push_back({i, q});
-            const size_t n_threads = std::min<size_t>(tasks.size(), std::max(1u, std::thread::hardware_concurrency()));
+            // (all cores: measured in the one-flow pipeline with 4 / 8 / 16 threads on 16 cores -- the segment phase loses ~40 ms to the
+            // contention, the tree's tail gains ~100 ms; ZKHIP_WITNESS_THREADS overrides)
+            static const unsigned cap = getenv("ZKHIP_WITNESS_THREADS") ? (unsigned)atoi(getenv("ZKHIP_WITNESS_THREADS")) : std::thread::hardware_concurrency();
+            const size_t n_threads = std::min<size_t>(tasks.size(), std::max(1u, cap));
             std::atomic<size_t> next{0};
             std::vector<std::vector<long>> tb(n_threads, std::vector<long>(n_sec, -1));
             std::vector<std::thread> th;
@@ -1583,6 +1588,11 @@ extern "C" int zkhip_recursion_tracegen(zkhip_ctx* ctx, zkhip_recursion* R, uint
         ZK_TRY(upload(ctx, R->d_gate_ids, ids.data(), ids.size() * 4));
         ZK_TRY(upload(ctx, R->d_perm_ids, pids.data(), pids.size() * 4));
         R->dev_ready_device = ctx->device;
+    }
+    if (R->pinned_vals != (void*)R->vals.data()) {
+        if (R->pinned_vals) (void)hipHostUnregister(R->pinned_vals);
+        R->pinned_vals = hipHostRegister(R->vals.data(), R->vals.size() * 16, hipHostRegisterDefault) == hipSuccess ? (void*)R->vals.data() : nullptr;
+        (void)hipGetLastError();
     }
     ZK_TRY(upload(ctx, R->d_wires, R->vals.data(), R->vals.size() * 16));
     const size_t N0 = (size_t)1 << R->log_height[0];
