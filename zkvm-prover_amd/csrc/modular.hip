@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_modmul_ts(const uint32_t* __restrict__ 
 }
 
 std::mutex g_mu;
-std::map<md::Modulus, std::vector<uint32_t>> g_programs;   // per modulus, kept for the life of the process
+std::map<std::pair<md::Modulus, std::pair<uint32_t, uint32_t>>, std::vector<uint32_t>> g_programs;   // per (modulus, buses), kept for the life of the process
 
 }  // namespace
 }  // namespace zk
@@ -148,7 +148,7 @@ int zkhip_modmul_air(const uint8_t modulus[32], uint32_t bitwise_bus, uint32_t t
     if (zero) return ZKHIP_ERR_INVALID;
     try {
         std::lock_guard<std::mutex> lk(g_mu);
-        md::Modulus key = m;   // (the buses are part of the program: one entry per (modulus, buses) in practice = per modulus)
+        const auto key = std::make_pair(m, std::make_pair(bitwise_bus, tuple_bus));
         auto it = g_programs.find(key);
         if (it == g_programs.end()) {
             zkhip::air::AirBuilder b(md::WIDTH, 0);
