@@ -1481,13 +1481,17 @@ inline void memory_access_air(AirBuilder& b, uint32_t range_bus = RANGE_BUS, uin
     }
     b.push_interaction(range_bus, {lo}, ok, Kind::Send);
     b.push_interaction(range_bus, {hi}, ok, Kind::Send);
+    {
+        const Expr h8 = hi * 8;   // gap_hi < 2^13: the gap cannot stand for a negative difference modulo p
+        b.push_interaction(range_bus, {h8}, ok, Kind::Send);
+    }
     b.push_interaction(range_bus, {d}, ok, Kind::Send);
     b.push_interaction(memory_bus, {as_, ptr, pd, pts}, ok, Kind::Receive);
     b.push_interaction(memory_bus, {as_, ptr, d, ts}, ok, Kind::Send);
 }
 
 // air.memory_boundary_air(pointer_bits, range_bus, memory_bus): AirBuilder(8, 0)
-inline void memory_boundary_air(AirBuilder& b, unsigned pointer_bits = 29, uint32_t range_bus = RANGE_BUS, uint32_t memory_bus = MEMORY_BUS) {
+inline void memory_boundary_air(AirBuilder& b, unsigned pointer_bits = 27, uint32_t range_bus = RANGE_BUS, uint32_t memory_bus = MEMORY_BUS) {
     Expr v[8];
     for (int i = 0; i < 8; i++) v[i] = b.var(i);
     const Expr as_ = v[0], ptr = v[1], init = v[2], fin = v[3], ts = v[4], ok = v[5], lo = v[6], hi = v[7];
@@ -1516,6 +1520,10 @@ inline void memory_boundary_air(AirBuilder& b, unsigned pointer_bits = 29, uint3
     }
     b.push_interaction(range_bus, {lo}, ok, Kind::Send);
     b.push_interaction(range_bus, {hi}, ok, Kind::Send);
+    {
+        const Expr h8 = hi * 8;   // keys and gaps below 2^29: two rows cannot carry one key
+        b.push_interaction(range_bus, {h8}, ok, Kind::Send);
+    }
     {
         const Expr z0 = b.constant(0);
         b.push_interaction(memory_bus, {as_, ptr, init, z0}, ok, Kind::Send);

@@ -152,7 +152,7 @@ public:
         uint32_t* d_init = const_cast<uint32_t*>(up(rec.bnd_initial));
         uint32_t* d_fin = const_cast<uint32_t*>(up(rec.bnd_final));
         if (n_bnd) check(zkhip_to_monty(ctx_, d_init, n_bnd)), check(zkhip_to_monty(ctx_, d_fin, n_bnd));
-        check(zkhip_memory_boundary_tracegen(ctx_, up(rec.bnd_as), up(rec.bnd_ptr), d_init, d_fin, up(rec.bnd_final_ts), n_bnd, 2, 29, lbnd, d_bnd));
+        check(zkhip_memory_boundary_tracegen(ctx_, up(rec.bnd_as), up(rec.bnd_ptr), d_init, d_fin, up(rec.bnd_final_ts), n_bnd, 2, 27, lbnd, d_bnd));
         // the 16-bit range checker's multiplicities, counted where the requesting columns lie (valid rows only)
         uint32_t* d_rng = dzeros(1u << 16);
         const size_t NA = (size_t)1 << lacc, NB = (size_t)1 << lbnd;
@@ -163,6 +163,9 @@ public:
         };
         count(d_acc + 8 * NA, n_acc), count(d_acc + 9 * NA, n_acc), count(d_acc + 4 * NA, n_acc);
         count(d_bnd + 6 * NB, n_bnd), count(d_bnd + 7 * NB, n_bnd);
+        // 8 gap_hi of both chips: the gaps stay below 2^29 (a request outside the table fails the generator)
+        if (n_acc) check(zkhip_range_counts_scaled_tracegen(ctx_, d_acc + 9 * NA, n_acc, 8, 16, d_rng, 1));
+        if (n_bnd) check(zkhip_range_counts_scaled_tracegen(ctx_, d_bnd + 7 * NB, n_bnd, 8, 16, d_rng, 1));
         const auto t2 = clk::now();
         gp.tracegen_time_mills = ms(t1, t2);
         // ---- 3. the AIR set and its preprocessed tables

@@ -106,8 +106,8 @@ def _memory_chips(zk, ora, rec, tamper=None):
     exp_acc, bad = ora.memory_access_trace(*[acc[k] for k in order], la)
     assert bad == 0 and (zk.download(d_acc).reshape(10, -1) == exp_acc).all()
     d_bnd = zk.memory_boundary_tracegen(as_dev(rec["bnd_as"]), as_dev(rec["bnd_ptr"]), zk.upload(rec["bnd_initial"]), zk.upload(rec["bnd_final"]),
-                                        as_dev(rec["bnd_final_ts"]), 2, 29, lb)
-    exp_bnd, bad = ora.memory_boundary_trace(rec["bnd_as"], rec["bnd_ptr"], rec["bnd_initial"], rec["bnd_final"], rec["bnd_final_ts"], 2, 29, lb)
+                                        as_dev(rec["bnd_final_ts"]), 2, 27, lb)
+    exp_bnd, bad = ora.memory_boundary_trace(rec["bnd_as"], rec["bnd_ptr"], rec["bnd_initial"], rec["bnd_final"], rec["bnd_final_ts"], 2, 27, lb)
     assert bad == 0 and (zk.download(d_bnd).reshape(8, -1) == exp_bnd).all()
     # the range table's multiplicities, counted on the device from the requesting columns (valid rows only)
     NA, NB = 1 << la, 1 << lb
@@ -116,8 +116,11 @@ def _memory_chips(zk, ora, rec, tamper=None):
         d_rng = zk.range_counts_tracegen(d_acc[col * NA: col * NA + n], 16, t_counts=d_rng, accumulate=d_rng is not None)
     for col in (6, 7):
         d_rng = zk.range_counts_tracegen(d_bnd[col * NB: col * NB + nb], 16, t_counts=d_rng, accumulate=True)
+    # 8 gap_hi of both chips (gaps below 2^29: a difference cannot wrap around p)
+    d_rng = zk.range_counts_scaled_tracegen(d_acc[9 * NA: 9 * NA + n], 8, 16, d_rng)
+    d_rng = zk.range_counts_scaled_tracegen(d_bnd[7 * NB: 7 * NB + nb], 8, 16, d_rng)
     cnt = np.zeros(1 << 16, np.int64)
-    for v in (exp_acc[8][:n], exp_acc[9][:n], exp_acc[4][:n], exp_bnd[6][:nb], exp_bnd[7][:nb]):
+    for v in (exp_acc[8][:n], exp_acc[9][:n], exp_acc[4][:n], exp_bnd[6][:nb], exp_bnd[7][:nb], 8 * exp_acc[9][:n], 8 * exp_bnd[7][:nb]):
         cnt += np.bincount(v.astype(np.int64), minlength=1 << 16)
     assert (zk.download(d_rng) == (cnt % P).astype(np.uint32)).all()
     airs = [dict(program=air.memory_access_air().program(), log_height=la, width=10, n_pvs=0, trace=exp_acc, pvs=NOPV),
@@ -214,10 +217,10 @@ def test_prove_guest_in_cpp_end_to_end(zk, ora, tmp_path):
     ls, rc, _ = ora.rv32_loadstore_trace(rec["ls_case"], rec["ls_read"], rec["ls_prev"], lls, range_counts=rc)
     order = ("as", "ptr", "prev_data", "prev_ts", "data", "ts", "is_read")
     acc, _ = ora.memory_access_trace(*[rec["acc_" + k] for k in order], lacc)
-    bnd, _ = ora.memory_boundary_trace(rec["bnd_as"], rec["bnd_ptr"], rec["bnd_initial"], rec["bnd_final"], rec["bnd_final_ts"], 2, 29, lbnd)
+    bnd, _ = ora.memory_boundary_trace(rec["bnd_as"], rec["bnd_ptr"], rec["bnd_initial"], rec["bnd_final"], rec["bnd_final_ts"], 2, 27, lbnd)
     n, nb = len(rec["acc_ts"]), len(rec["bnd_ptr"])
     cnt = np.zeros(1 << 16, np.int64)
-    for v in (acc[8][:n], acc[9][:n], acc[4][:n], bnd[6][:nb], bnd[7][:nb]):
+    for v in (acc[8][:n], acc[9][:n], acc[4][:n], bnd[6][:nb], bnd[7][:nb], 8 * acc[9][:n], 8 * bnd[7][:nb]):
         cnt += np.bincount(v.astype(np.int64), minlength=1 << 16)
     A = lambda program, lh, w, tr, prep=None: dict(program=program, log_height=lh, width=w, n_pvs=0, trace=tr, pvs=NOPV, **({"prep": prep} if prep is not None else {}))  # noqa: E731
     airs = [A(air.program_air().program(), lp, 10, np.concatenate([prog, freq.reshape(1, -1)])),

@@ -1178,7 +1178,9 @@ def memory_access_air(range_bus=5, memory_bus=1):
     """One row per access of a 16-bit memory cell (the access side of OpenVM's offline memory checking; memory_boundary_air() is
     the other side): columns as | ptr | prev_data | prev_ts | data | ts | is_read | is_valid | gap_lo | gap_hi.  A valid row
     receives (as, ptr, prev_data, prev_ts) and sends (as, ptr, data, ts) on the memory bus; a read leaves the value as it was;
-    time moves forward: ts - prev_ts - 1 = gap_lo + 2^16 gap_hi, the limbs and the cell value range-checked to 16 bits."""
+    time moves forward: ts - prev_ts - 1 = gap_lo + 2^16 gap_hi, the limbs and the cell value range-checked to 16 bits and 8 gap_hi
+    too: gap_hi < 2^13, the gap stays below 2^29 and cannot stand for a negative difference modulo p (timestamps below 2^29, as
+    OpenVM's timestamp_max_bits; the generators refuse larger ones)."""
     b = AirBuilder(MEMORY_ACCESS_WIDTH, 0)
     as_, ptr, pd, pts, d, ts, rd, ok, lo, hi = (b.var(i) for i in range(10))
     b.assert_zero(ok * (ok - 1))
@@ -1188,6 +1190,7 @@ def memory_access_air(range_bus=5, memory_bus=1):
     b.assert_zero(ok * (ts - pts - 1 - lo - hi * (1 << 16)))
     b.push_interaction(range_bus, [lo], ok, "send")
     b.push_interaction(range_bus, [hi], ok, "send")
+    b.push_interaction(range_bus, [hi * 8], ok, "send")
     b.push_interaction(range_bus, [d], ok, "send")
     b.push_interaction(memory_bus, [as_, ptr, pd, pts], ok, "receive")
     b.push_interaction(memory_bus, [as_, ptr, d, ts], ok, "send")
@@ -1220,11 +1223,13 @@ def exec_frame_air(bus=PROGRAM_BUS):
 MEMORY_BOUNDARY_WIDTH = 8
 
 
-def memory_boundary_air(pointer_bits=29, range_bus=5, memory_bus=1):
+def memory_boundary_air(pointer_bits=27, range_bus=5, memory_bus=1):
     """OpenVM VolatileBoundaryChip: columns as, ptr, initial, final, final_ts, is_valid, gap_lo, gap_hi.  Valid rows come
     first and are strictly sorted by key = as * 2^pointer_bits + ptr: key' - key - 1 = gap_lo + 2^16 gap_hi with both limbs
-    sent to the range checker; each valid row sends (as, ptr, initial, 0) and receives (as, ptr, final, final_ts) on the
-    memory bus (the initial / final memory states of the offline-checking argument)."""
+    and 8 gap_hi sent to the range checker (the gap stays below 2^29: with address spaces below 4 and pointers below 2^27 the keys
+    stay below 2^29 too, so the difference cannot wrap around p and two rows cannot carry one key); each valid row sends (as, ptr,
+    initial, 0) and receives (as, ptr, final, final_ts) on the memory bus (the initial / final memory states of the
+    offline-checking argument)."""
     b = AirBuilder(MEMORY_BOUNDARY_WIDTH, 0)
     as_, ptr, init, fin, ts, ok, lo, hi = (b.var(i) for i in range(8))
     ok_n = b.var(5, 1)
@@ -1235,6 +1240,7 @@ def memory_boundary_air(pointer_bits=29, range_bus=5, memory_bus=1):
     b.when_transition(ok_n * (key_n - key - 1 - lo - hi * (1 << 16)))
     b.push_interaction(range_bus, [lo], ok, "send")
     b.push_interaction(range_bus, [hi], ok, "send")
+    b.push_interaction(range_bus, [hi * 8], ok, "send")
     b.push_interaction(memory_bus, [as_, ptr, init, 0], ok, "send")
     b.push_interaction(memory_bus, [as_, ptr, fin, ts], ok, "receive")
     return b
