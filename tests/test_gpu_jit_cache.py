@@ -54,3 +54,32 @@ def test_disk_cache_round_trip(tmp_path):
     d3, _ = _run(tmp_path)
     assert d3 == d1
     print("keygen cold %.2f s, warm %.2f s" % (t_cold, t_warm))
+
+
+TILED_SCRIPT = r"""
+import hashlib
+import numpy as np
+import zkvm_prover_amd as z
+from zkvm_prover_amd import air
+ctx = z.Context(0)
+sa = air.SyntheticAir(width=90, n_free=24, n_bool=4, n_boundary=3, seed=7)
+tr, pv = sa.gen_trace(11, seed=2)
+airs = [dict(program=sa.program(), log_height=11, width=90, n_pvs=len(pv), trace=tr, pvs=pv)]
+params = (1, 0, 6, 2, 3)
+pk = z.ProvingKey(ctx, params, airs)
+proof = pk.prove([ctx.upload(tr.reshape(-1))], [pv])
+assert z.verify(params, airs, [pv], proof) == 0
+print("RESULT", hashlib.sha256(proof).hexdigest())
+"""
+
+
+def test_lds_tiled_constraint_kernel_gives_the_same_proof():
+    """The opt-in LDS-tiled form of the compiled constraint kernel (ZKHIP_JIT_TILE=1: a workgroup copies its 64 rows into LDS once and
+    eight waves share the constraints) against the plain class form and the interpreter: one AIR, three kernels, one proof."""
+    digests = []
+    for extra in (dict(ZKHIP_FORCE_JIT="1", ZKHIP_JIT_TILE="1"), dict(ZKHIP_FORCE_JIT="1"), dict(ZKHIP_NO_JIT="1")):
+        env = dict(os.environ, PYTHONPATH=ROOT, **extra)
+        out = subprocess.run([sys.executable, "-c", TILED_SCRIPT], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()[1])
+    assert digests[0] == digests[1] == digests[2]

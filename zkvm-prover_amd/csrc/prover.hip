@@ -790,6 +790,7 @@ struct AirPlan {
     uint32_t prep_commit[8] = {};      // canonical
     hipModule_t jit_mod = nullptr;   // keygen-compiled constraint kernel (null -> interpreter)
     hipFunction_t jit_fn = nullptr;
+    unsigned jit_rows_per_block = 256;   // 0: the LDS-tiled form (a fixed grid walks 64-row tiles)
     uint32_t* d_jit_tab = nullptr;   // per-instance leaf parameters of the shape classes
 };
 
@@ -1140,7 +1141,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
                                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n_nodes, forced ? ", interpreter form refused" : "");
                 }
             } jit_timer{jit_t0, a, (size_t)A.prog.n_nodes, !interp_ok};
-            if (quot_jit_build(A.prog, airs[a].log_height, pk->b, &A.jit_mod, &A.jit_fn, &tab, &msg) &&
+            if (quot_jit_build(A.prog, airs[a].log_height, pk->b, &A.jit_mod, &A.jit_fn, &tab, &msg, &A.jit_rows_per_block) &&
                 hipMalloc(&A.d_jit_tab, tab.size() * 4) == hipSuccess &&
                 hipMemcpyAsync(A.d_jit_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
                 hipStreamSynchronize(ctx->stream) == hipSuccess) {
@@ -1944,8 +1945,9 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
                           (void*)&tw_fwd, (void*)&qa.zh,  (void*)&qa.inv_zh,   (void*)&A.d_jit_tab,
                           (void*)&qa.gen, (void*)&qa.w_n_inv, (void*)&tw_shift, (void*)&qa.perm,
                           (void*)&qa.lchal, (void*)&qa.expo, (void*)&qa.prep, (void*)&h_bits, (void*)&nq_rows};
-        ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, (unsigned)((A.MQ + 255) / 256), 1, 1, 256, 1, 1, 0, st,
-                                                params, nullptr));
+        // (tiled form: one workgroup per CU holds its 150 KB tile; a few rounds of workgroups per CU even the tail out)
+        const unsigned blocks = A.jit_rows_per_block ? (unsigned)((A.MQ + 255) / 256) : (unsigned)std::min<size_t>(A.MQ / 64, 4 * 256);
+        ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, blocks, 1, 1, A.jit_rows_per_block ? 256 : 64 * QUOT_TILE_WAVES, 1, 1, 0, st, params, nullptr));
     }
     // chunk j = rows [jN,(j+1)N) of q, bit-reversed within the chunk: bring to natural order (all chips, all chunks: one
     // launch per kernel form), then extend from s_j*H to g*K (shift g/s_j) -- p3's quotient-chunk commitment

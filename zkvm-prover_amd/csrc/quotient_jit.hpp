@@ -310,6 +310,174 @@ inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b,
     return os.str();
 }
 
+// Third code shape: the class form over an LDS TILE.  The class form reads a trace cell from memory once per constraint that uses it
+// (the leaves are table-driven, so nothing can stay in a register between constraints): 3.9x the trace's bytes for the 300-column
+// AIR of the headline, at HBM speed.  Here a workgroup of four waves owns 64 consecutive rows: the waves first copy every (column,
+// rotation) the constraints use into LDS -- one 256-byte row segment per load, ~150 KB in flight per CU --, then wave w evaluates
+// constraints w, w + 4, ... of every class from the tile and the four partial sums meet in LDS.  The trace crosses HBM once.
+// (In bit-reversed storage the "next" rows of 64 consecutive rows are 64 consecutive rows too: the offset touches high bits only.)
+constexpr unsigned QUOT_TILE_ROWS = 64, QUOT_TILE_WAVES = 8, QUOT_TILE_MAX_LDS_WORDS = 39936;   // 156 KB of the CU's 160
+inline bool quot_jit_source_tiled(const AirProgram& p, unsigned lh, unsigned b, std::vector<JitClass>& classes, std::vector<uint32_t>* table,
+                                  std::string* src) {
+    // Measured on the headline AIR (2^22 x 300, 2^23 LDE rows): HBM traffic of the kernel 43.5 -> ~11 GB, but 17.4 ms
+    // against the plain class form's 6.0 ms (27.2 ms with four waves and a rolled load loop): one 84 KB tile per CU leaves nothing
+    // to overlap its load with (a second buffer does not fit 160 KB), the three barriers per tile and the selector inversions on
+    // one wave sit on the critical path, and the plain form already streams its re-reads at 7 TB/s.  Opt-in: ZKHIP_JIT_TILE=1.
+    if (lh + b < 12 || !getenv("ZKHIP_JIT_TILE")) return false;
+    // slots: the distinct (column, rotation) pairs of the main trace
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> slot_of;
+    size_t n_var_uses = 0;
+    for (const JitClass& C : classes) {
+        std::vector<int> pidx(C.entries.size(), -1);
+        for (size_t j = 0; j < C.param_entry.size(); j++) pidx[C.param_entry[j]] = (int)j + 1;
+        for (const auto& row : C.inst)
+            for (size_t e = 0; e < C.entries.size(); e++)
+                if (C.entries[e].op == A_VAR) {
+                    const auto key = std::make_pair(row[(size_t)pidx[e]], C.entries[e].a);
+                    if (!slot_of.count(key)) slot_of.emplace(key, (uint32_t)slot_of.size());
+                    n_var_uses++;
+                }
+    }
+    const size_t n_slots = slot_of.size(), lds_words = n_slots * QUOT_TILE_ROWS + QUOT_TILE_WAVES * 4 * QUOT_TILE_ROWS + 3 * QUOT_TILE_ROWS;
+    // worth it when cells are re-read (uses well above slots) and the tile fits
+    if (n_slots < 48 || lds_words > QUOT_TILE_MAX_LDS_WORDS || n_var_uses < 2 * n_slots) return false;
+    std::ostringstream os;
+    os << quot_jit_preamble();
+    (void)p;
+    os << "#define B " << b << "u\n#define M ((size_t)1 << H)\n#define NSLOTS " << n_slots << "u\n#define NW " << QUOT_TILE_WAVES << "u\n";
+    std::vector<uint32_t> slot_tab(n_slots);
+    for (const auto& kv : slot_of) slot_tab[kv.second] = kv.first.first | (kv.first.second ? 0x80000000u : 0u);
+    os << R"JIT(
+extern "C" __global__ __launch_bounds__(64 * NW) void quot_jit(const uint32_t* __restrict__ lde, uint32_t* __restrict__ q,
+        const uint32_t* __restrict__ pvs, const uint32_t* __restrict__ apow, const uint32_t* __restrict__ tw_fwd,
+        const uint32_t* __restrict__ zh_t, const uint32_t* __restrict__ inv_zh_t, const uint32_t* __restrict__ tab,
+        uint32_t gen, uint32_t w_n_inv, uint32_t tw_shift, const uint32_t* __restrict__ perm,
+        const uint32_t* __restrict__ lchal, const uint32_t* __restrict__ expo, const uint32_t* __restrict__ prep,
+        uint32_t H, uint32_t NQROWS) {
+    __shared__ uint32_t tile[NSLOTS * 64u + 4u * NW * 64u + 3u * 64u];
+    uint32_t* const red_s = tile + NSLOTS * 64u;      // [wave][coordinate][lane]
+    uint32_t* const sel_s = red_s + 4u * NW * 64u;    // first, trans, last per lane
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const gptr ldep = (gptr)lde;
+    const gptr permp = (gptr)perm;
+    const gptr prepp = (gptr)prep;
+    for (uint32_t t = blockIdx.x; t < (NQROWS >> 6); t += gridDim.x) {
+        const uint32_t r = (t << 6) + lane;
+        const uint32_t i = __brev(r) >> (32 - H);
+        const uint32_t rn = __brev((i + (1u << B)) & ((1u << H) - 1u)) >> (32 - H);
+        const uint32_t ro = r << 2, rno = rn << 2;
+        // sixteen row segments per wave in flight before the first LDS write (the loop alone keeps one)
+        for (uint32_t s0 = wv; s0 < NSLOTS; s0 += 16u * NW) {
+            uint32_t v[16];
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; u++) {
+                const uint32_t s = s0 + u * NW;
+                if (s < NSLOTS) {
+                    const uint32_t cr = ((cptr)tab)[SLOT_TAB + s];
+                    v[u] = LD(cr & 0x7fffffffu, (cr >> 31) ? rno : ro);
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; u++) {
+                const uint32_t s = s0 + u * NW;
+                if (s < NSLOTS) tile[s * 64u + lane] = v[u];
+            }
+        }
+        if (wv == 0) {
+            const uint32_t halfm = 1u << (H - 1);
+            const uint32_t wi = i < halfm ? tw_fwd[(size_t)i << tw_shift] : mneg(tw_fwd[(size_t)(i - halfm) << tw_shift]);
+            const uint32_t x = mmul(gen, wi);
+            const uint32_t zh = zh_t[i & ((1u << B) - 1u)];
+            const uint32_t st = msub(x, w_n_inv);
+            sel_s[lane] = mmul(zh, minv(msub(x, ONE))), sel_s[64u + lane] = st, sel_s[128u + lane] = mmul(zh, minv(st));
+        }
+        __syncthreads();
+        const uint32_t sel_first = sel_s[lane], sel_trans = sel_s[64u + lane], sel_last = sel_s[128u + lane];
+        uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+        uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+        uint32_t cnt = 0;
+)JIT";
+    for (size_t c = 0; c < classes.size(); c++) {
+        JitClass& C = classes[c];
+        C.table_off = table->size();
+        const size_t stride = 1 + C.param_entry.size();
+        std::vector<int> pidx(C.entries.size(), -1);
+        for (size_t j = 0; j < C.param_entry.size(); j++) pidx[C.param_entry[j]] = (int)j + 1;
+        for (const auto& row : C.inst) {   // main-trace leaves: the tile's word offset of their slot instead of the column
+            std::vector<uint32_t> rw = row;
+            for (size_t e = 0; e < C.entries.size(); e++)
+                if (C.entries[e].op == A_VAR) rw[(size_t)pidx[e]] = slot_of.at({row[(size_t)pidx[e]], C.entries[e].a}) * QUOT_TILE_ROWS;
+            table->insert(table->end(), rw.begin(), rw.end());
+        }
+        os << "        for (uint32_t it = wv; it < " << C.inst.size() << "u; it += NW) {\n";
+        os << "            cptr pr = (cptr)tab + " << C.table_off << "u + it * " << stride << "u;\n";
+        for (size_t e = 0; e < C.entries.size(); e++) {
+            const JitEntry& E = C.entries[e];
+            if (E.op == A_VAR) os << "            const uint32_t e" << e << " = tile[pr[" << pidx[e] << "] + lane];\n";
+            else if (E.op == A_PERM || E.op == A_PREP)
+                os << "            const uint32_t e" << e << " = " << (E.op == A_PERM ? "LDP" : "LDQ") << "(pr[" << pidx[e] << "], " << (E.a ? "rno" : "ro") << ");\n";
+        }
+        std::vector<uint8_t> only_mul(C.entries.size(), 1), used(C.entries.size(), 0);
+        for (size_t e = 0; e < C.entries.size(); e++) {
+            const JitEntry& E = C.entries[e];
+            if (E.op == A_ADD || E.op == A_SUB || E.op == A_MUL) {
+                used[E.a] = used[E.b] = 1;
+                if (E.op != A_MUL) only_mul[E.a] = only_mul[E.b] = 0;
+            } else if (E.op == A_NEG) {
+                used[E.a] = 1, only_mul[E.a] = 0;
+            }
+        }
+        auto stays_signed = [&](size_t e) { return C.entries[e].op == A_MUL && used[e] && only_mul[e] && e + 1 != C.entries.size(); };
+        for (size_t e = 0; e < C.entries.size(); e++) {
+            const JitEntry& E = C.entries[e];
+            switch (E.op) {
+                case A_VAR:
+                case A_PREP:
+                case A_PERM: break;
+                case A_CHAL: os << "            const uint32_t e" << e << " = ((cptr)lchal)[pr[" << pidx[e] << "]];\n"; break;
+                case A_EXPOSED: os << "            const uint32_t e" << e << " = ((cptr)expo)[pr[" << pidx[e] << "]];\n"; break;
+                case A_PUB: os << "            const uint32_t e" << e << " = PV(pr[" << pidx[e] << "]);\n"; break;
+                case A_CONST: os << "            const uint32_t e" << e << " = pr[" << pidx[e] << "];\n"; break;
+                case A_FIRST: os << "            const uint32_t e" << e << " = sel_first;\n"; break;
+                case A_LAST: os << "            const uint32_t e" << e << " = sel_last;\n"; break;
+                case A_TRANS: os << "            const uint32_t e" << e << " = sel_trans;\n"; break;
+                case A_NEG: os << "            const uint32_t e" << e << " = mneg(e" << E.a << ");\n"; break;
+                case A_MUL:
+                    if (stays_signed(e))
+                        os << "            const int32_t e" << e << " = sml((int32_t)e" << E.a << ", (int32_t)e" << E.b << ");\n";
+                    else
+                        os << "            const uint32_t e" << e << " = SC(sml((int32_t)e" << E.a << ", (int32_t)e" << E.b << "));\n";
+                    break;
+                default:
+                    os << "            const uint32_t e" << e << " = " << (E.op == A_ADD ? "madd" : "msub") << "(e" << E.a << ", e" << E.b << ");\n";
+            }
+        }
+        os << "            ACC(pr[0], e" << (C.entries.size() - 1) << ")\n        }\n";
+    }
+    const size_t slot_tab_off = table->size();
+    table->insert(table->end(), slot_tab.begin(), slot_tab.end());
+    os << R"JIT(
+        FINISH
+        red_s[(wv * 4u + 0u) * 64u + lane] = acc0, red_s[(wv * 4u + 1u) * 64u + lane] = acc1;
+        red_s[(wv * 4u + 2u) * 64u + lane] = acc2, red_s[(wv * 4u + 3u) * 64u + lane] = acc3;
+        __syncthreads();
+        if (wv < 4u) {   // wave c sums coordinate c over the waves
+            const uint32_t izh = inv_zh_t[i & ((1u << B) - 1u)];
+            uint32_t v = red_s[wv * 64u + lane];
+            for (uint32_t w = 1; w < NW; w++) v = madd(v, red_s[(w * 4u + wv) * 64u + lane]);
+            q[(size_t)wv * M + r] = mmul(v, izh);
+        }
+        __syncthreads();   // the tile and the partial sums are rewritten by the next round
+    }
+}
+)JIT";
+    std::string out = os.str();
+    const std::string key = "SLOT_TAB";
+    for (size_t pos = out.find(key); pos != std::string::npos; pos = out.find(key, pos)) out.replace(pos, key.size(), std::to_string(slot_tab_off) + "u");
+    *src = out;
+    return true;
+}
+
 // Second code shape, for AIRs whose constraints SHARE large sub-expressions instead of repeating small shapes (the
 // Poseidon2 AIR: 282 constraints over one 2701-node DAG in which every round's S-box outputs feed 16 constraints and the
 // partial rounds' lanes are linear expressions that grow for 13 rounds -- expanded per constraint that is 30x the DAG):
@@ -405,12 +573,19 @@ inline bool quot_jit_source_flat(const AirProgram& p, unsigned lh, unsigned b, s
 // call.  (Compiling the chips of an AIR set on several host threads was tried: hipRTC of ROCm 7.2 serialises the compiles of one
 // process -- five kernels took 24.1 s on five threads and 24.9 s in sequence -- and -O1 / -O2 compile as long as -O3: the time is the
 // backend's on these long basic blocks.)
-inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vector<uint32_t>* table, std::vector<char>* code_out, std::string* msg) {
+inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vector<uint32_t>* table, std::vector<char>* code_out, std::string* msg,
+                          unsigned* rows_per_block = nullptr) {
+    if (rows_per_block) *rows_per_block = 256;
     std::vector<JitClass> classes;
     std::string src;
     // ZKHIP_JIT_FLAT=1 prefers the flat form for every AIR (experiments)
     if (!getenv("ZKHIP_JIT_FLAT") && quot_jit_classify(p, &classes, msg)) {
-        src = quot_jit_source(p, lh, b, classes, table);
+        if (quot_jit_source_tiled(p, lh, b, classes, table, &src)) {
+            if (rows_per_block) *rows_per_block = 0;   // tiles of QUOT_TILE_ROWS rows walked by a fixed number of workgroups
+        } else {
+            table->clear();
+            src = quot_jit_source(p, lh, b, classes, table);
+        }
     } else {
         if (!quot_jit_source_flat(p, lh, b, &src, table, msg)) return false;
     }
@@ -499,9 +674,9 @@ inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vec
 // Compiles (or finds) and loads the module.  Returns false (with a message) on any failure; the caller then keeps the interpreter
 // kernel.
 inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModule_t* mod, hipFunction_t* fn,
-                           std::vector<uint32_t>* table, std::string* msg) {
+                           std::vector<uint32_t>* table, std::string* msg, unsigned* rows_per_block = nullptr) {
     std::vector<char> code;
-    if (!quot_jit_code(p, lh, b, table, &code, msg)) return false;
+    if (!quot_jit_code(p, lh, b, table, &code, msg, rows_per_block)) return false;
     if (hipModuleLoadData(mod, code.data()) != hipSuccess) {
         *msg = "hipModuleLoadData failed";
         return false;
