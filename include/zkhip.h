@@ -645,6 +645,20 @@ int zkhip_modmul_host(const uint32_t a[8], const uint32_t b[8], const uint32_t m
 int zkhip_modmul_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace,
                           uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
 
+/* ---- 256-bit ALU chip (include/zkhip_int256.hpp: a = b op c on 32 byte limbs, op = 0 add, 1 sub, 2 xor, 3 or, 4 and, one operation per
+ *      row, 101 columns, degree 3; 32 lookups per row in the 8-bit bitwise table; crates/circuits/chunk-circuit/openvm.toml:16-17 enables
+ *      `bigint`; OpenVM's chip is openvm-bigint-circuit's Rv32BaseAlu256, un-vendored).  Pinned to Python's integers
+ *      (tests/golden/int256_kat.json). ---- */
+#define ZKHIP_INT256_ALU_WIDTH 101
+int zkhip_int256_alu_air(uint32_t bitwise_bus, zkhip_air *out);   /* pointers valid for the life of the process */
+int zkhip_int256_alu_host(uint32_t op, const uint32_t b[8], const uint32_t c[8], uint32_t a[8]);   /* little-endian words (host) */
+/* d_records: n x 17 words (op | b[8] | c[8], plain integers); fills 2^log_height rows and adds the rows' lookups to the XOR column of
+ * the 8-bit bitwise table (d_bitwise_trace: 2 x 65536 Montgomery words) */
+int zkhip_int256_alu_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
+/* the chip inside the VM (102 columns: + the timestamp of call i on row i) */
+int zkhip_vm_int256_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height, uint32_t *d_trace,
+                             uint32_t *d_bitwise_trace);
+
 /* ---- aggregation layer: the verifier circuit.  Replaces, for this backend's proofs, the leaf /
  *      internal verifier programs the reference's SDK proves at the nodes of its aggregation tree and `commit_child_vk`
  *      (crates/prover/src/prover/mod.rs:47-60, 200-282; crates/integration/src/lib.rs:461-514).  A circuit is built for ONE

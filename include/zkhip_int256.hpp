@@ -1,0 +1,88 @@
+// zkhip_int256.hpp -- 256-bit ALU chip (crates/circuits/chunk-circuit/openvm.toml:16-17 enables `bigint`: the EVM's
+// 256-bit words).  OpenVM's chip is the RV32 base ALU core instantiated with 32 limbs (openvm-bigint-circuit Rv32BaseAlu256, un-vendored);
+// this is the 32-limb form of include/zkhip_chips.hpp's ALU core: ONE operation per row,
+//   a[32] (result) | b[32] | c[32] | is_add is_sub is_xor is_or is_and       byte limbs, little-endian; 101 columns
+// ADD / SUB through their carry chains (carry_i = (b_i + c_i + carry_{i-1} - a_i) / 256 boolean; SUB with a and b exchanged; the carry
+// out of limb 31 is dropped: arithmetic modulo 2^256); XOR / OR / AND -- and the byte range of every result limb -- through the bitwise
+// lookup: per limb (x, y, x ^ y, 1) with (x, y) = (b_i, c_i) for the bitwise opcodes and (a_i, a_i) for ADD / SUB, where x ^ y = a_i
+// (XOR), 2 a_i - b_i - c_i (OR), b_i + c_i - 2 a_i (AND), 0 (ADD / SUB).  Degree 3.
+// External parity: Python's integers (tests/golden/int256_kat.json).  Header-only; device generator: csrc/int256.hip.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "zkhip_air.hpp"
+
+namespace zkhip {
+namespace int256 {
+using air::AirBuilder;
+using air::Expr;
+using air::Kind;
+
+constexpr size_t LIMBS = 32, COL_A = 0, COL_B = 32, COL_C = 64, COL_FLAGS = 96, WIDTH = 101;
+enum Op : uint32_t { OP_ADD, OP_SUB, OP_XOR, OP_OR, OP_AND, N_OPS };
+
+// AirBuilder(WIDTH, 0)
+inline void alu256_air(AirBuilder& b, uint32_t bitwise_bus) {
+    Expr f[N_OPS];
+    Expr ok = b.constant(0);
+    for (size_t i = 0; i < N_OPS; i++) {
+        f[i] = b.var(COL_FLAGS + i);
+        b.assert_zero(f[i] * (f[i] - 1));
+        ok = ok + f[i];
+    }
+    b.assert_zero(ok * (ok - 1));
+    const int64_t inv256 = 2005401601;   // 256^-1 modulo the BabyBear prime
+    Expr carry_add = b.constant(0), carry_sub = b.constant(0);
+    for (size_t i = 0; i < LIMBS; i++) {
+        const Expr ai = b.var(COL_A + i), bi = b.var(COL_B + i), ci = b.var(COL_C + i);
+        carry_add = (bi + ci - ai + carry_add) * inv256;
+        carry_sub = (ai + ci - bi + carry_sub) * inv256;
+        b.assert_zero(f[OP_ADD] * (carry_add * (carry_add - 1)));
+        b.assert_zero(f[OP_SUB] * (carry_sub * (carry_sub - 1)));
+    }
+    const Expr bitwise = f[OP_XOR] + f[OP_OR] + f[OP_AND], one = b.constant(1);
+    for (size_t i = 0; i < LIMBS; i++) {
+        const Expr ai = b.var(COL_A + i), bi = b.var(COL_B + i), ci = b.var(COL_C + i);
+        const Expr x = bitwise * bi + (1 - bitwise) * ai, y = bitwise * ci + (1 - bitwise) * ai;
+        const Expr z = f[OP_XOR] * ai + f[OP_OR] * (ai * 2 - bi - ci) + f[OP_AND] * (bi + ci - ai * 2);
+        b.push_interaction(bitwise_bus, {x, y, z, one}, ok, Kind::Send);
+    }
+}
+
+// The chip inside the VM: + a timestamp column; the 24 words of a call (b, c read; a written) are received from the int256 adapter on
+// `word_bus` as (timestamp, word index, low half, high half, opcode).  AirBuilder(VM_WIDTH, 0)
+constexpr size_t COL_TS = WIDTH, VM_WIDTH = WIDTH + 1;
+inline void alu256_vm_air(AirBuilder& b, uint32_t bitwise_bus, uint32_t word_bus) {
+    alu256_air(b, bitwise_bus);
+    const Expr ts = b.var(COL_TS);
+    Expr ok = b.constant(0), op = b.constant(0);
+    for (size_t i = 0; i < N_OPS; i++) ok = ok + b.var(COL_FLAGS + i), op = op + b.var(COL_FLAGS + i) * (int64_t)i;
+    const size_t base[3] = {COL_B, COL_C, COL_A};
+    for (size_t o = 0; o < 3; o++)
+        for (size_t k = 0; k < 8; k++) {
+            const size_t c = base[o] + 4 * k;
+            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(8 * o + k)), b.var(c) + b.var(c + 1) * 256, b.var(c + 2) + b.var(c + 3) * 256, op}, ok, Kind::Receive);
+        }
+}
+
+// a <- b op c on little-endian 32-bit words (host)
+inline void alu256(uint32_t op, const uint32_t b[8], const uint32_t c[8], uint32_t a[8]) {
+    uint64_t carry = 0, borrow = 0;
+    for (int i = 0; i < 8; i++) {
+        switch (op) {
+            case OP_ADD: carry += (uint64_t)b[i] + c[i], a[i] = (uint32_t)carry, carry >>= 32; break;
+            case OP_SUB: {
+                const uint64_t d = (uint64_t)b[i] - c[i] - borrow;
+                a[i] = (uint32_t)d, borrow = (d >> 32) & 1u;
+                break;
+            }
+            case OP_XOR: a[i] = b[i] ^ c[i]; break;
+            case OP_OR: a[i] = b[i] | c[i]; break;
+            default: a[i] = b[i] & c[i]; break;
+        }
+    }
+}
+
+}  // namespace int256
+}  // namespace zkhip

@@ -88,6 +88,7 @@ struct SegmentCaps {
     }
     bool keccak() const { return pos(vmc::A_KECCAK) >= 0; }
     bool sha256() const { return pos(vmc::A_SHA256) >= 0; }
+    bool int256() const { return pos(vmc::A_INT256) >= 0; }
     std::vector<zkhip::modular::U256> moduli;   // the modular extension: chips A_MODMUL(i), A_MODMUL_IO(i) per modulus
     // heights for segments of about 2^log_frame instructions of an ordinary instruction mix
     // log_keccak: 0 = the app has no keccak extension (22 chips); otherwise the rows of the Keccak-f chip (24 per permutation call,
@@ -95,8 +96,9 @@ struct SegmentCaps {
     // part of the key only where openvm.toml asks for it (crates/circuits/chunk-circuit/openvm.toml `[app_vm_config.keccak]`).
     // log_sha256: likewise for the SHA-256 compression chip (65 rows per block, at least 128; `[app_vm_config.sha256]`).
     // moduli / log_modmul: one multiplication chip (one call per row) + adapter (24 rows per call) per modulus of `[app_vm_config.modular]`.
+    // log_int256: rows of the 256-bit ALU chip (one operation per row; `[app_vm_config.bigint]`), 0 = no bigint extension.
     static SegmentCaps for_frame(unsigned log_frame, unsigned log_program, unsigned log_keccak = 0, unsigned log_sha256 = 0,
-                                 const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_modmul = 0) {
+                                 const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_modmul = 0, unsigned log_int256 = 0) {
         SegmentCaps c;
         for (unsigned a = 0; a < vmc::N_BASE_AIRS; a++) c.ids.push_back(a);
         auto sub = [&](unsigned d) { return log_frame > d + 2 ? log_frame - d : 2u; };
@@ -116,6 +118,10 @@ struct SegmentCaps {
         if (log_sha256) {
             c.ids.push_back(vmc::A_SHA256), c.ids.push_back(vmc::A_SHA256_IO);
             c.log_height[vmc::A_SHA256] = std::max(log_sha256, 7u), c.log_height[vmc::A_SHA256_IO] = c.log_height[vmc::A_SHA256] - 1;       // 24 adapter rows per 65 chip rows
+        }
+        if (log_int256) {
+            c.ids.push_back(vmc::A_INT256), c.ids.push_back(vmc::A_INT256_IO);
+            c.log_height[vmc::A_INT256] = std::max(log_int256, 1u), c.log_height[vmc::A_INT256_IO] = c.log_height[vmc::A_INT256] + 5;   // 24 adapter rows per call
         }
         if (moduli.size() > vmc::MAX_MODULI) throw Error("at most " + std::to_string(vmc::MAX_MODULI) + " moduli");
         c.moduli = moduli;
@@ -139,6 +145,7 @@ struct SegmentRecords {
     std::vector<uint32_t> leaf_rows, merkle_rows, p2_inputs; // p2_inputs: [n][16] canonical, one row per hash-bus request
     std::vector<uint32_t> kk_states, kk_ts, kio_rows;        // keccak calls: 50 input words and the timestamp per call; the adapter's rows
     std::vector<uint32_t> sha_blocks, sha_ts, shaio_rows;    // sha256 calls: 24 words (state, block) and the timestamp per call; the adapter's rows
+    std::vector<uint32_t> i256_records, i256_ts, i256io_rows;   // int256 calls: op | b | c (17 words) and the timestamp per call; the adapter's rows
     // modmul calls per modulus: a | b (16 words) and the timestamp per call; the adapter's rows
     std::vector<uint32_t> mm_records[vmc::MAX_MODULI], mm_ts[vmc::MAX_MODULI], mmio_rows[vmc::MAX_MODULI];
     uint32_t pc_start = 0, pc_end = 0, ts_end = 0;
@@ -153,7 +160,7 @@ struct SegmentRecords {
     void clear() {
         core.clear();
         for (auto* v : {&f_x, &f_y, &f_z, &f_rdprev, &f_pcinc, &f_pts1, &f_pts2, &f_pts3, &ls_ts, &ls_base, &ls_imm, &ls_pts, &ecall_rows, &leaf_rows, &merkle_rows,
-                        &p2_inputs, &kk_states, &kk_ts, &kio_rows, &sha_blocks, &sha_ts, &shaio_rows})
+                        &p2_inputs, &kk_states, &kk_ts, &kio_rows, &sha_blocks, &sha_ts, &shaio_rows, &i256_records, &i256_ts, &i256io_rows})
             v->clear();
         for (unsigned i = 0; i < vmc::MAX_MODULI; i++) mm_records[i].clear(), mm_ts[i].clear(), mmio_rows[i].clear();
         n_instr = 0;
@@ -218,7 +225,7 @@ public:
                 if (d.wr_rd) want(1, d.rd);
                 if (d.cls == vmc::C_LS) want(2, ((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) >> 2);
                 if (d.cls == vmc::C_ECALL) want(1, 11), want(3, m_.reg(11) & 7u);
-                if (d.cls == vmc::C_ECALL && (m_.reg(17) == 3 || m_.reg(17) == 4 || m_.reg(17) == 5)) {
+                if (d.cls == vmc::C_ECALL && m_.reg(17) >= 3 && m_.reg(17) <= 6) {
                     const uint32_t n_words = m_.reg(17) == 3 ? 50 : 24;
                     for (uint32_t w = m_.reg(10) >> 2; w < (m_.reg(10) >> 2) + n_words; w += (w & 3u) ? 4 - (w & 3u) : 4) want(2, w);
                 }
@@ -241,6 +248,8 @@ public:
                 throw Error("the guest calls the keccak intrinsic but the app's openvm.toml does not enable the keccak extension");
             if (d.cls == vmc::C_ECALL && m_.reg(17) == 4 && !caps_.sha256())
                 throw Error("the guest calls the sha256 intrinsic but the app's openvm.toml does not enable the sha256 extension");
+            if (d.cls == vmc::C_ECALL && m_.reg(17) == 6 && !caps_.int256())
+                throw Error("the guest calls the int256 intrinsic but the app's openvm.toml does not enable the bigint extension");
             if (d.cls == vmc::C_ECALL && m_.reg(17) == 5 && m_.reg(11) >= caps_.moduli.size())
                 throw Error("the guest calls the modmul intrinsic for modulus " + std::to_string(m_.reg(11)) + " but the app's openvm.toml lists " +
                             std::to_string(caps_.moduli.size()) + " moduli");
@@ -249,6 +258,7 @@ public:
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 3 && 24 * (r.n_keccak() + 1) > caps_.rows(vmc::A_KECCAK)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 4 && 65 * (r.n_sha256() + 1) > caps_.rows(vmc::A_SHA256)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 5 && r.mm_ts[m_.reg(11)].size() + 1 > caps_.rows(vmc::A_MODMUL(m_.reg(11)))) ||
+                (d.cls == vmc::C_ECALL && m_.reg(17) == 6 && r.i256_ts.size() + 1 > caps_.rows(vmc::A_INT256)) ||
                 path_nodes_.size() + new_nodes > caps_.rows(vmc::A_MERKLE) ||
                 2 * (blk_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
                 if (r.n_instr == 0) throw Error("segment heights too small for a single instruction");
@@ -271,9 +281,9 @@ public:
                 memcpy(&pv_before, m_.public_values().data() + 4 * a1, 4);
             }
             uint32_t mm_in[24];
-            if (d.cls == vmc::C_ECALL && x == 5) {
+            if (d.cls == vmc::C_ECALL && (x == 5 || x == 6)) {
                 a1 = m_.reg(11);
-                if ((y & 3u) || (uint64_t)y + 96 > (1ull << 30)) throw Error("modmul buffer must be word-aligned and below 2^30");
+                if ((y & 3u) || (uint64_t)y + 96 > (1ull << 30)) throw Error("modmul / int256 buffer must be word-aligned and below 2^30");
                 for (uint32_t j = 0; j < 24; j++) mm_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
             }
             // snapshot the blocks this instruction is going to change
@@ -324,6 +334,23 @@ public:
                     };
                     gap(row + 21, read_word(1, 11, a1, ts + 4), ts + 4);
                     gap(row + 24, write_word(3, a1, y, ts + 5), ts + 5);
+                }
+                if (x == 6) {
+                    row[31] = 1, row[28] = (y & 255u) >> 2, row[17] = a1;
+                    auto gap3 = [&](uint32_t* dst, uint32_t pts, uint32_t at) { dst[0] = pts, dst[1] = (at - pts - 1) & 0xffffu, dst[2] = (at - pts - 1) >> 16; };
+                    gap3(row + 21, read_word(1, 11, a1, ts + 4), ts + 4);
+                    r.i256_ts.push_back(ts);
+                    r.i256_records.push_back(a1);
+                    r.i256_records.insert(r.i256_records.end(), mm_in, mm_in + 16);
+                    for (uint32_t k = 0; k < 24; k++) {   // the adapter's rows: b, c read, a written, all at ts + 5
+                        uint32_t sr[vmc::INT256_IO_WIDTH] = {};
+                        const uint32_t w = (y >> 2) + k, before = mm_in[k], after = mem_word(y + 4 * k);
+                        sr[k] = 1, sr[24] = ts, sr[25] = y >> 2, sr[33] = 1, sr[34] = a1;
+                        sr[26] = before & 0xffffu, sr[27] = before >> 16, sr[28] = after & 0xffffu, sr[29] = after >> 16;
+                        const uint32_t pts = k >= 16 ? write_word(2, w, after, ts + 5) : read_word(2, w, before, ts + 5), gap = ts + 5 - pts - 1;
+                        sr[30] = pts, sr[31] = gap & 0xffffu, sr[32] = gap >> 16;
+                        r.i256io_rows.insert(r.i256io_rows.end(), sr, sr + vmc::INT256_IO_WIDTH);
+                    }
                 }
                 if (x == 5) {
                     row[30] = 1, row[28] = (y & 255u) >> 2, row[17] = a1;

@@ -180,6 +180,10 @@ public:
             check(zkhip_vm_sha256_tracegen(ctx_, up(r.sha_blocks), up(r.sha_ts), r.n_sha256(), H(vmc::A_SHA256), T(vmc::A_SHA256)));
             check(zkhip_rows_tracegen(ctx_, up(r.shaio_rows), r.shaio_rows.size() / vmc::SHA_IO_WIDTH, vmc::SHA_IO_WIDTH, H(vmc::A_SHA256_IO), T(vmc::A_SHA256_IO), nullptr));
         }
+        if (caps_.int256()) {   // bigint extension: the chip's lookups are counted by its generator
+            check(zkhip_vm_int256_tracegen(ctx_, up(r.i256_records), up(r.i256_ts), r.i256_ts.size(), H(vmc::A_INT256), T(vmc::A_INT256), d_bw));
+            check(zkhip_rows_tracegen(ctx_, up(r.i256io_rows), r.i256io_rows.size() / vmc::INT256_IO_WIDTH, vmc::INT256_IO_WIDTH, H(vmc::A_INT256_IO), T(vmc::A_INT256_IO), nullptr));
+        }
         for (unsigned i = 0; i < caps_.moduli.size(); i++) {   // modular extension: the chip's lookups are counted by its generator
             check(zkhip_vm_modmul_tracegen(ctx_, caps_.moduli[i].w, up(r.mm_records[i]), up(r.mm_ts[i]), r.mm_ts[i].size(), H(vmc::A_MODMUL(i)), T(vmc::A_MODMUL(i)), d_bw,
                                            d_tup, TUPLE_X, TUPLE_Y));
@@ -216,9 +220,9 @@ public:
                     for (uint32_t v : {row[17] * 8192, row[17], row[22], row[25]}) misc.push_back(v);
                     tup_y.push_back(row[23]), tup_y.push_back(row[26]);
                 }
-                if (row[30]) misc.push_back(row[22]), tup_y.push_back(row[23]);   // modmul: the a1 read
+                if (row[30] || row[31]) misc.push_back(row[22]), tup_y.push_back(row[23]);   // modmul / int256: the a1 read
                 if (row[16]) bw_x.push_back(row[10]), bw_y.push_back(row[11]), bw_x.push_back(row[12]), bw_y.push_back(row[13]);
-                if (row[27] || row[29] || row[30])
+                if (row[27] || row[29] || row[30] || row[31])
                     for (uint32_t v : {row[28] * 1024, row[28], row[9] * 1024}) misc.push_back(v);
             }
             for (size_t i = 0; i < r.kio_rows.size() / vmc::KECCAK_IO_WIDTH; i++) {
@@ -231,6 +235,10 @@ public:
             }
             for (size_t i = 0; i < r.shaio_rows.size() / vmc::SHA_IO_WIDTH; i++) {
                 const uint32_t* row = &r.shaio_rows[i * vmc::SHA_IO_WIDTH];
+                misc.push_back(row[31]), tup_y.push_back(row[32]);
+            }
+            for (size_t i = 0; i < r.i256io_rows.size() / vmc::INT256_IO_WIDTH; i++) {
+                const uint32_t* row = &r.i256io_rows[i * vmc::INT256_IO_WIDTH];
                 misc.push_back(row[31]), tup_y.push_back(row[32]);
             }
             for (unsigned m = 0; m < caps_.moduli.size(); m++)
@@ -543,6 +551,10 @@ inline unsigned sha256_log_rows(const std::string& path_app_config, unsigned log
     const bool on = config_has_section(path_app_config, "[app_vm_config.sha256]") || config_has_section(path_app_config, "[app_vm_config.sha2]");   // (the reference's name)
     return on ? std::max(7u, log_frame > 5 ? log_frame - 5 : 0u) : 0u;
 }
+// `[app_vm_config.bigint]`: 2^(log_frame - 8) rows of the 256-bit ALU chip (one operation per row)
+inline unsigned int256_log_rows(const std::string& path_app_config, unsigned log_frame) {
+    return config_has_section(path_app_config, "[app_vm_config.bigint]") ? std::max(1u, log_frame > 8 ? log_frame - 8 : 0u) : 0u;
+}
 // `[app_vm_config.modular] supported_moduli = ["<decimal>", ...]` (the reference's chunk circuit lists six): the moduli as 256-bit words
 inline std::vector<zkhip::modular::U256> config_moduli(const std::string& path_app_config) {
     std::ifstream f(path_app_config);
@@ -579,8 +591,8 @@ inline std::vector<zkhip::modular::U256> config_moduli(const std::string& path_a
 }
 inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
                                         bool keep_segments = false, unsigned inflight = 2, unsigned log_keccak = 0, unsigned log_sha256 = 0,
-                                        const std::vector<zkhip::modular::U256>& moduli = {}) {
-    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak, log_sha256, moduli, log_frame > 8 ? log_frame - 8 : 1);
+                                        const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_int256 = 0) {
+    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak, log_sha256, moduli, log_frame > 8 ? log_frame - 8 : 1, log_int256);
     std::vector<std::unique_ptr<SegmentProver>> own;
     std::vector<SegmentProver*> lanes;
     for (unsigned l = 0; l < std::max(1u, inflight); l++) own.emplace_back(new SegmentProver(params, exe, caps, device)), lanes.push_back(own.back().get());
@@ -640,7 +652,7 @@ public:
         p.params_ = read_app_config(cfg.path_app_config);
         p.caps_ = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(p.exe_.program.size()), zkhip_vm::keccak_log_rows(cfg.path_app_config, log_frame),
                                                    zkhip_vm::sha256_log_rows(cfg.path_app_config, log_frame), zkhip_vm::config_moduli(cfg.path_app_config),
-                                                   log_frame > 8 ? log_frame - 8 : 1);
+                                                   log_frame > 8 ? log_frame - 8 : 1, zkhip_vm::int256_log_rows(cfg.path_app_config, log_frame));
         return p;
     }
     void reset() {   // mod.rs:106-108: releases the device-resident keys, circuits and workspaces

@@ -185,6 +185,9 @@ void ora_keccak_f_trace(const uint64_t *inputs, size_t n_perms, unsigned log_hei
 void ora_sha256_compress(uint32_t h[8], const uint32_t m[16]);
 void ora_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
 void ora_sha256_trace(const uint32_t *blocks, size_t n_blocks, unsigned log_height, uint32_t *trace);
+/* ---- 256-bit ALU (oracle/int256.c): a = b op c modulo 2^256 on bytes, the chip's trace ---- */
+void ora_int256_alu(uint32_t op, const uint8_t b[32], const uint8_t c[32], uint8_t a[32]);
+size_t ora_int256_alu_trace(const uint32_t *records, size_t n, unsigned log_height, uint32_t *trace, uint32_t *xor_counts);
 /* ---- modular multiplication (oracle/modular.c): r = a b mod P on bytes, the chip's trace ---- */
 int ora_modmul(const uint8_t a[32], const uint8_t b[32], const uint8_t p[32], uint8_t q[32], uint8_t r[32]);
 size_t ora_modmul_trace(const uint8_t *records, size_t n, const uint8_t p[32], unsigned log_height, uint32_t *trace, uint32_t *bitwise_range, uint32_t *tuple,

@@ -1,0 +1,75 @@
+"""GPU: the 256-bit ALU chip on the device: zkhip_int256_alu_tracegen == the oracle twin cell for cell (101 columns) and count for count
+in the bitwise table's XOR column, a = b op c is Python's, the HIP proof of the chip with its table == the oracle's."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import zkvm_prover_amd as z
+
+import int256_util as iu
+
+pytestmark = pytest.mark.gpu
+PARAMS = (1, 0, 4, 3, 3)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_device_int256_trace_and_proof(zk, ora):
+    kat = [(c["op"], int(c["b"], 16), int(c["c"], 16), int(c["a"], 16)) for c in json.load(open(os.path.join(HERE, "golden", "int256_kat.json")))["cases"]]
+    cases = [(op, b, c) for op, b, c, _ in kat]
+    log_h = 8
+    d_recs = torch.from_numpy(iu.records(cases).reshape(-1).view(np.int32)).to(zk.device)
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
+    d_tr = zk.int256_alu_tracegen(d_recs, len(cases), log_h, d_bw)
+    got = zk.download(d_tr).reshape(iu.WIDTH, -1)
+    tr, xc, bad = iu.ora_trace(ora, cases, log_h)
+    assert bad == 0 and (got == tr).all()
+    bw = zk.download(d_bw)
+    assert (bw[1 << 16:] == xc).all() and not bw[:1 << 16].any()
+    for row, (_, _, _, a) in enumerate(kat):
+        assert bytes(got[0:32, row].astype(np.uint8)) == a.to_bytes(32, "little")
+    inst = iu.instance(got, xc, log_h)
+    pk = z.ProvingKey(zk, PARAMS, inst)
+    pvs = [iu.NOPV] * 2
+    proof = pk.prove([d_tr, d_bw], pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, inst).tobytes()
+    bad_tr = d_tr.clone()
+    bad_tr[3] ^= 1   # another result limb
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, pk.prove([bad_tr, d_bw], pvs)) != 0
+    pk.close()
+
+
+def test_int256_chip_throughput(zk):
+    """2^18 operations: trace generation and proof at the reference's parameters (reported, not asserted on time)."""
+    import time
+    from zkvm_prover_amd import air
+
+    log_h, n = 18, 1 << 18
+    rng = np.random.default_rng(1)
+    recs = rng.integers(0, 1 << 32, size=(n, 17), dtype=np.uint64).astype(np.uint32)
+    recs[:, 0] %= 5
+    d_recs = torch.from_numpy(recs.reshape(-1).view(np.int32)).to(zk.device)
+    program, width = z.int256_alu_air(iu.BITWISE_BUS)
+    inst = [dict(program=program, log_height=log_h, width=width, n_pvs=0),
+            dict(program=air.bitwise_lookup_air(8, iu.BITWISE_BUS).program(), log_height=16, width=2, n_pvs=0, prep=air.bitwise_lookup_prep(8))]
+    pk = z.ProvingKey(zk, z.DEFAULT_PARAMS, inst)
+    pvs = [iu.NOPV] * 2
+
+    def gen():
+        d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
+        return [zk.int256_alu_tracegen(d_recs, n, log_h, d_bw), d_bw]
+    T = gen()
+    assert z.verify(z.DEFAULT_PARAMS, pk.verifying_airs(), pvs, pk.prove(T, pvs)) == 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    T = gen()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    pk.prove(T, pvs)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("int256 chip: %d operations, %.1f M cells: tracegen %.2f ms, proof %.1f ms" % (n, iu.WIDTH * (1 << log_h) / 1e6, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
+    pk.close()

@@ -17,8 +17,8 @@ import prover_mirror_util as pm
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import (SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, keccak_data, keccak_program, mixed_program, modmul_data,
-                         modmul_program, sha256_data, sha256_program)
+from test_vm_cpu import (INT256_OPERANDS, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
+                         keccak_program, mixed_program, modmul_data, modmul_program, sha256_data, sha256_program)
 
 pytestmark = pytest.mark.gpu
 PARAMS = (1, 0, 4, 3, 3)
@@ -68,6 +68,10 @@ def device_traces(zk, rec, prog, H):
         n_kk = len(rec["kk_ts"])
         T[v2.A_KECCAK] = zk.vm_keccak_tracegen(D(rec["kk_states"]) if n_kk else None, D(rec["kk_ts"]) if n_kk else None, n_kk, H[v2.A_KECCAK])
         T[v2.A_KECCAK_IO] = zk.rows_tracegen(D(rec["kio_rows"]), len(rec["kio_rows"]) // v2.KECCAK_IO_WIDTH, v2.KECCAK_IO_WIDTH, H[v2.A_KECCAK_IO])
+    if v2.A_INT256 in H.ids:   # the 256-bit ALU counts its own lookups into the XOR column
+        n_i = len(rec["i256_ts"])
+        T[v2.A_INT256] = zk.vm_int256_tracegen(D(rec["i256_records"]) if n_i else None, D(rec["i256_ts"]) if n_i else None, n_i, H[v2.A_INT256], d_bw)
+        T[v2.A_INT256_IO] = zk.rows_tracegen(D(rec["i256io_rows"]), len(rec["i256io_rows"]) // v2.INT256_IO_WIDTH, v2.INT256_IO_WIDTH, H[v2.A_INT256_IO])
     for i, p_ in enumerate(H.moduli):   # the multiplication chips count their own lookups into the two tables
         n_mm = len(rec["mm_ts_%d" % i])
         T[v2.A_MODMUL(i)] = zk.vm_modmul_tracegen(p_, D(rec["mm_records_%d" % i]) if n_mm else None, D(rec["mm_ts_%d" % i]) if n_mm else None, n_mm,
@@ -103,15 +107,18 @@ def device_traces(zk, rec, prog, H):
         if row[16]:
             bw_x += [int(row[10]), int(row[12])]
             bw_y += [int(row[11]), int(row[13])]
-        if row[30]:
+        if row[30] or row[31]:
             misc += [int(row[22])]
             tup_y += [int(row[23])]
-        if row[27] or row[29] or row[30]:
+        if row[27] or row[29] or row[30] or row[31]:
             misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
     for row in rec["kio_rows"].reshape(-1, v2.KECCAK_IO_WIDTH):
         misc += [int(row[36]), int(row[39])]
         tup_y += [int(row[37]), int(row[40])]
     for row in rec["shaio_rows"].reshape(-1, v2.SHA_IO_WIDTH):
+        misc += [int(row[31])]
+        tup_y += [int(row[32])]
+    for row in rec["i256io_rows"].reshape(-1, v2.INT256_IO_WIDTH):
         misc += [int(row[31])]
         tup_y += [int(row[32])]
     for i in range(len(H.moduli)):
@@ -317,6 +324,38 @@ def test_modmul_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     y2_low, x3_low = int.from_bytes(pv[:16], "little"), int.from_bytes(pv[16:28], "little")
     assert y2_low == SECP256K1_GY ** 2 % SECP256K1_P % (1 << 128) and x3_low == SECP256K1_GX ** 3 % SECP256K1_P % (1 << 96)
     assert (y2_low - x3_low - 7) % (1 << 96) == 0                        # y^2 = x^3 + 7 (no wrap in the low words here)
+    assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
+
+
+def test_int256_guest_device_traces_and_one_proof(zk, ora, tmp_path):
+    """A guest running the five 256-bit opcodes through the int256 intrinsic (bigint extension, 24 chips): device traces == CPU twins,
+    proof bytes == the oracle's; the whole flow from the ELF with `[app_vm_config.bigint]`: the root's public values are Python's."""
+    words, data = int256_program(), int256_data()
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, (), True)
+    k = next(i for i, s in enumerate(segs) if len(s["i256_ts"]))
+    inst = v2.segment_instance(segs[k], words, PC_BASE, H)
+    T = device_traces(zk, segs[k], v2.program_table(words, PC_BASE, H[0]), H)
+    assert len(inst) == len(T) == 24
+    for a, d in enumerate(inst):
+        assert (zk.download(T[a]).reshape(d["width"], -1) == d["trace"]).all(), "position %d" % a
+    pk = z.ProvingKey(zk, PARAMS, inst)
+    pvs = [d["pvs"] for d in inst]
+    proof = pk.prove(T, pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, inst).tobytes()
+    pk.close()
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words, data=data))
+    (tmp_path / "openvm.toml").write_text(pm.TOML.format(*PARAMS) + "\n[app_vm_config.bigint]\nrange_tuple_checker_sizes = [256, 8192]\n")
+    r = subprocess.run([pm.CLI, "prove-elf", str(exe), "-", str(tmp_path), str(tmp_path / "openvm.toml"), "8"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    model = rv.run(words, b"", data=data)
+    assert out["verified"] and out["total_cycles"] == model["instret"]
+    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * 34:4 * 34 + 32]
+    M = 1 << 256
+    want = [[(b + c) % M, (b - c) % M, b ^ c, b | c, b & c][op] for op, (b, c) in enumerate(INT256_OPERANDS)]
+    assert pv == bytes(model["pvs"]) and [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(5)] == [w & 0xFFFFFFFF for w in want]
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
 
 

@@ -1,0 +1,69 @@
+"""CPU: the 256-bit ALU chip (include/zkhip_int256.hpp) -- parity anchored OUTSIDE this repository.
+  * the oracle's byte-wise ALU (oracle/int256.c) and the product's host function (zkhip_int256_alu_host) against Python's integers
+    (tests/golden/int256_kat.json: add, sub, xor, or, and modulo 2^256 incl. the carry chain's edge cases);
+  * the chip's trace (oracle twin of zkhip_int256_alu_tracegen) with the bitwise table satisfies the AIRs and balances the bus; a
+    changed cell breaks a constraint or the bus; the oracle proves the set and both verifiers accept."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import zkvm_prover_amd as z
+from zkvm_prover_amd import air
+
+import int256_util as iu
+import vm2_util as v2
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PARAMS = (1, 0, 4, 3, 3)
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(os.path.join(HERE, "golden", "int256_kat.json")) as f:
+        return [(c["op"], int(c["b"], 16), int(c["c"], 16), int(c["a"], 16)) for c in json.load(f)["cases"]]
+
+
+def test_alu_against_python_integers(ora, kat):
+    M = 1 << 256
+    for op, b, c, a in kat:
+        assert a == [(b + c) % M, (b - c) % M, b ^ c, b | c, b & c][op]
+        assert iu.ora_alu(ora, op, b, c) == a and z.int256_alu_host(op, b, c) == a
+
+
+def test_trace_satisfies_the_air_and_the_bus_balances(ora, kat):
+    cases = [(op, b, c) for op, b, c, _ in kat[::3]][:60]
+    tr, xc, bad = iu.ora_trace(ora, cases, 6)
+    assert bad == 0
+    inst = iu.instance(tr, xc, 6)
+    for d in inst:
+        assert air.quotient_chunks(d["program"]) <= 2
+        assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == []
+    assert v2.bus_imbalance(inst) == {}
+    want = {(op, b, c): a for op, b, c, a in kat}
+    for row, (op, b, c) in enumerate(cases):
+        assert bytes(tr[0:32, row].astype(np.uint8)) == want[(op, b, c)].to_bytes(32, "little")
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        t2 = tr.copy()
+        col, r_ = int(rng.integers(0, iu.WIDTH)), int(rng.integers(0, len(cases)))
+        t2[col, r_] = (int(t2[col, r_]) + 1) % 2013265921
+        i2 = iu.instance(t2, xc, 6)
+        assert air.check_trace(i2[0]["program"], t2, iu.NOPV) != [] or v2.bus_imbalance(i2) != {}, (col, r_)
+
+
+def test_oracle_proves_the_chip_with_its_table(ora):
+    rng = np.random.default_rng(5)
+    cases = [(int(rng.integers(0, 5)), int.from_bytes(rng.bytes(32), "little"), int.from_bytes(rng.bytes(32), "little")) for _ in range(7)]
+    tr, xc, bad = iu.ora_trace(ora, cases, 3)
+    inst = iu.instance(tr, xc, 3)
+    proof = ora.stark_prove(PARAMS, inst)
+    assert ora.stark_verify(PARAMS, inst, proof) == 0
+    vk = []
+    for d in inst:
+        v = {k: d[k] for k in ("program", "log_height", "width", "n_pvs")}
+        if d.get("prep") is not None:
+            v["prep_commit"] = ora.prep_commit(PARAMS, d)
+        vk.append(v)
+    assert z.verify(PARAMS, vk, [iu.NOPV] * 2, proof.tobytes()) == 0

@@ -17,8 +17,8 @@ from zkvm_prover_amd import air
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import (SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, keccak_data, keccak_program, mixed_program, modmul_data,
-                         modmul_program, sha256_data, sha256_program)
+from test_vm_cpu import (INT256_OPERANDS, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
+                         keccak_program, mixed_program, modmul_data, modmul_program, sha256_data, sha256_program)
 
 PARAMS = (1, 0, 4, 3, 3)
 PC_BASE = 0x00200000
@@ -243,6 +243,39 @@ def test_modmul_intrinsic_is_part_of_the_statement(tmp_path):
     assert 18 in bad and 1 in bad                                         # modulus 0's word bus, memory bus
     # without the extension the guest has no proof
     with pytest.raises(AssertionError, match="lists 0 moduli"):
+        v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)
+
+
+def test_int256_intrinsic_is_part_of_the_statement(tmp_path):
+    """A guest that runs the five 256-bit opcodes through the int256 intrinsic under an app with the bigint extension (24 chips): the
+    revealed words are Python's; every trace satisfies its AIR, every bus balances; a forged result word, or a call whose adapter
+    claims another opcode than the ecall passed, breaks a bus."""
+    words, data = int256_program(), int256_data()
+    model = rv.run(words, b"", data=data)
+    pv = bytes(model["pvs"])
+    M = 1 << 256
+    want = [[(b + c) % M, (b - c) % M, b ^ c, b | c, b & c][op] for op, (b, c) in enumerate(INT256_OPERANDS)]
+    assert [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(5)] == [w & 0xFFFFFFFF for w in want]
+    assert [int.from_bytes(pv[20 + 4 * k:24 + 4 * k], "little") for k in range(3)] == [w >> 224 for w in want[:3]]
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, (), True)
+    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"]
+    assert len(H.ids) == 24 and H.ids[-2:] == (v2.A_INT256, v2.A_INT256_IO) and sum(len(s["i256_ts"]) for s in segs) == 5
+    for k, rec in enumerate(segs):
+        inst = v2.segment_instance(rec, words, PC_BASE, H)
+        for d in inst:
+            assert air.quotient_chunks(d["program"]) <= 2
+            assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], k
+        assert v2.bus_imbalance(inst) == {}
+    k = next(i for i, s in enumerate(segs) if len(s["i256_ts"]))
+    rec = {n: v.copy() for n, v in segs[k].items()}
+    rec["i256io_rows"].reshape(-1, v2.INT256_IO_WIDTH)[20, 28] ^= 1        # a result word that is not the ALU's
+    bad = v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
+    assert 31 in bad and 1 in bad                                         # the word bus, the memory bus
+    rec = {n: v.copy() for n, v in segs[k].items()}
+    rec["i256io_rows"].reshape(-1, v2.INT256_IO_WIDTH)[:24, 34] = 4        # the adapter of the first call claims opcode AND
+    bad = v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
+    assert 30 in bad and 31 in bad                                        # the request bus (ecall passed another opcode), the word bus
+    with pytest.raises(AssertionError, match="does not enable the bigint extension"):
         v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)
 
 

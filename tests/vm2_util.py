@@ -17,12 +17,14 @@ CLI = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
 P = ora.P
 NOPV = np.zeros(0, np.uint32)
 (A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
- A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, N_STATIC_AIRS) = range(27)
+ A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, A_INT256, A_INT256_IO,
+ N_STATIC_AIRS) = range(29)
 MAX_MODULI = 8
 N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI   # the modular extension: chips N_STATIC_AIRS + 2 i (multiplication), + 2 i + 1 (adapter) of modulus i
-PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 31, 43, 54, 42, 2634
+PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 32, 43, 54, 42, 2634
 SHA_IO_WIDTH, SHA_WIDTH = 34, 434
 MODMUL_IO_WIDTH, MODMUL_WIDTH = 34, 287
+INT256_IO_WIDTH, INT256_WIDTH = 35, 102
 TS_STEP, GAP_HI_BITS = 16, 11
 SX, SY = 256, 2048
 
@@ -66,7 +68,7 @@ def A_MODMUL_IO(i):
     return N_STATIC_AIRS + 2 * i + 1
 
 
-def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0, moduli=()):
+def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0, moduli=(), bigint=False):
     """Runs the C++ segmenting executor; returns (info json, heights, [segment record dicts], image root, pv openings)."""
     import json
 
@@ -74,8 +76,11 @@ def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0, 
     open(os.path.join(d, "exe.bin"), "wb").write(exe_bytes)
     open(os.path.join(d, "stdin.bin"), "wb").write(stdin)
     cmd = [CLI, "dump-segments", os.path.join(d, "exe.bin"), os.path.join(d, "stdin.bin"), d, str(log_frame), str(log_keccak), str(log_sha256)]
-    if moduli:
-        open(os.path.join(d, "moduli.toml"), "w").write("[app_vm_config.modular]\nsupported_moduli = [\n" + ",\n".join('    "%d"' % m for m in moduli) + "\n]\n")
+    if moduli or bigint:
+        toml = "[app_vm_config.bigint]\n" if bigint else ""
+        if moduli:
+            toml += "[app_vm_config.modular]\nsupported_moduli = [\n" + ",\n".join('    "%d"' % m for m in moduli) + "\n]\n"
+        open(os.path.join(d, "moduli.toml"), "w").write(toml)
         cmd.append(os.path.join(d, "moduli.toml"))
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -185,6 +190,23 @@ def sha256_vm_prep(log_height):
     return p
 
 
+def int256_traces(rec, H):
+    """int256 calls: the oracle's ALU-chip trace (and its XOR-column counts) + the call's timestamp; the adapter's rows"""
+    n = len(rec["i256_ts"])
+    l = ora.lib()
+    l.ora_int256_alu_trace.restype = C.c_size_t
+    l.ora_int256_alu_trace.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_uint, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lh = H[A_INT256]
+    body = np.zeros((INT256_WIDTH - 1, 1 << lh), np.uint32)
+    xcnt = np.zeros(1 << 16, np.uint32)
+    recs = np.ascontiguousarray(rec["i256_records"], dtype=np.uint32)
+    assert l.ora_int256_alu_trace(ora.p32(recs) if n else None, n, lh, ora.p32(body), ora.p32(xcnt)) == 0
+    tr = np.zeros((INT256_WIDTH, 1 << lh), np.uint32)
+    tr[:INT256_WIDTH - 1] = body
+    tr[INT256_WIDTH - 1, :n] = rec["i256_ts"]
+    return tr, rows_trace(rec["i256io_rows"], INT256_IO_WIDTH, H[A_INT256_IO]), xcnt.astype(np.int64)
+
+
 def modmul_traces(rec, H, i, p):
     """modmul calls of modulus i: the oracle's chip trace (and its lookup counts) + the call's timestamp; the adapter's rows"""
     n = len(rec["mm_ts_%d" % i])
@@ -257,6 +279,9 @@ def segment_instance(rec, words, pc_base, heights):
         tr[A_KECCAK], tr[A_KECCAK_IO] = keccak_traces(rec, H)
     if A_SHA256 in H.ids:
         tr[A_SHA256], tr[A_SHA256_IO] = sha256_traces(rec, H)
+    i256_xor = None
+    if A_INT256 in H.ids:
+        tr[A_INT256], tr[A_INT256_IO], i256_xor = int256_traces(rec, H)
     mm_counts = []
     for i, p_ in enumerate(H.moduli):
         tr[A_MODMUL(i)], tr[A_MODMUL_IO(i)], bw_i, tup_i = modmul_traces(rec, H, i, p_)
@@ -270,6 +295,8 @@ def segment_instance(rec, words, pc_base, heights):
     for bw_i, tup_i in mm_counts:   # the multiplication chips' own lookups (byte pairs, carries)
         rc += bw_i
         tc += tup_i
+    if i256_xor is not None:       # the 256-bit ALU's lookups go to the XOR column
+        xc = ((xc.astype(np.int64) + i256_xor) % P).astype(np.uint32)
     n, nls = n_instr, len(rec["ls_case"])
     fr, ls = tr[A_FRAME].astype(np.int64), tr[A_LS].astype(np.int64)
     for q in (18, 20, 22, 24, 26, 28):
@@ -293,16 +320,19 @@ def segment_instance(rec, words, pc_base, heights):
         if row[16]:
             rc[int(row[10]) * 256 + int(row[11])] += 1
             rc[int(row[12]) * 256 + int(row[13])] += 1
-        if row[30]:
+        if row[30] or row[31]:
             misc += [int(row[22])]
             tc[int(row[23])] += 1
-        if row[27] or row[29] or row[30]:
+        if row[27] or row[29] or row[30] or row[31]:
             misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
     for row in rec["kio_rows"].reshape(-1, KECCAK_IO_WIDTH):
         misc += [int(row[36]), int(row[39])]
         tc[int(row[37])] += 1
         tc[int(row[40])] += 1
     for row in rec["shaio_rows"].reshape(-1, SHA_IO_WIDTH):
+        misc += [int(row[31])]
+        tc[int(row[32])] += 1
+    for row in rec["i256io_rows"].reshape(-1, INT256_IO_WIDTH):
         misc += [int(row[31])]
         tc[int(row[32])] += 1
     for i in range(len(H.moduli)):

@@ -54,7 +54,8 @@ int main(int argc, char** argv) {
                 const zkhip_vm::Exe exe = zkhip_vm::parse_exe(raw);
                 const zkhip_vm::SegmentCaps caps = zkhip_vm::SegmentCaps::for_frame((unsigned)atoi(argv[5]), zkhip_vm::vm_log2_ceil(exe.program.size()),
                                                                                     argc >= 7 ? (unsigned)atoi(argv[6]) : 0u, argc >= 8 ? (unsigned)atoi(argv[7]) : 0u,
-                                                                                    argc >= 9 ? zkhip_vm::config_moduli(argv[8]) : std::vector<zkhip::modular::U256>(), 3);
+                                                                                    argc >= 9 ? zkhip_vm::config_moduli(argv[8]) : std::vector<zkhip::modular::U256>(), 3,
+                                                                                    argc >= 9 ? zkhip_vm::int256_log_rows(argv[8], 11) : 0u);
                 zkhip_vm::SegmentExecutor ex(exe, in, caps);
                 zkhip_vm::SegmentRecords r;
                 size_t k = 0;
@@ -80,6 +81,7 @@ int main(int argc, char** argv) {
                     PUT("f_pts1", r.f_pts1), PUT("f_pts2", r.f_pts2), PUT("f_pts3", r.f_pts3), PUT("ls_pts", r.ls_pts);
                     PUT("kk_states", r.kk_states), PUT("kk_ts", r.kk_ts), PUT("kio_rows", r.kio_rows);
                     PUT("sha_blocks", r.sha_blocks), PUT("sha_ts", r.sha_ts), PUT("shaio_rows", r.shaio_rows);
+                    PUT("i256_records", r.i256_records), PUT("i256_ts", r.i256_ts), PUT("i256io_rows", r.i256io_rows);
                     for (unsigned i = 0; i < caps.moduli.size(); i++) {
                         const std::string t = std::to_string(i);
                         put(d + "/mm_records_" + t + ".u32", r.mm_records[i]), put(d + "/mm_ts_" + t + ".u32", r.mm_ts[i]), put(d + "/mmio_rows_" + t + ".u32", r.mmio_rows[i]);
@@ -144,7 +146,8 @@ int main(int argc, char** argv) {
                     const zkhip_params params = read_app_config(cfg_path);
                     const unsigned log_keccak = zkhip_vm::keccak_log_rows(cfg_path, log_frame), log_sha256 = zkhip_vm::sha256_log_rows(cfg_path, log_frame);
                     const unsigned lanes = getenv("ZKHIP_LANES") ? (unsigned)atoi(getenv("ZKHIP_LANES")) : 2u;   // segment provers in flight
-                    const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false, lanes, log_keccak, log_sha256, zkhip_vm::config_moduli(cfg_path));
+                    const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false, lanes, log_keccak, log_sha256, zkhip_vm::config_moduli(cfg_path),
+                                                                                          zkhip_vm::int256_log_rows(cfg_path, log_frame));
                     (void)caps;
                     sp = UniversalProver::encode(g);
                     std::string why;

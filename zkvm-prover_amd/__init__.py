@@ -18,6 +18,8 @@ from ._binding import (  # noqa: F401
     RecursionCircuit,
     keccak_f_air,
     keccak_f1600_host,
+    int256_alu_air,
+    int256_alu_host,
     modmul_air,
     modmul_host,
     vm_modmul_air,

@@ -169,6 +169,10 @@ def load_library():
         "zkhip_keccak_f_air": (C.c_int, [C.POINTER(_Air)]),
         "zkhip_keccak_f1600_host": (C.c_int, [C.POINTER(C.c_uint64)]),
         "zkhip_keccak_f_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
+        "zkhip_int256_alu_air": (C.c_int, [C.c_uint32, C.POINTER(_Air)]),
+        "zkhip_int256_alu_host": (C.c_int, [C.c_uint32, u32p, u32p, u32p]),
+        "zkhip_int256_alu_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_vm_int256_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_modmul_air": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
         "zkhip_modmul_host": (C.c_int, [u32p, u32p, u32p, u32p, u32p]),
         "zkhip_modmul_tracegen": (C.c_int, [vp, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
@@ -650,6 +654,17 @@ class Context:
         self._check(self.lib.zkhip_keccak_f_tracegen(self.h, t_states.data_ptr() if n_perms else None, n_perms, log_height, out.data_ptr()))
         return out
 
+    def int256_alu_tracegen(self, t_records, n, log_height, t_bitwise_trace):
+        out = self._new(101 << log_height)
+        self._check(self.lib.zkhip_int256_alu_tracegen(self.h, t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr()))
+        return out
+
+    def vm_int256_tracegen(self, t_records, t_ts, n, log_height, t_bitwise_trace):
+        out = self._new(102 << log_height)
+        self._check(self.lib.zkhip_vm_int256_tracegen(self.h, t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height, out.data_ptr(),
+                                                      t_bitwise_trace.data_ptr()))
+        return out
+
     def modmul_tracegen(self, modulus, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
         out = self._new(286 << log_height)
         m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
@@ -934,6 +949,22 @@ def keccak_f1600_host(lanes):
 def _int_words(v):
     """a non-negative integer below 2^256 as eight little-endian 32-bit words"""
     return [(int(v) >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+
+
+def int256_alu_air(bitwise_bus):
+    """The 256-bit ALU chip's AIR: (program, width); its one definition is include/zkhip_int256.hpp."""
+    lib = load_library()
+    a = _Air()
+    assert lib.zkhip_int256_alu_air(bitwise_bus, C.byref(a)) == 0
+    return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
+
+
+def int256_alu_host(op, b, c):
+    """a = b op c modulo 2^256 through the library's host function (integers in, integer out)"""
+    wb, wc = (np.array(_int_words(v), dtype=np.uint32) for v in (b, c))
+    a = np.zeros(8, np.uint32)
+    assert load_library().zkhip_int256_alu_host(op, _u32p(wb), _u32p(wc), _u32p(a)) == 0
+    return sum(int(x) << (32 * i) for i, x in enumerate(a))
 
 
 def modmul_air(modulus, bitwise_bus, tuple_bus):

@@ -1,0 +1,128 @@
+// int256.hip -- the 256-bit ALU chip on the device (include/zkhip_int256.hpp: a = b op c on byte limbs, one operation per row, 101
+// columns).  Record = op | b[8] | c[8] (17 words).  One lane per row; the row's 32 lookups go into the bitwise table's XOR column in
+// the same pass (wave-merged atomics).  Replaces the trace generation of OpenVM's Rv32BaseAlu256 chip (openvm-bigint-circuit,
+// un-vendored).
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/zkhip.h"
+#include "../../include/zkhip_int256.hpp"
+#include "babybear.hpp"
+#include "hist.hpp"
+#include "zkhip_internal.hpp"
+
+namespace zk {
+namespace {
+namespace i2 = zkhip::int256;
+
+__global__ void k_i256_repr(uint32_t* c, size_t n, int to_m) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) c[i] = to_m ? to_monty(c[i] % P) : from_monty(c[i]);
+}
+
+__global__ __launch_bounds__(256) void k_alu256_trace(const uint32_t* __restrict__ recs, const uint32_t* __restrict__ ts, size_t n, size_t N, size_t width,
+                                                      uint32_t* __restrict__ trace, uint32_t* __restrict__ bitwise_xor, uint32_t* __restrict__ bad) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    if (row >= n) {
+        for (size_t c = 0; c < width; c++) trace[c * N + row] = 0u;
+        return;
+    }
+    const uint32_t op = recs[17 * row];
+    if (op >= i2::N_OPS) atomicAdd(bad, 1u);
+    uint32_t b[8], c[8], a[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) b[i] = recs[17 * row + 1 + i], c[i] = recs[17 * row + 9 + i];
+    uint64_t carry = 0, borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (op == i2::OP_ADD) {
+            carry += (uint64_t)b[i] + c[i], a[i] = (uint32_t)carry, carry >>= 32;
+        } else if (op == i2::OP_SUB) {
+            const uint64_t d = (uint64_t)b[i] - c[i] - borrow;
+            a[i] = (uint32_t)d, borrow = (d >> 32) & 1u;
+        } else {
+            a[i] = op == i2::OP_XOR ? b[i] ^ c[i] : op == i2::OP_OR ? b[i] | c[i] : b[i] & c[i];
+        }
+    }
+    auto byte_of = [](const uint32_t* w, int i) -> uint32_t { return (w[i >> 2] >> (8 * (i & 3))) & 255u; };
+    auto put = [&](size_t col, uint32_t v) { trace[col * N + row] = to_monty(v); };
+    const bool bitwise = op >= i2::OP_XOR;
+    for (int i = 0; i < 32; i++) {
+        const uint32_t ai = byte_of(a, i), bi = byte_of(b, i), ci = byte_of(c, i);
+        put(i2::COL_A + i, ai), put(i2::COL_B + i, bi), put(i2::COL_C + i, ci);
+        hist_add(bitwise_xor, bitwise ? bi * 256 + ci : ai * 256 + ai);
+    }
+    for (uint32_t f = 0; f < i2::N_OPS; f++) put(i2::COL_FLAGS + f, f == op ? 1u : 0u);
+    if (width > i2::WIDTH) put(i2::COL_TS, ts ? ts[row] % P : 0u);
+}
+
+std::mutex g_mu;
+std::map<uint32_t, std::vector<uint32_t>> g_programs;   // bitwise bus -> program
+
+int tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_ts, size_t n, unsigned log_height, size_t width, uint32_t* d_trace,
+             uint32_t* d_bitwise_trace, const char* what) {
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, what);
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    uint32_t* xor_col = d_bitwise_trace + ((size_t)1 << 16);   // the XOR multiplicities of the 8-bit table
+    const unsigned bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
+    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 0);
+    hipLaunchKernelGGL(k_alu256_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, d_ts, n, N, width, d_trace, xor_col, (uint32_t*)flag);
+    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return tracegen_finish(ctx, flag, std::string(what) + " (an opcode above 4)");
+}
+
+int air_of(uint32_t bitwise_bus, zkhip_air* out) {
+    try {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_programs.find(bitwise_bus);
+        if (it == g_programs.end()) {
+            zkhip::air::AirBuilder b(i2::WIDTH, 0);
+            i2::alu256_air(b, bitwise_bus);
+            it = g_programs.emplace(bitwise_bus, b.program()).first;
+        }
+        out->program = it->second.data(), out->program_len = it->second.size(), out->log_height = 0, out->width = i2::WIDTH, out->n_pvs = 0;
+        out->prep_trace = nullptr, out->prep_commit = nullptr;
+    } catch (const std::exception&) {
+        return ZKHIP_ERR_INVALID;
+    }
+    return ZKHIP_OK;
+}
+
+}  // namespace
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+int zkhip_int256_alu_air(uint32_t bitwise_bus, zkhip_air* out) { return out ? air_of(bitwise_bus, out) : ZKHIP_ERR_INVALID; }
+
+int zkhip_int256_alu_host(uint32_t op, const uint32_t b[8], const uint32_t c[8], uint32_t a[8]) {
+    if (!a || !b || !c || op >= i2::N_OPS) return ZKHIP_ERR_INVALID;
+    i2::alu256(op, b, c, a);
+    return ZKHIP_OK;
+}
+
+int zkhip_int256_alu_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 24 || (n && !d_records)) return ZKHIP_ERR_INVALID;
+    return tracegen(ctx, d_records, nullptr, n, log_height, i2::WIDTH, d_trace, d_bitwise_trace, "int256_alu_tracegen");
+}
+
+int zkhip_vm_int256_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_ts, size_t n, unsigned log_height, uint32_t* d_trace,
+                             uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 24 || (n && (!d_records || !d_ts))) return ZKHIP_ERR_INVALID;
+    return tracegen(ctx, d_records, d_ts, n, log_height, i2::VM_WIDTH, d_trace, d_bitwise_trace, "vm_int256_tracegen");
+}
+
+}  // extern "C"
