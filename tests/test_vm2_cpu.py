@@ -17,7 +17,7 @@ from zkvm_prover_amd import air
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import (INT256_OPERANDS, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
+from test_vm_cpu import (ALL_EXT_MSG, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
                          keccak_program, mixed_program, modmul_data, modmul_program, sha256_data, sha256_program)
 
 PARAMS = (1, 0, 4, 3, 3)
@@ -277,6 +277,26 @@ def test_int256_intrinsic_is_part_of_the_statement(tmp_path):
     assert 30 in bad and 31 in bad                                        # the request bus (ecall passed another opcode), the word bus
     with pytest.raises(AssertionError, match="does not enable the bigint extension"):
         v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)
+
+
+def test_all_extensions_of_the_chunk_circuit_in_one_statement(tmp_path):
+    """The chip set the reference's chunk-circuit configuration asks for (keccak, sha2, bigint, six moduli: 40 chips) and a guest that
+    uses all four intrinsics: SHA3-256 and SHA-256 of one message are hashlib's, the secp256k1 field product and the 256-bit difference
+    Python's; every trace satisfies its AIR and every bus balances."""
+    import hashlib
+
+    words, data = all_extensions_program(), all_extensions_data()
+    model = rv.run(words, b"", data=data, moduli=CHUNK_CIRCUIT_MODULI)
+    pv = bytes(model["pvs"])
+    assert pv[:8] == hashlib.sha3_256(ALL_EXT_MSG).digest()[:8]
+    assert b"".join(pv[8 + 4 * k:12 + 4 * k][::-1] for k in range(2)) == hashlib.sha256(ALL_EXT_MSG).digest()[:8]
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 5, 7, CHUNK_CIRCUIT_MODULI, True)
+    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"] and len(H.ids) == 40
+    for k, rec in enumerate(segs):
+        inst = v2.segment_instance(rec, words, PC_BASE, H)
+        for d in inst:
+            assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], k
+        assert v2.bus_imbalance(inst) == {}
 
 
 def test_decode_table_against_an_independent_decoder(mixed):
