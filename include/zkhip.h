@@ -655,6 +655,15 @@ int zkhip_int256_alu_host(uint32_t op, const uint32_t b[8], const uint32_t c[8],
 /* d_records: n x 17 words (op | b[8] | c[8], plain integers); fills 2^log_height rows and adds the rows' lookups to the XOR column of
  * the 8-bit bitwise table (d_bitwise_trace: 2 x 65536 Montgomery words) */
 int zkhip_int256_alu_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
+/* 256-bit multiplication chip (the low 256 bits of b c; 161 columns; byte pairs in the bitwise table, carries in the range-tuple table):
+ * d_records: n x 16 words (b[8] | c[8]); zkhip_int256_alu_host accepts op 5 for it */
+#define ZKHIP_INT256_MUL_WIDTH 161
+int zkhip_int256_mul_air(uint32_t bitwise_bus, uint32_t tuple_bus, zkhip_air *out);
+int zkhip_int256_mul_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace,
+                              uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+/* inside the VM (162 columns; records = the int256 calls' 17 words with op 5) */
+int zkhip_vm_mul256_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height, uint32_t *d_trace,
+                             uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
 /* the chip inside the VM (102 columns: + the timestamp of call i on row i) */
 int zkhip_vm_int256_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height, uint32_t *d_trace,
                              uint32_t *d_bitwise_trace);

@@ -66,6 +66,51 @@ inline void alu256_vm_air(AirBuilder& b, uint32_t bitwise_bus, uint32_t word_bus
         }
 }
 
+// ---- 256-bit multiplication (the low 256 bits of b c: OpenVM's Rv32Multiplication256) -- a chip of its own: per limb position k < 32
+//   sum_{i + j = k} b_i c_j + carry_{k-1} = a_k + 256 carry_k,   carry_k = cx_k + 256 cy_k with (cx_k, cy_k) in the range-tuple table
+// (a carry stays below 32 * 255^2 / 255 < 2^13; everything stays far below the field's characteristic, so the equations hold over the
+// integers).  Columns: a[32] | b[32] | c[32] | cx[32] | cy[32] | real; bytes looked up pairwise in the bitwise table.  Degree 3.
+constexpr uint32_t OP_MUL = 5;
+constexpr size_t MUL_COL_CX = 96, MUL_COL_CY = 128, MUL_COL_REAL = 160, MUL_WIDTH = 161;
+inline void mul256_air(AirBuilder& b, uint32_t bitwise_bus, uint32_t tuple_bus) {
+    const Expr real = b.var(MUL_COL_REAL), zero = b.constant(0);
+    b.assert_zero(real * (real - 1));
+    auto carry = [&](size_t k) { return b.var(MUL_COL_CX + k) + b.var(MUL_COL_CY + k) * 256; };
+    for (size_t k = 0; k < LIMBS; k++) {
+        Expr s = b.constant(0);
+        for (size_t i = 0; i <= k; i++) s = s + b.var(COL_B + i) * b.var(COL_C + k - i);
+        if (k > 0) s = s + carry(k - 1);
+        b.assert_zero(real * (s - b.var(COL_A + k) - carry(k) * 256));
+    }
+    for (size_t base : {COL_A, COL_B, COL_C})
+        for (size_t i = 0; i < LIMBS; i += 2) b.push_interaction(bitwise_bus, {b.var(base + i), b.var(base + i + 1), zero, zero}, real, Kind::Send);
+    for (size_t k = 0; k < LIMBS; k++) b.push_interaction(tuple_bus, {b.var(MUL_COL_CX + k), b.var(MUL_COL_CY + k)}, real, Kind::Send);
+}
+// inside the VM: + a timestamp column; the call's 24 words arrive on the ALU chip's word bus with opcode OP_MUL
+constexpr size_t MUL_COL_TS = MUL_WIDTH, MUL_VM_WIDTH = MUL_WIDTH + 1;
+inline void mul256_vm_air(AirBuilder& b, uint32_t bitwise_bus, uint32_t tuple_bus, uint32_t word_bus) {
+    mul256_air(b, bitwise_bus, tuple_bus);
+    const Expr ts = b.var(MUL_COL_TS), real = b.var(MUL_COL_REAL);
+    const size_t base[3] = {COL_B, COL_C, COL_A};
+    for (size_t o = 0; o < 3; o++)
+        for (size_t k = 0; k < 8; k++) {
+            const size_t c = base[o] + 4 * k;
+            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(8 * o + k)), b.var(c) + b.var(c + 1) * 256, b.var(c + 2) + b.var(c + 3) * 256, b.constant(OP_MUL)}, real,
+                               Kind::Receive);
+        }
+}
+inline void mul256(const uint32_t b[8], const uint32_t c[8], uint32_t a[8]) {
+    uint32_t t[8] = {};
+    for (int i = 0; i < 8; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; i + j < 8; j++) {
+            carry += (uint64_t)b[i] * c[j] + t[i + j];
+            t[i + j] = (uint32_t)carry, carry >>= 32;
+        }
+    }
+    for (int i = 0; i < 8; i++) a[i] = t[i];
+}
+
 // a <- b op c on little-endian 32-bit words (host)
 inline void alu256(uint32_t op, const uint32_t b[8], const uint32_t c[8], uint32_t a[8]) {
     uint64_t carry = 0, borrow = 0;

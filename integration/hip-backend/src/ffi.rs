@@ -15,6 +15,7 @@ pub const ZKHIP_ERR_CONSTRAINT: c_int = -8;
 pub const ZKHIP_DIGEST_WORDS: usize = 8;
 pub const ZKHIP_KECCAK_F_WIDTH: usize = 2633;
 pub const ZKHIP_INT256_ALU_WIDTH: usize = 101;
+pub const ZKHIP_INT256_MUL_WIDTH: usize = 161;
 pub const ZKHIP_MODMUL_WIDTH: usize = 286;
 pub const ZKHIP_SHA256_WIDTH: usize = 433;
 pub const ZKHIP_SHA256_PREP_WIDTH: usize = 6;
@@ -354,6 +355,11 @@ extern "C" {
                                      d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_vm_int256_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
                                     d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_int256_mul_air(bitwise_bus: u32, tuple_bus: u32, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_int256_mul_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32, d_bitwise_trace: *mut u32,
+                                     d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    pub fn zkhip_vm_mul256_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
+                                    d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
     pub fn zkhip_modmul_air(modulus: *const u8, bitwise_bus: u32, tuple_bus: u32, out: *mut zkhip_air) -> c_int;
     pub fn zkhip_modmul_host(a: *const u32, b: *const u32, modulus: *const u32, q: *mut u32, r: *mut u32) -> c_int;
     pub fn zkhip_modmul_tracegen(ctx: *mut zkhip_ctx, modulus: *const u32, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,

@@ -188,6 +188,8 @@ void ora_sha256_trace(const uint32_t *blocks, size_t n_blocks, unsigned log_heig
 /* ---- 256-bit ALU (oracle/int256.c): a = b op c modulo 2^256 on bytes, the chip's trace ---- */
 void ora_int256_alu(uint32_t op, const uint8_t b[32], const uint8_t c[32], uint8_t a[32]);
 size_t ora_int256_alu_trace(const uint32_t *records, size_t n, unsigned log_height, uint32_t *trace, uint32_t *xor_counts);
+size_t ora_mul256_trace(const uint32_t *records, size_t stride, size_t off, size_t n, unsigned log_height, uint32_t *trace, uint32_t *bitwise_range, uint32_t *tuple,
+                        uint32_t size_y);
 /* ---- modular multiplication (oracle/modular.c): r = a b mod P on bytes, the chip's trace ---- */
 int ora_modmul(const uint8_t a[32], const uint8_t b[32], const uint8_t p[32], uint8_t q[32], uint8_t r[32]);
 size_t ora_modmul_trace(const uint8_t *records, size_t n, const uint8_t p[32], unsigned log_height, uint32_t *trace, uint32_t *bitwise_range, uint32_t *tuple,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Known-answer vectors for the 256-bit ALU -> tests/golden/int256_kat.json.  Source of truth OUTSIDE this repository: Python's
-arbitrary-precision integers (a = (b op c) mod 2^256 for op = add, sub, xor, or, and): random operands and the edge cases of the carry
+arbitrary-precision integers (a = (b op c) mod 2^256 for op = add, sub, xor, or, and, mul): random operands and the edge cases of the carry
 chain (all ones, wrap-around, borrow through every limb)."""
 import json
 import os
@@ -8,7 +8,8 @@ import random
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 M = 1 << 256
-OPS = {0: lambda b, c: (b + c) % M, 1: lambda b, c: (b - c) % M, 2: lambda b, c: b ^ c, 3: lambda b, c: b | c, 4: lambda b, c: b & c}
+OPS = {0: lambda b, c: (b + c) % M, 1: lambda b, c: (b - c) % M, 2: lambda b, c: b ^ c, 3: lambda b, c: b | c, 4: lambda b, c: b & c,
+       5: lambda b, c: (b * c) % M}
 
 
 def main():
@@ -17,7 +18,7 @@ def main():
     pairs += [(rnd.getrandbits(256), rnd.getrandbits(256)) for _ in range(23)]
     cases = [{"op": op, "b": hex(b), "c": hex(c), "a": hex(f(b, c))} for op, f in OPS.items() for b, c in pairs]
     with open(os.path.join(HERE, "int256_kat.json"), "w") as f:
-        json.dump({"about": "a = (b op c) mod 2^256 from Python integers (generator: tests/golden/gen_int256_kat.py); op: 0 add 1 sub 2 xor 3 or 4 and",
+        json.dump({"about": "a = (b op c) mod 2^256 from Python integers (generator: tests/golden/gen_int256_kat.py); op: 0 add 1 sub 2 xor 3 or 4 and 5 mul (low 256 bits)",
                    "cases": cases}, f, indent=0)
     print("wrote", len(cases), "cases")
 

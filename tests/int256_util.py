@@ -6,7 +6,7 @@ import numpy as np
 import zkvm_prover_amd as z
 from zkvm_prover_amd import air
 
-WIDTH, BITWISE_BUS = 101, 9
+WIDTH, BITWISE_BUS, MUL_WIDTH, TUPLE_BUS, SX, SY = 101, 9, 161, 6, 256, 32
 NOPV = np.zeros(0, np.uint32)
 
 
@@ -48,3 +48,25 @@ def instance(trace, xc, log_height):
     bitwise = np.stack([np.zeros(1 << 16, np.uint32), xc])
     return [dict(program=program, log_height=log_height, width=width, n_pvs=0, trace=trace, pvs=NOPV),
             dict(program=air.bitwise_lookup_air(8, BITWISE_BUS).program(), log_height=16, width=2, n_pvs=0, trace=bitwise, pvs=NOPV, prep=air.bitwise_lookup_prep(8))]
+
+
+def ora_mul_trace(ora, pairs, log_height):
+    """(trace [161, N], bitwise range counts, tuple counts, bad) of the multiplication chip for [(b, c)]"""
+    l = ora.lib()
+    l.ora_mul256_trace.restype = C.c_size_t
+    l.ora_mul256_trace.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint32), C.c_uint32]
+    recs = np.array([words(b) + words(c) for b, c in pairs], dtype=np.uint32).reshape(-1, 16)
+    tr = np.zeros((MUL_WIDTH, 1 << log_height), np.uint32)
+    bw, tup = np.zeros(1 << 16, np.uint32), np.zeros(SX * SY, np.uint32)
+    bad = l.ora_mul256_trace(ora.p32(recs), 16, 0, len(pairs), log_height, ora.p32(tr), ora.p32(bw), ora.p32(tup), SY)
+    return tr, bw, tup, bad
+
+
+def mul_instance(trace, bw, tup, log_height):
+    program, width = z.int256_mul_air(BITWISE_BUS, TUPLE_BUS)
+    return [dict(program=program, log_height=log_height, width=width, n_pvs=0, trace=trace, pvs=NOPV),
+            dict(program=air.bitwise_lookup_air(8, BITWISE_BUS).program(), log_height=16, width=2, n_pvs=0, trace=np.stack([bw, np.zeros(1 << 16, np.uint32)]), pvs=NOPV,
+                 prep=air.bitwise_lookup_prep(8)),
+            dict(program=air.range_tuple_table_air(SX, SY, TUPLE_BUS).program(), log_height=13, width=1, n_pvs=0, trace=tup.reshape(1, -1), pvs=NOPV,
+                 prep=air.range_tuple_prep(SX, SY))]

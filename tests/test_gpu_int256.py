@@ -18,6 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def test_device_int256_trace_and_proof(zk, ora):
     kat = [(c["op"], int(c["b"], 16), int(c["c"], 16), int(c["a"], 16)) for c in json.load(open(os.path.join(HERE, "golden", "int256_kat.json")))["cases"]]
+    kat_mul = [(b, c, a) for op, b, c, a in kat if op == 5]
+    kat = [k for k in kat if k[0] < 5]
     cases = [(op, b, c) for op, b, c, _ in kat]
     log_h = 8
     d_recs = torch.from_numpy(iu.records(cases).reshape(-1).view(np.int32)).to(zk.device)
@@ -39,6 +41,22 @@ def test_device_int256_trace_and_proof(zk, ora):
     bad_tr = d_tr.clone()
     bad_tr[3] ^= 1   # another result limb
     assert z.verify(PARAMS, pk.verifying_airs(), pvs, pk.prove([bad_tr, d_bw], pvs)) != 0
+    pk.close()
+    # the multiplication chip with its two tables
+    pairs = [(b, c) for b, c, _ in kat_mul]
+    recs = np.array([iu.words(b) + iu.words(c) for b, c in pairs], dtype=np.uint32)
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
+    d_tup = torch.zeros(iu.SX * iu.SY, dtype=torch.int32, device=zk.device)
+    d_tr = zk.int256_mul_tracegen(torch.from_numpy(recs.reshape(-1).view(np.int32)).to(zk.device), len(pairs), 5, d_bw, d_tup, iu.SX, iu.SY)
+    got = zk.download(d_tr).reshape(iu.MUL_WIDTH, -1)
+    tr, bw, tup, bad = iu.ora_mul_trace(ora, pairs, 5)
+    assert bad == 0 and (got == tr).all() and (zk.download(d_bw)[:1 << 16] == bw).all() and (zk.download(d_tup) == tup).all()
+    for row, (_, _, a) in enumerate(kat_mul):
+        assert bytes(got[0:32, row].astype(np.uint8)) == a.to_bytes(32, "little")
+    inst = iu.mul_instance(got, bw, tup, 5)
+    pk = z.ProvingKey(zk, PARAMS, inst)
+    proof = pk.prove([d_tr, d_bw, d_tup], [iu.NOPV] * 3)
+    assert z.verify(PARAMS, pk.verifying_airs(), [iu.NOPV] * 3, proof) == 0 and proof == ora.stark_prove(PARAMS, inst).tobytes()
     pk.close()
 
 

@@ -72,6 +72,9 @@ def device_traces(zk, rec, prog, H):
         n_i = len(rec["i256_ts"])
         T[v2.A_INT256] = zk.vm_int256_tracegen(D(rec["i256_records"]) if n_i else None, D(rec["i256_ts"]) if n_i else None, n_i, H[v2.A_INT256], d_bw)
         T[v2.A_INT256_IO] = zk.rows_tracegen(D(rec["i256io_rows"]), len(rec["i256io_rows"]) // v2.INT256_IO_WIDTH, v2.INT256_IO_WIDTH, H[v2.A_INT256_IO])
+        n_m = len(rec["mul256_ts"])
+        T[v2.A_MUL256] = zk.vm_mul256_tracegen(D(rec["mul256_records"]) if n_m else None, D(rec["mul256_ts"]) if n_m else None, n_m, H[v2.A_MUL256], d_bw, d_tup,
+                                               v2.SX, v2.SY)
     for i, p_ in enumerate(H.moduli):   # the multiplication chips count their own lookups into the two tables
         n_mm = len(rec["mm_ts_%d" % i])
         T[v2.A_MODMUL(i)] = zk.vm_modmul_tracegen(p_, D(rec["mm_records_%d" % i]) if n_mm else None, D(rec["mm_ts_%d" % i]) if n_mm else None, n_mm,
@@ -328,14 +331,14 @@ def test_modmul_guest_device_traces_and_one_proof(zk, ora, tmp_path):
 
 
 def test_int256_guest_device_traces_and_one_proof(zk, ora, tmp_path):
-    """A guest running the five 256-bit opcodes through the int256 intrinsic (bigint extension, 24 chips): device traces == CPU twins,
+    """A guest running the six 256-bit opcodes through the int256 intrinsic (bigint extension, 25 chips): device traces == CPU twins,
     proof bytes == the oracle's; the whole flow from the ELF with `[app_vm_config.bigint]`: the root's public values are Python's."""
     words, data = int256_program(), int256_data()
     info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, (), True)
     k = next(i for i, s in enumerate(segs) if len(s["i256_ts"]))
     inst = v2.segment_instance(segs[k], words, PC_BASE, H)
     T = device_traces(zk, segs[k], v2.program_table(words, PC_BASE, H[0]), H)
-    assert len(inst) == len(T) == 24
+    assert len(inst) == len(T) == 25
     for a, d in enumerate(inst):
         assert (zk.download(T[a]).reshape(d["width"], -1) == d["trace"]).all(), "position %d" % a
     pk = z.ProvingKey(zk, PARAMS, inst)
@@ -354,14 +357,14 @@ def test_int256_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     assert out["verified"] and out["total_cycles"] == model["instret"]
     pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * 34:4 * 34 + 32]
     M = 1 << 256
-    want = [[(b + c) % M, (b - c) % M, b ^ c, b | c, b & c][op] for op, (b, c) in enumerate(INT256_OPERANDS)]
-    assert pv == bytes(model["pvs"]) and [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(5)] == [w & 0xFFFFFFFF for w in want]
+    want = [[(b + c) % M, (b - c) % M, b ^ c, b | c, b & c, (b * c) % M][op] for op, (b, c) in enumerate(INT256_OPERANDS)]
+    assert pv == bytes(model["pvs"]) and [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(6)] == [w & 0xFFFFFFFF for w in want]
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
 
 
 def test_the_chunk_circuit_configuration_end_to_end(tmp_path):
     """`prove-elf` under an openvm.toml with the sections of the reference's chunk circuit in the reference's syntax (keccak, sha2, bigint,
-    modular with its six moduli: 40 chips per segment) for a guest that uses all four intrinsics: ONE root proof whose public values
+    modular with its six moduli: 41 chips per segment) for a guest that uses all four intrinsics: ONE root proof whose public values
     carry hashlib's SHA3-256 / SHA-256 words and Python's field product and 256-bit difference."""
     import hashlib
 

@@ -247,19 +247,20 @@ def test_modmul_intrinsic_is_part_of_the_statement(tmp_path):
 
 
 def test_int256_intrinsic_is_part_of_the_statement(tmp_path):
-    """A guest that runs the five 256-bit opcodes through the int256 intrinsic under an app with the bigint extension (24 chips): the
+    """A guest that runs the six 256-bit opcodes through the int256 intrinsic under an app with the bigint extension (25 chips): the
     revealed words are Python's; every trace satisfies its AIR, every bus balances; a forged result word, or a call whose adapter
     claims another opcode than the ecall passed, breaks a bus."""
     words, data = int256_program(), int256_data()
     model = rv.run(words, b"", data=data)
     pv = bytes(model["pvs"])
     M = 1 << 256
-    want = [[(b + c) % M, (b - c) % M, b ^ c, b | c, b & c][op] for op, (b, c) in enumerate(INT256_OPERANDS)]
-    assert [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(5)] == [w & 0xFFFFFFFF for w in want]
-    assert [int.from_bytes(pv[20 + 4 * k:24 + 4 * k], "little") for k in range(3)] == [w >> 224 for w in want[:3]]
+    want = [[(b + c) % M, (b - c) % M, b ^ c, b | c, b & c, (b * c) % M][op] for op, (b, c) in enumerate(INT256_OPERANDS)]
+    assert [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(6)] == [w & 0xFFFFFFFF for w in want]
+    assert [int.from_bytes(pv[24 + 4 * j:28 + 4 * j], "little") for j in range(2)] == [want[1] >> 224, want[5] >> 224]
     info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, (), True)
     assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"]
-    assert len(H.ids) == 24 and H.ids[-2:] == (v2.A_INT256, v2.A_INT256_IO) and sum(len(s["i256_ts"]) for s in segs) == 5
+    assert len(H.ids) == 25 and H.ids[-3:] == (v2.A_INT256, v2.A_INT256_IO, v2.A_MUL256)
+    assert sum(len(s["i256_ts"]) for s in segs) == 5 and sum(len(s["mul256_ts"]) for s in segs) == 1
     for k, rec in enumerate(segs):
         inst = v2.segment_instance(rec, words, PC_BASE, H)
         for d in inst:
@@ -280,7 +281,7 @@ def test_int256_intrinsic_is_part_of_the_statement(tmp_path):
 
 
 def test_all_extensions_of_the_chunk_circuit_in_one_statement(tmp_path):
-    """The chip set the reference's chunk-circuit configuration asks for (keccak, sha2, bigint, six moduli: 40 chips) and a guest that
+    """The chip set the reference's chunk-circuit configuration asks for (keccak, sha2, bigint, six moduli: 41 chips) and a guest that
     uses all four intrinsics: SHA3-256 and SHA-256 of one message are hashlib's, the secp256k1 field product and the 256-bit difference
     Python's; every trace satisfies its AIR and every bus balances."""
     import hashlib
@@ -291,7 +292,7 @@ def test_all_extensions_of_the_chunk_circuit_in_one_statement(tmp_path):
     assert pv[:8] == hashlib.sha3_256(ALL_EXT_MSG).digest()[:8]
     assert b"".join(pv[8 + 4 * k:12 + 4 * k][::-1] for k in range(2)) == hashlib.sha256(ALL_EXT_MSG).digest()[:8]
     info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 5, 7, CHUNK_CIRCUIT_MODULI, True)
-    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"] and len(H.ids) == 40
+    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"] and len(H.ids) == 41
     for k, rec in enumerate(segs):
         inst = v2.segment_instance(rec, words, PC_BASE, H)
         for d in inst:

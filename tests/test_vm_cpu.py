@@ -88,21 +88,22 @@ def sha256_data(msg):
 
 
 def int256_program():
-    """256-bit words through the int256 intrinsic (a7 = 6, a1 = opcode): five buffers (b, c, result slot) at the data base, one per
-    opcode (add, sub, xor, or, and; int256_data); the five results' low words and three high words are revealed."""
+    """256-bit words through the int256 intrinsic (a7 = 6, a1 = opcode): six buffers (b, c, result slot) at the data base, one per
+    opcode (add, sub, xor, or, and, mul; int256_data); the six results' low words and two high words (sub, mul) are revealed."""
     p = rv.li(S0, 0x00400000)
-    for op in range(5):
+    for op in range(6):
         p += [("addi", A0, S0, 96 * op), ("addi", A1, 0, op), ("addi", A7, 0, 6), ("ecall",)]
-    for k in range(5):
+    for k in range(6):
         p += [("lw", A0, S0, 96 * k + 64), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
-    for k in range(3):
-        p += [("lw", A0, S0, 96 * k + 64 + 28), ("addi", A1, 0, 5 + k), ("addi", A7, 0, 1), ("ecall",)]
+    for j, k in enumerate((1, 5)):
+        p += [("lw", A0, S0, 96 * k + 64 + 28), ("addi", A1, 0, 6 + j), ("addi", A7, 0, 1), ("ecall",)]
     p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
     return rv.assemble(p)
 
 
 INT256_OPERANDS = [((1 << 256) - 5, 77), (3, 0xFFFF_FFFF_FFFF_FFFF_FFFF), (0x0123456789ABCDEF << 190 | 0xF0F0, 0xFEDCBA9876543210 << 180 | 0x0FF0),
-                   (0xAAAA << 240 | 0x5555, 0x1234 << 240 | 0xAAAA), (0xFFFF << 240 | 0xFF00FF, 0xF0F0 << 240 | 0x0FF0F0)]
+                   (0xAAAA << 240 | 0x5555, 0x1234 << 240 | 0xAAAA), (0xFFFF << 240 | 0xFF00FF, 0xF0F0 << 240 | 0x0FF0F0),
+                   (0xFEDCBA9876543210FEDCBA9876543210FEDCBA98, 0x123456789ABCDEF0123456789ABCDEF0123456789)]
 
 
 def int256_data():

@@ -17,14 +17,14 @@ CLI = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
 P = ora.P
 NOPV = np.zeros(0, np.uint32)
 (A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
- A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, A_INT256, A_INT256_IO,
- N_STATIC_AIRS) = range(29)
+ A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, A_INT256, A_INT256_IO, A_MUL256,
+ N_STATIC_AIRS) = range(30)
 MAX_MODULI = 8
 N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI   # the modular extension: chips N_STATIC_AIRS + 2 i (multiplication), + 2 i + 1 (adapter) of modulus i
 PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 32, 43, 54, 42, 2634
 SHA_IO_WIDTH, SHA_WIDTH = 34, 434
 MODMUL_IO_WIDTH, MODMUL_WIDTH = 34, 287
-INT256_IO_WIDTH, INT256_WIDTH = 35, 102
+INT256_IO_WIDTH, INT256_WIDTH, MUL256_WIDTH = 35, 102, 162
 TS_STEP, GAP_HI_BITS = 16, 11
 SX, SY = 256, 2048
 
@@ -207,6 +207,24 @@ def int256_traces(rec, H):
     return tr, rows_trace(rec["i256io_rows"], INT256_IO_WIDTH, H[A_INT256_IO]), xcnt.astype(np.int64)
 
 
+def mul256_traces(rec, H):
+    """int256 calls with opcode 5: the oracle's multiplication-chip trace (and its lookup counts) + the call's timestamp"""
+    n = len(rec["mul256_ts"])
+    l = ora.lib()
+    l.ora_mul256_trace.restype = C.c_size_t
+    l.ora_mul256_trace.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint32), C.c_uint32]
+    lh = H[A_MUL256]
+    body = np.zeros((MUL256_WIDTH - 1, 1 << lh), np.uint32)
+    bw, tup = np.zeros(1 << 16, np.uint32), np.zeros(SX * SY, np.uint32)
+    recs = np.ascontiguousarray(rec["mul256_records"], dtype=np.uint32)
+    assert l.ora_mul256_trace(ora.p32(recs) if n else None, 17, 1, n, lh, ora.p32(body), ora.p32(bw), ora.p32(tup), SY) == 0
+    tr = np.zeros((MUL256_WIDTH, 1 << lh), np.uint32)
+    tr[:MUL256_WIDTH - 1] = body
+    tr[MUL256_WIDTH - 1, :n] = rec["mul256_ts"]
+    return tr, bw.astype(np.int64), tup.astype(np.int64)
+
+
 def modmul_traces(rec, H, i, p):
     """modmul calls of modulus i: the oracle's chip trace (and its lookup counts) + the call's timestamp; the adapter's rows"""
     n = len(rec["mm_ts_%d" % i])
@@ -280,8 +298,11 @@ def segment_instance(rec, words, pc_base, heights):
     if A_SHA256 in H.ids:
         tr[A_SHA256], tr[A_SHA256_IO] = sha256_traces(rec, H)
     i256_xor = None
+    mul_counts = None
     if A_INT256 in H.ids:
         tr[A_INT256], tr[A_INT256_IO], i256_xor = int256_traces(rec, H)
+        tr[A_MUL256], mul_bw, mul_tup = mul256_traces(rec, H)
+        mul_counts = (mul_bw, mul_tup)
     mm_counts = []
     for i, p_ in enumerate(H.moduli):
         tr[A_MODMUL(i)], tr[A_MODMUL_IO(i)], bw_i, tup_i = modmul_traces(rec, H, i, p_)
@@ -295,6 +316,9 @@ def segment_instance(rec, words, pc_base, heights):
     for bw_i, tup_i in mm_counts:   # the multiplication chips' own lookups (byte pairs, carries)
         rc += bw_i
         tc += tup_i
+    if mul_counts is not None:     # the 256-bit multiplication chip's byte pairs and carries
+        rc += mul_counts[0]
+        tc += mul_counts[1]
     if i256_xor is not None:       # the 256-bit ALU's lookups go to the XOR column
         xc = ((xc.astype(np.int64) + i256_xor) % P).astype(np.uint32)
     n, nls = n_instr, len(rec["ls_case"])

@@ -20,6 +20,7 @@ from ._binding import (  # noqa: F401
     keccak_f1600_host,
     int256_alu_air,
     int256_alu_host,
+    int256_mul_air,
     modmul_air,
     modmul_host,
     vm_modmul_air,

@@ -173,6 +173,9 @@ def load_library():
         "zkhip_int256_alu_host": (C.c_int, [C.c_uint32, u32p, u32p, u32p]),
         "zkhip_int256_alu_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_vm_int256_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_int256_mul_air": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
+        "zkhip_int256_mul_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
+        "zkhip_vm_mul256_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_modmul_air": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
         "zkhip_modmul_host": (C.c_int, [u32p, u32p, u32p, u32p, u32p]),
         "zkhip_modmul_tracegen": (C.c_int, [vp, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
@@ -659,6 +662,18 @@ class Context:
         self._check(self.lib.zkhip_int256_alu_tracegen(self.h, t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr()))
         return out
 
+    def int256_mul_tracegen(self, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
+        out = self._new(161 << log_height)
+        self._check(self.lib.zkhip_int256_mul_tracegen(self.h, t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr(),
+                                                       t_tuple_counts.data_ptr(), size_x, size_y))
+        return out
+
+    def vm_mul256_tracegen(self, t_records, t_ts, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
+        out = self._new(162 << log_height)
+        self._check(self.lib.zkhip_vm_mul256_tracegen(self.h, t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height, out.data_ptr(),
+                                                      t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
+        return out
+
     def vm_int256_tracegen(self, t_records, t_ts, n, log_height, t_bitwise_trace):
         out = self._new(102 << log_height)
         self._check(self.lib.zkhip_vm_int256_tracegen(self.h, t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height, out.data_ptr(),
@@ -956,6 +971,14 @@ def int256_alu_air(bitwise_bus):
     lib = load_library()
     a = _Air()
     assert lib.zkhip_int256_alu_air(bitwise_bus, C.byref(a)) == 0
+    return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
+
+
+def int256_mul_air(bitwise_bus, tuple_bus):
+    """The 256-bit multiplication chip's AIR: (program, width); its one definition is include/zkhip_int256.hpp."""
+    lib = load_library()
+    a = _Air()
+    assert lib.zkhip_int256_mul_air(bitwise_bus, tuple_bus, C.byref(a)) == 0
     return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
 
 

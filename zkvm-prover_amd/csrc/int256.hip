@@ -60,6 +60,39 @@ __global__ __launch_bounds__(256) void k_alu256_trace(const uint32_t* __restrict
     if (width > i2::WIDTH) put(i2::COL_TS, ts ? ts[row] % P : 0u);
 }
 
+// 256-bit multiplication chip: record = b[8] | c[8]; the row's 48 byte pairs and 32 carry tuples are counted in the same pass
+__global__ __launch_bounds__(256) void k_mul256_trace(const uint32_t* __restrict__ recs, size_t rec_stride, size_t rec_off, const uint32_t* __restrict__ ts, size_t n,
+                                                      size_t N, size_t width, uint32_t* __restrict__ trace, uint32_t* __restrict__ bitwise_range,
+                                                      uint32_t* __restrict__ tuple, uint32_t tuple_y, uint32_t* __restrict__ bad) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    if (row >= n) {
+        for (size_t c = 0; c < width; c++) trace[c * N + row] = 0u;
+        return;
+    }
+    uint32_t b[8], c[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) b[i] = recs[rec_stride * row + rec_off + i], c[i] = recs[rec_stride * row + rec_off + 8 + i];
+    auto byte_of = [](const uint32_t* w, int i) -> uint32_t { return (w[i >> 2] >> (8 * (i & 3))) & 255u; };
+    auto put = [&](size_t col, uint32_t v) { trace[col * N + row] = to_monty(v); };
+    uint32_t carry = 0, a_bytes[32];
+    for (int k = 0; k < 32; k++) {
+        uint32_t s = carry;
+        for (int i = 0; i <= k; i++) s += byte_of(b, i) * byte_of(c, k - i);
+        a_bytes[k] = s & 255u, carry = s >> 8;
+        if ((carry >> 8) >= tuple_y) atomicAdd(bad, 1u);
+        put(i2::COL_A + k, a_bytes[k]), put(i2::COL_B + k, byte_of(b, k)), put(i2::COL_C + k, byte_of(c, k));
+        put(i2::MUL_COL_CX + k, carry & 255u), put(i2::MUL_COL_CY + k, carry >> 8);
+        hist_add(tuple, (carry & 255u) * tuple_y + (carry >> 8));
+    }
+    for (int i = 0; i < 32; i += 2) {
+        hist_add(bitwise_range, a_bytes[i] * 256 + a_bytes[i + 1]);
+        hist_add(bitwise_range, byte_of(b, i) * 256 + byte_of(b, i + 1)), hist_add(bitwise_range, byte_of(c, i) * 256 + byte_of(c, i + 1));
+    }
+    put(i2::MUL_COL_REAL, 1u);
+    if (width > i2::MUL_WIDTH) put(i2::MUL_COL_TS, ts ? ts[row] % P : 0u);
+}
+
 std::mutex g_mu;
 std::map<uint32_t, std::vector<uint32_t>> g_programs;   // bitwise bus -> program
 
@@ -97,6 +130,28 @@ int air_of(uint32_t bitwise_bus, zkhip_air* out) {
     return ZKHIP_OK;
 }
 
+int mul_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t rec_stride, size_t rec_off, const uint32_t* d_ts, size_t n, unsigned log_height, size_t width,
+                 uint32_t* d_trace, uint32_t* d_bitwise_trace, uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y, const char* what) {
+    const size_t N = (size_t)1 << log_height, T = (size_t)size_x * size_y;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": more records than rows");
+    if (size_x < 256 || size_y < 32 || T > ((size_t)1 << 27)) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": the tuple table must cover (x < 256, y < 32)");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, what);
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const unsigned tb = (unsigned)((T + 255) / 256), bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
+    hipLaunchKernelGGL(k_i256_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
+    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
+    hipLaunchKernelGGL(k_mul256_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, rec_stride, rec_off, d_ts, n, N, width, d_trace,
+                       d_bitwise_trace, d_tuple_counts, size_y, (uint32_t*)flag);
+    hipLaunchKernelGGL(k_i256_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
+    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return tracegen_finish(ctx, flag, std::string(what) + " (a carry outside the tuple table)");
+}
+
+std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> g_mul_programs;   // (bitwise bus, tuple bus) -> program
+
 }  // namespace
 }  // namespace zk
 
@@ -107,9 +162,43 @@ extern "C" {
 int zkhip_int256_alu_air(uint32_t bitwise_bus, zkhip_air* out) { return out ? air_of(bitwise_bus, out) : ZKHIP_ERR_INVALID; }
 
 int zkhip_int256_alu_host(uint32_t op, const uint32_t b[8], const uint32_t c[8], uint32_t a[8]) {
-    if (!a || !b || !c || op >= i2::N_OPS) return ZKHIP_ERR_INVALID;
-    i2::alu256(op, b, c, a);
+    if (!a || !b || !c || op > i2::OP_MUL) return ZKHIP_ERR_INVALID;
+    if (op == i2::OP_MUL) i2::mul256(b, c, a);
+    else i2::alu256(op, b, c, a);
     return ZKHIP_OK;
+}
+
+int zkhip_int256_mul_air(uint32_t bitwise_bus, uint32_t tuple_bus, zkhip_air* out) {
+    if (!out) return ZKHIP_ERR_INVALID;
+    try {
+        std::lock_guard<std::mutex> lk(g_mu);
+        const auto key = std::make_pair(bitwise_bus, tuple_bus);
+        auto it = g_mul_programs.find(key);
+        if (it == g_mul_programs.end()) {
+            zkhip::air::AirBuilder b(i2::MUL_WIDTH, 0);
+            i2::mul256_air(b, bitwise_bus, tuple_bus);
+            it = g_mul_programs.emplace(key, b.program()).first;
+        }
+        out->program = it->second.data(), out->program_len = it->second.size(), out->log_height = 0, out->width = i2::MUL_WIDTH, out->n_pvs = 0;
+        out->prep_trace = nullptr, out->prep_commit = nullptr;
+    } catch (const std::exception&) {
+        return ZKHIP_ERR_INVALID;
+    }
+    return ZKHIP_OK;
+}
+
+int zkhip_int256_mul_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace,
+                              uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || !d_tuple_counts || log_height > 24 || (n && !d_records)) return ZKHIP_ERR_INVALID;
+    return mul_tracegen(ctx, d_records, 16, 0, nullptr, n, log_height, i2::MUL_WIDTH, d_trace, d_bitwise_trace, d_tuple_counts, size_x, size_y, "int256_mul_tracegen");
+}
+
+int zkhip_vm_mul256_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_ts, size_t n, unsigned log_height, uint32_t* d_trace,
+                             uint32_t* d_bitwise_trace, uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || !d_tuple_counts || log_height > 24 || (n && (!d_records || !d_ts))) return ZKHIP_ERR_INVALID;
+    return mul_tracegen(ctx, d_records, 17, 1, d_ts, n, log_height, i2::MUL_VM_WIDTH, d_trace, d_bitwise_trace, d_tuple_counts, size_x, size_y, "vm_mul256_tracegen");
 }
 
 int zkhip_int256_alu_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
