@@ -1,4 +1,4 @@
-// zkhip_modular.hpp -- modular multiplication over a 256-bit modulus (crates/circuits/chunk-circuit/openvm.toml:8-59
+// zkhip_modular.hpp -- modular multiplication, addition and subtraction over a 256-bit modulus (crates/circuits/chunk-circuit/openvm.toml:8-59
 // lists `modular` with the secp256k1 / bn254 / bls12-381 field and scalar moduli: the arithmetic under the EVM guest's ecrecover and pairing
 // precompiles).  OpenVM's chips (openvm-algebra-circuit ModularMulDiv over its mod-builder, un-vendored) state r = a b mod P as an integer
 // identity on byte limbs with range-checked carries; this is the same statement in this repository's own columns, ONE multiplication
@@ -8,7 +8,8 @@
 //                             range-tuple table (cx < 256, cy < 2048): every quantity stays far below the field's characteristic, so the 63
 //                             limb equations hold over the integers and a b = q P + r exactly (the last carry is zero)
 //   marker[32], diff          r < P: the most significant limb where r and P differ is marked, P - r there is in 1..255
-//   real                      rows beyond the records are zero
+//   real, is_add, is_sub      rows beyond the records are zero; a real row multiplies unless one of the two flags is set: then the limb
+//                             identity is a + b = q P + r, resp. a - b + q P = r, in the same columns (OpenVM's ModularAddSub)
 // The modulus is a constant of the AIR (one chip per modulus, as OpenVM instantiates one per configured modulus).  a and b are bytes
 // but not required to be reduced; r is the canonical residue.  Every constraint has degree <= 3.
 // External parity: Python's integers (tests/golden/modular_kat.json: random and edge operands for the secp256k1 and bn254 field and
@@ -28,27 +29,31 @@ using air::Kind;
 
 constexpr size_t LIMBS = 32, N_CARRY = 2 * LIMBS - 2;
 constexpr size_t COL_A = 0, COL_B = 32, COL_Q = 64, COL_R = 96, COL_CX = 128, COL_CY = COL_CX + N_CARRY, COL_MARK = COL_CY + N_CARRY, COL_DIFF = COL_MARK + LIMBS,
-                 COL_REAL = COL_DIFF + 1, WIDTH = COL_REAL + 1;
+                 COL_REAL = COL_DIFF + 1, COL_IS_ADD = COL_REAL + 1, COL_IS_SUB = COL_REAL + 2, WIDTH = COL_REAL + 3;
+enum Op : uint32_t { OP_MUL, OP_ADD, OP_SUB, N_OPS };
 constexpr int64_t CARRY_OFFSET = 1 << 14;
 using Modulus = std::array<uint8_t, LIMBS>;   // little-endian bytes
 
 // AirBuilder(WIDTH, 0); bitwise_bus: (x, y, 0, 0) byte pairs; tuple_bus: (cx, cy)
 inline void modmul_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus, uint32_t tuple_bus) {
     const Expr real = b.var(COL_REAL), zero = b.constant(0);
-    b.assert_zero(real * (real - 1));
+    const Expr is_add = b.var(COL_IS_ADD), is_sub = b.var(COL_IS_SUB), is_mul = real - is_add - is_sub, q_sign = real - is_sub * 2;
+    for (const Expr& f : {real, is_add, is_sub, is_mul}) b.assert_zero(f * (f - 1));
     auto carry = [&](size_t k) { return b.var(COL_CX + k) + b.var(COL_CY + k) * 256 - CARRY_OFFSET; };
-    for (size_t k = 0; k <= N_CARRY; k++) {   // limb positions 0 .. 62
-        Expr s = b.constant(0);
+    for (size_t k = 0; k <= N_CARRY; k++) {   // limb positions 0 .. 62 of  [a b | a + b | a - b]  -  (+ | + | -) q P  -  r
+        Expr prod = b.constant(0), qp = b.constant(0);
         for (size_t i = 0; i < LIMBS; i++) {
             if (k < i || k - i >= LIMBS) continue;
             const size_t j = k - i;
-            s = s + b.var(COL_A + i) * b.var(COL_B + j);
-            if (P[j]) s = s - b.var(COL_Q + i) * (int64_t)P[j];
+            prod = prod + b.var(COL_A + i) * b.var(COL_B + j);
+            if (P[j]) qp = qp + b.var(COL_Q + i) * (int64_t)P[j];
         }
-        if (k < LIMBS) s = s - b.var(COL_R + k);
-        if (k > 0) s = s + carry(k - 1);
-        if (k < N_CARRY) s = s - carry(k) * 256;   // the carry out of position 62 is zero
-        b.assert_zero(real * s);
+        Expr s = is_mul * prod - q_sign * qp;
+        if (k < LIMBS) s = s + is_add * (b.var(COL_A + k) + b.var(COL_B + k)) + is_sub * (b.var(COL_A + k) - b.var(COL_B + k)) - real * b.var(COL_R + k);
+        Expr cs = b.constant(0);
+        if (k > 0) cs = cs + carry(k - 1);
+        if (k < N_CARRY) cs = cs - carry(k) * 256;   // the carry out of position 62 is zero
+        b.assert_zero(s + real * cs);
     }
     // r < P
     Expr n_marked = b.constant(0), diff = b.constant(0);
@@ -72,17 +77,17 @@ inline void modmul_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus, ui
 }
 
 // The chip inside the VM (include/zkhip_vm_circuit.hpp): the same AIR plus a timestamp column; the 24 words of a call -- a, b (read) and
-// r (written) -- are received from the modular adapter on `word_bus` as (timestamp, word index 0..23, low half, high half).
+// r (written) -- are received from the modular adapter on `word_bus` as (timestamp, word index 0..23, low half, high half, operation).
 // AirBuilder(VM_WIDTH, 0)
 constexpr size_t COL_TS = WIDTH, VM_WIDTH = WIDTH + 1;
 inline void modmul_vm_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus, uint32_t tuple_bus, uint32_t word_bus) {
     modmul_air(b, P, bitwise_bus, tuple_bus);
-    const Expr ts = b.var(COL_TS), real = b.var(COL_REAL);
+    const Expr ts = b.var(COL_TS), real = b.var(COL_REAL), op = b.var(COL_IS_ADD) + b.var(COL_IS_SUB) * 2;
     const size_t base[3] = {COL_A, COL_B, COL_R};
     for (size_t o = 0; o < 3; o++)
         for (size_t k = 0; k < 8; k++) {
             const size_t c = base[o] + 4 * k;
-            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(8 * o + k)), b.var(c) + b.var(c + 1) * 256, b.var(c + 2) + b.var(c + 3) * 256}, real, Kind::Receive);
+            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(8 * o + k)), b.var(c) + b.var(c + 1) * 256, b.var(c + 2) + b.var(c + 3) * 256, op}, real, Kind::Receive);
         }
 }
 
@@ -132,6 +137,49 @@ inline bool mulmod(const U256& a, const U256& b, const U256& p, U256* q, U256* r
     for (int k = 8; k < 16; k++) fits = fits && quo[k] == 0;
     for (int k = 0; k < 8; k++) q->w[k] = quo[k], r->w[k] = rem[k];
     return fits;
+}
+
+// (q, r) with a + b = q P + r (OP_ADD) or a - b + q P = r (OP_SUB; needs |a - b| < P), r < P; false if there is no such pair
+inline bool addsubmod(uint32_t op, const U256& a, const U256& b, const U256& p, U256* q, U256* r) {
+    uint32_t num[9] = {};
+    *q = U256{};
+    auto ge = [&](const uint32_t* x) {   // x (9 words) >= p
+        if (x[8]) return true;
+        for (int k = 7; k >= 0; k--)
+            if (x[k] != p.w[k]) return x[k] > p.w[k];
+        return true;
+    };
+    auto sub_p = [&](uint32_t* x) {
+        uint64_t br = 0;
+        for (int k = 0; k < 9; k++) {
+            const uint64_t d = (uint64_t)x[k] - (k < 8 ? p.w[k] : 0u) - br;
+            x[k] = (uint32_t)d, br = (d >> 32) & 1u;
+        }
+    };
+    if (op == OP_ADD) {
+        uint64_t c = 0;
+        for (int k = 0; k < 8; k++) c += (uint64_t)a.w[k] + b.w[k], num[k] = (uint32_t)c, c >>= 32;
+        num[8] = (uint32_t)c;
+        while (ge(num)) {
+            sub_p(num);
+            if (++q->w[0] == 0) return false;
+        }
+    } else {
+        uint64_t br = 0;
+        for (int k = 0; k < 8; k++) {
+            const uint64_t d = (uint64_t)a.w[k] - b.w[k] - br;
+            num[k] = (uint32_t)d, br = (d >> 32) & 1u;
+        }
+        if (br) {   // a < b: one P brings the difference back (if it does not, the operands are too far apart)
+            uint64_t c = 0;
+            for (int k = 0; k < 8; k++) c += (uint64_t)num[k] + p.w[k], num[k] = (uint32_t)c, c >>= 32;
+            if (!c) return false;
+            q->w[0] = 1;
+        }
+        if (ge(num)) return false;
+    }
+    for (int k = 0; k < 8; k++) r->w[k] = num[k];
+    return true;
 }
 
 }  // namespace modular

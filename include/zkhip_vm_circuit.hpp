@@ -18,8 +18,8 @@
 //                  OpenVM's keccak extension, crates/circuits/chunk-circuit/openvm.toml).
 //                  sha256 (a7 = 4: the SHA-256 compression function on the 24 words at a0 -- eight state words, then the sixteen message
 //                  words of a block; the state is replaced by compress(state, block); OpenVM's sha256 extension).
-//                  modmul (a7 = 5: r = a b mod P_i on the 24 words at a0 -- a, b, then the result's slot; a1 = i, the index of one
-//                  of the moduli the app's openvm.toml lists; OpenVM's modular extension).
+//                  modular (a7 = 5: r = a b, a + b or a - b mod P_i on the 24 words at a0 -- a, b, then the result's slot; a1 = i + 8 op:
+//                  i the index of one of the moduli the app's openvm.toml lists, op 0 mul, 1 add, 2 sub; OpenVM's modular extension).
 //                  int256 (a7 = 6: a = b op c on the 24 words at a0 -- b, c, then the result's slot; a1 = op: 0 add, 1 sub, 2 xor, 3 or,
 //                  4 and, 5 mul; 256-bit words, arithmetic modulo 2^256; OpenVM's bigint extension).
 //   int256 adapter one row per WORD of a call (24 rows): b, c read, a written; (timestamp, index, halves, opcode) goes to the 256-bit ALU
@@ -70,7 +70,7 @@ constexpr uint32_t TS_STEP = 16;   // timestamps per instruction: rs1 at +0; rs2
 constexpr uint32_t BLOCK_CELLS = 8, BLOCK_WORDS = 4, LABEL_BITS = 26, LEAF_LEVEL = LABEL_BITS + 2;  // block label = as * 2^26 + (word >> 2); the tree has 28 levels above the blocks
 constexpr uint32_t GAP_HI_BITS = 11;  // a timestamp gap is gap_lo + 2^16 gap_hi with gap_hi below 2^11 (one range-tuple lookup (0, gap_hi))
 enum Cls : uint32_t { C_ALU, C_LT, C_MUL, C_MULH, C_DIVREM, C_SHIFT, C_BEQ, C_BLT, C_JAL_LUI, C_AUIPC, C_JALR, C_LS, C_ECALL, N_CLS };
-constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 32, LEAF_WIDTH = 43, MERKLE_WIDTH = 54, KECCAK_IO_WIDTH = 42, SHA_IO_WIDTH = 34, MODMUL_IO_WIDTH = 34, INT256_IO_WIDTH = 35,
+constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 32, LEAF_WIDTH = 43, MERKLE_WIDTH = 54, KECCAK_IO_WIDTH = 42, SHA_IO_WIDTH = 34, MODMUL_IO_WIDTH = 35, INT256_IO_WIDTH = 35,
                  CONNECTOR_WIDTH = 2;
 constexpr uint32_t P = air::P;
 
@@ -468,11 +468,11 @@ inline void sha256_io_air(AirBuilder& b) {
 }
 
 // modular adapter of modulus `index`: AirBuilder(MODMUL_IO_WIDTH, 0).  The sha256 adapter's columns: word[24] (0..7 a, 8..15 b: read;
-// 16..23 r: written) | ts | base | v_lo v_hi | n_lo n_hi | prev_ts gap_lo gap_hi | ok.
+// 16..23 r: written) | ts | base | v_lo v_hi | n_lo n_hi | prev_ts gap_lo gap_hi | ok | op (the call's operation: a1 = index + 8 op).
 inline void modmul_io_air(AirBuilder& b, uint32_t index) {
     Expr sel[24];
     for (int k = 0; k < 24; k++) sel[k] = b.var(k);
-    const Expr ts = b.var(24), base = b.var(25), v_lo = b.var(26), v_hi = b.var(27), n_lo = b.var(28), n_hi = b.var(29), ok = b.var(33);
+    const Expr ts = b.var(24), base = b.var(25), v_lo = b.var(26), v_hi = b.var(27), n_lo = b.var(28), n_hi = b.var(29), ok = b.var(33), op = b.var(34);
     Expr sum = sel[0], idx = b.constant(0), is_read = sel[0];
     for (int k = 1; k < 24; k++) {
         sum = sum + sel[k], idx = idx + sel[k] * k;
@@ -488,9 +488,10 @@ inline void modmul_io_air(AirBuilder& b, uint32_t index) {
     b.when_transition(cont * (b.var(25, 1) - base));
     b.assert_zero(is_read * (n_lo - v_lo));
     b.assert_zero(is_read * (n_hi - v_hi));
-    b.push_interaction(MODMUL_REQ_BUS, {ts, base, b.constant(index)}, sel[0], Kind::Receive);
+    b.when_transition(cont * (b.var(34, 1) - op));
+    b.push_interaction(MODMUL_REQ_BUS, {ts, base, op * 8 + (int64_t)index}, sel[0], Kind::Receive);
     word_access(b, ok, ok, b.constant(2), base + idx, v_lo, v_hi, n_lo, n_hi, ts + 5, b.var(30), b.var(31), b.var(32));
-    b.push_interaction(MODMUL_WORD_BUS + index, {ts, idx, n_lo, n_hi}, ok, Kind::Send);
+    b.push_interaction(MODMUL_WORD_BUS + index, {ts, idx, n_lo, n_hi, op}, ok, Kind::Send);
 }
 
 // int256 adapter: AirBuilder(INT256_IO_WIDTH, 0).  The modular adapter's columns (0..7 b, 8..15 c: read; 16..23 a: written) + op (the

@@ -148,7 +148,7 @@ struct SegmentRecords {
     std::vector<uint32_t> sha_blocks, sha_ts, shaio_rows;    // sha256 calls: 24 words (state, block) and the timestamp per call; the adapter's rows
     std::vector<uint32_t> i256_records, i256_ts, i256io_rows;   // int256 calls: op | b | c (17 words) and the timestamp per call; the adapter's rows
     std::vector<uint32_t> mul256_records, mul256_ts;            // ... those with opcode 5: the multiplication chip's
-    // modmul calls per modulus: a | b (16 words) and the timestamp per call; the adapter's rows
+    // modular calls per modulus: op | a | b (17 words) and the timestamp per call; the adapter's rows
     std::vector<uint32_t> mm_records[vmc::MAX_MODULI], mm_ts[vmc::MAX_MODULI], mmio_rows[vmc::MAX_MODULI];
     uint32_t pc_start = 0, pc_end = 0, ts_end = 0;
     Digest root_init{}, root_final{};
@@ -252,14 +252,14 @@ public:
                 throw Error("the guest calls the sha256 intrinsic but the app's openvm.toml does not enable the sha256 extension");
             if (d.cls == vmc::C_ECALL && m_.reg(17) == 6 && !caps_.int256())
                 throw Error("the guest calls the int256 intrinsic but the app's openvm.toml does not enable the bigint extension");
-            if (d.cls == vmc::C_ECALL && m_.reg(17) == 5 && m_.reg(11) >= caps_.moduli.size())
-                throw Error("the guest calls the modmul intrinsic for modulus " + std::to_string(m_.reg(11)) + " but the app's openvm.toml lists " +
+            if (d.cls == vmc::C_ECALL && m_.reg(17) == 5 && ((m_.reg(11) & 7u) >= caps_.moduli.size() || (m_.reg(11) >> 3) >= zkhip::modular::N_OPS))
+                throw Error("the guest calls the modular intrinsic for modulus " + std::to_string(m_.reg(11) & 7u) + " but the app's openvm.toml lists " +
                             std::to_string(caps_.moduli.size()) + " moduli");
             if (r.n_instr + 1 > caps_.rows(vmc::A_FRAME) || n_cls[d.cls] + 1 > caps_.rows(vmc::A_ALU + d.cls) ||
                 blk_.size() + new_blocks > caps_.rows(vmc::A_LEAF) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 3 && 24 * (r.n_keccak() + 1) > caps_.rows(vmc::A_KECCAK)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 4 && 65 * (r.n_sha256() + 1) > caps_.rows(vmc::A_SHA256)) ||
-                (d.cls == vmc::C_ECALL && m_.reg(17) == 5 && r.mm_ts[m_.reg(11)].size() + 1 > caps_.rows(vmc::A_MODMUL(m_.reg(11)))) ||
+                (d.cls == vmc::C_ECALL && m_.reg(17) == 5 && r.mm_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_MODMUL(m_.reg(11) & 7u))) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 6 && (m_.reg(11) == 5 ? r.mul256_ts.size() : r.i256_ts.size()) + 1 > caps_.rows(vmc::A_INT256)) ||
                 path_nodes_.size() + new_nodes > caps_.rows(vmc::A_MERKLE) ||
                 2 * (blk_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
@@ -359,16 +359,18 @@ public:
                     row[30] = 1, row[28] = (y & 255u) >> 2, row[17] = a1;
                     auto gap3 = [&](uint32_t* dst, uint32_t pts, uint32_t at) { dst[0] = pts, dst[1] = (at - pts - 1) & 0xffffu, dst[2] = (at - pts - 1) >> 16; };
                     gap3(row + 21, read_word(1, 11, a1, ts + 4), ts + 4);
-                    r.mm_ts[a1].push_back(ts);
-                    r.mm_records[a1].insert(r.mm_records[a1].end(), mm_in, mm_in + 16);
+                    const uint32_t mi = a1 & 7u, mop = a1 >> 3;
+                    r.mm_ts[mi].push_back(ts);
+                    r.mm_records[mi].push_back(mop);
+                    r.mm_records[mi].insert(r.mm_records[mi].end(), mm_in, mm_in + 16);
                     for (uint32_t k = 0; k < 24; k++) {   // the adapter's rows: a, b read, r written, all at ts + 5
                         uint32_t sr[vmc::MODMUL_IO_WIDTH] = {};
                         const uint32_t w = (y >> 2) + k, before = mm_in[k], after = mem_word(y + 4 * k);
-                        sr[k] = 1, sr[24] = ts, sr[25] = y >> 2, sr[33] = 1;
+                        sr[k] = 1, sr[24] = ts, sr[25] = y >> 2, sr[33] = 1, sr[34] = mop;
                         sr[26] = before & 0xffffu, sr[27] = before >> 16, sr[28] = after & 0xffffu, sr[29] = after >> 16;
                         const uint32_t pts = k >= 16 ? write_word(2, w, after, ts + 5) : read_word(2, w, before, ts + 5), gap = ts + 5 - pts - 1;
                         sr[30] = pts, sr[31] = gap & 0xffffu, sr[32] = gap >> 16;
-                        r.mmio_rows[a1].insert(r.mmio_rows[a1].end(), sr, sr + vmc::MODMUL_IO_WIDTH);
+                        r.mmio_rows[mi].insert(r.mmio_rows[mi].end(), sr, sr + vmc::MODMUL_IO_WIDTH);
                     }
                 }
                 if (x == 4) {

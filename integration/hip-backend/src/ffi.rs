@@ -16,7 +16,7 @@ pub const ZKHIP_DIGEST_WORDS: usize = 8;
 pub const ZKHIP_KECCAK_F_WIDTH: usize = 2633;
 pub const ZKHIP_INT256_ALU_WIDTH: usize = 101;
 pub const ZKHIP_INT256_MUL_WIDTH: usize = 161;
-pub const ZKHIP_MODMUL_WIDTH: usize = 286;
+pub const ZKHIP_MODMUL_WIDTH: usize = 288;
 pub const ZKHIP_SHA256_WIDTH: usize = 433;
 pub const ZKHIP_SHA256_PREP_WIDTH: usize = 6;
 pub const ZKHIP_SHA256_ROWS_PER_BLOCK: usize = 65;
@@ -364,6 +364,9 @@ extern "C" {
     pub fn zkhip_modmul_host(a: *const u32, b: *const u32, modulus: *const u32, q: *mut u32, r: *mut u32) -> c_int;
     pub fn zkhip_modmul_tracegen(ctx: *mut zkhip_ctx, modulus: *const u32, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
                                  d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    pub fn zkhip_modular_tracegen(ctx: *mut zkhip_ctx, modulus: *const u32, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
+                                  d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    pub fn zkhip_modular_host(op: u32, a: *const u32, b: *const u32, modulus: *const u32, q: *mut u32, r: *mut u32) -> c_int;
     pub fn zkhip_sha256_air(log_height: c_uint, out: *mut zkhip_air) -> c_int;
     pub fn zkhip_sha256_compress_host(state: *mut u32, block: *const u32) -> c_int;
     pub fn zkhip_sha256_tracegen(ctx: *mut zkhip_ctx, d_blocks: *const u32, n_blocks: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;

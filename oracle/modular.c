@@ -56,18 +56,53 @@ int ora_modmul(const uint8_t a[32], const uint8_t b[32], const uint8_t p[32], ui
     return 0;
 }
 
-/* trace: 286 columns x 2^log_height rows, column-major, canonical; records[64 i] = a bytes | b bytes; adds the rows' lookups to
- * bitwise_range[65536] (index 256 x + y) and tuple[256 * size_y] (index x * size_y + y); returns the number of bad records */
-size_t ora_modmul_trace(const uint8_t *records, size_t n, const uint8_t p[32], unsigned log_height, uint32_t *trace, uint32_t *bitwise_range, uint32_t *tuple,
-                        uint32_t size_y) {
+/* a + b = q p + r (op 1) or a - b + q p = r (op 2; q is 0 or 1), r < p, on bytes; returns 0 if such q, r exist */
+int ora_modaddsub(unsigned op, const uint8_t a[32], const uint8_t b[32], const uint8_t p[32], uint8_t q[32], uint8_t r[32]) {
+    uint8_t num[33] = {0};
+    memset(q, 0, 32);
+    int c = 0;
+    if (op == 1) {
+        for (int i = 0; i < 32; i++) c += a[i] + b[i], num[i] = (uint8_t)c, c >>= 8;
+        num[32] = (uint8_t)c;
+        while (ge33(num, p)) {
+            int br = 0;
+            for (int i = 0; i < 33; i++) {
+                const int v = (int)num[i] - (i < 32 ? p[i] : 0) - br;
+                num[i] = (uint8_t)(v & 255), br = v < 0;
+            }
+            q[0]++;
+        }
+    } else {
+        for (int i = 0; i < 32; i++) {
+            const int v = (int)a[i] - b[i] - c;
+            num[i] = (uint8_t)(v & 255), c = v < 0;
+        }
+        if (c) { /* negative: one p must bring it back */
+            int cc = 0;
+            for (int i = 0; i < 32; i++) cc += num[i] + p[i], num[i] = (uint8_t)cc, cc >>= 8;
+            if (!cc) return 1;
+            q[0] = 1;
+        }
+        if (ge33(num, p)) return 1;
+    }
+    memcpy(r, num, 32);
+    return 0;
+}
+
+/* trace: 288 columns x 2^log_height rows, column-major, canonical; records[64 i] = a bytes | b bytes, ops[i] = 0 mul, 1 add, 2 sub (NULL:
+ * all mul); adds the rows' lookups to bitwise_range[65536] (index 256 x + y) and tuple[256 * size_y] (index x * size_y + y); returns
+ * the number of bad records */
+size_t ora_modular_trace(const uint8_t *records, const uint32_t *ops, size_t n, const uint8_t p[32], unsigned log_height, uint32_t *trace, uint32_t *bitwise_range,
+                         uint32_t *tuple, uint32_t size_y) {
     const size_t N = (size_t)1 << log_height;
-    enum { A = 0, B = 32, Q = 64, R = 96, CX = 128, CY = 190, MARK = 252, DIFF = 284, REAL = 285, WIDTH = 286 };
+    enum { A = 0, B = 32, Q = 64, R = 96, CX = 128, CY = 190, MARK = 252, DIFF = 284, REAL = 285, IS_ADD = 286, IS_SUB = 287, WIDTH = 288 };
     memset(trace, 0, (size_t)WIDTH * N * sizeof(uint32_t));
     size_t bad = 0;
     for (size_t row = 0; row < n && row < N; row++) {
         const uint8_t *a = records + 64 * row, *b = a + 32;
+        const unsigned op = ops ? ops[row] : 0;
         uint8_t q[32], r[32];
-        if (ora_modmul(a, b, p, q, r)) bad++;
+        if (op > 2 || (op == 0 ? ora_modmul(a, b, p, q, r) : ora_modaddsub(op, a, b, p, q, r))) bad++;
 #define PUT(col, v) trace[(size_t)(col) * N + row] = (uint32_t)(v)
         for (int i = 0; i < 32; i++) PUT(A + i, a[i]), PUT(B + i, b[i]), PUT(Q + i, q[i]), PUT(R + i, r[i]);
         for (int i = 0; i < 32; i += 2)
@@ -78,8 +113,11 @@ size_t ora_modmul_trace(const uint8_t *records, size_t n, const uint8_t p[32], u
             for (int i = 0; i < 32; i++) {
                 const int j = k - i;
                 if (j < 0 || j >= 32) continue;
-                s += (long long)a[i] * b[j] - (long long)q[i] * p[j];
+                if (op == 0) s += (long long)a[i] * b[j];
+                s -= (op == 2 ? -1 : 1) * (long long)q[i] * p[j];
             }
+            if (k < 32 && op == 1) s += a[k] + b[k];
+            if (k < 32 && op == 2) s += a[k] - b[k];
             if (k < 32) s -= r[k];
             c = s >> 8; /* exact: a b = q p + r */
             if (k < 62) {
@@ -96,9 +134,13 @@ size_t ora_modmul_trace(const uint8_t *records, size_t n, const uint8_t p[32], u
             }
         if (mark >= 0) PUT(MARK + mark, 1);
         const unsigned diff = mark >= 0 ? (unsigned)(p[mark] - r[mark]) : 0;
-        PUT(DIFF, diff), PUT(REAL, 1);
+        PUT(DIFF, diff), PUT(REAL, 1), PUT(IS_ADD, op == 1), PUT(IS_SUB, op == 2);
         bitwise_range[256 * ((diff - 1) & 255)]++;
 #undef PUT
     }
     return bad;
+}
+size_t ora_modmul_trace(const uint8_t *records, size_t n, const uint8_t p[32], unsigned log_height, uint32_t *trace, uint32_t *bitwise_range, uint32_t *tuple,
+                        uint32_t size_y) {
+    return ora_modular_trace(records, 0, n, p, log_height, trace, bitwise_range, tuple, size_y);
 }

@@ -192,6 +192,9 @@ size_t ora_mul256_trace(const uint32_t *records, size_t stride, size_t off, size
                         uint32_t size_y);
 /* ---- modular multiplication (oracle/modular.c): r = a b mod P on bytes, the chip's trace ---- */
 int ora_modmul(const uint8_t a[32], const uint8_t b[32], const uint8_t p[32], uint8_t q[32], uint8_t r[32]);
+int ora_modaddsub(unsigned op, const uint8_t a[32], const uint8_t b[32], const uint8_t p[32], uint8_t q[32], uint8_t r[32]);
+size_t ora_modular_trace(const uint8_t *records, const uint32_t *ops, size_t n, const uint8_t p[32], unsigned log_height, uint32_t *trace, uint32_t *bitwise_range,
+                         uint32_t *tuple, uint32_t size_y);
 size_t ora_modmul_trace(const uint8_t *records, size_t n, const uint8_t p[32], unsigned log_height, uint32_t *trace, uint32_t *bitwise_range, uint32_t *tuple,
                         uint32_t size_y);
 

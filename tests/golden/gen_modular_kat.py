@@ -20,7 +20,7 @@ GY = 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8
 
 def main():
     rnd = random.Random(20260303)
-    out = {"about": "q, r = divmod(a * b, p) from Python integers (generator: tests/golden/gen_modular_kat.py)", "moduli": {}, "cases": [],
+    out = {"about": "q, r = divmod(a * b, p) from Python integers (generator: tests/golden/gen_modular_kat.py)", "moduli": {}, "cases": [], "addsub": [],
            "secp256k1_generator": {"x": hex(GX), "y": hex(GY)}}
     assert (GY * GY - GX * GX * GX - 7) % MODULI["secp256k1_p"] == 0
     for name, p in MODULI.items():
@@ -31,6 +31,13 @@ def main():
             q, r = divmod(a * b, p)
             assert q < 1 << 256
             out["cases"].append({"modulus": name, "a": hex(a), "b": hex(b), "q": hex(q), "r": hex(r)})
+        # addition (a + b = q p + r) and subtraction (a - b + q p = r with q in {0, 1}: reduced operands)
+        red = [(0, 0), (p - 1, p - 1), (p - 1, 1), (1, p - 1), (0, 1), (5, 5)] + [(rnd.randrange(p), rnd.randrange(p)) for _ in range(10)]
+        for a, b in red:
+            q, r = divmod(a + b, p)
+            out["addsub"].append({"modulus": name, "op": 1, "a": hex(a), "b": hex(b), "q": hex(q), "r": hex(r)})
+            r = (a - b) % p
+            out["addsub"].append({"modulus": name, "op": 2, "a": hex(a), "b": hex(b), "q": hex(0 if a >= b else 1), "r": hex(r)})
     with open(os.path.join(HERE, "modular_kat.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("wrote", len(out["cases"]), "cases")

@@ -315,10 +315,11 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                 mem[off + 64:off + 96] = a_.to_bytes(32, "little")
             elif call == 5:   # r = a b mod moduli[a1] on the 24 words at a0 (a | b | r, little-endian)
                 off = rr(10) - data_base
-                p_ = moduli[rr(11)]
-                assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem)
+                sel = rr(11)                 # a1 = modulus index + 8 * operation (0 mul, 1 add, 2 sub)
+                p_, mop = moduli[sel & 7], sel >> 3
+                assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem) and mop < 3
                 a_, b_ = int.from_bytes(mem[off:off + 32], "little"), int.from_bytes(mem[off + 32:off + 64], "little")
-                mem[off + 64:off + 96] = (a_ * b_ % p_).to_bytes(32, "little")
+                mem[off + 64:off + 96] = [a_ * b_ % p_, (a_ + b_) % p_, (a_ - b_) % p_][mop].to_bytes(32, "little")
             elif call == 4:   # SHA-256 compression on the 24 words at a0: state[8] <- compress(state, block[16])
                 off = rr(10) - data_base
                 assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem)

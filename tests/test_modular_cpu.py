@@ -42,6 +42,32 @@ def test_divmod_against_python_integers(ora, kat):
     assert y2 == (x3 + 7) % p and mu.ora_modmul(ora, gy, gy, p)[2] == y2
 
 
+def test_addition_and_subtraction(ora, kat):
+    """ModularAddSub in the multiplication chip's columns: the oracle's byte-wise add / sub and the product's host function against
+    Python's integers; a trace that mixes the three operations satisfies the AIR and balances both buses; a sub row relabelled add fails."""
+    mod = {k: int(v, 16) for k, v in kat["moduli"].items()}
+    for c in kat["addsub"]:
+        p, op, a, b, q, r = mod[c["modulus"]], c["op"], int(c["a"], 16), int(c["b"], 16), int(c["q"], 16), int(c["r"], 16)
+        assert (a + b == q * p + r) if op == 1 else (a - b + q * p == r) and r < p
+        assert mu.ora_addsub(ora, op, a, b, p) == (0, q, r) and z.modular_host(op, a, b, p) == (q, r)
+    p = mod["secp256k1_n"]
+    rows = [(c["op"], int(c["a"], 16), int(c["b"], 16)) for c in kat["addsub"] if c["modulus"] == "secp256k1_n"][:10]
+    rows += [(0, int(c["a"], 16), int(c["b"], 16)) for c in kat["cases"] if c["modulus"] == "secp256k1_n"][:4]
+    tr, bw, tup, bad = mu.ora_trace(ora, [(a, b) for _, a, b in rows], p, 4, ops=[o for o, _, _ in rows])
+    assert bad == 0
+    inst = mu.instance(p, tr, bw, tup, 4)
+    for d in inst:
+        assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == []
+    assert v2.bus_imbalance(inst) == {}
+    for row, (op, a, b) in enumerate(rows):
+        want = [a * b % p, (a + b) % p, (a - b) % p][op]
+        assert bytes(tr[96:128, row].astype(np.uint8)) == want.to_bytes(32, "little")
+    k = next(i for i, (op, a, b) in enumerate(rows) if op == 2 and a != b)
+    t2 = tr.copy()
+    t2[286, k], t2[287, k] = 1, 0
+    assert air.check_trace(inst[0]["program"], t2, mu.NOPV) != []
+
+
 @pytest.mark.parametrize("name", ["secp256k1_p", "bn254_r"])
 def test_trace_satisfies_the_air_and_the_buses_balance(ora, kat, name):
     p = int(kat["moduli"][name], 16)

@@ -23,7 +23,7 @@ MAX_MODULI = 8
 N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI   # the modular extension: chips N_STATIC_AIRS + 2 i (multiplication), + 2 i + 1 (adapter) of modulus i
 PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 32, 43, 54, 42, 2634
 SHA_IO_WIDTH, SHA_WIDTH = 34, 434
-MODMUL_IO_WIDTH, MODMUL_WIDTH = 34, 287
+MODMUL_IO_WIDTH, MODMUL_WIDTH = 35, 289
 INT256_IO_WIDTH, INT256_WIDTH, MUL256_WIDTH = 35, 102, 162
 TS_STEP, GAP_HI_BITS = 16, 11
 SX, SY = 256, 2048
@@ -229,16 +229,18 @@ def modmul_traces(rec, H, i, p):
     """modmul calls of modulus i: the oracle's chip trace (and its lookup counts) + the call's timestamp; the adapter's rows"""
     n = len(rec["mm_ts_%d" % i])
     l = ora.lib()
-    l.ora_modmul_trace.restype = C.c_size_t
-    l.ora_modmul_trace.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8), C.c_uint, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
-                                   C.POINTER(C.c_uint32), C.c_uint32]
+    l.ora_modular_trace.restype = C.c_size_t
+    l.ora_modular_trace.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint8), C.c_uint, C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32]
     lh = H[A_MODMUL(i)]
     body = np.zeros((MODMUL_WIDTH - 1, 1 << lh), np.uint32)
     bw, tup = np.zeros(1 << 16, np.uint32), np.zeros(SX * SY, np.uint32)
-    recs = np.ascontiguousarray(rec["mm_records_%d" % i], dtype=np.uint32).view(np.uint8)
+    all_words = np.ascontiguousarray(rec["mm_records_%d" % i], dtype=np.uint32).reshape(-1, 17)   # op | a | b
+    ops = np.ascontiguousarray(all_words[:, 0])
+    recs = np.ascontiguousarray(all_words[:, 1:]).view(np.uint8)
     pb = np.frombuffer(int(p).to_bytes(32, "little"), dtype=np.uint8).copy()
-    bad = l.ora_modmul_trace(recs.ctypes.data_as(C.POINTER(C.c_uint8)) if n else None, n, pb.ctypes.data_as(C.POINTER(C.c_uint8)), lh, ora.p32(body), ora.p32(bw),
-                             ora.p32(tup), SY)
+    bad = l.ora_modular_trace(recs.ctypes.data_as(C.POINTER(C.c_uint8)) if n else None, ora.p32(ops) if n else None, n, pb.ctypes.data_as(C.POINTER(C.c_uint8)), lh,
+                              ora.p32(body), ora.p32(bw), ora.p32(tup), SY)
     assert bad == 0
     tr = np.zeros((MODMUL_WIDTH, 1 << lh), np.uint32)
     tr[:MODMUL_WIDTH - 1] = body

@@ -23,6 +23,7 @@ from ._binding import (  # noqa: F401
     int256_mul_air,
     modmul_air,
     modmul_host,
+    modular_host,
     vm_modmul_air,
     sha256_air,
     sha256_compress_host,

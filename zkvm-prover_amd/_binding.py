@@ -179,6 +179,8 @@ def load_library():
         "zkhip_modmul_air": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
         "zkhip_modmul_host": (C.c_int, [u32p, u32p, u32p, u32p, u32p]),
         "zkhip_modmul_tracegen": (C.c_int, [vp, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
+        "zkhip_modular_tracegen": (C.c_int, [vp, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
+        "zkhip_modular_host": (C.c_int, [C.c_uint32, u32p, u32p, u32p, u32p, u32p]),
         "zkhip_sha256_air": (C.c_int, [C.c_uint, C.POINTER(_Air)]),
         "zkhip_sha256_compress_host": (C.c_int, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "zkhip_sha256_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
@@ -623,7 +625,7 @@ class Context:
         return out
 
     def vm_modmul_tracegen(self, modulus, t_records, t_ts, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
-        out = self._new(287 << log_height)
+        out = self._new(289 << log_height)
         m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
         self._check(self.lib.zkhip_vm_modmul_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height,
                                                       out.data_ptr(), t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
@@ -657,6 +659,14 @@ class Context:
         self._check(self.lib.zkhip_keccak_f_tracegen(self.h, t_states.data_ptr() if n_perms else None, n_perms, log_height, out.data_ptr()))
         return out
 
+    def modular_tracegen(self, modulus, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
+        """records: n x 17 words (op | a | b; op 0 mul, 1 add, 2 sub)"""
+        out = self._new(288 << log_height)
+        m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
+        self._check(self.lib.zkhip_modular_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr(),
+                                                    t_tuple_counts.data_ptr(), size_x, size_y))
+        return out
+
     def int256_alu_tracegen(self, t_records, n, log_height, t_bitwise_trace):
         out = self._new(101 << log_height)
         self._check(self.lib.zkhip_int256_alu_tracegen(self.h, t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr()))
@@ -681,7 +691,7 @@ class Context:
         return out
 
     def modmul_tracegen(self, modulus, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
-        out = self._new(286 << log_height)
+        out = self._new(288 << log_height)
         m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
         self._check(self.lib.zkhip_modmul_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr(),
                                                    t_tuple_counts.data_ptr(), size_x, size_y))
@@ -1014,6 +1024,14 @@ def modmul_host(a, b, modulus):
     q, r = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
     rc = load_library().zkhip_modmul_host(_u32p(wa), _u32p(wb), _u32p(wm), _u32p(q), _u32p(r))
     assert rc == 0
+    return sum(int(x) << (32 * i) for i, x in enumerate(q)), sum(int(x) << (32 * i) for i, x in enumerate(r))
+
+
+def modular_host(op, a, b, modulus):
+    """(q, r) of a * b = q P + r (op 0), a + b = q P + r (1), a - b + q P = r (2) through the library's host function"""
+    wa, wb, wm = (np.array(_int_words(v), dtype=np.uint32) for v in (a, b, modulus))
+    q, r = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
+    assert load_library().zkhip_modular_host(op, _u32p(wa), _u32p(wb), _u32p(wm), _u32p(q), _u32p(r)) == 0
     return sum(int(x) << (32 * i) for i, x in enumerate(q)), sum(int(x) << (32 * i) for i, x in enumerate(r))
 
 

@@ -1,6 +1,6 @@
 // modular.hip -- the modular-multiplication chip on the device (include/zkhip_modular.hpp: r = a b mod P on byte limbs, one multiplication
-// per row, 286 columns).  Record = a[8] | b[8] (little-endian 32-bit words).  One lane per row: schoolbook product, binary long division
-// by the modulus (512 shift-compare-subtract steps on nine words: ~20 k integer operations next to 286 stores and 127 table increments),
+// per row, 288 columns).  Record = a[8] | b[8] (little-endian 32-bit words; with an operation word in front for the form that also adds and subtracts).  One lane per row: schoolbook product, binary long division
+// by the modulus (512 shift-compare-subtract steps on nine words: ~20 k integer operations next to 288 stores and 127 table increments),
 // then the carries of the limb equations; the row's lookups (65 byte pairs, 62 carry tuples) are counted into the bitwise and range-tuple
 // tables in the same pass (wave-merged atomics, csrc/hist.hpp).  Replaces the trace generation of OpenVM's ModularMulDiv chip
 // (openvm-algebra-circuit, un-vendored).
@@ -29,7 +29,7 @@ __global__ void k_mod_repr(uint32_t* c, size_t n, int to_m) {
     if (i < n) c[i] = to_m ? to_monty(c[i] % P) : from_monty(c[i]);
 }
 
-__global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict__ recs, size_t n, size_t N, ModWords pm, uint32_t* __restrict__ trace,
+__global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict__ recs, size_t rec_stride, size_t n, size_t N, ModWords pm, uint32_t* __restrict__ trace,
                                                       uint32_t* __restrict__ bitwise_range, uint32_t* __restrict__ tuple, uint32_t tuple_y,
                                                       uint32_t* __restrict__ bad) {
     const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -39,17 +39,39 @@ __global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict
         return;
     }
     uint32_t a[8], b[8], prod[16], rem[9], quo[8];
+    const size_t ro = rec_stride * row + (rec_stride - 16);
+    const uint32_t op = rec_stride == 17 ? recs[rec_stride * row] : 0u;   // 0 mul, 1 add, 2 sub
+    if (op >= md::N_OPS) atomicAdd(bad, 1u);
 #pragma unroll
-    for (int i = 0; i < 8; i++) a[i] = recs[16 * row + i], b[i] = recs[16 * row + 8 + i];
+    for (int i = 0; i < 8; i++) a[i] = recs[ro + i], b[i] = recs[ro + 8 + i];
 #pragma unroll
     for (int i = 0; i < 16; i++) prod[i] = 0;
-    for (int i = 0; i < 8; i++) {
+    bool sub_wrapped = false;
+    if (op == md::OP_ADD) {
         uint64_t c = 0;
-        for (int j = 0; j < 8; j++) {
-            c += (uint64_t)a[i] * b[j] + prod[i + j];
-            prod[i + j] = (uint32_t)c, c >>= 32;
+        for (int i = 0; i < 8; i++) c += (uint64_t)a[i] + b[i], prod[i] = (uint32_t)c, c >>= 32;
+        prod[8] = (uint32_t)c;
+    } else if (op == md::OP_SUB) {   // a - b, plus one P if that is negative: the numerator is then below P (or the record is refused)
+        uint32_t br = 0;
+        for (int i = 0; i < 8; i++) {
+            const uint64_t d = (uint64_t)a[i] - b[i] - br;
+            prod[i] = (uint32_t)d, br = (uint32_t)(d >> 32) & 1u;
         }
-        prod[i + 8] = (uint32_t)c;
+        if (br) {
+            uint64_t c = 0;
+            for (int i = 0; i < 8; i++) c += (uint64_t)prod[i] + pm.w[i], prod[i] = (uint32_t)c, c >>= 32;
+            if (!c) atomicAdd(bad, 1u);
+            sub_wrapped = true;
+        }
+    } else {
+        for (int i = 0; i < 8; i++) {
+            uint64_t c = 0;
+            for (int j = 0; j < 8; j++) {
+                c += (uint64_t)a[i] * b[j] + prod[i + j];
+                prod[i + j] = (uint32_t)c, c >>= 32;
+            }
+            prod[i + 8] = (uint32_t)c;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 9; i++) rem[i] = 0;
@@ -79,6 +101,12 @@ __global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict
         }
     }
     if (overflow) atomicAdd(bad, 1u);   // the quotient does not fit 256 bits: operands far above the modulus
+    if (op == md::OP_SUB) {             // a - b + q P = r: q is 0 or 1 and the numerator was already reduced
+        bool any = false;
+        for (int i = 0; i < 8; i++) any = any || quo[i];
+        if (any) atomicAdd(bad, 1u);    // |a - b| >= P
+        quo[0] = sub_wrapped ? 1u : 0u;
+    }
     auto byte_of = [](const uint32_t* w, int i) -> uint32_t { return (w[i >> 2] >> (8 * (i & 3))) & 255u; };
     auto put = [&](size_t col, uint32_t v) { trace[col * N + row] = to_monty(v); };
     for (int i = 0; i < 32; i++) {
@@ -90,13 +118,17 @@ __global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict
     }
     // carries of the limb equations: position k of a b - q P - r, plus the carry in, is 256 times the carry out
     int64_t c = 0;
+    const int64_t q_sign = op == md::OP_SUB ? -1 : 1;
     for (int k = 0; k <= (int)md::N_CARRY; k++) {
         int64_t s = c;
         for (int i = 0; i < 32; i++) {
             const int j = k - i;
             if (j < 0 || j >= 32) continue;
-            s += (int64_t)byte_of(a, i) * byte_of(b, j) - (int64_t)byte_of(quo, i) * byte_of(pm.w, j);
+            if (op == md::OP_MUL) s += (int64_t)byte_of(a, i) * byte_of(b, j);
+            s -= q_sign * (int64_t)byte_of(quo, i) * byte_of(pm.w, j);
         }
+        if (k < 32 && op == md::OP_ADD) s += (int64_t)byte_of(a, k) + byte_of(b, k);
+        if (k < 32 && op == md::OP_SUB) s += (int64_t)byte_of(a, k) - byte_of(b, k);
         if (k < 32) s -= byte_of(rem, k);
         if ((s & 255) != 0 && !overflow) atomicAdd(bad, 1u);   // (cannot happen: a b = q P + r)
         c = s >> 8;
@@ -119,7 +151,7 @@ __global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict
         }
     for (int i = 0; i < 32; i++) put(md::COL_MARK + i, i == mark ? 1u : 0u);
     const uint32_t diff = mark >= 0 ? byte_of(pm.w, mark) - byte_of(rem, mark) : 0u;
-    put(md::COL_DIFF, diff), put(md::COL_REAL, 1u);
+    put(md::COL_DIFF, diff), put(md::COL_REAL, 1u), put(md::COL_IS_ADD, op == md::OP_ADD ? 1u : 0u), put(md::COL_IS_SUB, op == md::OP_SUB ? 1u : 0u);
     hist_add(bitwise_range, ((diff - 1u) & 255u) * 256);
 }
 
@@ -175,8 +207,8 @@ int zkhip_modmul_host(const uint32_t a[8], const uint32_t b[8], const uint32_t m
     return fits ? ZKHIP_OK : ZKHIP_ERR_INVALID;
 }
 
-int zkhip_modmul_tracegen(zkhip_ctx* ctx, const uint32_t modulus[8], const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace,
-                          uint32_t* d_bitwise_trace, uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y) {
+static int modular_tracegen(zkhip_ctx* ctx, const uint32_t modulus[8], const uint32_t* d_records, size_t rec_stride, size_t n, unsigned log_height, uint32_t* d_trace,
+                            uint32_t* d_bitwise_trace, uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y) {
     ZK_BIND_DEVICE(ctx);
     if (!ctx || !modulus || !d_trace || !d_bitwise_trace || !d_tuple_counts || log_height > 24 || (n && !d_records)) return ZKHIP_ERR_INVALID;
     const size_t N = (size_t)1 << log_height, T = (size_t)size_x * size_y;
@@ -191,19 +223,41 @@ int zkhip_modmul_tracegen(zkhip_ctx* ctx, const uint32_t modulus[8], const uint3
     const unsigned tb = (unsigned)((T + 255) / 256), bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
     hipLaunchKernelGGL(k_mod_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
     hipLaunchKernelGGL(k_mod_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);   // the range column of the 8-bit table
-    hipLaunchKernelGGL(k_modmul_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, n, N, pm, d_trace, d_bitwise_trace, d_tuple_counts, size_y,
-                       (uint32_t*)flag);
+    hipLaunchKernelGGL(k_modmul_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, rec_stride, n, N, pm, d_trace, d_bitwise_trace,
+                       d_tuple_counts, size_y, (uint32_t*)flag);
     hipLaunchKernelGGL(k_mod_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
     hipLaunchKernelGGL(k_mod_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
-    return tracegen_finish(ctx, flag, "modmul_tracegen (a quotient beyond 256 bits: operands far above the modulus)");
+    return tracegen_finish(ctx, flag, "modular tracegen (a quotient beyond 256 bits, operands of a subtraction further apart than the modulus, or an unknown operation)");
+}
+
+int zkhip_modmul_tracegen(zkhip_ctx* ctx, const uint32_t modulus[8], const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace,
+                          uint32_t* d_bitwise_trace, uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y) {
+    return modular_tracegen(ctx, modulus, d_records, 16, n, log_height, d_trace, d_bitwise_trace, d_tuple_counts, size_x, size_y);
+}
+
+int zkhip_modular_tracegen(zkhip_ctx* ctx, const uint32_t modulus[8], const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace,
+                           uint32_t* d_bitwise_trace, uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y) {
+    return modular_tracegen(ctx, modulus, d_records, 17, n, log_height, d_trace, d_bitwise_trace, d_tuple_counts, size_x, size_y);
+}
+
+int zkhip_modular_host(uint32_t op, const uint32_t a[8], const uint32_t b[8], const uint32_t modulus[8], uint32_t q[8], uint32_t r[8]) {
+    if (op == md::OP_MUL) return zkhip_modmul_host(a, b, modulus, q, r);
+    if (!a || !b || !modulus || !q || !r || op >= md::N_OPS) return ZKHIP_ERR_INVALID;
+    md::U256 A, B, M, Q, R;
+    memcpy(A.w, a, 32), memcpy(B.w, b, 32), memcpy(M.w, modulus, 32);
+    bool zero = true;
+    for (uint32_t v : M.w) zero = zero && v == 0;
+    if (zero || !md::addsubmod(op, A, B, M, &Q, &R)) return ZKHIP_ERR_INVALID;
+    memcpy(q, Q.w, 32), memcpy(r, R.w, 32);
+    return ZKHIP_OK;
 }
 
 int zkhip_vm_modmul_tracegen(zkhip_ctx* ctx, const uint32_t modulus[8], const uint32_t* d_records, const uint32_t* d_ts, size_t n, unsigned log_height,
                              uint32_t* d_trace, uint32_t* d_bitwise_trace, uint32_t* d_tuple_counts, uint32_t size_x, uint32_t size_y) {
     ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_trace || (n && !d_ts)) return ZKHIP_ERR_INVALID;
-    ZK_TRY(zkhip_modmul_tracegen(ctx, modulus, d_records, n, log_height, d_trace, d_bitwise_trace, d_tuple_counts, size_x, size_y));
+    ZK_TRY(zkhip_modular_tracegen(ctx, modulus, d_records, n, log_height, d_trace, d_bitwise_trace, d_tuple_counts, size_x, size_y));   // 17-word records
     const size_t N = (size_t)1 << log_height;
     KernelScope ks(ctx, "vm_modmul_timestamps");
     hipLaunchKernelGGL(k_modmul_ts, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_ts, n, N, d_trace + (size_t)md::COL_TS * N);
