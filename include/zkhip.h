@@ -597,6 +597,12 @@ int zkhip_vm_sha256_prep(unsigned log_height, uint32_t *out);
 int zkhip_vm_modmul_air(const uint8_t modulus[32], unsigned index, int adapter, zkhip_air *out);
 int zkhip_vm_modmul_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height,
                              uint32_t *d_trace, uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+/* The two chips of curve `index` (< 4) of an app with the ecc extension: adapter == 0 the point chip inside the VM (773 columns:
+ * zkhip_ec_air + a timestamp column + the 48 word receives), adapter != 0 its adapter; zkhip_vm_ec_tracegen = zkhip_ec_tracegen + the
+ * timestamp of call i on row i. */
+int zkhip_vm_ec_air(const uint8_t modulus[32], const uint8_t a[32], unsigned index, int adapter, zkhip_air *out);
+int zkhip_vm_ec_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t a[8], const uint32_t *d_records, const uint32_t *d_ts, size_t n,
+                         unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
 /* Poseidon2 chip serving the hash bus (299 columns): zkhip_poseidon2_air_tracegen + multiplicity 1 on the first n rows. */
 int zkhip_vm_poseidon2_tracegen(zkhip_ctx *ctx, const uint32_t *d_inputs, size_t n, unsigned log_height, uint32_t *d_trace);
 /* n rows of `width` canonical words (row-major, device) -> column-major Montgomery trace of 2^log_height rows; the other rows get
@@ -649,6 +655,27 @@ int zkhip_modmul_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint3
 int zkhip_modular_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace,
                            uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
 int zkhip_modular_host(uint32_t op, const uint32_t a[8], const uint32_t b[8], const uint32_t modulus[8], uint32_t q[8], uint32_t r[8]);
+
+/* ---- elliptic-curve chip (include/zkhip_ecc.hpp: short-Weierstrass chord addition (x1 != x2) and tangent doubling over a 256-bit prime on
+ *      byte limbs, one point operation per row, 772 columns, degree 3: three limb identities with signed 33-byte quotients, byte pairs
+ *      looked up in the 8-bit bitwise table, carries in the range-tuple table (256 x 2048), x3 and y3 canonical;
+ *      crates/circuits/chunk-circuit/openvm.toml:38-59 lists `ecc.supported_curves` secp256k1, P-256, bn254 G1; OpenVM's chips are
+ *      openvm-ecc-circuit's EcAddNe / EcDouble, un-vendored).  Pinned to Python's integers and the published multiples of the
+ *      secp256k1 generator (tests/golden/ecc_kat.json). ---- */
+#define ZKHIP_EC_WIDTH 772
+#define ZKHIP_EC_RECORD_WORDS 41
+/* the AIR for one curve (modulus and coefficient a as 32 little-endian bytes; modulus odd, top byte non-zero) sending on the given
+ * buses; pointers valid for the life of the process */
+int zkhip_ec_air(const uint8_t modulus[32], const uint8_t a[32], uint32_t bitwise_bus, uint32_t tuple_bus, zkhip_air *out);
+/* one operation on the host (op 0: (x3, y3) = (x1, y1) + (x2, y2) with x1 != x2; op 1: the double of (x1, y1), y1 != 0): the slope and
+ * the result, little-endian words; ZKHIP_ERR_INVALID if an operand is not reduced or the slope does not exist */
+int zkhip_ec_host(uint32_t op, const uint32_t modulus[8], const uint32_t a[8], const uint32_t x1[8], const uint32_t y1[8], const uint32_t x2[8],
+                  const uint32_t y2[8], uint32_t slope[8], uint32_t x3[8], uint32_t y3[8]);
+/* d_records: n x 41 words (op | x1 y1 x2 y2 | slope, plain integers); fills 2^log_height rows and adds the rows' lookups to the bitwise
+ * table's range column (d_bitwise_trace, 8-bit table) and to the range-tuple table d_tuple_counts (size_x >= 256, size_y >= 2048);
+ * an error if a record's slope does not solve its identity */
+int zkhip_ec_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t a[8], const uint32_t *d_records, size_t n, unsigned log_height,
+                      uint32_t *d_trace, uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
 
 /* ---- 256-bit ALU chip (include/zkhip_int256.hpp: a = b op c on 32 byte limbs, op = 0 add, 1 sub, 2 xor, 3 or, 4 and, one operation per
  *      row, 101 columns, degree 3; 32 lookups per row in the 8-bit bitwise table; crates/circuits/chunk-circuit/openvm.toml:16-17 enables

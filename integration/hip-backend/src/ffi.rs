@@ -17,6 +17,8 @@ pub const ZKHIP_KECCAK_F_WIDTH: usize = 2633;
 pub const ZKHIP_INT256_ALU_WIDTH: usize = 101;
 pub const ZKHIP_INT256_MUL_WIDTH: usize = 161;
 pub const ZKHIP_MODMUL_WIDTH: usize = 288;
+pub const ZKHIP_EC_WIDTH: usize = 772;
+pub const ZKHIP_EC_RECORD_WORDS: usize = 41;
 pub const ZKHIP_SHA256_WIDTH: usize = 433;
 pub const ZKHIP_SHA256_PREP_WIDTH: usize = 6;
 pub const ZKHIP_SHA256_ROWS_PER_BLOCK: usize = 65;
@@ -360,6 +362,14 @@ extern "C" {
                                      d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
     pub fn zkhip_vm_mul256_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
                                     d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    pub fn zkhip_ec_air(modulus: *const u8, a: *const u8, bitwise_bus: u32, tuple_bus: u32, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_ec_host(op: u32, modulus: *const u32, a: *const u32, x1: *const u32, y1: *const u32, x2: *const u32, y2: *const u32, slope: *mut u32,
+                         x3: *mut u32, y3: *mut u32) -> c_int;
+    pub fn zkhip_ec_tracegen(ctx: *mut zkhip_ctx, modulus: *const u32, a: *const u32, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
+                             d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    pub fn zkhip_vm_ec_air(modulus: *const u8, a: *const u8, index: c_uint, adapter: c_int, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_vm_ec_tracegen(ctx: *mut zkhip_ctx, modulus: *const u32, a: *const u32, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint,
+                                d_trace: *mut u32, d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
     pub fn zkhip_modmul_air(modulus: *const u8, bitwise_bus: u32, tuple_bus: u32, out: *mut zkhip_air) -> c_int;
     pub fn zkhip_modmul_host(a: *const u32, b: *const u32, modulus: *const u32, q: *mut u32, r: *mut u32) -> c_int;
     pub fn zkhip_modmul_tracegen(ctx: *mut zkhip_ctx, modulus: *const u32, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,

@@ -21,6 +21,9 @@ from ._binding import (  # noqa: F401
     int256_alu_air,
     int256_alu_host,
     int256_mul_air,
+    ec_air,
+    ec_host,
+    vm_ec_air,
     modmul_air,
     modmul_host,
     modular_host,

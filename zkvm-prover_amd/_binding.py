@@ -196,6 +196,11 @@ def load_library():
         "zkhip_vm_modmul_air": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint, C.c_int, C.POINTER(_Air)]),
         "zkhip_vm_modmul_tracegen": (C.c_int, [vp, u32p, vp, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_vm_sha256_prep": (C.c_int, [C.c_uint, u32p]),
+        "zkhip_ec_air": (C.c_int, [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
+        "zkhip_ec_host": (C.c_int, [C.c_uint32] + [u32p] * 9),
+        "zkhip_ec_tracegen": (C.c_int, [vp, u32p, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
+        "zkhip_vm_ec_air": (C.c_int, [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_uint, C.c_int, C.POINTER(_Air)]),
+        "zkhip_vm_ec_tracegen": (C.c_int, [vp, u32p, u32p, vp, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_rows_tracegen": (C.c_int, [vp, vp, sz, sz, C.c_uint, vp, u32p]),
         "zkhip_range_counts_scaled_tracegen": (C.c_int, [vp, vp, sz, C.c_uint32, C.c_uint, vp, C.c_int]),
         "zkhip_recursion_build": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, sz, C.POINTER(_RecursionStmt), C.POINTER(vp)]),
@@ -690,6 +695,18 @@ class Context:
                                                       t_bitwise_trace.data_ptr()))
         return out
 
+    def ec_tracegen(self, modulus, coeff_a, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y, t_ts=None):
+        """records: n x 41 words (op | x1 y1 x2 y2 | slope); t_ts: the VM chip (773 columns: + the calls' timestamps)"""
+        out = self._new((772 if t_ts is None else 773) << log_height)
+        m, ca = (np.ascontiguousarray(_int_words(v), dtype=np.uint32) for v in (modulus, coeff_a))
+        if t_ts is None:
+            self._check(self.lib.zkhip_ec_tracegen(self.h, _u32p(m), _u32p(ca), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(),
+                                                   t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
+        else:
+            self._check(self.lib.zkhip_vm_ec_tracegen(self.h, _u32p(m), _u32p(ca), t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height,
+                                                      out.data_ptr(), t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
+        return out
+
     def modmul_tracegen(self, modulus, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
         out = self._new(288 << log_height)
         m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
@@ -1016,6 +1033,35 @@ def vm_modmul_air(modulus, index, adapter):
     m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
     assert lib.zkhip_vm_modmul_air(m, index, 1 if adapter else 0, C.byref(a)) == 0
     return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
+
+
+def ec_air(modulus, coeff_a, bitwise_bus, tuple_bus):
+    """The elliptic-curve chip's AIR for the curve y^2 = x^3 + a x + b over `modulus`: (program, width); its one definition is include/zkhip_ecc.hpp."""
+    lib = load_library()
+    a = _Air()
+    m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
+    ca = (C.c_uint8 * 32)(*int(coeff_a).to_bytes(32, "little"))
+    assert lib.zkhip_ec_air(m, ca, bitwise_bus, tuple_bus, C.byref(a)) == 0
+    return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
+
+
+def vm_ec_air(modulus, coeff_a, index, adapter):
+    """(program, width) of the VM's point chip (adapter False) or adapter chip (True) of curve `index`"""
+    lib = load_library()
+    a = _Air()
+    m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
+    ca = (C.c_uint8 * 32)(*int(coeff_a).to_bytes(32, "little"))
+    assert lib.zkhip_vm_ec_air(m, ca, index, 1 if adapter else 0, C.byref(a)) == 0
+    return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
+
+
+def ec_host(op, modulus, coeff_a, p1, p2):
+    """(slope, x3, y3) of p1 + p2 (op 0) or 2 p1 (op 1) through the library's host function (integers); None if it refuses the call"""
+    words = [np.array(_int_words(v), dtype=np.uint32) for v in (modulus, coeff_a, p1[0], p1[1], p2[0], p2[1])]
+    out = [np.zeros(8, np.uint32) for _ in range(3)]
+    if load_library().zkhip_ec_host(op, *[_u32p(w) for w in words], *[_u32p(o) for o in out]) != 0:
+        return None
+    return tuple(sum(int(x) << (32 * i) for i, x in enumerate(o)) for o in out)
 
 
 def modmul_host(a, b, modulus):

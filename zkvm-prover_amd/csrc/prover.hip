@@ -1127,6 +1127,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         // can afford to compile every chip: ~1.5 s each)
         static const unsigned jit_log = getenv("ZKHIP_JIT_MIN_LOG_WORK") ? (unsigned)atoi(getenv("ZKHIP_JIT_MIN_LOG_WORK")) : 26u;
         const bool big = (double)((size_t)1 << (airs[a].log_height + pk->b)) * (double)A.n_instr >= (double)(1ull << std::min(jit_log, 62u));
+        std::string jit_msg = "not attempted";
         if ((big || !interp_ok || getenv("ZKHIP_FORCE_JIT")) && !getenv("ZKHIP_NO_JIT")) {
             std::string msg;
             std::vector<uint32_t> tab;
@@ -1150,11 +1151,12 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
                 A.jit_mod = nullptr;
                 A.jit_fn = nullptr;
                 ctx->last_error = "constraint JIT unavailable, using the interpreter kernel: " + msg;
+                jit_msg = msg;
             }
         }
         if (!interp_ok && !A.jit_fn) {
             zkhip_pk_destroy(ctx, pk);  // also unloads the modules of the AIRs already compiled
-            return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + ": " + interp_err + " (interpreter form; no compiled form available either)");
+            return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + ": " + interp_err + " (interpreter form; no compiled form available either: " + jit_msg + ")");
         }
         ao[a].code = bp.take(comp[a].code.size() * 4 + 16);
         ao[a].consts = bp.take(comp[a].consts.size() * 4);
