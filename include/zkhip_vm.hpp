@@ -26,6 +26,7 @@
 #include <string>
 #include <vector>
 
+#include "zkhip_ecc.hpp"
 #include "zkhip_int256.hpp"
 #include "zkhip_keccak.hpp"
 #include "zkhip_modular.hpp"
@@ -155,6 +156,8 @@ public:
     }
     void set_memory_log(bool on) { log_memory_ = on; }
     void set_moduli(const std::vector<zkhip::modular::U256>& m) { moduli_ = m; }   // the modular extension's moduli (ecall 5)
+    void set_curves(const std::vector<zkhip::ecc::Curve>& c) { curves_ = c; }       // the ecc extension's curves (ecall 7)
+    const zkhip::modular::U256& last_slope() const { return last_slope_; }          // of the last ecc call (the chip's record carries it)
     bool done() const { return done_; }
     uint32_t pc() const { return pc_; }
     uint32_t last_result() const { return last_val_; }   // the value the last instruction computed for rd (also when rd = x0)
@@ -172,6 +175,8 @@ private:
     uint32_t x_[32], pc_ = 0, exit_code_ = 0, last_val_ = 0;
     bool log_memory_ = true;
     std::vector<zkhip::modular::U256> moduli_;
+    std::vector<zkhip::ecc::Curve> curves_;
+    zkhip::modular::U256 last_slope_{};
     uint64_t instret_ = 0;
     size_t in_pos_ = 0;
     bool done_ = false;
@@ -470,6 +475,20 @@ private:
                     if (op == zkhip::int256::OP_MUL) zkhip::int256::mul256(b, c, a);
                     else zkhip::int256::alu256(op, b, c, a);
                     memcpy(p + 64, a, 32);
+                } else if (call == 7) {
+                    // (x3, y3) = (x1, y1) + (x2, y2) (op 0; x1 != x2) or 2 (x1, y1) (op 1) on the 48 words at a0 (x1 y1 | x2 y2 | x3 y3,
+                    // little-endian 256-bit words) on curve i of the app's openvm.toml, a1 = i + 8 op (OpenVM's ecc extension)
+                    if (rec && log_memory_) throw Error("the ecc intrinsic is proven by the one-statement flow only");
+                    const uint32_t addr = reg_read(rec, 10), sel = reg_read(rec, 11), which = sel & 7u, eop = sel >> 3;
+                    if (which >= curves_.size()) throw Error("ecc: the app's openvm.toml lists no curve " + std::to_string(which));
+                    if (eop >= zkhip::ecc::N_OPS) throw Error("ecc: unknown operation " + std::to_string(eop));
+                    if (addr & 3u) throw Error("ecc buffer must be word-aligned");
+                    uint8_t* p = at(addr, 192);
+                    zkhip::modular::U256 c[4], x3, y3;
+                    for (int k = 0; k < 4; k++) memcpy(c[k].w, p + 32 * k, 32);
+                    if (!zkhip::ecc::ec_op(eop, curves_[which], c[0], c[1], c[2], c[3], &last_slope_, &x3, &y3))
+                        throw Error("ecc: coordinates not reduced, or no slope (equal abscissae in an addition, y = 0 in a doubling)");
+                    memcpy(p + 128, x3.w, 32), memcpy(p + 160, y3.w, 32);
                 } else {
                     throw Error("unknown environment call " + std::to_string(call));
                 }
@@ -591,8 +610,10 @@ inline Exe parse_exe(const std::vector<uint8_t>& raw) {
 
 // crates/prover/src/utils/vm.rs:13-48.  `records`, when given, receives the per-chip execution records of the run that
 // produced the result (the metered run, or the fall-back run).
+// `moduli` / `curves`: the app's modular and ecc extensions (openvm.toml), for guests that call those intrinsics.
 inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64_t max_cost = 0, ExecRecords* records = nullptr,
-                                     uint64_t max_instr = 0) {
+                                     uint64_t max_instr = 0, const std::vector<zkhip::modular::U256>& moduli = {},
+                                     const std::vector<zkhip::ecc::Curve>& curves = {}) {
     auto all_zero = [](const std::vector<uint8_t>& v) {
         for (uint8_t b : v)
             if (b) return false;
@@ -603,6 +624,7 @@ inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64
     {
         *rec = ExecRecords();
         Machine m(exe, inputs);
+        m.set_moduli(moduli), m.set_curves(curves);
         bool finished = false;
         try {
             finished = m.run(max_instr, max_cost, rec);
@@ -618,6 +640,7 @@ inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64
     // the plain executor: no cost bound, and -- like the reference's -- no instruction count (u64::MAX as the sentinel)
     *rec = ExecRecords();
     Machine m(exe, inputs);
+    m.set_moduli(moduli), m.set_curves(curves);
     if (!m.run(max_instr, 0, rec)) throw Error("instruction limit reached");  // max_instr: a service-side bound, 0 = none
     if (m.exit_code()) throw Error("guest exited with code " + std::to_string(m.exit_code()));
     if (all_zero(m.public_values())) throw Error("public_values are all 0s upon execute");

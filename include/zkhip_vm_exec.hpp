@@ -90,6 +90,7 @@ struct SegmentCaps {
     bool sha256() const { return pos(vmc::A_SHA256) >= 0; }
     bool int256() const { return pos(vmc::A_INT256) >= 0; }
     std::vector<zkhip::modular::U256> moduli;   // the modular extension: chips A_MODMUL(i), A_MODMUL_IO(i) per modulus
+    std::vector<zkhip::ecc::Curve> curves;      // the ecc extension: chips A_EC(i), A_EC_IO(i) per curve
     // heights for segments of about 2^log_frame instructions of an ordinary instruction mix
     // log_keccak: 0 = the app has no keccak extension (22 chips); otherwise the rows of the Keccak-f chip (24 per permutation call,
     // at least 32).  A wide chip costs every segment proof and every leaf circuit its 2634 openings per query, used or not, so it is
@@ -97,8 +98,10 @@ struct SegmentCaps {
     // log_sha256: likewise for the SHA-256 compression chip (65 rows per block, at least 128; `[app_vm_config.sha256]`).
     // moduli / log_modmul: one multiplication chip (one call per row) + adapter (24 rows per call) per modulus of `[app_vm_config.modular]`.
     // log_int256: rows of the 256-bit ALU chip (one operation per row; `[app_vm_config.bigint]`), 0 = no bigint extension.
+    // curves / log_ec: one point chip (one call per row) + adapter (48 rows per call) per curve of `[[app_vm_config.ecc.supported_curves]]`.
     static SegmentCaps for_frame(unsigned log_frame, unsigned log_program, unsigned log_keccak = 0, unsigned log_sha256 = 0,
-                                 const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_modmul = 0, unsigned log_int256 = 0) {
+                                 const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_modmul = 0, unsigned log_int256 = 0,
+                                 const std::vector<zkhip::ecc::Curve>& curves = {}, unsigned log_ec = 0) {
         SegmentCaps c;
         for (unsigned a = 0; a < vmc::N_BASE_AIRS; a++) c.ids.push_back(a);
         auto sub = [&](unsigned d) { return log_frame > d + 2 ? log_frame - d : 2u; };
@@ -130,6 +133,12 @@ struct SegmentCaps {
             c.ids.push_back(vmc::A_MODMUL(i)), c.ids.push_back(vmc::A_MODMUL_IO(i));
             c.log_height[vmc::A_MODMUL(i)] = std::max(log_modmul, 1u), c.log_height[vmc::A_MODMUL_IO(i)] = c.log_height[vmc::A_MODMUL(i)] + 5;   // 24 adapter rows per call
         }
+        if (curves.size() > vmc::MAX_CURVES) throw Error("at most " + std::to_string(vmc::MAX_CURVES) + " curves");
+        c.curves = curves;
+        for (unsigned i = 0; i < curves.size(); i++) {
+            c.ids.push_back(vmc::A_EC(i)), c.ids.push_back(vmc::A_EC_IO(i));
+            c.log_height[vmc::A_EC(i)] = std::max(log_ec, 1u), c.log_height[vmc::A_EC_IO(i)] = c.log_height[vmc::A_EC(i)] + 6;   // 48 adapter rows per call
+        }
         c.n_airs = (unsigned)c.ids.size();
         return c;
     }
@@ -150,6 +159,8 @@ struct SegmentRecords {
     std::vector<uint32_t> mul256_records, mul256_ts;            // ... those with opcode 5: the multiplication chip's
     // modular calls per modulus: op | a | b (17 words) and the timestamp per call; the adapter's rows
     std::vector<uint32_t> mm_records[vmc::MAX_MODULI], mm_ts[vmc::MAX_MODULI], mmio_rows[vmc::MAX_MODULI];
+    // ecc calls per curve: op | x1 y1 x2 y2 | slope (41 words) and the timestamp per call; the adapter's rows
+    std::vector<uint32_t> ec_records[vmc::MAX_CURVES], ec_ts[vmc::MAX_CURVES], ecio_rows[vmc::MAX_CURVES];
     uint32_t pc_start = 0, pc_end = 0, ts_end = 0;
     Digest root_init{}, root_final{};
     size_t n_instr = 0;
@@ -165,6 +176,7 @@ struct SegmentRecords {
                         &p2_inputs, &kk_states, &kk_ts, &kio_rows, &sha_blocks, &sha_ts, &shaio_rows, &i256_records, &i256_ts, &i256io_rows, &mul256_records, &mul256_ts})
             v->clear();
         for (unsigned i = 0; i < vmc::MAX_MODULI; i++) mm_records[i].clear(), mm_ts[i].clear(), mmio_rows[i].clear();
+        for (unsigned i = 0; i < vmc::MAX_CURVES; i++) ec_records[i].clear(), ec_ts[i].clear(), ecio_rows[i].clear();
         n_instr = 0;
     }
 };
@@ -177,6 +189,7 @@ public:
             throw Error("guest addresses must lie below 2^30");
         m_.set_memory_log(false);
         m_.set_moduli(caps.moduli);
+        m_.set_curves(caps.curves);
         dec_.reserve(exe.program.size());
         for (size_t k = 0; k < exe.program.size(); k++) dec_.push_back(vmc::decode(exe.program[k], exe.pc_base + 4 * (uint32_t)k));
         mem_lo_blk_ = exe.data_base / 16;
@@ -227,8 +240,8 @@ public:
                 if (d.wr_rd) want(1, d.rd);
                 if (d.cls == vmc::C_LS) want(2, ((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) >> 2);
                 if (d.cls == vmc::C_ECALL) want(1, 11), want(3, m_.reg(11) & 7u);
-                if (d.cls == vmc::C_ECALL && m_.reg(17) >= 3 && m_.reg(17) <= 6) {
-                    const uint32_t n_words = m_.reg(17) == 3 ? 50 : 24;
+                if (d.cls == vmc::C_ECALL && m_.reg(17) >= 3 && m_.reg(17) <= 7) {
+                    const uint32_t n_words = m_.reg(17) == 3 ? 50 : m_.reg(17) == 7 ? 48 : 24;
                     for (uint32_t w = m_.reg(10) >> 2; w < (m_.reg(10) >> 2) + n_words; w += (w & 3u) ? 4 - (w & 3u) : 4) want(2, w);
                 }
                 if (!all_known) {   // rare: count exactly what the instruction would add
@@ -255,11 +268,15 @@ public:
             if (d.cls == vmc::C_ECALL && m_.reg(17) == 5 && ((m_.reg(11) & 7u) >= caps_.moduli.size() || (m_.reg(11) >> 3) >= zkhip::modular::N_OPS))
                 throw Error("the guest calls the modular intrinsic for modulus " + std::to_string(m_.reg(11) & 7u) + " but the app's openvm.toml lists " +
                             std::to_string(caps_.moduli.size()) + " moduli");
+            if (d.cls == vmc::C_ECALL && m_.reg(17) == 7 && ((m_.reg(11) & 7u) >= caps_.curves.size() || (m_.reg(11) >> 3) >= zkhip::ecc::N_OPS))
+                throw Error("the guest calls the ecc intrinsic for curve " + std::to_string(m_.reg(11) & 7u) + " but the app's openvm.toml lists " +
+                            std::to_string(caps_.curves.size()) + " curves");
             if (r.n_instr + 1 > caps_.rows(vmc::A_FRAME) || n_cls[d.cls] + 1 > caps_.rows(vmc::A_ALU + d.cls) ||
                 blk_.size() + new_blocks > caps_.rows(vmc::A_LEAF) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 3 && 24 * (r.n_keccak() + 1) > caps_.rows(vmc::A_KECCAK)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 4 && 65 * (r.n_sha256() + 1) > caps_.rows(vmc::A_SHA256)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 5 && r.mm_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_MODMUL(m_.reg(11) & 7u))) ||
+                (d.cls == vmc::C_ECALL && m_.reg(17) == 7 && r.ec_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_EC(m_.reg(11) & 7u))) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 6 && (m_.reg(11) == 5 ? r.mul256_ts.size() : r.i256_ts.size()) + 1 > caps_.rows(vmc::A_INT256)) ||
                 path_nodes_.size() + new_nodes > caps_.rows(vmc::A_MERKLE) ||
                 2 * (blk_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
@@ -287,6 +304,12 @@ public:
                 a1 = m_.reg(11);
                 if ((y & 3u) || (uint64_t)y + 96 > (1ull << 30)) throw Error("modmul / int256 buffer must be word-aligned and below 2^30");
                 for (uint32_t j = 0; j < 24; j++) mm_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
+            }
+            uint32_t ec_in[48];
+            if (d.cls == vmc::C_ECALL && x == 7) {
+                a1 = m_.reg(11);
+                if ((y & 3u) || (uint64_t)y + 192 > (1ull << 30)) throw Error("ecc buffer must be word-aligned and below 2^30");
+                for (uint32_t j = 0; j < 48; j++) ec_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
             }
             // snapshot the blocks this instruction is going to change
             if (d.wr_rd) (void)block_of(1, d.rd);
@@ -353,6 +376,26 @@ public:
                         const uint32_t pts = k >= 16 ? write_word(2, w, after, ts + 5) : read_word(2, w, before, ts + 5), gap = ts + 5 - pts - 1;
                         sr[30] = pts, sr[31] = gap & 0xffffu, sr[32] = gap >> 16;
                         r.i256io_rows.insert(r.i256io_rows.end(), sr, sr + vmc::INT256_IO_WIDTH);
+                    }
+                }
+                if (x == 7) {
+                    row[32] = 1, row[28] = (y & 255u) >> 2, row[17] = a1;
+                    auto gap3 = [&](uint32_t* dst, uint32_t pts, uint32_t at) { dst[0] = pts, dst[1] = (at - pts - 1) & 0xffffu, dst[2] = (at - pts - 1) >> 16; };
+                    gap3(row + 21, read_word(1, 11, a1, ts + 4), ts + 4);
+                    const uint32_t ci = a1 & 7u, eop = a1 >> 3;
+                    r.ec_ts[ci].push_back(ts);
+                    r.ec_records[ci].push_back(eop);
+                    r.ec_records[ci].insert(r.ec_records[ci].end(), ec_in, ec_in + 32);
+                    r.ec_records[ci].insert(r.ec_records[ci].end(), m_.last_slope().w, m_.last_slope().w + 8);
+                    constexpr uint32_t W = 48;
+                    for (uint32_t k = 0; k < W; k++) {   // the adapter's rows: the operands read, the result written, all at ts + 5
+                        uint32_t sr[vmc::EC_IO_WIDTH] = {};
+                        const uint32_t w = (y >> 2) + k, before = ec_in[k], after = mem_word(y + 4 * k);
+                        sr[k] = 1, sr[W] = ts, sr[W + 1] = y >> 2, sr[W + 9] = 1, sr[W + 10] = eop;
+                        sr[W + 2] = before & 0xffffu, sr[W + 3] = before >> 16, sr[W + 4] = after & 0xffffu, sr[W + 5] = after >> 16;
+                        const uint32_t pts = k >= 32 ? write_word(2, w, after, ts + 5) : read_word(2, w, before, ts + 5), gap = ts + 5 - pts - 1;
+                        sr[W + 6] = pts, sr[W + 7] = gap & 0xffffu, sr[W + 8] = gap >> 16;
+                        r.ecio_rows[ci].insert(r.ecio_rows[ci].end(), sr, sr + vmc::EC_IO_WIDTH);
                     }
                 }
                 if (x == 5) {

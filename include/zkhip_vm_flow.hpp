@@ -44,7 +44,12 @@ inline SegmentAirs segment_airs(const Exe& exe, const SegmentCaps& caps) {
     s.airs.resize(caps.n_airs), s.prep_width.resize(caps.n_airs);
     for (unsigned p = 0; p < caps.n_airs; p++) {   // position p of the proof holds chip caps.ids[p] (base chips: p = id)
         const unsigned id = caps.ids[p];
-        if (id >= vmc::N_STATIC_AIRS) {   // the modular extension: chip / adapter of modulus i
+        if (id >= vmc::A_EC(0)) {   // the ecc extension: chip / adapter of curve i
+            const unsigned i = (id - vmc::A_EC(0)) / 2;
+            const zkhip::modular::Modulus m = zkhip::modular::modulus_bytes(caps.curves.at(i).p), ca = zkhip::modular::modulus_bytes(caps.curves.at(i).a);
+            if (zkhip_vm_ec_air(m.data(), ca.data(), i, (id - vmc::A_EC(0)) & 1, &s.airs[p]) != ZKHIP_OK) throw Error("zkhip_vm_ec_air failed (the modulus must be odd with a non-zero top byte)");
+            s.prep_width[p] = 0;
+        } else if (id >= vmc::N_STATIC_AIRS) {   // the modular extension: chip / adapter of modulus i
             const unsigned i = (id - vmc::N_STATIC_AIRS) / 2;
             const zkhip::modular::Modulus m = zkhip::modular::modulus_bytes(caps.moduli.at(i));
             if (zkhip_vm_modmul_air(m.data(), i, (id - vmc::N_STATIC_AIRS) & 1, &s.airs[p]) != ZKHIP_OK) throw Error("zkhip_vm_modmul_air failed");
@@ -191,6 +196,11 @@ public:
             check(zkhip_rows_tracegen(ctx_, up(r.mmio_rows[i]), r.mmio_rows[i].size() / vmc::MODMUL_IO_WIDTH, vmc::MODMUL_IO_WIDTH, H(vmc::A_MODMUL_IO(i)),
                                       T(vmc::A_MODMUL_IO(i)), nullptr));
         }
+        for (unsigned i = 0; i < caps_.curves.size(); i++) {   // ecc extension: the chip's lookups are counted by its generator
+            check(zkhip_vm_ec_tracegen(ctx_, caps_.curves[i].p.w, caps_.curves[i].a.w, up(r.ec_records[i]), up(r.ec_ts[i]), r.ec_ts[i].size(), H(vmc::A_EC(i)), T(vmc::A_EC(i)),
+                                       d_bw, d_tup, TUPLE_X, TUPLE_Y));
+            check(zkhip_rows_tracegen(ctx_, up(r.ecio_rows[i]), r.ecio_rows[i].size() / vmc::EC_IO_WIDTH, vmc::EC_IO_WIDTH, H(vmc::A_EC_IO(i)), T(vmc::A_EC_IO(i)), nullptr));
+        }
         // ---- lookup multiplicities of the new chips, counted from the requesting columns
         auto pairs = [&](unsigned a, size_t cx, size_t cy, size_t n) {
             if (n) check(zkhip_bitwise_lookup_tracegen(ctx_, T(a) + cx * N(a), T(a) + cy * N(a), d_zeros_, n, 8, d_bw, 1));
@@ -221,9 +231,9 @@ public:
                     for (uint32_t v : {row[17] * 8192, row[17], row[22], row[25]}) misc.push_back(v);
                     tup_y.push_back(row[23]), tup_y.push_back(row[26]);
                 }
-                if (row[30] || row[31]) misc.push_back(row[22]), tup_y.push_back(row[23]);   // modmul / int256: the a1 read
+                if (row[30] || row[31] || row[32]) misc.push_back(row[22]), tup_y.push_back(row[23]);   // modmul / int256 / ecc: the a1 read
                 if (row[16]) bw_x.push_back(row[10]), bw_y.push_back(row[11]), bw_x.push_back(row[12]), bw_y.push_back(row[13]);
-                if (row[27] || row[29] || row[30] || row[31])
+                if (row[27] || row[29] || row[30] || row[31] || row[32])
                     for (uint32_t v : {row[28] * 1024, row[28], row[9] * 1024}) misc.push_back(v);
             }
             for (size_t i = 0; i < r.kio_rows.size() / vmc::KECCAK_IO_WIDTH; i++) {
@@ -246,6 +256,11 @@ public:
                 for (size_t i = 0; i < r.mmio_rows[m].size() / vmc::MODMUL_IO_WIDTH; i++) {
                     const uint32_t* row = &r.mmio_rows[m][i * vmc::MODMUL_IO_WIDTH];
                     misc.push_back(row[31]), tup_y.push_back(row[32]);
+                }
+            for (unsigned m = 0; m < caps_.curves.size(); m++)
+                for (size_t i = 0; i < r.ecio_rows[m].size() / vmc::EC_IO_WIDTH; i++) {
+                    const uint32_t* row = &r.ecio_rows[m][i * vmc::EC_IO_WIDTH];
+                    misc.push_back(row[55]), tup_y.push_back(row[56]);
                 }
             uint32_t* d_misc = const_cast<uint32_t*>(up(misc));
             check(zkhip_to_monty(ctx_, d_misc, misc.size()));
@@ -556,6 +571,55 @@ inline unsigned sha256_log_rows(const std::string& path_app_config, unsigned log
 inline unsigned int256_log_rows(const std::string& path_app_config, unsigned log_frame) {
     return config_has_section(path_app_config, "[app_vm_config.bigint]") ? std::max(1u, log_frame > 8 ? log_frame - 8 : 0u) : 0u;
 }
+inline zkhip::modular::U256 parse_decimal_u256(const std::string& digits) {
+    zkhip::modular::U256 v{};
+    if (digits.empty()) throw Error("openvm.toml: an empty number");
+    for (char ch : digits) {   // decimal -> words
+        if (ch < '0' || ch > '9') throw Error("openvm.toml: a modulus or coefficient is not a decimal number");
+        uint64_t c = (uint64_t)(ch - '0');
+        for (int w = 0; w < 8; w++) {
+            c += (uint64_t)v.w[w] * 10u;
+            v.w[w] = (uint32_t)c, c >>= 32;
+        }
+        if (c) throw Error("openvm.toml: a modulus or coefficient does not fit 256 bits");
+    }
+    return v;
+}
+// `[[app_vm_config.ecc.supported_curves]]` blocks with `modulus = "<decimal>"` and `a = "<decimal>"` (the reference's chunk circuit
+// lists secp256k1, P-256 and bn254 G1; `scalar`, `b` and `struct_name` do not enter the chips): the curves in the file's order
+inline std::vector<zkhip::ecc::Curve> config_curves(const std::string& path_app_config) {
+    std::ifstream f(path_app_config);
+    std::string line;
+    std::vector<zkhip::ecc::Curve> out;
+    std::vector<std::pair<bool, bool>> have;
+    bool in_block = false;
+    auto value_of = [](const std::string& l) {
+        const size_t q0 = l.find('"'), q1 = q0 == std::string::npos ? q0 : l.find('"', q0 + 1);
+        if (q1 == std::string::npos) throw Error("openvm.toml: a curve parameter is not a quoted decimal number");
+        return l.substr(q0 + 1, q1 - q0 - 1);
+    };
+    while (std::getline(f, line)) {
+        const size_t b0 = line.find_first_not_of(" \t");
+        if (b0 == std::string::npos) continue;
+        if (line[b0] == '[') {
+            in_block = line.find("[[app_vm_config.ecc.supported_curves]]") != std::string::npos;
+            if (in_block) out.push_back(zkhip::ecc::Curve{}), have.push_back({false, false});
+            continue;
+        }
+        if (!in_block) continue;
+        const size_t eq = line.find('=');
+        if (eq == std::string::npos) continue;
+        std::string key = line.substr(b0, eq - b0);
+        while (!key.empty() && (key.back() == ' ' || key.back() == '\t')) key.pop_back();
+        if (key == "modulus") out.back().p = parse_decimal_u256(value_of(line)), have.back().first = true;
+        if (key == "a") out.back().a = parse_decimal_u256(value_of(line)), have.back().second = true;
+    }
+    for (size_t i = 0; i < out.size(); i++)
+        if (!have[i].first || !have[i].second) throw Error("openvm.toml: curve " + std::to_string(i) + " needs `modulus` and `a`");
+    return out;
+}
+// 2^(log_frame - 9) rows per curve's point chip (one operation per row)
+inline unsigned ec_log_rows(unsigned log_frame) { return log_frame > 10 ? log_frame - 9 : 1; }
 // `[app_vm_config.modular] supported_moduli = ["<decimal>", ...]` (the reference's chunk circuit lists six): the moduli as 256-bit words
 inline std::vector<zkhip::modular::U256> config_moduli(const std::string& path_app_config) {
     std::ifstream f(path_app_config);
@@ -575,16 +639,7 @@ inline std::vector<zkhip::modular::U256> config_moduli(const std::string& path_a
     for (size_t p = body.find('"'); p != std::string::npos;) {
         const size_t e = body.find('"', p + 1);
         if (e == std::string::npos) break;
-        zkhip::modular::U256 v{};
-        for (size_t k = p + 1; k < e; k++) {   // decimal -> words
-            if (body[k] < '0' || body[k] > '9') throw Error("openvm.toml: a modulus is not a decimal number");
-            uint64_t c = (uint64_t)(body[k] - '0');
-            for (int w = 0; w < 8; w++) {
-                c += (uint64_t)v.w[w] * 10u;
-                v.w[w] = (uint32_t)c, c >>= 32;
-            }
-            if (c) throw Error("openvm.toml: a modulus does not fit 256 bits");
-        }
+        const zkhip::modular::U256 v = parse_decimal_u256(body.substr(p + 1, e - p - 1));
         out.push_back(v);
         p = body.find('"', e + 1);
     }
@@ -592,8 +647,10 @@ inline std::vector<zkhip::modular::U256> config_moduli(const std::string& path_a
 }
 inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
                                         bool keep_segments = false, unsigned inflight = 2, unsigned log_keccak = 0, unsigned log_sha256 = 0,
-                                        const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_int256 = 0) {
-    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak, log_sha256, moduli, log_frame > 8 ? log_frame - 8 : 1, log_int256);
+                                        const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_int256 = 0,
+                                        const std::vector<zkhip::ecc::Curve>& curves = {}) {
+    const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak, log_sha256, moduli, log_frame > 8 ? log_frame - 8 : 1, log_int256,
+                                                    curves, ec_log_rows(log_frame));
     std::vector<std::unique_ptr<SegmentProver>> own;
     std::vector<SegmentProver*> lanes;
     for (unsigned l = 0; l < std::max(1u, inflight); l++) own.emplace_back(new SegmentProver(params, exe, caps, device)), lanes.push_back(own.back().get());
@@ -653,7 +710,8 @@ public:
         p.params_ = read_app_config(cfg.path_app_config);
         p.caps_ = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(p.exe_.program.size()), zkhip_vm::keccak_log_rows(cfg.path_app_config, log_frame),
                                                    zkhip_vm::sha256_log_rows(cfg.path_app_config, log_frame), zkhip_vm::config_moduli(cfg.path_app_config),
-                                                   log_frame > 8 ? log_frame - 8 : 1, zkhip_vm::int256_log_rows(cfg.path_app_config, log_frame));
+                                                   log_frame > 8 ? log_frame - 8 : 1, zkhip_vm::int256_log_rows(cfg.path_app_config, log_frame),
+                                                   zkhip_vm::config_curves(cfg.path_app_config), zkhip_vm::ec_log_rows(log_frame));
         return p;
     }
     void reset() {   // mod.rs:106-108: releases the device-resident keys, circuits and workspaces
@@ -662,7 +720,7 @@ public:
     // mod.rs:312-338
     uint64_t execute_and_check(const ProvingTask& task) const {
         try {
-            return zkhip_vm::execute_guest(exe_, task.build_guest_input()).total_cycle;
+            return zkhip_vm::execute_guest(exe_, task.build_guest_input(), 0, nullptr, 0, caps_.moduli, caps_.curves).total_cycle;
         } catch (const zkhip_vm::Error& e) {
             throw Error(Error::GenProof, e.what());
         }

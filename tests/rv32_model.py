@@ -105,7 +105,7 @@ def sx(v, bits):
     return v - (1 << bits) if v >> (bits - 1) else v
 
 
-def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_bytes=1 << 20, data=b"", max_instr=10**7, moduli=()):
+def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_bytes=1 << 20, data=b"", max_instr=10**7, moduli=(), curves=()):
     """Independent interpreter.  Returns dict(instret, pvs (32 bytes), exit_code, records)."""
     x = [0] * 32
     x[2] = data_base + memory_bytes
@@ -320,6 +320,16 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                 assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem) and mop < 3
                 a_, b_ = int.from_bytes(mem[off:off + 32], "little"), int.from_bytes(mem[off + 32:off + 64], "little")
                 mem[off + 64:off + 96] = [a_ * b_ % p_, (a_ + b_) % p_, (a_ - b_) % p_][mop].to_bytes(32, "little")
+            elif call == 7:   # (x3, y3) = p1 + p2 (op 0) or 2 p1 (op 1) on curves[a1 & 7] = (modulus, a), 48 words at a0 (p1 | p2 | p3)
+                off = rr(10) - data_base
+                sel = rr(11)
+                (p_, a_), eop = curves[sel & 7], sel >> 3
+                assert off % 4 == 0 and 0 <= off and off + 192 <= len(mem) and eop < 2
+                x1, y1, x2, y2 = (int.from_bytes(mem[off + 32 * k:off + 32 * k + 32], "little") for k in range(4))
+                lam = (3 * x1 * x1 + a_) * pow(2 * y1, -1, p_) % p_ if eop else (y2 - y1) * pow(x2 - x1, -1, p_) % p_
+                x3 = (lam * lam - x1 - (x1 if eop else x2)) % p_
+                mem[off + 128:off + 160] = x3.to_bytes(32, "little")
+                mem[off + 160:off + 192] = ((lam * (x1 - x3) - y1) % p_).to_bytes(32, "little")
             elif call == 4:   # SHA-256 compression on the 24 words at a0: state[8] <- compress(state, block[16])
                 off = rr(10) - data_base
                 assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem)

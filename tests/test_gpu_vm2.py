@@ -18,7 +18,7 @@ import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
 from test_vm_cpu import (ALL_EXT_MSG, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, chunk_circuit_toml, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
-                         keccak_program, mixed_program, modmul_data, modmul_program, sha256_data, sha256_program)
+                         keccak_program, mixed_program, modmul_data, modmul_program, sha256_data, sha256_program, EC_CURVES, ec_data, ec_program)
 
 pytestmark = pytest.mark.gpu
 PARAMS = (1, 0, 4, 3, 3)
@@ -81,6 +81,11 @@ def device_traces(zk, rec, prog, H):
                                                   H[v2.A_MODMUL(i)], d_bw, d_tup, v2.SX, v2.SY)
         T[v2.A_MODMUL_IO(i)] = zk.rows_tracegen(D(rec["mmio_rows_%d" % i]), len(rec["mmio_rows_%d" % i]) // v2.MODMUL_IO_WIDTH, v2.MODMUL_IO_WIDTH,
                                                 H[v2.A_MODMUL_IO(i)])
+    for i, (p_, a_) in enumerate(H.curves):   # the point chips count their own lookups into the two tables
+        n_ec = len(rec["ec_ts_%d" % i])
+        T[v2.A_EC(i)] = zk.ec_tracegen(p_, a_, D(rec["ec_records_%d" % i]) if n_ec else None, n_ec, H[v2.A_EC(i)], d_bw, d_tup, v2.SX, v2.SY,
+                                       t_ts=D(rec["ec_ts_%d" % i]) if n_ec else torch.zeros(1, dtype=torch.int32, device=dev))
+        T[v2.A_EC_IO(i)] = zk.rows_tracegen(D(rec["ecio_rows_%d" % i]), len(rec["ecio_rows_%d" % i]) // v2.EC_IO_WIDTH, v2.EC_IO_WIDTH, H[v2.A_EC_IO(i)])
     n, nls = len(rec["f_x"]), len(rec["ls_case"])
     zeros = torch.zeros(max(n, nls, 64), dtype=torch.int32, device=dev)
     NF, NL = 1 << H[v2.A_FRAME], 1 << H[v2.A_LS]
@@ -110,10 +115,10 @@ def device_traces(zk, rec, prog, H):
         if row[16]:
             bw_x += [int(row[10]), int(row[12])]
             bw_y += [int(row[11]), int(row[13])]
-        if row[30] or row[31]:
+        if row[30] or row[31] or row[32]:
             misc += [int(row[22])]
             tup_y += [int(row[23])]
-        if row[27] or row[29] or row[30] or row[31]:
+        if row[27] or row[29] or row[30] or row[31] or row[32]:
             misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
     for row in rec["kio_rows"].reshape(-1, v2.KECCAK_IO_WIDTH):
         misc += [int(row[36]), int(row[39])]
@@ -128,6 +133,10 @@ def device_traces(zk, rec, prog, H):
         for row in rec["mmio_rows_%d" % i].reshape(-1, v2.MODMUL_IO_WIDTH):
             misc += [int(row[31])]
             tup_y += [int(row[32])]
+    for i in range(len(H.curves)):
+        for row in rec["ecio_rows_%d" % i].reshape(-1, v2.EC_IO_WIDTH):
+            misc += [int(row[55])]
+            tup_y += [int(row[56])]
     for row in rec["leaf_rows"].reshape(-1, v2.LEAF_WIDTH):
         misc += [int(row[39]), int(row[40]) * 16, int(row[40]), int(row[41]), int(row[42]) * 64, int(row[42])]
     d_rng = zk.range_counts_tracegen(zk.upload(np.array(misc, np.uint32)), 16, t_counts=d_rng, accumulate=True)
@@ -327,6 +336,38 @@ def test_modmul_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     y2_low, x3_low = int.from_bytes(pv[:16], "little"), int.from_bytes(pv[16:28], "little")
     assert y2_low == SECP256K1_GY ** 2 % SECP256K1_P % (1 << 128) and x3_low == SECP256K1_GX ** 3 % SECP256K1_P % (1 << 96)
     assert (y2_low - x3_low - 7) % (1 << 96) == 0                        # y^2 = x^3 + 7 (no wrap in the low words here)
+    assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
+
+
+def test_ecc_guest_device_traces_and_one_proof(zk, ora, tmp_path):
+    """A guest computing 3 G = 2 G + G on secp256k1 and 2 G on bn254 with the ecc intrinsic, two curves (26 chips): device traces == CPU
+    twins, proof bytes == the oracle's; the whole flow from the ELF with the reference's `[[app_vm_config.ecc.supported_curves]]` syntax:
+    the root's public values carry the published 3 G."""
+    words, data = ec_program(), ec_data()
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, (), False, EC_CURVES)
+    k = next(i for i, s in enumerate(segs) if len(s["ec_ts_0"]))
+    inst = v2.segment_instance(segs[k], words, PC_BASE, H)
+    T = device_traces(zk, segs[k], v2.program_table(words, PC_BASE, H[0]), H)
+    assert len(inst) == len(T) == 26
+    for a, d in enumerate(inst):
+        assert (zk.download(T[a]).reshape(d["width"], -1) == d["trace"]).all(), "position %d" % a
+    pk = z.ProvingKey(zk, PARAMS, inst)
+    pvs = [d["pvs"] for d in inst]
+    proof = pk.prove(T, pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, inst).tobytes()
+    pk.close()
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words, data=data))
+    (tmp_path / "openvm.toml").write_text(pm.TOML.format(*PARAMS) + "\n" + v2.curves_toml(EC_CURVES))
+    r = subprocess.run([pm.CLI, "prove-elf", str(exe), "-", str(tmp_path), str(tmp_path / "openvm.toml"), "8"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    model = rv.run(words, b"", data=data, curves=EC_CURVES)
+    assert out["verified"] and out["total_cycles"] == model["instret"]
+    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * 34:4 * 34 + 32]
+    assert pv == bytes(model["pvs"])
+    assert pv[:16] == (0xF9308A019258C31049344F85F89D5229B531C845836F99B08601F113BCE036F9).to_bytes(32, "little")[:16]   # 3 G of secp256k1 (published)
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
 
 

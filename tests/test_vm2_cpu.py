@@ -17,7 +17,7 @@ from zkvm_prover_amd import air
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import (ALL_EXT_MSG, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
+from test_vm_cpu import (ALL_EXT_MSG, EC_CURVES, ec_data, ec_program, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
                          keccak_program, mixed_program, modmul_data, modmul_program, sha256_data, sha256_program)
 
 PARAMS = (1, 0, 4, 3, 3)
@@ -278,6 +278,40 @@ def test_int256_intrinsic_is_part_of_the_statement(tmp_path):
     assert 30 in bad and 31 in bad                                        # the request bus (ecall passed another opcode), the word bus
     with pytest.raises(AssertionError, match="does not enable the bigint extension"):
         v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)
+
+
+def test_ecc_intrinsic_is_part_of_the_statement(tmp_path):
+    """A guest that computes 3 G = 2 G + G on secp256k1 and 2 G on bn254 with the ecc intrinsic, under an app with two curves (26 chips: a
+    point chip and an adapter per curve): the revealed coordinates are the published 3 G of secp256k1 (and Python's); every trace
+    satisfies its AIR, every bus balances; a forged result word breaks the word bus; an addition of a point to itself has no execution."""
+    words, data = ec_program(), ec_data()
+    model = rv.run(words, b"", data=data, curves=EC_CURVES)
+    pv = bytes(model["pvs"])
+    x3g, y3g = 0xF9308A019258C31049344F85F89D5229B531C845836F99B08601F113BCE036F9, 0x388F7B0F632DE8140FE337E62A37F3566500A99934C2231B6CB9FD7584B8E672
+    bn2g = 1368015179489954701390400359078579693043519447331113978918064868415326638035
+    assert pv[:16] == x3g.to_bytes(32, "little")[:16] and pv[16:28] == y3g.to_bytes(32, "little")[:12]
+    assert int.from_bytes(pv[28:32], "little") == (y3g >> 96 & 0xFFFFFFFF) ^ (bn2g & 0xFFFFFFFF)
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, (), False, EC_CURVES)
+    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"]
+    assert len(H.ids) == 26 and sum(len(s["ec_ts_0"]) for s in segs) == 2 and sum(len(s["ec_ts_1"]) for s in segs) == 1
+    for k, rec in enumerate(segs):
+        inst = v2.segment_instance(rec, words, PC_BASE, H)
+        for d in inst:
+            assert air.quotient_chunks(d["program"]) <= 2
+            assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], k
+        assert v2.bus_imbalance(inst) == {}
+    k = next(i for i, s in enumerate(segs) if len(s["ec_ts_0"]))
+    rec = {n: v.copy() for n, v in segs[k].items()}
+    rec["ecio_rows_0"].reshape(-1, v2.EC_IO_WIDTH)[33, 52] ^= 1            # a result word that is not the chip's
+    bad = v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
+    assert 33 in bad and 1 in bad                                         # curve 0's word bus, memory bus
+    with pytest.raises(AssertionError, match="lists 0 curves"):
+        v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)
+    # G + G through the chord operation: no slope, no execution
+    g = SECP256K1_GX.to_bytes(32, "little") + SECP256K1_GY.to_bytes(32, "little")
+    same = rv.assemble(rv.li(8, 0x00400000) + [("addi", 10, 8, 0), ("addi", 11, 0, 0), ("addi", 17, 0, 7), ("ecall",), ("addi", 10, 0, 0), ("addi", 17, 0, 93), ("ecall",)])
+    with pytest.raises(AssertionError, match="no slope"):
+        v2.dump_segments(tmp_path, rv.exe_bytes(same, data=g + g + bytes(64)), b"", 7, 0, 0, (), False, EC_CURVES)
 
 
 def test_all_extensions_of_the_chunk_circuit_in_one_statement(tmp_path):

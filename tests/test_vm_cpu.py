@@ -196,6 +196,40 @@ def modmul_data():
             b32(SECP256K1_N - 2) + b32(SECP256K1_N - 3) + z32 + z32 + b32(7) + z32 + z32 + z32 + z32)
 
 
+BN254_P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+EC_CURVES = ((SECP256K1_P, 0), (BN254_P, 0))   # (modulus, a): secp256k1, bn254 G1
+
+
+def ec_program():
+    """3 G on secp256k1 through the ecc intrinsic (a7 = 7, a1 = curve index + 8 op): buffer 0 = (G, G, .) doubled, its result copied into
+    buffer 1 = (2 G, G, .) and added; buffer 2 = bn254's generator (1, 2) doubled under curve 1.  Reveals the low four words of 3 G's
+    abscissa and ordinate, the low word of bn254's 2 G folded into word 7."""
+    p = rv.li(S0, 0x00400000)
+    def call(buf, which):
+        return [("addi", A0, S0, 192 * buf), ("addi", A1, 0, which), ("addi", A7, 0, 7), ("ecall",)]
+    p += call(0, 8)                                                        # double on curve 0
+    for k in range(16):
+        p += [("lw", T0, S0, 128 + 4 * k), ("sw", T0, S0, 192 + 4 * k)]
+    p += call(1, 0)                                                        # chord addition on curve 0
+    p += call(2, 9)                                                        # double on curve 1
+    p += [("lw", T1, S0, 384 + 128)]
+    for k in range(4):
+        p += [("lw", A0, S0, 192 + 128 + 4 * k), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+    for k in range(4):
+        p += [("lw", A0, S0, 192 + 160 + 4 * k)]
+        if k == 3:
+            p += [("xor", A0, A0, T1)]
+        p += [("addi", A1, 0, 4 + k), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
+def ec_data():
+    b32 = lambda v: int(v).to_bytes(32, "little")  # noqa: E731
+    g = b32(SECP256K1_GX) + b32(SECP256K1_GY)
+    return g + g + bytes(64) + bytes(64) + g + bytes(64) + b32(1) + b32(2) + bytes(128)
+
+
 def mixed_program():
     """every instruction class: a checksum over a table in memory with multiplies, comparisons, shifts, division, bytes"""
     p = [("addi", A7, 0, 2), ("ecall",), ("add", S0, A0, 0)]          # seed
