@@ -17,7 +17,7 @@ import prover_mirror_util as pm
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import (ALL_EXT_MSG, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, chunk_circuit_toml, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
+from test_vm_cpu import (ALL_EXT_MSG, CHUNK_CIRCUIT_CURVES, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, chunk_circuit_toml, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
                          keccak_program, mixed_program, modmul_data, modmul_program, sha256_data, sha256_program, EC_CURVES, ec_data, ec_program)
 
 pytestmark = pytest.mark.gpu
@@ -405,18 +405,18 @@ def test_int256_guest_device_traces_and_one_proof(zk, ora, tmp_path):
 
 def test_the_chunk_circuit_configuration_end_to_end(tmp_path):
     """`prove-elf` under an openvm.toml with the sections of the reference's chunk circuit in the reference's syntax (keccak, sha2, bigint,
-    modular with its six moduli: 41 chips per segment) for a guest that uses all four intrinsics: ONE root proof whose public values
+    modular with its six moduli, ecc with its three curves: 47 chips per segment) for a guest that uses all five intrinsics: ONE root proof whose public values
     carry hashlib's SHA3-256 / SHA-256 words and Python's field product and 256-bit difference."""
     import hashlib
 
-    words, data = all_extensions_program(), all_extensions_data()
+    words, data = all_extensions_program(True), all_extensions_data()
     exe = tmp_path / "guest.elf"
     exe.write_bytes(rv.elf_bytes(words, data=data))
     (tmp_path / "openvm.toml").write_text(chunk_circuit_toml(PARAMS))
     r = subprocess.run([pm.CLI, "prove-elf", str(exe), "-", str(tmp_path), str(tmp_path / "openvm.toml"), "8"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    model = rv.run(words, b"", data=data, moduli=CHUNK_CIRCUIT_MODULI)
+    model = rv.run(words, b"", data=data, moduli=CHUNK_CIRCUIT_MODULI, curves=tuple((c[1], c[3]) for c in CHUNK_CIRCUIT_CURVES))
     assert out["verified"] and out["total_cycles"] == model["instret"]
     root = json.loads((tmp_path / "root.json").read_text())
     pv = pm.un_b64_bincode(root["user_pvs_proof"])[4 * 34:4 * 34 + 32]

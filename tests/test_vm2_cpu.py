@@ -17,7 +17,7 @@ from zkvm_prover_amd import air
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import (ALL_EXT_MSG, EC_CURVES, ec_data, ec_program, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
+from test_vm_cpu import (ALL_EXT_MSG, CHUNK_CIRCUIT_CURVES, EC_CURVES, ec_data, ec_program, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
                          keccak_program, mixed_program, modmul_data, modmul_program, sha256_data, sha256_program)
 
 PARAMS = (1, 0, 4, 3, 3)
@@ -315,18 +315,21 @@ def test_ecc_intrinsic_is_part_of_the_statement(tmp_path):
 
 
 def test_all_extensions_of_the_chunk_circuit_in_one_statement(tmp_path):
-    """The chip set the reference's chunk-circuit configuration asks for (keccak, sha2, bigint, six moduli: 41 chips) and a guest that
-    uses all four intrinsics: SHA3-256 and SHA-256 of one message are hashlib's, the secp256k1 field product and the 256-bit difference
-    Python's; every trace satisfies its AIR and every bus balances."""
+    """The chip set the reference's chunk-circuit configuration asks for (keccak, sha2, bigint, six moduli, three curves: 47 chips) and a
+    guest that uses all five intrinsics: SHA3-256 and SHA-256 of one message are hashlib's, the secp256k1 field product, the 256-bit
+    difference and the doubled generator Python's; every trace satisfies its AIR and every bus balances."""
     import hashlib
 
-    words, data = all_extensions_program(), all_extensions_data()
-    model = rv.run(words, b"", data=data, moduli=CHUNK_CIRCUIT_MODULI)
+    curves = tuple((c[1], c[3]) for c in CHUNK_CIRCUIT_CURVES)
+    words, data = all_extensions_program(True), all_extensions_data()
+    model = rv.run(words, b"", data=data, moduli=CHUNK_CIRCUIT_MODULI, curves=curves)
     pv = bytes(model["pvs"])
     assert pv[:8] == hashlib.sha3_256(ALL_EXT_MSG).digest()[:8]
     assert b"".join(pv[8 + 4 * k:12 + 4 * k][::-1] for k in range(2)) == hashlib.sha256(ALL_EXT_MSG).digest()[:8]
-    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 5, 7, CHUNK_CIRCUIT_MODULI, True)
-    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"] and len(H.ids) == 41
+    two_g_x = 0xC6047F9441ED7D6D3045406E95C07CD85C778E4B8CEF3CA7ABAC09B95C709EE5   # 2 G of secp256k1 (published)
+    assert int.from_bytes(pv[28:32], "little") == (((5 - 7) % (1 << 256)) >> 224) ^ (two_g_x & 0xFFFFFFFF)
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 5, 7, CHUNK_CIRCUIT_MODULI, True, curves)
+    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"] and len(H.ids) == 47
     for k, rec in enumerate(segs):
         inst = v2.segment_instance(rec, words, PC_BASE, H)
         for d in inst:

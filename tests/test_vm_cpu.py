@@ -126,10 +126,24 @@ def chunk_circuit_toml(params):
     return ("[app_fri_params.fri_params]\nlog_blowup = %d\nlog_final_poly_len = %d\nnum_queries = %d\ncommit_proof_of_work_bits = %d\n"
             "query_proof_of_work_bits = %d\n\n[app_vm_config.rv32i]\n\n[app_vm_config.io]\n\n[app_vm_config.keccak]\n\n[app_vm_config.rv32m]\n"
             "range_tuple_checker_sizes = [256, 8192]\n\n[app_vm_config.bigint]\nrange_tuple_checker_sizes = [256, 8192]\n\n[app_vm_config.modular]\n"
-            "supported_moduli = [\n" % tuple(params)) + ",\n".join('    "%d"' % m for m in CHUNK_CIRCUIT_MODULI) + "\n]\n\n[app_vm_config.sha2]\n"
+            "supported_moduli = [\n" % tuple(params)) + ",\n".join('    "%d"' % m for m in CHUNK_CIRCUIT_MODULI) + "\n]\n\n[app_vm_config.sha2]\n\n" + "".join(
+                '[[app_vm_config.ecc.supported_curves]]\nstruct_name = "%s"\nmodulus = "%d"\nscalar = "%d"\na = "%d"\nb = "%d"\n\n' % c for c in CHUNK_CIRCUIT_CURVES)
 
 
-def all_extensions_program():
+# crates/circuits/chunk-circuit/openvm.toml:38-59 (struct_name, modulus, scalar, a, b)
+CHUNK_CIRCUIT_CURVES = (
+    ("Secp256k1Point", 115792089237316195423570985008687907853269984665640564039457584007908834671663,
+     115792089237316195423570985008687907852837564279074904382605163141518161494337, 0, 7),
+    ("P256Point", 115792089210356248762697446949407573530086143415290314195533631308867097853951,
+     115792089210356248762697446949407573529996955224135760342422259061068512044369,
+     115792089210356248762697446949407573530086143415290314195533631308867097853948,
+     41058363725152142129326129780047268409114441015993725554835256314039467401291),
+    ("Bn254G1Affine", 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+     21888242871839275222246405745257275088548364400416034343698204186575808495617, 0, 3),
+)
+
+
+def all_extensions_program(with_ecc=False):
     """One guest, four intrinsics: keccak-f on the block at +0, sha256 compression on the buffer at +256, a secp256k1 field product
     (modulus 2 of the chunk circuit's list) at +384, a 256-bit subtraction at +480; reveals two words of each result."""
     p = rv.li(S0, 0x00400000)
@@ -137,8 +151,13 @@ def all_extensions_program():
     p += [("addi", A0, S0, 256), ("addi", A7, 0, 4), ("ecall",)]
     p += [("addi", A0, S0, 384), ("addi", A1, 0, 2), ("addi", A7, 0, 5), ("ecall",)]
     p += [("addi", A0, S0, 480), ("addi", A1, 0, 1), ("addi", A7, 0, 6), ("ecall",)]
+    if with_ecc:   # the double of the secp256k1 generator (curve 0 of the chunk circuit's list) at +576; its low word is folded into word 7
+        p += [("addi", A0, S0, 576), ("addi", A1, 0, 8), ("addi", A7, 0, 7), ("ecall",), ("lw", T1, S0, 576 + 128)]
     for k, off in enumerate((0, 4, 256, 260, 384 + 64, 384 + 68, 480 + 64, 480 + 92)):
-        p += [("lw", A0, S0, off), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+        p += [("lw", A0, S0, off)]
+        if with_ecc and k == 7:
+            p += [("xor", A0, A0, T1)]
+        p += [("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
     p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
     return rv.assemble(p)
 
@@ -149,7 +168,8 @@ ALL_EXT_MSG = b"four intrinsics, one statement"
 def all_extensions_data():
     sha, _ = sha256_data(ALL_EXT_MSG)          # IV | one padded block = 96 bytes
     b32 = lambda v: int(v).to_bytes(32, "little")  # noqa: E731
-    return (keccak_data(ALL_EXT_MSG) + bytes(56) + sha + bytes(32) + b32(SECP256K1_GX) + b32(SECP256K1_GY) + bytes(32) + b32(5) + b32(7) + bytes(32))
+    return (keccak_data(ALL_EXT_MSG) + bytes(56) + sha + bytes(32) + b32(SECP256K1_GX) + b32(SECP256K1_GY) + bytes(32) + b32(5) + b32(7) + bytes(32) +
+            b32(SECP256K1_GX) + b32(SECP256K1_GY) + bytes(128))
 
 
 def modmul_program():
