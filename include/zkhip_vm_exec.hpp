@@ -405,7 +405,12 @@ public:
                     const uint32_t mi = a1 & 7u, mop = a1 >> 3;
                     r.mm_ts[mi].push_back(ts);
                     r.mm_records[mi].push_back(mop);
-                    r.mm_records[mi].insert(r.mm_records[mi].end(), mm_in, mm_in + 16);
+                    if (mop == zkhip::modular::OP_DIV) {   // the chip's row is the product (x / y) y = x: the record holds the quotient and y
+                        for (uint32_t k = 0; k < 8; k++) r.mm_records[mi].push_back(mem_word(y + 64 + 4 * k));
+                        r.mm_records[mi].insert(r.mm_records[mi].end(), mm_in + 8, mm_in + 16);
+                    } else {
+                        r.mm_records[mi].insert(r.mm_records[mi].end(), mm_in, mm_in + 16);
+                    }
                     for (uint32_t k = 0; k < 24; k++) {   // the adapter's rows: a, b read, r written, all at ts + 5
                         uint32_t sr[vmc::MODMUL_IO_WIDTH] = {};
                         const uint32_t w = (y >> 2) + k, before = mm_in[k], after = mem_word(y + 4 * k);

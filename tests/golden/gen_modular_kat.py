@@ -20,7 +20,7 @@ GY = 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8
 
 def main():
     rnd = random.Random(20260303)
-    out = {"about": "q, r = divmod(a * b, p) from Python integers (generator: tests/golden/gen_modular_kat.py)", "moduli": {}, "cases": [], "addsub": [],
+    out = {"about": "q, r = divmod(a * b, p) from Python integers (generator: tests/golden/gen_modular_kat.py)", "moduli": {}, "cases": [], "addsub": [], "div": [],
            "secp256k1_generator": {"x": hex(GX), "y": hex(GY)}}
     assert (GY * GY - GX * GX * GX - 7) % MODULI["secp256k1_p"] == 0
     for name, p in MODULI.items():
@@ -38,6 +38,13 @@ def main():
             out["addsub"].append({"modulus": name, "op": 1, "a": hex(a), "b": hex(b), "q": hex(q), "r": hex(r)})
             r = (a - b) % p
             out["addsub"].append({"modulus": name, "op": 2, "a": hex(a), "b": hex(b), "q": hex(0 if a >= b else 1), "r": hex(r)})
+    # division x / y = x y^-1 (a generator of its own: the cases above keep their values); y invertible, x reduced
+    rnd_div = random.Random(20261003)
+    for name, p in MODULI.items():
+        for x, y in [(0, 1), (1, 1), (p - 1, p - 1), (1, 2), (p - 1, 2), (7, p - 1)] + [(rnd_div.randrange(p), rnd_div.randrange(1, p)) for _ in range(8)]:
+            r = x * pow(y, -1, p) % p
+            assert r * y % p == x
+            out["div"].append({"modulus": name, "a": hex(x), "b": hex(y), "r": hex(r)})
     with open(os.path.join(HERE, "modular_kat.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("wrote", len(out["cases"]), "cases")

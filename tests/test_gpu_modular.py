@@ -1,4 +1,4 @@
-"""GPU: the modular-multiplication chip on the device: zkhip_modmul_tracegen == the oracle twin cell for cell (286 columns) and count for
+"""GPU: the modular-multiplication chip on the device: zkhip_modmul_tracegen == the oracle twin cell for cell (322 columns) and count for
 count in both lookup tables, r = a b mod P is Python's, the HIP proof of the chip with its tables == the oracle's."""
 import json
 import os
@@ -45,6 +45,36 @@ def test_device_modmul_trace_and_proof(zk, ora):
         bad_tr[96 * (1 << log_h) + 2] ^= 1   # another residue
         assert z.verify(PARAMS, pk.verifying_airs(), pvs, pk.prove([bad_tr, d_bw, d_tup], pvs)) != 0
         pk.close()
+
+
+def test_device_modular_operations_trace(zk, ora):
+    """zkhip_modular_tracegen (17-word records: op | a | b) with the four operations mixed == the oracle twin cell for cell and count for
+    count; the results are Python's; a division record whose quotient is not reduced is refused."""
+    kat = json.load(open(os.path.join(HERE, "golden", "modular_kat.json")))
+    for name in ("secp256k1_n", "bn254_p"):
+        p = int(kat["moduli"][name], 16)
+        rows = [(3, int(c["r"], 16), int(c["b"], 16)) for c in kat["div"] if c["modulus"] == name]
+        rows += [(c["op"], int(c["a"], 16), int(c["b"], 16)) for c in kat["addsub"] if c["modulus"] == name][:10]
+        rows += [(0, int(c["a"], 16), int(c["b"], 16)) for c in kat["cases"] if c["modulus"] == name][:6]
+        log_h = 5
+        recs = np.array([[op] + mu.to_bytes(a).view("<u4").tolist() + mu.to_bytes(b).view("<u4").tolist() for op, a, b in rows], dtype=np.uint32).reshape(-1)
+        d_recs = torch.from_numpy(recs.view(np.int32)).to(zk.device)
+        d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
+        d_tup = torch.zeros(mu.SX * mu.SY, dtype=torch.int32, device=zk.device)
+        d_tr = zk.modular_tracegen(p, d_recs, len(rows), log_h, d_bw, d_tup, mu.SX, mu.SY)
+        got = zk.download(d_tr).reshape(mu.WIDTH, -1)
+        tr, bw, tup, bad = mu.ora_trace(ora, [(a, b) for _, a, b in rows], p, log_h, ops=[o for o, _, _ in rows])
+        assert bad == 0 and (got == tr).all()
+        assert (zk.download(d_bw)[:1 << 16] == bw).all() and (zk.download(d_tup) == tup).all()
+        divs = [c for c in kat["div"] if c["modulus"] == name]
+        for row, c in enumerate(divs):   # the r columns hold the dividend, the a columns the quotient
+            assert bytes(got[96:128, row].astype(np.uint8)) == int(c["a"], 16).to_bytes(32, "little")
+            assert int.from_bytes(bytes(got[0:32, row].astype(np.uint8)), "little") * int(c["b"], 16) % p == int(c["a"], 16)
+    p = int(kat["moduli"]["bn254_p"], 16)
+    recs = np.array([3] + mu.to_bytes(p + 5).view("<u4").tolist() + mu.to_bytes(3).view("<u4").tolist(), dtype=np.uint32)
+    with pytest.raises(Exception):
+        zk.modular_tracegen(p, torch.from_numpy(recs.view(np.int32)).to(zk.device), 1, 1, torch.zeros(2 << 16, dtype=torch.int32, device=zk.device),
+                            torch.zeros(mu.SX * mu.SY, dtype=torch.int32, device=zk.device), mu.SX, mu.SY)
 
 
 def test_modmul_chip_throughput(zk):

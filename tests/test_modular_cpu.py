@@ -68,6 +68,51 @@ def test_addition_and_subtraction(ora, kat):
     assert air.check_trace(inst[0]["program"], t2, mu.NOPV) != []
 
 
+def test_division(ora, kat):
+    """ModularMulDiv's division in the multiplication chip's columns: the host function against Python's integers; a division row is the
+    product (x / y) y = x with the quotient in the a columns; a trace mixing divisions with the other operations satisfies the AIR and
+    balances both buses; a quotient that is not reduced ((x / y) + P, where it fits) has no trace; the host function refuses a zero
+    divisor and a dividend that is not reduced."""
+    mod = {k: int(v, 16) for k, v in kat["moduli"].items()}
+    for c in kat["div"]:
+        p, x, y, r = mod[c["modulus"]], int(c["a"], 16), int(c["b"], 16), int(c["r"], 16)
+        assert r * y % p == x and r < p
+        assert z.modular_host(3, x, y, p) == (0, r)
+    p = mod["bn254_p"]
+    lib = z.load_library()
+    import ctypes as C
+    from zkvm_prover_amd._binding import _int_words, _u32p
+    def refused(x, y):
+        w = [np.array(_int_words(v), dtype=np.uint32) for v in (x, y, p)]
+        q, r = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
+        return lib.zkhip_modular_host(3, _u32p(w[0]), _u32p(w[1]), _u32p(w[2]), _u32p(q), _u32p(r)) != 0
+    assert refused(5, 0) and refused(5, p) and refused(p + 1, 3) and not refused(5, 3)
+    divs = [(int(c["a"], 16), int(c["b"], 16), int(c["r"], 16)) for c in kat["div"] if c["modulus"] == "bn254_p"]
+    rows = [(3, r, y) for _, y, r in divs[:9]]                      # the record of a division: (quotient, divisor)
+    rows += [(c["op"], int(c["a"], 16), int(c["b"], 16)) for c in kat["addsub"] if c["modulus"] == "bn254_p"][:3]
+    rows += [(0, int(c["a"], 16), int(c["b"], 16)) for c in kat["cases"] if c["modulus"] == "bn254_p"][:3]
+    tr, bw, tup, bad = mu.ora_trace(ora, [(a, b) for _, a, b in rows], p, 4, ops=[o for o, _, _ in rows])
+    assert bad == 0
+    inst = mu.instance(p, tr, bw, tup, 4)
+    for d in inst:
+        assert air.quotient_chunks(d["program"]) <= 2
+        assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == []
+    assert v2.bus_imbalance(inst) == {}
+    for row, (x, y, r) in enumerate(divs[:9]):
+        assert bytes(tr[96:128, row].astype(np.uint8)) == x.to_bytes(32, "little") and bytes(tr[0:32, row].astype(np.uint8)) == r.to_bytes(32, "little")
+        assert tr[288, row] == 1
+    # the quotient r + P (bn254: fits 256 bits) multiplies to the same x modulo P, but is not canonical: the oracle twin refuses the
+    # record, and the row it writes (without a marker) breaks the AIR
+    x, y, r = divs[8]
+    forged, _, _, bad = mu.ora_trace(ora, [(r + p, y)], p, 1, ops=[3])
+    assert bad == 1 and air.check_trace(inst[0]["program"], forged, mu.NOPV) != []
+    # a division row relabelled as a plain multiplication is fine by the AIR alone (it IS a product) -- inside the VM the word bus tells
+    # them apart (tests/test_vm2_cpu.py)
+    t2 = tr.copy()
+    t2[288, 0], t2[289:322, 0] = 0, 0
+    assert air.check_trace(inst[0]["program"], t2, mu.NOPV) == []
+
+
 @pytest.mark.parametrize("name", ["secp256k1_p", "bn254_r"])
 def test_trace_satisfies_the_air_and_the_buses_balance(ora, kat, name):
     p = int(kat["moduli"][name], 16)

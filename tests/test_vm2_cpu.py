@@ -229,7 +229,7 @@ def test_modmul_intrinsic_is_part_of_the_statement(tmp_path):
     assert int.from_bytes(pv[28:32], "little") == (x3 >> 96 & 0xFFFFFFFF) ^ (other & 0xFFFFFFFF)
     info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, moduli)
     assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"]
-    assert len(H.ids) == 26 and sum(len(s["mm_ts_0"]) for s in segs) == 5 and sum(len(s["mm_ts_1"]) for s in segs) == 1
+    assert len(H.ids) == 26 and sum(len(s["mm_ts_0"]) for s in segs) == 6 and sum(len(s["mm_ts_1"]) for s in segs) == 1
     for k, rec in enumerate(segs):
         inst = v2.segment_instance(rec, words, PC_BASE, H)
         for d in inst:
@@ -241,6 +241,15 @@ def test_modmul_intrinsic_is_part_of_the_statement(tmp_path):
     rec["mmio_rows_0"].reshape(-1, v2.MODMUL_IO_WIDTH)[17, 28] ^= 1        # a result word that is not the product's
     bad = v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
     assert 18 in bad and 1 in bad                                         # modulus 0's word bus, memory bus
+    # the division row relabelled as a multiplication in the chip: it is a product, but the adapter's words carry opcode 3 and the
+    # operands in the other order
+    kd = next(i for i, s in enumerate(segs) if 3 in s["mm_records_0"].reshape(-1, 17)[:, 0])
+    inst = v2.segment_instance(segs[kd], words, PC_BASE, H)
+    pos = H.ids.index(v2.A_MODMUL(0))
+    row = int(np.nonzero(segs[kd]["mm_records_0"].reshape(-1, 17)[:, 0] == 3)[0][0])
+    inst[pos]["trace"] = inst[pos]["trace"].copy()
+    inst[pos]["trace"][288:322, row] = 0
+    assert air.check_trace(inst[pos]["program"], inst[pos]["trace"], inst[pos]["pvs"]) == [] and 18 in v2.bus_imbalance(inst)
     # without the extension the guest has no proof
     with pytest.raises(AssertionError, match="lists 0 moduli"):
         v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)

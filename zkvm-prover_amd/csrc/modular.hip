@@ -1,6 +1,6 @@
-// modular.hip -- the modular-multiplication chip on the device (include/zkhip_modular.hpp: r = a b mod P on byte limbs, one multiplication
-// per row, 288 columns).  Record = a[8] | b[8] (little-endian 32-bit words; with an operation word in front for the form that also adds and subtracts).  One lane per row: schoolbook product, binary long division
-// by the modulus (512 shift-compare-subtract steps on nine words: ~20 k integer operations next to 288 stores and 127 table increments),
+// modular.hip -- the modular-multiplication chip on the device (include/zkhip_modular.hpp: r = a b mod P on byte limbs, one operation
+// per row, 322 columns).  Record = a[8] | b[8] (little-endian 32-bit words; with an operation word in front for the form that also adds and subtracts).  One lane per row: schoolbook product, binary long division
+// by the modulus (512 shift-compare-subtract steps on nine words: ~20 k integer operations next to 322 stores and 127 table increments),
 // then the carries of the limb equations; the row's lookups (65 byte pairs, 62 carry tuples) are counted into the bitwise and range-tuple
 // tables in the same pass (wave-merged atomics, csrc/hist.hpp).  Replaces the trace generation of OpenVM's ModularMulDiv chip
 // (openvm-algebra-circuit, un-vendored).
@@ -40,8 +40,10 @@ __global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict
     }
     uint32_t a[8], b[8], prod[16], rem[9], quo[8];
     const size_t ro = rec_stride * row + (rec_stride - 16);
-    const uint32_t op = rec_stride == 17 ? recs[rec_stride * row] : 0u;   // 0 mul, 1 add, 2 sub
-    if (op >= md::N_OPS) atomicAdd(bad, 1u);
+    const uint32_t op_in = rec_stride == 17 ? recs[rec_stride * row] : 0u;   // 0 mul, 1 add, 2 sub, 3 div (the record then holds the quotient x / y and y)
+    const bool is_div = op_in == md::OP_DIV;
+    const uint32_t op = is_div ? (uint32_t)md::OP_MUL : op_in;
+    if (op_in >= md::N_OPS) atomicAdd(bad, 1u);
 #pragma unroll
     for (int i = 0; i < 8; i++) a[i] = recs[ro + i], b[i] = recs[ro + 8 + i];
 #pragma unroll
@@ -153,6 +155,19 @@ __global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict
     const uint32_t diff = mark >= 0 ? byte_of(pm.w, mark) - byte_of(rem, mark) : 0u;
     put(md::COL_DIFF, diff), put(md::COL_REAL, 1u), put(md::COL_IS_ADD, op == md::OP_ADD ? 1u : 0u), put(md::COL_IS_SUB, op == md::OP_SUB ? 1u : 0u);
     hist_add(bitwise_range, ((diff - 1u) & 255u) * 256);
+    // a division's quotient (the a columns) is canonical as well
+    int mark2 = -1;
+    if (is_div)
+        for (int i = 31; i >= 0; i--)
+            if (byte_of(a, i) != byte_of(pm.w, i)) {
+                mark2 = byte_of(a, i) < byte_of(pm.w, i) ? i : -2;
+                break;
+            }
+    if (is_div && mark2 < 0) atomicAdd(bad, 1u);   // the record's quotient is not below the modulus
+    for (int i = 0; i < 32; i++) put(md::COL_MARK2 + i, i == mark2 ? 1u : 0u);
+    const uint32_t diff2 = mark2 >= 0 ? byte_of(pm.w, mark2) - byte_of(a, mark2) : 0u;
+    put(md::COL_IS_DIV, is_div ? 1u : 0u), put(md::COL_DIFF2, diff2);
+    if (is_div) hist_add(bitwise_range, ((diff2 - 1u) & 255u) * 256);
 }
 
 // the VM chip's timestamp column: row i carries the timestamp of call i
@@ -248,7 +263,13 @@ int zkhip_modular_host(uint32_t op, const uint32_t a[8], const uint32_t b[8], co
     memcpy(A.w, a, 32), memcpy(B.w, b, 32), memcpy(M.w, modulus, 32);
     bool zero = true;
     for (uint32_t v : M.w) zero = zero && v == 0;
-    if (zero || !md::addsubmod(op, A, B, M, &Q, &R)) return ZKHIP_ERR_INVALID;
+    if (zero) return ZKHIP_ERR_INVALID;
+    if (op == md::OP_DIV) {
+        Q = md::U256{};
+        if (!md::divmod_p(A, B, M, &R)) return ZKHIP_ERR_INVALID;
+    } else if (!md::addsubmod(op, A, B, M, &Q, &R)) {
+        return ZKHIP_ERR_INVALID;
+    }
     memcpy(q, Q.w, 32), memcpy(r, R.w, 32);
     return ZKHIP_OK;
 }
