@@ -697,6 +697,14 @@ int zkhip_int256_mul_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, size_t 
 /* inside the VM (162 columns; records = the int256 calls' 17 words with op 5) */
 int zkhip_vm_mul256_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height, uint32_t *d_trace,
                              uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+/* 256-bit comparison chip (b < c unsigned / signed, b == c; 103 columns; 34 lookups per row in the bitwise table's range column): d_records:
+ * n x 17 words (op | b[8] | c[8], op 6 sltu, 7 slt, 8 eq); zkhip_int256_alu_host accepts ops 6..8 for it (the result word is 0 or 1);
+ * inside the VM 104 columns (+ the timestamp) */
+#define ZKHIP_INT256_CMP_WIDTH 103
+int zkhip_int256_cmp_air(uint32_t bitwise_bus, zkhip_air *out);
+int zkhip_int256_cmp_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
+int zkhip_vm_cmp256_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height, uint32_t *d_trace,
+                             uint32_t *d_bitwise_trace);
 /* the chip inside the VM (102 columns: + the timestamp of call i on row i) */
 int zkhip_vm_int256_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height, uint32_t *d_trace,
                              uint32_t *d_bitwise_trace);

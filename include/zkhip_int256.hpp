@@ -99,6 +99,75 @@ inline void mul256_vm_air(AirBuilder& b, uint32_t bitwise_bus, uint32_t tuple_bu
                                Kind::Receive);
         }
 }
+// ---- 256-bit comparisons (OpenVM's Rv32LessThan256 and the equality its Rv32BranchEqual256 decides) -- a chip of its own, the RV32
+// less-than core (include/zkhip_chips.hpp) at 32 limbs with an equality output: ONE comparison per row,
+//   b[32] | c[32] | t | marker[32] | diff | b_msb c_msb | is_sltu is_slt is_eq                    103 columns
+// The most significant limb where b and c differ is marked; there (c_i - b_i) (2 t - 1) = diff is in 1..255 (one range lookup), so t says
+// which operand is smaller; limbs above the marker are equal; no marker = equal operands (then t = 0).  SLT reads the top limbs as
+// signed bytes (b_msb = b_31 or b_31 - 256, looked up shifted by 128).  Result word: t for SLTU / SLT, 1 - (a marker exists) for EQ.
+// b and c are looked up pairwise in the bitwise table (the comparison of limbs needs honest bytes).  Degree 3.
+constexpr uint32_t OP_SLTU = 6, OP_SLT = 7, OP_EQ = 8;
+constexpr size_t CMP_COL_B = 0, CMP_COL_C = 32, CMP_COL_T = 64, CMP_COL_MARK = 65, CMP_COL_DIFF = 97, CMP_COL_BMSB = 98, CMP_COL_CMSB = 99, CMP_COL_FLAGS = 100,
+                 CMP_WIDTH = 103;
+// the result limb 0 (the other limbs of the result word are zero)
+inline Expr cmp256_air(AirBuilder& b, uint32_t bitwise_bus) {
+    const Expr is_sltu = b.var(CMP_COL_FLAGS), is_slt = b.var(CMP_COL_FLAGS + 1), is_eq = b.var(CMP_COL_FLAGS + 2), real = is_sltu + is_slt + is_eq;
+    const Expr t = b.var(CMP_COL_T), dv = b.var(CMP_COL_DIFF), bm = b.var(CMP_COL_BMSB), cm = b.var(CMP_COL_CMSB), zero = b.constant(0);
+    for (const Expr& f : {is_sltu, is_slt, is_eq, real, t}) b.assert_zero(f * (f - 1));
+    const size_t top[2] = {CMP_COL_B + LIMBS - 1, CMP_COL_C + LIMBS - 1};
+    const Expr msb[2] = {bm, cm};
+    for (int o = 0; o < 2; o++) {
+        const Expr d = b.var(top[o]) - msb[o];   // 0, or 256 for a negative signed operand
+        b.assert_zero(d * (d - 256));
+        b.assert_zero((1 - is_slt) * d);
+    }
+    const Expr sign = t * 2 - 1;
+    Expr prefix = b.constant(0);
+    bool first = true;
+    for (size_t ii = LIMBS; ii-- > 0;) {
+        const Expr m = b.var(CMP_COL_MARK + ii);
+        b.assert_zero(m * (m - 1));
+        const Expr diff = ((ii == LIMBS - 1 ? cm : b.var(CMP_COL_C + ii)) - (ii == LIMBS - 1 ? bm : b.var(CMP_COL_B + ii))) * sign;
+        prefix = first ? m : prefix + m;
+        first = false;
+        b.assert_zero((1 - prefix) * diff);   // no marker at or above this limb: equal here
+        b.assert_zero(m * (dv - diff));
+    }
+    b.assert_zero(prefix * (prefix - 1));
+    b.assert_zero((1 - prefix) * t);          // equal operands are not less
+    b.assert_zero((1 - real) * prefix);       // rows beyond the records carry no marker
+    b.push_interaction(bitwise_bus, {bm + is_slt * 128, cm + is_slt * 128, zero, zero}, real, Kind::Send);
+    b.push_interaction(bitwise_bus, {dv - 1, zero, zero, zero}, prefix, Kind::Send);
+    for (size_t base : {CMP_COL_B, CMP_COL_C})
+        for (size_t i = 0; i < LIMBS; i += 2) b.push_interaction(bitwise_bus, {b.var(base + i), b.var(base + i + 1), zero, zero}, real, Kind::Send);
+    return is_eq * (1 - prefix) + (is_sltu + is_slt) * t;
+}
+// inside the VM: + a timestamp column; the call's 24 words arrive on the ALU chip's word bus with the comparison's opcode
+constexpr size_t CMP_COL_TS = CMP_WIDTH, CMP_VM_WIDTH = CMP_WIDTH + 1;
+inline void cmp256_vm_air(AirBuilder& b, uint32_t bitwise_bus, uint32_t word_bus) {
+    const Expr out = cmp256_air(b, bitwise_bus);
+    const Expr ts = b.var(CMP_COL_TS), is_sltu = b.var(CMP_COL_FLAGS), is_slt = b.var(CMP_COL_FLAGS + 1), is_eq = b.var(CMP_COL_FLAGS + 2);
+    const Expr real = is_sltu + is_slt + is_eq, op = is_sltu * (int64_t)OP_SLTU + is_slt * (int64_t)OP_SLT + is_eq * (int64_t)OP_EQ, zero = b.constant(0);
+    const size_t base[2] = {CMP_COL_B, CMP_COL_C};
+    for (size_t o = 0; o < 2; o++)
+        for (size_t k = 0; k < 8; k++) {
+            const size_t c = base[o] + 4 * k;
+            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(8 * o + k)), b.var(c) + b.var(c + 1) * 256, b.var(c + 2) + b.var(c + 3) * 256, op}, real, Kind::Receive);
+        }
+    for (size_t k = 0; k < 8; k++) b.push_interaction(word_bus, {ts, b.constant((uint32_t)(16 + k)), k == 0 ? out : zero, zero, op}, real, Kind::Receive);
+}
+// 0 / 1 (host)
+inline uint32_t cmp256(uint32_t op, const uint32_t b[8], const uint32_t c[8]) {
+    bool eq = true, lt = false;
+    for (int i = 7; i >= 0; i--)
+        if (b[i] != c[i]) {
+            eq = false, lt = b[i] < c[i];
+            break;
+        }
+    if (op == OP_EQ) return eq ? 1u : 0u;
+    if (op == OP_SLT && ((b[7] ^ c[7]) >> 31)) return b[7] >> 31;   // different signs: the negative one is smaller
+    return lt ? 1u : 0u;
+}
 inline void mul256(const uint32_t b[8], const uint32_t c[8], uint32_t a[8]) {
     uint32_t t[8] = {};
     for (int i = 0; i < 8; i++) {

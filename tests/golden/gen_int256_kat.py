@@ -17,9 +17,19 @@ def main():
     pairs = [(0, 0), (M - 1, 1), (0, 1), (M - 1, M - 1), (1 << 255, 1 << 255), (0xFF, 0x01), ((1 << 128) - 1, 1), (1 << 128, 1), (M - 1, 0)]
     pairs += [(rnd.getrandbits(256), rnd.getrandbits(256)) for _ in range(23)]
     cases = [{"op": op, "b": hex(b), "c": hex(c), "a": hex(f(b, c))} for op, f in OPS.items() for b, c in pairs]
+    # comparisons (a generator of their own: the cases above keep their values): 6 b < c unsigned, 7 b < c signed (two's complement), 8 b == c
+    rnd_cmp = random.Random(20261003)
+    sgn = lambda v: v - M if v >> 255 else v  # noqa: E731
+    cpairs = [(0, 0), (0, 1), (1, 0), (M - 1, 0), (0, M - 1), (M - 1, M - 1), (1 << 255, (1 << 255) - 1), ((1 << 255) - 1, 1 << 255), (1 << 255, 1 << 255),
+              (1 << 255, M - 1), (5 << 248, 5 << 248 | 1), (0x80 << 248, 0x7F << 248), (0xFF << 248, 0x80 << 248)]
+    for _ in range(12):
+        b = rnd_cmp.getrandbits(256)
+        cpairs += [(b, rnd_cmp.getrandbits(256)), (b, b ^ (1 << rnd_cmp.randrange(256))), (b, b)]
+    cmp_cases = [{"op": op, "b": hex(b), "c": hex(c), "a": hex(int(b < c) if op == 6 else int(sgn(b) < sgn(c)) if op == 7 else int(b == c))}
+                 for op in (6, 7, 8) for b, c in cpairs]
     with open(os.path.join(HERE, "int256_kat.json"), "w") as f:
         json.dump({"about": "a = (b op c) mod 2^256 from Python integers (generator: tests/golden/gen_int256_kat.py); op: 0 add 1 sub 2 xor 3 or 4 and 5 mul (low 256 bits)",
-                   "cases": cases}, f, indent=0)
+                   "cases": cases, "cmp": cmp_cases}, f, indent=0)
     print("wrote", len(cases), "cases")
 
 

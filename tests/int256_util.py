@@ -70,3 +70,47 @@ def mul_instance(trace, bw, tup, log_height):
                  prep=air.bitwise_lookup_prep(8)),
             dict(program=air.range_tuple_table_air(SX, SY, TUPLE_BUS).program(), log_height=13, width=1, n_pvs=0, trace=tup.reshape(1, -1), pvs=NOPV,
                  prep=air.range_tuple_prep(SX, SY))]
+
+
+CMP_WIDTH = 103
+
+
+def cmp_result(op, b, c):
+    """Python's answer: op 6 b < c unsigned, 7 b < c as two's-complement 256-bit integers, 8 b == c"""
+    sgn = lambda v: v - (1 << 256) if v >> 255 else v  # noqa: E731
+    return int(b < c) if op == 6 else int(sgn(b) < sgn(c)) if op == 7 else int(b == c)
+
+
+def cmp_twin_trace(cases, log_height):
+    """the tests' twin of zkhip_int256_cmp_tracegen for [(op, b, c)]: (trace [103, N] canonical, bitwise range counts [65536])"""
+    P = 2013265921
+    tr = np.zeros((CMP_WIDTH, 1 << log_height), np.uint32)
+    bw = np.zeros(1 << 16, np.uint32)
+    for row, (op, b, c) in enumerate(cases):
+        bl, cl = list(int(b).to_bytes(32, "little")), list(int(c).to_bytes(32, "little"))
+        tr[0:32, row], tr[32:64, row] = bl, cl
+        for i in range(0, 32, 2):
+            bw[bl[i] * 256 + bl[i + 1]] += 1
+            bw[cl[i] * 256 + cl[i + 1]] += 1
+        sb, sc = list(bl), list(cl)
+        if op == 7:
+            sb[31], sc[31] = (bl[31] - 256 if bl[31] >= 128 else bl[31]), (cl[31] - 256 if cl[31] >= 128 else cl[31])
+        mark = next((i for i in range(31, -1, -1) if sb[i] != sc[i]), -1)
+        lt = mark >= 0 and sb[mark] < sc[mark]
+        if mark >= 0:
+            diff = abs(sc[mark] - sb[mark])
+            tr[65 + mark, row], tr[97, row] = 1, diff
+            bw[(diff - 1) * 256] += 1
+        tr[64, row] = int(lt)
+        tr[98, row], tr[99, row] = sb[31] % P, sc[31] % P
+        shift = 128 if op == 7 else 0
+        bw[(sb[31] + shift) * 256 + (sc[31] + shift)] += 1
+        tr[100 + (op - 6), row] = 1
+    return tr, bw
+
+
+def cmp_instance(trace, bw, log_height):
+    program, width = z.int256_cmp_air(BITWISE_BUS)
+    return [dict(program=program, log_height=log_height, width=width, n_pvs=0, trace=trace, pvs=NOPV),
+            dict(program=air.bitwise_lookup_air(8, BITWISE_BUS).program(), log_height=16, width=2, n_pvs=0, trace=np.stack([bw, np.zeros(1 << 16, np.uint32)]), pvs=NOPV,
+                 prep=air.bitwise_lookup_prep(8))]

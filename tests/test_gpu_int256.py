@@ -91,3 +91,34 @@ def test_int256_chip_throughput(zk):
     t2 = time.perf_counter()
     print("int256 chip: %d operations, %.1f M cells: tracegen %.2f ms, proof %.1f ms" % (n, iu.WIDTH * (1 << log_h) / 1e6, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
     pk.close()
+
+
+def test_device_comparison_trace_and_proof(zk, ora):
+    """zkhip_int256_cmp_tracegen == the tests' twin cell for cell and count for count; the answers are Python's; the HIP proof of the chip
+    with the bitwise table == the oracle's; a non-comparison opcode is refused."""
+    kat = json.load(open(os.path.join(HERE, "golden", "int256_kat.json")))["cmp"]
+    cases = [(c["op"], int(c["b"], 16), int(c["c"], 16)) for c in kat]
+    log_h = 8
+    recs = iu.records(cases).reshape(-1)
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(zk.device)
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
+    d_tr = zk.int256_cmp_tracegen(d_recs, len(cases), log_h, d_bw)
+    got = zk.download(d_tr).reshape(iu.CMP_WIDTH, -1)
+    tr, bw = iu.cmp_twin_trace(cases, log_h)
+    assert (got == tr).all() and (zk.download(d_bw)[:1 << 16] == bw).all()
+    for row, c in enumerate(kat):
+        out = int(got[64, row]) if c["op"] != 8 else 1 - int(got[65:97, row].sum())
+        assert out == int(c["a"], 16)
+    inst = iu.cmp_instance(got, bw, log_h)
+    pk = z.ProvingKey(zk, PARAMS, inst)
+    pvs = [iu.NOPV] * 2
+    proof = pk.prove([d_tr, d_bw], pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, inst).tobytes()
+    bad_tr = d_tr.clone()
+    bad_tr[64 * (1 << log_h) + 1] ^= 1   # (the Montgomery form of) another answer
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, pk.prove([bad_tr, d_bw], pvs)) != 0
+    pk.close()
+    with pytest.raises(Exception):
+        zk.int256_cmp_tracegen(torch.from_numpy(iu.records([(2, 1, 2)]).reshape(-1).view(np.int32)).to(zk.device), 1, 1,
+                               torch.zeros(2 << 16, dtype=torch.int32, device=zk.device))

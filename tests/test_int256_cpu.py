@@ -86,6 +86,48 @@ def test_multiplication_chip(ora, kat):
     assert z.verify(PARAMS, vk, [iu.NOPV] * 3, proof.tobytes()) == 0
 
 
+@pytest.fixture(scope="module")
+def cmp_kat():
+    with open(os.path.join(HERE, "golden", "int256_kat.json")) as f:
+        return [(c["op"], int(c["b"], 16), int(c["c"], 16), int(c["a"], 16)) for c in json.load(f)["cmp"]]
+
+
+def test_comparison_chip(cmp_kat):
+    """Rv32LessThan256 / equality as a chip of its own: the host function against Python's integers (unsigned, signed, equal; operands
+    that differ in one bit, in the sign only, not at all); the tests' twin trace with the bitwise table satisfies the AIRs and balances the
+    bus; a flipped answer, a marker on a lower differing limb and an equality claimed for different operands have no trace."""
+    cases = cmp_kat
+    for op, b, c, a in cases:
+        assert iu.cmp_result(op, b, c) == a and z.int256_alu_host(op, b, c) == a
+    sel = cases[:13] + cases[49:62] + cases[98:111] + cases[20:30] + cases[70:80] + cases[120:125]
+    tr, bw = iu.cmp_twin_trace([(op, b, c) for op, b, c, _ in sel], 6)
+    inst = iu.cmp_instance(tr, bw, 6)
+    for d in inst:
+        assert air.quotient_chunks(d["program"]) <= 2
+        assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == []
+    assert v2.bus_imbalance(inst) == {}
+    program = inst[0]["program"]
+    # the answer flipped (t, for a less-than row with different operands)
+    k = next(i for i, (op, b, c, a) in enumerate(sel) if op == 6 and b != c)
+    t2 = tr.copy()
+    t2[64, k] ^= 1
+    i2 = iu.cmp_instance(t2, bw, 6)
+    assert air.check_trace(program, t2, iu.NOPV) != [] or v2.bus_imbalance(i2) != {}
+    # the marker moved to a lower differing limb
+    k = next(i for i, (op, b, c, a) in enumerate(sel) if bin(b ^ c).count("1") > 40)
+    marked = int(np.nonzero(tr[65:97, k])[0][0])
+    lower = next(i for i in range(marked - 1, -1, -1) if tr[i, k] != tr[32 + i, k])
+    t3 = tr.copy()
+    t3[65 + marked, k], t3[65 + lower, k] = 0, 1
+    t3[97, k] = abs(int(tr[32 + lower, k]) - int(tr[lower, k]))
+    assert air.check_trace(program, t3, iu.NOPV) != []
+    # "equal" claimed for different operands: the marker removed
+    k = next(i for i, (op, b, c, a) in enumerate(sel) if op == 8 and b != c)
+    t4 = tr.copy()
+    t4[65:97, k], t4[97, k], t4[64, k] = 0, 0, 0
+    assert air.check_trace(program, t4, iu.NOPV) != []
+
+
 def test_oracle_proves_the_chip_with_its_table(ora):
     rng = np.random.default_rng(5)
     cases = [(int(rng.integers(0, 5)), int.from_bytes(rng.bytes(32), "little"), int.from_bytes(rng.bytes(32), "little")) for _ in range(7)]

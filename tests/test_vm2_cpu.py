@@ -257,19 +257,19 @@ def test_modmul_intrinsic_is_part_of_the_statement(tmp_path):
 
 def test_int256_intrinsic_is_part_of_the_statement(tmp_path):
     """A guest that runs the six 256-bit opcodes through the int256 intrinsic under an app with the bigint extension (25 chips): the
-    revealed words are Python's; every trace satisfies its AIR, every bus balances; a forged result word, or a call whose adapter
-    claims another opcode than the ecall passed, breaks a bus."""
+    revealed words are Python's; every trace satisfies its AIR, every bus balances; a forged result word, a comparison answered the
+    other way, or a call whose adapter claims another opcode than the ecall passed, breaks a bus."""
     words, data = int256_program(), int256_data()
     model = rv.run(words, b"", data=data)
     pv = bytes(model["pvs"])
     M = 1 << 256
     want = [[(b + c) % M, (b - c) % M, b ^ c, b | c, b & c, (b * c) % M][op] for op, (b, c) in enumerate(INT256_OPERANDS)]
     assert [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(6)] == [w & 0xFFFFFFFF for w in want]
-    assert [int.from_bytes(pv[24 + 4 * j:28 + 4 * j], "little") for j in range(2)] == [want[1] >> 224, want[5] >> 224]
+    assert [int.from_bytes(pv[24 + 4 * j:28 + 4 * j], "little") for j in range(2)] == [want[1] >> 224, (want[5] >> 224) ^ 0b110]   # sltu 0, slt 1, eq 1
     info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, (), True)
     assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"]
-    assert len(H.ids) == 25 and H.ids[-3:] == (v2.A_INT256, v2.A_INT256_IO, v2.A_MUL256)
-    assert sum(len(s["i256_ts"]) for s in segs) == 5 and sum(len(s["mul256_ts"]) for s in segs) == 1
+    assert len(H.ids) == 26 and H.ids[-4:] == (v2.A_INT256, v2.A_INT256_IO, v2.A_MUL256, v2.A_CMP256)
+    assert sum(len(s["i256_ts"]) for s in segs) == 5 and sum(len(s["mul256_ts"]) for s in segs) == 1 and sum(len(s["cmp256_ts"]) for s in segs) == 3
     for k, rec in enumerate(segs):
         inst = v2.segment_instance(rec, words, PC_BASE, H)
         for d in inst:
@@ -285,6 +285,12 @@ def test_int256_intrinsic_is_part_of_the_statement(tmp_path):
     rec["i256io_rows"].reshape(-1, v2.INT256_IO_WIDTH)[:24, 34] = 4        # the adapter of the first call claims opcode AND
     bad = v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
     assert 30 in bad and 31 in bad                                        # the request bus (ecall passed another opcode), the word bus
+    kc = next(i for i, s in enumerate(segs) if len(s["cmp256_ts"]))
+    inst = v2.segment_instance(segs[kc], words, PC_BASE, H)
+    pos = H.ids.index(v2.A_CMP256)
+    inst[pos]["trace"] = inst[pos]["trace"].copy()
+    inst[pos]["trace"][64, 0] ^= 1                                        # "2^256 - 5 < 77" answered yes
+    assert air.check_trace(inst[pos]["program"], inst[pos]["trace"], inst[pos]["pvs"]) != [] or v2.bus_imbalance(inst) != {}
     with pytest.raises(AssertionError, match="does not enable the bigint extension"):
         v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)
 
@@ -324,7 +330,7 @@ def test_ecc_intrinsic_is_part_of_the_statement(tmp_path):
 
 
 def test_all_extensions_of_the_chunk_circuit_in_one_statement(tmp_path):
-    """The chip set the reference's chunk-circuit configuration asks for (keccak, sha2, bigint, six moduli, three curves: 47 chips) and a
+    """The chip set the reference's chunk-circuit configuration asks for (keccak, sha2, bigint, six moduli, three curves: 48 chips) and a
     guest that uses all five intrinsics: SHA3-256 and SHA-256 of one message are hashlib's, the secp256k1 field product, the 256-bit
     difference and the doubled generator Python's; every trace satisfies its AIR and every bus balances."""
     import hashlib
@@ -338,7 +344,7 @@ def test_all_extensions_of_the_chunk_circuit_in_one_statement(tmp_path):
     two_g_x = 0xC6047F9441ED7D6D3045406E95C07CD85C778E4B8CEF3CA7ABAC09B95C709EE5   # 2 G of secp256k1 (published)
     assert int.from_bytes(pv[28:32], "little") == (((5 - 7) % (1 << 256)) >> 224) ^ (two_g_x & 0xFFFFFFFF)
     info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 5, 7, CHUNK_CIRCUIT_MODULI, True, curves)
-    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"] and len(H.ids) == 47
+    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"] and len(H.ids) == 48
     for k, rec in enumerate(segs):
         inst = v2.segment_instance(rec, words, PC_BASE, H)
         for d in inst:

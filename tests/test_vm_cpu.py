@@ -88,15 +88,21 @@ def sha256_data(msg):
 
 
 def int256_program():
-    """256-bit words through the int256 intrinsic (a7 = 6, a1 = opcode): six buffers (b, c, result slot) at the data base, one per
-    opcode (add, sub, xor, or, and, mul; int256_data); the six results' low words and two high words (sub, mul) are revealed."""
+    """256-bit words through the int256 intrinsic (a7 = 6, a1 = opcode): nine buffers (b, c, result slot) at the data base, one per
+    opcode (add, sub, xor, or, and, mul, then the comparisons b < c unsigned, b < c signed, b == c; int256_data); the six results' low
+    words and two high words (sub, mul) are revealed, the three comparison bits folded into the last one."""
     p = rv.li(S0, 0x00400000)
-    for op in range(6):
+    for op in range(9):
         p += [("addi", A0, S0, 96 * op), ("addi", A1, 0, op), ("addi", A7, 0, 6), ("ecall",)]
+    p += [("lw", T1, S0, 96 * 6 + 64), ("lw", T2, S0, 96 * 7 + 64), ("slli", T2, T2, 1), ("or", T1, T1, T2), ("lw", T2, S0, 96 * 8 + 64), ("slli", T2, T2, 2),
+          ("or", T1, T1, T2)]
     for k in range(6):
         p += [("lw", A0, S0, 96 * k + 64), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
     for j, k in enumerate((1, 5)):
-        p += [("lw", A0, S0, 96 * k + 64 + 28), ("addi", A1, 0, 6 + j), ("addi", A7, 0, 1), ("ecall",)]
+        p += [("lw", A0, S0, 96 * k + 64 + 28)]
+        if k == 5:
+            p += [("xor", A0, A0, T1)]
+        p += [("addi", A1, 0, 6 + j), ("addi", A7, 0, 1), ("ecall",)]
     p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
     return rv.assemble(p)
 
@@ -106,8 +112,12 @@ INT256_OPERANDS = [((1 << 256) - 5, 77), (3, 0xFFFF_FFFF_FFFF_FFFF_FFFF), (0x012
                    (0xFEDCBA9876543210FEDCBA9876543210FEDCBA98, 0x123456789ABCDEF0123456789ABCDEF0123456789)]
 
 
+# sltu: 2^256 - 5 < 77 is false; slt: -5 < 77 is true; eq: true
+INT256_CMP_OPERANDS = [((1 << 256) - 5, 77), ((1 << 256) - 5, 77), (0x1234 << 200 | 99, 0x1234 << 200 | 99)]
+
+
 def int256_data():
-    return b"".join(int(b).to_bytes(32, "little") + int(c).to_bytes(32, "little") + bytes(32) for b, c in INT256_OPERANDS)
+    return b"".join(int(b).to_bytes(32, "little") + int(c).to_bytes(32, "little") + bytes(32) for b, c in INT256_OPERANDS + INT256_CMP_OPERANDS)
 
 
 # the six moduli of the reference's chunk circuit, in its order (crates/circuits/chunk-circuit/openvm.toml:20-28): bn254 p, bn254 r,

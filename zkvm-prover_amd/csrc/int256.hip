@@ -93,6 +93,49 @@ __global__ __launch_bounds__(256) void k_mul256_trace(const uint32_t* __restrict
     if (width > i2::MUL_WIDTH) put(i2::MUL_COL_TS, ts ? ts[row] % P : 0u);
 }
 
+// 256-bit comparison chip: record = op | b[8] | c[8] (op 6 sltu, 7 slt, 8 eq); the row's 34 lookups are counted in the same pass
+__global__ __launch_bounds__(256) void k_cmp256_trace(const uint32_t* __restrict__ recs, const uint32_t* __restrict__ ts, size_t n, size_t N, size_t width,
+                                                      uint32_t* __restrict__ trace, uint32_t* __restrict__ bitwise_range, uint32_t* __restrict__ bad) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    if (row >= n) {
+        for (size_t c = 0; c < width; c++) trace[c * N + row] = 0u;
+        return;
+    }
+    const uint32_t op = recs[17 * row];
+    if (op < i2::OP_SLTU || op > i2::OP_EQ) atomicAdd(bad, 1u);
+    uint32_t b[8], c[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) b[i] = recs[17 * row + 1 + i], c[i] = recs[17 * row + 9 + i];
+    auto byte_of = [](const uint32_t* w, int i) -> uint32_t { return (w[i >> 2] >> (8 * (i & 3))) & 255u; };
+    auto put = [&](size_t col, uint32_t v) { trace[col * N + row] = to_monty(v); };
+    auto put_signed = [&](size_t col, int v) { trace[col * N + row] = to_monty(v < 0 ? P - (uint32_t)(-v) : (uint32_t)v); };
+    const bool is_signed = op == i2::OP_SLT;
+    auto limb = [&](const uint32_t* w, int i) -> int {   // the top limb as a signed byte for SLT
+        const int v = (int)byte_of(w, i);
+        return i == 31 && is_signed && v >= 128 ? v - 256 : v;
+    };
+    int mark = -1;
+    for (int i = 31; i >= 0; i--)
+        if (limb(b, i) != limb(c, i)) {
+            mark = i;
+            break;
+        }
+    const bool lt = mark >= 0 && limb(b, mark) < limb(c, mark);
+    const uint32_t diff = mark < 0 ? 0u : (uint32_t)(lt ? limb(c, mark) - limb(b, mark) : limb(b, mark) - limb(c, mark));
+    for (int i = 0; i < 32; i++) {
+        put(i2::CMP_COL_B + i, byte_of(b, i)), put(i2::CMP_COL_C + i, byte_of(c, i)), put(i2::CMP_COL_MARK + i, i == mark ? 1u : 0u);
+        if (!(i & 1)) hist_add(bitwise_range, byte_of(b, i) * 256 + byte_of(b, i + 1)), hist_add(bitwise_range, byte_of(c, i) * 256 + byte_of(c, i + 1));
+    }
+    put(i2::CMP_COL_T, lt ? 1u : 0u), put(i2::CMP_COL_DIFF, diff);
+    put_signed(i2::CMP_COL_BMSB, limb(b, 31)), put_signed(i2::CMP_COL_CMSB, limb(c, 31));
+    const uint32_t shift = is_signed ? 128u : 0u;
+    hist_add(bitwise_range, ((uint32_t)(limb(b, 31) + (int)shift) & 255u) * 256 + ((uint32_t)(limb(c, 31) + (int)shift) & 255u));
+    if (mark >= 0) hist_add(bitwise_range, ((diff - 1u) & 255u) * 256);
+    put(i2::CMP_COL_FLAGS, op == i2::OP_SLTU ? 1u : 0u), put(i2::CMP_COL_FLAGS + 1, op == i2::OP_SLT ? 1u : 0u), put(i2::CMP_COL_FLAGS + 2, op == i2::OP_EQ ? 1u : 0u);
+    if (width > i2::CMP_WIDTH) put(i2::CMP_COL_TS, ts ? ts[row] % P : 0u);
+}
+
 std::mutex g_mu;
 std::map<uint32_t, std::vector<uint32_t>> g_programs;   // bitwise bus -> program
 
@@ -151,6 +194,23 @@ int mul_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t rec_stride, s
 }
 
 std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> g_mul_programs;   // (bitwise bus, tuple bus) -> program
+std::map<uint32_t, std::vector<uint32_t>> g_cmp_programs;   // bitwise bus -> program
+
+int cmp_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_ts, size_t n, unsigned log_height, size_t width, uint32_t* d_trace,
+                 uint32_t* d_bitwise_trace, const char* what) {
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, what);
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const unsigned bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
+    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);   // the range column of the 8-bit table
+    hipLaunchKernelGGL(k_cmp256_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, d_ts, n, N, width, d_trace, d_bitwise_trace, (uint32_t*)flag);
+    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return tracegen_finish(ctx, flag, std::string(what) + " (an opcode that is not a comparison)");
+}
 
 }  // namespace
 }  // namespace zk
@@ -162,8 +222,11 @@ extern "C" {
 int zkhip_int256_alu_air(uint32_t bitwise_bus, zkhip_air* out) { return out ? air_of(bitwise_bus, out) : ZKHIP_ERR_INVALID; }
 
 int zkhip_int256_alu_host(uint32_t op, const uint32_t b[8], const uint32_t c[8], uint32_t a[8]) {
-    if (!a || !b || !c || op > i2::OP_MUL) return ZKHIP_ERR_INVALID;
-    if (op == i2::OP_MUL) i2::mul256(b, c, a);
+    if (!a || !b || !c || op > i2::OP_EQ) return ZKHIP_ERR_INVALID;
+    if (op >= i2::OP_SLTU) {
+        for (int i = 1; i < 8; i++) a[i] = 0;
+        a[0] = i2::cmp256(op, b, c);
+    } else if (op == i2::OP_MUL) i2::mul256(b, c, a);
     else i2::alu256(op, b, c, a);
     return ZKHIP_OK;
 }
@@ -199,6 +262,37 @@ int zkhip_vm_mul256_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const ui
     ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_trace || !d_bitwise_trace || !d_tuple_counts || log_height > 24 || (n && (!d_records || !d_ts))) return ZKHIP_ERR_INVALID;
     return mul_tracegen(ctx, d_records, 17, 1, d_ts, n, log_height, i2::MUL_VM_WIDTH, d_trace, d_bitwise_trace, d_tuple_counts, size_x, size_y, "vm_mul256_tracegen");
+}
+
+int zkhip_int256_cmp_air(uint32_t bitwise_bus, zkhip_air* out) {
+    if (!out) return ZKHIP_ERR_INVALID;
+    try {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_cmp_programs.find(bitwise_bus);
+        if (it == g_cmp_programs.end()) {
+            zkhip::air::AirBuilder b(i2::CMP_WIDTH, 0);
+            (void)i2::cmp256_air(b, bitwise_bus);
+            it = g_cmp_programs.emplace(bitwise_bus, b.program()).first;
+        }
+        out->program = it->second.data(), out->program_len = it->second.size(), out->log_height = 0, out->width = i2::CMP_WIDTH, out->n_pvs = 0;
+        out->prep_trace = nullptr, out->prep_commit = nullptr;
+    } catch (const std::exception&) {
+        return ZKHIP_ERR_INVALID;
+    }
+    return ZKHIP_OK;
+}
+
+int zkhip_int256_cmp_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 24 || (n && !d_records)) return ZKHIP_ERR_INVALID;
+    return cmp_tracegen(ctx, d_records, nullptr, n, log_height, i2::CMP_WIDTH, d_trace, d_bitwise_trace, "int256_cmp_tracegen");
+}
+
+int zkhip_vm_cmp256_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_ts, size_t n, unsigned log_height, uint32_t* d_trace,
+                             uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 24 || (n && (!d_records || !d_ts))) return ZKHIP_ERR_INVALID;
+    return cmp_tracegen(ctx, d_records, d_ts, n, log_height, i2::CMP_VM_WIDTH, d_trace, d_bitwise_trace, "vm_cmp256_tracegen");
 }
 
 int zkhip_int256_alu_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
