@@ -705,6 +705,14 @@ int zkhip_int256_cmp_air(uint32_t bitwise_bus, zkhip_air *out);
 int zkhip_int256_cmp_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
 int zkhip_vm_cmp256_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height, uint32_t *d_trace,
                              uint32_t *d_bitwise_trace);
+/* 256-bit shift chip (b << / >> / >>arithmetic (c mod 256); 189 columns; 66 lookups per row in the 8-bit bitwise table, SRA's sign bit in
+ * its XOR column: d_bitwise_trace = both multiplicity columns, 2 x 65536): d_records: n x 17 words (op | b[8] | c[8], op 9 sll, 10 srl,
+ * 11 sra); zkhip_int256_alu_host accepts ops 9..11 for it; inside the VM 190 columns (+ the timestamp) */
+#define ZKHIP_INT256_SHIFT_WIDTH 189
+int zkhip_int256_shift_air(uint32_t bitwise_bus, zkhip_air *out);
+int zkhip_int256_shift_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
+int zkhip_vm_shift256_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height, uint32_t *d_trace,
+                               uint32_t *d_bitwise_trace);
 /* the chip inside the VM (102 columns: + the timestamp of call i on row i) */
 int zkhip_vm_int256_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height, uint32_t *d_trace,
                              uint32_t *d_bitwise_trace);

@@ -168,6 +168,108 @@ inline uint32_t cmp256(uint32_t op, const uint32_t b[8], const uint32_t c[8]) {
     if (op == OP_SLT && ((b[7] ^ c[7]) >> 31)) return b[7] >> 31;   // different signs: the negative one is smaller
     return lt ? 1u : 0u;
 }
+// ---- 256-bit shifts (OpenVM's Rv32Shift256: SLL / SRL / SRA by c mod 256) -- a chip of its own, in two steps per row:
+//   shift amount   c0 = bit_shift + 8 limb_shift with one-hot markers bm[8], lm[32] (c0, c1 looked up as bytes: the low half word of c
+//                  splits uniquely; the other halves of c only pass through to the bus); mult = 2^bit_shift = sum bm_i 2^i
+//   bit step       t = b shifted by bit_shift bits, limb by limb with carries cy_k < mult (looked up as (cy_k, mult - 1 - cy_k)):
+//                    left :  t_k + 256 cy_k = b_k mult + cy_{k-1}                          (the carry out of limb 31 is dropped)
+//                    right:  t'_m mult + cy_m = b_m + 256 cy_{m+1},  cy_32 = sign (mult - 1)   (sign = b's top bit for SRA, else 0)
+//                  a right shift stores t' REVERSED (column k holds t'_{31-k}): then both directions select limbs the same way
+//   limb step      [left] a_i, [right] a_{31-i}  =  sum_{j <= i} lm_j t_{i-j}  +  [right] 255 sign (sum_{j > i} lm_j)
+// so every product lm_j t_k occurs once (OpenVM's chip spells out all 32 x 32 (limb shift, limb) cases for both directions).
+// Columns: a[32] | b[32] | t[32] | cy[32] | c0 c1 c_hi0 | c words 1..7 as halves [14] | bm[8] | lm[32] | sign | is_sll is_srl is_sra   189
+// Lookups: 32 carries, t and b pairwise (the limb equations need honest bytes; a inherits from t), (c0, c1), the sign bit of b_31 as the
+// XOR (b_31, 128, b_31 + 128 - 256 sign) for SRA.  Degree 3.
+constexpr uint32_t OP_SLL = 9, OP_SRL = 10, OP_SRA = 11, N_INT256_OPS = 12;
+constexpr size_t SH_COL_A = 0, SH_COL_B = 32, SH_COL_T = 64, SH_COL_CY = 96, SH_COL_C0 = 128, SH_COL_C1 = 129, SH_COL_CHI0 = 130, SH_COL_CW = 131, SH_COL_BM = 145,
+                 SH_COL_LM = 153, SH_COL_SIGN = 185, SH_COL_FLAGS = 186, SH_WIDTH = 189;
+inline void shift256_air(AirBuilder& b, uint32_t bitwise_bus) {
+    const Expr sll = b.var(SH_COL_FLAGS), srl = b.var(SH_COL_FLAGS + 1), sra = b.var(SH_COL_FLAGS + 2), real = sll + srl + sra, right = srl + sra;
+    const Expr sign = b.var(SH_COL_SIGN), zero = b.constant(0), one = b.constant(1);
+    for (const Expr& f : {sll, srl, sra, real, sign}) b.assert_zero(f * (f - 1));
+    b.assert_zero(sign * (1 - sra));
+    Expr sbm = b.var(SH_COL_BM), mult = b.var(SH_COL_BM), amount = b.var(SH_COL_BM + 1), slm = b.var(SH_COL_LM);
+    b.assert_zero(b.var(SH_COL_BM) * (b.var(SH_COL_BM) - 1));
+    b.assert_zero(b.var(SH_COL_LM) * (b.var(SH_COL_LM) - 1));
+    for (size_t i = 1; i < 8; i++) {
+        const Expr m = b.var(SH_COL_BM + i);
+        b.assert_zero(m * (m - 1));
+        sbm = sbm + m, mult = mult + m * (int64_t)(1 << i);
+        if (i > 1) amount = amount + m * (int64_t)i;
+    }
+    for (size_t j = 1; j < LIMBS; j++) {
+        const Expr m = b.var(SH_COL_LM + j);
+        b.assert_zero(m * (m - 1));
+        slm = slm + m, amount = amount + m * (int64_t)(8 * j);
+    }
+    b.assert_zero(sbm - real);
+    b.assert_zero(slm - real);
+    b.assert_zero(b.var(SH_COL_C0) - amount);
+    auto cy = [&](size_t k) { return b.var(SH_COL_CY + k); };
+    auto t = [&](size_t k) { return b.var(SH_COL_T + k); };
+    // bit step
+    for (size_t k = 0; k < LIMBS; k++) {
+        Expr left = t(k) + cy(k) * 256 - b.var(SH_COL_B + k) * mult;
+        if (k > 0) left = left - cy(k - 1);
+        const size_t m = LIMBS - 1 - k;
+        const Expr in = k == 0 ? sign * (mult - 1) : cy(m + 1);
+        const Expr rgt = t(k) * mult + cy(m) - b.var(SH_COL_B + m) - in * 256;
+        b.assert_zero(sll * left + right * rgt);
+    }
+    // limb step (from the top: the sums of the markers above limb i grow one term at a time)
+    const Expr fill = right * sign * 255;
+    Expr above = b.constant(0);
+    bool any_above = false;
+    for (size_t ii = LIMBS; ii-- > 0;) {
+        Expr sel = b.var(SH_COL_LM) * t(ii);
+        for (size_t j = 1; j <= ii; j++) sel = sel + b.var(SH_COL_LM + j) * t(ii - j);
+        Expr rhs = sel;
+        if (any_above) rhs = rhs + fill * above;
+        b.assert_zero(sll * b.var(SH_COL_A + ii) + right * b.var(SH_COL_A + LIMBS - 1 - ii) - rhs);
+        above = any_above ? above + b.var(SH_COL_LM + ii) : b.var(SH_COL_LM + ii);
+        any_above = true;
+    }
+    for (size_t k = 0; k < LIMBS; k++) b.push_interaction(bitwise_bus, {cy(k), mult - 1 - cy(k), zero, zero}, real, Kind::Send);
+    for (size_t base : {SH_COL_T, SH_COL_B})
+        for (size_t i = 0; i < LIMBS; i += 2) b.push_interaction(bitwise_bus, {b.var(base + i), b.var(base + i + 1), zero, zero}, real, Kind::Send);
+    b.push_interaction(bitwise_bus, {b.var(SH_COL_C0), b.var(SH_COL_C1), zero, zero}, real, Kind::Send);
+    const Expr top = b.var(SH_COL_B + LIMBS - 1);
+    b.push_interaction(bitwise_bus, {top, b.constant(128), top + 128 - sign * 256, one}, sra, Kind::Send);
+}
+// inside the VM: + a timestamp column; the call's 24 words arrive on the ALU chip's word bus with the shift's opcode
+constexpr size_t SH_COL_TS = SH_WIDTH, SH_VM_WIDTH = SH_WIDTH + 1;
+inline void shift256_vm_air(AirBuilder& b, uint32_t bitwise_bus, uint32_t word_bus) {
+    shift256_air(b, bitwise_bus);
+    const Expr ts = b.var(SH_COL_TS), sll = b.var(SH_COL_FLAGS), srl = b.var(SH_COL_FLAGS + 1), sra = b.var(SH_COL_FLAGS + 2), real = sll + srl + sra;
+    const Expr op = sll * (int64_t)OP_SLL + srl * (int64_t)OP_SRL + sra * (int64_t)OP_SRA;
+    auto word = [&](size_t base, size_t k, Expr* lo, Expr* hi) { *lo = b.var(base + 4 * k) + b.var(base + 4 * k + 1) * 256, *hi = b.var(base + 4 * k + 2) + b.var(base + 4 * k + 3) * 256; };
+    for (size_t k = 0; k < 8; k++) {
+        Expr lo, hi;
+        word(SH_COL_B, k, &lo, &hi);
+        b.push_interaction(word_bus, {ts, b.constant((uint32_t)k), lo, hi, op}, real, Kind::Receive);
+        if (k == 0) lo = b.var(SH_COL_C0) + b.var(SH_COL_C1) * 256, hi = b.var(SH_COL_CHI0);
+        else lo = b.var(SH_COL_CW + 2 * (k - 1)), hi = b.var(SH_COL_CW + 2 * (k - 1) + 1);
+        b.push_interaction(word_bus, {ts, b.constant((uint32_t)(8 + k)), lo, hi, op}, real, Kind::Receive);
+        word(SH_COL_A, k, &lo, &hi);
+        b.push_interaction(word_bus, {ts, b.constant((uint32_t)(16 + k)), lo, hi, op}, real, Kind::Receive);
+    }
+}
+// a <- b shifted by c mod 256 (host)
+inline void shift256(uint32_t op, const uint32_t b[8], const uint32_t c[8], uint32_t a[8]) {
+    const unsigned s = c[0] & 255u, ws = s / 32, bs = s % 32;
+    const uint32_t fill = op == OP_SRA && (b[7] >> 31) ? 0xffffffffu : 0u;
+    for (int i = 0; i < 8; i++) {
+        if (op == OP_SLL) {
+            const int k = i - (int)ws;
+            const uint32_t lo = k >= 0 ? b[k] : 0u, below = k - 1 >= 0 ? b[k - 1] : 0u;
+            a[i] = bs ? (lo << bs) | (below >> (32 - bs)) : lo;
+        } else {
+            const unsigned k = (unsigned)i + ws;
+            const uint32_t lo = k < 8 ? b[k] : fill, up = k + 1 < 8 ? b[k + 1] : fill;
+            a[i] = bs ? (lo >> bs) | (up << (32 - bs)) : lo;
+        }
+    }
+}
 inline void mul256(const uint32_t b[8], const uint32_t c[8], uint32_t a[8]) {
     uint32_t t[8] = {};
     for (int i = 0; i < 8; i++) {

@@ -468,15 +468,17 @@ private:
                     memcpy(p + 64, r.w, 32);
                 } else if (call == 6) {
                     // a = b op c on the 24 words at a0 (b[8] | c[8] | a[8], little-endian 256-bit words), op = a1: 0 add, 1 sub, 2 xor,
-                    // 3 or, 4 and, 5 mul, 6 sltu, 7 slt, 8 eq (OpenVM's bigint extension)
+                    // 3 or, 4 and, 5 mul, 6 sltu, 7 slt, 8 eq, 9 sll, 10 srl, 11 sra (OpenVM's bigint extension)
                     if (rec && log_memory_) throw Error("the int256 intrinsic is proven by the one-statement flow only");
                     const uint32_t addr = reg_read(rec, 10), op = reg_read(rec, 11);
-                    if (op > zkhip::int256::OP_EQ) throw Error("int256: unknown opcode " + std::to_string(op));
+                    if (op >= zkhip::int256::N_INT256_OPS) throw Error("int256: unknown opcode " + std::to_string(op));
                     if (addr & 3u) throw Error("int256 buffer must be word-aligned");
                     uint8_t* p = at(addr, 96);
                     uint32_t b[8], c[8], a[8];
                     memcpy(b, p, 32), memcpy(c, p + 32, 32);
-                    if (op >= zkhip::int256::OP_SLTU) {
+                    if (op >= zkhip::int256::OP_SLL) {
+                        zkhip::int256::shift256(op, b, c, a);
+                    } else if (op >= zkhip::int256::OP_SLTU) {
                         memset(a, 0, sizeof a);
                         a[0] = zkhip::int256::cmp256(op, b, c);
                     } else if (op == zkhip::int256::OP_MUL) zkhip::int256::mul256(b, c, a);

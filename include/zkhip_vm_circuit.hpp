@@ -21,16 +21,16 @@
 //                  modular (a7 = 5: r = a b, a + b or a - b mod P_i on the 24 words at a0 -- a, b, then the result's slot; a1 = i + 8 op:
 //                  i the index of one of the moduli the app's openvm.toml lists, op 0 mul, 1 add, 2 sub; OpenVM's modular extension).
 //                  int256 (a7 = 6: a = b op c on the 24 words at a0 -- b, c, then the result's slot; a1 = op: 0 add, 1 sub, 2 xor, 3 or,
-//                  4 and, 5 mul, 6 b < c unsigned, 7 b < c signed, 8 b == c; 256-bit words, arithmetic modulo 2^256; OpenVM's bigint
-//                  extension).
+//                  4 and, 5 mul, 6 b < c unsigned, 7 b < c signed, 8 b == c, 9 / 10 / 11 b shifted left / right / right arithmetically by
+//                  c mod 256; 256-bit words, arithmetic modulo 2^256; OpenVM's bigint extension).
 //                  ecc (a7 = 7: (x3, y3) = (x1, y1) + (x2, y2) or the double of (x1, y1) on the 48 words at a0 -- the two operands, then
 //                  the result's slot; a1 = i + 8 op: i the index of one of the curves the app's openvm.toml lists, op 0 add (x1 != x2),
 //                  1 double; OpenVM's ecc extension).
 //   ecc adapter    one per curve, one row per WORD of a call (48 rows): operands read, result written; (timestamp, index, halves, op)
 //                  goes to that curve's point chip (include/zkhip_ecc.hpp, one operation per row).
 //   int256 adapter one row per WORD of a call (24 rows): b, c read, a written; (timestamp, index, halves, opcode) goes to the 256-bit ALU
-//                  chip or, for opcode 5, to the 256-bit multiplication chip, for 6..8 to the comparison chip (include/zkhip_int256.hpp,
-//                  one operation per row): all three listen on the word bus, each to its opcodes.
+//                  chip or, for opcode 5, to the 256-bit multiplication chip, for 6..8 to the comparison chip, for 9..11 to the shift
+//                  chip (include/zkhip_int256.hpp, one operation per row): all four listen on the word bus, each to its opcodes.
 //   modular adapter one per modulus, one row per WORD of a call (24 rows): a, b read, r written; (timestamp, index, halves) goes to that
 //                  modulus's multiplication chip (include/zkhip_modular.hpp, one multiplication per row).
 //   sha256 adapter one row per WORD of a call (24 rows): state words are read and replaced, message words read; (timestamp, index, limbs)
@@ -649,7 +649,7 @@ inline void connector_air(AirBuilder& b) {
 // ---- the segment's AIR set (order fixed: it is part of the verifying key) ----
 enum AirId : unsigned {
     A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
-    A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, A_INT256, A_INT256_IO, A_MUL256, A_CMP256, N_STATIC_AIRS
+    A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, A_INT256, A_INT256_IO, A_MUL256, A_CMP256, A_SHIFT256, N_STATIC_AIRS
 };
 // the modular extension brings two chips per configured modulus (openvm.toml `supported_moduli`): ids A_MODMUL(i), A_MODMUL_IO(i)
 constexpr unsigned MAX_MODULI = 8, MAX_CURVES = 4, N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES;
@@ -708,6 +708,7 @@ inline AirShape build_air(unsigned id) {
         case A_INT256_IO: make(INT256_IO_WIDTH, 0, 0, int256_io_air); break;
         case A_MUL256: make(int256::MUL_VM_WIDTH, 0, 0, [](AirBuilder& b) { int256::mul256_vm_air(b, BITWISE_BUS, RANGE_TUPLE_BUS, INT256_WORD_BUS); }); break;
         case A_CMP256: make(int256::CMP_VM_WIDTH, 0, 0, [](AirBuilder& b) { int256::cmp256_vm_air(b, BITWISE_BUS, INT256_WORD_BUS); }); break;
+        case A_SHIFT256: make(int256::SH_VM_WIDTH, 0, 0, [](AirBuilder& b) { int256::shift256_vm_air(b, BITWISE_BUS, INT256_WORD_BUS); }); break;
         default:
             if (id >= A_ALU && id <= A_JALR) {
                 const uint32_t cls = id - A_ALU;

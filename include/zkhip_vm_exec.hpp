@@ -123,8 +123,8 @@ struct SegmentCaps {
             c.log_height[vmc::A_SHA256] = std::max(log_sha256, 7u), c.log_height[vmc::A_SHA256_IO] = c.log_height[vmc::A_SHA256] - 1;       // 24 adapter rows per 65 chip rows
         }
         if (log_int256) {
-            c.ids.push_back(vmc::A_INT256), c.ids.push_back(vmc::A_INT256_IO), c.ids.push_back(vmc::A_MUL256), c.ids.push_back(vmc::A_CMP256);
-            c.log_height[vmc::A_INT256] = c.log_height[vmc::A_MUL256] = c.log_height[vmc::A_CMP256] = std::max(log_int256, 1u);
+            c.ids.push_back(vmc::A_INT256), c.ids.push_back(vmc::A_INT256_IO), c.ids.push_back(vmc::A_MUL256), c.ids.push_back(vmc::A_CMP256), c.ids.push_back(vmc::A_SHIFT256);
+            c.log_height[vmc::A_INT256] = c.log_height[vmc::A_MUL256] = c.log_height[vmc::A_CMP256] = c.log_height[vmc::A_SHIFT256] = std::max(log_int256, 1u);
             c.log_height[vmc::A_INT256_IO] = c.log_height[vmc::A_INT256] + 6;   // 24 adapter rows per call of either chip
         }
         if (moduli.size() > vmc::MAX_MODULI) throw Error("at most " + std::to_string(vmc::MAX_MODULI) + " moduli");
@@ -158,6 +158,7 @@ struct SegmentRecords {
     std::vector<uint32_t> i256_records, i256_ts, i256io_rows;   // int256 calls: op | b | c (17 words) and the timestamp per call; the adapter's rows
     std::vector<uint32_t> mul256_records, mul256_ts;            // ... those with opcode 5: the multiplication chip's
     std::vector<uint32_t> cmp256_records, cmp256_ts;            // ... those with opcodes 6..8: the comparison chip's
+    std::vector<uint32_t> sh256_records, sh256_ts;              // ... those with opcodes 9..11: the shift chip's
     // modular calls per modulus: op | a | b (17 words) and the timestamp per call; the adapter's rows
     std::vector<uint32_t> mm_records[vmc::MAX_MODULI], mm_ts[vmc::MAX_MODULI], mmio_rows[vmc::MAX_MODULI];
     // ecc calls per curve: op | x1 y1 x2 y2 | slope (41 words) and the timestamp per call; the adapter's rows
@@ -174,7 +175,7 @@ struct SegmentRecords {
     void clear() {
         core.clear();
         for (auto* v : {&f_x, &f_y, &f_z, &f_rdprev, &f_pcinc, &f_pts1, &f_pts2, &f_pts3, &ls_ts, &ls_base, &ls_imm, &ls_pts, &ecall_rows, &leaf_rows, &merkle_rows,
-                        &p2_inputs, &kk_states, &kk_ts, &kio_rows, &sha_blocks, &sha_ts, &shaio_rows, &i256_records, &i256_ts, &i256io_rows, &mul256_records, &mul256_ts, &cmp256_records, &cmp256_ts})
+                        &p2_inputs, &kk_states, &kk_ts, &kio_rows, &sha_blocks, &sha_ts, &shaio_rows, &i256_records, &i256_ts, &i256io_rows, &mul256_records, &mul256_ts, &cmp256_records, &cmp256_ts, &sh256_records, &sh256_ts})
             v->clear();
         for (unsigned i = 0; i < vmc::MAX_MODULI; i++) mm_records[i].clear(), mm_ts[i].clear(), mmio_rows[i].clear();
         for (unsigned i = 0; i < vmc::MAX_CURVES; i++) ec_records[i].clear(), ec_ts[i].clear(), ecio_rows[i].clear();
@@ -278,7 +279,7 @@ public:
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 4 && 65 * (r.n_sha256() + 1) > caps_.rows(vmc::A_SHA256)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 5 && r.mm_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_MODMUL(m_.reg(11) & 7u))) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 7 && r.ec_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_EC(m_.reg(11) & 7u))) ||
-                (d.cls == vmc::C_ECALL && m_.reg(17) == 6 && (m_.reg(11) == 5 ? r.mul256_ts.size() : m_.reg(11) > 5 ? r.cmp256_ts.size() : r.i256_ts.size()) + 1 > caps_.rows(vmc::A_INT256)) ||
+                (d.cls == vmc::C_ECALL && m_.reg(17) == 6 && (m_.reg(11) == 5 ? r.mul256_ts.size() : m_.reg(11) > 8 ? r.sh256_ts.size() : m_.reg(11) > 5 ? r.cmp256_ts.size() : r.i256_ts.size()) + 1 > caps_.rows(vmc::A_INT256)) ||
                 path_nodes_.size() + new_nodes > caps_.rows(vmc::A_MERKLE) ||
                 2 * (blk_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
                 if (r.n_instr == 0) throw Error("segment heights too small for a single instruction");
@@ -365,8 +366,8 @@ public:
                     row[31] = 1, row[28] = (y & 255u) >> 2, row[17] = a1;
                     auto gap3 = [&](uint32_t* dst, uint32_t pts, uint32_t at) { dst[0] = pts, dst[1] = (at - pts - 1) & 0xffffu, dst[2] = (at - pts - 1) >> 16; };
                     gap3(row + 21, read_word(1, 11, a1, ts + 4), ts + 4);
-                    auto& recs = a1 == 5 ? r.mul256_records : a1 > 5 ? r.cmp256_records : r.i256_records;
-                    (a1 == 5 ? r.mul256_ts : a1 > 5 ? r.cmp256_ts : r.i256_ts).push_back(ts);
+                    auto& recs = a1 == 5 ? r.mul256_records : a1 > 8 ? r.sh256_records : a1 > 5 ? r.cmp256_records : r.i256_records;
+                    (a1 == 5 ? r.mul256_ts : a1 > 8 ? r.sh256_ts : a1 > 5 ? r.cmp256_ts : r.i256_ts).push_back(ts);
                     recs.push_back(a1);
                     recs.insert(recs.end(), mm_in, mm_in + 16);
                     for (uint32_t k = 0; k < 24; k++) {   // the adapter's rows: b, c read, a written, all at ts + 5

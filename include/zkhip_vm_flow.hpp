@@ -190,6 +190,7 @@ public:
             check(zkhip_rows_tracegen(ctx_, up(r.i256io_rows), r.i256io_rows.size() / vmc::INT256_IO_WIDTH, vmc::INT256_IO_WIDTH, H(vmc::A_INT256_IO), T(vmc::A_INT256_IO), nullptr));
             check(zkhip_vm_mul256_tracegen(ctx_, up(r.mul256_records), up(r.mul256_ts), r.mul256_ts.size(), H(vmc::A_MUL256), T(vmc::A_MUL256), d_bw, d_tup, TUPLE_X, TUPLE_Y));
             check(zkhip_vm_cmp256_tracegen(ctx_, up(r.cmp256_records), up(r.cmp256_ts), r.cmp256_ts.size(), H(vmc::A_CMP256), T(vmc::A_CMP256), d_bw));
+            check(zkhip_vm_shift256_tracegen(ctx_, up(r.sh256_records), up(r.sh256_ts), r.sh256_ts.size(), H(vmc::A_SHIFT256), T(vmc::A_SHIFT256), d_bw));
         }
         for (unsigned i = 0; i < caps_.moduli.size(); i++) {   // modular extension: the chip's lookups are counted by its generator
             check(zkhip_vm_modmul_tracegen(ctx_, caps_.moduli[i].w, up(r.mm_records[i]), up(r.mm_ts[i]), r.mm_ts[i].size(), H(vmc::A_MODMUL(i)), T(vmc::A_MODMUL(i)), d_bw,

@@ -19,6 +19,7 @@ pub const ZKHIP_INT256_MUL_WIDTH: usize = 161;
 pub const ZKHIP_MODMUL_WIDTH: usize = 322;
 pub const ZKHIP_EC_WIDTH: usize = 772;
 pub const ZKHIP_INT256_CMP_WIDTH: usize = 103;
+pub const ZKHIP_INT256_SHIFT_WIDTH: usize = 189;
 pub const ZKHIP_EC_RECORD_WORDS: usize = 41;
 pub const ZKHIP_SHA256_WIDTH: usize = 433;
 pub const ZKHIP_SHA256_PREP_WIDTH: usize = 6;
@@ -365,6 +366,10 @@ extern "C" {
     pub fn zkhip_int256_cmp_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_vm_cmp256_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
                                     d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_int256_shift_air(bitwise_bus: u32, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_int256_shift_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_vm_shift256_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
+                                      d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_vm_mul256_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
                                     d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
     pub fn zkhip_ec_air(modulus: *const u8, a: *const u8, bitwise_bus: u32, tuple_bus: u32, out: *mut zkhip_air) -> c_int;

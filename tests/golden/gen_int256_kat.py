@@ -27,9 +27,18 @@ def main():
         cpairs += [(b, rnd_cmp.getrandbits(256)), (b, b ^ (1 << rnd_cmp.randrange(256))), (b, b)]
     cmp_cases = [{"op": op, "b": hex(b), "c": hex(c), "a": hex(int(b < c) if op == 6 else int(sgn(b) < sgn(c)) if op == 7 else int(b == c))}
                  for op in (6, 7, 8) for b, c in cpairs]
+    # shifts by c mod 256 (a generator of their own): 9 b << s, 10 b >> s, 11 arithmetic
+    rnd_sh = random.Random(20261004)
+    spairs = [(M - 1, 0), (M - 1, 1), (M - 1, 255), (1, 255), (1 << 255, 255), (1 << 255, 8), (1 << 255, 7), (0x80 << 248 | 0x55, 9), (0x7F << 248 | 0xAA, 9),
+              (M - 1, 256 + 4), (12345, (7 << 200) | 17), (0, 200)]
+    for _ in range(10):
+        b = rnd_sh.getrandbits(256)
+        spairs += [(b, rnd_sh.randrange(256)), (b | 1 << 255, rnd_sh.randrange(256)), (b, 8 * rnd_sh.randrange(32))]
+    sh = {9: lambda b, s: (b << s) % M, 10: lambda b, s: b >> s, 11: lambda b, s: (sgn(b) >> s) % M}
+    shift_cases = [{"op": op, "b": hex(b), "c": hex(c), "a": hex(sh[op](b, c % 256))} for op in (9, 10, 11) for b, c in spairs]
     with open(os.path.join(HERE, "int256_kat.json"), "w") as f:
         json.dump({"about": "a = (b op c) mod 2^256 from Python integers (generator: tests/golden/gen_int256_kat.py); op: 0 add 1 sub 2 xor 3 or 4 and 5 mul (low 256 bits)",
-                   "cases": cases, "cmp": cmp_cases}, f, indent=0)
+                   "cases": cases, "cmp": cmp_cases, "shift": shift_cases}, f, indent=0)
     print("wrote", len(cases), "cases")
 
 

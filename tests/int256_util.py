@@ -114,3 +114,65 @@ def cmp_instance(trace, bw, log_height):
     return [dict(program=program, log_height=log_height, width=width, n_pvs=0, trace=trace, pvs=NOPV),
             dict(program=air.bitwise_lookup_air(8, BITWISE_BUS).program(), log_height=16, width=2, n_pvs=0, trace=np.stack([bw, np.zeros(1 << 16, np.uint32)]), pvs=NOPV,
                  prep=air.bitwise_lookup_prep(8))]
+
+
+SH_WIDTH = 189
+
+
+def shift_result(op, b, c):
+    """Python's answer: op 9 b << s, 10 b >> s, 11 the arithmetic shift of b as a two's-complement 256-bit integer, s = c mod 256"""
+    s_, M = c % 256, 1 << 256
+    if op == 9:
+        return (b << s_) % M
+    if op == 10:
+        return b >> s_
+    return ((b - M if b >> 255 else b) >> s_) % M
+
+
+def shift_twin_trace(cases, log_height):
+    """the tests' twin of zkhip_int256_shift_tracegen for [(op, b, c)]: (trace [189, N] canonical, bitwise range counts, xor counts)"""
+    tr = np.zeros((SH_WIDTH, 1 << log_height), np.uint32)
+    bw, xc = np.zeros(1 << 16, np.uint32), np.zeros(1 << 16, np.uint32)
+    for row, (op, b, c) in enumerate(cases):
+        bl, cl = list(int(b).to_bytes(32, "little")), list(int(c).to_bytes(32, "little"))
+        amount = cl[0]
+        bs, ls, mult = amount & 7, amount >> 3, 1 << (amount & 7)
+        left = op == 9
+        sign = bl[31] >> 7 if op == 11 else 0
+        t, cy = [0] * 32, [0] * 32
+        if left:
+            carry = 0
+            for k in range(32):
+                v = bl[k] * mult + carry
+                t[k], carry = v & 255, v >> 8
+                cy[k] = carry
+        else:
+            inn = sign * (mult - 1)
+            for m in range(31, -1, -1):
+                v = bl[m] + 256 * inn
+                t[31 - m], cy[m] = v >> bs, v & (mult - 1)
+                inn = cy[m]
+        for i in range(32):
+            sel = t[i - ls] if i >= ls else (0 if left else 255 * sign)
+            tr[(i if left else 31 - i), row] = sel
+            tr[32 + i, row], tr[64 + i, row], tr[96 + i, row] = bl[i], t[i], cy[i]
+            bw[cy[i] * 256 + (mult - 1 - cy[i])] += 1
+        for i in range(0, 32, 2):
+            bw[t[i] * 256 + t[i + 1]] += 1
+            bw[bl[i] * 256 + bl[i + 1]] += 1
+        tr[128, row], tr[129, row], tr[130, row] = cl[0], cl[1], cl[2] + 256 * cl[3]
+        bw[cl[0] * 256 + cl[1]] += 1
+        for k in range(1, 8):
+            tr[131 + 2 * (k - 1), row], tr[132 + 2 * (k - 1), row] = cl[4 * k] + 256 * cl[4 * k + 1], cl[4 * k + 2] + 256 * cl[4 * k + 3]
+        tr[145 + bs, row], tr[153 + ls, row], tr[185, row] = 1, 1, sign
+        if op == 11:
+            xc[bl[31] * 256 + 128] += 1
+        tr[186 + (op - 9), row] = 1
+    return tr, bw, xc
+
+
+def shift_instance(trace, bw, xc, log_height):
+    program, width = z.int256_shift_air(BITWISE_BUS)
+    return [dict(program=program, log_height=log_height, width=width, n_pvs=0, trace=trace, pvs=NOPV),
+            dict(program=air.bitwise_lookup_air(8, BITWISE_BUS).program(), log_height=16, width=2, n_pvs=0, trace=np.stack([bw, xc]), pvs=NOPV,
+                 prep=air.bitwise_lookup_prep(8))]

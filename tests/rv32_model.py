@@ -309,11 +309,11 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
             elif call == 6:   # a = b op c modulo 2^256 on the 24 words at a0 (b | c | a), op = a1: add sub xor or and
                 off = rr(10) - data_base
                 op_ = rr(11)
-                assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem) and op_ < 9
+                assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem) and op_ < 12
                 b_, c_ = int.from_bytes(mem[off:off + 32], "little"), int.from_bytes(mem[off + 32:off + 64], "little")
                 sg = lambda v: v - (1 << 256) if v >> 255 else v  # noqa: E731
                 a_ = [(b_ + c_) % (1 << 256), (b_ - c_) % (1 << 256), b_ ^ c_, b_ | c_, b_ & c_, (b_ * c_) % (1 << 256), int(b_ < c_), int(sg(b_) < sg(c_)),
-                      int(b_ == c_)][op_]
+                      int(b_ == c_), (b_ << (c_ % 256)) % (1 << 256), b_ >> (c_ % 256), (sg(b_) >> (c_ % 256)) % (1 << 256)][op_]
                 mem[off + 64:off + 96] = a_.to_bytes(32, "little")
             elif call == 5:   # r = a b mod moduli[a1] on the 24 words at a0 (a | b | r, little-endian)
                 off = rr(10) - data_base

@@ -122,3 +122,33 @@ def test_device_comparison_trace_and_proof(zk, ora):
     with pytest.raises(Exception):
         zk.int256_cmp_tracegen(torch.from_numpy(iu.records([(2, 1, 2)]).reshape(-1).view(np.int32)).to(zk.device), 1, 1,
                                torch.zeros(2 << 16, dtype=torch.int32, device=zk.device))
+
+
+def test_device_shift_trace_and_proof(zk, ora):
+    """zkhip_int256_shift_tracegen == the tests' twin cell for cell and count for count (both columns of the bitwise table); the results are
+    Python's; the HIP proof of the chip with the bitwise table == the oracle's; a non-shift opcode is refused."""
+    kat = json.load(open(os.path.join(HERE, "golden", "int256_kat.json")))["shift"]
+    cases = [(c["op"], int(c["b"], 16), int(c["c"], 16)) for c in kat]
+    log_h = 7
+    recs = iu.records(cases).reshape(-1)
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(zk.device)
+    d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
+    d_tr = zk.int256_shift_tracegen(d_recs, len(cases), log_h, d_bw)
+    got = zk.download(d_tr).reshape(iu.SH_WIDTH, -1)
+    tr, bw, xc = iu.shift_twin_trace(cases, log_h)
+    assert (got == tr).all() and (zk.download(d_bw)[:1 << 16] == bw).all() and (zk.download(d_bw)[1 << 16:] == xc).all()
+    for row, c in enumerate(kat):
+        assert bytes(got[0:32, row].astype(np.uint8)) == int(c["a"], 16).to_bytes(32, "little")
+    inst = iu.shift_instance(got, bw, xc, log_h)
+    pk = z.ProvingKey(zk, PARAMS, inst)
+    pvs = [iu.NOPV] * 2
+    proof = pk.prove([d_tr, d_bw], pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, inst).tobytes()
+    bad_tr = d_tr.clone()
+    bad_tr[3 * (1 << log_h) + 1] ^= 1   # another result limb
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, pk.prove([bad_tr, d_bw], pvs)) != 0
+    pk.close()
+    with pytest.raises(Exception):
+        zk.int256_shift_tracegen(torch.from_numpy(iu.records([(6, 1, 2)]).reshape(-1).view(np.int32)).to(zk.device), 1, 1,
+                                 torch.zeros(2 << 16, dtype=torch.int32, device=zk.device))

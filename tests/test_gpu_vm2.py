@@ -78,6 +78,9 @@ def device_traces(zk, rec, prog, H):
         n_c = len(rec["cmp256_ts"])
         T[v2.A_CMP256] = zk.int256_cmp_tracegen(D(rec["cmp256_records"]) if n_c else None, n_c, H[v2.A_CMP256], d_bw,
                                                 t_ts=D(rec["cmp256_ts"]) if n_c else torch.zeros(1, dtype=torch.int32, device=dev))
+        n_s = len(rec["sh256_ts"])
+        T[v2.A_SHIFT256] = zk.int256_shift_tracegen(D(rec["sh256_records"]) if n_s else None, n_s, H[v2.A_SHIFT256], d_bw,
+                                                    t_ts=D(rec["sh256_ts"]) if n_s else torch.zeros(1, dtype=torch.int32, device=dev))
     for i, p_ in enumerate(H.moduli):   # the multiplication chips count their own lookups into the two tables
         n_mm = len(rec["mm_ts_%d" % i])
         T[v2.A_MODMUL(i)] = zk.vm_modmul_tracegen(p_, D(rec["mm_records_%d" % i]) if n_mm else None, D(rec["mm_ts_%d" % i]) if n_mm else None, n_mm,
@@ -375,14 +378,14 @@ def test_ecc_guest_device_traces_and_one_proof(zk, ora, tmp_path):
 
 
 def test_int256_guest_device_traces_and_one_proof(zk, ora, tmp_path):
-    """A guest running the six 256-bit opcodes through the int256 intrinsic (bigint extension, 26 chips): device traces == CPU twins,
+    """A guest running the six 256-bit opcodes through the int256 intrinsic (bigint extension, 27 chips): device traces == CPU twins,
     proof bytes == the oracle's; the whole flow from the ELF with `[app_vm_config.bigint]`: the root's public values are Python's."""
     words, data = int256_program(), int256_data()
     info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, (), True)
     k = next(i for i, s in enumerate(segs) if len(s["i256_ts"]))
     inst = v2.segment_instance(segs[k], words, PC_BASE, H)
     T = device_traces(zk, segs[k], v2.program_table(words, PC_BASE, H[0]), H)
-    assert len(inst) == len(T) == 26
+    assert len(inst) == len(T) == 27
     for a, d in enumerate(inst):
         assert (zk.download(T[a]).reshape(d["width"], -1) == d["trace"]).all(), "position %d" % a
     pk = z.ProvingKey(zk, PARAMS, inst)
@@ -408,7 +411,7 @@ def test_int256_guest_device_traces_and_one_proof(zk, ora, tmp_path):
 
 def test_the_chunk_circuit_configuration_end_to_end(tmp_path):
     """`prove-elf` under an openvm.toml with the sections of the reference's chunk circuit in the reference's syntax (keccak, sha2, bigint,
-    modular with its six moduli, ecc with its three curves: 48 chips per segment) for a guest that uses all five intrinsics: ONE root proof whose public values
+    modular with its six moduli, ecc with its three curves: 49 chips per segment) for a guest that uses all five intrinsics: ONE root proof whose public values
     carry hashlib's SHA3-256 / SHA-256 words and Python's field product and 256-bit difference."""
     import hashlib
 

@@ -128,6 +128,44 @@ def test_comparison_chip(cmp_kat):
     assert air.check_trace(program, t4, iu.NOPV) != []
 
 
+def test_shift_chip():
+    """Rv32Shift256 as a chip of its own: the host function against Python's integers (left, logical and arithmetic right; amounts 0,
+    1, 255, whole limbs, beyond 255 -- only c mod 256 counts); the tests' twin trace with the bitwise table satisfies the AIRs and
+    balances the bus; a result limb changed, another limb shift, and a logical shift of a negative word passed off as arithmetic have no
+    trace."""
+    with open(os.path.join(HERE, "golden", "int256_kat.json")) as f:
+        cases = [(c["op"], int(c["b"], 16), int(c["c"], 16), int(c["a"], 16)) for c in json.load(f)["shift"]]
+    for op, b, c, a in cases:
+        assert iu.shift_result(op, b, c) == a and z.int256_alu_host(op, b, c) == a
+    sel = cases[:20] + cases[42:62] + cases[84:104]
+    tr, bw, xc = iu.shift_twin_trace([(op, b, c) for op, b, c, _ in sel], 6)
+    for row, (_, _, _, a) in enumerate(sel):
+        assert bytes(tr[0:32, row].astype(np.uint8)) == a.to_bytes(32, "little")
+    inst = iu.shift_instance(tr, bw, xc, 6)
+    for d in inst:
+        assert air.quotient_chunks(d["program"]) <= 2
+        assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == []
+    assert v2.bus_imbalance(inst) == {}
+    program = inst[0]["program"]
+    rng = np.random.default_rng(4)
+    for _ in range(30):
+        t2 = tr.copy()
+        c_, r_ = int(rng.integers(0, 128)), int(rng.integers(0, len(sel)))       # a result, operand, shifted or carry limb
+        t2[c_, r_] = (int(t2[c_, r_]) + 1) % 2013265921
+        i2 = iu.shift_instance(t2, bw, xc, 6)
+        assert air.check_trace(program, t2, iu.NOPV) != [] or v2.bus_imbalance(i2) != {}, (c_, r_)
+    k = next(i for i, (op, b, c, a) in enumerate(sel) if 8 <= c % 256 < 240 and b)
+    t3 = tr.copy()
+    ls = int(np.nonzero(tr[153:185, k])[0][0])
+    t3[153 + ls, k], t3[153 + ls + 1, k] = 0, 1                                   # one limb further
+    assert air.check_trace(program, t3, iu.NOPV) != []
+    k = next(i for i, (op, b, c, a) in enumerate(sel) if op == 10 and b >> 255 and c % 256)
+    t4 = tr.copy()
+    t4[187, k], t4[188, k] = 0, 1                                                 # srl relabelled sra with sign = 0
+    i4 = iu.shift_instance(t4, bw, xc, 6)
+    assert air.check_trace(program, t4, iu.NOPV) != [] or v2.bus_imbalance(i4) != {}
+
+
 def test_oracle_proves_the_chip_with_its_table(ora):
     rng = np.random.default_rng(5)
     cases = [(int(rng.integers(0, 5)), int.from_bytes(rng.bytes(32), "little"), int.from_bytes(rng.bytes(32), "little")) for _ in range(7)]

@@ -17,7 +17,7 @@ from zkvm_prover_amd import air
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import (ALL_EXT_MSG, CHUNK_CIRCUIT_CURVES, EC_CURVES, ec_data, ec_program, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
+from test_vm_cpu import (INT256_SHIFT_OPERANDS, ALL_EXT_MSG, CHUNK_CIRCUIT_CURVES, EC_CURVES, ec_data, ec_program, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
                          keccak_program, mixed_program, modmul_data, modmul_program, sha256_data, sha256_program)
 
 PARAMS = (1, 0, 4, 3, 3)
@@ -265,11 +265,14 @@ def test_int256_intrinsic_is_part_of_the_statement(tmp_path):
     M = 1 << 256
     want = [[(b + c) % M, (b - c) % M, b ^ c, b | c, b & c, (b * c) % M][op] for op, (b, c) in enumerate(INT256_OPERANDS)]
     assert [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(6)] == [w & 0xFFFFFFFF for w in want]
-    assert [int.from_bytes(pv[24 + 4 * j:28 + 4 * j], "little") for j in range(2)] == [want[1] >> 224, (want[5] >> 224) ^ 0b110]   # sltu 0, slt 1, eq 1
+    M_ = 1 << 256
+    (sb, sc), (rb, rc), (ab, ac) = INT256_SHIFT_OPERANDS
+    folded = ((sb << sc) % M_ & 0xFFFFFFFF) ^ ((rb >> rc) >> 224) ^ ((((ab - M_) >> (ac % 256)) % M_) >> 224)
+    assert [int.from_bytes(pv[24 + 4 * j:28 + 4 * j], "little") for j in range(2)] == [(want[1] >> 224) ^ folded, (want[5] >> 224) ^ 0b110]   # sltu 0, slt 1, eq 1
     info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, (), True)
     assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"]
-    assert len(H.ids) == 26 and H.ids[-4:] == (v2.A_INT256, v2.A_INT256_IO, v2.A_MUL256, v2.A_CMP256)
-    assert sum(len(s["i256_ts"]) for s in segs) == 5 and sum(len(s["mul256_ts"]) for s in segs) == 1 and sum(len(s["cmp256_ts"]) for s in segs) == 3
+    assert len(H.ids) == 27 and H.ids[-5:] == (v2.A_INT256, v2.A_INT256_IO, v2.A_MUL256, v2.A_CMP256, v2.A_SHIFT256)
+    assert sum(len(s["i256_ts"]) for s in segs) == 5 and sum(len(s["mul256_ts"]) for s in segs) == 1 and sum(len(s["cmp256_ts"]) for s in segs) == 3 and sum(len(s["sh256_ts"]) for s in segs) == 3
     for k, rec in enumerate(segs):
         inst = v2.segment_instance(rec, words, PC_BASE, H)
         for d in inst:
@@ -330,7 +333,7 @@ def test_ecc_intrinsic_is_part_of_the_statement(tmp_path):
 
 
 def test_all_extensions_of_the_chunk_circuit_in_one_statement(tmp_path):
-    """The chip set the reference's chunk-circuit configuration asks for (keccak, sha2, bigint, six moduli, three curves: 48 chips) and a
+    """The chip set the reference's chunk-circuit configuration asks for (keccak, sha2, bigint, six moduli, three curves: 49 chips) and a
     guest that uses all five intrinsics: SHA3-256 and SHA-256 of one message are hashlib's, the secp256k1 field product, the 256-bit
     difference and the doubled generator Python's; every trace satisfies its AIR and every bus balances."""
     import hashlib
@@ -344,7 +347,7 @@ def test_all_extensions_of_the_chunk_circuit_in_one_statement(tmp_path):
     two_g_x = 0xC6047F9441ED7D6D3045406E95C07CD85C778E4B8CEF3CA7ABAC09B95C709EE5   # 2 G of secp256k1 (published)
     assert int.from_bytes(pv[28:32], "little") == (((5 - 7) % (1 << 256)) >> 224) ^ (two_g_x & 0xFFFFFFFF)
     info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 5, 7, CHUNK_CIRCUIT_MODULI, True, curves)
-    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"] and len(H.ids) == 48
+    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"] and len(H.ids) == 49
     for k, rec in enumerate(segs):
         inst = v2.segment_instance(rec, words, PC_BASE, H)
         for d in inst:

@@ -88,20 +88,21 @@ def sha256_data(msg):
 
 
 def int256_program():
-    """256-bit words through the int256 intrinsic (a7 = 6, a1 = opcode): nine buffers (b, c, result slot) at the data base, one per
-    opcode (add, sub, xor, or, and, mul, then the comparisons b < c unsigned, b < c signed, b == c; int256_data); the six results' low
-    words and two high words (sub, mul) are revealed, the three comparison bits folded into the last one."""
+    """256-bit words through the int256 intrinsic (a7 = 6, a1 = opcode): twelve buffers (b, c, result slot) at the data base, one per
+    opcode (add, sub, xor, or, and, mul, the comparisons b < c unsigned, b < c signed, b == c, the shifts left, right, right
+    arithmetic; int256_data); the six results' low words and two high words (sub, mul) are revealed, the three comparison bits folded
+    into the last one, the left shift's low word and the right shifts' high words into the one before."""
     p = rv.li(S0, 0x00400000)
-    for op in range(9):
+    for op in range(12):
         p += [("addi", A0, S0, 96 * op), ("addi", A1, 0, op), ("addi", A7, 0, 6), ("ecall",)]
+    p += [("lw", T3, S0, 96 * 9 + 64), ("lw", T2, S0, 96 * 10 + 64 + 28), ("xor", T3, T3, T2), ("lw", T2, S0, 96 * 11 + 64 + 28), ("xor", T3, T3, T2)]
     p += [("lw", T1, S0, 96 * 6 + 64), ("lw", T2, S0, 96 * 7 + 64), ("slli", T2, T2, 1), ("or", T1, T1, T2), ("lw", T2, S0, 96 * 8 + 64), ("slli", T2, T2, 2),
           ("or", T1, T1, T2)]
     for k in range(6):
         p += [("lw", A0, S0, 96 * k + 64), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
     for j, k in enumerate((1, 5)):
         p += [("lw", A0, S0, 96 * k + 64 + 28)]
-        if k == 5:
-            p += [("xor", A0, A0, T1)]
+        p += [("xor", A0, A0, T1 if k == 5 else T3)]
         p += [("addi", A1, 0, 6 + j), ("addi", A7, 0, 1), ("ecall",)]
     p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
     return rv.assemble(p)
@@ -114,10 +115,12 @@ INT256_OPERANDS = [((1 << 256) - 5, 77), (3, 0xFFFF_FFFF_FFFF_FFFF_FFFF), (0x012
 
 # sltu: 2^256 - 5 < 77 is false; slt: -5 < 77 is true; eq: true
 INT256_CMP_OPERANDS = [((1 << 256) - 5, 77), ((1 << 256) - 5, 77), (0x1234 << 200 | 99, 0x1234 << 200 | 99)]
+# sll by 13, srl by 100, sra by 77 of a negative word (the amount is c mod 256: 256 + 77)
+INT256_SHIFT_OPERANDS = [(0x0123456789ABCDEF0123456789ABCDEF, 13), (0xFEDCBA98 << 224 | 0x1234, 100), (0x87654321 << 224 | 0xABCD, 256 + 77)]
 
 
 def int256_data():
-    return b"".join(int(b).to_bytes(32, "little") + int(c).to_bytes(32, "little") + bytes(32) for b, c in INT256_OPERANDS + INT256_CMP_OPERANDS)
+    return b"".join(int(b).to_bytes(32, "little") + int(c).to_bytes(32, "little") + bytes(32) for b, c in INT256_OPERANDS + INT256_CMP_OPERANDS + INT256_SHIFT_OPERANDS)
 
 
 # the six moduli of the reference's chunk circuit, in its order (crates/circuits/chunk-circuit/openvm.toml:20-28): bn254 p, bn254 r,

@@ -18,14 +18,14 @@ P = ora.P
 NOPV = np.zeros(0, np.uint32)
 (A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
  A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, A_INT256, A_INT256_IO, A_MUL256,
- A_CMP256, N_STATIC_AIRS) = range(31)
+ A_CMP256, A_SHIFT256, N_STATIC_AIRS) = range(32)
 MAX_MODULI, MAX_CURVES = 8, 4
 # the modular extension: chips N_STATIC_AIRS + 2 i (multiplication), + 2 i + 1 (adapter) of modulus i; the ecc extension's follow
 N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES
 PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 33, 43, 54, 42, 2634
 SHA_IO_WIDTH, SHA_WIDTH = 34, 434
 MODMUL_IO_WIDTH, MODMUL_WIDTH = 35, 323
-INT256_IO_WIDTH, INT256_WIDTH, MUL256_WIDTH, CMP256_WIDTH = 35, 102, 162, 104
+INT256_IO_WIDTH, INT256_WIDTH, MUL256_WIDTH, CMP256_WIDTH, SHIFT256_WIDTH = 35, 102, 162, 104, 190
 EC_IO_WIDTH, EC_WIDTH = 59, 773
 TS_STEP, GAP_HI_BITS = 16, 11
 SX, SY = 256, 2048
@@ -272,6 +272,20 @@ def cmp256_traces(rec, H):
     return tr, bw.astype(np.int64)
 
 
+def shift256_traces(rec, H):
+    """int256 calls with opcodes 9..11: the tests' twin of the shift chip's trace (and its lookup counts) + the call's timestamp"""
+    import int256_util as iu
+
+    recs = np.ascontiguousarray(rec["sh256_records"], dtype=np.uint32).reshape(-1, 17)
+    val = lambda w: sum(int(x) << (32 * k) for k, x in enumerate(w))  # noqa: E731
+    lh = H[A_SHIFT256]
+    body, bw, xc = iu.shift_twin_trace([(int(r[0]), val(r[1:9]), val(r[9:17])) for r in recs], lh)
+    tr = np.zeros((SHIFT256_WIDTH, 1 << lh), np.uint32)
+    tr[:SHIFT256_WIDTH - 1] = body
+    tr[SHIFT256_WIDTH - 1, :len(recs)] = rec["sh256_ts"]
+    return tr, bw.astype(np.int64), xc.astype(np.int64)
+
+
 def modmul_traces(rec, H, i, p):
     """modmul calls of modulus i: the oracle's chip trace (and its lookup counts) + the call's timestamp; the adapter's rows"""
     n = len(rec["mm_ts_%d" % i])
@@ -352,7 +366,9 @@ def segment_instance(rec, words, pc_base, heights):
         tr[A_INT256], tr[A_INT256_IO], i256_xor = int256_traces(rec, H)
         tr[A_MUL256], mul_bw, mul_tup = mul256_traces(rec, H)
         tr[A_CMP256], cmp_bw = cmp256_traces(rec, H)
-        mul_counts = (mul_bw + cmp_bw, mul_tup)
+        tr[A_SHIFT256], sh_bw, sh_xor = shift256_traces(rec, H)
+        i256_xor = i256_xor + sh_xor
+        mul_counts = (mul_bw + cmp_bw + sh_bw, mul_tup)
     mm_counts = []
     for i, p_ in enumerate(H.moduli):
         tr[A_MODMUL(i)], tr[A_MODMUL_IO(i)], bw_i, tup_i = modmul_traces(rec, H, i, p_)

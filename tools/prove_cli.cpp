@@ -83,7 +83,7 @@ int main(int argc, char** argv) {
                     PUT("kk_states", r.kk_states), PUT("kk_ts", r.kk_ts), PUT("kio_rows", r.kio_rows);
                     PUT("sha_blocks", r.sha_blocks), PUT("sha_ts", r.sha_ts), PUT("shaio_rows", r.shaio_rows);
                     PUT("i256_records", r.i256_records), PUT("i256_ts", r.i256_ts), PUT("i256io_rows", r.i256io_rows);
-                    PUT("mul256_records", r.mul256_records), PUT("mul256_ts", r.mul256_ts), PUT("cmp256_records", r.cmp256_records), PUT("cmp256_ts", r.cmp256_ts);
+                    PUT("mul256_records", r.mul256_records), PUT("mul256_ts", r.mul256_ts), PUT("cmp256_records", r.cmp256_records), PUT("cmp256_ts", r.cmp256_ts), PUT("sh256_records", r.sh256_records), PUT("sh256_ts", r.sh256_ts);
                     for (unsigned i = 0; i < caps.moduli.size(); i++) {
                         const std::string t = std::to_string(i);
                         put(d + "/mm_records_" + t + ".u32", r.mm_records[i]), put(d + "/mm_ts_" + t + ".u32", r.mm_ts[i]), put(d + "/mmio_rows_" + t + ".u32", r.mmio_rows[i]);

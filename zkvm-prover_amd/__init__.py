@@ -21,6 +21,7 @@ from ._binding import (  # noqa: F401
     int256_alu_air,
     int256_alu_host,
     int256_cmp_air,
+    int256_shift_air,
     int256_mul_air,
     ec_air,
     ec_host,

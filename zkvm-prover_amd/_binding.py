@@ -177,6 +177,9 @@ def load_library():
         "zkhip_int256_mul_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_vm_mul256_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_int256_cmp_air": (C.c_int, [C.c_uint32, C.POINTER(_Air)]),
+        "zkhip_int256_shift_air": (C.c_int, [C.c_uint32, C.POINTER(_Air)]),
+        "zkhip_int256_shift_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_vm_shift256_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_int256_cmp_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_vm_cmp256_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_modmul_air": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
@@ -696,6 +699,16 @@ class Context:
                                                           t_bitwise_trace.data_ptr()))
         return out
 
+    def int256_shift_tracegen(self, t_records, n, log_height, t_bitwise_trace, t_ts=None):
+        """records: n x 17 words (op | b | c; op 9 sll, 10 srl, 11 sra); t_ts: the VM chip (190 columns: + the calls' timestamps)"""
+        out = self._new((189 if t_ts is None else 190) << log_height)
+        if t_ts is None:
+            self._check(self.lib.zkhip_int256_shift_tracegen(self.h, t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr()))
+        else:
+            self._check(self.lib.zkhip_vm_shift256_tracegen(self.h, t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height, out.data_ptr(),
+                                                            t_bitwise_trace.data_ptr()))
+        return out
+
     def vm_mul256_tracegen(self, t_records, t_ts, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
         out = self._new(162 << log_height)
         self._check(self.lib.zkhip_vm_mul256_tracegen(self.h, t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height, out.data_ptr(),
@@ -1027,6 +1040,14 @@ def int256_cmp_air(bitwise_bus):
     lib = load_library()
     a = _Air()
     assert lib.zkhip_int256_cmp_air(bitwise_bus, C.byref(a)) == 0
+    return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
+
+
+def int256_shift_air(bitwise_bus):
+    """The 256-bit shift chip's AIR: (program, width); its one definition is include/zkhip_int256.hpp."""
+    lib = load_library()
+    a = _Air()
+    assert lib.zkhip_int256_shift_air(bitwise_bus, C.byref(a)) == 0
     return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
 
 

@@ -136,6 +136,58 @@ __global__ __launch_bounds__(256) void k_cmp256_trace(const uint32_t* __restrict
     if (width > i2::CMP_WIDTH) put(i2::CMP_COL_TS, ts ? ts[row] % P : 0u);
 }
 
+// 256-bit shift chip: record = op | b[8] | c[8] (op 9 sll, 10 srl, 11 sra; the amount is c mod 256); the row's 66 lookups (carries,
+// byte pairs, the amount's bytes, SRA's sign bit in the XOR column) are counted in the same pass
+__global__ __launch_bounds__(256) void k_shift256_trace(const uint32_t* __restrict__ recs, const uint32_t* __restrict__ ts, size_t n, size_t N, size_t width,
+                                                        uint32_t* __restrict__ trace, uint32_t* __restrict__ bitwise_range, uint32_t* __restrict__ bitwise_xor,
+                                                        uint32_t* __restrict__ bad) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    if (row >= n) {
+        for (size_t c = 0; c < width; c++) trace[c * N + row] = 0u;
+        return;
+    }
+    const uint32_t op = recs[17 * row];
+    if (op < i2::OP_SLL || op > i2::OP_SRA) atomicAdd(bad, 1u);
+    uint32_t b[8], c[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) b[i] = recs[17 * row + 1 + i], c[i] = recs[17 * row + 9 + i];
+    auto byte_of = [](const uint32_t* w, int i) -> uint32_t { return (w[i >> 2] >> (8 * (i & 3))) & 255u; };
+    auto put = [&](size_t col, uint32_t v) { trace[col * N + row] = to_monty(v); };
+    const uint32_t amount = c[0] & 255u, bs = amount & 7u, ls = amount >> 3, mult = 1u << bs;
+    const bool left = op == i2::OP_SLL;
+    const uint32_t sign = op == i2::OP_SRA ? byte_of(b, 31) >> 7 : 0u;
+    uint32_t t[32], cy[32];
+    if (left) {
+        uint32_t carry = 0;
+        for (int k = 0; k < 32; k++) {
+            const uint32_t v = byte_of(b, k) * mult + carry;
+            t[k] = v & 255u, carry = v >> 8, cy[k] = carry;
+        }
+    } else {   // t stored reversed: column k holds limb 31 - k of b >> bit_shift
+        uint32_t in = sign * (mult - 1u);
+        for (int m = 31; m >= 0; m--) {
+            const uint32_t v = byte_of(b, m) + 256u * in;
+            t[31 - m] = v >> bs, cy[m] = v & (mult - 1u), in = cy[m];
+        }
+    }
+    for (int i = 0; i < 32; i++) {
+        const uint32_t sel = (uint32_t)i >= ls ? t[i - (int)ls] : (left ? 0u : 255u * sign);
+        put(i2::SH_COL_A + (left ? i : 31 - i), sel);
+        put(i2::SH_COL_B + i, byte_of(b, i)), put(i2::SH_COL_T + i, t[i]), put(i2::SH_COL_CY + i, cy[i]), put(i2::SH_COL_LM + i, (uint32_t)i == ls ? 1u : 0u);
+        hist_add(bitwise_range, cy[i] * 256 + (mult - 1u - cy[i]));
+    }
+    for (int i = 0; i < 32; i += 2) hist_add(bitwise_range, t[i] * 256 + t[i + 1]), hist_add(bitwise_range, byte_of(b, i) * 256 + byte_of(b, i + 1));
+    put(i2::SH_COL_C0, byte_of(c, 0)), put(i2::SH_COL_C1, byte_of(c, 1)), put(i2::SH_COL_CHI0, c[0] >> 16);
+    hist_add(bitwise_range, byte_of(c, 0) * 256 + byte_of(c, 1));
+    for (int k = 1; k < 8; k++) put(i2::SH_COL_CW + 2 * (k - 1), c[k] & 0xffffu), put(i2::SH_COL_CW + 2 * (k - 1) + 1, c[k] >> 16);
+    for (uint32_t i = 0; i < 8; i++) put(i2::SH_COL_BM + i, i == bs ? 1u : 0u);
+    put(i2::SH_COL_SIGN, sign);
+    if (op == i2::OP_SRA) hist_add(bitwise_xor, byte_of(b, 31) * 256 + 128u);
+    put(i2::SH_COL_FLAGS, op == i2::OP_SLL ? 1u : 0u), put(i2::SH_COL_FLAGS + 1, op == i2::OP_SRL ? 1u : 0u), put(i2::SH_COL_FLAGS + 2, op == i2::OP_SRA ? 1u : 0u);
+    if (width > i2::SH_WIDTH) put(i2::SH_COL_TS, ts ? ts[row] % P : 0u);
+}
+
 std::mutex g_mu;
 std::map<uint32_t, std::vector<uint32_t>> g_programs;   // bitwise bus -> program
 
@@ -195,6 +247,24 @@ int mul_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t rec_stride, s
 
 std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> g_mul_programs;   // (bitwise bus, tuple bus) -> program
 std::map<uint32_t, std::vector<uint32_t>> g_cmp_programs;   // bitwise bus -> program
+std::map<uint32_t, std::vector<uint32_t>> g_shift_programs;   // bitwise bus -> program
+
+int shift_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_ts, size_t n, unsigned log_height, size_t width, uint32_t* d_trace,
+                   uint32_t* d_bitwise_trace, const char* what) {
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, what);
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const unsigned bb = (unsigned)(((size_t)2 << 16) + 255) / 256;   // both multiplicity columns of the 8-bit table
+    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 0);
+    hipLaunchKernelGGL(k_shift256_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, d_ts, n, N, width, d_trace, d_bitwise_trace,
+                       d_bitwise_trace + ((size_t)1 << 16), (uint32_t*)flag);
+    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 1);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return tracegen_finish(ctx, flag, std::string(what) + " (an opcode that is not a shift)");
+}
 
 int cmp_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_ts, size_t n, unsigned log_height, size_t width, uint32_t* d_trace,
                  uint32_t* d_bitwise_trace, const char* what) {
@@ -222,8 +292,10 @@ extern "C" {
 int zkhip_int256_alu_air(uint32_t bitwise_bus, zkhip_air* out) { return out ? air_of(bitwise_bus, out) : ZKHIP_ERR_INVALID; }
 
 int zkhip_int256_alu_host(uint32_t op, const uint32_t b[8], const uint32_t c[8], uint32_t a[8]) {
-    if (!a || !b || !c || op > i2::OP_EQ) return ZKHIP_ERR_INVALID;
-    if (op >= i2::OP_SLTU) {
+    if (!a || !b || !c || op >= i2::N_INT256_OPS) return ZKHIP_ERR_INVALID;
+    if (op >= i2::OP_SLL) {
+        i2::shift256(op, b, c, a);
+    } else if (op >= i2::OP_SLTU) {
         for (int i = 1; i < 8; i++) a[i] = 0;
         a[0] = i2::cmp256(op, b, c);
     } else if (op == i2::OP_MUL) i2::mul256(b, c, a);
@@ -293,6 +365,37 @@ int zkhip_vm_cmp256_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const ui
     ZK_BIND_DEVICE(ctx);
     if (!ctx || !d_trace || !d_bitwise_trace || log_height > 24 || (n && (!d_records || !d_ts))) return ZKHIP_ERR_INVALID;
     return cmp_tracegen(ctx, d_records, d_ts, n, log_height, i2::CMP_VM_WIDTH, d_trace, d_bitwise_trace, "vm_cmp256_tracegen");
+}
+
+int zkhip_int256_shift_air(uint32_t bitwise_bus, zkhip_air* out) {
+    if (!out) return ZKHIP_ERR_INVALID;
+    try {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_shift_programs.find(bitwise_bus);
+        if (it == g_shift_programs.end()) {
+            zkhip::air::AirBuilder b(i2::SH_WIDTH, 0);
+            i2::shift256_air(b, bitwise_bus);
+            it = g_shift_programs.emplace(bitwise_bus, b.program()).first;
+        }
+        out->program = it->second.data(), out->program_len = it->second.size(), out->log_height = 0, out->width = i2::SH_WIDTH, out->n_pvs = 0;
+        out->prep_trace = nullptr, out->prep_commit = nullptr;
+    } catch (const std::exception&) {
+        return ZKHIP_ERR_INVALID;
+    }
+    return ZKHIP_OK;
+}
+
+int zkhip_int256_shift_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 24 || (n && !d_records)) return ZKHIP_ERR_INVALID;
+    return shift_tracegen(ctx, d_records, nullptr, n, log_height, i2::SH_WIDTH, d_trace, d_bitwise_trace, "int256_shift_tracegen");
+}
+
+int zkhip_vm_shift256_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_ts, size_t n, unsigned log_height, uint32_t* d_trace,
+                               uint32_t* d_bitwise_trace) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || !d_bitwise_trace || log_height > 24 || (n && (!d_records || !d_ts))) return ZKHIP_ERR_INVALID;
+    return shift_tracegen(ctx, d_records, d_ts, n, log_height, i2::SH_VM_WIDTH, d_trace, d_bitwise_trace, "vm_shift256_tracegen");
 }
 
 int zkhip_int256_alu_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace, uint32_t* d_bitwise_trace) {
