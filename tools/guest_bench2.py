@@ -1,7 +1,8 @@
 """ONE FLOW at scale: a Fibonacci guest of ~n instructions through `prove_cli prove-elf` (include/zkhip_vm_flow.hpp): execution in
 segments of fixed heights, every segment ONE statement (22 chips, adapters + execution bus + persistent memory), aggregation tree
 to ONE root proof, self-verified, at the reference's FRI parameters.  Prints the CLI's JSON line + instructions per second.
-Usage: python tools/guest_bench2.py [n_iterations] [log_frame]"""
+Usage: python tools/guest_bench2.py [n_iterations] [log_frame] [chunk]     (chunk: under the reference's chunk-circuit openvm.toml --
+keccak, sha2, bigint, six moduli, three curves: 49 chips per segment instead of 22)"""
 import json
 import os
 import subprocess
@@ -11,7 +12,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rv32_model as rv  # noqa: E402
-from test_vm_cpu import fib_program  # noqa: E402
+from test_vm_cpu import chunk_circuit_toml, fib_program  # noqa: E402
 
 
 def main():
@@ -22,7 +23,11 @@ def main():
     open(exe, "wb").write(rv.elf_bytes(fib_program()))
     open(inp, "wb").write(n.to_bytes(4, "little"))
     cli = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
-    r = subprocess.run([cli, "prove-elf", exe, inp, tmp, "-", log_frame], capture_output=True, text=True)
+    cfg = "-"
+    if len(sys.argv) > 3 and sys.argv[3] == "chunk":
+        cfg = os.path.join(tmp, "openvm.toml")
+        open(cfg, "w").write(chunk_circuit_toml((1, 0, 100, 16, 16)))
+    r = subprocess.run([cli, "prove-elf", exe, inp, tmp, cfg, log_frame], capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-3000:])
         sys.exit(r.returncode)
@@ -30,6 +35,7 @@ def main():
     info["instr_per_s_wall"] = round(info["total_cycles"] / info["wall_s"])
     info["instr_per_s_segments_only"] = round(info["total_cycles"] / max(1e-9, (info["execution_ms"] + info["segment_tracegen_and_proving_ms"]) / 1e3))
     info["log_frame"] = int(log_frame)
+    info["config"] = "chunk-circuit (49 chips)" if cfg != "-" else "base (22 chips)"
     print(json.dumps(info))
 
 

@@ -151,6 +151,18 @@ __global__ __launch_bounds__(QBS) void k_quotient(QuotMulti m) {
     for (int k = 0; k < 4; k++) a.q[(size_t)k * M + r] = mmul(acc.c[k], izh);
 }
 
+// A short, wide chip (few LDE rows, a long constraint program) runs the interpreter as several CONSTRAINT SLICES side by side: slice s
+// evaluates a contiguous range of the constraints into a partial quotient of its own (the quotient is linear in the constraints'
+// random combination); this kernel adds the partial columns up.  q, parts: 4 columns of stride M; rows below n_rows.
+__global__ __launch_bounds__(256) void k_quot_sum_slices(uint32_t* __restrict__ q, const uint32_t* __restrict__ parts, uint32_t n_slices, size_t M, uint32_t n_rows) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= 4 * (size_t)n_rows) return;
+    const size_t idx = (t / n_rows) * M + (t % n_rows);
+    uint32_t acc = parts[idx];
+    for (uint32_t s = 1; s < n_slices; s++) acc = madd(acc, parts[(size_t)s * 4 * M + idx]);
+    q[idx] = acc;
+}
+
 // alpha^(n_cons-1-k) for every chip at once: block = chip, one lane each (n_cons is a few hundred at most)
 struct PowDesc {
     uint32_t* out;
@@ -761,6 +773,10 @@ struct AirPlan {
     uint32_t* d_inv_zh = nullptr;  // 2^b
     uint32_t* d_pvs = nullptr;     // n_pvs (Montgomery), refreshed per proof
     uint32_t* d_lde = nullptr;     // width columns x M
+    // constraint slices of the interpreter form (short, wide chips): code / constants / instruction count per slice, partial quotients
+    std::vector<uint32_t*> d_slice_code, d_slice_consts;
+    std::vector<uint32_t> slice_n_instr;
+    uint32_t* d_q_part = nullptr;  // n_slices x 4 columns x M
     uint32_t* d_q = nullptr;       // 4 columns x M (quotient values, bit-reversed LDE order)
     uint32_t* d_qnat = nullptr;    // nq chunks x 4 columns x N (natural order)
     uint32_t* d_qlde = nullptr;    // nq chunks x 4 columns x M
@@ -1100,11 +1116,13 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
     Bump bp;
     const unsigned nch = pk->nch;
     struct AirOff {
-        size_t code, consts, zh, inv_zh, pvs, lde, q, qnat, qlde, apow_q;
+        size_t code, consts, zh, inv_zh, pvs, lde, q, qnat, qlde, apow_q, q_part;
+        std::vector<size_t> slice_code, slice_consts;
         size_t lu_tab, lu_code, lu_consts, lu_den, lu_totals, lu_sums, perm, perm_lde, prep, prep_lde, dig_prep, dig_cached;
     };
     std::vector<AirOff> ao(n_airs);
     std::vector<CompiledAir> comp(n_airs);
+    std::vector<std::vector<CompiledAir>> slices(n_airs);
     struct LuHost {
         std::vector<uint32_t> tab, code, consts;
     };
@@ -1158,6 +1176,44 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             zkhip_pk_destroy(ctx, pk);  // also unloads the modules of the AIRs already compiled
             return set_error(ctx, ZKHIP_ERR_INVALID, "AIR " + std::to_string(a) + ": " + interp_err + " (interpreter form; no compiled form available either: " + jit_msg + ")");
         }
+        // Constraint slices: with fewer than ~2 workgroups per CU the interpreter's time is one lane's walk through the whole program
+        // (a dependent load per instruction); cutting the constraints into S contiguous ranges gives S times the lanes, each with
+        // 1 / S of the walk.  Cut points: the ASSERTs of the whole program nearest to the multiples of n_instr / S.
+        // ZKHIP_NO_QUOT_SLICES=1 switches it off (measurements).
+        if (!A.jit_fn && interp_ok && A.n_instr >= 2048 && (A.MQ + QBS - 1) / QBS <= 256 && !getenv("ZKHIP_NO_QUOT_SLICES")) {
+            const uint32_t want = std::min<uint32_t>(16u, std::min<uint32_t>(A.n_instr / 1024u, (uint32_t)(2048u / ((A.MQ + QBS - 1) / QBS))));
+            std::vector<uint32_t> cut{0};   // constraint indices where slices start
+            if (want >= 2) {
+                const std::vector<uint32_t>& code = comp[a].code;
+                uint32_t next = 1, seen_max = 0;
+                for (uint32_t pc = 0; pc < A.n_instr && next < want; pc++) {
+                    if ((code[3 * pc] & 0xffu) != Q_ASSERT) continue;
+                    seen_max = std::max(seen_max, (code[3 * pc] >> 8) + 1u);
+                    if (pc >= (uint64_t)A.n_instr * next / want && seen_max > cut.back() && seen_max < A.prog.n_cons) cut.push_back(seen_max), next++;
+                }
+            }
+            if (cut.size() >= 2) {
+                cut.push_back(A.prog.n_cons);
+                bool ok = true;
+                for (size_t sl = 0; sl + 1 < cut.size() && ok; sl++) {
+                    std::vector<uint32_t> roots(A.prog.cons + cut[sl], A.prog.cons + cut[sl + 1]);
+                    CompiledAir part;
+                    std::string e2;
+                    ok = compile_air(A.prog, &part, &e2, &roots) == 0;
+                    for (size_t pc = 0; ok && pc < part.code.size() / 3; pc++)   // an ASSERT carries its index among the roots: back to the constraint's number
+                        if ((part.code[3 * pc] & 0xffu) == Q_ASSERT) part.code[3 * pc] = Q_ASSERT | (((part.code[3 * pc] >> 8) + cut[sl]) << 8);
+                    if (ok) slices[a].push_back(std::move(part));
+                }
+                if (!ok) slices[a].clear();
+            }
+            for (const CompiledAir& part : slices[a]) {
+                A.n_slots = std::max(A.n_slots, part.n_slots);
+                A.slice_n_instr.push_back((uint32_t)(part.code.size() / 3));
+                ao[a].slice_code.push_back(bp.take(part.code.size() * 4 + 16));
+                ao[a].slice_consts.push_back(bp.take(part.consts.size() * 4));
+            }
+            if (!slices[a].empty()) ao[a].q_part = bp.take(slices[a].size() * A.M * 4 * 4);
+        }
         ao[a].code = bp.take(comp[a].code.size() * 4 + 16);
         ao[a].consts = bp.take(comp[a].consts.size() * 4);
         ao[a].zh = bp.take(nch * 4);
@@ -1204,7 +1260,9 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             ao[a].perm_lde = bp.take(A.perm_w * A.M * 4);
         }
     }
-    const size_t o_quot_args = bp.take((n_airs + 1) * sizeof(QuotArgs)), o_quot_first = bp.take((n_airs + 2) * 4);
+    size_t n_quot_entries = n_airs + 1;
+    for (size_t a = 0; a < n_airs; a++) n_quot_entries += slices[a].size();
+    const size_t o_quot_args = bp.take(n_quot_entries * sizeof(QuotArgs)), o_quot_first = bp.take((n_quot_entries + 1) * 4);
     const size_t o_pow_desc = bp.take((n_airs + 1) * sizeof(PowDesc));
     const size_t o_br_tiled = bp.take((pk->n_quot + 1) * sizeof(BitrevSeg)), o_br_small = bp.take((pk->n_quot + 1) * sizeof(BitrevSeg));
     const size_t o_lu_den_all = bp.take(lu_den_elems * 16 + 16), o_lu_num_all = bp.take(lu_den_elems * 4 + 16);
@@ -1315,6 +1373,12 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         A.d_apow_q = (uint32_t*)(base + ao[a].apow_q);
         rc = upload(ctx, A.d_code, comp[a].code.data(), comp[a].code.size() * 4);
         if (rc == ZKHIP_OK) rc = upload(ctx, A.d_consts, comp[a].consts.data(), comp[a].consts.size() * 4);
+        for (size_t sl = 0; sl < slices[a].size() && rc == ZKHIP_OK; sl++) {
+            A.d_slice_code.push_back((uint32_t*)(base + ao[a].slice_code[sl])), A.d_slice_consts.push_back((uint32_t*)(base + ao[a].slice_consts[sl]));
+            rc = upload(ctx, A.d_slice_code[sl], slices[a][sl].code.data(), slices[a][sl].code.size() * 4);
+            if (rc == ZKHIP_OK) rc = upload(ctx, A.d_slice_consts[sl], slices[a][sl].consts.data(), slices[a][sl].consts.size() * 4);
+        }
+        if (!slices[a].empty()) A.d_q_part = (uint32_t*)(base + ao[a].q_part);
         // vanishing polynomial of H on the LDE coset: x^N = g^N * w_{2^b}^(i mod 2^b)
         std::vector<uint32_t> zh(nch), izh(nch);
         uint32_t gN = host_pow(to_monty(FIELD_GEN_CANON), A.N), wb = two_adic_generator(pk->b);
@@ -1596,9 +1660,14 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             pk->quot_args_host.push_back(qa);
             pows.push_back(PowDesc{A.d_apow_q, A.prog.n_cons, 0});
             if (!A.jit_fn) {
-                interp.push_back(qa);
-                first.push_back(acc);
-                acc += (uint32_t)((A.MQ + QBS - 1) / QBS);
+                const size_t n_entries = A.d_slice_code.empty() ? 1 : A.d_slice_code.size();
+                for (size_t sl = 0; sl < n_entries; sl++) {
+                    QuotArgs e = qa;
+                    if (!A.d_slice_code.empty()) e.code = A.d_slice_code[sl], e.consts = A.d_slice_consts[sl], e.n_instr = A.slice_n_instr[sl], e.q = A.d_q_part + sl * 4 * A.M;
+                    interp.push_back(e);
+                    first.push_back(acc);
+                    acc += (uint32_t)((A.MQ + QBS - 1) / QBS);
+                }
                 pk->quot_max_slots = std::max(pk->quot_max_slots, (uint32_t)A.n_slots);
             }
             for (unsigned j = 0; j < A.nq; j++) {
@@ -1933,6 +2002,12 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         KernelScope ks(ctx, "quotient_eval");
         const QuotMulti qm{pk->d_quot_args, pk->d_quot_first, pk->quot_n, ctx->d_tw_fwd, ctx->tw_log};
         hipLaunchKernelGGL(k_quotient, dim3(pk->quot_blocks), dim3(QBS), (size_t)pk->quot_max_slots * QBS * 4, st, qm);
+        for (size_t a = 0; a < n_airs; a++) {
+            AirPlan& A = pk->airs[a];
+            if (A.d_slice_code.empty()) continue;
+            hipLaunchKernelGGL(k_quot_sum_slices, dim3((unsigned)((4 * A.MQ + 255) / 256)), dim3(256), 0, st, A.d_q, A.d_q_part, (uint32_t)A.d_slice_code.size(), A.M,
+                               (uint32_t)A.MQ);
+        }
         ZK_HIP_CHECK(ctx, hipGetLastError());
     }
     for (size_t a = 0; a < n_airs; a++) {
