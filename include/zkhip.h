@@ -490,6 +490,9 @@ int zkhip_verify(const zkhip_params *params, const zkhip_air *airs, size_t n_air
  * zkhip_fri_fold_row: pair `index` of a layer that folds 2^(log_height+1) values (bit-reversed order) to 2^log_height:
  * out = e0 + (beta - x)(e1 - e0)/(-2x), x = two_adic_generator(log_height+1)^bitrev(index, log_height). */
 int zkhip_poseidon2_permute_host(uint32_t state[16]);
+/* the same permutation through the host's AVX-512 form (zkvm-prover_amd/csrc/poseidon2_avx512.cpp: what the prover's transcript uses for
+ * long absorptions); returns 1 -- state untouched -- on a CPU without AVX-512 */
+int zkhip_poseidon2_permute_host_avx512(uint32_t state[16]);
 int zkhip_mmcs_verify(const uint32_t root[8], const unsigned *log_heights, const size_t *widths, size_t n_mats,
                       uint64_t index, const uint32_t *opening);
 int zkhip_fri_fold_row(uint64_t index, unsigned log_height, const uint32_t beta[4], const uint32_t e0[4],

@@ -307,6 +307,7 @@ extern "C" {
 
     // the verifier's primitives on the host (no device)
     pub fn zkhip_poseidon2_permute_host(state: *mut u32) -> c_int;
+    pub fn zkhip_poseidon2_permute_host_avx512(state: *mut u32) -> c_int;
     pub fn zkhip_mmcs_verify(root: *const u32, log_heights: *const c_uint, widths: *const usize, n_mats: usize, index: u64,
                              opening: *const u32) -> c_int;
     pub fn zkhip_fri_fold_row(index: u64, log_height: c_uint, beta: *const u32, e0: *const u32, e1: *const u32, out: *mut u32) -> c_int;

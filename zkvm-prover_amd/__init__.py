@@ -36,6 +36,7 @@ from ._binding import (  # noqa: F401
     proof_layout,
     DEFAULT_PARAMS,
     poseidon2_permute_host,
+    poseidon2_permute_host_avx512,
     mmcs_verify,
     fri_fold_row,
     proof_decode_v1,

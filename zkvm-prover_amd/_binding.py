@@ -154,6 +154,7 @@ def load_library():
         "zkhip_proof_fetch": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), sz, C.POINTER(sz)]),
         "zkhip_verify": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(u32p), C.POINTER(C.c_uint8), sz]),
         "zkhip_poseidon2_permute_host": (C.c_int, [u32p]),
+        "zkhip_poseidon2_permute_host_avx512": (C.c_int, [u32p]),
         "zkhip_mmcs_verify": (C.c_int, [u32p, C.POINTER(C.c_uint), C.POINTER(sz), sz, C.c_uint64, u32p]),
         "zkhip_fri_fold_row": (C.c_int, [C.c_uint64, C.c_uint, u32p, u32p, u32p, u32p]),
         "zkhip_logup_exposed_check": (C.c_int, [u32p, sz]),
@@ -1244,6 +1245,17 @@ def poseidon2_permute_host(state):
     rc = load_library().zkhip_poseidon2_permute_host(_u32p(s))
     if rc != 0:
         raise ZkhipError("zkhip_poseidon2_permute_host returned %d" % rc)
+    return s
+
+
+def poseidon2_permute_host_avx512(state):
+    """the same through the host's AVX-512 form (the transcript's long absorptions); None on a CPU without AVX-512"""
+    s = np.ascontiguousarray(state, dtype=np.uint32).copy()
+    rc = load_library().zkhip_poseidon2_permute_host_avx512(_u32p(s))
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise ZkhipError("zkhip_poseidon2_permute_host_avx512 returned %d" % rc)
     return s
 
 

@@ -171,6 +171,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->hash_stream) (void)hipStreamDestroy(ctx->hash_stream);
     if (ctx->d_deferred_bad) (void)hipFree(ctx->d_deferred_bad);
+    if (ctx->h_sponge) (void)hipHostFree(ctx->h_sponge);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     for (auto& e : ctx->pipe_ev)
         if (e) (void)hipEventDestroy(e);

@@ -311,7 +311,7 @@ class Builder {
             uint32_t s[16];
             for (int j = 0; j < 4; j++)
                 for (int k = 0; k < 4; k++) s[4 * j + k] = in[j].c.c[k];
-            poseidon2_permute(s);
+            poseidon2_permute_host(s);
             std::array<V, 4> out;
             for (int j = 0; j < 4; j++) out[j] = cst(Ext{{s[4 * j], s[4 * j + 1], s[4 * j + 2], s[4 * j + 3]}});
             return out;
@@ -1404,7 +1404,7 @@ int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, co
                 uint32_t s[16];
                 for (int j = 0; j < 4; j++)
                     for (int k = 0; k < 4; k++) s[4 * j + k] = vals[p.in[j]].c[k];
-                poseidon2_permute(s);
+                poseidon2_permute_host(s);
                 for (int j = 0; j < 4; j++) vals[p.out[j]] = Ext{{s[4 * j], s[4 * j + 1], s[4 * j + 2], s[4 * j + 3]}};
                 continue;
             }

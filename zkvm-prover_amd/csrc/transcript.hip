@@ -186,9 +186,47 @@ int transcript_init(zkhip_ctx* ctx, DevTranscript* d_t) {
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
 }
+// Long absorptions on the host (csrc/poseidon2_avx512.cpp): the sponge is a chain of dependent permutations, ~1.5 us each on the device
+// whatever the occupancy, ~0.25 us in a 512-bit register of the host -- and the words absorbed here (the opened values) are part of the
+// proof, so they cross PCIe anyway.  One stream synchronisation; the state goes back with a 96-byte copy.  ZKHIP_NO_HOST_SPONGE=1 (or a
+// CPU without AVX-512) keeps everything on the device; ZKHIP_HOST_SPONGE_MIN_WORDS moves the threshold (default 2048 words).
+void poseidon2_permute_avx512(uint32_t s[16]);
+static bool host_sponge_available() {
+    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && !getenv("ZKHIP_NO_HOST_SPONGE");
+    return ok;
+}
+static int observe_on_host(zkhip_ctx* ctx, DevTranscript* d_t, const uint32_t* d_src, uint32_t n, bool canonical) {
+    const size_t bytes = sizeof(DevTranscript) + (size_t)n * 4;
+    if (ctx->h_sponge_bytes < bytes) {
+        if (ctx->h_sponge) (void)hipHostFree(ctx->h_sponge);
+        ctx->h_sponge = nullptr, ctx->h_sponge_bytes = 0;
+        if (hipHostMalloc(&ctx->h_sponge, bytes * 2, hipHostMallocDefault) != hipSuccess) return set_error(ctx, ZKHIP_ERR_NOMEM, "pinned staging of the host sponge");
+        ctx->h_sponge_bytes = bytes * 2;
+    }
+    DevTranscript* t = (DevTranscript*)ctx->h_sponge;
+    uint32_t* w = (uint32_t*)(t + 1);
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(t, d_t, sizeof(DevTranscript), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(w, d_src, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // the duplex challenger's observe, word by word: inputs overwrite the front of the state, eight of them trigger a permutation
+    // (tr_observe1 above)
+    uint32_t n_in = t->n_in;
+    for (uint32_t i = 0; i < n; i++) {
+        t->state[n_in++] = canonical ? to_monty(w[i]) : w[i];
+        if (n_in == 8) poseidon2_permute_avx512(t->state), n_in = 0;
+    }
+    t->n_in = n_in, t->n_out = n_in == 0 ? 8u : 0u;
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_t, t, sizeof(DevTranscript), hipMemcpyHostToDevice, ctx->stream));
+    // (the staging buffer is reused by the next call: the copy must have left it)
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKHIP_OK;
+}
+
 int transcript_observe(zkhip_ctx* ctx, DevTranscript* d_t, const uint32_t* d_src, uint32_t n, bool canonical) {
     if (n == 0) return ZKHIP_OK;
     KernelScope ks(ctx, "transcript");
+    static const uint32_t host_min = getenv("ZKHIP_HOST_SPONGE_MIN_WORDS") ? (uint32_t)atoi(getenv("ZKHIP_HOST_SPONGE_MIN_WORDS")) : 2048u;
+    if (n >= host_min && host_sponge_available()) return observe_on_host(ctx, d_t, d_src, n, canonical);
     hipLaunchKernelGGL(k_tr_observe, dim3(1), dim3(64), 0, ctx->stream, d_t, d_src, n, canonical ? 1 : 0);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;

@@ -22,7 +22,7 @@ struct HostChallenger {
     void duplex() {
         for (unsigned i = 0; i < n_in; i++) state[i] = in_buf[i];
         n_in = 0;
-        poseidon2_permute(state);
+        poseidon2_permute_host(state);
         memcpy(out_buf, state, sizeof out_buf);
         n_out = 8;
     }
@@ -120,6 +120,22 @@ extern "C" int zkhip_poseidon2_permute_host(uint32_t state[16]) {
         s[i] = to_monty(state[i]);
     }
     poseidon2_permute(s);
+    for (int i = 0; i < 16; i++) state[i] = from_monty(s[i]);
+    return ZKHIP_OK;
+}
+
+namespace zk {
+void poseidon2_permute_avx512(uint32_t s[16]);   // csrc/poseidon2_avx512.cpp
+}
+extern "C" int zkhip_poseidon2_permute_host_avx512(uint32_t state[16]) {
+    if (!state) return ZKHIP_ERR_INVALID;
+    if (!__builtin_cpu_supports("avx512f") || !__builtin_cpu_supports("avx512dq")) return 1;
+    uint32_t s[16];
+    for (int i = 0; i < 16; i++) {
+        if (state[i] >= P) return ZKHIP_ERR_INVALID;
+        s[i] = to_monty(state[i]);
+    }
+    zk::poseidon2_permute_avx512(s);
     for (int i = 0; i < 16; i++) state[i] = from_monty(s[i]);
     return ZKHIP_OK;
 }

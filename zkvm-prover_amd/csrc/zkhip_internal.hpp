@@ -57,6 +57,9 @@ struct zkhip_ctx {
     // deferred checks (zkhip_tracegen_defer_checks) the bad-record counts are summed on the device and read once (zkhip_tracegen_check)
     bool defer_tracegen_checks = false;
     uint32_t* d_deferred_bad = nullptr;
+    // pinned staging of the transcript's host sponge (csrc/transcript.hip: long absorptions run on the host's vector unit)
+    void* h_sponge = nullptr;
+    size_t h_sponge_bytes = 0;
 };
 
 namespace zk {
