@@ -55,7 +55,7 @@ def _plain_airs():
 def fuzz_exe(tmp_path_factory):
     exe = tmp_path_factory.mktemp("fuzz") / "fuzz_verify"
     csrc = os.path.join(ROOT, "zkvm-prover_amd", "csrc")
-    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-DZK_NO_HOST_AVX512", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
            "-I", os.path.join(ROOT, "include"), "-I", csrc, "-x", "c++", os.path.join(csrc, "verifier.hip"),
            os.path.join(ROOT, "tests", "fuzz_verify.cpp"), "-o", str(exe)]
     subprocess.check_call(cmd)
@@ -85,7 +85,7 @@ def test_codec_asan_ubsan_fuzz(tmp_path):
     ASan + UBSan; whatever still parses must re-encode to exactly its input."""
     exe = tmp_path / "fuzz_codec"
     csrc = os.path.join(ROOT, "zkvm-prover_amd", "csrc")
-    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-DZK_NO_HOST_AVX512", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
            "-I", os.path.join(ROOT, "include"), "-I", csrc, "-x", "c++", os.path.join(csrc, "codec.hip"),
            os.path.join(csrc, "verifier.hip"), os.path.join(ROOT, "tests", "fuzz_codec.cpp"), "-o", str(exe)]
     subprocess.check_call(cmd)

@@ -147,7 +147,9 @@ ZK_HD void poseidon2_permute(uint32_t s[16]) {
 
 // The host's permutation: the AVX-512 form (csrc/poseidon2_avx512.cpp, the whole state in one register: about half the scalar code's
 // time) where the CPU has it -- the verifier, the aggregation witness generator and the transcript's long absorptions hash on the host.
-#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+// (-DZK_NO_HOST_AVX512: builds of single sources without csrc/poseidon2_avx512.cpp, e.g. the sanitizer build of the verifier)
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__) && !defined(ZK_NO_HOST_AVX512)
+#define ZK_HAVE_HOST_AVX512 1
 void poseidon2_permute_avx512(uint32_t s[16]);
 inline void poseidon2_permute_host(uint32_t s[16]) {
     static const bool fast = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq");

@@ -124,11 +124,11 @@ extern "C" int zkhip_poseidon2_permute_host(uint32_t state[16]) {
     return ZKHIP_OK;
 }
 
-namespace zk {
-void poseidon2_permute_avx512(uint32_t s[16]);   // csrc/poseidon2_avx512.cpp
-}
 extern "C" int zkhip_poseidon2_permute_host_avx512(uint32_t state[16]) {
     if (!state) return ZKHIP_ERR_INVALID;
+#ifndef ZK_HAVE_HOST_AVX512
+    return 1;
+#else
     if (!__builtin_cpu_supports("avx512f") || !__builtin_cpu_supports("avx512dq")) return 1;
     uint32_t s[16];
     for (int i = 0; i < 16; i++) {
@@ -138,6 +138,7 @@ extern "C" int zkhip_poseidon2_permute_host_avx512(uint32_t state[16]) {
     zk::poseidon2_permute_avx512(s);
     for (int i = 0; i < 16; i++) state[i] = from_monty(s[i]);
     return ZKHIP_OK;
+#endif
 }
 
 extern "C" int zkhip_mmcs_verify(const uint32_t root[8], const unsigned* log_heights, const size_t* widths, size_t n_mats,
