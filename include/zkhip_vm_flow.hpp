@@ -431,6 +431,11 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     std::deque<std::pair<size_t, const SegmentProof*>> to_verify;   // (element addresses of a deque stay put while it grows)
     bool proving_done = false;
     const auto t_start = clk::now();
+    // Every segment proof is checked by the leaf circuit's witness generation (it replays the verifier and throws on a child that
+    // does not verify), every node proof by the level above and the root by verify_guest_stark -- as the reference verifies its final
+    // proof only (crates/prover/src/prover/mod.rs:407-411).  ZKHIP_VERIFY_SEGMENTS=1 adds the host verification of every segment
+    // proof beside the proving (it hashes as much as the witness generation does, on the same cores).
+    const bool verify_segments = getenv("ZKHIP_VERIFY_SEGMENTS") != nullptr;
     // the aggregation tree runs as a stream beside the segment proving: a leaf node starts when its four segment proofs exist
     scroll_zkvm_hip::AggregationProver::TreeStream tree(agg);
     for (SegmentProver* lane : lanes)
@@ -451,7 +456,7 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
                     std::lock_guard<std::mutex> lk(mu);
                     if (proofs.size() <= it.index) proofs.resize(it.index + 1);
                     proofs[it.index] = std::move(p);
-                    to_verify.push_back({it.index, &proofs[it.index]});
+                    if (verify_segments) to_verify.push_back({it.index, &proofs[it.index]});
                     pool.push_back(std::move(it.rec));
                     cv_pop.notify_all();
                 }
