@@ -180,7 +180,7 @@ def guest_flow():
 
     here = os.path.dirname(os.path.abspath(__file__))
     cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py"), "700000", "17"]
-    env = dict(os.environ, ZKHIP_LANES="2")
+    env = dict(os.environ, ZKHIP_LANES="3")
     try:
         runs = []
         for _ in range(2):
@@ -195,7 +195,7 @@ def guest_flow():
                 "execution_ms": g["execution_ms"], "segments_ms": g["segment_tracegen_and_proving_ms"],
                 "tree_tail_ms": g["aggregation_setup_wait_ms"] + g["aggregation_ms"], "process_wall_s": g["wall_s"],
                 "process_wall_s_first_run_on_this_box": runs[0]["wall_s"], "root_proof_bytes": g["root_proof_bytes"], "verified": g["verified"],
-                "command": "ZKHIP_LANES=2 python tools/guest_bench2.py 700000 17"}
+                "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 700000 17"}
     except Exception as e:   # a reported extra, never a gate
         return {"value": None, "note": "failed: %r" % (e,)}
 

@@ -801,7 +801,7 @@ private:
     zkhip_params params_{};
     zkhip_vm::SegmentCaps caps_;
     int device_ = 0;
-    unsigned inflight_ = 2;
+    unsigned inflight_ = 3;
     std::vector<std::unique_ptr<zkhip_vm::SegmentProver>> seg_;   // lanes: segment provers in flight on the device
     std::unique_ptr<AggregationProver> agg_;
     zkhip_vm::GuestStark last_;

@@ -151,7 +151,7 @@ int main(int argc, char** argv) {
                     const zkhip_vm::SegmentCaps caps = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(up.exe().program.size()));
                     const zkhip_params params = read_app_config(cfg_path);
                     const unsigned log_keccak = zkhip_vm::keccak_log_rows(cfg_path, log_frame), log_sha256 = zkhip_vm::sha256_log_rows(cfg_path, log_frame);
-                    const unsigned lanes = getenv("ZKHIP_LANES") ? (unsigned)atoi(getenv("ZKHIP_LANES")) : 2u;   // segment provers in flight
+                    const unsigned lanes = getenv("ZKHIP_LANES") ? (unsigned)atoi(getenv("ZKHIP_LANES")) : 3u;   // segment provers in flight (measured 1 / 2 / 3: DESIGN.md 5)
                     const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false, lanes, log_keccak, log_sha256, zkhip_vm::config_moduli(cfg_path),
                                                                                           zkhip_vm::int256_log_rows(cfg_path, log_frame), zkhip_vm::config_curves(cfg_path));
                     (void)caps;
