@@ -606,6 +606,11 @@ int zkhip_vm_modmul_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const ui
 int zkhip_vm_ec_air(const uint8_t modulus[32], const uint8_t a[32], unsigned index, int adapter, zkhip_air *out);
 int zkhip_vm_ec_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t a[8], const uint32_t *d_records, const uint32_t *d_ts, size_t n,
                          unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+/* The two chips of field `index` (< 2) of an app with the fp2 extension: adapter == 0 the Fp2 chip inside the VM (649 columns: zkhip_fp2_air
+ * + a timestamp column + the 48 word receives), adapter != 0 its adapter; zkhip_vm_fp2_tracegen = zkhip_fp2_tracegen + the timestamps. */
+int zkhip_vm_fp2_air(const uint8_t modulus[32], unsigned index, int adapter, zkhip_air *out);
+int zkhip_vm_fp2_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height,
+                          uint32_t *d_trace, uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
 /* Poseidon2 chip serving the hash bus (299 columns): zkhip_poseidon2_air_tracegen + multiplicity 1 on the first n rows. */
 int zkhip_vm_poseidon2_tracegen(zkhip_ctx *ctx, const uint32_t *d_inputs, size_t n, unsigned log_height, uint32_t *d_trace);
 /* n rows of `width` canonical words (row-major, device) -> column-major Montgomery trace of 2^log_height rows; the other rows get
@@ -680,6 +685,23 @@ int zkhip_ec_host(uint32_t op, const uint32_t modulus[8], const uint32_t a[8], c
  * an error if a record's slope does not solve its identity */
 int zkhip_ec_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t a[8], const uint32_t *d_records, size_t n, unsigned log_height,
                       uint32_t *d_trace, uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+
+/* ---- Fp2 chip (include/zkhip_fp2.hpp: multiplication, division, addition, subtraction in Fp[u] / (u^2 + 1) over a 256-bit prime on byte
+ *      limbs, one operation per row, 648 columns, degree 3: two component identities with signed 33-byte quotients, results canonical (and
+ *      the quotient of a division); crates/circuits/chunk-circuit/openvm.toml:30-33 lists `fp2.supported_moduli` with bn254's Fp2;
+ *      OpenVM's chips are openvm-algebra-circuit's Fp2AddSub / Fp2MulDiv, un-vendored).  Pinned to Python's integers
+ *      (tests/golden/fp2_kat.json). ---- */
+#define ZKHIP_FP2_WIDTH 648
+#define ZKHIP_FP2_RECORD_WORDS 33
+int zkhip_fp2_air(const uint8_t modulus[32], uint32_t bitwise_bus, uint32_t tuple_bus, zkhip_air *out);
+/* r = a op b on the host (op 0 mul, 1 add, 2 sub, 3 div; elements as c0[8] | c1[8] little-endian words, components below the modulus);
+ * ZKHIP_ERR_INVALID for an operand that is not reduced or a division by zero */
+int zkhip_fp2_host(uint32_t op, const uint32_t modulus[8], const uint32_t a[16], const uint32_t b[16], uint32_t r[16]);
+/* d_records: n x 33 words (op | a0 a1 | b0 b1; a division's record holds the quotient in the a slot and the divisor in b: the row is
+ * their product); fills 2^log_height rows and adds the rows' lookups to the bitwise table's range column and the range-tuple table
+ * (size_x >= 256, size_y >= 2048) */
+int zkhip_fp2_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace,
+                       uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
 
 /* ---- 256-bit ALU chip (include/zkhip_int256.hpp: a = b op c on 32 byte limbs, op = 0 add, 1 sub, 2 xor, 3 or, 4 and, one operation per
  *      row, 101 columns, degree 3; 32 lookups per row in the 8-bit bitwise table; crates/circuits/chunk-circuit/openvm.toml:16-17 enables

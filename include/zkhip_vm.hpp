@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "zkhip_ecc.hpp"
+#include "zkhip_fp2.hpp"
 #include "zkhip_int256.hpp"
 #include "zkhip_keccak.hpp"
 #include "zkhip_modular.hpp"
@@ -157,6 +158,7 @@ public:
     void set_memory_log(bool on) { log_memory_ = on; }
     void set_moduli(const std::vector<zkhip::modular::U256>& m) { moduli_ = m; }   // the modular extension's moduli (ecall 5)
     void set_curves(const std::vector<zkhip::ecc::Curve>& c) { curves_ = c; }       // the ecc extension's curves (ecall 7)
+    void set_fp2_moduli(const std::vector<zkhip::modular::U256>& m) { fp2_moduli_ = m; }   // the fp2 extension's fields (ecall 8)
     const zkhip::modular::U256& last_slope() const { return last_slope_; }          // of the last ecc call (the chip's record carries it)
     bool done() const { return done_; }
     uint32_t pc() const { return pc_; }
@@ -176,6 +178,7 @@ private:
     bool log_memory_ = true;
     std::vector<zkhip::modular::U256> moduli_;
     std::vector<zkhip::ecc::Curve> curves_;
+    std::vector<zkhip::modular::U256> fp2_moduli_;
     zkhip::modular::U256 last_slope_{};
     uint64_t instret_ = 0;
     size_t in_pos_ = 0;
@@ -498,6 +501,19 @@ private:
                     if (!zkhip::ecc::ec_op(eop, curves_[which], c[0], c[1], c[2], c[3], &last_slope_, &x3, &y3))
                         throw Error("ecc: coordinates not reduced, or no slope (equal abscissae in an addition, y = 0 in a doubling)");
                     memcpy(p + 128, x3.w, 32), memcpy(p + 160, y3.w, 32);
+                } else if (call == 8) {
+                    // r = a b, a + b, a - b or a / b in Fp[u] / (u^2 + 1) on the 48 words at a0 (a0 a1 | b0 b1 | r0 r1, little-endian 256-bit
+                    // words), field i of the app's openvm.toml, a1 = i + 8 op (OpenVM's fp2 extension)
+                    if (rec && log_memory_) throw Error("the fp2 intrinsic is proven by the one-statement flow only");
+                    const uint32_t addr = reg_read(rec, 10), sel = reg_read(rec, 11), which = sel & 7u, fop = sel >> 3;
+                    if (which >= fp2_moduli_.size()) throw Error("fp2: the app's openvm.toml lists no fp2 field " + std::to_string(which));
+                    if (fop >= zkhip::fp2::N_OPS) throw Error("fp2: unknown operation " + std::to_string(fop));
+                    if (addr & 3u) throw Error("fp2 buffer must be word-aligned");
+                    uint8_t* p = at(addr, 192);
+                    zkhip::fp2::Elem a, b, r;
+                    memcpy(a.c0.w, p, 32), memcpy(a.c1.w, p + 32, 32), memcpy(b.c0.w, p + 64, 32), memcpy(b.c1.w, p + 96, 32);
+                    if (!zkhip::fp2::fp2_op(fop, fp2_moduli_[which], a, b, &r)) throw Error("fp2: components not reduced, or a division by zero");
+                    memcpy(p + 128, r.c0.w, 32), memcpy(p + 160, r.c1.w, 32);
                 } else {
                     throw Error("unknown environment call " + std::to_string(call));
                 }
@@ -622,7 +638,7 @@ inline Exe parse_exe(const std::vector<uint8_t>& raw) {
 // `moduli` / `curves`: the app's modular and ecc extensions (openvm.toml), for guests that call those intrinsics.
 inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64_t max_cost = 0, ExecRecords* records = nullptr,
                                      uint64_t max_instr = 0, const std::vector<zkhip::modular::U256>& moduli = {},
-                                     const std::vector<zkhip::ecc::Curve>& curves = {}) {
+                                     const std::vector<zkhip::ecc::Curve>& curves = {}, const std::vector<zkhip::modular::U256>& fp2_moduli = {}) {
     auto all_zero = [](const std::vector<uint8_t>& v) {
         for (uint8_t b : v)
             if (b) return false;
@@ -633,7 +649,7 @@ inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64
     {
         *rec = ExecRecords();
         Machine m(exe, inputs);
-        m.set_moduli(moduli), m.set_curves(curves);
+        m.set_moduli(moduli), m.set_curves(curves), m.set_fp2_moduli(fp2_moduli);
         bool finished = false;
         try {
             finished = m.run(max_instr, max_cost, rec);
@@ -649,7 +665,7 @@ inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64
     // the plain executor: no cost bound, and -- like the reference's -- no instruction count (u64::MAX as the sentinel)
     *rec = ExecRecords();
     Machine m(exe, inputs);
-    m.set_moduli(moduli), m.set_curves(curves);
+    m.set_moduli(moduli), m.set_curves(curves), m.set_fp2_moduli(fp2_moduli);
     if (!m.run(max_instr, 0, rec)) throw Error("instruction limit reached");  // max_instr: a service-side bound, 0 = none
     if (m.exit_code()) throw Error("guest exited with code " + std::to_string(m.exit_code()));
     if (all_zero(m.public_values())) throw Error("public_values are all 0s upon execute");

@@ -26,6 +26,9 @@
 //                  ecc (a7 = 7: (x3, y3) = (x1, y1) + (x2, y2) or the double of (x1, y1) on the 48 words at a0 -- the two operands, then
 //                  the result's slot; a1 = i + 8 op: i the index of one of the curves the app's openvm.toml lists, op 0 add (x1 != x2),
 //                  1 double; OpenVM's ecc extension).
+//                  fp2 (a7 = 8: r = a b, a + b, a - b or a / b in Fp[u] / (u^2 + 1) on the 48 words at a0 -- a, b, then the result's slot,
+//                  two 256-bit components each; a1 = i + 8 op: i the index of one of the fields the app's openvm.toml lists; OpenVM's
+//                  fp2 extension).  Its adapter has the ecc adapter's shape on buses of its own.
 //   ecc adapter    one per curve, one row per WORD of a call (48 rows): operands read, result written; (timestamp, index, halves, op)
 //                  goes to that curve's point chip (include/zkhip_ecc.hpp, one operation per row).
 //   int256 adapter one row per WORD of a call (24 rows): b, c read, a written; (timestamp, index, halves, opcode) goes to the 256-bit ALU
@@ -59,6 +62,7 @@
 
 #include "zkhip_chips.hpp"
 #include "zkhip_ecc.hpp"
+#include "zkhip_fp2.hpp"
 #include "zkhip_int256.hpp"
 #include "zkhip_keccak.hpp"
 #include "zkhip_modular.hpp"
@@ -72,12 +76,13 @@ using air::Kind;
 
 constexpr uint32_t MEMORY_BUS = 1, EXEC_BUS = 2, OPERAND_BUS = 3, RANGE_BUS = 5, RANGE_TUPLE_BUS = 6, PROGRAM_BUS = 8, BITWISE_BUS = 9,
                    MERKLE_BUS = 10, HASH_BUS = 11, KECCAK_REQ_BUS = 12, KECCAK_LANE_BUS = 13, SHA_REQ_BUS = 14, SHA_MSG_BUS = 15, SHA_STATE_BUS = 16, MODMUL_REQ_BUS = 17, MODMUL_WORD_BUS = 18,   // modulus i: word bus 18 + i
-                   INT256_REQ_BUS = 30, INT256_WORD_BUS = 31, EC_REQ_BUS = 32, EC_WORD_BUS = 33;   // curve i: word bus 33 + i
+                   INT256_REQ_BUS = 30, INT256_WORD_BUS = 31, EC_REQ_BUS = 32, EC_WORD_BUS = 33,   // curve i: word bus 33 + i
+                   FP2_REQ_BUS = 37, FP2_WORD_BUS = 38;                                                // fp2 field i: word bus 38 + i
 constexpr uint32_t TS_STEP = 16;   // timestamps per instruction: rs1 at +0; rs2 at +2; the core's own accesses at +4 ..; rd at +12
 constexpr uint32_t BLOCK_CELLS = 8, BLOCK_WORDS = 4, LABEL_BITS = 26, LEAF_LEVEL = LABEL_BITS + 2;  // block label = as * 2^26 + (word >> 2); the tree has 28 levels above the blocks
 constexpr uint32_t GAP_HI_BITS = 11;  // a timestamp gap is gap_lo + 2^16 gap_hi with gap_hi below 2^11 (one range-tuple lookup (0, gap_hi))
 enum Cls : uint32_t { C_ALU, C_LT, C_MUL, C_MULH, C_DIVREM, C_SHIFT, C_BEQ, C_BLT, C_JAL_LUI, C_AUIPC, C_JALR, C_LS, C_ECALL, N_CLS };
-constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 33, LEAF_WIDTH = 43, MERKLE_WIDTH = 54, KECCAK_IO_WIDTH = 42, SHA_IO_WIDTH = 34, MODMUL_IO_WIDTH = 35, INT256_IO_WIDTH = 35, EC_IO_WIDTH = 59,
+constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 34, LEAF_WIDTH = 43, MERKLE_WIDTH = 54, KECCAK_IO_WIDTH = 42, SHA_IO_WIDTH = 34, MODMUL_IO_WIDTH = 35, INT256_IO_WIDTH = 35, EC_IO_WIDTH = 59,
                  CONNECTOR_WIDTH = 2;
 constexpr uint32_t P = air::P;
 
@@ -376,16 +381,16 @@ inline void loadstore_air(AirBuilder& b) {
 
 // ecall chip: AirBuilder(ECALL_WIDTH, 0).  Columns: pc ts | x[4] (a7) | y[4] (a0) | z[4] (a0 afterwards) | is_exit is_reveal is_read |
 // idx (a1, the public-value word index) | pv_prev_lo pv_prev_hi | pc_inc | (prev_ts gap_lo gap_hi) of the a1 read and the public-value write |
-// is_keccak | q (= a0's low byte / 4: the state must be word-aligned) | is_sha | is_mod | is_int | is_ec
+// is_keccak | q (= a0's low byte / 4: the state must be word-aligned) | is_sha | is_mod | is_int | is_ec | is_fp2
 inline void ecall_air(AirBuilder& b) {
     const Expr pc = b.var(0), ts = b.var(1);
     Expr x[4], y[4], z[4];
     for (int i = 0; i < 4; i++) x[i] = b.var(2 + i), y[i] = b.var(6 + i), z[i] = b.var(10 + i);
     const Expr is_exit = b.var(14), is_reveal = b.var(15), is_read = b.var(16), idx = b.var(17), pvp_lo = b.var(18), pvp_hi = b.var(19), pc_inc = b.var(20);
-    const Expr is_keccak = b.var(27), q = b.var(28), is_sha = b.var(29), is_mod = b.var(30), is_int = b.var(31), is_ec = b.var(32), is_hash = is_keccak + is_sha + is_mod + is_int + is_ec;
-    const Expr ok = is_exit + is_reveal + is_read + is_keccak + is_sha + is_mod + is_int + is_ec;
-    for (const Expr& f : {is_exit, is_reveal, is_read, is_keccak, is_sha, is_mod, is_int, is_ec, ok}) b.assert_zero(f * (f - 1));
-    b.assert_zero(x[0] - is_exit * 93 - is_reveal - is_read * 2 - is_keccak * 3 - is_sha * 4 - is_mod * 5 - is_int * 6 - is_ec * 7);
+    const Expr is_keccak = b.var(27), q = b.var(28), is_sha = b.var(29), is_mod = b.var(30), is_int = b.var(31), is_ec = b.var(32), is_fp2 = b.var(33), is_hash = is_keccak + is_sha + is_mod + is_int + is_ec + is_fp2;
+    const Expr ok = is_exit + is_reveal + is_read + is_keccak + is_sha + is_mod + is_int + is_ec + is_fp2;
+    for (const Expr& f : {is_exit, is_reveal, is_read, is_keccak, is_sha, is_mod, is_int, is_ec, is_fp2, ok}) b.assert_zero(f * (f - 1));
+    b.assert_zero(x[0] - is_exit * 93 - is_reveal - is_read * 2 - is_keccak * 3 - is_sha * 4 - is_mod * 5 - is_int * 6 - is_ec * 7 - is_fp2 * 8);
     for (int i = 1; i < 4; i++) b.assert_zero(x[i]);
     for (int i = 0; i < 4; i++) {
         b.assert_zero(is_exit * y[i]);                 // exit code 0: a failing guest has no proof
@@ -400,7 +405,7 @@ inline void ecall_air(AirBuilder& b) {
     const Expr one = b.constant(1), zero = b.constant(0), three = b.constant(3);
     // reveal: a1 (register 11) is the word index, below 8; the word a0 goes to word idx of address space 3
     // (modmul, int256 and ecc read a1 the same way: the index of the modulus / curve, the opcode)
-    word_access(b, is_reveal + is_mod + is_int + is_ec, is_reveal + is_mod + is_int + is_ec, one, b.constant(11), idx, zero, idx, zero, ts + 4, b.var(21), b.var(22), b.var(23));
+    word_access(b, is_reveal + is_mod + is_int + is_ec + is_fp2, is_reveal + is_mod + is_int + is_ec + is_fp2, one, b.constant(11), idx, zero, idx, zero, ts + 4, b.var(21), b.var(22), b.var(23));
     word_access(b, is_reveal, is_reveal, three, idx, pvp_lo, pvp_hi, y[0] + y[1] * 256, y[2] + y[3] * 256, ts + 5, b.var(24), b.var(25), b.var(26));
     b.push_interaction(RANGE_BUS, {idx * 8192}, is_reveal, Kind::Send);
     b.push_interaction(RANGE_BUS, {idx}, is_reveal, Kind::Send);
@@ -413,6 +418,7 @@ inline void ecall_air(AirBuilder& b) {
     b.push_interaction(MODMUL_REQ_BUS, {ts, wptr, idx}, is_mod, Kind::Send);
     b.push_interaction(INT256_REQ_BUS, {ts, wptr, idx}, is_int, Kind::Send);
     b.push_interaction(EC_REQ_BUS, {ts, wptr, idx}, is_ec, Kind::Send);
+    b.push_interaction(FP2_REQ_BUS, {ts, wptr, idx}, is_fp2, Kind::Send);
     b.push_interaction(RANGE_BUS, {q * 1024}, is_hash, Kind::Send);
     b.push_interaction(RANGE_BUS, {q}, is_hash, Kind::Send);
     b.push_interaction(RANGE_BUS, {y[3] * 1024}, is_hash, Kind::Send);
@@ -531,7 +537,8 @@ inline void int256_io_air(AirBuilder& b) {
 
 // ecc adapter of curve `index`: AirBuilder(EC_IO_WIDTH, 0).  The modular adapter's shape with 48 words: word[48] (0..15 x1 y1, 16..31
 // x2 y2: read; 32..47 x3 y3: written) | ts | base | v_lo v_hi | n_lo n_hi | prev_ts gap_lo gap_hi | ok | op (a1 = index + 8 op).
-inline void ec_io_air(AirBuilder& b, uint32_t index) {
+// (the fp2 adapter has the same shape on its own pair of buses: two operands of 16 words read, a result of 16 words written)
+inline void ec_io_air(AirBuilder& b, uint32_t index, uint32_t req_bus = EC_REQ_BUS, uint32_t word_bus_base = EC_WORD_BUS) {
     constexpr int W = 48;
     Expr sel[W];
     for (int k = 0; k < W; k++) sel[k] = b.var(k);
@@ -552,9 +559,9 @@ inline void ec_io_air(AirBuilder& b, uint32_t index) {
     b.when_transition(cont * (b.var(W + 10, 1) - op));
     b.assert_zero(is_read * (n_lo - v_lo));
     b.assert_zero(is_read * (n_hi - v_hi));
-    b.push_interaction(EC_REQ_BUS, {ts, base, op * 8 + (int64_t)index}, sel[0], Kind::Receive);
+    b.push_interaction(req_bus, {ts, base, op * 8 + (int64_t)index}, sel[0], Kind::Receive);
     word_access(b, ok, ok, b.constant(2), base + idx, v_lo, v_hi, n_lo, n_hi, ts + 5, b.var(W + 6), b.var(W + 7), b.var(W + 8));
-    b.push_interaction(EC_WORD_BUS + index, {ts, idx, n_lo, n_hi, op}, ok, Kind::Send);
+    b.push_interaction(word_bus_base + index, {ts, idx, n_lo, n_hi, op}, ok, Kind::Send);
 }
 
 // leaf chip: AirBuilder(LEAF_WIDTH, 0).  Columns: as blk | init[8] | fin[8] | fin_ts[4] | h_init[8] | h_fin[8] | ok | gap_lo gap_hi |
@@ -652,12 +659,15 @@ enum AirId : unsigned {
     A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, A_INT256, A_INT256_IO, A_MUL256, A_CMP256, A_SHIFT256, N_STATIC_AIRS
 };
 // the modular extension brings two chips per configured modulus (openvm.toml `supported_moduli`): ids A_MODMUL(i), A_MODMUL_IO(i)
-constexpr unsigned MAX_MODULI = 8, MAX_CURVES = 4, N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES;
+constexpr unsigned MAX_MODULI = 8, MAX_CURVES = 4, MAX_FP2 = 2, N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES + 2 * MAX_FP2;
 constexpr unsigned A_MODMUL(unsigned i) { return N_STATIC_AIRS + 2 * i; }
 constexpr unsigned A_MODMUL_IO(unsigned i) { return N_STATIC_AIRS + 2 * i + 1; }
 // the ecc extension likewise per configured curve (openvm.toml `[[app_vm_config.ecc.supported_curves]]`): A_EC(i), A_EC_IO(i)
 constexpr unsigned A_EC(unsigned i) { return N_STATIC_AIRS + 2 * MAX_MODULI + 2 * i; }
 constexpr unsigned A_EC_IO(unsigned i) { return N_STATIC_AIRS + 2 * MAX_MODULI + 2 * i + 1; }
+// the fp2 extension per configured field (openvm.toml `[app_vm_config.fp2] supported_moduli`): A_FP2(i), A_FP2_IO(i)
+constexpr unsigned A_FP2(unsigned i) { return N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES + 2 * i; }
+constexpr unsigned A_FP2_IO(unsigned i) { return N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES + 2 * i + 1; }
 constexpr unsigned N_BASE_AIRS = A_KECCAK;   // the extension chips come last: an app has the base chips + the extensions its openvm.toml enables
 struct AirShape {
     size_t width = 0, n_pvs = 0, prep_width = 0, cached_width = 0;
@@ -679,6 +689,15 @@ inline AirShape build_ec_air(const modular::Modulus& P, const modular::Modulus& 
     if (adapter) ec_io_air(b, index);
     else ecc::ec_vm_air(b, P, A, BITWISE_BUS, RANGE_TUPLE_BUS, EC_WORD_BUS + index);
     s.width = adapter ? EC_IO_WIDTH : ecc::VM_WIDTH, s.program = b.program();
+    return s;
+}
+// the two chips of fp2 field `index`
+inline AirShape build_fp2_air(const modular::Modulus& P, unsigned index, bool adapter) {
+    AirShape s;
+    AirBuilder b(adapter ? EC_IO_WIDTH : fp2::VM_WIDTH, 0, 0);
+    if (adapter) ec_io_air(b, index, FP2_REQ_BUS, FP2_WORD_BUS);
+    else fp2::fp2_vm_air(b, P, BITWISE_BUS, RANGE_TUPLE_BUS, FP2_WORD_BUS + index);
+    s.width = adapter ? EC_IO_WIDTH : fp2::VM_WIDTH, s.program = b.program();
     return s;
 }
 inline AirShape build_air(unsigned id) {

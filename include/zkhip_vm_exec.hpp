@@ -91,6 +91,7 @@ struct SegmentCaps {
     bool int256() const { return pos(vmc::A_INT256) >= 0; }
     std::vector<zkhip::modular::U256> moduli;   // the modular extension: chips A_MODMUL(i), A_MODMUL_IO(i) per modulus
     std::vector<zkhip::ecc::Curve> curves;      // the ecc extension: chips A_EC(i), A_EC_IO(i) per curve
+    std::vector<zkhip::modular::U256> fp2_moduli;   // the fp2 extension: chips A_FP2(i), A_FP2_IO(i) per field
     // heights for segments of about 2^log_frame instructions of an ordinary instruction mix
     // log_keccak: 0 = the app has no keccak extension (22 chips); otherwise the rows of the Keccak-f chip (24 per permutation call,
     // at least 32).  A wide chip costs every segment proof and every leaf circuit its 2634 openings per query, used or not, so it is
@@ -101,7 +102,8 @@ struct SegmentCaps {
     // curves / log_ec: one point chip (one call per row) + adapter (48 rows per call) per curve of `[[app_vm_config.ecc.supported_curves]]`.
     static SegmentCaps for_frame(unsigned log_frame, unsigned log_program, unsigned log_keccak = 0, unsigned log_sha256 = 0,
                                  const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_modmul = 0, unsigned log_int256 = 0,
-                                 const std::vector<zkhip::ecc::Curve>& curves = {}, unsigned log_ec = 0) {
+                                 const std::vector<zkhip::ecc::Curve>& curves = {}, unsigned log_ec = 0,
+                                 const std::vector<zkhip::modular::U256>& fp2_moduli = {}) {
         SegmentCaps c;
         for (unsigned a = 0; a < vmc::N_BASE_AIRS; a++) c.ids.push_back(a);
         auto sub = [&](unsigned d) { return log_frame > d + 2 ? log_frame - d : 2u; };
@@ -139,6 +141,12 @@ struct SegmentCaps {
             c.ids.push_back(vmc::A_EC(i)), c.ids.push_back(vmc::A_EC_IO(i));
             c.log_height[vmc::A_EC(i)] = std::max(log_ec, 1u), c.log_height[vmc::A_EC_IO(i)] = c.log_height[vmc::A_EC(i)] + 6;   // 48 adapter rows per call
         }
+        if (fp2_moduli.size() > vmc::MAX_FP2) throw Error("at most " + std::to_string(vmc::MAX_FP2) + " fp2 fields");
+        c.fp2_moduli = fp2_moduli;
+        for (unsigned i = 0; i < fp2_moduli.size(); i++) {   // (the heights of the ecc chips: one operation per row, 48 adapter rows per call)
+            c.ids.push_back(vmc::A_FP2(i)), c.ids.push_back(vmc::A_FP2_IO(i));
+            c.log_height[vmc::A_FP2(i)] = std::max(log_ec, 1u), c.log_height[vmc::A_FP2_IO(i)] = c.log_height[vmc::A_FP2(i)] + 6;
+        }
         c.n_airs = (unsigned)c.ids.size();
         return c;
     }
@@ -163,6 +171,8 @@ struct SegmentRecords {
     std::vector<uint32_t> mm_records[vmc::MAX_MODULI], mm_ts[vmc::MAX_MODULI], mmio_rows[vmc::MAX_MODULI];
     // ecc calls per curve: op | x1 y1 x2 y2 | slope (41 words) and the timestamp per call; the adapter's rows
     std::vector<uint32_t> ec_records[vmc::MAX_CURVES], ec_ts[vmc::MAX_CURVES], ecio_rows[vmc::MAX_CURVES];
+    // fp2 calls per field: op | a | b (33 words; a division's a slot holds the quotient) and the timestamp per call; the adapter's rows
+    std::vector<uint32_t> fp2_records[vmc::MAX_FP2], fp2_ts[vmc::MAX_FP2], fp2io_rows[vmc::MAX_FP2];
     uint32_t pc_start = 0, pc_end = 0, ts_end = 0;
     Digest root_init{}, root_final{};
     size_t n_instr = 0;
@@ -179,6 +189,7 @@ struct SegmentRecords {
             v->clear();
         for (unsigned i = 0; i < vmc::MAX_MODULI; i++) mm_records[i].clear(), mm_ts[i].clear(), mmio_rows[i].clear();
         for (unsigned i = 0; i < vmc::MAX_CURVES; i++) ec_records[i].clear(), ec_ts[i].clear(), ecio_rows[i].clear();
+        for (unsigned i = 0; i < vmc::MAX_FP2; i++) fp2_records[i].clear(), fp2_ts[i].clear(), fp2io_rows[i].clear();
         n_instr = 0;
     }
 };
@@ -192,6 +203,7 @@ public:
         m_.set_memory_log(false);
         m_.set_moduli(caps.moduli);
         m_.set_curves(caps.curves);
+        m_.set_fp2_moduli(caps.fp2_moduli);
         dec_.reserve(exe.program.size());
         for (size_t k = 0; k < exe.program.size(); k++) dec_.push_back(vmc::decode(exe.program[k], exe.pc_base + 4 * (uint32_t)k));
         mem_lo_blk_ = exe.data_base / 16;
@@ -242,8 +254,8 @@ public:
                 if (d.wr_rd) want(1, d.rd);
                 if (d.cls == vmc::C_LS) want(2, ((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) >> 2);
                 if (d.cls == vmc::C_ECALL) want(1, 11), want(3, m_.reg(11) & 7u);
-                if (d.cls == vmc::C_ECALL && m_.reg(17) >= 3 && m_.reg(17) <= 7) {
-                    const uint32_t n_words = m_.reg(17) == 3 ? 50 : m_.reg(17) == 7 ? 48 : 24;
+                if (d.cls == vmc::C_ECALL && m_.reg(17) >= 3 && m_.reg(17) <= 8) {
+                    const uint32_t n_words = m_.reg(17) == 3 ? 50 : m_.reg(17) >= 7 ? 48 : 24;
                     for (uint32_t w = m_.reg(10) >> 2; w < (m_.reg(10) >> 2) + n_words; w += (w & 3u) ? 4 - (w & 3u) : 4) want(2, w);
                 }
                 if (!all_known) {   // rare: count exactly what the instruction would add
@@ -273,12 +285,16 @@ public:
             if (d.cls == vmc::C_ECALL && m_.reg(17) == 7 && ((m_.reg(11) & 7u) >= caps_.curves.size() || (m_.reg(11) >> 3) >= zkhip::ecc::N_OPS))
                 throw Error("the guest calls the ecc intrinsic for curve " + std::to_string(m_.reg(11) & 7u) + " but the app's openvm.toml lists " +
                             std::to_string(caps_.curves.size()) + " curves");
+            if (d.cls == vmc::C_ECALL && m_.reg(17) == 8 && ((m_.reg(11) & 7u) >= caps_.fp2_moduli.size() || (m_.reg(11) >> 3) >= zkhip::fp2::N_OPS))
+                throw Error("the guest calls the fp2 intrinsic for field " + std::to_string(m_.reg(11) & 7u) + " but the app's openvm.toml lists " +
+                            std::to_string(caps_.fp2_moduli.size()) + " fp2 fields");
             if (r.n_instr + 1 > caps_.rows(vmc::A_FRAME) || n_cls[d.cls] + 1 > caps_.rows(vmc::A_ALU + d.cls) ||
                 blk_.size() + new_blocks > caps_.rows(vmc::A_LEAF) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 3 && 24 * (r.n_keccak() + 1) > caps_.rows(vmc::A_KECCAK)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 4 && 65 * (r.n_sha256() + 1) > caps_.rows(vmc::A_SHA256)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 5 && r.mm_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_MODMUL(m_.reg(11) & 7u))) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 7 && r.ec_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_EC(m_.reg(11) & 7u))) ||
+                (d.cls == vmc::C_ECALL && m_.reg(17) == 8 && r.fp2_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_FP2(m_.reg(11) & 7u))) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 6 && (m_.reg(11) == 5 ? r.mul256_ts.size() : m_.reg(11) > 8 ? r.sh256_ts.size() : m_.reg(11) > 5 ? r.cmp256_ts.size() : r.i256_ts.size()) + 1 > caps_.rows(vmc::A_INT256)) ||
                 path_nodes_.size() + new_nodes > caps_.rows(vmc::A_MERKLE) ||
                 2 * (blk_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
@@ -308,9 +324,9 @@ public:
                 for (uint32_t j = 0; j < 24; j++) mm_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
             }
             uint32_t ec_in[48];
-            if (d.cls == vmc::C_ECALL && x == 7) {
+            if (d.cls == vmc::C_ECALL && (x == 7 || x == 8)) {
                 a1 = m_.reg(11);
-                if ((y & 3u) || (uint64_t)y + 192 > (1ull << 30)) throw Error("ecc buffer must be word-aligned and below 2^30");
+                if ((y & 3u) || (uint64_t)y + 192 > (1ull << 30)) throw Error("ecc / fp2 buffer must be word-aligned and below 2^30");
                 for (uint32_t j = 0; j < 48; j++) ec_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
             }
             // snapshot the blocks this instruction is going to change
@@ -398,6 +414,30 @@ public:
                         const uint32_t pts = k >= 32 ? write_word(2, w, after, ts + 5) : read_word(2, w, before, ts + 5), gap = ts + 5 - pts - 1;
                         sr[W + 6] = pts, sr[W + 7] = gap & 0xffffu, sr[W + 8] = gap >> 16;
                         r.ecio_rows[ci].insert(r.ecio_rows[ci].end(), sr, sr + vmc::EC_IO_WIDTH);
+                    }
+                }
+                if (x == 8) {
+                    row[33] = 1, row[28] = (y & 255u) >> 2, row[17] = a1;
+                    auto gap3 = [&](uint32_t* dst, uint32_t pts, uint32_t at) { dst[0] = pts, dst[1] = (at - pts - 1) & 0xffffu, dst[2] = (at - pts - 1) >> 16; };
+                    gap3(row + 21, read_word(1, 11, a1, ts + 4), ts + 4);
+                    const uint32_t fi = a1 & 7u, fop = a1 >> 3;
+                    r.fp2_ts[fi].push_back(ts);
+                    r.fp2_records[fi].push_back(fop);
+                    if (fop == zkhip::fp2::OP_DIV) {   // the chip's row is the product (x / y) y = x: the record holds the quotient and y
+                        for (uint32_t k = 0; k < 16; k++) r.fp2_records[fi].push_back(mem_word(y + 128 + 4 * k));
+                        r.fp2_records[fi].insert(r.fp2_records[fi].end(), ec_in + 16, ec_in + 32);
+                    } else {
+                        r.fp2_records[fi].insert(r.fp2_records[fi].end(), ec_in, ec_in + 32);
+                    }
+                    constexpr uint32_t W = 48;
+                    for (uint32_t k = 0; k < W; k++) {   // the adapter's rows: the operands read, the result written, all at ts + 5
+                        uint32_t sr[vmc::EC_IO_WIDTH] = {};
+                        const uint32_t w = (y >> 2) + k, before = ec_in[k], after = mem_word(y + 4 * k);
+                        sr[k] = 1, sr[W] = ts, sr[W + 1] = y >> 2, sr[W + 9] = 1, sr[W + 10] = fop;
+                        sr[W + 2] = before & 0xffffu, sr[W + 3] = before >> 16, sr[W + 4] = after & 0xffffu, sr[W + 5] = after >> 16;
+                        const uint32_t pts = k >= 32 ? write_word(2, w, after, ts + 5) : read_word(2, w, before, ts + 5), gap = ts + 5 - pts - 1;
+                        sr[W + 6] = pts, sr[W + 7] = gap & 0xffffu, sr[W + 8] = gap >> 16;
+                        r.fp2io_rows[fi].insert(r.fp2io_rows[fi].end(), sr, sr + vmc::EC_IO_WIDTH);
                     }
                 }
                 if (x == 5) {

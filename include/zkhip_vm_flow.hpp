@@ -44,7 +44,12 @@ inline SegmentAirs segment_airs(const Exe& exe, const SegmentCaps& caps) {
     s.airs.resize(caps.n_airs), s.prep_width.resize(caps.n_airs);
     for (unsigned p = 0; p < caps.n_airs; p++) {   // position p of the proof holds chip caps.ids[p] (base chips: p = id)
         const unsigned id = caps.ids[p];
-        if (id >= vmc::A_EC(0)) {   // the ecc extension: chip / adapter of curve i
+        if (id >= vmc::A_FP2(0)) {   // the fp2 extension: chip / adapter of field i
+            const unsigned i = (id - vmc::A_FP2(0)) / 2;
+            const zkhip::modular::Modulus m = zkhip::modular::modulus_bytes(caps.fp2_moduli.at(i));
+            if (zkhip_vm_fp2_air(m.data(), i, (id - vmc::A_FP2(0)) & 1, &s.airs[p]) != ZKHIP_OK) throw Error("zkhip_vm_fp2_air failed (the modulus must be odd with a non-zero top byte)");
+            s.prep_width[p] = 0;
+        } else if (id >= vmc::A_EC(0)) {   // the ecc extension: chip / adapter of curve i
             const unsigned i = (id - vmc::A_EC(0)) / 2;
             const zkhip::modular::Modulus m = zkhip::modular::modulus_bytes(caps.curves.at(i).p), ca = zkhip::modular::modulus_bytes(caps.curves.at(i).a);
             if (zkhip_vm_ec_air(m.data(), ca.data(), i, (id - vmc::A_EC(0)) & 1, &s.airs[p]) != ZKHIP_OK) throw Error("zkhip_vm_ec_air failed (the modulus must be odd with a non-zero top byte)");
@@ -203,6 +208,11 @@ public:
                                        d_bw, d_tup, TUPLE_X, TUPLE_Y));
             check(zkhip_rows_tracegen(ctx_, up(r.ecio_rows[i]), r.ecio_rows[i].size() / vmc::EC_IO_WIDTH, vmc::EC_IO_WIDTH, H(vmc::A_EC_IO(i)), T(vmc::A_EC_IO(i)), nullptr));
         }
+        for (unsigned i = 0; i < caps_.fp2_moduli.size(); i++) {   // fp2 extension: the chip's lookups are counted by its generator
+            check(zkhip_vm_fp2_tracegen(ctx_, caps_.fp2_moduli[i].w, up(r.fp2_records[i]), up(r.fp2_ts[i]), r.fp2_ts[i].size(), H(vmc::A_FP2(i)), T(vmc::A_FP2(i)), d_bw, d_tup,
+                                        TUPLE_X, TUPLE_Y));
+            check(zkhip_rows_tracegen(ctx_, up(r.fp2io_rows[i]), r.fp2io_rows[i].size() / vmc::EC_IO_WIDTH, vmc::EC_IO_WIDTH, H(vmc::A_FP2_IO(i)), T(vmc::A_FP2_IO(i)), nullptr));
+        }
         // ---- lookup multiplicities of the new chips, counted from the requesting columns
         auto pairs = [&](unsigned a, size_t cx, size_t cy, size_t n) {
             if (n) check(zkhip_bitwise_lookup_tracegen(ctx_, T(a) + cx * N(a), T(a) + cy * N(a), d_zeros_, n, 8, d_bw, 1));
@@ -233,9 +243,9 @@ public:
                     for (uint32_t v : {row[17] * 8192, row[17], row[22], row[25]}) misc.push_back(v);
                     tup_y.push_back(row[23]), tup_y.push_back(row[26]);
                 }
-                if (row[30] || row[31] || row[32]) misc.push_back(row[22]), tup_y.push_back(row[23]);   // modmul / int256 / ecc: the a1 read
+                if (row[30] || row[31] || row[32] || row[33]) misc.push_back(row[22]), tup_y.push_back(row[23]);   // modmul / int256 / ecc / fp2: the a1 read
                 if (row[16]) bw_x.push_back(row[10]), bw_y.push_back(row[11]), bw_x.push_back(row[12]), bw_y.push_back(row[13]);
-                if (row[27] || row[29] || row[30] || row[31] || row[32])
+                if (row[27] || row[29] || row[30] || row[31] || row[32] || row[33])
                     for (uint32_t v : {row[28] * 1024, row[28], row[9] * 1024}) misc.push_back(v);
             }
             for (size_t i = 0; i < r.kio_rows.size() / vmc::KECCAK_IO_WIDTH; i++) {
@@ -262,6 +272,11 @@ public:
             for (unsigned m = 0; m < caps_.curves.size(); m++)
                 for (size_t i = 0; i < r.ecio_rows[m].size() / vmc::EC_IO_WIDTH; i++) {
                     const uint32_t* row = &r.ecio_rows[m][i * vmc::EC_IO_WIDTH];
+                    misc.push_back(row[55]), tup_y.push_back(row[56]);
+                }
+            for (unsigned m = 0; m < caps_.fp2_moduli.size(); m++)
+                for (size_t i = 0; i < r.fp2io_rows[m].size() / vmc::EC_IO_WIDTH; i++) {
+                    const uint32_t* row = &r.fp2io_rows[m][i * vmc::EC_IO_WIDTH];
                     misc.push_back(row[55]), tup_y.push_back(row[56]);
                 }
             uint32_t* d_misc = const_cast<uint32_t*>(up(misc));
@@ -625,6 +640,35 @@ inline std::vector<zkhip::ecc::Curve> config_curves(const std::string& path_app_
         if (!have[i].first || !have[i].second) throw Error("openvm.toml: curve " + std::to_string(i) + " needs `modulus` and `a`");
     return out;
 }
+// `[app_vm_config.fp2] supported_moduli = [["<name>", "<decimal>"], ...]` (the reference's chunk circuit lists bn254's Fp2): the moduli
+inline std::vector<zkhip::modular::U256> config_fp2_moduli(const std::string& path_app_config) {
+    std::ifstream f(path_app_config);
+    std::string line, body;
+    bool in_section = false, in_list = false;
+    int depth = 0;
+    while (std::getline(f, line)) {
+        const size_t b0 = line.find_first_not_of(" \t");
+        if (!in_list && b0 != std::string::npos && line[b0] == '[') in_section = line.find("[app_vm_config.fp2]") != std::string::npos;
+        if (!in_section) continue;
+        if (!in_list && line.find("supported_moduli") != std::string::npos) in_list = true, line = line.substr(line.find('=') + 1);
+        if (!in_list) continue;
+        body += line + " ";
+        for (char ch : line) depth += ch == '[' ? 1 : ch == ']' ? -1 : 0;
+        if (depth <= 0 && body.find('[') != std::string::npos) break;
+    }
+    std::vector<zkhip::modular::U256> out;
+    // every inner [ "name", "decimal" ] pair: the last quoted string of the pair is the modulus
+    for (size_t p = body.find('[', body.find('[') == std::string::npos ? 0 : body.find('[') + 1); p != std::string::npos; p = body.find('[', p + 1)) {
+        const size_t e = body.find(']', p);
+        if (e == std::string::npos) break;
+        const std::string pair = body.substr(p + 1, e - p - 1);
+        const size_t q1 = pair.rfind('"'), q0 = q1 == std::string::npos || q1 == 0 ? std::string::npos : pair.rfind('"', q1 - 1);
+        if (q0 == std::string::npos) throw Error("openvm.toml: an fp2 modulus entry is not [\"name\", \"decimal\"]");
+        out.push_back(parse_decimal_u256(pair.substr(q0 + 1, q1 - q0 - 1)));
+        p = e;
+    }
+    return out;
+}
 // 2^(log_frame - 9) rows per curve's point chip (one operation per row)
 inline unsigned ec_log_rows(unsigned log_frame) { return log_frame > 10 ? log_frame - 9 : 1; }
 // `[app_vm_config.modular] supported_moduli = ["<decimal>", ...]` (the reference's chunk circuit lists six): the moduli as 256-bit words
@@ -655,9 +699,9 @@ inline std::vector<zkhip::modular::U256> config_moduli(const std::string& path_a
 inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
                                         bool keep_segments = false, unsigned inflight = 2, unsigned log_keccak = 0, unsigned log_sha256 = 0,
                                         const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_int256 = 0,
-                                        const std::vector<zkhip::ecc::Curve>& curves = {}) {
+                                        const std::vector<zkhip::ecc::Curve>& curves = {}, const std::vector<zkhip::modular::U256>& fp2_moduli = {}) {
     const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak, log_sha256, moduli, log_frame > 8 ? log_frame - 8 : 1, log_int256,
-                                                    curves, ec_log_rows(log_frame));
+                                                    curves, ec_log_rows(log_frame), fp2_moduli);
     std::vector<std::unique_ptr<SegmentProver>> own;
     std::vector<SegmentProver*> lanes;
     for (unsigned l = 0; l < std::max(1u, inflight); l++) own.emplace_back(new SegmentProver(params, exe, caps, device)), lanes.push_back(own.back().get());
@@ -718,7 +762,8 @@ public:
         p.caps_ = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(p.exe_.program.size()), zkhip_vm::keccak_log_rows(cfg.path_app_config, log_frame),
                                                    zkhip_vm::sha256_log_rows(cfg.path_app_config, log_frame), zkhip_vm::config_moduli(cfg.path_app_config),
                                                    log_frame > 8 ? log_frame - 8 : 1, zkhip_vm::int256_log_rows(cfg.path_app_config, log_frame),
-                                                   zkhip_vm::config_curves(cfg.path_app_config), zkhip_vm::ec_log_rows(log_frame));
+                                                   zkhip_vm::config_curves(cfg.path_app_config), zkhip_vm::ec_log_rows(log_frame),
+                                                   zkhip_vm::config_fp2_moduli(cfg.path_app_config));
         return p;
     }
     void reset() {   // mod.rs:106-108: releases the device-resident keys, circuits and workspaces
@@ -727,7 +772,7 @@ public:
     // mod.rs:312-338
     uint64_t execute_and_check(const ProvingTask& task) const {
         try {
-            return zkhip_vm::execute_guest(exe_, task.build_guest_input(), 0, nullptr, 0, caps_.moduli, caps_.curves).total_cycle;
+            return zkhip_vm::execute_guest(exe_, task.build_guest_input(), 0, nullptr, 0, caps_.moduli, caps_.curves, caps_.fp2_moduli).total_cycle;
         } catch (const zkhip_vm::Error& e) {
             throw Error(Error::GenProof, e.what());
         }

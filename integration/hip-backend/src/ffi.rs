@@ -18,6 +18,8 @@ pub const ZKHIP_INT256_ALU_WIDTH: usize = 101;
 pub const ZKHIP_INT256_MUL_WIDTH: usize = 161;
 pub const ZKHIP_MODMUL_WIDTH: usize = 322;
 pub const ZKHIP_EC_WIDTH: usize = 772;
+pub const ZKHIP_FP2_WIDTH: usize = 648;
+pub const ZKHIP_FP2_RECORD_WORDS: usize = 33;
 pub const ZKHIP_INT256_CMP_WIDTH: usize = 103;
 pub const ZKHIP_INT256_SHIFT_WIDTH: usize = 189;
 pub const ZKHIP_EC_RECORD_WORDS: usize = 41;
@@ -373,6 +375,13 @@ extern "C" {
                                       d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_vm_mul256_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
                                     d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    pub fn zkhip_fp2_air(modulus: *const u8, bitwise_bus: u32, tuple_bus: u32, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_fp2_host(op: u32, modulus: *const u32, a: *const u32, b: *const u32, r: *mut u32) -> c_int;
+    pub fn zkhip_fp2_tracegen(ctx: *mut zkhip_ctx, modulus: *const u32, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
+                              d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    pub fn zkhip_vm_fp2_air(modulus: *const u8, index: c_uint, adapter: c_int, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_vm_fp2_tracegen(ctx: *mut zkhip_ctx, modulus: *const u32, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint,
+                                 d_trace: *mut u32, d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
     pub fn zkhip_ec_air(modulus: *const u8, a: *const u8, bitwise_bus: u32, tuple_bus: u32, out: *mut zkhip_air) -> c_int;
     pub fn zkhip_ec_host(op: u32, modulus: *const u32, a: *const u32, x1: *const u32, y1: *const u32, x2: *const u32, y2: *const u32, slope: *mut u32,
                          x3: *mut u32, y3: *mut u32) -> c_int;

@@ -105,7 +105,7 @@ def sx(v, bits):
     return v - (1 << bits) if v >> (bits - 1) else v
 
 
-def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_bytes=1 << 20, data=b"", max_instr=10**7, moduli=(), curves=()):
+def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_bytes=1 << 20, data=b"", max_instr=10**7, moduli=(), curves=(), fp2=()):
     """Independent interpreter.  Returns dict(instret, pvs (32 bytes), exit_code, records)."""
     x = [0] * 32
     x[2] = data_base + memory_bytes
@@ -333,6 +333,22 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                 x3 = (lam * lam - x1 - (x1 if eop else x2)) % p_
                 mem[off + 128:off + 160] = x3.to_bytes(32, "little")
                 mem[off + 160:off + 192] = ((lam * (x1 - x3) - y1) % p_).to_bytes(32, "little")
+            elif call == 8:   # r = a op b in Fp[u] / (u^2 + 1) over fp2[a1 & 7], 48 words at a0 (a0 a1 | b0 b1 | r0 r1); op 0 mul 1 add 2 sub 3 div
+                off = rr(10) - data_base
+                sel = rr(11)
+                p_, fop = fp2[sel & 7], sel >> 3
+                assert off % 4 == 0 and 0 <= off and off + 192 <= len(mem) and fop < 4
+                a0_, a1_, b0_, b1_ = (int.from_bytes(mem[off + 32 * k:off + 32 * k + 32], "little") for k in range(4))
+                if fop == 3:   # divide: multiply by the conjugate over the norm
+                    nrm = pow((b0_ * b0_ + b1_ * b1_) % p_, -1, p_)
+                    b0_, b1_ = b0_ * nrm % p_, -b1_ * nrm % p_
+                if fop in (0, 3):
+                    r0_, r1_ = (a0_ * b0_ - a1_ * b1_) % p_, (a0_ * b1_ + a1_ * b0_) % p_
+                else:
+                    sg = 1 if fop == 1 else -1
+                    r0_, r1_ = (a0_ + sg * b0_) % p_, (a1_ + sg * b1_) % p_
+                mem[off + 128:off + 160] = r0_.to_bytes(32, "little")
+                mem[off + 160:off + 192] = r1_.to_bytes(32, "little")
             elif call == 4:   # SHA-256 compression on the 24 words at a0: state[8] <- compress(state, block[16])
                 off = rr(10) - data_base
                 assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem)

@@ -18,7 +18,7 @@ import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
 from test_vm_cpu import (ALL_EXT_MSG, CHUNK_CIRCUIT_CURVES, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, chunk_circuit_toml, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
-                         keccak_program, mixed_program, modmul_data, modmul_program, sha256_data, sha256_program, EC_CURVES, ec_data, ec_program)
+                         keccak_program, mixed_program, modmul_data, modmul_program, sha256_data, sha256_program, EC_CURVES, ec_data, ec_program, BN254_P, fp2_data, fp2_program)
 
 pytestmark = pytest.mark.gpu
 PARAMS = (1, 0, 4, 3, 3)
@@ -92,6 +92,11 @@ def device_traces(zk, rec, prog, H):
         T[v2.A_EC(i)] = zk.ec_tracegen(p_, a_, D(rec["ec_records_%d" % i]) if n_ec else None, n_ec, H[v2.A_EC(i)], d_bw, d_tup, v2.SX, v2.SY,
                                        t_ts=D(rec["ec_ts_%d" % i]) if n_ec else torch.zeros(1, dtype=torch.int32, device=dev))
         T[v2.A_EC_IO(i)] = zk.rows_tracegen(D(rec["ecio_rows_%d" % i]), len(rec["ecio_rows_%d" % i]) // v2.EC_IO_WIDTH, v2.EC_IO_WIDTH, H[v2.A_EC_IO(i)])
+    for i, p_ in enumerate(H.fp2):   # the Fp2 chips count their own lookups into the two tables
+        n_f = len(rec["fp2_ts_%d" % i])
+        T[v2.A_FP2(i)] = zk.fp2_tracegen(p_, D(rec["fp2_records_%d" % i]) if n_f else None, n_f, H[v2.A_FP2(i)], d_bw, d_tup, v2.SX, v2.SY,
+                                         t_ts=D(rec["fp2_ts_%d" % i]) if n_f else torch.zeros(1, dtype=torch.int32, device=dev))
+        T[v2.A_FP2_IO(i)] = zk.rows_tracegen(D(rec["fp2io_rows_%d" % i]), len(rec["fp2io_rows_%d" % i]) // v2.EC_IO_WIDTH, v2.EC_IO_WIDTH, H[v2.A_FP2_IO(i)])
     n, nls = len(rec["f_x"]), len(rec["ls_case"])
     zeros = torch.zeros(max(n, nls, 64), dtype=torch.int32, device=dev)
     NF, NL = 1 << H[v2.A_FRAME], 1 << H[v2.A_LS]
@@ -121,10 +126,10 @@ def device_traces(zk, rec, prog, H):
         if row[16]:
             bw_x += [int(row[10]), int(row[12])]
             bw_y += [int(row[11]), int(row[13])]
-        if row[30] or row[31] or row[32]:
+        if row[30] or row[31] or row[32] or row[33]:
             misc += [int(row[22])]
             tup_y += [int(row[23])]
-        if row[27] or row[29] or row[30] or row[31] or row[32]:
+        if row[27] or row[29] or row[30] or row[31] or row[32] or row[33]:
             misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
     for row in rec["kio_rows"].reshape(-1, v2.KECCAK_IO_WIDTH):
         misc += [int(row[36]), int(row[39])]
@@ -141,6 +146,10 @@ def device_traces(zk, rec, prog, H):
             tup_y += [int(row[32])]
     for i in range(len(H.curves)):
         for row in rec["ecio_rows_%d" % i].reshape(-1, v2.EC_IO_WIDTH):
+            misc += [int(row[55])]
+            tup_y += [int(row[56])]
+    for i in range(len(H.fp2)):
+        for row in rec["fp2io_rows_%d" % i].reshape(-1, v2.EC_IO_WIDTH):
             misc += [int(row[55])]
             tup_y += [int(row[56])]
     for row in rec["leaf_rows"].reshape(-1, v2.LEAF_WIDTH):
@@ -377,6 +386,37 @@ def test_ecc_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
 
 
+def test_fp2_guest_device_traces_and_one_proof(zk, ora, tmp_path):
+    """A guest evaluating bn254's twist equation at the published G2 generator with the fp2 intrinsic (24 chips): device traces == CPU
+    twins, proof bytes == the oracle's; the whole flow from the ELF with the reference's `[app_vm_config.fp2]` syntax: both sides of the
+    equation in the root's public values agree."""
+    words, data = fp2_program(), fp2_data()
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, (), False, (), (BN254_P,))
+    k = next(i for i, s in enumerate(segs) if len(s["fp2_ts_0"]))
+    inst = v2.segment_instance(segs[k], words, PC_BASE, H)
+    T = device_traces(zk, segs[k], v2.program_table(words, PC_BASE, H[0]), H)
+    assert len(inst) == len(T) == 24
+    for a, d in enumerate(inst):
+        assert (zk.download(T[a]).reshape(d["width"], -1) == d["trace"]).all(), "position %d" % a
+    pk = z.ProvingKey(zk, PARAMS, inst)
+    pvs = [d["pvs"] for d in inst]
+    proof = pk.prove(T, pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, inst).tobytes()
+    pk.close()
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words, data=data))
+    (tmp_path / "openvm.toml").write_text(pm.TOML.format(*PARAMS) + "\n" + v2.fp2_toml((BN254_P,)))
+    r = subprocess.run([pm.CLI, "prove-elf", str(exe), "-", str(tmp_path), str(tmp_path / "openvm.toml"), "8"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    model = rv.run(words, b"", data=data, fp2=(BN254_P,))
+    assert out["verified"] and out["total_cycles"] == model["instret"]
+    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * 34:4 * 34 + 32]
+    assert pv == bytes(model["pvs"]) and pv[:16] == pv[16:]                # y^2 == x^3 + 3 / (9 + u) at EIP-197's G2 generator
+    assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
+
+
 def test_int256_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     """A guest running the six 256-bit opcodes through the int256 intrinsic (bigint extension, 27 chips): device traces == CPU twins,
     proof bytes == the oracle's; the whole flow from the ELF with `[app_vm_config.bigint]`: the root's public values are Python's."""
@@ -411,7 +451,7 @@ def test_int256_guest_device_traces_and_one_proof(zk, ora, tmp_path):
 
 def test_the_chunk_circuit_configuration_end_to_end(tmp_path):
     """`prove-elf` under an openvm.toml with the sections of the reference's chunk circuit in the reference's syntax (keccak, sha2, bigint,
-    modular with its six moduli, ecc with its three curves: 49 chips per segment) for a guest that uses all five intrinsics: ONE root proof whose public values
+    modular with its six moduli, fp2, ecc with its three curves: 51 chips per segment) for a guest that uses all five intrinsics: ONE root proof whose public values
     carry hashlib's SHA3-256 / SHA-256 words and Python's field product and 256-bit difference."""
     import hashlib
 

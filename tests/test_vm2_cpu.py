@@ -17,7 +17,7 @@ from zkvm_prover_amd import air
 import recursion_util as ru
 import rv32_model as rv
 import vm2_util as v2
-from test_vm_cpu import (INT256_SHIFT_OPERANDS, ALL_EXT_MSG, CHUNK_CIRCUIT_CURVES, EC_CURVES, ec_data, ec_program, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
+from test_vm_cpu import (BN254_G2X, BN254_G2Y, BN254_P, fp2_data, fp2_program, INT256_SHIFT_OPERANDS, ALL_EXT_MSG, CHUNK_CIRCUIT_CURVES, EC_CURVES, ec_data, ec_program, CHUNK_CIRCUIT_MODULI, INT256_OPERANDS, all_extensions_data, all_extensions_program, SECP256K1_GX, SECP256K1_GY, SECP256K1_N, SECP256K1_P, fib_program, int256_data, int256_program, keccak_data,
                          keccak_program, mixed_program, modmul_data, modmul_program, sha256_data, sha256_program)
 
 PARAMS = (1, 0, 4, 3, 3)
@@ -332,8 +332,38 @@ def test_ecc_intrinsic_is_part_of_the_statement(tmp_path):
         v2.dump_segments(tmp_path, rv.exe_bytes(same, data=g + g + bytes(64)), b"", 7, 0, 0, (), False, EC_CURVES)
 
 
+def test_fp2_intrinsic_is_part_of_the_statement(tmp_path):
+    """A guest that evaluates bn254's twist equation y^2 = x^3 + 3 / (9 + u) at the published G2 generator with the fp2 intrinsic
+    (multiplications, a division, an addition, a subtraction), under an app with the fp2 extension (24 chips): the revealed components
+    are Python's and both sides agree; every trace satisfies its AIR, every bus balances; a forged result word breaks the word bus."""
+    P2 = BN254_P
+    words, data = fp2_program(), fp2_data()
+    model = rv.run(words, b"", data=data, fp2=(P2,))
+    pv = bytes(model["pvs"])
+    mul = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % P2, (a[0] * b[1] + a[1] * b[0]) % P2)  # noqa: E731
+    y2 = mul(BN254_G2Y, BN254_G2Y)
+    low = lambda v: int(v % (1 << 64)).to_bytes(8, "little")  # noqa: E731
+    assert pv[:16] == low(y2[0]) + low(y2[1]) and pv[16:32] == pv[:16]      # x^3 + b' = y^2 (and the difference folded in is zero)
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, (), False, (), (P2,))
+    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"]
+    assert len(H.ids) == 24 and sum(len(s["fp2_ts_0"]) for s in segs) == 6
+    for k, rec in enumerate(segs):
+        inst = v2.segment_instance(rec, words, PC_BASE, H)
+        for d in inst:
+            assert air.quotient_chunks(d["program"]) <= 2
+            assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], k
+        assert v2.bus_imbalance(inst) == {}
+    k = next(i for i, s in enumerate(segs) if len(s["fp2_ts_0"]))
+    rec = {n: v.copy() for n, v in segs[k].items()}
+    rec["fp2io_rows_0"].reshape(-1, v2.EC_IO_WIDTH)[33, 52] ^= 1           # a result word that is not the chip's
+    bad = v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
+    assert 38 in bad and 1 in bad                                         # field 0's word bus, memory bus
+    with pytest.raises(AssertionError, match="lists 0 fp2 fields"):
+        v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)
+
+
 def test_all_extensions_of_the_chunk_circuit_in_one_statement(tmp_path):
-    """The chip set the reference's chunk-circuit configuration asks for (keccak, sha2, bigint, six moduli, three curves: 49 chips) and a
+    """The chip set the reference's chunk-circuit configuration asks for (keccak, sha2, bigint, six moduli, one fp2 field, three curves: 51 chips) and a
     guest that uses all five intrinsics: SHA3-256 and SHA-256 of one message are hashlib's, the secp256k1 field product, the 256-bit
     difference and the doubled generator Python's; every trace satisfies its AIR and every bus balances."""
     import hashlib
@@ -346,8 +376,8 @@ def test_all_extensions_of_the_chunk_circuit_in_one_statement(tmp_path):
     assert b"".join(pv[8 + 4 * k:12 + 4 * k][::-1] for k in range(2)) == hashlib.sha256(ALL_EXT_MSG).digest()[:8]
     two_g_x = 0xC6047F9441ED7D6D3045406E95C07CD85C778E4B8CEF3CA7ABAC09B95C709EE5   # 2 G of secp256k1 (published)
     assert int.from_bytes(pv[28:32], "little") == (((5 - 7) % (1 << 256)) >> 224) ^ (two_g_x & 0xFFFFFFFF)
-    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 5, 7, CHUNK_CIRCUIT_MODULI, True, curves)
-    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"] and len(H.ids) == 49
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 5, 7, CHUNK_CIRCUIT_MODULI, True, curves, (CHUNK_CIRCUIT_MODULI[0],))
+    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"] and len(H.ids) == 51
     for k, rec in enumerate(segs):
         inst = v2.segment_instance(rec, words, PC_BASE, H)
         for d in inst:

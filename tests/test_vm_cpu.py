@@ -139,7 +139,7 @@ def chunk_circuit_toml(params):
     return ("[app_fri_params.fri_params]\nlog_blowup = %d\nlog_final_poly_len = %d\nnum_queries = %d\ncommit_proof_of_work_bits = %d\n"
             "query_proof_of_work_bits = %d\n\n[app_vm_config.rv32i]\n\n[app_vm_config.io]\n\n[app_vm_config.keccak]\n\n[app_vm_config.rv32m]\n"
             "range_tuple_checker_sizes = [256, 8192]\n\n[app_vm_config.bigint]\nrange_tuple_checker_sizes = [256, 8192]\n\n[app_vm_config.modular]\n"
-            "supported_moduli = [\n" % tuple(params)) + ",\n".join('    "%d"' % m for m in CHUNK_CIRCUIT_MODULI) + "\n]\n\n[app_vm_config.sha2]\n\n" + "".join(
+            "supported_moduli = [\n" % tuple(params)) + ",\n".join('    "%d"' % m for m in CHUNK_CIRCUIT_MODULI) + "\n]\n\n[app_vm_config.fp2]\nsupported_moduli = [\n    [\"Bn254Fp2\",\"%d\"]\n]\n\n[app_vm_config.sha2]\n\n" % CHUNK_CIRCUIT_MODULI[0] + "".join(
                 '[[app_vm_config.ecc.supported_curves]]\nstruct_name = "%s"\nmodulus = "%d"\nscalar = "%d"\na = "%d"\nb = "%d"\n\n' % c for c in CHUNK_CIRCUIT_CURVES)
 
 
@@ -266,6 +266,42 @@ def ec_data():
     b32 = lambda v: int(v).to_bytes(32, "little")  # noqa: E731
     g = b32(SECP256K1_GX) + b32(SECP256K1_GY)
     return g + g + bytes(64) + bytes(64) + g + bytes(64) + b32(1) + b32(2) + bytes(128)
+
+
+# EIP-197's generator of bn254's G2 (x = X0 + X1 u, y = Y0 + Y1 u)
+BN254_G2X = (10857046999023057135944570762232829481370756359578518086990519993285655852781, 11559732032986387107991004021392285783925812861821192530917403151452391805634)
+BN254_G2Y = (8495653923123431417604973247489272438418190587263600148770280649306958101930, 4082367875863433681332203403145435568316851327593401208105741076214120093531)
+
+
+def fp2_program():
+    """The twist equation of bn254 at the published G2 generator through the fp2 intrinsic (a7 = 8, a1 = field index + 8 op): buffer 0 =
+    (y, y, .) multiplied, buffer 1 = (x, x, .) multiplied, its result copied into buffer 2 = (x^2, x, .) multiplied: x^3; buffer 3 =
+    (3, 9 + u, .) divided; buffer 4 = (x^3, 3 / (9 + u), .) added; buffer 5 = (y^2, x^3 + b', .) subtracted: zero.  Reveals the low words
+    of y^2 (both components, two words each) and of x^3 + b' (likewise), the difference's low words folded into the last one."""
+    p = rv.li(S0, 0x00400000)
+    def call(buf, which):
+        return [("addi", A0, S0, 192 * buf), ("addi", A1, 0, which), ("addi", A7, 0, 8), ("ecall",)]
+    def copy(src_buf, dst_buf, dst_slot):
+        out = []
+        for k in range(16):
+            out += [("lw", T0, S0, 192 * src_buf + 128 + 4 * k), ("sw", T0, S0, 192 * dst_buf + 64 * dst_slot + 4 * k)]
+        return out
+    p += call(0, 0) + call(1, 0) + copy(1, 2, 0) + call(2, 0) + call(3, 24) + copy(2, 4, 0) + copy(3, 4, 1) + call(4, 8) + copy(0, 5, 0) + copy(4, 5, 1) + call(5, 16)
+    p += [("lw", T1, S0, 192 * 5 + 128), ("lw", T2, S0, 192 * 5 + 160), ("or", T1, T1, T2)]
+    for k, off in enumerate((128, 132, 160, 164, 192 * 4 + 128, 192 * 4 + 132, 192 * 4 + 160, 192 * 4 + 164)):
+        p += [("lw", A0, S0, off)]
+        if k == 7:
+            p += [("xor", A0, A0, T1)]
+        p += [("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
+def fp2_data():
+    b32 = lambda v: int(v).to_bytes(32, "little")  # noqa: E731
+    el = lambda e: b32(e[0]) + b32(e[1])  # noqa: E731
+    z64 = bytes(64)
+    return (el(BN254_G2Y) + el(BN254_G2Y) + z64 + el(BN254_G2X) + el(BN254_G2X) + z64 + z64 + el(BN254_G2X) + z64 + el((3, 0)) + el((9, 1)) + z64 + z64 * 3 + z64 * 3)
 
 
 def mixed_program():

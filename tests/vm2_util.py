@@ -19,14 +19,14 @@ NOPV = np.zeros(0, np.uint32)
 (A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
  A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, A_INT256, A_INT256_IO, A_MUL256,
  A_CMP256, A_SHIFT256, N_STATIC_AIRS) = range(32)
-MAX_MODULI, MAX_CURVES = 8, 4
+MAX_MODULI, MAX_CURVES, MAX_FP2 = 8, 4, 2
 # the modular extension: chips N_STATIC_AIRS + 2 i (multiplication), + 2 i + 1 (adapter) of modulus i; the ecc extension's follow
-N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES
-PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 33, 43, 54, 42, 2634
+N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES + 2 * MAX_FP2
+PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 34, 43, 54, 42, 2634
 SHA_IO_WIDTH, SHA_WIDTH = 34, 434
 MODMUL_IO_WIDTH, MODMUL_WIDTH = 35, 323
 INT256_IO_WIDTH, INT256_WIDTH, MUL256_WIDTH, CMP256_WIDTH, SHIFT256_WIDTH = 35, 102, 162, 104, 190
-EC_IO_WIDTH, EC_WIDTH = 59, 773
+EC_IO_WIDTH, EC_WIDTH, FP2_WIDTH = 59, 773, 649
 TS_STEP, GAP_HI_BITS = 16, 11
 SX, SY = 256, 2048
 
@@ -61,6 +61,7 @@ class Heights(list):
     ids = ()
     moduli = ()
     curves = ()
+    fp2 = ()
 
 
 def A_MODMUL(i):
@@ -79,12 +80,24 @@ def A_EC_IO(i):
     return N_STATIC_AIRS + 2 * MAX_MODULI + 2 * i + 1
 
 
+def A_FP2(i):
+    return N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES + 2 * i
+
+
+def A_FP2_IO(i):
+    return N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES + 2 * i + 1
+
+
+def fp2_toml(fp2):
+    return "[app_vm_config.fp2]\nsupported_moduli = [\n" + ",\n".join('    ["Field%d","%d"]' % (i, p) for i, p in enumerate(fp2)) + "\n]\n\n" if fp2 else ""
+
+
 def curves_toml(curves):
     return "".join('[[app_vm_config.ecc.supported_curves]]\nstruct_name = "Curve%d"\nmodulus = "%d"\nscalar = "1"\na = "%d"\nb = "0"\n\n' % (i, p, a)
                    for i, (p, a) in enumerate(curves))
 
 
-def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0, moduli=(), bigint=False, curves=()):
+def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0, moduli=(), bigint=False, curves=(), fp2=()):
     """Runs the C++ segmenting executor; returns (info json, heights, [segment record dicts], image root, pv openings)."""
     import json
 
@@ -92,9 +105,9 @@ def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0, 
     open(os.path.join(d, "exe.bin"), "wb").write(exe_bytes)
     open(os.path.join(d, "stdin.bin"), "wb").write(stdin)
     cmd = [CLI, "dump-segments", os.path.join(d, "exe.bin"), os.path.join(d, "stdin.bin"), d, str(log_frame), str(log_keccak), str(log_sha256)]
-    if moduli or bigint or curves:
+    if moduli or bigint or curves or fp2:
         toml = "[app_vm_config.bigint]\n" if bigint else ""
-        toml += curves_toml(curves)
+        toml += curves_toml(curves) + fp2_toml(fp2)
         if moduli:
             toml += "[app_vm_config.modular]\nsupported_moduli = [\n" + ",\n".join('    "%d"' % m for m in moduli) + "\n]\n"
         open(os.path.join(d, "moduli.toml"), "w").write(toml)
@@ -105,7 +118,7 @@ def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0, 
     by_pos = np.fromfile(os.path.join(d, "heights.u32"), dtype=np.uint32).tolist()
     ids = np.fromfile(os.path.join(d, "air_ids.u32"), dtype=np.uint32).tolist()
     heights = Heights([None] * N_AIRS)
-    heights.ids, heights.moduli, heights.curves = tuple(ids), tuple(moduli), tuple(curves)
+    heights.ids, heights.moduli, heights.curves, heights.fp2 = tuple(ids), tuple(moduli), tuple(curves), tuple(fp2)
     for i, h in zip(ids, by_pos):
         heights[i] = h
     segs = []
@@ -286,6 +299,21 @@ def shift256_traces(rec, H):
     return tr, bw.astype(np.int64), xc.astype(np.int64)
 
 
+def fp2_traces(rec, H, i, p):
+    """fp2 calls of field i: the tests' twin of the chip's trace (and its lookup counts) + the call's timestamp; the adapter's rows"""
+    import fp2_util as fu
+
+    recs = np.ascontiguousarray(rec["fp2_records_%d" % i], dtype=np.uint32).reshape(-1, fu.RECORD_WORDS)
+    val = lambda w: sum(int(x) << (32 * k) for k, x in enumerate(w))  # noqa: E731
+    calls = [(int(r[0]), (val(r[1:9]), val(r[9:17])), (val(r[17:25]), val(r[25:33]))) for r in recs]
+    lh = H[A_FP2(i)]
+    body, bw, tup = fu.twin_trace(calls, p, lh)
+    tr = np.zeros((FP2_WIDTH, 1 << lh), np.uint32)
+    tr[:FP2_WIDTH - 1] = body
+    tr[FP2_WIDTH - 1, :len(calls)] = rec["fp2_ts_%d" % i]
+    return tr, rows_trace(rec["fp2io_rows_%d" % i], EC_IO_WIDTH, H[A_FP2_IO(i)]), bw.astype(np.int64), tup.astype(np.int64)
+
+
 def modmul_traces(rec, H, i, p):
     """modmul calls of modulus i: the oracle's chip trace (and its lookup counts) + the call's timestamp; the adapter's rows"""
     n = len(rec["mm_ts_%d" % i])
@@ -376,6 +404,9 @@ def segment_instance(rec, words, pc_base, heights):
     for i, cv in enumerate(H.curves):
         tr[A_EC(i)], tr[A_EC_IO(i)], bw_i, tup_i = ec_traces(rec, H, i, cv)
         mm_counts.append((bw_i, tup_i))
+    for i, p_ in enumerate(H.fp2):
+        tr[A_FP2(i)], tr[A_FP2_IO(i)], bw_i, tup_i = fp2_traces(rec, H, i, p_)
+        mm_counts.append((bw_i, tup_i))
     meta = rec["meta"]
     pc_start, pc_end, ts_end, n_instr = (int(x) for x in meta[:4])
     tr[A_CONNECTOR] = np.array([[ts_end & 0xFFFF], [ts_end >> 16]], np.uint32)
@@ -413,10 +444,10 @@ def segment_instance(rec, words, pc_base, heights):
         if row[16]:
             rc[int(row[10]) * 256 + int(row[11])] += 1
             rc[int(row[12]) * 256 + int(row[13])] += 1
-        if row[30] or row[31] or row[32]:
+        if row[30] or row[31] or row[32] or row[33]:
             misc += [int(row[22])]
             tc[int(row[23])] += 1
-        if row[27] or row[29] or row[30] or row[31] or row[32]:
+        if row[27] or row[29] or row[30] or row[31] or row[32] or row[33]:
             misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
     for row in rec["kio_rows"].reshape(-1, KECCAK_IO_WIDTH):
         misc += [int(row[36]), int(row[39])]
@@ -436,6 +467,10 @@ def segment_instance(rec, words, pc_base, heights):
         for row in rec["ecio_rows_%d" % i].reshape(-1, EC_IO_WIDTH):
             misc += [int(row[55])]
             tc[int(row[56])] += 1
+    for i in range(len(H.fp2)):
+        for row in rec["fp2io_rows_%d" % i].reshape(-1, EC_IO_WIDTH):
+            misc += [int(row[55])]
+            tc[int(row[56])] += 1
     for row in rec["leaf_rows"].reshape(-1, LEAF_WIDTH):
         misc += [int(row[39]), int(row[40]) * 16, int(row[40]), int(row[41]), int(row[42]) * 64, int(row[42])]
     cnt += np.bincount(np.array(misc, dtype=np.int64), minlength=1 << 16)
@@ -452,7 +487,11 @@ def segment_instance(rec, words, pc_base, heights):
     pvs = {A_MERKLE: np.concatenate([meta[4:12], meta[12:20]]).astype(np.uint32), A_CONNECTOR: np.array([pc_start, pc_end], np.uint32)}
     out = []
     for a in H.ids:   # proof order
-        if a >= A_EC(0):
+        if a >= A_FP2(0):
+            i = (a - A_FP2(0)) // 2
+            program, width = z.vm_fp2_air(H.fp2[i], i, (a - A_FP2(0)) & 1)
+            n_pvs, pw = 0, 0
+        elif a >= A_EC(0):
             i = (a - A_EC(0)) // 2
             program, width = z.vm_ec_air(H.curves[i][0], H.curves[i][1], i, (a - A_EC(0)) & 1)
             n_pvs, pw = 0, 0

@@ -56,7 +56,8 @@ int main(int argc, char** argv) {
                                                                                     argc >= 7 ? (unsigned)atoi(argv[6]) : 0u, argc >= 8 ? (unsigned)atoi(argv[7]) : 0u,
                                                                                     argc >= 9 ? zkhip_vm::config_moduli(argv[8]) : std::vector<zkhip::modular::U256>(), 3,
                                                                                     argc >= 9 ? zkhip_vm::int256_log_rows(argv[8], 11) : 0u,
-                                                                                    argc >= 9 ? zkhip_vm::config_curves(argv[8]) : std::vector<zkhip::ecc::Curve>(), 2);
+                                                                                    argc >= 9 ? zkhip_vm::config_curves(argv[8]) : std::vector<zkhip::ecc::Curve>(), 2,
+                                                                                    argc >= 9 ? zkhip_vm::config_fp2_moduli(argv[8]) : std::vector<zkhip::modular::U256>());
                 zkhip_vm::SegmentExecutor ex(exe, in, caps);
                 zkhip_vm::SegmentRecords r;
                 size_t k = 0;
@@ -87,6 +88,10 @@ int main(int argc, char** argv) {
                     for (unsigned i = 0; i < caps.moduli.size(); i++) {
                         const std::string t = std::to_string(i);
                         put(d + "/mm_records_" + t + ".u32", r.mm_records[i]), put(d + "/mm_ts_" + t + ".u32", r.mm_ts[i]), put(d + "/mmio_rows_" + t + ".u32", r.mmio_rows[i]);
+                    }
+                    for (unsigned i = 0; i < caps.fp2_moduli.size(); i++) {
+                        const std::string t = std::to_string(i);
+                        put(d + "/fp2_records_" + t + ".u32", r.fp2_records[i]), put(d + "/fp2_ts_" + t + ".u32", r.fp2_ts[i]), put(d + "/fp2io_rows_" + t + ".u32", r.fp2io_rows[i]);
                     }
                     for (unsigned i = 0; i < caps.curves.size(); i++) {
                         const std::string t = std::to_string(i);
@@ -153,7 +158,8 @@ int main(int argc, char** argv) {
                     const unsigned log_keccak = zkhip_vm::keccak_log_rows(cfg_path, log_frame), log_sha256 = zkhip_vm::sha256_log_rows(cfg_path, log_frame);
                     const unsigned lanes = getenv("ZKHIP_LANES") ? (unsigned)atoi(getenv("ZKHIP_LANES")) : 3u;   // segment provers in flight (measured 1 / 2 / 3: DESIGN.md 5)
                     const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false, lanes, log_keccak, log_sha256, zkhip_vm::config_moduli(cfg_path),
-                                                                                          zkhip_vm::int256_log_rows(cfg_path, log_frame), zkhip_vm::config_curves(cfg_path));
+                                                                                          zkhip_vm::int256_log_rows(cfg_path, log_frame), zkhip_vm::config_curves(cfg_path),
+                                                                                          zkhip_vm::config_fp2_moduli(cfg_path));
                     (void)caps;
                     sp = UniversalProver::encode(g);
                     std::string why;

@@ -24,6 +24,9 @@ from ._binding import (  # noqa: F401
     int256_shift_air,
     int256_mul_air,
     ec_air,
+    fp2_air,
+    fp2_host,
+    vm_fp2_air,
     ec_host,
     vm_ec_air,
     modmul_air,

@@ -203,6 +203,11 @@ def load_library():
         "zkhip_vm_modmul_air": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint, C.c_int, C.POINTER(_Air)]),
         "zkhip_vm_modmul_tracegen": (C.c_int, [vp, u32p, vp, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_vm_sha256_prep": (C.c_int, [C.c_uint, u32p]),
+        "zkhip_fp2_air": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
+        "zkhip_fp2_host": (C.c_int, [C.c_uint32, u32p, u32p, u32p, u32p]),
+        "zkhip_fp2_tracegen": (C.c_int, [vp, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
+        "zkhip_vm_fp2_air": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint, C.c_int, C.POINTER(_Air)]),
+        "zkhip_vm_fp2_tracegen": (C.c_int, [vp, u32p, vp, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_ec_air": (C.c_int, [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
         "zkhip_ec_host": (C.c_int, [C.c_uint32] + [u32p] * 9),
         "zkhip_ec_tracegen": (C.c_int, [vp, u32p, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
@@ -722,6 +727,18 @@ class Context:
                                                       t_bitwise_trace.data_ptr()))
         return out
 
+    def fp2_tracegen(self, modulus, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y, t_ts=None):
+        """records: n x 33 words (op | a0 a1 | b0 b1); t_ts: the VM chip (649 columns: + the calls' timestamps)"""
+        out = self._new((648 if t_ts is None else 649) << log_height)
+        m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
+        if t_ts is None:
+            self._check(self.lib.zkhip_fp2_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr(),
+                                                    t_tuple_counts.data_ptr(), size_x, size_y))
+        else:
+            self._check(self.lib.zkhip_vm_fp2_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height,
+                                                       out.data_ptr(), t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
+        return out
+
     def ec_tracegen(self, modulus, coeff_a, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y, t_ts=None):
         """records: n x 41 words (op | x1 y1 x2 y2 | slope); t_ts: the VM chip (773 columns: + the calls' timestamps)"""
         out = self._new((772 if t_ts is None else 773) << log_height)
@@ -1076,6 +1093,35 @@ def vm_modmul_air(modulus, index, adapter):
     m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
     assert lib.zkhip_vm_modmul_air(m, index, 1 if adapter else 0, C.byref(a)) == 0
     return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
+
+
+def fp2_air(modulus, bitwise_bus, tuple_bus):
+    """The Fp2 chip's AIR for Fp[u] / (u^2 + 1) over `modulus`: (program, width); its one definition is include/zkhip_fp2.hpp."""
+    lib = load_library()
+    a = _Air()
+    m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
+    assert lib.zkhip_fp2_air(m, bitwise_bus, tuple_bus, C.byref(a)) == 0
+    return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
+
+
+def vm_fp2_air(modulus, index, adapter):
+    """(program, width) of the VM's Fp2 chip (adapter False) or adapter chip (True) of field `index`"""
+    lib = load_library()
+    a = _Air()
+    m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
+    assert lib.zkhip_vm_fp2_air(m, index, 1 if adapter else 0, C.byref(a)) == 0
+    return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
+
+
+def fp2_host(op, modulus, a, b):
+    """a op b in Fp[u] / (u^2 + 1) through the library's host function ((c0, c1) integer pairs); None if it refuses the call"""
+    wm = np.array(_int_words(modulus), dtype=np.uint32)
+    wa = np.array(_int_words(a[0]) + _int_words(a[1]), dtype=np.uint32)
+    wb = np.array(_int_words(b[0]) + _int_words(b[1]), dtype=np.uint32)
+    r = np.zeros(16, np.uint32)
+    if load_library().zkhip_fp2_host(op, _u32p(wm), _u32p(wa), _u32p(wb), _u32p(r)) != 0:
+        return None
+    return tuple(sum(int(x) << (32 * i) for i, x in enumerate(r[8 * k:8 * k + 8])) for k in range(2))
 
 
 def ec_air(modulus, coeff_a, bitwise_bus, tuple_bus):

@@ -30,6 +30,7 @@ std::once_flag g_airs_once;
 vmc::AirShape g_airs[vmc::N_STATIC_AIRS];
 std::mutex g_mod_mu;
 std::map<std::pair<zkhip::modular::Modulus, unsigned>, vmc::AirShape> g_mod_airs;   // (modulus, 2 index + adapter) -> program
+std::map<std::pair<zkhip::modular::Modulus, unsigned>, vmc::AirShape> g_fp2_airs;   // likewise for the fp2 chips
 std::map<std::pair<std::pair<zkhip::modular::Modulus, zkhip::modular::Modulus>, unsigned>, vmc::AirShape> g_ec_airs;   // ((modulus, a), 2 index + adapter)
 
 __global__ __launch_bounds__(256) void k_vm_frame(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
@@ -193,6 +194,24 @@ int zkhip_vm_ec_air(const uint8_t modulus[32], const uint8_t a[32], unsigned ind
         const auto key = std::make_pair(std::make_pair(m, ca), 2 * index + (adapter ? 1u : 0u));
         auto it = g_ec_airs.find(key);
         if (it == g_ec_airs.end()) it = g_ec_airs.emplace(key, vmc::build_ec_air(m, ca, index, adapter != 0)).first;
+        const vmc::AirShape& s = it->second;
+        out->program = s.program.data(), out->program_len = s.program.size(), out->log_height = 0, out->width = s.width, out->n_pvs = 0;
+        out->prep_trace = nullptr, out->prep_commit = nullptr;
+    } catch (const std::exception&) {
+        return ZKHIP_ERR_INVALID;
+    }
+    return ZKHIP_OK;
+}
+
+int zkhip_vm_fp2_air(const uint8_t modulus[32], unsigned index, int adapter, zkhip_air* out) {
+    if (!modulus || !out || index >= vmc::MAX_FP2 || !(modulus[0] & 1u) || !modulus[31]) return ZKHIP_ERR_INVALID;
+    zkhip::modular::Modulus m;
+    memcpy(m.data(), modulus, 32);
+    try {
+        std::lock_guard<std::mutex> lk(g_mod_mu);
+        const auto key = std::make_pair(m, 2 * index + (adapter ? 1u : 0u));
+        auto it = g_fp2_airs.find(key);
+        if (it == g_fp2_airs.end()) it = g_fp2_airs.emplace(key, vmc::build_fp2_air(m, index, adapter != 0)).first;
         const vmc::AirShape& s = it->second;
         out->program = s.program.data(), out->program_len = s.program.size(), out->log_height = 0, out->width = s.width, out->n_pvs = 0;
         out->prep_trace = nullptr, out->prep_commit = nullptr;
