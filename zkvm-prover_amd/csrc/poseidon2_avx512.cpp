@@ -1,6 +1,7 @@
 // poseidon2_avx512.cpp -- the Poseidon2-BabyBear permutation on the HOST with the whole state in one 512-bit register (plain C++, built
 // with -mavx512f and called only after a run-time CPU check).  A duplex sponge is a chain of dependent permutations: absorbing the
-// opened values of a proof (4 k words for the base segment circuit, 110 k for the reference's full chunk-circuit configuration) takes
+// opened values of a proof (4 k words for the base segment circuit -- those stay on the device --, 110 k for the reference's full
+// chunk-circuit configuration) takes
 // one permutation per 8 words, ~1.5 us each for a cooperative wave on the device -- latency no occupancy can hide -- and ~0.25 us here.
 // csrc/transcript.hip hands long absorptions to this file (the words cross PCIe anyway: they are part of the proof) and keeps the short
 // ones on the device.  Same algorithm and constants as csrc/poseidon2.hpp (its scalar code is this file's checker:

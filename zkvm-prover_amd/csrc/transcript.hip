@@ -189,7 +189,8 @@ int transcript_init(zkhip_ctx* ctx, DevTranscript* d_t) {
 // Long absorptions on the host (csrc/poseidon2_avx512.cpp): the sponge is a chain of dependent permutations, ~1.5 us each on the device
 // whatever the occupancy, ~0.25 us in a 512-bit register of the host -- and the words absorbed here (the opened values) are part of the
 // proof, so they cross PCIe anyway.  One stream synchronisation; the state goes back with a 96-byte copy.  ZKHIP_NO_HOST_SPONGE=1 (or a
-// CPU without AVX-512) keeps everything on the device; ZKHIP_HOST_SPONGE_MIN_WORDS moves the threshold (default 2048 words).
+// CPU without AVX-512) keeps everything on the device; ZKHIP_HOST_SPONGE_MIN_WORDS moves the threshold (default 8192 words: below
+// that the device's ~0.2 us per word costs less than the synchronisation, after which the host has to catch up with its launches).
 void poseidon2_permute_avx512(uint32_t s[16]);
 static bool host_sponge_available() {
     static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && !getenv("ZKHIP_NO_HOST_SPONGE");
@@ -225,7 +226,7 @@ static int observe_on_host(zkhip_ctx* ctx, DevTranscript* d_t, const uint32_t* d
 int transcript_observe(zkhip_ctx* ctx, DevTranscript* d_t, const uint32_t* d_src, uint32_t n, bool canonical) {
     if (n == 0) return ZKHIP_OK;
     KernelScope ks(ctx, "transcript");
-    static const uint32_t host_min = getenv("ZKHIP_HOST_SPONGE_MIN_WORDS") ? (uint32_t)atoi(getenv("ZKHIP_HOST_SPONGE_MIN_WORDS")) : 2048u;
+    static const uint32_t host_min = getenv("ZKHIP_HOST_SPONGE_MIN_WORDS") ? (uint32_t)atoi(getenv("ZKHIP_HOST_SPONGE_MIN_WORDS")) : 8192u;
     if (n >= host_min && host_sponge_available()) return observe_on_host(ctx, d_t, d_src, n, canonical);
     hipLaunchKernelGGL(k_tr_observe, dim3(1), dim3(64), 0, ctx->stream, d_t, d_src, n, canonical ? 1 : 0);
     ZK_HIP_CHECK(ctx, hipGetLastError());
