@@ -594,7 +594,7 @@ int zkhip_vm_keccak_tracegen(zkhip_ctx *ctx, const uint32_t *d_states, const uin
  * zkhip_vm_sha256_prep writes its preprocessed trace (the standalone chip's six columns + input / digest / round-index). */
 int zkhip_vm_sha256_tracegen(zkhip_ctx *ctx, const uint32_t *d_blocks, const uint32_t *d_ts, size_t n_blocks, unsigned log_height, uint32_t *d_trace);
 int zkhip_vm_sha256_prep(unsigned log_height, uint32_t *out);
-/* The two chips of modulus `index` (< 8) of an app with the modular extension: adapter == 0 the multiplication chip inside the VM (323
+/* The two chips of modulus `index` (< 8) of an app with the modular extension: adapter == 0 the multiplication chip inside the VM (326
  * columns: zkhip_modmul_air + a timestamp column + the 24 word receives), adapter != 0 its adapter; zkhip_vm_modmul_tracegen =
  * zkhip_modular_tracegen (17-word records: op | a | b) + the timestamp of call i on row i. */
 int zkhip_vm_modmul_air(const uint8_t modulus[32], unsigned index, int adapter, zkhip_air *out);
@@ -646,10 +646,10 @@ int zkhip_sha256_compress_host(uint32_t state[8], const uint32_t block[16]);
 int zkhip_sha256_tracegen(zkhip_ctx *ctx, const uint32_t *d_blocks, size_t n_blocks, unsigned log_height, uint32_t *d_trace);
 
 /* ---- modular multiplication chip (include/zkhip_modular.hpp: r = a b mod P for a 256-bit modulus on byte limbs, one multiplication per
- *      row, 322 columns (flags is_add, is_sub: the same columns state a + b = q P + r and a - b + q P = r; is_div: the row (x / y, y, x) with the quotient canonical as well), degree 3; byte pairs looked up in the 8-bit bitwise table, carries in the range-tuple table;
+ *      row, 325 columns (flags is_add, is_sub: the same columns state a + b = q P + r and a - b + q P = r; is_div: the row (x / y, y, x) with the quotient canonical as well; is_eq on top of a subtraction row: the bit [a = b mod P]), degree 3; byte pairs looked up in the 8-bit bitwise table, carries in the range-tuple table;
  *      crates/circuits/chunk-circuit/openvm.toml:8-59 lists `modular` with the secp256k1 / bn254 / bls12-381 moduli; OpenVM's chip is
  *      openvm-algebra-circuit's ModularMulDiv, un-vendored).  Pinned to Python's integers (tests/golden/modular_kat.json). ---- */
-#define ZKHIP_MODMUL_WIDTH 322
+#define ZKHIP_MODMUL_WIDTH 325
 /* the AIR for one modulus (32 little-endian bytes, non-zero) sending on the given buses; pointers valid for the life of the process */
 int zkhip_modmul_air(const uint8_t modulus[32], uint32_t bitwise_bus, uint32_t tuple_bus, zkhip_air *out);
 /* (q, r) = divmod(a b, modulus) on little-endian 32-bit words (host); ZKHIP_ERR_INVALID if q does not fit 256 bits */
@@ -660,7 +660,7 @@ int zkhip_modmul_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint3
                           uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
 /* the same chip with an operation per record: d_records n x 17 words (op | a[8] | b[8]; op 0 mul, 1 add, 2 sub -- OpenVM's ModularAddSub in the
  * multiplication chip's columns; a subtraction needs |a - b| < P --, 3 div: the record holds (x / y, y), the row is the product (x / y) y = x);
- * zkhip_modular_host: (q, r) of one operation on the host (op 3: r = a / b mod P, q = 0; a < P, b invertible) */
+ * zkhip_modular_host: (q, r) of one operation on the host (op 3: r = a / b mod P, q = 0; a < P, b invertible; op 4: r = [a = b mod P] for |a - b| < P) */
 int zkhip_modular_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace,
                            uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
 int zkhip_modular_host(uint32_t op, const uint32_t a[8], const uint32_t b[8], const uint32_t modulus[8], uint32_t q[8], uint32_t r[8]);

@@ -15,6 +15,9 @@
 //                             from the other side (OpenVM's ModularMulDiv does the same); the quotient x / y sits in the a columns, so
 //                             a < P is enforced there as well (second marker set), and inside the VM the word indices of a and r swap.
 //                             As in OpenVM the caller guarantees y != 0 (mod P): the executor refuses the call otherwise
+//   is_eq, eq, inv            an equality test (OpenVM's ModularIsEqual) is a subtraction row with is_eq set on top: r = (a - b) mod P is
+//                             canonical, eq = [r = 0] through the sum S of r's limbs (bytes: S = 0 only for r = 0): eq S = 0 and
+//                             (is_eq - eq)(S inv - 1) = 0; inside the VM the result word is eq instead of r
 // The modulus is a constant of the AIR (one chip per modulus, as OpenVM instantiates one per configured modulus).  a and b are bytes
 // but not required to be reduced; r is the canonical residue.  Every constraint has degree <= 3.
 // External parity: Python's integers (tests/golden/modular_kat.json: random and edge operands for the secp256k1 and bn254 field and
@@ -35,9 +38,9 @@ using air::Kind;
 constexpr size_t LIMBS = 32, N_CARRY = 2 * LIMBS - 2;
 constexpr size_t COL_A = 0, COL_B = 32, COL_Q = 64, COL_R = 96, COL_CX = 128, COL_CY = COL_CX + N_CARRY, COL_MARK = COL_CY + N_CARRY, COL_DIFF = COL_MARK + LIMBS,
                  COL_REAL = COL_DIFF + 1, COL_IS_ADD = COL_REAL + 1, COL_IS_SUB = COL_REAL + 2, COL_IS_DIV = COL_REAL + 3, COL_MARK2 = COL_IS_DIV + 1,
-                 COL_DIFF2 = COL_MARK2 + LIMBS, WIDTH = COL_DIFF2 + 1;
-static_assert(WIDTH == 322, "modular chip width");
-enum Op : uint32_t { OP_MUL, OP_ADD, OP_SUB, OP_DIV, N_OPS };
+                 COL_DIFF2 = COL_MARK2 + LIMBS, COL_IS_EQ = COL_DIFF2 + 1, COL_EQ = COL_IS_EQ + 1, COL_INV = COL_IS_EQ + 2, WIDTH = COL_IS_EQ + 3;
+static_assert(WIDTH == 325, "modular chip width");
+enum Op : uint32_t { OP_MUL, OP_ADD, OP_SUB, OP_DIV, OP_IS_EQ, N_OPS };
 constexpr int64_t CARRY_OFFSET = 1 << 14;
 using Modulus = std::array<uint8_t, LIMBS>;   // little-endian bytes
 
@@ -47,6 +50,14 @@ inline void modmul_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus, ui
     const Expr is_add = b.var(COL_IS_ADD), is_sub = b.var(COL_IS_SUB), is_div = b.var(COL_IS_DIV), is_mul = real - is_add - is_sub, q_sign = real - is_sub * 2;
     // (is_mul covers the division rows: the same limb identity)
     for (const Expr& f : {real, is_add, is_sub, is_div, is_mul, is_mul - is_div}) b.assert_zero(f * (f - 1));
+    {   // equality test on top of a subtraction row
+        const Expr is_eq = b.var(COL_IS_EQ), eq = b.var(COL_EQ);
+        Expr sum = b.var(COL_R);
+        for (size_t i = 1; i < LIMBS; i++) sum = sum + b.var(COL_R + i);
+        for (const Expr& f : {is_eq, eq, is_sub - is_eq, is_eq - eq}) b.assert_zero(f * (f - 1));
+        b.assert_zero(eq * sum);
+        b.assert_zero((is_eq - eq) * (sum * b.var(COL_INV) - 1));
+    }
     auto carry = [&](size_t k) { return b.var(COL_CX + k) + b.var(COL_CY + k) * 256 - CARRY_OFFSET; };
     for (size_t k = 0; k <= N_CARRY; k++) {   // limb positions 0 .. 62 of  [a b | a + b | a - b]  -  (+ | + | -) q P  -  r
         Expr prod = b.constant(0), qp = b.constant(0);
@@ -107,7 +118,8 @@ inline void modmul_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus, ui
 constexpr size_t COL_TS = WIDTH, VM_WIDTH = WIDTH + 1;
 inline void modmul_vm_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus, uint32_t tuple_bus, uint32_t word_bus) {
     modmul_air(b, P, bitwise_bus, tuple_bus);
-    const Expr ts = b.var(COL_TS), real = b.var(COL_REAL), is_div = b.var(COL_IS_DIV), op = b.var(COL_IS_ADD) + b.var(COL_IS_SUB) * 2 + is_div * 3;
+    const Expr ts = b.var(COL_TS), real = b.var(COL_REAL), is_div = b.var(COL_IS_DIV), is_eq = b.var(COL_IS_EQ), eq = b.var(COL_EQ);
+    const Expr op = b.var(COL_IS_ADD) + b.var(COL_IS_SUB) * 2 + is_div * 3 + is_eq * 2;   // an equality test is a subtraction row: 2 + 2 = 4
     // words 0..7 the first operand, 8..15 the second, 16..23 the result: (a, b, r) -- for a division (r, b, a)
     auto half = [&](size_t base, size_t k, size_t h) { return b.var(base + 4 * k + 2 * h) + b.var(base + 4 * k + 2 * h + 1) * 256; };
     for (size_t k = 0; k < 8; k++) {
@@ -115,7 +127,9 @@ inline void modmul_vm_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus,
         const Expr sw_lo = is_div * (r_lo - a_lo), sw_hi = is_div * (r_hi - a_hi);
         b.push_interaction(word_bus, {ts, b.constant((uint32_t)k), a_lo + sw_lo, a_hi + sw_hi, op}, real, Kind::Receive);
         b.push_interaction(word_bus, {ts, b.constant((uint32_t)(8 + k)), half(COL_B, k, 0), half(COL_B, k, 1), op}, real, Kind::Receive);
-        b.push_interaction(word_bus, {ts, b.constant((uint32_t)(16 + k)), r_lo - sw_lo, r_hi - sw_hi, op}, real, Kind::Receive);
+        // the result: r -- a for a division, the equality bit for a test (is_div and is_eq exclude one another: is_div <= is_mul, is_eq <= is_sub)
+        b.push_interaction(word_bus, {ts, b.constant((uint32_t)(16 + k)), r_lo - sw_lo - is_eq * r_lo + (k == 0 ? eq : b.constant(0)), r_hi - sw_hi - is_eq * r_hi, op}, real,
+                           Kind::Receive);
     }
 }
 

@@ -455,19 +455,28 @@ private:
                     // r = a b mod P_i on the 24 words at a0 (a[8] | b[8] | r[8], little-endian words), i = a1: one of the moduli the
                     // app's openvm.toml lists (OpenVM's modular extension)
                     if (rec && log_memory_) throw Error("the modmul intrinsic is proven by the one-statement flow only");
-                    const uint32_t addr = reg_read(rec, 10), sel = reg_read(rec, 11), which = sel & 7u, mop = sel >> 3;   // a1 = index + 8 op: mul, add, sub, div
+                    const uint32_t addr = reg_read(rec, 10), sel = reg_read(rec, 11), which = sel & 7u, mop = sel >> 3;   // a1 = index + 8 op: mul, add, sub, div, is_eq
                     if (which >= moduli_.size()) throw Error("modmul: the app's openvm.toml lists no modulus " + std::to_string(which));
                     if (mop >= zkhip::modular::N_OPS) throw Error("modular: unknown operation " + std::to_string(mop));
                     if (addr & 3u) throw Error("modmul buffer must be word-aligned");
                     uint8_t* p = at(addr, 96);
                     zkhip::modular::U256 a, b, q, r;
                     memcpy(a.w, p, 32), memcpy(b.w, p + 32, 32);
-                    const bool ok_op = mop == zkhip::modular::OP_MUL   ? zkhip::modular::mulmod(a, b, moduli_[which], &q, &r)
-                                       : mop == zkhip::modular::OP_DIV ? zkhip::modular::divmod_p(a, b, moduli_[which], &r)
-                                                                       : zkhip::modular::addsubmod(mop, a, b, moduli_[which], &q, &r);
-                    if (!ok_op)
-                        throw Error("modular: operands too far from the modulus (a product's quotient beyond 256 bits, or a difference beyond the modulus), "
-                                    "or a division with a dividend that is not reduced or a divisor that is not invertible");
+                    if (mop == zkhip::modular::OP_IS_EQ) {   // r = [a = b (mod P)]: the difference's residue, then the bit
+                        if (!zkhip::modular::addsubmod(zkhip::modular::OP_SUB, a, b, moduli_[which], &q, &r))
+                            throw Error("modular: operands of an equality test further apart than the modulus");
+                        bool zero_r = true;
+                        for (uint32_t w : r.w) zero_r = zero_r && w == 0;
+                        r = zkhip::modular::U256{};
+                        r.w[0] = zero_r ? 1u : 0u;
+                    } else {
+                        const bool ok_op = mop == zkhip::modular::OP_MUL   ? zkhip::modular::mulmod(a, b, moduli_[which], &q, &r)
+                                           : mop == zkhip::modular::OP_DIV ? zkhip::modular::divmod_p(a, b, moduli_[which], &r)
+                                                                           : zkhip::modular::addsubmod(mop, a, b, moduli_[which], &q, &r);
+                        if (!ok_op)
+                            throw Error("modular: operands too far from the modulus (a product's quotient beyond 256 bits, or a difference beyond the modulus), "
+                                        "or a division with a dividend that is not reduced or a divisor that is not invertible");
+                    }
                     memcpy(p + 64, r.w, 32);
                 } else if (call == 6) {
                     // a = b op c on the 24 words at a0 (b[8] | c[8] | a[8], little-endian 256-bit words), op = a1: 0 add, 1 sub, 2 xor,

@@ -16,7 +16,7 @@ pub const ZKHIP_DIGEST_WORDS: usize = 8;
 pub const ZKHIP_KECCAK_F_WIDTH: usize = 2633;
 pub const ZKHIP_INT256_ALU_WIDTH: usize = 101;
 pub const ZKHIP_INT256_MUL_WIDTH: usize = 161;
-pub const ZKHIP_MODMUL_WIDTH: usize = 322;
+pub const ZKHIP_MODMUL_WIDTH: usize = 325;
 pub const ZKHIP_EC_WIDTH: usize = 772;
 pub const ZKHIP_FP2_WIDTH: usize = 648;
 pub const ZKHIP_FP2_RECORD_WORDS: usize = 33;

@@ -89,20 +89,21 @@ int ora_modaddsub(unsigned op, const uint8_t a[32], const uint8_t b[32], const u
     return 0;
 }
 
-/* trace: 322 columns x 2^log_height rows, column-major, canonical; records[64 i] = a bytes | b bytes, ops[i] = 0 mul, 1 add, 2 sub, 3 div
- * (a = the quotient x / y, b = y) (NULL: all mul); adds the rows' lookups to bitwise_range[65536] (index 256 x + y) and tuple[256 * size_y] (index x * size_y + y); returns
+/* trace: 325 columns x 2^log_height rows, column-major, canonical; records[64 i] = a bytes | b bytes, ops[i] = 0 mul, 1 add, 2 sub, 3 div
+ * (a = the quotient x / y, b = y), 4 equality test (NULL: all mul); adds the rows' lookups to bitwise_range[65536] (index 256 x + y) and tuple[256 * size_y] (index x * size_y + y); returns
  * the number of bad records */
 size_t ora_modular_trace(const uint8_t *records, const uint32_t *ops, size_t n, const uint8_t p[32], unsigned log_height, uint32_t *trace, uint32_t *bitwise_range,
                          uint32_t *tuple, uint32_t size_y) {
     const size_t N = (size_t)1 << log_height;
-    enum { A = 0, B = 32, Q = 64, R = 96, CX = 128, CY = 190, MARK = 252, DIFF = 284, REAL = 285, IS_ADD = 286, IS_SUB = 287, IS_DIV = 288, MARK2 = 289, DIFF2 = 321, WIDTH = 322 };
+    enum { A = 0, B = 32, Q = 64, R = 96, CX = 128, CY = 190, MARK = 252, DIFF = 284, REAL = 285, IS_ADD = 286, IS_SUB = 287, IS_DIV = 288, MARK2 = 289, DIFF2 = 321, IS_EQ = 322, EQ = 323, INV = 324, WIDTH = 325 };
     memset(trace, 0, (size_t)WIDTH * N * sizeof(uint32_t));
     size_t bad = 0;
     for (size_t row = 0; row < n && row < N; row++) {
         const uint8_t *a = records + 64 * row, *b = a + 32;
-        const unsigned op_in = ops ? ops[row] : 0, is_div = op_in == 3, op = is_div ? 0 : op_in; /* a division row = the product (x / y) y */
+        /* a division row = the product (x / y) y; an equality test (4) = a subtraction row with the bit on top */
+        const unsigned op_in = ops ? ops[row] : 0, is_div = op_in == 3, is_eq = op_in == 4, op = is_div ? 0 : is_eq ? 2 : op_in;
         uint8_t q[32], r[32];
-        if (op_in > 3 || (op == 0 ? ora_modmul(a, b, p, q, r) : ora_modaddsub(op, a, b, p, q, r))) bad++;
+        if (op_in > 4 || (op == 0 ? ora_modmul(a, b, p, q, r) : ora_modaddsub(op, a, b, p, q, r))) bad++;
 #define PUT(col, v) trace[(size_t)(col) * N + row] = (uint32_t)(v)
         for (int i = 0; i < 32; i++) PUT(A + i, a[i]), PUT(B + i, b[i]), PUT(Q + i, q[i]), PUT(R + i, r[i]);
         for (int i = 0; i < 32; i += 2)
@@ -151,6 +152,13 @@ size_t ora_modular_trace(const uint8_t *records, const uint32_t *ops, size_t n, 
                 bitwise_range[256 * ((d2 - 1) & 255)]++;
             }
             PUT(IS_DIV, 1);
+        }
+        if (is_eq) { /* eq = [r = 0] through the sum of r's limbs; its inverse modulo the BabyBear prime where it is not zero */
+            unsigned long long sum = 0, inv = 1, base, e = 2013265921ull - 2;
+            for (int i = 0; i < 32; i++) sum += r[i];
+            for (base = sum; e; e >>= 1, base = base * base % 2013265921ull)
+                if (e & 1) inv = inv * base % 2013265921ull;
+            PUT(IS_EQ, 1), PUT(EQ, sum == 0), PUT(INV, sum ? inv : 0);
         }
 #undef PUT
     }

@@ -6,7 +6,7 @@ import numpy as np
 import zkvm_prover_amd as z
 from zkvm_prover_amd import air
 
-WIDTH, BITWISE_BUS, TUPLE_BUS, SX, SY = 322, 9, 6, 256, 128
+WIDTH, BITWISE_BUS, TUPLE_BUS, SX, SY = 325, 9, 6, 256, 128
 NOPV = np.zeros(0, np.uint32)
 
 

@@ -317,11 +317,11 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                 mem[off + 64:off + 96] = a_.to_bytes(32, "little")
             elif call == 5:   # r = a b mod moduli[a1] on the 24 words at a0 (a | b | r, little-endian)
                 off = rr(10) - data_base
-                sel = rr(11)                 # a1 = modulus index + 8 * operation (0 mul, 1 add, 2 sub, 3 div)
+                sel = rr(11)                 # a1 = modulus index + 8 * operation (0 mul, 1 add, 2 sub, 3 div, 4 is_eq)
                 p_, mop = moduli[sel & 7], sel >> 3
-                assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem) and mop < 4
+                assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem) and mop < 5
                 a_, b_ = int.from_bytes(mem[off:off + 32], "little"), int.from_bytes(mem[off + 32:off + 64], "little")
-                res = a_ * pow(b_, -1, p_) % p_ if mop == 3 else [a_ * b_ % p_, (a_ + b_) % p_, (a_ - b_) % p_][mop]
+                res = int((a_ - b_) % p_ == 0) if mop == 4 else a_ * pow(b_, -1, p_) % p_ if mop == 3 else [a_ * b_ % p_, (a_ + b_) % p_, (a_ - b_) % p_][mop]
                 mem[off + 64:off + 96] = res.to_bytes(32, "little")
             elif call == 7:   # (x3, y3) = p1 + p2 (op 0) or 2 p1 (op 1) on curves[a1 & 7] = (modulus, a), 48 words at a0 (p1 | p2 | p3)
                 off = rr(10) - data_base

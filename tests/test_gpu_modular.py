@@ -1,4 +1,4 @@
-"""GPU: the modular-multiplication chip on the device: zkhip_modmul_tracegen == the oracle twin cell for cell (322 columns) and count for
+"""GPU: the modular-multiplication chip on the device: zkhip_modmul_tracegen == the oracle twin cell for cell (325 columns) and count for
 count in both lookup tables, r = a b mod P is Python's, the HIP proof of the chip with its tables == the oracle's."""
 import json
 import os
@@ -56,7 +56,8 @@ def test_device_modular_operations_trace(zk, ora):
         rows = [(3, int(c["r"], 16), int(c["b"], 16)) for c in kat["div"] if c["modulus"] == name]
         rows += [(c["op"], int(c["a"], 16), int(c["b"], 16)) for c in kat["addsub"] if c["modulus"] == name][:10]
         rows += [(0, int(c["a"], 16), int(c["b"], 16)) for c in kat["cases"] if c["modulus"] == name][:6]
-        log_h = 5
+        rows += [(4, 5, 5), (4, 5, 6), (4, p - 1, p - 1), (4, 0, p - 1)]      # equality tests
+        log_h = 6
         recs = np.array([[op] + mu.to_bytes(a).view("<u4").tolist() + mu.to_bytes(b).view("<u4").tolist() for op, a, b in rows], dtype=np.uint32).reshape(-1)
         d_recs = torch.from_numpy(recs.view(np.int32)).to(zk.device)
         d_bw = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)

@@ -113,6 +113,36 @@ def test_division(ora, kat):
     assert air.check_trace(inst[0]["program"], t2, mu.NOPV) == []
 
 
+def test_equality_test(ora, kat):
+    """ModularIsEqual on top of a subtraction row: the host function's bit is Python's; equal and different operands in one trace satisfy
+    the AIR and balance both buses; "equal" claimed for different operands and "different" claimed for equal ones have no trace."""
+    p = int(kat["moduli"]["secp256k1_n"], 16)
+    pairs = [(5, 5), (5, 6), (0, 0), (p - 1, p - 1), (p - 1, 0), (0, p - 1), (1 << 200, 1 << 200), (1 << 200, (1 << 200) + 256)]
+    for a, b in pairs:
+        assert z.modular_host(4, a, b, p) == (0, int(a == b))
+    rows = [(4, a, b) for a, b in pairs] + [(2, 9, 4), (1, 9, 4), (0, 9, 4)]
+    tr, bw, tup, bad = mu.ora_trace(ora, [(a, b) for _, a, b in rows], p, 4, ops=[o for o, _, _ in rows])
+    assert bad == 0
+    inst = mu.instance(p, tr, bw, tup, 4)
+    for d in inst:
+        assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == []
+    assert v2.bus_imbalance(inst) == {}
+    for row, (a, b) in enumerate(pairs):
+        assert tr[322, row] == 1 and tr[287, row] == 1 and tr[323, row] == int(a == b)
+    program = inst[0]["program"]
+    t2 = tr.copy()
+    t2[323, 1], t2[324, 1] = 1, 0                      # 5 == 6 claimed
+    assert air.check_trace(program, t2, mu.NOPV) != []
+    t3 = tr.copy()
+    t3[323, 0] = 0                                     # 5 != 5 claimed: no inverse of a zero sum
+    for inv in (0, 1, 12345):
+        t3[324, 0] = inv
+        assert air.check_trace(program, t3, mu.NOPV) != []
+    t4 = tr.copy()
+    t4[323, 8] = 1                                     # the bit set on a plain subtraction row
+    assert air.check_trace(program, t4, mu.NOPV) != []
+
+
 @pytest.mark.parametrize("name", ["secp256k1_p", "bn254_r"])
 def test_trace_satisfies_the_air_and_the_buses_balance(ora, kat, name):
     p = int(kat["moduli"][name], 16)

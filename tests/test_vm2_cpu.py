@@ -229,7 +229,7 @@ def test_modmul_intrinsic_is_part_of_the_statement(tmp_path):
     assert int.from_bytes(pv[28:32], "little") == (x3 >> 96 & 0xFFFFFFFF) ^ (other & 0xFFFFFFFF)
     info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 0, 0, moduli)
     assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"]
-    assert len(H.ids) == 26 and sum(len(s["mm_ts_0"]) for s in segs) == 6 and sum(len(s["mm_ts_1"]) for s in segs) == 1
+    assert len(H.ids) == 26 and sum(len(s["mm_ts_0"]) for s in segs) == 8 and sum(len(s["mm_ts_1"]) for s in segs) == 1
     for k, rec in enumerate(segs):
         inst = v2.segment_instance(rec, words, PC_BASE, H)
         for d in inst:

@@ -189,8 +189,8 @@ def modmul_program():
     """The secp256k1 generator's curve equation through the modmul intrinsic (a7 = 5, a1 = modulus index): buffer 0 = (Gy, Gy, .),
     buffer 1 = (Gx, Gx, .), buffer 2 = (Gx^2, Gx, .) at the data base (modmul_data); reveals the low words of y^2 and x^3 (words 0..3 and
     4..7) -- they differ by 7 modulo p -- and one product modulo the second modulus folded into word 7; then x^3 + 7 (modular
-    addition), (x^3 + 7) - y^2 (modular subtraction: zero) and (x^3 + 7) / y^2 (modular division: one) through the same intrinsic with
-    a1 = index + 8 op."""
+    addition), (x^3 + 7) - y^2 (modular subtraction: zero), (x^3 + 7) / y^2 (modular division: one) and the equality tests y^2 = x^3 + 7 (one), 5 = 6 (zero)
+    through the same intrinsic with a1 = index + 8 op."""
     p = rv.li(S0, 0x00400000)
     def call(buf, which):
         return [("addi", A0, S0, 96 * buf), ("addi", A1, 0, which), ("addi", A7, 0, 5), ("ecall",)]
@@ -210,6 +210,11 @@ def modmul_program():
     p += call(6, 24)                                                       # a1 = 0 + 8 * 3: modulus 0, division
     p += [("lw", T1, S0, 288 + 64), ("lw", T2, S0, 480 + 64), ("or", T1, T1, T2)]   # (the difference's low word is zero: folding it in changes nothing)
     p += [("lw", T2, S0, 576 + 64), ("addi", T2, T2, -1), ("or", T1, T1, T2), ("lw", T2, S0, 576 + 68), ("or", T1, T1, T2)]   # (nor does the quotient minus one)
+    for k in range(8):                                                     # is y^2 = (x^3 + 7) - 0?  buffer 7 = (y^2, x^3 + 7, .): the bit must be one
+        p += [("lw", T0, S0, 64 + 4 * k), ("sw", T0, S0, 672 + 4 * k), ("lw", T0, S0, 384 + 64 + 4 * k), ("sw", T0, S0, 672 + 32 + 4 * k)]
+    p += call(7, 32)                                                       # a1 = 0 + 8 * 4: modulus 0, equality test
+    p += call(8, 32)                                                       # buffer 8 = (5, 6, .): the bit must be zero
+    p += [("lw", T2, S0, 672 + 64), ("addi", T2, T2, -1), ("or", T1, T1, T2), ("lw", T2, S0, 768 + 64), ("or", T1, T1, T2)]   # (both as expected: nothing changes)
     for k in range(4):
         p += [("lw", A0, S0, 64 + 4 * k), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
     for k in range(4):
@@ -231,7 +236,7 @@ def modmul_data():
     b32 = lambda v: int(v).to_bytes(32, "little")  # noqa: E731
     z32 = bytes(32)
     return (b32(SECP256K1_GY) + b32(SECP256K1_GY) + z32 + b32(SECP256K1_GX) + b32(SECP256K1_GX) + z32 + z32 + b32(SECP256K1_GX) + z32 +
-            b32(SECP256K1_N - 2) + b32(SECP256K1_N - 3) + z32 + z32 + b32(7) + z32 + z32 + z32 + z32 + z32 + z32 + z32)
+            b32(SECP256K1_N - 2) + b32(SECP256K1_N - 3) + z32 + z32 + b32(7) + z32 + z32 + z32 + z32 + z32 + z32 + z32 + z32 + z32 + z32 + b32(5) + b32(6) + z32)
 
 
 BN254_P = 21888242871839275222246405745257275088696311157297823662689037894645226208583

@@ -24,7 +24,7 @@ MAX_MODULI, MAX_CURVES, MAX_FP2 = 8, 4, 2
 N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES + 2 * MAX_FP2
 PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 34, 43, 54, 42, 2634
 SHA_IO_WIDTH, SHA_WIDTH = 34, 434
-MODMUL_IO_WIDTH, MODMUL_WIDTH = 35, 323
+MODMUL_IO_WIDTH, MODMUL_WIDTH = 35, 326
 INT256_IO_WIDTH, INT256_WIDTH, MUL256_WIDTH, CMP256_WIDTH, SHIFT256_WIDTH = 35, 102, 162, 104, 190
 EC_IO_WIDTH, EC_WIDTH, FP2_WIDTH = 59, 773, 649
 TS_STEP, GAP_HI_BITS = 16, 11

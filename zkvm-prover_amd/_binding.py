@@ -642,7 +642,7 @@ class Context:
         return out
 
     def vm_modmul_tracegen(self, modulus, t_records, t_ts, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
-        out = self._new(323 << log_height)
+        out = self._new(326 << log_height)
         m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
         self._check(self.lib.zkhip_vm_modmul_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height,
                                                       out.data_ptr(), t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
@@ -678,7 +678,7 @@ class Context:
 
     def modular_tracegen(self, modulus, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
         """records: n x 17 words (op | a | b; op 0 mul, 1 add, 2 sub)"""
-        out = self._new(322 << log_height)
+        out = self._new(325 << log_height)
         m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
         self._check(self.lib.zkhip_modular_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr(),
                                                     t_tuple_counts.data_ptr(), size_x, size_y))
@@ -752,7 +752,7 @@ class Context:
         return out
 
     def modmul_tracegen(self, modulus, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
-        out = self._new(322 << log_height)
+        out = self._new(325 << log_height)
         m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
         self._check(self.lib.zkhip_modmul_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr(),
                                                    t_tuple_counts.data_ptr(), size_x, size_y))

@@ -1,6 +1,6 @@
 // modular.hip -- the modular-multiplication chip on the device (include/zkhip_modular.hpp: r = a b mod P on byte limbs, one operation
-// per row, 322 columns).  Record = a[8] | b[8] (little-endian 32-bit words; with an operation word in front for the form that also adds and subtracts).  One lane per row: schoolbook product, binary long division
-// by the modulus (512 shift-compare-subtract steps on nine words: ~20 k integer operations next to 322 stores and 127 table increments),
+// per row, 325 columns).  Record = a[8] | b[8] (little-endian 32-bit words; with an operation word in front for the form that also adds and subtracts).  One lane per row: schoolbook product, binary long division
+// by the modulus (512 shift-compare-subtract steps on nine words: ~20 k integer operations next to 325 stores and 127 table increments),
 // then the carries of the limb equations; the row's lookups (65 byte pairs, 62 carry tuples) are counted into the bitwise and range-tuple
 // tables in the same pass (wave-merged atomics, csrc/hist.hpp).  Replaces the trace generation of OpenVM's ModularMulDiv chip
 // (openvm-algebra-circuit, un-vendored).
@@ -41,8 +41,8 @@ __global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict
     uint32_t a[8], b[8], prod[16], rem[9], quo[8];
     const size_t ro = rec_stride * row + (rec_stride - 16);
     const uint32_t op_in = rec_stride == 17 ? recs[rec_stride * row] : 0u;   // 0 mul, 1 add, 2 sub, 3 div (the record then holds the quotient x / y and y)
-    const bool is_div = op_in == md::OP_DIV;
-    const uint32_t op = is_div ? (uint32_t)md::OP_MUL : op_in;
+    const bool is_div = op_in == md::OP_DIV, is_eq = op_in == md::OP_IS_EQ;   // (an equality test is a subtraction row with the bit on top)
+    const uint32_t op = is_div ? (uint32_t)md::OP_MUL : is_eq ? (uint32_t)md::OP_SUB : op_in;
     if (op_in >= md::N_OPS) atomicAdd(bad, 1u);
 #pragma unroll
     for (int i = 0; i < 8; i++) a[i] = recs[ro + i], b[i] = recs[ro + 8 + i];
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict
         }
     for (int i = 0; i < 32; i++) put(md::COL_MARK + i, i == mark ? 1u : 0u);
     const uint32_t diff = mark >= 0 ? byte_of(pm.w, mark) - byte_of(rem, mark) : 0u;
-    put(md::COL_DIFF, diff), put(md::COL_REAL, 1u), put(md::COL_IS_ADD, op == md::OP_ADD ? 1u : 0u), put(md::COL_IS_SUB, op == md::OP_SUB ? 1u : 0u);
+    put(md::COL_DIFF, diff), put(md::COL_REAL, 1u), put(md::COL_IS_ADD, op == md::OP_ADD ? 1u : 0u), put(md::COL_IS_SUB, op == md::OP_SUB ? 1u : 0u);   // (set on equality tests too)
     hist_add(bitwise_range, ((diff - 1u) & 255u) * 256);
     // a division's quotient (the a columns) is canonical as well
     int mark2 = -1;
@@ -167,6 +167,11 @@ __global__ __launch_bounds__(256) void k_modmul_trace(const uint32_t* __restrict
     for (int i = 0; i < 32; i++) put(md::COL_MARK2 + i, i == mark2 ? 1u : 0u);
     const uint32_t diff2 = mark2 >= 0 ? byte_of(pm.w, mark2) - byte_of(a, mark2) : 0u;
     put(md::COL_IS_DIV, is_div ? 1u : 0u), put(md::COL_DIFF2, diff2);
+    uint32_t limb_sum = 0;
+    for (int i = 0; i < 32; i++) limb_sum += byte_of(rem, i);
+    const bool eq = is_eq && limb_sum == 0;
+    put(md::COL_IS_EQ, is_eq ? 1u : 0u), put(md::COL_EQ, eq ? 1u : 0u);
+    trace[(size_t)md::COL_INV * N + row] = is_eq && !eq ? minv(to_monty(limb_sum)) : 0u;   // (Montgomery form, as every cell)
     if (is_div) hist_add(bitwise_range, ((diff2 - 1u) & 255u) * 256);
 }
 
@@ -264,7 +269,14 @@ int zkhip_modular_host(uint32_t op, const uint32_t a[8], const uint32_t b[8], co
     bool zero = true;
     for (uint32_t v : M.w) zero = zero && v == 0;
     if (zero) return ZKHIP_ERR_INVALID;
-    if (op == md::OP_DIV) {
+    if (op == md::OP_IS_EQ) {   // r = [a = b (mod P)] for |a - b| < P
+        Q = md::U256{};
+        if (!md::addsubmod(md::OP_SUB, A, B, M, &Q, &R)) return ZKHIP_ERR_INVALID;
+        bool zero_r = true;
+        for (uint32_t w : R.w) zero_r = zero_r && w == 0;
+        R = md::U256{}, Q = md::U256{};
+        R.w[0] = zero_r ? 1u : 0u;
+    } else if (op == md::OP_DIV) {
         Q = md::U256{};
         if (!md::divmod_p(A, B, M, &R)) return ZKHIP_ERR_INVALID;
     } else if (!md::addsubmod(op, A, B, M, &Q, &R)) {
