@@ -8,6 +8,8 @@ the segmenting executor's records (include/zkhip_vm_exec.hpp, `prove_cli dump-se
   * a tampered instruction result, swapped operands, a forged memory value, a skipped instruction, a wrong next pc: some bus no
     longer balances (what makes the proof fail);
   * the decode table against an independent decoder."""
+import os
+
 import numpy as np
 import pytest
 
@@ -383,6 +385,30 @@ def test_all_extensions_of_the_chunk_circuit_in_one_statement(tmp_path):
         for d in inst:
             assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], k
         assert v2.bus_imbalance(inst) == {}
+
+
+def test_the_reference_config_file_itself_gives_the_same_chip_set(tmp_path):
+    """crates/circuits/chunk-circuit/openvm.toml as it lies in the reference tree (read here only; skipped where the tree is absent, e.g. on
+    the GPU box) goes through the executor's configuration reader: the chip ids, the heights and the run of the all-extensions guest are
+    those of this repository's restatement of that file (test_vm_cpu.chunk_circuit_toml) -- 51 chips."""
+    import subprocess
+    from test_vm_cpu import chunk_circuit_toml
+
+    ref = "/root/reference/crates/circuits/chunk-circuit/openvm.toml"
+    if not os.path.exists(ref):
+        pytest.skip("no reference tree here")
+    words, data = all_extensions_program(True), all_extensions_data()
+    (tmp_path / "exe.bin").write_bytes(rv.exe_bytes(words, data=data))
+    (tmp_path / "stdin.bin").write_bytes(b"")
+    (tmp_path / "mine.toml").write_text(chunk_circuit_toml(PARAMS))
+    seen = []
+    for cfg in (ref, str(tmp_path / "mine.toml")):
+        out = tmp_path / ("out_%d" % len(seen))
+        out.mkdir()
+        r = subprocess.run([v2.CLI, "dump-segments", str(tmp_path / "exe.bin"), str(tmp_path / "stdin.bin"), str(out), "7", "5", "7", cfg], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        seen.append((np.fromfile(out / "air_ids.u32", dtype=np.uint32).tolist(), np.fromfile(out / "heights.u32", dtype=np.uint32).tolist(), r.stdout.strip().splitlines()[-1]))
+    assert seen[0] == seen[1] and len(seen[0][0]) == 51
 
 
 def test_decode_table_against_an_independent_decoder(mixed):
