@@ -603,7 +603,8 @@ inline zkhip::modular::U256 parse_decimal_u256(const std::string& digits) {
             c += (uint64_t)v.w[w] * 10u;
             v.w[w] = (uint32_t)c, c >>= 32;
         }
-        if (c) throw Error("openvm.toml: a modulus or coefficient does not fit 256 bits");
+        if (c) throw Error("openvm.toml: a modulus or coefficient does not fit 256 bits (the limb chips are built for 32 byte limbs: the 381-bit field of the "
+                           "reference's batch circuit is not supported)");
     }
     return v;
 }
