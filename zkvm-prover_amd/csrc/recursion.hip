@@ -1591,7 +1591,11 @@ extern "C" int zkhip_recursion_tracegen(zkhip_ctx* ctx, zkhip_recursion* R, uint
     }
     if (R->pinned_vals != (void*)R->vals.data()) {
         if (R->pinned_vals) (void)hipHostUnregister(R->pinned_vals);
-        R->pinned_vals = hipHostRegister(R->vals.data(), R->vals.size() * 16, hipHostRegisterDefault) == hipSuccess ? (void*)R->vals.data() : nullptr;
+        // Only a LARGE value array is page-locked in place: the allocator gives it a mapping of its own.  A small one lives in the shared
+        // heap -- locking its pages would lock its neighbours', and the heap may hand those pages back to the system while they are
+        // registered; a small array gains nothing anyway (the copy is staged).  ZKHIP_NO_PIN_WITNESS=1 never registers.
+        const bool pin = R->vals.size() * 16 >= ((size_t)4 << 20) && !getenv("ZKHIP_NO_PIN_WITNESS");
+        R->pinned_vals = pin && hipHostRegister(R->vals.data(), R->vals.size() * 16, hipHostRegisterDefault) == hipSuccess ? (void*)R->vals.data() : nullptr;
         (void)hipGetLastError();
     }
     ZK_TRY(upload(ctx, R->d_wires, R->vals.data(), R->vals.size() * 16));
