@@ -31,6 +31,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -1472,9 +1473,21 @@ int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, co
         auto keep_first = [](long& acc, long b) {
             if (b >= 0 && (acc < 0 || b < acc)) acc = b;
         };
+        // (a thread the system refuses -- a process at its thread limit -- is not fatal: the caller does that share itself)
+        auto spawn = [](std::vector<std::thread>& th, auto&& fn) {
+            try {
+                th.emplace_back(fn);
+                return true;
+            } catch (const std::system_error&) {
+                return false;
+            }
+        };
         if (!c.query_parallel) {
             std::vector<std::thread> th;
-            for (size_t i = 1; i < n_sec; i++) th.emplace_back([&, i]() { bad[i] = run(c.sections[i], c.sections[i + 1], true); });
+            for (size_t i = 1; i < n_sec; i++) {
+                auto part = [&, i]() { bad[i] = run(c.sections[i], c.sections[i + 1], true); };
+                if (!spawn(th, part)) part();
+            }
             bad[0] = run(c.sections[0], c.sections[1], true);
             for (auto& t : th) t.join();
         } else {
@@ -1482,7 +1495,10 @@ int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, co
             // follows the queries
             auto each_child = [&](auto&& f) {
                 std::vector<std::thread> th;
-                for (size_t i = 1; i < n_sec; i++) th.emplace_back([&, i]() { f(i); });
+                for (size_t i = 1; i < n_sec; i++) {
+                    auto part = [&, i]() { f(i); };
+                    if (!spawn(th, part)) part();
+                }
                 f(0);
                 for (auto& t : th) t.join();
             };
@@ -1497,13 +1513,15 @@ int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, co
             std::atomic<size_t> next{0};
             std::vector<std::vector<long>> tb(n_threads, std::vector<long>(n_sec, -1));
             std::vector<std::thread> th;
-            for (size_t t = 0; t < n_threads; t++)
-                th.emplace_back([&, t]() {
-                    for (size_t k; (k = next.fetch_add(1)) < tasks.size();) {
-                        const size_t i = tasks[k].first, q = tasks[k].second;
-                        keep_first(tb[t][i], run(c.sub[i][q], c.sub[i][q + 1], true));
-                    }
-                });
+            auto worker = [&](size_t t) {
+                for (size_t k; (k = next.fetch_add(1)) < tasks.size();) {
+                    const size_t i = tasks[k].first, q = tasks[k].second;
+                    keep_first(tb[t][i], run(c.sub[i][q], c.sub[i][q + 1], true));
+                }
+            };
+            for (size_t t = 1; t < n_threads; t++)
+                if (!spawn(th, [&, t]() { worker(t); })) break;
+            if (n_threads) worker(0);   // this thread takes tasks from the same counter
             for (auto& t : th) t.join();
             for (size_t t = 0; t < n_threads; t++)
                 for (size_t i = 0; i < n_sec; i++) keep_first(bad[i], tb[t][i]);
