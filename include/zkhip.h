@@ -761,14 +761,32 @@ typedef struct {
     size_t n_state;
     const uint32_t *start_air, *start_idx, *end_air, *end_idx;
     int child_is_node;
+    /* ONE AGGREGATION KEY (crates/prover/src/prover/mod.rs:147-170 one agg_vk; crates/verifier/src/verifier.rs:96-111): leaf and internal
+     * circuits share the AIR programs and -- padded -- the heights, so the only thing that tells their proofs apart is the three
+     * preprocessed commitments.  child_is_node = 2 builds the UNIFORM internal circuit: `child_airs` = the node AIR set at the common
+     * heights (prep_commit ignored), the children's preprocessed commitments are VALUES of the circuit, every child is a proof of the
+     * leaf circuit or of the internal circuit itself, and the node's public values end with [leaf commitment (8) | internal
+     * commitment (8)] = zkhip_recursion_key_commit of the two keys: each child's commitments hash to one of the two, an internal
+     * child states the same pair.  The verifier holds (internal key, leaf commitment) whatever the depth of the tree.
+     * uniform = 1 on a leaf circuit (child_is_node = 0) appends the 16 words (zero) so that its proofs have the internal circuit's
+     * public-value layout.  min_log_height pads the gate / Poseidon2 chip (0 = natural size). */
+    int uniform;
+    unsigned min_log_height[2];
 } zkhip_recursion_stmt;
 /* `airs[a].log_height` and `airs[a].prep_commit` are part of the child verifying key; program pointers are copied. */
 int zkhip_recursion_build(const zkhip_params *child_params, const zkhip_air *child_airs, size_t n_child_airs, size_t max_children,
                           const zkhip_recursion_stmt *stmt, zkhip_recursion **out);
 void zkhip_recursion_destroy(zkhip_recursion *r);
+/* a second user of the same circuit: wiring, programs and preprocessed traces shared, witness and device buffers its own (the levels of
+ * an aggregation tree above the leaves run ONE internal circuit side by side); destroy each with zkhip_recursion_destroy */
+int zkhip_recursion_fork(const zkhip_recursion *r, zkhip_recursion **out);
+/* lays the preprocessed traces out again at heights >= 2^log_height[0] (gate chip) / 2^log_height[1] (Poseidon2 chip); not on a forked circuit */
+int zkhip_recursion_pad(zkhip_recursion *r, const unsigned log_height[2]);
+/* digest of a node key's preprocessed commitments (n_commits x 8 canonical words, AIR order): the leaf / internal commitment of a uniform node */
+int zkhip_recursion_key_commit(const uint32_t *prep_commits, size_t n_commits, uint32_t out[8]);
 const char *zkhip_recursion_last_error(const zkhip_recursion *r); /* r = NULL: why the last zkhip_recursion_build of this thread failed */
 size_t zkhip_recursion_n_airs(const zkhip_recursion *r);            /* 3 */
-size_t zkhip_recursion_n_pvs(const zkhip_recursion *r);             /* 16 + 2 K */
+size_t zkhip_recursion_n_pvs(const zkhip_recursion *r);             /* 16 + 2 K (32 + 2 K under one key) */
 size_t zkhip_recursion_n_state(const zkhip_recursion *r);           /* K */
 size_t zkhip_recursion_max_children(const zkhip_recursion *r);
 size_t zkhip_recursion_child_proof_bytes(const zkhip_recursion *r);
@@ -783,6 +801,11 @@ int zkhip_recursion_air(const zkhip_recursion *r, size_t i, zkhip_air *out);
  * values are kept, so the traces can still be generated (and their proof will not verify). */
 int zkhip_recursion_witness(zkhip_recursion *r, const uint8_t *const *proofs, const size_t *proof_lens, const uint32_t *const *const *child_pvs,
                             size_t n_present, uint32_t *node_pvs_out);
+/* the witness of a UNIFORM node: child c is a proof under the key with preprocessed commitments child_prep_commits[c] (3 x 8 canonical
+ * words), of the leaf circuit (child_is_leaf[c] != 0) or the internal circuit; leaf_commit / internal_commit: see zkhip_recursion_stmt */
+int zkhip_recursion_witness_uniform(zkhip_recursion *r, const uint8_t *const *proofs, const size_t *proof_lens, const uint32_t *const *const *child_pvs,
+                                    const uint32_t *child_prep_commits, const int *child_is_leaf, const uint32_t leaf_commit[8],
+                                    const uint32_t internal_commit[8], size_t n_present, uint32_t *node_pvs_out);
 /* wire values of the last witness, canonical [n_wires + 1][4]; out = NULL: only the size */
 int zkhip_recursion_wires(const zkhip_recursion *r, uint32_t *out, size_t cap_words, size_t *n_words);
 /* device traces of the three chips from the last witness (Montgomery, column-major, stride = 2^log_height of the chip) */

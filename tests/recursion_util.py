@@ -95,3 +95,37 @@ def internal_accumulator(child_accs):
     for a in child_accs:
         acc = compress(acc, a)
     return acc
+
+
+def one_key_circuits(params, app_vk, stmt, arity_leaf=4, arity_internal=3, node_params=None):
+    """The two circuits of ONE aggregation key (include/zkhip_aggregation.hpp `AggregationProver::ensure_key`, restated): the leaf
+    circuit for the app's key with the uniform public-value layout, the uniform internal circuit for the node AIR set, both padded
+    to the smallest common heights (a fixed point: the internal circuit verifies proofs of its own height)."""
+    import zkvm_prover_amd as z
+
+    node_params = node_params or params
+    leaf = z.RecursionCircuit(params, app_vk, arity_leaf, stmt=stmt, uniform=True)
+    na = leaf.airs()
+    child = [{k: a[k] for k in ("program", "log_height", "width", "n_pvs")} for a in na]
+    H = [na[0]["log_height"], na[1]["log_height"]]
+    while True:
+        for c, h in zip(child, H + [0]):
+            c["log_height"] = h
+        internal = z.RecursionCircuit(node_params, child, arity_internal, stmt="uniform", min_log_height=H)
+        hh = internal.log_heights()[:2]
+        if hh == H:
+            break
+        H = hh
+    leaf.pad(*H)
+    assert leaf.log_heights() == internal.log_heights()
+    for a, b in zip(leaf.airs(), internal.airs()):
+        assert (a["program"] == b["program"]).all() and a["width"] == b["width"] and a["n_pvs"] == b["n_pvs"]
+    return leaf, internal
+
+
+def node_key_commits(params, node_airs):
+    """The three preprocessed commitments of a node key (oracle) and their digest (zkhip_recursion_key_commit)."""
+    import zkvm_prover_amd as z
+
+    pcs = [np.asarray(ora.prep_commit(params, dict(a, pvs=NOPV, trace=None)), np.uint32) for a in node_airs]
+    return pcs, z.key_commit(pcs)

@@ -178,3 +178,72 @@ def test_build_refuses_inconsistent_keys(ora, leaf):
         z.RecursionCircuit(PARAMS, leaf["vk"], 2, stmt=dict(start=[(0, 5)], end=[(0, 1)]))   # no such public value
     with pytest.raises(z.ZkhipError):
         z.RecursionCircuit(PARAMS, leaf["vk"], 2, stmt="node")                                # last AIR is not a public-value chip
+
+
+def test_one_aggregation_key_self_recursive_internal_circuit(ora):
+    """ONE aggregation key (crates/prover/src/prover/mod.rs:147-170, crates/verifier/src/verifier.rs:96-111: one agg vk): the leaf and
+    the internal circuit share programs and (padded) heights; the internal circuit takes its child's preprocessed commitments as values
+    and verifies proofs of the leaf circuit AND of itself.  Six segments -> three leaf nodes -> two internal nodes -> a root that is a
+    proof of the SAME internal key; the root states (leaf commitment, internal commitment); a child of another key, a child whose kind
+    is misstated and nodes that state another commitment pair have no witness."""
+    starts = [5, 12, 19, 26, 33, 40]
+    kids = [ru.counter_segment(s, seed=i) for i, s in enumerate(starts)]
+    proofs = [ora.stark_prove(PARAMS, k).tobytes() for k in kids]
+    pvs = [[a["pvs"] for a in k] for k in kids]
+    vk = ru.verifying(PARAMS, kids[0])
+    leaf, internal = ru.one_key_circuits(PARAMS, vk, ru.COUNTER_STMT)
+    assert leaf.n_pvs == internal.n_pvs == 8 + 1 + 1 + 8 + 16 and internal.n_state == 1
+    leaf_pcs, LC = ru.node_key_commits(PARAMS, leaf.airs())
+    int_pcs, IC = ru.node_key_commits(PARAMS, internal.airs())
+    assert LC.tolist() != IC.tolist()
+
+    def leaf_node(group):
+        st, npv = leaf.witness([proofs[i] for i in group], [pvs[i] for i in group])
+        assert st == 0, leaf.last_error()
+        assert (npv[-16:] == 0).all()
+        return ora.stark_prove(PARAMS, ru.node_instance(leaf, npv)).tobytes(), npv
+
+    def internal_node(circ, children, kinds):
+        st, npv = circ.witness([c[0] for c in children], [[NOPV, NOPV, c[1]] for c in children],
+                               prep_commits=[leaf_pcs if k else int_pcs for k in kinds], is_leaf=kinds, leaf_commit=LC, internal_commit=IC)
+        assert st == 0, circ.last_error()
+        node = ru.node_instance(circ, npv)
+        for a in node[:2]:
+            assert air.check_trace(a["program"], a["trace"], a["pvs"], a["prep"]) == []
+        return ora.stark_prove(PARAMS, node).tobytes(), npv
+
+    L = [leaf_node(g) for g in ([0, 1, 2], [3, 4], [5])]
+    n0 = internal_node(internal, L[:2], [1, 1])
+    fork = internal.fork()                                    # a second user of the same circuit (another level of the tree)
+    n1 = internal_node(fork, L[2:], [1])
+    root = internal_node(internal, [n0, n1], [0, 0])          # the internal circuit verifies proofs of ITSELF
+    rpv = root[1]
+    assert rpv[:8].tolist() == leaf.child_vk_digest().tolist()
+    assert int(rpv[8]) == 5 and int(rpv[9]) == 47
+    assert rpv[10:18].tolist() == ru.internal_accumulator([ru.internal_accumulator([L[0][1][10:18], L[1][1][10:18]]), ru.internal_accumulator([L[2][1][10:18]])]).tolist()
+    assert rpv[18:26].tolist() == LC.tolist() and rpv[26:].tolist() == IC.tolist()
+    # the root, the middle nodes: all proofs under the one internal key
+    ivk = ru.verifying(PARAMS, [dict(a, prep_commit=c) for a, c in zip(internal.airs(), int_pcs)])
+    for pr, npv in (n0, n1, root):
+        assert z.verify(PARAMS, ivk, [NOPV, NOPV, npv], pr) == 0
+    # a leaf proof and a node proof side by side
+    mixed = internal_node(fork, [n0, L[2]], [0, 1])
+    assert mixed[1][8:10].tolist() == [5, 47]
+
+    def status(kinds, preps, lc=LC, ic=IC, ch=(n0, n1)):
+        return internal.witness([c[0] for c in ch], [[NOPV, NOPV, c[1]] for c in ch], prep_commits=preps, is_leaf=kinds, leaf_commit=lc,
+                                internal_commit=ic)[0]
+
+    assert status([0, 0], [int_pcs, int_pcs]) == 0
+    assert status([1, 0], [int_pcs, int_pcs]) == -7            # the kind is misstated
+    assert status([0, 0], [leaf_pcs, int_pcs]) == -7           # a proof under another key than the one handed in
+    bad = IC.copy()
+    bad[0] ^= 1
+    assert status([0, 0], [int_pcs, int_pcs], ic=bad) == -7    # the children's commitments do not hash to the stated internal commitment
+    bad = LC.copy()
+    bad[3] ^= 1
+    assert status([0, 0], [int_pcs, int_pcs], lc=bad) == -7    # internal children state another leaf commitment
+    assert status([1, 1], [leaf_pcs, leaf_pcs], lc=bad, ch=(L[0], L[1])) == -7
+    # the per-key entry point refuses a uniform circuit and the other way round
+    assert internal.witness([n0[0]], [[NOPV, NOPV, n0[1]]])[0] == -3
+    assert leaf.witness([proofs[0]], [pvs[0]], prep_commits=[leaf_pcs], is_leaf=[1], leaf_commit=LC, internal_commit=IC)[0] == -3

@@ -16,6 +16,7 @@ from ._binding import (  # noqa: F401
     declared_symbols,
     ProvingKey,
     RecursionCircuit,
+    key_commit,
     keccak_f_air,
     keccak_f1600_host,
     int256_alu_air,

@@ -57,7 +57,8 @@ class _V1Summary(C.Structure):
 
 class _RecursionStmt(C.Structure):
     _fields_ = [("n_state", C.c_size_t), ("start_air", C.POINTER(C.c_uint32)), ("start_idx", C.POINTER(C.c_uint32)),
-                ("end_air", C.POINTER(C.c_uint32)), ("end_idx", C.POINTER(C.c_uint32)), ("child_is_node", C.c_int)]
+                ("end_air", C.POINTER(C.c_uint32)), ("end_idx", C.POINTER(C.c_uint32)), ("child_is_node", C.c_int),
+                ("uniform", C.c_int), ("min_log_height", C.c_uint * 2)]
 
 
 class _KernelStat(C.Structure):
@@ -228,6 +229,11 @@ def load_library():
         "zkhip_recursion_air": (C.c_int, [vp, sz, C.POINTER(_Air)]),
         "zkhip_recursion_witness": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(C.POINTER(u32p)), sz, u32p]),
         "zkhip_recursion_wires": (C.c_int, [vp, u32p, sz, C.POINTER(sz)]),
+        "zkhip_recursion_fork": (C.c_int, [vp, C.POINTER(vp)]),
+        "zkhip_recursion_pad": (C.c_int, [vp, C.POINTER(C.c_uint)]),
+        "zkhip_recursion_key_commit": (C.c_int, [u32p, sz, u32p]),
+        "zkhip_recursion_witness_uniform": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(C.POINTER(u32p)), u32p,
+                                                       C.POINTER(C.c_int), u32p, u32p, sz, u32p]),
         "zkhip_recursion_tracegen": (C.c_int, [vp, vp, vp, vp, vp]),
         "zkhip_profile_enable": (C.c_int, [vp, C.c_int]),
         "zkhip_profile_read": (C.c_int, [vp, C.POINTER(_KernelStat), sz]),
@@ -1187,20 +1193,42 @@ def sha256_compress_host(state, block):
     return st
 
 
+def key_commit(prep_commits):
+    """zkhip_recursion_key_commit: the digest of a node key's preprocessed commitments (list of 8-word arrays)."""
+    pc = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32).reshape(-1) for x in prep_commits]), dtype=np.uint32)
+    out = np.zeros(8, dtype=np.uint32)
+    rc = load_library().zkhip_recursion_key_commit(_u32p(pc), pc.size // 8, _u32p(out))
+    if rc != 0:
+        raise ZkhipError("zkhip_recursion_key_commit returned %d" % rc)
+    return out
+
+
 class RecursionCircuit:
     """zkhip_recursion: the verifier circuit of an aggregation node for ONE child verifying key (params + verifying AIRs with
     heights and preprocessed commitments) and up to `max_children` child proofs.  Building it and running the witness need no
-    GPU.  stmt: None (no chained state), "node" (the children are node proofs) or dict(start=[(air, idx)..], end=[(air, idx)..])."""
+    GPU.  stmt: None (no chained state), "node" (the children are node proofs of the level below, per-depth keys), "uniform" (ONE key:
+    the children are proofs of the leaf circuit or of this very circuit, their preprocessed commitments are values: witness_uniform) or
+    dict(start=[(air, idx)..], end=[(air, idx)..]); uniform=True on a leaf circuit appends the [leaf | internal commitment] words (zero)
+    to its public values; min_log_height = (gate chip, Poseidon2 chip) pads."""
 
-    def __init__(self, params, child_airs, max_children, stmt=None):
+    def __init__(self, params, child_airs, max_children, stmt=None, uniform=False, min_log_height=(0, 0), _fork_of=None):
         self.lib = load_library()
         self.params, self.child_airs = tuple(params), child_airs
+        if _fork_of is not None:
+            h = C.c_void_p()
+            assert self.lib.zkhip_recursion_fork(_fork_of.h, C.byref(h)) == 0
+            self._finish(h, max_children)
+            return
         prm = _Params(*self.params)
         arr, keep = _air_structs(child_airs)
         st = _RecursionStmt()
+        st.uniform = 1 if uniform else 0
+        st.min_log_height[0], st.min_log_height[1] = int(min_log_height[0]), int(min_log_height[1])
         keep2 = []
         if stmt == "node":
             st.child_is_node = 1
+        elif stmt == "uniform":
+            st.child_is_node = 2
         elif stmt:
             cols = [np.ascontiguousarray([x[k] for x in stmt[side]], dtype=np.uint32) for side in ("start", "end") for k in (0, 1)]
             keep2 = cols
@@ -1210,6 +1238,9 @@ class RecursionCircuit:
         rc = self.lib.zkhip_recursion_build(C.byref(prm), arr, len(child_airs), max_children, C.byref(st), C.byref(h))
         if rc != 0:
             raise ZkhipError("zkhip_recursion_build returned %d: %s" % (rc, self.lib.zkhip_recursion_last_error(None).decode()))
+        self._finish(h, max_children)
+
+    def _finish(self, h, max_children):
         self.h = h
         self.max_children = max_children
         self.n_pvs = self.lib.zkhip_recursion_n_pvs(h)
@@ -1236,8 +1267,23 @@ class RecursionCircuit:
         self.lib.zkhip_recursion_child_vk_digest(self.h, _u32p(out))
         return out
 
-    def witness(self, proofs, child_pvs):
-        """proofs: list of bytes; child_pvs[c][a]: public values of AIR a of child c.  Returns (status, node public values)."""
+    def fork(self):
+        """A second user of the same circuit (shared wiring, own witness)."""
+        return RecursionCircuit(self.params, self.child_airs, self.max_children, _fork_of=self)
+
+    def pad(self, log_gate, log_p2):
+        hh = (C.c_uint * 2)(int(log_gate), int(log_p2))
+        rc = self.lib.zkhip_recursion_pad(self.h, hh)
+        if rc != 0:
+            raise ZkhipError("zkhip_recursion_pad returned %d" % rc)
+
+    def log_heights(self):
+        return [a["log_height"] for a in self.airs()]
+
+    def witness(self, proofs, child_pvs, prep_commits=None, is_leaf=None, leaf_commit=None, internal_commit=None):
+        """proofs: list of bytes; child_pvs[c][a]: public values of AIR a of child c.  Returns (status, node public values).
+        A uniform circuit also takes prep_commits[c] (the three preprocessed commitments of child c's key, 3 x 8 words), is_leaf[c] and
+        the two circuit commitments (key_commit) it states."""
         n = len(proofs)
         bufs = [np.frombuffer(p, dtype=np.uint8) for p in proofs]
         pp = (C.POINTER(C.c_uint8) * n)(*[b.ctypes.data_as(C.POINTER(C.c_uint8)) for b in bufs])
@@ -1249,6 +1295,13 @@ class RecursionCircuit:
             rows.append(C.cast(pa, C.POINTER(C.POINTER(C.c_uint32))))
         pv = (C.POINTER(C.POINTER(C.c_uint32)) * n)(*rows)
         out = np.zeros(self.n_pvs, dtype=np.uint32)
+        if prep_commits is not None:
+            pc = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32).reshape(-1) for x in prep_commits]), dtype=np.uint32)
+            kinds = (C.c_int * n)(*[1 if x else 0 for x in is_leaf])
+            lc, ic = np.ascontiguousarray(leaf_commit, dtype=np.uint32), np.ascontiguousarray(internal_commit, dtype=np.uint32)
+            assert pc.size == 24 * n and lc.size == 8 and ic.size == 8
+            rc = self.lib.zkhip_recursion_witness_uniform(self.h, pp, lens, pv, _u32p(pc), kinds, _u32p(lc), _u32p(ic), n, _u32p(out))
+            return rc, out
         rc = self.lib.zkhip_recursion_witness(self.h, pp, lens, pv, n, _u32p(out))
         return rc, out
 

@@ -24,12 +24,15 @@
 // in the same order.  `zkhip_recursion_witness` runs the same DAG on concrete proofs (this is the "execution" of the node);
 // `zkhip_recursion_tracegen` gathers the wire values into the chips' traces on the device.
 #include <string.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
 #include <array>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <new>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -49,11 +52,15 @@ constexpr uint32_t WIRE_BUS = 77;
 constexpr size_t GATE_WIDTH = 16, GATE_PREP = 18, P2W_PREP = 13;
 
 enum GateKind : uint8_t { K_INPUT, K_LIN, K_INV, K_DIV, K_ASSERT };
-enum SrcKind : uint8_t { S_NONE, S_PROOF_BASE, S_PROOF_EXT, S_PV, S_FLAG, S_HINT_BIT, S_HINT_COORD };
+enum SrcKind : uint8_t { S_NONE, S_PROOF_BASE, S_PROOF_EXT, S_PV, S_FLAG, S_HINT_BIT, S_HINT_COORD,
+                         S_PREP,     // uniform node: word b of the preprocessed commitment of AIR a of the child's verifying key
+                         S_KIND,     // uniform node: 1 = the child is a proof of the leaf circuit, 0 = of the internal circuit
+                         S_COMMIT,   // uniform node: word b of the leaf (a = 0) / internal (a = 1) circuit commitment this node states
+                         S_AUX };    // deferral node: word a of the auxiliary data handed in with the child (openings of its public values)
 
 struct Src {
     uint8_t kind = S_NONE;
-    uint32_t child = 0, a = 0, b = 0;  // PROOF_*: a = word offset; PV: a = AIR, b = index; HINT_*: a = source wire, b = bit / coordinate
+    uint32_t child = 0, a = 0, b = 0;  // PROOF_*: a = word offset; PV, PREP: a = AIR, b = index; HINT_*: a = source wire, b = bit / coordinate
 };
 
 struct Gate {
@@ -546,7 +553,9 @@ static V bit_product(Builder& b, const std::vector<V>& bits, const std::vector<u
 }
 
 // The symbolic twin of zkhip_verify (verifier.hip:218-576) for child `ci`.
-static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci) {
+// `prep_sym` (uniform node): the child's preprocessed commitments are VALUES of the circuit (8 base words per AIR, indexed by AIR)
+// instead of constants of the child verifying key -- one circuit then verifies proofs of any key with this AIR set and these heights.
+static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci, const std::vector<std::array<V, 8>>* prep_sym = nullptr) {
     const zkhip_params& prm = vk.prm;
     const unsigned bl = prm.log_blowup, lfp = prm.log_final_poly_len;
     const size_t n_airs = vk.pg.size(), n_fin = (size_t)1 << lfp;
@@ -661,7 +670,10 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci) 
             ch.observe_const(vk.log_heights[a]), ch.observe_const((uint32_t)vk.widths[a]), ch.observe_const((uint32_t)vk.n_pvs[a]);
             for (int i = 0; i < 8; i++) ch.observe(Lane{cst_base(dg[i]), -1});
             if (pg[a].prep_width)
-                for (int i = 0; i < 8; i++) ch.observe_const(vk.prep_commit[a][i]);
+                for (int i = 0; i < 8; i++) {
+                    if (prep_sym) ch.observe_base((*prep_sym)[a][i]);
+                    else ch.observe_const(vk.prep_commit[a][i]);
+                }
             for (size_t i = 0; i < vk.n_pvs[a]; i++) ch.observe_base(out.pvs[a][i]);
         }
     }
@@ -825,8 +837,12 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci) 
         for (size_t a = 0; a < n_airs; a++)
             if (pg[a].prep_width) {
                 const auto& pc = vk.prep_commit[a];
-                const std::array<V, 2> root{cst(Ext{{to_monty(pc[0]), to_monty(pc[1]), to_monty(pc[2]), to_monty(pc[3])}}),
-                                            cst(Ext{{to_monty(pc[4]), to_monty(pc[5]), to_monty(pc[6]), to_monty(pc[7])}})};
+                std::array<V, 2> root{cst(Ext{{to_monty(pc[0]), to_monty(pc[1]), to_monty(pc[2]), to_monty(pc[3])}}),
+                                      cst(Ext{{to_monty(pc[4]), to_monty(pc[5]), to_monty(pc[6]), to_monty(pc[7])}})};
+                if (prep_sym) {
+                    const std::array<V, 8>& ps = (*prep_sym)[a];
+                    root = {b.pack({ps[0], ps[1], ps[2], ps[3]}), b.pack({ps[4], ps[5], ps[6], ps[7]})};
+                }
                 add_batch(cm_prep0 + k++, 1, root);
             }
     }
@@ -984,24 +1000,68 @@ using namespace zk;
 using namespace zk::rec;
 
 // ---- the node circuit: C ABI object -------------------------------------------------------------------------------------
-struct zkhip_recursion {
+// What is fixed when the circuit is built (shared by every fork: zkhip_recursion_fork) ...
+struct RecCore {
     ChildVk vk;
     StmtSpec spec;
+    int mode = 0;          // 0 = leaf (children: proofs of a fixed key), 1 = node of the level below (per-depth keys), 2 = uniform node (one key)
+    bool uniform = false;  // public values end with [leaf commitment (8) | internal commitment (8)]
     size_t max_children = 0, n_state = 0;
     Circuit c;
-    size_t child_proof_words = 0;
+    size_t child_proof_words = 0, n_aux = 0;
     // the three chips
     std::vector<uint32_t> prog[3], prep[3];
     unsigned log_height[3] = {0, 0, 0};
     size_t width[3] = {GATE_WIDTH, ZKHIP_POSEIDON2_AIR_WIDTH, 1}, prep_width[3] = {GATE_PREP, P2W_PREP, 0};
-    // witness of the last zkhip_recursion_witness call
-    std::vector<Ext> vals;
+    // device copies of the wiring (ids per slot) for the trace generators, one pair per device, shared by the forks
+    std::mutex dev_mu;
+    std::map<int, std::pair<uint32_t*, uint32_t*>> dev_ids;
+    ~RecCore() {
+        for (auto& kv : dev_ids) {
+            if (kv.second.first) (void)hipFree(kv.second.first);
+            if (kv.second.second) (void)hipFree(kv.second.second);
+        }
+    }
+};
+
+// The wire values of one run: a mapping of its own (never the shared heap), so that page-locking it for the copy to the device
+// (hipHostRegister, once, in zkhip_recursion_tracegen) locks exactly these pages and nothing the allocator may hand out or give back
+// while they are registered.  (Round 3 registered the storage of a std::vector in place)
+struct WireBuf {
+    Ext* p = nullptr;
+    size_t n = 0, bytes = 0;
+    bool registered = false;
+    void reset(size_t n_values) {
+        release();
+        const size_t page = 1 << 21;
+        bytes = (n_values * sizeof(Ext) + page - 1) / page * page;
+        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) throw std::bad_alloc();
+        p = (Ext*)m, n = n_values;   // (anonymous pages are zero)
+    }
+    void release() {
+        if (!p) return;
+        if (registered) (void)hipHostUnregister(p), registered = false;
+        munmap(p, bytes);
+        p = nullptr, n = 0, bytes = 0;
+    }
+    size_t size() const { return n; }
+    Ext& operator[](size_t i) { return p[i]; }
+    const Ext& operator[](size_t i) const { return p[i]; }
+    ~WireBuf() { release(); }
+    WireBuf() = default;
+    WireBuf(const WireBuf&) = delete;
+    WireBuf& operator=(const WireBuf&) = delete;
+};
+
+// ... and the state of one user of it: the witness of the last zkhip_recursion_witness call and its device buffers
+struct zkhip_recursion {
+    std::shared_ptr<RecCore> k;
+    WireBuf vals;
     std::vector<uint32_t> node_pvs;
     std::string error;
-    // device copies of the wiring (ids per slot) for the trace generators
     int dev_ready_device = -1;
-    uint32_t *d_gate_ids = nullptr, *d_perm_ids = nullptr, *d_wires = nullptr, *d_p2_inputs = nullptr;
-    void* pinned_vals = nullptr;   // vals.data() while it is registered as page-locked memory (42 MB of wire values cross PCIe per node)
+    uint32_t *d_wires = nullptr, *d_p2_inputs = nullptr;
 };
 
 namespace {
@@ -1015,9 +1075,10 @@ int upload(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return ZKHIP_OK;
 }
 
-void build_programs(zkhip_recursion* R) {
+// the chips' programs and preprocessed traces; `min_log` pads the gate / Poseidon2 chip (leaf and internal circuits of ONE key share heights)
+void build_programs(RecCore& K, const unsigned min_log[2]) {
     using namespace zkhip::air;
-    Circuit& c = R->c;
+    Circuit& c = K.c;
     // gate chip
     {
         AirBuilder b(GATE_WIDTH, 0, GATE_PREP);
@@ -1033,7 +1094,7 @@ void build_programs(zkhip_recursion* R) {
             for (int k = 1; k < 4; k++) b.assert_zero(qbase * b.var(4 * s + k));
         for (int s = 0; s < 4; s++)
             b.push_interaction(WIRE_BUS, {b.prep(s), b.var(4 * s), b.var(4 * s + 1), b.var(4 * s + 2), b.var(4 * s + 3)}, b.prep(4 + s), Kind::Send);
-        R->prog[0] = b.program();
+        K.prog[0] = b.program();
     }
     // Poseidon2 chip with wire interactions
     {
@@ -1045,19 +1106,19 @@ void build_programs(zkhip_recursion* R) {
         for (int j = 0; j < 4; j++)
             b.push_interaction(WIRE_BUS, {b.prep(4 + j), b.var(o0 + 4 * j), b.var(o0 + 4 * j + 1), b.var(o0 + 4 * j + 2), b.var(o0 + 4 * j + 3)},
                                b.prep(8 + j), Kind::Send);
-        R->prog[1] = b.program();
+        K.prog[1] = b.program();
     }
     // public-value chip: one row, one (constant) wire id per group of four public values
     {
         const size_t groups = c.pv_wires.size();
         AirBuilder b(1, c.n_pvs, groups);
-        R->prep_width[2] = groups;
+        K.prep_width[2] = groups;
         for (size_t g = 0; g < groups; g++) {
             std::vector<Expr> f{b.prep(g)};
             for (size_t k = 0; k < 4; k++) f.push_back(4 * g + k < c.n_pvs ? b.pub(4 * g + k) : b.constant(0));
             b.push_interaction(WIRE_BUS, f, b.constant(1), Kind::Receive);
         }
-        R->prog[2] = b.program();
+        K.prog[2] = b.program();
     }
     // preprocessed traces (canonical, column-major)
     auto ceil_log = [](size_t n) {
@@ -1065,12 +1126,12 @@ void build_programs(zkhip_recursion* R) {
         while (((size_t)1 << l) < n) l++;
         return l;
     };
-    R->log_height[0] = ceil_log(std::max<size_t>(c.gates.size(), 2));
-    R->log_height[1] = ceil_log(std::max<size_t>(c.perms.size(), 2));
-    R->log_height[2] = 0;
+    K.log_height[0] = std::max(ceil_log(std::max<size_t>(c.gates.size(), 2)), min_log ? min_log[0] : 0u);
+    K.log_height[1] = std::max(ceil_log(std::max<size_t>(c.perms.size(), 2)), min_log ? min_log[1] : 0u);
+    K.log_height[2] = 0;
     {
-        const size_t N = (size_t)1 << R->log_height[0];
-        auto& pr = R->prep[0];
+        const size_t N = (size_t)1 << K.log_height[0];
+        auto& pr = K.prep[0];
         pr.assign(GATE_PREP * N, 0);
         for (size_t g = 0; g < c.gates.size(); g++) {
             const Gate& G = c.gates[g];
@@ -1085,8 +1146,8 @@ void build_programs(zkhip_recursion* R) {
         }
     }
     {
-        const size_t N = (size_t)1 << R->log_height[1];
-        auto& pr = R->prep[1];
+        const size_t N = (size_t)1 << K.log_height[1];
+        auto& pr = K.prep[1];
         pr.assign(P2W_PREP * N, 0);
         for (size_t i = 0; i < c.perms.size(); i++) {
             for (int j = 0; j < 4; j++) {
@@ -1097,7 +1158,7 @@ void build_programs(zkhip_recursion* R) {
             pr[12 * N + i] = 1;
         }
     }
-    R->prep[2].assign(c.pv_wires.begin(), c.pv_wires.end());
+    K.prep[2].assign(c.pv_wires.begin(), c.pv_wires.end());
 }
 
 }  // namespace
@@ -1111,8 +1172,13 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
     if (prm->log_final_poly_len > ZKHIP_MAX_LOG_FINAL_POLY || prm->log_blowup < 1 || prm->log_blowup > 4 || prm->num_queries == 0 ||
         prm->commit_pow_bits > 30 || prm->query_pow_bits > 30)
         return ZKHIP_ERR_INVALID;
+    if (stmt->child_is_node < 0 || stmt->child_is_node > 2) return ZKHIP_ERR_INVALID;
     std::unique_ptr<zkhip_recursion> R(new zkhip_recursion());
-    ChildVk& vk = R->vk;
+    R->k.reset(new RecCore());
+    RecCore& K = *R->k;
+    K.mode = stmt->child_is_node;
+    K.uniform = K.mode == 2 || (K.mode == 0 && stmt->uniform);
+    ChildVk& vk = K.vk;
     vk.prm = *prm;
     vk.programs.resize(n_airs), vk.pg.resize(n_airs), vk.prep_commit.resize(n_airs), vk.has_prep.assign(n_airs, 0);
     for (size_t a = 0; a < n_airs; a++) {
@@ -1124,7 +1190,9 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
         if (vk.pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height + prm->log_blowup > 27 || airs[a].log_height < prm->log_final_poly_len) return ZKHIP_ERR_INVALID;
         if (vk.pg[a].log_qd() > prm->log_blowup) return ZKHIP_ERR_CONSTRAINT;
         vk.log_heights.push_back(airs[a].log_height), vk.widths.push_back(airs[a].width), vk.n_pvs.push_back(airs[a].n_pvs);
-        if (vk.pg[a].prep_width) {
+        if (vk.pg[a].prep_width && K.mode == 2) {
+            vk.has_prep[a] = 1;   // (the commitments are values of the circuit, not part of the key it is built for)
+        } else if (vk.pg[a].prep_width) {
             if (!airs[a].prep_commit) return ZKHIP_ERR_INVALID;
             for (int k = 0; k < 8; k++) {
                 if (airs[a].prep_commit[k] >= P) return ZKHIP_ERR_INVALID;
@@ -1144,27 +1212,29 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
             p2_hash_slice(pm.data(), pm.size(), dg);
             pre.push_back(vk.log_heights[a]), pre.push_back((uint32_t)vk.widths[a]), pre.push_back((uint32_t)vk.n_pvs[a]);
             for (int i = 0; i < 8; i++) pre.push_back(from_monty(dg[i]));
-            if (vk.has_prep[a])
+            if (vk.has_prep[a] && K.mode != 2)
                 for (int i = 0; i < 8; i++) pre.push_back(vk.prep_commit[a][i]);
         }
         for (auto& w : pre) w = to_monty(w);
         p2_hash_slice(pre.data(), pre.size(), vk.digest);
     }
     // statement layout
-    StmtSpec& sp = R->spec;
+    StmtSpec& sp = K.spec;
     sp.child_is_node = stmt->child_is_node != 0;
     if (sp.child_is_node) {
-        // the child is a node circuit: its last AIR is the public-value chip with [vk(8) start(K) end(K) acc(8)]
-        const size_t np = vk.n_pvs[n_airs - 1];
-        if (np < 16 || (np - 16) % 2) return ZKHIP_ERR_INVALID;
-        R->n_state = (np - 16) / 2;
-        for (size_t k = 0; k < R->n_state; k++) {
+        // the child is a node circuit: its last AIR is the public-value chip with [vk(8) start(K) end(K) acc(8)] (+ [leaf commitment (8) |
+        // internal commitment (8)] under one key)
+        const size_t np = vk.n_pvs[n_airs - 1], fixed = K.mode == 2 ? 32 : 16;
+        if (np < fixed || (np - fixed) % 2) return ZKHIP_ERR_INVALID;
+        if (K.mode == 2 && n_airs != 3) return ZKHIP_ERR_INVALID;
+        K.n_state = (np - fixed) / 2;
+        for (size_t k = 0; k < K.n_state; k++) {
             sp.start.push_back({(uint32_t)n_airs - 1, (uint32_t)(8 + k)});
-            sp.end.push_back({(uint32_t)n_airs - 1, (uint32_t)(8 + R->n_state + k)});
+            sp.end.push_back({(uint32_t)n_airs - 1, (uint32_t)(8 + K.n_state + k)});
         }
     } else {
         if (stmt->n_state > 16 || (stmt->n_state && (!stmt->start_air || !stmt->start_idx || !stmt->end_air || !stmt->end_idx))) return ZKHIP_ERR_INVALID;
-        R->n_state = stmt->n_state;
+        K.n_state = stmt->n_state;
         for (size_t k = 0; k < stmt->n_state; k++) {
             if (stmt->start_air[k] >= n_airs || stmt->start_idx[k] >= vk.n_pvs[stmt->start_air[k]] || stmt->end_air[k] >= n_airs ||
                 stmt->end_idx[k] >= vk.n_pvs[stmt->end_air[k]])
@@ -1173,12 +1243,12 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
             sp.end.push_back({stmt->end_air[k], stmt->end_idx[k]});
         }
     }
-    R->max_children = max_children;
+    K.max_children = max_children;
     {
         std::vector<zkhip_air> za(airs, airs + n_airs);
         zkhip_proof_layout lay;
         if (zkhip_proof_layout_of(prm, za.data(), n_airs, &lay) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
-        R->child_proof_words = vk.proof_words = lay.n_words;
+        K.child_proof_words = vk.proof_words = lay.n_words;
         unsigned hmax = 0;
         bool lu = false, prep = false, cached = false;
         for (size_t a = 0; a < n_airs; a++) {
@@ -1190,12 +1260,23 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
     }
     try {
         Builder b;
-        const size_t K = R->n_state;
+        const size_t NS = K.n_state;
         std::vector<ChildValues> kids;
+        std::vector<std::vector<std::array<V, 8>>> prep_in(max_children);   // uniform node: the children's preprocessed commitments
         for (size_t ci = 0; ci < max_children; ci++) {
             b.close_input_rows();
             b.c.sections.push_back(b.c.order.size());
-            kids.push_back(verify_child_sym(b, vk, (uint32_t)ci));
+            if (K.mode == 2) {
+                prep_in[ci].resize(n_airs);
+                for (size_t a = 0; a < n_airs; a++)
+                    if (vk.has_prep[a])
+                        for (uint32_t k = 0; k < 8; k++) {
+                            Src sr;
+                            sr.kind = S_PREP, sr.child = (uint32_t)ci, sr.a = (uint32_t)a, sr.b = k;
+                            prep_in[ci][a][k] = b.in_base(sr);
+                        }
+            }
+            kids.push_back(verify_child_sym(b, vk, (uint32_t)ci, K.mode == 2 ? &prep_in[ci] : nullptr));
         }
         b.close_input_rows();
         b.c.sections.push_back(b.c.order.size());
@@ -1220,11 +1301,46 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
             for (size_t ci = 1; ci < max_children; ci++)
                 for (int k = 0; k < 8; k++) b.assert_product_zero(flag[ci], b.sub(kids[ci].pvs[pa][k], vkd[k]));
         }
+        // one key: every child is a proof of the leaf circuit or of the internal circuit -- the digest of ITS preprocessed commitments
+        // equals the leaf / internal commitment this node states, and an internal child states the same pair (by induction every
+        // node below is under one of the two; the verifier holds the pair)
+        std::array<V, 8> leaf_commit, internal_commit;
+        for (int k = 0; k < 8; k++) leaf_commit[k] = internal_commit[k] = cst(ext_zero());
+        if (K.mode == 2) {
+            for (uint32_t which = 0; which < 2; which++)
+                for (uint32_t k = 0; k < 8; k++) {
+                    Src sr;
+                    sr.kind = S_COMMIT, sr.a = which, sr.b = k;
+                    (which ? internal_commit : leaf_commit)[k] = b.in_base(sr);
+                }
+            const std::array<V, 2> lc{b.pack({leaf_commit[0], leaf_commit[1], leaf_commit[2], leaf_commit[3]}),
+                                      b.pack({leaf_commit[4], leaf_commit[5], leaf_commit[6], leaf_commit[7]})};
+            const std::array<V, 2> ic{b.pack({internal_commit[0], internal_commit[1], internal_commit[2], internal_commit[3]}),
+                                      b.pack({internal_commit[4], internal_commit[5], internal_commit[6], internal_commit[7]})};
+            const size_t pa = n_airs - 1, o = 16 + 2 * NS;
+            for (size_t ci = 0; ci < max_children; ci++) {   // (an absent slot repeats child 0, commitments and kind included)
+                Src sr;
+                sr.kind = S_KIND, sr.child = (uint32_t)ci;
+                const V is_leaf = b.in_base(sr);
+                b.assert_bool(is_leaf);
+                std::vector<Lane> lanes;
+                for (size_t a = 0; a < n_airs; a++)
+                    if (vk.has_prep[a])
+                        for (int k = 0; k < 8; k++) lanes.push_back(Lane{prep_in[ci][a][k], -1});
+                const std::array<V, 2> d = b.sponge(lanes);
+                for (int k = 0; k < 2; k++) b.assert_eq(d[k], b.select(is_leaf, lc[k], ic[k]));
+                const V is_node = b.lin(0, is_leaf, V{}, b.NEG1, 0, V{}, 0, ext_one());
+                for (int k = 0; k < 8; k++) {
+                    b.assert_product_zero(is_node, b.sub(kids[ci].pvs[pa][o + k], leaf_commit[k]));
+                    b.assert_product_zero(is_node, b.sub(kids[ci].pvs[pa][o + 8 + k], internal_commit[k]));
+                }
+            }
+        }
         // chained state
-        std::vector<V> start(K), end(K);
-        for (size_t k = 0; k < K; k++) start[k] = pv_of(0, sp.start[k]), end[k] = pv_of(0, sp.end[k]);
+        std::vector<V> start(NS), end(NS);
+        for (size_t k = 0; k < NS; k++) start[k] = pv_of(0, sp.start[k]), end[k] = pv_of(0, sp.end[k]);
         for (size_t ci = 1; ci < max_children; ci++)
-            for (size_t k = 0; k < K; k++) {
+            for (size_t k = 0; k < NS; k++) {
                 b.assert_product_zero(flag[ci], b.sub(pv_of(ci, sp.start[k]), end[k]));
                 end[k] = b.select(flag[ci], pv_of(ci, sp.end[k]), end[k]);
             }
@@ -1238,7 +1354,7 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
                     for (const V& v : kids[ci].pvs[a]) lanes.push_back(Lane{v, -1});
                 h = b.sponge(lanes);
             } else {
-                const size_t pa = n_airs - 1, o = 8 + 2 * K;
+                const size_t pa = n_airs - 1, o = 8 + 2 * NS;
                 Lane l[8];
                 for (int k = 0; k < 8; k++) l[k] = Lane{kids[ci].pvs[pa][o + k], -1};
                 h = {b.pack_lanes(l), b.pack_lanes(l + 4)};
@@ -1246,12 +1362,17 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
             const std::array<V, 2> nx = b.compress(acc, h);
             for (int k = 0; k < 2; k++) acc[k] = b.select(flag[ci], nx[k], acc[k]);
         }
-        // public values of the node: [vk(8) start(K) end(K) acc(8)], bound four at a time
+        // public values of the node: [vk(8) start(K) end(K) acc(8)] (+ [leaf commitment (8) | internal commitment (8)] under one key: zero
+        // at a leaf, whose proofs must have the public-value layout of the internal circuit's), bound four at a time
         std::vector<Lane> pvl;
         for (int k = 0; k < 8; k++) pvl.push_back(Lane{vkd[k], -1});
-        for (size_t k = 0; k < K; k++) pvl.push_back(Lane{start[k], -1});
-        for (size_t k = 0; k < K; k++) pvl.push_back(Lane{end[k], -1});
+        for (size_t k = 0; k < NS; k++) pvl.push_back(Lane{start[k], -1});
+        for (size_t k = 0; k < NS; k++) pvl.push_back(Lane{end[k], -1});
         Builder::ext_lanes(acc[0], &pvl), Builder::ext_lanes(acc[1], &pvl);
+        if (K.uniform) {
+            for (int k = 0; k < 8; k++) pvl.push_back(Lane{leaf_commit[k], -1});
+            for (int k = 0; k < 8; k++) pvl.push_back(Lane{internal_commit[k], -1});
+        }
         b.c.n_pvs = pvl.size();
         while (pvl.size() % 4) pvl.push_back(Lane{cst(ext_zero()), -1});
         for (size_t g = 0; g < pvl.size(); g += 4) b.c.pv_wires.push_back(b.use(b.pack_lanes(&pvl[g])));
@@ -1300,49 +1421,87 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
                 }
             c.query_parallel = ok && !getenv("ZKHIP_RECURSION_SERIAL_QUERIES");
         }
-        R->c = std::move(b.c);
+        K.c = std::move(b.c);
     } catch (const BuildError& e) {
         g_build_error = e.msg;
         return ZKHIP_ERR_INVALID;
     }
-    build_programs(R.get());
+    build_programs(K, stmt->min_log_height);
     *out = R.release();
     return ZKHIP_OK;
 }
 
 void zkhip_recursion_destroy(zkhip_recursion* R) {
     if (!R) return;
-    for (uint32_t* p : {R->d_gate_ids, R->d_perm_ids, R->d_wires, R->d_p2_inputs})
+    for (uint32_t* p : {R->d_wires, R->d_p2_inputs})
         if (p) (void)hipFree(p);
-    if (R->pinned_vals) (void)hipHostUnregister(R->pinned_vals);
-    delete R;
+    delete R;   // (the wire buffer unregisters and unmaps itself; the shared part goes with its last user)
+}
+
+// A second user of the same circuit: the wiring, programs and preprocessed traces are shared (read-only), the witness and its device
+// buffers are the fork's own -- the levels of an aggregation tree above the leaves all run ONE internal circuit, side by side.
+int zkhip_recursion_fork(const zkhip_recursion* R, zkhip_recursion** out) {
+    if (!R || !out) return ZKHIP_ERR_INVALID;
+    zkhip_recursion* F = new zkhip_recursion();
+    F->k = R->k;
+    *out = F;
+    return ZKHIP_OK;
+}
+
+// Lays the preprocessed traces out again at heights of at least 2^log_height[0] (gate chip) / 2^log_height[1] (Poseidon2 chip): the
+// leaf and the internal circuit of one aggregation key share one height set.  Not while a fork is in use.
+int zkhip_recursion_pad(zkhip_recursion* R, const unsigned log_height[2]) {
+    if (!R || !log_height || log_height[0] > 27 || log_height[1] > 27) return ZKHIP_ERR_INVALID;
+    if (R->k.use_count() != 1) return ZKHIP_ERR_INVALID;
+    RecCore& K = *R->k;
+    if (log_height[0] < K.log_height[0] || log_height[1] < K.log_height[1]) return ZKHIP_ERR_INVALID;
+    build_programs(K, log_height);
+    return ZKHIP_OK;
 }
 
 size_t zkhip_recursion_n_airs(const zkhip_recursion* R) { return R ? 3 : 0; }
-size_t zkhip_recursion_n_pvs(const zkhip_recursion* R) { return R ? R->c.n_pvs : 0; }
-size_t zkhip_recursion_n_state(const zkhip_recursion* R) { return R ? R->n_state : 0; }
-size_t zkhip_recursion_max_children(const zkhip_recursion* R) { return R ? R->max_children : 0; }
-size_t zkhip_recursion_child_proof_bytes(const zkhip_recursion* R) { return R ? 4 * R->child_proof_words : 0; }
+size_t zkhip_recursion_n_pvs(const zkhip_recursion* R) { return R ? R->k->c.n_pvs : 0; }
+size_t zkhip_recursion_n_state(const zkhip_recursion* R) { return R ? R->k->n_state : 0; }
+size_t zkhip_recursion_max_children(const zkhip_recursion* R) { return R ? R->k->max_children : 0; }
+size_t zkhip_recursion_child_proof_bytes(const zkhip_recursion* R) { return R ? 4 * R->k->child_proof_words : 0; }
 
 int zkhip_recursion_stats(const zkhip_recursion* R, size_t out[4]) {
     if (!R || !out) return ZKHIP_ERR_INVALID;
-    out[0] = R->c.n_wires, out[1] = R->c.gates.size(), out[2] = R->c.perms.size(), out[3] = R->c.n_pvs;
+    const RecCore& K = *R->k;
+    out[0] = K.c.n_wires, out[1] = K.c.gates.size(), out[2] = K.c.perms.size(), out[3] = K.c.n_pvs;
+    return ZKHIP_OK;
+}
+
+// digest of a node key's preprocessed commitments (n_commits x 8 canonical words): what a uniform node states as its leaf / internal
+// circuit commitment -- the sponge the circuit computes over its child's commitments
+int zkhip_recursion_key_commit(const uint32_t* prep_commits, size_t n_commits, uint32_t out[8]) {
+    if (!prep_commits || !out || n_commits == 0 || n_commits > 64) return ZKHIP_ERR_INVALID;
+    std::vector<uint32_t> w(8 * n_commits);
+    for (size_t i = 0; i < w.size(); i++) {
+        if (prep_commits[i] >= P) return ZKHIP_ERR_INVALID;
+        w[i] = to_monty(prep_commits[i]);
+    }
+    uint32_t dg[8];
+    p2_hash_slice(w.data(), w.size(), dg);
+    for (int k = 0; k < 8; k++) out[k] = from_monty(dg[k]);
     return ZKHIP_OK;
 }
 
 int zkhip_recursion_air(const zkhip_recursion* R, size_t i, zkhip_air* out) {
     if (!R || !out || i >= 3) return ZKHIP_ERR_INVALID;
-    out->program = R->prog[i].data(), out->program_len = R->prog[i].size();
-    out->log_height = R->log_height[i], out->width = R->width[i];
-    out->n_pvs = i == 2 ? R->c.n_pvs : 0;
-    out->prep_trace = R->prep[i].data();
+    const RecCore& K = *R->k;
+    out->program = K.prog[i].data(), out->program_len = K.prog[i].size();
+    out->log_height = K.log_height[i], out->width = K.width[i];
+    out->n_pvs = i == 2 ? K.c.n_pvs : 0;
+    out->prep_trace = K.prep[i].data();
     out->prep_commit = nullptr;
     return ZKHIP_OK;
 }
 
 int zkhip_recursion_child_vk_digest(const zkhip_recursion* R, uint32_t out[8]) {
     if (!R || !out) return ZKHIP_ERR_INVALID;
-    for (int k = 0; k < 8; k++) out[k] = from_monty(R->vk.digest[k]);
+    const RecCore& K = *R->k;
+    for (int k = 0; k < 8; k++) out[k] = from_monty(K.vk.digest[k]);
     return ZKHIP_OK;
 }
 
@@ -1352,39 +1511,72 @@ const char* zkhip_recursion_last_error(const zkhip_recursion* R) { return R ? R-
 // child 0, whose verification is repeated but does not enter the statement).  Returns ZKHIP_ERR_VERIFY when an assertion of
 // the circuit fails -- the wire values are kept either way, so that a test can show that a proof of the resulting traces
 // does not verify.
-int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const size_t* proof_lens, const uint32_t* const* const* child_pvs,
-                            size_t n_present, uint32_t* node_pvs_out) {
-    if (!R || !proofs || !proof_lens || n_present == 0 || n_present > R->max_children) return ZKHIP_ERR_INVALID;
-    const Circuit& c = R->c;
-    const size_t n_airs = R->vk.pg.size();
-    std::vector<const uint32_t*> pw(R->max_children);
-    for (size_t ci = 0; ci < R->max_children; ci++) {
+}  // extern "C"
+
+namespace {
+// what a uniform node is told about its children beside their proofs
+struct UniformIn {
+    const uint32_t* prep_commits;   // [child][AIR with a preprocessed trace][8], canonical
+    const int* is_leaf;             // [child]
+    const uint32_t *leaf_commit, *internal_commit;
+};
+int recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const size_t* proof_lens, const uint32_t* const* const* child_pvs,
+                      size_t n_present, uint32_t* node_pvs_out, const UniformIn* uni) {
+    if (!R || !proofs || !proof_lens || n_present == 0 || n_present > R->k->max_children) return ZKHIP_ERR_INVALID;
+    const RecCore& K = *R->k;
+    if ((K.mode == 2) != (uni != nullptr)) {
+        R->error = K.mode == 2 ? "a uniform node circuit takes its children's commitments and kinds (zkhip_recursion_witness_uniform)"
+                               : "this circuit is built for one child verifying key (zkhip_recursion_witness)";
+        return ZKHIP_ERR_INVALID;
+    }
+    size_t n_prep_airs = 0;
+    std::vector<size_t> prep_slot(K.vk.pg.size(), 0);
+    for (size_t a = 0; a < K.vk.pg.size(); a++)
+        if (K.vk.has_prep[a]) prep_slot[a] = n_prep_airs++;
+    if (uni) {
+        if (!uni->prep_commits || !uni->is_leaf || !uni->leaf_commit || !uni->internal_commit) return ZKHIP_ERR_INVALID;
+        for (size_t i = 0; i < 8 * n_prep_airs * n_present; i++)
+            if (uni->prep_commits[i] >= P) return ZKHIP_ERR_INVALID;
+        for (int k = 0; k < 8; k++)
+            if (uni->leaf_commit[k] >= P || uni->internal_commit[k] >= P) return ZKHIP_ERR_INVALID;
+    }
+    const Circuit& c = K.c;
+    const size_t n_airs = K.vk.pg.size();
+    std::vector<const uint32_t*> pw(K.max_children);
+    for (size_t ci = 0; ci < K.max_children; ci++) {
         const size_t src = ci < n_present ? ci : 0;
-        if (!proofs[src] || proof_lens[src] != 4 * R->child_proof_words) {
+        if (!proofs[src] || proof_lens[src] != 4 * K.child_proof_words) {
             R->error = "child proof " + std::to_string(src) + " has the wrong size for this circuit's child verifying key";
             return ZKHIP_ERR_INVALID;
         }
         pw[ci] = reinterpret_cast<const uint32_t*>(proofs[src]);
         for (size_t a = 0; a < n_airs; a++)
-            if (R->vk.n_pvs[a] && (!child_pvs || !child_pvs[src] || !child_pvs[src][a])) return ZKHIP_ERR_INVALID;
+            if (K.vk.n_pvs[a] && (!child_pvs || !child_pvs[src] || !child_pvs[src][a])) return ZKHIP_ERR_INVALID;
     }
     for (size_t ci = 0; ci < n_present; ci++) {
         // the shape words are not part of the transcript: they are fixed by the child verifying key and checked here
-        if (memcmp(pw[ci], R->vk.header, 16) != 0) {
+        if (memcmp(pw[ci], K.vk.header, 16) != 0) {
             R->error = "child proof " + std::to_string(ci) + " does not have the shape of this circuit's child verifying key";
             return ZKHIP_ERR_VERIFY;
         }
-        for (size_t i = 0; i < R->child_proof_words; i++)
+        for (size_t i = 0; i < K.child_proof_words; i++)
             if (pw[ci][i] >= P) {
                 R->error = "child proof word not canonical";
                 return ZKHIP_ERR_VERIFY;
             }
         for (size_t a = 0; a < n_airs; a++)
-            for (size_t i = 0; i < R->vk.n_pvs[a]; i++)
+            for (size_t i = 0; i < K.vk.n_pvs[a]; i++)
                 if (child_pvs[ci][a][i] >= P) return ZKHIP_ERR_INVALID;
     }
-    std::vector<Ext>& vals = R->vals;
-    if (vals.size() != (size_t)c.n_wires + 1) vals.assign((size_t)c.n_wires + 1, ext_zero());   // (every wire has exactly one defining row: nothing stale survives a run)
+    WireBuf& vals = R->vals;
+    if (vals.size() != (size_t)c.n_wires + 1) {   // (every wire has exactly one defining row: nothing stale survives a run)
+        try {
+            vals.reset((size_t)c.n_wires + 1);
+        } catch (const std::bad_alloc&) {
+            R->error = "no memory for the wire values";
+            return ZKHIP_ERR_INVALID;
+        }
+    }
     auto lin_value = [&](const Gate& G) {
         Ext r = G.qK;
         const Ext &a = vals[G.w[0]], &bq = vals[G.w[1]], &d = vals[G.w[3]];
@@ -1423,6 +1615,9 @@ int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, co
                                 break;
                             case S_PV: v.c[0] = to_monty(child_pvs[sr.child < n_present ? sr.child : 0][sr.a][sr.b]); break;
                             case S_FLAG: v.c[0] = sr.child < n_present ? MONTY_ONE : 0; break;
+                            case S_PREP: v.c[0] = to_monty(uni->prep_commits[((sr.child < n_present ? sr.child : 0) * n_prep_airs + prep_slot[sr.a]) * 8 + sr.b]); break;
+                            case S_KIND: v.c[0] = uni->is_leaf[sr.child < n_present ? sr.child : 0] ? MONTY_ONE : 0; break;
+                            case S_COMMIT: v.c[0] = to_monty((sr.a ? uni->internal_commit : uni->leaf_commit)[sr.b]); break;
                             case S_HINT_BIT: v.c[0] = ((from_monty(vals[sr.a].c[0]) >> sr.b) & 1) ? MONTY_ONE : 0; break;
                             case S_HINT_COORD: v.c[0] = vals[sr.a].c[sr.b]; break;
                             default: break;
@@ -1542,6 +1737,25 @@ int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, co
     R->error.clear();
     return ZKHIP_OK;
 }
+}  // namespace
+
+extern "C" {
+
+int zkhip_recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const size_t* proof_lens, const uint32_t* const* const* child_pvs,
+                            size_t n_present, uint32_t* node_pvs_out) {
+    return recursion_witness(R, proofs, proof_lens, child_pvs, n_present, node_pvs_out, nullptr);
+}
+
+// The witness of a UNIFORM node (zkhip_recursion_stmt.child_is_node = 2): child c is a proof under the key whose preprocessed commitments
+// are child_prep_commits[c] (8 canonical words per AIR with a preprocessed trace, in AIR order), of the leaf circuit (child_is_leaf[c] != 0)
+// or of the internal circuit; leaf_commit / internal_commit = zkhip_recursion_key_commit of the two circuits' keys, which the node
+// states in its public values and requires of every node below it.
+int zkhip_recursion_witness_uniform(zkhip_recursion* R, const uint8_t* const* proofs, const size_t* proof_lens, const uint32_t* const* const* child_pvs,
+                                    const uint32_t* child_prep_commits, const int* child_is_leaf, const uint32_t leaf_commit[8],
+                                    const uint32_t internal_commit[8], size_t n_present, uint32_t* node_pvs_out) {
+    const UniformIn uni{child_prep_commits, child_is_leaf, leaf_commit, internal_commit};
+    return recursion_witness(R, proofs, proof_lens, child_pvs, n_present, node_pvs_out, &uni);
+}
 
 // wire values of the last witness call, canonical: [n_wires + 1][4] (wire 0 unused).  Host-side twin data for the oracle's
 // trace generators (tests) -- the product path keeps them inside and goes through zkhip_recursion_tracegen.
@@ -1588,48 +1802,56 @@ __global__ __launch_bounds__(256) void k_p2w_inputs(const uint32_t* __restrict__
 extern "C" int zkhip_recursion_tracegen(zkhip_ctx* ctx, zkhip_recursion* R, uint32_t* d_gate_trace, uint32_t* d_p2_trace, uint32_t* d_pv_trace) {
     ZK_BIND_DEVICE(ctx);
     if (!ctx || !R || !d_gate_trace || !d_p2_trace || !d_pv_trace) return ZKHIP_ERR_INVALID;
-    const Circuit& c = R->c;
+    RecCore& K = *R->k;
+    const Circuit& c = K.c;
     if (R->vals.size() != (size_t)c.n_wires + 1) return set_error(ctx, ZKHIP_ERR_INVALID, "recursion_tracegen: no witness (call zkhip_recursion_witness first)");
     const size_t ng = c.gates.size(), np = c.perms.size();
+    uint32_t *d_gate_ids = nullptr, *d_perm_ids = nullptr;
+    {
+        // the wiring ids of this device: uploaded by the first user, shared by the forks
+        std::lock_guard<std::mutex> lk(K.dev_mu);
+        auto it = K.dev_ids.find(ctx->device);
+        if (it == K.dev_ids.end()) {
+            ZK_HIP_CHECK(ctx, hipMalloc(&d_gate_ids, std::max<size_t>(1, 4 * ng) * 4));
+            ZK_HIP_CHECK(ctx, hipMalloc(&d_perm_ids, std::max<size_t>(1, 4 * np) * 4));
+            std::vector<uint32_t> ids(4 * ng), pids(4 * np);
+            for (size_t g = 0; g < ng; g++)
+                for (int s = 0; s < 4; s++) ids[(size_t)s * ng + g] = c.gates[g].w[s];
+            for (size_t i = 0; i < np; i++)
+                for (int j = 0; j < 4; j++) pids[(size_t)j * np + i] = c.perms[i].in[j];
+            ZK_TRY(upload(ctx, d_gate_ids, ids.data(), ids.size() * 4));
+            ZK_TRY(upload(ctx, d_perm_ids, pids.data(), pids.size() * 4));
+            it = K.dev_ids.emplace(ctx->device, std::make_pair(d_gate_ids, d_perm_ids)).first;
+        }
+        d_gate_ids = it->second.first, d_perm_ids = it->second.second;
+    }
     if (R->dev_ready_device != ctx->device) {
-        for (uint32_t** p : {&R->d_gate_ids, &R->d_perm_ids, &R->d_wires, &R->d_p2_inputs})
+        for (uint32_t** p : {&R->d_wires, &R->d_p2_inputs})
             if (*p) (void)hipFree(*p), *p = nullptr;
-        ZK_HIP_CHECK(ctx, hipMalloc(&R->d_gate_ids, std::max<size_t>(1, 4 * ng) * 4));
-        ZK_HIP_CHECK(ctx, hipMalloc(&R->d_perm_ids, std::max<size_t>(1, 4 * np) * 4));
         ZK_HIP_CHECK(ctx, hipMalloc(&R->d_wires, ((size_t)c.n_wires + 1) * 16));
         ZK_HIP_CHECK(ctx, hipMalloc(&R->d_p2_inputs, std::max<size_t>(1, np) * 64));
-        std::vector<uint32_t> ids(4 * ng), pids(4 * np);
-        for (size_t g = 0; g < ng; g++)
-            for (int s = 0; s < 4; s++) ids[(size_t)s * ng + g] = c.gates[g].w[s];
-        for (size_t i = 0; i < np; i++)
-            for (int j = 0; j < 4; j++) pids[(size_t)j * np + i] = c.perms[i].in[j];
-        ZK_TRY(upload(ctx, R->d_gate_ids, ids.data(), ids.size() * 4));
-        ZK_TRY(upload(ctx, R->d_perm_ids, pids.data(), pids.size() * 4));
         R->dev_ready_device = ctx->device;
     }
-    if (R->pinned_vals != (void*)R->vals.data()) {
-        if (R->pinned_vals) (void)hipHostUnregister(R->pinned_vals);
-        // Only a LARGE value array is page-locked in place: the allocator gives it a mapping of its own.  A small one lives in the shared
-        // heap -- locking its pages would lock its neighbours', and the heap may hand those pages back to the system while they are
-        // registered; a small array gains nothing anyway (the copy is staged).  ZKHIP_NO_PIN_WITNESS=1 never registers.
-        const bool pin = R->vals.size() * 16 >= ((size_t)4 << 20) && !getenv("ZKHIP_NO_PIN_WITNESS");
-        R->pinned_vals = pin && hipHostRegister(R->vals.data(), R->vals.size() * 16, hipHostRegisterDefault) == hipSuccess ? (void*)R->vals.data() : nullptr;
+    // The value array is a mapping of its own (WireBuf): page-locked once, for the life of the circuit's user, so that the 40 MB of a
+    // node's wire values cross PCIe without a staging copy.  ZKHIP_NO_PIN_WITNESS=1 leaves it pageable.
+    if (!R->vals.registered && !getenv("ZKHIP_NO_PIN_WITNESS")) {
+        R->vals.registered = hipHostRegister(R->vals.p, R->vals.bytes, hipHostRegisterDefault) == hipSuccess;
         (void)hipGetLastError();
     }
-    ZK_TRY(upload(ctx, R->d_wires, R->vals.data(), R->vals.size() * 16));
-    const size_t N0 = (size_t)1 << R->log_height[0];
+    ZK_TRY(upload(ctx, R->d_wires, R->vals.p, R->vals.size() * 16));
+    const size_t N0 = (size_t)1 << K.log_height[0];
     {
         KernelScope ks(ctx, "recursion_gate_trace");
-        hipLaunchKernelGGL(k_gate_trace, dim3((unsigned)((N0 + 255) / 256)), dim3(256), 0, ctx->stream, R->d_gate_ids, (const uint4*)R->d_wires, ng, N0,
+        hipLaunchKernelGGL(k_gate_trace, dim3((unsigned)((N0 + 255) / 256)), dim3(256), 0, ctx->stream, d_gate_ids, (const uint4*)R->d_wires, ng, N0,
                            d_gate_trace);
     }
     if (np) {
         KernelScope ks(ctx, "recursion_p2_inputs");
-        hipLaunchKernelGGL(k_p2w_inputs, dim3((unsigned)((4 * np + 255) / 256)), dim3(256), 0, ctx->stream, R->d_perm_ids, (const uint4*)R->d_wires, np,
+        hipLaunchKernelGGL(k_p2w_inputs, dim3((unsigned)((4 * np + 255) / 256)), dim3(256), 0, ctx->stream, d_perm_ids, (const uint4*)R->d_wires, np,
                            (uint4*)R->d_p2_inputs);
     }
     ZK_HIP_CHECK(ctx, hipGetLastError());
-    ZK_TRY(poseidon2_air_tracegen(ctx, R->d_p2_inputs, np, R->log_height[1], d_p2_trace));
+    ZK_TRY(poseidon2_air_tracegen(ctx, R->d_p2_inputs, np, K.log_height[1], d_p2_trace));
     ZK_HIP_CHECK(ctx, hipMemsetAsync(d_pv_trace, 0, 4, ctx->stream));
     return ZKHIP_OK;
 }
