@@ -5,12 +5,15 @@
 //   crates/prover/src/prover/mod.rs:200-282  `commit_child_vk` -> VerifyProver: a node proves "my children verify under the child vk"
 //   crates/integration/src/lib.rs:461-514    the data handed from one level to the next
 //
-// Here a node circuit is built for ONE child verifying key (zkhip_recursion_build) and its whole wiring is preprocessed, so
-// the chain of commitments is: app vk -> leaf circuit (verifies <= 4 segment proofs) -> internal circuit of level 1 (verifies
-// <= 3 leaf proofs) -> internal circuit of level 2 (verifies <= 3 level-1 proofs) -> ...  The verifying key of level l is
-// (three AIR programs, three heights, three preprocessed commitments); it pins everything below it.  A node's public values are
-// [app-vk digest (8) | start state (K) | end state (K) | accumulator (8)]; the children's states are chained in-circuit.
-// Every node proof is self-verified (crates/prover/src/prover/mod.rs:407-411 does that for every proof it returns).
+// ONE AGGREGATION KEY (crates/prover/src/prover/mod.rs:147-170 caches one `agg_vk`; crates/verifier/src/verifier.rs:96-111 verifies
+// every root under it): the LEAF circuit is built for the app's verifying key (zkhip_recursion_build: its wiring is preprocessed, so
+// its commitments pin the app) and verifies <= 4 segment proofs; the INTERNAL circuit verifies <= 3 proofs of the leaf circuit OR OF
+// ITSELF -- both circuits share the AIR programs and, padded, the heights; the child's preprocessed commitments are values of the
+// internal circuit, and every node states the pair (leaf commitment, internal commitment) it requires below it.  The root of a tree
+// of any depth is a proof of the internal circuit: the aggregation key = (internal verifying key, leaf commitment, app-vk digest).
+// A node's public values are [app-vk digest (8) | start state (K) | end state (K) | accumulator (8) | leaf commitment (8) | internal
+// commitment (8)]; the children's states are chained in-circuit.  Every node proof is self-verified (mod.rs:407-411 does that for
+// every proof it returns).  AggregationTreeConfig::one_key = false keeps round 3's per-depth keys (level l hard-wires level l - 1).
 #pragma once
 #include <chrono>
 #include <condition_variable>
@@ -38,6 +41,8 @@ struct VerifyingKey {
     zkhip_params params{};
     std::vector<AirDesc> airs;      // program, width, n_pvs, prep_commit (no tables)
     std::vector<unsigned> heights;  // fixed trace heights
+    // an AGGREGATION key also pins what the root must state beneath it: the leaf circuit's commitment (-> the app) and the app-vk digest
+    std::vector<uint32_t> leaf_commit, app_digest;   // 8 words each, empty on any other key
 
     std::vector<zkhip_air> as_airs() const {
         std::vector<zkhip_air> za(airs.size());
@@ -57,14 +62,67 @@ struct VerifyingKey {
         }
         return zkhip_verify(&params, za.data(), za.size(), pv.data(), p.proof.data(), p.proof.size()) == ZKHIP_OK;
     }
-    // the app-file form (encode_app_exe, tables omitted): UniversalVerifier::setup reads it back
+    // the app-file form (encode_app_exe, tables omitted): UniversalVerifier::setup reads it back.  An aggregation key appends
+    // [AGGKEY_MAGIC | leaf commitment (8) | app-vk digest (8)] (readers of the app-file form stop before it).
+    static constexpr uint32_t AGGKEY_MAGIC = 0x4B474741u;
     std::vector<uint8_t> to_app_exe() const {
         std::vector<AirDesc> a = airs;
         for (size_t i = 0; i < a.size(); i++) {
             a[i].prep.clear();
             if (a[i].has_prep) a[i].prep_log_height = heights[i];
         }
-        return encode_app_exe(a);
+        std::vector<uint8_t> out = encode_app_exe(a);
+        if (leaf_commit.size() == 8 && app_digest.size() == 8) {
+            std::vector<uint32_t> t{AGGKEY_MAGIC};
+            t.insert(t.end(), leaf_commit.begin(), leaf_commit.end()), t.insert(t.end(), app_digest.begin(), app_digest.end());
+            const uint8_t* b = reinterpret_cast<const uint8_t*>(t.data());
+            out.insert(out.end(), b, b + 4 * t.size());
+        }
+        return out;
+    }
+    static VerifyingKey read(const std::string& path, const zkhip_params& params) {
+        VerifyingKey vk;
+        vk.params = params;
+        vk.airs = read_app_exe(path);
+        for (const auto& a : vk.airs) vk.heights.push_back(a.prep_log_height);
+        std::ifstream f(path, std::ios::binary);
+        const std::vector<uint8_t> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        const size_t used = encode_app_exe(vk.airs).size();
+        if (raw.size() == used + 4 * 17) {
+            uint32_t t[17];
+            memcpy(t, raw.data() + used, sizeof t);
+            if (t[0] == AGGKEY_MAGIC) vk.leaf_commit.assign(t + 1, t + 9), vk.app_digest.assign(t + 9, t + 17);
+        }
+        return vk;
+    }
+    bool is_aggregation_key() const { return leaf_commit.size() == 8 && app_digest.size() == 8; }
+    // digest of this key's preprocessed commitments: what a node of the tree states as its internal (or leaf) commitment
+    std::vector<uint32_t> key_commit() const {
+        std::vector<uint32_t> pc;
+        for (const auto& a : airs)
+            if (a.has_prep) {
+                if (a.prep_commit.size() != 8) throw Error(Error::Setup, "a verifying key without its preprocessed commitments");
+                pc.insert(pc.end(), a.prep_commit.begin(), a.prep_commit.end());
+            }
+        std::vector<uint32_t> out(8);
+        if (pc.empty() || zkhip_recursion_key_commit(pc.data(), pc.size() / 8, out.data()) != ZKHIP_OK) throw Error(Error::Setup, "zkhip_recursion_key_commit");
+        return out;
+    }
+    // What a ROOT under an aggregation key must state beside verifying: the internal commitment is this key's own, the leaf commitment
+    // and the app-vk digest are the key's (root public values: [app digest (8) | start (K) | end (K) | accumulator (8) | leaf (8) | internal (8)]).
+    bool root_statement_matches(const std::vector<uint32_t>& root_pvs, std::string* why = nullptr) const {
+        auto fail = [&](const char* m) {
+            if (why) *why = m;
+            return false;
+        };
+        if (!is_aggregation_key()) return fail("not an aggregation key (no leaf commitment / app digest)");
+        if (root_pvs.size() < 32) return fail("the root statement is too short for an aggregation key");
+        const size_t n = root_pvs.size();
+        if (!std::equal(app_digest.begin(), app_digest.end(), root_pvs.begin())) return fail("the root is not about this app (app verifying-key digest)");
+        if (!std::equal(leaf_commit.begin(), leaf_commit.end(), root_pvs.begin() + (n - 16))) return fail("the tree's leaves are not proofs of this key's leaf circuit");
+        const std::vector<uint32_t> ic = key_commit();
+        if (!std::equal(ic.begin(), ic.end(), root_pvs.begin() + (n - 8))) return fail("the tree's internal nodes are not proofs of this key's internal circuit");
+        return true;
     }
 };
 
@@ -89,6 +147,13 @@ struct AggregationSystemParams {
         a.internal = zkhip_params{2, 0, 44, 16, 16};
         return a;
     }
+    // under ONE key leaf and internal proofs are verified by the same circuit: one parameter set for every node (the segments keep the app's)
+    static AggregationSystemParams nodes_100_bits_security() {
+        AggregationSystemParams a;
+        a.leaf = a.internal = zkhip_params{2, 0, 44, 16, 16};
+        return a;
+    }
+    bool same() const { return memcmp(&leaf, &internal, sizeof(zkhip_params)) == 0; }
 };
 
 class AggregationProver {
@@ -106,12 +171,16 @@ public:
         p.levels_mu_.reset(new std::mutex), p.dev_mu_.reset(new std::mutex), p.build_mu_.reset(new std::mutex);
         if (app.airs.size() != app.heights.size() || app.airs.empty()) throw Error(Error::Setup, "aggregation: the app verifying key needs one height per AIR");
         if (spec.start.size() != spec.end.size()) throw Error(Error::Setup, "aggregation: start and end state must have the same length");
+        if (cfg.one_key && !p.agg_params_.same())
+            throw Error(Error::Setup, "aggregation: under one key the leaf and the internal proofs are verified by one circuit and need one parameter set "
+                                      "(AggregationTreeConfig::one_key = false keeps a key per depth)");
         return p;
     }
     AggregationProver(AggregationProver&& o) noexcept { *this = std::move(o); }
     AggregationProver& operator=(AggregationProver&& o) noexcept {
         reset();
         app_ = std::move(o.app_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, agg_params_ = o.agg_params_, device_ = o.device_, ctx_ = o.ctx_, levels_ = std::move(o.levels_), stats = o.stats;
+        leaf_commit_ = std::move(o.leaf_commit_), internal_commit_ = std::move(o.internal_commit_);
         levels_mu_ = std::move(o.levels_mu_), dev_mu_ = std::move(o.dev_mu_), build_mu_ = std::move(o.build_mu_);
         o.ctx_ = nullptr;
         return *this;
@@ -121,7 +190,7 @@ public:
         for (auto& L : levels_) {
             for (void* d : L.d_traces)
                 if (d) zkhip_free(ctx_, d);
-            if (L.pk) zkhip_pk_destroy(ctx_, L.pk);
+            if (L.pk && L.owns_pk) zkhip_pk_destroy(ctx_, L.pk);
             if (L.circ) zkhip_recursion_destroy(L.circ);
         }
         levels_.clear();
@@ -130,11 +199,20 @@ public:
 
     Stats stats;
 
-    // verifying key of the node circuit of `level` (0 = leaf): the root vk of a tree with level + 1 levels
+    // verifying key of the node circuit of `level` (0 = leaf; under one key every level above is THE internal circuit)
     const VerifyingKey& node_vk(size_t level) {
         ensure_level(level);
         return lv(level).vk;
     }
+    // the key a root of a tree with `n_levels` levels verifies under: one key = the aggregation key whatever the depth
+    const VerifyingKey& root_vk(size_t n_levels = 2) {
+        if (!cfg_.one_key) return node_vk(n_levels - 1);
+        ensure_level(1);
+        return lv(1).vk;
+    }
+    bool one_key() const { return cfg_.one_key; }
+    const AggregationTreeConfig& tree_config() const { return cfg_; }
+    size_t first_root_layer() const { return cfg_.one_key ? 2 : 1; }
     size_t arity(size_t level) const { return level == 0 ? cfg_.num_children_leaf : cfg_.num_children_internal; }
 
     // proves one node: level 0 verifies up to 4 proofs of the app, level l > 0 up to 3 proofs of level l - 1
@@ -159,7 +237,7 @@ public:
         ensure_level(level);
         Level& L = lv(level);
         if (kids.empty() || kids.size() > arity(level)) throw Error(Error::GenProof, "aggregation: a node of level " + std::to_string(level) + " takes 1.." + std::to_string(arity(level)) + " children");
-        const VerifyingKey& cvk = level == 0 ? app_ : lv(level - 1).vk;
+        const VerifyingKey& cvk = level == 0 ? app_ : lv(level - 1).vk;   // (one key: the leaf's and the internal vk differ in the commitments only)
         std::vector<const uint8_t*> proofs;
         std::vector<size_t> lens;
         std::vector<std::vector<const uint32_t*>> pv_rows(kids.size());
@@ -174,7 +252,18 @@ public:
             pv_ptrs.push_back(pv_rows[c].data());
         }
         std::vector<uint32_t> npv(zkhip_recursion_n_pvs(L.circ));
-        int rc = zkhip_recursion_witness(L.circ, proofs.data(), lens.data(), pv_ptrs.data(), kids.size(), npv.data());
+        int rc;
+        if (cfg_.one_key && level > 0) {
+            // children of level 1 are proofs of the leaf circuit, above of the internal circuit itself
+            std::vector<uint32_t> pc;
+            std::vector<int> kinds(kids.size(), level == 1 ? 1 : 0);
+            for (size_t c = 0; c < kids.size(); c++)
+                for (const auto& a : cvk.airs) pc.insert(pc.end(), a.prep_commit.begin(), a.prep_commit.end());
+            rc = zkhip_recursion_witness_uniform(L.circ, proofs.data(), lens.data(), pv_ptrs.data(), pc.data(), kinds.data(), leaf_commit_.data(),
+                                                 internal_commit_.data(), kids.size(), npv.data());
+        } else {
+            rc = zkhip_recursion_witness(L.circ, proofs.data(), lens.data(), pv_ptrs.data(), kids.size(), npv.data());
+        }
         if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_recursion_last_error(L.circ));
         return npv;
     }
@@ -218,7 +307,7 @@ public:
             size_t root_layer = 0;
             cv_.wait(lk, [&] {
                 if (!err_.empty()) return true;
-                for (size_t i = 1; i < layers_.size(); i++)
+                for (size_t i = agg_.first_root_layer(); i < layers_.size(); i++)
                     if (layers_[i].total == 1 && !layers_[i].items.empty() && layers_[i].items[0]) {
                         root_layer = i;
                         return true;
@@ -322,8 +411,8 @@ public:
                                 if (stop_ || !err_.empty()) return true;
                                 const Layer& in = layers_[level];
                                 const size_t lo = a * k, hi = in.total == SIZE_MAX ? lo + a : std::min(lo + a, in.total);
-                                if (in.total != SIZE_MAX && (lo >= in.total || (level > 0 && in.total == 1))) {
-                                    end = true;   // no further node on this level (a single item above the segments is the root)
+                                if (in.total != SIZE_MAX && (lo >= in.total || (level >= agg_.first_root_layer() && in.total == 1))) {
+                                    end = true;   // no further node on this level (a single item of a root layer is the root)
                                     return true;
                                 }
                                 if (in.items.size() < hi) return false;
@@ -332,7 +421,7 @@ public:
                                 return true;
                             });
                             if (end) {
-                                layers_[level + 1].total = (level > 0 && layers_[level].total == 1) ? 0 : k;
+                                layers_[level + 1].total = (level >= agg_.first_root_layer() && layers_[level].total == 1) ? 0 : k;
                                 cv_.notify_all();
                             }
                             if (end || stop_ || !err_.empty()) break;
@@ -457,9 +546,11 @@ private:
     struct Level {
         zkhip_recursion* circ = nullptr;
         zkhip_pk* pk = nullptr;
+        bool owns_pk = true;   // one key: the levels above the first internal one share its proving key and fork its circuit
         VerifyingKey vk;
         std::vector<void*> d_traces;
     };
+    std::vector<uint32_t> leaf_commit_, internal_commit_;   // one key: zkhip_recursion_key_commit of the two circuits' keys
     VerifyingKey app_;
     StatementSpec spec_;
     AggregationTreeConfig cfg_;
@@ -500,56 +591,156 @@ private:
         out.proof.resize(len);
         return out;
     }
+    // a circuit's three chips as the AIRs of its verifying key (no commitments yet) + the zkhip_air view the key generator takes
+    static void circuit_airs(zkhip_recursion* circ, VerifyingKey* vk, std::vector<zkhip_air>* na) {
+        na->assign(3, zkhip_air{});
+        vk->airs.clear(), vk->heights.clear();
+        for (size_t i = 0; i < 3; i++) {
+            if (zkhip_recursion_air(circ, i, &(*na)[i]) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_air");
+            AirDesc d;
+            d.width = (*na)[i].width, d.n_pvs = (*na)[i].n_pvs, d.program.assign((*na)[i].program, (*na)[i].program + (*na)[i].program_len);
+            d.has_prep = true, d.prep_log_height = (*na)[i].log_height;
+            vk->airs.push_back(std::move(d));
+            vk->heights.push_back((*na)[i].log_height);
+        }
+    }
+    // proving key + preprocessed commitments + trace buffers of a built circuit
+    void keygen_level(Level& L, std::vector<zkhip_air>& na) {
+        std::lock_guard<std::mutex> dev(*dev_mu_);
+        int rc = zkhip_keygen(ctx_, &L.vk.params, na.data(), 3, &L.pk);
+        if (rc != ZKHIP_OK) throw Error(Error::Keygen, std::string("failed to generate STARK proving key: ") + zkhip_last_error(ctx_));
+        for (size_t i = 0; i < 3; i++) {
+            uint32_t c[8];
+            check(zkhip_pk_prep_commitment(ctx_, L.pk, i, c));
+            L.vk.airs[i].prep_commit.assign(c, c + 8);
+        }
+        alloc_traces(L);
+    }
+    void alloc_traces(Level& L) {
+        for (size_t i = 0; i < 3; i++) {
+            void* d = nullptr;
+            check(zkhip_malloc(ctx_, (L.vk.airs[i].width << L.vk.heights[i]) * 4, &d));
+            L.d_traces.push_back(d);
+        }
+    }
+    void ensure_ctx() {
+        if (ctx_) return;
+        std::lock_guard<std::mutex> dev(*dev_mu_);
+        int rc = zkhip_ctx_create(device_, &ctx_);
+        if (rc != ZKHIP_OK) throw Error(Error::Keygen, "no gfx950 device for the HIP backend (zkhip_ctx_create returned " + std::to_string(rc) + ")");
+    }
+    zkhip_recursion_stmt leaf_stmt(std::vector<uint32_t> (&cols)[4]) const {
+        zkhip_recursion_stmt st{};
+        for (auto& p : spec_.start) cols[0].push_back(p.first), cols[1].push_back(p.second);
+        for (auto& p : spec_.end) cols[2].push_back(p.first), cols[3].push_back(p.second);
+        st.n_state = cols[0].size(), st.start_air = cols[0].data(), st.start_idx = cols[1].data(), st.end_air = cols[2].data(), st.end_idx = cols[3].data();
+        return st;
+    }
+    // ONE KEY: the leaf circuit (for the app's key) and the internal circuit (for the node AIR set at the common heights) are built
+    // together -- the internal circuit verifies proofs of its own height, so the common height set is a fixed point: start from the leaf
+    // circuit's natural heights, build the internal circuit for children of that height, grow until it fits; then pad both.
+    void build_one_key() {
+        using clk = std::chrono::steady_clock;
+        ensure_ctx();
+        auto t0 = clk::now();
+        Level leaf, internal;
+        std::vector<uint32_t> cols[4];
+        zkhip_recursion_stmt st = leaf_stmt(cols);
+        st.uniform = 1;
+        std::vector<zkhip_air> za = app_.as_airs();
+        int rc = zkhip_recursion_build(&app_.params, za.data(), za.size(), arity(0), &st, &leaf.circ);
+        if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the leaf verifier circuit: ") + zkhip_recursion_last_error(nullptr));
+        std::vector<zkhip_air> la, ia;
+        leaf.vk.params = agg_params_.leaf, internal.vk.params = agg_params_.internal;
+        try {
+            circuit_airs(leaf.circ, &leaf.vk, &la);
+            unsigned H[2] = {la[0].log_height, la[1].log_height};
+            for (int round = 0;; round++) {
+                if (round > 8) throw Error(Error::Setup, "aggregation: the common height of the leaf and internal circuits does not settle");
+                std::vector<zkhip_air> child = la;   // the node AIR set: programs of the leaf circuit's chips, heights H
+                child[0].log_height = H[0], child[1].log_height = H[1];
+                for (auto& c : child) c.prep_trace = nullptr, c.prep_commit = nullptr;
+                zkhip_recursion_stmt is{};
+                is.child_is_node = 2, is.min_log_height[0] = H[0], is.min_log_height[1] = H[1];
+                if (internal.circ) zkhip_recursion_destroy(internal.circ), internal.circ = nullptr;
+                rc = zkhip_recursion_build(&agg_params_.leaf, child.data(), 3, arity(1), &is, &internal.circ);
+                if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the internal verifier circuit: ") + zkhip_recursion_last_error(nullptr));
+                circuit_airs(internal.circ, &internal.vk, &ia);
+                if (ia[0].log_height == H[0] && ia[1].log_height == H[1]) break;
+                H[0] = ia[0].log_height, H[1] = ia[1].log_height;
+            }
+            if (zkhip_recursion_pad(leaf.circ, H) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_pad");
+            circuit_airs(leaf.circ, &leaf.vk, &la);
+            for (size_t i = 0; i < 3; i++)
+                if (leaf.vk.airs[i].program != internal.vk.airs[i].program || leaf.vk.heights[i] != internal.vk.heights[i])
+                    throw Error(Error::Setup, "aggregation: the leaf and the internal circuit do not share one AIR set");
+            auto t1 = clk::now();
+            keygen_level(leaf, la);
+            keygen_level(internal, ia);
+            leaf_commit_ = leaf.vk.key_commit(), internal_commit_ = internal.vk.key_commit();
+            // the aggregation key: the internal verifying key + what a root must state beneath it
+            internal.vk.leaf_commit = leaf_commit_;
+            internal.vk.app_digest.resize(8);
+            if (zkhip_recursion_child_vk_digest(leaf.circ, internal.vk.app_digest.data()) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: child vk digest");
+            stats.build_seconds += std::chrono::duration<double>(t1 - t0).count();
+            stats.keygen_seconds += std::chrono::duration<double>(clk::now() - t1).count();
+        } catch (...) {
+            for (Level* L : {&leaf, &internal}) {
+                for (void* d : L->d_traces)
+                    if (d) zkhip_free(ctx_, d);
+                if (L->pk) zkhip_pk_destroy(ctx_, L->pk);
+                if (L->circ) zkhip_recursion_destroy(L->circ);
+            }
+            throw;
+        }
+        std::lock_guard<std::mutex> lk(*levels_mu_);
+        levels_.push_back(std::move(leaf));
+        levels_.push_back(std::move(internal));
+    }
     void ensure_level(size_t level) {
         using clk = std::chrono::steady_clock;
         while (n_levels() <= level) {
             std::lock_guard<std::mutex> build_lock(*build_mu_);   // per level: a thread that needs level 1 gets in between levels 1 and 2 of a warm-up
             const size_t l = n_levels();
             if (l > level) break;
-            if (!ctx_) {
-                std::lock_guard<std::mutex> dev(*dev_mu_);
-                int rc = zkhip_ctx_create(device_, &ctx_);
-                if (rc != ZKHIP_OK) throw Error(Error::Keygen, "no gfx950 device for the HIP backend (zkhip_ctx_create returned " + std::to_string(rc) + ")");
+            if (cfg_.one_key) {
+                if (l == 0) {
+                    build_one_key();
+                    continue;
+                }
+                // a further level of the tree: a fork of THE internal circuit (own witness, own trace buffers), the same proving key
+                Level& I = lv(1);
+                Level L;
+                if (zkhip_recursion_fork(I.circ, &L.circ) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_fork");
+                L.pk = I.pk, L.owns_pk = false, L.vk = I.vk;
+                {
+                    std::lock_guard<std::mutex> dev(*dev_mu_);
+                    alloc_traces(L);
+                }
+                std::lock_guard<std::mutex> lk(*levels_mu_);
+                levels_.push_back(std::move(L));
+                continue;
             }
+            ensure_ctx();
             const VerifyingKey& cvk = l == 0 ? app_ : lv(l - 1).vk;
             std::vector<zkhip_air> za = cvk.as_airs();
+            std::vector<uint32_t> cols[4];
             zkhip_recursion_stmt st{};
-            std::vector<uint32_t> sa, si, ea, ei;
-            if (l == 0) {
-                for (auto& p : spec_.start) sa.push_back(p.first), si.push_back(p.second);
-                for (auto& p : spec_.end) ea.push_back(p.first), ei.push_back(p.second);
-                st.n_state = sa.size(), st.start_air = sa.data(), st.start_idx = si.data(), st.end_air = ea.data(), st.end_idx = ei.data();
-            } else {
-                st.child_is_node = 1;
-            }
+            if (l == 0) st = leaf_stmt(cols);
+            else st.child_is_node = 1;
             Level L;
             auto t0 = clk::now();
             int rc = zkhip_recursion_build(&cvk.params, za.data(), za.size(), arity(l), &st, &L.circ);
             if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the verifier circuit of level ") + std::to_string(l) + ": " + zkhip_recursion_last_error(nullptr));
             auto t1 = clk::now();
             L.vk.params = l == 0 ? agg_params_.leaf : agg_params_.internal;
-            std::vector<zkhip_air> na(3);
-            for (size_t i = 0; i < 3; i++) {
-                if (zkhip_recursion_air(L.circ, i, &na[i]) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_air");
-                AirDesc d;
-                d.width = na[i].width, d.n_pvs = na[i].n_pvs, d.program.assign(na[i].program, na[i].program + na[i].program_len);
-                d.has_prep = true, d.prep_log_height = na[i].log_height;
-                L.vk.airs.push_back(std::move(d));
-                L.vk.heights.push_back(na[i].log_height);
-            }
-            std::lock_guard<std::mutex> dev(*dev_mu_);
-            rc = zkhip_keygen(ctx_, &L.vk.params, na.data(), 3, &L.pk);
-            if (rc != ZKHIP_OK) {
+            std::vector<zkhip_air> na;
+            try {
+                circuit_airs(L.circ, &L.vk, &na);
+                keygen_level(L, na);
+            } catch (...) {
                 zkhip_recursion_destroy(L.circ);
-                throw Error(Error::Keygen, std::string("failed to generate STARK proving key: ") + zkhip_last_error(ctx_));
-            }
-            for (size_t i = 0; i < 3; i++) {
-                uint32_t c[8];
-                check(zkhip_pk_prep_commitment(ctx_, L.pk, i, c));
-                L.vk.airs[i].prep_commit.assign(c, c + 8);
-                void* d = nullptr;
-                check(zkhip_malloc(ctx_, (na[i].width << na[i].log_height) * 4, &d));
-                L.d_traces.push_back(d);
+                throw;
             }
             stats.build_seconds += std::chrono::duration<double>(t1 - t0).count();
             stats.keygen_seconds += std::chrono::duration<double>(clk::now() - t1).count();

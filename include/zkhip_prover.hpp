@@ -721,6 +721,11 @@ private:
 // independent tasks over the lanes / GPUs of a BatchProver as soon as the level below is complete.
 struct AggregationTreeConfig {
     unsigned num_children_internal = 3, num_children_leaf = 4;
+    // ONE aggregation key (mod.rs:147-170 `agg_vk`, crates/verifier/src/verifier.rs:96-111): the root of every tree is a proof of the
+    // one internal circuit, so a tree has at least one internal level above its leaves -- a single leaf node is wrapped, as the
+    // reference's internal verifier wraps a single leaf proof.  false = the per-depth keys of round 3 (every level hard-wires the key
+    // of the level below; the root key depends on the depth).
+    bool one_key = true;
 };
 struct AggregationPlan {
     struct Node {
@@ -744,7 +749,7 @@ struct AggregationPlan {
             return lv;
         };
         p.levels.push_back(group(n_segments, cfg.num_children_leaf));
-        while (p.levels.back().size() > 1) p.levels.push_back(group(p.levels.back().size(), cfg.num_children_internal));
+        while (p.levels.back().size() > 1 || (cfg.one_key && p.levels.size() < 2)) p.levels.push_back(group(p.levels.back().size(), cfg.num_children_internal));
         return p;
     }
     size_t n_nodes() const {

@@ -565,10 +565,10 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     for (auto& p : proofs) seg_proofs.push_back(p.proof), g.sum_segment_tracegen_mills += p.tracegen_mills, g.sum_segment_prove_mills += p.proving_mills;
     if (keep_segments) g.segment_proofs.assign(std::make_move_iterator(proofs.begin()), std::make_move_iterator(proofs.end()));
     const auto t0 = clk::now();
-    const scroll_zkvm_hip::AggregationPlan plan = scroll_zkvm_hip::AggregationPlan::build(seg_proofs.size());
+    const scroll_zkvm_hip::AggregationPlan plan = scroll_zkvm_hip::AggregationPlan::build(seg_proofs.size(), agg.tree_config());
     g.root = tree.finish(seg_proofs.size());   // (what is left of the tree once the last segment proof exists)
     g.levels = plan.levels.size();
-    g.root_vk = agg.node_vk(plan.levels.size() - 1);
+    g.root_vk = agg.root_vk(plan.levels.size());   // (one aggregation key: the same for every depth)
     g.aggregation_mills = ms(clk::now() - t0);
     return g;
 }
@@ -725,7 +725,17 @@ inline bool verify_guest_proof(const VerifyingKey& root_vk, const ChildProof& ro
     };
     if (!root_vk.verify(root)) return fail("the root proof does not verify under the root verifying key");
     const std::vector<uint32_t>& pv = root.pvs.at(2);
-    if (pv.size() != 8 + 9 + 9 + 8) return fail("the root statement does not have the (pc, memory root) layout");
+    if (pv.size() != 8 + 9 + 9 + 8 && pv.size() != 8 + 9 + 9 + 8 + 16) return fail("the root statement does not have the (pc, memory root) layout");
+    // An aggregation key pins the tree beneath the root: its leaves are proofs of the key's leaf circuit (which hard-wires the app's
+    // verifying key: programs, heights, the committed program), its nodes proofs of the key's own circuit, the statement is about this
+    // app.  (A per-depth key of round 3 pins the same through its preprocessed commitments and carries no pair.)
+    if (pv.size() == 50) {
+        std::string w;
+        if (!root_vk.root_statement_matches(pv, &w)) {
+            if (why) *why = w;
+            return false;
+        }
+    }
     if (pv[8] != entry_pc) return fail("the run does not start at the guest's entry point");
     if (!std::equal(image_root.begin(), image_root.end(), pv.begin() + 9)) return fail("the run does not start on the guest's memory image");
     if (pv[17] != 0) return fail("the run does not end with exit code 0");
@@ -811,7 +821,7 @@ public:
     }
     // crates/verifier/src/verifier.rs:38-85 for this flow: the root proof under the root verifying key and the statement about THIS guest
     static bool verify_guest_stark(const StarkProof& sp, const VerifyingKey& root_vk, const zkhip_vm::Exe& exe, std::string* why = nullptr) {
-        const size_t n_stmt = 34, n_open = 2 * 8 * zkhip::vmc::LEAF_LEVEL;
+        const size_t n_stmt = root_vk.airs.empty() ? 0 : root_vk.airs.back().n_pvs, n_open = 2 * 8 * zkhip::vmc::LEAF_LEVEL;
         if (sp.user_pvs_proof.size() != 4 * n_stmt + zkhip_vm::NUM_PUBLIC_VALUE_BYTES + 4 * n_open) {
             if (why) *why = "user_pvs_proof has the wrong size";
             return false;

@@ -164,9 +164,9 @@ def test_aggregation_tree_over_a_batch(ora, tmp_path):
     assert info["segments"] == 6 and info["nodes"] == 3 and info["levels"] == 2
     assert pm.run_cli("verify", str(out / "root.vk"), cfg, str(out / "root.json")).returncode == 0
     accs = [ru.leaf_accumulator([[a["pvs"] for a in s] for s in all_airs[i:i + 4]]) for i in (0, 4)]
-    assert info["root_public_values"][8:] == ru.internal_accumulator(accs).tolist()
-    # the first leaf node's proof, re-derived: same circuit, same witness, the oracle's prover
-    rc = z.RecursionCircuit(PARAMS, [{k: a[k] for k in ("program", "log_height", "width", "n_pvs")} for a in all_airs[0]], 4)
+    assert info["root_public_values"][8:16] == ru.internal_accumulator(accs).tolist()
+    # the first leaf node's proof, re-derived: same circuit (the leaf circuit of the one aggregation key), same witness, the oracle's prover
+    rc, _ = ru.one_key_circuits(PARAMS, [{k: a[k] for k in ("program", "log_height", "width", "n_pvs")} for a in all_airs[0]], None)
     st, npv = rc.witness([ora.stark_prove(PARAMS, a).tobytes() for a in all_airs[:4]], [[a["pvs"] for a in s] for s in all_airs[:4]])
     assert st == 0
     leaf0 = json.loads((out / "agg-0-0.json").read_text())

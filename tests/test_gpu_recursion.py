@@ -115,24 +115,73 @@ def test_prove_agg_cli_69_segments_to_one_root(ora, tmp_path):
     accs = [ru.leaf_accumulator([[a["pvs"] for a in s] for s in segs[i:i + 4]]) for i in range(0, n_seg, 4)]
     while len(accs) > 1:
         accs = [ru.internal_accumulator(accs[i:i + 3]) for i in range(0, len(accs), 3)]
-    assert rpv[10:].tolist() == accs[0].tolist()
-    # a leaf node's proof against the oracle: same circuit, same witness -> same bytes
+    assert rpv[10:18].tolist() == accs[0].tolist()
+    # a leaf node's proof against the oracle: same circuit, same witness -> same bytes; so is an internal node's (the one circuit
+    # that verifies leaf proofs and proofs of itself)
     vk = ru.verifying(PARAMS, segs[0])
-    rc = z.RecursionCircuit(PARAMS, vk, 4, stmt=ru.COUNTER_STMT)
+    rc, irc = ru.one_key_circuits(PARAMS, vk, ru.COUNTER_STMT)
     assert rpv[:8].tolist() == rc.child_vk_digest().tolist()
     seg_proofs = [ora.stark_prove(PARAMS, s).tobytes() for s in segs[4:8]]
     st, npv = rc.witness(seg_proofs, [[a["pvs"] for a in s] for s in segs[4:8]])
     assert st == 0
     leaf1 = json.loads((out / "agg-0-1.json").read_text())
     assert pm.un_b64_bincode(leaf1["proof"]) == ora.stark_prove(PARAMS, ru.node_instance(rc, npv)).tobytes()
-    # a proof of another level does not verify under the root vk; a flipped public value neither
-    assert pm.run_cli("verify", str(out / "root.vk"), cfg, str(out / "agg-2-0.json")).returncode != 0
+    leaf_pcs, LC = ru.node_key_commits(PARAMS, rc.airs())
+    int_pcs, IC = ru.node_key_commits(PARAMS, irc.airs())
+    assert rpv[18:26].tolist() == LC.tolist() and rpv[26:34].tolist() == IC.tolist()
+    kids = [json.loads((out / ("agg-0-%d.json" % i)).read_text()) for i in range(3)]
+    kid_pvs = [np.frombuffer(pm.un_b64_bincode(k["user_pvs_proof"]), dtype=np.uint32) for k in kids]
+    st, ipv = irc.witness([pm.un_b64_bincode(k["proof"]) for k in kids], [[NOPV, NOPV, p] for p in kid_pvs], prep_commits=[leaf_pcs] * 3,
+                          is_leaf=[1, 1, 1], leaf_commit=LC, internal_commit=IC)
+    assert st == 0, irc.last_error()
+    int0 = json.loads((out / "agg-1-0.json").read_text())
+    assert pm.un_b64_bincode(int0["proof"]) == ora.stark_prove(PARAMS, ru.node_instance(irc, ipv)).tobytes()
+    # ONE key: a node of any level above the leaves is a proof of the internal circuit (its statement is about ITS segments); a leaf
+    # proof is not; a flipped public value is refused
+    for name in ("agg-1-0.json", "agg-2-1.json"):
+        assert pm.run_cli("verify", str(out / "root.vk"), cfg, str(out / name)).returncode == 0
+    assert pm.run_cli("verify", str(out / "root.vk"), cfg, str(out / "agg-0-0.json")).returncode != 0
     lie = dict(root)
     w = bytearray(pm.un_b64_bincode(root["user_pvs_proof"]))
     w[4 * 9] ^= 1
     lie["user_pvs_proof"] = pm.b64_bincode(bytes(w))
     (out / "lie.json").write_text(json.dumps(lie))
     assert pm.run_cli("verify", str(out / "root.vk"), cfg, str(out / "lie.json")).returncode != 0
+
+
+def test_root_key_does_not_depend_on_the_depth(tmp_path):
+    """3 segments (one leaf node under one internal node) and 40 segments (10 + 4 + 2 + 1 nodes): root.vk is the same file, each root
+    verifies under the other tree's key.  With round 3's per-depth keys (ZKHIP_AGG_PER_DEPTH_KEYS=1) the two keys differ."""
+    import os
+    import subprocess
+
+    keys = {}
+    for mode, env in (("one", {}), ("per_depth", {"ZKHIP_AGG_PER_DEPTH_KEYS": "1"})):
+        for n_seg in (3, 40):
+            start, tasks, segs = 50, [], []
+            d0 = tmp_path / ("%s-%d" % (mode, n_seg))
+            d0.mkdir()
+            for i in range(n_seg):
+                k = ru.counter_segment(start, seed=i)
+                segs.append(k)
+                d = d0 / ("s%d" % i)
+                d.mkdir()
+                tasks.append(pm.write_task(str(d), k, identifier="seg-%d" % i))
+                start += 7
+            exe, cfg = pm.write_app(str(d0), segs[0], PARAMS)
+            r = subprocess.run([pm.CLI, "prove-agg", exe, cfg, str(d0), "2", "0:0/0:1", *tasks], capture_output=True, text=True, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr[-3000:]
+            info = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            keys[(mode, n_seg)] = dict(vk=(d0 / "root.vk").read_bytes(), dir=d0, cfg=cfg, info=info)
+    assert keys[("one", 3)]["info"]["levels"] == 2 and keys[("one", 40)]["info"]["levels"] == 4
+    assert keys[("per_depth", 3)]["info"]["levels"] == 1 and keys[("per_depth", 40)]["info"]["levels"] == 4
+    assert keys[("one", 3)]["vk"] == keys[("one", 40)]["vk"]
+    assert keys[("per_depth", 3)]["vk"] != keys[("per_depth", 40)]["vk"]
+    a, b = keys[("one", 3)], keys[("one", 40)]
+    assert pm.run_cli("verify", str(a["dir"] / "root.vk"), a["cfg"], str(b["dir"] / "root.json")).returncode == 0
+    assert pm.run_cli("verify", str(b["dir"] / "root.vk"), b["cfg"], str(a["dir"] / "root.json")).returncode == 0
+    a, b = keys[("per_depth", 3)], keys[("per_depth", 40)]
+    assert pm.run_cli("verify", str(a["dir"] / "root.vk"), a["cfg"], str(b["dir"] / "root.json")).returncode != 0
 
 
 def test_prove_agg_refuses_a_broken_hand_over(tmp_path):

@@ -23,6 +23,7 @@ from test_vm_cpu import (ALL_EXT_MSG, CHUNK_CIRCUIT_CURVES, CHUNK_CIRCUIT_MODULI
 pytestmark = pytest.mark.gpu
 PARAMS = (1, 0, 4, 3, 3)
 PC_BASE = 0x00200000
+N_STMT = 8 + 9 + 9 + 8 + 16   # a root's statement: app digest, start / end state (pc, memory root), accumulator, leaf / internal commitment
 
 
 def device_traces(zk, rec, prog, H):
@@ -216,8 +217,8 @@ def test_prove_elf_one_flow_one_proof(tmp_path, which, seed):
     assert info["verified"] and info["total_cycles"] == model["instret"] and info["segments"] >= 3 and info["levels"] >= 2
     root = json.loads((tmp_path / "root.json").read_text())
     upv = pm.un_b64_bincode(root["user_pvs_proof"])
-    stmt = np.frombuffer(upv[:4 * 34], dtype=np.uint32)
-    assert upv[4 * 34:4 * 34 + 32] == bytes(model["pvs"]) and len(upv) == 4 * 34 + 32 + 4 * 2 * 8 * 28
+    stmt = np.frombuffer(upv[:4 * N_STMT], dtype=np.uint32)
+    assert upv[4 * N_STMT:4 * N_STMT + 32] == bytes(model["pvs"]) and len(upv) == 4 * N_STMT + 32 + 4 * 2 * 8 * 28
     assert int(stmt[8]) == PC_BASE and int(stmt[17]) == 0                                           # from the entry point to the exit
     cfg = str(tmp_path / "openvm.toml")
     # the root proof verifies under the root verifying key alone; the whole statement about this guest with verify-guest
@@ -235,7 +236,7 @@ def test_prove_elf_one_flow_one_proof(tmp_path, which, seed):
 
     lie = variant(lambda b: b.__setitem__(4 * 20, b[4 * 20] ^ 1), "lie_root.json")                    # another final memory root
     assert pm.run_cli("verify", str(tmp_path / "root.vk"), cfg, lie).returncode != 0
-    lie = variant(lambda b: b.__setitem__(4 * 34, b[4 * 34] ^ 1), "lie_pv.json")                      # other public values
+    lie = variant(lambda b: b.__setitem__(4 * N_STMT, b[4 * N_STMT] ^ 1), "lie_pv.json")                      # other public values
     assert pm.run_cli("verify", str(tmp_path / "root.vk"), cfg, lie).returncode == 0                  # (the node proof does not see them)
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), cfg, lie).returncode != 0  # the openings do
     # another initial memory image: the statement starts elsewhere (the PROGRAM is pinned by root.vk: the segment key holds the
@@ -243,6 +244,51 @@ def test_prove_elf_one_flow_one_proof(tmp_path, which, seed):
     other = tmp_path / "other.elf"
     other.write_bytes(rv.elf_bytes(words, data=b"\x01\x02\x03\x04"))
     assert pm.run_cli("verify-guest", str(other), str(tmp_path / "root.vk"), cfg, str(tmp_path / "root.json")).returncode != 0
+
+
+def test_one_aggregation_key_for_every_depth(tmp_path):
+    """ONE aggregation key (crates/prover/src/prover/mod.rs:147-170, crates/verifier/src/verifier.rs:96-111): the same guest run on a short
+    and on a long input gives trees of different depth whose roots verify under ONE key -- root.vk is byte-identical, each root verifies
+    under the other run's key; a key with another leaf commitment (another app) or another app digest refuses both."""
+    words = fib_program()
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words))
+    cfg = tmp_path / "openvm.toml"
+    cfg.write_text(pm.TOML.format(*PARAMS))
+    infos = {}
+    for name, n in (("short", 100), ("long", 3000)):
+        d = tmp_path / name
+        d.mkdir()
+        (d / "stdin.bin").write_bytes(int(n).to_bytes(4, "little"))
+        r = subprocess.run([pm.CLI, "prove-elf", str(exe), str(d / "stdin.bin"), str(d), str(cfg), "9"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        infos[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert infos["short"]["levels"] == 2 and infos["short"]["segments"] <= 4      # one leaf node wrapped by one internal node
+    assert infos["long"]["levels"] >= 4 and infos["long"]["segments"] > 27
+    key = (tmp_path / "short" / "root.vk").read_bytes()
+    assert key == (tmp_path / "long" / "root.vk").read_bytes()
+    for vk_of, root_of in (("short", "long"), ("long", "short")):
+        vk, root = str(tmp_path / vk_of / "root.vk"), str(tmp_path / root_of / "root.json")
+        assert pm.run_cli("verify", vk, str(cfg), root).returncode == 0
+        assert pm.run_cli("verify-guest", str(exe), vk, str(cfg), root).returncode == 0
+    # the key's trailer: [magic | leaf commitment (8) | app digest (8)]; another leaf commitment / app digest: refused
+    for word in (1, 9):
+        bad = bytearray(key)
+        bad[len(key) - 4 * 17 + 4 * word] ^= 1
+        (tmp_path / "bad.vk").write_bytes(bytes(bad))
+        for name in ("short", "long"):
+            r = pm.run_cli("verify", str(tmp_path / "bad.vk"), str(cfg), str(tmp_path / name / "root.json"))
+            assert r.returncode != 0 and ("leaf circuit" in r.stderr or "this app" in r.stderr), r.stderr
+    # another guest under the same configuration: another leaf circuit, hence another key
+    other = tmp_path / "mixed.elf"
+    other.write_bytes(rv.elf_bytes(mixed_program()))
+    d = tmp_path / "mixed"
+    d.mkdir()
+    (d / "stdin.bin").write_bytes(int(21).to_bytes(4, "little"))
+    r = subprocess.run([pm.CLI, "prove-elf", str(other), str(d / "stdin.bin"), str(d), str(cfg), "9"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (d / "root.vk").read_bytes() != key
+    assert pm.run_cli("verify", str(d / "root.vk"), str(cfg), str(tmp_path / "long" / "root.json")).returncode != 0
 
 
 def test_keccak_guest_device_traces_and_one_proof(zk, ora, tmp_path):
@@ -276,7 +322,7 @@ def test_keccak_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     assert out["verified"] and out["total_cycles"] == model["instret"]
     root = json.loads((tmp_path / "root.json").read_text())
     upv = pm.un_b64_bincode(root["user_pvs_proof"])
-    assert upv[4 * 34:4 * 34 + 28] == hashlib.sha3_256(msg).digest()[:28] and upv[4 * 34:4 * 34 + 32] == bytes(model["pvs"])
+    assert upv[4 * N_STMT:4 * N_STMT + 28] == hashlib.sha3_256(msg).digest()[:28] and upv[4 * N_STMT:4 * N_STMT + 32] == bytes(model["pvs"])
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
 
 
@@ -310,7 +356,7 @@ def test_sha256_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     model = rv.run(words, b"", data=data)
     assert out["verified"] and out["total_cycles"] == model["instret"]
     upv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])
-    pv = upv[4 * 34:4 * 34 + 32]
+    pv = upv[4 * N_STMT:4 * N_STMT + 32]
     assert b"".join(int.from_bytes(pv[4 * k:4 * k + 4], "little").to_bytes(4, "big") for k in range(8)) == hashlib.sha256(msg).digest()
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
     # the same guest under an app without the extension has no proof
@@ -346,7 +392,7 @@ def test_modmul_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     model = rv.run(words, b"", data=data, moduli=moduli)
     assert out["verified"] and out["total_cycles"] == model["instret"]
-    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * 34:4 * 34 + 32]
+    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * N_STMT:4 * N_STMT + 32]
     assert pv == bytes(model["pvs"])
     y2_low, x3_low = int.from_bytes(pv[:16], "little"), int.from_bytes(pv[16:28], "little")
     assert y2_low == SECP256K1_GY ** 2 % SECP256K1_P % (1 << 128) and x3_low == SECP256K1_GX ** 3 % SECP256K1_P % (1 << 96)
@@ -380,7 +426,7 @@ def test_ecc_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     model = rv.run(words, b"", data=data, curves=EC_CURVES)
     assert out["verified"] and out["total_cycles"] == model["instret"]
-    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * 34:4 * 34 + 32]
+    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * N_STMT:4 * N_STMT + 32]
     assert pv == bytes(model["pvs"])
     assert pv[:16] == (0xF9308A019258C31049344F85F89D5229B531C845836F99B08601F113BCE036F9).to_bytes(32, "little")[:16]   # 3 G of secp256k1 (published)
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
@@ -412,7 +458,7 @@ def test_fp2_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     model = rv.run(words, b"", data=data, fp2=(BN254_P,))
     assert out["verified"] and out["total_cycles"] == model["instret"]
-    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * 34:4 * 34 + 32]
+    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * N_STMT:4 * N_STMT + 32]
     assert pv == bytes(model["pvs"]) and pv[:16] == pv[16:]                # y^2 == x^3 + 3 / (9 + u) at EIP-197's G2 generator
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
 
@@ -442,7 +488,7 @@ def test_int256_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     model = rv.run(words, b"", data=data)
     assert out["verified"] and out["total_cycles"] == model["instret"]
-    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * 34:4 * 34 + 32]
+    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * N_STMT:4 * N_STMT + 32]
     M = 1 << 256
     want = [[(b + c) % M, (b - c) % M, b ^ c, b | c, b & c, (b * c) % M][op] for op, (b, c) in enumerate(INT256_OPERANDS)]
     assert pv == bytes(model["pvs"]) and [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(6)] == [w & 0xFFFFFFFF for w in want]
@@ -465,7 +511,7 @@ def test_the_chunk_circuit_configuration_end_to_end(tmp_path):
     model = rv.run(words, b"", data=data, moduli=CHUNK_CIRCUIT_MODULI, curves=tuple((c[1], c[3]) for c in CHUNK_CIRCUIT_CURVES))
     assert out["verified"] and out["total_cycles"] == model["instret"]
     root = json.loads((tmp_path / "root.json").read_text())
-    pv = pm.un_b64_bincode(root["user_pvs_proof"])[4 * 34:4 * 34 + 32]
+    pv = pm.un_b64_bincode(root["user_pvs_proof"])[4 * N_STMT:4 * N_STMT + 32]
     assert pv == bytes(model["pvs"]) and pv[:8] == hashlib.sha3_256(ALL_EXT_MSG).digest()[:8]
     assert b"".join(pv[8 + 4 * k:12 + 4 * k][::-1] for k in range(2)) == hashlib.sha256(ALL_EXT_MSG).digest()[:8]
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
@@ -503,9 +549,9 @@ def test_gen_proof_universal_from_an_elf_and_witness_bytes(tmp_path):
     assert set(root) == {"proof", "user_pvs_proof", "baseline", "deferral_merkle_proofs", "stat"}
     assert root["stat"]["total_cycles"] == model["instret"]
     upv = pm.un_b64_bincode(root["user_pvs_proof"])
-    assert upv[4 * 34:4 * 34 + 32] == bytes(model["pvs"])
+    assert upv[4 * N_STMT:4 * N_STMT + 32] == bytes(model["pvs"])
     total = sum(int.from_bytes(stream[i:i + 4], "little") for i in range(0, len(stream), 4)) & 0xFFFFFFFF
-    assert int.from_bytes(upv[4 * 34:4 * 34 + 4], "little") == total and upv[4 * 34 + 4] == 3
+    assert int.from_bytes(upv[4 * N_STMT:4 * N_STMT + 4], "little") == total and upv[4 * N_STMT + 4] == 3
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
     # a guest that fails (exit code 1) has no proof; neither has one whose public values stay zero
     bad = rv.assemble([("addi", A0, 0, 1), ("addi", A7, 0, 93), ("ecall",)])

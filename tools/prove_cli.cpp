@@ -195,10 +195,7 @@ int main(int argc, char** argv) {
             // verify-guest <guest.elf | exe.bin> <root.vk> <openvm.toml> <root.json>: the root proof under the root verifying key AND the
             // statement about this guest: entry pc, memory image, exit code 0, public values opened in the final memory root (host only)
             const zkhip_vm::Exe exe = zkhip_vm::parse_exe(slurp(argv[2]));
-            VerifyingKey vk;
-            vk.params = read_app_config(argv[4]);
-            vk.airs = read_app_exe(argv[3]);
-            for (const auto& a : vk.airs) vk.heights.push_back(a.prep_log_height);
+            const VerifyingKey vk = VerifyingKey::read(argv[3], read_app_config(argv[4]));   // (an aggregation key: + leaf commitment, app digest)
             std::ifstream f(argv[5]);
             std::stringstream ss;
             ss << f.rdbuf();
@@ -206,7 +203,7 @@ int main(int argc, char** argv) {
             std::string why;
             if (!UniversalProver::verify_guest_stark(sp, vk, exe, &why)) throw Error(Error::VerifyProof, "failed to verify proof: " + why);
             std::printf("verified: public values ");
-            for (size_t i = 0; i < 32; i++) std::printf("%02x", sp.user_pvs_proof[4 * 34 + i]);
+            for (size_t i = 0; i < 32; i++) std::printf("%02x", sp.user_pvs_proof[4 * vk.airs.back().n_pvs + i]);
             std::printf("\n");
             return 0;
         }
@@ -279,6 +276,17 @@ int main(int argc, char** argv) {
             auto js = slurp(argv[4]);
             StarkProof sp = StarkProof::from_json(std::string(js.begin(), js.end()));
             verifier.verify_stark_proof(sp);
+            // an AGGREGATION key (root.vk of prove-agg / prove-elf) also says what the root must state beneath it: the tree's leaves are
+            // proofs of the key's leaf circuit, its nodes of the key's own circuit, the app is the key's
+            const VerifyingKey vk = VerifyingKey::read(argv[2], read_app_config(argv[3]));
+            if (vk.is_aggregation_key()) {
+                const size_t n = vk.airs.back().n_pvs;
+                std::vector<uint32_t> stmt(n);
+                if (sp.user_pvs_proof.size() < 4 * n) throw Error(Error::VerifyProof, "failed to verify proof: short root statement");
+                memcpy(stmt.data(), sp.user_pvs_proof.data(), 4 * n);
+                std::string why;
+                if (!vk.root_statement_matches(stmt, &why)) throw Error(Error::VerifyProof, "failed to verify proof: " + why);
+            }
             std::printf("verified: %zu proof bytes, proving_time_mills=%llu\n", sp.proof.size(),
                         (unsigned long long)sp.stat.proving_time_mills);
             return 0;
@@ -465,8 +473,10 @@ int main(int argc, char** argv) {
                 a.prep.clear();
             }
             seg.reset();
-            AggregationProver agg = AggregationProver::setup(avk, spec);
-            AggregationPlan plan = AggregationPlan::build(seg_proofs.size());
+            AggregationTreeConfig tcfg;
+            tcfg.one_key = getenv("ZKHIP_AGG_PER_DEPTH_KEYS") == nullptr;   // (round 3's keys: every level hard-wires the level below)
+            AggregationProver agg = AggregationProver::setup(avk, spec, tcfg);
+            AggregationPlan plan = AggregationPlan::build(seg_proofs.size(), tcfg);
             std::vector<ChildProof> segs;
             for (const auto& sp : seg_proofs) segs.push_back(AggregationProver::from_stark_proof(sp, avk));
             (void)agg.node_vk(plan.levels.size() - 1);  // circuits + keys of every level: setup, not proving
@@ -474,7 +484,11 @@ int main(int argc, char** argv) {
             std::vector<std::vector<ChildProof>> all;
             ChildProof root = agg.prove_tree(plan, segs, &all);
             const auto t3 = std::chrono::steady_clock::now();
-            const VerifyingKey& rvk = agg.node_vk(plan.levels.size() - 1);
+            const VerifyingKey& rvk = agg.root_vk(plan.levels.size());   // one key: THE aggregation key, whatever the depth
+            if (rvk.is_aggregation_key()) {
+                std::string why;
+                if (!rvk.root_statement_matches(root.pvs[2], &why)) throw Error(Error::VerifyProof, "failed to verify proof: " + why);
+            }
             const std::string dir = argv[4];
             std::ofstream(dir + "/root.json") << AggregationProver::to_stark_proof(root, rvk).to_json();
             {
