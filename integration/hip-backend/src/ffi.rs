@@ -159,7 +159,12 @@ pub struct zkhip_recursion_stmt {
     pub start_idx: *const u32,
     pub end_air: *const u32,
     pub end_idx: *const u32,
+    /// 0 = leaf (children: proofs of a fixed key), 1 = node of the level below (per-depth keys), 2 = UNIFORM node (one aggregation key)
     pub child_is_node: c_int,
+    /// leaf circuit: append the [leaf commitment | internal commitment] words (zero) to the public values
+    pub uniform: c_int,
+    /// pads the gate / Poseidon2 chip (0 = natural size)
+    pub min_log_height: [c_uint; 2],
 }
 
 #[repr(C)]
@@ -416,6 +421,12 @@ extern "C" {
     pub fn zkhip_recursion_air(r: *const zkhip_recursion, i: usize, out: *mut zkhip_air) -> c_int;
     pub fn zkhip_recursion_witness(r: *mut zkhip_recursion, proofs: *const *const u8, proof_lens: *const usize,
                                    child_pvs: *const *const *const u32, n_present: usize, node_pvs_out: *mut u32) -> c_int;
+    pub fn zkhip_recursion_witness_uniform(r: *mut zkhip_recursion, proofs: *const *const u8, proof_lens: *const usize,
+                                           child_pvs: *const *const *const u32, child_prep_commits: *const u32, child_is_leaf: *const c_int,
+                                           leaf_commit: *const u32, internal_commit: *const u32, n_present: usize, node_pvs_out: *mut u32) -> c_int;
+    pub fn zkhip_recursion_fork(r: *const zkhip_recursion, out: *mut *mut zkhip_recursion) -> c_int;
+    pub fn zkhip_recursion_pad(r: *mut zkhip_recursion, log_height: *const c_uint) -> c_int;
+    pub fn zkhip_recursion_key_commit(prep_commits: *const u32, n_commits: usize, out: *mut u32) -> c_int;
     pub fn zkhip_recursion_wires(r: *const zkhip_recursion, out: *mut u32, cap_words: usize, n_words: *mut usize) -> c_int;
     pub fn zkhip_recursion_tracegen(ctx: *mut zkhip_ctx, r: *mut zkhip_recursion, d_gate_trace: *mut u32, d_p2_trace: *mut u32,
                                     d_pv_trace: *mut u32) -> c_int;
