@@ -769,7 +769,14 @@ typedef struct {
      * commitment (8)] = zkhip_recursion_key_commit of the two keys: each child's commitments hash to one of the two, an internal
      * child states the same pair.  The verifier holds (internal key, leaf commitment) whatever the depth of the tree.
      * uniform = 1 on a leaf circuit (child_is_node = 0) appends the 16 words (zero) so that its proofs have the internal circuit's
-     * public-value layout.  min_log_height pads the gate / Poseidon2 chip (0 = natural size). */
+     * public-value layout.  min_log_height pads the gate / Poseidon2 chip (0 = natural size).
+     * DEFERRAL (crates/prover/src/prover/mod.rs:200-282 `enable_deferral`: child agg vk -> VerifyProver; crates/types/circuit/src/lib.rs:137-154
+     * `verify_stark(input_commit, expected{exe commit, vm commit, public values})`): child_is_node = 3 builds the DEFERRAL NODE for the
+     * aggregation key of a child app (`child_airs` = its internal circuit's key, commitments included): every child is a ROOT proof of a
+     * guest flow; per child the circuit derives the claim a parent guest makes about it -- input commitment = sponge of the root's
+     * statement, exe commitment = compress(initial memory root, entry pc), vm commitment = compress(app-vk digest, leaf commitment), the
+     * 32 public-value bytes opened in the final memory root -- requires exit code 0 and the key's own internal commitment, and chains
+     * acc <- compress(acc, chunk) over the claim's five 8-element chunks.  Public values [acc before (8) | acc after (8)]. */
     int uniform;
     unsigned min_log_height[2];
 } zkhip_recursion_stmt;
@@ -777,6 +784,12 @@ typedef struct {
 int zkhip_recursion_build(const zkhip_params *child_params, const zkhip_air *child_airs, size_t n_child_airs, size_t max_children,
                           const zkhip_recursion_stmt *stmt, zkhip_recursion **out);
 void zkhip_recursion_destroy(zkhip_recursion *r);
+/* The JOIN of a guest that defers verification: child 0 = the guest's root proof under aggregation key A (its internal circuit's key,
+ * commitments included), child 1 = the deferral node's proof (key B) whose chain starts at zero.  Public values: the root's statement
+ * followed by the deferral accumulator (8): the verifier opens the guest's claims in the final memory root and hashes them.  Witness:
+ * zkhip_recursion_witness with the two proofs. */
+int zkhip_recursion_build_join(const zkhip_params *params_a, const zkhip_air *airs_a, size_t n_airs_a, const zkhip_params *params_b,
+                               const zkhip_air *airs_b, size_t n_airs_b, zkhip_recursion **out);
 /* a second user of the same circuit: wiring, programs and preprocessed traces shared, witness and device buffers its own (the levels of
  * an aggregation tree above the leaves run ONE internal circuit side by side); destroy each with zkhip_recursion_destroy */
 int zkhip_recursion_fork(const zkhip_recursion *r, zkhip_recursion **out);
@@ -806,6 +819,11 @@ int zkhip_recursion_witness(zkhip_recursion *r, const uint8_t *const *proofs, co
 int zkhip_recursion_witness_uniform(zkhip_recursion *r, const uint8_t *const *proofs, const size_t *proof_lens, const uint32_t *const *const *child_pvs,
                                     const uint32_t *child_prep_commits, const int *child_is_leaf, const uint32_t leaf_commit[8],
                                     const uint32_t internal_commit[8], size_t n_present, uint32_t *node_pvs_out);
+/* the witness of a DEFERRAL node: child_aux[c] = zkhip_recursion_n_aux words (232): the 16 cells of the child's two public-value blocks, then
+ * the 27 sibling digests above the block pair in its final memory root, bottom-up; acc_start = the claim chain before this node */
+int zkhip_recursion_witness_deferral(zkhip_recursion *r, const uint8_t *const *proofs, const size_t *proof_lens, const uint32_t *const *const *child_pvs,
+                                     const uint32_t *child_aux, const uint32_t acc_start[8], size_t n_present, uint32_t *node_pvs_out);
+size_t zkhip_recursion_n_aux(const zkhip_recursion *r);
 /* wire values of the last witness, canonical [n_wires + 1][4]; out = NULL: only the size */
 int zkhip_recursion_wires(const zkhip_recursion *r, uint32_t *out, size_t cap_words, size_t *n_words);
 /* device traces of the three chips from the last witness (Montgomery, column-major, stride = 2^log_height of the chip) */

@@ -424,6 +424,12 @@ extern "C" {
     pub fn zkhip_recursion_witness_uniform(r: *mut zkhip_recursion, proofs: *const *const u8, proof_lens: *const usize,
                                            child_pvs: *const *const *const u32, child_prep_commits: *const u32, child_is_leaf: *const c_int,
                                            leaf_commit: *const u32, internal_commit: *const u32, n_present: usize, node_pvs_out: *mut u32) -> c_int;
+    pub fn zkhip_recursion_build_join(params_a: *const zkhip_params, airs_a: *const zkhip_air, n_airs_a: usize, params_b: *const zkhip_params,
+                                      airs_b: *const zkhip_air, n_airs_b: usize, out: *mut *mut zkhip_recursion) -> c_int;
+    pub fn zkhip_recursion_witness_deferral(r: *mut zkhip_recursion, proofs: *const *const u8, proof_lens: *const usize,
+                                            child_pvs: *const *const *const u32, child_aux: *const u32, acc_start: *const u32,
+                                            n_present: usize, node_pvs_out: *mut u32) -> c_int;
+    pub fn zkhip_recursion_n_aux(r: *const zkhip_recursion) -> usize;
     pub fn zkhip_recursion_fork(r: *const zkhip_recursion, out: *mut *mut zkhip_recursion) -> c_int;
     pub fn zkhip_recursion_pad(r: *mut zkhip_recursion, log_height: *const c_uint) -> c_int;
     pub fn zkhip_recursion_key_commit(prep_commits: *const u32, n_commits: usize, out: *mut u32) -> c_int;

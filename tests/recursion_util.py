@@ -129,3 +129,56 @@ def node_key_commits(params, node_airs):
 
     pcs = [np.asarray(ora.prep_commit(params, dict(a, pvs=NOPV, trace=None)), np.uint32) for a in node_airs]
     return pcs, z.key_commit(pcs)
+
+
+# ---- a toy "guest flow" for the deferral circuits: segments whose public values are a (pc, memory root) state ----
+def state_air():
+    """1 column; 18 public values: start = (pc, memory root[8]), end = (pc, memory root[8]).  The column carries the start pc."""
+    b = air.AirBuilder(1, 18)
+    x = b.var(0)
+    b.when_first_row(x - b.pub(0))
+    b.when_transition(b.next(0) - x)
+    return b
+
+
+def state_segment(start, end, log_n=3):
+    pv = np.array(list(start) + list(end), np.uint32)
+    tr = np.full((1, 1 << log_n), int(start[0]), np.uint32)
+    return [dict(program=state_air().program(), log_height=log_n, width=1, n_pvs=18, trace=tr, pvs=pv)]
+
+
+STATE_STMT = dict(start=[(0, k) for k in range(9)], end=[(0, 9 + k) for k in range(9)])
+
+
+def block(cells):
+    return compress(cells, np.zeros(8, np.uint32))
+
+
+def memory_root_with_public_values(pv_bytes, rng):
+    """A final memory root in which the 32 public-value bytes open (address space 3, blocks 0 and 1 of the 2^28-leaf tree, as
+    include/zkhip_vm_flow.hpp `check_public_values`): random siblings above the block pair.  Returns (root, cells[16], siblings[27][8])."""
+    cells = np.array([pv_bytes[2 * j] | (pv_bytes[2 * j + 1] << 8) for j in range(16)], np.uint32)
+    cur = compress(block(cells[:8]), block(cells[8:]))
+    sibs = rng.integers(0, P, size=(27, 8), dtype=np.uint64).astype(np.uint32)
+    idx = (3 << 26) >> 1
+    for l in range(27):
+        cur = compress(sibs[l], cur) if idx & 1 else compress(cur, sibs[l])
+        idx >>= 1
+    return cur, cells, sibs
+
+
+def deferral_claim(root_pvs, cells):
+    """The five chunks a deferral node chains for a child root with statement `root_pvs` (50 words): what a parent guest states about it."""
+    root_pvs = np.asarray(root_pvs, np.uint32)
+    app, pc_start, root0, lc = root_pvs[:8], root_pvs[8], root_pvs[9:17], root_pvs[34:42]
+    input_commit = sponge(root_pvs)
+    exe_commit = compress(root0, np.array([pc_start, 0, 0, 0, 0, 0, 0, 0], np.uint32))
+    vm_commit = compress(app, lc)
+    return [input_commit, exe_commit, vm_commit, np.asarray(cells[:8], np.uint32), np.asarray(cells[8:], np.uint32)]
+
+
+def deferral_chain(acc, claims):
+    for chunks in claims:
+        for c in chunks:
+            acc = compress(acc, c)
+    return acc

@@ -229,6 +229,9 @@ def load_library():
         "zkhip_recursion_air": (C.c_int, [vp, sz, C.POINTER(_Air)]),
         "zkhip_recursion_witness": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(C.POINTER(u32p)), sz, u32p]),
         "zkhip_recursion_wires": (C.c_int, [vp, u32p, sz, C.POINTER(sz)]),
+        "zkhip_recursion_build_join": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(vp)]),
+        "zkhip_recursion_witness_deferral": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(C.POINTER(u32p)), u32p, u32p, sz, u32p]),
+        "zkhip_recursion_n_aux": (sz, [vp]),
         "zkhip_recursion_fork": (C.c_int, [vp, C.POINTER(vp)]),
         "zkhip_recursion_pad": (C.c_int, [vp, C.POINTER(C.c_uint)]),
         "zkhip_recursion_key_commit": (C.c_int, [u32p, sz, u32p]),
@@ -1211,9 +1214,20 @@ class RecursionCircuit:
     dict(start=[(air, idx)..], end=[(air, idx)..]); uniform=True on a leaf circuit appends the [leaf | internal commitment] words (zero)
     to its public values; min_log_height = (gate chip, Poseidon2 chip) pads."""
 
-    def __init__(self, params, child_airs, max_children, stmt=None, uniform=False, min_log_height=(0, 0), _fork_of=None):
+    def __init__(self, params, child_airs, max_children, stmt=None, uniform=False, min_log_height=(0, 0), _fork_of=None, _join_with=None):
         self.lib = load_library()
         self.params, self.child_airs = tuple(params), child_airs
+        if _join_with is not None:
+            params_b, airs_b = _join_with
+            pa, pb = _Params(*self.params), _Params(*tuple(params_b))
+            arr_a, keep_a = _air_structs(child_airs)
+            arr_b, keep_b = _air_structs(airs_b)
+            h = C.c_void_p()
+            rc = self.lib.zkhip_recursion_build_join(C.byref(pa), arr_a, len(child_airs), C.byref(pb), arr_b, len(airs_b), C.byref(h))
+            if rc != 0:
+                raise ZkhipError("zkhip_recursion_build_join returned %d: %s" % (rc, self.lib.zkhip_recursion_last_error(None).decode()))
+            self._finish(h, 2)
+            return
         if _fork_of is not None:
             h = C.c_void_p()
             assert self.lib.zkhip_recursion_fork(_fork_of.h, C.byref(h)) == 0
@@ -1229,6 +1243,8 @@ class RecursionCircuit:
             st.child_is_node = 1
         elif stmt == "uniform":
             st.child_is_node = 2
+        elif stmt == "deferral":
+            st.child_is_node = 3
         elif stmt:
             cols = [np.ascontiguousarray([x[k] for x in stmt[side]], dtype=np.uint32) for side in ("start", "end") for k in (0, 1)]
             keep2 = cols
@@ -1267,6 +1283,11 @@ class RecursionCircuit:
         self.lib.zkhip_recursion_child_vk_digest(self.h, _u32p(out))
         return out
 
+    @classmethod
+    def join(cls, params_a, airs_a, params_b, airs_b):
+        """zkhip_recursion_build_join: child 0 = a guest flow's root under aggregation key A, child 1 = the deferral node's proof (key B)."""
+        return cls(params_a, airs_a, 2, _join_with=(params_b, airs_b))
+
     def fork(self):
         """A second user of the same circuit (shared wiring, own witness)."""
         return RecursionCircuit(self.params, self.child_airs, self.max_children, _fork_of=self)
@@ -1280,7 +1301,7 @@ class RecursionCircuit:
     def log_heights(self):
         return [a["log_height"] for a in self.airs()]
 
-    def witness(self, proofs, child_pvs, prep_commits=None, is_leaf=None, leaf_commit=None, internal_commit=None):
+    def witness(self, proofs, child_pvs, prep_commits=None, is_leaf=None, leaf_commit=None, internal_commit=None, aux=None, acc_start=None):
         """proofs: list of bytes; child_pvs[c][a]: public values of AIR a of child c.  Returns (status, node public values).
         A uniform circuit also takes prep_commits[c] (the three preprocessed commitments of child c's key, 3 x 8 words), is_leaf[c] and
         the two circuit commitments (key_commit) it states."""
@@ -1295,6 +1316,12 @@ class RecursionCircuit:
             rows.append(C.cast(pa, C.POINTER(C.POINTER(C.c_uint32))))
         pv = (C.POINTER(C.POINTER(C.c_uint32)) * n)(*rows)
         out = np.zeros(self.n_pvs, dtype=np.uint32)
+        if aux is not None:   # a deferral node: the openings of the children's public values + the chain's value before this node
+            ax = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32).reshape(-1) for x in aux]), dtype=np.uint32)
+            a0 = np.ascontiguousarray(acc_start if acc_start is not None else np.zeros(8), dtype=np.uint32)
+            assert ax.size == n * self.lib.zkhip_recursion_n_aux(self.h) and a0.size == 8
+            rc = self.lib.zkhip_recursion_witness_deferral(self.h, pp, lens, pv, _u32p(ax), _u32p(a0), n, _u32p(out))
+            return rc, out
         if prep_commits is not None:
             pc = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32).reshape(-1) for x in prep_commits]), dtype=np.uint32)
             kinds = (C.c_int * n)(*[1 if x else 0 for x in is_leaf])

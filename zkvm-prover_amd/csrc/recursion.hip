@@ -1003,8 +1003,12 @@ using namespace zk::rec;
 // What is fixed when the circuit is built (shared by every fork: zkhip_recursion_fork) ...
 struct RecCore {
     ChildVk vk;
+    std::unique_ptr<ChildVk> vk_b;   // join: the key of slot 1 (the deferral node's)
+    const ChildVk& vk_of(size_t slot) const { return mode == 4 && slot == 1 ? *vk_b : vk; }
     StmtSpec spec;
-    int mode = 0;          // 0 = leaf (children: proofs of a fixed key), 1 = node of the level below (per-depth keys), 2 = uniform node (one key)
+    // 0 = leaf (children: proofs of a fixed key), 1 = node of the level below (per-depth keys), 2 = uniform node (one key),
+    // 3 = deferral node (children: root proofs under a fixed aggregation key), 4 = join (a root + a deferral node proof)
+    int mode = 0;
     bool uniform = false;  // public values end with [leaf commitment (8) | internal commitment (8)]
     size_t max_children = 0, n_state = 0;
     Circuit c;
@@ -1163,22 +1167,12 @@ void build_programs(RecCore& K, const unsigned min_log[2]) {
 
 }  // namespace
 
-extern "C" {
-
-int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, size_t max_children, const zkhip_recursion_stmt* stmt,
-                          zkhip_recursion** out) {
-    if (!prm || !airs || !out || n_airs == 0 || max_children == 0 || max_children > 8 || !stmt) return ZKHIP_ERR_INVALID;
-    *out = nullptr;
+// reads one child verifying key: programs, heights, commitments, the digest of its transcript preamble, the shape of its proofs
+static int load_child_vk(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, bool commitments_are_values, ChildVk& vk) {
+    if (!prm || !airs || n_airs == 0) return ZKHIP_ERR_INVALID;
     if (prm->log_final_poly_len > ZKHIP_MAX_LOG_FINAL_POLY || prm->log_blowup < 1 || prm->log_blowup > 4 || prm->num_queries == 0 ||
         prm->commit_pow_bits > 30 || prm->query_pow_bits > 30)
         return ZKHIP_ERR_INVALID;
-    if (stmt->child_is_node < 0 || stmt->child_is_node > 2) return ZKHIP_ERR_INVALID;
-    std::unique_ptr<zkhip_recursion> R(new zkhip_recursion());
-    R->k.reset(new RecCore());
-    RecCore& K = *R->k;
-    K.mode = stmt->child_is_node;
-    K.uniform = K.mode == 2 || (K.mode == 0 && stmt->uniform);
-    ChildVk& vk = K.vk;
     vk.prm = *prm;
     vk.programs.resize(n_airs), vk.pg.resize(n_airs), vk.prep_commit.resize(n_airs), vk.has_prep.assign(n_airs, 0);
     for (size_t a = 0; a < n_airs; a++) {
@@ -1190,7 +1184,7 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
         if (vk.pg[a].n_pvs != airs[a].n_pvs || airs[a].log_height + prm->log_blowup > 27 || airs[a].log_height < prm->log_final_poly_len) return ZKHIP_ERR_INVALID;
         if (vk.pg[a].log_qd() > prm->log_blowup) return ZKHIP_ERR_CONSTRAINT;
         vk.log_heights.push_back(airs[a].log_height), vk.widths.push_back(airs[a].width), vk.n_pvs.push_back(airs[a].n_pvs);
-        if (vk.pg[a].prep_width && K.mode == 2) {
+        if (vk.pg[a].prep_width && commitments_are_values) {
             vk.has_prep[a] = 1;   // (the commitments are values of the circuit, not part of the key it is built for)
         } else if (vk.pg[a].prep_width) {
             if (!airs[a].prep_commit) return ZKHIP_ERR_INVALID;
@@ -1212,58 +1206,51 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
             p2_hash_slice(pm.data(), pm.size(), dg);
             pre.push_back(vk.log_heights[a]), pre.push_back((uint32_t)vk.widths[a]), pre.push_back((uint32_t)vk.n_pvs[a]);
             for (int i = 0; i < 8; i++) pre.push_back(from_monty(dg[i]));
-            if (vk.has_prep[a] && K.mode != 2)
+            if (vk.has_prep[a] && !commitments_are_values)
                 for (int i = 0; i < 8; i++) pre.push_back(vk.prep_commit[a][i]);
         }
         for (auto& w : pre) w = to_monty(w);
         p2_hash_slice(pre.data(), pre.size(), vk.digest);
     }
-    // statement layout
-    StmtSpec& sp = K.spec;
-    sp.child_is_node = stmt->child_is_node != 0;
-    if (sp.child_is_node) {
-        // the child is a node circuit: its last AIR is the public-value chip with [vk(8) start(K) end(K) acc(8)] (+ [leaf commitment (8) |
-        // internal commitment (8)] under one key)
-        const size_t np = vk.n_pvs[n_airs - 1], fixed = K.mode == 2 ? 32 : 16;
-        if (np < fixed || (np - fixed) % 2) return ZKHIP_ERR_INVALID;
-        if (K.mode == 2 && n_airs != 3) return ZKHIP_ERR_INVALID;
-        K.n_state = (np - fixed) / 2;
-        for (size_t k = 0; k < K.n_state; k++) {
-            sp.start.push_back({(uint32_t)n_airs - 1, (uint32_t)(8 + k)});
-            sp.end.push_back({(uint32_t)n_airs - 1, (uint32_t)(8 + K.n_state + k)});
-        }
-    } else {
-        if (stmt->n_state > 16 || (stmt->n_state && (!stmt->start_air || !stmt->start_idx || !stmt->end_air || !stmt->end_idx))) return ZKHIP_ERR_INVALID;
-        K.n_state = stmt->n_state;
-        for (size_t k = 0; k < stmt->n_state; k++) {
-            if (stmt->start_air[k] >= n_airs || stmt->start_idx[k] >= vk.n_pvs[stmt->start_air[k]] || stmt->end_air[k] >= n_airs ||
-                stmt->end_idx[k] >= vk.n_pvs[stmt->end_air[k]])
-                return ZKHIP_ERR_INVALID;
-            sp.start.push_back({stmt->start_air[k], stmt->start_idx[k]});
-            sp.end.push_back({stmt->end_air[k], stmt->end_idx[k]});
-        }
+    std::vector<zkhip_air> za(airs, airs + n_airs);
+    zkhip_proof_layout lay;
+    if (zkhip_proof_layout_of(prm, za.data(), n_airs, &lay) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
+    vk.proof_words = lay.n_words;
+    unsigned hmax = 0;
+    bool lu = false, prep = false, cached = false;
+    for (size_t a = 0; a < n_airs; a++) {
+        hmax = std::max(hmax, vk.log_heights[a] + prm->log_blowup);
+        lu |= !vk.pg[a].ints.empty(), prep |= vk.pg[a].prep_width != 0, cached |= vk.pg[a].cached_width != 0;
     }
-    K.max_children = max_children;
-    {
-        std::vector<zkhip_air> za(airs, airs + n_airs);
-        zkhip_proof_layout lay;
-        if (zkhip_proof_layout_of(prm, za.data(), n_airs, &lay) != ZKHIP_OK) return ZKHIP_ERR_INVALID;
-        K.child_proof_words = vk.proof_words = lay.n_words;
-        unsigned hmax = 0;
-        bool lu = false, prep = false, cached = false;
-        for (size_t a = 0; a < n_airs; a++) {
-            hmax = std::max(hmax, vk.log_heights[a] + prm->log_blowup);
-            lu |= !vk.pg[a].ints.empty(), prep |= vk.pg[a].prep_width != 0, cached |= vk.pg[a].cached_width != 0;
-        }
-        vk.header[0] = PROOF_MAGIC + (lu ? 1u : 0u) + (prep ? 2u : 0u) + (cached ? 4u : 0u);
-        vk.header[1] = (uint32_t)n_airs, vk.header[2] = hmax, vk.header[3] = hmax - prm->log_blowup - prm->log_final_poly_len;
-    }
+    vk.header[0] = PROOF_MAGIC + (lu ? 1u : 0u) + (prep ? 2u : 0u) + (cached ? 4u : 0u);
+    vk.header[1] = (uint32_t)n_airs, vk.header[2] = hmax, vk.header[3] = hmax - prm->log_blowup - prm->log_final_poly_len;
+    return ZKHIP_OK;
+}
+
+// zkhip_recursion_key_commit of a fixed key, as a constant of the circuit (two packed wires)
+static std::array<V, 2> key_commit_const(const ChildVk& vk) {
+    std::vector<uint32_t> w;
+    for (size_t a = 0; a < vk.pg.size(); a++)
+        if (vk.has_prep[a])
+            for (int k = 0; k < 8; k++) w.push_back(to_monty(vk.prep_commit[a][k]));
+    uint32_t dg[8];
+    p2_hash_slice(w.data(), w.size(), dg);
+    return {cst(Ext{{dg[0], dg[1], dg[2], dg[3]}}), cst(Ext{{dg[4], dg[5], dg[6], dg[7]}})};
+}
+
+// The statement logic behind the verified children, then the public-value binding and the parallelism check.
+static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min_log_height, zkhip_recursion** out) {
+    RecCore& K = *R->k;
+    const size_t max_children = K.max_children;
+    const StmtSpec& sp = K.spec;
     try {
         Builder b;
         const size_t NS = K.n_state;
         std::vector<ChildValues> kids;
         std::vector<std::vector<std::array<V, 8>>> prep_in(max_children);   // uniform node: the children's preprocessed commitments
         for (size_t ci = 0; ci < max_children; ci++) {
+            const ChildVk& vk = K.vk_of(ci);
+            const size_t n_airs = vk.pg.size();
             b.close_input_rows();
             b.c.sections.push_back(b.c.order.size());
             if (K.mode == 2) {
@@ -1280,6 +1267,23 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
         }
         b.close_input_rows();
         b.c.sections.push_back(b.c.order.size());
+        const ChildVk& vk = K.vk;
+        const size_t n_airs = vk.pg.size();
+        std::vector<Lane> pvl;   // the node's public values
+        auto pack8 = [&](const V* v) { return std::array<V, 2>{b.pack({v[0], v[1], v[2], v[3]}), b.pack({v[4], v[5], v[6], v[7]})}; };
+        if (K.mode == 4) {
+            // JOIN (a batch-like proof = the guest's root + the proof of what it deferred): slot 0 is a root under aggregation key A
+            // (its internal commitment must be A's own), slot 1 a deferral node whose chain starts at zero.  Public values: the root's
+            // statement, then the deferral accumulator -- the verifier opens the guest's claims in the final memory root and hashes them.
+            const std::vector<V>& rp = kids[0].pvs[K.vk.pg.size() - 1];
+            const std::vector<V>& dp = kids[1].pvs[K.vk_b->pg.size() - 1];
+            const std::array<V, 2> ic = key_commit_const(K.vk);
+            const std::array<V, 2> got = pack8(&rp[rp.size() - 8]);
+            for (int k = 0; k < 2; k++) b.assert_eq(got[k], ic[k]);
+            for (int k = 0; k < 8; k++) b.assert_zero(dp[k]);
+            for (const V& v : rp) pvl.push_back(Lane{v, -1});
+            for (int k = 0; k < 8; k++) pvl.push_back(Lane{dp[8 + k], -1});
+        } else {
         // presence flags: child 0 is present, present children form a prefix
         std::vector<V> flag(max_children);
         flag[0] = cst(ext_one());
@@ -1290,6 +1294,59 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
             b.assert_bool(flag[ci]);
             if (ci > 1) b.assert_product_zero(flag[ci], b.lin(0, flag[ci - 1], V{}, b.NEG1, 0, V{}, 0, ext_one()));
         }
+        if (K.mode == 3) {
+            // DEFERRAL NODE (crates/prover/src/prover/mod.rs:200-282 VerifyProver; crates/types/circuit/src/lib.rs:137-154 verify_stark):
+            // every child is a ROOT proof under the fixed aggregation key of the child app.  Per child the circuit derives the claim a
+            // parent guest makes about it -- input commitment (sponge of the root's statement), exe commitment (entry pc, initial memory
+            // root), vm commitment (app-vk digest, leaf commitment), the 32 public-value bytes opened in the final memory root (their 16
+            // cells and the 27 siblings above the block pair are auxiliary inputs) -- requires exit code 0 and the key's own internal
+            // commitment, and chains acc <- compress(acc, chunk) over the claim's five 8-element chunks.
+            const size_t pa = n_airs - 1, NSc = 9;
+            const std::array<V, 2> ic = key_commit_const(vk);
+            std::array<V, 8> acc0;
+            for (uint32_t k = 0; k < 8; k++) {
+                Src sr;
+                sr.kind = S_COMMIT, sr.a = 2, sr.b = k;
+                acc0[k] = b.in_base(sr);
+            }
+            std::array<V, 2> acc = pack8(acc0.data());
+            for (size_t ci = 0; ci < max_children; ci++) {
+                const std::vector<V>& pv = kids[ci].pvs[pa];
+                const V* app = &pv[0];
+                const V pc_start = pv[8], pc_end = pv[8 + NSc];
+                const V *root0 = &pv[9], *root1 = &pv[9 + NSc], *lc = &pv[16 + 2 * NSc], *icv = &pv[24 + 2 * NSc];
+                const std::array<V, 2> got_ic = pack8(icv);
+                for (int k = 0; k < 2; k++) b.assert_eq(got_ic[k], ic[k]);
+                b.assert_zero(pc_end);
+                std::vector<V> aux(K.n_aux);
+                for (uint32_t i = 0; i < K.n_aux; i++) {
+                    Src sr;
+                    sr.kind = S_AUX, sr.child = (uint32_t)ci, sr.a = i;
+                    aux[i] = b.in_base(sr);
+                }
+                const V zero = cst(ext_zero());
+                const std::array<V, 2> z2{zero, zero};
+                const std::array<V, 2> cells0 = pack8(&aux[0]), cells1 = pack8(&aux[8]);
+                std::array<V, 2> cur = b.compress(b.compress(cells0, z2), b.compress(cells1, z2));   // the two public-value blocks are siblings
+                uint32_t idx = (3u << 26) >> 1;
+                for (unsigned l = 27; l > 0; l--, idx >>= 1) {
+                    const std::array<V, 2> sib = pack8(&aux[16 + 8 * (27 - l)]);
+                    cur = (idx & 1u) ? b.compress(sib, cur) : b.compress(cur, sib);
+                }
+                const std::array<V, 2> r1 = pack8(root1);
+                for (int k = 0; k < 2; k++) b.assert_eq(cur[k], r1[k]);
+                std::vector<Lane> stmt_lanes;
+                for (const V& v : pv) stmt_lanes.push_back(Lane{v, -1});
+                const std::array<V, 2> input_commit = b.sponge(stmt_lanes);
+                const std::array<V, 2> exe_commit = b.compress(pack8(root0), {b.pack({pc_start, zero, zero, zero}), zero});
+                const std::array<V, 2> vm_commit = b.compress(pack8(app), pack8(lc));
+                std::array<V, 2> nx = acc;
+                for (const std::array<V, 2>& chunk : {input_commit, exe_commit, vm_commit, cells0, cells1}) nx = b.compress(nx, chunk);
+                for (int k = 0; k < 2; k++) acc[k] = b.select(flag[ci], nx[k], acc[k]);
+            }
+            for (int k = 0; k < 8; k++) pvl.push_back(Lane{acc0[k], -1});
+            Builder::ext_lanes(acc[0], &pvl), Builder::ext_lanes(acc[1], &pvl);
+        } else {
         auto pv_of = [&](size_t ci, const std::pair<uint32_t, uint32_t>& at) { return kids[ci].pvs[at.first][at.second]; };
         // app vk digest: the constant digest of the child vk (leaf level) or what the children carry (all equal)
         std::array<V, 8> vkd;
@@ -1364,7 +1421,6 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
         }
         // public values of the node: [vk(8) start(K) end(K) acc(8)] (+ [leaf commitment (8) | internal commitment (8)] under one key: zero
         // at a leaf, whose proofs must have the public-value layout of the internal circuit's), bound four at a time
-        std::vector<Lane> pvl;
         for (int k = 0; k < 8; k++) pvl.push_back(Lane{vkd[k], -1});
         for (size_t k = 0; k < NS; k++) pvl.push_back(Lane{start[k], -1});
         for (size_t k = 0; k < NS; k++) pvl.push_back(Lane{end[k], -1});
@@ -1372,6 +1428,8 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
         if (K.uniform) {
             for (int k = 0; k < 8; k++) pvl.push_back(Lane{leaf_commit[k], -1});
             for (int k = 0; k < 8; k++) pvl.push_back(Lane{internal_commit[k], -1});
+        }
+        }
         }
         b.c.n_pvs = pvl.size();
         while (pvl.size() % 4) pvl.push_back(Lane{cst(ext_zero()), -1});
@@ -1426,9 +1484,84 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
         g_build_error = e.msg;
         return ZKHIP_ERR_INVALID;
     }
-    build_programs(K, stmt->min_log_height);
+    build_programs(K, min_log_height);
     *out = R.release();
     return ZKHIP_OK;
+}
+
+extern "C" {
+
+int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, size_t max_children, const zkhip_recursion_stmt* stmt,
+                          zkhip_recursion** out) {
+    if (!prm || !airs || !out || n_airs == 0 || max_children == 0 || max_children > 8 || !stmt) return ZKHIP_ERR_INVALID;
+    *out = nullptr;
+    if (stmt->child_is_node < 0 || stmt->child_is_node > 3) return ZKHIP_ERR_INVALID;
+    std::unique_ptr<zkhip_recursion> R(new zkhip_recursion());
+    R->k.reset(new RecCore());
+    RecCore& K = *R->k;
+    K.mode = stmt->child_is_node;
+    K.uniform = K.mode == 2 || (K.mode == 0 && stmt->uniform);
+    ChildVk& vk = K.vk;
+    {
+        const int rc = load_child_vk(prm, airs, n_airs, K.mode == 2, vk);
+        if (rc != ZKHIP_OK) return rc;
+    }
+    // statement layout
+    StmtSpec& sp = K.spec;
+    sp.child_is_node = K.mode == 1 || K.mode == 2;
+    if (K.mode == 3) {
+        // the children are ROOT proofs of a guest flow under one aggregation key: [app (8) | pc, memory root | pc, memory root | acc (8) | leaf (8) | internal (8)]
+        if (n_airs != 3 || vk.n_pvs[2] != 8 + 9 + 9 + 8 + 16 || !vk.has_prep[0] || !vk.has_prep[1] || !vk.has_prep[2]) return ZKHIP_ERR_INVALID;
+        K.n_state = 8;
+        K.n_aux = 16 + 27 * 8;
+    } else if (sp.child_is_node) {
+        // the child is a node circuit: its last AIR is the public-value chip with [vk(8) start(K) end(K) acc(8)] (+ [leaf commitment (8) |
+        // internal commitment (8)] under one key)
+        const size_t np = vk.n_pvs[n_airs - 1], fixed = K.mode == 2 ? 32 : 16;
+        if (np < fixed || (np - fixed) % 2) return ZKHIP_ERR_INVALID;
+        if (K.mode == 2 && n_airs != 3) return ZKHIP_ERR_INVALID;
+        K.n_state = (np - fixed) / 2;
+        for (size_t k = 0; k < K.n_state; k++) {
+            sp.start.push_back({(uint32_t)n_airs - 1, (uint32_t)(8 + k)});
+            sp.end.push_back({(uint32_t)n_airs - 1, (uint32_t)(8 + K.n_state + k)});
+        }
+    } else {
+        if (stmt->n_state > 16 || (stmt->n_state && (!stmt->start_air || !stmt->start_idx || !stmt->end_air || !stmt->end_idx))) return ZKHIP_ERR_INVALID;
+        K.n_state = stmt->n_state;
+        for (size_t k = 0; k < stmt->n_state; k++) {
+            if (stmt->start_air[k] >= n_airs || stmt->start_idx[k] >= vk.n_pvs[stmt->start_air[k]] || stmt->end_air[k] >= n_airs ||
+                stmt->end_idx[k] >= vk.n_pvs[stmt->end_air[k]])
+                return ZKHIP_ERR_INVALID;
+            sp.start.push_back({stmt->start_air[k], stmt->start_idx[k]});
+            sp.end.push_back({stmt->end_air[k], stmt->end_idx[k]});
+        }
+    }
+    K.max_children = max_children;
+    K.child_proof_words = vk.proof_words;
+    return finish_build(R, stmt->min_log_height, out);
+}
+
+// The JOIN circuit of a guest that defers verification (crates/prover/src/prover/mod.rs:200-282 `enable_deferral`): child 0 = the guest's
+// root proof under aggregation key A (params_a / airs_a: the internal circuit's key, commitments included), child 1 = the proof of the
+// deferral node (params_b / airs_b) that verified the child proofs the guest makes claims about.  Public values: the root's statement
+// followed by the deferral accumulator (8).
+int zkhip_recursion_build_join(const zkhip_params* params_a, const zkhip_air* airs_a, size_t n_airs_a, const zkhip_params* params_b,
+                               const zkhip_air* airs_b, size_t n_airs_b, zkhip_recursion** out) {
+    if (!out) return ZKHIP_ERR_INVALID;
+    *out = nullptr;
+    std::unique_ptr<zkhip_recursion> R(new zkhip_recursion());
+    R->k.reset(new RecCore());
+    RecCore& K = *R->k;
+    K.mode = 4;
+    K.vk_b.reset(new ChildVk());
+    int rc = load_child_vk(params_a, airs_a, n_airs_a, false, K.vk);
+    if (rc == ZKHIP_OK) rc = load_child_vk(params_b, airs_b, n_airs_b, false, *K.vk_b);
+    if (rc != ZKHIP_OK) return rc;
+    if (n_airs_a != 3 || K.vk.n_pvs[2] < 32 || !K.vk.has_prep[0] || !K.vk.has_prep[1] || !K.vk.has_prep[2] || K.vk_b->n_pvs[n_airs_b - 1] != 16) return ZKHIP_ERR_INVALID;
+    K.max_children = 2;
+    K.child_proof_words = K.vk.proof_words;
+    const unsigned none[2] = {0, 0};
+    return finish_build(R, none, out);
 }
 
 void zkhip_recursion_destroy(zkhip_recursion* R) {
@@ -1520,13 +1653,23 @@ struct UniformIn {
     const int* is_leaf;             // [child]
     const uint32_t *leaf_commit, *internal_commit;
 };
+// ... and a deferral node about its
+struct DeferralIn {
+    const uint32_t* aux;         // [child][16 public-value cells | 27 x 8 sibling digests above the block pair, bottom-up], canonical
+    const uint32_t* acc_start;   // the chain's value before this node's children
+};
 int recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const size_t* proof_lens, const uint32_t* const* const* child_pvs,
-                      size_t n_present, uint32_t* node_pvs_out, const UniformIn* uni) {
+                      size_t n_present, uint32_t* node_pvs_out, const UniformIn* uni, const DeferralIn* def = nullptr) {
     if (!R || !proofs || !proof_lens || n_present == 0 || n_present > R->k->max_children) return ZKHIP_ERR_INVALID;
     const RecCore& K = *R->k;
-    if ((K.mode == 2) != (uni != nullptr)) {
-        R->error = K.mode == 2 ? "a uniform node circuit takes its children's commitments and kinds (zkhip_recursion_witness_uniform)"
-                               : "this circuit is built for one child verifying key (zkhip_recursion_witness)";
+    if ((K.mode == 2) != (uni != nullptr) || (K.mode == 3) != (def != nullptr)) {
+        R->error = K.mode == 2   ? "a uniform node circuit takes its children's commitments and kinds (zkhip_recursion_witness_uniform)"
+                   : K.mode == 3 ? "a deferral node circuit takes the openings of its children's public values (zkhip_recursion_witness_deferral)"
+                                 : "this circuit is built for one child verifying key (zkhip_recursion_witness)";
+        return ZKHIP_ERR_INVALID;
+    }
+    if (K.mode == 4 && n_present != 2) {
+        R->error = "a join takes the root proof and the deferral node's proof";
         return ZKHIP_ERR_INVALID;
     }
     size_t n_prep_airs = 0;
@@ -1540,32 +1683,40 @@ int recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const si
         for (int k = 0; k < 8; k++)
             if (uni->leaf_commit[k] >= P || uni->internal_commit[k] >= P) return ZKHIP_ERR_INVALID;
     }
+    if (def) {
+        if (!def->aux || !def->acc_start) return ZKHIP_ERR_INVALID;
+        for (size_t i = 0; i < K.n_aux * n_present; i++)
+            if (def->aux[i] >= P) return ZKHIP_ERR_INVALID;
+        for (int k = 0; k < 8; k++)
+            if (def->acc_start[k] >= P) return ZKHIP_ERR_INVALID;
+    }
     const Circuit& c = K.c;
-    const size_t n_airs = K.vk.pg.size();
     std::vector<const uint32_t*> pw(K.max_children);
     for (size_t ci = 0; ci < K.max_children; ci++) {
         const size_t src = ci < n_present ? ci : 0;
-        if (!proofs[src] || proof_lens[src] != 4 * K.child_proof_words) {
+        const ChildVk& cvk = K.vk_of(ci);
+        if (!proofs[src] || proof_lens[src] != 4 * cvk.proof_words) {
             R->error = "child proof " + std::to_string(src) + " has the wrong size for this circuit's child verifying key";
             return ZKHIP_ERR_INVALID;
         }
         pw[ci] = reinterpret_cast<const uint32_t*>(proofs[src]);
-        for (size_t a = 0; a < n_airs; a++)
-            if (K.vk.n_pvs[a] && (!child_pvs || !child_pvs[src] || !child_pvs[src][a])) return ZKHIP_ERR_INVALID;
+        for (size_t a = 0; a < cvk.pg.size(); a++)
+            if (cvk.n_pvs[a] && (!child_pvs || !child_pvs[src] || !child_pvs[src][a])) return ZKHIP_ERR_INVALID;
     }
     for (size_t ci = 0; ci < n_present; ci++) {
+        const ChildVk& cvk = K.vk_of(ci);
         // the shape words are not part of the transcript: they are fixed by the child verifying key and checked here
-        if (memcmp(pw[ci], K.vk.header, 16) != 0) {
+        if (memcmp(pw[ci], cvk.header, 16) != 0) {
             R->error = "child proof " + std::to_string(ci) + " does not have the shape of this circuit's child verifying key";
             return ZKHIP_ERR_VERIFY;
         }
-        for (size_t i = 0; i < K.child_proof_words; i++)
+        for (size_t i = 0; i < cvk.proof_words; i++)
             if (pw[ci][i] >= P) {
                 R->error = "child proof word not canonical";
                 return ZKHIP_ERR_VERIFY;
             }
-        for (size_t a = 0; a < n_airs; a++)
-            for (size_t i = 0; i < K.vk.n_pvs[a]; i++)
+        for (size_t a = 0; a < cvk.pg.size(); a++)
+            for (size_t i = 0; i < cvk.n_pvs[a]; i++)
                 if (child_pvs[ci][a][i] >= P) return ZKHIP_ERR_INVALID;
     }
     WireBuf& vals = R->vals;
@@ -1617,7 +1768,8 @@ int recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const si
                             case S_FLAG: v.c[0] = sr.child < n_present ? MONTY_ONE : 0; break;
                             case S_PREP: v.c[0] = to_monty(uni->prep_commits[((sr.child < n_present ? sr.child : 0) * n_prep_airs + prep_slot[sr.a]) * 8 + sr.b]); break;
                             case S_KIND: v.c[0] = uni->is_leaf[sr.child < n_present ? sr.child : 0] ? MONTY_ONE : 0; break;
-                            case S_COMMIT: v.c[0] = to_monty((sr.a ? uni->internal_commit : uni->leaf_commit)[sr.b]); break;
+                            case S_COMMIT: v.c[0] = to_monty((sr.a == 2 ? def->acc_start : sr.a ? uni->internal_commit : uni->leaf_commit)[sr.b]); break;
+                            case S_AUX: v.c[0] = to_monty(def->aux[(sr.child < n_present ? sr.child : 0) * K.n_aux + sr.a]); break;
                             case S_HINT_BIT: v.c[0] = ((from_monty(vals[sr.a].c[0]) >> sr.b) & 1) ? MONTY_ONE : 0; break;
                             case S_HINT_COORD: v.c[0] = vals[sr.a].c[sr.b]; break;
                             default: break;
@@ -1756,6 +1908,16 @@ int zkhip_recursion_witness_uniform(zkhip_recursion* R, const uint8_t* const* pr
     const UniformIn uni{child_prep_commits, child_is_leaf, leaf_commit, internal_commit};
     return recursion_witness(R, proofs, proof_lens, child_pvs, n_present, node_pvs_out, &uni);
 }
+
+// The witness of a DEFERRAL node (zkhip_recursion_stmt.child_is_node = 3): child c is a guest flow's root proof; child_aux[c] = the 16 cells of
+// its two public-value blocks (bytes 2 j, 2 j + 1 of the 32 public-value bytes = cell j) and the 27 sibling digests above the block pair
+// in its final memory root, bottom-up (232 canonical words); acc_start = the claim chain before this node (zero for the first node).
+int zkhip_recursion_witness_deferral(zkhip_recursion* R, const uint8_t* const* proofs, const size_t* proof_lens, const uint32_t* const* const* child_pvs,
+                                     const uint32_t* child_aux, const uint32_t acc_start[8], size_t n_present, uint32_t* node_pvs_out) {
+    const DeferralIn def{child_aux, acc_start};
+    return recursion_witness(R, proofs, proof_lens, child_pvs, n_present, node_pvs_out, nullptr, &def);
+}
+size_t zkhip_recursion_n_aux(const zkhip_recursion* R) { return R ? R->k->n_aux : 0; }
 
 // wire values of the last witness call, canonical: [n_wires + 1][4] (wire 0 unused).  Host-side twin data for the oracle's
 // trace generators (tests) -- the product path keeps them inside and goes through zkhip_recursion_tracegen.
