@@ -43,6 +43,9 @@ struct VerifyingKey {
     std::vector<unsigned> heights;  // fixed trace heights
     // an AGGREGATION key also pins what the root must state beneath it: the leaf circuit's commitment (-> the app) and the app-vk digest
     std::vector<uint32_t> leaf_commit, app_digest;   // 8 words each, empty on any other key
+    // a JOIN key (deferral: the root's statement is followed by the deferral accumulator; the internal commitment of the tree beneath is
+    // pinned inside the join circuit, not by this key's own commitments)
+    bool join = false;
 
     std::vector<zkhip_air> as_airs() const {
         std::vector<zkhip_air> za(airs.size());
@@ -64,7 +67,7 @@ struct VerifyingKey {
     }
     // the app-file form (encode_app_exe, tables omitted): UniversalVerifier::setup reads it back.  An aggregation key appends
     // [AGGKEY_MAGIC | leaf commitment (8) | app-vk digest (8)] (readers of the app-file form stop before it).
-    static constexpr uint32_t AGGKEY_MAGIC = 0x4B474741u;
+    static constexpr uint32_t AGGKEY_MAGIC = 0x4B474741u, JOINKEY_MAGIC = 0x4B4E4F4Au;
     std::vector<uint8_t> to_app_exe() const {
         std::vector<AirDesc> a = airs;
         for (size_t i = 0; i < a.size(); i++) {
@@ -73,7 +76,7 @@ struct VerifyingKey {
         }
         std::vector<uint8_t> out = encode_app_exe(a);
         if (leaf_commit.size() == 8 && app_digest.size() == 8) {
-            std::vector<uint32_t> t{AGGKEY_MAGIC};
+            std::vector<uint32_t> t{join ? JOINKEY_MAGIC : AGGKEY_MAGIC};
             t.insert(t.end(), leaf_commit.begin(), leaf_commit.end()), t.insert(t.end(), app_digest.begin(), app_digest.end());
             const uint8_t* b = reinterpret_cast<const uint8_t*>(t.data());
             out.insert(out.end(), b, b + 4 * t.size());
@@ -91,7 +94,7 @@ struct VerifyingKey {
         if (raw.size() == used + 4 * 17) {
             uint32_t t[17];
             memcpy(t, raw.data() + used, sizeof t);
-            if (t[0] == AGGKEY_MAGIC) vk.leaf_commit.assign(t + 1, t + 9), vk.app_digest.assign(t + 9, t + 17);
+            if (t[0] == AGGKEY_MAGIC || t[0] == JOINKEY_MAGIC) vk.leaf_commit.assign(t + 1, t + 9), vk.app_digest.assign(t + 9, t + 17), vk.join = t[0] == JOINKEY_MAGIC;
         }
         return vk;
     }
@@ -116,10 +119,11 @@ struct VerifyingKey {
             return false;
         };
         if (!is_aggregation_key()) return fail("not an aggregation key (no leaf commitment / app digest)");
-        if (root_pvs.size() < 32) return fail("the root statement is too short for an aggregation key");
-        const size_t n = root_pvs.size();
+        if (root_pvs.size() < 32 + (join ? 8u : 0u)) return fail("the root statement is too short for an aggregation key");
+        const size_t n = root_pvs.size() - (join ? 8 : 0);   // (a join's statement ends with the deferral accumulator)
         if (!std::equal(app_digest.begin(), app_digest.end(), root_pvs.begin())) return fail("the root is not about this app (app verifying-key digest)");
         if (!std::equal(leaf_commit.begin(), leaf_commit.end(), root_pvs.begin() + (n - 16))) return fail("the tree's leaves are not proofs of this key's leaf circuit");
+        if (join) return true;   // (the join circuit requires the internal commitment of the key it was built for)
         const std::vector<uint32_t> ic = key_commit();
         if (!std::equal(ic.begin(), ic.end(), root_pvs.begin() + (n - 8))) return fail("the tree's internal nodes are not proofs of this key's internal circuit");
         return true;
@@ -747,6 +751,276 @@ private:
             std::lock_guard<std::mutex> lk(*levels_mu_);
             levels_.push_back(std::move(L));
         }
+    }
+};
+
+
+// ---- deferral (crates/prover/src/prover/mod.rs:200-282 `enable_deferral`; crates/integration/src/lib.rs:461-514 `compute_deferral_data`;
+//      guest side crates/types/circuit/src/lib.rs:137-154 `verify_stark::<0>(input_commit, &expected)`) ---------------------------------------
+// A parent guest (batch over chunks, bundle over batches) does not verify its children's proofs itself: it STATES claims -- "the proof
+// with this input commitment verifies, for the program with this exe / vm commitment, with these public values" -- and the proof system
+// backs every claim with a verified child proof.  Here a claim is 32 words the guest stores in its deferral region (see
+// zkhip_vm::deferral_base): [input commitment (8) | exe commitment (8) | vm commitment (8) | the child's 32 public-value bytes (8 words)];
+// the DEFERRAL NODE (zkhip_recursion_stmt.child_is_node = 3) verifies the child root proofs under the child app's aggregation key, derives
+// the same 32 words from each proof and chains them; the JOIN (zkhip_recursion_build_join) verifies the guest's own root and the deferral
+// node's proof and states [root statement | chain]; the verifier opens the region in the guest's final memory root and hashes it.
+using Digest8 = std::array<uint32_t, 8>;
+inline Digest8 p2_compress8(const Digest8& l, const Digest8& r) {
+    uint32_t st[16];
+    for (int i = 0; i < 8; i++) st[i] = l[i], st[8 + i] = r[i];
+    zkhip_poseidon2_permute_host(st);
+    Digest8 d;
+    std::copy(st, st + 8, d.begin());
+    return d;
+}
+inline Digest8 p2_sponge8(const uint32_t* v, size_t n) {   // PaddingFreeSponge<16, 8, 8>: overwrite, permute, no padding
+    uint32_t st[16] = {};
+    for (size_t i = 0; i < n; i += 8) {
+        for (size_t k = 0; k < 8 && i + k < n; k++) st[k] = v[i + k];
+        zkhip_poseidon2_permute_host(st);
+    }
+    Digest8 d;
+    std::copy(st, st + 8, d.begin());
+    return d;
+}
+// the program commitments a parent guest holds about a child app (crates/types/circuit/src/lib.rs `ProgramCommitment { exe, vm }`; the
+// reference generates them into crates/circuits/*-circuit/*_commit.rs): exe = compress(initial memory root, entry pc), vm =
+// compress(app-vk digest, leaf-circuit commitment of the app's aggregation key)
+struct ProgramCommitment {
+    Digest8 exe{}, vm{};
+    static ProgramCommitment of(const VerifyingKey& agg_key, uint32_t entry_pc, const Digest8& image_root) {
+        if (!agg_key.is_aggregation_key()) throw Error(Error::Setup, "program commitment: not an aggregation key");
+        ProgramCommitment c;
+        c.exe = p2_compress8(image_root, Digest8{entry_pc, 0, 0, 0, 0, 0, 0, 0});
+        Digest8 app, lc;
+        std::copy(agg_key.app_digest.begin(), agg_key.app_digest.end(), app.begin());
+        std::copy(agg_key.leaf_commit.begin(), agg_key.leaf_commit.end(), lc.begin());
+        c.vm = p2_compress8(app, lc);
+        return c;
+    }
+};
+// one deferred child: its root proof, the root's statement (50 words), the 32 public-value bytes and the sibling digests above the
+// public-value block pair in its final memory root (27 x 8, bottom-up)
+struct DeferralInput {
+    ChildProof root;
+    std::vector<uint8_t> public_values;
+    std::vector<uint32_t> siblings;
+    // from the StarkProof a guest flow returns: user_pvs_proof = [statement (50 words) | 32 bytes | openings of both blocks (2 x 28 x 8)]
+    static DeferralInput from_stark_proof(const StarkProof& sp) {
+        const size_t n_stmt = 50, n_open = 2 * 8 * 28;
+        if (sp.user_pvs_proof.size() != 4 * n_stmt + 32 + 4 * n_open) throw Error(Error::GenProof, "deferral: a child proof is not a guest flow's root (user_pvs_proof size)");
+        DeferralInput d;
+        d.root.proof = sp.proof;
+        d.root.pvs.resize(3);
+        d.root.pvs[2].resize(n_stmt);
+        memcpy(d.root.pvs[2].data(), sp.user_pvs_proof.data(), 4 * n_stmt);
+        d.public_values.assign(sp.user_pvs_proof.begin() + 4 * n_stmt, sp.user_pvs_proof.begin() + 4 * n_stmt + 32);
+        // block 0's opening, bottom-up: its first sibling is block 1's leaf digest (recomputed in-circuit); the 27 above are the pair's
+        d.siblings.resize(27 * 8);
+        memcpy(d.siblings.data(), sp.user_pvs_proof.data() + 4 * n_stmt + 32 + 4 * 8, 4 * 27 * 8);
+        return d;
+    }
+    std::array<uint32_t, 16> cells() const {
+        std::array<uint32_t, 16> c;
+        for (int j = 0; j < 16; j++) c[j] = public_values[2 * j] | ((uint32_t)public_values[2 * j + 1] << 8);
+        return c;
+    }
+    std::vector<uint32_t> aux() const {
+        const std::array<uint32_t, 16> c = cells();
+        std::vector<uint32_t> a(c.begin(), c.end());
+        a.insert(a.end(), siblings.begin(), siblings.end());
+        return a;
+    }
+    // the 32 words of the claim a parent guest states about this child
+    Digest8 input_commit() const { return p2_sponge8(root.pvs[2].data(), root.pvs[2].size()); }
+    std::array<uint32_t, 32> claim_words() const {
+        const std::vector<uint32_t>& s = root.pvs[2];
+        Digest8 app, lc, r0;
+        std::copy(s.begin(), s.begin() + 8, app.begin()), std::copy(s.begin() + 34, s.begin() + 42, lc.begin()), std::copy(s.begin() + 9, s.begin() + 17, r0.begin());
+        const Digest8 ic = input_commit(), exe = p2_compress8(r0, Digest8{s[8], 0, 0, 0, 0, 0, 0, 0}), vm = p2_compress8(app, lc);
+        std::array<uint32_t, 32> w;
+        std::copy(ic.begin(), ic.end(), w.begin()), std::copy(exe.begin(), exe.end(), w.begin() + 8), std::copy(vm.begin(), vm.end(), w.begin() + 16);
+        for (int k = 0; k < 8; k++) memcpy(&w[24 + k], public_values.data() + 4 * k, 4);
+        return w;
+    }
+};
+// acc <- compress(acc, chunk) over the five chunks of a claim: the three commitments as field elements, the public-value words as
+// their 16-bit cells (a word need not be a field element)
+inline bool chain_claim(Digest8& acc, const uint32_t claim[32]) {
+    for (int k = 0; k < 24; k++)
+        if (claim[k] >= 2013265921u) return false;   // a commitment word that is no field element backs nothing
+    for (int c = 0; c < 3; c++) {
+        Digest8 chunk;
+        std::copy(claim + 8 * c, claim + 8 * c + 8, chunk.begin());
+        acc = p2_compress8(acc, chunk);
+    }
+    for (int h = 0; h < 2; h++) {
+        Digest8 chunk;
+        for (int j = 0; j < 4; j++) chunk[2 * j] = claim[24 + 4 * h + j] & 0xffffu, chunk[2 * j + 1] = claim[24 + 4 * h + j] >> 16;
+        acc = p2_compress8(acc, chunk);
+    }
+    return true;
+}
+
+class DeferralProver {
+public:
+    // `child_key`: the CHILD app's aggregation key (crates/prover/src/prover/mod.rs:213 `child_prover.load_agg_vk()`); node_params: the
+    // parameters the deferral node and the join are proven under (mod.rs:239 `internal_params_with_100_bits_security`)
+    static std::unique_ptr<DeferralProver> setup(const VerifyingKey& child_key, const zkhip_params& node_params, int device = 0, size_t max_children = 4) {
+        if (!child_key.is_aggregation_key() || child_key.airs.size() != 3 || child_key.airs[2].n_pvs != 50)
+            throw Error(Error::Setup, "deferral: the child key is not the aggregation key of a guest flow");
+        std::unique_ptr<DeferralProver> p(new DeferralProver());
+        p->child_key_ = child_key, p->params_ = node_params, p->device_ = device, p->max_children_ = max_children;
+        int rc = zkhip_ctx_create(device, &p->ctx_);
+        if (rc != ZKHIP_OK) throw Error(Error::Keygen, "no gfx950 device for the HIP backend (zkhip_ctx_create returned " + std::to_string(rc) + ")");
+        std::vector<zkhip_air> za = child_key.as_airs();
+        zkhip_recursion_stmt st{};
+        st.child_is_node = 3;
+        rc = zkhip_recursion_build(&child_key.params, za.data(), za.size(), max_children, &st, &p->def_.circ);
+        if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("deferral: cannot build the deferral node: ") + zkhip_recursion_last_error(nullptr));
+        p->keygen(p->def_);
+        return p;
+    }
+    ~DeferralProver() {
+        for (Node* n : {&def_, &join_}) {
+            for (void* d : n->d_traces)
+                if (d) zkhip_free(ctx_, d);
+            if (n->pk) zkhip_pk_destroy(ctx_, n->pk);
+            if (n->circ) zkhip_recursion_destroy(n->circ);
+        }
+        if (ctx_) zkhip_ctx_destroy(ctx_);
+    }
+    DeferralProver(const DeferralProver&) = delete;
+    DeferralProver& operator=(const DeferralProver&) = delete;
+    size_t max_children() const { return max_children_; }
+    const VerifyingKey& child_key() const { return child_key_; }
+    const VerifyingKey& deferral_vk() const { return def_.vk; }
+    // crates/integration/src/lib.rs:461-514: what the task and the prover need from the child proofs -- the input commitments (they go
+    // into the guest's input stream), the deferral inputs, the chain's final value.  Every child is checked under the child key first.
+    struct Data {
+        std::vector<std::array<uint8_t, 32>> input_commits;
+        std::vector<DeferralInput> inputs;
+        Digest8 state{};
+    };
+    Data compute_deferral_data(const std::vector<const StarkProof*>& proofs) const {
+        if (proofs.empty()) throw Error(Error::GenProof, "no child proofs to compute deferral data");
+        if (proofs.size() > max_children_) throw Error(Error::GenProof, "deferral: " + std::to_string(proofs.size()) + " child proofs, the deferral node takes " + std::to_string(max_children_));
+        Data d;
+        for (size_t i = 0; i < proofs.size(); i++) {
+            DeferralInput in = DeferralInput::from_stark_proof(*proofs[i]);
+            std::string why;
+            if (!child_key_.verify(in.root)) throw Error(Error::GenProof, "deferral: child proof " + std::to_string(i) + " does not verify under the child aggregation key");
+            if (!child_key_.root_statement_matches(in.root.pvs[2], &why)) throw Error(Error::GenProof, "deferral: child proof " + std::to_string(i) + ": " + why);
+            const Digest8 ic = in.input_commit();
+            std::array<uint8_t, 32> b;
+            memcpy(b.data(), ic.data(), 32);
+            d.input_commits.push_back(b);
+            const std::array<uint32_t, 32> w = in.claim_words();
+            if (!chain_claim(d.state, w.data())) throw Error(Error::GenProof, "deferral: a commitment word is not a field element");
+            d.inputs.push_back(std::move(in));
+        }
+        return d;
+    }
+    // the deferral node over the child roots: witness (host) + traces and proof (device); self-verified
+    ChildProof prove_deferral(const std::vector<DeferralInput>& inputs) {
+        if (inputs.empty() || inputs.size() > max_children_) throw Error(Error::GenProof, "deferral: 1.." + std::to_string(max_children_) + " child proofs");
+        std::vector<const uint8_t*> proofs;
+        std::vector<size_t> lens;
+        std::vector<std::vector<const uint32_t*>> rows(inputs.size());
+        std::vector<const uint32_t* const*> pv_ptrs;
+        std::vector<uint32_t> aux;
+        for (size_t c = 0; c < inputs.size(); c++) {
+            proofs.push_back(inputs[c].root.proof.data()), lens.push_back(inputs[c].root.proof.size());
+            for (const auto& v : inputs[c].root.pvs) rows[c].push_back(v.data());
+            pv_ptrs.push_back(rows[c].data());
+            const std::vector<uint32_t> a = inputs[c].aux();
+            aux.insert(aux.end(), a.begin(), a.end());
+        }
+        const uint32_t zero[8] = {};
+        std::vector<uint32_t> npv(zkhip_recursion_n_pvs(def_.circ));
+        int rc = zkhip_recursion_witness_deferral(def_.circ, proofs.data(), lens.data(), pv_ptrs.data(), aux.data(), zero, inputs.size(), npv.data());
+        if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("deferral: ") + zkhip_recursion_last_error(def_.circ));
+        return prove(def_, std::move(npv));
+    }
+    // the join for the parent's own aggregation key (built once per parent key)
+    const VerifyingKey& join_vk(const VerifyingKey& own_key) {
+        if (!join_.circ) {
+            if (!own_key.is_aggregation_key()) throw Error(Error::Setup, "deferral: the parent key is not an aggregation key");
+            std::vector<zkhip_air> za = own_key.as_airs(), zb = def_.vk.as_airs();
+            int rc = zkhip_recursion_build_join(&own_key.params, za.data(), za.size(), &def_.vk.params, zb.data(), zb.size(), &join_.circ);
+            if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("deferral: cannot build the join: ") + zkhip_recursion_last_error(nullptr));
+            keygen(join_);
+            // what a root under the join must state beneath it: the parent app (its internal commitment is pinned inside the join)
+            join_.vk.leaf_commit = own_key.leaf_commit, join_.vk.app_digest = own_key.app_digest, join_.vk.join = true;
+        }
+        return join_.vk;
+    }
+    ChildProof prove_join(const VerifyingKey& own_key, const ChildProof& root, const ChildProof& deferral) {
+        (void)join_vk(own_key);
+        const uint8_t* proofs[2] = {root.proof.data(), deferral.proof.data()};
+        const size_t lens[2] = {root.proof.size(), deferral.proof.size()};
+        std::vector<const uint32_t*> r0, r1;
+        for (const auto& v : root.pvs) r0.push_back(v.data());
+        for (const auto& v : deferral.pvs) r1.push_back(v.data());
+        const uint32_t* const* pv[2] = {r0.data(), r1.data()};
+        std::vector<uint32_t> npv(zkhip_recursion_n_pvs(join_.circ));
+        int rc = zkhip_recursion_witness(join_.circ, proofs, lens, pv, 2, npv.data());
+        if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("deferral join: ") + zkhip_recursion_last_error(join_.circ));
+        return prove(join_, std::move(npv));
+    }
+
+private:
+    DeferralProver() = default;
+    struct Node {
+        zkhip_recursion* circ = nullptr;
+        zkhip_pk* pk = nullptr;
+        VerifyingKey vk;
+        std::vector<void*> d_traces;
+    };
+    VerifyingKey child_key_;
+    zkhip_params params_{};
+    int device_ = 0;
+    size_t max_children_ = 4;
+    zkhip_ctx* ctx_ = nullptr;
+    Node def_, join_;
+    void check(int rc) const {
+        if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("deferral: ") + zkhip_last_error(ctx_));
+    }
+    void keygen(Node& n) {
+        n.vk.params = params_;
+        std::vector<zkhip_air> na(3);
+        for (size_t i = 0; i < 3; i++) {
+            if (zkhip_recursion_air(n.circ, i, &na[i]) != ZKHIP_OK) throw Error(Error::Setup, "deferral: zkhip_recursion_air");
+            AirDesc d;
+            d.width = na[i].width, d.n_pvs = na[i].n_pvs, d.program.assign(na[i].program, na[i].program + na[i].program_len);
+            d.has_prep = true, d.prep_log_height = na[i].log_height;
+            n.vk.airs.push_back(std::move(d));
+            n.vk.heights.push_back(na[i].log_height);
+        }
+        int rc = zkhip_keygen(ctx_, &n.vk.params, na.data(), 3, &n.pk);
+        if (rc != ZKHIP_OK) throw Error(Error::Keygen, std::string("failed to generate STARK proving key: ") + zkhip_last_error(ctx_));
+        for (size_t i = 0; i < 3; i++) {
+            uint32_t c[8];
+            check(zkhip_pk_prep_commitment(ctx_, n.pk, i, c));
+            n.vk.airs[i].prep_commit.assign(c, c + 8);
+            void* d = nullptr;
+            check(zkhip_malloc(ctx_, (na[i].width << na[i].log_height) * 4, &d));
+            n.d_traces.push_back(d);
+        }
+    }
+    ChildProof prove(Node& n, std::vector<uint32_t> npv) {
+        check(zkhip_recursion_tracegen(ctx_, n.circ, (uint32_t*)n.d_traces[0], (uint32_t*)n.d_traces[1], (uint32_t*)n.d_traces[2]));
+        ChildProof out;
+        out.pvs.resize(3);
+        out.pvs[2] = std::move(npv);
+        out.proof.resize(zkhip_proof_size(n.pk));
+        const uint32_t* dt[3] = {(const uint32_t*)n.d_traces[0], (const uint32_t*)n.d_traces[1], (const uint32_t*)n.d_traces[2]};
+        const uint32_t* pv[3] = {nullptr, nullptr, out.pvs[2].data()};
+        size_t len = 0;
+        check(zkhip_prove(ctx_, n.pk, dt, pv, out.proof.data(), out.proof.size(), &len));
+        out.proof.resize(len);
+        if (!n.vk.verify(out)) throw Error(Error::VerifyProof, "deferral: a node proof does not verify");
+        return out;
     }
 };
 

@@ -222,6 +222,7 @@ public:
     uint64_t instret() const { return m_.instret(); }
     uint32_t exit_code() const { return m_.exit_code(); }
     const std::vector<uint8_t>& public_values() const { return m_.public_values(); }
+    uint32_t peek_memory(uint32_t addr) const { return mem_word(addr); }   // a word of the guest's memory as it is now (zero beyond its end)
 
     // Executes the next segment into `r`.  Returns true once the guest has exited (then r.pc_end = 0).
     bool run_segment(SegmentRecords& r) {

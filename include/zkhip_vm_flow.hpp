@@ -372,6 +372,8 @@ struct GuestStark {
     uint32_t entry_pc = 0;
     // openings of the two public-value blocks (address space 3) in the final memory root: sibling digests bottom-up, per block
     std::vector<uint32_t> pv_openings;
+    // the guest's deferral region in the final memory: its 2048 cells, then the 20 sibling digests above its subtree (deferral_base)
+    std::vector<uint32_t> deferral_opening;
     uint64_t execution_mills = 0, segment_proving_mills = 0, aggregation_mills = 0;
     uint64_t aggregation_setup_wait_mills = 0;   // waiting for the aggregation circuits / keys of this app to be built (first task only)
     uint64_t sum_segment_tracegen_mills = 0, sum_segment_prove_mills = 0;   // summed over the segments (lanes run side by side)
@@ -406,6 +408,69 @@ inline bool check_public_values(const std::vector<uint8_t>& pv, const std::vecto
             cur = (idx & 1u) ? p2_compress(s, cur) : p2_compress(cur, s);
         }
         if (!std::equal(cur.begin(), cur.end(), root)) return false;
+    }
+    return true;
+}
+
+// ---- the deferral region (crates/prover/src/prover/mod.rs:222-232: the reference reserves an address space of 2^25 cells for the deferral
+// state; crates/types/src/proof.rs `deferral_merkle_proofs`) ----
+// A guest that defers verification writes its claims into the 4 KiB (256 blocks = one subtree of the memory tree) that follow its
+// initial data image, 4 KiB-aligned: word 0 = the number of claims n, claim k = the 32 words at word 32 + 32 k
+// [input commitment (8) | exe commitment (8) | vm commitment (8) | the child's 32 public-value bytes].  Up to 31 claims.
+constexpr uint32_t DEFERRAL_REGION_BYTES = 4096, DEFERRAL_MAX_CLAIMS = 31, DEFERRAL_SUBTREE_LEVELS = 8;
+inline uint32_t deferral_base(const Exe& exe) {
+    const uint64_t end = (uint64_t)exe.data_base + exe.data.size();
+    return (uint32_t)((end + DEFERRAL_REGION_BYTES - 1) / DEFERRAL_REGION_BYTES * DEFERRAL_REGION_BYTES);
+}
+inline bool has_deferral_region(const Exe& exe) { return (uint64_t)deferral_base(exe) + DEFERRAL_REGION_BYTES <= (uint64_t)exe.data_base + exe.memory_bytes; }
+// the region's cells in the executor's final memory + the sibling digests above its subtree, bottom-up
+inline std::vector<uint32_t> open_deferral_region(const SegmentExecutor& ex, const Exe& exe) {
+    std::vector<uint32_t> out;
+    if (!has_deferral_region(exe)) return out;
+    const uint32_t base = deferral_base(exe);
+    for (uint32_t w = 0; w < DEFERRAL_REGION_BYTES / 4; w++) {
+        const uint32_t v = ex.peek_memory(base + 4 * w);
+        out.push_back(v & 0xffffu), out.push_back(v >> 16);
+    }
+    uint32_t idx = ((2u << vmc::LABEL_BITS) | (base / 16)) >> DEFERRAL_SUBTREE_LEVELS;
+    for (int l = (int)vmc::LEAF_LEVEL - (int)DEFERRAL_SUBTREE_LEVELS; l > 0; l--, idx >>= 1) {
+        const Digest sib = ex.tree().get((unsigned)l, idx ^ 1u);
+        out.insert(out.end(), sib.begin(), sib.end());
+    }
+    return out;
+}
+// what a verifier recomputes: the final memory root from the region's cells and the siblings; then the claims the guest made
+inline bool check_deferral_region(const Exe& exe, const std::vector<uint32_t>& opening, const uint32_t root[8], std::vector<std::array<uint32_t, 32>>* claims) {
+    const size_t n_cells = DEFERRAL_REGION_BYTES / 2, n_sib = vmc::LEAF_LEVEL - DEFERRAL_SUBTREE_LEVELS;
+    if (!has_deferral_region(exe) || opening.size() != n_cells + 8 * n_sib) return false;
+    for (size_t i = 0; i < n_cells; i++)
+        if (opening[i] > 0xffffu) return false;
+    std::vector<Digest> level(n_cells / 8);
+    for (size_t b = 0; b < level.size(); b++) level[b] = p2_block(&opening[8 * b]);
+    while (level.size() > 1) {
+        std::vector<Digest> up(level.size() / 2);
+        for (size_t i = 0; i < up.size(); i++) up[i] = p2_compress(level[2 * i], level[2 * i + 1]);
+        level = std::move(up);
+    }
+    Digest cur = level[0];
+    uint32_t idx = ((2u << vmc::LABEL_BITS) | (deferral_base(exe) / 16)) >> DEFERRAL_SUBTREE_LEVELS;
+    const uint32_t* sib = &opening[n_cells];
+    for (size_t l = 0; l < n_sib; l++, sib += 8, idx >>= 1) {
+        Digest s;
+        std::copy(sib, sib + 8, s.begin());
+        cur = (idx & 1u) ? p2_compress(s, cur) : p2_compress(cur, s);
+    }
+    if (!std::equal(cur.begin(), cur.end(), root)) return false;
+    auto word = [&](size_t w) { return opening[2 * w] | (opening[2 * w + 1] << 16); };
+    const uint32_t n = word(0);
+    if (n > DEFERRAL_MAX_CLAIMS) return false;
+    if (claims) {
+        claims->clear();
+        for (uint32_t k = 0; k < n; k++) {
+            std::array<uint32_t, 32> c;
+            for (size_t j = 0; j < 32; j++) c[j] = word(32 + 32 * k + j);
+            claims->push_back(c);
+        }
     }
     return true;
 }
@@ -560,6 +625,7 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     if (all_zero) throw Error("public_values are all 0s for unexpected reason");   // crates/prover/src/utils/vm.rs:34-46
     g.exec = ExecutionResult{ex.instret(), ex.public_values()};
     g.pv_openings = open_public_values(ex.tree());
+    g.deferral_opening = open_deferral_region(ex, exe);
     g.segments = n_seg;
     std::vector<ChildProof> seg_proofs;
     for (auto& p : proofs) seg_proofs.push_back(p.proof), g.sum_segment_tracegen_mills += p.tracegen_mills, g.sum_segment_prove_mills += p.proving_mills;
@@ -725,12 +791,13 @@ inline bool verify_guest_proof(const VerifyingKey& root_vk, const ChildProof& ro
     };
     if (!root_vk.verify(root)) return fail("the root proof does not verify under the root verifying key");
     const std::vector<uint32_t>& pv = root.pvs.at(2);
-    if (pv.size() != 8 + 9 + 9 + 8 && pv.size() != 8 + 9 + 9 + 8 + 16) return fail("the root statement does not have the (pc, memory root) layout");
+    if (pv.size() != 8 + 9 + 9 + 8 && pv.size() != 8 + 9 + 9 + 8 + 16 && pv.size() != 8 + 9 + 9 + 8 + 16 + 8) return fail("the root statement does not have the (pc, memory root) layout");
     // An aggregation key pins the tree beneath the root: its leaves are proofs of the key's leaf circuit (which hard-wires the app's
     // verifying key: programs, heights, the committed program), its nodes proofs of the key's own circuit, the statement is about this
     // app.  (A per-depth key of round 3 pins the same through its preprocessed commitments and carries no pair.)
-    if (pv.size() == 50) {
+    if (pv.size() >= 50) {
         std::string w;
+        if ((pv.size() == 58) != root_vk.join) return fail("the root statement does not match the kind of the root verifying key");
         if (!root_vk.root_statement_matches(pv, &w)) {
             if (why) *why = w;
             return false;
@@ -792,7 +859,10 @@ public:
         if (with_snark) throw Error(Error::GenProof, "the SNARK (EVM) wrap is outside the HIP backend's path");
         return gen_proof_stark(task);
     }
-    StarkProof gen_proof_stark(const ProvingTask& task) {
+    // mod.rs:342-413 `gen_proof_stark(stdin, def_inputs)`: with deferral inputs the guest's root is joined with the proof of the deferral
+    // node over them (crates/integration/src/lib.rs:556-571 `prove_task_with_deferral`)
+    StarkProof gen_proof_stark(const ProvingTask& task, const std::vector<DeferralInput>& def_inputs = {}) {
+        if (!def_inputs.empty() && !deferral_) throw Error(Error::GenProof, "deferral inputs given, but deferral is not enabled on this prover (enable_deferral)");
         try {
             ensure();
             const zkhip_vm::StdIn in = task.build_guest_input();
@@ -802,12 +872,51 @@ public:
         } catch (const zkhip_vm::Error& e) {
             throw Error(Error::GenProof, std::string("failed to generate proof: ") + e.what());
         }
+        if (deferral_) {
+            // a prover with deferral enabled returns proofs under the JOIN key, with or without claims in this task's run: the guest's root and the
+            // deferral node's proof (over the children the claims are about) under one more circuit
+            if (def_inputs.empty()) throw Error(Error::GenProof, "this prover has deferral enabled: a task needs its deferral inputs (compute_deferral_data)");
+            const auto t0 = std::chrono::steady_clock::now();
+            const VerifyingKey own = agg_->root_vk();
+            const ChildProof dproof = deferral_->prove_deferral(def_inputs);
+            last_deferral_ = dproof;
+            last_.root = deferral_->prove_join(own, last_.root, dproof);
+            last_.root_vk = deferral_->join_vk(own);
+            last_.aggregation_mills += (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        }
         StarkProof sp = encode(last_);
         std::string why;
         if (!verify_guest_stark(sp, last_.root_vk, exe_, &why)) throw Error(Error::VerifyProof, "failed to verify proof: " + why);   // mod.rs:407-411
         return sp;
     }
+    // mod.rs:200-282 `enable_deferral(child_prover)`: from now on this prover's guest may state claims about proofs of the CHILD app (its
+    // aggregation key is all that is needed: mod.rs:213 `child_prover.load_agg_vk()`), and every proof it returns is a join.
+    void enable_deferral(const VerifyingKey& child_agg_key, size_t max_children = 4) {
+        if (!zkhip_vm::has_deferral_region(exe_)) throw Error(Error::Setup, "enable_deferral: the guest's memory has no room for the deferral region");
+        reset();   // (mod.rs:265 `self.reset()`: the keys are rebuilt with deferral)
+        deferral_ = DeferralProver::setup(child_agg_key, params_, device_, max_children);
+    }
+    void enable_deferral(UniversalProver& child_prover, size_t max_children = 4) { enable_deferral(child_prover.get_agg_vk(), max_children); }
+    bool deferral_enabled() const { return (bool)deferral_; }
+    // crates/integration/src/lib.rs:461-514 `compute_deferral_data(child_prover, cached_commit, proofs)`
+    DeferralProver::Data compute_deferral_data(const std::vector<const StarkProof*>& proofs) const {
+        if (!deferral_) throw Error(Error::GenProof, "compute_deferral_data: deferral is not enabled on this prover");
+        return deferral_->compute_deferral_data(proofs);
+    }
+    // mod.rs:147-170 `get_agg_vk`: the key every proof of this prover verifies under (one aggregation key; with deferral: the join's)
+    const VerifyingKey& get_agg_vk() {
+        ensure();
+        const VerifyingKey& own = agg_->root_vk();
+        return deferral_ ? deferral_->join_vk(own) : own;
+    }
+    // what a PARENT guest holds about this app (crates/types/circuit/src/lib.rs ProgramCommitment)
+    ProgramCommitment program_commitment() {
+        ensure();
+        return ProgramCommitment::of(agg_->root_vk(), exe_.entry ? exe_.entry : exe_.pc_base, zkhip_vm::guest_image_root(exe_));
+    }
     const zkhip_vm::GuestStark& last() const { return last_; }
+    const ChildProof& last_deferral_proof() const { return last_deferral_; }   // the deferral node's proof of the last task (what the join verified)
+    const DeferralProver* deferral() const { return deferral_.get(); }
     const zkhip_vm::Exe& exe() const { return exe_; }
 
     static StarkProof encode(const zkhip_vm::GuestStark& g) {
@@ -815,6 +924,10 @@ public:
         sp.user_pvs_proof.insert(sp.user_pvs_proof.end(), g.exec.public_values.begin(), g.exec.public_values.end());
         const uint8_t* ob = reinterpret_cast<const uint8_t*>(g.pv_openings.data());
         sp.user_pvs_proof.insert(sp.user_pvs_proof.end(), ob, ob + 4 * g.pv_openings.size());
+        if (g.root_vk.join) {   // crates/types/src/proof.rs `deferral_merkle_proofs`: the guest's claims, opened in the final memory root
+            const uint8_t* db = reinterpret_cast<const uint8_t*>(g.deferral_opening.data());
+            sp.deferral_merkle_proofs.assign(db, db + 4 * g.deferral_opening.size());
+        }
         sp.stat.total_cycles = g.exec.total_cycle, sp.stat.execution_time_mills = g.execution_mills;
         sp.stat.proving_time_mills = g.segment_proving_mills + g.aggregation_mills;
         return sp;
@@ -844,7 +957,25 @@ public:
                 return false;
             }
         try {
-            return zkhip_vm::verify_guest_proof(root_vk, root, exe.entry ? exe.entry : exe.pc_base, zkhip_vm::guest_image_root(exe), pv, openings, why);
+            if (!zkhip_vm::verify_guest_proof(root_vk, root, exe.entry ? exe.entry : exe.pc_base, zkhip_vm::guest_image_root(exe), pv, openings, why)) return false;
+            if (!root_vk.join) return true;
+            // DEFERRAL: the claims the guest made (opened in its final memory root) chain to the accumulator the join took from the
+            // deferral node -- every claim is backed by a child proof the deferral node verified, in this order, and there is no other
+            auto fail = [&](const char* m) {
+                if (why) *why = m;
+                return false;
+            };
+            if (sp.deferral_merkle_proofs.size() % 4) return fail("deferral_merkle_proofs is not a word array");
+            std::vector<uint32_t> opening(sp.deferral_merkle_proofs.size() / 4);
+            if (!opening.empty()) memcpy(opening.data(), sp.deferral_merkle_proofs.data(), sp.deferral_merkle_proofs.size());
+            std::vector<std::array<uint32_t, 32>> claims;
+            if (!zkhip_vm::check_deferral_region(exe, opening, &root.pvs[2][18], &claims)) return fail("the deferral region does not open in the final memory root");
+            if (claims.empty()) return fail("a proof under a join key without claims");
+            Digest8 acc{};
+            for (const auto& c : claims)
+                if (!chain_claim(acc, c.data())) return fail("a claim's commitment is not a field element");
+            if (!std::equal(acc.begin(), acc.end(), root.pvs[2].begin() + 50)) return fail("the guest's claims are not the ones the deferral node verified");
+            return true;
         } catch (const zkhip_vm::Error& e) {
             if (why) *why = e.what();
             return false;
@@ -860,7 +991,9 @@ private:
     unsigned inflight_ = 3;
     std::vector<std::unique_ptr<zkhip_vm::SegmentProver>> seg_;   // lanes: segment provers in flight on the device
     std::unique_ptr<AggregationProver> agg_;
+    std::unique_ptr<DeferralProver> deferral_;
     zkhip_vm::GuestStark last_;
+    ChildProof last_deferral_;
     void ensure() {
         if (!seg_.empty()) return;
         for (unsigned l = 0; l < inflight_; l++) seg_.emplace_back(new zkhip_vm::SegmentProver(params_, exe_, caps_, device_));

@@ -83,3 +83,33 @@ def stark_proof_json(proof_bytes, airs, proving_ms=0):
 
 def run_cli(*args):
     return subprocess.run([CLI] + list(args), capture_output=True, text=True)
+
+
+def read_vk(path):
+    """A verifying key in app-file form (include/zkhip_prover.hpp encode_app_exe v2, tables omitted) as verifying AIR dicts; an
+    aggregation / join key's trailer [magic | leaf commitment (8) | app digest (8)] comes back as the second value (or None)."""
+    import numpy as np
+
+    w = np.frombuffer(open(path, "rb").read(), dtype=np.uint32)
+    assert w[0] == 0x58414B5B
+    n, p, airs = int(w[1]), 2, []
+    for _ in range(n):
+        width, n_pvs, plen = int(w[p]), int(w[p + 1]), int(w[p + 2])
+        p += 3
+        a = dict(width=width, n_pvs=n_pvs, program=w[p:p + plen].copy())
+        p += plen
+        has_prep = int(w[p])
+        p += 1
+        if has_prep:
+            a["log_height"], prep_len = int(w[p]), int(w[p + 1])
+            p += 2 + prep_len
+            has_commit = int(w[p])
+            p += 1
+            if has_commit:
+                a["prep_commit"] = w[p:p + 8].copy()
+                p += 8
+        airs.append(a)
+    trailer = None
+    if len(w) - p == 17:
+        trailer = dict(magic=int(w[p]), leaf_commit=w[p + 1:p + 9].copy(), app_digest=w[p + 9:p + 17].copy())
+    return airs, trailer

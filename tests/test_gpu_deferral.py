@@ -1,0 +1,147 @@
+"""GPU: deferral end to end (crates/prover/src/prover/mod.rs:200-282 `enable_deferral`, crates/integration/src/lib.rs:461-514
+`compute_deferral_data`, :556-571 `prove_task_with_deferral`; guest side crates/types/circuit/src/lib.rs:137-154 `verify_stark`).
+Three runs of a CHILD guest (Fibonacci; the reference: chunk proofs) are folded to three root proofs under the child's ONE aggregation
+key; a PARENT guest (the reference: the batch circuit) states one claim per child -- input commitment, the child app's program
+commitments (constants of the parent guest), the child's public values -- in its deferral region; `prove-deferral` proves the parent,
+the deferral node over the three child roots, and their join: ONE StarkProof.
+  * the parent's root verifies with verify-guest; its statement's deferral accumulator == the independent restatement of the chain
+    over the three children's statements (tests/recursion_util.py), i.e. it binds the three child commitments;
+  * the deferral node's proof == the oracle's proof of the same circuit and witness, byte for byte;
+  * a flipped byte in a child proof, a child of another executable image (another exe commitment), reordered children, a tampered
+    opening of the claims and a tampered accumulator all fail."""
+import json
+import subprocess
+
+import numpy as np
+import pytest
+
+import zkvm_prover_amd as z
+
+import prover_mirror_util as pm
+import recursion_util as ru
+import rv32_model as rv
+from test_vm_cpu import deferral_guest_program, deferral_guest_stdin, fib_program
+
+pytestmark = pytest.mark.gpu
+PARAMS = (1, 0, 4, 3, 3)
+NOPV = ru.NOPV
+N_STMT = 50
+
+
+def prove_child(d, elf, cfg, n):
+    d.mkdir()
+    (d / "stdin.bin").write_bytes(int(n).to_bytes(4, "little"))
+    r = subprocess.run([pm.CLI, "prove-elf", str(elf), str(d / "stdin.bin"), str(d), str(cfg), "9"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    root = json.loads((d / "root.json").read_text())
+    upv = pm.un_b64_bincode(root["user_pvs_proof"])
+    return dict(dir=d, json=str(d / "root.json"), root=root, stmt=np.frombuffer(upv[:4 * N_STMT], dtype=np.uint32), pvs=upv[4 * N_STMT:4 * N_STMT + 32],
+                openings=np.frombuffer(upv[4 * N_STMT + 32:], dtype=np.uint32))
+
+
+def test_three_children_one_parent_root(ora, tmp_path):
+    cfg = tmp_path / "openvm.toml"
+    cfg.write_text(pm.TOML.format(*PARAMS))
+    child_elf = tmp_path / "child.elf"
+    child_elf.write_bytes(rv.elf_bytes(fib_program()))
+    kids = [prove_child(tmp_path / ("c%d" % i), child_elf, cfg, n) for i, n in enumerate((100, 150, 210))]
+    child_vk = str(kids[0]["dir"] / "root.vk")
+    assert all((k["dir"] / "root.vk").read_bytes() == (kids[0]["dir"] / "root.vk").read_bytes() for k in kids)   # one key
+    # the child app's program commitments: constants of the parent guest
+    r = pm.run_cli("program-commit", str(child_elf), child_vk, str(cfg))
+    assert r.returncode == 0, r.stderr
+    pc = json.loads(r.stdout)
+    data = b"".join(int(x).to_bytes(4, "little") for x in pc["exe"] + pc["vm"])
+    parent = deferral_guest_program()
+    parent_elf = tmp_path / "parent.elf"
+    parent_elf.write_bytes(rv.elf_bytes(parent, data=data))
+    r = pm.run_cli("program-commit", str(parent_elf), child_vk, str(cfg))     # (only for the region's address: it follows the data image)
+    assert json.loads(r.stdout)["deferral_base"] == 0x00401000
+    witness = tmp_path / "witness.bin"
+    witness.write_bytes(b"".join(k["pvs"] for k in kids))
+    out = tmp_path / "parent"
+    out.mkdir()
+
+    def prove(outdir, jsons, wit=witness, elf=parent_elf):
+        return subprocess.run([pm.CLI, "prove-deferral", str(elf), str(cfg), str(outdir), "9", child_vk, str(cfg), str(wit)] + jsons, capture_output=True, text=True)
+
+    r = prove(out, [k["json"] for k in kids])
+    assert r.returncode == 0, r.stderr[-3000:]
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["children"] == 3 and info["verified"]
+    # the whole statement about the parent guest, under the JOIN key
+    v = pm.run_cli("verify-guest", str(parent_elf), str(out / "root.vk"), str(cfg), str(out / "root.json"))
+    assert v.returncode == 0, v.stderr
+    root = json.loads((out / "root.json").read_text())
+    upv = pm.un_b64_bincode(root["user_pvs_proof"])
+    stmt = np.frombuffer(upv[:4 * 58], dtype=np.uint32)
+    pv = upv[4 * 58:4 * 58 + 32]
+    fib = lambda n: (lambda f: [f := (f[1], (f[0] + f[1]) & 0xFFFFFFFF) for _ in range(n)][-1][0])((0, 1))   # noqa: E731
+    assert int.from_bytes(pv[:4], "little") == 3 and int.from_bytes(pv[4:8], "little") == (fib(100) + fib(150) + fib(210)) & 0xFFFFFFFF
+    # the deferral accumulator binds the three children: the chain over their statements, restated independently
+    cells = [np.array([k["pvs"][2 * j] | (k["pvs"][2 * j + 1] << 8) for j in range(16)], np.uint32) for k in kids]
+    want = ru.deferral_chain(np.zeros(8, np.uint32), [ru.deferral_claim(k["stmt"], c) for k, c in zip(kids, cells)])
+    assert stmt[50:58].tolist() == want.tolist() == info["deferral_state"]
+    # ... and the claims use the program commitments of the child app
+    claim0 = ru.deferral_claim(kids[0]["stmt"], cells[0])
+    assert claim0[1].tolist() == pc["exe"] and claim0[2].tolist() == pc["vm"]
+    # the join key's trailer pins the parent app; the generic verifier checks it too
+    assert pm.run_cli("verify", str(out / "root.vk"), str(cfg), str(out / "root.json")).returncode == 0
+    # the deferral node's proof == the oracle's proof of the same circuit and witness
+    key_airs, trailer = pm.read_vk(child_vk)
+    D = z.RecursionCircuit(PARAMS, key_airs, 4, stmt="deferral")
+    aux = [np.concatenate([c, k["openings"][8:8 * 28]]) for k, c in zip(kids, cells)]
+    st, dpv = D.witness([pm.un_b64_bincode(k["root"]["proof"]) for k in kids], [[NOPV, NOPV, k["stmt"]] for k in kids], aux=aux)
+    assert st == 0, D.last_error()
+    assert dpv[8:].tolist() == want.tolist()
+    dj = json.loads((out / "deferral.json").read_text())
+    assert pm.un_b64_bincode(dj["proof"]) == ora.stark_prove(PARAMS, ru.node_instance(D, dpv)).tobytes()
+
+    # ---- refusals ----
+    # a flipped byte in a child proof
+    bad = dict(kids[1]["root"])
+    pb = bytearray(pm.un_b64_bincode(bad["proof"]))
+    pb[4 * 500] ^= 1
+    bad["proof"] = pm.b64_bincode(bytes(pb))
+    (tmp_path / "bad_child.json").write_text(json.dumps(bad))
+    x = tmp_path / "x1"
+    x.mkdir()
+    r = prove(x, [kids[0]["json"], str(tmp_path / "bad_child.json"), kids[2]["json"]])
+    assert r.returncode != 0 and "does not verify under the child aggregation key" in r.stderr
+    # a child of another executable image: same program (same aggregation key), other initial memory -> another exe commitment than
+    # the one the parent guest holds
+    other_elf = tmp_path / "other.elf"
+    other_elf.write_bytes(rv.elf_bytes(fib_program(), data=b"\\x01\\x02\\x03\\x04"))
+    other = prove_child(tmp_path / "o", other_elf, cfg, 150)
+    assert (other["dir"] / "root.vk").read_bytes() == (kids[0]["dir"] / "root.vk").read_bytes()
+    assert other["pvs"] == kids[1]["pvs"]
+    x = tmp_path / "x2"
+    x.mkdir()
+    r = prove(x, [kids[0]["json"], other["json"], kids[2]["json"]])
+    assert r.returncode != 0 and "claims are not the ones the deferral node verified" in r.stderr, r.stderr[-2000:]
+    # reordered children (the witness keeps the order the guest was told)
+    x = tmp_path / "x3"
+    x.mkdir()
+    r = prove(x, [kids[1]["json"], kids[0]["json"], kids[2]["json"]])
+    assert r.returncode != 0 and "claims are not the ones the deferral node verified" in r.stderr
+    # a child of ANOTHER app (the parent guest itself as a child): not under the child aggregation key
+    # (its proof is a join: another shape altogether)
+    x = tmp_path / "x4"
+    x.mkdir()
+    r = prove(x, [kids[0]["json"], str(out / "root.json")])
+    assert r.returncode != 0
+    # the final proof: a tampered opening of the claims, a tampered accumulator, a tampered claim count
+    def variant(name, field, pos):
+        sp = dict(root)
+        b = bytearray(pm.un_b64_bincode(sp[field]))
+        b[pos] ^= 1
+        sp[field] = pm.b64_bincode(bytes(b))
+        (tmp_path / name).write_text(json.dumps(sp))
+        return str(tmp_path / name)
+
+    for name, field, pos in (("t1.json", "deferral_merkle_proofs", 4 * 64 + 1), ("t2.json", "deferral_merkle_proofs", 4 * 2048 + 5),
+                             ("t3.json", "deferral_merkle_proofs", 0), ("t4.json", "user_pvs_proof", 4 * 52)):
+        assert pm.run_cli("verify-guest", str(parent_elf), str(out / "root.vk"), str(cfg), variant(name, field, pos)).returncode != 0, name
+    # the parent's proof does not verify under the CHILD's key, nor a child's under the parent's
+    assert pm.run_cli("verify-guest", str(parent_elf), child_vk, str(cfg), str(out / "root.json")).returncode != 0
+    assert pm.run_cli("verify-guest", str(child_elf), str(out / "root.vk"), str(cfg), kids[0]["json"]).returncode != 0

@@ -309,6 +309,50 @@ def fp2_data():
     return (el(BN254_G2Y) + el(BN254_G2Y) + z64 + el(BN254_G2X) + el(BN254_G2X) + z64 + z64 + el(BN254_G2X) + z64 + el((3, 0)) + el((9, 1)) + z64 + z64 * 3 + z64 * 3)
 
 
+DEFERRAL_DATA_BYTES = 64   # the batch-like guest's data segment: the child app's exe commitment (8 words), vm commitment (8 words)
+
+
+def deferral_guest_program(deferral_base=0x00401000):
+    """A guest that DEFERS the verification of its children (the reference's batch guest: crates/types/circuit/src/lib.rs:137-154
+    `verify_stark::<0>(input_commit, &expected)` once per aggregated proof).  Input stream (ProvingTask::build_guest_input): one witness
+    item = the children's 32 public-value bytes each, then the input commitments [count | 8 words each].  For child k it writes the claim
+    [input commitment | exe commitment | vm commitment | public values] -- the program commitments are CONSTANTS of this guest (its data
+    segment, as the reference compiles crates/circuits/*-circuit/*_commit.rs into the parent) -- into the deferral region at word
+    32 + 32 k, then the number of claims at word 0.  Reveals word 0 = the number of children, word 1 = the sum of their first public words."""
+    p = rv.li(S0, deferral_base) + rv.li(S1, 0x00400000)
+    p += [("addi", A7, 0, 2), ("ecall",), ("srli", 18, A0, 5),           # s2 (x18) = byte length of the witness / 32 = n
+          ("addi", T0, S0, 128), ("addi", T1, 0, 0), ("addi", 19, 0, 0),  # t0 = claim pointer, t1 = k, s3 (x19) = the running sum
+          ("label", "pvs"), ("bge", T1, 18, "pvs_done")]
+    for j in range(8):
+        p += [("addi", A7, 0, 2), ("ecall",), ("sw", A0, T0, 96 + 4 * j)]
+        if j == 0:
+            p += [("add", 19, 19, A0)]
+    for j in range(16):
+        p += [("lw", T3, S1, 4 * j), ("sw", T3, T0, 32 + 4 * j)]
+    p += [("addi", T0, T0, 128), ("addi", T1, T1, 1), ("jal", 0, "pvs"), ("label", "pvs_done"),
+          ("addi", A7, 0, 2), ("ecall",),                                  # the count of input commitments (= n)
+          ("addi", T0, S0, 128), ("addi", T1, 0, 0),
+          ("label", "ics"), ("bge", T1, 18, "ics_done")]
+    for j in range(8):
+        p += [("addi", A7, 0, 2), ("ecall",), ("sw", A0, T0, 4 * j)]
+    p += [("addi", T0, T0, 128), ("addi", T1, T1, 1), ("jal", 0, "ics"), ("label", "ics_done"),
+          ("sw", 18, S0, 0),
+          ("add", A0, 18, 0), ("addi", A1, 0, 0), ("addi", A7, 0, 1), ("ecall",),
+          ("add", A0, 19, 0), ("addi", A1, 0, 1), ("ecall",),
+          ("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
+def deferral_guest_stdin(child_pvs, input_commits):
+    """ProvingTask::build_guest_input for one witness item (the children's public values) + the input commitments (8 words each)."""
+    w = b"".join(bytes(x) for x in child_pvs)
+    out = len(w).to_bytes(4, "little") + w + bytes(-len(w) % 4)
+    out += len(input_commits).to_bytes(4, "little")
+    for c in input_commits:
+        out += b"".join(int(x).to_bytes(4, "little") for x in c)
+    return out
+
+
 def mixed_program():
     """every instruction class: a checksum over a table in memory with multiplies, comparisons, shifts, division, bytes"""
     p = [("addi", A7, 0, 2), ("ecall",), ("add", S0, A0, 0)]          # seed
@@ -609,3 +653,23 @@ def test_text_segment_must_lie_below_two_to_the_30(tmp_path):
     inp.write_bytes((5).to_bytes(4, "little"))
     r = subprocess.run([VM, "exec", str(exe), str(inp), "-"], capture_output=True, text=True)
     assert r.returncode != 0 and "below 2^30" in r.stderr
+
+
+def test_deferral_guest_writes_its_claims(tmp_path):
+    """The batch-like guest on the executor: public values (number of children, sum of their first public words) == the Python model's."""
+    prog = deferral_guest_program()
+    rng = np.random.default_rng(3)
+    pvs = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(3)]
+    ics = [rng.integers(0, 2013265921, 8, dtype=np.uint32) for _ in range(3)]
+    data = b"".join(int(x).to_bytes(4, "little") for x in range(100, 116))
+    stdin = deferral_guest_stdin(pvs, ics)
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(prog, data=data))
+    (tmp_path / "stdin.bin").write_bytes(stdin)
+    r = subprocess.run([VM, "exec", str(exe), str(tmp_path / "stdin.bin"), "-"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    js = json.loads(r.stdout)
+    model = rv.run(prog, stdin, data=data)
+    assert js["total_cycle"] == model["instret"] and bytes(js["public_values"]) == model["pvs"]
+    total = sum(int.from_bytes(p[:4], "little") for p in pvs) & 0xFFFFFFFF
+    assert int.from_bytes(model["pvs"][:4], "little") == 3 and int.from_bytes(model["pvs"][4:8], "little") == total

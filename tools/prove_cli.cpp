@@ -191,6 +191,63 @@ int main(int argc, char** argv) {
                         (unsigned long long)g.segment_proving_mills, (unsigned long long)g.aggregation_mills, wall, g.root.proof.size());
             return 0;
         }
+        if (argc >= 5 && std::string(argv[1]) == "program-commit") {
+            // program-commit <guest.elf | exe.bin> <root.vk> <openvm.toml>: what a PARENT guest holds about this app (crates/types/circuit/src/lib.rs
+            // ProgramCommitment { exe, vm }; the reference generates it into crates/circuits/*-circuit/*_commit.rs): host only
+            const zkhip_vm::Exe exe = zkhip_vm::parse_exe(slurp(argv[2]));
+            const VerifyingKey vk = VerifyingKey::read(argv[3], read_app_config(argv[4]));
+            const ProgramCommitment pc = ProgramCommitment::of(vk, exe.entry ? exe.entry : exe.pc_base, zkhip_vm::guest_image_root(exe));
+            std::printf("{\"exe\": [");
+            for (int k = 0; k < 8; k++) std::printf("%s%u", k ? ", " : "", pc.exe[k]);
+            std::printf("], \"vm\": [");
+            for (int k = 0; k < 8; k++) std::printf("%s%u", k ? ", " : "", pc.vm[k]);
+            std::printf("], \"deferral_base\": %u}\n", zkhip_vm::deferral_base(exe));
+            return 0;
+        }
+        if (argc >= 10 && std::string(argv[1]) == "prove-deferral") {
+            // prove-deferral <guest.elf> <openvm.toml> <out_dir> <log_frame> <child root.vk> <child openvm.toml> <witness.bin | -> <child root.json>...
+            // A guest that DEFERS the verification of its children (crates/prover/src/prover/mod.rs:200-282 enable_deferral; crates/integration/
+            // src/lib.rs:461-514 compute_deferral_data, :556-571 prove_task_with_deferral): the child app's aggregation key + the child root
+            // proofs in, ONE StarkProof out -- the guest's root joined with the proof of the deferral node that verified the children.  The
+            // task's input stream = [witness.bin as one item][the input commitments].  Writes root.json and root.vk (the JOIN key).
+            const unsigned log_frame = (unsigned)atoi(argv[5]);
+            UniversalProver up = UniversalProver::setup(ProverConfig{argv[2], argv[3]}, "deferral", 0, log_frame);
+            const VerifyingKey child_key = VerifyingKey::read(argv[6], read_app_config(argv[7]));
+            const auto t0 = std::chrono::steady_clock::now();
+            up.enable_deferral(child_key);
+            std::vector<StarkProof> kids;
+            for (int i = 9; i < argc; i++) {
+                const auto js = slurp(argv[i]);
+                kids.push_back(StarkProof::from_json(std::string(js.begin(), js.end())));
+            }
+            std::vector<const StarkProof*> kp;
+            for (const auto& k : kids) kp.push_back(&k);
+            const DeferralProver::Data data = up.compute_deferral_data(kp);
+            ProvingTask task;
+            task.identifier = "deferral";
+            if (std::string(argv[8]) != "-") task.serialized_witness.push_back(slurp(argv[8]));
+            task.input_commits = data.input_commits;
+            const auto t1 = std::chrono::steady_clock::now();
+            const StarkProof sp = up.gen_proof_stark(task, data.inputs);
+            const auto t2 = std::chrono::steady_clock::now();
+            const std::string dir = argv[4];
+            const std::vector<uint8_t> vkb = up.get_agg_vk().to_app_exe();
+            std::ofstream(dir + "/root.vk", std::ios::binary).write((const char*)vkb.data(), (std::streamsize)vkb.size());
+            std::ofstream(dir + "/root.json") << sp.to_json();
+            {   // the deferral node's proof and key (what the join verified): for inspection and the oracle comparison of the tests
+                const VerifyingKey& dvk = up.deferral()->deferral_vk();
+                std::ofstream(dir + "/deferral.json") << AggregationProver::to_stark_proof(up.last_deferral_proof(), dvk).to_json();
+                const std::vector<uint8_t> db = dvk.to_app_exe();
+                std::ofstream(dir + "/deferral.vk", std::ios::binary).write((const char*)db.data(), (std::streamsize)db.size());
+            }
+            const zkhip_vm::GuestStark& g = up.last();
+            std::printf("{\"children\": %zu, \"total_cycles\": %llu, \"segments\": %zu, \"levels\": %zu, \"setup_s\": %.3f, \"prove_s\": %.3f, \"root_proof_bytes\": %zu, "
+                        "\"deferral_state\": [", kids.size(), (unsigned long long)g.exec.total_cycle, g.segments, g.levels,
+                        std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(), g.root.proof.size());
+            for (int k = 0; k < 8; k++) std::printf("%s%u", k ? ", " : "", data.state[k]);
+            std::printf("], \"verified\": true}\n");
+            return 0;
+        }
         if (argc >= 6 && std::string(argv[1]) == "verify-guest") {
             // verify-guest <guest.elf | exe.bin> <root.vk> <openvm.toml> <root.json>: the root proof under the root verifying key AND the
             // statement about this guest: entry pc, memory image, exit code 0, public values opened in the final memory root (host only)
