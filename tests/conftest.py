@@ -8,10 +8,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-# The witness generator page-locks its (large) value array in place for the copy to the device (csrc/recursion.hip).  Inside this long-lived
-# test process that is the one thing the driver is told about the process's own heap; the suite does not measure it (bench.py's guest
-# flow runs the default), so the tests keep every host array pageable.
-os.environ.setdefault("ZKHIP_NO_PIN_WITNESS", "1")
+# (Round 3 ran the suite with ZKHIP_NO_PIN_WITNESS=1: the witness generator page-locked the storage of a std::vector in place.  The wire
+# values now live in a mapping of their own (csrc/recursion.hip WireBuf), registered once per circuit user: the suite runs the default.)
 
 
 def pytest_configure(config):
