@@ -471,19 +471,24 @@ def main():
         # whole-proof VALU roofline from the committed counter pass (tools/pmc_valu3.py): one proof's VALU wave-instructions priced at
         # the cycles per instruction of the row-hash kernel's ISA mix on 1024 SIMDs at 2.4 GHz, against the measured time per proof
         valu_roof = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "round03_pmc_valu.json")) as f:
+        if log_n == 22 and width == 300:
+            pmc_file = next((f for f in ("round04_pmc_valu.json", "round03_pmc_valu.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pv = json.load(f)
-            if log_n == 22 and width == 300:
-                ms = dt / args.steps * 1e3  # every rank proves `steps` proofs in dt
-                valu_roof = {"valu_wave_instr_per_proof": pv["total_valu_wave_instr_per_proof"],
-                             "floor_ms_per_proof": pv["total_valu_roofline_ms_per_proof"],
-                             "ms_per_proof_per_gpu": round(ms, 2),
-                             "frac": round(pv["total_valu_roofline_ms_per_proof"] / ms, 3),
-                             "note": "profiles/round03_pmc_valu.json: SQ_INSTS_VALU summed over the kernels of one proof x 2.82 cycles per "
-                                     "wave-instruction (ISA mix of the row-hash kernel, which issues 69 % of them) / (1024 SIMDs x 2.4 GHz)"}
-        except Exception:
-            pass
+            # the totals from the per-kernel entries (round 3's file has no summed keys and the block came out null on the driver's line)
+            kern = pv["kernels"]
+            total_instr = pv.get("total_valu_wave_instr_per_proof") or sum(k["launches_per_proof"] * k["valu_wave_instr_per_launch"] for k in kern.values())
+            cpi = kern["zk::k_hash_rows"]["isa_mix"]["cycles_per_wave_instruction_model"]
+            floor_ms = pv.get("total_valu_roofline_ms_per_proof") or total_instr * cpi / (pv["peak"]["simds"] * pv["peak"]["clock_hz"]) * 1e3
+            ms = dt / args.steps * 1e3  # every rank proves `steps` proofs in dt
+            valu_roof = {"valu_wave_instr_per_proof": int(total_instr), "cycles_per_wave_instr_model": cpi,
+                         "floor_ms_per_proof": round(floor_ms, 2),
+                         "ms_per_proof_per_gpu": round(ms, 2),
+                         "frac": round(floor_ms / ms, 3),
+                         "hash_rows_share_of_valu_instr": round(2 * kern["zk::k_hash_rows"]["valu_wave_instr_per_launch"] / total_instr, 3),
+                         "note": "profiles/%s: SQ_INSTS_VALU summed over the kernels of one proof x the model cycles per wave-instruction "
+                                 "of the row-hash kernel's ISA mix / (1024 SIMDs x 2.4 GHz)" % pmc_file}
+            assert valu_roof["frac"] > 0, "the whole-proof VALU roofline of the headline configuration must not be empty"
         # whole-proof HBM roofline (SURVEY.md 8(d) cfg #4: unfused per-stage algorithmic bytes of one proof): the LDE reads
         # the trace and writes the codeword, the row hash and the constraint kernel each read the codeword once, the
         # quotient is written once, the fold loop moves ~2 x 2 x M ext elements.  The proof is integer-VALU bound, so
