@@ -779,6 +779,14 @@ typedef struct {
      * acc <- compress(acc, chunk) over the claim's five 8-element chunks.  Public values [acc before (8) | acc after (8)]. */
     int uniform;
     unsigned min_log_height[2];
+    /* PER-PROOF CHIP PRESENCE (the reference proves only the chips a segment used: AGENTS.md:183-185): an app has one segment key -- hence
+     * one leaf circuit -- per SHAPE (set of chips a segment may carry: the base chips; + the hash intrinsics; + every extension), all
+     * padded to one height set.  A uniform internal circuit built with n_leaf_shapes = S (<= 8; 0 = 1) takes the S leaf commitments as
+     * values, a one-hot selector per leaf child, and states as its leaf commitment the sponge of the list (S = 1: the commitment itself).
+     * app_id (leaf circuits; 8 canonical words or NULL): the statement's first 8 words, instead of the digest of the child key -- the
+     * leaf circuits of one app state ONE app id (zkhip_recursion_vk_digest of the full shape). */
+    size_t n_leaf_shapes;
+    const uint32_t *app_id;
 } zkhip_recursion_stmt;
 /* `airs[a].log_height` and `airs[a].prep_commit` are part of the child verifying key; program pointers are copied. */
 int zkhip_recursion_build(const zkhip_params *child_params, const zkhip_air *child_airs, size_t n_child_airs, size_t max_children,
@@ -795,6 +803,8 @@ int zkhip_recursion_build_join(const zkhip_params *params_a, const zkhip_air *ai
 int zkhip_recursion_fork(const zkhip_recursion *r, zkhip_recursion **out);
 /* lays the preprocessed traces out again at heights >= 2^log_height[0] (gate chip) / 2^log_height[1] (Poseidon2 chip); not on a forked circuit */
 int zkhip_recursion_pad(zkhip_recursion *r, const unsigned log_height[2]);
+/* digest of a verifying key (parameters, AIR programs, heights, preprocessed commitments): what a leaf circuit built for it states */
+int zkhip_recursion_vk_digest(const zkhip_params *params, const zkhip_air *airs, size_t n_airs, uint32_t out[8]);
 /* digest of a node key's preprocessed commitments (n_commits x 8 canonical words, AIR order): the leaf / internal commitment of a uniform node */
 int zkhip_recursion_key_commit(const uint32_t *prep_commits, size_t n_commits, uint32_t out[8]);
 const char *zkhip_recursion_last_error(const zkhip_recursion *r); /* r = NULL: why the last zkhip_recursion_build of this thread failed */
@@ -815,7 +825,8 @@ int zkhip_recursion_air(const zkhip_recursion *r, size_t i, zkhip_air *out);
 int zkhip_recursion_witness(zkhip_recursion *r, const uint8_t *const *proofs, const size_t *proof_lens, const uint32_t *const *const *child_pvs,
                             size_t n_present, uint32_t *node_pvs_out);
 /* the witness of a UNIFORM node: child c is a proof under the key with preprocessed commitments child_prep_commits[c] (3 x 8 canonical
- * words), of the leaf circuit (child_is_leaf[c] != 0) or the internal circuit; leaf_commit / internal_commit: see zkhip_recursion_stmt */
+ * words), of the internal circuit (child_is_leaf[c] = 0) or of leaf circuit j (child_is_leaf[c] = j + 1); leaf_commit = the S leaf
+ * commitments (8 S words), internal_commit: see zkhip_recursion_stmt */
 int zkhip_recursion_witness_uniform(zkhip_recursion *r, const uint8_t *const *proofs, const size_t *proof_lens, const uint32_t *const *const *child_pvs,
                                     const uint32_t *child_prep_commits, const int *child_is_leaf, const uint32_t leaf_commit[8],
                                     const uint32_t internal_commit[8], size_t n_present, uint32_t *node_pvs_out);

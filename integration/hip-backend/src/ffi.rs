@@ -165,6 +165,10 @@ pub struct zkhip_recursion_stmt {
     pub uniform: c_int,
     /// pads the gate / Poseidon2 chip (0 = natural size)
     pub min_log_height: [c_uint; 2],
+    /// uniform node: how many leaf circuits (shapes: sets of chips a segment may carry) its leaf children come from (0 = 1)
+    pub n_leaf_shapes: usize,
+    /// leaf circuits of one app state one app id (8 canonical words or null)
+    pub app_id: *const u32,
 }
 
 #[repr(C)]
@@ -432,6 +436,7 @@ extern "C" {
     pub fn zkhip_recursion_n_aux(r: *const zkhip_recursion) -> usize;
     pub fn zkhip_recursion_fork(r: *const zkhip_recursion, out: *mut *mut zkhip_recursion) -> c_int;
     pub fn zkhip_recursion_pad(r: *mut zkhip_recursion, log_height: *const c_uint) -> c_int;
+    pub fn zkhip_recursion_vk_digest(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize, out: *mut u32) -> c_int;
     pub fn zkhip_recursion_key_commit(prep_commits: *const u32, n_commits: usize, out: *mut u32) -> c_int;
     pub fn zkhip_recursion_wires(r: *const zkhip_recursion, out: *mut u32, cap_words: usize, n_words: *mut usize) -> c_int;
     pub fn zkhip_recursion_tracegen(ctx: *mut zkhip_ctx, r: *mut zkhip_recursion, d_gate_trace: *mut u32, d_p2_trace: *mut u32,

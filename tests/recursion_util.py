@@ -182,3 +182,28 @@ def deferral_chain(acc, claims):
         for c in chunks:
             acc = compress(acc, c)
     return acc
+
+
+def one_key_circuits_shapes(params, app_vks, stmt, arity_leaf=4, arity_internal=3):
+    """ONE aggregation key over several SHAPES of one app (per-proof chip presence: a segment carries only the chips it used, the app has
+    one segment key and one leaf circuit per shape): the leaf circuits state one app id -- the digest of the LAST (full) shape --, share
+    one height set with the internal circuit, and the internal circuit takes the list of their commitments."""
+    import zkvm_prover_amd as z
+
+    app_id = z.vk_digest(params, app_vks[-1])
+    leafs = [z.RecursionCircuit(params, vk, arity_leaf, stmt=stmt, uniform=True, app_id=app_id) for vk in app_vks]
+    na = leafs[0].airs()
+    child = [{k: a[k] for k in ("program", "log_height", "width", "n_pvs")} for a in na]
+    H = [max(l.log_heights()[i] for l in leafs) for i in (0, 1)]
+    while True:
+        for c, h in zip(child, H + [0]):
+            c["log_height"] = h
+        internal = z.RecursionCircuit(params, child, arity_internal, stmt="uniform", min_log_height=H, n_leaf_shapes=len(leafs))
+        hh = internal.log_heights()[:2]
+        if hh == H:
+            break
+        H = hh
+    for l in leafs:
+        l.pad(*H)
+        assert l.log_heights() == internal.log_heights()
+    return leafs, internal, app_id

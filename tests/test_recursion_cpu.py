@@ -247,3 +247,59 @@ def test_one_aggregation_key_self_recursive_internal_circuit(ora):
     # the per-key entry point refuses a uniform circuit and the other way round
     assert internal.witness([n0[0]], [[NOPV, NOPV, n0[1]]])[0] == -3
     assert leaf.witness([proofs[0]], [pvs[0]], prep_commits=[leaf_pcs], is_leaf=[1], leaf_commit=LC, internal_commit=IC)[0] == -3
+
+
+def test_one_key_over_several_shapes_of_one_app(ora):
+    """PER-PROOF CHIP PRESENCE (the reference proves only the chips a segment used, AGENTS.md:183-185): the app has one segment key -- and
+    one leaf circuit -- per shape.  Here shape A = four chips, shape B = the same without the Fibonacci chip.  Segments A A B A -> leaf
+    nodes [A A] [B] [A] (a leaf node takes proofs of ONE shape) -> one internal node over leaf proofs of both circuits: the root states the
+    sponge of the two leaf commitments and ONE app id; a leaf proof of a circuit outside the list, a misstated shape have no witness."""
+    starts = [5, 12, 19, 26]
+    full = [ru.counter_segment(s, seed=i) for i, s in enumerate(starts)]
+    segs = [full[0], full[1], [full[2][0], full[2][1], full[2][3]], full[3]]        # segment 2 carries no Fibonacci chip
+    shape_of = [0, 0, 1, 0]
+    vks = [ru.verifying(PARAMS, segs[2]), ru.verifying(PARAMS, full[0])]             # shapes: B (index 0), A = the full set (index 1, last)
+    shape_idx = [1, 1, 0, 1]
+    proofs = [ora.stark_prove(PARAMS, s).tobytes() for s in segs]
+    pvs = [[a["pvs"] for a in s] for s in segs]
+    leafs, internal, app_id = ru.one_key_circuits_shapes(PARAMS, vks, ru.COUNTER_STMT)
+    assert app_id.tolist() == z.vk_digest(PARAMS, vks[1]).tolist() != z.vk_digest(PARAMS, vks[0]).tolist()
+    keys = [ru.node_key_commits(PARAMS, l.airs()) for l in leafs]
+    int_pcs, IC = ru.node_key_commits(PARAMS, internal.airs())
+    LCs = [k[1] for k in keys]
+    LC_list = ru.sponge(np.concatenate(LCs))
+
+    def leaf_node(shape, group):
+        st, npv = leafs[shape].witness([proofs[i] for i in group], [pvs[i] for i in group])
+        assert st == 0, leafs[shape].last_error()
+        assert npv[:8].tolist() == app_id.tolist()                                   # both circuits state the one app id
+        return ora.stark_prove(PARAMS, ru.node_instance(leafs[shape], npv)).tobytes(), npv, shape
+
+    assert leafs[1].witness([proofs[1], proofs[2]], [pvs[1], pvs[2]])[0] != 0       # a leaf node takes proofs of ONE shape
+    L = [leaf_node(1, [0, 1]), leaf_node(0, [2]), leaf_node(1, [3])]
+    assert shape_of and shape_idx
+
+    def status(children, kinds, lcs=LCs, ic=IC):
+        return internal.witness([c[0] for c in children], [[NOPV, NOPV, c[1]] for c in children],
+                                prep_commits=[keys[k - 1][0] if k else int_pcs for k in kinds], is_leaf=kinds, leaf_commit=np.concatenate(lcs), internal_commit=ic)
+
+    st, rpv = status(L, [2, 1, 2])
+    assert st == 0, internal.last_error()
+    assert rpv[:8].tolist() == app_id.tolist() and int(rpv[8]) == 5 and int(rpv[9]) == 33
+    assert rpv[18:26].tolist() == LC_list.tolist() and rpv[26:34].tolist() == IC.tolist()
+    node = ru.node_instance(internal, rpv)
+    for a in node[:2]:
+        assert air.check_trace(a["program"], a["trace"], a["pvs"], a["prep"]) == []
+    root = ora.stark_prove(PARAMS, node).tobytes()
+    # ... and the internal circuit verifies its own proof beside a leaf proof, stating the same list
+    st, top = internal.witness([root], [[NOPV, NOPV, rpv]], prep_commits=[int_pcs], is_leaf=[0], leaf_commit=np.concatenate(LCs), internal_commit=IC)
+    assert st == 0 and top[18:26].tolist() == LC_list.tolist()
+    # refusals: a shape misstated, the list in another order (another statement: the children then fail their selector), a circuit outside the list
+    assert status(L, [2, 2, 2])[0] == -7
+    assert status(L, [1, 1, 2])[0] == -7
+    assert status(L, [2, 1, 2], lcs=LCs[::-1])[0] == -7
+    other = LCs[0].copy()
+    other[2] ^= 1
+    assert status(L, [2, 1, 2], lcs=[other, LCs[1]])[0] == -7
+    st, top2 = internal.witness([root], [[NOPV, NOPV, rpv]], prep_commits=[int_pcs], is_leaf=[0], leaf_commit=np.concatenate([other, LCs[1]]), internal_commit=IC)
+    assert st == -7                                                                  # an internal child states another list

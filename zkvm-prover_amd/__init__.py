@@ -17,6 +17,7 @@ from ._binding import (  # noqa: F401
     ProvingKey,
     RecursionCircuit,
     key_commit,
+    vk_digest,
     keccak_f_air,
     keccak_f1600_host,
     int256_alu_air,

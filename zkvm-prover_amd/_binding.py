@@ -58,7 +58,7 @@ class _V1Summary(C.Structure):
 class _RecursionStmt(C.Structure):
     _fields_ = [("n_state", C.c_size_t), ("start_air", C.POINTER(C.c_uint32)), ("start_idx", C.POINTER(C.c_uint32)),
                 ("end_air", C.POINTER(C.c_uint32)), ("end_idx", C.POINTER(C.c_uint32)), ("child_is_node", C.c_int),
-                ("uniform", C.c_int), ("min_log_height", C.c_uint * 2)]
+                ("uniform", C.c_int), ("min_log_height", C.c_uint * 2), ("n_leaf_shapes", C.c_size_t), ("app_id", C.POINTER(C.c_uint32))]
 
 
 class _KernelStat(C.Structure):
@@ -235,6 +235,7 @@ def load_library():
         "zkhip_recursion_fork": (C.c_int, [vp, C.POINTER(vp)]),
         "zkhip_recursion_pad": (C.c_int, [vp, C.POINTER(C.c_uint)]),
         "zkhip_recursion_key_commit": (C.c_int, [u32p, sz, u32p]),
+        "zkhip_recursion_vk_digest": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, u32p]),
         "zkhip_recursion_witness_uniform": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(C.POINTER(u32p)), u32p,
                                                        C.POINTER(C.c_int), u32p, u32p, sz, u32p]),
         "zkhip_recursion_tracegen": (C.c_int, [vp, vp, vp, vp, vp]),
@@ -1206,6 +1207,17 @@ def key_commit(prep_commits):
     return out
 
 
+def vk_digest(params, airs):
+    """zkhip_recursion_vk_digest: the digest a leaf circuit built for this verifying key states."""
+    prm = _Params(*tuple(params))
+    arr, keep = _air_structs(airs)
+    out = np.zeros(8, dtype=np.uint32)
+    rc = load_library().zkhip_recursion_vk_digest(C.byref(prm), arr, len(airs), _u32p(out))
+    if rc != 0:
+        raise ZkhipError("zkhip_recursion_vk_digest returned %d" % rc)
+    return out
+
+
 class RecursionCircuit:
     """zkhip_recursion: the verifier circuit of an aggregation node for ONE child verifying key (params + verifying AIRs with
     heights and preprocessed commitments) and up to `max_children` child proofs.  Building it and running the witness need no
@@ -1214,9 +1226,11 @@ class RecursionCircuit:
     dict(start=[(air, idx)..], end=[(air, idx)..]); uniform=True on a leaf circuit appends the [leaf | internal commitment] words (zero)
     to its public values; min_log_height = (gate chip, Poseidon2 chip) pads."""
 
-    def __init__(self, params, child_airs, max_children, stmt=None, uniform=False, min_log_height=(0, 0), _fork_of=None, _join_with=None):
+    def __init__(self, params, child_airs, max_children, stmt=None, uniform=False, min_log_height=(0, 0), n_leaf_shapes=1, app_id=None, _fork_of=None,
+                 _join_with=None):
         self.lib = load_library()
         self.params, self.child_airs = tuple(params), child_airs
+        self.n_leaf_shapes = int(_fork_of.n_leaf_shapes if _fork_of is not None else n_leaf_shapes)
         if _join_with is not None:
             params_b, airs_b = _join_with
             pa, pb = _Params(*self.params), _Params(*tuple(params_b))
@@ -1238,6 +1252,12 @@ class RecursionCircuit:
         st = _RecursionStmt()
         st.uniform = 1 if uniform else 0
         st.min_log_height[0], st.min_log_height[1] = int(min_log_height[0]), int(min_log_height[1])
+        st.n_leaf_shapes = int(n_leaf_shapes)
+        self.n_leaf_shapes = int(n_leaf_shapes)
+        aid = None
+        if app_id is not None:
+            aid = np.ascontiguousarray(app_id, dtype=np.uint32)
+            st.app_id = _u32p(aid)
         keep2 = []
         if stmt == "node":
             st.child_is_node = 1
@@ -1324,9 +1344,10 @@ class RecursionCircuit:
             return rc, out
         if prep_commits is not None:
             pc = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32).reshape(-1) for x in prep_commits]), dtype=np.uint32)
-            kinds = (C.c_int * n)(*[1 if x else 0 for x in is_leaf])
-            lc, ic = np.ascontiguousarray(leaf_commit, dtype=np.uint32), np.ascontiguousarray(internal_commit, dtype=np.uint32)
-            assert pc.size == 24 * n and lc.size == 8 and ic.size == 8
+            kinds = (C.c_int * n)(*[int(x) for x in is_leaf])   # 0 = internal, j + 1 = leaf circuit j
+            lc = np.ascontiguousarray(np.asarray(leaf_commit, dtype=np.uint32).reshape(-1), dtype=np.uint32)
+            ic = np.ascontiguousarray(internal_commit, dtype=np.uint32)
+            assert pc.size == 24 * n and lc.size == 8 * getattr(self, "n_leaf_shapes", 1) and ic.size == 8
             rc = self.lib.zkhip_recursion_witness_uniform(self.h, pp, lens, pv, _u32p(pc), kinds, _u32p(lc), _u32p(ic), n, _u32p(out))
             return rc, out
         rc = self.lib.zkhip_recursion_witness(self.h, pp, lens, pv, n, _u32p(out))

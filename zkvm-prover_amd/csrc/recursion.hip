@@ -1010,6 +1010,9 @@ struct RecCore {
     // 3 = deferral node (children: root proofs under a fixed aggregation key), 4 = join (a root + a deferral node proof)
     int mode = 0;
     bool uniform = false;  // public values end with [leaf commitment (8) | internal commitment (8)]
+    size_t n_leaf_shapes = 1;          // uniform node: how many leaf circuits (one per set of chips a segment may carry) its leaf children come from
+    bool has_app_id = false;           // leaf: the statement's first 8 words are this constant instead of the child key's digest
+    uint32_t app_id[8] = {};           // (Montgomery)
     size_t max_children = 0, n_state = 0;
     Circuit c;
     size_t child_proof_words = 0, n_aux = 0;
@@ -1351,7 +1354,8 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
         // app vk digest: the constant digest of the child vk (leaf level) or what the children carry (all equal)
         std::array<V, 8> vkd;
         if (!sp.child_is_node) {
-            for (int k = 0; k < 8; k++) vkd[k] = cst_base(vk.digest[k]);
+            // (several leaf circuits of one app -- one per set of chips a segment may carry -- state ONE app id: the digest of the full set)
+            for (int k = 0; k < 8; k++) vkd[k] = cst_base(K.has_app_id ? K.app_id[k] : vk.digest[k]);
         } else {
             const size_t pa = n_airs - 1;
             for (int k = 0; k < 8; k++) vkd[k] = kids[0].pvs[pa][k];
@@ -1364,28 +1368,64 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
         std::array<V, 8> leaf_commit, internal_commit;
         for (int k = 0; k < 8; k++) leaf_commit[k] = internal_commit[k] = cst(ext_zero());
         if (K.mode == 2) {
-            for (uint32_t which = 0; which < 2; which++)
+            // the leaf circuits' commitments (one per shape) and the internal circuit's: values of this node; what it STATES as its leaf
+            // commitment is the one commitment (one shape) or the sponge of the list
+            const size_t S = K.n_leaf_shapes;
+            std::vector<std::array<V, 8>> leaf_list(S);
+            for (uint32_t j = 0; j < S; j++)
                 for (uint32_t k = 0; k < 8; k++) {
                     Src sr;
-                    sr.kind = S_COMMIT, sr.a = which, sr.b = k;
-                    (which ? internal_commit : leaf_commit)[k] = b.in_base(sr);
+                    sr.kind = S_COMMIT, sr.a = 0, sr.b = 8 * j + k;
+                    leaf_list[j][k] = b.in_base(sr);
                 }
-            const std::array<V, 2> lc{b.pack({leaf_commit[0], leaf_commit[1], leaf_commit[2], leaf_commit[3]}),
-                                      b.pack({leaf_commit[4], leaf_commit[5], leaf_commit[6], leaf_commit[7]})};
+            for (uint32_t k = 0; k < 8; k++) {
+                Src sr;
+                sr.kind = S_COMMIT, sr.a = 1, sr.b = k;
+                internal_commit[k] = b.in_base(sr);
+            }
+            std::vector<std::array<V, 2>> lcs(S);
+            for (size_t j = 0; j < S; j++) lcs[j] = {b.pack({leaf_list[j][0], leaf_list[j][1], leaf_list[j][2], leaf_list[j][3]}),
+                                                   b.pack({leaf_list[j][4], leaf_list[j][5], leaf_list[j][6], leaf_list[j][7]})};
+            if (S == 1) {
+                leaf_commit = leaf_list[0];
+            } else {
+                std::vector<Lane> lanes;
+                for (size_t j = 0; j < S; j++)
+                    for (int k = 0; k < 8; k++) lanes.push_back(Lane{leaf_list[j][k], -1});
+                const std::array<V, 2> h = b.sponge(lanes);
+                const std::array<V, 4> h0 = b.unpack(h[0]), h1 = b.unpack(h[1]);
+                for (int k = 0; k < 4; k++) leaf_commit[k] = h0[k], leaf_commit[4 + k] = h1[k];
+            }
             const std::array<V, 2> ic{b.pack({internal_commit[0], internal_commit[1], internal_commit[2], internal_commit[3]}),
                                       b.pack({internal_commit[4], internal_commit[5], internal_commit[6], internal_commit[7]})};
             const size_t pa = n_airs - 1, o = 16 + 2 * NS;
             for (size_t ci = 0; ci < max_children; ci++) {   // (an absent slot repeats child 0, commitments and kind included)
                 Src sr;
-                sr.kind = S_KIND, sr.child = (uint32_t)ci;
+                sr.kind = S_KIND, sr.child = (uint32_t)ci, sr.a = 0;
                 const V is_leaf = b.in_base(sr);
                 b.assert_bool(is_leaf);
+                // which leaf circuit: a one-hot selector over the shapes (one shape: the selector is is_leaf itself)
+                std::vector<V> sel(S, is_leaf);
+                if (S > 1) {
+                    V sum = cst(ext_zero());
+                    for (uint32_t j = 0; j < S; j++) {
+                        sr.a = j + 1;
+                        sel[j] = b.in_base(sr);
+                        b.assert_bool(sel[j]);
+                        sum = b.add(sum, sel[j]);
+                    }
+                    b.assert_eq(sum, is_leaf);
+                }
                 std::vector<Lane> lanes;
                 for (size_t a = 0; a < n_airs; a++)
                     if (vk.has_prep[a])
                         for (int k = 0; k < 8; k++) lanes.push_back(Lane{prep_in[ci][a][k], -1});
                 const std::array<V, 2> d = b.sponge(lanes);
-                for (int k = 0; k < 2; k++) b.assert_eq(d[k], b.select(is_leaf, lc[k], ic[k]));
+                for (int k = 0; k < 2; k++) {
+                    V target = ic[k];   // ic + sum_j sel_j (lc_j - ic)
+                    for (size_t j = 0; j < S; j++) target = b.mul_add(sel[j], b.sub(lcs[j][k], ic[k]), target);
+                    b.assert_eq(d[k], target);
+                }
                 const V is_node = b.lin(0, is_leaf, V{}, b.NEG1, 0, V{}, 0, ext_one());
                 for (int k = 0; k < 8; k++) {
                     b.assert_product_zero(is_node, b.sub(kids[ci].pvs[pa][o + k], leaf_commit[k]));
@@ -1501,6 +1541,15 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
     RecCore& K = *R->k;
     K.mode = stmt->child_is_node;
     K.uniform = K.mode == 2 || (K.mode == 0 && stmt->uniform);
+    if (stmt->n_leaf_shapes > 8) return ZKHIP_ERR_INVALID;
+    K.n_leaf_shapes = K.mode == 2 ? std::max<size_t>(1, stmt->n_leaf_shapes) : 1;
+    if (K.mode == 0 && stmt->app_id) {
+        K.has_app_id = true;
+        for (int k = 0; k < 8; k++) {
+            if (stmt->app_id[k] >= P) return ZKHIP_ERR_INVALID;
+            K.app_id[k] = to_monty(stmt->app_id[k]);
+        }
+    }
     ChildVk& vk = K.vk;
     {
         const int rc = load_child_vk(prm, airs, n_airs, K.mode == 2, vk);
@@ -1620,6 +1669,17 @@ int zkhip_recursion_key_commit(const uint32_t* prep_commits, size_t n_commits, u
     return ZKHIP_OK;
 }
 
+// digest of a verifying key's transcript preamble (parameters, AIR programs, heights, preprocessed commitments): what a leaf circuit built
+// for this key states as the app's digest -- without building the circuit
+int zkhip_recursion_vk_digest(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, uint32_t out[8]) {
+    if (!out) return ZKHIP_ERR_INVALID;
+    ChildVk vk;
+    const int rc = load_child_vk(prm, airs, n_airs, false, vk);
+    if (rc != ZKHIP_OK) return rc;
+    for (int k = 0; k < 8; k++) out[k] = from_monty(vk.digest[k]);
+    return ZKHIP_OK;
+}
+
 int zkhip_recursion_air(const zkhip_recursion* R, size_t i, zkhip_air* out) {
     if (!R || !out || i >= 3) return ZKHIP_ERR_INVALID;
     const RecCore& K = *R->k;
@@ -1680,8 +1740,12 @@ int recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const si
         if (!uni->prep_commits || !uni->is_leaf || !uni->leaf_commit || !uni->internal_commit) return ZKHIP_ERR_INVALID;
         for (size_t i = 0; i < 8 * n_prep_airs * n_present; i++)
             if (uni->prep_commits[i] >= P) return ZKHIP_ERR_INVALID;
+        for (size_t k = 0; k < 8 * K.n_leaf_shapes; k++)
+            if (uni->leaf_commit[k] >= P) return ZKHIP_ERR_INVALID;
         for (int k = 0; k < 8; k++)
-            if (uni->leaf_commit[k] >= P || uni->internal_commit[k] >= P) return ZKHIP_ERR_INVALID;
+            if (uni->internal_commit[k] >= P) return ZKHIP_ERR_INVALID;
+        for (size_t c = 0; c < n_present; c++)
+            if (uni->is_leaf[c] < 0 || (size_t)uni->is_leaf[c] > K.n_leaf_shapes) return ZKHIP_ERR_INVALID;
     }
     if (def) {
         if (!def->aux || !def->acc_start) return ZKHIP_ERR_INVALID;
@@ -1767,7 +1831,11 @@ int recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const si
                             case S_PV: v.c[0] = to_monty(child_pvs[sr.child < n_present ? sr.child : 0][sr.a][sr.b]); break;
                             case S_FLAG: v.c[0] = sr.child < n_present ? MONTY_ONE : 0; break;
                             case S_PREP: v.c[0] = to_monty(uni->prep_commits[((sr.child < n_present ? sr.child : 0) * n_prep_airs + prep_slot[sr.a]) * 8 + sr.b]); break;
-                            case S_KIND: v.c[0] = uni->is_leaf[sr.child < n_present ? sr.child : 0] ? MONTY_ONE : 0; break;
+                            case S_KIND: {   // a = 0: is the child a leaf proof; a = j + 1: is it a proof of leaf circuit j
+                                const int kind = uni->is_leaf[sr.child < n_present ? sr.child : 0];
+                                v.c[0] = (sr.a == 0 ? kind != 0 : kind == (int)sr.a) ? MONTY_ONE : 0;
+                                break;
+                            }
                             case S_COMMIT: v.c[0] = to_monty((sr.a == 2 ? def->acc_start : sr.a ? uni->internal_commit : uni->leaf_commit)[sr.b]); break;
                             case S_AUX: v.c[0] = to_monty(def->aux[(sr.child < n_present ? sr.child : 0) * K.n_aux + sr.a]); break;
                             case S_HINT_BIT: v.c[0] = ((from_monty(vals[sr.a].c[0]) >> sr.b) & 1) ? MONTY_ONE : 0; break;
