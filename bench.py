@@ -170,21 +170,23 @@ def cpu_baseline(args, params, airs, host_traces, pvs, gpu_proof):
                          "EQUAL" if same else "DIFFER FROM")}
 
 
-def guest_flow():
+def guest_flow(chunk_config=False):
     """The path AROUND the headline kernel, reported beside it (never `value`): a Fibonacci guest of 4.2 M instructions through
     `prove_cli prove-elf` (tools/guest_bench2.py) -- segmenting executor, 22 chips per segment as ONE statement, device trace generation,
     segment proofs, aggregation tree on verifier circuits, ONE self-verified root proof, at the reference's FRI parameters.  Runs as a
     CHILD process BEFORE this process touches the GPU (a process that has initialised HIP must not start programs); twice: the first
-    run pays the hipRTC compiles of a fresh box, the second is the one reported."""
+    run pays the hipRTC compiles of a fresh box, the second is the one reported.  chunk_config: the same guest under the reference's
+    chunk-circuit openvm.toml (crates/circuits/chunk-circuit/openvm.toml: 51 chips in the full set; a Fibonacci guest's segments carry
+    the 22 base chips -- per-proof chip presence)."""
     import subprocess
 
     here = os.path.dirname(os.path.abspath(__file__))
-    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py"), "700000", "17"]
+    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py"), "700000", "17"] + (["chunk"] if chunk_config else [])
     env = dict(os.environ, ZKHIP_LANES="3")
     try:
         runs = []
         for _ in range(2):
-            r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
             if r.returncode != 0:
                 return {"value": None, "note": "failed: " + r.stderr[-300:]}
             runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
@@ -195,7 +197,9 @@ def guest_flow():
                 "execution_ms": g["execution_ms"], "segments_ms": g["segment_tracegen_and_proving_ms"],
                 "tree_tail_ms": g["aggregation_setup_wait_ms"] + g["aggregation_ms"], "process_wall_s": g["wall_s"],
                 "process_wall_s_first_run_on_this_box": runs[0]["wall_s"], "root_proof_bytes": g["root_proof_bytes"], "verified": g["verified"],
-                "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 700000 17"}
+                "chips_per_shape": g.get("chips_per_shape"), "segments_per_shape": g.get("segments_per_shape"),
+                "instr_per_s_segments_only": g.get("instr_per_s_segments_only"),
+                "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 700000 17" + (" chunk" if chunk_config else "")}
     except Exception as e:   # a reported extra, never a gate
         return {"value": None, "note": "failed: %r" % (e,)}
 
@@ -205,9 +209,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     plumbing = os.environ.get("ZKHIP_BENCH_PLUMBING_ONLY") == "1"
-    guest = None
-    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not plumbing and not args.no_guest_flow and not args.no_cpu_baseline and "torch" not in sys.modules):
-        guest = guest_flow()   # (before torch / HIP are loaded here; profiling runs pass --no-cpu-baseline and skip it)
+    guest = guest_chunk = None
+    # (child processes: only before torch / HIP are loaded here, and never under a profiler -- its preloaded library has initialised the GPU
+    # before this program starts; the profiling recipes pass --no-cpu-baseline or --no-guest-flow, either of which skips the guest flows)
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not plumbing and not args.no_guest_flow and not args.no_cpu_baseline and "torch" not in sys.modules:
+        guest = guest_flow()
+        guest_chunk = guest_flow(chunk_config=True)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -550,6 +557,8 @@ def main():
                                        "sample": "failed: %r" % (e,)}
         if guest is not None:
             out["guest_flow"] = guest
+        if guest_chunk is not None:
+            out["guest_flow_chunk_config"] = guest_chunk
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -840,6 +840,41 @@ int zkhip_recursion_wires(const zkhip_recursion *r, uint32_t *out, size_t cap_wo
 /* device traces of the three chips from the last witness (Montgomery, column-major, stride = 2^log_height of the chip) */
 int zkhip_recursion_tracegen(zkhip_ctx *ctx, zkhip_recursion *r, uint32_t *d_gate_trace, uint32_t *d_p2_trace, uint32_t *d_pv_trace);
 
+/* ---- configuration.  Every behaviour-changing switch of the library is a FIELD here; the ZKHIP_* environment variables are overrides
+ *      read in ONE place (zkhip_config_default) when a context is created -- or when the caller asks for the defaults -- and nowhere else.
+ *      (What stays a bare environment variable is listed in README.md: measurement / A-B switches of single kernels and
+ *      ZKHIP_KEYGEN_TIMING, none of which changes what the library computes or when it blocks.) ---- */
+typedef struct {
+    /* transcript: absorptions of >= host_sponge_min_words words (the opened values of a big proof) run on the host's 512-bit vector unit
+     * -- ~0.25 us per permutation against ~1.5 us for the dependent chain on the device.  NOTE: this makes zkhip_prove_async BLOCK the
+     * calling thread (two stream synchronisations) in the middle of such a proof; a host thread that drives several pipelines should
+     * set host_sponge = 0.  [ZKHIP_NO_HOST_SPONGE=1 -> 0; ZKHIP_HOST_SPONGE_MIN_WORDS] */
+    int host_sponge;
+    uint32_t host_sponge_min_words;
+    /* constraint kernels: 0 = interpreter only, 1 = compiled (hipRTC, at keygen) where 2^jit_min_log_work row-instructions repay the
+     * compile, 2 = always compiled.  [ZKHIP_NO_JIT=1 -> 0, ZKHIP_FORCE_JIT=1 -> 2; ZKHIP_JIT_MIN_LOG_WORK] */
+    int jit;
+    uint32_t jit_min_log_work;
+    /* directory of compiled constraint kernels kept across processes ("" = none).  Default: `jit_cache` next to libzkhip.so when it
+     * exists (populated by __graft_entry__.build() -- hipRTC needs no GPU), else none.  [ZKHIP_JIT_CACHE_DIR] */
+    char jit_cache_dir[256];
+    int quot_slices;               /* short, wide chips run as up to 16 constraint slices side by side [ZKHIP_NO_QUOT_SLICES=1 -> 0] */
+    uint32_t grind_sweep_shift;    /* a proof-of-work sweep covers 2^(bits + shift) candidates [ZKHIP_GRIND_SWEEP_SHIFT] */
+    uint32_t coop_max_log, coop_inj_max_log; /* largest tree layer (plain / with injected rows) in the cooperative form [ZKHIP_COOP_MAX_LOG, ZKHIP_COOP_INJ_MAX_LOG] */
+    uint32_t commit_parts, side_cus;         /* pipelined trace commit (zkhip_set_commit_pipeline / zkhip_set_cu_partition) [ZKHIP_COMMIT_PARTS, ZKHIP_SIDE_CUS] */
+    /* the verifier circuit's witness (no context): threads of the query parts (0 = all cores), page-locking of the wire values for the
+     * copy to the device, queries of a child side by side [ZKHIP_WITNESS_THREADS, ZKHIP_NO_PIN_WITNESS=1 -> 0, ZKHIP_RECURSION_SERIAL_QUERIES=1 -> 0] */
+    uint32_t witness_threads;
+    int pin_witness, parallel_queries;
+} zkhip_config;
+/* the built-in defaults with the environment's overrides applied */
+void zkhip_config_default(zkhip_config *out);
+/* a context's configuration (set at zkhip_ctx_create from zkhip_config_default); the witness fields are process-wide:
+ * zkhip_set_process_config stores them (and the rest as the default of contexts created later) */
+int zkhip_ctx_get_config(zkhip_ctx *ctx, zkhip_config *out);
+int zkhip_ctx_set_config(zkhip_ctx *ctx, const zkhip_config *cfg);
+int zkhip_set_process_config(const zkhip_config *cfg);
+
 /* ---- per-kernel timing (HIP events on the ctx stream), for bench.py's roofline ---- */
 int zkhip_profile_enable(zkhip_ctx *ctx, int on);
 /* copies up to cap entries; returns number of distinct kernel names recorded */

@@ -160,6 +160,25 @@ struct AggregationSystemParams {
     bool same() const { return memcmp(&leaf, &internal, sizeof(zkhip_params)) == 0; }
 };
 
+using Digest8 = std::array<uint32_t, 8>;
+inline Digest8 p2_compress8(const Digest8& l, const Digest8& r) {
+    uint32_t st[16];
+    for (int i = 0; i < 8; i++) st[i] = l[i], st[8 + i] = r[i];
+    zkhip_poseidon2_permute_host(st);
+    Digest8 d;
+    std::copy(st, st + 8, d.begin());
+    return d;
+}
+inline Digest8 p2_sponge8(const uint32_t* v, size_t n) {   // PaddingFreeSponge<16, 8, 8>: overwrite, permute, no padding
+    uint32_t st[16] = {};
+    for (size_t i = 0; i < n; i += 8) {
+        for (size_t k = 0; k < 8 && i + k < n; k++) st[k] = v[i + k];
+        zkhip_poseidon2_permute_host(st);
+    }
+    Digest8 d;
+    std::copy(st, st + 8, d.begin());
+    return d;
+}
 class AggregationProver {
 public:
     struct Stats {
@@ -167,10 +186,23 @@ public:
         double witness_seconds = 0, tracegen_prove_seconds = 0, verify_seconds = 0, keygen_seconds = 0, build_seconds = 0;
     };
 
+    // PER-PROOF CHIP PRESENCE (the reference proves only the chips a segment used: AGENTS.md:183-185): an app may have several SHAPES -- sets of
+    // chips a segment carries, each with a segment key of its own; the LAST one is the full set -- and the tree one leaf circuit per shape
+    // (one_key only).  A leaf node takes proofs of ONE shape; the internal circuit takes leaf proofs of any listed shape.
+    static AggregationProver setup_shapes(const std::vector<VerifyingKey>& shapes, const StatementSpec& spec, AggregationTreeConfig cfg = {}, int device = 0,
+                                          const AggregationSystemParams* agg_params = nullptr) {
+        if (shapes.empty() || shapes.size() > 8) throw Error(Error::Setup, "aggregation: 1..8 shapes");
+        if (shapes.size() > 1 && !cfg.one_key) throw Error(Error::Setup, "aggregation: several shapes need the one-key tree");
+        AggregationProver p = setup(shapes.back(), spec, cfg, device, agg_params);
+        p.apps_ = shapes;
+        for (const auto& a : shapes)
+            if (a.airs.size() != a.heights.size() || a.airs.empty()) throw Error(Error::Setup, "aggregation: the app verifying key needs one height per AIR");
+        return p;
+    }
     static AggregationProver setup(const VerifyingKey& app, const StatementSpec& spec, AggregationTreeConfig cfg = {}, int device = 0,
                                    const AggregationSystemParams* agg_params = nullptr) {
         AggregationProver p;
-        p.app_ = app, p.spec_ = spec, p.cfg_ = cfg, p.device_ = device;
+        p.app_ = app, p.apps_ = {app}, p.spec_ = spec, p.cfg_ = cfg, p.device_ = device;
         p.agg_params_ = agg_params ? *agg_params : AggregationSystemParams::defaults_for(app.params);
         p.levels_mu_.reset(new std::mutex), p.dev_mu_.reset(new std::mutex), p.build_mu_.reset(new std::mutex);
         if (app.airs.size() != app.heights.size() || app.airs.empty()) throw Error(Error::Setup, "aggregation: the app verifying key needs one height per AIR");
@@ -183,31 +215,34 @@ public:
     AggregationProver(AggregationProver&& o) noexcept { *this = std::move(o); }
     AggregationProver& operator=(AggregationProver&& o) noexcept {
         reset();
-        app_ = std::move(o.app_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, agg_params_ = o.agg_params_, device_ = o.device_, ctx_ = o.ctx_, levels_ = std::move(o.levels_), stats = o.stats;
-        leaf_commit_ = std::move(o.leaf_commit_), internal_commit_ = std::move(o.internal_commit_);
+        app_ = std::move(o.app_), apps_ = std::move(o.apps_), leafs_ = std::move(o.leafs_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, agg_params_ = o.agg_params_, device_ = o.device_, ctx_ = o.ctx_, levels_ = std::move(o.levels_), stats = o.stats;
+        leaf_commit_ = std::move(o.leaf_commit_), internal_commit_ = std::move(o.internal_commit_), leaf_list_ = std::move(o.leaf_list_);
         levels_mu_ = std::move(o.levels_mu_), dev_mu_ = std::move(o.dev_mu_), build_mu_ = std::move(o.build_mu_);
         o.ctx_ = nullptr;
         return *this;
     }
     ~AggregationProver() { reset(); }
     void reset() {
-        for (auto& L : levels_) {
-            for (void* d : L.d_traces)
-                if (d) zkhip_free(ctx_, d);
-            if (L.pk && L.owns_pk) zkhip_pk_destroy(ctx_, L.pk);
-            if (L.circ) zkhip_recursion_destroy(L.circ);
-        }
-        levels_.clear();
+        for (auto* set : {&levels_, &leafs_})
+            for (auto& L : *set) {
+                for (void* d : L.d_traces)
+                    if (d) zkhip_free(ctx_, d);
+                if (L.pk && L.owns_pk) zkhip_pk_destroy(ctx_, L.pk);
+                if (L.circ) zkhip_recursion_destroy(L.circ);
+            }
+        levels_.clear(), leafs_.clear();
         if (ctx_) zkhip_ctx_destroy(ctx_), ctx_ = nullptr;
     }
 
     Stats stats;
 
     // verifying key of the node circuit of `level` (0 = leaf; under one key every level above is THE internal circuit)
-    const VerifyingKey& node_vk(size_t level) {
+    const VerifyingKey& node_vk(size_t level, size_t shape = 0) {
         ensure_level(level);
-        return lv(level).vk;
+        return lv(level, shape).vk;
     }
+    size_t n_shapes() const { return apps_.size(); }
+    const VerifyingKey& app_vk(size_t shape = 0) const { return apps_.at(shape); }
     // the key a root of a tree with `n_levels` levels verifies under: one key = the aggregation key whatever the depth
     const VerifyingKey& root_vk(size_t n_levels = 2) {
         if (!cfg_.one_key) return node_vk(n_levels - 1);
@@ -220,14 +255,14 @@ public:
     size_t arity(size_t level) const { return level == 0 ? cfg_.num_children_leaf : cfg_.num_children_internal; }
 
     // proves one node: level 0 verifies up to 4 proofs of the app, level l > 0 up to 3 proofs of level l - 1
-    ChildProof prove_node(size_t level, const std::vector<const ChildProof*>& kids) {
+    ChildProof prove_node(size_t level, const std::vector<const ChildProof*>& kids, size_t shape = 0, const std::vector<size_t>* kid_shapes = nullptr) {
         using clk = std::chrono::steady_clock;
         auto t0 = clk::now();
-        std::vector<uint32_t> npv = witness_node(level, kids);
+        std::vector<uint32_t> npv = witness_node(level, kids, shape, kid_shapes);
         auto t1 = clk::now();
-        ChildProof out = prove_witnessed(level, std::move(npv));
+        ChildProof out = prove_witnessed(level, std::move(npv), shape);
         auto t2 = clk::now();
-        if (!lv(level).vk.verify(out)) throw Error(Error::VerifyProof, "aggregation: the node proof does not verify");
+        if (!lv(level, shape).vk.verify(out)) throw Error(Error::VerifyProof, "aggregation: the node proof does not verify");
         stats.nodes++;
         stats.witness_seconds += std::chrono::duration<double>(t1 - t0).count();
         stats.tracegen_prove_seconds += std::chrono::duration<double>(t2 - t1).count();
@@ -237,11 +272,12 @@ public:
 
     // "execution" of a node: runs the verifier circuit on the children (host; one thread per child inside the library) and
     // returns the node's public values.  Throws if a child does not verify or the states do not chain.
-    std::vector<uint32_t> witness_node(size_t level, const std::vector<const ChildProof*>& kids) {
+    // `shape` (level 0): which shape's segment proofs the node takes; `kid_shapes` (level 1): the shape of each leaf child (default 0)
+    std::vector<uint32_t> witness_node(size_t level, const std::vector<const ChildProof*>& kids, size_t shape = 0, const std::vector<size_t>* kid_shapes = nullptr) {
         ensure_level(level);
-        Level& L = lv(level);
+        Level& L = lv(level, shape);
         if (kids.empty() || kids.size() > arity(level)) throw Error(Error::GenProof, "aggregation: a node of level " + std::to_string(level) + " takes 1.." + std::to_string(arity(level)) + " children");
-        const VerifyingKey& cvk = level == 0 ? app_ : lv(level - 1).vk;   // (one key: the leaf's and the internal vk differ in the commitments only)
+        const VerifyingKey& cvk = level == 0 ? apps_.at(shape) : lv(level - 1).vk;   // (one key: the leaf's and the internal vk differ in the commitments only)
         std::vector<const uint8_t*> proofs;
         std::vector<size_t> lens;
         std::vector<std::vector<const uint32_t*>> pv_rows(kids.size());
@@ -260,10 +296,14 @@ public:
         if (cfg_.one_key && level > 0) {
             // children of level 1 are proofs of the leaf circuit, above of the internal circuit itself
             std::vector<uint32_t> pc;
-            std::vector<int> kinds(kids.size(), level == 1 ? 1 : 0);
-            for (size_t c = 0; c < kids.size(); c++)
-                for (const auto& a : cvk.airs) pc.insert(pc.end(), a.prep_commit.begin(), a.prep_commit.end());
-            rc = zkhip_recursion_witness_uniform(L.circ, proofs.data(), lens.data(), pv_ptrs.data(), pc.data(), kinds.data(), leaf_commit_.data(),
+            std::vector<int> kinds(kids.size(), 0);
+            for (size_t c = 0; c < kids.size(); c++) {
+                const size_t ks = level == 1 && kid_shapes ? kid_shapes->at(c) : 0;
+                if (level == 1) kinds[c] = (int)ks + 1;   // (0 = a proof of the internal circuit, j + 1 = of leaf circuit j)
+                const VerifyingKey& kvk = level == 1 ? lv(0, ks).vk : cvk;
+                for (const auto& a : kvk.airs) pc.insert(pc.end(), a.prep_commit.begin(), a.prep_commit.end());
+            }
+            rc = zkhip_recursion_witness_uniform(L.circ, proofs.data(), lens.data(), pv_ptrs.data(), pc.data(), kinds.data(), leaf_list_.data(),
                                                  internal_commit_.data(), kids.size(), npv.data());
         } else {
             rc = zkhip_recursion_witness(L.circ, proofs.data(), lens.data(), pv_ptrs.data(), kids.size(), npv.data());
@@ -272,10 +312,10 @@ public:
         return npv;
     }
     // device trace generation + proof of the node whose witness was computed last on this level
-    ChildProof prove_witnessed(size_t level, std::vector<uint32_t> node_pvs) {
+    ChildProof prove_witnessed(size_t level, std::vector<uint32_t> node_pvs, size_t shape = 0) {
         std::lock_guard<std::mutex> dev(*dev_mu_);
-        upload_witness(level);
-        return prove_uploaded(level, std::move(node_pvs));
+        upload_witness(level, shape);
+        return prove_uploaded(level, std::move(node_pvs), shape);
     }
 
     // The aggregation tree as a STREAM: segment proofs are pushed as they complete (any order, any thread) and every node starts as
@@ -301,7 +341,14 @@ public:
             cv_.notify_all();
             join_all();
         }
-        void push(size_t index, ChildProof seg) { put(0, index, std::move(seg)); }
+        void push(size_t index, ChildProof seg, size_t shape = 0) {
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (seg_shape_.size() <= index) seg_shape_.resize(index + 1, 0);
+                seg_shape_[index] = shape;
+            }
+            put(0, index, std::move(seg));
+        }
         // all `n_segments` proofs have been (or will be) pushed: waits for the root.  `all` (optional) receives every level's proofs.
         ChildProof finish(size_t n_segments, std::vector<std::vector<ChildProof>>* all = nullptr) {
             if (n_segments == 0) throw Error(Error::GenProof, "aggregation: no segment proofs");
@@ -354,6 +401,8 @@ public:
         std::mutex mu_;
         std::condition_variable cv_;
         std::deque<Layer> layers_;
+        std::vector<size_t> seg_shape_;     // shape of segment i (layer 0)
+        std::deque<size_t> leaf_shape_;     // shape of leaf proof k (layer 1), written when the node is formed
         std::vector<std::thread> threads_, verifiers_;
         std::string err_;
         bool stop_ = false;
@@ -398,30 +447,37 @@ public:
                 std::mutex m;
                 std::condition_variable c;
                 bool witness_ready = false, buffer_free = true, done = false;
-                size_t node = 0;
+                size_t node = 0, shape = 0;
                 std::vector<uint32_t> npv;
             };
             auto sh = std::make_shared<Shared>();
-            // witness thread: runs the circuit of node k once its children exist and the level's witness buffer is free
+            // witness thread: runs the circuit of node k once its children exist and the level's witness buffer is free.  Above the leaves node k
+            // takes children [a k, a k + a) of the layer below; a LEAF node takes the next run of segment proofs of one shape, at most a.
             threads_.emplace_back([this, level, sh] {
                 const size_t a = agg_.arity(level);
                 try {
+                    size_t next = 0;   // first child of the next node
                     for (size_t k = 0;; k++) {
                         std::vector<const ChildProof*> kids;
+                        std::vector<size_t> kid_shapes;
+                        size_t shape = 0;
                         {
                             std::unique_lock<std::mutex> lk(mu_);
                             bool end = false;
+                            size_t hi = next;
                             cv_.wait(lk, [&] {
                                 if (stop_ || !err_.empty()) return true;
                                 const Layer& in = layers_[level];
-                                const size_t lo = a * k, hi = in.total == SIZE_MAX ? lo + a : std::min(lo + a, in.total);
-                                if (in.total != SIZE_MAX && (lo >= in.total || (level >= agg_.first_root_layer() && in.total == 1))) {
+                                if (in.total != SIZE_MAX && (next >= in.total || (level >= agg_.first_root_layer() && in.total == 1))) {
                                     end = true;   // no further node on this level (a single item of a root layer is the root)
                                     return true;
                                 }
-                                if (in.items.size() < hi) return false;
-                                for (size_t c = lo; c < hi; c++)
-                                    if (!in.items[c]) return false;
+                                // the node's children: up to `a` present items from `next`; a leaf node stops where the shape changes
+                                for (hi = next; hi < next + a; hi++) {
+                                    if (in.total != SIZE_MAX && hi >= in.total) break;
+                                    if (in.items.size() <= hi || !in.items[hi]) return false;
+                                    if (level == 0 && hi > next && seg_shape_[hi] != seg_shape_[next]) break;
+                                }
                                 return true;
                             });
                             if (end) {
@@ -430,22 +486,30 @@ public:
                             }
                             if (end || stop_ || !err_.empty()) break;
                             const Layer& in = layers_[level];
-                            const size_t lo = a * k, hi = in.total == SIZE_MAX ? lo + a : std::min(lo + a, in.total);
-                            for (size_t c = lo; c < hi; c++) kids.push_back(in.items[c].get());
+                            for (size_t c = next; c < hi; c++) {
+                                kids.push_back(in.items[c].get());
+                                if (level == 1) kid_shapes.push_back(c < leaf_shape_.size() ? leaf_shape_[c] : 0);
+                            }
+                            if (level == 0) {
+                                shape = seg_shape_.size() > next ? seg_shape_[next] : 0;
+                                if (leaf_shape_.size() <= k) leaf_shape_.resize(k + 1, 0);
+                                leaf_shape_[k] = shape;
+                            }
+                            next = hi;
                         }
                         {
                             std::unique_lock<std::mutex> lk(sh->m);
                             sh->c.wait(lk, [&] { return sh->buffer_free; });
                         }
                         const auto t = std::chrono::steady_clock::now();
-                        std::vector<uint32_t> npv = agg_.witness_node(level, kids);
+                        std::vector<uint32_t> npv = agg_.witness_node(level, kids, shape, &kid_shapes);
                         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
                         {
                             std::lock_guard<std::mutex> lk(mu_);
                             agg_.stats.witness_seconds += dt;
                         }
                         std::lock_guard<std::mutex> lk(sh->m);
-                        sh->npv = std::move(npv), sh->node = k, sh->witness_ready = true, sh->buffer_free = false;
+                        sh->npv = std::move(npv), sh->node = k, sh->shape = shape, sh->witness_ready = true, sh->buffer_free = false;
                         sh->c.notify_all();
                     }
                 } catch (const std::exception& e) {
@@ -460,24 +524,24 @@ public:
                 try {
                     for (;;) {
                         std::vector<uint32_t> npv;
-                        size_t k;
+                        size_t k, shape;
                         {
                             std::unique_lock<std::mutex> lk(sh->m);
                             sh->c.wait(lk, [&] { return sh->witness_ready || sh->done; });
                             if (!sh->witness_ready) return;
-                            npv = std::move(sh->npv), k = sh->node, sh->witness_ready = false;
+                            npv = std::move(sh->npv), k = sh->node, shape = sh->shape, sh->witness_ready = false;
                         }
                         const auto t = std::chrono::steady_clock::now();
                         ChildProof out;
                         {
                             std::lock_guard<std::mutex> dev(*agg_.dev_mu_);
-                            agg_.upload_witness(level);
+                            agg_.upload_witness(level, shape);
                             {
                                 std::lock_guard<std::mutex> lk(sh->m);
                                 sh->buffer_free = true;
                                 sh->c.notify_all();
                             }
-                            out = agg_.prove_uploaded(level, std::move(npv));
+                            out = agg_.prove_uploaded(level, std::move(npv), shape);
                         }
                         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
                         {
@@ -487,9 +551,9 @@ public:
                         put(level + 1, k, std::move(out));
                         std::lock_guard<std::mutex> lk(mu_);
                         const ChildProof* made = layers_[level + 1].items[k].get();
-                        verifiers_.emplace_back([this, level, k, made] {
+                        verifiers_.emplace_back([this, level, k, made, shape] {
                             const auto tv = std::chrono::steady_clock::now();
-                            const bool ok = agg_.level_vk(level).verify(*made);
+                            const bool ok = agg_.level_vk(level, shape).verify(*made);
                             const double dv = std::chrono::duration<double>(std::chrono::steady_clock::now() - tv).count();
                             std::lock_guard<std::mutex> lk(mu_);
                             agg_.stats.verify_seconds += dv;
@@ -510,10 +574,11 @@ public:
     };
 
     // The whole tree of `plan` over the segment proofs; returns the root, `all` (optional) receives every level.
-    ChildProof prove_tree(const AggregationPlan& plan, const std::vector<ChildProof>& segments, std::vector<std::vector<ChildProof>>* all = nullptr) {
+    ChildProof prove_tree(const AggregationPlan& plan, const std::vector<ChildProof>& segments, std::vector<std::vector<ChildProof>>* all = nullptr,
+                          const std::vector<size_t>* shapes = nullptr) {
         if (segments.size() != plan.n_segments) throw Error(Error::GenProof, "aggregation: segment proof count does not match the plan");
         TreeStream ts(*this);
-        for (size_t i = 0; i < segments.size(); i++) ts.push(i, segments[i]);
+        for (size_t i = 0; i < segments.size(); i++) ts.push(i, segments[i], shapes ? shapes->at(i) : 0);
         return ts.finish(segments.size(), all);
     }
 
@@ -554,7 +619,11 @@ private:
         VerifyingKey vk;
         std::vector<void*> d_traces;
     };
-    std::vector<uint32_t> leaf_commit_, internal_commit_;   // one key: zkhip_recursion_key_commit of the two circuits' keys
+    // one key: zkhip_recursion_key_commit of the circuits' keys: leaf_list_ = the S leaf commitments (8 S words); leaf_commit_ = what a node
+    // STATES as its leaf commitment: the commitment itself (one shape) or the sponge of the list
+    std::vector<uint32_t> leaf_list_, leaf_commit_, internal_commit_;
+    std::vector<VerifyingKey> apps_;   // the shapes' segment keys (apps_.back() = app_ = the full set)
+    std::deque<Level> leafs_;          // one key: the leaf circuit of every shape (levels_[0] is then unused)
     VerifyingKey app_;
     StatementSpec spec_;
     AggregationTreeConfig cfg_;
@@ -565,25 +634,26 @@ private:
     // levels_mu_: the container (brief); build_mu_: one level is built at a time; dev_mu_: any call on ctx_.  Order: build -> dev;
     // levels_mu_ is never held while another one is taken.
     std::unique_ptr<std::mutex> levels_mu_, dev_mu_, build_mu_;
-    Level& lv(size_t level) {
+    Level& lv(size_t level, size_t shape = 0) {
         std::lock_guard<std::mutex> lk(*levels_mu_);
+        if (level == 0 && cfg_.one_key) return leafs_.at(shape);
         return levels_.at(level);
     }
     size_t n_levels() {
         std::lock_guard<std::mutex> lk(*levels_mu_);
         return levels_.size();
     }
-    const VerifyingKey& level_vk(size_t level) { return lv(level).vk; }
+    const VerifyingKey& level_vk(size_t level, size_t shape = 0) { return lv(level, shape).vk; }
 
     void check(int rc) const {
         if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_last_error(ctx_));
     }
-    void upload_witness(size_t level) {
-        Level& L = lv(level);
+    void upload_witness(size_t level, size_t shape = 0) {
+        Level& L = lv(level, shape);
         check(zkhip_recursion_tracegen(ctx_, L.circ, (uint32_t*)L.d_traces[0], (uint32_t*)L.d_traces[1], (uint32_t*)L.d_traces[2]));
     }
-    ChildProof prove_uploaded(size_t level, std::vector<uint32_t> node_pvs) {
-        Level& L = lv(level);
+    ChildProof prove_uploaded(size_t level, std::vector<uint32_t> node_pvs, size_t shape = 0) {
+        Level& L = lv(level, shape);
         ChildProof out;
         out.pvs.resize(3);
         out.pvs[2] = std::move(node_pvs);
@@ -647,49 +717,88 @@ private:
         using clk = std::chrono::steady_clock;
         ensure_ctx();
         auto t0 = clk::now();
-        Level leaf, internal;
-        std::vector<uint32_t> cols[4];
-        zkhip_recursion_stmt st = leaf_stmt(cols);
-        st.uniform = 1;
-        std::vector<zkhip_air> za = app_.as_airs();
-        int rc = zkhip_recursion_build(&app_.params, za.data(), za.size(), arity(0), &st, &leaf.circ);
-        if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the leaf verifier circuit: ") + zkhip_recursion_last_error(nullptr));
-        std::vector<zkhip_air> la, ia;
-        leaf.vk.params = agg_params_.leaf, internal.vk.params = agg_params_.internal;
+        const size_t S = apps_.size();
+        std::deque<Level> leafs(S);
+        Level internal;
+        std::vector<std::vector<zkhip_air>> la(S);
+        std::vector<zkhip_air> ia;
+        internal.vk.params = agg_params_.internal;
+        // several shapes state ONE app id: the digest of the full set's key (one shape: the leaf circuit's own child digest, as before)
+        std::vector<uint32_t> app_id(8);
+        {
+            std::vector<zkhip_air> za = app_.as_airs();
+            if (zkhip_recursion_vk_digest(&app_.params, za.data(), za.size(), app_id.data()) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_vk_digest");
+        }
         try {
-            circuit_airs(leaf.circ, &leaf.vk, &la);
-            unsigned H[2] = {la[0].log_height, la[1].log_height};
+            // the leaf circuits side by side (host only: seconds each for a 50-chip key)
+            std::vector<std::string> errs(S);
+            std::vector<std::thread> th;
+            for (size_t sh = 0; sh < S; sh++)
+                th.emplace_back([&, sh] {
+                    std::vector<uint32_t> cols[4];
+                    zkhip_recursion_stmt st = leaf_stmt(cols);
+                    st.uniform = 1;
+                    st.app_id = S > 1 ? app_id.data() : nullptr;
+                    std::vector<zkhip_air> za = apps_[sh].as_airs();
+                    const int rc = zkhip_recursion_build(&apps_[sh].params, za.data(), za.size(), arity(0), &st, &leafs[sh].circ);
+                    if (rc != ZKHIP_OK) errs[sh] = std::string("aggregation: cannot build the leaf verifier circuit of shape ") + std::to_string(sh) + ": " + zkhip_recursion_last_error(nullptr);
+                });
+            for (auto& t : th) t.join();
+            for (const auto& e : errs)
+                if (!e.empty()) throw Error(Error::Setup, e);
+            unsigned H[2] = {0, 0};
+            for (size_t sh = 0; sh < S; sh++) {
+                leafs[sh].vk.params = agg_params_.leaf;
+                circuit_airs(leafs[sh].circ, &leafs[sh].vk, &la[sh]);
+                H[0] = std::max(H[0], la[sh][0].log_height), H[1] = std::max(H[1], la[sh][1].log_height);
+            }
             for (int round = 0;; round++) {
                 if (round > 8) throw Error(Error::Setup, "aggregation: the common height of the leaf and internal circuits does not settle");
-                std::vector<zkhip_air> child = la;   // the node AIR set: programs of the leaf circuit's chips, heights H
+                std::vector<zkhip_air> child = la[0];   // the node AIR set: programs of the leaf circuit's chips, heights H
                 child[0].log_height = H[0], child[1].log_height = H[1];
                 for (auto& c : child) c.prep_trace = nullptr, c.prep_commit = nullptr;
                 zkhip_recursion_stmt is{};
-                is.child_is_node = 2, is.min_log_height[0] = H[0], is.min_log_height[1] = H[1];
+                is.child_is_node = 2, is.min_log_height[0] = H[0], is.min_log_height[1] = H[1], is.n_leaf_shapes = S;
                 if (internal.circ) zkhip_recursion_destroy(internal.circ), internal.circ = nullptr;
-                rc = zkhip_recursion_build(&agg_params_.leaf, child.data(), 3, arity(1), &is, &internal.circ);
+                const int rc = zkhip_recursion_build(&agg_params_.leaf, child.data(), 3, arity(1), &is, &internal.circ);
                 if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the internal verifier circuit: ") + zkhip_recursion_last_error(nullptr));
                 circuit_airs(internal.circ, &internal.vk, &ia);
                 if (ia[0].log_height == H[0] && ia[1].log_height == H[1]) break;
                 H[0] = ia[0].log_height, H[1] = ia[1].log_height;
             }
-            if (zkhip_recursion_pad(leaf.circ, H) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_pad");
-            circuit_airs(leaf.circ, &leaf.vk, &la);
-            for (size_t i = 0; i < 3; i++)
-                if (leaf.vk.airs[i].program != internal.vk.airs[i].program || leaf.vk.heights[i] != internal.vk.heights[i])
-                    throw Error(Error::Setup, "aggregation: the leaf and the internal circuit do not share one AIR set");
+            for (size_t sh = 0; sh < S; sh++) {
+                if (zkhip_recursion_pad(leafs[sh].circ, H) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_pad");
+                circuit_airs(leafs[sh].circ, &leafs[sh].vk, &la[sh]);
+                for (size_t i = 0; i < 3; i++)
+                    if (leafs[sh].vk.airs[i].program != internal.vk.airs[i].program || leafs[sh].vk.heights[i] != internal.vk.heights[i])
+                        throw Error(Error::Setup, "aggregation: the leaf and the internal circuit do not share one AIR set");
+            }
             auto t1 = clk::now();
-            keygen_level(leaf, la);
+            leaf_list_.clear();
+            for (size_t sh = 0; sh < S; sh++) {
+                keygen_level(leafs[sh], la[sh]);
+                const std::vector<uint32_t> c = leafs[sh].vk.key_commit();
+                leaf_list_.insert(leaf_list_.end(), c.begin(), c.end());
+            }
             keygen_level(internal, ia);
-            leaf_commit_ = leaf.vk.key_commit(), internal_commit_ = internal.vk.key_commit();
+            internal_commit_ = internal.vk.key_commit();
+            if (S == 1) {
+                leaf_commit_ = leaf_list_;
+            } else {
+                const Digest8 h = p2_sponge8(leaf_list_.data(), leaf_list_.size());
+                leaf_commit_.assign(h.begin(), h.end());
+            }
             // the aggregation key: the internal verifying key + what a root must state beneath it
             internal.vk.leaf_commit = leaf_commit_;
             internal.vk.app_digest.resize(8);
-            if (zkhip_recursion_child_vk_digest(leaf.circ, internal.vk.app_digest.data()) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: child vk digest");
+            if (S > 1) internal.vk.app_digest = app_id;
+            else if (zkhip_recursion_child_vk_digest(leafs[0].circ, internal.vk.app_digest.data()) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: child vk digest");
             stats.build_seconds += std::chrono::duration<double>(t1 - t0).count();
             stats.keygen_seconds += std::chrono::duration<double>(clk::now() - t1).count();
         } catch (...) {
-            for (Level* L : {&leaf, &internal}) {
+            std::vector<Level*> all{&internal};
+            for (auto& L : leafs) all.push_back(&L);
+            for (Level* L : all) {
                 for (void* d : L->d_traces)
                     if (d) zkhip_free(ctx_, d);
                 if (L->pk) zkhip_pk_destroy(ctx_, L->pk);
@@ -698,7 +807,8 @@ private:
             throw;
         }
         std::lock_guard<std::mutex> lk(*levels_mu_);
-        levels_.push_back(std::move(leaf));
+        leafs_ = std::move(leafs);
+        levels_.emplace_back();   // (level 0 lives in leafs_)
         levels_.push_back(std::move(internal));
     }
     void ensure_level(size_t level) {
@@ -764,25 +874,6 @@ private:
 // the DEFERRAL NODE (zkhip_recursion_stmt.child_is_node = 3) verifies the child root proofs under the child app's aggregation key, derives
 // the same 32 words from each proof and chains them; the JOIN (zkhip_recursion_build_join) verifies the guest's own root and the deferral
 // node's proof and states [root statement | chain]; the verifier opens the region in the guest's final memory root and hashes it.
-using Digest8 = std::array<uint32_t, 8>;
-inline Digest8 p2_compress8(const Digest8& l, const Digest8& r) {
-    uint32_t st[16];
-    for (int i = 0; i < 8; i++) st[i] = l[i], st[8 + i] = r[i];
-    zkhip_poseidon2_permute_host(st);
-    Digest8 d;
-    std::copy(st, st + 8, d.begin());
-    return d;
-}
-inline Digest8 p2_sponge8(const uint32_t* v, size_t n) {   // PaddingFreeSponge<16, 8, 8>: overwrite, permute, no padding
-    uint32_t st[16] = {};
-    for (size_t i = 0; i < n; i += 8) {
-        for (size_t k = 0; k < 8 && i + k < n; k++) st[k] = v[i + k];
-        zkhip_poseidon2_permute_host(st);
-    }
-    Digest8 d;
-    std::copy(st, st + 8, d.begin());
-    return d;
-}
 // the program commitments a parent guest holds about a child app (crates/types/circuit/src/lib.rs `ProgramCommitment { exe, vm }`; the
 // reference generates them into crates/circuits/*-circuit/*_commit.rs): exe = compress(initial memory root, entry pc), vm =
 // compress(app-vk digest, leaf-circuit commitment of the app's aggregation key)

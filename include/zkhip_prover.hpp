@@ -212,9 +212,36 @@ inline std::vector<uint8_t> encode_witness(unsigned log_height, const std::vecto
     return out;
 }
 
+// How the guest flow runs (include/zkhip_vm_flow.hpp): fields of the prover's configuration; the ZKHIP_* environment variables are
+// overrides read in ONE place (FlowOptions::from_env, which ProverConfig's default uses).
+struct FlowOptions {
+    unsigned lanes = 3;               // segment provers in flight per device (measured 1 / 2 / 3: DESIGN.md 5)          [ZKHIP_LANES]
+    bool verify_segments = false;     // host verification of every segment proof beside the proving (the leaf circuit's witness
+                                      // generation checks every child; the root is always verified)                     [ZKHIP_VERIFY_SEGMENTS=1]
+    bool one_shape = false;           // every segment under the app's full chip set instead of the smallest shape      [ZKHIP_ONE_SHAPE=1]
+    bool agg_nodes_100bit = false;    // node proofs under blow-up 4 / 44 queries instead of the app's parameters         [ZKHIP_AGG_100BIT=1]
+    bool per_depth_keys = false;      // round 3's aggregation keys (one per tree depth) instead of ONE key               [ZKHIP_AGG_PER_DEPTH_KEYS=1]
+    std::vector<int> devices;         // GPUs of the node the flow spreads over (empty = the prover's device)             [ZKHIP_DEVICES=0,1,..]
+    static FlowOptions from_env() {
+        FlowOptions o;
+        if (const char* e = getenv("ZKHIP_LANES")) o.lanes = std::max(1, atoi(e));
+        o.verify_segments = getenv("ZKHIP_VERIFY_SEGMENTS") != nullptr;
+        o.one_shape = getenv("ZKHIP_ONE_SHAPE") != nullptr;
+        o.agg_nodes_100bit = getenv("ZKHIP_AGG_100BIT") != nullptr;
+        o.per_depth_keys = getenv("ZKHIP_AGG_PER_DEPTH_KEYS") != nullptr;
+        if (const char* e = getenv("ZKHIP_DEVICES")) {
+            std::stringstream ss(e);
+            std::string item;
+            while (std::getline(ss, item, ','))
+                if (!item.empty()) o.devices.push_back(atoi(item.c_str()));
+        }
+        return o;
+    }
+};
 struct ProverConfig {
     std::string path_app_exe;     // AIR-set file: [0x58414B5A, n_airs, {width, n_pvs, program_len, program...}...]
     std::string path_app_config;  // openvm.toml (FRI parameter block)
+    FlowOptions flow = FlowOptions::from_env();
 };
 
 struct AirDesc {

@@ -82,6 +82,7 @@ inline SegmentAirs segment_airs(const Exe& exe, const SegmentCaps& caps) {
 struct SegmentProof {
     ChildProof proof;               // proof bytes + public values per AIR (merkle chip: roots; connector: pc_start, pc_end)
     uint64_t n_instr = 0, tracegen_mills = 0, proving_mills = 0;
+    size_t shape = 0;               // which of the app's shapes (sets of chips) the segment was proven under
 };
 
 // where the chained state of a segment proof lives: (pc, memory root) -- the StatementSpec of the aggregation layer
@@ -362,11 +363,89 @@ private:
     }
 };
 
+// ---- per-proof chip presence (the reference's engine proves only the chips a segment used -- the chunk circuit's 42 AIRs, AGENTS.md:183-185).
+// Here heights and AIR sets are part of a key, so an app has a few SHAPES instead: the base chips; + the hash intrinsics its openvm.toml
+// enables; the full set.  Each shape is a SegmentCaps (the same base heights: they depend on the frame only) with a segment key of its own;
+// a segment is proven under the smallest shape that holds every chip it used.  A shape without chip X has no receiver on X's request bus,
+// so a segment that called X cannot be proven under it (the LogUp sums do not cancel).
+struct SegmentShapes {
+    std::vector<SegmentCaps> caps;   // increasing sets of chips; caps.back() = the full set (the executor's limits)
+    static SegmentShapes of(const SegmentCaps& full, unsigned log_frame, unsigned log_program) {
+        SegmentShapes s;
+        const bool hash = full.keccak() || full.sha256();
+        const bool more = full.int256() || !full.moduli.empty() || !full.curves.empty() || !full.fp2_moduli.empty();
+        if (hash || more) s.caps.push_back(SegmentCaps::for_frame(log_frame, log_program));
+        if (hash && more)
+            s.caps.push_back(SegmentCaps::for_frame(log_frame, log_program, full.keccak() ? full.log_height[vmc::A_KECCAK] : 0, full.sha256() ? full.log_height[vmc::A_SHA256] : 0));
+        s.caps.push_back(full);
+        for (const SegmentCaps& c : s.caps)   // a shape shares every height with the full set
+            for (unsigned id : c.ids)
+                if (c.log_height[id] != full.log_height[id]) throw Error("internal: a shape's heights differ from the full set's");
+        return s;
+    }
+    static SegmentShapes only(const SegmentCaps& full) {
+        SegmentShapes s;
+        s.caps.push_back(full);
+        return s;
+    }
+    // the smallest shape that holds every chip the segment used
+    size_t shape_of(const SegmentRecords& r) const {
+        auto used = [&](unsigned id) -> bool {
+            if (id == vmc::A_KECCAK || id == vmc::A_KECCAK_IO) return r.n_keccak() != 0;
+            if (id == vmc::A_SHA256 || id == vmc::A_SHA256_IO) return r.n_sha256() != 0;
+            if (id >= vmc::A_INT256 && id <= vmc::A_SHIFT256) return !r.i256io_rows.empty();
+            if (id >= vmc::A_FP2(0)) return !r.fp2_ts[(id - vmc::A_FP2(0)) / 2].empty();
+            if (id >= vmc::A_EC(0)) return !r.ec_ts[(id - vmc::A_EC(0)) / 2].empty();
+            if (id >= vmc::N_STATIC_AIRS) return !r.mm_ts[(id - vmc::N_STATIC_AIRS) / 2].empty();
+            return false;   // (base chips are in every shape)
+        };
+        const SegmentCaps& full = caps.back();
+        for (size_t s = 0; s + 1 < caps.size(); s++) {
+            bool ok = true;
+            for (unsigned id : full.ids)
+                if (id >= vmc::N_BASE_AIRS && used(id) && caps[s].pos(id) < 0) ok = false;
+            if (ok) return s;
+        }
+        return caps.size() - 1;
+    }
+};
+// a lane of the flow: one SegmentProver per shape (built at the first segment of that shape; lane 0 builds all of them at setup: their keys
+// are the aggregation tree's leaf circuits)
+class ShapedSegmentProver {
+public:
+    ShapedSegmentProver(const zkhip_params& params, const Exe& exe, const SegmentShapes& shapes, int device = 0, bool build_all = false)
+        : params_(params), exe_(exe), shapes_(shapes), device_(device), provers_(shapes.caps.size()) {
+        if (build_all)
+            for (size_t s = 0; s < provers_.size(); s++) (void)prover(s);
+    }
+    size_t n_shapes() const { return provers_.size(); }
+    const VerifyingKey& vk(size_t shape) { return prover(shape).vk(); }
+    const VerifyingKey& vk() { return vk(provers_.size() - 1); }
+    SegmentProof prove(const SegmentRecords& r, bool self_verify = true, int force_shape = -1) {
+        const size_t s = force_shape >= 0 ? (size_t)force_shape : shapes_.shape_of(r);
+        SegmentProof p = prover(s).prove(r, self_verify);
+        p.shape = s;
+        return p;
+    }
+
+private:
+    zkhip_params params_;
+    const Exe& exe_;
+    SegmentShapes shapes_;
+    int device_;
+    std::vector<std::unique_ptr<SegmentProver>> provers_;
+    SegmentProver& prover(size_t s) {
+        if (!provers_.at(s)) provers_[s].reset(new SegmentProver(params_, exe_, shapes_.caps[s], device_));
+        return *provers_[s];
+    }
+};
+
 // ---- the whole flow ---------------------------------------------------------------------------------------------------------------------
 struct GuestStark {
     ChildProof root;                       // the root node's proof + public values [app-vk digest | (pc, root) start | (pc, root) end | accumulator]
     VerifyingKey root_vk;
     size_t levels = 0, segments = 0;
+    std::vector<size_t> segments_per_shape, chips_per_shape;   // how many segments were proven under each shape, and how many chips a shape carries
     ExecutionResult exec;
     Digest image_root{};
     uint32_t entry_pc = 0;
@@ -488,8 +567,9 @@ inline Digest guest_image_root(const Exe& exe) {
 // streams segments into a bounded queue; every lane (a SegmentProver with a context = HIP stream of its own) proves the segments it
 // takes, so the launch gaps and host-side pauses of one lane are filled by the other; the mandatory self-verification of the segment
 // proofs runs on host threads beside the lanes.  Segments are independent proofs; their order is restored.
-inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scroll_zkvm_hip::AggregationProver& agg, const Exe& exe, const StdIn& in,
-                                   const SegmentCaps& caps, bool keep_segments = false) {
+template <class Lane>
+inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_hip::AggregationProver& agg, const Exe& exe, const StdIn& in,
+                                   const SegmentCaps& caps, bool keep_segments = false, bool verify_segments = false) {
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::duration d) { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(d).count(); };
     if (lanes.empty()) throw Error("no segment prover lanes");
@@ -513,12 +593,11 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     const auto t_start = clk::now();
     // Every segment proof is checked by the leaf circuit's witness generation (it replays the verifier and throws on a child that
     // does not verify), every node proof by the level above and the root by verify_guest_stark -- as the reference verifies its final
-    // proof only (crates/prover/src/prover/mod.rs:407-411).  ZKHIP_VERIFY_SEGMENTS=1 adds the host verification of every segment
+    // proof only (crates/prover/src/prover/mod.rs:407-411).  FlowOptions::verify_segments adds the host verification of every segment
     // proof beside the proving (it hashes as much as the witness generation does, on the same cores).
-    const bool verify_segments = getenv("ZKHIP_VERIFY_SEGMENTS") != nullptr;
     // the aggregation tree runs as a stream beside the segment proving: a leaf node starts when its four segment proofs exist
     scroll_zkvm_hip::AggregationProver::TreeStream tree(agg);
-    for (SegmentProver* lane : lanes)
+    for (Lane* lane : lanes)
         workers.emplace_back([&, lane] {
             try {
                 for (;;) {
@@ -532,7 +611,7 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
                     }
                     cv_push.notify_one();
                     SegmentProof p = lane->prove(it.rec, /*self_verify=*/false);
-                    tree.push(it.index, p.proof);
+                    tree.push(it.index, p.proof, p.shape);
                     std::lock_guard<std::mutex> lk(mu);
                     if (proofs.size() <= it.index) proofs.resize(it.index + 1);
                     proofs[it.index] = std::move(p);
@@ -547,7 +626,6 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
                 cv_push.notify_all(), cv_pop.notify_all();
             }
         });
-    const VerifyingKey& seg_vk = lanes[0]->vk();
     for (size_t v = 0; v < std::max<size_t>(4, 2 * lanes.size()); v++)
         verifiers.emplace_back([&] {
             for (;;) {
@@ -560,7 +638,7 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
                     k = to_verify.front().first, made = to_verify.front().second;
                     to_verify.pop_front();
                 }
-                if (!seg_vk.verify(made->proof)) {
+                if (!agg.app_vk(made->shape).verify(made->proof)) {
                     std::lock_guard<std::mutex> lk(mu);
                     if (error.empty()) error = "the proof of segment " + std::to_string(k) + " does not verify";
                     failed = true;
@@ -628,7 +706,9 @@ inline GuestStark prove_guest_with(const std::vector<SegmentProver*>& lanes, scr
     g.deferral_opening = open_deferral_region(ex, exe);
     g.segments = n_seg;
     std::vector<ChildProof> seg_proofs;
-    for (auto& p : proofs) seg_proofs.push_back(p.proof), g.sum_segment_tracegen_mills += p.tracegen_mills, g.sum_segment_prove_mills += p.proving_mills;
+    g.segments_per_shape.assign(agg.n_shapes(), 0);
+    for (size_t sh = 0; sh < agg.n_shapes(); sh++) g.chips_per_shape.push_back(agg.app_vk(sh).airs.size());
+    for (auto& p : proofs) seg_proofs.push_back(p.proof), g.sum_segment_tracegen_mills += p.tracegen_mills, g.sum_segment_prove_mills += p.proving_mills, g.segments_per_shape.at(p.shape)++;
     if (keep_segments) g.segment_proofs.assign(std::make_move_iterator(proofs.begin()), std::make_move_iterator(proofs.end()));
     const auto t0 = clk::now();
     const scroll_zkvm_hip::AggregationPlan plan = scroll_zkvm_hip::AggregationPlan::build(seg_proofs.size(), agg.tree_config());
@@ -766,19 +846,24 @@ inline std::vector<zkhip::modular::U256> config_moduli(const std::string& path_a
 inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
                                         bool keep_segments = false, unsigned inflight = 2, unsigned log_keccak = 0, unsigned log_sha256 = 0,
                                         const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_int256 = 0,
-                                        const std::vector<zkhip::ecc::Curve>& curves = {}, const std::vector<zkhip::modular::U256>& fp2_moduli = {}) {
+                                        const std::vector<zkhip::ecc::Curve>& curves = {}, const std::vector<zkhip::modular::U256>& fp2_moduli = {},
+                                        const scroll_zkvm_hip::FlowOptions& flow = scroll_zkvm_hip::FlowOptions::from_env()) {
     const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak, log_sha256, moduli, log_frame > 8 ? log_frame - 8 : 1, log_int256,
                                                     curves, ec_log_rows(log_frame), fp2_moduli);
-    std::vector<std::unique_ptr<SegmentProver>> own;
-    std::vector<SegmentProver*> lanes;
-    for (unsigned l = 0; l < std::max(1u, inflight); l++) own.emplace_back(new SegmentProver(params, exe, caps, device)), lanes.push_back(own.back().get());
+    // a segment is proven under the smallest SHAPE (set of chips) that holds what it used (ZKHIP_ONE_SHAPE=1: always the full set, as round 3)
+    const SegmentShapes shapes = flow.one_shape ? SegmentShapes::only(caps) : SegmentShapes::of(caps, log_frame, vm_log2_ceil(exe.program.size()));
+    std::vector<std::unique_ptr<ShapedSegmentProver>> own;
+    std::vector<ShapedSegmentProver*> lanes;
+    for (unsigned l = 0; l < std::max(1u, inflight); l++) own.emplace_back(new ShapedSegmentProver(params, exe, shapes, device, /*build_all=*/l == 0)), lanes.push_back(own.back().get());
+    std::vector<VerifyingKey> shape_vks;
+    for (size_t sh = 0; sh < lanes[0]->n_shapes(); sh++) shape_vks.push_back(lanes[0]->vk(sh));
     // ZKHIP_AGG_100BIT=1 (measurements): the leaf / internal pair of AggregationSystemParams::with_100_bits_security() instead of the app's
     // parameters on every level (the root then verifies under ITS level's parameters: in-process through GuestStark::root_vk)
-    const scroll_zkvm_hip::AggregationSystemParams pair = scroll_zkvm_hip::AggregationSystemParams::with_100_bits_security();
+    const scroll_zkvm_hip::AggregationSystemParams pair = scroll_zkvm_hip::AggregationSystemParams::nodes_100_bits_security();
     scroll_zkvm_hip::AggregationProver agg =
-        scroll_zkvm_hip::AggregationProver::setup(lanes[0]->vk(), segment_statement(), {}, device, getenv("ZKHIP_AGG_100BIT") ? &pair : nullptr);
+        scroll_zkvm_hip::AggregationProver::setup_shapes(shape_vks, segment_statement(), {}, device, flow.agg_nodes_100bit ? &pair : nullptr);
     (void)agg.node_vk(0);   // the leaf circuit and its key: setup, like the segment keys
-    return prove_guest_with(lanes, agg, exe, in, caps, keep_segments);
+    return prove_guest_with(lanes, agg, exe, in, caps, keep_segments, flow.verify_segments);
 }
 
 // The verifier's side: the root proof under the root verifying key, then the statement: the run starts at the guest's entry on the
@@ -837,6 +922,7 @@ public:
             throw Error(Error::Setup, "failed to read or deserialize " + cfg.path_app_exe + ": " + e.what());
         }
         p.params_ = read_app_config(cfg.path_app_config);
+        p.log_frame_ = log_frame;
         p.caps_ = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(p.exe_.program.size()), zkhip_vm::keccak_log_rows(cfg.path_app_config, log_frame),
                                                    zkhip_vm::sha256_log_rows(cfg.path_app_config, log_frame), zkhip_vm::config_moduli(cfg.path_app_config),
                                                    log_frame > 8 ? log_frame - 8 : 1, zkhip_vm::int256_log_rows(cfg.path_app_config, log_frame),
@@ -866,9 +952,9 @@ public:
         try {
             ensure();
             const zkhip_vm::StdIn in = task.build_guest_input();
-            std::vector<zkhip_vm::SegmentProver*> lanes;
+            std::vector<zkhip_vm::ShapedSegmentProver*> lanes;
             for (auto& l : seg_) lanes.push_back(l.get());
-            last_ = zkhip_vm::prove_guest_with(lanes, *agg_, exe_, in, caps_);
+            last_ = zkhip_vm::prove_guest_with(lanes, *agg_, exe_, in, caps_, false, config.flow.verify_segments);
         } catch (const zkhip_vm::Error& e) {
             throw Error(Error::GenProof, std::string("failed to generate proof: ") + e.what());
         }
@@ -988,16 +1074,20 @@ private:
     zkhip_params params_{};
     zkhip_vm::SegmentCaps caps_;
     int device_ = 0;
-    unsigned inflight_ = 3;
-    std::vector<std::unique_ptr<zkhip_vm::SegmentProver>> seg_;   // lanes: segment provers in flight on the device
+    std::vector<std::unique_ptr<zkhip_vm::ShapedSegmentProver>> seg_;   // lanes: segment provers in flight on the device (one key per shape)
+    unsigned log_frame_ = 17;
     std::unique_ptr<AggregationProver> agg_;
     std::unique_ptr<DeferralProver> deferral_;
     zkhip_vm::GuestStark last_;
     ChildProof last_deferral_;
     void ensure() {
         if (!seg_.empty()) return;
-        for (unsigned l = 0; l < inflight_; l++) seg_.emplace_back(new zkhip_vm::SegmentProver(params_, exe_, caps_, device_));
-        agg_.reset(new AggregationProver(AggregationProver::setup(seg_[0]->vk(), zkhip_vm::segment_statement(), {}, device_)));
+        const zkhip_vm::SegmentShapes shapes = config.flow.one_shape ? zkhip_vm::SegmentShapes::only(caps_)
+                                                                         : zkhip_vm::SegmentShapes::of(caps_, log_frame_, zkhip_vm::vm_log2_ceil(exe_.program.size()));
+        for (unsigned l = 0; l < std::max(1u, config.flow.lanes); l++) seg_.emplace_back(new zkhip_vm::ShapedSegmentProver(params_, exe_, shapes, device_, l == 0));
+        std::vector<VerifyingKey> shape_vks;
+        for (size_t sh = 0; sh < seg_[0]->n_shapes(); sh++) shape_vks.push_back(seg_[0]->vk(sh));
+        agg_.reset(new AggregationProver(AggregationProver::setup_shapes(shape_vks, zkhip_vm::segment_statement(), {}, device_)));
     }
 };
 

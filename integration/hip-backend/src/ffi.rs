@@ -171,6 +171,27 @@ pub struct zkhip_recursion_stmt {
     pub app_id: *const u32,
 }
 
+/// include/zkhip.h `zkhip_config`: every behaviour-changing switch of the library; the ZKHIP_* environment variables are overrides read
+/// in one place (`zkhip_config_default`).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkhip_config {
+    pub host_sponge: c_int,
+    pub host_sponge_min_words: u32,
+    pub jit: c_int,
+    pub jit_min_log_work: u32,
+    pub jit_cache_dir: [c_char; 256],
+    pub quot_slices: c_int,
+    pub grind_sweep_shift: u32,
+    pub coop_max_log: u32,
+    pub coop_inj_max_log: u32,
+    pub commit_parts: u32,
+    pub side_cus: u32,
+    pub witness_threads: u32,
+    pub pin_witness: c_int,
+    pub parallel_queries: c_int,
+}
+
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct zkhip_kernel_stat {
@@ -428,6 +449,10 @@ extern "C" {
     pub fn zkhip_recursion_witness_uniform(r: *mut zkhip_recursion, proofs: *const *const u8, proof_lens: *const usize,
                                            child_pvs: *const *const *const u32, child_prep_commits: *const u32, child_is_leaf: *const c_int,
                                            leaf_commit: *const u32, internal_commit: *const u32, n_present: usize, node_pvs_out: *mut u32) -> c_int;
+    pub fn zkhip_config_default(out: *mut zkhip_config);
+    pub fn zkhip_ctx_get_config(ctx: *mut zkhip_ctx, out: *mut zkhip_config) -> c_int;
+    pub fn zkhip_ctx_set_config(ctx: *mut zkhip_ctx, cfg: *const zkhip_config) -> c_int;
+    pub fn zkhip_set_process_config(cfg: *const zkhip_config) -> c_int;
     pub fn zkhip_recursion_build_join(params_a: *const zkhip_params, airs_a: *const zkhip_air, n_airs_a: usize, params_b: *const zkhip_params,
                                       airs_b: *const zkhip_air, n_airs_b: usize, out: *mut *mut zkhip_recursion) -> c_int;
     pub fn zkhip_recursion_witness_deferral(r: *mut zkhip_recursion, proofs: *const *const u8, proof_lens: *const usize,

@@ -517,6 +517,74 @@ def test_the_chunk_circuit_configuration_end_to_end(tmp_path):
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
 
 
+def test_segments_carry_only_the_chips_they_use(zk, ora, tmp_path):
+    """PER-PROOF CHIP PRESENCE (the reference's engine proves only the chips a segment used: the chunk circuit's 42 AIRs, AGENTS.md:183-185).
+    Under an app with the keccak extension a segment WITHOUT keccak calls is proven under the base shape (22 chips): device traces ==
+    twins, proof == the oracle's proof of the 22-chip instance; the segment WITH the calls needs the 24-chip shape -- proven under the base
+    shape (the chip that receives its requests hidden) its bus does not balance and the verifier refuses.  Then `prove-elf` under the
+    reference's chunk-circuit configuration (51 chips): a Fibonacci guest's segments all carry 22 chips, a keccak guest's segments 22 or
+    26 (base + both hash intrinsics) and none 51; every root verifies under the app's ONE aggregation key."""
+    msg = b"one block of a message for the keccak intrinsic"
+    words, data = keccak_program(2), keccak_data(msg)
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, 6)
+    assert v2.A_KECCAK in H.ids and len(H.ids) == 24
+    base = v2.Heights(H)
+    base.ids = tuple(i for i in H.ids if i < v2.A_KECCAK)
+    assert len(base.ids) == 22
+    prog = v2.program_table(words, PC_BASE, H[0])
+    plain = next(i for i, s in enumerate(segs) if not len(s["kk_ts"]))
+    inst = v2.segment_instance(segs[plain], words, PC_BASE, base)
+    assert len(inst) == 22
+    T = device_traces(zk, segs[plain], prog, base)
+    for a, d in enumerate(inst):
+        assert (zk.download(T[a]).reshape(d["width"], -1) == d["trace"]).all(), "chip %d" % a
+    pk = z.ProvingKey(zk, PARAMS, inst)
+    pvs = [d["pvs"] for d in inst]
+    proof = pk.prove(T, pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, inst).tobytes()
+    # the same segment under the full set: another proof (24 chips), also the oracle's
+    full_inst = v2.segment_instance(segs[plain], words, PC_BASE, H)
+    fpk = z.ProvingKey(zk, PARAMS, full_inst)
+    fproof = fpk.prove(device_traces(zk, segs[plain], prog, H), [d["pvs"] for d in full_inst])
+    assert fproof == ora.stark_prove(PARAMS, full_inst).tobytes() and len(fproof) > len(proof)
+    fpk.close()
+    # a segment that CALLS keccak, with the chip hidden: pending traffic on the request bus -> refused
+    hashed = next(i for i, s in enumerate(segs) if len(s["kk_ts"]))
+    hidden = v2.segment_instance(segs[hashed], words, PC_BASE, base)
+    hproof = pk.prove(device_traces(zk, segs[hashed], prog, base), [d["pvs"] for d in hidden])
+    assert z.verify(PARAMS, pk.verifying_airs(), [d["pvs"] for d in hidden], hproof) != 0
+    assert ora.stark_verify(PARAMS, hidden, ora.stark_prove(PARAMS, hidden)) != 0
+    pk.close()
+    # ---- the flow under the reference's chunk-circuit configuration ----
+    (tmp_path / "openvm.toml").write_text(chunk_circuit_toml(PARAMS))
+    runs = {}
+    for name, w, dat, stdin in (("fib", fib_program(), b"", (400).to_bytes(4, "little")), ("keccak", words, data, b"")):
+        d = tmp_path / name
+        d.mkdir()
+        exe = d / "guest.elf"
+        exe.write_bytes(rv.elf_bytes(w, data=dat))
+        (d / "stdin.bin").write_bytes(stdin)
+        r = subprocess.run([pm.CLI, "prove-elf", str(exe), str(d / "stdin.bin"), str(d), str(tmp_path / "openvm.toml"), "8"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        runs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+        assert pm.run_cli("verify-guest", str(exe), str(d / "root.vk"), str(tmp_path / "openvm.toml"), str(d / "root.json")).returncode == 0
+    assert runs["fib"]["chips_per_shape"] == [22, 26, 51] == runs["keccak"]["chips_per_shape"]
+    assert runs["fib"]["segments_per_shape"][1:] == [0, 0] and runs["fib"]["segments_per_shape"][0] == runs["fib"]["segments"] >= 3
+    ks = runs["keccak"]["segments_per_shape"]
+    assert ks[1] >= 1 and ks[2] == 0 and sum(ks) == runs["keccak"]["segments"]     # a segment that calls only keccak carries <= 26 chips
+    # ZKHIP_ONE_SHAPE=1: every segment under the full set, as round 3 (another key: one leaf circuit)
+    import os
+    d = tmp_path / "one"
+    d.mkdir()
+    (d / "stdin.bin").write_bytes((400).to_bytes(4, "little"))
+    r = subprocess.run([pm.CLI, "prove-elf", str(tmp_path / "fib" / "guest.elf"), str(d / "stdin.bin"), str(d), str(tmp_path / "openvm.toml"), "8"], capture_output=True, text=True,
+                       env=dict(os.environ, ZKHIP_ONE_SHAPE="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    one = json.loads(r.stdout.strip().splitlines()[-1])
+    assert one["chips_per_shape"] == [51] and (d / "root.vk").read_bytes() != (tmp_path / "fib" / "root.vk").read_bytes()
+
+
 def test_gen_proof_universal_from_an_elf_and_witness_bytes(tmp_path):
     """Prover::gen_proof_universal (mod.rs:287-309) over the one-statement flow: the task's serialized witnesses reach the guest
     through ProvingTask::build_guest_input (length-framed items), the guest folds them into its public values, ONE proof comes out."""

@@ -6,6 +6,7 @@
 // task.bin: [u32 id_len][id][u32 n_witness]{[u64 len][bytes]}  (the fields of ProvingTask that
 // a leaf task uses, crates/types/src/task.rs:7-23)
 #include <cstdio>
+#include <filesystem>
 #include <fstream>
 #include <iostream>
 
@@ -21,6 +22,11 @@ static std::vector<uint8_t> slurp(const std::string& path) {
     return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 }
 
+static std::string list_of(const std::vector<size_t>& v) {
+    std::string o = "[";
+    for (size_t i = 0; i < v.size(); i++) o += (i ? ", " : "") + std::to_string(v[i]);
+    return o + "]";
+}
 static ProvingTask read_task(const std::string& path) {
     auto tb = slurp(path);
     ProvingTask task;
@@ -69,7 +75,9 @@ int main(int argc, char** argv) {
                 for (bool done = false; !done; k++) {
                     done = ex.run_segment(r);
                     const std::string d = std::string(argv[4]) + "/seg-" + std::to_string(k);
-                    if (system(("mkdir -p '" + d + "'").c_str()) != 0) throw Error(Error::Io, "cannot create " + d);
+                    std::error_code ec;
+                    std::filesystem::create_directories(d, ec);
+                    if (ec) throw Error(Error::Io, "cannot create " + d + ": " + ec.message());
                     const zkhip_vm::ExecRecords& c = r.core;
 #define PUT(name, vec) put(d + "/" name ".u32", vec)
                     PUT("pc_index", c.pc_index), PUT("alu_op", c.alu_op), PUT("alu_b", c.alu_b), PUT("alu_c", c.alu_c), PUT("lt_op", c.lt_op), PUT("lt_b", c.lt_b), PUT("lt_c", c.lt_c);
@@ -156,10 +164,11 @@ int main(int argc, char** argv) {
                     const zkhip_vm::SegmentCaps caps = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(up.exe().program.size()));
                     const zkhip_params params = read_app_config(cfg_path);
                     const unsigned log_keccak = zkhip_vm::keccak_log_rows(cfg_path, log_frame), log_sha256 = zkhip_vm::sha256_log_rows(cfg_path, log_frame);
-                    const unsigned lanes = getenv("ZKHIP_LANES") ? (unsigned)atoi(getenv("ZKHIP_LANES")) : 3u;   // segment provers in flight (measured 1 / 2 / 3: DESIGN.md 5)
+                    const FlowOptions flow = FlowOptions::from_env();
+                    const unsigned lanes = flow.lanes;   // segment provers in flight (measured 1 / 2 / 3: DESIGN.md 5)
                     const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false, lanes, log_keccak, log_sha256, zkhip_vm::config_moduli(cfg_path),
                                                                                           zkhip_vm::int256_log_rows(cfg_path, log_frame), zkhip_vm::config_curves(cfg_path),
-                                                                                          zkhip_vm::config_fp2_moduli(cfg_path));
+                                                                                          zkhip_vm::config_fp2_moduli(cfg_path), flow);
                     (void)caps;
                     sp = UniversalProver::encode(g);
                     std::string why;
@@ -170,11 +179,12 @@ int main(int argc, char** argv) {
                     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                     std::printf("{\"total_cycles\": %llu, \"segments\": %zu, \"levels\": %zu, \"lanes\": %u, \"execution_ms\": %llu, \"segment_tracegen_and_proving_ms\": %llu, "
                                 "\"sum_over_segments_tracegen_ms\": %llu, \"sum_over_segments_prove_ms\": %llu, "
-                                "\"aggregation_setup_wait_ms\": %llu, \"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, \"verified\": true}\n",
+                                "\"aggregation_setup_wait_ms\": %llu, \"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, \"chips_per_shape\": %s, "
+                                "\"segments_per_shape\": %s, \"verified\": true}\n",
                                 (unsigned long long)g.exec.total_cycle, g.segments, g.levels, lanes, (unsigned long long)g.execution_mills,
                                 (unsigned long long)g.segment_proving_mills, (unsigned long long)g.sum_segment_tracegen_mills,
                                 (unsigned long long)g.sum_segment_prove_mills, (unsigned long long)g.aggregation_setup_wait_mills,
-                                (unsigned long long)g.aggregation_mills, wall, g.root.proof.size());
+                                (unsigned long long)g.aggregation_mills, wall, g.root.proof.size(), list_of(g.chips_per_shape).c_str(), list_of(g.segments_per_shape).c_str());
                 } catch (const zkhip_vm::Error& e) {
                     throw Error(Error::GenProof, e.what());
                 }
@@ -531,7 +541,7 @@ int main(int argc, char** argv) {
             }
             seg.reset();
             AggregationTreeConfig tcfg;
-            tcfg.one_key = getenv("ZKHIP_AGG_PER_DEPTH_KEYS") == nullptr;   // (round 3's keys: every level hard-wires the level below)
+            tcfg.one_key = !FlowOptions::from_env().per_depth_keys;   // (round 3's keys: every level hard-wires the level below)
             AggregationProver agg = AggregationProver::setup(avk, spec, tcfg);
             AggregationPlan plan = AggregationPlan::build(seg_proofs.size(), tcfg);
             std::vector<ChildProof> segs;

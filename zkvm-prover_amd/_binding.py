@@ -61,6 +61,20 @@ class _RecursionStmt(C.Structure):
                 ("uniform", C.c_int), ("min_log_height", C.c_uint * 2), ("n_leaf_shapes", C.c_size_t), ("app_id", C.POINTER(C.c_uint32))]
 
 
+class Config(C.Structure):
+    """include/zkhip.h zkhip_config: every switch of the library as a field (the ZKHIP_* variables are overrides read in one place)."""
+    _fields_ = [("host_sponge", C.c_int), ("host_sponge_min_words", C.c_uint32), ("jit", C.c_int), ("jit_min_log_work", C.c_uint32),
+                ("jit_cache_dir", C.c_char * 256), ("quot_slices", C.c_int), ("grind_sweep_shift", C.c_uint32), ("coop_max_log", C.c_uint32),
+                ("coop_inj_max_log", C.c_uint32), ("commit_parts", C.c_uint32), ("side_cus", C.c_uint32), ("witness_threads", C.c_uint32),
+                ("pin_witness", C.c_int), ("parallel_queries", C.c_int)]
+
+    @classmethod
+    def default(cls):
+        c = cls()
+        load_library().zkhip_config_default(C.byref(c))
+        return c
+
+
 class _KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -229,6 +243,10 @@ def load_library():
         "zkhip_recursion_air": (C.c_int, [vp, sz, C.POINTER(_Air)]),
         "zkhip_recursion_witness": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(C.POINTER(u32p)), sz, u32p]),
         "zkhip_recursion_wires": (C.c_int, [vp, u32p, sz, C.POINTER(sz)]),
+        "zkhip_config_default": (None, [C.POINTER(Config)]),
+        "zkhip_ctx_get_config": (C.c_int, [vp, C.POINTER(Config)]),
+        "zkhip_ctx_set_config": (C.c_int, [vp, C.POINTER(Config)]),
+        "zkhip_set_process_config": (C.c_int, [C.POINTER(Config)]),
         "zkhip_recursion_build_join": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(vp)]),
         "zkhip_recursion_witness_deferral": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(C.POINTER(u32p)), u32p, u32p, sz, u32p]),
         "zkhip_recursion_n_aux": (sz, [vp]),

@@ -1,3 +1,6 @@
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <mutex>
 // api.hip -- the extern "C" surface of libzkhip.so (include/zkhip.h): context, memory pool,
 // profiling, and thin argument-checking wrappers around the stage launchers.
 #include <string.h>
@@ -150,12 +153,75 @@ int zkhip_ctx_create(int device, zkhip_ctx** out) {
         delete ctx;
         return ZKHIP_ERR_HIP;
     }
-    // pipelined trace commit (prover.hip): ZKHIP_COMMIT_PARTS=k column blocks, 0 / 1 = off; zkhip_set_commit_pipeline overrides
-    ctx->commit_parts = getenv("ZKHIP_COMMIT_PARTS") ? (unsigned)atoi(getenv("ZKHIP_COMMIT_PARTS")) : 0u;
-    if (ctx->commit_parts > 8) ctx->commit_parts = 8;
-    ctx->side_cus = getenv("ZKHIP_SIDE_CUS") ? (unsigned)atoi(getenv("ZKHIP_SIDE_CUS")) : 0u;
-    if (ctx->side_cus >= (unsigned)ctx->cu_count) ctx->side_cus = 0;
+    ctx->cfg = zk::process_config();
+    // pipelined trace commit (prover.hip): k column blocks, 0 / 1 = off; zkhip_set_commit_pipeline overrides
+    ctx->commit_parts = std::min(ctx->cfg.commit_parts, 8u);
+    ctx->side_cus = ctx->cfg.side_cus >= (unsigned)ctx->cu_count ? 0u : ctx->cfg.side_cus;
     *out = ctx;
+    return ZKHIP_OK;
+}
+
+// ---- configuration: the ONE place the library reads its ZKHIP_* environment overrides ----
+void zkhip_config_default(zkhip_config* c) {
+    if (!c) return;
+    auto num = [](const char* name, uint32_t dflt) { return getenv(name) ? (uint32_t)atoi(getenv(name)) : dflt; };
+    memset(c, 0, sizeof *c);
+    c->host_sponge = getenv("ZKHIP_NO_HOST_SPONGE") ? 0 : 1;
+    c->host_sponge_min_words = num("ZKHIP_HOST_SPONGE_MIN_WORDS", 8192u);
+    c->jit = getenv("ZKHIP_NO_JIT") ? 0 : getenv("ZKHIP_FORCE_JIT") ? 2 : 1;
+    c->jit_min_log_work = num("ZKHIP_JIT_MIN_LOG_WORK", 26u);
+    c->quot_slices = getenv("ZKHIP_NO_QUOT_SLICES") ? 0 : 1;
+    c->grind_sweep_shift = num("ZKHIP_GRIND_SWEEP_SHIFT", 0u);
+    c->coop_max_log = num("ZKHIP_COOP_MAX_LOG", 15u), c->coop_inj_max_log = num("ZKHIP_COOP_INJ_MAX_LOG", 15u);
+    c->commit_parts = num("ZKHIP_COMMIT_PARTS", 0u), c->side_cus = num("ZKHIP_SIDE_CUS", 0u);
+    c->witness_threads = num("ZKHIP_WITNESS_THREADS", 0u);
+    c->pin_witness = getenv("ZKHIP_NO_PIN_WITNESS") ? 0 : 1;
+    c->parallel_queries = getenv("ZKHIP_RECURSION_SERIAL_QUERIES") ? 0 : 1;
+    // compiled constraint kernels across processes: the variable if set (empty = none), else `jit_cache` beside this library if it exists
+    std::string dir;
+    if (const char* e = getenv("ZKHIP_JIT_CACHE_DIR")) {
+        dir = e;
+    } else {
+        Dl_info info;
+        if (dladdr((const void*)&zkhip_config_default, &info) && info.dli_fname) {
+            std::string p = info.dli_fname;
+            const size_t slash = p.rfind('/');
+            p = (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/jit_cache";
+            struct stat st;
+            if (stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) dir = p;
+        }
+    }
+    if (dir.size() < sizeof c->jit_cache_dir) memcpy(c->jit_cache_dir, dir.c_str(), dir.size() + 1);
+}
+extern "C++" {
+namespace zk {
+static zkhip_config g_process_config;
+static std::once_flag g_process_config_once;
+static std::mutex g_process_config_mu;
+const zkhip_config& process_config() {
+    std::call_once(g_process_config_once, [] { zkhip_config_default(&g_process_config); });
+    return g_process_config;
+}
+}  // namespace zk
+}  // extern "C++"
+int zkhip_set_process_config(const zkhip_config* cfg) {
+    if (!cfg) return ZKHIP_ERR_INVALID;
+    (void)zk::process_config();
+    std::lock_guard<std::mutex> lk(zk::g_process_config_mu);
+    zk::g_process_config = *cfg;
+    return ZKHIP_OK;
+}
+int zkhip_ctx_get_config(zkhip_ctx* ctx, zkhip_config* out) {
+    if (!ctx || !out) return ZKHIP_ERR_INVALID;
+    *out = ctx->cfg;
+    return ZKHIP_OK;
+}
+int zkhip_ctx_set_config(zkhip_ctx* ctx, const zkhip_config* cfg) {
+    if (!ctx || !cfg) return ZKHIP_ERR_INVALID;
+    if (cfg->jit < 0 || cfg->jit > 2 || cfg->coop_max_log > 27 || cfg->coop_inj_max_log > 27 || cfg->jit_min_log_work > 62) return set_error(ctx, ZKHIP_ERR_INVALID, "zkhip_ctx_set_config: field out of range");
+    ctx->cfg = *cfg;
+    ctx->cfg.jit_cache_dir[sizeof ctx->cfg.jit_cache_dir - 1] = 0;
+    ctx->commit_parts = std::min(cfg->commit_parts, 8u);
     return ZKHIP_OK;
 }
 

@@ -355,8 +355,7 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
         }
         KernelScope ks(ctx, "poseidon2_compress_layer");
         // (ZKHIP_COOP_MAX_LOG / ZKHIP_COOP_INJ_MAX_LOG: the largest layer, plain / with injected rows, that takes the cooperative form)
-        static const unsigned coop_max = getenv("ZKHIP_COOP_MAX_LOG") ? (unsigned)atoi(getenv("ZKHIP_COOP_MAX_LOG")) : 15u;
-        static const unsigned coop_inj_max = getenv("ZKHIP_COOP_INJ_MAX_LOG") ? (unsigned)atoi(getenv("ZKHIP_COOP_INJ_MAX_LOG")) : 15u;
+        const unsigned coop_max = ctx->cfg.coop_max_log, coop_inj_max = ctx->cfg.coop_inj_max_log;
         if (cnt <= ((size_t)1 << (t->level_cnt[level] ? coop_inj_max : coop_max)))
             hipLaunchKernelGGL(k_compress_layer_coop, dim3((unsigned)((cnt + 15) / 16)), dim3(256), 0, ctx->stream,
                                t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,

@@ -1143,10 +1143,10 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         // ZKHIP_FORCE_JIT=1 / ZKHIP_NO_JIT=1 override
         // ZKHIP_JIT_MIN_LOG_WORK=k moves the threshold to 2^k row-instructions (a fixed app that is proven many times
         // can afford to compile every chip: ~1.5 s each)
-        static const unsigned jit_log = getenv("ZKHIP_JIT_MIN_LOG_WORK") ? (unsigned)atoi(getenv("ZKHIP_JIT_MIN_LOG_WORK")) : 26u;
+        const unsigned jit_log = ctx->cfg.jit_min_log_work;
         const bool big = (double)((size_t)1 << (airs[a].log_height + pk->b)) * (double)A.n_instr >= (double)(1ull << std::min(jit_log, 62u));
         std::string jit_msg = "not attempted";
-        if ((big || !interp_ok || getenv("ZKHIP_FORCE_JIT")) && !getenv("ZKHIP_NO_JIT")) {
+        if ((big || !interp_ok || ctx->cfg.jit == 2) && ctx->cfg.jit != 0) {
             std::string msg;
             std::vector<uint32_t> tab;
             const auto jit_t0 = std::chrono::steady_clock::now();
@@ -1160,7 +1160,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
                                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), n_nodes, forced ? ", interpreter form refused" : "");
                 }
             } jit_timer{jit_t0, a, (size_t)A.prog.n_nodes, !interp_ok};
-            if (quot_jit_build(A.prog, airs[a].log_height, pk->b, &A.jit_mod, &A.jit_fn, &tab, &msg, &A.jit_rows_per_block) &&
+            if (quot_jit_build(A.prog, airs[a].log_height, pk->b, &A.jit_mod, &A.jit_fn, &tab, &msg, &A.jit_rows_per_block, ctx->cfg.jit_cache_dir) &&
                 hipMalloc(&A.d_jit_tab, tab.size() * 4) == hipSuccess &&
                 hipMemcpyAsync(A.d_jit_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
                 hipStreamSynchronize(ctx->stream) == hipSuccess) {
@@ -1180,7 +1180,7 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         // (a dependent load per instruction); cutting the constraints into S contiguous ranges gives S times the lanes, each with
         // 1 / S of the walk.  Cut points: the ASSERTs of the whole program nearest to the multiples of n_instr / S.
         // ZKHIP_NO_QUOT_SLICES=1 switches it off (measurements).
-        if (!A.jit_fn && interp_ok && A.n_instr >= 2048 && (A.MQ + QBS - 1) / QBS <= 256 && !getenv("ZKHIP_NO_QUOT_SLICES")) {
+        if (!A.jit_fn && interp_ok && A.n_instr >= 2048 && (A.MQ + QBS - 1) / QBS <= 256 && ctx->cfg.quot_slices) {
             const uint32_t want = std::min<uint32_t>(16u, std::min<uint32_t>(A.n_instr / 1024u, (uint32_t)(2048u / ((A.MQ + QBS - 1) / QBS))));
             std::vector<uint32_t> cut{0};   // constraint indices where slices start
             if (want >= 2) {

@@ -573,8 +573,9 @@ inline bool quot_jit_source_flat(const AirProgram& p, unsigned lh, unsigned b, s
 // call.  (Compiling the chips of an AIR set on several host threads was tried: hipRTC of ROCm 7.2 serialises the compiles of one
 // process -- five kernels took 24.1 s on five threads and 24.9 s in sequence -- and -O1 / -O2 compile as long as -O3: the time is the
 // backend's on these long basic blocks.)
+// `cache_dir` ("" / null = none): compiled code objects kept across processes (zkhip_config.jit_cache_dir)
 inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vector<uint32_t>* table, std::vector<char>* code_out, std::string* msg,
-                          unsigned* rows_per_block = nullptr) {
+                          unsigned* rows_per_block = nullptr, const char* cache_dir = nullptr) {
     if (rows_per_block) *rows_per_block = 256;
     std::vector<JitClass> classes;
     std::string src;
@@ -599,11 +600,11 @@ inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vec
         auto it = cache.find(src);
         if (it != cache.end()) code = it->second;
     }
-    // optional on-disk cache (ZKHIP_JIT_CACHE_DIR): code objects keyed by a 128-bit hash of the source, so that a
+    // optional on-disk cache (zkhip_config.jit_cache_dir): code objects keyed by a 128-bit hash of the source, so that a
     // service restarting with the same application skips hipRTC altogether (42 chips: ~90 s of compiles)
     std::string disk_path;
     if (code.empty()) {
-        if (const char* dir = getenv("ZKHIP_JIT_CACHE_DIR")) {
+        if (const char* dir = (cache_dir && cache_dir[0]) ? cache_dir : nullptr) {
             uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull;
             for (unsigned char ch : src) {
                 h1 = (h1 ^ ch) * 0x100000001b3ull;
@@ -674,9 +675,9 @@ inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vec
 // Compiles (or finds) and loads the module.  Returns false (with a message) on any failure; the caller then keeps the interpreter
 // kernel.
 inline bool quot_jit_build(const AirProgram& p, unsigned lh, unsigned b, hipModule_t* mod, hipFunction_t* fn,
-                           std::vector<uint32_t>* table, std::string* msg, unsigned* rows_per_block = nullptr) {
+                           std::vector<uint32_t>* table, std::string* msg, unsigned* rows_per_block = nullptr, const char* cache_dir = nullptr) {
     std::vector<char> code;
-    if (!quot_jit_code(p, lh, b, table, &code, msg, rows_per_block)) return false;
+    if (!quot_jit_code(p, lh, b, table, &code, msg, rows_per_block, cache_dir)) return false;
     if (hipModuleLoadData(mod, code.data()) != hipSuccess) {
         *msg = "hipModuleLoadData failed";
         return false;

@@ -1517,7 +1517,7 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
                         }
                     }
                 }
-            c.query_parallel = ok && !getenv("ZKHIP_RECURSION_SERIAL_QUERIES");
+            c.query_parallel = ok && process_config().parallel_queries;
         }
         K.c = std::move(b.c);
     } catch (const BuildError& e) {
@@ -1923,7 +1923,7 @@ int recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const si
                 for (size_t q = 0; q + 1 < c.sub[i].size(); q++) tasks.push_back({i, q});
             // (all cores: measured in the one-flow pipeline with 4 / 8 / 16 threads on 16 cores -- the segment phase loses ~40 ms to the
             // contention, the tree's tail gains ~100 ms; ZKHIP_WITNESS_THREADS overrides)
-            static const unsigned cap = getenv("ZKHIP_WITNESS_THREADS") ? (unsigned)atoi(getenv("ZKHIP_WITNESS_THREADS")) : std::thread::hardware_concurrency();
+            const unsigned cap = process_config().witness_threads ? process_config().witness_threads : std::thread::hardware_concurrency();
             const size_t n_threads = std::min<size_t>(tasks.size(), std::max(1u, cap));
             std::atomic<size_t> next{0};
             std::vector<std::vector<long>> tb(n_threads, std::vector<long>(n_sec, -1));
@@ -2063,8 +2063,8 @@ extern "C" int zkhip_recursion_tracegen(zkhip_ctx* ctx, zkhip_recursion* R, uint
         R->dev_ready_device = ctx->device;
     }
     // The value array is a mapping of its own (WireBuf): page-locked once, for the life of the circuit's user, so that the 40 MB of a
-    // node's wire values cross PCIe without a staging copy.  ZKHIP_NO_PIN_WITNESS=1 leaves it pageable.
-    if (!R->vals.registered && !getenv("ZKHIP_NO_PIN_WITNESS")) {
+    // node's wire values cross PCIe without a staging copy.  zkhip_config.pin_witness = 0 leaves it pageable.
+    if (!R->vals.registered && ctx->cfg.pin_witness) {
         R->vals.registered = hipHostRegister(R->vals.p, R->vals.bytes, hipHostRegisterDefault) == hipSuccess;
         (void)hipGetLastError();
     }

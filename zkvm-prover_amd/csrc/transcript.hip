@@ -188,12 +188,12 @@ int transcript_init(zkhip_ctx* ctx, DevTranscript* d_t) {
 }
 // Long absorptions on the host (csrc/poseidon2_avx512.cpp): the sponge is a chain of dependent permutations, ~1.5 us each on the device
 // whatever the occupancy, ~0.25 us in a 512-bit register of the host -- and the words absorbed here (the opened values) are part of the
-// proof, so they cross PCIe anyway.  One stream synchronisation; the state goes back with a 96-byte copy.  ZKHIP_NO_HOST_SPONGE=1 (or a
-// CPU without AVX-512) keeps everything on the device; ZKHIP_HOST_SPONGE_MIN_WORDS moves the threshold (default 8192 words: below
+// proof, so they cross PCIe anyway.  One stream synchronisation; the state goes back with a 96-byte copy.  zkhip_config.host_sponge = 0 (or a
+// CPU without AVX-512) keeps everything on the device; host_sponge_min_words moves the threshold (default 8192 words: below
 // that the device's ~0.2 us per word costs less than the synchronisation, after which the host has to catch up with its launches).
 void poseidon2_permute_avx512(uint32_t s[16]);
 static bool host_sponge_available() {
-    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && !getenv("ZKHIP_NO_HOST_SPONGE");
+    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq");
     return ok;
 }
 static int observe_on_host(zkhip_ctx* ctx, DevTranscript* d_t, const uint32_t* d_src, uint32_t n, bool canonical) {
@@ -226,8 +226,7 @@ static int observe_on_host(zkhip_ctx* ctx, DevTranscript* d_t, const uint32_t* d
 int transcript_observe(zkhip_ctx* ctx, DevTranscript* d_t, const uint32_t* d_src, uint32_t n, bool canonical) {
     if (n == 0) return ZKHIP_OK;
     KernelScope ks(ctx, "transcript");
-    static const uint32_t host_min = getenv("ZKHIP_HOST_SPONGE_MIN_WORDS") ? (uint32_t)atoi(getenv("ZKHIP_HOST_SPONGE_MIN_WORDS")) : 8192u;
-    if (n >= host_min && host_sponge_available()) return observe_on_host(ctx, d_t, d_src, n, canonical);
+    if (ctx->cfg.host_sponge && n >= ctx->cfg.host_sponge_min_words && host_sponge_available()) return observe_on_host(ctx, d_t, d_src, n, canonical);
     hipLaunchKernelGGL(k_tr_observe, dim3(1), dim3(64), 0, ctx->stream, d_t, d_src, n, canonical ? 1 : 0);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
@@ -256,7 +255,7 @@ int transcript_grind(zkhip_ctx* ctx, DevTranscript* d_t, unsigned bits, uint32_t
     if (bits != 0) {
         // a sweep covers 2^bits candidates (the expected position of the witness): measured on a node proof's 21 grinds 1.08 ms against
         // 1.22 ms with 2^(bits+1) and 1.64 ms with 2^(bits+2) per sweep -- a permutation per lane is latency, more lanes only queue
-        static const unsigned grind_shift = getenv("ZKHIP_GRIND_SWEEP_SHIFT") ? (unsigned)atoi(getenv("ZKHIP_GRIND_SWEEP_SHIFT")) : 0u;
+        const unsigned grind_shift = std::min(ctx->cfg.grind_sweep_shift, 8u);
         unsigned blocks = std::min(4096u, std::max(64u, ((1u << grind_shift) << bits) / 256u));
         hipLaunchKernelGGL(k_grind, dim3(blocks), dim3(256), 0, ctx->stream, d_t, bits, (uint32_t)P);
     }

@@ -57,6 +57,7 @@ struct zkhip_ctx {
     // deferred checks (zkhip_tracegen_defer_checks) the bad-record counts are summed on the device and read once (zkhip_tracegen_check)
     bool defer_tracegen_checks = false;
     uint32_t* d_deferred_bad = nullptr;
+    zkhip_config cfg{};   // every switch of the library (include/zkhip.h zkhip_config); the environment is read once, in zkhip_config_default
     // pinned staging of the transcript's host sponge (csrc/transcript.hip: long absorptions run on the host's vector unit)
     void* h_sponge = nullptr;
     size_t h_sponge_bytes = 0;
@@ -65,6 +66,7 @@ struct zkhip_ctx {
 namespace zk {
 
 int set_error(zkhip_ctx* ctx, int code, const std::string& msg);
+const zkhip_config& process_config();   // what contexts start from, and what the context-less entry points (the circuit's witness) use
 int ensure_twiddles(zkhip_ctx* ctx, unsigned log_n);
 int get_scratch(zkhip_ctx* ctx, int slot, size_t bytes, void** out);
 void profile_begin(zkhip_ctx* ctx, const char* name);
