@@ -183,6 +183,7 @@ class AggregationProver {
 public:
     struct Stats {
         size_t nodes = 0;
+        std::vector<size_t> nodes_per_slot;   // how the tree's nodes spread over the device slots
         double witness_seconds = 0, tracegen_prove_seconds = 0, verify_seconds = 0, keygen_seconds = 0, build_seconds = 0;
     };
 
@@ -204,7 +205,8 @@ public:
         AggregationProver p;
         p.app_ = app, p.apps_ = {app}, p.spec_ = spec, p.cfg_ = cfg, p.device_ = device;
         p.agg_params_ = agg_params ? *agg_params : AggregationSystemParams::defaults_for(app.params);
-        p.levels_mu_.reset(new std::mutex), p.dev_mu_.reset(new std::mutex), p.build_mu_.reset(new std::mutex);
+        p.levels_mu_.reset(new std::mutex), p.build_mu_.reset(new std::mutex);
+        p.devices_ = {device};
         if (app.airs.size() != app.heights.size() || app.airs.empty()) throw Error(Error::Setup, "aggregation: the app verifying key needs one height per AIR");
         if (spec.start.size() != spec.end.size()) throw Error(Error::Setup, "aggregation: start and end state must have the same length");
         if (cfg.one_key && !p.agg_params_.same())
@@ -212,26 +214,34 @@ public:
                                       "(AggregationTreeConfig::one_key = false keeps a key per depth)");
         return p;
     }
+    // The GPUs the tree's nodes run on ("Aggregation-tree proving of the gathered proofs ... sharded one node per GPU per tree
+    // level"): every device gets its own copy of the node proving keys and its own circuit forks; a node goes to whichever device's
+    // pipeline is free first.  A device may be listed more than once (several pipelines on one GPU).  Before the first node only.
+    void set_devices(const std::vector<int>& devices) {
+        if (devices.empty()) throw Error(Error::Setup, "aggregation: an empty device list");
+        if (!slots_.empty()) throw Error(Error::Setup, "aggregation: the device list is fixed once keys exist");
+        devices_ = devices;
+    }
+    size_t n_slots() const { return devices_.size(); }
+    std::mutex& slot_mutex(size_t slot) { return *slots_.at(slot).mu; }
     AggregationProver(AggregationProver&& o) noexcept { *this = std::move(o); }
     AggregationProver& operator=(AggregationProver&& o) noexcept {
         reset();
-        app_ = std::move(o.app_), apps_ = std::move(o.apps_), leafs_ = std::move(o.leafs_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, agg_params_ = o.agg_params_, device_ = o.device_, ctx_ = o.ctx_, levels_ = std::move(o.levels_), stats = o.stats;
+        app_ = std::move(o.app_), apps_ = std::move(o.apps_), leafs_ = std::move(o.leafs_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, agg_params_ = o.agg_params_, device_ = o.device_, levels_ = std::move(o.levels_), stats = o.stats;
         leaf_commit_ = std::move(o.leaf_commit_), internal_commit_ = std::move(o.internal_commit_), leaf_list_ = std::move(o.leaf_list_);
-        levels_mu_ = std::move(o.levels_mu_), dev_mu_ = std::move(o.dev_mu_), build_mu_ = std::move(o.build_mu_);
-        o.ctx_ = nullptr;
+        levels_mu_ = std::move(o.levels_mu_), build_mu_ = std::move(o.build_mu_);
+        devices_ = std::move(o.devices_), slots_ = std::move(o.slots_);
+        o.slots_.clear();
         return *this;
     }
     ~AggregationProver() { reset(); }
     void reset() {
         for (auto* set : {&levels_, &leafs_})
-            for (auto& L : *set) {
-                for (void* d : L.d_traces)
-                    if (d) zkhip_free(ctx_, d);
-                if (L.pk && L.owns_pk) zkhip_pk_destroy(ctx_, L.pk);
-                if (L.circ) zkhip_recursion_destroy(L.circ);
-            }
+            for (auto& L : *set) free_level(L);
         levels_.clear(), leafs_.clear();
-        if (ctx_) zkhip_ctx_destroy(ctx_), ctx_ = nullptr;
+        for (auto& sl : slots_)
+            if (sl.ctx) zkhip_ctx_destroy(sl.ctx);
+        slots_.clear();
     }
 
     Stats stats;
@@ -255,12 +265,12 @@ public:
     size_t arity(size_t level) const { return level == 0 ? cfg_.num_children_leaf : cfg_.num_children_internal; }
 
     // proves one node: level 0 verifies up to 4 proofs of the app, level l > 0 up to 3 proofs of level l - 1
-    ChildProof prove_node(size_t level, const std::vector<const ChildProof*>& kids, size_t shape = 0, const std::vector<size_t>* kid_shapes = nullptr) {
+    ChildProof prove_node(size_t level, const std::vector<const ChildProof*>& kids, size_t shape = 0, const std::vector<size_t>* kid_shapes = nullptr, size_t slot = 0) {
         using clk = std::chrono::steady_clock;
         auto t0 = clk::now();
-        std::vector<uint32_t> npv = witness_node(level, kids, shape, kid_shapes);
+        std::vector<uint32_t> npv = witness_node(level, kids, shape, kid_shapes, slot);
         auto t1 = clk::now();
-        ChildProof out = prove_witnessed(level, std::move(npv), shape);
+        ChildProof out = prove_witnessed(level, std::move(npv), shape, slot);
         auto t2 = clk::now();
         if (!lv(level, shape).vk.verify(out)) throw Error(Error::VerifyProof, "aggregation: the node proof does not verify");
         stats.nodes++;
@@ -273,9 +283,10 @@ public:
     // "execution" of a node: runs the verifier circuit on the children (host; one thread per child inside the library) and
     // returns the node's public values.  Throws if a child does not verify or the states do not chain.
     // `shape` (level 0): which shape's segment proofs the node takes; `kid_shapes` (level 1): the shape of each leaf child (default 0)
-    std::vector<uint32_t> witness_node(size_t level, const std::vector<const ChildProof*>& kids, size_t shape = 0, const std::vector<size_t>* kid_shapes = nullptr) {
+    std::vector<uint32_t> witness_node(size_t level, const std::vector<const ChildProof*>& kids, size_t shape = 0, const std::vector<size_t>* kid_shapes = nullptr,
+                                       size_t slot = 0) {
         ensure_level(level);
-        Level& L = lv(level, shape);
+        Replica& L = lv(level, shape).rep.at(slot);
         if (kids.empty() || kids.size() > arity(level)) throw Error(Error::GenProof, "aggregation: a node of level " + std::to_string(level) + " takes 1.." + std::to_string(arity(level)) + " children");
         const VerifyingKey& cvk = level == 0 ? apps_.at(shape) : lv(level - 1).vk;   // (one key: the leaf's and the internal vk differ in the commitments only)
         std::vector<const uint8_t*> proofs;
@@ -312,10 +323,10 @@ public:
         return npv;
     }
     // device trace generation + proof of the node whose witness was computed last on this level
-    ChildProof prove_witnessed(size_t level, std::vector<uint32_t> node_pvs, size_t shape = 0) {
-        std::lock_guard<std::mutex> dev(*dev_mu_);
-        upload_witness(level, shape);
-        return prove_uploaded(level, std::move(node_pvs), shape);
+    ChildProof prove_witnessed(size_t level, std::vector<uint32_t> node_pvs, size_t shape = 0, size_t slot = 0) {
+        std::lock_guard<std::mutex> dev(*slots_.at(slot).mu);
+        upload_witness(level, shape, slot);
+        return prove_uploaded(level, std::move(node_pvs), shape, slot);
     }
 
     // The aggregation tree as a STREAM: segment proofs are pushed as they complete (any order, any thread) and every node starts as
@@ -392,10 +403,17 @@ public:
         }
 
     private:
+        struct Task {   // one node of a level, formed by the level's grouper
+            size_t k = 0, shape = 0;
+            std::vector<const ChildProof*> kids;
+            std::vector<size_t> kid_shapes;
+        };
         struct Layer {
             std::deque<std::unique_ptr<ChildProof>> items;   // layer 0 = segment proofs, layer l + 1 = node proofs of level l
             size_t total = SIZE_MAX;                          // number of items once known
             bool started = false;                             // the threads of the level that consumes this layer exist
+            std::deque<Task> tasks;                           // nodes of the level that consumes this layer, waiting for a free slot
+            bool tasks_closed = false;
         };
         AggregationProver& agg_;
         std::mutex mu_;
@@ -439,10 +457,69 @@ public:
             std::lock_guard<std::mutex> lk(mu_);
             start_level_locked(level);
         }
-        // level `level` consumes layer `level` and produces layer `level + 1`
+        // level `level` consumes layer `level` and produces layer `level + 1`.  One GROUPER thread forms the level's nodes in order (above
+        // the leaves node k takes children [a k, a k + a) of the layer below; a LEAF node takes the next run of segment proofs of one shape,
+        // at most a) and queues them; every device slot has a pair of threads that takes nodes from the queue as it gets free: one runs
+        // the verifier circuit (witness, host cores) into the slot's fork of the circuit, one generates the traces on the slot's device and
+        // proves the node -- witness (node n + 1) beside device (node n) per slot, the slots beside each other.
         void start_level_locked(size_t level) {
             while (layers_.size() <= level + 1) layers_.emplace_back();
             layers_[level].started = true;
+            threads_.emplace_back([this, level] {
+                const size_t a = agg_.arity(level);
+                try {
+                    size_t next = 0;   // first child of the next node
+                    for (size_t k = 0;; k++) {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        bool end = false;
+                        size_t hi = next;
+                        cv_.wait(lk, [&] {
+                            if (stop_ || !err_.empty()) return true;
+                            const Layer& in = layers_[level];
+                            if (in.total != SIZE_MAX && (next >= in.total || (level >= agg_.first_root_layer() && in.total == 1))) {
+                                end = true;   // no further node on this level (a single item of a root layer is the root)
+                                return true;
+                            }
+                            // the node's children: up to `a` present items from `next`; a leaf node stops where the shape changes
+                            for (hi = next; hi < next + a; hi++) {
+                                if (in.total != SIZE_MAX && hi >= in.total) break;
+                                if (in.items.size() <= hi || !in.items[hi]) return false;
+                                if (level == 0 && hi > next && seg_shape_[hi] != seg_shape_[next]) break;
+                            }
+                            return true;
+                        });
+                        if (end) layers_[level + 1].total = (level >= agg_.first_root_layer() && layers_[level].total == 1) ? 0 : k;
+                        if (end || stop_ || !err_.empty()) {
+                            layers_[level].tasks_closed = true;
+                            cv_.notify_all();
+                            break;
+                        }
+                        Task t;
+                        t.k = k;
+                        const Layer& in = layers_[level];
+                        for (size_t c = next; c < hi; c++) {
+                            t.kids.push_back(in.items[c].get());
+                            if (level == 1) t.kid_shapes.push_back(c < leaf_shape_.size() ? leaf_shape_[c] : 0);
+                        }
+                        if (level == 0) {
+                            t.shape = seg_shape_.size() > next ? seg_shape_[next] : 0;
+                            if (leaf_shape_.size() <= k) leaf_shape_.resize(k + 1, 0);
+                            leaf_shape_[k] = t.shape;
+                        }
+                        next = hi;
+                        layers_[level].tasks.push_back(std::move(t));
+                        cv_.notify_all();
+                    }
+                } catch (const std::exception& e) {
+                    fail(e.what());
+                    std::lock_guard<std::mutex> lk(mu_);
+                    layers_[level].tasks_closed = true;
+                    cv_.notify_all();
+                }
+            });
+            for (size_t slot = 0; slot < agg_.n_slots(); slot++) start_pair_locked(level, slot);
+        }
+        void start_pair_locked(size_t level, size_t slot) {
             struct Shared {
                 std::mutex m;
                 std::condition_variable c;
@@ -451,65 +528,31 @@ public:
                 std::vector<uint32_t> npv;
             };
             auto sh = std::make_shared<Shared>();
-            // witness thread: runs the circuit of node k once its children exist and the level's witness buffer is free.  Above the leaves node k
-            // takes children [a k, a k + a) of the layer below; a LEAF node takes the next run of segment proofs of one shape, at most a.
-            threads_.emplace_back([this, level, sh] {
-                const size_t a = agg_.arity(level);
+            // witness thread of the slot: the next queued node, once the slot's witness buffer of that circuit is free
+            threads_.emplace_back([this, level, slot, sh] {
                 try {
-                    size_t next = 0;   // first child of the next node
-                    for (size_t k = 0;; k++) {
-                        std::vector<const ChildProof*> kids;
-                        std::vector<size_t> kid_shapes;
-                        size_t shape = 0;
+                    for (;;) {
+                        Task t;
                         {
                             std::unique_lock<std::mutex> lk(mu_);
-                            bool end = false;
-                            size_t hi = next;
-                            cv_.wait(lk, [&] {
-                                if (stop_ || !err_.empty()) return true;
-                                const Layer& in = layers_[level];
-                                if (in.total != SIZE_MAX && (next >= in.total || (level >= agg_.first_root_layer() && in.total == 1))) {
-                                    end = true;   // no further node on this level (a single item of a root layer is the root)
-                                    return true;
-                                }
-                                // the node's children: up to `a` present items from `next`; a leaf node stops where the shape changes
-                                for (hi = next; hi < next + a; hi++) {
-                                    if (in.total != SIZE_MAX && hi >= in.total) break;
-                                    if (in.items.size() <= hi || !in.items[hi]) return false;
-                                    if (level == 0 && hi > next && seg_shape_[hi] != seg_shape_[next]) break;
-                                }
-                                return true;
-                            });
-                            if (end) {
-                                layers_[level + 1].total = (level >= agg_.first_root_layer() && layers_[level].total == 1) ? 0 : k;
-                                cv_.notify_all();
-                            }
-                            if (end || stop_ || !err_.empty()) break;
-                            const Layer& in = layers_[level];
-                            for (size_t c = next; c < hi; c++) {
-                                kids.push_back(in.items[c].get());
-                                if (level == 1) kid_shapes.push_back(c < leaf_shape_.size() ? leaf_shape_[c] : 0);
-                            }
-                            if (level == 0) {
-                                shape = seg_shape_.size() > next ? seg_shape_[next] : 0;
-                                if (leaf_shape_.size() <= k) leaf_shape_.resize(k + 1, 0);
-                                leaf_shape_[k] = shape;
-                            }
-                            next = hi;
+                            cv_.wait(lk, [&] { return stop_ || !err_.empty() || !layers_[level].tasks.empty() || layers_[level].tasks_closed; });
+                            if (stop_ || !err_.empty() || layers_[level].tasks.empty()) break;
+                            t = std::move(layers_[level].tasks.front());
+                            layers_[level].tasks.pop_front();
                         }
                         {
                             std::unique_lock<std::mutex> lk(sh->m);
                             sh->c.wait(lk, [&] { return sh->buffer_free; });
                         }
-                        const auto t = std::chrono::steady_clock::now();
-                        std::vector<uint32_t> npv = agg_.witness_node(level, kids, shape, &kid_shapes);
-                        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+                        const auto t0 = std::chrono::steady_clock::now();
+                        std::vector<uint32_t> npv = agg_.witness_node(level, t.kids, t.shape, &t.kid_shapes, slot);
+                        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                         {
                             std::lock_guard<std::mutex> lk(mu_);
                             agg_.stats.witness_seconds += dt;
                         }
                         std::lock_guard<std::mutex> lk(sh->m);
-                        sh->npv = std::move(npv), sh->node = k, sh->shape = shape, sh->witness_ready = true, sh->buffer_free = false;
+                        sh->npv = std::move(npv), sh->node = t.k, sh->shape = t.shape, sh->witness_ready = true, sh->buffer_free = false;
                         sh->c.notify_all();
                     }
                 } catch (const std::exception& e) {
@@ -519,8 +562,8 @@ public:
                 sh->done = true;
                 sh->c.notify_all();
             });
-            // device thread: trace generation (frees the witness buffer) and proof of the node, then its self-verification elsewhere
-            threads_.emplace_back([this, level, sh] {
+            // device thread of the slot: trace generation (frees the witness buffer) and proof of the node, then its self-verification elsewhere
+            threads_.emplace_back([this, level, slot, sh] {
                 try {
                     for (;;) {
                         std::vector<uint32_t> npv;
@@ -534,19 +577,21 @@ public:
                         const auto t = std::chrono::steady_clock::now();
                         ChildProof out;
                         {
-                            std::lock_guard<std::mutex> dev(*agg_.dev_mu_);
-                            agg_.upload_witness(level, shape);
+                            std::lock_guard<std::mutex> dev(agg_.slot_mutex(slot));
+                            agg_.upload_witness(level, shape, slot);
                             {
                                 std::lock_guard<std::mutex> lk(sh->m);
                                 sh->buffer_free = true;
                                 sh->c.notify_all();
                             }
-                            out = agg_.prove_uploaded(level, std::move(npv), shape);
+                            out = agg_.prove_uploaded(level, std::move(npv), shape, slot);
                         }
                         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
                         {
                             std::lock_guard<std::mutex> lk(mu_);
                             agg_.stats.tracegen_prove_seconds += dt, agg_.stats.nodes++;
+                            if (agg_.stats.nodes_per_slot.size() <= slot) agg_.stats.nodes_per_slot.resize(slot + 1, 0);
+                            agg_.stats.nodes_per_slot[slot]++;
                         }
                         put(level + 1, k, std::move(out));
                         std::lock_guard<std::mutex> lk(mu_);
@@ -611,14 +656,40 @@ public:
     }
 
 private:
-    AggregationProver() : levels_mu_(new std::mutex), dev_mu_(new std::mutex), build_mu_(new std::mutex) {}
-    struct Level {
+    AggregationProver() : levels_mu_(new std::mutex), build_mu_(new std::mutex) {}
+    // a level's copy on one device slot: the circuit user (slot 0: the level's own circuit; others: forks), the proving key on that device
+    // (one key: the levels above the first internal one share its key), the trace buffers
+    struct Replica {
         zkhip_recursion* circ = nullptr;
+        bool owns_circ = false;
         zkhip_pk* pk = nullptr;
-        bool owns_pk = true;   // one key: the levels above the first internal one share its proving key and fork its circuit
-        VerifyingKey vk;
+        bool owns_pk = true;
         std::vector<void*> d_traces;
     };
+    struct Level {
+        zkhip_recursion* circ = nullptr;   // the level's circuit (owned)
+        VerifyingKey vk;
+        std::vector<Replica> rep;          // per device slot
+    };
+    struct Slot {
+        int device = 0;
+        zkhip_ctx* ctx = nullptr;
+        std::unique_ptr<std::mutex> mu;    // any call on ctx
+    };
+    std::vector<int> devices_;
+    std::deque<Slot> slots_;
+    void free_level(Level& L) {
+        for (size_t sl = 0; sl < L.rep.size(); sl++) {
+            Replica& r = L.rep[sl];
+            zkhip_ctx* c = slots_.at(sl).ctx;
+            for (void* d : r.d_traces)
+                if (d) zkhip_free(c, d);
+            if (r.pk && r.owns_pk) zkhip_pk_destroy(c, r.pk);
+            if (r.circ && r.owns_circ) zkhip_recursion_destroy(r.circ);
+        }
+        L.rep.clear();
+        if (L.circ) zkhip_recursion_destroy(L.circ), L.circ = nullptr;
+    }
     // one key: zkhip_recursion_key_commit of the circuits' keys: leaf_list_ = the S leaf commitments (8 S words); leaf_commit_ = what a node
     // STATES as its leaf commitment: the commitment itself (one shape) or the sponge of the list
     std::vector<uint32_t> leaf_list_, leaf_commit_, internal_commit_;
@@ -629,11 +700,10 @@ private:
     AggregationTreeConfig cfg_;
     AggregationSystemParams agg_params_;
     int device_ = 0;
-    zkhip_ctx* ctx_ = nullptr;
     std::deque<Level> levels_;                       // (stable references: levels are added while others are in use)
-    // levels_mu_: the container (brief); build_mu_: one level is built at a time; dev_mu_: any call on ctx_.  Order: build -> dev;
-    // levels_mu_ is never held while another one is taken.
-    std::unique_ptr<std::mutex> levels_mu_, dev_mu_, build_mu_;
+    // levels_mu_: the container (brief); build_mu_: one level is built at a time; a slot's mu: any call on its context.  Order: build ->
+    // slot; levels_mu_ is never held while another one is taken.
+    std::unique_ptr<std::mutex> levels_mu_, build_mu_;
     Level& lv(size_t level, size_t shape = 0) {
         std::lock_guard<std::mutex> lk(*levels_mu_);
         if (level == 0 && cfg_.one_key) return leafs_.at(shape);
@@ -645,15 +715,16 @@ private:
     }
     const VerifyingKey& level_vk(size_t level, size_t shape = 0) { return lv(level, shape).vk; }
 
-    void check(int rc) const {
-        if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_last_error(ctx_));
+    void check(int rc, size_t slot = 0) const {
+        if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_last_error(slots_.at(slot).ctx));
     }
-    void upload_witness(size_t level, size_t shape = 0) {
-        Level& L = lv(level, shape);
-        check(zkhip_recursion_tracegen(ctx_, L.circ, (uint32_t*)L.d_traces[0], (uint32_t*)L.d_traces[1], (uint32_t*)L.d_traces[2]));
+    void upload_witness(size_t level, size_t shape = 0, size_t slot = 0) {
+        Replica& L = lv(level, shape).rep.at(slot);
+        check(zkhip_recursion_tracegen(slots_[slot].ctx, L.circ, (uint32_t*)L.d_traces[0], (uint32_t*)L.d_traces[1], (uint32_t*)L.d_traces[2]), slot);
     }
-    ChildProof prove_uploaded(size_t level, std::vector<uint32_t> node_pvs, size_t shape = 0) {
-        Level& L = lv(level, shape);
+    ChildProof prove_uploaded(size_t level, std::vector<uint32_t> node_pvs, size_t shape = 0, size_t slot = 0) {
+        Replica& L = lv(level, shape).rep.at(slot);
+        zkhip_ctx* ctx_ = slots_[slot].ctx;
         ChildProof out;
         out.pvs.resize(3);
         out.pvs[2] = std::move(node_pvs);
@@ -661,7 +732,7 @@ private:
         const uint32_t* dt[3] = {(const uint32_t*)L.d_traces[0], (const uint32_t*)L.d_traces[1], (const uint32_t*)L.d_traces[2]};
         const uint32_t* pv[3] = {nullptr, nullptr, out.pvs[2].data()};
         size_t len = 0;
-        check(zkhip_prove(ctx_, L.pk, dt, pv, out.proof.data(), out.proof.size(), &len));
+        check(zkhip_prove(ctx_, L.pk, dt, pv, out.proof.data(), out.proof.size(), &len), slot);
         out.proof.resize(len);
         return out;
     }
@@ -678,30 +749,50 @@ private:
             vk->heights.push_back((*na)[i].log_height);
         }
     }
-    // proving key + preprocessed commitments + trace buffers of a built circuit
+    // proving keys (one per device slot) + preprocessed commitments + trace buffers + circuit forks of a built circuit
     void keygen_level(Level& L, std::vector<zkhip_air>& na) {
-        std::lock_guard<std::mutex> dev(*dev_mu_);
-        int rc = zkhip_keygen(ctx_, &L.vk.params, na.data(), 3, &L.pk);
-        if (rc != ZKHIP_OK) throw Error(Error::Keygen, std::string("failed to generate STARK proving key: ") + zkhip_last_error(ctx_));
-        for (size_t i = 0; i < 3; i++) {
-            uint32_t c[8];
-            check(zkhip_pk_prep_commitment(ctx_, L.pk, i, c));
-            L.vk.airs[i].prep_commit.assign(c, c + 8);
+        L.rep.resize(slots_.size());
+        for (size_t sl = 0; sl < slots_.size(); sl++) {
+            Replica& r = L.rep[sl];
+            if (sl == 0) {
+                r.circ = L.circ, r.owns_circ = false;
+            } else {
+                if (zkhip_recursion_fork(L.circ, &r.circ) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_fork");
+                r.owns_circ = true;
+            }
+            std::lock_guard<std::mutex> dev(*slots_[sl].mu);
+            zkhip_ctx* c = slots_[sl].ctx;
+            int rc = zkhip_keygen(c, &L.vk.params, na.data(), 3, &r.pk);
+            if (rc != ZKHIP_OK) throw Error(Error::Keygen, std::string("failed to generate STARK proving key: ") + zkhip_last_error(c));
+            for (size_t i = 0; i < 3; i++) {
+                uint32_t cm[8];
+                check(zkhip_pk_prep_commitment(c, r.pk, i, cm), sl);
+                if (sl == 0) L.vk.airs[i].prep_commit.assign(cm, cm + 8);
+                else if (!std::equal(cm, cm + 8, L.vk.airs[i].prep_commit.begin())) throw Error(Error::Keygen, "aggregation: two devices disagree on a preprocessed commitment");
+            }
+            alloc_traces(L, sl);
         }
-        alloc_traces(L);
     }
-    void alloc_traces(Level& L) {
+    void alloc_traces(Level& L, size_t sl) {
         for (size_t i = 0; i < 3; i++) {
             void* d = nullptr;
-            check(zkhip_malloc(ctx_, (L.vk.airs[i].width << L.vk.heights[i]) * 4, &d));
-            L.d_traces.push_back(d);
+            check(zkhip_malloc(slots_[sl].ctx, (L.vk.airs[i].width << L.vk.heights[i]) * 4, &d), sl);
+            L.rep[sl].d_traces.push_back(d);
         }
     }
     void ensure_ctx() {
-        if (ctx_) return;
-        std::lock_guard<std::mutex> dev(*dev_mu_);
-        int rc = zkhip_ctx_create(device_, &ctx_);
-        if (rc != ZKHIP_OK) throw Error(Error::Keygen, "no gfx950 device for the HIP backend (zkhip_ctx_create returned " + std::to_string(rc) + ")");
+        if (!slots_.empty()) return;
+        for (int d : devices_) {
+            Slot sl;
+            sl.device = d, sl.mu.reset(new std::mutex);
+            int rc = zkhip_ctx_create(d, &sl.ctx);
+            if (rc != ZKHIP_OK) {
+                for (auto& x : slots_) zkhip_ctx_destroy(x.ctx);
+                slots_.clear();
+                throw Error(Error::Keygen, "no gfx950 device " + std::to_string(d) + " for the HIP backend (zkhip_ctx_create returned " + std::to_string(rc) + ")");
+            }
+            slots_.push_back(std::move(sl));
+        }
     }
     zkhip_recursion_stmt leaf_stmt(std::vector<uint32_t> (&cols)[4]) const {
         zkhip_recursion_stmt st{};
@@ -796,14 +887,8 @@ private:
             stats.build_seconds += std::chrono::duration<double>(t1 - t0).count();
             stats.keygen_seconds += std::chrono::duration<double>(clk::now() - t1).count();
         } catch (...) {
-            std::vector<Level*> all{&internal};
-            for (auto& L : leafs) all.push_back(&L);
-            for (Level* L : all) {
-                for (void* d : L->d_traces)
-                    if (d) zkhip_free(ctx_, d);
-                if (L->pk) zkhip_pk_destroy(ctx_, L->pk);
-                if (L->circ) zkhip_recursion_destroy(L->circ);
-            }
+            free_level(internal);
+            for (auto& L : leafs) free_level(L);
             throw;
         }
         std::lock_guard<std::mutex> lk(*levels_mu_);
@@ -822,14 +907,20 @@ private:
                     build_one_key();
                     continue;
                 }
-                // a further level of the tree: a fork of THE internal circuit (own witness, own trace buffers), the same proving key
+                // a further level of the tree: forks of THE internal circuit (own witness, own trace buffers), the same proving keys
                 Level& I = lv(1);
                 Level L;
                 if (zkhip_recursion_fork(I.circ, &L.circ) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_fork");
-                L.pk = I.pk, L.owns_pk = false, L.vk = I.vk;
-                {
-                    std::lock_guard<std::mutex> dev(*dev_mu_);
-                    alloc_traces(L);
+                L.vk = I.vk;
+                L.rep.resize(slots_.size());
+                for (size_t sl = 0; sl < slots_.size(); sl++) {
+                    Replica& r = L.rep[sl];
+                    if (sl == 0) r.circ = L.circ, r.owns_circ = false;
+                    else if (zkhip_recursion_fork(I.circ, &r.circ) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_fork");
+                    else r.owns_circ = true;
+                    r.pk = I.rep[sl].pk, r.owns_pk = false;
+                    std::lock_guard<std::mutex> dev(*slots_[sl].mu);
+                    alloc_traces(L, sl);
                 }
                 std::lock_guard<std::mutex> lk(*levels_mu_);
                 levels_.push_back(std::move(L));
@@ -853,7 +944,7 @@ private:
                 circuit_airs(L.circ, &L.vk, &na);
                 keygen_level(L, na);
             } catch (...) {
-                zkhip_recursion_destroy(L.circ);
+                free_level(L);
                 throw;
             }
             stats.build_seconds += std::chrono::duration<double>(t1 - t0).count();

@@ -446,6 +446,7 @@ struct GuestStark {
     VerifyingKey root_vk;
     size_t levels = 0, segments = 0;
     std::vector<size_t> segments_per_shape, chips_per_shape;   // how many segments were proven under each shape, and how many chips a shape carries
+    std::vector<size_t> nodes_per_slot;                        // how the tree's nodes spread over the device slots
     ExecutionResult exec;
     Digest image_root{};
     uint32_t entry_pc = 0;
@@ -716,6 +717,7 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
     g.levels = plan.levels.size();
     g.root_vk = agg.root_vk(plan.levels.size());   // (one aggregation key: the same for every depth)
     g.aggregation_mills = ms(clk::now() - t0);
+    g.nodes_per_slot = agg.stats.nodes_per_slot;
     return g;
 }
 // Rows of the Keccak-f chip for an app: the reference enables the intrinsic per app in openvm.toml (`[app_vm_config.keccak]`,
@@ -852,9 +854,13 @@ inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& e
                                                     curves, ec_log_rows(log_frame), fp2_moduli);
     // a segment is proven under the smallest SHAPE (set of chips) that holds what it used (ZKHIP_ONE_SHAPE=1: always the full set, as round 3)
     const SegmentShapes shapes = flow.one_shape ? SegmentShapes::only(caps) : SegmentShapes::of(caps, log_frame, vm_log2_ceil(exe.program.size()));
+    // the segments of ONE task spread over the GPUs of the node -- `inflight` lanes per listed device, each device its
+    // own copy of the (read-only) segment keys; a segment goes to whichever lane is free first
+    const std::vector<int> devs = flow.devices.empty() ? std::vector<int>{device} : flow.devices;
     std::vector<std::unique_ptr<ShapedSegmentProver>> own;
     std::vector<ShapedSegmentProver*> lanes;
-    for (unsigned l = 0; l < std::max(1u, inflight); l++) own.emplace_back(new ShapedSegmentProver(params, exe, shapes, device, /*build_all=*/l == 0)), lanes.push_back(own.back().get());
+    for (int d : devs)
+        for (unsigned l = 0; l < std::max(1u, inflight); l++) own.emplace_back(new ShapedSegmentProver(params, exe, shapes, d, /*build_all=*/own.empty())), lanes.push_back(own.back().get());
     std::vector<VerifyingKey> shape_vks;
     for (size_t sh = 0; sh < lanes[0]->n_shapes(); sh++) shape_vks.push_back(lanes[0]->vk(sh));
     // ZKHIP_AGG_100BIT=1 (measurements): the leaf / internal pair of AggregationSystemParams::with_100_bits_security() instead of the app's
@@ -862,6 +868,7 @@ inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& e
     const scroll_zkvm_hip::AggregationSystemParams pair = scroll_zkvm_hip::AggregationSystemParams::nodes_100_bits_security();
     scroll_zkvm_hip::AggregationProver agg =
         scroll_zkvm_hip::AggregationProver::setup_shapes(shape_vks, segment_statement(), {}, device, flow.agg_nodes_100bit ? &pair : nullptr);
+    agg.set_devices(devs);   // the tree's nodes go to whichever device's pipeline is free first
     (void)agg.node_vk(0);   // the leaf circuit and its key: setup, like the segment keys
     return prove_guest_with(lanes, agg, exe, in, caps, keep_segments, flow.verify_segments);
 }
@@ -1084,10 +1091,13 @@ private:
         if (!seg_.empty()) return;
         const zkhip_vm::SegmentShapes shapes = config.flow.one_shape ? zkhip_vm::SegmentShapes::only(caps_)
                                                                          : zkhip_vm::SegmentShapes::of(caps_, log_frame_, zkhip_vm::vm_log2_ceil(exe_.program.size()));
-        for (unsigned l = 0; l < std::max(1u, config.flow.lanes); l++) seg_.emplace_back(new zkhip_vm::ShapedSegmentProver(params_, exe_, shapes, device_, l == 0));
+        const std::vector<int> devs = config.flow.devices.empty() ? std::vector<int>{device_} : config.flow.devices;
+        for (int d : devs)
+            for (unsigned l = 0; l < std::max(1u, config.flow.lanes); l++) seg_.emplace_back(new zkhip_vm::ShapedSegmentProver(params_, exe_, shapes, d, seg_.empty()));
         std::vector<VerifyingKey> shape_vks;
         for (size_t sh = 0; sh < seg_[0]->n_shapes(); sh++) shape_vks.push_back(seg_[0]->vk(sh));
         agg_.reset(new AggregationProver(AggregationProver::setup_shapes(shape_vks, zkhip_vm::segment_statement(), {}, device_)));
+        agg_->set_devices(devs);
     }
 };
 

@@ -585,6 +585,39 @@ def test_segments_carry_only_the_chips_they_use(zk, ora, tmp_path):
     assert one["chips_per_shape"] == [51] and (d / "root.vk").read_bytes() != (tmp_path / "fib" / "root.vk").read_bytes()
 
 
+def test_one_task_over_a_device_list(tmp_path):
+    """the segments of ONE task spread over the GPUs of a node, and the aggregation tree's nodes go to whichever device
+    is free.  ZKHIP_DEVICES=0,0,0 builds three device slots -- all mapped onto this box's one GPU -- each with its own copy of the segment
+    and node keys, its own lanes and its own circuit forks: the root proof is byte-identical to the one-device run, the tree's nodes are
+    spread over the slots, the key is the same.  A device that does not exist is an error, not a crash."""
+    import os
+
+    words = fib_program()
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words))
+    cfg = tmp_path / "openvm.toml"
+    cfg.write_text(pm.TOML.format(*PARAMS))
+    out = {}
+    for name, env in (("one", {}), ("three", {"ZKHIP_DEVICES": "0,0,0", "ZKHIP_LANES": "1"})):
+        d = tmp_path / name
+        d.mkdir()
+        (d / "stdin.bin").write_bytes((3000).to_bytes(4, "little"))
+        r = subprocess.run([pm.CLI, "prove-elf", str(exe), str(d / "stdin.bin"), str(d), str(cfg), "9"], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-3000:]
+        out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["one"]["segments"] == out["three"]["segments"] > 27
+    assert len(out["one"]["tree_nodes_per_device_slot"]) == 1 and len(out["three"]["tree_nodes_per_device_slot"]) == 3
+    assert sum(out["three"]["tree_nodes_per_device_slot"]) == sum(out["one"]["tree_nodes_per_device_slot"]) and min(out["three"]["tree_nodes_per_device_slot"]) >= 1
+    a, b = json.loads((tmp_path / "one" / "root.json").read_text()), json.loads((tmp_path / "three" / "root.json").read_text())
+    assert a["proof"] == b["proof"] and a["user_pvs_proof"] == b["user_pvs_proof"]
+    assert (tmp_path / "one" / "root.vk").read_bytes() == (tmp_path / "three" / "root.vk").read_bytes()
+    d = tmp_path / "bad"
+    d.mkdir()
+    (d / "stdin.bin").write_bytes((100).to_bytes(4, "little"))
+    r = subprocess.run([pm.CLI, "prove-elf", str(exe), str(d / "stdin.bin"), str(d), str(cfg), "9"], capture_output=True, text=True, env=dict(os.environ, ZKHIP_DEVICES="0,63"))
+    assert r.returncode == 1 and "device" in r.stderr
+
+
 def test_gen_proof_universal_from_an_elf_and_witness_bytes(tmp_path):
     """Prover::gen_proof_universal (mod.rs:287-309) over the one-statement flow: the task's serialized witnesses reach the guest
     through ProvingTask::build_guest_input (length-framed items), the guest folds them into its public values, ONE proof comes out."""
