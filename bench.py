@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--log-rows", type=int, default=22)
     ap.add_argument("--width", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aggregate", action="store_true",
+                    help="skip folding the gathered proofs of the last step to one root on rank 0 (`aggregate`, after the timed region)")
     ap.add_argument("--no-guest-flow", action="store_true",
                     help="skip the ELF -> root proof run reported next to the headline (`guest_flow`, N = 1 only)")
     ap.add_argument("--commit-parts", type=int, default=-1,
@@ -328,6 +330,8 @@ def main():
             commits, proofs = xch.wait()
             xstat["wait_s"] = time.perf_counter() - tw
             assert all(len(c) == world for c in commits) and (rank != 0 or all(len(pr) == world for pr in proofs))
+            if rank == 0 and proofs:
+                xstat["last_gathered"] = proofs[-1]
         return last
 
     # setup, not warm-up: the first proof of a proving key grows its context's scratch buffers and loads its code
@@ -376,6 +380,7 @@ def main():
             shard.exchange(last, device=coll_dev)
         exchange_alone_ms = (time.perf_counter() - te) / 4 * 1e3
     pvs = pipes[last_i % n_pipe]["pvs"]
+    last_gathered = xstat.get("last_gathered")
     steps_profiled = len(range(0, args.steps, n_pipe))  # proofs that ran on pipeline 0
     dt = t1 - t0
     if world > 1:
@@ -542,6 +547,29 @@ def main():
             "stage_note": "per-kernel HIP-event times of one proof running alone (measured after the timed region); "
                           "`roofline` is from the timed region itself",
         }
+        if not args.no_aggregate and not args.no_cpu_baseline:
+            # "gather of encoded proofs to rank 0 ... aggregation-tree proving of the gathered proofs runs on rank 0": the
+            # proofs the ranks made in the last step, folded to ONE root under one aggregation key (zkvm-prover_amd/aggregate.py: leaf
+            # node(s) over <= 4 proofs, wrapped by the internal circuit).  After the timed region; never part of `value`.
+            try:
+                from zkvm_prover_amd import aggregate
+
+                gathered = [last] if world == 1 else [bytes(b) for b in last_gathered]
+                t_a = time.perf_counter()
+                agg = aggregate.TreeAggregator(ctx, params, pk.verifying_airs())
+                t_b = time.perf_counter()
+                root, rpv, levels = agg.aggregate(gathered, [pvs] * len(gathered))
+                t_c = time.perf_counter()
+                root2, _, _ = agg.aggregate(gathered, [pvs] * len(gathered))
+                t_d = time.perf_counter()
+                out["aggregate"] = {"proofs_folded": len(gathered), "nodes_per_level": [len(l) for l in levels],
+                                    "root_ms": round((t_d - t_c) * 1e3, 1), "root_ms_first": round((t_c - t_b) * 1e3, 1),
+                                    "setup_s": round(t_b - t_a, 2), "circuit_build_s": round(agg.build_s, 2), "keygen_s": round(agg.keygen_s, 2),
+                                    "leaf_circuit": {"gate_rows": agg.leaf.n_gates, "permutations": agg.leaf.n_perms, "log_heights": agg.leaf.log_heights()[:2]},
+                                    "root_proof_bytes": len(root), "root_verified_under_one_key": True, "deterministic": root == root2,
+                                    "note": "witness generation on the host + device traces + proof, per node; every rank proves the same synthetic instance"}
+            except Exception as e:  # a reported extra, never a gate
+                out["aggregate"] = {"root_ms": None, "note": "failed: %r" % (e,)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 # the instance of pipeline 0, fetched from the device: the CPU proves exactly what the GPU proved
@@ -586,16 +614,25 @@ def plumbing_run(args, world, rank):
         dist.barrier()
     dt = time.perf_counter() - t0
     ok = all(len(c) == world for c in commits)
+    folded = None
     if rank == 0:
         for i, prs in enumerate(proofs):
             ok &= [bytes(b) for b in prs] == [StubProver(r).collect(i) for r in range(world)]
             ok &= [bytes(c) for c in commits[i]] == [shard.commitment_of(b) for b in prs]
+        # gather -> aggregate on rank 0 (the tree's shape with stub nodes: a node = the hash of its children)
+        import hashlib
+
+        from zkvm_prover_amd import aggregate
+
+        root, levels = aggregate.fold_tree([bytes(b) for b in proofs[-1]], lambda g: hashlib.sha256(b"L" + b"".join(g)).digest(),
+                                           lambda g, leaves: hashlib.sha256(b"I" + b"".join(g)).digest())
+        folded = {"proofs_folded": world, "nodes_per_level": [len(l) for l in levels], "stub_root": root.hex()[:16]}
         print(json.dumps({"metric": "chunk STARK proofs/sec (2^%d-row trace)" % args.log_rows, "value": None,
                           "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                           "config": {"workload": "PLUMBING ONLY: stub proofs, gloo, no GPU -- not a measurement",
-                                     "exchange_ok": bool(ok)}}))
+                                     "exchange_ok": bool(ok)}, "aggregate": folded}))
     if world > 1:
         dist.destroy_process_group()
     if not ok:

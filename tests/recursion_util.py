@@ -98,25 +98,13 @@ def internal_accumulator(child_accs):
 
 
 def one_key_circuits(params, app_vk, stmt, arity_leaf=4, arity_internal=3, node_params=None):
-    """The two circuits of ONE aggregation key (include/zkhip_aggregation.hpp `AggregationProver::ensure_key`, restated): the leaf
-    circuit for the app's key with the uniform public-value layout, the uniform internal circuit for the node AIR set, both padded
-    to the smallest common heights (a fixed point: the internal circuit verifies proofs of its own height)."""
-    import zkvm_prover_amd as z
+    """The two circuits of ONE aggregation key (zkvm-prover_amd/aggregate.py one_key_circuits; include/zkhip_aggregation.hpp
+    `AggregationProver::build_one_key` in C++): the leaf circuit for the app's key with the uniform public-value layout, the uniform
+    internal circuit for the node AIR set, both padded to the smallest common heights."""
+    from zkvm_prover_amd import aggregate
 
-    node_params = node_params or params
-    leaf = z.RecursionCircuit(params, app_vk, arity_leaf, stmt=stmt, uniform=True)
-    na = leaf.airs()
-    child = [{k: a[k] for k in ("program", "log_height", "width", "n_pvs")} for a in na]
-    H = [na[0]["log_height"], na[1]["log_height"]]
-    while True:
-        for c, h in zip(child, H + [0]):
-            c["log_height"] = h
-        internal = z.RecursionCircuit(node_params, child, arity_internal, stmt="uniform", min_log_height=H)
-        hh = internal.log_heights()[:2]
-        if hh == H:
-            break
-        H = hh
-    leaf.pad(*H)
+    leafs, internal, _ = aggregate.one_key_circuits(params, [app_vk], stmt, arity_leaf, arity_internal, node_params)
+    leaf = leafs[0]
     assert leaf.log_heights() == internal.log_heights()
     for a, b in zip(leaf.airs(), internal.airs()):
         assert (a["program"] == b["program"]).all() and a["width"] == b["width"] and a["n_pvs"] == b["n_pvs"]
@@ -188,22 +176,43 @@ def one_key_circuits_shapes(params, app_vks, stmt, arity_leaf=4, arity_internal=
     """ONE aggregation key over several SHAPES of one app (per-proof chip presence: a segment carries only the chips it used, the app has
     one segment key and one leaf circuit per shape): the leaf circuits state one app id -- the digest of the LAST (full) shape --, share
     one height set with the internal circuit, and the internal circuit takes the list of their commitments."""
-    import zkvm_prover_amd as z
+    from zkvm_prover_amd import aggregate
 
-    app_id = z.vk_digest(params, app_vks[-1])
-    leafs = [z.RecursionCircuit(params, vk, arity_leaf, stmt=stmt, uniform=True, app_id=app_id) for vk in app_vks]
-    na = leafs[0].airs()
-    child = [{k: a[k] for k in ("program", "log_height", "width", "n_pvs")} for a in na]
-    H = [max(l.log_heights()[i] for l in leafs) for i in (0, 1)]
-    while True:
-        for c, h in zip(child, H + [0]):
-            c["log_height"] = h
-        internal = z.RecursionCircuit(params, child, arity_internal, stmt="uniform", min_log_height=H, n_leaf_shapes=len(leafs))
-        hh = internal.log_heights()[:2]
-        if hh == H:
-            break
-        H = hh
+    leafs, internal, app_id = aggregate.one_key_circuits(params, app_vks, stmt, arity_leaf, arity_internal)
     for l in leafs:
-        l.pad(*H)
         assert l.log_heights() == internal.log_heights()
     return leafs, internal, app_id
+
+
+class OracleAggregator:
+    """zkvm-prover_amd/aggregate.py TreeAggregator with the ORACLE as the node prover (CPU: the circuits' witnesses run on the host anyway;
+    only the node proofs need a prover): folds gathered proofs of one app key to a root under one aggregation key."""
+
+    def __init__(self, params, app_vk, stmt=None):
+        from zkvm_prover_amd import aggregate
+
+        self.params = params
+        leafs, self.internal, _ = aggregate.one_key_circuits(params, [app_vk], stmt)
+        self.leaf = leafs[0]
+        self.leaf_commits, self.leaf_commit = node_key_commits(params, self.leaf.airs())
+        self.internal_commits, self.internal_commit = node_key_commits(params, self.internal.airs())
+
+    def root_vk(self):
+        return verifying(self.params, [dict(a, prep_commit=c) for a, c in zip(self.internal.airs(), self.internal_commits)])
+
+    def prove_leaf(self, group):
+        st, npv = self.leaf.witness([p for p, _ in group], [pv for _, pv in group])
+        assert st == 0, self.leaf.last_error()
+        return ora.stark_prove(self.params, node_instance(self.leaf, npv)).tobytes(), npv
+
+    def prove_internal(self, group, children_are_leaves):
+        commits = self.leaf_commits if children_are_leaves else self.internal_commits
+        st, npv = self.internal.witness([p for p, _ in group], [[NOPV, NOPV, pv] for _, pv in group], prep_commits=[commits] * len(group),
+                                        is_leaf=[1 if children_are_leaves else 0] * len(group), leaf_commit=self.leaf_commit, internal_commit=self.internal_commit)
+        assert st == 0, self.internal.last_error()
+        return ora.stark_prove(self.params, node_instance(self.internal, npv)).tobytes(), npv
+
+    def aggregate(self, proofs, pvs):
+        from zkvm_prover_amd import aggregate
+
+        return aggregate.fold_tree(list(zip(proofs, pvs)), self.prove_leaf, self.prove_internal)

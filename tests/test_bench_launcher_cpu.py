@@ -30,6 +30,8 @@ def test_bench_spawns_its_own_ranks(n):
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == n and out["steps"] == 5 and out["config"]["exchange_ok"] is True
+    # gather -> aggregate on rank 0: the gathered (stub) proofs of the last step folded through the one-key tree shape
+    assert out["aggregate"]["proofs_folded"] == n and out["aggregate"]["nodes_per_level"][0] == (n + 3) // 4 and out["aggregate"]["nodes_per_level"][-1] == 1
     assert out["scaling"] == "weak" and out["value"] is None  # plumbing only: no measurement is claimed
 
 

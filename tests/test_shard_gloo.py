@@ -1,6 +1,9 @@
 """CPU, world_size 2 over gloo: the N>1 path of bench.py / shard.py -- round-robin segment
 assignment, all-gather of commitments, proof gather -- with real proofs (made by the oracle here,
-by the HIP prover on GPUs) checked by the product's host verifier on rank 0."""
+by the HIP prover on GPUs) checked by the product's host verifier on rank 0; then rank 0 FOLDS the
+gathered proofs to one root under one aggregation key (zkvm-prover_amd/aggregate.py fold_tree over the
+real verifier circuits, the oracle as the node prover: what crates/integration/src/testers/batch.rs:97-107
+hands to the next layer)."""
 import os
 import sys
 
@@ -46,6 +49,22 @@ def _worker(rank, world, port, q):
             ok &= z.verify(PARAMS, a, [a[0]["pvs"]], proofs[r]) == 0
             ok &= shard.commitment_of(proofs[r]) == commits[r]
         ok &= commits[0] != commits[1]
+        # gather -> aggregate: the gathered proofs under ONE root (leaf node over both, wrapped by the internal circuit)
+        import recursion_util as ru
+
+        vk = [{k: a[k] for k in ("program", "log_height", "width", "n_pvs")} for a in _airs(100)]
+        agg = ru.OracleAggregator(PARAMS, vk)
+        (root, rpv), levels = agg.aggregate(proofs, [[_airs(100 + r)[0]["pvs"]] for r in range(world)])
+        ok &= [len(l) for l in levels] == [1, 1]
+        ok &= z.verify(PARAMS, agg.root_vk(), [ru.NOPV, ru.NOPV, rpv], root) == 0
+        ok &= rpv[-16:-8].tolist() == agg.leaf_commit.tolist() and rpv[-8:].tolist() == agg.internal_commit.tolist()
+        ok &= rpv[8:16].tolist() == ru.internal_accumulator([ru.leaf_accumulator([[_airs(100 + r)[0]["pvs"]] for r in range(world)])]).tolist()
+        # a gathered proof that was swapped for another rank's claim has no witness
+        try:
+            agg.aggregate(proofs[::-1], [[_airs(100 + r)[0]["pvs"]] for r in range(world)])
+            ok = False
+        except AssertionError:
+            pass
     else:
         assert proofs is None
     dist.barrier()
@@ -65,6 +84,22 @@ def test_two_rank_exchange_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_fold_tree_shape():
+    """aggregate.fold_tree: leaf groups of 4, internal groups of 3, at least one internal level (the root is a proof of the internal
+    circuit whatever the count) -- the shape of AggregationPlan::build under one key."""
+    from zkvm_prover_amd import aggregate
+
+    for n, want in ((1, [1, 1]), (4, [1, 1]), (5, [2, 1]), (13, [4, 2, 1]), (40, [10, 4, 2, 1])):
+        root, levels = aggregate.fold_tree(list(range(n)), lambda g: ("L", tuple(g)), lambda g, leaves: ("I", leaves, tuple(g)))
+        assert [len(l) for l in levels] == want and root[0] == "I"
+        assert all(node[1] for node in levels[1]) and not any(node[1] for lv in levels[2:] for node in lv)
+
+        def flat(node):
+            return [x for c in node[-1] for x in (flat(c) if isinstance(c, tuple) else [c])]
+
+        assert flat(root) == list(range(n))
 
 
 def test_assign_segments():
