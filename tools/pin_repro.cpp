@@ -6,6 +6,8 @@
 //   h2: the same, the copy's source straddling the END of the registered range (last bytes of the block + first bytes of the neighbour)
 //   h3: register a heap block, free() it WITHOUT unregistering, allocate again (same address, other size), copy from the new block
 //   h4: register / copy / unregister a block of a mapping of its own (what the product does now), same trial count
+//   h5: TWO live heap blocks that share a page (two circuits' small value arrays), both registered, copied from, both unregistered
+//   h6: h5, the first block unregistered and freed while the second stays registered and in use
 // build: hipcc -O1 tools/pin_repro.cpp -o gpurun_out/pin_repro ; run: gpurun_out/pin_repro [trials]
 #include <hip/hip_runtime.h>
 #include <malloc.h>
@@ -46,6 +48,24 @@ static int run(int h, int trials) {
         char* a = (char*)malloc(sa);
         char* b = (char*)malloc(sb);   // the next chunk of the heap: starts 16 bytes behind a's end
         memset(a, 1, sa), memset(b, 2, sb);
+        if (h == 5 || h == 6) {
+            errors += hipHostRegister(a, sa, hipHostRegisterDefault) != hipSuccess;
+            errors += hipHostRegister(b, sb, hipHostRegisterDefault) != hipSuccess;   // shares a's last page
+            errors += hipMemcpy(d, a, sa, hipMemcpyHostToDevice) != hipSuccess;
+            errors += hipMemcpy(d, b, sb, hipMemcpyHostToDevice) != hipSuccess;
+            errors += hipHostUnregister(a) != hipSuccess;
+            if (h == 6) {
+                free(a);
+                a = (char*)malloc(sa / 2);
+                memset(a, 4, sa / 2);
+                errors += hipMemcpy(d, a, sa / 2, hipMemcpyHostToDevice) != hipSuccess;
+            }
+            errors += hipMemcpy(d, b, sb, hipMemcpyHostToDevice) != hipSuccess;
+            errors += hipHostUnregister(b) != hipSuccess;
+            (void)hipGetLastError();
+            free(b), free(a);
+            continue;
+        }
         errors += hipHostRegister(a, sa, hipHostRegisterDefault) != hipSuccess;
         errors += hipMemcpy(d, a, sa, hipMemcpyHostToDevice) != hipSuccess;
         if (h == 1) errors += hipMemcpy(d, b, sb, hipMemcpyHostToDevice) != hipSuccess;
@@ -70,7 +90,7 @@ static int run(int h, int trials) {
 int main(int argc, char** argv) {
     const int trials = argc > 1 ? atoi(argv[1]) : 300;
     printf("{");
-    for (int h = 1; h <= 4; h++) {
+    for (int h = 1; h <= 6; h++) {
         fflush(stdout);
         const pid_t pid = fork();   // (the parent has not initialised the GPU)
         if (pid == 0) _exit(run(h, trials));
