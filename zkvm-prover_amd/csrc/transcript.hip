@@ -59,9 +59,10 @@ __global__ void k_tr_init(DevTranscript* t) {
     if (threadIdx.x < 16) t->state[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         t->n_in = t->n_out = 0;
-        t->pow_found = 0xffffffffu;
+        t->pow_found = 0xffffffffu;   // ARMED: between two grinds pow_found = 0xffffffff and pad (the blocks-done counter) = 0
         t->pow_applied = 0;
         t->error = 0;
+        t->pad = 0;
     }
 }
 
@@ -122,12 +123,33 @@ __global__ __launch_bounds__(64) void k_tr_sample_bits(DevTranscript* t, uint32_
     tr_store(t, r, lane);
 }
 
-// Proof-of-work search, one launch: every lane tests candidates base + gid, base advancing by the
-// grid size.  observe(w); sample_bits(bits) costs exactly one permutation whichever branch of the
-// duplex logic is taken.  A block leaves once a witness below its next candidate window is known;
-// since every block scans its candidates in increasing order, the atomicMin result is the global
-// minimum (= the first witness a sequential scan finds).
-__global__ __launch_bounds__(256) void k_grind(DevTranscript* t, unsigned bits, uint32_t limit) {
+// Applies the found witness to the live transcript and stores it (canonical); leaves the transcript armed for the next grind.
+__device__ __forceinline__ void grind_apply(DevTranscript* t, unsigned bits, uint32_t* witness_out, unsigned lane) {
+    const uint32_t w = __hip_atomic_load(&t->pow_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w == 0xffffffffu) {
+        if (lane == 0) t->error |= 1u, t->pad = 0;
+        return;
+    }
+    TrRegs r = tr_load(t, lane);
+    tr_observe1(r, lane, to_monty(w));
+    const uint32_t mask = bits ? ((1u << bits) - 1u) : 0u;
+    const uint32_t v = from_monty(tr_sample1(r, lane)) & mask;
+    tr_store(t, r, lane);
+    if (lane == 0) {
+        if (v != 0) t->error |= 2u;
+        if (witness_out) *witness_out = w;
+        t->pow_applied = 1;
+        t->pow_found = 0xffffffffu, t->pad = 0;   // armed again
+    }
+}
+
+// Proof-of-work search AND the application of the witness in ONE launch (round 4: a grind was three launches -- arm, search, finish --
+// and a proof has ~20 of them).  Every lane tests candidates base + gid, base advancing by the grid size.  observe(w);
+// sample_bits(bits) costs exactly one permutation whichever branch of the duplex logic is taken.  A block leaves once a witness below
+// its next candidate window is known; since every block scans its candidates in increasing order, the atomicMin result is the global
+// minimum (= the first witness a sequential scan finds).  The LAST block to leave (a counter in the transcript) applies the witness
+// with its first wave and re-arms the transcript.
+__global__ __launch_bounds__(256) void k_grind(DevTranscript* t, unsigned bits, uint32_t limit, uint32_t* witness_out) {
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t mask = (1u << bits) - 1u;
@@ -138,7 +160,7 @@ __global__ __launch_bounds__(256) void k_grind(DevTranscript* t, unsigned bits, 
     for (uint32_t base = 0; base < limit; base += stride) {
         // volatile read: other blocks publish with atomicMin (device scope)
         const uint32_t found = __hip_atomic_load(&t->pow_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (found < base) return;
+        if (found < base) break;
         const uint32_t w = base + gid;
         if (w >= limit || w < base) continue;
         uint32_t s[16];
@@ -151,27 +173,19 @@ __global__ __launch_bounds__(256) void k_grind(DevTranscript* t, unsigned bits, 
         poseidon2_permute(s);
         if ((from_monty(s[7]) & mask) == 0) atomicMin(&t->pow_found, w);
     }
+    // every lane of the block has read the state it needed and published what it found: count the block out
+    __shared__ uint32_t last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&t->pad, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    __threadfence();
+    grind_apply(t, bits, witness_out, threadIdx.x);
 }
 
-// Applies the found witness to the live transcript and stores it (canonical).
-__global__ __launch_bounds__(64) void k_grind_finish(DevTranscript* t, unsigned bits, uint32_t* witness_out) {
-    const unsigned lane = threadIdx.x;
-    const uint32_t w = t->pow_found;
-    if (w == 0xffffffffu) {
-        if (lane == 0) t->error |= 1u;
-        return;
-    }
-    TrRegs r = tr_load(t, lane);
-    tr_observe1(r, lane, to_monty(w));
-    const uint32_t mask = bits ? ((1u << bits) - 1u) : 0u;
-    const uint32_t v = from_monty(tr_sample1(r, lane)) & mask;
-    tr_store(t, r, lane);
-    if (lane == 0) {
-        if (v != 0) t->error |= 2u;
-        if (witness_out) *witness_out = w;
-        t->pow_applied = 1;
-    }
-}
+// grind(0): p3 semantics -- observe witness 0 and sample (no search)
+__global__ __launch_bounds__(64) void k_grind_finish(DevTranscript* t, unsigned bits, uint32_t* witness_out) { grind_apply(t, bits, witness_out, threadIdx.x); }
 
 __global__ void k_grind_arm(DevTranscript* t, uint32_t init) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -246,20 +260,21 @@ int transcript_sample_bits(zkhip_ctx* ctx, DevTranscript* d_t, uint32_t* d_dst, 
     return ZKHIP_OK;
 }
 
-// One search launch + one finish launch per grind; never needs the host.
+// One launch per grind (the search's last block applies the witness); never needs the host.
 int transcript_grind(zkhip_ctx* ctx, DevTranscript* d_t, unsigned bits, uint32_t* d_witness_out) {
     if (bits > 30) return set_error(ctx, ZKHIP_ERR_INVALID, "pow bits > 30");
     KernelScope ks(ctx, "pow_grind");
-    // p3 semantics: grind(0) observes witness 0 and samples
-    hipLaunchKernelGGL(k_grind_arm, dim3(1), dim3(64), 0, ctx->stream, d_t, bits == 0 ? 0u : 0xffffffffu);
-    if (bits != 0) {
+    if (bits == 0) {
+        // p3 semantics: grind(0) observes witness 0 and samples
+        hipLaunchKernelGGL(k_grind_arm, dim3(1), dim3(64), 0, ctx->stream, d_t, 0u);
+        hipLaunchKernelGGL(k_grind_finish, dim3(1), dim3(64), 0, ctx->stream, d_t, bits, d_witness_out);
+    } else {
         // a sweep covers 2^bits candidates (the expected position of the witness): measured on a node proof's 21 grinds 1.08 ms against
         // 1.22 ms with 2^(bits+1) and 1.64 ms with 2^(bits+2) per sweep -- a permutation per lane is latency, more lanes only queue
         const unsigned grind_shift = std::min(ctx->cfg.grind_sweep_shift, 8u);
         unsigned blocks = std::min(4096u, std::max(64u, ((1u << grind_shift) << bits) / 256u));
-        hipLaunchKernelGGL(k_grind, dim3(blocks), dim3(256), 0, ctx->stream, d_t, bits, (uint32_t)P);
+        hipLaunchKernelGGL(k_grind, dim3(blocks), dim3(256), 0, ctx->stream, d_t, bits, (uint32_t)P, d_witness_out);
     }
-    hipLaunchKernelGGL(k_grind_finish, dim3(1), dim3(64), 0, ctx->stream, d_t, bits, d_witness_out);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
 }
