@@ -867,6 +867,9 @@ typedef struct {
     uint32_t witness_threads;
     int pin_witness, parallel_queries;
 } zkhip_config;
+/* Compiles the constraint kernels of `airs` for blow-up 2^log_blowup into `cache_dir` (no GPU needed: hipRTC), where key generation finds
+ * them when zkhip_config.jit_cache_dir names the directory; *n_ok (may be NULL) = kernels present afterwards. */
+int zkhip_jit_prewarm(const zkhip_air *airs, size_t n_airs, unsigned log_blowup, const char *cache_dir, size_t *n_ok);
 /* the built-in defaults with the environment's overrides applied */
 void zkhip_config_default(zkhip_config *out);
 /* a context's configuration (set at zkhip_ctx_create from zkhip_config_default); the witness fields are process-wide:

@@ -942,6 +942,33 @@ int upload(zkhip_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 extern "C" {
 
+// Compiles the constraint kernels of `airs` (hipRTC needs no GPU) into `cache_dir`, where key generation looks for them
+// (zkhip_config.jit_cache_dir): __graft_entry__.build() does this for the chips of the guest flow, so that the first key generation of a
+// process on a fresh machine loads code objects instead of compiling for tens of seconds.  The source depends on the program and the
+// blow-up only.  *n_ok = kernels present afterwards; AIRs whose program the code generator refuses are skipped (they run interpreted).
+int zkhip_jit_prewarm(const zkhip_air* airs, size_t n_airs, unsigned log_blowup, const char* cache_dir, size_t* n_ok) {
+    if (!airs || !cache_dir || !cache_dir[0] || log_blowup < 1 || log_blowup > 4) return ZKHIP_ERR_INVALID;
+    size_t ok = 0;
+    for (size_t a = 0; a < n_airs; a++) {
+        if (!airs[a].program || airs[a].width == 0) return ZKHIP_ERR_INVALID;
+        AirProgram p;
+        std::string err;
+        if (parse_air(airs[a].program, airs[a].program_len, airs[a].width, &p, &err) != 0) return ZKHIP_ERR_INVALID;
+        // what key generation would compile (the rule of zkhip_keygen): evaluations of >= 2^jit_min_log_work row-instructions at the
+        // AIR's height, and AIRs the interpreter form refuses
+        CompiledAir comp;
+        const bool interp_ok = compile_air(p, &comp, &err) == 0;
+        const double work = (double)((size_t)1 << (airs[a].log_height + log_blowup)) * (double)(comp.code.size() / 3);
+        if (interp_ok && work < (double)(1ull << std::min(process_config().jit_min_log_work, 62u)) && process_config().jit != 2) continue;
+        std::vector<uint32_t> tab;
+        std::vector<char> code;
+        std::string msg;
+        if (quot_jit_code(p, airs[a].log_height, log_blowup, &tab, &code, &msg, nullptr, cache_dir)) ok++;
+    }
+    if (n_ok) *n_ok = ok;
+    return ZKHIP_OK;
+}
+
 int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* airs, size_t n_airs, zkhip_pk** out) {
     ZK_BIND_DEVICE(ctx);
     if (!ctx || !params || !airs || !out || n_airs == 0) return ZKHIP_ERR_INVALID;
