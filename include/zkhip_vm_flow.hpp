@@ -447,6 +447,8 @@ struct GuestStark {
     size_t levels = 0, segments = 0;
     std::vector<size_t> segments_per_shape, chips_per_shape;   // how many segments were proven under each shape, and how many chips a shape carries
     std::vector<size_t> nodes_per_slot;                        // how the tree's nodes spread over the device slots
+    double agg_build_seconds = 0, agg_keygen_seconds = 0;      // the aggregation circuits and their keys (a one-time cost of a prover that lives on)
+    std::vector<unsigned> node_log_heights;                    // heights of the node circuits' chips (gate, Poseidon2, public values)
     ExecutionResult exec;
     Digest image_root{};
     uint32_t entry_pc = 0;
@@ -718,6 +720,8 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
     g.root_vk = agg.root_vk(plan.levels.size());   // (one aggregation key: the same for every depth)
     g.aggregation_mills = ms(clk::now() - t0);
     g.nodes_per_slot = agg.stats.nodes_per_slot;
+    g.agg_build_seconds = agg.stats.build_seconds, g.agg_keygen_seconds = agg.stats.keygen_seconds;
+    g.node_log_heights = g.root_vk.heights;
     return g;
 }
 // Rows of the Keccak-f chip for an app: the reference enables the intrinsic per app in openvm.toml (`[app_vm_config.keccak]`,

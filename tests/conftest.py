@@ -24,6 +24,16 @@ def ora():
     return oracle_lib
 
 
+@pytest.fixture(autouse=True)
+def _restore_context_config(request):
+    """A test may change the session context's configuration (zk.set_config(jit=2)): the defaults come back afterwards."""
+    yield
+    if "zk" in request.fixturenames:
+        import zkvm_prover_amd as z
+
+        request.getfixturevalue("zk").set_config(z.Config.default())
+
+
 @pytest.fixture(scope="session")
 def zk():
     """HIP context on cuda:0; the GPU tests fail loudly if the extension is missing."""

@@ -41,11 +41,8 @@ def test_cached_partitions_match_the_oracle(zk, ora, lh_big, lh_small, params, f
     airs = _case(lh_big, lh_small)
     pvs = [a["pvs"] for a in airs]
     if force_jit:
-        os.environ["ZKHIP_FORCE_JIT"] = "1"
-    try:
-        pk = z.ProvingKey(zk, params, airs)
-    finally:
-        os.environ.pop("ZKHIP_FORCE_JIT", None)
+        zk.set_config(jit=2)   # (restored after the test: tests/conftest.py)
+    pk = z.ProvingKey(zk, params, airs)
     d = [zk.upload(a["trace"].reshape(-1)) for a in airs]
     proof = pk.prove(d, pvs)
     assert np.frombuffer(proof[:4], np.uint32)[0] == 0x31504B5A + 7

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("jit", ["interpreter", "jit"])
 def test_small_chipset_equals_oracle(zk, ora, jit, monkeypatch):
-    monkeypatch.setenv("ZKHIP_NO_JIT" if jit == "interpreter" else "ZKHIP_FORCE_JIT", "1")
+    zk.set_config(jit=0 if jit == "interpreter" else 2)   # (restored after the test: tests/conftest.py)
     params = (1, 0, 8, 3, 4)
     airs = air.ChipSet(n_chips=6, log_max=8, log_min=3, total_width=60, seed=1, log_table=2).gen(1)
     for a in airs:

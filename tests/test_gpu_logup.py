@@ -60,7 +60,7 @@ def _cases():
 @pytest.mark.parametrize("name", sorted(_cases()))
 @pytest.mark.parametrize("jit", ["interpreter", "jit"])
 def test_logup_proof_bytes_equal_oracle(zk, ora, name, jit, monkeypatch):
-    monkeypatch.setenv("ZKHIP_NO_JIT" if jit == "interpreter" else "ZKHIP_FORCE_JIT", "1")
+    zk.set_config(jit=0 if jit == "interpreter" else 2)   # (restored after the test: tests/conftest.py)
     params = (1, 0, 8, 3, 4)
     airs = _cases()[name]
     for a in airs:
@@ -186,7 +186,7 @@ def test_random_bus_expressions_match_oracle(zk, ora, seed):
 def test_four_interactions_per_column_group_at_blowup_4(zk, ora, jit, monkeypatch):
     """With blow-up 4 the degree budget is 5: four degree-1 interactions share one group of permutation columns
     (constraint phi * d1 d2 d3 d4 = sum +-count * prod of the other three, degree 5).  Proof bytes equal the oracle's."""
-    monkeypatch.setenv("ZKHIP_NO_JIT" if jit == "interpreter" else "ZKHIP_FORCE_JIT", "1")
+    zk.set_config(jit=0 if jit == "interpreter" else 2)   # (restored after the test: tests/conftest.py)
     b = air.bus_mix_air()
     b.max_constraint_degree = 5
     prog = b.program()

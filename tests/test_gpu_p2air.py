@@ -25,7 +25,7 @@ def test_device_trace_equals_oracle(zk, log_n, n_perms):
 
 @pytest.mark.parametrize("jit", ["interpreter", "jit"])
 def test_proof_from_device_trace_equals_oracle(zk, ora, jit, monkeypatch):
-    monkeypatch.setenv("ZKHIP_NO_JIT" if jit == "interpreter" else "ZKHIP_FORCE_JIT", "1")
+    zk.set_config(jit=0 if jit == "interpreter" else 2)   # (restored after the test: tests/conftest.py)
     params = (1, 0, 8, 3, 4)
     rng = np.random.default_rng(5)
     inputs = O.rand_field(rng, (200, 16))
@@ -85,7 +85,7 @@ def test_poseidon2_chip_on_a_bus_device_trace_equals_oracle(zk, ora, jit, monkey
     import torch
     from test_p2air_cpu import hasher_pair
 
-    monkeypatch.setenv("ZKHIP_NO_JIT" if jit == "interpreter" else "ZKHIP_FORCE_JIT", "1")
+    zk.set_config(jit=0 if jit == "interpreter" else 2)   # (restored after the test: tests/conftest.py)
     params = (1, 0, 8, 3, 4)
     airs, uniq = hasher_pair(log_user=6, n_req=40, log_chip=7, seed=11)
     pvs = [NOPV, NOPV]

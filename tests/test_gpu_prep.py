@@ -36,7 +36,7 @@ def _cases():
 @pytest.mark.parametrize("name", sorted(_cases()))
 @pytest.mark.parametrize("jit", ["interpreter", "jit"])
 def test_prep_proof_bytes_equal_oracle(zk, ora, name, jit, monkeypatch):
-    monkeypatch.setenv("ZKHIP_NO_JIT" if jit == "interpreter" else "ZKHIP_FORCE_JIT", "1")
+    zk.set_config(jit=0 if jit == "interpreter" else 2)   # (restored after the test: tests/conftest.py)
     params = (1, 0, 8, 3, 4)
     airs = _cases()[name]
     pvs = [a["pvs"] for a in airs]

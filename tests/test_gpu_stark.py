@@ -133,10 +133,9 @@ def test_jit_constraint_kernel_matches_interpreter_and_oracle(zk, ora, monkeypat
     params = (1, 0, 6, 3, 3)
     airs = [_syn(8, 40, 10, 31), _fib(6)]
     exp = ora.stark_prove(params, airs).tobytes()
-    monkeypatch.setenv("ZKHIP_FORCE_JIT", "1")
+    zk.set_config(jit=2)
     got_jit, _, _ = _prove_gpu(zk, params, airs)
-    monkeypatch.delenv("ZKHIP_FORCE_JIT")
-    monkeypatch.setenv("ZKHIP_NO_JIT", "1")
+    zk.set_config(jit=0)   # (restored after the test: tests/conftest.py)
     got_int, _, _ = _prove_gpu(zk, params, airs)
     assert got_jit == exp and got_int == exp
 
@@ -244,7 +243,7 @@ def test_random_constraint_dags_match_oracle(zk, ora, seed, jit, monkeypatch):
     airs = [dict(program=b.program(), log_height=log_n, width=width, n_pvs=n_pvs, trace=trace, pvs=pvs), _fib(3)]
     params = (1, 0, 4, 2, 2)
     exp = ora.stark_prove(params, airs).tobytes()
-    monkeypatch.setenv("ZKHIP_NO_JIT" if jit == "interpreter" else "ZKHIP_FORCE_JIT", "1")
+    zk.set_config(jit=0 if jit == "interpreter" else 2)   # (restored after the test: tests/conftest.py)
     got, _, _ = _prove_gpu(zk, params, airs)
     assert got == exp
 

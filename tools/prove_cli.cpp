@@ -50,6 +50,56 @@ static ProvingTask read_task(const std::string& path) {
 
 int main(int argc, char** argv) {
     try {
+        if (argc >= 5 && std::string(argv[1]) == "jit-prewarm") {
+            // jit-prewarm <openvm.toml | -> <log_frame> <cache_dir> [part n_parts]: compiles (hipRTC: no GPU needed) the constraint kernels key
+            // generation would compile for a guest flow under this configuration -- the segment chips of the full shape at their heights and
+            // the two wide chips of the aggregation node circuits -- into <cache_dir> (zkhip_config.jit_cache_dir; `jit_cache` beside
+            // libzkhip.so is found by default).  __graft_entry__.build() runs it, in parts side by side.
+            const std::string cfg_path = std::string(argv[2]) == "-" ? "" : argv[2];
+            const unsigned log_frame = (unsigned)atoi(argv[3]);
+            const size_t part = argc >= 7 ? (size_t)atoi(argv[5]) : 0, n_parts = argc >= 7 ? std::max(1, atoi(argv[6])) : 1;
+            zkhip_params params{1, 0, 100, 16, 16};
+            if (!cfg_path.empty()) params = read_app_config(cfg_path);
+            zkhip_vm::Exe exe;
+            exe.program.assign(64, 0x00000013u);   // (the chips' constraint programs do not depend on the guest)
+            const zkhip_vm::SegmentCaps caps = cfg_path.empty() ? zkhip_vm::SegmentCaps::for_frame(log_frame, 6)
+                : zkhip_vm::SegmentCaps::for_frame(log_frame, 6, zkhip_vm::keccak_log_rows(cfg_path, log_frame), zkhip_vm::sha256_log_rows(cfg_path, log_frame),
+                                                   zkhip_vm::config_moduli(cfg_path), log_frame > 8 ? log_frame - 8 : 1, zkhip_vm::int256_log_rows(cfg_path, log_frame),
+                                                   zkhip_vm::config_curves(cfg_path), zkhip_vm::ec_log_rows(log_frame), zkhip_vm::config_fp2_moduli(cfg_path));
+            const zkhip_vm::SegmentAirs sa = zkhip_vm::segment_airs(exe, caps);
+            std::vector<zkhip_air> airs = sa.airs;
+            // the node circuits' gate and Poseidon2 chips (their programs do not depend on the child key; heights of a real leaf circuit)
+            zkhip_recursion* toy = nullptr;
+            {
+                using namespace zkhip::air;
+                AirBuilder b(1, 18);
+                b.assert_zero(b.var(0) - b.var(0));
+                const std::vector<uint32_t> prog = b.program();
+                zkhip_air child{prog.data(), prog.size(), 3, 1, 18, nullptr, nullptr};
+                std::vector<uint32_t> sa_, si_, ea_, ei_;
+                for (uint32_t k = 0; k < 9; k++) sa_.push_back(0), si_.push_back(k), ea_.push_back(0), ei_.push_back(9 + k);
+                zkhip_recursion_stmt st{};
+                st.n_state = 9, st.start_air = sa_.data(), st.start_idx = si_.data(), st.end_air = ea_.data(), st.end_idx = ei_.data(), st.uniform = 1;
+                const zkhip_params toy_params{1, 0, 2, 1, 1};
+                if (zkhip_recursion_build(&toy_params, &child, 1, 1, &st, &toy) == ZKHIP_OK)
+                    for (size_t i = 0; i < 2; i++) {
+                        zkhip_air a{};
+                        if (zkhip_recursion_air(toy, i, &a) == ZKHIP_OK) a.log_height = i == 0 ? 21 : 18, a.prep_trace = nullptr, airs.push_back(a);
+                    }
+            }
+            size_t total = 0, mine = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (size_t a = 0; a < airs.size(); a++) {
+                if (a % n_parts != part) continue;
+                size_t ok = 0;
+                if (zkhip_jit_prewarm(&airs[a], 1, params.log_blowup, argv[4], &ok) != ZKHIP_OK) throw Error(Error::Setup, "zkhip_jit_prewarm failed for AIR " + std::to_string(a));
+                total += ok, mine++;
+            }
+            if (toy) zkhip_recursion_destroy(toy);
+            std::printf("{\"airs\": %zu, \"of\": %zu, \"kernels_in_cache\": %zu, \"seconds\": %.1f}\n", mine, airs.size(), total,
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            return 0;
+        }
         if (argc >= 6 && std::string(argv[1]) == "dump-segments") {
             // dump-segments <guest.elf | exe.bin> <stdin.bin | -> <out_dir> <log_frame>: the segmenting executor's records (include/zkhip_vm_exec.hpp)
             // as raw u32 arrays, one directory per segment -- what the tests' CPU twins of the trace generators read
@@ -180,11 +230,13 @@ int main(int argc, char** argv) {
                     std::printf("{\"total_cycles\": %llu, \"segments\": %zu, \"levels\": %zu, \"lanes\": %u, \"execution_ms\": %llu, \"segment_tracegen_and_proving_ms\": %llu, "
                                 "\"sum_over_segments_tracegen_ms\": %llu, \"sum_over_segments_prove_ms\": %llu, "
                                 "\"aggregation_setup_wait_ms\": %llu, \"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, \"chips_per_shape\": %s, "
-                                "\"segments_per_shape\": %s, \"tree_nodes_per_device_slot\": %s, \"verified\": true}\n",
+                                "\"segments_per_shape\": %s, \"tree_nodes_per_device_slot\": %s, \"aggregation_circuits_build_s\": %.2f, \"aggregation_keygen_s\": %.2f, "
+                                "\"node_log_heights\": [%u, %u], \"verified\": true}\n",
                                 (unsigned long long)g.exec.total_cycle, g.segments, g.levels, lanes, (unsigned long long)g.execution_mills,
                                 (unsigned long long)g.segment_proving_mills, (unsigned long long)g.sum_segment_tracegen_mills,
                                 (unsigned long long)g.sum_segment_prove_mills, (unsigned long long)g.aggregation_setup_wait_mills,
-                                (unsigned long long)g.aggregation_mills, wall, g.root.proof.size(), list_of(g.chips_per_shape).c_str(), list_of(g.segments_per_shape).c_str(), list_of(g.nodes_per_slot).c_str());
+                                (unsigned long long)g.aggregation_mills, wall, g.root.proof.size(), list_of(g.chips_per_shape).c_str(), list_of(g.segments_per_shape).c_str(), list_of(g.nodes_per_slot).c_str(), g.agg_build_seconds, g.agg_keygen_seconds,
+                                g.node_log_heights.at(0), g.node_log_heights.at(1));
                 } catch (const zkhip_vm::Error& e) {
                     throw Error(Error::GenProof, e.what());
                 }

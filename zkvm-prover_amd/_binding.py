@@ -301,6 +301,19 @@ class Context:
         s = torch.cuda.current_stream(self.device).cuda_stream
         self._check(self.lib.zkhip_set_stream(self.h, C.c_void_p(s)))
 
+    def config(self):
+        """This context's zkhip_config (a Config structure)."""
+        c = Config()
+        self._check(self.lib.zkhip_ctx_get_config(self.h, C.byref(c)))
+        return c
+
+    def set_config(self, cfg=None, **fields):
+        """zkhip_ctx_set_config: a whole Config, or single fields of the current one (set_config(jit=2, quot_slices=0))."""
+        c = cfg if cfg is not None else self.config()
+        for k, v in fields.items():
+            setattr(c, k, v.encode() if isinstance(v, str) else v)
+        self._check(self.lib.zkhip_ctx_set_config(self.h, C.byref(c)))
+
     def close(self):
         if self.h:
             self.lib.zkhip_ctx_destroy(self.h)
