@@ -227,7 +227,7 @@ public:
     AggregationProver(AggregationProver&& o) noexcept { *this = std::move(o); }
     AggregationProver& operator=(AggregationProver&& o) noexcept {
         reset();
-        app_ = std::move(o.app_), apps_ = std::move(o.apps_), leafs_ = std::move(o.leafs_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, agg_params_ = o.agg_params_, device_ = o.device_, levels_ = std::move(o.levels_), stats = o.stats;
+        app_ = std::move(o.app_), apps_ = std::move(o.apps_), leafs_ = std::move(o.leafs_), bigleafs_ = std::move(o.bigleafs_), policy_ = std::move(o.policy_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, agg_params_ = o.agg_params_, device_ = o.device_, levels_ = std::move(o.levels_), stats = o.stats;
         leaf_commit_ = std::move(o.leaf_commit_), internal_commit_ = std::move(o.internal_commit_), leaf_list_ = std::move(o.leaf_list_);
         levels_mu_ = std::move(o.levels_mu_), build_mu_ = std::move(o.build_mu_);
         devices_ = std::move(o.devices_), slots_ = std::move(o.slots_);
@@ -236,9 +236,9 @@ public:
     }
     ~AggregationProver() { reset(); }
     void reset() {
-        for (auto* set : {&levels_, &leafs_})
+        for (auto* set : {&levels_, &leafs_, &bigleafs_})
             for (auto& L : *set) free_level(L);
-        levels_.clear(), leafs_.clear();
+        levels_.clear(), leafs_.clear(), bigleafs_.clear();
         for (auto& sl : slots_)
             if (sl.ctx) zkhip_ctx_destroy(sl.ctx);
         slots_.clear();
@@ -262,7 +262,28 @@ public:
     bool one_key() const { return cfg_.one_key; }
     const AggregationTreeConfig& tree_config() const { return cfg_; }
     size_t first_root_layer() const { return cfg_.one_key ? 2 : 1; }
-    size_t arity(size_t level) const { return level == 0 ? cfg_.num_children_leaf : cfg_.num_children_internal; }
+    size_t arity(size_t level, size_t shape = 0) const {
+        if (level > 0) return cfg_.num_children_internal;
+        return shape < policy_.size() && policy_[shape].arity ? policy_[shape].arity : cfg_.num_children_leaf;
+    }
+    // How a shape's segment proofs enter the tree.  A leaf circuit's size grows with the total width of the chips it verifies; the tree's
+    // circuits share ONE height set, so a shape much wider than the base set would make every node of every tree as large as ITS leaf
+    // circuit (measured: the reference's chunk-circuit configuration, 51 chips, 2^25 gate rows instead of 2^22).  `arity`: how many
+    // segment proofs of the shape a leaf node takes (0 = the tree's leaf arity).  `wrapped`: the shape's leaf circuit keeps its natural
+    // (large) heights and its proofs enter the tree through a WRAPPER -- a circuit of the common size that verifies one proof of that
+    // leaf circuit and restates its public values; the wrapper's commitment is the shape's entry in the leaf-commitment list.
+    struct ShapePolicy {
+        unsigned arity = 0;
+        bool wrapped = false;
+    };
+    void set_shape_policies(const std::vector<ShapePolicy>& p) {
+        if (!slots_.empty()) throw Error(Error::Setup, "aggregation: shape policies are fixed once keys exist");
+        if (p.size() != apps_.size()) throw Error(Error::Setup, "aggregation: one policy per shape");
+        for (const auto& q : p)
+            if (q.arity > 8) throw Error(Error::Setup, "aggregation: a leaf node takes at most 8 proofs");
+        policy_ = p;
+    }
+    bool wrapped(size_t shape) const { return shape < policy_.size() && policy_[shape].wrapped; }
 
     // proves one node: level 0 verifies up to 4 proofs of the app, level l > 0 up to 3 proofs of level l - 1
     ChildProof prove_node(size_t level, const std::vector<const ChildProof*>& kids, size_t shape = 0, const std::vector<size_t>* kid_shapes = nullptr, size_t slot = 0) {
@@ -287,7 +308,7 @@ public:
                                        size_t slot = 0) {
         ensure_level(level);
         Replica& L = lv(level, shape).rep.at(slot);
-        if (kids.empty() || kids.size() > arity(level)) throw Error(Error::GenProof, "aggregation: a node of level " + std::to_string(level) + " takes 1.." + std::to_string(arity(level)) + " children");
+        if (kids.empty() || kids.size() > arity(level, shape)) throw Error(Error::GenProof, "aggregation: a node of level " + std::to_string(level) + " takes 1.." + std::to_string(arity(level, shape)) + " children");
         const VerifyingKey& cvk = level == 0 ? apps_.at(shape) : lv(level - 1).vk;   // (one key: the leaf's and the internal vk differ in the commitments only)
         std::vector<const uint8_t*> proofs;
         std::vector<size_t> lens;
@@ -321,6 +342,46 @@ public:
         }
         if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_recursion_last_error(L.circ));
         return npv;
+    }
+    // A leaf node of a WRAPPED shape: the shape's (large) leaf circuit over its segment proofs, then the wrapper over that proof -- what
+    // enters the tree is the wrapper's proof.  Host witness and device work of both, one after the other, on one slot.
+    ChildProof prove_wrapped(const std::vector<const ChildProof*>& kids, size_t shape, size_t slot = 0) {
+        ensure_level(0);
+        if (!wrapped(shape)) throw Error(Error::GenProof, "aggregation: not a wrapped shape");
+        Level& B = bigleafs_.at(shape);
+        Level& W = lv(0, shape);
+        auto run = [&](Level& L, const VerifyingKey& cvk, const std::vector<const ChildProof*>& ks) {
+            Replica& r = L.rep.at(slot);
+            std::vector<const uint8_t*> proofs;
+            std::vector<size_t> lens;
+            std::vector<std::vector<const uint32_t*>> rows(ks.size());
+            std::vector<const uint32_t* const*> pv;
+            for (size_t c = 0; c < ks.size(); c++) {
+                if (ks[c]->pvs.size() != cvk.airs.size()) throw Error(Error::GenProof, "aggregation: child public values do not match the child verifying key");
+                proofs.push_back(ks[c]->proof.data()), lens.push_back(ks[c]->proof.size());
+                for (const auto& v : ks[c]->pvs) rows[c].push_back(v.data());
+                pv.push_back(rows[c].data());
+            }
+            std::vector<uint32_t> npv(zkhip_recursion_n_pvs(r.circ));
+            if (zkhip_recursion_witness(r.circ, proofs.data(), lens.data(), pv.data(), ks.size(), npv.data()) != ZKHIP_OK)
+                throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_recursion_last_error(r.circ));
+            std::lock_guard<std::mutex> dev(*slots_.at(slot).mu);
+            zkhip_ctx* c = slots_[slot].ctx;
+            check(zkhip_recursion_tracegen(c, r.circ, (uint32_t*)r.d_traces[0], (uint32_t*)r.d_traces[1], (uint32_t*)r.d_traces[2]), slot);
+            ChildProof out;
+            out.pvs.resize(3);
+            out.pvs[2] = std::move(npv);
+            out.proof.resize(zkhip_proof_size(r.pk));
+            const uint32_t* dt[3] = {(const uint32_t*)r.d_traces[0], (const uint32_t*)r.d_traces[1], (const uint32_t*)r.d_traces[2]};
+            const uint32_t* pvp[3] = {nullptr, nullptr, out.pvs[2].data()};
+            size_t len = 0;
+            check(zkhip_prove(c, r.pk, dt, pvp, out.proof.data(), out.proof.size(), &len), slot);
+            out.proof.resize(len);
+            return out;
+        };
+        if (kids.empty() || kids.size() > arity(0, shape)) throw Error(Error::GenProof, "aggregation: too many segment proofs for a leaf node of this shape");
+        const ChildProof big = run(B, apps_.at(shape), kids);
+        return run(W, B.vk, {&big});
     }
     // device trace generation + proof of the node whose witness was computed last on this level
     ChildProof prove_witnessed(size_t level, std::vector<uint32_t> node_pvs, size_t shape = 0, size_t slot = 0) {
@@ -466,7 +527,6 @@ public:
             while (layers_.size() <= level + 1) layers_.emplace_back();
             layers_[level].started = true;
             threads_.emplace_back([this, level] {
-                const size_t a = agg_.arity(level);
                 try {
                     size_t next = 0;   // first child of the next node
                     for (size_t k = 0;; k++) {
@@ -474,6 +534,8 @@ public:
                         bool end = false;
                         size_t hi = next;
                         cv_.wait(lk, [&] {
+                            // (a leaf node takes as many proofs as its shape's policy says)
+                            const size_t a = agg_.arity(level, level == 0 && seg_shape_.size() > next ? seg_shape_[next] : 0);
                             if (stop_ || !err_.empty()) return true;
                             const Layer& in = layers_[level];
                             if (in.total != SIZE_MAX && (next >= in.total || (level >= agg_.first_root_layer() && in.total == 1))) {
@@ -543,6 +605,18 @@ public:
                         {
                             std::unique_lock<std::mutex> lk(sh->m);
                             sh->c.wait(lk, [&] { return sh->buffer_free; });
+                        }
+                        if (level == 0 && agg_.wrapped(t.shape)) {
+                            // the shape's own leaf circuit, then its wrapper: both here, the wrapper's proof enters layer 1
+                            const auto tw = std::chrono::steady_clock::now();
+                            ChildProof out = agg_.prove_wrapped(t.kids, t.shape, slot);
+                            const double dw = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+                            {
+                                std::lock_guard<std::mutex> lk(mu_);
+                                agg_.stats.tracegen_prove_seconds += dw, agg_.stats.nodes += 2;
+                            }
+                            put(level + 1, t.k, std::move(out));
+                            continue;
                         }
                         const auto t0 = std::chrono::steady_clock::now();
                         std::vector<uint32_t> npv = agg_.witness_node(level, t.kids, t.shape, &t.kid_shapes, slot);
@@ -694,7 +768,9 @@ private:
     // STATES as its leaf commitment: the commitment itself (one shape) or the sponge of the list
     std::vector<uint32_t> leaf_list_, leaf_commit_, internal_commit_;
     std::vector<VerifyingKey> apps_;   // the shapes' segment keys (apps_.back() = app_ = the full set)
-    std::deque<Level> leafs_;          // one key: the leaf circuit of every shape (levels_[0] is then unused)
+    std::deque<Level> leafs_;          // one key: the leaf circuit of every shape (a wrapped shape: its wrapper); levels_[0] is then unused
+    std::deque<Level> bigleafs_;       // ... and, for a wrapped shape, its own (large) leaf circuit
+    std::vector<ShapePolicy> policy_;
     VerifyingKey app_;
     StatementSpec spec_;
     AggregationTreeConfig cfg_;
@@ -809,7 +885,8 @@ private:
         ensure_ctx();
         auto t0 = clk::now();
         const size_t S = apps_.size();
-        std::deque<Level> leafs(S);
+        if (policy_.size() != S) policy_.assign(S, ShapePolicy{});
+        std::deque<Level> leafs(S), bigs(S);
         Level internal;
         std::vector<std::vector<zkhip_air>> la(S);
         std::vector<zkhip_air> ia;
@@ -831,12 +908,28 @@ private:
                     st.uniform = 1;
                     st.app_id = S > 1 ? app_id.data() : nullptr;
                     std::vector<zkhip_air> za = apps_[sh].as_airs();
-                    const int rc = zkhip_recursion_build(&apps_[sh].params, za.data(), za.size(), arity(0), &st, &leafs[sh].circ);
+                    const int rc = zkhip_recursion_build(&apps_[sh].params, za.data(), za.size(), arity(0, sh), &st, &leafs[sh].circ);
                     if (rc != ZKHIP_OK) errs[sh] = std::string("aggregation: cannot build the leaf verifier circuit of shape ") + std::to_string(sh) + ": " + zkhip_recursion_last_error(nullptr);
                 });
             for (auto& t : th) t.join();
             for (const auto& e : errs)
                 if (!e.empty()) throw Error(Error::Setup, e);
+            // a WRAPPED shape: its leaf circuit keeps its natural heights and gets its keys now (the wrapper is a circuit FOR that key); what
+            // takes the shape's place among the tree's leaf circuits is the wrapper (one child, the one-key public-value layout restated)
+            for (size_t sh = 0; sh < S; sh++) {
+                if (!policy_[sh].wrapped) continue;
+                bigs[sh] = std::move(leafs[sh]);
+                leafs[sh] = Level{};
+                bigs[sh].vk.params = agg_params_.leaf;
+                std::vector<zkhip_air> ba;
+                circuit_airs(bigs[sh].circ, &bigs[sh].vk, &ba);
+                keygen_level(bigs[sh], ba);
+                std::vector<zkhip_air> za = bigs[sh].vk.as_airs();
+                zkhip_recursion_stmt st{};
+                st.child_is_node = 1, st.uniform = 1;
+                const int rc = zkhip_recursion_build(&bigs[sh].vk.params, za.data(), za.size(), 1, &st, &leafs[sh].circ);
+                if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the wrapper of shape ") + std::to_string(sh) + ": " + zkhip_recursion_last_error(nullptr));
+            }
             unsigned H[2] = {0, 0};
             for (size_t sh = 0; sh < S; sh++) {
                 leafs[sh].vk.params = agg_params_.leaf;
@@ -889,10 +982,12 @@ private:
         } catch (...) {
             free_level(internal);
             for (auto& L : leafs) free_level(L);
+            for (auto& L : bigs) free_level(L);
             throw;
         }
         std::lock_guard<std::mutex> lk(*levels_mu_);
         leafs_ = std::move(leafs);
+        bigleafs_ = std::move(bigs);
         levels_.emplace_back();   // (level 0 lives in leafs_)
         levels_.push_back(std::move(internal));
     }

@@ -409,6 +409,29 @@ struct SegmentShapes {
         return caps.size() - 1;
     }
 };
+// How each shape's proofs enter the aggregation tree (AggregationProver::ShapePolicy), from the total width of its chips against the base
+// set's: the cost of verifying a segment proof in-circuit grows with the columns opened per query.  The base set: leaf nodes of 4 proofs.
+// A shape up to ~5.5 times as wide (the base chips + both hash intrinsics: ~5.2): leaf nodes of fewer proofs, so that its leaf circuit
+// keeps the common size.  Wider still (the full set of the reference's chunk circuit: ~11): one proof per leaf node of its own, large
+// circuit, which enters the tree through a wrapper of the common size.
+inline std::vector<scroll_zkvm_hip::AggregationProver::ShapePolicy> shape_policies(const std::vector<VerifyingKey>& shape_vks) {
+    auto width_of = [](const VerifyingKey& vk) {
+        size_t w = 0;
+        for (const auto& a : vk.airs) w += a.width;
+        return (double)w;
+    };
+    std::vector<scroll_zkvm_hip::AggregationProver::ShapePolicy> out;
+    const double base = width_of(shape_vks.front());
+    for (size_t sh = 0; sh < shape_vks.size(); sh++) {
+        scroll_zkvm_hip::AggregationProver::ShapePolicy p;
+        const double r = width_of(shape_vks[sh]) / base;
+        if (sh == 0 || shape_vks.size() == 1) p.arity = 0;
+        else if (r <= 5.5) p.arity = std::max(1u, (unsigned)(4.4 / r));
+        else p.arity = 1, p.wrapped = true;
+        out.push_back(p);
+    }
+    return out;
+}
 // a lane of the flow: one SegmentProver per shape (built at the first segment of that shape; lane 0 builds all of them at setup: their keys
 // are the aggregation tree's leaf circuits)
 class ShapedSegmentProver {
@@ -716,7 +739,8 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
     const auto t0 = clk::now();
     const scroll_zkvm_hip::AggregationPlan plan = scroll_zkvm_hip::AggregationPlan::build(seg_proofs.size(), agg.tree_config());
     g.root = tree.finish(seg_proofs.size());   // (what is left of the tree once the last segment proof exists)
-    g.levels = plan.levels.size();
+    g.levels = tree.levels();   // (leaf nodes are cut where the shape changes: the plan's fixed grouping is a lower bound)
+    (void)plan;
     g.root_vk = agg.root_vk(plan.levels.size());   // (one aggregation key: the same for every depth)
     g.aggregation_mills = ms(clk::now() - t0);
     g.nodes_per_slot = agg.stats.nodes_per_slot;
@@ -873,6 +897,7 @@ inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& e
     scroll_zkvm_hip::AggregationProver agg =
         scroll_zkvm_hip::AggregationProver::setup_shapes(shape_vks, segment_statement(), {}, device, flow.agg_nodes_100bit ? &pair : nullptr);
     agg.set_devices(devs);   // the tree's nodes go to whichever device's pipeline is free first
+    agg.set_shape_policies(shape_policies(shape_vks));
     (void)agg.node_vk(0);   // the leaf circuit and its key: setup, like the segment keys
     return prove_guest_with(lanes, agg, exe, in, caps, keep_segments, flow.verify_segments);
 }
@@ -1102,6 +1127,7 @@ private:
         for (size_t sh = 0; sh < seg_[0]->n_shapes(); sh++) shape_vks.push_back(seg_[0]->vk(sh));
         agg_.reset(new AggregationProver(AggregationProver::setup_shapes(shape_vks, zkhip_vm::segment_statement(), {}, device_)));
         agg_->set_devices(devs);
+        agg_->set_shape_policies(zkhip_vm::shape_policies(shape_vks));
     }
 };
 

@@ -303,3 +303,59 @@ def test_one_key_over_several_shapes_of_one_app(ora):
     assert status(L, [2, 1, 2], lcs=[other, LCs[1]])[0] == -7
     st, top2 = internal.witness([root], [[NOPV, NOPV, rpv]], prep_commits=[int_pcs], is_leaf=[0], leaf_commit=np.concatenate([other, LCs[1]]), internal_commit=IC)
     assert st == -7                                                                  # an internal child states another list
+
+
+def test_a_wide_shape_enters_the_tree_through_a_wrapper(ora):
+    """A shape whose leaf circuit is too large for the tree's common heights (the reference's chunk-circuit configuration: 51 chips, a leaf
+    circuit of 2^25 gate rows against 2^22) keeps a leaf circuit of its own, natural size; a WRAPPER -- a circuit of the common size that
+    verifies ONE proof of that leaf circuit and restates its public values in the one-key layout -- takes its place in the list of leaf
+    commitments.  Here the 'wide' shape is the four-chip set, the narrow one the three-chip set."""
+    full = [ru.counter_segment(s, seed=i) for i, s in enumerate([5, 12, 19])]
+    narrow_seg = [full[1][0], full[1][1], full[1][3]]
+    vk_narrow, vk_wide = ru.verifying(PARAMS, narrow_seg), ru.verifying(PARAMS, full[0])
+    app_id = z.vk_digest(PARAMS, vk_wide)
+    big = z.RecursionCircuit(PARAMS, vk_wide, 1, stmt=ru.COUNTER_STMT, uniform=True, app_id=app_id)          # natural size, one proof per node
+    big_pcs, _ = ru.node_key_commits(PARAMS, big.airs())
+    big_vk = ru.verifying(PARAMS, [dict(a, prep_commit=c) for a, c in zip(big.airs(), big_pcs)])
+    wrap = z.RecursionCircuit(PARAMS, big_vk, 1, stmt="node", uniform=True)
+    assert wrap.n_pvs == big.n_pvs == 34
+    narrow = z.RecursionCircuit(PARAMS, vk_narrow, 4, stmt=ru.COUNTER_STMT, uniform=True, app_id=app_id)
+    # the common heights: over the narrow leaf, the wrapper and the internal circuit -- NOT the wide leaf
+    child = [{k: a[k] for k in ("program", "log_height", "width", "n_pvs")} for a in narrow.airs()]
+    H = [max(c.log_heights()[i] for c in (narrow, wrap)) for i in (0, 1)]
+    while True:
+        for c, h in zip(child, H + [0]):
+            c["log_height"] = h
+        internal = z.RecursionCircuit(PARAMS, child, 3, stmt="uniform", min_log_height=H, n_leaf_shapes=2)
+        if internal.log_heights()[:2] == H:
+            break
+        H = internal.log_heights()[:2]
+    narrow.pad(*H), wrap.pad(*H)
+    keys = [ru.node_key_commits(PARAMS, c.airs()) for c in (narrow, wrap)]
+    int_pcs, IC = ru.node_key_commits(PARAMS, internal.airs())
+    segs = [full[0], narrow_seg, full[2]]                                                                      # wide, narrow, wide
+    proofs = [ora.stark_prove(PARAMS, s).tobytes() for s in segs]
+    pvs = [[a["pvs"] for a in s] for s in segs]
+
+    def through_wrapper(i):
+        st, npv = big.witness([proofs[i]], [pvs[i]])
+        assert st == 0, big.last_error()
+        bp = ora.stark_prove(PARAMS, ru.node_instance(big, npv)).tobytes()
+        st, wpv = wrap.witness([bp], [[NOPV, NOPV, npv]])
+        assert st == 0, wrap.last_error()
+        assert wpv[:10].tolist() == npv[:10].tolist() and (wpv[-16:] == 0).all()                              # app id, start, end restated
+        assert wpv[10:18].tolist() == ru.internal_accumulator([npv[10:18]]).tolist()
+        return ora.stark_prove(PARAMS, ru.node_instance(wrap, wpv)).tobytes(), wpv
+
+    st, npv1 = narrow.witness([proofs[1]], [pvs[1]])
+    assert st == 0
+    L = [through_wrapper(0), (ora.stark_prove(PARAMS, ru.node_instance(narrow, npv1)).tobytes(), npv1), through_wrapper(2)]
+    kinds = [2, 1, 2]
+    st, rpv = internal.witness([c[0] for c in L], [[NOPV, NOPV, c[1]] for c in L], prep_commits=[keys[k - 1][0] for k in kinds], is_leaf=kinds,
+                               leaf_commit=np.concatenate([keys[0][1], keys[1][1]]), internal_commit=IC)
+    assert st == 0, internal.last_error()
+    assert rpv[:8].tolist() == app_id.tolist() and int(rpv[8]) == 5 and int(rpv[9]) == 26
+    # a proof of the wide leaf circuit itself (not wrapped) is not a child of the internal circuit: another height set altogether
+    st, npv0 = big.witness([proofs[0]], [pvs[0]])
+    bp0 = ora.stark_prove(PARAMS, ru.node_instance(big, npv0)).tobytes()
+    assert internal.witness([bp0], [[NOPV, NOPV, npv0]], prep_commits=[big_pcs], is_leaf=[2], leaf_commit=np.concatenate([keys[0][1], keys[1][1]]), internal_commit=IC)[0] != 0

@@ -1540,7 +1540,7 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
     R->k.reset(new RecCore());
     RecCore& K = *R->k;
     K.mode = stmt->child_is_node;
-    K.uniform = K.mode == 2 || (K.mode == 0 && stmt->uniform);
+    K.uniform = K.mode == 2 || ((K.mode == 0 || K.mode == 1) && stmt->uniform);
     if (stmt->n_leaf_shapes > 8) return ZKHIP_ERR_INVALID;
     K.n_leaf_shapes = K.mode == 2 ? std::max<size_t>(1, stmt->n_leaf_shapes) : 1;
     if (K.mode == 0 && stmt->app_id) {
@@ -1566,7 +1566,10 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
     } else if (sp.child_is_node) {
         // the child is a node circuit: its last AIR is the public-value chip with [vk(8) start(K) end(K) acc(8)] (+ [leaf commitment (8) |
         // internal commitment (8)] under one key)
-        const size_t np = vk.n_pvs[n_airs - 1], fixed = K.mode == 2 ? 32 : 16;
+        // (child_is_node = 1 with `uniform`: a WRAPPER -- it verifies proofs of ONE fixed node key whose public values have the one-key
+        // layout and states them in the same layout, so that a leaf circuit too large for the tree's common heights enters the tree
+        // through a circuit of the common size)
+        const size_t np = vk.n_pvs[n_airs - 1], fixed = K.uniform ? 32 : 16;
         if (np < fixed || (np - fixed) % 2) return ZKHIP_ERR_INVALID;
         if (K.mode == 2 && n_airs != 3) return ZKHIP_ERR_INVALID;
         K.n_state = (np - fixed) / 2;
