@@ -50,6 +50,55 @@ __global__ __launch_bounds__(256) void k_hash_rows(const uint32_t* const* __rest
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
+// The row sponges of SEVERAL levels of a mixed-height tree in one launch (round 4): the leaf level and every level with injected
+// matrices that is too large for the cooperative layer form.  A proof of many chips of many heights hashes most of its rows at the
+// levels below the tallest one; hashed inside the layer kernel (one lane per node: compress, sponge, compress) those levels ran at
+// one or two waves per SIMD -- here their rows run beside the leaf level's at full occupancy, and the layer kernel is left with two
+// permutations per node (k_compress_layer_inj2).  The row digest of node i of a level is parked in the node's own slot of the digest
+// store until the layer kernel replaces it.
+struct RowHashLevels {
+    uint32_t n_levels;
+    uint32_t first_block[9];   // blocks [first_block[k], first_block[k + 1]) hash level k's rows
+    uint32_t col_off[8], n_cols[8];
+    uint64_t n_rows[8], out_off[8];   // out_off: word offset of the level's layer in the digest store
+};
+__global__ __launch_bounds__(256) void k_hash_rows_multi(const uint32_t* const* __restrict__ cols, RowHashLevels L, uint32_t* __restrict__ digests) {
+    uint32_t k = 0;
+    while (k + 1 < L.n_levels && blockIdx.x >= L.first_block[k + 1]) k++;   // (wave-uniform)
+    const uint32_t row = (blockIdx.x - L.first_block[k]) * blockDim.x + threadIdx.x;
+    if (row >= L.n_rows[k]) return;
+    uint32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = 0;
+    absorb_rows(s, cols + L.col_off[k], L.n_cols[k], row);
+    uint4* o = reinterpret_cast<uint4*>(digests + L.out_off[k] + (size_t)row * 8);
+    o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// next[i] = compress(compress(prev[2 i], prev[2 i + 1]), row digest parked in next[i]) -- the layer step of a level whose rows
+// k_hash_rows_multi has hashed
+__global__ __launch_bounds__(256) void k_compress_layer_inj2(const uint32_t* __restrict__ prev, uint32_t* __restrict__ next, size_t n_next) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_next) return;
+    uint32_t s[16];
+    const uint4* p = reinterpret_cast<const uint4*>(prev + i * 16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint4 v = p[q];
+        s[4 * q] = v.x, s[4 * q + 1] = v.y, s[4 * q + 2] = v.z, s[4 * q + 3] = v.w;
+    }
+    uint4* o = reinterpret_cast<uint4*>(next + i * 8);
+    const uint4 r0 = o[0], r1 = o[1];
+#pragma unroll 1
+    for (int step = 0; step < 2; step++) {
+        if (step == 1) s[8] = r0.x, s[9] = r0.y, s[10] = r0.z, s[11] = r0.w, s[12] = r1.x, s[13] = r1.y, s[14] = r1.z, s[15] = r1.w;
+        poseidon2_permute_rolled(s);
+    }
+    o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
 // One step of the same sponge over a block of columns, the 16-word state parked in HBM between steps ([16][rows]: a
 // lane's loads and stores are coalesced with its neighbours').  Lets the trace commit run as a pipeline: while the
 // sponge absorbs block k the LDE of block k+1 is computed on another stream.
@@ -336,10 +385,29 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
     const unsigned lh = t->log_height;
     const uint32_t* const* d_ptrs = (const uint32_t* const*)t->d_colptrs;
     size_t n = (size_t)1 << lh;
-    if (!leaves_ready) {
+    // the levels whose rows are hashed in bulk: the leaf level and every level with injected matrices above the cooperative form's size
+    const unsigned coop_inj_max_log = ctx->cfg.coop_inj_max_log;
+    std::vector<char> bulk(lh + 1, 0);
+    RowHashLevels L{};
+    auto add_level = [&](unsigned level) {
+        if (L.n_levels == 8) return;
+        const uint32_t k = L.n_levels++;
+        const size_t rows = (size_t)1 << level;
+        L.first_block[k + 1] = L.first_block[k] + (uint32_t)((rows + 255) / 256);
+        L.col_off[k] = (uint32_t)t->level_off[level], L.n_cols[k] = (uint32_t)t->level_cnt[level];
+        L.n_rows[k] = rows, L.out_off[k] = (uint64_t)t->layer_off[lh - level] * 8;
+        bulk[level] = 1;
+    };
+    if (!leaves_ready) add_level(lh);
+    for (unsigned level = lh; level-- > 0;)
+        if (t->level_cnt[level] && ((size_t)1 << level) > ((size_t)1 << coop_inj_max_log)) add_level(level);
+    if (L.n_levels == 1 && !leaves_ready) {
         KernelScope ks(ctx, "poseidon2_hash_rows");
         hipLaunchKernelGGL(k_hash_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                            d_ptrs + t->level_off[lh], (uint32_t)t->level_cnt[lh], n, t->d_digests);
+    } else if (L.n_levels) {
+        KernelScope ks(ctx, "poseidon2_hash_rows");
+        hipLaunchKernelGGL(k_hash_rows_multi, dim3(L.first_block[L.n_levels]), dim3(256), 0, ctx->stream, d_ptrs, L, t->d_digests);
     }
     // levels at which no shorter matrix is injected, counted from the root
     unsigned clean_top = 0;
@@ -360,6 +428,9 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
             hipLaunchKernelGGL(k_compress_layer_coop, dim3((unsigned)((cnt + 15) / 16)), dim3(256), 0, ctx->stream,
                                t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,
                                d_ptrs ? d_ptrs + t->level_off[level] : nullptr, (uint32_t)t->level_cnt[level]);
+        else if (t->level_cnt[level] && bulk[level])
+            hipLaunchKernelGGL(k_compress_layer_inj2, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                               t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt);
         else if (t->level_cnt[level])
             hipLaunchKernelGGL(k_compress_layer_inj, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
                                t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,
