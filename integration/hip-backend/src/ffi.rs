@@ -185,6 +185,7 @@ pub struct zkhip_config {
     pub grind_sweep_shift: u32,
     pub coop_max_log: u32,
     pub coop_inj_max_log: u32,
+    pub top_max_log: u32,
     pub commit_parts: u32,
     pub side_cus: u32,
     pub witness_threads: u32,

@@ -173,6 +173,7 @@ void zkhip_config_default(zkhip_config* c) {
     c->quot_slices = getenv("ZKHIP_NO_QUOT_SLICES") ? 0 : 1;
     c->grind_sweep_shift = num("ZKHIP_GRIND_SWEEP_SHIFT", 0u);
     c->coop_max_log = num("ZKHIP_COOP_MAX_LOG", 15u), c->coop_inj_max_log = num("ZKHIP_COOP_INJ_MAX_LOG", 15u);
+    c->top_max_log = num("ZKHIP_TOP_MAX_LOG", 6u);   // (measured 8 / 7 / 6 / 5 / 4 on the guest flow: 987 / 936 / 911 / 924 / 931 ms of segment proving with one lane)
     c->commit_parts = num("ZKHIP_COMMIT_PARTS", 0u), c->side_cus = num("ZKHIP_SIDE_CUS", 0u);
     c->witness_threads = num("ZKHIP_WITNESS_THREADS", 0u);
     c->pin_witness = getenv("ZKHIP_NO_PIN_WITNESS") ? 0 : 1;

@@ -415,7 +415,9 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
     for (unsigned l = 1; l <= lh; l++) {
         unsigned level = lh - l;
         size_t cnt = (size_t)1 << level;
-        if (cnt <= 256 && level < clean_top) {
+        // (the top of the tree in one workgroup: from 2^top_max_log nodes down; above that a layer is a launch of its own -- a layer of 256
+        // nodes is four sequential passes of the one workgroup, a permutation latency each)
+        if (cnt <= ((size_t)1 << std::min(ctx->cfg.top_max_log, 8u)) && level < clean_top) {
             // this and all remaining levels in one launch
             KernelScope ks(ctx, "poseidon2_compress_top");
             hipLaunchKernelGGL(k_compress_top, dim3(1), dim3(1024), 0, ctx->stream, t->d_digests, lh, l - 1);
