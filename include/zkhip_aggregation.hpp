@@ -974,9 +974,7 @@ private:
             }
             // the aggregation key: the internal verifying key + what a root must state beneath it
             internal.vk.leaf_commit = leaf_commit_;
-            internal.vk.app_digest.resize(8);
-            if (S > 1) internal.vk.app_digest = app_id;
-            else if (zkhip_recursion_child_vk_digest(leafs[0].circ, internal.vk.app_digest.data()) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: child vk digest");
+            internal.vk.app_digest = app_id;   // (one shape: what its leaf circuit states anyway -- the digest of the key it is built for)
             stats.build_seconds += std::chrono::duration<double>(t1 - t0).count();
             stats.keygen_seconds += std::chrono::duration<double>(clk::now() - t1).count();
         } catch (...) {

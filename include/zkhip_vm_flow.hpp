@@ -409,25 +409,22 @@ struct SegmentShapes {
         return caps.size() - 1;
     }
 };
-// How each shape's proofs enter the aggregation tree (AggregationProver::ShapePolicy), from the total width of its chips against the base
-// set's: the cost of verifying a segment proof in-circuit grows with the columns opened per query.  The base set: leaf nodes of 4 proofs.
-// A shape up to ~5.5 times as wide (the base chips + both hash intrinsics: ~5.2): leaf nodes of fewer proofs, so that its leaf circuit
-// keeps the common size.  Wider still (the full set of the reference's chunk circuit: ~11): one proof per leaf node of its own, large
-// circuit, which enters the tree through a wrapper of the common size.
-inline std::vector<scroll_zkvm_hip::AggregationProver::ShapePolicy> shape_policies(const std::vector<VerifyingKey>& shape_vks) {
-    auto width_of = [](const VerifyingKey& vk) {
+// How each shape's proofs enter the aggregation tree (AggregationProver::ShapePolicy).  The tree's circuits share ONE height set, and the
+// internal circuit (three node proofs at 100 queries) needs 2^21 gate rows whatever the app: a leaf circuit should fit that too.  The
+// cost of verifying a segment proof in-circuit grows with the columns opened per query -- measured on the 22 base chips (754 columns):
+// 0.63 M gate rows per child, i.e. ~835 per column (leaf arity 4: 2.51 M = 2^22, every node of the tree twice as large; arity 3:
+// 1.89 M = 2^21).  So a shape takes as many proofs per leaf node as fit 2^21 gate rows (at most the tree's leaf arity); a shape of which
+// not even one proof fits (base + the hash intrinsics: 3.9 k columns; the reference's full chunk-circuit set: 8 k) keeps a leaf
+// circuit of its own, natural size, one proof per node, and enters the tree through a wrapper of the common size.
+inline std::vector<scroll_zkvm_hip::AggregationProver::ShapePolicy> shape_policies(const std::vector<VerifyingKey>& shape_vks, unsigned max_arity = 4) {
+    std::vector<scroll_zkvm_hip::AggregationProver::ShapePolicy> out;
+    for (const VerifyingKey& vk : shape_vks) {
         size_t w = 0;
         for (const auto& a : vk.airs) w += a.width;
-        return (double)w;
-    };
-    std::vector<scroll_zkvm_hip::AggregationProver::ShapePolicy> out;
-    const double base = width_of(shape_vks.front());
-    for (size_t sh = 0; sh < shape_vks.size(); sh++) {
+        const double per_child = 835.0 * (double)w, room = 0.95 * (double)(1u << 21);
         scroll_zkvm_hip::AggregationProver::ShapePolicy p;
-        const double r = width_of(shape_vks[sh]) / base;
-        if (sh == 0 || shape_vks.size() == 1) p.arity = 0;
-        else if (r <= 5.5) p.arity = std::max(1u, (unsigned)(4.4 / r));
-        else p.arity = 1, p.wrapped = true;
+        p.arity = (unsigned)std::min<double>(max_arity, room / per_child);
+        if (p.arity == 0) p.arity = 1, p.wrapped = true;
         out.push_back(p);
     }
     return out;
