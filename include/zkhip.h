@@ -493,6 +493,9 @@ int zkhip_poseidon2_permute_host(uint32_t state[16]);
 /* the same permutation through the host's AVX-512 form (zkvm-prover_amd/csrc/poseidon2_avx512.cpp: what the prover's transcript uses for
  * long absorptions); returns 1 -- state untouched -- on a CPU without AVX-512 */
 int zkhip_poseidon2_permute_host_avx512(uint32_t state[16]);
+/* sixteen independent permutations side by side (states[16 k + w] = word w of state k): one state word of all sixteen per 512-bit
+ * register where the CPU has AVX-512 (what the aggregation witness generator advances its queries with), else sixteen scalar calls */
+int zkhip_poseidon2_permute16_host(uint32_t states[256]);
 int zkhip_mmcs_verify(const uint32_t root[8], const unsigned *log_heights, const size_t *widths, size_t n_mats,
                       uint64_t index, const uint32_t *opening);
 int zkhip_fri_fold_row(uint64_t index, unsigned log_height, const uint32_t beta[4], const uint32_t e0[4],

@@ -340,6 +340,7 @@ extern "C" {
 
     // the verifier's primitives on the host (no device)
     pub fn zkhip_poseidon2_permute_host(state: *mut u32) -> c_int;
+    pub fn zkhip_poseidon2_permute16_host(states: *mut u32) -> c_int;
     pub fn zkhip_poseidon2_permute_host_avx512(state: *mut u32) -> c_int;
     pub fn zkhip_mmcs_verify(root: *const u32, log_heights: *const c_uint, widths: *const usize, n_mats: usize, index: u64,
                              opening: *const u32) -> c_int;

@@ -30,3 +30,33 @@ def test_avx512_permutation_equals_scalar_and_oracle(ora):
     for _ in range(200):
         s, t = z.poseidon2_permute_host_avx512(s), z.poseidon2_permute_host(t)
     assert (s == t).all()
+
+
+def test_sixteen_permutations_side_by_side():
+    """zkhip_poseidon2_permute16_host (one state word of sixteen independent states per 512-bit register: what the aggregation witness
+    generator advances its queries with) == sixteen calls of the scalar permutation, bit for bit."""
+    import ctypes as C
+
+    import numpy as np
+
+    import zkvm_prover_amd as z
+    from zkvm_prover_amd import _binding as zb
+
+    lib = z.load_library()
+    lib.zkhip_poseidon2_permute16_host.argtypes = [C.POINTER(C.c_uint32)]
+    rng = np.random.default_rng(16)
+    for trial in range(20):
+        st = rng.integers(0, z.P, 256, dtype=np.uint64).astype(np.uint32)
+        if trial == 0:
+            st[:] = 0
+        if trial == 1:
+            st[:] = z.P - 1
+        got = st.copy()
+        assert lib.zkhip_poseidon2_permute16_host(zb._u32p(got)) == 0
+        for k in range(16):
+            s = st[16 * k:16 * k + 16].copy()
+            assert lib.zkhip_poseidon2_permute_host(zb._u32p(s)) == 0
+            assert (s == got[16 * k:16 * k + 16]).all(), (trial, k)
+    bad = np.zeros(256, np.uint32)
+    bad[77] = z.P
+    assert lib.zkhip_poseidon2_permute16_host(zb._u32p(bad)) != 0

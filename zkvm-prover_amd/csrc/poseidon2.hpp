@@ -151,6 +151,18 @@ ZK_HD void poseidon2_permute(uint32_t s[16]) {
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__) && !defined(ZK_NO_HOST_AVX512)
 #define ZK_HAVE_HOST_AVX512 1
 void poseidon2_permute_avx512(uint32_t s[16]);
+void poseidon2_permute16_avx512(uint32_t* t);   // sixteen independent permutations: t[16 w + k] = word w of instance k
+// sixteen states side by side (transposed): the vector form where the CPU has it, else sixteen scalar permutations
+inline void poseidon2_permute16_host(uint32_t* t) {
+    static const bool fast = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq");
+    if (fast) return poseidon2_permute16_avx512(t);
+    for (int k = 0; k < 16; k++) {
+        uint32_t s[16];
+        for (int w = 0; w < 16; w++) s[w] = t[16 * w + k];
+        poseidon2_permute(s);
+        for (int w = 0; w < 16; w++) t[16 * w + k] = s[w];
+    }
+}
 inline void poseidon2_permute_host(uint32_t s[16]) {
     static const bool fast = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq");
     if (fast) poseidon2_permute_avx512(s);
@@ -158,6 +170,14 @@ inline void poseidon2_permute_host(uint32_t s[16]) {
 }
 #else
 inline void poseidon2_permute_host(uint32_t s[16]) { poseidon2_permute(s); }
+inline void poseidon2_permute16_host(uint32_t* t) {
+    for (int k = 0; k < 16; k++) {
+        uint32_t s[16];
+        for (int w = 0; w < 16; w++) s[w] = t[16 * w + k];
+        poseidon2_permute(s);
+        for (int w = 0; w < 16; w++) t[16 * w + k] = s[w];
+    }
+}
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ZK_P2_PERMUTE_HERE(s) poseidon2_permute(s)

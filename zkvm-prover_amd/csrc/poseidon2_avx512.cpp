@@ -76,7 +76,77 @@ const Tables& tables() {
     return t;
 }
 
+// SIXTEEN independent permutations, one per lane: t[16 w + k] = word w of instance k (the states transposed), every register holds one
+// state word of all sixteen instances, every operation is lane-wise -- no shuffles, and sixteen results for roughly the instructions of
+// two single permutations.  The aggregation witness generator replays a hundred Merkle / FRI queries per child, each a chain of
+// permutations of its own: it advances sixteen queries side by side (csrc/recursion.hip).  Same field arithmetic, canonical lanes:
+// bit-identical to sixteen calls of the scalar code.
+struct Tables16 {
+    __m512i rc[141];     // every round constant broadcast
+    __m512i diag[16];    // the internal layer's diagonal, broadcast
+};
+const Tables16& tables16() {
+    static const Tables16 t = [] {
+        Tables16 x;
+        for (int i = 0; i < 141; i++) x.rc[i] = _mm512_set1_epi32((int)Poseidon2Consts::RC[i]);
+        const uint32_t one = MONTY_ONE, two = madd(one, one), half = minv(two);
+        auto pw = [&](uint32_t base, unsigned k) {
+            uint32_t r = one;
+            for (unsigned i = 0; i < k; i++) r = mmul(r, base);
+            return r;
+        };
+        const uint32_t d[16] = {mneg(two), one, two, half, madd(two, one), madd(two, two), mneg(half), mneg(madd(two, one)), mneg(madd(two, two)), pw(half, 8),
+                                pw(half, 2), pw(half, 3), pw(half, 27), mneg(pw(half, 8)), mneg(pw(half, 4)), mneg(pw(half, 27))};
+        for (int i = 0; i < 16; i++) x.diag[i] = _mm512_set1_epi32((int)d[i]);
+        return x;
+    }();
+    return t;
+}
+inline __m512i vsbox7(__m512i x, __m512i rc, __m512i vp, __m512i vmu) {
+    x = vadd(x, rc, vp);
+    const __m512i x2 = vmul(x, x, vp, vmu), x3 = vmul(x2, x, vp, vmu), x4 = vmul(x2, x2, vp, vmu);
+    return vmul(x3, x4, vp, vmu);
+}
+inline void external_linear16(__m512i (&s)[16], __m512i vp) {
+    for (int b = 0; b < 16; b += 4) {   // M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] on each 4-block (poseidon2.hpp p2_external_linear)
+        const __m512i x0 = s[b], x1 = s[b + 1], x2 = s[b + 2], x3 = s[b + 3];
+        const __m512i t01 = vadd(x0, x1, vp), t23 = vadd(x2, x3, vp), t0123 = vadd(t01, t23, vp);
+        const __m512i t01123 = vadd(t0123, x1, vp), t01233 = vadd(t0123, x3, vp);
+        s[b + 3] = vadd(vadd(t01233, x0, vp), x0, vp);
+        s[b + 1] = vadd(vadd(t01123, x2, vp), x2, vp);
+        s[b + 0] = vadd(t01123, t01, vp);
+        s[b + 2] = vadd(t01233, t23, vp);
+    }
+    for (int k = 0; k < 4; k++) {
+        const __m512i sum = vadd(vadd(s[k], s[4 + k], vp), vadd(s[8 + k], s[12 + k], vp), vp);
+        for (int b = 0; b < 16; b += 4) s[b + k] = vadd(s[b + k], sum, vp);
+    }
+}
+
 }  // namespace
+
+void poseidon2_permute16_avx512(uint32_t* t) {
+    const Tables16& T = tables16();
+    const __m512i vp = _mm512_set1_epi32((int)P), vmu = _mm512_set1_epi32((int)MONTY_MU);
+    __m512i s[16];
+    for (int i = 0; i < 16; i++) s[i] = _mm512_loadu_si512(t + 16 * i);
+    external_linear16(s, vp);
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 16; i++) s[i] = vsbox7(s[i], T.rc[r * 16 + i], vp, vmu);
+        external_linear16(s, vp);
+    }
+    for (int r = 0; r < 13; r++) {
+        s[0] = vsbox7(s[0], T.rc[64 + r], vp, vmu);
+        __m512i sum = vadd(vadd(vadd(s[0], s[1], vp), vadd(s[2], s[3], vp), vp), vadd(vadd(s[4], s[5], vp), vadd(s[6], s[7], vp), vp), vp);
+        sum = vadd(sum, vadd(vadd(vadd(s[8], s[9], vp), vadd(s[10], s[11], vp), vp), vadd(vadd(s[12], s[13], vp), vadd(s[14], s[15], vp), vp), vp), vp);
+        for (int i = 0; i < 16; i++) s[i] = vadd(vmul(s[i], T.diag[i], vp, vmu), sum, vp);
+    }
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 16; i++) s[i] = vsbox7(s[i], T.rc[77 + r * 16 + i], vp, vmu);
+        external_linear16(s, vp);
+    }
+    for (int i = 0; i < 16; i++) _mm512_storeu_si512(t + 16 * i, s[i]);
+}
 
 // s: 16 Montgomery words in [0, p), 64-byte alignment not required
 void poseidon2_permute_avx512(uint32_t s[16]) {

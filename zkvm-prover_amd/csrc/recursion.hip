@@ -1880,6 +1880,43 @@ int recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const si
         }
         return first_bad;
     };
+    // SIXTEEN query parts side by side: each part is advanced to its next permutation (gates are evaluated on the way), the sixteen
+    // pending states are permuted in ONE call -- a state word of all sixteen per 512-bit register (poseidon2_permute16_host) -- and
+    // scattered back.  The parts are independent (query_parallel) and built by the same code, so they stay in step; one that ends
+    // early rides along with a zero state.  Most of a node's ~170 k permutations are in the query parts.
+    auto run16 = [&](const size_t (*ranges)[2], size_t n_parts, long* bad_out) {
+        size_t pos[16];
+        for (size_t k = 0; k < 16; k++) pos[k] = k < n_parts ? ranges[k][0] : 0;
+        alignas(64) uint32_t t[256];
+        const Perm* pend[16];
+        for (;;) {
+            size_t n_pending = 0;
+            for (size_t k = 0; k < 16; k++) {
+                pend[k] = nullptr;
+                if (k >= n_parts) continue;
+                // gates up to the part's next permutation
+                size_t q = pos[k];
+                const size_t hi = ranges[k][1];
+                while (q < hi && !c.order[q].is_perm) q++;
+                if (q > pos[k]) {
+                    const long b = run(pos[k], q, true);
+                    if (b >= 0 && (bad_out[k] < 0 || b < bad_out[k])) bad_out[k] = b;
+                }
+                pos[k] = q;
+                if (q < hi) pend[k] = &c.perms[c.order[q].idx], n_pending++;
+            }
+            if (!n_pending) return;
+            for (size_t k = 0; k < 16; k++)
+                for (int j = 0; j < 4; j++)
+                    for (int w = 0; w < 4; w++) t[16 * (4 * j + w) + k] = pend[k] ? vals[pend[k]->in[j]].c[w] : 0u;
+            poseidon2_permute16_host(t);
+            for (size_t k = 0; k < 16; k++) {
+                if (!pend[k]) continue;
+                for (int j = 0; j < 4; j++) vals[pend[k]->out[j]] = Ext{{t[16 * (4 * j) + k], t[16 * (4 * j + 1) + k], t[16 * (4 * j + 2) + k], t[16 * (4 * j + 3) + k]}};
+                pos[k]++;
+            }
+        }
+    };
     // constant rows first (a constant's row sits in whichever section used it first), then one thread per child section,
     // then the statement logic behind them
     for (const Gate& G : c.gates)
@@ -1927,14 +1964,19 @@ int recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const si
             // (all cores: measured in the one-flow pipeline with 4 / 8 / 16 threads on 16 cores -- the segment phase loses ~40 ms to the
             // contention, the tree's tail gains ~100 ms; ZKHIP_WITNESS_THREADS overrides)
             const unsigned cap = process_config().witness_threads ? process_config().witness_threads : std::thread::hardware_concurrency();
-            const size_t n_threads = std::min<size_t>(tasks.size(), std::max(1u, cap));
+            const size_t n_threads = std::min<size_t>((tasks.size() + 15) / 16, std::max(1u, cap));
             std::atomic<size_t> next{0};
             std::vector<std::vector<long>> tb(n_threads, std::vector<long>(n_sec, -1));
             std::vector<std::thread> th;
             auto worker = [&](size_t t) {
-                for (size_t k; (k = next.fetch_add(1)) < tasks.size();) {
-                    const size_t i = tasks[k].first, q = tasks[k].second;
-                    keep_first(tb[t][i], run(c.sub[i][q], c.sub[i][q + 1], true));
+                // bundles of sixteen query parts from the shared counter, advanced side by side
+                for (size_t k0; (k0 = next.fetch_add(16)) < tasks.size();) {
+                    const size_t n = std::min<size_t>(16, tasks.size() - k0);
+                    size_t ranges[16][2];
+                    long bad16[16];
+                    for (size_t k = 0; k < n; k++) ranges[k][0] = c.sub[tasks[k0 + k].first][tasks[k0 + k].second], ranges[k][1] = c.sub[tasks[k0 + k].first][tasks[k0 + k].second + 1], bad16[k] = -1;
+                    run16(ranges, n, bad16);
+                    for (size_t k = 0; k < n; k++) keep_first(tb[t][tasks[k0 + k].first], bad16[k]);
                 }
             };
             for (size_t t = 1; t < n_threads; t++)

@@ -141,6 +141,21 @@ extern "C" int zkhip_poseidon2_permute_host_avx512(uint32_t state[16]) {
 #endif
 }
 
+// sixteen independent permutations at once (the aggregation witness generator's form): states[16 k + w] = word w of state k, canonical
+extern "C" int zkhip_poseidon2_permute16_host(uint32_t states[256]) {
+    if (!states) return ZKHIP_ERR_INVALID;
+    uint32_t t[256];
+    for (int k = 0; k < 16; k++)
+        for (int w = 0; w < 16; w++) {
+            if (states[16 * k + w] >= P) return ZKHIP_ERR_INVALID;
+            t[16 * w + k] = to_monty(states[16 * k + w]);
+        }
+    poseidon2_permute16_host(t);
+    for (int k = 0; k < 16; k++)
+        for (int w = 0; w < 16; w++) states[16 * k + w] = from_monty(t[16 * w + k]);
+    return ZKHIP_OK;
+}
+
 extern "C" int zkhip_mmcs_verify(const uint32_t root[8], const unsigned* log_heights, const size_t* widths, size_t n_mats,
                                  uint64_t index, const uint32_t* opening) {
     if (!root || !log_heights || !widths || !opening || n_mats == 0) return ZKHIP_ERR_INVALID;
