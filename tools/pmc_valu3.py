@@ -71,7 +71,13 @@ def main():
             if "measured_cycles_per_wave_instr_per_simd" in e:
                 e["issue_efficiency_at_measured_clock"] = round(m["cycles_per_wave_instruction_model"] / e["measured_cycles_per_wave_instr_per_simd"], 4)
         kernels[k] = e
-    json.dump({"source": "tools/pmc_valu3.py over separate rocprofv3 --pmc passes of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "
+    # the whole proof against the same absolute floor: every kernel's VALU wave-instructions priced at the row hash's model cycles
+    total_instr = sum(e["launches_per_proof"] * e["valu_wave_instr_per_launch"] for e in kernels.values())
+    cpi = next((e["isa_mix"]["cycles_per_wave_instruction_model"] for e in kernels.values() if "isa_mix" in e), None)
+    totals = {"total_valu_wave_instr_per_proof": round(total_instr)}
+    if cpi:
+        totals["total_valu_roofline_ms_per_proof"] = round(total_instr * cpi / (SIMDS * CLOCK_HZ) * 1e3, 3)
+    json.dump({**totals, "source": "tools/pmc_valu3.py over separate rocprofv3 --pmc passes of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "
                          "--inflight 1` (%d proofs per run)" % n_proofs,
                "peak": {"simds": SIMDS, "clock_hz": CLOCK_HZ},
                "note": "valu_roofline_ms_per_launch = SQ_INSTS_VALU x (4.2 cycles for the multiply-class share + 2.2 for the rest; shares from the "
