@@ -426,7 +426,7 @@ def main():
                 # HBM traffic of this kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
                 # corrected as MI355X_MICROARCH.md prescribes; bench.py cannot collect counters itself)
                 try:
-                    pmc_file = next(n for n in ("round03_pmc_traffic.json", "round02_pmc_traffic.json", "round01_pmc_traffic.json")
+                    pmc_file = next(n for n in ("round04_pmc_traffic.json", "round03_pmc_traffic.json", "round02_pmc_traffic.json", "round01_pmc_traffic.json")
                                     if os.path.exists(os.path.join(ROOT, "profiles", n)))
                     with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                         pmc = json.load(f)["kernels"]
@@ -443,12 +443,12 @@ def main():
                     roof["valu"] = {"perms_per_s": round(rate, 0),
                                     "note": "the kernel is integer-VALU bound (~570 Montgomery products and ~1300 modular add/sub per "
                                             "permutation, 6.1k VALU instructions), not HBM bound; frac above is vs HBM as BASELINE asks"}
-                    # ABSOLUTE VALU roofline from the committed counter pass (profiles/round03_pmc_valu.json, tools/pmc_valu3.py):
+                    # ABSOLUTE VALU roofline from the committed counter pass (profiles/round04_pmc_valu.json, tools/pmc_valu3.py):
                     # SQ_INSTS_VALU per launch x cycles per wave-instruction of the kernel's ISA mix (tools/isa_mix.py: multiply-class
                     # share x 4.2 + the rest x 2.2 cycles, costs measured by tools/ubench_valu.hip) / (1024 SIMDs x 2.4 GHz), against
                     # THIS run's HIP-event time per launch -- no rate of the kernel itself enters the floor
                     try:
-                        with open(os.path.join(ROOT, "profiles", "round03_pmc_valu.json")) as f:
+                        with open(os.path.join(ROOT, "profiles", "round04_pmc_valu.json")) as f:
                             pv3 = json.load(f)
                         kv = pv3["kernels"]["zk::k_hash_rows"]
                         if log_n == 22 and width == 300:
@@ -462,7 +462,7 @@ def main():
                                 "frac_of_valu_peak": round(kv["valu_roofline_ms_per_launch"] / ms_launch, 4),
                                 "clock_ghz_under_pmc": kv.get("clock_ghz_from_grbm_gui_active"),
                                 "issue_efficiency_at_measured_clock_under_pmc": kv.get("issue_efficiency_at_measured_clock"),
-                                "source": "profiles/round03_pmc_valu.json + profiles/round03_isa_mix_hash_rows.json"})
+                                "source": "profiles/round04_pmc_valu.json + profiles/round03_isa_mix_hash_rows.json (the kernel's code did not change)"})
                     except Exception:
                         pass
         # the memory-side kernels against the same HBM peak (algorithmic bytes / measured time)
