@@ -16,9 +16,11 @@
 // every proof it returns).  AggregationTreeConfig::one_key = false keeps round 3's per-depth keys (level l hard-wires level l - 1).
 #pragma once
 #include <chrono>
+#include <cstdio>
 #include <condition_variable>
 #include <deque>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <thread>
 
@@ -304,8 +306,10 @@ public:
     // "execution" of a node: runs the verifier circuit on the children (host; one thread per child inside the library) and
     // returns the node's public values.  Throws if a child does not verify or the states do not chain.
     // `shape` (level 0): which shape's segment proofs the node takes; `kid_shapes` (level 1): the shape of each leaf child (default 0)
+    // `kinds` (one key, level > 0; optional): per child 0 = a proof of the internal circuit, j + 1 = a proof of leaf circuit j -- the
+    // internal circuit takes any mix, which is what lets the tree take ANY shape (TreeStream's greedy fold)
     std::vector<uint32_t> witness_node(size_t level, const std::vector<const ChildProof*>& kids, size_t shape = 0, const std::vector<size_t>* kid_shapes = nullptr,
-                                       size_t slot = 0) {
+                                       size_t slot = 0, const std::vector<int>* kinds_in = nullptr) {
         ensure_level(level);
         Replica& L = lv(level, shape).rep.at(slot);
         if (kids.empty() || kids.size() > arity(level, shape)) throw Error(Error::GenProof, "aggregation: a node of level " + std::to_string(level) + " takes 1.." + std::to_string(arity(level, shape)) + " children");
@@ -330,9 +334,11 @@ public:
             std::vector<uint32_t> pc;
             std::vector<int> kinds(kids.size(), 0);
             for (size_t c = 0; c < kids.size(); c++) {
-                const size_t ks = level == 1 && kid_shapes ? kid_shapes->at(c) : 0;
-                if (level == 1) kinds[c] = (int)ks + 1;   // (0 = a proof of the internal circuit, j + 1 = of leaf circuit j)
-                const VerifyingKey& kvk = level == 1 ? lv(0, ks).vk : cvk;
+                const size_t ks = level == 1 && kid_shapes && !kinds_in ? kid_shapes->at(c) : 0;
+                if (kinds_in) kinds[c] = kinds_in->at(c);
+                else if (level == 1) kinds[c] = (int)ks + 1;   // (0 = a proof of the internal circuit, j + 1 = of leaf circuit j)
+                if (kinds[c] < 0 || (size_t)kinds[c] > leafs_.size()) throw Error(Error::GenProof, "aggregation: unknown kind of child");
+                const VerifyingKey& kvk = kinds[c] ? lv(0, (size_t)kinds[c] - 1).vk : lv(1).vk;
                 for (const auto& a : kvk.airs) pc.insert(pc.end(), a.prep_commit.begin(), a.prep_commit.end());
             }
             rc = zkhip_recursion_witness_uniform(L.circ, proofs.data(), lens.data(), pv_ptrs.data(), pc.data(), kinds.data(), leaf_list_.data(),
@@ -399,9 +405,21 @@ public:
     // lanes keep proving on contexts of their own); every node proof is self-verified on a thread of its own.
     class TreeStream {
     public:
-        explicit TreeStream(AggregationProver& agg) : agg_(agg) {
+        // `greedy` (one key only): above the leaf nodes the tree has no fixed shape -- whenever `arity` ADJACENT node proofs exist (leaf or
+        // internal, any mix) they are folded, leftmost first.  Every fold but the last takes a full set of children, so the number of
+        // internal nodes is the balanced tree's; but when the nodes keep up with the segments the result is a comb -- root = (everything
+        // before, the last two leaf nodes) -- and what is left once the last segment proof exists is ONE leaf node and the root instead of
+        // one node per level; when they do not keep up, waiting proofs fold among themselves and the shape drifts to the balanced one.
+        explicit TreeStream(AggregationProver& agg, bool greedy = false) : agg_(agg), greedy_(greedy && agg.one_key()), fold_(agg.arity(1)) {
             layers_.emplace_back();
             start_level(0);
+            if (greedy_) {
+                std::lock_guard<std::mutex> lk(mu_);
+                while (layers_.size() <= 3) layers_.emplace_back();
+                layers_[1].started = true;
+                for (size_t level : {1, 2})   // two internal-circuit workers per device slot (the forks the levels of a fixed tree use)
+                    for (size_t slot = 0; slot < agg_.n_slots(); slot++) start_pair_locked(level, slot);
+            }
         }
         TreeStream(const TreeStream&) = delete;
         TreeStream& operator=(const TreeStream&) = delete;
@@ -413,7 +431,14 @@ public:
             cv_.notify_all();
             join_all();
         }
+        bool trace = false;   // a line per event on stderr: milliseconds since the stream was made (FlowOptions::trace_tree)
+        void note(const char* what, size_t level, size_t k, size_t slot, size_t n_kids = 0) const {
+            if (!trace) return;
+            std::fprintf(stderr, "[tree %8.2f ms] %-14s level %zu node %zu slot %zu kids %zu\n",
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_made_).count(), what, level, k, slot, n_kids);
+        }
         void push(size_t index, ChildProof seg, size_t shape = 0) {
+            note("segment", 0, index, 0);
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 if (seg_shape_.size() <= index) seg_shape_.resize(index + 1, 0);
@@ -428,8 +453,10 @@ public:
             layers_[0].total = n_segments;
             cv_.notify_all();
             size_t root_layer = 0;
+            if (greedy_) greedy_schedule_locked();
             cv_.wait(lk, [&] {
                 if (!err_.empty()) return true;
+                if (greedy_) return groot_ != nullptr;
                 for (size_t i = agg_.first_root_layer(); i < layers_.size(); i++)
                     if (layers_[i].total == 1 && !layers_[i].items.empty() && layers_[i].items[0]) {
                         root_layer = i;
@@ -450,6 +477,14 @@ public:
             cv_.notify_all();
             join_all();   // the self-verification of the last nodes
             if (!err_.empty()) throw Error(Error::VerifyProof, err_);
+            if (greedy_) {   // all[0]: the leaf nodes in order; all[1]: the internal nodes in the order they were formed, the root last
+                if (all) {
+                    all->assign(2, {});
+                    for (const ChildProof* q : gleaves_) (*all)[0].push_back(*q);
+                    for (const ChildProof* q : ginternal_) (*all)[1].push_back(*q);
+                }
+                return *groot_;
+            }
             if (all)
                 for (size_t i = 1; i <= root_layer; i++) {
                     all->emplace_back();
@@ -458,6 +493,7 @@ public:
             return *layers_[root_layer].items[0];
         }
         size_t levels() const {
+            if (greedy_) return 1 + fold_.root_depth();
             size_t n = 0;
             for (size_t i = 1; i < layers_.size(); i++) n += !layers_[i].items.empty();
             return n;
@@ -468,6 +504,8 @@ public:
             size_t k = 0, shape = 0;
             std::vector<const ChildProof*> kids;
             std::vector<size_t> kid_shapes;
+            std::vector<int> kinds;         // greedy fold: per child 0 internal, j + 1 leaf circuit j
+            FoldLine::Fold fold;            // greedy fold: what FoldLine handed out
         };
         struct Layer {
             std::deque<std::unique_ptr<ChildProof>> items;   // layer 0 = segment proofs, layer l + 1 = node proofs of level l
@@ -477,6 +515,7 @@ public:
             bool tasks_closed = false;
         };
         AggregationProver& agg_;
+        const std::chrono::steady_clock::time_point t_made_ = std::chrono::steady_clock::now();
         std::mutex mu_;
         std::condition_variable cv_;
         std::deque<Layer> layers_;
@@ -485,6 +524,41 @@ public:
         std::vector<std::thread> threads_, verifiers_;
         std::string err_;
         bool stop_ = false;
+        // greedy fold (see the constructor; the decisions are FoldLine's, include/zkhip_prover.hpp)
+        const bool greedy_;
+        FoldLine fold_;
+        std::deque<Task> gq_;                                // folds waiting for a free internal worker
+        std::deque<std::unique_ptr<ChildProof>> gstore_;     // the internal nodes' proofs (stable addresses)
+        std::vector<const ChildProof*> gleaves_, ginternal_;
+        size_t gnext_id_ = 0;
+        bool gq_closed_ = false;
+        const ChildProof* groot_ = nullptr;
+
+        // mu_ held: queues every fold that can start now; notices the root
+        void greedy_schedule_locked() {
+            if (stop_ || !err_.empty() || groot_) return;
+            if (layers_[1].total != SIZE_MAX) fold_.set_total(layers_[1].total);   // the number of leaf nodes once known
+            FoldLine::Fold f;
+            while (fold_.next(&f)) {
+                Task t;
+                t.k = gnext_id_++, t.kinds = f.kinds;
+                for (const void* k : f.kids) t.kids.push_back((const ChildProof*)k);
+                t.fold = std::move(f);
+                gq_.push_back(std::move(t));
+            }
+            if (fold_.root()) groot_ = (const ChildProof*)fold_.root(), gq_closed_ = true;
+            cv_.notify_all();
+        }
+        // a fold's proof exists
+        const ChildProof* greedy_done(const Task& t, ChildProof p) {
+            std::lock_guard<std::mutex> lk(mu_);
+            gstore_.emplace_back(new ChildProof(std::move(p)));
+            const ChildProof* made = gstore_.back().get();
+            ginternal_.push_back(made);
+            fold_.done(t.fold, made);
+            greedy_schedule_locked();
+            return made;
+        }
 
         void join_all() {
             for (;;) {   // threads may start further threads until stop_ is seen
@@ -511,7 +585,15 @@ public:
             Layer& L = layers_[layer];
             if (L.items.size() <= index) L.items.resize(index + 1);
             L.items[index].reset(new ChildProof(std::move(p)));
-            if (layer > 0 && !L.started && !stop_) start_level_locked(layer);
+            if (greedy_ && layer == 1) {   // a leaf node's proof: a piece of the line
+                const ChildProof* made = L.items[index].get();
+                fold_.add(index, index + 1, (int)(index < leaf_shape_.size() ? leaf_shape_[index] : 0) + 1, 0, made);
+                if (gleaves_.size() <= index) gleaves_.resize(index + 1, nullptr);
+                gleaves_[index] = made;
+                greedy_schedule_locked();
+            } else if (layer > 0 && !L.started && !stop_) {
+                start_level_locked(layer);
+            }
             cv_.notify_all();
         }
         void start_level(size_t level) {
@@ -553,6 +635,7 @@ public:
                         if (end) layers_[level + 1].total = (level >= agg_.first_root_layer() && layers_[level].total == 1) ? 0 : k;
                         if (end || stop_ || !err_.empty()) {
                             layers_[level].tasks_closed = true;
+                            if (greedy_ && level == 0 && end) greedy_schedule_locked();   // (the number of leaf nodes is known now)
                             cv_.notify_all();
                             break;
                         }
@@ -588,6 +671,7 @@ public:
                 bool witness_ready = false, buffer_free = true, done = false;
                 size_t node = 0, shape = 0;
                 std::vector<uint32_t> npv;
+                Task task;
             };
             auto sh = std::make_shared<Shared>();
             // witness thread of the slot: the next queued node, once the slot's witness buffer of that circuit is free
@@ -597,10 +681,12 @@ public:
                         Task t;
                         {
                             std::unique_lock<std::mutex> lk(mu_);
-                            cv_.wait(lk, [&] { return stop_ || !err_.empty() || !layers_[level].tasks.empty() || layers_[level].tasks_closed; });
-                            if (stop_ || !err_.empty() || layers_[level].tasks.empty()) break;
-                            t = std::move(layers_[level].tasks.front());
-                            layers_[level].tasks.pop_front();
+                            const bool fold = greedy_ && level >= 1;
+                            std::deque<Task>& q = fold ? gq_ : layers_[level].tasks;
+                            cv_.wait(lk, [&] { return stop_ || !err_.empty() || !q.empty() || (fold ? gq_closed_ : layers_[level].tasks_closed); });
+                            if (stop_ || !err_.empty() || q.empty()) break;
+                            t = std::move(q.front());
+                            q.pop_front();
                         }
                         {
                             std::unique_lock<std::mutex> lk(sh->m);
@@ -619,14 +705,16 @@ public:
                             continue;
                         }
                         const auto t0 = std::chrono::steady_clock::now();
-                        std::vector<uint32_t> npv = agg_.witness_node(level, t.kids, t.shape, &t.kid_shapes, slot);
+                        note("witness starts", level, t.k, slot, t.kids.size());
+                        std::vector<uint32_t> npv = agg_.witness_node(level, t.kids, t.shape, &t.kid_shapes, slot, t.kinds.empty() ? nullptr : &t.kinds);
+                        note("witness done", level, t.k, slot, t.kids.size());
                         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                         {
                             std::lock_guard<std::mutex> lk(mu_);
                             agg_.stats.witness_seconds += dt;
                         }
                         std::lock_guard<std::mutex> lk(sh->m);
-                        sh->npv = std::move(npv), sh->node = t.k, sh->shape = t.shape, sh->witness_ready = true, sh->buffer_free = false;
+                        sh->npv = std::move(npv), sh->node = t.k, sh->shape = t.shape, sh->task = std::move(t), sh->witness_ready = true, sh->buffer_free = false;
                         sh->c.notify_all();
                     }
                 } catch (const std::exception& e) {
@@ -642,17 +730,21 @@ public:
                     for (;;) {
                         std::vector<uint32_t> npv;
                         size_t k, shape;
+                        Task task;
                         {
                             std::unique_lock<std::mutex> lk(sh->m);
                             sh->c.wait(lk, [&] { return sh->witness_ready || sh->done; });
                             if (!sh->witness_ready) return;
-                            npv = std::move(sh->npv), k = sh->node, shape = sh->shape, sh->witness_ready = false;
+                            npv = std::move(sh->npv), k = sh->node, shape = sh->shape, task = std::move(sh->task), sh->witness_ready = false;
                         }
                         const auto t = std::chrono::steady_clock::now();
                         ChildProof out;
+                        note("device waits", level, k, slot);
                         {
                             std::lock_guard<std::mutex> dev(agg_.slot_mutex(slot));
+                            note("device starts", level, k, slot);
                             agg_.upload_witness(level, shape, slot);
+                            note("traces done", level, k, slot);
                             {
                                 std::lock_guard<std::mutex> lk(sh->m);
                                 sh->buffer_free = true;
@@ -667,9 +759,12 @@ public:
                             if (agg_.stats.nodes_per_slot.size() <= slot) agg_.stats.nodes_per_slot.resize(slot + 1, 0);
                             agg_.stats.nodes_per_slot[slot]++;
                         }
-                        put(level + 1, k, std::move(out));
+                        note("proof done", level, k, slot);
+                        const ChildProof* folded = nullptr;
+                        if (greedy_ && level >= 1) folded = greedy_done(task, std::move(out));
+                        else put(level + 1, k, std::move(out));
                         std::lock_guard<std::mutex> lk(mu_);
-                        const ChildProof* made = layers_[level + 1].items[k].get();
+                        const ChildProof* made = folded ? folded : layers_[level + 1].items[k].get();
                         verifiers_.emplace_back([this, level, k, made, shape] {
                             const auto tv = std::chrono::steady_clock::now();
                             const bool ok = agg_.level_vk(level, shape).verify(*made);

@@ -221,6 +221,13 @@ struct FlowOptions {
     bool one_shape = false;           // every segment under the app's full chip set instead of the smallest shape      [ZKHIP_ONE_SHAPE=1]
     bool agg_nodes_100bit = false;    // node proofs under blow-up 4 / 44 queries instead of the app's parameters         [ZKHIP_AGG_100BIT=1]
     bool per_depth_keys = false;      // round 3's aggregation keys (one per tree depth) instead of ONE key               [ZKHIP_AGG_PER_DEPTH_KEYS=1]
+    bool balanced_tree = false;       // the aggregation tree in AggregationPlan's fixed grouping instead of the greedy fold
+                                      // (AggregationProver::TreeStream; the fold needs ONE key)                          [ZKHIP_TREE_BALANCED=1]
+    unsigned agg_slots = 3;           // node pipelines (witness thread + device thread, own keys) per device: the node proofs of one
+                                      // pipeline are proven one after the other -- with one pipeline the tree lags behind the segment
+                                      // lanes and is finished alone on the GPU, a 21 ms proof at a time (measured 1 / 2 / 3 / 4:
+                                      // DESIGN.md 15)                                                                     [ZKHIP_AGG_SLOTS=n]
+    bool trace_tree = false;          // a line per event of the aggregation tree on stderr (a measurement aid)           [ZKHIP_TREE_TRACE=1]
     std::vector<int> devices;         // GPUs of the node the flow spreads over (empty = the prover's device)             [ZKHIP_DEVICES=0,1,..]
     static FlowOptions from_env() {
         FlowOptions o;
@@ -229,6 +236,9 @@ struct FlowOptions {
         o.one_shape = getenv("ZKHIP_ONE_SHAPE") != nullptr;
         o.agg_nodes_100bit = getenv("ZKHIP_AGG_100BIT") != nullptr;
         o.per_depth_keys = getenv("ZKHIP_AGG_PER_DEPTH_KEYS") != nullptr;
+        o.balanced_tree = getenv("ZKHIP_TREE_BALANCED") != nullptr;
+        o.trace_tree = getenv("ZKHIP_TREE_TRACE") != nullptr;
+        if (const char* e = getenv("ZKHIP_AGG_SLOTS")) o.agg_slots = (unsigned)std::min(8, std::max(1, atoi(e)));
         if (const char* e = getenv("ZKHIP_DEVICES")) {
             std::stringstream ss(e);
             std::string item;
@@ -784,6 +794,84 @@ struct AggregationPlan {
         for (const auto& l : levels) n += l.size();
         return n;
     }
+};
+
+// The tree WITHOUT a fixed shape (one aggregation key: the internal circuit takes leaf-node and internal-node proofs in any mix, so any
+// grouping of ADJACENT proofs is a valid node).  FoldLine holds the finished node proofs ("pieces", each over a range [lo, hi) of leaf
+// nodes) and says what to fold next: the leftmost `arity` adjacent pieces, whenever there are such; once the number of leaf nodes is
+// known, everything has arrived and nothing is in flight, what is left (fewer than `arity` pieces) becomes the root -- a single leaf
+// node gets an internal node of its own, so the root is always a proof of the internal circuit.  Every fold but the last is full, so the
+// number of internal nodes is the balanced tree's, ceil((m - 1) / (arity - 1)); the SHAPE follows the arrival times: pieces that wait
+// fold among themselves (balanced), pieces that find the running fold finished join it (a comb: root = (everything before, the last
+// leaf nodes)), which leaves ONE leaf node and the root to do after the last segment proof instead of a node per level.
+// Pure bookkeeping (no proofs touched: a piece is a tag); the caller serialises calls.
+struct FoldLine {
+    struct Fold {
+        size_t lo = 0, hi = 0, depth = 0;     // the leaf nodes beneath, the height above them
+        std::vector<const void*> kids;        // the pieces' tags, in order
+        std::vector<int> kinds;               // per child: 0 internal, j + 1 leaf circuit j
+    };
+    explicit FoldLine(size_t arity) : arity_(arity < 2 ? 2 : arity) {}
+    // a finished piece: a leaf node (kind j + 1, depth 0, [k, k + 1)) or a fold's proof (done)
+    void add(size_t lo, size_t hi, int kind, size_t depth, const void* tag) {
+        Piece p;
+        p.hi = hi, p.kind = kind, p.depth = depth, p.tag = tag;
+        line_[lo] = p;
+    }
+    void set_total(size_t n_leaf_nodes) { total_ = n_leaf_nodes; }
+    // the next fold to start, if there is one (its pieces leave the line; it counts as in flight until done())
+    bool next(Fold* out) {
+        if (root_) return false;
+        auto first = line_.end();
+        size_t run = 0;
+        for (auto it = line_.begin(); it != line_.end(); ++it) {
+            auto prev = it;
+            if (run && (--prev)->second.hi == it->first) run++;
+            else run = 1, first = it;
+            if (run == arity_) break;
+        }
+        size_t take = run == arity_ ? arity_ : 0;
+        if (!take && total_ != SIZE_MAX && inflight_ == 0 && !line_.empty()) {
+            size_t end = 0;
+            bool contiguous = true;
+            for (const auto& kv : line_) contiguous = contiguous && kv.first == end, end = kv.second.hi;
+            if (contiguous && end == total_) {
+                if (line_.size() == 1 && line_.begin()->second.kind == 0) {
+                    root_ = line_.begin()->second.tag, depth_ = line_.begin()->second.depth;
+                    return false;
+                }
+                first = line_.begin(), take = line_.size();
+            }
+        }
+        if (!take) return false;
+        *out = Fold{};
+        out->lo = first->first;
+        auto it = first;
+        for (size_t c = 0; c < take; c++, ++it) {
+            out->kids.push_back(it->second.tag), out->kinds.push_back(it->second.kind);
+            out->hi = it->second.hi, out->depth = std::max(out->depth, it->second.depth + 1);
+        }
+        line_.erase(first, it);
+        inflight_++, folds_++;
+        return true;
+    }
+    void done(const Fold& f, const void* tag) {
+        inflight_--;
+        add(f.lo, f.hi, 0, f.depth, tag);
+    }
+    const void* root() const { return root_; }   // set by the next() that finds the line reduced to one internal piece over everything
+    size_t root_depth() const { return depth_; }
+    size_t folds() const { return folds_; }
+
+private:
+    struct Piece {
+        size_t hi = 0, depth = 0;
+        int kind = 0;
+        const void* tag = nullptr;
+    };
+    size_t arity_, total_ = SIZE_MAX, inflight_ = 0, folds_ = 0, depth_ = 0;
+    std::map<size_t, Piece> line_;   // by lo; adjacent = consecutive entries with a.hi == b.lo
+    const void* root_ = nullptr;
 };
 
 // Proves an aggregation plan on a BatchProver set up with the AGGREGATION app: `make_task(level, node, child_proofs)` builds

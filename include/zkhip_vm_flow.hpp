@@ -592,7 +592,7 @@ inline Digest guest_image_root(const Exe& exe) {
 // proofs runs on host threads beside the lanes.  Segments are independent proofs; their order is restored.
 template <class Lane>
 inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_hip::AggregationProver& agg, const Exe& exe, const StdIn& in,
-                                   const SegmentCaps& caps, bool keep_segments = false, bool verify_segments = false) {
+                                   const SegmentCaps& caps, bool keep_segments = false, bool verify_segments = false, bool greedy_tree = true, bool trace_tree = false) {
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::duration d) { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(d).count(); };
     if (lanes.empty()) throw Error("no segment prover lanes");
@@ -619,7 +619,8 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
     // proof only (crates/prover/src/prover/mod.rs:407-411).  FlowOptions::verify_segments adds the host verification of every segment
     // proof beside the proving (it hashes as much as the witness generation does, on the same cores).
     // the aggregation tree runs as a stream beside the segment proving: a leaf node starts when its four segment proofs exist
-    scroll_zkvm_hip::AggregationProver::TreeStream tree(agg);
+    scroll_zkvm_hip::AggregationProver::TreeStream tree(agg, greedy_tree);
+    tree.trace = trace_tree;
     for (Lane* lane : lanes)
         workers.emplace_back([&, lane] {
             try {
@@ -893,10 +894,14 @@ inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& e
     const scroll_zkvm_hip::AggregationSystemParams pair = scroll_zkvm_hip::AggregationSystemParams::nodes_100_bits_security();
     scroll_zkvm_hip::AggregationProver agg =
         scroll_zkvm_hip::AggregationProver::setup_shapes(shape_vks, segment_statement(), {}, device, flow.agg_nodes_100bit ? &pair : nullptr);
-    agg.set_devices(devs);   // the tree's nodes go to whichever device's pipeline is free first
+    {   // the tree's nodes go to whichever pipeline is free first: flow.agg_slots pipelines per device
+        std::vector<int> slots;
+        for (unsigned r = 0; r < std::max(1u, flow.agg_slots); r++) slots.insert(slots.end(), devs.begin(), devs.end());
+        agg.set_devices(slots);
+    }
     agg.set_shape_policies(shape_policies(shape_vks));
     (void)agg.node_vk(0);   // the leaf circuit and its key: setup, like the segment keys
-    return prove_guest_with(lanes, agg, exe, in, caps, keep_segments, flow.verify_segments);
+    return prove_guest_with(lanes, agg, exe, in, caps, keep_segments, flow.verify_segments, !flow.balanced_tree, flow.trace_tree);
 }
 
 // The verifier's side: the root proof under the root verifying key, then the statement: the run starts at the guest's entry on the
@@ -987,7 +992,7 @@ public:
             const zkhip_vm::StdIn in = task.build_guest_input();
             std::vector<zkhip_vm::ShapedSegmentProver*> lanes;
             for (auto& l : seg_) lanes.push_back(l.get());
-            last_ = zkhip_vm::prove_guest_with(lanes, *agg_, exe_, in, caps_, false, config.flow.verify_segments);
+            last_ = zkhip_vm::prove_guest_with(lanes, *agg_, exe_, in, caps_, false, config.flow.verify_segments, !config.flow.balanced_tree, config.flow.trace_tree);
         } catch (const zkhip_vm::Error& e) {
             throw Error(Error::GenProof, std::string("failed to generate proof: ") + e.what());
         }
@@ -1123,7 +1128,11 @@ private:
         std::vector<VerifyingKey> shape_vks;
         for (size_t sh = 0; sh < seg_[0]->n_shapes(); sh++) shape_vks.push_back(seg_[0]->vk(sh));
         agg_.reset(new AggregationProver(AggregationProver::setup_shapes(shape_vks, zkhip_vm::segment_statement(), {}, device_)));
-        agg_->set_devices(devs);
+        {
+            std::vector<int> slots;   // config.flow.agg_slots node pipelines per device
+            for (unsigned r = 0; r < std::max(1u, config.flow.agg_slots); r++) slots.insert(slots.end(), devs.begin(), devs.end());
+            agg_->set_devices(slots);
+        }
         agg_->set_shape_policies(zkhip_vm::shape_policies(shape_vks));
     }
 };

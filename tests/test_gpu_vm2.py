@@ -588,8 +588,10 @@ def test_segments_carry_only_the_chips_they_use(zk, ora, tmp_path):
 def test_one_task_over_a_device_list(tmp_path):
     """the segments of ONE task spread over the GPUs of a node, and the aggregation tree's nodes go to whichever device
     is free.  ZKHIP_DEVICES=0,0,0 builds three device slots -- all mapped onto this box's one GPU -- each with its own copy of the segment
-    and node keys, its own lanes and its own circuit forks: the root proof is byte-identical to the one-device run, the tree's nodes are
-    spread over the slots, the key is the same.  A device that does not exist is an error, not a crash."""
+    and node keys, its own lanes and its own circuit forks: under the tree's FIXED grouping the root proof is byte-identical to the
+    one-device run, the tree's nodes are spread over the slots, the key is the same.  The default (the greedy fold, three node pipelines
+    per device: the tree's shape follows the arrival times) states the same about the same run under the same key -- the root proof's
+    bytes and the statement's accumulator over the children depend on the shape; the app, the states, the commitments and the key do not.  A device that does not exist is an error, not a crash."""
     import os
 
     words = fib_program()
@@ -598,19 +600,31 @@ def test_one_task_over_a_device_list(tmp_path):
     cfg = tmp_path / "openvm.toml"
     cfg.write_text(pm.TOML.format(*PARAMS))
     out = {}
-    for name, env in (("one", {}), ("three", {"ZKHIP_DEVICES": "0,0,0", "ZKHIP_LANES": "1"})):
+    fixed = {"ZKHIP_TREE_BALANCED": "1", "ZKHIP_AGG_SLOTS": "1"}
+    for name, env in (("one", fixed), ("three", dict(fixed, ZKHIP_DEVICES="0,0,0", ZKHIP_LANES="1")), ("fold", {}), ("fold3", {"ZKHIP_DEVICES": "0,0,0"})):
         d = tmp_path / name
         d.mkdir()
         (d / "stdin.bin").write_bytes((3000).to_bytes(4, "little"))
         r = subprocess.run([pm.CLI, "prove-elf", str(exe), str(d / "stdin.bin"), str(d), str(cfg), "9"], capture_output=True, text=True, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-3000:]
         out[name] = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["one"]["segments"] == out["three"]["segments"] > 27
+    assert out["one"]["segments"] == out["three"]["segments"] == out["fold"]["segments"] > 27
     assert len(out["one"]["tree_nodes_per_device_slot"]) == 1 and len(out["three"]["tree_nodes_per_device_slot"]) == 3
     assert sum(out["three"]["tree_nodes_per_device_slot"]) == sum(out["one"]["tree_nodes_per_device_slot"]) and min(out["three"]["tree_nodes_per_device_slot"]) >= 1
     a, b = json.loads((tmp_path / "one" / "root.json").read_text()), json.loads((tmp_path / "three" / "root.json").read_text())
     assert a["proof"] == b["proof"] and a["user_pvs_proof"] == b["user_pvs_proof"]
     assert (tmp_path / "one" / "root.vk").read_bytes() == (tmp_path / "three" / "root.vk").read_bytes()
+    # the greedy fold: as many internal nodes as the fixed grouping needs at most, three (resp. nine) pipelines, the same statement and key
+    for name, n_slots in (("fold", 3), ("fold3", 9)):
+        assert len(out[name]["tree_nodes_per_device_slot"]) == n_slots
+        assert sum(out[name]["tree_nodes_per_device_slot"]) <= sum(out["one"]["tree_nodes_per_device_slot"])
+        f = json.loads((tmp_path / name / "root.json").read_text())
+        # [app (8) | pc, memory root | pc, memory root | accumulator (8) | leaf (8) | internal (8)] + the public values and their openings:
+        # all the same but the accumulator -- a hash over the children's payloads along the tree, which has another shape
+        fu, au = pm.un_b64_bincode(f["user_pvs_proof"]), pm.un_b64_bincode(a["user_pvs_proof"])
+        assert len(fu) == len(au) and fu[:4 * 26] == au[:4 * 26] and fu[4 * 34:] == au[4 * 34:]
+        assert (tmp_path / name / "root.vk").read_bytes() == (tmp_path / "one" / "root.vk").read_bytes()
+        assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "one" / "root.vk"), str(cfg), str(tmp_path / name / "root.json")).returncode == 0
     d = tmp_path / "bad"
     d.mkdir()
     (d / "stdin.bin").write_bytes((100).to_bytes(4, "little"))
