@@ -790,6 +790,14 @@ typedef struct {
      * leaf circuits of one app state ONE app id (zkhip_recursion_vk_digest of the full shape). */
     size_t n_leaf_shapes;
     const uint32_t *app_id;
+    /* BUNDLE OVER BATCHES (crates/integration/src/testers: chunk -> batch -> bundle, each layer deferring the verification of the one
+     * below): a deferral node (child_is_node = 3) with region_index != 0 takes JOIN proofs as children -- proofs of a guest that itself
+     * deferred.  `child_airs` = the join circuit's key; a child's statement is a root's 50 words followed by the chain (8) its own
+     * deferral node verified.  What the verifier of a join does on the host happens in the circuit: the child guest's deferral region
+     * (4 KiB = 256 blocks = one subtree of its memory tree, whose root is node `region_index` of the level 20 below the tree's root:
+     * ((2 << 26) | base / 16) >> 8) opens in the child's final memory root, its n claims chain to the stated value.  Auxiliary words
+     * per child then: 232 (public values) + 2048 cells + 20 x 8 siblings (bottom-up) + 31 flags (flag k = [k < n]). */
+    uint32_t region_index;
 } zkhip_recursion_stmt;
 /* `airs[a].log_height` and `airs[a].prep_commit` are part of the child verifying key; program pointers are copied. */
 int zkhip_recursion_build(const zkhip_params *child_params, const zkhip_air *child_airs, size_t n_child_airs, size_t max_children,
@@ -834,7 +842,8 @@ int zkhip_recursion_witness_uniform(zkhip_recursion *r, const uint8_t *const *pr
                                     const uint32_t *child_prep_commits, const int *child_is_leaf, const uint32_t leaf_commit[8],
                                     const uint32_t internal_commit[8], size_t n_present, uint32_t *node_pvs_out);
 /* the witness of a DEFERRAL node: child_aux[c] = zkhip_recursion_n_aux words (232): the 16 cells of the child's two public-value blocks, then
- * the 27 sibling digests above the block pair in its final memory root, bottom-up; acc_start = the claim chain before this node */
+ * the 27 sibling digests above the block pair in its final memory root, bottom-up (JOIN children: + the region opening, see
+ * zkhip_recursion_stmt.region_index: 2471 words); acc_start = the claim chain before this node */
 int zkhip_recursion_witness_deferral(zkhip_recursion *r, const uint8_t *const *proofs, const size_t *proof_lens, const uint32_t *const *const *child_pvs,
                                      const uint32_t *child_aux, const uint32_t acc_start[8], size_t n_present, uint32_t *node_pvs_out);
 size_t zkhip_recursion_n_aux(const zkhip_recursion *r);

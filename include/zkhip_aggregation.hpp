@@ -1171,15 +1171,25 @@ struct ProgramCommitment {
 };
 // one deferred child: its root proof, the root's statement (50 words), the 32 public-value bytes and the sibling digests above the
 // public-value block pair in its final memory root (27 x 8, bottom-up)
+inline bool chain_claim(Digest8& acc, const uint32_t claim[32]);
 struct DeferralInput {
     ChildProof root;
     std::vector<uint8_t> public_values;
     std::vector<uint32_t> siblings;
-    // from the StarkProof a guest flow returns: user_pvs_proof = [statement (50 words) | 32 bytes | openings of both blocks (2 x 28 x 8)]
-    static DeferralInput from_stark_proof(const StarkProof& sp) {
-        const size_t n_stmt = 50, n_open = 2 * 8 * 28;
+    // a JOIN child (a proof of a guest that itself deferred: a batch under a bundle): the opening of ITS deferral region in its final
+    // memory root -- 2048 cells, then the 20 sibling digests above the region's subtree (StarkProof::deferral_merkle_proofs)
+    std::vector<uint32_t> region;
+    static constexpr size_t REGION_CELLS = 2048, REGION_SIBS = 20, MAX_CLAIMS = 31;
+    // from the StarkProof a guest flow returns: user_pvs_proof = [statement (50 words; a join's: 58) | 32 bytes | openings of both blocks (2 x 28 x 8)]
+    static DeferralInput from_stark_proof(const StarkProof& sp, bool join = false) {
+        const size_t n_stmt = join ? 58 : 50, n_open = 2 * 8 * 28;
         if (sp.user_pvs_proof.size() != 4 * n_stmt + 32 + 4 * n_open) throw Error(Error::GenProof, "deferral: a child proof is not a guest flow's root (user_pvs_proof size)");
         DeferralInput d;
+        if (join) {
+            if (sp.deferral_merkle_proofs.size() != 4 * (REGION_CELLS + 8 * REGION_SIBS)) throw Error(Error::GenProof, "deferral: a child proof under a join key carries no opening of its deferral region");
+            d.region.resize(REGION_CELLS + 8 * REGION_SIBS);
+            memcpy(d.region.data(), sp.deferral_merkle_proofs.data(), sp.deferral_merkle_proofs.size());
+        }
         d.root.proof = sp.proof;
         d.root.pvs.resize(3);
         d.root.pvs[2].resize(n_stmt);
@@ -1199,7 +1209,54 @@ struct DeferralInput {
         const std::array<uint32_t, 16> c = cells();
         std::vector<uint32_t> a(c.begin(), c.end());
         a.insert(a.end(), siblings.begin(), siblings.end());
+        if (!region.empty()) {   // + the region's opening and the flags [k < n]
+            a.insert(a.end(), region.begin(), region.end());
+            const uint32_t n = region[0] | (region[1] << 16);
+            for (uint32_t k = 0; k < MAX_CLAIMS; k++) a.push_back(k < n ? 1u : 0u);
+        }
         return a;
+    }
+    // a JOIN child on the host (what the deferral node does in the circuit): the region opens in the child's final memory root as node
+    // `region_index` of its level, and its claims chain to the value the child's statement ends with
+    bool region_backs_the_chain(uint32_t region_index, std::string* why = nullptr) const {
+        auto fail = [&](const char* m) {
+            if (why) *why = m;
+            return false;
+        };
+        const std::vector<uint32_t>& s = root.pvs[2];
+        if (s.size() != 58 || region.size() != REGION_CELLS + 8 * REGION_SIBS) return fail("not a join child");
+        for (size_t i = 0; i < REGION_CELLS; i++)
+            if (region[i] > 0xffffu) return fail("a cell of the deferral region is not 16 bits");
+        std::vector<Digest8> level(REGION_CELLS / 8);
+        for (size_t b = 0; b < level.size(); b++) {
+            Digest8 cells;
+            std::copy(region.begin() + 8 * b, region.begin() + 8 * b + 8, cells.begin());
+            level[b] = p2_compress8(cells, Digest8{});
+        }
+        while (level.size() > 1) {
+            std::vector<Digest8> up(level.size() / 2);
+            for (size_t i = 0; i < up.size(); i++) up[i] = p2_compress8(level[2 * i], level[2 * i + 1]);
+            level = std::move(up);
+        }
+        Digest8 cur = level[0];
+        uint32_t idx = region_index;
+        for (size_t l = 0; l < REGION_SIBS; l++, idx >>= 1) {
+            Digest8 sib;
+            std::copy(region.begin() + REGION_CELLS + 8 * l, region.begin() + REGION_CELLS + 8 * l + 8, sib.begin());
+            cur = (idx & 1u) ? p2_compress8(sib, cur) : p2_compress8(cur, sib);
+        }
+        if (!std::equal(cur.begin(), cur.end(), s.begin() + 18)) return fail("the deferral region does not open in the child's final memory root");
+        auto word = [&](size_t w) { return region[2 * w] | (region[2 * w + 1] << 16); };
+        const uint32_t n = word(0);
+        if (n == 0 || n > MAX_CLAIMS) return fail("the child states no claims, or more than the region holds");
+        Digest8 acc{};
+        for (uint32_t k = 0; k < n; k++) {
+            uint32_t c[32];
+            for (size_t j = 0; j < 32; j++) c[j] = word(32 + 32 * k + j);
+            if (!chain_claim(acc, c)) return fail("a claim's commitment is not a field element");
+        }
+        if (!std::equal(acc.begin(), acc.end(), s.begin() + 50)) return fail("the child's claims are not the ones its deferral node verified");
+        return true;
     }
     // the 32 words of the claim a parent guest states about this child
     Digest8 input_commit() const { return p2_sponge8(root.pvs[2].data(), root.pvs[2].size()); }
@@ -1236,16 +1293,23 @@ class DeferralProver {
 public:
     // `child_key`: the CHILD app's aggregation key (crates/prover/src/prover/mod.rs:213 `child_prover.load_agg_vk()`); node_params: the
     // parameters the deferral node and the join are proven under (mod.rs:239 `internal_params_with_100_bits_security`)
-    static std::unique_ptr<DeferralProver> setup(const VerifyingKey& child_key, const zkhip_params& node_params, int device = 0, size_t max_children = 4) {
-        if (!child_key.is_aggregation_key() || child_key.airs.size() != 3 || child_key.airs[2].n_pvs != 50)
+    // `child_region_index`: for a child app that itself defers (its key is a JOIN key: a bundle over batches) -- where the CHILD guest's
+    // deferral region sits in its memory tree, ((2 << 26) | deferral_base(child exe) / 16) >> 8 (zkhip_vm::deferral_region_index)
+    static std::unique_ptr<DeferralProver> setup(const VerifyingKey& child_key, const zkhip_params& node_params, int device = 0, size_t max_children = 4,
+                                                 uint32_t child_region_index = 0) {
+        if (!child_key.is_aggregation_key() || child_key.airs.size() != 3 || child_key.airs[2].n_pvs != (child_key.join ? 58u : 50u))
             throw Error(Error::Setup, "deferral: the child key is not the aggregation key of a guest flow");
+        if (child_key.join != (child_region_index != 0))
+            throw Error(Error::Setup, child_key.join ? "deferral: the child key is a join key (the child app defers): its deferral region's place in its memory is needed"
+                                                     : "deferral: a region index for a child app that does not defer");
         std::unique_ptr<DeferralProver> p(new DeferralProver());
-        p->child_key_ = child_key, p->params_ = node_params, p->device_ = device, p->max_children_ = max_children;
+        p->child_key_ = child_key, p->params_ = node_params, p->device_ = device, p->max_children_ = max_children, p->region_index_ = child_region_index;
         int rc = zkhip_ctx_create(device, &p->ctx_);
         if (rc != ZKHIP_OK) throw Error(Error::Keygen, "no gfx950 device for the HIP backend (zkhip_ctx_create returned " + std::to_string(rc) + ")");
         std::vector<zkhip_air> za = child_key.as_airs();
         zkhip_recursion_stmt st{};
         st.child_is_node = 3;
+        st.region_index = child_region_index;
         rc = zkhip_recursion_build(&child_key.params, za.data(), za.size(), max_children, &st, &p->def_.circ);
         if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("deferral: cannot build the deferral node: ") + zkhip_recursion_last_error(nullptr));
         p->keygen(p->def_);
@@ -1263,6 +1327,7 @@ public:
     DeferralProver(const DeferralProver&) = delete;
     DeferralProver& operator=(const DeferralProver&) = delete;
     size_t max_children() const { return max_children_; }
+    uint32_t child_region_index() const { return region_index_; }
     const VerifyingKey& child_key() const { return child_key_; }
     const VerifyingKey& deferral_vk() const { return def_.vk; }
     // crates/integration/src/lib.rs:461-514: what the task and the prover need from the child proofs -- the input commitments (they go
@@ -1277,10 +1342,11 @@ public:
         if (proofs.size() > max_children_) throw Error(Error::GenProof, "deferral: " + std::to_string(proofs.size()) + " child proofs, the deferral node takes " + std::to_string(max_children_));
         Data d;
         for (size_t i = 0; i < proofs.size(); i++) {
-            DeferralInput in = DeferralInput::from_stark_proof(*proofs[i]);
+            DeferralInput in = DeferralInput::from_stark_proof(*proofs[i], child_key_.join);
             std::string why;
             if (!child_key_.verify(in.root)) throw Error(Error::GenProof, "deferral: child proof " + std::to_string(i) + " does not verify under the child aggregation key");
             if (!child_key_.root_statement_matches(in.root.pvs[2], &why)) throw Error(Error::GenProof, "deferral: child proof " + std::to_string(i) + ": " + why);
+            if (child_key_.join && !in.region_backs_the_chain(region_index_, &why)) throw Error(Error::GenProof, "deferral: child proof " + std::to_string(i) + ": " + why);
             const Digest8 ic = in.input_commit();
             std::array<uint8_t, 32> b;
             memcpy(b.data(), ic.data(), 32);
@@ -1351,6 +1417,7 @@ private:
     zkhip_params params_{};
     int device_ = 0;
     size_t max_children_ = 4;
+    uint32_t region_index_ = 0;
     zkhip_ctx* ctx_ = nullptr;
     Node def_, join_;
     void check(int rc) const {

@@ -524,6 +524,9 @@ inline uint32_t deferral_base(const Exe& exe) {
     const uint64_t end = (uint64_t)exe.data_base + exe.data.size();
     return (uint32_t)((end + DEFERRAL_REGION_BYTES - 1) / DEFERRAL_REGION_BYTES * DEFERRAL_REGION_BYTES);
 }
+// the node of the memory tree above the region's 256 blocks, on the level DEFERRAL_SUBTREE_LEVELS above the leaves (what a deferral node
+// over proofs of THIS guest hard-wires: zkhip_recursion_stmt.region_index)
+inline uint32_t deferral_region_index(const Exe& exe) { return ((2u << vmc::LABEL_BITS) | (deferral_base(exe) / 16)) >> DEFERRAL_SUBTREE_LEVELS; }
 inline bool has_deferral_region(const Exe& exe) { return (uint64_t)deferral_base(exe) + DEFERRAL_REGION_BYTES <= (uint64_t)exe.data_base + exe.memory_bytes; }
 // the region's cells in the executor's final memory + the sibling digests above its subtree, bottom-up
 inline std::vector<uint32_t> open_deferral_region(const SegmentExecutor& ex, const Exe& exe) {
@@ -1015,12 +1018,16 @@ public:
     }
     // mod.rs:200-282 `enable_deferral(child_prover)`: from now on this prover's guest may state claims about proofs of the CHILD app (its
     // aggregation key is all that is needed: mod.rs:213 `child_prover.load_agg_vk()`), and every proof it returns is a join.
-    void enable_deferral(const VerifyingKey& child_agg_key, size_t max_children = 4) {
+    // `child_region_index` (a child app that itself defers -- its key is a join key: this prover's guest is a bundle over batches):
+    // zkhip_vm::deferral_region_index(child exe)
+    void enable_deferral(const VerifyingKey& child_agg_key, size_t max_children = 4, uint32_t child_region_index = 0) {
         if (!zkhip_vm::has_deferral_region(exe_)) throw Error(Error::Setup, "enable_deferral: the guest's memory has no room for the deferral region");
         reset();   // (mod.rs:265 `self.reset()`: the keys are rebuilt with deferral)
-        deferral_ = DeferralProver::setup(child_agg_key, params_, device_, max_children);
+        deferral_ = DeferralProver::setup(child_agg_key, params_, device_, max_children, child_region_index);
     }
-    void enable_deferral(UniversalProver& child_prover, size_t max_children = 4) { enable_deferral(child_prover.get_agg_vk(), max_children); }
+    void enable_deferral(UniversalProver& child_prover, size_t max_children = 4) {
+        enable_deferral(child_prover.get_agg_vk(), max_children, child_prover.deferral_enabled() ? zkhip_vm::deferral_region_index(child_prover.exe()) : 0u);
+    }
     bool deferral_enabled() const { return (bool)deferral_; }
     // crates/integration/src/lib.rs:461-514 `compute_deferral_data(child_prover, cached_commit, proofs)`
     DeferralProver::Data compute_deferral_data(const std::vector<const StarkProof*>& proofs) const {

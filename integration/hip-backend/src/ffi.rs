@@ -169,6 +169,8 @@ pub struct zkhip_recursion_stmt {
     pub n_leaf_shapes: usize,
     /// leaf circuits of one app state one app id (8 canonical words or null)
     pub app_id: *const u32,
+    /// deferral node (child_is_node = 3) over JOIN proofs: the node of a child's memory tree above its deferral region (0 = plain roots)
+    pub region_index: u32,
 }
 
 /// include/zkhip.h `zkhip_config`: every behaviour-changing switch of the library; the ZKHIP_* environment variables are overrides read

@@ -155,8 +155,60 @@ def memory_root_with_public_values(pv_bytes, rng):
     return cur, cells, sibs
 
 
+def merkle_of_blocks(cells):
+    """root of the subtree over consecutive memory blocks (8 cells each; a power of two of them)"""
+    level = [block(cells[8 * i:8 * i + 8]) for i in range(len(cells) // 8)]
+    while len(level) > 1:
+        level = [compress(level[2 * i], level[2 * i + 1]) for i in range(len(level) // 2)]
+    return level[0]
+
+
+def memory_root_with_public_values_and_region(pv_bytes, region_cells, region_base, rng):
+    """A final memory root in which BOTH the 32 public-value bytes (address space 3, blocks 0 and 1) and a guest's 4 KiB deferral region
+    (address space 2, the 256 blocks from byte address `region_base`: include/zkhip_vm_flow.hpp `check_deferral_region`) open: random
+    siblings up to the two address spaces' subtrees, which are siblings one level below the root's right child.
+    Returns (root, pv cells[16], pv siblings[27][8], region siblings[20][8], region index)."""
+    region_cells = np.asarray(region_cells, np.uint32)
+    assert region_cells.size == 2048
+    cells = np.array([pv_bytes[2 * j] | (pv_bytes[2 * j + 1] << 8) for j in range(16)], np.uint32)
+    pv_sibs = rng.integers(0, P, size=(27, 8), dtype=np.uint64).astype(np.uint32)
+    reg_sibs = rng.integers(0, P, size=(20, 8), dtype=np.uint64).astype(np.uint32)
+    region_index = ((2 << 26) | (region_base // 16)) >> 8
+    cur, idx = merkle_of_blocks(region_cells), region_index
+    for l in range(18):
+        cur = compress(reg_sibs[l], cur) if idx & 1 else compress(cur, reg_sibs[l])
+        idx >>= 1
+    assert idx == 2
+    a2 = cur
+    cur, idx = compress(block(cells[:8]), block(cells[8:])), (3 << 26) >> 1
+    for l in range(25):
+        cur = compress(pv_sibs[l], cur) if idx & 1 else compress(cur, pv_sibs[l])
+        idx >>= 1
+    assert idx == 3
+    a3 = cur
+    s0 = pv_sibs[26]
+    reg_sibs[18], reg_sibs[19], pv_sibs[25] = a3, s0, a2
+    root = compress(s0, compress(a2, a3))
+    return root, cells, pv_sibs, reg_sibs, region_index
+
+
+def deferral_region_cells(claims):
+    """The 2048 cells of a deferral region holding `claims` (each the five chunks of deferral_claim): word 0 = their number, claim k = the
+    32 words from word 32 + 32 k -- three commitments (a field element per word), then the public values (two cells per word)."""
+    words = np.zeros(1024, np.uint32)
+    words[0] = len(claims)
+    for k, (ic, exe, vm, c0, c1) in enumerate(claims):
+        w = words[32 + 32 * k:64 + 32 * k]
+        w[0:8], w[8:16], w[16:24] = ic, exe, vm
+        pv = np.concatenate([c0, c1]).astype(np.uint32)
+        w[24:32] = pv[0::2] | (pv[1::2] << 16)
+    cells = np.zeros(2048, np.uint32)
+    cells[0::2], cells[1::2] = words & 0xFFFF, words >> 16
+    return cells
+
+
 def deferral_claim(root_pvs, cells):
-    """The five chunks a deferral node chains for a child root with statement `root_pvs` (50 words): what a parent guest states about it."""
+    """The five chunks a deferral node chains for a child root with statement `root_pvs` (50 words; a join's: 58): what a parent guest states about it."""
     root_pvs = np.asarray(root_pvs, np.uint32)
     app, pc_start, root0, lc = root_pvs[:8], root_pvs[8], root_pvs[9:17], root_pvs[34:42]
     input_commit = sponge(root_pvs)

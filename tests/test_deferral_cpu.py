@@ -8,7 +8,10 @@ aggregation key): building the circuits and running their witnesses need no GPU.
   * node traces satisfy the AIRs, the oracle proves the node, the product's verifier accepts it;
   * the join verifies (a root under key A, the deferral node's proof) and states [root statement | deferral accumulator];
   * a flipped byte in a child proof, a wrong opening, a child that did not exit with code 0 have no witness; reordered children give
-    another accumulator; a chain that does not start at zero cannot be joined."""
+    another accumulator; a chain that does not start at zero cannot be joined;
+  * BUNDLE OVER BATCHES: a deferral node with region_index != 0 takes JOIN proofs -- it opens the child guest's deferral region in the
+    child's final memory root and chains its claims in the circuit; a wrong claim count, a cell that does not open and a region whose
+    claims are not the ones the child's own deferral node verified have no witness."""
 import numpy as np
 import pytest
 
@@ -19,6 +22,7 @@ import recursion_util as ru
 
 PARAMS = (1, 0, 4, 3, 3)
 NOPV = ru.NOPV
+REGION_BASE = 0x00401000
 
 
 @pytest.fixture(scope="module")
@@ -35,8 +39,13 @@ def flows(ora):
     int_pcs, IC = ru.node_key_commits(PARAMS, internal.airs())
     ivk = ru.verifying(PARAMS, [dict(a, prep_commit=c) for a, c in zip(internal.airs(), int_pcs)])
 
-    def child_flow(pv_bytes, pc_end=0):
-        root1, cells, sibs = ru.memory_root_with_public_values(pv_bytes, rng)
+    def child_flow(pv_bytes, pc_end=0, region=None):
+        extra = {}
+        if region is None:
+            root1, cells, sibs = ru.memory_root_with_public_values(pv_bytes, rng)
+        else:   # a guest that itself deferred: its final memory also holds its claims
+            root1, cells, sibs, rsibs, ridx = ru.memory_root_with_public_values_and_region(pv_bytes, region, REGION_BASE, rng)
+            extra = dict(region=np.asarray(region, np.uint32), region_sibs=rsibs, region_index=ridx)
         segs = [ru.state_segment([0x200000] + list(image), [0x200040] + list(mid)), ru.state_segment([0x200040] + list(mid), [pc_end] + list(root1))]
         proofs = [ora.stark_prove(PARAMS, s).tobytes() for s in segs]
         st, npv = leaf.witness(proofs, [[a["pvs"] for a in s] for s in segs])
@@ -46,7 +55,7 @@ def flows(ora):
         assert st == 0, internal.last_error()
         rp = ora.stark_prove(PARAMS, ru.node_instance(internal, rpv)).tobytes()
         assert z.verify(PARAMS, ivk, [NOPV, NOPV, rpv], rp) == 0
-        return dict(proof=rp, pvs=rpv, aux=np.concatenate([cells, sibs.reshape(-1)]), cells=cells)
+        return dict(proof=rp, pvs=rpv, aux=np.concatenate([cells, sibs.reshape(-1)]), cells=cells, **extra)
 
     kids = [child_flow(bytes([i + 1] * 32)) for i in range(3)]
     return dict(kids=kids, ivk=ivk, child_flow=child_flow, LC=LC, IC=IC)
@@ -120,3 +129,64 @@ def test_deferral_node_refusals(ora, flows):
     assert _witness(D, [nz])[0] == -7
     # the other witness entry points refuse a deferral circuit
     assert D.witness([two[0]["proof"]], [[NOPV, NOPV, two[0]["pvs"]]])[0] == -3
+
+
+def test_deferral_over_join_children(ora, flows):
+    """chunk -> batch -> bundle: the bundle's deferral node over a BATCH proof (a join)."""
+    kids, ivk = flows["kids"], flows["ivk"]
+    claims = [ru.deferral_claim(k["pvs"], k["cells"]) for k in kids[:2]]
+    chain = ru.deferral_chain(np.zeros(8, np.uint32), claims)
+    D1 = z.RecursionCircuit(PARAMS, ivk, 4, stmt="deferral")
+    st, dpv = _witness(D1, kids[:2])
+    assert st == 0 and dpv[8:].tolist() == chain.tolist()
+    dnode = ru.node_instance(D1, dpv)
+    dproof, dvk = ora.stark_prove(PARAMS, dnode).tobytes(), ru.verifying(PARAMS, dnode)
+    J = z.RecursionCircuit.join(PARAMS, ivk, PARAMS, dvk)
+
+    def batch(region_claims):   # a guest flow whose memory holds `region_claims`, joined with the deferral node over kids[:2]
+        g = flows["child_flow"](bytes([0x42] * 32), region=ru.deferral_region_cells(region_claims))
+        st, jpv = J.witness([g["proof"], dproof], [[NOPV, NOPV, g["pvs"]], [NOPV, NOPV, dpv]])
+        assert st == 0, J.last_error()
+        jnode = ru.node_instance(J, jpv)
+        return dict(g, jpv=jpv, jproof=ora.stark_prove(PARAMS, jnode).tobytes(), jvk=ru.verifying(PARAMS, jnode))
+
+    b = batch(claims)
+    assert b["jpv"].size == 58 and b["jpv"][50:].tolist() == chain.tolist()
+    with pytest.raises(z.ZkhipError):   # a join key needs the region's place; a plain key refuses one
+        z.RecursionCircuit(PARAMS, b["jvk"], 2, stmt="deferral")
+    with pytest.raises(z.ZkhipError):
+        z.RecursionCircuit(PARAMS, ivk, 2, stmt="deferral", region_index=b["region_index"])
+    D2 = z.RecursionCircuit(PARAMS, b["jvk"], 2, stmt="deferral", region_index=b["region_index"])
+    assert D2.n_pvs == 16
+
+    def aux(x, n_flags=None, region=None):
+        reg = x["region"] if region is None else region
+        n = int(reg[0]) if n_flags is None else n_flags
+        return np.concatenate([x["aux"], reg, x["region_sibs"].reshape(-1), np.array([1 if k < n else 0 for k in range(31)], np.uint32)])
+
+    def wit(x, **kw):
+        return D2.witness([x["jproof"]], [[NOPV, NOPV, x["jpv"]]], aux=[aux(x, **kw)])
+
+    st, pv2 = wit(b)
+    assert st == 0, D2.last_error()
+    want = ru.deferral_chain(np.zeros(8, np.uint32), [ru.deferral_claim(b["jpv"], b["cells"])])
+    assert (pv2[:8] == 0).all() and pv2[8:].tolist() == want.tolist()
+    node = ru.node_instance(D2, pv2)
+    for a in node[:2]:
+        assert air.check_trace(a["program"], a["trace"], a["pvs"], a["prep"]) == []
+    assert z.verify(PARAMS, ru.verifying(PARAMS, node), [NOPV, NOPV, pv2], ora.stark_prove(PARAMS, node).tobytes()) == 0
+    # a wrong claim count, no claim counted, a cell that is not the one in the batch's memory, a sibling
+    assert wit(b, n_flags=1)[0] == -7 and wit(b, n_flags=3)[0] == -7 and wit(b, n_flags=0)[0] == -7
+    for pos in (2 * 40, 2 * 70 + 1, 0):
+        reg = b["region"].copy()
+        reg[pos] ^= 1
+        assert wit(b, region=reg)[0] == -7
+    sib = dict(b, region_sibs=b["region_sibs"].copy())
+    sib["region_sibs"][3][1] ^= 1
+    assert wit(sib)[0] == -7
+    # a batch whose memory states OTHER claims than the ones its deferral node verified (the join itself does not look at the memory)
+    liar = batch(claims[::-1])
+    assert D2.witness([liar["jproof"]], [[NOPV, NOPV, liar["jpv"]]], aux=[aux(liar)])[0] == -7
+    # ... and one that states none
+    none = batch([])
+    assert D2.witness([none["jproof"]], [[NOPV, NOPV, none["jpv"]]], aux=[aux(none)])[0] == -7

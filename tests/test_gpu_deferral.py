@@ -145,3 +145,111 @@ def test_three_children_one_parent_root(ora, tmp_path):
     # the parent's proof does not verify under the CHILD's key, nor a child's under the parent's
     assert pm.run_cli("verify-guest", str(parent_elf), child_vk, str(cfg), str(out / "root.json")).returncode != 0
     assert pm.run_cli("verify-guest", str(child_elf), str(out / "root.vk"), str(cfg), kids[0]["json"]).returncode != 0
+
+
+def test_bundle_over_batches_three_layers(ora, tmp_path):
+    """chunk -> batch -> bundle (crates/integration/src/testers: every layer defers the verification of the one below).  Two chunk
+    proofs (Fibonacci) -> two BATCH proofs (a deferring guest over chunk roots: proofs under the batch's JOIN key) -> one BUNDLE proof (the
+    same guest program with the batch app's commitments in its data segment, over the two batch proofs): the bundle's deferral node takes
+    JOIN proofs as children -- it opens each batch's deferral region in that batch's final memory root and chains its claims in the
+    circuit, what verify-guest does on the host for a single join.
+      * the bundle verifies with verify-guest under ITS join key; its chain == the independent restatement over the batch statements;
+      * the bundle's deferral node proof == the oracle's proof of the same circuit and witness, byte for byte;
+      * a batch proof with a tampered region opening, a witness with a wrong claim count and a region cell that does not open are refused."""
+    cfg = tmp_path / "openvm.toml"
+    cfg.write_text(pm.TOML.format(*PARAMS))
+    chunk_elf = tmp_path / "chunk.elf"
+    chunk_elf.write_bytes(rv.elf_bytes(fib_program()))
+    chunks = [prove_child(tmp_path / ("c%d" % i), chunk_elf, cfg, n) for i, n in enumerate((100, 150))]
+    chunk_vk = str(chunks[0]["dir"] / "root.vk")
+    pc = json.loads(pm.run_cli("program-commit", str(chunk_elf), chunk_vk, str(cfg)).stdout)
+    batch_elf = tmp_path / "batch.elf"
+    batch_elf.write_bytes(rv.elf_bytes(deferral_guest_program(), data=b"".join(int(x).to_bytes(4, "little") for x in pc["exe"] + pc["vm"])))
+
+    def prove_deferral(outdir, elf, child_vk, jsons, pvs):
+        outdir.mkdir()
+        (outdir / "witness.bin").write_bytes(b"".join(pvs))
+        r = subprocess.run([pm.CLI, "prove-deferral", str(elf), str(cfg), str(outdir), "9", child_vk, str(cfg), str(outdir / "witness.bin")] + jsons,
+                           capture_output=True, text=True)
+        return r
+
+    batches = []
+    for i, ks in enumerate(([chunks[0], chunks[1]], [chunks[1]])):
+        d = tmp_path / ("b%d" % i)
+        r = prove_deferral(d, batch_elf, chunk_vk, [k["json"] for k in ks], [k["pvs"] for k in ks])
+        assert r.returncode == 0, r.stderr[-3000:]
+        root = json.loads((d / "root.json").read_text())
+        upv = pm.un_b64_bincode(root["user_pvs_proof"])
+        batches.append(dict(dir=d, json=str(d / "root.json"), root=root, stmt=np.frombuffer(upv[:4 * 58], dtype=np.uint32), pvs=upv[4 * 58:4 * 58 + 32],
+                            openings=np.frombuffer(upv[4 * 58 + 32:], dtype=np.uint32),
+                            region=np.frombuffer(pm.un_b64_bincode(root["deferral_merkle_proofs"]), dtype=np.uint32)))
+    batch_vk = str(batches[0]["dir"] / "root.vk")
+    assert (batches[1]["dir"] / "root.vk").read_bytes() == (batches[0]["dir"] / "root.vk").read_bytes()   # one JOIN key for the batch app
+    r = pm.run_cli("program-commit", str(batch_elf), batch_vk, str(cfg))
+    assert r.returncode == 0, r.stderr
+    bpc = json.loads(r.stdout)
+    assert bpc["deferral_base"] == 0x00401000 and (bpc["exe"], bpc["vm"]) != (pc["exe"], pc["vm"])
+    bundle_elf = tmp_path / "bundle.elf"
+    bundle_elf.write_bytes(rv.elf_bytes(deferral_guest_program(), data=b"".join(int(x).to_bytes(4, "little") for x in bpc["exe"] + bpc["vm"])))
+    # a join key as the child key needs the child guest (where its deferral region sits)
+    r = prove_deferral(tmp_path / "no_elf", bundle_elf, batch_vk, [b["json"] for b in batches], [b["pvs"] for b in batches])
+    assert r.returncode != 0 and "join key" in r.stderr
+    out = tmp_path / "bundle"
+    r = prove_deferral(out, bundle_elf, batch_vk + "@" + str(batch_elf), [b["json"] for b in batches], [b["pvs"] for b in batches])
+    assert r.returncode == 0, r.stderr[-3000:]
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["children"] == 2 and info["verified"]
+    v = pm.run_cli("verify-guest", str(bundle_elf), str(out / "root.vk"), str(cfg), str(out / "root.json"))
+    assert v.returncode == 0, v.stderr
+    assert (out / "root.vk").read_bytes() != (batches[0]["dir"] / "root.vk").read_bytes()
+    root = json.loads((out / "root.json").read_text())
+    upv = pm.un_b64_bincode(root["user_pvs_proof"])
+    stmt, pv = np.frombuffer(upv[:4 * 58], dtype=np.uint32), upv[4 * 58:4 * 58 + 32]
+    assert int.from_bytes(pv[:4], "little") == 2 and int.from_bytes(pv[4:8], "little") == 2 + 1   # two batches; of two and of one chunk
+    cells = [np.array([b["pvs"][2 * j] | (b["pvs"][2 * j + 1] << 8) for j in range(16)], np.uint32) for b in batches]
+    want = ru.deferral_chain(np.zeros(8, np.uint32), [ru.deferral_claim(b["stmt"], c) for b, c in zip(batches, cells)])
+    assert stmt[50:58].tolist() == want.tolist() == info["deferral_state"]
+    claim0 = ru.deferral_claim(batches[0]["stmt"], cells[0])
+    assert claim0[1].tolist() == bpc["exe"] and claim0[2].tolist() == bpc["vm"]
+    # each batch's own chain is over ITS chunks (the bundle's node re-derives it from the batch's memory)
+    ccells = [np.array([k["pvs"][2 * j] | (k["pvs"][2 * j + 1] << 8) for j in range(16)], np.uint32) for k in chunks]
+    assert batches[0]["stmt"][50:58].tolist() == ru.deferral_chain(np.zeros(8, np.uint32), [ru.deferral_claim(k["stmt"], c) for k, c in zip(chunks, ccells)]).tolist()
+    # the bundle's deferral node: the oracle proves the same circuit and witness to the same bytes
+    key_airs, trailer = pm.read_vk(batch_vk)
+    region_index = ((2 << 26) | (bpc["deferral_base"] // 16)) >> 8
+    D = z.RecursionCircuit(PARAMS, key_airs, 4, stmt="deferral", region_index=region_index)
+
+    def aux_of(b, c, n_flags=None, region=None):
+        reg = b["region"] if region is None else region
+        n = int(reg[0]) | (int(reg[1]) << 16)
+        flags = np.array([1 if k < (n if n_flags is None else n_flags) else 0 for k in range(31)], np.uint32)
+        return np.concatenate([c, b["openings"][8:8 * 28], reg, flags])
+
+    proofs = [pm.un_b64_bincode(b["root"]["proof"]) for b in batches]
+    pvs = [[NOPV, NOPV, b["stmt"]] for b in batches]
+    st, dpv = D.witness(proofs, pvs, aux=[aux_of(b, c) for b, c in zip(batches, cells)])
+    assert st == 0, D.last_error()
+    assert dpv[8:].tolist() == want.tolist()
+    dj = json.loads((out / "deferral.json").read_text())
+    assert pm.un_b64_bincode(dj["proof"]) == ora.stark_prove(PARAMS, ru.node_instance(D, dpv)).tobytes()
+    # the circuit refuses: one claim too many / too few counted, a region cell that is not the one in the batch's memory
+    for n_flags in (1, 3):
+        st, _ = D.witness(proofs, pvs, aux=[aux_of(batches[0], cells[0], n_flags=n_flags), aux_of(batches[1], cells[1])])
+        assert st != 0
+    reg = batches[0]["region"].copy()
+    reg[2 * 40] ^= 1
+    st, _ = D.witness(proofs, pvs, aux=[aux_of(batches[0], cells[0], region=reg), aux_of(batches[1], cells[1])])
+    assert st != 0
+    # ... and so does the host before it: a batch proof whose region opening was tampered with
+    bad = dict(batches[0]["root"])
+    rb = bytearray(pm.un_b64_bincode(bad["deferral_merkle_proofs"]))
+    rb[4 * 2 * 40] ^= 1
+    bad["deferral_merkle_proofs"] = pm.b64_bincode(bytes(rb))
+    (tmp_path / "bad_batch.json").write_text(json.dumps(bad))
+    r = prove_deferral(tmp_path / "x1", bundle_elf, batch_vk + "@" + str(batch_elf), [str(tmp_path / "bad_batch.json"), batches[1]["json"]], [b["pvs"] for b in batches])
+    assert r.returncode != 0 and "does not open" in r.stderr
+    # a CHUNK proof is no child of the bundle (not under the batch's join key), and a batch proof none of a batch
+    r = prove_deferral(tmp_path / "x2", bundle_elf, batch_vk + "@" + str(batch_elf), [chunks[0]["json"]], [chunks[0]["pvs"]])
+    assert r.returncode != 0
+    r = prove_deferral(tmp_path / "x3", batch_elf, chunk_vk, [batches[0]["json"]], [batches[0]["pvs"]])
+    assert r.returncode != 0

@@ -274,9 +274,15 @@ int main(int argc, char** argv) {
             // task's input stream = [witness.bin as one item][the input commitments].  Writes root.json and root.vk (the JOIN key).
             const unsigned log_frame = (unsigned)atoi(argv[5]);
             UniversalProver up = UniversalProver::setup(ProverConfig{argv[2], argv[3]}, "deferral", 0, log_frame);
-            const VerifyingKey child_key = VerifyingKey::read(argv[6], read_app_config(argv[7]));
+            // (<child root.vk>@<child guest.elf>: a child app that itself defers -- its key is a join key, a BUNDLE over batches -- whose
+            // deferral region's place in its memory the deferral node hard-wires)
+            std::string child_vk_path = argv[6], child_elf;
+            if (const size_t at = child_vk_path.find('@'); at != std::string::npos) child_elf = child_vk_path.substr(at + 1), child_vk_path.resize(at);
+            const VerifyingKey child_key = VerifyingKey::read(child_vk_path, read_app_config(argv[7]));
+            if (child_key.join && child_elf.empty()) throw Error(Error::Setup, "the child key is a join key (the child app defers): give <child root.vk>@<child guest.elf>");
+            const uint32_t child_region = child_elf.empty() ? 0u : zkhip_vm::deferral_region_index(zkhip_vm::parse_exe(slurp(child_elf)));
             const auto t0 = std::chrono::steady_clock::now();
-            up.enable_deferral(child_key);
+            up.enable_deferral(child_key, 4, child_key.join ? child_region : 0u);
             std::vector<StarkProof> kids;
             for (int i = 9; i < argc; i++) {
                 const auto js = slurp(argv[i]);

@@ -58,7 +58,8 @@ class _V1Summary(C.Structure):
 class _RecursionStmt(C.Structure):
     _fields_ = [("n_state", C.c_size_t), ("start_air", C.POINTER(C.c_uint32)), ("start_idx", C.POINTER(C.c_uint32)),
                 ("end_air", C.POINTER(C.c_uint32)), ("end_idx", C.POINTER(C.c_uint32)), ("child_is_node", C.c_int),
-                ("uniform", C.c_int), ("min_log_height", C.c_uint * 2), ("n_leaf_shapes", C.c_size_t), ("app_id", C.POINTER(C.c_uint32))]
+                ("uniform", C.c_int), ("min_log_height", C.c_uint * 2), ("n_leaf_shapes", C.c_size_t), ("app_id", C.POINTER(C.c_uint32)),
+                ("region_index", C.c_uint32)]
 
 
 class Config(C.Structure):
@@ -1256,10 +1257,11 @@ class RecursionCircuit:
     GPU.  stmt: None (no chained state), "node" (the children are node proofs of the level below, per-depth keys), "uniform" (ONE key:
     the children are proofs of the leaf circuit or of this very circuit, their preprocessed commitments are values: witness_uniform) or
     dict(start=[(air, idx)..], end=[(air, idx)..]); uniform=True on a leaf circuit appends the [leaf | internal commitment] words (zero)
-    to its public values; min_log_height = (gate chip, Poseidon2 chip) pads."""
+    to its public values; min_log_height = (gate chip, Poseidon2 chip) pads; stmt "deferral": the deferral node over root proofs of a child
+    app's aggregation key (region_index != 0: over JOIN proofs, include/zkhip.h zkhip_recursion_stmt.region_index)."""
 
     def __init__(self, params, child_airs, max_children, stmt=None, uniform=False, min_log_height=(0, 0), n_leaf_shapes=1, app_id=None, _fork_of=None,
-                 _join_with=None):
+                 _join_with=None, region_index=0):
         self.lib = load_library()
         self.params, self.child_airs = tuple(params), child_airs
         self.n_leaf_shapes = int(_fork_of.n_leaf_shapes if _fork_of is not None else n_leaf_shapes)
@@ -1297,6 +1299,7 @@ class RecursionCircuit:
             st.child_is_node = 2
         elif stmt == "deferral":
             st.child_is_node = 3
+            st.region_index = int(region_index)   # != 0: the children are JOIN proofs (a bundle over batches)
         elif stmt:
             cols = [np.ascontiguousarray([x[k] for x in stmt[side]], dtype=np.uint32) for side in ("start", "end") for k in (0, 1)]
             keep2 = cols

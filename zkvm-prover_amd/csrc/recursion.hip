@@ -1011,6 +1011,7 @@ struct RecCore {
     int mode = 0;
     bool uniform = false;  // public values end with [leaf commitment (8) | internal commitment (8)]
     size_t n_leaf_shapes = 1;          // uniform node: how many leaf circuits (one per set of chips a segment may carry) its leaf children come from
+    uint32_t region_index = 0;         // deferral node over JOIN proofs: the node of a child's memory tree above its deferral region (0: plain roots)
     bool has_app_id = false;           // leaf: the statement's first 8 words are this constant instead of the child key's digest
     uint32_t app_id[8] = {};           // (Montgomery)
     size_t max_children = 0, n_state = 0;
@@ -1241,6 +1242,10 @@ static std::array<V, 2> key_commit_const(const ChildVk& vk) {
     return {cst(Ext{{dg[0], dg[1], dg[2], dg[3]}}), cst(Ext{{dg[4], dg[5], dg[6], dg[7]}})};
 }
 
+// deferral node: auxiliary words per child -- the opening of its public values (16 cells + 27 siblings), and for a JOIN child the opening
+// of its deferral region (2048 cells + 20 siblings; include/zkhip_vm_flow.hpp DEFERRAL_REGION_BYTES) and the claim-count flags
+constexpr size_t DEFERRAL_PV_AUX = 16 + 27 * 8, DEFERRAL_REGION_CELLS = 2048, DEFERRAL_REGION_SIBS = 20, DEFERRAL_MAX_CLAIMS = 31;
+
 // The statement logic behind the verified children, then the public-value binding and the parallelism check.
 static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min_log_height, zkhip_recursion** out) {
     RecCore& K = *R->k;
@@ -1318,8 +1323,10 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
                 const V* app = &pv[0];
                 const V pc_start = pv[8], pc_end = pv[8 + NSc];
                 const V *root0 = &pv[9], *root1 = &pv[9 + NSc], *lc = &pv[16 + 2 * NSc], *icv = &pv[24 + 2 * NSc];
-                const std::array<V, 2> got_ic = pack8(icv);
-                for (int k = 0; k < 2; k++) b.assert_eq(got_ic[k], ic[k]);
+                if (!K.region_index) {   // (a join pins its root's internal commitment itself)
+                    const std::array<V, 2> got_ic = pack8(icv);
+                    for (int k = 0; k < 2; k++) b.assert_eq(got_ic[k], ic[k]);
+                }
                 b.assert_zero(pc_end);
                 std::vector<V> aux(K.n_aux);
                 for (uint32_t i = 0; i < K.n_aux; i++) {
@@ -1338,6 +1345,56 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
                 }
                 const std::array<V, 2> r1 = pack8(root1);
                 for (int k = 0; k < 2; k++) b.assert_eq(cur[k], r1[k]);
+                if (K.region_index) {
+                    // The child is a JOIN proof (a batch under a bundle: a proof whose own guest deferred verification).  Its statement ends
+                    // with the chain its deferral node verified; what a verifier of the join does on the host -- open the guest's deferral
+                    // region (2048 cells = 256 blocks, one subtree of the memory tree) in the final memory root, read the n claims, chain
+                    // them, compare -- happens here: cells, the 20 siblings above the subtree and n one-hot-prefix flags are auxiliary inputs.
+                    // (A commitment word is read as the field element lo + 2^16 hi: a word >= p, which the host verifier refuses, is its
+                    // residue here.)
+                    const V* rc = &aux[DEFERRAL_PV_AUX];
+                    const V* rs = rc + DEFERRAL_REGION_CELLS;
+                    const V* fl = rs + 8 * DEFERRAL_REGION_SIBS;
+                    std::vector<std::array<V, 2>> level(DEFERRAL_REGION_CELLS / 8);
+                    for (size_t blk = 0; blk < level.size(); blk++) level[blk] = b.compress(pack8(rc + 8 * blk), z2);
+                    while (level.size() > 1) {
+                        std::vector<std::array<V, 2>> up(level.size() / 2);
+                        for (size_t i = 0; i < up.size(); i++) up[i] = b.compress(level[2 * i], level[2 * i + 1]);
+                        level = std::move(up);
+                    }
+                    std::array<V, 2> node = level[0];
+                    uint32_t ridx = K.region_index;
+                    for (size_t l = 0; l < DEFERRAL_REGION_SIBS; l++, ridx >>= 1) {
+                        const std::array<V, 2> sib = pack8(rs + 8 * l);
+                        node = (ridx & 1u) ? b.compress(sib, node) : b.compress(node, sib);
+                    }
+                    for (int k = 0; k < 2; k++) b.assert_eq(node[k], r1[k]);
+                    // word 0 of the region = n <= 31: flags f_0 >= f_1 >= ... with sum n; at least one claim (a join without claims is refused)
+                    b.assert_zero(rc[1]);
+                    V count = cst(ext_zero());
+                    for (size_t k = 0; k < DEFERRAL_MAX_CLAIMS; k++) {
+                        b.assert_bool(fl[k]);
+                        if (k > 0) b.assert_product_zero(fl[k], b.lin(0, fl[k - 1], V{}, b.NEG1, 0, V{}, 0, ext_one()));
+                        count = b.add(count, fl[k]);
+                    }
+                    b.assert_eq(count, rc[0]);
+                    b.assert_eq(fl[0], cst(ext_one()));
+                    std::array<V, 2> chain{zero, zero};
+                    const uint32_t two16 = to_monty(65536);
+                    for (size_t k = 0; k < DEFERRAL_MAX_CLAIMS; k++) {
+                        const V* cw = rc + 2 * (32 + 32 * k);   // the claim's 32 words as 64 cells
+                        std::array<V, 2> nx = chain;
+                        for (int c3 = 0; c3 < 3; c3++) {
+                            V e[8];
+                            for (int j = 0; j < 8; j++) e[j] = b.lin3(cw[2 * (8 * c3 + j)], b.ONE, cw[2 * (8 * c3 + j) + 1], two16, V{}, 0);
+                            nx = b.compress(nx, pack8(e));
+                        }
+                        for (int h = 0; h < 2; h++) nx = b.compress(nx, pack8(cw + 48 + 8 * h));
+                        for (int q = 0; q < 2; q++) chain[q] = b.select(fl[k], nx[q], chain[q]);
+                    }
+                    const std::array<V, 2> stated = pack8(&pv[50]);
+                    for (int k = 0; k < 2; k++) b.assert_eq(chain[k], stated[k]);
+                }
                 std::vector<Lane> stmt_lanes;
                 for (const V& v : pv) stmt_lanes.push_back(Lane{v, -1});
                 const std::array<V, 2> input_commit = b.sponge(stmt_lanes);
@@ -1560,9 +1617,12 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
     sp.child_is_node = K.mode == 1 || K.mode == 2;
     if (K.mode == 3) {
         // the children are ROOT proofs of a guest flow under one aggregation key: [app (8) | pc, memory root | pc, memory root | acc (8) | leaf (8) | internal (8)]
-        if (n_airs != 3 || vk.n_pvs[2] != 8 + 9 + 9 + 8 + 16 || !vk.has_prep[0] || !vk.has_prep[1] || !vk.has_prep[2]) return ZKHIP_ERR_INVALID;
+        // (region_index != 0: JOIN proofs -- the same 50 words followed by the chain (8) the join's deferral node verified)
+        K.region_index = stmt->region_index;
+        if (n_airs != 3 || vk.n_pvs[2] != 8 + 9 + 9 + 8 + 16 + (K.region_index ? 8u : 0u) || !vk.has_prep[0] || !vk.has_prep[1] || !vk.has_prep[2]) return ZKHIP_ERR_INVALID;
+        if (K.region_index >> (DEFERRAL_REGION_SIBS + 1)) return ZKHIP_ERR_INVALID;   // (a node of the level 20 below the root)
         K.n_state = 8;
-        K.n_aux = 16 + 27 * 8;
+        K.n_aux = DEFERRAL_PV_AUX + (K.region_index ? DEFERRAL_REGION_CELLS + 8 * DEFERRAL_REGION_SIBS + DEFERRAL_MAX_CLAIMS : 0);
     } else if (sp.child_is_node) {
         // the child is a node circuit: its last AIR is the public-value chip with [vk(8) start(K) end(K) acc(8)] (+ [leaf commitment (8) |
         // internal commitment (8)] under one key)
