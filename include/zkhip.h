@@ -794,9 +794,9 @@ typedef struct {
      * below): a deferral node (child_is_node = 3) with region_index != 0 takes JOIN proofs as children -- proofs of a guest that itself
      * deferred.  `child_airs` = the join circuit's key; a child's statement is a root's 50 words followed by the chain (8) its own
      * deferral node verified.  What the verifier of a join does on the host happens in the circuit: the child guest's deferral region
-     * (4 KiB = 256 blocks = one subtree of its memory tree, whose root is node `region_index` of the level 20 below the tree's root:
-     * ((2 << 26) | base / 16) >> 8) opens in the child's final memory root, its n claims chain to the stated value.  Auxiliary words
-     * per child then: 232 (public values) + 2048 cells + 20 x 8 siblings (bottom-up) + 31 flags (flag k = [k < n]). */
+     * (8 KiB = 512 blocks = one subtree of its memory tree, whose root is node `region_index` of the level 19 below the tree's root:
+     * ((2 << 26) | base / 16) >> 9) opens in the child's final memory root, its n claims chain to the stated value.  Auxiliary words
+     * per child then: 232 (public values) + 4096 cells + 19 x 8 siblings (bottom-up) + 63 flags (flag k = [k < n]). */
     uint32_t region_index;
 } zkhip_recursion_stmt;
 /* `airs[a].log_height` and `airs[a].prep_commit` are part of the child verifying key; program pointers are copied. */
@@ -806,7 +806,10 @@ void zkhip_recursion_destroy(zkhip_recursion *r);
 /* The JOIN of a guest that defers verification: child 0 = the guest's root proof under aggregation key A (its internal circuit's key,
  * commitments included), child 1 = the deferral node's proof (key B) whose chain starts at zero.  Public values: the root's statement
  * followed by the deferral accumulator (8): the verifier opens the guest's claims in the final memory root and hashes them.  Witness:
- * zkhip_recursion_witness with the two proofs. */
+ * zkhip_recursion_witness with the two proofs.  Child 1 may also be a FOLD of deferral nodes (a task with more children than one
+ * deferral node takes: up to 45 chunks in a batch, crates/types/batch/src/payload/v6.rs:10): a node circuit over deferral-node proofs
+ * (child_is_node = 0, the chain as its chained state: start = public values 0..7 of the deferral node, end = 8..15), whose 32 public
+ * values are [key digest | chain before | chain after | accumulator]. */
 int zkhip_recursion_build_join(const zkhip_params *params_a, const zkhip_air *airs_a, size_t n_airs_a, const zkhip_params *params_b,
                                const zkhip_air *airs_b, size_t n_airs_b, zkhip_recursion **out);
 /* a second user of the same circuit: wiring, programs and preprocessed traces shared, witness and device buffers its own (the levels of
@@ -843,7 +846,7 @@ int zkhip_recursion_witness_uniform(zkhip_recursion *r, const uint8_t *const *pr
                                     const uint32_t internal_commit[8], size_t n_present, uint32_t *node_pvs_out);
 /* the witness of a DEFERRAL node: child_aux[c] = zkhip_recursion_n_aux words (232): the 16 cells of the child's two public-value blocks, then
  * the 27 sibling digests above the block pair in its final memory root, bottom-up (JOIN children: + the region opening, see
- * zkhip_recursion_stmt.region_index: 2471 words); acc_start = the claim chain before this node */
+ * zkhip_recursion_stmt.region_index: 4543 words); acc_start = the claim chain before this node */
 int zkhip_recursion_witness_deferral(zkhip_recursion *r, const uint8_t *const *proofs, const size_t *proof_lens, const uint32_t *const *const *child_pvs,
                                      const uint32_t *child_aux, const uint32_t acc_start[8], size_t n_present, uint32_t *node_pvs_out);
 size_t zkhip_recursion_n_aux(const zkhip_recursion *r);

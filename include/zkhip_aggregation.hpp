@@ -1177,9 +1177,9 @@ struct DeferralInput {
     std::vector<uint8_t> public_values;
     std::vector<uint32_t> siblings;
     // a JOIN child (a proof of a guest that itself deferred: a batch under a bundle): the opening of ITS deferral region in its final
-    // memory root -- 2048 cells, then the 20 sibling digests above the region's subtree (StarkProof::deferral_merkle_proofs)
+    // memory root -- 4096 cells, then the 19 sibling digests above the region's subtree (StarkProof::deferral_merkle_proofs)
     std::vector<uint32_t> region;
-    static constexpr size_t REGION_CELLS = 2048, REGION_SIBS = 20, MAX_CLAIMS = 31;
+    static constexpr size_t REGION_CELLS = 4096, REGION_SIBS = 19, MAX_CLAIMS = 63;
     // from the StarkProof a guest flow returns: user_pvs_proof = [statement (50 words; a join's: 58) | 32 bytes | openings of both blocks (2 x 28 x 8)]
     static DeferralInput from_stark_proof(const StarkProof& sp, bool join = false) {
         const size_t n_stmt = join ? 58 : 50, n_open = 2 * 8 * 28;
@@ -1294,16 +1294,20 @@ public:
     // `child_key`: the CHILD app's aggregation key (crates/prover/src/prover/mod.rs:213 `child_prover.load_agg_vk()`); node_params: the
     // parameters the deferral node and the join are proven under (mod.rs:239 `internal_params_with_100_bits_security`)
     // `child_region_index`: for a child app that itself defers (its key is a JOIN key: a bundle over batches) -- where the CHILD guest's
-    // deferral region sits in its memory tree, ((2 << 26) | deferral_base(child exe) / 16) >> 8 (zkhip_vm::deferral_region_index)
+    // deferral region sits in its memory tree, ((2 << 26) | deferral_base(child exe) / 16) >> 9 (zkhip_vm::deferral_region_index)
+    // `max_nodes` > 1: a task may have more children than one deferral node takes (a batch holds up to 45 chunks: crates/types/batch/src/
+    // payload/v6.rs:10) -- up to max_nodes deferral nodes, each continuing the chain of the one before, and a FOLD over their proofs (a node
+    // circuit with the chain as its chained state); the join then verifies the fold, for EVERY task of this prover (one key per app)
     static std::unique_ptr<DeferralProver> setup(const VerifyingKey& child_key, const zkhip_params& node_params, int device = 0, size_t max_children = 4,
-                                                 uint32_t child_region_index = 0) {
+                                                 uint32_t child_region_index = 0, size_t max_nodes = 1) {
         if (!child_key.is_aggregation_key() || child_key.airs.size() != 3 || child_key.airs[2].n_pvs != (child_key.join ? 58u : 50u))
             throw Error(Error::Setup, "deferral: the child key is not the aggregation key of a guest flow");
         if (child_key.join != (child_region_index != 0))
             throw Error(Error::Setup, child_key.join ? "deferral: the child key is a join key (the child app defers): its deferral region's place in its memory is needed"
                                                      : "deferral: a region index for a child app that does not defer");
         std::unique_ptr<DeferralProver> p(new DeferralProver());
-        p->child_key_ = child_key, p->params_ = node_params, p->device_ = device, p->max_children_ = max_children, p->region_index_ = child_region_index;
+        if (max_nodes == 0 || max_nodes > 8) throw Error(Error::Setup, "deferral: 1..8 deferral nodes per task");
+        p->child_key_ = child_key, p->params_ = node_params, p->device_ = device, p->max_children_ = max_children, p->region_index_ = child_region_index, p->max_nodes_ = max_nodes;
         int rc = zkhip_ctx_create(device, &p->ctx_);
         if (rc != ZKHIP_OK) throw Error(Error::Keygen, "no gfx950 device for the HIP backend (zkhip_ctx_create returned " + std::to_string(rc) + ")");
         std::vector<zkhip_air> za = child_key.as_airs();
@@ -1313,10 +1317,20 @@ public:
         rc = zkhip_recursion_build(&child_key.params, za.data(), za.size(), max_children, &st, &p->def_.circ);
         if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("deferral: cannot build the deferral node: ") + zkhip_recursion_last_error(nullptr));
         p->keygen(p->def_);
+        if (max_nodes > 1) {   // the fold: children = deferral-node proofs, chained state = (chain before, chain after)
+            std::vector<zkhip_air> da = p->def_.vk.as_airs();
+            uint32_t air2[8], lo[8], hi[8];
+            for (uint32_t k = 0; k < 8; k++) air2[k] = 2, lo[k] = k, hi[k] = 8 + k;
+            zkhip_recursion_stmt fs{};
+            fs.n_state = 8, fs.start_air = air2, fs.start_idx = lo, fs.end_air = air2, fs.end_idx = hi, fs.child_is_node = 0;
+            rc = zkhip_recursion_build(&p->def_.vk.params, da.data(), da.size(), max_nodes, &fs, &p->fold_.circ);
+            if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("deferral: cannot build the fold of deferral nodes: ") + zkhip_recursion_last_error(nullptr));
+            p->keygen(p->fold_);
+        }
         return p;
     }
     ~DeferralProver() {
-        for (Node* n : {&def_, &join_}) {
+        for (Node* n : {&def_, &fold_, &join_}) {
             for (void* d : n->d_traces)
                 if (d) zkhip_free(ctx_, d);
             if (n->pk) zkhip_pk_destroy(ctx_, n->pk);
@@ -1326,8 +1340,10 @@ public:
     }
     DeferralProver(const DeferralProver&) = delete;
     DeferralProver& operator=(const DeferralProver&) = delete;
-    size_t max_children() const { return max_children_; }
+    size_t max_children() const { return max_children_ * max_nodes_; }   // per task
+    size_t max_nodes() const { return max_nodes_; }
     uint32_t child_region_index() const { return region_index_; }
+    const VerifyingKey& join_child_vk() const { return max_nodes_ > 1 ? fold_.vk : def_.vk; }   // what the join verifies beside the root
     const VerifyingKey& child_key() const { return child_key_; }
     const VerifyingKey& deferral_vk() const { return def_.vk; }
     // crates/integration/src/lib.rs:461-514: what the task and the prover need from the child proofs -- the input commitments (they go
@@ -1339,7 +1355,7 @@ public:
     };
     Data compute_deferral_data(const std::vector<const StarkProof*>& proofs) const {
         if (proofs.empty()) throw Error(Error::GenProof, "no child proofs to compute deferral data");
-        if (proofs.size() > max_children_) throw Error(Error::GenProof, "deferral: " + std::to_string(proofs.size()) + " child proofs, the deferral node takes " + std::to_string(max_children_));
+        if (proofs.size() > max_children()) throw Error(Error::GenProof, "deferral: " + std::to_string(proofs.size()) + " child proofs, this prover's deferral nodes take " + std::to_string(max_children()));
         Data d;
         for (size_t i = 0; i < proofs.size(); i++) {
             DeferralInput in = DeferralInput::from_stark_proof(*proofs[i], child_key_.join);
@@ -1357,33 +1373,57 @@ public:
         }
         return d;
     }
-    // the deferral node over the child roots: witness (host) + traces and proof (device); self-verified
+    // the deferral node(s) over the child roots: witness (host) + traces and proof (device); self-verified.  With max_nodes > 1: the
+    // children in groups of max_children per node, every node's chain starting where the one before ended, then the fold over the nodes
     ChildProof prove_deferral(const std::vector<DeferralInput>& inputs) {
-        if (inputs.empty() || inputs.size() > max_children_) throw Error(Error::GenProof, "deferral: 1.." + std::to_string(max_children_) + " child proofs");
+        if (inputs.empty() || inputs.size() > max_children()) throw Error(Error::GenProof, "deferral: 1.." + std::to_string(max_children()) + " child proofs");
+        std::vector<ChildProof> nodes;
+        uint32_t acc[8] = {};
+        for (size_t g = 0; g < inputs.size(); g += max_children_) {
+            const size_t n = std::min(max_children_, inputs.size() - g);
+            std::vector<const uint8_t*> proofs;
+            std::vector<size_t> lens;
+            std::vector<std::vector<const uint32_t*>> rows(n);
+            std::vector<const uint32_t* const*> pv_ptrs;
+            std::vector<uint32_t> aux;
+            for (size_t c = 0; c < n; c++) {
+                const DeferralInput& in = inputs[g + c];
+                proofs.push_back(in.root.proof.data()), lens.push_back(in.root.proof.size());
+                for (const auto& v : in.root.pvs) rows[c].push_back(v.data());
+                pv_ptrs.push_back(rows[c].data());
+                const std::vector<uint32_t> a = in.aux();
+                aux.insert(aux.end(), a.begin(), a.end());
+            }
+            std::vector<uint32_t> npv(zkhip_recursion_n_pvs(def_.circ));
+            int rc = zkhip_recursion_witness_deferral(def_.circ, proofs.data(), lens.data(), pv_ptrs.data(), aux.data(), acc, n, npv.data());
+            if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("deferral: ") + zkhip_recursion_last_error(def_.circ));
+            std::copy(npv.begin() + 8, npv.begin() + 16, acc);   // the next node continues here
+            nodes.push_back(prove(def_, std::move(npv)));
+        }
+        if (max_nodes_ == 1) return std::move(nodes[0]);
         std::vector<const uint8_t*> proofs;
         std::vector<size_t> lens;
-        std::vector<std::vector<const uint32_t*>> rows(inputs.size());
+        std::vector<std::vector<const uint32_t*>> rows(nodes.size());
         std::vector<const uint32_t* const*> pv_ptrs;
-        std::vector<uint32_t> aux;
-        for (size_t c = 0; c < inputs.size(); c++) {
-            proofs.push_back(inputs[c].root.proof.data()), lens.push_back(inputs[c].root.proof.size());
-            for (const auto& v : inputs[c].root.pvs) rows[c].push_back(v.data());
+        for (size_t c = 0; c < nodes.size(); c++) {
+            proofs.push_back(nodes[c].proof.data()), lens.push_back(nodes[c].proof.size());
+            for (const auto& v : nodes[c].pvs) rows[c].push_back(v.data());
             pv_ptrs.push_back(rows[c].data());
-            const std::vector<uint32_t> a = inputs[c].aux();
-            aux.insert(aux.end(), a.begin(), a.end());
         }
-        const uint32_t zero[8] = {};
-        std::vector<uint32_t> npv(zkhip_recursion_n_pvs(def_.circ));
-        int rc = zkhip_recursion_witness_deferral(def_.circ, proofs.data(), lens.data(), pv_ptrs.data(), aux.data(), zero, inputs.size(), npv.data());
-        if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("deferral: ") + zkhip_recursion_last_error(def_.circ));
-        return prove(def_, std::move(npv));
+        std::vector<uint32_t> fpv(zkhip_recursion_n_pvs(fold_.circ));
+        int rc = zkhip_recursion_witness(fold_.circ, proofs.data(), lens.data(), pv_ptrs.data(), nodes.size(), fpv.data());
+        if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("deferral fold: ") + zkhip_recursion_last_error(fold_.circ));
+        last_nodes_ = std::move(nodes);
+        return prove(fold_, std::move(fpv));
     }
+    const std::vector<ChildProof>& last_node_proofs() const { return last_nodes_; }   // (max_nodes > 1: the deferral nodes beneath the last fold)
     // the join for the parent's own aggregation key (built once per parent key)
     const VerifyingKey& join_vk(const VerifyingKey& own_key) {
         if (!join_.circ) {
             if (!own_key.is_aggregation_key()) throw Error(Error::Setup, "deferral: the parent key is not an aggregation key");
-            std::vector<zkhip_air> za = own_key.as_airs(), zb = def_.vk.as_airs();
-            int rc = zkhip_recursion_build_join(&own_key.params, za.data(), za.size(), &def_.vk.params, zb.data(), zb.size(), &join_.circ);
+            std::vector<zkhip_air> za = own_key.as_airs(), zb = join_child_vk().as_airs();
+            const zkhip_params& pb = join_child_vk().params;
+            int rc = zkhip_recursion_build_join(&own_key.params, za.data(), za.size(), &pb, zb.data(), zb.size(), &join_.circ);
             if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("deferral: cannot build the join: ") + zkhip_recursion_last_error(nullptr));
             keygen(join_);
             // what a root under the join must state beneath it: the parent app (its internal commitment is pinned inside the join)
@@ -1418,8 +1458,10 @@ private:
     int device_ = 0;
     size_t max_children_ = 4;
     uint32_t region_index_ = 0;
+    size_t max_nodes_ = 1;
     zkhip_ctx* ctx_ = nullptr;
-    Node def_, join_;
+    Node def_, fold_, join_;
+    std::vector<ChildProof> last_nodes_;
     void check(int rc) const {
         if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("deferral: ") + zkhip_last_error(ctx_));
     }

@@ -227,6 +227,9 @@ struct FlowOptions {
                                       // pipeline are proven one after the other -- with one pipeline the tree lags behind the segment
                                       // lanes and is finished alone on the GPU, a 21 ms proof at a time (measured 1 / 2 / 3 / 4:
                                       // DESIGN.md 15)                                                                     [ZKHIP_AGG_SLOTS=n]
+    unsigned deferral_children = 4;   // child proofs per deferral node (<= 8), and deferral nodes per task (<= 8; more than one: every
+    unsigned deferral_nodes = 1;      // task's nodes are FOLDED before the join -- 6 x 8 covers the reference's 45 chunks per batch)
+                                      //                                                   [ZKHIP_DEFERRAL_CHILDREN, ZKHIP_DEFERRAL_NODES]
     bool trace_tree = false;          // a line per event of the aggregation tree on stderr (a measurement aid)           [ZKHIP_TREE_TRACE=1]
     std::vector<int> devices;         // GPUs of the node the flow spreads over (empty = the prover's device)             [ZKHIP_DEVICES=0,1,..]
     static FlowOptions from_env() {
@@ -238,6 +241,8 @@ struct FlowOptions {
         o.per_depth_keys = getenv("ZKHIP_AGG_PER_DEPTH_KEYS") != nullptr;
         o.balanced_tree = getenv("ZKHIP_TREE_BALANCED") != nullptr;
         o.trace_tree = getenv("ZKHIP_TREE_TRACE") != nullptr;
+        if (const char* e = getenv("ZKHIP_DEFERRAL_CHILDREN")) o.deferral_children = (unsigned)std::min(8, std::max(1, atoi(e)));
+        if (const char* e = getenv("ZKHIP_DEFERRAL_NODES")) o.deferral_nodes = (unsigned)std::min(8, std::max(1, atoi(e)));
         if (const char* e = getenv("ZKHIP_AGG_SLOTS")) o.agg_slots = (unsigned)std::min(8, std::max(1, atoi(e)));
         if (const char* e = getenv("ZKHIP_DEVICES")) {
             std::stringstream ss(e);

@@ -474,7 +474,7 @@ struct GuestStark {
     uint32_t entry_pc = 0;
     // openings of the two public-value blocks (address space 3) in the final memory root: sibling digests bottom-up, per block
     std::vector<uint32_t> pv_openings;
-    // the guest's deferral region in the final memory: its 2048 cells, then the 20 sibling digests above its subtree (deferral_base)
+    // the guest's deferral region in the final memory: its 4096 cells, then the 19 sibling digests above its subtree (deferral_base)
     std::vector<uint32_t> deferral_opening;
     uint64_t execution_mills = 0, segment_proving_mills = 0, aggregation_mills = 0;
     uint64_t aggregation_setup_wait_mills = 0;   // waiting for the aggregation circuits / keys of this app to be built (first task only)
@@ -516,15 +516,15 @@ inline bool check_public_values(const std::vector<uint8_t>& pv, const std::vecto
 
 // ---- the deferral region (crates/prover/src/prover/mod.rs:222-232: the reference reserves an address space of 2^25 cells for the deferral
 // state; crates/types/src/proof.rs `deferral_merkle_proofs`) ----
-// A guest that defers verification writes its claims into the 4 KiB (256 blocks = one subtree of the memory tree) that follow its
-// initial data image, 4 KiB-aligned: word 0 = the number of claims n, claim k = the 32 words at word 32 + 32 k
-// [input commitment (8) | exe commitment (8) | vm commitment (8) | the child's 32 public-value bytes].  Up to 31 claims.
-constexpr uint32_t DEFERRAL_REGION_BYTES = 4096, DEFERRAL_MAX_CLAIMS = 31, DEFERRAL_SUBTREE_LEVELS = 8;
+// A guest that defers verification writes its claims into the 8 KiB (512 blocks = one subtree of the memory tree) that follow its
+// initial data image, 8 KiB-aligned: word 0 = the number of claims n, claim k = the 32 words at word 32 + 32 k
+// [input commitment (8) | exe commitment (8) | vm commitment (8) | the child's 32 public-value bytes].  Up to 63 claims (a batch holds up to 45 chunks: crates/types/batch/src/payload/v6.rs:10).
+constexpr uint32_t DEFERRAL_REGION_BYTES = 8192, DEFERRAL_MAX_CLAIMS = 63, DEFERRAL_SUBTREE_LEVELS = 9;
 inline uint32_t deferral_base(const Exe& exe) {
     const uint64_t end = (uint64_t)exe.data_base + exe.data.size();
     return (uint32_t)((end + DEFERRAL_REGION_BYTES - 1) / DEFERRAL_REGION_BYTES * DEFERRAL_REGION_BYTES);
 }
-// the node of the memory tree above the region's 256 blocks, on the level DEFERRAL_SUBTREE_LEVELS above the leaves (what a deferral node
+// the node of the memory tree above the region's 512 blocks, on the level DEFERRAL_SUBTREE_LEVELS above the leaves (what a deferral node
 // over proofs of THIS guest hard-wires: zkhip_recursion_stmt.region_index)
 inline uint32_t deferral_region_index(const Exe& exe) { return ((2u << vmc::LABEL_BITS) | (deferral_base(exe) / 16)) >> DEFERRAL_SUBTREE_LEVELS; }
 inline bool has_deferral_region(const Exe& exe) { return (uint64_t)deferral_base(exe) + DEFERRAL_REGION_BYTES <= (uint64_t)exe.data_base + exe.memory_bytes; }
@@ -1020,13 +1020,14 @@ public:
     // aggregation key is all that is needed: mod.rs:213 `child_prover.load_agg_vk()`), and every proof it returns is a join.
     // `child_region_index` (a child app that itself defers -- its key is a join key: this prover's guest is a bundle over batches):
     // zkhip_vm::deferral_region_index(child exe)
-    void enable_deferral(const VerifyingKey& child_agg_key, size_t max_children = 4, uint32_t child_region_index = 0) {
+    // `max_nodes` > 1: up to max_nodes deferral nodes of max_children each per task, folded (DeferralProver::setup)
+    void enable_deferral(const VerifyingKey& child_agg_key, size_t max_children = 4, uint32_t child_region_index = 0, size_t max_nodes = 1) {
         if (!zkhip_vm::has_deferral_region(exe_)) throw Error(Error::Setup, "enable_deferral: the guest's memory has no room for the deferral region");
         reset();   // (mod.rs:265 `self.reset()`: the keys are rebuilt with deferral)
-        deferral_ = DeferralProver::setup(child_agg_key, params_, device_, max_children, child_region_index);
+        deferral_ = DeferralProver::setup(child_agg_key, params_, device_, max_children, child_region_index, max_nodes);
     }
-    void enable_deferral(UniversalProver& child_prover, size_t max_children = 4) {
-        enable_deferral(child_prover.get_agg_vk(), max_children, child_prover.deferral_enabled() ? zkhip_vm::deferral_region_index(child_prover.exe()) : 0u);
+    void enable_deferral(UniversalProver& child_prover, size_t max_children = 4, size_t max_nodes = 1) {
+        enable_deferral(child_prover.get_agg_vk(), max_children, child_prover.deferral_enabled() ? zkhip_vm::deferral_region_index(child_prover.exe()) : 0u, max_nodes);
     }
     bool deferral_enabled() const { return (bool)deferral_; }
     // crates/integration/src/lib.rs:461-514 `compute_deferral_data(child_prover, cached_commit, proofs)`

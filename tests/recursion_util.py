@@ -164,18 +164,18 @@ def merkle_of_blocks(cells):
 
 
 def memory_root_with_public_values_and_region(pv_bytes, region_cells, region_base, rng):
-    """A final memory root in which BOTH the 32 public-value bytes (address space 3, blocks 0 and 1) and a guest's 4 KiB deferral region
-    (address space 2, the 256 blocks from byte address `region_base`: include/zkhip_vm_flow.hpp `check_deferral_region`) open: random
+    """A final memory root in which BOTH the 32 public-value bytes (address space 3, blocks 0 and 1) and a guest's 8 KiB deferral region
+    (address space 2, the 512 blocks from byte address `region_base`: include/zkhip_vm_flow.hpp `check_deferral_region`) open: random
     siblings up to the two address spaces' subtrees, which are siblings one level below the root's right child.
-    Returns (root, pv cells[16], pv siblings[27][8], region siblings[20][8], region index)."""
+    Returns (root, pv cells[16], pv siblings[27][8], region siblings[19][8], region index)."""
     region_cells = np.asarray(region_cells, np.uint32)
-    assert region_cells.size == 2048
+    assert region_cells.size == 4096
     cells = np.array([pv_bytes[2 * j] | (pv_bytes[2 * j + 1] << 8) for j in range(16)], np.uint32)
     pv_sibs = rng.integers(0, P, size=(27, 8), dtype=np.uint64).astype(np.uint32)
-    reg_sibs = rng.integers(0, P, size=(20, 8), dtype=np.uint64).astype(np.uint32)
-    region_index = ((2 << 26) | (region_base // 16)) >> 8
+    reg_sibs = rng.integers(0, P, size=(19, 8), dtype=np.uint64).astype(np.uint32)
+    region_index = ((2 << 26) | (region_base // 16)) >> 9
     cur, idx = merkle_of_blocks(region_cells), region_index
-    for l in range(18):
+    for l in range(17):
         cur = compress(reg_sibs[l], cur) if idx & 1 else compress(cur, reg_sibs[l])
         idx >>= 1
     assert idx == 2
@@ -187,22 +187,22 @@ def memory_root_with_public_values_and_region(pv_bytes, region_cells, region_bas
     assert idx == 3
     a3 = cur
     s0 = pv_sibs[26]
-    reg_sibs[18], reg_sibs[19], pv_sibs[25] = a3, s0, a2
+    reg_sibs[17], reg_sibs[18], pv_sibs[25] = a3, s0, a2
     root = compress(s0, compress(a2, a3))
     return root, cells, pv_sibs, reg_sibs, region_index
 
 
 def deferral_region_cells(claims):
-    """The 2048 cells of a deferral region holding `claims` (each the five chunks of deferral_claim): word 0 = their number, claim k = the
+    """The 4096 cells of a deferral region holding `claims` (each the five chunks of deferral_claim): word 0 = their number, claim k = the
     32 words from word 32 + 32 k -- three commitments (a field element per word), then the public values (two cells per word)."""
-    words = np.zeros(1024, np.uint32)
+    words = np.zeros(2048, np.uint32)
     words[0] = len(claims)
     for k, (ic, exe, vm, c0, c1) in enumerate(claims):
         w = words[32 + 32 * k:64 + 32 * k]
         w[0:8], w[8:16], w[16:24] = ic, exe, vm
         pv = np.concatenate([c0, c1]).astype(np.uint32)
         w[24:32] = pv[0::2] | (pv[1::2] << 16)
-    cells = np.zeros(2048, np.uint32)
+    cells = np.zeros(4096, np.uint32)
     cells[0::2], cells[1::2] = words & 0xFFFF, words >> 16
     return cells
 

@@ -22,7 +22,7 @@ import recursion_util as ru
 
 PARAMS = (1, 0, 4, 3, 3)
 NOPV = ru.NOPV
-REGION_BASE = 0x00401000
+REGION_BASE = 0x00402000
 
 
 @pytest.fixture(scope="module")
@@ -162,7 +162,7 @@ def test_deferral_over_join_children(ora, flows):
     def aux(x, n_flags=None, region=None):
         reg = x["region"] if region is None else region
         n = int(reg[0]) if n_flags is None else n_flags
-        return np.concatenate([x["aux"], reg, x["region_sibs"].reshape(-1), np.array([1 if k < n else 0 for k in range(31)], np.uint32)])
+        return np.concatenate([x["aux"], reg, x["region_sibs"].reshape(-1), np.array([1 if k < n else 0 for k in range(63)], np.uint32)])
 
     def wit(x, **kw):
         return D2.witness([x["jproof"]], [[NOPV, NOPV, x["jpv"]]], aux=[aux(x, **kw)])
@@ -190,3 +190,43 @@ def test_deferral_over_join_children(ora, flows):
     # ... and one that states none
     none = batch([])
     assert D2.witness([none["jproof"]], [[NOPV, NOPV, none["jpv"]]], aux=[aux(none)])[0] == -7
+
+
+def test_fold_of_deferral_nodes(ora, flows):
+    """A task with more children than one deferral node takes (a batch holds up to 45 chunks): several deferral nodes, each continuing the
+    chain of the one before, a FOLD over their proofs (a node circuit with the chain as its chained state), the join over the fold."""
+    kids, ivk = flows["kids"], flows["ivk"]
+    claims = [ru.deferral_claim(k["pvs"], k["cells"]) for k in kids]
+    zero = np.zeros(8, np.uint32)
+    mid, end = ru.deferral_chain(zero, claims[:2]), ru.deferral_chain(zero, claims)
+    D = z.RecursionCircuit(PARAMS, ivk, 2, stmt="deferral")
+    st, d0 = _witness(D, kids[:2])
+    assert st == 0 and d0[:8].tolist() == [0] * 8 and d0[8:].tolist() == mid.tolist()
+    n0 = ru.node_instance(D, d0)
+    p0, dvk = ora.stark_prove(PARAMS, n0).tobytes(), ru.verifying(PARAMS, n0)
+    st, d1 = _witness(D, kids[2:], acc_start=mid)
+    assert st == 0 and d1[:8].tolist() == mid.tolist() and d1[8:].tolist() == end.tolist()
+    p1 = ora.stark_prove(PARAMS, ru.node_instance(D, d1)).tobytes()
+    F = z.RecursionCircuit(PARAMS, dvk, 3, stmt=dict(start=[(2, k) for k in range(8)], end=[(2, 8 + k) for k in range(8)]))
+    assert F.n_pvs == 32
+    st, fpv = F.witness([p0, p1], [[NOPV, NOPV, d0], [NOPV, NOPV, d1]])
+    assert st == 0, F.last_error()
+    assert fpv[8:16].tolist() == [0] * 8 and fpv[16:24].tolist() == end.tolist()
+    fnode = ru.node_instance(F, fpv)
+    for a in fnode[:2]:
+        assert air.check_trace(a["program"], a["trace"], a["pvs"], a["prep"]) == []
+    fproof, fvk = ora.stark_prove(PARAMS, fnode).tobytes(), ru.verifying(PARAMS, fnode)
+    assert z.verify(PARAMS, fvk, [NOPV, NOPV, fpv], fproof) == 0
+    # nodes the other way round: the chain does not continue
+    assert F.witness([p1, p0], [[NOPV, NOPV, d1], [NOPV, NOPV, d0]])[0] == -7
+    # the join over (root, fold): the statement ends with the chain over all three children
+    J = z.RecursionCircuit.join(PARAMS, ivk, PARAMS, fvk)
+    g = kids[0]
+    st, jpv = J.witness([g["proof"], fproof], [[NOPV, NOPV, g["pvs"]], [NOPV, NOPV, fpv]])
+    assert st == 0, J.last_error()
+    assert jpv.size == 58 and jpv[:50].tolist() == g["pvs"].tolist() and jpv[50:].tolist() == end.tolist()
+    # a fold whose chain does not start at zero (the second node alone) cannot be joined
+    st, f1 = F.witness([p1], [[NOPV, NOPV, d1]])
+    assert st == 0 and f1[8:16].tolist() == mid.tolist()
+    f1proof = ora.stark_prove(PARAMS, ru.node_instance(F, f1)).tobytes()
+    assert J.witness([g["proof"], f1proof], [[NOPV, NOPV, g["pvs"]], [NOPV, NOPV, f1]])[0] == -7

@@ -56,7 +56,7 @@ def test_three_children_one_parent_root(ora, tmp_path):
     parent_elf = tmp_path / "parent.elf"
     parent_elf.write_bytes(rv.elf_bytes(parent, data=data))
     r = pm.run_cli("program-commit", str(parent_elf), child_vk, str(cfg))     # (only for the region's address: it follows the data image)
-    assert json.loads(r.stdout)["deferral_base"] == 0x00401000
+    assert json.loads(r.stdout)["deferral_base"] == 0x00402000
     witness = tmp_path / "witness.bin"
     witness.write_bytes(b"".join(k["pvs"] for k in kids))
     out = tmp_path / "parent"
@@ -139,7 +139,7 @@ def test_three_children_one_parent_root(ora, tmp_path):
         (tmp_path / name).write_text(json.dumps(sp))
         return str(tmp_path / name)
 
-    for name, field, pos in (("t1.json", "deferral_merkle_proofs", 4 * 64 + 1), ("t2.json", "deferral_merkle_proofs", 4 * 2048 + 5),
+    for name, field, pos in (("t1.json", "deferral_merkle_proofs", 4 * 64 + 1), ("t2.json", "deferral_merkle_proofs", 4 * 4096 + 5),
                              ("t3.json", "deferral_merkle_proofs", 0), ("t4.json", "user_pvs_proof", 4 * 52)):
         assert pm.run_cli("verify-guest", str(parent_elf), str(out / "root.vk"), str(cfg), variant(name, field, pos)).returncode != 0, name
     # the parent's proof does not verify under the CHILD's key, nor a child's under the parent's
@@ -188,7 +188,7 @@ def test_bundle_over_batches_three_layers(ora, tmp_path):
     r = pm.run_cli("program-commit", str(batch_elf), batch_vk, str(cfg))
     assert r.returncode == 0, r.stderr
     bpc = json.loads(r.stdout)
-    assert bpc["deferral_base"] == 0x00401000 and (bpc["exe"], bpc["vm"]) != (pc["exe"], pc["vm"])
+    assert bpc["deferral_base"] == 0x00402000 and (bpc["exe"], bpc["vm"]) != (pc["exe"], pc["vm"])
     bundle_elf = tmp_path / "bundle.elf"
     bundle_elf.write_bytes(rv.elf_bytes(deferral_guest_program(), data=b"".join(int(x).to_bytes(4, "little") for x in bpc["exe"] + bpc["vm"])))
     # a join key as the child key needs the child guest (where its deferral region sits)
@@ -216,13 +216,13 @@ def test_bundle_over_batches_three_layers(ora, tmp_path):
     assert batches[0]["stmt"][50:58].tolist() == ru.deferral_chain(np.zeros(8, np.uint32), [ru.deferral_claim(k["stmt"], c) for k, c in zip(chunks, ccells)]).tolist()
     # the bundle's deferral node: the oracle proves the same circuit and witness to the same bytes
     key_airs, trailer = pm.read_vk(batch_vk)
-    region_index = ((2 << 26) | (bpc["deferral_base"] // 16)) >> 8
+    region_index = ((2 << 26) | (bpc["deferral_base"] // 16)) >> 9
     D = z.RecursionCircuit(PARAMS, key_airs, 4, stmt="deferral", region_index=region_index)
 
     def aux_of(b, c, n_flags=None, region=None):
         reg = b["region"] if region is None else region
         n = int(reg[0]) | (int(reg[1]) << 16)
-        flags = np.array([1 if k < (n if n_flags is None else n_flags) else 0 for k in range(31)], np.uint32)
+        flags = np.array([1 if k < (n if n_flags is None else n_flags) else 0 for k in range(63)], np.uint32)
         return np.concatenate([c, b["openings"][8:8 * 28], reg, flags])
 
     proofs = [pm.un_b64_bincode(b["root"]["proof"]) for b in batches]
@@ -253,3 +253,62 @@ def test_bundle_over_batches_three_layers(ora, tmp_path):
     assert r.returncode != 0
     r = prove_deferral(tmp_path / "x3", batch_elf, chunk_vk, [batches[0]["json"]], [batches[0]["pvs"]])
     assert r.returncode != 0
+
+
+def test_a_batch_of_more_children_than_one_deferral_node_takes(tmp_path):
+    """A batch holds up to 45 chunks (crates/types/batch/src/payload/v6.rs:10).  With FlowOptions::deferral_nodes > 1 a prover's tasks
+    run up to that many deferral nodes, each continuing the chain of the one before, and FOLD them; the join verifies the fold.  Five
+    chunk proofs under deferral nodes of two children: three nodes, one fold, one join -- the statement's chain is the chain over all five,
+    in order; the same prover's key serves a task with a single child; six children are refused."""
+    import os
+
+    cfg = tmp_path / "openvm.toml"
+    cfg.write_text(pm.TOML.format(*PARAMS))
+    chunk_elf = tmp_path / "chunk.elf"
+    chunk_elf.write_bytes(rv.elf_bytes(fib_program()))
+    ns = (60, 70, 80, 90, 100)
+    chunks = [prove_child(tmp_path / ("c%d" % i), chunk_elf, cfg, n) for i, n in enumerate(ns)]
+    chunk_vk = str(chunks[0]["dir"] / "root.vk")
+    pc = json.loads(pm.run_cli("program-commit", str(chunk_elf), chunk_vk, str(cfg)).stdout)
+    batch_elf = tmp_path / "batch.elf"
+    batch_elf.write_bytes(rv.elf_bytes(deferral_guest_program(), data=b"".join(int(x).to_bytes(4, "little") for x in pc["exe"] + pc["vm"])))
+    env = dict(os.environ, ZKHIP_DEFERRAL_CHILDREN="2", ZKHIP_DEFERRAL_NODES="3")
+
+    def prove(outdir, ks):
+        outdir.mkdir()
+        (outdir / "witness.bin").write_bytes(b"".join(k["pvs"] for k in ks))
+        return subprocess.run([pm.CLI, "prove-deferral", str(batch_elf), str(cfg), str(outdir), "9", chunk_vk, str(cfg), str(outdir / "witness.bin")] + [k["json"] for k in ks],
+                              capture_output=True, text=True, env=env)
+
+    out = tmp_path / "five"
+    r = prove(out, chunks)
+    assert r.returncode == 0, r.stderr[-3000:]
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["children"] == 5 and info["verified"]
+    assert pm.run_cli("verify-guest", str(batch_elf), str(out / "root.vk"), str(cfg), str(out / "root.json")).returncode == 0
+    upv = pm.un_b64_bincode(json.loads((out / "root.json").read_text())["user_pvs_proof"])
+    stmt, pv = np.frombuffer(upv[:4 * 58], dtype=np.uint32), upv[4 * 58:4 * 58 + 32]
+    fib = lambda n: (lambda f: [f := (f[1], (f[0] + f[1]) & 0xFFFFFFFF) for _ in range(n)][-1][0])((0, 1))   # noqa: E731
+    assert int.from_bytes(pv[:4], "little") == 5 and int.from_bytes(pv[4:8], "little") == sum(fib(n) for n in ns) & 0xFFFFFFFF
+    cells = [np.array([k["pvs"][2 * j] | (k["pvs"][2 * j + 1] << 8) for j in range(16)], np.uint32) for k in chunks]
+    want = ru.deferral_chain(np.zeros(8, np.uint32), [ru.deferral_claim(k["stmt"], c) for k, c in zip(chunks, cells)])
+    assert stmt[50:58].tolist() == want.tolist() == info["deferral_state"]
+    # what the join verified beside the root is a FOLD: [key digest | chain before = 0 | chain after | accumulator]
+    fold = np.frombuffer(pm.un_b64_bincode(json.loads((out / "deferral.json").read_text())["user_pvs_proof"]), dtype=np.uint32)
+    assert fold.size == 32 and fold[8:16].tolist() == [0] * 8 and fold[16:24].tolist() == want.tolist()
+    # one child under the same prover configuration: the same key
+    one = tmp_path / "one"
+    r = prove(one, chunks[:1])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (one / "root.vk").read_bytes() == (out / "root.vk").read_bytes()
+    assert pm.run_cli("verify-guest", str(batch_elf), str(out / "root.vk"), str(cfg), str(one / "root.json")).returncode == 0
+    # ... which is not the key of a prover without the fold
+    plain = tmp_path / "plain"
+    plain.mkdir()
+    (plain / "witness.bin").write_bytes(chunks[0]["pvs"])
+    r = subprocess.run([pm.CLI, "prove-deferral", str(batch_elf), str(cfg), str(plain), "9", chunk_vk, str(cfg), str(plain / "witness.bin"), chunks[0]["json"]],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and (plain / "root.vk").read_bytes() != (out / "root.vk").read_bytes()
+    # seven children: more than 3 x 2
+    r = prove(tmp_path / "seven", chunks + chunks[:2])
+    assert r.returncode != 0 and "take 6" in r.stderr

@@ -312,7 +312,7 @@ def fp2_data():
 DEFERRAL_DATA_BYTES = 64   # the batch-like guest's data segment: the child app's exe commitment (8 words), vm commitment (8 words)
 
 
-def deferral_guest_program(deferral_base=0x00401000):
+def deferral_guest_program(deferral_base=0x00402000):
     """A guest that DEFERS the verification of its children (the reference's batch guest: crates/types/circuit/src/lib.rs:137-154
     `verify_stark::<0>(input_commit, &expected)` once per aggregated proof).  Input stream (ProvingTask::build_guest_input): one witness
     item = the children's 32 public-value bytes each, then the input commitments [count | 8 words each].  For child k it writes the claim

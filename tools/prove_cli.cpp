@@ -282,7 +282,7 @@ int main(int argc, char** argv) {
             if (child_key.join && child_elf.empty()) throw Error(Error::Setup, "the child key is a join key (the child app defers): give <child root.vk>@<child guest.elf>");
             const uint32_t child_region = child_elf.empty() ? 0u : zkhip_vm::deferral_region_index(zkhip_vm::parse_exe(slurp(child_elf)));
             const auto t0 = std::chrono::steady_clock::now();
-            up.enable_deferral(child_key, 4, child_key.join ? child_region : 0u);
+            up.enable_deferral(child_key, up.config.flow.deferral_children, child_key.join ? child_region : 0u, up.config.flow.deferral_nodes);
             std::vector<StarkProof> kids;
             for (int i = 9; i < argc; i++) {
                 const auto js = slurp(argv[i]);
@@ -303,7 +303,7 @@ int main(int argc, char** argv) {
             std::ofstream(dir + "/root.vk", std::ios::binary).write((const char*)vkb.data(), (std::streamsize)vkb.size());
             std::ofstream(dir + "/root.json") << sp.to_json();
             {   // the deferral node's proof and key (what the join verified): for inspection and the oracle comparison of the tests
-                const VerifyingKey& dvk = up.deferral()->deferral_vk();
+                const VerifyingKey& dvk = up.deferral()->join_child_vk();   // (the deferral node's key, or the fold's)
                 std::ofstream(dir + "/deferral.json") << AggregationProver::to_stark_proof(up.last_deferral_proof(), dvk).to_json();
                 const std::vector<uint8_t> db = dvk.to_app_exe();
                 std::ofstream(dir + "/deferral.vk", std::ios::binary).write((const char*)db.data(), (std::streamsize)db.size());

@@ -1243,8 +1243,8 @@ static std::array<V, 2> key_commit_const(const ChildVk& vk) {
 }
 
 // deferral node: auxiliary words per child -- the opening of its public values (16 cells + 27 siblings), and for a JOIN child the opening
-// of its deferral region (2048 cells + 20 siblings; include/zkhip_vm_flow.hpp DEFERRAL_REGION_BYTES) and the claim-count flags
-constexpr size_t DEFERRAL_PV_AUX = 16 + 27 * 8, DEFERRAL_REGION_CELLS = 2048, DEFERRAL_REGION_SIBS = 20, DEFERRAL_MAX_CLAIMS = 31;
+// of its deferral region (4096 cells + 19 siblings; include/zkhip_vm_flow.hpp DEFERRAL_REGION_BYTES) and the claim-count flags
+constexpr size_t DEFERRAL_PV_AUX = 16 + 27 * 8, DEFERRAL_REGION_CELLS = 4096, DEFERRAL_REGION_SIBS = 19, DEFERRAL_MAX_CLAIMS = 63;
 
 // The statement logic behind the verified children, then the public-value binding and the parallelism check.
 static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min_log_height, zkhip_recursion** out) {
@@ -1288,9 +1288,12 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
             const std::array<V, 2> ic = key_commit_const(K.vk);
             const std::array<V, 2> got = pack8(&rp[rp.size() - 8]);
             for (int k = 0; k < 2; k++) b.assert_eq(got[k], ic[k]);
-            for (int k = 0; k < 8; k++) b.assert_zero(dp[k]);
+            // (slot 1 may also be a FOLD of deferral nodes -- a node over their proofs with the chain as its chained state,
+            // [key digest (8) | chain before (8) | chain after (8) | accumulator (8)]: a task with more children than one deferral node takes)
+            const size_t o = dp.size() == 32 ? 8 : 0;
+            for (int k = 0; k < 8; k++) b.assert_zero(dp[o + k]);
             for (const V& v : rp) pvl.push_back(Lane{v, -1});
-            for (int k = 0; k < 8; k++) pvl.push_back(Lane{dp[8 + k], -1});
+            for (int k = 0; k < 8; k++) pvl.push_back(Lane{dp[o + 8 + k], -1});
         } else {
         // presence flags: child 0 is present, present children form a prefix
         std::vector<V> flag(max_children);
@@ -1348,7 +1351,7 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
                 if (K.region_index) {
                     // The child is a JOIN proof (a batch under a bundle: a proof whose own guest deferred verification).  Its statement ends
                     // with the chain its deferral node verified; what a verifier of the join does on the host -- open the guest's deferral
-                    // region (2048 cells = 256 blocks, one subtree of the memory tree) in the final memory root, read the n claims, chain
+                    // region (4096 cells = 512 blocks, one subtree of the memory tree) in the final memory root, read the n claims, chain
                     // them, compare -- happens here: cells, the 20 siblings above the subtree and n one-hot-prefix flags are auxiliary inputs.
                     // (A commitment word is read as the field element lo + 2^16 hi: a word >= p, which the host verifier refuses, is its
                     // residue here.)
@@ -1369,7 +1372,7 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
                         node = (ridx & 1u) ? b.compress(sib, node) : b.compress(node, sib);
                     }
                     for (int k = 0; k < 2; k++) b.assert_eq(node[k], r1[k]);
-                    // word 0 of the region = n <= 31: flags f_0 >= f_1 >= ... with sum n; at least one claim (a join without claims is refused)
+                    // word 0 of the region = n <= 63: flags f_0 >= f_1 >= ... with sum n; at least one claim (a join without claims is refused)
                     b.assert_zero(rc[1]);
                     V count = cst(ext_zero());
                     for (size_t k = 0; k < DEFERRAL_MAX_CLAIMS; k++) {
@@ -1620,7 +1623,7 @@ int zkhip_recursion_build(const zkhip_params* prm, const zkhip_air* airs, size_t
         // (region_index != 0: JOIN proofs -- the same 50 words followed by the chain (8) the join's deferral node verified)
         K.region_index = stmt->region_index;
         if (n_airs != 3 || vk.n_pvs[2] != 8 + 9 + 9 + 8 + 16 + (K.region_index ? 8u : 0u) || !vk.has_prep[0] || !vk.has_prep[1] || !vk.has_prep[2]) return ZKHIP_ERR_INVALID;
-        if (K.region_index >> (DEFERRAL_REGION_SIBS + 1)) return ZKHIP_ERR_INVALID;   // (a node of the level 20 below the root)
+        if (K.region_index >> (DEFERRAL_REGION_SIBS + 1)) return ZKHIP_ERR_INVALID;   // (a node of the level 19 below the root)
         K.n_state = 8;
         K.n_aux = DEFERRAL_PV_AUX + (K.region_index ? DEFERRAL_REGION_CELLS + 8 * DEFERRAL_REGION_SIBS + DEFERRAL_MAX_CLAIMS : 0);
     } else if (sp.child_is_node) {
@@ -1669,7 +1672,9 @@ int zkhip_recursion_build_join(const zkhip_params* params_a, const zkhip_air* ai
     int rc = load_child_vk(params_a, airs_a, n_airs_a, false, K.vk);
     if (rc == ZKHIP_OK) rc = load_child_vk(params_b, airs_b, n_airs_b, false, *K.vk_b);
     if (rc != ZKHIP_OK) return rc;
-    if (n_airs_a != 3 || K.vk.n_pvs[2] < 32 || !K.vk.has_prep[0] || !K.vk.has_prep[1] || !K.vk.has_prep[2] || K.vk_b->n_pvs[n_airs_b - 1] != 16) return ZKHIP_ERR_INVALID;
+    if (n_airs_a != 3 || K.vk.n_pvs[2] < 32 || !K.vk.has_prep[0] || !K.vk.has_prep[1] || !K.vk.has_prep[2] ||
+        (K.vk_b->n_pvs[n_airs_b - 1] != 16 && K.vk_b->n_pvs[n_airs_b - 1] != 32))
+        return ZKHIP_ERR_INVALID;
     K.max_children = 2;
     K.child_proof_words = K.vk.proof_words;
     const unsigned none[2] = {0, 0};
