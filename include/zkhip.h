@@ -614,6 +614,35 @@ int zkhip_vm_ec_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32
 int zkhip_vm_fp2_air(const uint8_t modulus[32], unsigned index, int adapter, zkhip_air *out);
 int zkhip_vm_fp2_tracegen(zkhip_ctx *ctx, const uint32_t modulus[8], const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height,
                           uint32_t *d_trace, uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+/* The `_x` forms of the limb chips take the modulus's width: n_limbs = 32 (a modulus below 2^256; the functions above) or 48 (below 2^384:
+ * BLS12-381's base field, its Fp2 and G1 -- crates/circuits/batch-circuit/openvm.toml:18-36; OpenVM instantiates its chips with 32 or 48
+ * limbs likewise); n_words = n_limbs / 4.  Operands, records and results are n_words words each; the chips have 485 / 1156 / 968 columns
+ * (+ the timestamp inside the VM), the adapters 3 n_words + 11 (modular) and 6 n_words + 11 (ecc, fp2). */
+int zkhip_vm_modmul_air_x(const uint8_t *modulus, uint32_t n_limbs, unsigned index, int adapter, zkhip_air *out);
+int zkhip_vm_modmul_tracegen_x(zkhip_ctx *ctx, uint32_t n_words, const uint32_t *modulus, const uint32_t *d_records, const uint32_t *d_ts, size_t n,
+                               unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+int zkhip_vm_ec_air_x(const uint8_t *modulus, const uint8_t *a, uint32_t n_limbs, unsigned index, int adapter, zkhip_air *out);
+int zkhip_vm_ec_tracegen_x(zkhip_ctx *ctx, uint32_t n_words, const uint32_t *modulus, const uint32_t *a, const uint32_t *d_records, const uint32_t *d_ts, size_t n,
+                           unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+int zkhip_vm_fp2_air_x(const uint8_t *modulus, uint32_t n_limbs, unsigned index, int adapter, zkhip_air *out);
+int zkhip_vm_fp2_tracegen_x(zkhip_ctx *ctx, uint32_t n_words, const uint32_t *modulus, const uint32_t *d_records, const uint32_t *d_ts, size_t n,
+                            unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+/* the standalone chips and the host arithmetic (records: op | a | b = 2 n_words + 1 words; op | x1 y1 x2 y2 | slope = 5 n_words + 1;
+ * op | a0 a1 | b0 b1 = 4 n_words + 1) */
+int zkhip_modmul_air_x(const uint8_t *modulus, uint32_t n_limbs, uint32_t bitwise_bus, uint32_t tuple_bus, zkhip_air *out);
+int zkhip_modular_host_x(uint32_t op, uint32_t n_words, const uint32_t *a, const uint32_t *b, const uint32_t *modulus, uint32_t *q, uint32_t *r);
+int zkhip_modular_tracegen_x(zkhip_ctx *ctx, uint32_t n_words, const uint32_t *modulus, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace,
+                             uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+int zkhip_ec_air_x(const uint8_t *modulus, const uint8_t *a, uint32_t n_limbs, uint32_t bitwise_bus, uint32_t tuple_bus, zkhip_air *out);
+int zkhip_ec_host_x(uint32_t op, uint32_t n_words, const uint32_t *modulus, const uint32_t *a, const uint32_t *x1, const uint32_t *y1, const uint32_t *x2,
+                    const uint32_t *y2, uint32_t *slope, uint32_t *x3, uint32_t *y3);
+int zkhip_ec_tracegen_x(zkhip_ctx *ctx, uint32_t n_words, const uint32_t *modulus, const uint32_t *a, const uint32_t *d_records, size_t n, unsigned log_height,
+                        uint32_t *d_trace, uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+int zkhip_fp2_air_x(const uint8_t *modulus, uint32_t n_limbs, uint32_t bitwise_bus, uint32_t tuple_bus, zkhip_air *out);
+int zkhip_fp2_host_x(uint32_t op, uint32_t n_words, const uint32_t *modulus, const uint32_t *a, const uint32_t *b, uint32_t *r);
+int zkhip_fp2_tracegen_x(zkhip_ctx *ctx, uint32_t n_words, const uint32_t *modulus, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace,
+                         uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
+
 /* Poseidon2 chip serving the hash bus (299 columns): zkhip_poseidon2_air_tracegen + multiplicity 1 on the first n rows. */
 int zkhip_vm_poseidon2_tracegen(zkhip_ctx *ctx, const uint32_t *d_inputs, size_t n, unsigned log_height, uint32_t *d_trace);
 /* n rows of `width` canonical words (row-major, device) -> column-major Montgomery trace of 2^log_height rows; the other rows get

@@ -37,18 +37,32 @@ using air::Kind;
 using modular::Modulus;
 using modular::U256;
 
-constexpr size_t LIMBS = 32, Q_LIMBS = 33, N_POS = LIMBS + Q_LIMBS - 1, N_CARRY = N_POS - 1, N_EQ = 3;
-constexpr size_t COL_X1 = 0, COL_Y1 = 32, COL_X2 = 64, COL_Y2 = 96, COL_L = 128, COL_X3 = 160, COL_Y3 = 192, COL_Q = 224, COL_QS = COL_Q + N_EQ * Q_LIMBS,
-                 COL_CX = COL_QS + N_EQ, COL_CY = COL_CX + N_EQ * N_CARRY, COL_MARK = COL_CY + N_EQ * N_CARRY, COL_DIFF = COL_MARK + 2 * LIMBS,
-                 COL_REAL = COL_DIFF + 2, COL_IS_DOUBLE = COL_REAL + 1, WIDTH = COL_REAL + 2;
+constexpr size_t N_EQ = 3;
+// column layout for L limbs (32: a prime below 2^256; 48: below 2^384 -- BLS12-381 G1 of the reference's batch circuit)
+struct Cols {
+    size_t L, Q_LIMBS, N_POS, N_CARRY, X1, Y1, X2, Y2, LAM, X3, Y3, Q, QS, CX, CY, MARK, DIFF, REAL, IS_DOUBLE, WIDTH, TS, VM_WIDTH, CALL_WORDS, RECORD_WORDS;
+    constexpr explicit Cols(size_t l)
+        : L(l), Q_LIMBS(l + 1), N_POS(2 * l), N_CARRY(2 * l - 1), X1(0), Y1(l), X2(2 * l), Y2(3 * l), LAM(4 * l), X3(5 * l), Y3(6 * l), Q(7 * l), QS(Q + N_EQ * Q_LIMBS),
+          CX(QS + N_EQ), CY(CX + N_EQ * N_CARRY), MARK(CY + N_EQ * N_CARRY), DIFF(MARK + 2 * l), REAL(DIFF + 2), IS_DOUBLE(REAL + 1), WIDTH(REAL + 2), TS(WIDTH),
+          VM_WIDTH(WIDTH + 1), CALL_WORDS(6 * (l / 4)), RECORD_WORDS(1 + 5 * (l / 4)) {}
+};
+constexpr Cols C32(32);
+constexpr size_t LIMBS = 32, Q_LIMBS = C32.Q_LIMBS, N_POS = C32.N_POS, N_CARRY = C32.N_CARRY;
+constexpr size_t COL_X1 = C32.X1, COL_Y1 = C32.Y1, COL_X2 = C32.X2, COL_Y2 = C32.Y2, COL_L = C32.LAM, COL_X3 = C32.X3, COL_Y3 = C32.Y3, COL_Q = C32.Q, COL_QS = C32.QS,
+                 COL_CX = C32.CX, COL_CY = C32.CY, COL_MARK = C32.MARK, COL_DIFF = C32.DIFF, COL_REAL = C32.REAL, COL_IS_DOUBLE = C32.IS_DOUBLE, WIDTH = C32.WIDTH;
 static_assert(WIDTH == 772, "ecc chip width");
+static_assert(Cols(48).WIDTH == 1156, "ecc chip width, 48 limbs");
 enum Op : uint32_t { OP_ADD_NE, OP_DOUBLE, N_OPS };
 constexpr int64_t CARRY_OFFSET = 1 << 18;
-constexpr size_t CALL_WORDS = 48;   // x1 y1 | x2 y2 (read) | x3 y3 (written), eight 32-bit words each
-constexpr size_t RECORD_WORDS = 41; // op | x1 y1 x2 y2 | slope
+constexpr size_t CALL_WORDS = C32.CALL_WORDS;     // x1 y1 | x2 y2 (read) | x3 y3 (written), L / 4 32-bit words each
+constexpr size_t RECORD_WORDS = C32.RECORD_WORDS; // op | x1 y1 x2 y2 | slope
 
 // AirBuilder(WIDTH, 0); bitwise_bus: (x, y, 0, 0) byte pairs; tuple_bus: (cx, cy)
 inline void ec_air(AirBuilder& b, const Modulus& P, const Modulus& A, uint32_t bitwise_bus, uint32_t tuple_bus) {
+    const Cols C(P.limbs);
+    const size_t LIMBS = C.L, Q_LIMBS = C.Q_LIMBS, N_POS = C.N_POS, N_CARRY = C.N_CARRY;
+    const size_t COL_X1 = C.X1, COL_Y1 = C.Y1, COL_X2 = C.X2, COL_Y2 = C.Y2, COL_L = C.LAM, COL_X3 = C.X3, COL_Y3 = C.Y3, COL_Q = C.Q, COL_QS = C.QS, COL_CX = C.CX,
+                 COL_CY = C.CY, COL_MARK = C.MARK, COL_DIFF = C.DIFF, COL_REAL = C.REAL, COL_IS_DOUBLE = C.IS_DOUBLE;
     const Expr real = b.var(COL_REAL), is_dbl = b.var(COL_IS_DOUBLE), is_add = real - is_dbl, zero = b.constant(0);
     for (const Expr& f : {real, is_dbl, is_add}) b.assert_zero(f * (f - 1));
     auto limb = [&](size_t base, size_t i) { return b.var(base + i); };
@@ -61,7 +75,7 @@ inline void ec_air(AirBuilder& b, const Modulus& P, const Modulus& A, uint32_t b
     }
     // (position by position, the three identities side by side, and the quotient limbs grouped by the modulus byte they meet: the
     // builder shares equal subexpressions, and a product shared between far-apart constraints would stay live in between --
-    // csrc/air_compile.hpp keeps at most 60 intermediates)
+    // csrc/air_compile.hpp keeps at most 96 intermediates, 64 without raising the kernel's LDS limit)
     for (size_t k = 0; k < N_POS; k++)
         for (size_t e : {0, 2, 1}) {   // (identities 1 and 3 share the products l_i x1_j)
             Expr s = b.constant(0), qp = b.constant(0);
@@ -133,18 +147,20 @@ inline void ec_air(AirBuilder& b, const Modulus& P, const Modulus& A, uint32_t b
     }
 }
 
-// The chip inside the VM (include/zkhip_vm_circuit.hpp): the same AIR plus a timestamp column; the 48 words of a call -- (x1, y1),
-// (x2, y2) read and (x3, y3) written -- are received from the curve's adapter on `word_bus` as (timestamp, word index 0..47, low half,
-// high half, operation).  AirBuilder(VM_WIDTH, 0)
-constexpr size_t COL_TS = WIDTH, VM_WIDTH = WIDTH + 1;
+// The chip inside the VM (include/zkhip_vm_circuit.hpp): the same AIR plus a timestamp column; the 6 L / 4 words of a call -- (x1, y1),
+// (x2, y2) read and (x3, y3) written -- are received from the curve's adapter on `word_bus` as (timestamp, word index, low half,
+// high half, operation).  AirBuilder(Cols(P.limbs).VM_WIDTH, 0)
+constexpr size_t COL_TS = WIDTH, VM_WIDTH = WIDTH + 1;   // (32 limbs)
 inline void ec_vm_air(AirBuilder& b, const Modulus& P, const Modulus& A, uint32_t bitwise_bus, uint32_t tuple_bus, uint32_t word_bus) {
     ec_air(b, P, A, bitwise_bus, tuple_bus);
-    const Expr ts = b.var(COL_TS), real = b.var(COL_REAL), op = b.var(COL_IS_DOUBLE);
-    const size_t base[6] = {COL_X1, COL_Y1, COL_X2, COL_Y2, COL_X3, COL_Y3};
+    const Cols C(P.limbs);
+    const size_t NW = C.L / 4;
+    const Expr ts = b.var(C.TS), real = b.var(C.REAL), op = b.var(C.IS_DOUBLE);
+    const size_t base[6] = {C.X1, C.Y1, C.X2, C.Y2, C.X3, C.Y3};
     for (size_t o = 0; o < 6; o++)
-        for (size_t k = 0; k < 8; k++) {
+        for (size_t k = 0; k < NW; k++) {
             const size_t c = base[o] + 4 * k;
-            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(8 * o + k)), b.var(c) + b.var(c + 1) * 256, b.var(c + 2) + b.var(c + 3) * 256, op}, real, Kind::Receive);
+            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(NW * o + k)), b.var(c) + b.var(c + 1) * 256, b.var(c + 2) + b.var(c + 3) * 256, op}, real, Kind::Receive);
         }
 }
 
@@ -158,7 +174,7 @@ inline bool is_zero(const U256& x) {
     return o == 0;
 }
 inline bool less(const U256& x, const U256& y) {
-    for (int k = 7; k >= 0; k--)
+    for (int k = (int)modular::MAX_WORDS - 1; k >= 0; k--)
         if (x.w[k] != y.w[k]) return x.w[k] < y.w[k];
     return false;
 }
@@ -177,74 +193,12 @@ inline U256 mod_mul(const U256& x, const U256& y, const U256& p) {
     modular::mulmod(x, y, p, &q, &r);
     return r;
 }
-// x^-1 mod p for odd p and 0 < x < p with gcd(x, p) = 1 (binary extended Euclid on nine words); false if there is none
+// x^-1 mod p for odd p and 0 < x < p with gcd(x, p) = 1; false if there is none
 inline bool mod_inv(const U256& x, const U256& p, U256* out) {
     if (is_zero(x) || !(p.w[0] & 1u) || !less(x, p)) return false;
-    struct W9 {
-        uint32_t w[9];
-    };
-    auto from = [](const U256& v) {
-        W9 r{};
-        for (int k = 0; k < 8; k++) r.w[k] = v.w[k];
-        return r;
-    };
-    auto is_one = [](const W9& v) {
-        uint32_t o = v.w[0] ^ 1u;
-        for (int k = 1; k < 9; k++) o |= v.w[k];
-        return o == 0;
-    };
-    auto zero9 = [](const W9& v) {
-        uint32_t o = 0;
-        for (int k = 0; k < 9; k++) o |= v.w[k];
-        return o == 0;
-    };
-    auto shr1 = [](W9& v) {
-        for (int k = 0; k < 8; k++) v.w[k] = (v.w[k] >> 1) | (v.w[k + 1] << 31);
-        v.w[8] >>= 1;
-    };
-    auto add = [](W9& v, const W9& y) {
-        uint64_t c = 0;
-        for (int k = 0; k < 9; k++) c += (uint64_t)v.w[k] + y.w[k], v.w[k] = (uint32_t)c, c >>= 32;
-    };
-    auto sub = [](W9& v, const W9& y) {   // v >= y
-        uint64_t br = 0;
-        for (int k = 0; k < 9; k++) {
-            const uint64_t d = (uint64_t)v.w[k] - y.w[k] - br;
-            v.w[k] = (uint32_t)d, br = (d >> 32) & 1u;
-        }
-    };
-    auto ge = [](const W9& v, const W9& y) {
-        for (int k = 8; k >= 0; k--)
-            if (v.w[k] != y.w[k]) return v.w[k] > y.w[k];
-        return true;
-    };
-    const W9 P = from(p);
-    W9 u = from(x), v = P, x1{}, x2{};
-    x1.w[0] = 1;
-    auto halve = [&](W9& t, W9& c) {
-        while (!(t.w[0] & 1u)) {
-            shr1(t);
-            if (c.w[0] & 1u) add(c, P);
-            shr1(c);
-        }
-    };
-    for (int guard = 0; guard < 2048 && !is_one(u) && !is_one(v); guard++) {
-        if (zero9(u) || zero9(v)) return false;
-        halve(u, x1), halve(v, x2);
-        if (ge(u, v)) {
-            sub(u, v);
-            if (!ge(x1, x2)) add(x1, P);
-            sub(x1, x2);
-        } else {
-            sub(v, u);
-            if (!ge(x2, x1)) add(x2, P);
-            sub(x2, x1);
-        }
-    }
-    if (!is_one(u) && !is_one(v)) return false;
-    const W9& r = is_one(u) ? x1 : x2;
-    for (int k = 0; k < 8; k++) out->w[k] = r.w[k];
-    return true;
+    U256 one{};
+    one.w[0] = 1;
+    return modular::divmod_p(one, x, p, out);
 }
 // the slope and the result of one operation; false if an operand is not reduced or the slope does not exist (x1 = x2, resp. y1 = 0)
 inline bool ec_op(uint32_t op, const Curve& c, const U256& x1, const U256& y1, const U256& x2, const U256& y2, U256* l, U256* x3, U256* y3) {

@@ -32,18 +32,32 @@ using air::Kind;
 using modular::Modulus;
 using modular::U256;
 
-constexpr size_t LIMBS = 32, Q_LIMBS = 33, N_POS = LIMBS + Q_LIMBS - 1, N_CARRY = N_POS - 1;
-constexpr size_t COL_A0 = 0, COL_A1 = 32, COL_B0 = 64, COL_B1 = 96, COL_R0 = 128, COL_R1 = 160, COL_Q = 192, COL_QS = COL_Q + 2 * Q_LIMBS, COL_CX = COL_QS + 2,
-                 COL_CY = COL_CX + 2 * N_CARRY, COL_MARK = COL_CY + 2 * N_CARRY, COL_DIFF = COL_MARK + 2 * LIMBS, COL_MARK2 = COL_DIFF + 2,
-                 COL_DIFF2 = COL_MARK2 + 2 * LIMBS, COL_REAL = COL_DIFF2 + 2, COL_IS_ADD = COL_REAL + 1, COL_IS_SUB = COL_REAL + 2, COL_IS_DIV = COL_REAL + 3,
-                 WIDTH = COL_REAL + 4;
+// column layout for L limbs (32: a prime below 2^256; 48: below 2^384 -- BLS12-381's Fp2 of the reference's batch circuit)
+struct Cols {
+    size_t L, Q_LIMBS, N_POS, N_CARRY, A0, A1, B0, B1, R0, R1, Q, QS, CX, CY, MARK, DIFF, MARK2, DIFF2, REAL, IS_ADD, IS_SUB, IS_DIV, WIDTH, TS, VM_WIDTH, RECORD_WORDS;
+    constexpr explicit Cols(size_t l)
+        : L(l), Q_LIMBS(l + 1), N_POS(2 * l), N_CARRY(2 * l - 1), A0(0), A1(l), B0(2 * l), B1(3 * l), R0(4 * l), R1(5 * l), Q(6 * l), QS(Q + 2 * Q_LIMBS), CX(QS + 2),
+          CY(CX + 2 * N_CARRY), MARK(CY + 2 * N_CARRY), DIFF(MARK + 2 * l), MARK2(DIFF + 2), DIFF2(MARK2 + 2 * l), REAL(DIFF2 + 2), IS_ADD(REAL + 1), IS_SUB(REAL + 2),
+          IS_DIV(REAL + 3), WIDTH(REAL + 4), TS(WIDTH), VM_WIDTH(WIDTH + 1), RECORD_WORDS(1 + l) {}
+};
+constexpr Cols C32(32);
+constexpr size_t LIMBS = 32, Q_LIMBS = C32.Q_LIMBS, N_POS = C32.N_POS, N_CARRY = C32.N_CARRY;
+constexpr size_t COL_A0 = C32.A0, COL_A1 = C32.A1, COL_B0 = C32.B0, COL_B1 = C32.B1, COL_R0 = C32.R0, COL_R1 = C32.R1, COL_Q = C32.Q, COL_QS = C32.QS, COL_CX = C32.CX,
+                 COL_CY = C32.CY, COL_MARK = C32.MARK, COL_DIFF = C32.DIFF, COL_MARK2 = C32.MARK2, COL_DIFF2 = C32.DIFF2, COL_REAL = C32.REAL, COL_IS_ADD = C32.IS_ADD,
+                 COL_IS_SUB = C32.IS_SUB, COL_IS_DIV = C32.IS_DIV, WIDTH = C32.WIDTH;
 static_assert(WIDTH == 648, "fp2 chip width");
+static_assert(Cols(48).WIDTH == 968, "fp2 chip width, 48 limbs");
 enum Op : uint32_t { OP_MUL, OP_ADD, OP_SUB, OP_DIV, N_OPS };
 constexpr int64_t CARRY_OFFSET = 1 << 18;
-constexpr size_t RECORD_WORDS = 33;   // op | a0 a1 | b0 b1   (a division's record holds the quotient x / y in the a slot)
+constexpr size_t RECORD_WORDS = C32.RECORD_WORDS;   // op | a0 a1 | b0 b1   (a division's record holds the quotient x / y in the a slot)
 
 // AirBuilder(WIDTH, 0); bitwise_bus: (x, y, 0, 0) byte pairs; tuple_bus: (cx, cy)
 inline void fp2_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus, uint32_t tuple_bus) {
+    const Cols C(P.limbs);
+    const size_t LIMBS = C.L, Q_LIMBS = C.Q_LIMBS, N_POS = C.N_POS, N_CARRY = C.N_CARRY;
+    const size_t COL_A0 = C.A0, COL_A1 = C.A1, COL_B0 = C.B0, COL_B1 = C.B1, COL_R0 = C.R0, COL_R1 = C.R1, COL_Q = C.Q, COL_QS = C.QS, COL_CX = C.CX, COL_CY = C.CY,
+                 COL_MARK = C.MARK, COL_DIFF = C.DIFF, COL_MARK2 = C.MARK2, COL_DIFF2 = C.DIFF2, COL_REAL = C.REAL, COL_IS_ADD = C.IS_ADD, COL_IS_SUB = C.IS_SUB,
+                 COL_IS_DIV = C.IS_DIV;
     const Expr real = b.var(COL_REAL), is_add = b.var(COL_IS_ADD), is_sub = b.var(COL_IS_SUB), is_div = b.var(COL_IS_DIV), is_mul = real - is_add - is_sub,
                zero = b.constant(0);
     // (is_mul covers the division rows: the same limb identities)
@@ -112,22 +126,24 @@ inline void fp2_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus, uint3
     }
 }
 
-// The chip inside the VM: + a timestamp column; the 48 words of a call -- a, b read and r written, two 256-bit components each -- are
-// received from the field's adapter on `word_bus` as (timestamp, word index 0..47, low half, high half, operation); for a division the
-// first operand's words are the r columns and the result's the a columns.  AirBuilder(VM_WIDTH, 0)
-constexpr size_t COL_TS = WIDTH, VM_WIDTH = WIDTH + 1;
+// The chip inside the VM: + a timestamp column; the 6 L / 4 words of a call -- a, b read and r written, two components each -- are
+// received from the field's adapter on `word_bus` as (timestamp, word index, low half, high half, operation); for a division the
+// first operand's words are the r columns and the result's the a columns.  AirBuilder(Cols(P.limbs).VM_WIDTH, 0)
+constexpr size_t COL_TS = WIDTH, VM_WIDTH = WIDTH + 1;   // (32 limbs)
 inline void fp2_vm_air(AirBuilder& b, const Modulus& P, uint32_t bitwise_bus, uint32_t tuple_bus, uint32_t word_bus) {
     fp2_air(b, P, bitwise_bus, tuple_bus);
-    const Expr ts = b.var(COL_TS), real = b.var(COL_REAL), is_div = b.var(COL_IS_DIV), op = b.var(COL_IS_ADD) + b.var(COL_IS_SUB) * 2 + is_div * 3;
+    const Cols C(P.limbs);
+    const size_t NW = C.L / 4;
+    const Expr ts = b.var(C.TS), real = b.var(C.REAL), is_div = b.var(C.IS_DIV), op = b.var(C.IS_ADD) + b.var(C.IS_SUB) * 2 + is_div * 3;
     auto half = [&](size_t base, size_t k, size_t h) { return b.var(base + 4 * k + 2 * h) + b.var(base + 4 * k + 2 * h + 1) * 256; };
-    const size_t A[2] = {COL_A0, COL_A1}, B[2] = {COL_B0, COL_B1}, R[2] = {COL_R0, COL_R1};
+    const size_t A[2] = {C.A0, C.A1}, B[2] = {C.B0, C.B1}, R[2] = {C.R0, C.R1};
     for (size_t e = 0; e < 2; e++)
-        for (size_t k = 0; k < 8; k++) {
+        for (size_t k = 0; k < NW; k++) {
             const Expr a_lo = half(A[e], k, 0), a_hi = half(A[e], k, 1), r_lo = half(R[e], k, 0), r_hi = half(R[e], k, 1);
             const Expr sw_lo = is_div * (r_lo - a_lo), sw_hi = is_div * (r_hi - a_hi);
-            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(8 * e + k)), a_lo + sw_lo, a_hi + sw_hi, op}, real, Kind::Receive);
-            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(16 + 8 * e + k)), half(B[e], k, 0), half(B[e], k, 1), op}, real, Kind::Receive);
-            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(32 + 8 * e + k)), r_lo - sw_lo, r_hi - sw_hi, op}, real, Kind::Receive);
+            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(NW * e + k)), a_lo + sw_lo, a_hi + sw_hi, op}, real, Kind::Receive);
+            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(2 * NW + NW * e + k)), half(B[e], k, 0), half(B[e], k, 1), op}, real, Kind::Receive);
+            b.push_interaction(word_bus, {ts, b.constant((uint32_t)(4 * NW + NW * e + k)), r_lo - sw_lo, r_hi - sw_hi, op}, real, Kind::Receive);
         }
 }
 

@@ -459,9 +459,9 @@ private:
                     if (which >= moduli_.size()) throw Error("modmul: the app's openvm.toml lists no modulus " + std::to_string(which));
                     if (mop >= zkhip::modular::N_OPS) throw Error("modular: unknown operation " + std::to_string(mop));
                     if (addr & 3u) throw Error("modmul buffer must be word-aligned");
-                    uint8_t* p = at(addr, 96);
-                    zkhip::modular::U256 a, b, q, r;
-                    memcpy(a.w, p, 32), memcpy(b.w, p + 32, 32);
+                    const size_t nb = 4 * zkhip::modular::words_of(moduli_[which]);   // bytes per operand: 32, or 48 for a modulus above 2^256
+                    uint8_t* p = at(addr, 3 * nb);
+                    zkhip::modular::U256 a = zkhip::modular::load_words(p, nb / 4), b = zkhip::modular::load_words(p + nb, nb / 4), q{}, r{};
                     if (mop == zkhip::modular::OP_IS_EQ) {   // r = [a = b (mod P)]: the difference's residue, then the bit
                         if (!zkhip::modular::addsubmod(zkhip::modular::OP_SUB, a, b, moduli_[which], &q, &r))
                             throw Error("modular: operands of an equality test further apart than the modulus");
@@ -477,7 +477,7 @@ private:
                             throw Error("modular: operands too far from the modulus (a product's quotient beyond 256 bits, or a difference beyond the modulus), "
                                         "or a division with a dividend that is not reduced or a divisor that is not invertible");
                     }
-                    memcpy(p + 64, r.w, 32);
+                    memcpy(p + 2 * nb, r.w, nb);
                 } else if (call == 6) {
                     // a = b op c on the 24 words at a0 (b[8] | c[8] | a[8], little-endian 256-bit words), op = a1: 0 add, 1 sub, 2 xor,
                     // 3 or, 4 and, 5 mul, 6 sltu, 7 slt, 8 eq, 9 sll, 10 srl, 11 sra (OpenVM's bigint extension)
@@ -504,12 +504,13 @@ private:
                     if (which >= curves_.size()) throw Error("ecc: the app's openvm.toml lists no curve " + std::to_string(which));
                     if (eop >= zkhip::ecc::N_OPS) throw Error("ecc: unknown operation " + std::to_string(eop));
                     if (addr & 3u) throw Error("ecc buffer must be word-aligned");
-                    uint8_t* p = at(addr, 192);
+                    const size_t nb = 4 * zkhip::modular::words_of(curves_[which].p);
+                    uint8_t* p = at(addr, 6 * nb);
                     zkhip::modular::U256 c[4], x3, y3;
-                    for (int k = 0; k < 4; k++) memcpy(c[k].w, p + 32 * k, 32);
+                    for (int k = 0; k < 4; k++) c[k] = zkhip::modular::load_words(p + nb * k, nb / 4);
                     if (!zkhip::ecc::ec_op(eop, curves_[which], c[0], c[1], c[2], c[3], &last_slope_, &x3, &y3))
                         throw Error("ecc: coordinates not reduced, or no slope (equal abscissae in an addition, y = 0 in a doubling)");
-                    memcpy(p + 128, x3.w, 32), memcpy(p + 160, y3.w, 32);
+                    memcpy(p + 4 * nb, x3.w, nb), memcpy(p + 5 * nb, y3.w, nb);
                 } else if (call == 8) {
                     // r = a b, a + b, a - b or a / b in Fp[u] / (u^2 + 1) on the 48 words at a0 (a0 a1 | b0 b1 | r0 r1, little-endian 256-bit
                     // words), field i of the app's openvm.toml, a1 = i + 8 op (OpenVM's fp2 extension)
@@ -518,11 +519,12 @@ private:
                     if (which >= fp2_moduli_.size()) throw Error("fp2: the app's openvm.toml lists no fp2 field " + std::to_string(which));
                     if (fop >= zkhip::fp2::N_OPS) throw Error("fp2: unknown operation " + std::to_string(fop));
                     if (addr & 3u) throw Error("fp2 buffer must be word-aligned");
-                    uint8_t* p = at(addr, 192);
-                    zkhip::fp2::Elem a, b, r;
-                    memcpy(a.c0.w, p, 32), memcpy(a.c1.w, p + 32, 32), memcpy(b.c0.w, p + 64, 32), memcpy(b.c1.w, p + 96, 32);
+                    const size_t nb = 4 * zkhip::modular::words_of(fp2_moduli_[which]);
+                    uint8_t* p = at(addr, 6 * nb);
+                    using zkhip::modular::load_words;
+                    zkhip::fp2::Elem a{load_words(p, nb / 4), load_words(p + nb, nb / 4)}, b{load_words(p + 2 * nb, nb / 4), load_words(p + 3 * nb, nb / 4)}, r;
                     if (!zkhip::fp2::fp2_op(fop, fp2_moduli_[which], a, b, &r)) throw Error("fp2: components not reduced, or a division by zero");
-                    memcpy(p + 128, r.c0.w, 32), memcpy(p + 160, r.c1.w, 32);
+                    memcpy(p + 4 * nb, r.c0.w, nb), memcpy(p + 5 * nb, r.c1.w, nb);
                 } else {
                     throw Error("unknown environment call " + std::to_string(call));
                 }

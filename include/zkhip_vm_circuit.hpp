@@ -481,30 +481,34 @@ inline void sha256_io_air(AirBuilder& b) {
     b.push_interaction(SHA_STATE_BUS, {ts, idx, v_lo, v_hi, n_lo, n_hi}, is_state, Kind::Send);
 }
 
-// modular adapter of modulus `index`: AirBuilder(MODMUL_IO_WIDTH, 0).  The sha256 adapter's columns: word[24] (0..7 a, 8..15 b: read;
-// 16..23 r: written) | ts | base | v_lo v_hi | n_lo n_hi | prev_ts gap_lo gap_hi | ok | op (the call's operation: a1 = index + 8 op).
-inline void modmul_io_air(AirBuilder& b, uint32_t index) {
-    Expr sel[24];
-    for (int k = 0; k < 24; k++) sel[k] = b.var(k);
-    const Expr ts = b.var(24), base = b.var(25), v_lo = b.var(26), v_hi = b.var(27), n_lo = b.var(28), n_hi = b.var(29), ok = b.var(33), op = b.var(34);
+// modular adapter of modulus `index`: AirBuilder(modmul_io_width(nw), 0) for a modulus of nw words (8: up to 256 bits; 12: up to 384).
+// The sha256 adapter's columns: word[3 nw] (a, b: read; r: written) | ts | base | v_lo v_hi | n_lo n_hi | prev_ts gap_lo gap_hi | ok |
+// op (the call's operation: a1 = index + 8 op).
+constexpr size_t modmul_io_width(size_t nw) { return 3 * nw + 11; }
+constexpr size_t ec_io_width(size_t nw) { return 6 * nw + 11; }
+inline void modmul_io_air(AirBuilder& b, uint32_t index, size_t nw = 8) {
+    const int W = (int)(3 * nw), RD = (int)(2 * nw);
+    std::vector<Expr> sel(W);
+    for (int k = 0; k < W; k++) sel[k] = b.var(k);
+    const Expr ts = b.var(W), base = b.var(W + 1), v_lo = b.var(W + 2), v_hi = b.var(W + 3), n_lo = b.var(W + 4), n_hi = b.var(W + 5), ok = b.var(W + 9), op = b.var(W + 10);
     Expr sum = sel[0], idx = b.constant(0), is_read = sel[0];
-    for (int k = 1; k < 24; k++) {
+    for (int k = 1; k < W; k++) {
         sum = sum + sel[k], idx = idx + sel[k] * k;
-        if (k < 16) is_read = is_read + sel[k];
+        if (k < RD) is_read = is_read + sel[k];
     }
-    for (int k = 0; k < 24; k++) b.assert_zero(sel[k] * (sel[k] - 1));
+    for (int k = 0; k < W; k++) b.assert_zero(sel[k] * (sel[k] - 1));
     b.assert_zero(ok * (ok - 1));
     b.assert_zero(sum - ok);
-    for (int k = 0; k < 23; k++) b.when_transition(b.var(k + 1, 1) - sel[k]);
+    for (int k = 0; k + 1 < W; k++) b.when_transition(b.var(k + 1, 1) - sel[k]);
     b.when_first_row(sum - sel[0]);
-    const Expr cont = b.var(33, 1) - b.var(0, 1);
-    b.when_transition(cont * (b.var(24, 1) - ts));
-    b.when_transition(cont * (b.var(25, 1) - base));
+    const Expr cont = b.var(W + 9, 1) - b.var(0, 1);
+    b.when_transition(cont * (b.var(W, 1) - ts));
+    b.when_transition(cont * (b.var(W + 1, 1) - base));
     b.assert_zero(is_read * (n_lo - v_lo));
     b.assert_zero(is_read * (n_hi - v_hi));
-    b.when_transition(cont * (b.var(34, 1) - op));
+    b.when_transition(cont * (b.var(W + 10, 1) - op));
     b.push_interaction(MODMUL_REQ_BUS, {ts, base, op * 8 + (int64_t)index}, sel[0], Kind::Receive);
-    word_access(b, ok, ok, b.constant(2), base + idx, v_lo, v_hi, n_lo, n_hi, ts + 5, b.var(30), b.var(31), b.var(32));
+    word_access(b, ok, ok, b.constant(2), base + idx, v_lo, v_hi, n_lo, n_hi, ts + 5, b.var(W + 6), b.var(W + 7), b.var(W + 8));
     b.push_interaction(MODMUL_WORD_BUS + index, {ts, idx, n_lo, n_hi, op}, ok, Kind::Send);
 }
 
@@ -535,18 +539,18 @@ inline void int256_io_air(AirBuilder& b) {
     b.push_interaction(INT256_WORD_BUS, {ts, idx, n_lo, n_hi, op}, ok, Kind::Send);
 }
 
-// ecc adapter of curve `index`: AirBuilder(EC_IO_WIDTH, 0).  The modular adapter's shape with 48 words: word[48] (0..15 x1 y1, 16..31
-// x2 y2: read; 32..47 x3 y3: written) | ts | base | v_lo v_hi | n_lo n_hi | prev_ts gap_lo gap_hi | ok | op (a1 = index + 8 op).
-// (the fp2 adapter has the same shape on its own pair of buses: two operands of 16 words read, a result of 16 words written)
-inline void ec_io_air(AirBuilder& b, uint32_t index, uint32_t req_bus = EC_REQ_BUS, uint32_t word_bus_base = EC_WORD_BUS) {
-    constexpr int W = 48;
-    Expr sel[W];
+// ecc adapter of curve `index`: AirBuilder(ec_io_width(nw), 0).  The modular adapter's shape with 6 nw words: word[6 nw] (x1 y1, x2 y2:
+// read; x3 y3: written) | ts | base | v_lo v_hi | n_lo n_hi | prev_ts gap_lo gap_hi | ok | op (a1 = index + 8 op).
+// (the fp2 adapter has the same shape on its own pair of buses: two operands of 2 nw words read, a result of 2 nw words written)
+inline void ec_io_air(AirBuilder& b, uint32_t index, uint32_t req_bus = EC_REQ_BUS, uint32_t word_bus_base = EC_WORD_BUS, size_t nw = 8) {
+    const int W = (int)(6 * nw), RD = (int)(4 * nw);
+    std::vector<Expr> sel(W);
     for (int k = 0; k < W; k++) sel[k] = b.var(k);
     const Expr ts = b.var(W), base = b.var(W + 1), v_lo = b.var(W + 2), v_hi = b.var(W + 3), n_lo = b.var(W + 4), n_hi = b.var(W + 5), ok = b.var(W + 9), op = b.var(W + 10);
     Expr sum = sel[0], idx = b.constant(0), is_read = sel[0];
     for (int k = 1; k < W; k++) {
         sum = sum + sel[k], idx = idx + sel[k] * k;
-        if (k < 32) is_read = is_read + sel[k];
+        if (k < RD) is_read = is_read + sel[k];
     }
     for (int k = 0; k < W; k++) b.assert_zero(sel[k] * (sel[k] - 1));
     b.assert_zero(ok * (ok - 1));
@@ -676,28 +680,31 @@ struct AirShape {
 // the two chips of modulus `index`
 inline AirShape build_modmul_air(const modular::Modulus& P, unsigned index, bool adapter) {
     AirShape s;
-    AirBuilder b(adapter ? MODMUL_IO_WIDTH : modular::VM_WIDTH, 0, 0);
-    if (adapter) modmul_io_air(b, index);
+    const size_t nw = P.limbs / 4, w = adapter ? modmul_io_width(nw) : modular::Cols(P.limbs).VM_WIDTH;
+    AirBuilder b(w, 0, 0);
+    if (adapter) modmul_io_air(b, index, nw);
     else modular::modmul_vm_air(b, P, BITWISE_BUS, RANGE_TUPLE_BUS, MODMUL_WORD_BUS + index);
-    s.width = adapter ? MODMUL_IO_WIDTH : modular::VM_WIDTH, s.program = b.program();
+    s.width = w, s.program = b.program();
     return s;
 }
 // the two chips of curve `index`
 inline AirShape build_ec_air(const modular::Modulus& P, const modular::Modulus& A, unsigned index, bool adapter) {
     AirShape s;
-    AirBuilder b(adapter ? EC_IO_WIDTH : ecc::VM_WIDTH, 0, 0);
-    if (adapter) ec_io_air(b, index);
+    const size_t nw = P.limbs / 4, w = adapter ? ec_io_width(nw) : ecc::Cols(P.limbs).VM_WIDTH;
+    AirBuilder b(w, 0, 0);
+    if (adapter) ec_io_air(b, index, EC_REQ_BUS, EC_WORD_BUS, nw);
     else ecc::ec_vm_air(b, P, A, BITWISE_BUS, RANGE_TUPLE_BUS, EC_WORD_BUS + index);
-    s.width = adapter ? EC_IO_WIDTH : ecc::VM_WIDTH, s.program = b.program();
+    s.width = w, s.program = b.program();
     return s;
 }
 // the two chips of fp2 field `index`
 inline AirShape build_fp2_air(const modular::Modulus& P, unsigned index, bool adapter) {
     AirShape s;
-    AirBuilder b(adapter ? EC_IO_WIDTH : fp2::VM_WIDTH, 0, 0);
-    if (adapter) ec_io_air(b, index, FP2_REQ_BUS, FP2_WORD_BUS);
+    const size_t nw = P.limbs / 4, w = adapter ? ec_io_width(nw) : fp2::Cols(P.limbs).VM_WIDTH;
+    AirBuilder b(w, 0, 0);
+    if (adapter) ec_io_air(b, index, FP2_REQ_BUS, FP2_WORD_BUS, nw);
     else fp2::fp2_vm_air(b, P, BITWISE_BUS, RANGE_TUPLE_BUS, FP2_WORD_BUS + index);
-    s.width = adapter ? EC_IO_WIDTH : fp2::VM_WIDTH, s.program = b.program();
+    s.width = w, s.program = b.program();
     return s;
 }
 inline AirShape build_air(unsigned id) {

@@ -133,19 +133,19 @@ struct SegmentCaps {
         c.moduli = moduli;
         for (unsigned i = 0; i < moduli.size(); i++) {
             c.ids.push_back(vmc::A_MODMUL(i)), c.ids.push_back(vmc::A_MODMUL_IO(i));
-            c.log_height[vmc::A_MODMUL(i)] = std::max(log_modmul, 1u), c.log_height[vmc::A_MODMUL_IO(i)] = c.log_height[vmc::A_MODMUL(i)] + 5;   // 24 adapter rows per call
+            c.log_height[vmc::A_MODMUL(i)] = std::max(log_modmul, 1u), c.log_height[vmc::A_MODMUL_IO(i)] = c.log_height[vmc::A_MODMUL(i)] + (zkhip::modular::words_of(moduli[i]) == 12 ? 6 : 5);   // 24 (36) adapter rows per call
         }
         if (curves.size() > vmc::MAX_CURVES) throw Error("at most " + std::to_string(vmc::MAX_CURVES) + " curves");
         c.curves = curves;
         for (unsigned i = 0; i < curves.size(); i++) {
             c.ids.push_back(vmc::A_EC(i)), c.ids.push_back(vmc::A_EC_IO(i));
-            c.log_height[vmc::A_EC(i)] = std::max(log_ec, 1u), c.log_height[vmc::A_EC_IO(i)] = c.log_height[vmc::A_EC(i)] + 6;   // 48 adapter rows per call
+            c.log_height[vmc::A_EC(i)] = std::max(log_ec, 1u), c.log_height[vmc::A_EC_IO(i)] = c.log_height[vmc::A_EC(i)] + (zkhip::modular::words_of(curves[i].p) == 12 ? 7 : 6);   // 48 (72) adapter rows per call
         }
         if (fp2_moduli.size() > vmc::MAX_FP2) throw Error("at most " + std::to_string(vmc::MAX_FP2) + " fp2 fields");
         c.fp2_moduli = fp2_moduli;
         for (unsigned i = 0; i < fp2_moduli.size(); i++) {   // (the heights of the ecc chips: one operation per row, 48 adapter rows per call)
             c.ids.push_back(vmc::A_FP2(i)), c.ids.push_back(vmc::A_FP2_IO(i));
-            c.log_height[vmc::A_FP2(i)] = std::max(log_ec, 1u), c.log_height[vmc::A_FP2_IO(i)] = c.log_height[vmc::A_FP2(i)] + 6;
+            c.log_height[vmc::A_FP2(i)] = std::max(log_ec, 1u), c.log_height[vmc::A_FP2_IO(i)] = c.log_height[vmc::A_FP2(i)] + (zkhip::modular::words_of(fp2_moduli[i]) == 12 ? 7 : 6);
         }
         c.n_airs = (unsigned)c.ids.size();
         return c;
@@ -225,6 +225,15 @@ public:
     uint32_t peek_memory(uint32_t addr) const { return mem_word(addr); }   // a word of the guest's memory as it is now (zero beyond its end)
 
     // Executes the next segment into `r`.  Returns true once the guest has exited (then r.pc_end = 0).
+    // words of the buffer of an intrinsic call (a7 = call, a1 = index + 8 op): operands of 8 words, or 12 for a modulus above 2^256
+    uint32_t call_words(uint32_t call, uint32_t a1) const {
+        const uint32_t i = a1 & 7u;
+        auto nw = [](const zkhip::modular::UInt& p) { return (uint32_t)zkhip::modular::words_of(p); };
+        if (call == 5) return 3 * (i < caps_.moduli.size() ? nw(caps_.moduli[i]) : 8u);
+        if (call == 7) return 6 * (i < caps_.curves.size() ? nw(caps_.curves[i].p) : 8u);
+        if (call == 8) return 6 * (i < caps_.fp2_moduli.size() ? nw(caps_.fp2_moduli[i]) : 8u);
+        return 24;   // (int256)
+    }
     bool run_segment(SegmentRecords& r) {
         r.clear();
         reset_blocks();
@@ -242,7 +251,7 @@ public:
             // would one more instruction overflow a chip?  (the blocks and path nodes it would add are counted exactly)
             size_t new_blocks = 0, new_nodes = 0;
             {
-                uint32_t labels[5 + 14];
+                uint32_t labels[5 + 20];
                 unsigned nl = 0;
                 bool all_known = true;
                 auto want = [&](uint32_t as, uint32_t word) {
@@ -256,7 +265,7 @@ public:
                 if (d.cls == vmc::C_LS) want(2, ((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) >> 2);
                 if (d.cls == vmc::C_ECALL) want(1, 11), want(3, m_.reg(11) & 7u);
                 if (d.cls == vmc::C_ECALL && m_.reg(17) >= 3 && m_.reg(17) <= 8) {
-                    const uint32_t n_words = m_.reg(17) == 3 ? 50 : m_.reg(17) >= 7 ? 48 : 24;
+                    const uint32_t n_words = m_.reg(17) == 3 ? 50 : call_words(m_.reg(17), m_.reg(11));
                     for (uint32_t w = m_.reg(10) >> 2; w < (m_.reg(10) >> 2) + n_words; w += (w & 3u) ? 4 - (w & 3u) : 4) want(2, w);
                 }
                 if (!all_known) {   // rare: count exactly what the instruction would add
@@ -318,17 +327,19 @@ public:
                 if (a1 >= 8) throw Error("public value index out of range");
                 memcpy(&pv_before, m_.public_values().data() + 4 * a1, 4);
             }
-            uint32_t mm_in[24];
+            // (a call's buffer: 3 nw words for the modular intrinsic, 6 nw for ecc / fp2 -- nw = 8 or 12 words per operand)
+            uint32_t mm_in[36];
+            const uint32_t cw = d.cls == vmc::C_ECALL && x >= 5 && x <= 8 ? call_words(x, m_.reg(11)) : 0u, nw = x == 5 || x == 6 ? cw / 3 : cw / 6;
             if (d.cls == vmc::C_ECALL && (x == 5 || x == 6)) {
                 a1 = m_.reg(11);
-                if ((y & 3u) || (uint64_t)y + 96 > (1ull << 30)) throw Error("modmul / int256 buffer must be word-aligned and below 2^30");
-                for (uint32_t j = 0; j < 24; j++) mm_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
+                if ((y & 3u) || (uint64_t)y + 4 * cw > (1ull << 30)) throw Error("modmul / int256 buffer must be word-aligned and below 2^30");
+                for (uint32_t j = 0; j < cw; j++) mm_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
             }
-            uint32_t ec_in[48];
+            uint32_t ec_in[72];
             if (d.cls == vmc::C_ECALL && (x == 7 || x == 8)) {
                 a1 = m_.reg(11);
-                if ((y & 3u) || (uint64_t)y + 192 > (1ull << 30)) throw Error("ecc / fp2 buffer must be word-aligned and below 2^30");
-                for (uint32_t j = 0; j < 48; j++) ec_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
+                if ((y & 3u) || (uint64_t)y + 4 * cw > (1ull << 30)) throw Error("ecc / fp2 buffer must be word-aligned and below 2^30");
+                for (uint32_t j = 0; j < cw; j++) ec_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
             }
             // snapshot the blocks this instruction is going to change
             if (d.wr_rd) (void)block_of(1, d.rd);
@@ -404,17 +415,17 @@ public:
                     const uint32_t ci = a1 & 7u, eop = a1 >> 3;
                     r.ec_ts[ci].push_back(ts);
                     r.ec_records[ci].push_back(eop);
-                    r.ec_records[ci].insert(r.ec_records[ci].end(), ec_in, ec_in + 32);
-                    r.ec_records[ci].insert(r.ec_records[ci].end(), m_.last_slope().w, m_.last_slope().w + 8);
-                    constexpr uint32_t W = 48;
+                    r.ec_records[ci].insert(r.ec_records[ci].end(), ec_in, ec_in + 4 * nw);
+                    r.ec_records[ci].insert(r.ec_records[ci].end(), m_.last_slope().w, m_.last_slope().w + nw);
+                    const uint32_t W = cw, IOW = (uint32_t)vmc::ec_io_width(nw);
                     for (uint32_t k = 0; k < W; k++) {   // the adapter's rows: the operands read, the result written, all at ts + 5
-                        uint32_t sr[vmc::EC_IO_WIDTH] = {};
+                        uint32_t sr[vmc::ec_io_width(12)] = {};
                         const uint32_t w = (y >> 2) + k, before = ec_in[k], after = mem_word(y + 4 * k);
                         sr[k] = 1, sr[W] = ts, sr[W + 1] = y >> 2, sr[W + 9] = 1, sr[W + 10] = eop;
                         sr[W + 2] = before & 0xffffu, sr[W + 3] = before >> 16, sr[W + 4] = after & 0xffffu, sr[W + 5] = after >> 16;
-                        const uint32_t pts = k >= 32 ? write_word(2, w, after, ts + 5) : read_word(2, w, before, ts + 5), gap = ts + 5 - pts - 1;
+                        const uint32_t pts = k >= 4 * nw ? write_word(2, w, after, ts + 5) : read_word(2, w, before, ts + 5), gap = ts + 5 - pts - 1;
                         sr[W + 6] = pts, sr[W + 7] = gap & 0xffffu, sr[W + 8] = gap >> 16;
-                        r.ecio_rows[ci].insert(r.ecio_rows[ci].end(), sr, sr + vmc::EC_IO_WIDTH);
+                        r.ecio_rows[ci].insert(r.ecio_rows[ci].end(), sr, sr + IOW);
                     }
                 }
                 if (x == 8) {
@@ -425,20 +436,20 @@ public:
                     r.fp2_ts[fi].push_back(ts);
                     r.fp2_records[fi].push_back(fop);
                     if (fop == zkhip::fp2::OP_DIV) {   // the chip's row is the product (x / y) y = x: the record holds the quotient and y
-                        for (uint32_t k = 0; k < 16; k++) r.fp2_records[fi].push_back(mem_word(y + 128 + 4 * k));
-                        r.fp2_records[fi].insert(r.fp2_records[fi].end(), ec_in + 16, ec_in + 32);
+                        for (uint32_t k = 0; k < 2 * nw; k++) r.fp2_records[fi].push_back(mem_word(y + 16 * nw + 4 * k));
+                        r.fp2_records[fi].insert(r.fp2_records[fi].end(), ec_in + 2 * nw, ec_in + 4 * nw);
                     } else {
-                        r.fp2_records[fi].insert(r.fp2_records[fi].end(), ec_in, ec_in + 32);
+                        r.fp2_records[fi].insert(r.fp2_records[fi].end(), ec_in, ec_in + 4 * nw);
                     }
-                    constexpr uint32_t W = 48;
+                    const uint32_t W = cw, IOW = (uint32_t)vmc::ec_io_width(nw);
                     for (uint32_t k = 0; k < W; k++) {   // the adapter's rows: the operands read, the result written, all at ts + 5
-                        uint32_t sr[vmc::EC_IO_WIDTH] = {};
+                        uint32_t sr[vmc::ec_io_width(12)] = {};
                         const uint32_t w = (y >> 2) + k, before = ec_in[k], after = mem_word(y + 4 * k);
                         sr[k] = 1, sr[W] = ts, sr[W + 1] = y >> 2, sr[W + 9] = 1, sr[W + 10] = fop;
                         sr[W + 2] = before & 0xffffu, sr[W + 3] = before >> 16, sr[W + 4] = after & 0xffffu, sr[W + 5] = after >> 16;
-                        const uint32_t pts = k >= 32 ? write_word(2, w, after, ts + 5) : read_word(2, w, before, ts + 5), gap = ts + 5 - pts - 1;
+                        const uint32_t pts = k >= 4 * nw ? write_word(2, w, after, ts + 5) : read_word(2, w, before, ts + 5), gap = ts + 5 - pts - 1;
                         sr[W + 6] = pts, sr[W + 7] = gap & 0xffffu, sr[W + 8] = gap >> 16;
-                        r.fp2io_rows[fi].insert(r.fp2io_rows[fi].end(), sr, sr + vmc::EC_IO_WIDTH);
+                        r.fp2io_rows[fi].insert(r.fp2io_rows[fi].end(), sr, sr + IOW);
                     }
                 }
                 if (x == 5) {
@@ -449,19 +460,20 @@ public:
                     r.mm_ts[mi].push_back(ts);
                     r.mm_records[mi].push_back(mop);
                     if (mop == zkhip::modular::OP_DIV) {   // the chip's row is the product (x / y) y = x: the record holds the quotient and y
-                        for (uint32_t k = 0; k < 8; k++) r.mm_records[mi].push_back(mem_word(y + 64 + 4 * k));
-                        r.mm_records[mi].insert(r.mm_records[mi].end(), mm_in + 8, mm_in + 16);
+                        for (uint32_t k = 0; k < nw; k++) r.mm_records[mi].push_back(mem_word(y + 8 * nw + 4 * k));
+                        r.mm_records[mi].insert(r.mm_records[mi].end(), mm_in + nw, mm_in + 2 * nw);
                     } else {
-                        r.mm_records[mi].insert(r.mm_records[mi].end(), mm_in, mm_in + 16);
+                        r.mm_records[mi].insert(r.mm_records[mi].end(), mm_in, mm_in + 2 * nw);
                     }
-                    for (uint32_t k = 0; k < 24; k++) {   // the adapter's rows: a, b read, r written, all at ts + 5
-                        uint32_t sr[vmc::MODMUL_IO_WIDTH] = {};
+                    const uint32_t W = cw, IOW = (uint32_t)vmc::modmul_io_width(nw);
+                    for (uint32_t k = 0; k < W; k++) {   // the adapter's rows: a, b read, r written, all at ts + 5
+                        uint32_t sr[vmc::modmul_io_width(12)] = {};
                         const uint32_t w = (y >> 2) + k, before = mm_in[k], after = mem_word(y + 4 * k);
-                        sr[k] = 1, sr[24] = ts, sr[25] = y >> 2, sr[33] = 1, sr[34] = mop;
-                        sr[26] = before & 0xffffu, sr[27] = before >> 16, sr[28] = after & 0xffffu, sr[29] = after >> 16;
-                        const uint32_t pts = k >= 16 ? write_word(2, w, after, ts + 5) : read_word(2, w, before, ts + 5), gap = ts + 5 - pts - 1;
-                        sr[30] = pts, sr[31] = gap & 0xffffu, sr[32] = gap >> 16;
-                        r.mmio_rows[mi].insert(r.mmio_rows[mi].end(), sr, sr + vmc::MODMUL_IO_WIDTH);
+                        sr[k] = 1, sr[W] = ts, sr[W + 1] = y >> 2, sr[W + 9] = 1, sr[W + 10] = mop;
+                        sr[W + 2] = before & 0xffffu, sr[W + 3] = before >> 16, sr[W + 4] = after & 0xffffu, sr[W + 5] = after >> 16;
+                        const uint32_t pts = k >= 2 * nw ? write_word(2, w, after, ts + 5) : read_word(2, w, before, ts + 5), gap = ts + 5 - pts - 1;
+                        sr[W + 6] = pts, sr[W + 7] = gap & 0xffffu, sr[W + 8] = gap >> 16;
+                        r.mmio_rows[mi].insert(r.mmio_rows[mi].end(), sr, sr + IOW);
                     }
                 }
                 if (x == 4) {

@@ -47,17 +47,17 @@ inline SegmentAirs segment_airs(const Exe& exe, const SegmentCaps& caps) {
         if (id >= vmc::A_FP2(0)) {   // the fp2 extension: chip / adapter of field i
             const unsigned i = (id - vmc::A_FP2(0)) / 2;
             const zkhip::modular::Modulus m = zkhip::modular::modulus_bytes(caps.fp2_moduli.at(i));
-            if (zkhip_vm_fp2_air(m.data(), i, (id - vmc::A_FP2(0)) & 1, &s.airs[p]) != ZKHIP_OK) throw Error("zkhip_vm_fp2_air failed (the modulus must be odd with a non-zero top byte)");
+            if (zkhip_vm_fp2_air_x(m.data(), m.limbs, i, (id - vmc::A_FP2(0)) & 1, &s.airs[p]) != ZKHIP_OK) throw Error("zkhip_vm_fp2_air failed (the modulus must be odd with a non-zero top byte)");
             s.prep_width[p] = 0;
         } else if (id >= vmc::A_EC(0)) {   // the ecc extension: chip / adapter of curve i
             const unsigned i = (id - vmc::A_EC(0)) / 2;
-            const zkhip::modular::Modulus m = zkhip::modular::modulus_bytes(caps.curves.at(i).p), ca = zkhip::modular::modulus_bytes(caps.curves.at(i).a);
-            if (zkhip_vm_ec_air(m.data(), ca.data(), i, (id - vmc::A_EC(0)) & 1, &s.airs[p]) != ZKHIP_OK) throw Error("zkhip_vm_ec_air failed (the modulus must be odd with a non-zero top byte)");
+            const zkhip::modular::Modulus m = zkhip::modular::modulus_bytes(caps.curves.at(i).p), ca = zkhip::modular::modulus_bytes(caps.curves.at(i).a, m.limbs);
+            if (zkhip_vm_ec_air_x(m.data(), ca.data(), m.limbs, i, (id - vmc::A_EC(0)) & 1, &s.airs[p]) != ZKHIP_OK) throw Error("zkhip_vm_ec_air failed (the modulus must be odd with a non-zero top byte)");
             s.prep_width[p] = 0;
         } else if (id >= vmc::N_STATIC_AIRS) {   // the modular extension: chip / adapter of modulus i
             const unsigned i = (id - vmc::N_STATIC_AIRS) / 2;
             const zkhip::modular::Modulus m = zkhip::modular::modulus_bytes(caps.moduli.at(i));
-            if (zkhip_vm_modmul_air(m.data(), i, (id - vmc::N_STATIC_AIRS) & 1, &s.airs[p]) != ZKHIP_OK) throw Error("zkhip_vm_modmul_air failed");
+            if (zkhip_vm_modmul_air_x(m.data(), m.limbs, i, (id - vmc::N_STATIC_AIRS) & 1, &s.airs[p]) != ZKHIP_OK) throw Error("zkhip_vm_modmul_air failed");
             s.prep_width[p] = 0;
         } else if (zkhip_vm_air(id, &s.airs[p], &s.prep_width[p]) != ZKHIP_OK) {
             throw Error("zkhip_vm_air failed");
@@ -199,20 +199,25 @@ public:
             check(zkhip_vm_shift256_tracegen(ctx_, up(r.sh256_records), up(r.sh256_ts), r.sh256_ts.size(), H(vmc::A_SHIFT256), T(vmc::A_SHIFT256), d_bw));
         }
         for (unsigned i = 0; i < caps_.moduli.size(); i++) {   // modular extension: the chip's lookups are counted by its generator
-            check(zkhip_vm_modmul_tracegen(ctx_, caps_.moduli[i].w, up(r.mm_records[i]), up(r.mm_ts[i]), r.mm_ts[i].size(), H(vmc::A_MODMUL(i)), T(vmc::A_MODMUL(i)), d_bw,
-                                           d_tup, TUPLE_X, TUPLE_Y));
-            check(zkhip_rows_tracegen(ctx_, up(r.mmio_rows[i]), r.mmio_rows[i].size() / vmc::MODMUL_IO_WIDTH, vmc::MODMUL_IO_WIDTH, H(vmc::A_MODMUL_IO(i)),
-                                      T(vmc::A_MODMUL_IO(i)), nullptr));
+            const uint32_t nw = (uint32_t)zkhip::modular::words_of(caps_.moduli[i]);
+            const size_t iow = vmc::modmul_io_width(nw);
+            check(zkhip_vm_modmul_tracegen_x(ctx_, nw, caps_.moduli[i].w, up(r.mm_records[i]), up(r.mm_ts[i]), r.mm_ts[i].size(), H(vmc::A_MODMUL(i)), T(vmc::A_MODMUL(i)), d_bw,
+                                             d_tup, TUPLE_X, TUPLE_Y));
+            check(zkhip_rows_tracegen(ctx_, up(r.mmio_rows[i]), r.mmio_rows[i].size() / iow, iow, H(vmc::A_MODMUL_IO(i)), T(vmc::A_MODMUL_IO(i)), nullptr));
         }
         for (unsigned i = 0; i < caps_.curves.size(); i++) {   // ecc extension: the chip's lookups are counted by its generator
-            check(zkhip_vm_ec_tracegen(ctx_, caps_.curves[i].p.w, caps_.curves[i].a.w, up(r.ec_records[i]), up(r.ec_ts[i]), r.ec_ts[i].size(), H(vmc::A_EC(i)), T(vmc::A_EC(i)),
-                                       d_bw, d_tup, TUPLE_X, TUPLE_Y));
-            check(zkhip_rows_tracegen(ctx_, up(r.ecio_rows[i]), r.ecio_rows[i].size() / vmc::EC_IO_WIDTH, vmc::EC_IO_WIDTH, H(vmc::A_EC_IO(i)), T(vmc::A_EC_IO(i)), nullptr));
+            const uint32_t nw = (uint32_t)zkhip::modular::words_of(caps_.curves[i].p);
+            const size_t iow = vmc::ec_io_width(nw);
+            check(zkhip_vm_ec_tracegen_x(ctx_, nw, caps_.curves[i].p.w, caps_.curves[i].a.w, up(r.ec_records[i]), up(r.ec_ts[i]), r.ec_ts[i].size(), H(vmc::A_EC(i)), T(vmc::A_EC(i)),
+                                         d_bw, d_tup, TUPLE_X, TUPLE_Y));
+            check(zkhip_rows_tracegen(ctx_, up(r.ecio_rows[i]), r.ecio_rows[i].size() / iow, iow, H(vmc::A_EC_IO(i)), T(vmc::A_EC_IO(i)), nullptr));
         }
         for (unsigned i = 0; i < caps_.fp2_moduli.size(); i++) {   // fp2 extension: the chip's lookups are counted by its generator
-            check(zkhip_vm_fp2_tracegen(ctx_, caps_.fp2_moduli[i].w, up(r.fp2_records[i]), up(r.fp2_ts[i]), r.fp2_ts[i].size(), H(vmc::A_FP2(i)), T(vmc::A_FP2(i)), d_bw, d_tup,
-                                        TUPLE_X, TUPLE_Y));
-            check(zkhip_rows_tracegen(ctx_, up(r.fp2io_rows[i]), r.fp2io_rows[i].size() / vmc::EC_IO_WIDTH, vmc::EC_IO_WIDTH, H(vmc::A_FP2_IO(i)), T(vmc::A_FP2_IO(i)), nullptr));
+            const uint32_t nw = (uint32_t)zkhip::modular::words_of(caps_.fp2_moduli[i]);
+            const size_t iow = vmc::ec_io_width(nw);
+            check(zkhip_vm_fp2_tracegen_x(ctx_, nw, caps_.fp2_moduli[i].w, up(r.fp2_records[i]), up(r.fp2_ts[i]), r.fp2_ts[i].size(), H(vmc::A_FP2(i)), T(vmc::A_FP2(i)), d_bw, d_tup,
+                                          TUPLE_X, TUPLE_Y));
+            check(zkhip_rows_tracegen(ctx_, up(r.fp2io_rows[i]), r.fp2io_rows[i].size() / iow, iow, H(vmc::A_FP2_IO(i)), T(vmc::A_FP2_IO(i)), nullptr));
         }
         // ---- lookup multiplicities of the new chips, counted from the requesting columns
         auto pairs = [&](unsigned a, size_t cx, size_t cy, size_t n) {
@@ -265,21 +270,28 @@ public:
                 const uint32_t* row = &r.i256io_rows[i * vmc::INT256_IO_WIDTH];
                 misc.push_back(row[31]), tup_y.push_back(row[32]);
             }
-            for (unsigned m = 0; m < caps_.moduli.size(); m++)
-                for (size_t i = 0; i < r.mmio_rows[m].size() / vmc::MODMUL_IO_WIDTH; i++) {
-                    const uint32_t* row = &r.mmio_rows[m][i * vmc::MODMUL_IO_WIDTH];
-                    misc.push_back(row[31]), tup_y.push_back(row[32]);
+            // (an adapter row: word[W] | ts | base | v_lo v_hi | n_lo n_hi | prev_ts gap_lo gap_hi | ..: the gap's halves at W + 7, W + 8)
+            for (unsigned m = 0; m < caps_.moduli.size(); m++) {
+                const size_t nw = zkhip::modular::words_of(caps_.moduli[m]), iow = vmc::modmul_io_width(nw), W = 3 * nw;
+                for (size_t i = 0; i < r.mmio_rows[m].size() / iow; i++) {
+                    const uint32_t* row = &r.mmio_rows[m][i * iow];
+                    misc.push_back(row[W + 7]), tup_y.push_back(row[W + 8]);
                 }
-            for (unsigned m = 0; m < caps_.curves.size(); m++)
-                for (size_t i = 0; i < r.ecio_rows[m].size() / vmc::EC_IO_WIDTH; i++) {
-                    const uint32_t* row = &r.ecio_rows[m][i * vmc::EC_IO_WIDTH];
-                    misc.push_back(row[55]), tup_y.push_back(row[56]);
+            }
+            for (unsigned m = 0; m < caps_.curves.size(); m++) {
+                const size_t nw = zkhip::modular::words_of(caps_.curves[m].p), iow = vmc::ec_io_width(nw), W = 6 * nw;
+                for (size_t i = 0; i < r.ecio_rows[m].size() / iow; i++) {
+                    const uint32_t* row = &r.ecio_rows[m][i * iow];
+                    misc.push_back(row[W + 7]), tup_y.push_back(row[W + 8]);
                 }
-            for (unsigned m = 0; m < caps_.fp2_moduli.size(); m++)
-                for (size_t i = 0; i < r.fp2io_rows[m].size() / vmc::EC_IO_WIDTH; i++) {
-                    const uint32_t* row = &r.fp2io_rows[m][i * vmc::EC_IO_WIDTH];
-                    misc.push_back(row[55]), tup_y.push_back(row[56]);
+            }
+            for (unsigned m = 0; m < caps_.fp2_moduli.size(); m++) {
+                const size_t nw = zkhip::modular::words_of(caps_.fp2_moduli[m]), iow = vmc::ec_io_width(nw), W = 6 * nw;
+                for (size_t i = 0; i < r.fp2io_rows[m].size() / iow; i++) {
+                    const uint32_t* row = &r.fp2io_rows[m][i * iow];
+                    misc.push_back(row[W + 7]), tup_y.push_back(row[W + 8]);
                 }
+            }
             uint32_t* d_misc = const_cast<uint32_t*>(up(misc));
             check(zkhip_to_monty(ctx_, d_misc, misc.size()));
             count(d_misc, misc.size());
@@ -776,12 +788,11 @@ inline zkhip::modular::U256 parse_decimal_u256(const std::string& digits) {
     for (char ch : digits) {   // decimal -> words
         if (ch < '0' || ch > '9') throw Error("openvm.toml: a modulus or coefficient is not a decimal number");
         uint64_t c = (uint64_t)(ch - '0');
-        for (int w = 0; w < 8; w++) {
+        for (size_t w = 0; w < zkhip::modular::MAX_WORDS; w++) {
             c += (uint64_t)v.w[w] * 10u;
             v.w[w] = (uint32_t)c, c >>= 32;
         }
-        if (c) throw Error("openvm.toml: a modulus or coefficient does not fit 256 bits (the limb chips are built for 32 byte limbs: the 381-bit field of the "
-                           "reference's batch circuit is not supported)");
+        if (c) throw Error("openvm.toml: a modulus or coefficient does not fit 384 bits (the limb chips are built for 32 or 48 byte limbs)");
     }
     return v;
 }

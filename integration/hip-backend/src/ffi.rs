@@ -409,6 +409,29 @@ extern "C" {
                                       d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_vm_mul256_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
                                     d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    // the `_x` forms of the limb chips: n_limbs = 32 or 48 (BLS12-381's base field, Fp2 and G1 of the batch circuit), n_words = n_limbs / 4
+    pub fn zkhip_vm_modmul_air_x(modulus: *const u8, n_limbs: u32, index: c_uint, adapter: c_int, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_vm_modmul_tracegen_x(ctx: *mut zkhip_ctx, n_words: u32, modulus: *const u32, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint,
+                                      d_trace: *mut u32, d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    pub fn zkhip_vm_ec_air_x(modulus: *const u8, a: *const u8, n_limbs: u32, index: c_uint, adapter: c_int, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_vm_ec_tracegen_x(ctx: *mut zkhip_ctx, n_words: u32, modulus: *const u32, a: *const u32, d_records: *const u32, d_ts: *const u32, n: usize,
+                                  log_height: c_uint, d_trace: *mut u32, d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    pub fn zkhip_vm_fp2_air_x(modulus: *const u8, n_limbs: u32, index: c_uint, adapter: c_int, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_vm_fp2_tracegen_x(ctx: *mut zkhip_ctx, n_words: u32, modulus: *const u32, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint,
+                                   d_trace: *mut u32, d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    pub fn zkhip_modmul_air_x(modulus: *const u8, n_limbs: u32, bitwise_bus: u32, tuple_bus: u32, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_modular_host_x(op: u32, n_words: u32, a: *const u32, b: *const u32, modulus: *const u32, q: *mut u32, r: *mut u32) -> c_int;
+    pub fn zkhip_modular_tracegen_x(ctx: *mut zkhip_ctx, n_words: u32, modulus: *const u32, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
+                                    d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    pub fn zkhip_ec_air_x(modulus: *const u8, a: *const u8, n_limbs: u32, bitwise_bus: u32, tuple_bus: u32, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_ec_host_x(op: u32, n_words: u32, modulus: *const u32, a: *const u32, x1: *const u32, y1: *const u32, x2: *const u32, y2: *const u32,
+                           slope: *mut u32, x3: *mut u32, y3: *mut u32) -> c_int;
+    pub fn zkhip_ec_tracegen_x(ctx: *mut zkhip_ctx, n_words: u32, modulus: *const u32, a: *const u32, d_records: *const u32, n: usize, log_height: c_uint,
+                               d_trace: *mut u32, d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
+    pub fn zkhip_fp2_air_x(modulus: *const u8, n_limbs: u32, bitwise_bus: u32, tuple_bus: u32, out: *mut zkhip_air) -> c_int;
+    pub fn zkhip_fp2_host_x(op: u32, n_words: u32, modulus: *const u32, a: *const u32, b: *const u32, r: *mut u32) -> c_int;
+    pub fn zkhip_fp2_tracegen_x(ctx: *mut zkhip_ctx, n_words: u32, modulus: *const u32, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
+                                d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
     pub fn zkhip_fp2_air(modulus: *const u8, bitwise_bus: u32, tuple_bus: u32, out: *mut zkhip_air) -> c_int;
     pub fn zkhip_fp2_host(op: u32, modulus: *const u32, a: *const u32, b: *const u32, r: *mut u32) -> c_int;
     pub fn zkhip_fp2_tracegen(ctx: *mut zkhip_ctx, modulus: *const u32, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,

@@ -11,12 +11,25 @@ COL_Q, COL_QS, COL_CX, COL_CY, COL_MARK, COL_DIFF, COL_REAL, COL_DBL = 224, 323,
 NOPV = np.zeros(0, np.uint32)
 
 
-def words(v):
-    return [(int(v) >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+def words(v, n=8):
+    return [(int(v) >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
 
 
-def record(op, p1, p2, slope):
-    return [op] + words(p1[0]) + words(p1[1]) + words(p2[0]) + words(p2[1]) + words(slope)
+def record(op, p1, p2, slope, n=8):
+    """n = words per coordinate: 8, or 12 for a modulus above 2^256 (48 limbs)"""
+    return [op] + words(p1[0], n) + words(p1[1], n) + words(p2[0], n) + words(p2[1], n) + words(slope, n)
+
+
+def cols(L):
+    """column offsets of the chip for L limbs (include/zkhip_ecc.hpp `Cols`)"""
+    ql, nc = L + 1, 2 * L - 1
+    c = dict(L=L, Q_LIMBS=ql, N_POS=2 * L, N_CARRY=nc, Q=7 * L, QS=7 * L + 3 * ql)
+    c["CX"] = c["QS"] + 3
+    c["CY"] = c["CX"] + 3 * nc
+    c["MARK"] = c["CY"] + 3 * nc
+    c["DIFF"] = c["MARK"] + 2 * L
+    c["REAL"], c["DBL"], c["WIDTH"] = c["DIFF"] + 2, c["DIFF"] + 3, c["DIFF"] + 4
+    return c
 
 
 def slope_of(op, p, a, p1, p2):
@@ -26,12 +39,17 @@ def slope_of(op, p, a, p1, p2):
 
 
 def twin_trace(calls, p, a, log_height):
-    """calls: [(op, (x1, y1), (x2, y2), slope)] -> (trace [772, N] canonical, bitwise range counts [65536], tuple counts [SX * SY])"""
+    """calls: [(op, (x1, y1), (x2, y2), slope)] -> (trace [WIDTH, N] canonical, bitwise range counts [65536], tuple counts [SX * SY]);
+    32 limbs (772 columns) for a modulus below 2^256, 48 (1156 columns) above"""
+    NL = 32 if p < 1 << 256 else 48
+    C = cols(NL)
+    WIDTH, Q_LIMBS, N_POS, N_CARRY = C["WIDTH"], C["Q_LIMBS"], C["N_POS"], C["N_CARRY"]
+    COL_Q, COL_QS, COL_CX, COL_CY, COL_MARK, COL_DIFF, COL_REAL, COL_DBL = C["Q"], C["QS"], C["CX"], C["CY"], C["MARK"], C["DIFF"], C["REAL"], C["DBL"]
     N = 1 << log_height
     tr = np.zeros((WIDTH, N), np.uint32)
     bw, tup = np.zeros(1 << 16, np.uint32), np.zeros(SX * SY, np.uint32)
-    pb = p.to_bytes(32, "little")
-    ab = a.to_bytes(32, "little")
+    pb = p.to_bytes(NL, "little")
+    ab = a.to_bytes(NL, "little")
     for row, (op, p1, p2, lam) in enumerate(calls):
         x1, y1, x2, y2 = p1[0], p1[1], p2[0], p2[1]
         dbl = op == 1
@@ -42,10 +60,10 @@ def twin_trace(calls, p, a, log_height):
         y3 = (lam * (x1 - x3) - y1) % p
         v3 = lam * (x1 - x3) - y1 - y3
         qs = [v // p for v in (v1, v2, v3)]
-        L = [v.to_bytes(32, "little") for v in (x1, y1, x2, y2, lam, x3, y3)]
+        L = [v.to_bytes(NL, "little") for v in (x1, y1, x2, y2, lam, x3, y3)]
         for o, limbs in enumerate(L):
-            tr[32 * o:32 * o + 32, row] = np.frombuffer(limbs, dtype=np.uint8)
-            for i in range(0, 32, 2):
+            tr[NL * o:NL * o + NL, row] = np.frombuffer(limbs, dtype=np.uint8)
+            for i in range(0, NL, 2):
                 bw[limbs[i] * 256 + limbs[i + 1]] += 1
         X1, Y1, X2, Y2, LM, X3, Y3 = L
         for e, q in enumerate(qs):
@@ -60,10 +78,10 @@ def twin_trace(calls, p, a, log_height):
                 s = c
                 for i in range(Q_LIMBS):
                     j = k - i
-                    if j < 0 or j >= 32:
+                    if j < 0 or j >= NL:
                         continue
                     s -= (-1 if neg else 1) * ql[i] * pb[j]
-                    if i >= 32:
+                    if i >= NL:
                         continue
                     if e == 0:
                         s += 2 * LM[i] * Y1[j] - 3 * X1[i] * X1[j] if dbl else LM[i] * (X2[j] - X1[j])
@@ -71,7 +89,7 @@ def twin_trace(calls, p, a, log_height):
                         s += LM[i] * LM[j]
                     else:
                         s += LM[i] * (X1[j] - X3[j])
-                if k < 32:
+                if k < NL:
                     if e == 0:
                         s -= ab[k] if dbl else Y2[k] - Y1[k]
                     elif e == 1:
@@ -88,8 +106,8 @@ def twin_trace(calls, p, a, log_height):
                 else:
                     assert c == 0
         for o, limbs in enumerate((X3, Y3)):
-            mark = max(i for i in range(32) if limbs[i] != pb[i])
-            tr[COL_MARK + 32 * o + mark, row] = 1
+            mark = max(i for i in range(NL) if limbs[i] != pb[i])
+            tr[COL_MARK + NL * o + mark, row] = 1
             diff = pb[mark] - limbs[mark]
             assert 1 <= diff <= 255
             tr[COL_DIFF + o, row] = diff

@@ -11,21 +11,41 @@ COL_Q, COL_QS, COL_CX, COL_CY, COL_MARK, COL_DIFF, COL_MARK2, COL_DIFF2, COL_REA
 NOPV = np.zeros(0, np.uint32)
 
 
-def words(v):
-    return [(int(v) >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+def words(v, n=8):
+    return [(int(v) >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
 
 
-def record(op, a, b):
-    """the device record of a call: for a division (a, b) is (quotient, divisor)"""
-    return [op] + words(a[0]) + words(a[1]) + words(b[0]) + words(b[1])
+def record(op, a, b, n=8):
+    """the device record of a call: for a division (a, b) is (quotient, divisor); n = words per component (12 for a 48-limb modulus)"""
+    return [op] + words(a[0], n) + words(a[1], n) + words(b[0], n) + words(b[1], n)
+
+
+def cols(L):
+    """column offsets of the chip for L limbs (include/zkhip_fp2.hpp `Cols`)"""
+    ql, nc = L + 1, 2 * L - 1
+    c = dict(L=L, Q_LIMBS=ql, N_POS=2 * L, N_CARRY=nc, Q=6 * L, QS=6 * L + 2 * ql)
+    c["CX"] = c["QS"] + 2
+    c["CY"] = c["CX"] + 2 * nc
+    c["MARK"] = c["CY"] + 2 * nc
+    c["DIFF"] = c["MARK"] + 2 * L
+    c["MARK2"] = c["DIFF"] + 2
+    c["DIFF2"] = c["MARK2"] + 2 * L
+    c["REAL"] = c["DIFF2"] + 2
+    c["WIDTH"] = c["REAL"] + 4
+    return c
 
 
 def twin_trace(calls, p, log_height):
-    """calls: [(op, (a0, a1), (b0, b1))] as the RECORDS hold them -> (trace [648, N] canonical, bitwise range counts, tuple counts)"""
+    """calls: [(op, (a0, a1), (b0, b1))] as the RECORDS hold them -> (trace [WIDTH, N] canonical, bitwise range counts, tuple counts);
+    32 limbs (648 columns) for a modulus below 2^256, 48 (968 columns) above"""
+    NL = 32 if p < 1 << 256 else 48
+    C = cols(NL)
+    WIDTH, Q_LIMBS, N_POS, N_CARRY = C["WIDTH"], C["Q_LIMBS"], C["N_POS"], C["N_CARRY"]
+    COL_Q, COL_QS, COL_CX, COL_CY, COL_MARK, COL_DIFF, COL_MARK2, COL_DIFF2, COL_REAL = (C[k] for k in ("Q", "QS", "CX", "CY", "MARK", "DIFF", "MARK2", "DIFF2", "REAL"))
     N = 1 << log_height
     tr = np.zeros((WIDTH, N), np.uint32)
     bw, tup = np.zeros(1 << 16, np.uint32), np.zeros(SX * SY, np.uint32)
-    pb = p.to_bytes(32, "little")
+    pb = p.to_bytes(NL, "little")
     for row, (op_in, a, b) in enumerate(calls):
         is_div = op_in == 3
         op = 0 if is_div else op_in
@@ -37,10 +57,10 @@ def twin_trace(calls, p, log_height):
             v = [a[0] - b[0], a[1] - b[1]]
         r = [x % p for x in v]
         qs = [(x - y) // p for x, y in zip(v, r)]
-        L = [x.to_bytes(32, "little") for x in (a[0], a[1], b[0], b[1], r[0], r[1])]
+        L = [x.to_bytes(NL, "little") for x in (a[0], a[1], b[0], b[1], r[0], r[1])]
         for o, limbs in enumerate(L):
-            tr[32 * o:32 * o + 32, row] = np.frombuffer(limbs, dtype=np.uint8)
-            for i in range(0, 32, 2):
+            tr[NL * o:NL * o + NL, row] = np.frombuffer(limbs, dtype=np.uint8)
+            for i in range(0, NL, 2):
                 bw[limbs[i] * 256 + limbs[i + 1]] += 1
         A = (L[0], L[1])
         B = (L[2], L[3])
@@ -57,13 +77,13 @@ def twin_trace(calls, p, log_height):
                 s = c
                 for i in range(Q_LIMBS):
                     j = k - i
-                    if j < 0 or j >= 32:
+                    if j < 0 or j >= NL:
                         continue
                     s -= (-1 if neg else 1) * ql[i] * pb[j]
-                    if i >= 32 or op != 0:
+                    if i >= NL or op != 0:
                         continue
                     s += A[0][i] * B[0][j] - A[1][i] * B[1][j] if e == 0 else A[0][i] * B[1][j] + A[1][i] * B[0][j]
-                if k < 32:
+                if k < NL:
                     if op == 1:
                         s += A[e][k] + B[e][k]
                     if op == 2:
@@ -84,8 +104,8 @@ def twin_trace(calls, p, log_height):
             for e in range(2):
                 x = limbs2[e]
                 assert int.from_bytes(x, "little") < p
-                mark = max(i for i in range(32) if x[i] != pb[i])
-                tr[mcol + 32 * e + mark, row] = 1
+                mark = max(i for i in range(NL) if x[i] != pb[i])
+                tr[mcol + NL * e + mark, row] = 1
                 diff = pb[mark] - x[mark]
                 tr[dcol + e, row] = diff
                 bw[(diff - 1) * 256] += 1

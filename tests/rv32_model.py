@@ -319,26 +319,29 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                 off = rr(10) - data_base
                 sel = rr(11)                 # a1 = modulus index + 8 * operation (0 mul, 1 add, 2 sub, 3 div, 4 is_eq)
                 p_, mop = moduli[sel & 7], sel >> 3
-                assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem) and mop < 5
-                a_, b_ = int.from_bytes(mem[off:off + 32], "little"), int.from_bytes(mem[off + 32:off + 64], "little")
+                nb = 32 if p_ < 1 << 256 else 48   # bytes per operand: a modulus above 2^256 (BLS12-381's base field) has 48-byte operands
+                assert off % 4 == 0 and 0 <= off and off + 3 * nb <= len(mem) and mop < 5
+                a_, b_ = int.from_bytes(mem[off:off + nb], "little"), int.from_bytes(mem[off + nb:off + 2 * nb], "little")
                 res = int((a_ - b_) % p_ == 0) if mop == 4 else a_ * pow(b_, -1, p_) % p_ if mop == 3 else [a_ * b_ % p_, (a_ + b_) % p_, (a_ - b_) % p_][mop]
-                mem[off + 64:off + 96] = res.to_bytes(32, "little")
+                mem[off + 2 * nb:off + 3 * nb] = res.to_bytes(nb, "little")
             elif call == 7:   # (x3, y3) = p1 + p2 (op 0) or 2 p1 (op 1) on curves[a1 & 7] = (modulus, a), 48 words at a0 (p1 | p2 | p3)
                 off = rr(10) - data_base
                 sel = rr(11)
                 (p_, a_), eop = curves[sel & 7], sel >> 3
-                assert off % 4 == 0 and 0 <= off and off + 192 <= len(mem) and eop < 2
-                x1, y1, x2, y2 = (int.from_bytes(mem[off + 32 * k:off + 32 * k + 32], "little") for k in range(4))
+                nb = 32 if p_ < 1 << 256 else 48
+                assert off % 4 == 0 and 0 <= off and off + 6 * nb <= len(mem) and eop < 2
+                x1, y1, x2, y2 = (int.from_bytes(mem[off + nb * k:off + nb * k + nb], "little") for k in range(4))
                 lam = (3 * x1 * x1 + a_) * pow(2 * y1, -1, p_) % p_ if eop else (y2 - y1) * pow(x2 - x1, -1, p_) % p_
                 x3 = (lam * lam - x1 - (x1 if eop else x2)) % p_
-                mem[off + 128:off + 160] = x3.to_bytes(32, "little")
-                mem[off + 160:off + 192] = ((lam * (x1 - x3) - y1) % p_).to_bytes(32, "little")
+                mem[off + 4 * nb:off + 5 * nb] = x3.to_bytes(nb, "little")
+                mem[off + 5 * nb:off + 6 * nb] = ((lam * (x1 - x3) - y1) % p_).to_bytes(nb, "little")
             elif call == 8:   # r = a op b in Fp[u] / (u^2 + 1) over fp2[a1 & 7], 48 words at a0 (a0 a1 | b0 b1 | r0 r1); op 0 mul 1 add 2 sub 3 div
                 off = rr(10) - data_base
                 sel = rr(11)
                 p_, fop = fp2[sel & 7], sel >> 3
-                assert off % 4 == 0 and 0 <= off and off + 192 <= len(mem) and fop < 4
-                a0_, a1_, b0_, b1_ = (int.from_bytes(mem[off + 32 * k:off + 32 * k + 32], "little") for k in range(4))
+                nb = 32 if p_ < 1 << 256 else 48
+                assert off % 4 == 0 and 0 <= off and off + 6 * nb <= len(mem) and fop < 4
+                a0_, a1_, b0_, b1_ = (int.from_bytes(mem[off + nb * k:off + nb * k + nb], "little") for k in range(4))
                 if fop == 3:   # divide: multiply by the conjugate over the norm
                     nrm = pow((b0_ * b0_ + b1_ * b1_) % p_, -1, p_)
                     b0_, b1_ = b0_ * nrm % p_, -b1_ * nrm % p_
@@ -347,8 +350,8 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                 else:
                     sg = 1 if fop == 1 else -1
                     r0_, r1_ = (a0_ + sg * b0_) % p_, (a1_ + sg * b1_) % p_
-                mem[off + 128:off + 160] = r0_.to_bytes(32, "little")
-                mem[off + 160:off + 192] = r1_.to_bytes(32, "little")
+                mem[off + 4 * nb:off + 5 * nb] = r0_.to_bytes(nb, "little")
+                mem[off + 5 * nb:off + 6 * nb] = r1_.to_bytes(nb, "little")
             elif call == 4:   # SHA-256 compression on the 24 words at a0: state[8] <- compress(state, block[16])
                 off = rr(10) - data_base
                 assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem)

@@ -309,6 +309,89 @@ def fp2_data():
     return (el(BN254_G2Y) + el(BN254_G2Y) + z64 + el(BN254_G2X) + el(BN254_G2X) + z64 + z64 + el(BN254_G2X) + z64 + el((3, 0)) + el((9, 1)) + z64 + z64 * 3 + z64 * 3)
 
 
+# ---- the reference's BATCH circuit: BLS12-381 (crates/circuits/batch-circuit/openvm.toml:18-36) -- a base field above 2^256: operands of
+# 48 bytes, limb chips of 48 limbs ----
+BLS12_381_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+BLS12_381_R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+# the standard generators of G1 (y^2 = x^3 + 4) and G2 (y^2 = x^3 + 4 (1 + u) over Fp[u] / (u^2 + 1)); test_limbs48_cpu checks both equations
+BLS12_381_G1 = (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
+                0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1)
+BLS12_381_G2X = (0x024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8,
+                 0x13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e)
+BLS12_381_G2Y = (0x0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801,
+                 0x0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be)
+BATCH_CIRCUIT_MODULI = (BLS12_381_P, BLS12_381_R)
+BATCH_CIRCUIT_CURVES = (("Bls12_381G1Affine", BLS12_381_P, BLS12_381_R, 0, 4),)
+
+
+def batch_circuit_toml(params):
+    """the sections of the reference's batch-circuit openvm.toml, in the reference's syntax and order (castf, native and pairing bring no
+    chip here: DESIGN.md 8)"""
+    return ("[app_fri_params.fri_params]\nlog_blowup = %d\nlog_final_poly_len = %d\nnum_queries = %d\ncommit_proof_of_work_bits = %d\n"
+            "query_proof_of_work_bits = %d\n\n[app_vm_config.rv32i]\n\n[app_vm_config.rv32m]\n\n[app_vm_config.io]\n\n[app_vm_config.keccak]\n\n"
+            "[app_vm_config.castf]\n\n[app_vm_config.modular]\nsupported_moduli = [\n" % tuple(params)) + "".join('    "%d",\n' % m for m in BATCH_CIRCUIT_MODULI) + (
+                "]\n[app_vm_config.native]\n[app_vm_config.pairing]\nsupported_curves = [\"Bls12_381\"]\n[app_vm_config.sha2]\n[app_vm_config.fp2]\nsupported_moduli = [\n"
+                "    [\"Bls12_381Fp2\",\"%d\"]\n]\n" % BLS12_381_P) + "".join(
+                    '[[app_vm_config.ecc.supported_curves]]\nstruct_name = "%s"\nmodulus = "%d"\nscalar = "%d"\na = "%d"\nb = "%d"\n' % c for c in BATCH_CIRCUIT_CURVES)
+
+
+BLS_MOD, BLS_EC, BLS_FP2 = 0x00400000, 0x00400400, 0x00400800   # the three regions of bls_data
+
+
+def bls_program():
+    """BLS12-381 through the three limb intrinsics with 48-byte operands (modulus 0 = p; modulus 1 = r: 32-byte operands beside them).
+    modular (stride 144): y^2, x^2, x^3, x^3 + 4, [y^2 = x^3 + 4] at the G1 generator; one product modulo r (stride 96).
+    ecc (stride 288): 2 G, then 3 G = 2 G + G.  fp2 (stride 288): y^2, x^2, x^3, x^3 + (4 + 4 u), y^2 - that at the G2 generator.
+    Reveals: 0 the equality bit, 1 / 2 the low words of 3 G, 3 / 4 the low words of y^2 and of x^3 + 4 (1 + u) in Fp2 (first component),
+    5 every word of their difference OR-ed together (zero), 6 the low word of the product modulo r, 7 the low word of y^2 modulo p."""
+    R_MOD, R_EC, R_FP2 = S0, S1, 18
+    p = rv.li(R_MOD, BLS_MOD) + rv.li(R_EC, BLS_EC) + rv.li(R_FP2, BLS_FP2)
+
+    def call(n, reg, off, which):
+        return [("addi", A0, reg, off), ("addi", A1, 0, which), ("addi", A7, 0, n), ("ecall",)]
+
+    def copy(reg, src, dst, n_words):
+        out = []
+        for k in range(n_words):
+            out += [("lw", T0, reg, src + 4 * k), ("sw", T0, reg, dst + 4 * k)]
+        return out
+    # modular: buffers of 144 bytes (a | b | r)
+    p += call(5, R_MOD, 0, 0) + call(5, R_MOD, 144, 0) + copy(R_MOD, 144 + 96, 288, 12) + call(5, R_MOD, 288, 0)
+    p += copy(R_MOD, 288 + 96, 432, 12) + call(5, R_MOD, 432, 8)                                  # x^3 + 4
+    p += copy(R_MOD, 96, 576, 12) + copy(R_MOD, 432 + 96, 576 + 48, 12) + call(5, R_MOD, 576, 32)   # [y^2 = x^3 + 4]
+    p += call(5, R_MOD, 720, 1)                                                                   # (r - 2)(r - 3) mod r, 32-byte operands
+    # ecc: buffers of 288 bytes (x1 y1 | x2 y2 | x3 y3)
+    p += call(7, R_EC, 0, 8) + copy(R_EC, 192, 288, 24) + call(7, R_EC, 288, 0)
+    # fp2: buffers of 288 bytes (a0 a1 | b0 b1 | r0 r1)
+    p += call(8, R_FP2, 0, 0) + call(8, R_FP2, 288, 0) + copy(R_FP2, 288 + 192, 576, 24) + call(8, R_FP2, 576, 0)
+    p += copy(R_FP2, 576 + 192, 864, 24) + call(8, R_FP2, 864, 8)                                 # x^3 + (4 + 4 u)
+    p += copy(R_FP2, 192, 1152, 24) + copy(R_FP2, 864 + 192, 1152 + 96, 24) + call(8, R_FP2, 1152, 16)   # y^2 - (x^3 + 4 + 4 u)
+    p += [("addi", T1, 0, 0)]
+    for k in range(24):
+        p += [("lw", T2, R_FP2, 1152 + 192 + 4 * k), ("or", T1, T1, T2)]
+    for k, (reg, off) in enumerate(((R_MOD, 576 + 96), (R_EC, 288 + 192), (R_EC, 288 + 240), (R_FP2, 192), (R_FP2, 864 + 192), (None, 0), (R_MOD, 720 + 64), (R_MOD, 96))):
+        p += [("add", A0, T1, 0)] if reg is None else [("lw", A0, reg, off)]
+        p += [("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
+def bls_data():
+    b48, b32 = (lambda v: int(v).to_bytes(48, "little")), (lambda v: int(v).to_bytes(32, "little"))  # noqa: E731
+    gx, gy = BLS12_381_G1
+    z48 = bytes(48)
+    mod = (b48(gy) + b48(gy) + z48) + (b48(gx) + b48(gx) + z48) + (z48 + b48(gx) + z48) + (z48 + b48(4) + z48) + (z48 * 3)
+    mod += b32(BLS12_381_R - 2) + b32(BLS12_381_R - 3) + bytes(32)
+    mod += bytes(BLS_EC - BLS_MOD - len(mod))
+    g = b48(gx) + b48(gy)
+    ec = (g + g + bytes(96)) + (bytes(96) + g + bytes(96))
+    ec += bytes(BLS_FP2 - BLS_EC - len(ec))
+    el = lambda e: b48(e[0]) + b48(e[1])  # noqa: E731
+    z96 = bytes(96)
+    f = (el(BLS12_381_G2Y) + el(BLS12_381_G2Y) + z96) + (el(BLS12_381_G2X) + el(BLS12_381_G2X) + z96) + (z96 + el(BLS12_381_G2X) + z96) + (z96 + el((4, 4)) + z96) + z96 * 3
+    return mod + ec + f
+
+
 DEFERRAL_DATA_BYTES = 64   # the batch-like guest's data segment: the child app's exe commitment (8 words), vm commitment (8 words)
 
 

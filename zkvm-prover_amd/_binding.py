@@ -200,6 +200,21 @@ def load_library():
         "zkhip_int256_cmp_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_vm_cmp256_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_modmul_air": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
+        "zkhip_modmul_air_x": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
+        "zkhip_modular_host_x": (C.c_int, [C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p, u32p]),
+        "zkhip_modular_tracegen_x": (C.c_int, [vp, C.c_uint32, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
+        "zkhip_vm_modmul_air_x": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint, C.c_int, C.POINTER(_Air)]),
+        "zkhip_vm_modmul_tracegen_x": (C.c_int, [vp, C.c_uint32, u32p, vp, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
+        "zkhip_fp2_air_x": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
+        "zkhip_fp2_host_x": (C.c_int, [C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p]),
+        "zkhip_fp2_tracegen_x": (C.c_int, [vp, C.c_uint32, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
+        "zkhip_vm_fp2_air_x": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint, C.c_int, C.POINTER(_Air)]),
+        "zkhip_vm_fp2_tracegen_x": (C.c_int, [vp, C.c_uint32, u32p, vp, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
+        "zkhip_ec_air_x": (C.c_int, [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
+        "zkhip_ec_host_x": (C.c_int, [C.c_uint32, C.c_uint32] + [u32p] * 9),
+        "zkhip_ec_tracegen_x": (C.c_int, [vp, C.c_uint32, u32p, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
+        "zkhip_vm_ec_air_x": (C.c_int, [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_uint32, C.c_uint, C.c_int, C.POINTER(_Air)]),
+        "zkhip_vm_ec_tracegen_x": (C.c_int, [vp, C.c_uint32, u32p, u32p, vp, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_modmul_host": (C.c_int, [u32p, u32p, u32p, u32p, u32p]),
         "zkhip_modmul_tracegen": (C.c_int, [vp, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
         "zkhip_modular_tracegen": (C.c_int, [vp, u32p, vp, sz, C.c_uint, vp, vp, vp, C.c_uint32, C.c_uint32]),
@@ -685,10 +700,11 @@ class Context:
         return out
 
     def vm_modmul_tracegen(self, modulus, t_records, t_ts, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
-        out = self._new(326 << log_height)
-        m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
-        self._check(self.lib.zkhip_vm_modmul_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height,
-                                                      out.data_ptr(), t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
+        nw = limb_words(modulus)
+        out = self._new((40 * nw + 6) << log_height)   # 326 columns (485 + 1 for a 48-limb modulus)
+        m = np.ascontiguousarray(_int_words(modulus, nw), dtype=np.uint32)
+        self._check(self.lib.zkhip_vm_modmul_tracegen_x(self.h, nw, _u32p(m), t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height,
+                                                        out.data_ptr(), t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
         return out
 
     def vm_sha256_tracegen(self, t_blocks, t_ts, n_blocks, log_height):
@@ -720,11 +736,12 @@ class Context:
         return out
 
     def modular_tracegen(self, modulus, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
-        """records: n x 17 words (op | a | b; op 0 mul, 1 add, 2 sub)"""
-        out = self._new(325 << log_height)
-        m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
-        self._check(self.lib.zkhip_modular_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr(),
-                                                    t_tuple_counts.data_ptr(), size_x, size_y))
+        """records: n x (2 nw + 1) words (op | a | b; op 0 mul, 1 add, 2 sub, 3 div, 4 is_eq), nw = limb_words(modulus)"""
+        nw = limb_words(modulus)
+        out = self._new((40 * nw + 5) << log_height)   # 325 columns (485 for a 48-limb modulus)
+        m = np.ascontiguousarray(_int_words(modulus, nw), dtype=np.uint32)
+        self._check(self.lib.zkhip_modular_tracegen_x(self.h, nw, _u32p(m), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr(),
+                                                      t_tuple_counts.data_ptr(), size_x, size_y))
         return out
 
     def int256_alu_tracegen(self, t_records, n, log_height, t_bitwise_trace):
@@ -771,27 +788,29 @@ class Context:
         return out
 
     def fp2_tracegen(self, modulus, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y, t_ts=None):
-        """records: n x 33 words (op | a0 a1 | b0 b1); t_ts: the VM chip (649 columns: + the calls' timestamps)"""
-        out = self._new((648 if t_ts is None else 649) << log_height)
-        m = np.ascontiguousarray(_int_words(modulus), dtype=np.uint32)
+        """records: n x (4 nw + 1) words (op | a0 a1 | b0 b1); t_ts: the VM chip (+ the calls' timestamps)"""
+        nw = limb_words(modulus)
+        out = self._new((80 * nw + 8 + (0 if t_ts is None else 1)) << log_height)   # 648 columns (968 for a 48-limb modulus)
+        m = np.ascontiguousarray(_int_words(modulus, nw), dtype=np.uint32)
         if t_ts is None:
-            self._check(self.lib.zkhip_fp2_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr(),
-                                                    t_tuple_counts.data_ptr(), size_x, size_y))
+            self._check(self.lib.zkhip_fp2_tracegen_x(self.h, nw, _u32p(m), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr(),
+                                                      t_tuple_counts.data_ptr(), size_x, size_y))
         else:
-            self._check(self.lib.zkhip_vm_fp2_tracegen(self.h, _u32p(m), t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height,
-                                                       out.data_ptr(), t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
+            self._check(self.lib.zkhip_vm_fp2_tracegen_x(self.h, nw, _u32p(m), t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height,
+                                                         out.data_ptr(), t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
         return out
 
     def ec_tracegen(self, modulus, coeff_a, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y, t_ts=None):
-        """records: n x 41 words (op | x1 y1 x2 y2 | slope); t_ts: the VM chip (773 columns: + the calls' timestamps)"""
-        out = self._new((772 if t_ts is None else 773) << log_height)
-        m, ca = (np.ascontiguousarray(_int_words(v), dtype=np.uint32) for v in (modulus, coeff_a))
+        """records: n x (5 nw + 1) words (op | x1 y1 x2 y2 | slope); t_ts: the VM chip (+ the calls' timestamps)"""
+        nw = limb_words(modulus)
+        out = self._new((96 * nw + 4 + (0 if t_ts is None else 1)) << log_height)   # 772 columns (1156 for a 48-limb modulus)
+        m, ca = (np.ascontiguousarray(_int_words(v, nw), dtype=np.uint32) for v in (modulus, coeff_a))
         if t_ts is None:
-            self._check(self.lib.zkhip_ec_tracegen(self.h, _u32p(m), _u32p(ca), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(),
-                                                   t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
+            self._check(self.lib.zkhip_ec_tracegen_x(self.h, nw, _u32p(m), _u32p(ca), t_records.data_ptr() if n else None, n, log_height, out.data_ptr(),
+                                                     t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
         else:
-            self._check(self.lib.zkhip_vm_ec_tracegen(self.h, _u32p(m), _u32p(ca), t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height,
-                                                      out.data_ptr(), t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
+            self._check(self.lib.zkhip_vm_ec_tracegen_x(self.h, nw, _u32p(m), _u32p(ca), t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height,
+                                                        out.data_ptr(), t_bitwise_trace.data_ptr(), t_tuple_counts.data_ptr(), size_x, size_y))
         return out
 
     def modmul_tracegen(self, modulus, t_records, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):
@@ -1075,9 +1094,16 @@ def keccak_f1600_host(lanes):
     return st
 
 
-def _int_words(v):
-    """a non-negative integer below 2^256 as eight little-endian 32-bit words"""
-    return [(int(v) >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+def _int_words(v, n=8):
+    """a non-negative integer below 2^(32 n) as n little-endian 32-bit words"""
+    return [(int(v) >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+
+
+def limb_words(modulus):
+    """words per operand of the limb chips for `modulus`: 8 (32 byte limbs) below 2^256, 12 (48 limbs) below 2^384 -- the BLS12-381 base
+    field of the reference's batch circuit (crates/circuits/batch-circuit/openvm.toml:18-36)"""
+    assert 0 < int(modulus) < 1 << 384
+    return 8 if int(modulus) < 1 << 256 else 12
 
 
 def int256_alu_air(bitwise_bus):
@@ -1124,8 +1150,9 @@ def modmul_air(modulus, bitwise_bus, tuple_bus):
     """The modular-multiplication chip's AIR for `modulus` (an integer): (program, width); its one definition is include/zkhip_modular.hpp."""
     lib = load_library()
     a = _Air()
-    m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
-    assert lib.zkhip_modmul_air(m, bitwise_bus, tuple_bus, C.byref(a)) == 0
+    nl = 4 * limb_words(modulus)
+    m = (C.c_uint8 * nl)(*int(modulus).to_bytes(nl, "little"))
+    assert lib.zkhip_modmul_air_x(m, nl, bitwise_bus, tuple_bus, C.byref(a)) == 0
     return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
 
 
@@ -1133,8 +1160,9 @@ def vm_modmul_air(modulus, index, adapter):
     """(program, width) of the VM's multiplication chip (adapter False) or adapter chip (True) of modulus `index`"""
     lib = load_library()
     a = _Air()
-    m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
-    assert lib.zkhip_vm_modmul_air(m, index, 1 if adapter else 0, C.byref(a)) == 0
+    nl = 4 * limb_words(modulus)
+    m = (C.c_uint8 * nl)(*int(modulus).to_bytes(nl, "little"))
+    assert lib.zkhip_vm_modmul_air_x(m, nl, index, 1 if adapter else 0, C.byref(a)) == 0
     return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
 
 
@@ -1142,8 +1170,9 @@ def fp2_air(modulus, bitwise_bus, tuple_bus):
     """The Fp2 chip's AIR for Fp[u] / (u^2 + 1) over `modulus`: (program, width); its one definition is include/zkhip_fp2.hpp."""
     lib = load_library()
     a = _Air()
-    m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
-    assert lib.zkhip_fp2_air(m, bitwise_bus, tuple_bus, C.byref(a)) == 0
+    nl = 4 * limb_words(modulus)
+    m = (C.c_uint8 * nl)(*int(modulus).to_bytes(nl, "little"))
+    assert lib.zkhip_fp2_air_x(m, nl, bitwise_bus, tuple_bus, C.byref(a)) == 0
     return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
 
 
@@ -1151,29 +1180,32 @@ def vm_fp2_air(modulus, index, adapter):
     """(program, width) of the VM's Fp2 chip (adapter False) or adapter chip (True) of field `index`"""
     lib = load_library()
     a = _Air()
-    m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
-    assert lib.zkhip_vm_fp2_air(m, index, 1 if adapter else 0, C.byref(a)) == 0
+    nl = 4 * limb_words(modulus)
+    m = (C.c_uint8 * nl)(*int(modulus).to_bytes(nl, "little"))
+    assert lib.zkhip_vm_fp2_air_x(m, nl, index, 1 if adapter else 0, C.byref(a)) == 0
     return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
 
 
 def fp2_host(op, modulus, a, b):
     """a op b in Fp[u] / (u^2 + 1) through the library's host function ((c0, c1) integer pairs); None if it refuses the call"""
-    wm = np.array(_int_words(modulus), dtype=np.uint32)
-    wa = np.array(_int_words(a[0]) + _int_words(a[1]), dtype=np.uint32)
-    wb = np.array(_int_words(b[0]) + _int_words(b[1]), dtype=np.uint32)
-    r = np.zeros(16, np.uint32)
-    if load_library().zkhip_fp2_host(op, _u32p(wm), _u32p(wa), _u32p(wb), _u32p(r)) != 0:
+    nw = limb_words(modulus)
+    wm = np.array(_int_words(modulus, nw), dtype=np.uint32)
+    wa = np.array(_int_words(a[0], nw) + _int_words(a[1], nw), dtype=np.uint32)
+    wb = np.array(_int_words(b[0], nw) + _int_words(b[1], nw), dtype=np.uint32)
+    r = np.zeros(2 * nw, np.uint32)
+    if load_library().zkhip_fp2_host_x(op, nw, _u32p(wm), _u32p(wa), _u32p(wb), _u32p(r)) != 0:
         return None
-    return tuple(sum(int(x) << (32 * i) for i, x in enumerate(r[8 * k:8 * k + 8])) for k in range(2))
+    return tuple(sum(int(x) << (32 * i) for i, x in enumerate(r[nw * k:nw * k + nw])) for k in range(2))
 
 
 def ec_air(modulus, coeff_a, bitwise_bus, tuple_bus):
     """The elliptic-curve chip's AIR for the curve y^2 = x^3 + a x + b over `modulus`: (program, width); its one definition is include/zkhip_ecc.hpp."""
     lib = load_library()
     a = _Air()
-    m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
-    ca = (C.c_uint8 * 32)(*int(coeff_a).to_bytes(32, "little"))
-    assert lib.zkhip_ec_air(m, ca, bitwise_bus, tuple_bus, C.byref(a)) == 0
+    nl = 4 * limb_words(modulus)
+    m = (C.c_uint8 * nl)(*int(modulus).to_bytes(nl, "little"))
+    ca = (C.c_uint8 * nl)(*int(coeff_a).to_bytes(nl, "little"))
+    assert lib.zkhip_ec_air_x(m, ca, nl, bitwise_bus, tuple_bus, C.byref(a)) == 0
     return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
 
 
@@ -1181,35 +1213,39 @@ def vm_ec_air(modulus, coeff_a, index, adapter):
     """(program, width) of the VM's point chip (adapter False) or adapter chip (True) of curve `index`"""
     lib = load_library()
     a = _Air()
-    m = (C.c_uint8 * 32)(*int(modulus).to_bytes(32, "little"))
-    ca = (C.c_uint8 * 32)(*int(coeff_a).to_bytes(32, "little"))
-    assert lib.zkhip_vm_ec_air(m, ca, index, 1 if adapter else 0, C.byref(a)) == 0
+    nl = 4 * limb_words(modulus)
+    m = (C.c_uint8 * nl)(*int(modulus).to_bytes(nl, "little"))
+    ca = (C.c_uint8 * nl)(*int(coeff_a).to_bytes(nl, "little"))
+    assert lib.zkhip_vm_ec_air_x(m, ca, nl, index, 1 if adapter else 0, C.byref(a)) == 0
     return np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy(), int(a.width)
 
 
 def ec_host(op, modulus, coeff_a, p1, p2):
     """(slope, x3, y3) of p1 + p2 (op 0) or 2 p1 (op 1) through the library's host function (integers); None if it refuses the call"""
-    words = [np.array(_int_words(v), dtype=np.uint32) for v in (modulus, coeff_a, p1[0], p1[1], p2[0], p2[1])]
-    out = [np.zeros(8, np.uint32) for _ in range(3)]
-    if load_library().zkhip_ec_host(op, *[_u32p(w) for w in words], *[_u32p(o) for o in out]) != 0:
+    nw = limb_words(modulus)
+    words = [np.array(_int_words(v, nw), dtype=np.uint32) for v in (modulus, coeff_a, p1[0], p1[1], p2[0], p2[1])]
+    out = [np.zeros(nw, np.uint32) for _ in range(3)]
+    if load_library().zkhip_ec_host_x(op, nw, *[_u32p(w) for w in words], *[_u32p(o) for o in out]) != 0:
         return None
     return tuple(sum(int(x) << (32 * i) for i, x in enumerate(o)) for o in out)
 
 
 def modmul_host(a, b, modulus):
     """(q, r) = divmod(a * b, modulus) through the library's host function (integers in, integers out)"""
-    wa, wb, wm = (np.array(_int_words(v), dtype=np.uint32) for v in (a, b, modulus))
-    q, r = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
-    rc = load_library().zkhip_modmul_host(_u32p(wa), _u32p(wb), _u32p(wm), _u32p(q), _u32p(r))
+    nw = limb_words(modulus)
+    wa, wb, wm = (np.array(_int_words(v, nw), dtype=np.uint32) for v in (a, b, modulus))
+    q, r = np.zeros(nw, np.uint32), np.zeros(nw, np.uint32)
+    rc = load_library().zkhip_modular_host_x(0, nw, _u32p(wa), _u32p(wb), _u32p(wm), _u32p(q), _u32p(r))
     assert rc == 0
     return sum(int(x) << (32 * i) for i, x in enumerate(q)), sum(int(x) << (32 * i) for i, x in enumerate(r))
 
 
 def modular_host(op, a, b, modulus):
     """(q, r) of a * b = q P + r (op 0), a + b = q P + r (1), a - b + q P = r (2) through the library's host function"""
-    wa, wb, wm = (np.array(_int_words(v), dtype=np.uint32) for v in (a, b, modulus))
-    q, r = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
-    assert load_library().zkhip_modular_host(op, _u32p(wa), _u32p(wb), _u32p(wm), _u32p(q), _u32p(r)) == 0
+    nw = limb_words(modulus)
+    wa, wb, wm = (np.array(_int_words(v, nw), dtype=np.uint32) for v in (a, b, modulus))
+    q, r = np.zeros(nw, np.uint32), np.zeros(nw, np.uint32)
+    assert load_library().zkhip_modular_host_x(op, nw, _u32p(wa), _u32p(wb), _u32p(wm), _u32p(q), _u32p(r)) == 0
     return sum(int(x) << (32 * i) for i, x in enumerate(q)), sum(int(x) << (32 * i) for i, x in enumerate(r))
 
 

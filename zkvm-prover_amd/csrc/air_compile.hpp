@@ -228,7 +228,9 @@ inline int parse_air(const uint32_t* w, size_t len, size_t width, AirProgram* p,
 enum QOp : uint32_t { Q_ADD, Q_SUB, Q_MUL, Q_NEG, Q_ASSERT };
 // PERM payload like VAR (column of the permutation LDE); CHAL / EXPO index the per-proof challenge block
 enum QKind : uint32_t { K_SLOT, K_VAR, K_PUB, K_CONST, K_SEL, K_PERM, K_CHAL, K_EXPO, K_PREP };
-constexpr unsigned Q_MAX_SLOTS = 60;
+// live intermediates of the interpreter form: one LDS word per lane each (256 lanes: 1 KiB per slot).  Up to 64 fit the default 64 KiB
+// of dynamic LDS; the limb chips at 48 limbs (ecc: 61) need a few more -- the launch raises the kernel's limit (gfx950: 160 KiB per CU)
+constexpr unsigned Q_MAX_SLOTS = 96;
 
 struct CompiledAir {
     std::vector<uint32_t> code;    // 3 words per instruction

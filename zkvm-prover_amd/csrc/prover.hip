@@ -2028,6 +2028,8 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     if (pk->quot_n) {
         KernelScope ks(ctx, "quotient_eval");
         const QuotMulti qm{pk->d_quot_args, pk->d_quot_first, pk->quot_n, ctx->d_tw_fwd, ctx->tw_log};
+        if ((size_t)pk->quot_max_slots * QBS * 4 > 65536)   // (more than the default dynamic LDS: a chip with > 64 live intermediates)
+            ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_quotient, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(Q_MAX_SLOTS * QBS * 4)));
         hipLaunchKernelGGL(k_quotient, dim3(pk->quot_blocks), dim3(QBS), (size_t)pk->quot_max_slots * QBS * 4, st, qm);
         for (size_t a = 0; a < n_airs; a++) {
             AirPlan& A = pk->airs[a];
@@ -2290,6 +2292,8 @@ int zkhip_constraint_eval(zkhip_ctx* ctx, const uint32_t* program, size_t progra
     {
         KernelScope ks(ctx, "quotient_eval");
         const QuotMulti qm{(const QuotArgs*)(base + o_args), (const uint32_t*)(base + o_first), 1u, ctx->d_tw_fwd, ctx->tw_log};
+        if ((size_t)comp.n_slots * QBS * 4 > 65536)
+            ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_quotient, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(Q_MAX_SLOTS * QBS * 4)));
         hipLaunchKernelGGL(k_quotient, dim3(first[1]), dim3(QBS), (size_t)comp.n_slots * QBS * 4, ctx->stream, qm);
     }
     ZK_HIP_CHECK(ctx, hipGetLastError());

@@ -167,10 +167,12 @@ int zkhip_vm_air(unsigned id, zkhip_air* out, size_t* prep_width) {
     return ZKHIP_OK;
 }
 
-int zkhip_vm_modmul_air(const uint8_t modulus[32], unsigned index, int adapter, zkhip_air* out) {
-    if (!modulus || !out || index >= vmc::MAX_MODULI) return ZKHIP_ERR_INVALID;
+int zkhip_vm_modmul_air(const uint8_t modulus[32], unsigned index, int adapter, zkhip_air* out) { return zkhip_vm_modmul_air_x(modulus, 32, index, adapter, out); }
+int zkhip_vm_modmul_air_x(const uint8_t* modulus, uint32_t n_limbs, unsigned index, int adapter, zkhip_air* out) {
+    if (!modulus || !out || index >= vmc::MAX_MODULI || (n_limbs != 32 && n_limbs != 48)) return ZKHIP_ERR_INVALID;
     zkhip::modular::Modulus m;
-    memcpy(m.data(), modulus, 32);
+    m.limbs = n_limbs;
+    memcpy(m.data(), modulus, n_limbs);
     try {
         std::lock_guard<std::mutex> lk(g_mod_mu);
         const auto key = std::make_pair(m, 2 * index + (adapter ? 1u : 0u));
@@ -186,9 +188,13 @@ int zkhip_vm_modmul_air(const uint8_t modulus[32], unsigned index, int adapter, 
 }
 
 int zkhip_vm_ec_air(const uint8_t modulus[32], const uint8_t a[32], unsigned index, int adapter, zkhip_air* out) {
-    if (!modulus || !a || !out || index >= vmc::MAX_CURVES || !(modulus[0] & 1u) || !modulus[31]) return ZKHIP_ERR_INVALID;
+    return zkhip_vm_ec_air_x(modulus, a, 32, index, adapter, out);
+}
+int zkhip_vm_ec_air_x(const uint8_t* modulus, const uint8_t* a, uint32_t n_limbs, unsigned index, int adapter, zkhip_air* out) {
+    if (!modulus || !a || !out || index >= vmc::MAX_CURVES || (n_limbs != 32 && n_limbs != 48) || !(modulus[0] & 1u) || !modulus[n_limbs - 1]) return ZKHIP_ERR_INVALID;
     zkhip::modular::Modulus m, ca;
-    memcpy(m.data(), modulus, 32), memcpy(ca.data(), a, 32);
+    m.limbs = ca.limbs = n_limbs;
+    memcpy(m.data(), modulus, n_limbs), memcpy(ca.data(), a, n_limbs);
     try {
         std::lock_guard<std::mutex> lk(g_mod_mu);
         const auto key = std::make_pair(std::make_pair(m, ca), 2 * index + (adapter ? 1u : 0u));
@@ -203,10 +209,12 @@ int zkhip_vm_ec_air(const uint8_t modulus[32], const uint8_t a[32], unsigned ind
     return ZKHIP_OK;
 }
 
-int zkhip_vm_fp2_air(const uint8_t modulus[32], unsigned index, int adapter, zkhip_air* out) {
-    if (!modulus || !out || index >= vmc::MAX_FP2 || !(modulus[0] & 1u) || !modulus[31]) return ZKHIP_ERR_INVALID;
+int zkhip_vm_fp2_air(const uint8_t modulus[32], unsigned index, int adapter, zkhip_air* out) { return zkhip_vm_fp2_air_x(modulus, 32, index, adapter, out); }
+int zkhip_vm_fp2_air_x(const uint8_t* modulus, uint32_t n_limbs, unsigned index, int adapter, zkhip_air* out) {
+    if (!modulus || !out || index >= vmc::MAX_FP2 || (n_limbs != 32 && n_limbs != 48) || !(modulus[0] & 1u) || !modulus[n_limbs - 1]) return ZKHIP_ERR_INVALID;
     zkhip::modular::Modulus m;
-    memcpy(m.data(), modulus, 32);
+    m.limbs = n_limbs;
+    memcpy(m.data(), modulus, n_limbs);
     try {
         std::lock_guard<std::mutex> lk(g_mod_mu);
         const auto key = std::make_pair(m, 2 * index + (adapter ? 1u : 0u));
