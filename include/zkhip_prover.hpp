@@ -219,6 +219,8 @@ struct FlowOptions {
     bool verify_segments = false;     // host verification of every segment proof beside the proving (the leaf circuit's witness
                                       // generation checks every child; the root is always verified)                     [ZKHIP_VERIFY_SEGMENTS=1]
     bool one_shape = false;           // every segment under the app's full chip set instead of the smallest shape      [ZKHIP_ONE_SHAPE=1]
+    bool lean_shape = true;           // one more shape: the base chips with a small memory system, for segments that stay in their
+                                      // registers (zkhip_vm::SegmentShapes::lean_caps)                                   [ZKHIP_NO_LEAN_SHAPE=1 -> false]
     bool agg_nodes_100bit = false;    // node proofs under blow-up 4 / 44 queries instead of the app's parameters         [ZKHIP_AGG_100BIT=1]
     bool per_depth_keys = false;      // round 3's aggregation keys (one per tree depth) instead of ONE key               [ZKHIP_AGG_PER_DEPTH_KEYS=1]
     bool balanced_tree = false;       // the aggregation tree in AggregationPlan's fixed grouping instead of the greedy fold
@@ -237,6 +239,7 @@ struct FlowOptions {
         if (const char* e = getenv("ZKHIP_LANES")) o.lanes = std::max(1, atoi(e));
         o.verify_segments = getenv("ZKHIP_VERIFY_SEGMENTS") != nullptr;
         o.one_shape = getenv("ZKHIP_ONE_SHAPE") != nullptr;
+        o.lean_shape = getenv("ZKHIP_NO_LEAN_SHAPE") == nullptr;
         o.agg_nodes_100bit = getenv("ZKHIP_AGG_100BIT") != nullptr;
         o.per_depth_keys = getenv("ZKHIP_AGG_PER_DEPTH_KEYS") != nullptr;
         o.balanced_tree = getenv("ZKHIP_TREE_BALANCED") != nullptr;

@@ -382,17 +382,37 @@ private:
 // so a segment that called X cannot be proven under it (the LogUp sums do not cancel).
 struct SegmentShapes {
     std::vector<SegmentCaps> caps;   // increasing sets of chips; caps.back() = the full set (the executor's limits)
-    static SegmentShapes of(const SegmentCaps& full, unsigned log_frame, unsigned log_program) {
+    bool lean = false;               // caps[0] = the base chips with a SMALL memory system (see lean_caps)
+    // The base chips for a segment that stays in its registers: the memory system's chips -- load / store, touched blocks, the memory
+    // tree's path nodes, and the Poseidon2 chip that hashes both -- hold 28 % of the base set's cells at the heights a segment MAY need
+    // (2^(f - 1) loads / stores, 2^(f - 5) blocks, 2^(f - 4) nodes, 2^(f - 2) permutations per 2^f instructions) and a compute-bound
+    // segment fills a few hundred rows of them.  The reference's engine proves every chip at the height the segment needs; here heights
+    // are part of a key, so this is one more shape: the same 22 chips, those four at 1 / 16 .. 1 / 8 of their height.
+    static SegmentCaps lean_caps(SegmentCaps base, unsigned log_frame) {
+        auto down = [&](unsigned id, unsigned by, unsigned floor) { base.log_height[id] = std::max(floor, base.log_height[id] > by ? base.log_height[id] - by : 0u); };
+        (void)log_frame;
+        down(vmc::A_LS, 4, 2), down(vmc::A_LEAF, 4, 4), down(vmc::A_MERKLE, 3, 8);
+        base.log_height[vmc::A_POSEIDON2] = std::max(base.log_height[vmc::A_MERKLE] + 2, base.log_height[vmc::A_POSEIDON2] > 3 ? base.log_height[vmc::A_POSEIDON2] - 3 : 0u);
+        return base;
+    }
+    static SegmentShapes of(const SegmentCaps& full, unsigned log_frame, unsigned log_program, bool with_lean = true) {
         SegmentShapes s;
         const bool hash = full.keccak() || full.sha256();
         const bool more = full.int256() || !full.moduli.empty() || !full.curves.empty() || !full.fp2_moduli.empty();
-        if (hash || more) s.caps.push_back(SegmentCaps::for_frame(log_frame, log_program));
+        const SegmentCaps base = SegmentCaps::for_frame(log_frame, log_program);
+        if (with_lean) {
+            const SegmentCaps l = lean_caps(base, log_frame);
+            bool smaller = false;
+            for (unsigned id : l.ids) smaller = smaller || l.log_height[id] < base.log_height[id];
+            if (smaller) s.caps.push_back(l), s.lean = true;   // (tiny frames sit on the floors already)
+        }
+        if (hash || more) s.caps.push_back(base);
         if (hash && more)
             s.caps.push_back(SegmentCaps::for_frame(log_frame, log_program, full.keccak() ? full.log_height[vmc::A_KECCAK] : 0, full.sha256() ? full.log_height[vmc::A_SHA256] : 0));
         s.caps.push_back(full);
-        for (const SegmentCaps& c : s.caps)   // a shape shares every height with the full set
-            for (unsigned id : c.ids)
-                if (c.log_height[id] != full.log_height[id]) throw Error("internal: a shape's heights differ from the full set's");
+        for (size_t k = s.lean ? 1 : 0; k < s.caps.size(); k++)   // beside the lean one a shape shares every height with the full set
+            for (unsigned id : s.caps[k].ids)
+                if (s.caps[k].log_height[id] != full.log_height[id]) throw Error("internal: a shape's heights differ from the full set's");
         return s;
     }
     static SegmentShapes only(const SegmentCaps& full) {
@@ -416,6 +436,9 @@ struct SegmentShapes {
             bool ok = true;
             for (unsigned id : full.ids)
                 if (id >= vmc::N_BASE_AIRS && used(id) && caps[s].pos(id) < 0) ok = false;
+            if (ok && lean && s == 0)   // the small memory system holds what the segment touched
+                ok = r.core.ls_case.size() <= caps[0].rows(vmc::A_LS) && r.n_leaf() <= caps[0].rows(vmc::A_LEAF) && r.n_merkle() <= caps[0].rows(vmc::A_MERKLE) &&
+                     r.n_p2() <= caps[0].rows(vmc::A_POSEIDON2);
             if (ok) return s;
         }
         return caps.size() - 1;
@@ -893,7 +916,7 @@ inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& e
     const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak, log_sha256, moduli, log_frame > 8 ? log_frame - 8 : 1, log_int256,
                                                     curves, ec_log_rows(log_frame), fp2_moduli);
     // a segment is proven under the smallest SHAPE (set of chips) that holds what it used (ZKHIP_ONE_SHAPE=1: always the full set, as round 3)
-    const SegmentShapes shapes = flow.one_shape ? SegmentShapes::only(caps) : SegmentShapes::of(caps, log_frame, vm_log2_ceil(exe.program.size()));
+    const SegmentShapes shapes = flow.one_shape ? SegmentShapes::only(caps) : SegmentShapes::of(caps, log_frame, vm_log2_ceil(exe.program.size()), flow.lean_shape);
     // the segments of ONE task spread over the GPUs of the node -- `inflight` lanes per listed device, each device its
     // own copy of the (read-only) segment keys; a segment goes to whichever lane is free first
     const std::vector<int> devs = flow.devices.empty() ? std::vector<int>{device} : flow.devices;
@@ -1140,7 +1163,7 @@ private:
     void ensure() {
         if (!seg_.empty()) return;
         const zkhip_vm::SegmentShapes shapes = config.flow.one_shape ? zkhip_vm::SegmentShapes::only(caps_)
-                                                                         : zkhip_vm::SegmentShapes::of(caps_, log_frame_, zkhip_vm::vm_log2_ceil(exe_.program.size()));
+                                                                         : zkhip_vm::SegmentShapes::of(caps_, log_frame_, zkhip_vm::vm_log2_ceil(exe_.program.size()), config.flow.lean_shape);
         const std::vector<int> devs = config.flow.devices.empty() ? std::vector<int>{device_} : config.flow.devices;
         for (int d : devs)
             for (unsigned l = 0; l < std::max(1u, config.flow.lanes); l++) seg_.emplace_back(new zkhip_vm::ShapedSegmentProver(params_, exe_, shapes, d, seg_.empty()));

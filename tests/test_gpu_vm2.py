@@ -569,10 +569,13 @@ def test_segments_carry_only_the_chips_they_use(zk, ora, tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         runs[name] = json.loads(r.stdout.strip().splitlines()[-1])
         assert pm.run_cli("verify-guest", str(exe), str(d / "root.vk"), str(tmp_path / "openvm.toml"), str(d / "root.json")).returncode == 0
-    assert runs["fib"]["chips_per_shape"] == [22, 26, 51] == runs["keccak"]["chips_per_shape"]
-    assert runs["fib"]["segments_per_shape"][1:] == [0, 0] and runs["fib"]["segments_per_shape"][0] == runs["fib"]["segments"] >= 3
+    # shape 0 = the base chips with a SMALL memory system (a segment that stays in its registers), 1 = the base chips, 2 = + the hash
+    # intrinsics, 3 = everything the configuration lists
+    assert runs["fib"]["chips_per_shape"] == [22, 22, 26, 51] == runs["keccak"]["chips_per_shape"]
+    fs = runs["fib"]["segments_per_shape"]
+    assert fs[2:] == [0, 0] and fs[0] >= 1 and fs[0] + fs[1] == runs["fib"]["segments"] >= 3      # Fibonacci never leaves its registers
     ks = runs["keccak"]["segments_per_shape"]
-    assert ks[1] >= 1 and ks[2] == 0 and sum(ks) == runs["keccak"]["segments"]     # a segment that calls only keccak carries <= 26 chips
+    assert ks[2] >= 1 and ks[3] == 0 and sum(ks) == runs["keccak"]["segments"]     # a segment that calls only keccak carries <= 26 chips
     # ZKHIP_ONE_SHAPE=1: every segment under the full set, as round 3 (another key: one leaf circuit)
     import os
     d = tmp_path / "one"
@@ -583,6 +586,15 @@ def test_segments_carry_only_the_chips_they_use(zk, ora, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     one = json.loads(r.stdout.strip().splitlines()[-1])
     assert one["chips_per_shape"] == [51] and (d / "root.vk").read_bytes() != (tmp_path / "fib" / "root.vk").read_bytes()
+    # ZKHIP_NO_LEAN_SHAPE=1: round 4's first set of shapes (another key again: three leaf circuits instead of four)
+    d = tmp_path / "nolean"
+    d.mkdir()
+    (d / "stdin.bin").write_bytes((400).to_bytes(4, "little"))
+    r = subprocess.run([pm.CLI, "prove-elf", str(tmp_path / "fib" / "guest.elf"), str(d / "stdin.bin"), str(d), str(tmp_path / "openvm.toml"), "8"], capture_output=True, text=True,
+                       env=dict(os.environ, ZKHIP_NO_LEAN_SHAPE="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    nl = json.loads(r.stdout.strip().splitlines()[-1])
+    assert nl["chips_per_shape"] == [22, 26, 51] and nl["segments_per_shape"][0] == nl["segments"] and (d / "root.vk").read_bytes() != (tmp_path / "fib" / "root.vk").read_bytes()
 
 
 def test_one_task_over_a_device_list(tmp_path):
