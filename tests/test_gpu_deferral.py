@@ -312,3 +312,54 @@ def test_a_batch_of_more_children_than_one_deferral_node_takes(tmp_path):
     # seven children: more than 3 x 2
     r = prove(tmp_path / "seven", chunks + chunks[:2])
     assert r.returncode != 0 and "take 6" in r.stderr
+
+
+def test_three_layers_at_the_reference_parameters(tmp_path):
+    """chunk -> batch -> bundle once more at the reference's FRI parameters (crates/circuits/*/openvm.toml: blow-up 2, 100 queries, 16 + 16
+    proof-of-work bits) instead of the toy ones the byte-parity tests above use: every proof of the three layers is made and verified under
+    the parameters a deployment runs, the chains are the independent restatement's."""
+    ref = (1, 0, 100, 16, 16)
+    cfg = tmp_path / "openvm.toml"
+    cfg.write_text(pm.TOML.format(*ref))
+    chunk_elf = tmp_path / "chunk.elf"
+    chunk_elf.write_bytes(rv.elf_bytes(fib_program()))
+    chunks = [prove_child(tmp_path / ("c%d" % i), chunk_elf, cfg, n) for i, n in enumerate((120, 130))]
+    chunk_vk = str(chunks[0]["dir"] / "root.vk")
+    pc = json.loads(pm.run_cli("program-commit", str(chunk_elf), chunk_vk, str(cfg)).stdout)
+    batch_elf = tmp_path / "batch.elf"
+    batch_elf.write_bytes(rv.elf_bytes(deferral_guest_program(), data=b"".join(int(x).to_bytes(4, "little") for x in pc["exe"] + pc["vm"])))
+
+    def prove_deferral(outdir, elf, child_vk, ks):
+        outdir.mkdir()
+        (outdir / "witness.bin").write_bytes(b"".join(k["pvs"] for k in ks))
+        r = subprocess.run([pm.CLI, "prove-deferral", str(elf), str(cfg), str(outdir), "9", child_vk, str(cfg), str(outdir / "witness.bin")] + [k["json"] for k in ks],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        root = json.loads((outdir / "root.json").read_text())
+        upv = pm.un_b64_bincode(root["user_pvs_proof"])
+        return dict(dir=outdir, json=str(outdir / "root.json"), stmt=np.frombuffer(upv[:4 * 58], dtype=np.uint32), pvs=upv[4 * 58:4 * 58 + 32])
+
+    cells = lambda k: np.array([k["pvs"][2 * j] | (k["pvs"][2 * j + 1] << 8) for j in range(16)], np.uint32)  # noqa: E731
+    batch = prove_deferral(tmp_path / "batch", batch_elf, chunk_vk, chunks)
+    assert pm.run_cli("verify-guest", str(batch_elf), str(batch["dir"] / "root.vk"), str(cfg), batch["json"]).returncode == 0
+    assert batch["stmt"][50:58].tolist() == ru.deferral_chain(np.zeros(8, np.uint32), [ru.deferral_claim(k["stmt"], cells(k)) for k in chunks]).tolist()
+    batch_vk = str(batch["dir"] / "root.vk")
+    bpc = json.loads(pm.run_cli("program-commit", str(batch_elf), batch_vk, str(cfg)).stdout)
+    bundle_elf = tmp_path / "bundle.elf"
+    bundle_elf.write_bytes(rv.elf_bytes(deferral_guest_program(), data=b"".join(int(x).to_bytes(4, "little") for x in bpc["exe"] + bpc["vm"])))
+    bundle = prove_deferral(tmp_path / "bundle", bundle_elf, batch_vk + "@" + str(batch_elf), [batch])
+    assert pm.run_cli("verify-guest", str(bundle_elf), str(bundle["dir"] / "root.vk"), str(cfg), bundle["json"]).returncode == 0
+    assert bundle["stmt"][50:58].tolist() == ru.deferral_chain(np.zeros(8, np.uint32), [ru.deferral_claim(batch["stmt"], cells(batch))]).tolist()
+    assert int.from_bytes(bundle["pvs"][:4], "little") == 1 and int.from_bytes(bundle["pvs"][4:8], "little") == 2     # one batch, of two chunks
+    # a flipped byte in the batch proof is refused before anything is proven
+    bad = json.loads((batch["dir"] / "root.json").read_text())
+    pb = bytearray(pm.un_b64_bincode(bad["proof"]))
+    pb[4 * 777] ^= 1
+    bad["proof"] = pm.b64_bincode(bytes(pb))
+    (tmp_path / "bad.json").write_text(json.dumps(bad))
+    x = tmp_path / "x"
+    x.mkdir()
+    (x / "witness.bin").write_bytes(batch["pvs"])
+    r = subprocess.run([pm.CLI, "prove-deferral", str(bundle_elf), str(cfg), str(x), "9", batch_vk + "@" + str(batch_elf), str(cfg), str(x / "witness.bin"), str(tmp_path / "bad.json")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "does not verify under the child aggregation key" in r.stderr
