@@ -201,6 +201,7 @@ def guest_flow(chunk_config=False):
                 "process_wall_s_first_run_on_this_box": runs[0]["wall_s"], "root_proof_bytes": g["root_proof_bytes"], "verified": g["verified"],
                 "chips_per_shape": g.get("chips_per_shape"), "segments_per_shape": g.get("segments_per_shape"),
                 "instr_per_s_segments_only": g.get("instr_per_s_segments_only"),
+                "instr_per_s_segments_plus_executor_busy_time": g.get("instr_per_s_segments_plus_executor_busy_time"),
                 "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 700000 17" + (" chunk" if chunk_config else "")}
     except Exception as e:   # a reported extra, never a gate
         return {"value": None, "note": "failed: %r" % (e,)}
