@@ -1008,6 +1008,16 @@ public:
     void reset() {   // mod.rs:106-108: releases the device-resident keys, circuits and workspaces
         agg_.reset(), seg_.clear();
     }
+    // what the first task would otherwise build on its way: the segment keys, the aggregation circuits and their keys (the reference's
+    // get_sdk / keygen behind its OnceLock: mod.rs:78,115-126) -- setup, not proving
+    void warm_up() {
+        try {
+            ensure();
+            (void)agg_->node_vk(0);
+        } catch (const zkhip_vm::Error& e) {
+            throw Error(Error::Setup, e.what());
+        }
+    }
     // mod.rs:312-338
     uint64_t execute_and_check(const ProvingTask& task) const {
         try {

@@ -291,6 +291,7 @@ int main(int argc, char** argv) {
             std::vector<const StarkProof*> kp;
             for (const auto& k : kids) kp.push_back(&k);
             const DeferralProver::Data data = up.compute_deferral_data(kp);
+            up.warm_up();   // (the guest flow's own keys and circuits: setup)
             ProvingTask task;
             task.identifier = "deferral";
             if (std::string(argv[8]) != "-") task.serialized_witness.push_back(slurp(argv[8]));
