@@ -225,6 +225,11 @@ struct FlowOptions {
     bool per_depth_keys = false;      // round 3's aggregation keys (one per tree depth) instead of ONE key               [ZKHIP_AGG_PER_DEPTH_KEYS=1]
     bool balanced_tree = false;       // the aggregation tree in AggregationPlan's fixed grouping instead of the greedy fold
                                       // (AggregationProver::TreeStream; the fold needs ONE key)                          [ZKHIP_TREE_BALANCED=1]
+    unsigned internal_arity = 5;      // children of an internal node of the aggregation tree.  The reference's default is 3
+                                      // (crates/prover/src/prover/mod.rs:57-60); here the tree's common heights (2^21 gate rows, 2^18
+                                      // permutations: what ONE leaf node over three segment proofs needs) hold an internal node of up
+                                      // to five node proofs (1.89 M rows, 216 k permutations; six: 2.26 M) -- fewer nodes, the same
+                                      // heights (measured 3 / 4 / 5: DESIGN.md 15)                                       [ZKHIP_INTERNAL_ARITY=n]
     unsigned agg_slots = 3;           // node pipelines (witness thread + device thread, own keys) per device: the node proofs of one
                                       // pipeline are proven one after the other -- with one pipeline the tree lags behind the segment
                                       // lanes and is finished alone on the GPU, a 21 ms proof at a time (measured 1 / 2 / 3 / 4:
@@ -246,6 +251,7 @@ struct FlowOptions {
         o.trace_tree = getenv("ZKHIP_TREE_TRACE") != nullptr;
         if (const char* e = getenv("ZKHIP_DEFERRAL_CHILDREN")) o.deferral_children = (unsigned)std::min(8, std::max(1, atoi(e)));
         if (const char* e = getenv("ZKHIP_DEFERRAL_NODES")) o.deferral_nodes = (unsigned)std::min(8, std::max(1, atoi(e)));
+        if (const char* e = getenv("ZKHIP_INTERNAL_ARITY")) o.internal_arity = (unsigned)std::min(8, std::max(2, atoi(e)));
         if (const char* e = getenv("ZKHIP_AGG_SLOTS")) o.agg_slots = (unsigned)std::min(8, std::max(1, atoi(e)));
         if (const char* e = getenv("ZKHIP_DEVICES")) {
             std::stringstream ss(e);

@@ -929,8 +929,10 @@ inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& e
     // ZKHIP_AGG_100BIT=1 (measurements): the leaf / internal pair of AggregationSystemParams::with_100_bits_security() instead of the app's
     // parameters on every level (the root then verifies under ITS level's parameters: in-process through GuestStark::root_vk)
     const scroll_zkvm_hip::AggregationSystemParams pair = scroll_zkvm_hip::AggregationSystemParams::nodes_100_bits_security();
+    scroll_zkvm_hip::AggregationTreeConfig tree_cfg;
+    tree_cfg.num_children_internal = flow.internal_arity;
     scroll_zkvm_hip::AggregationProver agg =
-        scroll_zkvm_hip::AggregationProver::setup_shapes(shape_vks, segment_statement(), {}, device, flow.agg_nodes_100bit ? &pair : nullptr);
+        scroll_zkvm_hip::AggregationProver::setup_shapes(shape_vks, segment_statement(), tree_cfg, device, flow.agg_nodes_100bit ? &pair : nullptr);
     {   // the tree's nodes go to whichever pipeline is free first: flow.agg_slots pipelines per device
         std::vector<int> slots;
         for (unsigned r = 0; r < std::max(1u, flow.agg_slots); r++) slots.insert(slots.end(), devs.begin(), devs.end());
@@ -1179,7 +1181,9 @@ private:
             for (unsigned l = 0; l < std::max(1u, config.flow.lanes); l++) seg_.emplace_back(new zkhip_vm::ShapedSegmentProver(params_, exe_, shapes, d, seg_.empty()));
         std::vector<VerifyingKey> shape_vks;
         for (size_t sh = 0; sh < seg_[0]->n_shapes(); sh++) shape_vks.push_back(seg_[0]->vk(sh));
-        agg_.reset(new AggregationProver(AggregationProver::setup_shapes(shape_vks, zkhip_vm::segment_statement(), {}, device_)));
+        AggregationTreeConfig tree_cfg;
+        tree_cfg.num_children_internal = config.flow.internal_arity;
+        agg_.reset(new AggregationProver(AggregationProver::setup_shapes(shape_vks, zkhip_vm::segment_statement(), tree_cfg, device_)));
         {
             std::vector<int> slots;   // config.flow.agg_slots node pipelines per device
             for (unsigned r = 0; r < std::max(1u, config.flow.agg_slots); r++) slots.insert(slots.end(), devs.begin(), devs.end());
