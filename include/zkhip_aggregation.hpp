@@ -788,10 +788,11 @@ public:
     };
 
     // The whole tree of `plan` over the segment proofs; returns the root, `all` (optional) receives every level.
+    // (`greedy`: TreeStream's fold without a fixed shape above the leaf nodes -- one key only; `all` then holds two layers)
     ChildProof prove_tree(const AggregationPlan& plan, const std::vector<ChildProof>& segments, std::vector<std::vector<ChildProof>>* all = nullptr,
-                          const std::vector<size_t>* shapes = nullptr) {
+                          const std::vector<size_t>* shapes = nullptr, bool greedy = false) {
         if (segments.size() != plan.n_segments) throw Error(Error::GenProof, "aggregation: segment proof count does not match the plan");
-        TreeStream ts(*this);
+        TreeStream ts(*this, greedy);
         for (size_t i = 0; i < segments.size(); i++) ts.push(i, segments[i], shapes ? shapes->at(i) : 0);
         return ts.finish(segments.size(), all);
     }

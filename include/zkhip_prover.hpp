@@ -225,6 +225,8 @@ struct FlowOptions {
     bool per_depth_keys = false;      // round 3's aggregation keys (one per tree depth) instead of ONE key               [ZKHIP_AGG_PER_DEPTH_KEYS=1]
     bool balanced_tree = false;       // the aggregation tree in AggregationPlan's fixed grouping instead of the greedy fold
                                       // (AggregationProver::TreeStream; the fold needs ONE key)                          [ZKHIP_TREE_BALANCED=1]
+    bool agg_cli_greedy = false;      // `prove_cli prove-agg` (a tree over segment proofs handed in) with the greedy fold instead of the
+                                      // plan's grouping (tests: errors inside the fold)                                  [ZKHIP_AGG_GREEDY=1]
     unsigned internal_arity = 5;      // children of an internal node of the aggregation tree.  The reference's default is 3
                                       // (crates/prover/src/prover/mod.rs:57-60); here the tree's common heights (2^21 gate rows, 2^18
                                       // permutations: what ONE leaf node over three segment proofs needs) hold an internal node of up
@@ -249,6 +251,7 @@ struct FlowOptions {
         o.per_depth_keys = getenv("ZKHIP_AGG_PER_DEPTH_KEYS") != nullptr;
         o.balanced_tree = getenv("ZKHIP_TREE_BALANCED") != nullptr;
         o.trace_tree = getenv("ZKHIP_TREE_TRACE") != nullptr;
+        o.agg_cli_greedy = getenv("ZKHIP_AGG_GREEDY") != nullptr;
         if (const char* e = getenv("ZKHIP_DEFERRAL_CHILDREN")) o.deferral_children = (unsigned)std::min(8, std::max(1, atoi(e)));
         if (const char* e = getenv("ZKHIP_DEFERRAL_NODES")) o.deferral_nodes = (unsigned)std::min(8, std::max(1, atoi(e)));
         if (const char* e = getenv("ZKHIP_INTERNAL_ARITY")) o.internal_arity = (unsigned)std::min(8, std::max(2, atoi(e)));

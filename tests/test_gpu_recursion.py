@@ -6,6 +6,7 @@
     the oracle's; one flipped byte in one segment proof and the node's witness is unsatisfiable."""
 import json
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -194,4 +195,50 @@ def test_prove_agg_refuses_a_broken_hand_over(tmp_path):
         tasks.append(pm.write_task(str(d), k, identifier="seg-%d" % i))
     exe, cfg = pm.write_app(str(tmp_path), segs[0], PARAMS)
     r = pm.run_cli("prove-agg", exe, cfg, str(tmp_path), "1", "0:0/0:1", *tasks)
+    assert r.returncode == 1 and "not satisfied" in r.stderr, r.stderr[-2000:]
+
+
+def test_the_greedy_fold_reports_errors_and_folds_to_the_same_statement(tmp_path):
+    """ZKHIP_AGG_GREEDY=1: `prove-agg` with TreeStream's fold without a fixed shape (what the guest flow runs).  Nine segments fold to a root
+    that states the same app, states and commitments as the fixed grouping's, under the same key; a hand-over that breaks INSIDE a leaf
+    node and one that breaks BETWEEN two leaf nodes (noticed by the fold that joins them) both end the run with the error -- no hang."""
+    import os
+
+    def run(name, starts, greedy=True, arity="0:0/0:1"):
+        d = tmp_path / name
+        d.mkdir()
+        tasks, segs = [], []
+        for i, s in enumerate(starts):
+            k = ru.counter_segment(s, seed=i)
+            segs.append(k)
+            sd = d / ("s%d" % i)
+            sd.mkdir()
+            tasks.append(pm.write_task(str(sd), k, identifier="seg-%d" % i))
+        exe, cfg = pm.write_app(str(d), segs[0], PARAMS)
+        env = dict(os.environ, ZKHIP_AGG_GREEDY="1") if greedy else dict(os.environ)
+        r = subprocess.run([pm.CLI, "prove-agg", exe, cfg, str(d), "1", arity] + tasks, capture_output=True, text=True, env=env, timeout=600)
+        return d, cfg, r
+
+    good = [10 + 7 * i for i in range(9)]
+    d, cfg, r = run("greedy", good)
+    assert r.returncode == 0, r.stderr[-3000:]
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["segments"] == 9 and info["levels"] == 2
+    d2, cfg2, r2 = run("fixed", good, greedy=False)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    a, b = info["root_public_values"], json.loads(r2.stdout.strip().splitlines()[-1])["root_public_values"]
+    n = len(a)
+    assert a[:n - 24] == b[:n - 24] and a[n - 16:] == b[n - 16:]          # all but the accumulator over the children
+    assert (d / "root.vk").read_bytes() == (d2 / "root.vk").read_bytes()
+    assert pm.run_cli("verify", str(d2 / "root.vk"), cfg2, str(d / "root.json")).returncode == 0
+    # segment 2 does not start where segment 1 ends: inside the first leaf node
+    bad = list(good)
+    bad[2] += 1
+    _, _, r = run("bad_leaf", bad)
+    assert r.returncode == 1 and "not satisfied" in r.stderr, r.stderr[-2000:]
+    # segment 4 does not start where segment 3 ends: every leaf node (four segments each) is fine, the fold that joins leaf nodes 0 and 1 is not
+    bad = list(good)
+    for i in range(4, 9):
+        bad[i] += 1
+    _, _, r = run("bad_fold", bad)
     assert r.returncode == 1 and "not satisfied" in r.stderr, r.stderr[-2000:]

@@ -608,7 +608,8 @@ int main(int argc, char** argv) {
             (void)agg.node_vk(plan.levels.size() - 1);  // circuits + keys of every level: setup, not proving
             const auto t2 = std::chrono::steady_clock::now();
             std::vector<std::vector<ChildProof>> all;
-            ChildProof root = agg.prove_tree(plan, segs, &all);
+            const bool greedy = tcfg.one_key && FlowOptions::from_env().agg_cli_greedy;
+            ChildProof root = agg.prove_tree(plan, segs, &all, nullptr, greedy);
             const auto t3 = std::chrono::steady_clock::now();
             const VerifyingKey& rvk = agg.root_vk(plan.levels.size());   // one key: THE aggregation key, whatever the depth
             if (rvk.is_aggregation_key()) {
@@ -624,11 +625,12 @@ int main(int argc, char** argv) {
             for (size_t l = 0; l < all.size(); l++)
                 for (size_t n = 0; n < all[l].size(); n++)
                     std::ofstream(dir + "/agg-" + std::to_string(l) + "-" + std::to_string(n) + ".json") << AggregationProver::to_stark_proof(all[l][n], agg.node_vk(l)).to_json();
+            const size_t n_nodes = greedy ? all[0].size() + all[1].size() : plan.n_nodes(), n_levels = greedy ? 2 : plan.levels.size();
             auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
             std::printf("{\"segments\": %zu, \"nodes\": %zu, \"levels\": %zu, \"segment_seconds\": %.4f, \"setup_seconds\": %.4f, \"tree_seconds\": %.4f, "
                         "\"proofs_folded_per_s\": %.2f, \"witness_seconds\": %.4f, \"tracegen_prove_seconds\": %.4f, \"self_verify_seconds\": %.4f, "
                         "\"root_proof_bytes\": %zu, \"root_public_values\": [",
-                        seg_proofs.size(), plan.n_nodes(), plan.levels.size(), secs(t0, t1), secs(t1, t2), secs(t2, t3), seg_proofs.size() / secs(t2, t3),
+                        seg_proofs.size(), n_nodes, n_levels, secs(t0, t1), secs(t1, t2), secs(t2, t3), seg_proofs.size() / secs(t2, t3),
                         agg.stats.witness_seconds, agg.stats.tracegen_prove_seconds, agg.stats.verify_seconds, root.proof.size());
             for (size_t i = 0; i < root.pvs[2].size(); i++) std::printf("%s%u", i ? ", " : "", root.pvs[2][i]);
             std::printf("]}\n");
