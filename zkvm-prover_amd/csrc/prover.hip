@@ -2152,13 +2152,8 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         }
         ZK_TRY(merkle_build(ctx, pk->t_fri[l], true));
         const uint32_t* d_root = zkhip_tree_root_device(pk->t_fri[l]);
-        ZK_TRY(transcript_observe(ctx, pk->d_tr, d_root, 8, false));
-        {
-            KernelScope ks(ctx, "copy_canon");
-            hipLaunchKernelGGL(k_copy_canon, dim3(1), dim3(64), 0, st, d_root, pf + pk->off_fri + 9 * (size_t)l, 8u);
-        }
-        ZK_TRY(transcript_grind(ctx, pk->d_tr, pk->params.commit_pow_bits, pf + pk->off_fri + 9 * (size_t)l + 8));
-        ZK_TRY(transcript_sample(ctx, pk->d_tr, d_betas + 4 * l, nullptr, 4));
+        // observe(root); proof <- root; grind; proof <- witness; sample(beta): one launch (four before)
+        ZK_TRY(transcript_fri_round(ctx, pk->d_tr, d_root, pk->params.commit_pow_bits, pf + pk->off_fri + 9 * (size_t)l, d_betas + 4 * l));
         ZK_TRY(fri_fold(ctx, pk->d_flayer[l], pk->d_flayer[l + 1], log_len - 1, d_betas + 4 * l,
                         pk->d_ro[log_len - 1], pk->d_ro[log_len - 1] != nullptr));
     }

@@ -184,6 +184,79 @@ __global__ __launch_bounds__(256) void k_grind(DevTranscript* t, unsigned bits, 
     grind_apply(t, bits, witness_out, threadIdx.x);
 }
 
+// One ROUND of the FRI commit phase on the transcript in ONE launch: observe the layer's root (8 words), grind `bits` bits, sample the
+// folding challenge (4 words) -- four launches before (observe, copy of the root into the proof, grind, sample), twenty rounds per proof.
+// Every lane absorbs the root into its OWN copy of the state before it tests its candidates (one more permutation at most, beside the
+// one per candidate); the last block to leave redoes the absorption on the live transcript with its first wave, applies the witness,
+// samples, and writes [root (canonical) | witness] into the proof and the challenge where the fold reads it.  bits = 0: no search (p3's
+// grind(0): witness 0).
+__global__ __launch_bounds__(256) void k_fri_round_transcript(DevTranscript* t, const uint32_t* __restrict__ root, unsigned bits, uint32_t limit,
+                                                               uint32_t* __restrict__ proof_out, uint32_t* __restrict__ beta_out) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t mask = bits ? (1u << bits) - 1u : 0u;
+    if (bits) {
+        uint32_t s0[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) s0[i] = t->state[i];
+        uint32_t n_in = t->n_in;
+        for (int k = 0; k < 8; k++) {   // observe(root[k]) on the private copy
+            const uint32_t v = root[k];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if ((uint32_t)i == n_in) s0[i] = v;
+            if (++n_in == 8) poseidon2_permute(s0), n_in = 0;
+        }
+        for (uint32_t base = 0; base < limit; base += stride) {
+            const uint32_t found = __hip_atomic_load(&t->pow_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (found < base) break;
+            const uint32_t w = base + gid;
+            if (w >= limit || w < base) continue;
+            uint32_t s[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) s[i] = s0[i];
+            const uint32_t wm = to_monty(w);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if ((uint32_t)i == n_in) s[i] = wm;
+            poseidon2_permute(s);
+            if ((from_monty(s[7]) & mask) == 0) atomicMin(&t->pow_found, w);
+        }
+    }
+    __shared__ uint32_t last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&t->pad, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    __threadfence();
+    const unsigned lane = threadIdx.x;
+    const uint32_t w = bits ? __hip_atomic_load(&t->pow_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (w == 0xffffffffu) {
+        if (lane == 0) t->error |= 1u, t->pad = 0;
+        return;
+    }
+    TrRegs r = tr_load(t, lane);
+    for (int k = 0; k < 8; k++) {
+        const uint32_t v = root[k];
+        tr_observe1(r, lane, v);
+        if (lane == 0) proof_out[k] = from_monty(v);
+    }
+    tr_observe1(r, lane, to_monty(w));
+    const uint32_t chk = from_monty(tr_sample1(r, lane)) & mask;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b = tr_sample1(r, lane);
+        if (lane == 0) beta_out[k] = b;
+    }
+    tr_store(t, r, lane);
+    if (lane == 0) {
+        if (chk != 0) t->error |= 2u;
+        proof_out[8] = w;
+        t->pow_applied = 1;
+        t->pow_found = 0xffffffffu, t->pad = 0;   // armed again
+    }
+}
+
 // grind(0): p3 semantics -- observe witness 0 and sample (no search)
 __global__ __launch_bounds__(64) void k_grind_finish(DevTranscript* t, unsigned bits, uint32_t* witness_out) { grind_apply(t, bits, witness_out, threadIdx.x); }
 
@@ -275,6 +348,17 @@ int transcript_grind(zkhip_ctx* ctx, DevTranscript* d_t, unsigned bits, uint32_t
         unsigned blocks = std::min(4096u, std::max(64u, ((1u << grind_shift) << bits) / 256u));
         hipLaunchKernelGGL(k_grind, dim3(blocks), dim3(256), 0, ctx->stream, d_t, bits, (uint32_t)P, d_witness_out);
     }
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
+}
+
+// observe(root) + grind(bits) + sample(4) of one FRI commit round in one launch; d_proof_out: 9 words [root | witness] (canonical)
+int transcript_fri_round(zkhip_ctx* ctx, DevTranscript* d_t, const uint32_t* d_root, unsigned bits, uint32_t* d_proof_out, uint32_t* d_beta_out) {
+    if (bits > 30) return set_error(ctx, ZKHIP_ERR_INVALID, "pow bits > 30");
+    KernelScope ks(ctx, "fri_round_transcript");
+    const unsigned grind_shift = std::min(ctx->cfg.grind_sweep_shift, 8u);
+    const unsigned blocks = bits ? std::min(4096u, std::max(64u, ((1u << grind_shift) << bits) / 256u)) : 1u;
+    hipLaunchKernelGGL(k_fri_round_transcript, dim3(blocks), dim3(256), 0, ctx->stream, d_t, d_root, bits, (uint32_t)P, d_proof_out, d_beta_out);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
 }

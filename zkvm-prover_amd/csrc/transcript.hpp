@@ -27,5 +27,8 @@ int transcript_sample(zkhip_ctx* ctx, DevTranscript* d_t, uint32_t* d_monty, uin
 int transcript_sample_bits(zkhip_ctx* ctx, DevTranscript* d_t, uint32_t* d_dst, uint32_t n, unsigned bits);
 // d_witness_out: optional device word receiving the canonical witness
 int transcript_grind(zkhip_ctx* ctx, DevTranscript* d_t, unsigned bits, uint32_t* d_witness_out);
+// one FRI commit round: observe the layer's root (8 Montgomery words on the device), grind, sample the folding challenge -- ONE launch;
+// d_proof_out receives [root (8, canonical) | witness], d_beta_out the challenge (4 words, Montgomery)
+int transcript_fri_round(zkhip_ctx* ctx, DevTranscript* d_t, const uint32_t* d_root, unsigned bits, uint32_t* d_proof_out, uint32_t* d_beta_out);
 
 }  // namespace zk
