@@ -1,7 +1,8 @@
 """ONE FLOW at scale: a Fibonacci guest of ~n instructions through `prove_cli prove-elf` (include/zkhip_vm_flow.hpp): execution in
 segments of fixed heights, every segment ONE statement (22 chips, adapters + execution bus + persistent memory), aggregation tree
 to ONE root proof, self-verified, at the reference's FRI parameters.  Prints the CLI's JSON line + instructions per second.
-Usage: python tools/guest_bench2.py [n_iterations] [log_frame] [chunk]     (chunk: under the reference's chunk-circuit openvm.toml --
+Usage: python tools/guest_bench2.py [n_iterations] [log_frame] [chunk | mem]     (mem: a memory-bound guest, n = passes over a 64 KiB array)
+       python tools/guest_bench2.py [n_iterations] [log_frame] [chunk]     (chunk: under the reference's chunk-circuit openvm.toml --
 keccak, sha2, bigint, six moduli, three curves: 49 chips per segment instead of 22)"""
 import json
 import os
@@ -15,12 +16,31 @@ import rv32_model as rv  # noqa: E402
 from test_vm_cpu import chunk_circuit_toml, fib_program  # noqa: E402
 
 
+def memsum_program(n_words=16384):
+    """A MEMORY-bound guest beside the register-bound Fibonacci one: fills an array of n_words words (64 KiB: 4096 memory blocks), then sums
+    it `passes` times (the input) with a load per element -- four instructions per element, one of them a load; every segment touches
+    every block of the array, so its memory chips (blocks, path nodes, permutations) are full where Fibonacci's are empty."""
+    A0, A1, A7, T0, T1, T2, T3, S0, S1 = 10, 11, 17, 5, 6, 7, 28, 8, 9
+    p = [("addi", A7, 0, 2), ("ecall",), ("add", S1, A0, 0)]                       # s1 = passes
+    p += rv.li(S0, 0x00400000) + rv.li(T3, 4 * n_words)
+    p += [("add", T3, T3, S0), ("add", T0, S0, 0), ("addi", T1, 0, 1),
+          ("label", "fill"), ("sw", T1, T0, 0), ("addi", T1, T1, 3), ("addi", T0, T0, 4), ("bne", T0, T3, "fill"),
+          ("addi", T2, 0, 0),
+          ("label", "pass"), ("beq", S1, 0, "done"), ("add", T0, S0, 0),
+          ("label", "sum"), ("lw", T1, T0, 0), ("add", T2, T2, T1), ("addi", T0, T0, 4), ("bne", T0, T3, "sum"),
+          ("addi", S1, S1, -1), ("jal", 0, "pass"),
+          ("label", "done"), ("add", A0, T2, 0), ("addi", A1, 0, 0), ("addi", A7, 0, 1), ("ecall",),
+          ("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
     log_frame = sys.argv[2] if len(sys.argv) > 2 else "17"
     tmp = tempfile.mkdtemp(prefix="zkhip_guest2_")
     exe, inp = os.path.join(tmp, "fib.elf"), os.path.join(tmp, "stdin.bin")
-    open(exe, "wb").write(rv.elf_bytes(fib_program()))
+    mem = len(sys.argv) > 3 and sys.argv[3] == "mem"     # n = the number of passes over the array (64: ~4.3 M instructions)
+    open(exe, "wb").write(rv.elf_bytes(memsum_program() if mem else fib_program()))
     open(inp, "wb").write(n.to_bytes(4, "little"))
     cli = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
     cfg = "-"
@@ -40,6 +60,10 @@ def main():
     info["instr_per_s_segments_plus_executor_busy_time"] = round(info["total_cycles"] / max(1e-9, (info["execution_ms"] + info["segment_tracegen_and_proving_ms"]) / 1e3))
     info["log_frame"] = int(log_frame)
     info["config"] = "chunk-circuit (49 chips)" if cfg != "-" else "base (22 chips)"
+    info["guest"] = "memsum (a load every fourth instruction, 4096 blocks touched per segment)" if mem else "fibonacci (register-bound)"
+    if mem:
+        expect = (sum(1 + 3 * i for i in range(16384)) * n) & 0xFFFFFFFF
+        info["public_value_word0_expected"] = expect
     print(json.dumps(info))
 
 
