@@ -15,6 +15,7 @@
 // commitment (8)]; the children's states are chained in-circuit.  Every node proof is self-verified (mod.rs:407-411 does that for
 // every proof it returns).  AggregationTreeConfig::one_key = false keeps round 3's per-depth keys (level l hard-wires level l - 1).
 #pragma once
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <condition_variable>
@@ -924,26 +925,36 @@ private:
     // proving keys (one per device slot) + preprocessed commitments + trace buffers + circuit forks of a built circuit
     void keygen_level(Level& L, std::vector<zkhip_air>& na) {
         L.rep.resize(slots_.size());
-        for (size_t sl = 0; sl < slots_.size(); sl++) {
-            Replica& r = L.rep[sl];
-            if (sl == 0) {
-                r.circ = L.circ, r.owns_circ = false;
-            } else {
-                if (zkhip_recursion_fork(L.circ, &r.circ) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_fork");
-                r.owns_circ = true;
-            }
-            std::lock_guard<std::mutex> dev(*slots_[sl].mu);
-            zkhip_ctx* c = slots_[sl].ctx;
-            int rc = zkhip_keygen(c, &L.vk.params, na.data(), 3, &r.pk);
-            if (rc != ZKHIP_OK) throw Error(Error::Keygen, std::string("failed to generate STARK proving key: ") + zkhip_last_error(c));
-            for (size_t i = 0; i < 3; i++) {
-                uint32_t cm[8];
-                check(zkhip_pk_prep_commitment(c, r.pk, i, cm), sl);
-                if (sl == 0) L.vk.airs[i].prep_commit.assign(cm, cm + 8);
-                else if (!std::equal(cm, cm + 8, L.vk.airs[i].prep_commit.begin())) throw Error(Error::Keygen, "aggregation: two devices disagree on a preprocessed commitment");
-            }
-            alloc_traces(L, sl);
+        for (size_t sl = 1; sl < slots_.size(); sl++) {
+            if (zkhip_recursion_fork(L.circ, &L.rep[sl].circ) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_fork");
+            L.rep[sl].owns_circ = true;
         }
+        L.rep[0].circ = L.circ, L.rep[0].owns_circ = false;
+        // one key per device slot (a key holds the scratch of ITS proofs), generated side by side: every slot has a context of its own
+        std::vector<std::array<uint32_t, 24>> commits(slots_.size());
+        std::vector<std::string> errs(slots_.size());
+        auto one = [&](size_t sl) {
+            try {
+                Replica& r = L.rep[sl];
+                std::lock_guard<std::mutex> dev(*slots_[sl].mu);
+                zkhip_ctx* c = slots_[sl].ctx;
+                int rc = zkhip_keygen(c, &L.vk.params, na.data(), 3, &r.pk);
+                if (rc != ZKHIP_OK) throw Error(Error::Keygen, std::string("failed to generate STARK proving key: ") + zkhip_last_error(c));
+                for (size_t i = 0; i < 3; i++) check(zkhip_pk_prep_commitment(c, r.pk, i, &commits[sl][8 * i]), sl);
+                alloc_traces(L, sl);
+            } catch (const std::exception& e) {
+                errs[sl] = e.what();
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t sl = 1; sl < slots_.size(); sl++) th.emplace_back(one, sl);
+        one(0);
+        for (auto& t : th) t.join();
+        for (const std::string& e : errs)
+            if (!e.empty()) throw Error(Error::Keygen, e);
+        for (size_t i = 0; i < 3; i++) L.vk.airs[i].prep_commit.assign(&commits[0][8 * i], &commits[0][8 * i] + 8);
+        for (size_t sl = 1; sl < slots_.size(); sl++)
+            if (commits[sl] != commits[0]) throw Error(Error::Keygen, "aggregation: two devices disagree on a preprocessed commitment");
     }
     void alloc_traces(Level& L, size_t sl) {
         for (size_t i = 0; i < 3; i++) {
