@@ -1,0 +1,25 @@
+# Runs the guest flow many times over (different lengths, both configurations, device lists) and counts what does not end with a verified
+# root: the greedy fold, three node pipelines and six internal workers are threads racing for proofs -- a rare ordering bug shows up here.
+# Usage: bash tools/flow_stress.sh [runs]   (writes gpurun_out/flow_stress.json)
+cd ${GRAFT_REPO_ROOT:-.}
+N=${1:-60}
+mkdir -p /tmp/fs gpurun_out
+python3 tools/make_guest_files.py /tmp/fs 300000 > /dev/null
+cp /tmp/fs/openvm.toml /tmp/fs_chunk.toml
+ok=0; bad=0; t0=$(date +%s)
+for i in $(seq 1 $N); do
+  n=$((20000 + (i * 7919) % 400000))
+  python3 -c "import sys; open('/tmp/fs/stdin.bin','wb').write(($n).to_bytes(4,'little'))"
+  cfg=-; [ $((i % 5)) = 0 ] && cfg=/tmp/fs_chunk.toml
+  lf=17; [ $((i % 3)) = 0 ] && lf=14
+  env=""; [ $((i % 7)) = 0 ] && env="ZKHIP_DEVICES=0,0"
+  out=/tmp/fs/o$i; mkdir -p $out
+  if env $env timeout 300 ./zkvm-prover_amd/prove_cli prove-elf /tmp/fs/fib.elf /tmp/fs/stdin.bin $out $cfg $lf > $out/log.json 2> $out/err.txt \
+     && ./zkvm-prover_amd/prove_cli verify-guest /tmp/fs/fib.elf $out/root.vk $([ $cfg = - ] && echo $out/openvm.toml || echo $cfg) $out/root.json > /dev/null 2>> $out/err.txt; then
+    ok=$((ok+1))
+  else
+    bad=$((bad+1)); echo "run $i (n=$n cfg=$cfg lf=$lf $env) FAILED: $(tail -c 300 $out/err.txt)"
+  fi
+  rm -rf $out
+done
+echo "{\"runs\": $N, \"verified\": $ok, \"failed\": $bad, \"seconds\": $(( $(date +%s) - t0 ))}" | tee gpurun_out/flow_stress.json
