@@ -51,6 +51,10 @@ def test_host_arithmetic_is_pythons():
         if b:
             assert z.modular_host(3, a, b, P)[1] == a * pow(b, -1, P) % P
         assert z.modular_host(4, a, b, P)[1] == int(a == b)
+    top = (1 << 384) - 1                                          # unreduced operands: fine while the quotient fits 48 limbs
+    assert z.modular_host(1, top, top, P) == divmod(2 * top, P) and z.modmul_host(top, 7, P) == divmod(7 * top, P)
+    with pytest.raises(AssertionError):
+        z.modmul_host(top, top, P)                                # q ~ 2^387: refused
     # the 255-bit scalar field keeps 32-limb operands
     assert z.limb_words(P) == 12 and z.limb_words(R) == 8
     assert z.modmul_host(R - 2, R - 3, R) == divmod((R - 2) * (R - 3), R)
@@ -86,11 +90,12 @@ def test_chip_and_adapter_widths():
 def test_modular_chip_48_limbs_python_twin_satisfies_the_air(ora):
     rng = np.random.default_rng(7)
     big = lambda: int.from_bytes(rng.bytes(48), "little") % P  # noqa: E731
+    top = (1 << 384) - 1                                          # operands need not be reduced (bytes, not residues): the quotient must fit 48 limbs
     rows = [(0, big(), big()) for _ in range(5)] + [(1, big(), big()), (1, P - 1, P - 1), (2, big(), big()), (2, 3, 5), (3, big(), big()), (3, 1, P - 1),
-                                                   (4, 5, 5), (4, 5, 6), (0, P - 1, P - 1), (0, 0, 0)]
-    log_h = 4
+                                                   (4, 5, 5), (4, 5, 6), (0, P - 1, P - 1), (0, 0, 0), (1, top, top), (0, top, 7), (2, top, top - 3)]
+    log_h = 5
     tr, bw, tup = mu.py_trace(rows, P, log_h)
-    assert tr.shape == (485, 16)
+    assert tr.shape == (485, 32)
     program, width = z.modmul_air(P, mu.BITWISE_BUS, mu.TUPLE_BUS)
     assert air.check_trace(program, tr, mu.NOPV, None) == []
     for row, (op, a, b) in enumerate(rows):   # the r columns (a division: the dividend there, the quotient in the a columns)
