@@ -21,6 +21,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <stdexcept>
 #include <algorithm>
 #include <string>
@@ -182,6 +183,7 @@ private:
     zkhip::modular::U256 last_slope_{};
     uint64_t instret_ = 0;
     size_t in_pos_ = 0;
+    std::deque<uint32_t> hints_;   // the hint stream: words phantom instructions computed, read by the input ecall before the input stream
     bool done_ = false;
     // Per-cell state of the memory log for the CURRENT segment, kept in flat tables (register cells, then memory cells) instead
     // of a hash map: a slot belongs to the segment whose number its `seg` field holds, so closing a segment costs nothing
@@ -226,6 +228,100 @@ private:
         if (i == 0) v = 0;  // x0 is a cell that only ever holds zero
         touch(rec, 1, 2 * i, x_[i] & 0xffffu, true, v & 0xffffu), touch(rec, 1, 2 * i + 1, x_[i] >> 16, true, v >> 16);
         x_[i] = v;
+    }
+    // Phantom sub-executors (OpenVM's algebra extension: ModularPhantom::{HintNonQr, HintSqrt}; pairing extension: HintFinalExp).  The
+    // circuit proves nothing about them -- the guest checks what it reads (a square root by one multiplication and an equality test).
+    //   kind 0, buffer [modulus index]:            pushes a quadratic non-residue z of that modulus (nw words)
+    //   kind 1, buffer [modulus index | x (nw)]:   pushes [s | r (nw)]: s = 1 and r^2 = x if x is a square, else s = 0 and r^2 = x z
+    //   kind 2: the pairing extension's final-exponentiation witness -- not built
+    void phantom(uint32_t kind, uint32_t ptr) {
+        using namespace zkhip::modular;
+        if (kind == 2) throw Error("the pairing extension's final-exponentiation hint is not built");
+        if (kind > 2) throw Error("unknown phantom instruction " + std::to_string(kind));
+        if (ptr & 3u) throw Error("phantom operand must be word-aligned");
+        uint32_t which;
+        memcpy(&which, at(ptr, 4), 4);
+        if (which >= moduli_.size()) throw Error("phantom hint: the app's openvm.toml lists no modulus " + std::to_string(which));
+        const UInt p = moduli_[which];
+        const size_t nw = words_of(p);
+        if (!(p.w[0] & 1u)) throw Error("phantom hint: the modulus is even");
+        auto mul = [&](const UInt& a, const UInt& b) {
+            UInt q, r;
+            mulmod(a, b, p, &q, &r);
+            return r;
+        };
+        auto is_zero = [](const UInt& a) {
+            uint32_t o = 0;
+            for (uint32_t w : a.w) o |= w;
+            return o == 0;
+        };
+        auto equal = [](const UInt& a, const UInt& b) { return memcmp(a.w, b.w, sizeof a.w) == 0; };
+        auto shr1 = [](UInt a) {
+            for (size_t k = 0; k + 1 < MAX_WORDS; k++) a.w[k] = (a.w[k] >> 1) | (a.w[k + 1] << 31);
+            a.w[MAX_WORDS - 1] >>= 1;
+            return a;
+        };
+        UInt one{};
+        one.w[0] = 1;
+        auto pow = [&](UInt base, UInt e) {
+            UInt acc = one;
+            while (!is_zero(e)) {
+                if (e.w[0] & 1u) acc = mul(acc, base);
+                base = mul(base, base), e = shr1(e);
+            }
+            return acc;
+        };
+        UInt pm1 = p;
+        pm1.w[0] -= 1;   // (p odd)
+        const UInt half = shr1(pm1);
+        // the smallest non-residue
+        UInt z{};
+        for (uint32_t c = 2;; c++) {
+            z = UInt{};
+            z.w[0] = c;
+            if (equal(pow(z, half), pm1)) break;
+            if (c > 1000) throw Error("phantom hint: no small quadratic non-residue (is the modulus prime?)");
+        }
+        auto push = [&](const UInt& v) {
+            for (size_t k = 0; k < nw; k++) hints_.push_back(v.w[k]);
+        };
+        if (kind == 0) return push(z);
+        UInt x = load_words(at(ptr + 4, (unsigned)(4 * nw)), nw);
+        {   // reduce
+            UInt q, r;
+            mulmod(x, one, p, &q, &r);
+            x = r;
+        }
+        const bool square = is_zero(x) || equal(pow(x, half), one);
+        const UInt target = square ? x : mul(x, z);
+        // Tonelli - Shanks: p - 1 = q 2^s
+        UInt q = pm1;
+        unsigned s = 0;
+        while (!(q.w[0] & 1u)) q = shr1(q), s++;
+        UInt r{};
+        if (!is_zero(target)) {
+            UInt qp1 = q;   // (q + 1) / 2
+            {
+                uint64_t c = 1;
+                for (size_t k = 0; k < MAX_WORDS; k++) c += qp1.w[k], qp1.w[k] = (uint32_t)c, c >>= 32;
+            }
+            UInt c = pow(z, q), t = pow(target, q);
+            r = pow(target, shr1(qp1));
+            unsigned m = s;
+            while (!equal(t, one)) {
+                unsigned i = 0;
+                UInt t2 = t;
+                while (!equal(t2, one)) {
+                    t2 = mul(t2, t2), i++;
+                    if (i >= m) throw Error("phantom hint: the modulus is not prime");
+                }
+                UInt b = c;
+                for (unsigned k = 0; k + i + 1 < m; k++) b = mul(b, b);
+                r = mul(r, b), c = mul(b, b), t = mul(t, c), m = i;
+            }
+        }
+        hints_.push_back(square ? 1u : 0u);
+        push(r);
     }
     uint8_t* at(uint32_t addr, unsigned n) {
         const uint64_t off = (uint64_t)addr - exe_.data_base;
@@ -425,9 +521,14 @@ private:
                     if (off + 4 > pv_.size()) throw Error("public value index out of range");
                     memcpy(pv_.data() + off, &word, 4);
                 } else if (call == 2) {
-                    if (in_pos_ + 4 > in_.bytes.size()) throw Error("input stream exhausted");
-                    memcpy(&val, in_.bytes.data() + in_pos_, 4);
-                    in_pos_ += 4;
+                    if (!hints_.empty()) {   // what a phantom instruction left for the guest comes first
+                        val = hints_.front();
+                        hints_.pop_front();
+                    } else {
+                        if (in_pos_ + 4 > in_.bytes.size()) throw Error("input stream exhausted");
+                        memcpy(&val, in_.bytes.data() + in_pos_, 4);
+                        in_pos_ += 4;
+                    }
                     reg_write(rec, 10, val);
                 } else if (call == 3) {
                     // Keccak-f[1600] in place on the 200 bytes at a0 (25 little-endian lanes): the intrinsic behind OpenVM's keccak
@@ -530,7 +631,12 @@ private:
                 }
                 break;
             }
-            case 0x0f: break;  // FENCE: a single hart with one memory -- no operation (ordinary rv32im toolchains emit it)
+            case 0x0f:   // FENCE: a single hart with one memory -- no operation (ordinary rv32im toolchains emit it)
+                // ... and the carrier of PHANTOM instructions (OpenVM: instructions the circuit sees as no-ops, whose sub-executors leave
+                // advice in the hint stream): fm = 0101, kind in the pred / succ bits, the operand pointer in rs1
+                if ((w >> 28) == 5u) phantom((w >> 20) & 0xffu, x_[(w >> 15) & 31]);
+                (void)alu(0, 0, 0);   // what the circuit proves for it: add x0, x0, 0 (the frame chip hands the ALU chip that row)
+                break;
             default: throw Error("illegal instruction " + std::to_string(w) + " at pc " + std::to_string(pc_));
         }
         last_val_ = val;

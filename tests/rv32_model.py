@@ -73,6 +73,10 @@ def assemble(lines):
             w = _i(0x67, 0, ln[1], ln[2], ln[3])
         elif op == "ecall":
             w = 0x73
+        elif op == "fence":
+            w = 0x0FF0000F
+        elif op == "phantom":   # ("phantom", kind, rs1): a FENCE-coded no-op whose sub-executor leaves advice in the hint stream (fm = 0101)
+            w = (5 << 28) | ((ln[1] & 0xFF) << 20) | (ln[2] << 15) | 0x0F
         else:
             raise ValueError(op)
         out.append(w & M32)
@@ -105,6 +109,28 @@ def sx(v, bits):
     return v - (1 << bits) if v >> (bits - 1) else v
 
 
+def _sqrts(a, p):
+    """square roots of a modulo the odd prime p (a a square): Tonelli - Shanks, written for this model; yields the root the product's
+    sub-executor computes first (the algorithm is deterministic: same non-residue, same steps)"""
+    if a == 0:
+        yield 0
+        return
+    q, s = p - 1, 0
+    while q % 2 == 0:
+        q //= 2
+        s += 1
+    z = next(c for c in range(2, 1000) if pow(c, (p - 1) // 2, p) == p - 1)
+    m, c, t, r = s, pow(z, q, p), pow(a, q, p), pow(a, (q + 1) // 2, p)
+    while t != 1:
+        i, t2 = 0, t
+        while t2 != 1:
+            t2 = t2 * t2 % p
+            i += 1
+        b = pow(c, 1 << (m - i - 1), p)
+        m, c, t, r = i, b * b % p, t * b * b % p, r * b % p
+    yield r
+
+
 def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_bytes=1 << 20, data=b"", max_instr=10**7, moduli=(), curves=(), fp2=()):
     """Independent interpreter.  Returns dict(instret, pvs (32 bytes), exit_code, records)."""
     x = [0] * 32
@@ -113,6 +139,7 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
     mem[:len(data)] = data
     pvs = bytearray(32)
     pc, n, pos = pc_base, 0, 0
+    hints = []   # the hint stream (phantom instructions fill it, the input ecall drains it first)
     rec = dict(pc_index=[], alu=[], lt=[], mul=[], shift=0, branch=0, jump=0, load_store=0, mulh=0, divrem=0, lui_auipc=0, ecall=0,
                acc=[], bnd=[], shifts=[], beq=[], blt=[], jal=[], auipc=[], jalr=[], mulhs=[], ls=[], divs=[])
     s32 = lambda v: sx(v, 32)  # noqa: E731
@@ -172,7 +199,26 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
             s &= 31
             return [(p << s) & M32, p >> s, (s32(p) >> s) & M32][k]
 
-        if op == 0x37:
+        if op == 0x0F:   # FENCE: no operation; with fm = 0101 a phantom instruction (advice for the guest, nothing the circuit sees)
+            if w >> 28 == 5:
+                kind, ptr = (w >> 20) & 0xFF, x[(w >> 15) & 31]
+                off = ptr - data_base
+                p_ = moduli[struct.unpack_from("<I", mem, off)[0]]
+                nb = 32 if p_ < 1 << 256 else 48
+                z_ = next(c for c in range(2, 1000) if pow(c, (p_ - 1) // 2, p_) == p_ - 1)
+                words_of = lambda v: [(v >> (32 * i)) & M32 for i in range(nb // 4)]  # noqa: E731
+                if kind == 0:
+                    hints.extend(words_of(z_))
+                elif kind == 1:
+                    xv = int.from_bytes(mem[off + 4:off + 4 + nb], "little") % p_
+                    sq = xv == 0 or pow(xv, (p_ - 1) // 2, p_) == 1
+                    tgt = xv if sq else xv * z_ % p_
+                    r_ = next(c for c in _sqrts(tgt, p_))
+                    hints.extend([int(sq)] + words_of(r_))
+                else:
+                    raise ValueError("phantom kind")
+            rec["alu"].append((0, 0, 0))
+        elif op == 0x37:
             val, wr = w & 0xFFFFF000, True
             rec["lui_auipc"] += 1
             rec["jal"].append((1, pc, w >> 12))
@@ -300,8 +346,11 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                 k = rr(11)
                 pvs[4 * k:4 * k + 4] = struct.pack("<I", word)
             elif call == 2:
-                rw(10, struct.unpack_from("<I", stdin, pos)[0])
-                pos += 4
+                if hints:   # what a phantom instruction left comes before the input stream
+                    rw(10, hints.pop(0))
+                else:
+                    rw(10, struct.unpack_from("<I", stdin, pos)[0])
+                    pos += 4
             elif call == 3:   # Keccak-f[1600] in place on the 200 bytes at a0 (the memory log of this model does not cover it)
                 off = rr(10) - data_base
                 assert off % 4 == 0 and 0 <= off and off + 200 <= len(mem)

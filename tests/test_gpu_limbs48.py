@@ -142,3 +142,22 @@ def test_bls12_381_guest_under_the_batch_circuit_config_one_flow_one_proof(tmp_p
     (tmp_path / "small.toml").write_text(pm.TOML.format(*PARAMS))
     r = subprocess.run([pm.CLI, "prove-elf", str(exe), "-", str(tmp_path), str(tmp_path / "small.toml"), "10"], capture_output=True, text=True)
     assert r.returncode != 0 and "modular intrinsic" in r.stderr
+
+
+def test_phantom_hints_guest_one_flow_one_proof(tmp_path):
+    """Phantom instructions (square root / non-residue advice: tests/test_phantom_cpu.py) inside the one-statement flow: the circuit sees
+    no-ops and the reads of the hint stream, the guest's own checks with the modular intrinsic (32- and 48-limb chips) are what is proven."""
+    from test_vm_cpu import PHANTOM_MODULI, phantom_data, phantom_program
+
+    words, data = phantom_program(), phantom_data()
+    model = rv.run(words, b"", data=data, moduli=PHANTOM_MODULI)
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words, data=data))
+    (tmp_path / "openvm.toml").write_text(pm.TOML.format(*PARAMS) + "\n[app_vm_config.modular]\nsupported_moduli = [\n" + ",\n".join('    "%d"' % m for m in PHANTOM_MODULI) + "\n]\n")
+    r = subprocess.run([pm.CLI, "prove-elf", str(exe), "-", str(tmp_path), str(tmp_path / "openvm.toml"), "10"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["verified"] and out["total_cycles"] == model["instret"]
+    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * N_STMT:4 * N_STMT + 32]
+    assert pv == bytes(model["pvs"]) and [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(3)] == [3, 3, 4]
+    assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0

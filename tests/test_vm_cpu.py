@@ -392,6 +392,66 @@ def bls_data():
     return mod + ec + f
 
 
+# ---- phantom instructions (OpenVM's algebra extension: ModularPhantom::{HintNonQr, HintSqrt}): advice the circuit does not see ----
+PHANTOM_MODULI = (SECP256K1_P, SECP256K1_N, BLS12_381_P)   # (n = 1 mod 4: the square root takes Tonelli - Shanks' loop)
+
+
+def phantom_cases():
+    """(modulus index, x): a square modulo p, a value modulo n (square or not: Python decides), the smallest non-residue modulo BLS12-381's p"""
+    z = next(c for c in range(2, 100) if pow(c, (BLS12_381_P - 1) // 2, BLS12_381_P) == BLS12_381_P - 1)
+    return ((0, SECP256K1_GY * SECP256K1_GY % SECP256K1_P), (1, 0xDEADBEEF12345), (2, z))
+
+
+def phantom_layout():
+    """per case a region of 1024 bytes: H = [index | x] at 0, B0 = (r | r | .) at 256, B1 = (x | z | .) at 448, B2 = (r^2 | x | .) at 640,
+    B3 = (r^2 | x z | .) at 832 -- the three-operand buffers of the modular intrinsic (3 nb bytes, nb = 32 or 48)"""
+    return dict(H=0, B0=256, B1=448, B2=640, B3=832, stride=1024)
+
+
+def phantom_program():
+    """For every case: ask for the square root (phantom 1) and for the non-residue (phantom 0), read both from the hint stream, then CHECK
+    them with the modular intrinsic: r^2 (mul), x z (mul), [r^2 = x], [r^2 = x z] (is_eq).  Reveals per case s | eq1 << 1 | eq2 << 2
+    (a square: 3, a non-square: 4), and the low word of the first root."""
+    L = phantom_layout()
+    p = []
+    for k, (mi, _) in enumerate(phantom_cases()):
+        nw = 8 if PHANTOM_MODULI[mi] < 1 << 256 else 12
+        nb = 4 * nw
+        p += rv.li(S0, 0x00400000 + k * L["stride"])
+        p += [("phantom", 1, S0), ("addi", A7, 0, 2), ("ecall",), ("add", S1, A0, 0)]                 # s
+        for j in range(nw):                                                                             # r into B0's two operands
+            p += [("addi", A7, 0, 2), ("ecall",), ("sw", A0, S0, L["B0"] + 4 * j), ("sw", A0, S0, L["B0"] + nb + 4 * j)]
+        p += [("phantom", 0, S0)]
+        for j in range(nw):                                                                             # z into B1's second operand
+            p += [("addi", A7, 0, 2), ("ecall",), ("sw", A0, S0, L["B1"] + nb + 4 * j)]
+        for j in range(nw):                                                                             # x into B1's first, B2's second operand
+            p += [("lw", T0, S0, L["H"] + 4 + 4 * j), ("sw", T0, S0, L["B1"] + 4 * j), ("sw", T0, S0, L["B2"] + nb + 4 * j)]
+        call = lambda off, op: [("addi", A0, S0, off), ("addi", A1, 0, mi + 8 * op), ("addi", A7, 0, 5), ("ecall",)]  # noqa: E731
+        p += call(L["B0"], 0) + call(L["B1"], 0)
+        for j in range(nw):                                                                             # r^2 into B2 / B3, x z into B3
+            p += [("lw", T0, S0, L["B0"] + 2 * nb + 4 * j), ("sw", T0, S0, L["B2"] + 4 * j), ("sw", T0, S0, L["B3"] + 4 * j),
+                  ("lw", T0, S0, L["B1"] + 2 * nb + 4 * j), ("sw", T0, S0, L["B3"] + nb + 4 * j)]
+        p += call(L["B2"], 4) + call(L["B3"], 4)
+        p += [("lw", T0, S0, L["B2"] + 2 * nb), ("slli", T0, T0, 1), ("lw", T1, S0, L["B3"] + 2 * nb), ("slli", T1, T1, 2), ("or", T0, T0, T1), ("or", A0, T0, S1),
+              ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+        if k == 0:
+            p += [("lw", A0, S0, L["B0"]), ("addi", A1, 0, 7), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("fence",), ("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
+def phantom_data():
+    L = phantom_layout()
+    out = b""
+    for mi, x in phantom_cases():
+        nb = 32 if PHANTOM_MODULI[mi] < 1 << 256 else 48
+        region = bytearray(L["stride"])
+        region[0:4] = mi.to_bytes(4, "little")
+        region[4:4 + nb] = x.to_bytes(nb, "little")
+        out += bytes(region)
+    return out
+
+
 DEFERRAL_DATA_BYTES = 64   # the batch-like guest's data segment: the child app's exe commitment (8 words), vm commitment (8 words)
 
 
