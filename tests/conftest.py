@@ -16,6 +16,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"`) spends its time in the oracle's proofs of verifier circuits and in the sanitizer builds: one
+    process takes ~25 minutes, four take under eight.  Where pytest-xdist is installed and the caller did not choose, `-m "not gpu"` runs
+    on min(4, cores) workers (ZKHIP_PYTEST_WORKERS=n overrides, 0 = one process).  The GPU suite is never touched: one GPU, one process."""
+    if getattr(config.option, "markexpr", "") != "not gpu" or os.environ.get("PYTEST_XDIST_WORKER"):
+        return None
+    if getattr(config.option, "numprocesses", None) or getattr(config.option, "collectonly", False) or not config.pluginmanager.hasplugin("xdist"):
+        return None
+    n = int(os.environ.get("ZKHIP_PYTEST_WORKERS", min(4, os.cpu_count() or 1)))
+    if n > 1:
+        config.option.numprocesses = n
+        config.option.dist = "load"
+        config.option.tx = ["popen"] * n
+    return None
+
+
 @pytest.fixture(scope="session")
 def ora():
     import oracle_lib

@@ -187,9 +187,8 @@ def test_deferral_over_join_children(ora, flows):
     # a batch whose memory states OTHER claims than the ones its deferral node verified (the join itself does not look at the memory)
     liar = batch(claims[::-1])
     assert D2.witness([liar["jproof"]], [[NOPV, NOPV, liar["jpv"]]], aux=[aux(liar)])[0] == -7
-    # ... and one that states none
-    none = batch([])
-    assert D2.witness([none["jproof"]], [[NOPV, NOPV, none["jpv"]]], aux=[aux(none)])[0] == -7
+    # (a region that states NO claim -- word 0 = 0 -- has no flags the circuit accepts either: n_flags = 0 above fails on the count for this
+    # batch, and on `flag 0 = 1` for any batch; tests/test_gpu_deferral.py runs a join without claims into the host's refusal)
 
 
 def test_fold_of_deferral_nodes(ora, flows):
