@@ -188,7 +188,7 @@ def test_deferral_over_join_children(ora, flows):
     liar = batch(claims[::-1])
     assert D2.witness([liar["jproof"]], [[NOPV, NOPV, liar["jpv"]]], aux=[aux(liar)])[0] == -7
     # (a region that states NO claim -- word 0 = 0 -- has no flags the circuit accepts either: n_flags = 0 above fails on the count for this
-    # batch, and on `flag 0 = 1` for any batch; tests/test_gpu_deferral.py runs a join without claims into the host's refusal)
+    # batch, and on `flag 0 = 1` for any batch)
 
 
 def test_fold_of_deferral_nodes(ora, flows):
