@@ -231,6 +231,40 @@ __global__ __launch_bounds__(256) void k_compress_layer_coop(const uint32_t* __r
     if (i < n_next && lane < 8) next[i * 8 + lane] = x;
 }
 
+// Up to FIVE plain layers in one launch (round 4: the flow's profile had 8 100 cooperative layer launches of 11.6 us for 65 proofs -- a
+// few microseconds of permutations behind a launch each).  A workgroup produces 16 nodes of the first layer (one 16-lane row per
+// node), keeps them in LDS, and goes on with the 8 / 4 / 2 / 1 parents that depend on nothing else: a permutation latency per layer, no
+// launch in between.  Every layer is written to the tree's digest store as before.
+struct CoopMulti {
+    uint64_t out_off[5];   // word offsets of the produced layers in the digest store
+    uint32_t m;            // layers to produce (1..5)
+};
+__global__ __launch_bounds__(256) void k_compress_coop_multi(const uint32_t* __restrict__ prev, uint32_t* __restrict__ digests, size_t n_next, CoopMulti cm) {
+    __shared__ uint32_t buf[2][16 * 8];
+    const unsigned lane = threadIdx.x & 15u, row = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + row;
+    const size_t ii = i < n_next ? i : 0;  // all 16 lanes of every row stay active through the DPP permutation
+    const CoopConsts cc = coop_load_consts(lane);
+    uint32_t x = coop_permute_regs(prev[ii * 16 + lane], lane, cc);
+    if (lane < 8) {
+        if (i < n_next) digests[cm.out_off[0] + i * 8 + lane] = x;
+        buf[0][row * 8 + lane] = x;
+    }
+    unsigned cur = 0, rows = 16;
+    for (uint32_t j = 1; j < cm.m; j++) {
+        __syncthreads();
+        rows >>= 1;
+        const unsigned r = row < rows ? row : 0;
+        x = coop_permute_regs(buf[cur][16 * r + lane], lane, cc);   // the two children's digests are neighbours in the buffer
+        const size_t o = ((size_t)blockIdx.x * 16 >> j) + row;
+        if (row < rows && lane < 8) {
+            if (o < (n_next >> j)) digests[cm.out_off[j] + o * 8 + lane] = x;
+            buf[cur ^ 1][row * 8 + lane] = x;
+        }
+        cur ^= 1;
+    }
+}
+
 // Top of a tree in ONE launch: from a layer of <= 512 nodes down to the root.  Each 16-lane row
 // computes one compression cooperatively (poseidon2_coop.hpp), the working layer lives in LDS,
 // every produced layer is also written to the tree's digest store for later openings.
@@ -426,6 +460,25 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
         KernelScope ks(ctx, "poseidon2_compress_layer");
         // (ZKHIP_COOP_MAX_LOG / ZKHIP_COOP_INJ_MAX_LOG: the largest layer, plain / with injected rows, that takes the cooperative form)
         const unsigned coop_max = ctx->cfg.coop_max_log, coop_inj_max = ctx->cfg.coop_inj_max_log;
+        if (t->level_cnt[level] == 0 && cnt <= ((size_t)1 << coop_max) && cnt >= 16) {
+            // this plain layer and the plain layers above it that the top kernel does not take, up to five, in one launch
+            const unsigned top_log = std::min(ctx->cfg.top_max_log, 8u);
+            CoopMulti cm{};
+            unsigned m = 0;
+            while (m < 5 && level >= m) {
+                const unsigned lv = level - m;
+                if (t->level_cnt[lv] != 0) break;
+                if (m > 0 && ((size_t)1 << lv) <= ((size_t)1 << top_log) && lv < clean_top) break;   // the top kernel's from here
+                cm.out_off[m] = (uint64_t)t->layer_off[l + m] * 8;
+                m++;
+            }
+            if (m >= 2) {
+                cm.m = m;
+                hipLaunchKernelGGL(k_compress_coop_multi, dim3((unsigned)(cnt / 16)), dim3(256), 0, ctx->stream, t->d_digests + t->layer_off[l - 1] * 8, t->d_digests, cnt, cm);
+                l += m - 1;
+                continue;
+            }
+        }
         if (cnt <= ((size_t)1 << (t->level_cnt[level] ? coop_inj_max : coop_max)))
             hipLaunchKernelGGL(k_compress_layer_coop, dim3((unsigned)((cnt + 15) / 16)), dim3(256), 0, ctx->stream,
                                t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,
