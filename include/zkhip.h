@@ -912,6 +912,11 @@ typedef struct {
     uint32_t witness_threads;
     int pin_witness, parallel_queries;
 } zkhip_config;
+/* While `on`, the trace generators treat the shared lookup-count tables handed to them (the 8-bit bitwise table, the range-tuple table, the
+ * range table) as canonical counts and leave them canonical -- none converts a table from Montgomery form and back around its increments.
+ * The caller zeroes the tables, switches this on, runs a segment's generators, switches it off and converts each table once
+ * (zkhip_to_monty).  A property of the context; off by default (every generator then leaves Montgomery tables, as its standalone tests expect). */
+int zkhip_tables_canonical(zkhip_ctx *ctx, int on);
 /* Compiles the constraint kernels of `airs` for blow-up 2^log_blowup into `cache_dir` (no GPU needed: hipRTC), where key generation finds
  * them when zkhip_config.jit_cache_dir names the directory; *n_ok (may be NULL) = kernels present afterwards. */
 int zkhip_jit_prewarm(const zkhip_air *airs, size_t n_airs, unsigned log_blowup, const char *cache_dir, size_t *n_ok);

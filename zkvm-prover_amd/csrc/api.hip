@@ -212,6 +212,16 @@ int zkhip_set_process_config(const zkhip_config* cfg) {
     zk::g_process_config = *cfg;
     return ZKHIP_OK;
 }
+// While on, the trace generators take the shared lookup-count tables handed to them (8-bit bitwise table, range-tuple table, range table)
+// as CANONICAL counts and leave them so: a segment's ~20 generators each converted those tables from Montgomery form and back around their
+// increments (45 launches per segment).  The caller zeroes the tables, switches this on, runs the generators, switches it off and converts
+// each table once (zkhip_to_monty).
+int zkhip_tables_canonical(zkhip_ctx* ctx, int on) {
+    if (!ctx) return ZKHIP_ERR_INVALID;
+    ctx->tables_canonical = on != 0;
+    return ZKHIP_OK;
+}
+
 int zkhip_ctx_get_config(zkhip_ctx* ctx, zkhip_config* out) {
     if (!ctx || !out) return ZKHIP_ERR_INVALID;
     *out = ctx->cfg;

@@ -228,16 +228,16 @@ int zkhip_ec_tracegen_x(zkhip_ctx* ctx, uint32_t n_words, const uint32_t* modulu
     KernelScope ks(ctx, "ec_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256), bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
-    hipLaunchKernelGGL(k_ec_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
-    hipLaunchKernelGGL(k_ec_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);   // the range column of the 8-bit table
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_ec_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_ec_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);   // the range column of the 8-bit table
     if (n_words == 8)
         hipLaunchKernelGGL(k_ec_trace<8>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, ctx->stream, d_records, n, N, cw, d_trace, d_bitwise_trace, d_tuple_counts, size_y,
                            (uint32_t*)flag);
     else
         hipLaunchKernelGGL(k_ec_trace<12>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, ctx->stream, d_records, n, N, cw, d_trace, d_bitwise_trace, d_tuple_counts, size_y,
                            (uint32_t*)flag);
-    hipLaunchKernelGGL(k_ec_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
-    hipLaunchKernelGGL(k_ec_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_ec_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_ec_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return tracegen_finish(ctx, flag, "ec tracegen (a slope that does not solve the chord / tangent identity, a quotient beyond L + 1 bytes, or an unknown operation)");
 }

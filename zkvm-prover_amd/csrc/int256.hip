@@ -201,9 +201,9 @@ int tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_ts, si
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     uint32_t* xor_col = d_bitwise_trace + ((size_t)1 << 16);   // the XOR multiplicities of the 8-bit table
     const unsigned bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
-    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 0);
     hipLaunchKernelGGL(k_alu256_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, d_ts, n, N, width, d_trace, xor_col, (uint32_t*)flag);
-    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return tracegen_finish(ctx, flag, std::string(what) + " (an opcode above 4)");
 }
@@ -235,12 +235,12 @@ int mul_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t rec_stride, s
     KernelScope ks(ctx, what);
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256), bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
-    hipLaunchKernelGGL(k_i256_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
-    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
     hipLaunchKernelGGL(k_mul256_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, rec_stride, rec_off, d_ts, n, N, width, d_trace,
                        d_bitwise_trace, d_tuple_counts, size_y, (uint32_t*)flag);
-    hipLaunchKernelGGL(k_i256_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
-    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return tracegen_finish(ctx, flag, std::string(what) + " (a carry outside the tuple table)");
 }
@@ -258,10 +258,10 @@ int shift_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_
     KernelScope ks(ctx, what);
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned bb = (unsigned)(((size_t)2 << 16) + 255) / 256;   // both multiplicity columns of the 8-bit table
-    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 0);
     hipLaunchKernelGGL(k_shift256_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, d_ts, n, N, width, d_trace, d_bitwise_trace,
                        d_bitwise_trace + ((size_t)1 << 16), (uint32_t*)flag);
-    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return tracegen_finish(ctx, flag, std::string(what) + " (an opcode that is not a shift)");
 }
@@ -275,9 +275,9 @@ int cmp_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_ts
     KernelScope ks(ctx, what);
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
-    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);   // the range column of the 8-bit table
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);   // the range column of the 8-bit table
     hipLaunchKernelGGL(k_cmp256_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, d_ts, n, N, width, d_trace, d_bitwise_trace, (uint32_t*)flag);
-    hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return tracegen_finish(ctx, flag, std::string(what) + " (an opcode that is not a comparison)");
 }

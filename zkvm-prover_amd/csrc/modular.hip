@@ -270,16 +270,16 @@ static int modular_tracegen(zkhip_ctx* ctx, uint32_t n_words, const uint32_t* mo
     KernelScope ks(ctx, "modmul_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256), bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
-    hipLaunchKernelGGL(k_mod_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
-    hipLaunchKernelGGL(k_mod_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);   // the range column of the 8-bit table
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_mod_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_mod_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);   // the range column of the 8-bit table
     if (n_words == 8)
         hipLaunchKernelGGL(k_modmul_trace<8>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, rec_stride, n, N, pm, d_trace, d_bitwise_trace,
                            d_tuple_counts, size_y, (uint32_t*)flag);
     else
         hipLaunchKernelGGL(k_modmul_trace<12>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, rec_stride, n, N, pm, d_trace, d_bitwise_trace,
                            d_tuple_counts, size_y, (uint32_t*)flag);
-    hipLaunchKernelGGL(k_mod_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
-    hipLaunchKernelGGL(k_mod_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_mod_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_mod_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return tracegen_finish(ctx, flag, "modular tracegen (a quotient beyond the modulus's limbs, operands of a subtraction further apart than the modulus, or an unknown operation)");
 }

@@ -136,13 +136,13 @@ int range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d_values, size_t n, un
     KernelScope ks(ctx, "range_counts_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
-    if (accumulate) hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
-    else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
+    if (!accumulate) ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
+    else if (!ctx->tables_canonical) hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
     if (n) {
         const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 32 - 1) / (256 * 32), 1024);
         hipLaunchKernelGGL(k_range_counts, dim3(blocks), dim3(256), 0, ctx->stream, d_values, n, log_table, d_counts, (uint32_t*)flag);
     }
-    hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return tracegen_finish(ctx, flag, "range_counts_tracegen (values outside the table)");
 }

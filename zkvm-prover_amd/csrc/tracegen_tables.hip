@@ -128,13 +128,13 @@ extern "C" int zkhip_range_tuple_counts_tracegen(zkhip_ctx* ctx, const uint32_t*
     KernelScope ks(ctx, "range_tuple_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
-    if (accumulate) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
-    else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
+    if (!accumulate) ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
+    else if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
     if (n) {
         const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), HOT_MAX_BLOCKS);
         hipLaunchKernelGGL(k_tuple_counts, dim3(blocks), dim3(256), 0, ctx->stream, d_x, d_y, n, size_x, size_y, d_counts, (uint32_t*)flag);
     }
-    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "range_tuple_counts_tracegen");
 }
@@ -149,13 +149,13 @@ extern "C" int zkhip_bitwise_lookup_tracegen(zkhip_ctx* ctx, const uint32_t* d_x
     KernelScope ks(ctx, "bitwise_lookup_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
-    if (accumulate) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_trace, T, 0);
-    else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_trace, 0, T * 4, ctx->stream));
+    if (!accumulate) ZK_HIP_CHECK(ctx, hipMemsetAsync(d_trace, 0, T * 4, ctx->stream));
+    else if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_trace, T, 0);
     if (n) {
         const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), HOT_MAX_BLOCKS);
         hipLaunchKernelGGL(k_bitwise_counts, dim3(blocks), dim3(256), 0, ctx->stream, d_x, d_y, d_op, n, num_bits, d_trace, (uint32_t*)flag);
     }
-    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_trace, T, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_trace, T, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "bitwise_lookup_tracegen");
 }
@@ -255,10 +255,10 @@ extern "C" int zkhip_rv32_alu_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode,
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     // the XOR multiplicity column of the 8-bit bitwise lookup table (column 1 of its 2 x 2^16 trace): Montgomery -> counts -> Montgomery
     uint32_t* xor_col = d_bitwise_trace + (1u << 16);
-    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 0);
     hipLaunchKernelGGL(k_rv32_alu, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, xor_col,
                        (uint32_t*)flag);
-    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_alu_tracegen (opcode > 4)");
 }
@@ -315,9 +315,9 @@ extern "C" int zkhip_rv32_mul_tracegen(zkhip_ctx* ctx, const uint32_t* d_b, cons
     if (size_x < 256 || size_y < 1024 || T > ((size_t)1 << 27)) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_mul_tracegen: the tuple table must cover (limb < 256, carry < 1024)");
     KernelScope ks(ctx, "rv32_mul_tracegen");
     const unsigned tb = (unsigned)((T + 255) / 256);
-    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
     hipLaunchKernelGGL(k_rv32_mul, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_b, d_c, n, N, d_trace, d_tuple_counts, size_y);
-    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
 }
@@ -464,10 +464,10 @@ extern "C" int zkhip_rv32_lt_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, 
     KernelScope ks(ctx, "rv32_lt_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     // the RANGE multiplicity column of the 8-bit bitwise lookup table (column 0 of its 2 x 2^16 trace)
-    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
     hipLaunchKernelGGL(k_rv32_lt, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_bitwise_trace,
                        (uint32_t*)flag);
-    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_lt_tracegen (opcode > 1)");
 }
@@ -593,10 +593,10 @@ extern "C" int zkhip_rv32_shift_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcod
     ZK_TRY(get_scratch(ctx, 2, 16, &flag));
     KernelScope ks(ctx, "rv32_shift_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_tab_repr, dim3(512), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 0);  // both columns
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(512), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 0);  // both columns
     hipLaunchKernelGGL(k_rv32_shift, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace,
                        d_bitwise_trace, d_bitwise_trace + (1u << 16), (uint32_t*)flag);
-    hipLaunchKernelGGL(k_tab_repr, dim3(512), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(512), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_shift_tracegen (opcode > 2)");
 }
@@ -720,10 +720,10 @@ extern "C" int zkhip_rv32_branch_lt_tracegen(zkhip_ctx* ctx, const uint32_t* d_o
     ZK_TRY(get_scratch(ctx, 2, 16, &flag));
     KernelScope ks(ctx, "rv32_branch_lt_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
     hipLaunchKernelGGL(k_rv32_branch_lt, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_a, d_b, d_imm, n, N, d_trace,
                        d_bitwise_trace, (uint32_t*)flag);
-    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_branch_lt_tracegen (opcode > 3 or offset not a field element)");
 }
@@ -843,9 +843,9 @@ int jump_chip_tracegen(zkhip_ctx* ctx, const char* name, size_t n, unsigned log_
     ZK_TRY(get_scratch(ctx, 2, 16, &flag));
     KernelScope ks(ctx, name);
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
     launch(dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), N, (uint32_t*)flag);
-    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, name);
 }
@@ -950,12 +950,12 @@ extern "C" int zkhip_rv32_mulh_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode
     KernelScope ks(ctx, "rv32_mulh_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
-    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
-    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
     hipLaunchKernelGGL(k_rv32_mulh, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_tuple_counts, size_y,
                        d_bitwise_trace, (uint32_t*)flag);
-    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
-    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_mulh_tracegen (opcode > 2)");
 }
@@ -1119,12 +1119,12 @@ extern "C" int zkhip_rv32_divrem_tracegen(zkhip_ctx* ctx, const uint32_t* d_opco
     KernelScope ks(ctx, "rv32_divrem_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
-    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
-    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
     hipLaunchKernelGGL(k_rv32_divrem, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_tuple_counts,
                        size_y, d_bitwise_trace, (uint32_t*)flag);
-    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
-    hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "rv32_divrem_tracegen (opcode > 3)");
 }
@@ -1252,13 +1252,13 @@ extern "C" int zkhip_var_range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d
     KernelScope ks(ctx, "var_range_counts_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
-    if (accumulate) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
-    else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
+    if (!accumulate) ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
+    else if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
     if (n) {
         const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), HOT_MAX_BLOCKS);
         hipLaunchKernelGGL(k_var_range_counts, dim3(blocks), dim3(256), 0, ctx->stream, d_values, d_bits, const_bits, n, max_bits, d_counts, (uint32_t*)flag);
     }
-    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "var_range_counts_tracegen (bits > max_bits or value >= 2^bits)");
 }
@@ -1305,9 +1305,9 @@ extern "C" int zkhip_castf_tracegen(zkhip_ctx* ctx, const uint32_t* d_x, size_t 
     KernelScope ks(ctx, "castf_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
-    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_var_range_counts, T, 0);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_var_range_counts, T, 0);
     hipLaunchKernelGGL(k_castf, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_x, n, N, d_trace, d_var_range_counts, (uint32_t*)flag);
-    hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_var_range_counts, T, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_var_range_counts, T, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "castf_tracegen (value >= 2^30)");
 }

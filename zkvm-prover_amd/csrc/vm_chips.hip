@@ -324,13 +324,13 @@ int zkhip_range_counts_scaled_tracegen(zkhip_ctx* ctx, const uint32_t* d_values,
     KernelScope ks(ctx, "range_counts_scaled_tracegen");
     ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
-    if (accumulate) hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
-    else ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
+    if (!accumulate) ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
+    else if (!ctx->tables_canonical) hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
     if (n) {
         const unsigned blocks = (unsigned)std::min<size_t>((n + 256 * 8 - 1) / (256 * 8), HOT_MAX_BLOCKS);
         hipLaunchKernelGGL(k_range_counts_scaled, dim3(blocks), dim3(256), 0, ctx->stream, d_values, n, scale, (uint32_t)T, d_counts, (uint32_t*)flag);
     }
-    hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
+    if (!ctx->tables_canonical) hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 1);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return check_flag(ctx, flag, "range_counts_scaled_tracegen (scaled value outside the table)");
 }

@@ -30,6 +30,9 @@ struct zkhip_ctx {
     hipStream_t stream = nullptr;       // where all work is issued: the context's own stream unless zkhip_set_stream gave another
     hipStream_t own_stream = nullptr;   // created with the context (non-blocking): several contexts on one GPU overlap by default
     std::string last_error;
+    // the shared lookup-count tables handed to trace generators are CANONICAL counts for now (zkhip_tables_canonical): no generator converts
+    // them from / to Montgomery form around its increments; the caller converts once when every chip of the segment has counted
+    bool tables_canonical = false;
     // twiddle tables: w^e (fwd) and w^-e (inv) for w = two_adic_generator(tw_log), e < 2^(tw_log-1)
     unsigned tw_log = 0;
     uint32_t* d_tw_fwd = nullptr;
