@@ -47,6 +47,44 @@ def test_bitwise_lookup_counts(zk, ora):
                                    zk.upload(np.array([0], np.uint32)), 8)
 
 
+def test_count_tables_kept_canonical_across_generators(zk, ora):
+    """zkhip_tables_canonical: while on, the generators take the shared count tables as canonical counts and leave them so (a segment's
+    ~20 generators otherwise convert each table from Montgomery form and back around their increments); one conversion at the end gives
+    the table the default mode builds."""
+    import ctypes as C
+    import torch
+
+    rng = np.random.default_rng(9)
+    n = 50000
+    xs, ys = rng.integers(0, 256, n).astype(np.uint32), rng.integers(0, 256, n).astype(np.uint32)
+    ops = rng.integers(0, 2, n).astype(np.uint32)
+    tx, ty = rng.integers(0, 256, n).astype(np.uint32), rng.integers(0, 2048, n).astype(np.uint32)
+    dx, dy, dop, dtx, dty = (zk.upload(v) for v in (xs, ys, ops, tx, ty))
+    # default mode: two batches accumulated
+    bw = zk.bitwise_lookup_tracegen(dx, dy, dop, 8)
+    bw = zk.bitwise_lookup_tracegen(dy, dx, dop, 8, t_trace=bw, accumulate=True)
+    tup = zk.range_tuple_counts_tracegen(dtx, dty, 256, 2048)
+    tup = zk.range_tuple_counts_tracegen(dtx, dty, 256, 2048, t_counts=tup, accumulate=True)
+    # canonical mode: tables zeroed, the same calls, one conversion
+    bw2 = torch.zeros(2 << 16, dtype=torch.int32, device=zk.device)
+    tup2 = torch.zeros(256 * 2048, dtype=torch.int32, device=zk.device)
+    assert zk.lib.zkhip_tables_canonical(zk.h, 1) == 0
+    try:
+        zk.bitwise_lookup_tracegen(dx, dy, dop, 8, t_trace=bw2, accumulate=True)
+        zk.bitwise_lookup_tracegen(dy, dx, dop, 8, t_trace=bw2, accumulate=True)
+        zk.range_tuple_counts_tracegen(dtx, dty, 256, 2048, t_counts=tup2, accumulate=True)
+        zk.range_tuple_counts_tracegen(dtx, dty, 256, 2048, t_counts=tup2, accumulate=True)
+        zk.sync()
+        raw = bw2.cpu().numpy().view(np.uint32)                      # canonical counts as they are
+        exp = ora.bitwise_lookup_counts(xs, ys, ops, 8)[0] + ora.bitwise_lookup_counts(ys, xs, ops, 8)[0]
+        assert (raw.reshape(2, -1) == exp).all()
+    finally:
+        assert zk.lib.zkhip_tables_canonical(zk.h, 0) == 0
+    for t in (bw2, tup2):
+        zk._check(zk.lib.zkhip_to_monty(zk.h, C.c_void_p(t.data_ptr()), t.numel()))
+    assert torch.equal(bw, bw2) and torch.equal(tup, tup2)
+
+
 @pytest.mark.parametrize("n,log_height", [(0, 3), (1, 0), (5, 3), (1000, 10), (70000, 17)])
 def test_memory_boundary_trace_sorted_on_device(zk, ora, n, log_height):
     rng = np.random.default_rng(n)
