@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -656,7 +657,9 @@ inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vec
         hiprtcGetCode(prog, code.data());
         hiprtcDestroyProgram(&prog);
         if (!disk_path.empty()) {  // write to a temporary name, then rename: concurrent keygens never see a partial file
-            const std::string tmp = disk_path + ".tmp" + std::to_string((unsigned long long)getpid());
+            // (... nor do two threads of one process -- the device slots' keys are generated side by side -- share a temporary file)
+            static std::atomic<unsigned> tmp_serial{0};
+            const std::string tmp = disk_path + ".tmp" + std::to_string((unsigned long long)getpid()) + "_" + std::to_string(tmp_serial.fetch_add(1));
             if (FILE* f = fopen(tmp.c_str(), "wb")) {
                 const uint64_t sl = src.size();
                 const bool ok = fwrite(&sl, 8, 1, f) == 1 && fwrite(src.data(), 1, src.size(), f) == src.size() &&
