@@ -347,7 +347,27 @@ public:
         } else {
             rc = zkhip_recursion_witness(L.circ, proofs.data(), lens.data(), pv_ptrs.data(), kids.size(), npv.data());
         }
-        if (rc != ZKHIP_OK) throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_recursion_last_error(L.circ));
+        if (rc != ZKHIP_OK) {
+            // which child, and whose fault: the same proofs through the host verifier (a child it accepts and the circuit refuses points
+            // at the witness generator; one it refuses too at the prover that made it)
+            std::string detail = zkhip_recursion_last_error(L.circ);
+            if (rc == ZKHIP_ERR_VERIFY) {
+                for (size_t c = 0; c < kids.size(); c++) {
+                    const VerifyingKey* kvk = &cvk;
+                    if (cfg_.one_key && level > 0) {
+                        const int kind = kinds_in ? kinds_in->at(c) : level == 1 ? (int)(kid_shapes ? kid_shapes->at(c) : 0) + 1 : 0;
+                        kvk = kind ? &lv(0, (size_t)kind - 1).vk : &lv(1).vk;
+                    }
+                    bool ok = false;
+                    try {
+                        ok = kvk->verify(*kids[c]);
+                    } catch (...) {
+                    }
+                    detail += std::string("; child ") + std::to_string(c) + (ok ? " verifies on the host" : " does NOT verify on the host");
+                }
+            }
+            throw Error(Error::GenProof, "aggregation: " + detail);
+        }
         return npv;
     }
     // A leaf node of a WRAPPED shape: the shape's (large) leaf circuit over its segment proofs, then the wrapper over that proof -- what
