@@ -480,6 +480,10 @@ int zkhip_proof_fetch(zkhip_ctx *ctx, const zkhip_pk *pk, uint8_t *out, size_t c
  * for this backend's proofs).  Needs no device. */
 int zkhip_verify(const zkhip_params *params, const zkhip_air *airs, size_t n_airs,
                  const uint32_t *const *pvs, const uint8_t *proof, size_t len);
+/* the same; on ZKHIP_ERR_VERIFY `*where` (optional) is the line of csrc/verifier.hip whose check refused the proof -- a diagnosis
+ * for the prover's own failure messages (which commitment, query or fold), not an interface */
+int zkhip_verify_where(const zkhip_params *params, const zkhip_air *airs, size_t n_airs,
+                       const uint32_t *const *pvs, const uint8_t *proof, size_t len, int *where);
 
 /* The verifier's primitives on the HOST (no device, canonical words in and out).  They are what p3's permutation,
  * `Mmcs::verify_batch` (MerkleTreeMmcs over PaddingFreeSponge / TruncatedPermutation) and p3-fri's `fold_row` are to
@@ -911,6 +915,9 @@ typedef struct {
      * copy to the device, queries of a child side by side [ZKHIP_WITNESS_THREADS, ZKHIP_NO_PIN_WITNESS=1 -> 0, ZKHIP_RECURSION_SERIAL_QUERIES=1 -> 0] */
     uint32_t witness_threads;
     int pin_witness, parallel_queries;
+    /* diagnosis: after every proof the prover recomputes every plain layer of the proof's Merkle trees (and the FRI leaves) on the device
+     * and fetches the proof twice; what differs is reported on stderr and the proof fails with ZKHIP_ERR_HIP [ZKHIP_SELF_CHECK=1] */
+    int self_check;
 } zkhip_config;
 /* While `on`, the trace generators treat the shared lookup-count tables handed to them (the 8-bit bitwise table, the range-tuple table, the
  * range table) as canonical counts and leave them canonical -- none converts a table from Montgomery form and back around its increments.

@@ -68,6 +68,19 @@ struct VerifyingKey {
         }
         return zkhip_verify(&params, za.data(), za.size(), pv.data(), p.proof.data(), p.proof.size()) == ZKHIP_OK;
     }
+    // for failure messages: 0 when the proof verifies, else the line of csrc/verifier.hip that refuses it (-1: malformed for this key)
+    int refused_at(const ChildProof& p) const {
+        if (p.pvs.size() != airs.size()) return -1;
+        std::vector<zkhip_air> za = as_airs();
+        std::vector<const uint32_t*> pv(airs.size());
+        for (size_t a = 0; a < airs.size(); a++) {
+            if (p.pvs[a].size() != airs[a].n_pvs) return -1;
+            pv[a] = p.pvs[a].data();
+        }
+        int where = 0;
+        const int rc = zkhip_verify_where(&params, za.data(), za.size(), pv.data(), p.proof.data(), p.proof.size(), &where);
+        return rc == ZKHIP_OK ? 0 : (where ? where : -1);
+    }
     // the app-file form (encode_app_exe, tables omitted): UniversalVerifier::setup reads it back.  An aggregation key appends
     // [AGGKEY_MAGIC | leaf commitment (8) | app-vk digest (8)] (readers of the app-file form stop before it).
     static constexpr uint32_t AGGKEY_MAGIC = 0x4B474741u, JOINKEY_MAGIC = 0x4B4E4F4Au;
@@ -358,12 +371,13 @@ public:
                         const int kind = kinds_in ? kinds_in->at(c) : level == 1 ? (int)(kid_shapes ? kid_shapes->at(c) : 0) + 1 : 0;
                         kvk = kind ? &lv(0, (size_t)kind - 1).vk : &lv(1).vk;
                     }
-                    bool ok = false;
+                    int at = -1;
                     try {
-                        ok = kvk->verify(*kids[c]);
+                        at = kvk->refused_at(*kids[c]);
                     } catch (...) {
                     }
-                    detail += std::string("; child ") + std::to_string(c) + (ok ? " verifies on the host" : " does NOT verify on the host");
+                    detail += std::string("; child ") + std::to_string(c) +
+                              (at == 0 ? " verifies on the host" : " does NOT verify on the host (verifier.hip:" + std::to_string(at) + ")");
                 }
             }
             throw Error(Error::GenProof, "aggregation: " + detail);

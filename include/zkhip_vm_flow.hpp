@@ -706,7 +706,9 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
                 }
                 if (!agg.app_vk(made->shape).verify(made->proof)) {
                     std::lock_guard<std::mutex> lk(mu);
-                    if (error.empty()) error = "the proof of segment " + std::to_string(k) + " does not verify";
+                    if (error.empty())
+                        error = "the proof of segment " + std::to_string(k) + " (shape " + std::to_string(made->shape) + ") does not verify: verifier.hip:" +
+                                std::to_string(agg.app_vk(made->shape).refused_at(made->proof)) + " refuses it";
                     failed = true;
                     cv_push.notify_all(), cv_pop.notify_all();
                 }

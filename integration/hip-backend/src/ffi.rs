@@ -193,6 +193,7 @@ pub struct zkhip_config {
     pub witness_threads: u32,
     pub pin_witness: c_int,
     pub parallel_queries: c_int,
+    pub self_check: c_int,
 }
 
 #[repr(C)]
@@ -336,6 +337,8 @@ extern "C" {
     pub fn zkhip_proof_fetch(ctx: *mut zkhip_ctx, pk: *const zkhip_pk, out: *mut u8, cap: usize, out_len: *mut usize) -> c_int;
     pub fn zkhip_verify(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize, pvs: *const *const u32,
                         proof: *const u8, len: usize) -> c_int;
+    pub fn zkhip_verify_where(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize, pvs: *const *const u32,
+                        proof: *const u8, len: usize, where_: *mut c_int) -> c_int;
 
     pub fn zkhip_proof_layout_of(params: *const zkhip_params, airs: *const zkhip_air, n_airs: usize,
                                  out: *mut zkhip_proof_layout) -> c_int;

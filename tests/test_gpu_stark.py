@@ -114,6 +114,15 @@ def test_large_trace_verifies(zk):
     bad = bytearray(proof)
     bad[400] ^= 1
     assert z.verify(params, airs, [pv], bytes(bad)) != 0
+    # the verifier's diagnosis: nothing to say about a proof it accepts; a line of csrc/verifier.hip for one it refuses, and a flipped
+    # sibling digest of the last query is refused later in the file than a flipped root
+    assert z.verify_where(params, airs, [pv], proof) == (0, 0)
+    rc, at_root = z.verify_where(params, airs, [pv], bytes(bad))
+    assert rc != 0 and at_root > 0
+    late = bytearray(proof)
+    late[-5] ^= 1
+    rc, at_query = z.verify_where(params, airs, [pv], bytes(late))
+    assert rc != 0 and at_query > at_root
 
 
 def test_keygen_rejects_bad_programs(zk):

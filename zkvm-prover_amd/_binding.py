@@ -67,7 +67,7 @@ class Config(C.Structure):
     _fields_ = [("host_sponge", C.c_int), ("host_sponge_min_words", C.c_uint32), ("jit", C.c_int), ("jit_min_log_work", C.c_uint32),
                 ("jit_cache_dir", C.c_char * 256), ("quot_slices", C.c_int), ("grind_sweep_shift", C.c_uint32), ("coop_max_log", C.c_uint32),
                 ("coop_inj_max_log", C.c_uint32), ("top_max_log", C.c_uint32), ("commit_parts", C.c_uint32), ("side_cus", C.c_uint32), ("witness_threads", C.c_uint32),
-                ("pin_witness", C.c_int), ("parallel_queries", C.c_int)]
+                ("pin_witness", C.c_int), ("parallel_queries", C.c_int), ("self_check", C.c_int)]
 
     @classmethod
     def default(cls):
@@ -169,6 +169,7 @@ def load_library():
         "zkhip_prove_async": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(u32p)]),
         "zkhip_proof_fetch": (C.c_int, [vp, vp, C.POINTER(C.c_uint8), sz, C.POINTER(sz)]),
         "zkhip_verify": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(u32p), C.POINTER(C.c_uint8), sz]),
+        "zkhip_verify_where": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(u32p), C.POINTER(C.c_uint8), sz, C.POINTER(C.c_int)]),
         "zkhip_poseidon2_permute_host": (C.c_int, [u32p]),
         "zkhip_poseidon2_permute_host_avx512": (C.c_int, [u32p]),
         "zkhip_mmcs_verify": (C.c_int, [u32p, C.POINTER(C.c_uint), C.POINTER(sz), sz, C.c_uint64, u32p]),
@@ -1079,6 +1080,18 @@ def verify(params, airs, pvs, proof_bytes):
     pa, keep2 = _pvs_array(pvs)
     buf = np.frombuffer(proof_bytes, dtype=np.uint8)
     return lib.zkhip_verify(C.byref(prm), arr, len(airs), pa, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size)
+
+
+def verify_where(params, airs, pvs, proof_bytes):
+    """The host verifier with its diagnosis: (status, line of csrc/verifier.hip whose check refused the proof -- 0 when accepted)."""
+    lib = load_library()
+    prm = _Params(*params)
+    arr, keep = _air_structs(airs)
+    pa, keep2 = _pvs_array(pvs)
+    buf = np.frombuffer(proof_bytes, dtype=np.uint8)
+    where = C.c_int(0)
+    rc = lib.zkhip_verify_where(C.byref(prm), arr, len(airs), pa, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.size, C.byref(where))
+    return rc, where.value
 
 
 def keccak_f_air():

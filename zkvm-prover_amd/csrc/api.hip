@@ -178,6 +178,7 @@ void zkhip_config_default(zkhip_config* c) {
     c->witness_threads = num("ZKHIP_WITNESS_THREADS", 0u);
     c->pin_witness = getenv("ZKHIP_NO_PIN_WITNESS") ? 0 : 1;
     c->parallel_queries = getenv("ZKHIP_RECURSION_SERIAL_QUERIES") ? 0 : 1;
+    c->self_check = getenv("ZKHIP_SELF_CHECK") ? 1 : 0;
     // compiled constraint kernels across processes: the variable if set (empty = none), else `jit_cache` beside this library if it exists
     std::string dir;
     if (const char* e = getenv("ZKHIP_JIT_CACHE_DIR")) {

@@ -246,22 +246,29 @@ __global__ __launch_bounds__(256) void k_compress_coop_multi(const uint32_t* __r
     const size_t ii = i < n_next ? i : 0;  // all 16 lanes of every row stay active through the DPP permutation
     const CoopConsts cc = coop_load_consts(lane);
     uint32_t x = coop_permute_regs(prev[ii * 16 + lane], lane, cc);
-    if (lane < 8) {
-        if (i < n_next) digests[cm.out_off[0] + i * 8 + lane] = x;
-        buf[0][row * 8 + lane] = x;
-    }
+    // every layer's word stays in a register of its own and goes to the digest store at the END of the kernel, behind the last
+    // permutation: the store's data register is never written again (the stale node of the guest flow)
+    uint32_t keep[5];
+    keep[0] = x;
+    if (lane < 8) buf[0][row * 8 + lane] = x;
     unsigned cur = 0, rows = 16;
-    for (uint32_t j = 1; j < cm.m; j++) {
+#pragma unroll
+    for (uint32_t j = 1; j < 5; j++) {
+        if (j >= cm.m) break;
         __syncthreads();
         rows >>= 1;
         const unsigned r = row < rows ? row : 0;
         x = coop_permute_regs(buf[cur][16 * r + lane], lane, cc);   // the two children's digests are neighbours in the buffer
-        const size_t o = ((size_t)blockIdx.x * 16 >> j) + row;
-        if (row < rows && lane < 8) {
-            if (o < (n_next >> j)) digests[cm.out_off[j] + o * 8 + lane] = x;
-            buf[cur ^ 1][row * 8 + lane] = x;
-        }
+        keep[j] = x;
+        if (row < rows && lane < 8) buf[cur ^ 1][row * 8 + lane] = x;
         cur ^= 1;
+    }
+    if (lane >= 8) return;
+#pragma unroll
+    for (uint32_t j = 0; j < 5; j++) {
+        if (j >= cm.m) break;
+        const size_t o = ((size_t)blockIdx.x * 16 >> j) + row;
+        if (row < (16u >> j) && o < (n_next >> j)) digests[cm.out_off[j] + o * 8 + lane] = keep[j];
     }
 }
 
@@ -277,15 +284,17 @@ __global__ __launch_bounds__(1024) void k_compress_top(uint32_t* __restrict__ di
     for (unsigned e = tid; e < n * 8; e += 1024) buf[0][e] = digests[layer_off(l0) * 8 + e];
     __syncthreads();
     unsigned cur = 0;
-    for (unsigned l = l0 + 1; l <= lh; l++) {
+    // layers of more than 64 nodes (top_max_log 7, 8): several nodes per row, stored as they are made; from 64 nodes down a row makes
+    // one node per layer, keeps it in a register of its own and stores it at the END of the kernel (as k_compress_coop_multi does)
+    uint32_t keep[7];
+    unsigned l = l0 + 1;
+    for (; l <= lh && (1u << (lh - l)) > 64u; l++) {
         const unsigned n_next = 1u << (lh - l);
         uint32_t* out = digests + layer_off(l) * 8;
-        for (unsigned i = grp; i < ((n_next + 63u) & ~63u); i += 64) {
-            // all 16 lanes of a row stay active through the DPP permutation
-            const unsigned ii = i < n_next ? i : 0;
-            uint32_t x = buf[cur][16 * ii + lane];
+        for (unsigned i = grp; i < n_next; i += 64) {
+            uint32_t x = buf[cur][16 * i + lane];
             x = coop_permute_regs(x, lane, cc);
-            if (i < n_next && lane < 8) {
+            if (lane < 8) {
                 buf[cur ^ 1][8 * i + lane] = x;
                 out[8 * i + lane] = x;
             }
@@ -293,6 +302,51 @@ __global__ __launch_bounds__(1024) void k_compress_top(uint32_t* __restrict__ di
         __syncthreads();
         cur ^= 1;
     }
+    const unsigned l1 = l;   // first layer of <= 64 nodes
+#pragma unroll
+    for (unsigned k = 0; k < 7; k++) {
+        if (l1 + k > lh) break;
+        const unsigned n_next = 1u << (lh - l1 - k);
+        // all 16 lanes of a row stay active through the DPP permutation
+        const unsigned ii = grp < n_next ? grp : 0;
+        const uint32_t x = coop_permute_regs(buf[cur][16 * ii + lane], lane, cc);
+        keep[k] = x;
+        if (grp < n_next && lane < 8) buf[cur ^ 1][8 * grp + lane] = x;
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (lane >= 8) return;
+#pragma unroll
+    for (unsigned k = 0; k < 7; k++) {
+        if (l1 + k > lh) break;
+        if (grp < (1u << (lh - l1 - k))) digests[layer_off(l1 + k) * 8 + 8 * grp + lane] = keep[k];
+    }
+}
+
+// Diagnosis (zkhip_config.self_check): every node of a plain layer against the compression of its children, one lane per node, through the
+// plain (non-cooperative) permutation.  report[0] = mismatching nodes, report[1] = the smallest (layer << 24 | index) among them.
+__global__ __launch_bounds__(256) void k_check_layer(const uint32_t* __restrict__ prev, const uint32_t* __restrict__ next, size_t n_next, uint32_t layer,
+                                                     uint32_t* report) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_next) return;
+    uint32_t s[16];
+    for (int q = 0; q < 16; q++) s[q] = prev[i * 16 + q];
+    poseidon2_permute_rolled(s);
+    bool same = true;
+    for (int q = 0; q < 8; q++) same = same && s[q] == next[i * 8 + q];
+    if (!same) atomicAdd(&report[0], 1u), atomicMin(&report[1], (layer << 24) | (uint32_t)(i & 0xffffffu));
+}
+int merkle_check_tree(zkhip_ctx* ctx, const zkhip_tree* t, uint32_t* d_report) {
+    const unsigned lh = t->log_height;
+    for (unsigned l = 1; l <= lh; l++) {
+        const unsigned level = lh - l;
+        if (level < t->level_cnt.size() && t->level_cnt[level]) continue;   // (a layer with injected rows: not checked here)
+        const size_t cnt = (size_t)1 << level;
+        hipLaunchKernelGGL(k_check_layer, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, t->d_digests + t->layer_off[l - 1] * 8,
+                           t->d_digests + t->layer_off[l] * 8, cnt, l, d_report);
+    }
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return ZKHIP_OK;
 }
 
 int permute_batch(zkhip_ctx* ctx, uint32_t* d_states, size_t n) {

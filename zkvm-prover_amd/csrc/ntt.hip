@@ -571,8 +571,8 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
                             uint32_t* tmp, uint32_t* tmp2, size_t tmp_stride, unsigned log_n, size_t width,
                             unsigned log_sub, bool inverse, const BrSrc* brsrc = nullptr,
                             const uint32_t* const* src_cols = nullptr, uint32_t* const* dst_cols = nullptr) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need(ctx->device)) {
         const int lds_max = ((17u << P4_MAX_LOG_R) + (1u << (P4_MAX_LOG_R - 1))) * 4;
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4<11, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4<10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
@@ -582,7 +582,7 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4_ct<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4_ct<7, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        attr_set = true;
+        attr_set.mark(ctx->device);
     }
     unsigned a[3];
     const unsigned n_pass = fourstep_split(log_n, a);
@@ -711,11 +711,11 @@ int ntt_dif_inplace(zkhip_ctx* ctx, const uint32_t* src, size_t src_stride, uint
         }
         return ZKHIP_OK;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need(ctx->device)) {
         ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_dif_pass,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 << MAX_LOG_TILE));
-        attr_set = true;
+        attr_set.mark(ctx->device);
     }
     unsigned n_pass = (log_n + MAX_LOG_R - 1) / MAX_LOG_R;
     unsigned base = log_n / n_pass, rem = log_n % n_pass;

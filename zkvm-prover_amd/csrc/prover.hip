@@ -20,6 +20,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <map>
+#include <mutex>
 
 #include "air_compile.hpp"
 #include "poseidon2_coop.hpp"
@@ -703,6 +705,21 @@ __global__ __launch_bounds__(256) void k_hash_pairs(const uint4* __restrict__ la
     uint4* o = reinterpret_cast<uint4*>(out + i * 8);
     o[0] = make_uint4(s[0], s[1], s[2], s[3]);
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// diagnosis (zkhip_config.self_check): every tree's digests as the previous proof left them
+static std::mutex g_shadow_mu;
+static std::map<const zkhip_tree*, std::vector<uint32_t>> g_shadow;
+// diagnosis (zkhip_config.self_check): the leaf digests of a FRI layer against the pairs they hash
+__global__ __launch_bounds__(256) void k_check_pairs(const uint4* __restrict__ layer, size_t n_leaves, const uint32_t* __restrict__ digests, uint32_t* report) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves) return;
+    uint4 a = layer[2 * i], b = layer[2 * i + 1];
+    uint32_t s[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, 0, 0, 0, 0, 0, 0, 0, 0};
+    poseidon2_permute_rolled(s);
+    bool same = true;
+    for (int q = 0; q < 8; q++) same = same && s[q] == digests[i * 8 + q];
+    if (!same) atomicAdd(&report[0], 1u), atomicMin(&report[1], (uint32_t)(i & 0xffffffu));
 }
 
 struct FriLayerDesc {
@@ -2223,6 +2240,79 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
                            pk->d_indices, pq, pk->query_pitch);
     }
     ZK_HIP_CHECK(ctx, hipGetLastError());
+    if (ctx->cfg.self_check) {
+        // diagnosis: every plain layer of every tree of this proof against its children, the FRI leaves against the layers they hash
+        std::vector<std::pair<std::string, const zkhip_tree*>> trees{{"main", pk->t_main}, {"quotient", pk->t_quot}};
+        if (pk->n_lu) trees.push_back({"permutation", pk->t_perm});
+        for (size_t a = 0; a < n_airs; a++) {
+            if (pk->airs[a].t_cached) trees.push_back({"cached " + std::to_string(a), pk->airs[a].t_cached});
+            if (pk->airs[a].t_prep) trees.push_back({"preprocessed " + std::to_string(a), pk->airs[a].t_prep});
+        }
+        for (unsigned l = 0; l < pk->n_layers; l++) trees.push_back({"fri " + std::to_string(l), pk->t_fri[l]});
+        const size_t n_rep = trees.size() + pk->n_layers;
+        std::vector<uint32_t> rep(2 * n_rep);
+        for (size_t i = 0; i < n_rep; i++) rep[2 * i] = 0, rep[2 * i + 1] = 0xffffffffu;
+        uint32_t* d_rep = nullptr;
+        ZK_HIP_CHECK(ctx, hipMalloc(&d_rep, rep.size() * 4));
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_rep, rep.data(), rep.size() * 4, hipMemcpyHostToDevice, st));
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        for (size_t i = 0; i < trees.size(); i++) ZK_TRY(merkle_check_tree(ctx, trees[i].second, d_rep + 2 * i));
+        for (unsigned l = 0; l < pk->n_layers; l++) {
+            const size_t half = (size_t)1 << (hmax - l - 1);
+            hipLaunchKernelGGL(k_check_pairs, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, (const uint4*)pk->d_flayer[l], half,
+                               (const uint32_t*)pk->t_fri[l]->d_digests, d_rep + 2 * (trees.size() + l));
+        }
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(rep.data(), d_rep, rep.size() * 4, hipMemcpyDeviceToHost, st));
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        std::string bad;
+        for (size_t i = 0; i < trees.size(); i++)
+            if (rep[2 * i]) {   // the first differing node: what memory holds (read by a copy, not a kernel), what its children hash to, and a second look
+                const zkhip_tree* t = trees[i].second;
+                const unsigned l = rep[2 * i + 1] >> 24;
+                const size_t idx = rep[2 * i + 1] & 0xffffffu;
+                uint32_t node[8], kids[16], again[2] = {0, 0xffffffffu};
+                ZK_HIP_CHECK(ctx, hipMemcpy(node, t->d_digests + (t->layer_off[l] + idx) * 8, 32, hipMemcpyDeviceToHost));
+                ZK_HIP_CHECK(ctx, hipMemcpy(kids, t->d_digests + (t->layer_off[l - 1] + 2 * idx) * 8, 64, hipMemcpyDeviceToHost));
+                poseidon2_permute_host(kids);
+                char line[400];
+                std::snprintf(line, sizeof line, "[node read by copy %08x %08x %08x %08x %08x %08x %08x %08x | children hash to %08x %08x %08x %08x %08x %08x %08x %08x] ", node[0], node[1],
+                              node[2], node[3], node[4], node[5], node[6], node[7], kids[0], kids[1], kids[2], kids[3], kids[4], kids[5], kids[6], kids[7]);
+                bad += line;
+                {   // is it what the previous proof of this key left at that place?
+                    std::lock_guard<std::mutex> lk(g_shadow_mu);
+                    auto it = g_shadow.find(t);
+                    if (it != g_shadow.end() && it->second.size() >= (t->layer_off[l] + idx + 1) * 8)
+                        bad += memcmp(&it->second[(t->layer_off[l] + idx) * 8], node, 32) == 0 ? "[= the node the PREVIOUS proof had there] " : "[not the previous proof's node] ";
+                    else
+                        bad += "[no previous proof] ";
+                }
+                ZK_HIP_CHECK(ctx, hipMemcpy(d_rep, again, 8, hipMemcpyHostToDevice));
+                ZK_TRY(merkle_check_tree(ctx, t, d_rep));
+                ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));
+                ZK_HIP_CHECK(ctx, hipMemcpy(again, d_rep, 8, hipMemcpyDeviceToHost));
+                bad += "[a second check finds " + std::to_string(again[0]) + " differing nodes] ";
+            }
+        (void)hipFree(d_rep);
+        for (size_t i = 0; i < trees.size(); i++) {   // what this proof leaves, for the next one's diagnosis
+            const zkhip_tree* t = trees[i].second;
+            if (t->log_height > 16) continue;   // (the large trees' copies would take longer than the proof)
+            std::vector<uint32_t> copy(merkle_digest_count(t->log_height) * 8);
+            ZK_HIP_CHECK(ctx, hipMemcpy(copy.data(), t->d_digests, copy.size() * 4, hipMemcpyDeviceToHost));
+            std::lock_guard<std::mutex> lk(g_shadow_mu);
+            g_shadow[t].swap(copy);
+        }
+        for (size_t i = 0; i < n_rep; i++)
+            if (rep[2 * i]) {
+                const std::string name = i < trees.size() ? "tree " + trees[i].first + " (height 2^" + std::to_string(trees[i].second->log_height) + ")"
+                                                          : "leaves of fri " + std::to_string(i - trees.size());
+                bad += name + ": " + std::to_string(rep[2 * i]) + " nodes differ from the hash of their children, first layer " + std::to_string(rep[2 * i + 1] >> 24) +
+                       " index " + std::to_string(rep[2 * i + 1] & 0xffffffu) + "; ";
+            }
+        if (!bad.empty()) {
+            std::fprintf(stderr, "[zkhip self-check] %s\n", bad.c_str());
+            return set_error(ctx, ZKHIP_ERR_HIP, "self-check: " + bad);
+        }
+    }
     return ZKHIP_OK;
 }
 
@@ -2307,6 +2397,21 @@ int zkhip_proof_fetch(zkhip_ctx* ctx, const zkhip_pk* pk, uint8_t* out, size_t c
     ZK_HIP_CHECK(ctx, hipMemcpyAsync(&h, pk->d_tr, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (h.error) return set_error(ctx, ZKHIP_ERR_POW_FAILED, "proof-of-work search failed");
+    if (ctx->cfg.self_check) {   // diagnosis: the same bytes a second time
+        std::vector<uint8_t> again(bytes);
+        ZK_HIP_CHECK(ctx, hipMemcpyAsync(again.data(), pk->d_proof, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (memcmp(again.data(), out, bytes) != 0) {
+            size_t first = 0, n = 0;
+            for (size_t i = 0; i < bytes; i++)
+                if (again[i] != out[i]) {
+                    if (!n) first = i;
+                    n++;
+                }
+            std::fprintf(stderr, "[zkhip self-check] two copies of one proof differ in %zu bytes from byte %zu of %zu\n", n, first, bytes);
+            return set_error(ctx, ZKHIP_ERR_HIP, "self-check: two device-to-host copies of one proof differ");
+        }
+    }
     return ZKHIP_OK;
 }
 

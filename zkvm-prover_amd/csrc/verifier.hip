@@ -261,8 +261,13 @@ extern "C" int zkhip_proof_layout_of(const zkhip_params* prm, const zkhip_air* a
     return ZKHIP_OK;
 }
 
-extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, const uint32_t* const* pvs,
-                            const uint8_t* proof_bytes, size_t len) {
+// a rejection notes the line of this file that refused (zkhip_verify_where: which check a proof fails, for diagnosis)
+static inline int rejected(int* where, int line) {
+    if (where) *where = line;
+    return ZKHIP_ERR_VERIFY;
+}
+static int verify_where(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, const uint32_t* const* pvs,
+                        const uint8_t* proof_bytes, size_t len, int* where) {
     if (!prm || !airs || !proof_bytes || n_airs == 0 || (len & 3)) return ZKHIP_ERR_INVALID;
     const unsigned b = prm->log_blowup;
     const unsigned lfp = prm->log_final_poly_len;  // the fold loop stops at 2^(b+lfp) values: a polynomial of degree < 2^lfp
@@ -270,12 +275,12 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     if (prm->num_queries == 0 || prm->commit_pow_bits > 30 || prm->query_pow_bits > 30) return ZKHIP_ERR_INVALID;  // as zkhip_keygen
     const size_t n_fin = (size_t)1 << lfp;
     const size_t n_words = len / 4;
-    if (n_words < 4) return ZKHIP_ERR_VERIFY;
+    if (n_words < 4) return rejected(where, __LINE__);
     std::vector<uint32_t> pw(n_words);
     memcpy(pw.data(), proof_bytes, len);
     const uint32_t* proof = pw.data();
     for (size_t i = 0; i < n_words; i++)
-        if (proof[i] >= P) return ZKHIP_ERR_VERIFY;
+        if (proof[i] >= P) return rejected(where, __LINE__);
     std::vector<AirProgram> pg(n_airs);
     unsigned hmax = 0;
     size_t n_lu = 0, n_prep = 0, n_cached = 0;
@@ -328,10 +333,10 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     const unsigned n_layers = hmax - b - lfp;
     size_t r = 0;
     const size_t lu_words = n_lu ? 8 + 4 * n_lu : 0;
-    if (n_words < 4 + 16 + 8 * n_cached + lu_words + 4 * n_open + 9 * (size_t)n_layers + 4 * n_fin + 1) return ZKHIP_ERR_VERIFY;
+    if (n_words < 4 + 16 + 8 * n_cached + lu_words + 4 * n_open + 9 * (size_t)n_layers + 4 * n_fin + 1) return rejected(where, __LINE__);
     if (proof[0] != PROOF_MAGIC + (n_lu ? 1u : 0u) + (n_prep ? 2u : 0u) + (n_cached ? 4u : 0u) || proof[1] != n_airs || proof[2] != hmax ||
         proof[3] != n_layers)
-        return ZKHIP_ERR_VERIFY;
+        return rejected(where, __LINE__);
     r = 4;
     const uint32_t* root_main = proof + r;
     r += 8;
@@ -392,7 +397,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         }
         ch.observe_canon(root_perm, 8);
         ch.observe_canon(exposed_c, 4 * n_lu);
-        if (zkhip_logup_exposed_check(exposed_c, n_lu) != ZKHIP_OK) return ZKHIP_ERR_VERIFY;
+        if (zkhip_logup_exposed_check(exposed_c, n_lu) != ZKHIP_OK) return rejected(where, __LINE__);
     }
     const Ext alpha = ch.sample_ext();
     ch.observe_canon(root_quot, 8);
@@ -489,7 +494,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
             }
             rhs = ext_add(rhs, ext_mul(v, zps));
         }
-        if (!ext_eq(lhs, rhs)) return ZKHIP_ERR_VERIFY;
+        if (!ext_eq(lhs, rhs)) return rejected(where, __LINE__);
     }
 
     // ---- FRI transcript ----
@@ -498,11 +503,11 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
     for (unsigned l = 0; l < n_layers; l++) {
         ch.observe_canon(fri_hdr + 9 * l, 8);
         for (int k = 0; k < 8; k++) froots_m[8 * l + k] = to_monty(fri_hdr[9 * l + k]);
-        if (!ch.check_witness(prm->commit_pow_bits, fri_hdr[9 * l + 8])) return ZKHIP_ERR_VERIFY;
+        if (!ch.check_witness(prm->commit_pow_bits, fri_hdr[9 * l + 8])) return rejected(where, __LINE__);
         betas[l] = ch.sample_ext();
     }
     ch.observe_canon(fin_c, 4 * n_fin);
-    if (!ch.check_witness(prm->query_pow_bits, qpow)) return ZKHIP_ERR_VERIFY;
+    if (!ch.check_witness(prm->query_pow_bits, qpow)) return rejected(where, __LINE__);
     std::vector<Ext> fin(n_fin);
     for (size_t j = 0; j < n_fin; j++) fin[j] = ext_from_canon(fin_c + 4 * j);
 
@@ -550,10 +555,10 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         for (size_t bi = 0; bi < batches.size(); bi++) {
             const Batch& bt = batches[bi];
             const size_t n_op = bt.tw + 8 * (size_t)bt.bh;
-            if (r + n_op > n_words) return ZKHIP_ERR_VERIFY;
+            if (r + n_op > n_words) return rejected(where, __LINE__);
             rows_of[bi] = proof + r;
             r += n_op;
-            if (!verify_opening(bt.root_m, bt.lhs, bt.ws, idx >> (hmax - bt.bh), rows_of[bi])) return ZKHIP_ERR_VERIFY;
+            if (!verify_opening(bt.root_m, bt.lhs, bt.ws, idx >> (hmax - bt.bh), rows_of[bi])) return rejected(where, __LINE__);
         }
         std::fill(roq.begin(), roq.end(), ext_zero());
         std::fill(has.begin(), has.end(), 0);
@@ -593,7 +598,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
         for (unsigned l = 0; l < n_layers; l++) {
             const unsigned log_len = hmax - l;
             const size_t il = idx >> l, n_path = 8 * (size_t)(log_len - 1);
-            if (r + 4 + n_path > n_words) return ZKHIP_ERR_VERIFY;
+            if (r + 4 + n_path > n_words) return rejected(where, __LINE__);
             const uint32_t *sib = proof + r, *path = proof + r + 4;
             r += 4 + n_path;
             std::vector<uint32_t> opening(8 + n_path);
@@ -602,7 +607,7 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
                 opening[4 * ((il & 1) ^ 1) + k] = sib[k];
             }
             memcpy(opening.data() + 8, path, n_path * 4);
-            if (!verify_opening(&froots_m[8 * l], {log_len - 1}, {8}, il >> 1, opening.data())) return ZKHIP_ERR_VERIFY;
+            if (!verify_opening(&froots_m[8 * l], {log_len - 1}, {8}, il >> 1, opening.data())) return rejected(where, __LINE__);
             const Ext e0 = ext_from_canon(opening.data()), e1 = ext_from_canon(opening.data() + 4);
             eval = fold_row(il >> 1, log_len - 1, betas[l], e0, e1);
             if (has[log_len - 1]) eval = ext_add(eval, ext_mul(ext_mul(betas[l], betas[l]), roq[log_len - 1]));
@@ -613,8 +618,18 @@ extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size
             const uint32_t xf = mpow(two_adic_generator(b + lfp), bitrev32((uint32_t)(idx >> n_layers), b + lfp));
             for (size_t j = n_fin - 1; j-- > 0;) want = ext_add(ext_mul_base(want, xf), fin[j]);
         }
-        if (!ext_eq(eval, want)) return ZKHIP_ERR_VERIFY;
+        if (!ext_eq(eval, want)) return rejected(where, __LINE__);
     }
-    if (r != n_words) return ZKHIP_ERR_VERIFY;
+    if (r != n_words) return rejected(where, __LINE__);
     return ZKHIP_OK;
+}
+
+extern "C" int zkhip_verify(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, const uint32_t* const* pvs, const uint8_t* proof_bytes,
+                            size_t len) {
+    return verify_where(prm, airs, n_airs, pvs, proof_bytes, len, nullptr);
+}
+extern "C" int zkhip_verify_where(const zkhip_params* prm, const zkhip_air* airs, size_t n_airs, const uint32_t* const* pvs,
+                                  const uint8_t* proof_bytes, size_t len, int* where) {
+    if (where) *where = 0;
+    return verify_where(prm, airs, n_airs, pvs, proof_bytes, len, where);
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -99,6 +100,14 @@ int tracegen_finish(zkhip_ctx* ctx, void* flag, const std::string& what);
         if (_rc != ZKHIP_OK) return _rc; \
     } while (0)
 
+// kernel attributes are per DEVICE (hipFuncSetAttribute acts on the current one): set once per device, by whichever thread gets there first
+// (two threads racing set them twice, which is harmless; the bit is published after the calls)
+struct DeviceOnce {
+    std::atomic<uint64_t> done{0};
+    bool need(int device) const { return !((done.load(std::memory_order_acquire) >> (device & 63)) & 1); }
+    void mark(int device) { done.fetch_or(1ull << (device & 63), std::memory_order_release); }
+};
+
 // RAII-ish scope for per-kernel timing: records HIP events on the ctx stream when profiling is on
 struct KernelScope {
     zkhip_ctx* ctx;
@@ -161,6 +170,8 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready);
 // `last` writes the leaf digests, otherwise the state goes back to d_state
 int merkle_leaves_part(zkhip_ctx* ctx, zkhip_tree* t, size_t col_begin, size_t col_end, bool first, bool last, uint32_t* d_state);
 size_t merkle_digest_count(unsigned log_height);
+// diagnosis: recomputes every plain layer of the tree; d_report[0] += mismatching nodes, d_report[1] = min(layer << 24 | index)
+int merkle_check_tree(zkhip_ctx* ctx, const zkhip_tree* t, uint32_t* d_report);
 // gathers openings for n leaf indices (device array of u32 indices) into a device buffer (canonical)
 int merkle_open_device(zkhip_ctx* ctx, const zkhip_tree* tree, const uint32_t* d_indices, unsigned index_shift,
                        size_t n, uint32_t* d_out, size_t out_pitch_words);
