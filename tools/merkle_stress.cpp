@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
                 zkhip_tree* tree = nullptr;
                 uint32_t root[8];
                 if (zkhip_merkle_commit(ctx, &m, 1, &tree, root) != ZKHIP_OK) { std::fprintf(stderr, "commit: %s\n", zkhip_last_error(ctx)); exit(2); }
+                if (it == 0 && t == 0) std::printf("root of thread 0's tree: %08x %08x %08x %08x %08x %08x %08x %08x\n", root[0], root[1], root[2], root[3], root[4], root[5], root[6], root[7]);
                 for (unsigned l = 0; l <= my_lh; l++) {
                     auto& dst = it == 0 ? ref[l] : got[l];
                     dst.resize((size_t)8 << (my_lh - l));
