@@ -1,8 +1,12 @@
 # Runs the guest flow many times over (different lengths, both configurations, device lists) and counts what does not end with a verified
 # root: the greedy fold, three node pipelines and six internal workers are threads racing for proofs -- a rare ordering bug shows up here.
-# Usage: bash tools/flow_stress.sh [runs]   (writes gpurun_out/flow_stress.json)
+# Usage: bash tools/flow_stress.sh [runs] [frame]   (writes gpurun_out/flow_stress.json)
+# With a frame (e.g. 14: ~100 segment proofs per run) every run uses it, the host verifies every segment proof beside the proving
+# (ZKHIP_VERIFY_SEGMENTS=1: a failure names the segment and the verifier's check) and extra variables pass through FLOW_STRESS_ENV
+# (e.g. FLOW_STRESS_ENV=ZKHIP_SELF_CHECK=1) -- the form that found the stored tree node of DESIGN.md 15 (3 % of runs before the change).
 cd ${GRAFT_REPO_ROOT:-.}
 N=${1:-60}
+FRAME=${2:-}
 mkdir -p /tmp/fs gpurun_out
 python3 tools/make_guest_files.py /tmp/fs 300000 > /dev/null
 cp /tmp/fs/openvm.toml /tmp/fs_chunk.toml
@@ -12,7 +16,8 @@ for i in $(seq 1 $N); do
   python3 -c "import sys; open('/tmp/fs/stdin.bin','wb').write(($n).to_bytes(4,'little'))"
   cfg=-; [ $((i % 5)) = 0 ] && cfg=/tmp/fs_chunk.toml
   lf=17; [ $((i % 3)) = 0 ] && lf=14
-  env=""; [ $((i % 7)) = 0 ] && env="ZKHIP_DEVICES=0,0"
+  env="ZKHIP_X=1"; [ $((i % 7)) = 0 ] && env="ZKHIP_DEVICES=0,0"
+  if [ -n "$FRAME" ]; then lf=$FRAME; env="$env ZKHIP_VERIFY_SEGMENTS=1 $FLOW_STRESS_ENV"; fi
   out=/tmp/fs/o$i; mkdir -p $out
   if env $env timeout 300 ./zkvm-prover_amd/prove_cli prove-elf /tmp/fs/fib.elf /tmp/fs/stdin.bin $out $cfg $lf > $out/log.json 2> $out/err.txt \
      && ./zkvm-prover_amd/prove_cli verify-guest /tmp/fs/fib.elf $out/root.vk $([ $cfg = - ] && echo $out/openvm.toml || echo $cfg) $out/root.json > /dev/null 2>> $out/err.txt; then
