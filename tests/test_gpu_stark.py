@@ -120,7 +120,7 @@ def test_large_trace_verifies(zk):
     rc, at_root = z.verify_where(params, airs, [pv], bytes(bad))
     assert rc != 0 and at_root > 0
     late = bytearray(proof)
-    late[-5] ^= 1
+    late[-4] ^= 1
     rc, at_query = z.verify_where(params, airs, [pv], bytes(late))
     assert rc != 0 and at_query > at_root
 
