@@ -438,14 +438,17 @@ public:
     // root.  Per level two host threads: one runs the verifier circuit of the next node (witness, host cores), one generates its
     // traces on the device and proves it (the levels share the prover's context: device sections are serialised, while the segment
     // lanes keep proving on contexts of their own); every node proof is self-verified on a thread of its own.
-    class TreeStream {
+    // (a template over the prover, so that the scheduling -- threads, queues, the greedy fold -- runs under ThreadSanitizer against a prover
+    // that makes stub proofs: tests/tree_stream_tsan.cpp)
+    template <class Agg>
+    class TreeStreamT {
     public:
         // `greedy` (one key only): above the leaf nodes the tree has no fixed shape -- whenever `arity` ADJACENT node proofs exist (leaf or
         // internal, any mix) they are folded, leftmost first.  Every fold but the last takes a full set of children, so the number of
         // internal nodes is the balanced tree's; but when the nodes keep up with the segments the result is a comb -- root = (everything
         // before, the last two leaf nodes) -- and what is left once the last segment proof exists is ONE leaf node and the root instead of
         // one node per level; when they do not keep up, waiting proofs fold among themselves and the shape drifts to the balanced one.
-        explicit TreeStream(AggregationProver& agg, bool greedy = false) : agg_(agg), greedy_(greedy && agg.one_key()), fold_(agg.arity(1)) {
+        explicit TreeStreamT(Agg& agg, bool greedy = false) : agg_(agg), greedy_(greedy && agg.one_key()), fold_(agg.arity(1)) {
             layers_.emplace_back();
             start_level(0);
             if (greedy_) {
@@ -456,9 +459,9 @@ public:
                     for (size_t slot = 0; slot < agg_.n_slots(); slot++) start_pair_locked(level, slot);
             }
         }
-        TreeStream(const TreeStream&) = delete;
-        TreeStream& operator=(const TreeStream&) = delete;
-        ~TreeStream() {
+        TreeStreamT(const TreeStreamT&) = delete;
+        TreeStreamT& operator=(const TreeStreamT&) = delete;
+        ~TreeStreamT() {
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 stop_ = true;
@@ -549,7 +552,7 @@ public:
             std::deque<Task> tasks;                           // nodes of the level that consumes this layer, waiting for a free slot
             bool tasks_closed = false;
         };
-        AggregationProver& agg_;
+        Agg& agg_;
         const std::chrono::steady_clock::time_point t_made_ = std::chrono::steady_clock::now();
         std::mutex mu_;
         std::condition_variable cv_;
@@ -821,6 +824,7 @@ public:
             });
         }
     };
+    using TreeStream = TreeStreamT<AggregationProver>;
 
     // The whole tree of `plan` over the segment proofs; returns the root, `all` (optional) receives every level.
     // (`greedy`: TreeStream's fold without a fixed shape above the leaf nodes -- one key only; `all` then holds two layers)
