@@ -239,7 +239,7 @@ struct CoopMulti {
     uint64_t out_off[5];   // word offsets of the produced layers in the digest store
     uint32_t m;            // layers to produce (1..5)
 };
-__global__ __launch_bounds__(256) void k_compress_coop_multi(const uint32_t* __restrict__ prev, uint32_t* __restrict__ digests, size_t n_next, CoopMulti cm) {
+__global__ __launch_bounds__(256) void k_compress_coop_multi(const uint32_t* prev, uint32_t* digests, size_t n_next, CoopMulti cm) {   // (prev points into digests: no __restrict__)
     __shared__ uint32_t buf[2][16 * 8];
     const unsigned lane = threadIdx.x & 15u, row = threadIdx.x >> 4;
     const size_t i = (size_t)blockIdx.x * 16 + row;
