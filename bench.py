@@ -449,8 +449,7 @@ def main():
                     # share x 4.2 + the rest x 2.2 cycles, costs measured by tools/ubench_valu.hip) / (1024 SIMDs x 2.4 GHz), against
                     # THIS run's HIP-event time per launch -- no rate of the kernel itself enters the floor
                     try:
-                        with open(os.path.join(ROOT, "profiles", "round04_pmc_valu.json")) as f:
-                            pv3 = json.load(f)
+                        pv_name, pv3, pv_stale, pv_note = valu_counts()
                         kv = pv3["kernels"]["zk::k_hash_rows"]
                         if log_n == 22 and width == 300:
                             ms_launch = per_step_ms / (launches / steps_profiled)
@@ -463,9 +462,12 @@ def main():
                                 "frac_of_valu_peak": round(kv["valu_roofline_ms_per_launch"] / ms_launch, 4),
                                 "clock_ghz_under_pmc": kv.get("clock_ghz_from_grbm_gui_active"),
                                 "issue_efficiency_at_measured_clock_under_pmc": kv.get("issue_efficiency_at_measured_clock"),
-                                "source": "profiles/round04_pmc_valu.json + profiles/round03_isa_mix_hash_rows.json (the kernel's code did not change)"})
-                    except Exception:
-                        pass
+                                "stale": pv_stale, "code_check": pv_note,
+                                "source": "profiles/%s (instruction counts and ISA mix of the body whose hash is checked above)" % pv_name})
+                            if pv_stale:   # the counts describe another body of the kernel: no fraction from them
+                                roof["valu"].pop("frac_of_valu_peak", None)
+                    except Exception as e:
+                        roof["valu"]["counts_note"] = "failed: %r" % (e,)
         # the memory-side kernels against the same HBM peak (algorithmic bytes / measured time)
         others = {}
         cols_all = width + 2 + 16  # trace columns + quotient-chunk columns that go through the LDE
@@ -485,23 +487,24 @@ def main():
         # the cycles per instruction of the row-hash kernel's ISA mix on 1024 SIMDs at 2.4 GHz, against the measured time per proof
         valu_roof = None
         if log_n == 22 and width == 300:
-            pmc_file = next((f for f in ("round04_pmc_valu.json", "round03_pmc_valu.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
-            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
-                pv = json.load(f)
-            # the totals from the per-kernel entries (round 3's file has no summed keys and the block came out null on the driver's line)
-            kern = pv["kernels"]
-            total_instr = pv.get("total_valu_wave_instr_per_proof") or sum(k["launches_per_proof"] * k["valu_wave_instr_per_launch"] for k in kern.values())
-            cpi = kern["zk::k_hash_rows"]["isa_mix"]["cycles_per_wave_instruction_model"]
-            floor_ms = pv.get("total_valu_roofline_ms_per_proof") or total_instr * cpi / (pv["peak"]["simds"] * pv["peak"]["clock_hz"]) * 1e3
-            ms = dt / args.steps * 1e3  # every rank proves `steps` proofs in dt
-            valu_roof = {"valu_wave_instr_per_proof": int(total_instr), "cycles_per_wave_instr_model": cpi,
-                         "floor_ms_per_proof": round(floor_ms, 2),
-                         "ms_per_proof_per_gpu": round(ms, 2),
-                         "frac": round(floor_ms / ms, 3),
-                         "hash_rows_share_of_valu_instr": round(2 * kern["zk::k_hash_rows"]["valu_wave_instr_per_launch"] / total_instr, 3),
-                         "note": "profiles/%s: SQ_INSTS_VALU summed over the kernels of one proof x the model cycles per wave-instruction "
-                                 "of the row-hash kernel's ISA mix / (1024 SIMDs x 2.4 GHz)" % pmc_file}
-            assert valu_roof["frac"] > 0, "the whole-proof VALU roofline of the headline configuration must not be empty"
+            try:   # a reported extra after the timed region: a missing or stale committed profile must not lose the headline line
+                pmc_file, pv, pv_stale, pv_note = valu_counts()
+                # the totals from the per-kernel entries (round 3's file has no summed keys and the block came out null on the driver's line)
+                kern = pv["kernels"]
+                total_instr = pv.get("total_valu_wave_instr_per_proof") or sum(k["launches_per_proof"] * k["valu_wave_instr_per_launch"] for k in kern.values())
+                cpi = kern["zk::k_hash_rows"]["isa_mix"]["cycles_per_wave_instruction_model"]
+                floor_ms = pv.get("total_valu_roofline_ms_per_proof") or total_instr * cpi / (pv["peak"]["simds"] * pv["peak"]["clock_hz"]) * 1e3
+                ms = dt / args.steps * 1e3  # every rank proves `steps` proofs in dt
+                valu_roof = {"valu_wave_instr_per_proof": int(total_instr), "cycles_per_wave_instr_model": cpi,
+                             "floor_ms_per_proof": round(floor_ms, 2),
+                             "ms_per_proof_per_gpu": round(ms, 2),
+                             "frac": None if pv_stale else round(floor_ms / ms, 3),
+                             "stale": pv_stale, "code_check": pv_note,
+                             "hash_rows_share_of_valu_instr": round(2 * kern["zk::k_hash_rows"]["valu_wave_instr_per_launch"] / total_instr, 3),
+                             "note": "profiles/%s: SQ_INSTS_VALU summed over the kernels of one proof x the model cycles per wave-instruction "
+                                     "of the row-hash kernel's ISA mix / (1024 SIMDs x 2.4 GHz)" % pmc_file}
+            except Exception as e:
+                valu_roof = {"frac": None, "note": "failed: %r" % (e,)}
         # whole-proof HBM roofline (SURVEY.md 8(d) cfg #4: unfused per-stage algorithmic bytes of one proof): the LDE reads
         # the trace and writes the codeword, the row hash and the constraint kernel each read the codeword once, the
         # quotient is written once, the fold loop moves ~2 x 2 x M ext elements.  The proof is integer-VALU bound, so
@@ -567,7 +570,7 @@ def main():
                                     "root_ms": round((t_d - t_c) * 1e3, 1), "root_ms_first": round((t_c - t_b) * 1e3, 1),
                                     "setup_s": round(t_b - t_a, 2), "circuit_build_s": round(agg.build_s, 2), "keygen_s": round(agg.keygen_s, 2),
                                     "leaf_circuit": {"gate_rows": agg.leaf.n_gates, "permutations": agg.leaf.n_perms, "log_heights": agg.leaf.log_heights()[:2]},
-                                    "root_proof_bytes": len(root), "root_verified_under_one_key": True, "deterministic": root == root2,
+                                    "root_proof_bytes": len(root), "root_verified_under_one_key": bool(agg.verify_root(root, rpv)), "deterministic": root == root2,
                                     "note": "witness generation on the host + device traces + proof, per node; every rank proves the same synthetic instance"}
             except Exception as e:  # a reported extra, never a gate
                 out["aggregate"] = {"root_ms": None, "note": "failed: %r" % (e,)}
@@ -591,6 +594,33 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+
+def valu_counts():
+    """The committed VALU counter pass (profiles/roundNN_pmc_valu.json, newest first) and whether it still describes the code that runs:
+    (file name, parsed file, stale flag, note).  The counts belong to ONE compiled body of zk::k_hash_rows; the pass stores that body's
+    sha256 (tools/code_object_hash.py) and this recomputes it from the libzkhip.so that is loaded -- a kernel edited since the pass makes
+    every figure derived from the file stale.  stale is None when the file carries no hash."""
+    name = next((f for f in ("round05_pmc_valu.json", "round04_pmc_valu.json", "round03_pmc_valu.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+    if name is None:
+        return None, None, None, "no profiles/round*_pmc_valu.json"
+    with open(os.path.join(ROOT, "profiles", name)) as f:
+        pv = json.load(f)
+    want = pv.get("kernels", {}).get("zk::k_hash_rows", {}).get("code_sha256")
+    if not want:
+        return name, pv, None, "profiles/%s carries no code hash: unchecked" % name
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import code_object_hash
+
+    so = os.environ.get("ZKHIP_LIBRARY_FOR_HASH") or os.path.join(ROOT, "zkvm-prover_amd", "libzkhip.so")
+    try:
+        have, _ = code_object_hash.kernel_code_sha256(so, code_object_hash.HASH_ROWS)
+    except Exception as e:
+        return name, pv, True, "cannot hash zk::k_hash_rows in %s: %r" % (so, e)
+    if have != want:
+        return name, pv, True, "zk::k_hash_rows in the loaded library (sha256 %s...) is not the body profiles/%s was counted on (%s...)" % (have[:12], name, want[:12])
+    return name, pv, False, "zk::k_hash_rows code sha256 %s... == profiles/%s" % (have[:12], name)
 
 
 def plumbing_run(args, world, rank):

@@ -918,6 +918,10 @@ typedef struct {
     /* diagnosis: after every proof the prover recomputes every plain layer of the proof's Merkle trees (and the FRI leaves) on the device
      * and fetches the proof twice; what differs is reported on stderr and the proof fails with ZKHIP_ERR_HIP [ZKHIP_SELF_CHECK=1] */
     int self_check;
+    /* TEST ONLY: the round-4 bodies of the two fused tree kernels ("store a layer's word, then compute on"), the form under which the guest
+     * flow stored a wrong tree node in ~3 % of runs -- kept for the A/B of docs/stale_node.md and the test that must go red on it
+     * [ZKHIP_TREE_STORE_EARLY=1] */
+    int tree_store_early;
 } zkhip_config;
 /* While `on`, the trace generators treat the shared lookup-count tables handed to them (the 8-bit bitwise table, the range-tuple table, the
  * range table) as canonical counts and leave them canonical -- none converts a table from Montgomery form and back around its increments.
@@ -930,7 +934,9 @@ int zkhip_jit_prewarm(const zkhip_air *airs, size_t n_airs, unsigned log_blowup,
 /* the built-in defaults with the environment's overrides applied */
 void zkhip_config_default(zkhip_config *out);
 /* a context's configuration (set at zkhip_ctx_create from zkhip_config_default); the witness fields are process-wide:
- * zkhip_set_process_config stores them (and the rest as the default of contexts created later) */
+ * zkhip_set_process_config stores them (and the rest as the default of contexts created later).  zkhip_ctx_set_config applies every
+ * field or refuses the call (ZKHIP_ERR_INVALID: jit 0..2, coop_* <= 27, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8,
+ * commit_parts <= 8, side_cus < the device's CUs); a changed side_cus re-partitions as zkhip_set_cu_partition does. */
 int zkhip_ctx_get_config(zkhip_ctx *ctx, zkhip_config *out);
 int zkhip_ctx_set_config(zkhip_ctx *ctx, const zkhip_config *cfg);
 int zkhip_set_process_config(const zkhip_config *cfg);

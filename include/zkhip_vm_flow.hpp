@@ -154,7 +154,16 @@ public:
         check(zkhip_zero(ctx_, T(vmc::A_BITWISE), (2u << 16) * 4)), check(zkhip_zero(ctx_, T(vmc::A_RANGE_TUPLE), (1u << 19) * 4));
         uint32_t *d_bw = T(vmc::A_BITWISE), *d_tup = T(vmc::A_RANGE_TUPLE), *d_rng = T(vmc::A_RANGE);
         // (the three count tables stay canonical until every chip has counted: one conversion each at the end instead of two per generator)
+        // (switched back when this scope is left, also by a throwing check(): a context left in canonical mode would hand non-Montgomery
+        // count tables to any later standalone generator call -- ADVICE round 4)
+        struct CanonicalTables {
+            zkhip_ctx* ctx;
+            explicit CanonicalTables(zkhip_ctx* c) : ctx(c) {}
+            ~CanonicalTables() { if (ctx) (void)zkhip_tables_canonical(ctx, 0); }
+            int release() { zkhip_ctx* c = ctx; ctx = nullptr; return zkhip_tables_canonical(c, 0); }
+        };
         check(zkhip_tables_canonical(ctx_, 1));
+        CanonicalTables canonical_guard(ctx_);
         // ---- program frequencies, frame
         const uint32_t* d_idx = up(c.pc_index);
         check(zkhip_program_freq_tracegen(ctx_, d_idx, c.pc_index.size(), H(vmc::A_PROGRAM), T(vmc::A_PROGRAM)));
@@ -308,7 +317,7 @@ public:
                 check(zkhip_bitwise_lookup_tracegen(ctx_, d_x, d_y, d_zeros_, bw_x.size(), 8, d_bw, 1));
             }
         }
-        check(zkhip_tables_canonical(ctx_, 0));
+        check(canonical_guard.release());
         check(zkhip_to_monty(ctx_, d_bw, (size_t)2 << 16)), check(zkhip_to_monty(ctx_, d_tup, (size_t)1 << 19)), check(zkhip_to_monty(ctx_, d_rng, N(vmc::A_RANGE)));
         check(zkhip_tracegen_check(ctx_));
         const auto t1 = clk::now();

@@ -194,6 +194,7 @@ pub struct zkhip_config {
     pub pin_witness: c_int,
     pub parallel_queries: c_int,
     pub self_check: c_int,
+    pub tree_store_early: c_int,
 }
 
 #[repr(C)]

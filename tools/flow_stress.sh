@@ -24,7 +24,8 @@ for i in $(seq 1 $N); do
     ok=$((ok+1))
   else
     bad=$((bad+1)); echo "run $i (n=$n cfg=$cfg lf=$lf $env) FAILED: $(tail -c 300 $out/err.txt)"
+    cp $out/err.txt gpurun_out/flow_stress_${FLOW_STRESS_TAG:-run}_fail_$i.txt   # (the self-check's whole diagnosis)
   fi
   rm -rf $out
 done
-echo "{\"runs\": $N, \"verified\": $ok, \"failed\": $bad, \"seconds\": $(( $(date +%s) - t0 ))}" | tee gpurun_out/flow_stress.json
+echo "{\"runs\": $N, \"verified\": $ok, \"failed\": $bad, \"seconds\": $(( $(date +%s) - t0 )), \"frame\": \"$FRAME\", \"env\": \"$FLOW_STRESS_ENV\"}" | tee gpurun_out/flow_stress${FLOW_STRESS_TAG:+_$FLOW_STRESS_TAG}.json

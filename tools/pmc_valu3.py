@@ -70,6 +70,16 @@ def main():
             e["valu_roofline_frac_under_pmc"] = round(floor_ms / e["ms_per_launch_under_pmc"], 4)
             if "measured_cycles_per_wave_instr_per_simd" in e:
                 e["issue_efficiency_at_measured_clock"] = round(m["cycles_per_wave_instruction_model"] / e["measured_cycles_per_wave_instr_per_simd"], 4)
+        if mangled:
+            # which compiled body these counts belong to: bench.py recomputes the hash from the library it loads (tools/code_object_hash.py)
+            try:
+                sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+                import code_object_hash
+                e["code_sha256"], e["code_bytes"] = code_object_hash.kernel_code_sha256(
+                    os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "zkvm-prover_amd", "libzkhip.so"), mangled)
+            except Exception as ex:   # (the counts are still worth keeping)
+                e["code_sha256"] = None
+                e["code_sha256_note"] = repr(ex)
         kernels[k] = e
     # the whole proof against the same absolute floor: every kernel's VALU wave-instructions priced at the row hash's model cycles
     total_instr = sum(e["launches_per_proof"] * e["valu_wave_instr_per_launch"] for e in kernels.values())

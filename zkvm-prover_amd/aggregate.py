@@ -93,6 +93,11 @@ class TreeAggregator:
             raise z.ZkhipError("aggregation: " + self.internal.last_error())
         return self._prove(self.internal, self.internal_pk, npv), npv
 
+    def verify_root(self, root, rpv):
+        """True iff `root` verifies under the aggregation key and states this key's two commitments (what aggregate() insists on)."""
+        return (z.verify(self.node_params, self.root_vk(), [NOPV, NOPV, rpv], root) == 0 and rpv[-16:-8].tolist() == self.leaf_commit.tolist()
+                and rpv[-8:].tolist() == self.internal_commit.tolist())
+
     def aggregate(self, proofs, pvs):
         """proofs: list of proof bytes of the app; pvs[i][a]: public values of AIR a of proof i.  Returns (root proof, root public values, levels)."""
         (root, rpv), levels = fold_tree(list(zip(proofs, pvs)), self.prove_leaf, self.prove_internal)

@@ -323,6 +323,59 @@ __global__ __launch_bounds__(1024) void k_compress_top(uint32_t* __restrict__ di
     }
 }
 
+// The round-4 bodies of the two fused kernels ("store a layer's word, then compute on"), kept behind zkhip_config.tree_store_early for the
+// A/B of the stale node (docs/stale_node.md): TEST ONLY -- the form that stored a wrong node in ~3 % of guest-flow runs.
+__global__ __launch_bounds__(256) void k_compress_coop_multi_early(const uint32_t* __restrict__ prev, uint32_t* __restrict__ digests, size_t n_next, CoopMulti cm) {
+    __shared__ uint32_t buf[2][16 * 8];
+    const unsigned lane = threadIdx.x & 15u, row = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + row;
+    const size_t ii = i < n_next ? i : 0;
+    const CoopConsts cc = coop_load_consts(lane);
+    uint32_t x = coop_permute_regs(prev[ii * 16 + lane], lane, cc);
+    if (lane < 8) {
+        if (i < n_next) digests[cm.out_off[0] + i * 8 + lane] = x;
+        buf[0][row * 8 + lane] = x;
+    }
+    unsigned cur = 0, rows = 16;
+    for (uint32_t j = 1; j < cm.m; j++) {
+        __syncthreads();
+        rows >>= 1;
+        const unsigned r = row < rows ? row : 0;
+        x = coop_permute_regs(buf[cur][16 * r + lane], lane, cc);
+        const size_t o = ((size_t)blockIdx.x * 16 >> j) + row;
+        if (row < rows && lane < 8) {
+            if (o < (n_next >> j)) digests[cm.out_off[j] + o * 8 + lane] = x;
+            buf[cur ^ 1][row * 8 + lane] = x;
+        }
+        cur ^= 1;
+    }
+}
+__global__ __launch_bounds__(1024) void k_compress_top_early(uint32_t* __restrict__ digests, unsigned lh, unsigned l0) {
+    __shared__ uint32_t buf[2][512 * 8];
+    const unsigned tid = threadIdx.x, lane = tid & 15u, grp = tid >> 4;  // 64 groups
+    auto layer_off = [&](unsigned l) -> size_t { return ((size_t)2 << lh) - ((size_t)2 << (lh - l)); };
+    unsigned n = 1u << (lh - l0);
+    const CoopConsts cc = coop_load_consts(lane);
+    for (unsigned e = tid; e < n * 8; e += 1024) buf[0][e] = digests[layer_off(l0) * 8 + e];
+    __syncthreads();
+    unsigned cur = 0;
+    for (unsigned l = l0 + 1; l <= lh; l++) {
+        const unsigned n_next = 1u << (lh - l);
+        uint32_t* out = digests + layer_off(l) * 8;
+        for (unsigned i = grp; i < ((n_next + 63u) & ~63u); i += 64) {
+            const unsigned ii = i < n_next ? i : 0;
+            uint32_t x = buf[cur][16 * ii + lane];
+            x = coop_permute_regs(x, lane, cc);
+            if (i < n_next && lane < 8) {
+                buf[cur ^ 1][8 * i + lane] = x;
+                out[8 * i + lane] = x;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // Diagnosis (zkhip_config.self_check): every node of a plain layer against the compression of its children, one lane per node, through the
 // plain (non-cooperative) permutation.  report[0] = mismatching nodes, report[1] = the smallest (layer << 24 | index) among them.
 __global__ __launch_bounds__(256) void k_check_layer(const uint32_t* __restrict__ prev, const uint32_t* __restrict__ next, size_t n_next, uint32_t layer,
@@ -508,7 +561,8 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
         if (cnt <= ((size_t)1 << std::min(ctx->cfg.top_max_log, 8u)) && level < clean_top) {
             // this and all remaining levels in one launch
             KernelScope ks(ctx, "poseidon2_compress_top");
-            hipLaunchKernelGGL(k_compress_top, dim3(1), dim3(1024), 0, ctx->stream, t->d_digests, lh, l - 1);
+            if (ctx->cfg.tree_store_early) hipLaunchKernelGGL(k_compress_top_early, dim3(1), dim3(1024), 0, ctx->stream, t->d_digests, lh, l - 1);
+            else hipLaunchKernelGGL(k_compress_top, dim3(1), dim3(1024), 0, ctx->stream, t->d_digests, lh, l - 1);
             break;
         }
         KernelScope ks(ctx, "poseidon2_compress_layer");
@@ -528,7 +582,10 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
             }
             if (m >= 2) {
                 cm.m = m;
-                hipLaunchKernelGGL(k_compress_coop_multi, dim3((unsigned)(cnt / 16)), dim3(256), 0, ctx->stream, t->d_digests + t->layer_off[l - 1] * 8, t->d_digests, cnt, cm);
+                if (ctx->cfg.tree_store_early)
+                    hipLaunchKernelGGL(k_compress_coop_multi_early, dim3((unsigned)(cnt / 16)), dim3(256), 0, ctx->stream, t->d_digests + t->layer_off[l - 1] * 8, t->d_digests, cnt, cm);
+                else
+                    hipLaunchKernelGGL(k_compress_coop_multi, dim3((unsigned)(cnt / 16)), dim3(256), 0, ctx->stream, t->d_digests + t->layer_off[l - 1] * 8, t->d_digests, cnt, cm);
                 l += m - 1;
                 continue;
             }

@@ -2266,38 +2266,80 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));
         std::string bad;
         for (size_t i = 0; i < trees.size(); i++)
-            if (rep[2 * i]) {   // the first differing node: what memory holds (read by a copy, not a kernel), what its children hash to, and a second look
+            if (rep[2 * i]) {
+                // every differing node of the tree (first 8): what memory holds (read by copies, not kernels), what its stored children hash
+                // to, what the PREVIOUS proof of this key left in the node's place, and where else either value lies -- a lost store leaves
+                // the previous proof's node, a misdirected store puts the right node somewhere else, a foreign write leaves neither
                 const zkhip_tree* t = trees[i].second;
-                const unsigned l = rep[2 * i + 1] >> 24;
-                const size_t idx = rep[2 * i + 1] & 0xffffffu;
-                uint32_t node[8], kids[16], again[2] = {0, 0xffffffffu};
-                ZK_HIP_CHECK(ctx, hipMemcpy(node, t->d_digests + (t->layer_off[l] + idx) * 8, 32, hipMemcpyDeviceToHost));
-                ZK_HIP_CHECK(ctx, hipMemcpy(kids, t->d_digests + (t->layer_off[l - 1] + 2 * idx) * 8, 64, hipMemcpyDeviceToHost));
-                poseidon2_permute_host(kids);
-                char line[400];
-                std::snprintf(line, sizeof line, "[node read by copy %08x %08x %08x %08x %08x %08x %08x %08x | children hash to %08x %08x %08x %08x %08x %08x %08x %08x] ", node[0], node[1],
-                              node[2], node[3], node[4], node[5], node[6], node[7], kids[0], kids[1], kids[2], kids[3], kids[4], kids[5], kids[6], kids[7]);
-                bad += line;
-                {   // is it what the previous proof of this key left at that place?
+                const unsigned lh = t->log_height;
+                std::vector<uint32_t> all(merkle_digest_count(lh) * 8);
+                ZK_HIP_CHECK(ctx, hipMemcpy(all.data(), t->d_digests, all.size() * 4, hipMemcpyDeviceToHost));
+                std::vector<uint32_t> shadow;
+                size_t shadow_first = 0;   // (first node of the shadow copy)
+                {
                     std::lock_guard<std::mutex> lk(g_shadow_mu);
                     auto it = g_shadow.find(t);
-                    if (it != g_shadow.end() && it->second.size() >= (t->layer_off[l] + idx + 1) * 8)
-                        bad += memcmp(&it->second[(t->layer_off[l] + idx) * 8], node, 32) == 0 ? "[= the node the PREVIOUS proof had there] " : "[not the previous proof's node] ";
-                    else
-                        bad += "[no previous proof] ";
+                    if (it != g_shadow.end()) shadow = it->second, shadow_first = merkle_digest_count(lh) - shadow.size() / 8;
                 }
+                auto words = [](const uint32_t* w) {
+                    char b[80];
+                    std::snprintf(b, sizeof b, "%08x %08x %08x %08x %08x %08x %08x %08x", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+                    return std::string(b);
+                };
+                auto where = [&](size_t node) {   // node number -> "layer l index i"
+                    unsigned l = 0;
+                    while (l < lh && node >= t->layer_off[l + 1]) l++;
+                    return "layer " + std::to_string(l) + " index " + std::to_string(node - t->layer_off[l]);
+                };
+                auto find_in = [&](const std::vector<uint32_t>& hay, size_t first_node, const uint32_t* w, size_t skip_node) {
+                    std::string r;
+                    for (size_t n = 0; n * 8 + 8 <= hay.size(); n++)
+                        if (n + first_node != skip_node && memcmp(&hay[n * 8], w, 32) == 0) r += (r.empty() ? "" : ", ") + where(n + first_node);
+                    return r.empty() ? std::string("nowhere") : r;
+                };
+                unsigned shown = 0;
+                for (unsigned l = 1; l <= lh && shown < 8; l++) {
+                    const unsigned level = lh - l;
+                    if (level < t->level_cnt.size() && t->level_cnt[level]) continue;
+                    for (size_t idx = 0; idx < ((size_t)1 << level) && shown < 8; idx++) {
+                        uint32_t kids[16];
+                        memcpy(kids, &all[(t->layer_off[l - 1] + 2 * idx) * 8], 64);
+                        poseidon2_permute_host(kids);
+                        const size_t node = t->layer_off[l] + idx;
+                        const uint32_t* stored = &all[node * 8];
+                        if (memcmp(kids, stored, 32) == 0) continue;
+                        shown++;
+                        unsigned diff_mask = 0;
+                        for (int q = 0; q < 8; q++) diff_mask |= (stored[q] != kids[q]) << q;
+                        char head[200];
+                        std::snprintf(head, sizeof head, "{node layer %u index %zu (byte offset 0x%zx in the store, device address %p) words differing: 0x%02x; ", l, idx, node * 32,
+                                      (const void*)(t->d_digests + node * 8), diff_mask);
+                        bad += head;
+                        bad += "stored [" + words(stored) + "]; children hash to [" + words(kids) + "]; ";
+                        if (!shadow.empty() && node >= shadow_first) {
+                            const uint32_t* prevw = &shadow[(node - shadow_first) * 8];
+                            bad += "previous proof had [" + words(prevw) + "] there: " + (memcmp(prevw, stored, 32) == 0 ? "THE SAME (a store that did not land)" : "different") + "; ";
+                            bad += "the stored value lies in the previous proof's store at: " + find_in(shadow, shadow_first, stored, (size_t)-1) + "; ";
+                        } else {
+                            bad += "no copy of the previous proof's node; ";
+                        }
+                        bad += "the stored value lies elsewhere in this store at: " + find_in(all, 0, stored, node) + "; the right value lies elsewhere at: " + find_in(all, 0, kids, node) + "} ";
+                    }
+                }
+                uint32_t again[2] = {0, 0xffffffffu};
                 ZK_HIP_CHECK(ctx, hipMemcpy(d_rep, again, 8, hipMemcpyHostToDevice));
                 ZK_TRY(merkle_check_tree(ctx, t, d_rep));
                 ZK_HIP_CHECK(ctx, hipStreamSynchronize(st));
                 ZK_HIP_CHECK(ctx, hipMemcpy(again, d_rep, 8, hipMemcpyDeviceToHost));
-                bad += "[a second check finds " + std::to_string(again[0]) + " differing nodes] ";
+                bad += "[the host finds " + std::to_string(shown) + " differing nodes in the copy; a second device check finds " + std::to_string(again[0]) + "] ";
             }
         (void)hipFree(d_rep);
         for (size_t i = 0; i < trees.size(); i++) {   // what this proof leaves, for the next one's diagnosis
             const zkhip_tree* t = trees[i].second;
-            if (t->log_height > 16) continue;   // (the large trees' copies would take longer than the proof)
-            std::vector<uint32_t> copy(merkle_digest_count(t->log_height) * 8);
-            ZK_HIP_CHECK(ctx, hipMemcpy(copy.data(), t->d_digests, copy.size() * 4, hipMemcpyDeviceToHost));
+            // (the tail of the store: the layers of <= 2^13 nodes -- all the fused kernels' layers; a large tree's whole store would take longer than the proof)
+            const size_t total = merkle_digest_count(t->log_height), keep = std::min(total, ((size_t)2 << 13) - 1);
+            std::vector<uint32_t> copy(keep * 8);
+            ZK_HIP_CHECK(ctx, hipMemcpy(copy.data(), t->d_digests + (total - keep) * 8, copy.size() * 4, hipMemcpyDeviceToHost));
             std::lock_guard<std::mutex> lk(g_shadow_mu);
             g_shadow[t].swap(copy);
         }

@@ -593,6 +593,15 @@ inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vec
     }
     // process-wide cache of compiled code objects keyed by the generated source: several contexts
     // (one per HIP stream) and repeated keygens of the same AIR share one hipRTC compile
+    // what else decides the code object, as the source's first line: the caches (this process's map, the files of jit_cache_dir) compare
+    // the whole text, so a cache filled under another optimisation level, architecture or hipRTC is never loaded
+    static const char* opt_level = getenv("ZKHIP_JIT_OPT") ? getenv("ZKHIP_JIT_OPT") : "-O3";   // (experiments: compile time against kernel time)
+    static const std::string key_line = [] {
+        int major = 0, minor = 0;
+        (void)hiprtcVersion(&major, &minor);
+        return "// zkhip quot_jit: --offload-arch=gfx950 " + std::string(opt_level) + " -ffp-contract=off, hipRTC " + std::to_string(major) + "." + std::to_string(minor) + "\n";
+    }();
+    src = key_line + src;
     static std::mutex cache_mu;
     static std::map<std::string, std::vector<char>> cache;
     std::vector<char> code;
@@ -639,7 +648,6 @@ inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vec
             *msg = "hiprtcCreateProgram failed";
             return false;
         }
-        static const char* opt_level = getenv("ZKHIP_JIT_OPT") ? getenv("ZKHIP_JIT_OPT") : "-O3";   // (experiments: compile time against kernel time)
         const char* opts[] = {"--offload-arch=gfx950", opt_level, "-ffp-contract=off"};
         hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
         if (rc != HIPRTC_SUCCESS) {

@@ -70,7 +70,7 @@ struct zkhip_ctx {
 namespace zk {
 
 int set_error(zkhip_ctx* ctx, int code, const std::string& msg);
-const zkhip_config& process_config();   // what contexts start from, and what the context-less entry points (the circuit's witness) use
+zkhip_config process_config();   // what contexts start from, and what the context-less entry points (the circuit's witness) use
 int ensure_twiddles(zkhip_ctx* ctx, unsigned log_n);
 int get_scratch(zkhip_ctx* ctx, int slot, size_t bytes, void** out);
 void profile_begin(zkhip_ctx* ctx, const char* name);
