@@ -372,6 +372,13 @@ typedef struct zkhip_tree zkhip_tree;
  * HOST buffer of 8 canonical words (synchronises); pass NULL to stay asynchronous. */
 int zkhip_merkle_commit(zkhip_ctx *ctx, const zkhip_matrix *mats, size_t n_mats,
                         zkhip_tree **tree, uint32_t *root_out);
+/* Rebuilds a committed tree in place from its matrices' current contents: the commit's launches on the same digest store; no allocation,
+ * asynchronous on the context's stream.  (What a prover does proof after proof on its key's workspace; tools/merkle_stress.cpp.) */
+int zkhip_merkle_rebuild(zkhip_ctx *ctx, zkhip_tree *tree);
+/* Diagnosis: every plain layer (no injected matrices) against the compression of its stored children, recomputed on the device through
+ * the plain one-lane-per-node permutation.  *n_bad = differing nodes, *first (may be NULL) = layer << 24 | index of the first one.
+ * Synchronises.  The check zkhip_config.self_check runs after every proof. */
+int zkhip_tree_check(zkhip_ctx *ctx, const zkhip_tree *tree, uint32_t *n_bad, uint32_t *first);
 /* device pointer to the Montgomery root digest (8 words) */
 const uint32_t *zkhip_tree_root_device(const zkhip_tree *tree);
 unsigned zkhip_tree_log_height(const zkhip_tree *tree);

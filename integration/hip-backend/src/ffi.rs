@@ -301,6 +301,8 @@ extern "C" {
     pub fn zkhip_tree_root_device(tree: *const zkhip_tree) -> *const u32;
     pub fn zkhip_tree_log_height(tree: *const zkhip_tree) -> c_uint;
     pub fn zkhip_tree_layer(ctx: *mut zkhip_ctx, tree: *const zkhip_tree, layer: c_uint, out: *mut u32) -> c_int;
+    pub fn zkhip_merkle_rebuild(ctx: *mut zkhip_ctx, tree: *mut zkhip_tree) -> c_int;
+    pub fn zkhip_tree_check(ctx: *mut zkhip_ctx, tree: *const zkhip_tree, n_bad: *mut u32, first: *mut u32) -> c_int;
     pub fn zkhip_merkle_opening_words(tree: *const zkhip_tree) -> usize;
     pub fn zkhip_merkle_open(ctx: *mut zkhip_ctx, tree: *const zkhip_tree, indices: *const u64, n: usize, out: *mut u32,
                              cap_words: usize) -> c_int;

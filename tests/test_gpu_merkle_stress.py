@@ -1,8 +1,16 @@
-"""GPU: the tree kernels under concurrency and across their launch forms (tools/merkle_stress.cpp, through the C ABI).
+"""GPU: the tree kernels under real concurrency, and the cause of round 4's stale node measured (docs/stale_node.md).
 
-Several threads, each with a context of its own on the one GPU, commit the same matrices again and again; every digest layer must equal
-the first commit's -- what the rare stale node of the guest flow would have broken -- and every form of the top of the
-tree (the one-workgroup top kernel from 2^3 .. 2^8 nodes, the fused cooperative layers on and off) must give one root."""
+1. tools/ubench_barrier_race.hip (outside the prover): gfx950's s_barrier does NOT wait for a wave's LDS writes in flight -- the shape
+   `ds_write ; s_barrier` lets another wave read stale LDS contents, `ds_write ; s_waitcnt lgkmcnt(0) ; s_barrier` never does.
+2. tools/merkle_stress.cpp through the C ABI: tree threads rebuild their trees in place (no allocation, no synchronisation in the loop)
+   beside LDS-heavy transforms on other streams; the device recomputes every plain layer from its stored children.  The kernels that ship
+   must never differ; the round-4 body (zkhip_config.tree_store_early, TEST ONLY) is run the same way and what it does is reported --
+   its red/green verdict is the static one of tests/test_barrier_waits_cpu.py, which does not depend on a one-in-10^7 event.
+3. every form of the top of the tree (the one-workgroup top kernel from 2^3 .. 2^8 nodes, fused layers on and off, the round-4 body) gives
+   one root.
+4. a bounded guest-flow loop at frame 2^14 with every segment proof verified beside the proving and the device self-check on: the
+   configuration that showed the stale node in 3 - 5 % of runs."""
+import json
 import os
 import re
 import subprocess
@@ -22,19 +30,56 @@ def stress_exe(tmp_path_factory):
     return str(exe)
 
 
-def _run(exe, args, **env):
+def _run(exe, args, expect_clean=True, **env):
     out = subprocess.run([exe] + [str(a) for a in args], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert re.search(r", 0 differing layers", out.stdout), out.stdout[-2000:]
-    return re.search(r"root of thread 0's tree: (.*)", out.stdout).group(1)
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    if expect_clean:
+        assert out.returncode == 0 and rep["checks_with_a_wrong_node"] == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    return rep, re.search(r"root of thread 0's tree: (.*)", out.stdout).group(1)
 
 
-def test_layers_stay_equal_under_concurrent_commits(stress_exe):
-    _run(stress_exe, [3, 1500, 15, 24])
-    _run(stress_exe, [6, 600, 14, 40])
+def test_s_barrier_does_not_wait_for_lds_writes_in_flight(tmp_path):
+    exe = tmp_path / "ubench_barrier_race"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", os.path.join(ROOT, "tools", "ubench_barrier_race.hip"), "-o", str(exe)])
+    out = subprocess.run([str(exe), "4000", "1024", "16"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    racy, waited = [json.loads(l) for l in out.stdout.strip().splitlines()]
+    print(racy, waited)
+    assert waited["stale_reads"] == 0, waited
+    assert racy["stale_reads"] > 0, "ds_write ; s_barrier gave no stale read: the premise of docs/stale_node.md does not hold on this device"
+
+
+def test_layers_stay_right_under_concurrent_rebuilds(stress_exe):
+    rep, _ = _run(stress_exe, [3, 4000, 12, 8, 2, 8])
+    assert rep["checks"] >= 1500
+    _run(stress_exe, [6, 1500, 14, 40, 2, 4])
+
+
+def test_the_round4_body_under_the_same_stress_is_reported(stress_exe):
+    rep, _ = _run(stress_exe, [3, 4000, 12, 8, 2, 1], expect_clean=False, ZKHIP_TREE_STORE_EARLY="1")
+    print("round-4 body of the fused tree kernel under LDS-heavy neighbours:", rep)
+    assert rep["early_form"] is True and rep["checks"] >= 4000
 
 
 def test_every_form_of_the_tree_top_gives_one_root(stress_exe):
-    roots = {_run(stress_exe, [1, 2, 13, 9], **{name: value}) for name, value in
-             [("ZKHIP_TOP_MAX_LOG", "6"), ("ZKHIP_TOP_MAX_LOG", "8"), ("ZKHIP_TOP_MAX_LOG", "7"), ("ZKHIP_TOP_MAX_LOG", "3"), ("ZKHIP_COOP_MAX_LOG", "3")]}
+    roots = {_run(stress_exe, [1, 2, 13, 9, 0, 1], **{name: value})[1] for name, value in
+             [("ZKHIP_TOP_MAX_LOG", "6"), ("ZKHIP_TOP_MAX_LOG", "8"), ("ZKHIP_TOP_MAX_LOG", "7"), ("ZKHIP_TOP_MAX_LOG", "3"), ("ZKHIP_COOP_MAX_LOG", "3"),
+              ("ZKHIP_TREE_STORE_EARLY", "1")]}
     assert len(roots) == 1, roots
+
+
+def test_guest_flow_loop_with_self_check(tmp_path):
+    cli = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_guest_files.py"), str(tmp_path), "300000"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ZKHIP_VERIFY_SEGMENTS="1", ZKHIP_SELF_CHECK="1")
+    segments = 0
+    for i, n in enumerate([249651, 384274, 126816, 364386, 336579, 305084]):   # (lengths of failing runs of the round-5 hunt)
+        open(tmp_path / "stdin.bin", "wb").write(n.to_bytes(4, "little"))
+        out = tmp_path / ("o%d" % i)
+        out.mkdir()
+        r = subprocess.run([cli, "prove-elf", str(tmp_path / "fib.elf"), str(tmp_path / "stdin.bin"), str(out), "-", "14"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["verified"] is True
+        segments += line["segments"]
+    assert segments > 300

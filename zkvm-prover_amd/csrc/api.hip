@@ -426,6 +426,29 @@ int zkhip_merkle_commit(zkhip_ctx* ctx, const zkhip_matrix* mats, size_t n_mats,
     }
     return ZKHIP_OK;
 }
+// Rebuilds a committed tree in place: the same launches as the commit on the same digest store -- no allocation, no synchronisation.
+int zkhip_merkle_rebuild(zkhip_ctx* ctx, zkhip_tree* tree) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !tree || tree->mats.empty()) return ZKHIP_ERR_INVALID;
+    return merkle_build(ctx, tree, false);
+}
+// Every plain layer of the tree against the compression of its children, recomputed on the device through the plain (one lane per node)
+// permutation: *n_bad = nodes that differ, *first = (layer << 24 | index) of the first one (0xffffffff if none).  Synchronises.
+int zkhip_tree_check(zkhip_ctx* ctx, const zkhip_tree* tree, uint32_t* n_bad, uint32_t* first) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !tree || !n_bad) return ZKHIP_ERR_INVALID;
+    void* d_rep = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &d_rep));
+    const uint32_t init[2] = {0, 0xffffffffu};
+    ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_rep, init, 8, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // (`init` is a local)
+    ZK_TRY(merkle_check_tree(ctx, tree, (uint32_t*)d_rep));
+    uint32_t rep[2];
+    ZK_TRY(zkhip_d2h(ctx, rep, d_rep, 8));
+    *n_bad = rep[0];
+    if (first) *first = rep[1];
+    return ZKHIP_OK;
+}
 const uint32_t* zkhip_tree_root_device(const zkhip_tree* t) {
     return t ? t->d_digests + t->layer_off[t->log_height] * 8 : nullptr;
 }

@@ -8,6 +8,8 @@
 
 #include <cstdint>
 
+#include "lds_barrier.hpp"
+
 namespace zk {
 
 __device__ __forceinline__ void hist_add(uint32_t* counts, uint32_t idx) {
@@ -31,7 +33,7 @@ constexpr uint32_t HOT_SLOTS = 1024, HOT_EMPTY = 0xffffffffu;
 
 __device__ __forceinline__ void hot_init(uint32_t* keys, uint32_t* cnts) {
     for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += blockDim.x) keys[i] = HOT_EMPTY, cnts[i] = 0;
-    __syncthreads();
+    zk_syncthreads();
 }
 __device__ __forceinline__ void hot_add(uint32_t* keys, uint32_t* cnts, uint32_t* table, uint32_t idx) {
     const unsigned lane = __lane_id();
@@ -51,7 +53,7 @@ __device__ __forceinline__ void hot_add(uint32_t* keys, uint32_t* cnts, uint32_t
 }
 // every thread of the workgroup must call it (after its last hot_add)
 __device__ __forceinline__ void hot_flush(const uint32_t* keys, const uint32_t* cnts, uint32_t* table) {
-    __syncthreads();
+    zk_syncthreads();
     for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += blockDim.x)
         if (keys[i] != HOT_EMPTY && cnts[i]) atomicAdd(&table[keys[i]], cnts[i]);
 }

@@ -13,6 +13,7 @@
 // not HBM bound -- see DESIGN.md "Rooflines".
 #include <algorithm>
 
+#include "lds_barrier.hpp"
 #include "poseidon2_coop.hpp"
 #include "zkhip_internal.hpp"
 
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void k_compress_coop_multi(const uint32_t* pre
 #pragma unroll
     for (uint32_t j = 1; j < 5; j++) {
         if (j >= cm.m) break;
-        __syncthreads();
+        zk_syncthreads();
         rows >>= 1;
         const unsigned r = row < rows ? row : 0;
         x = coop_permute_regs(buf[cur][16 * r + lane], lane, cc);   // the two children's digests are neighbours in the buffer
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(1024) void k_compress_top(uint32_t* __restrict__ di
     unsigned n = 1u << (lh - l0);
     const CoopConsts cc = coop_load_consts(lane);
     for (unsigned e = tid; e < n * 8; e += 1024) buf[0][e] = digests[layer_off(l0) * 8 + e];
-    __syncthreads();
+    zk_syncthreads();
     unsigned cur = 0;
     // layers of more than 64 nodes (top_max_log 7, 8): several nodes per row, stored as they are made; from 64 nodes down a row makes
     // one node per layer, keeps it in a register of its own and stores it at the END of the kernel (as k_compress_coop_multi does)
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(1024) void k_compress_top(uint32_t* __restrict__ di
                 out[8 * i + lane] = x;
             }
         }
-        __syncthreads();
+        zk_syncthreads();
         cur ^= 1;
     }
     const unsigned l1 = l;   // first layer of <= 64 nodes
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(1024) void k_compress_top(uint32_t* __restrict__ di
         const uint32_t x = coop_permute_regs(buf[cur][16 * ii + lane], lane, cc);
         keep[k] = x;
         if (grp < n_next && lane < 8) buf[cur ^ 1][8 * grp + lane] = x;
-        __syncthreads();
+        zk_syncthreads();
         cur ^= 1;
     }
     if (lane >= 8) return;

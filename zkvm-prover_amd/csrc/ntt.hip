@@ -21,6 +21,7 @@
 
 #include <algorithm>
 
+#include "lds_barrier.hpp"
 #include "zkhip_internal.hpp"
 
 namespace zk {
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(1024) void k_ntt_dif_pass(PassArgs a) {
             lds[(r << a.log_c) + (g << log_S) + low] = src[base + e];
         }
     }
-    __syncthreads();
+    zk_syncthreads();
     const unsigned low0 = wide ? (u0 & S_mask) : 0u;
     for (unsigned j = 0; j < a.log_r; j++) {
         const unsigned log_half = a.log_r - 1 - j;  // half_r = 2^log_half
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(1024) void k_ntt_dif_pass(PassArgs a) {
             lds[ia] = madd(x, y);
             lds[ib] = mmul(msub(x, y), w);
         }
-        __syncthreads();
+        zk_syncthreads();
     }
     if (wide) {
         for (unsigned e = tid; e < total; e += nt) {
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
     const unsigned cg_bits = a.log_f - log_c;
     const unsigned X = tile >> cg_bits, F0 = (tile & ((1u << cg_bits) - 1u)) << log_c;
     const size_t in_base = (size_t)X * a.in_x_stride + F0;
-    __syncthreads();
+    zk_syncthreads();
     // ---- round 1: radix-16 straight from HBM ----
     {
         const unsigned log_rq = log_r - 4;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
             for (int k = 0; k < 16; k++) lv[(j + ((unsigned)k << log_rq)) * pitch + c] = v[k];
         }
     }
-    __syncthreads();
+    zk_syncthreads();
     // ---- remaining stages out of LDS ----
     unsigned log_rcur = log_r - 4;
     while (log_rcur > 0) {
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4(Pass4Args a) {
             default: lds_round<1>(lv, twl, log_r, log_rcur, log_c, tid, nt); break;
         }
         log_rcur -= q;
-        __syncthreads();
+        zk_syncthreads();
     }
     // ---- write-out: each tile column is one contiguous run of R words ----
     const unsigned lo_mask = (1u << a.log_lo) - 1u;
@@ -395,7 +396,7 @@ __device__ __forceinline__ void lds_rounds_ct(uint32_t* lv, const uint32_t* twl,
 #pragma unroll
             for (int k = 0; k < (1 << Q); k++) base[(k << LOG_RQ) * pitch] = v[k];
         }
-        __syncthreads();
+        zk_syncthreads();
         lds_rounds_ct<LOG_R, LOG_C, LOG_RCUR - Q>(lv, twl, tid);
     }
 }
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
     }
     const unsigned cg_bits = a.log_f - LOG_C;
     const unsigned X = tile >> cg_bits, F0 = (tile & ((1u << cg_bits) - 1u)) << LOG_C;
-    __syncthreads();
+    zk_syncthreads();
     // ---- round 1: one radix-16 unit per lane straight from HBM ----
     {
         // Which unit a lane takes is free in this round (a unit's rows sit 2^LOG_RQ apart, HBM sees the same
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
 #pragma unroll
         for (int k = 0; k < 16; k++) base[(k << LOG_RQ) * pitch] = v[k];
     }
-    __syncthreads();
+    zk_syncthreads();
 #if !defined(NTT_ABL) || (NTT_ABL != 4 && NTT_ABL != 5)
     lds_rounds_ct<LOG_R, LOG_C, LOG_RQ>(lv, twl, tid);
 #endif
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(256) void k_bitrev_scale_tiled(BitrevArgs a) {
         unsigned hi5 = ty + 8 * rr;
         tile[hi5][tx] = src[((size_t)hi5 << (a.log_n - 5)) + ((size_t)mid << 5) + tx];
     }
-    __syncthreads();
+    zk_syncthreads();
     const unsigned brmid = bitrev32(mid, log_mid);
 #pragma unroll
     for (unsigned rr = 0; rr < 4; rr++) {
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(256) void k_bitrev_copy_tiled_multi(const BitrevSeg
         unsigned hi5 = ty + 8 * rr;
         tile[hi5][tx] = src[((size_t)hi5 << (sg.log_n - 5)) + ((size_t)mid << 5) + tx];
     }
-    __syncthreads();
+    zk_syncthreads();
     const unsigned brmid = bitrev32(mid, log_mid);
 #pragma unroll
     for (unsigned rr = 0; rr < 4; rr++) {

@@ -392,7 +392,7 @@ extern "C" __global__ __launch_bounds__(64 * NW) void quot_jit(const uint32_t* _
             const uint32_t st = msub(x, w_n_inv);
             sel_s[lane] = mmul(zh, minv(msub(x, ONE))), sel_s[64u + lane] = st, sel_s[128u + lane] = mmul(zh, minv(st));
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xc07f); __syncthreads();   // (lds_barrier.hpp: the LDS wait stated in front of the barrier)
         const uint32_t sel_first = sel_s[lane], sel_trans = sel_s[64u + lane], sel_last = sel_s[128u + lane];
         uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
         uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
@@ -461,14 +461,14 @@ extern "C" __global__ __launch_bounds__(64 * NW) void quot_jit(const uint32_t* _
         FINISH
         red_s[(wv * 4u + 0u) * 64u + lane] = acc0, red_s[(wv * 4u + 1u) * 64u + lane] = acc1;
         red_s[(wv * 4u + 2u) * 64u + lane] = acc2, red_s[(wv * 4u + 3u) * 64u + lane] = acc3;
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xc07f); __syncthreads();
         if (wv < 4u) {   // wave c sums coordinate c over the waves
             const uint32_t izh = inv_zh_t[i & ((1u << B) - 1u)];
             uint32_t v = red_s[wv * 64u + lane];
             for (uint32_t w = 1; w < NW; w++) v = madd(v, red_s[(w * 4u + wv) * 64u + lane]);
             q[(size_t)wv * M + r] = mmul(v, izh);
         }
-        __syncthreads();   // the tile and the partial sums are rewritten by the next round
+        __builtin_amdgcn_s_waitcnt(0xc07f); __syncthreads();   // the tile and the partial sums are rewritten by the next round
     }
 }
 )JIT";

@@ -14,6 +14,7 @@
 // All are HBM-streaming (16-byte lanes, coalesced 1 KiB per wave instruction).
 #include <algorithm>
 
+#include "lds_barrier.hpp"
 #include "zkhip_internal.hpp"
 
 namespace zk {
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_scan_local(uint32_t* __restrict__ data,
 #pragma unroll
         for (int q = 0; q < 4; q++) wave_tot[wave][q] = incl.c[q];
     }
-    __syncthreads();
+    zk_syncthreads();
     Ext off = ext_sub(incl, run);  // exclusive prefix of this lane inside its wave
     for (unsigned w = 0; w < wave; w++)
         off = ext_add(off, Ext{{wave_tot[w][0], wave_tot[w][1], wave_tot[w][2], wave_tot[w][3]}});
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(1024) void k_scan_totals(uint32_t* __restrict__ tot
     __shared__ uint32_t carry[4];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid < 4) carry[tid] = 0;
-    __syncthreads();
+    zk_syncthreads();
     for (size_t start = 0; start < n_blocks; start += 1024) {
         size_t i = start + tid;
         Ext v = i < n_blocks ? ld4(totals, i) : ext_zero();
@@ -132,18 +133,18 @@ __global__ __launch_bounds__(1024) void k_scan_totals(uint32_t* __restrict__ tot
 #pragma unroll
             for (int q = 0; q < 4; q++) wave_tot[wave][q] = incl.c[q];
         }
-        __syncthreads();
+        zk_syncthreads();
         Ext off{{carry[0], carry[1], carry[2], carry[3]}};
         for (unsigned w = 0; w < wave; w++)
             off = ext_add(off, Ext{{wave_tot[w][0], wave_tot[w][1], wave_tot[w][2], wave_tot[w][3]}});
         Ext r = ext_add(incl, off);
         if (i < n_blocks) st4(totals, i, r);
-        __syncthreads();
+        zk_syncthreads();
         if (tid == 1023) {
 #pragma unroll
             for (int q = 0; q < 4; q++) carry[q] = r.c[q];
         }
-        __syncthreads();
+        zk_syncthreads();
     }
 }
 // phase 3: add the preceding workgroups' total
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void k_scan_local_multi(const ScanSeg* __restr
 #pragma unroll
         for (int q = 0; q < 4; q++) wave_tot[wave][q] = incl.c[q];
     }
-    __syncthreads();
+    zk_syncthreads();
     Ext off = ext_sub(incl, run);
     for (unsigned w = 0; w < wave; w++)
         off = ext_add(off, Ext{{wave_tot[w][0], wave_tot[w][1], wave_tot[w][2], wave_tot[w][3]}});
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(1024) void k_scan_totals_multi(const ScanSeg* __res
     uint32_t* totals = sg.totals;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid < 4) carry[tid] = 0;
-    __syncthreads();
+    zk_syncthreads();
     for (size_t start = 0; start < n_blocks; start += 1024) {
         size_t i = start + tid;
         Ext v = i < n_blocks ? ld4(totals, i) : ext_zero();
@@ -231,18 +232,18 @@ __global__ __launch_bounds__(1024) void k_scan_totals_multi(const ScanSeg* __res
 #pragma unroll
             for (int q = 0; q < 4; q++) wave_tot[wave][q] = incl.c[q];
         }
-        __syncthreads();
+        zk_syncthreads();
         Ext off{{carry[0], carry[1], carry[2], carry[3]}};
         for (unsigned w = 0; w < wave; w++)
             off = ext_add(off, Ext{{wave_tot[w][0], wave_tot[w][1], wave_tot[w][2], wave_tot[w][3]}});
         Ext r = ext_add(incl, off);
         if (i < n_blocks) st4(totals, i, r);
-        __syncthreads();
+        zk_syncthreads();
         if (tid == 1023) {
 #pragma unroll
             for (int q = 0; q < 4; q++) carry[q] = r.c[q];
         }
-        __syncthreads();
+        zk_syncthreads();
     }
 }
 __global__ __launch_bounds__(256) void k_scan_add_multi(const ScanSeg* __restrict__ segs, uint32_t n_seg) {
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void k_sumcheck_partial(SumcheckArgs a, uint32
             for (int off = 32; off >= 1; off >>= 1) x = madd(x, __shfl_xor(x, off, 64));
             if (lane == 0) red[wave][t * 4 + q] = x;
         }
-    __syncthreads();
+    zk_syncthreads();
     if (tid < (a.k + 1) * 4) {
         uint32_t x = madd(madd(red[0][tid], red[1][tid]), madd(red[2][tid], red[3][tid]));
         partial[(size_t)blockIdx.x * ((SCR_MAXK + 1) * 4) + tid] = x;

@@ -10,6 +10,7 @@
 //
 // One row per lane: the 298 stores of a wave are 298 contiguous 256-byte runs (column-major trace), the 16 input words
 // of a row are four 16-byte loads.  HBM-bound on the writes: 1192 B per row written, 64 B read.
+#include "lds_barrier.hpp"
 #include "poseidon2.hpp"
 #include "hist.hpp"
 #include "poseidon2_coop.hpp"
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_range_counts(const uint32_t* __restrict
     __shared__ uint32_t bins[1u << RC_LDS_LOG];
     const uint32_t T = 1u << log_table, L = T < (1u << RC_LDS_LOG) ? T : (1u << RC_LDS_LOG);
     for (uint32_t i = threadIdx.x; i < L; i += 256) bins[i] = 0;
-    __syncthreads();
+    zk_syncthreads();
     uint32_t n_bad = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const uint32_t v = from_monty(values[i]);
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void k_range_counts(const uint32_t* __restrict
         else hist_add(hist, v);
     }
     if (n_bad) atomicAdd(bad, n_bad);
-    __syncthreads();
+    zk_syncthreads();
     for (uint32_t i = threadIdx.x; i < L; i += 256)
         if (bins[i]) atomicAdd(&hist[i], bins[i]);
 }

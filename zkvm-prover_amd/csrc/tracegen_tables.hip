@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <string>
 
+#include "lds_barrier.hpp"
 #include "../../include/zkhip.h"
 #include "hist.hpp"
 #include "babybear.hpp"
@@ -340,14 +341,14 @@ __global__ __launch_bounds__(256) void k_program_freq(const uint32_t* __restrict
     __shared__ uint32_t bins[1u << 13];
     const uint32_t L = N < (1u << 13) ? (uint32_t)N : (1u << 13);
     for (uint32_t i = threadIdx.x; i < L; i += 256) bins[i] = 0;
-    __syncthreads();
+    zk_syncthreads();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const uint32_t k = idx[i];
         if (k >= N) atomicAdd(bad, 1u);
         else if (k < L) atomicAdd(&bins[k], 1u);
         else hist_add(freq, k);
     }
-    __syncthreads();
+    zk_syncthreads();
     for (uint32_t i = threadIdx.x; i < L; i += 256)
         if (bins[i]) atomicAdd(&freq[i], bins[i]);
 }

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "lds_barrier.hpp"
 #include "poseidon2_coop.hpp"
 #include "transcript.hpp"
 #include "zkhip_internal.hpp"
@@ -176,9 +177,9 @@ __global__ __launch_bounds__(256) void k_grind(DevTranscript* t, unsigned bits, 
     // every lane of the block has read the state it needed and published what it found: count the block out
     __shared__ uint32_t last;
     __threadfence();
-    __syncthreads();
+    zk_syncthreads();
     if (threadIdx.x == 0) last = atomicAdd(&t->pad, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
+    zk_syncthreads();
     if (!last || threadIdx.x >= 64) return;
     __threadfence();
     grind_apply(t, bits, witness_out, threadIdx.x);
@@ -225,9 +226,9 @@ __global__ __launch_bounds__(256) void k_fri_round_transcript(DevTranscript* t, 
     }
     __shared__ uint32_t last;
     __threadfence();
-    __syncthreads();
+    zk_syncthreads();
     if (threadIdx.x == 0) last = atomicAdd(&t->pad, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
+    zk_syncthreads();
     if (!last || threadIdx.x >= 64) return;
     __threadfence();
     const unsigned lane = threadIdx.x;
