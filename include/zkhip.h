@@ -781,6 +781,22 @@ int zkhip_int256_shift_air(uint32_t bitwise_bus, zkhip_air *out);
 int zkhip_int256_shift_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);
 int zkhip_vm_shift256_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height, uint32_t *d_trace,
                                uint32_t *d_bitwise_trace);
+/* ---- NATIVE field / extension / castf chips of the one-statement circuit (`[app_vm_config.native]`, `[app_vm_config.castf]`: the chips
+ *      of openvm-native-circuit the reference's batch and bundle circuits enable, crates/circuits/batch-circuit/openvm.toml:16,24 and
+ *      bundle-circuit/openvm.toml:16,18; include/zkhip_native.hpp, include/zkhip_vm_circuit.hpp native_arith_air / native_ext_air /
+ *      castf_vm_air; AIRs through zkhip_vm_air).  ONE row per call, core and memory adapter together; the rows are made on the device
+ *      from the executor's call records (canonical words):
+ *        native arith (27 columns), 9 words per call:  op | b | c | the result word before | word pointer | ts | previous timestamps of
+ *                                                       the three words          (op 0 add, 1 sub, 2 mul, 3 div)
+ *        native ext (90 columns), 27 words per call:    op | x[4] | y[4] | the result words before [4] | word pointer | ts | previous
+ *                                                       timestamps of the twelve words
+ *        castf (16 columns), 6 words per call:          x (< 2^30) | the output word before | word pointer | ts | previous timestamps of
+ *                                                       the two words
+ *      The chips' lookups (range, range-tuple, bitwise) are counted from the trace columns by the caller (include/zkhip_vm_flow.hpp).
+ *      ZKHIP_ERR_INVALID for an unknown operation, a division by zero, a castf operand >= 2^30 or a timestamp gap out of range. ---- */
+int zkhip_vm_native_arith_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace);
+int zkhip_vm_native_ext_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace);
+int zkhip_vm_castf_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace);
 /* the chip inside the VM (102 columns: + the timestamp of call i on row i) */
 int zkhip_vm_int256_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, const uint32_t *d_ts, size_t n, unsigned log_height, uint32_t *d_trace,
                              uint32_t *d_bitwise_trace);

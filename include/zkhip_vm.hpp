@@ -32,6 +32,7 @@
 #include "zkhip_int256.hpp"
 #include "zkhip_keccak.hpp"
 #include "zkhip_modular.hpp"
+#include "zkhip_native.hpp"
 #include "zkhip_sha256.hpp"
 
 namespace zkhip_vm {
@@ -160,6 +161,8 @@ public:
     void set_moduli(const std::vector<zkhip::modular::U256>& m) { moduli_ = m; }   // the modular extension's moduli (ecall 5)
     void set_curves(const std::vector<zkhip::ecc::Curve>& c) { curves_ = c; }       // the ecc extension's curves (ecall 7)
     void set_fp2_moduli(const std::vector<zkhip::modular::U256>& m) { fp2_moduli_ = m; }   // the fp2 extension's fields (ecall 8)
+    // `[app_vm_config.native]` (ecalls 9, 10), `[app_vm_config.castf]` (ecall 11), `[app_vm_config.pairing]` (phantom kind 2)
+    void set_native(const zkhip::native::Enabled& e) { native_ = e.native, castf_ = e.castf, pairing_ = e.pairing; }
     const zkhip::modular::U256& last_slope() const { return last_slope_; }          // of the last ecc call (the chip's record carries it)
     bool done() const { return done_; }
     uint32_t pc() const { return pc_; }
@@ -180,6 +183,7 @@ private:
     std::vector<zkhip::modular::U256> moduli_;
     std::vector<zkhip::ecc::Curve> curves_;
     std::vector<zkhip::modular::U256> fp2_moduli_;
+    bool native_ = false, castf_ = false, pairing_ = false;
     zkhip::modular::U256 last_slope_{};
     uint64_t instret_ = 0;
     size_t in_pos_ = 0;
@@ -626,6 +630,38 @@ private:
                     zkhip::fp2::Elem a{load_words(p, nb / 4), load_words(p + nb, nb / 4)}, b{load_words(p + 2 * nb, nb / 4), load_words(p + 3 * nb, nb / 4)}, r;
                     if (!zkhip::fp2::fp2_op(fop, fp2_moduli_[which], a, b, &r)) throw Error("fp2: components not reduced, or a division by zero");
                     memcpy(p + 4 * nb, r.c0.w, nb), memcpy(p + 5 * nb, r.c1.w, nb);
+                } else if (call == zkhip::native::CALL_ARITH || call == zkhip::native::CALL_EXT) {
+                    // r = a op b over BabyBear (3 words at a0) or its quartic extension (12 words: a[4] | b[4] | r[4]), a1 = op: 0 add, 1 sub,
+                    // 2 mul, 3 div; a word is read as a field element (value mod p), results are canonical (OpenVM's native extension:
+                    // FieldArithmetic / FieldExtension; include/zkhip_native.hpp)
+                    if (rec && log_memory_) throw Error("the native field intrinsics are proven by the one-statement flow only");
+                    if (!native_) throw Error("native: the app's openvm.toml does not enable the native extension");
+                    const uint32_t addr = reg_read(rec, 10), op = reg_read(rec, 11);
+                    if (addr & 3u) throw Error("native buffer must be word-aligned");
+                    if (call == zkhip::native::CALL_ARITH) {
+                        uint32_t w3[3];
+                        uint8_t* p = at(addr, 12);
+                        memcpy(w3, p, 12);
+                        if (!zkhip::native::arith(op, w3[0], w3[1], &w3[2])) throw Error("native: unknown operation or a division by zero");
+                        memcpy(p + 8, &w3[2], 4);
+                    } else {
+                        uint32_t w12[12];
+                        uint8_t* p = at(addr, 48);
+                        memcpy(w12, p, 48);
+                        if (!zkhip::native::ext_arith(op, w12, w12 + 4, w12 + 8)) throw Error("native extension: unknown operation or a division by zero");
+                        memcpy(p + 32, w12 + 8, 16);
+                    }
+                } else if (call == zkhip::native::CALL_CASTF) {
+                    // the word at a0, a native field element below 2^30, as four bytes in the word at a0 + 4 (OpenVM's CastF)
+                    if (rec && log_memory_) throw Error("the castf intrinsic is proven by the one-statement flow only");
+                    if (!castf_) throw Error("castf: the app's openvm.toml does not enable the castf extension");
+                    const uint32_t addr = reg_read(rec, 10);
+                    if (addr & 3u) throw Error("castf buffer must be word-aligned");
+                    uint8_t* p = at(addr, 8);
+                    uint32_t v;
+                    memcpy(&v, p, 4);
+                    if (v >= zkhip::native::CASTF_BOUND) throw Error("castf: the field element does not lie below 2^30");
+                    memcpy(p + 4, &v, 4);
                 } else {
                     throw Error("unknown environment call " + std::to_string(call));
                 }
@@ -755,7 +791,8 @@ inline Exe parse_exe(const std::vector<uint8_t>& raw) {
 // `moduli` / `curves`: the app's modular and ecc extensions (openvm.toml), for guests that call those intrinsics.
 inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64_t max_cost = 0, ExecRecords* records = nullptr,
                                      uint64_t max_instr = 0, const std::vector<zkhip::modular::U256>& moduli = {},
-                                     const std::vector<zkhip::ecc::Curve>& curves = {}, const std::vector<zkhip::modular::U256>& fp2_moduli = {}) {
+                                     const std::vector<zkhip::ecc::Curve>& curves = {}, const std::vector<zkhip::modular::U256>& fp2_moduli = {},
+                                     const zkhip::native::Enabled& native_ext = zkhip::native::Enabled()) {
     auto all_zero = [](const std::vector<uint8_t>& v) {
         for (uint8_t b : v)
             if (b) return false;
@@ -766,7 +803,7 @@ inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64
     {
         *rec = ExecRecords();
         Machine m(exe, inputs);
-        m.set_moduli(moduli), m.set_curves(curves), m.set_fp2_moduli(fp2_moduli);
+        m.set_moduli(moduli), m.set_curves(curves), m.set_fp2_moduli(fp2_moduli), m.set_native(native_ext);
         bool finished = false;
         try {
             finished = m.run(max_instr, max_cost, rec);
@@ -782,7 +819,7 @@ inline ExecutionResult execute_guest(const Exe& exe, const StdIn& inputs, uint64
     // the plain executor: no cost bound, and -- like the reference's -- no instruction count (u64::MAX as the sentinel)
     *rec = ExecRecords();
     Machine m(exe, inputs);
-    m.set_moduli(moduli), m.set_curves(curves), m.set_fp2_moduli(fp2_moduli);
+    m.set_moduli(moduli), m.set_curves(curves), m.set_fp2_moduli(fp2_moduli), m.set_native(native_ext);
     if (!m.run(max_instr, 0, rec)) throw Error("instruction limit reached");  // max_instr: a service-side bound, 0 = none
     if (m.exit_code()) throw Error("guest exited with code " + std::to_string(m.exit_code()));
     if (all_zero(m.public_values())) throw Error("public_values are all 0s upon execute");

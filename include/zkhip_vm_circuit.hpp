@@ -29,6 +29,10 @@
 //                  fp2 (a7 = 8: r = a b, a + b, a - b or a / b in Fp[u] / (u^2 + 1) on the 48 words at a0 -- a, b, then the result's slot,
 //                  two 256-bit components each; a1 = i + 8 op: i the index of one of the fields the app's openvm.toml lists; OpenVM's
 //                  fp2 extension).  Its adapter has the ecc adapter's shape on buses of its own.
+//                  native field (a7 = 9), native extension (a7 = 10), castf (a7 = 11): include/zkhip_native.hpp -- OpenVM's native and
+//                  castf extensions (crates/circuits/batch-circuit/openvm.toml:16,24; bundle-circuit/openvm.toml:16,18).
+//   native chips   ONE row per call, core and memory adapter in one chip (like load/store): the field-arithmetic chip reads two
+//                  words and writes one, the extension chip reads 8 and writes 4, the castf chip reads one and writes one.
 //   ecc adapter    one per curve, one row per WORD of a call (48 rows): operands read, result written; (timestamp, index, halves, op)
 //                  goes to that curve's point chip (include/zkhip_ecc.hpp, one operation per row).
 //   int256 adapter one row per WORD of a call (24 rows): b, c read, a written; (timestamp, index, halves, opcode) goes to the 256-bit ALU
@@ -66,6 +70,7 @@
 #include "zkhip_int256.hpp"
 #include "zkhip_keccak.hpp"
 #include "zkhip_modular.hpp"
+#include "zkhip_native.hpp"
 #include "zkhip_sha256.hpp"
 
 namespace zkhip {
@@ -77,12 +82,13 @@ using air::Kind;
 constexpr uint32_t MEMORY_BUS = 1, EXEC_BUS = 2, OPERAND_BUS = 3, RANGE_BUS = 5, RANGE_TUPLE_BUS = 6, PROGRAM_BUS = 8, BITWISE_BUS = 9,
                    MERKLE_BUS = 10, HASH_BUS = 11, KECCAK_REQ_BUS = 12, KECCAK_LANE_BUS = 13, SHA_REQ_BUS = 14, SHA_MSG_BUS = 15, SHA_STATE_BUS = 16, MODMUL_REQ_BUS = 17, MODMUL_WORD_BUS = 18,   // modulus i: word bus 18 + i
                    INT256_REQ_BUS = 30, INT256_WORD_BUS = 31, EC_REQ_BUS = 32, EC_WORD_BUS = 33,   // curve i: word bus 33 + i
-                   FP2_REQ_BUS = 37, FP2_WORD_BUS = 38;                                                // fp2 field i: word bus 38 + i
+                   FP2_REQ_BUS = 37, FP2_WORD_BUS = 38,                                                // fp2 field i: word bus 38 + i
+                   NATIVE_REQ_BUS = 40, NATIVE_EXT_REQ_BUS = 41, CASTF_REQ_BUS = 42;
 constexpr uint32_t TS_STEP = 16;   // timestamps per instruction: rs1 at +0; rs2 at +2; the core's own accesses at +4 ..; rd at +12
 constexpr uint32_t BLOCK_CELLS = 8, BLOCK_WORDS = 4, LABEL_BITS = 26, LEAF_LEVEL = LABEL_BITS + 2;  // block label = as * 2^26 + (word >> 2); the tree has 28 levels above the blocks
 constexpr uint32_t GAP_HI_BITS = 11;  // a timestamp gap is gap_lo + 2^16 gap_hi with gap_hi below 2^11 (one range-tuple lookup (0, gap_hi))
 enum Cls : uint32_t { C_ALU, C_LT, C_MUL, C_MULH, C_DIVREM, C_SHIFT, C_BEQ, C_BLT, C_JAL_LUI, C_AUIPC, C_JALR, C_LS, C_ECALL, N_CLS };
-constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 34, LEAF_WIDTH = 43, MERKLE_WIDTH = 54, KECCAK_IO_WIDTH = 42, SHA_IO_WIDTH = 34, MODMUL_IO_WIDTH = 35, INT256_IO_WIDTH = 35, EC_IO_WIDTH = 59,
+constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 37, NATIVE_ARITH_WIDTH = 27, NATIVE_EXT_WIDTH = 90, CASTF_WIDTH = 16, LEAF_WIDTH = 43, MERKLE_WIDTH = 54, KECCAK_IO_WIDTH = 42, SHA_IO_WIDTH = 34, MODMUL_IO_WIDTH = 35, INT256_IO_WIDTH = 35, EC_IO_WIDTH = 59,
                  CONNECTOR_WIDTH = 2;
 constexpr uint32_t P = air::P;
 
@@ -381,16 +387,18 @@ inline void loadstore_air(AirBuilder& b) {
 
 // ecall chip: AirBuilder(ECALL_WIDTH, 0).  Columns: pc ts | x[4] (a7) | y[4] (a0) | z[4] (a0 afterwards) | is_exit is_reveal is_read |
 // idx (a1, the public-value word index) | pv_prev_lo pv_prev_hi | pc_inc | (prev_ts gap_lo gap_hi) of the a1 read and the public-value write |
-// is_keccak | q (= a0's low byte / 4: the state must be word-aligned) | is_sha | is_mod | is_int | is_ec | is_fp2
+// is_keccak | q (= a0's low byte / 4: the state must be word-aligned) | is_sha | is_mod | is_int | is_ec | is_fp2 | is_nat | is_next | is_castf
 inline void ecall_air(AirBuilder& b) {
     const Expr pc = b.var(0), ts = b.var(1);
     Expr x[4], y[4], z[4];
     for (int i = 0; i < 4; i++) x[i] = b.var(2 + i), y[i] = b.var(6 + i), z[i] = b.var(10 + i);
     const Expr is_exit = b.var(14), is_reveal = b.var(15), is_read = b.var(16), idx = b.var(17), pvp_lo = b.var(18), pvp_hi = b.var(19), pc_inc = b.var(20);
-    const Expr is_keccak = b.var(27), q = b.var(28), is_sha = b.var(29), is_mod = b.var(30), is_int = b.var(31), is_ec = b.var(32), is_fp2 = b.var(33), is_hash = is_keccak + is_sha + is_mod + is_int + is_ec + is_fp2;
-    const Expr ok = is_exit + is_reveal + is_read + is_keccak + is_sha + is_mod + is_int + is_ec + is_fp2;
-    for (const Expr& f : {is_exit, is_reveal, is_read, is_keccak, is_sha, is_mod, is_int, is_ec, is_fp2, ok}) b.assert_zero(f * (f - 1));
-    b.assert_zero(x[0] - is_exit * 93 - is_reveal - is_read * 2 - is_keccak * 3 - is_sha * 4 - is_mod * 5 - is_int * 6 - is_ec * 7 - is_fp2 * 8);
+    const Expr is_keccak = b.var(27), q = b.var(28), is_sha = b.var(29), is_mod = b.var(30), is_int = b.var(31), is_ec = b.var(32), is_fp2 = b.var(33), is_nat = b.var(34),
+               is_next = b.var(35), is_castf = b.var(36), is_hash = is_keccak + is_sha + is_mod + is_int + is_ec + is_fp2 + is_nat + is_next + is_castf;
+    const Expr ok = is_exit + is_reveal + is_read + is_keccak + is_sha + is_mod + is_int + is_ec + is_fp2 + is_nat + is_next + is_castf;
+    for (const Expr& f : {is_exit, is_reveal, is_read, is_keccak, is_sha, is_mod, is_int, is_ec, is_fp2, is_nat, is_next, is_castf, ok}) b.assert_zero(f * (f - 1));
+    b.assert_zero(x[0] - is_exit * 93 - is_reveal - is_read * 2 - is_keccak * 3 - is_sha * 4 - is_mod * 5 - is_int * 6 - is_ec * 7 - is_fp2 * 8 - is_nat * (int64_t)native::CALL_ARITH -
+                  is_next * (int64_t)native::CALL_EXT - is_castf * (int64_t)native::CALL_CASTF);
     for (int i = 1; i < 4; i++) b.assert_zero(x[i]);
     for (int i = 0; i < 4; i++) {
         b.assert_zero(is_exit * y[i]);                 // exit code 0: a failing guest has no proof
@@ -405,7 +413,9 @@ inline void ecall_air(AirBuilder& b) {
     const Expr one = b.constant(1), zero = b.constant(0), three = b.constant(3);
     // reveal: a1 (register 11) is the word index, below 8; the word a0 goes to word idx of address space 3
     // (modmul, int256 and ecc read a1 the same way: the index of the modulus / curve, the opcode)
-    word_access(b, is_reveal + is_mod + is_int + is_ec + is_fp2, is_reveal + is_mod + is_int + is_ec + is_fp2, one, b.constant(11), idx, zero, idx, zero, ts + 4, b.var(21), b.var(22), b.var(23));
+    // (the native field and extension calls read their opcode there too; castf has no second argument)
+    const Expr reads_a1 = is_reveal + is_mod + is_int + is_ec + is_fp2 + is_nat + is_next;
+    word_access(b, reads_a1, reads_a1, one, b.constant(11), idx, zero, idx, zero, ts + 4, b.var(21), b.var(22), b.var(23));
     word_access(b, is_reveal, is_reveal, three, idx, pvp_lo, pvp_hi, y[0] + y[1] * 256, y[2] + y[3] * 256, ts + 5, b.var(24), b.var(25), b.var(26));
     b.push_interaction(RANGE_BUS, {idx * 8192}, is_reveal, Kind::Send);
     b.push_interaction(RANGE_BUS, {idx}, is_reveal, Kind::Send);
@@ -419,6 +429,9 @@ inline void ecall_air(AirBuilder& b) {
     b.push_interaction(INT256_REQ_BUS, {ts, wptr, idx}, is_int, Kind::Send);
     b.push_interaction(EC_REQ_BUS, {ts, wptr, idx}, is_ec, Kind::Send);
     b.push_interaction(FP2_REQ_BUS, {ts, wptr, idx}, is_fp2, Kind::Send);
+    b.push_interaction(NATIVE_REQ_BUS, {ts, wptr, idx}, is_nat, Kind::Send);
+    b.push_interaction(NATIVE_EXT_REQ_BUS, {ts, wptr, idx}, is_next, Kind::Send);
+    b.push_interaction(CASTF_REQ_BUS, {ts, wptr}, is_castf, Kind::Send);
     b.push_interaction(RANGE_BUS, {q * 1024}, is_hash, Kind::Send);
     b.push_interaction(RANGE_BUS, {q}, is_hash, Kind::Send);
     b.push_interaction(RANGE_BUS, {y[3] * 1024}, is_hash, Kind::Send);
@@ -568,6 +581,103 @@ inline void ec_io_air(AirBuilder& b, uint32_t index, uint32_t req_bus = EC_REQ_B
     b.push_interaction(word_bus_base + index, {ts, idx, n_lo, n_hi, op}, ok, Kind::Send);
 }
 
+// A native field element in memory: ONE word (lo, hi halves) holding a value read as lo + 2^16 hi (mod p).  A RESULT is written canonical:
+// hi <= 0x7800 (both hi and hi_gap = 0x7800 - hi in the range table) and, where hi = 0x7800 (flag `top`, decided through an inverse of
+// hi_gap), lo = 0 -- i.e. the word is below p = 0x78000001.  Columns of one result: lo hi hi_gap top top_inv.
+inline void canonical_word(AirBuilder& b, Expr ok, Expr lo, Expr hi, Expr hi_gap, Expr top, Expr top_inv) {
+    b.assert_zero(top * (top - 1));
+    b.assert_zero(ok * (hi_gap + hi - (int64_t)native::P_HI));
+    b.assert_zero(ok * (hi_gap * top_inv - 1 + top));
+    b.assert_zero(top * hi_gap);
+    b.assert_zero(top * lo);
+    b.push_interaction(RANGE_BUS, {lo}, ok, Kind::Send);
+    b.push_interaction(RANGE_BUS, {hi}, ok, Kind::Send);
+    b.push_interaction(RANGE_BUS, {hi_gap}, ok, Kind::Send);
+}
+
+// native field-arithmetic chip: AirBuilder(NATIVE_ARITH_WIDTH, 0), ONE row per call (a7 = 9).  Columns: ts | base (word pointer of the
+// 3-word buffer) | b_lo b_hi | c_lo c_hi (the operands, read) | a_lo a_hi a_hi_gap top top_inv (the result a = b op c, canonical) |
+// ap_lo ap_hi (the result word before) | is_add is_sub is_mul is_div | div_inv (c^-1 on a division) | (prev_ts gap_lo gap_hi) of the
+// three word accesses.  The core is OpenVM's FieldArithmeticCoreAir (air.py field_arith_air); the accesses are its native adapter's.
+inline void native_arith_air(AirBuilder& b) {
+    const Expr ts = b.var(0), base = b.var(1), b_lo = b.var(2), b_hi = b.var(3), c_lo = b.var(4), c_hi = b.var(5), a_lo = b.var(6), a_hi = b.var(7), ap_lo = b.var(11),
+               ap_hi = b.var(12), add = b.var(13), sub = b.var(14), mul = b.var(15), div = b.var(16), inv = b.var(17);
+    const Expr ok = add + sub + mul + div;
+    for (const Expr& f : {add, sub, mul, div, ok}) b.assert_zero(f * (f - 1));
+    const Expr bv = b_lo + b_hi * 65536, cv = c_lo + c_hi * 65536, av = a_lo + a_hi * 65536;
+    b.assert_zero(add * (av - bv - cv));
+    b.assert_zero(sub * (av - bv + cv));
+    b.assert_zero(mul * (av - bv * cv));
+    b.assert_zero(div * (bv - av * cv));
+    b.assert_zero(div * (cv * inv - 1));
+    canonical_word(b, ok, a_lo, a_hi, b.var(8), b.var(9), b.var(10));
+    b.push_interaction(NATIVE_REQ_BUS, {ts, base, sub + mul * 2 + div * 3}, ok, Kind::Receive);
+    const Expr two = b.constant(2);
+    word_access(b, ok, ok, two, base, b_lo, b_hi, b_lo, b_hi, ts + 5, b.var(18), b.var(19), b.var(20));
+    word_access(b, ok, ok, two, base + 1, c_lo, c_hi, c_lo, c_hi, ts + 5, b.var(21), b.var(22), b.var(23));
+    word_access(b, ok, ok, two, base + 2, ap_lo, ap_hi, a_lo, a_hi, ts + 5, b.var(24), b.var(25), b.var(26));
+}
+
+// native extension chip: AirBuilder(NATIVE_EXT_WIDTH, 0), ONE row per call (a7 = 10) on F[X] / (X^4 - 11).  Columns: ts | base | x[4] (lo hi) |
+// y[4] (lo hi) | z[4] (lo hi hi_gap top top_inv: the result, canonical) | zp[4] (lo hi: the result words before) | is_add is_sub is_mul
+// is_div | inv[4] (y^-1 on a division) | (prev_ts gap_lo gap_hi) of the twelve word accesses.  Core: OpenVM's FieldExtensionCoreAir
+// (air.py field_ext_air): z = x op y; a division is z = x inv with y inv = 1.
+inline void native_ext_air(AirBuilder& b) {
+    const Expr ts = b.var(0), base = b.var(1);
+    Expr xl[4], xh[4], yl[4], yh[4], zl[4], zh[4], zpl[4], zph[4], x[4], y[4], z[4], inv[4];
+    for (int i = 0; i < 4; i++) {
+        xl[i] = b.var(2 + 2 * i), xh[i] = b.var(3 + 2 * i), yl[i] = b.var(10 + 2 * i), yh[i] = b.var(11 + 2 * i);
+        zl[i] = b.var(18 + 5 * i), zh[i] = b.var(19 + 5 * i), zpl[i] = b.var(38 + 2 * i), zph[i] = b.var(39 + 2 * i), inv[i] = b.var(50 + i);
+        x[i] = xl[i] + xh[i] * 65536, y[i] = yl[i] + yh[i] * 65536, z[i] = zl[i] + zh[i] * 65536;
+    }
+    const Expr add = b.var(46), sub = b.var(47), mul = b.var(48), div = b.var(49), ok = add + sub + mul + div;
+    for (const Expr& f : {add, sub, mul, div, ok}) b.assert_zero(f * (f - 1));
+    auto ext_mul = [&](const Expr* p, const Expr* q, Expr* r) {   // (p q) mod (X^4 - 11)
+        for (int k = 0; k < 4; k++) {
+            Expr lo = b.constant(0), hi = b.constant(0);
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++) {
+                    if (i + j == k) lo = lo + p[i] * q[j];
+                    if (i + j == k + 4) hi = hi + p[i] * q[j];
+                }
+            r[k] = lo + hi * (int64_t)native::W;
+        }
+    };
+    Expr xy[4], xi[4], yi[4];
+    ext_mul(x, y, xy), ext_mul(x, inv, xi), ext_mul(y, inv, yi);
+    for (int i = 0; i < 4; i++) {
+        b.assert_zero(add * (z[i] - x[i] - y[i]));
+        b.assert_zero(sub * (z[i] - x[i] + y[i]));
+        b.assert_zero(mul * (z[i] - xy[i]));
+        b.assert_zero(div * (z[i] - xi[i]));
+        b.assert_zero(div * (yi[i] - (i == 0 ? 1 : 0)));
+        canonical_word(b, ok, zl[i], zh[i], b.var(20 + 5 * i), b.var(21 + 5 * i), b.var(22 + 5 * i));
+    }
+    b.push_interaction(NATIVE_EXT_REQ_BUS, {ts, base, sub + mul * 2 + div * 3}, ok, Kind::Receive);
+    const Expr two = b.constant(2);
+    for (int i = 0; i < 4; i++) {
+        word_access(b, ok, ok, two, base + i, xl[i], xh[i], xl[i], xh[i], ts + 5, b.var(54 + 3 * i), b.var(55 + 3 * i), b.var(56 + 3 * i));
+        word_access(b, ok, ok, two, base + (4 + i), yl[i], yh[i], yl[i], yh[i], ts + 5, b.var(66 + 3 * i), b.var(67 + 3 * i), b.var(68 + 3 * i));
+        word_access(b, ok, ok, two, base + (8 + i), zpl[i], zph[i], zl[i], zh[i], ts + 5, b.var(78 + 3 * i), b.var(79 + 3 * i), b.var(80 + 3 * i));
+    }
+}
+
+// castf chip: AirBuilder(CASTF_WIDTH, 0), ONE row per call (a7 = 11).  Columns: ts | base | limb[4] (8, 8, 8, 6 bits: OpenVM's CastFCoreAir) |
+// limb3_x4 (= 4 limb_3: a byte, so limb_3 < 64) | op_lo op_hi (the output word before) | (prev_ts gap_lo gap_hi) of the read of word `base`
+// and of the write of word `base + 1` | ok.  The input word's halves ARE limb_0 + 256 limb_1 and limb_2 + 256 limb_3: it lies below 2^30.
+inline void castf_vm_air(AirBuilder& b) {
+    const Expr ts = b.var(0), base = b.var(1), l0 = b.var(2), l1 = b.var(3), l2 = b.var(4), l3 = b.var(5), l3x4 = b.var(6), op_lo = b.var(7), op_hi = b.var(8), ok = b.var(15);
+    b.assert_zero(ok * (ok - 1));
+    b.assert_zero(l3x4 - l3 * 4);
+    const Expr lo = l0 + l1 * 256, hi = l2 + l3 * 256, zero = b.constant(0), two = b.constant(2);
+    b.push_interaction(CASTF_REQ_BUS, {ts, base}, ok, Kind::Receive);
+    word_access(b, ok, ok, two, base, lo, hi, lo, hi, ts + 5, b.var(9), b.var(10), b.var(11));
+    word_access(b, ok, ok, two, base + 1, op_lo, op_hi, lo, hi, ts + 5, b.var(12), b.var(13), b.var(14));
+    b.push_interaction(BITWISE_BUS, {l0, l1, zero, zero}, ok, Kind::Send);
+    b.push_interaction(BITWISE_BUS, {l2, l3, zero, zero}, ok, Kind::Send);
+    b.push_interaction(BITWISE_BUS, {l3x4, zero, zero, zero}, ok, Kind::Send);
+}
+
 // leaf chip: AirBuilder(LEAF_WIDTH, 0).  Columns: as blk | init[8] | fin[8] | fin_ts[4] | h_init[8] | h_fin[8] | ok | gap_lo gap_hi |
 // blk_lo blk_hi.  One row per touched block of 4 words (cells 2 j, 2 j + 1 = the halves of word j), strictly increasing
 // label = as 2^26 + blk; padding rows carry as = 1.
@@ -660,7 +770,7 @@ inline void connector_air(AirBuilder& b) {
 // ---- the segment's AIR set (order fixed: it is part of the verifying key) ----
 enum AirId : unsigned {
     A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
-    A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, A_INT256, A_INT256_IO, A_MUL256, A_CMP256, A_SHIFT256, N_STATIC_AIRS
+    A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, A_INT256, A_INT256_IO, A_MUL256, A_CMP256, A_SHIFT256, A_NATIVE_ARITH, A_NATIVE_EXT, A_CASTF, N_STATIC_AIRS
 };
 // the modular extension brings two chips per configured modulus (openvm.toml `supported_moduli`): ids A_MODMUL(i), A_MODMUL_IO(i)
 constexpr unsigned MAX_MODULI = 8, MAX_CURVES = 4, MAX_FP2 = 2, N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES + 2 * MAX_FP2;
@@ -735,6 +845,9 @@ inline AirShape build_air(unsigned id) {
         case A_MUL256: make(int256::MUL_VM_WIDTH, 0, 0, [](AirBuilder& b) { int256::mul256_vm_air(b, BITWISE_BUS, RANGE_TUPLE_BUS, INT256_WORD_BUS); }); break;
         case A_CMP256: make(int256::CMP_VM_WIDTH, 0, 0, [](AirBuilder& b) { int256::cmp256_vm_air(b, BITWISE_BUS, INT256_WORD_BUS); }); break;
         case A_SHIFT256: make(int256::SH_VM_WIDTH, 0, 0, [](AirBuilder& b) { int256::shift256_vm_air(b, BITWISE_BUS, INT256_WORD_BUS); }); break;
+        case A_NATIVE_ARITH: make(NATIVE_ARITH_WIDTH, 0, 0, native_arith_air); break;
+        case A_NATIVE_EXT: make(NATIVE_EXT_WIDTH, 0, 0, native_ext_air); break;
+        case A_CASTF: make(CASTF_WIDTH, 0, 0, castf_vm_air); break;
         default:
             if (id >= A_ALU && id <= A_JALR) {
                 const uint32_t cls = id - A_ALU;

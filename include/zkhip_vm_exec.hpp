@@ -92,6 +92,12 @@ struct SegmentCaps {
     std::vector<zkhip::modular::U256> moduli;   // the modular extension: chips A_MODMUL(i), A_MODMUL_IO(i) per modulus
     std::vector<zkhip::ecc::Curve> curves;      // the ecc extension: chips A_EC(i), A_EC_IO(i) per curve
     std::vector<zkhip::modular::U256> fp2_moduli;   // the fp2 extension: chips A_FP2(i), A_FP2_IO(i) per field
+    // `[app_vm_config.native]`: the native field and extension chips; `[app_vm_config.castf]`: the castf chip; `[app_vm_config.pairing]`
+    // brings no chip (OpenVM's pairing extension is a phantom sub-executor: the final-exponentiation hint, include/zkhip_vm.hpp phantom kind 2)
+    using NativeExt = zkhip::native::Enabled;
+    NativeExt ext;
+    bool native() const { return pos(vmc::A_NATIVE_ARITH) >= 0; }
+    bool castf() const { return pos(vmc::A_CASTF) >= 0; }
     // heights for segments of about 2^log_frame instructions of an ordinary instruction mix
     // log_keccak: 0 = the app has no keccak extension (22 chips); otherwise the rows of the Keccak-f chip (24 per permutation call,
     // at least 32).  A wide chip costs every segment proof and every leaf circuit its 2634 openings per query, used or not, so it is
@@ -103,7 +109,7 @@ struct SegmentCaps {
     static SegmentCaps for_frame(unsigned log_frame, unsigned log_program, unsigned log_keccak = 0, unsigned log_sha256 = 0,
                                  const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_modmul = 0, unsigned log_int256 = 0,
                                  const std::vector<zkhip::ecc::Curve>& curves = {}, unsigned log_ec = 0,
-                                 const std::vector<zkhip::modular::U256>& fp2_moduli = {}) {
+                                 const std::vector<zkhip::modular::U256>& fp2_moduli = {}, const NativeExt& ext = NativeExt()) {
         SegmentCaps c;
         for (unsigned a = 0; a < vmc::N_BASE_AIRS; a++) c.ids.push_back(a);
         auto sub = [&](unsigned d) { return log_frame > d + 2 ? log_frame - d : 2u; };
@@ -147,6 +153,14 @@ struct SegmentCaps {
             c.ids.push_back(vmc::A_FP2(i)), c.ids.push_back(vmc::A_FP2_IO(i));
             c.log_height[vmc::A_FP2(i)] = std::max(log_ec, 1u), c.log_height[vmc::A_FP2_IO(i)] = c.log_height[vmc::A_FP2(i)] + (zkhip::modular::words_of(fp2_moduli[i]) == 12 ? 7 : 6);
         }
+        // native / castf: one call per row; a call is an ecall plus the instructions that set it up (at least a0, a1, a7), so 2^(f - 2)
+        // rows hold whatever a frame of 2^f instructions can ask for
+        c.ext = ext;
+        if (ext.native) {
+            c.ids.push_back(vmc::A_NATIVE_ARITH), c.ids.push_back(vmc::A_NATIVE_EXT);
+            c.log_height[vmc::A_NATIVE_ARITH] = sub(2), c.log_height[vmc::A_NATIVE_EXT] = sub(3);
+        }
+        if (ext.castf) c.ids.push_back(vmc::A_CASTF), c.log_height[vmc::A_CASTF] = sub(3);
         c.n_airs = (unsigned)c.ids.size();
         return c;
     }
@@ -173,6 +187,14 @@ struct SegmentRecords {
     std::vector<uint32_t> ec_records[vmc::MAX_CURVES], ec_ts[vmc::MAX_CURVES], ecio_rows[vmc::MAX_CURVES];
     // fp2 calls per field: op | a | b (33 words; a division's a slot holds the quotient) and the timestamp per call; the adapter's rows
     std::vector<uint32_t> fp2_records[vmc::MAX_FP2], fp2_ts[vmc::MAX_FP2], fp2io_rows[vmc::MAX_FP2];
+    // native field calls: op | b | c | previous result word | word pointer | ts | previous timestamps of the three words (9 words per call)
+    // native extension calls: op | x[4] | y[4] | previous result words [4] | word pointer | ts | previous timestamps of the twelve words (27 words)
+    // castf calls: x | previous output word | word pointer | ts | previous timestamps of the two words (6 words)
+    static constexpr size_t NAT_RECORD = 9, NEXT_RECORD = 27, CASTF_RECORD = 6;
+    std::vector<uint32_t> nat_records, next_records, castf_records;
+    size_t n_nat() const { return nat_records.size() / NAT_RECORD; }
+    size_t n_next() const { return next_records.size() / NEXT_RECORD; }
+    size_t n_castf() const { return castf_records.size() / CASTF_RECORD; }
     uint32_t pc_start = 0, pc_end = 0, ts_end = 0;
     Digest root_init{}, root_final{};
     size_t n_instr = 0;
@@ -185,7 +207,7 @@ struct SegmentRecords {
     void clear() {
         core.clear();
         for (auto* v : {&f_x, &f_y, &f_z, &f_rdprev, &f_pcinc, &f_pts1, &f_pts2, &f_pts3, &ls_ts, &ls_base, &ls_imm, &ls_pts, &ecall_rows, &leaf_rows, &merkle_rows,
-                        &p2_inputs, &kk_states, &kk_ts, &kio_rows, &sha_blocks, &sha_ts, &shaio_rows, &i256_records, &i256_ts, &i256io_rows, &mul256_records, &mul256_ts, &cmp256_records, &cmp256_ts, &sh256_records, &sh256_ts})
+                        &p2_inputs, &kk_states, &kk_ts, &kio_rows, &sha_blocks, &sha_ts, &shaio_rows, &i256_records, &i256_ts, &i256io_rows, &mul256_records, &mul256_ts, &cmp256_records, &cmp256_ts, &sh256_records, &sh256_ts, &nat_records, &next_records, &castf_records})
             v->clear();
         for (unsigned i = 0; i < vmc::MAX_MODULI; i++) mm_records[i].clear(), mm_ts[i].clear(), mmio_rows[i].clear();
         for (unsigned i = 0; i < vmc::MAX_CURVES; i++) ec_records[i].clear(), ec_ts[i].clear(), ecio_rows[i].clear();
@@ -204,6 +226,7 @@ public:
         m_.set_moduli(caps.moduli);
         m_.set_curves(caps.curves);
         m_.set_fp2_moduli(caps.fp2_moduli);
+        m_.set_native(caps.ext);
         dec_.reserve(exe.program.size());
         for (size_t k = 0; k < exe.program.size(); k++) dec_.push_back(vmc::decode(exe.program[k], exe.pc_base + 4 * (uint32_t)k));
         mem_lo_blk_ = exe.data_base / 16;
@@ -232,6 +255,9 @@ public:
         if (call == 5) return 3 * (i < caps_.moduli.size() ? nw(caps_.moduli[i]) : 8u);
         if (call == 7) return 6 * (i < caps_.curves.size() ? nw(caps_.curves[i].p) : 8u);
         if (call == 8) return 6 * (i < caps_.fp2_moduli.size() ? nw(caps_.fp2_moduli[i]) : 8u);
+        if (call == zkhip::native::CALL_ARITH) return 3;
+        if (call == zkhip::native::CALL_EXT) return 12;
+        if (call == zkhip::native::CALL_CASTF) return 2;
         return 24;   // (int256)
     }
     bool run_segment(SegmentRecords& r) {
@@ -264,7 +290,7 @@ public:
                 if (d.wr_rd) want(1, d.rd);
                 if (d.cls == vmc::C_LS) want(2, ((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) >> 2);
                 if (d.cls == vmc::C_ECALL) want(1, 11), want(3, m_.reg(11) & 7u);
-                if (d.cls == vmc::C_ECALL && m_.reg(17) >= 3 && m_.reg(17) <= 8) {
+                if (d.cls == vmc::C_ECALL && m_.reg(17) >= 3 && m_.reg(17) <= 11) {
                     const uint32_t n_words = m_.reg(17) == 3 ? 50 : call_words(m_.reg(17), m_.reg(11));
                     for (uint32_t w = m_.reg(10) >> 2; w < (m_.reg(10) >> 2) + n_words; w += (w & 3u) ? 4 - (w & 3u) : 4) want(2, w);
                 }
@@ -298,6 +324,10 @@ public:
             if (d.cls == vmc::C_ECALL && m_.reg(17) == 8 && ((m_.reg(11) & 7u) >= caps_.fp2_moduli.size() || (m_.reg(11) >> 3) >= zkhip::fp2::N_OPS))
                 throw Error("the guest calls the fp2 intrinsic for field " + std::to_string(m_.reg(11) & 7u) + " but the app's openvm.toml lists " +
                             std::to_string(caps_.fp2_moduli.size()) + " fp2 fields");
+            if (d.cls == vmc::C_ECALL && (m_.reg(17) == zkhip::native::CALL_ARITH || m_.reg(17) == zkhip::native::CALL_EXT) && !caps_.native())
+                throw Error("the guest calls a native field intrinsic but the app's openvm.toml does not enable the native extension");
+            if (d.cls == vmc::C_ECALL && m_.reg(17) == zkhip::native::CALL_CASTF && !caps_.castf())
+                throw Error("the guest calls the castf intrinsic but the app's openvm.toml does not enable the castf extension");
             if (r.n_instr + 1 > caps_.rows(vmc::A_FRAME) || n_cls[d.cls] + 1 > caps_.rows(vmc::A_ALU + d.cls) ||
                 blk_.size() + new_blocks > caps_.rows(vmc::A_LEAF) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 3 && 24 * (r.n_keccak() + 1) > caps_.rows(vmc::A_KECCAK)) ||
@@ -306,6 +336,9 @@ public:
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 7 && r.ec_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_EC(m_.reg(11) & 7u))) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 8 && r.fp2_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_FP2(m_.reg(11) & 7u))) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 6 && (m_.reg(11) == 5 ? r.mul256_ts.size() : m_.reg(11) > 8 ? r.sh256_ts.size() : m_.reg(11) > 5 ? r.cmp256_ts.size() : r.i256_ts.size()) + 1 > caps_.rows(vmc::A_INT256)) ||
+                (d.cls == vmc::C_ECALL && m_.reg(17) == zkhip::native::CALL_ARITH && r.n_nat() + 1 > caps_.rows(vmc::A_NATIVE_ARITH)) ||
+                (d.cls == vmc::C_ECALL && m_.reg(17) == zkhip::native::CALL_EXT && r.n_next() + 1 > caps_.rows(vmc::A_NATIVE_EXT)) ||
+                (d.cls == vmc::C_ECALL && m_.reg(17) == zkhip::native::CALL_CASTF && r.n_castf() + 1 > caps_.rows(vmc::A_CASTF)) ||
                 path_nodes_.size() + new_nodes > caps_.rows(vmc::A_MERKLE) ||
                 2 * (blk_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
                 if (r.n_instr == 0) throw Error("segment heights too small for a single instruction");
@@ -340,6 +373,13 @@ public:
                 a1 = m_.reg(11);
                 if ((y & 3u) || (uint64_t)y + 4 * cw > (1ull << 30)) throw Error("ecc / fp2 buffer must be word-aligned and below 2^30");
                 for (uint32_t j = 0; j < cw; j++) ec_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
+            }
+            uint32_t nat_in[12];
+            const uint32_t nat_words = d.cls == vmc::C_ECALL && x >= zkhip::native::CALL_ARITH && x <= zkhip::native::CALL_CASTF ? call_words(x, 0) : 0u;
+            if (nat_words) {
+                a1 = m_.reg(11);
+                if ((y & 3u) || (uint64_t)y + 4 * nat_words > (1ull << 30)) throw Error("native / castf buffer must be word-aligned and below 2^30");
+                for (uint32_t j = 0; j < nat_words; j++) nat_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
             }
             // snapshot the blocks this instruction is going to change
             if (d.wr_rd) (void)block_of(1, d.rd);
@@ -451,6 +491,21 @@ public:
                         sr[W + 6] = pts, sr[W + 7] = gap & 0xffffu, sr[W + 8] = gap >> 16;
                         r.fp2io_rows[fi].insert(r.fp2io_rows[fi].end(), sr, sr + IOW);
                     }
+                }
+                if (nat_words) {   // native field / extension / castf: one record per call; the chip's row is made on the device
+                    row[x == zkhip::native::CALL_ARITH ? 34 : x == zkhip::native::CALL_EXT ? 35 : 36] = 1, row[28] = (y & 255u) >> 2;
+                    if (x != zkhip::native::CALL_CASTF) {
+                        row[17] = a1;
+                        const uint32_t pts = read_word(1, 11, a1, ts + 4), gap = ts + 4 - pts - 1;
+                        row[21] = pts, row[22] = gap & 0xffffu, row[23] = gap >> 16;
+                    }
+                    const uint32_t n_rd = x == zkhip::native::CALL_ARITH ? 2 : x == zkhip::native::CALL_EXT ? 8 : 1, n_wr = nat_words - n_rd;
+                    auto& rec = x == zkhip::native::CALL_ARITH ? r.nat_records : x == zkhip::native::CALL_EXT ? r.next_records : r.castf_records;
+                    if (x != zkhip::native::CALL_CASTF) rec.push_back(a1);
+                    rec.insert(rec.end(), nat_in, nat_in + nat_words);   // operands, then the result words as they were before
+                    rec.push_back(y >> 2), rec.push_back(ts);
+                    for (uint32_t k = 0; k < n_rd; k++) rec.push_back(read_word(2, (y >> 2) + k, nat_in[k], ts + 5));
+                    for (uint32_t k = 0; k < n_wr; k++) rec.push_back(write_word(2, (y >> 2) + n_rd + k, mem_word(y + 4 * (n_rd + k)), ts + 5));
                 }
                 if (x == 5) {
                     row[30] = 1, row[28] = (y & 255u) >> 2, row[17] = a1;

@@ -12,6 +12,7 @@
 //      (initial pc and memory root = the guest image's; final pc = 0 = exited with code 0; the public values' Merkle openings in the
 //      final root -- the `user_pvs_proof` of crates/types/src/proof.rs:52-67).
 #pragma once
+#include <cstdio>
 #include <fstream>
 #include <chrono>
 #include <condition_variable>
@@ -230,6 +231,12 @@ public:
                                           TUPLE_X, TUPLE_Y));
             check(zkhip_rows_tracegen(ctx_, up(r.fp2io_rows[i]), r.fp2io_rows[i].size() / iow, iow, H(vmc::A_FP2_IO(i)), T(vmc::A_FP2_IO(i)), nullptr));
         }
+        // ---- native field / extension / castf calls: ONE row per call, made on the device from the call's record
+        if (caps_.native()) {
+            check(zkhip_vm_native_arith_tracegen(ctx_, up(r.nat_records), r.n_nat(), H(vmc::A_NATIVE_ARITH), T(vmc::A_NATIVE_ARITH)));
+            check(zkhip_vm_native_ext_tracegen(ctx_, up(r.next_records), r.n_next(), H(vmc::A_NATIVE_EXT), T(vmc::A_NATIVE_EXT)));
+        }
+        if (caps_.castf()) check(zkhip_vm_castf_tracegen(ctx_, up(r.castf_records), r.n_castf(), H(vmc::A_CASTF), T(vmc::A_CASTF)));
         // ---- lookup multiplicities of the new chips, counted from the requesting columns
         auto pairs = [&](unsigned a, size_t cx, size_t cy, size_t n) {
             if (n) check(zkhip_bitwise_lookup_tracegen(ctx_, T(a) + cx * N(a), T(a) + cy * N(a), d_zeros_, n, 8, d_bw, 1));
@@ -251,6 +258,28 @@ public:
         if (n_ls) check(zkhip_range_tuple_counts_tracegen(ctx_, d_zeros_, T(vmc::A_LS) + 47 * NL, n_ls, TUPLE_X, TUPLE_Y, d_tup, 1));
         count(T(vmc::A_LS) + 40 * NL, n_ls), count(T(vmc::A_LS) + 41 * NL, n_ls, 4), count(T(vmc::A_LS) + 44 * NL, n_ls, 4);
         count(T(vmc::A_LS) + 44 * NL, n_ls), count(T(vmc::A_LS) + 41 * NL, n_ls);
+        // native chips: a canonical result word asks for (lo, hi, hi_gap) in the range table; every word access for its gap_lo there and for
+        // (0, gap_hi) in the range-tuple table; castf for its limbs as byte pairs
+        auto access = [&](unsigned a, size_t first, size_t n) {   // columns prev_ts gap_lo gap_hi from `first`
+            if (!n) return;
+            count(T(a) + (first + 1) * N(a), n);
+            check(zkhip_range_tuple_counts_tracegen(ctx_, d_zeros_, T(a) + (first + 2) * N(a), n, TUPLE_X, TUPLE_Y, d_tup, 1));
+        };
+        if (caps_.native()) {
+            const size_t na = r.n_nat(), ne = r.n_next();
+            if (na) for (size_t q : {6, 7, 8}) count(T(vmc::A_NATIVE_ARITH) + q * N(vmc::A_NATIVE_ARITH), na);
+            for (size_t q : {18, 21, 24}) access(vmc::A_NATIVE_ARITH, q, na);
+            if (ne)
+                for (size_t i = 0; i < 4; i++)
+                    for (size_t q : {18 + 5 * i, 19 + 5 * i, 20 + 5 * i}) count(T(vmc::A_NATIVE_EXT) + q * N(vmc::A_NATIVE_EXT), ne);
+            for (size_t k = 0; k < 12; k++) access(vmc::A_NATIVE_EXT, 54 + 3 * k, ne);
+        }
+        if (caps_.castf()) {
+            const size_t nc = r.n_castf();
+            pairs(vmc::A_CASTF, 2, 3, nc), pairs(vmc::A_CASTF, 4, 5, nc);
+            if (nc) check(zkhip_bitwise_lookup_tracegen(ctx_, T(vmc::A_CASTF) + 6 * N(vmc::A_CASTF), d_zeros_, d_zeros_, nc, 8, d_bw, 1));
+            access(vmc::A_CASTF, 9, nc), access(vmc::A_CASTF, 12, nc);
+        }
         {
             // the few range requests of the ecall, leaf and connector chips, listed on the host
             std::vector<uint32_t> misc{r.ts_end & 0xffffu, 8 * (r.ts_end >> 16), r.ts_end >> 16}, tup_y, bw_x, bw_y;
@@ -260,9 +289,9 @@ public:
                     for (uint32_t v : {row[17] * 8192, row[17], row[22], row[25]}) misc.push_back(v);
                     tup_y.push_back(row[23]), tup_y.push_back(row[26]);
                 }
-                if (row[30] || row[31] || row[32] || row[33]) misc.push_back(row[22]), tup_y.push_back(row[23]);   // modmul / int256 / ecc / fp2: the a1 read
+                if (row[30] || row[31] || row[32] || row[33] || row[34] || row[35]) misc.push_back(row[22]), tup_y.push_back(row[23]);   // modmul / int256 / ecc / fp2 / native: the a1 read
                 if (row[16]) bw_x.push_back(row[10]), bw_y.push_back(row[11]), bw_x.push_back(row[12]), bw_y.push_back(row[13]);
-                if (row[27] || row[29] || row[30] || row[31] || row[32] || row[33])
+                if (row[27] || row[29] || row[30] || row[31] || row[32] || row[33] || row[34] || row[35] || row[36])
                     for (uint32_t v : {row[28] * 1024, row[28], row[9] * 1024}) misc.push_back(v);
             }
             for (size_t i = 0; i < r.kio_rows.size() / vmc::KECCAK_IO_WIDTH; i++) {
@@ -412,7 +441,8 @@ struct SegmentShapes {
         SegmentShapes s;
         const bool hash = full.keccak() || full.sha256();
         const bool more = full.int256() || !full.moduli.empty() || !full.curves.empty() || !full.fp2_moduli.empty();
-        const SegmentCaps base = SegmentCaps::for_frame(log_frame, log_program);
+        // (the native / castf chips -- 27 + 90 + 16 columns -- are part of every shape of an app that enables them)
+        const SegmentCaps base = SegmentCaps::for_frame(log_frame, log_program, 0, 0, {}, 0, 0, {}, 0, {}, full.ext);
         if (with_lean) {
             const SegmentCaps l = lean_caps(base, log_frame);
             bool smaller = false;
@@ -421,7 +451,8 @@ struct SegmentShapes {
         }
         if (hash || more) s.caps.push_back(base);
         if (hash && more)
-            s.caps.push_back(SegmentCaps::for_frame(log_frame, log_program, full.keccak() ? full.log_height[vmc::A_KECCAK] : 0, full.sha256() ? full.log_height[vmc::A_SHA256] : 0));
+            s.caps.push_back(SegmentCaps::for_frame(log_frame, log_program, full.keccak() ? full.log_height[vmc::A_KECCAK] : 0, full.sha256() ? full.log_height[vmc::A_SHA256] : 0, {}, 0, 0,
+                                                    {}, 0, {}, full.ext));
         s.caps.push_back(full);
         for (size_t k = s.lean ? 1 : 0; k < s.caps.size(); k++)   // beside the lean one a shape shares every height with the full set
             for (unsigned id : s.caps[k].ids)
@@ -685,7 +716,15 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
                         queue.pop_front();
                     }
                     cv_push.notify_one();
-                    SegmentProof p = lane->prove(it.rec, /*self_verify=*/false);
+                    // a segment proof that fails (a refused trace check, the device self-check of zkhip_config.self_check, a device error)
+                    // is made once more from the same records before the run is given up; a second failure ends it
+                    SegmentProof p;
+                    try {
+                        p = lane->prove(it.rec, /*self_verify=*/false);
+                    } catch (const std::exception& e) {
+                        std::fprintf(stderr, "[zkhip flow] segment %zu failed (%s): proving it once more\n", it.index, e.what());
+                        p = lane->prove(it.rec, /*self_verify=*/false);
+                    }
                     tree.push(it.index, p.proof, p.shape);
                     std::lock_guard<std::mutex> lk(mu);
                     if (proofs.size() <= it.index) proofs.resize(it.index + 1);
@@ -923,13 +962,29 @@ inline std::vector<zkhip::modular::U256> config_moduli(const std::string& path_a
     }
     return out;
 }
+// `[app_vm_config.native]`, `[app_vm_config.castf]`, `[app_vm_config.pairing]` (crates/circuits/batch-circuit/openvm.toml:16,24,25;
+// bundle-circuit/openvm.toml:16,18; chunk-circuit/openvm.toml:35): include/zkhip_native.hpp
+inline zkhip::native::Enabled config_native(const std::string& path_app_config) {
+    zkhip::native::Enabled e;
+    e.native = config_has_section(path_app_config, "[app_vm_config.native]");
+    e.castf = config_has_section(path_app_config, "[app_vm_config.castf]");
+    e.pairing = config_has_section(path_app_config, "[app_vm_config.pairing]");
+    return e;
+}
+// the chips of an app: every section of its openvm.toml at the heights of a 2^log_frame frame (no section is ignored)
+inline SegmentCaps config_caps(const std::string& path_app_config, unsigned log_frame, unsigned log_program) {
+    return SegmentCaps::for_frame(log_frame, log_program, keccak_log_rows(path_app_config, log_frame), sha256_log_rows(path_app_config, log_frame), config_moduli(path_app_config),
+                                  log_frame > 8 ? log_frame - 8 : 1, int256_log_rows(path_app_config, log_frame), config_curves(path_app_config), ec_log_rows(log_frame),
+                                  config_fp2_moduli(path_app_config), config_native(path_app_config));
+}
 inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
                                         bool keep_segments = false, unsigned inflight = 2, unsigned log_keccak = 0, unsigned log_sha256 = 0,
                                         const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_int256 = 0,
                                         const std::vector<zkhip::ecc::Curve>& curves = {}, const std::vector<zkhip::modular::U256>& fp2_moduli = {},
-                                        const scroll_zkvm_hip::FlowOptions& flow = scroll_zkvm_hip::FlowOptions::from_env()) {
+                                        const scroll_zkvm_hip::FlowOptions& flow = scroll_zkvm_hip::FlowOptions::from_env(),
+                                        const zkhip::native::Enabled& native_ext = zkhip::native::Enabled()) {
     const SegmentCaps caps = SegmentCaps::for_frame(log_frame, vm_log2_ceil(exe.program.size()), log_keccak, log_sha256, moduli, log_frame > 8 ? log_frame - 8 : 1, log_int256,
-                                                    curves, ec_log_rows(log_frame), fp2_moduli);
+                                                    curves, ec_log_rows(log_frame), fp2_moduli, native_ext);
     // a segment is proven under the smallest SHAPE (set of chips) that holds what it used (ZKHIP_ONE_SHAPE=1: always the full set, as round 3)
     const SegmentShapes shapes = flow.one_shape ? SegmentShapes::only(caps) : SegmentShapes::of(caps, log_frame, vm_log2_ceil(exe.program.size()), flow.lean_shape);
     // the segments of ONE task spread over the GPUs of the node -- `inflight` lanes per listed device, each device its
@@ -1015,11 +1070,7 @@ public:
         }
         p.params_ = read_app_config(cfg.path_app_config);
         p.log_frame_ = log_frame;
-        p.caps_ = zkhip_vm::SegmentCaps::for_frame(log_frame, zkhip_vm::vm_log2_ceil(p.exe_.program.size()), zkhip_vm::keccak_log_rows(cfg.path_app_config, log_frame),
-                                                   zkhip_vm::sha256_log_rows(cfg.path_app_config, log_frame), zkhip_vm::config_moduli(cfg.path_app_config),
-                                                   log_frame > 8 ? log_frame - 8 : 1, zkhip_vm::int256_log_rows(cfg.path_app_config, log_frame),
-                                                   zkhip_vm::config_curves(cfg.path_app_config), zkhip_vm::ec_log_rows(log_frame),
-                                                   zkhip_vm::config_fp2_moduli(cfg.path_app_config));
+        p.caps_ = zkhip_vm::config_caps(cfg.path_app_config, log_frame, zkhip_vm::vm_log2_ceil(p.exe_.program.size()));
         return p;
     }
     void reset() {   // mod.rs:106-108: releases the device-resident keys, circuits and workspaces
@@ -1038,7 +1089,7 @@ public:
     // mod.rs:312-338
     uint64_t execute_and_check(const ProvingTask& task) const {
         try {
-            return zkhip_vm::execute_guest(exe_, task.build_guest_input(), 0, nullptr, 0, caps_.moduli, caps_.curves, caps_.fp2_moduli).total_cycle;
+            return zkhip_vm::execute_guest(exe_, task.build_guest_input(), 0, nullptr, 0, caps_.moduli, caps_.curves, caps_.fp2_moduli, caps_.ext).total_cycle;
         } catch (const zkhip_vm::Error& e) {
             throw Error(Error::GenProof, e.what());
         }

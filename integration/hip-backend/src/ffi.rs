@@ -413,6 +413,9 @@ extern "C" {
     pub fn zkhip_int256_shift_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32, d_bitwise_trace: *mut u32) -> c_int;
     pub fn zkhip_vm_shift256_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
                                       d_bitwise_trace: *mut u32) -> c_int;
+    pub fn zkhip_vm_native_arith_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;
+    pub fn zkhip_vm_native_ext_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;
+    pub fn zkhip_vm_castf_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32) -> c_int;
     pub fn zkhip_vm_mul256_tracegen(ctx: *mut zkhip_ctx, d_records: *const u32, d_ts: *const u32, n: usize, log_height: c_uint, d_trace: *mut u32,
                                     d_bitwise_trace: *mut u32, d_tuple_counts: *mut u32, size_x: u32, size_y: u32) -> c_int;
     // the `_x` forms of the limb chips: n_limbs = 32 or 48 (BLS12-381's base field, Fp2 and G1 of the batch circuit), n_words = n_limbs / 4

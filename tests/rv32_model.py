@@ -131,6 +131,28 @@ def _sqrts(a, p):
     yield r
 
 
+BABYBEAR = 2013265921
+
+
+def ext4_mul(a, b):
+    """(a b) mod (X^4 - 11) over BabyBear, schoolbook with Python integers"""
+    t = [0] * 7
+    for i in range(4):
+        for j in range(4):
+            t[i + j] += a[i] * b[j]
+    return [(t[k] + 11 * (t[k + 4] if k < 3 else 0)) % BABYBEAR for k in range(4)]
+
+
+def ext4_pow(a, e):
+    r = [1, 0, 0, 0]
+    while e:
+        if e & 1:
+            r = ext4_mul(r, a)
+        a = ext4_mul(a, a)
+        e >>= 1
+    return r
+
+
 def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_bytes=1 << 20, data=b"", max_instr=10**7, moduli=(), curves=(), fp2=()):
     """Independent interpreter.  Returns dict(instret, pvs (32 bytes), exit_code, records)."""
     x = [0] * 32
@@ -406,6 +428,28 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                 assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem)
                 buf = list(struct.unpack_from("<24I", mem, off))
                 struct.pack_into("<8I", mem, off, *sha256_compress(buf[:8], buf[8:]))
+            elif call in (9, 10):   # native field (3 words: a | b | r) / its quartic extension X^4 = 11 (12 words); a1 = op: add sub mul div
+                off = rr(10) - data_base
+                fop = rr(11)
+                nwd = 3 if call == 9 else 12
+                assert off % 4 == 0 and 0 <= off and off + 4 * nwd <= len(mem) and fop < 4
+                wds = list(struct.unpack_from("<%dI" % nwd, mem, off))
+                if call == 9:
+                    a_, b_ = wds[0] % BABYBEAR, wds[1] % BABYBEAR
+                    r_ = [(a_ + b_) % BABYBEAR, (a_ - b_) % BABYBEAR, a_ * b_ % BABYBEAR, a_ * pow(b_, -1, BABYBEAR) % BABYBEAR if fop == 3 else 0][fop]
+                    struct.pack_into("<I", mem, off + 8, r_)
+                else:
+                    a_, b_ = [v % BABYBEAR for v in wds[:4]], [v % BABYBEAR for v in wds[4:8]]
+                    if fop == 3:
+                        b_ = ext4_pow(b_, BABYBEAR ** 4 - 2)   # the inverse by Fermat: independent of the C++ norm formula
+                    r_ = ext4_mul(a_, b_) if fop in (2, 3) else [(u + (v if fop == 0 else -v)) % BABYBEAR for u, v in zip(a_, b_)]
+                    struct.pack_into("<4I", mem, off + 32, *r_)
+            elif call == 11:   # castf: the word at a0 (below 2^30) copied to the word at a0 + 4
+                off = rr(10) - data_base
+                assert off % 4 == 0 and 0 <= off and off + 8 <= len(mem)
+                v, = struct.unpack_from("<I", mem, off)
+                assert v < 1 << 30
+                struct.pack_into("<I", mem, off + 4, v)
             else:
                 raise ValueError("ecall %d" % call)
         else:

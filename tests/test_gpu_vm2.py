@@ -98,6 +98,12 @@ def device_traces(zk, rec, prog, H):
         T[v2.A_FP2(i)] = zk.fp2_tracegen(p_, D(rec["fp2_records_%d" % i]) if n_f else None, n_f, H[v2.A_FP2(i)], d_bw, d_tup, v2.SX, v2.SY,
                                          t_ts=D(rec["fp2_ts_%d" % i]) if n_f else torch.zeros(1, dtype=torch.int32, device=dev))
         T[v2.A_FP2_IO(i)] = zk.rows_tracegen(D(rec["fp2io_rows_%d" % i]), len(rec["fp2io_rows_%d" % i]) // v2.EC_IO_WIDTH, v2.EC_IO_WIDTH, H[v2.A_FP2_IO(i)])
+    n_nat, n_next, n_cf = len(rec["nat_records"]) // 9, len(rec["next_records"]) // 27, len(rec["castf_records"]) // 6
+    if v2.A_NATIVE_ARITH in H.ids:   # native chips: ONE row per call, made on the device from the call's record
+        T[v2.A_NATIVE_ARITH] = zk.vm_native_tracegen("arith", D(rec["nat_records"]) if n_nat else None, n_nat, H[v2.A_NATIVE_ARITH])
+        T[v2.A_NATIVE_EXT] = zk.vm_native_tracegen("ext", D(rec["next_records"]) if n_next else None, n_next, H[v2.A_NATIVE_EXT])
+    if v2.A_CASTF in H.ids:
+        T[v2.A_CASTF] = zk.vm_native_tracegen("castf", D(rec["castf_records"]) if n_cf else None, n_cf, H[v2.A_CASTF])
     n, nls = len(rec["f_x"]), len(rec["ls_case"])
     zeros = torch.zeros(max(n, nls, 64), dtype=torch.int32, device=dev)
     NF, NL = 1 << H[v2.A_FRAME], 1 << H[v2.A_LS]
@@ -118,6 +124,33 @@ def device_traces(zk, rec, prog, H):
         if not nls:
             continue
         d_rng = zk.range_counts_tracegen(col, 16, t_counts=d_rng, accumulate=True) if s == 1 else zk.range_counts_scaled_tracegen(col, s, 16, d_rng)
+    # the native chips' lookups, counted from their trace columns as the flow does (include/zkhip_vm_flow.hpp)
+    def col(a, q, cnt):
+        N_ = 1 << H[a]
+        return T[a][q * N_:q * N_ + cnt]
+
+    def access(a, first, cnt):
+        nonlocal d_rng
+        if cnt:
+            d_rng = zk.range_counts_tracegen(col(a, first + 1, cnt), 16, t_counts=d_rng, accumulate=True)
+            zk.range_tuple_counts_tracegen(zeros[:cnt], col(a, first + 2, cnt), v2.SX, v2.SY, t_counts=d_tup, accumulate=True)
+
+    if v2.A_NATIVE_ARITH in H.ids:
+        for q in (6, 7, 8):
+            if n_nat:
+                d_rng = zk.range_counts_tracegen(col(v2.A_NATIVE_ARITH, q, n_nat), 16, t_counts=d_rng, accumulate=True)
+        for q in (18, 21, 24):
+            access(v2.A_NATIVE_ARITH, q, n_nat)
+        for q in [18 + 5 * i + k for i in range(4) for k in range(3)]:
+            if n_next:
+                d_rng = zk.range_counts_tracegen(col(v2.A_NATIVE_EXT, q, n_next), 16, t_counts=d_rng, accumulate=True)
+        for k in range(12):
+            access(v2.A_NATIVE_EXT, 54 + 3 * k, n_next)
+    if v2.A_CASTF in H.ids and n_cf:
+        for qx, qy in ((2, 3), (4, 5)):
+            zk.bitwise_lookup_tracegen(col(v2.A_CASTF, qx, n_cf), col(v2.A_CASTF, qy, n_cf), zeros[:n_cf], 8, d_bw, accumulate=True)
+        zk.bitwise_lookup_tracegen(col(v2.A_CASTF, 6, n_cf), zeros[:n_cf], zeros[:n_cf], 8, d_bw, accumulate=True)
+        access(v2.A_CASTF, 9, n_cf), access(v2.A_CASTF, 12, n_cf)
     misc = [ts_end & 0xFFFF, 8 * (ts_end >> 16), ts_end >> 16]
     tup_y, bw_x, bw_y = [], [], []
     for row in rec["ecall_rows"].reshape(-1, v2.ECALL_WIDTH):
@@ -127,10 +160,10 @@ def device_traces(zk, rec, prog, H):
         if row[16]:
             bw_x += [int(row[10]), int(row[12])]
             bw_y += [int(row[11]), int(row[13])]
-        if row[30] or row[31] or row[32] or row[33]:
+        if row[30] or row[31] or row[32] or row[33] or row[34] or row[35]:
             misc += [int(row[22])]
             tup_y += [int(row[23])]
-        if row[27] or row[29] or row[30] or row[31] or row[32] or row[33]:
+        if row[27] or row[29] or row[30] or row[31] or row[32] or row[33] or row[34] or row[35] or row[36]:
             misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
     for row in rec["kio_rows"].reshape(-1, v2.KECCAK_IO_WIDTH):
         misc += [int(row[36]), int(row[39])]
@@ -461,6 +494,43 @@ def test_fp2_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * N_STMT:4 * N_STMT + 32]
     assert pv == bytes(model["pvs"]) and pv[:16] == pv[16:]                # y^2 == x^3 + 3 / (9 + u) at EIP-197's G2 generator
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
+
+
+def test_native_and_castf_guest_device_traces_and_one_proof(zk, ora, tmp_path):
+    """A guest running BabyBear arithmetic, its quartic extension and casts through the native intrinsics (`[app_vm_config.native]` +
+    `[app_vm_config.castf]`, the sections of the reference's batch and bundle circuits; 25 chips): device traces == CPU twins, proof bytes ==
+    the oracle's; the whole flow from the ELF at the reference's parameters' syntax: the root's public values are Python's."""
+    from test_vm_cpu import native_data, native_program
+
+    words, data = native_program(), native_data()
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, sections=("native", "castf"))
+    k = next(i for i, s in enumerate(segs) if len(s["nat_records"]))
+    inst = v2.segment_instance(segs[k], words, PC_BASE, H)
+    T = device_traces(zk, segs[k], v2.program_table(words, PC_BASE, H[0]), H)
+    assert len(inst) == len(T) == 25
+    for a, d in enumerate(inst):
+        assert (zk.download(T[a]).reshape(d["width"], -1) == d["trace"]).all(), "position %d" % a
+    pk = z.ProvingKey(zk, PARAMS, inst)
+    pvs = [d["pvs"] for d in inst]
+    proof = pk.prove(T, pvs)
+    assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+    assert proof == ora.stark_prove(PARAMS, inst).tobytes()
+    pk.close()
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words, data=data))
+    (tmp_path / "openvm.toml").write_text(pm.TOML.format(*PARAMS) + "\n[app_vm_config.castf]\n\n[app_vm_config.native]\n")
+    r = subprocess.run([pm.CLI, "prove-elf", str(exe), "-", str(tmp_path), str(tmp_path / "openvm.toml"), "8"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    model = rv.run(words, b"", data=data)
+    assert out["verified"] and out["total_cycles"] == model["instret"]
+    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * N_STMT:4 * N_STMT + 32]
+    assert pv == bytes(model["pvs"])
+    assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
+    # the same guest under an app without the sections has no proof
+    (tmp_path / "plain.toml").write_text(pm.TOML.format(*PARAMS))
+    r = subprocess.run([pm.CLI, "prove-elf", str(exe), "-", str(tmp_path), str(tmp_path / "plain.toml"), "8"], capture_output=True, text=True)
+    assert r.returncode != 0 and "native extension" in r.stderr
 
 
 def test_int256_guest_device_traces_and_one_proof(zk, ora, tmp_path):

@@ -440,3 +440,62 @@ def test_decode_table_against_an_independent_decoder(mixed):
                 assert f[1] == 11 and f[15] == 1
             elif opc == 0x73:
                 assert f[1] == 12 and f[3:6] == [10, 17, 10]
+
+
+def test_native_and_castf_intrinsics_are_part_of_the_statement(tmp_path):
+    """A guest that runs BabyBear arithmetic, its quartic extension and the cast to bytes through the native intrinsics under an app with
+    `[app_vm_config.native]` and `[app_vm_config.castf]` (the sections of the reference's batch and bundle circuits; 25 chips): the revealed
+    words are Python's integers'; every trace satisfies its AIR, every bus balances; a forged result, a non-canonical result word and a
+    cast of a value that is not below 2^30 are refused; an app without the sections refuses the guest."""
+    from test_vm_cpu import BABYBEAR, CASTF_VALUES, NATIVE_EXT_OPERANDS, NATIVE_OPERANDS, NATIVE_OPS, native_data, native_program
+
+    words, data = native_program(), native_data()
+    model = rv.run(words, b"", data=data)
+    pv = [int.from_bytes(bytes(model["pvs"])[4 * k:4 * k + 4], "little") for k in range(8)]
+    F = BABYBEAR
+    want = [[(b + c) % F, (b - c) % F, b * c % F, b * pow(c, -1, F) % F][op] for op, (b, c) in zip(NATIVE_OPS, NATIVE_OPERANDS)]
+    assert pv[:4] == want[:4] and pv[4] == want[4] ^ want[5] and want[4] == 0 and want[5] == (0x80000005 % F) * (0xFFFFFFFF % F) % F
+    x, y = NATIVE_EXT_OPERANDS[2]
+    assert pv[5] == (x[0] * y[0] + 11 * (x[1] * y[3] + x[2] * y[2] + x[3] * y[1])) % F       # the product's constant coefficient
+    xq, yq = NATIVE_EXT_OPERANDS[3]
+    assert pv[6] == 1 and xq == yq                                                             # x / x = 1
+    assert pv[7] == CASTF_VALUES[0] ^ CASTF_VALUES[1]
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, sections=("native", "castf"))
+    assert bytes.fromhex(info["public_values"]) == bytes(model["pvs"]) and info["total_cycle"] == model["instret"]
+    assert len(H.ids) == 25 and H.ids[-3:] == (v2.A_NATIVE_ARITH, v2.A_NATIVE_EXT, v2.A_CASTF)
+    assert sum(len(s["nat_records"]) for s in segs) == 9 * 6 and sum(len(s["next_records"]) for s in segs) == 27 * 5 and sum(len(s["castf_records"]) for s in segs) == 6 * 2
+    for k, rec in enumerate(segs):
+        inst = v2.segment_instance(rec, words, PC_BASE, H)
+        for d in inst:
+            assert air.quotient_chunks(d["program"]) <= 2
+            assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], k
+        assert v2.bus_imbalance(inst) == {}
+    k = next(i for i, s in enumerate(segs) if len(s["nat_records"]))
+    inst = v2.segment_instance(segs[k], words, PC_BASE, H)
+    pos = H.ids.index(v2.A_NATIVE_ARITH)
+    # a forged result: the chip's own constraints refuse it
+    forged = {n: (v.copy() if hasattr(v, "copy") else v) for n, v in inst[pos].items()}
+    forged["trace"] = inst[pos]["trace"].copy()
+    forged["trace"][6, 0] = (int(forged["trace"][6, 0]) + 1) % v2.P
+    assert air.check_trace(forged["program"], forged["trace"], forged["pvs"], None) != []
+    # the same residue written non-canonically (r + p, split into halves): the canonical-word constraints refuse it
+    r0 = int(inst[pos]["trace"][6, 0]) + (int(inst[pos]["trace"][7, 0]) << 16)
+    if r0 + F < 1 << 32:
+        nc = inst[pos]["trace"].copy()
+        nc[6, 0], nc[7, 0] = (r0 + F) & 0xFFFF, (r0 + F) >> 16
+        assert air.check_trace(inst[pos]["program"], nc, inst[pos]["pvs"], None) != []
+    # a record the executor did not write (another operand): the memory bus no longer balances
+    rec = {n: v.copy() for n, v in segs[k].items()}
+    rec["nat_records"][1] ^= 1
+    bad = v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
+    assert 1 in bad
+    # an app without the sections has no such intrinsic
+    with pytest.raises(AssertionError, match="does not enable the native extension"):
+        v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)
+    with pytest.raises(AssertionError, match="does not enable the castf extension"):
+        v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7, sections=("native",))
+    # a cast of 2^30 is no cast
+    import struct
+    big = data[:-16] + struct.pack("<2I", 1 << 30, 0) + data[-8:]
+    with pytest.raises(AssertionError, match="does not lie below 2\\^30"):
+        v2.dump_segments(tmp_path, rv.exe_bytes(words, data=big), b"", 7, sections=("native", "castf"))

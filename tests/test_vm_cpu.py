@@ -309,6 +309,50 @@ def fp2_data():
     return (el(BN254_G2Y) + el(BN254_G2Y) + z64 + el(BN254_G2X) + el(BN254_G2X) + z64 + z64 + el(BN254_G2X) + z64 + el((3, 0)) + el((9, 1)) + z64 + z64 * 3 + z64 * 3)
 
 
+
+# ---- the native / castf sections of the reference's batch and bundle circuits (crates/circuits/batch-circuit/openvm.toml:16,24;
+# bundle-circuit/openvm.toml:16,18): BabyBear arithmetic, its quartic extension, the cast of a field element to bytes ----
+BABYBEAR = 2013265921
+NATIVE_OPERANDS = [(5, BABYBEAR - 3), (7, 9), (BABYBEAR - 2, BABYBEAR - 5), (1000, 7),            # add (wraps), sub (negative), mul, div
+                   (BABYBEAR - 1, 1), (0x80000005, 0xFFFFFFFF)]                                    # add to the top canonical word p - 1 + ... ; operands that are not reduced
+NATIVE_OPS = [0, 1, 2, 3, 0, 2]
+NATIVE_EXT_OPERANDS = [((1, 2, 3, 4), (BABYBEAR - 1, 5, 0, 7)), ((0, 0, 0, 0), (1, 1, 1, 1)), ((3, 1, 4, 1), (5, 9, 2, 6)), ((2, 7, 1, 8), (2, 7, 1, 8)),
+                       ((2, 7, 1, 8), (2, 8, 1, BABYBEAR - 8))]   # add sub mul div (x / x) div
+CASTF_VALUES = [0x3FFFFFFF, 0x00C0FFEE]
+
+
+def native_program():
+    """BabyBear arithmetic through the native intrinsics: six field operations (a7 = 9: buffers of 3 words), five extension operations (a7 =
+    10: buffers of 12 words: add, sub, mul, x / x, x / y), two casts (a7 = 11: buffers of 2 words).  Reveals: the results of the
+    first four field operations, the XOR of the last two, the extension product's and quotient's first coefficients, the two cast words
+    folded into one."""
+    p = rv.li(S0, 0x00400000)
+    for k, op in enumerate(NATIVE_OPS):
+        p += [("addi", A0, S0, 12 * k), ("addi", A1, 0, op), ("addi", A7, 0, 9), ("ecall",)]
+    e0 = 12 * len(NATIVE_OPS)
+    for k, op in enumerate((0, 1, 2, 3, 3)):
+        p += [("addi", A0, S0, e0 + 48 * k), ("addi", A1, 0, op), ("addi", A7, 0, 10), ("ecall",)]
+    c0 = e0 + 48 * 5
+    for k in range(len(CASTF_VALUES)):
+        p += [("addi", A0, S0, c0 + 8 * k), ("addi", A7, 0, 11), ("ecall",)]
+    for k in range(4):
+        p += [("lw", A0, S0, 12 * k + 8), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("lw", A0, S0, 12 * 4 + 8), ("lw", T0, S0, 12 * 5 + 8), ("xor", A0, A0, T0), ("addi", A1, 0, 4), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("lw", A0, S0, e0 + 48 * 2 + 32), ("addi", A1, 0, 5), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("lw", A0, S0, e0 + 48 * 3 + 32), ("addi", A1, 0, 6), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("lw", A0, S0, c0 + 4), ("lw", T0, S0, c0 + 12), ("xor", A0, A0, T0), ("addi", A1, 0, 7), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
+def native_data():
+    import struct
+
+    out = b"".join(struct.pack("<3I", b, c, 0xDEADBEEF) for b, c in NATIVE_OPERANDS)            # (the result slots hold junk: they are overwritten)
+    out += b"".join(struct.pack("<12I", *x, *y, 11, 22, 33, 44) for x, y in NATIVE_EXT_OPERANDS)
+    out += b"".join(struct.pack("<2I", v, 0x55AA55AA) for v in CASTF_VALUES)
+    return out
+
 # ---- the reference's BATCH circuit: BLS12-381 (crates/circuits/batch-circuit/openvm.toml:18-36) -- a base field above 2^256: operands of
 # 48 bytes, limb chips of 48 limbs ----
 BLS12_381_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab

@@ -18,11 +18,12 @@ P = ora.P
 NOPV = np.zeros(0, np.uint32)
 (A_PROGRAM, A_FRAME, A_ALU, A_LT, A_MUL, A_MULH, A_DIVREM, A_SHIFT, A_BEQ, A_BLT, A_JAL_LUI, A_AUIPC, A_JALR, A_LS, A_ECALL, A_LEAF,
  A_MERKLE, A_POSEIDON2, A_CONNECTOR, A_BITWISE, A_RANGE_TUPLE, A_RANGE, A_KECCAK, A_KECCAK_IO, A_SHA256, A_SHA256_IO, A_INT256, A_INT256_IO, A_MUL256,
- A_CMP256, A_SHIFT256, N_STATIC_AIRS) = range(32)
+ A_CMP256, A_SHIFT256, A_NATIVE_ARITH, A_NATIVE_EXT, A_CASTF, N_STATIC_AIRS) = range(35)
 MAX_MODULI, MAX_CURVES, MAX_FP2 = 8, 4, 2
 # the modular extension: chips N_STATIC_AIRS + 2 i (multiplication), + 2 i + 1 (adapter) of modulus i; the ecc extension's follow
 N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES + 2 * MAX_FP2
-PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 34, 43, 54, 42, 2634
+PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 37, 43, 54, 42, 2634
+NATIVE_ARITH_WIDTH, NATIVE_EXT_WIDTH, CASTF_WIDTH, P_HI = 27, 90, 16, 0x7800
 SHA_IO_WIDTH, SHA_WIDTH = 34, 434
 MODMUL_IO_WIDTH, MODMUL_WIDTH = 35, 326
 INT256_IO_WIDTH, INT256_WIDTH, MUL256_WIDTH, CMP256_WIDTH, SHIFT256_WIDTH = 35, 102, 162, 104, 190
@@ -97,7 +98,7 @@ def curves_toml(curves):
                    for i, (p, a) in enumerate(curves))
 
 
-def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0, moduli=(), bigint=False, curves=(), fp2=()):
+def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0, moduli=(), bigint=False, curves=(), fp2=(), sections=()):
     """Runs the C++ segmenting executor; returns (info json, heights, [segment record dicts], image root, pv openings)."""
     import json
 
@@ -105,8 +106,9 @@ def dump_segments(tmp, exe_bytes, stdin, log_frame, log_keccak=0, log_sha256=0, 
     open(os.path.join(d, "exe.bin"), "wb").write(exe_bytes)
     open(os.path.join(d, "stdin.bin"), "wb").write(stdin)
     cmd = [CLI, "dump-segments", os.path.join(d, "exe.bin"), os.path.join(d, "stdin.bin"), d, str(log_frame), str(log_keccak), str(log_sha256)]
-    if moduli or bigint or curves or fp2:
+    if moduli or bigint or curves or fp2 or sections:   # sections: further `[app_vm_config.<name>]` lines, e.g. ("native", "castf")
         toml = "[app_vm_config.bigint]\n" if bigint else ""
+        toml += "".join("[app_vm_config.%s]\n" % name for name in sections)
         toml += curves_toml(curves) + fp2_toml(fp2)
         if moduli:
             toml += "[app_vm_config.modular]\nsupported_moduli = [\n" + ",\n".join('    "%d"' % m for m in moduli) + "\n]\n"
@@ -352,6 +354,88 @@ def sha256_traces(rec, H):
     return tr, rows_trace(rec["shaio_rows"], SHA_IO_WIDTH, H[A_SHA256_IO])
 
 
+# ---- the native field / extension / castf chips (include/zkhip_vm_circuit.hpp native_arith_air, native_ext_air, castf_vm_air): the rows the
+# ---- device makes from the executor's call records, restated with Python integers ------------------------------------------------
+def _canonical_cols(v):
+    lo, hi = v & 0xFFFF, v >> 16
+    gap = P_HI - hi
+    assert v < P and gap >= 0
+    return [lo, hi, gap, 1 if gap == 0 else 0, 0 if gap == 0 else pow(gap, -1, P)]
+
+
+def _access_cols(prev, at):
+    gap = at - prev - 1
+    assert 0 <= gap < 1 << (16 + GAP_HI_BITS)
+    return [prev % P, gap & 0xFFFF, gap >> 16]
+
+
+def _ext4_mul(a, b):
+    t = [0] * 7
+    for i in range(4):
+        for j in range(4):
+            t[i + j] += a[i] * b[j]
+    return [(t[k] + 11 * (t[k + 4] if k < 3 else 0)) % P for k in range(4)]
+
+
+def _ext4_inv(a):
+    r, e, b = [1, 0, 0, 0], P ** 4 - 2, list(a)
+    while e:
+        if e & 1:
+            r = _ext4_mul(r, b)
+        b = _ext4_mul(b, b)
+        e >>= 1
+    return r
+
+
+def native_arith_trace(rec, H):
+    recs = rec["nat_records"].reshape(-1, 9).astype(np.int64).tolist()
+    tr = np.zeros((NATIVE_ARITH_WIDTH, 1 << H[A_NATIVE_ARITH]), np.uint32)
+    for r, (op, bw, cw, prev, base, ts, *pts) in enumerate(recs):
+        b_, c_ = bw % P, cw % P
+        inv = pow(c_, -1, P) if op == 3 else 0
+        a_ = [(b_ + c_) % P, (b_ - c_) % P, b_ * c_ % P, b_ * inv % P][op]
+        flags = [1 if op == k else 0 for k in range(4)]
+        row = [ts, base, bw & 0xFFFF, bw >> 16, cw & 0xFFFF, cw >> 16] + _canonical_cols(a_) + [prev & 0xFFFF, prev >> 16] + flags + [inv]
+        for k in range(3):
+            row += _access_cols(pts[k], ts + 5)
+        tr[:, r] = row
+    return tr
+
+
+def native_ext_trace(rec, H):
+    recs = rec["next_records"].reshape(-1, 27).astype(np.int64).tolist()
+    tr = np.zeros((NATIVE_EXT_WIDTH, 1 << H[A_NATIVE_EXT]), np.uint32)
+    for r, w in enumerate(recs):
+        op, xw, yw, zp, base, ts, pts = w[0], w[1:5], w[5:9], w[9:13], w[13], w[14], w[15:27]
+        x, y = [v % P for v in xw], [v % P for v in yw]
+        inv = _ext4_inv(y) if op == 3 else [0, 0, 0, 0]
+        z = [(u + v) % P for u, v in zip(x, y)] if op == 0 else [(u - v) % P for u, v in zip(x, y)] if op == 1 else _ext4_mul(x, y) if op == 2 else _ext4_mul(x, inv)
+        row = [ts, base]
+        for v in xw:
+            row += [v & 0xFFFF, v >> 16]
+        for v in yw:
+            row += [v & 0xFFFF, v >> 16]
+        for v in z:
+            row += _canonical_cols(v)
+        for v in zp:
+            row += [v & 0xFFFF, v >> 16]
+        row += [1 if op == k else 0 for k in range(4)] + inv
+        for k in range(12):
+            row += _access_cols(pts[k], ts + 5)
+        tr[:, r] = row
+    return tr
+
+
+def castf_trace(rec, H):
+    recs = rec["castf_records"].reshape(-1, 6).astype(np.int64).tolist()
+    tr = np.zeros((CASTF_WIDTH, 1 << H[A_CASTF]), np.uint32)
+    for r, (x, prev, base, ts, p0, p1) in enumerate(recs):
+        assert x < 1 << 30
+        limbs = [(x >> (8 * i)) & 255 for i in range(4)]
+        tr[:, r] = [ts, base] + limbs + [4 * limbs[3], prev & 0xFFFF, prev >> 16] + _access_cols(p0, ts + 5) + _access_cols(p1, ts + 5) + [1]
+    return tr
+
+
 def segment_instance(rec, words, pc_base, heights):
     """The 24 AIR dicts (program, shapes, trace, pvs[, prep]) of one segment, traces from the CPU twins."""
     H = heights
@@ -407,6 +491,10 @@ def segment_instance(rec, words, pc_base, heights):
     for i, p_ in enumerate(H.fp2):
         tr[A_FP2(i)], tr[A_FP2_IO(i)], bw_i, tup_i = fp2_traces(rec, H, i, p_)
         mm_counts.append((bw_i, tup_i))
+    if A_NATIVE_ARITH in H.ids:
+        tr[A_NATIVE_ARITH], tr[A_NATIVE_EXT] = native_arith_trace(rec, H), native_ext_trace(rec, H)
+    if A_CASTF in H.ids:
+        tr[A_CASTF] = castf_trace(rec, H)
     meta = rec["meta"]
     pc_start, pc_end, ts_end, n_instr = (int(x) for x in meta[:4])
     tr[A_CONNECTOR] = np.array([[ts_end & 0xFFFF], [ts_end >> 16]], np.uint32)
@@ -444,10 +532,10 @@ def segment_instance(rec, words, pc_base, heights):
         if row[16]:
             rc[int(row[10]) * 256 + int(row[11])] += 1
             rc[int(row[12]) * 256 + int(row[13])] += 1
-        if row[30] or row[31] or row[32] or row[33]:
+        if row[30] or row[31] or row[32] or row[33] or row[34] or row[35]:
             misc += [int(row[22])]
             tc[int(row[23])] += 1
-        if row[27] or row[29] or row[30] or row[31] or row[32] or row[33]:
+        if row[27] or row[29] or row[30] or row[31] or row[32] or row[33] or row[34] or row[35] or row[36]:
             misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
     for row in rec["kio_rows"].reshape(-1, KECCAK_IO_WIDTH):
         misc += [int(row[36]), int(row[39])]
@@ -471,6 +559,27 @@ def segment_instance(rec, words, pc_base, heights):
         for row in rec["fp2io_rows_%d" % i].reshape(-1, EC_IO_WIDTH):
             misc += [int(row[55])]
             tc[int(row[56])] += 1
+    # the native chips: (lo, hi, hi_gap) of every canonical result word, every access's gap_lo / (0, gap_hi); castf's limbs as byte pairs
+    if A_NATIVE_ARITH in H.ids:
+        t_ = tr[A_NATIVE_ARITH].astype(np.int64)[:, :len(rec["nat_records"]) // 9]
+        for q in (6, 7, 8, 19, 22, 25):
+            cnt += np.bincount(t_[q], minlength=1 << 16)
+        for q in (20, 23, 26):
+            tc += np.bincount(t_[q], minlength=SX * SY)
+        t_ = tr[A_NATIVE_EXT].astype(np.int64)[:, :len(rec["next_records"]) // 27]
+        for q in [18 + 5 * i + k for i in range(4) for k in range(3)] + [55 + 3 * k for k in range(12)]:
+            cnt += np.bincount(t_[q], minlength=1 << 16)
+        for q in [56 + 3 * k for k in range(12)]:
+            tc += np.bincount(t_[q], minlength=SX * SY)
+    if A_CASTF in H.ids:
+        t_ = tr[A_CASTF].astype(np.int64)[:, :len(rec["castf_records"]) // 6]
+        for qx, qy in ((2, 3), (4, 5)):
+            rc += np.bincount(t_[qx] * 256 + t_[qy], minlength=1 << 16)
+        rc += np.bincount(t_[6] * 256, minlength=1 << 16)
+        for q in (10, 13):
+            cnt += np.bincount(t_[q], minlength=1 << 16)
+        for q in (11, 14):
+            tc += np.bincount(t_[q], minlength=SX * SY)
     for row in rec["leaf_rows"].reshape(-1, LEAF_WIDTH):
         misc += [int(row[39]), int(row[40]) * 16, int(row[40]), int(row[41]), int(row[42]) * 64, int(row[42])]
     cnt += np.bincount(np.array(misc, dtype=np.int64), minlength=1 << 16)

@@ -62,10 +62,7 @@ int main(int argc, char** argv) {
             if (!cfg_path.empty()) params = read_app_config(cfg_path);
             zkhip_vm::Exe exe;
             exe.program.assign(64, 0x00000013u);   // (the chips' constraint programs do not depend on the guest)
-            const zkhip_vm::SegmentCaps caps = cfg_path.empty() ? zkhip_vm::SegmentCaps::for_frame(log_frame, 6)
-                : zkhip_vm::SegmentCaps::for_frame(log_frame, 6, zkhip_vm::keccak_log_rows(cfg_path, log_frame), zkhip_vm::sha256_log_rows(cfg_path, log_frame),
-                                                   zkhip_vm::config_moduli(cfg_path), log_frame > 8 ? log_frame - 8 : 1, zkhip_vm::int256_log_rows(cfg_path, log_frame),
-                                                   zkhip_vm::config_curves(cfg_path), zkhip_vm::ec_log_rows(log_frame), zkhip_vm::config_fp2_moduli(cfg_path));
+            const zkhip_vm::SegmentCaps caps = cfg_path.empty() ? zkhip_vm::SegmentCaps::for_frame(log_frame, 6) : zkhip_vm::config_caps(cfg_path, log_frame, 6);
             const zkhip_vm::SegmentAirs sa = zkhip_vm::segment_airs(exe, caps);
             std::vector<zkhip_air> airs = sa.airs;
             // the node circuits' gate and Poseidon2 chips (their programs do not depend on the child key; heights of a real leaf circuit)
@@ -100,6 +97,34 @@ int main(int argc, char** argv) {
                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
             return 0;
         }
+        if (argc >= 3 && std::string(argv[1]) == "chips") {
+            // chips <openvm.toml> [log_frame = 17]: the chips the app's configuration asks for -- every `[app_vm_config.*]` section of the file, none
+            // ignored (the reference's chunk / batch / bundle circuits: crates/circuits/*/openvm.toml) -- as a JSON line: name, columns, log height
+            const unsigned log_frame = argc >= 4 ? (unsigned)atoi(argv[3]) : 17;
+            const zkhip_vm::SegmentCaps caps = zkhip_vm::config_caps(argv[2], log_frame, 10);
+            zkhip_vm::Exe exe;
+            exe.program.assign(64, 0x00000013u);
+            const zkhip_vm::SegmentAirs sa = zkhip_vm::segment_airs(exe, caps);
+            namespace vmc = zkhip::vmc;
+            auto name_of = [&](unsigned id) -> std::string {
+                static const char* base[] = {"program", "frame", "alu", "lt", "mul", "mulh", "divrem", "shift", "beq", "blt", "jal_lui", "auipc", "jalr", "loadstore", "ecall", "leaf",
+                                             "merkle", "poseidon2", "connector", "bitwise", "range_tuple", "range", "keccak", "keccak_io", "sha256", "sha256_io", "int256", "int256_io",
+                                             "mul256", "cmp256", "shift256", "native_arith", "native_ext", "castf"};
+                if (id < vmc::N_STATIC_AIRS) return base[id];
+                if (id >= vmc::A_FP2(0)) return std::string((id - vmc::A_FP2(0)) & 1 ? "fp2_io_" : "fp2_") + std::to_string((id - vmc::A_FP2(0)) / 2);
+                if (id >= vmc::A_EC(0)) return std::string((id - vmc::A_EC(0)) & 1 ? "ec_io_" : "ec_") + std::to_string((id - vmc::A_EC(0)) / 2);
+                return std::string((id - vmc::N_STATIC_AIRS) & 1 ? "modmul_io_" : "modmul_") + std::to_string((id - vmc::N_STATIC_AIRS) / 2);
+            };
+            std::printf("{\"config\": \"%s\", \"log_frame\": %u, \"n_chips\": %u, \"phantom_hints\": [%s], \"chips\": [", argv[2], log_frame, caps.n_airs,
+                        caps.ext.pairing ? "\"modular non-residue / square root\", \"pairing final exponentiation\"" : caps.moduli.empty() ? "" : "\"modular non-residue / square root\"");
+            size_t cells = 0;
+            for (unsigned p = 0; p < caps.n_airs; p++) {
+                std::printf("%s{\"name\": \"%s\", \"columns\": %zu, \"log_height\": %u}", p ? ", " : "", name_of(caps.ids[p]).c_str(), sa.airs[p].width, sa.airs[p].log_height);
+                cells += sa.airs[p].width << sa.airs[p].log_height;
+            }
+            std::printf("], \"main_cells\": %zu}\n", cells);
+            return 0;
+        }
         if (argc >= 6 && std::string(argv[1]) == "dump-segments") {
             // dump-segments <guest.elf | exe.bin> <stdin.bin | -> <out_dir> <log_frame>: the segmenting executor's records (include/zkhip_vm_exec.hpp)
             // as raw u32 arrays, one directory per segment -- what the tests' CPU twins of the trace generators read
@@ -113,7 +138,8 @@ int main(int argc, char** argv) {
                                                                                     argc >= 9 ? zkhip_vm::config_moduli(argv[8]) : std::vector<zkhip::modular::U256>(), 3,
                                                                                     argc >= 9 ? zkhip_vm::int256_log_rows(argv[8], 11) : 0u,
                                                                                     argc >= 9 ? zkhip_vm::config_curves(argv[8]) : std::vector<zkhip::ecc::Curve>(), 2,
-                                                                                    argc >= 9 ? zkhip_vm::config_fp2_moduli(argv[8]) : std::vector<zkhip::modular::U256>());
+                                                                                    argc >= 9 ? zkhip_vm::config_fp2_moduli(argv[8]) : std::vector<zkhip::modular::U256>(),
+                                                                                    argc >= 9 ? zkhip_vm::config_native(argv[8]) : zkhip::native::Enabled());
                 zkhip_vm::SegmentExecutor ex(exe, in, caps);
                 zkhip_vm::SegmentRecords r;
                 size_t k = 0;
@@ -142,6 +168,7 @@ int main(int argc, char** argv) {
                     PUT("kk_states", r.kk_states), PUT("kk_ts", r.kk_ts), PUT("kio_rows", r.kio_rows);
                     PUT("sha_blocks", r.sha_blocks), PUT("sha_ts", r.sha_ts), PUT("shaio_rows", r.shaio_rows);
                     PUT("i256_records", r.i256_records), PUT("i256_ts", r.i256_ts), PUT("i256io_rows", r.i256io_rows);
+                    PUT("nat_records", r.nat_records), PUT("next_records", r.next_records), PUT("castf_records", r.castf_records);
                     PUT("mul256_records", r.mul256_records), PUT("mul256_ts", r.mul256_ts), PUT("cmp256_records", r.cmp256_records), PUT("cmp256_ts", r.cmp256_ts), PUT("sh256_records", r.sh256_records), PUT("sh256_ts", r.sh256_ts);
                     for (unsigned i = 0; i < caps.moduli.size(); i++) {
                         const std::string t = std::to_string(i);
@@ -218,7 +245,7 @@ int main(int argc, char** argv) {
                     const unsigned lanes = flow.lanes;   // segment provers in flight (measured 1 / 2 / 3: DESIGN.md 5)
                     const zkhip_vm::GuestStark g = zkhip_vm::prove_guest_universal(params, up.exe(), in, log_frame, 0, false, lanes, log_keccak, log_sha256, zkhip_vm::config_moduli(cfg_path),
                                                                                           zkhip_vm::int256_log_rows(cfg_path, log_frame), zkhip_vm::config_curves(cfg_path),
-                                                                                          zkhip_vm::config_fp2_moduli(cfg_path), flow);
+                                                                                          zkhip_vm::config_fp2_moduli(cfg_path), flow, zkhip_vm::config_native(cfg_path));
                     (void)caps;
                     sp = UniversalProver::encode(g);
                     std::string why;

@@ -198,6 +198,11 @@ def load_library():
         "zkhip_int256_shift_air": (C.c_int, [C.c_uint32, C.POINTER(_Air)]),
         "zkhip_int256_shift_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_vm_shift256_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp]),
+        "zkhip_vm_native_arith_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
+        "zkhip_vm_native_ext_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
+        "zkhip_vm_castf_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp]),
+        "zkhip_merkle_rebuild": (C.c_int, [vp, vp]),
+        "zkhip_tree_check": (C.c_int, [vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "zkhip_int256_cmp_tracegen": (C.c_int, [vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_vm_cmp256_tracegen": (C.c_int, [vp, vp, vp, sz, C.c_uint, vp, vp]),
         "zkhip_modmul_air": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.POINTER(_Air)]),
@@ -775,6 +780,15 @@ class Context:
         else:
             self._check(self.lib.zkhip_vm_shift256_tracegen(self.h, t_records.data_ptr() if n else None, t_ts.data_ptr() if n else None, n, log_height, out.data_ptr(),
                                                             t_bitwise_trace.data_ptr()))
+        return out
+
+    def vm_native_tracegen(self, kind, t_records, n, log_height):
+        """The rows of a native chip of the one-statement circuit from the executor's call records (include/zkhip.h): kind "arith" (27
+        columns, 9 words per call), "ext" (90 columns, 27 words), "castf" (16 columns, 6 words)"""
+        width, fn = {"arith": (27, self.lib.zkhip_vm_native_arith_tracegen), "ext": (90, self.lib.zkhip_vm_native_ext_tracegen),
+                     "castf": (16, self.lib.zkhip_vm_castf_tracegen)}[kind]
+        out = self._new(width << log_height)
+        self._check(fn(self.h, t_records.data_ptr() if n else None, n, log_height, out.data_ptr()))
         return out
 
     def vm_mul256_tracegen(self, t_records, t_ts, n, log_height, t_bitwise_trace, t_tuple_counts, size_x, size_y):

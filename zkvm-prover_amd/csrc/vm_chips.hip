@@ -140,6 +140,131 @@ __global__ __launch_bounds__(256) void k_range_counts_scaled(const uint32_t* __r
     hot_flush(hk, hc, hist);
 }
 
+// ---- native field / extension / castf chips (include/zkhip_vm_circuit.hpp native_arith_air, native_ext_air, castf_vm_air): ONE row per
+// call, core and memory adapter together; the records are what the segmenting executor saw (operands, the result words before, the word
+// pointer, the timestamp, the words' previous accesses) -- the result, the inverse and the canonical-word columns are computed here.
+__device__ __forceinline__ uint32_t nat_inv(uint32_t a_monty) { return mpow(a_monty, P - 2); }
+// columns lo hi hi_gap top top_inv of a canonical word v < p
+__device__ __forceinline__ void canonical_cols(uint32_t v, uint32_t* col) {
+    const uint32_t lo = v & 0xffffu, hi = v >> 16, gap = zkhip::native::P_HI - hi;
+    col[0] = to_monty(lo), col[1] = to_monty(hi), col[2] = to_monty(gap), col[3] = gap == 0 ? MONTY_ONE : 0u, col[4] = gap == 0 ? 0u : nat_inv(to_monty(gap));
+}
+// columns prev_ts gap_lo gap_hi of a word access at timestamp `at`
+__device__ __forceinline__ void access_cols(uint32_t prev, uint32_t at, uint32_t* col, uint32_t* bad) {
+    const uint32_t gap = at - prev - 1;
+    if (prev >= at || (gap >> (16 + vmc::GAP_HI_BITS))) atomicAdd(bad, 1u);
+    col[0] = to_monty(prev % P), col[1] = to_monty(gap & 0xffffu), col[2] = to_monty((gap >> 16) & ((1u << vmc::GAP_HI_BITS) - 1));
+}
+__global__ __launch_bounds__(256) void k_vm_native_arith(const uint32_t* __restrict__ recs, size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[vmc::NATIVE_ARITH_WIDTH];
+#pragma unroll
+    for (unsigned q = 0; q < vmc::NATIVE_ARITH_WIDTH; q++) col[q] = 0;
+    if (r < n) {
+        const uint32_t* rec = recs + r * 9;   // op | b | c | previous result word | word pointer | ts | previous timestamps of the three words
+        const uint32_t op = rec[0], bw = rec[1], cw = rec[2], prev = rec[3], base = rec[4], ts = rec[5];
+        const uint32_t bm = to_monty(bw % P), cm = to_monty(cw % P);
+        uint32_t am = 0, inv = 0;
+        if (op == 0) am = madd(bm, cm);
+        else if (op == 1) am = msub(bm, cm);
+        else if (op == 2) am = mmul(bm, cm);
+        else if (op == 3 && cm != 0) inv = nat_inv(cm), am = mmul(bm, inv);
+        else atomicAdd(bad, 1u);
+        col[0] = to_monty(ts % P), col[1] = to_monty(base % P);
+        col[2] = to_monty(bw & 0xffffu), col[3] = to_monty(bw >> 16), col[4] = to_monty(cw & 0xffffu), col[5] = to_monty(cw >> 16);
+        canonical_cols(from_monty(am), col + 6);
+        col[11] = to_monty(prev & 0xffffu), col[12] = to_monty(prev >> 16);
+        if (op < 4) col[13 + op] = MONTY_ONE;
+        col[17] = inv;
+        for (int k = 0; k < 3; k++) access_cols(rec[6 + k], ts + 5, col + 18 + 3 * k, bad);
+    }
+#pragma unroll
+    for (unsigned q = 0; q < vmc::NATIVE_ARITH_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+__device__ __forceinline__ void nat_ext_mul(const uint32_t* x, const uint32_t* y, uint32_t* z) {   // Montgomery, X^4 = 11
+    const uint32_t w = to_monty(zkhip::native::W);
+    uint32_t t[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) t[i + j] = madd(t[i + j], mmul(x[i], y[j]));
+    for (int i = 0; i < 3; i++) z[i] = madd(t[i], mmul(w, t[i + 4]));
+    z[3] = t[3];
+}
+__global__ __launch_bounds__(256) void k_vm_native_ext(const uint32_t* __restrict__ recs, size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    auto put = [&](unsigned q, uint32_t v) { trace[(size_t)q * N + r] = v; };
+    if (r >= n) {
+        for (unsigned q = 0; q < vmc::NATIVE_EXT_WIDTH; q++) put(q, 0u);
+        return;
+    }
+    const uint32_t* rec = recs + r * 27;   // op | x[4] | y[4] | previous result words [4] | word pointer | ts | previous timestamps of the twelve words
+    const uint32_t op = rec[0], base = rec[13], ts = rec[14];
+    uint32_t x[4], y[4], z[4], inv[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) x[i] = to_monty(rec[1 + i] % P), y[i] = to_monty(rec[5 + i] % P);
+    if (op == 0) for (int i = 0; i < 4; i++) z[i] = madd(x[i], y[i]);
+    else if (op == 1) for (int i = 0; i < 4; i++) z[i] = msub(x[i], y[i]);
+    else if (op == 2) nat_ext_mul(x, y, z);
+    else if (op == 3) {
+        // y^-1 through the norm to F[X^2] and on to F (include/zkhip_native.hpp ext_inv): y = A + X B, D = A^2 - X^2 B^2, y^-1 = (A - X B) / D
+        const uint32_t w = to_monty(zkhip::native::W);
+        auto kmul = [&](const uint32_t* a, const uint32_t* b, uint32_t* o) {
+            const uint32_t o0 = madd(mmul(a[0], b[0]), mmul(w, mmul(a[1], b[1]))), o1 = madd(mmul(a[0], b[1]), mmul(a[1], b[0]));
+            o[0] = o0, o[1] = o1;
+        };
+        const uint32_t A[2] = {y[0], y[2]}, B[2] = {y[1], y[3]};
+        uint32_t A2[2], B2[2], D[2], Di[2], RA[2], RB[2];
+        kmul(A, A, A2), kmul(B, B, B2);
+        D[0] = msub(A2[0], mmul(w, B2[1])), D[1] = msub(A2[1], B2[0]);
+        const uint32_t nrm = msub(mmul(D[0], D[0]), mmul(w, mmul(D[1], D[1])));
+        if (nrm == 0) atomicAdd(bad, 1u);
+        const uint32_t ni = nat_inv(nrm);
+        Di[0] = mmul(D[0], ni), Di[1] = mmul(msub(0u, D[1]), ni);
+        kmul(A, Di, RA), kmul(B, Di, RB);
+        inv[0] = RA[0], inv[2] = RA[1], inv[1] = msub(0u, RB[0]), inv[3] = msub(0u, RB[1]);
+        nat_ext_mul(x, inv, z);
+    } else {
+        atomicAdd(bad, 1u);
+        for (int i = 0; i < 4; i++) z[i] = 0;
+    }
+    put(0, to_monty(ts % P)), put(1, to_monty(base % P));
+    for (int i = 0; i < 4; i++) {
+        put(2 + 2 * i, to_monty(rec[1 + i] & 0xffffu)), put(3 + 2 * i, to_monty(rec[1 + i] >> 16));
+        put(10 + 2 * i, to_monty(rec[5 + i] & 0xffffu)), put(11 + 2 * i, to_monty(rec[5 + i] >> 16));
+        uint32_t c5[5];
+        canonical_cols(from_monty(z[i]), c5);
+        for (int k = 0; k < 5; k++) put(18 + 5 * i + k, c5[k]);
+        put(38 + 2 * i, to_monty(rec[9 + i] & 0xffffu)), put(39 + 2 * i, to_monty(rec[9 + i] >> 16));
+        put(46 + i, op == (uint32_t)i ? MONTY_ONE : 0u);
+        put(50 + i, inv[i]);
+    }
+    for (int k = 0; k < 12; k++) {
+        uint32_t c3[3];
+        access_cols(rec[15 + k], ts + 5, c3, bad);
+        for (int q = 0; q < 3; q++) put(54 + 3 * k + q, c3[q]);
+    }
+}
+__global__ __launch_bounds__(256) void k_vm_castf(const uint32_t* __restrict__ recs, size_t n, size_t N, uint32_t* __restrict__ trace, uint32_t* __restrict__ bad) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    uint32_t col[vmc::CASTF_WIDTH];
+#pragma unroll
+    for (unsigned q = 0; q < vmc::CASTF_WIDTH; q++) col[q] = 0;
+    if (r < n) {
+        const uint32_t* rec = recs + r * 6;   // x | previous output word | word pointer | ts | previous timestamps of the two words
+        const uint32_t x = rec[0], prev = rec[1], base = rec[2], ts = rec[3];
+        if (x >= zkhip::native::CASTF_BOUND) atomicAdd(bad, 1u);
+        col[0] = to_monty(ts % P), col[1] = to_monty(base % P);
+        for (int i = 0; i < 4; i++) col[2 + i] = to_monty((x >> (8 * i)) & 255u);
+        col[6] = to_monty(((x >> 24) & 63u) * 4u);
+        col[7] = to_monty(prev & 0xffffu), col[8] = to_monty(prev >> 16);
+        access_cols(rec[4], ts + 5, col + 9, bad), access_cols(rec[5], ts + 5, col + 12, bad);
+        col[15] = MONTY_ONE;
+    }
+#pragma unroll
+    for (unsigned q = 0; q < vmc::CASTF_WIDTH; q++) trace[(size_t)q * N + r] = col[q];
+}
+
 int check_flag(zkhip_ctx* ctx, void* flag, const char* what) { return tracegen_finish(ctx, flag, what); }
 
 }  // namespace
@@ -291,6 +416,33 @@ int zkhip_vm_poseidon2_tracegen(zkhip_ctx* ctx, const uint32_t* d_inputs, size_t
     hipLaunchKernelGGL(k_fill_prefix, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_trace + (size_t)ZKHIP_POSEIDON2_AIR_WIDTH * N, n, N);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
+}
+
+// the rows of the native field / extension / castf chips from the executor's call records (include/zkhip_vm_exec.hpp SegmentRecords)
+static int native_rows(zkhip_ctx* ctx, const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace, int which, const char* name) {
+    ZK_BIND_DEVICE(ctx);
+    if (!ctx || !d_trace || log_height > 27 || (n && !d_records)) return ZKHIP_ERR_INVALID;
+    const size_t N = (size_t)1 << log_height;
+    if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(name) + ": more records than rows");
+    void* flag = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    KernelScope ks(ctx, name);
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    const dim3 grid((unsigned)((N + 255) / 256)), block(256);
+    if (which == 0) hipLaunchKernelGGL(k_vm_native_arith, grid, block, 0, ctx->stream, d_records, n, N, d_trace, (uint32_t*)flag);
+    else if (which == 1) hipLaunchKernelGGL(k_vm_native_ext, grid, block, 0, ctx->stream, d_records, n, N, d_trace, (uint32_t*)flag);
+    else hipLaunchKernelGGL(k_vm_castf, grid, block, 0, ctx->stream, d_records, n, N, d_trace, (uint32_t*)flag);
+    ZK_HIP_CHECK(ctx, hipGetLastError());
+    return check_flag(ctx, flag, (std::string(name) + " (an unknown operation, a division by zero, a castf operand of 2^30 or more, or a timestamp gap out of range)").c_str());
+}
+int zkhip_vm_native_arith_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace) {
+    return native_rows(ctx, d_records, n, log_height, d_trace, 0, "vm_native_arith_tracegen");
+}
+int zkhip_vm_native_ext_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace) {
+    return native_rows(ctx, d_records, n, log_height, d_trace, 1, "vm_native_ext_tracegen");
+}
+int zkhip_vm_castf_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t n, unsigned log_height, uint32_t* d_trace) {
+    return native_rows(ctx, d_records, n, log_height, d_trace, 2, "vm_castf_tracegen");
 }
 
 int zkhip_rows_tracegen(zkhip_ctx* ctx, const uint32_t* d_rows, size_t n, size_t width, unsigned log_height, uint32_t* d_trace, const uint32_t* pad_row) {
