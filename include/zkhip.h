@@ -945,6 +945,10 @@ typedef struct {
      * flow stored a wrong tree node in ~3 % of runs -- kept for the A/B of docs/stale_node.md and the test that must go red on it
      * [ZKHIP_TREE_STORE_EARLY=1] */
     int tree_store_early;
+    /* lanes per workgroup of the row-sponge kernel of trees of >= 2^20 rows (a multiple of 64, 64..768).  256: eight workgroups fill every wave
+     * slot of a CU.  768: two workgroups of 12 waves hold 6 of a SIMD's 8 slots and a third does not fit -- two slots, 176 VGPRs and the LDS
+     * of every CU stay free for the memory-bound kernels (NTT passes, constraint kernel) of the other proofs in flight [ZKHIP_HASH_BLOCK] */
+    uint32_t hash_block;
 } zkhip_config;
 /* While `on`, the trace generators treat the shared lookup-count tables handed to them (the 8-bit bitwise table, the range-tuple table, the
  * range table) as canonical counts and leave them canonical -- none converts a table from Montgomery form and back around its increments.
@@ -959,7 +963,7 @@ void zkhip_config_default(zkhip_config *out);
 /* a context's configuration (set at zkhip_ctx_create from zkhip_config_default); the witness fields are process-wide:
  * zkhip_set_process_config stores them (and the rest as the default of contexts created later).  zkhip_ctx_set_config applies every
  * field or refuses the call (ZKHIP_ERR_INVALID: jit 0..2, coop_* <= 27, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8,
- * commit_parts <= 8, side_cus < the device's CUs); a changed side_cus re-partitions as zkhip_set_cu_partition does. */
+ * commit_parts <= 8, side_cus < the device's CUs, hash_block a multiple of 64 in 64..768); a changed side_cus re-partitions as zkhip_set_cu_partition does. */
 int zkhip_ctx_get_config(zkhip_ctx *ctx, zkhip_config *out);
 int zkhip_ctx_set_config(zkhip_ctx *ctx, const zkhip_config *cfg);
 int zkhip_set_process_config(const zkhip_config *cfg);

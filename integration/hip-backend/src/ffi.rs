@@ -195,6 +195,7 @@ pub struct zkhip_config {
     pub parallel_queries: c_int,
     pub self_check: c_int,
     pub tree_store_early: c_int,
+    pub hash_block: u32,
 }
 
 #[repr(C)]

@@ -38,7 +38,9 @@ __device__ __forceinline__ void absorb_rows(uint32_t (&s)[16], const uint32_t* c
     }
 }
 
-__global__ __launch_bounds__(256) void k_hash_rows(const uint32_t* const* __restrict__ cols, uint32_t n_cols,
+// (launched with 256 lanes per workgroup, or with 768 -- zkhip_config.hash_block: two workgroups of 12 waves fill 6 of a SIMD's 8 wave slots
+// and a third does not fit, so two slots, 176 VGPRs and the whole LDS of every CU stay free for a memory-bound kernel of another stream)
+__global__ __launch_bounds__(768) void k_hash_rows(const uint32_t* const* __restrict__ cols, uint32_t n_cols,
                                                    size_t n_rows, uint32_t* __restrict__ out) {
     const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;  // heights are <= 2^27: 32-bit offsets
     if (row >= n_rows) return;
@@ -545,7 +547,8 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
         if (t->level_cnt[level] && ((size_t)1 << level) > ((size_t)1 << coop_inj_max_log)) add_level(level);
     if (L.n_levels == 1 && !leaves_ready) {
         KernelScope ks(ctx, "poseidon2_hash_rows");
-        hipLaunchKernelGGL(k_hash_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+        const unsigned hb = n >= ((size_t)1 << 20) ? std::max(64u, std::min(768u, ctx->cfg.hash_block)) : 256u;   // (small trees: more workgroups matter more)
+        hipLaunchKernelGGL(k_hash_rows, dim3((unsigned)((n + hb - 1) / hb)), dim3(hb), 0, ctx->stream,
                            d_ptrs + t->level_off[lh], (uint32_t)t->level_cnt[lh], n, t->d_digests);
     } else if (L.n_levels) {
         KernelScope ks(ctx, "poseidon2_hash_rows");
