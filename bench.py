@@ -172,6 +172,37 @@ def cpu_baseline(args, params, airs, host_traces, pvs, gpu_proof):
                          "EQUAL" if same else "DIFFER FROM")}
 
 
+def guest_flow_mixed():
+    """A CHUNK-LIKE guest under the reference's chunk-circuit configuration: tools/guest_bench2.py `mixed` -- register
+    loops, strided loads, Keccak-f, SHA-256, secp256k1 additions / doublings, modular and 256-bit arithmetic in phases (ratios in the tool's
+    output), so that segments land in the lean 22-chip, the 26-chip (base + hashes) and the full 51-chip shapes.  Reported: instructions per
+    second from the ELF to the verified root, the reference's own figure (MHz = cycles / 1e6 / seconds of proving, crates/prover/src/prover/
+    mod.rs:358-366), segments per shape and milliseconds per segment proof per shape.  Child process before this one touches the GPU; the
+    second of two runs is reported."""
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py"), "1536", "17", "mixed"]
+    try:
+        runs = []
+        for _ in range(2):
+            r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, ZKHIP_LANES="3"), timeout=300)
+            if r.returncode != 0:
+                return {"value": None, "note": "failed: " + r.stderr[-300:]}
+            runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        g = runs[1]
+        secs = (g["segment_tracegen_and_proving_ms"] + g["aggregation_setup_wait_ms"] + g["aggregation_ms"]) / 1e3
+        return {"metric": "guest_instructions_per_sec_elf_to_verified_root", "value": round(g["total_cycles"] / secs), "unit": "instr/s",
+                "prove_speed_mhz": g.get("prove_speed_mhz"), "instructions": g["total_cycles"], "segments": g["segments"], "aggregation_levels": g["levels"],
+                "chips_per_shape": g.get("chips_per_shape"), "segments_per_shape": g.get("segments_per_shape"),
+                "ms_per_segment_proof_per_shape": g.get("ms_per_segment_proof_per_shape"), "instructions_per_segment_per_shape": g.get("instructions_per_segment_per_shape"),
+                "execution_ms": g["execution_ms"], "segments_ms": g["segment_tracegen_and_proving_ms"], "tree_tail_ms": g["aggregation_setup_wait_ms"] + g["aggregation_ms"],
+                "process_wall_s": g["wall_s"], "process_wall_s_first_run_on_this_box": runs[0]["wall_s"], "verified": g["verified"], "guest": g.get("guest"),
+                "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 1536 17 mixed"}
+    except Exception as e:   # a reported extra, never a gate
+        return {"value": None, "note": "failed: %r" % (e,)}
+
+
 def guest_flow(chunk_config=False):
     """The path AROUND the headline kernel, reported beside it (never `value`): a Fibonacci guest of 4.2 M instructions through
     `prove_cli prove-elf` (tools/guest_bench2.py) -- segmenting executor, 22 chips per segment as ONE statement, device trace generation,
@@ -212,12 +243,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     plumbing = os.environ.get("ZKHIP_BENCH_PLUMBING_ONLY") == "1"
-    guest = guest_chunk = None
+    guest = guest_chunk = guest_mixed = None
     # (child processes: only before torch / HIP are loaded here, and never under a profiler -- its preloaded library has initialised the GPU
     # before this program starts; the profiling recipes pass --no-cpu-baseline or --no-guest-flow, either of which skips the guest flows)
     if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not plumbing and not args.no_guest_flow and not args.no_cpu_baseline and "torch" not in sys.modules:
         guest = guest_flow()
         guest_chunk = guest_flow(chunk_config=True)
+        guest_mixed = guest_flow_mixed()
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -591,6 +623,8 @@ def main():
             out["guest_flow"] = guest
         if guest_chunk is not None:
             out["guest_flow_chunk_config"] = guest_chunk
+        if guest_mixed is not None:
+            out["guest_flow_mixed"] = guest_mixed
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

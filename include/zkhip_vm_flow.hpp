@@ -545,6 +545,7 @@ struct GuestStark {
     VerifyingKey root_vk;
     size_t levels = 0, segments = 0;
     std::vector<size_t> segments_per_shape, chips_per_shape;   // how many segments were proven under each shape, and how many chips a shape carries
+    std::vector<size_t> instr_per_shape, prove_ms_per_shape, tracegen_ms_per_shape;   // per shape: instructions, summed proving / trace-generation time of its segments
     std::vector<size_t> nodes_per_slot;                        // how the tree's nodes spread over the device slots
     double agg_build_seconds = 0, agg_keygen_seconds = 0;      // the aggregation circuits and their keys (a one-time cost of a prover that lives on)
     std::vector<unsigned> node_log_heights;                    // heights of the node circuits' chips (gate, Poseidon2, public values)
@@ -822,7 +823,8 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
     g.deferral_opening = open_deferral_region(ex, exe);
     g.segments = n_seg;
     std::vector<ChildProof> seg_proofs;
-    g.segments_per_shape.assign(agg.n_shapes(), 0);
+    g.segments_per_shape.assign(agg.n_shapes(), 0), g.instr_per_shape.assign(agg.n_shapes(), 0), g.prove_ms_per_shape.assign(agg.n_shapes(), 0), g.tracegen_ms_per_shape.assign(agg.n_shapes(), 0);
+    for (auto& p : proofs) g.instr_per_shape.at(p.shape) += p.n_instr, g.prove_ms_per_shape.at(p.shape) += p.proving_mills, g.tracegen_ms_per_shape.at(p.shape) += p.tracegen_mills;
     for (size_t sh = 0; sh < agg.n_shapes(); sh++) g.chips_per_shape.push_back(agg.app_vk(sh).airs.size());
     for (auto& p : proofs) seg_proofs.push_back(p.proof), g.sum_segment_tracegen_mills += p.tracegen_mills, g.sum_segment_prove_mills += p.proving_mills, g.segments_per_shape.at(p.shape)++;
     if (keep_segments) g.segment_proofs.assign(std::make_move_iterator(proofs.begin()), std::make_move_iterator(proofs.end()));

@@ -499,3 +499,52 @@ def test_native_and_castf_intrinsics_are_part_of_the_statement(tmp_path):
     big = data[:-16] + struct.pack("<2I", 1 << 30, 0) + data[-8:]
     with pytest.raises(AssertionError, match="does not lie below 2\\^30"):
         v2.dump_segments(tmp_path, rv.exe_bytes(words, data=big), b"", 7, sections=("native", "castf"))
+
+
+def test_the_mixed_chunk_like_guest_runs_the_same_in_the_executor_and_the_model(tmp_path):
+    """tools/guest_bench2.py's `mixed` guest (tests/test_vm_cpu.py mixed_chunk_program: register loops, strided loads, Keccak-f, SHA-256,
+    secp256k1 additions and doublings, modular and 256-bit arithmetic in phases) under the reference's chunk-circuit configuration: the C++
+    segmenting executor and the independent Python model agree on the instruction count and on all eight revealed words; the point sums
+    are Python's (Q = (2 + k) G, D = 2^k G after k full iterations); segments chain; a segment of every phase satisfies its AIRs and
+    balances every bus."""
+    from test_vm_cpu import MIXED_PHASE_ITERATIONS, mixed_chunk_data, mixed_chunk_program
+
+    curves = tuple((c[1], c[3]) for c in CHUNK_CIRCUIT_CURVES)
+    words, data = mixed_chunk_program(), mixed_chunk_data()
+    n = 3 * MIXED_PHASE_ITERATIONS + 5                       # plain, hash, hash, then five full iterations
+    stdin = n.to_bytes(4, "little")
+    model = rv.run(words, stdin, data=data, moduli=CHUNK_CIRCUIT_MODULI, curves=curves)
+    pv = [int.from_bytes(bytes(model["pvs"])[4 * k:4 * k + 4], "little") for k in range(8)]
+    # secp256k1 with Python integers: Q = (2 + 5) G, D = 2^5 G
+    P_ = SECP256K1_P
+
+    def add(p1, p2):
+        if p1 == p2:
+            lam = 3 * p1[0] * p1[0] * pow(2 * p1[1], -1, P_) % P_
+        else:
+            lam = (p2[1] - p1[1]) * pow(p2[0] - p1[0], -1, P_) % P_
+        x3 = (lam * lam - p1[0] - p2[0]) % P_
+        return x3, (lam * (p1[0] - x3) - p1[1]) % P_
+
+    G = (SECP256K1_GX, SECP256K1_GY)
+    q = add(G, G)
+    for _ in range(5):
+        q = add(q, G)
+    d = G
+    for _ in range(5):
+        d = add(d, d)
+    assert pv[3] == q[0] & 0xFFFFFFFF and pv[4] == d[1] & 0xFFFFFFFF
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), stdin, 12, 5, 7, CHUNK_CIRCUIT_MODULI, True, curves, (CHUNK_CIRCUIT_MODULI[0],))
+    assert bytes.fromhex(info["public_values"]) == bytes(model["pvs"]) and info["total_cycle"] == model["instret"] and len(H.ids) == 51
+    meta = [s_["meta"] for s_ in segs]
+    for a, b in zip(meta, meta[1:]):
+        assert int(a[1]) == int(b[0]) != 0 and a[12:20].tolist() == b[4:12].tolist()
+    assert int(meta[-1][1]) == 0
+    plain = next(k for k, s_ in enumerate(segs) if not len(s_["kk_ts"]) and not len(s_["ec_ts_0"]))
+    hashy = next(k for k, s_ in enumerate(segs) if len(s_["kk_ts"]) and len(s_["sha_ts"]) and not len(s_["ec_ts_0"]))
+    full = next(k for k, s_ in enumerate(segs) if len(s_["ec_ts_0"]) and len(s_["mm_ts_2"]) and len(s_["i256_ts"]) and len(s_["mul256_ts"]))
+    for k in (plain, hashy, full):
+        inst = v2.segment_instance(segs[k], words, PC_BASE, H)
+        for d_ in inst:
+            assert air.check_trace(d_["program"], d_["trace"], d_["pvs"], d_.get("prep")) == [], k
+        assert v2.bus_imbalance(inst) == {}

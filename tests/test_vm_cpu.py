@@ -310,6 +310,86 @@ def fp2_data():
 
 
 
+
+# ---- a CHUNK-LIKE guest: what a chunk circuit's guest spends its instructions on -- register arithmetic, strided
+# loads, Keccak-f and SHA-256 calls (MPT hashing), secp256k1 point additions / doublings (ecrecover), modular and 256-bit arithmetic -- in
+# PHASES, so that the segments of one run land in all of the app's shapes: plain phases in the lean 22-chip shape, hash phases in the
+# 26-chip shape (base + keccak + sha256), full phases in the 51-chip shape of the reference's chunk-circuit configuration.
+MIXED_PHASE_ITERATIONS = 128          # iterations per phase; the phase of iteration i is (i >> 7) & 3: 0 plain, 1 and 2 hash, 3 full
+MIXED_MIX = {"plain instructions per iteration": 5 * 256 + 4 * 64 + 12, "strided loads per iteration": 64, "keccak_f per hash / full iteration": 1,
+             "sha256 blocks per hash / full iteration": 1, "secp256k1 add + double per full iteration": 2, "modular mul + div per full iteration": 2,
+             "int256 add + mul per full iteration": 2}
+_MX = dict(KK=0x000, SHA=0x100, ECA=0x200, ECD=0x300, MM=0x400, MD=0x480, I1=0x500, I2=0x580, ARR=0x1000)
+
+
+def mixed_chunk_program():
+    """reads the iteration count n from the input stream; every iteration runs a register-only loop (256 x 5 instructions) and a strided
+    load loop (64 x 4, stride 68 bytes); iterations of a hash phase add one Keccak-f call and one SHA-256 block; iterations of a full phase
+    add Q <- Q + G and D <- 2 D on secp256k1 (curve 0), a <- a b and r = a / b modulo secp256k1's p (modulus 2) and a 256-bit addition and
+    multiplication.  Reveals words of every running state (the checks of tests/test_vm2_cpu.py compare them with the Python model)."""
+    S2, S3, S4, T5 = 18, 19, 20, 30
+    X = _MX
+    p = [("addi", A7, 0, 2), ("ecall",), ("add", S1, A0, 0)]                       # s1 = n
+    p += rv.li(S0, 0x00400000) + rv.li(S3, 0x00400000 + X["ARR"])
+    p += [("addi", S2, 0, 0), ("addi", S4, 0, 0),
+          ("label", "outer"), ("bge", S2, S1, "done"),
+          # ---- every phase: a register-only loop, then strided loads
+          ("addi", T0, 0, 0), ("addi", T1, 0, 1), ("addi", T2, 0, 256),
+          ("label", "fib"), ("add", T3, T0, T1), ("add", T0, T1, 0), ("add", T1, T3, 0), ("addi", T2, T2, -1), ("bne", T2, 0, "fib"),
+          ("add", S4, S4, T0),
+          ("add", T4, S3, 0), ("addi", T2, 0, 64),
+          ("label", "lds"), ("lw", T3, T4, 0), ("add", S4, S4, T3), ("addi", T4, T4, 68), ("addi", T2, T2, -1), ("bne", T2, 0, "lds")]
+    # the phase: (i >> 7) & 3   (bne over the addi/ecall blocks: branch targets are labels)
+    p += [("srli", T5, S2, 7), ("andi", T5, T5, 3), ("beq", T5, 0, "next"),
+          # ---- hash phases: Keccak-f in place, one SHA-256 compression (the state chains)
+          ("addi", A0, S0, X["KK"]), ("addi", A7, 0, 3), ("ecall",),
+          ("addi", A0, S0, X["SHA"]), ("addi", A7, 0, 4), ("ecall",),
+          ("addi", T0, 0, 3), ("bne", T5, T0, "next"),
+          # ---- full phase: Q <- Q + G
+          ("addi", A0, S0, X["ECA"]), ("addi", A1, 0, 0), ("addi", A7, 0, 7), ("ecall",)]
+    for k in range(16):
+        p += [("lw", T0, S0, X["ECA"] + 128 + 4 * k), ("sw", T0, S0, X["ECA"] + 4 * k)]
+    p += [("addi", A0, S0, X["ECD"]), ("addi", A1, 0, 8), ("addi", A7, 0, 7), ("ecall",)]          # D <- 2 D
+    for k in range(16):
+        p += [("lw", T0, S0, X["ECD"] + 128 + 4 * k), ("sw", T0, S0, X["ECD"] + 4 * k)]
+    p += [("addi", A0, S0, X["MM"]), ("addi", A1, 0, 2), ("addi", A7, 0, 5), ("ecall",)]           # a <- a b mod secp256k1 p
+    for k in range(8):
+        p += [("lw", T0, S0, X["MM"] + 64 + 4 * k), ("sw", T0, S0, X["MM"] + 4 * k), ("sw", T0, S0, X["MD"] + 4 * k)]
+    p += [("addi", A0, S0, X["MD"]), ("addi", A1, 0, 2 + 8 * 3), ("addi", A7, 0, 5), ("ecall",)]   # r = a / b
+    p += [("addi", A0, S0, X["I1"]), ("addi", A1, 0, 0), ("addi", A7, 0, 6), ("ecall",)]           # 256-bit a = b + c; b <- a
+    for k in range(8):
+        p += [("lw", T0, S0, X["I1"] + 64 + 4 * k), ("sw", T0, S0, X["I1"] + 4 * k)]
+    p += [("addi", A0, S0, X["I2"]), ("addi", A1, 0, 5), ("addi", A7, 0, 6), ("ecall",)]           # 256-bit a = b c; b <- a
+    for k in range(8):
+        p += [("lw", T0, S0, X["I2"] + 64 + 4 * k), ("sw", T0, S0, X["I2"] + 4 * k)]
+    p += [("label", "next"), ("addi", S2, S2, 1), ("jal", 0, "outer"), ("label", "done")]
+    reveal = [("add", A0, S4, 0)] , [("lw", A0, S0, X["KK"])], [("lw", A0, S0, X["SHA"])], [("lw", A0, S0, X["ECA"])], [("lw", A0, S0, X["ECD"] + 32)], \
+             [("lw", A0, S0, X["MM"])], [("lw", A0, S0, X["MD"] + 64), ("lw", T0, S0, X["I1"]), ("xor", A0, A0, T0)], [("lw", A0, S0, X["I2"])]
+    for k, ld in enumerate(reveal):
+        p += list(ld) + [("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
+def mixed_chunk_data():
+    import struct
+
+    b32 = lambda v: int(v).to_bytes(32, "little")  # noqa: E731
+    X = _MX
+    two_g = (0xC6047F9441ED7D6D3045406E95C07CD85C778E4B8CEF3CA7ABAC09B95C709EE5, 0x1AE168FEA63DC339A3C58419466CEAEEF7F632653266D0E1236431A950CFE52A)   # 2 G (published)
+    d = bytearray(X["ARR"] + 64 * 68 + 64)
+    d[X["KK"]:X["KK"] + 200] = keccak_data(b"scroll-zkvm mixed guest")
+    d[X["SHA"]:X["SHA"] + 96] = sha256_data(b"mixed")[0][:96]
+    d[X["ECA"]:X["ECA"] + 128] = b32(two_g[0]) + b32(two_g[1]) + b32(SECP256K1_GX) + b32(SECP256K1_GY)                 # Q = 2 G, G
+    d[X["ECD"]:X["ECD"] + 64] = b32(SECP256K1_GX) + b32(SECP256K1_GY)                                                  # D = G
+    d[X["MM"]:X["MM"] + 64] = b32(SECP256K1_GX) + b32(SECP256K1_GY)                                                    # a, b
+    d[X["MD"] + 32:X["MD"] + 64] = b32(SECP256K1_GY)                                                                   # the divisor
+    d[X["I1"]:X["I1"] + 64] = b32(0x0123456789ABCDEF << 128 | 77) + b32((1 << 255) + 12345)
+    d[X["I2"]:X["I2"] + 64] = b32(3) + b32(0x10001)
+    for k in range(64 * 17 + 16):
+        struct.pack_into("<I", d, X["ARR"] + 4 * k, (2654435761 * (k + 1)) & 0xFFFFFFFF)
+    return bytes(d)
+
 # ---- the native / castf sections of the reference's batch and bundle circuits (crates/circuits/batch-circuit/openvm.toml:16,24;
 # bundle-circuit/openvm.toml:16,18): BabyBear arithmetic, its quartic extension, the cast of a field element to bytes ----
 BABYBEAR = 2013265921
