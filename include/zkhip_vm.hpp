@@ -33,6 +33,7 @@
 #include "zkhip_keccak.hpp"
 #include "zkhip_modular.hpp"
 #include "zkhip_native.hpp"
+#include "zkhip_pairing.hpp"
 #include "zkhip_sha256.hpp"
 
 namespace zkhip_vm {
@@ -237,12 +238,23 @@ private:
     // circuit proves nothing about them -- the guest checks what it reads (a square root by one multiplication and an equality test).
     //   kind 0, buffer [modulus index]:            pushes a quadratic non-residue z of that modulus (nw words)
     //   kind 1, buffer [modulus index | x (nw)]:   pushes [s | r (nw)]: s = 1 and r^2 = x if x is a square, else s = 0 and r^2 = x z
-    //   kind 2: the pairing extension's final-exponentiation witness -- not built
+    //   kind 2, buffer [pairing curve | f (96 words)]: the pairing extension's final-exponentiation witness (include/zkhip_pairing.hpp): pushes
+    //           c and u (96 words each, OpenVM's SexticExtField<Fp2> layout) with c^lambda = f u; curve 0 = Bn254, needs `[app_vm_config.pairing]`
     void phantom(uint32_t kind, uint32_t ptr) {
         using namespace zkhip::modular;
-        if (kind == 2) throw Error("the pairing extension's final-exponentiation hint is not built");
         if (kind > 2) throw Error("unknown phantom instruction " + std::to_string(kind));
         if (ptr & 3u) throw Error("phantom operand must be word-aligned");
+        if (kind == 2) {
+            if (!pairing_) throw Error("pairing hint: the app's openvm.toml does not enable the pairing extension");
+            uint32_t buf[97];
+            memcpy(buf, at(ptr, 4 * 97), 4 * 97);
+            if (buf[0] != 0) throw Error("pairing hint: curve " + std::to_string(buf[0]) + " (only 0 = Bn254 is built; BLS12-381's witness needs another construction)");
+            uint32_t out[192];
+            const char* why = "";
+            if (!zkhip::pairing::final_exp_hint_bn254(buf + 1, out, &why)) throw Error(std::string("pairing hint: ") + why);
+            hints_.insert(hints_.end(), out, out + 192);
+            return;
+        }
         uint32_t which;
         memcpy(&which, at(ptr, 4), 4);
         if (which >= moduli_.size()) throw Error("phantom hint: the app's openvm.toml lists no modulus " + std::to_string(which));

@@ -225,6 +225,20 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
             if w >> 28 == 5:
                 kind, ptr = (w >> 20) & 0xFF, x[(w >> 15) & 31]
                 off = ptr - data_base
+                if kind == 2:   # the pairing extension's final-exponentiation witness (tests/pairing_util.py): [curve | f] -> c, u
+                    import pairing_util as pu
+
+                    wds = struct.unpack_from("<97I", mem, off)
+                    assert wds[0] == 0
+                    el = lambda k: sum(wds[1 + 8 * k + i] << (32 * i) for i in range(8))  # noqa: E731
+                    c_, u_ = pu.final_exp_hint(pu.from_sextic([(el(2 * k), el(2 * k + 1)) for k in range(6)]))
+                    for v in (c_, u_):
+                        for a_, b_ in pu.to_sextic(v):
+                            for e_ in (a_, b_):
+                                hints.extend((e_ >> (32 * i)) & M32 for i in range(8))
+                    rec["alu"].append((0, 0, 0))
+                    pc, n = pc + 4, n + 1
+                    continue
                 p_ = moduli[struct.unpack_from("<I", mem, off)[0]]
                 nb = 32 if p_ < 1 << 256 else 48
                 z_ = next(c for c in range(2, 1000) if pow(c, (p_ - 1) // 2, p_) == p_ - 1)

@@ -131,7 +131,7 @@ def test_bls12_381_guest_under_the_batch_circuit_config_one_flow_one_proof(tmp_p
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["verified"] and out["total_cycles"] == model["instret"]
-    assert out["chips_per_shape"][-1] == 22 + 2 + 2 + 4 + 2 + 2      # base + keccak + sha2 + two moduli + one curve + one Fp2 field
+    assert out["chips_per_shape"][-1] == 22 + 2 + 2 + 4 + 2 + 2 + 3  # base + keccak + sha2 + two moduli + one curve + one Fp2 field + native (2) + castf (round 5)
     pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * N_STMT:4 * N_STMT + 32]
     assert pv == bytes(model["pvs"])
     w = [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(8)]

@@ -390,6 +390,28 @@ def mixed_chunk_data():
         struct.pack_into("<I", d, X["ARR"] + 4 * k, (2654435761 * (k + 1)) & 0xFFFFFFFF)
     return bytes(d)
 
+
+# ---- the pairing extension (`[app_vm_config.pairing] supported_curves = ["Bn254"]`, crates/circuits/chunk-circuit/openvm.toml:35-36): no chip,
+# a phantom sub-executor that leaves the final-exponentiation witness in the hint stream (include/zkhip_pairing.hpp) ----
+def pairing_hint_program():
+    """phantom kind 2 on the buffer [curve = 0 | f] at the data base; then the 192 hinted words (c, u) are read one by one (a7 = 2) and
+    XOR-folded into eight words (word k into fold k mod 8), which are revealed"""
+    S2 = 18
+    p = rv.li(S0, 0x00400000) + [("phantom", 2, S0), ("addi", S2, 0, 0), ("addi", T2, 0, 192),
+                                 ("label", "rd"), ("addi", A7, 0, 2), ("ecall",),
+                                 ("andi", T0, S2, 7), ("slli", T0, T0, 2), ("add", T0, T0, S0), ("lw", T1, T0, 0x200), ("xor", T1, T1, A0), ("sw", T1, T0, 0x200),
+                                 ("addi", S2, S2, 1), ("bne", S2, T2, "rd")]
+    for k in range(8):
+        p += [("lw", A0, S0, 0x200 + 4 * k), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
+def pairing_hint_data(f_sextic):
+    """f_sextic: six (a, b) pairs of integers"""
+    out = (0).to_bytes(4, "little") + b"".join(int(a).to_bytes(32, "little") + int(b).to_bytes(32, "little") for a, b in f_sextic)
+    return out + bytes(0x240 - len(out))
+
 # ---- the native / castf sections of the reference's batch and bundle circuits (crates/circuits/batch-circuit/openvm.toml:16,24;
 # bundle-circuit/openvm.toml:16,18): BabyBear arithmetic, its quartic extension, the cast of a field element to bytes ----
 BABYBEAR = 2013265921
@@ -449,8 +471,8 @@ BATCH_CIRCUIT_CURVES = (("Bls12_381G1Affine", BLS12_381_P, BLS12_381_R, 0, 4),)
 
 
 def batch_circuit_toml(params):
-    """the sections of the reference's batch-circuit openvm.toml, in the reference's syntax and order (castf, native and pairing bring no
-    chip here: DESIGN.md 8)"""
+    """the sections of the reference's batch-circuit openvm.toml, in the reference's syntax and order (since round 5 castf and native bring their
+    chips; pairing brings the phantom hint of include/zkhip_pairing.hpp -- built for Bn254, refused for this file's Bls12_381)"""
     return ("[app_fri_params.fri_params]\nlog_blowup = %d\nlog_final_poly_len = %d\nnum_queries = %d\ncommit_proof_of_work_bits = %d\n"
             "query_proof_of_work_bits = %d\n\n[app_vm_config.rv32i]\n\n[app_vm_config.rv32m]\n\n[app_vm_config.io]\n\n[app_vm_config.keccak]\n\n"
             "[app_vm_config.castf]\n\n[app_vm_config.modular]\nsupported_moduli = [\n" % tuple(params)) + "".join('    "%d",\n' % m for m in BATCH_CIRCUIT_MODULI) + (
