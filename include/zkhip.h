@@ -949,6 +949,9 @@ typedef struct {
      * slot of a CU.  768: two workgroups of 12 waves hold 6 of a SIMD's 8 slots and a third does not fit -- two slots, 176 VGPRs and the LDS
      * of every CU stay free for the memory-bound kernels (NTT passes, constraint kernel) of the other proofs in flight [ZKHIP_HASH_BLOCK] */
     uint32_t hash_block;
+    /* small tree layers (<= 2^min(coop_max_log, coop_inj_max_log) nodes) in groups of up to five per launch, injected rows included
+     * (k_compress_coop_fused); 0 = one launch per layer with injected rows, as round 4 [ZKHIP_NO_COOP_FUSED=1 -> 0] */
+    int coop_fused;
 } zkhip_config;
 /* While `on`, the trace generators treat the shared lookup-count tables handed to them (the 8-bit bitwise table, the range-tuple table, the
  * range table) as canonical counts and leave them canonical -- none converts a table from Montgomery form and back around its increments.

@@ -196,6 +196,7 @@ pub struct zkhip_config {
     pub self_check: c_int,
     pub tree_store_early: c_int,
     pub hash_block: u32,
+    pub coop_fused: c_int,
 }
 
 #[repr(C)]

@@ -180,7 +180,8 @@ void zkhip_config_default(zkhip_config* c) {
     c->parallel_queries = getenv("ZKHIP_RECURSION_SERIAL_QUERIES") ? 0 : 1;
     c->self_check = getenv("ZKHIP_SELF_CHECK") ? 1 : 0;
     c->tree_store_early = getenv("ZKHIP_TREE_STORE_EARLY") ? 1 : 0;
-    c->hash_block = num("ZKHIP_HASH_BLOCK", 256u);   // (test only: the round-4 bodies of the fused tree kernels)
+    c->hash_block = num("ZKHIP_HASH_BLOCK", 256u);
+    c->coop_fused = getenv("ZKHIP_NO_COOP_FUSED") ? 0 : 1;   // (test only: the round-4 bodies of the fused tree kernels)
     // compiled constraint kernels across processes: the variable if set (empty = none), else `jit_cache` beside this library if it exists
     std::string dir;
     if (const char* e = getenv("ZKHIP_JIT_CACHE_DIR")) {

@@ -275,6 +275,52 @@ __global__ __launch_bounds__(256) void k_compress_coop_multi(const uint32_t* pre
     }
 }
 
+// Up to FIVE layers in one launch, plain or with injected rows (round 5: a segment proof's main, permutation and quotient trees carry chips
+// of a dozen heights, so nearly every small layer has injected rows and was a launch of k_compress_layer_coop of its own -- 127 such
+// launches per proof of the guest flow, a permutation latency behind a launch each).  A workgroup of 16 rows produces 16 nodes of the
+// first layer (node = compress(left, right), then compress(node, sponge(row of the matrices injected at this height)) where the layer has
+// any), hands them on through the LDS and goes on with the 8 / 4 / 2 / 1 parents.  With n_next <= 16 the one workgroup ends at the root.
+// The loop is rolled: zk_syncthreads() states the LDS wait in front of every barrier (docs/stale_node.md).
+struct CoopFused {
+    uint64_t out_off[5];   // word offsets of the produced layers in the digest store
+    uint32_t inj_off[5];   // first injected column of the layer in the column-pointer table
+    uint32_t inj_cnt[5];   // injected columns of the layer (0: a plain layer)
+    uint32_t m;            // layers to produce (1..5)
+};
+__global__ __launch_bounds__(256) void k_compress_coop_fused(const uint32_t* prev, uint32_t* digests, size_t n_next, const uint32_t* const* __restrict__ cols, CoopFused cf) {
+    __shared__ uint32_t buf[2][16 * 8];
+    const unsigned lane = threadIdx.x & 15u, row = threadIdx.x >> 4;
+    const CoopConsts cc = coop_load_consts(lane);
+    size_t node = (size_t)blockIdx.x * 16 + row;
+    unsigned rows = 16;
+    uint32_t in = prev[(node < n_next ? node : 0) * 16 + lane];   // all 16 lanes of every row stay active through the DPP permutation
+#pragma unroll 1
+    for (uint32_t j = 0; j < cf.m; j++) {
+        const size_t n_j = n_next >> j;
+        const bool active = row < rows && node < n_j;
+        const size_t idx = active ? node : 0;
+        uint32_t x = coop_permute_regs(in, lane, cc);
+        const uint32_t n_inj = cf.inj_cnt[j];
+        if (n_inj) {
+            const uint32_t* const* ic = cols + cf.inj_off[j];
+            uint32_t h = 0;   // sponge over the injected row: lane k < 8 absorbs column c + k, lanes 8..15 are the capacity
+            for (uint32_t c = 0; c < n_inj; c += 8) {
+                if (lane < 8 && c + lane < n_inj) h = ic[c + lane][idx];
+                h = coop_permute_regs(h, lane, cc);
+            }
+            const uint32_t hh = dpp<ZK_ROR(8)>(h);   // lane 8 + k reads the digest word k
+            x = coop_permute_regs(lane < 8 ? x : hh, lane, cc);
+        }
+        if (active && lane < 8) digests[cf.out_off[j] + node * 8 + lane] = x;
+        if (j + 1 == cf.m) break;
+        if (row < rows && lane < 8) buf[j & 1][row * 8 + lane] = x;
+        zk_syncthreads();
+        rows >>= 1;
+        node = ((size_t)blockIdx.x * 16 >> (j + 1)) + row;
+        in = buf[j & 1][16 * (row < rows ? row : 0) + lane];   // the two children's digests are neighbours in the buffer
+    }
+}
+
 // Top of a tree in ONE launch: from a layer of <= 512 nodes down to the root.  Each 16-lane row
 // computes one compression cooperatively (poseidon2_coop.hpp), the working layer lives in LDS,
 // every produced layer is also written to the tree's digest store for later openings.
@@ -572,6 +618,32 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
         KernelScope ks(ctx, "poseidon2_compress_layer");
         // (ZKHIP_COOP_MAX_LOG / ZKHIP_COOP_INJ_MAX_LOG: the largest layer, plain / with injected rows, that takes the cooperative form)
         const unsigned coop_max = ctx->cfg.coop_max_log, coop_inj_max = ctx->cfg.coop_inj_max_log;
+        if (ctx->cfg.coop_fused && cnt <= ((size_t)1 << std::min(coop_max, coop_inj_max))) {
+            // this layer and up to four above it in one launch, injected rows included; a group stops where the one-workgroup top kernel
+            // takes over (a clean top), and the groups are cut so that the last one ends at the root
+            const unsigned top_log = std::min(ctx->cfg.top_max_log, 8u);
+            unsigned avail = 0;   // layers from this one up that the fused form may take
+            while (avail <= level) {
+                const unsigned lv = level - avail;
+                if (avail > 0 && ((size_t)1 << lv) <= ((size_t)1 << top_log) && lv < clean_top) break;   // the top kernel's from here
+                avail++;
+            }
+            unsigned m = avail % 5 ? avail % 5 : 5;
+            bool any_inj = false;
+            for (unsigned q = 0; q < m; q++) any_inj = any_inj || t->level_cnt[level - q] != 0;
+            if (any_inj || m >= 2 || level == 0) {
+                CoopFused cf{};
+                cf.m = m;
+                for (unsigned q = 0; q < m; q++) {
+                    cf.out_off[q] = (uint64_t)t->layer_off[l + q] * 8;
+                    cf.inj_off[q] = (uint32_t)t->level_off[level - q], cf.inj_cnt[q] = (uint32_t)t->level_cnt[level - q];
+                }
+                hipLaunchKernelGGL(k_compress_coop_fused, dim3((unsigned)((cnt + 15) / 16)), dim3(256), 0, ctx->stream, t->d_digests + t->layer_off[l - 1] * 8, t->d_digests, cnt,
+                                   d_ptrs, cf);
+                l += m - 1;
+                continue;
+            }
+        }
         if (t->level_cnt[level] == 0 && cnt <= ((size_t)1 << coop_max) && cnt >= 16) {
             // this plain layer and the plain layers above it that the top kernel does not take, up to five, in one launch
             const unsigned top_log = std::min(ctx->cfg.top_max_log, 8u);
