@@ -253,6 +253,7 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
     profile_flush(ctx);
     if (ctx->d_tw_fwd) (void)hipFree(ctx->d_tw_fwd);
     if (ctx->d_tw_inv) (void)hipFree(ctx->d_tw_inv);
+    for (auto& kv : ctx->lde_tables) (void)hipFree(kv.second);
     for (int i = 0; i < 8; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);

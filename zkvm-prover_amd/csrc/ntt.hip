@@ -957,6 +957,34 @@ int ntt_batch(zkhip_ctx* ctx, uint32_t* d_mat, unsigned log_n, size_t width, siz
     return ZKHIP_OK;
 }
 
+// The scale tables of a four-step LDE (d_col | d_row | d_rho, see k_gen_lde_scales) depend on (log_n, added_bits, shift) only: generated once
+// per context (and waited for: later users may sit on another stream of the context), read-only afterwards.
+static int lde_scale_tables(zkhip_ctx* ctx, unsigned log_n, unsigned added_bits, uint32_t shift_monty, unsigned log_f, unsigned log_rq, uint32_t** out) {
+    const uint64_t key = ((uint64_t)log_n << 56) | ((uint64_t)added_bits << 48) | ((uint64_t)log_f << 40) | ((uint64_t)log_rq << 32) | shift_monty;
+    auto it = ctx->lde_tables.find(key);
+    if (it != ctx->lde_tables.end()) {
+        *out = it->second;
+        return ZKHIP_OK;
+    }
+    const unsigned n_co = 1u << added_bits;
+    const size_t n = (size_t)1 << log_n, n_col = (size_t)1 << log_f, n_row = (size_t)1 << log_rq, cnt = n_co * (n_col + n_row + 1);
+    uint32_t* tabs = nullptr;
+    if (hipMalloc(&tabs, cnt * 4) != hipSuccess) return set_error(ctx, ZKHIP_ERR_NOMEM, "lde scale tables");
+    {
+        KernelScope ks(ctx, "gen_coset_powers");
+        const uint32_t n_inv = minv(to_monty((uint32_t)(n % P)));
+        hipLaunchKernelGGL(k_gen_lde_scales, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, tabs, tabs + n_co * n_col, tabs + n_co * (n_col + n_row), shift_monty,
+                           two_adic_generator(log_n + added_bits), n_inv, added_bits, log_f, log_rq);
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipFree(tabs);
+        return set_error(ctx, ZKHIP_ERR_HIP, "lde scale tables");
+    }
+    ctx->lde_tables[key] = tabs;
+    *out = tabs;
+    return ZKHIP_OK;
+}
+
 int lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* d_out, size_t out_stride,
               unsigned log_n, unsigned added_bits, size_t width, uint32_t shift_monty) {
     if (width == 0) return ZKHIP_OK;
@@ -975,19 +1003,10 @@ int lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* 
         fourstep_split(log_n, a);
         const unsigned log_f = log_n - a[0], log_rq = a[0] - 4, n_co = 1u << added_bits;
         const size_t n_col = (size_t)1 << log_f, n_row = (size_t)1 << log_rq;
-        void* tabs;
-        ZK_TRY(get_scratch(ctx, 1, (n_co * (n_col + n_row + 1)) * 4, &tabs));
-        uint32_t* d_col = (uint32_t*)tabs;
+        uint32_t* d_col = nullptr;
+        ZK_TRY(lde_scale_tables(ctx, log_n, added_bits, shift_monty, log_f, log_rq, &d_col));
         uint32_t* d_row = d_col + n_co * n_col;
         uint32_t* d_rho = d_row + n_co * n_row;
-        {
-            KernelScope ks(ctx, "gen_coset_powers");
-            size_t cnt = n_co * (n_col + n_row + 1);
-            uint32_t n_inv = minv(to_monty((uint32_t)(n % P)));
-            hipLaunchKernelGGL(k_gen_lde_scales, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, d_col, d_row,
-                               d_rho, shift_monty, two_adic_generator(log_n + added_bits), n_inv, added_bits, log_f, log_rq);
-        }
-        ZK_HIP_CHECK(ctx, hipGetLastError());
         BrSrc bs{d_col, d_row, d_rho};
         const size_t per_col = n << added_bits;
         const bool three = log_n > 2 * p4_log_r_limit();
@@ -1001,16 +1020,29 @@ int lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* 
     // 2. per-coset power tables
     unsigned lb = (log_n + 1) / 2;
     unsigned per = (1u << lb) + (1u << (log_n - lb));
-    void* pw;
-    ZK_TRY(get_scratch(ctx, 1, ((size_t)per << added_bits) * 4, &pw));
+    // (the power tables depend on (log_n, added_bits, shift) only: once per context, like the four-step form's scale tables)
+    uint32_t* pw = nullptr;
     {
-        KernelScope ks(ctx, "gen_coset_powers");
-        unsigned cnt = per << added_bits, bs = 256;
-        uint32_t n_inv = minv(to_monty((uint32_t)(n % P)));
-        hipLaunchKernelGGL(k_gen_coset_powers, dim3((cnt + bs - 1) / bs), dim3(bs), 0, ctx->stream, (uint32_t*)pw,
-                           shift_monty, two_adic_generator(log_n + added_bits), n_inv, log_n, added_bits, lb);
+        const uint64_t key = ((uint64_t)1 << 63) | ((uint64_t)log_n << 56) | ((uint64_t)added_bits << 48) | shift_monty;
+        auto it = ctx->lde_tables.find(key);
+        if (it == ctx->lde_tables.end()) {
+            const unsigned cnt = per << added_bits, bs = 256;
+            if (hipMalloc(&pw, (size_t)cnt * 4) != hipSuccess) return set_error(ctx, ZKHIP_ERR_NOMEM, "lde power tables");
+            {
+                KernelScope ks(ctx, "gen_coset_powers");
+                const uint32_t n_inv = minv(to_monty((uint32_t)(n % P)));
+                hipLaunchKernelGGL(k_gen_coset_powers, dim3((cnt + bs - 1) / bs), dim3(bs), 0, ctx->stream, pw, shift_monty, two_adic_generator(log_n + added_bits), n_inv, log_n,
+                                   added_bits, lb);
+            }
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                (void)hipFree(pw);
+                return set_error(ctx, ZKHIP_ERR_HIP, "lde power tables");
+            }
+            ctx->lde_tables[key] = pw;
+        } else {
+            pw = it->second;
+        }
     }
-    ZK_HIP_CHECK(ctx, hipGetLastError());
     // 3. bit-reverse to natural order, scaling into every coset block of the output
     BitrevArgs a{(const uint32_t*)coeffs, n, d_out, out_stride, (const uint32_t*)pw, MONTY_ONE, log_n, added_bits, lb};
     ZK_TRY(launch_bitrev(ctx, a, width));
@@ -1043,19 +1075,10 @@ int lde_batch_cols(zkhip_ctx* ctx, const uint32_t* const* d_src_cols, uint32_t* 
     fourstep_split(log_n, a);
     const unsigned log_f = log_n - a[0], log_rq = a[0] - 4, n_co = 1u << added_bits;
     const size_t n_col = (size_t)1 << log_f, n_row = (size_t)1 << log_rq;
-    void* tabs;
-    ZK_TRY(get_scratch(ctx, 1, (n_co * (n_col + n_row + 1)) * 4, &tabs));
-    uint32_t* d_col = (uint32_t*)tabs;
+    uint32_t* d_col = nullptr;
+    ZK_TRY(lde_scale_tables(ctx, log_n, added_bits, shift_monty, log_f, log_rq, &d_col));
     uint32_t* d_row = d_col + n_co * n_col;
     uint32_t* d_rho = d_row + n_co * n_row;
-    {
-        KernelScope ks(ctx, "gen_coset_powers");
-        size_t cnt = n_co * (n_col + n_row + 1);
-        uint32_t n_inv = minv(to_monty((uint32_t)(n % P)));
-        hipLaunchKernelGGL(k_gen_lde_scales, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, d_col, d_row,
-                           d_rho, shift_monty, two_adic_generator(log_n + added_bits), n_inv, added_bits, log_f, log_rq);
-    }
-    ZK_HIP_CHECK(ctx, hipGetLastError());
     BrSrc bs{d_col, d_row, d_rho};
     const size_t per_col = n << added_bits;
     const bool three = log_n > 2 * p4_log_r_limit();

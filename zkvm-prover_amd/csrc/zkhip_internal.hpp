@@ -65,6 +65,9 @@ struct zkhip_ctx {
     // pinned staging of the transcript's host sponge (csrc/transcript.hip: long absorptions run on the host's vector unit)
     void* h_sponge = nullptr;
     size_t h_sponge_bytes = 0;
+    // the scale tables of a four-step LDE (ntt.hip: column / row / rho powers of the coset shifts) depend on (log_n, added_bits, shift) only:
+    // made once per context and read-only afterwards (a segment proof extends ~20 heights: a launch each, every proof, before round 5)
+    std::map<uint64_t, uint32_t*> lde_tables;
 };
 
 namespace zk {
