@@ -1,6 +1,6 @@
 # The VALU floor of the reference-shaped 17-AIR proof: SQ_INSTS_VALU over a run of tools/refshape_bench.py with one
-# proof in flight and 10 timed proofs (12 proofs in all with the verified and the profiled one; the key generation's kernels are in the
-# sum, a few per cent), priced like the headline's: x 2.823 cycles per wave-instruction / (1024 SIMDs x 2.4 GHz).  Writes
+# proof in flight and 10 timed proofs (18 proofs in all: the verified one, the profiled one, five best-of runs, one warm-up, ten timed; the
+# key generation's kernels are in the sum, a few per cent), priced like the headline's: x 2.823 cycles per wave-instruction / (1024 SIMDs x 2.4 GHz).  Writes
 # gpurun_out/r5refshape/.
 set -x
 cd $GRAFT_REPO_ROOT
@@ -18,7 +18,7 @@ for f in glob.glob(O + "/v/**/*counter_collection.csv", recursive=True):
         if r["Counter_Name"] == "SQ_INSTS_VALU":
             v = float(r["Counter_Value"]); tot += v
             k = r["Kernel_Name"].split("(")[0]; per[k] = per.get(k, 0.0) + v
-n_proofs = 12
+n_proofs = 18
 floor_ms = tot / n_proofs * 2.823 / (1024 * 2.4e9) * 1e3
 top = sorted(per.items(), key=lambda kv: -kv[1])[:8]
 out = {"valu_wave_instr_per_proof": round(tot / n_proofs), "proofs_in_the_counted_run": n_proofs, "cycles_per_wave_instr_model": 2.823,
