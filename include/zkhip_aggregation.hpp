@@ -15,6 +15,10 @@
 // commitment (8)]; the children's states are chained in-circuit.  Every node proof is self-verified (mod.rs:407-411 does that for
 // every proof it returns).  AggregationTreeConfig::one_key = false keeps round 3's per-depth keys (level l hard-wires level l - 1).
 #pragma once
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <array>
 #include <chrono>
 #include <cstdio>
@@ -245,6 +249,7 @@ public:
         reset();
         app_ = std::move(o.app_), apps_ = std::move(o.apps_), leafs_ = std::move(o.leafs_), bigleafs_ = std::move(o.bigleafs_), policy_ = std::move(o.policy_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, agg_params_ = o.agg_params_, device_ = o.device_, levels_ = std::move(o.levels_), stats = o.stats;
         leaf_commit_ = std::move(o.leaf_commit_), internal_commit_ = std::move(o.internal_commit_), leaf_list_ = std::move(o.leaf_list_);
+        lazy_ = std::move(o.lazy_), common_h_[0] = o.common_h_[0], common_h_[1] = o.common_h_[1];
         levels_mu_ = std::move(o.levels_mu_), build_mu_ = std::move(o.build_mu_);
         devices_ = std::move(o.devices_), slots_ = std::move(o.slots_);
         o.slots_.clear();
@@ -265,6 +270,7 @@ public:
     // verifying key of the node circuit of `level` (0 = leaf; under one key every level above is THE internal circuit)
     const VerifyingKey& node_vk(size_t level, size_t shape = 0) {
         ensure_level(level);
+        if (level == 0 && cfg_.one_key) ensure_leaf(shape);
         return lv(level, shape).vk;
     }
     size_t n_shapes() const { return apps_.size(); }
@@ -325,6 +331,7 @@ public:
     std::vector<uint32_t> witness_node(size_t level, const std::vector<const ChildProof*>& kids, size_t shape = 0, const std::vector<size_t>* kid_shapes = nullptr,
                                        size_t slot = 0, const std::vector<int>* kinds_in = nullptr) {
         ensure_level(level);
+        if (level == 0 && cfg_.one_key) ensure_leaf(shape);
         Replica& L = lv(level, shape).rep.at(slot);
         if (kids.empty() || kids.size() > arity(level, shape)) throw Error(Error::GenProof, "aggregation: a node of level " + std::to_string(level) + " takes 1.." + std::to_string(arity(level, shape)) + " children");
         const VerifyingKey& cvk = level == 0 ? apps_.at(shape) : lv(level - 1).vk;   // (one key: the leaf's and the internal vk differ in the commitments only)
@@ -388,6 +395,7 @@ public:
     // enters the tree is the wrapper's proof.  Host witness and device work of both, one after the other, on one slot.
     ChildProof prove_wrapped(const std::vector<const ChildProof*>& kids, size_t shape, size_t slot = 0) {
         ensure_level(0);
+        if (cfg_.one_key) ensure_leaf(shape);
         if (!wrapped(shape)) throw Error(Error::GenProof, "aggregation: not a wrapped shape");
         Level& B = bigleafs_.at(shape);
         Level& W = lv(0, shape);
@@ -902,6 +910,12 @@ private:
     // one key: zkhip_recursion_key_commit of the circuits' keys: leaf_list_ = the S leaf commitments (8 S words); leaf_commit_ = what a node
     // STATES as its leaf commitment: the commitment itself (one shape) or the sponge of the list
     std::vector<uint32_t> leaf_list_, leaf_commit_, internal_commit_;
+    // LAZY leaf circuits (round 5): a shape whose commitment and natural heights are known from the on-disk cache of this key
+    // (agg_cache_path) is not built at setup -- the wide shapes of the chunk configuration cost 3 - 4 s of circuit building and key
+    // generation per process, used or not -- but when its first segment proof arrives (ensure_leaf), and what is built then must commit
+    // to exactly what the cache said (the aggregation key already states it).
+    std::vector<char> lazy_;
+    unsigned common_h_[2] = {0, 0};
     std::vector<VerifyingKey> apps_;   // the shapes' segment keys (apps_.back() = app_ = the full set)
     std::deque<Level> leafs_;          // one key: the leaf circuit of every shape (a wrapped shape: its wrapper); levels_[0] is then unused
     std::deque<Level> bigleafs_;       // ... and, for a wrapped shape, its own (large) leaf circuit
@@ -1022,6 +1036,160 @@ private:
         st.n_state = cols[0].size(), st.start_air = cols[0].data(), st.start_idx = cols[1].data(), st.end_air = cols[2].data(), st.end_idx = cols[3].data();
         return st;
     }
+    // ---- the pieces of build_one_key, per shape (also what ensure_leaf runs for a shape that was left out at setup) ----
+    void build_leaf_circuit(size_t sh, const std::vector<uint32_t>& app_id, Level* leaf) {
+        std::vector<uint32_t> cols[4];
+        zkhip_recursion_stmt st = leaf_stmt(cols);
+        st.uniform = 1;
+        st.app_id = apps_.size() > 1 ? app_id.data() : nullptr;
+        std::vector<zkhip_air> za = apps_[sh].as_airs();
+        const int rc = zkhip_recursion_build(&apps_[sh].params, za.data(), za.size(), arity(0, sh), &st, &leaf->circ);
+        if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the leaf verifier circuit of shape ") + std::to_string(sh) + ": " + zkhip_recursion_last_error(nullptr));
+    }
+    // leaf (built, natural heights) -> big = that circuit with its keys, leaf = the wrapper over it
+    void wrap_leaf(size_t sh, Level* leaf, Level* big) {
+        *big = std::move(*leaf);
+        *leaf = Level{};
+        big->vk.params = agg_params_.leaf;
+        std::vector<zkhip_air> ba;
+        circuit_airs(big->circ, &big->vk, &ba);
+        keygen_level(*big, ba);
+        std::vector<zkhip_air> za = big->vk.as_airs();
+        zkhip_recursion_stmt st{};
+        st.child_is_node = 1, st.uniform = 1;
+        const int rc = zkhip_recursion_build(&big->vk.params, za.data(), za.size(), 1, &st, &leaf->circ);
+        if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the wrapper of shape ") + std::to_string(sh) + ": " + zkhip_recursion_last_error(nullptr));
+    }
+    void pad_leaf(Level& leaf, const Level& internal, std::vector<zkhip_air>* la) {
+        if (zkhip_recursion_pad(leaf.circ, common_h_) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_pad");
+        leaf.vk.params = agg_params_.leaf;
+        circuit_airs(leaf.circ, &leaf.vk, la);
+        for (size_t i = 0; i < 3; i++)
+            if (leaf.vk.airs[i].program != internal.vk.airs[i].program || leaf.vk.heights[i] != internal.vk.heights[i])
+                throw Error(Error::Setup, "aggregation: the leaf and the internal circuit do not share one AIR set");
+    }
+    // The on-disk cache of ONE aggregation key: file name = a digest of everything the key depends on (every shape's segment-key digest,
+    // the node parameters, arities, shape policies, the statement layout, and the size and time stamp of libzkhip.so: another build of the
+    // circuit builder is another key).  Content: [magic, S, H0, H1, then per shape: natural heights (2), commitment (8)].  Directory:
+    // ZKHIP_AGG_CACHE_DIR, else the library's jit_cache_dir; none = no cache.
+    struct AggCache {
+        bool hit = false;
+        std::string path;
+        unsigned h[2] = {0, 0};
+        std::vector<std::array<unsigned, 2>> nat;
+        std::vector<std::array<uint32_t, 8>> commit;
+    };
+    std::string agg_cache_path(const std::vector<uint32_t>& app_id) const {
+        std::string dir;
+        if (const char* e = getenv("ZKHIP_AGG_CACHE_DIR")) {
+            dir = e;
+        } else {
+            zkhip_config c;
+            zkhip_config_default(&c);
+            dir = c.jit_cache_dir;
+        }
+        if (dir.empty()) return "";
+        std::vector<uint32_t> words{0x41474B43u /* "AGKC" */, (uint32_t)apps_.size(), (uint32_t)cfg_.num_children_leaf, (uint32_t)cfg_.num_children_internal, (uint32_t)spec_.start.size()};
+        words.insert(words.end(), app_id.begin(), app_id.end());
+        for (const VerifyingKey& a : apps_) {
+            uint32_t d[8] = {};
+            std::vector<zkhip_air> za = a.as_airs();
+            if (zkhip_recursion_vk_digest(&a.params, za.data(), za.size(), d) != ZKHIP_OK) return "";
+            words.insert(words.end(), d, d + 8);
+        }
+        for (const zkhip_params* q : {&agg_params_.leaf, &agg_params_.internal})
+            for (uint32_t v : {q->log_blowup, q->log_final_poly_len, q->num_queries, q->commit_pow_bits, q->query_pow_bits}) words.push_back(v);
+        for (const ShapePolicy& q : policy_) words.push_back(q.arity), words.push_back(q.wrapped ? 1u : 0u);
+        for (const auto& q : spec_.start) words.push_back(q.first), words.push_back(q.second);
+        for (const auto& q : spec_.end) words.push_back(q.first), words.push_back(q.second);
+        {   // the builder's identity: size and modification time of the loaded library
+            Dl_info info;
+            struct stat st;
+            if (dladdr((const void*)&zkhip_recursion_build, &info) && info.dli_fname && stat(info.dli_fname, &st) == 0)
+                words.push_back((uint32_t)st.st_size), words.push_back((uint32_t)st.st_mtime), words.push_back((uint32_t)((uint64_t)st.st_mtime >> 32));
+        }
+        for (uint32_t& w : words) w %= 0x78000001u;
+        const Digest8 h = p2_sponge8(words.data(), words.size());
+        char name[96];
+        std::snprintf(name, sizeof name, "/agg_%08x%08x%08x%08x.key", h[0], h[1], h[2], h[3]);
+        return dir + name;
+    }
+    AggCache load_agg_cache(const std::vector<uint32_t>& app_id) const {
+        AggCache c;
+        c.path = agg_cache_path(app_id);
+        if (c.path.empty()) return c;
+        FILE* f = std::fopen(c.path.c_str(), "rb");
+        if (!f) return c;
+        const size_t S = apps_.size();
+        std::vector<uint32_t> w(4 + 10 * S);
+        const bool ok = std::fread(w.data(), 4, w.size(), f) == w.size() && w[0] == 0x41474B43u && w[1] == S;
+        std::fclose(f);
+        if (!ok) return c;
+        c.h[0] = w[2], c.h[1] = w[3];
+        for (size_t sh = 0; sh < S; sh++) {
+            c.nat.push_back({w[4 + 10 * sh], w[5 + 10 * sh]});
+            std::array<uint32_t, 8> k;
+            std::copy(w.begin() + 6 + 10 * sh, w.begin() + 14 + 10 * sh, k.begin());
+            c.commit.push_back(k);
+        }
+        c.hit = true;
+        return c;
+    }
+    void store_agg_cache(const std::vector<uint32_t>& app_id, const unsigned H[2], const std::vector<std::array<unsigned, 2>>& nat, const std::vector<uint32_t>& leaf_list) const {
+        const std::string path = agg_cache_path(app_id);
+        if (path.empty()) return;
+        const size_t S = apps_.size();
+        std::vector<uint32_t> w{0x41474B43u, (uint32_t)S, H[0], H[1]};
+        for (size_t sh = 0; sh < S; sh++) {
+            w.push_back(nat[sh][0]), w.push_back(nat[sh][1]);
+            w.insert(w.end(), leaf_list.begin() + 8 * sh, leaf_list.begin() + 8 * sh + 8);
+        }
+        const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)getpid());
+        if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
+            const bool ok = std::fwrite(w.data(), 4, w.size(), f) == w.size();
+            std::fclose(f);
+            if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+        }
+    }
+    // a shape that was left out at setup: built now (its first segment proof has arrived), padded to the common heights, given its keys --
+    // and it must commit to what the aggregation key already states
+    void ensure_leaf(size_t sh) {
+        {
+            std::lock_guard<std::mutex> lk(*levels_mu_);
+            if (sh >= lazy_.size() || !lazy_[sh]) return;
+        }
+        std::lock_guard<std::mutex> build_lock(*build_mu_);
+        {
+            std::lock_guard<std::mutex> lk(*levels_mu_);
+            if (!lazy_[sh]) return;
+        }
+        using clk = std::chrono::steady_clock;
+        const auto t0 = clk::now();
+        std::vector<uint32_t> app_id(8);
+        {
+            std::vector<zkhip_air> za = app_.as_airs();
+            if (zkhip_recursion_vk_digest(&app_.params, za.data(), za.size(), app_id.data()) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_vk_digest");
+        }
+        Level leaf, big;
+        std::vector<zkhip_air> la;
+        try {
+            build_leaf_circuit(sh, app_id, &leaf);
+            if (policy_[sh].wrapped) wrap_leaf(sh, &leaf, &big);
+            pad_leaf(leaf, lv(1), &la);
+            keygen_level(leaf, la);
+            const std::vector<uint32_t> c = leaf.vk.key_commit();
+            if (!std::equal(c.begin(), c.end(), leaf_list_.begin() + 8 * sh))
+                throw Error(Error::Setup, "aggregation: shape " + std::to_string(sh) + " commits to another key than the cached one the aggregation key states (a stale key cache: delete it)");
+        } catch (...) {
+            free_level(leaf), free_level(big);
+            throw;
+        }
+        stats.build_seconds += std::chrono::duration<double>(clk::now() - t0).count();
+        std::lock_guard<std::mutex> lk(*levels_mu_);
+        leafs_[sh] = std::move(leaf);
+        bigleafs_[sh] = std::move(big);
+        lazy_[sh] = 0;
+    }
     // ONE KEY: the leaf circuit (for the app's key) and the internal circuit (for the node AIR set at the common heights) are built
     // together -- the internal circuit verifies proofs of its own height, so the common height set is a fixed point: start from the leaf
     // circuit's natural heights, build the internal circuit for children of that height, grow until it fits; then pad both.
@@ -1043,43 +1211,42 @@ private:
             if (zkhip_recursion_vk_digest(&app_.params, za.data(), za.size(), app_id.data()) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_vk_digest");
         }
         try {
+            // what an earlier process of this very key left on disk: per shape the natural heights of its leaf circuit (or wrapper) and the
+            // commitment of its padded key.  Shape 0 (the smallest: every run uses it, and its chips' programs are the node AIR set) is
+            // always built; the others only if the cache does not know them.
+            AggCache cache = load_agg_cache(app_id);
+            lazy_.assign(S, 0);
+            for (size_t sh = 1; sh < S; sh++) lazy_[sh] = cache.hit && !getenv("ZKHIP_AGG_NO_LAZY") ? 1 : 0;
             // the leaf circuits side by side (host only: seconds each for a 50-chip key)
             std::vector<std::string> errs(S);
             std::vector<std::thread> th;
             for (size_t sh = 0; sh < S; sh++)
-                th.emplace_back([&, sh] {
-                    std::vector<uint32_t> cols[4];
-                    zkhip_recursion_stmt st = leaf_stmt(cols);
-                    st.uniform = 1;
-                    st.app_id = S > 1 ? app_id.data() : nullptr;
-                    std::vector<zkhip_air> za = apps_[sh].as_airs();
-                    const int rc = zkhip_recursion_build(&apps_[sh].params, za.data(), za.size(), arity(0, sh), &st, &leafs[sh].circ);
-                    if (rc != ZKHIP_OK) errs[sh] = std::string("aggregation: cannot build the leaf verifier circuit of shape ") + std::to_string(sh) + ": " + zkhip_recursion_last_error(nullptr);
-                });
+                if (!lazy_[sh])
+                    th.emplace_back([&, sh] {
+                        try {
+                            build_leaf_circuit(sh, app_id, &leafs[sh]);
+                        } catch (const std::exception& e) {
+                            errs[sh] = e.what();
+                        }
+                    });
             for (auto& t : th) t.join();
             for (const auto& e : errs)
                 if (!e.empty()) throw Error(Error::Setup, e);
             // a WRAPPED shape: its leaf circuit keeps its natural heights and gets its keys now (the wrapper is a circuit FOR that key); what
             // takes the shape's place among the tree's leaf circuits is the wrapper (one child, the one-key public-value layout restated)
-            for (size_t sh = 0; sh < S; sh++) {
-                if (!policy_[sh].wrapped) continue;
-                bigs[sh] = std::move(leafs[sh]);
-                leafs[sh] = Level{};
-                bigs[sh].vk.params = agg_params_.leaf;
-                std::vector<zkhip_air> ba;
-                circuit_airs(bigs[sh].circ, &bigs[sh].vk, &ba);
-                keygen_level(bigs[sh], ba);
-                std::vector<zkhip_air> za = bigs[sh].vk.as_airs();
-                zkhip_recursion_stmt st{};
-                st.child_is_node = 1, st.uniform = 1;
-                const int rc = zkhip_recursion_build(&bigs[sh].vk.params, za.data(), za.size(), 1, &st, &leafs[sh].circ);
-                if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the wrapper of shape ") + std::to_string(sh) + ": " + zkhip_recursion_last_error(nullptr));
-            }
+            for (size_t sh = 0; sh < S; sh++)
+                if (policy_[sh].wrapped && !lazy_[sh]) wrap_leaf(sh, &leafs[sh], &bigs[sh]);
             unsigned H[2] = {0, 0};
+            std::vector<std::array<unsigned, 2>> nat(S);
             for (size_t sh = 0; sh < S; sh++) {
-                leafs[sh].vk.params = agg_params_.leaf;
-                circuit_airs(leafs[sh].circ, &leafs[sh].vk, &la[sh]);
-                H[0] = std::max(H[0], la[sh][0].log_height), H[1] = std::max(H[1], la[sh][1].log_height);
+                if (lazy_[sh]) {
+                    nat[sh] = cache.nat.at(sh);
+                } else {
+                    leafs[sh].vk.params = agg_params_.leaf;
+                    circuit_airs(leafs[sh].circ, &leafs[sh].vk, &la[sh]);
+                    nat[sh] = {la[sh][0].log_height, la[sh][1].log_height};
+                }
+                H[0] = std::max(H[0], nat[sh][0]), H[1] = std::max(H[1], nat[sh][1]);
             }
             for (int round = 0;; round++) {
                 if (round > 8) throw Error(Error::Setup, "aggregation: the common height of the leaf and internal circuits does not settle");
@@ -1095,19 +1262,29 @@ private:
                 if (ia[0].log_height == H[0] && ia[1].log_height == H[1]) break;
                 H[0] = ia[0].log_height, H[1] = ia[1].log_height;
             }
+            common_h_[0] = H[0], common_h_[1] = H[1];
+            if (cache.hit && (cache.h[0] != H[0] || cache.h[1] != H[1])) throw Error(Error::Setup, "aggregation: the key cache " + cache.path + " does not belong to this build (common heights differ): delete it");
             for (size_t sh = 0; sh < S; sh++) {
-                if (zkhip_recursion_pad(leafs[sh].circ, H) != ZKHIP_OK) throw Error(Error::Setup, "aggregation: zkhip_recursion_pad");
-                circuit_airs(leafs[sh].circ, &leafs[sh].vk, &la[sh]);
-                for (size_t i = 0; i < 3; i++)
-                    if (leafs[sh].vk.airs[i].program != internal.vk.airs[i].program || leafs[sh].vk.heights[i] != internal.vk.heights[i])
-                        throw Error(Error::Setup, "aggregation: the leaf and the internal circuit do not share one AIR set");
+                if (lazy_[sh]) continue;
+                pad_leaf(leafs[sh], internal, &la[sh]);
             }
             auto t1 = clk::now();
-            leaf_list_.clear();
+            leaf_list_.assign(8 * S, 0);
             for (size_t sh = 0; sh < S; sh++) {
+                if (lazy_[sh]) {
+                    std::copy(cache.commit.at(sh).begin(), cache.commit.at(sh).end(), leaf_list_.begin() + 8 * sh);
+                    continue;
+                }
                 keygen_level(leafs[sh], la[sh]);
                 const std::vector<uint32_t> c = leafs[sh].vk.key_commit();
-                leaf_list_.insert(leaf_list_.end(), c.begin(), c.end());
+                std::copy(c.begin(), c.end(), leaf_list_.begin() + 8 * sh);
+                if (cache.hit && !std::equal(c.begin(), c.end(), cache.commit.at(sh).begin()))
+                    throw Error(Error::Setup, "aggregation: the key cache " + cache.path + " does not belong to this build (shape " + std::to_string(sh) + " commits differently): delete it");
+            }
+            if (!cache.hit) {
+                bool all = true;
+                for (size_t sh = 0; sh < S; sh++) all = all && !lazy_[sh];
+                if (all) store_agg_cache(app_id, H, nat, leaf_list_);
             }
             keygen_level(internal, ia);
             internal_commit_ = internal.vk.key_commit();

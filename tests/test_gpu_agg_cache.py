@@ -1,0 +1,79 @@
+"""GPU: leaf circuits built on demand, their commitments cached on disk (include/zkhip_aggregation.hpp ensure_leaf / load_agg_cache; VERDICT
+round 4 item 3: under the chunk-circuit configuration the 26- and 51-chip leaf circuits cost seconds of every process, used or not).
+
+The first run of a key builds every shape's leaf circuit and writes the cache; later runs build shape 0 and the internal circuit only, take
+the other shapes' commitments from the file -- the aggregation key (root.vk) must be byte-identical -- and build a shape when its first
+segment proof arrives, insisting that it commits to what the key states."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import prover_mirror_util as pm  # noqa: E402
+import rv32_model as rv  # noqa: E402
+from test_vm_cpu import CHUNK_CIRCUIT_CURVES, CHUNK_CIRCUIT_MODULI, MIXED_PHASE_ITERATIONS, chunk_circuit_toml, fib_program, mixed_chunk_data, mixed_chunk_program  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+PARAMS = (1, 0, 100, 16, 16)
+
+
+def prove(tmp, name, elf, stdin, frame, **env):
+    out = tmp / name
+    out.mkdir()
+    r = subprocess.run([pm.CLI, "prove-elf", str(elf), str(stdin), str(out), str(tmp / "openvm.toml"), str(frame)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["verified"]
+    return info, (out / "root.vk").read_bytes(), out
+
+
+def test_unused_shapes_are_not_built_and_the_key_does_not_change(tmp_path):
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    (tmp_path / "openvm.toml").write_text(chunk_circuit_toml(PARAMS))
+    elf, stdin = tmp_path / "fib.elf", tmp_path / "stdin.bin"
+    elf.write_bytes(rv.elf_bytes(fib_program()))
+    stdin.write_bytes((60000).to_bytes(4, "little"))
+    env = {"ZKHIP_AGG_CACHE_DIR": str(cache)}
+    first, vk1, _ = prove(tmp_path, "first", elf, stdin, 14, **env)
+    assert len(list(cache.glob("agg_*.key"))) == 1
+    second, vk2, out2 = prove(tmp_path, "second", elf, stdin, 14, **env)
+    eager, vk3, _ = prove(tmp_path, "eager", elf, stdin, 14, ZKHIP_AGG_NO_LAZY="1", **env)
+    assert vk1 == vk2 == vk3                                                   # ONE aggregation key, cached or not
+    assert first["segments_per_shape"][2:] == [0, 0]                           # a Fibonacci guest never needs the wide shapes ...
+    assert second["aggregation_circuits_build_s"] + second["aggregation_keygen_s"] < 0.6 * (first["aggregation_circuits_build_s"] + first["aggregation_keygen_s"])
+    print("setup (circuits + keys): first %.2f s, with the cache %.2f s; wall %.2f -> %.2f s" % (
+        first["aggregation_circuits_build_s"] + first["aggregation_keygen_s"], second["aggregation_circuits_build_s"] + second["aggregation_keygen_s"], first["wall_s"], second["wall_s"]))
+    assert pm.run_cli("verify-guest", str(elf), str(out2 / "root.vk"), str(tmp_path / "openvm.toml"), str(out2 / "root.json")).returncode == 0
+
+
+def test_a_cached_shape_is_built_when_its_first_segment_arrives(tmp_path):
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    (tmp_path / "openvm.toml").write_text(chunk_circuit_toml(PARAMS))
+    words, data = mixed_chunk_program(), mixed_chunk_data()
+    elf, stdin = tmp_path / "mixed.elf", tmp_path / "stdin.bin"
+    elf.write_bytes(rv.elf_bytes(words, data=data))
+    n = 3 * MIXED_PHASE_ITERATIONS + 5
+    stdin.write_bytes(n.to_bytes(4, "little"))
+    env = {"ZKHIP_AGG_CACHE_DIR": str(cache)}
+    first, vk1, _ = prove(tmp_path, "first", elf, stdin, 15, **env)
+    second, vk2, out2 = prove(tmp_path, "second", elf, stdin, 15, **env)           # the wide shapes come from the cache and are built on demand
+    assert vk1 == vk2
+    assert second["segments_per_shape"][2] > 0 and second["segments_per_shape"][3] > 0
+    model = rv.run(words, n.to_bytes(4, "little"), data=data, moduli=CHUNK_CIRCUIT_MODULI, curves=tuple((c[1], c[3]) for c in CHUNK_CIRCUIT_CURVES))
+    assert second["total_cycles"] == model["instret"]
+    assert pm.run_cli("verify-guest", str(elf), str(out2 / "root.vk"), str(tmp_path / "openvm.toml"), str(out2 / "root.json")).returncode == 0
+    # a cache file that states another commitment for a wide shape is caught when that shape is built
+    f = next(cache.glob("agg_*.key"))
+    b = bytearray(f.read_bytes())
+    b[-4] ^= 1
+    f.write_bytes(bytes(b))
+    out = tmp_path / "stale"
+    out.mkdir()
+    r = subprocess.run([pm.CLI, "prove-elf", str(elf), str(stdin), str(out), str(tmp_path / "openvm.toml"), "15"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "stale key cache" in r.stderr

@@ -144,8 +144,8 @@ def test_batch_circuit_config_and_a_bls12_381_guest(tmp_path):
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert bytes.fromhex(info["public_values"]) == bytes(model["pvs"]) and info["total_cycle"] == model["instret"]
     ids = np.fromfile(tmp_path / "air_ids.u32", dtype=np.uint32).tolist()
-    # the base chips + keccak (2) + sha2 (2) + two moduli (4) + one curve (2) + one Fp2 field (2)
-    assert len(ids) == 22 + 2 + 2 + 4 + 2 + 2
+    # the base chips + keccak (2) + sha2 (2) + two moduli (4) + one curve (2) + one Fp2 field (2) + native (2) + castf (1): no section ignored
+    assert len(ids) == 22 + 2 + 2 + 4 + 2 + 2 + 3
     segs = [tmp_path / ("seg-%d" % k) for k in range(info["segments"])]
     rec = lambda name: np.concatenate([np.fromfile(s / (name + ".u32"), dtype=np.uint32) for s in segs])  # noqa: E731
     # records of 12-word operands: op | a | b (25), op | x1 y1 x2 y2 | slope (61), op | a0 a1 | b0 b1 (49); adapter rows of 36 + 11 and 72 + 11 columns

@@ -548,3 +548,62 @@ def test_the_mixed_chunk_like_guest_runs_the_same_in_the_executor_and_the_model(
         for d_ in inst:
             assert air.check_trace(d_["program"], d_["trace"], d_["pvs"], d_.get("prep")) == [], k
         assert v2.bus_imbalance(inst) == {}
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_native_calls_agree_with_python_and_satisfy_the_chips(tmp_path, seed):
+    """Seeded random operands (any 32-bit words: the chips read them modulo p), every opcode of the field and the extension chip, casts of
+    random values below 2^30: the executor's memory after the calls is the Python model's (the guest XOR-folds every result word into its
+    public values), every trace satisfies its AIR and every bus balances."""
+    import random
+    import struct
+
+    from test_vm_cpu import A0, A1, A7, S0, T0, T1
+
+    rnd = random.Random(seed)
+    F = 2013265921
+    n_a, n_e, n_c = 24, 12, 6
+    arith = [(rnd.randrange(4), rnd.choice([rnd.randrange(1 << 32), rnd.randrange(F), F - 1, 0, 1]), rnd.choice([rnd.randrange(1, 1 << 32), F - 1, 1, 2])) for _ in range(n_a)]
+    arith = [(op, b, c if (op != 3 or c % F) else 7) for op, b, c in arith]                         # no division by zero
+    ext = [(rnd.randrange(4), [rnd.randrange(1 << 32) for _ in range(4)], [rnd.randrange(1, F) for _ in range(4)]) for _ in range(n_e)]
+    casts = [rnd.randrange(1 << 30) for _ in range(n_c)]
+    data = b"".join(struct.pack("<3I", b, c, 0) for _, b, c in arith) + b"".join(struct.pack("<12I", *x, *y, 0, 0, 0, 0) for _, x, y in ext) + b"".join(struct.pack("<2I", v, 0) for v in casts)
+    data += bytes(64)
+    p = rv.li(S0, 0x00400000)
+    e0, c0 = 12 * n_a, 12 * n_a + 48 * n_e
+    fold0 = c0 + 8 * n_c
+    for k, (op, _, _) in enumerate(arith):
+        p += [("addi", A0, S0, 12 * k), ("addi", A1, 0, op), ("addi", A7, 0, 9), ("ecall",), ("lw", T0, S0, 12 * k + 8), ("lw", T1, S0, fold0 + 4 * (k % 8)), ("xor", T1, T1, T0), ("sw", T1, S0, fold0 + 4 * (k % 8))]
+    for k, (op, _, _) in enumerate(ext):
+        p += [("addi", A0, S0, e0 + 48 * k), ("addi", A1, 0, op), ("addi", A7, 0, 10), ("ecall",)]
+        for q in range(4):
+            p += [("lw", T0, S0, e0 + 48 * k + 32 + 4 * q), ("lw", T1, S0, fold0 + 4 * ((k + q) % 8)), ("xor", T1, T1, T0), ("sw", T1, S0, fold0 + 4 * ((k + q) % 8))]
+    for k in range(n_c):
+        p += [("addi", A0, S0, c0 + 8 * k), ("addi", A7, 0, 11), ("ecall",), ("lw", T0, S0, c0 + 8 * k + 4), ("lw", T1, S0, fold0 + 4 * (k % 8)), ("xor", T1, T1, T0), ("sw", T1, S0, fold0 + 4 * (k % 8))]
+    for k in range(8):
+        p += [("lw", A0, S0, fold0 + 4 * k), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+    p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    words = rv.assemble(p)
+    model = rv.run(words, b"", data=data)
+    # the model's results against plain modular arithmetic (the field chip's four operations)
+    fold = [0] * 8
+    for k, (op, b, c) in enumerate(arith):
+        b_, c_ = b % F, c % F
+        fold[k % 8] ^= [(b_ + c_) % F, (b_ - c_) % F, b_ * c_ % F, b_ * pow(c_, -1, F) % F][op]
+    for k, (op, x, y) in enumerate(ext):
+        x_, y_ = [v % F for v in x], [v % F for v in y]
+        z = [(u + v) % F for u, v in zip(x_, y_)] if op == 0 else [(u - v) % F for u, v in zip(x_, y_)] if op == 1 else rv.ext4_mul(x_, y_) if op == 2 else rv.ext4_mul(x_, rv.ext4_pow(y_, F ** 4 - 2))
+        if op == 3:
+            assert rv.ext4_mul(z, y_) == x_                                                          # a quotient is what multiplies back
+        for q in range(4):
+            fold[(k + q) % 8] ^= z[q]
+    for k, v in enumerate(casts):
+        fold[k % 8] ^= v
+    assert [int.from_bytes(bytes(model["pvs"])[4 * k:4 * k + 4], "little") for k in range(8)] == fold
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 9, sections=("native", "castf"))
+    assert bytes.fromhex(info["public_values"]) == bytes(model["pvs"]) and info["total_cycle"] == model["instret"]
+    for rec in segs:
+        inst = v2.segment_instance(rec, words, PC_BASE, H)
+        for d_ in inst:
+            assert air.check_trace(d_["program"], d_["trace"], d_["pvs"], d_.get("prep")) == []
+        assert v2.bus_imbalance(inst) == {}

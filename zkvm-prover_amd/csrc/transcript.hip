@@ -56,39 +56,6 @@ __device__ __forceinline__ uint32_t tr_sample1(TrRegs& r, unsigned lane) {
     return __shfl(r.s, (int)r.n_out, 64);
 }
 
-// The same three steps for a state that lives in ONE 16-lane row of a wave (any row: the proof-of-work searches give every row a candidate
-// of its own), with the round constants preloaded.
-__device__ __forceinline__ void tr_observe1_row(TrRegs& r, unsigned lane16, uint32_t v, const CoopConsts& cc) {
-    r.n_out = 0;
-    if (lane16 == r.n_in) r.s = v;
-    r.n_in++;
-    if (r.n_in == 8) r.s = coop_permute_regs(r.s, lane16, cc), r.n_in = 0, r.n_out = 8;
-}
-__device__ __forceinline__ uint32_t tr_sample1_row(TrRegs& r, unsigned lane16, const CoopConsts& cc) {
-    if (r.n_in != 0 || r.n_out == 0) r.s = coop_permute_regs(r.s, lane16, cc), r.n_in = 0, r.n_out = 8;
-    r.n_out--;
-    return __shfl(r.s, (int)((threadIdx.x & 48u) + r.n_out), 64);
-}
-// One sweep of a proof-of-work search with ONE CANDIDATE PER 16-LANE ROW (round 5): observe(w); sample_bits(bits) on a private copy `r0` of
-// the transcript through the cooperative permutation -- ~3 us of dependent instructions per candidate where one lane per candidate took
-// ~20 (the search is a latency, not a throughput: 2^16 candidates are one permutation deep on this chip either way).  Rows take candidates
-// base + row, base advancing by the number of rows; a row leaves once a witness below its next window is known, so the atomicMin result is
-// the smallest witness, as before.
-__device__ __forceinline__ void grind_rows(DevTranscript* t, const TrRegs& r0, unsigned lane16, const CoopConsts& cc, uint32_t mask, uint32_t limit) {
-    const uint32_t n_rows = (gridDim.x * blockDim.x) >> 4, row = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    for (uint32_t base = 0; base < limit; base += n_rows) {
-        const uint32_t found = __hip_atomic_load(&t->pow_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (found < base) break;
-        const uint32_t w = base + row;
-        if (w >= limit || w < base) continue;   // (uniform over the row: its 16 lanes stay together through the DPP permutation)
-        TrRegs r = r0;
-        tr_observe1_row(r, lane16, to_monty(w), cc);
-        const uint32_t chk = from_monty(tr_sample1_row(r, lane16, cc)) & mask;
-        if (lane16 == 0 && chk == 0) atomicMin(&t->pow_found, w);
-        if (base + n_rows < base) break;   // (no wrap-around)
-    }
-}
-
 __global__ void k_tr_init(DevTranscript* t) {
     if (threadIdx.x < 16) t->state[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
@@ -184,12 +151,28 @@ __device__ __forceinline__ void grind_apply(DevTranscript* t, unsigned bits, uin
 // minimum (= the first witness a sequential scan finds).  The LAST block to leave (a counter in the transcript) applies the witness
 // with its first wave and re-arms the transcript.
 __global__ __launch_bounds__(256) void k_grind(DevTranscript* t, unsigned bits, uint32_t limit, uint32_t* witness_out) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t mask = (1u << bits) - 1u;
-    {
-        const unsigned lane16 = threadIdx.x & 15u;
-        const CoopConsts cc = coop_load_consts(lane16);
-        const TrRegs r0 = tr_load(t, threadIdx.x);
-        grind_rows(t, r0, lane16, cc, mask, limit);
+    uint32_t s0[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s0[i] = t->state[i];
+    const uint32_t n_in = t->n_in;
+    for (uint32_t base = 0; base < limit; base += stride) {
+        // volatile read: other blocks publish with atomicMin (device scope)
+        const uint32_t found = __hip_atomic_load(&t->pow_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (found < base) break;
+        const uint32_t w = base + gid;
+        if (w >= limit || w < base) continue;
+        uint32_t s[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = s0[i];
+        const uint32_t wm = to_monty(w);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if ((uint32_t)i == n_in) s[i] = wm;
+        poseidon2_permute(s);
+        if ((from_monty(s[7]) & mask) == 0) atomicMin(&t->pow_found, w);
     }
     // every lane of the block has read the state it needed and published what it found: count the block out
     __shared__ uint32_t last;
@@ -210,13 +193,36 @@ __global__ __launch_bounds__(256) void k_grind(DevTranscript* t, unsigned bits, 
 // grind(0): witness 0).
 __global__ __launch_bounds__(256) void k_fri_round_transcript(DevTranscript* t, const uint32_t* __restrict__ root, unsigned bits, uint32_t limit,
                                                                uint32_t* __restrict__ proof_out, uint32_t* __restrict__ beta_out) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t mask = bits ? (1u << bits) - 1u : 0u;
     if (bits) {
-        const unsigned lane16 = threadIdx.x & 15u;
-        const CoopConsts cc = coop_load_consts(lane16);
-        TrRegs r0 = tr_load(t, threadIdx.x);
-        for (int k = 0; k < 8; k++) tr_observe1_row(r0, lane16, root[k], cc);   // observe(root) on the row's private copy
-        grind_rows(t, r0, lane16, cc, mask, limit);
+        uint32_t s0[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) s0[i] = t->state[i];
+        uint32_t n_in = t->n_in;
+        for (int k = 0; k < 8; k++) {   // observe(root[k]) on the private copy
+            const uint32_t v = root[k];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if ((uint32_t)i == n_in) s0[i] = v;
+            if (++n_in == 8) poseidon2_permute(s0), n_in = 0;
+        }
+        for (uint32_t base = 0; base < limit; base += stride) {
+            const uint32_t found = __hip_atomic_load(&t->pow_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (found < base) break;
+            const uint32_t w = base + gid;
+            if (w >= limit || w < base) continue;
+            uint32_t s[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) s[i] = s0[i];
+            const uint32_t wm = to_monty(w);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if ((uint32_t)i == n_in) s[i] = wm;
+            poseidon2_permute(s);
+            if ((from_monty(s[7]) & mask) == 0) atomicMin(&t->pow_found, w);
+        }
     }
     __shared__ uint32_t last;
     __threadfence();
@@ -340,7 +346,7 @@ int transcript_grind(zkhip_ctx* ctx, DevTranscript* d_t, unsigned bits, uint32_t
         // a sweep covers 2^bits candidates (the expected position of the witness): measured on a node proof's 21 grinds 1.08 ms against
         // 1.22 ms with 2^(bits+1) and 1.64 ms with 2^(bits+2) per sweep -- a permutation per lane is latency, more lanes only queue
         const unsigned grind_shift = std::min(ctx->cfg.grind_sweep_shift, 8u);
-        unsigned blocks = std::min(4096u, std::max(64u, ((1u << grind_shift) << bits) / 16u));
+        unsigned blocks = std::min(4096u, std::max(64u, ((1u << grind_shift) << bits) / 256u));
         hipLaunchKernelGGL(k_grind, dim3(blocks), dim3(256), 0, ctx->stream, d_t, bits, (uint32_t)P, d_witness_out);
     }
     ZK_HIP_CHECK(ctx, hipGetLastError());
@@ -352,7 +358,7 @@ int transcript_fri_round(zkhip_ctx* ctx, DevTranscript* d_t, const uint32_t* d_r
     if (bits > 30) return set_error(ctx, ZKHIP_ERR_INVALID, "pow bits > 30");
     KernelScope ks(ctx, "fri_round_transcript");
     const unsigned grind_shift = std::min(ctx->cfg.grind_sweep_shift, 8u);
-    const unsigned blocks = bits ? std::min(4096u, std::max(64u, ((1u << grind_shift) << bits) / 16u)) : 1u;
+    const unsigned blocks = bits ? std::min(4096u, std::max(64u, ((1u << grind_shift) << bits) / 256u)) : 1u;
     hipLaunchKernelGGL(k_fri_round_transcript, dim3(blocks), dim3(256), 0, ctx->stream, d_t, d_root, bits, (uint32_t)P, d_proof_out, d_beta_out);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return ZKHIP_OK;
