@@ -118,7 +118,11 @@ struct SegmentCaps {
         c.log_height[vmc::A_DIVREM] = sub(5), c.log_height[vmc::A_SHIFT] = sub(3), c.log_height[vmc::A_BEQ] = sub(2), c.log_height[vmc::A_BLT] = sub(2);
         c.log_height[vmc::A_JAL_LUI] = sub(3), c.log_height[vmc::A_AUIPC] = sub(5), c.log_height[vmc::A_JALR] = sub(4), c.log_height[vmc::A_LS] = sub(1);
         // (floors: a handful of touched blocks already needs ~28 path nodes each and two permutations per row)
-        c.log_height[vmc::A_ECALL] = std::max(sub(7), 3u), c.log_height[vmc::A_LEAF] = std::max(sub(5), 4u);
+        c.log_height[vmc::A_ECALL] = std::max(sub(7), 3u);
+        // (touched blocks: as many rows as the path-node chip -- a DENSE footprint has about one path node per block, and the Poseidon2 chip below holds
+        // two permutations for each of both; round 4 had half as many rows here, and a guest sweeping a 64 KiB array ended every segment at one
+        // sweep, its frame half empty: 66 segments where 34 do)
+        c.log_height[vmc::A_LEAF] = std::max(sub(4), 4u);
         c.log_height[vmc::A_MERKLE] = std::max(sub(4), 8u);
         c.log_height[vmc::A_POSEIDON2] = std::max(sub(2), c.log_height[vmc::A_MERKLE] + 2), c.log_height[vmc::A_CONNECTOR] = 0, c.log_height[vmc::A_BITWISE] = 16;
         c.log_height[vmc::A_RANGE_TUPLE] = 19, c.log_height[vmc::A_RANGE] = 16;
