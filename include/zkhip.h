@@ -934,8 +934,10 @@ typedef struct {
     uint32_t coop_max_log, coop_inj_max_log; /* largest tree layer (plain / with injected rows) in the cooperative form [ZKHIP_COOP_MAX_LOG, ZKHIP_COOP_INJ_MAX_LOG] */
     uint32_t top_max_log;                    /* the layers from 2^top_max_log nodes down to the root are ONE launch of one workgroup (<= 8) [ZKHIP_TOP_MAX_LOG] */
     uint32_t commit_parts, side_cus;         /* pipelined trace commit (zkhip_set_commit_pipeline / zkhip_set_cu_partition) [ZKHIP_COMMIT_PARTS, ZKHIP_SIDE_CUS] */
-    /* the verifier circuit's witness (no context): threads of the query parts (0 = all cores), page-locking of the wire values for the
-     * copy to the device, queries of a child side by side [ZKHIP_WITNESS_THREADS, ZKHIP_NO_PIN_WITNESS=1 -> 0, ZKHIP_RECURSION_SERIAL_QUERIES=1 -> 0] */
+    /* the verifier circuit's witness: threads of the query parts (0 = all cores) and queries of a child side by side are read from the
+     * PROCESS configuration (the witness generator has no context: zkhip_set_process_config); page-locking of the wire values for the copy
+     * to the device is a property of the CONTEXT that generates the node's traces (zkhip_recursion_tracegen reads its ctx's field)
+     * [ZKHIP_WITNESS_THREADS, ZKHIP_NO_PIN_WITNESS=1 -> 0, ZKHIP_RECURSION_SERIAL_QUERIES=1 -> 0] */
     uint32_t witness_threads;
     int pin_witness, parallel_queries;
     /* diagnosis: after every proof the prover recomputes every plain layer of the proof's Merkle trees (and the FRI leaves) on the device

@@ -205,6 +205,7 @@ public:
         size_t nodes = 0;
         std::vector<size_t> nodes_per_slot;   // how the tree's nodes spread over the device slots
         double witness_seconds = 0, tracegen_prove_seconds = 0, verify_seconds = 0, keygen_seconds = 0, build_seconds = 0;
+        size_t leafs_at_setup = 0, leafs_on_demand = 0;   // leaf circuits built with the key / when a shape's first segment proof arrived
     };
 
     // PER-PROOF CHIP PRESENCE (the reference proves only the chips a segment used: AGENTS.md:183-185): an app may have several SHAPES -- sets of
@@ -1185,6 +1186,7 @@ private:
             throw;
         }
         stats.build_seconds += std::chrono::duration<double>(clk::now() - t0).count();
+        stats.leafs_on_demand++;
         std::lock_guard<std::mutex> lk(*levels_mu_);
         leafs_[sh] = std::move(leaf);
         bigleafs_[sh] = std::move(big);
@@ -1263,6 +1265,7 @@ private:
                 H[0] = ia[0].log_height, H[1] = ia[1].log_height;
             }
             common_h_[0] = H[0], common_h_[1] = H[1];
+            for (size_t sh = 0; sh < S; sh++) stats.leafs_at_setup += lazy_[sh] ? 0 : 1;
             if (cache.hit && (cache.h[0] != H[0] || cache.h[1] != H[1])) throw Error(Error::Setup, "aggregation: the key cache " + cache.path + " does not belong to this build (common heights differ): delete it");
             for (size_t sh = 0; sh < S; sh++) {
                 if (lazy_[sh]) continue;

@@ -238,21 +238,25 @@ private:
     // circuit proves nothing about them -- the guest checks what it reads (a square root by one multiplication and an equality test).
     //   kind 0, buffer [modulus index]:            pushes a quadratic non-residue z of that modulus (nw words)
     //   kind 1, buffer [modulus index | x (nw)]:   pushes [s | r (nw)]: s = 1 and r^2 = x if x is a square, else s = 0 and r^2 = x z
-    //   kind 2, buffer [pairing curve | f (96 words)]: the pairing extension's final-exponentiation witness (include/zkhip_pairing.hpp): pushes
-    //           c and u (96 words each, OpenVM's SexticExtField<Fp2> layout) with c^lambda = f u; curve 0 = Bn254, needs `[app_vm_config.pairing]`
+    //   kind 2, buffer [pairing curve | f]: the pairing extension's final-exponentiation witness (include/zkhip_pairing.hpp): pushes c and the
+    //           scaling factor (OpenVM's SexticExtField<Fp2> layout: 96 words each for curve 0 = Bn254, 144 for curve 1 = Bls12_381) with
+    //           c^lambda = f u; needs `[app_vm_config.pairing]`
     void phantom(uint32_t kind, uint32_t ptr) {
         using namespace zkhip::modular;
         if (kind > 2) throw Error("unknown phantom instruction " + std::to_string(kind));
         if (ptr & 3u) throw Error("phantom operand must be word-aligned");
         if (kind == 2) {
             if (!pairing_) throw Error("pairing hint: the app's openvm.toml does not enable the pairing extension");
-            uint32_t buf[97];
-            memcpy(buf, at(ptr, 4 * 97), 4 * 97);
-            if (buf[0] != 0) throw Error("pairing hint: curve " + std::to_string(buf[0]) + " (only 0 = Bn254 is built; BLS12-381's witness needs another construction)");
-            uint32_t out[192];
+            uint32_t curve;
+            memcpy(&curve, at(ptr, 4), 4);
+            if (curve > 1) throw Error("pairing hint: curve " + std::to_string(curve) + " (0 = Bn254, 1 = Bls12_381)");
+            const unsigned n_in = curve ? 144u : 96u;
+            uint32_t buf[144], out[288];
+            memcpy(buf, at(ptr + 4, 4 * n_in), 4 * n_in);
             const char* why = "";
-            if (!zkhip::pairing::final_exp_hint_bn254(buf + 1, out, &why)) throw Error(std::string("pairing hint: ") + why);
-            hints_.insert(hints_.end(), out, out + 192);
+            const bool ok = curve ? zkhip::pairing::final_exp_hint_bls12_381(buf, out, &why) : zkhip::pairing::final_exp_hint_bn254(buf, out, &why);
+            if (!ok) throw Error(std::string("pairing hint: ") + why);
+            hints_.insert(hints_.end(), out, out + 2 * n_in);
             return;
         }
         uint32_t which;

@@ -547,6 +547,7 @@ struct GuestStark {
     std::vector<size_t> segments_per_shape, chips_per_shape;   // how many segments were proven under each shape, and how many chips a shape carries
     std::vector<size_t> instr_per_shape, prove_ms_per_shape, tracegen_ms_per_shape;   // per shape: instructions, summed proving / trace-generation time of its segments
     std::vector<size_t> nodes_per_slot;                        // how the tree's nodes spread over the device slots
+    size_t leaf_circuits_at_setup = 0, leaf_circuits_on_demand = 0;   // leaf circuits built with the aggregation key / when a shape's first segment arrived
     double agg_build_seconds = 0, agg_keygen_seconds = 0;      // the aggregation circuits and their keys (a one-time cost of a prover that lives on)
     std::vector<unsigned> node_log_heights;                    // heights of the node circuits' chips (gate, Poseidon2, public values)
     ExecutionResult exec;
@@ -837,6 +838,7 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
     g.aggregation_mills = ms(clk::now() - t0);
     g.nodes_per_slot = agg.stats.nodes_per_slot;
     g.agg_build_seconds = agg.stats.build_seconds, g.agg_keygen_seconds = agg.stats.keygen_seconds;
+    g.leaf_circuits_at_setup = agg.stats.leafs_at_setup, g.leaf_circuits_on_demand = agg.stats.leafs_on_demand;
     g.node_log_heights = g.root_vk.heights;
     return g;
 }

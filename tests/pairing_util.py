@@ -89,3 +89,67 @@ def sample_f(seed):
 
     g = [int.from_bytes(hashlib.sha256(b"zkhip pairing hint %d %d" % (seed, k)).digest(), "big") % P for k in range(12)]
     return power(g, R)
+
+
+# ---- BLS12-381 (`[app_vm_config.pairing] supported_curves = ["Bls12_381"]`, crates/circuits/batch-circuit/openvm.toml:25-26) ----------------
+# c^lambda = f s with lambda = p + |x|.  (p^12 - 1) / r = 27 * ((|x| + 1) / 3) * C, C coprime to the other two factors and to lambda: the
+# scaling factor s takes f to its component of order C (f s = f^e with e = 1 mod C and e = 0 mod the rest) and c is the lambda-th root there
+# (gnark's / OpenVM's construction).  Fp12 = Fp[w] / (w^12 - 2 w^6 + 2) (w^6 = 1 + u, u^2 = -1).
+class Bls12_381:
+    X = -0xd201000000010000
+    P = (X - 1)**2 * (X**4 - X**2 + 1) // 3 + X
+    R = X**4 - X**2 + 1
+    N = P**12 - 1
+    H = N // R
+    LAMBDA = P - X
+    SMALL = 27 * (abs(X - 1) // 3)
+    C = H // SMALL
+    ONE = [1] + [0] * 11
+
+    @classmethod
+    def mul(cls, a, b):
+        t = [0] * 23
+        for i, x in enumerate(a):
+            if x:
+                for j, y in enumerate(b):
+                    t[i + j] += x * y
+        for k in range(22, 11, -1):
+            c = t[k]
+            if c:
+                t[k - 6] += 2 * c
+                t[k - 12] -= 2 * c
+        return [v % cls.P for v in t[:12]]
+
+    @classmethod
+    def power(cls, a, e):
+        r, b = cls.ONE, a
+        while e:
+            if e & 1:
+                r = cls.mul(r, b)
+            b = cls.mul(b, b)
+            e >>= 1
+        return r
+
+    @classmethod
+    def from_sextic(cls, c):
+        return [(c[k][0] - c[k][1]) % cls.P for k in range(6)] + [c[k][1] % cls.P for k in range(6)]
+
+    @classmethod
+    def to_sextic(cls, f):
+        return [((f[k] + f[k + 6]) % cls.P, f[k + 6]) for k in range(6)]
+
+    @classmethod
+    def final_exp_hint(cls, f):
+        assert cls.H % cls.SMALL == 0 and cls.LAMBDA % cls.R == 0
+        assert cls.power(f, cls.H) == cls.ONE, "f is not in the subgroup a Miller loop's output lies in"
+        e = cls.SMALL * pow(cls.SMALL, -1, cls.C) % cls.H
+        s = cls.power(f, (e - 1) % cls.H)
+        c = cls.power(f, e * pow(cls.LAMBDA, -1, cls.C) % cls.H)
+        return c, s
+
+    @classmethod
+    def sample_f(cls, seed):
+        import hashlib
+
+        g = [int.from_bytes(hashlib.sha512(b"zkhip pairing hint bls %d %d" % (seed, k)).digest(), "big") % cls.P for k in range(12)]
+        return cls.power(g, cls.R)

@@ -228,14 +228,17 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
                 if kind == 2:   # the pairing extension's final-exponentiation witness (tests/pairing_util.py): [curve | f] -> c, u
                     import pairing_util as pu
 
-                    wds = struct.unpack_from("<97I", mem, off)
-                    assert wds[0] == 0
-                    el = lambda k: sum(wds[1 + 8 * k + i] << (32 * i) for i in range(8))  # noqa: E731
-                    c_, u_ = pu.final_exp_hint(pu.from_sextic([(el(2 * k), el(2 * k + 1)) for k in range(6)]))
+                    curve, = struct.unpack_from("<I", mem, off)
+                    assert curve in (0, 1)
+                    ew = 12 if curve else 8                      # words per base-field element
+                    wds = struct.unpack_from("<%dI" % (12 * ew), mem, off + 4)
+                    el = lambda k: sum(wds[ew * k + i] << (32 * i) for i in range(ew))  # noqa: E731
+                    cv = pu.Bls12_381 if curve else pu
+                    c_, u_ = cv.final_exp_hint(cv.from_sextic([(el(2 * k), el(2 * k + 1)) for k in range(6)]))
                     for v in (c_, u_):
-                        for a_, b_ in pu.to_sextic(v):
+                        for a_, b_ in cv.to_sextic(v):
                             for e_ in (a_, b_):
-                                hints.extend((e_ >> (32 * i)) & M32 for i in range(8))
+                                hints.extend((e_ >> (32 * i)) & M32 for i in range(ew))
                     rec["alu"].append((0, 0, 0))
                     pc, n = pc + 4, n + 1
                     continue

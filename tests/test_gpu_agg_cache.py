@@ -45,7 +45,8 @@ def test_unused_shapes_are_not_built_and_the_key_does_not_change(tmp_path):
     eager, vk3, _ = prove(tmp_path, "eager", elf, stdin, 14, ZKHIP_AGG_NO_LAZY="1", **env)
     assert vk1 == vk2 == vk3                                                   # ONE aggregation key, cached or not
     assert first["segments_per_shape"][2:] == [0, 0]                           # a Fibonacci guest never needs the wide shapes ...
-    assert second["aggregation_circuits_build_s"] + second["aggregation_keygen_s"] < 0.6 * (first["aggregation_circuits_build_s"] + first["aggregation_keygen_s"])
+    assert first["leaf_circuits_at_setup"] == eager["leaf_circuits_at_setup"] == len(first["chips_per_shape"]) and first["leaf_circuits_on_demand"] == 0
+    assert second["leaf_circuits_at_setup"] == 1 and second["leaf_circuits_on_demand"] == 0      # ... and with the cache they are never built
     print("setup (circuits + keys): first %.2f s, with the cache %.2f s; wall %.2f -> %.2f s" % (
         first["aggregation_circuits_build_s"] + first["aggregation_keygen_s"], second["aggregation_circuits_build_s"] + second["aggregation_keygen_s"], first["wall_s"], second["wall_s"]))
     assert pm.run_cli("verify-guest", str(elf), str(out2 / "root.vk"), str(tmp_path / "openvm.toml"), str(out2 / "root.json")).returncode == 0
@@ -65,6 +66,7 @@ def test_a_cached_shape_is_built_when_its_first_segment_arrives(tmp_path):
     second, vk2, out2 = prove(tmp_path, "second", elf, stdin, 15, **env)           # the wide shapes come from the cache and are built on demand
     assert vk1 == vk2
     assert second["segments_per_shape"][2] > 0 and second["segments_per_shape"][3] > 0
+    assert second["leaf_circuits_at_setup"] == 1 and second["leaf_circuits_on_demand"] == sum(1 for k, n_ in enumerate(second["segments_per_shape"]) if k and n_)
     model = rv.run(words, n.to_bytes(4, "little"), data=data, moduli=CHUNK_CIRCUIT_MODULI, curves=tuple((c[1], c[3]) for c in CHUNK_CIRCUIT_CURVES))
     assert second["total_cycles"] == model["instret"]
     assert pm.run_cli("verify-guest", str(elf), str(out2 / "root.vk"), str(tmp_path / "openvm.toml"), str(out2 / "root.json")).returncode == 0

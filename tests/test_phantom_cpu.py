@@ -100,10 +100,42 @@ def test_the_pairing_hint_refuses_what_it_cannot_witness(tmp_path):
     assert r.returncode != 0 and "does not lie in the subgroup" in r.stderr
     r = run(pairing_hint_data(f_bad), toml=None)                         # an app without the pairing section has no such phantom
     assert r.returncode != 0 and "does not enable the pairing extension" in r.stderr
-    bls = bytearray(pairing_hint_data(f_bad))
-    bls[0] = 1                                                            # curve 1 = Bls12_381: not built, and said so
-    r = run(bytes(bls))
-    assert r.returncode != 0 and "only 0 = Bn254 is built" in r.stderr
+    other = bytearray(pairing_hint_data(f_bad))
+    other[0] = 2                                                          # there are two pairing curves
+    r = run(bytes(other))
+    assert r.returncode != 0 and "0 = Bn254, 1 = Bls12_381" in r.stderr
+
+
+def test_the_bls12_381_pairing_hint_is_pythons(tmp_path):
+    """curve 1 (`[app_vm_config.pairing] supported_curves = ["Bls12_381"]`, the batch circuit's): (c, s) with c^lambda = f s, lambda = p + |x|,
+    48-byte field elements -- the golden vectors are Python integers', the equation is checked on them, the C++ sub-executor leaves the same
+    288 words in the hint stream and the independent model agrees."""
+    import os
+
+    import pairing_util as pu
+    from test_vm_cpu import pairing_hint_data, pairing_hint_program
+
+    B = pu.Bls12_381
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pairing_hint_kat.json")))["bls12_381"]
+    words = pairing_hint_program(288)
+    (tmp_path / "stdin.bin").write_bytes(b"")
+    (tmp_path / "pairing.toml").write_text('[app_vm_config.pairing]\nsupported_curves = ["Bls12_381"]\n')
+    for case in kat["cases"][:2]:
+        f, c, sc = ([(int(a, 16), int(b, 16)) for a, b in case[name]] for name in ("f", "c", "s"))
+        assert B.power(B.from_sextic(c), int(kat["lambda"], 16)) == B.mul(B.from_sextic(f), B.from_sextic(sc))
+        hint_words = [(e >> (32 * i)) & 0xFFFFFFFF for v in (c, sc) for pair in v for e in pair for i in range(12)]
+        fold = [0] * 8
+        for k, wd in enumerate(hint_words):
+            fold[k % 8] ^= wd
+        data = pairing_hint_data(f, curve=1)
+        (tmp_path / "exe.bin").write_bytes(rv.exe_bytes(words, data=data))
+        r = subprocess.run([v2.CLI, "dump-segments", str(tmp_path / "exe.bin"), str(tmp_path / "stdin.bin"), str(tmp_path), "10", "0", "0", str(tmp_path / "pairing.toml")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        assert [int.from_bytes(bytes.fromhex(info["public_values"])[4 * k:4 * k + 4], "little") for k in range(8)] == fold, case["seed"]
+    model = rv.run(words, b"", data=data)
+    assert bytes(model["pvs"]) == bytes.fromhex(info["public_values"]) and info["total_cycle"] == model["instret"]
     # an ordinary FENCE stays a no-op
     words = rv.assemble([("fence",), ("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)])
     r = dump(tmp_path, words, bytes(64), PHANTOM_MODULI)

@@ -393,24 +393,25 @@ def mixed_chunk_data():
 
 # ---- the pairing extension (`[app_vm_config.pairing] supported_curves = ["Bn254"]`, crates/circuits/chunk-circuit/openvm.toml:35-36): no chip,
 # a phantom sub-executor that leaves the final-exponentiation witness in the hint stream (include/zkhip_pairing.hpp) ----
-def pairing_hint_program():
-    """phantom kind 2 on the buffer [curve = 0 | f] at the data base; then the 192 hinted words (c, u) are read one by one (a7 = 2) and
-    XOR-folded into eight words (word k into fold k mod 8), which are revealed"""
+def pairing_hint_program(n_hint_words=192):
+    """phantom kind 2 on the buffer [curve | f] at the data base; then the hinted words (c and the scaling factor: 192 for Bn254, 288 for
+    Bls12_381) are read one by one (a7 = 2) and XOR-folded into eight words (word k into fold k mod 8), which are revealed"""
     S2 = 18
-    p = rv.li(S0, 0x00400000) + [("phantom", 2, S0), ("addi", S2, 0, 0), ("addi", T2, 0, 192),
+    p = rv.li(S0, 0x00400000) + [("phantom", 2, S0), ("addi", S2, 0, 0), ("addi", T2, 0, n_hint_words),
                                  ("label", "rd"), ("addi", A7, 0, 2), ("ecall",),
-                                 ("andi", T0, S2, 7), ("slli", T0, T0, 2), ("add", T0, T0, S0), ("lw", T1, T0, 0x200), ("xor", T1, T1, A0), ("sw", T1, T0, 0x200),
+                                 ("andi", T0, S2, 7), ("slli", T0, T0, 2), ("add", T0, T0, S0), ("lw", T1, T0, 0x300), ("xor", T1, T1, A0), ("sw", T1, T0, 0x300),
                                  ("addi", S2, S2, 1), ("bne", S2, T2, "rd")]
     for k in range(8):
-        p += [("lw", A0, S0, 0x200 + 4 * k), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
+        p += [("lw", A0, S0, 0x300 + 4 * k), ("addi", A1, 0, k), ("addi", A7, 0, 1), ("ecall",)]
     p += [("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
     return rv.assemble(p)
 
 
-def pairing_hint_data(f_sextic):
-    """f_sextic: six (a, b) pairs of integers"""
-    out = (0).to_bytes(4, "little") + b"".join(int(a).to_bytes(32, "little") + int(b).to_bytes(32, "little") for a, b in f_sextic)
-    return out + bytes(0x240 - len(out))
+def pairing_hint_data(f_sextic, curve=0):
+    """f_sextic: six (a, b) pairs of integers; curve 0 = Bn254 (32-byte elements), 1 = Bls12_381 (48-byte)"""
+    nb = 48 if curve else 32
+    out = int(curve).to_bytes(4, "little") + b"".join(int(a).to_bytes(nb, "little") + int(b).to_bytes(nb, "little") for a, b in f_sextic)
+    return out + bytes(0x340 - len(out))
 
 # ---- the native / castf sections of the reference's batch and bundle circuits (crates/circuits/batch-circuit/openvm.toml:16,24;
 # bundle-circuit/openvm.toml:16,18): BabyBear arithmetic, its quartic extension, the cast of a field element to bytes ----
