@@ -182,7 +182,7 @@ def guest_flow_mixed():
     import subprocess
 
     here = os.path.dirname(os.path.abspath(__file__))
-    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py"), "1536", "17", "mixed"]
+    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py"), "4096", "19", "mixed"]
     try:
         runs = []
         for _ in range(2):
@@ -198,15 +198,17 @@ def guest_flow_mixed():
                 "ms_per_segment_proof_per_shape": g.get("ms_per_segment_proof_per_shape"), "instructions_per_segment_per_shape": g.get("instructions_per_segment_per_shape"),
                 "execution_ms": g["execution_ms"], "segments_ms": g["segment_tracegen_and_proving_ms"], "tree_tail_ms": g["aggregation_setup_wait_ms"] + g["aggregation_ms"],
                 "process_wall_s": g["wall_s"], "process_wall_s_first_run_on_this_box": runs[0]["wall_s"], "verified": g["verified"], "guest": g.get("guest"),
-                "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 1536 17 mixed"}
+                "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 4096 19 mixed"}
     except Exception as e:   # a reported extra, never a gate
         return {"value": None, "note": "failed: %r" % (e,)}
 
 
-def guest_flow(chunk_config=False):
-    """The path AROUND the headline kernel, reported beside it (never `value`): a Fibonacci guest of 4.2 M instructions through
+def guest_flow(chunk_config=False, memory_bound=False):
+    """The path AROUND the headline kernel, reported beside it (never `value`): a Fibonacci guest of 8.4 M instructions through
     `prove_cli prove-elf` (tools/guest_bench2.py) -- segmenting executor, 22 chips per segment as ONE statement, device trace generation,
-    segment proofs, aggregation tree on verifier circuits, ONE self-verified root proof, at the reference's FRI parameters.  Runs as a
+    segment proofs, aggregation tree on verifier circuits, ONE self-verified root proof, at the reference's FRI parameters, in frames of
+    2^19 instructions (round 5: `profiles/round05_frame_sweep.txt` -- 3.3 / 5.6 / 8.2 / 10.5 / 10.7 M instr/s at 2^16 .. 2^20; rounds 3 - 4
+    measured at 2^17).  memory_bound: the guest that sweeps a 64 KiB array 256 times (a load every fourth instruction).  Runs as a
     CHILD process BEFORE this process touches the GPU (a process that has initialised HIP must not start programs); twice: the first
     run pays the hipRTC compiles of a fresh box, the second is the one reported.  chunk_config: the same guest under the reference's
     chunk-circuit openvm.toml (crates/circuits/chunk-circuit/openvm.toml: 51 chips in the full set; a Fibonacci guest's segments carry
@@ -214,7 +216,7 @@ def guest_flow(chunk_config=False):
     import subprocess
 
     here = os.path.dirname(os.path.abspath(__file__))
-    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py"), "700000", "17"] + (["chunk"] if chunk_config else [])
+    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py")] + (["256", "19", "mem"] if memory_bound else ["1400000", "19"] + (["chunk"] if chunk_config else []))
     env = dict(os.environ, ZKHIP_LANES="3")
     try:
         runs = []
@@ -233,7 +235,8 @@ def guest_flow(chunk_config=False):
                 "chips_per_shape": g.get("chips_per_shape"), "segments_per_shape": g.get("segments_per_shape"),
                 "instr_per_s_segments_only": g.get("instr_per_s_segments_only"),
                 "instr_per_s_segments_plus_executor_busy_time": g.get("instr_per_s_segments_plus_executor_busy_time"),
-                "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 700000 17" + (" chunk" if chunk_config else "")}
+                "prove_speed_mhz": g.get("prove_speed_mhz"), "log_frame": g.get("log_frame"), "guest": g.get("guest"),
+                "command": "ZKHIP_LANES=3 python " + " ".join(["tools/guest_bench2.py"] + cmd[2:])}
     except Exception as e:   # a reported extra, never a gate
         return {"value": None, "note": "failed: %r" % (e,)}
 
@@ -243,13 +246,14 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     plumbing = os.environ.get("ZKHIP_BENCH_PLUMBING_ONLY") == "1"
-    guest = guest_chunk = guest_mixed = None
+    guest = guest_chunk = guest_mixed = guest_mem = None
     # (child processes: only before torch / HIP are loaded here, and never under a profiler -- its preloaded library has initialised the GPU
     # before this program starts; the profiling recipes pass --no-cpu-baseline or --no-guest-flow, either of which skips the guest flows)
     if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not plumbing and not args.no_guest_flow and not args.no_cpu_baseline and "torch" not in sys.modules:
         guest = guest_flow()
         guest_chunk = guest_flow(chunk_config=True)
         guest_mixed = guest_flow_mixed()
+        guest_mem = guest_flow(memory_bound=True)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -625,6 +629,8 @@ def main():
             out["guest_flow_chunk_config"] = guest_chunk
         if guest_mixed is not None:
             out["guest_flow_mixed"] = guest_mixed
+        if guest_mem is not None:
+            out["guest_flow_memory_bound"] = guest_mem
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -250,14 +250,34 @@ public:
         reset();
         app_ = std::move(o.app_), apps_ = std::move(o.apps_), leafs_ = std::move(o.leafs_), bigleafs_ = std::move(o.bigleafs_), policy_ = std::move(o.policy_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, agg_params_ = o.agg_params_, device_ = o.device_, levels_ = std::move(o.levels_), stats = o.stats;
         leaf_commit_ = std::move(o.leaf_commit_), internal_commit_ = std::move(o.internal_commit_), leaf_list_ = std::move(o.leaf_list_);
-        lazy_ = std::move(o.lazy_), common_h_[0] = o.common_h_[0], common_h_[1] = o.common_h_[1];
-        levels_mu_ = std::move(o.levels_mu_), build_mu_ = std::move(o.build_mu_);
+        lazy_ = std::move(o.lazy_), prefetching_ = std::move(o.prefetching_), prefetch_threads_ = std::move(o.prefetch_threads_), common_h_[0] = o.common_h_[0], common_h_[1] = o.common_h_[1];
+        levels_mu_ = std::move(o.levels_mu_), build_mu_ = std::move(o.build_mu_), shape_mu_ = std::move(o.shape_mu_);
         devices_ = std::move(o.devices_), slots_ = std::move(o.slots_);
         o.slots_.clear();
         return *this;
     }
     ~AggregationProver() { reset(); }
+    // A segment of `shape` has been EXECUTED (its proof is still being made): if the shape's leaf circuit was left out at setup, start
+    // building it now, beside the segment proving -- by the time the tree needs it, it is there (or ensure_leaf waits for the rest).
+    void prefetch_leaf(size_t shape) {
+        {
+            std::lock_guard<std::mutex> lk(*levels_mu_);
+            if (shape >= lazy_.size() || !lazy_[shape]) return;
+            if (prefetching_.size() < lazy_.size()) prefetching_.resize(lazy_.size(), 0);
+            if (prefetching_[shape]) return;
+            prefetching_[shape] = 1;
+        }
+        prefetch_threads_.emplace_back([this, shape] {
+            try {
+                ensure_leaf(shape);
+            } catch (...) {   // (the node that needs the shape runs ensure_leaf itself and reports)
+            }
+        });
+    }
     void reset() {
+        for (auto& t : prefetch_threads_)
+            if (t.joinable()) t.join();
+        prefetch_threads_.clear();
         for (auto* set : {&levels_, &leafs_, &bigleafs_})
             for (auto& L : *set) free_level(L);
         levels_.clear(), leafs_.clear(), bigleafs_.clear();
@@ -915,7 +935,8 @@ private:
     // (agg_cache_path) is not built at setup -- the wide shapes of the chunk configuration cost 3 - 4 s of circuit building and key
     // generation per process, used or not -- but when its first segment proof arrives (ensure_leaf), and what is built then must commit
     // to exactly what the cache said (the aggregation key already states it).
-    std::vector<char> lazy_;
+    std::vector<char> lazy_, prefetching_;
+    std::vector<std::thread> prefetch_threads_;   // (joined in reset(): they call ensure_leaf on this object)
     unsigned common_h_[2] = {0, 0};
     std::vector<VerifyingKey> apps_;   // the shapes' segment keys (apps_.back() = app_ = the full set)
     std::deque<Level> leafs_;          // one key: the leaf circuit of every shape (a wrapped shape: its wrapper); levels_[0] is then unused
@@ -930,6 +951,7 @@ private:
     // levels_mu_: the container (brief); build_mu_: one level is built at a time; a slot's mu: any call on its context.  Order: build ->
     // slot; levels_mu_ is never held while another one is taken.
     std::unique_ptr<std::mutex> levels_mu_, build_mu_;
+    std::vector<std::unique_ptr<std::mutex>> shape_mu_;   // ensure_leaf: one per shape.  Order: shape -> slot; shape -> levels_mu_ (brief)
     Level& lv(size_t level, size_t shape = 0) {
         std::lock_guard<std::mutex> lk(*levels_mu_);
         if (level == 0 && cfg_.one_key) return leafs_.at(shape);
@@ -1159,7 +1181,15 @@ private:
             std::lock_guard<std::mutex> lk(*levels_mu_);
             if (sh >= lazy_.size() || !lazy_[sh]) return;
         }
-        std::lock_guard<std::mutex> build_lock(*build_mu_);
+        // one shape is built once; DIFFERENT shapes side by side (the circuit builder is host code, seconds for a 50-chip key; the key
+        // generation takes the device slots' own locks) -- a guest whose segments fall into two wide shapes waits for the longer build, not
+        // for their sum
+        std::mutex* shape_mu;
+        {
+            std::lock_guard<std::mutex> lk(*levels_mu_);
+            shape_mu = shape_mu_.at(sh).get();
+        }
+        std::lock_guard<std::mutex> build_lock(*shape_mu);
         {
             std::lock_guard<std::mutex> lk(*levels_mu_);
             if (!lazy_[sh]) return;
@@ -1185,9 +1215,9 @@ private:
             free_level(leaf), free_level(big);
             throw;
         }
+        std::lock_guard<std::mutex> lk(*levels_mu_);
         stats.build_seconds += std::chrono::duration<double>(clk::now() - t0).count();
         stats.leafs_on_demand++;
-        std::lock_guard<std::mutex> lk(*levels_mu_);
         leafs_[sh] = std::move(leaf);
         bigleafs_[sh] = std::move(big);
         lazy_[sh] = 0;
@@ -1218,6 +1248,8 @@ private:
             // always built; the others only if the cache does not know them.
             AggCache cache = load_agg_cache(app_id);
             lazy_.assign(S, 0);
+            shape_mu_.clear();
+            for (size_t sh = 0; sh < S; sh++) shape_mu_.emplace_back(new std::mutex);
             for (size_t sh = 1; sh < S; sh++) lazy_[sh] = cache.hit && !getenv("ZKHIP_AGG_NO_LAZY") ? 1 : 0;
             // the leaf circuits side by side (host only: seconds each for a 50-chip key)
             std::vector<std::string> errs(S);

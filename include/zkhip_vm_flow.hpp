@@ -520,6 +520,7 @@ public:
     size_t n_shapes() const { return provers_.size(); }
     const VerifyingKey& vk(size_t shape) { return prover(shape).vk(); }
     const VerifyingKey& vk() { return vk(provers_.size() - 1); }
+    size_t shape_of(const SegmentRecords& r) const { return shapes_.shape_of(r); }
     SegmentProof prove(const SegmentRecords& r, bool self_verify = true, int force_shape = -1) {
         const size_t s = force_shape >= 0 ? (size_t)force_shape : shapes_.shape_of(r);
         SegmentProof p = prover(s).prove(r, self_verify);
@@ -787,6 +788,7 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
             const auto a = clk::now();
             done = ex.run_segment(it.rec);
             t_exec += clk::now() - a;
+            agg.prefetch_leaf(lanes[0]->shape_of(it.rec));   // (a shape whose leaf circuit was left out at setup is built beside the proving, from now)
             std::unique_lock<std::mutex> lk(mu);
             cv_push.wait(lk, [&] { return queue.size() < 2 * lanes.size() || failed; });
             queue.push_back(std::move(it));
@@ -981,7 +983,7 @@ inline SegmentCaps config_caps(const std::string& path_app_config, unsigned log_
                                   log_frame > 8 ? log_frame - 8 : 1, int256_log_rows(path_app_config, log_frame), config_curves(path_app_config), ec_log_rows(log_frame),
                                   config_fp2_moduli(path_app_config), config_native(path_app_config));
 }
-inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 17, int device = 0,
+inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 19, int device = 0,
                                         bool keep_segments = false, unsigned inflight = 2, unsigned log_keccak = 0, unsigned log_sha256 = 0,
                                         const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_int256 = 0,
                                         const std::vector<zkhip::ecc::Curve>& curves = {}, const std::vector<zkhip::modular::U256>& fp2_moduli = {},
@@ -1061,7 +1063,7 @@ public:
     std::string prover_name;
     ProverConfig config;
 
-    static UniversalProver setup(const ProverConfig& cfg, const char* name = nullptr, int device = 0, unsigned log_frame = 17) {
+    static UniversalProver setup(const ProverConfig& cfg, const char* name = nullptr, int device = 0, unsigned log_frame = 19) {
         UniversalProver p;
         p.config = cfg, p.prover_name = name ? name : "universal", p.device_ = device;
         std::ifstream f(cfg.path_app_exe, std::ios::binary);
@@ -1237,7 +1239,7 @@ private:
     zkhip_vm::SegmentCaps caps_;
     int device_ = 0;
     std::vector<std::unique_ptr<zkhip_vm::ShapedSegmentProver>> seg_;   // lanes: segment provers in flight on the device (one key per shape)
-    unsigned log_frame_ = 17;
+    unsigned log_frame_ = 19;
     std::unique_ptr<AggregationProver> agg_;
     std::unique_ptr<DeferralProver> deferral_;
     zkhip_vm::GuestStark last_;

@@ -98,9 +98,9 @@ int main(int argc, char** argv) {
             return 0;
         }
         if (argc >= 3 && std::string(argv[1]) == "chips") {
-            // chips <openvm.toml> [log_frame = 17]: the chips the app's configuration asks for -- every `[app_vm_config.*]` section of the file, none
+            // chips <openvm.toml> [log_frame = 19]: the chips the app's configuration asks for -- every `[app_vm_config.*]` section of the file, none
             // ignored (the reference's chunk / batch / bundle circuits: crates/circuits/*/openvm.toml) -- as a JSON line: name, columns, log height
-            const unsigned log_frame = argc >= 4 ? (unsigned)atoi(argv[3]) : 17;
+            const unsigned log_frame = argc >= 4 ? (unsigned)atoi(argv[3]) : 19;
             const zkhip_vm::SegmentCaps caps = zkhip_vm::config_caps(argv[2], log_frame, 10);
             zkhip_vm::Exe exe;
             exe.program.assign(64, 0x00000013u);
@@ -219,7 +219,7 @@ int main(int argc, char** argv) {
                 std::ofstream(cfg_path) << "[app_fri_params.fri_params]\nlog_blowup = 1\nlog_final_poly_len = 0\nnum_queries = 100\n"
                                            "commit_proof_of_work_bits = 16\nquery_proof_of_work_bits = 16\n";
             }
-            const unsigned log_frame = argc >= 7 ? (unsigned)atoi(argv[6]) : 17;
+            const unsigned log_frame = argc >= 7 ? (unsigned)atoi(argv[6]) : 19;
             UniversalProver up = UniversalProver::setup(ProverConfig{argv[2], cfg_path}, nullptr, 0, log_frame);
             ProvingTask task;
             if (is_task) {

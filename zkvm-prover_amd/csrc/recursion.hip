@@ -1141,17 +1141,25 @@ void build_programs(RecCore& K, const unsigned min_log[2]) {
         const size_t N = (size_t)1 << K.log_height[0];
         auto& pr = K.prep[0];
         pr.assign(GATE_PREP * N, 0);
-        for (size_t g = 0; g < c.gates.size(); g++) {
-            const Gate& G = c.gates[g];
-            for (int s = 0; s < 4; s++) {
-                pr[(size_t)s * N + g] = G.w[s];
-                pr[(size_t)(4 + s) * N + g] = G.role[s] == 1 ? zk::P - 1 : (G.role[s] == 2 ? c.fanout[G.w[s]] % zk::P : 0);
+        // (column-major: 18 scattered stores per gate, 6.7 M gates for a 51-chip child -- ranges of rows side by side)
+        const size_t n_gates = c.gates.size(), n_th = n_gates >= ((size_t)1 << 18) ? 4 : 1;
+        auto fill = [&](size_t g0, size_t g1) {
+            for (size_t g = g0; g < g1; g++) {
+                const Gate& G = c.gates[g];
+                for (int s = 0; s < 4; s++) {
+                    pr[(size_t)s * N + g] = G.w[s];
+                    pr[(size_t)(4 + s) * N + g] = G.role[s] == 1 ? zk::P - 1 : (G.role[s] == 2 ? c.fanout[G.w[s]] % zk::P : 0);
+                }
+                pr[8 * N + g] = from_monty(G.qM), pr[9 * N + g] = from_monty(G.qA), pr[10 * N + g] = from_monty(G.qB);
+                pr[11 * N + g] = from_monty(G.qC), pr[12 * N + g] = from_monty(G.qD);
+                for (int k = 0; k < 4; k++) pr[(size_t)(13 + k) * N + g] = from_monty(G.qK.c[k]);
+                pr[17 * N + g] = G.base;
             }
-            pr[8 * N + g] = from_monty(G.qM), pr[9 * N + g] = from_monty(G.qA), pr[10 * N + g] = from_monty(G.qB);
-            pr[11 * N + g] = from_monty(G.qC), pr[12 * N + g] = from_monty(G.qD);
-            for (int k = 0; k < 4; k++) pr[(size_t)(13 + k) * N + g] = from_monty(G.qK.c[k]);
-            pr[17 * N + g] = G.base;
-        }
+        };
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < n_th; t++) th.emplace_back(fill, n_gates * t / n_th, n_gates * (t + 1) / n_th);
+        fill(0, n_gates / n_th);
+        for (auto& t : th) t.join();
     }
     {
         const size_t N = (size_t)1 << K.log_height[1];
@@ -1251,6 +1259,13 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
     RecCore& K = *R->k;
     const size_t max_children = K.max_children;
     const StmtSpec& sp = K.spec;
+    const bool timing = getenv("ZKHIP_RECURSION_TIMING") != nullptr;   // stage times of the circuit builder on stderr
+    auto tprev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (timing) std::fprintf(stderr, "[recursion build] %-28s %.3f s\n", what, std::chrono::duration<double>(now - tprev).count());
+        tprev = now;
+    };
     try {
         Builder b;
         const size_t NS = K.n_state;
@@ -1275,6 +1290,7 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
         }
         b.close_input_rows();
         b.c.sections.push_back(b.c.order.size());
+        lap("children verified");
         const ChildVk& vk = K.vk;
         const size_t n_airs = vk.pg.size();
         std::vector<Lane> pvl;   // the node's public values
@@ -1534,6 +1550,7 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
         b.c.n_pvs = pvl.size();
         while (pvl.size() % 4) pvl.push_back(Lane{cst(ext_zero()), -1});
         for (size_t g = 0; g < pvl.size(); g += 4) b.c.pv_wires.push_back(b.use(b.pack_lanes(&pvl[g])));
+        lap("statement");
         // May the queries of a child run side by side?  Every wire a query part reads must be written by a constant row, by the child's
         // part before its queries, or by the same query part (roles: 2 = written here, 1 = read here; a permutation reads in, writes out).
         {
@@ -1552,10 +1569,23 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
                 const size_t k = std::upper_bound(sb.begin(), sb.end(), oi) - sb.begin();   // 0 = before the queries
                 return (uint32_t)(i * stride + k + 1);
             };
-            for (size_t pass = 0; pass < 2 && ok; pass++)
+            for (size_t pass = 0; pass < 2 && ok; pass++) {
+                size_t cur_i = 0, cur_k = 0;   // part_at(oi) for rising oi without its two binary searches (11 M rows for a 51-chip child)
                 for (size_t oi = 0; oi < c.order.size() && ok; oi++) {
                     const Op& op = c.order[oi];
-                    const uint32_t part = part_at(oi);
+                    uint32_t part;
+                    if (oi < c.sections[0]) {
+                        part = part_at(oi);
+                    } else {
+                        while (cur_i + 1 < c.sections.size() && c.sections[cur_i + 1] <= oi) cur_i++, cur_k = 0;
+                        if (cur_i >= n_children) {
+                            part = (uint32_t)(n_children * stride + 1);
+                        } else {
+                            const auto& sb = c.sub[cur_i];
+                            while (cur_k < sb.size() && sb[cur_k] <= oi) cur_k++;
+                            part = (uint32_t)(cur_i * stride + cur_k + 1);
+                        }
+                    }
                     const size_t i = (part - 1) / stride, k = (part - 1) % stride;
                     const bool is_query = i < n_children && k >= 1 && k + 1 < c.sub[i].size() + 1 && k <= c.sub[i].size() - 1;
                     auto wr = [&](uint32_t w, bool constant) {
@@ -1577,14 +1607,17 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
                         }
                     }
                 }
+            }
             c.query_parallel = ok && process_config().parallel_queries;
         }
+        lap("query independence");
         K.c = std::move(b.c);
     } catch (const BuildError& e) {
         g_build_error = e.msg;
         return ZKHIP_ERR_INVALID;
     }
     build_programs(K, min_log_height);
+    lap("chip programs");
     *out = R.release();
     return ZKHIP_OK;
 }
