@@ -965,6 +965,11 @@ int zkhip_tables_canonical(zkhip_ctx *ctx, int on);
 int zkhip_jit_prewarm(const zkhip_air *airs, size_t n_airs, unsigned log_blowup, const char *cache_dir, size_t *n_ok);
 /* the built-in defaults with the environment's overrides applied */
 void zkhip_config_default(zkhip_config *out);
+/* CPUs this process may actually use: min(scheduler affinity, the cgroup's CPU quota -- /sys/fs/cgroup/cpu.max, or cpu.cfs_quota_us of
+ * cgroup v1).  A container can SEE every host thread (256 on the MI355X boxes of this pool) while its cgroup grants 16: one thread per
+ * visible CPU then spends its time throttled.  What the host-side thread counts of the library and of include/ *.hpp default to (the
+ * aggregation witness generator, the executor's memory close, the host verification of segment proofs). */
+unsigned zkhip_host_cpus(void);
 /* a context's configuration (set at zkhip_ctx_create from zkhip_config_default); the witness fields are process-wide:
  * zkhip_set_process_config stores them (and the rest as the default of contexts created later).  zkhip_ctx_set_config applies every
  * field or refuses the call (ZKHIP_ERR_INVALID: jit 0..2, coop_* <= 27, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8,

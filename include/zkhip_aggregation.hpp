@@ -20,6 +20,7 @@
 #include <unistd.h>
 
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <condition_variable>
@@ -244,12 +245,22 @@ public:
         devices_ = devices;
     }
     size_t n_slots() const { return devices_.size(); }
-    std::mutex& slot_mutex(size_t slot) { return *slots_.at(slot).mu; }
+    // (a node proof gives way to a key generation that waits for the slot: a leaf circuit built on demand would otherwise queue behind
+    // every node proof the slot's workers re-lock for -- std::mutex is not fair; measured 2.5 s of waiting in a guest of two wide shapes)
+    void wait_turn(size_t slot) {
+        const std::atomic<int>& u = *slots_.at(slot).urgent;
+        while (u.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    std::mutex& slot_mutex(size_t slot) {
+        wait_turn(slot);
+        return *slots_.at(slot).mu;
+    }
     AggregationProver(AggregationProver&& o) noexcept { *this = std::move(o); }
     AggregationProver& operator=(AggregationProver&& o) noexcept {
         reset();
         app_ = std::move(o.app_), apps_ = std::move(o.apps_), leafs_ = std::move(o.leafs_), bigleafs_ = std::move(o.bigleafs_), policy_ = std::move(o.policy_), spec_ = std::move(o.spec_), cfg_ = o.cfg_, agg_params_ = o.agg_params_, device_ = o.device_, levels_ = std::move(o.levels_), stats = o.stats;
         leaf_commit_ = std::move(o.leaf_commit_), internal_commit_ = std::move(o.internal_commit_), leaf_list_ = std::move(o.leaf_list_);
+        used_ = std::move(o.used_), used_on_disk_ = std::move(o.used_on_disk_), nat_ = std::move(o.nat_), cache_path_ = std::move(o.cache_path_), cache_stored_ = o.cache_stored_;
         lazy_ = std::move(o.lazy_), prefetching_ = std::move(o.prefetching_), prefetch_threads_ = std::move(o.prefetch_threads_), common_h_[0] = o.common_h_[0], common_h_[1] = o.common_h_[1];
         levels_mu_ = std::move(o.levels_mu_), build_mu_ = std::move(o.build_mu_), shape_mu_ = std::move(o.shape_mu_);
         devices_ = std::move(o.devices_), slots_ = std::move(o.slots_);
@@ -278,12 +289,28 @@ public:
         for (auto& t : prefetch_threads_)
             if (t.joinable()) t.join();
         prefetch_threads_.clear();
+        remember_used_shapes();
         for (auto* set : {&levels_, &leafs_, &bigleafs_})
             for (auto& L : *set) free_level(L);
         levels_.clear(), leafs_.clear(), bigleafs_.clear();
         for (auto& sl : slots_)
             if (sl.ctx) zkhip_ctx_destroy(sl.ctx);
         slots_.clear();
+    }
+
+    // the cache file learns which shapes this guest's flows use (see AggCache); called when a flow ends and at reset()
+    void remember_used_shapes() {
+        if (!levels_mu_) return;   // (moved from)
+        std::lock_guard<std::mutex> lk(*levels_mu_);
+        if (!cache_stored_ || cache_path_.empty() || used_.size() != used_on_disk_.size() || nat_.size() != used_.size()) return;
+        bool grew = false;
+        for (size_t sh = 0; sh < used_.size(); sh++)
+            if (used_[sh] && !used_on_disk_[sh]) used_on_disk_[sh] = 1, grew = true;
+        if (grew) store_agg_cache(cache_path_, common_h_, nat_, leaf_list_, used_on_disk_);
+    }
+    void mark_used(size_t shape) {
+        std::lock_guard<std::mutex> lk(*levels_mu_);
+        if (shape < used_.size()) used_[shape] = 1;
     }
 
     Stats stats;
@@ -352,7 +379,7 @@ public:
     std::vector<uint32_t> witness_node(size_t level, const std::vector<const ChildProof*>& kids, size_t shape = 0, const std::vector<size_t>* kid_shapes = nullptr,
                                        size_t slot = 0, const std::vector<int>* kinds_in = nullptr) {
         ensure_level(level);
-        if (level == 0 && cfg_.one_key) ensure_leaf(shape);
+        if (level == 0 && cfg_.one_key) ensure_leaf(shape), mark_used(shape);
         Replica& L = lv(level, shape).rep.at(slot);
         if (kids.empty() || kids.size() > arity(level, shape)) throw Error(Error::GenProof, "aggregation: a node of level " + std::to_string(level) + " takes 1.." + std::to_string(arity(level, shape)) + " children");
         const VerifyingKey& cvk = level == 0 ? apps_.at(shape) : lv(level - 1).vk;   // (one key: the leaf's and the internal vk differ in the commitments only)
@@ -416,7 +443,7 @@ public:
     // enters the tree is the wrapper's proof.  Host witness and device work of both, one after the other, on one slot.
     ChildProof prove_wrapped(const std::vector<const ChildProof*>& kids, size_t shape, size_t slot = 0) {
         ensure_level(0);
-        if (cfg_.one_key) ensure_leaf(shape);
+        if (cfg_.one_key) ensure_leaf(shape), mark_used(shape);
         if (!wrapped(shape)) throw Error(Error::GenProof, "aggregation: not a wrapped shape");
         Level& B = bigleafs_.at(shape);
         Level& W = lv(0, shape);
@@ -435,6 +462,7 @@ public:
             std::vector<uint32_t> npv(zkhip_recursion_n_pvs(r.circ));
             if (zkhip_recursion_witness(r.circ, proofs.data(), lens.data(), pv.data(), ks.size(), npv.data()) != ZKHIP_OK)
                 throw Error(Error::GenProof, std::string("aggregation: ") + zkhip_recursion_last_error(r.circ));
+            wait_turn(slot);
             std::lock_guard<std::mutex> dev(*slots_.at(slot).mu);
             zkhip_ctx* c = slots_[slot].ctx;
             check(zkhip_recursion_tracegen(c, r.circ, (uint32_t*)r.d_traces[0], (uint32_t*)r.d_traces[1], (uint32_t*)r.d_traces[2]), slot);
@@ -455,6 +483,7 @@ public:
     }
     // device trace generation + proof of the node whose witness was computed last on this level
     ChildProof prove_witnessed(size_t level, std::vector<uint32_t> node_pvs, size_t shape = 0, size_t slot = 0) {
+        wait_turn(slot);
         std::lock_guard<std::mutex> dev(*slots_.at(slot).mu);
         upload_witness(level, shape, slot);
         return prove_uploaded(level, std::move(node_pvs), shape, slot);
@@ -913,6 +942,7 @@ private:
         int device = 0;
         zkhip_ctx* ctx = nullptr;
         std::unique_ptr<std::mutex> mu;    // any call on ctx
+        std::unique_ptr<std::atomic<int>> urgent = std::unique_ptr<std::atomic<int>>(new std::atomic<int>(0));   // key generations waiting for mu
     };
     std::vector<int> devices_;
     std::deque<Slot> slots_;
@@ -936,6 +966,10 @@ private:
     // generation per process, used or not -- but when its first segment proof arrives (ensure_leaf), and what is built then must commit
     // to exactly what the cache said (the aggregation key already states it).
     std::vector<char> lazy_, prefetching_;
+    std::vector<char> used_, used_on_disk_;            // shapes whose proofs entered the tree in this process / as the cache file knows them
+    std::vector<std::array<unsigned, 2>> nat_;         // (what the cache file holds beside leaf_list_: rewritten when `used` grows)
+    std::string cache_path_;
+    bool cache_stored_ = false;
     std::vector<std::thread> prefetch_threads_;   // (joined in reset(): they call ensure_leaf on this object)
     unsigned common_h_[2] = {0, 0};
     std::vector<VerifyingKey> apps_;   // the shapes' segment keys (apps_.back() = app_ = the full set)
@@ -1011,7 +1045,9 @@ private:
         auto one = [&](size_t sl) {
             try {
                 Replica& r = L.rep[sl];
-                std::lock_guard<std::mutex> dev(*slots_[sl].mu);
+                slots_[sl].urgent->fetch_add(1, std::memory_order_acq_rel);
+                std::unique_lock<std::mutex> dev(*slots_[sl].mu);
+                slots_[sl].urgent->fetch_sub(1, std::memory_order_acq_rel);
                 zkhip_ctx* c = slots_[sl].ctx;
                 int rc = zkhip_keygen(c, &L.vk.params, na.data(), 3, &r.pk);
                 if (rc != ZKHIP_OK) throw Error(Error::Keygen, std::string("failed to generate STARK proving key: ") + zkhip_last_error(c));
@@ -1093,14 +1129,19 @@ private:
     }
     // The on-disk cache of ONE aggregation key: file name = a digest of everything the key depends on (every shape's segment-key digest,
     // the node parameters, arities, shape policies, the statement layout, and the size and time stamp of libzkhip.so: another build of the
-    // circuit builder is another key).  Content: [magic, S, H0, H1, then per shape: natural heights (2), commitment (8)].  Directory:
-    // ZKHIP_AGG_CACHE_DIR, else the library's jit_cache_dir; none = no cache.
+    // circuit builder is another key).  Content: [magic, S, H0, H1, then per shape: natural heights (2), commitment (8), used (1)].
+    // Directory: ZKHIP_AGG_CACHE_DIR, else the library's jit_cache_dir; none = no cache.
+    // `used`: the key depends on the guest (the program chip's commitment is part of every shape's key), so the file is per guest -- and
+    // it remembers which shapes this guest's flows put into the tree.  A shape the guest used before is built at setup again (its circuit
+    // is needed, and building it BESIDE the segment proving costs more than it saves: measured 1.5 - 2.5 M instr/s against 2.9 M for the
+    // mixed guest on the 16-CPU boxes); a shape no flow of this guest ever used stays out until a segment proof of it arrives.
     struct AggCache {
         bool hit = false;
         std::string path;
         unsigned h[2] = {0, 0};
         std::vector<std::array<unsigned, 2>> nat;
         std::vector<std::array<uint32_t, 8>> commit;
+        std::vector<char> used;   // a flow of an earlier process put segment proofs of this shape into the tree
     };
     std::string agg_cache_path(const std::vector<uint32_t>& app_id) const {
         std::string dir;
@@ -1144,28 +1185,30 @@ private:
         FILE* f = std::fopen(c.path.c_str(), "rb");
         if (!f) return c;
         const size_t S = apps_.size();
-        std::vector<uint32_t> w(4 + 10 * S);
-        const bool ok = std::fread(w.data(), 4, w.size(), f) == w.size() && w[0] == 0x41474B43u && w[1] == S;
+        std::vector<uint32_t> w(4 + 11 * S);
+        const bool ok = std::fread(w.data(), 4, w.size(), f) == w.size() && w[0] == 0x41474B44u && w[1] == S;
         std::fclose(f);
         if (!ok) return c;
         c.h[0] = w[2], c.h[1] = w[3];
         for (size_t sh = 0; sh < S; sh++) {
-            c.nat.push_back({w[4 + 10 * sh], w[5 + 10 * sh]});
+            c.nat.push_back({w[4 + 11 * sh], w[5 + 11 * sh]});
             std::array<uint32_t, 8> k;
-            std::copy(w.begin() + 6 + 10 * sh, w.begin() + 14 + 10 * sh, k.begin());
+            std::copy(w.begin() + 6 + 11 * sh, w.begin() + 14 + 11 * sh, k.begin());
             c.commit.push_back(k);
+            c.used.push_back(w[14 + 11 * sh] ? 1 : 0);
         }
         c.hit = true;
         return c;
     }
-    void store_agg_cache(const std::vector<uint32_t>& app_id, const unsigned H[2], const std::vector<std::array<unsigned, 2>>& nat, const std::vector<uint32_t>& leaf_list) const {
-        const std::string path = agg_cache_path(app_id);
+    void store_agg_cache(const std::string& path, const unsigned H[2], const std::vector<std::array<unsigned, 2>>& nat, const std::vector<uint32_t>& leaf_list,
+                         const std::vector<char>& used) const {
         if (path.empty()) return;
         const size_t S = apps_.size();
-        std::vector<uint32_t> w{0x41474B43u, (uint32_t)S, H[0], H[1]};
+        std::vector<uint32_t> w{0x41474B44u, (uint32_t)S, H[0], H[1]};
         for (size_t sh = 0; sh < S; sh++) {
             w.push_back(nat[sh][0]), w.push_back(nat[sh][1]);
             w.insert(w.end(), leaf_list.begin() + 8 * sh, leaf_list.begin() + 8 * sh + 8);
+            w.push_back(sh < used.size() && used[sh] ? 1u : 0u);
         }
         const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)getpid());
         if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
@@ -1250,7 +1293,10 @@ private:
             lazy_.assign(S, 0);
             shape_mu_.clear();
             for (size_t sh = 0; sh < S; sh++) shape_mu_.emplace_back(new std::mutex);
-            for (size_t sh = 1; sh < S; sh++) lazy_[sh] = cache.hit && !getenv("ZKHIP_AGG_NO_LAZY") ? 1 : 0;
+            for (size_t sh = 1; sh < S; sh++) lazy_[sh] = cache.hit && !cache.used.at(sh) && !getenv("ZKHIP_AGG_NO_LAZY") ? 1 : 0;
+            cache_path_ = cache.path, nat_.assign(S, {0, 0});
+            used_.assign(S, 0), used_on_disk_.assign(S, 0);
+            if (cache.hit) used_on_disk_ = cache.used;
             // the leaf circuits side by side (host only: seconds each for a 50-chip key)
             std::vector<std::string> errs(S);
             std::vector<std::thread> th;
@@ -1316,10 +1362,13 @@ private:
                 if (cache.hit && !std::equal(c.begin(), c.end(), cache.commit.at(sh).begin()))
                     throw Error(Error::Setup, "aggregation: the key cache " + cache.path + " does not belong to this build (shape " + std::to_string(sh) + " commits differently): delete it");
             }
+            nat_ = nat;
             if (!cache.hit) {
                 bool all = true;
                 for (size_t sh = 0; sh < S; sh++) all = all && !lazy_[sh];
-                if (all) store_agg_cache(app_id, H, nat, leaf_list_);
+                if (all) store_agg_cache(cache_path_, H, nat, leaf_list_, used_on_disk_), cache_stored_ = true;
+            } else {
+                cache_stored_ = true;
             }
             keygen_level(internal, ia);
             internal_commit_ = internal.vk.key_commit();

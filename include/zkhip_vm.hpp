@@ -225,13 +225,14 @@ private:
         c.data = write ? value : c.data, c.ts = clock_;
         rec->acc_data.push_back(c.data), rec->acc_ts.push_back(clock_), rec->acc_is_read.push_back(write ? 0u : 1u);
     }
+    // (the segmenting executor keeps the memory log of its own -- log_memory_ off: nothing to record per cell, and this is its inner loop)
     uint32_t reg_read(ExecRecords* rec, unsigned i) {
-        touch(rec, 1, 2 * i, x_[i] & 0xffffu, false, 0), touch(rec, 1, 2 * i + 1, x_[i] >> 16, false, 0);
+        if (rec && log_memory_) touch(rec, 1, 2 * i, x_[i] & 0xffffu, false, 0), touch(rec, 1, 2 * i + 1, x_[i] >> 16, false, 0);
         return x_[i];
     }
     void reg_write(ExecRecords* rec, unsigned i, uint32_t v) {
         if (i == 0) v = 0;  // x0 is a cell that only ever holds zero
-        touch(rec, 1, 2 * i, x_[i] & 0xffffu, true, v & 0xffffu), touch(rec, 1, 2 * i + 1, x_[i] >> 16, true, v >> 16);
+        if (rec && log_memory_) touch(rec, 1, 2 * i, x_[i] & 0xffffu, true, v & 0xffffu), touch(rec, 1, 2 * i + 1, x_[i] >> 16, true, v >> 16);
         x_[i] = v;
     }
     // Phantom sub-executors (OpenVM's algebra extension: ModularPhantom::{HintNonQr, HintSqrt}; pairing extension: HintFinalExp).  The
@@ -363,13 +364,19 @@ private:
         if (addr % n) throw Error("misaligned load");
         uint32_t v = 0;
         memcpy(&v, at(addr, n), n);
-        const uint32_t first = (addr - exe_.data_base) >> 1, last = (addr - exe_.data_base + n - 1) >> 1;
-        for (uint32_t c = first; c <= last; c++) touch(rec, 2, c, cell_value(c), false, 0);
+        if (rec && log_memory_) {
+            const uint32_t first = (addr - exe_.data_base) >> 1, last = (addr - exe_.data_base + n - 1) >> 1;
+            for (uint32_t c = first; c <= last; c++) touch(rec, 2, c, cell_value(c), false, 0);
+        }
         return v;
     }
     void store(ExecRecords* rec, uint32_t addr, uint32_t v, unsigned n) {
         if (addr % n) throw Error("misaligned store");
         uint8_t* p = at(addr, n);
+        if (!(rec && log_memory_)) {
+            memcpy(p, &v, n);
+            return;
+        }
         const uint32_t first = (addr - exe_.data_base) >> 1, last = (addr - exe_.data_base + n - 1) >> 1;
         const uint16_t before[2] = {cell_value(first), cell_value(last)};
         memcpy(p, &v, n);

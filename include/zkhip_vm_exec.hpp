@@ -208,9 +208,13 @@ struct SegmentRecords {
     size_t n_p2() const { return p2_inputs.size() / 16; }
     size_t n_keccak() const { return kk_ts.size(); }
     size_t n_sha256() const { return sha_ts.size(); }
-    void clear() {
+    // keep_frame: the eight frame arrays keep their size -- the executor sizes them to the frame's rows, writes by index and cuts them to
+    // n_instr at the end of the segment, so a recycled record pays no zero-fill for them (2 MB each at 2^19 rows)
+    void clear(bool keep_frame = false) {
         core.clear();
-        for (auto* v : {&f_x, &f_y, &f_z, &f_rdprev, &f_pcinc, &f_pts1, &f_pts2, &f_pts3, &ls_ts, &ls_base, &ls_imm, &ls_pts, &ecall_rows, &leaf_rows, &merkle_rows,
+        if (!keep_frame)
+            for (auto* v : {&f_x, &f_y, &f_z, &f_rdprev, &f_pcinc, &f_pts1, &f_pts2, &f_pts3}) v->clear();
+        for (auto* v : {&ls_ts, &ls_base, &ls_imm, &ls_pts, &ecall_rows, &leaf_rows, &merkle_rows,
                         &p2_inputs, &kk_states, &kk_ts, &kio_rows, &sha_blocks, &sha_ts, &shaio_rows, &i256_records, &i256_ts, &i256io_rows, &mul256_records, &mul256_ts, &cmp256_records, &cmp256_ts, &sh256_records, &sh256_ts, &nat_records, &next_records, &castf_records})
             v->clear();
         for (unsigned i = 0; i < vmc::MAX_MODULI; i++) mm_records[i].clear(), mm_ts[i].clear(), mmio_rows[i].clear();
@@ -249,7 +253,8 @@ public:
     uint64_t instret() const { return m_.instret(); }
     uint32_t exit_code() const { return m_.exit_code(); }
     const std::vector<uint8_t>& public_values() const { return m_.public_values(); }
-    uint32_t peek_memory(uint32_t addr) const { return mem_word(addr); }   // a word of the guest's memory as it is now (zero beyond its end)
+    uint32_t peek_memory(uint32_t addr) const { return mem_word(addr); }
+    double close_seconds() const { return close_seconds_; }   // of run_segment's time: hashing the touched blocks and their paths, leaf / merkle rows   // a word of the guest's memory as it is now (zero beyond its end)
 
     // Executes the next segment into `r`.  Returns true once the guest has exited (then r.pc_end = 0).
     // words of the buffer of an intrinsic call (a7 = call, a1 = index + 8 op): operands of 8 words, or 12 for a modulus above 2^256
@@ -265,10 +270,19 @@ public:
         return 24;   // (int256)
     }
     bool run_segment(SegmentRecords& r) {
-        r.clear();
+        r.clear(/*keep_frame=*/true);
         reset_blocks();
-        for (auto* v : {&r.f_x, &r.f_y, &r.f_z, &r.f_rdprev, &r.f_pcinc, &r.f_pts1, &r.f_pts2, &r.f_pts3, &r.core.pc_index})
-            if (v->capacity() < caps_.rows(vmc::A_FRAME)) v->reserve(caps_.rows(vmc::A_FRAME));
+        const size_t frame_rows = caps_.rows(vmc::A_FRAME);
+        if (r.core.pc_index.capacity() < frame_rows) r.core.pc_index.reserve(frame_rows);
+        for (auto* v : {&r.f_x, &r.f_y, &r.f_z, &r.f_rdprev, &r.f_pcinc, &r.f_pts1, &r.f_pts2, &r.f_pts3}) v->resize(frame_rows);
+        uint32_t *const fx = r.f_x.data(), *const fy = r.f_y.data(), *const fz = r.f_z.data(), *const frd = r.f_rdprev.data(), *const fpc = r.f_pcinc.data();
+        uint32_t *const fp1 = r.f_pts1.data(), *const fp2 = r.f_pts2.data(), *const fp3 = r.f_pts3.data();
+        struct CutFrame {   // (also when an instruction throws: the arrays never hold rows beyond n_instr)
+            SegmentRecords& r;
+            ~CutFrame() {
+                for (auto* v : {&r.f_x, &r.f_y, &r.f_z, &r.f_rdprev, &r.f_pcinc, &r.f_pts1, &r.f_pts2, &r.f_pts3}) v->resize(r.n_instr);
+            }
+        } cut_frame{r};
         r.pc_start = m_.pc();
         r.root_init = tree_.root();
         size_t n_cls[vmc::N_CLS] = {};
@@ -286,7 +300,7 @@ public:
                 bool all_known = true;
                 auto want = [&](uint32_t as, uint32_t word) {
                     labels[nl] = (as << vmc::LABEL_BITS) | (word >> 2);
-                    all_known = all_known && find_block(labels[nl]) != nullptr;
+                    all_known = all_known && touched(labels[nl]);
                     nl++;
                 };
                 if (d.use_rs1) want(1, d.rs1);
@@ -562,14 +576,19 @@ public:
                 r.ls_pts.push_back(store ? write_word(2, addr >> 2, mem_word(addr & ~3u), ts + 4) : read_word(2, addr >> 2, word_before, ts + 4));
             }
             const uint32_t pts3 = d.wr_rd ? write_word(1, d.rd, z, ts + 12) : 0;
-            r.f_pts1.push_back(pts1), r.f_pts2.push_back(pts2), r.f_pts3.push_back(pts3);
-            r.f_x.push_back(x), r.f_y.push_back(y), r.f_z.push_back(z), r.f_rdprev.push_back(d.wr_rd ? rd_prev : 0), r.f_pcinc.push_back(pc_inc);
+            const size_t row = r.n_instr;
+            fp1[row] = pts1, fp2[row] = pts2, fp3[row] = pts3;
+            fx[row] = x, fy[row] = y, fz[row] = z, frd[row] = d.wr_rd ? rd_prev : 0, fpc[row] = pc_inc;
             n_cls[d.cls]++;
             r.n_instr++;
         }
         r.pc_end = m_.done() ? 0 : m_.pc();
         r.ts_end = 1 + vmc::TS_STEP * (uint32_t)r.n_instr;
-        close_memory(r);
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            close_memory(r);
+            close_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
         return m_.done();
     }
 
@@ -591,6 +610,7 @@ private:
     std::unordered_map<uint32_t, uint32_t> other_slot_;
     std::unordered_set<uint64_t> path_nodes_;        // internal nodes above them
     std::vector<vmc::Decoded> dec_;
+    double close_seconds_ = 0;
 
     uint32_t* slot_of(uint32_t label, bool create) {
         const uint32_t as = label >> vmc::LABEL_BITS, blk = label & ((1u << vmc::LABEL_BITS) - 1);
@@ -600,6 +620,10 @@ private:
         if (create) return &other_slot_[label];
         auto it = other_slot_.find(label);
         return it == other_slot_.end() ? nullptr : &it->second;
+    }
+    bool touched(uint32_t label) {
+        const uint32_t* s = slot_of(label, false);
+        return s && *s;
     }
     Block* find_block(uint32_t label) {
         const uint32_t* s = slot_of(label, false);
@@ -673,82 +697,136 @@ private:
         return prev;
     }
 
-    // leaf rows, merkle rows, Poseidon2 requests; commits the segment's final memory to the tree
+    // leaf rows, merkle rows, Poseidon2 requests; commits the segment's final memory to the tree.  A memory-bound guest touches thousands
+    // of blocks per segment (4096 blocks + 4100 path nodes in the guest of tools/guest_bench2.py `mem`): the hashes go sixteen at a time
+    // through zkhip_poseidon2_permute16_host, levels are walked over SORTED index arrays (a parent's touched children are neighbours),
+    // rows are built side by side; the tree itself (a hash map) is only read until every level is done.
     void close_memory(SegmentRecords& r) {
-        std::vector<uint32_t> labels(blk_label_);
-        std::sort(labels.begin(), labels.end());
-        std::unordered_map<uint64_t, Digest> fin;   // final digests of the touched blocks and path nodes
-        auto add_p2 = [&](const uint32_t* a, const uint32_t* b8) {
-            for (int i = 0; i < 8; i++) r.p2_inputs.push_back(a[i]);
-            for (int i = 0; i < 8; i++) r.p2_inputs.push_back(b8 ? b8[i] : 0u);
+        const size_t nL = blk_label_.size();
+        std::vector<std::pair<uint32_t, uint32_t>> order(nL);   // (label, index into blk_)
+        for (size_t i = 0; i < nL; i++) order[i] = {blk_label_[i], (uint32_t)i};
+        std::sort(order.begin(), order.end());
+        // n independent permutations; fill(k, st) writes the 16 input words of state k, the first 8 output words are out[k]
+        auto hash_many = [&](size_t n, auto&& fill, Digest* out) {
+            parallel_for((n + 15) / 16, 16, [&](size_t bt) {
+                const size_t k0 = 16 * bt, k1 = std::min<size_t>(16, n - k0);
+                if (k1 == 1) {
+                    uint32_t st[16];
+                    fill(k0, st);
+                    zkhip_poseidon2_permute_host(st);
+                    for (int w = 0; w < 8; w++) out[k0][w] = st[w];
+                    return;
+                }
+                uint32_t st[256] = {};
+                for (size_t k = 0; k < k1; k++) fill(k0 + k, st + 16 * k);
+                zkhip_poseidon2_permute16_host(st);
+                for (size_t k = 0; k < k1; k++)
+                    for (int w = 0; w < 8; w++) out[k0 + k][w] = st[16 * k + w];
+            });
         };
-        std::vector<Digest> h_fin(labels.size());
-        parallel_for(labels.size(), [&](size_t i) { h_fin[i] = p2_block(find_block(labels[i])->cur); });
-        for (size_t i = 0; i < labels.size(); i++) {
-            const uint32_t label = labels[i];
-            const Block& b = *find_block(label);
+        std::vector<uint32_t> leaf_idx(nL);
+        std::vector<Digest> leaf_fin(nL);
+        for (size_t i = 0; i < nL; i++) leaf_idx[i] = order[i].first;
+        hash_many(nL, [&](size_t i, uint32_t* st) {
+            const Block& b = blk_[order[i].second];
+            for (int j = 0; j < 8; j++) st[j] = b.cur[j], st[8 + j] = 0;
+        }, leaf_fin.data());
+        r.leaf_rows.assign(nL * vmc::LEAF_WIDTH, 0);
+        const size_t p2_0 = r.p2_inputs.size();
+        r.p2_inputs.resize(p2_0 + 32 * nL, 0);
+        parallel_for(nL, 512, [&](size_t i) {
+            const uint32_t label = leaf_idx[i];
+            const Block& b = blk_[order[i].second];
             const Digest hi = tree_.get(vmc::LEAF_LEVEL, label);
-            fin[MemoryTree::key(vmc::LEAF_LEVEL, label)] = h_fin[i];
-            uint32_t row[vmc::LEAF_WIDTH] = {};
+            uint32_t* row = &r.leaf_rows[i * vmc::LEAF_WIDTH];
             row[0] = label >> vmc::LABEL_BITS, row[1] = label & ((1u << vmc::LABEL_BITS) - 1);
-            for (int j = 0; j < 8; j++) row[2 + j] = b.init[j], row[10 + j] = b.cur[j], row[22 + j] = hi[j], row[30 + j] = h_fin[i][j];
+            for (int j = 0; j < 8; j++) row[2 + j] = b.init[j], row[10 + j] = b.cur[j], row[22 + j] = hi[j], row[30 + j] = leaf_fin[i][j];
             for (int j = 0; j < 4; j++) row[18 + j] = b.ts[j];
             row[38] = 1;
-            const uint32_t gap = i + 1 < labels.size() ? labels[i + 1] - label - 1 : 0;
+            const uint32_t gap = i + 1 < nL ? leaf_idx[i + 1] - label - 1 : 0;
             row[39] = gap & 0xffffu, row[40] = gap >> 16, row[41] = row[1] & 0xffffu, row[42] = row[1] >> 16;
-            r.leaf_rows.insert(r.leaf_rows.end(), row, row + vmc::LEAF_WIDTH);
-            add_p2(b.init, nullptr), add_p2(b.cur, nullptr);
-        }
-        // path nodes level by level, bottom-up; the root's row goes first in the chip
-        std::vector<std::vector<uint32_t>> by_level(vmc::LEAF_LEVEL);
-        for (uint64_t k : path_nodes_) by_level[k >> 32].push_back((uint32_t)k);
-        std::vector<std::vector<uint32_t>> rows_by_level(vmc::LEAF_LEVEL);
+            uint32_t* q = &r.p2_inputs[p2_0 + 32 * i];   // two requests per block: its initial and its final cells (the second half of a request is zero)
+            for (int j = 0; j < 8; j++) q[j] = b.init[j], q[16 + j] = b.cur[j];
+        });
+        // path nodes level by level, bottom-up: the parents of a sorted index array are sorted, a parent's touched children are neighbours
+        struct Level {
+            std::vector<uint32_t> idx;
+            std::vector<Digest> fin;
+            std::vector<uint32_t> rows;
+        };
+        std::vector<Level> lv(vmc::LEAF_LEVEL);
+        const std::vector<uint32_t>* c_idx = &leaf_idx;
+        const std::vector<Digest>* c_fin = &leaf_fin;
+        std::vector<uint32_t> first;
+        std::vector<Digest> lf, rf;
+        std::vector<uint8_t> on;
+        size_t n_nodes = 0;
         for (int l = (int)vmc::LEAF_LEVEL - 1; l >= 0; l--) {
-            auto& idxs = by_level[l];
-            std::sort(idxs.begin(), idxs.end());
-            std::vector<Digest> pf(idxs.size());
-            auto child_fin = [&](uint32_t ci, bool* on) {
-                auto it = fin.find(MemoryTree::key((unsigned)l + 1, ci));
-                *on = it != fin.end();
-                return *on ? it->second : tree_.get((unsigned)l + 1, ci);
-            };
-            parallel_for(idxs.size(), [&](size_t i) {
-                bool a, b;
-                pf[i] = p2_compress(child_fin(2 * idxs[i], &a), child_fin(2 * idxs[i] + 1, &b));
-            });
-            for (size_t i = 0; i < idxs.size(); i++) {
-                const uint32_t idx = idxs[i];
-                bool l_on, r_on;
-                const Digest lf = child_fin(2 * idx, &l_on), rf = child_fin(2 * idx + 1, &r_on);
-                const Digest li = tree_.get((unsigned)l + 1, 2 * idx), ri = tree_.get((unsigned)l + 1, 2 * idx + 1), pi = tree_.get((unsigned)l, idx);
-                uint32_t row[vmc::MERKLE_WIDTH] = {};
-                row[0] = (uint32_t)l, row[1] = idx;
-                for (int q = 0; q < 8; q++) row[2 + q] = li[q], row[10 + q] = ri[q], row[18 + q] = lf[q], row[26 + q] = rf[q], row[34 + q] = pi[q], row[42 + q] = pf[i][q];
-                row[50] = l_on, row[51] = r_on, row[52] = 1, row[53] = l == 0;
-                rows_by_level[l].insert(rows_by_level[l].end(), row, row + vmc::MERKLE_WIDTH);
+            Level& L = lv[l];
+            first.clear();
+            for (size_t i = 0; i < c_idx->size(); i++) {
+                const uint32_t p = (*c_idx)[i] >> 1;
+                if (L.idx.empty() || L.idx.back() != p) L.idx.push_back(p), first.push_back((uint32_t)i);
             }
-            for (size_t i = 0; i < idxs.size(); i++) fin[MemoryTree::key((unsigned)l, idxs[i])] = pf[i];
+            const size_t n = L.idx.size();
+            n_nodes += n;
+            L.fin.resize(n), lf.resize(n), rf.resize(n), on.resize(2 * n);
+            parallel_for(n, 512, [&](size_t i) {
+                const uint32_t p = L.idx[i];
+                const size_t pos = first[i];
+                const bool l_on = (*c_idx)[pos] == 2 * p;
+                const size_t rpos = pos + (l_on ? 1 : 0);
+                const bool r_on = rpos < c_idx->size() && (*c_idx)[rpos] == 2 * p + 1;
+                lf[i] = l_on ? (*c_fin)[pos] : tree_.get((unsigned)l + 1, 2 * p);
+                rf[i] = r_on ? (*c_fin)[rpos] : tree_.get((unsigned)l + 1, 2 * p + 1);
+                on[2 * i] = l_on, on[2 * i + 1] = r_on;
+            });
+            hash_many(n, [&](size_t i, uint32_t* st) {
+                for (int q = 0; q < 8; q++) st[q] = lf[i][q], st[8 + q] = rf[i][q];
+            }, L.fin.data());
+            L.rows.assign(n * vmc::MERKLE_WIDTH, 0);
+            parallel_for(n, 512, [&](size_t i) {
+                const uint32_t idx = L.idx[i];
+                const Digest li = on[2 * i] ? tree_.get((unsigned)l + 1, 2 * idx) : lf[i], ri = on[2 * i + 1] ? tree_.get((unsigned)l + 1, 2 * idx + 1) : rf[i];
+                const Digest pi = tree_.get((unsigned)l, idx);
+                uint32_t* row = &L.rows[i * vmc::MERKLE_WIDTH];
+                row[0] = (uint32_t)l, row[1] = idx;
+                for (int q = 0; q < 8; q++) row[2 + q] = li[q], row[10 + q] = ri[q], row[18 + q] = lf[i][q], row[26 + q] = rf[i][q], row[34 + q] = pi[q], row[42 + q] = L.fin[i][q];
+                row[50] = on[2 * i], row[51] = on[2 * i + 1], row[52] = 1, row[53] = l == 0;
+            });
+            c_idx = &L.idx, c_fin = &L.fin;
         }
-        for (unsigned l = 0; l < vmc::LEAF_LEVEL; l++) r.merkle_rows.insert(r.merkle_rows.end(), rows_by_level[l].begin(), rows_by_level[l].end());
-        for (size_t i = 0; i < r.n_merkle(); i++) {
+        if (n_nodes != path_nodes_.size()) throw Error("internal: the touched path nodes and the touched blocks' ancestors differ");
+        // the root's row goes first in the chip; two Poseidon2 requests per row (initial children, final children)
+        r.merkle_rows.clear();
+        r.merkle_rows.reserve(n_nodes * vmc::MERKLE_WIDTH);
+        for (unsigned l = 0; l < vmc::LEAF_LEVEL; l++) r.merkle_rows.insert(r.merkle_rows.end(), lv[l].rows.begin(), lv[l].rows.end());
+        const size_t p2_1 = r.p2_inputs.size();
+        r.p2_inputs.resize(p2_1 + 32 * n_nodes);
+        parallel_for(n_nodes, 512, [&](size_t i) {
             const uint32_t* row = &r.merkle_rows[i * vmc::MERKLE_WIDTH];
-            add_p2(row + 2, row + 10), add_p2(row + 18, row + 26);
-        }
-        for (const auto& kv : fin) tree_.set((unsigned)(kv.first >> 32), (uint32_t)kv.first, kv.second);
+            uint32_t* q = &r.p2_inputs[p2_1 + 32 * i];
+            for (int k = 0; k < 16; k++) q[k] = row[2 + k], q[16 + k] = row[18 + k];
+        });
+        for (size_t i = 0; i < nL; i++) tree_.set(vmc::LEAF_LEVEL, leaf_idx[i], leaf_fin[i]);
+        for (unsigned l = 0; l < vmc::LEAF_LEVEL; l++)
+            for (size_t i = 0; i < lv[l].idx.size(); i++) tree_.set(l, lv[l].idx[i], lv[l].fin[i]);
         r.root_final = tree_.root();
     }
+    // f(i) for i < n on up to zkhip_host_cpus() threads, each taking at least `grain` indices (fewer than 2 grains: the caller's thread)
     template <class F>
-    static void parallel_for(size_t n, F&& f) {
-        const size_t nt = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), n / 256);
+    static void parallel_for(size_t n, size_t grain, F&& f) {
+        const size_t nt = std::min<size_t>(std::max(1u, zkhip_host_cpus()), n / std::max<size_t>(1, grain));
         if (nt <= 1) {
             for (size_t i = 0; i < n; i++) f(i);
             return;
         }
         std::vector<std::thread> th;
-        for (size_t t = 0; t < nt; t++)
+        for (size_t t = 1; t < nt; t++)
             th.emplace_back([&, t]() {
-                for (size_t i = t; i < n; i += nt) f(i);
+                for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) f(i);
             });
+        for (size_t i = 0; i < n / nt; i++) f(i);
         for (auto& t : th) t.join();
     }
 };

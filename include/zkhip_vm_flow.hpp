@@ -834,6 +834,7 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
     const auto t0 = clk::now();
     const scroll_zkvm_hip::AggregationPlan plan = scroll_zkvm_hip::AggregationPlan::build(seg_proofs.size(), agg.tree_config());
     g.root = tree.finish(seg_proofs.size());   // (what is left of the tree once the last segment proof exists)
+    agg.remember_used_shapes();                // (the key cache learns which shapes this guest puts into the tree)
     g.levels = tree.levels();   // (leaf nodes are cut where the shape changes: the plan's fixed grouping is a lower bound)
     (void)plan;
     g.root_vk = agg.root_vk(plan.levels.size());   // (one aggregation key: the same for every depth)

@@ -427,7 +427,7 @@ inline SegmentedProof prove_segments(const zkhip_params& params, const Exe& exe,
     if (sp.segments.size() != n_segments) throw Error("segment prover: proofs missing");
     sp.execution_time_mills = ms(exec_time);
     {
-        const size_t n_ver = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), sp.segments.size());
+        const size_t n_ver = std::min<size_t>(std::max(1u, zkhip_host_cpus()), sp.segments.size());
         std::vector<std::thread> vt;
         std::atomic<size_t> nv{0};
         std::atomic<int> bad{0};

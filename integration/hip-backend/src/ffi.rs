@@ -488,6 +488,7 @@ extern "C" {
                                            child_pvs: *const *const *const u32, child_prep_commits: *const u32, child_is_leaf: *const c_int,
                                            leaf_commit: *const u32, internal_commit: *const u32, n_present: usize, node_pvs_out: *mut u32) -> c_int;
     pub fn zkhip_tables_canonical(ctx: *mut zkhip_ctx, on: c_int) -> c_int;
+    pub fn zkhip_host_cpus() -> c_uint;
     pub fn zkhip_jit_prewarm(airs: *const zkhip_air, n_airs: usize, log_blowup: c_uint, cache_dir: *const c_char, n_ok: *mut usize) -> c_int;
     pub fn zkhip_config_default(out: *mut zkhip_config);
     pub fn zkhip_ctx_get_config(ctx: *mut zkhip_ctx, out: *mut zkhip_config) -> c_int;

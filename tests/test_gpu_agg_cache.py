@@ -3,7 +3,8 @@ round 4 item 3: under the chunk-circuit configuration the 26- and 51-chip leaf c
 
 The first run of a key builds every shape's leaf circuit and writes the cache; later runs build shape 0 and the internal circuit only, take
 the other shapes' commitments from the file -- the aggregation key (root.vk) must be byte-identical -- and build a shape when its first
-segment proof arrives, insisting that it commits to what the key states."""
+segment proof arrives, insisting that it commits to what the key states.  The file (one per guest: the program's commitment is part of the
+key) remembers which shapes the guest's flows used; those are built at setup again."""
 import json
 import os
 import subprocess
@@ -52,6 +53,23 @@ def test_unused_shapes_are_not_built_and_the_key_does_not_change(tmp_path):
     assert pm.run_cli("verify-guest", str(elf), str(out2 / "root.vk"), str(tmp_path / "openvm.toml"), str(out2 / "root.json")).returncode == 0
 
 
+def _edit_cache(cache, forget=False, flip_last_commit=False):
+    """the cache file: [magic, S, H0, H1, then per shape: natural heights (2), commitment (8), used (1)]"""
+    import numpy as np
+
+    f = next(cache.glob("agg_*.key"))
+    w = np.frombuffer(f.read_bytes(), dtype=np.uint32).copy()
+    S = int(w[1])
+    assert w.size == 4 + 11 * S
+    if forget:
+        for sh in range(S):
+            w[4 + 11 * sh + 10] = 0
+    if flip_last_commit:
+        w[4 + 11 * (S - 1) + 9] ^= 1
+    f.write_bytes(w.tobytes())
+    return [int(w[4 + 11 * sh + 10]) for sh in range(S)]
+
+
 def test_a_cached_shape_is_built_when_its_first_segment_arrives(tmp_path):
     cache = tmp_path / "cache"
     cache.mkdir()
@@ -63,18 +81,32 @@ def test_a_cached_shape_is_built_when_its_first_segment_arrives(tmp_path):
     stdin.write_bytes(n.to_bytes(4, "little"))
     env = {"ZKHIP_AGG_CACHE_DIR": str(cache)}
     first, vk1, _ = prove(tmp_path, "first", elf, stdin, 15, **env)
-    second, vk2, out2 = prove(tmp_path, "second", elf, stdin, 15, **env)           # the wide shapes come from the cache and are built on demand
+    wide_used = sum(1 for k, n_ in enumerate(first["segments_per_shape"]) if k and n_)
+    assert first["segments_per_shape"][2] > 0 and first["segments_per_shape"][3] > 0
+    assert first["leaf_circuits_at_setup"] == len(first["chips_per_shape"])
+    # the file is per guest (the program's commitment is part of the key) and remembers which shapes this guest put into the tree: those
+    # are built at setup again -- beside the segment proving they would cost more than they save -- the others stay out
+    assert _edit_cache(cache) == [1 if n_ else 0 for n_ in first["segments_per_shape"]]
+    second, vk2, _ = prove(tmp_path, "second", elf, stdin, 15, **env)
     assert vk1 == vk2
-    assert second["segments_per_shape"][2] > 0 and second["segments_per_shape"][3] > 0
-    assert second["leaf_circuits_at_setup"] == 1 and second["leaf_circuits_on_demand"] == sum(1 for k, n_ in enumerate(second["segments_per_shape"]) if k and n_)
+    assert second["leaf_circuits_at_setup"] == 1 + wide_used and second["leaf_circuits_on_demand"] == 0
+    # a file that does not know it (an earlier run of this key that never met the wide shapes): built when their first segment proof arrives
+    _edit_cache(cache, forget=True)
+    third, vk3, out3 = prove(tmp_path, "third", elf, stdin, 15, **env)
+    assert vk1 == vk3
+    assert third["leaf_circuits_at_setup"] == 1 and third["leaf_circuits_on_demand"] == wide_used
     model = rv.run(words, n.to_bytes(4, "little"), data=data, moduli=CHUNK_CIRCUIT_MODULI, curves=tuple((c[1], c[3]) for c in CHUNK_CIRCUIT_CURVES))
-    assert second["total_cycles"] == model["instret"]
-    assert pm.run_cli("verify-guest", str(elf), str(out2 / "root.vk"), str(tmp_path / "openvm.toml"), str(out2 / "root.json")).returncode == 0
-    # a cache file that states another commitment for a wide shape is caught when that shape is built
-    f = next(cache.glob("agg_*.key"))
-    b = bytearray(f.read_bytes())
-    b[-4] ^= 1
-    f.write_bytes(bytes(b))
+    assert third["total_cycles"] == model["instret"]
+    assert pm.run_cli("verify-guest", str(elf), str(out3 / "root.vk"), str(tmp_path / "openvm.toml"), str(out3 / "root.json")).returncode == 0
+    assert _edit_cache(cache) == [1 if n_ else 0 for n_ in first["segments_per_shape"]]          # ... and the file has learnt it again
+    # a cache file that states another commitment for a wide shape is caught: at setup when the shape is built there ...
+    _edit_cache(cache, flip_last_commit=True)
+    out = tmp_path / "stale_setup"
+    out.mkdir()
+    r = subprocess.run([pm.CLI, "prove-elf", str(elf), str(stdin), str(out), str(tmp_path / "openvm.toml"), "15"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "does not belong to this build" in r.stderr
+    # ... and when it is built on demand
+    _edit_cache(cache, forget=True)
     out = tmp_path / "stale"
     out.mkdir()
     r = subprocess.run([pm.CLI, "prove-elf", str(elf), str(stdin), str(out), str(tmp_path / "openvm.toml"), "15"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)

@@ -607,3 +607,42 @@ def test_random_native_calls_agree_with_python_and_satisfy_the_chips(tmp_path, s
         for d_ in inst:
             assert air.check_trace(d_["program"], d_["trace"], d_["pvs"], d_.get("prep")) == []
         assert v2.bus_imbalance(inst) == {}
+
+
+def test_a_segment_that_touches_two_thousand_blocks(tmp_path):
+    """A guest that stores one word into each of 1 900 blocks and reads every other one back: a segment whose memory chips carry thousands
+    of rows -- the executor closes it with batched hashes (sixteen permutations at a time) and rows built on several threads
+    (include/zkhip_vm_exec.hpp close_memory: those paths need >= 512 blocks).  The leaf, merkle and Poseidon2 traces satisfy their AIRs,
+    every bus balances (the hash bus: every request of the memory chips is a row of the Poseidon2 chip), roots chain, the run is the model's."""
+    A0, A1, A7, T0, T1, T2, T3 = 10, 11, 17, 5, 6, 7, 28
+    n_blocks = 1900
+    p = rv.li(T0, 0x00400000) + rv.li(T3, 0x00400000 + 16 * n_blocks)
+    p += [("addi", T1, 0, 5),
+          ("label", "fill"), ("sw", T1, T0, 4), ("addi", T1, T1, 7), ("addi", T0, T0, 16), ("bne", T0, T3, "fill")]
+    p += rv.li(T0, 0x00400000) + [("addi", T2, 0, 0),
+          ("label", "sum"), ("lw", T1, T0, 4), ("add", T2, T2, T1), ("addi", T0, T0, 32), ("blt", T0, T3, "sum"),
+          ("add", A0, T2, 0), ("addi", A1, 0, 0), ("addi", A7, 0, 1), ("ecall",),
+          ("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    words = rv.assemble(p)
+    model = rv.run(words, b"")
+    expect = sum(5 + 7 * i for i in range(0, n_blocks, 2)) & 0xFFFFFFFF
+    assert int.from_bytes(bytes(model["pvs"])[:4], "little") == expect
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words), b"", 15)
+    assert bytes.fromhex(info["public_values"]) == bytes(model["pvs"]) and info["total_cycle"] == model["instret"]
+    assert len(segs) == 1 and segs[0]["leaf_rows"].size // v2.LEAF_WIDTH >= n_blocks
+    meta = segs[0]["meta"]
+    assert meta[4:12].tolist() == image_root.tolist() and int(meta[1]) == 0
+    inst = v2.segment_instance(segs[0], words, PC_BASE, H)
+    for a, d in enumerate(inst):
+        assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], a
+    assert v2.bus_imbalance(inst) == {}
+    # the public values open in the final root (the tree the executor keeps is what the rows state)
+    pv = bytes(model["pvs"])
+    for blk in range(2):
+        cur = ru.sponge([pv[16 * blk + 2 * j] | (pv[16 * blk + 2 * j + 1] << 8) for j in range(8)])
+        idx = (3 << 26) | blk
+        sib = pv_open[blk * 8 * 28:(blk + 1) * 8 * 28].reshape(28, 8)
+        for lvl in range(28):
+            cur = ru.compress(sib[lvl], cur) if idx & 1 else ru.compress(cur, sib[lvl])
+            idx >>= 1
+        assert cur.tolist() == meta[12:20].tolist()

@@ -1,20 +1,23 @@
 # Round-5 kernel stats of the guest flow: one lane and one node pipeline (every launch in sequence), and the default three + three.
+# Usage: bash tools/profile_round5_flow.sh [log_frame = 19] [fibonacci iterations = 1400000]
 set -x
+F=${1:-19}
+N=${2:-1400000}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r5flow
+O=$GRAFT_REPO_ROOT/gpurun_out/r5flow$F
 mkdir -p $O /tmp/gf /tmp/o
-python3 tools/make_guest_files.py /tmp/gf 700000
-./zkvm-prover_amd/prove_cli prove-elf /tmp/gf/fib.elf /tmp/gf/stdin.bin /tmp/o - 17 > /dev/null 2>&1
+python3 tools/make_guest_files.py /tmp/gf $N
+./zkvm-prover_amd/prove_cli prove-elf /tmp/gf/fib.elf /tmp/gf/stdin.bin /tmp/o - $F > /dev/null 2>&1
 export ZKHIP_LANES=1 ZKHIP_AGG_SLOTS=1
-rocprofv3 --kernel-trace --stats -d $O/a -o a --output-format csv -- ./zkvm-prover_amd/prove_cli prove-elf /tmp/gf/fib.elf /tmp/gf/stdin.bin /tmp/o - 17 > $O/a.json 2> $O/a_err.txt
+rocprofv3 --kernel-trace --stats -d $O/a -o a --output-format csv -- ./zkvm-prover_amd/prove_cli prove-elf /tmp/gf/fib.elf /tmp/gf/stdin.bin /tmp/o - $F > $O/a.json 2> $O/a_err.txt
 export ZKHIP_LANES=3 ZKHIP_AGG_SLOTS=3
-rocprofv3 --kernel-trace --stats -d $O/b -o b --output-format csv -- ./zkvm-prover_amd/prove_cli prove-elf /tmp/gf/fib.elf /tmp/gf/stdin.bin /tmp/o - 17 > $O/b.json 2> $O/b_err.txt
+rocprofv3 --kernel-trace --stats -d $O/b -o b --output-format csv -- ./zkvm-prover_amd/prove_cli prove-elf /tmp/gf/fib.elf /tmp/gf/stdin.bin /tmp/o - $F > $O/b.json 2> $O/b_err.txt
 cp $(find $O/a -name "*kernel_stats.csv" | head -1) $O/a_kernel_stats.csv
 cp $(find $O/b -name "*kernel_stats.csv" | head -1) $O/b_kernel_stats.csv
-python3 - <<'PY'
+F=$F python3 - <<'PY'
 import csv,glob,os
-O=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/r5flow"
+O=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/r5flow"+os.environ["F"]
 for tag in "ab":
     f=glob.glob(O+"/%s/**/*kernel_trace.csv"%tag, recursive=True)
     if not f: continue

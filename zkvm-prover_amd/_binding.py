@@ -267,6 +267,7 @@ def load_library():
         "zkhip_recursion_wires": (C.c_int, [vp, u32p, sz, C.POINTER(sz)]),
         "zkhip_jit_prewarm": (C.c_int, [C.POINTER(_Air), sz, C.c_uint, C.c_char_p, C.POINTER(sz)]),
         "zkhip_tables_canonical": (C.c_int, [vp, C.c_int]),
+        "zkhip_host_cpus": (C.c_uint, []),
         "zkhip_config_default": (None, [C.POINTER(Config)]),
         "zkhip_ctx_get_config": (C.c_int, [vp, C.POINTER(Config)]),
         "zkhip_ctx_set_config": (C.c_int, [vp, C.POINTER(Config)]),

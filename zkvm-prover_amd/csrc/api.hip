@@ -1,3 +1,6 @@
+#include <sched.h>
+#include <cstring>
+#include <thread>
 #include <dlfcn.h>
 #include <sys/stat.h>
 #include <mutex>
@@ -159,6 +162,34 @@ int zkhip_ctx_create(int device, zkhip_ctx** out) {
     ctx->side_cus = ctx->cfg.side_cus >= (unsigned)ctx->cu_count ? 0u : ctx->cfg.side_cus;
     *out = ctx;
     return ZKHIP_OK;
+}
+
+unsigned zkhip_host_cpus(void) {
+    static const unsigned cached = [] {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = std::min<unsigned>(n, (unsigned)CPU_COUNT(&set));
+        auto read2 = [](const char* path, long long* a, long long* b) {   // "<a> [<b>]"; a may be the word "max" (-> -1)
+            FILE* f = std::fopen(path, "r");
+            if (!f) return 0;
+            char w[32] = {};
+            long long y = 0;
+            const int got = std::fscanf(f, "%31s %lld", w, &y);
+            std::fclose(f);
+            if (got < 1) return 0;
+            *a = std::strcmp(w, "max") == 0 ? -1 : std::atoll(w), *b = y;
+            return got;
+        };
+        long long q = -1, per = 0;
+        if (read2("/sys/fs/cgroup/cpu.max", &q, &per) == 2) {
+            if (q > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, q / per));
+        } else if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &q, &per) >= 1 && q > 0) {
+            long long p1 = 0, dummy = 0;
+            if (read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &p1, &dummy) >= 1 && p1 > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, q / p1));
+        }
+        return n;
+    }();
+    return cached;
 }
 
 // ---- configuration: the ONE place the library reads its ZKHIP_* environment overrides ----

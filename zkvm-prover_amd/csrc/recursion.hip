@@ -2059,9 +2059,10 @@ int recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const si
             std::vector<std::pair<size_t, size_t>> tasks;
             for (size_t i = 0; i < n_sec; i++)
                 for (size_t q = 0; q + 1 < c.sub[i].size(); q++) tasks.push_back({i, q});
-            // (all cores: measured in the one-flow pipeline with 4 / 8 / 16 threads on 16 cores -- the segment phase loses ~40 ms to the
+            // (all cores the process may use -- zkhip_host_cpus: the cgroup's quota, not the 256 host threads a container sees;
+            // measured in the one-flow pipeline with 4 / 8 / 16 threads on 16 cores -- the segment phase loses ~40 ms to the
             // contention, the tree's tail gains ~100 ms; ZKHIP_WITNESS_THREADS overrides)
-            const unsigned cap = process_config().witness_threads ? process_config().witness_threads : std::thread::hardware_concurrency();
+            const unsigned cap = process_config().witness_threads ? process_config().witness_threads : zkhip_host_cpus();
             const size_t n_threads = std::min<size_t>((tasks.size() + 15) / 16, std::max(1u, cap));
             std::atomic<size_t> next{0};
             std::vector<std::vector<long>> tb(n_threads, std::vector<long>(n_sec, -1));
