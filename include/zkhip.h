@@ -954,6 +954,12 @@ typedef struct {
     /* small tree layers (<= 2^min(coop_max_log, coop_inj_max_log) nodes) in groups of up to five per launch, injected rows included
      * (k_compress_coop_fused); 0 = one launch per layer with injected rows, as round 4 [ZKHIP_NO_COOP_FUSED=1 -> 0] */
     int coop_fused;
+    /* the rows of EVERY level of a mixed-height tree that has matrices are hashed by one launch beside the leaf level's (the layer kernels then
+     * find a row's digest parked in its node's slot); 0 = only the levels above 2^coop_inj_max_log rows, at most eight, the others' rows inside
+     * the cooperative layer kernels (rounds 4 - 5).  A level of at most 2^rows_coop_max_log rows whose rows are so wide that one lane's chain of
+     * permutations would outlast the launch is hashed with 16 lanes per row [ZKHIP_NO_ROWS_IN_BULK=1 -> 0; ZKHIP_ROWS_COOP_MAX_LOG] */
+    int rows_in_bulk;
+    uint32_t rows_coop_max_log;
 } zkhip_config;
 /* While `on`, the trace generators treat the shared lookup-count tables handed to them (the 8-bit bitwise table, the range-tuple table, the
  * range table) as canonical counts and leave them canonical -- none converts a table from Montgomery form and back around its increments.
@@ -972,7 +978,7 @@ void zkhip_config_default(zkhip_config *out);
 unsigned zkhip_host_cpus(void);
 /* a context's configuration (set at zkhip_ctx_create from zkhip_config_default); the witness fields are process-wide:
  * zkhip_set_process_config stores them (and the rest as the default of contexts created later).  zkhip_ctx_set_config applies every
- * field or refuses the call (ZKHIP_ERR_INVALID: jit 0..2, coop_* <= 27, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8,
+ * field or refuses the call (ZKHIP_ERR_INVALID: jit 0..2, coop_* <= 27, rows_coop_max_log <= 27, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8,
  * commit_parts <= 8, side_cus < the device's CUs, hash_block a multiple of 64 in 64..768); a changed side_cus re-partitions as zkhip_set_cu_partition does. */
 int zkhip_ctx_get_config(zkhip_ctx *ctx, zkhip_config *out);
 int zkhip_ctx_set_config(zkhip_ctx *ctx, const zkhip_config *cfg);

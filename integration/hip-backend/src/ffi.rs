@@ -197,6 +197,8 @@ pub struct zkhip_config {
     pub tree_store_early: c_int,
     pub hash_block: u32,
     pub coop_fused: c_int,
+    pub rows_in_bulk: c_int,
+    pub rows_coop_max_log: u32,
 }
 
 #[repr(C)]

@@ -145,6 +145,30 @@ def test_merkle_commit_and_open(zk, ora, shapes):
         assert ot.verify(q, ops[i])
 
 
+def test_merkle_many_heights_wide_short_levels(zk, ora):
+    """A tree of fourteen heights -- more than the eight levels the row-sponge launch took before zkhip_config.rows_in_bulk -- with WIDE matrices
+    of few rows (the chunk-circuit configuration's Keccak / limb chips: hundreds of permutations per row; they take the 16-lanes-per-row form
+    of k_hash_rows_multi) beside narrow tall ones: every layer and a few openings against the oracle, under both settings of the switch."""
+    shapes = [(17, 3), (16, 2), (15, 9), (14, 17), (13, 300), (12, 1), (11, 1500), (10, 8), (9, 5), (8, 3), (7, 700), (5, 2), (2, 9), (0, 3)]
+    rng = np.random.default_rng(5)
+    mats = _mats(ora, rng, shapes)
+    ot = ora.Tree(mats)
+    dev = [(zk.upload(m.reshape(-1)), lh, w) for m, (lh, w) in zip(mats, shapes)]
+    cfg0 = zk.config()
+    try:
+        for bulk, coop_log in ((1, 15), (1, 0), (0, 15)):
+            zk.set_config(rows_in_bulk=bulk, rows_coop_max_log=coop_log)
+            t = zk.merkle_commit(dev)
+            assert t.root.tolist() == ot.root.tolist(), (bulk, coop_log)
+            for l in range(t.log_height + 1):
+                assert (t.layer(l) == ot.layer(l)).all(), (bulk, coop_log, l)
+            n = 1 << t.log_height
+            for i, q in enumerate(sorted({0, n - 1, n // 3})):
+                assert (t.open([q])[0] == ot.open(q)).all()
+    finally:
+        zk.set_config(cfg0)
+
+
 def test_merkle_golden(zk, kat):
     for case in kat["merkle"]:
         dev = []

@@ -59,17 +59,48 @@ __global__ __launch_bounds__(768) void k_hash_rows(const uint32_t* const* __rest
 // one or two waves per SIMD -- here their rows run beside the leaf level's at full occupancy, and the layer kernel is left with two
 // permutations per node (k_compress_layer_inj2).  The row digest of node i of a level is parked in the node's own slot of the digest
 // store until the layer kernel replaces it.
+// (second session of round 5) EVERY level with injected matrices is hashed here, whatever its size (zkhip_config.rows_in_bulk): a segment proof of the
+// chunk-circuit configuration carries wide chips of few rows (Keccak-f: 2634 columns x 2^14 LDE rows = 330 permutations per row; the limb chips: ~3000
+// columns at 2^11 - 2^12 rows), and the cooperative tree kernels ran those sponges on every 16-lane row of every workgroup of the group's FIRST layer --
+// rows that a deeper layer no longer uses included: 12.7 + 8.9 ms of a 74 ms proof in two launches (gpurun_out/r5mixed19_trace).  A level's blocks take
+// one of two forms: one lane per row, or -- a level of few rows and many columns, whose one-lane chain of hundreds of permutations would outlast the
+// rest of the launch -- one 16-lane row per matrix row (the cooperative permutation: ~2.7x the VALU work, an eighth of the chain).  The levels with the
+// longest chains come first in the grid and run at wave priority 3, so that the chains end under the bulk of the launch instead of behind it.
+constexpr unsigned ZK_MAX_ROW_LEVELS = 28;
 struct RowHashLevels {
     uint32_t n_levels;
-    uint32_t first_block[9];   // blocks [first_block[k], first_block[k + 1]) hash level k's rows
-    uint32_t col_off[8], n_cols[8];
-    uint64_t n_rows[8], out_off[8];   // out_off: word offset of the level's layer in the digest store
+    uint32_t first_block[ZK_MAX_ROW_LEVELS + 1];   // blocks [first_block[k], first_block[k + 1]) hash entry k's rows
+    uint32_t col_off[ZK_MAX_ROW_LEVELS], n_cols[ZK_MAX_ROW_LEVELS];
+    uint8_t log_rows[ZK_MAX_ROW_LEVELS];
+    uint8_t mode[ZK_MAX_ROW_LEVELS];               // bit 0: cooperative form (16 lanes per row), bit 1: wave priority 3
+    uint64_t out_off[ZK_MAX_ROW_LEVELS];           // word offset of the level's layer in the digest store
 };
 __global__ __launch_bounds__(256) void k_hash_rows_multi(const uint32_t* const* __restrict__ cols, RowHashLevels L, uint32_t* __restrict__ digests) {
     uint32_t k = 0;
     while (k + 1 < L.n_levels && blockIdx.x >= L.first_block[k + 1]) k++;   // (wave-uniform)
-    const uint32_t row = (blockIdx.x - L.first_block[k]) * blockDim.x + threadIdx.x;
-    if (row >= L.n_rows[k]) return;
+    const uint32_t mode = L.mode[k];
+    if (mode & 2u) __builtin_amdgcn_s_setprio(3);
+    const size_t n_rows = (size_t)1 << L.log_rows[k];
+    const uint32_t blk = blockIdx.x - L.first_block[k];
+    if (mode & 1u) {
+        // sponge over the row: lane q < 8 of the 16-lane row absorbs column c + q, lanes 8..15 are the capacity; the next block's cells are
+        // requested before this block's permutation
+        const unsigned lane = threadIdx.x & 15u;
+        const size_t row = (size_t)blk * 16 + (threadIdx.x >> 4);
+        const size_t rr = row < n_rows ? row : 0;   // all 16 lanes of every row stay active through the DPP permutation
+        const uint32_t* const* ic = cols + L.col_off[k];
+        const uint32_t n = L.n_cols[k];
+        uint32_t h = 0, nxt = (lane < 8 && lane < n) ? ic[lane][rr] : 0;
+        for (uint32_t c = 0; c < n; c += 8) {
+            if (lane < 8 && c + lane < n) h = nxt;
+            if (lane < 8 && c + 8 + lane < n) nxt = ic[c + 8 + lane][rr];
+            h = coop_permute(h, lane);
+        }
+        if (row < n_rows && lane < 8) digests[L.out_off[k] + row * 8 + lane] = h;
+        return;
+    }
+    const uint32_t row = blk * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
     uint32_t s[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = 0;
@@ -216,13 +247,17 @@ __global__ void k_permute_batch(uint32_t* states, size_t n) {
 // matrices of many heights are injected).
 __global__ __launch_bounds__(256) void k_compress_layer_coop(const uint32_t* __restrict__ prev, uint32_t* __restrict__ next,
                                                              size_t n_next, const uint32_t* const* __restrict__ inj_cols,
-                                                             uint32_t n_inj_cols) {
+                                                             uint32_t n_inj_cols, int parked) {
     const unsigned lane = threadIdx.x & 15u;
     const size_t i = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const size_t ii = i < n_next ? i : 0;  // all 16 lanes of every row stay active through the DPP permutation
     const CoopConsts cc = coop_load_consts(lane);
     uint32_t x = coop_permute_regs(prev[ii * 16 + lane], lane, cc);
-    if (n_inj_cols) {
+    if (n_inj_cols && parked) {
+        // the row's digest is parked in the node's slot (k_hash_rows_multi): lane 8 + k reads word k
+        const uint32_t hh = next[ii * 8 + (lane & 7u)];
+        x = coop_permute_regs(lane < 8 ? x : hh, lane, cc);
+    } else if (n_inj_cols) {
         uint32_t h = 0;  // sponge over the injected row: lane k < 8 absorbs column j + k, lanes 8..15 are the capacity
         for (uint32_t j = 0; j < n_inj_cols; j += 8) {
             if (lane < 8 && j + lane < n_inj_cols) h = inj_cols[j + lane][ii];
@@ -285,6 +320,7 @@ struct CoopFused {
     uint64_t out_off[5];   // word offsets of the produced layers in the digest store
     uint32_t inj_off[5];   // first injected column of the layer in the column-pointer table
     uint32_t inj_cnt[5];   // injected columns of the layer (0: a plain layer)
+    uint32_t parked[5];    // the rows of the layer's matrices are hashed already: the digest waits in the node's slot (k_hash_rows_multi)
     uint32_t m;            // layers to produce (1..5)
 };
 __global__ __launch_bounds__(256) void k_compress_coop_fused(const uint32_t* prev, uint32_t* digests, size_t n_next, const uint32_t* const* __restrict__ cols, CoopFused cf) {
@@ -301,7 +337,10 @@ __global__ __launch_bounds__(256) void k_compress_coop_fused(const uint32_t* pre
         const size_t idx = active ? node : 0;
         uint32_t x = coop_permute_regs(in, lane, cc);
         const uint32_t n_inj = cf.inj_cnt[j];
-        if (n_inj) {
+        if (n_inj && cf.parked[j]) {
+            const uint32_t hh = digests[cf.out_off[j] + idx * 8 + (lane & 7u)];   // lane 8 + k reads word k of the row's digest
+            x = coop_permute_regs(lane < 8 ? x : hh, lane, cc);
+        } else if (n_inj) {
             const uint32_t* const* ic = cols + cf.inj_off[j];
             uint32_t h = 0;   // sponge over the injected row: lane k < 8 absorbs column c + k, lanes 8..15 are the capacity
             for (uint32_t c = 0; c < n_inj; c += 8) {
@@ -575,22 +614,48 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
     const unsigned lh = t->log_height;
     const uint32_t* const* d_ptrs = (const uint32_t* const*)t->d_colptrs;
     size_t n = (size_t)1 << lh;
-    // the levels whose rows are hashed in bulk: the leaf level and every level with injected matrices above the cooperative form's size
+    // the levels whose rows are hashed in bulk: the leaf level and every level with injected matrices (zkhip_config.rows_in_bulk; 0: only the
+    // levels above the cooperative layer form's size, at most eight, as rounds 4 - 5)
     const unsigned coop_inj_max_log = ctx->cfg.coop_inj_max_log;
+    const bool all_levels = ctx->cfg.rows_in_bulk != 0;
     std::vector<char> bulk(lh + 1, 0);
-    RowHashLevels L{};
-    auto add_level = [&](unsigned level) {
-        if (L.n_levels == 8) return;
-        const uint32_t k = L.n_levels++;
-        const size_t rows = (size_t)1 << level;
-        L.first_block[k + 1] = L.first_block[k] + (uint32_t)((rows + 255) / 256);
-        L.col_off[k] = (uint32_t)t->level_off[level], L.n_cols[k] = (uint32_t)t->level_cnt[level];
-        L.n_rows[k] = rows, L.out_off[k] = (uint64_t)t->layer_off[lh - level] * 8;
+    struct Entry {
+        unsigned level;
+        size_t cols, perms;   // permutations per row
+        bool coop;
+    };
+    std::vector<Entry> entries;
+    auto want_level = [&](unsigned level) {
+        if (entries.size() == (all_levels ? ZK_MAX_ROW_LEVELS : 8u)) return;
+        entries.push_back({level, t->level_cnt[level], (t->level_cnt[level] + 7) / 8, false});
         bulk[level] = 1;
     };
-    if (!leaves_ready) add_level(lh);
+    if (!leaves_ready) want_level(lh);
     for (unsigned level = lh; level-- > 0;)
-        if (t->level_cnt[level] && ((size_t)1 << level) > ((size_t)1 << coop_inj_max_log)) add_level(level);
+        if (t->level_cnt[level] && (all_levels || ((size_t)1 << level) > ((size_t)1 << coop_inj_max_log))) want_level(level);
+    RowHashLevels L{};
+    if (!entries.empty()) {
+        // A level's chain: `perms` permutations one after the other on a lane (~9 us each when the wave is served first), a third of that in
+        // the cooperative form.  The launch as a whole: all permutations at the chip's rate (~7500 per us).  A level of at most 2^rows_coop_max_log
+        // rows whose one-lane chain would outlast the launch takes the cooperative form; levels are ordered by the length of their chains, and
+        // every chain of more than 64 permutations runs at wave priority 3.
+        double total = 0;
+        for (const Entry& e : entries) total += (double)e.perms * (double)((size_t)1 << e.level);
+        const double launch_us = total / 7500.0;
+        if (all_levels)
+            for (Entry& e : entries)
+                e.coop = e.level <= ctx->cfg.rows_coop_max_log && e.perms >= 16 && (double)e.perms * 9.0 > std::max(launch_us, 300.0);
+        auto chain_us = [](const Entry& e) { return (double)e.perms * (e.coop ? 3.0 : 9.0); };
+        if (all_levels) std::stable_sort(entries.begin(), entries.end(), [&](const Entry& a, const Entry& b) { return chain_us(a) > chain_us(b); });
+        for (const Entry& e : entries) {
+            const uint32_t k = L.n_levels++;
+            const size_t rows = (size_t)1 << e.level, per_block = e.coop ? 16 : 256;
+            L.first_block[k + 1] = L.first_block[k] + (uint32_t)((rows + per_block - 1) / per_block);
+            L.col_off[k] = (uint32_t)t->level_off[e.level], L.n_cols[k] = (uint32_t)e.cols;
+            L.log_rows[k] = (uint8_t)e.level, L.out_off[k] = (uint64_t)t->layer_off[lh - e.level] * 8;
+            L.mode[k] = (uint8_t)((e.coop ? 1u : 0u) | (all_levels && e.perms > 64 ? 2u : 0u));
+        }
+    }
     if (L.n_levels == 1 && !leaves_ready) {
         KernelScope ks(ctx, "poseidon2_hash_rows");
         const unsigned hb = n >= ((size_t)1 << 20) ? std::max(64u, std::min(768u, ctx->cfg.hash_block)) : 256u;   // (small trees: more workgroups matter more)
@@ -637,6 +702,7 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
                 for (unsigned q = 0; q < m; q++) {
                     cf.out_off[q] = (uint64_t)t->layer_off[l + q] * 8;
                     cf.inj_off[q] = (uint32_t)t->level_off[level - q], cf.inj_cnt[q] = (uint32_t)t->level_cnt[level - q];
+                    cf.parked[q] = bulk[level - q] ? 1u : 0u;
                 }
                 hipLaunchKernelGGL(k_compress_coop_fused, dim3((unsigned)((cnt + 15) / 16)), dim3(256), 0, ctx->stream, t->d_digests + t->layer_off[l - 1] * 8, t->d_digests, cnt,
                                    d_ptrs, cf);
@@ -669,7 +735,7 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
         if (cnt <= ((size_t)1 << (t->level_cnt[level] ? coop_inj_max : coop_max)))
             hipLaunchKernelGGL(k_compress_layer_coop, dim3((unsigned)((cnt + 15) / 16)), dim3(256), 0, ctx->stream,
                                t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt,
-                               d_ptrs ? d_ptrs + t->level_off[level] : nullptr, (uint32_t)t->level_cnt[level]);
+                               d_ptrs ? d_ptrs + t->level_off[level] : nullptr, (uint32_t)t->level_cnt[level], bulk[level] ? 1 : 0);
         else if (t->level_cnt[level] && bulk[level])
             hipLaunchKernelGGL(k_compress_layer_inj2, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
                                t->d_digests + t->layer_off[l - 1] * 8, t->d_digests + t->layer_off[l] * 8, cnt);
