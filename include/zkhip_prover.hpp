@@ -227,11 +227,13 @@ struct FlowOptions {
                                       // (AggregationProver::TreeStream; the fold needs ONE key)                          [ZKHIP_TREE_BALANCED=1]
     bool agg_cli_greedy = false;      // `prove_cli prove-agg` (a tree over segment proofs handed in) with the greedy fold instead of the
                                       // plan's grouping (tests: errors inside the fold)                                  [ZKHIP_AGG_GREEDY=1]
-    unsigned internal_arity = 5;      // children of an internal node of the aggregation tree.  The reference's default is 3
-                                      // (crates/prover/src/prover/mod.rs:57-60); here the tree's common heights (2^21 gate rows, 2^18
-                                      // permutations: what ONE leaf node over three segment proofs needs) hold an internal node of up
-                                      // to five node proofs (1.89 M rows, 216 k permutations; six: 2.26 M) -- fewer nodes, the same
-                                      // heights (measured 3 / 4 / 5: DESIGN.md 15)                                       [ZKHIP_INTERNAL_ARITY=n]
+    unsigned internal_arity = 3;      // children of an internal node of the aggregation tree: the reference's default
+                                      // (crates/prover/src/prover/mod.rs:57-60).  With the gate chip's Horner rows (second session of round 5)
+                                      // the tree's common heights are 2^20 gate rows / 2^17 permutations -- ONE leaf node over two segment
+                                      // proofs of the base chips (0.80 M rows, 114 k permutations), an internal node over three node proofs
+                                      // (122 k permutations); four or five children need 2^21 / 2^18 for every node of the tree (measured
+                                      // 3 / 4 on the mixed and the Fibonacci guest: 5.2 / 4.6 MHz, 17.0 / 14.6 MHz; rounds 4 - 5 ran five
+                                      // children at 2^21 / 2^18)                                                         [ZKHIP_INTERNAL_ARITY=n]
     unsigned agg_slots = 3;           // node pipelines (witness thread + device thread, own keys) per device: the node proofs of one
                                       // pipeline are proven one after the other -- with one pipeline the tree lags behind the segment
                                       // lanes and is finished alone on the GPU, a 21 ms proof at a time (measured 1 / 2 / 3 / 4:

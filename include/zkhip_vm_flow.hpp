@@ -488,21 +488,26 @@ struct SegmentShapes {
         return caps.size() - 1;
     }
 };
-// How each shape's proofs enter the aggregation tree (AggregationProver::ShapePolicy).  The tree's circuits share ONE height set, and the
-// internal circuit (three node proofs at 100 queries) needs 2^21 gate rows whatever the app: a leaf circuit should fit that too.  The
-// cost of verifying a segment proof in-circuit grows with the columns opened per query -- measured on the 22 base chips (754 columns):
-// 0.63 M gate rows per child, i.e. ~835 per column (leaf arity 4: 2.51 M = 2^22, every node of the tree twice as large; arity 3:
-// 1.89 M = 2^21).  So a shape takes as many proofs per leaf node as fit 2^21 gate rows (at most the tree's leaf arity); a shape of which
-// not even one proof fits (base + the hash intrinsics: 3.9 k columns; the reference's full chunk-circuit set: 8 k) keeps a leaf
-// circuit of its own, natural size, one proof per node, and enters the tree through a wrapper of the common size.
+// How each shape's proofs enter the aggregation tree (AggregationProver::ShapePolicy).  The tree's circuits share ONE height set.  Since the
+// second session of round 5 (packed opened rows + Horner rows of the gate chip, csrc/recursion.hip Builder::hstep) the internal circuit --
+// three node proofs at 100 queries -- needs 2^20 gate rows and 2^17 permutations, and a leaf circuit should fit that too.  Verifying a
+// segment proof in-circuit costs, measured with `prove_cli leaf-stats` on the reference's three openvm.toml files at frames of 2^19
+// (base 22 chips / + hash intrinsics / the chunk circuit's 51 chips / the batch circuit's 37):
+//     gate rows    ~ 335 k + 28 per main column + 0.61 per word of the chips' constraint programs   (399 k / 587 k / 1377 k / 1053 k)
+//     permutations ~ 42 k + 8.9 per main column + 0.11 per program word                              (57 k / 103 k / 270 k / 196 k)
+// (round 4: 835 rows per column, 2^21 / 2^18).  A shape takes as many proofs per leaf node as fit 2^20 rows and 2^17 permutations (the base
+// chips: 2; + the hash intrinsics: 1); a shape of which not even one proof fits (the full chunk- and batch-circuit sets) keeps a leaf circuit
+// of its own, natural size (2^21 / 2^19 for the chunk circuit's -- it was 2^23 / 2^19), one proof per node, and enters the tree through a
+// wrapper of the common size.  The estimate only steers arity and wrapping: the common heights are the fixed point of the circuits as built.
 inline std::vector<scroll_zkvm_hip::AggregationProver::ShapePolicy> shape_policies(const std::vector<VerifyingKey>& shape_vks, unsigned max_arity = 4) {
     std::vector<scroll_zkvm_hip::AggregationProver::ShapePolicy> out;
     for (const VerifyingKey& vk : shape_vks) {
-        size_t w = 0;
-        for (const auto& a : vk.airs) w += a.width;
-        const double per_child = 835.0 * (double)w, room = 0.95 * (double)(1u << 21);
+        size_t w = 0, words = 0;
+        for (const auto& a : vk.airs) w += a.width, words += a.program.size();
+        const double rows = 335e3 + 28.0 * (double)w + 0.61 * (double)words, perms = 42e3 + 8.9 * (double)w + 0.11 * (double)words;
+        const double fit = std::min(0.97 * (double)(1u << 20) / rows, 0.97 * (double)(1u << 17) / perms);
         scroll_zkvm_hip::AggregationProver::ShapePolicy p;
-        p.arity = (unsigned)std::min<double>(max_arity, room / per_child);
+        p.arity = (unsigned)std::min<double>(max_arity, fit);
         if (p.arity == 0) p.arity = 1, p.wrapped = true;
         out.push_back(p);
     }

@@ -52,9 +52,25 @@ def node_traces(rc):
     W = rc.wires()
     na = rc.airs()
     g, p2 = na[0], na[1]
-    gt = np.zeros((16, 1 << g["log_height"]), np.uint32)
+    gt = np.zeros((28, 1 << g["log_height"]), np.uint32)
     for s in range(4):
         gt[4 * s:4 * s + 4] = W[g["prep"][s]].T
+    # Horner rows (preprocessed column 18 = the row's flag, 19 + j = coordinate j of slot b is taken): the values between the steps in slots 4 .. 6,
+    # t <- t * d + b[j] for j = 3, 2, 1 where taken (the last step, j = 0, ends in slot c: a wire), restated with Python integers
+    rows = np.nonzero(g["prep"][18])[0]
+    if len(rows):
+        t = gt[0:4, rows].astype(object)
+        al = gt[12:16, rows].astype(object)
+        for i in range(3):
+            j = 3 - i
+            take = g["prep"][19 + j][rows] == 1
+            prod = [(t[0] * al[0] + 11 * (t[1] * al[3] + t[2] * al[2] + t[3] * al[1])) % P,
+                    (t[0] * al[1] + t[1] * al[0] + 11 * (t[2] * al[3] + t[3] * al[2])) % P,
+                    (t[0] * al[2] + t[1] * al[1] + t[2] * al[0] + 11 * t[3] * al[3]) % P,
+                    (t[0] * al[3] + t[1] * al[2] + t[2] * al[1] + t[3] * al[0]) % P]
+            prod[0] = (prod[0] + gt[4 + j, rows].astype(object)) % P
+            t = np.array([np.where(take, prod[k], t[k]) for k in range(4)], dtype=object)
+            gt[16 + 4 * i:20 + 4 * i, rows] = t.astype(np.uint32)
     inp = np.zeros((rc.n_perms, 16), np.uint32)
     for j in range(4):
         inp[:, 4 * j:4 * j + 4] = W[p2["prep"][j][:rc.n_perms]]

@@ -100,6 +100,42 @@ def test_node_traces_satisfy_the_airs_and_prove(ora, leaf):
     leaf["node"] = dict(instance=node, proof=proof, vk=nvk, pvs=npv)
 
 
+def test_horner_rows_bind_their_steps(ora, leaf):
+    """The gate chip's Horner rows (csrc/recursion.hip Builder::hstep: the reduced opening of a query walks the coordinates of the packed
+    opened rows, up to four steps per row): the circuit has them, every step is constrained -- a changed value between two steps, a changed
+    coordinate that a step takes, or a changed result breaks a constraint of exactly that row --, a coordinate the row does NOT take is free,
+    and on other rows the three extra slots must not matter to the gate constraint."""
+    rc, proofs, pvs = leaf["rc"], leaf["proofs"], leaf["pvs"]
+    st, npv = rc.witness([p.tobytes() for p in proofs], pvs)
+    assert st == 0
+    g = ru.node_instance(rc, npv)[0]
+    prep, tr = g["prep"], g["trace"]
+    rows = np.nonzero(prep[18])[0]
+    assert len(rows) > 100 and tr.shape[0] == 28
+    full = [r for r in rows if all(prep[19 + j][r] for j in range(4))]
+    part = [r for r in rows if not all(prep[19 + j][r] for j in range(4))]
+    assert full and part   # (matrix widths that are no multiples of four leave partly taken values)
+
+    def bad_rows(t):
+        return {r for (_, r) in air.check_trace(g["program"], t, g["pvs"], g["prep"])}
+
+    assert bad_rows(tr) == set()
+    r = int(full[len(full) // 2])
+    for col in (16, 21, 26, 8, 4 + 2, 0, 12):   # the three values between the steps, the result, a taken coordinate, the start, alpha
+        t = tr.copy()
+        t[col, r] = (int(t[col, r]) + 1) % ora.P
+        assert bad_rows(t) == {r}, col
+    r = int(part[0])
+    j = [j for j in range(4) if not prep[19 + j][r]][0]
+    t = tr.copy()
+    t[4 + j, r] = (int(t[4 + j, r]) + 1) % ora.P   # (the wire bus would notice: the chip's own constraints do not)
+    assert bad_rows(t) == set()
+    other = int(np.nonzero(prep[18] == 0)[0][5])
+    t = tr.copy()
+    t[20, other] = 7
+    assert bad_rows(t) == set()
+
+
 def test_traces_of_a_tampered_child_do_not_prove(ora, leaf):
     rc, proofs, pvs = leaf["rc"], leaf["proofs"], leaf["pvs"]
     bad = proofs[0].copy()

@@ -125,6 +125,40 @@ int main(int argc, char** argv) {
             std::printf("], \"main_cells\": %zu}\n", cells);
             return 0;
         }
+        if (argc >= 3 && std::string(argv[1]) == "leaf-stats") {
+            // leaf-stats <openvm.toml | -> [log_frame = 19] [children = 1]: builds, on the host, the leaf verifier circuit of every shape of the configuration
+            // (dummy preprocessed commitments: the wiring does not depend on them) and prints its size -- wires, gate rows, permutations -- per shape;
+            // with ZKHIP_RECURSION_TIMING=1 the builder also prints where the rows go.  No GPU.
+            const unsigned log_frame = argc >= 4 ? (unsigned)atoi(argv[3]) : 19;
+            const size_t children = argc >= 5 ? (size_t)atoi(argv[4]) : 1;
+            const zkhip_vm::SegmentCaps full = zkhip_vm::config_caps(argv[2], log_frame, 10);
+            const zkhip_vm::SegmentShapes shapes = zkhip_vm::SegmentShapes::of(full, log_frame, 10);
+            zkhip_vm::Exe exe;
+            exe.program.assign(64, 0x00000013u);
+            const zkhip_params prm{1, 0, 100, 16, 16};
+            static const uint32_t zero_commit[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t sh = 0; sh < shapes.caps.size(); sh++) {
+                zkhip_vm::SegmentAirs sa = zkhip_vm::segment_airs(exe, shapes.caps[sh]);
+                size_t width = 0, prog_words = 0;
+                for (size_t p = 0; p < sa.airs.size(); p++) {
+                    if (sa.prep_width[p]) sa.airs[p].prep_commit = zero_commit;
+                    sa.airs[p].prep_trace = nullptr;
+                    width += sa.airs[p].width, prog_words += sa.airs[p].program_len;
+                }
+                zkhip_recursion_stmt st{};
+                zkhip_recursion* rc = nullptr;
+                if (zkhip_recursion_build(&prm, sa.airs.data(), sa.airs.size(), children, &st, &rc) != ZKHIP_OK) {
+                    std::fprintf(stderr, "shape %zu: %s\n", sh, zkhip_recursion_last_error(nullptr));
+                    return 1;
+                }
+                size_t stt[4];
+                zkhip_recursion_stats(rc, stt);
+                std::printf("{\"shape\": %zu, \"chips\": %u, \"main_columns\": %zu, \"program_words\": %zu, \"children\": %zu, \"wires\": %zu, \"gate_rows\": %zu, \"permutations\": %zu, \"gate_rows_per_column_per_child\": %.1f}\n",
+                            sh, shapes.caps[sh].n_airs, width, prog_words, children, stt[0], stt[1], stt[2], (double)stt[1] / (double)width / (double)children);
+                zkhip_recursion_destroy(rc);
+            }
+            return 0;
+        }
         if (argc >= 6 && std::string(argv[1]) == "dump-segments") {
             // dump-segments <guest.elf | exe.bin> <stdin.bin | -> <out_dir> <log_frame>: the segmenting executor's records (include/zkhip_vm_exec.hpp)
             // as raw u32 arrays, one directory per segment -- what the tests' CPU twins of the trace generators read

@@ -1394,7 +1394,7 @@ class RecursionCircuit:
             rc = self.lib.zkhip_recursion_air(self.h, i, C.byref(a))
             assert rc == 0
             prog = np.ctypeslib.as_array(a.program, shape=(a.program_len,)).copy()
-            pw = [18, 13, (self.n_pvs + 3) // 4][i]
+            pw = [23, 13, (self.n_pvs + 3) // 4][i]   # (csrc/recursion.hip GATE_PREP, P2W_PREP)
             prep = np.ctypeslib.as_array(a.prep_trace, shape=(pw << a.log_height,)).copy().reshape(pw, -1)
             out.append(dict(program=prog, log_height=int(a.log_height), width=int(a.width), n_pvs=int(a.n_pvs), prep=prep))
         return out

@@ -335,8 +335,10 @@ struct OpenGroupDev {
     uint32_t lh, n_pts;
     uint32_t shift, w_n, s_pow_n, scale_base;  // Montgomery: coset shift s, generator of H, s^N, 1/(N s^N)
     uint32_t col_first, n_cols;                // slice of the column pointer / destination tables
-    uint32_t n_tiles;                          // 512-row tiles (one wave each)
-    uint32_t tile_first;                       // first tile inside the flattened tile grid of ITS point-count class
+    uint32_t n_tiles;                          // 512-row tiles
+    uint32_t n_chunks;                         // column chunks: a wave reduces ONE chunk of one tile (a group of few rows and thousands of columns -- the
+                                               // limb chips at 2^10 rows: 2 tiles x 2969 columns -- was two waves walking 2969 columns: 6.4 ms of a 54 ms proof)
+    uint32_t tile_first;                       // first (tile, chunk) unit inside the flattened grid of ITS point-count class
     uint32_t wblk_first;                       // first 256-row block inside the flattened weights grid
     uint32_t fin_first;                        // first (column, point) block inside the flattened finish grid
     uint64_t weights_off;                      // ext offset of weights[pt][i] inside d_weights
@@ -433,10 +435,14 @@ __global__ __launch_bounds__(256) void k_col_reduce(OpenMulti m) {
         gi = idx[lo];
     }
     const OpenGroupDev& a = m.g[gi];
-    const size_t tile = gtile - a.tile_first;
-    if (tile >= a.n_tiles) return;  // beyond the last group's tiles (grid rounded up to 4 waves per block)
+    const size_t unit = gtile - a.tile_first;
+    if (unit >= (size_t)a.n_tiles * a.n_chunks) return;  // beyond the last group's units (grid rounded up to 4 waves per block)
+    const size_t tile = unit % a.n_tiles;
     const size_t N = (size_t)1 << a.lh;
     const uint32_t n_cols = a.n_cols;
+    const uint32_t per_chunk = (n_cols + a.n_chunks - 1) / a.n_chunks;
+    const uint32_t c_begin = (uint32_t)(unit / a.n_tiles) * per_chunk, c_end = c_begin + per_chunk < n_cols ? c_begin + per_chunk : n_cols;
+    if (c_begin >= c_end) return;
     const uint32_t* const* __restrict__ col_ptrs = m.col_ptrs + a.col_first;
     const uint32_t* __restrict__ weights = m.weights + 4 * a.weights_off;
     uint32_t* __restrict__ partial = m.partial + a.partial_off;
@@ -460,10 +466,10 @@ __global__ __launch_bounds__(256) void k_col_reduce(OpenMulti m) {
 #pragma unroll
     for (int k = 0; k < RK; k++) {
         size_t r = row0 + (size_t)k * 64;
-        x[k] = r < N ? col_ptrs[0][r] : 0u;
+        x[k] = r < N ? col_ptrs[c_begin][r] : 0u;
     }
-    for (uint32_t c = 0; c < n_cols; c++) {
-        if (c + 1 < n_cols) {
+    for (uint32_t c = c_begin; c < c_end; c++) {
+        if (c + 1 < c_end) {
             const uint32_t* col = col_ptrs[c + 1];  // columns of every matrix of this height: wave-uniform pointer table
 #pragma unroll
             for (int k = 0; k < RK; k++) {
@@ -1503,9 +1509,11 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
             d.scale_base = minv(mmul(to_monty((uint32_t)(N % P)), d.s_pow_n));
             d.col_first = g.first, d.n_cols = g.n_cols;
             d.n_tiles = (uint32_t)((N + 511) / 512);
+            // chunks of at least 16 columns, as many as give the group ~1024 waves
+            d.n_chunks = (uint32_t)std::max<size_t>(1, std::min<size_t>((g.n_cols + 15) / 16, (1024 + d.n_tiles - 1) / d.n_tiles));
             uint32_t& tiles = g.n_pts == 2 ? pk->og2_tiles : pk->og1_tiles;
             d.tile_first = tiles;
-            tiles += d.n_tiles;
+            tiles += d.n_tiles * d.n_chunks;
             d.wblk_first = pk->og_wblocks;
             pk->og_wblocks += (uint32_t)((N + 255) / 256);
             d.fin_first = pk->og_fin_blocks;

@@ -49,14 +49,17 @@ int poseidon2_air_tracegen(zkhip_ctx* ctx, const uint32_t* d_inputs, size_t n_pe
 namespace rec {
 
 constexpr uint32_t WIRE_BUS = 77;
-constexpr size_t GATE_WIDTH = 16, GATE_PREP = 18, P2W_PREP = 13;
+// gate chip: slots a b c d (four extension values: 16 columns) + three intermediate values of a Horner row (12 columns, zero on other rows);
+// preprocessed: wire ids (4), multiplicities (4), qM qA qB qC qD (5), qK (4), base flag (1), Horner row flag qH and h0..h3 = qH * [coordinate j taken] (5)
+constexpr size_t GATE_WIDTH = 28, GATE_PREP = 23, P2W_PREP = 13;
 
-enum GateKind : uint8_t { K_INPUT, K_LIN, K_INV, K_DIV, K_ASSERT };
+enum GateKind : uint8_t { K_INPUT, K_LIN, K_INV, K_DIV, K_ASSERT, K_HSTEP };
 enum SrcKind : uint8_t { S_NONE, S_PROOF_BASE, S_PROOF_EXT, S_PV, S_FLAG, S_HINT_BIT, S_HINT_COORD,
                          S_PREP,     // uniform node: word b of the preprocessed commitment of AIR a of the child's verifying key
                          S_KIND,     // uniform node: 1 = the child is a proof of the leaf circuit, 0 = of the internal circuit
                          S_COMMIT,   // uniform node: word b of the leaf (a = 0) / internal (a = 1) circuit commitment this node states
-                         S_AUX };    // deferral node: word a of the auxiliary data handed in with the child (openings of its public values)
+                         S_AUX,      // deferral node: word a of the auxiliary data handed in with the child (openings of its public values)
+                         S_PROOF_PACK };   // four BASE words of the proof as the coordinates of one value: word offsets Circuit::packs[a] (~0: a zero)
 
 struct Src {
     uint8_t kind = S_NONE;
@@ -69,6 +72,7 @@ struct Gate {
     uint32_t qM = 0, qA = 0, qB = 0, qC = 0, qD = 0;  // Montgomery
     Ext qK = {{0, 0, 0, 0}};
     uint8_t kind = K_LIN, base = 0;
+    uint8_t hmask = 0;  // K_HSTEP: bit j = coordinate j of slot b is taken
     Src src[4];  // K_INPUT: where each defined slot's value comes from
 };
 struct Perm {
@@ -108,6 +112,7 @@ struct Circuit {
     std::vector<Op> order;
     std::vector<uint32_t> pv_wires;  // groups of 4 public values bound to one wire each
     size_t n_pvs = 0;
+    std::vector<std::array<uint32_t, 4>> packs;  // S_PROOF_PACK: the proof words behind the coordinates of a packed input
     // order[sections[i] .. sections[i + 1]) verifies child i and touches only that child's wires and constant wires: the
     // sections can be evaluated side by side once the constant rows are done
     std::vector<size_t> sections;
@@ -153,7 +158,11 @@ class Builder {
     void push_gate(const Gate& g) {
         c.gates.push_back(g);
         c.order.push_back({0, (uint32_t)c.gates.size() - 1});
+        phase_gates[phase]++;
     }
+    // where the rows go (ZKHIP_RECURSION_TIMING prints the table): the part of the verifier being built when a row / permutation is added
+    const char* phase = "other";
+    std::map<std::string, size_t> phase_gates, phase_perms;
 
     // ---- inputs (four per row) ----
     V input(const Src& s, bool base) {
@@ -178,6 +187,13 @@ class Builder {
     void close_input_rows() { in_gate_[0] = in_gate_[1] = SIZE_MAX; }  // the next input opens a fresh row (section boundary)
     V in_base(const Src& s) { return input(s, true); }
     V in_ext(const Src& s) { return input(s, false); }
+    // four base words of child `child`'s proof as ONE value (offsets[k] = ~0u: coordinate k is zero)
+    V in_packed(uint32_t child, const std::array<uint32_t, 4>& offsets) {
+        Src s;
+        s.kind = S_PROOF_PACK, s.child = child, s.a = (uint32_t)c.packs.size();
+        c.packs.push_back(offsets);
+        return input(s, false);
+    }
 
     // ---- the general gate: c = qM a b + qA a + qB b + qD d + k ----
     V lin(uint32_t qM, const V& a, const V& b, uint32_t qA, uint32_t qB, const V& d, uint32_t qD, const Ext& k) {
@@ -313,6 +329,29 @@ class Builder {
         *right = lin3(x, ONE, y, ONE, *left, NEG1);
     }
 
+    // ---- a HORNER row over the coordinates of a packed value: out = acc, then for j = 3 .. 0 with bit j of `mask` set: out = out alpha + W_j ----
+    // (W_j = coordinate j of w, a BASE value.  One row where four rows of mul_add and three of pack stood: the reduced openings of a query
+    // walk every opened row once, and the opened rows are handed in packed, four to a value, as the sponge takes them.)
+    V hstep(const V& acc, const V& w, unsigned mask, const V& alpha) {
+        if (!(mask & 15u)) return acc;
+        if (acc.k && w.k && alpha.k) {
+            Ext t = acc.c;
+            for (int j = 3; j >= 0; j--)
+                if (mask >> j & 1u) t = ext_add(ext_mul(t, alpha.c), ext_from_base(w.c.c[j]));
+            return cst(t);
+        }
+        Gate g;
+        g.kind = K_HSTEP, g.hmask = (uint8_t)(mask & 15u);
+        g.w[0] = use(acc), g.role[0] = 1;
+        g.w[1] = use(w), g.role[1] = 1;
+        g.w[3] = use(alpha), g.role[3] = 1;
+        V out;
+        out.wire = g.w[2] = new_wire();
+        g.role[2] = 2;
+        push_gate(g);
+        return out;
+    }
+
     // ---- Poseidon2 on four wires of four lanes ----
     std::array<V, 4> permute(const std::array<V, 4>& in) {
         if (in[0].k && in[1].k && in[2].k && in[3].k) {
@@ -330,6 +369,7 @@ class Builder {
         for (int j = 0; j < 4; j++) out[j].wire = p.out[j] = new_wire();
         c.perms.push_back(p);
         c.order.push_back({1, (uint32_t)c.perms.size() - 1});
+        phase_perms[phase]++;
         return out;
     }
 
@@ -512,7 +552,7 @@ struct ChildValues {  // what one verified child hands to the statement logic
 
 // recompute the root implied by an opening of a mixed-height commitment (verifier.hip verify_opening) and require it
 static void verify_opening_sym(Builder& b, const std::array<V, 2>& root, const std::vector<unsigned>& lhs, const std::vector<size_t>& ws,
-                               const std::vector<V>& index_bits, const std::vector<V>& cells, const std::vector<std::array<V, 2>>& path) {
+                               const std::vector<V>& index_bits, const std::vector<Lane>& cells, const std::vector<std::array<V, 2>>& path) {
     unsigned lh = 0;
     for (unsigned h : lhs) lh = std::max(lh, h);
     std::array<V, 2> cur;
@@ -522,7 +562,7 @@ static void verify_opening_sym(Builder& b, const std::array<V, 2>& root, const s
         bool any = false;
         for (size_t m = 0; m < lhs.size(); m++) {
             if (lhs[m] == level) {
-                for (size_t k = 0; k < ws[m]; k++) lanes.push_back(Lane{cells[off + k], -1});
+                for (size_t k = 0; k < ws[m]; k++) lanes.push_back(cells[off + k]);
                 any = true;
             }
             off += ws[m];
@@ -595,6 +635,7 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci, 
     const unsigned n_layers = hmax - bl - lfp;
 
     // ---- the proof's fixed part as inputs (word offsets as in verifier.hip) ----
+    b.phase = "proof inputs";
     size_t r = 4;
     auto in_digest = [&](size_t off) -> std::array<V, 2> {
         Src s;
@@ -658,6 +699,7 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci, 
         }
 
     // ---- transcript ----
+    b.phase = "transcript";
     SymChallenger ch(b);
     {
         const uint32_t hdr[7] = {PROTO_TAG, (uint32_t)n_airs, prm.log_blowup, prm.log_final_poly_len, prm.num_queries, prm.commit_pow_bits, prm.query_pow_bits};
@@ -717,6 +759,7 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci, 
     const uint32_t gen = to_monty(FIELD_GEN_CANON);
 
     // ---- constraints at zeta ----
+    b.phase = "constraints at zeta";
     size_t k_lu = 0, k_prep = 0, k_cached = 0;
     std::map<unsigned, V> zn_of;  // zeta^(2^lh)
     for (size_t a = 0; a < n_airs; a++) {
@@ -802,6 +845,7 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci, 
     }
 
     // ---- FRI transcript ----
+    b.phase = "transcript";
     std::vector<V> betas(n_layers), betas_sq(n_layers);
     for (unsigned l = 0; l < n_layers; l++) {
         ch.observe_ext(fri_roots[l][0]), ch.observe_ext(fri_roots[l][1]);
@@ -849,6 +893,7 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci, 
     if (n_lu) add_batch(cm_perm0, n_lu, root_perm);
     add_batch(cm_quot0, qoff[n_airs], root_quot);
 
+    b.phase = "reduced openings, per proof";
     // ---- per-proof parts of the reduced openings: alpha_f powers, sum_k alpha_f^k p_k(z) per (matrix, point), alpha_f^offset ----
     size_t max_w = 1;
     for (const auto& m : cm) max_w = std::max(max_w, m.width);
@@ -887,6 +932,7 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci, 
             if (!z_of.count({M.h, pt})) z_of[{M.h, pt}] = pt == 0 ? zeta : b.scale(zeta, two_adic_generator(M.lh));
 
     // ---- queries ----
+    b.phase = "query indices";
     const uint32_t half = minv(to_monty(2));
     // the query indices first (the challenger is a chain: nothing else touches it from here on), then the queries, each a part of the
     // circuit of its own
@@ -897,10 +943,33 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci, 
         b.close_input_rows();
         b.c.sub.back().push_back(b.c.order.size());
         const std::vector<V>& idx = idx_of[qn];
-        std::vector<std::vector<V>> rows_of(batches.size());
+        std::vector<std::vector<Lane>> rows_of(batches.size());
         for (size_t bi = 0; bi < batches.size(); bi++) {
+            b.phase = "query: opened rows (inputs, sponge, paths)";
             const Batch& bt = batches[bi];
-            for (size_t k = 0; k < bt.tw; k++) rows_of[bi].push_back(in_base_at(r + k));
+            // The opened row of the batch comes in PACKED, four cells to a value, in the order the level's sponge takes them (per level: its
+            // matrices one after the other): the sponge then absorbs the values as they are -- no row that packs four base wires --, and the
+            // reduced opening below walks the coordinates of the same values (Builder::hstep).
+            rows_of[bi].resize(bt.tw);
+            {
+                std::vector<size_t> moff(bt.n + 1, 0);
+                for (size_t mi = 0; mi < bt.n; mi++) moff[mi + 1] = moff[mi] + bt.ws[mi];
+                std::vector<unsigned> levels(bt.lhs);
+                std::sort(levels.begin(), levels.end(), std::greater<unsigned>());
+                levels.erase(std::unique(levels.begin(), levels.end()), levels.end());
+                for (unsigned lv : levels) {
+                    std::vector<size_t> seq;
+                    for (size_t mi = 0; mi < bt.n; mi++)
+                        if (bt.lhs[mi] == lv)
+                            for (size_t k = 0; k < bt.ws[mi]; k++) seq.push_back(moff[mi] + k);
+                    for (size_t j = 0; j < seq.size(); j += 4) {
+                        std::array<uint32_t, 4> offs;
+                        for (size_t q = 0; q < 4; q++) offs[q] = j + q < seq.size() ? (uint32_t)(r + seq[j + q]) : ~0u;
+                        const V w = b.in_packed(ci, offs);
+                        for (size_t q = 0; q < 4 && j + q < seq.size(); q++) rows_of[bi][seq[j + q]] = Lane{w, (int)q};
+                    }
+                }
+            }
             r += bt.tw;
             std::vector<std::array<V, 2>> path(bt.bh);
             for (unsigned l = 0; l < bt.bh; l++) path[l] = in_digest(r + 8 * (size_t)l);
@@ -909,6 +978,7 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci, 
             verify_opening_sym(b, bt.root, bt.lhs, bt.ws, ibits, rows_of[bi], path);
         }
         // evaluation points of this query per LDE height, and 1 / (z - x)
+        b.phase = "query: reduced openings";
         std::map<unsigned, V> x_of;
         std::map<std::pair<unsigned, unsigned>, V> invd;
         std::vector<V> roq(hmax + 1, cst(ext_zero()));
@@ -925,8 +995,14 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci, 
                     for (unsigned j = 0; j < h; j++) roots[j] = mpow(two_adic_generator(h), (uint64_t)1 << (h - 1 - j));
                     x_of[h] = bit_product(b, bits, roots, cst_base(gen));
                 }
+                // sum_k alpha_f^k p_k(x), last cell first: the cells of this matrix that share a packed value take ONE row
                 V rrow = cst(ext_zero());
-                for (size_t k = M.width; k-- > 0;) rrow = b.mul_add(rrow, alpha_f, rows_of[bi][off + k]);
+                for (size_t k = M.width; k > 0;) {
+                    const Lane& top = rows_of[bi][off + k - 1];
+                    unsigned mask = 0;
+                    while (k > 0 && rows_of[bi][off + k - 1].v.wire == top.v.wire) mask |= 1u << rows_of[bi][off + k - 1].coord, k--;
+                    rrow = b.hstep(rrow, top.v, mask, alpha_f);
+                }
                 for (unsigned pt = 0; pt < M.n_pts; pt++) {
                     if (!invd.count({h, pt})) invd[{h, pt}] = b.inv(b.sub(z_of[{h, pt}], x_of[h]));
                     const V t = b.mul(b.sub(ro_terms[m].ry[pt], rrow), invd[{h, pt}]);
@@ -935,6 +1011,7 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci, 
                 off += M.width;
             }
         }
+        b.phase = "query: fold layers";
         V eval = roq[hmax];
         V xi;  // 1 / x of the current layer's pair
         for (unsigned l = 0; l < n_layers; l++) {
@@ -989,6 +1066,7 @@ static ChildValues verify_child_sym(Builder& b, const ChildVk& vk, uint32_t ci, 
     }
     b.close_input_rows();
     b.c.sub.back().push_back(b.c.order.size());
+    b.phase = "statement";
     if (r != vk.proof_words) throw BuildError{"internal: the circuit's walk over the proof does not end at its last word"};
     return out;
 }
@@ -1100,6 +1178,27 @@ void build_programs(RecCore& K, const unsigned min_log[2]) {
         for (int k = 0; k < 4; k++) b.assert_zero(qM * ab[k] + qA * a[k] + qB * bb[k] + qC * cc[k] + qD * d[k] + b.prep(13 + k));
         for (int s = 0; s < 4; s++)
             for (int k = 1; k < 4; k++) b.assert_zero(qbase * b.var(4 * s + k));
+        // the Horner row (K_HSTEP): t0 = a; t_{i+1} = taken(3 - i) ? t_i d + b[3 - i] : t_i; c = t_4 -- the three values between in slots 4 .. 6.
+        // h_j = qH * [coordinate j taken] is ONE preprocessed column, so the products stay of degree 3.  (On other rows qH = h_j = 0.)
+        {
+            const Expr qH = b.prep(18);
+            std::array<Expr, 4> t = a;
+            for (int i = 0; i < 4; i++) {
+                const int j = 3 - i;
+                const Expr hj = b.prep(19 + j);
+                const std::array<Expr, 4> nx = i < 3 ? slot(4 + i) : cc;
+                const Expr td[4] = {t[0] * d[0] + (t[1] * d[3] + t[2] * d[2] + t[3] * d[1]) * 11,
+                                    t[0] * d[1] + t[1] * d[0] + (t[2] * d[3] + t[3] * d[2]) * 11,
+                                    t[0] * d[2] + t[1] * d[1] + t[2] * d[0] + t[3] * d[3] * 11,
+                                    t[0] * d[3] + t[1] * d[2] + t[2] * d[1] + t[3] * d[0]};
+                for (int k = 0; k < 4; k++) {
+                    Expr step = td[k] - t[k];
+                    if (k == 0) step = step + bb[j];
+                    b.assert_zero(qH * (nx[k] - t[k]) - hj * step);
+                }
+                t = nx;
+            }
+        }
         for (int s = 0; s < 4; s++)
             b.push_interaction(WIRE_BUS, {b.prep(s), b.var(4 * s), b.var(4 * s + 1), b.var(4 * s + 2), b.var(4 * s + 3)}, b.prep(4 + s), Kind::Send);
         K.prog[0] = b.program();
@@ -1154,6 +1253,10 @@ void build_programs(RecCore& K, const unsigned min_log[2]) {
                 pr[11 * N + g] = from_monty(G.qC), pr[12 * N + g] = from_monty(G.qD);
                 for (int k = 0; k < 4; k++) pr[(size_t)(13 + k) * N + g] = from_monty(G.qK.c[k]);
                 pr[17 * N + g] = G.base;
+                if (G.kind == K_HSTEP) {
+                    pr[18 * N + g] = 1;
+                    for (int j = 0; j < 4; j++) pr[(size_t)(19 + j) * N + g] = G.hmask >> j & 1u;
+                }
             }
         };
         std::vector<std::thread> th;
@@ -1291,6 +1394,10 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
         b.close_input_rows();
         b.c.sections.push_back(b.c.order.size());
         lap("children verified");
+        if (timing) {
+            for (const auto& kv : b.phase_gates) std::fprintf(stderr, "[recursion build]   rows %-48s %10zu\n", kv.first.c_str(), kv.second);
+            for (const auto& kv : b.phase_perms) std::fprintf(stderr, "[recursion build]   perm %-48s %10zu\n", kv.first.c_str(), kv.second);
+        }
         const ChildVk& vk = K.vk;
         const size_t n_airs = vk.pg.size();
         std::vector<Lane> pvl;   // the node's public values
@@ -1929,6 +2036,11 @@ int recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const si
                             case S_PROOF_EXT:
                                 for (int k = 0; k < 4; k++) v.c[k] = to_monty(pw[sr.child][sr.a + k]);
                                 break;
+                            case S_PROOF_PACK: {
+                                const std::array<uint32_t, 4>& o = c.packs[sr.a];
+                                for (int k = 0; k < 4; k++) v.c[k] = o[k] == ~0u ? 0u : to_monty(pw[sr.child][o[k]]);
+                                break;
+                            }
                             case S_PV: v.c[0] = to_monty(child_pvs[sr.child < n_present ? sr.child : 0][sr.a][sr.b]); break;
                             case S_FLAG: v.c[0] = sr.child < n_present ? MONTY_ONE : 0; break;
                             case S_PREP: v.c[0] = to_monty(uni->prep_commits[((sr.child < n_present ? sr.child : 0) * n_prep_airs + prep_slot[sr.a]) * 8 + sr.b]); break;
@@ -1950,6 +2062,17 @@ int recursion_witness(zkhip_recursion* R, const uint8_t* const* proofs, const si
                     if (skip_const && is_const_row(G)) break;
                     vals[G.w[2]] = lin_value(G);
                     break;
+                case K_HSTEP: {
+                    Ext t = vals[G.w[0]];
+                    const Ext &wv = vals[G.w[1]], &al = vals[G.w[3]];
+                    for (int j = 3; j >= 0; j--)
+                        if (G.hmask >> j & 1u) {
+                            t = ext_mul(t, al);
+                            t.c[0] = madd(t.c[0], wv.c[j]);
+                        }
+                    vals[G.w[2]] = t;
+                    break;
+                }
                 case K_INV: {
                     const Ext& a = vals[G.w[0]];
                     if (is_zero(a)) {
@@ -2149,17 +2272,34 @@ int zkhip_recursion_wires(const zkhip_recursion* R, uint32_t* out, size_t cap_wo
 // ---- device trace generation: gather the wire values into the chips' traces ----
 namespace {
 
-// gate chip: trace[4 s + k][row] = wires[ids[s][row]][k]
+// gate chip: trace[4 s + k][row] = wires[ids[s][row]][k]; on a Horner row (ids[4][row] = its coordinate mask, else 0) the three values between
+// its steps are computed here into slots 4 .. 6 (they are no wires)
 __global__ __launch_bounds__(256) void k_gate_trace(const uint32_t* __restrict__ ids, const uint4* __restrict__ wires, size_t n_gates, size_t N,
                                                     uint32_t* __restrict__ trace) {
     const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= N) return;
+    uint4 v[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < n_gates) v = wires[ids[(size_t)s * n_gates + row]];
-        trace[(size_t)(4 * s + 0) * N + row] = v.x, trace[(size_t)(4 * s + 1) * N + row] = v.y;
-        trace[(size_t)(4 * s + 2) * N + row] = v.z, trace[(size_t)(4 * s + 3) * N + row] = v.w;
+        v[s] = make_uint4(0, 0, 0, 0);
+        if (row < n_gates) v[s] = wires[ids[(size_t)s * n_gates + row]];
+        trace[(size_t)(4 * s + 0) * N + row] = v[s].x, trace[(size_t)(4 * s + 1) * N + row] = v[s].y;
+        trace[(size_t)(4 * s + 2) * N + row] = v[s].z, trace[(size_t)(4 * s + 3) * N + row] = v[s].w;
+    }
+    const uint32_t mask = row < n_gates ? ids[(size_t)4 * n_gates + row] : 0u;
+    Ext t = Ext{{v[0].x, v[0].y, v[0].z, v[0].w}};
+    const Ext al = Ext{{v[3].x, v[3].y, v[3].z, v[3].w}};
+    const uint32_t wv[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int j = 3 - i;
+        if (mask >> j & 1u) {
+            t = ext_mul(t, al);
+            t.c[0] = madd(t.c[0], wv[j]);
+        }
+        const Ext o = mask ? t : ext_zero();
+#pragma unroll
+        for (int k = 0; k < 4; k++) trace[(size_t)(16 + 4 * i + k) * N + row] = o.c[k];
     }
 }
 // Poseidon2 chip: inputs[row][4 j + k] = wires[in_ids[j][row]][k]
@@ -2186,11 +2326,13 @@ extern "C" int zkhip_recursion_tracegen(zkhip_ctx* ctx, zkhip_recursion* R, uint
         std::lock_guard<std::mutex> lk(K.dev_mu);
         auto it = K.dev_ids.find(ctx->device);
         if (it == K.dev_ids.end()) {
-            ZK_HIP_CHECK(ctx, hipMalloc(&d_gate_ids, std::max<size_t>(1, 4 * ng) * 4));
+            ZK_HIP_CHECK(ctx, hipMalloc(&d_gate_ids, std::max<size_t>(1, 5 * ng) * 4));
             ZK_HIP_CHECK(ctx, hipMalloc(&d_perm_ids, std::max<size_t>(1, 4 * np) * 4));
-            std::vector<uint32_t> ids(4 * ng), pids(4 * np);
-            for (size_t g = 0; g < ng; g++)
+            std::vector<uint32_t> ids(5 * ng), pids(4 * np);
+            for (size_t g = 0; g < ng; g++) {
                 for (int s = 0; s < 4; s++) ids[(size_t)s * ng + g] = c.gates[g].w[s];
+                ids[(size_t)4 * ng + g] = c.gates[g].kind == K_HSTEP ? c.gates[g].hmask : 0u;
+            }
             for (size_t i = 0; i < np; i++)
                 for (int j = 0; j < 4; j++) pids[(size_t)j * np + i] = c.perms[i].in[j];
             ZK_TRY(upload(ctx, d_gate_ids, ids.data(), ids.size() * 4));
