@@ -181,6 +181,9 @@ struct Pass4Args {
     // src + col * src_col_stride (first pass of a transform) / dst + col * dst_col_stride (last pass)
     const uint32_t* const* src_cols;
     uint32_t* const* dst_cols;
+    // wave priority of the pass (s_setprio; experiment ZKHIP_NTT_PRIO=1..3): a pass beside another proof's row sponge issues its few VALU
+    // bursts ahead of the sponge's waves instead of taking turns with them
+    unsigned prio;
 };
 
 template <int Q>
@@ -404,6 +407,9 @@ __device__ __forceinline__ void lds_rounds_ct(uint32_t* lv, const uint32_t* twl,
 template <int LOG_R, int LOG_C>
 __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
     static_assert(LOG_R >= 7 && LOG_R - 4 + LOG_C == 10, "one radix-16 unit per lane in the first round");
+    if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
     extern __shared__ uint32_t sm[];
     constexpr unsigned R = 1u << LOG_R, C = 1u << LOG_C, pitch = C + 1u;
     constexpr int LOG_RQ = LOG_R - 4;
@@ -617,6 +623,8 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         dim3 grid(n_x << (pa.log_f - pa.log_c), (unsigned)(width << log_sub));
         KernelScope ks(ctx, inverse ? "ntt_pass_inv" : "ntt_pass_fwd");
         static const bool legacy = getenv("ZKHIP_NTT_LEGACY") != nullptr;  // A/B switch for experiments
+        static const unsigned prio_env = getenv("ZKHIP_NTT_PRIO") ? (unsigned)atoi(getenv("ZKHIP_NTT_PRIO")) : 0u;
+        pa.prio = prio_env;
         if (pa.log_r == 11 && pa.log_c == 3 && !legacy)
             hipLaunchKernelGGL((k_ntt_pass4_ct<11, 3>), grid, dim3(threads), lds, ctx->stream, pa);
         else if (pa.log_r == 10 && pa.log_c == 4 && !legacy)

@@ -15,6 +15,10 @@
 //         qM a b + qA a + qB b + qC c + qD d + qK = 0          (q* preprocessed base scalars, qK a preprocessed ext constant)
 //     which covers add / sub / mul / mul-add / inverse / division / assertions / booleanity / free inputs, plus a
 //     preprocessed flag forcing the row's slots into the base field (proof words that must be base elements).
+//     HORNER rows (round 5, second session): slots a = acc, b = a PACKED value (four base cells of an opened row, as the sponge takes
+//     them), d = alpha, c = the result; for j = 3 .. 0 with bit j of a preprocessed mask set: t <- t alpha + b[j] -- the three values
+//     between the steps sit in three further slots (28 columns in all).  The reduced opening of a query is one such row per four
+//     opened cells instead of an input row, three packing rows and four multiply-add rows (Builder::hstep; docs/round5_b.md).
 //   * Poseidon2 chip: the 298-column Poseidon2 AIR (zkhip_poseidon2_air_tracegen) whose 16 input and 16 output lanes leave /
 //     enter as 4 + 4 wires of 4 lanes each -- digests, sponge states and transcript states never get unpacked.
 //   * public-value chip: one row binding wires to the node's public values.
