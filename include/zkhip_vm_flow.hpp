@@ -505,7 +505,7 @@ inline std::vector<scroll_zkvm_hip::AggregationProver::ShapePolicy> shape_polici
         size_t w = 0, words = 0;
         for (const auto& a : vk.airs) w += a.width, words += a.program.size();
         const double rows = 335e3 + 28.0 * (double)w + 0.61 * (double)words, perms = 42e3 + 8.9 * (double)w + 0.11 * (double)words;
-        const double fit = std::min(0.97 * (double)(1u << 20) / rows, 0.97 * (double)(1u << 17) / perms);
+        const double fit = std::min(0.97 * (double)(1u << 20) / rows, 0.93 * (double)(1u << 17) / perms);   // (a leaf that misses doubles EVERY node of the tree)
         scroll_zkvm_hip::AggregationProver::ShapePolicy p;
         p.arity = (unsigned)std::min<double>(max_arity, fit);
         if (p.arity == 0) p.arity = 1, p.wrapped = true;
