@@ -343,7 +343,7 @@ public:
     // (large) heights and its proofs enter the tree through a WRAPPER -- a circuit of the common size that verifies one proof of that
     // leaf circuit and restates its public values; the wrapper's commitment is the shape's entry in the leaf-commitment list.
     struct ShapePolicy {
-        unsigned arity = 0;
+        unsigned arity = 0;     // (a wrapped shape: proofs of its leaf circuit -- one segment proof each -- per wrapper)
         bool wrapped = false;
     };
     void set_shape_policies(const std::vector<ShapePolicy>& p) {
@@ -478,8 +478,13 @@ public:
             return out;
         };
         if (kids.empty() || kids.size() > arity(0, shape)) throw Error(Error::GenProof, "aggregation: too many segment proofs for a leaf node of this shape");
-        const ChildProof big = run(B, apps_.at(shape), kids);
-        return run(W, B.vk, {&big});
+        // (second session of round 5) the large leaf circuit takes ONE segment proof; the wrapper takes up to arity(0, shape) of its proofs -- two for the
+        // chunk circuit's full shape: a wrapper per PAIR of wide segments instead of one each
+        std::vector<ChildProof> bigs;
+        for (const ChildProof* k : kids) bigs.push_back(run(B, apps_.at(shape), {k}));
+        std::vector<const ChildProof*> bp;
+        for (const ChildProof& b : bigs) bp.push_back(&b);
+        return run(W, B.vk, bp);
     }
     // device trace generation + proof of the node whose witness was computed last on this level
     ChildProof prove_witnessed(size_t level, std::vector<uint32_t> node_pvs, size_t shape = 0, size_t slot = 0) {
@@ -1102,7 +1107,7 @@ private:
         st.uniform = 1;
         st.app_id = apps_.size() > 1 ? app_id.data() : nullptr;
         std::vector<zkhip_air> za = apps_[sh].as_airs();
-        const int rc = zkhip_recursion_build(&apps_[sh].params, za.data(), za.size(), arity(0, sh), &st, &leaf->circ);
+        const int rc = zkhip_recursion_build(&apps_[sh].params, za.data(), za.size(), wrapped(sh) ? 1 : arity(0, sh), &st, &leaf->circ);
         if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the leaf verifier circuit of shape ") + std::to_string(sh) + ": " + zkhip_recursion_last_error(nullptr));
     }
     // leaf (built, natural heights) -> big = that circuit with its keys, leaf = the wrapper over it
@@ -1116,7 +1121,7 @@ private:
         std::vector<zkhip_air> za = big->vk.as_airs();
         zkhip_recursion_stmt st{};
         st.child_is_node = 1, st.uniform = 1;
-        const int rc = zkhip_recursion_build(&big->vk.params, za.data(), za.size(), 1, &st, &leaf->circ);
+        const int rc = zkhip_recursion_build(&big->vk.params, za.data(), za.size(), arity(0, sh), &st, &leaf->circ);
         if (rc != ZKHIP_OK) throw Error(Error::Setup, std::string("aggregation: cannot build the wrapper of shape ") + std::to_string(sh) + ": " + zkhip_recursion_last_error(nullptr));
     }
     void pad_leaf(Level& leaf, const Level& internal, std::vector<zkhip_air>* la) {

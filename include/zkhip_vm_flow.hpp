@@ -508,7 +508,7 @@ inline std::vector<scroll_zkvm_hip::AggregationProver::ShapePolicy> shape_polici
         const double fit = std::min(0.97 * (double)(1u << 20) / rows, 0.93 * (double)(1u << 17) / perms);   // (a leaf that misses doubles EVERY node of the tree)
         scroll_zkvm_hip::AggregationProver::ShapePolicy p;
         p.arity = (unsigned)std::min<double>(max_arity, fit);
-        if (p.arity == 0) p.arity = 1, p.wrapped = true;
+        if (p.arity == 0) p.arity = 2, p.wrapped = true;   // (a wrapper verifies up to two proofs of the shape's own leaf circuit: ~0.35 M rows, 44 k permutations each)
         out.push_back(p);
     }
     return out;
