@@ -960,6 +960,10 @@ typedef struct {
      * permutations would outlast the launch is hashed with 16 lanes per row [ZKHIP_NO_ROWS_IN_BULK=1 -> 0; ZKHIP_ROWS_COOP_MAX_LOG] */
     int rows_in_bulk;
     uint32_t rows_coop_max_log;
+    /* log2 of the lanes of a transform-pass workgroup for passes of at most 2^10 rows (8, 9 or 10): 10 = tiles of 2^14 words in 1024-lane
+     * workgroups with 70 KiB of LDS (two per CU), 9 / 8 = tiles of 2^13 / 2^12 words (four / eight per CU) -- the short transforms of a proof
+     * with many small chips get scheduled beside the other streams' kernels instead of waiting for half a CU [ZKHIP_NTT_LOG_LANES] */
+    uint32_t ntt_log_lanes;
 } zkhip_config;
 /* While `on`, the trace generators treat the shared lookup-count tables handed to them (the 8-bit bitwise table, the range-tuple table, the
  * range table) as canonical counts and leave them canonical -- none converts a table from Montgomery form and back around its increments.
@@ -978,7 +982,7 @@ void zkhip_config_default(zkhip_config *out);
 unsigned zkhip_host_cpus(void);
 /* a context's configuration (set at zkhip_ctx_create from zkhip_config_default); the witness fields are process-wide:
  * zkhip_set_process_config stores them (and the rest as the default of contexts created later).  zkhip_ctx_set_config applies every
- * field or refuses the call (ZKHIP_ERR_INVALID: jit 0..2, coop_* <= 27, rows_coop_max_log <= 27, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8,
+ * field or refuses the call (ZKHIP_ERR_INVALID: jit 0..2, coop_* <= 27, rows_coop_max_log <= 27, ntt_log_lanes 8..10, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8,
  * commit_parts <= 8, side_cus < the device's CUs, hash_block a multiple of 64 in 64..768); a changed side_cus re-partitions as zkhip_set_cu_partition does. */
 int zkhip_ctx_get_config(zkhip_ctx *ctx, zkhip_config *out);
 int zkhip_ctx_set_config(zkhip_ctx *ctx, const zkhip_config *cfg);

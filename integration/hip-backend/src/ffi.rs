@@ -199,6 +199,7 @@ pub struct zkhip_config {
     pub coop_fused: c_int,
     pub rows_in_bulk: c_int,
     pub rows_coop_max_log: u32,
+    pub ntt_log_lanes: u32,
 }
 
 #[repr(C)]

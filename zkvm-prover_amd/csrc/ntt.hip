@@ -376,7 +376,7 @@ __device__ __forceinline__ void load_unit_twiddles(const uint32_t* twl, unsigned
         for (int kl = 0; kl < half; kl++) w[woff + kl] = tb[kl << (LOG_RQ + t + TSHIFT)];
     }
 }
-template <int LOG_R, int LOG_C, int LOG_RCUR>
+template <int LOG_R, int LOG_C, int LOG_RCUR, unsigned NT = 1024u>
 __device__ __forceinline__ void lds_rounds_ct(uint32_t* lv, const uint32_t* twl, unsigned tid) {
     if constexpr (LOG_RCUR > 0) {
         constexpr int Q = LOG_RCUR >= 4 ? 4 : LOG_RCUR;
@@ -384,7 +384,7 @@ __device__ __forceinline__ void lds_rounds_ct(uint32_t* lv, const uint32_t* twl,
         constexpr unsigned n_units = 1u << (LOG_R - Q + LOG_C);
         constexpr unsigned pitch = (1u << LOG_C) + 1u;
 #pragma unroll
-        for (unsigned u0 = 0; u0 < n_units; u0 += 1024) {
+        for (unsigned u0 = 0; u0 < n_units; u0 += NT) {
             const unsigned u = u0 + tid;
             const unsigned c = u & ((1u << LOG_C) - 1u), jj = u >> LOG_C;
             const unsigned j = jj & ((1u << LOG_RQ) - 1u), blk = jj >> LOG_RQ;
@@ -400,13 +400,16 @@ __device__ __forceinline__ void lds_rounds_ct(uint32_t* lv, const uint32_t* twl,
             for (int k = 0; k < (1 << Q); k++) base[(k << LOG_RQ) * pitch] = v[k];
         }
         zk_syncthreads();
-        lds_rounds_ct<LOG_R, LOG_C, LOG_RCUR - Q>(lv, twl, tid);
+        lds_rounds_ct<LOG_R, LOG_C, LOG_RCUR - Q, NT>(lv, twl, tid);
     }
 }
 
-template <int LOG_R, int LOG_C>
-__global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
-    static_assert(LOG_R >= 7 && LOG_R - 4 + LOG_C == 10, "one radix-16 unit per lane in the first round");
+// LOG_T: log2 of the workgroup's lanes (10; 9 / 8 for the short transforms of proofs with many small chips: a 1024-lane, 70 KiB workgroup waits
+// for a quarter of a CU to fall free at once, and beside the other kernels of a guest flow's streams it mostly waits -- docs/round5_b.md)
+template <int LOG_R, int LOG_C, int LOG_T = 10>
+__global__ __launch_bounds__(1 << LOG_T) void k_ntt_pass4_ct(Pass4Args a) {
+    static_assert(LOG_R >= 7 && LOG_R - 4 + LOG_C == LOG_T, "one radix-16 unit per lane in the first round");
+    constexpr unsigned NT = 1u << LOG_T;
     if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
     uint32_t* lv = sm;
     uint32_t* twl = sm + R * pitch;
     const unsigned tid = threadIdx.x;
-    if (tid < (R >> 1)) twl[tid] = a.tw[(size_t)tid << (a.tw_log - LOG_R)];
+    for (unsigned e = tid; e < (R >> 1); e += NT) twl[e] = a.tw[(size_t)e << (a.tw_log - LOG_R)];
     const unsigned col = blockIdx.y;
     const unsigned sub = col & ((1u << a.log_sub) - 1u);
     const size_t mcol = col >> a.log_sub;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
         // consecutive rows (profiles/round01_ntt_ablation.txt).
         const unsigned c = tid & (C - 1u), jj = tid >> LOG_C;
         unsigned j = jj;
-        if constexpr (LOG_C <= 4) {
+        if constexpr (LOG_C <= 4 && LOG_C >= 3 && LOG_R - 4 >= (5 - LOG_C) + (LOG_C == 3 ? 3 : 4)) {
             constexpr unsigned HB = 5 - LOG_C;           // unit-index bits inside a half-wave (2 or 1)
             constexpr unsigned SP = LOG_C == 3 ? 3 : 4;  // log2 of the row spacing wanted
             j = ((jj & ((1u << HB) - 1u)) << SP) | ((jj >> HB) & ((1u << SP) - 1u)) | (jj & ~((1u << (HB + SP)) - 1u));
@@ -512,17 +515,17 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
     }
     zk_syncthreads();
 #if !defined(NTT_ABL) || (NTT_ABL != 4 && NTT_ABL != 5)
-    lds_rounds_ct<LOG_R, LOG_C, LOG_RQ>(lv, twl, tid);
+    lds_rounds_ct<LOG_R, LOG_C, LOG_RQ, NT>(lv, twl, tid);
 #endif
     // ---- write-out: each tile column is one contiguous run of R words; the column of every store is
     // a compile-time constant, so its HBM base is scalar and the LDS address an immediate ----
     const unsigned lo_mask = (1u << a.log_lo) - 1u;
     uint32_t* dst = (a.dst_cols ? a.dst_cols[mcol] : a.dst + mcol * a.dst_col_stride) + ((size_t)sub << a.log_m) + (size_t)X * a.out_x_stride;
-    if constexpr (LOG_R >= 10) {
+    if constexpr (LOG_R >= LOG_T) {
         const uint32_t* lrow = lv + tid * pitch;
 #pragma unroll
-        for (unsigned i = 0; i < (R * C) / 1024u; i++) {
-            const unsigned c = (1024u * i) >> LOG_R, p0 = (1024u * i) & (R - 1u);
+        for (unsigned i = 0; i < (R * C) / NT; i++) {
+            const unsigned c = (NT * i) >> LOG_R, p0 = (NT * i) & (R - 1u);
             const unsigned F = F0 + c;
             uint32_t* dcol = dst + (size_t)(F >> a.log_lo) * a.out_hi_stride + (size_t)(F & lo_mask) * a.out_lo_stride + p0;
 #if defined(NTT_ABL) && NTT_ABL == 3
@@ -536,10 +539,10 @@ __global__ __launch_bounds__(1024) void k_ntt_pass4_ct(Pass4Args a) {
         const unsigned p = tid & (R - 1u), c_lane = tid >> LOG_R;
         const uint32_t* lrow = lv + p * pitch + c_lane;
 #pragma unroll
-        for (unsigned i = 0; i < (R * C) / 1024u; i++) {
-            const unsigned F = F0 + c_lane + i * (1024u >> LOG_R);
+        for (unsigned i = 0; i < (R * C) / NT; i++) {
+            const unsigned F = F0 + c_lane + i * (NT >> LOG_R);
             uint32_t* dcol = dst + (size_t)(F >> a.log_lo) * a.out_hi_stride + (size_t)(F & lo_mask) * a.out_lo_stride + p;
-            *dcol = lrow[i * (1024u >> LOG_R)];
+            *dcol = lrow[i * (NT >> LOG_R)];
         }
     }
 }
@@ -616,6 +619,13 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         // tiles of 2^14 words (one radix-16 unit per lane): [2^11 x 8], [2^10 x 16], and for the short passes of
         // three-pass sizes [2^9 x 32], [2^8 x 64], [2^7 x 128]
         pa.log_c = log_c_env ? (unsigned)log_c_env : (pa.log_r >= 11 ? 3u : (pa.log_r >= 7 ? 14u - pa.log_r : 4u));
+        // workgroups of 2^log_t lanes for the passes of at most 2^10 rows (zkhip_config.ntt_log_lanes: 10 = the 1024-lane tiles above; 9 / 8 =
+        // tiles of 2^13 / 2^12 words, 37 / 18 KiB of LDS, four / eight workgroups per CU)
+        unsigned log_t = 10;
+        if (!log_c_env && pa.log_r >= 7 && pa.log_r <= 10 && ctx->cfg.ntt_log_lanes >= 8 && ctx->cfg.ntt_log_lanes <= 9) {
+            const unsigned lc = ctx->cfg.ntt_log_lanes + 4 - pa.log_r;
+            if (lc >= 2 && lc <= pa.log_f) log_t = ctx->cfg.ntt_log_lanes, pa.log_c = lc;
+        }
         if (pa.log_c > pa.log_f) pa.log_c = pa.log_f;
         const unsigned C = 1u << pa.log_c;
         const unsigned threads = std::min(1024u, std::max(64u, (R >> 4) * C));
@@ -625,7 +635,17 @@ static int ntt_dif_fourstep(zkhip_ctx* ctx, const uint32_t* src, size_t src_stri
         static const bool legacy = getenv("ZKHIP_NTT_LEGACY") != nullptr;  // A/B switch for experiments
         static const unsigned prio_env = getenv("ZKHIP_NTT_PRIO") ? (unsigned)atoi(getenv("ZKHIP_NTT_PRIO")) : 0u;
         pa.prio = prio_env;
-        if (pa.log_r == 11 && pa.log_c == 3 && !legacy)
+#define ZK_NTT_CT(R_, C_, T_) hipLaunchKernelGGL((k_ntt_pass4_ct<R_, C_, T_>), grid, dim3(1u << T_), lds, ctx->stream, pa)
+        if (log_t == 9 && pa.log_r == 10 && pa.log_c == 3) ZK_NTT_CT(10, 3, 9);
+        else if (log_t == 9 && pa.log_r == 9 && pa.log_c == 4) ZK_NTT_CT(9, 4, 9);
+        else if (log_t == 9 && pa.log_r == 8 && pa.log_c == 5) ZK_NTT_CT(8, 5, 9);
+        else if (log_t == 9 && pa.log_r == 7 && pa.log_c == 6) ZK_NTT_CT(7, 6, 9);
+        else if (log_t == 8 && pa.log_r == 10 && pa.log_c == 2) ZK_NTT_CT(10, 2, 8);
+        else if (log_t == 8 && pa.log_r == 9 && pa.log_c == 3) ZK_NTT_CT(9, 3, 8);
+        else if (log_t == 8 && pa.log_r == 8 && pa.log_c == 4) ZK_NTT_CT(8, 4, 8);
+        else if (log_t == 8 && pa.log_r == 7 && pa.log_c == 5) ZK_NTT_CT(7, 5, 8);
+#undef ZK_NTT_CT
+        else if (pa.log_r == 11 && pa.log_c == 3 && !legacy)
             hipLaunchKernelGGL((k_ntt_pass4_ct<11, 3>), grid, dim3(threads), lds, ctx->stream, pa);
         else if (pa.log_r == 10 && pa.log_c == 4 && !legacy)
             hipLaunchKernelGGL((k_ntt_pass4_ct<10, 4>), grid, dim3(threads), lds, ctx->stream, pa);
