@@ -1,4 +1,4 @@
-"""Runs a command and prints its wall time and the CPU seconds (user + system) its process tree consumed: python3 tools/timeit.py <label> <cmd ...>"""
+"""Runs a command and prints its wall time and the CPU seconds (user + system) its process tree consumed: python3 tools/cpu_seconds.py <label> <cmd ...>"""
 import os, subprocess, sys, time
 t0 = time.time()
 c0 = os.times()

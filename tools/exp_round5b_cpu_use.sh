@@ -15,7 +15,7 @@ export ZKHIP_LANES=3
 ./zkvm-prover_amd/prove_cli prove-elf /tmp/gm/fib.elf /tmp/gm/fib.in /tmp/om - 19 > /dev/null 2>&1
 for w in 0 4 8; do
 echo "witness_threads=$w"
-ZKHIP_WITNESS_THREADS=$w python3 tools/timeit.py fib ./zkvm-prover_amd/prove_cli prove-elf /tmp/gm/fib.elf /tmp/gm/fib.in /tmp/om - 19 2>&1 | python3 -c "
+ZKHIP_WITNESS_THREADS=$w python3 tools/cpu_seconds.py fib ./zkvm-prover_amd/prove_cli prove-elf /tmp/gm/fib.elf /tmp/gm/fib.in /tmp/om - 19 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
@@ -23,7 +23,7 @@ for l in sys.stdin:
     else: print(l.strip())"
 done
 ./zkvm-prover_amd/prove_cli prove-elf /tmp/gm/mixed.elf /tmp/gm/mixed.in /tmp/om /tmp/gm/openvm.toml 19 > /dev/null 2>&1
-python3 tools/timeit.py mixed ./zkvm-prover_amd/prove_cli prove-elf /tmp/gm/mixed.elf /tmp/gm/mixed.in /tmp/om /tmp/gm/openvm.toml 19 2>&1 | python3 -c "
+python3 tools/cpu_seconds.py mixed ./zkvm-prover_amd/prove_cli prove-elf /tmp/gm/mixed.elf /tmp/gm/mixed.in /tmp/om /tmp/gm/openvm.toml 19 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
