@@ -199,7 +199,7 @@ def guest_flow_mixed():
     import subprocess
 
     here = os.path.dirname(os.path.abspath(__file__))
-    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py"), "8192", "19", "mixed"]
+    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py"), "8192", "20", "mixed"]
     try:
         first, g, rates = _flow_runs(cmd, dict(os.environ, ZKHIP_LANES="3"))
         secs = (g["segment_tracegen_and_proving_ms"] + g["aggregation_setup_wait_ms"] + g["aggregation_ms"]) / 1e3
@@ -210,7 +210,7 @@ def guest_flow_mixed():
                 "execution_ms": g["execution_ms"], "segments_ms": g["segment_tracegen_and_proving_ms"], "tree_tail_ms": g["aggregation_setup_wait_ms"] + g["aggregation_ms"],
                 "process_wall_s": g["wall_s"], "process_wall_s_first_run_on_this_box": first["wall_s"], "instr_per_s_of_the_three_measured_runs": rates,
                 "leaf_circuits_at_setup": g.get("leaf_circuits_at_setup"), "leaf_circuits_on_demand": g.get("leaf_circuits_on_demand"), "verified": g["verified"], "guest": g.get("guest"),
-                "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 8192 19 mixed"}
+                "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 8192 20 mixed"}
     except Exception as e:   # a reported extra, never a gate
         return {"value": None, "note": "failed: %r" % (e,)}
 
@@ -219,8 +219,9 @@ def guest_flow(chunk_config=False, memory_bound=False):
     """The path AROUND the headline kernel, reported beside it (never `value`): a Fibonacci guest of 16.8 M instructions through
     `prove_cli prove-elf` (tools/guest_bench2.py) -- segmenting executor, 22 chips per segment as ONE statement, device trace generation,
     segment proofs, aggregation tree on verifier circuits, ONE self-verified root proof, at the reference's FRI parameters, in frames of
-    2^19 instructions (round 5: `profiles/round05_frame_sweep.txt` -- 3.3 / 5.6 / 8.2 / 10.5 / 10.7 M instr/s at 2^16 .. 2^20; rounds 3 - 4
-    measured at 2^17).  The rate depends on the guest's length: after the executor's last instruction the last segment proofs and the
+    2^20 instructions (round 5: `profiles/round05_frame_sweep.txt` -- 3.3 / 5.6 / 8.2 / 10.5 / 10.7 M instr/s at 2^16 .. 2^20 while the executor
+    bound the flow; its second session, with smaller tree nodes and a faster executor: 17.3 at 2^19, 21.6 at 2^20 -- `profiles/round05b_frame20.txt`;
+    rounds 3 - 4 measured at 2^17).  The rate depends on the guest's length: after the executor's last instruction the last segment proofs and the
     tree's last three levels take ~270 ms whatever the length (`profiles/round05_guest_length.txt`: 14 / 18.3 M instr/s at 8.4 / 33.6 M
     instructions).  memory_bound: the guest that sweeps a 64 KiB array 512 times (33.7 M instructions) (a load every fourth instruction).  Runs as a
     CHILD process BEFORE this process touches the GPU (a process that has initialised HIP must not start programs); four times: the
@@ -230,7 +231,7 @@ def guest_flow(chunk_config=False, memory_bound=False):
     import subprocess
 
     here = os.path.dirname(os.path.abspath(__file__))
-    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py")] + (["512", "19", "mem"] if memory_bound else ["2800000", "19"] + (["chunk"] if chunk_config else []))
+    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py")] + (["512", "20", "mem"] if memory_bound else ["2800000", "20"] + (["chunk"] if chunk_config else []))
     env = dict(os.environ, ZKHIP_LANES="3")
     try:
         first, g, rates = _flow_runs(cmd, env)

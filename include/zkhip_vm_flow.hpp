@@ -989,7 +989,7 @@ inline SegmentCaps config_caps(const std::string& path_app_config, unsigned log_
                                   log_frame > 8 ? log_frame - 8 : 1, int256_log_rows(path_app_config, log_frame), config_curves(path_app_config), ec_log_rows(log_frame),
                                   config_fp2_moduli(path_app_config), config_native(path_app_config));
 }
-inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 19, int device = 0,
+inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& exe, const StdIn& in, unsigned log_frame = 20, int device = 0,
                                         bool keep_segments = false, unsigned inflight = 2, unsigned log_keccak = 0, unsigned log_sha256 = 0,
                                         const std::vector<zkhip::modular::U256>& moduli = {}, unsigned log_int256 = 0,
                                         const std::vector<zkhip::ecc::Curve>& curves = {}, const std::vector<zkhip::modular::U256>& fp2_moduli = {},
@@ -1069,7 +1069,7 @@ public:
     std::string prover_name;
     ProverConfig config;
 
-    static UniversalProver setup(const ProverConfig& cfg, const char* name = nullptr, int device = 0, unsigned log_frame = 19) {
+    static UniversalProver setup(const ProverConfig& cfg, const char* name = nullptr, int device = 0, unsigned log_frame = 20) {
         UniversalProver p;
         p.config = cfg, p.prover_name = name ? name : "universal", p.device_ = device;
         std::ifstream f(cfg.path_app_exe, std::ios::binary);
@@ -1245,7 +1245,7 @@ private:
     zkhip_vm::SegmentCaps caps_;
     int device_ = 0;
     std::vector<std::unique_ptr<zkhip_vm::ShapedSegmentProver>> seg_;   // lanes: segment provers in flight on the device (one key per shape)
-    unsigned log_frame_ = 19;
+    unsigned log_frame_ = 20;
     std::unique_ptr<AggregationProver> agg_;
     std::unique_ptr<DeferralProver> deferral_;
     zkhip_vm::GuestStark last_;

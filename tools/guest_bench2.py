@@ -39,7 +39,7 @@ def memsum_program(n_words=16384):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
-    log_frame = sys.argv[2] if len(sys.argv) > 2 else "19"
+    log_frame = sys.argv[2] if len(sys.argv) > 2 else "20"
     tmp = tempfile.mkdtemp(prefix="zkhip_guest2_")
     exe, inp = os.path.join(tmp, "fib.elf"), os.path.join(tmp, "stdin.bin")
     mem = len(sys.argv) > 3 and sys.argv[3] == "mem"     # n = the number of passes over the array (64: ~4.3 M instructions)

@@ -81,7 +81,9 @@ int main(int argc, char** argv) {
                 if (zkhip_recursion_build(&toy_params, &child, 1, 1, &st, &toy) == ZKHIP_OK)
                     for (size_t i = 0; i < 2; i++) {
                         zkhip_air a{};
-                        if (zkhip_recursion_air(toy, i, &a) == ZKHIP_OK) a.log_height = i == 0 ? 21 : 18, a.prep_trace = nullptr, airs.push_back(a);
+                        if (zkhip_recursion_air(toy, i, &a) == ZKHIP_OK)
+                            for (unsigned h : (i == 0 ? std::vector<unsigned>{20, 21} : std::vector<unsigned>{17, 18, 19}))   // common nodes 2^20 / 2^17; a wide shape's own leaf circuit 2^21 / 2^19
+                                a.log_height = h, a.prep_trace = nullptr, airs.push_back(a);
                     }
             }
             size_t total = 0, mine = 0;
@@ -98,9 +100,9 @@ int main(int argc, char** argv) {
             return 0;
         }
         if (argc >= 3 && std::string(argv[1]) == "chips") {
-            // chips <openvm.toml> [log_frame = 19]: the chips the app's configuration asks for -- every `[app_vm_config.*]` section of the file, none
+            // chips <openvm.toml> [log_frame = 20]: the chips the app's configuration asks for -- every `[app_vm_config.*]` section of the file, none
             // ignored (the reference's chunk / batch / bundle circuits: crates/circuits/*/openvm.toml) -- as a JSON line: name, columns, log height
-            const unsigned log_frame = argc >= 4 ? (unsigned)atoi(argv[3]) : 19;
+            const unsigned log_frame = argc >= 4 ? (unsigned)atoi(argv[3]) : 20;
             const zkhip_vm::SegmentCaps caps = zkhip_vm::config_caps(argv[2], log_frame, 10);
             zkhip_vm::Exe exe;
             exe.program.assign(64, 0x00000013u);
@@ -126,10 +128,10 @@ int main(int argc, char** argv) {
             return 0;
         }
         if (argc >= 3 && std::string(argv[1]) == "leaf-stats") {
-            // leaf-stats <openvm.toml | -> [log_frame = 19] [children = 1]: builds, on the host, the leaf verifier circuit of every shape of the configuration
+            // leaf-stats <openvm.toml | -> [log_frame = 20] [children = 1]: builds, on the host, the leaf verifier circuit of every shape of the configuration
             // (dummy preprocessed commitments: the wiring does not depend on them) and prints its size -- wires, gate rows, permutations -- per shape;
             // with ZKHIP_RECURSION_TIMING=1 the builder also prints where the rows go.  No GPU.
-            const unsigned log_frame = argc >= 4 ? (unsigned)atoi(argv[3]) : 19;
+            const unsigned log_frame = argc >= 4 ? (unsigned)atoi(argv[3]) : 20;
             const size_t children = argc >= 5 ? (size_t)atoi(argv[4]) : 1;
             const zkhip_vm::SegmentCaps full = zkhip_vm::config_caps(argv[2], log_frame, 10);
             const zkhip_vm::SegmentShapes shapes = zkhip_vm::SegmentShapes::of(full, log_frame, 10);
@@ -253,7 +255,7 @@ int main(int argc, char** argv) {
                 std::ofstream(cfg_path) << "[app_fri_params.fri_params]\nlog_blowup = 1\nlog_final_poly_len = 0\nnum_queries = 100\n"
                                            "commit_proof_of_work_bits = 16\nquery_proof_of_work_bits = 16\n";
             }
-            const unsigned log_frame = argc >= 7 ? (unsigned)atoi(argv[6]) : 19;
+            const unsigned log_frame = argc >= 7 ? (unsigned)atoi(argv[6]) : 20;
             UniversalProver up = UniversalProver::setup(ProverConfig{argv[2], cfg_path}, nullptr, 0, log_frame);
             ProvingTask task;
             if (is_task) {
