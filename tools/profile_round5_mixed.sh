@@ -7,8 +7,8 @@ export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r5mixed19
 mkdir -p $O /tmp/gm /tmp/om
 export ZKHIP_LANES=3
-python3 tools/guest_bench2.py 8192 19 mixed > $O/run1.json 2> $O/run1_err.txt
-python3 tools/guest_bench2.py 8192 19 mixed > $O/run2.json 2> $O/run2_err.txt
+python3 tools/guest_bench2.py 8192 ${FRAME:-20} mixed > $O/run1.json 2> $O/run1_err.txt
+python3 tools/guest_bench2.py 8192 ${FRAME:-20} mixed > $O/run2.json 2> $O/run2_err.txt
 python3 - <<'PY'
 import os, sys
 sys.path.insert(0, "tests")
@@ -18,7 +18,7 @@ open("/tmp/gm/mixed.elf", "wb").write(rv.elf_bytes(mixed_chunk_program(), data=m
 open("/tmp/gm/stdin.bin", "wb").write((8192).to_bytes(4, "little"))
 open("/tmp/gm/openvm.toml", "w").write(chunk_circuit_toml((1, 0, 100, 16, 16)))
 PY
-rocprofv3 --kernel-trace --stats -d $O/p -o p --output-format csv -- ./zkvm-prover_amd/prove_cli prove-elf /tmp/gm/mixed.elf /tmp/gm/stdin.bin /tmp/om /tmp/gm/openvm.toml 19 > $O/profiled.json 2> $O/profiled_err.txt
+rocprofv3 --kernel-trace --stats -d $O/p -o p --output-format csv -- ./zkvm-prover_amd/prove_cli prove-elf /tmp/gm/mixed.elf /tmp/gm/stdin.bin /tmp/om /tmp/gm/openvm.toml ${FRAME:-20} > $O/profiled.json 2> $O/profiled_err.txt
 cp $(find $O/p -name "*kernel_stats.csv" | head -1) $O/mixed_flow_kernel_stats.csv
 python3 - <<'PY'
 import csv, glob, os
