@@ -494,7 +494,7 @@ struct SegmentShapes {
 // segment proof in-circuit costs, measured with `prove_cli leaf-stats` on the reference's three openvm.toml files at frames of 2^19
 // (base 22 chips / + hash intrinsics / the chunk circuit's 51 chips / the batch circuit's 37):
 //     gate rows    ~ 335 k + 28 per main column + 0.61 per word of the chips' constraint programs   (399 k / 587 k / 1377 k / 1053 k)
-//     permutations ~ 42 k + 8.9 per main column + 0.11 per program word                              (57 k / 103 k / 270 k / 196 k)
+//     permutations ~ 39 k + 3.8 per main column + 0.21 per program word (narrow shapes)              (57 k / 103 k / 270 k / 196 k)
 // (round 4: 835 rows per column, 2^21 / 2^18).  A shape takes as many proofs per leaf node as fit 2^20 rows and 2^17 permutations (the base
 // chips: 2; + the hash intrinsics: 1); a shape of which not even one proof fits (the full chunk- and batch-circuit sets) keeps a leaf circuit
 // of its own, natural size (2^21 / 2^19 for the chunk circuit's -- it was 2^23 / 2^19), one proof per node, and enters the tree through a
@@ -504,8 +504,13 @@ inline std::vector<scroll_zkvm_hip::AggregationProver::ShapePolicy> shape_polici
     for (const VerifyingKey& vk : shape_vks) {
         size_t w = 0, words = 0;
         for (const auto& a : vk.airs) w += a.width, words += a.program.size();
-        const double rows = 335e3 + 28.0 * (double)w + 0.61 * (double)words, perms = 42e3 + 8.9 * (double)w + 0.11 * (double)words;
-        const double fit = std::min(0.97 * (double)(1u << 20) / rows, 0.93 * (double)(1u << 17) / perms);   // (a leaf that misses doubles EVERY node of the tree)
+        unsigned lh = 0;
+        for (unsigned h : vk.heights) lh = std::max(lh, h);
+        const double up = (double)lh - 19.0;   // (a taller frame: one more level on every path -- ~20 k rows, ~2.4 k permutations per child)
+        const double rows = 335e3 + 28.0 * (double)w + 0.61 * (double)words + 20e3 * up, perms = 39.4e3 + 3.8 * (double)w + 0.206 * (double)words + 2.4e3 * up;
+        // (the permutation estimate is exact to 1 % on the base chips with and without the native extension and on the 26-chip shape, and high for
+        // the wide shapes, which are wrapped either way.  A leaf that misses doubles EVERY node of the tree; one proof less per leaf costs half a node.)
+        const double fit = std::min(0.97 * (double)(1u << 20) / rows, 0.98 * (double)(1u << 17) / perms);
         scroll_zkvm_hip::AggregationProver::ShapePolicy p;
         p.arity = (unsigned)std::min<double>(max_arity, fit);
         if (p.arity == 0) p.arity = 2, p.wrapped = true;   // (a wrapper verifies up to two proofs of the shape's own leaf circuit: ~0.35 M rows, 44 k permutations each)

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(768) void k_hash_rows(const uint32_t* const* __rest
 // (second session of round 5) EVERY level with injected matrices is hashed here, whatever its size (zkhip_config.rows_in_bulk): a segment proof of the
 // chunk-circuit configuration carries wide chips of few rows (Keccak-f: 2634 columns x 2^14 LDE rows = 330 permutations per row; the limb chips: ~3000
 // columns at 2^11 - 2^12 rows), and the cooperative tree kernels ran those sponges on every 16-lane row of every workgroup of the group's FIRST layer --
-// rows that a deeper layer no longer uses included: 12.7 + 8.9 ms of a 74 ms proof in two launches (gpurun_out/r5mixed19_trace).  A level's blocks take
+// rows that a deeper layer no longer uses included: 12.7 + 8.9 ms of a 74 ms proof in two launches (docs/round5_b.md).  A level's blocks take
 // one of two forms: one lane per row, or -- a level of few rows and many columns, whose one-lane chain of hundreds of permutations would outlast the
 // rest of the launch -- one 16-lane row per matrix row (the cooperative permutation: ~2.7x the VALU work, an eighth of the chain).  The levels with the
 // longest chains come first in the grid and run at wave priority 3, so that the chains end under the bulk of the launch instead of behind it.

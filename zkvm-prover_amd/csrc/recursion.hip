@@ -166,7 +166,7 @@ class Builder {
     }
     // where the rows go (ZKHIP_RECURSION_TIMING prints the table): the part of the verifier being built when a row / permutation is added
     const char* phase = "other";
-    std::map<std::string, size_t> phase_gates, phase_perms;
+    std::map<const char*, size_t> phase_gates, phase_perms;   // (keyed by the literal's address: a row costs a pointer lookup)
 
     // ---- inputs (four per row) ----
     V input(const Src& s, bool base) {
@@ -1399,8 +1399,11 @@ static int finish_build(std::unique_ptr<zkhip_recursion>& R, const unsigned* min
         b.c.sections.push_back(b.c.order.size());
         lap("children verified");
         if (timing) {
-            for (const auto& kv : b.phase_gates) std::fprintf(stderr, "[recursion build]   rows %-48s %10zu\n", kv.first.c_str(), kv.second);
-            for (const auto& kv : b.phase_perms) std::fprintf(stderr, "[recursion build]   perm %-48s %10zu\n", kv.first.c_str(), kv.second);
+            std::map<std::string, size_t> rows, perms;   // (one literal may live at several addresses)
+            for (const auto& kv : b.phase_gates) rows[kv.first] += kv.second;
+            for (const auto& kv : b.phase_perms) perms[kv.first] += kv.second;
+            for (const auto& kv : rows) std::fprintf(stderr, "[recursion build]   rows %-48s %10zu\n", kv.first.c_str(), kv.second);
+            for (const auto& kv : perms) std::fprintf(stderr, "[recursion build]   perm %-48s %10zu\n", kv.first.c_str(), kv.second);
         }
         const ChildVk& vk = K.vk;
         const size_t n_airs = vk.pg.size();
