@@ -354,6 +354,9 @@ public:
         policy_ = p;
     }
     bool wrapped(size_t shape) const { return shape < policy_.size() && policy_[shape].wrapped; }
+    // the shapes an earlier process of this guest put into the tree, as the key cache remembers them (empty: no cache, or no key yet) -- what the
+    // flow's other lanes build their segment keys for at setup instead of inside the first segment proof of that shape
+    std::vector<char> shapes_used_before() const { return used_on_disk_; }
 
     // proves one node: level 0 verifies up to 4 proofs of the app, level l > 0 up to 3 proofs of level l - 1
     ChildProof prove_node(size_t level, const std::vector<const ChildProof*>& kids, size_t shape = 0, const std::vector<size_t>* kid_shapes = nullptr, size_t slot = 0) {
@@ -593,6 +596,14 @@ public:
                 }
             return *layers_[root_layer].items[0];
         }
+        // node proofs formed and waiting for a free pipeline (every level).  The flow's lanes look at it before they start a segment proof: a tree that
+        // lags behind the segment proofs is finished alone, three streams on an under-filled GPU (mixed guest at frames of 2^20: a 700 ms tail).
+        // (counted in SEGMENT PROOFS handed in whose leaf node's proof does not exist yet: queued node proofs are no measure -- a pipeline's witness
+        // thread takes a node off the queue as soon as its buffer is free)
+        size_t backlog() {
+            std::lock_guard<std::mutex> lk(mu_);
+            return segs_pushed_ - std::min(segs_pushed_, segs_in_leaf_proofs_);
+        }
         size_t levels() const {
             if (greedy_) return 1 + fold_.root_depth();
             size_t n = 0;
@@ -620,6 +631,8 @@ public:
         std::mutex mu_;
         std::condition_variable cv_;
         std::deque<Layer> layers_;
+        size_t segs_pushed_ = 0, segs_in_leaf_proofs_ = 0;   // backlog(): segment proofs handed in / covered by finished leaf nodes
+        std::deque<size_t> leaf_n_kids_;                     // segment proofs under leaf node k (written when the node is formed)
         std::vector<size_t> seg_shape_;     // shape of segment i (layer 0)
         std::deque<size_t> leaf_shape_;     // shape of leaf proof k (layer 1), written when the node is formed
         std::vector<std::thread> threads_, verifiers_;
@@ -686,6 +699,8 @@ public:
             Layer& L = layers_[layer];
             if (L.items.size() <= index) L.items.resize(index + 1);
             L.items[index].reset(new ChildProof(std::move(p)));
+            if (layer == 0) segs_pushed_++;
+            if (layer == 1) segs_in_leaf_proofs_ += index < leaf_n_kids_.size() ? leaf_n_kids_[index] : 1;
             if (greedy_ && layer == 1) {   // a leaf node's proof: a piece of the line
                 const ChildProof* made = L.items[index].get();
                 fold_.add(index, index + 1, (int)(index < leaf_shape_.size() ? leaf_shape_[index] : 0) + 1, 0, made);
@@ -751,6 +766,8 @@ public:
                             t.shape = seg_shape_.size() > next ? seg_shape_[next] : 0;
                             if (leaf_shape_.size() <= k) leaf_shape_.resize(k + 1, 0);
                             leaf_shape_[k] = t.shape;
+                            if (leaf_n_kids_.size() <= k) leaf_n_kids_.resize(k + 1, 0);
+                            leaf_n_kids_[k] = hi - next;
                         }
                         next = hi;
                         layers_[level].tasks.push_back(std::move(t));

@@ -242,6 +242,9 @@ struct FlowOptions {
     unsigned deferral_nodes = 1;      // task's nodes are FOLDED before the join -- 6 x 8 covers the reference's 45 chunks per batch)
                                       //                                                   [ZKHIP_DEFERRAL_CHILDREN, ZKHIP_DEFERRAL_NODES]
     bool trace_tree = false;          // a line per event of the aggregation tree on stderr (a measurement aid)           [ZKHIP_TREE_TRACE=1]
+    unsigned wide_in_flight = 0;      // > 0: at most so many segment proofs of WRAPPED shapes (the chunk circuit's 51-chip set) in flight at a time,
+                                      // whatever the lanes -- the segment waits at the head of the queue.  Measured on the mixed guest at frames of
+                                      // 2^20 (three lanes): 2: 4.9 - 6.2 MHz against 6.0 - 6.5 without (docs/round5_b.md 9); off   [ZKHIP_WIDE_IN_FLIGHT=n]
     std::vector<int> devices;         // GPUs of the node the flow spreads over (empty = the prover's device)             [ZKHIP_DEVICES=0,1,..]
     static FlowOptions from_env() {
         FlowOptions o;
@@ -253,6 +256,7 @@ struct FlowOptions {
         o.per_depth_keys = getenv("ZKHIP_AGG_PER_DEPTH_KEYS") != nullptr;
         o.balanced_tree = getenv("ZKHIP_TREE_BALANCED") != nullptr;
         o.trace_tree = getenv("ZKHIP_TREE_TRACE") != nullptr;
+        if (const char* e = getenv("ZKHIP_WIDE_IN_FLIGHT")) o.wide_in_flight = (unsigned)std::max(0, atoi(e));
         o.agg_cli_greedy = getenv("ZKHIP_AGG_GREEDY") != nullptr;
         if (const char* e = getenv("ZKHIP_DEFERRAL_CHILDREN")) o.deferral_children = (unsigned)std::min(8, std::max(1, atoi(e)));
         if (const char* e = getenv("ZKHIP_DEFERRAL_NODES")) o.deferral_nodes = (unsigned)std::min(8, std::max(1, atoi(e)));

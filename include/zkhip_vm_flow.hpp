@@ -518,6 +518,23 @@ inline std::vector<scroll_zkvm_hip::AggregationProver::ShapePolicy> shape_polici
     }
     return out;
 }
+// Lane 0 builds the segment keys of every shape at setup (their verifying keys make the aggregation key); the other lanes build a shape's key when its
+// first segment arrives -- inside the timed proving, 0.2 - 0.4 s for the chunk circuit's 51-chip shape.  warm_lanes builds, side by side, the keys of the
+// shapes this guest's earlier flows used (the aggregation key cache remembers them) on every other lane before the flow starts: key generation is
+// setup, as the reference's `Sdk::app_keygen` is (crates/prover/src/prover/mod.rs:147-170).  Without a cache file nothing is known and nothing is built.
+template <class Lane>
+inline void warm_lanes(const std::vector<Lane*>& lanes, const std::vector<char>& used_before) {
+    std::vector<std::thread> th;
+    for (size_t l = 1; l < lanes.size(); l++)
+        th.emplace_back([&, l] {
+            try {
+                for (size_t sh = 0; sh < used_before.size() && sh < lanes[l]->n_shapes(); sh++)
+                    if (used_before[sh]) (void)lanes[l]->vk(sh);
+            } catch (...) {   // (the lane builds the key again, and reports, when a segment of the shape arrives)
+            }
+        });
+    for (auto& t : th) t.join();
+}
 // a lane of the flow: one SegmentProver per shape (built at the first segment of that shape; lane 0 builds all of them at setup: their keys
 // are the aggregation tree's leaf circuits)
 class ShapedSegmentProver {
@@ -687,7 +704,8 @@ inline Digest guest_image_root(const Exe& exe) {
 // proofs runs on host threads beside the lanes.  Segments are independent proofs; their order is restored.
 template <class Lane>
 inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_hip::AggregationProver& agg, const Exe& exe, const StdIn& in,
-                                   const SegmentCaps& caps, bool keep_segments = false, bool verify_segments = false, bool greedy_tree = true, bool trace_tree = false) {
+                                   const SegmentCaps& caps, bool keep_segments = false, bool verify_segments = false, bool greedy_tree = true, bool trace_tree = false,
+                                   size_t wide_in_flight = 0) {
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::duration d) { return (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(d).count(); };
     if (lanes.empty()) throw Error("no segment prover lanes");
@@ -697,6 +715,7 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
     struct Item {
         size_t index;
         SegmentRecords rec;
+        bool wide = false;   // a segment of a WRAPPED shape (FlowOptions::wide_in_flight)
     };
     std::deque<Item> queue;
     std::vector<SegmentRecords> pool;
@@ -716,6 +735,7 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
     // the aggregation tree runs as a stream beside the segment proving: a leaf node starts when its four segment proofs exist
     scroll_zkvm_hip::AggregationProver::TreeStream tree(agg, greedy_tree);
     tree.trace = trace_tree;
+    size_t n_wide = 0;
     for (Lane* lane : lanes)
         workers.emplace_back([&, lane] {
             try {
@@ -723,12 +743,30 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
                     Item it;
                     {
                         std::unique_lock<std::mutex> lk(mu);
-                        cv_pop.wait(lk, [&] { return !queue.empty() || closed || failed; });
+                        // FlowOptions::wide_in_flight > 0 (an experiment, off): at most so many proofs of WRAPPED shapes at a time; the segment stays at
+                        // the head of the queue meanwhile -- a lane that held it back would hand the tree its segment proofs out of order, and
+                        // the tree folds neighbours.
+                        cv_pop.wait(lk, [&] { return failed || (queue.empty() ? closed : !(queue.front().wide && n_wide >= wide_in_flight)); });
                         if (failed || queue.empty()) return;
                         it = std::move(queue.front());
                         queue.pop_front();
+                        if (it.wide) n_wide++;
                     }
                     cv_push.notify_one();
+                    struct WideSlot {   // (given back when the proof exists or fails)
+                        std::mutex& mu;
+                        std::condition_variable& cv;
+                        size_t& n;
+                        bool held;
+                        ~WideSlot() {
+                            if (!held) return;
+                            {
+                                std::lock_guard<std::mutex> lk(mu);
+                                n--;
+                            }
+                            cv.notify_all();
+                        }
+                    } wide_slot{mu, cv_pop, n_wide, it.wide};
                     // a segment proof that fails (a refused trace check, the device self-check of zkhip_config.self_check, a device error)
                     // is made once more from the same records before the run is given up; a second failure ends it
                     SegmentProof p;
@@ -798,7 +836,9 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
             const auto a = clk::now();
             done = ex.run_segment(it.rec);
             t_exec += clk::now() - a;
-            agg.prefetch_leaf(lanes[0]->shape_of(it.rec));   // (a shape whose leaf circuit was left out at setup is built beside the proving, from now)
+            const size_t seg_shape = lanes[0]->shape_of(it.rec);
+            it.wide = wide_in_flight && agg.wrapped(seg_shape);
+            agg.prefetch_leaf(seg_shape);   // (a shape whose leaf circuit was left out at setup is built beside the proving, from now)
             std::unique_lock<std::mutex> lk(mu);
             cv_push.wait(lk, [&] { return queue.size() < 2 * lanes.size() || failed; });
             queue.push_back(std::move(it));
@@ -1027,7 +1067,8 @@ inline GuestStark prove_guest_universal(const zkhip_params& params, const Exe& e
     }
     agg.set_shape_policies(shape_policies(shape_vks));
     (void)agg.node_vk(0);   // the leaf circuit and its key: setup, like the segment keys
-    return prove_guest_with(lanes, agg, exe, in, caps, keep_segments, flow.verify_segments, !flow.balanced_tree, flow.trace_tree);
+    warm_lanes(lanes, agg.shapes_used_before());
+    return prove_guest_with(lanes, agg, exe, in, caps, keep_segments, flow.verify_segments, !flow.balanced_tree, flow.trace_tree, flow.wide_in_flight);
 }
 
 // The verifier's side: the root proof under the root verifying key, then the statement: the run starts at the guest's entry on the
@@ -1124,7 +1165,8 @@ public:
             const zkhip_vm::StdIn in = task.build_guest_input();
             std::vector<zkhip_vm::ShapedSegmentProver*> lanes;
             for (auto& l : seg_) lanes.push_back(l.get());
-            last_ = zkhip_vm::prove_guest_with(lanes, *agg_, exe_, in, caps_, false, config.flow.verify_segments, !config.flow.balanced_tree, config.flow.trace_tree);
+            last_ = zkhip_vm::prove_guest_with(lanes, *agg_, exe_, in, caps_, false, config.flow.verify_segments, !config.flow.balanced_tree, config.flow.trace_tree,
+                                               config.flow.wide_in_flight);
         } catch (const zkhip_vm::Error& e) {
             throw Error(Error::GenProof, std::string("failed to generate proof: ") + e.what());
         }
