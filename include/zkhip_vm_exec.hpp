@@ -606,6 +606,7 @@ private:
     std::vector<Block> blk_;
     std::vector<uint32_t> blk_label_;
     uint32_t reg_slot_[8] = {}, pv_slot_[2] = {}, mem_lo_blk_ = 0;
+    uint32_t reg_ts_[32] = {};                       // last access of register j in this segment (its block's ts[] and cur[] are written at the close)
     std::vector<uint32_t> mem_slot_;                 // index + 1 into blk_, 0 = untouched
     std::unordered_map<uint32_t, uint32_t> other_slot_;
     std::unordered_set<uint64_t> path_nodes_;        // internal nodes above them
@@ -636,6 +637,7 @@ private:
         }
         other_slot_.clear();
         blk_.clear(), blk_label_.clear(), path_nodes_.clear();
+        memset(reg_ts_, 0, sizeof reg_ts_);
     }
 
     uint32_t mem_word(uint32_t addr) const { return m_.peek_word(addr); }
@@ -681,19 +683,31 @@ private:
     // changes it: run_segment calls block_of for every word an instruction will write before step_one.  Both return the timestamp of
     // the word's previous access (0 = untouched in this segment: the leaf chip's initial state).
     uint32_t read_word(uint32_t as, uint32_t word, uint32_t value, uint32_t ts) {
+        if (as == 1 && word < 32) {   // a register: three of these per instruction -- the timestamp lives in reg_ts_, the block is completed at the close
+            if (!reg_slot_[word >> 2]) (void)block_of(1, word);
+            const uint32_t prev = reg_ts_[word];
+            reg_ts_[word] = ts;
+            return prev;
+        }
+        (void)value;   // (the words' values at the close come from the machine: close_memory)
         Block& b = block_of(as, word);
         const unsigned j = word & 3u;
-        if ((b.cur[2 * j] | (b.cur[2 * j + 1] << 16)) != value) throw Error("internal: memory log out of step with the machine");
         const uint32_t prev = b.ts[j];
         b.ts[j] = ts;
         return prev;
     }
     uint32_t write_word(uint32_t as, uint32_t word, uint32_t value, uint32_t ts) {
+        if (as == 1 && word < 32) {
+            if (!reg_slot_[word >> 2]) throw Error("internal: write to a block that was not snapshotted");
+            const uint32_t prev = reg_ts_[word];
+            reg_ts_[word] = ts;
+            return prev;
+        }
         Block* known = find_block((as << vmc::LABEL_BITS) | (word >> 2));
         if (!known) throw Error("internal: write to a block that was not snapshotted");
         const unsigned j = word & 3u;
         const uint32_t prev = known->ts[j];
-        known->cur[2 * j] = value & 0xffffu, known->cur[2 * j + 1] = value >> 16, known->ts[j] = ts;
+        known->ts[j] = ts;
         return prev;
     }
 
@@ -703,6 +717,17 @@ private:
     // rows are built side by side; the tree itself (a hash map) is only read until every level is done.
     void close_memory(SegmentRecords& r) {
         const size_t nL = blk_label_.size();
+        // every touched block's FINAL cells are the machine's words now (read_word / write_word keep timestamps only); the register blocks'
+        // timestamps come from reg_ts_
+        for (size_t i = 0; i < nL; i++) {
+            const uint32_t label = blk_label_[i], as = label >> vmc::LABEL_BITS, blk = label & ((1u << vmc::LABEL_BITS) - 1);
+            Block& b = blk_[i];
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t w = word_now(as, 4 * blk + j);
+                b.cur[2 * j] = w & 0xffffu, b.cur[2 * j + 1] = w >> 16;
+                if (as == 1 && blk < 8) b.ts[j] = reg_ts_[4 * blk + j];
+            }
+        }
         std::vector<std::pair<uint32_t, uint32_t>> order(nL);   // (label, index into blk_)
         for (size_t i = 0; i < nL; i++) order[i] = {blk_label_[i], (uint32_t)i};
         std::sort(order.begin(), order.end());
