@@ -58,24 +58,38 @@ struct Error : std::runtime_error {
 };
 
 // Per-chip records, in the argument layout of the device trace generators (plain integers).
+// a record array of the interpreter's inner loop: std::vector<uint32_t> with an append that skips the capacity check (ExecRecords::reserved: the
+// segmenting executor reserves a whole frame's rows before the segment starts; four appends per instruction were a fifth of its time)
+struct U32Vec : std::vector<uint32_t> {
+    using std::vector<uint32_t>::vector;
+#if defined(__GLIBCXX__)
+    void put_unchecked(uint32_t x) {
+        *this->_M_impl._M_finish = x;
+        ++this->_M_impl._M_finish;
+    }
+#else
+    void put_unchecked(uint32_t x) { this->push_back(x); }
+#endif
+};
 struct ExecRecords {
-    std::vector<uint32_t> pc_index;                   // every executed instruction: its row in the program
-    std::vector<uint32_t> alu_op, alu_b, alu_c;       // 0 add 1 sub 2 xor 3 or 4 and (register and immediate forms)
-    std::vector<uint32_t> lt_op, lt_b, lt_c;          // 0 slt 1 sltu
-    std::vector<uint32_t> mul_b, mul_c;               // mul (low word)
-    std::vector<uint32_t> mulh_op, mulh_b, mulh_c;    // 0 mulh 1 mulhsu 2 mulhu
-    std::vector<uint32_t> div_op, div_b, div_c;       // 0 div 1 divu 2 rem 3 remu; b = dividend, c = divisor
-    std::vector<uint32_t> shift_op, shift_b, shift_c; // 0 sll 1 srl 2 sra; c = the shift operand (register value or shamt)
-    std::vector<uint32_t> beq_op, beq_a, beq_b, beq_imm;  // 0 beq 1 bne; imm = the offset as a canonical BabyBear element
-    std::vector<uint32_t> blt_op, blt_a, blt_b, blt_imm;  // 0 blt 1 bltu 2 bge 3 bgeu; imm as above
-    std::vector<uint32_t> jal_op, jal_pc, jal_imm;        // 0 jal (imm = the offset as a field element) 1 lui (imm = the 20-bit immediate)
-    std::vector<uint32_t> auipc_pc, auipc_imm;            // imm = the 20-bit immediate
-    std::vector<uint32_t> jalr_pc, jalr_rs1, jalr_imm;    // imm = the raw 12-bit immediate
+    U32Vec pc_index;                   // every executed instruction: its row in the program
+    U32Vec alu_op, alu_b, alu_c;       // 0 add 1 sub 2 xor 3 or 4 and (register and immediate forms)
+    U32Vec lt_op, lt_b, lt_c;          // 0 slt 1 sltu
+    U32Vec mul_b, mul_c;               // mul (low word)
+    U32Vec mulh_op, mulh_b, mulh_c;    // 0 mulh 1 mulhsu 2 mulhu
+    U32Vec div_op, div_b, div_c;       // 0 div 1 divu 2 rem 3 remu; b = dividend, c = divisor
+    U32Vec shift_op, shift_b, shift_c; // 0 sll 1 srl 2 sra; c = the shift operand (register value or shamt)
+    U32Vec beq_op, beq_a, beq_b, beq_imm;  // 0 beq 1 bne; imm = the offset as a canonical BabyBear element
+    U32Vec blt_op, blt_a, blt_b, blt_imm;  // 0 blt 1 bltu 2 bge 3 bgeu; imm as above
+    U32Vec jal_op, jal_pc, jal_imm;        // 0 jal (imm = the offset as a field element) 1 lui (imm = the 20-bit immediate)
+    U32Vec auipc_pc, auipc_imm;            // imm = the 20-bit immediate
+    U32Vec jalr_pc, jalr_rs1, jalr_imm;    // imm = the raw 12-bit immediate
     // loads and stores: case 0..19 (LW, LHU@0 LHU@2, LBU@0..3, SW, SH@0 SH@2, SB@0..3, LH@0 LH@2, LB@0..3; @k = byte offset inside the
     // word, words aligned from data_base), read = the aligned memory word (loads) / the stored register (stores), prev = what the
     // destination register (loads) / the aligned memory word (stores) held before
-    std::vector<uint32_t> ls_case, ls_read, ls_prev;
+    U32Vec ls_case, ls_read, ls_prev;
     uint64_t n_shift = 0, n_branch = 0, n_jump = 0, n_load_store = 0, n_mulh = 0, n_divrem = 0, n_lui_auipc = 0, n_ecall = 0;
+    uint64_t reserved = 0;   // != 0: every U32Vec above has room for the rows of a whole segment (set by the segmenting executor; survives clear())
     // Memory log for the offline memory-checking argument (OpenVM's memory bus): state is kept in 16-bit CELLS -- address space
     // 1 = registers (cell 2 i + half of x_i), 2 = read-write memory (cell = halfword index from data_base) -- so that a cell's
     // value is a field element.  One entry per cell access, in execution order, timestamps 1, 2, 3, ...:
@@ -87,7 +101,7 @@ struct ExecRecords {
 
     // empties every array but keeps its storage: a recycled ExecRecords spares the next segment ~25 MB of fresh pages
     void clear() {
-        for (std::vector<uint32_t>* v :
+        for (std::vector<uint32_t>* v : std::initializer_list<std::vector<uint32_t>*>
              {&pc_index, &alu_op, &alu_b, &alu_c, &lt_op, &lt_b, &lt_c, &mul_b, &mul_c, &mulh_op, &mulh_b, &mulh_c, &div_op, &div_b, &div_c, &shift_op,
               &shift_b, &shift_c, &beq_op, &beq_a, &beq_b, &beq_imm, &blt_op, &blt_a, &blt_b, &blt_imm, &jal_op, &jal_pc, &jal_imm, &auipc_pc, &auipc_imm,
               &jalr_pc, &jalr_rs1, &jalr_imm, &ls_case, &ls_read, &ls_prev, &acc_as, &acc_ptr, &acc_prev_data, &acc_prev_ts, &acc_data, &acc_ts,
@@ -96,7 +110,7 @@ struct ExecRecords {
         n_shift = n_branch = n_jump = n_load_store = n_mulh = n_divrem = n_lui_auipc = n_ecall = 0;
     }
 };
-static_assert(sizeof(ExecRecords) == 49 * sizeof(std::vector<uint32_t>) + 8 * sizeof(uint64_t), "ExecRecords::clear() must list every array");
+static_assert(sizeof(ExecRecords) == 49 * sizeof(std::vector<uint32_t>) + 9 * sizeof(uint64_t), "ExecRecords::clear() must list every array");
 
 constexpr unsigned NUM_PUBLIC_VALUE_BYTES = 32;
 // trace widths used by the cost model (cells per record) = the widths of the device trace generators (include/zkhip.h
@@ -119,9 +133,28 @@ inline uint64_t trace_cells(const ExecRecords& r, size_t program_len) {
            cells(r.acc_ts.size(), W_MEM_ACCESS);
 }
 
+// an append of the interpreter (see U32Vec)
+static inline void put(ExecRecords* rec, U32Vec& v, uint32_t x) {
+    if (rec->reserved) v.put_unchecked(x);
+    else v.push_back(x);
+}
 class Machine {
 public:
     Machine(const Exe& exe, const StdIn& in) : exe_(exe), in_(in), mem_(exe.memory_bytes, 0), pv_(NUM_PUBLIC_VALUE_BYTES, 0) {
+        pre_.resize(exe.program.size());
+        for (size_t i = 0; i < pre_.size(); i++) {
+            const uint32_t w = exe.program[i];
+            Pre& q = pre_[i];
+            // immediates: assembled as unsigned fields, sign-extended once (shifting a negative value left is undefined before C++20)
+            auto sext = [](uint32_t v, unsigned bits) { const uint32_t m = 1u << (bits - 1); return (int32_t)((v ^ m) - m); };
+            q.w = w, q.op = w & 0x7f, q.rd = (w >> 7) & 31, q.f3 = (w >> 12) & 7, q.rs1 = (w >> 15) & 31, q.rs2 = (w >> 20) & 31, q.f7 = (uint8_t)(w >> 25);
+            q.uses_rs1 = q.op == 0x67 || q.op == 0x63 || q.op == 0x03 || q.op == 0x23 || q.op == 0x13 || q.op == 0x33;
+            q.uses_rs2 = q.op == 0x63 || q.op == 0x23 || q.op == 0x33;
+            q.imm_i = sext(w >> 20, 12);
+            q.imm_s = sext(((w >> 25) << 5) | ((w >> 7) & 31u), 12);
+            q.imm_b = sext(((w >> 31) << 12) | (((w >> 7) & 1u) << 11) | (((w >> 25) & 63u) << 5) | (((w >> 8) & 15u) << 1), 13);
+            q.imm_j = sext(((w >> 31) << 20) | (((w >> 12) & 255u) << 12) | (((w >> 20) & 1u) << 11) | (((w >> 21) & 1023u) << 1), 21);
+        }
         if (exe.data.size() > mem_.size()) throw Error("initial data larger than memory");
         if (!exe.data.empty()) memcpy(mem_.data(), exe.data.data(), exe.data.size());
         memset(x_, 0, sizeof x_);
@@ -178,6 +211,13 @@ public:
 private:
     const Exe& exe_;
     const StdIn& in_;
+    struct Pre {   // a program word, decoded
+        uint32_t w;
+        int32_t imm_i, imm_s, imm_b, imm_j;
+        uint8_t op, rd, f3, rs1, rs2, f7;
+        bool uses_rs1, uses_rs2;
+    };
+    std::vector<Pre> pre_;
     std::vector<uint8_t> mem_, pv_;
     uint32_t x_[32], pc_ = 0, exit_code_ = 0, last_val_ = 0;
     bool log_memory_ = true;
@@ -385,53 +425,48 @@ private:
     void step(ExecRecords* rec) {
         const uint64_t idx64 = ((uint64_t)pc_ - exe_.pc_base) / 4;
         if (pc_ < exe_.pc_base || (pc_ & 3u) || idx64 >= exe_.program.size()) throw Error("pc outside the program: " + std::to_string(pc_));
-        const uint32_t w = exe_.program[idx64];
-        const uint32_t op = w & 0x7f, rd = (w >> 7) & 31, f3 = (w >> 12) & 7, rs1 = (w >> 15) & 31, rs2 = (w >> 20) & 31, f7 = w >> 25;
+        // the word's fields and immediates, decoded once per program word (pre_: the interpreter is a third of the segmenting executor's time)
+        const Pre& q = pre_[idx64];
+        const uint32_t w = q.w;
+        const uint32_t op = q.op, rd = q.rd, f3 = q.f3, rs1 = q.rs1, rs2 = q.rs2, f7 = q.f7;
         // registers the instruction reads, in the order rs1, rs2 (logged for the memory argument)
-        const bool uses_rs1 = op == 0x67 || op == 0x63 || op == 0x03 || op == 0x23 || op == 0x13 || op == 0x33;
-        const bool uses_rs2 = op == 0x63 || op == 0x23 || op == 0x33;
-        const uint32_t a = uses_rs1 ? reg_read(rec, rs1) : 0, b = uses_rs2 ? reg_read(rec, rs2) : 0;
-        // immediates: assembled as unsigned fields, sign-extended once (shifting a negative value left is undefined before C++20)
-        auto sext = [](uint32_t v, unsigned bits) { const uint32_t m = 1u << (bits - 1); return (int32_t)((v ^ m) - m); };
-        const int32_t imm_i = sext(w >> 20, 12);
-        const int32_t imm_s = sext(((w >> 25) << 5) | ((w >> 7) & 31u), 12);
-        const int32_t imm_b = sext(((w >> 31) << 12) | (((w >> 7) & 1u) << 11) | (((w >> 25) & 63u) << 5) | (((w >> 8) & 15u) << 1), 13);
-        const int32_t imm_j = sext(((w >> 31) << 20) | (((w >> 12) & 255u) << 12) | (((w >> 20) & 1u) << 11) | (((w >> 21) & 1023u) << 1), 21);
+        const uint32_t a = q.uses_rs1 ? reg_read(rec, rs1) : 0, b = q.uses_rs2 ? reg_read(rec, rs2) : 0;
+        const int32_t imm_i = q.imm_i, imm_s = q.imm_s, imm_b = q.imm_b, imm_j = q.imm_j;
         uint32_t next = pc_ + 4, val = 0;
         bool wr = false;
-        if (rec) rec->pc_index.push_back((uint32_t)idx64);
+        if (rec) put(rec, rec->pc_index, (uint32_t)idx64);
         auto alu = [&](uint32_t o, uint32_t x, uint32_t y) {
-            if (rec) rec->alu_op.push_back(o), rec->alu_b.push_back(x), rec->alu_c.push_back(y);
+            if (rec) put(rec, rec->alu_op, o), put(rec, rec->alu_b, x), put(rec, rec->alu_c, y);
             return o == 0 ? x + y : o == 1 ? x - y : o == 2 ? (x ^ y) : o == 3 ? (x | y) : (x & y);
         };
         auto lt = [&](uint32_t o, uint32_t x, uint32_t y) {
-            if (rec) rec->lt_op.push_back(o), rec->lt_b.push_back(x), rec->lt_c.push_back(y);
+            if (rec) put(rec, rec->lt_op, o), put(rec, rec->lt_b, x), put(rec, rec->lt_c, y);
             return (uint32_t)(o == 0 ? (int32_t)x < (int32_t)y : x < y);
         };
         auto shift = [&](uint32_t kind, uint32_t x, uint32_t s) {
-            if (rec) rec->n_shift++, rec->shift_op.push_back(kind), rec->shift_b.push_back(x), rec->shift_c.push_back(s);
+            if (rec) rec->n_shift++, put(rec, rec->shift_op, kind), put(rec, rec->shift_b, x), put(rec, rec->shift_c, s);
             s &= 31;
             return kind == 0 ? x << s : kind == 1 ? x >> s : (uint32_t)((int32_t)x >> s);
         };
         switch (op) {
             case 0x37:  // LUI
                 val = w & 0xfffff000u, wr = true;
-                if (rec) rec->n_lui_auipc++, rec->jal_op.push_back(1), rec->jal_pc.push_back(pc_), rec->jal_imm.push_back(w >> 12);
+                if (rec) rec->n_lui_auipc++, put(rec, rec->jal_op, 1), put(rec, rec->jal_pc, pc_), put(rec, rec->jal_imm, w >> 12);
                 break;
             case 0x17:  // AUIPC
                 val = pc_ + (w & 0xfffff000u), wr = true;
-                if (rec) rec->n_lui_auipc++, rec->auipc_pc.push_back(pc_), rec->auipc_imm.push_back(w >> 12);
+                if (rec) rec->n_lui_auipc++, put(rec, rec->auipc_pc, pc_), put(rec, rec->auipc_imm, w >> 12);
                 break;
             case 0x6f:  // JAL
                 val = pc_ + 4, wr = true, next = pc_ + (uint32_t)imm_j;
                 if (rec) {
-                    rec->n_jump++, rec->jal_op.push_back(0), rec->jal_pc.push_back(pc_);
-                    rec->jal_imm.push_back(imm_j < 0 ? 2013265921u - (uint32_t)(-imm_j) : (uint32_t)imm_j);
+                    rec->n_jump++, put(rec, rec->jal_op, 0), put(rec, rec->jal_pc, pc_);
+                    put(rec, rec->jal_imm, imm_j < 0 ? 2013265921u - (uint32_t)(-imm_j) : (uint32_t)imm_j);
                 }
                 break;
             case 0x67:  // JALR
                 val = pc_ + 4, wr = true, next = (a + (uint32_t)imm_i) & ~1u;
-                if (rec) rec->n_jump++, rec->jalr_pc.push_back(pc_), rec->jalr_rs1.push_back(a), rec->jalr_imm.push_back(w >> 20);
+                if (rec) rec->n_jump++, put(rec, rec->jalr_pc, pc_), put(rec, rec->jalr_rs1, a), put(rec, rec->jalr_imm, w >> 20);
                 break;
             case 0x63: {
                 bool t;
@@ -449,10 +484,10 @@ private:
                 if (rec) {
                     const uint32_t off = imm_b < 0 ? 2013265921u - (uint32_t)(-imm_b) : (uint32_t)imm_b;
                     if (f3 < 2) {
-                        rec->beq_op.push_back(f3), rec->beq_a.push_back(a), rec->beq_b.push_back(b), rec->beq_imm.push_back(off);
+                        put(rec, rec->beq_op, f3), put(rec, rec->beq_a, a), put(rec, rec->beq_b, b), put(rec, rec->beq_imm, off);
                     } else {   // funct3 4 blt, 5 bge, 6 bltu, 7 bgeu -> the chip's opcode order blt, bltu, bge, bgeu
-                        rec->blt_op.push_back(((f3 & 1u) << 1) | ((f3 >> 1) & 1u));
-                        rec->blt_a.push_back(a), rec->blt_b.push_back(b), rec->blt_imm.push_back(off);
+                        put(rec, rec->blt_op, ((f3 & 1u) << 1) | ((f3 >> 1) & 1u));
+                        put(rec, rec->blt_a, a), put(rec, rec->blt_b, b), put(rec, rec->blt_imm, off);
                     }
                 }
                 break;
@@ -471,7 +506,7 @@ private:
                 if (rec) {
                     const uint32_t off = (addr - exe_.data_base) & 3u;
                     const uint32_t cs = f3 == 2 ? 0 : f3 == 5 ? 1 + off / 2 : f3 == 4 ? 3 + off : f3 == 1 ? 14 + off / 2 : 16 + off;
-                    rec->n_load_store++, rec->ls_case.push_back(cs), rec->ls_read.push_back(word_around(addr)), rec->ls_prev.push_back(x_[rd]);
+                    rec->n_load_store++, put(rec, rec->ls_case, cs), put(rec, rec->ls_read, word_around(addr)), put(rec, rec->ls_prev, x_[rd]);
                 }
                 break;
             }
@@ -481,8 +516,8 @@ private:
                 if (rec) {
                     at(addr, 1u << f3);   // range check before the word is read
                     const uint32_t off = (addr - exe_.data_base) & 3u;
-                    rec->n_load_store++, rec->ls_case.push_back(f3 == 2 ? 7 : f3 == 1 ? 8 + off / 2 : 10 + off);
-                    rec->ls_read.push_back(b), rec->ls_prev.push_back(word_around(addr));
+                    rec->n_load_store++, put(rec, rec->ls_case, f3 == 2 ? 7 : f3 == 1 ? 8 + off / 2 : 10 + off);
+                    put(rec, rec->ls_read, b), put(rec, rec->ls_prev, word_around(addr));
                 }
                 store(rec, addr, b, 1u << f3);
                 break;
@@ -508,7 +543,7 @@ private:
                     const int64_t sa = (int32_t)a, sb = (int32_t)b;
                     const uint64_t ua = a, ub = b;
                     switch (f3) {
-                        case 0: val = a * b; if (rec) rec->mul_b.push_back(a), rec->mul_c.push_back(b); break;
+                        case 0: val = a * b; if (rec) put(rec, rec->mul_b, a), put(rec, rec->mul_c, b); break;
                         case 1: val = (uint32_t)((uint64_t)(sa * sb) >> 32); break;
                         case 2: val = (uint32_t)((uint64_t)(sa * (int64_t)ub) >> 32); break;
                         case 3: val = (uint32_t)((ua * ub) >> 32); break;
@@ -517,8 +552,8 @@ private:
                         case 6: val = b == 0 ? a : (a == 0x80000000u && b == 0xffffffffu) ? 0 : (uint32_t)((int32_t)a % (int32_t)b); break;
                         default: val = b == 0 ? a : a % b; break;
                     }
-                    if (rec && f3 >= 4) rec->div_op.push_back(f3 - 4), rec->div_b.push_back(a), rec->div_c.push_back(b);
-                    if (rec && f3 >= 1 && f3 <= 3) rec->n_mulh++, rec->mulh_op.push_back(f3 - 1), rec->mulh_b.push_back(a), rec->mulh_c.push_back(b);
+                    if (rec && f3 >= 4) put(rec, rec->div_op, f3 - 4), put(rec, rec->div_b, a), put(rec, rec->div_c, b);
+                    if (rec && f3 >= 1 && f3 <= 3) rec->n_mulh++, put(rec, rec->mulh_op, f3 - 1), put(rec, rec->mulh_b, a), put(rec, rec->mulh_c, b);
                     if (f3 >= 4 && rec) rec->n_divrem++;
                 } else if (f7 == 0 || f7 == 0x20) {
                     switch (f3) {

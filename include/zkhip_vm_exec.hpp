@@ -273,7 +273,15 @@ public:
         r.clear(/*keep_frame=*/true);
         reset_blocks();
         const size_t frame_rows = caps_.rows(vmc::A_FRAME);
-        if (r.core.pc_index.capacity() < frame_rows) r.core.pc_index.reserve(frame_rows);
+        // room for a whole frame in every array the interpreter appends to (an instruction leaves at most one entry per array): its appends
+        // then skip the capacity check (ExecRecords::reserved, U32Vec::put_unchecked).  Address space only: pages are touched as rows are written.
+        for (zkhip_vm::U32Vec* v : {&r.core.pc_index, &r.core.alu_op, &r.core.alu_b, &r.core.alu_c, &r.core.lt_op, &r.core.lt_b, &r.core.lt_c, &r.core.mul_b, &r.core.mul_c,
+                                    &r.core.mulh_op, &r.core.mulh_b, &r.core.mulh_c, &r.core.div_op, &r.core.div_b, &r.core.div_c, &r.core.shift_op, &r.core.shift_b,
+                                    &r.core.shift_c, &r.core.beq_op, &r.core.beq_a, &r.core.beq_b, &r.core.beq_imm, &r.core.blt_op, &r.core.blt_a, &r.core.blt_b,
+                                    &r.core.blt_imm, &r.core.jal_op, &r.core.jal_pc, &r.core.jal_imm, &r.core.auipc_pc, &r.core.auipc_imm, &r.core.jalr_pc,
+                                    &r.core.jalr_rs1, &r.core.jalr_imm, &r.core.ls_case, &r.core.ls_read, &r.core.ls_prev})
+            if (v->capacity() < frame_rows + 8) v->reserve(frame_rows + 8);
+        r.core.reserved = 1;
         for (auto* v : {&r.f_x, &r.f_y, &r.f_z, &r.f_rdprev, &r.f_pcinc, &r.f_pts1, &r.f_pts2, &r.f_pts3}) v->resize(frame_rows);
         uint32_t *const fx = r.f_x.data(), *const fy = r.f_y.data(), *const fz = r.f_z.data(), *const frd = r.f_rdprev.data(), *const fpc = r.f_pcinc.data();
         uint32_t *const fp1 = r.f_pts1.data(), *const fp2 = r.f_pts2.data(), *const fp3 = r.f_pts3.data();
