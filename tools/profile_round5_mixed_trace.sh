@@ -16,8 +16,8 @@ open("/tmp/gm/stdin.bin", "wb").write((2048).to_bytes(4, "little"))
 open("/tmp/gm/openvm.toml", "w").write(chunk_circuit_toml((1, 0, 100, 16, 16)))
 PY
 export ZKHIP_LANES=1 ZKHIP_AGG_SLOTS=1
-./zkvm-prover_amd/prove_cli prove-elf /tmp/gm/mixed.elf /tmp/gm/stdin.bin /tmp/om /tmp/gm/openvm.toml 19 > $O/warm.json 2> $O/warm_err.txt
-rocprofv3 --kernel-trace --stats -d $O/p -o p --output-format csv -- ./zkvm-prover_amd/prove_cli prove-elf /tmp/gm/mixed.elf /tmp/gm/stdin.bin /tmp/om /tmp/gm/openvm.toml 19 > $O/profiled.json 2> $O/profiled_err.txt
+./zkvm-prover_amd/prove_cli prove-elf /tmp/gm/mixed.elf /tmp/gm/stdin.bin /tmp/om /tmp/gm/openvm.toml ${FRAME:-20} > $O/warm.json 2> $O/warm_err.txt
+rocprofv3 --kernel-trace --stats -d $O/p -o p --output-format csv -- ./zkvm-prover_amd/prove_cli prove-elf /tmp/gm/mixed.elf /tmp/gm/stdin.bin /tmp/om /tmp/gm/openvm.toml ${FRAME:-20} > $O/profiled.json 2> $O/profiled_err.txt
 cp $(find $O/p -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 python3 - <<'PY'
 import csv, glob, os
