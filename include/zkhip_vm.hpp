@@ -89,7 +89,7 @@ struct ExecRecords {
     // destination register (loads) / the aligned memory word (stores) held before
     U32Vec ls_case, ls_read, ls_prev;
     uint64_t n_shift = 0, n_branch = 0, n_jump = 0, n_load_store = 0, n_mulh = 0, n_divrem = 0, n_lui_auipc = 0, n_ecall = 0;
-    uint64_t reserved = 0;   // != 0: every U32Vec above has room for the rows of a whole segment (set by the segmenting executor; survives clear())
+    uint64_t reserved = 0;   // != 0: every U32Vec above has room for the rows of a whole segment (set by the segmenting executor after clear())
     // Memory log for the offline memory-checking argument (OpenVM's memory bus): state is kept in 16-bit CELLS -- address space
     // 1 = registers (cell 2 i + half of x_i), 2 = read-write memory (cell = halfword index from data_base) -- so that a cell's
     // value is a field element.  One entry per cell access, in execution order, timestamps 1, 2, 3, ...:
@@ -108,6 +108,7 @@ struct ExecRecords {
               &acc_is_read, &bnd_as, &bnd_ptr, &bnd_initial, &bnd_final, &bnd_final_ts})
             v->clear();
         n_shift = n_branch = n_jump = n_load_store = n_mulh = n_divrem = n_lui_auipc = n_ecall = 0;
+        reserved = 0;   // (whoever reserves says so again: the segmenting executor, per segment)
     }
 };
 static_assert(sizeof(ExecRecords) == 49 * sizeof(std::vector<uint32_t>) + 9 * sizeof(uint64_t), "ExecRecords::clear() must list every array");
