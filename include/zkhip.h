@@ -964,6 +964,11 @@ typedef struct {
      * workgroups with 70 KiB of LDS (two per CU), 9 / 8 = tiles of 2^13 / 2^12 words (four / eight per CU) -- the short transforms of a proof
      * with many small chips get scheduled beside the other streams' kernels instead of waiting for half a CU [ZKHIP_NTT_LOG_LANES] */
     uint32_t ntt_log_lanes;
+    /* the compiled constraint kernels of one proof (one per chip, independent of each other) go round-robin over so many further streams of the
+     * context, forked from and joined to the proof's stream by events -- the short chips' kernels (a few workgroups, a long program per row) run
+     * beside the large ones instead of one after the other; 0 (the default) = all on the proof's stream; <= 4.  Off while the per-kernel timing of
+     * zkhip_profile_enable is on (it times the proof's stream) [ZKHIP_QUOT_STREAMS] */
+    uint32_t quot_streams;
 } zkhip_config;
 /* While `on`, the trace generators treat the shared lookup-count tables handed to them (the 8-bit bitwise table, the range-tuple table, the
  * range table) as canonical counts and leave them canonical -- none converts a table from Montgomery form and back around its increments.
@@ -982,7 +987,7 @@ void zkhip_config_default(zkhip_config *out);
 unsigned zkhip_host_cpus(void);
 /* a context's configuration (set at zkhip_ctx_create from zkhip_config_default); the witness fields are process-wide:
  * zkhip_set_process_config stores them (and the rest as the default of contexts created later).  zkhip_ctx_set_config applies every
- * field or refuses the call (ZKHIP_ERR_INVALID: jit 0..2, coop_* <= 27, rows_coop_max_log <= 27, ntt_log_lanes 8..10, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8,
+ * field or refuses the call (ZKHIP_ERR_INVALID: jit 0..2, coop_* <= 27, rows_coop_max_log <= 27, ntt_log_lanes 8..10, quot_streams <= 4, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8,
  * commit_parts <= 8, side_cus < the device's CUs, hash_block a multiple of 64 in 64..768); a changed side_cus re-partitions as zkhip_set_cu_partition does. */
 int zkhip_ctx_get_config(zkhip_ctx *ctx, zkhip_config *out);
 int zkhip_ctx_set_config(zkhip_ctx *ctx, const zkhip_config *cfg);

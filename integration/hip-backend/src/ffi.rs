@@ -200,6 +200,7 @@ pub struct zkhip_config {
     pub rows_in_bulk: c_int,
     pub rows_coop_max_log: u32,
     pub ntt_log_lanes: u32,
+    pub quot_streams: u32,
 }
 
 #[repr(C)]

@@ -68,7 +68,7 @@ class Config(C.Structure):
                 ("jit_cache_dir", C.c_char * 256), ("quot_slices", C.c_int), ("grind_sweep_shift", C.c_uint32), ("coop_max_log", C.c_uint32),
                 ("coop_inj_max_log", C.c_uint32), ("top_max_log", C.c_uint32), ("commit_parts", C.c_uint32), ("side_cus", C.c_uint32), ("witness_threads", C.c_uint32),
                 ("pin_witness", C.c_int), ("parallel_queries", C.c_int), ("self_check", C.c_int), ("tree_store_early", C.c_int), ("hash_block", C.c_uint32), ("coop_fused", C.c_int),
-                ("rows_in_bulk", C.c_int), ("rows_coop_max_log", C.c_uint32), ("ntt_log_lanes", C.c_uint32)]
+                ("rows_in_bulk", C.c_int), ("rows_coop_max_log", C.c_uint32), ("ntt_log_lanes", C.c_uint32), ("quot_streams", C.c_uint32)]
 
     @classmethod
     def default(cls):

@@ -216,6 +216,7 @@ void zkhip_config_default(zkhip_config* c) {
     c->rows_in_bulk = getenv("ZKHIP_NO_ROWS_IN_BULK") ? 0 : 1;
     c->rows_coop_max_log = num("ZKHIP_ROWS_COOP_MAX_LOG", 15u);
     c->ntt_log_lanes = num("ZKHIP_NTT_LOG_LANES", 10u);
+    c->quot_streams = num("ZKHIP_QUOT_STREAMS", 0u);   // (measured: + 7 % for ONE lane of the mixed guest, nothing with three lanes: docs/round5_b.md 6)
     // compiled constraint kernels across processes: the variable if set (empty = none), else `jit_cache` beside this library if it exists
     std::string dir;
     if (const char* e = getenv("ZKHIP_JIT_CACHE_DIR")) {
@@ -270,9 +271,9 @@ int zkhip_ctx_get_config(zkhip_ctx* ctx, zkhip_config* out) {
 int zkhip_ctx_set_config(zkhip_ctx* ctx, const zkhip_config* cfg) {
     if (!ctx || !cfg) return ZKHIP_ERR_INVALID;
     // every field is applied or refused: nothing is silently clamped at its place of use
-    if (cfg->jit < 0 || cfg->jit > 2 || cfg->coop_max_log > 27 || cfg->coop_inj_max_log > 27 || cfg->rows_coop_max_log > 27 || cfg->ntt_log_lanes < 8 || cfg->ntt_log_lanes > 10 || cfg->jit_min_log_work > 62 || cfg->top_max_log > 8 || cfg->grind_sweep_shift > 8 ||
+    if (cfg->jit < 0 || cfg->jit > 2 || cfg->coop_max_log > 27 || cfg->coop_inj_max_log > 27 || cfg->rows_coop_max_log > 27 || cfg->ntt_log_lanes < 8 || cfg->ntt_log_lanes > 10 || cfg->quot_streams > 4 || cfg->jit_min_log_work > 62 || cfg->top_max_log > 8 || cfg->grind_sweep_shift > 8 ||
         cfg->commit_parts > 8 || cfg->side_cus >= (unsigned)ctx->cu_count || cfg->hash_block < 64 || cfg->hash_block > 768 || cfg->hash_block % 64)
-        return set_error(ctx, ZKHIP_ERR_INVALID, "zkhip_ctx_set_config: field out of range (jit 0..2, coop_* <= 27, rows_coop_max_log <= 27, ntt_log_lanes 8..10, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8, commit_parts <= 8, side_cus < CUs, hash_block a multiple of 64 in 64..768)");
+        return set_error(ctx, ZKHIP_ERR_INVALID, "zkhip_ctx_set_config: field out of range (jit 0..2, coop_* <= 27, rows_coop_max_log <= 27, ntt_log_lanes 8..10, quot_streams <= 4, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8, commit_parts <= 8, side_cus < CUs, hash_block a multiple of 64 in 64..768)");
     ZK_TRY(zkhip_set_cu_partition(ctx, cfg->side_cus));   // (drops the masked side streams if the partition changes)
     ctx->cfg = *cfg;
     ctx->cfg.jit_cache_dir[sizeof ctx->cfg.jit_cache_dir - 1] = 0;
@@ -292,6 +293,11 @@ void zkhip_ctx_destroy(zkhip_ctx* ctx) {
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->hash_stream) (void)hipStreamDestroy(ctx->hash_stream);
+    for (auto& q : ctx->quot_streams)
+        if (q) (void)hipStreamDestroy(q);
+    if (ctx->quot_fork) (void)hipEventDestroy(ctx->quot_fork);
+    for (auto& e : ctx->quot_join)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->d_deferred_bad) (void)hipFree(ctx->d_deferred_bad);
     if (ctx->h_sponge) (void)hipHostFree(ctx->h_sponge);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

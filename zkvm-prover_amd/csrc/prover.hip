@@ -2049,6 +2049,24 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         KernelScope ks(ctx, "ext_powers");  // alpha powers of every chip: one launch, one lane per chip
         hipLaunchKernelGGL(k_ext_powers_multi, dim3((unsigned)n_airs), dim3(64), 0, st, d_alpha, pk->d_pow_desc);
     }
+    // the compiled kernels (one per chip, each writes its own quotient columns) round-robin over the context's further streams: a proof of fifty
+    // chips has a dozen of them that occupy a few workgroups for half a millisecond each (zkhip_config.quot_streams); forked HERE, so that they also run
+    // beside the interpreter's launch
+    // (only the SHORT ones: at most two workgroups per CU.  A kernel that fills the chip gains nothing beside another one -- the Fibonacci guest's
+    // six large chips lost 3 - 10 % when they were spread too)
+    auto jit_blocks = [&](const AirPlan& A) { return A.jit_rows_per_block ? (unsigned)((A.MQ + 255) / 256) : (unsigned)std::min<size_t>(A.MQ / 64, 4 * 256); };
+    unsigned n_jit = 0, fan = 0;
+    for (size_t a = 0; a < n_airs; a++) n_jit += pk->airs[a].jit_fn && jit_blocks(pk->airs[a]) <= 2u * (unsigned)ctx->cu_count ? 1u : 0u;
+    if (n_jit >= 3 && !ctx->profiling && ctx->cfg.quot_streams) {
+        fan = std::min(4u, ctx->cfg.quot_streams);
+        if (!ctx->quot_fork) ZK_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->quot_fork, hipEventDisableTiming));
+        for (unsigned q = 0; q < fan; q++) {
+            if (!ctx->quot_streams[q]) ZK_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->quot_streams[q], hipStreamNonBlocking));
+            if (!ctx->quot_join[q]) ZK_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->quot_join[q], hipEventDisableTiming));
+        }
+        ZK_HIP_CHECK(ctx, hipEventRecord(ctx->quot_fork, st));
+        for (unsigned q = 0; q < fan; q++) ZK_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->quot_streams[q], ctx->quot_fork, 0));
+    }
     // chips without a compiled kernel: the interpreter runs over all of them in one launch
     if (pk->quot_n) {
         KernelScope ks(ctx, "quotient_eval");
@@ -2064,9 +2082,13 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         }
         ZK_HIP_CHECK(ctx, hipGetLastError());
     }
+    unsigned i_jit = 0;
     for (size_t a = 0; a < n_airs; a++) {
         AirPlan& A = pk->airs[a];
         if (!A.jit_fn) continue;
+        // (the large kernels stay on the proof's own stream, one after the other)
+        const bool small_one = fan && jit_blocks(A) <= 2u * (unsigned)ctx->cu_count;
+        hipStream_t qs = small_one ? ctx->quot_streams[i_jit++ % fan] : st;
         QuotArgs qa = pk->quot_args_host[a];
         const uint32_t* tw_fwd = ctx->d_tw_fwd;
         unsigned tw_shift = ctx->tw_log - A.h;
@@ -2077,8 +2099,12 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
                           (void*)&qa.gen, (void*)&qa.w_n_inv, (void*)&tw_shift, (void*)&qa.perm,
                           (void*)&qa.lchal, (void*)&qa.expo, (void*)&qa.prep, (void*)&h_bits, (void*)&nq_rows};
         // (tiled form: one workgroup per CU holds its 150 KB tile; a few rounds of workgroups per CU even the tail out)
-        const unsigned blocks = A.jit_rows_per_block ? (unsigned)((A.MQ + 255) / 256) : (unsigned)std::min<size_t>(A.MQ / 64, 4 * 256);
-        ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, blocks, 1, 1, A.jit_rows_per_block ? 256 : 64 * QUOT_TILE_WAVES, 1, 1, 0, st, params, nullptr));
+        const unsigned blocks = jit_blocks(A);
+        ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, blocks, 1, 1, A.jit_rows_per_block ? 256 : 64 * QUOT_TILE_WAVES, 1, 1, 0, qs, params, nullptr));
+    }
+    for (unsigned q = 0; q < fan; q++) {
+        ZK_HIP_CHECK(ctx, hipEventRecord(ctx->quot_join[q], ctx->quot_streams[q]));
+        ZK_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->quot_join[q], 0));
     }
     // chunk j = rows [jN,(j+1)N) of q, bit-reversed within the chunk: bring to natural order (all chips, all chunks: one
     // launch per kernel form), then extend from s_j*H to g*K (shift g/s_j) -- p3's quotient-chunk commitment

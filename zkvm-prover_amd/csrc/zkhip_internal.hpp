@@ -57,6 +57,10 @@ struct zkhip_ctx {
     // remaining CUs, so that neither queue waits behind the other's workgroups.  0 = unmasked streams.
     unsigned side_cus = 0;
     hipStream_t hash_stream = nullptr;
+    // the constraint kernels of one proof are independent of each other: with zkhip_config.quot_streams = k > 0 the compiled ones go round-robin
+    // over k further streams of the context (forked from and joined to the proof's stream with events; created at first use)
+    hipStream_t quot_streams[4] = {};
+    hipEvent_t quot_fork = nullptr, quot_join[4] = {};
     // trace generators check their records on the device and normally report at once (one stream synchronisation per call); with
     // deferred checks (zkhip_tracegen_defer_checks) the bad-record counts are summed on the device and read once (zkhip_tracegen_check)
     bool defer_tracegen_checks = false;
