@@ -186,6 +186,8 @@ def _flow_runs(cmd, env):
             raise RuntimeError(r.stderr[-300:])
         runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     measured = sorted(runs[1:], key=rate)
+    # segment proofs made twice (FlowOptions::retry_segments) are counted over ALL four runs: a clean line says 0
+    measured[1]["segments_retried_in_all_four_runs"] = sum(g.get("segments_retried", 0) for g in runs)
     return runs[0], measured[1], [round(rate(g)) for g in runs[1:]]
 
 
@@ -210,6 +212,7 @@ def guest_flow_mixed():
                 "execution_ms": g["execution_ms"], "segments_ms": g["segment_tracegen_and_proving_ms"], "tree_tail_ms": g["aggregation_setup_wait_ms"] + g["aggregation_ms"],
                 "process_wall_s": g["wall_s"], "process_wall_s_first_run_on_this_box": first["wall_s"], "instr_per_s_of_the_three_measured_runs": rates,
                 "leaf_circuits_at_setup": g.get("leaf_circuits_at_setup"), "leaf_circuits_on_demand": g.get("leaf_circuits_on_demand"), "verified": g["verified"], "guest": g.get("guest"),
+                "segments_retried": g.get("segments_retried"), "segments_retried_in_all_four_runs": g.get("segments_retried_in_all_four_runs"),
                 "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 8192 20 mixed"}
     except Exception as e:   # a reported extra, never a gate
         return {"value": None, "note": "failed: %r" % (e,)}
@@ -245,6 +248,7 @@ def guest_flow(chunk_config=False, memory_bound=False):
                 "instr_per_s_segments_only": g.get("instr_per_s_segments_only"),
                 "instr_per_s_segments_plus_executor_busy_time": g.get("instr_per_s_segments_plus_executor_busy_time"),
                 "prove_speed_mhz": g.get("prove_speed_mhz"), "log_frame": g.get("log_frame"), "guest": g.get("guest"),
+                "segments_retried": g.get("segments_retried"), "segments_retried_in_all_four_runs": g.get("segments_retried_in_all_four_runs"),
                 "command": "ZKHIP_LANES=3 python " + " ".join(["tools/guest_bench2.py"] + cmd[2:])}
     except Exception as e:   # a reported extra, never a gate
         return {"value": None, "note": "failed: %r" % (e,)}

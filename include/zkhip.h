@@ -944,8 +944,9 @@ typedef struct {
      * and fetches the proof twice; what differs is reported on stderr and the proof fails with ZKHIP_ERR_HIP [ZKHIP_SELF_CHECK=1] */
     int self_check;
     /* TEST ONLY: the round-4 bodies of the two fused tree kernels ("store a layer's word, then compute on"), the form under which the guest
-     * flow stored a wrong tree node in ~3 % of runs -- kept for the A/B of docs/stale_node.md and the test that must go red on it
-     * [ZKHIP_TREE_STORE_EARLY=1] */
+     * flow stored a wrong tree node in ~3 % of runs -- kept for the A/B of docs/stale_node.md and the test that must go red on it.  The
+     * kernels exist only in libzkhip_test.so (csrc/Makefile, -DZKHIP_TEST_KERNELS: zkhip_has_test_kernels() == 1); libzkhip.so refuses a
+     * non-zero value in zkhip_ctx_set_config and ignores the variable [ZKHIP_TREE_STORE_EARLY=1, test library only] */
     int tree_store_early;
     /* lanes per workgroup of the row-sponge kernel of trees of >= 2^20 rows (a multiple of 64, 64..768).  256: eight workgroups fill every wave
      * slot of a CU.  768: two workgroups of 12 waves hold 6 of a SIMD's 8 slots and a third does not fit -- two slots, 176 VGPRs and the LDS
@@ -990,6 +991,8 @@ unsigned zkhip_host_cpus(void);
  * field or refuses the call (ZKHIP_ERR_INVALID: jit 0..2, coop_* <= 27, rows_coop_max_log <= 27, ntt_log_lanes 8..10, quot_streams <= 4, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8,
  * commit_parts <= 8, side_cus < the device's CUs, hash_block a multiple of 64 in 64..768); a changed side_cus re-partitions as zkhip_set_cu_partition does. */
 int zkhip_ctx_get_config(zkhip_ctx *ctx, zkhip_config *out);
+/* 1 in libzkhip_test.so (the A/B bodies behind zkhip_config.tree_store_early are compiled in), 0 in the library that ships */
+int zkhip_has_test_kernels(void);
 int zkhip_ctx_set_config(zkhip_ctx *ctx, const zkhip_config *cfg);
 int zkhip_set_process_config(const zkhip_config *cfg);
 

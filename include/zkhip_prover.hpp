@@ -245,6 +245,10 @@ struct FlowOptions {
     unsigned wide_in_flight = 0;      // > 0: at most so many segment proofs of WRAPPED shapes (the chunk circuit's 51-chip set) in flight at a time,
                                       // whatever the lanes -- the segment waits at the head of the queue.  Measured on the mixed guest at frames of
                                       // 2^20 (three lanes): 2: 4.9 - 6.2 MHz against 6.0 - 6.5 without (docs/round5_b.md 9); off   [ZKHIP_WIDE_IN_FLIGHT=n]
+    bool retry_segments = true;       // a segment proof that fails (a refused trace check, the device self-check, a device error) is made once
+                                      // more from the same records before the task is given up; every retry is COUNTED (GuestStark::
+                                      // segments_retried, the flow's JSON line).  Off: the first failure ends the task -- what the stress
+                                      // loops run with, so that a retried wrong node cannot pass for a clean run          [ZKHIP_NO_RETRY=1 -> false]
     std::vector<int> devices;         // GPUs of the node the flow spreads over (empty = the prover's device)             [ZKHIP_DEVICES=0,1,..]
     static FlowOptions from_env() {
         FlowOptions o;
@@ -256,6 +260,7 @@ struct FlowOptions {
         o.per_depth_keys = getenv("ZKHIP_AGG_PER_DEPTH_KEYS") != nullptr;
         o.balanced_tree = getenv("ZKHIP_TREE_BALANCED") != nullptr;
         o.trace_tree = getenv("ZKHIP_TREE_TRACE") != nullptr;
+        o.retry_segments = getenv("ZKHIP_NO_RETRY") == nullptr;
         if (const char* e = getenv("ZKHIP_WIDE_IN_FLIGHT")) o.wide_in_flight = (unsigned)std::max(0, atoi(e));
         o.agg_cli_greedy = getenv("ZKHIP_AGG_GREEDY") != nullptr;
         if (const char* e = getenv("ZKHIP_DEFERRAL_CHILDREN")) o.deferral_children = (unsigned)std::min(8, std::max(1, atoi(e)));

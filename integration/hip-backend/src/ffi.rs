@@ -496,6 +496,7 @@ extern "C" {
     pub fn zkhip_jit_prewarm(airs: *const zkhip_air, n_airs: usize, log_blowup: c_uint, cache_dir: *const c_char, n_ok: *mut usize) -> c_int;
     pub fn zkhip_config_default(out: *mut zkhip_config);
     pub fn zkhip_ctx_get_config(ctx: *mut zkhip_ctx, out: *mut zkhip_config) -> c_int;
+    pub fn zkhip_has_test_kernels() -> c_int;
     pub fn zkhip_ctx_set_config(ctx: *mut zkhip_ctx, cfg: *const zkhip_config) -> c_int;
     pub fn zkhip_set_process_config(cfg: *const zkhip_config) -> c_int;
     pub fn zkhip_recursion_build_join(params_a: *const zkhip_params, airs_a: *const zkhip_air, n_airs_a: usize, params_b: *const zkhip_params,

@@ -21,13 +21,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def stress_exe(tmp_path_factory):
-    exe = tmp_path_factory.mktemp("merkle_stress") / "merkle_stress"
+def _build_stress(tmp_path_factory, lib):
+    exe = tmp_path_factory.mktemp("merkle_stress_" + lib) / "merkle_stress"
     lib_dir = os.path.join(ROOT, "zkvm-prover_amd")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "merkle_stress.cpp"), "-o", str(exe),
-                           "-L", lib_dir, "-lzkhip", "-Wl,-rpath," + lib_dir, "-lpthread"])
+                           "-L", lib_dir, "-l" + lib, "-Wl,-rpath," + lib_dir, "-lpthread"])
     return str(exe)
+
+
+@pytest.fixture(scope="module")
+def stress_exe(tmp_path_factory):
+    return _build_stress(tmp_path_factory, "zkhip")
+
+
+@pytest.fixture(scope="module")
+def stress_exe_test_kernels(tmp_path_factory):
+    """The same program over libzkhip_test.so -- the only library that holds the round-4 bodies (csrc/Makefile, -DZKHIP_TEST_KERNELS)."""
+    return _build_stress(tmp_path_factory, "zkhip_test")
 
 
 def _run(exe, args, expect_clean=True, **env):
@@ -55,23 +65,44 @@ def test_layers_stay_right_under_concurrent_rebuilds(stress_exe):
     _run(stress_exe, [6, 1500, 14, 40, 2, 4])
 
 
-def test_the_round4_body_under_the_same_stress_is_reported(stress_exe):
-    rep, _ = _run(stress_exe, [3, 4000, 12, 8, 2, 1], expect_clean=False, ZKHIP_TREE_STORE_EARLY="1")
+def test_the_round4_body_under_the_same_stress_is_reported(stress_exe_test_kernels):
+    rep, _ = _run(stress_exe_test_kernels, [3, 4000, 12, 8, 2, 1], expect_clean=False, ZKHIP_TREE_STORE_EARLY="1")
     print("round-4 body of the fused tree kernel under LDS-heavy neighbours:", rep)
     assert rep["early_form"] is True and rep["checks"] >= 4000
 
 
-def test_every_form_of_the_tree_top_gives_one_root(stress_exe):
+def test_every_form_of_the_tree_top_gives_one_root(stress_exe, stress_exe_test_kernels):
     roots = {_run(stress_exe, [1, 2, 13, 9, 0, 1], **{name: value})[1] for name, value in
-             [("ZKHIP_TOP_MAX_LOG", "6"), ("ZKHIP_TOP_MAX_LOG", "8"), ("ZKHIP_TOP_MAX_LOG", "7"), ("ZKHIP_TOP_MAX_LOG", "3"), ("ZKHIP_COOP_MAX_LOG", "3"),
-              ("ZKHIP_TREE_STORE_EARLY", "1")]}
+             [("ZKHIP_TOP_MAX_LOG", "6"), ("ZKHIP_TOP_MAX_LOG", "8"), ("ZKHIP_TOP_MAX_LOG", "7"), ("ZKHIP_TOP_MAX_LOG", "3"), ("ZKHIP_COOP_MAX_LOG", "3")]}
+    rep, root = _run(stress_exe_test_kernels, [1, 2, 13, 9, 0, 1], ZKHIP_TREE_STORE_EARLY="1")
+    assert rep["early_form"] is True
+    roots.add(root)
     assert len(roots) == 1, roots
+
+
+def test_the_shipped_library_has_no_test_kernels_and_refuses_the_switch(stress_exe):
+    import ctypes as C
+
+    import zkvm_prover_amd as z
+
+    lib = z.load_library()
+    assert lib.zkhip_has_test_kernels() == 0
+    ctx = z.Context(0)
+    cfg = ctx.config()
+    assert cfg.tree_store_early == 0
+    cfg.tree_store_early = 1
+    assert lib.zkhip_ctx_set_config(ctx.h, C.byref(cfg)) != 0   # ZKHIP_ERR_INVALID: the kernels are not in this library
+    # ... and the variable is ignored: the run is the shipped form
+    rep, _ = _run(stress_exe, [1, 2, 13, 9, 0, 1], ZKHIP_TREE_STORE_EARLY="1")
+    assert rep["early_form"] is False
 
 
 def test_guest_flow_loop_with_self_check(tmp_path):
     cli = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
     subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_guest_files.py"), str(tmp_path), "300000"], stdout=subprocess.DEVNULL)
-    env = dict(os.environ, ZKHIP_VERIFY_SEGMENTS="1", ZKHIP_SELF_CHECK="1")
+    # ZKHIP_NO_RETRY: a segment proof that the self-check refuses ends the run instead of being made again (FlowOptions::retry_segments) --
+    # and the flow's line must say that nothing was retried
+    env = dict(os.environ, ZKHIP_VERIFY_SEGMENTS="1", ZKHIP_SELF_CHECK="1", ZKHIP_NO_RETRY="1")
     segments = 0
     for i, n in enumerate([249651, 384274, 126816, 364386, 336579, 305084]):   # (lengths of failing runs of the round-5 hunt)
         open(tmp_path / "stdin.bin", "wb").write(n.to_bytes(4, "little"))
@@ -81,5 +112,6 @@ def test_guest_flow_loop_with_self_check(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["verified"] is True
+        assert line["retry_enabled"] is False and line["segments_retried"] == 0 and line["segments_retried_detail"] == [], line
         segments += line["segments"]
     assert segments > 300

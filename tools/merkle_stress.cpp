@@ -82,6 +82,6 @@ int main(int argc, char** argv) {
     for (auto& x : noise) x.join();
     std::printf("{\"tree_threads\": %d, \"noise_threads\": %d, \"rebuilds_per_thread\": %d, \"log_height\": %u, \"width\": %u, \"checks\": %ld, \"checks_with_a_wrong_node\": %ld, "
                 "\"wrong_nodes\": %ld, \"seconds\": %.1f, \"early_form\": %s}\n",
-                T, K, iters, lh, width, checks.load(), bad_checks.load(), bad_nodes.load(), secs, getenv("ZKHIP_TREE_STORE_EARLY") ? "true" : "false");
+                T, K, iters, lh, width, checks.load(), bad_checks.load(), bad_nodes.load(), secs, (zkhip_has_test_kernels() && getenv("ZKHIP_TREE_STORE_EARLY")) ? "true" : "false");
     return bad_checks.load() ? 1 : 0;
 }

@@ -22,6 +22,20 @@ static std::vector<uint8_t> slurp(const std::string& path) {
     return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 }
 
+// the retried segments of a flow as JSON: [{"segment": i, "message": "..."}, ...] (GuestStark::segments_retried)
+static std::string retried_json(const std::vector<std::pair<size_t, std::string>>& v) {
+    std::string out = "[";
+    for (size_t i = 0; i < v.size(); i++) {
+        out += (i ? ", {\"segment\": " : "{\"segment\": ") + std::to_string(v[i].first) + ", \"message\": \"";
+        for (char ch : v[i].second) {
+            if (ch == '"' || ch == '\\') out += '\\', out += ch;
+            else if ((unsigned char)ch < 0x20) out += ' ';
+            else out += ch;
+        }
+        out += "\"}";
+    }
+    return out + "]";
+}
 static std::string list_of(const std::vector<size_t>& v) {
     std::string o = "[";
     for (size_t i = 0; i < v.size(); i++) o += (i ? ", " : "") + std::to_string(v[i]);
@@ -294,11 +308,13 @@ int main(int argc, char** argv) {
                                 "\"sum_over_segments_tracegen_ms\": %llu, \"sum_over_segments_prove_ms\": %llu, "
                                 "\"aggregation_setup_wait_ms\": %llu, \"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, \"chips_per_shape\": %s, "
                                 "\"segments_per_shape\": %s, \"instructions_per_shape\": %s, \"sum_prove_ms_per_shape\": %s, \"sum_tracegen_ms_per_shape\": %s, \"tree_nodes_per_device_slot\": %s, \"aggregation_circuits_build_s\": %.2f, \"aggregation_keygen_s\": %.2f, \"leaf_circuits_at_setup\": %zu, \"leaf_circuits_on_demand\": %zu, "
+                                "\"segments_retried\": %zu, \"segments_retried_detail\": %s, \"retry_enabled\": %s, "
                                 "\"node_log_heights\": [%u, %u], \"verified\": true}\n",
                                 (unsigned long long)g.exec.total_cycle, g.segments, g.levels, lanes, (unsigned long long)g.execution_mills,
                                 (unsigned long long)g.segment_proving_mills, (unsigned long long)g.sum_segment_tracegen_mills,
                                 (unsigned long long)g.sum_segment_prove_mills, (unsigned long long)g.aggregation_setup_wait_mills,
                                 (unsigned long long)g.aggregation_mills, wall, g.root.proof.size(), list_of(g.chips_per_shape).c_str(), list_of(g.segments_per_shape).c_str(), list_of(g.instr_per_shape).c_str(), list_of(g.prove_ms_per_shape).c_str(), list_of(g.tracegen_ms_per_shape).c_str(), list_of(g.nodes_per_slot).c_str(), g.agg_build_seconds, g.agg_keygen_seconds, g.leaf_circuits_at_setup, g.leaf_circuits_on_demand,
+                                g.segments_retried.size(), retried_json(g.segments_retried).c_str(), flow.retry_segments ? "true" : "false",
                                 g.node_log_heights.at(0), g.node_log_heights.at(1));
                 } catch (const zkhip_vm::Error& e) {
                     throw Error(Error::GenProof, e.what());
@@ -311,9 +327,11 @@ int main(int argc, char** argv) {
             std::ofstream(dir + "/root.json") << sp.to_json();
             const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             std::printf("{\"identifier\": \"%s\", \"total_cycles\": %llu, \"segments\": %zu, \"levels\": %zu, \"execution_ms\": %llu, "
-                        "\"segment_tracegen_and_proving_ms\": %llu, \"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, \"verified\": true}\n",
+                        "\"segment_tracegen_and_proving_ms\": %llu, \"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, "
+                        "\"segments_retried\": %zu, \"segments_retried_detail\": %s, \"verified\": true}\n",
                         task.identifier.c_str(), (unsigned long long)g.exec.total_cycle, g.segments, g.levels, (unsigned long long)g.execution_mills,
-                        (unsigned long long)g.segment_proving_mills, (unsigned long long)g.aggregation_mills, wall, g.root.proof.size());
+                        (unsigned long long)g.segment_proving_mills, (unsigned long long)g.aggregation_mills, wall, g.root.proof.size(),
+                        g.segments_retried.size(), retried_json(g.segments_retried).c_str());
             return 0;
         }
         if (argc >= 5 && std::string(argv[1]) == "program-commit") {

@@ -271,6 +271,7 @@ def load_library():
         "zkhip_host_cpus": (C.c_uint, []),
         "zkhip_config_default": (None, [C.POINTER(Config)]),
         "zkhip_ctx_get_config": (C.c_int, [vp, C.POINTER(Config)]),
+        "zkhip_has_test_kernels": (C.c_int, []),
         "zkhip_ctx_set_config": (C.c_int, [vp, C.POINTER(Config)]),
         "zkhip_set_process_config": (C.c_int, [C.POINTER(Config)]),
         "zkhip_recursion_build_join": (C.c_int, [C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(_Params), C.POINTER(_Air), sz, C.POINTER(vp)]),

@@ -195,28 +195,36 @@ unsigned zkhip_host_cpus(void) {
 // ---- configuration: the ONE place the library reads its ZKHIP_* environment overrides ----
 void zkhip_config_default(zkhip_config* c) {
     if (!c) return;
-    auto num = [](const char* name, uint32_t dflt) { return getenv(name) ? (uint32_t)atoi(getenv(name)) : dflt; };
+    // (an override outside the range zkhip_ctx_set_config accepts is clamped into it here, so that a get_config / set_config round trip of
+    // the defaults never fails: ADVICE round 5)
+    auto num = [](const char* name, uint32_t dflt, uint32_t lo = 0, uint32_t hi = 0xffffffffu) {
+        if (!getenv(name)) return dflt;
+        const long long v = atoll(getenv(name));
+        return (uint32_t)std::min<long long>(hi, std::max<long long>(lo, v));
+    };
     memset(c, 0, sizeof *c);
     c->host_sponge = getenv("ZKHIP_NO_HOST_SPONGE") ? 0 : 1;
     c->host_sponge_min_words = num("ZKHIP_HOST_SPONGE_MIN_WORDS", 8192u);
     c->jit = getenv("ZKHIP_NO_JIT") ? 0 : getenv("ZKHIP_FORCE_JIT") ? 2 : 1;
-    c->jit_min_log_work = num("ZKHIP_JIT_MIN_LOG_WORK", 26u);
+    c->jit_min_log_work = num("ZKHIP_JIT_MIN_LOG_WORK", 26u, 0, 62);
     c->quot_slices = getenv("ZKHIP_NO_QUOT_SLICES") ? 0 : 1;
-    c->grind_sweep_shift = num("ZKHIP_GRIND_SWEEP_SHIFT", 0u);
-    c->coop_max_log = num("ZKHIP_COOP_MAX_LOG", 15u), c->coop_inj_max_log = num("ZKHIP_COOP_INJ_MAX_LOG", 15u);
-    c->top_max_log = num("ZKHIP_TOP_MAX_LOG", 6u);   // (measured 8 / 7 / 6 / 5 / 4 on the guest flow: 987 / 936 / 911 / 924 / 931 ms of segment proving with one lane)
-    c->commit_parts = num("ZKHIP_COMMIT_PARTS", 0u), c->side_cus = num("ZKHIP_SIDE_CUS", 0u);
+    c->grind_sweep_shift = num("ZKHIP_GRIND_SWEEP_SHIFT", 0u, 0, 8);
+    c->coop_max_log = num("ZKHIP_COOP_MAX_LOG", 15u, 0, 27), c->coop_inj_max_log = num("ZKHIP_COOP_INJ_MAX_LOG", 15u, 0, 27);
+    c->top_max_log = num("ZKHIP_TOP_MAX_LOG", 6u, 0, 8);   // (measured 8 / 7 / 6 / 5 / 4 on the guest flow: 987 / 936 / 911 / 924 / 931 ms of segment proving with one lane)
+    c->commit_parts = num("ZKHIP_COMMIT_PARTS", 0u, 0, 8), c->side_cus = num("ZKHIP_SIDE_CUS", 0u);
     c->witness_threads = num("ZKHIP_WITNESS_THREADS", 0u);
     c->pin_witness = getenv("ZKHIP_NO_PIN_WITNESS") ? 0 : 1;
     c->parallel_queries = getenv("ZKHIP_RECURSION_SERIAL_QUERIES") ? 0 : 1;
     c->self_check = getenv("ZKHIP_SELF_CHECK") ? 1 : 0;
-    c->tree_store_early = getenv("ZKHIP_TREE_STORE_EARLY") ? 1 : 0;
-    c->hash_block = num("ZKHIP_HASH_BLOCK", 256u);
+#ifdef ZKHIP_TEST_KERNELS
+    c->tree_store_early = getenv("ZKHIP_TREE_STORE_EARLY") ? 1 : 0;   // (libzkhip_test.so only: the shipped library has no such kernels)
+#endif
+    c->hash_block = num("ZKHIP_HASH_BLOCK", 256u, 64, 768) / 64 * 64;
     c->coop_fused = getenv("ZKHIP_NO_COOP_FUSED") ? 0 : 1;   // (test only: the round-4 bodies of the fused tree kernels)
     c->rows_in_bulk = getenv("ZKHIP_NO_ROWS_IN_BULK") ? 0 : 1;
-    c->rows_coop_max_log = num("ZKHIP_ROWS_COOP_MAX_LOG", 15u);
-    c->ntt_log_lanes = num("ZKHIP_NTT_LOG_LANES", 10u);
-    c->quot_streams = num("ZKHIP_QUOT_STREAMS", 0u);   // (measured: + 7 % for ONE lane of the mixed guest, nothing with three lanes: docs/round5_b.md 6)
+    c->rows_coop_max_log = num("ZKHIP_ROWS_COOP_MAX_LOG", 15u, 0, 27);
+    c->ntt_log_lanes = num("ZKHIP_NTT_LOG_LANES", 10u, 8, 10);
+    c->quot_streams = num("ZKHIP_QUOT_STREAMS", 0u, 0, 4);   // (measured: + 7 % for ONE lane of the mixed guest, nothing with three lanes: docs/round5_b.md 6)
     // compiled constraint kernels across processes: the variable if set (empty = none), else `jit_cache` beside this library if it exists
     std::string dir;
     if (const char* e = getenv("ZKHIP_JIT_CACHE_DIR")) {
@@ -263,6 +271,14 @@ int zkhip_tables_canonical(zkhip_ctx* ctx, int on) {
     return ZKHIP_OK;
 }
 
+int zkhip_has_test_kernels(void) {
+#ifdef ZKHIP_TEST_KERNELS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int zkhip_ctx_get_config(zkhip_ctx* ctx, zkhip_config* out) {
     if (!ctx || !out) return ZKHIP_ERR_INVALID;
     *out = ctx->cfg;
@@ -274,6 +290,10 @@ int zkhip_ctx_set_config(zkhip_ctx* ctx, const zkhip_config* cfg) {
     if (cfg->jit < 0 || cfg->jit > 2 || cfg->coop_max_log > 27 || cfg->coop_inj_max_log > 27 || cfg->rows_coop_max_log > 27 || cfg->ntt_log_lanes < 8 || cfg->ntt_log_lanes > 10 || cfg->quot_streams > 4 || cfg->jit_min_log_work > 62 || cfg->top_max_log > 8 || cfg->grind_sweep_shift > 8 ||
         cfg->commit_parts > 8 || cfg->side_cus >= (unsigned)ctx->cu_count || cfg->hash_block < 64 || cfg->hash_block > 768 || cfg->hash_block % 64)
         return set_error(ctx, ZKHIP_ERR_INVALID, "zkhip_ctx_set_config: field out of range (jit 0..2, coop_* <= 27, rows_coop_max_log <= 27, ntt_log_lanes 8..10, quot_streams <= 4, jit_min_log_work <= 62, top_max_log <= 8, grind_sweep_shift <= 8, commit_parts <= 8, side_cus < CUs, hash_block a multiple of 64 in 64..768)");
+#ifndef ZKHIP_TEST_KERNELS
+    if (cfg->tree_store_early)
+        return set_error(ctx, ZKHIP_ERR_INVALID, "zkhip_ctx_set_config: tree_store_early names TEST kernels that this library was built without (libzkhip_test.so holds them)");
+#endif
     ZK_TRY(zkhip_set_cu_partition(ctx, cfg->side_cus));   // (drops the masked side streams if the partition changes)
     ctx->cfg = *cfg;
     ctx->cfg.jit_cache_dir[sizeof ctx->cfg.jit_cache_dir - 1] = 0;

@@ -412,7 +412,10 @@ __global__ __launch_bounds__(1024) void k_compress_top(uint32_t* __restrict__ di
 }
 
 // The round-4 bodies of the two fused kernels ("store a layer's word, then compute on"), kept behind zkhip_config.tree_store_early for the
-// A/B of the stale node (docs/stale_node.md): TEST ONLY -- the form that stored a wrong node in ~3 % of guest-flow runs.
+// A/B of the stale node (docs/stale_node.md): TEST ONLY -- the form that stored a wrong node in ~3 % of guest-flow runs.  They are compiled
+// only under -DZKHIP_TEST_KERNELS, i.e. into libzkhip_test.so (csrc/Makefile), which the stress tests load; libzkhip.so does not hold them and
+// refuses zkhip_config.tree_store_early.
+#ifdef ZKHIP_TEST_KERNELS
 __global__ __launch_bounds__(256) void k_compress_coop_multi_early(const uint32_t* __restrict__ prev, uint32_t* __restrict__ digests, size_t n_next, CoopMulti cm) {
     __shared__ uint32_t buf[2][16 * 8];
     const unsigned lane = threadIdx.x & 15u, row = threadIdx.x >> 4;
@@ -463,6 +466,7 @@ __global__ __launch_bounds__(1024) void k_compress_top_early(uint32_t* __restric
         cur ^= 1;
     }
 }
+#endif  // ZKHIP_TEST_KERNELS
 
 // Diagnosis (zkhip_config.self_check): every node of a plain layer against the compression of its children, one lane per node, through the
 // plain (non-cooperative) permutation.  report[0] = mismatching nodes, report[1] = the smallest (layer << 24 | index) among them.
@@ -676,8 +680,11 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
         if (cnt <= ((size_t)1 << std::min(ctx->cfg.top_max_log, 8u)) && level < clean_top) {
             // this and all remaining levels in one launch
             KernelScope ks(ctx, "poseidon2_compress_top");
+#ifdef ZKHIP_TEST_KERNELS
             if (ctx->cfg.tree_store_early) hipLaunchKernelGGL(k_compress_top_early, dim3(1), dim3(1024), 0, ctx->stream, t->d_digests, lh, l - 1);
-            else hipLaunchKernelGGL(k_compress_top, dim3(1), dim3(1024), 0, ctx->stream, t->d_digests, lh, l - 1);
+            else
+#endif
+                hipLaunchKernelGGL(k_compress_top, dim3(1), dim3(1024), 0, ctx->stream, t->d_digests, lh, l - 1);
             break;
         }
         KernelScope ks(ctx, "poseidon2_compress_layer");
@@ -724,9 +731,11 @@ int merkle_build(zkhip_ctx* ctx, zkhip_tree* t, bool leaves_ready) {
             }
             if (m >= 2) {
                 cm.m = m;
+#ifdef ZKHIP_TEST_KERNELS
                 if (ctx->cfg.tree_store_early)
                     hipLaunchKernelGGL(k_compress_coop_multi_early, dim3((unsigned)(cnt / 16)), dim3(256), 0, ctx->stream, t->d_digests + t->layer_off[l - 1] * 8, t->d_digests, cnt, cm);
                 else
+#endif
                     hipLaunchKernelGGL(k_compress_coop_multi, dim3((unsigned)(cnt / 16)), dim3(256), 0, ctx->stream, t->d_digests + t->layer_off[l - 1] * 8, t->d_digests, cnt, cm);
                 l += m - 1;
                 continue;
