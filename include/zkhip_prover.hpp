@@ -249,6 +249,15 @@ struct FlowOptions {
                                       // more from the same records before the task is given up; every retry is COUNTED (GuestStark::
                                       // segments_retried, the flow's JSON line).  Off: the first failure ends the task -- what the stress
                                       // loops run with, so that a retried wrong node cannot pass for a clean run          [ZKHIP_NO_RETRY=1 -> false]
+    int fail_segment_once = -1;       // TEST: the first attempt at this segment's proof throws (tests of the retry and of its counter)   [ZKHIP_TEST_FAIL_SEGMENT=n]
+    int exec_threads = -1;            // record passes of the PARALLEL executor (include/zkhip_vm_exec.hpp: a metered pass cuts the run and keeps
+                                      // the memory tree, so many record passes replay the segments side by side; the reference meters first too,
+                                      // crates/prover/src/utils/vm.rs:19).  0 = the serial executor on the feeding thread (rounds 3 - 5);
+                                      // -1 = auto: a quarter of the CPUs this process may use, at least 2, at most 6       [ZKHIP_EXEC_THREADS=n]
+    unsigned exec_threads_or_auto() const {
+        if (exec_threads >= 0) return (unsigned)exec_threads;
+        return std::min(6u, std::max(2u, zkhip_host_cpus() / 4));
+    }
     std::vector<int> devices;         // GPUs of the node the flow spreads over (empty = the prover's device)             [ZKHIP_DEVICES=0,1,..]
     static FlowOptions from_env() {
         FlowOptions o;
@@ -261,6 +270,8 @@ struct FlowOptions {
         o.balanced_tree = getenv("ZKHIP_TREE_BALANCED") != nullptr;
         o.trace_tree = getenv("ZKHIP_TREE_TRACE") != nullptr;
         o.retry_segments = getenv("ZKHIP_NO_RETRY") == nullptr;
+        if (const char* e = getenv("ZKHIP_TEST_FAIL_SEGMENT")) o.fail_segment_once = atoi(e);
+        if (const char* e = getenv("ZKHIP_EXEC_THREADS")) o.exec_threads = std::min(64, std::max(0, atoi(e)));
         if (const char* e = getenv("ZKHIP_WIDE_IN_FLIGHT")) o.wide_in_flight = (unsigned)std::max(0, atoi(e));
         o.agg_cli_greedy = getenv("ZKHIP_AGG_GREEDY") != nullptr;
         if (const char* e = getenv("ZKHIP_DEFERRAL_CHILDREN")) o.deferral_children = (unsigned)std::min(8, std::max(1, atoi(e)));

@@ -19,6 +19,7 @@
 // Environment calls (a7): 93 = exit(a0) (non-zero = guest failure), 1 = reveal the word a0 as public-value bytes
 // [4 a1, 4 a1 + 4), 2 = read the next word of the input stream into a0.  Header-only; no GPU code.
 #pragma once
+#include <cassert>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -64,6 +65,7 @@ struct U32Vec : std::vector<uint32_t> {
     using std::vector<uint32_t>::vector;
 #if defined(__GLIBCXX__)
     void put_unchecked(uint32_t x) {
+        assert(this->_M_impl._M_finish != this->_M_impl._M_end_of_storage && "U32Vec::put_unchecked beyond the reserved rows");
         *this->_M_impl._M_finish = x;
         ++this->_M_impl._M_finish;
     }
@@ -89,7 +91,18 @@ struct ExecRecords {
     // destination register (loads) / the aligned memory word (stores) held before
     U32Vec ls_case, ls_read, ls_prev;
     uint64_t n_shift = 0, n_branch = 0, n_jump = 0, n_load_store = 0, n_mulh = 0, n_divrem = 0, n_lui_auipc = 0, n_ecall = 0;
-    uint64_t reserved = 0;   // != 0: every U32Vec above has room for the rows of a whole segment (set by the segmenting executor after clear())
+    // != 0: every U32Vec above has room for the rows of a whole segment (set by the segmenting executor for the duration of run_segment).  A COPY
+    // of the records starts at 0: the flag speaks about capacities, and a copied vector's capacity is its size.
+    struct Reserved {
+        uint64_t v = 0;
+        Reserved() = default;
+        Reserved(const Reserved&) {}
+        Reserved(Reserved&& o) noexcept : v(o.v) {}
+        Reserved& operator=(const Reserved&) { v = 0; return *this; }
+        Reserved& operator=(Reserved&& o) noexcept { v = o.v; return *this; }
+        Reserved& operator=(uint64_t x) { v = x; return *this; }
+        explicit operator bool() const { return v != 0; }
+    } reserved;
     // Memory log for the offline memory-checking argument (OpenVM's memory bus): state is kept in 16-bit CELLS -- address space
     // 1 = registers (cell 2 i + half of x_i), 2 = read-write memory (cell = halfword index from data_base) -- so that a cell's
     // value is a field element.  One entry per cell access, in execution order, timestamps 1, 2, 3, ...:
@@ -199,6 +212,59 @@ public:
     // `[app_vm_config.native]` (ecalls 9, 10), `[app_vm_config.castf]` (ecall 11), `[app_vm_config.pairing]` (phantom kind 2)
     void set_native(const zkhip::native::Enabled& e) { native_ = e.native, castf_ = e.castf, pairing_ = e.pairing; }
     const zkhip::modular::U256& last_slope() const { return last_slope_; }          // of the last ecc call (the chip's record carries it)
+    // ---- snapshots (the parallel executor of include/zkhip_vm_exec.hpp: a metered first pass cuts the run, record passes replay the
+    // segments on other threads).  A State is everything but the memory: that travels as the 4 KiB PAGES written since the previous
+    // snapshot (track_dirty + take_dirty_pages on the machine that runs ahead, apply_pages on the ones that follow). ----
+    static constexpr uint32_t PAGE_BYTES = 4096;
+    struct Page {
+        uint32_t index;                       // byte offset / PAGE_BYTES from data_base
+        std::vector<uint8_t> bytes;           // PAGE_BYTES (less for the last page of the region)
+    };
+    struct State {
+        uint32_t x[32] = {}, pc = 0, exit_code = 0, last_val = 0;
+        bool done = false;
+        uint64_t instret = 0;
+        size_t in_pos = 0;
+        std::deque<uint32_t> hints;
+        std::vector<uint8_t> pv;
+        zkhip::modular::U256 last_slope{};
+    };
+    State save_state() const {
+        State st;
+        memcpy(st.x, x_, sizeof x_);
+        st.pc = pc_, st.exit_code = exit_code_, st.last_val = last_val_, st.done = done_, st.instret = instret_, st.in_pos = in_pos_;
+        st.hints = hints_, st.pv = pv_, st.last_slope = last_slope_;
+        return st;
+    }
+    void restore_state(const State& st) {
+        memcpy(x_, st.x, sizeof x_);
+        pc_ = st.pc, exit_code_ = st.exit_code, last_val_ = st.last_val, done_ = st.done, instret_ = st.instret, in_pos_ = st.in_pos;
+        hints_ = st.hints, pv_ = st.pv, last_slope_ = st.last_slope;
+    }
+    void track_dirty(bool on) {
+        dirty_.assign(on ? (mem_.size() + PAGE_BYTES - 1) / PAGE_BYTES : 0, 0);
+        dirty_list_.clear();
+    }
+    // the pages written since the last call (or since track_dirty(true)), with their contents NOW, in ascending order
+    std::vector<Page> take_dirty_pages() {
+        std::sort(dirty_list_.begin(), dirty_list_.end());
+        std::vector<Page> out;
+        out.reserve(dirty_list_.size());
+        for (uint32_t pg : dirty_list_) {
+            const size_t off = (size_t)pg * PAGE_BYTES, n = std::min<size_t>(PAGE_BYTES, mem_.size() - off);
+            out.push_back(Page{pg, std::vector<uint8_t>(mem_.begin() + (std::ptrdiff_t)off, mem_.begin() + (std::ptrdiff_t)(off + n))});
+            dirty_[pg] = 0;
+        }
+        dirty_list_.clear();
+        return out;
+    }
+    void apply_pages(const std::vector<Page>& pages) {
+        for (const Page& pg : pages) {
+            const size_t off = (size_t)pg.index * PAGE_BYTES;
+            if (off + pg.bytes.size() > mem_.size()) throw Error("internal: a memory page beyond the region");
+            memcpy(mem_.data() + off, pg.bytes.data(), pg.bytes.size());
+        }
+    }
     bool done() const { return done_; }
     uint32_t pc() const { return pc_; }
     uint32_t last_result() const { return last_val_; }   // the value the last instruction computed for rd (also when rd = x0)
@@ -222,6 +288,13 @@ private:
     std::vector<uint8_t> mem_, pv_;
     uint32_t x_[32], pc_ = 0, exit_code_ = 0, last_val_ = 0;
     bool log_memory_ = true;
+    std::vector<uint8_t> dirty_;          // per page: written since the last take_dirty_pages (empty = not tracked)
+    std::vector<uint32_t> dirty_list_;
+    void mark_dirty(size_t off, unsigned n) {
+        if (dirty_.empty()) return;
+        for (size_t pg = off / PAGE_BYTES; pg <= (off + n - 1) / PAGE_BYTES; pg++)
+            if (!dirty_[pg]) dirty_[pg] = 1, dirty_list_.push_back((uint32_t)pg);
+    }
     std::vector<zkhip::modular::U256> moduli_;
     std::vector<zkhip::ecc::Curve> curves_;
     std::vector<zkhip::modular::U256> fp2_moduli_;
@@ -290,11 +363,11 @@ private:
         if (kind == 2) {
             if (!pairing_) throw Error("pairing hint: the app's openvm.toml does not enable the pairing extension");
             uint32_t curve;
-            memcpy(&curve, at(ptr, 4), 4);
+            memcpy(&curve, at_ro(ptr, 4), 4);
             if (curve > 1) throw Error("pairing hint: curve " + std::to_string(curve) + " (0 = Bn254, 1 = Bls12_381)");
             const unsigned n_in = curve ? 144u : 96u;
             uint32_t buf[144], out[288];
-            memcpy(buf, at(ptr + 4, 4 * n_in), 4 * n_in);
+            memcpy(buf, at_ro(ptr + 4, 4 * n_in), 4 * n_in);
             const char* why = "";
             const bool ok = curve ? zkhip::pairing::final_exp_hint_bls12_381(buf, out, &why) : zkhip::pairing::final_exp_hint_bn254(buf, out, &why);
             if (!ok) throw Error(std::string("pairing hint: ") + why);
@@ -302,7 +375,7 @@ private:
             return;
         }
         uint32_t which;
-        memcpy(&which, at(ptr, 4), 4);
+        memcpy(&which, at_ro(ptr, 4), 4);
         if (which >= moduli_.size()) throw Error("phantom hint: the app's openvm.toml lists no modulus " + std::to_string(which));
         const UInt p = moduli_[which];
         const size_t nw = words_of(p);
@@ -348,7 +421,7 @@ private:
             for (size_t k = 0; k < nw; k++) hints_.push_back(v.w[k]);
         };
         if (kind == 0) return push(z);
-        UInt x = load_words(at(ptr + 4, (unsigned)(4 * nw)), nw);
+        UInt x = load_words(at_ro(ptr + 4, (unsigned)(4 * nw)), nw);
         {   // reduce
             UInt q, r;
             mulmod(x, one, p, &q, &r);
@@ -385,7 +458,14 @@ private:
         hints_.push_back(square ? 1u : 0u);
         push(r);
     }
+    // (at: the pointer of a range that is about to be WRITTEN -- stores, the intrinsic calls' buffers; at_ro: of one that is only read)
     uint8_t* at(uint32_t addr, unsigned n) {
+        const uint64_t off = (uint64_t)addr - exe_.data_base;
+        if (addr < exe_.data_base || off + n > mem_.size()) throw Error("memory access out of range at pc " + std::to_string(pc_));
+        if (n) mark_dirty((size_t)off, n);
+        return mem_.data() + off;
+    }
+    const uint8_t* at_ro(uint32_t addr, unsigned n) const {
         const uint64_t off = (uint64_t)addr - exe_.data_base;
         if (addr < exe_.data_base || off + n > mem_.size()) throw Error("memory access out of range at pc " + std::to_string(pc_));
         return mem_.data() + off;
@@ -404,7 +484,7 @@ private:
     uint32_t load(ExecRecords* rec, uint32_t addr, unsigned n) {
         if (addr % n) throw Error("misaligned load");
         uint32_t v = 0;
-        memcpy(&v, at(addr, n), n);
+        memcpy(&v, at_ro(addr, n), n);
         if (rec && log_memory_) {
             const uint32_t first = (addr - exe_.data_base) >> 1, last = (addr - exe_.data_base + n - 1) >> 1;
             for (uint32_t c = first; c <= last; c++) touch(rec, 2, c, cell_value(c), false, 0);
@@ -515,7 +595,7 @@ private:
                 const uint32_t addr = a + (uint32_t)imm_s;
                 if (f3 > 2) throw Error("illegal store");
                 if (rec) {
-                    at(addr, 1u << f3);   // range check before the word is read
+                    (void)at_ro(addr, 1u << f3);   // range check before the word is read
                     const uint32_t off = (addr - exe_.data_base) & 3u;
                     rec->n_load_store++, put(rec, rec->ls_case, f3 == 2 ? 7 : f3 == 1 ? 8 + off / 2 : 10 + off);
                     put(rec, rec->ls_read, b), put(rec, rec->ls_prev, word_around(addr));

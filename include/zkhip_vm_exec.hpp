@@ -13,6 +13,11 @@
 // Host only; Poseidon2 through the library's host entry point (zkhip_poseidon2_permute_host).
 #pragma once
 #include <array>
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
@@ -224,9 +229,37 @@ struct SegmentRecords {
     }
 };
 
+// a touched block of the current segment (8 cells = 4 words) and what the close of a segment works on
+struct MemBlock {
+    uint32_t init[8], cur[8], ts[4];   // cells 2 j, 2 j + 1 = the halves of word j; ts[j] = the word's last access in this segment
+};
+struct CloseJob {
+    std::vector<MemBlock> blk;      // in the order of first touch, final cells filled in
+    std::vector<uint32_t> label;
+    size_t n_path = 0;              // internal nodes above them
+};
+
+// What the METERED first pass knows about a segment (ParallelSegmentExecutor below; the role of OpenVM's metered execution before its
+// per-segment preflight runs, reached by the reference through execute_metered_cost, crates/prover/src/utils/vm.rs:19): where it starts (the
+// machine's state; the memory pages written since the previous cut), where it ends (n_instr), and everything of the segment's records that
+// hangs on the PERSISTENT memory tree -- the one chain that runs through all segments: touched blocks (sorted), leaf rows (their timestamp
+// columns are the record pass's), path-node rows, hash requests, the roots.
+struct SegmentPlan {
+    size_t index = 0;
+    Machine::State start;
+    std::shared_ptr<const std::vector<Machine::Page>> pages;   // written during the PREVIOUS segment (none for segment 0)
+    size_t n_instr = 0;
+    bool last = false;
+    uint32_t pc_start = 0, pc_end = 0;
+    Digest root_init{}, root_final{};
+    std::vector<uint32_t> leaf_rows, merkle_rows, p2_inputs;
+    CloseJob job;   // between the metered run and its close (SegmentExecutor::meter_run / meter_close)
+};
+
 class SegmentExecutor {
 public:
-    SegmentExecutor(const Exe& exe, const StdIn& in, const SegmentCaps& caps) : exe_(exe), m_(exe, in), caps_(caps) {
+    // replay_only: a record-pass worker of ParallelSegmentExecutor -- it never owns the persistent tree (the metered pass does)
+    SegmentExecutor(const Exe& exe, const StdIn& in, const SegmentCaps& caps, bool replay_only = false) : exe_(exe), m_(exe, in), caps_(caps) {
         if (exe.data_base % 16) throw Error("the one-statement flow needs a 16-byte aligned data base");
         if ((uint64_t)exe.data_base + exe.memory_bytes > (1ull << 30) || (uint64_t)exe.pc_base + 4 * exe.program.size() > (1ull << 30))
             throw Error("guest addresses must lie below 2^30");
@@ -237,8 +270,11 @@ public:
         m_.set_native(caps.ext);
         dec_.reserve(exe.program.size());
         for (size_t k = 0; k < exe.program.size(); k++) dec_.push_back(vmc::decode(exe.program[k], exe.pc_base + 4 * (uint32_t)k));
+        for (const vmc::Decoded& d : dec_)   // the register BLOCKS (four registers each) an instruction touches, as a mask
+            dec_regmask_.push_back((uint8_t)((d.use_rs1 ? 1u << (d.rs1 >> 2) : 0u) | (d.use_rs2 ? 1u << (d.rs2 >> 2) : 0u) | (d.wr_rd ? 1u << (d.rd >> 2) : 0u)));
         mem_lo_blk_ = exe.data_base / 16;
         mem_slot_.assign(((size_t)exe.memory_bytes + 15) / 16 + 1, 0);
+        if (replay_only) return;
         // the initial memory image: registers (sp), the data segment
         std::vector<std::pair<uint32_t, std::array<uint32_t, 8>>> blocks;
         for (uint32_t blk = 0; blk < 8; blk++) push_nonzero(blocks, 1, blk);
@@ -269,10 +305,51 @@ public:
         if (call == zkhip::native::CALL_CASTF) return 2;
         return 24;   // (int256)
     }
-    bool run_segment(SegmentRecords& r) {
-        r.clear(/*keep_frame=*/true);
+    bool run_segment(SegmentRecords& r) { return run_impl<SERIAL>(r, nullptr); }
+    // The metered pass: the next segment's cut and its memory-tree records into `plan`, no execution records (the machine runs without a
+    // record sink).  track_dirty(true) on the machine before the first call.
+    bool meter_segment(SegmentPlan& plan) {
+        const bool done = meter_run(plan);
+        meter_close(plan);
+        return done;
+    }
+    // ... in two halves that may run on two threads, one plan behind the other: the RUN (the machine, the touched blocks) and the CLOSE (the
+    // persistent tree: hashing the touched blocks and their paths, leaf / path-node rows) -- the tree is the close's alone
+    bool meter_run(SegmentPlan& plan) {
+        plan.start = m_.save_state();
+        plan.pages = std::make_shared<const std::vector<Machine::Page>>(m_.take_dirty_pages());
+        const bool done = run_impl<METER>(meter_scratch_, &plan);
+        plan.n_instr = meter_scratch_.n_instr, plan.last = done;
+        plan.pc_start = meter_scratch_.pc_start, plan.pc_end = meter_scratch_.pc_end;
+        return done;
+    }
+    void meter_close(SegmentPlan& plan) {
+        const auto t0 = std::chrono::steady_clock::now();
+        SegmentRecords& r = close_scratch_;
+        r.leaf_rows.clear(), r.merkle_rows.clear(), r.p2_inputs.clear();
+        plan.root_init = tree_.root();
+        close_job(plan.job, r);
+        plan.root_final = r.root_final;
+        plan.leaf_rows.swap(r.leaf_rows), plan.merkle_rows.swap(r.merkle_rows), plan.p2_inputs.swap(r.p2_inputs);
+        plan.job = CloseJob();
+        close_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    // The record pass of one planned segment: the machine is put where the plan starts (its memory must already be the memory of that cut:
+    // machine().apply_pages of every plan since the one this executor last replayed) and runs plan.n_instr instructions into `r`.
+    bool replay_segment(const SegmentPlan& plan, SegmentRecords& r) {
+        m_.restore_state(plan.start);
+        return run_impl<REPLAY>(r, const_cast<SegmentPlan*>(&plan));
+    }
+    Machine& machine() { return m_; }
+
+private:
+    enum Mode { SERIAL = 0, METER = 1, REPLAY = 2 };
+    SegmentRecords meter_scratch_, close_scratch_;
+    template <int MODE>
+    bool run_impl(SegmentRecords& r, SegmentPlan* plan) {
+        r.clear(/*keep_frame=*/MODE != METER);
         reset_blocks();
-        const size_t frame_rows = caps_.rows(vmc::A_FRAME);
+        const size_t frame_rows = MODE == METER ? 0 : caps_.rows(vmc::A_FRAME);
         // room for a whole frame in every array the interpreter appends to (an instruction leaves at most one entry per array): its appends
         // then skip the capacity check (ExecRecords::reserved, U32Vec::put_unchecked).  Address space only: pages are touched as rows are written.
         for (zkhip_vm::U32Vec* v : {&r.core.pc_index, &r.core.alu_op, &r.core.alu_b, &r.core.alu_c, &r.core.lt_op, &r.core.lt_b, &r.core.lt_c, &r.core.mul_b, &r.core.mul_c,
@@ -280,29 +357,45 @@ public:
                                     &r.core.shift_c, &r.core.beq_op, &r.core.beq_a, &r.core.beq_b, &r.core.beq_imm, &r.core.blt_op, &r.core.blt_a, &r.core.blt_b,
                                     &r.core.blt_imm, &r.core.jal_op, &r.core.jal_pc, &r.core.jal_imm, &r.core.auipc_pc, &r.core.auipc_imm, &r.core.jalr_pc,
                                     &r.core.jalr_rs1, &r.core.jalr_imm, &r.core.ls_case, &r.core.ls_read, &r.core.ls_prev})
-            if (v->capacity() < frame_rows + 8) v->reserve(frame_rows + 8);
-        r.core.reserved = 1;
+            if (MODE != METER && v->capacity() < frame_rows + 8) v->reserve(frame_rows + 8);
+        r.core.reserved = MODE != METER;
         for (auto* v : {&r.f_x, &r.f_y, &r.f_z, &r.f_rdprev, &r.f_pcinc, &r.f_pts1, &r.f_pts2, &r.f_pts3}) v->resize(frame_rows);
         uint32_t *const fx = r.f_x.data(), *const fy = r.f_y.data(), *const fz = r.f_z.data(), *const frd = r.f_rdprev.data(), *const fpc = r.f_pcinc.data();
         uint32_t *const fp1 = r.f_pts1.data(), *const fp2 = r.f_pts2.data(), *const fp3 = r.f_pts3.data();
         struct CutFrame {   // (also when an instruction throws: the arrays never hold rows beyond n_instr)
             SegmentRecords& r;
             ~CutFrame() {
-                for (auto* v : {&r.f_x, &r.f_y, &r.f_z, &r.f_rdprev, &r.f_pcinc, &r.f_pts1, &r.f_pts2, &r.f_pts3}) v->resize(r.n_instr);
+                for (auto* v : {&r.f_x, &r.f_y, &r.f_z, &r.f_rdprev, &r.f_pcinc, &r.f_pts1, &r.f_pts2, &r.f_pts3}) v->resize(MODE == METER ? 0 : r.n_instr);
+                r.core.reserved = 0;   // (the promise of room ends with the segment: ADVICE round 5)
             }
         } cut_frame{r};
         r.pc_start = m_.pc();
-        r.root_init = tree_.root();
+        if (MODE == REPLAY) r.root_init = plan->root_init;
+        if (MODE == SERIAL) r.root_init = tree_.root();   // (the metered pass leaves the tree to meter_close, which may be another thread)
         size_t n_cls[vmc::N_CLS] = {};
+        size_t rows_cls[vmc::N_CLS];
+        for (unsigned c = 0; c < vmc::N_CLS; c++) rows_cls[c] = caps_.rows(vmc::A_ALU + c);
+        const size_t rows_frame = caps_.rows(vmc::A_FRAME);
         while (!m_.done()) {
             const uint32_t pc = m_.pc();
             const uint64_t k = ((uint64_t)pc - exe_.pc_base) / 4;
             if (pc < exe_.pc_base || (pc & 3u) || k >= exe_.program.size()) throw Error("pc outside the program: " + std::to_string(pc));
             const vmc::Decoded& d = dec_[k];
             if (!d.legal) throw Error("illegal instruction at pc " + std::to_string(pc));
+            // The metered pass's common case: no environment call, every block the instruction touches is one the segment has already
+            // touched (so it adds no block, no path node, no hash request -- the counts below cannot grow) and its class has a row left:
+            // the instruction runs and is counted.  Everything else takes the general path, which is the serial executor's.
+            if (MODE == METER && d.cls != vmc::C_ECALL && !(dec_regmask_[k] & ~reg_known_) && r.n_instr < rows_frame && n_cls[d.cls] < rows_cls[d.cls] &&
+                (d.cls != vmc::C_LS || mem_block_known(((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) >> 4))) {
+                m_.step_one(nullptr);
+                n_cls[d.cls]++, r.n_instr++;
+                continue;
+            }
             // would one more instruction overflow a chip?  (the blocks and path nodes it would add are counted exactly)
+            // (a record pass does not ask: it ends where the metered pass cut)
+            if (MODE == REPLAY && r.n_instr == plan->n_instr) break;
             size_t new_blocks = 0, new_nodes = 0;
-            {
+            if (MODE != REPLAY) {
                 uint32_t labels[5 + 20];
                 unsigned nl = 0;
                 bool all_known = true;
@@ -354,7 +447,7 @@ public:
                 throw Error("the guest calls a native field intrinsic but the app's openvm.toml does not enable the native extension");
             if (d.cls == vmc::C_ECALL && m_.reg(17) == zkhip::native::CALL_CASTF && !caps_.castf())
                 throw Error("the guest calls the castf intrinsic but the app's openvm.toml does not enable the castf extension");
-            if (r.n_instr + 1 > caps_.rows(vmc::A_FRAME) || n_cls[d.cls] + 1 > caps_.rows(vmc::A_ALU + d.cls) ||
+            if (MODE != REPLAY && (r.n_instr + 1 > caps_.rows(vmc::A_FRAME) || n_cls[d.cls] + 1 > caps_.rows(vmc::A_ALU + d.cls) ||
                 blk_.size() + new_blocks > caps_.rows(vmc::A_LEAF) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 3 && 24 * (r.n_keccak() + 1) > caps_.rows(vmc::A_KECCAK)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 4 && 65 * (r.n_sha256() + 1) > caps_.rows(vmc::A_SHA256)) ||
@@ -366,7 +459,7 @@ public:
                 (d.cls == vmc::C_ECALL && m_.reg(17) == zkhip::native::CALL_EXT && r.n_next() + 1 > caps_.rows(vmc::A_NATIVE_EXT)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == zkhip::native::CALL_CASTF && r.n_castf() + 1 > caps_.rows(vmc::A_CASTF)) ||
                 path_nodes_.size() + new_nodes > caps_.rows(vmc::A_MERKLE) ||
-                2 * (blk_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2)) {
+                2 * (blk_.size() + new_blocks + path_nodes_.size() + new_nodes) > caps_.rows(vmc::A_POSEIDON2))) {
                 if (r.n_instr == 0) throw Error("segment heights too small for a single instruction");
                 break;
             }
@@ -422,9 +515,23 @@ public:
                 for (uint32_t j = 0; j < 24; j++) sha_in[j] = mem_word(y + 4 * j), (void)block_of(2, (y >> 2) + j);
             }
             const size_t n_ls_before = r.core.ls_case.size();
-            m_.step_one(&r.core);
+            m_.step_one(MODE == METER ? nullptr : &r.core);
             uint32_t z = 0, pc_inc;
-            if (d.cls == vmc::C_ECALL) {
+            if (MODE == METER && d.cls == vmc::C_ECALL) {
+                // the metered pass keeps the COUNTS the cut rule reads (one entry per call), none of the rows
+                if (m_.done() && m_.exit_code()) throw Error("guest exited with code " + std::to_string(m_.exit_code()));
+                z = x == 2 ? m_.last_result() : y;
+                pc_inc = 4;
+                if (x == 3) r.kk_ts.push_back(ts);
+                if (x == 4) r.sha_ts.push_back(ts);
+                if (x == 5) r.mm_ts[a1 & 7u].push_back(ts);
+                if (x == 6) (a1 == 5 ? r.mul256_ts : a1 > 8 ? r.sh256_ts : a1 > 5 ? r.cmp256_ts : r.i256_ts).push_back(ts);
+                if (x == 7) r.ec_ts[a1 & 7u].push_back(ts);
+                if (x == 8) r.fp2_ts[a1 & 7u].push_back(ts);
+                if (x == zkhip::native::CALL_ARITH) r.nat_records.resize(r.nat_records.size() + SegmentRecords::NAT_RECORD);
+                if (x == zkhip::native::CALL_EXT) r.next_records.resize(r.next_records.size() + SegmentRecords::NEXT_RECORD);
+                if (x == zkhip::native::CALL_CASTF) r.castf_records.resize(r.castf_records.size() + SegmentRecords::CASTF_RECORD);
+            } else if (d.cls == vmc::C_ECALL) {
                 z = x == 2 ? m_.last_result() : y;
                 pc_inc = m_.done() ? vmc::field_of(-(int32_t)pc) : 4;
                 if (m_.done() && m_.exit_code()) throw Error("guest exited with code " + std::to_string(m_.exit_code()));
@@ -577,38 +684,45 @@ public:
                 z = has_result ? m_.last_result() : 0;
                 pc_inc = vmc::field_of((int32_t)(m_.pc() - pc));
             }
-            if (d.cls == vmc::C_LS) {
+            if (MODE != METER && d.cls == vmc::C_LS) {
                 if (r.core.ls_case.size() != n_ls_before + 1) throw Error("internal: load/store record missing");
                 r.ls_ts.push_back(ts), r.ls_base.push_back(x), r.ls_imm.push_back(imm32);
                 const bool store = d.op >= 3 && d.op <= 5;
                 r.ls_pts.push_back(store ? write_word(2, addr >> 2, mem_word(addr & ~3u), ts + 4) : read_word(2, addr >> 2, word_before, ts + 4));
             }
             const uint32_t pts3 = d.wr_rd ? write_word(1, d.rd, z, ts + 12) : 0;
-            const size_t row = r.n_instr;
-            fp1[row] = pts1, fp2[row] = pts2, fp3[row] = pts3;
-            fx[row] = x, fy[row] = y, fz[row] = z, frd[row] = d.wr_rd ? rd_prev : 0, fpc[row] = pc_inc;
+            if (MODE != METER) {
+                const size_t row = r.n_instr;
+                fp1[row] = pts1, fp2[row] = pts2, fp3[row] = pts3;
+                fx[row] = x, fy[row] = y, fz[row] = z, frd[row] = d.wr_rd ? rd_prev : 0, fpc[row] = pc_inc;
+            }
             n_cls[d.cls]++;
             r.n_instr++;
         }
+        if (MODE == REPLAY && (r.n_instr != plan->n_instr || m_.done() != plan->last || (m_.done() ? 0 : m_.pc()) != plan->pc_end))
+            throw Error("internal: the record pass of segment " + std::to_string(plan->index) + " left the metered pass's path");
         r.pc_end = m_.done() ? 0 : m_.pc();
         r.ts_end = 1 + vmc::TS_STEP * (uint32_t)r.n_instr;
+        if (MODE == METER) {   // the close is meter_close's (possibly another thread's): hand the touched blocks over
+            finish_blocks();
+            detach_blocks(plan->job);
+            return m_.done();
+        }
         {
             const auto t0 = std::chrono::steady_clock::now();
-            close_memory(r);
+            if (MODE == REPLAY) close_replay(r, *plan);
+            else close_memory(r);
             close_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
         return m_.done();
     }
 
-private:
     const Exe& exe_;
     Machine m_;
     SegmentCaps caps_;
     MemoryTree tree_;
     Digest image_root_{};
-    struct Block {
-        uint32_t init[8], cur[8], ts[4];   // cells 2 j, 2 j + 1 = the halves of word j; ts[j] = the word's last access in this segment
-    };
+    using Block = MemBlock;
     // touched blocks of the current segment: dense storage + direct-mapped slot tables (registers, public values, the guest's
     // read-write region) so that the common lookup is an array access; anything else (addresses outside the region) goes through a map
     std::vector<Block> blk_;
@@ -619,6 +733,8 @@ private:
     std::unordered_map<uint32_t, uint32_t> other_slot_;
     std::unordered_set<uint64_t> path_nodes_;        // internal nodes above them
     std::vector<vmc::Decoded> dec_;
+    std::vector<uint8_t> dec_regmask_;
+    uint32_t reg_known_ = 0;   // register blocks touched in this segment (bit = block)
     double close_seconds_ = 0;
 
     uint32_t* slot_of(uint32_t label, bool create) {
@@ -629,6 +745,11 @@ private:
         if (create) return &other_slot_[label];
         auto it = other_slot_.find(label);
         return it == other_slot_.end() ? nullptr : &it->second;
+    }
+    // (a block of the guest's read-write region: the direct-mapped table alone -- anything else is "not known" and takes the general path)
+    bool mem_block_known(uint32_t blk) const {
+        const uint32_t off = blk - mem_lo_blk_;
+        return off < mem_slot_.size() && mem_slot_[off] != 0;
     }
     bool touched(uint32_t label) {
         const uint32_t* s = slot_of(label, false);
@@ -646,6 +767,7 @@ private:
         other_slot_.clear();
         blk_.clear(), blk_label_.clear(), path_nodes_.clear();
         memset(reg_ts_, 0, sizeof reg_ts_);
+        reg_known_ = 0;
     }
 
     uint32_t mem_word(uint32_t addr) const { return m_.peek_word(addr); }
@@ -685,6 +807,7 @@ private:
         }
         blk_.push_back(b), blk_label_.push_back(label);
         *slot_of(label, true) = (uint32_t)blk_.size();
+        if (as == 1 && (word >> 2) < 8) reg_known_ |= 1u << (word >> 2);
         return blk_.back();
     }
     // A block is snapshotted at its first touch in the segment, which must happen BEFORE the machine executes an instruction that
@@ -719,14 +842,35 @@ private:
         return prev;
     }
 
+    // The close of a RECORD pass: rows and roots are the metered pass's (it owns the tree); this pass contributes the words' last-access
+    // timestamps (leaf-row columns 18..21) and checks that it touched the same blocks with the same initial and final cells.
+    void close_replay(SegmentRecords& r, const SegmentPlan& plan) {
+        const size_t nL = blk_label_.size();
+        if (plan.leaf_rows.size() != nL * vmc::LEAF_WIDTH) throw Error("internal: the record pass of segment " + std::to_string(plan.index) + " touched other blocks than the metered pass");
+        finish_blocks();
+        std::vector<std::pair<uint32_t, uint32_t>> order(nL);
+        for (size_t i = 0; i < nL; i++) order[i] = {blk_label_[i], (uint32_t)i};
+        std::sort(order.begin(), order.end());
+        r.leaf_rows = plan.leaf_rows, r.merkle_rows = plan.merkle_rows, r.p2_inputs = plan.p2_inputs;
+        for (size_t i = 0; i < nL; i++) {
+            uint32_t* row = &r.leaf_rows[i * vmc::LEAF_WIDTH];
+            const Block& b = blk_[order[i].second];
+            bool same = ((row[0] << vmc::LABEL_BITS) | row[1]) == order[i].first;
+            for (int j = 0; j < 8; j++) same = same && row[2 + j] == b.init[j] && row[10 + j] == b.cur[j];
+            if (!same) throw Error("internal: the record pass of segment " + std::to_string(plan.index) + " and the metered pass disagree on a touched block");
+            for (int j = 0; j < 4; j++) row[18 + j] = b.ts[j];
+        }
+        r.root_final = plan.root_final;
+    }
+
     // leaf rows, merkle rows, Poseidon2 requests; commits the segment's final memory to the tree.  A memory-bound guest touches thousands
     // of blocks per segment (4096 blocks + 4100 path nodes in the guest of tools/guest_bench2.py `mem`): the hashes go sixteen at a time
     // through zkhip_poseidon2_permute16_host, levels are walked over SORTED index arrays (a parent's touched children are neighbours),
     // rows are built side by side; the tree itself (a hash map) is only read until every level is done.
-    void close_memory(SegmentRecords& r) {
+    // every touched block's FINAL cells are the machine's words now (read_word / write_word keep timestamps only); the register blocks'
+    // timestamps come from reg_ts_
+    void finish_blocks() {
         const size_t nL = blk_label_.size();
-        // every touched block's FINAL cells are the machine's words now (read_word / write_word keep timestamps only); the register blocks'
-        // timestamps come from reg_ts_
         for (size_t i = 0; i < nL; i++) {
             const uint32_t label = blk_label_[i], as = label >> vmc::LABEL_BITS, blk = label & ((1u << vmc::LABEL_BITS) - 1);
             Block& b = blk_[i];
@@ -736,6 +880,34 @@ private:
                 if (as == 1 && blk < 8) b.ts[j] = reg_ts_[4 * blk + j];
             }
         }
+    }
+    // the segment's touched blocks leave this executor (their slots are freed: the next segment starts clean)
+    void detach_blocks(CloseJob& job) {
+        for (uint32_t label : blk_label_) {
+            uint32_t* s = slot_of(label, false);
+            if (s) *s = 0;
+        }
+        other_slot_.clear();
+        job.blk = std::move(blk_), job.label = std::move(blk_label_), job.n_path = path_nodes_.size();
+        blk_.clear(), blk_label_.clear(), path_nodes_.clear();
+        memset(reg_ts_, 0, sizeof reg_ts_);
+        reg_known_ = 0;
+    }
+    void close_memory(SegmentRecords& r) {
+        finish_blocks();
+        CloseJob job;
+        job.blk.swap(blk_), job.label.swap(blk_label_), job.n_path = path_nodes_.size();
+        struct GiveBack {   // (reset_blocks frees the slots from the labels at the start of the next segment)
+            SegmentExecutor& ex;
+            CloseJob& job;
+            ~GiveBack() { ex.blk_.swap(job.blk), ex.blk_label_.swap(job.label); }
+        } give_back{*this, job};
+        close_job(job, r);
+    }
+    void close_job(const CloseJob& job, SegmentRecords& r) {
+        const std::vector<Block>& blk_ = job.blk;
+        const std::vector<uint32_t>& blk_label_ = job.label;
+        const size_t nL = blk_label_.size();
         std::vector<std::pair<uint32_t, uint32_t>> order(nL);   // (label, index into blk_)
         for (size_t i = 0; i < nL; i++) order[i] = {blk_label_[i], (uint32_t)i};
         std::sort(order.begin(), order.end());
@@ -829,7 +1001,7 @@ private:
             });
             c_idx = &L.idx, c_fin = &L.fin;
         }
-        if (n_nodes != path_nodes_.size()) throw Error("internal: the touched path nodes and the touched blocks' ancestors differ");
+        if (n_nodes != job.n_path) throw Error("internal: the touched path nodes and the touched blocks' ancestors differ");
         // the root's row goes first in the chip; two Poseidon2 requests per row (initial children, final children)
         r.merkle_rows.clear();
         r.merkle_rows.reserve(n_nodes * vmc::MERKLE_WIDTH);
@@ -861,6 +1033,216 @@ private:
             });
         for (size_t i = 0; i < n / nt; i++) f(i);
         for (auto& t : th) t.join();
+    }
+};
+// The PARALLEL executor: a metered first pass on one thread (SegmentExecutor::meter_segment: the interpreter without a record sink plus
+// the cut rule, ~3-4 x the speed of the recording executor) decides where every segment ends, snapshots the machine there and keeps the
+// persistent memory tree; `threads` record passes (SegmentExecutor::replay_segment, each on a machine of its own) replay the planned
+// segments side by side and hand them out IN ORDER.  The segments, cut points and records are those of the serial SegmentExecutor byte for
+// byte (tests/test_exec_parallel_cpu.py).  This is how the reference's stack executes: execute_metered_cost first
+// (crates/prover/src/utils/vm.rs:19), then OpenVM replays the segments; host parallelism is a first-class tool there
+// (crates/integration/src/testers/chunk.rs:352-368).  threads == 0: the serial executor on the caller's thread, as before.
+class ParallelSegmentExecutor {
+public:
+    ParallelSegmentExecutor(const Exe& exe, const StdIn& in, const SegmentCaps& caps, unsigned threads)
+        : exe_(exe), in_(in), caps_(caps), meter_(exe, in, caps), n_workers_(threads), window_(2 * (size_t)threads + 2) {
+        if (!n_workers_) return;
+        meter_.machine().track_dirty(true);
+        pos_.assign(n_workers_, 0);
+        busy_.assign(n_workers_, 0.0);
+        meter_thread_ = std::thread([this] { meter_loop(); });
+        closer_thread_ = std::thread([this] { closer_loop(); });
+        for (unsigned w = 0; w < n_workers_; w++) workers_.emplace_back([this, w] { worker_loop(w); });
+    }
+    ~ParallelSegmentExecutor() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (meter_thread_.joinable()) meter_thread_.join();
+        if (closer_thread_.joinable()) closer_thread_.join();
+        for (auto& t : workers_) t.join();
+    }
+    ParallelSegmentExecutor(const ParallelSegmentExecutor&) = delete;
+    ParallelSegmentExecutor& operator=(const ParallelSegmentExecutor&) = delete;
+
+    // the next segment, in order; true once the guest has exited.  `r`'s storage is recycled.
+    bool run_segment(SegmentRecords& r) {
+        if (!n_workers_) return meter_.run_segment(r);
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return failed_ || ready_.count(delivered_); });
+        if (failed_ && !ready_.count(delivered_)) throw Error(error_);
+        auto it = ready_.find(delivered_);
+        std::swap(r, it->second.rec);
+        const bool last = it->second.last;
+        free_.push_back(std::move(it->second.rec));
+        ready_.erase(it);
+        delivered_++;
+        lk.unlock();
+        cv_.notify_all();
+        return last;
+    }
+    // (the end state is the metered machine's: valid once run_segment has returned true)
+    const Digest& image_root() const { return meter_.image_root(); }
+    const MemoryTree& tree() const { return meter_.tree(); }
+    bool done() const { return meter_.done(); }
+    uint64_t instret() const { return meter_.instret(); }
+    uint32_t exit_code() const { return meter_.exit_code(); }
+    const std::vector<uint8_t>& public_values() const { return meter_.public_values(); }
+    uint32_t peek_memory(uint32_t addr) const { return meter_.peek_memory(addr); }
+    double close_seconds() const { return meter_.close_seconds(); }
+    unsigned threads() const { return n_workers_; }
+    // busy seconds of the metered pass / summed over the record passes (0 for the serial executor)
+    double metered_seconds() const { return meter_busy_; }
+    double tree_seconds() const { return closer_busy_; }
+    double record_seconds() const {
+        double s = 0;
+        for (double b : busy_) s += b;
+        return s;
+    }
+
+private:
+    using clk = std::chrono::steady_clock;
+    struct Ready {
+        SegmentRecords rec;
+        bool last = false;
+    };
+    const Exe& exe_;
+    const StdIn& in_;
+    SegmentCaps caps_;
+    SegmentExecutor meter_;
+    unsigned n_workers_;
+    size_t window_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false, failed_ = false, metered_all_ = false;
+    std::string error_;
+    std::map<size_t, std::shared_ptr<SegmentPlan>> plans_;                                // produced, not yet replayed
+    std::map<size_t, std::shared_ptr<const std::vector<Machine::Page>>> pages_;          // per plan index, until every worker is past it
+    std::map<size_t, Ready> ready_;
+    std::vector<SegmentRecords> free_;
+    std::vector<size_t> pos_;        // per worker: the cut its machine's memory stands at
+    std::vector<double> busy_;
+    size_t produced_ = 0, next_claim_ = 0, delivered_ = 0;
+    double meter_busy_ = 0;
+    std::deque<std::shared_ptr<SegmentPlan>> to_close_;   // run by the metered pass, their memory close pending (in order)
+    size_t metered_ = 0;                                  // plans the metered pass has run
+    bool meter_finished_ = false;
+    double closer_busy_ = 0;
+    std::thread meter_thread_, closer_thread_;
+    std::vector<std::thread> workers_;
+
+    void fail(const std::string& what) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!failed_) failed_ = true, error_ = what;
+        }
+        cv_.notify_all();
+    }
+    // the machine: runs ahead of the record passes by at most `window_` segments
+    void meter_loop() {
+        try {
+            for (bool done = false; !done;) {
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return stop_ || failed_ || metered_ - delivered_ < window_; });
+                    if (stop_ || failed_) return;
+                }
+                auto plan = std::make_shared<SegmentPlan>();
+                const auto t0 = clk::now();
+                done = meter_.meter_run(*plan);
+                meter_busy_ += std::chrono::duration<double>(clk::now() - t0).count();
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    plan->index = metered_++;
+                    to_close_.push_back(std::move(plan));
+                    meter_finished_ = done;
+                }
+                cv_.notify_all();
+            }
+        } catch (const std::exception& e) {
+            fail(e.what());
+        }
+    }
+    // the persistent memory tree: one plan behind the machine, on a thread of its own (a memory-bound guest hashes ~8 k nodes per segment)
+    void closer_loop() {
+        try {
+            for (;;) {
+                std::shared_ptr<SegmentPlan> plan;
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return stop_ || failed_ || !to_close_.empty() || meter_finished_; });
+                    if (stop_ || failed_) return;
+                    if (to_close_.empty()) return;   // (the metered pass has finished and everything is closed)
+                    plan = std::move(to_close_.front());
+                    to_close_.pop_front();
+                }
+                const auto t0 = clk::now();
+                meter_.meter_close(*plan);
+                closer_busy_ += std::chrono::duration<double>(clk::now() - t0).count();
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    const bool last = plan->last;
+                    pages_[produced_] = plan->pages;
+                    plans_[produced_] = std::move(plan);
+                    produced_++;
+                    metered_all_ = last;
+                }
+                cv_.notify_all();
+            }
+        } catch (const std::exception& e) {
+            fail(e.what());
+        }
+    }
+    void worker_loop(unsigned w) {
+        try {
+            SegmentExecutor ex(exe_, in_, caps_, /*replay_only=*/true);
+            for (;;) {
+                std::shared_ptr<SegmentPlan> plan;
+                std::vector<std::shared_ptr<const std::vector<Machine::Page>>> catch_up;
+                size_t target;
+                SegmentRecords rec;
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    // a claim, or -- for a worker that has been idle for a while -- catching its memory up with the cuts the others have
+                    // taken, so that the pages of old cuts can be dropped
+                    cv_.wait(lk, [&] { return stop_ || failed_ || next_claim_ < produced_ || next_claim_ > pos_[w] + 8 || (metered_all_ && next_claim_ == produced_); });
+                    if (stop_ || failed_) return;
+                    if (next_claim_ < produced_) {
+                        target = next_claim_++;
+                        plan = plans_.at(target);
+                        plans_.erase(target);
+                        if (!free_.empty()) rec = std::move(free_.back()), free_.pop_back();
+                    } else if (next_claim_ > pos_[w] + 8) {
+                        target = next_claim_ - 1;   // (every segment below next_claim_ is someone else's: this worker's next claim lies at or beyond it)
+                    } else {
+                        return;   // every segment has been claimed
+                    }
+                    for (size_t i = pos_[w] + 1; i <= target; i++) catch_up.push_back(pages_.at(i));
+                }
+                const auto t0 = clk::now();
+                for (const auto& pg : catch_up) ex.machine().apply_pages(*pg);
+                bool last = false;
+                if (plan) last = ex.replay_segment(*plan, rec);
+                const double dt = std::chrono::duration<double>(clk::now() - t0).count();
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    busy_[w] += dt;
+                    pos_[w] = plan ? target + 1 : target;
+                    if (plan) {
+                        Ready& slot = ready_[target];
+                        slot.rec = std::move(rec), slot.last = last;
+                    }
+                    size_t low = pos_[0];
+                    for (size_t p : pos_) low = std::min(low, p);
+                    while (!pages_.empty() && pages_.begin()->first <= low) pages_.erase(pages_.begin());
+                }
+                cv_.notify_all();
+            }
+        } catch (const std::exception& e) {
+            fail(e.what());
+        }
     }
 };
 

@@ -115,3 +115,19 @@ def test_guest_flow_loop_with_self_check(tmp_path):
         assert line["retry_enabled"] is False and line["segments_retried"] == 0 and line["segments_retried_detail"] == [], line
         segments += line["segments"]
     assert segments > 300
+
+
+def test_a_retried_segment_is_counted_and_without_the_retry_it_ends_the_run(tmp_path):
+    """FlowOptions::retry_segments: a segment proof that fails once is made again AND counted in the flow's line (segment index + message);
+    with ZKHIP_NO_RETRY=1 the same failure ends the run.  The failure is injected (ZKHIP_TEST_FAIL_SEGMENT)."""
+    cli = os.path.join(ROOT, "zkvm-prover_amd", "prove_cli")
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "make_guest_files.py"), str(tmp_path), "300000"], stdout=subprocess.DEVNULL)
+    open(tmp_path / "stdin.bin", "wb").write((60000).to_bytes(4, "little"))
+    cmd = [cli, "prove-elf", str(tmp_path / "fib.elf"), str(tmp_path / "stdin.bin"), str(tmp_path), "-", "14"]
+    r = subprocess.run(cmd, env=dict(os.environ, ZKHIP_TEST_FAIL_SEGMENT="3"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["verified"] is True and line["retry_enabled"] is True and line["segments_retried"] == 1, line
+    assert line["segments_retried_detail"] == [{"segment": 3, "message": "injected failure (FlowOptions::fail_segment_once)"}], line
+    r = subprocess.run(cmd, env=dict(os.environ, ZKHIP_TEST_FAIL_SEGMENT="3", ZKHIP_NO_RETRY="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "injected failure" in r.stderr, r.stderr[-3000:]

@@ -1,7 +1,7 @@
 // exec_bench.cpp -- the segmenting executor alone (include/zkhip_vm_exec.hpp), no GPU needed (libzkhip for the host Poseidon2): instructions per second of `run_segment` over a guest,
 // the stage that bounds the guest flow once frames are 2^19 instructions (docs/round5.md).  Host only.
 //   g++ -O2 -std=c++17 -pthread -I include tools/exec_bench.cpp -o /tmp/exec_bench -Lzkvm-prover_amd -lzkhip -Wl,-rpath,$PWD/zkvm-prover_amd
-//   /tmp/exec_bench <guest.elf> <stdin.bin | -> [log_frame = 19] [repeats = 3]
+//   /tmp/exec_bench <guest.elf> <stdin.bin | -> [log_frame = 19] [repeats = 3] [record threads = 0: the serial executor; n: metered pass + n record passes]
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -20,7 +20,7 @@ static std::vector<uint8_t> slurp(const char* p) {
 
 int main(int argc, char** argv) {
     if (argc < 3) return 2;
-    const unsigned log_frame = argc > 3 ? (unsigned)atoi(argv[3]) : 19, reps = argc > 4 ? (unsigned)atoi(argv[4]) : 3;
+    const unsigned log_frame = argc > 3 ? (unsigned)atoi(argv[3]) : 19, reps = argc > 4 ? (unsigned)atoi(argv[4]) : 3, threads = argc > 5 ? (unsigned)atoi(argv[5]) : 0;
     const zkhip_vm::Exe exe = zkhip_vm::parse_exe(slurp(argv[1]));
     zkhip_vm::StdIn in;
     if (std::string(argv[2]) != "-") in.bytes = slurp(argv[2]);
@@ -35,7 +35,29 @@ int main(int argc, char** argv) {
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::printf("{\"interpreter_alone_instr_per_s\": %.0f}\n", m.instret() / s);
     }
-    for (unsigned rep = 0; rep < reps; rep++) {
+    if (threads) {   // the metered pass alone: the ceiling of the parallel executor
+        zkhip_vm::SegmentExecutor ex(exe, in, caps);
+        ex.machine().track_dirty(true);
+        const auto t0 = std::chrono::steady_clock::now();
+        size_t k = 0;
+        for (bool done = false; !done; k++) {
+            zkhip_vm::SegmentPlan plan;
+            done = ex.meter_segment(plan);
+        }
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("{\"metered_pass_alone_instr_per_s\": %.0f, \"segments\": %zu}\n", ex.instret() / s, k);
+    }
+    for (unsigned rep = 0; rep < reps && threads; rep++) {
+        zkhip_vm::ParallelSegmentExecutor ex(exe, in, caps, threads);
+        zkhip_vm::SegmentRecords r;
+        size_t k = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (bool done = false; !done; k++) done = ex.run_segment(r);
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("{\"segments\": %zu, \"instructions\": %llu, \"seconds\": %.3f, \"instr_per_s\": %.0f, \"record_threads\": %u, \"metered_pass_busy_s\": %.3f, \"record_passes_busy_s_sum\": %.3f}\n", k,
+                    (unsigned long long)ex.instret(), s, ex.instret() / s, threads, ex.metered_seconds(), ex.record_seconds());
+    }
+    for (unsigned rep = 0; rep < reps && !threads; rep++) {
         zkhip_vm::SegmentExecutor ex(exe, in, caps);
         zkhip_vm::SegmentRecords r;
         size_t k = 0;

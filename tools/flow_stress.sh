@@ -6,6 +6,7 @@
 # (e.g. FLOW_STRESS_ENV=ZKHIP_SELF_CHECK=1) -- the form that found the stored tree node of DESIGN.md 15 (3 % of runs before the change).
 # With a frame the runs also carry ZKHIP_NO_RETRY=1 (a failed segment proof ends the run instead of being made once more), and every run's
 # JSON line is read: "retried" sums `segments_retried` over the runs and must stay 0 -- a retried wrong node cannot pass for a clean run.
+# FLOW_STRESS_RETRY=1 leaves the retry on (to show that the counter sees what the retry would otherwise hide).
 # FLOW_STRESS_LIB=test runs prove_cli over libzkhip_test.so (LD_PRELOAD; the A/B bodies of ZKHIP_TREE_STORE_EARLY exist only there).
 cd ${GRAFT_REPO_ROOT:-.}
 N=${1:-60}
@@ -21,7 +22,7 @@ for i in $(seq 1 $N); do
   cfg=-; [ $((i % 5)) = 0 ] && cfg=/tmp/fs_chunk.toml
   lf=17; [ $((i % 3)) = 0 ] && lf=14
   env="ZKHIP_X=1"; [ $((i % 7)) = 0 ] && env="ZKHIP_DEVICES=0,0"
-  if [ -n "$FRAME" ]; then lf=$FRAME; env="$env ZKHIP_VERIFY_SEGMENTS=1 ZKHIP_NO_RETRY=1 $FLOW_STRESS_ENV"; fi
+  if [ -n "$FRAME" ]; then lf=$FRAME; env="$env ZKHIP_VERIFY_SEGMENTS=1 $FLOW_STRESS_ENV"; [ -z "$FLOW_STRESS_RETRY" ] && env="$env ZKHIP_NO_RETRY=1"; fi
   out=/tmp/fs/o$i; mkdir -p $out
   if env $env $PRE timeout 300 ./zkvm-prover_amd/prove_cli prove-elf /tmp/fs/fib.elf /tmp/fs/stdin.bin $out $cfg $lf > $out/log.json 2> $out/err.txt \
      && ./zkvm-prover_amd/prove_cli verify-guest /tmp/fs/fib.elf $out/root.vk $([ $cfg = - ] && echo $out/openvm.toml || echo $cfg) $out/root.json > /dev/null 2>> $out/err.txt; then
@@ -35,4 +36,4 @@ for i in $(seq 1 $N); do
   fi
   rm -rf $out
 done
-echo "{\"runs\": $N, \"verified\": $ok, \"failed\": $bad, \"segments_retried\": $retried, \"segment_proofs\": $segs, \"library\": \"${FLOW_STRESS_LIB:-shipped}\", \"seconds\": $(( $(date +%s) - t0 )), \"frame\": \"$FRAME\", \"env\": \"$FLOW_STRESS_ENV\"}" | tee gpurun_out/flow_stress${FLOW_STRESS_TAG:+_$FLOW_STRESS_TAG}.json
+echo "{\"runs\": $N, \"verified\": $ok, \"failed\": $bad, \"segments_retried\": $retried, \"segment_proofs\": $segs, \"library\": \"${FLOW_STRESS_LIB:-shipped}\", \"retry\": \"${FLOW_STRESS_RETRY:-off}\", \"seconds\": $(( $(date +%s) - t0 )), \"frame\": \"$FRAME\", \"env\": \"$FLOW_STRESS_ENV\"}" | tee gpurun_out/flow_stress${FLOW_STRESS_TAG:+_$FLOW_STRESS_TAG}.json
