@@ -1188,17 +1188,36 @@ private:
         for (const ShapePolicy& q : policy_) words.push_back(q.arity), words.push_back(q.wrapped ? 1u : 0u);
         for (const auto& q : spec_.start) words.push_back(q.first), words.push_back(q.second);
         for (const auto& q : spec_.end) words.push_back(q.first), words.push_back(q.second);
-        {   // the builder's identity: size and modification time of the loaded library
-            Dl_info info;
-            struct stat st;
-            if (dladdr((const void*)&zkhip_recursion_build, &info) && info.dli_fname && stat(info.dli_fname, &st) == 0)
-                words.push_back((uint32_t)st.st_size), words.push_back((uint32_t)st.st_mtime), words.push_back((uint32_t)((uint64_t)st.st_mtime >> 32));
+        {   // the builder's identity: the CONTENT of the loaded library (size + a 64-bit hash of its bytes, once per process) and its version --
+            // not its modification time: reproducible builds and images fix the mtime, and a cache directory may travel between boxes
+            // 
+            static const std::array<uint32_t, 4> id = [] {
+                std::array<uint32_t, 4> out{0, 0, 0, (uint32_t)zkhip_version()};
+                Dl_info info;
+                if (!dladdr((const void*)&zkhip_recursion_build, &info) || !info.dli_fname) return out;
+                FILE* f = std::fopen(info.dli_fname, "rb");
+                if (!f) return out;
+                uint64_t h = 1469598103934665603ull, n = 0;   // FNV-1a over 8-byte words (the tail byte-wise)
+                std::vector<unsigned char> buf(1 << 20);
+                for (size_t got; (got = std::fread(buf.data(), 1, buf.size(), f)) > 0; n += got)
+                    for (size_t i = 0; i < got; i++) h = (h ^ buf[i]) * 1099511628211ull;
+                std::fclose(f);
+                out[0] = (uint32_t)n, out[1] = (uint32_t)h, out[2] = (uint32_t)(h >> 32);
+                return out;
+            }();
+            words.insert(words.end(), id.begin(), id.end());
         }
         for (uint32_t& w : words) w %= 0x78000001u;
         const Digest8 h = p2_sponge8(words.data(), words.size());
         char name[96];
         std::snprintf(name, sizeof name, "/agg_%08x%08x%08x%08x.key", h[0], h[1], h[2], h[3]);
         return dir + name;
+    }
+    static constexpr uint32_t AGG_CACHE_MAGIC = 0x41474B45u;
+    static Digest8 agg_cache_digest(const uint32_t* w, size_t n) {
+        std::vector<uint32_t> r(w, w + n);
+        for (uint32_t& x : r) x %= 0x78000001u;
+        return p2_sponge8(r.data(), r.size());
     }
     AggCache load_agg_cache(const std::vector<uint32_t>& app_id) const {
         AggCache c;
@@ -1207,10 +1226,21 @@ private:
         FILE* f = std::fopen(c.path.c_str(), "rb");
         if (!f) return c;
         const size_t S = apps_.size();
-        std::vector<uint32_t> w(4 + 11 * S);
-        const bool ok = std::fread(w.data(), 4, w.size(), f) == w.size() && w[0] == 0x41474B44u && w[1] == S;
+        // [magic, S, H0, H1, per shape: natural heights (2), commitment (8), used (1)] + the Poseidon2 sponge of all that (8 words): a file of
+        // another length, with another magic or a body that does not hash to its last eight words is no cache at all (the setup builds
+        // every shape and rewrites it)
+        std::vector<uint32_t> w(4 + 11 * S + 8 + 1);
+        const size_t got = std::fread(w.data(), 4, w.size(), f);
         std::fclose(f);
-        if (!ok) return c;
+        bool ok = got == 4 + 11 * S + 8 && w[0] == AGG_CACHE_MAGIC && w[1] == S;
+        if (ok) {
+            const Digest8 d = agg_cache_digest(w.data(), 4 + 11 * S);
+            ok = std::equal(d.begin(), d.end(), w.begin() + 4 + 11 * S);
+        }
+        if (!ok) {
+            std::fprintf(stderr, "[zkhip aggregation] %s is not a key cache of this build (length, magic or digest): ignored and rewritten\n", c.path.c_str());
+            return c;
+        }
         c.h[0] = w[2], c.h[1] = w[3];
         for (size_t sh = 0; sh < S; sh++) {
             c.nat.push_back({w[4 + 11 * sh], w[5 + 11 * sh]});
@@ -1226,12 +1256,14 @@ private:
                          const std::vector<char>& used) const {
         if (path.empty()) return;
         const size_t S = apps_.size();
-        std::vector<uint32_t> w{0x41474B44u, (uint32_t)S, H[0], H[1]};
+        std::vector<uint32_t> w{AGG_CACHE_MAGIC, (uint32_t)S, H[0], H[1]};
         for (size_t sh = 0; sh < S; sh++) {
             w.push_back(nat[sh][0]), w.push_back(nat[sh][1]);
             w.insert(w.end(), leaf_list.begin() + 8 * sh, leaf_list.begin() + 8 * sh + 8);
             w.push_back(sh < used.size() && used[sh] ? 1u : 0u);
         }
+        const Digest8 d = agg_cache_digest(w.data(), w.size());
+        w.insert(w.end(), d.begin(), d.end());
         const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)getpid());
         if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
             const bool ok = std::fwrite(w.data(), 4, w.size(), f) == w.size();
@@ -1239,6 +1271,22 @@ private:
             if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
         }
     }
+public:
+    // Every shape whose commitment came from the key cache WITHOUT being recomputed in this process is built now and must commit to what the
+    // aggregation key states (ensure_leaf throws otherwise).  What a process does before it hands the key to someone ELSE -- a verifier, a
+    // parent guest's program commitment (UniversalProver::get_agg_vk / program_commitment): the flow's own root proof is verified under the
+    // key either way, but a stale cache would make that key differ from the one a cache-less process derives.
+    void verify_lazy_shapes() {
+        (void)root_vk();
+        size_t n;
+        {
+            std::lock_guard<std::mutex> lk(*levels_mu_);
+            n = lazy_.size();
+        }
+        for (size_t sh = 0; sh < n; sh++) ensure_leaf(sh);
+    }
+
+private:
     // a shape that was left out at setup: built now (its first segment proof has arrived), padded to the common heights, given its keys --
     // and it must commit to what the aggregation key already states
     void ensure_leaf(size_t sh) {

@@ -7,6 +7,13 @@
 // (zkvm-prover_amd/air.py field_arith_air / field_ext_air / castf_air, zkhip_field_arith_tracegen ...); round 5 puts them on the
 // execution and memory buses of the one-statement circuit (include/zkhip_vm_circuit.hpp: native_arith_air, native_ext_air, castf_vm_air).
 //
+// DEVIATION FROM OPENVM (stated, not hidden: ADVICE round 5).  openvm-native-circuit is not vendored, so this is recollection: besides the three
+// chips above, OpenVM's native extension is believed to bring a NATIVE ADDRESS SPACE with its own load / store, branch, jal and range-check
+// chips, and the FRI reduced-opening and Poseidon2 verify-batch chips its in-VM STARK verifier runs on.  None of those is built here.  The
+// three arithmetic chips sit behind CUSTOM ecalls (9 / 10 / 11) on the RV32 memory, not behind OpenVM's native opcodes: a guest that uses
+// openvm `verify_stark` (a native-address-space recursion program) cannot run on this executor.  `[app_vm_config.native]` is therefore
+// COVERED IN PART: its field arithmetic, not its instruction set (docs/gaps.md).
+//
 // Guest interface (environment calls, like the other intrinsics; a native field element is ONE memory word holding its canonical value):
 //   a7 = 9   native field:  r = a op b on the 3 words at a0 (a, b, then r's slot); a1 = op: 0 add, 1 sub, 2 mul, 3 div (b != 0)
 //   a7 = 10  native ext:    r = a op b on the 12 words at a0 (a[4], b[4], then r[4]), coefficients of 1, X, X^2, X^3; a1 = op as above

@@ -929,8 +929,11 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
 inline bool config_has_section(const std::string& path_app_config, const char* section) {
     std::ifstream f(path_app_config);
     std::string line;
-    while (std::getline(f, line))
-        if (line.find(section) != std::string::npos) return true;
+    // (a section HEADER: the line, trimmed, starts with it -- the name inside a comment or a value is not the section: ADVICE round 5)
+    while (std::getline(f, line)) {
+        const size_t b0 = line.find_first_not_of(" \t");
+        if (b0 != std::string::npos && line.compare(b0, strlen(section), section) == 0) return true;
+    }
     return false;
 }
 inline unsigned keccak_log_rows(const std::string& path_app_config, unsigned log_frame) {
@@ -1238,12 +1241,14 @@ public:
     // mod.rs:147-170 `get_agg_vk`: the key every proof of this prover verifies under (one aggregation key; with deferral: the join's)
     const VerifyingKey& get_agg_vk() {
         ensure();
+        agg_->verify_lazy_shapes();   // (the key leaves this process: nothing in it may rest on an unchecked cache file)
         const VerifyingKey& own = agg_->root_vk();
         return deferral_ ? deferral_->join_vk(own) : own;
     }
     // what a PARENT guest holds about this app (crates/types/circuit/src/lib.rs ProgramCommitment)
     ProgramCommitment program_commitment() {
         ensure();
+        agg_->verify_lazy_shapes();
         return ProgramCommitment::of(agg_->root_vk(), exe_.entry ? exe_.entry : exe_.pc_base, zkhip_vm::guest_image_root(exe_));
     }
     const zkhip_vm::GuestStark& last() const { return last_; }

@@ -53,19 +53,39 @@ def test_unused_shapes_are_not_built_and_the_key_does_not_change(tmp_path):
     assert pm.run_cli("verify-guest", str(elf), str(out2 / "root.vk"), str(tmp_path / "openvm.toml"), str(out2 / "root.json")).returncode == 0
 
 
-def _edit_cache(cache, forget=False, flip_last_commit=False):
-    """the cache file: [magic, S, H0, H1, then per shape: natural heights (2), commitment (8), used (1)]"""
+def _body_digest(words):
+    """the file's last eight words: the Poseidon2 sponge (overwrite 8, permute, no padding) of the body reduced mod p, through the library's host
+    permutation (zkhip_poseidon2_permute_host: no GPU work)"""
+    import ctypes as C
+
+    import zkvm_prover_amd as z
+
+    lib = z.load_library()
+    st = (C.c_uint32 * 16)()
+    for i in range(0, len(words), 8):
+        for k, v in enumerate(words[i:i + 8]):
+            st[k] = int(v) % 2013265921
+        lib.zkhip_poseidon2_permute_host(st)
+    return [st[k] for k in range(8)]
+
+
+def _edit_cache(cache, forget=False, flip_last_commit=False, fix_digest=True):
+    """the cache file: [magic, S, H0, H1, then per shape: natural heights (2), commitment (8), used (1)] + the body's digest (8 words);
+    fix_digest: the edited body gets a matching digest (what a stale file of another build, or a careful forger, would carry)"""
     import numpy as np
 
     f = next(cache.glob("agg_*.key"))
     w = np.frombuffer(f.read_bytes(), dtype=np.uint32).copy()
     S = int(w[1])
-    assert w.size == 4 + 11 * S
+    assert w.size == 4 + 11 * S + 8
+    assert [int(x) for x in w[-8:]] == _body_digest(w[:-8])
     if forget:
         for sh in range(S):
             w[4 + 11 * sh + 10] = 0
     if flip_last_commit:
         w[4 + 11 * (S - 1) + 9] ^= 1
+    if fix_digest:
+        w[-8:] = _body_digest(w[:-8])
     f.write_bytes(w.tobytes())
     return [int(w[4 + 11 * sh + 10]) for sh in range(S)]
 
@@ -99,7 +119,12 @@ def test_a_cached_shape_is_built_when_its_first_segment_arrives(tmp_path):
     assert third["total_cycles"] == model["instret"]
     assert pm.run_cli("verify-guest", str(elf), str(out3 / "root.vk"), str(tmp_path / "openvm.toml"), str(out3 / "root.json")).returncode == 0
     assert _edit_cache(cache) == [1 if n_ else 0 for n_ in first["segments_per_shape"]]          # ... and the file has learnt it again
-    # a cache file that states another commitment for a wide shape is caught: at setup when the shape is built there ...
+    # a corrupted file (its body no longer hashes to its digest) is no cache at all: every shape is built, the key is the same, the file rewritten
+    good = next(cache.glob("agg_*.key")).read_bytes()
+    _edit_cache(cache, flip_last_commit=True, fix_digest=False)
+    fourth, vk4, _ = prove(tmp_path, "corrupt", elf, stdin, 15, **env)
+    assert vk4 == vk1 and fourth["leaf_circuits_at_setup"] == len(first["chips_per_shape"]) and next(cache.glob("agg_*.key")).read_bytes() == good
+    # a cache file that states another commitment for a wide shape UNDER A VALID DIGEST is caught: at setup when the shape is built there ...
     _edit_cache(cache, flip_last_commit=True)
     out = tmp_path / "stale_setup"
     out.mkdir()
@@ -111,3 +136,29 @@ def test_a_cached_shape_is_built_when_its_first_segment_arrives(tmp_path):
     out.mkdir()
     r = subprocess.run([pm.CLI, "prove-elf", str(elf), str(stdin), str(out), str(tmp_path / "openvm.toml"), "15"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "stale key cache" in r.stderr
+
+
+def test_a_key_that_leaves_the_process_rests_on_no_unchecked_cache_entry(tmp_path):
+    """`prove_cli agg-vk` (UniversalProver::get_agg_vk: the key handed to a verifier or into a parent guest's program commitment) builds every
+    shape the cache would have left out and compares its commitment.  With a stale entry (valid digest, another commitment) for a shape the
+    guest never uses, a flow still ends -- its root verifies under the key it derived, which is NOT the key of a cache-less process --, but
+    the key that leaves the process is refused."""
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    (tmp_path / "openvm.toml").write_text(chunk_circuit_toml(PARAMS))
+    elf, stdin = tmp_path / "fib.elf", tmp_path / "stdin.bin"
+    elf.write_bytes(rv.elf_bytes(fib_program()))
+    stdin.write_bytes((20000).to_bytes(4, "little"))
+    env = dict(os.environ, ZKHIP_AGG_CACHE_DIR=str(cache))
+    _, vk1, _ = prove(tmp_path, "first", elf, stdin, 14, ZKHIP_AGG_CACHE_DIR=str(cache))
+
+    def agg_vk(name):
+        return subprocess.run([pm.CLI, "agg-vk", str(elf), str(tmp_path / "openvm.toml"), str(tmp_path / name), "14"], env=env, capture_output=True, text=True, timeout=900)
+
+    r = agg_vk("a.vk")
+    assert r.returncode == 0 and (tmp_path / "a.vk").read_bytes() == vk1, r.stderr[-2000:]
+    _edit_cache(cache, flip_last_commit=True)          # (the last shape: the 51-chip one, which a Fibonacci guest never uses)
+    _, vk2, _ = prove(tmp_path, "second", elf, stdin, 14, ZKHIP_AGG_CACHE_DIR=str(cache))
+    assert vk2 != vk1                                   # the flow's key follows the file: exactly why it must not be handed on unchecked
+    r = agg_vk("b.vk")
+    assert r.returncode != 0 and "stale key cache" in r.stderr, r.stderr[-2000:]

@@ -336,6 +336,17 @@ int main(int argc, char** argv) {
                         g.segments_retried.size(), retried_json(g.segments_retried).c_str());
             return 0;
         }
+        if (argc >= 5 && std::string(argv[1]) == "agg-vk") {
+            // agg-vk <guest.elf> <openvm.toml> <out root.vk> [log_frame = 20]: THE aggregation key of this app for someone else (a verifier, a
+            // parent guest's program commitment) -- crates/prover/src/prover/mod.rs:147-170 `get_agg_vk`.  Unlike a flow, which takes the
+            // commitments of shapes it does not use from the key cache, this builds every shape and refuses a cache entry that does not match.
+            const unsigned log_frame = argc >= 6 ? (unsigned)atoi(argv[5]) : 20;
+            UniversalProver up = UniversalProver::setup(ProverConfig{argv[2], argv[3]}, nullptr, 0, log_frame);
+            const std::vector<uint8_t> vkb = up.get_agg_vk().to_app_exe();
+            std::ofstream(argv[4], std::ios::binary).write((const char*)vkb.data(), (std::streamsize)vkb.size());
+            std::printf("{\"root_vk_bytes\": %zu}\n", vkb.size());
+            return 0;
+        }
         if (argc >= 5 && std::string(argv[1]) == "program-commit") {
             // program-commit <guest.elf | exe.bin> <root.vk> <openvm.toml>: what a PARENT guest holds about this app (crates/types/circuit/src/lib.rs
             // ProgramCommitment { exe, vm }; the reference generates it into crates/circuits/*-circuit/*_commit.rs): host only

@@ -2056,6 +2056,18 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     // six large chips lost 3 - 10 % when they were spread too)
     auto jit_blocks = [&](const AirPlan& A) { return A.jit_rows_per_block ? (unsigned)((A.MQ + 255) / 256) : (unsigned)std::min<size_t>(A.MQ / 64, 4 * 256); };
     unsigned n_jit = 0, fan = 0;
+    // (an error between fork and join returns from this function: the side streams are drained first -- buffers the next proof reuses may
+    // still be written by a kernel queued on them: ADVICE round 5)
+    struct DrainSideStreams {
+        zkhip_ctx* ctx;
+        const unsigned& fan;
+        bool joined = false;
+        ~DrainSideStreams() {
+            if (joined) return;
+            for (unsigned q = 0; q < fan; q++)
+                if (ctx->quot_streams[q]) (void)hipStreamSynchronize(ctx->quot_streams[q]);
+        }
+    } drain_side_streams{ctx, fan};
     for (size_t a = 0; a < n_airs; a++) n_jit += pk->airs[a].jit_fn && jit_blocks(pk->airs[a]) <= 2u * (unsigned)ctx->cu_count ? 1u : 0u;
     if (n_jit >= 3 && !ctx->profiling && ctx->cfg.quot_streams) {
         fan = std::min(4u, ctx->cfg.quot_streams);
@@ -2106,6 +2118,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
         ZK_HIP_CHECK(ctx, hipEventRecord(ctx->quot_join[q], ctx->quot_streams[q]));
         ZK_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->quot_join[q], 0));
     }
+    drain_side_streams.joined = true;
     // chunk j = rows [jN,(j+1)N) of q, bit-reversed within the chunk: bring to natural order (all chips, all chunks: one
     // launch per kernel form), then extend from s_j*H to g*K (shift g/s_j) -- p3's quotient-chunk commitment
     ZK_TRY(ntt_bitrev_copy_multi(ctx, pk->d_br_tiled, pk->br_n_tiled, pk->br_blocks_tiled, pk->d_br_small, pk->br_n_small,
