@@ -254,11 +254,82 @@ def guest_flow(chunk_config=False, memory_bound=False):
         return {"value": None, "note": "failed: %r" % (e,)}
 
 
+def guest_flow_devices(n, plumbing=False):
+    """SURVEY.md 8(e)(ii) beside 8(e)(i): ONE guest task over the N GPUs of the node (`FlowOptions::devices`, ZKHIP_DEVICES=0..N-1): the
+    Fibonacci guest with N times the one-GPU flow's instructions (weak, like the headline), three segment lanes and three node pipelines
+    per device, all fed by the one parallel executor (a metered pass + record passes, include/zkhip_vm_exec.hpp).  Reported: instructions
+    per second from the ELF to the verified root, segment proofs per device, tree nodes per device slot and the executor's share (busy
+    time of its slowest stage over the segment phase) -- on eight GPUs the executor is what a single task can become bound by.  The
+    reference proves a batch's chunks one after the other (crates/integration/src/testers/batch.rs:97-107).  Runs as a child process of a
+    process that has not touched the GPU: the launcher before it starts its ranks, or rank 0 under torch.distributed.run while the other
+    ranks wait for its flag file.  One warm-up run (keys for every device), one measured."""
+    import subprocess
+
+    devs = ",".join(str(d) for d in range(n))
+    here = os.path.dirname(os.path.abspath(__file__))
+    iters = 2800000 * n
+    command = "ZKHIP_DEVICES=%s ZKHIP_LANES=3 python tools/guest_bench2.py %d 20" % (devs, iters)
+    if plumbing:
+        return {"plumbing_only": True, "devices": list(range(n)), "value": None, "command": command}
+    try:
+        runs = []
+        for _ in range(2):
+            r = subprocess.run([sys.executable, os.path.join(here, "tools", "guest_bench2.py"), str(iters), "20"], capture_output=True, text=True,
+                               env=dict(os.environ, ZKHIP_DEVICES=devs, ZKHIP_LANES="3"), timeout=900)
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr[-300:])
+            runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        g = runs[-1]
+        secs = (g["segment_tracegen_and_proving_ms"] + g["aggregation_setup_wait_ms"] + g["aggregation_ms"]) / 1e3
+        lanes = g.get("lanes") or 3
+        per_lane = g.get("segments_per_lane") or []
+        per_dev = [sum(per_lane[d * lanes:(d + 1) * lanes]) for d in range(n)] if len(per_lane) == n * lanes else None
+        threads = max(1, g.get("executor_record_threads") or 1)
+        stage = max(g.get("executor_metered_pass_busy_ms") or 0, (g.get("executor_record_passes_busy_ms_sum") or 0) / threads, g.get("executor_memory_tree_busy_ms") or 0)
+        return {"metric": "guest_instructions_per_sec_elf_to_verified_root_one_task_over_n_gpus", "value": round(g["total_cycles"] / secs), "unit": "instr/s",
+                "devices": list(range(n)), "instructions": g["total_cycles"], "segments": g["segments"], "segments_per_device": per_dev,
+                "tree_nodes_per_device_slot": g.get("tree_nodes_per_device_slot"), "aggregation_levels": g["levels"],
+                "segments_ms": g["segment_tracegen_and_proving_ms"], "tree_tail_ms": g["aggregation_setup_wait_ms"] + g["aggregation_ms"],
+                "feeding_thread_waited_for_executor_ms": g["execution_ms"], "executor_record_threads": g.get("executor_record_threads"),
+                "executor_metered_pass_busy_ms": g.get("executor_metered_pass_busy_ms"), "executor_record_passes_busy_ms_sum": g.get("executor_record_passes_busy_ms_sum"),
+                "executor_share_of_segment_phase": round(stage / max(1, g["segment_tracegen_and_proving_ms"]), 3),
+                "segments_retried": g.get("segments_retried"), "process_wall_s": g["wall_s"], "process_wall_s_first_run": runs[0]["wall_s"],
+                "verified": g["verified"], "command": command}
+    except Exception as e:   # a reported extra, never a gate
+        return {"value": None, "devices": list(range(n)), "note": "failed: %r" % (e,), "command": command}
+
+
+def devices_flow_before_the_ranks_touch_the_gpu(args, plumbing):
+    """N > 1: the one-task-over-N-GPUs flow runs ONCE, while no rank uses a GPU: in the launcher (`python bench.py --gpus N`) before it
+    starts its ranks -- handed to them in ZKHIP_BENCH_DEVICES_FLOW --, or, under torch.distributed.run, in rank 0 before it loads torch,
+    the other ranks waiting for its flag file (named after MASTER_PORT) before they load theirs.  Returns the block (rank 0) or None."""
+    if args.no_guest_flow or args.gpus < 2:
+        return None
+    if "ZKHIP_BENCH_DEVICES_FLOW" in os.environ:
+        return json.loads(os.environ["ZKHIP_BENCH_DEVICES_FLOW"]) if os.environ.get("RANK", "0") == "0" else None
+    if os.environ.get("ZKHIP_BENCH_DRYRUN_1GPU") == "1":
+        return None
+    flag = "/tmp/zkhip_bench_devices_%s.json" % os.environ.get("MASTER_PORT", "0")
+    if os.environ.get("RANK", "0") == "0":
+        block = guest_flow_devices(args.gpus, plumbing)
+        with open(flag + ".tmp", "w") as f:
+            json.dump(block, f)
+        os.replace(flag + ".tmp", flag)
+        return block
+    t0 = time.time()
+    while not os.path.exists(flag) and time.time() - t0 < 1200:
+        time.sleep(0.2)
+    return None
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not args.no_guest_flow and os.environ.get("ZKHIP_BENCH_DRYRUN_1GPU") != "1":
+            os.environ["ZKHIP_BENCH_DEVICES_FLOW"] = json.dumps(guest_flow_devices(args.gpus, os.environ.get("ZKHIP_BENCH_PLUMBING_ONLY") == "1"))
         sys.exit(spawn_ranks(args))
     plumbing = os.environ.get("ZKHIP_BENCH_PLUMBING_ONLY") == "1"
+    guest_devices = devices_flow_before_the_ranks_touch_the_gpu(args, plumbing) if "torch" not in sys.modules else None
     guest = guest_chunk = guest_mixed = guest_mem = None
     # (child processes: only before torch / HIP are loaded here, and never under a profiler -- its preloaded library has initialised the GPU
     # before this program starts; the profiling recipes pass --no-cpu-baseline or --no-guest-flow, either of which skips the guest flows)
@@ -281,7 +352,7 @@ def main():
     # collectives on host tensors).  A plumbing check only -- never a measurement.
     dry = world > 1 and os.environ.get("ZKHIP_BENCH_DRYRUN_1GPU") == "1"
     if plumbing:
-        return plumbing_run(args, world, rank)
+        return plumbing_run(args, world, rank, guest_devices)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -476,8 +547,9 @@ def main():
                 # HBM traffic of this kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
                 # corrected as MI355X_MICROARCH.md prescribes; bench.py cannot collect counters itself)
                 try:
-                    pmc_file = next(n for n in ("round04_pmc_traffic.json", "round03_pmc_traffic.json", "round02_pmc_traffic.json", "round01_pmc_traffic.json")
-                                    if os.path.exists(os.path.join(ROOT, "profiles", n)))
+                    # (the NEWEST committed pass: profiles/roundNN[x]_pmc_traffic.json, highest round first -- VERDICT round 5, 9b)
+                    import re as _re
+                    pmc_file = sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if _re.fullmatch(r"round\d+[a-z]?_pmc_traffic\.json", n)), reverse=True)[0]
                     with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                         pmc = json.load(f)["kernels"]
                     key = {"poseidon2_hash_rows": "zk::k_hash_rows"}.get(name)
@@ -644,6 +716,8 @@ def main():
             out["guest_flow_mixed"] = guest_mixed
         if guest_mem is not None:
             out["guest_flow_memory_bound"] = guest_mem
+        if guest_devices is not None:
+            out["guest_flow_devices"] = guest_devices
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -655,7 +729,9 @@ def valu_counts():
     (file name, parsed file, stale flag, note).  The counts belong to ONE compiled body of zk::k_hash_rows; the pass stores that body's
     sha256 (tools/code_object_hash.py) and this recomputes it from the libzkhip.so that is loaded -- a kernel edited since the pass makes
     every figure derived from the file stale.  stale is None when the file carries no hash."""
-    name = next((f for f in ("round05_pmc_valu.json", "round04_pmc_valu.json", "round03_pmc_valu.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+    import re
+    names = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"round\d+[a-z]?_pmc_valu\.json", f)), reverse=True)
+    name = names[0] if names else None
     if name is None:
         return None, None, None, "no profiles/round*_pmc_valu.json"
     with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -676,7 +752,7 @@ def valu_counts():
     return name, pv, False, "zk::k_hash_rows code sha256 %s... == profiles/%s" % (have[:12], name)
 
 
-def plumbing_run(args, world, rank):
+def plumbing_run(args, world, rank, guest_devices=None):
     """ZKHIP_BENCH_PLUMBING_ONLY=1: the launcher, the rendezvous, the asynchronous exchange and the JSON line with stub
     proofs over gloo -- what a box without a GPU can check (tests/test_bench_launcher_cpu.py).  Not a measurement."""
     import torch.distributed as dist
@@ -716,7 +792,7 @@ def plumbing_run(args, world, rank):
                           "ms_per_step": round(dt / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                           "config": {"workload": "PLUMBING ONLY: stub proofs, gloo, no GPU -- not a measurement",
-                                     "exchange_ok": bool(ok)}, "aggregate": folded}))
+                                     "exchange_ok": bool(ok)}, "aggregate": folded, "guest_flow_devices": guest_devices}))
     if world > 1:
         dist.destroy_process_group()
     if not ok:

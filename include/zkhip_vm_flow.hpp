@@ -575,6 +575,7 @@ struct GuestStark {
     std::vector<size_t> segments_per_shape, chips_per_shape;   // how many segments were proven under each shape, and how many chips a shape carries
     std::vector<size_t> instr_per_shape, prove_ms_per_shape, tracegen_ms_per_shape;   // per shape: instructions, summed proving / trace-generation time of its segments
     std::vector<size_t> nodes_per_slot;                        // how the tree's nodes spread over the device slots
+    std::vector<size_t> segments_per_lane;                     // segment proofs per lane (lanes are listed device by device: FlowOptions::lanes per device)
     size_t leaf_circuits_at_setup = 0, leaf_circuits_on_demand = 0;   // leaf circuits built with the aggregation key / when a shape's first segment arrived
     double agg_build_seconds = 0, agg_keygen_seconds = 0;      // the aggregation circuits and their keys (a one-time cost of a prover that lives on)
     std::vector<unsigned> node_log_heights;                    // heights of the node circuits' chips (gate, Poseidon2, public values)
@@ -747,8 +748,10 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
     scroll_zkvm_hip::AggregationProver::TreeStream tree(agg, greedy_tree);
     tree.trace = trace_tree;
     size_t n_wide = 0;
-    for (Lane* lane : lanes)
-        workers.emplace_back([&, lane] {
+    std::vector<size_t> seg_per_lane(lanes.size(), 0);
+    for (size_t lane_index = 0; lane_index < lanes.size(); lane_index++)
+        workers.emplace_back([&, lane_index] {
+            Lane* const lane = lanes[lane_index];
             try {
                 for (;;) {
                     Item it;
@@ -803,6 +806,7 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
                     }
                     tree.push(it.index, p.proof, p.shape);
                     std::lock_guard<std::mutex> lk(mu);
+                    seg_per_lane[lane_index]++;
                     if (proofs.size() <= it.index) proofs.resize(it.index + 1);
                     proofs[it.index] = std::move(p);
                     if (verify_segments) to_verify.push_back({it.index, &proofs[it.index]});
@@ -902,6 +906,7 @@ inline GuestStark prove_guest_with(const std::vector<Lane*>& lanes, scroll_zkvm_
     g.pv_openings = open_public_values(ex.tree());
     g.deferral_opening = open_deferral_region(ex, exe);
     g.segments = n_seg;
+    g.segments_per_lane = seg_per_lane;
     std::sort(retried.begin(), retried.end());
     g.segments_retried = std::move(retried);
     std::vector<ChildProof> seg_proofs;

@@ -33,6 +33,9 @@ def test_bench_spawns_its_own_ranks(n):
     # gather -> aggregate on rank 0: the gathered (stub) proofs of the last step folded through the one-key tree shape
     assert out["aggregate"]["proofs_folded"] == n and out["aggregate"]["nodes_per_level"][0] == (n + 3) // 4 and out["aggregate"]["nodes_per_level"][-1] == 1
     assert out["scaling"] == "weak" and out["value"] is None  # plumbing only: no measurement is claimed
+    # SURVEY.md 8(e)(ii) beside (i): ONE guest task over the N devices, run by the launcher before its ranks exist and handed to rank 0
+    gd = out["guest_flow_devices"]
+    assert gd["plumbing_only"] is True and gd["devices"] == list(range(n)) and ("ZKHIP_DEVICES=" + ",".join(map(str, range(n)))) in gd["command"]
 
 
 def test_bench_under_a_launcher_uses_the_given_ranks():
@@ -50,7 +53,11 @@ def test_bench_under_a_launcher_uses_the_given_ranks():
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
     assert [p.returncode for p in procs] == [0, 0], outs
-    assert json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][0])["n_gpus"] == 2
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 2
+    # under a launcher rank 0 runs the one-task-over-N-devices flow before it loads torch; rank 1 waited for its flag file
+    assert line["guest_flow_devices"]["devices"] == [0, 1] and os.path.exists("/tmp/zkhip_bench_devices_%d.json" % port)
+    os.remove("/tmp/zkhip_bench_devices_%d.json" % port)
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]
 
 

@@ -308,14 +308,15 @@ int main(int argc, char** argv) {
                                 "\"sum_over_segments_tracegen_ms\": %llu, \"sum_over_segments_prove_ms\": %llu, "
                                 "\"aggregation_setup_wait_ms\": %llu, \"aggregation_ms\": %llu, \"wall_s\": %.3f, \"root_proof_bytes\": %zu, \"chips_per_shape\": %s, "
                                 "\"segments_per_shape\": %s, \"instructions_per_shape\": %s, \"sum_prove_ms_per_shape\": %s, \"sum_tracegen_ms_per_shape\": %s, \"tree_nodes_per_device_slot\": %s, \"aggregation_circuits_build_s\": %.2f, \"aggregation_keygen_s\": %.2f, \"leaf_circuits_at_setup\": %zu, \"leaf_circuits_on_demand\": %zu, "
-                                "\"segments_retried\": %zu, \"segments_retried_detail\": %s, \"retry_enabled\": %s, "
-                                "\"executor_record_threads\": %u, \"executor_metered_pass_busy_ms\": %llu, \"executor_record_passes_busy_ms_sum\": %llu, \"executor_memory_tree_busy_ms\": %llu, "
+                                "\"segments_retried\": %zu, \"segments_retried_detail\": %s, \"retry_enabled\": %s, \"library_has_test_kernels\": %d, "
+                                "\"segments_per_lane\": %s, \"devices\": %s, \"executor_record_threads\": %u, \"executor_metered_pass_busy_ms\": %llu, \"executor_record_passes_busy_ms_sum\": %llu, \"executor_memory_tree_busy_ms\": %llu, "
                                 "\"node_log_heights\": [%u, %u], \"verified\": true}\n",
                                 (unsigned long long)g.exec.total_cycle, g.segments, g.levels, lanes, (unsigned long long)g.execution_mills,
                                 (unsigned long long)g.segment_proving_mills, (unsigned long long)g.sum_segment_tracegen_mills,
                                 (unsigned long long)g.sum_segment_prove_mills, (unsigned long long)g.aggregation_setup_wait_mills,
                                 (unsigned long long)g.aggregation_mills, wall, g.root.proof.size(), list_of(g.chips_per_shape).c_str(), list_of(g.segments_per_shape).c_str(), list_of(g.instr_per_shape).c_str(), list_of(g.prove_ms_per_shape).c_str(), list_of(g.tracegen_ms_per_shape).c_str(), list_of(g.nodes_per_slot).c_str(), g.agg_build_seconds, g.agg_keygen_seconds, g.leaf_circuits_at_setup, g.leaf_circuits_on_demand,
                                 g.segments_retried.size(), retried_json(g.segments_retried).c_str(), flow.retry_segments ? "true" : "false", zkhip_has_test_kernels(),
+                                list_of(g.segments_per_lane).c_str(), list_of(std::vector<size_t>(flow.devices.begin(), flow.devices.end())).c_str(),
                                 g.executor_threads, (unsigned long long)g.executor_metered_mills, (unsigned long long)g.executor_record_mills_sum, (unsigned long long)g.executor_tree_mills,
                                 g.node_log_heights.at(0), g.node_log_heights.at(1));
                 } catch (const zkhip_vm::Error& e) {
