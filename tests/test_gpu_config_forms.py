@@ -85,3 +85,23 @@ def test_row_sponge_workgroups_of_other_sizes(zk, ora, hash_block):
     zk.set_config(hash_block=hash_block)
     assert z.ProvingKey(zk, z.DEFAULT_PARAMS, airs).prove([dt], [pv]) == base
     assert z.verify(z.DEFAULT_PARAMS, airs, [pv], base) == 0
+
+
+def test_the_fused_middle_of_the_lde_is_bit_exact(zk, ora, monkeypatch):
+    """ZKHIP_LDE_FUSED=1: inverse pass 2 and every coset's forward pass 1 in one kernel over one LDS tile (csrc/ntt.hip k_ntt_lde_fused; off
+    by default -- measured no faster, profiles/round06_lde_fused.txt).  2^22 points: == the four-pass form's bytes, == the oracle on a
+    column; both occupancy variants."""
+    log_n, width = 22, 3
+    rng = np.random.default_rng(22)
+    m = ora.rand_field(rng, (width, 1 << log_n))
+    d = zk.upload(m.reshape(-1))
+    base = zk.download(zk.lde_batch(d, log_n, 1, width, 31))
+    assert (base.reshape(width, -1)[1] == ora.coset_lde_batch(m[1:2], log_n, 1, 31, bitrev_out=True)[0]).all()
+    for waves in ("8", "4"):
+        monkeypatch.setenv("ZKHIP_LDE_FUSED", "1")
+        monkeypatch.setenv("ZKHIP_LDE_FUSED_WAVES", waves)
+        got = zk.download(zk.lde_batch(d, log_n, 1, width, 31))
+        assert (got == base).all(), "fused LDE differs (waves %s)" % waves
+        base4 = zk.download(zk.lde_batch(d, log_n, 2, width, 7))          # four cosets, another shift
+        monkeypatch.delenv("ZKHIP_LDE_FUSED")
+        assert (zk.download(zk.lde_batch(d, log_n, 2, width, 7)) == base4).all()

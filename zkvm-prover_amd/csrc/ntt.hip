@@ -547,6 +547,151 @@ __global__ __launch_bounds__(1 << LOG_T) void k_ntt_pass4_ct(Pass4Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The LDE's middle, fused (round 6).  A coset LDE of 2^(2 LOG_R) points was four passes over HBM: inverse pass 1, inverse pass 2
+// (coefficients, bit-reversed, written to scratch), then per coset forward pass 1 (which read those coefficients back, once per coset)
+// and forward pass 2 -- 12 N words moved for N read and 2 N written.  The inverse's last pass leaves in its LDS tile, per tile column
+// p1, ALL coefficients whose bit-reversed index begins with p1 -- exactly one column F = bitrev(p1) of the forward transform's first pass
+// (which transforms along the other digit, column by column).  So the tile stays where it is: every lane takes its radix-16 unit's sixteen
+// coefficients out of the tile into registers (they sit in one 16-row chunk, bit-reversed -- the layout forward pass 1 reads from HBM
+// today), and for each coset scales them by s_c^i / N, runs the forward pass's rounds over the same LDS and writes the column out in the
+// layout forward pass 2 expects.  The coefficient array is never written or read: 9 N words instead of 12 N, one launch fewer.
+// Only for transforms whose two passes have the same number of stages (LOG_R = 11: 2^22 points).
+// MEASURED (round 6, profiles/round06_lde_fused.txt; 2^22 x 302 columns, blow-up 2, one stream): the four-pass form takes 6.81 ms (inverse) +
+// 12.93 ms (forward) = 19.74 ms; this form 3.00 (inverse pass 1) + 9.93 (fused) + 6.98 (forward pass 2) = 19.91 ms with two workgroups per
+// CU, 20.9 ms with one (ZKHIP_LDE_FUSED_WAVES=4).  A quarter of the HBM traffic is gone and the time is the same: the fused kernel costs
+// what the two passes it replaces cost together (3.4 + 6.0 ms), although it drops a tile load per coset and a tile store -- the passes are
+// not waiting for HBM.  They are bound by what a tile's sixteen waves execute between barriers (1.1 k VALU instructions per wave at 3.0
+// cycles each on the kernel's own mix, ~500 SALU, 77 LDS instructions: ~14 k of the ~25 k cycles a CU spends per tile are VALU issue), so
+// neither this nor an LDS-DMA double buffer -- which could only hide the same loads -- moves them.  OFF by default (no gain, one more code
+// path); ZKHIP_LDE_FUSED=1 selects it, tests/test_gpu_config_forms.py keeps it bit-exact.
+struct LdeFusedArgs {
+    const uint32_t* src;        // inverse pass 1's output, [d2][p1] per column
+    size_t src_col_stride;
+    uint32_t* dst;              // forward pass 1's output, per column 2^log_cosets blocks of [F][p]
+    size_t dst_col_stride;
+    const uint32_t *tw_inv, *tw_fwd;
+    unsigned tw_log, log_m, log_cosets;
+    const uint32_t *scale_col, *scale_row, *scale_rho;   // lde_scale_tables
+};
+// MIN_WAVES: waves per SIMD the register allocation must leave room for (8 = two workgroups per CU, 64 VGPRs, the sixteen kept coefficients
+// partly in scratch; 4 = one workgroup per CU, no spill) -- ZKHIP_LDE_FUSED_WAVES picks the instantiation for measurements
+template <int LOG_R, int LOG_C, int MIN_WAVES>
+__global__ __launch_bounds__(1024, MIN_WAVES) void k_ntt_lde_fused(LdeFusedArgs a) {
+    constexpr int LOG_T = 10;
+    static_assert(LOG_R - 4 + LOG_C == LOG_T, "one radix-16 unit per lane");
+    constexpr unsigned NT = 1u << LOG_T;
+    extern __shared__ uint32_t sm[];
+    constexpr unsigned R = 1u << LOG_R, C = 1u << LOG_C, pitch = C + 1u;
+    constexpr int LOG_RQ = LOG_R - 4;
+    constexpr unsigned log_f = LOG_R;   // both digits have LOG_R bits
+    uint32_t* lv = sm;
+    uint32_t* twl = sm + R * pitch;
+    const unsigned tid = threadIdx.x;
+    for (unsigned e = tid; e < (R >> 1); e += NT) twl[e] = a.tw_inv[(size_t)e << (a.tw_log - LOG_R)];
+    const size_t mcol = blockIdx.y;
+    unsigned tile = blockIdx.x;
+    if (LOG_C == 3) {   // (XCD-aware tile order: as k_ntt_pass4_ct)
+        unsigned k = gridDim.x >> 3;
+        if (k > 16u) k = 16u;
+        if (k >= 2u && (k & (k - 1u)) == 0 && (gridDim.x & (8u * k - 1u)) == 0) {
+            const unsigned within = tile & (8u * k - 1u);
+            tile = (tile & ~(8u * k - 1u)) | ((within & 7u) * k) | (within >> 3);
+        }
+    }
+    const unsigned F0 = tile << LOG_C;   // (two passes: the tile index is the column group)
+    const unsigned c = tid & (C - 1u), jj = tid >> LOG_C;
+    unsigned j = jj;
+    if constexpr (LOG_C <= 4 && LOG_C >= 3 && LOG_R - 4 >= (5 - LOG_C) + (LOG_C == 3 ? 3 : 4)) {   // (bank-friendly unit order: as k_ntt_pass4_ct)
+        constexpr unsigned HB = 5 - LOG_C;
+        constexpr unsigned SP = LOG_C == 3 ? 3 : 4;
+        j = ((jj & ((1u << HB) - 1u)) << SP) | ((jj >> HB) & ((1u << SP) - 1u)) | (jj & ~((1u << (HB + SP)) - 1u));
+    }
+    zk_syncthreads();
+    // ---- the inverse transform's second pass: rows d2, columns p1 = F0 + c, twiddle w_M^-(bitrev(p1) d2) on the way in ----
+    {
+        uint32_t v[16];
+        const uint32_t* tile_src = a.src + mcol * a.src_col_stride + F0;
+        const uint32_t lane_off = (j << log_f) + c;
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = (tile_src + ((size_t)k << (LOG_RQ + log_f)))[lane_off];
+        {
+            const unsigned log_tt = 2 * LOG_R;
+            const uint32_t mask = (1u << log_tt) - 1u;
+            const uint32_t kc = bitrev32(F0 + c, LOG_R);
+            const uint32_t e0 = (kc * j) & mask;
+            const uint32_t de = (kc * (1u << LOG_RQ)) & mask;
+            const unsigned sh = a.tw_log - log_tt;
+            const uint32_t half = 1u << (log_tt - 1);
+            uint32_t t = e0 < half ? a.tw_inv[(size_t)e0 << sh] : mneg(a.tw_inv[(size_t)(e0 - half) << sh]);
+            const uint32_t rho = de < half ? a.tw_inv[(size_t)de << sh] : mneg(a.tw_inv[(size_t)(de - half) << sh]);
+            int32_t ts = (int32_t)t;
+            v[0] = mmul(v[0], t);
+#pragma unroll
+            for (int k = 1; k < 16; k++) {
+                ts = smml(ts, (int32_t)rho);
+                v[k] = canon_signed(smml((int32_t)v[k], ts));
+            }
+        }
+        uint32_t w[15];
+        load_unit_twiddles<4, LOG_RQ, 0>(twl, j, w);
+        dif_unit_w<4>(v, w);
+        uint32_t* base = lv + j * pitch + c;
+#pragma unroll
+        for (int k = 0; k < 16; k++) base[(k << LOG_RQ) * pitch] = v[k];
+    }
+    zk_syncthreads();
+    lds_rounds_ct<LOG_R, LOG_C, LOG_RQ, NT>(lv, twl, tid);
+    // (the tile now holds, in row p2 of column c, the coefficient with bit-reversed index (F0 + c) 2^LOG_R + p2, not yet divided by N)
+    // ---- the forward transform's first pass, per coset, out of the same tile ----
+    for (unsigned e = tid; e < (R >> 1); e += NT) twl[e] = a.tw_fwd[(size_t)e << (a.tw_log - LOG_R)];
+    uint32_t raw[16];
+    {
+        // the unit of forward column F = bitrev(F0 + c) with first row j takes coefficients d1 = j + k 2^LOG_RQ: tile rows bitrev(d1) =
+        // 16 bitrev(j) + bitrev4(k)
+        const uint32_t* chunk = lv + ((size_t)bitrev32(j, LOG_RQ) << 4) * pitch + c;
+#pragma unroll
+        for (int k = 0; k < 16; k++) raw[k] = chunk[(((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3)) * pitch];
+    }
+    zk_syncthreads();
+    const unsigned Ff = bitrev32(F0 + c, log_f);
+    for (unsigned sub = 0; sub < (1u << a.log_cosets); sub++) {
+        {
+            uint32_t v[16];
+            const uint32_t t = mmul(a.scale_col[((size_t)sub << log_f) + Ff], a.scale_row[((size_t)sub << LOG_RQ) + j]);
+            const uint32_t rho = a.scale_rho[sub];
+            int32_t ts = (int32_t)t;
+            v[0] = mmul(raw[0], t);
+#pragma unroll
+            for (int k = 1; k < 16; k++) {
+                ts = smml(ts, (int32_t)rho);
+                v[k] = canon_signed(smml((int32_t)raw[k], ts));
+            }
+            uint32_t w[15];
+            load_unit_twiddles<4, LOG_RQ, 0>(twl, j, w);
+            dif_unit_w<4>(v, w);
+            uint32_t* base = lv + j * pitch + c;
+#pragma unroll
+            for (int k = 0; k < 16; k++) base[(k << LOG_RQ) * pitch] = v[k];
+        }
+        zk_syncthreads();
+        lds_rounds_ct<LOG_R, LOG_C, LOG_RQ, NT>(lv, twl, tid);
+        // write-out: tile column cc is forward column bitrev(F0 + cc): one contiguous run of R words at [F][p] of this coset's block
+        uint32_t* dst = a.dst + mcol * a.dst_col_stride + ((size_t)sub << a.log_m);
+        if constexpr (LOG_R >= LOG_T) {
+            const uint32_t* lrow = lv + tid * pitch;
+#pragma unroll
+            for (unsigned i = 0; i < (R * C) / NT; i++) {
+                const unsigned cc = (NT * i) >> LOG_R, p0 = (NT * i) & (R - 1u);
+                const unsigned F = bitrev32(F0 + cc, log_f);
+                uint32_t* dcol = dst + ((size_t)F << LOG_R) + p0;
+                dcol[tid] = lrow[p0 * pitch + cc];
+            }
+        }
+        zk_syncthreads();   // (the next coset's units overwrite the tile)
+    }
+}
+
 static constexpr unsigned P4_MAX_LOG_R = 11;
 static constexpr unsigned P4_MIN_LOG_M = 12;
 // stages per pass: 11 = two passes up to 2^22 (128 KiB tiles, one workgroup per CU);
@@ -1013,6 +1158,84 @@ static int lde_scale_tables(zkhip_ctx* ctx, unsigned log_n, unsigned added_bits,
     return ZKHIP_OK;
 }
 
+// The fused middle of a coset LDE (k_ntt_lde_fused): inverse pass 1 -> [fused: inverse pass 2 + every coset's forward pass 1] -> forward
+// pass 2.  `applies`: transforms of 2^22 points (two passes of eleven stages), and only when ZKHIP_LDE_FUSED=1 asks for it (see the kernel's
+// header: measured, no faster than the four-pass form).  Read per call: the parity test switches it inside one process.
+static bool lde_fused_applies(unsigned log_n) {
+    const char* e = getenv("ZKHIP_LDE_FUSED");
+    unsigned a[3];
+    return e && e[0] == '1' && fourstep_split(log_n, a) == 2 && a[0] == a[1] && a[0] == 11;
+}
+static int lde_fused(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, const uint32_t* const* d_src_cols, uint32_t* d_out, size_t out_stride,
+                     uint32_t* const* d_dst_cols, unsigned log_n, unsigned added_bits, size_t width, uint32_t shift_monty) {
+    const size_t n = (size_t)1 << log_n, per_col = n << added_bits;
+    unsigned a[3];
+    fourstep_split(log_n, a);
+    const unsigned a1 = a[0], a2 = a[1];
+    const unsigned log_f = log_n - a1, log_rq = a1 - 4, n_co = 1u << added_bits;
+    uint32_t* d_col = nullptr;
+    ZK_TRY(lde_scale_tables(ctx, log_n, added_bits, shift_monty, log_f, log_rq, &d_col));
+    uint32_t* d_row = d_col + n_co * ((size_t)1 << log_f);
+    uint32_t* d_rho = d_row + n_co * ((size_t)1 << log_rq);
+    void *t1v, *t2v;
+    ZK_TRY(get_scratch(ctx, 0, n * width * 4, &t1v));
+    ZK_TRY(get_scratch(ctx, 4, per_col * width * 4, &t2v));
+    uint32_t *t1 = (uint32_t*)t1v, *t2 = (uint32_t*)t2v;
+    static DeviceOnce attr_set;
+    const int lds = (int)(((((size_t)1 << a2) * 9u) + ((size_t)1 << (a2 - 1))) * 4);   // [2^11][8 + 1] + the twiddle table
+    if (attr_set.need(ctx->device)) {
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_lde_fused<11, 3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_lde_fused<11, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ZK_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_ntt_pass4_ct<11, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set.mark(ctx->device);
+    }
+    // inverse pass 1 alone: the first launch of ntt_dif_fourstep's two-pass form (digit d1 in rows, F = d2; out [d2][p1])
+    {
+        Pass4Args pa;
+        memset(&pa, 0, sizeof pa);
+        pa.log_r = a1, pa.log_f = a2, pa.in_x_stride = 0, pa.in_rs = (size_t)1 << a2;
+        pa.out_x_stride = 0, pa.out_hi_stride = (size_t)1 << a1, pa.out_lo_stride = 0, pa.log_lo = 0, pa.in_tw = 0;
+        pa.src = d_in, pa.src_col_stride = in_stride, pa.src_cols = d_src_cols;
+        pa.dst = t1, pa.dst_col_stride = n;
+        pa.tw = ctx->d_tw_inv, pa.tw_log = ctx->tw_log, pa.log_sub = 0, pa.log_m = log_n, pa.log_c = 3;
+        KernelScope ks(ctx, "ntt_pass_inv");
+        const dim3 grid(1u << (pa.log_f - pa.log_c), (unsigned)width);
+        const size_t lds1 = ((((size_t)1 << a1) * 9u) + ((size_t)1 << (a1 - 1))) * 4;
+        hipLaunchKernelGGL((k_ntt_pass4_ct<11, 3>), grid, dim3(1024), lds1, ctx->stream, pa);
+        ZK_HIP_CHECK(ctx, hipGetLastError());
+    }
+    {
+        LdeFusedArgs fa;
+        memset(&fa, 0, sizeof fa);
+        fa.src = t1, fa.src_col_stride = n, fa.dst = t2, fa.dst_col_stride = per_col;
+        fa.tw_inv = ctx->d_tw_inv, fa.tw_fwd = ctx->d_tw_fwd, fa.tw_log = ctx->tw_log, fa.log_m = log_n, fa.log_cosets = added_bits;
+        fa.scale_col = d_col, fa.scale_row = d_row, fa.scale_rho = d_rho;
+        KernelScope ks(ctx, "ntt_lde_fused");
+        const dim3 grid(1u << (a1 - 3), (unsigned)width);
+        const bool one_wg = getenv("ZKHIP_LDE_FUSED_WAVES") && atoi(getenv("ZKHIP_LDE_FUSED_WAVES")) == 4;
+        if (one_wg) hipLaunchKernelGGL((k_ntt_lde_fused<11, 3, 4>), grid, dim3(1024), (size_t)lds, ctx->stream, fa);
+        else hipLaunchKernelGGL((k_ntt_lde_fused<11, 3, 8>), grid, dim3(1024), (size_t)lds, ctx->stream, fa);
+        ZK_HIP_CHECK(ctx, hipGetLastError());
+    }
+    // forward pass 2 alone: the second launch of the two-pass form (digit d2 in rows, F = p1; twiddle w_M^(k1 d2)), every coset
+    {
+        Pass4Args pa;
+        memset(&pa, 0, sizeof pa);
+        pa.log_r = a2, pa.log_f = a1, pa.in_x_stride = 0, pa.in_rs = (size_t)1 << a1;
+        pa.out_x_stride = 0, pa.out_hi_stride = (size_t)1 << a2, pa.out_lo_stride = 0, pa.log_lo = 0;
+        pa.in_tw = 1, pa.log_prev = a1, pa.log_tt = log_n, pa.tw_a = 1, pa.tw_bx = 0;
+        pa.src = t2, pa.src_col_stride = per_col;
+        pa.dst = d_out, pa.dst_col_stride = out_stride, pa.dst_cols = d_dst_cols;
+        pa.tw = ctx->d_tw_fwd, pa.tw_log = ctx->tw_log, pa.log_sub = added_bits, pa.log_m = log_n, pa.log_c = 3;
+        KernelScope ks(ctx, "ntt_pass_fwd");
+        const dim3 grid(1u << (pa.log_f - pa.log_c), (unsigned)(width << added_bits));
+        const size_t lds2 = ((((size_t)1 << a2) * 9u) + ((size_t)1 << (a2 - 1))) * 4;
+        hipLaunchKernelGGL((k_ntt_pass4_ct<11, 3>), grid, dim3(1024), lds2, ctx->stream, pa);
+        ZK_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return ZKHIP_OK;
+}
+
 int lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* d_out, size_t out_stride,
               unsigned log_n, unsigned added_bits, size_t width, uint32_t shift_monty) {
     if (width == 0) return ZKHIP_OK;
@@ -1020,6 +1243,7 @@ int lde_batch(zkhip_ctx* ctx, const uint32_t* d_in, size_t in_stride, uint32_t* 
     if (in_stride < n || out_stride < (n << added_bits)) return set_error(ctx, ZKHIP_ERR_INVALID, "stride < height");
     if (log_n + added_bits > 27) return set_error(ctx, ZKHIP_ERR_INVALID, "LDE size exceeds two-adicity");
     ZK_TRY(ensure_twiddles(ctx, log_n + added_bits));
+    if (lde_fused_applies(log_n)) return lde_fused(ctx, d_in, in_stride, nullptr, d_out, out_stride, nullptr, log_n, added_bits, width, shift_monty);
     // 1. inverse DIF into scratch: coefficients (unnormalised) in bit-reversed order
     void* coeffs;
     ZK_TRY(get_scratch(ctx, 0, n * width * 4, &coeffs));
@@ -1088,6 +1312,7 @@ int lde_batch_cols(zkhip_ctx* ctx, const uint32_t* const* d_src_cols, uint32_t* 
     if (log_n + added_bits > 27) return set_error(ctx, ZKHIP_ERR_INVALID, "LDE size exceeds two-adicity");
     const size_t n = (size_t)1 << log_n;
     ZK_TRY(ensure_twiddles(ctx, log_n + added_bits));
+    if (lde_fused_applies(log_n)) return lde_fused(ctx, nullptr, 0, d_src_cols, nullptr, 0, d_dst_cols, log_n, added_bits, n_cols, shift_monty);
     void* coeffs;
     ZK_TRY(get_scratch(ctx, 0, n * n_cols * 4, &coeffs));
     {

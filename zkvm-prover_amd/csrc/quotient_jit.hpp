@@ -252,22 +252,24 @@ inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b,
     (void)p;
     std::ostringstream os;
     quot_jit_prologue(os, lh, b, p.qd());
+    // Instances of a class are evaluated UNROLL at a time: the parameter rows (scalar loads) and the trace cells (vector loads) of all of
+    // them are requested before the first product, so that a wave waits for memory once per group instead of three times per instance
+    // (the rolled loop's body was: parameter row -> wait -> six cell loads -> two more parameters -> wait -> arithmetic -> the row of
+    // alpha powers -> wait; its waves were parked 72 % of their cycles: profiles/round05b_pmc_wave_cycles.json).  The order of the
+    // accumulation is the rolled loop's, so the sums are too.  ZKHIP_JIT_UNROLL=n (1 .. 8) for measurements; part of the source text, so of
+    // every cache key.
+    static const unsigned unroll = [] {
+        const char* e = getenv("ZKHIP_JIT_UNROLL");
+        const int v = e ? atoi(e) : 8;   // (measured on the headline's 300-column chip: 6.07 / 5.90 / 5.94 / 5.33 ms at 1 / 2 / 4 / 8)
+        return (unsigned)(v < 1 ? 1 : v > 8 ? 8 : v);
+    }();
     for (size_t c = 0; c < classes.size(); c++) {
         JitClass& C = classes[c];
         C.table_off = table->size();
         const size_t stride = 1 + C.param_entry.size();
         for (const auto& row : C.inst) table->insert(table->end(), row.begin(), row.end());
-        os << "    for (uint32_t it = 0; it < " << C.inst.size() << "u; it++) {\n";
-        os << "        cptr pr = (cptr)tab + " << C.table_off << "u + it * " << stride << "u;\n";
-        // parameters first (scalar), then the trace loads back to back, then the arithmetic
         std::vector<int> pidx(C.entries.size(), -1);
         for (size_t j = 0; j < C.param_entry.size(); j++) pidx[C.param_entry[j]] = (int)j + 1;
-        for (size_t e = 0; e < C.entries.size(); e++) {
-            const JitEntry& E = C.entries[e];
-            if (E.op == A_VAR || E.op == A_PERM || E.op == A_PREP)
-                os << "        const uint32_t e" << e << " = " << (E.op == A_VAR ? "LD" : E.op == A_PERM ? "LDP" : "LDQ") << "(pr[" << pidx[e] << "], "
-                   << (E.a ? "rno" : "ro") << ");\n";
-        }
         // a product used only by other products keeps the signed form (2 instructions fewer than a reduced one)
         std::vector<uint8_t> only_mul(C.entries.size(), 1), used(C.entries.size(), 0);
         for (size_t e = 0; e < C.entries.size(); e++) {
@@ -280,31 +282,58 @@ inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b,
             }
         }
         auto stays_signed = [&](size_t e) { return C.entries[e].op == A_MUL && used[e] && only_mul[e] && e + 1 != C.entries.size(); };
-        for (size_t e = 0; e < C.entries.size(); e++) {
-            const JitEntry& E = C.entries[e];
-            switch (E.op) {
-                case A_VAR:
-                case A_PREP:
-                case A_PERM: break;
-                case A_CHAL: os << "        const uint32_t e" << e << " = ((cptr)lchal)[pr[" << pidx[e] << "]];\n"; break;
-                case A_EXPOSED: os << "        const uint32_t e" << e << " = ((cptr)expo)[pr[" << pidx[e] << "]];\n"; break;
-                case A_PUB: os << "        const uint32_t e" << e << " = PV(pr[" << pidx[e] << "]);\n"; break;
-                case A_CONST: os << "        const uint32_t e" << e << " = pr[" << pidx[e] << "];\n"; break;
-                case A_FIRST: os << "        const uint32_t e" << e << " = sel_first;\n"; break;
-                case A_LAST: os << "        const uint32_t e" << e << " = sel_last;\n"; break;
-                case A_TRANS: os << "        const uint32_t e" << e << " = sel_trans;\n"; break;
-                case A_NEG: os << "        const uint32_t e" << e << " = mneg(e" << E.a << ");\n"; break;
-                case A_MUL:
-                    if (stays_signed(e))
-                        os << "        const int32_t e" << e << " = sml((int32_t)e" << E.a << ", (int32_t)e" << E.b << ");\n";
-                    else
-                        os << "        const uint32_t e" << e << " = SC(sml((int32_t)e" << E.a << ", (int32_t)e" << E.b << "));\n";
-                    break;
-                default:
-                    os << "        const uint32_t e" << e << " = " << (E.op == A_ADD ? "madd" : "msub") << "(e" << E.a << ", e" << E.b << ");\n";
+        // the trace loads of instance u (its parameter row is pr<u>), then its arithmetic
+        auto emit_loads = [&](unsigned u) {
+            for (size_t e = 0; e < C.entries.size(); e++) {
+                const JitEntry& E = C.entries[e];
+                if (E.op == A_VAR || E.op == A_PERM || E.op == A_PREP)
+                    os << "        const uint32_t e" << e << "_" << u << " = " << (E.op == A_VAR ? "LD" : E.op == A_PERM ? "LDP" : "LDQ") << "(pr" << u << "[" << pidx[e] << "], "
+                       << (E.a ? "rno" : "ro") << ");\n";
             }
+        };
+        auto emit_arith = [&](unsigned u) {
+            auto v = [&](size_t e) { return "e" + std::to_string(e) + "_" + std::to_string(u); };
+            for (size_t e = 0; e < C.entries.size(); e++) {
+                const JitEntry& E = C.entries[e];
+                switch (E.op) {
+                    case A_VAR:
+                    case A_PREP:
+                    case A_PERM: break;
+                    case A_CHAL: os << "        const uint32_t " << v(e) << " = ((cptr)lchal)[pr" << u << "[" << pidx[e] << "]];\n"; break;
+                    case A_EXPOSED: os << "        const uint32_t " << v(e) << " = ((cptr)expo)[pr" << u << "[" << pidx[e] << "]];\n"; break;
+                    case A_PUB: os << "        const uint32_t " << v(e) << " = PV(pr" << u << "[" << pidx[e] << "]);\n"; break;
+                    case A_CONST: os << "        const uint32_t " << v(e) << " = pr" << u << "[" << pidx[e] << "];\n"; break;
+                    case A_FIRST: os << "        const uint32_t " << v(e) << " = sel_first;\n"; break;
+                    case A_LAST: os << "        const uint32_t " << v(e) << " = sel_last;\n"; break;
+                    case A_TRANS: os << "        const uint32_t " << v(e) << " = sel_trans;\n"; break;
+                    case A_NEG: os << "        const uint32_t " << v(e) << " = mneg(" << v(E.a) << ");\n"; break;
+                    case A_MUL:
+                        if (stays_signed(e))
+                            os << "        const int32_t " << v(e) << " = sml((int32_t)" << v(E.a) << ", (int32_t)" << v(E.b) << ");\n";
+                        else
+                            os << "        const uint32_t " << v(e) << " = SC(sml((int32_t)" << v(E.a) << ", (int32_t)" << v(E.b) << "));\n";
+                        break;
+                    default:
+                        os << "        const uint32_t " << v(e) << " = " << (E.op == A_ADD ? "madd" : "msub") << "(" << v(E.a) << ", " << v(E.b) << ");\n";
+                }
+            }
+            os << "        ACC(pr" << u << "[0], " << v(C.entries.size() - 1) << ")\n";
+        };
+        const size_t n_inst = C.inst.size(), U = n_inst >= 2 * unroll ? unroll : 1, n_main = n_inst / U * U;
+        if (U > 1) {
+            os << "    for (uint32_t it = 0; it < " << n_main << "u; it += " << U << "u) {\n";
+            for (unsigned u = 0; u < U; u++) os << "        cptr pr" << u << " = (cptr)tab + " << C.table_off << "u + (it + " << u << "u) * " << stride << "u;\n";
+            for (unsigned u = 0; u < U; u++) emit_loads(u);
+            for (unsigned u = 0; u < U; u++) emit_arith(u);
+            os << "    }\n";
         }
-        os << "        ACC(pr[0], e" << (C.entries.size() - 1) << ")\n    }\n";
+        if (n_main < n_inst || U == 1) {
+            os << "    for (uint32_t it = " << (U > 1 ? n_main : 0) << "u; it < " << n_inst << "u; it++) {\n";
+            os << "        cptr pr0 = (cptr)tab + " << C.table_off << "u + it * " << stride << "u;\n";
+            emit_loads(0);
+            emit_arith(0);
+            os << "    }\n";
+        }
     }
     quot_jit_epilogue(os);
     if (table->empty()) table->push_back(0);
