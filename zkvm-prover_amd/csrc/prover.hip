@@ -829,7 +829,7 @@ struct AirPlan {
     uint32_t prep_commit[8] = {};      // canonical
     hipModule_t jit_mod = nullptr;   // keygen-compiled constraint kernel (null -> interpreter)
     hipFunction_t jit_fn = nullptr;
-    unsigned jit_rows_per_block = 256;   // 0: the LDS-tiled form (a fixed grid walks 64-row tiles)
+    unsigned jit_rows_per_block = 256;   // 0: the LDS-tiled form (a fixed grid walks 64-row tiles); 64: the shared-rows form (csrc/quotient_jit.hpp)
     uint32_t* d_jit_tab = nullptr;   // per-instance leaf parameters of the shape classes
 };
 
@@ -2054,7 +2054,10 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     // beside the interpreter's launch
     // (only the SHORT ones: at most two workgroups per CU.  A kernel that fills the chip gains nothing beside another one -- the Fibonacci guest's
     // six large chips lost 3 - 10 % when they were spread too)
-    auto jit_blocks = [&](const AirPlan& A) { return A.jit_rows_per_block ? (unsigned)((A.MQ + 255) / 256) : (unsigned)std::min<size_t>(A.MQ / 64, 4 * 256); };
+    // (jit_rows_per_block: 256 = the plain form, 64 = the shared-rows form -- sixteen waves per 64 rows --, 0 = the LDS-tiled form, a fixed grid)
+    auto jit_blocks = [&](const AirPlan& A) {
+        return A.jit_rows_per_block == 64 ? (unsigned)(A.MQ / 64) : A.jit_rows_per_block ? (unsigned)((A.MQ + 255) / 256) : (unsigned)std::min<size_t>(A.MQ / 64, 4 * 256);
+    };
     unsigned n_jit = 0, fan = 0;
     // (an error between fork and join returns from this function: the side streams are drained first -- buffers the next proof reuses may
     // still be written by a kernel queued on them: ADVICE round 5)
@@ -2112,7 +2115,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
                           (void*)&qa.lchal, (void*)&qa.expo, (void*)&qa.prep, (void*)&h_bits, (void*)&nq_rows};
         // (tiled form: one workgroup per CU holds its 150 KB tile; a few rounds of workgroups per CU even the tail out)
         const unsigned blocks = jit_blocks(A);
-        ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, blocks, 1, 1, A.jit_rows_per_block ? 256 : 64 * QUOT_TILE_WAVES, 1, 1, 0, qs, params, nullptr));
+        ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, blocks, 1, 1, A.jit_rows_per_block == 64 ? 64 * QUOT_SHARED_WAVES : A.jit_rows_per_block ? 256 : 64 * QUOT_TILE_WAVES, 1, 1, 0, qs, params, nullptr));
     }
     for (unsigned q = 0; q < fan; q++) {
         ZK_HIP_CHECK(ctx, hipEventRecord(ctx->quot_join[q], ctx->quot_streams[q]));

@@ -247,11 +247,54 @@ inline void quot_jit_epilogue(std::ostringstream& os) {
 }
 
 // Emits the kernel source and the parameter table.
+// shared: the SHARED-ROWS form (round 6).  The plain form gives every wave 64 rows of its own and walks all constraints: a wave's working set is
+// 64 rows x every column (77 KB for the 300-column chip), 32 waves per CU and 32 CUs per XCD hold 78 MB against 4 MB of L2 -- every re-read of
+// a cell (3.9 per cell on that chip) misses the L2 and crosses the fabric to the Infinity Cache (the "43 GB at 7 TB/s" of
+// profiles/round05_pmc_traffic.json: FETCH_SIZE counts L2 misses, not HBM bytes).  Here a workgroup of SIXTEEN waves owns ONE block of 64 rows:
+// wave w evaluates instances w, w + 16, ... of every class, so the rows in flight per XCD are a sixteenth (4.9 MB) and a cell's re-reads by
+// the other waves of the workgroup find it in the L2; the sixteen partial sums meet in LDS.  The two selector inversions are done once per
+// workgroup (waves 0 and 1) while the other waves evaluate the classes that need neither.
+constexpr unsigned QUOT_SHARED_WAVES = 16;
 inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b, std::vector<JitClass>& classes,
-                                   std::vector<uint32_t>* table) {
+                                   std::vector<uint32_t>* table, bool shared = false) {
     (void)p;
     std::ostringstream os;
-    quot_jit_prologue(os, lh, b, p.qd());
+    if (!shared) {
+        quot_jit_prologue(os, lh, b, p.qd());
+    } else {
+        os << quot_jit_preamble();
+        os << "#define B " << b << "u\n#define M ((size_t)1 << H)\n#define NW " << QUOT_SHARED_WAVES << "u\n";
+        os << R"JIT(
+extern "C" __global__ __launch_bounds__(64 * NW) void quot_jit(const uint32_t* __restrict__ lde, uint32_t* __restrict__ q,
+        const uint32_t* __restrict__ pvs, const uint32_t* __restrict__ apow, const uint32_t* __restrict__ tw_fwd,
+        const uint32_t* __restrict__ zh_t, const uint32_t* __restrict__ inv_zh_t, const uint32_t* __restrict__ tab,
+        uint32_t gen, uint32_t w_n_inv, uint32_t tw_shift, const uint32_t* __restrict__ perm,
+        const uint32_t* __restrict__ lchal, const uint32_t* __restrict__ expo, const uint32_t* __restrict__ prep,
+        uint32_t H, uint32_t NQROWS) {
+    __shared__ uint32_t red_s[4u * NW * 64u + 2u * 64u];   // [wave][coordinate][lane], then sel_first, sel_last per lane
+    uint32_t* const sel_s = red_s + 4u * NW * 64u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (wave-uniform: the parameter rows stay scalar loads)
+    const uint32_t r = blockIdx.x * 64u + lane;   // (NQROWS is a multiple of 64: the form is chosen for tall chips only)
+    const uint32_t i = __brev(r) >> (32 - H);
+    const uint32_t rn = __brev((i + (1u << B)) & ((1u << H) - 1u)) >> (32 - H);
+    const uint32_t halfm = 1u << (H - 1);
+    const uint32_t wi = i < halfm ? tw_fwd[(size_t)i << tw_shift] : mneg(tw_fwd[(size_t)(i - halfm) << tw_shift]);
+    const uint32_t x = mmul(gen, wi);
+    const uint32_t zh = zh_t[i & ((1u << B) - 1u)];
+    const uint32_t sel_trans = msub(x, w_n_inv);
+    if (wv == 0u) sel_s[lane] = mmul(zh, minv(msub(x, ONE)));
+    if (wv == 1u) sel_s[64u + lane] = mmul(zh, minv(sel_trans));
+    uint32_t sel_first = 0, sel_last = 0;
+    uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    uint32_t cnt = 0;
+    const uint32_t ro = r << 2, rno = rn << 2;
+    const gptr ldep = (gptr)lde;
+    const gptr permp = (gptr)perm;
+    const gptr prepp = (gptr)prep;
+)JIT";
+    }
     // Instances of a class are evaluated UNROLL at a time: the parameter rows (scalar loads) and the trace cells (vector loads) of all of
     // them are requested before the first product, so that a wave waits for memory once per group instead of three times per instance
     // (the rolled loop's body was: parameter row -> wait -> six cell loads -> two more parameters -> wait -> arithmetic -> the row of
@@ -320,6 +363,7 @@ inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b,
             os << "        ACC(pr" << u << "[0], " << v(C.entries.size() - 1) << ")\n";
         };
         const size_t n_inst = C.inst.size(), U = n_inst >= 2 * unroll ? unroll : 1, n_main = n_inst / U * U;
+        if (shared) continue;   // (the shared-rows form emits its loops below, in two groups around the selectors' barrier)
         if (U > 1) {
             os << "    for (uint32_t it = 0; it < " << n_main << "u; it += " << U << "u) {\n";
             for (unsigned u = 0; u < U; u++) os << "        cptr pr" << u << " = (cptr)tab + " << C.table_off << "u + (it + " << u << "u) * " << stride << "u;\n";
@@ -334,6 +378,96 @@ inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b,
             emit_arith(0);
             os << "    }\n";
         }
+    }
+    if (shared) {
+        // wave w takes instances w, w + NW, ... of a class, SU of them per iteration: an index beyond the class is clamped to its last instance
+        // (evaluated again, not accumulated), so the loads of an iteration are unconditional and issue together
+        auto emit_class = [&](size_t c) {
+            JitClass& C = classes[c];
+            const size_t stride = 1 + C.param_entry.size(), n_inst = C.inst.size();
+            std::vector<int> pidx(C.entries.size(), -1);
+            for (size_t j = 0; j < C.param_entry.size(); j++) pidx[C.param_entry[j]] = (int)j + 1;
+            std::vector<uint8_t> only_mul(C.entries.size(), 1), used(C.entries.size(), 0);
+            for (size_t e = 0; e < C.entries.size(); e++) {
+                const JitEntry& E = C.entries[e];
+                if (E.op == A_ADD || E.op == A_SUB || E.op == A_MUL) {
+                    used[E.a] = used[E.b] = 1;
+                    if (E.op != A_MUL) only_mul[E.a] = only_mul[E.b] = 0;
+                } else if (E.op == A_NEG) {
+                    used[E.a] = 1, only_mul[E.a] = 0;
+                }
+            }
+            auto stays_signed = [&](size_t e) { return C.entries[e].op == A_MUL && used[e] && only_mul[e] && e + 1 != C.entries.size(); };
+            const unsigned per_wave = (unsigned)((n_inst + QUOT_SHARED_WAVES - 1) / QUOT_SHARED_WAVES);
+            const unsigned SU = std::min<unsigned>(per_wave, std::min<unsigned>(unroll, 4u));
+            os << "    for (uint32_t it = wv; it < " << n_inst << "u; it += " << SU << "u * NW) {\n";
+            for (unsigned u = 0; u < SU; u++) {
+                os << "        const uint32_t i" << u << " = it + " << u << "u * NW;\n";
+                os << "        cptr pr" << u << " = (cptr)tab + " << C.table_off << "u + (i" << u << " < " << n_inst << "u ? i" << u << " : " << (n_inst - 1) << "u) * " << stride << "u;\n";
+            }
+            for (unsigned u = 0; u < SU; u++)
+                for (size_t e = 0; e < C.entries.size(); e++) {
+                    const JitEntry& E = C.entries[e];
+                    if (E.op == A_VAR || E.op == A_PERM || E.op == A_PREP)
+                        os << "        const uint32_t e" << e << "_" << u << " = " << (E.op == A_VAR ? "LD" : E.op == A_PERM ? "LDP" : "LDQ") << "(pr" << u << "[" << pidx[e] << "], "
+                           << (E.a ? "rno" : "ro") << ");\n";
+                }
+            for (unsigned u = 0; u < SU; u++) {
+                auto v = [&](size_t e) { return "e" + std::to_string(e) + "_" + std::to_string(u); };
+                for (size_t e = 0; e < C.entries.size(); e++) {
+                    const JitEntry& E = C.entries[e];
+                    switch (E.op) {
+                        case A_VAR:
+                        case A_PREP:
+                        case A_PERM: break;
+                        case A_CHAL: os << "        const uint32_t " << v(e) << " = ((cptr)lchal)[pr" << u << "[" << pidx[e] << "]];\n"; break;
+                        case A_EXPOSED: os << "        const uint32_t " << v(e) << " = ((cptr)expo)[pr" << u << "[" << pidx[e] << "]];\n"; break;
+                        case A_PUB: os << "        const uint32_t " << v(e) << " = PV(pr" << u << "[" << pidx[e] << "]);\n"; break;
+                        case A_CONST: os << "        const uint32_t " << v(e) << " = pr" << u << "[" << pidx[e] << "];\n"; break;
+                        case A_FIRST: os << "        const uint32_t " << v(e) << " = sel_first;\n"; break;
+                        case A_LAST: os << "        const uint32_t " << v(e) << " = sel_last;\n"; break;
+                        case A_TRANS: os << "        const uint32_t " << v(e) << " = sel_trans;\n"; break;
+                        case A_NEG: os << "        const uint32_t " << v(e) << " = mneg(" << v(E.a) << ");\n"; break;
+                        case A_MUL:
+                            if (stays_signed(e))
+                                os << "        const int32_t " << v(e) << " = sml((int32_t)" << v(E.a) << ", (int32_t)" << v(E.b) << ");\n";
+                            else
+                                os << "        const uint32_t " << v(e) << " = SC(sml((int32_t)" << v(E.a) << ", (int32_t)" << v(E.b) << "));\n";
+                            break;
+                        default:
+                            os << "        const uint32_t " << v(e) << " = " << (E.op == A_ADD ? "madd" : "msub") << "(" << v(E.a) << ", " << v(E.b) << ");\n";
+                    }
+                }
+                os << "        if (i" << u << " < " << n_inst << "u) ACC(pr" << u << "[0], " << v(C.entries.size() - 1) << ")\n";
+            }
+            os << "    }\n";
+        };
+        auto needs_sel = [&](const JitClass& C) {
+            for (const JitEntry& E : C.entries)
+                if (E.op == A_FIRST || E.op == A_LAST) return true;
+            return false;
+        };
+        for (size_t c = 0; c < classes.size(); c++)
+            if (!needs_sel(classes[c])) emit_class(c);
+        os << "    __builtin_amdgcn_s_waitcnt(0xc07f); __syncthreads();   // (lds_barrier.hpp: the LDS wait stated in front of the barrier)\n";
+        os << "    sel_first = sel_s[lane], sel_last = sel_s[64u + lane];\n";
+        for (size_t c = 0; c < classes.size(); c++)
+            if (needs_sel(classes[c])) emit_class(c);
+        os << R"JIT(
+    FINISH
+    red_s[(wv * 4u + 0u) * 64u + lane] = acc0, red_s[(wv * 4u + 1u) * 64u + lane] = acc1;
+    red_s[(wv * 4u + 2u) * 64u + lane] = acc2, red_s[(wv * 4u + 3u) * 64u + lane] = acc3;
+    __builtin_amdgcn_s_waitcnt(0xc07f); __syncthreads();
+    if (wv < 4u) {   // wave c sums coordinate c over the waves
+        const uint32_t izh = inv_zh_t[i & ((1u << B) - 1u)];
+        uint32_t v = red_s[wv * 64u + lane];
+        for (uint32_t w = 1; w < NW; w++) v = madd(v, red_s[(w * 4u + wv) * 64u + lane]);
+        q[(size_t)wv * M + r] = mmul(v, izh);
+    }
+}
+)JIT";
+        if (table->empty()) table->push_back(0);
+        return os.str();
     }
     quot_jit_epilogue(os);
     if (table->empty()) table->push_back(0);
@@ -614,8 +748,14 @@ inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vec
         if (quot_jit_source_tiled(p, lh, b, classes, table, &src)) {
             if (rows_per_block) *rows_per_block = 0;   // tiles of QUOT_TILE_ROWS rows walked by a fixed number of workgroups
         } else {
+            // the shared-rows form for tall chips with enough constraints to give sixteen waves work (ZKHIP_JIT_SHARED=0 / 1 forces)
+            size_t n_inst = 0;
+            for (const JitClass& C : classes) n_inst += C.inst.size();
+            static const int shared_env = getenv("ZKHIP_JIT_SHARED") ? atoi(getenv("ZKHIP_JIT_SHARED")) : -1;
+            const bool shared = lh + b >= 12 && (shared_env == 1 || (shared_env < 0 && lh + b >= 20 && n_inst >= 8 * QUOT_SHARED_WAVES));
             table->clear();
-            src = quot_jit_source(p, lh, b, classes, table);
+            src = quot_jit_source(p, lh, b, classes, table, shared);
+            if (shared && rows_per_block) *rows_per_block = 64;
         }
     } else {
         if (!quot_jit_source_flat(p, lh, b, &src, table, msg)) return false;
