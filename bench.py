@@ -191,7 +191,22 @@ def _flow_runs(cmd, env):
     return runs[0], measured[1], [round(rate(g)) for g in runs[1:]]
 
 
-def guest_flow_mixed():
+def launches_per_shape():
+    """kernel launches of one segment proof per shape, from the newest committed per-proof trace of the mixed guest on ONE lane (rocprofv3
+    --kernel-trace split into proofs by tools/trace_split_proofs.py; bench.py cannot count launches itself): {chips: launches}, with its source"""
+    import re
+    try:
+        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        name = sorted((n for n in os.listdir(d) if re.fullmatch(r"round\d+[a-z]?_launches_per_shape\.json", n)), reverse=True)[0]
+        with open(os.path.join(d, name)) as f:
+            out = json.load(f)
+        out["source_file"] = "profiles/" + name
+        return out
+    except Exception as e:
+        return {"note": "no profiles/roundNN_launches_per_shape.json: %r" % (e,)}
+
+
+def guest_flow_mixed(log_frame=20):
     """A CHUNK-LIKE guest under the reference's chunk-circuit configuration: tools/guest_bench2.py `mixed` -- register
     loops, strided loads, Keccak-f, SHA-256, secp256k1 additions / doublings, modular and 256-bit arithmetic in phases (ratios in the tool's
     output), so that segments land in the lean 22-chip, the 26-chip (base + hashes) and the full 51-chip shapes.  Reported: instructions per
@@ -201,7 +216,9 @@ def guest_flow_mixed():
     import subprocess
 
     here = os.path.dirname(os.path.abspath(__file__))
-    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py"), "8192", "20", "mixed"]
+    # (log_frame = 19: at frames of 2^20 instructions every segment of this guest spans a full phase and lands in the 51-chip shape; at 2^19
+    # about half of them hold plain and hash phases only -- the 26-chip shape gets a number on the driver line again: VERDICT round 5, 9a)
+    cmd = [sys.executable, os.path.join(here, "tools", "guest_bench2.py"), "8192", str(log_frame), "mixed"]
     try:
         first, g, rates = _flow_runs(cmd, dict(os.environ, ZKHIP_LANES="3"))
         secs = (g["segment_tracegen_and_proving_ms"] + g["aggregation_setup_wait_ms"] + g["aggregation_ms"]) / 1e3
@@ -213,7 +230,8 @@ def guest_flow_mixed():
                 "process_wall_s": g["wall_s"], "process_wall_s_first_run_on_this_box": first["wall_s"], "instr_per_s_of_the_three_measured_runs": rates,
                 "leaf_circuits_at_setup": g.get("leaf_circuits_at_setup"), "leaf_circuits_on_demand": g.get("leaf_circuits_on_demand"), "verified": g["verified"], "guest": g.get("guest"),
                 "segments_retried": g.get("segments_retried"), "segments_retried_in_all_four_runs": g.get("segments_retried_in_all_four_runs"),
-                "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 8192 20 mixed"}
+                "log_frame": log_frame, "launches_per_segment_proof_per_shape": launches_per_shape(),
+                "command": "ZKHIP_LANES=3 python tools/guest_bench2.py 8192 %d mixed" % log_frame}
     except Exception as e:   # a reported extra, never a gate
         return {"value": None, "note": "failed: %r" % (e,)}
 
@@ -330,13 +348,14 @@ def main():
         sys.exit(spawn_ranks(args))
     plumbing = os.environ.get("ZKHIP_BENCH_PLUMBING_ONLY") == "1"
     guest_devices = devices_flow_before_the_ranks_touch_the_gpu(args, plumbing) if "torch" not in sys.modules else None
-    guest = guest_chunk = guest_mixed = guest_mem = None
+    guest = guest_chunk = guest_mixed = guest_mixed19 = guest_mem = None
     # (child processes: only before torch / HIP are loaded here, and never under a profiler -- its preloaded library has initialised the GPU
     # before this program starts; the profiling recipes pass --no-cpu-baseline or --no-guest-flow, either of which skips the guest flows)
     if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not plumbing and not args.no_guest_flow and not args.no_cpu_baseline and "torch" not in sys.modules:
         guest = guest_flow()
         guest_chunk = guest_flow(chunk_config=True)
         guest_mixed = guest_flow_mixed()
+        guest_mixed19 = guest_flow_mixed(19)
         guest_mem = guest_flow(memory_bound=True)
     import numpy as np
     import torch
@@ -615,11 +634,27 @@ def main():
                 total_instr = pv.get("total_valu_wave_instr_per_proof") or sum(k["launches_per_proof"] * k["valu_wave_instr_per_launch"] for k in kern.values())
                 cpi = kern["zk::k_hash_rows"]["isa_mix"]["cycles_per_wave_instruction_model"]
                 floor_ms = pv.get("total_valu_roofline_ms_per_proof") or total_instr * cpi / (pv["peak"]["simds"] * pv["peak"]["clock_hz"]) * 1e3
+                # ... and every kernel priced with ITS OWN instruction mix where one is committed (profiles/roundNN_isa_mix_by_kernel.json:
+                # the transform passes and the constraint kernel carry more multiply-class instructions than the sponge -- VERDICT round 5, 9c)
+                own_floor_ms = own_note = None
+                try:
+                    import re as _re2
+                    mix_file = sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if _re2.fullmatch(r"round\d+[a-z]?_isa_mix_by_kernel\.json", n)), reverse=True)[0]
+                    with open(os.path.join(ROOT, "profiles", mix_file)) as f:
+                        own = json.load(f)["cycles_per_wave_instruction_model"]
+                    cyc = sum(k["launches_per_proof"] * k["valu_wave_instr_per_launch"] * own.get(name, cpi) for name, k in kern.items())
+                    own_floor_ms = cyc / (pv["peak"]["simds"] * pv["peak"]["clock_hz"]) * 1e3
+                    own_note = "profiles/%s: %s; every other kernel at the sponge's %.3f" % (mix_file, ", ".join("%s %.2f" % (n, c) for n, c in sorted(own.items()) if n in kern), cpi)
+                except Exception as e:
+                    own_note = "no per-kernel mix: %r" % (e,)
                 ms = dt / args.steps * 1e3  # every rank proves `steps` proofs in dt
                 valu_roof = {"valu_wave_instr_per_proof": int(total_instr), "cycles_per_wave_instr_model": cpi,
                              "floor_ms_per_proof": round(floor_ms, 2),
                              "ms_per_proof_per_gpu": round(ms, 2),
                              "frac": None if pv_stale else round(floor_ms / ms, 3),
+                             "floor_ms_per_proof_each_kernel_at_its_own_mix": None if own_floor_ms is None else round(own_floor_ms, 2),
+                             "frac_each_kernel_at_its_own_mix": None if (pv_stale or own_floor_ms is None) else round(own_floor_ms / ms, 3),
+                             "own_mix_note": own_note,
                              "stale": pv_stale, "code_check": pv_note,
                              "hash_rows_share_of_valu_instr": round(2 * kern["zk::k_hash_rows"]["valu_wave_instr_per_launch"] / total_instr, 3),
                              "note": "profiles/%s: SQ_INSTS_VALU summed over the kernels of one proof x the model cycles per wave-instruction "
@@ -714,6 +749,8 @@ def main():
             out["guest_flow_chunk_config"] = guest_chunk
         if guest_mixed is not None:
             out["guest_flow_mixed"] = guest_mixed
+        if guest_mixed19 is not None:
+            out["guest_flow_mixed_frame19"] = guest_mixed19
         if guest_mem is not None:
             out["guest_flow_memory_bound"] = guest_mem
         if guest_devices is not None:
