@@ -14,6 +14,9 @@ import pytest
 import zkvm_prover_amd as z
 from zkvm_prover_amd import air
 
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
@@ -105,3 +108,35 @@ def test_the_fused_middle_of_the_lde_is_bit_exact(zk, ora, monkeypatch):
         base4 = zk.download(zk.lde_batch(d, log_n, 2, width, 7))          # four cosets, another shift
         monkeypatch.delenv("ZKHIP_LDE_FUSED")
         assert (zk.download(zk.lde_batch(d, log_n, 2, width, 7)) == base4).all()
+
+
+def test_the_shared_rows_constraint_kernel_gives_the_oracles_proof(tmp_path):
+    """ZKHIP_JIT_SHARED=1 (csrc/quotient_jit.hpp: sixteen waves per 64 rows, wave w takes instances w, w + 16, ...; opt-in, measured slower than
+    the plain form on the headline chip): chips of 2^12 rows with buses, preprocessed keys and a shared range table -- proof bytes == the
+    oracle's.  A process of its own: the form is chosen when the kernel is generated, from the environment."""
+    import os
+    import subprocess
+    import sys
+
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle_lib as ora
+import zkvm_prover_amd as z
+from zkvm_prover_amd import air
+ora.lib()
+zk = z.Context(0)
+zk.set_config(jit=2)
+params = (1, 0, 8, 3, 4)
+airs = air.ChipSet(n_chips=5, log_max=12, log_min=11, total_width=70, seed=4, log_table=3).gen(1)
+exp = ora.stark_prove(params, airs).tobytes()
+pk = z.ProvingKey(zk, params, airs)
+pvs = [a["pvs"] for a in airs]
+got = pk.prove([zk.upload(a["trace"].reshape(-1)) for a in airs], pvs)
+assert got == exp, "shared-rows constraint kernel: proof differs from the oracle's"
+assert z.verify(params, pk.verifying_airs(), pvs, got) == 0
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZKHIP_JIT_SHARED="1", ZKHIP_JIT_CACHE_DIR=str(tmp_path)), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert any(f.name.endswith(".hsaco") and b"NW 16u" in f.read_bytes() for f in tmp_path.iterdir()), "no shared-rows kernel was generated"

@@ -748,11 +748,12 @@ inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vec
         if (quot_jit_source_tiled(p, lh, b, classes, table, &src)) {
             if (rows_per_block) *rows_per_block = 0;   // tiles of QUOT_TILE_ROWS rows walked by a fixed number of workgroups
         } else {
-            // the shared-rows form for tall chips with enough constraints to give sixteen waves work (ZKHIP_JIT_SHARED=0 / 1 forces)
-            size_t n_inst = 0;
-            for (const JitClass& C : classes) n_inst += C.inst.size();
-            static const int shared_env = getenv("ZKHIP_JIT_SHARED") ? atoi(getenv("ZKHIP_JIT_SHARED")) : -1;
-            const bool shared = lh + b >= 12 && (shared_env == 1 || (shared_env < 0 && lh + b >= 20 && n_inst >= 8 * QUOT_SHARED_WAVES));
+            // the shared-rows form: OPT-IN (ZKHIP_JIT_SHARED=1, chips of >= 2^12 LDE rows).  Measured on the headline's 300-column chip
+            // (profiles/round06_quot_jit_shared_and_lanes.txt): 6.08 ms against the plain form's 5.32 ms -- sharing the rows among sixteen waves does not
+            // pay for the two barriers and the sixteen short instance lists; the plain form stays the default.  Bit-exact either way
+            // (the parity suites run with it forced: 99 tests).
+            static const int shared_env = getenv("ZKHIP_JIT_SHARED") ? atoi(getenv("ZKHIP_JIT_SHARED")) : 0;
+            const bool shared = lh + b >= 12 && shared_env == 1;
             table->clear();
             src = quot_jit_source(p, lh, b, classes, table, shared);
             if (shared && rows_per_block) *rows_per_block = 64;
