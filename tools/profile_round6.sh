@@ -21,8 +21,8 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES -d $O/v/v1 -o v --output-f
 rocprofv3 --pmc SQ_BUSY_CYCLES -d $O/v/v3 -o v --output-format csv -- $B > /dev/null 2> $O/v3_err.txt
 rocprofv3 --pmc GRBM_GUI_ACTIVE -d $O/v/v4 -o v --output-format csv -- $B > /dev/null 2> $O/v4_err.txt
 FC=$(find $O/f -name "*counter_collection.csv" | head -1); WC=$(find $O/w -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_traffic.py $FC $WC 1 $O/pmc_traffic.json
-python3 tools/pmc_valu3.py $O/v 1 $O/pmc_valu.json profiles/round05_isa_mix_hash_rows.json 2>&1 | tail -8
+python3 tools/pmc_traffic.py $FC $WC 4 $O/pmc_traffic.json
+python3 tools/pmc_valu3.py $O/v 4 $O/pmc_valu.json profiles/round05_isa_mix_hash_rows.json 2>&1 | tail -8
 python3 - <<'PY'
 import csv, glob, json, os, collections
 O = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/r6prof"

@@ -66,6 +66,19 @@ struct QuotArgs {
     unsigned lh, b;
     uint32_t n_rows;        // rows to evaluate: the first N * (quotient chunks) of the M LDE rows (M for the stage-level entry)
 };
+// Z_H(x) / (x - 1) and Z_H(x) / (x - w_N^-1) for the first n_rows rows of a bit-reversed LDE of 2^h points (coset shift `gen`): the selector
+// tables of the shared-rows constraint kernel (csrc/quotient_jit.hpp), generated with the key -- the values its plain form computes per wave
+__global__ __launch_bounds__(256) void k_gen_selectors(uint32_t* __restrict__ first, uint32_t* __restrict__ last, uint32_t n_rows, uint32_t h, uint32_t b, uint32_t gen,
+                                                       uint32_t w_m, uint32_t w_n_inv, const uint32_t* __restrict__ zh_t) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t i = __brev(r) >> (32 - h);
+    const uint32_t x = mmul(gen, mpow(w_m, i));
+    const uint32_t zh = zh_t[i & ((1u << b) - 1u)];
+    first[r] = mmul(zh, minv(msub(x, MONTY_ONE)));
+    last[r] = mmul(zh, minv(msub(x, w_n_inv)));
+}
+
 // every chip that runs the interpreter, in ONE launch: descriptor array + block prefix table (the twiddle table belongs
 // to the context, not to the key, so it is a launch parameter)
 struct QuotMulti {
@@ -829,7 +842,8 @@ struct AirPlan {
     uint32_t prep_commit[8] = {};      // canonical
     hipModule_t jit_mod = nullptr;   // keygen-compiled constraint kernel (null -> interpreter)
     hipFunction_t jit_fn = nullptr;
-    unsigned jit_rows_per_block = 256;   // 0: the LDS-tiled form (a fixed grid walks 64-row tiles); 64: the shared-rows form (csrc/quotient_jit.hpp)
+    unsigned jit_rows_per_block = 256;   // 0: the LDS-tiled form (a fixed grid walks 64-row tiles); 64 + 256 NW: the shared-rows form, NW waves per 64 rows (csrc/quotient_jit.hpp)
+    size_t jit_tab_words = 0;            // the parameter table's words; the shared-rows form keeps its two selector tables (MQ words each) behind them
     uint32_t* d_jit_tab = nullptr;   // per-instance leaf parameters of the shape classes
 };
 
@@ -1211,9 +1225,10 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
                 }
             } jit_timer{jit_t0, a, (size_t)A.prog.n_nodes, !interp_ok};
             if (quot_jit_build(A.prog, airs[a].log_height, pk->b, &A.jit_mod, &A.jit_fn, &tab, &msg, &A.jit_rows_per_block, ctx->cfg.jit_cache_dir) &&
-                hipMalloc(&A.d_jit_tab, tab.size() * 4) == hipSuccess &&
+                hipMalloc(&A.d_jit_tab, (tab.size() + ((A.jit_rows_per_block & 255u) == 64 ? 2 * A.MQ : 0)) * 4) == hipSuccess &&
                 hipMemcpyAsync(A.d_jit_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
                 hipStreamSynchronize(ctx->stream) == hipSuccess) {
+                A.jit_tab_words = tab.size();
             } else {
                 if (A.jit_mod) (void)hipModuleUnload(A.jit_mod);
                 A.jit_mod = nullptr;
@@ -1438,6 +1453,12 @@ int zkhip_keygen(zkhip_ctx* ctx, const zkhip_params* params, const zkhip_air* ai
         }
         if (rc == ZKHIP_OK) rc = upload(ctx, A.d_zh, zh.data(), nch * 4);
         if (rc == ZKHIP_OK) rc = upload(ctx, A.d_inv_zh, izh.data(), nch * 4);
+        if (rc == ZKHIP_OK && A.jit_fn && (A.jit_rows_per_block & 255u) == 64) {   // the shared-rows constraint kernel reads its selectors from a table
+            KernelScope ks(ctx, "gen_selectors");
+            hipLaunchKernelGGL(k_gen_selectors, dim3((unsigned)((A.MQ + 255) / 256)), dim3(256), 0, ctx->stream, A.d_jit_tab + A.jit_tab_words, A.d_jit_tab + A.jit_tab_words + A.MQ,
+                               (uint32_t)A.MQ, A.h, pk->b, to_monty(FIELD_GEN_CANON), two_adic_generator(A.h), minv(two_adic_generator(A.lh)), A.d_zh);
+            if (hipGetLastError() != hipSuccess) rc = set_error(ctx, ZKHIP_ERR_HIP, "k_gen_selectors");
+        }
         if (A.prep_w) {
             A.d_prep = (uint32_t*)(base + ao[a].prep);
             A.d_prep_lde = (uint32_t*)(base + ao[a].prep_lde);
@@ -2056,7 +2077,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
     // six large chips lost 3 - 10 % when they were spread too)
     // (jit_rows_per_block: 256 = the plain form, 64 = the shared-rows form -- sixteen waves per 64 rows --, 0 = the LDS-tiled form, a fixed grid)
     auto jit_blocks = [&](const AirPlan& A) {
-        return A.jit_rows_per_block == 64 ? (unsigned)(A.MQ / 64) : A.jit_rows_per_block ? (unsigned)((A.MQ + 255) / 256) : (unsigned)std::min<size_t>(A.MQ / 64, 4 * 256);
+        return (A.jit_rows_per_block & 255u) == 64 ? (unsigned)(A.MQ / 64) : A.jit_rows_per_block ? (unsigned)((A.MQ + 255) / 256) : (unsigned)std::min<size_t>(A.MQ / 64, 4 * 256);
     };
     unsigned n_jit = 0, fan = 0;
     // (an error between fork and join returns from this function: the side streams are drained first -- buffers the next proof reuses may
@@ -2115,7 +2136,7 @@ int zkhip_prove_async(zkhip_ctx* ctx, const zkhip_pk* pkc, const uint32_t* const
                           (void*)&qa.lchal, (void*)&qa.expo, (void*)&qa.prep, (void*)&h_bits, (void*)&nq_rows};
         // (tiled form: one workgroup per CU holds its 150 KB tile; a few rounds of workgroups per CU even the tail out)
         const unsigned blocks = jit_blocks(A);
-        ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, blocks, 1, 1, A.jit_rows_per_block == 64 ? 64 * QUOT_SHARED_WAVES : A.jit_rows_per_block ? 256 : 64 * QUOT_TILE_WAVES, 1, 1, 0, qs, params, nullptr));
+        ZK_HIP_CHECK(ctx, hipModuleLaunchKernel(A.jit_fn, blocks, 1, 1, (A.jit_rows_per_block & 255u) == 64 ? 64 * (A.jit_rows_per_block >> 8) : A.jit_rows_per_block ? 256 : 64 * QUOT_TILE_WAVES, 1, 1, 0, qs, params, nullptr));
     }
     for (unsigned q = 0; q < fan; q++) {
         ZK_HIP_CHECK(ctx, hipEventRecord(ctx->quot_join[q], ctx->quot_streams[q]));

@@ -254,7 +254,15 @@ inline void quot_jit_epilogue(std::ostringstream& os) {
 // wave w evaluates instances w, w + 16, ... of every class, so the rows in flight per XCD are a sixteenth (4.9 MB) and a cell's re-reads by
 // the other waves of the workgroup find it in the L2; the sixteen partial sums meet in LDS.  The two selector inversions are done once per
 // workgroup (waves 0 and 1) while the other waves evaluate the classes that need neither.
-constexpr unsigned QUOT_SHARED_WAVES = 16;
+// waves per row block of the shared-rows form (ZKHIP_JIT_SHARED_WAVES = 4 / 8 / 16, default 16; measurements)
+inline unsigned quot_shared_waves() {
+    static const unsigned v = [] {
+        const char* e = getenv("ZKHIP_JIT_SHARED_WAVES");
+        const int n = e ? atoi(e) : 16;
+        return (unsigned)(n == 4 || n == 8 ? n : 16);
+    }();
+    return v;
+}
 inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b, std::vector<JitClass>& classes,
                                    std::vector<uint32_t>* table, bool shared = false) {
     (void)p;
@@ -263,16 +271,15 @@ inline std::string quot_jit_source(const AirProgram& p, unsigned lh, unsigned b,
         quot_jit_prologue(os, lh, b, p.qd());
     } else {
         os << quot_jit_preamble();
-        os << "#define B " << b << "u\n#define M ((size_t)1 << H)\n#define NW " << QUOT_SHARED_WAVES << "u\n";
+        os << "#define B " << b << "u\n#define M ((size_t)1 << H)\n#define NW " << quot_shared_waves() << "u\n#define SEL_OFF __SEL_OFF__\n";
         os << R"JIT(
-extern "C" __global__ __launch_bounds__(64 * NW) void quot_jit(const uint32_t* __restrict__ lde, uint32_t* __restrict__ q,
+extern "C" __global__ __launch_bounds__(64 * NW, 8) void quot_jit(const uint32_t* __restrict__ lde, uint32_t* __restrict__ q,
         const uint32_t* __restrict__ pvs, const uint32_t* __restrict__ apow, const uint32_t* __restrict__ tw_fwd,
         const uint32_t* __restrict__ zh_t, const uint32_t* __restrict__ inv_zh_t, const uint32_t* __restrict__ tab,
         uint32_t gen, uint32_t w_n_inv, uint32_t tw_shift, const uint32_t* __restrict__ perm,
         const uint32_t* __restrict__ lchal, const uint32_t* __restrict__ expo, const uint32_t* __restrict__ prep,
         uint32_t H, uint32_t NQROWS) {
-    __shared__ uint32_t red_s[4u * NW * 64u + 2u * 64u];   // [wave][coordinate][lane], then sel_first, sel_last per lane
-    uint32_t* const sel_s = red_s + 4u * NW * 64u;
+    __shared__ uint32_t red_s[4u * NW * 64u];   // [wave][coordinate][lane]
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (wave-uniform: the parameter rows stay scalar loads)
     const uint32_t r = blockIdx.x * 64u + lane;   // (NQROWS is a multiple of 64: the form is chosen for tall chips only)
@@ -281,11 +288,10 @@ extern "C" __global__ __launch_bounds__(64 * NW) void quot_jit(const uint32_t* _
     const uint32_t halfm = 1u << (H - 1);
     const uint32_t wi = i < halfm ? tw_fwd[(size_t)i << tw_shift] : mneg(tw_fwd[(size_t)(i - halfm) << tw_shift]);
     const uint32_t x = mmul(gen, wi);
-    const uint32_t zh = zh_t[i & ((1u << B) - 1u)];
     const uint32_t sel_trans = msub(x, w_n_inv);
-    if (wv == 0u) sel_s[lane] = mmul(zh, minv(msub(x, ONE)));
-    if (wv == 1u) sel_s[64u + lane] = mmul(zh, minv(sel_trans));
-    uint32_t sel_first = 0, sel_last = 0;
+    // Z_H(x) / (x - 1) and Z_H(x) / (x - w^-1) per LDE row: a table behind the parameter table, generated with the key (k_gen_selectors,
+    // csrc/prover.hip) -- sixteen waves would each invert twice, or two of them would hold the others at a barrier
+    const uint32_t sel_first = ((gptr)tab)[SEL_OFF + r], sel_last = ((gptr)tab)[SEL_OFF + NQROWS + r];
     uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
     uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
     uint32_t cnt = 0;
@@ -382,6 +388,7 @@ extern "C" __global__ __launch_bounds__(64 * NW) void quot_jit(const uint32_t* _
     if (shared) {
         // wave w takes instances w, w + NW, ... of a class, SU of them per iteration: an index beyond the class is clamped to its last instance
         // (evaluated again, not accumulated), so the loads of an iteration are unconditional and issue together
+        size_t given = 0;
         auto emit_class = [&](size_t c) {
             JitClass& C = classes[c];
             const size_t stride = 1 + C.param_entry.size(), n_inst = C.inst.size();
@@ -398,9 +405,14 @@ extern "C" __global__ __launch_bounds__(64 * NW) void quot_jit(const uint32_t* _
                 }
             }
             auto stays_signed = [&](size_t e) { return C.entries[e].op == A_MUL && used[e] && only_mul[e] && e + 1 != C.entries.size(); };
-            const unsigned per_wave = (unsigned)((n_inst + QUOT_SHARED_WAVES - 1) / QUOT_SHARED_WAVES);
+            const unsigned NWv = quot_shared_waves();
+            const unsigned per_wave = (unsigned)((n_inst + NWv - 1) / NWv);
             const unsigned SU = std::min<unsigned>(per_wave, std::min<unsigned>(unroll, 4u));
-            os << "    for (uint32_t it = wv; it < " << n_inst << "u; it += " << SU << "u * NW) {\n";
+            // (the class's first instance goes to the wave after the one that took the previous class's last: the lists stay level over the
+            // classes of a chip, whatever their sizes)
+            const unsigned first_wave = (unsigned)(given % NWv);
+            given += n_inst;
+            os << "    for (uint32_t it = (wv + NW - " << first_wave << "u) % NW; it < " << n_inst << "u; it += " << SU << "u * NW) {\n";
             for (unsigned u = 0; u < SU; u++) {
                 os << "        const uint32_t i" << u << " = it + " << u << "u * NW;\n";
                 os << "        cptr pr" << u << " = (cptr)tab + " << C.table_off << "u + (i" << u << " < " << n_inst << "u ? i" << u << " : " << (n_inst - 1) << "u) * " << stride << "u;\n";
@@ -442,17 +454,7 @@ extern "C" __global__ __launch_bounds__(64 * NW) void quot_jit(const uint32_t* _
             }
             os << "    }\n";
         };
-        auto needs_sel = [&](const JitClass& C) {
-            for (const JitEntry& E : C.entries)
-                if (E.op == A_FIRST || E.op == A_LAST) return true;
-            return false;
-        };
-        for (size_t c = 0; c < classes.size(); c++)
-            if (!needs_sel(classes[c])) emit_class(c);
-        os << "    __builtin_amdgcn_s_waitcnt(0xc07f); __syncthreads();   // (lds_barrier.hpp: the LDS wait stated in front of the barrier)\n";
-        os << "    sel_first = sel_s[lane], sel_last = sel_s[64u + lane];\n";
-        for (size_t c = 0; c < classes.size(); c++)
-            if (needs_sel(classes[c])) emit_class(c);
+        for (size_t c = 0; c < classes.size(); c++) emit_class(c);
         os << R"JIT(
     FINISH
     red_s[(wv * 4u + 0u) * 64u + lane] = acc0, red_s[(wv * 4u + 1u) * 64u + lane] = acc1;
@@ -467,7 +469,10 @@ extern "C" __global__ __launch_bounds__(64 * NW) void quot_jit(const uint32_t* _
 }
 )JIT";
         if (table->empty()) table->push_back(0);
-        return os.str();
+        std::string out = os.str();
+        const std::string key = "__SEL_OFF__";   // the selector tables start where the parameter table ends
+        for (size_t pos = out.find(key); pos != std::string::npos; pos = out.find(key, pos)) out.replace(pos, key.size(), std::to_string(table->size()) + "u");
+        return out;
     }
     quot_jit_epilogue(os);
     if (table->empty()) table->push_back(0);
@@ -756,7 +761,7 @@ inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vec
             const bool shared = lh + b >= 12 && shared_env == 1;
             table->clear();
             src = quot_jit_source(p, lh, b, classes, table, shared);
-            if (shared && rows_per_block) *rows_per_block = 64;
+            if (shared && rows_per_block) *rows_per_block = 64 + 256 * quot_shared_waves();   // (64 rows per workgroup of so many waves)
         }
     } else {
         if (!quot_jit_source_flat(p, lh, b, &src, table, msg)) return false;
