@@ -254,12 +254,13 @@ inline void quot_jit_epilogue(std::ostringstream& os) {
 // wave w evaluates instances w, w + 16, ... of every class, so the rows in flight per XCD are a sixteenth (4.9 MB) and a cell's re-reads by
 // the other waves of the workgroup find it in the L2; the sixteen partial sums meet in LDS.  The two selector inversions are done once per
 // workgroup (waves 0 and 1) while the other waves evaluate the classes that need neither.
-// waves per row block of the shared-rows form (ZKHIP_JIT_SHARED_WAVES = 4 / 8 / 16, default 16; measurements)
+// waves per row block of the shared-rows form (ZKHIP_JIT_SHARED_WAVES = 2 / 4 / 8 / 16; measured on the headline's chip, with the selector
+// tables: 16: 5.89 ms, 8: 5.32, 4: 4.99 against the plain form's 5.29 -- profiles/round06_quot_jit_shared_v2.txt; default 4)
 inline unsigned quot_shared_waves() {
     static const unsigned v = [] {
         const char* e = getenv("ZKHIP_JIT_SHARED_WAVES");
-        const int n = e ? atoi(e) : 16;
-        return (unsigned)(n == 4 || n == 8 ? n : 16);
+        const int n = e ? atoi(e) : 4;
+        return (unsigned)(n == 2 || n == 8 || n == 16 ? n : 4);
     }();
     return v;
 }
@@ -753,12 +754,15 @@ inline bool quot_jit_code(const AirProgram& p, unsigned lh, unsigned b, std::vec
         if (quot_jit_source_tiled(p, lh, b, classes, table, &src)) {
             if (rows_per_block) *rows_per_block = 0;   // tiles of QUOT_TILE_ROWS rows walked by a fixed number of workgroups
         } else {
-            // the shared-rows form: OPT-IN (ZKHIP_JIT_SHARED=1, chips of >= 2^12 LDE rows).  Measured on the headline's 300-column chip
-            // (profiles/round06_quot_jit_shared_and_lanes.txt): 6.08 ms against the plain form's 5.32 ms -- sharing the rows among sixteen waves does not
-            // pay for the two barriers and the sixteen short instance lists; the plain form stays the default.  Bit-exact either way
-            // (the parity suites run with it forced: 99 tests).
-            static const int shared_env = getenv("ZKHIP_JIT_SHARED") ? atoi(getenv("ZKHIP_JIT_SHARED")) : 0;
-            const bool shared = lh + b >= 12 && shared_env == 1;
+            // the shared-rows form: for TALL chips with enough constraints (>= 2^20 LDE rows, >= 64 instances; ZKHIP_JIT_SHARED=0 / 1 forces it
+            // off / on for every chip of >= 2^12 LDE rows).  Measured on the headline's 300-column chip: first cut (sixteen waves, selectors
+            // inverted by two of them, a barrier in the middle) 6.08 ms against the plain form's 5.32 (profiles/round06_quot_jit_shared_and_lanes.txt);
+            // with the selectors in a table, level instance lists and FOUR waves per row block 4.99 ms (profiles/round06_quot_jit_shared_v2.txt)
+            // at a third of the plain form's L2 misses.  Bit-exact either way (the parity suites run with it forced).
+            size_t n_inst = 0;
+            for (const JitClass& C : classes) n_inst += C.inst.size();
+            static const int shared_env = getenv("ZKHIP_JIT_SHARED") ? atoi(getenv("ZKHIP_JIT_SHARED")) : -1;
+            const bool shared = lh + b >= 12 && (shared_env == 1 || (shared_env < 0 && lh + b >= 20 && n_inst >= 64));
             table->clear();
             src = quot_jit_source(p, lh, b, classes, table, shared);
             if (shared && rows_per_block) *rows_per_block = 64 + 256 * quot_shared_waves();   // (64 rows per workgroup of so many waves)
