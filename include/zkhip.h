@@ -767,7 +767,10 @@ int zkhip_vm_mul256_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, const ui
                              uint32_t *d_bitwise_trace, uint32_t *d_tuple_counts, uint32_t size_x, uint32_t size_y);
 /* 256-bit comparison chip (b < c unsigned / signed, b == c; 103 columns; 34 lookups per row in the bitwise table's range column): d_records:
  * n x 17 words (op | b[8] | c[8], op 6 sltu, 7 slt, 8 eq); zkhip_int256_alu_host accepts ops 6..8 for it (the result word is 0 or 1);
- * inside the VM 104 columns (+ the timestamp) */
+ * inside the VM 108 columns: + the timestamp and the 256-BIT BRANCH columns is_br | neg | taken | opcode -- there d_records may also carry
+ * the branch opcodes 12 beq, 13 bne, 14 bltu, 15 blt, 16 bgeu, 17 bge (OpenVM's Rv32BranchEqual256 / Rv32BranchLessThan256,
+ * /root/reference/crates/circuits/chunk-circuit/openvm.toml:17-18): the row is the comparison's they rest on, `taken` = its result XOR neg goes to
+ * the ecall chip, whose row steps the pc by 4 or by a2 (include/zkhip_int256.hpp cmp256_vm_air, include/zkhip_vm_circuit.hpp ecall_air) */
 #define ZKHIP_INT256_CMP_WIDTH 103
 int zkhip_int256_cmp_air(uint32_t bitwise_bus, zkhip_air *out);
 int zkhip_int256_cmp_tracegen(zkhip_ctx *ctx, const uint32_t *d_records, size_t n, unsigned log_height, uint32_t *d_trace, uint32_t *d_bitwise_trace);

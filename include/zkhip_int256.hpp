@@ -142,12 +142,36 @@ inline Expr cmp256_air(AirBuilder& b, uint32_t bitwise_bus) {
         for (size_t i = 0; i < LIMBS; i += 2) b.push_interaction(bitwise_bus, {b.var(base + i), b.var(base + i + 1), zero, zero}, real, Kind::Send);
     return is_eq * (1 - prefix) + (is_sltu + is_slt) * t;
 }
-// inside the VM: + a timestamp column; the call's 24 words arrive on the ALU chip's word bus with the comparison's opcode
-constexpr size_t CMP_COL_TS = CMP_WIDTH, CMP_VM_WIDTH = CMP_WIDTH + 1;
-inline void cmp256_vm_air(AirBuilder& b, uint32_t bitwise_bus, uint32_t word_bus) {
+// inside the VM: + a timestamp column; the call's 24 words arrive on the ALU chip's word bus with the comparison's opcode.
+// 256-BIT BRANCHES (round 6; OpenVM's Rv32BranchEqual256 / Rv32BranchLessThan256, crates/circuits/chunk-circuit/openvm.toml:17-18): the same
+// comparison decides a branch.  Opcodes 12 beq, 13 bne, 14 bltu, 15 blt, 16 bgeu, 17 bge: the row is the comparison's (equality for 12 / 13,
+// unsigned less-than for 14 / 16, signed for 15 / 17; the result word is still written, as the comparison's), plus
+//   is_br   the call is a branch            neg   the branch is taken when the comparison is FALSE (bne, bgeu, bge)
+//   taken   = out XOR neg: sent to the ecall chip on the branch bus with the call's timestamp -- there it chooses between pc + 4 and
+//           pc + a2 (include/zkhip_vm_circuit.hpp ecall_air).
+constexpr uint32_t OP_BEQ = 12, OP_BNE = 13, OP_BLTU = 14, OP_BLT = 15, OP_BGEU = 16, OP_BGE = 17;
+inline bool is_branch_op(uint32_t op) { return op >= OP_BEQ && op <= OP_BGE; }
+inline bool branch_negates(uint32_t op) { return op == OP_BNE || op == OP_BGEU || op == OP_BGE; }
+// the comparison a branch opcode rests on (OP_EQ / OP_SLTU / OP_SLT); other opcodes unchanged
+inline uint32_t compare_op_of(uint32_t op) { return op == OP_BEQ || op == OP_BNE ? 8u : op == OP_BLTU || op == OP_BGEU ? 6u : op == OP_BLT || op == OP_BGE ? 7u : op; }
+//   opc     the call's opcode as the adapter announces it (a column, so that the 24 word-bus messages stay of degree 1)
+constexpr size_t CMP_COL_TS = CMP_WIDTH, CMP_COL_BR = CMP_WIDTH + 1, CMP_COL_NEG = CMP_WIDTH + 2, CMP_COL_TAKEN = CMP_WIDTH + 3, CMP_COL_OPC = CMP_WIDTH + 4,
+                 CMP_VM_WIDTH = CMP_WIDTH + 5;
+inline void cmp256_vm_air(AirBuilder& b, uint32_t bitwise_bus, uint32_t word_bus, uint32_t branch_bus) {
     const Expr out = cmp256_air(b, bitwise_bus);
     const Expr ts = b.var(CMP_COL_TS), is_sltu = b.var(CMP_COL_FLAGS), is_slt = b.var(CMP_COL_FLAGS + 1), is_eq = b.var(CMP_COL_FLAGS + 2);
-    const Expr real = is_sltu + is_slt + is_eq, op = is_sltu * (int64_t)OP_SLTU + is_slt * (int64_t)OP_SLT + is_eq * (int64_t)OP_EQ, zero = b.constant(0);
+    const Expr is_br = b.var(CMP_COL_BR), neg = b.var(CMP_COL_NEG), taken = b.var(CMP_COL_TAKEN);
+    const Expr real = is_sltu + is_slt + is_eq, zero = b.constant(0);
+    for (const Expr& f : {is_br, neg, taken}) b.assert_zero(f * (f - 1));
+    b.assert_zero(is_br * (1 - real));    // a branch is a real comparison row
+    b.assert_zero(neg * (1 - is_br));     // only a branch negates
+    b.assert_zero(taken * (1 - is_br));
+    b.assert_zero(taken - is_br * out - neg + out * neg * 2);     // taken = out XOR neg on a branch row, 0 elsewhere (neg implies is_br); degree 3
+    // the opcode the adapter announces on the word bus: 6 / 7 / 8 for a comparison, 14 + 2 neg / 15 + 2 neg / 12 + neg for a branch
+    const Expr op = b.var(CMP_COL_OPC);
+    b.assert_zero(op - (is_sltu * (int64_t)OP_SLTU + is_slt * (int64_t)OP_SLT + is_eq * (int64_t)OP_EQ +
+                        is_br * (is_sltu * (int64_t)(OP_BLTU - OP_SLTU) + is_slt * (int64_t)(OP_BLT - OP_SLT) + is_eq * (int64_t)(OP_BEQ - OP_EQ)) + neg * (is_sltu + is_slt) * 2 + neg * is_eq));
+    b.push_interaction(branch_bus, {ts, taken}, is_br, Kind::Send);
     const size_t base[2] = {CMP_COL_B, CMP_COL_C};
     for (size_t o = 0; o < 2; o++)
         for (size_t k = 0; k < 8; k++) {
@@ -164,10 +188,13 @@ inline uint32_t cmp256(uint32_t op, const uint32_t b[8], const uint32_t c[8]) {
             eq = false, lt = b[i] < c[i];
             break;
         }
+    op = compare_op_of(op);   // (a branch opcode: the comparison it rests on)
     if (op == OP_EQ) return eq ? 1u : 0u;
     if (op == OP_SLT && ((b[7] ^ c[7]) >> 31)) return b[7] >> 31;   // different signs: the negative one is smaller
     return lt ? 1u : 0u;
 }
+// a 256-bit branch: taken?
+inline bool branch256_taken(uint32_t op, const uint32_t b[8], const uint32_t c[8]) { return (cmp256(op, b, c) != 0) != branch_negates(op); }
 // ---- 256-bit shifts (OpenVM's Rv32Shift256: SLL / SRL / SRA by c mod 256) -- a chip of its own, in two steps per row:
 //   shift amount   c0 = bit_shift + 8 limb_shift with one-hot markers bm[8], lm[32] (c0, c1 looked up as bytes: the low half word of c
 //                  splits uniquely; the other halves of c only pass through to the bus); mult = 2^bit_shift = sum bm_i 2^i
@@ -180,7 +207,7 @@ inline uint32_t cmp256(uint32_t op, const uint32_t b[8], const uint32_t c[8]) {
 // Columns: a[32] | b[32] | t[32] | cy[32] | c0 c1 c_hi0 | c words 1..7 as halves [14] | bm[8] | lm[32] | sign | is_sll is_srl is_sra   189
 // Lookups: 32 carries, t and b pairwise (the limb equations need honest bytes; a inherits from t), (c0, c1), the sign bit of b_31 as the
 // XOR (b_31, 128, b_31 + 128 - 256 sign) for SRA.  Degree 3.
-constexpr uint32_t OP_SLL = 9, OP_SRL = 10, OP_SRA = 11, N_INT256_OPS = 12;
+constexpr uint32_t OP_SLL = 9, OP_SRL = 10, OP_SRA = 11, N_INT256_OPS = 18;   // (12 .. 17: the branches, above)
 constexpr size_t SH_COL_A = 0, SH_COL_B = 32, SH_COL_T = 64, SH_COL_CY = 96, SH_COL_C0 = 128, SH_COL_C1 = 129, SH_COL_CHI0 = 130, SH_COL_CW = 131, SH_COL_BM = 145,
                  SH_COL_LM = 153, SH_COL_SIGN = 185, SH_COL_FLAGS = 186, SH_WIDTH = 189;
 inline void shift256_air(AirBuilder& b, uint32_t bitwise_bus) {

@@ -732,7 +732,16 @@ private:
                     uint8_t* p = at(addr, 96);
                     uint32_t b[8], c[8], a[8];
                     memcpy(b, p, 32), memcpy(c, p + 32, 32);
-                    if (op >= zkhip::int256::OP_SLL) {
+                    if (zkhip::int256::is_branch_op(op)) {
+                        // 12 beq, 13 bne, 14 bltu, 15 blt, 16 bgeu, 17 bge (OpenVM's Rv32BranchEqual256 / Rv32BranchLessThan256): compares b and
+                        // c, leaves the comparison's 0 / 1 in a like opcodes 6 .. 8, and continues at pc + a2 (a byte offset, a multiple of
+                        // four, backwards when negative) if the branch is taken
+                        memset(a, 0, sizeof a);
+                        a[0] = zkhip::int256::cmp256(op, b, c);
+                        const uint32_t off = reg_read(rec, 12);
+                        if (off & 3u) throw Error("int256 branch: the offset in a2 must be a multiple of four");
+                        if ((a[0] != 0) != zkhip::int256::branch_negates(op)) next = pc_ + off;
+                    } else if (op >= zkhip::int256::OP_SLL) {
                         zkhip::int256::shift256(op, b, c, a);
                     } else if (op >= zkhip::int256::OP_SLTU) {
                         memset(a, 0, sizeof a);

@@ -83,12 +83,13 @@ constexpr uint32_t MEMORY_BUS = 1, EXEC_BUS = 2, OPERAND_BUS = 3, RANGE_BUS = 5,
                    MERKLE_BUS = 10, HASH_BUS = 11, KECCAK_REQ_BUS = 12, KECCAK_LANE_BUS = 13, SHA_REQ_BUS = 14, SHA_MSG_BUS = 15, SHA_STATE_BUS = 16, MODMUL_REQ_BUS = 17, MODMUL_WORD_BUS = 18,   // modulus i: word bus 18 + i
                    INT256_REQ_BUS = 30, INT256_WORD_BUS = 31, EC_REQ_BUS = 32, EC_WORD_BUS = 33,   // curve i: word bus 33 + i
                    FP2_REQ_BUS = 37, FP2_WORD_BUS = 38,                                                // fp2 field i: word bus 38 + i
-                   NATIVE_REQ_BUS = 40, NATIVE_EXT_REQ_BUS = 41, CASTF_REQ_BUS = 42;
+                   NATIVE_REQ_BUS = 40, NATIVE_EXT_REQ_BUS = 41, CASTF_REQ_BUS = 42,
+                   BRANCH256_BUS = 43;   // (ts, taken): the comparison chip's decision of a 256-bit branch, to the ecall chip
 constexpr uint32_t TS_STEP = 16;   // timestamps per instruction: rs1 at +0; rs2 at +2; the core's own accesses at +4 ..; rd at +12
 constexpr uint32_t BLOCK_CELLS = 8, BLOCK_WORDS = 4, LABEL_BITS = 26, LEAF_LEVEL = LABEL_BITS + 2;  // block label = as * 2^26 + (word >> 2); the tree has 28 levels above the blocks
 constexpr uint32_t GAP_HI_BITS = 11;  // a timestamp gap is gap_lo + 2^16 gap_hi with gap_hi below 2^11 (one range-tuple lookup (0, gap_hi))
 enum Cls : uint32_t { C_ALU, C_LT, C_MUL, C_MULH, C_DIVREM, C_SHIFT, C_BEQ, C_BLT, C_JAL_LUI, C_AUIPC, C_JALR, C_LS, C_ECALL, N_CLS };
-constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 37, NATIVE_ARITH_WIDTH = 27, NATIVE_EXT_WIDTH = 90, CASTF_WIDTH = 16, LEAF_WIDTH = 43, MERKLE_WIDTH = 54, KECCAK_IO_WIDTH = 42, SHA_IO_WIDTH = 34, MODMUL_IO_WIDTH = 35, INT256_IO_WIDTH = 35, EC_IO_WIDTH = 59,
+constexpr size_t PROGRAM_FIELDS = 17, FRAME_WIDTH = 43, LS_WIDTH = 48, ECALL_WIDTH = 45, NATIVE_ARITH_WIDTH = 27, NATIVE_EXT_WIDTH = 90, CASTF_WIDTH = 16, LEAF_WIDTH = 43, MERKLE_WIDTH = 54, KECCAK_IO_WIDTH = 42, SHA_IO_WIDTH = 34, MODMUL_IO_WIDTH = 35, INT256_IO_WIDTH = 35, EC_IO_WIDTH = 59,
                  CONNECTOR_WIDTH = 2;
 constexpr uint32_t P = air::P;
 
@@ -387,7 +388,11 @@ inline void loadstore_air(AirBuilder& b) {
 
 // ecall chip: AirBuilder(ECALL_WIDTH, 0).  Columns: pc ts | x[4] (a7) | y[4] (a0) | z[4] (a0 afterwards) | is_exit is_reveal is_read |
 // idx (a1, the public-value word index) | pv_prev_lo pv_prev_hi | pc_inc | (prev_ts gap_lo gap_hi) of the a1 read and the public-value write |
-// is_keccak | q (= a0's low byte / 4: the state must be word-aligned) | is_sha | is_mod | is_int | is_ec | is_fp2 | is_nat | is_next | is_castf
+// is_keccak | q (= a0's low byte / 4: the state must be word-aligned) | is_sha | is_mod | is_int | is_ec | is_fp2 | is_nat | is_next | is_castf |
+// is_br taken | off_lo off_hi off_neg | (prev_ts gap_lo gap_hi) of the a2 read
+// A 256-BIT BRANCH (round 6; OpenVM's Rv32BranchEqual256 / Rv32BranchLessThan256) is an int256 call (is_int) with is_br: the comparison chip
+// sends its decision `taken` on the branch bus, a2 (register 12, read at ts + 6) is the byte offset, and the row's pc_inc is
+// 4 + taken (off - 4), off = off_lo + 2^16 off_hi - 2^32 off_neg (off_neg = the word's sign bit: backward branches).
 inline void ecall_air(AirBuilder& b) {
     const Expr pc = b.var(0), ts = b.var(1);
     Expr x[4], y[4], z[4];
@@ -396,7 +401,10 @@ inline void ecall_air(AirBuilder& b) {
     const Expr is_keccak = b.var(27), q = b.var(28), is_sha = b.var(29), is_mod = b.var(30), is_int = b.var(31), is_ec = b.var(32), is_fp2 = b.var(33), is_nat = b.var(34),
                is_next = b.var(35), is_castf = b.var(36), is_hash = is_keccak + is_sha + is_mod + is_int + is_ec + is_fp2 + is_nat + is_next + is_castf;
     const Expr ok = is_exit + is_reveal + is_read + is_keccak + is_sha + is_mod + is_int + is_ec + is_fp2 + is_nat + is_next + is_castf;
-    for (const Expr& f : {is_exit, is_reveal, is_read, is_keccak, is_sha, is_mod, is_int, is_ec, is_fp2, is_nat, is_next, is_castf, ok}) b.assert_zero(f * (f - 1));
+    const Expr is_br = b.var(37), taken = b.var(38), off_lo = b.var(39), off_hi = b.var(40), off_neg = b.var(41);
+    for (const Expr& f : {is_exit, is_reveal, is_read, is_keccak, is_sha, is_mod, is_int, is_ec, is_fp2, is_nat, is_next, is_castf, ok, is_br, taken, off_neg}) b.assert_zero(f * (f - 1));
+    b.assert_zero(is_br * (1 - is_int));   // a branch is an int256 call
+    b.assert_zero(taken * (1 - is_br));
     b.assert_zero(x[0] - is_exit * 93 - is_reveal - is_read * 2 - is_keccak * 3 - is_sha * 4 - is_mod * 5 - is_int * 6 - is_ec * 7 - is_fp2 * 8 - is_nat * (int64_t)native::CALL_ARITH -
                   is_next * (int64_t)native::CALL_EXT - is_castf * (int64_t)native::CALL_CASTF);
     for (int i = 1; i < 4; i++) b.assert_zero(x[i]);
@@ -405,7 +413,11 @@ inline void ecall_air(AirBuilder& b) {
         b.assert_zero((ok - is_read) * (z[i] - y[i]));  // only the hint read changes a0
     }
     b.assert_zero(is_exit * (pc_inc + pc));             // the execution ends at pc = 0
-    b.assert_zero((ok - is_exit) * (pc_inc - 4));
+    b.assert_zero((ok - is_exit - is_br) * (pc_inc - 4));
+    {   // a 256-bit branch: pc + 4, or pc + a2 when the comparison chip says so
+        const Expr off = off_lo + off_hi * 65536 - off_neg * (int64_t)(4294967296ull % 2013265921ull);
+        b.assert_zero(is_br * (pc_inc - 4 - taken * (off - 4)));
+    }
     OperandMsg m = blank_msg(b);
     m.pc = pc, m.pc_inc = pc_inc, m.ts = ts;
     for (int i = 0; i < 4; i++) m.x[i] = x[i], m.y[i] = y[i], m.z[i] = z[i];
@@ -419,6 +431,11 @@ inline void ecall_air(AirBuilder& b) {
     word_access(b, is_reveal, is_reveal, three, idx, pvp_lo, pvp_hi, y[0] + y[1] * 256, y[2] + y[3] * 256, ts + 5, b.var(24), b.var(25), b.var(26));
     b.push_interaction(RANGE_BUS, {idx * 8192}, is_reveal, Kind::Send);
     b.push_interaction(RANGE_BUS, {idx}, is_reveal, Kind::Send);
+    // the branch: a2 read (its halves are whatever the register holds: honest 16-bit cells by the memory argument), its sign bit split off
+    // by one range lookup ((off_hi - 2^15 off_neg) 2 < 2^16), the decision from the comparison chip
+    word_access(b, is_br, is_br, one, b.constant(12), off_lo, off_hi, off_lo, off_hi, ts + 6, b.var(42), b.var(43), b.var(44));
+    b.push_interaction(RANGE_BUS, {(off_hi - off_neg * 32768) * 2}, is_br, Kind::Send);
+    b.push_interaction(BRANCH256_BUS, {ts, taken}, is_br, Kind::Receive);
     // keccak: the state's word pointer = a0 / 4 (a0 word-aligned, below 2^30) goes to the keccak adapter with the call's timestamp
     // (sha256: the same with the 24-word state-and-block buffer and the SHA-256 adapter)
     b.assert_zero(is_hash * (y[0] - q * 4));
@@ -843,7 +860,7 @@ inline AirShape build_air(unsigned id) {
         case A_INT256: make(int256::VM_WIDTH, 0, 0, [](AirBuilder& b) { int256::alu256_vm_air(b, BITWISE_BUS, INT256_WORD_BUS); }); break;
         case A_INT256_IO: make(INT256_IO_WIDTH, 0, 0, int256_io_air); break;
         case A_MUL256: make(int256::MUL_VM_WIDTH, 0, 0, [](AirBuilder& b) { int256::mul256_vm_air(b, BITWISE_BUS, RANGE_TUPLE_BUS, INT256_WORD_BUS); }); break;
-        case A_CMP256: make(int256::CMP_VM_WIDTH, 0, 0, [](AirBuilder& b) { int256::cmp256_vm_air(b, BITWISE_BUS, INT256_WORD_BUS); }); break;
+        case A_CMP256: make(int256::CMP_VM_WIDTH, 0, 0, [](AirBuilder& b) { int256::cmp256_vm_air(b, BITWISE_BUS, INT256_WORD_BUS, BRANCH256_BUS); }); break;
         case A_SHIFT256: make(int256::SH_VM_WIDTH, 0, 0, [](AirBuilder& b) { int256::shift256_vm_air(b, BITWISE_BUS, INT256_WORD_BUS); }); break;
         case A_NATIVE_ARITH: make(NATIVE_ARITH_WIDTH, 0, 0, native_arith_air); break;
         case A_NATIVE_EXT: make(NATIVE_EXT_WIDTH, 0, 0, native_ext_air); break;

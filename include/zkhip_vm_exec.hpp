@@ -396,7 +396,7 @@ private:
             if (MODE == REPLAY && r.n_instr == plan->n_instr) break;
             size_t new_blocks = 0, new_nodes = 0;
             if (MODE != REPLAY) {
-                uint32_t labels[5 + 20];
+                uint32_t labels[6 + 20];
                 unsigned nl = 0;
                 bool all_known = true;
                 auto want = [&](uint32_t as, uint32_t word) {
@@ -409,6 +409,7 @@ private:
                 if (d.wr_rd) want(1, d.rd);
                 if (d.cls == vmc::C_LS) want(2, ((d.use_rs1 ? m_.reg(d.rs1) : 0) + (d.imm_lo | (d.imm_hi << 16))) >> 2);
                 if (d.cls == vmc::C_ECALL) want(1, 11), want(3, m_.reg(11) & 7u);
+                if (d.cls == vmc::C_ECALL && m_.reg(17) == 6 && zkhip::int256::is_branch_op(m_.reg(11))) want(1, 12);   // (a 256-bit branch reads its offset from a2)
                 if (d.cls == vmc::C_ECALL && m_.reg(17) >= 3 && m_.reg(17) <= 11) {
                     const uint32_t n_words = m_.reg(17) == 3 ? 50 : call_words(m_.reg(17), m_.reg(11));
                     for (uint32_t w = m_.reg(10) >> 2; w < (m_.reg(10) >> 2) + n_words; w += (w & 3u) ? 4 - (w & 3u) : 4) want(2, w);
@@ -454,7 +455,7 @@ private:
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 5 && r.mm_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_MODMUL(m_.reg(11) & 7u))) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 7 && r.ec_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_EC(m_.reg(11) & 7u))) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == 8 && r.fp2_ts[m_.reg(11) & 7u].size() + 1 > caps_.rows(vmc::A_FP2(m_.reg(11) & 7u))) ||
-                (d.cls == vmc::C_ECALL && m_.reg(17) == 6 && (m_.reg(11) == 5 ? r.mul256_ts.size() : m_.reg(11) > 8 ? r.sh256_ts.size() : m_.reg(11) > 5 ? r.cmp256_ts.size() : r.i256_ts.size()) + 1 > caps_.rows(vmc::A_INT256)) ||
+                (d.cls == vmc::C_ECALL && m_.reg(17) == 6 && (m_.reg(11) == 5 ? r.mul256_ts.size() : m_.reg(11) >= 12 ? r.cmp256_ts.size() : m_.reg(11) > 8 ? r.sh256_ts.size() : m_.reg(11) > 5 ? r.cmp256_ts.size() : r.i256_ts.size()) + 1 > caps_.rows(vmc::A_INT256)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == zkhip::native::CALL_ARITH && r.n_nat() + 1 > caps_.rows(vmc::A_NATIVE_ARITH)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == zkhip::native::CALL_EXT && r.n_next() + 1 > caps_.rows(vmc::A_NATIVE_EXT)) ||
                 (d.cls == vmc::C_ECALL && m_.reg(17) == zkhip::native::CALL_CASTF && r.n_castf() + 1 > caps_.rows(vmc::A_CASTF)) ||
@@ -525,7 +526,11 @@ private:
                 if (x == 3) r.kk_ts.push_back(ts);
                 if (x == 4) r.sha_ts.push_back(ts);
                 if (x == 5) r.mm_ts[a1 & 7u].push_back(ts);
-                if (x == 6) (a1 == 5 ? r.mul256_ts : a1 > 8 ? r.sh256_ts : a1 > 5 ? r.cmp256_ts : r.i256_ts).push_back(ts);
+                if (x == 6) (a1 == 5 ? r.mul256_ts : a1 >= 12 ? r.cmp256_ts : a1 > 8 ? r.sh256_ts : a1 > 5 ? r.cmp256_ts : r.i256_ts).push_back(ts);
+                // (the register blocks the ecall chip's own reads touch -- a1 for the calls with a second argument, a2 for a 256-bit branch --
+                // are touched here as the record pass touches them: the two passes must agree on the segment's blocks)
+                if (x == 1 || (x >= 5 && x <= 8) || x == zkhip::native::CALL_ARITH || x == zkhip::native::CALL_EXT) (void)read_word(1, 11, a1, ts + 4);
+                if (x == 6 && zkhip::int256::is_branch_op(a1)) (void)read_word(1, 12, 0, ts + 6);
                 if (x == 7) r.ec_ts[a1 & 7u].push_back(ts);
                 if (x == 8) r.fp2_ts[a1 & 7u].push_back(ts);
                 if (x == zkhip::native::CALL_ARITH) r.nat_records.resize(r.nat_records.size() + SegmentRecords::NAT_RECORD);
@@ -533,7 +538,7 @@ private:
                 if (x == zkhip::native::CALL_CASTF) r.castf_records.resize(r.castf_records.size() + SegmentRecords::CASTF_RECORD);
             } else if (d.cls == vmc::C_ECALL) {
                 z = x == 2 ? m_.last_result() : y;
-                pc_inc = m_.done() ? vmc::field_of(-(int32_t)pc) : 4;
+                pc_inc = m_.done() ? vmc::field_of(-(int32_t)pc) : vmc::field_of((int32_t)(m_.pc() - pc));   // (4, or a taken 256-bit branch's offset)
                 if (m_.done() && m_.exit_code()) throw Error("guest exited with code " + std::to_string(m_.exit_code()));
                 uint32_t row[vmc::ECALL_WIDTH] = {};
                 row[0] = pc, row[1] = ts;
@@ -567,8 +572,15 @@ private:
                     row[31] = 1, row[28] = (y & 255u) >> 2, row[17] = a1;
                     auto gap3 = [&](uint32_t* dst, uint32_t pts, uint32_t at) { dst[0] = pts, dst[1] = (at - pts - 1) & 0xffffu, dst[2] = (at - pts - 1) >> 16; };
                     gap3(row + 21, read_word(1, 11, a1, ts + 4), ts + 4);
-                    auto& recs = a1 == 5 ? r.mul256_records : a1 > 8 ? r.sh256_records : a1 > 5 ? r.cmp256_records : r.i256_records;
-                    (a1 == 5 ? r.mul256_ts : a1 > 8 ? r.sh256_ts : a1 > 5 ? r.cmp256_ts : r.i256_ts).push_back(ts);
+                    const bool branch = zkhip::int256::is_branch_op(a1);   // (12 .. 17: the comparison chip decides a branch)
+                    auto& recs = a1 == 5 ? r.mul256_records : branch ? r.cmp256_records : a1 > 8 ? r.sh256_records : a1 > 5 ? r.cmp256_records : r.i256_records;
+                    (a1 == 5 ? r.mul256_ts : branch ? r.cmp256_ts : a1 > 8 ? r.sh256_ts : a1 > 5 ? r.cmp256_ts : r.i256_ts).push_back(ts);
+                    if (branch) {
+                        const uint32_t off = m_.reg(12);
+                        row[37] = 1, row[38] = zkhip::int256::branch256_taken(a1, mm_in, mm_in + 8) ? 1u : 0u;   // (mm_in: b | c | a as they were before the call)
+                        row[39] = off & 0xffffu, row[40] = off >> 16, row[41] = off >> 31;
+                        gap3(row + 42, read_word(1, 12, off, ts + 6), ts + 6);
+                    }
                     recs.push_back(a1);
                     recs.insert(recs.end(), mm_in, mm_in + 16);
                     for (uint32_t k = 0; k < 24; k++) {   // the adapter's rows: b, c read, a written, all at ts + 5

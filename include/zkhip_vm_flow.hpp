@@ -290,6 +290,7 @@ public:
                     tup_y.push_back(row[23]), tup_y.push_back(row[26]);
                 }
                 if (row[30] || row[31] || row[32] || row[33] || row[34] || row[35]) misc.push_back(row[22]), tup_y.push_back(row[23]);   // modmul / int256 / ecc / fp2 / native: the a1 read
+                if (row[37]) misc.push_back(row[43]), tup_y.push_back(row[44]), misc.push_back((row[40] - 32768u * row[41]) * 2u);   // a 256-bit branch: the a2 read, the offset's sign split
                 if (row[16]) bw_x.push_back(row[10]), bw_y.push_back(row[11]), bw_x.push_back(row[12]), bw_y.push_back(row[13]);
                 if (row[27] || row[29] || row[30] || row[31] || row[32] || row[33] || row[34] || row[35] || row[36])
                     for (uint32_t v : {row[28] * 1024, row[28], row[9] * 1024}) misc.push_back(v);

@@ -397,12 +397,20 @@ def run(program, stdin=b"", pc_base=0x00200000, data_base=0x00400000, memory_byt
             elif call == 6:   # a = b op c modulo 2^256 on the 24 words at a0 (b | c | a), op = a1: add sub xor or and
                 off = rr(10) - data_base
                 op_ = rr(11)
-                assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem) and op_ < 12
+                assert off % 4 == 0 and 0 <= off and off + 96 <= len(mem) and op_ < 18
                 b_, c_ = int.from_bytes(mem[off:off + 32], "little"), int.from_bytes(mem[off + 32:off + 64], "little")
                 sg = lambda v: v - (1 << 256) if v >> 255 else v  # noqa: E731
-                a_ = [(b_ + c_) % (1 << 256), (b_ - c_) % (1 << 256), b_ ^ c_, b_ | c_, b_ & c_, (b_ * c_) % (1 << 256), int(b_ < c_), int(sg(b_) < sg(c_)),
-                      int(b_ == c_), (b_ << (c_ % 256)) % (1 << 256), b_ >> (c_ % 256), (sg(b_) >> (c_ % 256)) % (1 << 256)][op_]
-                mem[off + 64:off + 96] = a_.to_bytes(32, "little")
+                if op_ >= 12:   # 256-bit branches: 12 beq, 13 bne, 14 bltu, 15 blt, 16 bgeu, 17 bge -- the comparison's 0 / 1 goes to a, pc += a2 if taken
+                    cmp_ = [int(b_ == c_), int(b_ == c_), int(b_ < c_), int(sg(b_) < sg(c_)), int(b_ < c_), int(sg(b_) < sg(c_))][op_ - 12]
+                    mem[off + 64:off + 96] = cmp_.to_bytes(32, "little")
+                    off_ = rr(12)
+                    assert off_ % 4 == 0
+                    if bool(cmp_) != (op_ in (13, 16, 17)):
+                        nxt = (pc + off_) & M32
+                else:
+                    a_ = [(b_ + c_) % (1 << 256), (b_ - c_) % (1 << 256), b_ ^ c_, b_ | c_, b_ & c_, (b_ * c_) % (1 << 256), int(b_ < c_), int(sg(b_) < sg(c_)),
+                          int(b_ == c_), (b_ << (c_ % 256)) % (1 << 256), b_ >> (c_ % 256), (sg(b_) >> (c_ % 256)) % (1 << 256)][op_]
+                    mem[off + 64:off + 96] = a_.to_bytes(32, "little")
             elif call == 5:   # r = a b mod moduli[a1] on the 24 words at a0 (a | b | r, little-endian)
                 off = rr(10) - data_base
                 sel = rr(11)                 # a1 = modulus index + 8 * operation (0 mul, 1 add, 2 sub, 3 div, 4 is_eq)

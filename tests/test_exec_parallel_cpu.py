@@ -114,3 +114,9 @@ def test_under_thread_sanitizer(exe_tsan, tmp_path):
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["equal"] is True, r.stdout + r.stderr[-2000:]
     r = run(tmp_path / "fib.elf", tmp_path / "in.bin", 9, 4, "-", "parallel-only", 2)
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["segments_taken"] == 2, r.stdout + r.stderr[-2000:]
+
+
+def test_256_bit_branches_across_cuts(exe, tmp_path):
+    """the bigint extension's branches read a2 in the ecall chip's row: the metered pass touches that register block as the record pass does"""
+    _compare(exe, tmp_path, rv.elf_bytes(t.branch256_program(), data=t.branch256_data()), b"", 5, 3, "[app_vm_config.bigint]\n")
+    _compare(exe, tmp_path, rv.elf_bytes(t.branch256_program(), data=t.branch256_data()), b"", 4, 2, "[app_vm_config.bigint]\n")

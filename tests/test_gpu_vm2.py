@@ -163,6 +163,9 @@ def device_traces(zk, rec, prog, H):
         if row[30] or row[31] or row[32] or row[33] or row[34] or row[35]:
             misc += [int(row[22])]
             tup_y += [int(row[23])]
+        if row[37]:                                          # a 256-bit branch: the a2 read's gap, the offset's sign split
+            misc += [int(row[43]), (int(row[40]) - 32768 * int(row[41])) * 2]
+            tup_y += [int(row[44])]
         if row[27] or row[29] or row[30] or row[31] or row[32] or row[33] or row[34] or row[35] or row[36]:
             misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
     for row in rec["kio_rows"].reshape(-1, v2.KECCAK_IO_WIDTH):
@@ -562,6 +565,45 @@ def test_int256_guest_device_traces_and_one_proof(zk, ora, tmp_path):
     M = 1 << 256
     want = [[(b + c) % M, (b - c) % M, b ^ c, b | c, b & c, (b * c) % M][op] for op, (b, c) in enumerate(INT256_OPERANDS)]
     assert pv == bytes(model["pvs"]) and [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(6)] == [w & 0xFFFFFFFF for w in want]
+    assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
+
+
+def test_256_bit_branch_guest_device_traces_and_one_proof(zk, ora, tmp_path):
+    """The bigint extension's 256-bit branches (int256 opcodes 12 .. 17; crates/circuits/chunk-circuit/openvm.toml:17-18): a guest that takes and
+    does not take every one and closes a loop with a backward bne256 -- device traces == CPU twins in every segment, proof bytes == the
+    oracle's, and the whole flow from the ELF: the root's public values are the Python model's."""
+    from test_vm_cpu import BRANCH256_LOOP, branch256_data, branch256_program
+
+    words, data = branch256_program(), branch256_data()
+    model = rv.run(words, b"", data=data)
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 6, 0, 0, (), True)
+    assert len(segs) >= 2 and sum(len(s["cmp256_ts"]) for s in segs) == 12 + BRANCH256_LOOP
+    proven = 0
+    for k, rec in enumerate(segs):
+        if not len(rec["cmp256_ts"]):
+            continue
+        inst = v2.segment_instance(rec, words, PC_BASE, H)
+        T = device_traces(zk, rec, v2.program_table(words, PC_BASE, H[0]), H)
+        assert len(inst) == len(T) == 27
+        for a, d in enumerate(inst):
+            assert (zk.download(T[a]).reshape(d["width"], -1) == d["trace"]).all(), "segment %d position %d" % (k, a)
+        if proven < 2:
+            pk = z.ProvingKey(zk, PARAMS, inst)
+            pvs = [d["pvs"] for d in inst]
+            proof = pk.prove(T, pvs)
+            assert z.verify(PARAMS, pk.verifying_airs(), pvs, proof) == 0
+            assert proof == ora.stark_prove(PARAMS, inst).tobytes()
+            pk.close()
+            proven += 1
+    exe = tmp_path / "guest.elf"
+    exe.write_bytes(rv.elf_bytes(words, data=data))
+    (tmp_path / "openvm.toml").write_text(pm.TOML.format(*PARAMS) + "\n[app_vm_config.bigint]\nrange_tuple_checker_sizes = [256, 8192]\n")
+    r = subprocess.run([pm.CLI, "prove-elf", str(exe), "-", str(tmp_path), str(tmp_path / "openvm.toml"), "6"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["verified"] and out["total_cycles"] == model["instret"] and out["segments"] >= 2 and out["segments_retried"] == 0
+    pv = pm.un_b64_bincode(json.loads((tmp_path / "root.json").read_text())["user_pvs_proof"])[4 * N_STMT:4 * N_STMT + 32]
+    assert pv == bytes(model["pvs"]) and [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(3)] == [0b1111110, BRANCH256_LOOP, 1]
     assert pm.run_cli("verify-guest", str(exe), str(tmp_path / "root.vk"), str(tmp_path / "openvm.toml"), str(tmp_path / "root.json")).returncode == 0
 
 

@@ -646,3 +646,60 @@ def test_a_segment_that_touches_two_thousand_blocks(tmp_path):
             cur = ru.compress(sib[lvl], cur) if idx & 1 else ru.compress(cur, sib[lvl])
             idx >>= 1
         assert cur.tolist() == meta[12:20].tolist()
+
+
+def test_256_bit_branches_are_part_of_the_statement(tmp_path):
+    """The bigint extension's 256-bit branches (crates/circuits/chunk-circuit/openvm.toml:17-18; OpenVM's Rv32BranchEqual256 /
+    Rv32BranchLessThan256): int256 opcodes 12 beq, 13 bne, 14 bltu, 15 blt, 16 bgeu, 17 bge -- the comparison chip decides, the ecall chip's
+    row steps the pc by 4 or by a2.  A guest that takes and does not take every one of them and closes a loop with a BACKWARD bne256: the
+    revealed words are the Python model's (mask of the branches not taken, the loop's count); every trace satisfies its AIR, every bus
+    balances, at frames small enough that branches fall on both sides of segment cuts; a decision answered the other way, a forged offset
+    and a comparison chip that disagrees with the ecall chip are refused."""
+    from test_vm_cpu import BRANCH256_LOOP, branch256_data, branch256_program
+
+    words, data = branch256_program(), branch256_data()
+    model = rv.run(words, b"", data=data)
+    pv = bytes(model["pvs"])
+    assert [int.from_bytes(pv[4 * k:4 * k + 4], "little") for k in range(3)] == [0b1111110, BRANCH256_LOOP, 1]
+    info, H, segs, image_root, pv_open = v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 6, 0, 0, (), True)
+    assert bytes.fromhex(info["public_values"]) == pv and info["total_cycle"] == model["instret"] and len(segs) >= 2
+    assert sum(len(s["cmp256_ts"]) for s in segs) == 12 + BRANCH256_LOOP
+    n_br = 0
+    for k, rec in enumerate(segs):
+        inst = v2.segment_instance(rec, words, PC_BASE, H)
+        for d in inst:
+            assert air.quotient_chunks(d["program"]) <= 2
+            assert air.check_trace(d["program"], d["trace"], d["pvs"], d.get("prep")) == [], (k, d.get("name"))
+        assert v2.bus_imbalance(inst) == {}, k
+        n_br += int(rec["ecall_rows"].reshape(-1, v2.ECALL_WIDTH)[:, 37].sum())
+    assert n_br == 12 + BRANCH256_LOOP
+    # forgeries, on a segment that holds a branch
+    kb = next(i for i, s in enumerate(segs) if s["ecall_rows"].reshape(-1, v2.ECALL_WIDTH)[:, 37].any())
+    rows = segs[kb]["ecall_rows"].reshape(-1, v2.ECALL_WIDTH)
+    rb = int(np.nonzero(rows[:, 37])[0][0])
+    pos_e, pos_c = H.ids.index(v2.A_ECALL), H.ids.index(v2.A_CMP256)
+    # (i) the ecall chip claims the other decision: its own pc_inc constraint or the branch bus refuses
+    rec = {n: v.copy() for n, v in segs[kb].items()}
+    rec["ecall_rows"].reshape(-1, v2.ECALL_WIDTH)[rb, 38] ^= 1
+    inst = v2.segment_instance(rec, words, PC_BASE, H)
+    assert air.check_trace(inst[pos_e]["program"], inst[pos_e]["trace"], inst[pos_e]["pvs"]) != [] or 43 in v2.bus_imbalance(inst)
+    # (ii) ... and adjusts pc_inc to match: the branch bus (the comparison chip's word against the ecall chip's) is out of balance
+    rec = {n: v.copy() for n, v in segs[kb].items()}
+    er = rec["ecall_rows"].reshape(-1, v2.ECALL_WIDTH)
+    off = int(er[rb, 39]) + (int(er[rb, 40]) << 16) - (int(er[rb, 41]) << 32)
+    er[rb, 38] ^= 1
+    er[rb, 20] = (off if er[rb, 38] else 4) % 2013265921
+    bad = v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
+    assert 43 in bad                                                      # (and the execution bus: the next instruction sits elsewhere)
+    # (iii) the comparison chip's row says the other thing: its own constraint taken = out XOR neg
+    inst = v2.segment_instance(segs[kb], words, PC_BASE, H)
+    tr = inst[pos_c]["trace"] = inst[pos_c]["trace"].copy()
+    r0 = int(np.nonzero(tr[104])[0][0])
+    tr[106, r0] ^= 1
+    assert air.check_trace(inst[pos_c]["program"], tr, inst[pos_c]["pvs"]) != []
+    # (iv) a forged offset: the memory bus (the a2 read) is out of balance
+    rec = {n: v.copy() for n, v in segs[kb].items()}
+    rec["ecall_rows"].reshape(-1, v2.ECALL_WIDTH)[rb, 39] ^= 4
+    assert 1 in v2.bus_imbalance(v2.segment_instance(rec, words, PC_BASE, H))
+    with pytest.raises(AssertionError, match="does not enable the bigint extension"):
+        v2.dump_segments(tmp_path, rv.exe_bytes(words, data=data), b"", 7)

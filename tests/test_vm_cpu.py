@@ -123,6 +123,38 @@ def int256_data():
     return b"".join(int(b).to_bytes(32, "little") + int(c).to_bytes(32, "little") + bytes(32) for b, c in INT256_OPERANDS + INT256_CMP_OPERANDS + INT256_SHIFT_OPERANDS)
 
 
+# ---- 256-bit branches (round 6; the bigint extension's Rv32BranchEqual256 / Rv32BranchLessThan256, crates/circuits/chunk-circuit/openvm.toml:17-18):
+# int256 opcodes 12 beq, 13 bne, 14 bltu, 15 blt, 16 bgeu, 17 bge; a2 = the byte offset from the ecall ----
+A2 = 12
+# (b, c) per opcode 12 .. 17, twice: first six pairs make the branch TAKEN, the other six NOT taken
+BRANCH256_OPERANDS = [(7 << 200 | 5, 7 << 200 | 5), (1 << 255, 1), (3, 1 << 250), ((1 << 256) - 9, 4), (1 << 255, 1 << 254), (6, (1 << 256) - 6),
+                      (7 << 200 | 5, 7 << 200 | 4), (99, 99), (1 << 250, 3), (4, (1 << 256) - 9), (1 << 254, 1 << 255), ((1 << 256) - 6, 6)]
+BRANCH256_LOOP = 5     # the backward branch: a loop that runs until a 256-bit counter's low word reaches this
+
+
+def branch256_program():
+    """Twelve forward branches (every opcode taken once and not taken once): a taken branch skips the `addi t1, t1, 1` before t1 is shifted
+    left (t1 = the mask of the branches NOT taken, branch k at bit 12 - k); then a
+    loop closed by a BACKWARD bne256 (a2 negative): t2 counts up in the low word of a 256-bit value until it equals BRANCH256_LOOP.  Reveals
+    t1 (the mask of the branches that were NOT taken), t2 (the loop's count), and the comparison word the last forward branch left in its buffer."""
+    p = rv.li(S0, 0x00400000) + [("addi", T1, 0, 0)]
+    for k in range(12):
+        p += [("addi", A0, S0, 96 * k), ("addi", A1, 0, 12 + k % 6), ("addi", A2, 0, 8), ("addi", A7, 0, 6), ("ecall",), ("addi", T1, T1, 1), ("slli", T1, T1, 1)]
+    # the loop: buffer 12 = [limit | counter | slot]; counter's low word = t2
+    p += [("addi", T2, 0, 0), ("label", "loop"), ("addi", T2, T2, 1), ("sw", T2, S0, 96 * 12 + 32),
+          ("addi", A0, S0, 96 * 12), ("addi", A1, 0, 13), ("addi", A2, 0, -24), ("addi", A7, 0, 6), ("ecall",)]     # bne256 limit, counter: back to "loop" (6 instructions up)
+    p += [("add", A0, T1, 0), ("addi", A1, 0, 0), ("addi", A7, 0, 1), ("ecall",),
+          ("add", A0, T2, 0), ("addi", A1, 0, 1), ("addi", A7, 0, 1), ("ecall",),
+          ("lw", A0, S0, 96 * 11 + 64), ("addi", A1, 0, 2), ("addi", A7, 0, 1), ("ecall",),
+          ("addi", A0, 0, 0), ("addi", A7, 0, 93), ("ecall",)]
+    return rv.assemble(p)
+
+
+def branch256_data():
+    out = b"".join(int(b).to_bytes(32, "little") + int(c).to_bytes(32, "little") + bytes(32) for b, c in BRANCH256_OPERANDS)
+    return out + int(BRANCH256_LOOP).to_bytes(32, "little") + bytes(64)
+
+
 # the six moduli of the reference's chunk circuit, in its order (crates/circuits/chunk-circuit/openvm.toml:20-28): bn254 p, bn254 r,
 # secp256k1 p, secp256k1 n, P-256 p, P-256 n
 CHUNK_CIRCUIT_MODULI = (

@@ -22,11 +22,11 @@ NOPV = np.zeros(0, np.uint32)
 MAX_MODULI, MAX_CURVES, MAX_FP2 = 8, 4, 2
 # the modular extension: chips N_STATIC_AIRS + 2 i (multiplication), + 2 i + 1 (adapter) of modulus i; the ecc extension's follow
 N_AIRS = N_STATIC_AIRS + 2 * MAX_MODULI + 2 * MAX_CURVES + 2 * MAX_FP2
-PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 37, 43, 54, 42, 2634
+PROGRAM_FIELDS, FRAME_WIDTH, LS_WIDTH, ECALL_WIDTH, LEAF_WIDTH, MERKLE_WIDTH, KECCAK_IO_WIDTH, KECCAK_WIDTH = 17, 43, 48, 45, 43, 54, 42, 2634
 NATIVE_ARITH_WIDTH, NATIVE_EXT_WIDTH, CASTF_WIDTH, P_HI = 27, 90, 16, 0x7800
 SHA_IO_WIDTH, SHA_WIDTH = 34, 434
 MODMUL_IO_WIDTH, MODMUL_WIDTH = 35, 326
-INT256_IO_WIDTH, INT256_WIDTH, MUL256_WIDTH, CMP256_WIDTH, SHIFT256_WIDTH = 35, 102, 162, 104, 190
+INT256_IO_WIDTH, INT256_WIDTH, MUL256_WIDTH, CMP256_WIDTH, SHIFT256_WIDTH = 35, 102, 162, 108, 190
 EC_IO_WIDTH, EC_WIDTH, FP2_WIDTH = 59, 773, 649
 TS_STEP, GAP_HI_BITS = 16, 11
 SX, SY = 256, 2048
@@ -274,16 +274,24 @@ def ec_traces(rec, H, i, curve):
 
 
 def cmp256_traces(rec, H):
-    """int256 calls with opcodes 6..8: the tests' twin of the comparison chip's trace (and its lookup counts) + the call's timestamp"""
+    """int256 calls with opcodes 6..8 and the 256-bit branches 12..17: the tests' twin of the comparison chip's trace (and its lookup counts) +
+    the call's timestamp + the branch columns (is_br | neg | taken | the opcode the adapter announces)"""
     import int256_util as iu
 
     recs = np.ascontiguousarray(rec["cmp256_records"], dtype=np.uint32).reshape(-1, 17)
     val = lambda w: sum(int(x) << (32 * k) for k, x in enumerate(w))  # noqa: E731
     lh = H[A_CMP256]
-    body, bw = iu.cmp_twin_trace([(int(r[0]), val(r[1:9]), val(r[9:17])) for r in recs], lh)
+    core = {12: 8, 13: 8, 14: 6, 16: 6, 15: 7, 17: 7}     # the comparison a branch opcode rests on: eq / sltu / slt
+    body, bw = iu.cmp_twin_trace([(core.get(int(r[0]), int(r[0])), val(r[1:9]), val(r[9:17])) for r in recs], lh)
+    n_core = body.shape[0]                                  # 103: the stand-alone chip's columns
     tr = np.zeros((CMP256_WIDTH, 1 << lh), np.uint32)
-    tr[:CMP256_WIDTH - 1] = body
-    tr[CMP256_WIDTH - 1, :len(recs)] = rec["cmp256_ts"]
+    tr[:n_core] = body
+    tr[n_core, :len(recs)] = rec["cmp256_ts"]
+    for row, r in enumerate(recs):
+        op = int(r[0])
+        is_br, neg = int(op >= 12), int(op in (13, 16, 17))
+        out = int(body[65:97, row].sum() == 0) if core.get(op, op) == 8 else int(body[64, row])     # eq: no marker; less-than: t
+        tr[n_core + 1, row], tr[n_core + 2, row], tr[n_core + 3, row], tr[n_core + 4, row] = is_br, neg, is_br & (out ^ neg), op
     return tr, bw.astype(np.int64)
 
 
@@ -535,6 +543,9 @@ def segment_instance(rec, words, pc_base, heights):
         if row[30] or row[31] or row[32] or row[33] or row[34] or row[35]:
             misc += [int(row[22])]
             tc[int(row[23])] += 1
+        if row[37]:                                          # a 256-bit branch: the a2 read's gap, the offset's sign split
+            misc += [int(row[43]), (int(row[40]) - 32768 * int(row[41])) * 2]
+            tc[int(row[44])] += 1
         if row[27] or row[29] or row[30] or row[31] or row[32] or row[33] or row[34] or row[35] or row[36]:
             misc += [int(row[28]) * 1024, int(row[28]), int(row[9]) * 1024]
     for row in rec["kio_rows"].reshape(-1, KECCAK_IO_WIDTH):

@@ -766,8 +766,9 @@ class Context:
         return out
 
     def int256_cmp_tracegen(self, t_records, n, log_height, t_bitwise_trace, t_ts=None):
-        """records: n x 17 words (op | b | c; op 6 sltu, 7 slt, 8 eq); t_ts: the VM chip (104 columns: + the calls' timestamps)"""
-        out = self._new((103 if t_ts is None else 104) << log_height)
+        """records: n x 17 words (op | b | c; op 6 sltu, 7 slt, 8 eq); t_ts: the VM chip (108 columns: + the calls' timestamps and the branch columns
+        is_br | neg | taken | opcode -- there the records may also carry the branch opcodes 12 .. 17)"""
+        out = self._new((103 if t_ts is None else 108) << log_height)
         if t_ts is None:
             self._check(self.lib.zkhip_int256_cmp_tracegen(self.h, t_records.data_ptr() if n else None, n, log_height, out.data_ptr(), t_bitwise_trace.data_ptr()))
         else:

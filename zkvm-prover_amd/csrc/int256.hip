@@ -102,7 +102,10 @@ __global__ __launch_bounds__(256) void k_cmp256_trace(const uint32_t* __restrict
         for (size_t c = 0; c < width; c++) trace[c * N + row] = 0u;
         return;
     }
-    const uint32_t op = recs[17 * row];
+    const uint32_t op_rec = recs[17 * row];
+    // (the VM form also takes the branch opcodes 12 .. 17: the comparison they rest on + the branch columns)
+    const bool is_br = op_rec >= i2::OP_BEQ && op_rec <= i2::OP_BGE && width > i2::CMP_COL_OPC;
+    const uint32_t op = is_br ? (op_rec == i2::OP_BEQ || op_rec == i2::OP_BNE ? i2::OP_EQ : op_rec == i2::OP_BLTU || op_rec == i2::OP_BGEU ? i2::OP_SLTU : i2::OP_SLT) : op_rec;
     if (op < i2::OP_SLTU || op > i2::OP_EQ) atomicAdd(bad, 1u);
     uint32_t b[8], c[8];
 #pragma unroll
@@ -134,6 +137,12 @@ __global__ __launch_bounds__(256) void k_cmp256_trace(const uint32_t* __restrict
     if (mark >= 0) hist_add(bitwise_range, ((diff - 1u) & 255u) * 256);
     put(i2::CMP_COL_FLAGS, op == i2::OP_SLTU ? 1u : 0u), put(i2::CMP_COL_FLAGS + 1, op == i2::OP_SLT ? 1u : 0u), put(i2::CMP_COL_FLAGS + 2, op == i2::OP_EQ ? 1u : 0u);
     if (width > i2::CMP_WIDTH) put(i2::CMP_COL_TS, ts ? ts[row] % P : 0u);
+    if (width > i2::CMP_COL_OPC) {   // the VM form's branch columns: is_br | neg | taken | the opcode the adapter announces
+        const bool neg = is_br && (op_rec == i2::OP_BNE || op_rec == i2::OP_BGEU || op_rec == i2::OP_BGE);
+        const bool out = op == i2::OP_EQ ? mark < 0 : lt;
+        put(i2::CMP_COL_BR, is_br ? 1u : 0u), put(i2::CMP_COL_NEG, neg ? 1u : 0u), put(i2::CMP_COL_TAKEN, is_br && (out != neg) ? 1u : 0u);
+        put(i2::CMP_COL_OPC, op_rec);
+    }
 }
 
 // 256-bit shift chip: record = op | b[8] | c[8] (op 9 sll, 10 srl, 11 sra; the amount is c mod 256); the row's 66 lookups (carries,
@@ -293,9 +302,9 @@ int zkhip_int256_alu_air(uint32_t bitwise_bus, zkhip_air* out) { return out ? ai
 
 int zkhip_int256_alu_host(uint32_t op, const uint32_t b[8], const uint32_t c[8], uint32_t a[8]) {
     if (!a || !b || !c || op >= i2::N_INT256_OPS) return ZKHIP_ERR_INVALID;
-    if (op >= i2::OP_SLL) {
+    if (op >= i2::OP_SLL && !i2::is_branch_op(op)) {
         i2::shift256(op, b, c, a);
-    } else if (op >= i2::OP_SLTU) {
+    } else if (op >= i2::OP_SLTU) {   // (a branch opcode answers with the comparison it rests on)
         for (int i = 1; i < 8; i++) a[i] = 0;
         a[0] = i2::cmp256(op, b, c);
     } else if (op == i2::OP_MUL) i2::mul256(b, c, a);
