@@ -193,9 +193,10 @@ def device_traces(zk, rec, prog, H):
         misc += [int(row[39]), int(row[40]) * 16, int(row[40]), int(row[41]), int(row[42]) * 64, int(row[42])]
     d_rng = zk.range_counts_tracegen(zk.upload(np.array(misc, np.uint32)), 16, t_counts=d_rng, accumulate=True)
     if tup_y:
-        zk.range_tuple_counts_tracegen(zeros[:len(tup_y)], zk.upload(np.array(tup_y, np.uint32)), v2.SX, v2.SY, t_counts=d_tup, accumulate=True)
+        # (a zero column of the lists' own length: at tiny frames the adapters' rows outnumber the frame's)
+        zk.range_tuple_counts_tracegen(torch.zeros(len(tup_y), dtype=torch.int32, device=dev), zk.upload(np.array(tup_y, np.uint32)), v2.SX, v2.SY, t_counts=d_tup, accumulate=True)
     if bw_x:
-        zk.bitwise_lookup_tracegen(zk.upload(np.array(bw_x, np.uint32)), zk.upload(np.array(bw_y, np.uint32)), zeros[:len(bw_x)], 8, d_bw, accumulate=True)
+        zk.bitwise_lookup_tracegen(zk.upload(np.array(bw_x, np.uint32)), zk.upload(np.array(bw_y, np.uint32)), torch.zeros(len(bw_x), dtype=torch.int32, device=dev), 8, d_bw, accumulate=True)
     T[v2.A_BITWISE], T[v2.A_RANGE_TUPLE], T[v2.A_RANGE] = d_bw, d_tup, d_rng
     return [T[a] for a in H.ids]   # proof order
 
