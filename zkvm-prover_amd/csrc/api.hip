@@ -107,7 +107,20 @@ static int selftest(zkhip_ctx* ctx) {
 __global__ void k_accumulate_flag(const uint32_t* flag, uint32_t* total) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && *flag) atomicAdd(total, *flag);
 }
+// The error counter a trace generator's kernel increments.  While the checks are deferred (zkhip_defer_tracegen_checks: a segment's ~20
+// generators, one verdict at the end) it IS the context's accumulator: no memset before the kernel, no accumulate launch after it -- two tiny
+// launches per generator less (40 - 100 of a segment proof's 490 - 830, round 6).  Otherwise a scratch word, zeroed here.
+int tracegen_flag(zkhip_ctx* ctx, void** flag) {
+    if (ctx->defer_tracegen_checks && ctx->d_deferred_bad) {
+        *flag = ctx->d_deferred_bad;
+        return ZKHIP_OK;
+    }
+    ZK_TRY(get_scratch(ctx, 2, 16, flag));
+    ZK_HIP_CHECK(ctx, hipMemsetAsync(*flag, 0, 4, ctx->stream));
+    return ZKHIP_OK;
+}
 int tracegen_finish(zkhip_ctx* ctx, void* flag, const std::string& what) {
+    if (ctx->defer_tracegen_checks && ctx->d_deferred_bad && flag == (void*)ctx->d_deferred_bad) return ZKHIP_OK;   // (counted in place)
     if (ctx->defer_tracegen_checks && ctx->d_deferred_bad) {
         hipLaunchKernelGGL(k_accumulate_flag, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)flag, ctx->d_deferred_bad);
         ZK_HIP_CHECK(ctx, hipGetLastError());

@@ -194,9 +194,8 @@ int zkhip_fp2_tracegen_x(zkhip_ctx* ctx, uint32_t n_words, const uint32_t* modul
     Fp2Words cw{};
     memcpy(cw.p, modulus, 4 * n_words);
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "fp2_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256), bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_fp2_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_fp2_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);

@@ -205,9 +205,8 @@ int tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_ts, si
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, what);
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     uint32_t* xor_col = d_bitwise_trace + ((size_t)1 << 16);   // the XOR multiplicities of the 8-bit table
     const unsigned bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 0);
@@ -240,9 +239,8 @@ int mul_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, size_t rec_stride, s
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": more records than rows");
     if (size_x < 256 || size_y < 32 || T > ((size_t)1 << 27)) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": the tuple table must cover (x < 256, y < 32)");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, what);
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256), bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
@@ -263,9 +261,8 @@ int shift_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, what);
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned bb = (unsigned)(((size_t)2 << 16) + 255) / 256;   // both multiplicity columns of the 8-bit table
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 0);
     hipLaunchKernelGGL(k_shift256_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, d_ts, n, N, width, d_trace, d_bitwise_trace,
@@ -280,9 +277,8 @@ int cmp_tracegen(zkhip_ctx* ctx, const uint32_t* d_records, const uint32_t* d_ts
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(what) + ": more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, what);
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_i256_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);   // the range column of the 8-bit table
     hipLaunchKernelGGL(k_cmp256_trace, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_records, d_ts, n, N, width, d_trace, d_bitwise_trace, (uint32_t*)flag);

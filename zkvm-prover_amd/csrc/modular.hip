@@ -266,9 +266,8 @@ static int modular_tracegen(zkhip_ctx* ctx, uint32_t n_words, const uint32_t* mo
     memcpy(pm.w, modulus, 4 * n_words);
     const size_t rec_stride = 2 * n_words + (with_op ? 1 : 0);
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "modmul_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256), bb = (unsigned)(((size_t)1 << 16) + 255) / 256;
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_mod_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_mod_repr, dim3(bb), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);   // the range column of the 8-bit table

@@ -133,9 +133,8 @@ int range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d_values, size_t n, un
     if (log_table > 27) return set_error(ctx, ZKHIP_ERR_INVALID, "range_counts_tracegen: log_table > 27");
     const size_t T = (size_t)1 << log_table;
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "range_counts_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
     if (!accumulate) ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
     else if (!ctx->tables_canonical) hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
@@ -246,9 +245,8 @@ extern "C" int zkhip_duplex_tracegen(zkhip_ctx* ctx, const uint32_t* d_n_observe
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "duplex_tracegen: more duplexings than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "duplex_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     ZK_HIP_CHECK(ctx, hipMemsetAsync(d_trace, 0, (size_t)ZKHIP_DUPLEX_WIDTH * N * 4, ctx->stream));
     ZK_HIP_CHECK(ctx, hipMemsetAsync(d_hash_inputs, 0, 16 * N * 4, ctx->stream));
     if (n) hipLaunchKernelGGL(k_duplex_rows, dim3(1), dim3(64), 0, ctx->stream, d_n_observed, d_observed, d_n_sampled, n, N, d_trace, d_hash_inputs, (uint32_t*)flag);
@@ -267,9 +265,8 @@ extern "C" int zkhip_mmcs_path_tracegen(zkhip_ctx* ctx, const uint32_t* d_leaf, 
         return ZKHIP_ERR_INVALID;
     const size_t N = (size_t)1 << log_height;
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "mmcs_path_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     ZK_HIP_CHECK(ctx, hipMemsetAsync(d_trace, 0, (size_t)ZKHIP_MMCS_PATH_WIDTH * N * 4, ctx->stream));
     ZK_HIP_CHECK(ctx, hipMemsetAsync(d_hash_inputs, 0, 16 * N * 4, ctx->stream));
     if (n_paths)

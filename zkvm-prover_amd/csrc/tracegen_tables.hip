@@ -125,9 +125,8 @@ extern "C" int zkhip_range_tuple_counts_tracegen(zkhip_ctx* ctx, const uint32_t*
     const size_t T = (size_t)size_x * size_y;
     if (T > ((size_t)1 << 27) || (T & (T - 1))) return set_error(ctx, ZKHIP_ERR_INVALID, "range tuple table: size_x * size_y must be a power of two <= 2^27");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "range_tuple_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
     if (!accumulate) ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
     else if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
@@ -146,9 +145,8 @@ extern "C" int zkhip_bitwise_lookup_tracegen(zkhip_ctx* ctx, const uint32_t* d_x
     if (!ctx || !d_trace || (n && (!d_x || !d_y || !d_op)) || num_bits == 0 || num_bits > 12) return ZKHIP_ERR_INVALID;
     const size_t T = (size_t)2 << (2 * num_bits);  // two columns
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "bitwise_lookup_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
     if (!accumulate) ZK_HIP_CHECK(ctx, hipMemsetAsync(d_trace, 0, T * 4, ctx->stream));
     else if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_trace, T, 0);
@@ -171,9 +169,8 @@ extern "C" int zkhip_memory_boundary_tracegen(zkhip_ctx* ctx, const uint32_t* d_
     if (n > N || (n && (!d_addr_space || !d_pointer || !d_initial || !d_final || !d_timestamp)))
         return set_error(ctx, ZKHIP_ERR_INVALID, "memory_boundary_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "memory_boundary_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     uint64_t* keys_sorted = nullptr;
     uint32_t* idx_sorted = nullptr;
     if (n) {
@@ -251,9 +248,8 @@ extern "C" int zkhip_rv32_alu_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode,
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_alu_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "rv32_alu_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     // the XOR multiplicity column of the 8-bit bitwise lookup table (column 1 of its 2 x 2^16 trace): Montgomery -> counts -> Montgomery
     uint32_t* xor_col = d_bitwise_trace + (1u << 16);
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, xor_col, (size_t)1 << 16, 0);
@@ -371,9 +367,8 @@ extern "C" int zkhip_program_freq_tracegen(zkhip_ctx* ctx, const uint32_t* d_pc_
     if (!ctx || !d_freq || log_height > 27 || (n && !d_pc_index)) return ZKHIP_ERR_INVALID;
     const size_t N = (size_t)1 << log_height;
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "program_freq_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     ZK_HIP_CHECK(ctx, hipMemsetAsync(d_freq, 0, N * 4, ctx->stream));
     if (n)
         hipLaunchKernelGGL(k_program_freq, dim3((unsigned)std::min<size_t>((n + 256 * 32 - 1) / (256 * 32), 1024)), dim3(256), 0, ctx->stream, d_pc_index, n, N,
@@ -390,9 +385,8 @@ extern "C" int zkhip_exec_frame_tracegen(zkhip_ctx* ctx, const uint32_t* d_pc_in
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "exec_frame_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "exec_frame_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_exec_frames, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_pc_index, n, d_program, n_program, N, d_trace,
                        (uint32_t*)flag);
     ZK_HIP_CHECK(ctx, hipGetLastError());
@@ -461,9 +455,8 @@ extern "C" int zkhip_rv32_lt_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode, 
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_lt_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "rv32_lt_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     // the RANGE multiplicity column of the 8-bit bitwise lookup table (column 0 of its 2 x 2^16 trace)
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
     hipLaunchKernelGGL(k_rv32_lt, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, d_bitwise_trace,
@@ -515,9 +508,8 @@ extern "C" int zkhip_memory_access_tracegen(zkhip_ctx* ctx, const uint32_t* d_ad
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "memory_access_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "memory_access_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_memory_access, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_addr_space, d_pointer, d_prev_data, d_prev_ts,
                        d_data, d_ts, d_is_read, n, N, d_trace, (uint32_t*)flag);
     ZK_HIP_CHECK(ctx, hipGetLastError());
@@ -591,9 +583,8 @@ extern "C" int zkhip_rv32_shift_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcod
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_shift_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "rv32_shift_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(512), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)2 << 16, 0);  // both columns
     hipLaunchKernelGGL(k_rv32_shift, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace,
                        d_bitwise_trace, d_bitwise_trace + (1u << 16), (uint32_t*)flag);
@@ -650,9 +641,8 @@ extern "C" int zkhip_rv32_branch_eq_tracegen(zkhip_ctx* ctx, const uint32_t* d_o
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_branch_eq_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "rv32_branch_eq_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_rv32_branch_eq, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_a, d_b, d_imm, n, N, d_trace,
                        (uint32_t*)flag);
     ZK_HIP_CHECK(ctx, hipGetLastError());
@@ -718,9 +708,8 @@ extern "C" int zkhip_rv32_branch_lt_tracegen(zkhip_ctx* ctx, const uint32_t* d_o
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_branch_lt_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "rv32_branch_lt_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
     hipLaunchKernelGGL(k_rv32_branch_lt, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_opcode, d_a, d_b, d_imm, n, N, d_trace,
                        d_bitwise_trace, (uint32_t*)flag);
@@ -841,9 +830,8 @@ int jump_chip_tracegen(zkhip_ctx* ctx, const char* name, size_t n, unsigned log_
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, name);
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
     launch(dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), N, (uint32_t*)flag);
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 1);
@@ -947,9 +935,8 @@ extern "C" int zkhip_rv32_mulh_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode
     if (size_x < 256 || size_y < 2048 || T > ((size_t)1 << 27))
         return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_mulh_tracegen: the tuple table must cover (limb < 256, carry < 2048)");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "rv32_mulh_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
@@ -1116,9 +1103,8 @@ extern "C" int zkhip_rv32_divrem_tracegen(zkhip_ctx* ctx, const uint32_t* d_opco
     if (size_x < 256 || size_y < 2048 || T > ((size_t)1 << 27))
         return set_error(ctx, ZKHIP_ERR_INVALID, "rv32_divrem_tracegen: the tuple table must cover (limb < 256, carry < 2048)");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "rv32_divrem_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_tuple_counts, T, 0);
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(256), dim3(256), 0, ctx->stream, d_bitwise_trace, (size_t)1 << 16, 0);
@@ -1196,9 +1182,8 @@ extern "C" int zkhip_field_arith_tracegen(zkhip_ctx* ctx, const uint32_t* d_opco
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "field_arith_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "field_arith_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_field_arith, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_b, d_c, n, N, d_trace, (uint32_t*)flag);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "field_arith_tracegen (opcode > 3, operand not a field element, or division by zero)");
@@ -1212,9 +1197,8 @@ extern "C" int zkhip_field_ext_tracegen(zkhip_ctx* ctx, const uint32_t* d_opcode
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "field_ext_tracegen: more records than rows");
     if (((uintptr_t)d_x | (uintptr_t)d_y) & 15u) return set_error(ctx, ZKHIP_ERR_INVALID, "field_ext_tracegen: operands must be 16-byte aligned");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "field_ext_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_field_ext, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_opcode, d_x, d_y, n, N, d_trace, (uint32_t*)flag);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "field_ext_tracegen (opcode > 3, operand not a field element, or division by zero)");
@@ -1249,9 +1233,8 @@ extern "C" int zkhip_var_range_counts_tracegen(zkhip_ctx* ctx, const uint32_t* d
     if (!ctx || !d_counts || (n && !d_values) || max_bits > 26) return ZKHIP_ERR_INVALID;
     const size_t T = (size_t)1 << (max_bits + 1);
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "var_range_counts_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
     if (!accumulate) ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
     else if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);
@@ -1302,9 +1285,8 @@ extern "C" int zkhip_castf_tracegen(zkhip_ctx* ctx, const uint32_t* d_x, size_t 
     const size_t N = (size_t)1 << log_height, T = (size_t)1 << (max_bits + 1);
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "castf_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "castf_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
     if (!ctx->tables_canonical) hipLaunchKernelGGL(k_tab_repr, dim3(tb), dim3(256), 0, ctx->stream, d_var_range_counts, T, 0);
     hipLaunchKernelGGL(k_castf, dim3((unsigned)std::min<size_t>((N + 255) / 256, HOT_MAX_BLOCKS)), dim3(256), 0, ctx->stream, d_x, n, N, d_trace, d_var_range_counts, (uint32_t*)flag);
@@ -1359,9 +1341,8 @@ extern "C" int zkhip_fri_fold_chip_tracegen(zkhip_ctx* ctx, const uint32_t* d_e0
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "fri_fold_chip_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "fri_fold_chip_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_fri_fold_chip, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_e0, d_e1, d_beta, d_k, d_log_n_out, n, N, d_trace,
                        (uint32_t*)flag);
     ZK_HIP_CHECK(ctx, hipGetLastError());
@@ -1400,9 +1381,8 @@ extern "C" int zkhip_domain_point_tracegen(zkhip_ctx* ctx, const uint32_t* d_k, 
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "domain_point_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "domain_point_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_domain_point, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_k, d_mult, n, N, d_trace, (uint32_t*)flag);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return finish_counts(ctx, flag, "domain_point_tracegen (a pair index of more than 26 bits or a multiplicity that is not a field element)");

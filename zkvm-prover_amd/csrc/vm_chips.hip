@@ -380,9 +380,8 @@ int zkhip_vm_frame_tracegen(zkhip_ctx* ctx, const uint32_t* d_pc_index, const ui
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "vm_frame_tracegen: more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "vm_frame_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_vm_frame, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_pc_index, d_x, d_y, d_z, d_rd_prev, d_pc_inc,
                        d_prev_ts_rs1, d_prev_ts_rs2, d_prev_ts_rd, n, d_program, n_program, N, d_trace, (uint32_t*)flag);
     ZK_HIP_CHECK(ctx, hipGetLastError());
@@ -399,9 +398,8 @@ int zkhip_vm_loadstore_tracegen(zkhip_ctx* ctx, const uint32_t* d_case, const ui
     ZK_TRY(zkhip_rv32_loadstore_tracegen(ctx, d_case, d_read, d_prev, n, log_height, d_trace, d_bitwise_trace));
     const size_t N = (size_t)1 << log_height;
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "vm_loadstore_adapter_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_vm_ls_adapter, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_ts, d_base, d_imm, d_prev_ts, n, N, d_trace, (uint32_t*)flag);
     ZK_HIP_CHECK(ctx, hipGetLastError());
     return check_flag(ctx, flag, "vm_loadstore_tracegen (a timestamp gap out of range)");
@@ -425,9 +423,8 @@ static int native_rows(zkhip_ctx* ctx, const uint32_t* d_records, size_t n, unsi
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, std::string(name) + ": more records than rows");
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, name);
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const dim3 grid((unsigned)((N + 255) / 256)), block(256);
     if (which == 0) hipLaunchKernelGGL(k_vm_native_arith, grid, block, 0, ctx->stream, d_records, n, N, d_trace, (uint32_t*)flag);
     else if (which == 1) hipLaunchKernelGGL(k_vm_native_ext, grid, block, 0, ctx->stream, d_records, n, N, d_trace, (uint32_t*)flag);
@@ -450,13 +447,18 @@ int zkhip_rows_tracegen(zkhip_ctx* ctx, const uint32_t* d_rows, size_t n, size_t
     if (!ctx || !d_trace || width == 0 || width > 4096 || log_height > 27 || (n && !d_rows)) return ZKHIP_ERR_INVALID;
     const size_t N = (size_t)1 << log_height;
     if (n > N) return set_error(ctx, ZKHIP_ERR_INVALID, "rows_tracegen: more rows than the trace height");
-    void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16 + 4 * 4096, &flag));
+    void *flag = nullptr, *scratch = nullptr;
+    ZK_TRY(get_scratch(ctx, 2, 16 + 4 * 4096, &scratch));   // [error flag | the padding row]
     uint32_t* d_pad = nullptr;
     KernelScope ks(ctx, "rows_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    if (ctx->defer_tracegen_checks && ctx->d_deferred_bad) {
+        flag = ctx->d_deferred_bad;   // (counted in place: tracegen_flag, csrc/api.hip)
+    } else {
+        flag = scratch;
+        ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    }
     if (pad_row) {
-        d_pad = (uint32_t*)flag + 4;
+        d_pad = (uint32_t*)scratch + 4;
         ZK_HIP_CHECK(ctx, hipMemcpyAsync(d_pad, pad_row, width * 4, hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // pad_row may be a temporary of the caller
     }
@@ -472,9 +474,8 @@ int zkhip_range_counts_scaled_tracegen(zkhip_ctx* ctx, const uint32_t* d_values,
     if (!ctx || !d_counts || log_table > 27 || scale == 0 || (n && !d_values)) return ZKHIP_ERR_INVALID;
     const size_t T = (size_t)1 << log_table;
     void* flag = nullptr;
-    ZK_TRY(get_scratch(ctx, 2, 16, &flag));
+    ZK_TRY(tracegen_flag(ctx, &flag));
     KernelScope ks(ctx, "range_counts_scaled_tracegen");
-    ZK_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
     const unsigned tb = (unsigned)((T + 255) / 256);
     if (!accumulate) ZK_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, T * 4, ctx->stream));
     else if (!ctx->tables_canonical) hipLaunchKernelGGL(k_counts_repr, dim3(tb), dim3(256), 0, ctx->stream, d_counts, T, 0);

@@ -84,6 +84,7 @@ void profile_begin(zkhip_ctx* ctx, const char* name);
 void profile_end(zkhip_ctx* ctx);
 int profile_flush(zkhip_ctx* ctx);
 // end of a trace generator: `flag` = device counter of bad records of this call; reports now, or adds it to the deferred total
+int tracegen_flag(zkhip_ctx* ctx, void** flag);
 int tracegen_finish(zkhip_ctx* ctx, void* flag, const std::string& what);
 
 // every entry point that takes a context runs on the context's device, whatever device the calling thread had current
