@@ -254,13 +254,14 @@ inline void quot_jit_epilogue(std::ostringstream& os) {
 // wave w evaluates instances w, w + 16, ... of every class, so the rows in flight per XCD are a sixteenth (4.9 MB) and a cell's re-reads by
 // the other waves of the workgroup find it in the L2; the sixteen partial sums meet in LDS.  The two selector inversions are done once per
 // workgroup (waves 0 and 1) while the other waves evaluate the classes that need neither.
-// waves per row block of the shared-rows form (ZKHIP_JIT_SHARED_WAVES = 2 / 4 / 8 / 16; measured on the headline's chip, with the selector
+// waves per row block of the shared-rows form (ZKHIP_JIT_SHARED_WAVES = 4 / 8 / 16 -- at least four: waves 0 .. 3 sum the four coordinates of the
+// result; a 2-wave variant failed the parity fuzz for exactly that reason and is not offered; measured on the headline's chip, with the selector
 // tables: 16: 5.89 ms, 8: 5.32, 4: 4.99 against the plain form's 5.29 -- profiles/round06_quot_jit_shared_v2.txt; default 4)
 inline unsigned quot_shared_waves() {
     static const unsigned v = [] {
         const char* e = getenv("ZKHIP_JIT_SHARED_WAVES");
         const int n = e ? atoi(e) : 4;
-        return (unsigned)(n == 2 || n == 8 || n == 16 ? n : 4);
+        return (unsigned)(n == 8 || n == 16 ? n : 4);
     }();
     return v;
 }
