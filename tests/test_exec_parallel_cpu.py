@@ -120,3 +120,10 @@ def test_256_bit_branches_across_cuts(exe, tmp_path):
     """the bigint extension's branches read a2 in the ecall chip's row: the metered pass touches that register block as the record pass does"""
     _compare(exe, tmp_path, rv.elf_bytes(t.branch256_program(), data=t.branch256_data()), b"", 5, 3, "[app_vm_config.bigint]\n")
     _compare(exe, tmp_path, rv.elf_bytes(t.branch256_program(), data=t.branch256_data()), b"", 4, 2, "[app_vm_config.bigint]\n")
+
+
+@pytest.mark.parametrize("seed", [3, 21])
+def test_every_instruction_class(exe, tmp_path, seed):
+    """tests/test_vm_cpu.py mixed_program: every RV32IM instruction class (ALU, shifts, comparisons, mul / mulh / div / rem, branches, jumps,
+    loads and stores of every width and sign) -- the metered pass runs them without a record sink, the record passes with one"""
+    _compare(exe, tmp_path, rv.elf_bytes(t.mixed_program()), int(seed).to_bytes(4, "little"), 8, 3)
