@@ -1054,6 +1054,9 @@ private:
 // byte (tests/test_exec_parallel_cpu.py).  This is how the reference's stack executes: execute_metered_cost first
 // (crates/prover/src/utils/vm.rs:19), then OpenVM replays the segments; host parallelism is a first-class tool there
 // (crates/integration/src/testers/chunk.rs:352-368).  threads == 0: the serial executor on the caller's thread, as before.
+// Memory: at most `window_` = 2 threads + 2 segments are planned, replayed or waiting for the caller at a time; each holds its records (what the
+// serial executor holds once) and the 4 KiB pages its predecessor wrote -- at most the guest's whole memory per segment, in practice the working
+// set of 2^20 instructions; pages are dropped as soon as every record pass has moved beyond them.
 class ParallelSegmentExecutor {
 public:
     ParallelSegmentExecutor(const Exe& exe, const StdIn& in, const SegmentCaps& caps, unsigned threads)
